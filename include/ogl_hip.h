@@ -1,0 +1,159 @@
+/*
+ * ogl_hip.h — C-ABI of libogl_hip.so: the MI355X (gfx950) streaming-GraphSAGE update path.
+ *
+ * The reference (MassimoPerini/online-gnn-learning, "R/" = its repo root) has no FFI: its hot path
+ * is Python calling DGL / ATen.  Each entry point below replaces one of those call sites; the
+ * reference-side binding a maintainer would add is the ctypes stub in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns an int status: 0 = OGL_OK, negative = OGL_E*; nothing throws;
+ *  - all data pointers are CALLER-OWNED DEVICE buffers sized by the caller; the library never
+ *    allocates on the hot path (the only allocations are inside ogl_graph_create);
+ *  - matrices are row-major float32 with an explicit leading dimension `ld*` in ELEMENTS
+ *    (ld >= logical width; pad columns are don't-care on input and left untouched on output);
+ *  - vertex ids are int64 at the boundary (DGL / torch.LongTensor convention), block-local
+ *    indices are int32, "no neighbour" is -1;
+ *  - the last argument is the hipStream_t (passed as void*) the work is enqueued on; calls are
+ *    asynchronous and re-entrant per stream; no call synchronises the device;
+ *  - workspaces are explicit: query the size, allocate it yourself, pass it in.
+ */
+#ifndef OGL_HIP_H
+#define OGL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OGL_VERSION 100
+
+enum {
+  OGL_OK = 0,
+  OGL_EINVAL = -1,     /* bad argument (null pointer, negative size, misaligned ld, id out of range) */
+  OGL_ENOMEM = -2,     /* hipMalloc failed inside ogl_graph_create */
+  OGL_EHIP = -3,       /* a HIP runtime call / kernel launch failed; see ogl_last_hip_error() */
+  OGL_EWORKSPACE = -4  /* workspace pointer null or smaller than the queried size */
+};
+
+enum { OGL_REDUCE_MEAN = 0, OGL_REDUCE_MAX = 1, OGL_REDUCE_SUM = 2 };
+
+typedef struct ogl_graph ogl_graph_t;
+typedef void* ogl_stream_t; /* hipStream_t */
+
+int ogl_version(void);
+const char* ogl_status_string(int status);
+int ogl_last_hip_error(void); /* hipError_t of the most recent OGL_EHIP on this thread */
+
+/* ------------------------------------------------------------------------------------------
+ * Snapshot adjacency (replaces the DGLGraph the sampler reads:
+ * R/train/graph/dynamic_graph_vertex.py:85,132-141 `graph.subgraph(evolving_vertices)`;
+ * R/train/graph/dynamic_graph_edge.py:190-218 `add_nodes` + 2x `add_edges`).
+ * One time-ordered CSR of the FINAL graph; a snapshot is a (n_present, cut) pair.
+ *   indptr  [n+1] int64, indices [nnz] int32 : in-neighbours of v = indices[indptr[v]..indptr[v+1])
+ *   keys    [nnz] int32, ascending inside each list (NULL = use `indices`):
+ *           vertex stream: key = neighbour id  (ids are arrival-ordered), cut = n_present;
+ *           edge stream  : key = row of the time-sorted edge table,       cut = t*edges_per_snapshot.
+ * The handle borrows the three arrays (they must outlive it) and owns an int32[n] degree array.
+ * ---------------------------------------------------------------------------------------- */
+int ogl_graph_create(const int64_t* indptr, const int32_t* indices, const int32_t* keys,
+                     int64_t n, int64_t nnz, ogl_graph_t** out);
+/* deg_t[v] = #{e in adj(v): keys[e] < cut} for v < n_present, else 0.  This IS evolve(). */
+int ogl_graph_set_snapshot(ogl_graph_t* g, int64_t n_present, int64_t cut, ogl_stream_t stream);
+int ogl_graph_degrees(const ogl_graph_t* g, const int32_t** deg_out); /* device pointer, int32[n] */
+int ogl_graph_copy_degrees(const ogl_graph_t* g, int32_t* out /* device int32[n] */, ogl_stream_t stream);
+int ogl_graph_destroy(ogl_graph_t* g);
+
+/* ------------------------------------------------------------------------------------------
+ * One layer of dgl.sampling.MultiLayerNeighborSampler([S,S], replace=True)
+ * (R/train/graphsage/pytorch/model.py:44,128,174,224,280,312): for every dst, `fanout` uniform
+ * draws with replacement from its snapshot in-neighbours; -1 everywhere when the in-degree is 0.
+ * Draw j of dst d = word (j&3) of Philox4x32-10(counter = {j>>2 | layer<<16, d_lo, d_hi, ctr_lo},
+ * key = {seed_lo, seed_hi ^ ctr_hi}); offset = (draw * deg) >> 32.  picks: int64 [n_dst, fanout].
+ * ---------------------------------------------------------------------------------------- */
+int ogl_sample_layer(const ogl_graph_t* g, const int64_t* dst, int64_t n_dst, int fanout,
+                     uint64_t seed, uint64_t ctr, int layer, int64_t* picks, ogl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * dgl.to_block relabelling (inside NodeDataLoader, same call sites): src nodes = dst nodes first
+ * (local id i = dst[i]), then new ids in first-appearance order of row-major `picks`.
+ *   src_ids   int64 [>= n_dst*(1+fanout)]  out (first *n_src_out entries valid)
+ *   n_src_out int64 [1]                    out (device)
+ *   local_idx int32 [n_dst, fanout]        out (-1 where picks == -1)
+ * ---------------------------------------------------------------------------------------- */
+int64_t ogl_block_workspace_bytes(int64_t n_dst, int fanout);
+int ogl_build_block(const int64_t* dst, int64_t n_dst, const int64_t* picks, int fanout,
+                    int64_t* src_ids, int64_t* n_src_out, int32_t* local_idx,
+                    void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * graph.ndata['feat'][input_nodes] / graph.ndata['target'][seeds]
+ * (R/train/graphsage/pytorch/model.py:54,88,91,182-183,232-233).  ld, ldo multiples of 4 floats
+ * and 16-byte aligned bases select the 16-B/lane path; anything else falls back to dword copies.
+ * ids outside [0, n_rows) never touch memory: they yield a zero row / label -1.
+ * ---------------------------------------------------------------------------------------- */
+int ogl_gather_rows(const float* table, int64_t ld, int64_t n_rows, const int64_t* ids, int64_t n,
+                    int d, float* out, int64_t ldo, ogl_stream_t stream);
+int ogl_gather_i64(const int64_t* table, int64_t n_rows, const int64_t* ids, int64_t n,
+                   int64_t* out, ogl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fixed-fanout neighbour reduction = the aggregator (DGL copy_src -> max on the live 'pool'
+ * layer; mailbox.mean/.sum(axis=1) in R/train/graphsage/pytorch/aggregator_dgl.py:158,165,185).
+ *   out[d,:] = op_j src[row(d,j), 0:d]   with row(d,j) = idx32[d,j] (block-local) or idx64[d,j]
+ *   (global row of a table, e.g. sampler picks used directly against a cached projection);
+ *   exactly one of idx32 / idx64 is non-NULL.  A dst whose slot 0 is -1 yields zeros.
+ *   mean = float32 sum in slot order 0..S-1 then division by S; max keeps the first slot on ties.
+ *   argmax (nullable, int32 [n_dst, d]): row index of the winning source (-1 if none), max only.
+ * Backward (mean/sum: every slot; max: the argmax row only) accumulates into a PRE-ZEROED dsrc
+ * with float atomics.  Row indices outside [0, n_src) are skipped, never dereferenced.
+ * On the 16-B path the pad columns of `out` up to round_up(d,4) are overwritten.
+ * ---------------------------------------------------------------------------------------- */
+int ogl_reduce_fwd(const float* src, int64_t lds, int64_t n_src, const int32_t* idx32,
+                   const int64_t* idx64, int64_t n_dst, int fanout, int d, int op, float* out,
+                   int64_t ldo, int32_t* argmax, ogl_stream_t stream);
+int ogl_reduce_bwd(const float* dout, int64_t ldo, const int32_t* idx32, const int32_t* argmax,
+                   int64_t n_dst, int fanout, int d, int op, int64_t n_src, float* dsrc,
+                   int64_t lds, ogl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense projections (torch.nn.Linear inside SAGEConv: fc_pool / fc_self / fc_neigh), fp32 MFMA.
+ *   fwd:  y[M,N] = act( x[rows?] . w^T  (+ x2[rows2?] . w2^T)  + bias )
+ *         x [*,K] (ldx), w [N,K] (ldw); the optional second pair gives fc_self(h)+fc_neigh(n) and
+ *         concat->Linear in one pass; x_rows/x2_rows (nullable int64[M]) gather rows on the fly
+ *         from a table of x_nrows rows (out-of-range rows read as zeros).
+ *   bwd_input:  dx[M,K] = (dy (.) [ymask>0]) . w           (ymask nullable = the relu output)
+ *   bwd_weight: dw[N,K] = (dy (.) [ymask>0])^T . x[rows?], db[N] = column sums (nullable);
+ *         deterministic split over M through `workspace` (no atomics).
+ * ---------------------------------------------------------------------------------------- */
+int ogl_linear_fwd(const float* x, int64_t ldx, const int64_t* x_rows, int64_t x_nrows,
+                   int64_t M, int K, const float* w, int64_t ldw, int N, const float* bias,
+                   const float* x2, int64_t ldx2, const int64_t* x2_rows, int64_t x2_nrows, int K2,
+                   const float* w2, int64_t ldw2,
+                   int relu, float* y, int64_t ldy, ogl_stream_t stream);
+int ogl_linear_bwd_input(const float* dy, int64_t ldy, const float* ymask, int64_t ldm,
+                         int64_t M, int N, const float* w, int64_t ldw, int K,
+                         float* dx, int64_t lddx, ogl_stream_t stream);
+int64_t ogl_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K);
+int ogl_linear_bwd_weight(const float* dy, int64_t ldy, const float* ymask, int64_t ldm,
+                          const float* x, int64_t ldx, const int64_t* x_rows, int64_t x_nrows,
+                          int64_t M, int N, int K, float* dw, int64_t lddw, float* db,
+                          void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * nn.CrossEntropyLoss (R/train/graphsage/pytorch/model.py:20,105,147,198,244):
+ *   loss_rows[i] = logsumexp(logits[i,:]) - logits[i, labels[i]]            (reduction='none')
+ *   dlogits (nullable) = grad_scale * (softmax - onehot)   (grad_scale = 1/B for the mean loss)
+ * ---------------------------------------------------------------------------------------- */
+int ogl_ce_fwd_bwd(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C,
+                   float grad_scale, float* loss_rows, float* dlogits, int64_t lddl,
+                   ogl_stream_t stream);
+
+/* torch.optim.Adam(lr) single-tensor update (R/train/graphsage/pytorch/model.py:24-25,107). */
+int ogl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step,
+                  float lr, float beta1, float beta2, float eps, ogl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OGL_HIP_H */

@@ -1,0 +1,77 @@
+"""ctypes binding of include/ogl_hip.h.  No fallback: if libogl_hip.so is missing or a call
+returns a non-zero status this raises — the product path never routes around the HIP library."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libogl_hip.so")
+
+OGL_OK = 0
+REDUCE_MEAN, REDUCE_MAX, REDUCE_SUM = 0, 1, 2
+REDUCE_OPS = {"mean": REDUCE_MEAN, "max": REDUCE_MAX, "sum": REDUCE_SUM}
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_i = C.c_int
+_f = C.c_float
+_u64 = C.c_uint64
+
+# name -> (restype, argtypes): mirrors include/ogl_hip.h one to one
+SIGNATURES = {
+    "ogl_version": (_i, []),
+    "ogl_status_string": (C.c_char_p, [_i]),
+    "ogl_last_hip_error": (_i, []),
+    "ogl_graph_create": (_i, [_p, _p, _p, _i64, _i64, C.POINTER(_p)]),
+    "ogl_graph_set_snapshot": (_i, [_p, _i64, _i64, _p]),
+    "ogl_graph_degrees": (_i, [_p, C.POINTER(_p)]),
+    "ogl_graph_copy_degrees": (_i, [_p, _p, _p]),
+    "ogl_graph_destroy": (_i, [_p]),
+    "ogl_sample_layer": (_i, [_p, _p, _i64, _i, _u64, _u64, _i, _p, _p]),
+    "ogl_block_workspace_bytes": (_i64, [_i64, _i]),
+    "ogl_build_block": (_i, [_p, _i64, _p, _i, _p, _p, _p, _p, _i64, _p]),
+    "ogl_gather_rows": (_i, [_p, _i64, _i64, _p, _i64, _i, _p, _i64, _p]),
+    "ogl_gather_i64": (_i, [_p, _i64, _p, _i64, _p, _p]),
+    "ogl_reduce_fwd": (_i, [_p, _i64, _i64, _p, _p, _i64, _i, _i, _i, _p, _i64, _p, _p]),
+    "ogl_reduce_bwd": (_i, [_p, _i64, _p, _p, _i64, _i, _i, _i, _i64, _p, _i64, _p]),
+    "ogl_linear_fwd": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p,
+                            _p, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p]),
+    "ogl_linear_bwd_input": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p, _i64, _p]),
+    "ogl_linear_bwd_weight_workspace_bytes": (_i64, [_i64, _i, _i]),
+    "ogl_linear_bwd_weight": (_i, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i, _i, _p, _i64, _p,
+                                   _p, _i64, _p]),
+    "ogl_ce_fwd_bwd": (_i, [_p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p]),
+    "ogl_adam_step": (_i, [_p, _p, _p, _p, _i64, _i, _f, _f, _f, _f, _p]),
+}
+
+_lib = None
+
+
+class OglError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libogl_hip.so once (after torch, so both share one HIP runtime)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libogl_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first; ours binds to the same SONAME)
+        h = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)   # AttributeError here = header/library drift
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(status, what=""):
+    if status != OGL_OK:
+        h = lib()
+        msg = h.ogl_status_string(int(status)).decode()
+        if status == -3:
+            msg += " (hipError_t=%d)" % h.ogl_last_hip_error()
+        raise OglError("%s failed: %s" % (what or "libogl_hip call", msg))

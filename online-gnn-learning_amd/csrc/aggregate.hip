@@ -1,0 +1,302 @@
+// Row gather + fixed-fanout neighbour reduction (the aggregator) and its backward.
+// Replaces: graph.ndata['feat'][input_nodes] (R/train/graphsage/pytorch/model.py:54,88,182,232) and the
+// message-passing reduce of SAGEConv — DGL copy_src->max on the live 'pool' layer, mailbox
+// .mean/.sum(axis=1) in R/train/graphsage/pytorch/aggregator_dgl.py:158,165,175,185.
+//
+// HBM-bound.  One 64-lane wavefront per destination; lanes stride the feature row in 16-B pieces
+// (a 602-float row padded to ld=608 is 152 float4 = 2.375 wave-instructions), four neighbour rows
+// in flight per wave, row bases wave-uniform (v_readlane -> scalar address), max/sum kept in
+// registers, one coalesced store per destination.  Algorithmic bytes per launch:
+// E*(4*D + idx) + n_dst*4*D  (SURVEY.md §8d).
+#include "ogl_common.h"
+
+#define WAVES_PER_BLOCK 4
+
+__device__ __forceinline__ int64_t bcast_idx(int32_t v, int j) { return (int64_t)__builtin_amdgcn_readlane(v, j); }
+__device__ __forceinline__ int64_t bcast_idx(int64_t v, int j) {
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v & 0xFFFFFFFF), j);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), j);
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// ---- vectorised forward: NCH float4 chunks per lane (d <= 256*NCH floats) -------------------
+template <int OP, typename IdxT, bool ARG, int NCH>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK)
+k_reduce_fwd_v4(const float* __restrict__ src, int64_t lds, int64_t n_src, const IdxT* __restrict__ idx,
+                int64_t n_dst, int S, int d, float* __restrict__ out, int64_t ldo,
+                int32_t* __restrict__ argmax) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (w >= n_dst) return;
+  const int d4 = (d + 3) >> 2;
+  float4 acc[NCH];
+  int arg[NCH][4];
+  bool any = false;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    arg[c][0] = arg[c][1] = arg[c][2] = arg[c][3] = -1;
+  }
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int sc = min(64, S - s0);
+    IdxT mine = lane < sc ? idx[w * S + s0 + lane] : (IdxT)-1;
+    for (int j0 = 0; j0 < sc; j0 += 4) {
+      float4 v[4][NCH];
+      int64_t r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int j = j0 + u;
+        r[u] = j < sc ? bcast_idx(mine, j < sc ? j : 0) : -1;
+        if (r[u] >= n_src) r[u] = -1;
+        if (r[u] >= 0) {
+          const float4* rp = (const float4*)(src + r[u] * lds);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            int ch = c * 64 + lane;
+            if (ch < d4) v[u][c] = rp[ch];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r[u] < 0) continue;  // wave-uniform
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          if (OP == OGL_REDUCE_MAX) {
+            if (!any) {
+              acc[c] = v[u][c];
+              if (ARG) arg[c][0] = arg[c][1] = arg[c][2] = arg[c][3] = (int)r[u];
+            } else {
+              if (v[u][c].x > acc[c].x) { acc[c].x = v[u][c].x; if (ARG) arg[c][0] = (int)r[u]; }
+              if (v[u][c].y > acc[c].y) { acc[c].y = v[u][c].y; if (ARG) arg[c][1] = (int)r[u]; }
+              if (v[u][c].z > acc[c].z) { acc[c].z = v[u][c].z; if (ARG) arg[c][2] = (int)r[u]; }
+              if (v[u][c].w > acc[c].w) { acc[c].w = v[u][c].w; if (ARG) arg[c][3] = (int)r[u]; }
+            }
+          } else {
+            acc[c].x += v[u][c].x; acc[c].y += v[u][c].y; acc[c].z += v[u][c].z; acc[c].w += v[u][c].w;
+          }
+        }
+        any = true;
+      }
+    }
+  }
+  const float fS = (float)S;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    int ch = c * 64 + lane;
+    if (ch < d4) {
+      float4 o = acc[c];
+      if (OP == OGL_REDUCE_MEAN && any) { o.x /= fS; o.y /= fS; o.z /= fS; o.w /= fS; }
+      ((float4*)(out + w * ldo))[ch] = o;
+      if (ARG) {
+        int base = ch * 4;
+        int32_t* ap = argmax + w * (int64_t)d + base;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (base + e < d) ap[e] = arg[c][e];
+      }
+    }
+  }
+}
+
+// ---- generic forward (any d / alignment): one wave per destination, dword accesses ------------
+template <int OP, typename IdxT, bool ARG>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK)
+k_reduce_fwd_generic(const float* __restrict__ src, int64_t lds, int64_t n_src, const IdxT* __restrict__ idx,
+                     int64_t n_dst, int S, int d, float* __restrict__ out, int64_t ldo,
+                     int32_t* __restrict__ argmax) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (w >= n_dst) return;
+  for (int c = lane; c < d; c += 64) {
+    float acc = 0.f;
+    int arg = -1;
+    bool any = false;
+    for (int j = 0; j < S; ++j) {
+      int64_t r = (int64_t)idx[w * S + j];
+      if (r < 0 || r >= n_src) continue;
+      float v = src[r * lds + c];
+      if (OP == OGL_REDUCE_MAX) {
+        if (!any || v > acc) { acc = v; arg = (int)r; }
+      } else {
+        acc += v;
+      }
+      any = true;
+    }
+    if (OP == OGL_REDUCE_MEAN && any) acc /= (float)S;
+    out[w * ldo + c] = acc;
+    if (ARG) argmax[w * (int64_t)d + c] = arg;
+  }
+}
+
+template <int OP, typename IdxT, bool ARG>
+static int launch_reduce_fwd(const float* src, int64_t lds, int64_t n_src, const IdxT* idx, int64_t n_dst,
+                             int S, int d, float* out, int64_t ldo, int32_t* argmax, hipStream_t stream) {
+  dim3 grid((unsigned)ogl_cdiv(n_dst, WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
+  const int d4 = (d + 3) / 4;
+  const bool vec = (lds % 4 == 0) && (ldo % 4 == 0) && (lds >= 4 * d4) && (ldo >= 4 * d4) &&
+                   (((uintptr_t)src & 15) == 0) && (((uintptr_t)out & 15) == 0) && d4 <= 256;
+  if (!vec) {
+    hipLaunchKernelGGL((k_reduce_fwd_generic<OP, IdxT, ARG>), grid, block, 0, stream, src, lds, n_src, idx,
+                       n_dst, S, d, out, ldo, argmax);
+  } else if (d4 <= 64) {
+    hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 1>), grid, block, 0, stream, src, lds, n_src, idx,
+                       n_dst, S, d, out, ldo, argmax);
+  } else if (d4 <= 128) {
+    hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 2>), grid, block, 0, stream, src, lds, n_src, idx,
+                       n_dst, S, d, out, ldo, argmax);
+  } else if (d4 <= 192) {
+    hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 3>), grid, block, 0, stream, src, lds, n_src, idx,
+                       n_dst, S, d, out, ldo, argmax);
+  } else {
+    hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 4>), grid, block, 0, stream, src, lds, n_src, idx,
+                       n_dst, S, d, out, ldo, argmax);
+  }
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+template <typename IdxT>
+static int dispatch_reduce_fwd(const float* src, int64_t lds, int64_t n_src, const IdxT* idx, int64_t n_dst,
+                               int S, int d, int op, float* out, int64_t ldo, int32_t* argmax,
+                               hipStream_t stream) {
+  switch (op) {
+    case OGL_REDUCE_MAX:
+      return argmax ? launch_reduce_fwd<OGL_REDUCE_MAX, IdxT, true>(src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, stream)
+                    : launch_reduce_fwd<OGL_REDUCE_MAX, IdxT, false>(src, lds, n_src, idx, n_dst, S, d, out, ldo, nullptr, stream);
+    case OGL_REDUCE_MEAN:
+      return launch_reduce_fwd<OGL_REDUCE_MEAN, IdxT, false>(src, lds, n_src, idx, n_dst, S, d, out, ldo, nullptr, stream);
+    case OGL_REDUCE_SUM:
+      return launch_reduce_fwd<OGL_REDUCE_SUM, IdxT, false>(src, lds, n_src, idx, n_dst, S, d, out, ldo, nullptr, stream);
+    default:
+      return OGL_EINVAL;
+  }
+}
+
+extern "C" int ogl_reduce_fwd(const float* src, int64_t lds, int64_t n_src, const int32_t* idx32,
+                              const int64_t* idx64, int64_t n_dst, int fanout, int d, int op, float* out,
+                              int64_t ldo, int32_t* argmax, ogl_stream_t stream) {
+  if (n_dst < 0 || fanout < 0 || d < 0 || n_src < 0 || lds < d || ldo < d) return OGL_EINVAL;
+  if ((idx32 != nullptr) == (idx64 != nullptr) && fanout > 0 && n_dst > 0) return OGL_EINVAL;
+  if (n_dst == 0 || d == 0) return OGL_OK;
+  if (!out || (!src && n_src > 0)) return OGL_EINVAL;
+  if (idx32) return dispatch_reduce_fwd<int32_t>(src, lds, n_src, idx32, n_dst, fanout, d, op, out, ldo, argmax, (hipStream_t)stream);
+  return dispatch_reduce_fwd<int64_t>(src, lds, n_src, idx64, n_dst, fanout, d, op, out, ldo, argmax, (hipStream_t)stream);
+}
+
+// ---- backward ----------------------------------------------------------------------------------
+// max: only the winning source row receives the gradient (n_dst*d float atomics).
+__global__ void __launch_bounds__(256) k_reduce_bwd_max(const float* __restrict__ dout, int64_t ldo,
+                                                        const int32_t* __restrict__ argmax, int64_t n_dst, int d,
+                                                        int64_t n_src, float* __restrict__ dsrc, int64_t lds) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_dst) return;
+  for (int c = lane; c < d; c += 64) {
+    int a = argmax[w * (int64_t)d + c];
+    if (a >= 0 && a < n_src) atomicAdd(&dsrc[(int64_t)a * lds + c], dout[w * ldo + c]);
+  }
+}
+
+// mean/sum: every sampled slot receives dout (scaled by 1/S for mean); one 256-B contiguous
+// atomic wave-instruction per (slot, 64 columns) — the shape the float-atomic path runs at full rate.
+__global__ void __launch_bounds__(256) k_reduce_bwd_sum(const float* __restrict__ dout, int64_t ldo,
+                                                        const int32_t* __restrict__ idx, int64_t n_dst, int S, int d,
+                                                        float scale, int64_t n_src, float* __restrict__ dsrc,
+                                                        int64_t lds) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_dst) return;
+  for (int c0 = 0; c0 < d; c0 += 64) {
+    int c = c0 + lane;
+    float g = c < d ? dout[w * ldo + c] * scale : 0.f;
+    for (int j = 0; j < S; ++j) {
+      int r = idx[w * S + j];
+      if (r < 0 || r >= n_src) continue;
+      if (c < d) atomicAdd(&dsrc[(int64_t)r * lds + c], g);
+    }
+  }
+}
+
+extern "C" int ogl_reduce_bwd(const float* dout, int64_t ldo, const int32_t* idx32, const int32_t* argmax,
+                              int64_t n_dst, int fanout, int d, int op, int64_t n_src, float* dsrc,
+                              int64_t lds, ogl_stream_t stream) {
+  if (n_dst < 0 || fanout < 0 || d < 0 || n_src < 0 || lds < d || ldo < d) return OGL_EINVAL;
+  if (n_dst == 0 || d == 0 || fanout == 0) return OGL_OK;
+  if (!dout || !dsrc) return OGL_EINVAL;
+  dim3 grid((unsigned)ogl_cdiv(n_dst, 4)), block(256);
+  if (op == OGL_REDUCE_MAX) {
+    if (!argmax) return OGL_EINVAL;
+    hipLaunchKernelGGL(k_reduce_bwd_max, grid, block, 0, (hipStream_t)stream, dout, ldo, argmax, n_dst, d, n_src, dsrc, lds);
+  } else if (op == OGL_REDUCE_MEAN || op == OGL_REDUCE_SUM) {
+    if (!idx32) return OGL_EINVAL;
+    float scale = op == OGL_REDUCE_MEAN ? 1.0f / (float)fanout : 1.0f;
+    hipLaunchKernelGGL(k_reduce_bwd_sum, grid, block, 0, (hipStream_t)stream, dout, ldo, idx32, n_dst, fanout, d, scale, n_src, dsrc, lds);
+  } else {
+    return OGL_EINVAL;
+  }
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+// ---- row gather ----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gather_rows_v4(const float* __restrict__ table, int64_t ld, int64_t n_rows,
+                                                        const int64_t* __restrict__ ids, int64_t n, int d4,
+                                                        float* __restrict__ out, int64_t ldo) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n) return;
+  int64_t r = ids[w];
+  const bool ok = r >= 0 && r < n_rows;
+  const float4* rp = (const float4*)(table + (ok ? r : 0) * ld);
+  float4* op = (float4*)(out + w * ldo);
+  for (int c = lane; c < d4; c += 64) op[c] = ok ? rp[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ void __launch_bounds__(256) k_gather_rows_generic(const float* __restrict__ table, int64_t ld, int64_t n_rows,
+                                                             const int64_t* __restrict__ ids, int64_t n, int d,
+                                                             float* __restrict__ out, int64_t ldo) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n) return;
+  int64_t r = ids[w];
+  const bool ok = r >= 0 && r < n_rows;
+  for (int c = lane; c < d; c += 64) out[w * ldo + c] = ok ? table[r * ld + c] : 0.f;
+}
+
+extern "C" int ogl_gather_rows(const float* table, int64_t ld, int64_t n_rows, const int64_t* ids, int64_t n,
+                               int d, float* out, int64_t ldo, ogl_stream_t stream) {
+  if (n < 0 || d < 0 || ld < d || ldo < d || n_rows < 0) return OGL_EINVAL;
+  if (n == 0 || d == 0) return OGL_OK;
+  if (!table || !ids || !out) return OGL_EINVAL;
+  const int d4 = (d + 3) / 4;
+  const bool vec = (ld % 4 == 0) && (ldo % 4 == 0) && ld >= 4 * d4 && ldo >= 4 * d4 &&
+                   (((uintptr_t)table & 15) == 0) && (((uintptr_t)out & 15) == 0);
+  dim3 grid((unsigned)ogl_cdiv(n, 4)), block(256);
+  if (vec)
+    hipLaunchKernelGGL(k_gather_rows_v4, grid, block, 0, (hipStream_t)stream, table, ld, n_rows, ids, n, d4, out, ldo);
+  else
+    hipLaunchKernelGGL(k_gather_rows_generic, grid, block, 0, (hipStream_t)stream, table, ld, n_rows, ids, n, d, out, ldo);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+__global__ void __launch_bounds__(256) k_gather_i64(const int64_t* __restrict__ table, int64_t n_rows,
+                                                    const int64_t* __restrict__ ids, int64_t n,
+                                                    int64_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t r = ids[i];
+  out[i] = (r >= 0 && r < n_rows) ? table[r] : -1;
+}
+
+extern "C" int ogl_gather_i64(const int64_t* table, int64_t n_rows, const int64_t* ids, int64_t n, int64_t* out,
+                              ogl_stream_t stream) {
+  if (n < 0 || n_rows < 0) return OGL_EINVAL;
+  if (n == 0) return OGL_OK;
+  if (!table || !ids || !out) return OGL_EINVAL;
+  hipLaunchKernelGGL(k_gather_i64, dim3((unsigned)ogl_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, table,
+                     n_rows, ids, n, out);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}

@@ -1,0 +1,194 @@
+// Block construction (dgl.to_block semantics restated): dst-first, first-appearance relabelling.
+// Replaces the relabel step inside dgl.sampling.NodeDataLoader
+// (R/train/graphsage/pytorch/model.py:45-47,129-131,175-178,225-227,281-284,313-316).
+//
+// Deterministic on the GPU: a global open-addressing hash keyed by vertex id records the MINIMUM
+// flat position p at which the id appears in [dst | picks row-major]; positions that own their
+// id's minimum are "first appearances"; a 3-phase exclusive scan of those flags gives the local
+// index.  Integer/HBM-bound work, no MFMA.
+#include "ogl_common.h"
+
+#define BLK_SCAN 1024
+
+struct block_ws {
+  int32_t* tkey;   // [T]  vertex id or -1
+  int32_t* tmin;   // [T]  min flat position
+  int32_t* tlidx;  // [T]  local index of the id
+  int32_t* slot;   // [P]  table slot of position p (or -1)
+  int32_t* bsum;   // [NB + 1]
+  int64_t T, P, NB;
+};
+
+static inline int64_t table_size(int64_t P) {
+  int64_t T = 1024;
+  while (T < 2 * P) T <<= 1;
+  return T;
+}
+
+static inline int64_t ws_bytes(int64_t P) {
+  int64_t T = table_size(P);
+  int64_t NB = ogl_cdiv(P, BLK_SCAN);
+  return 4 * (3 * T + ogl_round_up(P, 4) + ogl_round_up(NB + 1, 4));
+}
+
+extern "C" int64_t ogl_block_workspace_bytes(int64_t n_dst, int fanout) {
+  if (n_dst < 0 || fanout < 0) return OGL_EINVAL;
+  return ws_bytes(n_dst * (1 + (int64_t)fanout));
+}
+
+__device__ __forceinline__ int64_t flat_id(const int64_t* __restrict__ dst, const int64_t* __restrict__ picks,
+                                           int64_t n_dst, int64_t p) {
+  return p < n_dst ? dst[p] : picks[p - n_dst];
+}
+
+__global__ void __launch_bounds__(256) k_block_insert(const int64_t* __restrict__ dst,
+                                                      const int64_t* __restrict__ picks, int64_t n_dst,
+                                                      int64_t P, int32_t* tkey, int32_t* tmin,
+                                                      int32_t* __restrict__ slot, uint32_t mask, int shift) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  int64_t id64 = flat_id(dst, picks, n_dst, p);
+  if (id64 < 0) { slot[p] = -1; return; }
+  int32_t id = (int32_t)id64;
+  uint32_t h = ((uint32_t)id * 0x9E3779B1u) >> shift;
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    int32_t old = atomicCAS(&tkey[h], -1, id);
+    if (old == -1 || old == id) {
+      atomicMin(&tmin[h], (int32_t)p);
+      slot[p] = (int32_t)h;
+      return;
+    }
+    h = (h + 1) & mask;
+  }
+  slot[p] = -1;  // unreachable: the table holds >= 2P slots
+}
+
+__device__ __forceinline__ int is_first(const int32_t* __restrict__ tmin, const int32_t* __restrict__ slot,
+                                        int64_t n_dst, int64_t P, int64_t p) {
+  if (p >= P) return 0;
+  if (p < n_dst) return 1;  // every dst keeps its own source row
+  int32_t s = slot[p];
+  return (s >= 0 && tmin[s] == (int32_t)p) ? 1 : 0;
+}
+
+// exclusive scan of one flag per thread over a 1024-thread block; returns prefix, *total = sum
+__device__ __forceinline__ int block_scan_1024(int f, int* total) {
+  __shared__ int wsum[16];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  unsigned long long b = __ballot(f);
+  int pre = __popcll(b & ((1ull << lane) - 1ull));
+  if (lane == 0) wsum[wid] = __popcll(b);
+  __syncthreads();
+  int woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    int s = wsum[w];
+    if (w < wid) woff += s;
+    tot += s;
+  }
+  *total = tot;
+  __syncthreads();
+  return pre + woff;
+}
+
+__global__ void __launch_bounds__(BLK_SCAN) k_block_count(const int32_t* __restrict__ tmin,
+                                                          const int32_t* __restrict__ slot, int64_t n_dst,
+                                                          int64_t P, int32_t* __restrict__ bsum) {
+  int64_t p = (int64_t)blockIdx.x * BLK_SCAN + threadIdx.x;
+  int tot;
+  (void)block_scan_1024(is_first(tmin, slot, n_dst, P, p), &tot);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of bsum[0..NB) in place, bsum[NB] = total, n_src_out = total
+__global__ void __launch_bounds__(BLK_SCAN) k_block_scan_sums(int32_t* bsum, int64_t NB, int64_t* n_src_out) {
+  __shared__ int carry_s;
+  __shared__ int part[BLK_SCAN];
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < NB; base += BLK_SCAN) {
+    int64_t i = base + threadIdx.x;
+    int v = i < NB ? bsum[i] : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    // Hillis-Steele inclusive scan in LDS (NB is a few hundred; this runs once per block build)
+    for (int off = 1; off < BLK_SCAN; off <<= 1) {
+      int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+      __syncthreads();
+      part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    int incl = part[threadIdx.x];
+    int carry = carry_s;
+    if (i < NB) bsum[i] = carry + incl - v;
+    __syncthreads();
+    if (threadIdx.x == BLK_SCAN - 1) carry_s = carry + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { bsum[NB] = carry_s; *n_src_out = (int64_t)carry_s; }
+}
+
+__global__ void __launch_bounds__(BLK_SCAN) k_block_assign(const int64_t* __restrict__ dst,
+                                                           const int64_t* __restrict__ picks,
+                                                           const int32_t* __restrict__ tmin,
+                                                           const int32_t* __restrict__ slot,
+                                                           const int32_t* __restrict__ bsum, int64_t n_dst,
+                                                           int64_t P, int64_t* __restrict__ src_ids,
+                                                           int32_t* __restrict__ tlidx) {
+  int64_t p = (int64_t)blockIdx.x * BLK_SCAN + threadIdx.x;
+  int f = is_first(tmin, slot, n_dst, P, p);
+  int tot;
+  int pre = block_scan_1024(f, &tot);
+  if (f) {
+    int32_t li = bsum[blockIdx.x] + pre;
+    src_ids[li] = flat_id(dst, picks, n_dst, p);
+    int32_t s = slot[p];
+    if (s >= 0 && tmin[s] == (int32_t)p) tlidx[s] = li;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_block_lookup(const int32_t* __restrict__ slot,
+                                                      const int32_t* __restrict__ tlidx, int64_t n_dst,
+                                                      int64_t P, int32_t* __restrict__ local_idx) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= P - n_dst) return;
+  int32_t s = slot[n_dst + e];
+  local_idx[e] = s >= 0 ? tlidx[s] : -1;
+}
+
+extern "C" int ogl_build_block(const int64_t* dst, int64_t n_dst, const int64_t* picks, int fanout,
+                               int64_t* src_ids, int64_t* n_src_out, int32_t* local_idx,
+                               void* workspace, int64_t workspace_bytes, ogl_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_dst < 0 || fanout < 0 || !n_src_out) return OGL_EINVAL;
+  if (n_dst == 0) { OGL_CHECK_HIP(hipMemsetAsync(n_src_out, 0, sizeof(int64_t), stream)); return OGL_OK; }
+  if (!dst || !src_ids || (fanout > 0 && (!picks || !local_idx))) return OGL_EINVAL;
+  const int64_t P = n_dst * (1 + (int64_t)fanout);
+  if (P >= ((int64_t)1 << 30)) return OGL_EINVAL;
+  if (!workspace || workspace_bytes < ws_bytes(P)) return OGL_EWORKSPACE;
+  block_ws ws;
+  ws.T = table_size(P); ws.P = P; ws.NB = ogl_cdiv(P, BLK_SCAN);
+  int32_t* base = (int32_t*)workspace;
+  ws.tkey = base; ws.tmin = base + ws.T; ws.tlidx = base + 2 * ws.T; ws.slot = base + 3 * ws.T;
+  ws.bsum = ws.slot + ogl_round_up(P, 4);
+  int logT = 0; while (((int64_t)1 << logT) < ws.T) ++logT;
+  OGL_CHECK_HIP(hipMemsetAsync(ws.tkey, 0xFF, sizeof(int32_t) * ws.T, stream));   // -1
+  OGL_CHECK_HIP(hipMemsetAsync(ws.tmin, 0x7F, sizeof(int32_t) * ws.T, stream));   // 0x7F7F7F7F > P
+  hipLaunchKernelGGL(k_block_insert, dim3((unsigned)ogl_cdiv(P, 256)), dim3(256), 0, stream, dst, picks,
+                     n_dst, P, ws.tkey, ws.tmin, ws.slot, (uint32_t)(ws.T - 1), 32 - logT);
+  OGL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_block_count, dim3((unsigned)ws.NB), dim3(BLK_SCAN), 0, stream, ws.tmin, ws.slot,
+                     n_dst, P, ws.bsum);
+  OGL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_block_scan_sums, dim3(1), dim3(BLK_SCAN), 0, stream, ws.bsum, ws.NB, n_src_out);
+  OGL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_block_assign, dim3((unsigned)ws.NB), dim3(BLK_SCAN), 0, stream, dst, picks, ws.tmin,
+                     ws.slot, ws.bsum, n_dst, P, src_ids, ws.tlidx);
+  OGL_CHECK_LAUNCH();
+  if (fanout > 0) {
+    hipLaunchKernelGGL(k_block_lookup, dim3((unsigned)ogl_cdiv(P - n_dst, 256)), dim3(256), 0, stream,
+                       ws.slot, ws.tlidx, n_dst, P, local_idx);
+    OGL_CHECK_LAUNCH();
+  }
+  return OGL_OK;
+}

@@ -1,0 +1,144 @@
+// Snapshot adjacency handle + k-hop sampler layer.
+// Replaces: DGLGraph snapshot state (R/train/graph/dynamic_graph_vertex.py:132-141,
+// R/train/graph/dynamic_graph_edge.py:190-218) and dgl.sampling.sample_neighbors inside
+// MultiLayerNeighborSampler (R/train/graphsage/pytorch/model.py:44,128,174,224,280,312).
+#include "ogl_common.h"
+
+thread_local int g_ogl_last_hip_error = 0;
+
+extern "C" int ogl_version(void) { return OGL_VERSION; }
+extern "C" int ogl_last_hip_error(void) { return g_ogl_last_hip_error; }
+extern "C" const char* ogl_status_string(int s) {
+  switch (s) {
+    case OGL_OK: return "OGL_OK";
+    case OGL_EINVAL: return "OGL_EINVAL: bad argument";
+    case OGL_ENOMEM: return "OGL_ENOMEM: device allocation failed";
+    case OGL_EHIP: return "OGL_EHIP: HIP runtime error";
+    case OGL_EWORKSPACE: return "OGL_EWORKSPACE: workspace missing or too small";
+    default: return "OGL_E?: unknown status";
+  }
+}
+
+// ---- prefix-degree cut: one thread per vertex, lower_bound(keys[adj(v)], cut) ---------------
+__global__ void __launch_bounds__(256) k_snapshot_degrees(const int64_t* __restrict__ indptr,
+                                                          const int32_t* __restrict__ keys,
+                                                          int64_t n, int64_t n_present, int64_t cut,
+                                                          int32_t* __restrict__ deg) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  int32_t d = 0;
+  if (v < n_present) {
+    int64_t lo = indptr[v], hi = indptr[v + 1];
+    const int64_t base = lo;
+    while (lo < hi) {
+      int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)keys[mid] < cut) lo = mid + 1; else hi = mid;
+    }
+    d = (int32_t)(lo - base);
+  }
+  deg[v] = d;
+}
+
+extern "C" int ogl_graph_create(const int64_t* indptr, const int32_t* indices, const int32_t* keys,
+                                int64_t n, int64_t nnz, ogl_graph_t** out) {
+  if (!indptr || !out || n < 0 || nnz < 0 || (nnz > 0 && !indices)) return OGL_EINVAL;
+  if (n >= ((int64_t)1 << 31)) return OGL_EINVAL;  // block hash + indices are int32
+  ogl_graph* g = new (std::nothrow) ogl_graph();
+  if (!g) return OGL_ENOMEM;
+  g->indptr = indptr; g->indices = indices; g->keys = keys ? keys : indices;
+  g->n = n; g->nnz = nnz; g->deg = nullptr; g->n_present = 0; g->cut = 0;
+  if (n > 0) {
+    hipError_t e = hipMalloc((void**)&g->deg, sizeof(int32_t) * (size_t)n);
+    if (e != hipSuccess) { g_ogl_last_hip_error = (int)e; delete g; return OGL_ENOMEM; }
+    e = hipMemset(g->deg, 0, sizeof(int32_t) * (size_t)n);
+    if (e != hipSuccess) { g_ogl_last_hip_error = (int)e; (void)hipFree(g->deg); delete g; return OGL_EHIP; }
+  }
+  *out = g;
+  return OGL_OK;
+}
+
+extern "C" int ogl_graph_set_snapshot(ogl_graph_t* g, int64_t n_present, int64_t cut, ogl_stream_t stream) {
+  if (!g || n_present < 0 || n_present > g->n) return OGL_EINVAL;
+  g->n_present = n_present; g->cut = cut;
+  if (g->n == 0) return OGL_OK;
+  dim3 grid((unsigned)ogl_cdiv(g->n, 256));
+  hipLaunchKernelGGL(k_snapshot_degrees, grid, dim3(256), 0, (hipStream_t)stream,
+                     g->indptr, g->keys, g->n, n_present, cut, g->deg);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+extern "C" int ogl_graph_degrees(const ogl_graph_t* g, const int32_t** deg_out) {
+  if (!g || !deg_out) return OGL_EINVAL;
+  *deg_out = g->deg;
+  return OGL_OK;
+}
+
+extern "C" int ogl_graph_copy_degrees(const ogl_graph_t* g, int32_t* out, ogl_stream_t stream) {
+  if (!g || (g->n > 0 && !out)) return OGL_EINVAL;
+  if (g->n == 0) return OGL_OK;
+  OGL_CHECK_HIP(hipMemcpyAsync(out, g->deg, sizeof(int32_t) * (size_t)g->n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return OGL_OK;
+}
+
+extern "C" int ogl_graph_destroy(ogl_graph_t* g) {
+  if (!g) return OGL_OK;
+  if (g->deg) (void)hipFree(g->deg);
+  delete g;
+  return OGL_OK;
+}
+
+// ---- sampler: one thread per (dst, 4 slots) ------------------------------------------------
+// HBM-bound integer work: per dst 8 B id + 4 B degree + 8 B indptr, per slot one 4-B neighbour
+// read (random) and one 8-B pick write (coalesced: a thread owns 32 contiguous bytes).
+__global__ void __launch_bounds__(256) k_sample_layer(const int64_t* __restrict__ indptr,
+                                                      const int32_t* __restrict__ indices,
+                                                      const int32_t* __restrict__ deg_t, int64_t n,
+                                                      const int64_t* __restrict__ dst, int64_t n_dst,
+                                                      int fanout, int quads, uint32_t k0, uint32_t k1,
+                                                      uint32_t c3, uint32_t layer_bits,
+                                                      int64_t* __restrict__ picks) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_dst * quads) return;
+  int64_t i = t / quads;
+  int q = (int)(t - i * quads);
+  int64_t d = dst[i];
+  uint32_t deg = 0;
+  int64_t base = 0;
+  if (d >= 0 && d < n) { deg = (uint32_t)deg_t[d]; base = indptr[d]; }
+  int j0 = q * 4;
+  int64_t* out = picks + i * fanout + j0;
+  int cnt = min(4, fanout - j0);
+  if (deg == 0) {
+    for (int j = 0; j < cnt; ++j) out[j] = -1;
+    return;
+  }
+  philox4 r = philox4x32_10((uint32_t)q | layer_bits, (uint32_t)((uint64_t)d & 0xFFFFFFFFu),
+                            (uint32_t)((uint64_t)d >> 32), c3, k0, k1);
+  uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j < cnt) {
+      uint32_t off = (uint32_t)(((uint64_t)w[j] * (uint64_t)deg) >> 32);
+      out[j] = (int64_t)indices[base + off];
+    }
+  }
+}
+
+extern "C" int ogl_sample_layer(const ogl_graph_t* g, const int64_t* dst, int64_t n_dst, int fanout,
+                                uint64_t seed, uint64_t ctr, int layer, int64_t* picks,
+                                ogl_stream_t stream) {
+  if (!g || n_dst < 0 || fanout < 0 || layer < 0 || layer > 0xFFFF) return OGL_EINVAL;
+  if (n_dst == 0 || fanout == 0) return OGL_OK;
+  if (!dst || !picks) return OGL_EINVAL;
+  int quads = (fanout + 3) / 4;
+  int64_t total = n_dst * quads;
+  uint32_t k0 = (uint32_t)(seed & 0xFFFFFFFFu);
+  uint32_t k1 = (uint32_t)((seed >> 32) ^ (ctr >> 32));
+  uint32_t c3 = (uint32_t)(ctr & 0xFFFFFFFFu);
+  dim3 grid((unsigned)ogl_cdiv(total, 256));
+  hipLaunchKernelGGL(k_sample_layer, grid, dim3(256), 0, (hipStream_t)stream, g->indptr, g->indices,
+                     g->deg, g->n, dst, n_dst, fanout, quads, k0, k1, c3, (uint32_t)layer << 16, picks);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}

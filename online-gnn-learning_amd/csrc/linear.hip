@@ -1,0 +1,375 @@
+// Dense projections of SAGEConv (fc_pool / fc_self / fc_neigh = torch.nn.Linear in the reference,
+// R/train/graphsage/pytorch/aggregator_dgl.py:85-94,171,181,206; DGL 'pool' parameterisation
+// R/inference_optimized.py:136-139,260,276) as ONE LDS-tiled fp32-MFMA GEMM kernel.
+//
+// MFMA-bound (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD, 157 TFLOP/s peak).
+//   C[i,j] = epilogue( sum_parts sum_r  A(i,r) * B(r,j) )
+// Every operand X(p,r) (p = output index, r = reduction index) comes in one of two layouts
+//   RC ("reduction-contiguous"):  X(p,r) = ptr[row(p)*ld + r]
+//   NC ("non-reduction-contiguous"): X(p,r) = ptr[row(r)*ld + p]
+// which covers forward (x RC, w RC), input-gradient (dy RC, w NC) and weight-gradient (dy NC, x NC)
+// without materialising a transpose.  `row()` is an optional int64 gather (feature rows are read
+// straight from the resident table), `mask` an optional ReLU mask (dy (.) [y>0]) applied on load.
+// Tiles are staged k-major in LDS (Xs[r][p], row stride P+4) so each MFMA operand is one
+// conflict-free ds_read_b32; global loads are 16 B/lane when the operand is 16-B aligned.
+// Block -> tile mapping is XCD-aware: the NJ column tiles of one row panel run on one XCD so the
+// panel is fetched into that XCD's L2 once.
+#include "ogl_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GEMM_BK 16
+#define GEMM_THREADS 256
+
+struct Operand {
+  const float* ptr;
+  int64_t ld;
+  const int64_t* rows;  // optional gather on the major (row) index
+  int64_t nrows;        // bound for gathered rows (rows outside -> zeros)
+  const float* mask;    // optional: value kept only where mask > 0 (same layout/ld as ptr, no gather)
+  int64_t ldm;
+  int vec;              // 16-B loads allowed
+};
+
+struct GemmPart {
+  Operand a, b;
+  int64_t R;  // reduction length of this part
+};
+
+struct GemmArgs {
+  GemmPart part[2];
+  int nparts;
+  int64_t M;        // i range (output rows)
+  int64_t N;        // j range (output cols), includes the synthetic ones column if ones_col
+  int ones_col;     // B(r, N-1) == 1  -> column N-1 of the result = row sums of A (bias gradient)
+  float* C; int64_t ldc;
+  const float* bias;  // [N] or null, added per output column
+  int relu;
+  float* db;        // destination of column N-1 when ones_col
+  int nsplit;       // >1: partial sums go to ws[split][M][ws_ld], epilogue runs in k_splitk_reduce
+  int tiles_per_split;
+  float* ws; int64_t ws_ld;
+  int NI, NJ;
+};
+
+template <int P, bool RC>
+struct TileLoader {
+  static constexpr int NV = P / 64;  // float4 per thread
+  float4 reg[NV];
+
+  // RC: thread -> (p = tid/4 + 64h, r = (tid&3)*4..+3);  NC: thread -> (r = tid/(P/4) + (1024/P)h, p = (tid%(P/4))*4..+3)
+  __device__ __forceinline__ void load(const Operand& op, int64_t p0, int64_t Plim, int64_t r0, int64_t R,
+                                       int64_t ones_p, int tid) {
+#pragma unroll
+    for (int h = 0; h < NV; ++h) {
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (RC) {
+        const int64_t p = p0 + (tid >> 2) + 64 * h;
+        const int64_t r = r0 + (tid & 3) * 4;
+        if (p < Plim && r < R) {
+          if (p == ones_p) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (r + e < R) ? 1.f : 0.f;
+          } else {
+            int64_t row = op.rows ? op.rows[p] : p;
+            if (!op.rows || (row >= 0 && row < op.nrows)) {
+              const float* src = op.ptr + row * op.ld + r;
+              if (op.vec && r + 3 < R) {
+                float4 t = *(const float4*)src;
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (r + e < R) v[e] = src[e];
+              }
+              if (op.mask) {
+                const float* ms = op.mask + p * op.ldm + r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (r + e < R && !(ms[e] > 0.f)) v[e] = 0.f;
+              }
+            }
+          }
+        }
+      } else {
+        const int64_t r = r0 + tid / (P / 4) + (1024 / P) * h;
+        const int64_t p = p0 + (tid % (P / 4)) * 4;
+        if (r < R && p < Plim) {
+          int64_t row = op.rows ? op.rows[r] : r;
+          if (!op.rows || (row >= 0 && row < op.nrows)) {
+            const float* src = op.ptr + row * op.ld + p;
+            const int64_t psrc = ones_p >= 0 ? ones_p : Plim;  // #columns really present in memory
+            if (op.vec && p + 3 < psrc) {
+              float4 t = *(const float4*)src;
+              v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) if (p + e < psrc) v[e] = src[e];
+            }
+            if (op.mask) {
+              const float* ms = op.mask + r * op.ldm + p;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) if (p + e < psrc && !(ms[e] > 0.f)) v[e] = 0.f;
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (p + e == ones_p) v[e] = 1.f;
+        }
+      }
+      reg[h] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+
+  __device__ __forceinline__ void store(float (*Xs)[P + 4], int tid) const {
+#pragma unroll
+    for (int h = 0; h < NV; ++h) {
+      if (RC) {
+        const int pl = (tid >> 2) + 64 * h;
+        const int rl = (tid & 3) * 4;
+        Xs[rl + 0][pl] = reg[h].x; Xs[rl + 1][pl] = reg[h].y;
+        Xs[rl + 2][pl] = reg[h].z; Xs[rl + 3][pl] = reg[h].w;
+      } else {
+        const int rl = tid / (P / 4) + (1024 / P) * h;
+        const int pl = (tid % (P / 4)) * 4;
+        *(float4*)&Xs[rl][pl] = reg[h];
+      }
+    }
+  }
+};
+
+template <bool A_RC, bool B_RC, int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
+  constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+  __shared__ __attribute__((aligned(16))) float As[2][GEMM_BK][BM + 4];
+  __shared__ __attribute__((aligned(16))) float Bs[2][GEMM_BK][BN + 4];
+
+  // XCD-aware tile mapping (blocks b and b+8 share an XCD): the NJ column tiles of a row panel
+  // are dealt to the same XCD.  Bijective over the padded grid; padded row panels exit.
+  const int lin = blockIdx.x;
+  const int xcd = lin & 7, q = lin >> 3;
+  const int ti = (q / g.NJ) * 8 + xcd, tj = q % g.NJ;
+  if (ti >= g.NI) return;
+  const int64_t i0 = (int64_t)ti * BM, j0 = (int64_t)tj * BN;
+  const int split = blockIdx.y;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  int nk[2];
+  nk[0] = (int)((g.part[0].R + GEMM_BK - 1) / GEMM_BK);
+  nk[1] = g.nparts > 1 ? (int)((g.part[1].R + GEMM_BK - 1) / GEMM_BK) : 0;
+  const int nk_total = nk[0] + nk[1];
+  int kt_begin = 0, kt_end = nk_total;
+  if (g.nsplit > 1) {
+    kt_begin = split * g.tiles_per_split;
+    kt_end = min(nk_total, kt_begin + g.tiles_per_split);
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  TileLoader<BM, A_RC> la;
+  TileLoader<BN, B_RC> lb;
+  const int64_t ones_p = g.ones_col ? g.N - 1 : -1;
+
+  auto issue = [&](int kt) {
+    const int pi = kt < nk[0] ? 0 : 1;
+    const int64_t r0 = (int64_t)(pi == 0 ? kt : kt - nk[0]) * GEMM_BK;
+    const GemmPart& pt = g.part[pi];
+    la.load(pt.a, i0, g.M, r0, pt.R, -1, tid);
+    lb.load(pt.b, j0, g.N, r0, pt.R, ones_p, tid);
+  };
+
+  if (kt_begin < kt_end) {
+    issue(kt_begin);
+    la.store(As[0], tid);
+    lb.store(Bs[0], tid);
+  }
+  __syncthreads();
+
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    const bool more = kt + 1 < kt_end;
+    if (more) issue(kt + 1);
+#pragma unroll
+    for (int kk = 0; kk < GEMM_BK; kk += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) a[t] = As[buf][kk + half][wm * TM * 32 + t * 32 + l31];
+#pragma unroll
+      for (int t = 0; t < TN; ++t) b[t] = Bs[buf][kk + half][wn * TN * 32 + t * 32 + l31];
+#pragma unroll
+      for (int x = 0; x < TM; ++x)
+#pragma unroll
+        for (int y = 0; y < TN; ++y)
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+    }
+    if (more) {
+      la.store(As[buf ^ 1], tid);
+      lb.store(Bs[buf ^ 1], tid);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int x = 0; x < TM; ++x) {
+#pragma unroll
+    for (int y = 0; y < TN; ++y) {
+      const int64_t col = j0 + wn * TN * 32 + y * 32 + l31;
+      if (col >= g.N) continue;
+      const float bv = (g.nsplit == 1 && g.bias && !(g.ones_col && col == g.N - 1)) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = i0 + wm * TM * 32 + x * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (row >= g.M) continue;
+        float v = acc[x][y][e];
+        if (g.nsplit > 1) {
+          g.ws[((int64_t)split * g.M + row) * g.ws_ld + col] = v;
+        } else {
+          v += bv;
+          if (g.relu) v = fmaxf(v, 0.f);
+          if (g.ones_col && col == g.N - 1) { if (g.db) g.db[row] = v; }
+          else g.C[row * g.ldc + col] = v;
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_splitk_reduce(GemmArgs g) {
+  const int64_t total = g.M * g.N;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = t / g.N, col = t - row * g.N;
+    float v = 0.f;
+    for (int s = 0; s < g.nsplit; ++s) v += g.ws[((int64_t)s * g.M + row) * g.ws_ld + col];  // fixed order
+    const bool oc = g.ones_col && col == g.N - 1;
+    if (g.bias && !oc) v += g.bias[col];
+    if (g.relu) v = fmaxf(v, 0.f);
+    if (oc) { if (g.db) g.db[row] = v; }
+    else g.C[row * g.ldc + col] = v;
+  }
+}
+
+static inline int operand_vec(const float* p, int64_t ld, const float* mask, int64_t ldm) {
+  (void)mask; (void)ldm;
+  return (p != nullptr) && (ld % 4 == 0) && (((uintptr_t)p & 15) == 0);
+}
+
+template <bool A_RC, bool B_RC>
+static int launch_gemm(GemmArgs& g, hipStream_t stream) {
+  if (g.M <= 0 || g.N <= 0) return OGL_OK;
+  const bool narrow = g.N <= 64;
+  const int BM = narrow ? 256 : 128, BN = narrow ? 64 : 128;
+  g.NI = (int)ogl_cdiv(g.M, BM);
+  g.NJ = (int)ogl_cdiv(g.N, BN);
+  const int64_t NIp = ogl_round_up(g.NI, 8);
+  dim3 grid((unsigned)(NIp * g.NJ), (unsigned)g.nsplit), block(GEMM_THREADS);
+  if (narrow)
+    hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 4, 1, 2, 2>), grid, block, 0, stream, g);
+  else
+    hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 2, 2, 2, 2>), grid, block, 0, stream, g);
+  OGL_CHECK_LAUNCH();
+  if (g.nsplit > 1) {
+    int64_t total = g.M * g.N;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)min((int64_t)2048, ogl_cdiv(total, 256))), dim3(256), 0,
+                       stream, g);
+    OGL_CHECK_LAUNCH();
+  }
+  return OGL_OK;
+}
+
+static inline void zero_args(GemmArgs& g) { g = GemmArgs(); g.nsplit = 1; }
+
+extern "C" int ogl_linear_fwd(const float* x, int64_t ldx, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
+                              const float* w, int64_t ldw, int N, const float* bias,
+                              const float* x2, int64_t ldx2, const int64_t* x2_rows, int64_t x2_nrows, int K2,
+                              const float* w2, int64_t ldw2, int relu, float* y, int64_t ldy,
+                              ogl_stream_t stream) {
+  if (M < 0 || K < 0 || N < 0 || K2 < 0 || ldx < K || ldw < K || ldy < N) return OGL_EINVAL;
+  if (M == 0 || N == 0) return OGL_OK;
+  if (!y || (K > 0 && (!x || !w)) || (K2 > 0 && (!x2 || !w2 || ldx2 < K2 || ldw2 < K2))) return OGL_EINVAL;
+  GemmArgs g; zero_args(g);
+  g.part[0].a = Operand{x, ldx, x_rows, x_nrows, nullptr, 0, operand_vec(x, ldx, nullptr, 0)};
+  g.part[0].b = Operand{w, ldw, nullptr, 0, nullptr, 0, operand_vec(w, ldw, nullptr, 0)};
+  g.part[0].R = K;
+  g.nparts = 1;
+  if (K2 > 0) {
+    g.part[1].a = Operand{x2, ldx2, x2_rows, x2_nrows, nullptr, 0, operand_vec(x2, ldx2, nullptr, 0)};
+    g.part[1].b = Operand{w2, ldw2, nullptr, 0, nullptr, 0, operand_vec(w2, ldw2, nullptr, 0)};
+    g.part[1].R = K2;
+    g.nparts = 2;
+  }
+  g.M = M; g.N = N; g.C = y; g.ldc = ldy; g.bias = bias; g.relu = relu;
+  return launch_gemm<true, true>(g, (hipStream_t)stream);
+}
+
+extern "C" int ogl_linear_bwd_input(const float* dy, int64_t ldy, const float* ymask, int64_t ldm, int64_t M,
+                                    int N, const float* w, int64_t ldw, int K, float* dx, int64_t lddx,
+                                    ogl_stream_t stream) {
+  if (M < 0 || N < 0 || K < 0 || ldy < N || ldw < K || lddx < K || (ymask && ldm < N)) return OGL_EINVAL;
+  if (M == 0 || K == 0) return OGL_OK;
+  if (!dx || (N > 0 && (!dy || !w))) return OGL_EINVAL;
+  GemmArgs g; zero_args(g);
+  // dx[m,k] = sum_n dy[m,n] w[n,k] : A = dy (RC over n, mask), B = w (NC: B(r=n, j=k) = w[n*ldw + k])
+  g.part[0].a = Operand{dy, ldy, nullptr, 0, ymask, ldm, operand_vec(dy, ldy, ymask, ldm)};
+  g.part[0].b = Operand{w, ldw, nullptr, 0, nullptr, 0, operand_vec(w, ldw, nullptr, 0)};
+  g.part[0].R = N;
+  g.nparts = 1;
+  g.M = M; g.N = K; g.C = dx; g.ldc = lddx;
+  return launch_gemm<true, false>(g, (hipStream_t)stream);
+}
+
+static void bwd_weight_plan(int64_t M, int N, int K, int* nsplit, int* tps) {
+  const int No = K + 1;  // + ones column
+  const bool narrow = No <= 64;
+  const int BM = narrow ? 256 : 128, BN = narrow ? 64 : 128;
+  const int64_t tiles = ogl_cdiv(N, BM) * ogl_cdiv(No, BN);
+  const int64_t nk = ogl_cdiv(M, GEMM_BK);
+  if (nk == 0) { *nsplit = 1; *tps = 0; return; }
+  int64_t s = 1024 / (tiles > 0 ? tiles : 1);
+  if (s < 1) s = 1;
+  if (s > nk) s = nk > 0 ? nk : 1;
+  // at least 8 k-tiles per split so the slab traffic stays small next to the MFMA work
+  if (nk / s < 8) s = nk / 8 > 0 ? nk / 8 : 1;
+  *tps = (int)ogl_cdiv(nk, s);
+  *nsplit = (int)ogl_cdiv(nk, *tps);
+  if (*nsplit < 1) *nsplit = 1;
+}
+
+extern "C" int64_t ogl_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K) {
+  if (M < 0 || N < 0 || K < 0) return OGL_EINVAL;
+  int nsplit, tps;
+  bwd_weight_plan(M, N, K, &nsplit, &tps);
+  if (nsplit <= 1) return 16;
+  return (int64_t)nsplit * N * ogl_round_up(K + 1, 4) * 4;
+}
+
+extern "C" int ogl_linear_bwd_weight(const float* dy, int64_t ldy, const float* ymask, int64_t ldm,
+                                     const float* x, int64_t ldx, const int64_t* x_rows, int64_t x_nrows,
+                                     int64_t M, int N, int K, float* dw, int64_t lddw, float* db,
+                                     void* workspace, int64_t workspace_bytes, ogl_stream_t stream) {
+  if (M < 0 || N < 0 || K < 0 || ldy < N || ldx < K || lddw < K || (ymask && ldm < N)) return OGL_EINVAL;
+  if (N == 0) return OGL_OK;
+  if (!dw || (M > 0 && (!dy || (K > 0 && !x)))) return OGL_EINVAL;
+  GemmArgs g; zero_args(g);
+  // [dw | db][n, k] = sum_m dy[m,n] * [x | 1][m,k]: A = dy (NC: A(i=n, r=m) = dy[m*ldy + n], mask),
+  // B = x (NC: B(r=m, j=k) = x[row(m)*ldx + k]) with a synthetic ones column at j = K.
+  g.part[0].a = Operand{dy, ldy, nullptr, 0, ymask, ldm, operand_vec(dy, ldy, ymask, ldm)};
+  g.part[0].b = Operand{x, ldx, x_rows, x_nrows, nullptr, 0, operand_vec(x, ldx, nullptr, 0)};
+  g.part[0].R = M;
+  g.nparts = 1;
+  g.M = N; g.N = K + 1; g.ones_col = 1; g.C = dw; g.ldc = lddw; g.db = db;
+  bwd_weight_plan(M, N, K, &g.nsplit, &g.tiles_per_split);
+  if (g.nsplit > 1) {
+    g.ws_ld = ogl_round_up(K + 1, 4);
+    if (!workspace || workspace_bytes < (int64_t)g.nsplit * N * g.ws_ld * 4) return OGL_EWORKSPACE;
+    g.ws = (float*)workspace;
+  }
+  return launch_gemm<false, false>(g, (hipStream_t)stream);
+}

@@ -1,0 +1,89 @@
+// Cross-entropy (forward + gradient) and the Adam update.
+// Replaces nn.CrossEntropyLoss(reduction='mean'|'none') (R/train/graphsage/pytorch/model.py:20,105,147,198,244)
+// and torch.optim.Adam(lr=1e-3).step() (R/train/graphsage/pytorch/model.py:24-25,107,202).
+// Both are tiny HBM-bound elementwise/row kernels.
+#include "ogl_common.h"
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// one wavefront per row
+__global__ void __launch_bounds__(256) k_ce_fwd_bwd(const float* __restrict__ logits, int64_t ldl,
+                                                    const int64_t* __restrict__ labels, int64_t B, int C,
+                                                    float grad_scale, float* __restrict__ loss_rows,
+                                                    float* __restrict__ dlogits, int64_t lddl) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float* x = logits + row * ldl;
+  float m = -INFINITY;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, x[c]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += expf(x[c] - m);
+  s = wave_sum(s);
+  const float lse = m + logf(s);
+  const int64_t y = labels[row];
+  const bool ok = y >= 0 && y < C;
+  if (lane == 0 && loss_rows) loss_rows[row] = ok ? lse - x[y] : 0.f;
+  if (dlogits) {
+    float* g = dlogits + row * lddl;
+    for (int c = lane; c < C; c += 64) {
+      float p = expf(x[c] - lse);
+      g[c] = grad_scale * (p - ((ok && c == (int)y) ? 1.f : 0.f));
+    }
+  }
+}
+
+extern "C" int ogl_ce_fwd_bwd(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C,
+                              float grad_scale, float* loss_rows, float* dlogits, int64_t lddl,
+                              ogl_stream_t stream) {
+  if (B < 0 || C <= 0 || ldl < C || (dlogits && lddl < C)) return OGL_EINVAL;
+  if (B == 0) return OGL_OK;
+  if (!logits || !labels) return OGL_EINVAL;
+  hipLaunchKernelGGL(k_ce_fwd_bwd, dim3((unsigned)ogl_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, logits, ldl,
+                     labels, B, C, grad_scale, loss_rows, dlogits, lddl);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+// torch.optim.Adam single-tensor form: m.lerp_(g, 1-b1); v = b2*v + (1-b2)*g*g;
+// denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= (lr/(1-b1^t)) * m/denom
+__global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g,
+                                              float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                              float one_minus_b1, float b2, float one_minus_b2,
+                                              float inv_sqrt_bc2, float step_size, float eps) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    float mi = m[i];
+    mi = mi + one_minus_b1 * (gi - mi);
+    float vi = v[i] * b2 + one_minus_b2 * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+extern "C" int ogl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr,
+                             float beta1, float beta2, float eps, ogl_stream_t stream) {
+  if (n < 0 || step < 1) return OGL_EINVAL;
+  if (n == 0) return OGL_OK;
+  if (!p || !g || !m || !v) return OGL_EINVAL;
+  const double bc1 = 1.0 - pow((double)beta1, step);
+  const double bc2 = 1.0 - pow((double)beta2, step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)min((int64_t)2048, ogl_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream,
+                     p, g, m, v, n, 1.0f - beta1, beta2, 1.0f - beta2, inv_sqrt_bc2, step_size, eps);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}

@@ -1,0 +1,342 @@
+"""Thin torch-side wrappers over the C-ABI (include/ogl_hip.h) + autograd glue.
+
+torch is plumbing here: device memory, the current HIP stream and autograd bookkeeping.  Every
+arithmetic step of the hot path is a call into libogl_hip.so; nothing in this file computes on
+the CPU or through ATen kernels except trivial reshapes / scalar reads.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import REDUCE_OPS, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def padded_ld(cols: int) -> int:
+    """Leading dimension used for matrices this package allocates (16-B rows; 128-B rows when wide)."""
+    return (cols + 31) // 32 * 32 if cols > 64 else max(4, (cols + 3) // 4 * 4)
+
+
+def empty_mat(rows: int, cols: int, device, zero: bool = False):
+    """[rows, cols] float32 view of a [rows, padded_ld(cols)] allocation (pad columns are don't-care)."""
+    ld = padded_ld(cols)
+    buf = (torch.zeros if zero else torch.empty)((max(rows, 0), ld), dtype=torch.float32, device=device)
+    return buf[:, :cols]
+
+
+def as_mat(t: torch.Tensor) -> torch.Tensor:
+    """Return a float32 2-D CUDA tensor whose rows are contiguous (stride(1)==1, stride(0)>=cols)."""
+    if t.dim() != 2:
+        raise ValueError("expected a 2-D tensor, got shape %s" % (tuple(t.shape),))
+    if not t.is_cuda:
+        raise RuntimeError("ogl_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.shape[0] > 1 and (t.stride(1) != 1 or t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    elif t.shape[0] <= 1 and t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    return t
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0) if t.stride(0) >= t.shape[1] else t.shape[1])
+
+
+def _ids(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.int64 or not t.is_cuda or not t.is_contiguous():
+        raise ValueError("ids must be a contiguous CUDA int64 tensor")
+    return t
+
+
+# --------------------------------------------------------------------------------------------
+# graph + sampler + block
+# --------------------------------------------------------------------------------------------
+class GraphHandle:
+    """Owns an ogl_graph_t over device CSR arrays (kept alive here)."""
+
+    def __init__(self, indptr: torch.Tensor, indices: torch.Tensor, keys: torch.Tensor | None = None):
+        assert indptr.is_cuda and indptr.dtype == torch.int64 and indptr.is_contiguous()
+        assert indices.is_cuda and indices.dtype == torch.int32 and indices.is_contiguous()
+        if keys is not None:
+            assert keys.is_cuda and keys.dtype == torch.int32 and keys.is_contiguous() and keys.numel() == indices.numel()
+        self.indptr, self.indices, self.keys = indptr, indices, keys
+        self.n = indptr.numel() - 1
+        self.nnz = indices.numel()
+        h = C.c_void_p()
+        check(_lib.lib().ogl_graph_create(_ptr(indptr), _ptr(indices), _ptr(keys), self.n, self.nnz, C.byref(h)),
+              "ogl_graph_create")
+        self._h = h
+        self.n_present, self.cut = 0, 0
+
+    def set_snapshot(self, n_present: int, cut: int):
+        check(_lib.lib().ogl_graph_set_snapshot(self._h, int(n_present), int(cut), _stream()), "ogl_graph_set_snapshot")
+        self.n_present, self.cut = int(n_present), int(cut)
+
+    def degrees(self) -> torch.Tensor:
+        """Copy of the current snapshot in-degrees, int32[n] (device)."""
+        out = torch.empty(self.n, dtype=torch.int32, device=self.indptr.device)
+        check(_lib.lib().ogl_graph_copy_degrees(self._h, _ptr(out), _stream()), "ogl_graph_copy_degrees")
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().ogl_graph_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def sample_layer(g: GraphHandle, dst: torch.Tensor, fanout: int, seed: int, ctr: int, layer: int) -> torch.Tensor:
+    dst = _ids(dst)
+    picks = torch.empty((dst.numel(), fanout), dtype=torch.int64, device=dst.device)
+    check(_lib.lib().ogl_sample_layer(g._h, _ptr(dst), dst.numel(), int(fanout), C.c_uint64(seed & (2 ** 64 - 1)),
+                                      C.c_uint64(ctr & (2 ** 64 - 1)), int(layer), _ptr(picks), _stream()),
+          "ogl_sample_layer")
+    return picks
+
+
+def build_block_async(dst: torch.Tensor, picks: torch.Tensor):
+    """Enqueue the relabelling; returns (src_ids[cap], n_src_dev[1], local_idx) without synchronising."""
+    dst = _ids(dst)
+    n_dst, fanout = picks.shape
+    assert n_dst == dst.numel() and picks.dtype == torch.int64 and picks.is_contiguous()
+    dev = dst.device
+    cap = n_dst * (1 + fanout)
+    src_ids = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+    n_src = torch.zeros(1, dtype=torch.int64, device=dev)
+    local_idx = torch.empty((n_dst, fanout), dtype=torch.int32, device=dev)
+    nbytes = int(_lib.lib().ogl_block_workspace_bytes(n_dst, fanout))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    check(_lib.lib().ogl_build_block(_ptr(dst), n_dst, _ptr(picks), int(fanout), _ptr(src_ids), _ptr(n_src),
+                                     _ptr(local_idx), _ptr(ws), nbytes, _stream()), "ogl_build_block")
+    return src_ids, n_src, local_idx
+
+
+def build_block(dst: torch.Tensor, picks: torch.Tensor):
+    src_ids, n_src, local_idx = build_block_async(dst, picks)
+    n = int(n_src.item())
+    return src_ids[:n], local_idx, n
+
+
+# --------------------------------------------------------------------------------------------
+# gather / reduce
+# --------------------------------------------------------------------------------------------
+def gather_rows(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    table = as_mat(table)
+    ids = _ids(ids)
+    d = table.shape[1]
+    out = empty_mat(ids.numel(), d, table.device)
+    check(_lib.lib().ogl_gather_rows(_ptr(table), _ld(table), table.shape[0], _ptr(ids), ids.numel(), d,
+                                     _ptr(out), _ld(out), _stream()), "ogl_gather_rows")
+    return out
+
+
+def gather_i64(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    flat = table.reshape(-1)
+    assert flat.dtype == torch.int64 and flat.is_cuda and flat.is_contiguous()
+    ids = _ids(ids)
+    out = torch.empty(ids.numel(), dtype=torch.int64, device=ids.device)
+    check(_lib.lib().ogl_gather_i64(_ptr(flat), flat.numel(), _ptr(ids), ids.numel(), _ptr(out), _stream()),
+          "ogl_gather_i64")
+    return out
+
+
+def reduce_fwd(src: torch.Tensor, idx: torch.Tensor, op: str, want_argmax: bool = False):
+    """out[d] = op_j src[idx[d, j]].  idx int32 (block-local) or int64 (global rows)."""
+    src = as_mat(src)
+    assert idx.is_cuda and idx.dim() == 2 and idx.is_contiguous()
+    n_dst, fanout = idx.shape
+    d = src.shape[1]
+    out = empty_mat(n_dst, d, src.device)
+    argmax = torch.empty((n_dst, d), dtype=torch.int32, device=src.device) if (want_argmax and op == "max") else None
+    i32 = idx if idx.dtype == torch.int32 else None
+    i64 = idx if idx.dtype == torch.int64 else None
+    if i32 is None and i64 is None:
+        raise ValueError("idx must be int32 or int64")
+    check(_lib.lib().ogl_reduce_fwd(_ptr(src), _ld(src), src.shape[0], _ptr(i32), _ptr(i64), n_dst, fanout, d,
+                                    REDUCE_OPS[op], _ptr(out), _ld(out), _ptr(argmax), _stream()), "ogl_reduce_fwd")
+    return out, argmax
+
+
+def reduce_bwd(dout: torch.Tensor, idx32: torch.Tensor, argmax, op: str, n_src: int) -> torch.Tensor:
+    dout = as_mat(dout)
+    n_dst, d = dout.shape
+    fanout = idx32.shape[1]
+    dsrc = empty_mat(n_src, d, dout.device, zero=True)
+    check(_lib.lib().ogl_reduce_bwd(_ptr(dout), _ld(dout), _ptr(idx32), _ptr(argmax), n_dst, fanout, d,
+                                    REDUCE_OPS[op], n_src, _ptr(dsrc), _ld(dsrc), _stream()), "ogl_reduce_bwd")
+    return dsrc
+
+
+# --------------------------------------------------------------------------------------------
+# dense projections
+# --------------------------------------------------------------------------------------------
+def linear_fwd(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_rows=None, out=None):
+    x = as_mat(x); w = as_mat(w)
+    M = x_rows.numel() if x_rows is not None else x.shape[0]
+    K, N = x.shape[1], w.shape[0]
+    assert w.shape[1] == K
+    K2 = 0
+    if x2 is not None:
+        x2 = as_mat(x2); w2 = as_mat(w2)
+        K2 = x2.shape[1]
+        assert w2.shape == (N, K2)
+        assert (x2_rows.numel() if x2_rows is not None else x2.shape[0]) == M
+    y = out if out is not None else empty_mat(M, N, x.device)
+    check(_lib.lib().ogl_linear_fwd(
+        _ptr(x), _ld(x), _ptr(x_rows), x.shape[0], M, K, _ptr(w), _ld(w), N, _ptr(bias),
+        _ptr(x2), _ld(x2) if x2 is not None else 0, _ptr(x2_rows), x2.shape[0] if x2 is not None else 0, K2,
+        _ptr(w2), _ld(w2) if w2 is not None else 0, int(bool(relu)), _ptr(y), _ld(y), _stream()), "ogl_linear_fwd")
+    return y
+
+
+def linear_bwd_input(dy, w, ymask=None):
+    dy = as_mat(dy); w = as_mat(w)
+    M, N = dy.shape
+    K = w.shape[1]
+    if ymask is not None:
+        ymask = as_mat(ymask)
+    dx = empty_mat(M, K, dy.device)
+    check(_lib.lib().ogl_linear_bwd_input(_ptr(dy), _ld(dy), _ptr(ymask), _ld(ymask) if ymask is not None else 0,
+                                          M, N, _ptr(w), _ld(w), K, _ptr(dx), _ld(dx), _stream()),
+          "ogl_linear_bwd_input")
+    return dx
+
+
+def linear_bwd_weight(dy, x, ymask=None, x_rows=None, want_bias=True, dw_out=None):
+    dy = as_mat(dy); x = as_mat(x)
+    M, N = dy.shape
+    K = x.shape[1]
+    if ymask is not None:
+        ymask = as_mat(ymask)
+    dev = dy.device
+    dw = dw_out if dw_out is not None else torch.empty((N, K), dtype=torch.float32, device=dev)
+    db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
+    nbytes = int(_lib.lib().ogl_linear_bwd_weight_workspace_bytes(M, N, K))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    check(_lib.lib().ogl_linear_bwd_weight(
+        _ptr(dy), _ld(dy), _ptr(ymask), _ld(ymask) if ymask is not None else 0, _ptr(x), _ld(x), _ptr(x_rows),
+        x.shape[0], M, N, K, _ptr(dw), _ld(dw), _ptr(db), _ptr(ws), nbytes, _stream()), "ogl_linear_bwd_weight")
+    return dw, db
+
+
+# --------------------------------------------------------------------------------------------
+# loss / optimiser
+# --------------------------------------------------------------------------------------------
+def ce_fwd_bwd(logits, labels, grad_scale=1.0, want_grad=True):
+    logits = as_mat(logits)
+    labels = labels.reshape(-1)
+    assert labels.dtype == torch.int64 and labels.is_cuda and labels.is_contiguous() and labels.numel() == logits.shape[0]
+    B, Cc = logits.shape
+    loss = torch.empty(B, dtype=torch.float32, device=logits.device)
+    dl = empty_mat(B, Cc, logits.device) if want_grad else None
+    check(_lib.lib().ogl_ce_fwd_bwd(_ptr(logits), _ld(logits), _ptr(labels), B, Cc, C.c_float(grad_scale), _ptr(loss),
+                                    _ptr(dl), _ld(dl) if dl is not None else 0, _stream()), "ogl_ce_fwd_bwd")
+    return loss, dl
+
+
+def adam_step(p, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
+    for t in (p, g, m, v):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+    check(_lib.lib().ogl_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(step), C.c_float(lr),
+                                   C.c_float(beta1), C.c_float(beta2), C.c_float(eps), _stream()), "ogl_adam_step")
+
+
+# --------------------------------------------------------------------------------------------
+# autograd glue
+# --------------------------------------------------------------------------------------------
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, x2, w2, relu, x_rows, x2_rows):
+        y = linear_fwd(x, w, bias, x2, w2, relu, x_rows, x2_rows)
+        ctx.relu = bool(relu)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w, x2, w2, y if relu else None, x_rows, x2_rows)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, x2, w2, y, x_rows, x2_rows = ctx.saved_tensors
+        dy = as_mat(dy)
+        need = ctx.needs_input_grad
+        dx = dw = db = dx2 = dw2 = None
+        if need[0]:
+            if x_rows is not None:
+                raise RuntimeError("gradient w.r.t. a row-gathered table is not supported (features carry no grad)")
+            dx = linear_bwd_input(dy, w, y)
+        if need[1] or (need[2] and ctx.has_bias):
+            dw, db = linear_bwd_weight(dy, x, y, x_rows, want_bias=ctx.has_bias)
+        if x2 is not None:
+            if need[3]:
+                if x2_rows is not None:
+                    raise RuntimeError("gradient w.r.t. a row-gathered table is not supported")
+                dx2 = linear_bwd_input(dy, w2, y)
+            if need[4]:
+                dw2, _ = linear_bwd_weight(dy, x2, y, x2_rows, want_bias=False)
+        return dx, dw, (db if ctx.has_bias else None), dx2, dw2, None, None, None
+
+
+def linear(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_rows=None):
+    """y = act(x[rows] @ w.T (+ x2[rows2] @ w2.T) + bias), differentiable."""
+    return _LinearFn.apply(x, w, bias, x2, w2, relu, x_rows, x2_rows)
+
+
+class _ReduceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, idx, op):
+        need_grad = src.requires_grad
+        out, argmax = reduce_fwd(src, idx, op, want_argmax=need_grad)
+        ctx.op, ctx.n_src = op, src.shape[0]
+        ctx.save_for_backward(idx if idx.dtype == torch.int32 else None, argmax)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        idx32, argmax = ctx.saved_tensors
+        if ctx.op == "max" and argmax is None:
+            raise RuntimeError("max-reduce backward needs the argmax recorded in forward")
+        if ctx.op != "max" and idx32 is None:
+            raise RuntimeError("mean/sum-reduce backward needs block-local int32 indices")
+        return reduce_bwd(dout, idx32, argmax, ctx.op, ctx.n_src), None, None
+
+
+def neighbor_reduce(src, idx, op):
+    """Differentiable fixed-fanout reduction (``max`` | ``mean`` | ``sum``)."""
+    return _ReduceFn.apply(src, idx, op)
+
+
+class _CrossEntropyRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        loss, dl = ce_fwd_bwd(logits, labels, 1.0, want_grad=logits.requires_grad)
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dl,) = ctx.saved_tensors
+        return dl * dloss.reshape(-1, 1), None
+
+
+def cross_entropy(logits, labels, reduction="mean"):
+    """nn.CrossEntropyLoss(reduction) on the HIP kernel; 'none' returns the per-seed vector."""
+    rows = _CrossEntropyRowsFn.apply(logits, labels)
+    if reduction == "none":
+        return rows
+    if reduction == "mean":
+        return rows.mean()
+    if reduction == "sum":
+        return rows.sum()
+    raise ValueError("unknown reduction %r" % (reduction,))

@@ -1,0 +1,245 @@
+"""HIP-vs-oracle parity through the C-ABI (run with -m gpu on the MI355X box).
+
+Tolerances: integer work (picks, block indices, argmax) bit-exact; max reduce
+bit-exact; mean reduce bit-exact (same slot-order summation); fp32-MFMA GEMM outputs
+rtol 1e-4 / atol 1e-5 vs torch-CPU fp32; losses rtol 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GEMM_RTOL, GEMM_ATOL = 1e-4, 1e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops as _ops
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return _ops
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def rand_csr(rng, n, max_deg, hubs=0):
+    deg = rng.integers(0, max_deg + 1, n)
+    for h in range(hubs):
+        deg[rng.integers(0, n)] = n // 2
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    indices = np.concatenate([np.sort(rng.integers(0, n, d)) for d in deg] + [np.zeros(0, np.int64)]).astype(np.int32)
+    return indptr, indices
+
+
+@pytest.mark.parametrize("n,max_deg,hubs,n_present,fanout,n_dst", [
+    (50, 5, 0, 30, 3, 7), (2000, 12, 3, 1500, 25, 512), (2000, 12, 3, 2000, 10, 1), (300, 4, 0, 300, 64, 33),
+    (300, 4, 0, 1, 25, 5), (20000, 30, 5, 17000, 25, 4096),
+])
+def test_sampler_bit_exact(ops, n, max_deg, hubs, n_present, fanout, n_dst):
+    rng = np.random.default_rng(n + fanout)
+    indptr, indices = rand_csr(rng, n, max_deg, hubs)
+    g = ops.GraphHandle(dev(indptr), dev(indices))
+    g.set_snapshot(n_present, n_present)
+    deg_ref = O.snapshot_degrees_fast(indptr, indices, n_present, n_present)
+    assert np.array_equal(g.degrees().cpu().numpy(), deg_ref)
+    dst = rng.integers(0, n_present, n_dst).astype(np.int64)
+    for layer, ctr, seed in [(0, 0, 1), (1, 5, 1), (1, 2 ** 33 + 7, 2 ** 40 + 3)]:
+        got = ops.sample_layer(g, dev(dst), fanout, seed, ctr, layer).cpu().numpy()
+        want = O.sample_layer(indptr, indices, deg_ref, dst, fanout, seed, ctr, layer)
+        assert np.array_equal(got, want)
+
+
+def test_sampler_edge_stream_keys(ops):
+    """Edge streams: adjacency sorted by edge-table row, cut = t * edges_per_snapshot."""
+    rng = np.random.default_rng(5)
+    n, E = 400, 3000
+    src = rng.integers(0, n, E); dst = rng.integers(0, n, E)
+    rows = np.concatenate([np.arange(E), np.arange(E)])
+    u = np.concatenate([src, dst]); v = np.concatenate([dst, src])     # in-neighbours of v: u
+    order = np.lexsort((rows, v))
+    indices = u[order].astype(np.int32); keys = rows[order].astype(np.int32)
+    indptr = np.concatenate([[0], np.cumsum(np.bincount(v, minlength=n))]).astype(np.int64)
+    g = ops.GraphHandle(dev(indptr), dev(indices), dev(keys))
+    for cut in (0, 1, 777, E):
+        g.set_snapshot(n, cut)
+        want = O.snapshot_degrees_fast(indptr, keys, n, cut)
+        assert np.array_equal(g.degrees().cpu().numpy(), want)
+        d = rng.integers(0, n, 64).astype(np.int64)
+        got = ops.sample_layer(g, dev(d), 25, 9, 3, 1).cpu().numpy()
+        assert np.array_equal(got, O.sample_layer(indptr, indices, want, d, 25, 9, 3, 1))
+
+
+@pytest.mark.parametrize("n_dst,fanout,universe,iso", [
+    (1, 1, 5, 0.0), (7, 3, 20, 0.3), (512, 25, 5000, 0.1), (1000, 25, 300, 0.0), (4096, 25, 200000, 0.05),
+    (33, 64, 1000, 0.5), (5, 4, 10, 1.0),
+])
+def test_block_bit_exact(ops, n_dst, fanout, universe, iso):
+    rng = np.random.default_rng(n_dst * 31 + fanout)
+    dst = rng.permutation(max(universe, n_dst))[:n_dst].astype(np.int64)
+    picks = rng.integers(0, universe, size=(n_dst, fanout)).astype(np.int64)
+    picks[rng.random(n_dst) < iso] = -1
+    src_ref, li_ref = O.build_block(dst, picks)
+    src, li, n = ops.build_block(dev(dst), dev(picks))
+    assert n == len(src_ref)
+    assert np.array_equal(src.cpu().numpy(), src_ref)
+    assert np.array_equal(li.cpu().numpy(), li_ref)
+
+
+def test_block_duplicate_dst(ops):
+    dst = np.array([4, 9, 4, 2], dtype=np.int64)
+    picks = np.array([[9, 7], [4, 4], [-1, -1], [7, 8]], dtype=np.int64)
+    src_ref, li_ref = O.build_block(dst, picks)
+    src, li, n = ops.build_block(dev(dst), dev(picks))
+    assert np.array_equal(src.cpu().numpy(), src_ref) and np.array_equal(li.cpu().numpy(), li_ref)
+
+
+@pytest.mark.parametrize("n_src,n_dst,fanout,d", [
+    (9, 4, 3, 6), (700, 96, 25, 50), (5000, 512, 25, 602), (3000, 300, 25, 600), (2000, 100, 10, 128),
+    (500, 64, 70, 33), (4000, 128, 25, 1000), (100, 10, 5, 1100),
+])
+@pytest.mark.parametrize("op", ["max", "mean", "sum"])
+def test_reduce_fwd_bit_exact(ops, n_src, n_dst, fanout, d, op):
+    rng = np.random.default_rng(n_src + d)
+    src = rng.standard_normal((n_src, d)).astype(np.float32)
+    li = rng.integers(0, n_src, size=(n_dst, fanout)).astype(np.int32)
+    li[rng.random(n_dst) < 0.1] = -1
+    want, arg = O.reduce_fwd(src, li, op)
+    # 16-B-aligned padded rows (vector path) and tight rows (generic path when d % 4 != 0)
+    padded = ops.empty_mat(n_src, d, "cuda").copy_(torch.as_tensor(src))
+    for srct in (dev(src), padded):
+        got, garg = ops.reduce_fwd(srct, dev(li), op, want_argmax=True)
+        assert np.array_equal(got.cpu().numpy(), want), (op, srct.stride())
+        if op == "max":
+            assert np.array_equal(garg.cpu().numpy(), arg)
+    # int64 global-row indexing gives the same values
+    got64, _ = ops.reduce_fwd(dev(src), dev(li.astype(np.int64)), op)
+    assert np.array_equal(got64.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("op", ["max", "mean", "sum"])
+def test_reduce_bwd(ops, op):
+    rng = np.random.default_rng(8)
+    n_src, n_dst, fanout, d = 900, 200, 25, 77
+    src = torch.tensor(rng.standard_normal((n_src, d)).astype(np.float32), requires_grad=True)
+    li = rng.integers(0, n_src, size=(n_dst, fanout)).astype(np.int32)
+    li[::7] = -1
+    gy = torch.tensor(rng.standard_normal((n_dst, d)).astype(np.float32))
+    O._neigh_torch(src, li, op).backward(gy)
+    s = src.detach().cuda().requires_grad_(True)
+    ops.neighbor_reduce(s, dev(li), op).backward(gy.cuda())
+    np.testing.assert_allclose(s.grad.cpu().numpy(), src.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_gather_rows(ops):
+    rng = np.random.default_rng(2)
+    for d in (602, 128, 7):
+        tab = rng.standard_normal((1000, d)).astype(np.float32)
+        ids = rng.integers(0, 1000, 333).astype(np.int64)
+        t = ops.empty_mat(1000, d, "cuda"); t.copy_(torch.as_tensor(tab))
+        assert np.array_equal(ops.gather_rows(t, dev(ids)).cpu().numpy(), tab[ids])
+        assert np.array_equal(ops.gather_rows(dev(tab), dev(ids)).cpu().numpy(), tab[ids])
+    lab = rng.integers(0, 41, (1000, 1)).astype(np.int64)
+    assert np.array_equal(ops.gather_i64(dev(lab), dev(ids)).cpu().numpy(), lab[ids, 0])
+
+
+GEMM_SHAPES = [(1, 1, 1), (5, 7, 3), (130, 33, 17), (257, 602, 602), (1000, 600, 41), (300, 128, 32), (64, 500, 32),
+               (513, 602, 600), (2048, 32, 3)]
+
+
+@pytest.mark.parametrize("M,K,N", GEMM_SHAPES)
+@pytest.mark.parametrize("relu", [False, True])
+def test_linear_fwd(ops, M, K, N, relu):
+    torch.manual_seed(M + K + N)
+    x = torch.randn(M, K); w = torch.randn(N, K) / K ** 0.5; b = torch.randn(N)
+    want = torch.nn.functional.linear(x, w, b)
+    if relu:
+        want = want.relu()
+    for xm in (x.cuda(), ops.empty_mat(M, K, "cuda").copy_(x)):
+        got = ops.linear_fwd(xm, w.cuda(), b.cuda(), relu=relu)
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL)
+
+
+def test_linear_fwd_dual_and_rows(ops):
+    torch.manual_seed(3)
+    T, M, K, K2, N = 900, 300, 602, 602, 600
+    tab = torch.randn(T, K); rows = torch.randint(0, T, (M,))
+    x2 = torch.randn(M, K2); w = torch.randn(N, K) / 25; w2 = torch.randn(N, K2) / 25; b = torch.randn(N)
+    want = (tab[rows] @ w.T + x2 @ w2.T + b).relu()
+    tabm = ops.empty_mat(T, K, "cuda").copy_(tab)
+    got = ops.linear_fwd(tabm, w.cuda(), b.cuda(), x2=x2.cuda(), w2=w2.cuda(), relu=True, x_rows=rows.cuda())
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=GEMM_RTOL, atol=2e-5)
+    # concat -> Linear expressed as two column slices of one weight (in-repo layer, aggregator_dgl.py:206)
+    W = torch.randn(N, K + K2) / 30
+    Wc = W.cuda()
+    got = ops.linear_fwd(tab[rows].cuda(), Wc[:, :K], b.cuda(), x2=x2.cuda(), w2=Wc[:, K:])
+    want = torch.cat((tab[rows], x2), 1) @ W.T + b
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=GEMM_RTOL, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,K,N", GEMM_SHAPES + [(20000, 602, 602), (5000, 128, 128)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_linear_bwd(ops, M, K, N, relu):
+    torch.manual_seed(M * 3 + K + N)
+    x = torch.randn(M, K, requires_grad=True)
+    w = (torch.randn(N, K) / K ** 0.5).requires_grad_(True)
+    b = torch.randn(N, requires_grad=True)
+    y = torch.nn.functional.linear(x, w, b)
+    if relu:
+        y = y.relu()
+    gy = torch.randn(M, N)
+    y.backward(gy)
+    xc = x.detach().cuda().requires_grad_(True); wc = w.detach().cuda().requires_grad_(True)
+    bc = b.detach().cuda().requires_grad_(True)
+    ops.linear(xc, wc, bc, relu=relu).backward(gy.cuda())
+    scale = max(1.0, float(M) ** 0.5)
+    np.testing.assert_allclose(xc.grad.cpu().numpy(), x.grad.numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL)
+    np.testing.assert_allclose(wc.grad.cpu().numpy(), w.grad.numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL * scale)
+    np.testing.assert_allclose(bc.grad.cpu().numpy(), b.grad.numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL * scale)
+
+
+def test_linear_bwd_weight_rows(ops):
+    torch.manual_seed(4)
+    T, M, K, N = 5000, 3000, 602, 602
+    tab = torch.randn(T, K); rows = torch.randint(0, T, (M,)); dy = torch.randn(M, N)
+    want_w = dy.T @ tab[rows]; want_b = dy.sum(0)
+    tabm = ops.empty_mat(T, K, "cuda").copy_(tab)
+    dw, db = ops.linear_bwd_weight(dy.cuda(), tabm, x_rows=rows.cuda())
+    np.testing.assert_allclose(dw.cpu().numpy(), want_w.numpy(), rtol=GEMM_RTOL, atol=1e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), want_b.numpy(), rtol=GEMM_RTOL, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,C", [(1, 3), (32, 3), (512, 41), (1024, 40), (7, 200)])
+def test_cross_entropy(ops, B, C):
+    torch.manual_seed(B + C)
+    logits = (torch.randn(B, C) * 3).requires_grad_(True)
+    labels = torch.randint(0, C, (B, 1))
+    for red in ("none", "mean"):
+        logits.grad = None
+        want = torch.nn.functional.cross_entropy(logits, labels.flatten(), reduction=red)
+        (want.sum() if red == "none" else want).backward()
+        lc = logits.detach().cuda().requires_grad_(True)
+        got = ops.cross_entropy(lc, labels.cuda(), red)
+        (got.sum() if red == "none" else got).backward()
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(lc.grad.cpu().numpy(), logits.grad.numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_adam(ops):
+    torch.manual_seed(0)
+    n = 100003
+    p = torch.randn(n); m = torch.zeros(n); v = torch.zeros(n)
+    pc, mc, vc = p.cuda(), m.cuda(), v.cuda()
+    for step in range(1, 5):
+        g = torch.randn(n)
+        O.adam_step(p, g, m, v, step)
+        ops.adam_step(pc, g.cuda(), mc, vc, step)
+    np.testing.assert_allclose(pc.cpu().numpy(), p.numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(vc.cpu().numpy(), v.numpy(), rtol=1e-5, atol=1e-9)
