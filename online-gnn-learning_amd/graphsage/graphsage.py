@@ -1,0 +1,29 @@
+"""GraphSAGE model: same constructor and ``forward(blocks, x)`` as
+R/train/graphsage/pytorch/graphsage_dgl.py:5-59; state_dict keys
+``layers.{i}.{fc_pool,fc_self,fc_neigh}.{weight,bias}`` (what R/export_model.py:107 saves and
+R/inference_optimized.py:136-139 reads)."""
+import torch.nn as nn
+
+from .sageconv import SAGEConv
+
+
+class GraphSAGE(nn.Module):
+    def __init__(self, in_feats, n_hidden, n_classes, n_layers, activation, dropout, aggregator_type, edge_feats=None,
+                 pool_feats=None):
+        super().__init__()
+        # the live reference layer (DGL SAGEConv) takes neither edge_feats nor pool_feats (graphsage_dgl.py:41
+        # comments them out); the in-repo layer does, so they are forwarded for its modes only
+        extra = {}
+        if aggregator_type != "pool":
+            extra = dict(edge_feats=edge_feats, pool_feats=pool_feats)
+        self.layers = nn.ModuleList()
+        self.layers.append(SAGEConv(in_feats, n_hidden, aggregator_type, feat_drop=dropout, activation=activation, **extra))
+        for _ in range(n_layers - 1):
+            self.layers.append(SAGEConv(n_hidden, n_hidden, aggregator_type, feat_drop=dropout, activation=activation, **extra))
+        self.layers.append(SAGEConv(n_hidden, n_classes, aggregator_type, feat_drop=dropout, activation=None, **extra))
+
+    def forward(self, blocks, x):
+        h = x
+        for layer, block in zip(self.layers, blocks):
+            h = layer(block, h)
+        return h

@@ -1,0 +1,293 @@
+"""Strategy layer: the classes ``utils.init`` hands to the driver loop.
+
+Mirrors R/train/graphsage/model.py:18-117 (backend-agnostic base: timing, evaluation, CSV rows) and
+R/train/graphsage/pytorch/model.py:12-323 (RBR / PBR / no-rehearsal / offline strategies): same
+constructor arguments, method names, return values and quiet early-returns.  The per-batch body is
+the MI355X path: GPU sampler + block builder, row gather fused into the projection GEMM, HIP
+aggregator, HIP cross-entropy and Adam — and the loader samples a whole snapshot's batches up front.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+from .. import ops, optim, sampling
+from .sageconv import GatheredRows
+
+
+def _to_numpy(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+class SupervisedGraphSage:
+    """Base class (R/train/graphsage/model.py:18-117)."""
+
+    def __init__(self, graphsage_model, batch_per_timestep, batch_size, labels, samples, n_workers, cuda, batch_full):
+        self.graphsage_model = graphsage_model
+        self.batch_size = batch_size
+        self.batch_per_timestep = batch_per_timestep
+        self.samples = samples
+        self.n_workers = n_workers
+        self.labels = labels
+        self._cuda_var = cuda
+        self.batch_full = batch_full
+        self.amount_of_train = {}
+        self.delay = 0.0
+        self.fuse_gather = True     # read feature rows straight from the resident table inside the GEMM
+
+    def build_optimizer(self):
+        raise NotImplementedError
+
+    def evaluate(self, graph_util, path):
+        return self._evaluate_vertices(graph_util, path, np.array(graph_util.get_test_set()))
+
+    def evaluate_next_snapshots(self, temporal_graph, delta, path, at_least=20):
+        new_vertices, labelled = temporal_graph.get_added_vertices(delta)
+        test = np.array(new_vertices)[np.asarray(labelled, dtype=bool)]
+        if len(test) < at_least:
+            with open(path, "a+") as f:
+                f.write(self.get_model() + ";;;\n")
+            return
+        return self._evaluate_vertices(temporal_graph, path, test)
+
+    def _evaluate_vertices(self, graph_util, path, batch_nids):
+        from sklearn.metrics import confusion_matrix, f1_score
+        id_to_subgraph = graph_util.get_original_to_subgraph_map()
+        subgraph_to_id = graph_util.get_subgraph_to_original_map()
+        graph = graph_util.get_graph()
+        vertices = id_to_subgraph[batch_nids]
+        output_data = self._run_custom_eval(graph, subgraph_to_id, id_to_subgraph, vertices)
+        if len(output_data) == 0:
+            return
+        output_data = np.concatenate(output_data)
+        if len(output_data) == 0:
+            return
+        vt = torch.as_tensor(np.asarray(vertices), dtype=torch.int64).to(graph.device)
+        labels = _to_numpy(ops.gather_i64(graph.ndata["target"], vt))
+        pred = output_data.argmax(axis=1)
+        cm = [int(item) for row in confusion_matrix(labels, pred) for item in row]
+        f1 = f1_score(labels, pred, average="macro")
+        with open(path, "a+") as f:
+            f.write(self.get_model() + ";" + str(f1) + ";" + str(self.delay) + ";" + str(cm) + "\n")
+        return f1
+
+    def _run_custom_eval(self, graph, subgraph_to_id, id_to_subgraph, test_vertices):
+        raise NotImplementedError
+
+    def get_model(self):
+        return "base_model"
+
+    def choose_vertices(self, graph_util):
+        raise NotImplementedError
+
+    def train_timestep(self, graph_util):
+        batch_nodes = self.choose_vertices(graph_util)
+        start = time.time()
+        id_to_subgraph = graph_util.get_original_to_subgraph_map()
+        subgraph_to_id = graph_util.get_subgraph_to_original_map()
+        graph = graph_util.get_graph()
+        self._run_custom_train(graph, subgraph_to_id, id_to_subgraph, id_to_subgraph[batch_nodes], graph_util)
+        torch.cuda.synchronize()            # the reference's delay includes the device work (it syncs per batch)
+        self.delay = time.time() - start
+
+
+class HipSupervisedGraphSage(SupervisedGraphSage):
+    """Counterpart of PytorchSupervisedGraphSage (R/train/graphsage/pytorch/model.py:12-108)."""
+
+    def __init__(self, graphsage_model, batch_per_timestep, batch_size, labels, samples, reduction="mean", n_workers=1,
+                 cuda=True, batch_full=512):
+        super().__init__(graphsage_model, batch_per_timestep, batch_size, labels, samples, n_workers, cuda, batch_full)
+        if not cuda:
+            raise RuntimeError("the hip backend runs on the GPU only: construct it with cuda=True")
+        self.reduction = reduction
+        self.xent = lambda scores, labels_: ops.cross_entropy(scores, labels_, reduction)
+
+    def build_optimizer(self):
+        self.optimizer = optim.Adam(self.graphsage_model.parameters(), lr=0.001)
+
+    def _sampler(self):
+        return sampling.MultiLayerNeighborSampler([self.samples for _ in range(2)], replace=True, return_eids=True)
+
+    def _inputs(self, graph, input_nodes):
+        if self.fuse_gather:
+            return GatheredRows(graph.ndata["feat"], input_nodes)
+        return ops.gather_rows(graph.ndata["feat"], input_nodes)
+
+    def _run_custom_eval(self, graph, subgraph_to_id, id_to_subgraph, test_vertices):
+        output_data = []
+        self.graphsage_model.eval()
+        seeds_all = torch.as_tensor(np.asarray(test_vertices), dtype=torch.int64)
+        if seeds_all.numel() == 0:
+            return output_data
+        loader = sampling.NodeDataLoader(graph, seeds_all, self._sampler(), batch_size=self.batch_full, shuffle=False,
+                                         drop_last=False, num_workers=self.n_workers)
+        outs = []
+        with torch.no_grad():
+            for input_nodes, seeds, blocks in loader:
+                outs.append(self.graphsage_model(blocks, self._inputs(graph, input_nodes)))
+        # one device->host transfer for the pass instead of one per batch
+        return [o.cpu().numpy() for o in outs]
+
+    def get_model(self):
+        return "base_model"
+
+    def train_step(self, graph, blocks, input_nodes, seeds, subgraph_to_id):
+        self.optimizer.zero_grad()
+        batch_inputs = self._inputs(graph, input_nodes)
+        batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
+        scores = self.graphsage_model(blocks, batch_inputs)
+        loss = self.xent(scores, batch_labels)
+        loss.backward()
+        self.optimizer.step()
+        return loss
+
+
+class RandomHipSupervisedGraphSage(HipSupervisedGraphSage):
+    """RBR: random rehearsal (R/.../pytorch/model.py:110-138)."""
+
+    def __init__(self, model, batch_per_timestep, batch_size, labels, samples, cuda=True, batch_full=512, n_workers=0):
+        super().__init__(model, batch_per_timestep, batch_size, labels, samples, n_workers=n_workers, cuda=cuda,
+                         batch_full=batch_full)
+
+    def choose_vertices(self, graph_util):
+        batch_nodes = []
+        for _ in range(self.batch_per_timestep):
+            batch_nodes += graph_util.draw_random_train_nodes(self.batch_size)
+        return batch_nodes
+
+    def _run_custom_train(self, graph, subgraph_to_id, id_to_subgraph, train_vertices, graph_util):
+        self.graphsage_model.train()
+        train_vertices = torch.as_tensor(np.asarray(train_vertices), dtype=torch.int64)
+        loader = sampling.NodeDataLoader(graph, train_vertices, self._sampler(),
+                                         batch_size=len(train_vertices) // self.batch_per_timestep,
+                                         shuffle=False, drop_last=False, num_workers=self.n_workers)
+        for input_nodes, seeds, blocks in loader:
+            self.train_step(graph, blocks, input_nodes, seeds, subgraph_to_id)
+
+    def get_model(self):
+        return "random"
+
+
+class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
+    """PBR: prioritised rehearsal (R/.../pytorch/model.py:141-257)."""
+
+    def __init__(self, model, batch_per_timestep, batch_size, labels, samples, priority_strategy, full_pass=2, cuda=True,
+                 batch_full=512, n_workers=0):
+        super().__init__(model, batch_per_timestep, batch_size, labels, samples, reduction="none", n_workers=n_workers,
+                         cuda=cuda, batch_full=batch_full)
+        self.time_step = 0
+        self.pass_var = 0
+        self.full_pass = full_pass
+        self.priority_strategy = priority_strategy
+
+    def choose_vertices(self, graph_util):
+        if self.time_step % self.full_pass == 0:
+            self.pass_var += 1
+            self.recompute_priorities(graph_util, graph_util.get_train_set())
+        elif len(graph_util.get_new_train_nodes()) > 1:
+            self.recompute_priorities(graph_util, graph_util.get_new_train_nodes())
+        batch_nodes = []
+        for _ in range(self.batch_per_timestep):
+            batch_nodes += graph_util.draw_priority_train_nodes(self.batch_size)
+        return batch_nodes
+
+    def _run_custom_train(self, graph, subgraph_to_id, id_to_subgraph, train_vertices, graph_util):
+        train_vertices = torch.as_tensor(np.asarray(train_vertices), dtype=torch.int64)
+        loader = sampling.NodeDataLoader(graph, train_vertices, self._sampler(),
+                                         batch_size=len(train_vertices) // self.batch_per_timestep,
+                                         shuffle=False, drop_last=False, num_workers=self.n_workers)
+        for input_nodes, seeds, blocks in loader:
+            batch_nodes_seed = subgraph_to_id[_to_numpy(seeds)]
+            batch_inputs = self._inputs(graph, input_nodes)
+            batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
+            self.optimizer.zero_grad()
+            scores = self.graphsage_model(blocks, batch_inputs)
+            unaggregated_loss = self.xent(scores, batch_labels)
+            loss = torch.mean(unaggregated_loss)
+            loss.backward()
+            self.optimizer.step()
+            priorities = self.priority_strategy.get_priorities(batch_nodes_seed, _to_numpy(unaggregated_loss))
+            graph_util.update_priorities(dict(zip(np.asarray(batch_nodes_seed).tolist(), np.asarray(priorities).tolist())))
+        self.time_step += 1
+
+    def recompute_priorities(self, graph_util, train_set):
+        """Priority forward: inference over ``train_set`` in batches of ``batch_full``, per-seed CE loss ->
+        ``graph_util.update_priorities`` (R/.../pytorch/model.py:210-254).  Runs under no_grad (the
+        reference builds and discards an autograd graph) and returns the losses to the host once."""
+        self.graphsage_model.eval()
+        id_to_subgraph = graph_util.get_original_to_subgraph_map()
+        subgraph_to_id = graph_util.get_subgraph_to_original_map()
+        train_set = list(train_set)
+        if len(train_set) == 0:
+            return
+        seeds_all = torch.as_tensor(np.asarray(id_to_subgraph[train_set]), dtype=torch.int64)
+        graph = graph_util.get_graph()
+        loader = sampling.NodeDataLoader(graph, seeds_all, self._sampler(), batch_size=self.batch_full, shuffle=False,
+                                         drop_last=False, num_workers=self.n_workers)
+        losses, nid_chunks = [], []
+        with torch.no_grad():
+            for input_nodes, seeds, blocks in loader:
+                batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
+                scores = self.graphsage_model(blocks, self._inputs(graph, input_nodes))
+                loss_rows, _ = ops.ce_fwd_bwd(scores, batch_labels, want_grad=False)
+                losses.append(loss_rows)
+                nid_chunks.append(seeds)
+        unaggregated_loss = torch.cat(losses).cpu().numpy()
+        batch_nids_l = list(subgraph_to_id[torch.cat(nid_chunks).cpu().numpy()])
+        priorities = self.priority_strategy.get_priorities(batch_nids_l, unaggregated_loss)
+        graph_util.update_priorities(dict(zip(np.asarray(batch_nids_l).tolist(), np.asarray(priorities).tolist())))
+
+    def get_model(self):
+        return "prioritized"
+
+
+class FullHipSupervisedGraphSage(HipSupervisedGraphSage):
+    """Offline GraphSAGE retrained on the whole train set (R/.../pytorch/model.py:260-290)."""
+
+    def __init__(self, model, batch_per_timestep, batch_size, labels, samples, cuda=True, batch_full=512, n_workers=0):
+        super().__init__(model, batch_per_timestep, batch_size, labels, samples, n_workers=n_workers, cuda=cuda,
+                         batch_full=batch_full)
+
+    def choose_vertices(self, graph_util):
+        return graph_util.get_train_set().copy()
+
+    def _run_custom_train(self, graph, subgraph_to_id, id_to_subgraph, batch_nodes, graph_util):
+        self.graphsage_model.train()
+        train_set = torch.as_tensor(np.asarray(batch_nodes), dtype=torch.int64)
+        for _ in range(self.batch_per_timestep):
+            train_set = train_set.view(-1)[torch.randperm(train_set.nelement())].view(train_set.size())
+            loader = sampling.NodeDataLoader(graph, train_set, self._sampler(), batch_size=self.batch_size, shuffle=False,
+                                             drop_last=False, num_workers=self.n_workers)
+            for input_nodes, seeds, blocks in loader:
+                self.train_step(graph, blocks, input_nodes, seeds, subgraph_to_id)
+
+    def get_model(self):
+        return "offline"
+
+
+class NoRehHipSupervisedGraphSage(HipSupervisedGraphSage):
+    """Trains on newly arrived vertices only (R/.../pytorch/model.py:293-323)."""
+
+    def __init__(self, model, batch_per_timestep, batch_size, labels, samples, cuda=True, batch_full=512, n_workers=0):
+        super().__init__(model, batch_per_timestep, batch_size, labels, samples, n_workers=n_workers, cuda=cuda,
+                         batch_full=batch_full)
+
+    def choose_vertices(self, graph_util):
+        return []
+
+    def _run_custom_train(self, graph, subgraph_to_id, id_to_subgraph, batch_nodes, graph_util):
+        self.graphsage_model.train()
+        for _ in range(self.batch_per_timestep):
+            idxs = graph_util.get_new_train_nodes(self.batch_size)
+            if len(idxs) < 2:
+                return
+            batch_nodes = id_to_subgraph[idxs]
+            loader = sampling.NodeDataLoader(graph, batch_nodes, self._sampler(), batch_size=len(batch_nodes),
+                                             shuffle=True, drop_last=False, num_workers=self.n_workers)
+            for input_nodes, seeds, blocks in loader:
+                self.train_step(graph, blocks, input_nodes, seeds, subgraph_to_id)
+
+    def get_model(self):
+        return "no_rehersal"

@@ -1,0 +1,142 @@
+"""GraphSAGE layer on fixed-fanout blocks, every arithmetic step a libogl_hip kernel.
+
+Two parameterisations, selected by ``aggregator_type`` exactly as in the reference:
+
+* ``'pool'`` — the layer the live ``backend=pytorch`` path trains: DGL's
+  ``SAGEConv(aggregator_type='pool')`` (imported at R/train/graphsage/pytorch/graphsage_dgl.py:3,
+  constructed at :41-46 with ``"pool"`` from R/train/__main__.py:124-127).  ``fc_pool: in->in``,
+  ReLU, elementwise MAX over the sampled in-neighbours, ``fc_self(h_dst) + fc_neigh(neigh)``.
+  Parameter names/shapes corroborated by R/inference_optimized.py:136-139,260,276.
+* ``'mean' | 'gcn' | 'meanpool' | 'maxpool'`` — the in-repo layer
+  R/train/graphsage/pytorch/aggregator_dgl.py:49-216: ``fc_pool: in->pool_feats`` (pool modes),
+  reduce, ``fc_neigh(cat(h_self, h_neigh))`` (gcn: ``fc_neigh((sum + h_dst)/(deg+1))``).
+  ``cat -> Linear`` runs as ONE dual-input GEMM over two column slices of ``fc_neigh.weight``.
+  (``maxpool`` is implemented as the elementwise max it documents; the reference's
+  ``.max(axis=1)`` at :175 returns a namedtuple and fails.)  ``'lstm'`` is outside the hot path.
+Unknown types raise ``KeyError`` from ``forward`` like the reference (:196-197).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .. import ops
+
+
+class GatheredRows:
+    """Lazy ``table[ids]``: the row gather is fused into the consuming GEMM / reduction loaders so
+    ``graph.ndata['feat'][input_nodes]`` (R/.../pytorch/model.py:54,88,182,232) is never materialised."""
+
+    def __init__(self, table: torch.Tensor, ids: torch.Tensor):
+        self.table, self.ids = table, ids
+
+    @property
+    def shape(self):
+        return (self.ids.numel(), self.table.shape[1])
+
+    def head(self, n):
+        return GatheredRows(self.table, self.ids[:n])
+
+    def materialize(self):
+        return ops.gather_rows(self.table, self.ids)
+
+
+def _is_relu(fn):
+    return fn is F.relu or fn is torch.relu or isinstance(fn, nn.ReLU)
+
+
+class SAGEConv(nn.Module):
+    def __init__(self, in_feats, out_feats, aggregator_type, feat_drop=0., bias=True, norm=None, edge_feats=None,
+                 activation=None, pool_feats=None):
+        super().__init__()
+        self._in_feats, self._out_feats, self._aggre_type = in_feats, out_feats, aggregator_type
+        self.norm, self.activation = norm, activation
+        self.feat_drop = nn.Dropout(feat_drop)
+        self.fc_pool = self.fc_self = self.fc_neigh = None
+        if edge_feats:
+            raise NotImplementedError("edge features are outside the hot path (settings use edge_feats=0)")
+        if aggregator_type == "lstm":
+            raise NotImplementedError("the lstm aggregator is outside the hot path")
+        in_neigh = in_feats
+        if aggregator_type == "pool":
+            self.fc_pool = nn.Linear(in_feats, in_feats)
+            self.fc_self = nn.Linear(in_feats, out_feats, bias=bias)
+            self.fc_neigh = nn.Linear(in_feats, out_feats, bias=bias)
+        else:
+            if pool_feats is not None and aggregator_type in ("maxpool", "meanpool"):
+                in_neigh = pool_feats
+            if aggregator_type in ("maxpool", "meanpool"):
+                self.fc_pool = nn.Linear(in_feats, in_neigh)
+            if aggregator_type == "gcn":
+                self.fc_neigh = nn.Linear(in_neigh, out_feats, bias=bias)
+            else:
+                self.fc_neigh = nn.Linear(in_neigh + in_feats, out_feats, bias=bias)
+        self.in_neigh_feats = in_neigh
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        """xavier_uniform(gain=sqrt 2) on every weight, default Linear bias init (aggregator_dgl.py:99-114;
+        DGL's SAGEConv does the same for fc_pool / fc_self / fc_neigh)."""
+        gain = nn.init.calculate_gain("relu")
+        for lin in (self.fc_pool, self.fc_self, self.fc_neigh):
+            if lin is not None:
+                nn.init.xavier_uniform_(lin.weight, gain=gain)
+
+    # ------------------------------------------------------------------------------------------
+    def _project(self, lin, x, relu=False, x2=None, w2=None, bias=None, w=None):
+        w = lin.weight if w is None else w
+        b = lin.bias if bias is None else bias
+        if isinstance(x, GatheredRows):
+            return ops.linear(x.table, w, b, x2, w2, relu, x.ids, None)
+        return ops.linear(x, w, b, x2, w2, relu, None, None)
+
+    def forward(self, graph, feat):
+        t = self._aggre_type
+        if t not in ("pool", "mean", "gcn", "meanpool", "maxpool"):
+            raise KeyError("Aggregator type {} not recognized.".format(t))
+        lazy = isinstance(feat, GatheredRows)
+        if not lazy and self.feat_drop.p > 0:
+            feat = self.feat_drop(feat)
+        n_dst = graph.number_of_dst_nodes()
+        idx = graph.local_idx
+        feat_dst = feat.head(n_dst) if lazy else feat[:n_dst]
+        fuse_relu = _is_relu(self.activation)
+
+        if t == "pool":
+            p = self._project(self.fc_pool, feat, relu=True)
+            h_neigh = ops.neighbor_reduce(p, idx, "max")
+            bias = None
+            if self.fc_self.bias is not None:
+                bias = self.fc_self.bias + self.fc_neigh.bias
+            rst = self._linear2(feat_dst, self.fc_self.weight, h_neigh, self.fc_neigh.weight, bias, fuse_relu)
+        elif t in ("meanpool", "maxpool"):
+            p = self._project(self.fc_pool, feat, relu=True)
+            h_neigh = ops.neighbor_reduce(p, idx, "mean" if t == "meanpool" else "max")
+            W = self.fc_neigh.weight
+            rst = self._linear2(feat_dst, W[:, :self._in_feats], h_neigh, W[:, self._in_feats:], self.fc_neigh.bias,
+                                fuse_relu)
+        elif t == "mean":
+            src = feat.materialize() if lazy else feat
+            h_neigh = ops.neighbor_reduce(src, idx, "mean")
+            W = self.fc_neigh.weight
+            rst = self._linear2(feat_dst, W[:, :self._in_feats], h_neigh, W[:, self._in_feats:], self.fc_neigh.bias,
+                                fuse_relu)
+        else:  # gcn
+            src = feat.materialize() if lazy else feat
+            s = ops.neighbor_reduce(src, idx, "sum")
+            degs = graph.in_degrees().to(s.dtype)
+            h_neigh = (s + src[:n_dst]) / (degs.unsqueeze(-1) + 1)
+            rst = ops.linear(h_neigh, self.fc_neigh.weight, self.fc_neigh.bias, None, None, fuse_relu, None, None)
+
+        if self.activation is not None and not fuse_relu:
+            rst = self.activation(rst)
+        if self.norm is not None:
+            rst = self.norm(rst)
+        return rst
+
+    @staticmethod
+    def _linear2(x1, w1, x2, w2, bias, relu):
+        if isinstance(x1, GatheredRows):
+            return ops.linear(x1.table, w1, bias, x2, w2, relu, x1.ids, None)
+        return ops.linear(x1, w1, bias, x2, w2, relu, None, None)

@@ -1,0 +1,152 @@
+"""Block sampler + loader with the surface the reference uses from DGL.
+
+Replaces ``dgl.sampling.MultiLayerNeighborSampler([S, S], replace=True, return_eids=True)`` and
+``dgl.sampling.NodeDataLoader(graph, seeds, sampler, batch_size, shuffle, drop_last, num_workers)``
+(call sites R/train/graphsage/pytorch/model.py:44-47,128-131,174-178,224-227,280-284,312-316).
+
+MI355X-first differences (documented in DESIGN.md):
+* sampling runs on the GPU over the resident time-ordered CSR (ogl_sample_layer / ogl_build_block),
+  so ``num_workers`` is accepted and ignored (HIP is not fork-safe; the forked CPU samplers are
+  what this replaces);
+* a loader samples ALL its batches layer by layer before yielding the first one, so the host
+  synchronises once per layer per loader (to learn the block sizes) instead of once per batch;
+* randomness is a counter-based Philox stream keyed by (seed, batch counter, layer, dst id, slot):
+  reproducible, independent of batch composition and of how seeds are sharded over GPUs.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+NID = "_ID"   # same key DGL uses for block.srcdata[dgl.NID]
+EID = "_EID"
+
+_STATE = {"seed": 1, "ctr": 0}
+
+
+def seed(value: int):
+    """Reset the sampler stream (the analogue of ``dgl.seed``; the reference never calls it)."""
+    _STATE["seed"] = int(value)
+    _STATE["ctr"] = 0
+
+
+def _next_ctr() -> int:
+    c = _STATE["ctr"]
+    _STATE["ctr"] = c + 1
+    return c
+
+
+def get_state():
+    return dict(_STATE)
+
+
+def set_state(state):
+    _STATE.update(state)
+
+
+class Block:
+    """Fixed-fanout bipartite block: edge j of dst d comes from src ``local_idx[d, j]``.
+
+    Offers what the reference touches on a DGL block: ``number_of_dst_nodes()``,
+    ``number_of_src_nodes()``, ``number_of_edges()``, ``in_degrees()``, ``srcdata[NID]``,
+    ``dstdata[NID]``, ``edata``, ``is_block`` and ``to(device)`` (R/.../pytorch/model.py:62,99,191).
+    """
+    is_block = True
+
+    def __init__(self, src_ids, dst_ids, local_idx, picks=None):
+        self.src_ids = src_ids            # int64 [n_src]  (dst nodes first)
+        self.dst_ids = dst_ids            # int64 [n_dst]
+        self.local_idx = local_idx        # int32 [n_dst, fanout], -1 = no neighbour
+        self.picks = picks                # int64 [n_dst, fanout] global ids (kept for the cached-projection path)
+        self.srcdata = {NID: src_ids}
+        self.dstdata = {NID: dst_ids}
+        self.edata = {}
+        self._n_edges = None
+
+    @property
+    def fanout(self):
+        return self.local_idx.shape[1]
+
+    def number_of_dst_nodes(self):
+        return int(self.dst_ids.numel())
+
+    def number_of_src_nodes(self):
+        return int(self.src_ids.numel())
+
+    def number_of_edges(self):
+        if self._n_edges is None:
+            self._n_edges = int((self.local_idx >= 0).sum().item())
+        return self._n_edges
+
+    def in_degrees(self):
+        return (self.local_idx >= 0).sum(dim=1)
+
+    def to(self, device):
+        dev = torch.device(device)
+        if dev.type == "cuda":
+            return self
+        raise RuntimeError("blocks live on the GPU; the HIP path has no CPU fallback")
+
+
+class MultiLayerNeighborSampler:
+    """fanouts[l] neighbours per dst of block l, uniform WITH replacement (``replace`` must be True:
+    every reference call site passes replace=True; fixed fanout is what makes blocks ELL-shaped)."""
+
+    def __init__(self, fanouts, replace=True, return_eids=False):
+        if not replace:
+            raise NotImplementedError("only replace=True (the mode the reference uses) is implemented")
+        if any(f is None for f in fanouts):
+            raise NotImplementedError("full-neighbour sampling (fanout None) is outside the hot path")
+        self.fanouts = [int(f) for f in fanouts]
+        self.return_eids = return_eids
+
+    def sample_batches(self, graph, seed_batches):
+        """Sample every batch, output layer first.  Returns a list of (input_nodes, seeds, blocks)."""
+        g = graph.handle
+        L = len(self.fanouts)
+        ctrs = [_next_ctr() for _ in seed_batches]
+        blocks = [[None] * L for _ in seed_batches]
+        dsts = list(seed_batches)
+        for layer in reversed(range(L)):
+            pend = []
+            for bi, dst in enumerate(dsts):
+                picks = ops.sample_layer(g, dst, self.fanouts[layer], _STATE["seed"], ctrs[bi], layer)
+                src_ids, n_src, local_idx = ops.build_block_async(dst, picks)
+                pend.append((picks, src_ids, n_src, local_idx))
+            if not pend:
+                break
+            counts = torch.cat([p[2] for p in pend]).cpu().tolist()      # the one sync of this layer
+            for bi, ((picks, src_ids, _, local_idx), n) in enumerate(zip(pend, counts)):
+                src = src_ids[:n]
+                blocks[bi][layer] = Block(src, dsts[bi], local_idx, picks)
+                dsts[bi] = src
+        return [(blk[0].src_ids, seeds, blk) for seeds, blk in zip(seed_batches, blocks)]
+
+
+class NodeDataLoader:
+    """Iterable of ``(input_nodes, seeds, blocks)`` in seed order; the last partial batch is kept
+    unless ``drop_last``; ``shuffle`` permutes the seeds first (torch CPU generator, as DataLoader does)."""
+
+    def __init__(self, graph, nids, sampler, batch_size=1, shuffle=False, drop_last=False, num_workers=0):
+        if batch_size is None or batch_size <= 0:
+            raise ValueError("batch_size should be a positive integer value, but got batch_size={}".format(batch_size))
+        self.graph, self.sampler = graph, sampler
+        self.batch_size, self.shuffle, self.drop_last = int(batch_size), shuffle, drop_last
+        self.num_workers = num_workers   # accepted for API parity; sampling is on the GPU
+        nids = torch.as_tensor(nids, dtype=torch.int64).reshape(-1)
+        self.nids = nids
+
+    def __len__(self):
+        n = self.nids.numel()
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        nids = self.nids
+        if self.shuffle:
+            nids = nids[torch.randperm(nids.numel())]
+        nids = nids.to(self.graph.device, non_blocking=True).contiguous()
+        n, bs = nids.numel(), self.batch_size
+        stops = list(range(0, n, bs))
+        batches = [nids[s:s + bs] for s in stops if not (self.drop_last and s + bs > n)]
+        return iter(self.sampler.sample_batches(self.graph, batches))

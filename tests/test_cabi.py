@@ -1,0 +1,62 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/ogl_hip.h declares
+(no compute calls here: those are the -m gpu tests)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "ogl_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ogl_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound():
+    import ogl_amd  # noqa: F401
+    from ogl_amd import _lib
+    names = _declared()
+    assert len(names) >= 20
+    h = _lib.lib()
+    for n in names:
+        assert hasattr(h, n), "libogl_hip.so does not export %s" % n
+    # the ctypes table covers the header one to one
+    assert sorted(_lib.SIGNATURES) == names
+    assert h.ogl_version() == 100
+    assert b"OGL_EWORKSPACE" in h.ogl_status_string(-4)
+
+
+def test_argument_validation_without_gpu():
+    """Entry points reject bad arguments before touching the device."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import _lib
+    h = _lib.lib()
+    out = ctypes.c_void_p()
+    assert h.ogl_graph_create(None, None, None, 5, 0, ctypes.byref(out)) == -1
+    assert h.ogl_sample_layer(None, None, 4, 25, 1, 0, 0, None, None) == -1
+    assert h.ogl_block_workspace_bytes(-1, 3) == -1
+    assert h.ogl_block_workspace_bytes(512, 25) >= 4 * 3 * 2 * 512 * 26
+    assert h.ogl_reduce_fwd(None, 4, 0, None, None, -1, 1, 4, 0, None, 4, None, None) == -1
+    assert h.ogl_linear_fwd(None, 2, None, 0, 4, 8, None, 8, 4, None, None, 0, None, 0, 0, None, 0, 0, None, 4, None) == -1
+    assert h.ogl_adam_step(None, None, None, None, 10, 0, 1e-3, 0.9, 0.999, 1e-8, None) == -1
+    assert h.ogl_linear_bwd_weight_workspace_bytes(233000, 602, 602) > 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    import ogl_amd  # noqa: F401
+    from ogl_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    import pytest
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_cpu_tensor_is_rejected():
+    import pytest
+    import torch
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.as_mat(torch.zeros(3, 4))

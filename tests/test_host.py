@@ -1,0 +1,173 @@
+"""Host-side logic that needs no GPU: replay buffer vs the reference-generated golden vectors
+(tests/golden/replay.json), sum tree, time-ordered CSR construction, synthetic generators,
+TrainTestGraph behaviour over a stub dynamic graph."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import ogl_amd  # noqa: F401
+from ogl_amd.graph.snapshot_graph import build_time_ordered_csr
+from ogl_amd.prioritized_replay import LossPriority, PrioritizedReplayBuffer, SumTree, TrendPriority
+from oracle import oracle as O
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "replay.json")))
+
+
+def test_sum_tree_matches_reference_golden():
+    g = GOLD["tree"]
+    t = SumTree(g["capacity"])
+    for i, v in enumerate(g["values"]):
+        t[i] = v
+    assert t.sum(0, 3) == g["sum_0_3"] and t.sum() == g["sum_all"] and t.sum(2, 7) == g["sum_2_7"]
+    assert [t.find_prefixsum_idx(q) for q in g["prefix_queries"]] == g["prefix_idx"]
+
+
+def test_sum_tree_growth_is_invisible():
+    rng = np.random.default_rng(0)
+    vals = rng.random(3000)
+    small, big = SumTree(4), SumTree(1 << 14)
+    small.set_many(np.arange(3000), vals)
+    big.set_many(np.arange(3000), vals)
+    assert small.sum(0, 2999) == big.sum(0, 2999)
+    for q in rng.random(200) * vals.sum():
+        assert small.find_prefixsum_idx(q) == big.find_prefixsum_idx(q)
+
+
+def test_replay_buffer_matches_reference_golden():
+    g = GOLD["buffer"]
+    buf = PrioritizedReplayBuffer(g["size"], g["alpha"], max_priority=g["max_priority"], min_priority=g["min_priority"])
+    first = {int(k): v for k, v in g["first"].items()}
+    second = {int(k): v for k, v in g["second"].items()}
+    buf.add_all(first)
+    np.testing.assert_allclose(buf.dump_priorities(list(first)), g["dump_after_first"], rtol=1e-13, atol=0)
+    buf.add_all(second)
+    keys = list(first) + list(second)
+    np.testing.assert_allclose(buf.dump_priorities(keys), g["dump_after_second"], rtol=1e-13, atol=0)
+    buf.update_priorities({int(k): v for k, v in g["update"].items()})
+    np.testing.assert_allclose(buf.dump_priorities(keys), g["dump_after_update"], rtol=1e-13, atol=0)
+    assert buf.get_min_priority() == g["min_val"] and buf.get_max_priority() == g["max_val"]
+    assert [int(x) for x in buf._storage] == g["storage"]
+    random.seed(1)
+    assert sorted(int(i) for i in buf._sample_proportional(8)) == g["sample8_seed1"]
+    random.seed(2)
+    assert sorted(int(i) for i in buf._sample_proportional(16)) == g["sample16_seed2"]
+    random.seed(3)
+    assert sorted(int(i) for i in buf._sample_proportional(100)) == g["sample100_seed3"]
+    random.seed(4)
+    got = buf.sample(8)
+    assert len(got) == 8 and set(got) <= set(keys)
+
+
+def test_priority_strategies():
+    g = GOLD["loss_priority"]
+    out = LossPriority().get_priorities(g["nodes"], np.array(g["losses"], dtype=np.float32))
+    np.testing.assert_array_equal(np.asarray(out, dtype=np.float32), np.array(g["out"], dtype=np.float32))
+    tp = TrendPriority(10)
+    p1 = tp.get_priorities([1, 2], np.array([1.0, 2.0]))
+    p2 = tp.get_priorities([1, 2], np.array([3.0, 1.0]))
+    assert p1.shape == (2,) and p2[0] > p2[1] >= 0
+
+
+def test_time_ordered_csr_vertex_and_edge():
+    rng = np.random.default_rng(1)
+    n, e = 50, 400
+    s, d = rng.integers(0, n, e), rng.integers(0, n, e)
+    ip, ix, ky = build_time_ordered_csr(n, s, d, s)
+    assert ip[-1] == e and (ix == ky).all()
+    for v in range(n):
+        row = ix[ip[v]:ip[v + 1]]
+        assert (np.diff(row) >= 0).all() and sorted(row.tolist()) == sorted(s[d == v].tolist())
+    rows = np.arange(e)
+    ip, ix, ky = build_time_ordered_csr(n, np.concatenate([s, d]), np.concatenate([d, s]), np.concatenate([rows, rows]))
+    for v in range(n):
+        assert (np.diff(ky[ip[v]:ip[v + 1]]) >= 0).all()
+    # snapshot degrees at a cut = number of incident rows before the cut (self loops count twice)
+    cut = 123
+    deg = O.snapshot_degrees_fast(ip, ky, n, cut)
+    want = np.bincount(np.concatenate([s[:cut], d[:cut]]), minlength=n)
+    assert (deg == want).all()
+    with pytest.raises(ValueError):
+        build_time_ordered_csr(3, [0, 5], [1, 1], [0, 1])
+
+
+def test_synthetic_generators_are_seeded_and_shaped():
+    from ogl_amd import synthetic
+    a = synthetic.make_arrays("toy")
+    b = synthetic.make_arrays("toy")
+    assert a["n"] == 600 and a["feat"].shape == (600, 20) and a["labels"].max() < 4
+    assert (a["src"] == b["src"]).all() and (a["feat"] == b["feat"]).all() and (a["order"] == b["order"]).all()
+    e = synthetic.make_arrays("toy_edge")
+    flat = np.stack([e["src"], e["dst"]], 1).reshape(-1)
+    seen = np.concatenate([[-1], np.maximum.accumulate(flat)[:-1]])
+    assert (flat <= seen + 1).all(), "edge-stream ids must be relabelled by first appearance"
+    assert e["n"] == flat.max() + 1
+    spec = synthetic.SPECS["reddit"]
+    assert (spec["n"], spec["f"], spec["c"]) == (232965, 602, 41)
+
+
+class _StubDynamicGraph:
+    """10 labelled vertices per snapshot; enough surface for TrainTestGraph."""
+
+    def __init__(self, snapshots=6, per=10):
+        self.snapshots, self.per, self.evolution_index = snapshots, per, 1
+
+    def __len__(self):
+        return self.snapshots
+
+    def get_graph(self):
+        return None
+
+    def get_added_vertices(self, delta=None):
+        lo = (self.evolution_index - 1) * self.per
+        v = list(range(lo, lo + self.per))
+        return v, [True] * len(v)
+
+    def evolve(self):
+        self.evolution_index += 1
+
+    def get_original_to_subgraph_map(self):
+        return np.arange(1000)
+
+    def get_subgraph_to_original_map(self):
+        return np.arange(1000)
+
+
+def test_train_test_graph_behaviour():
+    from ogl_amd.graph.train_test_graph import TrainTestGraph
+    np.random.seed(1); random.seed(1)
+    g = TrainTestGraph(_StubDynamicGraph(), split=0.15, start_prior_alpha=4, end_prior_alpha=50, scale=1, max_priority=10)
+    assert len(g.get_train_set()) == 8 and len(g.get_test_set()) == 2            # 85/15 of 10
+    assert set(g.get_train_set()) | set(g.get_test_set()) == set(range(10))
+    assert g.priority_replay_buffer.get_max_priority() == 2                       # start_priority while empty
+    g.evolve()
+    assert len(g.get_train_set()) == 16 and g.prior_alpha == pytest.approx(4 + (46 / 6) * 1)
+    assert len(g.get_new_train_nodes()) == 8 and len(g.get_new_train_nodes(3)) == 3
+    # uniform shuffle prefix whenever n <= |train| (reference quirk kept), buffer sampling otherwise
+    draw = g.draw_priority_train_nodes(5)
+    assert len(draw) == 5 and set(draw) <= set(g.get_train_set())
+    assert set(g.draw_random_train_nodes(100)) == set(g.get_train_set())
+    # partial update keeps the buffer, a full-size update re-creates it
+    before = g.priority_replay_buffer
+    g.update_priorities({g.get_train_set()[0]: 3.0})
+    assert g.priority_replay_buffer is before
+    g.update_priorities({v: 1.0 + i for i, v in enumerate(g.get_train_set())})
+    assert g.priority_replay_buffer is not before and len(g.priority_replay_buffer) == 16
+    with pytest.raises(AssertionError):
+        g.update_priorities({v: 1.0 for v in range(100)})
+
+
+def test_loader_batching_rules():
+    import torch
+    from ogl_amd import sampling
+    ld = sampling.NodeDataLoader(None, torch.arange(103), None, batch_size=103 // 2)
+    assert len(ld) == 3                                   # len//bpt batches + one remainder batch (drop_last=False)
+    assert len(sampling.NodeDataLoader(None, torch.arange(103), None, batch_size=51, drop_last=True)) == 2
+    with pytest.raises(ValueError):
+        sampling.NodeDataLoader(None, torch.arange(3), None, batch_size=3 // 8)
+    with pytest.raises(NotImplementedError):
+        sampling.MultiLayerNeighborSampler([5, 5], replace=False)
+    sampling.seed(7)
+    assert sampling.get_state() == {"seed": 7, "ctr": 0}
