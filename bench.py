@@ -1,0 +1,252 @@
+#!/usr/bin/env python
+"""Headline benchmark: streamed vertices/sec of the RBR training update on the Reddit-shaped stream
+(BASELINE.json configs[3]: depth=2, samples=25, batch=512, F=602/H=600/C=41, pool aggregator),
+plus the aggregator's achieved HBM GB/s and the projection GEMM's MFMA TFLOP/s against CDNA4 peaks,
+next to the CPU oracle ("port") timed on this node's host cores.
+
+  python bench.py --gpus N --steps K --warmup W         (N > 1: launched by torch.distributed.run)
+
+A "step" = one pass of the hot path over one replay batch of 512 seeds per GPU: 2-hop sampling +
+block construction, feature-row gather (fused into the GEMM loaders), 2-layer GraphSAGE forward, cross
+entropy, backward, Adam.  Sampling is done per snapshot for `batch_timestep` batches at once and is
+inside the timed region; seed selection (choose_vertices) is outside, as in the reference's `delay`
+(R/train/graphsage/model.py:108-117).  Inputs (CSR, feature table, labels, weights) are resident in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+WORKLOADS = {
+    # name:     dataset  B    S   H    batch_timestep
+    "reddit_rbr": dict(dataset="reddit", batch=512, samples=25, hidden=600, batch_timestep=50),
+    "arxiv_rbr": dict(dataset="arxiv", batch=32, samples=25, hidden=32, batch_timestep=1),
+    "pubmed_rbr": dict(dataset="pubmed", batch=32, samples=25, hidden=32, batch_timestep=2),
+    "toy_rbr": dict(dataset="toy", batch=32, samples=5, hidden=16, batch_timestep=2),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="reddit_rbr", choices=sorted(WORKLOADS))
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the synthetic graph (debugging only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops, optim, parallel, sampling, synthetic
+    from ogl_amd.graphsage import GatheredRows, GraphSAGE
+
+    wl = WORKLOADS[args.workload]
+    B, S, H, bt = wl["batch"], wl["samples"], wl["hidden"], wl["batch_timestep"]
+    t0 = time.time()
+    feat_size, labels_np, dyn, n_classes, _unused = None, None, None, None, None
+    arrays = synthetic.make_arrays(wl["dataset"], args.scale)
+    feat_size, n_classes = arrays["f"], arrays["c"]
+    # last snapshot of the stream: every vertex and edge present (the most work per seed)
+    if arrays["stream"] == "edge":
+        from ogl_amd.graph.dynamic_graph_edge import DynamicGraphEdge
+        dyn = DynamicGraphEdge(arrays["snapshots"], set(), device="cuda")
+        dyn.build(arrays["feat"], arrays["labels"], True, edge_timestamps={"src": arrays["src"], "dst": arrays["dst"]})
+        g = dyn.get_graph()
+        g.set_snapshot(g.n_total, len(arrays["src"]))
+    else:
+        from ogl_amd.graph.dynamic_graph_vertex import DynamicGraphVertex, FullGraphData
+        gd = FullGraphData(arrays["n"], np.concatenate([arrays["src"], arrays["dst"]]),
+                           np.concatenate([arrays["dst"], arrays["src"]]), arrays["feat"], arrays["labels"])
+        dyn = DynamicGraphVertex(gd, arrays["snapshots"], set(), device="cuda")
+        dyn.build(vertex_timestamps={int(v): int(t) for t, v in enumerate(arrays["order"])})
+        g = dyn.get_graph()
+        g.set_snapshot(g.n_total, g.n_total)
+    setup_s = time.time() - t0
+
+    torch.manual_seed(1)                                     # identical replicas on every rank
+    model = GraphSAGE(feat_size, H, n_classes, 1, F.relu, 0, "pool", edge_feats=0, pool_feats=H).cuda()
+    opt = optim.Adam(model.parameters(), lr=1e-3)
+    gsync = parallel.GradSynchronizer(model.parameters()) if world > 1 else None
+    sampler = sampling.MultiLayerNeighborSampler([S, S], replace=True, return_eids=True)
+    sampling.seed(1)
+    split_rng = np.random.default_rng(synthetic.SEEDS["split"])
+    train_set = np.sort(split_rng.permutation(g.n_present)[: int(0.85 * g.n_present)])
+    seed_rng = np.random.default_rng(1000 + rank)            # every rank rehearses its own B seeds (weak scaling)
+
+    def draw(nb):
+        return torch.as_tensor(np.concatenate([seed_rng.choice(train_set, B, replace=False) for _ in range(nb)]))
+
+    stats = dict(n0=[], n1=[])
+
+    def run(nsteps, seeds_per_snapshot):
+        done = 0
+        for seeds in seeds_per_snapshot:
+            loader = sampling.NodeDataLoader(g, seeds, sampler, batch_size=B)
+            for input_nodes, sd, blocks in loader:
+                if done >= nsteps:
+                    return
+                opt.zero_grad()
+                labels = ops.gather_i64(g.ndata["target"], sd)
+                logits = model(blocks, GatheredRows(g.ndata["feat"], input_nodes))
+                loss = ops.cross_entropy(logits, labels, "mean")
+                loss.backward()
+                if gsync is not None:
+                    gsync.sync()
+                opt.step()
+                stats["n0"].append(input_nodes.numel()); stats["n1"].append(blocks[1].number_of_src_nodes())
+                done += 1
+
+    def plan(nsteps):
+        out, left = [], nsteps
+        while left > 0:
+            nb = min(bt, left)
+            out.append(draw(nb)); left -= nb
+        return out
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup, plan(args.warmup))
+    seeds_plan = plan(args.steps)
+    stats = dict(n0=[], n1=[])
+    barrier()
+    t1 = time.perf_counter()
+    run(args.steps, seeds_plan)
+    barrier()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    n0_avg, n1_avg = float(np.mean(stats["n0"])), float(np.mean(stats["n1"]))
+
+    # ---- per-kernel HIP-event timing (same workload, separate instrumented pass) -----------------
+    prof_steps = min(args.steps, bt)
+    prof_plan = plan(prof_steps)
+    barrier()
+    ops.profile_start()
+    run(prof_steps, prof_plan)
+    rec = ops.profile_stop()
+    agg = {}
+    for name, meta, ms in rec:
+        key = name
+        if name == "ogl_reduce_fwd":
+            key = "reduce_fwd_L0" if meta["n_dst"] > B else "reduce_fwd_L1"
+        elif name.startswith("ogl_linear"):
+            big = meta["M"] > 4 * B * (1 + S) // 2 or (name == "ogl_linear_bwd_weight" and meta["M"] > B * (1 + S))
+            key = name[4:] + ("_pool0" if meta["M"] > B * (1 + S) else "_other")
+            del big
+        a = agg.setdefault(key, dict(ms=0.0, calls=0, bytes=0.0, flops=0.0))
+        a["ms"] += ms; a["calls"] += 1
+        if name == "ogl_reduce_fwd":
+            E = meta["n_dst"] * meta["fanout"]
+            a["bytes"] += E * (4 * meta["d"] + meta["idx_bytes"]) + meta["n_dst"] * 4 * meta["d"] * (2 if meta["argmax"] else 1)
+        if name == "ogl_linear_fwd":
+            a["flops"] += 2.0 * meta["M"] * meta["N"] * (meta["K"] + meta["K2"])
+        if name in ("ogl_linear_bwd_input", "ogl_linear_bwd_weight"):
+            a["flops"] += 2.0 * meta["M"] * meta["N"] * meta["K"]
+    kernels = {k: dict(avg_ms=v["ms"] / v["calls"], ms_per_step=v["ms"] / prof_steps, calls_per_step=v["calls"] / prof_steps,
+                       gbs=(v["bytes"] / v["ms"] / 1e6) if v["bytes"] else None,
+                       tflops=(v["flops"] / v["ms"] / 1e9) if v["flops"] else None) for k, v in agg.items()}
+    ragg = agg.get("reduce_fwd_L0")
+    roof_aggr = None
+    if ragg:
+        ach = ragg["bytes"] / ragg["ms"] / 1e6
+        roof_aggr = dict(kernel="k_reduce_fwd_v4 (layer-0 gather+max, argmax kept)", bound="hbm", achieved=round(ach, 1),
+                         peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                         avg_launch_ms=round(ragg["ms"] / ragg["calls"], 4),
+                         algorithmic_bytes_per_launch=round(ragg["bytes"] / ragg["calls"]))
+    gemm_keys = [k for k in agg if k.startswith("linear") and agg[k]["flops"] > 0]
+    gflops = sum(agg[k]["flops"] for k in gemm_keys); gms = sum(agg[k]["ms"] for k in gemm_keys)
+    dom = max(gemm_keys, key=lambda k: agg[k]["ms"]) if gemm_keys else None
+    roof_gemm = None
+    if dom:
+        ach = agg[dom]["flops"] / agg[dom]["ms"] / 1e9
+        roof_gemm = dict(kernel="k_gemm fp32 MFMA 32x32x2 (%s)" % dom, bound="mfma", achieved=round(ach, 2),
+                         peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+                         avg_launch_ms=round(agg[dom]["ms"] / agg[dom]["calls"], 4),
+                         algorithmic_flops_per_launch=round(agg[dom]["flops"] / agg[dom]["calls"]),
+                         all_gemms_tflops=round(gflops / gms / 1e9, 2) if gms else None)
+
+    # ---- CPU baseline: the oracle ("port" of the reference path) on this node's host cores ---------
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        h = g.handle
+        indptr, indices = h.indptr.cpu().numpy(), h.indices.cpu().numpy()
+        keys = (h.keys if h.keys is not None else h.indices).cpu().numpy()
+        deg = O.snapshot_degrees_fast(indptr, keys, g.n_present, g.cut)
+        feat_cpu = g.ndata["feat"].cpu().contiguous()
+        lab_cpu = g.ndata["target"].cpu()
+        cpu = O.CpuModel("pool", feat_size, H, n_classes, pool_feats=H, seed=1)
+        tc, nstep = time.perf_counter(), 0
+        while nstep < 1 or (time.perf_counter() - tc < args.cpu_seconds and nstep < 8):
+            sd = seed_rng.choice(train_set, B, replace=False)
+            cpu.train_step(feat_cpu, lab_cpu, indptr, indices, deg, sd, S, 1, 10 ** 6 + nstep)
+            nstep += 1
+        dt = time.perf_counter() - tc
+        cpu_baseline = dict(value=round(nstep * B / dt, 2), unit="vertices/s", cores=cores, kind="port",
+                            sample="%d RBR train steps of %d seeds (same graph, shapes and sampler) in %.1f s; torch-CPU fp32, "
+                                   "%d threads" % (nstep, B, dt, cores))
+
+    if rank == 0:
+        value = args.steps * B * world / elapsed
+        line = {
+            "metric": "streamed vertices/sec (RBR train update), Reddit-shaped stream depth=2 samples=25",
+            "value": round(value, 1), "unit": "vertices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %s-like %s stream, last snapshot (N=%d, CSR nnz=%d), F=%d H=%d C=%d, "
+                                   "aggregator=pool(max), depth=2 samples=%d batch=%d/GPU batch_timestep=%d, "
+                                   "sample+gather+fwd+CE+bwd+Adam" % (args.workload, wl["dataset"], arrays["stream"], g.n_present,
+                                                                        int(h_nnz(g)), feat_size, H, n_classes, S, B, bt),
+                       "global_batch": B * world, "parallelism": "dp%d (seed-sharded replicas, flat-bucket grad all-reduce)" % world,
+                       "avg_unique_input_nodes_n0": round(n0_avg, 1), "avg_n1": round(n1_avg, 1), "setup_s": round(setup_s, 1)},
+            "roofline": roof_gemm if roof_gemm else roof_aggr,
+            "roofline_aggregator": roof_aggr,
+            "cpu_baseline": cpu_baseline,
+            "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in sorted(kernels.items())},
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def h_nnz(g):
+    return g.handle.nnz
+
+
+if __name__ == "__main__":
+    main()

@@ -149,9 +149,10 @@ int ogl_ce_fwd_bwd(const float* logits, int64_t ldl, const int64_t* labels, int6
                    float grad_scale, float* loss_rows, float* dlogits, int64_t lddl,
                    ogl_stream_t stream);
 
-/* torch.optim.Adam(lr) single-tensor update (R/train/graphsage/pytorch/model.py:24-25,107). */
+/* torch.optim.Adam(lr) single-tensor update (R/train/graphsage/pytorch/model.py:24-25,107).
+ * Hyper-parameters are doubles (as Python floats are) so 1-beta is rounded to fp32 once, like torch. */
 int ogl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step,
-                  float lr, float beta1, float beta2, float eps, ogl_stream_t stream);
+                  double lr, double beta1, double beta2, double eps, ogl_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@ _p = C.c_void_p
 _i64 = C.c_int64
 _i = C.c_int
 _f = C.c_float
+_d = C.c_double
 _u64 = C.c_uint64
 
 # name -> (restype, argtypes): mirrors include/ogl_hip.h one to one
@@ -40,7 +41,7 @@ SIGNATURES = {
     "ogl_linear_bwd_weight": (_i, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i, _i, _p, _i64, _p,
                                    _p, _i64, _p]),
     "ogl_ce_fwd_bwd": (_i, [_p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p]),
-    "ogl_adam_step": (_i, [_p, _p, _p, _p, _i64, _i, _f, _f, _f, _f, _p]),
+    "ogl_adam_step": (_i, [_p, _p, _p, _p, _i64, _i, _d, _d, _d, _d, _p]),
 }
 
 _lib = None

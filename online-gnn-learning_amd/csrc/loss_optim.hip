@@ -73,17 +73,18 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
   }
 }
 
-extern "C" int ogl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr,
-                             float beta1, float beta2, float eps, ogl_stream_t stream) {
+extern "C" int ogl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, double lr,
+                             double beta1, double beta2, double eps, ogl_stream_t stream) {
   if (n < 0 || step < 1) return OGL_EINVAL;
   if (n == 0) return OGL_OK;
   if (!p || !g || !m || !v) return OGL_EINVAL;
-  const double bc1 = 1.0 - pow((double)beta1, step);
-  const double bc2 = 1.0 - pow((double)beta2, step);
-  const float step_size = (float)((double)lr / bc1);
+  const double bc1 = 1.0 - pow(beta1, step);
+  const double bc2 = 1.0 - pow(beta2, step);
+  const float step_size = (float)(lr / bc1);
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   hipLaunchKernelGGL(k_adam, dim3((unsigned)min((int64_t)2048, ogl_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream,
-                     p, g, m, v, n, 1.0f - beta1, beta2, 1.0f - beta2, inv_sqrt_bc2, step_size, eps);
+                     p, g, m, v, n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), inv_sqrt_bc2, step_size,
+                     (float)eps);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }

@@ -18,6 +18,36 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Optional per-call HIP-event timing (bench.py's roofline leg).  Events are recorded on the stream the
+# kernels are launched on (torch's current stream), so elapsed_time brackets exactly that call's kernels.
+_PROFILE = None
+
+
+def profile_start():
+    global _PROFILE
+    _PROFILE = []
+
+
+def profile_stop():
+    """Returns [(name, meta, milliseconds)] for every C-ABI launch since profile_start()."""
+    global _PROFILE
+    rec, _PROFILE = _PROFILE or [], None
+    torch.cuda.synchronize()
+    return [(n, m, s.elapsed_time(e)) for n, m, s, e in rec]
+
+
+def _launch(name, fn, *args, meta=None):
+    if _PROFILE is None:
+        check(fn(*args), name)
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    st = fn(*args)
+    e.record()
+    _PROFILE.append((name, meta, s, e))
+    check(st, name)
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -101,9 +131,8 @@ class GraphHandle:
 def sample_layer(g: GraphHandle, dst: torch.Tensor, fanout: int, seed: int, ctr: int, layer: int) -> torch.Tensor:
     dst = _ids(dst)
     picks = torch.empty((dst.numel(), fanout), dtype=torch.int64, device=dst.device)
-    check(_lib.lib().ogl_sample_layer(g._h, _ptr(dst), dst.numel(), int(fanout), C.c_uint64(seed & (2 ** 64 - 1)),
-                                      C.c_uint64(ctr & (2 ** 64 - 1)), int(layer), _ptr(picks), _stream()),
-          "ogl_sample_layer")
+    _launch("ogl_sample_layer", _lib.lib().ogl_sample_layer, g._h, _ptr(dst), dst.numel(), int(fanout), C.c_uint64(seed & (2 ** 64 - 1)),
+                                      C.c_uint64(ctr & (2 ** 64 - 1)), int(layer), _ptr(picks), _stream(), meta=dict(n_dst=dst.numel(), fanout=int(fanout)))
     return picks
 
 
@@ -119,8 +148,8 @@ def build_block_async(dst: torch.Tensor, picks: torch.Tensor):
     local_idx = torch.empty((n_dst, fanout), dtype=torch.int32, device=dev)
     nbytes = int(_lib.lib().ogl_block_workspace_bytes(n_dst, fanout))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
-    check(_lib.lib().ogl_build_block(_ptr(dst), n_dst, _ptr(picks), int(fanout), _ptr(src_ids), _ptr(n_src),
-                                     _ptr(local_idx), _ptr(ws), nbytes, _stream()), "ogl_build_block")
+    _launch("ogl_build_block", _lib.lib().ogl_build_block, _ptr(dst), n_dst, _ptr(picks), int(fanout), _ptr(src_ids), _ptr(n_src),
+                                     _ptr(local_idx), _ptr(ws), nbytes, _stream(), meta=dict(n_dst=n_dst, fanout=int(fanout)))
     return src_ids, n_src, local_idx
 
 
@@ -138,8 +167,8 @@ def gather_rows(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     ids = _ids(ids)
     d = table.shape[1]
     out = empty_mat(ids.numel(), d, table.device)
-    check(_lib.lib().ogl_gather_rows(_ptr(table), _ld(table), table.shape[0], _ptr(ids), ids.numel(), d,
-                                     _ptr(out), _ld(out), _stream()), "ogl_gather_rows")
+    _launch("ogl_gather_rows", _lib.lib().ogl_gather_rows, _ptr(table), _ld(table), table.shape[0], _ptr(ids), ids.numel(), d,
+                                     _ptr(out), _ld(out), _stream(), meta=dict(n=ids.numel(), d=d))
     return out
 
 
@@ -165,8 +194,8 @@ def reduce_fwd(src: torch.Tensor, idx: torch.Tensor, op: str, want_argmax: bool 
     i64 = idx if idx.dtype == torch.int64 else None
     if i32 is None and i64 is None:
         raise ValueError("idx must be int32 or int64")
-    check(_lib.lib().ogl_reduce_fwd(_ptr(src), _ld(src), src.shape[0], _ptr(i32), _ptr(i64), n_dst, fanout, d,
-                                    REDUCE_OPS[op], _ptr(out), _ld(out), _ptr(argmax), _stream()), "ogl_reduce_fwd")
+    _launch("ogl_reduce_fwd", _lib.lib().ogl_reduce_fwd, _ptr(src), _ld(src), src.shape[0], _ptr(i32), _ptr(i64), n_dst, fanout, d,
+                                    REDUCE_OPS[op], _ptr(out), _ld(out), _ptr(argmax), _stream(), meta=dict(n_dst=n_dst, fanout=fanout, d=d, op=op, argmax=argmax is not None, idx_bytes=idx.element_size()))
     return out, argmax
 
 
@@ -175,8 +204,8 @@ def reduce_bwd(dout: torch.Tensor, idx32: torch.Tensor, argmax, op: str, n_src: 
     n_dst, d = dout.shape
     fanout = idx32.shape[1]
     dsrc = empty_mat(n_src, d, dout.device, zero=True)
-    check(_lib.lib().ogl_reduce_bwd(_ptr(dout), _ld(dout), _ptr(idx32), _ptr(argmax), n_dst, fanout, d,
-                                    REDUCE_OPS[op], n_src, _ptr(dsrc), _ld(dsrc), _stream()), "ogl_reduce_bwd")
+    _launch("ogl_reduce_bwd", _lib.lib().ogl_reduce_bwd, _ptr(dout), _ld(dout), _ptr(idx32), _ptr(argmax), n_dst, fanout, d,
+                                    REDUCE_OPS[op], n_src, _ptr(dsrc), _ld(dsrc), _stream(), meta=dict(n_dst=n_dst, fanout=fanout, d=d, op=op))
     return dsrc
 
 
@@ -195,10 +224,10 @@ def linear_fwd(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_ro
         assert w2.shape == (N, K2)
         assert (x2_rows.numel() if x2_rows is not None else x2.shape[0]) == M
     y = out if out is not None else empty_mat(M, N, x.device)
-    check(_lib.lib().ogl_linear_fwd(
+    _launch("ogl_linear_fwd", _lib.lib().ogl_linear_fwd, 
         _ptr(x), _ld(x), _ptr(x_rows), x.shape[0], M, K, _ptr(w), _ld(w), N, _ptr(bias),
         _ptr(x2), _ld(x2) if x2 is not None else 0, _ptr(x2_rows), x2.shape[0] if x2 is not None else 0, K2,
-        _ptr(w2), _ld(w2) if w2 is not None else 0, int(bool(relu)), _ptr(y), _ld(y), _stream()), "ogl_linear_fwd")
+        _ptr(w2), _ld(w2) if w2 is not None else 0, int(bool(relu)), _ptr(y), _ld(y), _stream(), meta=dict(M=M, K=K, N=N, K2=K2))
     return y
 
 
@@ -209,9 +238,8 @@ def linear_bwd_input(dy, w, ymask=None):
     if ymask is not None:
         ymask = as_mat(ymask)
     dx = empty_mat(M, K, dy.device)
-    check(_lib.lib().ogl_linear_bwd_input(_ptr(dy), _ld(dy), _ptr(ymask), _ld(ymask) if ymask is not None else 0,
-                                          M, N, _ptr(w), _ld(w), K, _ptr(dx), _ld(dx), _stream()),
-          "ogl_linear_bwd_input")
+    _launch("ogl_linear_bwd_input", _lib.lib().ogl_linear_bwd_input, _ptr(dy), _ld(dy), _ptr(ymask), _ld(ymask) if ymask is not None else 0,
+                                          M, N, _ptr(w), _ld(w), K, _ptr(dx), _ld(dx), _stream(), meta=dict(M=M, K=K, N=N))
     return dx
 
 
@@ -226,9 +254,9 @@ def linear_bwd_weight(dy, x, ymask=None, x_rows=None, want_bias=True, dw_out=Non
     db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
     nbytes = int(_lib.lib().ogl_linear_bwd_weight_workspace_bytes(M, N, K))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
-    check(_lib.lib().ogl_linear_bwd_weight(
+    _launch("ogl_linear_bwd_weight", _lib.lib().ogl_linear_bwd_weight, 
         _ptr(dy), _ld(dy), _ptr(ymask), _ld(ymask) if ymask is not None else 0, _ptr(x), _ld(x), _ptr(x_rows),
-        x.shape[0], M, N, K, _ptr(dw), _ld(dw), _ptr(db), _ptr(ws), nbytes, _stream()), "ogl_linear_bwd_weight")
+        x.shape[0], M, N, K, _ptr(dw), _ld(dw), _ptr(db), _ptr(ws), nbytes, _stream(), meta=dict(M=M, K=K, N=N))
     return dw, db
 
 
@@ -242,16 +270,16 @@ def ce_fwd_bwd(logits, labels, grad_scale=1.0, want_grad=True):
     B, Cc = logits.shape
     loss = torch.empty(B, dtype=torch.float32, device=logits.device)
     dl = empty_mat(B, Cc, logits.device) if want_grad else None
-    check(_lib.lib().ogl_ce_fwd_bwd(_ptr(logits), _ld(logits), _ptr(labels), B, Cc, C.c_float(grad_scale), _ptr(loss),
-                                    _ptr(dl), _ld(dl) if dl is not None else 0, _stream()), "ogl_ce_fwd_bwd")
+    _launch("ogl_ce_fwd_bwd", _lib.lib().ogl_ce_fwd_bwd, _ptr(logits), _ld(logits), _ptr(labels), B, Cc, C.c_float(grad_scale), _ptr(loss),
+                                    _ptr(dl), _ld(dl) if dl is not None else 0, _stream(), meta=dict(B=B, C=Cc))
     return loss, dl
 
 
 def adam_step(p, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
     for t in (p, g, m, v):
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
-    check(_lib.lib().ogl_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(step), C.c_float(lr),
-                                   C.c_float(beta1), C.c_float(beta2), C.c_float(eps), _stream()), "ogl_adam_step")
+    _launch("ogl_adam_step", _lib.lib().ogl_adam_step, _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(step), C.c_double(lr),
+                                   C.c_double(beta1), C.c_double(beta2), C.c_double(eps), _stream(), meta=dict(n=p.numel()))
 
 
 # --------------------------------------------------------------------------------------------

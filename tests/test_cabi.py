@@ -39,7 +39,7 @@ def test_argument_validation_without_gpu():
     assert h.ogl_block_workspace_bytes(512, 25) >= 4 * 3 * 2 * 512 * 26
     assert h.ogl_reduce_fwd(None, 4, 0, None, None, -1, 1, 4, 0, None, 4, None, None) == -1
     assert h.ogl_linear_fwd(None, 2, None, 0, 4, 8, None, 8, 4, None, None, 0, None, 0, 0, None, 0, 0, None, 4, None) == -1
-    assert h.ogl_adam_step(None, None, None, None, 10, 0, 1e-3, 0.9, 0.999, 1e-8, None) == -1
+    assert h.ogl_adam_step(None, None, None, None, 10, 0, 1e-3, 0.9, 0.999, 1e-8, None) == -1   # step < 1
     assert h.ogl_linear_bwd_weight_workspace_bytes(233000, 602, 602) > 0
 
 
