@@ -12,8 +12,8 @@
 // straight from the resident table), `mask` an optional ReLU mask (dy (.) [y>0]) applied on load.
 // Tiles are staged k-major in LDS (Xs[r][p], row stride P+4) so each MFMA operand is one
 // conflict-free ds_read_b32; global loads are 16 B/lane when the operand is 16-B aligned.
-// Block -> tile mapping is XCD-aware: the NJ column tiles of one row panel run on one XCD so the
-// panel is fetched into that XCD's L2 once.
+// Block -> tile mapping is XCD-aware and bijective (see k_gemm): consecutive logical tiles, which share
+// an operand panel, run on one XCD so the panel is fetched into that XCD's L2 once.
 #include "ogl_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -52,69 +52,114 @@ struct GemmArgs {
   int NI, NJ;
 };
 
+// 16-byte load from a 4-byte-aligned address: gfx950 under HSA runs in unaligned-access mode, the
+// compiler emits one global_load_dwordx4 (rows such as K = 602 floats are only 8-B aligned).
+__device__ __forceinline__ float4 ld16(const float* p) {
+  float4 t;
+  __builtin_memcpy(&t, p, 16);
+  return t;
+}
+
+// Stages one P x BK operand tile: global -> registers (load) -> LDS k-major (store).
+// All per-thread addressing that does not depend on the k-tile is hoisted into init(); interior
+// tiles take a branch-free path (invalid rows read row 0 and are zeroed by a select), only the
+// last partial k-tile / partial column group takes guarded dword loads.
 template <int P, bool RC>
 struct TileLoader {
   static constexpr int NV = P / 64;  // float4 per thread
   float4 reg[NV];
+  const float* ptr[NV];   // RC: row base + this thread's k offset.  NC: unused
+  const float* mptr[NV];
+  bool ok[NV];
+  int64_t pcol;           // NC: first of this thread's 4 columns
+  int pmode;              // NC: 0 none, 1 four real columns, 2 partial / contains the synthetic ones column
 
-  // RC: thread -> (p = tid/4 + 64h, r = (tid&3)*4..+3);  NC: thread -> (r = tid/(P/4) + (1024/P)h, p = (tid%(P/4))*4..+3)
-  __device__ __forceinline__ void load(const Operand& op, int64_t p0, int64_t Plim, int64_t r0, int64_t R,
-                                       int64_t ones_p, int tid) {
+  __device__ __forceinline__ void init(const Operand& op, int64_t p0, int64_t Plim, int64_t ones_p, int tid) {
+    if (RC) {
 #pragma unroll
-    for (int h = 0; h < NV; ++h) {
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (RC) {
+      for (int h = 0; h < NV; ++h) {
         const int64_t p = p0 + (tid >> 2) + 64 * h;
-        const int64_t r = r0 + (tid & 3) * 4;
-        if (p < Plim && r < R) {
-          if (p == ones_p) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (r + e < R) ? 1.f : 0.f;
-          } else {
-            int64_t row = op.rows ? op.rows[p] : p;
-            if (!op.rows || (row >= 0 && row < op.nrows)) {
-              const float* src = op.ptr + row * op.ld + r;
-              if (op.vec && r + 3 < R) {
-                float4 t = *(const float4*)src;
-                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-              } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (r + e < R) v[e] = src[e];
-              }
-              if (op.mask) {
-                const float* ms = op.mask + p * op.ldm + r;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (r + e < R && !(ms[e] > 0.f)) v[e] = 0.f;
-              }
-            }
-          }
+        bool v = p < Plim;
+        int64_t row = p;
+        if (op.rows) {
+          row = v ? op.rows[p] : 0;
+          v = v && row >= 0 && row < op.nrows;
         }
-      } else {
-        const int64_t r = r0 + tid / (P / 4) + (1024 / P) * h;
-        const int64_t p = p0 + (tid % (P / 4)) * 4;
-        if (r < R && p < Plim) {
-          int64_t row = op.rows ? op.rows[r] : r;
-          if (!op.rows || (row >= 0 && row < op.nrows)) {
-            const float* src = op.ptr + row * op.ld + p;
-            const int64_t psrc = ones_p >= 0 ? ones_p : Plim;  // #columns really present in memory
-            if (op.vec && p + 3 < psrc) {
-              float4 t = *(const float4*)src;
-              v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) if (p + e < psrc) v[e] = src[e];
-            }
-            if (op.mask) {
-              const float* ms = op.mask + r * op.ldm + p;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) if (p + e < psrc && !(ms[e] > 0.f)) v[e] = 0.f;
-            }
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (p + e == ones_p) v[e] = 1.f;
-        }
+        if (!v) row = 0;
+        ok[h] = v;
+        ptr[h] = op.ptr + row * op.ld + (tid & 3) * 4;
+        mptr[h] = op.mask ? op.mask + (v ? p : 0) * op.ldm + (tid & 3) * 4 : nullptr;
       }
-      reg[h] = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      pcol = p0 + (tid % (P / 4)) * 4;
+      const int64_t psrc = ones_p >= 0 ? ones_p : Plim;
+      pmode = pcol >= Plim ? 0 : (pcol + 3 < psrc ? 1 : 2);
+    }
+  }
+
+  __device__ __forceinline__ void load(const Operand& op, int64_t Plim, int64_t r0, int64_t R, int64_t ones_p, int tid) {
+    if (RC) {
+      const bool interior = r0 + GEMM_BK <= R;  // block-uniform
+#pragma unroll
+      for (int h = 0; h < NV; ++h) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (interior) {
+          v = ld16(ptr[h] + r0);
+          if (mptr[h]) {
+            float4 m = ld16(mptr[h] + r0);
+            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+            v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+          }
+          if (!ok[h]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (ok[h]) {
+          const int64_t r = r0 + (tid & 3) * 4;
+          float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (r + q < R) {
+              float x = ptr[h][r0 + q];
+              if (mptr[h] && !(mptr[h][r0 + q] > 0.f)) x = 0.f;
+              e[q] = x;
+            }
+          v = make_float4(e[0], e[1], e[2], e[3]);
+        }
+        reg[h] = v;
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < NV; ++h) {
+        const int64_t r = r0 + tid / (P / 4) + (1024 / P) * h;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool valid = r < R && pmode != 0;
+        int64_t row = valid ? r : 0;
+        if (op.rows) {
+          row = valid ? op.rows[r] : 0;
+          if (row < 0 || row >= op.nrows) { valid = false; row = 0; }
+        }
+        if (pmode == 1) {
+          v = ld16(op.ptr + row * op.ld + pcol);
+          if (op.mask) {
+            float4 m = ld16(op.mask + (valid ? r : 0) * op.ldm + pcol);
+            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+            v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+          }
+          if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (pmode == 2 && r < R) {
+          const int64_t psrc = ones_p >= 0 ? ones_p : Plim;
+          float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (valid && pcol + q < psrc) {
+              float x = op.ptr[row * op.ld + pcol + q];
+              if (op.mask && !(op.mask[r * op.ldm + pcol + q] > 0.f)) x = 0.f;
+              e[q] = x;
+            }
+            if (pcol + q == ones_p) e[q] = 1.f;
+          }
+          v = make_float4(e[0], e[1], e[2], e[3]);
+        }
+        reg[h] = v;
+      }
     }
   }
 
@@ -142,14 +187,20 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float As[2][GEMM_BK][BM + 4];
   __shared__ __attribute__((aligned(16))) float Bs[2][GEMM_BK][BN + 4];
 
-  // XCD-aware tile mapping (blocks b and b+8 share an XCD): the NJ column tiles of a row panel
-  // are dealt to the same XCD.  Bijective over the padded grid; padded row panels exit.
-  const int lin = blockIdx.x;
-  const int xcd = lin & 7, q = lin >> 3;
-  const int ti = (q / g.NJ) * 8 + xcd, tj = q % g.NJ;
-  if (ti >= g.NI) return;
+  // XCD-aware, bijective tile mapping.  Hardware deals block L to XCD L % 8; the logical tile space
+  // (split, row panel, column tile), column tile fastest, is cut into 8 contiguous chunks and chunk c
+  // is served by the blocks with L % 8 == c.  Consecutive logical tiles share the A row panel (and, for
+  // split-K, the same slice of both operands), so each XCD's L2 fetches a panel once.  No padding: every
+  // XCD gets work whatever NI is.  Placement only affects speed, never results.
+  const int T = g.NI * g.NJ * g.nsplit;
+  const int L = blockIdx.x;
+  const int xcd = L & 7, kth = L >> 3;
+  const int base = T >> 3, rem = T & 7;
+  const int logical = xcd * base + min(xcd, rem) + kth;
+  const int split = logical / (g.NI * g.NJ);
+  const int tile = logical - split * (g.NI * g.NJ);
+  const int ti = tile / g.NJ, tj = tile - ti * g.NJ;
   const int64_t i0 = (int64_t)ti * BM, j0 = (int64_t)tj * BN;
-  const int split = blockIdx.y;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
@@ -176,13 +227,19 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
   TileLoader<BM, A_RC> la;
   TileLoader<BN, B_RC> lb;
   const int64_t ones_p = g.ones_col ? g.N - 1 : -1;
+  int cur_part = -1;
 
   auto issue = [&](int kt) {
     const int pi = kt < nk[0] ? 0 : 1;
-    const int64_t r0 = (int64_t)(pi == 0 ? kt : kt - nk[0]) * GEMM_BK;
     const GemmPart& pt = g.part[pi];
-    la.load(pt.a, i0, g.M, r0, pt.R, -1, tid);
-    lb.load(pt.b, j0, g.N, r0, pt.R, ones_p, tid);
+    if (pi != cur_part) {   // block-uniform: (re)derive the per-thread row pointers of this part
+      la.init(pt.a, i0, g.M, -1, tid);
+      lb.init(pt.b, j0, g.N, ones_p, tid);
+      cur_part = pi;
+    }
+    const int64_t r0 = (int64_t)(pi == 0 ? kt : kt - nk[0]) * GEMM_BK;
+    la.load(pt.a, g.M, r0, pt.R, -1, tid);
+    lb.load(pt.b, g.N, r0, pt.R, ones_p, tid);
   };
 
   if (kt_begin < kt_end) {
@@ -257,21 +314,30 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(GemmArgs g) {
 }
 
 static inline int operand_vec(const float* p, int64_t ld, const float* mask, int64_t ldm) {
-  (void)mask; (void)ldm;
-  return (p != nullptr) && (ld % 4 == 0) && (((uintptr_t)p & 15) == 0);
+  (void)p; (void)ld; (void)mask; (void)ldm;
+  return 1;  // unaligned-access mode: 16-B loads are legal at any 4-B aligned address (see ld16)
+}
+
+// 0: 128x128 (2x2 waves of 64x64)   1: 256x64 (narrow N)   2: 64x64 (few tiles: fill the chip / cut the tail)
+static inline int gemm_config(int64_t M, int64_t N, int nsplit, int* BM, int* BN) {
+  if (N <= 64) { *BM = 256; *BN = 64; return 1; }
+  const int64_t big_tiles = ogl_cdiv(M, 128) * ogl_cdiv(N, 128);
+  if (nsplit == 1 && big_tiles < 3 * 256) { *BM = 64; *BN = 64; return 2; }
+  *BM = 128; *BN = 128; return 0;
 }
 
 template <bool A_RC, bool B_RC>
 static int launch_gemm(GemmArgs& g, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0) return OGL_OK;
-  const bool narrow = g.N <= 64;
-  const int BM = narrow ? 256 : 128, BN = narrow ? 64 : 128;
+  int BM, BN;
+  const int cfg = gemm_config(g.M, g.N, g.nsplit, &BM, &BN);
   g.NI = (int)ogl_cdiv(g.M, BM);
   g.NJ = (int)ogl_cdiv(g.N, BN);
-  const int64_t NIp = ogl_round_up(g.NI, 8);
-  dim3 grid((unsigned)(NIp * g.NJ), (unsigned)g.nsplit), block(GEMM_THREADS);
-  if (narrow)
+  dim3 grid((unsigned)((int64_t)g.NI * g.NJ * g.nsplit)), block(GEMM_THREADS);
+  if (cfg == 1)
     hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 4, 1, 2, 2>), grid, block, 0, stream, g);
+  else if (cfg == 2)
+    hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 2, 2, 1, 1>), grid, block, 0, stream, g);
   else
     hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 2, 2, 2, 2>), grid, block, 0, stream, g);
   OGL_CHECK_LAUNCH();
@@ -332,7 +398,7 @@ static void bwd_weight_plan(int64_t M, int N, int K, int* nsplit, int* tps) {
   const int64_t tiles = ogl_cdiv(N, BM) * ogl_cdiv(No, BN);
   const int64_t nk = ogl_cdiv(M, GEMM_BK);
   if (nk == 0) { *nsplit = 1; *tps = 0; return; }
-  int64_t s = 1024 / (tiles > 0 ? tiles : 1);
+  int64_t s = 768 / (tiles > 0 ? tiles : 1);  // 3 resident blocks per CU x 256 CUs: one full round
   if (s < 1) s = 1;
   if (s > nk) s = nk > 0 ? nk : 1;
   // at least 8 k-tiles per split so the slab traffic stays small next to the MFMA work
