@@ -1,0 +1,93 @@
+"""N > 1 path on CPU: world_size-2 gloo processes run the seed-sharded update (compute = the oracle,
+tests only) through ogl_amd.parallel and must reproduce the 1-rank result on the same seeds:
+identical sampled neighbourhoods per seed (Philox is keyed by vertex id, not by batch composition),
+per-seed losses equal in seed order, and all-reduced gradients equal to the full-batch gradients."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import ogl_amd  # noqa: F401
+from ogl_amd import parallel
+from oracle import oracle as O
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _problem():
+    rng = np.random.default_rng(0)
+    n, F, C = 300, 12, 4
+    deg = rng.integers(0, 9, n)
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    indices = np.concatenate([np.sort(rng.integers(0, n, d)) for d in deg]).astype(np.int32)
+    feat = torch.tensor(rng.standard_normal((n, F)).astype(np.float32))
+    labels = torch.tensor(rng.integers(0, C, (n, 1)))
+    seeds = rng.permutation(n)[:37].astype(np.int64)          # ragged over 2 ranks: 19 + 18
+    deg_t = O.snapshot_degrees_fast(indptr, indices, n, n)
+    return indptr, indices, deg_t, feat, labels, seeds, F, C
+
+
+def _grads(model, feat, labels, indptr, indices, deg_t, seeds):
+    input_nodes, sd, blocks = O.sample_blocks(indptr, indices, deg_t, seeds, [5, 5], 9, 3)
+    logits = model.forward(feat[torch.as_tensor(input_nodes)], blocks)
+    rows = O.cross_entropy(logits, labels[torch.as_tensor(sd)], "none")
+    for p in model.opt.param_groups[0]["params"]:
+        p.grad = None
+    rows.mean().backward()
+    return rows.detach(), blocks
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    indptr, indices, deg_t, feat, labels, seeds, F, C = _problem()
+    model = O.CpuModel("pool", F, 8, C, seed=3)
+    params = model.opt.param_groups[0]["params"]
+    mine = parallel.shard_seeds(seeds)
+    rows, _ = _grads(model, feat, labels, indptr, indices, deg_t, mine)
+    sync = parallel.GradSynchronizer(params)
+    sync.sync(weight=len(mine) / len(seeds))
+    all_rows = parallel.all_gather_rows(rows)
+    if rank == 0:
+        torch.save(dict(grads=[p.grad.clone() for p in params], rows=all_rows), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_update_equals_one_rank(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    indptr, indices, deg_t, feat, labels, seeds, F, C = _problem()
+    model = O.CpuModel("pool", F, 8, C, seed=3)
+    rows, _ = _grads(model, feat, labels, indptr, indices, deg_t, seeds)
+    np.testing.assert_allclose(got["rows"].numpy(), rows.numpy(), rtol=1e-5, atol=1e-6)
+    for g, p in zip(got["grads"], model.opt.param_groups[0]["params"]):
+        np.testing.assert_allclose(g.numpy(), p.grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_shard_ranges_cover_in_order():
+    for n in (0, 1, 7, 512, 513):
+        for w in (1, 2, 3, 8):
+            parts = [parallel.shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            assert max(hi - lo for lo, hi in parts) - min(hi - lo for lo, hi in parts) <= 1
+    seeds = list(range(10))
+    assert parallel.shard_seeds(seeds, 1, 3) == [4, 5, 6]
+
+
+def test_sampling_is_independent_of_sharding():
+    indptr, indices, deg_t, *_ = _problem()
+    dst = np.arange(40, dtype=np.int64)
+    full = O.sample_layer(indptr, indices, deg_t, dst, 5, 9, 3, 1)
+    lo, hi = parallel.shard_range(40, 1, 2)
+    part = O.sample_layer(indptr, indices, deg_t, dst[lo:hi], 5, 9, 3, 1)
+    assert np.array_equal(full[lo:hi], part)
