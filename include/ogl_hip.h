@@ -107,14 +107,16 @@ int ogl_gather_i64(const int64_t* table, int64_t n_rows, const int64_t* ids, int
  *   argmax (nullable, int32 [n_dst, d]): row index of the winning source (-1 if none), max only.
  * Backward (mean/sum: every slot; max: the argmax row only) accumulates into a PRE-ZEROED dsrc
  * with float atomics.  Row indices outside [0, n_src) are skipped, never dereferenced.
+ * relu_out (nullable, max only) = the forward output: when the reduced rows were ReLU outputs the winner's
+ * value is out[d,c], so (out > 0) is its ReLU mask and is applied here instead of in the projection's backward.
  * On the 16-B path the pad columns of `out` up to round_up(d,4) are overwritten.
  * ---------------------------------------------------------------------------------------- */
 int ogl_reduce_fwd(const float* src, int64_t lds, int64_t n_src, const int32_t* idx32,
                    const int64_t* idx64, int64_t n_dst, int fanout, int d, int op, float* out,
                    int64_t ldo, int32_t* argmax, ogl_stream_t stream);
 int ogl_reduce_bwd(const float* dout, int64_t ldo, const int32_t* idx32, const int32_t* argmax,
-                   int64_t n_dst, int fanout, int d, int op, int64_t n_src, float* dsrc,
-                   int64_t lds, ogl_stream_t stream);
+                   const float* relu_out, int64_t ldr, int64_t n_dst, int fanout, int d, int op,
+                   int64_t n_src, float* dsrc, int64_t lds, ogl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense projections (torch.nn.Linear inside SAGEConv: fc_pool / fc_self / fc_neigh), fp32 MFMA.

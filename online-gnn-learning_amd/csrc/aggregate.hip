@@ -186,15 +186,21 @@ extern "C" int ogl_reduce_fwd(const float* src, int64_t lds, int64_t n_src, cons
 
 // ---- backward ----------------------------------------------------------------------------------
 // max: only the winning source row receives the gradient (n_dst*d float atomics).
+// relu_out (nullable) = the forward max output: when the reduced rows were ReLU outputs, out[d,c] is the
+// winner's value, so (out > 0) IS the winner's ReLU mask and the projection's backward needs no mask pass.
 __global__ void __launch_bounds__(256) k_reduce_bwd_max(const float* __restrict__ dout, int64_t ldo,
-                                                        const int32_t* __restrict__ argmax, int64_t n_dst, int d,
-                                                        int64_t n_src, float* __restrict__ dsrc, int64_t lds) {
+                                                        const int32_t* __restrict__ argmax,
+                                                        const float* __restrict__ relu_out, int64_t ldr,
+                                                        int64_t n_dst, int d, int64_t n_src,
+                                                        float* __restrict__ dsrc, int64_t lds) {
   const int lane = threadIdx.x & 63;
   const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (w >= n_dst) return;
   for (int c = lane; c < d; c += 64) {
     int a = argmax[w * (int64_t)d + c];
-    if (a >= 0 && a < n_src) atomicAdd(&dsrc[(int64_t)a * lds + c], dout[w * ldo + c]);
+    if (a < 0 || a >= n_src) continue;
+    if (relu_out && !(relu_out[w * ldr + c] > 0.f)) continue;
+    atomicAdd(&dsrc[(int64_t)a * lds + c], dout[w * ldo + c]);
   }
 }
 
@@ -219,17 +225,18 @@ __global__ void __launch_bounds__(256) k_reduce_bwd_sum(const float* __restrict_
 }
 
 extern "C" int ogl_reduce_bwd(const float* dout, int64_t ldo, const int32_t* idx32, const int32_t* argmax,
-                              int64_t n_dst, int fanout, int d, int op, int64_t n_src, float* dsrc,
-                              int64_t lds, ogl_stream_t stream) {
+                              const float* relu_out, int64_t ldr, int64_t n_dst, int fanout, int d, int op,
+                              int64_t n_src, float* dsrc, int64_t lds, ogl_stream_t stream) {
   if (n_dst < 0 || fanout < 0 || d < 0 || n_src < 0 || lds < d || ldo < d) return OGL_EINVAL;
   if (n_dst == 0 || d == 0 || fanout == 0) return OGL_OK;
   if (!dout || !dsrc) return OGL_EINVAL;
   dim3 grid((unsigned)ogl_cdiv(n_dst, 4)), block(256);
   if (op == OGL_REDUCE_MAX) {
-    if (!argmax) return OGL_EINVAL;
-    hipLaunchKernelGGL(k_reduce_bwd_max, grid, block, 0, (hipStream_t)stream, dout, ldo, argmax, n_dst, d, n_src, dsrc, lds);
+    if (!argmax || (relu_out && ldr < d)) return OGL_EINVAL;
+    hipLaunchKernelGGL(k_reduce_bwd_max, grid, block, 0, (hipStream_t)stream, dout, ldo, argmax, relu_out, ldr, n_dst, d,
+                       n_src, dsrc, lds);
   } else if (op == OGL_REDUCE_MEAN || op == OGL_REDUCE_SUM) {
-    if (!idx32) return OGL_EINVAL;
+    if (!idx32 || relu_out) return OGL_EINVAL;
     float scale = op == OGL_REDUCE_MEAN ? 1.0f / (float)fanout : 1.0f;
     hipLaunchKernelGGL(k_reduce_bwd_sum, grid, block, 0, (hipStream_t)stream, dout, ldo, idx32, n_dst, fanout, d, scale, n_src, dsrc, lds);
   } else {

@@ -15,6 +15,7 @@
 // Block -> tile mapping is XCD-aware and bijective (see k_gemm): consecutive logical tiles, which share
 // an operand panel, run on one XCD so the panel is fetched into that XCD's L2 once.
 #include "ogl_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -67,14 +68,17 @@ __device__ __forceinline__ float4 ld16(const float* p) {
 template <int P, bool RC>
 struct TileLoader {
   static constexpr int NV = P / 64;  // float4 per thread
-  float4 reg[NV];
   const float* ptr[NV];   // RC: row base + this thread's k offset.  NC: unused
   const float* mptr[NV];
   bool ok[NV];
-  int64_t pcol;           // NC: first of this thread's 4 columns
-  int pmode;              // NC: 0 none, 1 four real columns, 2 partial / contains the synthetic ones column
+  int pcol;               // NC: first of this thread's 4 columns
+  int pmode;              // NC: 0 none, 1 one 16-B load (+ per-component select), 2 guarded dword loads (tight rows)
+  int keep;               // NC: how many of the 4 columns exist in memory
+  int onesq;              // NC: component holding the synthetic ones column, or -1
+  int nrow[NV];           // NC + gather: row id of the NEXT k-tile (fetched one tile ahead: no dependent-load stall)
 
-  __device__ __forceinline__ void init(const Operand& op, int64_t p0, int64_t Plim, int64_t ones_p, int tid) {
+  __device__ __forceinline__ void init(const Operand& op, int64_t p0, int64_t Plim, int64_t ones_p, int tid,
+                                       int64_t r_first, int64_t R) {
     if (RC) {
 #pragma unroll
       for (int h = 0; h < NV; ++h) {
@@ -91,13 +95,25 @@ struct TileLoader {
         mptr[h] = op.mask ? op.mask + (v ? p : 0) * op.ldm + (tid & 3) * 4 : nullptr;
       }
     } else {
-      pcol = p0 + (tid % (P / 4)) * 4;
+      pcol = (int)(p0 + (tid % (P / 4)) * 4);
       const int64_t psrc = ones_p >= 0 ? ones_p : Plim;
-      pmode = pcol >= Plim ? 0 : (pcol + 3 < psrc ? 1 : 2);
+      const int64_t left = psrc - pcol;
+      keep = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
+      onesq = (ones_p >= pcol && ones_p < pcol + 4) ? (int)(ones_p - pcol) : -1;
+      // a partial group is still one 16-B load when the row stride leaves room for it (padded matrices): the
+      // pad is read and discarded by a select, so no lane diverges inside the k-loop
+      const bool vec_ok = keep == 4 || (keep > 0 && op.ld >= pcol + 4) || (keep == 0 && onesq >= 0);
+      pmode = pcol >= Plim ? 0 : (vec_ok ? 1 : 2);
+#pragma unroll
+      for (int h = 0; h < NV; ++h) {
+        const int64_t r = r_first + tid / (P / 4) + (1024 / P) * h;
+        nrow[h] = (op.rows && r < R) ? (int)op.rows[r] : 0;   // row ids fit 31 bits (checked at graph create)
+      }
     }
   }
 
-  __device__ __forceinline__ void load(const Operand& op, int64_t Plim, int64_t r0, int64_t R, int64_t ones_p, int tid) {
+  __device__ __forceinline__ void load(const Operand& op, int64_t Plim, int64_t r0, int64_t R, int64_t ones_p, int tid,
+                                       float4 (&reg)[NV]) {
     if (RC) {
       const bool interior = r0 + GEMM_BK <= R;  // block-uniform
 #pragma unroll
@@ -133,17 +149,29 @@ struct TileLoader {
         bool valid = r < R && pmode != 0;
         int64_t row = valid ? r : 0;
         if (op.rows) {
-          row = valid ? op.rows[r] : 0;
-          if (row < 0 || row >= op.nrows) { valid = false; row = 0; }
+          row = nrow[h];                                       // fetched while the previous tile was computed
+          nrow[h] = (r + GEMM_BK < R) ? (int)op.rows[r + GEMM_BK] : 0;
+          if (!valid || row < 0 || row >= op.nrows) { valid = false; row = 0; }
         }
         if (pmode == 1) {
-          v = ld16(op.ptr + row * op.ld + pcol);
-          if (op.mask) {
-            float4 m = ld16(op.mask + (valid ? r : 0) * op.ldm + pcol);
-            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
-            v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+          if (keep > 0) {
+            v = ld16(op.ptr + (int64_t)((uint64_t)(uint32_t)row * (uint32_t)op.ld) + pcol);
+            if (op.mask) {
+              float4 m = ld16(op.mask + (valid ? r : 0) * op.ldm + pcol);
+              v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+              v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+            }
+          }
+          if (keep < 4) {
+            v.w = 0.f;
+            if (keep < 3) v.z = 0.f;
+            if (keep < 2) v.y = 0.f;
+            if (keep < 1) v.x = 0.f;
           }
           if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (onesq >= 0 && r < R) {
+            if (onesq == 0) v.x = 1.f; else if (onesq == 1) v.y = 1.f; else if (onesq == 2) v.z = 1.f; else v.w = 1.f;
+          }
         } else if (pmode == 2 && r < R) {
           const int64_t psrc = ones_p >= 0 ? ones_p : Plim;
           float e[4] = {0.f, 0.f, 0.f, 0.f};
@@ -163,7 +191,7 @@ struct TileLoader {
     }
   }
 
-  __device__ __forceinline__ void store(float (*Xs)[P + 4], int tid) const {
+  __device__ __forceinline__ void store(float (*Xs)[P + 4], int tid, const float4 (&reg)[NV]) const {
 #pragma unroll
     for (int h = 0; h < NV; ++h) {
       if (RC) {
@@ -226,33 +254,24 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
 
   TileLoader<BM, A_RC> la;
   TileLoader<BN, B_RC> lb;
+  float4 ra0[BM / 64], rb0[BN / 64], ra1[BM / 64], rb1[BN / 64];   // two register staging sets (2-tile-deep prefetch)
   const int64_t ones_p = g.ones_col ? g.N - 1 : -1;
   int cur_part = -1;
 
-  auto issue = [&](int kt) {
+  auto issue = [&](int kt, float4 (&ra)[BM / 64], float4 (&rb)[BN / 64]) {
     const int pi = kt < nk[0] ? 0 : 1;
     const GemmPart& pt = g.part[pi];
+    const int64_t r0 = (int64_t)(pi == 0 ? kt : kt - nk[0]) * GEMM_BK;
     if (pi != cur_part) {   // block-uniform: (re)derive the per-thread row pointers of this part
-      la.init(pt.a, i0, g.M, -1, tid);
-      lb.init(pt.b, j0, g.N, ones_p, tid);
+      la.init(pt.a, i0, g.M, -1, tid, r0, pt.R);
+      lb.init(pt.b, j0, g.N, ones_p, tid, r0, pt.R);
       cur_part = pi;
     }
-    const int64_t r0 = (int64_t)(pi == 0 ? kt : kt - nk[0]) * GEMM_BK;
-    la.load(pt.a, g.M, r0, pt.R, -1, tid);
-    lb.load(pt.b, g.N, r0, pt.R, ones_p, tid);
+    la.load(pt.a, g.M, r0, pt.R, -1, tid, ra);
+    lb.load(pt.b, g.N, r0, pt.R, ones_p, tid, rb);
   };
 
-  if (kt_begin < kt_end) {
-    issue(kt_begin);
-    la.store(As[0], tid);
-    lb.store(Bs[0], tid);
-  }
-  __syncthreads();
-
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int buf = (kt - kt_begin) & 1;
-    const bool more = kt + 1 < kt_end;
-    if (more) issue(kt + 1);
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int kk = 0; kk < GEMM_BK; kk += 2) {
       float a[TM], b[TN];
@@ -266,12 +285,37 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
         for (int y = 0; y < TN; ++y)
           acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
     }
-    if (more) {
-      la.store(As[buf ^ 1], tid);
-      lb.store(Bs[buf ^ 1], tid);
+  };
+
+  // Pipeline: while tile t is multiplied out of LDS buffer t&1, tile t+1 sits in one register set (written to the
+  // other LDS buffer after the MFMAs) and tile t+2 is in flight into the other set: global latency is covered by
+  // two tiles of MFMA work.  The loop is unrolled by two so both sets are statically indexed (no scratch).
+  if (kt_begin < kt_end) {
+    issue(kt_begin, ra0, rb0);
+    la.store(As[0], tid, ra0);
+    lb.store(Bs[0], tid, rb0);
+    if (kt_begin + 1 < kt_end) issue(kt_begin + 1, ra1, rb1);
+  }
+  __syncthreads();
+
+  int kt = kt_begin;
+  for (; kt + 1 < kt_end; kt += 2) {
+    // even step: compute buffer 0, tile kt+1 waits in set 1, fetch kt+2 into set 0
+    if (kt + 2 < kt_end) issue(kt + 2, ra0, rb0);
+    compute(0);
+    la.store(As[1], tid, ra1);
+    lb.store(Bs[1], tid, rb1);
+    __syncthreads();
+    // odd step: compute buffer 1, tile kt+2 waits in set 0, fetch kt+3 into set 1
+    if (kt + 3 < kt_end) issue(kt + 3, ra1, rb1);
+    compute(1);
+    if (kt + 2 < kt_end) {
+      la.store(As[0], tid, ra0);
+      lb.store(Bs[0], tid, rb0);
     }
     __syncthreads();
   }
+  if (kt < kt_end) compute(0);   // odd tile count: the last tile is already in buffer 0
 
   // epilogue: D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -295,6 +339,92 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
           else g.C[row * g.ldc + col] = v;
         }
       }
+    }
+  }
+}
+
+
+// ---- skinny forward GEMM: few rows x few columns x long K (the [B, 2H] -> C output projection) -------
+// One 32-row x (32*NT)-column output tile per block; the 4 waves split K (wave w takes 8-deep chunks
+// c = w mod 4), operands go global -> registers directly (16 B per lane: row l&31, k = k0 + 4*(l>>5) ..+3;
+// MFMA step j uses component j of both operands, so half 0 supplies k0+j and half 1 supplies k0+4+j),
+// partial accumulators are summed through LDS.  Launch-latency bound shapes only.
+template <int NT>
+__global__ void __launch_bounds__(256) k_gemm_skinny(GemmArgs g) {
+  __shared__ float red[4][NT][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int64_t i0 = (int64_t)blockIdx.x * 32;
+  const int64_t j0 = (int64_t)blockIdx.y * 32 * NT;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  for (int pi = 0; pi < g.nparts; ++pi) {
+    const GemmPart& pt = g.part[pi];
+    const int64_t R = pt.R;
+    const int64_t i = i0 + l31;
+    bool aok = i < g.M;
+    int64_t arow = i;
+    if (pt.a.rows) { arow = aok ? pt.a.rows[i] : 0; aok = aok && arow >= 0 && arow < pt.a.nrows; }
+    const float* ap = pt.a.ptr + (aok ? arow : 0) * pt.a.ld;
+    const float* bp[NT];
+    bool bok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int64_t j = j0 + t * 32 + l31;
+      bok[t] = j < g.N;
+      bp[t] = pt.b.ptr + (bok[t] ? j : 0) * pt.b.ld;
+    }
+    const int64_t nchunk = (R + 7) / 8;
+    for (int64_t c = wid; c < nchunk; c += 4) {
+      const int64_t k = c * 8 + 4 * half;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b[NT];
+      const bool full = k + 3 < R;
+      if (full) {
+        a = ld16(ap + k);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = ld16(bp[t] + k);
+      } else {
+        float ea[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (k + q < R) ea[q] = ap[k + q];
+        a = make_float4(ea[0], ea[1], ea[2], ea[3]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          float eb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (k + q < R) eb[q] = bp[t][k + q];
+          b[t] = make_float4(eb[0], eb[1], eb[2], eb[3]);
+        }
+      }
+      if (!aok) a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (!bok[t]) b[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[wid][t][e][lane] = acc[t][e];
+  __syncthreads();
+  // 256 threads sum the 4 partials: NT*16*64 values
+  for (int v = tid; v < NT * 16 * 64; v += 256) {
+    const int t = v / (16 * 64), e = (v / 64) % 16, ln = v % 64;
+    float sum = red[0][t][e][ln] + red[1][t][e][ln] + red[2][t][e][ln] + red[3][t][e][ln];
+    const int64_t row = i0 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
+    const int64_t col = j0 + t * 32 + (ln & 31);
+    if (row < g.M && col < g.N) {
+      if (g.bias) sum += g.bias[col];
+      if (g.relu) sum = fmaxf(sum, 0.f);
+      g.C[row * g.ldc + col] = sum;
     }
   }
 }
@@ -372,6 +502,15 @@ extern "C" int ogl_linear_fwd(const float* x, int64_t ldx, const int64_t* x_rows
     g.nparts = 2;
   }
   g.M = M; g.N = N; g.C = y; g.ldc = ldy; g.bias = bias; g.relu = relu;
+  // few output tiles and a long reduction: in-block split-K straight from global memory
+  const int64_t Ktot = (int64_t)K + K2;
+  if (N <= 64 && M <= 4096 && Ktot >= 256) {
+    dim3 grid((unsigned)ogl_cdiv(M, 32), (unsigned)ogl_cdiv(N, 64));
+    if (N <= 32) { grid.y = 1; hipLaunchKernelGGL(k_gemm_skinny<1>, grid, dim3(256), 0, (hipStream_t)stream, g); }
+    else hipLaunchKernelGGL(k_gemm_skinny<2>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    OGL_CHECK_LAUNCH();
+    return OGL_OK;
+  }
   return launch_gemm<true, true>(g, (hipStream_t)stream);
 }
 
@@ -398,7 +537,8 @@ static void bwd_weight_plan(int64_t M, int N, int K, int* nsplit, int* tps) {
   const int64_t tiles = ogl_cdiv(N, BM) * ogl_cdiv(No, BN);
   const int64_t nk = ogl_cdiv(M, GEMM_BK);
   if (nk == 0) { *nsplit = 1; *tps = 0; return; }
-  int64_t s = 768 / (tiles > 0 ? tiles : 1);  // 3 resident blocks per CU x 256 CUs: one full round
+  static const int64_t target = getenv("OGL_BWW_TARGET") ? atoll(getenv("OGL_BWW_TARGET")) : 768;
+  int64_t s = target / (tiles > 0 ? tiles : 1);  // 3 resident blocks per CU x 256 CUs: one full round
   if (s < 1) s = 1;
   if (s > nk) s = nk > 0 ? nk : 1;
   // at least 8 k-tiles per split so the slab traffic stays small next to the MFMA work

@@ -104,15 +104,17 @@ class SAGEConv(nn.Module):
         fuse_relu = _is_relu(self.activation)
 
         if t == "pool":
-            p = self._project(self.fc_pool, feat, relu=True)
-            h_neigh = ops.neighbor_reduce(p, idx, "max")
+            h_neigh = self._pool_max(feat, idx)
             bias = None
             if self.fc_self.bias is not None:
                 bias = self.fc_self.bias + self.fc_neigh.bias
             rst = self._linear2(feat_dst, self.fc_self.weight, h_neigh, self.fc_neigh.weight, bias, fuse_relu)
         elif t in ("meanpool", "maxpool"):
-            p = self._project(self.fc_pool, feat, relu=True)
-            h_neigh = ops.neighbor_reduce(p, idx, "mean" if t == "meanpool" else "max")
+            if t == "maxpool":
+                h_neigh = self._pool_max(feat, idx)
+            else:
+                p = self._project(self.fc_pool, feat, relu=True)
+                h_neigh = ops.neighbor_reduce(p, idx, "mean")
             W = self.fc_neigh.weight
             rst = self._linear2(feat_dst, W[:, :self._in_feats], h_neigh, W[:, self._in_feats:], self.fc_neigh.bias,
                                 fuse_relu)
@@ -134,6 +136,11 @@ class SAGEConv(nn.Module):
         if self.norm is not None:
             rst = self.norm(rst)
         return rst
+
+    def _pool_max(self, feat, idx):
+        if isinstance(feat, GatheredRows):
+            return ops.pool_max(feat.table, self.fc_pool.weight, self.fc_pool.bias, idx, feat.ids)
+        return ops.pool_max(feat, self.fc_pool.weight, self.fc_pool.bias, idx, None)
 
     @staticmethod
     def _linear2(x1, w1, x2, w2, bias, relu):

@@ -199,12 +199,15 @@ def reduce_fwd(src: torch.Tensor, idx: torch.Tensor, op: str, want_argmax: bool 
     return out, argmax
 
 
-def reduce_bwd(dout: torch.Tensor, idx32: torch.Tensor, argmax, op: str, n_src: int) -> torch.Tensor:
+def reduce_bwd(dout: torch.Tensor, idx32, argmax, op: str, n_src: int, fanout=None, relu_out=None) -> torch.Tensor:
     dout = as_mat(dout)
     n_dst, d = dout.shape
-    fanout = idx32.shape[1]
+    fanout = idx32.shape[1] if idx32 is not None else int(fanout)
     dsrc = empty_mat(n_src, d, dout.device, zero=True)
-    _launch("ogl_reduce_bwd", _lib.lib().ogl_reduce_bwd, _ptr(dout), _ld(dout), _ptr(idx32), _ptr(argmax), n_dst, fanout, d,
+    if relu_out is not None:
+        relu_out = as_mat(relu_out)
+    _launch("ogl_reduce_bwd", _lib.lib().ogl_reduce_bwd, _ptr(dout), _ld(dout), _ptr(idx32), _ptr(argmax), _ptr(relu_out),
+            _ld(relu_out) if relu_out is not None else 0, n_dst, fanout, d,
                                     REDUCE_OPS[op], n_src, _ptr(dsrc), _ld(dsrc), _stream(), meta=dict(n_dst=n_dst, fanout=fanout, d=d, op=op))
     return dsrc
 
@@ -326,7 +329,7 @@ class _ReduceFn(torch.autograd.Function):
     def forward(ctx, src, idx, op):
         need_grad = src.requires_grad
         out, argmax = reduce_fwd(src, idx, op, want_argmax=need_grad)
-        ctx.op, ctx.n_src = op, src.shape[0]
+        ctx.op, ctx.n_src, ctx.fanout = op, src.shape[0], idx.shape[1]
         ctx.save_for_backward(idx if idx.dtype == torch.int32 else None, argmax)
         return out
 
@@ -337,7 +340,43 @@ class _ReduceFn(torch.autograd.Function):
             raise RuntimeError("max-reduce backward needs the argmax recorded in forward")
         if ctx.op != "max" and idx32 is None:
             raise RuntimeError("mean/sum-reduce backward needs block-local int32 indices")
-        return reduce_bwd(dout, idx32, argmax, ctx.op, ctx.n_src), None, None
+        return reduce_bwd(dout, idx32, argmax, ctx.op, ctx.n_src, fanout=ctx.fanout), None, None
+
+
+class _PoolMaxFn(torch.autograd.Function):
+    """relu(fc_pool(x[rows])) -> elementwise max over the sampled neighbours, as one autograd node.
+
+    The projected rows P are transient: backward needs only the max output (its sign is the winner's ReLU mask,
+    applied inside the scatter), the argmax and the projection input, so the [n_src, D] activation is freed right
+    after the forward and neither backward GEMM reads a mask."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, x_rows, idx):
+        p = linear_fwd(x, w, bias, relu=True, x_rows=x_rows)
+        need = x.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad)
+        out, argmax = reduce_fwd(p, idx, "max", want_argmax=need)
+        ctx.n_src, ctx.fanout, ctx.has_bias = p.shape[0], idx.shape[1], bias is not None
+        ctx.save_for_backward(x, w, x_rows, out, argmax)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, x_rows, out, argmax = ctx.saved_tensors
+        dp = reduce_bwd(dout, None, argmax, "max", ctx.n_src, fanout=ctx.fanout, relu_out=out)
+        need = ctx.needs_input_grad
+        dx = dw = db = None
+        if need[0]:
+            if x_rows is not None:
+                raise RuntimeError("gradient w.r.t. a row-gathered table is not supported (features carry no grad)")
+            dx = linear_bwd_input(dp, w, None)
+        if need[1] or (need[2] and ctx.has_bias):
+            dw, db = linear_bwd_weight(dp, x, None, x_rows, want_bias=ctx.has_bias)
+        return dx, dw, (db if ctx.has_bias else None), None, None
+
+
+def pool_max(x, w, bias, idx, x_rows=None):
+    """max_j relu(fc_pool(x))[idx[:, j]] — the aggregator of the live 'pool' layer (and in-repo 'maxpool')."""
+    return _PoolMaxFn.apply(x, w, bias, x_rows, idx)
 
 
 def neighbor_reduce(src, idx, op):

@@ -138,6 +138,26 @@ def test_reduce_bwd(ops, op):
     np.testing.assert_allclose(s.grad.cpu().numpy(), src.grad.numpy(), rtol=1e-5, atol=1e-6)
 
 
+def test_pool_max_fused_backward(ops):
+    """relu(fc_pool) -> max as one node: ReLU mask applied inside the scatter (no mask pass in the GEMMs)."""
+    torch.manual_seed(1)
+    rng = np.random.default_rng(1)
+    n_src, n_dst, S, D = 700, 150, 25, 70
+    x = torch.randn(n_src, D); w = torch.randn(D, D) / D ** 0.5; b = torch.randn(D) * 0.1
+    li = rng.integers(0, n_src, size=(n_dst, S)).astype(np.int32); li[::9] = -1
+    gy = torch.randn(n_dst, D)
+    xc = x.cuda().requires_grad_(True); wc = w.cuda().requires_grad_(True); bc = b.cuda().requires_grad_(True)
+    out = ops.pool_max(xc, wc, bc, dev(li))
+    out.backward(gy.cuda())
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    ref = O._neigh_torch(torch.relu(xr @ wr.T + br), li, "max")
+    ref.backward(gy)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL)
+    np.testing.assert_allclose(wc.grad.cpu().numpy(), wr.grad.numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(bc.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(xc.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-3, atol=1e-4)
+
+
 def test_gather_rows(ops):
     rng = np.random.default_rng(2)
     for d in (602, 128, 7):
@@ -181,6 +201,24 @@ def test_linear_fwd_dual_and_rows(ops):
     Wc = W.cuda()
     got = ops.linear_fwd(tab[rows].cuda(), Wc[:, :K], b.cuda(), x2=x2.cuda(), w2=Wc[:, K:])
     want = torch.cat((tab[rows], x2), 1) @ W.T + b
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=GEMM_RTOL, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,K,K2,N,relu", [(512, 600, 600, 41, False), (33, 300, 7, 3, True), (4096, 258, 0, 64, True),
+                                             (100, 1001, 0, 33, False)])
+def test_linear_fwd_skinny(ops, M, K, K2, N, relu):
+    """Few output tiles x long K: the in-block split-K kernel (final [B, 2H] -> C projection)."""
+    torch.manual_seed(M + K)
+    x = torch.randn(M, K); w = torch.randn(N, K) / K ** 0.5; b = torch.randn(N)
+    want = x @ w.T + b
+    kw = {}
+    if K2:
+        x2 = torch.randn(M, K2); w2 = torch.randn(N, K2) / K2 ** 0.5
+        want = want + x2 @ w2.T
+        kw = dict(x2=x2.cuda(), w2=w2.cuda())
+    if relu:
+        want = want.relu()
+    got = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda(), relu=relu, **kw)
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=GEMM_RTOL, atol=2e-5)
 
 
