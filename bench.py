@@ -35,6 +35,10 @@ WORKLOADS = {
     "arxiv_rbr": dict(dataset="arxiv", batch=32, samples=25, hidden=32, batch_timestep=1),
     "pubmed_rbr": dict(dataset="pubmed", batch=32, samples=25, hidden=32, batch_timestep=2),
     "toy_rbr": dict(dataset="toy", batch=32, samples=5, hidden=16, batch_timestep=2),
+    # PBR priority forward: inference over the train set in batches of batch_full, per-seed CE loss
+    "reddit_pbr_forward": dict(dataset="reddit", batch=1024, samples=25, hidden=600, batch_timestep=50, forward=True),
+    "arxiv_pbr_forward": dict(dataset="arxiv", batch=1024, samples=25, hidden=32, batch_timestep=1, forward=True),
+    "toy_pbr_forward": dict(dataset="toy", batch=64, samples=5, hidden=16, batch_timestep=2, forward=True),
 }
 
 
@@ -46,6 +50,7 @@ def parse():
     ap.add_argument("--workload", default="reddit_rbr", choices=sorted(WORKLOADS))
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the synthetic graph (debugging only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-projection-cache", action="store_true", help="priority forward: recompute fc_pool_0 per batch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -104,6 +109,10 @@ def main():
         return torch.as_tensor(np.concatenate([seed_rng.choice(train_set, B, replace=False) for _ in range(nb)]))
 
     stats = dict(n0=[], n1=[])
+
+    if wl.get("forward"):
+        forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size, n_classes, setup_s)
+        return
 
     def run(nsteps, seeds_per_snapshot):
         done = 0
@@ -256,6 +265,87 @@ def main():
 
 def h_nnz(g):
     return g.handle.nnz
+
+
+def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size, n_classes, setup_s):
+    """PBR priority forward: K batches of batch_full seeds, eval mode, per-seed CE loss returned to the host once."""
+    from ogl_amd import ops, parallel
+    from ogl_amd.graphsage.model import HipSupervisedGraphSage
+    B, S = wl["batch"], wl["samples"]
+    strat = HipSupervisedGraphSage(model, wl["batch_timestep"], 32, None, S, reduction="none", cuda=True, batch_full=B)
+    strat.cache_projection = not args.no_projection_cache
+    model.eval()
+    lo, hi = parallel.shard_range(len(train_set), rank, world)
+    mine = train_set[lo:hi]
+
+    def run(nb):
+        seeds = torch.as_tensor(np.resize(mine, nb * B))
+        losses = []
+        with torch.no_grad():
+            for sd, scores in strat._inference_batches(g, seeds):
+                labels = ops.gather_i64(g.ndata["target"], sd)
+                rows, _ = ops.ce_fwd_bwd(scores, labels, want_grad=False)
+                losses.append(rows)
+        return torch.cat(losses).cpu()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(max(args.warmup, 1))
+    barrier()
+    t1 = time.perf_counter()
+    out = run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ops.profile_start()
+    run(min(args.steps, 20))
+    rec = ops.profile_stop()
+    nprof = min(args.steps, 20)
+    agg = {}
+    for name, meta, ms in rec:
+        key = name
+        if name == "ogl_reduce_fwd":
+            key = "reduce_fwd_L0" if meta["n_dst"] > B else "reduce_fwd_L1"
+        a = agg.setdefault(key, dict(ms=0.0, calls=0, bytes=0.0, flops=0.0))
+        a["ms"] += ms; a["calls"] += 1
+        if name == "ogl_reduce_fwd":
+            E = meta["n_dst"] * meta["fanout"]
+            a["bytes"] += E * (4 * meta["d"] + meta["idx_bytes"]) + meta["n_dst"] * 4 * meta["d"]
+        if name == "ogl_linear_fwd":
+            a["flops"] += 2.0 * meta["M"] * meta["N"] * (meta["K"] + meta["K2"])
+    kernels = {k: dict(ms_per_step=round(v["ms"] / nprof, 4), calls_per_step=round(v["calls"] / nprof, 2),
+                       gbs=round(v["bytes"] / v["ms"] / 1e6, 1) if v["bytes"] else None,
+                       tflops=round(v["flops"] / v["ms"] / 1e9, 2) if v["flops"] else None) for k, v in sorted(agg.items())}
+    ragg = agg.get("reduce_fwd_L0")
+    roof = None
+    if ragg:
+        ach = ragg["bytes"] / ragg["ms"] / 1e6
+        roof = dict(kernel="k_reduce_fwd_v4 (layer-0 max over the cached projection table, int64 global picks)", bound="hbm",
+                    achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                    avg_launch_ms=round(ragg["ms"] / ragg["calls"], 4),
+                    algorithmic_bytes_per_launch=round(ragg["bytes"] / ragg["calls"]))
+    if rank == 0:
+        assert out.numel() == args.steps * B and bool(torch.isfinite(out).all())
+        print(json.dumps({
+            "metric": "streamed vertices/sec (PBR priority forward), %s-shaped stream depth=2 samples=%d" % (wl["dataset"], S),
+            "value": round(args.steps * B * world / elapsed, 1), "unit": "vertices/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: last snapshot (N=%d), F=%d H=%d C=%d, pool(max), batch_full=%d/GPU, inference sample+forward+CE(none), "
+                                   "projection cache %s" % (args.workload, g.n_present, feat_size, wl["hidden"], n_classes, B,
+                                                            "on" if strat.cache_projection else "off"),
+                       "global_batch": B * world, "parallelism": "dp%d (train set block-partitioned, no collective)" % world,
+                       "setup_s": round(setup_s, 1)},
+            "roofline": roof, "cpu_baseline": None, "kernels": kernels}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -36,6 +36,7 @@ class SupervisedGraphSage:
         self.amount_of_train = {}
         self.delay = 0.0
         self.fuse_gather = True     # read feature rows straight from the resident table inside the GEMM
+        self.cache_projection = True  # inference passes reuse relu(fc_pool_0(X)) across batches
 
     def build_optimizer(self):
         raise NotImplementedError
@@ -115,18 +116,34 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             return GatheredRows(graph.ndata["feat"], input_nodes)
         return ops.gather_rows(graph.ndata["feat"], input_nodes)
 
+    def _inference_batches(self, graph, seeds_all):
+        """Forward-only pass over ``seeds_all`` in batches of ``batch_full``; yields (seeds, logits).
+
+        When the pass is long enough that its batches would project more input rows than the snapshot holds,
+        ``P0 = relu(fc_pool_0(X))`` is computed ONCE for every present vertex (weights are fixed during the pass)
+        and every batch reduces straight from it: no layer-0 GEMM over the unique inputs, no input-block relabel."""
+        layer0 = self.graphsage_model.layers[0]
+        n_batches = -(-seeds_all.numel() // self.batch_full)
+        per_batch_rows = min(self.batch_full * (1 + self.samples) ** 2 * 0.3, graph.n_present)
+        use_cache = (self.cache_projection and layer0.fc_pool is not None and not layer0.training
+                     and n_batches * per_batch_rows > graph.n_present)
+        loader = sampling.NodeDataLoader(graph, seeds_all, self._sampler(), batch_size=self.batch_full, shuffle=False,
+                                         drop_last=False, num_workers=self.n_workers, relabel_input=not use_cache)
+        proj = layer0.project_table(graph.ndata["feat"]) if use_cache else None
+        for input_nodes, seeds, blocks in loader:
+            x = GatheredRows(graph.ndata["feat"], None, proj) if use_cache else self._inputs(graph, input_nodes)
+            yield seeds, self.graphsage_model(blocks, x)
+
     def _run_custom_eval(self, graph, subgraph_to_id, id_to_subgraph, test_vertices):
         output_data = []
         self.graphsage_model.eval()
         seeds_all = torch.as_tensor(np.asarray(test_vertices), dtype=torch.int64)
         if seeds_all.numel() == 0:
             return output_data
-        loader = sampling.NodeDataLoader(graph, seeds_all, self._sampler(), batch_size=self.batch_full, shuffle=False,
-                                         drop_last=False, num_workers=self.n_workers)
         outs = []
         with torch.no_grad():
-            for input_nodes, seeds, blocks in loader:
-                outs.append(self.graphsage_model(blocks, self._inputs(graph, input_nodes)))
+            for _, logits in self._inference_batches(graph, seeds_all):
+                outs.append(logits)
         # one device->host transfer for the pass instead of one per batch
         return [o.cpu().numpy() for o in outs]
 
@@ -224,13 +241,10 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
             return
         seeds_all = torch.as_tensor(np.asarray(id_to_subgraph[train_set]), dtype=torch.int64)
         graph = graph_util.get_graph()
-        loader = sampling.NodeDataLoader(graph, seeds_all, self._sampler(), batch_size=self.batch_full, shuffle=False,
-                                         drop_last=False, num_workers=self.n_workers)
         losses, nid_chunks = [], []
         with torch.no_grad():
-            for input_nodes, seeds, blocks in loader:
+            for seeds, scores in self._inference_batches(graph, seeds_all):
                 batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
-                scores = self.graphsage_model(blocks, self._inputs(graph, input_nodes))
                 loss_rows, _ = ops.ce_fwd_bwd(scores, batch_labels, want_grad=False)
                 losses.append(loss_rows)
                 nid_chunks.append(seeds)

@@ -28,15 +28,18 @@ class GatheredRows:
     """Lazy ``table[ids]``: the row gather is fused into the consuming GEMM / reduction loaders so
     ``graph.ndata['feat'][input_nodes]`` (R/.../pytorch/model.py:54,88,182,232) is never materialised."""
 
-    def __init__(self, table: torch.Tensor, ids: torch.Tensor):
-        self.table, self.ids = table, ids
+    def __init__(self, table: torch.Tensor, ids, proj: torch.Tensor = None):
+        # proj (optional, inference only): relu(fc_pool(table)) for EVERY table row, computed once per weight
+        # version.  With it the first layer reduces straight from `proj` through the block's global picks and
+        # `ids` may be None (the input block then needs no relabelling at all).
+        self.table, self.ids, self.proj = table, ids, proj
 
     @property
     def shape(self):
         return (self.ids.numel(), self.table.shape[1])
 
     def head(self, n):
-        return GatheredRows(self.table, self.ids[:n])
+        return GatheredRows(self.table, self.ids[:n], self.proj)
 
     def materialize(self):
         return ops.gather_rows(self.table, self.ids)
@@ -100,8 +103,10 @@ class SAGEConv(nn.Module):
             feat = self.feat_drop(feat)
         n_dst = graph.number_of_dst_nodes()
         idx = graph.local_idx
-        feat_dst = feat.head(n_dst) if lazy else feat[:n_dst]
         fuse_relu = _is_relu(self.activation)
+        if lazy and feat.proj is not None:
+            return self._forward_cached(graph, feat, fuse_relu)
+        feat_dst = feat.head(n_dst) if lazy else feat[:n_dst]
 
         if t == "pool":
             h_neigh = self._pool_max(feat, idx)
@@ -136,6 +141,36 @@ class SAGEConv(nn.Module):
         if self.norm is not None:
             rst = self.norm(rst)
         return rst
+
+    def _forward_cached(self, graph, feat, fuse_relu):
+        """Inference against a cached projection table (the idea of R/inference_optimized.py:169,258): the
+        neighbour max reads proj[picks] directly, fc_self reads the raw rows of the dst ids."""
+        t = self._aggre_type
+        if t not in ("pool", "maxpool", "meanpool"):
+            raise KeyError("cached projections apply to the pooling aggregators only, not {}".format(t))
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("the cached-projection path is inference only (run it under torch.no_grad())")
+        h_neigh, _ = ops.reduce_fwd(feat.proj, graph.picks, "mean" if t == "meanpool" else "max")
+        dst_rows = graph.dst_ids
+        if t == "pool":
+            bias = self.fc_self.bias + self.fc_neigh.bias if self.fc_self.bias is not None else None
+            rst = ops.linear_fwd(feat.table, self.fc_self.weight, bias, x2=h_neigh, w2=self.fc_neigh.weight, relu=fuse_relu,
+                                 x_rows=dst_rows)
+        else:
+            W = self.fc_neigh.weight
+            rst = ops.linear_fwd(feat.table, W[:, :self._in_feats], self.fc_neigh.bias, x2=h_neigh, w2=W[:, self._in_feats:],
+                                 relu=fuse_relu, x_rows=dst_rows)
+        if self.activation is not None and not fuse_relu:
+            rst = self.activation(rst)
+        if self.norm is not None:
+            rst = self.norm(rst)
+        return rst
+
+    def project_table(self, table):
+        """relu(fc_pool(table)) for every row — the per-weight-version cache consumed by _forward_cached."""
+        if self.fc_pool is None:
+            raise KeyError("aggregator {} has no pooling projection".format(self._aggre_type))
+        return ops.linear_fwd(table, self.fc_pool.weight, self.fc_pool.bias, relu=True)
 
     def _pool_max(self, feat, idx):
         if isinstance(feat, GatheredRows):

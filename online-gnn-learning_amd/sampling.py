@@ -66,21 +66,25 @@ class Block:
 
     @property
     def fanout(self):
-        return self.local_idx.shape[1]
+        return (self.local_idx if self.local_idx is not None else self.picks).shape[1]
 
     def number_of_dst_nodes(self):
         return int(self.dst_ids.numel())
 
     def number_of_src_nodes(self):
+        if self.src_ids is None:
+            raise RuntimeError("this input block was sampled with relabel_input=False: it has global picks only")
         return int(self.src_ids.numel())
 
     def number_of_edges(self):
         if self._n_edges is None:
-            self._n_edges = int((self.local_idx >= 0).sum().item())
+            idx = self.local_idx if self.local_idx is not None else self.picks
+            self._n_edges = int((idx >= 0).sum().item())
         return self._n_edges
 
     def in_degrees(self):
-        return (self.local_idx >= 0).sum(dim=1)
+        idx = self.local_idx if self.local_idx is not None else self.picks
+        return (idx >= 0).sum(dim=1)
 
     def to(self, device):
         dev = torch.device(device)
@@ -101,8 +105,11 @@ class MultiLayerNeighborSampler:
         self.fanouts = [int(f) for f in fanouts]
         self.return_eids = return_eids
 
-    def sample_batches(self, graph, seed_batches):
-        """Sample every batch, output layer first.  Returns a list of (input_nodes, seeds, blocks)."""
+    def sample_batches(self, graph, seed_batches, relabel_input=True):
+        """Sample every batch, output layer first.  Returns a list of (input_nodes, seeds, blocks).
+
+        ``relabel_input=False`` (inference against a cached layer-0 projection): the input block keeps only its
+        global ``picks`` — no hash relabel, no size read-back; ``input_nodes`` is then ``None``."""
         g = graph.handle
         L = len(self.fanouts)
         ctrs = [_next_ctr() for _ in seed_batches]
@@ -110,6 +117,11 @@ class MultiLayerNeighborSampler:
         dsts = list(seed_batches)
         for layer in reversed(range(L)):
             pend = []
+            if layer == 0 and not relabel_input:
+                for bi, dst in enumerate(dsts):
+                    picks = ops.sample_layer(g, dst, self.fanouts[layer], _STATE["seed"], ctrs[bi], layer)
+                    blocks[bi][layer] = Block(None, dst, None, picks)
+                return [(None, seeds, blk) for seeds, blk in zip(seed_batches, blocks)]
             for bi, dst in enumerate(dsts):
                 picks = ops.sample_layer(g, dst, self.fanouts[layer], _STATE["seed"], ctrs[bi], layer)
                 src_ids, n_src, local_idx = ops.build_block_async(dst, picks)
@@ -128,7 +140,9 @@ class NodeDataLoader:
     """Iterable of ``(input_nodes, seeds, blocks)`` in seed order; the last partial batch is kept
     unless ``drop_last``; ``shuffle`` permutes the seeds first (torch CPU generator, as DataLoader does)."""
 
-    def __init__(self, graph, nids, sampler, batch_size=1, shuffle=False, drop_last=False, num_workers=0):
+    def __init__(self, graph, nids, sampler, batch_size=1, shuffle=False, drop_last=False, num_workers=0,
+                 relabel_input=True):
+        self.relabel_input = relabel_input
         if batch_size is None or batch_size <= 0:
             raise ValueError("batch_size should be a positive integer value, but got batch_size={}".format(batch_size))
         self.graph, self.sampler = graph, sampler
@@ -149,4 +163,4 @@ class NodeDataLoader:
         n, bs = nids.numel(), self.batch_size
         stops = list(range(0, n, bs))
         batches = [nids[s:s + bs] for s in stops if not (self.drop_last and s + bs > n)]
-        return iter(self.sampler.sample_batches(self.graph, batches))
+        return iter(self.sampler.sample_batches(self.graph, batches, relabel_input=self.relabel_input))

@@ -159,6 +159,37 @@ def test_two_layer_model_step_matches_oracle(pkg, mode, pool, fuse):
                                        rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("mode,pool", [("pool", None), ("maxpool", 9), ("meanpool", 12)])
+def test_cached_projection_inference_matches_per_batch(pkg, mode, pool):
+    """Priority-forward fast path: logits from the cached relu(fc_pool_0(X)) table + unrelabelled input block equal
+    the per-batch path on the same Philox stream (same picks), within GEMM tolerance."""
+    from ogl_amd import sampling
+    from ogl_amd.graphsage import GatheredRows, GraphSAGE
+    feat_size, _, dyn, n_classes = toy_graph(pkg)
+    g = dyn.get_graph()
+    torch.manual_seed(2)
+    model = GraphSAGE(feat_size, 16, n_classes, 1, F.relu, 0, mode, edge_feats=0, pool_feats=pool).cuda().eval()
+    seeds = torch.as_tensor(np.random.default_rng(4).permutation(g.n_present)[:150].astype(np.int64))
+    smp = sampling.MultiLayerNeighborSampler([6, 6])
+    with torch.no_grad():
+        sampling.seed(21)
+        ref = [model(b, GatheredRows(g.ndata["feat"], i)) for i, _, b in sampling.NodeDataLoader(g, seeds, smp, batch_size=64)]
+        sampling.seed(21)
+        proj = model.layers[0].project_table(g.ndata["feat"])
+        got = []
+        for i, sd, b in sampling.NodeDataLoader(g, seeds, smp, batch_size=64, relabel_input=False):
+            assert i is None and b[0].local_idx is None and b[0].picks.shape == (b[1].number_of_src_nodes(), 6)
+            got.append(model(b, GatheredRows(g.ndata["feat"], None, proj)))
+    assert len(ref) == len(got) == 3
+    for a, b in zip(ref, got):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    # training mode refuses the cache
+    model.train()
+    with pytest.raises(RuntimeError):
+        model(b if False else sampling.NodeDataLoader(g, seeds[:8], smp, batch_size=8, relabel_input=False).__iter__().__next__()[2],
+              GatheredRows(g.ndata["feat"], None, proj))
+
+
 def test_unknown_aggregator_raises_keyerror(pkg):
     from ogl_amd.graphsage import SAGEConv
     from ogl_amd.sampling import Block
