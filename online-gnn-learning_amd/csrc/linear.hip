@@ -15,7 +15,6 @@
 // Block -> tile mapping is XCD-aware and bijective (see k_gemm): consecutive logical tiles, which share
 // an operand panel, run on one XCD so the panel is fetched into that XCD's L2 once.
 #include "ogl_common.h"
-#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -51,6 +50,7 @@ struct GemmArgs {
   int tiles_per_split;
   float* ws; int64_t ws_ld;
   int NI, NJ;
+  int force_cfg;    // host-side only: 1 + tile configuration chosen by the caller's plan, 0 = automatic
 };
 
 // 16-byte load from a 4-byte-aligned address: gfx950 under HSA runs in unaligned-access mode, the
@@ -460,7 +460,12 @@ template <bool A_RC, bool B_RC>
 static int launch_gemm(GemmArgs& g, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0) return OGL_OK;
   int BM, BN;
-  const int cfg = gemm_config(g.M, g.N, g.nsplit, &BM, &BN);
+  int cfg = gemm_config(g.M, g.N, g.nsplit, &BM, &BN);
+  if (g.force_cfg) {
+    cfg = g.force_cfg - 1;
+    BM = cfg == 1 ? 256 : (cfg == 2 ? 64 : 128);
+    BN = cfg == 0 ? 128 : 64;
+  }
   g.NI = (int)ogl_cdiv(g.M, BM);
   g.NJ = (int)ogl_cdiv(g.N, BN);
   dim3 grid((unsigned)((int64_t)g.NI * g.NJ * g.nsplit)), block(GEMM_THREADS);
@@ -530,18 +535,19 @@ extern "C" int ogl_linear_bwd_input(const float* dy, int64_t ldy, const float* y
   return launch_gemm<true, false>(g, (hipStream_t)stream);
 }
 
-static void bwd_weight_plan(int64_t M, int N, int K, int* nsplit, int* tps) {
+// Split plan of the weight-gradient GEMM: [N, K+1] output, reduction over M rows.  Aim at one full round of
+// resident blocks (3 per CU x 256 CUs) with at least 8 k-tiles each.  (64x64 tiles with fewer splits were
+// measured slower for the n1-row reductions: 88 vs 75 us per call.)
+static void bwd_weight_plan(int64_t M, int N, int K, int* nsplit, int* tps, int* cfg) {
   const int No = K + 1;  // + ones column
-  const bool narrow = No <= 64;
-  const int BM = narrow ? 256 : 128, BN = narrow ? 64 : 128;
-  const int64_t tiles = ogl_cdiv(N, BM) * ogl_cdiv(No, BN);
   const int64_t nk = ogl_cdiv(M, GEMM_BK);
+  *cfg = No <= 64 ? 1 : 0;
   if (nk == 0) { *nsplit = 1; *tps = 0; return; }
-  static const int64_t target = getenv("OGL_BWW_TARGET") ? atoll(getenv("OGL_BWW_TARGET")) : 768;
-  int64_t s = target / (tiles > 0 ? tiles : 1);  // 3 resident blocks per CU x 256 CUs: one full round
+  int BM = No <= 64 ? 256 : 128, BN = No <= 64 ? 64 : 128;
+  int64_t tiles = ogl_cdiv(N, BM) * ogl_cdiv(No, BN);
+  int64_t s = 768 / (tiles > 0 ? tiles : 1);
   if (s < 1) s = 1;
-  if (s > nk) s = nk > 0 ? nk : 1;
-  // at least 8 k-tiles per split so the slab traffic stays small next to the MFMA work
+  if (s > nk) s = nk;
   if (nk / s < 8) s = nk / 8 > 0 ? nk / 8 : 1;
   *tps = (int)ogl_cdiv(nk, s);
   *nsplit = (int)ogl_cdiv(nk, *tps);
@@ -550,8 +556,8 @@ static void bwd_weight_plan(int64_t M, int N, int K, int* nsplit, int* tps) {
 
 extern "C" int64_t ogl_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K) {
   if (M < 0 || N < 0 || K < 0) return OGL_EINVAL;
-  int nsplit, tps;
-  bwd_weight_plan(M, N, K, &nsplit, &tps);
+  int nsplit, tps, cfg;
+  bwd_weight_plan(M, N, K, &nsplit, &tps, &cfg);
   if (nsplit <= 1) return 16;
   return (int64_t)nsplit * N * ogl_round_up(K + 1, 4) * 4;
 }
@@ -571,7 +577,8 @@ extern "C" int ogl_linear_bwd_weight(const float* dy, int64_t ldy, const float* 
   g.part[0].R = M;
   g.nparts = 1;
   g.M = N; g.N = K + 1; g.ones_col = 1; g.C = dw; g.ldc = lddw; g.db = db;
-  bwd_weight_plan(M, N, K, &g.nsplit, &g.tiles_per_split);
+  bwd_weight_plan(M, N, K, &g.nsplit, &g.tiles_per_split, &g.force_cfg);
+  g.force_cfg += 1;   // 0 = let launch_gemm choose
   if (g.nsplit > 1) {
     g.ws_ld = ogl_round_up(K + 1, 4);
     if (!workspace || workspace_bytes < (int64_t)g.nsplit * N * g.ws_ld * 4) return OGL_EWORKSPACE;

@@ -88,3 +88,61 @@ extern "C" int ogl_adam_step(float* p, const float* g, float* m, float* v, int64
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }
+
+// All parameter tensors of the model in ONE launch (the reference's optimizer.step() loops over 12 tensors).
+// Pointers travel by value in the kernel argument block: no device-side table, no extra copy.
+#define OGL_ADAM_MAX_TENSORS 32
+struct AdamBatch {
+  float* p[OGL_ADAM_MAX_TENSORS];
+  const float* g[OGL_ADAM_MAX_TENSORS];
+  float* m[OGL_ADAM_MAX_TENSORS];
+  float* v[OGL_ADAM_MAX_TENSORS];
+  int64_t n[OGL_ADAM_MAX_TENSORS];
+};
+
+__global__ void __launch_bounds__(256) k_adam_multi(AdamBatch b, float one_minus_b1, float b2, float one_minus_b2,
+                                                    float inv_sqrt_bc2, float step_size, float eps) {
+  const int t = blockIdx.y;
+  float* __restrict__ p = b.p[t];
+  const float* __restrict__ g = b.g[t];
+  float* __restrict__ m = b.m[t];
+  float* __restrict__ v = b.v[t];
+  const int64_t n = b.n[t];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    float mi = m[i];
+    mi = mi + one_minus_b1 * (gi - mi);
+    const float vi = v[i] * b2 + one_minus_b2 * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+  }
+}
+
+extern "C" int ogl_adam_step_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
+                                   const int64_t* n, int step, double lr, double beta1, double beta2, double eps,
+                                   ogl_stream_t stream) {
+  if (count < 0 || step < 1) return OGL_EINVAL;
+  if (count == 0) return OGL_OK;
+  if (!p || !g || !m || !v || !n) return OGL_EINVAL;
+  const double bc1 = 1.0 - pow(beta1, step);
+  const double bc2 = 1.0 - pow(beta2, step);
+  const float step_size = (float)(lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  for (int base = 0; base < count; base += OGL_ADAM_MAX_TENSORS) {
+    AdamBatch b;
+    const int c = min(OGL_ADAM_MAX_TENSORS, count - base);
+    int64_t nmax = 0;
+    for (int i = 0; i < c; ++i) {
+      if (n[base + i] < 0 || (n[base + i] > 0 && (!p[base + i] || !g[base + i] || !m[base + i] || !v[base + i]))) return OGL_EINVAL;
+      b.p[i] = p[base + i]; b.g[i] = g[base + i]; b.m[i] = m[base + i]; b.v[i] = v[base + i]; b.n[i] = n[base + i];
+      nmax = n[base + i] > nmax ? n[base + i] : nmax;
+    }
+    if (nmax == 0) continue;
+    dim3 grid((unsigned)min((int64_t)256, ogl_cdiv(nmax, 256)), (unsigned)c);
+    hipLaunchKernelGGL(k_adam_multi, grid, dim3(256), 0, (hipStream_t)stream, b, (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), inv_sqrt_bc2, step_size, (float)eps);
+    OGL_CHECK_LAUNCH();
+  }
+  return OGL_OK;
+}

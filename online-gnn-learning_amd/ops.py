@@ -285,6 +285,18 @@ def adam_step(p, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
                                    C.c_double(beta1), C.c_double(beta2), C.c_double(eps), _stream(), meta=dict(n=p.numel()))
 
 
+def adam_step_multi(ps, gs, ms, vs, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
+    """One launch for every parameter tensor (same step count for all)."""
+    k = len(ps)
+    for p, g, m, v in zip(ps, gs, ms, vs):
+        for t in (p, g, m, v):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+    arr = lambda ts: (C.c_void_p * k)(*[t.data_ptr() for t in ts])
+    n = (C.c_int64 * k)(*[p.numel() for p in ps])
+    _launch("ogl_adam_step_multi", _lib.lib().ogl_adam_step_multi, k, arr(ps), arr(gs), arr(ms), arr(vs), n, int(step),
+            C.c_double(lr), C.c_double(beta1), C.c_double(beta2), C.c_double(eps), _stream(), meta=dict(n=sum(p.numel() for p in ps)))
+
+
 # --------------------------------------------------------------------------------------------
 # autograd glue
 # --------------------------------------------------------------------------------------------

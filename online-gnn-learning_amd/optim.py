@@ -17,6 +17,7 @@ class Adam(torch.optim.Optimizer):
                 loss = closure()
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            buckets = {}
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -27,5 +28,8 @@ class Adam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                ops.adam_step(p.data, g, st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"], b1, b2, group["eps"])
+                buckets.setdefault(st["step"], []).append((p.data, g, st["exp_avg"], st["exp_avg_sq"]))
+            for step, items in buckets.items():      # normally one bucket: every tensor in ONE launch
+                ps, gs, ms, vs = zip(*items)
+                ops.adam_step_multi(ps, gs, ms, vs, step, group["lr"], b1, b2, group["eps"])
         return loss

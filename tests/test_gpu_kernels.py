@@ -281,3 +281,17 @@ def test_adam(ops):
         ops.adam_step(pc, g.cuda(), mc, vc, step)
     np.testing.assert_allclose(pc.cpu().numpy(), p.numpy(), rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(vc.cpu().numpy(), v.numpy(), rtol=1e-5, atol=1e-9)
+
+
+def test_adam_multi(ops):
+    torch.manual_seed(1)
+    shapes = [(602, 602), (602,), (600, 602), (41, 600), (41,), (1,)]
+    ps = [torch.randn(*s_) for s_ in shapes]; ms = [torch.zeros_like(p) for p in ps]; vs = [torch.zeros_like(p) for p in ps]
+    pc = [p.cuda() for p in ps]; mc = [m.cuda() for m in ms]; vc = [v.cuda() for v in vs]
+    for step in range(1, 4):
+        gs = [torch.randn_like(p) for p in ps]
+        for p, g, m, v in zip(ps, gs, ms, vs):
+            O.adam_step(p, g, m, v, step)
+        ops.adam_step_multi(pc, [g.cuda() for g in gs], mc, vc, step)
+    for a, b in zip(pc, ps):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=1e-5, atol=1e-7)
