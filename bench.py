@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--workload", default="reddit_rbr", choices=sorted(WORKLOADS))
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the synthetic graph (debugging only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm", default="auto", choices=["f32", "bf16x6", "auto"],
+                    help="projection arithmetic: exact fp32 MFMA, split-bf16 (x6, fp32-accurate) MFMA, or per-layout best")
     ap.add_argument("--no-projection-cache", action="store_true", help="priority forward: recompute fc_pool_0 per batch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -72,6 +74,7 @@ def main():
     from ogl_amd import ops, optim, parallel, sampling, synthetic
     from ogl_amd.graphsage import GatheredRows, GraphSAGE
 
+    ops.set_gemm_mode(args.gemm)
     wl = WORKLOADS[args.workload]
     B, S, H, bt = wl["batch"], wl["samples"], wl["hidden"], wl["batch_timestep"]
     t0 = time.time()
@@ -201,7 +204,7 @@ def main():
     roof_gemm = None
     if dom:
         ach = agg[dom]["flops"] / agg[dom]["ms"] / 1e9
-        roof_gemm = dict(kernel="k_gemm fp32 MFMA 32x32x2 (%s)" % dom, bound="mfma", achieved=round(ach, 2),
+        roof_gemm = dict(kernel="k_gemm (%s; %s)" % (dom, "fp32 MFMA 32x32x2" if ("bwd_weight" in dom or args.gemm == "f32") else "split-bf16 x6 MFMA 32x32x16"), bound="mfma", achieved=round(ach, 2),
                          peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
                          avg_launch_ms=round(agg[dom]["ms"] / agg[dom]["calls"], 4),
                          algorithmic_flops_per_launch=round(agg[dom]["flops"] / agg[dom]["calls"]),
@@ -247,7 +250,7 @@ def main():
             "value": round(value, 1), "unit": "vertices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %s-like %s stream, last snapshot (N=%d, CSR nnz=%d), F=%d H=%d C=%d, "
+            "config": {"gemm_arithmetic": gemm_desc(args.gemm), "workload": "%s: %s-like %s stream, last snapshot (N=%d, CSR nnz=%d), F=%d H=%d C=%d, "
                                    "aggregator=pool(max), depth=2 samples=%d batch=%d/GPU batch_timestep=%d, "
                                    "sample+gather+fwd+CE+bwd+Adam" % (args.workload, wl["dataset"], arrays["stream"], g.n_present,
                                                                         int(h_nnz(g)), feat_size, H, n_classes, S, B, bt),
@@ -265,6 +268,13 @@ def main():
 
 def h_nnz(g):
     return g.handle.nnz
+
+
+def gemm_desc(mode):
+    return {"f32": "fp32 MFMA (exact fp32 fma chain)",
+            "bf16x6": "split-bf16 x6 MFMA, fp32 accumulate (fp32-GEMM accuracy, same test tolerances)",
+            "auto": "forward/input-gradient GEMMs: split-bf16 x6 MFMA with fp32 accumulate (fp32-GEMM accuracy, same test "
+                    "tolerances); weight-gradient GEMMs: exact fp32 MFMA"}[mode]
 
 
 def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size, n_classes, setup_s):
@@ -338,7 +348,7 @@ def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size,
             "value": round(args.steps * B * world / elapsed, 1), "unit": "vertices/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: last snapshot (N=%d), F=%d H=%d C=%d, pool(max), batch_full=%d/GPU, inference sample+forward+CE(none), "
+            "config": {"gemm_arithmetic": gemm_desc(args.gemm), "workload": "%s: last snapshot (N=%d), F=%d H=%d C=%d, pool(max), batch_full=%d/GPU, inference sample+forward+CE(none), "
                                    "projection cache %s" % (args.workload, g.n_present, feat_size, wl["hidden"], n_classes, B,
                                                             "on" if strat.cache_projection else "off"),
                        "global_batch": B * world, "parallelism": "dp%d (train set block-partitioned, no collective)" % world,

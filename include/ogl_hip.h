@@ -38,6 +38,17 @@ enum {
 
 enum { OGL_REDUCE_MEAN = 0, OGL_REDUCE_MAX = 1, OGL_REDUCE_SUM = 2 };
 
+/* Arithmetic of the dense projections (process-wide switch, default OGL_GEMM_F32):
+ *   OGL_GEMM_F32    v_mfma_f32_32x32x2_f32 — bit-for-bit an fp32 fma chain;
+ *   OGL_GEMM_BF16X6 every fp32 operand split exactly into 3 bf16 terms, the 6 leading cross products on
+ *                   v_mfma_f32_32x32x16_bf16 with fp32 accumulation — fp32-GEMM accuracy (dropped terms
+ *                   <= 2^-23 |a*b|), same tolerances in the tests; 1.2-1.4x faster where an operand is
+ *                   reduction-contiguous, slower for the weight-gradient layout;
+ *   OGL_GEMM_AUTO   BF16X6 for forward / input-gradient GEMMs, F32 for weight-gradient GEMMs. */
+enum { OGL_GEMM_F32 = 0, OGL_GEMM_BF16X6 = 1, OGL_GEMM_AUTO = 2 };
+int ogl_set_gemm_mode(int mode);
+int ogl_get_gemm_mode(void);
+
 typedef struct ogl_graph ogl_graph_t;
 typedef void* ogl_stream_t; /* hipStream_t */
 

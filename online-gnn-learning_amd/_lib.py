@@ -22,6 +22,8 @@ SIGNATURES = {
     "ogl_version": (_i, []),
     "ogl_status_string": (C.c_char_p, [_i]),
     "ogl_last_hip_error": (_i, []),
+    "ogl_set_gemm_mode": (_i, [_i]),
+    "ogl_get_gemm_mode": (_i, []),
     "ogl_graph_create": (_i, [_p, _p, _p, _i64, _i64, C.POINTER(_p)]),
     "ogl_graph_set_snapshot": (_i, [_p, _i64, _i64, _p]),
     "ogl_graph_degrees": (_i, [_p, C.POINTER(_p)]),

@@ -17,6 +17,30 @@
 #include "ogl_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef v4i16 __attribute__((address_space(3))) lds_v4i16;
+
+// ---- split-bf16 ("x6") arithmetic -------------------------------------------------------------------------------
+// An fp32 value is split EXACTLY into three bf16 terms x = x1 + x2 + x3 (8 + 8 + 8 significand bits, each
+// residual is exact in fp32); a*b = sum_{i,j} a_i*b_j and the six terms with i + j <= 4 are accumulated in fp32
+// by v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are exact in fp32).  The dropped terms are <= 2^-23 |a*b|,
+// i.e. at the level of one fp32 rounding of the product, so the result carries fp32-GEMM accuracy while the matrix
+// pipe runs at 16x the fp32-MFMA rate for 6x the instructions.
+__device__ __forceinline__ unsigned pk_bf16(float x, float y) {
+  f32x2 v = {x, y};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
+}
+__device__ __forceinline__ void split3(float x, float y, unsigned& h, unsigned& m, unsigned& l) {
+  h = pk_bf16(x, y);
+  const float rx = x - __builtin_bit_cast(float, h << 16), ry = y - __builtin_bit_cast(float, h & 0xFFFF0000u);
+  m = pk_bf16(rx, ry);
+  const float sx = rx - __builtin_bit_cast(float, m << 16), sy = ry - __builtin_bit_cast(float, m & 0xFFFF0000u);
+  l = pk_bf16(sx, sy);
+}
+#define X6_ROW_U4 7   // LDS row of a P x 16 tile: 3 splits x 2 k-halves x 16 B + 16 B pad = 112 B (odd multiple of 16 B)
 
 #define GEMM_BK 16
 #define GEMM_THREADS 256
@@ -106,7 +130,7 @@ struct TileLoader {
       pmode = pcol >= Plim ? 0 : (vec_ok ? 1 : 2);
 #pragma unroll
       for (int h = 0; h < NV; ++h) {
-        const int64_t r = r_first + tid / (P / 4) + (1024 / P) * h;
+        const int64_t r = r_first + (tid / (P / 4)) * NV + h;
         nrow[h] = (op.rows && r < R) ? (int)op.rows[r] : 0;   // row ids fit 31 bits (checked at graph create)
       }
     }
@@ -144,7 +168,7 @@ struct TileLoader {
     } else {
 #pragma unroll
       for (int h = 0; h < NV; ++h) {
-        const int64_t r = r0 + tid / (P / 4) + (1024 / P) * h;
+        const int64_t r = r0 + (tid / (P / 4)) * NV + h;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         bool valid = r < R && pmode != 0;
         int64_t row = valid ? r : 0;
@@ -191,6 +215,39 @@ struct TileLoader {
     }
   }
 
+  // split-bf16 image: Xs[p][s*2 + kh] = the 8 bf16 of split s, k = 8*kh .. 8*kh+7, of row p (MFMA operand order)
+  __device__ __forceinline__ void store_x6(uint4 (*Xs)[X6_ROW_U4], int tid, const float4 (&reg)[NV]) const {
+#pragma unroll
+    for (int h = 0; h < NV; ++h) {
+      if (RC) {
+        const int pl = (tid >> 2) + 64 * h, q = tid & 3;            // k = 4q .. 4q+3
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3(reg[h].x, reg[h].y, h0, m0, l0);
+        split3(reg[h].z, reg[h].w, h1, m1, l1);
+        uint2* row = (uint2*)&Xs[pl][0];                             // 8-B granules: granule = chunk*2 + (q&1)
+        row[(0 * 2 + (q >> 1)) * 2 + (q & 1)] = make_uint2(h0, h1);
+        row[(1 * 2 + (q >> 1)) * 2 + (q & 1)] = make_uint2(m0, m1);
+        row[(2 * 2 + (q >> 1)) * 2 + (q & 1)] = make_uint2(l0, l1);
+      }
+    }
+  }
+
+  // split-bf16 image of an NC-sourced tile: kept k-major exactly as it arrives, Xk[s][k][p] (row stride P + 32
+  // halfwords = conflict-free for the transposed reads); the MFMA fragments are gathered by ds_read_b64_tr_b16.
+  __device__ __forceinline__ void store_x6k(unsigned short (*Xk)[GEMM_BK][P + 32], int tid, const float4 (&reg)[NV]) const {
+#pragma unroll
+    for (int h = 0; h < NV; ++h) {
+      const int rl = (tid / (P / 4)) * NV + h;
+      const int pl = (tid % (P / 4)) * 4;
+      unsigned h0, m0, l0, h1, m1, l1;
+      split3(reg[h].x, reg[h].y, h0, m0, l0);
+      split3(reg[h].z, reg[h].w, h1, m1, l1);
+      *(uint2*)&Xk[0][rl][pl] = make_uint2(h0, h1);
+      *(uint2*)&Xk[1][rl][pl] = make_uint2(m0, m1);
+      *(uint2*)&Xk[2][rl][pl] = make_uint2(l0, l1);
+    }
+  }
+
   __device__ __forceinline__ void store(float (*Xs)[P + 4], int tid, const float4 (&reg)[NV]) const {
 #pragma unroll
     for (int h = 0; h < NV; ++h) {
@@ -200,7 +257,7 @@ struct TileLoader {
         Xs[rl + 0][pl] = reg[h].x; Xs[rl + 1][pl] = reg[h].y;
         Xs[rl + 2][pl] = reg[h].z; Xs[rl + 3][pl] = reg[h].w;
       } else {
-        const int rl = tid / (P / 4) + (1024 / P) * h;
+        const int rl = (tid / (P / 4)) * NV + h;
         const int pl = (tid % (P / 4)) * 4;
         *(float4*)&Xs[rl][pl] = reg[h];
       }
@@ -208,12 +265,20 @@ struct TileLoader {
   }
 };
 
-template <bool A_RC, bool B_RC, int WAVES_M, int WAVES_N, int TM, int TN>
+template <bool A_RC, bool B_RC, int WAVES_M, int WAVES_N, int TM, int TN, bool X6>
 __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
-  __shared__ __attribute__((aligned(16))) float As[2][GEMM_BK][BM + 4];
-  __shared__ __attribute__((aligned(16))) float Bs[2][GEMM_BK][BN + 4];
+  // one LDS arena, two images: fp32 k-major tiles (exact fp32 MFMA) or split-bf16 operand-order tiles (x6)
+  constexpr int A_BYTES = X6 ? (A_RC ? BM * X6_ROW_U4 * 16 : 3 * GEMM_BK * (BM + 32) * 2) : GEMM_BK * (BM + 4) * 4;
+  constexpr int B_BYTES = X6 ? (B_RC ? BN * X6_ROW_U4 * 16 : 3 * GEMM_BK * (BN + 32) * 2) : GEMM_BK * (BN + 4) * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+  float (*As)[GEMM_BK][BM + 4] = (float (*)[GEMM_BK][BM + 4])smem;
+  float (*Bs)[GEMM_BK][BN + 4] = (float (*)[GEMM_BK][BN + 4])(smem + 2 * A_BYTES);
+  uint4 (*Ax)[BM][X6_ROW_U4] = (uint4 (*)[BM][X6_ROW_U4])smem;                                   // RC-sourced x6 image
+  uint4 (*Bx)[BN][X6_ROW_U4] = (uint4 (*)[BN][X6_ROW_U4])(smem + 2 * A_BYTES);
+  unsigned short (*Ak)[3][GEMM_BK][BM + 32] = (unsigned short (*)[3][GEMM_BK][BM + 32])smem;     // NC-sourced x6 image
+  unsigned short (*Bk)[3][GEMM_BK][BN + 32] = (unsigned short (*)[3][GEMM_BK][BN + 32])(smem + 2 * A_BYTES);
 
   // XCD-aware, bijective tile mapping.  Hardware deals block L to XCD L % 8; the logical tile space
   // (split, row panel, column tile), column tile fastest, is cut into 8 contiguous chunks and chunk c
@@ -258,20 +323,79 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
   const int64_t ones_p = g.ones_col ? g.N - 1 : -1;
   int cur_part = -1;
 
+  // tiles at or beyond kt_end (the pipeline below always runs an even number of tiles) load as zeros
   auto issue = [&](int kt, float4 (&ra)[BM / 64], float4 (&rb)[BN / 64]) {
-    const int pi = kt < nk[0] ? 0 : 1;
+    const bool live = kt < kt_end;
+    const int pi = (live && kt >= nk[0]) ? 1 : 0;
     const GemmPart& pt = g.part[pi];
-    const int64_t r0 = (int64_t)(pi == 0 ? kt : kt - nk[0]) * GEMM_BK;
+    const int64_t r0 = live ? (int64_t)(pi == 0 ? kt : kt - nk[0]) * GEMM_BK : 0;
+    const int64_t Reff = live ? pt.R : 0;
     if (pi != cur_part) {   // block-uniform: (re)derive the per-thread row pointers of this part
-      la.init(pt.a, i0, g.M, -1, tid, r0, pt.R);
-      lb.init(pt.b, j0, g.N, ones_p, tid, r0, pt.R);
+      la.init(pt.a, i0, g.M, -1, tid, r0, Reff);
+      lb.init(pt.b, j0, g.N, ones_p, tid, r0, Reff);
       cur_part = pi;
     }
-    la.load(pt.a, g.M, r0, pt.R, -1, tid, ra);
-    lb.load(pt.b, g.N, r0, pt.R, ones_p, tid, rb);
+    la.load(pt.a, g.M, r0, Reff, -1, tid, ra);
+    lb.load(pt.b, g.N, r0, Reff, ones_p, tid, rb);
+  };
+
+  auto stage = [&](int buf, const float4 (&ra)[BM / 64], const float4 (&rb)[BN / 64]) {
+    if (X6) {
+      if (A_RC) la.store_x6(Ax[buf], tid, ra); else la.store_x6k(Ak[buf], tid, ra);
+      if (B_RC) lb.store_x6(Bx[buf], tid, rb); else lb.store_x6k(Bk[buf], tid, rb);
+    } else {
+      la.store(As[buf], tid, ra);
+      lb.store(Bs[buf], tid, rb);
+    }
   };
 
   auto compute = [&](int buf) {
+    if (X6) {
+      // one 16-deep MFMA step per tile: operand fragments are single ds_read_b128 (conflict-free: 112-B rows)
+      bf16x8 a[TM][3], b[TN][3];
+      // transposed-read lane roles (per 16-lane group): lane 4q+p supplies row q, columns 4p..4p+3 of a 4 x 16 block and
+      // receives column (lane & 15); groups 0/1 are rows 0-15 / 16-31 of the fragment, lanes 32+ the upper k half
+      const int tq = (lane & 15) >> 2, tp = lane & 3, tc = 16 * ((lane >> 4) & 1);
+#pragma unroll
+      for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) {
+          if (A_RC) {
+            a[t][sp] = __builtin_bit_cast(bf16x8, Ax[buf][wm * TM * 32 + t * 32 + l31][sp * 2 + half]);
+          } else {
+            const int c = wm * TM * 32 + t * 32 + tc + 4 * tp;
+            v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)&Ak[buf][sp][8 * half + tq][c]);
+            v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)&Ak[buf][sp][8 * half + 4 + tq][c]);
+            a[t][sp] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          }
+        }
+#pragma unroll
+      for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) {
+          if (B_RC) {
+            b[t][sp] = __builtin_bit_cast(bf16x8, Bx[buf][wn * TN * 32 + t * 32 + l31][sp * 2 + half]);
+          } else {
+            const int c = wn * TN * 32 + t * 32 + tc + 4 * tp;
+            v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)&Bk[buf][sp][8 * half + tq][c]);
+            v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)&Bk[buf][sp][8 * half + 4 + tq][c]);
+            b[t][sp] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          }
+        }
+#pragma unroll
+      for (int x = 0; x < TM; ++x)
+#pragma unroll
+        for (int y = 0; y < TN; ++y) {
+          // smallest terms first (i + j = 4, then 3, then 2)
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][2], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][1], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][2], b[y][0], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][1], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][0], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][0], acc[x][y], 0, 0, 0);
+        }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < GEMM_BK; kk += 2) {
       float a[TM], b[TN];
@@ -290,32 +414,37 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
   // Pipeline: while tile t is multiplied out of LDS buffer t&1, tile t+1 sits in one register set (written to the
   // other LDS buffer after the MFMAs) and tile t+2 is in flight into the other set: global latency is covered by
   // two tiles of MFMA work.  The loop is unrolled by two so both sets are statically indexed (no scratch).
-  if (kt_begin < kt_end) {
-    issue(kt_begin, ra0, rb0);
-    la.store(As[0], tid, ra0);
-    lb.store(Bs[0], tid, rb0);
-    if (kt_begin + 1 < kt_end) issue(kt_begin + 1, ra1, rb1);
-  }
+  issue(kt_begin, ra0, rb0);
+  stage(0, ra0, rb0);
+  issue(kt_begin + 1, ra1, rb1);
   __syncthreads();
 
-  int kt = kt_begin;
-  for (; kt + 1 < kt_end; kt += 2) {
-    // even step: compute buffer 0, tile kt+1 waits in set 1, fetch kt+2 into set 0
-    if (kt + 2 < kt_end) issue(kt + 2, ra0, rb0);
-    compute(0);
-    la.store(As[1], tid, ra1);
-    lb.store(Bs[1], tid, rb1);
-    __syncthreads();
-    // odd step: compute buffer 1, tile kt+2 waits in set 0, fetch kt+3 into set 1
-    if (kt + 3 < kt_end) issue(kt + 3, ra1, rb1);
-    compute(1);
-    if (kt + 2 < kt_end) {
-      la.store(As[0], tid, ra0);
-      lb.store(Bs[0], tid, rb0);
+  // one pipeline step: multiply tile t out of LDS buffer `buf` while tile t+1 (already in registers) is converted
+  // and written to the other buffer.  In x6 mode the split/pack VALU work and the LDS writes are interleaved with the
+  // 24 MFMAs (one MFMA : ~4 VALU : DS write every other MFMA) so the matrix pipe is not left idle behind them.
+  auto step = [&](int buf, const float4 (&ra)[BM / 64], const float4 (&rb)[BN / 64]) {
+    compute(buf);
+    stage(buf ^ 1, ra, rb);
+    if (X6) {
+      __builtin_amdgcn_sched_group_barrier(0x100, (A_RC ? 1 : 2) * TM * 3 + (B_RC ? 1 : 2) * TN * 3, 0);   // fragment ds_reads first
+#pragma unroll
+      for (int i = 0; i < TM * TN * 6; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);               // 4 VALU (split / pack / address)
+        if (i & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // 1 DS write
+      }
     }
+  };
+
+  // the loop body is branch-free: an odd tile count is padded with one all-zero tile (see issue())
+  for (int kt = kt_begin; kt < kt_end; kt += 2) {
+    issue(kt + 2, ra0, rb0);
+    step(0, ra1, rb1);                     // tile kt out of buffer 0, tile kt+1 -> buffer 1
+    __syncthreads();
+    issue(kt + 3, ra1, rb1);
+    step(1, ra0, rb0);                     // tile kt+1 out of buffer 1, tile kt+2 -> buffer 0
     __syncthreads();
   }
-  if (kt < kt_end) compute(0);   // odd tile count: the last tile is already in buffer 0
 
   // epilogue: D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -443,6 +572,15 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(GemmArgs g) {
   }
 }
 
+static int g_gemm_mode = OGL_GEMM_F32;
+
+extern "C" int ogl_set_gemm_mode(int mode) {
+  if (mode != OGL_GEMM_F32 && mode != OGL_GEMM_BF16X6 && mode != OGL_GEMM_AUTO) return OGL_EINVAL;
+  g_gemm_mode = mode;
+  return OGL_OK;
+}
+extern "C" int ogl_get_gemm_mode(void) { return g_gemm_mode; }
+
 static inline int operand_vec(const float* p, int64_t ld, const float* mask, int64_t ldm) {
   (void)p; (void)ld; (void)mask; (void)ldm;
   return 1;  // unaligned-access mode: 16-B loads are legal at any 4-B aligned address (see ld16)
@@ -469,12 +607,19 @@ static int launch_gemm(GemmArgs& g, hipStream_t stream) {
   g.NI = (int)ogl_cdiv(g.M, BM);
   g.NJ = (int)ogl_cdiv(g.N, BN);
   dim3 grid((unsigned)((int64_t)g.NI * g.NJ * g.nsplit)), block(GEMM_THREADS);
-  if (cfg == 1)
-    hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 4, 1, 2, 2>), grid, block, 0, stream, g);
-  else if (cfg == 2)
-    hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 2, 2, 1, 1>), grid, block, 0, stream, g);
-  else
-    hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 2, 2, 2, 2>), grid, block, 0, stream, g);
+  // AUTO: split-bf16 where it is measured faster (operands with at least one reduction-contiguous side: forward and
+  // input-gradient GEMMs); the weight-gradient GEMM converts both operands on the fly and stays on the fp32 MFMA.
+  const bool x6 = g_gemm_mode == OGL_GEMM_BF16X6 || (g_gemm_mode == OGL_GEMM_AUTO && (A_RC || B_RC));
+  if (cfg == 1) {
+    if (x6) hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 4, 1, 2, 2, true>), grid, block, 0, stream, g);
+    else hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 4, 1, 2, 2, false>), grid, block, 0, stream, g);
+  } else if (cfg == 2) {
+    if (x6) hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 2, 2, 1, 1, true>), grid, block, 0, stream, g);
+    else hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 2, 2, 1, 1, false>), grid, block, 0, stream, g);
+  } else {
+    if (x6) hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 2, 2, 2, 2, true>), grid, block, 0, stream, g);
+    else hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 2, 2, 2, 2, false>), grid, block, 0, stream, g);
+  }
   OGL_CHECK_LAUNCH();
   if (g.nsplit > 1) {
     int64_t total = g.M * g.N;

@@ -52,6 +52,20 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+GEMM_MODES = {"f32": 0, "bf16x6": 1, "auto": 2}
+
+
+def set_gemm_mode(mode: str):
+    """'f32' = exact fp32 MFMA (default); 'bf16x6' = split-bf16 MFMA at fp32 accuracy; 'auto' = bf16x6 where it is
+    faster (forward / input-gradient GEMMs), f32 for weight gradients (see include/ogl_hip.h)."""
+    check(_lib.lib().ogl_set_gemm_mode(GEMM_MODES[mode]), "ogl_set_gemm_mode")
+
+
+def get_gemm_mode() -> str:
+    m = _lib.lib().ogl_get_gemm_mode()
+    return [k for k, v in GEMM_MODES.items() if v == m][0]
+
+
 def padded_ld(cols: int) -> int:
     """Leading dimension used for matrices this package allocates (16-B rows; 128-B rows when wide)."""
     return (cols + 31) // 32 * 32 if cols > 64 else max(4, (cols + 3) // 4 * 4)

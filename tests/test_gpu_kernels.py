@@ -23,6 +23,14 @@ def ops():
     return _ops
 
 
+@pytest.fixture(params=["f32", "bf16x6", "auto"])
+def gemm_mode(request, ops):
+    """Both GEMM arithmetics must meet the SAME tolerances: exact fp32 MFMA and the split-bf16 (x6) MFMA path."""
+    ops.set_gemm_mode(request.param)
+    yield request.param
+    ops.set_gemm_mode("f32")
+
+
 def dev(x, dtype=None):
     t = torch.as_tensor(np.ascontiguousarray(x))
     if dtype is not None:
@@ -138,7 +146,7 @@ def test_reduce_bwd(ops, op):
     np.testing.assert_allclose(s.grad.cpu().numpy(), src.grad.numpy(), rtol=1e-5, atol=1e-6)
 
 
-def test_pool_max_fused_backward(ops):
+def test_pool_max_fused_backward(ops, gemm_mode):
     """relu(fc_pool) -> max as one node: ReLU mask applied inside the scatter (no mask pass in the GEMMs)."""
     torch.manual_seed(1)
     rng = np.random.default_rng(1)
@@ -176,7 +184,7 @@ GEMM_SHAPES = [(1, 1, 1), (5, 7, 3), (130, 33, 17), (257, 602, 602), (1000, 600,
 
 @pytest.mark.parametrize("M,K,N", GEMM_SHAPES)
 @pytest.mark.parametrize("relu", [False, True])
-def test_linear_fwd(ops, M, K, N, relu):
+def test_linear_fwd(ops, gemm_mode, M, K, N, relu):
     torch.manual_seed(M + K + N)
     x = torch.randn(M, K); w = torch.randn(N, K) / K ** 0.5; b = torch.randn(N)
     want = torch.nn.functional.linear(x, w, b)
@@ -187,7 +195,7 @@ def test_linear_fwd(ops, M, K, N, relu):
         np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL)
 
 
-def test_linear_fwd_dual_and_rows(ops):
+def test_linear_fwd_dual_and_rows(ops, gemm_mode):
     torch.manual_seed(3)
     T, M, K, K2, N = 900, 300, 602, 602, 600
     tab = torch.randn(T, K); rows = torch.randint(0, T, (M,))
@@ -224,7 +232,7 @@ def test_linear_fwd_skinny(ops, M, K, K2, N, relu):
 
 @pytest.mark.parametrize("M,K,N", GEMM_SHAPES + [(20000, 602, 602), (5000, 128, 128)])
 @pytest.mark.parametrize("relu", [False, True])
-def test_linear_bwd(ops, M, K, N, relu):
+def test_linear_bwd(ops, gemm_mode, M, K, N, relu):
     torch.manual_seed(M * 3 + K + N)
     x = torch.randn(M, K)
     w = torch.randn(N, K) / K ** 0.5
@@ -243,7 +251,7 @@ def test_linear_bwd(ops, M, K, N, relu):
     np.testing.assert_allclose(bc.grad.cpu().numpy(), want_b.numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL * scale)
 
 
-def test_linear_bwd_weight_rows(ops):
+def test_linear_bwd_weight_rows(ops, gemm_mode):
     torch.manual_seed(4)
     T, M, K, N = 5000, 3000, 602, 602
     tab = torch.randn(T, K); rows = torch.randint(0, T, (M,)); dy = torch.randn(M, N)
@@ -295,3 +303,22 @@ def test_adam_multi(ops):
         ops.adam_step_multi(pc, [g.cuda() for g in gs], mc, vc, step)
     for a, b in zip(pc, ps):
         np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_x6_split_is_exact_and_accurate(ops):
+    """x6 vs exact-fp32 MFMA on an ill-scaled problem (wide dynamic range, K = 4096): both within fp32-GEMM error of fp64."""
+    torch.manual_seed(9)
+    M, K, N = 257, 4096, 130
+    x = torch.randn(M, K) * torch.logspace(-3, 3, K)[None, :]
+    w = torch.randn(N, K) * torch.logspace(2, -2, K)[None, :]
+    ref = (x.double() @ w.double().T)
+    scale = (x.double().abs() @ w.double().abs().T)              # sum |a||b|: the natural error unit
+    outs = {}
+    for mode in ("f32", "bf16x6"):
+        ops.set_gemm_mode(mode)
+        outs[mode] = ops.linear_fwd(x.cuda(), w.cuda()).cpu().double()
+    ops.set_gemm_mode("f32")
+    e32 = ((outs["f32"] - ref).abs() / scale).max().item()
+    e6 = ((outs["bf16x6"] - ref).abs() / scale).max().item()
+    assert e32 < 1e-6 and e6 < 1e-6, (e32, e6)                     # fp32 chain: ~K * 2^-24 worst case, typically 1e-7
+    assert e6 < 4 * max(e32, 6e-8), (e32, e6)

@@ -190,6 +190,17 @@ def test_cached_projection_inference_matches_per_batch(pkg, mode, pool):
               GatheredRows(g.ndata["feat"], None, proj))
 
 
+def test_model_step_bf16x6_mode(pkg):
+    """The whole train step under the split-bf16 GEMM mode meets the same tolerances against the oracle."""
+    from ogl_amd import ops
+    ops.set_gemm_mode("bf16x6")
+    try:
+        test_two_layer_model_step_matches_oracle(pkg, "pool", None, True)
+        test_two_layer_model_step_matches_oracle(pkg, "meanpool", 12, True)
+    finally:
+        ops.set_gemm_mode("f32")
+
+
 def test_unknown_aggregator_raises_keyerror(pkg):
     from ogl_amd.graphsage import SAGEConv
     from ogl_amd.sampling import Block

@@ -17,6 +17,9 @@ def timeit(fn, iters=10):
 
 
 def main():
+    if len(sys.argv) > 1:
+        ops.set_gemm_mode(sys.argv[1])
+        print("gemm mode", ops.get_gemm_mode())
     torch.manual_seed(0)
     n0, n1, B, F, H, C = 63000, 7071, 512, 602, 600, 41
     T = 232965
