@@ -1,0 +1,144 @@
+"""Parity at BASELINE.json's full sizes (Reddit-shaped stream: N=232 965, 23.2 M CSR entries, F=602, H=600, C=41,
+B=512, S=25).  The vectorised numpy/torch oracle still finishes in seconds at these sizes, so the comparisons are
+the same bit-exact / tolerance checks as the small cases — plus size-independent properties.  Run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def reddit():
+    import ogl_amd  # noqa: F401
+    from ogl_amd import synthetic
+    from ogl_amd.graph.dynamic_graph_edge import DynamicGraphEdge
+    a = synthetic.make_arrays("reddit")
+    dyn = DynamicGraphEdge(a["snapshots"], set(), device="cuda")
+    dyn.build(a["feat"], a["labels"], True, edge_timestamps={"src": a["src"], "dst": a["dst"]})
+    g = dyn.get_graph()
+    h = g.handle
+    host = dict(indptr=h.indptr.cpu().numpy(), indices=h.indices.cpu().numpy(), keys=h.keys.cpu().numpy())
+    return a, dyn, g, host
+
+
+def test_fullsize_snapshot_sampler_block_bit_exact(reddit):
+    from ogl_amd import ops, sampling
+    a, dyn, g, host = reddit
+    E = len(a["src"])
+    for frac in (0.37, 1.0):
+        cut = int(E * frac)
+        n_present = dyn._n_present_at(cut)
+        g.set_snapshot(n_present, cut)
+        deg = O.snapshot_degrees_fast(host["indptr"], host["keys"], n_present, cut)
+        assert np.array_equal(g.handle.degrees().cpu().numpy(), deg)
+        # property: sum of snapshot degrees = 2 x rows before the cut (both directions of every row)
+        assert int(deg.sum()) == 2 * cut
+        seeds = np.random.default_rng(5).choice(n_present, 512, replace=False).astype(np.int64)
+        sampling.seed(77)
+        (input_nodes, sd, blocks), = list(sampling.NodeDataLoader(g, torch.as_tensor(seeds),
+                                                                   sampling.MultiLayerNeighborSampler([25, 25]), batch_size=512))
+        want_in, _, want_blocks = O.sample_blocks(host["indptr"], host["indices"], deg, seeds, [25, 25], 77, 0)
+        assert np.array_equal(input_nodes.cpu().numpy(), want_in)
+        for b, wb in zip(blocks, want_blocks):
+            assert np.array_equal(b.picks.cpu().numpy(), wb["picks"])
+            assert np.array_equal(b.local_idx.cpu().numpy(), wb["local_idx"])
+            assert np.array_equal(b.src_ids.cpu().numpy(), wb["src_ids"])
+        # properties: exactly S picks iff deg > 0; every pick is a present vertex; block maps back to the picks
+        p1 = blocks[1].picks
+        has = torch.as_tensor(deg[seeds] > 0).cuda()
+        assert bool(((p1 >= 0).all(dim=1) == has).all()) and bool(((p1 < 0).all(dim=1) == ~has).all())
+        assert int(p1.max()) < n_present
+        m = blocks[0].local_idx >= 0
+        assert bool((blocks[0].src_ids[blocks[0].local_idx[m].long()] == blocks[0].picks[m]).all())
+    g.set_snapshot(g.n_total, E)
+
+
+def test_fullsize_aggregator_bit_exact(reddit):
+    from ogl_amd import ops
+    rng = np.random.default_rng(3)
+    n0, n1, S, D = 62000, 7000, 25, 602
+    src = rng.standard_normal((n0, D)).astype(np.float32)
+    li = rng.integers(0, n0, size=(n1, S)).astype(np.int32)
+    li[rng.random(n1) < 0.02] = -1
+    srct = ops.empty_mat(n0, D, "cuda").copy_(torch.as_tensor(src))
+    for op in ("max", "mean"):
+        want, arg = O.reduce_fwd(src, li, op)
+        got, garg = ops.reduce_fwd(srct, torch.as_tensor(li).cuda(), op, want_argmax=True)
+        assert np.array_equal(got.cpu().numpy(), want)
+        if op == "max":
+            assert np.array_equal(garg.cpu().numpy(), arg)
+            # idempotence: reducing the reduced rows with identity indices returns them unchanged
+            ident = torch.arange(n1, dtype=torch.int32, device="cuda").reshape(-1, 1)
+            again, _ = ops.reduce_fwd(got, ident, "max")
+            assert torch.equal(again, got)
+
+
+@pytest.mark.parametrize("mode", ["f32", "auto"])
+def test_fullsize_projection_gemm(reddit, mode):
+    from ogl_amd import ops
+    a, dyn, g, host = reddit
+    torch.manual_seed(0)
+    ops.set_gemm_mode(mode)
+    try:
+        rows = torch.randint(0, g.n_total, (62750,))
+        w = torch.randn(602, 602) / 602 ** 0.5
+        b = torch.randn(602)
+        want = F.relu(F.linear(a["feat"][rows], w, b))
+        got = ops.linear_fwd(g.feat_table, w.cuda(), b.cuda(), relu=True, x_rows=rows.cuda())
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
+        # linearity (size-independent): f(2x) with zero bias = 2 f(x) exactly in binary floating point
+        y1 = ops.linear_fwd(g.feat_table, w.cuda(), None, x_rows=rows[:4096].cuda())
+        t2 = ops.empty_mat(g.n_total, 602, "cuda").copy_(g.feat_table * 2)
+        y2 = ops.linear_fwd(t2, w.cuda(), None, x_rows=rows[:4096].cuda())
+        assert torch.equal(y2, y1 * 2)
+    finally:
+        ops.set_gemm_mode("f32")
+
+
+def test_fullsize_train_step_matches_oracle(reddit):
+    """One RBR train step at the Reddit rung: loss and parameter updates against the torch-CPU oracle."""
+    from ogl_amd import ops, optim, sampling
+    from ogl_amd.graphsage import GatheredRows, GraphSAGE
+    a, dyn, g, host = reddit
+    deg = O.snapshot_degrees_fast(host["indptr"], host["keys"], g.n_present, g.cut)
+    cpu = O.CpuModel("pool", 602, 600, 41, seed=1)
+    model = GraphSAGE(602, 600, 41, 1, F.relu, 0, "pool").cuda()
+    with torch.no_grad():
+        for l, prm in zip(model.layers, cpu.params):
+            for k, v in prm.items():
+                mod, attr = k.split(".")
+                getattr(getattr(l, mod), attr).copy_(v)
+    opt = optim.Adam(model.parameters(), lr=1e-3)
+    seeds = np.random.default_rng(11).choice(g.n_present, 512, replace=False).astype(np.int64)
+    sampling.seed(5)
+    (input_nodes, sd, blocks), = list(sampling.NodeDataLoader(g, torch.as_tensor(seeds),
+                                                               sampling.MultiLayerNeighborSampler([25, 25]), batch_size=512))
+    labels = ops.gather_i64(g.ndata["target"], sd)
+    loss = ops.cross_entropy(model(blocks, GatheredRows(g.ndata["feat"], input_nodes)), labels, "mean")
+    loss.backward()
+    opt.step()
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    loss_ref = cpu.train_step(a["feat"], torch.as_tensor(a["labels"]).reshape(-1, 1), host["indptr"], host["indices"], deg,
+                              seeds, 25, 5, 0)
+    assert abs(float(loss) - loss_ref) <= 1e-4 * abs(loss_ref)
+    # Gradients.  Elementwise max over 25 candidates x 4.2 M (dst, column) pairs has near-ties at fp32 resolution: the
+    # GPU and CPU projections differ in the last bits, a handful of winners flip, and each flip re-routes one finite
+    # gradient contribution inside fc_pool's weight gradient (the values that flow on are equal to ~1e-6, so every
+    # OTHER gradient of that layer is well conditioned).  Gradients are therefore compared in relative Frobenius norm.
+    rels = {}
+    for li, (l, prm) in enumerate(zip(model.layers, cpu.params)):
+        for k, v in prm.items():
+            mod, attr = k.split(".")
+            got = getattr(getattr(l, mod), attr).grad.cpu().numpy()
+            ref = v.grad.numpy()
+            rels["layers.%d.%s" % (li, k)] = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    print("relative gradient errors:", rels)
+    # flips in the OUTPUT layer's max also perturb everything upstream of it, so only the output layer's
+    # fc_self / fc_neigh gradients are free of them: those are held to GEMM accuracy, the rest to 2 %
+    for k, r in rels.items():
+        tight = k.startswith("layers.1.") and "fc_pool" not in k
+        assert r < (1e-4 if tight else 2e-2), (k, r, rels)
