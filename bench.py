@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--workload", default="reddit_rbr", choices=sorted(WORKLOADS))
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the synthetic graph (debugging only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (one GPU per rank); gloo = rehearsal of the N>1 path with several ranks on one GPU")
     ap.add_argument("--gemm", default="auto", choices=["f32", "bf16x6", "auto"],
                     help="projection arithmetic: exact fp32 MFMA, split-bf16 (x6, fp32-accurate) MFMA, or per-layout best")
     ap.add_argument("--no-projection-cache", action="store_true", help="priority forward: recompute fc_pool_0 per batch")
@@ -66,9 +68,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    if args.dist_backend == "nccl" and world > 1 and local_rank >= ndev:
+        raise RuntimeError("rank %d needs its own GPU (found %d); use --dist-backend gloo to rehearse on one GPU" % (local_rank, ndev))
+    torch.cuda.set_device(local_rank % max(ndev, 1))
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import ogl_amd  # noqa: F401
     from ogl_amd import ops, optim, parallel, sampling, synthetic

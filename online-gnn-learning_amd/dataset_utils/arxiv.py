@@ -1,0 +1,9 @@
+"""`load` for the arxiv vertex stream — same files and return tuple as R/train/dataset_utils/arxiv.py:18-54."""
+from .common_utils import load_vertex_stream
+
+FILES = ["feats.npy", "targets.npy", "graph.adjlist", "vertex_timestamp.json"]
+
+
+def load(path, snapshots=100, cuda=True, copy_to_gpu=True):
+    """-> (feat_size, targets[N,1], dynamic_graph, n_classes, dynamic_graph_test)"""
+    return load_vertex_stream(path, "feats.npy", "vertex_timestamp.json", snapshots, cuda, copy_to_gpu)

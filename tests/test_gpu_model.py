@@ -269,3 +269,43 @@ def test_state_dict_roundtrip_names(pkg, tmp_path):
     m2 = GraphSAGE(20, 8, 4, 1, F.relu, 0, "pool").cuda()
     m2.load_state_dict(torch.load(tmp_path / "gnn.pt"))
     assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def test_on_disk_loaders_roundtrip(pkg, tmp_path):
+    """Write a toy dataset in the reference's file formats, load it through dataset_utils, and check the streams
+    equal the ones built directly from the same arrays."""
+    import json
+    from ogl_amd import dataset_utils, synthetic
+    a = synthetic.make_arrays("toy")
+    d = tmp_path / "pubmed"; d.mkdir()
+    np.save(d / "feat_data.npy", a["feat"].numpy().astype(np.float64))
+    lab = a["labels"].copy(); lab[::10] = -1
+    np.save(d / "targets.npy", lab.astype(np.float64))
+    adj = {}
+    for u, v in zip(a["src"].tolist(), a["dst"].tolist()):
+        adj.setdefault(u, []).append(v)
+    (d / "graph.adjlist").write_text("\n".join("%d %s" % (u, " ".join(map(str, vs))) for u, vs in adj.items()) + "\n")
+    ts = {int(v): float(t) for t, v in enumerate(a["order"])}
+    (d / "postponed_timestamp.json").write_text(json.dumps(ts))
+    feat_size, targets, dyn, n_classes, dyn_test = dataset_utils.pubmed.load(str(d), snapshots=20)
+    assert feat_size == 20 and targets.shape == (600, 1) and n_classes == len(np.unique(lab))
+    g = dyn.get_graph()
+    assert g.n_present == 30 and len(dyn) == 20
+    assert 0 not in dyn.labelled_vertices and 1 in dyn.labelled_vertices
+    # features arrive in arrival order, float64 -> float32
+    order = np.array(a["order"][:30])
+    np.testing.assert_array_equal(g.ndata["feat"].cpu().numpy(), a["feat"].numpy()[order])
+    assert np.array_equal(dyn.get_subgraph_to_original_map(), order)
+    dyn.evolve(); dyn_test.evolve(); dyn_test.evolve()
+    assert dyn.get_graph().n_present == 60 and dyn_test.get_graph().n_present == 90
+    # edge stream
+    e = synthetic.make_arrays("toy_edge")
+    d2 = tmp_path / "reddit"; d2.mkdir()
+    np.save(d2 / "feat_data.npy", e["feat"].numpy().astype(np.float64)); np.save(d2 / "targets.npy", e["labels"])
+    rows = ["idx,src,dst"] + ["%d,%d,%d" % (i, s, t) for i, (s, t) in enumerate(zip(e["src"], e["dst"]))]
+    (d2 / "edges_dataframe.csv").write_text("\n".join(rows) + "\n")
+    fs, tg, dyn_e, nc, _ = dataset_utils.reddit.load(str(d2), snapshots=20)
+    ge = dyn_e.get_graph()
+    assert fs == 20 and ge.cut == len(e["src"]) // 20 and nc == 4
+    with pytest.raises(FileNotFoundError):
+        dataset_utils.arxiv.load(str(d), snapshots=5)

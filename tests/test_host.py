@@ -171,3 +171,21 @@ def test_loader_batching_rules():
         sampling.MultiLayerNeighborSampler([5, 5], replace=False)
     sampling.seed(7)
     assert sampling.get_state() == {"seed": 7, "ctr": 0}
+
+
+def test_dataset_file_parsers(tmp_path):
+    """File formats of R/train/dataset_utils/*: adjlist, timestamp json, edge csv (parsing needs no GPU)."""
+    from ogl_amd.dataset_utils import common_utils as cu
+    (tmp_path / "graph.adjlist").write_text("# comment\n0 1 2\n1 2\n2\n3 3\n4 0 # trailing\n")
+    src, dst = cu.read_adjlist(str(tmp_path / "graph.adjlist"))
+    pairs = sorted(zip(src.tolist(), dst.tolist()))
+    assert pairs == sorted([(0, 1), (1, 0), (0, 2), (2, 0), (1, 2), (2, 1), (0, 4), (4, 0), (3, 3)])
+    (tmp_path / "vertex_timestamp.json").write_text(json.dumps({"0": 5.0, "3": 1.5}))
+    assert cu.read_timestamps(str(tmp_path / "vertex_timestamp.json")) == {0: 5.0, 3: 1.5}
+    (tmp_path / "edges_dataframe.csv").write_text(",src,dst,time\n0,0,1,10\n1,1,2,11\n2,0,2,12\n")
+    t = cu.read_edge_table(str(tmp_path / "edges_dataframe.csv"))
+    assert t["src"].tolist() == [0, 1, 0] and t["dst"].tolist() == [1, 2, 2]
+    with pytest.raises(FileNotFoundError, match="targets.npy"):
+        cu._need(str(tmp_path), ["graph.adjlist", "targets.npy"])
+    from ogl_amd.dataset_utils import pubmed, arxiv, reddit
+    assert pubmed.FILES[3] == "postponed_timestamp.json" and arxiv.FILES[0] == "feats.npy" and "edges_dataframe.csv" in reddit.FILES
