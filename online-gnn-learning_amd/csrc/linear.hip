@@ -594,9 +594,36 @@ static inline int gemm_config(int64_t M, int64_t N, int nsplit, int* BM, int* BN
   *BM = 128; *BN = 128; return 0;
 }
 
+// epilogue of an empty product (every part has a zero-length reduction): C = act(bias), db = 0
+__global__ void __launch_bounds__(256) k_gemm_empty(GemmArgs g) {
+  const int64_t total = g.M * g.N;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = t / g.N, col = t - row * g.N;
+    const bool oc = g.ones_col && col == g.N - 1;
+    float v = (g.bias && !oc) ? g.bias[col] : 0.f;
+    if (g.relu) v = fmaxf(v, 0.f);
+    if (oc) { if (g.db) g.db[row] = 0.f; }
+    else g.C[row * g.ldc + col] = v;
+  }
+}
+
 template <bool A_RC, bool B_RC>
 static int launch_gemm(GemmArgs& g, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0) return OGL_OK;
+  // The loaders read row 0 of an operand for masked-off lanes (branch-free), so an operand must have memory behind
+  // it: parts with an empty reduction (torch passes nullptr for empty tensors) are dropped here.
+  {
+    int n = 0;
+    for (int pi = 0; pi < g.nparts; ++pi)
+      if (g.part[pi].R > 0 && g.part[pi].a.ptr && g.part[pi].b.ptr) g.part[n++] = g.part[pi];
+    g.nparts = n;
+    if (n == 0) {
+      hipLaunchKernelGGL(k_gemm_empty, dim3((unsigned)min((int64_t)1024, ogl_cdiv(g.M * g.N, 256))), dim3(256), 0, stream, g);
+      OGL_CHECK_LAUNCH();
+      return OGL_OK;
+    }
+    if (n == 1) g.part[1] = GemmPart();
+  }
   int BM, BN;
   int cfg = gemm_config(g.M, g.N, g.nsplit, &BM, &BN);
   if (g.force_cfg) {
@@ -654,7 +681,7 @@ extern "C" int ogl_linear_fwd(const float* x, int64_t ldx, const int64_t* x_rows
   g.M = M; g.N = N; g.C = y; g.ldc = ldy; g.bias = bias; g.relu = relu;
   // few output tiles and a long reduction: in-block split-K straight from global memory
   const int64_t Ktot = (int64_t)K + K2;
-  if (N <= 64 && M <= 4096 && Ktot >= 256) {
+  if (N <= 64 && M <= 4096 && Ktot >= 256 && K > 0 && (K2 == 0 || g.nparts == 2)) {
     dim3 grid((unsigned)ogl_cdiv(M, 32), (unsigned)ogl_cdiv(N, 64));
     if (N <= 32) { grid.y = 1; hipLaunchKernelGGL(k_gemm_skinny<1>, grid, dim3(256), 0, (hipStream_t)stream, g); }
     else hipLaunchKernelGGL(k_gemm_skinny<2>, grid, dim3(256), 0, (hipStream_t)stream, g);
@@ -724,6 +751,7 @@ extern "C" int ogl_linear_bwd_weight(const float* dy, int64_t ldy, const float* 
   g.M = N; g.N = K + 1; g.ones_col = 1; g.C = dw; g.ldc = lddw; g.db = db;
   bwd_weight_plan(M, N, K, &g.nsplit, &g.tiles_per_split, &g.force_cfg);
   g.force_cfg += 1;   // 0 = let launch_gemm choose
+  if (M == 0 || K == 0) { g.nsplit = 1; g.tiles_per_split = 0; }
   if (g.nsplit > 1) {
     g.ws_ld = ogl_round_up(K + 1, 4);
     if (!workspace || workspace_bytes < (int64_t)g.nsplit * N * g.ws_ld * 4) return OGL_EWORKSPACE;
