@@ -167,6 +167,12 @@ int ogl_ce_fwd_bwd(const float* logits, int64_t ldl, const int64_t* labels, int6
 int ogl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step,
                   double lr, double beta1, double beta2, double eps, ogl_stream_t stream);
 
+/* Evaluation on the device: pred[i] = argmax_c logits[i, c] (first maximum) and confusion[true*C + pred] += 1
+ * (int64 [C*C], ACCUMULATED: zero it before the first batch).  Replaces argmax + sklearn confusion_matrix,
+ * R/train/graphsage/model.py:84-87; pred / confusion / labels are each optional. */
+int ogl_argmax_confusion(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C,
+                         int64_t* pred, int64_t* confusion, ogl_stream_t stream);
+
 /* The same update for `count` tensors in one launch; p/g/m/v/n are HOST arrays of device pointers / lengths. */
 int ogl_adam_step_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
                         const int64_t* n, int step, double lr, double beta1, double beta2, double eps,

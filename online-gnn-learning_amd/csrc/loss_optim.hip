@@ -146,3 +146,43 @@ extern "C" int ogl_adam_step_multi(int count, float* const* p, const float* cons
   }
   return OGL_OK;
 }
+
+// Evaluation on the device: argmax of every logits row (first maximum, like numpy) and
+// the C x C confusion matrix confusion[true][pred], so only C*C counters cross PCIe instead of [n, C] logits.
+// Replaces output_data.argmax(axis=1) + sklearn.metrics.confusion_matrix (R/train/graphsage/model.py:84-87).
+__global__ void __launch_bounds__(256) k_argmax_confusion(const float* __restrict__ logits, int64_t ldl,
+                                                          const int64_t* __restrict__ labels, int64_t B, int C,
+                                                          int64_t* __restrict__ pred, unsigned long long* __restrict__ confusion) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float* x = logits + row * ldl;
+  float best = -INFINITY;
+  int arg = C;                                         // lanes without a column never win
+  for (int c = lane; c < C; c += 64) {
+    const float v = x[c];
+    if (v > best || (arg == C)) { if (v > best || arg == C) { best = v; arg = c; } }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o);
+    const int oa = __shfl_xor(arg, o);
+    if (oa < C && (arg >= C || ob > best || (ob == best && oa < arg))) { best = ob; arg = oa; }
+  }
+  if (lane == 0) {
+    if (pred) pred[row] = arg;
+    const int64_t y = labels ? labels[row] : -1;
+    if (confusion && y >= 0 && y < C && arg < C) atomicAdd(&confusion[y * C + arg], 1ull);
+  }
+}
+
+extern "C" int ogl_argmax_confusion(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C,
+                                    int64_t* pred, int64_t* confusion, ogl_stream_t stream) {
+  if (B < 0 || C <= 0 || ldl < C) return OGL_EINVAL;
+  if (B == 0) return OGL_OK;
+  if (!logits || (confusion && !labels)) return OGL_EINVAL;
+  hipLaunchKernelGGL(k_argmax_confusion, dim3((unsigned)ogl_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, logits, ldl, labels,
+                     B, C, pred, (unsigned long long*)confusion);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}

@@ -21,6 +21,20 @@ def _to_numpy(t):
     return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
 
 
+def macro_f1_from_confusion(cm_full):
+    """sklearn semantics of R/train/graphsage/model.py:85-87 from a full C x C count matrix: classes that occur neither as
+    a label nor as a prediction are dropped (``confusion_matrix`` / ``f1_score(average='macro')`` use the labels present),
+    a class with no predicted and no true samples... cannot remain after that; F1 of a class with zero denominator is 0.
+    Returns (macro F1, flattened confusion matrix over the present classes)."""
+    cm_full = np.asarray(cm_full, dtype=np.int64)
+    present = np.nonzero((cm_full.sum(0) + cm_full.sum(1)) > 0)[0]
+    cm = cm_full[np.ix_(present, present)]
+    tp = np.diag(cm).astype(np.float64)
+    denom = cm.sum(0) + cm.sum(1)                     # 2 TP + FP + FN
+    f1 = np.where(denom > 0, 2 * tp / np.maximum(denom, 1), 0.0)
+    return float(f1.mean()) if len(f1) else 0.0, [int(x) for x in cm.reshape(-1)]
+
+
 class SupervisedGraphSage:
     """Base class (R/train/graphsage/model.py:18-117)."""
 
@@ -54,25 +68,37 @@ class SupervisedGraphSage:
         return self._evaluate_vertices(temporal_graph, path, test)
 
     def _evaluate_vertices(self, graph_util, path, batch_nids):
-        from sklearn.metrics import confusion_matrix, f1_score
         id_to_subgraph = graph_util.get_original_to_subgraph_map()
         subgraph_to_id = graph_util.get_subgraph_to_original_map()
         graph = graph_util.get_graph()
         vertices = id_to_subgraph[batch_nids]
-        output_data = self._run_custom_eval(graph, subgraph_to_id, id_to_subgraph, vertices)
-        if len(output_data) == 0:
+        res = self._eval_confusion(graph, subgraph_to_id, id_to_subgraph, vertices)
+        if res is None:
             return
-        output_data = np.concatenate(output_data)
-        if len(output_data) == 0:
+        cm_full, n = res
+        if n == 0:
             return
-        vt = torch.as_tensor(np.asarray(vertices), dtype=torch.int64).to(graph.device)
-        labels = _to_numpy(ops.gather_i64(graph.ndata["target"], vt))
-        pred = output_data.argmax(axis=1)
-        cm = [int(item) for row in confusion_matrix(labels, pred) for item in row]
-        f1 = f1_score(labels, pred, average="macro")
+        f1, cm = macro_f1_from_confusion(cm_full)
         with open(path, "a+") as f:
             f.write(self.get_model() + ";" + str(f1) + ";" + str(self.delay) + ";" + str(cm) + "\n")
         return f1
+
+    def _eval_confusion(self, graph, subgraph_to_id, id_to_subgraph, vertices):
+        """Default (backend-agnostic) path: logits to the host, argmax + confusion matrix there."""
+        output_data = self._run_custom_eval(graph, subgraph_to_id, id_to_subgraph, vertices)
+        if len(output_data) == 0:
+            return None
+        output_data = np.concatenate(output_data)
+        if len(output_data) == 0:
+            return None
+        vt = torch.as_tensor(np.asarray(vertices), dtype=torch.int64).to(graph.device)
+        labels = _to_numpy(ops.gather_i64(graph.ndata["target"], vt))
+        pred = output_data.argmax(axis=1)
+        C = output_data.shape[1]
+        cm = np.zeros((C, C), dtype=np.int64)
+        ok = (labels >= 0) & (labels < C)
+        np.add.at(cm, (labels[ok], pred[ok]), 1)
+        return cm, len(pred)
 
     def _run_custom_eval(self, graph, subgraph_to_id, id_to_subgraph, test_vertices):
         raise NotImplementedError
@@ -146,6 +172,24 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
                 outs.append(logits)
         # one device->host transfer for the pass instead of one per batch
         return [o.cpu().numpy() for o in outs]
+
+    def _eval_confusion(self, graph, subgraph_to_id, id_to_subgraph, vertices):
+        """Device path: argmax + C x C confusion counters are accumulated on the GPU; only C*C int64 cross PCIe."""
+        self.graphsage_model.eval()
+        seeds_all = torch.as_tensor(np.asarray(vertices), dtype=torch.int64)
+        if seeds_all.numel() == 0:
+            return None
+        cm = None
+        n = 0
+        with torch.no_grad():
+            for seeds, logits in self._inference_batches(graph, seeds_all):
+                if cm is None:
+                    C_ = logits.shape[1]
+                    cm = torch.zeros(C_ * C_, dtype=torch.int64, device=logits.device)
+                ops.argmax_confusion(logits, ops.gather_i64(graph.ndata["target"], seeds), cm, want_pred=False)
+                n += seeds.numel()
+        C_ = int(round(cm.numel() ** 0.5))
+        return cm.cpu().numpy().reshape(C_, C_), n
 
     def get_model(self):
         return "base_model"

@@ -292,6 +292,21 @@ def ce_fwd_bwd(logits, labels, grad_scale=1.0, want_grad=True):
     return loss, dl
 
 
+def argmax_confusion(logits, labels=None, confusion=None, want_pred=True):
+    """pred = argmax over classes; ``confusion`` (int64 [C, C], accumulated in place) counts (true, pred) pairs."""
+    logits = as_mat(logits)
+    B, Cc = logits.shape
+    pred = torch.empty(B, dtype=torch.int64, device=logits.device) if want_pred else None
+    if labels is not None:
+        labels = labels.reshape(-1)
+        assert labels.dtype == torch.int64 and labels.is_cuda and labels.is_contiguous() and labels.numel() == B
+    if confusion is not None:
+        assert confusion.dtype == torch.int64 and confusion.is_cuda and confusion.is_contiguous() and confusion.numel() == Cc * Cc
+    _launch("ogl_argmax_confusion", _lib.lib().ogl_argmax_confusion, _ptr(logits), _ld(logits), _ptr(labels), B, Cc, _ptr(pred),
+            _ptr(confusion), _stream(), meta=dict(B=B, C=Cc))
+    return pred
+
+
 def adam_step(p, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
     for t in (p, g, m, v):
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()

@@ -34,39 +34,27 @@ def shard_seeds(seeds, rank=None, world=None):
 
 
 class GradSynchronizer:
-    """All-reduce(mean) of every parameter gradient through ONE flat bucket."""
+    """All-reduce(mean) of every parameter gradient through ONE flat bucket: one concatenation, one scale, one
+    collective per step; afterwards each ``p.grad`` is a view of the reduced bucket (no copy back)."""
 
     def __init__(self, params, group=None):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        n = sum(p.numel() for p in self.params)
-        ref = self.params[0]
-        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
 
     def sync(self, weight=None):
         """grads <- sum_r w_r * grad_r (w_r = 1/world by default; pass n_local/n_global for ragged shards)."""
         if self.world == 1:
             return
-        off = 0
         w = (1.0 / self.world) if weight is None else float(weight)
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
-        self.flat.mul_(w)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        pieces = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
+        flat = torch.cat(pieces)
+        flat.mul_(w)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         off = 0
         for p in self.params:
             n = p.numel()
-            g = self.flat[off:off + n].view_as(p)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
+            p.grad = flat[off:off + n].view_as(p)
             off += n
 
 

@@ -374,4 +374,4 @@ class CpuModel:
         loss = cross_entropy(logits, y, "mean")
         loss.backward()
         self.opt.step()
-        return float(loss)
+        return float(loss.detach())

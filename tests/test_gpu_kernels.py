@@ -322,3 +322,20 @@ def test_x6_split_is_exact_and_accurate(ops):
     e6 = ((outs["bf16x6"] - ref).abs() / scale).max().item()
     assert e32 < 1e-6 and e6 < 1e-6, (e32, e6)                     # fp32 chain: ~K * 2^-24 worst case, typically 1e-7
     assert e6 < 4 * max(e32, 6e-8), (e32, e6)
+
+
+@pytest.mark.parametrize("B,C", [(1, 3), (513, 41), (1000, 200), (64, 64)])
+def test_argmax_confusion(ops, B, C):
+    rng = np.random.default_rng(B + C)
+    logits = rng.standard_normal((B, C)).astype(np.float32)
+    logits[::7, :] = np.round(logits[::7, :])                     # ties: the first maximum wins, like numpy
+    labels = rng.integers(0, C, B).astype(np.int64)
+    cm = torch.zeros(C * C, dtype=torch.int64).cuda()
+    lt = ops.empty_mat(B, C, "cuda").copy_(torch.as_tensor(logits))
+    pred = ops.argmax_confusion(lt, dev(labels), cm)
+    want = logits.argmax(axis=1)
+    assert np.array_equal(pred.cpu().numpy(), want)
+    ref = np.zeros((C, C), dtype=np.int64); np.add.at(ref, (labels, want), 1)
+    assert np.array_equal(cm.cpu().numpy().reshape(C, C), ref)
+    ops.argmax_confusion(lt, dev(labels), cm, want_pred=False)       # accumulates
+    assert np.array_equal(cm.cpu().numpy().reshape(C, C), 2 * ref)

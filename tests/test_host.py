@@ -189,3 +189,19 @@ def test_dataset_file_parsers(tmp_path):
         cu._need(str(tmp_path), ["graph.adjlist", "targets.npy"])
     from ogl_amd.dataset_utils import pubmed, arxiv, reddit
     assert pubmed.FILES[3] == "postponed_timestamp.json" and arxiv.FILES[0] == "feats.npy" and "edges_dataframe.csv" in reddit.FILES
+
+
+def test_macro_f1_from_confusion_matches_sklearn():
+    """CSV row contents of R/train/graphsage/model.py:84-91 from a full C x C count matrix."""
+    from sklearn.metrics import confusion_matrix, f1_score
+    from ogl_amd.graphsage.model import macro_f1_from_confusion
+    rng = np.random.default_rng(0)
+    for C in (3, 7, 41):
+        y = rng.integers(0, C, 500); p = rng.integers(0, max(1, C - 2), 500)
+        if C > 3:
+            y[y == 1] = 0; p[p == 1] = 0                       # a class that never occurs is dropped, as sklearn does
+        cm = np.zeros((C, C), dtype=np.int64); np.add.at(cm, (y, p), 1)
+        f1, flat = macro_f1_from_confusion(cm)
+        assert abs(f1 - f1_score(y, p, average="macro")) < 1e-12
+        assert flat == [int(v) for row in confusion_matrix(y, p) for v in row]
+    assert macro_f1_from_confusion(np.zeros((4, 4)))[0] == 0.0
