@@ -1,2 +1,2 @@
 from .replay_buffer import PrioritizedReplayBuffer, SumTree  # noqa: F401
-from .generate_priority import GeneratePriority, LossPriority, TrendPriority, HybridPriority  # noqa: F401
+from .priorities import GeneratePriority, LossPriority, TrendPriority, HybridPriority  # noqa: F401
