@@ -40,6 +40,7 @@ class TrainTestGraph:
         self.train_set, self.test_set = set(), set()
         self.train_set_list, self.test_set_list = [], []
         self.train, self.test = [], []                   # the arrivals of the latest snapshot only
+        self.exact_shuffle = False                       # see _shuffle_prefix
         self.priority_replay_buffer = self._fresh_buffer()
         self._admit(_labelled(*graph.get_added_vertices()))
 
@@ -107,8 +108,19 @@ class TrainTestGraph:
         return fresh
 
     def _shuffle_prefix(self, n_nodes):
-        random.shuffle(self.train_set_list)
-        return self.train_set_list[:n_nodes]
+        """Uniform random ``n_nodes``-subset of the train set in random order.  The reference shuffles the WHOLE list
+        and slices (``random.shuffle`` of 2e5 ids, 100 times per Reddit snapshot: ~0.1 s each); a partial Fisher-Yates
+        pass over the first ``n_nodes`` positions yields the same distribution in O(n_nodes).  ``exact_shuffle=True``
+        restores the reference's RNG consumption (identical draws under the same ``random.seed``)."""
+        lst = self.train_set_list
+        if self.exact_shuffle:
+            random.shuffle(lst)
+            return lst[:n_nodes]
+        total = len(lst)
+        for i in range(n_nodes):
+            j = random.randrange(i, total)
+            lst[i], lst[j] = lst[j], lst[i]
+        return lst[:n_nodes]
 
     def draw_random_train_nodes(self, n_nodes):
         return self._shuffle_prefix(n_nodes) if n_nodes <= len(self.train_set_list) else self.train_set_list

@@ -259,8 +259,8 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
         loader = sampling.NodeDataLoader(graph, train_vertices, self._sampler(),
                                          batch_size=len(train_vertices) // self.batch_per_timestep,
                                          shuffle=False, drop_last=False, num_workers=self.n_workers)
+        pending = []
         for input_nodes, seeds, blocks in loader:
-            batch_nodes_seed = subgraph_to_id[_to_numpy(seeds)]
             batch_inputs = self._inputs(graph, input_nodes)
             batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
             self.optimizer.zero_grad()
@@ -269,8 +269,20 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
             loss = torch.mean(unaggregated_loss)
             loss.backward()
             self.optimizer.step()
-            priorities = self.priority_strategy.get_priorities(batch_nodes_seed, _to_numpy(unaggregated_loss))
-            graph_util.update_priorities(dict(zip(np.asarray(batch_nodes_seed).tolist(), np.asarray(priorities).tolist())))
+            pending.append((seeds, unaggregated_loss.detach()))
+        # The reference copies every batch's losses to the host right away (a device sync per batch).  Nothing reads the
+        # buffer while the snapshot's batches train (they were drawn beforehand), so the per-batch updates are applied in
+        # the same order after ONE transfer: identical buffer contents, no pipeline drain between batches.
+        if pending:
+            sizes = [sd.numel() for sd, _ in pending]
+            all_seeds = torch.cat([sd for sd, _ in pending]).cpu().numpy()
+            all_loss = torch.cat([ls for _, ls in pending]).cpu().numpy()
+            off = 0
+            for n in sizes:
+                batch_nodes_seed = subgraph_to_id[all_seeds[off:off + n]]
+                priorities = self.priority_strategy.get_priorities(batch_nodes_seed, all_loss[off:off + n])
+                graph_util.update_priorities(dict(zip(np.asarray(batch_nodes_seed).tolist(), np.asarray(priorities).tolist())))
+                off += n
         self.time_step += 1
 
     def recompute_priorities(self, graph_util, train_set):

@@ -145,6 +145,17 @@ def test_train_test_graph_behaviour():
     g.evolve()
     assert len(g.get_train_set()) == 16 and g.prior_alpha == pytest.approx(4 + (46 / 6) * 1)
     assert len(g.get_new_train_nodes()) == 8 and len(g.get_new_train_nodes(3)) == 3
+    # partial Fisher-Yates == full shuffle in distribution; exact_shuffle reproduces the reference's draws bit for bit
+    g.exact_shuffle = True
+    random.seed(5); ref_list = list(g.train_set_list); random.shuffle(ref_list)
+    random.seed(5); assert g.draw_random_train_nodes(4) == ref_list[:4]
+    g.exact_shuffle = False
+    counts = {}
+    random.seed(6)
+    for _ in range(4000):
+        for v in g.draw_random_train_nodes(3):
+            counts[v] = counts.get(v, 0) + 1
+    assert set(counts) == set(g.get_train_set()) and max(counts.values()) < 1.25 * min(counts.values())
     # uniform shuffle prefix whenever n <= |train| (reference quirk kept), buffer sampling otherwise
     draw = g.draw_priority_train_nodes(5)
     assert len(draw) == 5 and set(draw) <= set(g.get_train_set())
