@@ -135,8 +135,9 @@ int ogl_reduce_bwd(const float* dout, int64_t ldo, const int32_t* idx32, const i
  *         x [*,K] (ldx), w [N,K] (ldw); the optional second pair gives fc_self(h)+fc_neigh(n) and
  *         concat->Linear in one pass; x_rows/x2_rows (nullable int64[M]) gather rows on the fly
  *         from a table of x_nrows rows (out-of-range rows read as zeros).
- *   bwd_input:  dx[M,K] = (dy (.) [ymask>0]) . w           (ymask nullable = the relu output)
- *   bwd_weight: dw[N,K] = (dy (.) [ymask>0])^T . x[rows?], db[N] = column sums (nullable);
+ *   relu_bwd:   out = dy (.) [y > 0]   — the mask of a fused-ReLU projection, applied once before its backward GEMMs
+ *   bwd_input:  dx[M,K] = dy . w
+ *   bwd_weight: dw[N,K] = dy^T . x[rows?], db[N] = column sums of dy (nullable);
  *         deterministic split over M through `workspace` (no atomics).
  * ---------------------------------------------------------------------------------------- */
 int ogl_linear_fwd(const float* x, int64_t ldx, const int64_t* x_rows, int64_t x_nrows,
@@ -144,11 +145,12 @@ int ogl_linear_fwd(const float* x, int64_t ldx, const int64_t* x_rows, int64_t x
                    const float* x2, int64_t ldx2, const int64_t* x2_rows, int64_t x2_nrows, int K2,
                    const float* w2, int64_t ldw2,
                    int relu, float* y, int64_t ldy, ogl_stream_t stream);
-int ogl_linear_bwd_input(const float* dy, int64_t ldy, const float* ymask, int64_t ldm,
-                         int64_t M, int N, const float* w, int64_t ldw, int K,
-                         float* dx, int64_t lddx, ogl_stream_t stream);
+int ogl_relu_bwd(const float* dy, int64_t ldy, const float* y, int64_t ldyy, int64_t M, int N,
+                 float* out, int64_t ldo, ogl_stream_t stream);
+int ogl_linear_bwd_input(const float* dy, int64_t ldy, int64_t M, int N, const float* w, int64_t ldw,
+                         int K, float* dx, int64_t lddx, ogl_stream_t stream);
 int64_t ogl_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K);
-int ogl_linear_bwd_weight(const float* dy, int64_t ldy, const float* ymask, int64_t ldm,
+int ogl_linear_bwd_weight(const float* dy, int64_t ldy,
                           const float* x, int64_t ldx, const int64_t* x_rows, int64_t x_nrows,
                           int64_t M, int N, int K, float* dw, int64_t lddw, float* db,
                           void* workspace, int64_t workspace_bytes, ogl_stream_t stream);

@@ -9,7 +9,8 @@
 //   NC ("non-reduction-contiguous"): X(p,r) = ptr[row(r)*ld + p]
 // which covers forward (x RC, w RC), input-gradient (dy RC, w NC) and weight-gradient (dy NC, x NC)
 // without materialising a transpose.  `row()` is an optional int64 gather (feature rows are read
-// straight from the resident table), `mask` an optional ReLU mask (dy (.) [y>0]) applied on load.
+// straight from the resident table), the ReLU mask of a
+// backward pass is applied by ogl_relu_bwd before the GEMM (nothing in the loaders consumes a loaded value).
 // Tiles are staged k-major in LDS (Xs[r][p], row stride P+4) so each MFMA operand is one
 // conflict-free ds_read_b32; global loads are 16 B/lane when the operand is 16-B aligned.
 // Block -> tile mapping is XCD-aware and bijective (see k_gemm): consecutive logical tiles, which share
@@ -50,9 +51,6 @@ struct Operand {
   int64_t ld;
   const int64_t* rows;  // optional gather on the major (row) index
   int64_t nrows;        // bound for gathered rows (rows outside -> zeros)
-  const float* mask;    // optional: value kept only where mask > 0 (same layout/ld as ptr, no gather)
-  int64_t ldm;
-  int vec;              // 16-B loads allowed
 };
 
 struct GemmPart {
@@ -93,13 +91,12 @@ template <int P, bool RC>
 struct TileLoader {
   static constexpr int NV = P / 64;  // float4 per thread
   const float* ptr[NV];   // RC: row base + this thread's k offset.  NC: unused
-  const float* mptr[NV];
   bool ok[NV];
   int pcol;               // NC: first of this thread's 4 columns
-  int pmode;              // NC: 0 none, 1 one 16-B load (+ per-component select), 2 guarded dword loads (tight rows)
+  int pmode;              // NC: 0 none, 1 one 16-B load (fixed up later), 2 guarded dword loads (tight rows)
   int keep;               // NC: how many of the 4 columns exist in memory
   int onesq;              // NC: component holding the synthetic ones column, or -1
-  int nrow[NV];           // NC + gather: row id of the NEXT k-tile (fetched one tile ahead: no dependent-load stall)
+  int nrow[NV];           // NC + gather: row id of the NEXT k-tile (fetched one tile ahead)
 
   __device__ __forceinline__ void init(const Operand& op, int64_t p0, int64_t Plim, int64_t ones_p, int tid,
                                        int64_t r_first, int64_t R) {
@@ -116,7 +113,6 @@ struct TileLoader {
         if (!v) row = 0;
         ok[h] = v;
         ptr[h] = op.ptr + row * op.ld + (tid & 3) * 4;
-        mptr[h] = op.mask ? op.mask + (v ? p : 0) * op.ldm + (tid & 3) * 4 : nullptr;
       }
     } else {
       pcol = (int)(p0 + (tid % (P / 4)) * 4);
@@ -124,8 +120,8 @@ struct TileLoader {
       const int64_t left = psrc - pcol;
       keep = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
       onesq = (ones_p >= pcol && ones_p < pcol + 4) ? (int)(ones_p - pcol) : -1;
-      // a partial group is still one 16-B load when the row stride leaves room for it (padded matrices): the
-      // pad is read and discarded by a select, so no lane diverges inside the k-loop
+      // a partial group is still one 16-B load when the row stride leaves room for it (padded matrices): the pad
+      // is read and discarded at fix-up time, so no lane diverges inside the k-loop
       const bool vec_ok = keep == 4 || (keep > 0 && op.ld >= pcol + 4) || (keep == 0 && onesq >= 0);
       pmode = pcol >= Plim ? 0 : (vec_ok ? 1 : 2);
 #pragma unroll
@@ -136,79 +132,81 @@ struct TileLoader {
     }
   }
 
+  // RAW loads.  On the hot paths (RC interior tile, NC 16-B group) NOTHING here consumes a loaded value — no select,
+  // no compare — so the compiler's s_waitcnt lands in fix(), after the MFMAs of the tile being multiplied, and the
+  // loads of a wave overlap its own matrix work.  Lanes that must not contribute read a safe address (row 0) and are
+  // zeroed in fix().  `bad` collects gathered rows that were out of range (bit h).
   __device__ __forceinline__ void load(const Operand& op, int64_t Plim, int64_t r0, int64_t R, int64_t ones_p, int tid,
-                                       float4 (&reg)[NV]) {
+                                       float4 (&reg)[NV], unsigned& bad) {
+    bad = 0;
     if (RC) {
       const bool interior = r0 + GEMM_BK <= R;  // block-uniform
 #pragma unroll
       for (int h = 0; h < NV; ++h) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!ok[h]) bad |= 1u << h;             // validity travels with the staging set (the loader may have moved on
+                                                // to the second part of a dual GEMM by the time this tile is fixed up)
         if (interior) {
-          v = ld16(ptr[h] + r0);
-          if (mptr[h]) {
-            float4 m = ld16(mptr[h] + r0);
-            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
-            v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
-          }
-          if (!ok[h]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        } else if (ok[h]) {
+          reg[h] = ld16(ptr[h] + r0);
+        } else {                                // last, partial k-tile of the part: guarded dwords (once per block)
           const int64_t r = r0 + (tid & 3) * 4;
           float e[4] = {0.f, 0.f, 0.f, 0.f};
+          if (ok[h]) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (r + q < R) {
-              float x = ptr[h][r0 + q];
-              if (mptr[h] && !(mptr[h][r0 + q] > 0.f)) x = 0.f;
-              e[q] = x;
-            }
-          v = make_float4(e[0], e[1], e[2], e[3]);
+            for (int q = 0; q < 4; ++q)
+              if (r + q < R) e[q] = ptr[h][r0 + q];
+          }
+          reg[h] = make_float4(e[0], e[1], e[2], e[3]);
         }
-        reg[h] = v;
       }
     } else {
 #pragma unroll
       for (int h = 0; h < NV; ++h) {
         const int64_t r = r0 + (tid / (P / 4)) * NV + h;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        bool valid = r < R && pmode != 0;
-        int64_t row = valid ? r : 0;
+        const bool rv = r < R;
+        int64_t row = rv ? r : 0;
         if (op.rows) {
           row = nrow[h];                                       // fetched while the previous tile was computed
           nrow[h] = (r + GEMM_BK < R) ? (int)op.rows[r + GEMM_BK] : 0;
-          if (!valid || row < 0 || row >= op.nrows) { valid = false; row = 0; }
+          if (!rv || row < 0 || row >= op.nrows) { if (rv) bad |= 1u << h; row = 0; }
         }
-        if (pmode == 1) {
-          if (keep > 0) {
-            v = ld16(op.ptr + (int64_t)((uint64_t)(uint32_t)row * (uint32_t)op.ld) + pcol);
-            if (op.mask) {
-              float4 m = ld16(op.mask + (valid ? r : 0) * op.ldm + pcol);
-              v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
-              v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
-            }
-          }
-          if (keep < 4) {
-            v.w = 0.f;
-            if (keep < 3) v.z = 0.f;
-            if (keep < 2) v.y = 0.f;
-            if (keep < 1) v.x = 0.f;
-          }
-          if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (onesq >= 0 && r < R) {
-            if (onesq == 0) v.x = 1.f; else if (onesq == 1) v.y = 1.f; else if (onesq == 2) v.z = 1.f; else v.w = 1.f;
-          }
-        } else if (pmode == 2 && r < R) {
+        if (pmode == 1 && keep > 0) {
+          reg[h] = ld16(op.ptr + (int64_t)((uint64_t)(uint32_t)row * (uint32_t)op.ld) + pcol);
+        } else if (pmode == 2 && rv && !((bad >> h) & 1)) {    // tight rows (ld < pcol + 4): guarded dwords
           const int64_t psrc = ones_p >= 0 ? ones_p : Plim;
           float e[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (valid && pcol + q < psrc) {
-              float x = op.ptr[row * op.ld + pcol + q];
-              if (op.mask && !(op.mask[r * op.ldm + pcol + q] > 0.f)) x = 0.f;
-              e[q] = x;
-            }
-            if (pcol + q == ones_p) e[q] = 1.f;
-          }
-          v = make_float4(e[0], e[1], e[2], e[3]);
+          for (int q = 0; q < 4; ++q)
+            if (pcol + q < psrc) e[q] = op.ptr[row * op.ld + pcol + q];
+          reg[h] = make_float4(e[0], e[1], e[2], e[3]);
+        } else {
+          reg[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
+  }
+
+  // Fix-ups of a loaded tile, applied right before it is written to LDS: zero the lanes that must not contribute,
+  // drop pad columns, plant the synthetic ones column.  Pure selects.
+  __device__ __forceinline__ void fix(float4 (&reg)[NV], int64_t r0, int64_t R, int tid, unsigned bad) const {
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (RC) {
+#pragma unroll
+      for (int h = 0; h < NV; ++h)
+        if ((bad >> h) & 1) reg[h] = zero;
+    } else {
+#pragma unroll
+      for (int h = 0; h < NV; ++h) {
+        const int64_t r = r0 + (tid / (P / 4)) * NV + h;
+        float4 v = reg[h];
+        if (keep < 4) {
+          v.w = 0.f;
+          if (keep < 3) v.z = 0.f;
+          if (keep < 2) v.y = 0.f;
+          if (keep < 1) v.x = 0.f;
+        }
+        if (!(r < R) || pmode == 0 || ((bad >> h) & 1)) v = zero;
+        if (onesq >= 0 && r < R && pmode != 0) {
+          if (onesq == 0) v.x = 1.f; else if (onesq == 1) v.y = 1.f; else if (onesq == 2) v.z = 1.f; else v.w = 1.f;
         }
         reg[h] = v;
       }
@@ -320,11 +318,12 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
   TileLoader<BM, A_RC> la;
   TileLoader<BN, B_RC> lb;
   float4 ra0[BM / 64], rb0[BN / 64], ra1[BM / 64], rb1[BN / 64];   // two register staging sets (2-tile-deep prefetch)
+  unsigned ma0 = 0, mb0 = 0, ma1 = 0, mb1 = 0;                      // per-set "gathered row out of range" bits
   const int64_t ones_p = g.ones_col ? g.N - 1 : -1;
   int cur_part = -1;
 
   // tiles at or beyond kt_end (the pipeline below always runs an even number of tiles) load as zeros
-  auto issue = [&](int kt, float4 (&ra)[BM / 64], float4 (&rb)[BN / 64]) {
+  auto issue = [&](int kt, float4 (&ra)[BM / 64], float4 (&rb)[BN / 64], unsigned& ma, unsigned& mb) {
     const bool live = kt < kt_end;
     const int pi = (live && kt >= nk[0]) ? 1 : 0;
     const GemmPart& pt = g.part[pi];
@@ -335,11 +334,20 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
       lb.init(pt.b, j0, g.N, ones_p, tid, r0, Reff);
       cur_part = pi;
     }
-    la.load(pt.a, g.M, r0, Reff, -1, tid, ra);
-    lb.load(pt.b, g.N, r0, Reff, ones_p, tid, rb);
+    la.load(pt.a, g.M, r0, Reff, -1, tid, ra, ma);
+    lb.load(pt.b, g.N, r0, Reff, ones_p, tid, rb, mb);
   };
 
-  auto stage = [&](int buf, const float4 (&ra)[BM / 64], const float4 (&rb)[BN / 64]) {
+  // the tile in a staging set is fixed up (this is where its loads are first waited for) and written to LDS
+  auto stage = [&](int buf, int kt, float4 (&ra)[BM / 64], float4 (&rb)[BN / 64], unsigned ma, unsigned mb) {
+    {
+      const bool live = kt < kt_end;
+      const int pi = (live && kt >= nk[0]) ? 1 : 0;
+      const int64_t r0 = live ? (int64_t)(pi == 0 ? kt : kt - nk[0]) * GEMM_BK : 0;
+      const int64_t Reff = live ? g.part[pi].R : 0;
+      la.fix(ra, r0, Reff, tid, ma);
+      lb.fix(rb, r0, Reff, tid, mb);
+    }
     if (X6) {
       if (A_RC) la.store_x6(Ax[buf], tid, ra); else la.store_x6k(Ak[buf], tid, ra);
       if (B_RC) lb.store_x6(Bx[buf], tid, rb); else lb.store_x6k(Bk[buf], tid, rb);
@@ -414,17 +422,17 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
   // Pipeline: while tile t is multiplied out of LDS buffer t&1, tile t+1 sits in one register set (written to the
   // other LDS buffer after the MFMAs) and tile t+2 is in flight into the other set: global latency is covered by
   // two tiles of MFMA work.  The loop is unrolled by two so both sets are statically indexed (no scratch).
-  issue(kt_begin, ra0, rb0);
-  stage(0, ra0, rb0);
-  issue(kt_begin + 1, ra1, rb1);
+  issue(kt_begin, ra0, rb0, ma0, mb0);
+  stage(0, kt_begin, ra0, rb0, ma0, mb0);
+  issue(kt_begin + 1, ra1, rb1, ma1, mb1);
   __syncthreads();
 
   // one pipeline step: multiply tile t out of LDS buffer `buf` while tile t+1 (already in registers) is converted
   // and written to the other buffer.  In x6 mode the split/pack VALU work and the LDS writes are interleaved with the
   // 24 MFMAs (one MFMA : ~4 VALU : DS write every other MFMA) so the matrix pipe is not left idle behind them.
-  auto step = [&](int buf, const float4 (&ra)[BM / 64], const float4 (&rb)[BN / 64]) {
+  auto step = [&](int buf, int kt_next, float4 (&ra)[BM / 64], float4 (&rb)[BN / 64], unsigned ma, unsigned mb) {
     compute(buf);
-    stage(buf ^ 1, ra, rb);
+    stage(buf ^ 1, kt_next, ra, rb, ma, mb);
     if (X6) {
       __builtin_amdgcn_sched_group_barrier(0x100, (A_RC ? 1 : 2) * TM * 3 + (B_RC ? 1 : 2) * TN * 3, 0);   // fragment ds_reads first
 #pragma unroll
@@ -438,11 +446,11 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
 
   // the loop body is branch-free: an odd tile count is padded with one all-zero tile (see issue())
   for (int kt = kt_begin; kt < kt_end; kt += 2) {
-    issue(kt + 2, ra0, rb0);
-    step(0, ra1, rb1);                     // tile kt out of buffer 0, tile kt+1 -> buffer 1
+    issue(kt + 2, ra0, rb0, ma0, mb0);
+    step(0, kt + 1, ra1, rb1, ma1, mb1);   // tile kt out of buffer 0, tile kt+1 -> buffer 1
     __syncthreads();
-    issue(kt + 3, ra1, rb1);
-    step(1, ra0, rb0);                     // tile kt+1 out of buffer 1, tile kt+2 -> buffer 0
+    issue(kt + 3, ra1, rb1, ma1, mb1);
+    step(1, kt + 2, ra0, rb0, ma0, mb0);   // tile kt+1 out of buffer 1, tile kt+2 -> buffer 0
     __syncthreads();
   }
 
@@ -581,11 +589,6 @@ extern "C" int ogl_set_gemm_mode(int mode) {
 }
 extern "C" int ogl_get_gemm_mode(void) { return g_gemm_mode; }
 
-static inline int operand_vec(const float* p, int64_t ld, const float* mask, int64_t ldm) {
-  (void)p; (void)ld; (void)mask; (void)ldm;
-  return 1;  // unaligned-access mode: 16-B loads are legal at any 4-B aligned address (see ld16)
-}
-
 // 0: 128x128 (2x2 waves of 64x64)   1: 256x64 (narrow N)   2: 64x64 (few tiles: fill the chip / cut the tail)
 static inline int gemm_config(int64_t M, int64_t N, int nsplit, int* BM, int* BN) {
   if (N <= 64) { *BM = 256; *BN = 64; return 1; }
@@ -659,6 +662,27 @@ static int launch_gemm(GemmArgs& g, hipStream_t stream) {
 
 static inline void zero_args(GemmArgs& g) { g = GemmArgs(); g.nsplit = 1; }
 
+// dy (.) [y > 0]: the backward of a fused-ReLU projection, applied once before its two backward GEMMs
+__global__ void __launch_bounds__(256) k_relu_bwd(const float* __restrict__ dy, int64_t ldy, const float* __restrict__ y,
+                                                  int64_t ldyy, int64_t M, int N, float* __restrict__ out, int64_t ldo) {
+  const int64_t total = M * N;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / N, c = t - r * N;
+    out[r * ldo + c] = y[r * ldyy + c] > 0.f ? dy[r * ldy + c] : 0.f;
+  }
+}
+
+extern "C" int ogl_relu_bwd(const float* dy, int64_t ldy, const float* y, int64_t ldyy, int64_t M, int N, float* out,
+                            int64_t ldo, ogl_stream_t stream) {
+  if (M < 0 || N < 0 || ldy < N || ldyy < N || ldo < N) return OGL_EINVAL;
+  if (M == 0 || N == 0) return OGL_OK;
+  if (!dy || !y || !out) return OGL_EINVAL;
+  hipLaunchKernelGGL(k_relu_bwd, dim3((unsigned)min((int64_t)4096, ogl_cdiv(M * N, 256))), dim3(256), 0, (hipStream_t)stream, dy,
+                     ldy, y, ldyy, M, N, out, ldo);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
 extern "C" int ogl_linear_fwd(const float* x, int64_t ldx, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
                               const float* w, int64_t ldw, int N, const float* bias,
                               const float* x2, int64_t ldx2, const int64_t* x2_rows, int64_t x2_nrows, int K2,
@@ -668,13 +692,13 @@ extern "C" int ogl_linear_fwd(const float* x, int64_t ldx, const int64_t* x_rows
   if (M == 0 || N == 0) return OGL_OK;
   if (!y || (K > 0 && (!x || !w)) || (K2 > 0 && (!x2 || !w2 || ldx2 < K2 || ldw2 < K2))) return OGL_EINVAL;
   GemmArgs g; zero_args(g);
-  g.part[0].a = Operand{x, ldx, x_rows, x_nrows, nullptr, 0, operand_vec(x, ldx, nullptr, 0)};
-  g.part[0].b = Operand{w, ldw, nullptr, 0, nullptr, 0, operand_vec(w, ldw, nullptr, 0)};
+  g.part[0].a = Operand{x, ldx, x_rows, x_nrows};
+  g.part[0].b = Operand{w, ldw, nullptr, 0};
   g.part[0].R = K;
   g.nparts = 1;
   if (K2 > 0) {
-    g.part[1].a = Operand{x2, ldx2, x2_rows, x2_nrows, nullptr, 0, operand_vec(x2, ldx2, nullptr, 0)};
-    g.part[1].b = Operand{w2, ldw2, nullptr, 0, nullptr, 0, operand_vec(w2, ldw2, nullptr, 0)};
+    g.part[1].a = Operand{x2, ldx2, x2_rows, x2_nrows};
+    g.part[1].b = Operand{w2, ldw2, nullptr, 0};
     g.part[1].R = K2;
     g.nparts = 2;
   }
@@ -691,16 +715,16 @@ extern "C" int ogl_linear_fwd(const float* x, int64_t ldx, const int64_t* x_rows
   return launch_gemm<true, true>(g, (hipStream_t)stream);
 }
 
-extern "C" int ogl_linear_bwd_input(const float* dy, int64_t ldy, const float* ymask, int64_t ldm, int64_t M,
+extern "C" int ogl_linear_bwd_input(const float* dy, int64_t ldy, int64_t M,
                                     int N, const float* w, int64_t ldw, int K, float* dx, int64_t lddx,
                                     ogl_stream_t stream) {
-  if (M < 0 || N < 0 || K < 0 || ldy < N || ldw < K || lddx < K || (ymask && ldm < N)) return OGL_EINVAL;
+  if (M < 0 || N < 0 || K < 0 || ldy < N || ldw < K || lddx < K) return OGL_EINVAL;
   if (M == 0 || K == 0) return OGL_OK;
   if (!dx || (N > 0 && (!dy || !w))) return OGL_EINVAL;
   GemmArgs g; zero_args(g);
-  // dx[m,k] = sum_n dy[m,n] w[n,k] : A = dy (RC over n, mask), B = w (NC: B(r=n, j=k) = w[n*ldw + k])
-  g.part[0].a = Operand{dy, ldy, nullptr, 0, ymask, ldm, operand_vec(dy, ldy, ymask, ldm)};
-  g.part[0].b = Operand{w, ldw, nullptr, 0, nullptr, 0, operand_vec(w, ldw, nullptr, 0)};
+  // dx[m,k] = sum_n dy[m,n] w[n,k] : A = dy (RC over n), B = w (NC: B(r=n, j=k) = w[n*ldw + k])
+  g.part[0].a = Operand{dy, ldy, nullptr, 0};
+  g.part[0].b = Operand{w, ldw, nullptr, 0};
   g.part[0].R = N;
   g.nparts = 1;
   g.M = M; g.N = K; g.C = dx; g.ldc = lddx;
@@ -734,18 +758,18 @@ extern "C" int64_t ogl_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K
   return (int64_t)nsplit * N * ogl_round_up(K + 1, 4) * 4;
 }
 
-extern "C" int ogl_linear_bwd_weight(const float* dy, int64_t ldy, const float* ymask, int64_t ldm,
+extern "C" int ogl_linear_bwd_weight(const float* dy, int64_t ldy,
                                      const float* x, int64_t ldx, const int64_t* x_rows, int64_t x_nrows,
                                      int64_t M, int N, int K, float* dw, int64_t lddw, float* db,
                                      void* workspace, int64_t workspace_bytes, ogl_stream_t stream) {
-  if (M < 0 || N < 0 || K < 0 || ldy < N || ldx < K || lddw < K || (ymask && ldm < N)) return OGL_EINVAL;
+  if (M < 0 || N < 0 || K < 0 || ldy < N || ldx < K || lddw < K) return OGL_EINVAL;
   if (N == 0) return OGL_OK;
   if (!dw || (M > 0 && (!dy || (K > 0 && !x)))) return OGL_EINVAL;
   GemmArgs g; zero_args(g);
-  // [dw | db][n, k] = sum_m dy[m,n] * [x | 1][m,k]: A = dy (NC: A(i=n, r=m) = dy[m*ldy + n], mask),
+  // [dw | db][n, k] = sum_m dy[m,n] * [x | 1][m,k]: A = dy (NC: A(i=n, r=m) = dy[m*ldy + n]),
   // B = x (NC: B(r=m, j=k) = x[row(m)*ldx + k]) with a synthetic ones column at j = K.
-  g.part[0].a = Operand{dy, ldy, nullptr, 0, ymask, ldm, operand_vec(dy, ldy, ymask, ldm)};
-  g.part[0].b = Operand{x, ldx, x_rows, x_nrows, nullptr, 0, operand_vec(x, ldx, nullptr, 0)};
+  g.part[0].a = Operand{dy, ldy, nullptr, 0};
+  g.part[0].b = Operand{x, ldx, x_rows, x_nrows};
   g.part[0].R = M;
   g.nparts = 1;
   g.M = N; g.N = K + 1; g.ones_col = 1; g.C = dw; g.ldc = lddw; g.db = db;

@@ -248,32 +248,41 @@ def linear_fwd(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_ro
     return y
 
 
+def relu_bwd(dy, y):
+    """dy (.) [y > 0] (the mask of a fused-ReLU projection; applied once, the backward GEMMs stay mask-free)."""
+    dy = as_mat(dy); y = as_mat(y)
+    M, N = dy.shape
+    out = empty_mat(M, N, dy.device)
+    _launch("ogl_relu_bwd", _lib.lib().ogl_relu_bwd, _ptr(dy), _ld(dy), _ptr(y), _ld(y), M, N, _ptr(out), _ld(out), _stream(),
+            meta=dict(M=M, N=N))
+    return out
+
+
 def linear_bwd_input(dy, w, ymask=None):
     dy = as_mat(dy); w = as_mat(w)
+    if ymask is not None:
+        dy = relu_bwd(dy, ymask)
     M, N = dy.shape
     K = w.shape[1]
-    if ymask is not None:
-        ymask = as_mat(ymask)
     dx = empty_mat(M, K, dy.device)
-    _launch("ogl_linear_bwd_input", _lib.lib().ogl_linear_bwd_input, _ptr(dy), _ld(dy), _ptr(ymask), _ld(ymask) if ymask is not None else 0,
-                                          M, N, _ptr(w), _ld(w), K, _ptr(dx), _ld(dx), _stream(), meta=dict(M=M, K=K, N=N))
+    _launch("ogl_linear_bwd_input", _lib.lib().ogl_linear_bwd_input, _ptr(dy), _ld(dy), M, N, _ptr(w), _ld(w), K, _ptr(dx), _ld(dx),
+            _stream(), meta=dict(M=M, K=K, N=N))
     return dx
 
 
 def linear_bwd_weight(dy, x, ymask=None, x_rows=None, want_bias=True, dw_out=None):
     dy = as_mat(dy); x = as_mat(x)
+    if ymask is not None:
+        dy = relu_bwd(dy, ymask)
     M, N = dy.shape
     K = x.shape[1]
-    if ymask is not None:
-        ymask = as_mat(ymask)
     dev = dy.device
     dw = dw_out if dw_out is not None else torch.empty((N, K), dtype=torch.float32, device=dev)
     db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
     nbytes = int(_lib.lib().ogl_linear_bwd_weight_workspace_bytes(M, N, K))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
-    _launch("ogl_linear_bwd_weight", _lib.lib().ogl_linear_bwd_weight, 
-        _ptr(dy), _ld(dy), _ptr(ymask), _ld(ymask) if ymask is not None else 0, _ptr(x), _ld(x), _ptr(x_rows),
-        x.shape[0], M, N, K, _ptr(dw), _ld(dw), _ptr(db), _ptr(ws), nbytes, _stream(), meta=dict(M=M, K=K, N=N))
+    _launch("ogl_linear_bwd_weight", _lib.lib().ogl_linear_bwd_weight, _ptr(dy), _ld(dy), _ptr(x), _ld(x), _ptr(x_rows), x.shape[0],
+            M, N, K, _ptr(dw), _ld(dw), _ptr(db), _ptr(ws), nbytes, _stream(), meta=dict(M=M, K=K, N=N))
     return dw, db
 
 
@@ -342,6 +351,9 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, x2, w2, y, x_rows, x2_rows = ctx.saved_tensors
         dy = as_mat(dy)
+        if y is not None:
+            dy = relu_bwd(dy, y)        # once; the (up to four) backward GEMMs below are mask-free
+            y = None
         need = ctx.needs_input_grad
         dx = dw = db = dx2 = dw2 = None
         if need[0]:

@@ -13,11 +13,16 @@ wp = torch.randn(F, F, device="cuda") / 25
 b = torch.randn(F, device="cuda")
 p0 = ops.linear_fwd(table, wp, b, relu=True, x_rows=rows0)
 dp0 = ops.empty_mat(n0, F, "cuda"); dp0.normal_()
+xm = ops.gather_rows(table, rows0)
 for _ in range(5):
     if which == "fwd":
         ops.linear_fwd(table, wp, b, relu=True, x_rows=rows0)
     elif which == "bww":
         ops.linear_bwd_weight(dp0, table, p0, rows0)
+    elif which == "bwwnm":
+        ops.linear_bwd_weight(dp0, table, None, rows0)
+    elif which == "bwwnr":
+        ops.linear_bwd_weight(dp0, xm, None, None)
     else:
         ops.linear_bwd_input(dp0, wp, p0)
 torch.cuda.synchronize()
