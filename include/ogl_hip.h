@@ -155,6 +155,17 @@ int ogl_linear_bwd_weight(const float* dy, int64_t ldy,
                           int64_t M, int N, int K, float* dw, int64_t lddw, float* db,
                           void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
 
+/* Weight gradient from TRANSPOSED operands: dw[N,K] = dyT[N,M] . xT[K,M]^T, db[N] = row sums of dyT (nullable).
+ * Same result as ogl_linear_bwd_weight; both operands are reduction-contiguous, so it runs on the forward GEMM's
+ * fast path (split-bf16 arithmetic in BF16X6 / AUTO mode).  ogl_transpose produces the operands:
+ * dst[j, i] = src[row(i), j] for i < M, j < N (rows nullable = gather from a table of nrows rows). */
+int64_t ogl_linear_bwd_weight_t_workspace_bytes(int64_t M, int N, int K);
+int ogl_linear_bwd_weight_t(const float* dyT, int64_t lddyT, const float* xT, int64_t ldxT, int64_t M, int N,
+                            int K, float* dw, int64_t lddw, float* db, void* workspace,
+                            int64_t workspace_bytes, ogl_stream_t stream);
+int ogl_transpose(const float* src, int64_t ld, const int64_t* rows, int64_t nrows, int64_t M, int N,
+                  float* dst, int64_t ldt, ogl_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * nn.CrossEntropyLoss (R/train/graphsage/pytorch/model.py:20,105,147,198,244):
  *   loss_rows[i] = logsumexp(logits[i,:]) - logits[i, labels[i]]            (reduction='none')

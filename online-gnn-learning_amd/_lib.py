@@ -42,6 +42,9 @@ SIGNATURES = {
     "ogl_linear_bwd_input": (_i, [_p, _i64, _i64, _i, _p, _i64, _i, _p, _i64, _p]),
     "ogl_linear_bwd_weight_workspace_bytes": (_i64, [_i64, _i, _i]),
     "ogl_linear_bwd_weight": (_i, [_p, _i64, _p, _i64, _p, _i64, _i64, _i, _i, _p, _i64, _p, _p, _i64, _p]),
+    "ogl_linear_bwd_weight_t_workspace_bytes": (_i64, [_i64, _i, _i]),
+    "ogl_linear_bwd_weight_t": (_i, [_p, _i64, _p, _i64, _i64, _i, _i, _p, _i64, _p, _p, _i64, _p]),
+    "ogl_transpose": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _p]),
     "ogl_ce_fwd_bwd": (_i, [_p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p]),
     "ogl_adam_step": (_i, [_p, _p, _p, _p, _i64, _i, _d, _d, _d, _d, _p]),
     "ogl_argmax_confusion": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p]),

@@ -92,6 +92,7 @@ struct TileLoader {
   static constexpr int NV = P / 64;  // float4 per thread
   const float* ptr[NV];   // RC: row base + this thread's k offset.  NC: unused
   bool ok[NV];
+  bool one[NV];           // RC: this row is the synthetic all-ones row (bias gradient of the transposed weight-gradient form)
   int pcol;               // NC: first of this thread's 4 columns
   int pmode;              // NC: 0 none, 1 one 16-B load (fixed up later), 2 guarded dword loads (tight rows)
   int keep;               // NC: how many of the 4 columns exist in memory
@@ -110,6 +111,8 @@ struct TileLoader {
           row = v ? op.rows[p] : 0;
           v = v && row >= 0 && row < op.nrows;
         }
+        one[h] = p == ones_p;
+        if (one[h]) v = false;
         if (!v) row = 0;
         ok[h] = v;
         ptr[h] = op.ptr + row * op.ld + (tid & 3) * 4;
@@ -145,6 +148,7 @@ struct TileLoader {
       for (int h = 0; h < NV; ++h) {
         if (!ok[h]) bad |= 1u << h;             // validity travels with the staging set (the loader may have moved on
                                                 // to the second part of a dual GEMM by the time this tile is fixed up)
+        if (one[h]) bad |= 1u << (8 + h);
         if (interior) {
           reg[h] = ld16(ptr[h] + r0);
         } else {                                // last, partial k-tile of the part: guarded dwords (once per block)
@@ -188,26 +192,28 @@ struct TileLoader {
   // Fix-ups of a loaded tile, applied right before it is written to LDS: zero the lanes that must not contribute,
   // drop pad columns, plant the synthetic ones column.  Pure selects.
   __device__ __forceinline__ void fix(float4 (&reg)[NV], int64_t r0, int64_t R, int tid, unsigned bad) const {
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     if (RC) {
+      const int64_t rr = r0 + (tid & 3) * 4;        // pure selects: no branch may split the MFMA / staging region
+      const float4 ones = make_float4(rr < R ? 1.f : 0.f, rr + 1 < R ? 1.f : 0.f, rr + 2 < R ? 1.f : 0.f, rr + 3 < R ? 1.f : 0.f);
 #pragma unroll
-      for (int h = 0; h < NV; ++h)
-        if ((bad >> h) & 1) reg[h] = zero;
+      for (int h = 0; h < NV; ++h) {
+        const bool z = (bad >> h) & 1, o = (bad >> (8 + h)) & 1;
+        float4 v = reg[h];
+        v.x = o ? ones.x : (z ? 0.f : v.x); v.y = o ? ones.y : (z ? 0.f : v.y);
+        v.z = o ? ones.z : (z ? 0.f : v.z); v.w = o ? ones.w : (z ? 0.f : v.w);
+        reg[h] = v;
+      }
     } else {
 #pragma unroll
       for (int h = 0; h < NV; ++h) {
         const int64_t r = r0 + (tid / (P / 4)) * NV + h;
         float4 v = reg[h];
-        if (keep < 4) {
-          v.w = 0.f;
-          if (keep < 3) v.z = 0.f;
-          if (keep < 2) v.y = 0.f;
-          if (keep < 1) v.x = 0.f;
-        }
-        if (!(r < R) || pmode == 0 || ((bad >> h) & 1)) v = zero;
-        if (onesq >= 0 && r < R && pmode != 0) {
-          if (onesq == 0) v.x = 1.f; else if (onesq == 1) v.y = 1.f; else if (onesq == 2) v.z = 1.f; else v.w = 1.f;
-        }
+        const bool dead = !(r < R) || pmode == 0 || ((bad >> h) & 1);
+        const bool oneok = r < R && pmode != 0;
+        v.x = (dead || keep < 1) ? 0.f : v.x; v.y = (dead || keep < 2) ? 0.f : v.y;
+        v.z = (dead || keep < 3) ? 0.f : v.z; v.w = (dead || keep < 4) ? 0.f : v.w;
+        v.x = (oneok && onesq == 0) ? 1.f : v.x; v.y = (oneok && onesq == 1) ? 1.f : v.y;
+        v.z = (oneok && onesq == 2) ? 1.f : v.z; v.w = (oneok && onesq == 3) ? 1.f : v.w;
         reg[h] = v;
       }
     }
@@ -301,6 +307,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
   nk[0] = (int)((g.part[0].R + GEMM_BK - 1) / GEMM_BK);
   nk[1] = g.nparts > 1 ? (int)((g.part[1].R + GEMM_BK - 1) / GEMM_BK) : 0;
   const int nk_total = nk[0] + nk[1];
+  const int64_t R_part0 = g.part[0].R, R_part1 = g.nparts > 1 ? g.part[1].R : 0;
   int kt_begin = 0, kt_end = nk_total;
   if (g.nsplit > 1) {
     kt_begin = split * g.tiles_per_split;
@@ -341,10 +348,12 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
   // the tile in a staging set is fixed up (this is where its loads are first waited for) and written to LDS
   auto stage = [&](int buf, int kt, float4 (&ra)[BM / 64], float4 (&rb)[BN / 64], unsigned ma, unsigned mb) {
     {
+      // scalar selects only (R of both parts is held in SGPRs): a dynamic g.part[pi] access would put a branch and a
+      // scalar load between the MFMAs and the staging code and split the region the scheduler interleaves
       const bool live = kt < kt_end;
-      const int pi = (live && kt >= nk[0]) ? 1 : 0;
-      const int64_t r0 = live ? (int64_t)(pi == 0 ? kt : kt - nk[0]) * GEMM_BK : 0;
-      const int64_t Reff = live ? g.part[pi].R : 0;
+      const bool second = live && kt >= nk[0];
+      const int64_t r0 = live ? (int64_t)(second ? kt - nk[0] : kt) * GEMM_BK : 0;
+      const int64_t Reff = live ? (second ? R_part1 : R_part0) : 0;
       la.fix(ra, r0, Reff, tid, ma);
       lb.fix(rb, r0, Reff, tid, mb);
     }
@@ -782,4 +791,90 @@ extern "C" int ogl_linear_bwd_weight(const float* dy, int64_t ldy,
     g.ws = (float*)workspace;
   }
   return launch_gemm<false, false>(g, (hipStream_t)stream);
+}
+
+
+// ---- weight gradient from TRANSPOSED operands ------------------------------------------------------------------------
+// dw[n,k] = sum_m dyT[n,m] * xT[k,m] is a reduction-contiguous x reduction-contiguous product: it runs on the same
+// fast path as the forward GEMM (and on the split-bf16 arithmetic in BF16X6 / AUTO mode) instead of the k-major
+// (NC x NC) path.  db = row sums of dyT through a synthetic all-ones row of the second operand.
+extern "C" int64_t ogl_linear_bwd_weight_t_workspace_bytes(int64_t M, int N, int K) {
+  return ogl_linear_bwd_weight_workspace_bytes(M, N, K);
+}
+
+extern "C" int ogl_linear_bwd_weight_t(const float* dyT, int64_t lddyT, const float* xT, int64_t ldxT, int64_t M, int N,
+                                       int K, float* dw, int64_t lddw, float* db, void* workspace,
+                                       int64_t workspace_bytes, ogl_stream_t stream) {
+  if (M < 0 || N < 0 || K < 0 || lddyT < M || ldxT < M || lddw < K) return OGL_EINVAL;
+  if (N == 0) return OGL_OK;
+  if (!dw || (M > 0 && (!dyT || (K > 0 && !xT)))) return OGL_EINVAL;
+  GemmArgs g; zero_args(g);
+  g.part[0].a = Operand{dyT, lddyT, nullptr, 0};
+  g.part[0].b = Operand{xT, ldxT, nullptr, 0};
+  g.part[0].R = M;
+  g.nparts = 1;
+  g.M = N; g.N = K + 1; g.ones_col = 1; g.C = dw; g.ldc = lddw; g.db = db;
+  bwd_weight_plan(M, N, K, &g.nsplit, &g.tiles_per_split, &g.force_cfg);
+  g.force_cfg += 1;
+  if (M == 0 || K == 0) { g.nsplit = 1; g.tiles_per_split = 0; }
+  if (g.nsplit > 1) {
+    g.ws_ld = ogl_round_up(K + 1, 4);
+    if (!workspace || workspace_bytes < (int64_t)g.nsplit * N * g.ws_ld * 4) return OGL_EWORKSPACE;
+    g.ws = (float*)workspace;
+  }
+  return launch_gemm<true, true>(g, (hipStream_t)stream);
+}
+
+// dst[j, i] = src[row(i), j]: 64 x 64 tiles through LDS (both sides 16-B vectorised and coalesced), optional row gather
+__global__ void __launch_bounds__(256) k_transpose(const float* __restrict__ src, int64_t ld, const int64_t* __restrict__ rows,
+                                                   int64_t nrows, int64_t M, int N, float* __restrict__ dst, int64_t ldt) {
+  __shared__ float tile[64][65];
+  const int64_t i0 = (int64_t)blockIdx.x * 64;
+  const int j0 = blockIdx.y * 64;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = (tid & 15) * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t i = i0 + ty + 16 * k;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < M) {
+      int64_t row = rows ? rows[i] : i;
+      if (!rows || (row >= 0 && row < nrows)) {
+        const float* p = src + row * ld + j0 + tx;
+        if (j0 + tx + 3 < N) v = ld16(p);
+        else {
+          if (j0 + tx < N) v.x = p[0];
+          if (j0 + tx + 1 < N) v.y = p[1];
+          if (j0 + tx + 2 < N) v.z = p[2];
+        }
+      }
+    }
+    tile[ty + 16 * k][tx] = v.x; tile[ty + 16 * k][tx + 1] = v.y; tile[ty + 16 * k][tx + 2] = v.z; tile[ty + 16 * k][tx + 3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j = j0 + ty + 16 * k;
+    if (j >= N) continue;
+    const int64_t i = i0 + tx;
+    float* o = dst + (int64_t)j * ldt + i;
+    const float a = tile[tx][ty + 16 * k], b = tile[tx + 1][ty + 16 * k], c = tile[tx + 2][ty + 16 * k], d = tile[tx + 3][ty + 16 * k];
+    if (i + 3 < M && (ldt & 3) == 0 && (((uintptr_t)dst & 15) == 0)) *(float4*)o = make_float4(a, b, c, d);
+    else {
+      if (i < M) o[0] = a;
+      if (i + 1 < M) o[1] = b;
+      if (i + 2 < M) o[2] = c;
+      if (i + 3 < M) o[3] = d;
+    }
+  }
+}
+
+extern "C" int ogl_transpose(const float* src, int64_t ld, const int64_t* rows, int64_t nrows, int64_t M, int N, float* dst,
+                             int64_t ldt, ogl_stream_t stream) {
+  if (M < 0 || N < 0 || ld < N || ldt < M) return OGL_EINVAL;
+  if (M == 0 || N == 0) return OGL_OK;
+  if (!src || !dst) return OGL_EINVAL;
+  dim3 grid((unsigned)ogl_cdiv(M, 64), (unsigned)ogl_cdiv(N, 64));
+  hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, (hipStream_t)stream, src, ld, rows, nrows, M, N, dst, ldt);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
 }

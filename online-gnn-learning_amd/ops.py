@@ -55,10 +55,14 @@ def _ptr(t):
 GEMM_MODES = {"f32": 0, "bf16x6": 1, "auto": 2}
 
 
+_MODE = {"name": "f32"}
+
+
 def set_gemm_mode(mode: str):
     """'f32' = exact fp32 MFMA (default); 'bf16x6' = split-bf16 MFMA at fp32 accuracy; 'auto' = bf16x6 where it is
     faster (forward / input-gradient GEMMs), f32 for weight gradients (see include/ogl_hip.h)."""
     check(_lib.lib().ogl_set_gemm_mode(GEMM_MODES[mode]), "ogl_set_gemm_mode")
+    _MODE["name"] = mode
 
 
 def get_gemm_mode() -> str:
@@ -286,6 +290,44 @@ def linear_bwd_weight(dy, x, ymask=None, x_rows=None, want_bias=True, dw_out=Non
     return dw, db
 
 
+def transpose(src, rows=None):
+    """[N, M] = src[rows?].T (LDS-tiled, optional row gather): operands of the transposed weight-gradient form."""
+    src = as_mat(src)
+    M = rows.numel() if rows is not None else src.shape[0]
+    N = src.shape[1]
+    dst = empty_mat(N, M, src.device)
+    _launch("ogl_transpose", _lib.lib().ogl_transpose, _ptr(src), _ld(src), _ptr(rows), src.shape[0], M, N, _ptr(dst), _ld(dst),
+            _stream(), meta=dict(M=M, N=N))
+    return dst
+
+
+def linear_bwd_weight_t(dyT, xT, want_bias=True):
+    """dw [N, K] = dyT [N, M] @ xT [K, M].T, db = dyT.sum(1): the weight gradient as a reduction-contiguous product."""
+    dyT = as_mat(dyT); xT = as_mat(xT)
+    N, M = dyT.shape
+    K = xT.shape[0]
+    assert xT.shape[1] == M
+    dev = dyT.device
+    dw = torch.empty((N, K), dtype=torch.float32, device=dev)
+    db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
+    nbytes = int(_lib.lib().ogl_linear_bwd_weight_t_workspace_bytes(M, N, K))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    _launch("ogl_linear_bwd_weight_t", _lib.lib().ogl_linear_bwd_weight_t, _ptr(dyT), _ld(dyT), _ptr(xT), _ld(xT), M, N, K, _ptr(dw),
+            _ld(dw), _ptr(db), _ptr(ws), nbytes, _stream(), meta=dict(M=M, K=K, N=N))
+    return dw, db
+
+
+def weight_grad(dy, x, x_rows=None, want_bias=True, dyT=None):
+    """dW, db of a projection.  In the bf16x6 / auto arithmetic both operands are transposed first (two LDS-tiled
+    copies) so the product runs on the reduction-contiguous split-bf16 path; the exact-fp32 mode keeps the direct
+    k-major kernel.  ``dyT`` lets the two weight gradients of a dual-input Linear share one transpose."""
+    if _MODE["name"] == "f32" or dy.shape[0] < 1024:
+        return linear_bwd_weight(dy, x, None, x_rows, want_bias=want_bias)
+    if dyT is None:
+        dyT = transpose(dy)
+    return linear_bwd_weight_t(dyT, transpose(x, x_rows), want_bias=want_bias)
+
+
 # --------------------------------------------------------------------------------------------
 # loss / optimiser
 # --------------------------------------------------------------------------------------------
@@ -360,15 +402,18 @@ class _LinearFn(torch.autograd.Function):
             if x_rows is not None:
                 raise RuntimeError("gradient w.r.t. a row-gathered table is not supported (features carry no grad)")
             dx = linear_bwd_input(dy, w, y)
+        dyT = None
+        if _MODE["name"] != "f32" and dy.shape[0] >= 1024 and x2 is not None and need[1] and need[4]:
+            dyT = transpose(dy)          # shared by the two weight gradients of a dual-input projection
         if need[1] or (need[2] and ctx.has_bias):
-            dw, db = linear_bwd_weight(dy, x, y, x_rows, want_bias=ctx.has_bias)
+            dw, db = weight_grad(dy, x, x_rows, want_bias=ctx.has_bias, dyT=dyT)
         if x2 is not None:
             if need[3]:
                 if x2_rows is not None:
                     raise RuntimeError("gradient w.r.t. a row-gathered table is not supported")
                 dx2 = linear_bwd_input(dy, w2, y)
             if need[4]:
-                dw2, _ = linear_bwd_weight(dy, x2, y, x2_rows, want_bias=False)
+                dw2, _ = weight_grad(dy, x2, x2_rows, want_bias=False, dyT=dyT)
         return dx, dw, (db if ctx.has_bias else None), dx2, dw2, None, None, None
 
 
@@ -423,7 +468,7 @@ class _PoolMaxFn(torch.autograd.Function):
                 raise RuntimeError("gradient w.r.t. a row-gathered table is not supported (features carry no grad)")
             dx = linear_bwd_input(dp, w, None)
         if need[1] or (need[2] and ctx.has_bias):
-            dw, db = linear_bwd_weight(dp, x, None, x_rows, want_bias=ctx.has_bias)
+            dw, db = weight_grad(dp, x, x_rows, want_bias=ctx.has_bias)
         return dx, dw, (db if ctx.has_bias else None), None, None
 
 

@@ -339,3 +339,30 @@ def test_argmax_confusion(ops, B, C):
     assert np.array_equal(cm.cpu().numpy().reshape(C, C), ref)
     ops.argmax_confusion(lt, dev(labels), cm, want_pred=False)       # accumulates
     assert np.array_equal(cm.cpu().numpy().reshape(C, C), 2 * ref)
+
+
+@pytest.mark.parametrize("M,N", [(1, 1), (70, 33), (5000, 602), (64, 64), (129, 600)])
+def test_transpose(ops, M, N):
+    rng = np.random.default_rng(M + N)
+    a = rng.standard_normal((M, N)).astype(np.float32)
+    got = ops.transpose(ops.empty_mat(M, N, "cuda").copy_(torch.as_tensor(a)))
+    assert got.shape == (N, M) and np.array_equal(got.cpu().numpy(), a.T)
+    assert np.array_equal(ops.transpose(dev(a)).cpu().numpy(), a.T)
+    rows = rng.integers(0, M, 77).astype(np.int64)
+    assert np.array_equal(ops.transpose(dev(a), dev(rows)).cpu().numpy(), a[rows].T)
+
+
+@pytest.mark.parametrize("M,K,N", [(5, 7, 3), (1500, 602, 600), (20000, 602, 602), (4096, 128, 32), (2000, 600, 41)])
+def test_weight_grad_transposed_form(ops, gemm_mode, M, K, N):
+    """dW, db from transposed operands (reduction-contiguous product + ones row) == dy.T @ x, dy.sum(0)."""
+    torch.manual_seed(M + K)
+    T = M + 50
+    tab = torch.randn(T, K); rows = torch.randint(0, T, (M,)); dy = torch.randn(M, N)
+    tabc = ops.empty_mat(T, K, "cuda").copy_(tab)
+    dyT = ops.transpose(dy.cuda()); xT = ops.transpose(tabc, rows.cuda())
+    dw, db = ops.linear_bwd_weight_t(dyT, xT)
+    scale = max(1.0, float(M) ** 0.5)
+    np.testing.assert_allclose(dw.cpu().numpy(), (dy.T @ tab[rows]).numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL * scale)
+    np.testing.assert_allclose(db.cpu().numpy(), dy.sum(0).numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL * scale)
+    dw2, db2 = ops.weight_grad(dy.cuda(), tabc, rows.cuda())          # whichever form the mode selects
+    np.testing.assert_allclose(dw2.cpu().numpy(), (dy.T @ tab[rows]).numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL * scale)
