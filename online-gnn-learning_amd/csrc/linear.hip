@@ -87,7 +87,7 @@ __device__ __forceinline__ float4 ld16(const float* p) {
 // All per-thread addressing that does not depend on the k-tile is hoisted into init(); interior
 // tiles take a branch-free path (invalid rows read row 0 and are zeroed by a select), only the
 // last partial k-tile / partial column group takes guarded dword loads.
-template <int P, bool RC>
+template <int P, bool RC, bool ONES_ROW = false>
 struct TileLoader {
   static constexpr int NV = P / 64;  // float4 per thread
   const float* ptr[NV];   // RC: row base + this thread's k offset.  NC: unused
@@ -111,7 +111,7 @@ struct TileLoader {
           row = v ? op.rows[p] : 0;
           v = v && row >= 0 && row < op.nrows;
         }
-        one[h] = p == ones_p;
+        one[h] = ONES_ROW && p == ones_p;
         if (one[h]) v = false;
         if (!v) row = 0;
         ok[h] = v;
@@ -148,7 +148,7 @@ struct TileLoader {
       for (int h = 0; h < NV; ++h) {
         if (!ok[h]) bad |= 1u << h;             // validity travels with the staging set (the loader may have moved on
                                                 // to the second part of a dual GEMM by the time this tile is fixed up)
-        if (one[h]) bad |= 1u << (8 + h);
+        if (ONES_ROW && one[h]) bad |= 1u << (8 + h);
         if (interior) {
           reg[h] = ld16(ptr[h] + r0);
         } else {                                // last, partial k-tile of the part: guarded dwords (once per block)
@@ -197,7 +197,7 @@ struct TileLoader {
       const float4 ones = make_float4(rr < R ? 1.f : 0.f, rr + 1 < R ? 1.f : 0.f, rr + 2 < R ? 1.f : 0.f, rr + 3 < R ? 1.f : 0.f);
 #pragma unroll
       for (int h = 0; h < NV; ++h) {
-        const bool z = (bad >> h) & 1, o = (bad >> (8 + h)) & 1;
+        const bool z = (bad >> h) & 1, o = ONES_ROW && ((bad >> (8 + h)) & 1);
         float4 v = reg[h];
         v.x = o ? ones.x : (z ? 0.f : v.x); v.y = o ? ones.y : (z ? 0.f : v.y);
         v.z = o ? ones.z : (z ? 0.f : v.z); v.w = o ? ones.w : (z ? 0.f : v.w);
@@ -269,7 +269,7 @@ struct TileLoader {
   }
 };
 
-template <bool A_RC, bool B_RC, int WAVES_M, int WAVES_N, int TM, int TN, bool X6>
+template <bool A_RC, bool B_RC, int WAVES_M, int WAVES_N, int TM, int TN, bool X6, bool B_ONES = false>
 __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
   TileLoader<BM, A_RC> la;
-  TileLoader<BN, B_RC> lb;
+  TileLoader<BN, B_RC, B_ONES> lb;   // the all-ones row exists only in the transposed weight-gradient product
   float4 ra0[BM / 64], rb0[BN / 64], ra1[BM / 64], rb1[BN / 64];   // two register staging sets (2-tile-deep prefetch)
   unsigned ma0 = 0, mb0 = 0, ma1 = 0, mb1 = 0;                      // per-set "gathered row out of range" bits
   const int64_t ones_p = g.ones_col ? g.N - 1 : -1;
@@ -655,6 +655,9 @@ static int launch_gemm(GemmArgs& g, hipStream_t stream) {
   } else if (cfg == 2) {
     if (x6) hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 2, 2, 1, 1, true>), grid, block, 0, stream, g);
     else hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 2, 2, 1, 1, false>), grid, block, 0, stream, g);
+  } else if (B_RC && g.ones_col) {
+    if (x6) hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 2, 2, 2, 2, true, B_RC>), grid, block, 0, stream, g);
+    else hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 2, 2, 2, 2, false, B_RC>), grid, block, 0, stream, g);
   } else {
     if (x6) hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 2, 2, 2, 2, true>), grid, block, 0, stream, g);
     else hipLaunchKernelGGL((k_gemm<A_RC, B_RC, 2, 2, 2, 2, false>), grid, block, 0, stream, g);
@@ -815,7 +818,7 @@ extern "C" int ogl_linear_bwd_weight_t(const float* dyT, int64_t lddyT, const fl
   g.nparts = 1;
   g.M = N; g.N = K + 1; g.ones_col = 1; g.C = dw; g.ldc = lddw; g.db = db;
   bwd_weight_plan(M, N, K, &g.nsplit, &g.tiles_per_split, &g.force_cfg);
-  g.force_cfg += 1;
+  g.force_cfg = 1;      // 128 x 128 tiles: the only configuration built with the ones-row loader
   if (M == 0 || K == 0) { g.nsplit = 1; g.tiles_per_split = 0; }
   if (g.nsplit > 1) {
     g.ws_ld = ogl_round_up(K + 1, 4);
