@@ -184,17 +184,15 @@ def main():
         if name == "ogl_reduce_fwd":
             key = "reduce_fwd_L0" if meta["n_dst"] > B else "reduce_fwd_L1"
         elif name.startswith("ogl_linear"):
-            big = meta["M"] > 4 * B * (1 + S) // 2 or (name == "ogl_linear_bwd_weight" and meta["M"] > B * (1 + S))
             key = name[4:] + ("_pool0" if meta["M"] > B * (1 + S) else "_other")
-            del big
         a = agg.setdefault(key, dict(ms=0.0, calls=0, bytes=0.0, flops=0.0))
         a["ms"] += ms; a["calls"] += 1
         if name == "ogl_reduce_fwd":
             E = meta["n_dst"] * meta["fanout"]
             a["bytes"] += E * (4 * meta["d"] + meta["idx_bytes"]) + meta["n_dst"] * 4 * meta["d"] * (2 if meta["argmax"] else 1)
-        if name == "ogl_linear_fwd":
+        if name in ("ogl_linear_fwd", "ogl_linear_fwd_x3"):
             a["flops"] += 2.0 * meta["M"] * meta["N"] * (meta["K"] + meta["K2"])
-        if name in ("ogl_linear_bwd_input", "ogl_linear_bwd_weight"):
+        if name in ("ogl_linear_bwd_input", "ogl_linear_bwd_weight", "ogl_linear_bwd_weight_t", "ogl_linear_bwd_weight_x3"):
             a["flops"] += 2.0 * meta["M"] * meta["N"] * meta["K"]
     kernels = {k: dict(avg_ms=v["ms"] / v["calls"], ms_per_step=v["ms"] / prof_steps, calls_per_step=v["calls"] / prof_steps,
                        gbs=(v["bytes"] / v["ms"] / 1e6) if v["bytes"] else None,
@@ -214,9 +212,9 @@ def main():
     if dom:
         ach = agg[dom]["flops"] / agg[dom]["ms"] / 1e9
         # which arithmetic did this launch run on?  (ops.weight_grad / linear.hip AUTO policy)
-        x6 = args.gemm == "bf16x6" or (args.gemm == "auto" and ("bwd_weight_t" in dom or "bwd_weight" not in dom))
+        x6 = args.gemm == "bf16x6" or (args.gemm == "auto" and ("_x3" in dom or "bwd_weight_t" in dom or "bwd_weight" not in dom))
         peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if x6 else MFMA_F32_PEAK_TFLOPS
-        roof_gemm = dict(kernel="k_gemm (%s; %s)" % (dom, "split-bf16 x6 on v_mfma_f32_32x32x16_bf16, fp32 accumulate" if x6
+        roof_gemm = dict(kernel="%s (%s; %s)" % ("k_gemm_x3" if "_x3" in dom else "k_gemm", dom, "split-bf16 x6 on v_mfma_f32_32x32x16_bf16, fp32 accumulate" if x6
                                                       else "v_mfma_f32_32x32x2_f32"),
                          bound="mfma", achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
                          traffic=None, avg_launch_ms=round(agg[dom]["ms"] / agg[dom]["calls"], 4),
@@ -289,7 +287,8 @@ def gemm_desc(mode):
     return {"f32": "fp32 MFMA (exact fp32 fma chain)",
             "bf16x6": "split-bf16 x6 MFMA, fp32 accumulate (fp32-GEMM accuracy, same test tolerances)",
             "auto": "forward/input-gradient GEMMs: split-bf16 x6 MFMA with fp32 accumulate (fp32-GEMM accuracy, same test "
-                    "tolerances); weight-gradient GEMMs: exact fp32 MFMA"}[mode]
+                    "tolerances); weight-gradient GEMMs: the same x6 arithmetic on transposed operands when M >= 1024 (ogl_transpose + "
+                    "ogl_linear_bwd_weight_t), exact fp32 MFMA below that"}[mode]
 
 
 def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size, n_classes, setup_s):

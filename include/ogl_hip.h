@@ -167,6 +167,45 @@ int ogl_transpose(const float* src, int64_t ld, const int64_t* rows, int64_t nro
                   float* dst, int64_t ldt, ogl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The same projections on PRE-SPLIT operands ("bf16x3 images", linear_x3.hip): the exact 3-term bf16 split of the
+ * x6 arithmetic is done once per matrix by ogl_x3_split / ogl_x3_split_t instead of by every GEMM block, and the
+ * GEMM stages its tiles global -> LDS by LDS-DMA.  Same results as OGL_GEMM_BF16X6 (same products, same order).
+ * Used for the large layer-0 products: the static feature table (R/train/graphsage/pytorch/model.py:62,
+ * `graph.ndata['feat'][input_nodes]`) is split once per dataset, weights once per call.
+ *
+ * Image of an fp32 matrix [R, K]: (R + 1) rows (row R is all zero) of ceil(K/32) groups of 192 bytes; a group holds
+ * 32 consecutive reduction elements as three 64-byte bf16 planes (hi, mid, lo term), pad elements are zero.
+ *   ogl_x3_split    image row r = split(src[row(r), 0:K])           (rows nullable; ids outside [0, nrows) -> zero row).
+ *                   append != 0 gives the image ONE extra reduction element at k = K (image reduction length K + 1:
+ *                   size it with ogl_x3_image_bytes(R, K + 1)): append = 1 -> 1.0 in every row INCLUDING the zero row
+ *                   (activations side), append = 2 -> append_vec[r] (weights side: the bias).  The product of two
+ *                   such images is x . w^T + bias: the bias is added by the matrix pipe, ogl_linear_fwd_x3 has no
+ *                   bias argument.
+ *   ogl_x3_split_t  image row n = split(src[row(0:M), n]) for n < N: the image of the TRANSPOSE (reduction over the M
+ *                   source rows); ones_row != 0 appends image row N = 1.0 for m < M (bias-gradient operand).  The image
+ *                   then has N + 1 (+ zero) rows: size it with ogl_x3_image_bytes(N + 1, M).
+ *   ogl_linear_fwd_x3         y[M,N] = act(x_img[row(i), :] . w_img^T), K = the images' reduction length (both built
+ *                             with the same append choice); x image [x_img_rows, K] (x_img_rows = the R it was built
+ *                             with: the zero row sits there) with optional gather by x_rows (ids outside
+ *                             [0, x_nrows), x_nrows <= x_img_rows, read the zero row); w image [N, K].  y's pad
+ *                             columns up to the next multiple of 4 may be overwritten.
+ *   ogl_linear_bwd_weight_x3  dw[N,K], db[N] (nullable) from the images of dy^T ([N rows, M]) and [x | 1]^T
+ *                             ([K + 1 rows, M], ones_row = 1)
+ * ---------------------------------------------------------------------------------------- */
+int64_t ogl_x3_row_bytes(int64_t K);
+int64_t ogl_x3_image_bytes(int64_t rows, int64_t K);
+int ogl_x3_split(const float* src, int64_t ld, const int64_t* rows, int64_t nrows, int64_t R, int K, int append,
+                 const float* append_vec, void* image, ogl_stream_t stream);
+int ogl_x3_split_t(const float* src, int64_t ld, const int64_t* rows, int64_t nrows, int64_t M, int N, int ones_row,
+                   void* image, ogl_stream_t stream);
+int ogl_linear_fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
+                      const void* w_img, int N, int relu, float* y, int64_t ldy, ogl_stream_t stream);
+int64_t ogl_linear_bwd_weight_x3_workspace_bytes(int64_t M, int N, int K);
+int ogl_linear_bwd_weight_x3(const void* dyT_img, const void* xT_img, int64_t M, int N, int K, float* dw,
+                             int64_t lddw, float* db, void* workspace, int64_t workspace_bytes,
+                             ogl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * nn.CrossEntropyLoss (R/train/graphsage/pytorch/model.py:20,105,147,198,244):
  *   loss_rows[i] = logsumexp(logits[i,:]) - logits[i, labels[i]]            (reduction='none')
  *   dlogits (nullable) = grad_scale * (softmax - onehot)   (grad_scale = 1/B for the mean loss)

@@ -45,6 +45,13 @@ SIGNATURES = {
     "ogl_linear_bwd_weight_t_workspace_bytes": (_i64, [_i64, _i, _i]),
     "ogl_linear_bwd_weight_t": (_i, [_p, _i64, _p, _i64, _i64, _i, _i, _p, _i64, _p, _p, _i64, _p]),
     "ogl_transpose": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _p]),
+    "ogl_x3_row_bytes": (_i64, [_i64]),
+    "ogl_x3_image_bytes": (_i64, [_i64, _i64]),
+    "ogl_x3_split": (_i, [_p, _i64, _p, _i64, _i64, _i, _i, _p, _p, _p]),
+    "ogl_x3_split_t": (_i, [_p, _i64, _p, _i64, _i64, _i, _i, _p, _p]),
+    "ogl_linear_fwd_x3": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i, _i, _p, _i64, _p]),
+    "ogl_linear_bwd_weight_x3_workspace_bytes": (_i64, [_i64, _i, _i]),
+    "ogl_linear_bwd_weight_x3": (_i, [_p, _p, _i64, _i, _i, _p, _i64, _p, _p, _i64, _p]),
     "ogl_ce_fwd_bwd": (_i, [_p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p]),
     "ogl_adam_step": (_i, [_p, _p, _p, _p, _i64, _i, _d, _d, _d, _d, _p]),
     "ogl_argmax_confusion": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p]),

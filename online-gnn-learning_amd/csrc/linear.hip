@@ -17,30 +17,8 @@
 // an operand panel, run on one XCD so the panel is fetched into that XCD's L2 once.
 #include "ogl_common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef short v4i16 __attribute__((ext_vector_type(4)));
-typedef v4i16 __attribute__((address_space(3))) lds_v4i16;
+#include "x6_arith.h"
 
-// ---- split-bf16 ("x6") arithmetic -------------------------------------------------------------------------------
-// An fp32 value is split EXACTLY into three bf16 terms x = x1 + x2 + x3 (8 + 8 + 8 significand bits, each
-// residual is exact in fp32); a*b = sum_{i,j} a_i*b_j and the six terms with i + j <= 4 are accumulated in fp32
-// by v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are exact in fp32).  The dropped terms are <= 2^-23 |a*b|,
-// i.e. at the level of one fp32 rounding of the product, so the result carries fp32-GEMM accuracy while the matrix
-// pipe runs at 16x the fp32-MFMA rate for 6x the instructions.
-__device__ __forceinline__ unsigned pk_bf16(float x, float y) {
-  f32x2 v = {x, y};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
-}
-__device__ __forceinline__ void split3(float x, float y, unsigned& h, unsigned& m, unsigned& l) {
-  h = pk_bf16(x, y);
-  const float rx = x - __builtin_bit_cast(float, h << 16), ry = y - __builtin_bit_cast(float, h & 0xFFFF0000u);
-  m = pk_bf16(rx, ry);
-  const float sx = rx - __builtin_bit_cast(float, m << 16), sy = ry - __builtin_bit_cast(float, m & 0xFFFF0000u);
-  l = pk_bf16(sx, sy);
-}
 #define X6_ROW_U4 7   // LDS row of a P x 16 tile: 3 splits x 2 k-halves x 16 B + 16 B pad = 112 B (odd multiple of 16 B)
 
 #define GEMM_BK 16
@@ -74,14 +52,6 @@ struct GemmArgs {
   int NI, NJ;
   int force_cfg;    // host-side only: 1 + tile configuration chosen by the caller's plan, 0 = automatic
 };
-
-// 16-byte load from a 4-byte-aligned address: gfx950 under HSA runs in unaligned-access mode, the
-// compiler emits one global_load_dwordx4 (rows such as K = 602 floats are only 8-B aligned).
-__device__ __forceinline__ float4 ld16(const float* p) {
-  float4 t;
-  __builtin_memcpy(&t, p, 16);
-  return t;
-}
 
 // Stages one P x BK operand tile: global -> registers (load) -> LDS k-major (store).
 // All per-thread addressing that does not depend on the k-tile is hoisted into init(); interior

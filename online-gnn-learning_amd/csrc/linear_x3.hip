@@ -1,0 +1,525 @@
+// Dense projections on PRE-SPLIT operands ("bf16x3 images"): the same split-bf16 x6 arithmetic as linear.hip
+// (x6_arith.h), but the exact 3-term bf16 split of every fp32 operand is done ONCE by a streaming kernel instead of
+// by every GEMM block that touches the element.  What that buys on gfx950: the GEMM's staging becomes a pure byte
+// copy, so tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip, no VALU, no ds_write)
+// and the matrix pipe only waits for ds_read_b128 fragments.  Replaces the same torch.nn.Linear call sites as
+// linear.hip (R/train/graphsage/pytorch/aggregator_dgl.py:85-94,171,181,206) for the large layer-0 products.
+//
+// Image of an fp32 matrix X[R, K] (reduction index contiguous): R rows + ONE all-zero row (index R), each row
+// G = ceil(K/32) groups of 192 bytes; group g holds k = 32g .. 32g+31 as three 64-byte planes (hi, mid, lo terms
+// of the split), pad k >= K is zero.  One (row, group) is therefore 192 contiguous bytes: a BK = 32 GEMM step reads
+// 12 consecutive 16-byte pieces per row.
+//
+// k_gemm_x3: C[i, j] = epilogue(sum_k A[i, k] B[j, k]), both operands images (A optionally gathered by an int64 row
+// list: rows outside the table read the zero row).  8 waves per block, one block per CU (144 KB LDS: two stages of
+// (BM + BN) x 192 B), 2 waves per SIMD.  LDS image of a stage = the 12 pieces of row r at pieces 12r .. 12r+11 with
+// the chunk index XOR-ed by (r >> 2) & 3 inside each plane: the DMA is lane-linear (piece i of the stage lands at
+// byte 16 i), the swizzle is applied on the per-lane SOURCE address, and every 32x16 MFMA fragment is one
+// conflict-free ds_read_b128 (16-lane groups {0-3,12-15,20-27}, ... hit 16 distinct 16-byte slots of the 256-byte
+// bank row: slot = 4 ((plane - r) mod 4) + (chunk ^ ((r >> 2) & 3))).
+#include <algorithm>
+#include <cstdlib>
+#include "x6_arith.h"
+
+#define X3_GROUP_BYTES 192
+
+struct X3Operand {
+  const unsigned char* img;
+  int64_t row_bytes;
+  const int64_t* rows;   // optional gather (A only)
+  int64_t nrows;         // valid row ids are [0, nrows)
+  int64_t zero_row;      // index of the image's all-zero row (>= nrows): where invalid ids and tile padding point
+};
+
+struct X3Args {
+  X3Operand a, b;
+  int64_t M, N;          // output rows / columns (N includes the ones column when ones_col)
+  int nsteps;            // 32-deep reduction groups
+  int ones_col;          // column N-1 = row sums of A (the B image carries an all-ones row there): bias gradient
+  float* C; int64_t ldc;
+  int relu;
+  float* db;
+  int nsplit, steps_per_split;
+  float* ws; int64_t ws_ld;
+  int NI, NJ;
+};
+
+__device__ float4 g_x3_trash[64];   // where epilogue lanes with nothing to store aim their (statically counted) stores
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
+  constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
+  constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32, ROWS = BM + BN;
+  constexpr int PIECES = ROWS * 12;
+  static_assert(PIECES % NT == 0, "every thread issues the same number of DMA pieces");
+  constexpr int NLOAD = PIECES / NT;
+  constexpr int STAGE = PIECES * 16;
+  // the first BM * 12 / NT pieces a thread moves are A pieces, the rest B pieces (static)
+  constexpr int NLOAD_A = BM * 12 / NT;
+  static_assert(BM * 12 % NT == 0, "A / B pieces split on a load boundary");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  // PERSISTENT blocks, XCD-aware and bijective.  Hardware deals block L to XCD L % 8; the logical tile space (split,
+  // row panel, column tile — column tile fastest) is cut into 8 contiguous chunks and the blocks of XCD c walk chunk
+  // c with stride gridDim / 8: tiles that run at the same time on one XCD share the A row panel (and, for split-K,
+  // the same slice of both operands), so each XCD's L2 fetches a panel once.  One block per CU (144 KB LDS).
+  const int T = g.NI * g.NJ * g.nsplit;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int chunk_begin = xcd * (T >> 3) + min(xcd, T & 7), chunk_len = (T >> 3) + (xcd < (T & 7) ? 1 : 0);
+  if (slot >= chunk_len) return;
+
+  struct Tile { int64_t i0, j0; int split, ks_begin, ks_end; };
+  auto decode = [&](int logical) {
+    Tile t;
+    t.split = logical / (g.NI * g.NJ);
+    const int tile = logical - t.split * (g.NI * g.NJ);
+    const int ti = tile / g.NJ, tj = tile - ti * g.NJ;
+    t.i0 = (int64_t)ti * BM; t.j0 = (int64_t)tj * BN;
+    t.ks_begin = 0; t.ks_end = g.nsteps;
+    if (g.nsplit > 1) {
+      t.ks_begin = t.split * g.steps_per_split;
+      t.ks_end = min(g.nsteps, t.ks_begin + g.steps_per_split);
+    }
+    return t;
+  };
+
+  // gathered row ids of a tile's A pieces (independent loads, clamped index; validity is applied in make_src)
+  auto load_rids = [&](const Tile& t, int64_t (&rid)[NLOAD_A]) {
+    if (g.a.rows) {
+#pragma unroll
+      for (int u = 0; u < NLOAD_A; ++u) {
+        const int64_t gi = t.i0 + (u * NT + tid) / 12;
+        rid[u] = g.a.rows[gi < g.M ? gi : g.M - 1];   // raw: nothing here consumes the loaded value
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NLOAD_A; ++u) rid[u] = t.i0 + (u * NT + tid) / 12;
+    }
+  };
+  // per-lane DMA sources: piece i = u * NT + tid of a stage = (row r = i / 12, plane p, swizzled chunk c)
+  const unsigned char* src[NLOAD];
+  auto make_src = [&](const Tile& t, const int64_t (&rid)[NLOAD_A]) {
+#pragma unroll
+    for (int u = 0; u < NLOAD; ++u) {
+      const int i = u * NT + tid;
+      const int r = i / 12, j = i - r * 12;
+      const int p = j >> 2, c = (j & 3) ^ ((r >> 2) & 3);
+      const unsigned char* rowp;
+      if (u < NLOAD_A) {
+        const int64_t id = rid[u < NLOAD_A ? u : 0];
+        const bool ok = t.i0 + r < g.M && id >= 0 && id < g.a.nrows;
+        rowp = g.a.img + (ok ? id : g.a.zero_row) * g.a.row_bytes;
+      } else {
+        const int64_t gj = t.j0 + (r - BM);
+        rowp = g.b.img + (gj < g.N ? gj : g.b.zero_row) * g.b.row_bytes;
+      }
+      src[u] = rowp + (int64_t)t.ks_begin * X3_GROUP_BYTES + p * 64 + c * 16;
+    }
+  };
+
+  // per-lane fragment offsets inside a stage (bytes), plane 0, for both 16-deep halves of the 32-deep step
+  int offa[TM][2], offb[TN][2];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int r = wm * TM * 32 + t * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) offa[t][s] = (r * 12 + ((2 * s + half) ^ ((r >> 2) & 3))) * 16;
+  }
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int r = BM + wn * TN * 32 + t * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) offb[t][s] = (r * 12 + ((2 * s + half) ^ ((r >> 2) & 3))) * 16;
+  }
+
+  f32x16 acc[TM][TN];
+
+  auto issue = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < NLOAD; ++u) {
+      __builtin_amdgcn_global_load_lds((gptr_t)src[u], (lptr_t)(smem + buf * STAGE + (u * NT + wid * 64) * 16), 16, 0, 0);
+      src[u] += X3_GROUP_BYTES;
+    }
+  };
+
+  // One 32-deep step = two 16-deep MFMA sub-steps (fragment registers are reused: the accumulators of the finished
+  // tile stay live under the next tile's first step, so the register budget goes to them, not to deeper prefetch).
+  auto load_frags = [&](const unsigned char* st, int s, bf16x8 (&a)[TM][3], bf16x8 (&b)[TN][3]) {
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp) a[t][sp] = *(const bf16x8*)(st + offa[t][s] + sp * 64);
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp) b[t][sp] = *(const bf16x8*)(st + offb[t][s] + sp * 64);
+  };
+  auto mfma_block = [&](const bf16x8 (&a)[TM][3], const bf16x8 (&b)[TN][3]) {
+#pragma unroll
+    for (int x = 0; x < TM; ++x)
+#pragma unroll
+      for (int y = 0; y < TN; ++y) {
+        // smallest terms first (i + j = 4, then 3, then 2) — same order as k_gemm's x6 path.
+        // The weight-side fragment goes in as the MFMA's first operand: the accumulator then holds C^T tiles, i.e.
+        // lane = output row, registers = 4-column groups, and the epilogue stores 16 bytes per lane.
+        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[y][2], a[x][0], acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[y][1], a[x][1], acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[y][0], a[x][2], acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[y][1], a[x][0], acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[y][0], a[x][1], acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[y][0], a[x][0], acc[x][y], 0, 0, 0);
+      }
+  };
+  auto compute = [&](int buf) {
+    const unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[TM][3], b[TN][3];
+      load_frags(st, s, a, b);
+      mfma_block(a, b);
+    }
+  };
+
+  // Epilogue of a finished tile.  res[x][y] holds the TRANSPOSED 32x32 tile: lane -> output row (lane & 31), register
+  // e -> output column (e & 3) + 8 (e >> 2) + 4 (lane >> 5): four 4-column groups per lane.  Every thread issues
+  // EXACTLY TM*TN*4 16-byte stores, whatever the tile's position: lanes with nothing to store (rows >= M, columns
+  // >= N, unaligned destinations) aim theirs at a scratch line.  The static count is what lets the next tile's first
+  // barrier wait for its DMA only (s_waitcnt vmcnt(NSTORE)) while these stores are still draining.
+  auto epilogue = [&](const f32x16 (&res)[TM][TN], const Tile& t) {
+    float* const dst = g.nsplit > 1 ? g.ws + (int64_t)t.split * g.M * g.ws_ld : g.C;
+    const int64_t ldd = g.nsplit > 1 ? g.ws_ld : g.ldc;
+    const bool vec_ok = (ldd & 3) == 0 && ((uintptr_t)dst & 15) == 0;
+    const bool fin = g.nsplit == 1;
+    float* const trash = (float*)&g_x3_trash[lane];
+#pragma unroll
+    for (int x = 0; x < TM; ++x) {
+      const int64_t row = t.i0 + wm * TM * 32 + x * 32 + l31;
+      const bool rok = row < g.M;
+#pragma unroll
+      for (int y = 0; y < TN; ++y) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t col = t.j0 + wn * TN * 32 + y * 32 + 8 * q + 4 * half;
+          float v[4] = {res[x][y][4 * q], res[x][y][4 * q + 1], res[x][y][4 * q + 2], res[x][y][4 * q + 3]};
+          const bool has_oc = fin && g.ones_col && col + 3 >= g.N - 1 && col < g.N;   // this group holds the ones column
+          if (fin && g.relu) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+          }
+          // the 16-byte store: whole groups, and partial groups whose tail falls into the row's pad columns
+          const bool vec = rok && vec_ok && !has_oc && col < g.N && col + 4 <= ldd;
+          *(float4*)(vec ? dst + row * ldd + col : trash) = make_float4(v[0], v[1], v[2], v[3]);
+          if (rok && !vec && col < g.N) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (col + c >= g.N) continue;
+              if (fin && g.ones_col && col + c == g.N - 1) { if (g.db) g.db[row] = v[c]; }
+              else dst[row * ldd + col + c] = v[c];
+            }
+          }
+        }
+      }
+    }
+  };
+
+  // Two-stage ring that runs ACROSS tiles.  The barrier at the top of a step (a) retires this wave's DMA of the
+  // stage about to be multiplied (vmcnt(0) before s_barrier) and makes every wave's pieces visible, (b) guarantees
+  // all waves finished reading the other buffer, which the next DMA overwrites.  The last step of a tile already
+  // fetches the first stage of the block's next tile, so the pipeline fill (row-id gather, first DMA) of every
+  // tile but the first is covered by matrix work, and the epilogue stores drain under the fill's tail.
+  int cur = chunk_begin + slot;
+  Tile tc = decode(cur);
+  int buf = 0;
+  bool first_tile = true;
+  constexpr int NSTORE = TM * TN * 4;
+  {
+    int64_t rid[NLOAD_A];
+    load_rids(tc, rid);
+    make_src(tc, rid);
+  }
+  issue(0);
+  while (true) {
+    const int nxt = cur + nslots;
+    const bool has_next = nxt - chunk_begin < chunk_len;
+    Tile tn = tc;
+    int64_t rid_next[NLOAD_A];
+    if (has_next) tn = decode(nxt);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    for (int ks = tc.ks_begin; ks < tc.ks_end; ++ks) {
+      if (ks == tc.ks_begin && !first_tile) {
+        // the previous tile's NSTORE epilogue stores were issued AFTER this stage's DMA: leave them in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+        __builtin_amdgcn_s_barrier();
+      } else {
+        __syncthreads();
+      }
+      // row ids of the NEXT tile: fetched after this tile's first barrier (behind the previous epilogue's stores, which
+      // nothing waits for any more), consumed at the last step
+      if (ks == tc.ks_begin && has_next) load_rids(tn, rid_next);
+      if (ks + 1 < tc.ks_end) {
+        issue(buf ^ 1);
+      } else if (has_next) {
+        make_src(tn, rid_next);
+        issue(buf ^ 1);
+      }
+      compute(buf);
+      buf ^= 1;
+    }
+    epilogue(acc, tc);
+    if (!has_next) break;
+    cur = nxt; tc = tn; first_tile = false;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_x3_splitk_reduce(X3Args g) {
+  const int64_t total = g.M * g.N;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = t / g.N, col = t - row * g.N;
+    float v = 0.f;
+    for (int s = 0; s < g.nsplit; ++s) v += g.ws[((int64_t)s * g.M + row) * g.ws_ld + col];  // fixed order
+    const bool oc = g.ones_col && col == g.N - 1;
+    if (g.relu) v = fmaxf(v, 0.f);
+    if (oc) { if (g.db) g.db[row] = v; }
+    else g.C[row * g.ldc + col] = v;
+  }
+}
+
+// ---- image builders ---------------------------------------------------------------------------------------------------
+// image[r][k/32][plane][k%32] = split(src[row(r), k]); one thread per (row, 8 consecutive k).  Row R (all zeros) is
+// written too.  `append`: the image carries ONE extra reduction element k = K — 1.0 in every row including the zero
+// row (append = 1: the activations side) or append_vec[r] (append = 2: the weights side, i.e. the bias) — so that a
+// product of two such images is x . w^T + bias with the bias added by the matrix pipe (no bias pass in the epilogue).
+__global__ void __launch_bounds__(256) k_x3_split(const float* __restrict__ src, int64_t ld, const int64_t* __restrict__ rows,
+                                                  int64_t nrows_src, int64_t R, int K, int append,
+                                                  const float* __restrict__ append_vec, unsigned char* __restrict__ img,
+                                                  int64_t row_bytes) {
+  const int cpr = (int)(row_bytes / X3_GROUP_BYTES) * 4;   // 8-element chunks per row
+  const int64_t total = (R + 1) * cpr;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / cpr;
+    const int ch = (int)(t - r * cpr);
+    const int k = ch * 8;
+    float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool ok = r < R;
+    int64_t row = r;
+    if (ok && rows) { row = rows[r]; ok = row >= 0 && row < nrows_src; }
+    if (ok && k < K) {
+      const float* p = src + row * ld + k;
+      if (k + 8 <= K) {
+        const float4 lo = ld16(p), hi = ld16(p + 4);
+        e[0] = lo.x; e[1] = lo.y; e[2] = lo.z; e[3] = lo.w; e[4] = hi.x; e[5] = hi.y; e[6] = hi.z; e[7] = hi.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (k + q < K) e[q] = p[q];
+      }
+    }
+    if (append && K >= k && K < k + 8) {
+      const float av = append == 1 ? 1.f : (r < R ? append_vec[r] : 0.f);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) if (k + q == K) e[q] = av;
+    }
+    uint4 o[3];
+    split3(e[0], e[1], o[0].x, o[1].x, o[2].x);
+    split3(e[2], e[3], o[0].y, o[1].y, o[2].y);
+    split3(e[4], e[5], o[0].z, o[1].z, o[2].z);
+    split3(e[6], e[7], o[0].w, o[1].w, o[2].w);
+    unsigned char* d = img + r * row_bytes + (int64_t)(ch >> 2) * X3_GROUP_BYTES + (ch & 3) * 16;
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) *(uint4*)(d + sp * 64) = o[sp];
+  }
+}
+
+// image of the TRANSPOSE: image row n, reduction index m:  image[n][m/32][plane][m%32] = split(src[row(m), n]),
+// 64 x 64 tiles through LDS.  ones_row: image row N is 1.0 for m < M (bias gradient operand).  Pad m >= M is zero.
+__global__ void __launch_bounds__(256) k_x3_split_t(const float* __restrict__ src, int64_t ld, const int64_t* __restrict__ rows,
+                                                    int64_t nrows_src, int64_t M, int N, int ones_row,
+                                                    unsigned char* __restrict__ img, int64_t row_bytes) {
+  __shared__ float tile[64][65];
+  const int64_t m0 = (int64_t)blockIdx.x * 64;
+  const int n0 = blockIdx.y * 64;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = (tid & 15) * 4;
+  const int G = (int)(row_bytes / X3_GROUP_BYTES);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t i = m0 + ty + 16 * k;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < M) {
+      const int64_t row = rows ? rows[i] : i;
+      if (!rows || (row >= 0 && row < nrows_src)) {
+        const float* p = src + row * ld + n0 + tx;
+        if (n0 + tx + 3 < N) v = ld16(p);
+        else {
+          if (n0 + tx < N) v.x = p[0];
+          if (n0 + tx + 1 < N) v.y = p[1];
+          if (n0 + tx + 2 < N) v.z = p[2];
+        }
+      }
+    }
+    tile[ty + 16 * k][tx] = v.x; tile[ty + 16 * k][tx + 1] = v.y; tile[ty + 16 * k][tx + 2] = v.z; tile[ty + 16 * k][tx + 3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int u = tid + 256 * k;                 // unit = (n local, group of the tile, 8-element chunk)
+    const int c = u & 3, gl = (u >> 2) & 1, nl = u >> 3;
+    const int n = n0 + nl;
+    const int64_t grp = m0 / 32 + gl;
+    if (n >= N || grp >= G) continue;
+    const int ml = gl * 32 + c * 8;
+    uint4 o[3];
+    split3(tile[ml + 0][nl], tile[ml + 1][nl], o[0].x, o[1].x, o[2].x);
+    split3(tile[ml + 2][nl], tile[ml + 3][nl], o[0].y, o[1].y, o[2].y);
+    split3(tile[ml + 4][nl], tile[ml + 5][nl], o[0].z, o[1].z, o[2].z);
+    split3(tile[ml + 6][nl], tile[ml + 7][nl], o[0].w, o[1].w, o[2].w);
+    unsigned char* d = img + (int64_t)n * row_bytes + grp * X3_GROUP_BYTES + c * 16;
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) *(uint4*)(d + sp * 64) = o[sp];
+  }
+  if (ones_row && blockIdx.y == 0 && tid < 8) {   // 8 chunks of 8 m: row N of the image
+    const int c = tid & 3, gl = tid >> 2;
+    const int64_t grp = m0 / 32 + gl;
+    if (grp < G) {
+      const int64_t mb = m0 + gl * 32 + c * 8;
+      unsigned w[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        w[q] = (mb + 2 * q < M ? 0x3F80u : 0u) | (mb + 2 * q + 1 < M ? 0x3F800000u : 0u);   // bf16 1.0 pairs
+      unsigned char* d = img + (int64_t)N * row_bytes + grp * X3_GROUP_BYTES + c * 16;
+      *(uint4*)d = make_uint4(w[0], w[1], w[2], w[3]);
+      *(uint4*)(d + 64) = make_uint4(0, 0, 0, 0);
+      *(uint4*)(d + 128) = make_uint4(0, 0, 0, 0);
+    }
+  }
+}
+
+extern "C" int64_t ogl_x3_row_bytes(int64_t K) {
+  if (K < 0) return OGL_EINVAL;
+  return ogl_cdiv(K, 32) * X3_GROUP_BYTES;
+}
+
+extern "C" int64_t ogl_x3_image_bytes(int64_t rows, int64_t K) {
+  if (rows < 0 || K < 0) return OGL_EINVAL;
+  return (rows + 1) * ogl_cdiv(K, 32) * X3_GROUP_BYTES;
+}
+
+extern "C" int ogl_x3_split(const float* src, int64_t ld, const int64_t* rows, int64_t nrows_src, int64_t R, int K, int append,
+                            const float* append_vec, void* image, ogl_stream_t stream) {
+  if (R < 0 || K < 0 || ld < K || append < 0 || append > 2 || (append == 2 && R > 0 && !append_vec)) return OGL_EINVAL;
+  const int Ki = K + (append ? 1 : 0);   // reduction length of the image
+  if (Ki == 0) return OGL_OK;
+  if (!image || (R > 0 && K > 0 && !src) || ((uintptr_t)image & 15)) return OGL_EINVAL;
+  const int64_t row_bytes = ogl_cdiv(Ki, 32) * X3_GROUP_BYTES;
+  const int64_t total = (R + 1) * (row_bytes / X3_GROUP_BYTES) * 4;
+  hipLaunchKernelGGL(k_x3_split, dim3((unsigned)min((int64_t)65536, ogl_cdiv(total, 256))), dim3(256), 0, (hipStream_t)stream, src,
+                     ld, rows, nrows_src, R, K, append, append_vec, (unsigned char*)image, row_bytes);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+extern "C" int ogl_x3_split_t(const float* src, int64_t ld, const int64_t* rows, int64_t nrows_src, int64_t M, int N, int ones_row,
+                              void* image, ogl_stream_t stream) {
+  if (M < 0 || N < 0 || ld < N) return OGL_EINVAL;
+  if (M == 0) return OGL_OK;
+  if (!image || (N > 0 && !src) || ((uintptr_t)image & 15)) return OGL_EINVAL;
+  const int64_t row_bytes = ogl_cdiv(M, 32) * X3_GROUP_BYTES;
+  const int64_t img_rows = (int64_t)N + (ones_row ? 1 : 0);
+  OGL_CHECK_HIP(hipMemsetAsync((unsigned char*)image + img_rows * row_bytes, 0, (size_t)row_bytes, (hipStream_t)stream));   // zero row
+  if (N == 0 && !ones_row) return OGL_OK;
+  dim3 grid((unsigned)ogl_cdiv(M, 64), (unsigned)(N > 0 ? ogl_cdiv(N, 64) : 1));
+  hipLaunchKernelGGL(k_x3_split_t, grid, dim3(256), 0, (hipStream_t)stream, src, ld, rows, nrows_src, M, N, ones_row,
+                     (unsigned char*)image, row_bytes);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+// 0: 256 x 128 (4 x 2 waves of 64 x 64)   1: 128 x 128 (2 x 4 waves of 64 x 32)
+static int x3_config(int64_t M, int64_t N) {
+  const int64_t w0 = ogl_cdiv(M, 256) * 256 * ogl_cdiv(N, 128) * 128;
+  const int64_t w1 = ogl_cdiv(M, 128) * 128 * ogl_cdiv(N, 128) * 128;
+  return w1 * 10 < w0 * 9 ? 1 : 0;   // the wider wave tile unless it pads > 10 % more MFMA work
+}
+
+static int launch_x3(X3Args& g, hipStream_t stream) {
+  if (g.M <= 0 || g.N <= 0) return OGL_OK;
+  const int cfg = x3_config(g.M, g.N);
+  const int BM = cfg == 0 ? 256 : 128, BN = 128;
+  g.NI = (int)ogl_cdiv(g.M, BM);
+  g.NJ = (int)ogl_cdiv(g.N, BN);
+  const int64_t T = (int64_t)g.NI * g.NJ * g.nsplit;
+  dim3 grid((unsigned)(8 * std::min<int64_t>(32, ogl_cdiv(T, 8)))), block(512);   // persistent: at most one block per CU
+  if (cfg == 0) hipLaunchKernelGGL((k_gemm_x3<4, 2, 2, 2>), grid, block, 0, stream, g);
+  else hipLaunchKernelGGL((k_gemm_x3<2, 4, 2, 1>), grid, block, 0, stream, g);
+  OGL_CHECK_LAUNCH();
+  if (g.nsplit > 1) {
+    hipLaunchKernelGGL(k_x3_splitk_reduce, dim3((unsigned)min((int64_t)2048, ogl_cdiv(g.M * g.N, 256))), dim3(256), 0, stream, g);
+    OGL_CHECK_LAUNCH();
+  }
+  return OGL_OK;
+}
+
+extern "C" int ogl_linear_fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M,
+                                 int K, const void* w_img, int N, int relu, float* y, int64_t ldy, ogl_stream_t stream) {
+  if (M < 0 || K <= 0 || N < 0 || x_img_rows < 0 || x_nrows < 0 || x_nrows > x_img_rows || ldy < N) return OGL_EINVAL;
+  if (M == 0 || N == 0) return OGL_OK;
+  if (!x_img || !w_img || !y || (!x_rows && M > x_img_rows)) return OGL_EINVAL;
+  X3Args g = X3Args();
+  const int64_t rb = ogl_cdiv(K, 32) * X3_GROUP_BYTES;
+  g.a = X3Operand{(const unsigned char*)x_img, rb, x_rows, x_rows ? x_nrows : x_img_rows, x_img_rows};
+  g.b = X3Operand{(const unsigned char*)w_img, rb, nullptr, N, N};
+  g.M = M; g.N = N; g.nsteps = (int)ogl_cdiv(K, 32);
+  g.C = y; g.ldc = ldy; g.relu = relu; g.nsplit = 1;
+  return launch_x3(g, (hipStream_t)stream);
+}
+
+// split plan of the weight gradient: one round of blocks (one 8-wave block per CU), >= 8 steps per block
+static void x3_bww_plan(int64_t M, int N, int K, int* nsplit, int* sps) {
+  const int64_t steps = ogl_cdiv(M, 32);
+  const int cfg = x3_config(N, K + 1);
+  const int64_t tiles = ogl_cdiv(N, cfg == 0 ? 256 : 128) * ogl_cdiv(K + 1, 128);
+  int64_t s = 256 / (tiles > 0 ? tiles : 1);
+  if (s < 1) s = 1;
+  if (steps / s < 8) s = steps / 8 > 0 ? steps / 8 : 1;
+  *sps = (int)ogl_cdiv(steps > 0 ? steps : 1, s);
+  *nsplit = (int)ogl_cdiv(steps > 0 ? steps : 1, *sps);
+}
+
+extern "C" int64_t ogl_linear_bwd_weight_x3_workspace_bytes(int64_t M, int N, int K) {
+  if (M < 0 || N < 0 || K < 0) return OGL_EINVAL;
+  int nsplit, sps;
+  x3_bww_plan(M, N, K, &nsplit, &sps);
+  if (nsplit <= 1) return 16;
+  return (int64_t)nsplit * N * ogl_round_up(K + 1, 4) * 4;
+}
+
+extern "C" int ogl_linear_bwd_weight_x3(const void* dyT_img, const void* xT_img, int64_t M, int N, int K, float* dw,
+                                        int64_t lddw, float* db, void* workspace, int64_t workspace_bytes,
+                                        ogl_stream_t stream) {
+  if (M <= 0 || N < 0 || K < 0 || lddw < K) return OGL_EINVAL;
+  if (N == 0) return OGL_OK;
+  if (!dw || !dyT_img || !xT_img) return OGL_EINVAL;
+  X3Args g = X3Args();
+  const int64_t rb = ogl_cdiv(M, 32) * X3_GROUP_BYTES;
+  g.a = X3Operand{(const unsigned char*)dyT_img, rb, nullptr, N, N};
+  g.b = X3Operand{(const unsigned char*)xT_img, rb, nullptr, (int64_t)K + 1, (int64_t)K + 1};   // row K = the all-ones row
+  g.M = N; g.N = K + 1; g.ones_col = 1; g.nsteps = (int)ogl_cdiv(M, 32);
+  g.C = dw; g.ldc = lddw; g.db = db;
+  x3_bww_plan(M, N, K, &g.nsplit, &g.steps_per_split);
+  if (g.nsplit > 1) {
+    g.ws_ld = ogl_round_up(K + 1, 4);
+    if (!workspace || workspace_bytes < (int64_t)g.nsplit * N * g.ws_ld * 4) return OGL_EWORKSPACE;
+    g.ws = (float*)workspace;
+  }
+  return launch_x3(g, (hipStream_t)stream);
+}

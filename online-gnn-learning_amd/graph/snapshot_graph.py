@@ -57,6 +57,7 @@ class SnapshotGraph:
         assert feat.shape[0] == n
         self.feat_table = ops.empty_mat(n, feat.shape[1], self.device)   # rows padded to 128 B multiples
         self.feat_table.copy_(feat.to(self.device))
+        ops.register_static_table(self.feat_table)          # layer-0 projections read its pre-split image (built lazily)
         target = torch.as_tensor(np.asarray(target)).reshape(n, -1)[:, :1].to(torch.int64)
         self.target_table = target.to(self.device).contiguous()
         self.edata = {}

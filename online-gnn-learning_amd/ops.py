@@ -244,6 +244,13 @@ def linear_fwd(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_ro
         K2 = x2.shape[1]
         assert w2.shape == (N, K2)
         assert (x2_rows.numel() if x2_rows is not None else x2.shape[0]) == M
+    if out is None and _x3_forward_ok(x, M, x2):
+        # rows of a registered static table: pre-split image of the table, the weights are split (with the bias in the
+        # appended slot) per call — 12 us for a 602 x 602 matrix
+        img = _static_image(x)
+        if img is not None:
+            bvec = bias if bias is not None else torch.zeros(N, dtype=torch.float32, device=x.device)
+            return linear_fwd_x3(img, x_rows, x3_split(w, append_vec=bvec), relu=relu, x_nrows=x.shape[0], M=M)
     y = out if out is not None else empty_mat(M, N, x.device)
     _launch("ogl_linear_fwd", _lib.lib().ogl_linear_fwd, 
         _ptr(x), _ld(x), _ptr(x_rows), x.shape[0], M, K, _ptr(w), _ld(w), N, _ptr(bias),
@@ -317,12 +324,115 @@ def linear_bwd_weight_t(dyT, xT, want_bias=True):
     return dw, db
 
 
+class X3Image:
+    """bf16x3 image of an fp32 matrix (include/ogl_hip.h, "pre-split operands"): ``rows`` image rows over a reduction of
+    length ``K``.  ``buf`` is the raw device allocation (ogl_x3_image_bytes)."""
+
+    def __init__(self, buf, rows, K):
+        self.buf, self.rows, self.K = buf, int(rows), int(K)
+
+    @property
+    def nbytes(self):
+        return self.buf.numel()
+
+
+def _x3_alloc(rows, K, device):
+    n = int(_lib.lib().ogl_x3_image_bytes(rows, K))
+    return torch.empty(max(n, 16), dtype=torch.uint8, device=device)
+
+
+def x3_split(x, rows=None, append_ones=False, append_vec=None):
+    """Image of x[rows] (or of x): one image row per matrix row, reduction over the columns.  ``append_ones`` /
+    ``append_vec`` add the extra reduction element that folds a bias into the product (activations / weights side)."""
+    x = as_mat(x)
+    R = rows.numel() if rows is not None else x.shape[0]
+    K = x.shape[1]
+    append = 2 if append_vec is not None else (1 if append_ones else 0)
+    Ki = K + (1 if append else 0)
+    buf = _x3_alloc(R, Ki, x.device)
+    _launch("ogl_x3_split", _lib.lib().ogl_x3_split, _ptr(x), _ld(x), _ptr(_ids(rows) if rows is not None else None), x.shape[0],
+            R, K, append, _ptr(append_vec), _ptr(buf), _stream(), meta=dict(R=R, K=K))
+    return X3Image(buf, R, Ki)
+
+
+def x3_split_t(x, rows=None, ones_row=False):
+    """Image of x[rows].T (reduction over the M rows); ``ones_row`` appends the all-ones image row."""
+    x = as_mat(x)
+    M = rows.numel() if rows is not None else x.shape[0]
+    N = x.shape[1]
+    nimg = N + (1 if ones_row else 0)
+    buf = _x3_alloc(nimg, M, x.device)
+    _launch("ogl_x3_split_t", _lib.lib().ogl_x3_split_t, _ptr(x), _ld(x), _ptr(_ids(rows) if rows is not None else None), x.shape[0],
+            M, N, 1 if ones_row else 0, _ptr(buf), _stream(), meta=dict(M=M, N=N))
+    return X3Image(buf, nimg, M)
+
+
+def linear_fwd_x3(x_img, x_rows, w_img, relu=False, x_nrows=None, M=None):
+    """y = act(x_img[x_rows] @ w_img.T); a bias is folded into the images (x3_split append_ones / append_vec).
+    ``x_nrows`` bounds the valid gather ids (default: every image row); without a gather ``M`` selects a row prefix."""
+    M = x_rows.numel() if x_rows is not None else (x_img.rows if M is None else M)
+    x_nrows = x_img.rows if x_nrows is None else x_nrows
+    K, N = x_img.K, w_img.rows
+    assert w_img.K == K, "both images must be built with the same append choice"
+    y = empty_mat(M, N, x_img.buf.device)
+    _launch("ogl_linear_fwd_x3", _lib.lib().ogl_linear_fwd_x3, _ptr(x_img.buf), x_img.rows,
+            _ptr(_ids(x_rows) if x_rows is not None else None), x_nrows, M, K, _ptr(w_img.buf), N, 1 if relu else 0, _ptr(y),
+            _ld(y), _stream(), meta=dict(M=M, K=K, N=N, K2=0))
+    return y
+
+
+def linear_bwd_weight_x3(dyT_img, xT_img, want_bias=True):
+    """dw [N, K], db [N] from the images of dy.T ([N rows, M]) and [x | 1].T ([K + 1 rows, M])."""
+    N, M, K = dyT_img.rows, dyT_img.K, xT_img.rows - 1
+    assert xT_img.K == M
+    dev = dyT_img.buf.device
+    dw = torch.empty((N, K), dtype=torch.float32, device=dev)
+    db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
+    nbytes = int(_lib.lib().ogl_linear_bwd_weight_x3_workspace_bytes(M, N, K))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    _launch("ogl_linear_bwd_weight_x3", _lib.lib().ogl_linear_bwd_weight_x3, _ptr(dyT_img.buf), _ptr(xT_img.buf), M, N, K, _ptr(dw),
+            _ld(dw), _ptr(db), _ptr(ws), nbytes, _stream(), meta=dict(M=M, K=K, N=N))
+    return dw, db
+
+
+# Static tables (the resident feature table) are split ONCE; projections that gather their rows from such a table and
+# are large enough run on the pre-split kernels.  Keyed by the allocation, so row-prefix views (ndata['feat'] of a
+# snapshot) resolve to the same image.
+_X3_TABLES = {}
+X3_BWW_MIN_ROWS = 16384   # weight gradients with at least this many reduction rows use the image kernels
+X3_MIN_ROWS = 8192        # below this the on-the-fly kernel is as fast (one wave of tiles either way)
+
+
+def register_static_table(table):
+    """Declare ``table`` (a [rows, cols] matrix whose contents never change) as a projection input: its bf16x3 image
+    (+ the bias slot) is built lazily on first use and reused by every forward pass."""
+    table = as_mat(table)
+    _X3_TABLES[(table.data_ptr(), _ld(table), table.shape[1])] = [table, None]
+
+
+def _static_image(x):
+    ent = _X3_TABLES.get((x.data_ptr(), _ld(x), x.shape[1])) if x.dim() == 2 else None
+    if ent is None or x.shape[0] > ent[0].shape[0]:
+        return None
+    if ent[1] is None:
+        ent[1] = x3_split(ent[0], append_ones=True)
+    return ent[1]
+
+
+def _x3_forward_ok(x, M, x2):
+    return (_MODE["name"] != "f32" and x2 is None and M >= X3_MIN_ROWS and x.is_cuda and x.dim() == 2
+            and (x.data_ptr(), _ld(x), x.shape[1]) in _X3_TABLES)
+
+
 def weight_grad(dy, x, x_rows=None, want_bias=True, dyT=None):
     """dW, db of a projection.  In the bf16x6 / auto arithmetic both operands are transposed first (two LDS-tiled
     copies) so the product runs on the reduction-contiguous split-bf16 path; the exact-fp32 mode keeps the direct
     k-major kernel.  ``dyT`` lets the two weight gradients of a dual-input Linear share one transpose."""
     if _MODE["name"] == "f32" or dy.shape[0] < 1024:
         return linear_bwd_weight(dy, x, None, x_rows, want_bias=want_bias)
+    if dyT is None and dy.shape[0] >= X3_BWW_MIN_ROWS:
+        # both operands as bf16x3 images of their transposes (one fused gather + transpose + split pass each)
+        return linear_bwd_weight_x3(x3_split_t(dy), x3_split_t(x, x_rows, ones_row=True), want_bias=want_bias)
     if dyT is None:
         dyT = transpose(dy)
     return linear_bwd_weight_t(dyT, transpose(x, x_rows), want_bias=want_bias)

@@ -1,0 +1,222 @@
+"""Pre-split ("bf16x3 image") projections through the C-ABI: image format bit-exact against a numpy model of the
+split, forward GEMM bit-identical to the on-the-fly x6 kernel (same products, same order) and within the GEMM
+tolerance of fp64, gather semantics, weight gradient + bias gradient.  Run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GEMM_RTOL, GEMM_ATOL = 1e-4, 1e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops as _ops
+    return _ops
+
+
+def bf16_split3(x):
+    """numpy/torch-CPU model of split3 (csrc/x6_arith.h): three round-to-nearest-even bf16 terms, residuals in fp32."""
+    x = torch.as_tensor(x, dtype=torch.float32)
+    h = x.to(torch.bfloat16)
+    r = x - h.float()
+    m = r.to(torch.bfloat16)
+    s = r - m.float()
+    l = s.to(torch.bfloat16)
+    return h, m, l
+
+
+def image_model(x):
+    """[R, K] fp32 -> uint8 image [(R + 1), ceil(K/32), 3, 32] bf16 as raw bytes (include/ogl_hip.h)."""
+    R, K = x.shape
+    G = (K + 31) // 32
+    pad = torch.zeros((R + 1, G * 32), dtype=torch.float32)
+    pad[:R, :K] = x
+    planes = torch.stack(bf16_split3(pad), 0)                     # [3, R+1, G*32] bf16
+    img = planes.view(3, R + 1, G, 32).permute(1, 2, 0, 3).contiguous()
+    return img.view(torch.int16).numpy().view(np.uint8).reshape(-1)
+
+
+@pytest.mark.parametrize("R,K", [(1, 1), (7, 31), (33, 32), (50, 33), (129, 602), (5, 1204)])
+def test_image_bit_exact(ops, R, K):
+    torch.manual_seed(R * 1000 + K)
+    x = torch.randn(R, K) * torch.logspace(-3, 3, K)[None, :]
+    xm = ops.empty_mat(R, K, "cuda"); xm.copy_(x)
+    img = ops.x3_split(xm)
+    assert img.rows == R and img.K == K and img.nbytes == (R + 1) * ((K + 31) // 32) * 192
+    assert np.array_equal(img.buf.cpu().numpy(), image_model(x))
+    # the split is exact: the three terms sum back to the fp32 value
+    h, m, l = bf16_split3(x)
+    assert torch.equal((h.float() + m.float()) + l.float(), x)
+    # appended reduction element: ones on the activations side (zero row included), a vector on the weights side
+    vec = torch.randn(R)
+    ones = torch.cat([x, torch.ones(R, 1)], 1)
+    want1 = image_model(ones).reshape(R + 1, -1).copy()
+    want1[R] = image_model(torch.cat([torch.zeros(1, K), torch.ones(1, 1)], 1)).reshape(2, -1)[0]
+    assert np.array_equal(ops.x3_split(xm, append_ones=True).buf.cpu().numpy(), want1.reshape(-1))
+    img2 = ops.x3_split(xm, append_vec=vec.cuda())
+    assert img2.K == K + 1
+    assert np.array_equal(img2.buf.cpu().numpy(), image_model(torch.cat([x, vec[:, None]], 1)))
+
+
+@pytest.mark.parametrize("M,N,ones", [(1, 1, False), (40, 7, True), (64, 64, True), (65, 130, False), (1000, 41, True), (2500, 602, True)])
+def test_transposed_image_bit_exact(ops, M, N, ones):
+    torch.manual_seed(M + N)
+    T = M + 13
+    tab = torch.randn(T, N)
+    rows = torch.randint(0, T, (M,))
+    tm = ops.empty_mat(T, N, "cuda"); tm.copy_(tab)
+    img = ops.x3_split_t(tm, rows.cuda(), ones_row=ones)
+    want = tab[rows].T.contiguous()
+    if ones:
+        want = torch.cat([want, torch.ones(1, M)], 0)
+    assert img.rows == N + int(ones) and img.K == M
+    assert np.array_equal(img.buf.cpu().numpy(), image_model(want))
+    img2 = ops.x3_split_t(tm[:M], None, ones_row=ones)           # ungathered
+    want2 = tab[:M].T.contiguous()
+    if ones:
+        want2 = torch.cat([want2, torch.ones(1, M)], 0)
+    assert np.array_equal(img2.buf.cpu().numpy(), image_model(want2))
+
+
+@pytest.mark.parametrize("M,K,N,relu", [(1, 1, 1, False), (37, 33, 5, True), (255, 602, 41, False), (257, 64, 129, True),
+                                         (1000, 602, 602, True), (3000, 1204, 256, False), (513, 31, 600, True),
+                                         (700, 32, 130, False), (2600, 608, 602, True)])
+def test_forward_matches_on_the_fly_x6_and_fp64(ops, M, K, N, relu):
+    torch.manual_seed(M * 7 + K + N)
+    T = M + 50
+    tab = torch.randn(T, K); w = torch.randn(N, K) / np.sqrt(K); b = torch.randn(N)
+    rows = torch.randint(0, T, (M,))
+    tm = ops.empty_mat(T, K, "cuda"); tm.copy_(tab)
+    wc, bc, rc = w.cuda(), b.cuda(), rows.cuda()
+    # bias folded into the images (one extra reduction element: ones on the x side, the bias on the w side)
+    got = ops.linear_fwd_x3(ops.x3_split(tm, append_ones=True), rc, ops.x3_split(wc, append_vec=bc), relu=relu)
+    want = tab[rows].double() @ w.double().T + b.double()
+    if relu:
+        want = want.clamp_min(0)
+    np.testing.assert_allclose(got.cpu().numpy(), want.float().numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL)
+    # without a bias the products and their order are those of the on-the-fly x6 kernel: bit-identical
+    got0 = ops.linear_fwd_x3(ops.x3_split(tm), rc, ops.x3_split(wc), relu=relu)
+    old = ops.get_gemm_mode()
+    try:
+        ops.set_gemm_mode("bf16x6")
+        ref = ops.linear_fwd(tm, wc, None, relu=relu, x_rows=rc)
+    finally:
+        ops.set_gemm_mode(old)
+    if N > 64 or M > 4096:                                        # (the skinny kernel sums K in another order)
+        assert torch.equal(got0, ref)
+    # ungathered operand
+    got2 = ops.linear_fwd_x3(ops.x3_split(tm[:M]), None, ops.x3_split(wc), relu=False)
+    np.testing.assert_allclose(got2.cpu().numpy(), (tab[:M].double() @ w.double().T).float().numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL)
+
+
+def test_forward_many_tiles_per_block(ops):
+    """More row tiles than CUs: every persistent block walks several tiles (cross-tile prefetch, stores left in flight)."""
+    torch.manual_seed(11)
+    M, K, N = 256 * 300 + 17, 70, 200
+    x = torch.randn(M, K); w = torch.randn(N, K); b = torch.randn(N)
+    xm = ops.empty_mat(M, K, "cuda"); xm.copy_(x)
+    got = ops.linear_fwd_x3(ops.x3_split(xm, append_ones=True), None, ops.x3_split(w.cuda(), append_vec=b.cuda()), relu=True)
+    want = (x.double() @ w.double().T + b.double()).clamp_min(0).float()
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL)
+    y2 = ops.linear_fwd_x3(ops.x3_split(xm, append_ones=True), None, ops.x3_split(w.cuda(), append_vec=b.cuda()), relu=True)
+    assert torch.equal(got, y2)
+
+
+def test_forward_out_of_range_rows_are_zero_rows(ops):
+    torch.manual_seed(3)
+    tab = torch.randn(20, 40); w = torch.randn(9, 40); b = torch.randn(9)
+    tm = ops.empty_mat(20, 40, "cuda"); tm.copy_(tab)
+    rows = torch.tensor([3, 20, -1, 19, 10**9, 2**32 + 3], dtype=torch.int64).cuda()
+    y = ops.linear_fwd_x3(ops.x3_split(tm, append_ones=True), rows, ops.x3_split(w.cuda(), append_vec=b.cuda())).cpu()
+    np.testing.assert_allclose(y[0].numpy(), (tab[3] @ w.T + b).numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(y[3].numpy(), (tab[19] @ w.T + b).numpy(), rtol=1e-4, atol=1e-5)
+    for i in (1, 2, 4, 5):
+        assert torch.equal(y[i], b)                               # zero row . w + bias: the bias exactly
+    y0 = ops.linear_fwd_x3(ops.x3_split(tm), rows, ops.x3_split(w.cuda())).cpu()
+    assert (y0[[1, 2, 4, 5]] == 0).all()
+    # a row-prefix bound below the image's row count: ids in [x_nrows, image rows) read the zero row, not table rows
+    y1 = ops.linear_fwd_x3(ops.x3_split(tm), rows, ops.x3_split(w.cuda()), x_nrows=19).cpu()
+    assert (y1[3] == 0).all() and torch.equal(y1[0], y0[0])
+    # ungathered row prefix
+    y2 = ops.linear_fwd_x3(ops.x3_split(tm), None, ops.x3_split(w.cuda()), M=7).cpu()
+    np.testing.assert_allclose(y2.numpy(), (tab[:7] @ w.T).numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_registered_table_dispatch(ops):
+    """ops.linear_fwd / weight_grad route large products over a registered static table to the image kernels."""
+    torch.manual_seed(4)
+    T, K, N, M = 30000, 70, 50, 20000
+    tab = ops.empty_mat(T, K, "cuda"); tab.normal_()
+    w = torch.randn(N, K).cuda(); b = torch.randn(N).cuda()
+    rows = torch.randint(0, T - 100, (M,)).cuda()
+    old = ops.get_gemm_mode()
+    try:
+        ops.set_gemm_mode("auto")
+        ref = ops.linear_fwd(tab, w, b, relu=True, x_rows=rows)          # not registered: on-the-fly kernel
+        ops.register_static_table(tab)
+        ops.profile_start()
+        got = ops.linear_fwd(tab[:T - 100], w, b, relu=True, x_rows=rows)   # a row-prefix view resolves to the same image
+        full = ops.linear_fwd(tab[:T - 100], w, b, relu=True)
+        dy = ops.empty_mat(M, N, "cuda"); dy.normal_()
+        dw, db = ops.weight_grad(dy, tab, rows)
+        names = [r[0] for r in ops.profile_stop()]
+    finally:
+        ops.set_gemm_mode(old)
+        ops._X3_TABLES.clear()
+    assert names.count("ogl_linear_fwd_x3") == 2 and "ogl_linear_bwd_weight_x3" in names and "ogl_linear_fwd" not in names
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    want_full = (tab[:T - 100].double() @ w.double().T + b.double()).clamp_min(0).float()
+    np.testing.assert_allclose(full.cpu().numpy(), want_full.cpu().numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL)
+    want_w = (dy.double().T @ tab[rows].double()).float()
+    np.testing.assert_allclose(dw.cpu().numpy(), want_w.cpu().numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL * 150)
+    np.testing.assert_allclose(db.cpu().numpy(), dy.double().sum(0).float().cpu().numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL * 150)
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 1, 1), (100, 33, 7), (1024, 602, 602), (7000, 602, 600), (20000, 256, 41), (333, 1204, 130)])
+def test_weight_gradient(ops, M, K, N):
+    torch.manual_seed(M + K * 3 + N)
+    T = M + 9
+    tab = torch.randn(T, K); dy = torch.randn(M, N)
+    rows = torch.randint(0, T, (M,))
+    tm = ops.empty_mat(T, K, "cuda"); tm.copy_(tab)
+    dym = ops.empty_mat(M, N, "cuda"); dym.copy_(dy)
+    dw, db = ops.linear_bwd_weight_x3(ops.x3_split_t(dym), ops.x3_split_t(tm, rows.cuda(), ones_row=True))
+    scale = max(1.0, np.sqrt(M))
+    want_w = (dy.double().T @ tab[rows].double()).float()
+    np.testing.assert_allclose(dw.cpu().numpy(), want_w.numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL * scale)
+    np.testing.assert_allclose(db.cpu().numpy(), dy.double().sum(0).float().numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL * scale)
+    dw2, db2 = ops.linear_bwd_weight_x3(ops.x3_split_t(dym), ops.x3_split_t(tm, rows.cuda(), ones_row=True), want_bias=False)
+    assert db2 is None and torch.equal(dw, dw2)                   # deterministic (fixed split-K order)
+
+
+def test_x3_accuracy_ill_scaled(ops):
+    """< 1e-6 * sum|a||b| of fp64 on an ill-scaled K = 4096 product (the bound the on-the-fly x6 path is held to)."""
+    torch.manual_seed(5)
+    M, K, N = 300, 4096, 200
+    a = torch.randn(M, K) * torch.logspace(-4, 4, K)[None, :]
+    b = torch.randn(N, K) * torch.logspace(4, -4, K)[None, :]
+    am = ops.empty_mat(M, K, "cuda"); am.copy_(a)
+    bm = ops.empty_mat(N, K, "cuda"); bm.copy_(b)
+    got = ops.linear_fwd_x3(ops.x3_split(am), None, ops.x3_split(bm)).cpu().double()
+    want = a.double() @ b.double().T
+    bound = a.double().abs() @ b.double().abs().T
+    assert float(((got - want).abs() / bound).max()) < 1e-6
+
+
+def test_status_codes(ops):
+    import ctypes as C
+    from ogl_amd import _lib
+    h = _lib.lib()
+    assert h.ogl_x3_row_bytes(602) == 19 * 192 and h.ogl_x3_image_bytes(10, 33) == 11 * 2 * 192
+    assert h.ogl_x3_row_bytes(-1) == -1
+    x = torch.zeros(4, 8).cuda(); img = torch.zeros(4096, dtype=torch.uint8).cuda()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    assert h.ogl_x3_split(p(x), 4, None, 0, 4, 8, 0, None, p(img), None) == -1   # ld < K
+    assert h.ogl_x3_split(p(x), 8, None, 0, 4, 8, 0, None, None, None) == -1     # no image
+    assert h.ogl_x3_split(p(x), 8, None, 0, 4, 8, 2, None, p(img), None) == -1   # append = vector without a vector
+    assert h.ogl_linear_fwd_x3(p(img), 4, None, 4, 9, 8, p(img), 4, 0, p(x), 8, None) == -1   # M > image rows, no gather
+    assert h.ogl_linear_fwd_x3(p(img), 4, p(img), 5, 4, 8, p(img), 4, 0, p(x), 8, None) == -1   # id bound beyond the image
+    assert h.ogl_linear_bwd_weight_x3(p(img), p(img), 64, 4, 4, p(x), 8, None, None, 0, None) in (0, -4)

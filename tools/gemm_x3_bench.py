@@ -1,0 +1,57 @@
+"""Micro-benchmark of the pre-split (bf16x3 image) projections against the on-the-fly x6 GEMM at the layer-0 shapes."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import ogl_amd  # noqa
+from ogl_amd import ops
+
+
+def timeit(fn, iters=20):
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    ops.set_gemm_mode("auto")
+    torch.manual_seed(0)
+    n0, F = 62750, 602
+    T = 232965
+    table = ops.empty_mat(T, F, "cuda"); table.normal_()
+    rows0 = torch.randint(0, T, (n0,), device="cuda")
+    wp = torch.randn(F, F, device="cuda") / 25
+    b = torch.randn(F, device="cuda")
+    dp0 = ops.empty_mat(n0, F, "cuda"); dp0.normal_()
+    fl = 2.0 * n0 * F * F
+
+    def rep(name, ms, flops=None):
+        print("%-56s %8.3f ms  %s" % (name, ms, "%7.1f TFLOP/s" % (flops / ms / 1e9) if flops else ""), flush=True)
+    t_img = ops.x3_split(table, append_ones=True)
+    w_img = ops.x3_split(wp, append_vec=b)
+    rep("x3_split table [%d,602] (once per dataset)" % T, timeit(lambda: ops.x3_split(table), 3))
+    rep("x3_split weight [602,602] (+bias)", timeit(lambda: ops.x3_split(wp, append_vec=b)))
+    rep("fwd pool0 on-the-fly x6 (rows+relu)", timeit(lambda: ops.linear_fwd(table, wp, b, relu=True, x_rows=rows0)), fl)
+    rep("fwd pool0 x3 images (rows+relu)", timeit(lambda: ops.linear_fwd_x3(t_img, rows0, w_img, relu=True)), fl)
+    rep("fwd whole table x3 [%d]" % T, timeit(lambda: ops.linear_fwd_x3(t_img, None, w_img, relu=True), 5), 2.0 * T * F * F)
+    rep("fwd whole table on-the-fly x6", timeit(lambda: ops.linear_fwd(table, wp, b, relu=True), 5), 2.0 * T * F * F)
+    rep("transpose dy + transpose x[rows] (fp32)", timeit(lambda: (ops.transpose(dp0), ops.transpose(table, rows0))))
+    rep("x3_split_t dy + x3_split_t x[rows] (+ones)", timeit(lambda: (ops.x3_split_t(dp0), ops.x3_split_t(table, rows0, ones_row=True))))
+    dyT, xT = ops.transpose(dp0), ops.transpose(table, rows0)
+    rep("bwd_weight_t pool0 on-the-fly x6", timeit(lambda: ops.linear_bwd_weight_t(dyT, xT)), fl)
+    dyI, xI = ops.x3_split_t(dp0), ops.x3_split_t(table, rows0, ones_row=True)
+    rep("bwd_weight pool0 x3 images", timeit(lambda: ops.linear_bwd_weight_x3(dyI, xI)), fl)
+    n1, H = 7054, 600
+    x1 = ops.empty_mat(n1, F, "cuda"); x1.normal_()
+    ws_ = torch.randn(H, F, device="cuda") / 25
+    rep("fwd [n1,602]->600 on-the-fly x6", timeit(lambda: ops.linear_fwd(x1, ws_, b[:H], relu=True)), 2.0 * n1 * H * F)
+    xi1 = ops.x3_split(x1, append_ones=True); wi1 = ops.x3_split(ws_, append_vec=b[:H])
+    rep("fwd [n1,602]->600 x3", timeit(lambda: ops.linear_fwd_x3(xi1, None, wi1, relu=True)), 2.0 * n1 * H * F)
+    rep("x3_split [n1,602]", timeit(lambda: ops.x3_split(x1)))
+
+
+if __name__ == "__main__":
+    main()
