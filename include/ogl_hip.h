@@ -183,7 +183,10 @@ int ogl_transpose(const float* src, int64_t ld, const int64_t* rows, int64_t nro
  *                   bias argument.
  *   ogl_x3_split_t  image row n = split(src[row(0:M), n]) for n < N: the image of the TRANSPOSE (reduction over the M
  *                   source rows); ones_row != 0 appends image row N = 1.0 for m < M (bias-gradient operand).  The image
- *                   then has N + 1 (+ zero) rows: size it with ogl_x3_image_bytes(N + 1, M).
+ *                   then has N + 1 (+ zero) rows: size it with ogl_x3_image_bytes(N + 1, M).  interleave = G > 0 deals
+ *                   the reduction index round-robin over G groups of 32 (the layout ogl_pool_bwd_x3 produces): the
+ *                   image's reduction length becomes 32 * G (>= M required) and index m holds source row
+ *                   (m % 32) * G + m / 32, zeros where that is >= M; the ones row covers every index < 32 * G.
  *   ogl_linear_fwd_x3         y[M,N] = act(x_img[row(i), :] . w_img^T), K = the images' reduction length (both built
  *                             with the same append choice); x image [x_img_rows, K] (x_img_rows = the R it was built
  *                             with: the zero row sits there) with optional gather by x_rows (ids outside
@@ -192,12 +195,26 @@ int ogl_transpose(const float* src, int64_t ld, const int64_t* rows, int64_t nro
  *   ogl_linear_bwd_weight_x3  dw[N,K], db[N] (nullable) from the images of dy^T ([N rows, M]) and [x | 1]^T
  *                             ([K + 1 rows, M], ones_row = 1)
  * ---------------------------------------------------------------------------------------- */
+/* Backward of relu -> max-pool over sampled neighbours, fused down to the weight-gradient operand (pool_bwd_x3.hip):
+ * the bf16x3 image of dP^T, where dP[s, f] = sum over {i : argmax[i, f] == s} of dout[i, f] * [relu_out[i, f] > 0]
+ * (relu_out nullable: no mask) is what ogl_reduce_bwd(OGL_REDUCE_MAX) would scatter — without materialising dP and
+ * without global float atomics.  idx32 = the block's [n_dst, fanout] local indices (argmax values are drawn from it);
+ * fanout <= 63, d <= 640.
+ * The image has d rows over a reduction of length 32 * G, G = ceil(n_src / 32), and its reduction index is DEALT
+ * round-robin: index m stands for source row (m % 32) * G + m / 32 (sources >= n_src contribute zeros), so that
+ * frequently sampled sources — numbered first by block builders — spread over all 32-deep groups.  Build the other
+ * operand of the weight-gradient product with the same dealing: ogl_x3_split_t(..., interleave = G).
+ * image: ogl_x3_image_bytes(d, 32 * G) bytes. */
+int64_t ogl_pool_bwd_x3_workspace_bytes(int64_t n_dst, int fanout, int d, int64_t n_src);
+int ogl_pool_bwd_x3(const float* dout, int64_t ldo, const int32_t* argmax, const float* relu_out, int64_t ldr,
+                    const int32_t* idx32, int64_t n_dst, int fanout, int d, int64_t n_src, void* image,
+                    void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
 int64_t ogl_x3_row_bytes(int64_t K);
 int64_t ogl_x3_image_bytes(int64_t rows, int64_t K);
 int ogl_x3_split(const float* src, int64_t ld, const int64_t* rows, int64_t nrows, int64_t R, int K, int append,
                  const float* append_vec, void* image, ogl_stream_t stream);
 int ogl_x3_split_t(const float* src, int64_t ld, const int64_t* rows, int64_t nrows, int64_t M, int N, int ones_row,
-                   void* image, ogl_stream_t stream);
+                   int64_t interleave, void* image, ogl_stream_t stream);
 int ogl_linear_fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
                       const void* w_img, int N, int relu, float* y, int64_t ldy, ogl_stream_t stream);
 int64_t ogl_linear_bwd_weight_x3_workspace_bytes(int64_t M, int N, int K);

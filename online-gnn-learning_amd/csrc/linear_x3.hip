@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(256) k_x3_split(const float* __restrict__ src,
 // image of the TRANSPOSE: image row n, reduction index m:  image[n][m/32][plane][m%32] = split(src[row(m), n]),
 // 64 x 64 tiles through LDS.  ones_row: image row N is 1.0 for m < M (bias gradient operand).  Pad m >= M is zero.
 __global__ void __launch_bounds__(256) k_x3_split_t(const float* __restrict__ src, int64_t ld, const int64_t* __restrict__ rows,
-                                                    int64_t nrows_src, int64_t M, int N, int ones_row,
+                                                    int64_t nrows_src, int64_t M, int N, int ones_row, int64_t G_il, int64_t Mi,
                                                     unsigned char* __restrict__ img, int64_t row_bytes) {
   __shared__ float tile[64][65];
   const int64_t m0 = (int64_t)blockIdx.x * 64;
@@ -353,9 +353,10 @@ __global__ void __launch_bounds__(256) k_x3_split_t(const float* __restrict__ sr
   const int G = (int)(row_bytes / X3_GROUP_BYTES);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int64_t i = m0 + ty + 16 * k;
+    const int64_t ip = m0 + ty + 16 * k;                          // position in the image's reduction index
+    const int64_t i = G_il ? (ip & 31) * G_il + (ip >> 5) : ip;   // the source row it stands for (round-robin dealing)
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < M) {
+    if (ip < Mi && i < M) {
       const int64_t row = rows ? rows[i] : i;
       if (!rows || (row >= 0 && row < nrows_src)) {
         const float* p = src + row * ld + n0 + tx;
@@ -395,7 +396,7 @@ __global__ void __launch_bounds__(256) k_x3_split_t(const float* __restrict__ sr
       unsigned w[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        w[q] = (mb + 2 * q < M ? 0x3F80u : 0u) | (mb + 2 * q + 1 < M ? 0x3F800000u : 0u);   // bf16 1.0 pairs
+        w[q] = (mb + 2 * q < Mi ? 0x3F80u : 0u) | (mb + 2 * q + 1 < Mi ? 0x3F800000u : 0u);   // bf16 1.0 pairs
       unsigned char* d = img + (int64_t)N * row_bytes + grp * X3_GROUP_BYTES + c * 16;
       *(uint4*)d = make_uint4(w[0], w[1], w[2], w[3]);
       *(uint4*)(d + 64) = make_uint4(0, 0, 0, 0);
@@ -429,16 +430,17 @@ extern "C" int ogl_x3_split(const float* src, int64_t ld, const int64_t* rows, i
 }
 
 extern "C" int ogl_x3_split_t(const float* src, int64_t ld, const int64_t* rows, int64_t nrows_src, int64_t M, int N, int ones_row,
-                              void* image, ogl_stream_t stream) {
-  if (M < 0 || N < 0 || ld < N) return OGL_EINVAL;
+                              int64_t interleave, void* image, ogl_stream_t stream) {
+  if (M < 0 || N < 0 || ld < N || interleave < 0 || (interleave > 0 && 32 * interleave < M)) return OGL_EINVAL;
   if (M == 0) return OGL_OK;
   if (!image || (N > 0 && !src) || ((uintptr_t)image & 15)) return OGL_EINVAL;
-  const int64_t row_bytes = ogl_cdiv(M, 32) * X3_GROUP_BYTES;
+  const int64_t Mi = interleave ? 32 * interleave : M;            // reduction length of the image
+  const int64_t row_bytes = ogl_cdiv(Mi, 32) * X3_GROUP_BYTES;
   const int64_t img_rows = (int64_t)N + (ones_row ? 1 : 0);
   OGL_CHECK_HIP(hipMemsetAsync((unsigned char*)image + img_rows * row_bytes, 0, (size_t)row_bytes, (hipStream_t)stream));   // zero row
   if (N == 0 && !ones_row) return OGL_OK;
-  dim3 grid((unsigned)ogl_cdiv(M, 64), (unsigned)(N > 0 ? ogl_cdiv(N, 64) : 1));
-  hipLaunchKernelGGL(k_x3_split_t, grid, dim3(256), 0, (hipStream_t)stream, src, ld, rows, nrows_src, M, N, ones_row,
+  dim3 grid((unsigned)ogl_cdiv(Mi, 64), (unsigned)(N > 0 ? ogl_cdiv(N, 64) : 1));
+  hipLaunchKernelGGL(k_x3_split_t, grid, dim3(256), 0, (hipStream_t)stream, src, ld, rows, nrows_src, M, N, ones_row, interleave, Mi,
                      (unsigned char*)image, row_bytes);
   OGL_CHECK_LAUNCH();
   return OGL_OK;

@@ -1,0 +1,240 @@
+// Backward of the layer-0 'pool' aggregator, fused down to the operand the weight-gradient GEMM consumes.
+//
+// Forward (aggregate.hip / linear*.hip): P = relu(fc_pool(X[input_nodes])), out[d, f] = max_j P[idx[d, j], f] with
+// argmax[d, f] = the winning block-local source row (R/train/graphsage/pytorch/aggregator_dgl.py:85-94,171: DGL's
+// 'pool' SAGEConv = fc_pool -> ReLU -> max).  Backward: dP[s, f] = sum over {d : argmax[d, f] == s} of
+// dout[d, f] * [out[d, f] > 0], and for layer 0 dP has ONE consumer — the weight gradient dW = dP^T . X, which
+// wants dP^T as a bf16x3 image (linear_x3.hip).  The unfused path is three passes over the [n_src, D] matrix (zero
+// fill, float-atomic scatter at the L2 atomic rate, transpose + split); here dP is never materialised:
+//
+//   k_pool_bucket    one wave per destination: finds the sampling slot of every winner, counting-sorts the row's D
+//                    (column, gradient) entries by slot (LDS), writes them with the slot offsets, and marks
+//                    bitmap[group][d] for every source group the destination samples (atomicOr, order-free).
+//   k_pool_bwd_x3    one block per source group (32 sources = one 32-deep reduction group of the image): 16-lane
+//                    teams take the group's destinations, read ONLY the entry segments whose slot points into the
+//                    group and add them into the group's 32 x D slab in LDS (ds_add_f32); then the slab is split and
+//                    written as the group's 192-byte pieces of every image row.
+//
+// Sources are dealt to groups ROUND-ROBIN (source s sits in group s % G, lane s / G; G = number of groups): block
+// builders number frequently sampled vertices first, and contiguous groups would put all the hubs — and a long serial
+// tail — into the first few blocks.  The image's reduction index m therefore stands for source (m & 31) * G + (m >> 5);
+// the other operand of the product is built with the same dealing (ogl_x3_split_t, interleave = G).
+//
+// HBM-bound integer/float streaming: 3 D floats read + 8 D bytes written per destination by the bucket pass, then
+// 8 bytes read per entry (each entry is read once) and 6 bytes written per slab element.
+#include "x6_arith.h"
+
+#define PB_THREADS 640              // 10 waves = 40 teams of 16 lanes
+#define PB_TEAMS (PB_THREADS / 16)
+#define PB_CHUNK_WORDS 64           // bitmap words per list chunk: 2048 destinations, uint16 offsets
+#define PB_MAX_D 640                // columns per destination row the bucket pass keeps in registers (10 per lane)
+#define PB_MAX_S 63                 // sampling slots (one lane each, plus one lane for the end offset)
+
+struct PbDiv { unsigned mul; unsigned shift; unsigned G; };   // floor(x / G) = (x * mul) >> shift for 0 <= x < 2^31
+__device__ __forceinline__ unsigned pb_div(unsigned x, PbDiv v) { return (unsigned)(((uint64_t)x * v.mul) >> v.shift); }
+
+__global__ void __launch_bounds__(256) k_pool_bucket(const float* __restrict__ dout, int64_t ldo, const int32_t* __restrict__ argmax,
+                                                     const float* __restrict__ relu_out, int64_t ldr,
+                                                     const int32_t* __restrict__ idx, int64_t n_dst, int S, int D, int64_t n_src,
+                                                     PbDiv dv, unsigned* __restrict__ bitmap, int64_t words,
+                                                     unsigned short* __restrict__ off, uint2* __restrict__ ent) {
+  __shared__ int cnt[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t d = (int64_t)blockIdx.x * 4 + wv;
+  if (d >= n_dst) return;
+  const int my = lane < S ? idx[d * S + lane] : -1;
+  if (my >= 0 && my < n_src) {
+    const unsigned q = pb_div((unsigned)my, dv);
+    atomicOr(&bitmap[(int64_t)((unsigned)my - q * dv.G) * words + (d >> 5)], 1u << (d & 31));
+  }
+  cnt[wv][lane] = 0;
+  constexpr int NI = PB_MAX_D / 64;
+  int slot[NI], pos[NI];
+  float gv[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int f = lane + 64 * i;
+    const bool in = f < D;
+    const int fc = in ? f : 0;
+    const int a = argmax[d * D + fc];
+    gv[i] = dout[d * ldo + fc];
+    const float m = relu_out ? relu_out[d * ldr + fc] : 1.f;
+    const bool ok = in && a >= 0 && a < n_src && m > 0.f;
+    int sl = -1;
+    for (int j = 0; j < S; ++j) {
+      const int sj = __shfl(my, j);
+      if (ok && sl < 0 && sj == a) sl = j;      // the FIRST slot holding the winner (duplicate samples own nothing)
+    }
+    slot[i] = sl;
+    pos[i] = sl >= 0 ? atomicAdd(&cnt[wv][sl], 1) : 0;
+  }
+  // exclusive scan of the S bucket sizes (lane j = bucket j, lane S = end)
+  const int c = cnt[wv][lane];
+  int s = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(s, o);
+    if (lane >= o) s += v;
+  }
+  const int start = s - c;
+  if (lane <= S) off[d * (S + 1) + lane] = (unsigned short)start;
+  cnt[wv][lane] = start;
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+    if (slot[i] >= 0)
+      ent[d * D + cnt[wv][slot[i]] + pos[i]] = make_uint2((unsigned)(lane + 64 * i), __float_as_uint(gv[i]));
+}
+
+__global__ void __launch_bounds__(PB_THREADS) k_pool_bwd_x3(const int32_t* __restrict__ idx, int S, const unsigned short* __restrict__ off,
+                                                            const uint2* __restrict__ ent, const unsigned* __restrict__ bitmap,
+                                                            int64_t words, int64_t n_src, PbDiv dv, int D, int DP,
+                                                            unsigned char* __restrict__ img, int64_t row_bytes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pb_smem[];
+  float* T = (float*)pb_smem;                                     // [32][DP] slab of dP for this source group
+  unsigned short* list = (unsigned short*)(T + 32 * DP);          // destinations of the current chunk (offsets)
+  int* scan = (int*)(list + PB_CHUNK_WORDS * 32);                 // [PB_CHUNK_WORDS + 1] prefix of the chunk's popcounts
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  for (int i = tid; i < 32 * DP; i += PB_THREADS) T[i] = 0.f;
+  const unsigned* bm = bitmap + (int64_t)b * words;
+  const int team = tid >> 4, tl = tid & 15;
+  const int tshift = tid & 48;                                    // first lane of this team inside its wave
+
+  for (int64_t w0 = 0; w0 < words; w0 += PB_CHUNK_WORDS) {
+    // ---- list of this group's destinations inside the chunk --------------------------------------------------------
+    const int nw = (int)min((int64_t)PB_CHUNK_WORDS, words - w0);
+    unsigned word = 0;
+    if (tid < nw) word = bm[w0 + tid];
+    __syncthreads();                                              // previous chunk's list fully consumed (and T zeroed)
+    if (tid < PB_CHUNK_WORDS) scan[tid + 1] = __popc(word);
+    if (tid == 0) scan[0] = 0;
+    __syncthreads();
+    if (tid < 64) {                                               // one wave: inclusive scan of the 64 counts
+      int s = scan[tid + 1];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(s, o);
+        if (tid >= o) s += v;
+      }
+      scan[tid + 1] = s;
+    }
+    __syncthreads();
+    const int L = scan[PB_CHUNK_WORDS];
+    if (tid < nw) {
+      int pos = scan[tid];
+      unsigned wbits = word;
+      while (wbits) {
+        const int bit = __builtin_ctz(wbits);
+        wbits &= wbits - 1;
+        list[pos++] = (unsigned short)(tid * 32 + bit);
+      }
+    }
+    __syncthreads();
+    // ---- one destination per 16-lane team: slots whose source belongs to this group -> their entry segments ---------
+    const int64_t dbase = w0 * 32;
+    const int rounds = (L + PB_TEAMS - 1) / PB_TEAMS;             // wave-uniform trip count (the ballots below need whole waves)
+    for (int rd = 0; rd < rounds; ++rd) {
+      const int i = rd * PB_TEAMS + team;
+      const bool live = i < L;
+      const int64_t d = dbase + list[live ? i : 0];
+      for (int r = 0; 16 * r < S; ++r) {                          // lane tl looks at slots tl, tl + 16, ...
+        const int j = tl + 16 * r;
+        int a = -1, lo = 0, hi = 0;
+        if (live && j < S) {
+          a = idx[d * S + j];
+          lo = off[d * (S + 1) + j];
+          hi = off[d * (S + 1) + j + 1];
+        }
+        int sloc = -1;
+        if (a >= 0 && a < n_src && hi > lo) {
+          const unsigned q = pb_div((unsigned)a, dv);
+          if ((unsigned)a - q * dv.G == (unsigned)b) sloc = (int)q;
+        }
+        unsigned mask = (unsigned)((__ballot(sloc >= 0) >> tshift) & 0xFFFFull);   // this team's matching slots
+        // teams of one wave run the loop together: it ends when the slowest team has no slot left
+        while (__any(mask != 0)) {
+          const int src_lane = mask ? __builtin_ctz(mask) : 0;
+          const bool act = mask != 0;
+          mask &= mask - 1;
+          const int sl = __shfl(sloc, tshift + src_lane);
+          const int e0 = __shfl(lo, tshift + src_lane), e1 = __shfl(hi, tshift + src_lane);
+          if (act)
+            for (int e = e0 + tl; e < e1; e += 16) {
+              const uint2 en = ent[d * D + e];
+              __hip_atomic_fetch_add(&T[sl * DP + (int)en.x], __uint_as_float(en.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- emit: image row f, group b = split(T[0..31][f]); one 16-byte piece (plane p, chunk c) per unit, 12 consecutive
+  // lanes write the 192 contiguous bytes of one row's group ------------------------------------------------------------
+  for (int u = tid; u < D * 12; u += PB_THREADS) {
+    const int fo = u / 12, j = u - fo * 12;
+    const int p = j >> 2, c = j & 3;
+    const float* col = T + (8 * c) * DP + fo;
+    unsigned o[3][4];
+    split3(col[0], col[DP], o[0][0], o[1][0], o[2][0]);
+    split3(col[2 * DP], col[3 * DP], o[0][1], o[1][1], o[2][1]);
+    split3(col[4 * DP], col[5 * DP], o[0][2], o[1][2], o[2][2]);
+    split3(col[6 * DP], col[7 * DP], o[0][3], o[1][3], o[2][3]);
+    const unsigned* sel = p == 0 ? o[0] : (p == 1 ? o[1] : o[2]);
+    *(uint4*)(img + (int64_t)fo * row_bytes + (int64_t)b * 192 + p * 64 + c * 16) = make_uint4(sel[0], sel[1], sel[2], sel[3]);
+  }
+}
+
+static inline int64_t pb_words(int64_t n_dst) { return ogl_cdiv(n_dst, 32); }
+static inline int64_t pb_bitmap_bytes(int64_t n_dst, int64_t n_src) { return ogl_round_up(ogl_cdiv(n_src, 32) * pb_words(n_dst) * 4 + 16, 256); }
+static inline int64_t pb_off_bytes(int64_t n_dst, int fanout) { return ogl_round_up(n_dst * (fanout + 1) * 2 + 16, 256); }
+
+static PbDiv pb_make_div(unsigned G) {
+  unsigned l = 0;
+  while ((1ull << l) < G) ++l;                                    // l = ceil(log2 G)
+  PbDiv v;
+  v.G = G;
+  v.mul = (unsigned)((1ull << (31 + l)) / G + 1);                 // < 2^32; exact quotients for every x < 2^31
+  v.shift = 31 + l;
+  return v;
+}
+
+extern "C" int64_t ogl_pool_bwd_x3_workspace_bytes(int64_t n_dst, int fanout, int d, int64_t n_src) {
+  if (n_dst < 0 || n_src < 0 || fanout < 0 || d < 0) return OGL_EINVAL;
+  return pb_bitmap_bytes(n_dst, n_src) + pb_off_bytes(n_dst, fanout) + ogl_round_up(n_dst * (int64_t)d * 8 + 16, 256);
+}
+
+extern "C" int ogl_pool_bwd_x3(const float* dout, int64_t ldo, const int32_t* argmax, const float* relu_out, int64_t ldr,
+                               const int32_t* idx32, int64_t n_dst, int fanout, int d, int64_t n_src, void* image,
+                               void* workspace, int64_t workspace_bytes, ogl_stream_t stream) {
+  if (n_dst < 0 || fanout < 0 || d <= 0 || n_src <= 0 || ldo < d || (relu_out && ldr < d)) return OGL_EINVAL;
+  if (d > PB_MAX_D || fanout > PB_MAX_S || n_src >= (1ll << 31) || n_dst * (int64_t)d >= (1ll << 31)) return OGL_EINVAL;
+  if (!image || ((uintptr_t)image & 15)) return OGL_EINVAL;
+  if (n_dst > 0 && fanout > 0 && (!dout || !argmax || !idx32)) return OGL_EINVAL;
+  const int64_t groups = ogl_cdiv(n_src, 32), words = pb_words(n_dst);
+  if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < ogl_pool_bwd_x3_workspace_bytes(n_dst, fanout, d, n_src))
+    return OGL_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* bitmap = (unsigned*)workspace;
+  unsigned short* off = (unsigned short*)((unsigned char*)workspace + pb_bitmap_bytes(n_dst, n_src));
+  uint2* ent = (uint2*)((unsigned char*)off + pb_off_bytes(n_dst, fanout));
+  const int64_t row_bytes = groups * 192;
+  OGL_CHECK_HIP(hipMemsetAsync(bitmap, 0, (size_t)(groups * words * 4 + 16), st));
+  OGL_CHECK_HIP(hipMemsetAsync((unsigned char*)image + (int64_t)d * row_bytes, 0, (size_t)row_bytes, st));   // the image's zero row
+  const PbDiv dv = pb_make_div((unsigned)groups);
+  if (n_dst > 0 && fanout > 0) {
+    hipLaunchKernelGGL(k_pool_bucket, dim3((unsigned)ogl_cdiv(n_dst, 4)), dim3(256), 0, st, dout, ldo, argmax, relu_out, ldr, idx32,
+                       n_dst, fanout, d, n_src, dv, bitmap, words, off, ent);
+    OGL_CHECK_LAUNCH();
+  }
+  const int DP = d | 1;                                            // odd slab stride: conflict-free column reads in the emit phase
+  const size_t lds = (size_t)32 * DP * 4 + PB_CHUNK_WORDS * 32 * 2 + (PB_CHUNK_WORDS + 1) * 4 + 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OGL_CHECK_HIP(hipFuncSetAttribute((const void*)k_pool_bwd_x3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_pool_bwd_x3, dim3((unsigned)groups), dim3(PB_THREADS), lds, st, idx32, fanout, off, ent, bitmap, words, n_src,
+                     dv, d, DP, (unsigned char*)image, row_bytes);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}

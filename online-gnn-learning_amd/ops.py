@@ -355,16 +355,18 @@ def x3_split(x, rows=None, append_ones=False, append_vec=None):
     return X3Image(buf, R, Ki)
 
 
-def x3_split_t(x, rows=None, ones_row=False):
-    """Image of x[rows].T (reduction over the M rows); ``ones_row`` appends the all-ones image row."""
+def x3_split_t(x, rows=None, ones_row=False, interleave=0):
+    """Image of x[rows].T (reduction over the M rows); ``ones_row`` appends the all-ones image row; ``interleave`` = G
+    deals the reduction index round-robin over G groups of 32 (the layout of pool_bwd_x3)."""
     x = as_mat(x)
     M = rows.numel() if rows is not None else x.shape[0]
     N = x.shape[1]
     nimg = N + (1 if ones_row else 0)
-    buf = _x3_alloc(nimg, M, x.device)
+    Mi = 32 * interleave if interleave else M
+    buf = _x3_alloc(nimg, Mi, x.device)
     _launch("ogl_x3_split_t", _lib.lib().ogl_x3_split_t, _ptr(x), _ld(x), _ptr(_ids(rows) if rows is not None else None), x.shape[0],
-            M, N, 1 if ones_row else 0, _ptr(buf), _stream(), meta=dict(M=M, N=N))
-    return X3Image(buf, nimg, M)
+            M, N, 1 if ones_row else 0, interleave, _ptr(buf), _stream(), meta=dict(M=M, N=N))
+    return X3Image(buf, nimg, Mi)
 
 
 def linear_fwd_x3(x_img, x_rows, w_img, relu=False, x_nrows=None, M=None):
@@ -379,6 +381,23 @@ def linear_fwd_x3(x_img, x_rows, w_img, relu=False, x_nrows=None, M=None):
             _ptr(_ids(x_rows) if x_rows is not None else None), x_nrows, M, K, _ptr(w_img.buf), N, 1 if relu else 0, _ptr(y),
             _ld(y), _stream(), meta=dict(M=M, K=K, N=N, K2=0))
     return y
+
+
+def pool_bwd_x3(dout, argmax, relu_out, idx32, n_src):
+    """Image of dP^T for the relu -> max-pool backward (see include/ogl_hip.h): rows = features, reduction = the source
+    rows dealt round-robin over G = ceil(n_src / 32) groups (build the other operand with x3_split_t(interleave=G))."""
+    dout = as_mat(dout)
+    n_dst, d = dout.shape
+    assert idx32.dtype == torch.int32 and idx32.is_contiguous() and argmax.dtype == torch.int32 and argmax.is_contiguous()
+    G = (n_src + 31) // 32
+    buf = _x3_alloc(d, 32 * G, dout.device)
+    nbytes = int(_lib.lib().ogl_pool_bwd_x3_workspace_bytes(n_dst, idx32.shape[1], d, n_src))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dout.device)
+    relu_out = as_mat(relu_out) if relu_out is not None else None
+    _launch("ogl_pool_bwd_x3", _lib.lib().ogl_pool_bwd_x3, _ptr(dout), _ld(dout), _ptr(argmax), _ptr(relu_out),
+            _ld(relu_out) if relu_out is not None else 0, _ptr(idx32), n_dst, idx32.shape[1], d, n_src, _ptr(buf), _ptr(ws), nbytes,
+            _stream(), meta=dict(n_dst=n_dst, d=d, n_src=n_src, fanout=idx32.shape[1]))
+    return X3Image(buf, d, 32 * G)
 
 
 def linear_bwd_weight_x3(dyT_img, xT_img, want_bias=True):
@@ -564,14 +583,22 @@ class _PoolMaxFn(torch.autograd.Function):
         need = x.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad)
         out, argmax = reduce_fwd(p, idx, "max", want_argmax=need)
         ctx.n_src, ctx.fanout, ctx.has_bias = p.shape[0], idx.shape[1], bias is not None
-        ctx.save_for_backward(x, w, x_rows, out, argmax)
+        ctx.save_for_backward(x, w, x_rows, out, argmax, idx if idx.dtype == torch.int32 else None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, w, x_rows, out, argmax = ctx.saved_tensors
-        dp = reduce_bwd(dout, None, argmax, "max", ctx.n_src, fanout=ctx.fanout, relu_out=out)
+        x, w, x_rows, out, argmax, idx32 = ctx.saved_tensors
         need = ctx.needs_input_grad
+        if (not need[0] and idx32 is not None and _MODE["name"] != "f32" and ctx.n_src >= X3_BWW_MIN_ROWS
+                and out.shape[1] <= 640 and ctx.fanout <= 63 and (need[1] or (need[2] and ctx.has_bias))):
+            # layer 0: the projection input carries no gradient, so dP has one consumer — the weight gradient — and goes
+            # straight from (dout, argmax) to the image of its transpose
+            dyT = pool_bwd_x3(dout, argmax, out, idx32, ctx.n_src)
+            dw, db = linear_bwd_weight_x3(dyT, x3_split_t(x, x_rows, ones_row=True, interleave=(ctx.n_src + 31) // 32),
+                                          want_bias=ctx.has_bias)
+            return None, dw, (db if ctx.has_bias else None), None, None
+        dp = reduce_bwd(dout, None, argmax, "max", ctx.n_src, fanout=ctx.fanout, relu_out=out)
         dx = dw = db = None
         if need[0]:
             if x_rows is not None:

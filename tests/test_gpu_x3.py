@@ -220,3 +220,102 @@ def test_status_codes(ops):
     assert h.ogl_linear_fwd_x3(p(img), 4, None, 4, 9, 8, p(img), 4, 0, p(x), 8, None) == -1   # M > image rows, no gather
     assert h.ogl_linear_fwd_x3(p(img), 4, p(img), 5, 4, 8, p(img), 4, 0, p(x), 8, None) == -1   # id bound beyond the image
     assert h.ogl_linear_bwd_weight_x3(p(img), p(img), 64, 4, 4, p(x), 8, None, None, 0, None) in (0, -4)
+
+
+def image_decode(buf, rows, K):
+    """uint8 image -> [rows, ceil(K/32)*32] fp32 (the three planes summed; exact)."""
+    G = (K + 31) // 32
+    raw = torch.as_tensor(buf.cpu().numpy().view(np.int16).reshape(rows + 1, G, 3, 32)).view(torch.bfloat16).float()
+    return ((raw[:, :, 0] + raw[:, :, 1]) + raw[:, :, 2]).reshape(rows + 1, G * 32)[:rows]
+
+
+@pytest.mark.parametrize("M,N,G", [(40, 7, 2), (64, 64, 2), (1000, 41, 32), (2500, 130, 79), (33, 5, 4)])
+def test_transposed_image_interleaved(ops, M, N, G):
+    """interleave = G: image reduction index m holds source row (m % 32) * G + m // 32 (zeros past M)."""
+    torch.manual_seed(M + N + G)
+    tab = torch.randn(M + 5, N)
+    rows = torch.randint(0, M + 5, (M,))
+    tm = ops.empty_mat(M + 5, N, "cuda"); tm.copy_(tab)
+    img = ops.x3_split_t(tm, rows.cuda(), ones_row=True, interleave=G)
+    assert img.rows == N + 1 and img.K == 32 * G
+    m = np.arange(32 * G)
+    s_of_m = (m % 32) * G + m // 32
+    want = torch.zeros(N + 1, 32 * G)
+    ok = s_of_m < M
+    want[:N, ok] = tab[rows[s_of_m[ok]]].T
+    want[N, :] = 1.0
+    assert np.array_equal(img.buf.cpu().numpy(), image_model(want))
+
+
+@pytest.mark.parametrize("n_dst,S,D,n_src,relu", [(1, 1, 1, 1, True), (50, 4, 33, 70, True), (300, 25, 602, 2000, True),
+                                                   (2500, 10, 130, 900, False), (700, 25, 64, 40, True), (4100, 25, 40, 5000, True)])
+def test_pool_backward_image(ops, n_dst, S, D, n_src, relu):
+    """Fused relu->max backward == fp32 scatter of the winners' gradients, as the dealt transposed image."""
+    torch.manual_seed(n_dst + D)
+    rng = np.random.default_rng(n_dst * 3 + D)
+    idx = rng.integers(0, n_src, (n_dst, S)).astype(np.int32)
+    idx[rng.random((n_dst, S)) < 0.05] = -1                           # missing neighbours
+    p = torch.randn(n_src, D).clamp_min(0)                            # ReLU'd projections: many exact zeros
+    pm = ops.empty_mat(n_src, D, "cuda"); pm.copy_(p)
+    out, argmax = ops.reduce_fwd(pm, torch.as_tensor(idx).cuda(), "max", want_argmax=True)
+    dout = torch.randn(n_dst, D)
+    dm = ops.empty_mat(n_dst, D, "cuda"); dm.copy_(dout)
+    img = ops.pool_bwd_x3(dm, argmax, out if relu else None, torch.as_tensor(idx).cuda(), n_src)
+    G = (n_src + 31) // 32
+    assert img.rows == D and img.K == 32 * G
+    a = argmax.cpu().numpy(); o = out.cpu().numpy(); g = dout.numpy()
+    dP = np.zeros((n_src, D), np.float64)
+    cnt = np.zeros((n_src, D), np.int64)
+    cols = np.arange(D)
+    for d in range(n_dst):
+        m = a[d] >= 0
+        if relu:
+            m &= o[d] > 0
+        dP[a[d, m], cols[m]] += g[d, m]
+        cnt[a[d, m], cols[m]] += 1
+    got = image_decode(img.buf, D, 32 * G).numpy()                     # [D, 32 G], dealt
+    mm = np.arange(32 * G)
+    s_of_m = (mm % 32) * G + mm // 32
+    ok = s_of_m < n_src
+    assert (got[:, ~ok] == 0).all()
+    got_s = np.zeros((n_src, D), np.float32)
+    got_s[s_of_m[ok]] = got[:, ok].T
+    # cells with at most two contributions are order-independent: exactly the fp32 sum
+    two = cnt <= 2
+    assert np.array_equal(got_s[two], dP.astype(np.float32)[two]) or np.allclose(got_s[two], dP[two], rtol=0, atol=0)
+    np.testing.assert_allclose(got_s, dP, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(dP).max()))
+    # the unfused path agrees
+    dP2 = ops.reduce_bwd(dm, None, argmax, "max", n_src, fanout=S, relu_out=out if relu else None)
+    np.testing.assert_allclose(dP2.cpu().numpy(), dP, rtol=1e-4, atol=1e-4)
+
+
+def test_pool_max_autograd_uses_fused_backward(ops):
+    """pool_max over a registered table: backward runs pool_bwd_x3 + the image weight gradient and matches the unfused path."""
+    torch.manual_seed(8)
+    T, K, H, n_src, n_dst, S = 40000, 50, 48, 20000, 1500, 25
+    tab = ops.empty_mat(T, K, "cuda"); tab.normal_()
+    rows = torch.randperm(T)[:n_src].cuda()
+    idx = torch.randint(0, n_src, (n_dst, S), dtype=torch.int32).cuda()
+    w = (torch.randn(H, K) / 7).cuda(); b = torch.randn(H).cuda()
+    gout = torch.randn(n_dst, H).cuda()
+    res = {}
+    old = ops.get_gemm_mode()
+    try:
+        ops.set_gemm_mode("auto")
+        for tag in ("unfused", "fused"):
+            if tag == "fused":
+                ops.register_static_table(tab)
+            wv, bv = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            ops.profile_start()
+            out = ops.pool_max(tab, wv, bv, idx, rows)
+            out.backward(gout)
+            names = [r[0] for r in ops.profile_stop()]
+            res[tag] = (out.detach(), wv.grad, bv.grad, names)
+    finally:
+        ops.set_gemm_mode(old)
+        ops._X3_TABLES.clear()
+    assert "ogl_pool_bwd_x3" in res["fused"][3] and "ogl_reduce_bwd" not in res["fused"][3]
+    np.testing.assert_allclose(res["fused"][0].cpu().numpy(), res["unfused"][0].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    scale = float(res["unfused"][1].abs().max())
+    np.testing.assert_allclose(res["fused"][1].cpu().numpy(), res["unfused"][1].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+    np.testing.assert_allclose(res["fused"][2].cpu().numpy(), res["unfused"][2].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
