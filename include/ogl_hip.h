@@ -183,7 +183,10 @@ int ogl_transpose(const float* src, int64_t ld, const int64_t* rows, int64_t nro
  *                   bias argument.
  *   ogl_x3_split_t  image row n = split(src[row(0:M), n]) for n < N: the image of the TRANSPOSE (reduction over the M
  *                   source rows); ones_row != 0 appends image row N = 1.0 for m < M (bias-gradient operand).  The image
- *                   then has N + 1 (+ zero) rows: size it with ogl_x3_image_bytes(N + 1, M).  interleave = G > 0 deals
+ *                   then has N + 1 (+ zero) rows: size it with ogl_x3_image_bytes(N + 1, M).  Transposed images are
+ *                   stored GROUP-MAJOR — [group][image row][192 bytes] instead of [image row][group][192 bytes] — so
+ *                   that the rows of one reduction step are contiguous for their producers and for the GEMM's
+ *                   stage loads; they are consumed only by ogl_linear_bwd_weight_x3.  interleave = G > 0 deals
  *                   the reduction index round-robin over G groups of 32 (the layout ogl_pool_bwd_x3 produces): the
  *                   image's reduction length becomes 32 * G (>= M required) and index m holds source row
  *                   (m % 32) * G + m / 32, zeros where that is >= M; the ones row covers every index < 32 * G.

@@ -25,7 +25,8 @@
 
 struct X3Operand {
   const unsigned char* img;
-  int64_t row_bytes;
+  int64_t row_bytes;     // distance between two image rows
+  int64_t step_bytes;    // distance between two consecutive 32-deep groups of one row
   const int64_t* rows;   // optional gather (A only)
   int64_t nrows;         // valid row ids are [0, nrows)
   int64_t zero_row;      // index of the image's all-zero row (>= nrows): where invalid ids and tile padding point
@@ -115,12 +116,12 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
       if (u < NLOAD_A) {
         const int64_t id = rid[u < NLOAD_A ? u : 0];
         const bool ok = t.i0 + r < g.M && id >= 0 && id < g.a.nrows;
-        rowp = g.a.img + (ok ? id : g.a.zero_row) * g.a.row_bytes;
+        rowp = g.a.img + (ok ? id : g.a.zero_row) * g.a.row_bytes + (int64_t)t.ks_begin * g.a.step_bytes;
       } else {
         const int64_t gj = t.j0 + (r - BM);
-        rowp = g.b.img + (gj < g.N ? gj : g.b.zero_row) * g.b.row_bytes;
+        rowp = g.b.img + (gj < g.N ? gj : g.b.zero_row) * g.b.row_bytes + (int64_t)t.ks_begin * g.b.step_bytes;
       }
-      src[u] = rowp + (int64_t)t.ks_begin * X3_GROUP_BYTES + p * 64 + c * 16;
+      src[u] = rowp + p * 64 + c * 16;
     }
   };
 
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
 #pragma unroll
     for (int u = 0; u < NLOAD; ++u) {
       __builtin_amdgcn_global_load_lds((gptr_t)src[u], (lptr_t)(smem + buf * STAGE + (u * NT + wid * 64) * 16), 16, 0, 0);
-      src[u] += X3_GROUP_BYTES;
+      src[u] += u < NLOAD_A ? g.a.step_bytes : g.b.step_bytes;
     }
   };
 
@@ -341,8 +342,9 @@ __global__ void __launch_bounds__(256) k_x3_split(const float* __restrict__ src,
   }
 }
 
-// image of the TRANSPOSE: image row n, reduction index m:  image[n][m/32][plane][m%32] = split(src[row(m), n]),
-// 64 x 64 tiles through LDS.  ones_row: image row N is 1.0 for m < M (bias gradient operand).  Pad m >= M is zero.
+// image of the TRANSPOSE: image row n, reduction index m, stored GROUP-MAJOR (the rows of one 32-deep reduction step are
+// contiguous: one tile of this kernel writes two 12 KB runs, and a GEMM stage reads one run):
+// image[m/32][n][plane][m%32] = split(src[row(m), n]), 64 x 64 tiles through LDS.  ones_row: image row N is 1.0 for m < M (bias gradient operand).  Pad m >= M is zero.
 __global__ void __launch_bounds__(256) k_x3_split_t(const float* __restrict__ src, int64_t ld, const int64_t* __restrict__ rows,
                                                     int64_t nrows_src, int64_t M, int N, int ones_row, int64_t G_il, int64_t Mi,
                                                     unsigned char* __restrict__ img, int64_t row_bytes) {
@@ -351,6 +353,8 @@ __global__ void __launch_bounds__(256) k_x3_split_t(const float* __restrict__ sr
   const int n0 = blockIdx.y * 64;
   const int tid = threadIdx.x, ty = tid >> 4, tx = (tid & 15) * 4;
   const int G = (int)(row_bytes / X3_GROUP_BYTES);
+  const int64_t zero_row = (int64_t)N + (ones_row ? 1 : 0);
+  const int64_t gstride = (zero_row + 1) * X3_GROUP_BYTES;       // GROUP-MAJOR image: [group][image row][192 B]
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int64_t ip = m0 + ty + 16 * k;                          // position in the image's reduction index
@@ -384,9 +388,14 @@ __global__ void __launch_bounds__(256) k_x3_split_t(const float* __restrict__ sr
     split3(tile[ml + 2][nl], tile[ml + 3][nl], o[0].y, o[1].y, o[2].y);
     split3(tile[ml + 4][nl], tile[ml + 5][nl], o[0].z, o[1].z, o[2].z);
     split3(tile[ml + 6][nl], tile[ml + 7][nl], o[0].w, o[1].w, o[2].w);
-    unsigned char* d = img + (int64_t)n * row_bytes + grp * X3_GROUP_BYTES + c * 16;
+    unsigned char* d = img + grp * gstride + (int64_t)n * X3_GROUP_BYTES + c * 16;
 #pragma unroll
     for (int sp = 0; sp < 3; ++sp) *(uint4*)(d + sp * 64) = o[sp];
+  }
+  if (blockIdx.y == 0 && tid >= 64 && tid < 64 + 24) {            // the zero row (last row of every group slab)
+    const int t = tid - 64, gl = t / 12;
+    const int64_t grp = m0 / 32 + gl;
+    if (grp < G) *(uint4*)(img + grp * gstride + zero_row * X3_GROUP_BYTES + (t - gl * 12) * 16) = make_uint4(0, 0, 0, 0);
   }
   if (ones_row && blockIdx.y == 0 && tid < 8) {   // 8 chunks of 8 m: row N of the image
     const int c = tid & 3, gl = tid >> 2;
@@ -397,7 +406,7 @@ __global__ void __launch_bounds__(256) k_x3_split_t(const float* __restrict__ sr
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         w[q] = (mb + 2 * q < Mi ? 0x3F80u : 0u) | (mb + 2 * q + 1 < Mi ? 0x3F800000u : 0u);   // bf16 1.0 pairs
-      unsigned char* d = img + (int64_t)N * row_bytes + grp * X3_GROUP_BYTES + c * 16;
+      unsigned char* d = img + grp * gstride + (int64_t)N * X3_GROUP_BYTES + c * 16;
       *(uint4*)d = make_uint4(w[0], w[1], w[2], w[3]);
       *(uint4*)(d + 64) = make_uint4(0, 0, 0, 0);
       *(uint4*)(d + 128) = make_uint4(0, 0, 0, 0);
@@ -436,9 +445,6 @@ extern "C" int ogl_x3_split_t(const float* src, int64_t ld, const int64_t* rows,
   if (!image || (N > 0 && !src) || ((uintptr_t)image & 15)) return OGL_EINVAL;
   const int64_t Mi = interleave ? 32 * interleave : M;            // reduction length of the image
   const int64_t row_bytes = ogl_cdiv(Mi, 32) * X3_GROUP_BYTES;
-  const int64_t img_rows = (int64_t)N + (ones_row ? 1 : 0);
-  OGL_CHECK_HIP(hipMemsetAsync((unsigned char*)image + img_rows * row_bytes, 0, (size_t)row_bytes, (hipStream_t)stream));   // zero row
-  if (N == 0 && !ones_row) return OGL_OK;
   dim3 grid((unsigned)ogl_cdiv(Mi, 64), (unsigned)(N > 0 ? ogl_cdiv(N, 64) : 1));
   hipLaunchKernelGGL(k_x3_split_t, grid, dim3(256), 0, (hipStream_t)stream, src, ld, rows, nrows_src, M, N, ones_row, interleave, Mi,
                      (unsigned char*)image, row_bytes);
@@ -478,8 +484,8 @@ extern "C" int ogl_linear_fwd_x3(const void* x_img, int64_t x_img_rows, const in
   if (!x_img || !w_img || !y || (!x_rows && M > x_img_rows)) return OGL_EINVAL;
   X3Args g = X3Args();
   const int64_t rb = ogl_cdiv(K, 32) * X3_GROUP_BYTES;
-  g.a = X3Operand{(const unsigned char*)x_img, rb, x_rows, x_rows ? x_nrows : x_img_rows, x_img_rows};
-  g.b = X3Operand{(const unsigned char*)w_img, rb, nullptr, N, N};
+  g.a = X3Operand{(const unsigned char*)x_img, rb, X3_GROUP_BYTES, x_rows, x_rows ? x_nrows : x_img_rows, x_img_rows};
+  g.b = X3Operand{(const unsigned char*)w_img, rb, X3_GROUP_BYTES, nullptr, N, N};
   g.M = M; g.N = N; g.nsteps = (int)ogl_cdiv(K, 32);
   g.C = y; g.ldc = ldy; g.relu = relu; g.nsplit = 1;
   return launch_x3(g, (hipStream_t)stream);
@@ -512,9 +518,10 @@ extern "C" int ogl_linear_bwd_weight_x3(const void* dyT_img, const void* xT_img,
   if (N == 0) return OGL_OK;
   if (!dw || !dyT_img || !xT_img) return OGL_EINVAL;
   X3Args g = X3Args();
-  const int64_t rb = ogl_cdiv(M, 32) * X3_GROUP_BYTES;
-  g.a = X3Operand{(const unsigned char*)dyT_img, rb, nullptr, N, N};
-  g.b = X3Operand{(const unsigned char*)xT_img, rb, nullptr, (int64_t)K + 1, (int64_t)K + 1};   // row K = the all-ones row
+  // transposed images are GROUP-MAJOR: [group][image row][192 B] (rows of one reduction step are contiguous)
+  g.a = X3Operand{(const unsigned char*)dyT_img, X3_GROUP_BYTES, ((int64_t)N + 1) * X3_GROUP_BYTES, nullptr, N, N};
+  g.b = X3Operand{(const unsigned char*)xT_img, X3_GROUP_BYTES, ((int64_t)K + 2) * X3_GROUP_BYTES, nullptr, (int64_t)K + 1,
+                  (int64_t)K + 1};   // row K = the all-ones row
   g.M = N; g.N = K + 1; g.ones_col = 1; g.nsteps = (int)ogl_cdiv(M, 32);
   g.C = dw; g.ldc = lddw; g.db = db;
   x3_bww_plan(M, N, K, &g.nsplit, &g.steps_per_split);

@@ -26,7 +26,7 @@
 
 #define PB_THREADS 640              // 10 waves = 40 teams of 16 lanes
 #define PB_TEAMS (PB_THREADS / 16)
-#define PB_CHUNK_WORDS 64           // bitmap words per list chunk: 2048 destinations, uint16 offsets
+#define PB_LIST 512                 // destinations per pass (uint16 offsets inside a super-chunk of 640 words)
 #define PB_MAX_D 640                // columns per destination row the bucket pass keeps in registers (10 per lane)
 #define PB_MAX_S 63                 // sampling slots (one lane each, plus one lane for the end offset)
 
@@ -88,88 +88,96 @@ __global__ void __launch_bounds__(256) k_pool_bucket(const float* __restrict__ d
 __global__ void __launch_bounds__(PB_THREADS) k_pool_bwd_x3(const int32_t* __restrict__ idx, int S, const unsigned short* __restrict__ off,
                                                             const uint2* __restrict__ ent, const unsigned* __restrict__ bitmap,
                                                             int64_t words, int64_t n_src, PbDiv dv, int D, int DP,
-                                                            unsigned char* __restrict__ img, int64_t row_bytes) {
+                                                            unsigned char* __restrict__ img, int64_t gstride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pb_smem[];
   float* T = (float*)pb_smem;                                     // [32][DP] slab of dP for this source group
-  unsigned short* list = (unsigned short*)(T + 32 * DP);          // destinations of the current chunk (offsets)
-  int* scan = (int*)(list + PB_CHUNK_WORDS * 32);                 // [PB_CHUNK_WORDS + 1] prefix of the chunk's popcounts
-  const int tid = threadIdx.x;
+  unsigned short* list = (unsigned short*)(T + 32 * DP);          // up to PB_LIST destinations of the current pass
+  int* wsum = (int*)(list + PB_LIST);                             // per-wave popcount totals of the current super-chunk
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.x;
   for (int i = tid; i < 32 * DP; i += PB_THREADS) T[i] = 0.f;
   const unsigned* bm = bitmap + (int64_t)b * words;
   const int team = tid >> 4, tl = tid & 15;
   const int tshift = tid & 48;                                    // first lane of this team inside its wave
 
-  for (int64_t w0 = 0; w0 < words; w0 += PB_CHUNK_WORDS) {
-    // ---- list of this group's destinations inside the chunk --------------------------------------------------------
-    const int nw = (int)min((int64_t)PB_CHUNK_WORDS, words - w0);
+  // super-chunks of PB_THREADS bitmap words (one word per thread: 20480 destinations); a typical group references
+  // ~100 destinations, so the whole list is built and consumed in one pass
+  for (int64_t w0 = 0; w0 < words; w0 += PB_THREADS) {
     unsigned word = 0;
-    if (tid < nw) word = bm[w0 + tid];
-    __syncthreads();                                              // previous chunk's list fully consumed (and T zeroed)
-    if (tid < PB_CHUNK_WORDS) scan[tid + 1] = __popc(word);
-    if (tid == 0) scan[0] = 0;
-    __syncthreads();
-    if (tid < 64) {                                               // one wave: inclusive scan of the 64 counts
-      int s = scan[tid + 1];
+    if (w0 + tid < words) word = bm[w0 + tid];
+    const int c = __popc(word);
+    int s = c;                                                    // inclusive scan inside the wave
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(s, o);
-        if (tid >= o) s += v;
-      }
-      scan[tid + 1] = s;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(s, o);
+      if (lane >= o) s += v;
     }
+    __syncthreads();                                              // previous super-chunk fully consumed (and T zeroed)
+    if (lane == 63) wsum[wv] = s;
     __syncthreads();
-    const int L = scan[PB_CHUNK_WORDS];
-    if (tid < nw) {
-      int pos = scan[tid];
-      unsigned wbits = word;
-      while (wbits) {
-        const int bit = __builtin_ctz(wbits);
-        wbits &= wbits - 1;
-        list[pos++] = (unsigned short)(tid * 32 + bit);
-      }
+    int before = 0, L = 0;
+#pragma unroll
+    for (int k = 0; k < PB_THREADS / 64; ++k) {
+      const int t = wsum[k];
+      if (k < wv) before += t;
+      L += t;
     }
-    __syncthreads();
-    // ---- one destination per 16-lane team: slots whose source belongs to this group -> their entry segments ---------
+    const int rank0 = before + s - c;                             // rank of this thread's first destination
     const int64_t dbase = w0 * 32;
-    const int rounds = (L + PB_TEAMS - 1) / PB_TEAMS;             // wave-uniform trip count (the ballots below need whole waves)
-    for (int rd = 0; rd < rounds; ++rd) {
-      const int i = rd * PB_TEAMS + team;
-      const bool live = i < L;
-      const int64_t d = dbase + list[live ? i : 0];
-      for (int r = 0; 16 * r < S; ++r) {                          // lane tl looks at slots tl, tl + 16, ...
-        const int j = tl + 16 * r;
-        int a = -1, lo = 0, hi = 0;
-        if (live && j < S) {
-          a = idx[d * S + j];
-          lo = off[d * (S + 1) + j];
-          hi = off[d * (S + 1) + j + 1];
+    for (int p0 = 0; p0 < L; p0 += PB_LIST) {
+      if (p0 > 0) __syncthreads();                                // the previous pass's list is consumed
+      {
+        int rk = rank0;
+        unsigned wbits = word;
+        while (wbits) {
+          const int bit = __builtin_ctz(wbits);
+          wbits &= wbits - 1;
+          if (rk >= p0 && rk < p0 + PB_LIST) list[rk - p0] = (unsigned short)(tid * 32 + bit);
+          ++rk;
         }
-        int sloc = -1;
-        if (a >= 0 && a < n_src && hi > lo) {
-          const unsigned q = pb_div((unsigned)a, dv);
-          if ((unsigned)a - q * dv.G == (unsigned)b) sloc = (int)q;
-        }
-        unsigned mask = (unsigned)((__ballot(sloc >= 0) >> tshift) & 0xFFFFull);   // this team's matching slots
-        // teams of one wave run the loop together: it ends when the slowest team has no slot left
-        while (__any(mask != 0)) {
-          const int src_lane = mask ? __builtin_ctz(mask) : 0;
-          const bool act = mask != 0;
-          mask &= mask - 1;
-          const int sl = __shfl(sloc, tshift + src_lane);
-          const int e0 = __shfl(lo, tshift + src_lane), e1 = __shfl(hi, tshift + src_lane);
-          if (act)
-            for (int e = e0 + tl; e < e1; e += 16) {
-              const uint2 en = ent[d * D + e];
-              __hip_atomic_fetch_add(&T[sl * DP + (int)en.x], __uint_as_float(en.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+      }
+      __syncthreads();
+      const int Lp = min(PB_LIST, L - p0);
+      // ---- one destination per 16-lane team: slots whose source belongs to this group -> their entry segments -------
+      const int rounds = (Lp + PB_TEAMS - 1) / PB_TEAMS;          // wave-uniform trip count (the ballots below need whole waves)
+      for (int rd = 0; rd < rounds; ++rd) {
+        const int i = rd * PB_TEAMS + team;
+        const bool live = i < Lp;
+        const int64_t d = dbase + list[live ? i : 0];
+        for (int r = 0; 16 * r < S; ++r) {                        // lane tl looks at slots tl, tl + 16, ...
+          const int j = tl + 16 * r;
+          int a = -1, lo = 0, hi = 0;
+          if (live && j < S) {
+            a = idx[d * S + j];
+            lo = off[d * (S + 1) + j];
+            hi = off[d * (S + 1) + j + 1];
+          }
+          int sloc = -1;
+          if (a >= 0 && a < n_src && hi > lo) {
+            const unsigned q = pb_div((unsigned)a, dv);
+            if ((unsigned)a - q * dv.G == (unsigned)b) sloc = (int)q;
+          }
+          unsigned mask = (unsigned)((__ballot(sloc >= 0) >> tshift) & 0xFFFFull);   // this team's matching slots
+          // teams of one wave run the loop together: it ends when the slowest team has no slot left
+          while (__any(mask != 0)) {
+            const int src_lane = mask ? __builtin_ctz(mask) : 0;
+            const bool act = mask != 0;
+            mask &= mask - 1;
+            const int sl = __shfl(sloc, tshift + src_lane);
+            const int e0 = __shfl(lo, tshift + src_lane), e1 = __shfl(hi, tshift + src_lane);
+            if (act)
+              for (int e = e0 + tl; e < e1; e += 16) {
+                const uint2 en = ent[d * D + e];
+                __hip_atomic_fetch_add(&T[sl * DP + (int)en.x], __uint_as_float(en.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+          }
         }
       }
     }
   }
   __syncthreads();
   // ---- emit: image row f, group b = split(T[0..31][f]); one 16-byte piece (plane p, chunk c) per unit, 12 consecutive
-  // lanes write the 192 contiguous bytes of one row's group ------------------------------------------------------------
+  // lanes write the 192 contiguous bytes of one row's group; the whole slab is one contiguous (D + 1) * 192-byte run ------------------------------------------------------------
   for (int u = tid; u < D * 12; u += PB_THREADS) {
     const int fo = u / 12, j = u - fo * 12;
     const int p = j >> 2, c = j & 3;
@@ -180,8 +188,9 @@ __global__ void __launch_bounds__(PB_THREADS) k_pool_bwd_x3(const int32_t* __res
     split3(col[4 * DP], col[5 * DP], o[0][2], o[1][2], o[2][2]);
     split3(col[6 * DP], col[7 * DP], o[0][3], o[1][3], o[2][3]);
     const unsigned* sel = p == 0 ? o[0] : (p == 1 ? o[1] : o[2]);
-    *(uint4*)(img + (int64_t)fo * row_bytes + (int64_t)b * 192 + p * 64 + c * 16) = make_uint4(sel[0], sel[1], sel[2], sel[3]);
+    *(uint4*)(img + (int64_t)b * gstride + (int64_t)fo * 192 + p * 64 + c * 16) = make_uint4(sel[0], sel[1], sel[2], sel[3]);
   }
+  if (tid < 12) *(uint4*)(img + (int64_t)b * gstride + (int64_t)D * 192 + tid * 16) = make_uint4(0, 0, 0, 0);   // the zero row
 }
 
 static inline int64_t pb_words(int64_t n_dst) { return ogl_cdiv(n_dst, 32); }
@@ -217,9 +226,8 @@ extern "C" int ogl_pool_bwd_x3(const float* dout, int64_t ldo, const int32_t* ar
   unsigned* bitmap = (unsigned*)workspace;
   unsigned short* off = (unsigned short*)((unsigned char*)workspace + pb_bitmap_bytes(n_dst, n_src));
   uint2* ent = (uint2*)((unsigned char*)off + pb_off_bytes(n_dst, fanout));
-  const int64_t row_bytes = groups * 192;
+  const int64_t gstride = ((int64_t)d + 1) * 192;                 // GROUP-MAJOR image: [group][d rows + zero row][192 B]
   OGL_CHECK_HIP(hipMemsetAsync(bitmap, 0, (size_t)(groups * words * 4 + 16), st));
-  OGL_CHECK_HIP(hipMemsetAsync((unsigned char*)image + (int64_t)d * row_bytes, 0, (size_t)row_bytes, st));   // the image's zero row
   const PbDiv dv = pb_make_div((unsigned)groups);
   if (n_dst > 0 && fanout > 0) {
     hipLaunchKernelGGL(k_pool_bucket, dim3((unsigned)ogl_cdiv(n_dst, 4)), dim3(256), 0, st, dout, ldo, argmax, relu_out, ldr, idx32,
@@ -227,14 +235,14 @@ extern "C" int ogl_pool_bwd_x3(const float* dout, int64_t ldo, const int32_t* ar
     OGL_CHECK_LAUNCH();
   }
   const int DP = d | 1;                                            // odd slab stride: conflict-free column reads in the emit phase
-  const size_t lds = (size_t)32 * DP * 4 + PB_CHUNK_WORDS * 32 * 2 + (PB_CHUNK_WORDS + 1) * 4 + 16;
+  const size_t lds = (size_t)32 * DP * 4 + PB_LIST * 2 + (PB_THREADS / 64) * 4 + 16;
   static bool attr_set = false;
   if (!attr_set) {
     OGL_CHECK_HIP(hipFuncSetAttribute((const void*)k_pool_bwd_x3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   hipLaunchKernelGGL(k_pool_bwd_x3, dim3((unsigned)groups), dim3(PB_THREADS), lds, st, idx32, fanout, off, ent, bitmap, words, n_src,
-                     dv, d, DP, (unsigned char*)image, row_bytes);
+                     dv, d, DP, (unsigned char*)image, gstride);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }

@@ -39,6 +39,13 @@ def image_model(x):
     return img.view(torch.int16).numpy().view(np.uint8).reshape(-1)
 
 
+def image_model_t(x):
+    """Transposed images are GROUP-MAJOR: [ceil(K/32)][R + 1][3][32] (include/ogl_hip.h)."""
+    R, K = x.shape
+    G = (K + 31) // 32
+    return image_model(x).reshape(R + 1, G, 192).transpose(1, 0, 2).copy().reshape(-1)
+
+
 @pytest.mark.parametrize("R,K", [(1, 1), (7, 31), (33, 32), (50, 33), (129, 602), (5, 1204)])
 def test_image_bit_exact(ops, R, K):
     torch.manual_seed(R * 1000 + K)
@@ -73,12 +80,12 @@ def test_transposed_image_bit_exact(ops, M, N, ones):
     if ones:
         want = torch.cat([want, torch.ones(1, M)], 0)
     assert img.rows == N + int(ones) and img.K == M
-    assert np.array_equal(img.buf.cpu().numpy(), image_model(want))
+    assert np.array_equal(img.buf.cpu().numpy(), image_model_t(want))
     img2 = ops.x3_split_t(tm[:M], None, ones_row=ones)           # ungathered
     want2 = tab[:M].T.contiguous()
     if ones:
         want2 = torch.cat([want2, torch.ones(1, M)], 0)
-    assert np.array_equal(img2.buf.cpu().numpy(), image_model(want2))
+    assert np.array_equal(img2.buf.cpu().numpy(), image_model_t(want2))
 
 
 @pytest.mark.parametrize("M,K,N,relu", [(1, 1, 1, False), (37, 33, 5, True), (255, 602, 41, False), (257, 64, 129, True),
@@ -222,11 +229,13 @@ def test_status_codes(ops):
     assert h.ogl_linear_bwd_weight_x3(p(img), p(img), 64, 4, 4, p(x), 8, None, None, 0, None) in (0, -4)
 
 
-def image_decode(buf, rows, K):
-    """uint8 image -> [rows, ceil(K/32)*32] fp32 (the three planes summed; exact)."""
+def image_decode_t(buf, rows, K):
+    """uint8 group-major (transposed) image -> [rows, ceil(K/32)*32] fp32 (the three planes summed; exact)."""
     G = (K + 31) // 32
-    raw = torch.as_tensor(buf.cpu().numpy().view(np.int16).reshape(rows + 1, G, 3, 32)).view(torch.bfloat16).float()
-    return ((raw[:, :, 0] + raw[:, :, 1]) + raw[:, :, 2]).reshape(rows + 1, G * 32)[:rows]
+    raw = torch.as_tensor(buf.cpu().numpy().view(np.int16).reshape(G, rows + 1, 3, 32).copy()).view(torch.bfloat16).float()
+    val = (raw[:, :, 0] + raw[:, :, 1]) + raw[:, :, 2]                 # [G, rows + 1, 32]
+    assert (val[:, rows] == 0).all()                                   # the zero row of every group
+    return val[:, :rows].permute(1, 0, 2).reshape(rows, G * 32)
 
 
 @pytest.mark.parametrize("M,N,G", [(40, 7, 2), (64, 64, 2), (1000, 41, 32), (2500, 130, 79), (33, 5, 4)])
@@ -244,7 +253,7 @@ def test_transposed_image_interleaved(ops, M, N, G):
     ok = s_of_m < M
     want[:N, ok] = tab[rows[s_of_m[ok]]].T
     want[N, :] = 1.0
-    assert np.array_equal(img.buf.cpu().numpy(), image_model(want))
+    assert np.array_equal(img.buf.cpu().numpy(), image_model_t(want))
 
 
 @pytest.mark.parametrize("n_dst,S,D,n_src,relu", [(1, 1, 1, 1, True), (50, 4, 33, 70, True), (300, 25, 602, 2000, True),
@@ -273,7 +282,7 @@ def test_pool_backward_image(ops, n_dst, S, D, n_src, relu):
             m &= o[d] > 0
         dP[a[d, m], cols[m]] += g[d, m]
         cnt[a[d, m], cols[m]] += 1
-    got = image_decode(img.buf, D, 32 * G).numpy()                     # [D, 32 G], dealt
+    got = image_decode_t(img.buf, D, 32 * G).numpy()                     # [D, 32 G], dealt
     mm = np.arange(32 * G)
     s_of_m = (mm % 32) * G + mm // 32
     ok = s_of_m < n_src
