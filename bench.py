@@ -253,6 +253,11 @@ def main():
         if roof_aggr and args.workload == "reddit_rbr":
             roof_aggr["traffic"] = pmc["k_reduce_fwd_v4_L0"]["traffic_bytes"]
             roof_aggr["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+        if roof_gemm and args.workload == "reddit_rbr" and args.gemm == "auto":
+            key = {"linear_fwd_x3_pool0": "k_gemm_x3_fwd_pool0", "linear_bwd_weight_x3_pool0": "k_gemm_x3_bww_pool0"}.get(dom)
+            if key:
+                roof_gemm["traffic"] = pmc[key]["traffic_bytes"]
+                roof_gemm["traffic_source"] = "profiles/r01_pmc_traffic.json (HBM-side bytes per launch; an MFMA-bound kernel)"
     except Exception:
         pass
 
