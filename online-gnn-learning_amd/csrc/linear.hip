@@ -719,9 +719,9 @@ extern "C" int ogl_linear_bwd_input(const float* dy, int64_t ldy, int64_t M,
 static void bwd_weight_plan(int64_t M, int N, int K, int* nsplit, int* tps, int* cfg) {
   const int No = K + 1;  // + ones column
   const int64_t nk = ogl_cdiv(M, GEMM_BK);
-  *cfg = No <= 64 ? 1 : 0;
+  *cfg = No <= 64 ? 1 : (N <= 64 ? 2 : 0);   // few output rows (the [C, 2H] output layer): 64 x 64 tiles, 128-row tiles would be 2/3 padding
   if (nk == 0) { *nsplit = 1; *tps = 0; return; }
-  int BM = No <= 64 ? 256 : 128, BN = No <= 64 ? 64 : 128;
+  int BM = No <= 64 ? 256 : (N <= 64 ? 64 : 128), BN = (No <= 64 || N <= 64) ? 64 : 128;
   int64_t tiles = ogl_cdiv(N, BM) * ogl_cdiv(No, BN);
   int64_t s = 768 / (tiles > 0 ? tiles : 1);
   if (s < 1) s = 1;

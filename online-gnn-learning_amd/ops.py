@@ -418,7 +418,7 @@ def linear_bwd_weight_x3(dyT_img, xT_img, want_bias=True):
 # are large enough run on the pre-split kernels.  Keyed by the allocation, so row-prefix views (ndata['feat'] of a
 # snapshot) resolve to the same image.
 _X3_TABLES = {}
-X3_BWW_MIN_ROWS = 16384   # weight gradients with at least this many reduction rows use the image kernels
+X3_BWW_MIN_ROWS = 2048    # weight gradients with at least this many reduction rows use the image kernels
 X3_MIN_ROWS = 8192        # below this the on-the-fly kernel is as fast (one wave of tiles either way)
 
 
@@ -449,12 +449,18 @@ def weight_grad(dy, x, x_rows=None, want_bias=True, dyT=None):
     k-major kernel.  ``dyT`` lets the two weight gradients of a dual-input Linear share one transpose."""
     if _MODE["name"] == "f32" or dy.shape[0] < 1024:
         return linear_bwd_weight(dy, x, None, x_rows, want_bias=want_bias)
-    if dyT is None and dy.shape[0] >= X3_BWW_MIN_ROWS:
-        # both operands as bf16x3 images of their transposes (one fused gather + transpose + split pass each)
-        return linear_bwd_weight_x3(x3_split_t(dy), x3_split_t(x, x_rows, ones_row=True), want_bias=want_bias)
     if dyT is None:
-        dyT = transpose(dy)
+        dyT = transposed_operand(dy)
+    if isinstance(dyT, X3Image):
+        # both operands as bf16x3 images of their transposes (one fused gather + transpose + split pass each)
+        return linear_bwd_weight_x3(dyT, x3_split_t(x, x_rows, ones_row=True), want_bias=want_bias)
     return linear_bwd_weight_t(dyT, transpose(x, x_rows), want_bias=want_bias)
+
+
+def transposed_operand(dy):
+    """dy^T in the form the weight-gradient product of this size consumes: a bf16x3 image (>= X3_BWW_MIN_ROWS reduction
+    rows) or an fp32 matrix.  Shared by the two weight gradients of a dual-input Linear."""
+    return x3_split_t(dy) if dy.shape[0] >= X3_BWW_MIN_ROWS else transpose(dy)
 
 
 # --------------------------------------------------------------------------------------------
@@ -533,7 +539,7 @@ class _LinearFn(torch.autograd.Function):
             dx = linear_bwd_input(dy, w, y)
         dyT = None
         if _MODE["name"] != "f32" and dy.shape[0] >= 1024 and x2 is not None and need[1] and need[4]:
-            dyT = transpose(dy)          # shared by the two weight gradients of a dual-input projection
+            dyT = transposed_operand(dy)   # shared by the two weight gradients of a dual-input projection
         if need[1] or (need[2] and ctx.has_bias):
             dw, db = weight_grad(dy, x, x_rows, want_bias=ctx.has_bias, dyT=dyT)
         if x2 is not None:
