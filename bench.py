@@ -291,9 +291,10 @@ def h_nnz(g):
 def gemm_desc(mode):
     return {"f32": "fp32 MFMA (exact fp32 fma chain)",
             "bf16x6": "split-bf16 x6 MFMA, fp32 accumulate (fp32-GEMM accuracy, same test tolerances)",
-            "auto": "forward/input-gradient GEMMs: split-bf16 x6 MFMA with fp32 accumulate (fp32-GEMM accuracy, same test "
-                    "tolerances); weight-gradient GEMMs: the same x6 arithmetic on transposed operands when M >= 1024 (ogl_transpose + "
-                    "ogl_linear_bwd_weight_t), exact fp32 MFMA below that"}[mode]
+            "auto": "split-bf16 x6 MFMA with fp32 accumulate everywhere it is faster (fp32-GEMM accuracy, same test tolerances): "
+                    "layer-0 products and all weight gradients with >= 2048 reduction rows on pre-split bf16x3 images "
+                    "(k_gemm_x3, LDS-DMA staged), the n1-row forward / input-gradient GEMMs with on-the-fly splitting "
+                    "(k_gemm), exact fp32 MFMA for the 512-row output layer"}[mode]
 
 
 def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size, n_classes, setup_s):

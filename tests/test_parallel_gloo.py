@@ -52,7 +52,7 @@ def _worker(rank, world, port, out):
     params = model.opt.param_groups[0]["params"]
     mine = parallel.shard_seeds(seeds)
     rows, _ = _grads(model, feat, labels, indptr, indices, deg_t, mine)
-    sync = parallel.GradSynchronizer(params)
+    sync = parallel.GradSynchronizer(params, overlap=False)
     sync.sync(weight=len(mine) / len(seeds))
     all_rows = parallel.all_gather_rows(rows)
     if rank == 0:
@@ -71,6 +71,44 @@ def test_two_rank_update_equals_one_rank(tmp_path):
     np.testing.assert_allclose(got["rows"].numpy(), rows.numpy(), rtol=1e-5, atol=1e-6)
     for g, p in zip(got["grads"], model.opt.param_groups[0]["params"]):
         np.testing.assert_allclose(g.numpy(), p.grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def _worker_overlap(rank, world, port, out):
+    """Three steps with the overlapped synchronizer (equal shards): step 1 learns the arrival order with one bucket,
+    steps 2-3 launch the early bucket from the gradient hooks; every step must equal the plain mean of the rank grads."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    indptr, indices, deg_t, feat, labels, seeds, F, C = _problem()
+    seeds = seeds[:36]                                          # equal shards: the default 1/world weight is exact
+    model = O.CpuModel("pool", F, 8, C, seed=3)
+    params = model.opt.param_groups[0]["params"]
+    sync = parallel.GradSynchronizer(params, overlap=True)
+    mine = parallel.shard_seeds(seeds)
+    res = []
+    for step in range(3):
+        _grads(model, feat, labels, indptr, indices, deg_t, mine)
+        local = [p.grad.clone() for p in params]
+        launched = sync._pending is not None
+        sync.sync()
+        want = []
+        for g in local:                                         # reference: explicit mean over ranks
+            t = g.clone(); dist.all_reduce(t); want.append(t / world)
+        res.append(dict(launched=launched, ok=all(torch.allclose(p.grad, w, rtol=1e-6, atol=1e-7) for p, w in zip(params, want)),
+                        early=None if sync._early is None else len(sync._early), late=None if sync._late is None else len(sync._late)))
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucket_allreduce(tmp_path):
+    out = str(tmp_path / "ov.pt")
+    mp.spawn(_worker_overlap, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert [r["ok"] for r in res] == [True, True, True]
+    assert res[0]["launched"] is False and res[1]["launched"] is True and res[2]["launched"] is True
+    assert res[1]["early"] >= 1 and res[1]["late"] >= 1
 
 
 def test_shard_ranges_cover_in_order():
