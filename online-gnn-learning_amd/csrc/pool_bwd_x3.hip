@@ -60,13 +60,22 @@ __global__ void __launch_bounds__(256) k_pool_bucket(const float* __restrict__ d
     gv[i] = dout[d * ldo + fc];
     const float m = relu_out ? relu_out[d * ldr + fc] : 1.f;
     const bool ok = in && a >= 0 && a < n_src && m > 0.f;
-    int sl = -1;
-    for (int j = 0; j < S; ++j) {
-      const int sj = __shfl(my, j);
-      if (ok && sl < 0 && sj == a) sl = j;      // the FIRST slot holding the winner (duplicate samples own nothing)
-    }
-    slot[i] = sl;
-    pos[i] = sl >= 0 ? atomicAdd(&cnt[wv][sl], 1) : 0;
+    slot[i] = ok ? a : -1;                        // winner's source id for now; the slot search follows
+  }
+  // the FIRST slot holding each winner (duplicate samples own nothing): slots from the last to the first, so the
+  // lowest match is the one that sticks; idx values are broadcast through an SGPR (v_readlane), not through LDS
+  int sl[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) sl[i] = -1;
+  for (int j = S - 1; j >= 0; --j) {
+    const int sj = __builtin_amdgcn_readlane(my, j);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) sl[i] = (slot[i] == sj && sj >= 0) ? j : sl[i];
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    slot[i] = slot[i] >= 0 ? sl[i] : -1;
+    pos[i] = slot[i] >= 0 ? atomicAdd(&cnt[wv][slot[i]], 1) : 0;
   }
   // exclusive scan of the S bucket sizes (lane j = bucket j, lane S = end)
   const int c = cnt[wv][lane];
@@ -95,7 +104,7 @@ __global__ void __launch_bounds__(PB_THREADS) k_pool_bwd_x3(const int32_t* __res
   int* wsum = (int*)(list + PB_LIST);                             // per-wave popcount totals of the current super-chunk
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.x;
-  for (int i = tid; i < 32 * DP; i += PB_THREADS) T[i] = 0.f;
+  for (int i = tid; i < 8 * DP; i += PB_THREADS) ((float4*)T)[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // 32 * DP floats
   const unsigned* bm = bitmap + (int64_t)b * words;
   const int team = tid >> 4, tl = tid & 15;
   const int tshift = tid & 48;                                    // first lane of this team inside its wave
@@ -176,19 +185,18 @@ __global__ void __launch_bounds__(PB_THREADS) k_pool_bwd_x3(const int32_t* __res
     }
   }
   __syncthreads();
-  // ---- emit: image row f, group b = split(T[0..31][f]); one 16-byte piece (plane p, chunk c) per unit, 12 consecutive
-  // lanes write the 192 contiguous bytes of one row's group; the whole slab is one contiguous (D + 1) * 192-byte run ------------------------------------------------------------
-  for (int u = tid; u < D * 12; u += PB_THREADS) {
-    const int fo = u / 12, j = u - fo * 12;
-    const int p = j >> 2, c = j & 3;
+  // ---- emit: image row f, group b = split(T[0..31][f]); the whole slab is one contiguous (D + 1) * 192-byte run ------------------------------------------------------------
+  for (int u = tid; u < D * 4; u += PB_THREADS) {                 // unit = (row f, 8-source chunk c): one split, three stores
+    const int fo = u >> 2, c = u & 3;
     const float* col = T + (8 * c) * DP + fo;
-    unsigned o[3][4];
-    split3(col[0], col[DP], o[0][0], o[1][0], o[2][0]);
-    split3(col[2 * DP], col[3 * DP], o[0][1], o[1][1], o[2][1]);
-    split3(col[4 * DP], col[5 * DP], o[0][2], o[1][2], o[2][2]);
-    split3(col[6 * DP], col[7 * DP], o[0][3], o[1][3], o[2][3]);
-    const unsigned* sel = p == 0 ? o[0] : (p == 1 ? o[1] : o[2]);
-    *(uint4*)(img + (int64_t)b * gstride + (int64_t)fo * 192 + p * 64 + c * 16) = make_uint4(sel[0], sel[1], sel[2], sel[3]);
+    uint4 o[3];
+    split3(col[0], col[DP], o[0].x, o[1].x, o[2].x);
+    split3(col[2 * DP], col[3 * DP], o[0].y, o[1].y, o[2].y);
+    split3(col[4 * DP], col[5 * DP], o[0].z, o[1].z, o[2].z);
+    split3(col[6 * DP], col[7 * DP], o[0].w, o[1].w, o[2].w);
+    unsigned char* d = img + (int64_t)b * gstride + (int64_t)fo * 192 + c * 16;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *(uint4*)(d + p * 64) = o[p];
   }
   if (tid < 12) *(uint4*)(img + (int64_t)b * gstride + (int64_t)D * 192 + tid * 16) = make_uint4(0, 0, 0, 0);   // the zero row
 }
