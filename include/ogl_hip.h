@@ -225,6 +225,20 @@ int ogl_linear_bwd_weight_x3(const void* dyT_img, const void* xT_img, int64_t M,
                              int64_t lddw, float* db, void* workspace, int64_t workspace_bytes,
                              ogl_stream_t stream);
 
+/* Batched forms of the sampler and of the block build: nb independent batches in one set of launches (a loader samples
+ * every batch of a snapshot, layer by layer; per-batch launches of these microsecond-sized kernels are latency-bound).
+ * dst_start / dst_count / ctr are HOST arrays [nb]: batch b's destinations are dst_base[dst_start[b] .. + dst_count[b]),
+ * its Philox batch counter is ctr[b].  Outputs are PACKED by the running sum r_b of the counts: picks / local_idx rows
+ * r_b .. r_b + dst_count[b], src_ids at r_b * (1 + fanout) (capacity dst_count[b] * (1 + fanout)), n_src_out[b].
+ * Per batch the results are bit-identical to ogl_sample_layer / ogl_build_block. */
+int ogl_sample_layer_batched(const ogl_graph_t* g, const int64_t* dst_base, const int64_t* dst_start,
+                             const int64_t* dst_count, int nb, int fanout, uint64_t seed, const uint64_t* ctr,
+                             int layer, int64_t* picks, ogl_stream_t stream);
+int64_t ogl_block_workspace_bytes_batched(const int64_t* dst_count, int nb, int fanout);
+int ogl_build_block_batched(const int64_t* dst_base, const int64_t* dst_start, const int64_t* dst_count, int nb,
+                            const int64_t* picks, int fanout, int64_t* src_ids, int64_t* n_src_out,
+                            int32_t* local_idx, void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * nn.CrossEntropyLoss (R/train/graphsage/pytorch/model.py:20,105,147,198,244):
  *   loss_rows[i] = logsumexp(logits[i,:]) - logits[i, labels[i]]            (reduction='none')

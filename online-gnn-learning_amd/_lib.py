@@ -45,6 +45,9 @@ SIGNATURES = {
     "ogl_linear_bwd_weight_t_workspace_bytes": (_i64, [_i64, _i, _i]),
     "ogl_linear_bwd_weight_t": (_i, [_p, _i64, _p, _i64, _i64, _i, _i, _p, _i64, _p, _p, _i64, _p]),
     "ogl_transpose": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _p]),
+    "ogl_sample_layer_batched": (_i, [_p, _p, _p, _p, _i, _i, _u64, _p, _i, _p, _p]),
+    "ogl_block_workspace_bytes_batched": (_i64, [_p, _i, _i]),
+    "ogl_build_block_batched": (_i, [_p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _i64, _p]),
     "ogl_pool_bwd_x3_workspace_bytes": (_i64, [_i64, _i, _i, _i64]),
     "ogl_pool_bwd_x3": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i, _i, _i64, _p, _p, _i64, _p]),
     "ogl_x3_row_bytes": (_i64, [_i64]),

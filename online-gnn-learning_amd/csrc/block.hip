@@ -192,3 +192,188 @@ extern "C" int ogl_build_block(const int64_t* dst, int64_t n_dst, const int64_t*
   }
   return OGL_OK;
 }
+
+
+// ---- batched build: every batch of a loader layer in one set of launches ------------------------------------------------
+// Same algorithm, same results as ogl_build_block per batch (bit-exact); blockIdx.y = batch.  All batches of a chunk
+// share one table size (that of the largest), so the workspace is nb x (3 T) + slots + per-batch scan sums.
+struct block_batch {
+  ogl_batch_desc bd;
+  int fanout;
+  int64_t T;          // table entries per batch
+  int64_t NBmax;      // scan blocks of the largest batch
+  int32_t* tkey; int32_t* tmin; int32_t* tlidx;   // [nb][T]
+  int32_t* slot;      // packed like src_ids: batch b at row_off[b] * (1 + fanout)
+  int32_t* bsum;      // [nb][NBmax + 1]
+  uint32_t mask; int shift;
+};
+
+__global__ void __launch_bounds__(256) k_block_insert_b(const int64_t* __restrict__ dst_base, const int64_t* __restrict__ picks,
+                                                        block_batch w) {
+  const int b = blockIdx.y;
+  const int64_t n_dst = w.bd.row_off[b + 1] - w.bd.row_off[b];
+  const int64_t P = n_dst * (1 + (int64_t)w.fanout);
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  int32_t* tkey = w.tkey + (int64_t)b * w.T; int32_t* tmin = w.tmin + (int64_t)b * w.T;
+  int32_t* slot = w.slot + w.bd.row_off[b] * (1 + (int64_t)w.fanout);
+  const int64_t id64 = flat_id(dst_base + w.bd.dst_start[b], picks + w.bd.row_off[b] * w.fanout, n_dst, p);
+  if (id64 < 0) { slot[p] = -1; return; }
+  int32_t id = (int32_t)id64;
+  uint32_t h = ((uint32_t)id * 0x9E3779B1u) >> w.shift;
+  for (uint32_t probe = 0; probe <= w.mask; ++probe) {
+    int32_t old = atomicCAS(&tkey[h], -1, id);
+    if (old == -1 || old == id) {
+      atomicMin(&tmin[h], (int32_t)p);
+      slot[p] = (int32_t)h;
+      return;
+    }
+    h = (h + 1) & w.mask;
+  }
+  slot[p] = -1;
+}
+
+__global__ void __launch_bounds__(BLK_SCAN) k_block_count_b(block_batch w) {
+  const int b = blockIdx.y;
+  const int64_t n_dst = w.bd.row_off[b + 1] - w.bd.row_off[b];
+  const int64_t P = n_dst * (1 + (int64_t)w.fanout);
+  if ((int64_t)blockIdx.x * BLK_SCAN >= P) return;               // block-uniform
+  int64_t p = (int64_t)blockIdx.x * BLK_SCAN + threadIdx.x;
+  int tot;
+  (void)block_scan_1024(is_first(w.tmin + (int64_t)b * w.T, w.slot + w.bd.row_off[b] * (1 + (int64_t)w.fanout), n_dst, P, p), &tot);
+  if (threadIdx.x == 0) w.bsum[(int64_t)b * (w.NBmax + 1) + blockIdx.x] = tot;
+}
+
+// one block per batch: exclusive scan of its bsum[0..NB) in place, bsum[NB] = total = n_src_out[b]
+__global__ void __launch_bounds__(BLK_SCAN) k_block_scan_sums_b(block_batch w, int64_t* __restrict__ n_src_out) {
+  __shared__ int carry_s;
+  __shared__ int part[BLK_SCAN];
+  const int b = blockIdx.x;
+  const int64_t n_dst = w.bd.row_off[b + 1] - w.bd.row_off[b];
+  const int64_t NB = ogl_cdiv_dev(n_dst * (1 + (int64_t)w.fanout), BLK_SCAN);
+  int32_t* bsum = w.bsum + (int64_t)b * (w.NBmax + 1);
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < NB; base += BLK_SCAN) {
+    int64_t i = base + threadIdx.x;
+    int v = i < NB ? bsum[i] : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < BLK_SCAN; off <<= 1) {
+      int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+      __syncthreads();
+      part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    int incl = part[threadIdx.x];
+    int carry = carry_s;
+    if (i < NB) bsum[i] = carry + incl - v;
+    __syncthreads();
+    if (threadIdx.x == BLK_SCAN - 1) carry_s = carry + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { bsum[NB] = carry_s; n_src_out[b] = (int64_t)carry_s; }
+}
+
+__global__ void __launch_bounds__(BLK_SCAN) k_block_assign_b(const int64_t* __restrict__ dst_base, const int64_t* __restrict__ picks,
+                                                             block_batch w, int64_t* __restrict__ src_ids) {
+  const int b = blockIdx.y;
+  const int64_t n_dst = w.bd.row_off[b + 1] - w.bd.row_off[b];
+  const int64_t P = n_dst * (1 + (int64_t)w.fanout);
+  if ((int64_t)blockIdx.x * BLK_SCAN >= P) return;               // block-uniform
+  const int32_t* tmin = w.tmin + (int64_t)b * w.T;
+  const int32_t* slot = w.slot + w.bd.row_off[b] * (1 + (int64_t)w.fanout);
+  int64_t p = (int64_t)blockIdx.x * BLK_SCAN + threadIdx.x;
+  int f = is_first(tmin, slot, n_dst, P, p);
+  int tot;
+  int pre = block_scan_1024(f, &tot);
+  if (f) {
+    int32_t li = w.bsum[(int64_t)b * (w.NBmax + 1) + blockIdx.x] + pre;
+    src_ids[w.bd.row_off[b] * (1 + (int64_t)w.fanout) + li] =
+        flat_id(dst_base + w.bd.dst_start[b], picks + w.bd.row_off[b] * w.fanout, n_dst, p);
+    int32_t s = slot[p];
+    if (s >= 0 && tmin[s] == (int32_t)p) w.tlidx[(int64_t)b * w.T + s] = li;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_block_lookup_b(block_batch w, int32_t* __restrict__ local_idx) {
+  const int b = blockIdx.y;
+  const int64_t n_dst = w.bd.row_off[b + 1] - w.bd.row_off[b];
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_dst * w.fanout) return;
+  int32_t s = w.slot[w.bd.row_off[b] * (1 + (int64_t)w.fanout) + n_dst + e];
+  local_idx[w.bd.row_off[b] * w.fanout + e] = s >= 0 ? w.tlidx[(int64_t)b * w.T + s] : -1;
+}
+
+static int64_t batched_ws_bytes(const int64_t* dst_count, int nb, int fanout) {
+  // chunks of OGL_MAX_BATCH reuse the same workspace: size it for the worst chunk
+  int64_t worst = 16;
+  for (int b0 = 0; b0 < nb; b0 += OGL_MAX_BATCH) {
+    const int m = nb - b0 < OGL_MAX_BATCH ? nb - b0 : OGL_MAX_BATCH;
+    int64_t mx = 0, rows = 0;
+    for (int b = 0; b < m; ++b) { mx = mx > dst_count[b0 + b] ? mx : dst_count[b0 + b]; rows += dst_count[b0 + b]; }
+    const int64_t Pmax = mx * (1 + (int64_t)fanout);
+    const int64_t T = table_size(Pmax), NBmax = ogl_cdiv(Pmax, BLK_SCAN);
+    const int64_t bytes = 4 * (3 * T * m + ogl_round_up(rows * (1 + (int64_t)fanout), 4) + ogl_round_up((NBmax + 1) * m, 4));
+    worst = worst > bytes ? worst : bytes;
+  }
+  return worst;
+}
+
+extern "C" int64_t ogl_block_workspace_bytes_batched(const int64_t* dst_count, int nb, int fanout) {
+  if (nb < 0 || fanout < 0 || (nb > 0 && !dst_count)) return OGL_EINVAL;
+  for (int b = 0; b < nb; ++b) if (dst_count[b] < 0) return OGL_EINVAL;
+  return batched_ws_bytes(dst_count, nb, fanout);
+}
+
+extern "C" int ogl_build_block_batched(const int64_t* dst_base, const int64_t* dst_start, const int64_t* dst_count, int nb,
+                                       const int64_t* picks, int fanout, int64_t* src_ids, int64_t* n_src_out,
+                                       int32_t* local_idx, void* workspace, int64_t workspace_bytes, ogl_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (nb < 0 || fanout < 0) return OGL_EINVAL;
+  if (nb == 0) return OGL_OK;
+  if (!dst_start || !dst_count || !n_src_out) return OGL_EINVAL;
+  for (int b = 0; b < nb; ++b) if (dst_count[b] < 0 || dst_start[b] < 0) return OGL_EINVAL;
+  if (!workspace || workspace_bytes < batched_ws_bytes(dst_count, nb, fanout)) return OGL_EWORKSPACE;
+  int64_t row = 0;
+  for (int b0 = 0; b0 < nb; b0 += OGL_MAX_BATCH) {
+    const int m = nb - b0 < OGL_MAX_BATCH ? nb - b0 : OGL_MAX_BATCH;
+    block_batch w;
+    int64_t mx = 0, rows = 0;
+    const int64_t row0 = row;
+    for (int b = 0; b < m; ++b) {
+      w.bd.dst_start[b] = dst_start[b0 + b]; w.bd.row_off[b] = row; w.bd.ctr[b] = 0;
+      row += dst_count[b0 + b]; rows += dst_count[b0 + b];
+      mx = mx > dst_count[b0 + b] ? mx : dst_count[b0 + b];
+    }
+    w.bd.row_off[m] = row;
+    if (mx == 0) { OGL_CHECK_HIP(hipMemsetAsync(n_src_out + b0, 0, sizeof(int64_t) * m, stream)); continue; }
+    if (!dst_base || !src_ids || (fanout > 0 && (!picks || !local_idx))) return OGL_EINVAL;
+    const int64_t Pmax = mx * (1 + (int64_t)fanout);
+    if (Pmax >= ((int64_t)1 << 30)) return OGL_EINVAL;
+    w.fanout = fanout; w.T = table_size(Pmax); w.NBmax = ogl_cdiv(Pmax, BLK_SCAN);
+    int32_t* base = (int32_t*)workspace;
+    w.tkey = base; w.tmin = base + w.T * m; w.tlidx = base + 2 * w.T * m;
+    // slots are addressed by the GLOBAL packed row offset: rebase so that batch b0's rows start at the array's head
+    int32_t* slot0 = base + 3 * w.T * m;
+    w.slot = slot0 - row0 * (1 + (int64_t)fanout);
+    w.bsum = slot0 + ogl_round_up(rows * (1 + (int64_t)fanout), 4);
+    int logT = 0; while (((int64_t)1 << logT) < w.T) ++logT;
+    w.mask = (uint32_t)(w.T - 1); w.shift = 32 - logT;
+    OGL_CHECK_HIP(hipMemsetAsync(w.tkey, 0xFF, sizeof(int32_t) * w.T * m, stream));   // -1
+    OGL_CHECK_HIP(hipMemsetAsync(w.tmin, 0x7F, sizeof(int32_t) * w.T * m, stream));   // 0x7F7F7F7F > P
+    hipLaunchKernelGGL(k_block_insert_b, dim3((unsigned)ogl_cdiv(Pmax, 256), (unsigned)m), dim3(256), 0, stream, dst_base, picks, w);
+    OGL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_block_count_b, dim3((unsigned)w.NBmax, (unsigned)m), dim3(BLK_SCAN), 0, stream, w);
+    OGL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_block_scan_sums_b, dim3((unsigned)m), dim3(BLK_SCAN), 0, stream, w, n_src_out + b0);
+    OGL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_block_assign_b, dim3((unsigned)w.NBmax, (unsigned)m), dim3(BLK_SCAN), 0, stream, dst_base, picks, w, src_ids);
+    OGL_CHECK_LAUNCH();
+    if (fanout > 0) {
+      hipLaunchKernelGGL(k_block_lookup_b, dim3((unsigned)ogl_cdiv(mx * fanout, 256), (unsigned)m), dim3(256), 0, stream, w, local_idx);
+      OGL_CHECK_LAUNCH();
+    }
+  }
+  return OGL_OK;
+}

@@ -2,6 +2,7 @@
 // Replaces: DGLGraph snapshot state (R/train/graph/dynamic_graph_vertex.py:132-141,
 // R/train/graph/dynamic_graph_edge.py:190-218) and dgl.sampling.sample_neighbors inside
 // MultiLayerNeighborSampler (R/train/graphsage/pytorch/model.py:44,128,174,224,280,312).
+#include <algorithm>
 #include "ogl_common.h"
 
 thread_local int g_ogl_last_hip_error = 0;
@@ -140,5 +141,74 @@ extern "C" int ogl_sample_layer(const ogl_graph_t* g, const int64_t* dst, int64_
   hipLaunchKernelGGL(k_sample_layer, grid, dim3(256), 0, (hipStream_t)stream, g->indptr, g->indices,
                      g->deg, g->n, dst, n_dst, fanout, quads, k0, k1, c3, (uint32_t)layer << 16, picks);
   OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+
+// ---- batched sampler: the loader samples EVERY batch of a snapshot layer in one launch -------------------------------
+// (per-batch launches of this microsecond-sized kernel are latency-bound: 50 batches x 2 layers per snapshot.)
+// Batch b's destinations are dst_base[dst_start[b] .. + dst_count[b]); its picks rows start at row_off[b] = the running
+// sum of the counts; its Philox counter is ctr[b].  Same draws as ogl_sample_layer per batch (bit-exact).
+__global__ void __launch_bounds__(256) k_sample_layer_batched(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                              const int32_t* __restrict__ deg_t, int64_t n,
+                                                              const int64_t* __restrict__ dst_base, ogl_batch_desc bd, int fanout,
+                                                              int quads, uint32_t seed_lo, uint32_t seed_hi, uint32_t layer_bits,
+                                                              int64_t* __restrict__ picks) {
+  const int b = blockIdx.y;
+  const int64_t n_dst = bd.row_off[b + 1] - bd.row_off[b];
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_dst * quads) return;
+  int64_t i = t / quads;
+  int q = (int)(t - i * quads);
+  int64_t d = dst_base[bd.dst_start[b] + i];
+  uint32_t deg = 0;
+  int64_t base = 0;
+  if (d >= 0 && d < n) { deg = (uint32_t)deg_t[d]; base = indptr[d]; }
+  int j0 = q * 4;
+  int64_t* out = picks + (bd.row_off[b] + i) * fanout + j0;
+  int cnt = min(4, fanout - j0);
+  if (deg == 0) {
+    for (int j = 0; j < cnt; ++j) out[j] = -1;
+    return;
+  }
+  const uint64_t ctr = bd.ctr[b];
+  philox4 r = philox4x32_10((uint32_t)q | layer_bits, (uint32_t)((uint64_t)d & 0xFFFFFFFFu), (uint32_t)((uint64_t)d >> 32),
+                            (uint32_t)(ctr & 0xFFFFFFFFu), seed_lo, seed_hi ^ (uint32_t)(ctr >> 32));
+  uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j < cnt) {
+      uint32_t off = (uint32_t)(((uint64_t)w[j] * (uint64_t)deg) >> 32);
+      out[j] = (int64_t)indices[base + off];
+    }
+  }
+}
+
+extern "C" int ogl_sample_layer_batched(const ogl_graph_t* g, const int64_t* dst_base, const int64_t* dst_start,
+                                        const int64_t* dst_count, int nb, int fanout, uint64_t seed, const uint64_t* ctr,
+                                        int layer, int64_t* picks, ogl_stream_t stream) {
+  if (!g || nb < 0 || fanout < 0 || layer < 0 || layer > 0xFFFF) return OGL_EINVAL;
+  if (nb == 0 || fanout == 0) return OGL_OK;
+  if (!dst_base || !dst_start || !dst_count || !ctr || !picks) return OGL_EINVAL;
+  const int quads = (fanout + 3) / 4;
+  int64_t row = 0;
+  for (int b0 = 0; b0 < nb; b0 += OGL_MAX_BATCH) {
+    ogl_batch_desc bd;
+    const int m = std::min(nb - b0, (int)OGL_MAX_BATCH);
+    int64_t mx = 0;
+    for (int b = 0; b < m; ++b) {
+      if (dst_count[b0 + b] < 0 || dst_start[b0 + b] < 0) return OGL_EINVAL;
+      bd.dst_start[b] = dst_start[b0 + b]; bd.row_off[b] = row; bd.ctr[b] = ctr[b0 + b];
+      row += dst_count[b0 + b];
+      mx = std::max(mx, dst_count[b0 + b]);
+    }
+    bd.row_off[m] = row;
+    if (mx == 0) continue;
+    dim3 grid((unsigned)ogl_cdiv(mx * quads, 256), (unsigned)m);
+    hipLaunchKernelGGL(k_sample_layer_batched, grid, dim3(256), 0, (hipStream_t)stream, g->indptr, g->indices, g->deg, g->n,
+                       dst_base, bd, fanout, quads, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), (uint32_t)layer << 16,
+                       picks);
+    OGL_CHECK_LAUNCH();
+  }
   return OGL_OK;
 }

@@ -19,6 +19,15 @@ extern thread_local int g_ogl_last_hip_error;
 
 static inline int64_t ogl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t ogl_round_up(int64_t a, int64_t b) { return ogl_cdiv(a, b) * b; }
+__device__ static inline int64_t ogl_cdiv_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Descriptor of up to OGL_MAX_BATCH independent (destinations -> picks -> block) problems, passed by value in the kernarg.
+#define OGL_MAX_BATCH 64
+struct ogl_batch_desc {
+  int64_t dst_start[OGL_MAX_BATCH];     // batch b's destinations: dst_base[dst_start[b] ..)
+  int64_t row_off[OGL_MAX_BATCH + 1];   // packed output rows: running sum of the destination counts
+  uint64_t ctr[OGL_MAX_BATCH];          // Philox batch counters (sampler only)
+};
 
 struct ogl_graph {
   const int64_t* indptr;

@@ -171,6 +171,44 @@ def build_block_async(dst: torch.Tensor, picks: torch.Tensor):
     return src_ids, n_src, local_idx
 
 
+def _host_i64(vals):
+    arr = (C.c_int64 * max(len(vals), 1))(*[int(v) for v in vals])
+    return arr
+
+
+def sample_layer_batched(g: GraphHandle, dst_base: torch.Tensor, starts, counts, fanout: int, seed: int, ctrs, layer: int):
+    """Every batch of a loader layer in one launch: batch b samples for dst_base[starts[b] : starts[b] + counts[b]] with
+    Philox counter ctrs[b]; returns the packed picks [sum(counts), fanout] (bit-identical to sample_layer per batch)."""
+    dst_base = _ids(dst_base)
+    nb, total = len(counts), int(sum(counts))
+    picks = torch.empty((total, fanout), dtype=torch.int64, device=dst_base.device)
+    c_ctr = (C.c_uint64 * max(nb, 1))(*[int(c) & (2 ** 64 - 1) for c in ctrs])
+    _launch("ogl_sample_layer_batched", _lib.lib().ogl_sample_layer_batched, g._h, _ptr(dst_base), _host_i64(starts), _host_i64(counts),
+            nb, int(fanout), C.c_uint64(seed & (2 ** 64 - 1)), c_ctr, int(layer), _ptr(picks), _stream(),
+            meta=dict(n_dst=total, fanout=int(fanout), nb=nb))
+    return picks
+
+
+def build_block_batched_async(dst_base: torch.Tensor, starts, counts, picks: torch.Tensor):
+    """Relabel every batch in one set of launches.  Returns (src_ids packed at row_off * (1 + fanout), n_src_dev [nb],
+    local_idx packed like picks) without synchronising; row_off = running sum of counts."""
+    dst_base = _ids(dst_base)
+    nb, total = len(counts), int(sum(counts))
+    fanout = picks.shape[1]
+    assert picks.shape[0] == total and picks.dtype == torch.int64 and picks.is_contiguous()
+    dev = dst_base.device
+    src_ids = torch.empty(max(total * (1 + fanout), 1), dtype=torch.int64, device=dev)
+    n_src = torch.zeros(max(nb, 1), dtype=torch.int64, device=dev)
+    local_idx = torch.empty((total, fanout), dtype=torch.int32, device=dev)
+    h_counts = _host_i64(counts)
+    nbytes = int(_lib.lib().ogl_block_workspace_bytes_batched(h_counts, nb, int(fanout)))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    _launch("ogl_build_block_batched", _lib.lib().ogl_build_block_batched, _ptr(dst_base), _host_i64(starts), h_counts, nb, _ptr(picks),
+            int(fanout), _ptr(src_ids), _ptr(n_src), _ptr(local_idx), _ptr(ws), nbytes, _stream(),
+            meta=dict(n_dst=total, fanout=int(fanout), nb=nb))
+    return src_ids, n_src, local_idx
+
+
 def build_block(dst: torch.Tensor, picks: torch.Tensor):
     src_ids, n_src, local_idx = build_block_async(dst, picks)
     n = int(n_src.item())

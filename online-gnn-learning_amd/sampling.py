@@ -8,7 +8,8 @@ MI355X-first differences (documented in DESIGN.md):
 * sampling runs on the GPU over the resident time-ordered CSR (ogl_sample_layer / ogl_build_block),
   so ``num_workers`` is accepted and ignored (HIP is not fork-safe; the forked CPU samplers are
   what this replaces);
-* a loader samples ALL its batches layer by layer before yielding the first one, so the host
+* a loader samples ALL its batches layer by layer before yielding the first one — one batched sampler launch and
+  one batched block-build sequence per layer (ogl_sample_layer_batched / ogl_build_block_batched) — so the host
   synchronises once per layer per loader (to learn the block sizes) instead of once per batch;
 * randomness is a counter-based Philox stream keyed by (seed, batch counter, layer, dst id, slot):
   reproducible, independent of batch composition and of how seeds are sharded over GPUs.
@@ -112,27 +113,39 @@ class MultiLayerNeighborSampler:
         global ``picks`` — no hash relabel, no size read-back; ``input_nodes`` is then ``None``."""
         g = graph.handle
         L = len(self.fanouts)
+        nb = len(seed_batches)
+        if nb == 0:
+            return []
         ctrs = [_next_ctr() for _ in seed_batches]
         blocks = [[None] * L for _ in seed_batches]
-        dsts = list(seed_batches)
+        # every batch of a layer goes through ONE sampler launch and ONE block-build sequence (batched C-ABI entry points):
+        # batch b's destinations are dst_base[starts[b] : starts[b] + counts[b]]
+        counts = [int(t.numel()) for t in seed_batches]
+        dst_base = seed_batches[0] if nb == 1 else torch.cat([t.reshape(-1) for t in seed_batches])
+        starts, acc = [], 0
+        for c in counts:
+            starts.append(acc); acc += c
         for layer in reversed(range(L)):
-            pend = []
+            S = self.fanouts[layer]
+            picks_all = ops.sample_layer_batched(g, dst_base, starts, counts, S, _STATE["seed"], ctrs, layer)
+            rows, acc = [], 0
+            for c in counts:
+                rows.append(acc); acc += c
+            dsts = [dst_base[s:s + c] for s, c in zip(starts, counts)]
             if layer == 0 and not relabel_input:
-                for bi, dst in enumerate(dsts):
-                    picks = ops.sample_layer(g, dst, self.fanouts[layer], _STATE["seed"], ctrs[bi], layer)
-                    blocks[bi][layer] = Block(None, dst, None, picks)
+                for bi in range(nb):
+                    blocks[bi][layer] = Block(None, dsts[bi], None, picks_all[rows[bi]:rows[bi] + counts[bi]])
                 return [(None, seeds, blk) for seeds, blk in zip(seed_batches, blocks)]
-            for bi, dst in enumerate(dsts):
-                picks = ops.sample_layer(g, dst, self.fanouts[layer], _STATE["seed"], ctrs[bi], layer)
-                src_ids, n_src, local_idx = ops.build_block_async(dst, picks)
-                pend.append((picks, src_ids, n_src, local_idx))
-            if not pend:
-                break
-            counts = torch.cat([p[2] for p in pend]).cpu().tolist()      # the one sync of this layer
-            for bi, ((picks, src_ids, _, local_idx), n) in enumerate(zip(pend, counts)):
-                src = src_ids[:n]
-                blocks[bi][layer] = Block(src, dsts[bi], local_idx, picks)
-                dsts[bi] = src
+            src_all, n_src, lidx_all = ops.build_block_batched_async(dst_base, starts, counts, picks_all)
+            n_next = n_src[:nb].cpu().tolist()                            # the one sync of this layer
+            nstarts = []
+            for bi in range(nb):
+                r0, c = rows[bi], counts[bi]
+                s0 = r0 * (1 + S)
+                src = src_all[s0:s0 + n_next[bi]]
+                blocks[bi][layer] = Block(src, dsts[bi], lidx_all[r0:r0 + c], picks_all[r0:r0 + c])
+                nstarts.append(s0)
+            dst_base, starts, counts = src_all, nstarts, n_next
         return [(blk[0].src_ids, seeds, blk) for seeds, blk in zip(seed_batches, blocks)]
 
 

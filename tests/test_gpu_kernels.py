@@ -366,3 +366,37 @@ def test_weight_grad_transposed_form(ops, gemm_mode, M, K, N):
     np.testing.assert_allclose(db.cpu().numpy(), dy.sum(0).numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL * scale)
     dw2, db2 = ops.weight_grad(dy.cuda(), tabc, rows.cuda())          # whichever form the mode selects
     np.testing.assert_allclose(dw2.cpu().numpy(), (dy.T @ tab[rows]).numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL * scale)
+
+
+def test_batched_sampler_and_block_build_bit_exact(ops):
+    """ogl_sample_layer_batched / ogl_build_block_batched == the per-batch entry points, batch by batch (ragged sizes,
+    an empty batch, more batches than one descriptor chunk holds)."""
+    rng = np.random.default_rng(5)
+    n = 4000
+    deg = rng.integers(0, 12, n); deg[rng.random(n) < 0.1] = 0
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    indices = np.concatenate([np.sort(rng.integers(0, n, d)) for d in deg] + [np.zeros(0, np.int64)]).astype(np.int32)
+    g = ops.GraphHandle(dev(indptr), dev(indices)); g.set_snapshot(n, n)
+    sizes = [37, 0, 512, 1, 100] + [int(x) for x in rng.integers(1, 60, 70)]            # 75 batches > 64
+    base = dev(rng.integers(0, n, sum(sizes) + 50).astype(np.int64))
+    starts, acc = [], 7
+    for c in sizes:
+        starts.append(acc); acc += c
+    ctrs = list(range(100, 100 + len(sizes)))
+    S = 6
+    picks = ops.sample_layer_batched(g, base, starts, sizes, S, 9, ctrs, 1)
+    src_all, n_src, lidx_all = ops.build_block_batched_async(base, starts, sizes, picks)
+    n_src = n_src.cpu().tolist()
+    r = 0
+    for b, c in enumerate(sizes):
+        dst = base[starts[b]:starts[b] + c]
+        want_p = ops.sample_layer(g, dst, S, 9, ctrs[b], 1)
+        assert torch.equal(picks[r:r + c], want_p)
+        if c:
+            s_ref, li_ref, n_ref = ops.build_block(dst, want_p)
+            assert n_src[b] == n_ref
+            assert torch.equal(src_all[r * (1 + S): r * (1 + S) + n_ref], s_ref)
+            assert torch.equal(lidx_all[r:r + c], li_ref)
+        else:
+            assert n_src[b] == 0
+        r += c
