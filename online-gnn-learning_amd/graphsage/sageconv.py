@@ -108,6 +108,11 @@ class SAGEConv(nn.Module):
             return self._forward_cached(graph, feat, fuse_relu)
         feat_dst = feat.head(n_dst) if lazy else feat[:n_dst]
 
+        if (t == "pool" and not lazy and self.norm is None and (self.activation is None or fuse_relu)
+                and (self.fc_self.bias is None) == (self.fc_neigh.bias is None) and idx.dtype == torch.int32):
+            # input with a gradient (every layer but the first): the whole layer is one autograd node
+            return ops.sage_pool_layer(feat, self.fc_pool.weight, self.fc_pool.bias, self.fc_self.weight, self.fc_neigh.weight,
+                                       self.fc_self.bias, self.fc_neigh.bias, idx, n_dst, fuse_relu)
         if t == "pool":
             h_neigh = self._pool_max(feat, idx)
             bias = None

@@ -653,6 +653,52 @@ class _PoolMaxFn(torch.autograd.Function):
         return dx, dw, (db if ctx.has_bias else None), None, None
 
 
+class _SagePoolLayerFn(torch.autograd.Function):
+    """One autograd node for a whole 'pool' SAGEConv layer whose input carries a gradient (every layer but the first):
+    out = act(fc_self(h[:n_dst]) + fc_neigh(max_j relu(fc_pool(h))[idx]) + b_self + b_neigh).
+    h has two consumers (its first n_dst rows feed fc_self, all rows feed fc_pool); as separate nodes autograd pays a
+    slice-backward (zero fill + copy of a [n_src, K] matrix) and a full-size gradient add per step.  Here the input
+    gradient is the pool path's matrix with the fc_self part added in place to its first n_dst rows."""
+
+    @staticmethod
+    def forward(ctx, h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu):
+        h = as_mat(h)
+        p = linear_fwd(h, w_pool, b_pool, relu=True)
+        need = any(t is not None and t.requires_grad for t in (h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh))
+        neigh, argmax = reduce_fwd(p, idx, "max", want_argmax=need)
+        bias = None
+        if b_self is not None:
+            bias = b_self + b_neigh
+        out = linear_fwd(h[:n_dst], w_self, bias, x2=neigh, w2=w_neigh, relu=relu)
+        ctx.relu, ctx.n_dst, ctx.fanout, ctx.has_bias, ctx.has_pool_bias = bool(relu), n_dst, idx.shape[1], b_self is not None, b_pool is not None
+        ctx.save_for_backward(h, w_pool, w_self, w_neigh, neigh, argmax, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, w_pool, w_self, w_neigh, neigh, argmax, out = ctx.saved_tensors
+        dy = as_mat(dy)
+        if out is not None:
+            dy = relu_bwd(dy, out)
+        n_dst, n_src = ctx.n_dst, h.shape[0]
+        h_dst = h[:n_dst]
+        dyT = transposed_operand(dy) if (_MODE["name"] != "f32" and dy.shape[0] >= 1024) else None
+        dw_self, db = weight_grad(dy, h_dst, None, want_bias=ctx.has_bias, dyT=dyT)
+        dw_neigh, _ = weight_grad(dy, neigh, None, want_bias=False, dyT=dyT)
+        dneigh = linear_bwd_input(dy, w_neigh, None)
+        dp = reduce_bwd(dneigh, None, argmax, "max", n_src, fanout=ctx.fanout, relu_out=neigh)
+        dh = linear_bwd_input(dp, w_pool, None)
+        dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias)
+        dx_self = linear_bwd_input(dy, w_self, None)
+        dh[:n_dst].add_(dx_self)                                  # the fc_self path, in place on the first n_dst rows
+        return (dh, dw_pool, db_pool if ctx.has_pool_bias else None, dw_self, dw_neigh, db if ctx.has_bias else None,
+                db if ctx.has_bias else None, None, None, None)
+
+
+def sage_pool_layer(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu):
+    return _SagePoolLayerFn.apply(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu)
+
+
 def pool_max(x, w, bias, idx, x_rows=None):
     """max_j relu(fc_pool(x))[idx[:, j]] — the aggregator of the live 'pool' layer (and in-repo 'maxpool')."""
     return _PoolMaxFn.apply(x, w, bias, x_rows, idx)
