@@ -722,8 +722,26 @@ class _CrossEntropyRowsFn(torch.autograd.Function):
         return dl * dloss.reshape(-1, 1), None
 
 
+class _CrossEntropyMeanFn(torch.autograd.Function):
+    """reduction='mean' as one node: the kernel writes dlogits already scaled by 1/B, backward is one scalar multiply."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        B = max(logits.shape[0], 1)
+        rows, dl = ce_fwd_bwd(logits, labels, 1.0 / B, want_grad=logits.requires_grad)
+        ctx.save_for_backward(dl)
+        return rows.mean()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dl,) = ctx.saved_tensors
+        return dl * dloss, None
+
+
 def cross_entropy(logits, labels, reduction="mean"):
     """nn.CrossEntropyLoss(reduction) on the HIP kernel; 'none' returns the per-seed vector."""
+    if reduction == "mean":
+        return _CrossEntropyMeanFn.apply(logits, labels)
     rows = _CrossEntropyRowsFn.apply(logits, labels)
     if reduction == "none":
         return rows
