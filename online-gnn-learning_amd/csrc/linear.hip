@@ -494,7 +494,33 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(GemmArgs g) {
       bp[t] = pt.b.ptr + (bok[t] ? j : 0) * pt.b.ld;
     }
     const int64_t nchunk = (R + 7) / 8;
-    for (int64_t c = wid; c < nchunk; c += 4) {
+    // four whole chunks per round, all their loads issued before the first MFMA: this kernel is a serial chain of
+    // global round trips (few blocks, long K), so the number of rounds is what it costs
+    const int64_t nfull = R / 8;
+    int64_t c = wid;
+    for (; c + 12 < nfull; c += 16) {
+      float4 a4[4], b4[4][NT];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t k = (c + 4 * u) * 8 + 4 * half;
+        a4[u] = ld16(ap + k);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b4[u][t] = ld16(bp[t] + k);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 a = aok ? a4[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float4 b = bok[t] ? b4[u][t] : make_float4(0.f, 0.f, 0.f, 0.f);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    for (; c < nchunk; c += 4) {
       const int64_t k = c * 8 + 4 * half;
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b[NT];
       const bool full = k + 3 < R;
