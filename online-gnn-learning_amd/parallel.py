@@ -104,8 +104,13 @@ class GradSynchronizer:
                 break
             late.append(i); acc += n
         late = list(reversed(late))
+        early = [i for i in order if i not in set(late)]
+        # every rank must cut the SAME buckets (the collectives are matched by order and size): rank 0's split wins
+        box = [early, late]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        early, late = box
         self._late = late
-        self._early = [i for i in order if i not in set(late)]
+        self._early = early
         self._early_set = set(self._early)
         if not self._early:
             self._early = None
