@@ -328,3 +328,37 @@ def test_pool_max_autograd_uses_fused_backward(ops):
     scale = float(res["unfused"][1].abs().max())
     np.testing.assert_allclose(res["fused"][1].cpu().numpy(), res["unfused"][1].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
     np.testing.assert_allclose(res["fused"][2].cpu().numpy(), res["unfused"][2].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+
+
+def test_pool_backward_limits(ops):
+    """Largest shapes the fused pool backward accepts (fanout 63, 640 columns) and its argument errors."""
+    import ctypes as C
+    from ogl_amd import _lib
+    torch.manual_seed(2)
+    n_dst, S, D, n_src = 90, 63, 640, 3000
+    idx = torch.randint(0, n_src, (n_dst, S), dtype=torch.int32).cuda()
+    pm = ops.empty_mat(n_src, D, "cuda"); pm.normal_().clamp_min_(0)
+    out, argmax = ops.reduce_fwd(pm, idx, "max", want_argmax=True)
+    dm = ops.empty_mat(n_dst, D, "cuda"); dm.normal_()
+    img = ops.pool_bwd_x3(dm, argmax, out, idx, n_src)
+    G = (n_src + 31) // 32
+    got = image_decode_t(img.buf, D, 32 * G)
+    dP = ops.reduce_bwd(dm, None, argmax, "max", n_src, fanout=S, relu_out=out).cpu()
+    mm = np.arange(32 * G); s_of_m = (mm % 32) * G + mm // 32; ok = s_of_m < n_src
+    np.testing.assert_allclose(got[:, ok].T.numpy(), dP[s_of_m[ok]].numpy(), rtol=1e-5, atol=1e-5)
+    h = _lib.lib()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    ws = torch.empty(1 << 20, dtype=torch.uint8).cuda()
+    args = lambda fan, d: (p(dm), 640, p(argmax), p(out), 640, p(idx), n_dst, fan, d, n_src, p(img.buf), p(ws), ws.numel(), None)
+    assert h.ogl_pool_bwd_x3(*args(64, 640)) == -1                 # fanout > 63
+    assert h.ogl_pool_bwd_x3(*args(63, 641)) == -1                 # more columns than a bucket wave holds
+    assert h.ogl_pool_bwd_x3(p(dm), 640, p(argmax), p(out), 640, p(idx), n_dst, S, D, n_src, p(img.buf), p(ws), 64, None) == -4
+
+
+def test_forward_degenerate_shapes(ops):
+    torch.manual_seed(6)
+    for M, K, N in [(70000, 1, 1), (300, 5, 1), (1, 700, 3)]:
+        x = torch.randn(M, K); w = torch.randn(N, K); b = torch.randn(N)
+        xm = ops.empty_mat(M, K, "cuda"); xm.copy_(x)
+        y = ops.linear_fwd_x3(ops.x3_split(xm, append_ones=True), None, ops.x3_split(w.cuda(), append_vec=b.cuda()))
+        np.testing.assert_allclose(y.cpu().numpy(), (x.double() @ w.double().T + b.double()).float().numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL)
