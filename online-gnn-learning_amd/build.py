@@ -20,7 +20,23 @@ def needs_build():
     return any(os.path.getmtime(p) > t for p in deps)
 
 
+HOST_LIB = os.path.join(HERE, "libogl_host.so")
+HOST_SRC = os.path.join(HERE, "csrc_host", "host_replay.c")
+
+
+def build_host(force=False, verbose=False):
+    """The optional host helper (replay-buffer arithmetic as a C loop; pure-Python fallback when it is absent)."""
+    if not force and os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) >= os.path.getmtime(HOST_SRC):
+        return HOST_LIB
+    cmd = ["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", HOST_SRC, "-lm", "-o", HOST_LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return HOST_LIB
+
+
 def build(force=False, verbose=False):
+    build_host(force, verbose)
     if not force and not needs_build():
         return LIB
     cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",

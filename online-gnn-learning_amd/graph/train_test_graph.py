@@ -16,6 +16,8 @@ from __future__ import annotations
 
 import random
 
+import numpy as np
+
 from sklearn.model_selection import train_test_split
 
 from ..prioritized_replay.replay_buffer import PrioritizedReplayBuffer
@@ -68,7 +70,8 @@ class TrainTestGraph:
         else:
             lo = buf.get_min_priority()
             entry = lo + (hi - lo) * 0.95
-        buf.add_all(dict.fromkeys(self.train, entry))
+        fresh = list(dict.fromkeys(self.train))
+        buf.add_all_arrays(np.asarray(fresh, dtype=np.int64), np.full(len(fresh), float(entry))) if fresh else None
 
     # ---- stream ---------------------------------------------------------------------------------------------
     def __len__(self):
@@ -133,6 +136,16 @@ class TrainTestGraph:
     # ---- priorities -----------------------------------------------------------------------------------------
     def dump_priorities(self, vertex_list):
         return self.priority_replay_buffer.dump_priorities(vertex_list)
+
+    def update_priorities_arrays(self, ids, priorities):
+        """update_priorities(dict(zip(ids, priorities))) without the dict: distinct original vertex ids as an array."""
+        ids = np.asarray(ids)
+        assert len(ids) <= len(self.train_set)
+        if len(ids) == len(self.train_set):
+            self.priority_replay_buffer = self._fresh_buffer()
+            self.priority_replay_buffer.add_all_arrays(ids, priorities)
+        else:
+            self.priority_replay_buffer.update_arrays(ids, priorities)
 
     def update_priorities(self, d_priorities):
         """{original vertex id: new priority}.  A partial update rewrites leaves; a full one rebuilds the buffer."""

@@ -281,7 +281,7 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
             for n in sizes:
                 batch_nodes_seed = subgraph_to_id[all_seeds[off:off + n]]
                 priorities = self.priority_strategy.get_priorities(batch_nodes_seed, all_loss[off:off + n])
-                graph_util.update_priorities(dict(zip(np.asarray(batch_nodes_seed).tolist(), np.asarray(priorities).tolist())))
+                graph_util.update_priorities_arrays(np.asarray(batch_nodes_seed), np.asarray(priorities, dtype=np.float64))
                 off += n
         self.time_step += 1
 
@@ -307,7 +307,7 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
         unaggregated_loss = torch.cat(losses).cpu().numpy()
         batch_nids_l = list(subgraph_to_id[torch.cat(nid_chunks).cpu().numpy()])
         priorities = self.priority_strategy.get_priorities(batch_nids_l, unaggregated_loss)
-        graph_util.update_priorities(dict(zip(np.asarray(batch_nids_l).tolist(), np.asarray(priorities).tolist())))
+        graph_util.update_priorities_arrays(np.asarray(batch_nids_l), np.asarray(priorities, dtype=np.float64))
 
     def get_model(self):
         return "prioritized"

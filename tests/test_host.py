@@ -216,3 +216,43 @@ def test_macro_f1_from_confusion_matches_sklearn():
         assert abs(f1 - f1_score(y, p, average="macro")) < 1e-12
         assert flat == [int(v) for row in confusion_matrix(y, p) for v in row]
     assert macro_f1_from_confusion(np.zeros((4, 4)))[0] == 0.0
+
+
+def _tree_state(buf):
+    n = len(buf)
+    return (buf._it_sum.node[buf._it_sum.capacity:buf._it_sum.capacity + n].copy(), buf._it_sum.node[1],
+            buf._max_priority, buf._min_priority, buf.max_val, buf.min_val)
+
+
+@pytest.mark.parametrize("helper", [True, False])
+def test_replay_array_entry_points_equal_dict_api(helper, monkeypatch):
+    """add_all_arrays / update_arrays (the C loop of libogl_host.so, or its Python fallback) leave EXACTLY the state the
+    dict API leaves: leaves, root, running extrema — over growing trees, changing extrema, alpha up to 50."""
+    from ogl_amd.prioritized_replay import replay_buffer as rb
+    monkeypatch.setattr(rb, "_HOST", None if helper else False)
+    if helper and rb.host_helper() is None:
+        pytest.skip("libogl_host.so not built")
+    rng = np.random.default_rng(7)
+    for alpha in (0.6, 4.0, 50.0):
+        a = PrioritizedReplayBuffer(10_000_000, alpha, 10, 1e-7)
+        b = PrioritizedReplayBuffer(10_000_000, alpha, 10, 1e-7)
+        keys = rng.permutation(40_000)[:5_000].astype(np.int64)
+        pr = np.exp(rng.uniform(-20, 4, keys.size))                      # far outside the clip range on both sides
+        a.add_all(dict(zip(keys.tolist(), pr.tolist())))
+        b.add_all_arrays(keys, pr)
+        for step in range(12):
+            sel = rng.choice(keys, 300, replace=False)
+            newp = np.exp(rng.uniform(-25 + step, 6 - step * 0.3, 300)).astype(np.float32)   # float32 losses, as from the GPU
+            a.update_priorities(dict(zip(sel.tolist(), newp.tolist())))
+            b.update_arrays(sel, newp)
+            more = np.arange(50_000 + step * 900, 50_000 + (step + 1) * 900, dtype=np.int64)   # forces tree growth
+            a.add_all(dict.fromkeys(more.tolist(), 3.5))
+            b.add_all_arrays(more, np.full(more.size, 3.5))
+        sa, sb = _tree_state(a), _tree_state(b)
+        assert np.array_equal(sa[0], sb[0]) and sa[1:] == sb[1:]
+        assert a.dump_priorities(keys[:100].tolist()) == b.dump_priorities(keys[:100].tolist())
+        random.seed(5); ia = sorted(a._sample_proportional(200))
+        random.seed(5); ib = sorted(b._sample_proportional(200))
+        assert ia == ib
+    with pytest.raises(KeyError):
+        b.update_arrays(np.array([10 ** 7], dtype=np.int64), np.array([1.0]))
