@@ -140,7 +140,11 @@ class GradSynchronizer:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             self._scatter(idxs, flat)
             if self.overlap and self._early is None and weight is None:
-                self._learn()
+                try:
+                    self._learn()
+                except Exception:                 # the exchange stays correct with the single bucket; only the overlap is lost
+                    self._early = self._late = None
+                    self.overlap = False
         self._pending = None
         self._arrived = 0
         self._order = []
