@@ -362,3 +362,44 @@ def test_forward_degenerate_shapes(ops):
         xm = ops.empty_mat(M, K, "cuda"); xm.copy_(x)
         y = ops.linear_fwd_x3(ops.x3_split(xm, append_ones=True), None, ops.x3_split(w.cuda(), append_vec=b.cuda()))
         np.testing.assert_allclose(y.cpu().numpy(), (x.double() @ w.double().T + b.double()).float().numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL)
+
+
+def test_random_shape_sweep(ops):
+    """Seeded sweep over ragged shapes: image GEMMs (forward with folded bias, weight gradient) and the fused pool
+    backward against fp64 / the unfused path.  Sizes straddle every tile, group and chunk boundary."""
+    rng = np.random.default_rng(2026)
+    for _ in range(24):
+        M = int(rng.choice([1, 31, 32, 33, 127, 128, 129, 255, 256, 257, 511, 1000, 4097]))
+        K = int(rng.choice([1, 7, 31, 32, 33, 63, 64, 65, 200, 602]))
+        N = int(rng.choice([1, 3, 31, 32, 33, 127, 128, 129, 300]))
+        x = torch.tensor(rng.standard_normal((M, K)), dtype=torch.float32)
+        w = torch.tensor(rng.standard_normal((N, K)) / np.sqrt(K), dtype=torch.float32)
+        b = torch.tensor(rng.standard_normal(N), dtype=torch.float32)
+        xm = ops.empty_mat(M, K, "cuda"); xm.copy_(x)
+        y = ops.linear_fwd_x3(ops.x3_split(xm, append_ones=True), None, ops.x3_split(w.cuda(), append_vec=b.cuda()), relu=bool(M & 1))
+        want = x.double() @ w.double().T + b.double()
+        if M & 1:
+            want = want.clamp_min(0)
+        np.testing.assert_allclose(y.cpu().numpy(), want.float().numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL * 2, err_msg=str((M, K, N)))
+        dy = torch.tensor(rng.standard_normal((M, N)), dtype=torch.float32)
+        dym = ops.empty_mat(M, N, "cuda"); dym.copy_(dy)
+        G = (M + 31) // 32 if (K & 1) else 0
+        dw, db = ops.linear_bwd_weight_x3(ops.x3_split_t(dym, interleave=G), ops.x3_split_t(xm, None, ones_row=True, interleave=G))
+        scale = max(1.0, np.sqrt(M))
+        np.testing.assert_allclose(dw.cpu().numpy(), (dy.double().T @ x.double()).float().numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL * scale,
+                                   err_msg=str((M, K, N)))
+        np.testing.assert_allclose(db.cpu().numpy(), dy.double().sum(0).float().numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL * scale)
+    for _ in range(12):
+        n_dst = int(rng.choice([1, 5, 64, 333, 2049])); S = int(rng.choice([1, 2, 16, 17, 25, 40]))
+        D = int(rng.choice([1, 63, 64, 65, 130, 602])); n_src = int(rng.choice([1, 31, 32, 33, 500, 5000]))
+        idx = torch.tensor(rng.integers(-1, n_src, (n_dst, S)), dtype=torch.int32).cuda()
+        pm = ops.empty_mat(n_src, D, "cuda"); pm.copy_(torch.tensor(rng.standard_normal((n_src, D)), dtype=torch.float32).clamp_min(0))
+        out, argmax = ops.reduce_fwd(pm, idx, "max", want_argmax=True)
+        dm = ops.empty_mat(n_dst, D, "cuda"); dm.copy_(torch.tensor(rng.standard_normal((n_dst, D)), dtype=torch.float32))
+        img = ops.pool_bwd_x3(dm, argmax, out, idx, n_src)
+        G = (n_src + 31) // 32
+        got = image_decode_t(img.buf, D, 32 * G)
+        dP = ops.reduce_bwd(dm, None, argmax, "max", n_src, fanout=S, relu_out=out).cpu()
+        mm = np.arange(32 * G); s_of_m = (mm % 32) * G + mm // 32; ok = s_of_m < n_src
+        assert (got[:, ~ok] == 0).all()
+        np.testing.assert_allclose(got[:, ok].T.numpy(), dP[s_of_m[ok]].numpy(), rtol=1e-4, atol=1e-4, err_msg=str((n_dst, S, D, n_src)))
