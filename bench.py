@@ -214,7 +214,8 @@ def main():
         # which arithmetic did this launch run on?  (ops.weight_grad / linear.hip AUTO policy)
         x6 = args.gemm == "bf16x6" or (args.gemm == "auto" and ("_x3" in dom or "bwd_weight_t" in dom or "bwd_weight" not in dom))
         peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if x6 else MFMA_F32_PEAK_TFLOPS
-        roof_gemm = dict(kernel="%s (%s; %s)" % ("k_gemm_x3" if "_x3" in dom else "k_gemm", dom, "split-bf16 x6 on v_mfma_f32_32x32x16_bf16, fp32 accumulate" if x6
+        roof_gemm = dict(kernel="%s (%s; %s)" % ("k_gemm_x3" if "_x3" in dom else "k_gemm", dom, ("split-bf16 x6 on v_mfma_f32_16x16x32_bf16, fp32 accumulate" if "_x3" in dom else
+                                                       "split-bf16 x6 on v_mfma_f32_32x32x16_bf16, fp32 accumulate") if x6
                                                       else "v_mfma_f32_32x32x2_f32"),
                          bound="mfma", achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
                          traffic=None, avg_launch_ms=round(agg[dom]["ms"] / agg[dom]["calls"], 4),

@@ -169,7 +169,8 @@ int ogl_transpose(const float* src, int64_t ld, const int64_t* rows, int64_t nro
 /* ------------------------------------------------------------------------------------------
  * The same projections on PRE-SPLIT operands ("bf16x3 images", linear_x3.hip): the exact 3-term bf16 split of the
  * x6 arithmetic is done once per matrix by ogl_x3_split / ogl_x3_split_t instead of by every GEMM block, and the
- * GEMM stages its tiles global -> LDS by LDS-DMA.  Same results as OGL_GEMM_BF16X6 (same products, same order).
+ * GEMM stages its tiles global -> LDS by LDS-DMA.  Same six product terms as OGL_GEMM_BF16X6 (fp32 accuracy; the
+ * summation order inside a term differs, so the two agree to fp32 rounding noise, not bit for bit).
  * Used for the large layer-0 products: the static feature table (R/train/graphsage/pytorch/model.py:62,
  * `graph.ndata['feat'][input_nodes]`) is split once per dataset, weights once per call.
  *

@@ -104,7 +104,8 @@ def test_forward_matches_on_the_fly_x6_and_fp64(ops, M, K, N, relu):
     if relu:
         want = want.clamp_min(0)
     np.testing.assert_allclose(got.cpu().numpy(), want.float().numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL)
-    # without a bias the products and their order are those of the on-the-fly x6 kernel: bit-identical
+    # without a bias the six product terms are those of the on-the-fly x6 kernel; the image kernel sums each term over
+    # 32 reduction elements per MFMA (16x16x32) where that one sums over 16 (32x32x16): fp32 summation-order noise only
     got0 = ops.linear_fwd_x3(ops.x3_split(tm), rc, ops.x3_split(wc), relu=relu)
     old = ops.get_gemm_mode()
     try:
@@ -112,8 +113,7 @@ def test_forward_matches_on_the_fly_x6_and_fp64(ops, M, K, N, relu):
         ref = ops.linear_fwd(tm, wc, None, relu=relu, x_rows=rc)
     finally:
         ops.set_gemm_mode(old)
-    if N > 64 or M > 4096:                                        # (the skinny kernel sums K in another order)
-        assert torch.equal(got0, ref)
+    np.testing.assert_allclose(got0.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-6)
     # ungathered operand
     got2 = ops.linear_fwd_x3(ops.x3_split(tm[:M]), None, ops.x3_split(wc), relu=False)
     np.testing.assert_allclose(got2.cpu().numpy(), (tab[:M].double() @ w.double().T).float().numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL)

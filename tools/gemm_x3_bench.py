@@ -27,6 +27,8 @@ def main():
     b = torch.randn(F, device="cuda")
     dp0 = ops.empty_mat(n0, F, "cuda"); dp0.normal_()
     fl = 2.0 * n0 * F * F
+    if os.environ.get("X3_ZERO"):   # DVFS probe: same launches on all-zero operands (the clock the chip holds differs)
+        table.zero_(); wp.zero_(); b.zero_(); dp0.zero_()
 
     def rep(name, ms, flops=None):
         print("%-56s %8.3f ms  %s" % (name, ms, "%7.1f TFLOP/s" % (flops / ms / 1e9) if flops else ""), flush=True)
@@ -36,6 +38,11 @@ def main():
     rep("x3_split weight [602,602] (+bias)", timeit(lambda: ops.x3_split(wp, append_vec=b)))
     rep("fwd pool0 on-the-fly x6 (rows+relu)", timeit(lambda: ops.linear_fwd(table, wp, b, relu=True, x_rows=rows0)), fl)
     rep("fwd pool0 x3 images (rows+relu)", timeit(lambda: ops.linear_fwd_x3(t_img, rows0, w_img, relu=True)), fl)
+    rows_c = torch.arange(n0, device="cuda")
+    rows_s = torch.sort(rows0).values
+    rep("fwd pool0 x3, rows = arange (gather path, contiguous)", timeit(lambda: ops.linear_fwd_x3(t_img, rows_c, w_img, relu=True)), fl)
+    rep("fwd pool0 x3, rows = sorted random", timeit(lambda: ops.linear_fwd_x3(t_img, rows_s, w_img, relu=True)), fl)
+    rep("fwd pool0 x3, no gather [n0 rows]", timeit(lambda: ops.linear_fwd_x3(t_img, None, w_img, relu=True, M=n0)), fl)
     rep("fwd whole table x3 [%d]" % T, timeit(lambda: ops.linear_fwd_x3(t_img, None, w_img, relu=True), 5), 2.0 * T * F * F)
     rep("fwd whole table on-the-fly x6", timeit(lambda: ops.linear_fwd(table, wp, b, relu=True), 5), 2.0 * T * F * F)
     rep("transpose dy + transpose x[rows] (fp32)", timeit(lambda: (ops.transpose(dp0), ops.transpose(table, rows0))))
