@@ -21,6 +21,7 @@
 // The matrix instruction is v_mfma_f32_16x16x32_bf16 (one MFMA = one product term over the whole 32-deep step).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "x6_arith.h"
 
 #define X3_GROUP_BYTES 192
@@ -45,14 +46,24 @@ struct X3Args {
   int nsplit, steps_per_split;
   float* ws; int64_t ws_ld;
   int NI, NJ;
+  unsigned long long* stamps;   // diagnostics only (ogl_x3_debug_stamps): per block {s_memtime, s_memrealtime} at entry and exit
 };
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) — indices into register arrays stay constants
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>());
+    static_for<B + 1, E>(f);
+  }
+}
 
 __device__ float4 g_x3_trash[64];   // where epilogue lanes with nothing to store aim their (statically counted) stores
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int MT>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int MT, bool SPREAD>
 __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
   static_assert(MT == 32 || MT == 16, "v_mfma_f32_32x32x16_bf16 or v_mfma_f32_16x16x32_bf16");
   constexpr int RB = TM * 32 / MT, CB = TN * 32 / MT;   // MFMA row / column blocks of a wave tile
@@ -67,7 +78,8 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
   static_assert(BM * 12 % NT == 0, "A / B pieces split on a load boundary");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the LDS base of every DMA piece is scalar
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
   const int l31 = lane & 31, half = lane >> 5;
   const int l15 = lane & 15, quad = lane >> 4;
@@ -83,6 +95,11 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   const int chunk_begin = xcd * (T >> 3) + min(xcd, T & 7), chunk_len = (T >> 3) + (xcd < (T & 7) ? 1 : 0);
   if (slot >= chunk_len) return;
+  if (g.stamps && tid == 0) {
+    g.stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
+    g.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  }
 
   struct Tile { int64_t i0, j0; int split, ks_begin, ks_end; };
   auto decode = [&](int logical) {
@@ -180,7 +197,7 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
   // finished tile stay live under the next tile's first step, so the register budget goes to them, not to deeper
   // prefetch).  MT 16: every MFMA spans the whole step; the A fragments stay, the B fragments are streamed per block.
   // Per accumulator the six products go smallest terms first (i + j = 4, then 3, then 2) — as in k_gemm's x6 path.
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, int fetch_buf) __attribute__((always_inline)) {   // fetch_buf >= 0: also issue the next stage's DMA into it
     const unsigned char* st = smem + buf * STAGE;
     if constexpr (MT == 32) {
 #pragma unroll
@@ -207,26 +224,46 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
           }
       }
     } else {
-      bf16x8 a[RB][3];
+      // A fragments first, B blocks streamed one ahead (two-deep ring), and the DMA pieces of the NEXT stage spread
+      // between the MFMA groups of the first three quarters of the step: a DMA instruction holds its wave for 40-300
+      // cycles (the CU's address unit takes one per ~38 cycles when all eight waves feed it), issued in one burst at
+      // the top of the step they idle the matrix pipe; spread out, the SIMD's other wave multiplies meanwhile.
+      bf16x8 a[RB][3], b[2][3];
 #pragma unroll
       for (int t = 0; t < RB; ++t)
 #pragma unroll
         for (int sp = 0; sp < 3; ++sp) a[t][sp] = *(const bf16x8*)(st + offa[t][0] + sp * 64);
 #pragma unroll
-      for (int y = 0; y < CB; ++y) {
-        bf16x8 b[3];
+      for (int sp = 0; sp < 3; ++sp) b[0][sp] = *(const bf16x8*)(st + offb[0][0] + sp * 64);
+      constexpr int NG = RB * CB, NGI = NG / 2;   // DMA slots: the MFMA groups of the first half of the step
+      static_for<0, CB>([&](auto yc) __attribute__((always_inline)) {
+        constexpr int y = decltype(yc)::value;
+        if constexpr (y + 1 < CB) {
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) b[sp] = *(const bf16x8*)(st + offb[y][0] + sp * 64);
-#pragma unroll
-        for (int x = 0; x < RB; ++x) {
-          acc4[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[2], a[x][0], acc4[x][y], 0, 0, 0);
-          acc4[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1], a[x][1], acc4[x][y], 0, 0, 0);
-          acc4[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[x][2], acc4[x][y], 0, 0, 0);
-          acc4[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1], a[x][0], acc4[x][y], 0, 0, 0);
-          acc4[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[x][1], acc4[x][y], 0, 0, 0);
-          acc4[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[x][0], acc4[x][y], 0, 0, 0);
+          for (int sp = 0; sp < 3; ++sp) b[(y + 1) & 1][sp] = *(const bf16x8*)(st + offb[y + 1][0] + sp * 64);
         }
-      }
+        static_for<0, RB>([&](auto xc) __attribute__((always_inline)) {
+          constexpr int x = decltype(xc)::value, gi = y * RB + x;
+          acc4[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][2], a[x][0], acc4[x][y], 0, 0, 0);
+          acc4[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][1], a[x][1], acc4[x][y], 0, 0, 0);
+          acc4[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][2], acc4[x][y], 0, 0, 0);
+          acc4[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][1], a[x][0], acc4[x][y], 0, 0, 0);
+          acc4[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][1], acc4[x][y], 0, 0, 0);
+          acc4[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][0], acc4[x][y], 0, 0, 0);
+          // the pieces u with u * NGI / NLOAD == gi go out behind this group
+          static_for<0, NLOAD>([&](auto uc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value;
+            if constexpr (u * NGI / NLOAD == gi) {
+              if (fetch_buf >= 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src[u], (lptr_t)(smem + fetch_buf * STAGE + (u * NT + wid * 64) * 16), 16, 0, 0);
+                src[u] += u < NLOAD_A ? g.a.step_bytes : g.b.step_bytes;
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          });
+        });
+      });
     }
   };
 
@@ -327,17 +364,24 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
       // row ids of the NEXT tile: fetched after this tile's first barrier (behind the previous epilogue's stores, which
       // nothing waits for any more), consumed at the last step
       if (ks == tc.ks_begin && has_next) load_rids(tn, rid_next);
-      if (ks + 1 < tc.ks_end) {
-        issue(buf ^ 1);
-      } else if (has_next) {
-        make_src(tn, rid_next);
-        issue(buf ^ 1);
+      const bool more = ks + 1 < tc.ks_end;
+      if (!more && has_next) make_src(tn, rid_next);
+      if constexpr (MT == 32 || !SPREAD) {
+        if (more || has_next) issue(buf ^ 1);
+        compute(buf, -1);
+      } else {
+        compute(buf, more || has_next ? buf ^ 1 : -1);
       }
-      compute(buf);
       buf ^= 1;
     }
     epilogue(tc);
-    if (!has_next) break;
+    if (!has_next) {
+      if (g.stamps && tid == 0) {
+        g.stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+        g.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+      }
+      break;
+    }
     cur = nxt; tc = tn; first_tile = false;
   }
 }
@@ -517,8 +561,18 @@ static int x3_config(int64_t M, int64_t N) {
   return w1 * 10 < w0 * 9 ? 1 : 0;   // the wider wave tile unless it pads > 10 % more MFMA work
 }
 
+// Diagnostics: when set, every k_gemm_x3 launch writes per block {s_memtime, s_memrealtime} at entry and at exit (4 x u64
+// per block, <= 256 blocks) into `buf` — the in-kernel shader clock is d(memtime) / d(memrealtime) x 100 MHz.
+static unsigned long long* g_x3_stamps = nullptr;
+extern "C" int ogl_x3_debug_stamps(void* buf, int probe) {
+  (void)probe;
+  g_x3_stamps = (unsigned long long*)buf;
+  return OGL_OK;
+}
+
 static int launch_x3(X3Args& g, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0) return OGL_OK;
+  g.stamps = g_x3_stamps;
   const int cfg = x3_config(g.M, g.N);
   const int BM = cfg == 0 ? 256 : 128, BN = 128;
   g.NI = (int)ogl_cdiv(g.M, BM);
@@ -527,8 +581,10 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
   dim3 grid((unsigned)(8 * std::min<int64_t>(32, ogl_cdiv(T, 8)))), block(512);   // persistent: at most one block per CU
   // MT = 16 (v_mfma_f32_16x16x32_bf16): same cycles per flop as the 32x32x16 form (MT = 32, kept in the template),
   // but the chip holds a higher clock under it on random data: measured 8-9 % faster at the layer-0 shapes
-  if (cfg == 0) hipLaunchKernelGGL((k_gemm_x3<4, 2, 2, 2, 16>), grid, block, 0, stream, g);
-  else hipLaunchKernelGGL((k_gemm_x3<2, 4, 2, 1, 16>), grid, block, 0, stream, g);
+  // DMA issue: spread between the MFMA groups for the 256 x 128 tile (2-3 % faster, A/B on one device), in one burst at
+  // the top of the step for the 128 x 128 tile (its steps are too short to hide a late piece: spread measured 9 % slower)
+  if (cfg == 0) hipLaunchKernelGGL((k_gemm_x3<4, 2, 2, 2, 16, true>), grid, block, 0, stream, g);
+  else hipLaunchKernelGGL((k_gemm_x3<2, 4, 2, 1, 16, false>), grid, block, 0, stream, g);
   OGL_CHECK_LAUNCH();
   if (g.nsplit > 1) {
     hipLaunchKernelGGL(k_x3_splitk_reduce, dim3((unsigned)min((int64_t)2048, ogl_cdiv(g.M * g.N, 256))), dim3(256), 0, stream, g);

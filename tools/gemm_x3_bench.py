@@ -60,5 +60,52 @@ def main():
     rep("x3_split [n1,602]", timeit(lambda: ops.x3_split(x1)))
 
 
+def clock_probe():
+    """In-kernel shader clock of k_gemm_x3 (MI355X_MICROARCH.md, DVFS give-back item 6): >= 2 s of back-to-back launches,
+    then d(s_memtime) / d(s_memrealtime) x 100 MHz per block of the last launch; median over blocks."""
+    import time
+    from ogl_amd import _lib
+    ops.set_gemm_mode("auto")
+    torch.manual_seed(0)
+    T, F = 232965, 602
+    table = ops.empty_mat(T, F, "cuda"); table.normal_()
+    wp = torch.randn(F, F, device="cuda") / 25
+    if os.environ.get("X3_ZERO"):
+        table.zero_(); wp.zero_()
+    t_img = ops.x3_split(table, append_ones=True)
+    w_img = ops.x3_split(wp, append_vec=torch.zeros(F, device="cuda"))
+    probe = 1 if os.environ.get("X3_PROBE") else 0
+    stamps = torch.zeros(1024 + 256 * 8 * 4, dtype=torch.int64, device="cuda")
+    _lib.lib().ogl_x3_debug_stamps(stamps.data_ptr(), probe)
+    t0 = time.time(); n = 0
+    while time.time() - t0 < 2.5:
+        for _ in range(20):
+            ops.linear_fwd_x3(t_img, None, w_img, relu=True)
+        torch.cuda.synchronize(); n += 20
+    ms = (time.time() - t0) / n * 1e3
+    _lib.lib().ogl_x3_debug_stamps(None, 0)
+    ph = stamps.cpu()[1024:].view(256, 8, 4).double()
+    st = stamps.cpu()[:1024].view(256, 4).double()
+    st = st[st[:, 3] > st[:, 1]]
+    ghz = ((st[:, 2] - st[:, 0]) / (st[:, 3] - st[:, 1]) * 0.1)
+    cyc = (st[:, 2] - st[:, 0]).median().item()
+    fl = 2.0 * T * F * F
+    print("whole-table forward [%d x %d -> %d], %s operands: %.3f ms/launch wall, in-kernel clock median %.3f GHz (min %.3f, max %.3f), "
+          "%.0f k cycles per block, %.1f TFLOP/s" % (T, F, F, "ZERO" if os.environ.get("X3_ZERO") else "random", ms, ghz.median().item(),
+                                                     ghz.min().item(), ghz.max().item(), cyc / 1e3, fl / ms / 1e9), flush=True)
+    # matrix-pipe occupancy at the held clock: 6 MFMA terms x padded tiles x 16 cycles per 16x16x32 MFMA per SIMD
+    mfma_cycles = 6.0 * (-(-T // 256) * 256) * 640 * 608 / (16 * 16 * 32) * 16 / (256 * 4)
+    if probe:
+        tot = ph.sum(2)
+        print("  PROBE build, cycles per wave summed over the launch (mean over 2048 waves; min..max): total %.0f k" % (tot.mean().item() / 1e3))
+        for i, name in enumerate(("wait+barrier", "load segment", "multiply segment", "-")):
+            v = ph[:, :, i]
+            print("    %-16s %8.0f k  (%4.1f %%)   %.0f..%.0f k   by wave: %s" % (name, v.mean().item() / 1e3, 100 * v.mean().item() / tot.mean().item(),
+                  v.min().item() / 1e3, v.max().item() / 1e3, " ".join("%.0f" % (x / 1e3) for x in v.mean(0).tolist())))
+    print("  MFMA cycles needed per SIMD %.0f k -> matrix pipe busy %.1f %% of the in-kernel cycles" % (mfma_cycles / 1e3, 100 * mfma_cycles / cyc))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "clock":
+        clock_probe(); sys.exit(0)
     main()
