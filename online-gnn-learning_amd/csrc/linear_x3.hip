@@ -63,10 +63,11 @@ __device__ float4 g_x3_trash[64];   // where epilogue lanes with nothing to stor
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int MT, bool SPREAD>
+// TM, TN: the wave tile in units of 32 rows / columns; SPREAD: the next stage's DMA pieces go out between the MFMA groups
+// of the first half of a step instead of in one burst at its top.
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool SPREAD>
 __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
-  static_assert(MT == 32 || MT == 16, "v_mfma_f32_32x32x16_bf16 or v_mfma_f32_16x16x32_bf16");
-  constexpr int RB = TM * 32 / MT, CB = TN * 32 / MT;   // MFMA row / column blocks of a wave tile
+  constexpr int RB = TM * 2, CB = TN * 2;   // 16 x 16 MFMA row / column blocks of a wave tile
   constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32, ROWS = BM + BN;
   constexpr int PIECES = ROWS * 12;
@@ -81,10 +82,10 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the LDS base of every DMA piece is scalar
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-  const int l31 = lane & 31, half = lane >> 5;
   const int l15 = lane & 15, quad = lane >> 4;
-  // row swizzle of the 16-byte chunk index inside a plane: a bijection of (r >> 2) & 3 chosen so that BOTH fragment
-  // shapes read conflict-free (32x32x16: lane -> row l & 31, chunk 2 s + (l >> 5); 16x16x32: row l & 15, chunk l >> 4)
+  // row swizzle of the 16-byte chunk index inside a plane: a bijection of (r >> 2) & 3 chosen so that the 16x16x32
+  // fragment (lane -> row l & 15, chunk l >> 4) reads conflict-free (the plain (r >> 2) & 3 does not: a 16-lane
+  // ds_read_b128 group holds rows 0-3, 12-15 at chunk c and rows 4-11 at chunk c ^ 1)
   auto swz = [](int r) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; };   // 0, 2, 3, 1
 
   // PERSISTENT blocks, XCD-aware and bijective.  Hardware deals block L to XCD L % 8; the logical tile space (split,
@@ -150,41 +151,24 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
     }
   };
 
-  // per-lane fragment offsets inside a stage (bytes), plane 0: MT 32 — both 16-deep halves of the step; MT 16 — the
-  // lane's 8-element chunk of the whole 32-deep step
-  int offa[MT == 32 ? TM : RB][MT == 32 ? 2 : 1], offb[MT == 32 ? TN : CB][MT == 32 ? 2 : 1];
-  if constexpr (MT == 32) {
+  // per-lane fragment offsets inside a stage (bytes), plane 0: the lane's 8-element chunk of the 32-deep step
+  int offa[RB], offb[CB];
 #pragma unroll
-    for (int t = 0; t < TM; ++t) {
-      const int r = wm * TM * 32 + t * 32 + l31;
+  for (int t = 0; t < RB; ++t) {
+    const int r = wm * TM * 32 + t * 16 + l15;
+    offa[t] = (r * 12 + (quad ^ swz(r))) * 16;
+  }
 #pragma unroll
-      for (int s = 0; s < 2; ++s) offa[t][s] = (r * 12 + ((2 * s + half) ^ swz(r))) * 16;
-    }
-#pragma unroll
-    for (int t = 0; t < TN; ++t) {
-      const int r = BM + wn * TN * 32 + t * 32 + l31;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) offb[t][s] = (r * 12 + ((2 * s + half) ^ swz(r))) * 16;
-    }
-  } else {
-#pragma unroll
-    for (int t = 0; t < RB; ++t) {
-      const int r = wm * TM * 32 + t * 16 + l15;
-      offa[t][0] = (r * 12 + (quad ^ swz(r))) * 16;
-    }
-#pragma unroll
-    for (int t = 0; t < CB; ++t) {
-      const int r = BM + wn * TN * 32 + t * 16 + l15;
-      offb[t][0] = (r * 12 + (quad ^ swz(r))) * 16;
-    }
+  for (int t = 0; t < CB; ++t) {
+    const int r = BM + wn * TN * 32 + t * 16 + l15;
+    offb[t] = (r * 12 + (quad ^ swz(r))) * 16;
   }
 
-  // accumulators: C^T tiles (the weight-side fragment is the MFMA's first operand), so a lane holds 4-column groups
-  // of ONE output row: MT 32 — row l & 31, columns 8 q + 4 (l >> 5) + (0..3) in registers 4 q ..; MT 16 — row l & 15,
-  // columns 4 (l >> 4) + (0..3)
+  // accumulators: C^T tiles (the weight-side fragment is the MFMA's first operand), so a lane holds a 4-column group
+  // of ONE output row: row l & 15, columns 4 (l >> 4) + (0..3) of the 16 x 16 block
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  f32x16 acc[MT == 32 ? TM : 1][MT == 32 ? TN : 1];
-  f32x4 acc4[MT == 16 ? RB : 1][MT == 16 ? CB : 1];
+  f32x4 acc[RB][CB];
+
   auto issue = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < NLOAD; ++u) {
@@ -193,81 +177,54 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
     }
   };
 
-  // One 32-deep step.  MT 32: two 16-deep MFMA sub-steps (fragment registers are reused: the accumulators of the
-  // finished tile stay live under the next tile's first step, so the register budget goes to them, not to deeper
-  // prefetch).  MT 16: every MFMA spans the whole step; the A fragments stay, the B fragments are streamed per block.
-  // Per accumulator the six products go smallest terms first (i + j = 4, then 3, then 2) — as in k_gemm's x6 path.
-  auto compute = [&](int buf, int fetch_buf) __attribute__((always_inline)) {   // fetch_buf >= 0: also issue the next stage's DMA into it
+  // One 32-deep step = RB x CB x 6 v_mfma_f32_16x16x32_bf16 (one MFMA = one product term over the whole step; same
+  // cycles per flop as 32x32x16, but the chip holds a higher clock under it: +8 %).  A fragments first, B blocks streamed
+  // one ahead (two-deep ring).  Per accumulator the six terms go smallest first (i + j = 4, then 3, then 2) — as in
+  // k_gemm's x6 path.  fetch_buf >= 0 (SPREAD): the DMA pieces of the NEXT stage go out behind the MFMA groups of the
+  // first half of the step — a DMA instruction holds its wave for 40-300 cycles (the CU's address path takes one per
+  // ~38 cycles when all eight waves feed it); issued in one burst at the top of the step they idle the matrix pipe,
+  // spread out the SIMD's other wave multiplies meanwhile.
+  auto compute = [&](int buf, int fetch_buf) __attribute__((always_inline)) {
     const unsigned char* st = smem + buf * STAGE;
-    if constexpr (MT == 32) {
+    bf16x8 a[RB][3], b[2][3];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8 a[TM][3], b[TN][3];
+    for (int t = 0; t < RB; ++t)
 #pragma unroll
-        for (int t = 0; t < TM; ++t)
+      for (int sp = 0; sp < 3; ++sp) a[t][sp] = *(const bf16x8*)(st + offa[t] + sp * 64);
 #pragma unroll
-          for (int sp = 0; sp < 3; ++sp) a[t][sp] = *(const bf16x8*)(st + offa[t][s] + sp * 64);
+    for (int sp = 0; sp < 3; ++sp) b[0][sp] = *(const bf16x8*)(st + offb[0] + sp * 64);
+    constexpr int NG = RB * CB, NGI = NG / 2;   // DMA slots: the MFMA groups of the first half of the step
+    static_for<0, CB>([&](auto yc) __attribute__((always_inline)) {
+      constexpr int y = decltype(yc)::value;
+      if constexpr (y + 1 < CB) {
 #pragma unroll
-        for (int t = 0; t < TN; ++t)
-#pragma unroll
-          for (int sp = 0; sp < 3; ++sp) b[t][sp] = *(const bf16x8*)(st + offb[t][s] + sp * 64);
-#pragma unroll
-        for (int x = 0; x < TM; ++x)
-#pragma unroll
-          for (int y = 0; y < TN; ++y) {
-            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[y][2], a[x][0], acc[x][y], 0, 0, 0);
-            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[y][1], a[x][1], acc[x][y], 0, 0, 0);
-            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[y][0], a[x][2], acc[x][y], 0, 0, 0);
-            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[y][1], a[x][0], acc[x][y], 0, 0, 0);
-            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[y][0], a[x][1], acc[x][y], 0, 0, 0);
-            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[y][0], a[x][0], acc[x][y], 0, 0, 0);
-          }
+        for (int sp = 0; sp < 3; ++sp) b[(y + 1) & 1][sp] = *(const bf16x8*)(st + offb[y + 1] + sp * 64);
       }
-    } else {
-      // A fragments first, B blocks streamed one ahead (two-deep ring), and the DMA pieces of the NEXT stage spread
-      // between the MFMA groups of the first three quarters of the step: a DMA instruction holds its wave for 40-300
-      // cycles (the CU's address unit takes one per ~38 cycles when all eight waves feed it), issued in one burst at
-      // the top of the step they idle the matrix pipe; spread out, the SIMD's other wave multiplies meanwhile.
-      bf16x8 a[RB][3], b[2][3];
-#pragma unroll
-      for (int t = 0; t < RB; ++t)
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp) a[t][sp] = *(const bf16x8*)(st + offa[t][0] + sp * 64);
-#pragma unroll
-      for (int sp = 0; sp < 3; ++sp) b[0][sp] = *(const bf16x8*)(st + offb[0][0] + sp * 64);
-      constexpr int NG = RB * CB, NGI = NG / 2;   // DMA slots: the MFMA groups of the first half of the step
-      static_for<0, CB>([&](auto yc) __attribute__((always_inline)) {
-        constexpr int y = decltype(yc)::value;
-        if constexpr (y + 1 < CB) {
-#pragma unroll
-          for (int sp = 0; sp < 3; ++sp) b[(y + 1) & 1][sp] = *(const bf16x8*)(st + offb[y + 1][0] + sp * 64);
-        }
-        static_for<0, RB>([&](auto xc) __attribute__((always_inline)) {
-          constexpr int x = decltype(xc)::value, gi = y * RB + x;
-          acc4[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][2], a[x][0], acc4[x][y], 0, 0, 0);
-          acc4[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][1], a[x][1], acc4[x][y], 0, 0, 0);
-          acc4[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][2], acc4[x][y], 0, 0, 0);
-          acc4[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][1], a[x][0], acc4[x][y], 0, 0, 0);
-          acc4[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][1], acc4[x][y], 0, 0, 0);
-          acc4[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][0], acc4[x][y], 0, 0, 0);
-          // the pieces u with u * NGI / NLOAD == gi go out behind this group
-          static_for<0, NLOAD>([&](auto uc) __attribute__((always_inline)) {
-            constexpr int u = decltype(uc)::value;
-            if constexpr (u * NGI / NLOAD == gi) {
-              if (fetch_buf >= 0) {
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_global_load_lds((gptr_t)src[u], (lptr_t)(smem + fetch_buf * STAGE + (u * NT + wid * 64) * 16), 16, 0, 0);
-                src[u] += u < NLOAD_A ? g.a.step_bytes : g.b.step_bytes;
-                __builtin_amdgcn_sched_barrier(0);
-              }
+      static_for<0, RB>([&](auto xc) __attribute__((always_inline)) {
+        constexpr int x = decltype(xc)::value, gi = y * RB + x;
+        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][2], a[x][0], acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][1], a[x][1], acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][2], acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][1], a[x][0], acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][1], acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][0], acc[x][y], 0, 0, 0);
+        // the pieces u with u * NGI / NLOAD == gi go out behind this group
+        static_for<0, NLOAD>([&](auto uc) __attribute__((always_inline)) {
+          constexpr int u = decltype(uc)::value;
+          if constexpr (u * NGI / NLOAD == gi) {
+            if (fetch_buf >= 0) {
+              __builtin_amdgcn_sched_barrier(0);
+              __builtin_amdgcn_global_load_lds((gptr_t)src[u], (lptr_t)(smem + fetch_buf * STAGE + (u * NT + wid * 64) * 16), 16, 0, 0);
+              src[u] += u < NLOAD_A ? g.a.step_bytes : g.b.step_bytes;
+              __builtin_amdgcn_sched_barrier(0);
             }
-          });
+          }
         });
       });
-    }
+    });
   };
 
-  // Epilogue of a finished tile: every lane owns 4-column groups of one output row (see the accumulator layouts).
+  // Epilogue of a finished tile: every lane owns 4-column groups of one output row (see the accumulator layout).
   // Every thread issues EXACTLY NSTORE = TM * TN * 4 16-byte stores, whatever the tile's position: lanes with nothing
   // to store (rows >= M, columns >= N, unaligned destinations) aim theirs at a scratch line.  The static count is what
   // lets the next tile's first barrier wait for its DMA only (s_waitcnt vmcnt(NSTORE)) while these stores drain.
@@ -297,23 +254,12 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
         }
       }
     };
-    if constexpr (MT == 32) {
 #pragma unroll
-      for (int x = 0; x < TM; ++x)
+    for (int x = 0; x < RB; ++x)
 #pragma unroll
-        for (int y = 0; y < TN; ++y)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            store_group(t.i0 + wm * TM * 32 + x * 32 + l31, t.j0 + wn * TN * 32 + y * 32 + 8 * q + 4 * half,
-                        acc[x][y][4 * q], acc[x][y][4 * q + 1], acc[x][y][4 * q + 2], acc[x][y][4 * q + 3]);
-    } else {
-#pragma unroll
-      for (int x = 0; x < RB; ++x)
-#pragma unroll
-        for (int y = 0; y < CB; ++y)
-          store_group(t.i0 + wm * TM * 32 + x * 16 + l15, t.j0 + wn * TN * 32 + y * 16 + 4 * quad,
-                      acc4[x][y][0], acc4[x][y][1], acc4[x][y][2], acc4[x][y][3]);
-    }
+      for (int y = 0; y < CB; ++y)
+        store_group(t.i0 + wm * TM * 32 + x * 16 + l15, t.j0 + wn * TN * 32 + y * 16 + 4 * quad,
+                    acc[x][y][0], acc[x][y][1], acc[x][y][2], acc[x][y][3]);
   };
 
   // Two-stage ring that runs ACROSS tiles.  The barrier at the top of a step (a) retires this wave's DMA of the
@@ -325,7 +271,7 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
   Tile tc = decode(cur);
   int buf = 0;
   bool first_tile = true;
-  constexpr int NSTORE = TM * TN * 4;
+  constexpr int NSTORE = RB * CB;
   {
     int64_t rid[NLOAD_A];
     load_rids(tc, rid);
@@ -338,21 +284,12 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
     Tile tn = tc;
     int64_t rid_next[NLOAD_A];
     if (has_next) tn = decode(nxt);
-    if constexpr (MT == 32) {
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
+    for (int a = 0; a < RB; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
+      for (int b = 0; b < CB; ++b)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    } else {
-#pragma unroll
-      for (int a = 0; a < RB; ++a)
-#pragma unroll
-        for (int b = 0; b < CB; ++b)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc4[a][b][e] = 0.f;
-    }
+        for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.f;
     for (int ks = tc.ks_begin; ks < tc.ks_end; ++ks) {
       if (ks == tc.ks_begin && !first_tile) {
         // the previous tile's NSTORE epilogue stores were issued AFTER this stage's DMA: leave them in flight
@@ -366,7 +303,7 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
       if (ks == tc.ks_begin && has_next) load_rids(tn, rid_next);
       const bool more = ks + 1 < tc.ks_end;
       if (!more && has_next) make_src(tn, rid_next);
-      if constexpr (MT == 32 || !SPREAD) {
+      if constexpr (!SPREAD) {
         if (more || has_next) issue(buf ^ 1);
         compute(buf, -1);
       } else {
@@ -579,12 +516,10 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
   g.NJ = (int)ogl_cdiv(g.N, BN);
   const int64_t T = (int64_t)g.NI * g.NJ * g.nsplit;
   dim3 grid((unsigned)(8 * std::min<int64_t>(32, ogl_cdiv(T, 8)))), block(512);   // persistent: at most one block per CU
-  // MT = 16 (v_mfma_f32_16x16x32_bf16): same cycles per flop as the 32x32x16 form (MT = 32, kept in the template),
-  // but the chip holds a higher clock under it on random data: measured 8-9 % faster at the layer-0 shapes
   // DMA issue: spread between the MFMA groups for the 256 x 128 tile (2-3 % faster, A/B on one device), in one burst at
   // the top of the step for the 128 x 128 tile (its steps are too short to hide a late piece: spread measured 9 % slower)
-  if (cfg == 0) hipLaunchKernelGGL((k_gemm_x3<4, 2, 2, 2, 16, true>), grid, block, 0, stream, g);
-  else hipLaunchKernelGGL((k_gemm_x3<2, 4, 2, 1, 16, false>), grid, block, 0, stream, g);
+  if (cfg == 0) hipLaunchKernelGGL((k_gemm_x3<4, 2, 2, 2, true>), grid, block, 0, stream, g);
+  else hipLaunchKernelGGL((k_gemm_x3<2, 4, 2, 1, false>), grid, block, 0, stream, g);
   OGL_CHECK_LAUNCH();
   if (g.nsplit > 1) {
     hipLaunchKernelGGL(k_x3_splitk_reduce, dim3((unsigned)min((int64_t)2048, ogl_cdiv(g.M * g.N, 256))), dim3(256), 0, stream, g);

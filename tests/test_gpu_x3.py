@@ -403,3 +403,29 @@ def test_random_shape_sweep(ops):
         mm = np.arange(32 * G); s_of_m = (mm % 32) * G + mm // 32; ok = s_of_m < n_src
         assert (got[:, ~ok] == 0).all()
         np.testing.assert_allclose(got[:, ok].T.numpy(), dP[s_of_m[ok]].numpy(), rtol=1e-4, atol=1e-4, err_msg=str((n_dst, S, D, n_src)))
+
+
+def test_debug_stamps_report_a_plausible_clock(ops):
+    """ogl_x3_debug_stamps: per block {s_memtime, s_memrealtime} at entry and exit of the image GEMM (diagnostics only)."""
+    from ogl_amd import _lib
+    torch.manual_seed(5)
+    M, K, N = 20000, 602, 602
+    xm = ops.empty_mat(M, K, "cuda"); xm.normal_()
+    xi, wi = ops.x3_split(xm), ops.x3_split(torch.randn(N, K, device="cuda"))
+    ref = ops.linear_fwd_x3(xi, None, wi)
+    stamps = torch.zeros(1024 + 256 * 8 * 4, dtype=torch.int64, device="cuda")
+    assert _lib.lib().ogl_x3_debug_stamps(stamps.data_ptr(), 0) == 0
+    try:
+        got = ops.linear_fwd_x3(xi, None, wi)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().ogl_x3_debug_stamps(None, 0)
+    assert torch.equal(got, ref)                                   # the stamps do not touch the result
+    st = stamps.cpu()[:1024].view(256, 4).double()
+    st = st[st[:, 3] > st[:, 1]]
+    assert st.shape[0] >= 64                                       # every launched block stamped entry and exit
+    ghz = (st[:, 2] - st[:, 0]) / (st[:, 3] - st[:, 1]) * 0.1     # s_memrealtime ticks at 100 MHz
+    assert 0.5 < ghz.median().item() < 3.0
+    after = stamps.clone()
+    ops.linear_fwd_x3(xi, None, wi); torch.cuda.synchronize()
+    assert torch.equal(stamps, after)                              # switched off again
