@@ -317,7 +317,10 @@ def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size,
                 labels = ops.gather_i64(g.ndata["target"], sd)
                 rows, _ = ops.ce_fwd_bwd(scores, labels, want_grad=False)
                 losses.append(rows)
-        return torch.cat(losses).cpu()
+        local = torch.cat(losses)
+        if world > 1:                     # the exchange step of the sharded pass: every replay-buffer replica gets every loss
+            local = parallel.all_gather_rows(local)
+        return local.cpu()
 
     def barrier():
         torch.cuda.synchronize()
@@ -363,7 +366,7 @@ def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size,
                     avg_launch_ms=round(ragg["ms"] / ragg["calls"], 4),
                     algorithmic_bytes_per_launch=round(ragg["bytes"] / ragg["calls"]))
     if rank == 0:
-        assert out.numel() == args.steps * B and bool(torch.isfinite(out).all())
+        assert out.numel() == args.steps * B * world and bool(torch.isfinite(out).all())
         print(json.dumps({
             "metric": "streamed vertices/sec (PBR priority forward), %s-shaped stream depth=2 samples=%d" % (wl["dataset"], S),
             "value": round(args.steps * B * world / elapsed, 1), "unit": "vertices/s", "n_gpus": world, "steps": args.steps,
@@ -372,7 +375,7 @@ def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size,
             "config": {"gemm_arithmetic": gemm_desc(args.gemm), "workload": "%s: last snapshot (N=%d), F=%d H=%d C=%d, pool(max), batch_full=%d/GPU, inference sample+forward+CE(none), "
                                    "projection cache %s" % (args.workload, g.n_present, feat_size, wl["hidden"], n_classes, B,
                                                             "on" if strat.cache_projection else "off"),
-                       "global_batch": B * world, "parallelism": "dp%d (train set block-partitioned, no collective)" % world,
+                       "global_batch": B * world, "parallelism": "dp%d (train set block-partitioned over the ranks%s)" % (world, ", per-seed losses all-gathered to every rank" if world > 1 else ""),
                        "setup_s": round(setup_s, 1)},
             "roofline": roof, "cpu_baseline": None, "kernels": kernels}))
     if world > 1:

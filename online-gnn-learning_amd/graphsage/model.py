@@ -13,7 +13,7 @@ import time
 import numpy as np
 import torch
 
-from .. import ops, optim, sampling
+from .. import ops, optim, parallel, sampling
 from .sageconv import GatheredRows
 
 
@@ -130,9 +130,50 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             raise RuntimeError("the hip backend runs on the GPU only: construct it with cuda=True")
         self.reduction = reduction
         self.xent = lambda scores, labels_: ops.cross_entropy(scores, labels_, reduction)
+        self.gsync = None                      # set by build_optimizer() under torch.distributed
 
     def build_optimizer(self):
         self.optimizer = optim.Adam(self.graphsage_model.parameters(), lr=0.001)
+        # Under torch.distributed (one process per GPU, identical replicas, identical host RNG seeds on every rank)
+        # each rank trains on its shard_range slice of every replay batch; the weighted gradient all-reduce makes the
+        # update that of the whole batch, and the sharded PBR passes all-gather their per-seed losses (parallel.py).
+        self.gsync = parallel.GradSynchronizer(self.graphsage_model.parameters(), overlap=False) \
+            if parallel.is_distributed() else None
+
+    def _local_batches(self, graph, seeds, batch_size, shuffle=False):
+        """The snapshot's train batches as this rank sees them: yields (input_nodes, local_seeds, blocks, n_global).
+        One rank: the reference's NodeDataLoader batches.  N ranks: every batch is cut by ``parallel.shard_range`` in seed
+        order (the sampler is keyed per seed, so a vertex draws the same neighbours on whichever rank it lands)."""
+        seeds = torch.as_tensor(np.asarray(seeds), dtype=torch.int64).reshape(-1)
+        if shuffle:
+            seeds = seeds[torch.randperm(seeds.numel())]
+        rank, world = parallel.rank_world()
+        bs = int(batch_size)
+        if bs <= 0:
+            raise ValueError("batch_size should be a positive integer value, but got batch_size={}".format(bs))
+        seeds = seeds.to(graph.device).contiguous()
+        full = [seeds[s0:s0 + bs] for s0 in range(0, seeds.numel(), bs)]
+        local = [b[slice(*parallel.shard_range(b.numel(), rank, world))] for b in full]
+        live = [i for i, b in enumerate(local) if b.numel() > 0]
+        out = iter(self._sampler().sample_batches(graph, [local[i] for i in live]))
+        for i, b in enumerate(full):
+            if local[i].numel() > 0:
+                input_nodes, sd, blocks = next(out)
+                yield input_nodes, sd, blocks, b.numel()
+            else:
+                yield None, local[i], None, b.numel()         # more ranks than seeds in this batch
+
+    def _backward_and_step(self, loss_sum_local, n_local, n_global):
+        """d(mean over the GLOBAL batch) -> optimiser step.  ``loss_sum_local`` = sum of this rank's per-seed losses."""
+        self.optimizer.zero_grad()
+        if n_local > 0:
+            (loss_sum_local / n_global).backward()
+        if self.gsync is not None:
+            for p in self.gsync.params:                            # a rank without seeds contributes zeros
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            self.gsync.sync(weight=1.0)                            # the 1 / n_global is already in the loss
+        self.optimizer.step()
 
     def _sampler(self):
         return sampling.MultiLayerNeighborSampler([self.samples for _ in range(2)], replace=True, return_eids=True)
@@ -179,30 +220,51 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         seeds_all = torch.as_tensor(np.asarray(vertices), dtype=torch.int64)
         if seeds_all.numel() == 0:
             return None
-        cm = None
-        n = 0
+        n_all = int(seeds_all.numel())
+        rank, world = parallel.rank_world()
+        if world > 1:                           # N ranks: block-partitioned pass, C x C counters summed over the ranks
+            seeds_all = seeds_all[slice(*parallel.shard_range(n_all, rank, world))]
+        last = self.graphsage_model.layers[-1]
+        C_ = int((last.fc_self if last.fc_self is not None else last.fc_neigh).weight.shape[0])
+        cm = torch.zeros(C_ * C_, dtype=torch.int64, device=graph.device)
         with torch.no_grad():
-            for seeds, logits in self._inference_batches(graph, seeds_all):
-                if cm is None:
-                    C_ = logits.shape[1]
-                    cm = torch.zeros(C_ * C_, dtype=torch.int64, device=logits.device)
-                ops.argmax_confusion(logits, ops.gather_i64(graph.ndata["target"], seeds), cm, want_pred=False)
-                n += seeds.numel()
-        C_ = int(round(cm.numel() ** 0.5))
-        return cm.cpu().numpy().reshape(C_, C_), n
+            if seeds_all.numel() > 0:
+                for seeds, logits in self._inference_batches(graph, seeds_all):
+                    ops.argmax_confusion(logits, ops.gather_i64(graph.ndata["target"], seeds), cm, want_pred=False)
+        cm = cm.cpu()
+        if world > 1:
+            import torch.distributed as dist
+            if dist.get_backend() == "gloo":
+                dist.all_reduce(cm, op=dist.ReduceOp.SUM)
+            else:
+                cmd = cm.to(graph.device)
+                dist.all_reduce(cmd, op=dist.ReduceOp.SUM)
+                cm = cmd.cpu()
+        return cm.numpy().reshape(C_, C_), n_all
 
     def get_model(self):
         return "base_model"
 
-    def train_step(self, graph, blocks, input_nodes, seeds, subgraph_to_id):
-        self.optimizer.zero_grad()
-        batch_inputs = self._inputs(graph, input_nodes)
-        batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
-        scores = self.graphsage_model(blocks, batch_inputs)
-        loss = self.xent(scores, batch_labels)
-        loss.backward()
-        self.optimizer.step()
-        return loss
+    def train_step(self, graph, blocks, input_nodes, seeds, subgraph_to_id, n_global=None):
+        if self.gsync is None and (n_global is None or n_global == seeds.numel()):
+            self.optimizer.zero_grad()
+            batch_inputs = self._inputs(graph, input_nodes)
+            batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
+            scores = self.graphsage_model(blocks, batch_inputs)
+            loss = self.xent(scores, batch_labels)
+            loss.backward()
+            self.optimizer.step()
+            return loss
+        # rank-sharded batch: this rank's seeds only; the gradient is that of the mean over the whole batch
+        n_local = int(seeds.numel())
+        loss_sum = None
+        if n_local > 0:
+            batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
+            scores = self.graphsage_model(blocks, self._inputs(graph, input_nodes))
+            loss_sum = ops.cross_entropy(scores, batch_labels, "none").sum() if self.reduction == "mean" \
+                else self.xent(scores, batch_labels).sum()
+        self._backward_and_step(loss_sum, n_local, n_global)
+        return loss_sum
 
 
 class RandomHipSupervisedGraphSage(HipSupervisedGraphSage):
@@ -220,12 +282,9 @@ class RandomHipSupervisedGraphSage(HipSupervisedGraphSage):
 
     def _run_custom_train(self, graph, subgraph_to_id, id_to_subgraph, train_vertices, graph_util):
         self.graphsage_model.train()
-        train_vertices = torch.as_tensor(np.asarray(train_vertices), dtype=torch.int64)
-        loader = sampling.NodeDataLoader(graph, train_vertices, self._sampler(),
-                                         batch_size=len(train_vertices) // self.batch_per_timestep,
-                                         shuffle=False, drop_last=False, num_workers=self.n_workers)
-        for input_nodes, seeds, blocks in loader:
-            self.train_step(graph, blocks, input_nodes, seeds, subgraph_to_id)
+        for input_nodes, seeds, blocks, n_global in self._local_batches(graph, train_vertices,
+                                                                       len(train_vertices) // self.batch_per_timestep):
+            self.train_step(graph, blocks, input_nodes, seeds, subgraph_to_id, n_global)
 
     def get_model(self):
         return "random"
@@ -256,27 +315,46 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
 
     def _run_custom_train(self, graph, subgraph_to_id, id_to_subgraph, train_vertices, graph_util):
         train_vertices = torch.as_tensor(np.asarray(train_vertices), dtype=torch.int64)
-        loader = sampling.NodeDataLoader(graph, train_vertices, self._sampler(),
-                                         batch_size=len(train_vertices) // self.batch_per_timestep,
-                                         shuffle=False, drop_last=False, num_workers=self.n_workers)
-        pending = []
-        for input_nodes, seeds, blocks in loader:
-            batch_inputs = self._inputs(graph, input_nodes)
-            batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
-            self.optimizer.zero_grad()
-            scores = self.graphsage_model(blocks, batch_inputs)
-            unaggregated_loss = self.xent(scores, batch_labels)
-            loss = torch.mean(unaggregated_loss)
-            loss.backward()
-            self.optimizer.step()
+        bs = len(train_vertices) // self.batch_per_timestep
+        distributed = self.gsync is not None
+        pending, full_sizes = [], []
+        for input_nodes, seeds, blocks, n_global in self._local_batches(graph, train_vertices, bs):
+            full_sizes.append(n_global)
+            if seeds.numel() > 0:
+                batch_inputs = self._inputs(graph, input_nodes)
+                batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
+            if not distributed:
+                self.optimizer.zero_grad()
+                scores = self.graphsage_model(blocks, batch_inputs)
+                unaggregated_loss = self.xent(scores, batch_labels)
+                loss = torch.mean(unaggregated_loss)
+                loss.backward()
+                self.optimizer.step()
+            else:
+                unaggregated_loss = None
+                if seeds.numel() > 0:
+                    unaggregated_loss = self.xent(self.graphsage_model(blocks, batch_inputs), batch_labels)
+                self._backward_and_step(unaggregated_loss.sum() if unaggregated_loss is not None else None,
+                                        int(seeds.numel()), n_global)
+                if unaggregated_loss is None:
+                    unaggregated_loss = torch.zeros(0, device=graph.device)
             pending.append((seeds, unaggregated_loss.detach()))
         # The reference copies every batch's losses to the host right away (a device sync per batch).  Nothing reads the
         # buffer while the snapshot's batches train (they were drawn beforehand), so the per-batch updates are applied in
         # the same order after ONE transfer: identical buffer contents, no pipeline drain between batches.
         if pending:
-            sizes = [sd.numel() for sd, _ in pending]
-            all_seeds = torch.cat([sd for sd, _ in pending]).cpu().numpy()
-            all_loss = torch.cat([ls for _, ls in pending]).cpu().numpy()
+            if distributed:
+                # the exchange step of the sharded PBR update: every rank needs the losses of ALL seeds of every batch to
+                # keep its replay-buffer replica identical (one all-gather per snapshot)
+                losses = parallel.all_gather_sharded([ls for _, ls in pending], full_sizes)
+                all_seeds_t = train_vertices.reshape(-1)
+                sizes = full_sizes
+                all_seeds = all_seeds_t.numpy()
+                all_loss = torch.cat(losses).cpu().numpy()
+            else:
+                sizes = [sd.numel() for sd, _ in pending]
+                all_seeds = torch.cat([sd for sd, _ in pending]).cpu().numpy()
+                all_loss = torch.cat([ls for _, ls in pending]).cpu().numpy()
             off = 0
             for n in sizes:
                 batch_nodes_seed = subgraph_to_id[all_seeds[off:off + n]]
@@ -297,15 +375,26 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
             return
         seeds_all = torch.as_tensor(np.asarray(id_to_subgraph[train_set]), dtype=torch.int64)
         graph = graph_util.get_graph()
+        # N ranks: the pass is block-partitioned over the ranks in seed order and the per-seed losses are all-gathered,
+        # so every replica of the replay buffer receives every priority (north star: "PBR sharded across the GPUs")
+        rank, world = parallel.rank_world()
+        lo, hi = parallel.shard_range(seeds_all.numel(), rank, world)
+        mine = seeds_all[lo:hi]
         losses, nid_chunks = [], []
         with torch.no_grad():
-            for seeds, scores in self._inference_batches(graph, seeds_all):
-                batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
-                loss_rows, _ = ops.ce_fwd_bwd(scores, batch_labels, want_grad=False)
-                losses.append(loss_rows)
-                nid_chunks.append(seeds)
-        unaggregated_loss = torch.cat(losses).cpu().numpy()
-        batch_nids_l = list(subgraph_to_id[torch.cat(nid_chunks).cpu().numpy()])
+            if mine.numel() > 0:
+                for seeds, scores in self._inference_batches(graph, mine):
+                    batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
+                    loss_rows, _ = ops.ce_fwd_bwd(scores, batch_labels, want_grad=False)
+                    losses.append(loss_rows)
+                    nid_chunks.append(seeds)
+        local = torch.cat(losses) if losses else torch.zeros(0, device=graph.device)
+        if world > 1:
+            unaggregated_loss = parallel.all_gather_sharded([local], [seeds_all.numel()])[0].cpu().numpy()
+            batch_nids_l = list(subgraph_to_id[seeds_all.numpy()])
+        else:
+            unaggregated_loss = local.cpu().numpy()
+            batch_nids_l = list(subgraph_to_id[torch.cat(nid_chunks).cpu().numpy()])
         priorities = self.priority_strategy.get_priorities(batch_nids_l, unaggregated_loss)
         graph_util.update_priorities_arrays(np.asarray(batch_nids_l), np.asarray(priorities, dtype=np.float64))
 
@@ -328,10 +417,8 @@ class FullHipSupervisedGraphSage(HipSupervisedGraphSage):
         train_set = torch.as_tensor(np.asarray(batch_nodes), dtype=torch.int64)
         for _ in range(self.batch_per_timestep):
             train_set = train_set.view(-1)[torch.randperm(train_set.nelement())].view(train_set.size())
-            loader = sampling.NodeDataLoader(graph, train_set, self._sampler(), batch_size=self.batch_size, shuffle=False,
-                                             drop_last=False, num_workers=self.n_workers)
-            for input_nodes, seeds, blocks in loader:
-                self.train_step(graph, blocks, input_nodes, seeds, subgraph_to_id)
+            for input_nodes, seeds, blocks, n_global in self._local_batches(graph, train_set, self.batch_size):
+                self.train_step(graph, blocks, input_nodes, seeds, subgraph_to_id, n_global)
 
     def get_model(self):
         return "offline"
@@ -354,10 +441,8 @@ class NoRehHipSupervisedGraphSage(HipSupervisedGraphSage):
             if len(idxs) < 2:
                 return
             batch_nodes = id_to_subgraph[idxs]
-            loader = sampling.NodeDataLoader(graph, batch_nodes, self._sampler(), batch_size=len(batch_nodes),
-                                             shuffle=True, drop_last=False, num_workers=self.n_workers)
-            for input_nodes, seeds, blocks in loader:
-                self.train_step(graph, blocks, input_nodes, seeds, subgraph_to_id)
+            for input_nodes, seeds, blocks, n_global in self._local_batches(graph, batch_nodes, len(batch_nodes), shuffle=True):
+                self.train_step(graph, blocks, input_nodes, seeds, subgraph_to_id, n_global)
 
     def get_model(self):
         return "no_rehersal"

@@ -4,9 +4,11 @@ the build's own addition (§8e).
 
 Seeds are independent units, so a replay batch is block-partitioned across ranks in seed order and
 every rank keeps a replica of the adjacency and the feature table (Reddit: 0.1 GB + 0.57 GB against
-288 GB of HBM) — there is NO data-path collective and no halo exchange.  The only exchange step is
-the gradient all-reduce of the ~1.5 M fp32 parameters (~6 MB): one flat bucket, one collective per
-step, then the identical Adam update on every rank.  Because the Philox sampler is keyed by
+288 GB of HBM) — sampled neighbourhoods never cross a partition, so there is no halo exchange.  The
+exchange steps are (1) the gradient all-reduce of the ~1.5 M fp32 parameters (~6 MB), then the identical Adam
+update on every rank, and (2) for the sharded PBR passes (train update, priority forward over the train set) ONE
+all-gather of the per-seed losses per pass, so that every rank's replay-buffer replica receives every priority
+(``all_gather_sharded``); the sharded evaluation pass all-reduces its C x C confusion counters.  Because the Philox sampler is keyed by
 (seed, batch counter, layer, vertex id, slot), a vertex draws the same neighbours on whichever rank
 it lands: an N-rank step is bit-identical in sampled indices to the 1-rank step on the same seeds.
 """
@@ -21,6 +23,17 @@ def shard_range(n, rank, world):
     base, rem = divmod(n, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def is_distributed(group=None):
+    """True when torch.distributed is initialised with more than one rank."""
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def rank_world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
 
 
 def shard_seeds(seeds, rank=None, world=None):
@@ -150,11 +163,45 @@ class GradSynchronizer:
         self._order = []
 
 
+def all_gather_sharded(local, full_sizes, group=None):
+    """The exchange step of a rank-sharded pass over batches: every rank holds, for batch b of ``full_sizes[b]`` seeds,
+    the values of ITS ``shard_range`` slice (``local[b]``, 1-D); returns the full per-batch value tensors, in seed
+    order, on every rank.  ONE all-gather of the concatenated slices (the slice sizes follow from ``shard_range``, so
+    nothing but the values travels).  This is the collective of the sharded PBR passes: per-seed losses -> priorities."""
+    rank, world = rank_world(group)
+    if world == 1:
+        return list(local)
+    per_rank = [[shard_range(n, r, world) for n in full_sizes] for r in range(world)]
+    counts = [sum(hi - lo for lo, hi in pr) for pr in per_rank]
+    mine = torch.cat([x.reshape(-1) for x in local]) if local else torch.zeros(0)
+    assert mine.numel() == counts[rank], "local slices do not match shard_range of the batch sizes"
+    mx = max(counts)
+    dev = mine.device
+    staged = dist.get_backend(group) == "gloo" and mine.is_cuda          # gloo: through the host
+    pad = torch.zeros(mx, dtype=mine.dtype, device="cpu" if staged else dev)
+    pad[:mine.numel()] = mine.cpu() if staged else mine
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad, group=group)
+    full = []
+    offs = [0] * world
+    for b, n in enumerate(full_sizes):
+        parts = []
+        for r in range(world):
+            lo, hi = per_rank[r][b]
+            parts.append(out[r][offs[r]:offs[r] + hi - lo])
+            offs[r] += hi - lo
+        full.append(torch.cat(parts).to(dev))
+    return full
+
+
 def all_gather_rows(t, group=None):
     """all-gather(v) of a per-rank 1-D tensor (per-seed losses of a sharded priority forward) to every rank."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return t
     world = dist.get_world_size(group)
+    dev = t.device
+    if dist.get_backend(group) == "gloo" and t.is_cuda:                   # gloo: through the host
+        t = t.cpu()
     sizes = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([t.numel()], dtype=torch.int64, device=t.device), group=group)
     sizes = [int(s.item()) for s in sizes]
@@ -163,4 +210,4 @@ def all_gather_rows(t, group=None):
     pad[:t.numel()] = t
     out = [torch.empty(mx, dtype=t.dtype, device=t.device) for _ in range(world)]
     dist.all_gather(out, pad, group=group)
-    return torch.cat([o[:s] for o, s in zip(out, sizes)])
+    return torch.cat([o[:s] for o, s in zip(out, sizes)]).to(dev)

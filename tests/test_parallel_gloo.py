@@ -129,3 +129,30 @@ def test_sampling_is_independent_of_sharding():
     lo, hi = parallel.shard_range(40, 1, 2)
     part = O.sample_layer(indptr, indices, deg_t, dst[lo:hi], 5, 9, 3, 1)
     assert np.array_equal(full[lo:hi], part)
+
+
+def _worker_sharded_gather(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sizes = [9, 1, 0, 14, 2]                                   # ragged batches, one empty, one smaller than the world
+    full = [torch.arange(n, dtype=torch.float32) + 100 * b for b, n in enumerate(sizes)]
+    local = [f[slice(*parallel.shard_range(n, rank, world))] for f, n in zip(full, sizes)]
+    got = parallel.all_gather_sharded(local, sizes)
+    ok = all(torch.equal(g, f) for g, f in zip(got, full)) and len(got) == len(sizes)
+    flags = [torch.zeros(1) for _ in range(world)]
+    dist.all_gather(flags, torch.tensor([1.0 if ok else 0.0]))
+    if rank == 0:
+        torch.save(dict(ok=[bool(f.item()) for f in flags]), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_all_gather_sharded_restores_seed_order(tmp_path, world):
+    """The collective of the sharded PBR passes: per-batch shard_range slices -> full per-batch tensors on every rank."""
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_worker_sharded_gather, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert torch.load(out)["ok"] == [True] * world
+    # one rank: the identity
+    assert [t.tolist() for t in parallel.all_gather_sharded([torch.arange(3.0)], [3])] == [[0.0, 1.0, 2.0]]
+    assert parallel.rank_world() == (0, 1) and not parallel.is_distributed()
