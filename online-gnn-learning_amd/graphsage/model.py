@@ -62,8 +62,9 @@ class SupervisedGraphSage:
         new_vertices, labelled = temporal_graph.get_added_vertices(delta)
         test = np.array(new_vertices)[np.asarray(labelled, dtype=bool)]
         if len(test) < at_least:
-            with open(path, "a+") as f:
-                f.write(self.get_model() + ";;;\n")
+            if parallel.rank_world()[0] == 0:
+                with open(path, "a+") as f:
+                    f.write(self.get_model() + ";;;\n")
             return
         return self._evaluate_vertices(temporal_graph, path, test)
 
@@ -79,8 +80,9 @@ class SupervisedGraphSage:
         if n == 0:
             return
         f1, cm = macro_f1_from_confusion(cm_full)
-        with open(path, "a+") as f:
-            f.write(self.get_model() + ";" + str(f1) + ";" + str(self.delay) + ";" + str(cm) + "\n")
+        if parallel.rank_world()[0] == 0:          # N ranks hold the same (all-reduced) counters: one row per evaluation
+            with open(path, "a+") as f:
+                f.write(self.get_model() + ";" + str(f1) + ";" + str(self.delay) + ";" + str(cm) + "\n")
         return f1
 
     def _eval_confusion(self, graph, subgraph_to_id, id_to_subgraph, vertices):
