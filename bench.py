@@ -207,7 +207,9 @@ def main():
                          algorithmic_bytes_per_launch=round(ragg["bytes"] / ragg["calls"]))
     gemm_keys = [k for k in agg if k.startswith("linear") and agg[k]["flops"] > 0]
     gflops = sum(agg[k]["flops"] for k in gemm_keys); gms = sum(agg[k]["ms"] for k in gemm_keys)
-    dom = max(gemm_keys, key=lambda k: agg[k]["ms"]) if gemm_keys else None
+    # the dominant GEMM = the single LAUNCH (one shape, one kernel) with the longest duration; the "*_other" keys pool
+    # several launches of different shapes (their per-launch numbers are in "kernels") and are not one kernel launch
+    dom = max(gemm_keys, key=lambda k: agg[k]["ms"] / agg[k]["calls"]) if gemm_keys else None
     roof_gemm = None
     if dom:
         ach = agg[dom]["flops"] / agg[dom]["ms"] / 1e9

@@ -313,6 +313,11 @@ def linear_bwd_input(dy, w, ymask=None):
         dy = relu_bwd(dy, ymask)
     M, N = dy.shape
     K = w.shape[1]
+    if M >= BWD_INPUT_VIA_FWD_MIN_ROWS and get_gemm_mode() != "f32":
+        # dX = dY . W as dY . (W^T)^T: with the (small) weight transposed first, both operands of the product are
+        # reduction-contiguous and it runs on the forward kernel — 60 us against 75-84 us at the n1-row shapes (the
+        # 13 us transpose included), bit-identical results (tools/_bwd_input_probe.py)
+        return linear_fwd(dy, transpose(w), None)
     dx = empty_mat(M, K, dy.device)
     _launch("ogl_linear_bwd_input", _lib.lib().ogl_linear_bwd_input, _ptr(dy), _ld(dy), M, N, _ptr(w), _ld(w), K, _ptr(dx), _ld(dx),
             _stream(), meta=dict(M=M, K=K, N=N))
@@ -456,6 +461,7 @@ def linear_bwd_weight_x3(dyT_img, xT_img, want_bias=True):
 # are large enough run on the pre-split kernels.  Keyed by the allocation, so row-prefix views (ndata['feat'] of a
 # snapshot) resolve to the same image.
 _X3_TABLES = {}
+BWD_INPUT_VIA_FWD_MIN_ROWS = 2048       # input gradients with at least this many rows go through transpose(W) + forward kernel
 X3_BWW_MIN_ROWS = 2048    # weight gradients with at least this many reduction rows use the image kernels
 X3_MIN_ROWS = 8192        # below this the on-the-fly kernel is as fast (one wave of tiles either way)
 
