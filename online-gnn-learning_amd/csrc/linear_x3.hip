@@ -6,9 +6,10 @@
 // linear.hip (R/train/graphsage/pytorch/aggregator_dgl.py:85-94,171,181,206) for the large layer-0 products.
 //
 // Image of an fp32 matrix X[R, K] (reduction index contiguous): R rows + ONE all-zero row (index R), each row
-// G = ceil(K/32) groups of 192 bytes; group g holds k = 32g .. 32g+31 as three 64-byte planes (hi, mid, lo terms
-// of the split), pad k >= K is zero.  One (row, group) is therefore 192 contiguous bytes: a BK = 32 GEMM step reads
-// 12 consecutive 16-byte pieces per row.
+// G = ceil(K/32) groups of 192 bytes; group g holds k = 32g .. 32g+31 as two 96-byte HALVES of 16 elements, each half
+// three 32-byte planes (hi, mid, lo terms of the split): element e of plane p sits at byte (e / 16) * 96 + p * 32 +
+// (e % 16) * 2 (x3_piece, x6_arith.h); pad k >= K is zero.  One (row, group) is 192 contiguous bytes = the 12 pieces of a
+// 32-deep GEMM step, one (row, half) 96 contiguous bytes = the 6 pieces of a 16-deep step.
 //
 // k_gemm_x3: C[i, j] = epilogue(sum_k A[i, k] B[j, k]), both operands images (A optionally gathered by an int64 row
 // list: rows outside the table read the zero row).  8 waves per block, one block per CU (144 KB LDS: two stages of
@@ -136,8 +137,8 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
 #pragma unroll
     for (int u = 0; u < NLOAD; ++u) {
       const int i = u * NT + tid;
-      const int r = i / 12, j = i - r * 12;
-      const int p = j >> 2, c = (j & 3) ^ swz(r);
+      const int r = i / 12, jp = i - r * 12;                 // physical piece jp of LDS row r holds the row's logical piece
+      const int j = (jp & ~3) | ((jp & 3) ^ swz(r));         // j (its low two bits swizzled): byte offset 16 j in the group
       const unsigned char* rowp;
       if (u < NLOAD_A) {
         const int64_t id = rid[u < NLOAD_A ? u : 0];
@@ -147,22 +148,26 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
         const int64_t gj = t.j0 + (r - BM);
         rowp = g.b.img + (gj < g.N ? gj : g.b.zero_row) * g.b.row_bytes + (int64_t)t.ks_begin * g.b.step_bytes;
       }
-      src[u] = rowp + p * 64 + c * 16;
+      src[u] = rowp + j * 16;
     }
   };
 
-  // per-lane fragment offsets inside a stage (bytes), plane 0: the lane's 8-element chunk of the 32-deep step
-  int offa[RB], offb[CB];
+  // per-lane fragment offsets inside a stage (bytes): row base + the (swizzled) piece of the lane's 8-element chunk
+  // `quad` in plane p.  The swizzle depends on (r >> 2) & 3, which is the same for every 16-row block of a lane (block
+  // bases are multiples of 16), so the three plane offsets are per-lane constants shared by all A and B row blocks.
+  int offa[RB], offb[CB], offp[3];
+  {
+    const int q = swz(l15);
 #pragma unroll
-  for (int t = 0; t < RB; ++t) {
-    const int r = wm * TM * 32 + t * 16 + l15;
-    offa[t] = (r * 12 + (quad ^ swz(r))) * 16;
+    for (int sp = 0; sp < 3; ++sp) {
+      const int j = x3_piece(quad, sp);
+      offp[sp] = ((j & ~3) | ((j & 3) ^ q)) * 16;
+    }
   }
 #pragma unroll
-  for (int t = 0; t < CB; ++t) {
-    const int r = BM + wn * TN * 32 + t * 16 + l15;
-    offb[t] = (r * 12 + (quad ^ swz(r))) * 16;
-  }
+  for (int t = 0; t < RB; ++t) offa[t] = (wm * TM * 32 + t * 16 + l15) * 192;
+#pragma unroll
+  for (int t = 0; t < CB; ++t) offb[t] = (BM + wn * TN * 32 + t * 16 + l15) * 192;
 
   // accumulators: C^T tiles (the weight-side fragment is the MFMA's first operand), so a lane holds a 4-column group
   // of ONE output row: row l & 15, columns 4 (l >> 4) + (0..3) of the 16 x 16 block
@@ -190,15 +195,15 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
 #pragma unroll
     for (int t = 0; t < RB; ++t)
 #pragma unroll
-      for (int sp = 0; sp < 3; ++sp) a[t][sp] = *(const bf16x8*)(st + offa[t] + sp * 64);
+      for (int sp = 0; sp < 3; ++sp) a[t][sp] = *(const bf16x8*)(st + offa[t] + offp[sp]);
 #pragma unroll
-    for (int sp = 0; sp < 3; ++sp) b[0][sp] = *(const bf16x8*)(st + offb[0] + sp * 64);
+    for (int sp = 0; sp < 3; ++sp) b[0][sp] = *(const bf16x8*)(st + offb[0] + offp[sp]);
     constexpr int NG = RB * CB, NGI = NG / 2;   // DMA slots: the MFMA groups of the first half of the step
     static_for<0, CB>([&](auto yc) __attribute__((always_inline)) {
       constexpr int y = decltype(yc)::value;
       if constexpr (y + 1 < CB) {
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) b[(y + 1) & 1][sp] = *(const bf16x8*)(st + offb[y + 1] + sp * 64);
+        for (int sp = 0; sp < 3; ++sp) b[(y + 1) & 1][sp] = *(const bf16x8*)(st + offb[y + 1] + offp[sp]);
       }
       static_for<0, RB>([&](auto xc) __attribute__((always_inline)) {
         constexpr int x = decltype(xc)::value, gi = y * RB + x;
@@ -375,9 +380,9 @@ __global__ void __launch_bounds__(256) k_x3_split(const float* __restrict__ src,
     split3(e[2], e[3], o[0].y, o[1].y, o[2].y);
     split3(e[4], e[5], o[0].z, o[1].z, o[2].z);
     split3(e[6], e[7], o[0].w, o[1].w, o[2].w);
-    unsigned char* d = img + r * row_bytes + (int64_t)(ch >> 2) * X3_GROUP_BYTES + (ch & 3) * 16;
+    unsigned char* d = img + r * row_bytes + (int64_t)(ch >> 2) * X3_GROUP_BYTES;
 #pragma unroll
-    for (int sp = 0; sp < 3; ++sp) *(uint4*)(d + sp * 64) = o[sp];
+    for (int sp = 0; sp < 3; ++sp) *(uint4*)(d + x3_piece(ch & 3, sp) * 16) = o[sp];
   }
 }
 
@@ -427,9 +432,9 @@ __global__ void __launch_bounds__(256) k_x3_split_t(const float* __restrict__ sr
     split3(tile[ml + 2][nl], tile[ml + 3][nl], o[0].y, o[1].y, o[2].y);
     split3(tile[ml + 4][nl], tile[ml + 5][nl], o[0].z, o[1].z, o[2].z);
     split3(tile[ml + 6][nl], tile[ml + 7][nl], o[0].w, o[1].w, o[2].w);
-    unsigned char* d = img + grp * gstride + (int64_t)n * X3_GROUP_BYTES + c * 16;
+    unsigned char* d = img + grp * gstride + (int64_t)n * X3_GROUP_BYTES;
 #pragma unroll
-    for (int sp = 0; sp < 3; ++sp) *(uint4*)(d + sp * 64) = o[sp];
+    for (int sp = 0; sp < 3; ++sp) *(uint4*)(d + x3_piece(c, sp) * 16) = o[sp];
   }
   if (blockIdx.y == 0 && tid >= 64 && tid < 64 + 24) {            // the zero row (last row of every group slab)
     const int t = tid - 64, gl = t / 12;
@@ -445,10 +450,10 @@ __global__ void __launch_bounds__(256) k_x3_split_t(const float* __restrict__ sr
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         w[q] = (mb + 2 * q < Mi ? 0x3F80u : 0u) | (mb + 2 * q + 1 < Mi ? 0x3F800000u : 0u);   // bf16 1.0 pairs
-      unsigned char* d = img + grp * gstride + (int64_t)N * X3_GROUP_BYTES + c * 16;
-      *(uint4*)d = make_uint4(w[0], w[1], w[2], w[3]);
-      *(uint4*)(d + 64) = make_uint4(0, 0, 0, 0);
-      *(uint4*)(d + 128) = make_uint4(0, 0, 0, 0);
+      unsigned char* d = img + grp * gstride + (int64_t)N * X3_GROUP_BYTES;
+      *(uint4*)(d + x3_piece(c, 0) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+      *(uint4*)(d + x3_piece(c, 1) * 16) = make_uint4(0, 0, 0, 0);
+      *(uint4*)(d + x3_piece(c, 2) * 16) = make_uint4(0, 0, 0, 0);
     }
   }
 }

@@ -194,9 +194,9 @@ __global__ void __launch_bounds__(PB_THREADS) k_pool_bwd_x3(const int32_t* __res
     split3(col[2 * DP], col[3 * DP], o[0].y, o[1].y, o[2].y);
     split3(col[4 * DP], col[5 * DP], o[0].z, o[1].z, o[2].z);
     split3(col[6 * DP], col[7 * DP], o[0].w, o[1].w, o[2].w);
-    unsigned char* d = img + (int64_t)b * gstride + (int64_t)fo * 192 + c * 16;
+    unsigned char* d = img + (int64_t)b * gstride + (int64_t)fo * 192;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) *(uint4*)(d + p * 64) = o[p];
+    for (int p = 0; p < 3; ++p) *(uint4*)(d + x3_piece(c, p) * 16) = o[p];
   }
   if (tid < 12) *(uint4*)(img + (int64_t)b * gstride + (int64_t)D * 192 + tid * 16) = make_uint4(0, 0, 0, 0);   // the zero row
 }
