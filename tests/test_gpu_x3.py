@@ -429,3 +429,15 @@ def test_debug_stamps_report_a_plausible_clock(ops):
     after = stamps.clone()
     ops.linear_fwd_x3(xi, None, wi); torch.cuda.synchronize()
     assert torch.equal(stamps, after)                              # switched off again
+
+
+def test_experimental_wide_kernel_parity():
+    """k_gemm_x3w (256 x 320 tile on 16-deep half-steps, alternating wave halves, MUBUF LDS-DMA; off by default) stays
+    parity-green: the forward / weight-gradient / dispatch tests of this file with OGL_X3_WIDE=1 (the switch is read once
+    per process, hence the child interpreter)."""
+    import os, subprocess, sys
+    env = dict(os.environ, OGL_X3_WIDE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x",
+                        "-k", "forward or weight or random or dispatch or limits", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -96,9 +96,9 @@ def clock_probe():
     # matrix-pipe occupancy at the held clock: 6 MFMA terms x padded tiles x 16 cycles per 16x16x32 MFMA per SIMD
     mfma_cycles = 6.0 * (-(-T // 256) * 256) * 640 * 608 / (16 * 16 * 32) * 16 / (256 * 4)
     if probe:
-        tot = ph.sum(2)
+        tot = ph[:, :, :3].sum(2)
         print("  PROBE build, cycles per wave summed over the launch (mean over 2048 waves; min..max): total %.0f k" % (tot.mean().item() / 1e3))
-        for i, name in enumerate(("wait+barrier", "load segment", "multiply segment", "-")):
+        for i, name in enumerate(("wait+barrier", "load segment", "multiply segment", "(of which vmcnt wait)")):
             v = ph[:, :, i]
             print("    %-16s %8.0f k  (%4.1f %%)   %.0f..%.0f k   by wave: %s" % (name, v.mean().item() / 1e3, 100 * v.mean().item() / tot.mean().item(),
                   v.min().item() / 1e3, v.max().item() / 1e3, " ".join("%.0f" % (x / 1e3) for x in v.mean(0).tolist())))
