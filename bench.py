@@ -216,7 +216,7 @@ def main():
         # which arithmetic did this launch run on?  (ops.weight_grad / linear.hip AUTO policy)
         x6 = args.gemm == "bf16x6" or (args.gemm == "auto" and ("_x3" in dom or "bwd_weight_t" in dom or "bwd_weight" not in dom))
         peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if x6 else MFMA_F32_PEAK_TFLOPS
-        roof_gemm = dict(kernel="%s (%s; %s)" % ("k_gemm_x3" if "_x3" in dom else "k_gemm", dom, ("split-bf16 x6 on v_mfma_f32_16x16x32_bf16, fp32 accumulate" if "_x3" in dom else
+        roof_gemm = dict(kernel="%s (%s; %s)" % ("k_gemm_x3p" if "_x3" in dom else "k_gemm", dom, ("split-bf16 x6 on v_mfma_f32_16x16x32_bf16, fp32 accumulate" if "_x3" in dom else
                                                        "split-bf16 x6 on v_mfma_f32_32x32x16_bf16, fp32 accumulate") if x6
                                                       else "v_mfma_f32_32x32x2_f32"),
                          bound="mfma", achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
@@ -296,7 +296,7 @@ def gemm_desc(mode):
             "bf16x6": "split-bf16 x6 MFMA, fp32 accumulate (fp32-GEMM accuracy, same test tolerances)",
             "auto": "split-bf16 x6 MFMA with fp32 accumulate everywhere it is faster (fp32-GEMM accuracy, same test tolerances): "
                     "layer-0 products and all weight gradients with >= 2048 reduction rows on pre-split bf16x3 images "
-                    "(k_gemm_x3, LDS-DMA staged), the n1-row forward / input-gradient GEMMs with on-the-fly splitting "
+                    "(k_gemm_x3p: producer / consumer waves, LDS-DMA staged), the n1-row forward / input-gradient GEMMs with on-the-fly splitting "
                     "(k_gemm), exact fp32 MFMA for the 512-row output layer"}[mode]
 
 

@@ -220,12 +220,11 @@ int ogl_x3_split(const float* src, int64_t ld, const int64_t* rows, int64_t nrow
                  const float* append_vec, void* image, ogl_stream_t stream);
 int ogl_x3_split_t(const float* src, int64_t ld, const int64_t* rows, int64_t nrows, int64_t M, int N, int ones_row,
                    int64_t interleave, void* image, ogl_stream_t stream);
-/* Diagnostics (tools/gemm_x3_bench.py): while `buf` (device memory, >= 73 728 bytes) is set, every image-GEMM launch
- * records per block {s_memtime, s_memrealtime} at entry and exit; the shader clock the chip held inside the kernel is
- * d(s_memtime) / d(s_memrealtime) x 100 MHz.  probe != 0 additionally runs the 256 x 128 tile in a stamped build that
- * sums, per wave, the cycles of each phase of a reduction step (wait + barrier / DMA issue / fragment reads + MFMAs /
- * epilogue) at u64 index 1024 + (block * 8 + wave) * 4.  Pass NULL to switch off.  Not part of the hot path. */
-int ogl_x3_debug_stamps(void* buf, int probe);
+/* Diagnostics (tools/gemm_x3_bench.py clock): while `buf` (device memory, >= 8 192 bytes) is set, every image-GEMM launch
+ * records per block {s_memtime, s_memrealtime} at entry and exit (u64[4] per block); the shader clock the chip held inside
+ * the kernel is d(s_memtime) / d(s_memrealtime) x 100 MHz.  Pass NULL to switch off.  `reserved` is ignored.  Not part of
+ * the hot path. */
+int ogl_x3_debug_stamps(void* buf, int reserved);
 
 int ogl_linear_fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
                       const void* w_img, int N, int relu, float* y, int64_t ldy, ogl_stream_t stream);

@@ -50,14 +50,6 @@ struct X3Args {
   unsigned long long* stamps;   // diagnostics only (ogl_x3_debug_stamps): per block {s_memtime, s_memrealtime} at entry and exit
 };
 
-// PROBE builds (diagnostics, tools/gemm_x3_bench.py clock): s_memtime stamps around the segments of every step, summed per wave
-#define X3_STAMP(t)                                                                      \
-  do {                                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                   \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");            \
-    __builtin_amdgcn_sched_barrier(0);                                                   \
-  } while (0)
-
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) — indices into register arrays stay constants
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -336,45 +328,31 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
   }
 }
 
-// ---- the WIDE tile: 256 x 320 outputs on 16-deep half-steps, halves of the block alternating between multiplying and
-// loading ------------------------------------------------------------------------------------------------------------
-// What bounds k_gemm_x3 is the ISSUE of its stage DMA: a wave gets one LDS-DMA instruction
-// accepted per 60-300 cycles and multiplies nothing meanwhile.  This kernel attacks both factors:
-//  * 1.67 x fewer DMA pieces per flop: a 256 x 320 tile; to double-buffer 576 rows in 160 KB a stage is one 96-byte HALF
-//    of a group (16 reduction elements): 2 x 57 KB.  The matrix instruction is therefore v_mfma_f32_32x32x16_bf16.
-//  * the block's waves form two HALVES (waves 0-3 and 4-7: waves w and w + 4 share a SIMD) that alternate per segment —
-//    two segments per half-step, a barrier after each: one half MULTIPLIES (60 MFMAs per wave; its A fragments sit in
-//    registers, the ten 32-column B blocks are streamed from LDS one ahead), the other half LOADS: issues its DMA pieces
-//    of a later stage (buffer_load_dwordx4 ... lds: a third cheaper to issue than global_load_lds with 64-bit lane
-//    addresses), reads its next A fragments, and stores a finished tile.  With n = the block's running half-step and
-//    stage n in LDS buffer n & 1:
-//      half 0 multiplies step n in segment 2n,  loads in segment 2n+1: DMA(A rows of stage n+2), fragments of step n+1
-//      half 1 loads in segment 2n: DMA(B rows of stage n+1), fragments of step n;  multiplies step n in segment 2n+1
-//    Half 0 moves ONLY A rows and half 1 ONLY B rows: the B rows of buffer n & 1 are read (streamed) during both multiply
-//    segments of step n and rewritten by half 1 in segment 2n+2 at the earliest; the A rows are read in the load segments
-//    2n-1 / 2n and rewritten by half 0 from segment 2n+1 on.  A wave waits for its own DMA of stage n+1 before the
-//    barrier that ends segment 2n (half 0 after multiplying — its pieces have had a whole segment — half 1 at the end of
-//    the load segment that issued them).
-// One wave = 32 rows x 320 columns of the tile (accumulators: 160 registers).  Images must be < 4 GB (32-bit offsets).
-template <bool PROBE>
-__global__ void __launch_bounds__(512) k_gemm_x3w(X3Args g) {
-#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the body uses device-only buffer builtins)
-  constexpr int BM = 256, BN = 320, NYB = BN / 32;
-  constexpr int NLA = BM * 6 / 256;                       // 6 A pieces per thread of half 0 per stage
-  constexpr int NLB = (BN * 6 + 255) / 256;               // 8 B pieces per thread of half 1 (the last load half dead)
-  constexpr int A_STAGE = BM * 96, B_STAGE = NLB * 256 * 16;   // bytes of one stage's A rows / B rows (+ dead pieces)
-  constexpr int NA = 3, NB = 2;                           // ring depths: A rows come from HBM (2-3 us), B rows from L2
-  constexpr int B_REGION = NA * A_STAGE;
-  constexpr int NLH = NLA > NLB ? NLA : NLB;
-  constexpr int NSTORE = NYB * 4;
-  static_assert(NA * A_STAGE + NB * B_STAGE <= 160 * 1024, "the rings fit one CU");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NA * A_STAGE + NB * B_STAGE];
+// ---- PRODUCER / CONSUMER form of the same tiles: 12 waves per block ---------------------------------------------------
+// What idles the matrix pipe in k_gemm_x3 is the ISSUE of the stage DMA by the waves that should be multiplying (a wave
+// gets one LDS-DMA instruction accepted per 60-300 cycles and issues in order).  Here waves 0-7 (two per SIMD) only
+// multiply: fragments from LDS, RB x CB x 6 v_mfma_f32_16x16x32_bf16 per step, epilogue stores — they never issue a DMA
+// instruction, so nothing holds them between barriers but the matrix pipe.  Waves 8-11 (one per SIMD) only move data:
+// after the barrier that opens step n they issue ALL of stage n + 1 (MUBUF LDS-DMA: 18 pieces per lane for the 256 x 128
+// tile) into the buffer step n - 1 just released, wait for them to land, and meet the multipliers at the next barrier.
+// One barrier per step.  Three waves per SIMD = 168 registers per wave: the multipliers keep accumulators (64), A
+// fragments (48) and a two-deep B ring (24), the movers their piece offsets.  Images must be < 4 GB (32-bit offsets).
+// Measured against k_gemm_x3: matrix pipe busy 73 % of the in-kernel cycles instead of 56 %.
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(WAVES_M * WAVES_N == 8, "eight multiplier waves + four mover waves");
+  constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32, RB = TM * 2, CB = TN * 2;
+  static_assert(((BM + BN) * 12) % 256 == 0 && (BM * 12) % 256 == 0, "pieces split evenly over the 256 mover lanes");
+  constexpr int PIECES = (BM + BN) * 12, STAGE = PIECES * 16, A_PIECES = BM * 12;
+  constexpr int NLP = PIECES / 256;                        // 18 pieces per mover lane per stage
+  constexpr int NLP_A = A_PIECES / 256;                    // the first 12 are A rows
+  constexpr int NSTORE = RB * CB;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = wid >> 2, ht = tid - h * 256;
-  const int l31 = lane & 31, hi = lane >> 5;
-
+  const bool mover = wid >= 8;
   const int T = g.NI * g.NJ * g.nsplit;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   const int chunk_begin = xcd * (T >> 3) + min(xcd, T & 7), chunk_len = (T >> 3) + (xcd < (T & 7) ? 1 : 0);
@@ -385,174 +363,22 @@ __global__ void __launch_bounds__(512) k_gemm_x3w(X3Args g) {
     __builtin_amdgcn_s_waitcnt(0xC07F);
   }
   const int first = chunk_begin + slot, last_logical = chunk_begin + chunk_len;
-
-  struct Tile { int ti, tj, split, hs_begin, hs_end; };   // hs_*: half-steps (two per 32-deep group)
+  struct Tile { int ti, tj, split, ks_begin, ks_end; };
   auto decode = [&](int logical) __attribute__((always_inline)) {
     Tile t;
     t.split = logical / (g.NI * g.NJ);
     const int tile = logical - t.split * (g.NI * g.NJ);
     t.ti = tile / g.NJ; t.tj = tile - t.ti * g.NJ;
-    int kb = 0, ke = g.nsteps;
+    t.ks_begin = 0; t.ks_end = g.nsteps;
     if (g.nsplit > 1) {
-      kb = t.split * g.steps_per_split;
-      ke = min(g.nsteps, kb + g.steps_per_split);
+      t.ks_begin = t.split * g.steps_per_split;
+      t.ks_end = min(g.nsteps, t.ks_begin + g.steps_per_split);
     }
-    t.hs_begin = 2 * kb; t.hs_end = 2 * ke;
     return t;
   };
   int total = 0;
-  for (int l = first; l < last_logical; l += nslots) { const Tile t = decode(l); total += t.hs_end - t.hs_begin; }
-
-  // ---- fetch side ----------------------------------------------------------------------------------------------------
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(h == 0 ? g.a.img : g.b.img), 0, 0xFFFFFFFF, 0x00020000);
-  const unsigned step_bytes = (unsigned)(h == 0 ? g.a.step_bytes : g.b.step_bytes);
-  unsigned src[NLH];
-  auto load_rids = [&](const Tile& t, int64_t (&rid)[NLA]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int u = 0; u < NLA; ++u) {
-      const int64_t gi = (int64_t)t.ti * BM + (u * 256 + ht) / 6;
-      rid[u] = gi;
-      if (g.a.rows) rid[u] = g.a.rows[gi < g.M ? gi : g.M - 1];       // raw: nothing here consumes the value
-    }
-  };
-  auto make_src = [&](const Tile& t, const int64_t (&rid)[NLA]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int u = 0; u < NLH; ++u) {
-      int i = u * 256 + ht;
-      asm volatile("" : "+v"(i));                          // keep the piece geometry out of the always-live set
-      const int r = i / 6, jp = i - r * 6;
-      const int j = jp ^ ((r >> 3) & 1);                   // physical piece jp of LDS row r holds logical piece j of the half
-      int64_t off;
-      if (h == 0) {
-        const int64_t id = rid[u < NLA ? u : 0];
-        const bool ok = u < NLA && (int64_t)t.ti * BM + r < g.M && id >= 0 && id < g.a.nrows;
-        off = (ok ? id : g.a.zero_row) * g.a.row_bytes + (int64_t)(t.hs_begin >> 1) * g.a.step_bytes;
-      } else {
-        const int64_t gj = (int64_t)t.tj * BN + r;
-        off = (r < BN && gj < g.N ? gj : g.b.zero_row) * g.b.row_bytes + (int64_t)(t.hs_begin >> 1) * g.b.step_bytes;
-      }
-      src[u] = (unsigned)(off + j * 16);
-    }
-  };
-  int f_logical = first, fhs, fhs_end, fstage = 0;
-  bool f_more = true;
-  {
-    const Tile t = decode(first);
-    int64_t rid[NLA];
-    if (h == 0) load_rids(t, rid);
-    make_src(t, rid);
-    fhs = t.hs_begin; fhs_end = t.hs_end;
-  }
-
-  // ---- multiply side ---------------------------------------------------------------------------------------------------
-  // fragment offsets inside a stage: row (96 bytes) + the swizzled piece 2 p + (lane >> 5) of plane p; the swizzle bit
-  // (r >> 3) & 1 of a lane is the same in every 32-row block
-  int offp[3];
-#pragma unroll
-  for (int sp = 0; sp < 3; ++sp) offp[sp] = ((2 * sp + hi) ^ ((l31 >> 3) & 1)) * 16;
-  const int rowa = (wid * 32 + l31) * 96, rowb = l31 * 96;
-  f32x16 acc[NYB];
-  auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int y = 0; y < NYB; ++y)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[y][e] = 0.f;
-  };
-  bf16x8 fa[3], fb[2][3];
-  // the A fragments of step n (a load segment reads them ahead; the B blocks are all read inside the multiply)
-  auto read_one = [&](int n, auto kc) __attribute__((always_inline)) {
-    constexpr int k = decltype(kc)::value;
-    if constexpr (k < 3) fa[k] = *(const bf16x8*)(smem + (n % NA) * A_STAGE + rowa + offp[k]);
-    else fb[0][k - 3] = *(const bf16x8*)(smem + B_REGION + (n & 1) * B_STAGE + rowb + offp[k - 3]);
-  };
-  auto read_frags = [&](int n) __attribute__((always_inline)) {
-    static_for<0, 6>([&](auto kc) __attribute__((always_inline)) { read_one(n, kc); });
-  };
-  // fetch(): this thread's pieces of the next stage of ITS operand (half 0: A rows, half 1: B rows) into its ring slot;
-  // read_n >= 0: the A fragment reads of step read_n are spread between the DMA instructions
-  auto fetch = [&](int read_n) __attribute__((always_inline)) {
-    if (!f_more) {
-      if (read_n >= 0) read_frags(read_n);
-      return;
-    }
-    const bool tile_ends = fhs + 1 == fhs_end, has_next = f_logical + nslots < last_logical;
-    Tile tn = Tile();
-    int64_t rid[NLA];
-    if (tile_ends && has_next) {
-      tn = decode(f_logical + nslots);
-      if (h == 0) load_rids(tn, rid);
-    }
-    const unsigned adv = (fhs & 1) ? step_bytes - 96 : 96;  // after the second half of a group: on to the next group
-    static_for<0, NLH>([&](auto uc) __attribute__((always_inline)) {
-      constexpr int u = decltype(uc)::value;
-      if (u < NLA || h == 1) {
-        const int slot_off = h == 0 ? (fstage % NA) * A_STAGE : B_REGION + (fstage & 1) * B_STAGE;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(smem + slot_off + (u * 256 + (wid & 3) * 64) * 16), 16, src[u], 0, 0, 0);
-        src[u] += adv;
-      }
-      if constexpr (u < 6) {
-        if (read_n >= 0) read_one(read_n, uc);
-      }
-    });
-    ++fstage; ++fhs;
-    if (tile_ends) {
-      if (!has_next) { f_more = false; return; }
-      make_src(tn, rid);
-      f_logical += nslots; fhs = tn.hs_begin; fhs_end = tn.hs_end;
-    }
-  };
-  // one half-step: 10 column blocks x 6 v_mfma_f32_32x32x16_bf16, B block y + 1 read while block y multiplies.  The
-  // weight-side fragment is the first operand: the accumulator holds C^T, a lane owns 4-column groups of ONE output row.
-  auto multiply = [&](int n) __attribute__((always_inline)) {
-    const unsigned char* st = smem + B_REGION + (n & 1) * B_STAGE + rowb;
-    static_for<0, NYB>([&](auto yc) __attribute__((always_inline)) {
-      constexpr int y = decltype(yc)::value;
-      if constexpr (y + 1 < NYB) {
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp) fb[(y + 1) & 1][sp] = *(const bf16x8*)(st + (y + 1) * 32 * 96 + offp[sp]);
-      }
-      acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[y & 1][2], fa[0], acc[y], 0, 0, 0);
-      acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[y & 1][1], fa[1], acc[y], 0, 0, 0);
-      acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[y & 1][0], fa[2], acc[y], 0, 0, 0);
-      acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[y & 1][1], fa[0], acc[y], 0, 0, 0);
-      acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[y & 1][0], fa[1], acc[y], 0, 0, 0);
-      acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[y & 1][0], fa[0], acc[y], 0, 0, 0);
-    });
-  };
-  // epilogue: lane -> output row l & 31, register e -> column (e & 3) + 8 (e >> 2) + 4 (lane >> 5); exactly NSTORE
-  // 16-byte stores per thread (dead lanes aim at a scratch line), so that a wave can wait for the DMA it issued BEFORE them
-  auto epilogue = [&](const Tile& t) __attribute__((always_inline)) {
-    float* const dst = g.nsplit > 1 ? g.ws + (int64_t)t.split * g.M * g.ws_ld : g.C;
-    const int64_t ldd = g.nsplit > 1 ? g.ws_ld : g.ldc;
-    const bool vec_ok = (ldd & 3) == 0 && ((uintptr_t)dst & 15) == 0;
-    const bool fin = g.nsplit == 1;
-    float* const trash = (float*)&g_x3_trash[lane];
-    const int64_t row = (int64_t)t.ti * BM + wid * 32 + l31;
-    const bool rok = row < g.M;
-#pragma unroll
-    for (int y = 0; y < NYB; ++y)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int64_t col = (int64_t)t.tj * BN + y * 32 + 8 * q + 4 * hi;
-        float v[4] = {acc[y][4 * q], acc[y][4 * q + 1], acc[y][4 * q + 2], acc[y][4 * q + 3]};
-        const bool has_oc = fin && g.ones_col && col + 3 >= g.N - 1 && col < g.N;
-        if (fin && g.relu) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
-        }
-        const bool vec = rok && vec_ok && !has_oc && col < g.N && col + 4 <= ldd;
-        *(float4*)(vec ? dst + row * ldd + col : trash) = make_float4(v[0], v[1], v[2], v[3]);
-        if (rok && !vec && col < g.N) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (col + c >= g.N) continue;
-            if (fin && g.ones_col && col + c == g.N - 1) { if (g.db) g.db[row] = v[c]; }
-            else dst[row * ldd + col + c] = v[c];
-          }
-        }
-      }
-  };
-  // segment boundary: nothing — MFMAs included, which a memory clobber alone does not pin — may be scheduled across it
+  for (int l = first; l < last_logical; l += nslots) { const Tile t = decode(l); total += t.ks_end - t.ks_begin; }
+  auto swz = [](int r) __attribute__((always_inline)) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; };
   auto barrier = [&]() __attribute__((always_inline)) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -561,90 +387,158 @@ __global__ void __launch_bounds__(512) k_gemm_x3w(X3Args g) {
     asm volatile("" ::: "memory");
   };
 
-  unsigned long long p_wait = 0, p_load = 0, p_mul = 0, p_vm = 0, ta = 0, tb = 0, tc = 0;   // PROBE only
-  auto wait_keep = [&](bool fetch_behind, bool stores) __attribute__((always_inline)) {
-    // wait for this wave's OLDER DMA; left in flight: the pieces of the one fetch issued after it (fetch_behind) and the
-    // finished tile's stores issued after that (stores) — both static counts
-    if (fetch_behind && stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + NSTORE) : "memory");
-    else if (fetch_behind) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA) : "memory");
-    else if (stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-  zero_acc();
-  // One loop per half; the step counter starts at -3: the pipeline fill runs through the same code, multiply switched off.
-  //   half 0, step n: multiply(n) | wait A(n+1), leaving A(n+2) in flight | barrier | fetch A(n+3), A fragments of n+1 | barrier
-  //   half 1, step n: fetch B(n+1), fragments of n, wait B(n+1) | barrier | multiply(n) | barrier
-  // A ring of three (HBM latency: a stage has 3.5 segments to land), B ring of two (L2 hits: 1.5 segments).
-  auto run = [&](auto half_tag) __attribute__((always_inline)) {
-    constexpr int H = decltype(half_tag)::value;
-    bool stores_pending = false;
-    int m_logical = first, mhs = 0, mhs_end = 0, mhs_begin = 0;
-    { const Tile t = decode(first); mhs = mhs_begin = t.hs_begin; mhs_end = t.hs_end; }
-    for (int n = -3; n < total; ++n) {
-      const bool live = n >= 0;
-      const bool last = live && mhs + 1 == mhs_end;
-      if constexpr (PROBE) X3_STAMP(ta);
-      if (H == 0) {
-        if (live) multiply(n);
-        if constexpr (PROBE) { X3_STAMP(tb); p_mul += tb - ta; }
-        // A(n+1) must have landed; A(n+2) (fetched one load segment ago, if it exists) may stay in flight
-        wait_keep(n + 2 >= 0 && n + 2 < total, stores_pending);
-        stores_pending = false;
-        if constexpr (PROBE) { X3_STAMP(tc); p_vm += tc - tb; }
-        barrier();
-        if constexpr (PROBE) { X3_STAMP(ta); p_wait += ta - tb; }
-        const bool rd = n + 1 >= 0 && n + 1 < total;
-        fetch(rd && !last ? n + 1 : -1);                   // A rows of stage n + 3, A fragments of step n + 1
-        if (last) {                                        // the finished tile goes out before the fragment registers fill
-          epilogue(decode(m_logical));
-          zero_acc();
-          stores_pending = true;
-          if (rd) read_frags(n + 1);
-        }
-        if constexpr (PROBE) { X3_STAMP(tb); p_load += tb - ta; }
-        barrier();
-        if constexpr (PROBE) { X3_STAMP(ta); p_wait += ta - tb; }
-      } else {
-        const bool prev_tile = live && mhs == mhs_begin && m_logical != first;
-        if (n >= -1) fetch(live && !prev_tile ? n : -1);   // B rows of stage n + 1, A fragments of step n
-        if (prev_tile) {                                   // the tile BEFORE step n's tile: its stores go out behind the DMA
-          epilogue(decode(m_logical - nslots));
-          zero_acc();
-          read_frags(n);
-          stores_pending = true;
-        }
-        if constexpr (PROBE) X3_STAMP(tc);
-        wait_keep(false, stores_pending);                  // B(n+1), issued at the top of this segment: half 0 reads it next
-        stores_pending = false;
-        if constexpr (PROBE) { unsigned long long td; X3_STAMP(td); p_vm += td - tc; }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // half 0 refills this stage's A slot two segments on
-        if constexpr (PROBE) { X3_STAMP(tb); p_load += tb - ta; }
-        barrier();
-        if constexpr (PROBE) { X3_STAMP(ta); p_wait += ta - tb; }
-        if (live) multiply(n);
-        if constexpr (PROBE) { X3_STAMP(tb); p_mul += tb - ta; }
-        barrier();
-        if constexpr (PROBE) { X3_STAMP(ta); p_wait += ta - tb; }
+  if (mover) {
+    // ---- movers: the fetch cursor walks the block's stages in order, across tiles -------------------------------------
+    const int ml = (wid - 8) * 64 + lane;                  // lane of the 256-lane mover group
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)g.a.img, 0, 0xFFFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)g.b.img, 0, 0xFFFFFFFF, 0x00020000);
+    const unsigned step_a = (unsigned)g.a.step_bytes, step_b = (unsigned)g.b.step_bytes;
+    unsigned src[NLP];
+    auto make_src = [&](const Tile& t) __attribute__((always_inline)) {
+      int64_t rid[NLP_A];
+#pragma unroll
+      for (int u = 0; u < NLP_A; ++u) {
+        const int64_t gi = (int64_t)t.ti * BM + (u * 256 + ml) / 12;
+        rid[u] = gi;
+        if (g.a.rows) rid[u] = g.a.rows[gi < g.M ? gi : g.M - 1];
       }
-      if (live && ++mhs == mhs_end && n + 1 < total) {
-        m_logical += nslots;
-        const Tile t = decode(m_logical);
-        mhs = mhs_begin = t.hs_begin; mhs_end = t.hs_end;
+#pragma unroll
+      for (int u = 0; u < NLP; ++u) {
+        const int i = u * 256 + ml;
+        const int r = i / 12, jp = i - r * 12;
+        const int j = (jp & ~3) | ((jp & 3) ^ swz(r));
+        int64_t off;
+        if (u < NLP_A) {
+          const int64_t id = rid[u < NLP_A ? u : 0];
+          const bool ok = (int64_t)t.ti * BM + r < g.M && id >= 0 && id < g.a.nrows;
+          off = (ok ? id : g.a.zero_row) * g.a.row_bytes + (int64_t)t.ks_begin * g.a.step_bytes;
+        } else {
+          const int64_t gj = (int64_t)t.tj * BN + (r - BM);
+          off = (gj < g.N ? gj : g.b.zero_row) * g.b.row_bytes + (int64_t)t.ks_begin * g.b.step_bytes;
+        }
+        src[u] = (unsigned)(off + j * 16);
+      }
+    };
+    int f_logical = first, fks, fks_end;
+    { const Tile t = decode(first); make_src(t); fks = t.ks_begin; fks_end = t.ks_end; }
+    auto fetch = [&](int stage) __attribute__((always_inline)) {
+      static_for<0, NLP>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(u < NLP_A ? rsrc_a : rsrc_b,
+                                                 (lptr_t)(smem + (stage & 1) * STAGE + (u * 256 + (wid - 8) * 64) * 16), 16, src[u], 0, 0, 0);
+        src[u] += u < NLP_A ? step_a : step_b;
+      });
+      if (++fks == fks_end && f_logical + nslots < last_logical) {     // on to the next tile
+        f_logical += nslots;
+        const Tile t = decode(f_logical);
+        make_src(t);
+        fks = t.ks_begin; fks_end = t.ks_end;
+      }
+    };
+    fetch(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int n = 0; n < total; ++n) {
+      barrier();                                           // opens step n: buffer (n + 1) & 1 is free
+      if (n + 1 < total) {
+        fetch(n + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     }
-    if (H == 1) epilogue(decode(m_logical));               // the block's last tile
-  };
-  if (h == 0) run(std::integral_constant<int, 0>());
-  else run(std::integral_constant<int, 1>());
+  } else {
+    // ---- multipliers: 4 x 2 waves of 64 x 64 ------------------------------------------------------------------------------
+    const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+    const int l15 = lane & 15, quad = lane >> 4;
+    int offp[3];
+    {
+      const int q = swz(l15);
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp) {
+        const int j = x3_piece(quad, sp);
+        offp[sp] = ((j & ~3) | ((j & 3) ^ q)) * 16;
+      }
+    }
+    const int rowa = (wm * TM * 32 + l15) * 192, rowb = (BM + wn * TN * 32 + l15) * 192;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc[RB][CB];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int a = 0; a < RB; ++a)
+#pragma unroll
+        for (int b = 0; b < CB; ++b)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.f;
+    };
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+      const unsigned char* st = smem + buf * STAGE;
+      bf16x8 a[RB][3], b[2][3];
+#pragma unroll
+      for (int t = 0; t < RB; ++t)
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) a[t][sp] = *(const bf16x8*)(st + rowa + t * 16 * 192 + offp[sp]);
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp) b[0][sp] = *(const bf16x8*)(st + rowb + offp[sp]);
+      static_for<0, CB>([&](auto yc) __attribute__((always_inline)) {
+        constexpr int y = decltype(yc)::value;
+        if constexpr (y + 1 < CB) {
+#pragma unroll
+          for (int sp = 0; sp < 3; ++sp) b[(y + 1) & 1][sp] = *(const bf16x8*)(st + rowb + (y + 1) * 16 * 192 + offp[sp]);
+        }
+#pragma unroll
+        for (int x = 0; x < RB; ++x) {
+          acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][2], a[x][0], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][1], a[x][1], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][2], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][1], a[x][0], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][1], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][0], acc[x][y], 0, 0, 0);
+        }
+      });
+    };
+    auto epilogue = [&](const Tile& t) __attribute__((always_inline)) {
+      float* const dst = g.nsplit > 1 ? g.ws + (int64_t)t.split * g.M * g.ws_ld : g.C;
+      const int64_t ldd = g.nsplit > 1 ? g.ws_ld : g.ldc;
+      const bool vec_ok = (ldd & 3) == 0 && ((uintptr_t)dst & 15) == 0;
+      const bool fin = g.nsplit == 1;
+#pragma unroll
+      for (int x = 0; x < RB; ++x)
+#pragma unroll
+        for (int y = 0; y < CB; ++y) {
+          const int64_t row = (int64_t)t.ti * BM + wm * TM * 32 + x * 16 + l15, col = (int64_t)t.tj * BN + wn * TN * 32 + y * 16 + 4 * quad;
+          float v[4] = {acc[x][y][0], acc[x][y][1], acc[x][y][2], acc[x][y][3]};
+          const bool rok = row < g.M;
+          const bool has_oc = fin && g.ones_col && col + 3 >= g.N - 1 && col < g.N;
+          if (fin && g.relu) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+          }
+          const bool vec = rok && vec_ok && !has_oc && col < g.N && col + 4 <= ldd;
+          if (vec) *(float4*)(dst + row * ldd + col) = make_float4(v[0], v[1], v[2], v[3]);
+          else if (rok && col < g.N) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (col + c >= g.N) continue;
+              if (fin && g.ones_col && col + c == g.N - 1) { if (g.db) g.db[row] = v[c]; }
+              else dst[row * ldd + col + c] = v[c];
+            }
+          }
+        }
+    };
+    zero_acc();
+    int n = 0;
+    for (int logical = first; logical < last_logical; logical += nslots) {
+      const Tile tc = decode(logical);
+      for (int ks = tc.ks_begin; ks < tc.ks_end; ++ks, ++n) {
+        barrier();                                         // stage n has landed (the movers waited for it)
+        compute(n & 1);
+      }
+      epilogue(tc);
+      zero_acc();
+    }
+  }
+  (void)NSTORE;
   if (g.stamps && tid == 0) {
     g.stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
     g.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
-  }
-  if constexpr (PROBE) {
-    if (g.stamps && lane == 0) {
-      unsigned long long* o = g.stamps + 1024 + (blockIdx.x * 8 + wid) * 4;
-      o[0] = p_wait; o[1] = p_load; o[2] = p_mul; o[3] = p_vm;
-    }
   }
 #endif
 }
@@ -827,10 +721,9 @@ static int x3_config(int64_t M, int64_t N) {
 // Diagnostics: when set, every k_gemm_x3 launch writes per block {s_memtime, s_memrealtime} at entry and at exit (4 x u64
 // per block, <= 256 blocks) into `buf` — the in-kernel shader clock is d(memtime) / d(memrealtime) x 100 MHz.
 static unsigned long long* g_x3_stamps = nullptr;
-static int g_x3_probe = 0;
-extern "C" int ogl_x3_debug_stamps(void* buf, int probe) {
+extern "C" int ogl_x3_debug_stamps(void* buf, int reserved) {
+  (void)reserved;
   g_x3_stamps = (unsigned long long*)buf;
-  g_x3_probe = buf ? probe : 0;    // probe != 0: the wide kernel's stamped build (per-wave cycles of wait / load / multiply)
   return OGL_OK;
 }
 
@@ -841,17 +734,18 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
   const int64_t a_bytes = std::max((g.a.zero_row + 1) * g.a.row_bytes, (int64_t)g.nsteps * g.a.step_bytes);
   const int64_t b_bytes = std::max((g.b.zero_row + 1) * g.b.row_bytes, (int64_t)g.nsteps * g.b.step_bytes);
   const int cfg = x3_config(g.M, g.N);
-  // k_gemm_x3w is EXPERIMENTAL and off by default: parity-green, but 10-18 % slower than the tiles below at the layer-0
-  // shapes (DESIGN.md section 8-1 has the per-segment stamps).  OGL_X3_WIDE=1 routes every eligible product through it.
-  static const char* wide_env = getenv("OGL_X3_WIDE");
-  const bool wide = wide_env && wide_env[0] == '1' && a_bytes < (1ll << 32) && b_bytes < (1ll << 32);
-  if (wide) {
-    g.NI = (int)ogl_cdiv(g.M, 256);
-    g.NJ = (int)ogl_cdiv(g.N, 320);
+  // producer / consumer kernels (k_gemm_x3p) whenever both images fit 32-bit offsets; OGL_X3_PC=0 forces the
+  // self-fetching kernels (experiments)
+  static const char* pc_env = getenv("OGL_X3_PC");
+  const bool pc = !(pc_env && pc_env[0] == '0') && a_bytes < (1ll << 32) && b_bytes < (1ll << 32);
+  if (pc) {
+    const int BMp = cfg == 0 ? 256 : 128;
+    g.NI = (int)ogl_cdiv(g.M, BMp);
+    g.NJ = (int)ogl_cdiv(g.N, 128);
     const int64_t T = (int64_t)g.NI * g.NJ * g.nsplit;
-    dim3 grid((unsigned)(8 * std::min<int64_t>(32, ogl_cdiv(T, 8)))), block(512);
-    if (g_x3_probe) hipLaunchKernelGGL((k_gemm_x3w<true>), grid, block, 0, stream, g);
-    else hipLaunchKernelGGL((k_gemm_x3w<false>), grid, block, 0, stream, g);
+    dim3 grid((unsigned)(8 * std::min<int64_t>(32, ogl_cdiv(T, 8)))), block(768);
+    if (cfg == 0) hipLaunchKernelGGL((k_gemm_x3p<4, 2, 2, 2>), grid, block, 0, stream, g);
+    else hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1>), grid, block, 0, stream, g);
     OGL_CHECK_LAUNCH();
   } else {
   const int BM = cfg == 0 ? 256 : 128, BN = 128;

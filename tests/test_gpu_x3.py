@@ -431,12 +431,13 @@ def test_debug_stamps_report_a_plausible_clock(ops):
     assert torch.equal(stamps, after)                              # switched off again
 
 
-def test_experimental_wide_kernel_parity():
-    """k_gemm_x3w (256 x 320 tile on 16-deep half-steps, alternating wave halves, MUBUF LDS-DMA; off by default) stays
-    parity-green: the forward / weight-gradient / dispatch tests of this file with OGL_X3_WIDE=1 (the switch is read once
-    per process, hence the child interpreter)."""
+
+def test_self_fetching_kernels_parity():
+    """The image GEMM has two forms: producer / consumer (k_gemm_x3p, the default while both images fit 32-bit offsets)
+    and self-fetching (k_gemm_x3: images of 4 GB and more).  OGL_X3_PC=0 forces the second form; the forward / weight-
+    gradient / dispatch tests of this file must pass on it too (the switch is read once per process: child interpreter)."""
     import os, subprocess, sys
-    env = dict(os.environ, OGL_X3_WIDE="1")
+    env = dict(os.environ, OGL_X3_PC="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x",
                         "-k", "forward or weight or random or dispatch or limits", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -74,7 +74,7 @@ def clock_probe():
         table.zero_(); wp.zero_()
     t_img = ops.x3_split(table, append_ones=True)
     w_img = ops.x3_split(wp, append_vec=torch.zeros(F, device="cuda"))
-    probe = 1 if os.environ.get("X3_PROBE") else 0
+    probe = 0
     stamps = torch.zeros(1024 + 256 * 8 * 4, dtype=torch.int64, device="cuda")
     _lib.lib().ogl_x3_debug_stamps(stamps.data_ptr(), probe)
     t0 = time.time(); n = 0
@@ -95,13 +95,6 @@ def clock_probe():
                                                      ghz.min().item(), ghz.max().item(), cyc / 1e3, fl / ms / 1e9), flush=True)
     # matrix-pipe occupancy at the held clock: 6 MFMA terms x padded tiles x 16 cycles per 16x16x32 MFMA per SIMD
     mfma_cycles = 6.0 * (-(-T // 256) * 256) * 640 * 608 / (16 * 16 * 32) * 16 / (256 * 4)
-    if probe:
-        tot = ph[:, :, :3].sum(2)
-        print("  PROBE build, cycles per wave summed over the launch (mean over 2048 waves; min..max): total %.0f k" % (tot.mean().item() / 1e3))
-        for i, name in enumerate(("wait+barrier", "load segment", "multiply segment", "(of which vmcnt wait)")):
-            v = ph[:, :, i]
-            print("    %-16s %8.0f k  (%4.1f %%)   %.0f..%.0f k   by wave: %s" % (name, v.mean().item() / 1e3, 100 * v.mean().item() / tot.mean().item(),
-                  v.min().item() / 1e3, v.max().item() / 1e3, " ".join("%.0f" % (x / 1e3) for x in v.mean(0).tolist())))
     print("  MFMA cycles needed per SIMD %.0f k -> matrix pipe busy %.1f %% of the in-kernel cycles" % (mfma_cycles / 1e3, 100 * mfma_cycles / cyc))
 
 
