@@ -471,12 +471,13 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
     auto compute = [&](int buf) __attribute__((always_inline)) {
       const unsigned char* st = smem + buf * STAGE;
       bf16x8 a[RB][3], b[2][3];
+      // reads in the order of first use: the first MFMA group needs b[0] and a[0] only and starts after six reads
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp) b[0][sp] = *(const bf16x8*)(st + rowb + offp[sp]);
 #pragma unroll
       for (int t = 0; t < RB; ++t)
 #pragma unroll
         for (int sp = 0; sp < 3; ++sp) a[t][sp] = *(const bf16x8*)(st + rowa + t * 16 * 192 + offp[sp]);
-#pragma unroll
-      for (int sp = 0; sp < 3; ++sp) b[0][sp] = *(const bf16x8*)(st + rowb + offp[sp]);
       static_for<0, CB>([&](auto yc) __attribute__((always_inline)) {
         constexpr int y = decltype(yc)::value;
         if constexpr (y + 1 < CB) {
