@@ -175,8 +175,7 @@ int ogl_transpose(const float* src, int64_t ld, const int64_t* rows, int64_t nro
  * `graph.ndata['feat'][input_nodes]`) is split once per dataset, weights once per call.
  *
  * Image of an fp32 matrix [R, K]: (R + 1) rows (row R is all zero) of ceil(K/32) groups of 192 bytes; a group holds
- * 32 consecutive reduction elements as two 96-byte halves of 16 elements, each half three 32-byte bf16 planes (hi,
- * mid, lo term): element e of plane p sits at byte (e / 16) * 96 + p * 32 + (e % 16) * 2.  Pad elements are zero.
+ * 32 consecutive reduction elements as three 64-byte bf16 planes (hi, mid, lo term), pad elements are zero.
  *   ogl_x3_split    image row r = split(src[row(r), 0:K])           (rows nullable; ids outside [0, nrows) -> zero row).
  *                   append != 0 gives the image ONE extra reduction element at k = K (image reduction length K + 1:
  *                   size it with ogl_x3_image_bytes(R, K + 1)): append = 1 -> 1.0 in every row INCLUDING the zero row

@@ -6,10 +6,9 @@
 // linear.hip (R/train/graphsage/pytorch/aggregator_dgl.py:85-94,171,181,206) for the large layer-0 products.
 //
 // Image of an fp32 matrix X[R, K] (reduction index contiguous): R rows + ONE all-zero row (index R), each row
-// G = ceil(K/32) groups of 192 bytes; group g holds k = 32g .. 32g+31 as two 96-byte HALVES of 16 elements, each half
-// three 32-byte planes (hi, mid, lo terms of the split): element e of plane p sits at byte (e / 16) * 96 + p * 32 +
-// (e % 16) * 2 (x3_piece, x6_arith.h); pad k >= K is zero.  One (row, group) is 192 contiguous bytes = the 12 pieces of a
-// 32-deep GEMM step, one (row, half) 96 contiguous bytes = the 6 pieces of a 16-deep step.
+// G = ceil(K/32) groups of 192 bytes; group g holds k = 32g .. 32g+31 as three 64-byte planes (hi, mid, lo terms
+// of the split; x3_piece, x6_arith.h), pad k >= K is zero.  One (row, group) is therefore 192 contiguous bytes: a 32-deep
+// GEMM step reads 12 consecutive 16-byte pieces per row.
 //
 // k_gemm_x3: C[i, j] = epilogue(sum_k A[i, k] B[j, k]), both operands images (A optionally gathered by an int64 row
 // list: rows outside the table read the zero row).  8 waves per block, one block per CU (144 KB LDS: two stages of
@@ -468,30 +467,40 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.f;
     };
-    auto compute = [&](int buf) __attribute__((always_inline)) {
+    // rbv / cbv: how many of the wave tile's 16-row / 16-column blocks hold any real output (the rest is tile padding:
+    // M or N not a multiple of the tile).  Padding blocks are not multiplied: the kernel is paced by power, not by the
+    // busiest SIMD, so every MFMA not issued comes back as clock (N = 602: 2 of 40 column blocks, 5-10 % of the MFMAs).
+    auto compute = [&](int buf, int rbv, int cbv) __attribute__((always_inline)) {
       const unsigned char* st = smem + buf * STAGE;
       bf16x8 a[RB][3], b[2][3];
-      // reads in the order of first use: the first MFMA group needs b[0] and a[0] only and starts after six reads
+      if (rbv <= 0 || cbv <= 0) return;
 #pragma unroll
       for (int sp = 0; sp < 3; ++sp) b[0][sp] = *(const bf16x8*)(st + rowb + offp[sp]);
 #pragma unroll
       for (int t = 0; t < RB; ++t)
+        if (t < rbv) {
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) a[t][sp] = *(const bf16x8*)(st + rowa + t * 16 * 192 + offp[sp]);
+          for (int sp = 0; sp < 3; ++sp) a[t][sp] = *(const bf16x8*)(st + rowa + t * 16 * 192 + offp[sp]);
+        }
       static_for<0, CB>([&](auto yc) __attribute__((always_inline)) {
         constexpr int y = decltype(yc)::value;
-        if constexpr (y + 1 < CB) {
+        if (y < cbv) {
+          if constexpr (y + 1 < CB) {
+            if (y + 1 < cbv) {
 #pragma unroll
-          for (int sp = 0; sp < 3; ++sp) b[(y + 1) & 1][sp] = *(const bf16x8*)(st + rowb + (y + 1) * 16 * 192 + offp[sp]);
-        }
+              for (int sp = 0; sp < 3; ++sp) b[(y + 1) & 1][sp] = *(const bf16x8*)(st + rowb + (y + 1) * 16 * 192 + offp[sp]);
+            }
+          }
 #pragma unroll
-        for (int x = 0; x < RB; ++x) {
-          acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][2], a[x][0], acc[x][y], 0, 0, 0);
-          acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][1], a[x][1], acc[x][y], 0, 0, 0);
-          acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][2], acc[x][y], 0, 0, 0);
-          acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][1], a[x][0], acc[x][y], 0, 0, 0);
-          acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][1], acc[x][y], 0, 0, 0);
-          acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][0], acc[x][y], 0, 0, 0);
+          for (int x = 0; x < RB; ++x)
+            if (x < rbv) {
+              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][2], a[x][0], acc[x][y], 0, 0, 0);
+              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][1], a[x][1], acc[x][y], 0, 0, 0);
+              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][2], acc[x][y], 0, 0, 0);
+              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][1], a[x][0], acc[x][y], 0, 0, 0);
+              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][1], acc[x][y], 0, 0, 0);
+              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][0], acc[x][y], 0, 0, 0);
+            }
         }
       });
     };
@@ -528,9 +537,11 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
     int n = 0;
     for (int logical = first; logical < last_logical; logical += nslots) {
       const Tile tc = decode(logical);
+      const int64_t rleft = g.M - ((int64_t)tc.ti * BM + wm * TM * 32), cleft = g.N - ((int64_t)tc.tj * BN + wn * TN * 32);
+      const int rbv = rleft >= RB * 16 ? RB : (int)((rleft + 15) >> 4), cbv = cleft >= CB * 16 ? CB : (int)((cleft + 15) >> 4);
       for (int ks = tc.ks_begin; ks < tc.ks_end; ++ks, ++n) {
         barrier();                                         // stage n has landed (the movers waited for it)
-        compute(n & 1);
+        compute(n & 1, rbv, cbv);
       }
       epilogue(tc);
       zero_acc();

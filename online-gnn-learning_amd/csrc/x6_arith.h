@@ -28,11 +28,11 @@ __device__ __forceinline__ void split3(float x, float y, unsigned& h, unsigned& 
   l = pk_bf16(sx, sy);
 }
 
-// Byte order inside one 192-byte group of a bf16x3 image (32 reduction elements): two 96-byte HALVES of 16 elements,
-// each half = three 32-byte planes (hi, mid, lo term).  x3_piece(c, p) = index of the 16-byte piece holding elements
-// 8c .. 8c+7 of plane p (its byte offset is 16 x that): a 16-deep GEMM step reads one contiguous 96-byte half per row
-// (pieces 0-5 or 6-11), a 32-deep step the whole group.
-__host__ __device__ __forceinline__ constexpr int x3_piece(int c, int p) { return (c >> 1) * 6 + p * 2 + (c & 1); }
+// Byte order inside one 192-byte group of a bf16x3 image (32 reduction elements): three 64-byte planes (hi, mid, lo
+// term of the split).  x3_piece(c, p) = index of the 16-byte piece holding elements 8c .. 8c+7 of plane p (its byte offset
+// is 16 x that).  (A half-major order — [2 halves][3 planes][16], for 16-deep GEMM steps — was tried and measured 14 %
+// slower in the image producers: their 16-byte stores then come in 32-byte runs instead of 64-byte ones.)
+__host__ __device__ __forceinline__ constexpr int x3_piece(int c, int p) { return p * 4 + c; }
 
 // 16-byte load from a 4-byte-aligned address: gfx950 under HSA runs in unaligned-access mode, the
 // compiler emits one global_load_dwordx4 (rows such as K = 602 floats are only 8-B aligned).

@@ -29,18 +29,18 @@ def bf16_split3(x):
 
 
 def image_model(x):
-    """[R, K] fp32 -> uint8 image [(R + 1), ceil(K/32), 2 halves, 3 planes, 16] bf16 as raw bytes (include/ogl_hip.h)."""
+    """[R, K] fp32 -> uint8 image [(R + 1), ceil(K/32), 3, 32] bf16 as raw bytes (include/ogl_hip.h)."""
     R, K = x.shape
     G = (K + 31) // 32
     pad = torch.zeros((R + 1, G * 32), dtype=torch.float32)
     pad[:R, :K] = x
     planes = torch.stack(bf16_split3(pad), 0)                     # [3, R+1, G*32] bf16
-    img = planes.view(3, R + 1, G, 2, 16).permute(1, 2, 3, 0, 4).contiguous()
+    img = planes.view(3, R + 1, G, 32).permute(1, 2, 0, 3).contiguous()
     return img.view(torch.int16).numpy().view(np.uint8).reshape(-1)
 
 
 def image_model_t(x):
-    """Transposed images are GROUP-MAJOR: [ceil(K/32)][R + 1][2][3][16] (include/ogl_hip.h)."""
+    """Transposed images are GROUP-MAJOR: [ceil(K/32)][R + 1][3][32] (include/ogl_hip.h)."""
     R, K = x.shape
     G = (K + 31) // 32
     return image_model(x).reshape(R + 1, G, 192).transpose(1, 0, 2).copy().reshape(-1)
@@ -232,8 +232,8 @@ def test_status_codes(ops):
 def image_decode_t(buf, rows, K):
     """uint8 group-major (transposed) image -> [rows, ceil(K/32)*32] fp32 (the three planes summed; exact)."""
     G = (K + 31) // 32
-    raw = torch.as_tensor(buf.cpu().numpy().view(np.int16).reshape(G, rows + 1, 2, 3, 16).copy()).view(torch.bfloat16).float()
-    val = ((raw[:, :, :, 0] + raw[:, :, :, 1]) + raw[:, :, :, 2]).reshape(G, rows + 1, 32)
+    raw = torch.as_tensor(buf.cpu().numpy().view(np.int16).reshape(G, rows + 1, 3, 32).copy()).view(torch.bfloat16).float()
+    val = (raw[:, :, 0] + raw[:, :, 1]) + raw[:, :, 2]                 # [G, rows + 1, 32]
     assert (val[:, rows] == 0).all()                                   # the zero row of every group
     return val[:, :rows].permute(1, 0, 2).reshape(rows, G * 32)
 
