@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
 // One barrier per step.  Three waves per SIMD = 168 registers per wave: the multipliers keep accumulators (64), A
 // fragments (48) and a two-deep B ring (24), the movers their piece offsets.  Images must be < 4 GB (32-bit offsets).
 // Measured against k_gemm_x3: matrix pipe busy 73 % of the in-kernel cycles instead of 56 %.
-template <int WAVES_M, int WAVES_N, int TM, int TN>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE>
 __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(WAVES_M * WAVES_N == 8, "eight multiplier waves + four mover waves");
@@ -347,7 +347,9 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
   constexpr int NLP = PIECES / 256;                        // 18 pieces per mover lane per stage
   constexpr int NLP_A = A_PIECES / 256;                    // the first 12 are A rows
   constexpr int NSTORE = RB * CB;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+  static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
+  static_assert(NSTAGE * STAGE <= 160 * 1024, "the ring fits one CU");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -424,7 +426,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
       static_for<0, NLP>([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(u < NLP_A ? rsrc_a : rsrc_b,
-                                                 (lptr_t)(smem + (stage & 1) * STAGE + (u * 256 + (wid - 8) * 64) * 16), 16, src[u], 0, 0, 0);
+                                                 (lptr_t)(smem + (stage % NSTAGE) * STAGE + (u * 256 + (wid - 8) * 64) * 16), 16, src[u], 0, 0, 0);
         src[u] += u < NLP_A ? step_a : step_b;
       });
       if (++fks == fks_end && f_logical + nslots < last_logical) {     // on to the next tile
@@ -434,14 +436,19 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         fks = t.ks_begin; fks_end = t.ks_end;
       }
     };
-    fetch(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the movers run NSTAGE - 1 stages ahead of the multipliers: after the barrier that opens step n they issue stage
+    // n + NSTAGE - 1 into the buffer step n - 1 released, then wait for stage n + 1 only (with three stages the newest
+    // NLP pieces stay in flight across the barrier: a stage has two steps to land)
+    int issued = 0;
+    for (; issued < NSTAGE - 1 && issued < total; ++issued) fetch(issued);
+    if (NSTAGE == 3 && issued == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int n = 0; n < total; ++n) {
-      barrier();                                           // opens step n: buffer (n + 1) & 1 is free
-      if (n + 1 < total) {
-        fetch(n + 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      barrier();                                           // opens step n: the buffer of step n - 1 is free
+      if (issued < total) { fetch(issued); ++issued; }
+      // stage n + 1 must have landed before the next barrier; what was issued after it may stay in flight
+      if (NSTAGE == 3 && issued >= n + 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   } else {
     // ---- multipliers: 4 x 2 waves of 64 x 64 ------------------------------------------------------------------------------
@@ -541,7 +548,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
       const int rbv = rleft >= RB * 16 ? RB : (int)((rleft + 15) >> 4), cbv = cleft >= CB * 16 ? CB : (int)((cleft + 15) >> 4);
       for (int ks = tc.ks_begin; ks < tc.ks_end; ++ks, ++n) {
         barrier();                                         // stage n has landed (the movers waited for it)
-        compute(n & 1, rbv, cbv);
+        compute(n % NSTAGE, rbv, cbv);
       }
       epilogue(tc);
       zero_acc();
@@ -756,8 +763,10 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     g.NJ = (int)ogl_cdiv(g.N, 128);
     const int64_t T = (int64_t)g.NI * g.NJ * g.nsplit;
     dim3 grid((unsigned)(8 * std::min<int64_t>(32, ogl_cdiv(T, 8)))), block(768);
-    if (cfg == 0) hipLaunchKernelGGL((k_gemm_x3p<4, 2, 2, 2>), grid, block, 0, stream, g);
-    else hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1>), grid, block, 0, stream, g);
+    // ring depth: two stages of the 256 x 128 tile fill the LDS (144 KB); the 128 x 128 tile takes three (144 KB): its movers
+    // run two stages ahead (+4 % on the layer-0 weight gradient, whose operands both stream from HBM)
+    if (cfg == 0) hipLaunchKernelGGL((k_gemm_x3p<4, 2, 2, 2, 2>), grid, block, 0, stream, g);
+    else hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1, 3>), grid, block, 0, stream, g);
     OGL_CHECK_LAUNCH();
   } else {
   const int BM = cfg == 0 ? 256 : 128, BN = 128;
