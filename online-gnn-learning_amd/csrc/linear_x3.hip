@@ -10,9 +10,12 @@
 // of the split; x3_piece, x6_arith.h), pad k >= K is zero.  One (row, group) is therefore 192 contiguous bytes: a 32-deep
 // GEMM step reads 12 consecutive 16-byte pieces per row.
 //
-// k_gemm_x3: C[i, j] = epilogue(sum_k A[i, k] B[j, k]), both operands images (A optionally gathered by an int64 row
-// list: rows outside the table read the zero row).  8 waves per block, one block per CU (144 KB LDS: two stages of
-// (BM + BN) x 192 B), 2 waves per SIMD.  LDS image of a stage = the 12 pieces of row r at pieces 12r .. 12r+11 with
+// Two kernels compute C[i, j] = epilogue(sum_k A[i, k] B[j, k]) on images (A optionally gathered by an int64 row list:
+// rows outside the table read the zero row), persistent, one block per CU, LDS stages of (BM + BN) x 192 B:
+//   k_gemm_x3p (the default): PRODUCER / CONSUMER — eight multiplier waves that never issue a load + four mover waves
+//               that issue the stage DMA (MUBUF, 32-bit offsets: images < 4 GB); matrix pipe busy 73 % of the cycles;
+//   k_gemm_x3  (images >= 4 GB): eight waves that fetch for themselves (64-bit global_load_lds); 56 %.
+// Both share the LDS image of a stage = the 12 pieces of row r at pieces 12r .. 12r+11 with
 // the chunk index XOR-ed inside each plane by swz(r) = {0, 2, 3, 1}[(r >> 2) & 3]: the DMA is lane-linear (piece i of
 // the stage lands at byte 16 i), the swizzle is applied on the per-lane SOURCE address, and every MFMA fragment is one
 // conflict-free ds_read_b128 (16-lane groups {0-3,12-15,20-27}, ... hit 16 distinct 16-byte slots of the 256-byte
