@@ -20,15 +20,22 @@ __device__ __forceinline__ int64_t bcast_idx(int64_t v, int j) {
 }
 
 // ---- vectorised forward: NCH float4 chunks per lane (d <= 256*NCH floats) -------------------
-template <int OP, typename IdxT, bool ARG, int NCH>
+// One wave per (destination, column slice): `parts` waves share a destination, each reducing a contiguous slice of
+// ceil(d4 / parts) float4 columns.  A batch of 7 000 destinations is only 1.4 rounds of one-wave-per-destination on the
+// chip (256 CUs x 20 waves): two slices per destination make it 2 rounds of smaller waves — no half-empty tail round.
+template <int OP, typename IdxT, bool ARG, int NCH, int U = (NCH == 1 ? 8 : 4)>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK)
 k_reduce_fwd_v4(const float* __restrict__ src, int64_t lds, int64_t n_src, const IdxT* __restrict__ idx,
                 int64_t n_dst, int S, int d, float* __restrict__ out, int64_t ldo,
-                int32_t* __restrict__ argmax) {
+                int32_t* __restrict__ argmax, int parts) {
   const int lane = threadIdx.x & 63;
-  const int64_t w = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  const int64_t wg = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  const int64_t w = wg / parts;
   if (w >= n_dst) return;
-  const int d4 = (d + 3) >> 2;
+  const int part = (int)(wg - w * parts);
+  const int dall4 = (d + 3) >> 2, cper = (dall4 + parts - 1) / parts;
+  const int c0 = part * cper;
+  const int d4 = min(dall4, c0 + cper);            // this wave's slice: float4 columns [c0, d4)
   float4 acc[NCH];
   int arg[NCH][4];
   bool any = false;
@@ -40,26 +47,30 @@ k_reduce_fwd_v4(const float* __restrict__ src, int64_t lds, int64_t n_src, const
   for (int s0 = 0; s0 < S; s0 += 64) {
     const int sc = min(64, S - s0);
     IdxT mine = lane < sc ? idx[w * S + s0 + lane] : (IdxT)-1;
-    for (int j0 = 0; j0 < sc; j0 += 4) {
-      float4 v[4][NCH];
-      int64_t r[4];
+    for (int j0 = 0; j0 < sc; j0 += U) {
+      // The U x NCH row loads are issued back to back with nothing between them that needs a wait: all row ids are
+      // broadcast first (scalars), a missing row (past S, id -1, id >= n_src) reads row 0 and is skipped below, a lane
+      // past the slice reads the slice's last float4.  (A branch around each row's loads makes the compiler drain
+      // vmcnt at every join, i.e. one row in flight per wave — measured 0.086 ms against 0.060 ms for layer 0.)
+      float4 v[U][NCH];
+      int64_t r[U];
+      bool ok[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        int j = j0 + u;
-        r[u] = j < sc ? bcast_idx(mine, j < sc ? j : 0) : -1;
-        if (r[u] >= n_src) r[u] = -1;
-        if (r[u] >= 0) {
-          const float4* rp = (const float4*)(src + r[u] * lds);
-#pragma unroll
-          for (int c = 0; c < NCH; ++c) {
-            int ch = c * 64 + lane;
-            if (ch < d4) v[u][c] = rp[ch];
-          }
-        }
+      for (int u = 0; u < U; ++u) {
+        const int j = j0 + u;
+        const int64_t q = bcast_idx(mine, j < sc ? j : sc - 1);
+        ok[u] = (j < sc) && q >= 0 && q < n_src;
+        r[u] = ok[u] ? q : 0;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (r[u] < 0) continue;  // wave-uniform
+      for (int u = 0; u < U; ++u) {
+        const float4* rp = (const float4*)(src + r[u] * lds);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) v[u][c] = rp[min(c0 + c * 64 + lane, d4 - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;  // wave-uniform
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
           if (OP == OGL_REDUCE_MAX) {
@@ -83,7 +94,7 @@ k_reduce_fwd_v4(const float* __restrict__ src, int64_t lds, int64_t n_src, const
   const float fS = (float)S;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    int ch = c * 64 + lane;
+    int ch = c0 + c * 64 + lane;
     if (ch < d4) {
       float4 o = acc[c];
       if (OP == OGL_REDUCE_MEAN && any) { o.x /= fS; o.y /= fS; o.z /= fS; o.w /= fS; }
@@ -135,22 +146,30 @@ static int launch_reduce_fwd(const float* src, int64_t lds, int64_t n_src, const
   dim3 grid((unsigned)ogl_cdiv(n_dst, WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
   const int d4 = (d + 3) / 4;
   const bool vec = (lds % 4 == 0) && (ldo % 4 == 0) && (lds >= 4 * d4) && (ldo >= 4 * d4) &&
-                   (((uintptr_t)src & 15) == 0) && (((uintptr_t)out & 15) == 0) && d4 <= 256;
+                   (((uintptr_t)src & 15) == 0) && (((uintptr_t)out & 15) == 0) && d4 <= 256 && n_src > 0;
+  // column slices per destination: two when one wave per destination would not even fill two rounds of the chip
+  // column slices per destination: the fewest (at most 4, at least 32 float4 columns each) that put two full rounds
+  // of waves on the chip.  Measured (MI355X): 7 054 x 604 floats, 25 rows each: 1 slice 0.0607 ms, 2 slices 0.0595 ms,
+  // 3 slices 0.0586 ms; 512 x 600: 1 slice 0.0168 ms, 2 slices 0.0148 ms, 4 slices 0.0137 ms.
+  int parts = 1;
+  while (vec && parts < 4 && n_dst * parts < 2 * 256 * 20 && d4 / (parts + 1) >= 32) ++parts;
+  const int cper = (d4 + parts - 1) / parts;
+  if (vec) grid.x = (unsigned)ogl_cdiv(n_dst * parts, WAVES_PER_BLOCK);
   if (!vec) {
     hipLaunchKernelGGL((k_reduce_fwd_generic<OP, IdxT, ARG>), grid, block, 0, stream, src, lds, n_src, idx,
                        n_dst, S, d, out, ldo, argmax);
-  } else if (d4 <= 64) {
+  } else if (cper <= 64) {
     hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 1>), grid, block, 0, stream, src, lds, n_src, idx,
-                       n_dst, S, d, out, ldo, argmax);
-  } else if (d4 <= 128) {
+                       n_dst, S, d, out, ldo, argmax, parts);
+  } else if (cper <= 128) {
     hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 2>), grid, block, 0, stream, src, lds, n_src, idx,
-                       n_dst, S, d, out, ldo, argmax);
-  } else if (d4 <= 192) {
+                       n_dst, S, d, out, ldo, argmax, parts);
+  } else if (cper <= 192) {
     hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 3>), grid, block, 0, stream, src, lds, n_src, idx,
-                       n_dst, S, d, out, ldo, argmax);
+                       n_dst, S, d, out, ldo, argmax, parts);
   } else {
     hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 4>), grid, block, 0, stream, src, lds, n_src, idx,
-                       n_dst, S, d, out, ldo, argmax);
+                       n_dst, S, d, out, ldo, argmax, parts);
   }
   OGL_CHECK_LAUNCH();
   return OGL_OK;
