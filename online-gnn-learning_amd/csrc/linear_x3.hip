@@ -626,33 +626,68 @@ __global__ void __launch_bounds__(256) k_x3_split(const float* __restrict__ src,
 // image of the TRANSPOSE: image row n, reduction index m, stored GROUP-MAJOR (the rows of one 32-deep reduction step are
 // contiguous: one tile of this kernel writes two 12 KB runs, and a GEMM stage reads one run):
 // image[m/32][n][plane][m%32] = split(src[row(m), n]), 64 x 64 tiles through LDS.  ones_row: image row N is 1.0 for m < M (bias gradient operand).  Pad m >= M is zero.
+template <bool ROWS, bool WIDE>
 __global__ void __launch_bounds__(256) k_x3_split_t(const float* __restrict__ src, int64_t ld, const int64_t* __restrict__ rows,
                                                     int64_t nrows_src, int64_t M, int N, int ones_row, int64_t G_il, int64_t Mi,
                                                     unsigned char* __restrict__ img, int64_t row_bytes) {
   __shared__ float tile[64][65];
+  const int nt = blockIdx.y;
   const int64_t m0 = (int64_t)blockIdx.x * 64;
-  const int n0 = blockIdx.y * 64;
+  const int n0 = nt * 64;
   const int tid = threadIdx.x, ty = tid >> 4, tx = (tid & 15) * 4;
   const int G = (int)(row_bytes / X3_GROUP_BYTES);
   const int64_t zero_row = (int64_t)N + (ones_row ? 1 : 0);
   const int64_t gstride = (zero_row + 1) * X3_GROUP_BYTES;       // GROUP-MAJOR image: [group][image row][192 B]
+  // The 4 row ids first, then the 4 row reads, nothing between the loads that waits: a missing row (padding, id out
+  // of range) reads row 0 and is zeroed afterwards; the last float4 of a row whose length is not a multiple of 4 is
+  // read 16 bytes back from the row's end and shifted.  (With a branch per row each of the 8 loads waited for the one
+  // before; measured gain of issuing them together: ~4 % of this kernel — it moves 380 MB in ~72 us for the
+  // 62 750 x 602 image, i.e. it was already near what HBM gives a gather + write mix.)
+  const bool have = !ROWS || nrows_src > 0;                       // any readable row at all (block-uniform)
+  const int col0 = n0 + tx;
+  constexpr bool wide = WIDE;                                     // N >= 4
+  const int cl = wide ? min(col0, N - 4) : 0, sh = col0 - cl;     // sh = 0: a whole float4; 1..3: a row tail; >= 4: past the row
+  bool okk[4];
+  int64_t rk[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int64_t ip = m0 + ty + 16 * k;                          // position in the image's reduction index
     const int64_t i = G_il ? (ip & 31) * G_il + (ip >> 5) : ip;   // the source row it stands for (round-robin dealing)
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ip < Mi && i < M) {
-      const int64_t row = rows ? rows[i] : i;
-      if (!rows || (row >= 0 && row < nrows_src)) {
-        const float* p = src + row * ld + n0 + tx;
-        if (n0 + tx + 3 < N) v = ld16(p);
-        else {
-          if (n0 + tx < N) v.x = p[0];
-          if (n0 + tx + 1 < N) v.y = p[1];
-          if (n0 + tx + 2 < N) v.z = p[2];
-        }
+    okk[k] = have && ip < Mi && i < M;
+    rk[k] = ROWS ? rows[okk[k] ? i : 0] : i;
+  }
+  float4 w[4];
+  const float* pk[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    okk[k] = okk[k] && (!ROWS || (rk[k] >= 0 && rk[k] < nrows_src));
+    pk[k] = src + (okk[k] ? rk[k] : 0) * ld;
+    w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (have) {
+    if (wide) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = ld16(pk[k] + cl);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (col0 < N) w[k].x = pk[k][col0];
+        if (col0 + 1 < N) w[k].y = pk[k][col0 + 1];
+        if (col0 + 2 < N) w[k].z = pk[k][col0 + 2];
       }
     }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float4 v = w[k];
+    if (wide && sh) {                                             // elements col0 .. col0 + 3 of which only those < N exist
+      const float4 t = v;
+      v.x = sh == 1 ? t.y : sh == 2 ? t.z : sh == 3 ? t.w : 0.f;
+      v.y = sh == 1 ? t.z : sh == 2 ? t.w : 0.f;
+      v.z = sh == 1 ? t.w : 0.f;
+      v.w = 0.f;
+    }
+    if (!okk[k]) v = make_float4(0.f, 0.f, 0.f, 0.f);
     tile[ty + 16 * k][tx] = v.x; tile[ty + 16 * k][tx + 1] = v.y; tile[ty + 16 * k][tx + 2] = v.z; tile[ty + 16 * k][tx + 3] = v.w;
   }
   __syncthreads();
@@ -673,12 +708,12 @@ __global__ void __launch_bounds__(256) k_x3_split_t(const float* __restrict__ sr
 #pragma unroll
     for (int sp = 0; sp < 3; ++sp) *(uint4*)(d + x3_piece(c, sp) * 16) = o[sp];
   }
-  if (blockIdx.y == 0 && tid >= 64 && tid < 64 + 24) {            // the zero row (last row of every group slab)
+  if (nt == 0 && tid >= 64 && tid < 64 + 24) {            // the zero row (last row of every group slab)
     const int t = tid - 64, gl = t / 12;
     const int64_t grp = m0 / 32 + gl;
     if (grp < G) *(uint4*)(img + grp * gstride + zero_row * X3_GROUP_BYTES + (t - gl * 12) * 16) = make_uint4(0, 0, 0, 0);
   }
-  if (ones_row && blockIdx.y == 0 && tid < 8) {   // 8 chunks of 8 m: row N of the image
+  if (ones_row && nt == 0 && tid < 8) {   // 8 chunks of 8 m: row N of the image
     const int c = tid & 3, gl = tid >> 2;
     const int64_t grp = m0 / 32 + gl;
     if (grp < G) {
@@ -727,8 +762,12 @@ extern "C" int ogl_x3_split_t(const float* src, int64_t ld, const int64_t* rows,
   const int64_t Mi = interleave ? 32 * interleave : M;            // reduction length of the image
   const int64_t row_bytes = ogl_cdiv(Mi, 32) * X3_GROUP_BYTES;
   dim3 grid((unsigned)ogl_cdiv(Mi, 64), (unsigned)(N > 0 ? ogl_cdiv(N, 64) : 1));
-  hipLaunchKernelGGL(k_x3_split_t, grid, dim3(256), 0, (hipStream_t)stream, src, ld, rows, nrows_src, M, N, ones_row, interleave, Mi,
-                     (unsigned char*)image, row_bytes);
+#define OGL_SPLIT_T(R, W)                                                                                                       \
+  hipLaunchKernelGGL((k_x3_split_t<R, W>), grid, dim3(256), 0, (hipStream_t)stream, src, ld, rows, nrows_src, M, N, ones_row,  \
+                     interleave, Mi, (unsigned char*)image, row_bytes)
+  if (rows) { if (N >= 4) OGL_SPLIT_T(true, true); else OGL_SPLIT_T(true, false); }
+  else { if (N >= 4) OGL_SPLIT_T(false, true); else OGL_SPLIT_T(false, false); }
+#undef OGL_SPLIT_T
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }
