@@ -178,6 +178,9 @@ def main():
     ops.profile_start()
     run(prof_steps, prof_plan)
     rec = ops.profile_stop()
+    if os.environ.get("OGL_BENCH_DUMP_CALLS") and rank == 0:        # every C-ABI call of the first profiled step, in order
+        for name, meta, ms in rec[:len(rec) // prof_steps]:
+            print("call %-28s %8.4f ms  %s" % (name, ms, meta), file=sys.stderr)
     agg = {}
     for name, meta, ms in rec:
         key = name

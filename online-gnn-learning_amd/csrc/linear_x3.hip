@@ -772,7 +772,7 @@ extern "C" int ogl_x3_split_t(const float* src, int64_t ld, const int64_t* rows,
   return OGL_OK;
 }
 
-// 0: 256 x 128 (4 x 2 waves of 64 x 64)   1: 128 x 128 (2 x 4 waves of 64 x 32)
+// 0: 256 x 128 (4 x 2 waves of 64 x 64)   1: 128 x 128 (2 x 4 waves of 64 x 32)   2 (launch_x3 only, one-round products): 192 x 128 (2 x 4 waves of 96 x 32)
 static int x3_config(int64_t M, int64_t N) {
   const int64_t w0 = ogl_cdiv(M, 256) * 256 * ogl_cdiv(N, 128) * 128;
   const int64_t w1 = ogl_cdiv(M, 128) * 128 * ogl_cdiv(N, 128) * 128;
@@ -794,13 +794,21 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
   // (row-major image: rows x row_bytes; group-major image: groups x step_bytes)
   const int64_t a_bytes = std::max((g.a.zero_row + 1) * g.a.row_bytes, (int64_t)g.nsteps * g.a.step_bytes);
   const int64_t b_bytes = std::max((g.b.zero_row + 1) * g.b.row_bytes, (int64_t)g.nsteps * g.b.step_bytes);
-  const int cfg = x3_config(g.M, g.N);
+  int cfg = x3_config(g.M, g.N);
   // producer / consumer kernels (k_gemm_x3p) whenever both images fit 32-bit offsets; OGL_X3_PC=0 forces the
   // self-fetching kernels (experiments)
   static const char* pc_env = getenv("OGL_X3_PC");
   const bool pc = !(pc_env && pc_env[0] == '0') && a_bytes < (1ll << 32) && b_bytes < (1ll << 32);
   if (pc) {
-    const int BMp = cfg == 0 ? 256 : 128;
+    // a product that is one round of tiles either way takes the smallest tile that still is one round (one block per
+    // CU): its critical path is one tile.  [7 199, 602] -> 600: 145 tiles of 256 x 128, 285 of 128 x 128, 190 of 192 x 128
+    // (measured 45 us on 256 x 128, 37 us on 192 x 128).
+    static const char* c2_env = getenv("OGL_X3_CFG2");
+    if (g.nsplit == 1 && !(c2_env && c2_env[0] == '0') && ogl_cdiv(g.M, 256) * ogl_cdiv(g.N, 128) <= 256) {
+      if (ogl_cdiv(g.M, 128) * ogl_cdiv(g.N, 128) <= 256) cfg = 1;
+      else if (ogl_cdiv(g.M, 192) * ogl_cdiv(g.N, 128) <= 256) cfg = 2;
+    }
+    const int BMp = cfg == 0 ? 256 : cfg == 2 ? 192 : 128;
     g.NI = (int)ogl_cdiv(g.M, BMp);
     g.NJ = (int)ogl_cdiv(g.N, 128);
     const int64_t T = (int64_t)g.NI * g.NJ * g.nsplit;
@@ -808,9 +816,11 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     // ring depth: two stages of the 256 x 128 tile fill the LDS (144 KB); the 128 x 128 tile takes three (144 KB): its movers
     // run two stages ahead (+4 % on the layer-0 weight gradient, whose operands both stream from HBM)
     if (cfg == 0) hipLaunchKernelGGL((k_gemm_x3p<4, 2, 2, 2, 2>), grid, block, 0, stream, g);
+    else if (cfg == 2) hipLaunchKernelGGL((k_gemm_x3p<2, 4, 3, 1, 2>), grid, block, 0, stream, g);
     else hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1, 3>), grid, block, 0, stream, g);
     OGL_CHECK_LAUNCH();
   } else {
+  if (cfg == 2) cfg = 1;
   const int BM = cfg == 0 ? 256 : 128, BN = 128;
   g.NI = (int)ogl_cdiv(g.M, BM);
   g.NJ = (int)ogl_cdiv(g.N, BN);

@@ -90,7 +90,8 @@ def test_transposed_image_bit_exact(ops, M, N, ones):
 
 @pytest.mark.parametrize("M,K,N,relu", [(1, 1, 1, False), (37, 33, 5, True), (255, 602, 41, False), (257, 64, 129, True),
                                          (1000, 602, 602, True), (3000, 1204, 256, False), (513, 31, 600, True),
-                                         (700, 32, 130, False), (2600, 608, 602, True)])
+                                         (700, 32, 130, False), (2600, 608, 602, True),
+                                         (7199, 602, 600, True), (6700, 96, 640, False)])   # the last two: 192 x 128 tiles
 def test_forward_matches_on_the_fly_x6_and_fp64(ops, M, K, N, relu):
     torch.manual_seed(M * 7 + K + N)
     T = M + 50
