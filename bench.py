@@ -272,6 +272,19 @@ def main():
 
     if rank == 0:
         value = args.steps * B * world / elapsed
+        hbm_copy = None
+        if world == 1:          # the box's own streaming figure beside the nominal peak: 1 GiB device copy
+            src_b = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()
+            dst_b = torch.empty_like(src_b)
+            dst_b.copy_(src_b); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                dst_b.copy_(src_b)
+            e1.record(); torch.cuda.synchronize()
+            hbm_copy = dict(gbs=round(10 * 2 * src_b.numel() * 4 / e0.elapsed_time(e1) / 1e6, 1),
+                            what="1 GiB fp32 device-to-device copy (read + write bytes), 10 repeats, same process")
+            del src_b, dst_b
         line = {
             "metric": "streamed vertices/sec (RBR train update), Reddit-shaped stream depth=2 samples=25",
             "value": round(value, 1), "unit": "vertices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -285,6 +298,7 @@ def main():
                        "avg_unique_input_nodes_n0": round(n0_avg, 1), "avg_n1": round(n1_avg, 1), "setup_s": round(setup_s, 1)},
             "roofline": roof_gemm if roof_gemm else roof_aggr,
             "roofline_aggregator": roof_aggr,
+            "hbm_copy_measured": hbm_copy,
             "cpu_baseline": cpu_baseline,
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in sorted(kernels.items())},
         }
