@@ -461,108 +461,96 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
 
 
 // ---- skinny forward GEMM: few rows x few columns x long K (the [B, 2H] -> C output projection) -------
-// One 32-row x (32*NT)-column output tile per block; the 4 waves split K (wave w takes 8-deep chunks
-// c = w mod 4), operands go global -> registers directly (16 B per lane: row l&31, k = k0 + 4*(l>>5) ..+3;
+// One 32-row x 32-column output tile per block; the SK_WAVES waves split K (wave w takes the 8-deep chunks
+// c = w mod SK_WAVES), operands go global -> registers directly (16 B per lane: row l&31, k = k0 + 4*(l>>5) ..+3;
 // MFMA step j uses component j of both operands, so half 0 supplies k0+j and half 1 supplies k0+4+j),
-// partial accumulators are summed through LDS.  Launch-latency bound shapes only.
-template <int NT>
-__global__ void __launch_bounds__(256) k_gemm_skinny(GemmArgs g) {
-  __shared__ float red[4][NT][16][64];
+// partial accumulators are summed through LDS.  Launch-latency bound shapes only: few blocks, long K — the kernel is
+// a serial chain of global round trips followed by exact-fp32 MFMAs on a handful of CUs, so what it costs is the
+// NUMBER of rounds and the MFMAs per block.  A round is up to SK_U chunks per wave OF EACH INPUT with every load
+// issued before the first MFMA and nothing between the loads that waits (a chunk past the end reads chunk 0 and is
+// zeroed): [512, 600 + 600] -> 41 is ONE round on 16 x 2 blocks (4 waves x 4 chunks on 16 blocks of 64 columns took
+// ten rounds and twice the MFMAs per block: 26 us).
+#define SK_WAVES 8
+#define SK_U 10
+template <int NPARTS>
+__global__ void __launch_bounds__(64 * SK_WAVES) k_gemm_skinny(GemmArgs g) {
+  __shared__ float red[SK_WAVES][16][64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int64_t i0 = (int64_t)blockIdx.x * 32;
-  const int64_t j0 = (int64_t)blockIdx.y * 32 * NT;
-  f32x16 acc[NT];
+  const int64_t j0 = (int64_t)blockIdx.y * 32;
+  f32x16 acc;
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int64_t i = i0 + l31, j = j0 + l31;
+  const bool bok = j < g.N;
+  const float* ap[NPARTS];
+  const float* bp[NPARTS];
+  bool aok[NPARTS];
+  int64_t nfull[NPARTS], most = 0;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-  for (int pi = 0; pi < g.nparts; ++pi) {
-    const GemmPart& pt = g.part[pi];
-    const int64_t R = pt.R;
-    const int64_t i = i0 + l31;
-    bool aok = i < g.M;
+  for (int p = 0; p < NPARTS; ++p) {
+    const GemmPart& pt = g.part[p];
+    aok[p] = i < g.M;
     int64_t arow = i;
-    if (pt.a.rows) { arow = aok ? pt.a.rows[i] : 0; aok = aok && arow >= 0 && arow < pt.a.nrows; }
-    const float* ap = pt.a.ptr + (aok ? arow : 0) * pt.a.ld;
-    const float* bp[NT];
-    bool bok[NT];
+    if (pt.a.rows) { arow = aok[p] ? pt.a.rows[i] : 0; aok[p] = aok[p] && arow >= 0 && arow < pt.a.nrows; }
+    ap[p] = pt.a.ptr + (aok[p] ? arow : 0) * pt.a.ld;
+    bp[p] = pt.b.ptr + (bok ? j : 0) * pt.b.ld;
+    nfull[p] = pt.R / 8;                                   // whole 8-deep chunks
+    most = nfull[p] > most ? nfull[p] : most;
+  }
+  for (int64_t c = wid; c < most; c += SK_WAVES * SK_U) {
+    float4 a4[NPARTS][SK_U], b4[NPARTS][SK_U];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int64_t j = j0 + t * 32 + l31;
-      bok[t] = j < g.N;
-      bp[t] = pt.b.ptr + (bok[t] ? j : 0) * pt.b.ld;
-    }
-    const int64_t nchunk = (R + 7) / 8;
-    // four whole chunks per round, all their loads issued before the first MFMA: this kernel is a serial chain of
-    // global round trips (few blocks, long K), so the number of rounds is what it costs
-    const int64_t nfull = R / 8;
-    int64_t c = wid;
-    for (; c + 12 < nfull; c += 16) {
-      float4 a4[4], b4[4][NT];
+    for (int p = 0; p < NPARTS; ++p)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int64_t k = (c + 4 * u) * 8 + 4 * half;
-        a4[u] = ld16(ap + k);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) b4[u][t] = ld16(bp[t] + k);
+      for (int u = 0; u < SK_U; ++u) {
+        const int64_t cu = c + SK_WAVES * u;
+        const int64_t k = (cu < nfull[p] ? cu : 0) * 8 + 4 * half;
+        a4[p][u] = ld16(ap[p] + k);
+        b4[p][u] = ld16(bp[p] + k);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float4 a = aok ? a4[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < NPARTS; ++p)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const float4 b = bok[t] ? b4[u][t] : make_float4(0.f, 0.f, 0.f, 0.f);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
-        }
+      for (int u = 0; u < SK_U; ++u) {
+        const bool live = c + SK_WAVES * u < nfull[p];     // wave-uniform
+        const float4 a = (aok[p] && live) ? a4[p][u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 b = bok ? b4[p][u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
       }
-    }
-    for (; c < nchunk; c += 4) {
-      const int64_t k = c * 8 + 4 * half;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b[NT];
-      const bool full = k + 3 < R;
-      if (full) {
-        a = ld16(ap + k);
+  }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) b[t] = ld16(bp[t] + k);
-      } else {
-        float ea[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < NPARTS; ++p) {
+    const int64_t R = g.part[p].R;
+    if ((R & 7) && wid == (int)(nfull[p] % SK_WAVES)) {   // the ragged last chunk: element-wise, one wave
+      const int64_t k = nfull[p] * 8 + 4 * half;
+      float ea[4] = {0.f, 0.f, 0.f, 0.f}, eb[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) if (k + q < R) ea[q] = ap[k + q];
-        a = make_float4(ea[0], ea[1], ea[2], ea[3]);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          float eb[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) if (k + q < R) eb[q] = bp[t][k + q];
-          b[t] = make_float4(eb[0], eb[1], eb[2], eb[3]);
-        }
+      for (int q = 0; q < 4; ++q) {
+        if (aok[p] && k + q < R) ea[q] = ap[p][k + q];
+        if (bok && k + q < R) eb[q] = bp[p][k + q];
       }
-      if (!aok) a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        if (!bok[t]) b[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
-      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ea[0], eb[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ea[1], eb[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ea[2], eb[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ea[3], eb[3], acc, 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) red[wid][t][e][lane] = acc[t][e];
+  for (int e = 0; e < 16; ++e) red[wid][e][lane] = acc[e];
   __syncthreads();
-  // 256 threads sum the 4 partials: NT*16*64 values
-  for (int v = tid; v < NT * 16 * 64; v += 256) {
-    const int t = v / (16 * 64), e = (v / 64) % 16, ln = v % 64;
-    float sum = red[0][t][e][ln] + red[1][t][e][ln] + red[2][t][e][ln] + red[3][t][e][ln];
+  // the block's threads sum the SK_WAVES partials (fixed order): 16*64 values
+  for (int v = tid; v < 16 * 64; v += 64 * SK_WAVES) {
+    const int e = v / 64, ln = v % 64;
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < SK_WAVES; ++w) sum += red[w][e][ln];
     const int64_t row = i0 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
-    const int64_t col = j0 + t * 32 + (ln & 31);
+    const int64_t col = j0 + (ln & 31);
     if (row < g.M && col < g.N) {
       if (g.bias) sum += g.bias[col];
       if (g.relu) sum = fmaxf(sum, 0.f);
@@ -714,9 +702,9 @@ extern "C" int ogl_linear_fwd(const float* x, int64_t ldx, const int64_t* x_rows
   // few output tiles and a long reduction: in-block split-K straight from global memory
   const int64_t Ktot = (int64_t)K + K2;
   if (N <= 64 && M <= 4096 && Ktot >= 256 && K > 0 && (K2 == 0 || g.nparts == 2)) {
-    dim3 grid((unsigned)ogl_cdiv(M, 32), (unsigned)ogl_cdiv(N, 64));
-    if (N <= 32) { grid.y = 1; hipLaunchKernelGGL(k_gemm_skinny<1>, grid, dim3(256), 0, (hipStream_t)stream, g); }
-    else hipLaunchKernelGGL(k_gemm_skinny<2>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    dim3 grid((unsigned)ogl_cdiv(M, 32), (unsigned)ogl_cdiv(N, 32));
+    if (g.nparts == 1) hipLaunchKernelGGL(k_gemm_skinny<1>, grid, dim3(64 * SK_WAVES), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(k_gemm_skinny<2>, grid, dim3(64 * SK_WAVES), 0, (hipStream_t)stream, g);
     OGL_CHECK_LAUNCH();
     return OGL_OK;
   }
@@ -752,7 +740,10 @@ static void bwd_weight_plan(int64_t M, int N, int K, int* nsplit, int* tps, int*
   int64_t s = 768 / (tiles > 0 ? tiles : 1);
   if (s < 1) s = 1;
   if (s > nk) s = nk;
-  if (nk / s < 8) s = nk / 8 > 0 ? nk / 8 : 1;
+  // k-steps per block: >= 8 amortise a block's prologue / epilogue; the few-row output layer ([C, H] from 512 rows:
+  // 10 tiles) is latency-bound instead — 16 splits of 2 steps measured 16.9 us against 20.9 us for 4 splits of 8
+  const int min_steps = N <= 64 ? 2 : 8;
+  if (nk / s < min_steps) s = nk / min_steps > 0 ? nk / min_steps : 1;
   *tps = (int)ogl_cdiv(nk, s);
   *nsplit = (int)ogl_cdiv(nk, *tps);
   if (*nsplit < 1) *nsplit = 1;
