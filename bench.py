@@ -171,6 +171,25 @@ def main():
         elapsed = float(tt.item())
     n0_avg, n1_avg = float(np.mean(stats["n0"])), float(np.mean(stats["n1"]))
 
+    # ---- host side: time to ENQUEUE a step (no synchronisation inside the bracket): the margin between this and
+    # ms_per_step is how far the step is from being launch-bound on this box's host cores
+    hsteps = min(args.steps, bt)
+    hplan = plan(hsteps)
+    barrier()
+    th = time.perf_counter()
+    run(hsteps, hplan)
+    host_ms = 1000 * (time.perf_counter() - th) / hsteps
+    barrier()
+    if os.environ.get("OGL_BENCH_CPROFILE") and rank == 0:          # where the host time of a step goes (stderr)
+        import cProfile, pstats
+        torch.autograd.set_multithreading_enabled(False)            # backward in this thread, so that it is seen
+        pr = cProfile.Profile()
+        hplan = plan(hsteps)
+        pr.enable(); run(hsteps, hplan); pr.disable()
+        torch.autograd.set_multithreading_enabled(True)
+        barrier()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(45)
+
     # ---- per-kernel HIP-event timing (same workload, separate instrumented pass) -----------------
     prof_steps = min(args.steps, bt)
     prof_plan = plan(prof_steps)
@@ -299,6 +318,7 @@ def main():
             "roofline": roof_gemm if roof_gemm else roof_aggr,
             "roofline_aggregator": roof_aggr,
             "hbm_copy_measured": hbm_copy,
+            "host_enqueue_ms_per_step": round(host_ms, 4),
             "cpu_baseline": cpu_baseline,
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in sorted(kernels.items())},
         }

@@ -15,7 +15,9 @@ from ._lib import REDUCE_OPS, check
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # torch's current HIP stream of the current device, through the raw getters: torch.cuda.current_stream() builds a
+    # Stream object and re-checks lazy initialisation — ~10 us of host time per call, ~30 calls per train step
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 # Optional per-call HIP-event timing (bench.py's roofline leg).  Events are recorded on the stream the
