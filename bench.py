@@ -137,7 +137,7 @@ def main():
                 labels = ops.gather_i64(g.ndata["target"], sd)
                 logits = model(blocks, GatheredRows(g.ndata["feat"], input_nodes))
                 loss = ops.cross_entropy(logits, labels, "mean")
-                loss.backward()
+                ops.backward(loss)
                 if gsync is not None:
                     gsync.sync()
                 opt.step()

@@ -749,6 +749,81 @@ static void bwd_weight_plan(int64_t M, int N, int K, int* nsplit, int* tps, int*
   if (*nsplit < 1) *nsplit = 1;
 }
 
+// ---- weight gradient of a FEW-COLUMN projection (the [H, C] output layer: N = C <= 64 output rows of dw) -------------
+// [dw | db][n, k] = sum_m dy[m, n] * [x | 1][row(m), k] with N <= 64 and a short reduction (M = batch size).  The tiled
+// kernel needs split-K plus a reduce launch for 10 output tiles (8.7 + 7 us at M = 512, K = 600, N = 41); here one block
+// owns 8 columns k of [dw | db] for ALL n: thread (mg, kk) runs over the rows m = mg, mg + 64, ... with one x value and
+// the whole dy row (float4s, N accumulators in registers) per row, plain fp32 FMAs; the 64 row groups are summed
+// through LDS in a fixed order.  One launch (~10 us), no workspace, deterministic.
+#define BWS_KT 8
+#define BWS_MG 64
+template <int NV>                                                // float4s per dy row held in registers: N <= 4 * NV
+__global__ void __launch_bounds__(BWS_KT * BWS_MG) k_bwd_weight_skinny(const float* __restrict__ dy, int64_t ldy,
+                                                                       const float* __restrict__ x, int64_t ldx,
+                                                                       const int64_t* __restrict__ x_rows, int64_t x_nrows,
+                                                                       int64_t M, int N, int K, float* __restrict__ dw,
+                                                                       int64_t lddw, float* __restrict__ db) {
+  __shared__ float red[BWS_MG][16][BWS_KT + 1];
+  const int tid = threadIdx.x, kk = tid & (BWS_KT - 1), mg = tid / BWS_KT;
+  const int64_t k = (int64_t)blockIdx.x * BWS_KT + kk;            // column of [dw | db]; k == K is the ones column
+  const bool kx = k < K, kone = (k == K);
+  const int nvr = (N + 3) / 4;                                    // float4s a dy row really has
+  float4 acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // rows m = mg, mg + 64, ...: two rows per trip, every load of the trip issued before the first FMA (a row past M
+  // re-reads row mg and is weighted by 0)
+  for (int64_t m0 = mg; m0 < M; m0 += 2 * BWS_MG) {
+    float xv[2];
+    float4 d4[2][NV];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t m = m0 + u * BWS_MG;
+      const bool live = m < M;
+      const int64_t mm = live ? m : mg;
+      int64_t r = mm;
+      bool ok = live;
+      if (x_rows) { r = x_rows[mm]; ok = ok && r >= 0 && r < x_nrows; }
+      const float xr = x[(ok ? r : 0) * ldx + (kx ? k : 0)];
+      xv[u] = kone ? (live ? 1.f : 0.f) : ((kx && ok) ? xr : 0.f);
+      const float4* dr = (const float4*)(dy + mm * ldy);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) d4[u][i] = dr[i < nvr ? i : 0];   // float4s past the row's end are never read
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        acc[i].x += d4[u][i].x * xv[u]; acc[i].y += d4[u][i].y * xv[u];
+        acc[i].z += d4[u][i].z * xv[u]; acc[i].w += d4[u][i].w * xv[u];
+      }
+  }
+  // the row groups' partials, 16 output rows n at a time, summed in a fixed order
+#pragma unroll
+  for (int c4 = 0; c4 < NV; c4 += 4) {
+    __syncthreads();                                             // the previous chunk's partials are consumed
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (c4 + i < NV) {
+        red[mg][4 * i + 0][kk] = acc[c4 + i].x; red[mg][4 * i + 1][kk] = acc[c4 + i].y;
+        red[mg][4 * i + 2][kk] = acc[c4 + i].z; red[mg][4 * i + 3][kk] = acc[c4 + i].w;
+      }
+    __syncthreads();
+    if (tid < 16 * BWS_KT) {                                      // thread = (n local, kk)
+      const int i = tid / BWS_KT, c = tid & (BWS_KT - 1);
+      float sum = 0.f;
+#pragma unroll
+      for (int g = 0; g < BWS_MG; ++g) sum += red[g][i][c];
+      const int n = 4 * c4 + i;
+      const int64_t kc = (int64_t)blockIdx.x * BWS_KT + c;
+      if (n < N && n < 4 * NV) {
+        if (kc < K) dw[n * lddw + kc] = sum;
+        else if (kc == K && db) db[n] = sum;
+      }
+    }
+  }
+}
+
 extern "C" int64_t ogl_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K) {
   if (M < 0 || N < 0 || K < 0) return OGL_EINVAL;
   int nsplit, tps, cfg;
@@ -764,6 +839,18 @@ extern "C" int ogl_linear_bwd_weight(const float* dy, int64_t ldy,
   if (M < 0 || N < 0 || K < 0 || ldy < N || ldx < K || lddw < K) return OGL_EINVAL;
   if (N == 0) return OGL_OK;
   if (!dw || (M > 0 && (!dy || (K > 0 && !x)))) return OGL_EINVAL;
+  // the output layer: one launch, no split-K (dy rows are read as float4s: 16-B aligned rows padded to a multiple of 4)
+  if (N <= 64 && M > 0 && M <= 4096 && K >= 64 && x && ldy % 4 == 0 && ldy >= (N + 3) / 4 * 4 && ((uintptr_t)dy & 15) == 0) {
+    dim3 grid((unsigned)ogl_cdiv((int64_t)K + 1, BWS_KT)), block(BWS_KT * BWS_MG);
+    const int nv = (N + 3) / 4;
+#define OGL_BWS(NV_)                                                                                                   \
+    hipLaunchKernelGGL(k_bwd_weight_skinny<NV_>, grid, block, 0, (hipStream_t)stream, dy, ldy, x, ldx, x_rows, x_nrows, M, N, K, \
+                       dw, lddw, db)
+    if (nv <= 4) OGL_BWS(4); else if (nv <= 8) OGL_BWS(8); else if (nv <= 12) OGL_BWS(12); else OGL_BWS(16);
+#undef OGL_BWS
+    OGL_CHECK_LAUNCH();
+    return OGL_OK;
+  }
   GemmArgs g; zero_args(g);
   // [dw | db][n, k] = sum_m dy[m,n] * [x | 1][m,k]: A = dy (NC: A(i=n, r=m) = dy[m*ldy + n]),
   // B = x (NC: B(r=m, j=k) = x[row(m)*ldx + k]) with a synthetic ones column at j = K.

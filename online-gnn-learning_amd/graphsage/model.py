@@ -254,7 +254,7 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
             scores = self.graphsage_model(blocks, batch_inputs)
             loss = self.xent(scores, batch_labels)
-            loss.backward()
+            ops.backward(loss)
             self.optimizer.step()
             return loss
         # rank-sharded batch: this rank's seeds only; the gradient is that of the mean over the whole batch
@@ -330,7 +330,7 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
                 scores = self.graphsage_model(blocks, batch_inputs)
                 unaggregated_loss = self.xent(scores, batch_labels)
                 loss = torch.mean(unaggregated_loss)
-                loss.backward()
+                ops.backward(loss)
                 self.optimizer.step()
             else:
                 unaggregated_loss = None

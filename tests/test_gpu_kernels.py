@@ -251,9 +251,10 @@ def test_linear_bwd(ops, gemm_mode, M, K, N, relu):
     np.testing.assert_allclose(bc.grad.cpu().numpy(), want_b.numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL * scale)
 
 
-def test_linear_bwd_weight_rows(ops, gemm_mode):
+@pytest.mark.parametrize("T,M,K,N", [(5000, 3000, 602, 602), (900, 700, 300, 41), (600, 512, 601, 3), (100, 33, 64, 64)])
+def test_linear_bwd_weight_rows(ops, gemm_mode, T, M, K, N):
+    """(the last three: the one-launch few-column kernel of the output layer, gathered rows)"""
     torch.manual_seed(4)
-    T, M, K, N = 5000, 3000, 602, 602
     tab = torch.randn(T, K); rows = torch.randint(0, T, (M,)); dy = torch.randn(M, N)
     want_w = dy.T @ tab[rows]; want_b = dy.sum(0)
     tabm = ops.empty_mat(T, K, "cuda").copy_(tab)
