@@ -235,7 +235,8 @@ extern "C" int ogl_pool_bwd_x3(const float* dout, int64_t ldo, const int32_t* ar
   unsigned short* off = (unsigned short*)((unsigned char*)workspace + pb_bitmap_bytes(n_dst, n_src));
   uint2* ent = (uint2*)((unsigned char*)off + pb_off_bytes(n_dst, fanout));
   const int64_t gstride = ((int64_t)d + 1) * 192;                 // GROUP-MAJOR image: [group][d rows + zero row][192 B]
-  OGL_CHECK_HIP(hipMemsetAsync(bitmap, 0, (size_t)(groups * words * 4 + 16), st));
+  // the whole 256-B-rounded region: a size that is not a multiple of the runtime's fill width costs two extra launches
+  OGL_CHECK_HIP(hipMemsetAsync(bitmap, 0, (size_t)pb_bitmap_bytes(n_dst, n_src), st));
   const PbDiv dv = pb_make_div((unsigned)groups);
   if (n_dst > 0 && fanout > 0) {
     hipLaunchKernelGGL(k_pool_bucket, dim3((unsigned)ogl_cdiv(n_dst, 4)), dim3(256), 0, st, dout, ldo, argmax, relu_out, ldr, idx32,
