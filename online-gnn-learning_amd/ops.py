@@ -17,7 +17,7 @@ from ._lib import REDUCE_OPS, check
 def _stream():
     # torch's current HIP stream of the current device, through the raw getters: torch.cuda.current_stream() builds a
     # Stream object and re-checks lazy initialisation — ~10 us of host time per call, ~30 calls per train step
-    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())   # plain int: the argtypes convert it
 
 
 # Optional per-call HIP-event timing (bench.py's roofline leg).  Events are recorded on the stream the
@@ -51,7 +51,7 @@ def _launch(name, fn, *args, meta=None):
 
 
 def _ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    return t.data_ptr() if t is not None else None      # plain int / None: the argtypes (c_void_p) convert them
 
 
 GEMM_MODES = {"f32": 0, "bf16x6": 1, "auto": 2}
