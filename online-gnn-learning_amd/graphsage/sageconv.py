@@ -110,6 +110,12 @@ class SAGEConv(nn.Module):
 
         if (t == "pool" and not lazy and self.norm is None and (self.activation is None or fuse_relu)
                 and (self.fc_self.bias is None) == (self.fc_neigh.bias is None) and idx.dtype == torch.int32):
+            if not torch.is_grad_enabled():
+                # inference: the same three launches without the autograd node, the summed bias from the cache
+                p = ops.linear_fwd(feat, self.fc_pool.weight, self.fc_pool.bias, relu=True)
+                neigh, _ = ops.reduce_fwd(p, idx, "max", want_argmax=False)
+                return ops.linear_fwd(feat[:n_dst], self.fc_self.weight, self._summed_bias(), x2=neigh, w2=self.fc_neigh.weight,
+                                      relu=fuse_relu)
             # input with a gradient (every layer but the first): the whole layer is one autograd node
             return ops.sage_pool_layer(feat, self.fc_pool.weight, self.fc_pool.bias, self.fc_self.weight, self.fc_neigh.weight,
                                        self.fc_self.bias, self.fc_neigh.bias, idx, n_dst, fuse_relu)
@@ -158,7 +164,7 @@ class SAGEConv(nn.Module):
         h_neigh, _ = ops.reduce_fwd(feat.proj, graph.picks, "mean" if t == "meanpool" else "max")
         dst_rows = graph.dst_ids
         if t == "pool":
-            bias = self.fc_self.bias + self.fc_neigh.bias if self.fc_self.bias is not None else None
+            bias = self._summed_bias()
             rst = ops.linear_fwd(feat.table, self.fc_self.weight, bias, x2=h_neigh, w2=self.fc_neigh.weight, relu=fuse_relu,
                                  x_rows=dst_rows)
         else:
@@ -170,6 +176,20 @@ class SAGEConv(nn.Module):
         if self.norm is not None:
             rst = self.norm(rst)
         return rst
+
+    def _summed_bias(self):
+        """b_self + b_neigh for the inference paths, kept until either bias is written again (tensor version counters):
+        a priority forward runs hundreds of batches on one weight version, and the add is a launch per layer per batch."""
+        bs, bn = self.fc_self.bias, self.fc_neigh.bias
+        if bs is None:
+            return None
+        key = (bs._version, bn._version, bs.data_ptr(), bn.data_ptr())
+        hit = getattr(self, "_bias_sum_cache", None)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, bs + bn)
+            self._bias_sum_cache = hit
+        return hit[1]
 
     def project_table(self, table):
         """relu(fc_pool(table)) for every row — the per-weight-version cache consumed by _forward_cached."""
