@@ -701,7 +701,8 @@ extern "C" int ogl_linear_fwd(const float* x, int64_t ldx, const int64_t* x_rows
   g.M = M; g.N = N; g.C = y; g.ldc = ldy; g.bias = bias; g.relu = relu;
   // few output tiles and a long reduction: in-block split-K straight from global memory
   const int64_t Ktot = (int64_t)K + K2;
-  if (N <= 64 && M <= 4096 && Ktot >= 256 && K > 0 && (K2 == 0 || g.nparts == 2)) {
+  // (every input at least one whole 8-deep chunk: a chunk past an input's end re-reads its chunk 0)
+  if (N <= 64 && M <= 4096 && Ktot >= 256 && K >= 8 && (K2 == 0 || (g.nparts == 2 && K2 >= 8))) {
     dim3 grid((unsigned)ogl_cdiv(M, 32), (unsigned)ogl_cdiv(N, 32));
     if (g.nparts == 1) hipLaunchKernelGGL(k_gemm_skinny<1>, grid, dim3(64 * SK_WAVES), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(k_gemm_skinny<2>, grid, dim3(64 * SK_WAVES), 0, (hipStream_t)stream, g);
@@ -840,7 +841,7 @@ extern "C" int ogl_linear_bwd_weight(const float* dy, int64_t ldy,
   if (N == 0) return OGL_OK;
   if (!dw || (M > 0 && (!dy || (K > 0 && !x)))) return OGL_EINVAL;
   // the output layer: one launch, no split-K (dy rows are read as float4s: 16-B aligned rows padded to a multiple of 4)
-  if (N <= 64 && M > 0 && M <= 4096 && K >= 64 && x && ldy % 4 == 0 && ldy >= (N + 3) / 4 * 4 && ((uintptr_t)dy & 15) == 0) {
+  if (N <= 64 && M > 0 && M <= 4096 && K >= 64 && x && (!x_rows || x_nrows > 0) && ldy % 4 == 0 && ldy >= (N + 3) / 4 * 4 && ((uintptr_t)dy & 15) == 0) {
     dim3 grid((unsigned)ogl_cdiv((int64_t)K + 1, BWS_KT)), block(BWS_KT * BWS_MG);
     const int nv = (N + 3) / 4;
 #define OGL_BWS(NV_)                                                                                                   \

@@ -213,7 +213,8 @@ def test_linear_fwd_dual_and_rows(ops, gemm_mode):
 
 
 @pytest.mark.parametrize("M,K,K2,N,relu", [(512, 600, 600, 41, False), (33, 300, 7, 3, True), (4096, 258, 0, 64, True),
-                                             (100, 1001, 0, 33, False)])
+                                             (100, 1001, 0, 33, False), (512, 602, 13, 41, False), (64, 1500, 900, 41, True),
+                                             (2000, 8, 600, 17, False)])
 def test_linear_fwd_skinny(ops, M, K, K2, N, relu):
     """Few output tiles x long K: the in-block split-K kernel (final [B, 2H] -> C projection)."""
     torch.manual_seed(M + K)
