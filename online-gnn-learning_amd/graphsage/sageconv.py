@@ -121,10 +121,8 @@ class SAGEConv(nn.Module):
                                        self.fc_self.bias, self.fc_neigh.bias, idx, n_dst, fuse_relu)
         if t == "pool":
             h_neigh = self._pool_max(feat, idx)
-            bias = None
-            if self.fc_self.bias is not None:
-                bias = self.fc_self.bias + self.fc_neigh.bias
-            rst = self._linear2(feat_dst, self.fc_self.weight, h_neigh, self.fc_neigh.weight, bias, fuse_relu)
+            rst = self._linear2(feat_dst, self.fc_self.weight, h_neigh, self.fc_neigh.weight, self.fc_self.bias, fuse_relu,
+                                bias2=self.fc_neigh.bias if self.fc_self.bias is not None else None)
         elif t in ("meanpool", "maxpool"):
             if t == "maxpool":
                 h_neigh = self._pool_max(feat, idx)
@@ -203,7 +201,7 @@ class SAGEConv(nn.Module):
         return ops.pool_max(feat, self.fc_pool.weight, self.fc_pool.bias, idx, None)
 
     @staticmethod
-    def _linear2(x1, w1, x2, w2, bias, relu):
+    def _linear2(x1, w1, x2, w2, bias, relu, bias2=None):
         if isinstance(x1, GatheredRows):
-            return ops.linear(x1.table, w1, bias, x2, w2, relu, x1.ids, None)
-        return ops.linear(x1, w1, bias, x2, w2, relu, None, None)
+            return ops.linear(x1.table, w1, bias, x2, w2, relu, x1.ids, None, bias2)
+        return ops.linear(x1, w1, bias, x2, w2, relu, None, None, bias2)

@@ -563,7 +563,13 @@ def adam_step_multi(ps, gs, ms, vs, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1
 # --------------------------------------------------------------------------------------------
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, x2, w2, relu, x_rows, x2_rows):
+    def forward(ctx, x, w, bias, x2, w2, relu, x_rows, x2_rows, bias2=None):
+        # bias2: the second projection's own bias (a layer with fc_self.bias and fc_neigh.bias): summed here, and each
+        # gets its gradient from its own weight-gradient product in backward (their ones columns are free) — a tracked
+        # `bias + bias2` outside would hand ONE gradient tensor to two parameters, which autograd clones (a launch)
+        ctx.has_bias2 = bias2 is not None
+        if bias2 is not None:
+            bias = bias + bias2
         y = linear_fwd(x, w, bias, x2, w2, relu, x_rows, x2_rows)
         ctx.relu = bool(relu)
         ctx.has_bias = bias is not None
@@ -578,7 +584,7 @@ class _LinearFn(torch.autograd.Function):
             dy = relu_bwd(dy, y)        # once; the (up to four) backward GEMMs below are mask-free
             y = None
         need = ctx.needs_input_grad
-        dx = dw = db = dx2 = dw2 = None
+        dx = dw = db = dx2 = dw2 = db2 = None
         if need[0]:
             if x_rows is not None:
                 raise RuntimeError("gradient w.r.t. a row-gathered table is not supported (features carry no grad)")
@@ -593,14 +599,16 @@ class _LinearFn(torch.autograd.Function):
                 if x2_rows is not None:
                     raise RuntimeError("gradient w.r.t. a row-gathered table is not supported")
                 dx2 = linear_bwd_input(dy, w2, y)
-            if need[4]:
-                dw2, _ = weight_grad(dy, x2, x2_rows, want_bias=False, dyT=dyT)
-        return dx, dw, (db if ctx.has_bias else None), dx2, dw2, None, None, None
+            if need[4] or ctx.has_bias2:
+                dw2, db2 = weight_grad(dy, x2, x2_rows, want_bias=ctx.has_bias2, dyT=dyT)
+        return dx, dw, (db if ctx.has_bias else None), dx2, dw2, None, None, None, (db2 if ctx.has_bias2 else None)
 
 
-def linear(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_rows=None):
-    """y = act(x[rows] @ w.T (+ x2[rows2] @ w2.T) + bias), differentiable."""
-    return _LinearFn.apply(x, w, bias, x2, w2, relu, x_rows, x2_rows)
+def linear(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_rows=None, bias2=None):
+    """y = act(x[rows] @ w.T (+ x2[rows2] @ w2.T) + bias (+ bias2)), differentiable."""
+    if bias2 is not None and (bias is None or x2 is None):
+        raise ValueError("bias2 belongs to the second projection of a dual-input Linear that has a first bias")
+    return _LinearFn.apply(x, w, bias, x2, w2, relu, x_rows, x2_rows, bias2)
 
 
 class _ReduceFn(torch.autograd.Function):
@@ -692,7 +700,9 @@ class _SagePoolLayerFn(torch.autograd.Function):
         h_dst = h[:n_dst]
         dyT = transposed_operand(dy) if (_MODE["name"] != "f32" and dy.shape[0] >= 1024) else None
         dw_self, db = weight_grad(dy, h_dst, None, want_bias=ctx.has_bias, dyT=dyT)
-        dw_neigh, _ = weight_grad(dy, neigh, None, want_bias=False, dyT=dyT)
+        # the bias gradient once more from the second product (its ones column is free): two tensors for the two biases —
+        # one tensor returned for both makes autograd clone it (a launch)
+        dw_neigh, db2 = weight_grad(dy, neigh, None, want_bias=ctx.has_bias, dyT=dyT)
         dneigh = linear_bwd_input(dy, w_neigh, None)
         dp = reduce_bwd(dneigh, None, argmax, "max", n_src, fanout=ctx.fanout, relu_out=neigh)
         dh = linear_bwd_input(dp, w_pool, None)
@@ -700,7 +710,7 @@ class _SagePoolLayerFn(torch.autograd.Function):
         dx_self = linear_bwd_input(dy, w_self, None)
         dh[:n_dst].add_(dx_self)                                  # the fc_self path, in place on the first n_dst rows
         return (dh, dw_pool, db_pool if ctx.has_pool_bias else None, dw_self, dw_neigh, db if ctx.has_bias else None,
-                db if ctx.has_bias else None, None, None, None)
+                db2 if ctx.has_bias else None, None, None, None)
 
 
 def sage_pool_layer(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu):
