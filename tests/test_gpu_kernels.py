@@ -132,6 +132,24 @@ def test_reduce_fwd_bit_exact(ops, n_src, n_dst, fanout, d, op):
     assert np.array_equal(got64.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("n_dst,d", [(7054, 602), (5200, 600), (10300, 602), (512, 600), (2000, 260)])
+def test_reduce_fwd_column_slices_bit_exact(ops, n_dst, d):
+    """BASELINE-size destinations: the kernel cuts them into 1-4 column slices (one wave each) by batch size; values and
+    argmax stay bit-exact whatever the cut."""
+    rng = np.random.default_rng(n_dst + d)
+    n_src, fanout = 20000, 25
+    src = rng.standard_normal((n_src, d)).astype(np.float32)
+    li = rng.integers(0, n_src, size=(n_dst, fanout)).astype(np.int32)
+    li[rng.random(n_dst) < 0.05] = -1
+    padded = ops.empty_mat(n_src, d, "cuda").copy_(torch.as_tensor(src))
+    for op in ("max", "mean"):
+        want, arg = O.reduce_fwd(src, li, op)
+        got, garg = ops.reduce_fwd(padded, dev(li), op, want_argmax=(op == "max"))
+        assert np.array_equal(got.cpu().numpy(), want), op
+        if op == "max":
+            assert np.array_equal(garg.cpu().numpy(), arg)
+
+
 @pytest.mark.parametrize("op", ["max", "mean", "sum"])
 def test_reduce_bwd(ops, op):
     rng = np.random.default_rng(8)
