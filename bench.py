@@ -26,6 +26,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
+PMC_TRAFFIC_FILE = "r01_pmc_traffic.json"   # the committed rocprofv3 --pmc pass `roofline.traffic` is quoted from
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 MFMA_F32_PEAK_TFLOPS = 157.3
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense (MI355X_MICROARCH.md); AMD's 5 PF headline includes 2:1 sparsity
@@ -56,7 +57,13 @@ def parse():
     ap.add_argument("--gemm", default="auto", choices=["f32", "bf16x6", "auto"],
                     help="projection arithmetic: exact fp32 MFMA, split-bf16 (x6, fp32-accurate) MFMA, or per-layout best")
     ap.add_argument("--no-projection-cache", action="store_true", help="priority forward: recompute fc_pool_0 per batch")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of EACH cpu_baseline leg (multi-thread, one thread)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = the workload's batch per GPU (global batch grows with N); strong = the workload's batch in "
+                         "total, cut over the GPUs (RBR: every 512-seed batch; PBR forward: the K batches of the pass)")
+    ap.add_argument("--partition", default="replicated", choices=["replicated", "features"],
+                    help="PBR forward, N > 1: 'features' = every rank projects only its vertex range and the projection tables are "
+                         "exchanged by one halo all-gather each (the partitioned-feature mode); 'replicated' = every rank projects all rows")
     return ap.parse_args()
 
 
@@ -115,10 +122,17 @@ def main():
     sampling.seed(1)
     split_rng = np.random.default_rng(synthetic.SEEDS["split"])
     train_set = np.sort(split_rng.permutation(g.n_present)[: int(0.85 * g.n_present)])
-    seed_rng = np.random.default_rng(1000 + rank)            # every rank rehearses its own B seeds (weak scaling)
+    strong = args.scaling == "strong" and world > 1
+    # weak: every rank rehearses its own B seeds; strong: ONE B-seed batch per step, every rank takes its shard_range slice
+    seed_rng = np.random.default_rng(1000 if strong else 1000 + rank)
+    B_local = len(range(*parallel.shard_range(B, rank, world))) if strong else B
 
     def draw(nb):
-        return torch.as_tensor(np.concatenate([seed_rng.choice(train_set, B, replace=False) for _ in range(nb)]))
+        out = []
+        for _ in range(nb):
+            sd = seed_rng.choice(train_set, B, replace=False)
+            out.append(sd[slice(*parallel.shard_range(B, rank, world))] if strong else sd)
+        return torch.as_tensor(np.concatenate(out))
 
     stats = dict(n0=[], n1=[])
 
@@ -129,7 +143,7 @@ def main():
     def run(nsteps, seeds_per_snapshot):
         done = 0
         for seeds in seeds_per_snapshot:
-            loader = sampling.NodeDataLoader(g, seeds, sampler, batch_size=B)
+            loader = sampling.NodeDataLoader(g, seeds, sampler, batch_size=B_local)
             for input_nodes, sd, blocks in loader:
                 if done >= nsteps:
                     return
@@ -255,42 +269,60 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
-        cores = os.cpu_count() or 1
-        torch.set_num_threads(cores)
         h = g.handle
         indptr, indices = h.indptr.cpu().numpy(), h.indices.cpu().numpy()
         keys = (h.keys if h.keys is not None else h.indices).cpu().numpy()
         deg = O.snapshot_degrees_fast(indptr, keys, g.n_present, g.cut)
         feat_cpu = g.ndata["feat"].cpu().contiguous()
         lab_cpu = g.ndata["target"].cpu()
-        cpu = O.CpuModel("pool", feat_size, H, n_classes, pool_feats=H, seed=1)
-        tc, nstep = time.perf_counter(), 0
-        while nstep < 1 or (time.perf_counter() - tc < args.cpu_seconds and nstep < 8):
-            sd = seed_rng.choice(train_set, B, replace=False)
-            cpu.train_step(feat_cpu, lab_cpu, indptr, indices, deg, sd, S, 1, 10 ** 6 + nstep)
-            nstep += 1
-        dt = time.perf_counter() - tc
-        cpu_baseline = dict(value=round(nstep * B / dt, 2), unit="vertices/s", cores=cores, kind="port",
-                            sample="%d RBR train steps of %d seeds (same graph, shapes and sampler) in %.1f s; torch-CPU fp32, "
-                                   "%d threads" % (nstep, B, dt, cores))
+
+        def cpu_leg(threads, batch):
+            """One untimed warm-up step (thread pool, allocator, first-touch), then >= 3 timed steps within the budget."""
+            torch.set_num_threads(threads)
+            cpu = O.CpuModel("pool", feat_size, H, n_classes, pool_feats=H, seed=1)
+            cpu.train_step(feat_cpu, lab_cpu, indptr, indices, deg, seed_rng.choice(train_set, batch, replace=False), S, 1, 10 ** 6)
+            tc, nstep = time.perf_counter(), 0
+            while nstep < 3 or (time.perf_counter() - tc < args.cpu_seconds and nstep < 8):
+                cpu.train_step(feat_cpu, lab_cpu, indptr, indices, deg, seed_rng.choice(train_set, batch, replace=False), S, 1,
+                               10 ** 6 + 1 + nstep)
+                nstep += 1
+            dt = time.perf_counter() - tc
+            return dict(value=round(nstep * batch / dt, 2), steps=nstep, batch=batch, seconds=round(dt, 2), threads=threads)
+
+        # the reference's own path is one Python thread driving torch-CPU intra-op threads (n_sampling_workers = 0,
+        # R/train/__main__.py:39); more threads than physical cores (or than ~64) only oversubscribe its small GEMMs
+        cores = min(os.cpu_count() or 1, 64)
+        multi = cpu_leg(cores, B)
+        single = cpu_leg(1, max(32, B // 4))          # a quarter batch per step keeps the one-thread leg inside the budget
+        cpu_baseline = dict(value=multi["value"], unit="vertices/s", cores=cores, kind="port",
+                            sample="1 warm-up + %d timed RBR train steps of %d seeds (same graph, shapes and sampler) in %.1f s; "
+                                   "torch-CPU fp32, %d threads (host has %d)" % (multi["steps"], B, multi["seconds"], cores,
+                                                                                os.cpu_count() or 1),
+                            single_thread=dict(value=single["value"], unit="vertices/s", cores=1,
+                                               sample="1 warm-up + %d timed steps of %d seeds in %.1f s, 1 thread (the per-seed cost "
+                                                      "of a smaller batch is slightly higher: fewer shared input rows)"
+                                                      % (single["steps"], single["batch"], single["seconds"])))
+        torch.set_num_threads(os.cpu_count() or 1)
 
     # HBM traffic per launch comes from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled
     # as the gfx950 guide prescribes); bench.py cannot collect PMC counters on itself, so it quotes the committed pass.
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
+        stamp = "%s, collected %s at HEAD %s — a constant quoted from that pass, NOT measured in this run" % (
+            "profiles/" + PMC_TRAFFIC_FILE, pmc.get("collected", "?"), pmc.get("head", "?"))
         if roof_aggr and args.workload == "reddit_rbr":
             roof_aggr["traffic"] = pmc["k_reduce_fwd_v4_L0"]["traffic_bytes"]
-            roof_aggr["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+            roof_aggr["traffic_source"] = stamp + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
         if roof_gemm and args.workload == "reddit_rbr" and args.gemm == "auto":
             key = {"linear_fwd_x3_pool0": "k_gemm_x3_fwd_pool0", "linear_bwd_weight_x3_pool0": "k_gemm_x3_bww_pool0"}.get(dom)
-            if key:
+            if key and key in pmc:
                 roof_gemm["traffic"] = pmc[key]["traffic_bytes"]
-                roof_gemm["traffic_source"] = "profiles/r01_pmc_traffic.json (HBM-side bytes per launch; an MFMA-bound kernel)"
+                roof_gemm["traffic_source"] = stamp + " (HBM-side bytes per launch; an MFMA-bound kernel)"
     except Exception:
         pass
 
     if rank == 0:
-        value = args.steps * B * world / elapsed
+        value = args.steps * (B if strong else B * world) / elapsed
         hbm_copy = None
         if world == 1:          # the box's own streaming figure beside the nominal peak (SURVEY §8d): 1 GiB device copy
             src_b = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()
@@ -305,15 +337,18 @@ def main():
                             what="1 GiB fp32 device-to-device copy (read + write bytes), 10 repeats, same process")
             del src_b, dst_b
         line = {
-            "metric": "streamed vertices/sec (RBR train update), Reddit-shaped stream depth=2 samples=25",
+            "metric": "streamed vertices/sec (RBR train update), %s-shaped stream depth=2 samples=%d" % (wl["dataset"], S),
             "value": round(value, 1), "unit": "vertices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1000 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1000 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"gemm_arithmetic": gemm_desc(args.gemm), "workload": "%s: %s-like %s stream, last snapshot (N=%d, CSR nnz=%d), F=%d H=%d C=%d, "
-                                   "aggregator=pool(max), depth=2 samples=%d batch=%d/GPU batch_timestep=%d, "
+                                   "aggregator=pool(max), depth=2 samples=%d batch=%s batch_timestep=%d, "
                                    "sample+gather+fwd+CE+bwd+Adam" % (args.workload, wl["dataset"], arrays["stream"], g.n_present,
-                                                                        int(h_nnz(g)), feat_size, H, n_classes, S, B, bt),
-                       "global_batch": B * world, "parallelism": "dp%d (seed-sharded replicas, flat-bucket grad all-reduce)" % world,
+                                                                        int(h_nnz(g)), feat_size, H, n_classes, S,
+                                                                        ("%d in total (%d on this rank)" % (B, B_local)) if strong else "%d/GPU" % B, bt),
+                       "global_batch": B if strong else B * world,
+                       "parallelism": "dp%d (seed-sharded replicas, two-bucket grad all-reduce overlapped with backward)" % world,
                        "avg_unique_input_nodes_n0": round(n0_avg, 1), "avg_n1": round(n1_avg, 1), "setup_s": round(setup_s, 1)},
             "roofline": roof_gemm if roof_gemm else roof_aggr,
             "roofline_aggregator": roof_aggr,
@@ -347,21 +382,25 @@ def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size,
     B, S = wl["batch"], wl["samples"]
     strat = HipSupervisedGraphSage(model, wl["batch_timestep"], 32, None, S, reduction="none", cuda=True, batch_full=B)
     strat.cache_projection = not args.no_projection_cache
+    strat.partition_features = args.partition == "features"
     model.eval()
-    lo, hi = parallel.shard_range(len(train_set), rank, world)
-    mine = train_set[lo:hi]
+    strong = args.scaling == "strong" and world > 1
+    total_batches = lambda nb: nb if strong else nb * world     # noqa: E731  (weak: nb batches PER RANK)
 
     def run(nb):
-        seeds = torch.as_tensor(np.resize(mine, nb * B))
+        # ONE pass over the (replicated) seed list; whole batches are block-partitioned over the ranks (parallel.batch_shard)
+        n_all = total_batches(nb) * B
+        seeds = torch.as_tensor(np.resize(train_set, n_all))
         losses = []
         with torch.no_grad():
-            for sd, scores in strat._inference_batches(g, seeds):
+            for sd, scores in strat._inference_batches(g, seeds, shard=True):
                 labels = ops.gather_i64(g.ndata["target"], sd)
                 rows, _ = ops.ce_fwd_bwd(scores, labels, want_grad=False)
                 losses.append(rows)
-        local = torch.cat(losses)
+        local = torch.cat(losses) if losses else torch.zeros(0, device="cuda")
         if world > 1:                     # the exchange step of the sharded pass: every replay-buffer replica gets every loss
-            local = parallel.all_gather_rows(local)
+            counts = [parallel.batch_shard(n_all, B, r, world)[3] - parallel.batch_shard(n_all, B, r, world)[2] for r in range(world)]
+            local = parallel.all_gather_counts(local, counts)
         return local.cpu()
 
     def barrier():
@@ -411,16 +450,20 @@ def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size,
                     "the 256 MB infinity cache does not come from HBM, so the algorithmic rate can approach or exceed the "
                     "8 TB/s pin rate — `traffic` (PMC) is what crossed the HBM interface")
     if rank == 0:
-        assert out.numel() == args.steps * B * world and bool(torch.isfinite(out).all())
+        assert out.numel() == total_batches(args.steps) * B and bool(torch.isfinite(out).all())
         print(json.dumps({
             "metric": "streamed vertices/sec (PBR priority forward), %s-shaped stream depth=2 samples=%d" % (wl["dataset"], S),
-            "value": round(args.steps * B * world / elapsed, 1), "unit": "vertices/s", "n_gpus": world, "steps": args.steps,
+            "value": round(total_batches(args.steps) * B / elapsed, 1), "unit": "vertices/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"gemm_arithmetic": gemm_desc(args.gemm), "workload": "%s: last snapshot (N=%d), F=%d H=%d C=%d, pool(max), batch_full=%d/GPU, inference sample+forward+CE(none), "
                                    "projection cache %s" % (args.workload, g.n_present, feat_size, wl["hidden"], n_classes, B,
                                                             "on" if strat.cache_projection else "off"),
-                       "global_batch": B * world, "parallelism": "dp%d (train set block-partitioned over the ranks%s)" % (world, ", per-seed losses all-gathered to every rank" if world > 1 else ""),
+                       "global_batch": B * world,
+                       "parallelism": "dp%d (whole batches of the pass block-partitioned over the ranks%s; projection tables %s)" % (
+                           world, ", per-seed losses all-gathered to every rank" if world > 1 else "",
+                           "built per vertex range + halo all-gather (partitioned features)" if (strat.partition_features and world > 1)
+                           else "built on every rank (replicated features)"),
                        "setup_s": round(setup_s, 1)},
             "roofline": roof, "cpu_baseline": None, "kernels": kernels}))
     if world > 1:

@@ -108,6 +108,15 @@ int ogl_gather_rows(const float* table, int64_t ld, int64_t n_rows, const int64_
 int ogl_gather_i64(const int64_t* table, int64_t n_rows, const int64_t* ids, int64_t n,
                    int64_t* out, ogl_stream_t stream);
 
+/* feat_drop of a SAGEConv layer (R/train/graphsage/pytorch/graphsage_dgl.py:41 `feat_drop=dropout` -> nn.Dropout on the
+ * layer input; `--dropout`, R/train/__main__.py:36,124), optionally fused with the row gather of the layer-0 input:
+ *   out[i, j] = keep(i, j) ? src[row(i), j] / (1 - p) : 0     for i < M, j < N  (rows nullable; ids outside [0, nrows) -> 0)
+ *   keep(i, j) = word (j & 3) of Philox4x32-10(counter = {j >> 2, i_lo, i_hi, ctr_lo}, key = {seed_lo, seed_hi ^ ctr_hi})
+ *                >= floor(p * 2^32);   0 <= p < 1.
+ * The mask depends on (i, j, seed, ctr) only, so the backward pass is the same call on the output gradient (rows = NULL). */
+int ogl_dropout_rows(const float* src, int64_t ld, const int64_t* rows, int64_t nrows, int64_t M, int N, double p,
+                     uint64_t seed, uint64_t ctr, float* out, int64_t ldo, ogl_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fixed-fanout neighbour reduction = the aggregator (DGL copy_src -> max on the live 'pool'
  * layer; mailbox.mean/.sum(axis=1) in R/train/graphsage/pytorch/aggregator_dgl.py:158,165,185).

@@ -5,5 +5,6 @@ runs in libogl_hip.so (hand-written HIP for gfx950) through the C-ABI in include
 Import as ``ogl_amd`` (see ogl_amd.py at the repo root).
 """
 from . import _lib  # noqa: F401
+from . import torch_ops  # noqa: F401  (registers torch.ops.ogl.*)
 
 __version__ = "0.1.0"

@@ -326,3 +326,47 @@ extern "C" int ogl_gather_i64(const int64_t* table, int64_t n_rows, const int64_
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }
+
+// ---- feat_drop: counter-based dropout, optionally fused with the row gather ------------------------------------
+// One thread per 4 consecutive columns of one output row = one Philox4x32-10 block (the sampler's keying with the
+// output row in place of the vertex id); keep iff draw >= thr; kept values are divided by keep_prob (one IEEE division,
+// what the oracle's numpy statement does).
+__global__ void __launch_bounds__(256) k_dropout_rows(const float* __restrict__ src, int64_t ld,
+                                                      const int64_t* __restrict__ rows, int64_t nrows, int64_t M, int N,
+                                                      int n4, uint32_t thr, float keep_prob, uint32_t k0, uint32_t k1,
+                                                      uint32_t c3, float* __restrict__ out, int64_t ldo) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= M * (int64_t)n4) return;
+  const int64_t i = t / n4;
+  const int q = (int)(t - i * n4);
+  const int64_t r = rows ? rows[i] : i;
+  const bool ok = r >= 0 && r < nrows;
+  const philox4 d = philox4x32_10((uint32_t)q, (uint32_t)((uint64_t)i & 0xFFFFFFFFu), (uint32_t)((uint64_t)i >> 32), c3, k0, k1);
+  const uint32_t draw[4] = {d.x, d.y, d.z, d.w};
+  const float* sp = src + (ok ? r : 0) * ld;
+  float* op = out + i * ldo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int j = 4 * q + e;
+    if (j < N) {
+      const float v = ok ? sp[j] : 0.f;
+      op[j] = draw[e] >= thr ? v / keep_prob : 0.f;
+    }
+  }
+}
+
+extern "C" int ogl_dropout_rows(const float* src, int64_t ld, const int64_t* rows, int64_t nrows, int64_t M, int N,
+                                double p, uint64_t seed, uint64_t ctr, float* out, int64_t ldo, ogl_stream_t stream) {
+  if (M < 0 || N < 0 || ld < N || ldo < N || nrows < 0 || !(p >= 0.0) || !(p < 1.0)) return OGL_EINVAL;
+  if (M == 0 || N == 0) return OGL_OK;
+  if (!src || !out) return OGL_EINVAL;
+  const double scaled = p * 4294967296.0;
+  const uint32_t thr = scaled >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)scaled;
+  const float keep_prob = (float)(1.0 - p);
+  const int n4 = (N + 3) / 4;
+  const uint32_t k0 = (uint32_t)(seed & 0xFFFFFFFFu), k1 = (uint32_t)((seed >> 32) ^ (ctr >> 32));
+  hipLaunchKernelGGL(k_dropout_rows, dim3((unsigned)ogl_cdiv(M * (int64_t)n4, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     ld, rows, nrows, M, N, n4, thr, keep_prob, k0, k1, (uint32_t)(ctr & 0xFFFFFFFFu), out, ldo);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}

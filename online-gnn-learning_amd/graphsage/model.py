@@ -50,7 +50,8 @@ class SupervisedGraphSage:
         self.amount_of_train = {}
         self.delay = 0.0
         self.fuse_gather = True     # read feature rows straight from the resident table inside the GEMM
-        self.cache_projection = True  # inference passes reuse relu(fc_pool_0(X)) across batches
+        self.cache_projection = True  # inference passes reuse the layer-0 projection tables across batches
+        self.partition_features = False  # N ranks: build those tables per vertex range + halo all-gather (parallel.py)
 
     def build_optimizer(self):
         raise NotImplementedError
@@ -139,7 +140,9 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         # Under torch.distributed (one process per GPU, identical replicas, identical host RNG seeds on every rank)
         # each rank trains on its shard_range slice of every replay batch; the weighted gradient all-reduce makes the
         # update that of the whole batch, and the sharded PBR passes all-gather their per-seed losses (parallel.py).
-        self.gsync = parallel.GradSynchronizer(self.graphsage_model.parameters(), overlap=False) \
+        # (the loss of a shard already carries 1 / n_global, hence weight 1; the two-bucket overlap works for ragged and
+        # empty shards alike: every rank issues the same two collectives per step)
+        self.gsync = parallel.GradSynchronizer(self.graphsage_model.parameters(), overlap=True, weight=1.0) \
             if parallel.is_distributed() else None
 
     def _local_batches(self, graph, seeds, batch_size, shuffle=False):
@@ -153,11 +156,14 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         bs = int(batch_size)
         if bs <= 0:
             raise ValueError("batch_size should be a positive integer value, but got batch_size={}".format(bs))
+        if world > 1:
+            parallel.assert_replicated(seeds, "the snapshot's train seeds")
         seeds = seeds.to(graph.device).contiguous()
         full = [seeds[s0:s0 + bs] for s0 in range(0, seeds.numel(), bs)]
         local = [b[slice(*parallel.shard_range(b.numel(), rank, world))] for b in full]
         live = [i for i, b in enumerate(local) if b.numel() > 0]
-        out = iter(self._sampler().sample_batches(graph, [local[i] for i in live]))
+        ctrs = sampling.reserve_ctrs(len(full))           # every batch of the one-rank loader, also those empty here
+        out = iter(self._sampler().sample_batches(graph, [local[i] for i in live], ctrs=[ctrs[i] for i in live]))
         for i, b in enumerate(full):
             if local[i].numel() > 0:
                 input_nodes, sd, blocks = next(out)
@@ -174,7 +180,7 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             for p in self.gsync.params:                            # a rank without seeds contributes zeros
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
-            self.gsync.sync(weight=1.0)                            # the 1 / n_global is already in the loss
+            self.gsync.sync()                                      # weight 1: the 1 / n_global is already in the loss
         self.optimizer.step()
 
     def _sampler(self):
@@ -185,22 +191,57 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             return GatheredRows(graph.ndata["feat"], input_nodes)
         return ops.gather_rows(graph.ndata["feat"], input_nodes)
 
-    def _inference_batches(self, graph, seeds_all):
+    # Expected unique layer-0 input rows of an inference batch as a fraction of its upper bound B (1 + S)^2: measured
+    # 0.18 (Reddit-like, B = 512: n0 = 62.7 k of 346 k) to 0.3 (arxiv- / pubmed-like, B = 1024, before the n_present cap);
+    # it only decides when a pass is long enough for the per-pass tables to pay — both paths give the same results.
+    UNIQUE_INPUT_FRACTION = 0.3
+
+    def _projection_tables(self, graph, layer0):
+        """(P0, S0) of ``SAGEConv.project_tables`` for every present vertex, once per pass (weights are fixed during it).
+        One rank, or replicated mode: computed locally.  ``partition_features`` under N ranks — the partitioned-feature mode
+        of the north star: each rank projects ONLY the rows of its vertex range (the pass reads no other raw feature row on
+        that rank: a batch takes its self term from S0 and its neighbour term from P0), written in place into its block of
+        the full tables, then ONE all-gather per table exchanges the blocks: the rows outside a rank's range are the halo
+        embeddings its sampled neighbourhoods reach into (on a power-law graph every batch does)."""
+        feat = graph.ndata["feat"]
+        dev = graph.device
+
+        def project(lo, hi, blocks):
+            rows = None if (lo == 0 and hi == graph.n_present) else torch.arange(lo, hi, dtype=torch.int64, device=dev)
+            layer0.project_tables(feat, rows=rows, out=blocks)
+
+        widths = [layer0.fc_pool.weight.shape[0], layer0._out_feats]
+        P, S = parallel.build_row_tables(graph.n_present, widths, project, dev, partition=self.partition_features,
+                                         padded_ld=ops.padded_ld)
+        return P, S
+
+    def _inference_batches(self, graph, seeds_all, shard=False):
         """Forward-only pass over ``seeds_all`` in batches of ``batch_full``; yields (seeds, logits).
 
-        When the pass is long enough that its batches would project more input rows than the snapshot holds,
-        ``P0 = relu(fc_pool_0(X))`` is computed ONCE for every present vertex (weights are fixed during the pass)
-        and every batch reduces straight from it: no layer-0 GEMM over the unique inputs, no input-block relabel."""
+        ``shard`` (N ranks): this rank runs WHOLE batches of the one-rank pass (``parallel.batch_shard``) with their
+        sampler counters, so its logits are bit-identical to the one-rank pass's for the same seeds; every rank must
+        iterate the generator (the table build below is a collective in partitioned mode) even without a batch of its own.
+
+        When the pass is long enough that its batches would project more input rows than the snapshot holds, the
+        layer-0 projection tables are computed ONCE for every present vertex (``_projection_tables``) and every batch
+        reduces straight from them: no layer-0 GEMM over the unique inputs, no input-block relabel."""
         layer0 = self.graphsage_model.layers[0]
-        n_batches = -(-seeds_all.numel() // self.batch_full)
-        per_batch_rows = min(self.batch_full * (1 + self.samples) ** 2 * 0.3, graph.n_present)
+        n, bf = int(seeds_all.numel()), int(self.batch_full)
+        rank, world = parallel.rank_world() if shard else (0, 1)
+        nb = -(-n // bf)
+        ctrs = sampling.reserve_ctrs(nb)
+        b_lo, b_hi, s_lo, s_hi = parallel.batch_shard(n, bf, rank, world)
+        per_batch_rows = min(bf * (1 + self.samples) ** 2 * self.UNIQUE_INPUT_FRACTION, graph.n_present)
         use_cache = (self.cache_projection and layer0.fc_pool is not None and not layer0.training
-                     and n_batches * per_batch_rows > graph.n_present)
-        loader = sampling.NodeDataLoader(graph, seeds_all, self._sampler(), batch_size=self.batch_full, shuffle=False,
-                                         drop_last=False, num_workers=self.n_workers, relabel_input=not use_cache)
-        proj = layer0.project_table(graph.ndata["feat"]) if use_cache else None
-        for input_nodes, seeds, blocks in loader:
-            x = GatheredRows(graph.ndata["feat"], None, proj) if use_cache else self._inputs(graph, input_nodes)
+                     and nb * per_batch_rows > graph.n_present)          # a function of global quantities: same on every rank
+        tables = self._projection_tables(graph, layer0) if use_cache else None
+        if b_hi <= b_lo:
+            return
+        mine = seeds_all[s_lo:s_hi].to(graph.device, non_blocking=True).contiguous()
+        batches = [mine[s:s + bf] for s in range(0, mine.numel(), bf)]
+        for input_nodes, seeds, blocks in self._sampler().sample_batches(graph, batches, relabel_input=not use_cache,
+                                                                         ctrs=ctrs[b_lo:b_hi]):
+            x = GatheredRows(graph.ndata["feat"], None, tables) if use_cache else self._inputs(graph, input_nodes)
             yield seeds, self.graphsage_model(blocks, x)
 
     def _run_custom_eval(self, graph, subgraph_to_id, id_to_subgraph, test_vertices):
@@ -224,15 +265,15 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             return None
         n_all = int(seeds_all.numel())
         rank, world = parallel.rank_world()
-        if world > 1:                           # N ranks: block-partitioned pass, C x C counters summed over the ranks
-            seeds_all = seeds_all[slice(*parallel.shard_range(n_all, rank, world))]
+        if world > 1:
+            parallel.assert_replicated(seeds_all, "the evaluation vertices")
         last = self.graphsage_model.layers[-1]
         C_ = int((last.fc_self if last.fc_self is not None else last.fc_neigh).weight.shape[0])
         cm = torch.zeros(C_ * C_, dtype=torch.int64, device=graph.device)
         with torch.no_grad():
-            if seeds_all.numel() > 0:
-                for seeds, logits in self._inference_batches(graph, seeds_all):
-                    ops.argmax_confusion(logits, ops.gather_i64(graph.ndata["target"], seeds), cm, want_pred=False)
+            # N ranks: whole batches of the pass are block-partitioned over the ranks, C x C counters summed over them
+            for seeds, logits in self._inference_batches(graph, seeds_all, shard=True):
+                ops.argmax_confusion(logits, ops.gather_i64(graph.ndata["target"], seeds), cm, want_pred=False)
         cm = cm.cpu()
         if world > 1:
             import torch.distributed as dist
@@ -377,26 +418,27 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
             return
         seeds_all = torch.as_tensor(np.asarray(id_to_subgraph[train_set]), dtype=torch.int64)
         graph = graph_util.get_graph()
-        # N ranks: the pass is block-partitioned over the ranks in seed order and the per-seed losses are all-gathered,
-        # so every replica of the replay buffer receives every priority (north star: "PBR sharded across the GPUs")
+        # N ranks: whole batches of the pass are block-partitioned over the ranks (seed order kept) and the per-seed losses
+        # are all-gathered, so every replica of the replay buffer receives every priority (north star: "PBR sharded across
+        # the GPUs"); the lengths every rank contributes follow from the partition, only values travel
         rank, world = parallel.rank_world()
-        lo, hi = parallel.shard_range(seeds_all.numel(), rank, world)
-        mine = seeds_all[lo:hi]
-        losses, nid_chunks = [], []
+        if world > 1:
+            parallel.assert_replicated(seeds_all, "the priority-forward seeds")
+        losses = []
         with torch.no_grad():
-            if mine.numel() > 0:
-                for seeds, scores in self._inference_batches(graph, mine):
-                    batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
-                    loss_rows, _ = ops.ce_fwd_bwd(scores, batch_labels, want_grad=False)
-                    losses.append(loss_rows)
-                    nid_chunks.append(seeds)
+            for seeds, scores in self._inference_batches(graph, seeds_all, shard=True):
+                batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
+                loss_rows, _ = ops.ce_fwd_bwd(scores, batch_labels, want_grad=False)
+                losses.append(loss_rows)
         local = torch.cat(losses) if losses else torch.zeros(0, device=graph.device)
         if world > 1:
-            unaggregated_loss = parallel.all_gather_sharded([local], [seeds_all.numel()])[0].cpu().numpy()
-            batch_nids_l = list(subgraph_to_id[seeds_all.numpy()])
-        else:
-            unaggregated_loss = local.cpu().numpy()
-            batch_nids_l = list(subgraph_to_id[torch.cat(nid_chunks).cpu().numpy()])
+            counts = []
+            for r in range(world):
+                _, _, a, b = parallel.batch_shard(seeds_all.numel(), self.batch_full, r, world)
+                counts.append(b - a)
+            local = parallel.all_gather_counts(local, counts)
+        unaggregated_loss = local.cpu().numpy()
+        batch_nids_l = list(subgraph_to_id[seeds_all.numpy()])
         priorities = self.priority_strategy.get_priorities(batch_nids_l, unaggregated_loss)
         graph_util.update_priorities_arrays(np.asarray(batch_nids_l), np.asarray(priorities, dtype=np.float64))
 

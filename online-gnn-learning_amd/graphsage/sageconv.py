@@ -29,9 +29,9 @@ class GatheredRows:
     ``graph.ndata['feat'][input_nodes]`` (R/.../pytorch/model.py:54,88,182,232) is never materialised."""
 
     def __init__(self, table: torch.Tensor, ids, proj: torch.Tensor = None):
-        # proj (optional, inference only): relu(fc_pool(table)) for EVERY table row, computed once per weight
-        # version.  With it the first layer reduces straight from `proj` through the block's global picks and
-        # `ids` may be None (the input block then needs no relabelling at all).
+        # proj (optional, inference only): the (P0, S0) pair of SAGEConv.project_tables for EVERY table row, computed
+        # once per weight version.  With it the first layer reduces straight from P0 through the block's global picks,
+        # takes its self term from S0, and `ids` may be None (the input block then needs no relabelling at all).
         self.table, self.ids, self.proj = table, ids, proj
 
     @property
@@ -43,6 +43,17 @@ class GatheredRows:
 
     def materialize(self):
         return ops.gather_rows(self.table, self.ids)
+
+
+_EYE = {}
+
+
+def _eye(n, device):
+    key = (n, device.type, device.index)
+    t = _EYE.get(key)
+    if t is None:
+        t = _EYE[key] = ops.empty_mat(n, n, device).copy_(torch.eye(n, dtype=torch.float32, device=device))
+    return t
 
 
 def _is_relu(fn):
@@ -99,8 +110,13 @@ class SAGEConv(nn.Module):
         if t not in ("pool", "mean", "gcn", "meanpool", "maxpool"):
             raise KeyError("Aggregator type {} not recognized.".format(t))
         lazy = isinstance(feat, GatheredRows)
-        if not lazy and self.feat_drop.p > 0:
-            feat = self.feat_drop(feat)
+        if self.training and self.feat_drop.p > 0:
+            # feat_drop on the layer input (graphsage_dgl.py:41): one HIP launch, fused with the row gather when the input
+            # is a lazy table[ids] (the layer then runs on the materialised, dropped rows)
+            if lazy and feat.proj is not None:
+                raise RuntimeError("the cached-projection path is inference only (model.eval())")
+            feat = ops.dropout(feat.table, self.feat_drop.p, rows=feat.ids) if lazy else ops.dropout(feat, self.feat_drop.p)
+            lazy = False
         n_dst = graph.number_of_dst_nodes()
         idx = graph.local_idx
         fuse_relu = _is_relu(self.activation)
@@ -152,23 +168,20 @@ class SAGEConv(nn.Module):
         return rst
 
     def _forward_cached(self, graph, feat, fuse_relu):
-        """Inference against a cached projection table (the idea of R/inference_optimized.py:169,258): the
-        neighbour max reads proj[picks] directly, fc_self reads the raw rows of the dst ids."""
+        """Inference against the per-pass projection tables (the idea of R/inference_optimized.py:169,258 — its
+        ``h0proj`` / ``neigh`` caches): the neighbour max reads ``P0[picks]`` directly and the self term is the row
+        ``S0[dst]``, so a batch touches no raw feature row (what lets the tables be built per vertex range and exchanged,
+        model.HipSupervisedGraphSage._projection_tables).  ``S0[dst] + fc_neigh(neigh)`` runs as the dual-input GEMM with
+        an identity first weight: exact (x * 1 and zeros), same launch count as the fc_self it replaces."""
         t = self._aggre_type
         if t not in ("pool", "maxpool", "meanpool"):
             raise KeyError("cached projections apply to the pooling aggregators only, not {}".format(t))
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise RuntimeError("the cached-projection path is inference only (run it under torch.no_grad())")
-        h_neigh, _ = ops.reduce_fwd(feat.proj, graph.picks, "mean" if t == "meanpool" else "max")
-        dst_rows = graph.dst_ids
-        if t == "pool":
-            bias = self._summed_bias()
-            rst = ops.linear_fwd(feat.table, self.fc_self.weight, bias, x2=h_neigh, w2=self.fc_neigh.weight, relu=fuse_relu,
-                                 x_rows=dst_rows)
-        else:
-            W = self.fc_neigh.weight
-            rst = ops.linear_fwd(feat.table, W[:, :self._in_feats], self.fc_neigh.bias, x2=h_neigh, w2=W[:, self._in_feats:],
-                                 relu=fuse_relu, x_rows=dst_rows)
+        P0, S0 = feat.proj
+        h_neigh, _ = ops.reduce_fwd(P0, graph.picks, "mean" if t == "meanpool" else "max")
+        w_neigh = self.fc_neigh.weight if t == "pool" else self.fc_neigh.weight[:, self._in_feats:]
+        rst = ops.linear_fwd(S0, _eye(S0.shape[1], S0.device), None, x2=h_neigh, w2=w_neigh, relu=fuse_relu, x_rows=graph.dst_ids)
         if self.activation is not None and not fuse_relu:
             rst = self.activation(rst)
         if self.norm is not None:
@@ -189,11 +202,20 @@ class SAGEConv(nn.Module):
             self._bias_sum_cache = hit
         return hit[1]
 
-    def project_table(self, table):
-        """relu(fc_pool(table)) for every row — the per-weight-version cache consumed by _forward_cached."""
+    def project_tables(self, table, rows=None, out=None):
+        """The per-weight-version tables consumed by _forward_cached, for ``table[rows]`` (default: every row):
+        ``P0 = relu(fc_pool(x))`` and ``S0`` = the self term of the combine with every bias of it folded in
+        (``fc_self(x) + b_self + b_neigh`` for 'pool', ``x . W[:, :in]^T + b`` of the concat -> fc_neigh modes).
+        ``out = (P0_rows, S0_rows)`` writes into caller-owned row blocks (a rank's slice of the exchanged tables)."""
         if self.fc_pool is None:
             raise KeyError("aggregator {} has no pooling projection".format(self._aggre_type))
-        return ops.linear_fwd(table, self.fc_pool.weight, self.fc_pool.bias, relu=True)
+        if self._aggre_type == "pool":
+            w_self, b_self = self.fc_self.weight, self._summed_bias()
+        else:
+            w_self, b_self = self.fc_neigh.weight[:, :self._in_feats], self.fc_neigh.bias
+        p0 = ops.linear_fwd(table, self.fc_pool.weight, self.fc_pool.bias, relu=True, x_rows=rows, out=out[0] if out else None)
+        s0 = ops.linear_fwd(table, w_self, b_self, x_rows=rows, out=out[1] if out else None)
+        return p0, s0
 
     def _pool_max(self, feat, idx):
         if isinstance(feat, GatheredRows):

@@ -240,6 +240,51 @@ def gather_i64(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# feat_drop: counter-based (Philox) dropout stream, the analogue of the sampler's: reproducible, and the mask of an
+# application is a function of (seed, application counter, row, column), so backward re-derives it instead of storing it
+_DROPOUT = {"seed": 1, "ctr": 0}
+
+
+def dropout_seed(value: int):
+    """Reset the dropout stream (the reference never seeds torch's RNG, R/train/__main__.py:211-212)."""
+    _DROPOUT["seed"], _DROPOUT["ctr"] = int(value), 0
+
+
+def dropout_rows(x, p, seed, ctr, rows=None):
+    """x[rows?] with Bernoulli(1 - p) dropout scaled by 1 / (1 - p) (ogl_dropout_rows)."""
+    x = as_mat(x)
+    M = rows.numel() if rows is not None else x.shape[0]
+    N = x.shape[1]
+    out = empty_mat(M, N, x.device)
+    _launch("ogl_dropout_rows", _lib.lib().ogl_dropout_rows, _ptr(x), _ld(x), _ptr(_ids(rows) if rows is not None else None),
+            x.shape[0], M, N, C.c_double(float(p)), C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(ctr & (2 ** 64 - 1)), _ptr(out),
+            _ld(out), _stream(), meta=dict(M=M, N=N))
+    return out
+
+
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rows, p, seed, ctr):
+        ctx.p, ctx.seed, ctx.ctr, ctx.gathered = p, seed, ctr, rows is not None
+        return dropout_rows(x, p, seed, ctr, rows)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.gathered:
+            raise RuntimeError("gradient w.r.t. a row-gathered table is not supported (features carry no grad)")
+        return dropout_rows(dy, ctx.p, ctx.seed, ctx.ctr), None, None, None, None
+
+
+def dropout(x, p, rows=None):
+    """nn.Dropout(p)(x[rows?]) in training mode on the HIP kernel, differentiable w.r.t. an ungathered x; takes the next
+    counter of the dropout stream."""
+    ctr = _DROPOUT["ctr"]
+    _DROPOUT["ctr"] = ctr + 1
+    if rows is not None or not x.requires_grad:
+        return dropout_rows(x, p, _DROPOUT["seed"], ctr, rows)
+    return _DropoutFn.apply(x, None, p, _DROPOUT["seed"], ctr)
+
+
 def reduce_fwd(src: torch.Tensor, idx: torch.Tensor, op: str, want_argmax: bool = False):
     """out[d] = op_j src[idx[d, j]].  idx int32 (block-local) or int64 (global rows)."""
     src = as_mat(src)
@@ -284,13 +329,13 @@ def linear_fwd(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_ro
         K2 = x2.shape[1]
         assert w2.shape == (N, K2)
         assert (x2_rows.numel() if x2_rows is not None else x2.shape[0]) == M
-    if out is None and _x3_forward_ok(x, M, x2):
+    if _x3_forward_ok(x, M, x2):
         # rows of a registered static table: pre-split image of the table, the weights are split (with the bias in the
         # appended slot) per call — 12 us for a 602 x 602 matrix
         img = _static_image(x)
         if img is not None:
             bvec = bias if bias is not None else torch.zeros(N, dtype=torch.float32, device=x.device)
-            return linear_fwd_x3(img, x_rows, x3_split(w, append_vec=bvec), relu=relu, x_nrows=x.shape[0], M=M)
+            return linear_fwd_x3(img, x_rows, x3_split(w, append_vec=bvec), relu=relu, x_nrows=x.shape[0], M=M, out=out)
     y = out if out is not None else empty_mat(M, N, x.device)
     _launch("ogl_linear_fwd", _lib.lib().ogl_linear_fwd, 
         _ptr(x), _ld(x), _ptr(x_rows), x.shape[0], M, K, _ptr(w), _ld(w), N, _ptr(bias),
@@ -414,14 +459,15 @@ def x3_split_t(x, rows=None, ones_row=False, interleave=0):
     return X3Image(buf, nimg, Mi)
 
 
-def linear_fwd_x3(x_img, x_rows, w_img, relu=False, x_nrows=None, M=None):
+def linear_fwd_x3(x_img, x_rows, w_img, relu=False, x_nrows=None, M=None, out=None):
     """y = act(x_img[x_rows] @ w_img.T); a bias is folded into the images (x3_split append_ones / append_vec).
     ``x_nrows`` bounds the valid gather ids (default: every image row); without a gather ``M`` selects a row prefix."""
     M = x_rows.numel() if x_rows is not None else (x_img.rows if M is None else M)
     x_nrows = x_img.rows if x_nrows is None else x_nrows
     K, N = x_img.K, w_img.rows
     assert w_img.K == K, "both images must be built with the same append choice"
-    y = empty_mat(M, N, x_img.buf.device)
+    y = out if out is not None else empty_mat(M, N, x_img.buf.device)
+    assert y.shape[0] == M and y.shape[1] == N
     _launch("ogl_linear_fwd_x3", _lib.lib().ogl_linear_fwd_x3, _ptr(x_img.buf), x_img.rows,
             _ptr(_ids(x_rows) if x_rows is not None else None), x_nrows, M, K, _ptr(w_img.buf), N, 1 if relu else 0, _ptr(y),
             _ld(y), _stream(), meta=dict(M=M, K=K, N=N, K2=0))
@@ -630,6 +676,17 @@ class _ReduceFn(torch.autograd.Function):
         return reduce_bwd(dout, idx32, argmax, ctx.op, ctx.n_src, fanout=ctx.fanout), None, None
 
 
+# Test hook: while a list is installed, every differentiable pool layer appends dict(argmax, neigh[, out]) — the winners and
+# ReLU masks the device chose — so that a parity test can route the oracle's backward through the same winners
+# (tests/test_gpu_fullsize.py).  Not used by the product path.
+_CAPTURE = None
+
+
+def capture_pool_winners(store):
+    global _CAPTURE
+    _CAPTURE = store
+
+
 class _PoolMaxFn(torch.autograd.Function):
     """relu(fc_pool(x[rows])) -> elementwise max over the sampled neighbours, as one autograd node.
 
@@ -642,6 +699,8 @@ class _PoolMaxFn(torch.autograd.Function):
         p = linear_fwd(x, w, bias, relu=True, x_rows=x_rows)
         need = x.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad)
         out, argmax = reduce_fwd(p, idx, "max", want_argmax=need)
+        if _CAPTURE is not None:
+            _CAPTURE.append(dict(argmax=argmax, neigh=out))
         ctx.n_src, ctx.fanout, ctx.has_bias = p.shape[0], idx.shape[1], bias is not None
         ctx.save_for_backward(x, w, x_rows, out, argmax, idx if idx.dtype == torch.int32 else None)
         return out
@@ -686,6 +745,8 @@ class _SagePoolLayerFn(torch.autograd.Function):
         if b_self is not None:
             bias = b_self + b_neigh
         out = linear_fwd(h[:n_dst], w_self, bias, x2=neigh, w2=w_neigh, relu=relu)
+        if _CAPTURE is not None:
+            _CAPTURE.append(dict(argmax=argmax, neigh=neigh, out=out if relu else None))
         ctx.relu, ctx.n_dst, ctx.fanout, ctx.has_bias, ctx.has_pool_bias = bool(relu), n_dst, idx.shape[1], b_self is not None, b_pool is not None
         ctx.save_for_backward(h, w_pool, w_self, w_neigh, neigh, argmax, out if relu else None)
         return out

@@ -8,9 +8,13 @@ every rank keeps a replica of the adjacency and the feature table (Reddit: 0.1 G
 exchange steps are (1) the gradient all-reduce of the ~1.5 M fp32 parameters (~6 MB), then the identical Adam
 update on every rank, and (2) for the sharded PBR passes (train update, priority forward over the train set) ONE
 all-gather of the per-seed losses per pass, so that every rank's replay-buffer replica receives every priority
-(``all_gather_sharded``); the sharded evaluation pass all-reduces its C x C confusion counters.  Because the Philox sampler is keyed by
-(seed, batch counter, layer, vertex id, slot), a vertex draws the same neighbours on whichever rank
-it lands: an N-rank step is bit-identical in sampled indices to the 1-rank step on the same seeds.
+(``all_gather_sharded`` / ``all_gather_counts``); the sharded evaluation pass all-reduces its C x C confusion counters.
+The Philox sampler is keyed by (seed, batch counter, layer, vertex id, slot) and every rank reserves the counters of ALL
+batches of the one-rank pass (train batches are cut by seeds inside a batch, inference passes are cut by whole batches:
+``batch_shard``), so a vertex draws the same neighbours on whichever rank it lands and the sampler state after a pass is
+the one-rank state: an N-rank pass is bit-identical in sampled indices to the 1-rank pass on the same seeds.
+
+Partitioned-feature mode (``FeaturePartition``): see its docstring.
 """
 from __future__ import annotations
 
@@ -47,7 +51,7 @@ def shard_seeds(seeds, rank=None, world=None):
 
 
 class GradSynchronizer:
-    """All-reduce(mean) of every parameter gradient through flat buckets, overlapped with the backward pass.
+    """All-reduce(sum of weight * grad) of every parameter gradient through flat buckets, overlapped with the backward pass.
 
     The first ``sync()`` learns the order in which gradients become ready (post-accumulate hooks) and reduces ONE flat
     bucket.  From then on the parameters are split into an EARLY bucket — everything except the gradients that arrive
@@ -56,19 +60,32 @@ class GradSynchronizer:
     stream under the layer-0 backward kernels; ``sync()`` then reduces the small late bucket and waits for the early
     one.  Afterwards each ``p.grad`` is a view of a reduced bucket (no copy back).  xGMI is point-to-point, so the
     bucket count stays at two: a ring all-reduce is latency-bound at these sizes (4.5 MB + 1.5 MB for the Reddit model).
-    """
 
-    def __init__(self, params, group=None, overlap=True, late_fraction=0.35):
+    The sequence of collectives is the SAME on every rank whatever happened locally (collectives are matched by order and
+    size): once the split is learnt — rank 0's split, broadcast in a step every rank takes part in — every ``sync()``
+    issues early then late.  A rank whose hooks did not complete the early bucket (no seeds in its shard, so no
+    backward) launches it from ``sync()``.  The late bucket carries one extra element, a flag a rank raises when a
+    gradient of its early bucket changed after the launch (a second ``backward()`` before ``sync()``: gradient
+    accumulation); the reduced flag is the same on every rank, and when it is set every rank reduces the early bucket
+    again from its current gradients.  ``no_sync()`` suspends the hook launch for accumulation steps (then nothing is
+    wasted).  ``weight`` scales this rank's gradients before the sum: 1 / world (a mean) by default, 1.0 when the loss
+    already carries the 1 / n_global of a ragged shard (the strategies)."""
+
+    def __init__(self, params, group=None, overlap=True, late_fraction=0.35, weight=None):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.overlap = bool(overlap) and self.world > 1
         self.late_fraction = late_fraction
+        self.weight = (1.0 / self.world) if weight is None else float(weight)
         self._order = []            # arrival order of the current backward (indices into self.params)
         self._early = None          # indices of the early bucket once learnt
         self._late = None
-        self._pending = None        # (work handle, flat tensor) of the early bucket in flight
-        self._arrived = 0
+        self._early_set = set()
+        self._pending = None        # (work handle, flat tensor, weight used) of the early bucket in flight
+        self._fired = {}            # parameter index -> hook firings since the last sync()
+        self._stale = False         # an early-bucket gradient changed after the launch
+        self._suspended = False
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._hooks = []
         if self.overlap:
@@ -79,22 +96,42 @@ class GradSynchronizer:
     def _on_grad(self, p):
         i = self._index[id(p)]
         self._order.append(i)
-        if self._early is not None and self._pending is None and i in self._early_set:
-            self._arrived += 1
-            if self._arrived == len(self._early):
-                self._launch_early()
+        self._fired[i] = self._fired.get(i, 0) + 1
+        if self._early is None or i not in self._early_set:
+            return
+        if self._pending is not None:
+            self._stale = True                       # accumulated into after the launch: sync() reduces the bucket again
+            return
+        if not self._suspended and all(self._fired.get(j, 0) >= 1 for j in self._early):
+            self._launch_early(self.weight)
 
-    def _flatten(self, idxs, w):
+    def no_sync(self):
+        """Context manager for gradient-accumulation steps: backward passes inside it never launch the early bucket."""
+        gs = self
+
+        class _Ctx:
+            def __enter__(self_inner):
+                gs._suspended = True
+
+            def __exit__(self_inner, *exc):
+                gs._suspended = False
+                return False
+        return _Ctx()
+
+    def _flatten(self, idxs, w, extra=0):
         pieces = [(self.params[i].grad if self.params[i].grad is not None else torch.zeros_like(self.params[i])).reshape(-1)
                   for i in idxs]
+        if extra:
+            pieces.append(torch.zeros(extra, dtype=pieces[0].dtype, device=pieces[0].device) if pieces else torch.zeros(extra))
         flat = torch.cat(pieces)
-        flat.mul_(w)
+        if w != 1.0:
+            flat.mul_(w)
         return flat
 
-    def _launch_early(self):
-        flat = self._flatten(self._early, 1.0 / self.world)
+    def _launch_early(self, w):
+        flat = self._flatten(self._early, w)
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._pending = (work, flat)
+        self._pending = (work, flat, w)
 
     def _scatter(self, idxs, flat):
         off = 0
@@ -105,62 +142,159 @@ class GradSynchronizer:
             off += n
 
     def _learn(self):
-        """Split by arrival order: the trailing gradients (at most late_fraction of the elements) form the late bucket."""
-        order = list(dict.fromkeys(self._order))
-        if len(order) != len(self.params):
-            return                                   # some parameter got no gradient this step: keep the single bucket
-        total = sum(p.numel() for p in self.params)
-        late, acc = [], 0
-        for i in reversed(order):
-            n = self.params[i].numel()
-            if late and acc + n > self.late_fraction * total:
-                break
-            late.append(i); acc += n
-        late = list(reversed(late))
-        early = [i for i in order if i not in set(late)]
-        # every rank must cut the SAME buckets (the collectives are matched by order and size): rank 0's split wins
-        box = [early, late]
-        dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        """Split by arrival order: the trailing gradients (at most late_fraction of the elements) form the late bucket.
+        EVERY rank calls this in the same step; rank 0's split wins (a rank without a backward has seen no arrivals)."""
+        box = [None, None]
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        if dist.get_rank() == src:
+            order = list(dict.fromkeys(self._order))
+            if len(order) == len(self.params):       # otherwise some parameter got no gradient: keep the single bucket
+                total = sum(p.numel() for p in self.params)
+                late, acc = [], 0
+                for i in reversed(order):
+                    n = self.params[i].numel()
+                    if late and acc + n > self.late_fraction * total:
+                        break
+                    late.append(i); acc += n
+                late = list(reversed(late))
+                box = [[i for i in order if i not in set(late)], late]
+        dist.broadcast_object_list(box, src=src, group=self.group)
         early, late = box
-        self._late = late
-        self._early = early
-        self._early_set = set(self._early)
-        if not self._early:
-            self._early = None
+        if early and late:
+            self._early, self._late, self._early_set = early, late, set(early)
 
     # -- the step's exchange ---------------------------------------------------------------------------------------
     def sync(self, weight=None):
-        """grads <- sum_r w_r * grad_r (w_r = 1/world by default; pass n_local/n_global for ragged shards — a custom
-        weight is applied to one flat bucket at sync time, without overlap)."""
+        """grads <- sum_r w_r * grad_r, w_r = ``weight`` (default: the constructor's)."""
         if self.world == 1:
             return
-        w = (1.0 / self.world) if weight is None else float(weight)
-        if self._pending is not None and weight is None:
-            work, flat_e = self._pending
-            flat_l = self._flatten(self._late, w)
-            dist.all_reduce(flat_l, op=dist.ReduceOp.SUM, group=self.group)
-            work.wait()
-            self._scatter(self._early, flat_e)
-            self._scatter(self._late, flat_l)
-        else:
-            if self._pending is not None:            # an early bucket is in flight with the default weight: finish and undo
-                work, flat_e = self._pending
-                work.wait()
-                raise RuntimeError("GradSynchronizer: a custom weight cannot follow an overlapped launch; "
-                                   "construct with overlap=False for ragged shards")
+        w = self.weight if weight is None else float(weight)
+        if self._early is None:
             idxs = list(range(len(self.params)))
             flat = self._flatten(idxs, w)
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             self._scatter(idxs, flat)
-            if self.overlap and self._early is None and weight is None:
-                try:
-                    self._learn()
-                except Exception:                 # the exchange stays correct with the single bucket; only the overlap is lost
-                    self._early = self._late = None
-                    self.overlap = False
+            if self.overlap:
+                self._learn()
+        else:
+            if self._pending is None:                # the hooks did not complete the bucket on this rank: same collective, here
+                self._launch_early(w)
+            work, flat_e, w_used = self._pending
+            flat_l = self._flatten(self._late, w, extra=1)
+            if self._stale:
+                flat_l[-1] = 1.0
+            dist.all_reduce(flat_l, op=dist.ReduceOp.SUM, group=self.group)
+            work.wait()
+            if float(flat_l[-1]) > 0:                # on some rank the early gradients changed after the launch: every
+                flat_e = self._flatten(self._early, w)   # rank reduces the bucket again from what it holds now
+                dist.all_reduce(flat_e, op=dist.ReduceOp.SUM, group=self.group)
+            elif w_used != w:
+                flat_e.mul_(w / w_used)
+            self._scatter(self._early, flat_e)
+            self._scatter(self._late, flat_l[:-1])
         self._pending = None
-        self._arrived = 0
+        self._stale = False
+        self._fired = {}
         self._order = []
+
+
+def assert_replicated(values, what="value", group=None):
+    """Raise when ``values`` (array-like of integers) is not identical on every rank: the sharded passes pair losses
+    computed by other ranks with THIS rank's seed list, which is only right while every rank drew the same seeds (identical
+    host RNG state).  One 2-element all-reduce."""
+    if not is_distributed(group):
+        return
+    import numpy as np
+    a = np.ascontiguousarray(np.asarray(values, dtype=np.int64).reshape(-1))
+    with np.errstate(over="ignore"):
+        h = int(((a.astype(np.uint64) + np.uint64(0x9E3779B97F4A7C15)) * (np.arange(a.size, dtype=np.uint64) * np.uint64(2) + np.uint64(1))).sum()
+                & np.uint64((1 << 62) - 1)) + a.size
+    dev = "cpu" if dist.get_backend(group) == "gloo" else torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor([h, -h], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    if int(t[0]) != -int(t[1]):
+        raise RuntimeError("ranks disagree on %s: the replicas' host RNG streams have drifted (seed random / numpy / torch / "
+                           "ogl_amd.sampling identically on every rank)" % what)
+
+
+def batch_shard(n, batch, rank, world):
+    """Rank's share of a pass over ``n`` seeds in batches of ``batch``: WHOLE batches of the one-rank pass, block-partitioned
+    (so every local batch is a batch of the one-rank pass, with that batch's sampler counter).  Returns
+    (first batch, last batch + 1, first seed position, last seed position + 1)."""
+    nb = -(-n // batch) if n > 0 else 0
+    b_lo, b_hi = shard_range(nb, rank, world)
+    return b_lo, b_hi, min(b_lo * batch, n), min(b_hi * batch, n)
+
+
+def partition_rows(n, world):
+    """Rows per rank of the vertex-range partition of an n-row table: equal blocks (a multiple of 32 rows), the last
+    ones short or empty — rank r owns rows [r * per, min((r + 1) * per, n))."""
+    per = -(-max(int(n), 1) // world)
+    return (per + 31) // 32 * 32
+
+
+def all_gather_row_blocks(full, per, group=None):
+    """The halo exchange of the partitioned-feature mode: ``full`` is a [world * per, D] table of which this rank has
+    written row block ``rank`` (rows [rank * per, (rank + 1) * per)); afterwards every rank holds every block — global row
+    order, no copy-back.  xGMI is point-to-point: one all-gather of a rank's 1 / world of the table (Reddit P0: 70 MB per
+    rank to each of 7 peers over 7 links in parallel)."""
+    rank, world = rank_world(group)
+    if world == 1:
+        return full
+    assert full.shape[0] == world * per
+    blocks = [full[r * per:(r + 1) * per] for r in range(world)]
+    if dist.get_backend(group) == "gloo" and full.is_cuda:                # gloo: through the host
+        mine = blocks[rank].cpu()
+        out = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(out, mine, group=group)
+        for r in range(world):
+            if r != rank:
+                blocks[r].copy_(out[r])
+        return full
+    dist.all_gather(blocks, blocks[rank], group=group)
+    return full
+
+
+def build_row_tables(n, widths, project, device, partition=True, padded_ld=None, group=None):
+    """Per-vertex tables of a pass (one [>= n, width] fp32 matrix per entry of ``widths``), each row a function of that
+    vertex's raw features only.  ``project(lo, hi, blocks)`` must fill ``blocks[k][: hi - lo]`` with the rows of
+    vertices [lo, hi).  One rank or ``partition=False``: one call over [0, n).  Otherwise — the partitioned-feature mode
+    — this rank projects ONLY its vertex range (``partition_rows``) in place into its block of the full tables and one
+    all-gather per table exchanges the blocks (``all_gather_row_blocks``): rows outside the range are the halo."""
+    rank, world = rank_world(group)
+    ld = padded_ld or (lambda c: c)
+    if world == 1 or not partition:
+        bufs = [torch.empty((max(n, 0), ld(w)), dtype=torch.float32, device=device) for w in widths]
+        views = [b[:, :w] for b, w in zip(bufs, widths)]
+        if n > 0:
+            project(0, n, views)
+        return views
+    per = partition_rows(n, world)
+    lo, hi = min(rank * per, n), min((rank + 1) * per, n)
+    bufs = [torch.empty((world * per, ld(w)), dtype=torch.float32, device=device) for w in widths]   # whole padded rows travel
+    views = [b[:, :w] for b, w in zip(bufs, widths)]
+    if hi > lo:
+        project(lo, hi, [v[lo:hi] for v in views])
+    for b in bufs:
+        all_gather_row_blocks(b, per, group)
+    return views
+
+
+def all_gather_counts(local, counts, group=None):
+    """all-gather(v) of 1-D tensors whose per-rank lengths ``counts`` every rank already knows; returns the concatenation
+    in rank order on ``local``'s device."""
+    rank, world = rank_world(group)
+    if world == 1:
+        return local
+    assert local.numel() == counts[rank], "local length does not match the agreed count"
+    mx = max(max(counts), 1)
+    dev = local.device
+    staged = dist.get_backend(group) == "gloo" and local.is_cuda          # gloo: through the host
+    pad = torch.zeros(mx, dtype=local.dtype, device="cpu" if staged else dev)
+    pad[:local.numel()] = local.cpu() if staged else local
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad, group=group)
+    return torch.cat([o[:c] for o, c in zip(out, counts)]).to(dev)
 
 
 def all_gather_sharded(local, full_sizes, group=None):

@@ -38,6 +38,15 @@ def _next_ctr() -> int:
     return c
 
 
+def reserve_ctrs(n: int):
+    """The next ``n`` batch counters.  A rank-sharded pass reserves the counters of ALL batches of the one-rank pass on
+    every rank and samples its own batches with theirs: the stream state after the pass — and every batch's draws — are
+    those of the one-rank run."""
+    c = _STATE["ctr"]
+    _STATE["ctr"] = c + int(n)
+    return list(range(c, c + int(n)))
+
+
 def get_state():
     return dict(_STATE)
 
@@ -106,17 +115,20 @@ class MultiLayerNeighborSampler:
         self.fanouts = [int(f) for f in fanouts]
         self.return_eids = return_eids
 
-    def sample_batches(self, graph, seed_batches, relabel_input=True):
+    def sample_batches(self, graph, seed_batches, relabel_input=True, ctrs=None):
         """Sample every batch, output layer first.  Returns a list of (input_nodes, seeds, blocks).
 
         ``relabel_input=False`` (inference against a cached layer-0 projection): the input block keeps only its
-        global ``picks`` — no hash relabel, no size read-back; ``input_nodes`` is then ``None``."""
+        global ``picks`` — no hash relabel, no size read-back; ``input_nodes`` is then ``None``.
+        ``ctrs``: the batches' Philox counters (default: the next ones of the stream, see ``reserve_ctrs``)."""
         g = graph.handle
         L = len(self.fanouts)
         nb = len(seed_batches)
+        if ctrs is None:
+            ctrs = reserve_ctrs(nb)
+        assert len(ctrs) == nb
         if nb == 0:
             return []
-        ctrs = [_next_ctr() for _ in seed_batches]
         blocks = [[None] * L for _ in seed_batches]
         # every batch of a layer goes through ONE sampler launch and ONE block-build sequence (batched C-ABI entry points):
         # batch b's destinations are dst_base[starts[b] : starts[b] + counts[b]]

@@ -227,10 +227,23 @@ def reduce_fwd(src, local_idx, op):
 # --------------------------------------------------------------------------------------------
 # Layers (torch CPU fp32).
 # --------------------------------------------------------------------------------------------
-def _neigh_torch(p, local_idx, op):
-    """Differentiable torch version of reduce_fwd (used for gradient parity)."""
+def _neigh_torch(p, local_idx, op, forced=None):
+    """Differentiable torch version of reduce_fwd (used for gradient parity).
+
+    ``forced`` (max only; tests of the full-size step): dict(argmax=int [n_dst, D] local source row of the winner the
+    DEVICE chose, -1 = none; mask=bool [n_dst, D] the device's ReLU mask of the pooled value).  ``p`` is then the
+    PRE-activation projection and the result is ``where(mask, p[argmax[d, c], c], 0)``: the same function of p wherever
+    the two evaluations agree on the winner, and on an fp32 near-tie (two candidates equal to the last bits, or a pooled
+    value within rounding of 0) the gradient is routed the way the device routed it instead of the way a second fp32
+    evaluation happens to break the tie.  relu is monotonic, so max_j relu(p_j) = relu(max_j p_j)."""
     li = torch.as_tensor(np.asarray(local_idx), dtype=torch.long)
     n_dst, S = li.shape
+    if forced is not None:
+        assert op == "max"
+        am = torch.as_tensor(np.asarray(forced["argmax"]), dtype=torch.long)
+        mask = torch.as_tensor(np.asarray(forced["mask"]), dtype=torch.bool) & (am >= 0)
+        picked = p.gather(0, am.clamp(min=0))
+        return torch.where(mask, picked, torch.zeros((), dtype=p.dtype))
     has = (li[:, 0] >= 0) if S > 0 else torch.zeros(n_dst, dtype=torch.bool)
     out = p.new_zeros((n_dst, p.shape[1]))
     if has.any():
@@ -251,7 +264,7 @@ def _neigh_torch(p, local_idx, op):
     return out
 
 
-def sageconv_forward(mode, h_src, n_dst, local_idx, params, activation=None):
+def sageconv_forward(mode, h_src, n_dst, local_idx, params, activation=None, forced=None, dropout=None):
     """One SAGEConv layer on a fixed-fanout block.
 
     mode ``pool``      — live DGL layer (max; fc_pool in->in; fc_self + fc_neigh).
@@ -259,12 +272,22 @@ def sageconv_forward(mode, h_src, n_dst, local_idx, params, activation=None):
     (fc_pool in->pool_feats; ``fc_neigh(cat(h_self, h_neigh))``; gcn: ``(sum + h_dst)/(deg+1)``).
     ``params``: dict of torch tensors named like the reference state_dict
     (fc_pool.weight, fc_pool.bias, fc_self.*, fc_neigh.*).
+    ``forced`` (mode ``pool`` only): the device's winners / ReLU masks, see :func:`_neigh_torch`; an optional
+    ``act_mask`` replaces the output ReLU by the device's mask of it.
+    ``dropout``: dict(p, seed, ctr) — ``feat_drop`` on the layer input (R/.../graphsage_dgl.py:41 passes
+    ``feat_drop=dropout``), with the counter-based mask of :func:`dropout_mask`.
     """
+    if dropout is not None and dropout["p"] > 0:
+        keep = torch.as_tensor(dropout_mask(h_src.shape[0], h_src.shape[1], dropout["p"], dropout["seed"], dropout["ctr"]))
+        h_src = torch.where(keep, h_src / np.float32(1.0 - dropout["p"]), torch.zeros((), dtype=h_src.dtype))
     h_dst = h_src[:n_dst]
     li = np.asarray(local_idx)
     if mode == "pool":
-        p = F.relu(F.linear(h_src, params["fc_pool.weight"], params["fc_pool.bias"]))
-        neigh = _neigh_torch(p, li, "max")
+        pre = F.linear(h_src, params["fc_pool.weight"], params["fc_pool.bias"])
+        if forced is not None:
+            neigh = _neigh_torch(pre, li, "max", forced)
+        else:
+            neigh = _neigh_torch(F.relu(pre), li, "max")
         rst = F.linear(h_dst, params["fc_self.weight"], params["fc_self.bias"]) + \
             F.linear(neigh, params["fc_neigh.weight"], params["fc_neigh.bias"])
     elif mode in ("meanpool", "maxpool"):
@@ -283,18 +306,45 @@ def sageconv_forward(mode, h_src, n_dst, local_idx, params, activation=None):
     else:
         raise KeyError("Aggregator type {} not recognized.".format(mode))
     if activation is not None:
-        rst = activation(rst)
+        if forced is not None and forced.get("act_mask") is not None:
+            rst = torch.where(torch.as_tensor(np.asarray(forced["act_mask"]), dtype=torch.bool), rst,
+                              torch.zeros((), dtype=rst.dtype))
+        else:
+            rst = activation(rst)
     return rst
 
 
-def graphsage_forward(mode, x, blocks, layer_params):
-    """R/train/graphsage/pytorch/graphsage_dgl.py:48-59 — relu on every layer but the last."""
+def graphsage_forward(mode, x, blocks, layer_params, forced=None, dropout=None):
+    """R/train/graphsage/pytorch/graphsage_dgl.py:48-59 — relu on every layer but the last.
+    ``forced`` / ``dropout``: per-layer lists (entries may be None), see :func:`sageconv_forward`."""
     h = x
     L = len(layer_params)
     for l, (blk, prm) in enumerate(zip(blocks, layer_params)):
         h = sageconv_forward(mode, h, len(blk["dst_ids"]), blk["local_idx"], prm,
-                             activation=F.relu if l < L - 1 else None)
+                             activation=F.relu if l < L - 1 else None,
+                             forced=forced[l] if forced is not None else None,
+                             dropout=dropout[l] if dropout is not None else None)
     return h
+
+
+def dropout_mask(rows, cols, p, seed, ctr):
+    """keep[i, j] of the counter-based dropout the HIP path uses for ``feat_drop`` (ogl_dropout_rows): Philox4x32-10 with
+    counter (j >> 2, i_lo32, i_hi32, ctr_lo32), key (seed_lo32, seed_hi32 ^ ctr_hi32) — the sampler's keying with the
+    output row in place of the vertex id —, word j & 3 is the 32-bit draw r; keep iff r >= floor(p * 2**32).
+    (torch's nn.Dropout draws from an unseeded-by-the-reference global stream, R/train/__main__.py:211-212; only the
+    distribution — Bernoulli(1 - p), scaled by 1 / (1 - p) — is the reference's.)"""
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    ctr = int(ctr) & 0xFFFFFFFFFFFFFFFF
+    k0 = seed & 0xFFFFFFFF
+    k1 = ((seed >> 32) ^ (ctr >> 32)) & 0xFFFFFFFF
+    j = np.arange(cols, dtype=np.uint64)[None, :]
+    i = np.arange(rows, dtype=np.uint64)[:, None]
+    z = np.zeros((rows, cols), dtype=np.uint64)
+    r = philox4x32_10((j >> np.uint64(2)) + z, (i & _MASK32) + z, (i >> np.uint64(32)) + z, np.uint64(ctr & 0xFFFFFFFF), k0, k1)
+    word = (np.arange(cols) & 3)[None, :] + np.zeros((rows, 1), dtype=np.int64)
+    r32 = np.choose(word, r).astype(np.uint64)
+    thr = np.uint64(min(int(float(p) * 4294967296.0), 0xFFFFFFFF))
+    return r32 >= thr
 
 
 def cross_entropy(logits, labels, reduction="mean"):
@@ -362,16 +412,80 @@ class CpuModel:
                 prm[k].requires_grad_(True)
         self.opt = torch.optim.Adam([t for prm in self.params for t in prm.values()], lr=1e-3)
 
-    def forward(self, x, blocks):
-        return graphsage_forward(self.mode, x, blocks, self.params)
+    def forward(self, x, blocks, forced=None, dropout=None):
+        return graphsage_forward(self.mode, x, blocks, self.params, forced=forced, dropout=dropout)
 
-    def train_step(self, feat, labels, indptr, indices, deg_t, seeds, fanout, seed, ctr):
+    def train_step(self, feat, labels, indptr, indices, deg_t, seeds, fanout, seed, ctr, forced=None):
         input_nodes, seeds, blocks = sample_blocks(indptr, indices, deg_t, seeds, [fanout, fanout], seed, ctr)
         x = feat[torch.as_tensor(input_nodes)]
         y = labels[torch.as_tensor(seeds)]
         self.opt.zero_grad()
-        logits = self.forward(x, blocks)
+        logits = self.forward(x, blocks, forced=forced)
         loss = cross_entropy(logits, y, "mean")
         loss.backward()
         self.opt.step()
         return float(loss.detach())
+
+    def seed_losses(self, feat, labels, indptr, indices, deg_t, seeds, fanout, seed, ctr):
+        """Per-seed CE (reduction='none') of ONE inference batch: the body of the PBR priority forward,
+        R/train/graphsage/pytorch/model.py:229-248 (the reference builds and discards an autograd graph; no_grad here).
+        Returns (losses float32 [B], logits [B, C])."""
+        input_nodes, seeds, blocks = sample_blocks(indptr, indices, deg_t, seeds, [fanout, fanout], seed, ctr)
+        with torch.no_grad():
+            logits = self.forward(feat[torch.as_tensor(input_nodes)], blocks)
+            rows = cross_entropy(logits, labels[torch.as_tensor(seeds)], "none")
+        return rows.numpy(), logits.numpy()
+
+
+# --------------------------------------------------------------------------------------------
+# Vertex-stream snapshots on the host + the no-rehearsal loop (BASELINE config 1: "Pubmed pytorch CPU,
+# no-rehearsal, depth=2 samples=10 batch=32 (plumbing, no GPU)").
+# --------------------------------------------------------------------------------------------
+class HostVertexStream:
+    """Snapshots of a vertex stream as the reference forms them (R/train/graph/dynamic_graph_vertex.py:39-94,132-141):
+    vertices sorted by timestamp, chunked into ``snapshots`` groups of ``N // snapshots``; snapshot t is the induced
+    subgraph on the first t groups, vertex ids = positions in the time-sorted list.  Restated as ONE arrival-ordered CSR
+    (in-neighbour lists sorted by arrival id) + ``n_present(t)``; ``deg(t)`` is the prefix-degree cut."""
+
+    def __init__(self, n, src, dst, order, snapshots, feat, labels):
+        order = np.asarray(order, dtype=np.int64)            # arrival position -> original id
+        inv = np.empty(n, dtype=np.int64)
+        inv[order] = np.arange(n)
+        s = np.concatenate([inv[np.asarray(src)], inv[np.asarray(dst)]])      # both directions, arrival ids
+        d = np.concatenate([inv[np.asarray(dst)], inv[np.asarray(src)]])
+        o = np.lexsort((s, d))                               # rows by dst, neighbours ascending inside a row
+        self.indices = s[o].astype(np.int32)
+        self.indptr = np.concatenate([[0], np.cumsum(np.bincount(d, minlength=n))]).astype(np.int64)
+        self.n, self.order = n, order
+        self.per = int(n / snapshots)
+        self.feat = torch.as_tensor(np.asarray(feat))[torch.as_tensor(order)].float().contiguous()
+        self.labels = torch.as_tensor(np.asarray(labels).reshape(-1)[order]).reshape(-1, 1)
+        self.t = 1
+
+    @property
+    def n_present(self):
+        return min(self.t * self.per, self.n)
+
+    def arrivals(self):
+        """Snapshot ids of the vertices added by the latest snapshot."""
+        return np.arange((self.t - 1) * self.per, self.n_present, dtype=np.int64)
+
+    def degrees(self):
+        return snapshot_degrees_fast(self.indptr, self.indices, self.n_present, self.n_present)
+
+    def evolve(self):
+        self.t += 1
+
+
+def no_rehearsal_stream(stream, model, fanout, seeds_per_snapshot, seed, ctr0=0):
+    """The no-rehearsal strategy's loop body over consecutive snapshots (R/train/graphsage/pytorch/model.py:300-323 +
+    R/train/__main__.py:161-196): per snapshot ONE batch of the newly arrived train vertices (``seeds_per_snapshot[t]``,
+    snapshot ids, in the order the loader sees them — the reference shuffles them with an unseeded RNG, so the caller
+    fixes the order), sampled at ``[fanout, fanout]``, one Adam step; then ``evolve``.  Returns the per-snapshot losses."""
+    losses = []
+    for t, sd in enumerate(seeds_per_snapshot):
+        if len(sd) >= 2:                                     # the reference returns early below two new nodes (:308-309)
+            losses.append(model.train_step(stream.feat, stream.labels, stream.indptr, stream.indices, stream.degrees(),
+                                           np.asarray(sd, dtype=np.int64), fanout, seed, ctr0 + len(losses)))
+        stream.evolve()
+    return losses

@@ -175,7 +175,7 @@ def test_cached_projection_inference_matches_per_batch(pkg, mode, pool):
         sampling.seed(21)
         ref = [model(b, GatheredRows(g.ndata["feat"], i)) for i, _, b in sampling.NodeDataLoader(g, seeds, smp, batch_size=64)]
         sampling.seed(21)
-        proj = model.layers[0].project_table(g.ndata["feat"])
+        proj = model.layers[0].project_tables(g.ndata["feat"])
         got = []
         for i, sd, b in sampling.NodeDataLoader(g, seeds, smp, batch_size=64, relabel_input=False):
             assert i is None and b[0].local_idx is None and b[0].picks.shape == (b[1].number_of_src_nodes(), 6)

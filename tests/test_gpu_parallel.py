@@ -99,3 +99,96 @@ def test_two_ranks_match_one_rank(tmp_path):
             torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(a["prio"], b["prio"], rtol=1e-4, atol=1e-6)
     assert np.isfinite(b["prio_all"]).all() and len(b["prio_all"]) == len(a["prio_all"])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json config 5 at the Reddit size on two ranks sharing the one GPU: the sharded priority forward (replicated
+# tables AND the partitioned-feature mode with its halo all-gather) and one sharded PBR train update, against one rank.
+# ------------------------------------------------------------------------------------------------------------------
+def _run_reddit(rank, world, port, out_path, partition):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops, sampling, synthetic
+    from ogl_amd.graph import TrainTestGraph
+    from ogl_amd.prioritized_replay import LossPriority
+    from ogl_amd.utils import Lib_supported, init
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    np.random.seed(3); random.seed(3); torch.manual_seed(3); sampling.seed(3)
+    GraphSAGE, Random, Prioritized, NoReh, Full, act = init(Lib_supported.HIP, True, 0)
+    feat_size, labels, graph, n_classes, _ = synthetic.load("reddit", snapshots=2, device="cuda")
+    gu = TrainTestGraph(graph, split=0.15, start_prior_alpha=4, end_prior_alpha=50, scale=1, max_priority=10)
+    graph.evolve()                                                    # the full graph; nothing more is admitted
+    ops.set_gemm_mode("auto")
+    model = GraphSAGE(feat_size, 600, n_classes, 1, act, 0, "pool", edge_feats=0, pool_feats=600).cuda()
+    pri = Prioritized(model, 2, 512, labels, 25, LossPriority(), cuda=True, full_pass=1, batch_full=1024)
+    pri.build_optimizer()
+    pri.partition_features = partition
+    pri.optimizer = torch.optim.SGD(model.parameters(), lr=0.05)
+    train = np.asarray(sorted(gu.get_train_set()))
+    seen = []
+    inner = gu.update_priorities_arrays
+    gu.update_priorities_arrays = lambda ids, pr: (seen.append((np.asarray(ids).copy(), np.asarray(pr).copy())), inner(ids, pr))
+    # A — the priority forward on the initial weights (identical on every run): 2 full batches + a ragged one
+    subset = train[:2 * 1024 + 100]
+    sampling.seed(5)
+    pri.recompute_priorities(gu, list(subset))
+    ids_a, loss_a = seen[-1]
+    assert np.array_equal(ids_a, subset)
+    state_after_a = sampling.get_state()
+    # B — one PBR train update: 2 batches of 512, every batch cut over the ranks
+    id2s, s2id = gu.get_original_to_subgraph_map(), gu.get_subgraph_to_original_map()
+    fixed = train[5000:5000 + 1024]
+    sampling.seed(6)
+    pri._run_custom_train(graph.get_graph(), s2id, id2s, id2s[fixed], gu)
+    res = dict(loss_a=loss_a, weights=[p.detach().cpu().clone() for p in model.parameters()],
+               prio=np.asarray(gu.dump_priorities(list(fixed))), ctr_a=state_after_a["ctr"], ctr_b=sampling.get_state()["ctr"])
+    # C — the forward again on the updated weights
+    sampling.seed(7)
+    pri.recompute_priorities(gu, list(subset))
+    res["loss_c"] = seen[-1][1]
+    if world > 1:
+        mine = torch.cat([torch.as_tensor(res["loss_c"], dtype=torch.float64), torch.as_tensor(res["prio"], dtype=torch.float64)]
+                         + [p.reshape(-1).double() for p in res["weights"]])
+        other = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(other, mine)
+        assert all(torch.equal(o, other[0]) for o in other)          # every replica: same weights, same buffer
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        torch.save(res, out_path)
+
+
+def _spawn(target, world, args):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + args) for r in range(world)]
+    for q in procs:
+        q.start()
+    for q in procs:
+        q.join(900)
+    assert [q.exitcode for q in procs] == [0] * world
+
+
+def test_reddit_pbr_two_ranks_replicated_and_partitioned(tmp_path):
+    one, rep, par = (str(tmp_path / n) for n in ("one.pt", "rep.pt", "par.pt"))
+    _spawn(_run_reddit, 1, (one, False))
+    _spawn(_run_reddit, 2, (rep, False))
+    _spawn(_run_reddit, 2, (par, True))
+    a, b, c = (torch.load(p, weights_only=False) for p in (one, rep, par))
+    assert len(a["loss_a"]) == 2 * 1024 + 100 and np.isfinite(a["loss_a"]).all()
+    # whole batches with their one-rank sampler counters, row-independent projections: the sharded passes reproduce the
+    # one-rank losses BIT FOR BIT, whether the tables were built locally or per vertex range + halo all-gather
+    assert np.array_equal(a["loss_a"], b["loss_a"]) and np.array_equal(a["loss_a"], c["loss_a"])
+    # the sampler stream ends every pass in the one-rank state
+    assert a["ctr_a"] == b["ctr_a"] == c["ctr_a"] == 3 and a["ctr_b"] == b["ctr_b"] == c["ctr_b"] == 2
+    for other in (b, c):
+        for x, y in zip(a["weights"], other["weights"]):
+            torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-5)     # the sharded update: fp32 summation order only
+        np.testing.assert_allclose(a["prio"], other["prio"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(a["loss_c"], other["loss_c"], rtol=1e-3, atol=1e-5)
+    assert np.array_equal(b["loss_c"], c["loss_c"]) or np.allclose(b["loss_c"], c["loss_c"], rtol=1e-5, atol=1e-6)

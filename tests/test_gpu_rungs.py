@@ -1,0 +1,319 @@
+"""Oracle parity on the BASELINE.json rungs the toy / Reddit-RBR tests do not reach (run with -m gpu):
+
+  config 1  pubmed-like, no-rehearsal, S=10, B=32 — the strategy class against the oracle's loop over 3 snapshots
+            (its CPU half is tests/test_config1_cpu.py);
+  config 2  pubmed-like RBR, S=25, B=32, batch_timestep=2 (R/settings/pubmed.json:1: F=500 / H=32 / C=3);
+  config 3  arxiv-like PBR, S=25: RBR-shaped train steps at B=32 AND the priority forward at batch_full=1024
+            (R/settings/arxiv.json:1: F=128 / H=32 / C=40), cached and uncached;
+  config 4/5 the priority forward at the Reddit size (>= 2 batches of 1024), cached and uncached
+            (the 2-rank form of config 5 is tests/test_gpu_parallel.py).
+
+The priority forward (SURVEY §8 a8, R/train/graphsage/pytorch/model.py:210-254) is checked end to end: per-seed losses
+against the oracle (rtol 1e-4), then LossPriority -> TrainTestGraph.update_priorities_arrays -> dump_priorities against
+the reference-semantics buffer (golden-pinned dict API) fed with the ORACLE's losses.
+
+Tolerances: as tests/test_gpu_model.py — logits rtol 1e-4 / atol 1e-5, losses rtol 1e-4, gradients rtol 1e-3 / atol 1e-5,
+weights after Adam rtol 1e-4 / atol 1e-5; sampled ids bit-exact.
+"""
+import copy
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RUNGS = {
+    #          hidden  train batch  batch_timestep
+    "pubmed": dict(H=32, B=32, bt=2),
+    "arxiv": dict(H=32, B=32, bt=1),
+    "reddit": dict(H=600, B=512, bt=50),
+}
+
+
+def _copy_params(model, layer_params):
+    with torch.no_grad():
+        for l, prm in zip(model.layers, layer_params):
+            for k, v in prm.items():
+                mod, attr = k.split(".")
+                getattr(getattr(l, mod), attr).copy_(v.detach())
+
+
+def _host_csr(g):
+    h = g.handle
+    keys = (h.keys if h.keys is not None else h.indices).cpu().numpy()
+    return h.indptr.cpu().numpy(), h.indices.cpu().numpy(), keys
+
+
+@pytest.fixture(scope="module")
+def streams():
+    """name -> (arrays, labels, dynamic graph with few, large snapshots) built lazily, once per module."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import synthetic
+    cache = {}
+
+    def get(name, snapshots):
+        key = (name, snapshots)
+        if key not in cache:
+            a = synthetic.make_arrays(name)
+            feat_size, labels, dyn, n_classes, _ = synthetic.load(name, snapshots=snapshots, device="cuda")
+            cache[key] = (a, labels, dyn, feat_size, n_classes)
+        return cache[key]
+    return get
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# configs 2 / 3: RBR-shaped train steps through the strategy class
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("gemm", ["f32", "auto"])
+@pytest.mark.parametrize("name", ["pubmed", "arxiv"])
+def test_rbr_train_steps_match_oracle(streams, name, gemm):
+    from ogl_amd import ops, sampling
+    from ogl_amd.graphsage import GraphSAGE
+    from ogl_amd.graphsage.model import RandomHipSupervisedGraphSage
+    cfg = RUNGS[name]
+    a, labels, dyn, feat_size, n_classes = streams(name, 4)
+    while dyn.evolution_index < 3:                   # 3 of 4 snapshot groups present: a real prefix-degree cut
+        dyn.evolve()
+    g = dyn.get_graph()
+    indptr, indices, keys = _host_csr(g)
+    deg = O.snapshot_degrees_fast(indptr, keys, g.n_present, g.cut)
+    assert 0 < g.n_present < g.n_total
+    ops.set_gemm_mode(gemm)
+    try:
+        cpu = O.CpuModel("pool", feat_size, cfg["H"], n_classes, seed=7)
+        model = GraphSAGE(feat_size, cfg["H"], n_classes, 1, F.relu, 0, "pool", edge_feats=0, pool_feats=cfg["H"]).cuda()
+        _copy_params(model, cpu.params)
+        strat = RandomHipSupervisedGraphSage(model, cfg["bt"], cfg["B"], labels, 25, cuda=True, batch_full=1024)
+        strat.build_optimizer()
+        seeds = np.random.default_rng(3).choice(g.n_present, cfg["B"] * cfg["bt"], replace=False).astype(np.int64)
+        rec = []
+        inner = strat.train_step
+
+        def spy(graph, blocks, input_nodes, sd, s2id, n_global=None):
+            loss = inner(graph, blocks, input_nodes, sd, s2id, n_global)
+            rec.append(dict(loss=float(loss), seeds=sd.cpu().numpy(), n0=input_nodes.numel(),
+                            grads=[p.grad.detach().cpu().clone() for p in model.parameters()]))
+            return loss
+        strat.train_step = spy
+        sampling.seed(13)
+        strat._run_custom_train(g, dyn.get_subgraph_to_original_map(), dyn.get_original_to_subgraph_map(), seeds, None)
+        assert len(rec) == cfg["bt"]
+        feat_cpu = g.ndata["feat"].cpu().contiguous()
+        lab_cpu = g.ndata["target"].cpu()
+        names = [n for n, _ in model.named_parameters()]
+        for ctr, r in enumerate(rec):
+            assert np.array_equal(r["seeds"], seeds[ctr * cfg["B"]:(ctr + 1) * cfg["B"]])
+            in_ref, _, _ = O.sample_blocks(indptr, indices, deg, r["seeds"], [25, 25], 13, ctr)
+            assert len(in_ref) == r["n0"]
+            loss_ref = cpu.train_step(feat_cpu, lab_cpu, indptr, indices, deg, r["seeds"], 25, 13, ctr)
+            assert abs(r["loss"] - loss_ref) <= 1e-4 * abs(loss_ref), (ctr, r["loss"], loss_ref)
+            ref_grads = {"layers.%d.%s" % (li, k): v.grad for li, prm in enumerate(cpu.params) for k, v in prm.items()}
+            for n_, got in zip(names, r["grads"]):
+                np.testing.assert_allclose(got.numpy(), ref_grads[n_].numpy(), rtol=1e-3, atol=1e-5, err_msg="%s step %d" % (n_, ctr))
+        for li, prm in enumerate(cpu.params):
+            for k, v in prm.items():
+                mod, attr = k.split(".")
+                np.testing.assert_allclose(getattr(getattr(model.layers[li], mod), attr).detach().cpu().numpy(),
+                                           v.detach().numpy(), rtol=1e-4, atol=1e-5)
+    finally:
+        ops.set_gemm_mode("f32")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# a8: the PBR priority forward, losses -> priorities -> buffer
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cached", [True, False])
+@pytest.mark.parametrize("name,n_seeds", [("arxiv", 3 * 1024 + 77), ("reddit", 2 * 1024 + 100)])
+def test_priority_forward_matches_oracle(streams, name, n_seeds, cached):
+    from ogl_amd import ops, sampling
+    from ogl_amd.graph import TrainTestGraph
+    from ogl_amd.graphsage import GraphSAGE
+    from ogl_amd.graphsage.model import PrioritizedHipSupervisedGraphSage
+    from ogl_amd.prioritized_replay import LossPriority
+    cfg = RUNGS[name]
+    a, labels, dyn, feat_size, n_classes = streams(name, 2)
+    np.random.seed(5); random.seed(5)
+    # a fresh replay state over the latest of two snapshot groups (thousands of train vertices); the graph itself is
+    # moved to its last snapshot without admitting anything more: the forward runs on the full graph
+    gu = TrainTestGraph(dyn, split=0.15, start_prior_alpha=4, end_prior_alpha=50, scale=1, max_priority=10)
+    if dyn.evolution_index < 2:
+        dyn.evolve()
+    g = dyn.get_graph()
+    assert dyn.evolution_index == 2
+    train = np.asarray(gu.get_train_set())
+    assert len(train) > n_seeds
+    subset = np.sort(np.random.default_rng(9).choice(train, n_seeds, replace=False))
+    ops.set_gemm_mode("auto")
+    try:
+        cpu = O.CpuModel("pool", feat_size, cfg["H"], n_classes, seed=11)
+        model = GraphSAGE(feat_size, cfg["H"], n_classes, 1, F.relu, 0, "pool", edge_feats=0, pool_feats=cfg["H"]).cuda()
+        _copy_params(model, cpu.params)
+        strat = PrioritizedHipSupervisedGraphSage(model, cfg["bt"], cfg["B"], labels, 25, LossPriority(), full_pass=1,
+                                                  cuda=True, batch_full=1024)
+        strat.cache_projection = cached
+        before = copy.deepcopy(gu.priority_replay_buffer)
+        rest = np.setdiff1d(train, subset)[:50]
+        rest_before = np.asarray(before.dump_priorities(list(rest)))
+        seen = {}
+        inner = gu.update_priorities_arrays
+        gu.update_priorities_arrays = lambda ids, pr: (seen.update(ids=np.asarray(ids).copy(), pr=np.asarray(pr).copy()), inner(ids, pr))
+        used = []
+        orig_tables = strat._projection_tables
+        strat._projection_tables = lambda *args: (used.append(1), orig_tables(*args))[1]
+        sampling.seed(21)
+        strat.recompute_priorities(gu, list(subset))
+        assert bool(used) == cached                      # the pass really took the path under test
+        # oracle: the same batches of batch_full seeds, the same Philox counters
+        id2s = gu.get_original_to_subgraph_map()
+        sub_ids = np.asarray(id2s[list(subset)], dtype=np.int64)
+        indptr, indices, keys = _host_csr(g)
+        deg = O.snapshot_degrees_fast(indptr, keys, g.n_present, g.cut)
+        feat_cpu = g.ndata["feat"].cpu().contiguous()
+        lab_cpu = g.ndata["target"].cpu()
+        want = np.concatenate([cpu.seed_losses(feat_cpu, lab_cpu, indptr, indices, deg, sub_ids[s:s + 1024], 25, 21, b)[0]
+                               for b, s in enumerate(range(0, n_seeds, 1024))])
+        assert np.array_equal(seen["ids"], subset) and seen["pr"].dtype == np.float64
+        np.testing.assert_allclose(seen["pr"], want, rtol=1e-4, atol=1e-6)
+        # losses -> LossPriority (identity, R/train/prioritized_replay/generate_priority.py:7-9) -> buffer: the same
+        # update through the golden-pinned dict API, fed with the oracle's losses
+        ref_buf = before
+        ref_buf.update_priorities({int(k): float(v) for k, v in zip(subset, want)})
+        got_pr = np.asarray(gu.dump_priorities(list(subset)))
+        want_pr = np.asarray(ref_buf.dump_priorities(list(subset)))
+        # d(priority) = alpha v^(alpha-1) dv with v = (log loss - lo) / scale in [0, 1]: a 1e-4 relative loss error moves
+        # a priority by at most alpha * 1e-4 / scale
+        scale = ref_buf._max_priority - ref_buf._min_priority
+        np.testing.assert_allclose(got_pr, want_pr, rtol=0, atol=ref_buf._alpha * 1e-4 / scale + 1e-12)
+        assert gu.priority_replay_buffer.get_max_priority() == pytest.approx(ref_buf.get_max_priority(), rel=1e-4)
+        # untouched entries keep their admission priority
+        assert np.array_equal(np.asarray(gu.dump_priorities(list(rest))), rest_before)
+    finally:
+        ops.set_gemm_mode("f32")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# config 1 (GPU twin of tests/test_config1_cpu.py): the no-rehearsal strategy over 3 snapshots
+# ------------------------------------------------------------------------------------------------------------------
+def test_no_rehearsal_pubmed_matches_oracle_loop():
+    import ogl_amd  # noqa: F401
+    from ogl_amd import sampling, synthetic
+    from ogl_amd.graph import TrainTestGraph
+    from ogl_amd.graphsage import GraphSAGE
+    from ogl_amd.graphsage.model import NoRehHipSupervisedGraphSage
+    np.random.seed(2); random.seed(2); torch.manual_seed(2); sampling.seed(31)
+    feat_size, labels, dyn, n_classes, _ = synthetic.load("pubmed", device="cuda")        # 400 snapshots of 49 vertices
+    a = synthetic.make_arrays("pubmed")
+    gu = TrainTestGraph(dyn, split=0.15, start_prior_alpha=4, end_prior_alpha=50, scale=1, max_priority=10)
+    cpu = O.CpuModel("pool", feat_size, 32, n_classes, seed=4)
+    model = GraphSAGE(feat_size, 32, n_classes, 1, F.relu, 0, "pool", edge_feats=0, pool_feats=32).cuda()
+    _copy_params(model, cpu.params)
+    strat = NoRehHipSupervisedGraphSage(model, 1, 32, labels, 10, cuda=True, batch_full=1024)      # S=10, B=32: config 1
+    strat.build_optimizer()
+    rec = []
+    inner = strat.train_step
+
+    def spy(graph, blocks, input_nodes, sd, s2id, n_global=None):
+        loss = inner(graph, blocks, input_nodes, sd, s2id, n_global)
+        rec.append((sd.cpu().numpy(), float(loss)))
+        return loss
+    strat.train_step = spy
+    for _ in range(3):
+        strat.train_timestep(gu)
+        gu.evolve()
+    assert len(rec) == 3 and all(len(sd) == 32 for sd, _ in rec)
+    stream = O.HostVertexStream(a["n"], a["src"], a["dst"], a["order"], a["snapshots"], a["feat"], a["labels"])
+    # the strategy's seeds are snapshot ids of that snapshot's arrivals (new TRAIN vertices only)
+    for t, (sd, _) in enumerate(rec):
+        assert sd.min() >= t * stream.per and sd.max() < (t + 1) * stream.per
+    want = O.no_rehearsal_stream(stream, cpu, 10, [sd for sd, _ in rec], 31)
+    np.testing.assert_allclose([l for _, l in rec], want, rtol=1e-4)
+    for li, prm in enumerate(cpu.params):
+        for k, v in prm.items():
+            mod, attr = k.split(".")
+            np.testing.assert_allclose(getattr(getattr(model.layers[li], mod), attr).detach().cpu().numpy(),
+                                       v.detach().numpy(), rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# dropout > 0 (a live CLI knob: R/train/__main__.py:36,124) on the fused-gather input and on the hidden layer
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fuse", [True, False])
+def test_dropout_train_step_matches_oracle(fuse):
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops, optim, sampling, synthetic
+    from ogl_amd.graphsage import GatheredRows, GraphSAGE
+    feat_size, _, dyn, n_classes, _ = synthetic.load("toy", device="cuda")
+    for _ in range(8):
+        dyn.evolve()
+    g = dyn.get_graph()
+    p = 0.3
+    cpu = O.CpuModel("pool", feat_size, 16, n_classes, seed=5)
+    model = GraphSAGE(feat_size, 16, n_classes, 1, F.relu, p, "pool").cuda()
+    _copy_params(model, cpu.params)
+    opt = optim.Adam(model.parameters(), lr=1e-3)
+    indptr, indices, keys = _host_csr(g)
+    deg = O.snapshot_degrees_fast(indptr, keys, g.n_present, g.cut)
+    feat_cpu, lab_cpu = g.ndata["feat"].cpu().contiguous(), g.ndata["target"].cpu()
+    sampling.seed(3); ops.dropout_seed(17)
+    seeds = torch.as_tensor(np.random.default_rng(1).permutation(g.n_present)[:96].astype(np.int64))
+    model.train()
+    for ctr, (input_nodes, sd, blocks) in enumerate(sampling.NodeDataLoader(g, seeds, sampling.MultiLayerNeighborSampler([7, 7]), batch_size=48)):
+        x = GatheredRows(g.ndata["feat"], input_nodes) if fuse else ops.gather_rows(g.ndata["feat"], input_nodes)
+        opt.zero_grad()
+        logits = model(blocks, x)
+        loss = ops.cross_entropy(logits, ops.gather_i64(g.ndata["target"], sd), "mean")
+        loss.backward()
+        in_ref, _, blocks_ref = O.sample_blocks(indptr, indices, deg, sd.cpu().numpy(), [7, 7], 3, ctr)
+        cpu.opt.zero_grad()
+        drop = [dict(p=p, seed=17, ctr=2 * ctr), dict(p=p, seed=17, ctr=2 * ctr + 1)]
+        logits_ref = cpu.forward(feat_cpu[torch.as_tensor(in_ref)], blocks_ref, dropout=drop)
+        O.cross_entropy(logits_ref, lab_cpu[sd.cpu()], "mean").backward()
+        np.testing.assert_allclose(logits.detach().cpu().numpy(), logits_ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+        for l, prm in zip(model.layers, cpu.params):
+            for k, v in prm.items():
+                mod, attr = k.split(".")
+                np.testing.assert_allclose(getattr(getattr(l, mod), attr).grad.cpu().numpy(), v.grad.numpy(), rtol=1e-3, atol=1e-5)
+        opt.step(); cpu.opt.step()
+    # the mask itself: bit-exact against the oracle's Philox statement, rate ~ p, eval mode applies none
+    xs = torch.randn(300, 37).cuda()
+    got = ops.dropout_rows(xs, p, 17, 5)
+    keep = O.dropout_mask(300, 37, p, 17, 5)
+    want = np.where(keep, xs.cpu().numpy() / np.float32(1.0 - p), np.float32(0))
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert abs(1.0 - keep.mean() - p) < 0.02
+    model.eval()
+    with torch.no_grad():
+        sampling.seed(3)
+        (i1, s1, b1), = list(sampling.NodeDataLoader(g, seeds[:48], sampling.MultiLayerNeighborSampler([7, 7]), batch_size=48))
+        e1 = model(b1, GatheredRows(g.ndata["feat"], i1))
+        e2 = model(b1, GatheredRows(g.ndata["feat"], i1))
+    assert torch.equal(e1, e2)
+
+
+def test_torch_ops_namespace():
+    """The C-ABI entry points are reachable as torch.ops.ogl.* custom ops, with autograd through the HIP backward."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    x = torch.randn(70, 24).cuda().requires_grad_(True)
+    w = torch.randn(9, 24).cuda().requires_grad_(True)
+    b = torch.randn(9).cuda().requires_grad_(True)
+    y = torch.ops.ogl.linear(x, w, b, relu=True)
+    ref = F.relu(F.linear(x.detach().cpu(), w.detach().cpu(), b.detach().cpu()))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
+    y.sum().backward()
+    xr = x.detach().cpu().requires_grad_(True)
+    F.relu(F.linear(xr, w.detach().cpu(), b.detach().cpu())).sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-3, atol=1e-5)
+    idx = torch.randint(0, 70, (11, 5), dtype=torch.int32).cuda()
+    out, arg = torch.ops.ogl.reduce_fwd(y.detach(), idx, "max", True)
+    want, warg = O.reduce_fwd(y.detach().cpu().numpy(), idx.cpu().numpy(), "max")
+    assert np.array_equal(out.cpu().numpy(), want) and np.array_equal(arg.cpu().numpy(), warg)
+    assert torch.equal(torch.ops.ogl.gather_rows(y.detach(), torch.tensor([3, 0]).cuda()), y.detach()[[3, 0]])
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.ogl.gather_rows(torch.zeros(3, 4), torch.zeros(2, dtype=torch.int64))     # no CPU kernel, no fallback
+    assert ops.get_gemm_mode() == "f32"

@@ -156,3 +156,207 @@ def test_all_gather_sharded_restores_seed_order(tmp_path, world):
     # one rank: the identity
     assert [t.tolist() for t in parallel.all_gather_sharded([torch.arange(3.0)], [3])] == [[0.0, 1.0, 2.0]]
     assert parallel.rank_world() == (0, 1) and not parallel.is_distributed()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GradSynchronizer under unequal local histories (the collectives must stay matched): a rank that accumulates two
+# backward passes before sync(), a rank without any backward (no seeds in its shard), no_sync() accumulation.
+# ------------------------------------------------------------------------------------------------------------------
+def _worker_unequal(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    indptr, indices, deg_t, feat, labels, seeds, F, C = _problem()
+    model = O.CpuModel("pool", F, 8, C, seed=3)
+    params = model.opt.param_groups[0]["params"]
+    sync = parallel.GradSynchronizer(params, overlap=True, weight=1.0)
+    mine = parallel.shard_seeds(seeds[:36])
+
+    def backward(ctr, reset):
+        input_nodes, sd, blocks = O.sample_blocks(indptr, indices, deg_t, mine, [5, 5], 9, ctr)
+        rows = O.cross_entropy(model.forward(feat[torch.as_tensor(input_nodes)], blocks), labels[torch.as_tensor(sd)], "none")
+        if reset:
+            for p in params:
+                p.grad = None
+        rows.sum().backward()
+
+    plan = [  # per step: number of backward passes of (rank 0, the last rank, everyone else), inside no_sync()?
+        (1, 1, 1, False),       # learns the buckets
+        (2, 1, 1, False),       # rank 0 accumulates a second pass AFTER its hooks launched the early bucket: stale -> redone
+        (1, 0, 1, False),       # the last rank has no backward at all: it launches the early bucket from sync()
+        (2, 1, 1, True),        # rank 0 accumulates under no_sync(): nothing launched early on it, nothing wasted
+        (1, 1, 1, False),
+    ]
+    res = []
+    for step, (n0, nl, ne, nosync) in enumerate(plan):
+        n = n0 if rank == 0 else (nl if rank == world - 1 else ne)
+        for p in params:
+            p.grad = None
+        if rank == 0 and nosync:
+            with sync.no_sync():
+                backward(2 * step, False)
+            backward(2 * step + 1, False)
+        else:
+            for k in range(n):
+                backward(2 * step + k, False)
+        local = [(p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for p in params]
+        launched = sync._pending is not None
+        sync.sync()
+        want = []
+        for g in local:
+            t = g.clone(); dist.all_reduce(t); want.append(t)            # weight 1.0: the plain sum over the ranks
+        res.append(dict(launched=launched, ok=all(torch.allclose(p.grad, w, rtol=1e-5, atol=1e-6) for p, w in zip(params, want)),
+                        split=sync._early is not None))
+    allres = [None] * world
+    dist.all_gather_object(allres, res)
+    if rank == 0:
+        torch.save(allres, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_grad_sync_matched_collectives_under_unequal_histories(tmp_path, world):
+    out = str(tmp_path / "uneq.pt")
+    mp.spawn(_worker_unequal, args=(world, _free_port(), out), nprocs=world, join=True)
+    allres = torch.load(out)
+    for rank, res in enumerate(allres):
+        assert [r["ok"] for r in res] == [True] * 5, (rank, res)
+        assert [r["split"] for r in res] == [True] * 5          # the split is learnt in step 0 (flag read after sync)
+    r0, rl = allres[0], allres[-1]
+    assert [r["launched"] for r in r0] == [False, True, True, True, True]
+    assert rl[2]["launched"] is False and rl[1]["launched"] is True   # no backward -> nothing launched from hooks
+
+
+def test_grad_sync_first_step_without_arrivals_on_a_rank(tmp_path):
+    """Step 0 on a rank WITHOUT a backward: every rank still takes part in the bucket-learning broadcast (rank 0's split)."""
+    out = str(tmp_path / "first.pt")
+    mp.spawn(_worker_first_empty, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert torch.load(out) == [True, True]
+
+
+def _worker_first_empty(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    indptr, indices, deg_t, feat, labels, seeds, F, C = _problem()
+    model = O.CpuModel("pool", F, 8, C, seed=3)
+    params = model.opt.param_groups[0]["params"]
+    sync = parallel.GradSynchronizer(params, overlap=True, weight=1.0)
+    oks = []
+    for step in range(2):
+        for p in params:
+            p.grad = None
+        if not (step == 0 and rank == 1):                         # rank 1 has no seeds in the first step
+            _grads(model, feat, labels, indptr, indices, deg_t, seeds[:10 + rank])
+        local = [(p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for p in params]
+        sync.sync()
+        want = []
+        for g in local:
+            t = g.clone(); dist.all_reduce(t); want.append(t)
+        oks.append(all(torch.allclose(p.grad, w, rtol=1e-5, atol=1e-6) for p, w in zip(params, want)))
+    flags = [None] * world
+    dist.all_gather_object(flags, all(oks) and sync._early is not None)
+    if rank == 0:
+        torch.save(flags, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The sharded priority forward: whole batches per rank (batch_shard), per-vertex tables built locally (replicated) or
+# per vertex range + halo all-gather (partitioned), losses all-gathered by agreed counts.  partitioned == replicated ==
+# one rank, bit for bit; and equal to the plain (table-free) oracle forward to 1e-5.
+# ------------------------------------------------------------------------------------------------------------------
+def _tables_cpu(model, feat, n, partition):
+    prm = model.params[0]
+
+    def project(lo, hi, blocks):
+        x = feat[lo:hi]
+        with torch.no_grad():
+            blocks[0].copy_(torch.relu(torch.nn.functional.linear(x, prm["fc_pool.weight"], prm["fc_pool.bias"])))
+            blocks[1].copy_(torch.nn.functional.linear(x, prm["fc_self.weight"], prm["fc_self.bias"] + prm["fc_neigh.bias"]))
+    return parallel.build_row_tables(n, [feat.shape[1], prm["fc_self.weight"].shape[0]], project, "cpu", partition=partition)
+
+
+def _losses_from_tables(model, tables, labels, indptr, indices, deg_t, seeds, ctr):
+    """CPU model of SAGEConv._forward_cached: neighbour max from P0[picks], self term S0[dst]; layer 1 as usual."""
+    P0, S0 = tables
+    _, sd, blocks = O.sample_blocks(indptr, indices, deg_t, seeds, [5, 5], 9, ctr)
+    picks, dst = blocks[0]["picks"], blocks[0]["dst_ids"]
+    with torch.no_grad():
+        rows = P0[torch.as_tensor(np.maximum(picks, 0))]                       # [n1, S, F]
+        neigh = torch.where(torch.as_tensor(picks[:, :1] >= 0), rows.amax(dim=1), torch.zeros(()))
+        h1 = torch.relu(S0[torch.as_tensor(dst)] + torch.nn.functional.linear(neigh, model.params[0]["fc_neigh.weight"]))
+        logits = O.sageconv_forward("pool", h1, len(sd), blocks[1]["local_idx"], model.params[1])
+        return O.cross_entropy(logits, labels[torch.as_tensor(sd)], "none"), logits
+
+
+def _worker_partitioned(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    indptr, indices, deg_t, feat, labels, seeds, F, C = _problem()
+    n = feat.shape[0]
+    model = O.CpuModel("pool", F, 8, C, seed=3)
+    bf = 8                                                          # 37 seeds: 5 batches, the last ragged
+    res = {}
+    for partition in (False, True):
+        tables = _tables_cpu(model, feat, n, partition)
+        b_lo, b_hi, s_lo, s_hi = parallel.batch_shard(len(seeds), bf, rank, world)
+        local = [ _losses_from_tables(model, tables, labels, indptr, indices, deg_t, seeds[b * bf:(b + 1) * bf], 40 + b)[0]
+                  for b in range(b_lo, b_hi)]
+        local = torch.cat(local) if local else torch.zeros(0)
+        counts = [parallel.batch_shard(len(seeds), bf, r, world)[3] - parallel.batch_shard(len(seeds), bf, r, world)[2]
+                  for r in range(world)]
+        res["part" if partition else "rep"] = dict(losses=parallel.all_gather_counts(local, counts),
+                                                    P0=tables[0][:n].clone(), S0=tables[1][:n].clone())
+    parallel.assert_replicated(seeds, "seeds")
+    try:
+        parallel.assert_replicated(seeds + rank, "shifted seeds")
+        drift = False
+    except RuntimeError:
+        drift = True
+    res["drift_detected"] = drift
+    allres = [None] * world
+    dist.all_gather_object(allres, res)
+    if rank == 0:
+        torch.save(allres, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_equals_replicated_equals_one_rank(tmp_path, world):
+    out = str(tmp_path / "part.pt")
+    mp.spawn(_worker_partitioned, args=(world, _free_port(), out), nprocs=world, join=True)
+    allres = torch.load(out)
+    indptr, indices, deg_t, feat, labels, seeds, F, C = _problem()
+    model = O.CpuModel("pool", F, 8, C, seed=3)
+    tables = _tables_cpu(model, feat, feat.shape[0], False)                  # one rank
+    one, plain = [], []
+    for b in range(5):
+        sd = seeds[b * 8:(b + 1) * 8]
+        one.append(_losses_from_tables(model, tables, labels, indptr, indices, deg_t, sd, 40 + b))
+        plain.append(model.seed_losses(feat, labels, indptr, indices, deg_t, sd, 5, 9, 40 + b))
+    one_losses = torch.cat([l for l, _ in one])
+    for res in allres:
+        assert res["drift_detected"] is True
+        for mode in ("rep", "part"):
+            assert torch.equal(res[mode]["losses"], one_losses)              # bit-equal, in seed order, on every rank
+            assert torch.equal(res[mode]["P0"], tables[0]) and torch.equal(res[mode]["S0"], tables[1])
+    np.testing.assert_allclose(torch.cat([lg for _, lg in one]).numpy(), np.concatenate([lg for _, lg in plain]), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(one_losses.numpy(), np.concatenate([l for l, _ in plain]), rtol=1e-5, atol=1e-6)
+
+
+def test_batch_shard_and_partition_rows():
+    for n, bf in ((0, 4), (1, 4), (37, 8), (2148, 1024), (4096, 1024)):
+        for w in (1, 2, 3, 8):
+            parts = [parallel.batch_shard(n, bf, r, w) for r in range(w)]
+            assert parts[0][2] == 0 and parts[-1][3] == n
+            assert all(a[3] == b[2] and a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            assert all(p[2] % bf == 0 or p[2] == p[3] == n for p in parts)                        # every local batch is a batch of the one-rank pass
+    for n in (1, 31, 32, 33, 232965):
+        for w in (1, 2, 3, 8):
+            per = parallel.partition_rows(n, w)
+            assert per % 32 == 0 and per * w >= n and (per - 32) * w < n + 32 * w
