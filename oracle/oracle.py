@@ -227,8 +227,13 @@ def reduce_fwd(src, local_idx, op):
 # --------------------------------------------------------------------------------------------
 # Layers (torch CPU fp32).
 # --------------------------------------------------------------------------------------------
-def _neigh_torch(p, local_idx, op, forced=None):
+def _neigh_torch(p, local_idx, op, forced=None, connect_empty=False):
     """Differentiable torch version of reduce_fwd (used for gradient parity).
+
+    ``connect_empty``: a block WITHOUT any edge still returns a result that depends on ``p`` (with zero gradient), as DGL's
+    builtin ``update_all(copy_src, max)`` of the live 'pool' layer does — ``fc_pool`` then receives a ZERO gradient tensor
+    and Adam counts the step; the in-repo layer's zero-edge guard (R/.../aggregator_dgl.py:151-154) instead leaves
+    ``fc_pool`` without a gradient (``None``: torch.optim.Adam skips the parameter).
 
     ``forced`` (max only; tests of the full-size step): dict(argmax=int [n_dst, D] local source row of the winner the
     DEVICE chose, -1 = none; mask=bool [n_dst, D] the device's ReLU mask of the pooled value).  ``p`` is then the
@@ -261,6 +266,8 @@ def _neigh_torch(p, local_idx, op, forced=None):
                 acc = acc + rows[:, j, :]
             red = acc
         out = out.index_put((torch.nonzero(has)[:, 0],), red)
+    elif connect_empty:
+        out = out + p[:0].sum() * 0
     return out
 
 
@@ -287,7 +294,7 @@ def sageconv_forward(mode, h_src, n_dst, local_idx, params, activation=None, for
         if forced is not None:
             neigh = _neigh_torch(pre, li, "max", forced)
         else:
-            neigh = _neigh_torch(F.relu(pre), li, "max")
+            neigh = _neigh_torch(F.relu(pre), li, "max", connect_empty=True)
         rst = F.linear(h_dst, params["fc_self.weight"], params["fc_self.bias"]) + \
             F.linear(neigh, params["fc_neigh.weight"], params["fc_neigh.bias"])
     elif mode in ("meanpool", "maxpool"):
@@ -477,15 +484,18 @@ class HostVertexStream:
         self.t += 1
 
 
-def no_rehearsal_stream(stream, model, fanout, seeds_per_snapshot, seed, ctr0=0):
+def no_rehearsal_stream(stream, model, fanout, seeds_per_snapshot, seed, ctr0=0, after_step=None):
     """The no-rehearsal strategy's loop body over consecutive snapshots (R/train/graphsage/pytorch/model.py:300-323 +
     R/train/__main__.py:161-196): per snapshot ONE batch of the newly arrived train vertices (``seeds_per_snapshot[t]``,
     snapshot ids, in the order the loader sees them — the reference shuffles them with an unseeded RNG, so the caller
-    fixes the order), sampled at ``[fanout, fanout]``, one Adam step; then ``evolve``.  Returns the per-snapshot losses."""
+    fixes the order), sampled at ``[fanout, fanout]``, one Adam step; then ``evolve``.  Returns the per-snapshot losses.
+    ``after_step(t, model)`` (tests) runs after each snapshot's step."""
     losses = []
     for t, sd in enumerate(seeds_per_snapshot):
         if len(sd) >= 2:                                     # the reference returns early below two new nodes (:308-309)
             losses.append(model.train_step(stream.feat, stream.labels, stream.indptr, stream.indices, stream.degrees(),
                                            np.asarray(sd, dtype=np.int64), fanout, seed, ctr0 + len(losses)))
+            if after_step is not None:
+                after_step(t, model)
         stream.evolve()
     return losses

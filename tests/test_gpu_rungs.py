@@ -43,6 +43,33 @@ def _copy_params(model, layer_params):
                 getattr(getattr(l, mod), attr).copy_(v.detach())
 
 
+def _params_close_then_sync(model_or_snapshot, cpu, what):
+    """Weights after an Adam step, then oracle <- device.
+
+    Adam's step is lr * m / (sqrt(v) + eps) = lr * g / (|g| + 1e-8) on the first step: an entry whose gradient is within
+    summation noise of zero (|g| < ~1e-7: the two sides agree on it to atol 1e-5, not on its sign) moves by anything in
+    [-lr, lr] on either side, and a weight that is off by 1e-3 shifts the NEXT step's gradients of its column by a percent.
+    Both evaluations are correct; so per step the weights are held to 2e-5 per entry with at most 1e-3 of the entries
+    outside (each by no more than 2 lr per step taken), and the oracle then continues from the device's weights — every
+    step's loss / logits / gradients are compared from identical parameters, the optimiser state stays each side's own."""
+    bad = total = 0
+    with torch.no_grad():
+        for li, prm in enumerate(cpu.params):
+            for k, v in prm.items():
+                got = model_or_snapshot[li][k]
+                d = (got - v.detach()).abs()
+                bad += int((d > 2e-5).sum()); total += d.numel()
+                assert float(d.max()) <= 2.5e-3, (what, li, k, float(d.max()))
+                v.copy_(got)
+    assert bad <= 1e-3 * total, (what, bad, total)
+
+
+def _snapshot(model):
+    return [{k: getattr(getattr(l, k.split(".")[0]), k.split(".")[1]).detach().cpu().clone()
+             for k in ("fc_pool.weight", "fc_pool.bias", "fc_self.weight", "fc_self.bias", "fc_neigh.weight", "fc_neigh.bias")}
+            for l in model.layers]
+
+
 def _host_csr(g):
     h = g.handle
     keys = (h.keys if h.keys is not None else h.indices).cpu().numpy()
@@ -97,7 +124,7 @@ def test_rbr_train_steps_match_oracle(streams, name, gemm):
         def spy(graph, blocks, input_nodes, sd, s2id, n_global=None):
             loss = inner(graph, blocks, input_nodes, sd, s2id, n_global)
             rec.append(dict(loss=float(loss), seeds=sd.cpu().numpy(), n0=input_nodes.numel(),
-                            grads=[p.grad.detach().cpu().clone() for p in model.parameters()]))
+                            grads=[p.grad.detach().cpu().clone() for p in model.parameters()], after=_snapshot(model)))
             return loss
         strat.train_step = spy
         sampling.seed(13)
@@ -115,11 +142,7 @@ def test_rbr_train_steps_match_oracle(streams, name, gemm):
             ref_grads = {"layers.%d.%s" % (li, k): v.grad for li, prm in enumerate(cpu.params) for k, v in prm.items()}
             for n_, got in zip(names, r["grads"]):
                 np.testing.assert_allclose(got.numpy(), ref_grads[n_].numpy(), rtol=1e-3, atol=1e-5, err_msg="%s step %d" % (n_, ctr))
-        for li, prm in enumerate(cpu.params):
-            for k, v in prm.items():
-                mod, attr = k.split(".")
-                np.testing.assert_allclose(getattr(getattr(model.layers[li], mod), attr).detach().cpu().numpy(),
-                                           v.detach().numpy(), rtol=1e-4, atol=1e-5)
+            _params_close_then_sync(r["after"], cpu, "%s step %d" % (name, ctr))
     finally:
         ops.set_gemm_mode("f32")
 
@@ -138,9 +161,12 @@ def test_priority_forward_matches_oracle(streams, name, n_seeds, cached):
     cfg = RUNGS[name]
     a, labels, dyn, feat_size, n_classes = streams(name, 2)
     np.random.seed(5); random.seed(5)
-    # a fresh replay state over the latest of two snapshot groups (thousands of train vertices); the graph itself is
-    # moved to its last snapshot without admitting anything more: the forward runs on the full graph
-    gu = TrainTestGraph(dyn, split=0.15, start_prior_alpha=4, end_prior_alpha=50, scale=1, max_priority=10)
+    # the replay state admits the FIRST of two snapshot groups (tens of thousands of train vertices; built once per stream,
+    # its buffer carries over between the parametrisations); the graph itself is moved to its last snapshot without
+    # admitting anything more: the forward runs on the full graph
+    if not hasattr(dyn, "_test_gu"):
+        dyn._test_gu = TrainTestGraph(dyn, split=0.15, start_prior_alpha=4, end_prior_alpha=50, scale=1, max_priority=10)
+    gu = dyn._test_gu
     if dyn.evolution_index < 2:
         dyn.evolve()
     g = dyn.get_graph()
@@ -179,20 +205,32 @@ def test_priority_forward_matches_oracle(streams, name, n_seeds, cached):
                                for b, s in enumerate(range(0, n_seeds, 1024))])
         assert np.array_equal(seen["ids"], subset) and seen["pr"].dtype == np.float64
         np.testing.assert_allclose(seen["pr"], want, rtol=1e-4, atol=1e-6)
-        # losses -> LossPriority (identity, R/train/prioritized_replay/generate_priority.py:7-9) -> buffer: the same
-        # update through the golden-pinned dict API, fed with the oracle's losses
+        # losses -> LossPriority (identity, R/train/prioritized_replay/generate_priority.py:7-9) -> buffer.
+        # (1) the array entry point the strategy uses == the golden-pinned dict API on the SAME (device) losses, bit for bit
+        same_buf = copy.deepcopy(before)
+        same_buf.update_priorities({int(k): float(v) for k, v in zip(subset, seen["pr"])})
+        got_pr = np.asarray(gu.dump_priorities(list(subset)))
+        assert np.array_equal(got_pr, np.asarray(same_buf.dump_priorities(list(subset))))
+        # (2) against the buffer fed with the ORACLE's losses.  priority = v^alpha, v = (log L - lo) / (hi - lo) + 1e-6 with
+        # RUNNING extrema lo / hi of log L.  The loss check above allows |dL| <= 1e-4 L + 1e-6, i.e. d(log L) <= e(L) =
+        # 1e-4 + 1e-6 / L (a loss of 1e-3 is only known to 1e-3 relative), and the extrema are themselves log-losses of
+        # this update, so dv <= (e(L) + 2 e_ext) / (hi - lo) and d(priority) <= alpha v^(alpha-1) dv (second order added).
         ref_buf = before
         ref_buf.update_priorities({int(k): float(v) for k, v in zip(subset, want)})
-        got_pr = np.asarray(gu.dump_priorities(list(subset)))
         want_pr = np.asarray(ref_buf.dump_priorities(list(subset)))
-        # d(priority) = alpha v^(alpha-1) dv with v = (log loss - lo) / scale in [0, 1]: a 1e-4 relative loss error moves
-        # a priority by at most alpha * 1e-4 / scale
-        scale = ref_buf._max_priority - ref_buf._min_priority
-        np.testing.assert_allclose(got_pr, want_pr, rtol=0, atol=ref_buf._alpha * 1e-4 / scale + 1e-12)
+        alpha, lo, hi = ref_buf._alpha, ref_buf._min_priority, ref_buf._max_priority
+        Lc = np.clip(want.astype(np.float64), 1e-7, 10.0)
+        e = 1e-4 + 1e-6 / Lc
+        e_ext = max(e[np.argmin(Lc)], e[np.argmax(Lc)])
+        dv = (e + 2 * e_ext) / (hi - lo)
+        v = want_pr ** (1.0 / alpha)
+        tol = alpha * (v + dv) ** (alpha - 1) * dv + 1e-12
+        assert (np.abs(got_pr - want_pr) <= tol).all(), float((np.abs(got_pr - want_pr) / tol).max())
         assert gu.priority_replay_buffer.get_max_priority() == pytest.approx(ref_buf.get_max_priority(), rel=1e-4)
         # untouched entries keep their admission priority
         assert np.array_equal(np.asarray(gu.dump_priorities(list(rest))), rest_before)
     finally:
+        gu.__dict__.pop("update_priorities_arrays", None)
         ops.set_gemm_mode("f32")
 
 
@@ -219,24 +257,21 @@ def test_no_rehearsal_pubmed_matches_oracle_loop():
 
     def spy(graph, blocks, input_nodes, sd, s2id, n_global=None):
         loss = inner(graph, blocks, input_nodes, sd, s2id, n_global)
-        rec.append((sd.cpu().numpy(), float(loss)))
+        rec.append((sd.cpu().numpy(), float(loss), _snapshot(model)))
         return loss
     strat.train_step = spy
     for _ in range(3):
         strat.train_timestep(gu)
         gu.evolve()
-    assert len(rec) == 3 and all(len(sd) == 32 for sd, _ in rec)
+    assert len(rec) == 3 and all(len(r[0]) == 32 for r in rec)
     stream = O.HostVertexStream(a["n"], a["src"], a["dst"], a["order"], a["snapshots"], a["feat"], a["labels"])
     # the strategy's seeds are snapshot ids of that snapshot's arrivals (new TRAIN vertices only)
-    for t, (sd, _) in enumerate(rec):
+    for t, (sd, _, _) in enumerate(rec):
         assert sd.min() >= t * stream.per and sd.max() < (t + 1) * stream.per
-    want = O.no_rehearsal_stream(stream, cpu, 10, [sd for sd, _ in rec], 31)
-    np.testing.assert_allclose([l for _, l in rec], want, rtol=1e-4)
-    for li, prm in enumerate(cpu.params):
-        for k, v in prm.items():
-            mod, attr = k.split(".")
-            np.testing.assert_allclose(getattr(getattr(model.layers[li], mod), attr).detach().cpu().numpy(),
-                                       v.detach().numpy(), rtol=1e-4, atol=1e-5)
+    # after each snapshot's step: weights equal up to Adam's near-zero-gradient entries, then oracle <- device
+    want = O.no_rehearsal_stream(stream, cpu, 10, [r[0] for r in rec], 31,
+                                 after_step=lambda t, m: _params_close_then_sync(rec[t][2], m, "snapshot %d" % t))
+    np.testing.assert_allclose([r[1] for r in rec], want, rtol=1e-4)
 
 
 # ------------------------------------------------------------------------------------------------------------------
