@@ -56,6 +56,7 @@ def parse():
                     help="nccl = RCCL over xGMI (one GPU per rank); gloo = rehearsal of the N>1 path with several ranks on one GPU")
     ap.add_argument("--gemm", default="auto", choices=["f32", "bf16x6", "auto"],
                     help="projection arithmetic: exact fp32 MFMA, split-bf16 (x6, fp32-accurate) MFMA, or per-layout best")
+    ap.add_argument("--no-graphs", action="store_true", help="enqueue every launch from Python instead of replaying captured steps")
     ap.add_argument("--no-projection-cache", action="store_true", help="priority forward: recompute fc_pool_0 per batch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of EACH cpu_baseline leg (multi-thread, one thread)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -116,47 +117,40 @@ def main():
 
     torch.manual_seed(1)                                     # identical replicas on every rank
     model = GraphSAGE(feat_size, H, n_classes, 1, F.relu, 0, "pool", edge_feats=0, pool_feats=H).cuda()
-    opt = optim.Adam(model.parameters(), lr=1e-3)
-    gsync = parallel.GradSynchronizer(model.parameters()) if world > 1 else None
-    sampler = sampling.MultiLayerNeighborSampler([S, S], replace=True, return_eids=True)
     sampling.seed(1)
     split_rng = np.random.default_rng(synthetic.SEEDS["split"])
     train_set = np.sort(split_rng.permutation(g.n_present)[: int(0.85 * g.n_present)])
     strong = args.scaling == "strong" and world > 1
-    # weak: every rank rehearses its own B seeds; strong: ONE B-seed batch per step, every rank takes its shard_range slice
-    seed_rng = np.random.default_rng(1000 if strong else 1000 + rank)
-    B_local = len(range(*parallel.shard_range(B, rank, world))) if strong else B
-
-    def draw(nb):
-        out = []
-        for _ in range(nb):
-            sd = seed_rng.choice(train_set, B, replace=False)
-            out.append(sd[slice(*parallel.shard_range(B, rank, world))] if strong else sd)
-        return torch.as_tensor(np.concatenate(out))
-
-    stats = dict(n0=[], n1=[])
+    # The product path: the RBR strategy class (graphsage/model.py).  N ranks: every rank draws the SAME global batch
+    # (identical host RNG, asserted by the strategy) and trains on its shard_range slice — weak: B seeds per GPU (global
+    # batch B * N), strong: B seeds in total; gradient all-reduce in two buckets overlapped with backward.
+    seed_rng = np.random.default_rng(1000)
+    B_global = B if (strong or world == 1) else B * world
+    B_local = len(range(*parallel.shard_range(B_global, rank, world)))
 
     if wl.get("forward"):
         forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size, n_classes, setup_s)
         return
 
+    from ogl_amd.graphsage.model import RandomHipSupervisedGraphSage
+    strat = RandomHipSupervisedGraphSage(model, bt, B_global, None, S, cuda=True, batch_full=1024)
+    strat.use_graphs = not args.no_graphs
+    strat.build_optimizer()
+    model.train()
+    stats = dict(n0=[], n1=[], forms={})
+
+    def hook(info):
+        stats["forms"][info["form"]] = stats["forms"].get(info["form"], 0) + 1
+        if "n0" in info:
+            stats["n0"].append(info["n0"]); stats["n1"].append(info["n1"])
+    strat.step_hook = hook
+
+    def draw(nb):
+        return np.concatenate([seed_rng.choice(train_set, B_global, replace=False) for _ in range(nb)])
+
     def run(nsteps, seeds_per_snapshot):
-        done = 0
-        for seeds in seeds_per_snapshot:
-            loader = sampling.NodeDataLoader(g, seeds, sampler, batch_size=B_local)
-            for input_nodes, sd, blocks in loader:
-                if done >= nsteps:
-                    return
-                opt.zero_grad()
-                labels = ops.gather_i64(g.ndata["target"], sd)
-                logits = model(blocks, GatheredRows(g.ndata["feat"], input_nodes))
-                loss = ops.cross_entropy(logits, labels, "mean")
-                ops.backward(loss)
-                if gsync is not None:
-                    gsync.sync()
-                opt.step()
-                stats["n0"].append(input_nodes.numel()); stats["n1"].append(blocks[1].number_of_src_nodes())
-                done += 1
+        for seeds in seeds_per_snapshot:          # one snapshot's update: batch_timestep batches of B_global seeds
+            strat._train_batches(g, seeds, B_global)
 
     def plan(nsteps):
         out, left = [], nsteps
@@ -173,7 +167,7 @@ def main():
 
     run(args.warmup, plan(args.warmup))
     seeds_plan = plan(args.steps)
-    stats = dict(n0=[], n1=[])
+    stats["n0"], stats["n1"], stats["forms"] = [], [], {}
     barrier()
     t1 = time.perf_counter()
     run(args.steps, seeds_plan)
@@ -183,7 +177,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    n0_avg, n1_avg = float(np.mean(stats["n0"])), float(np.mean(stats["n1"]))
+    forms_timed = dict(stats["forms"])
 
     # ---- host side: time to ENQUEUE a step (no synchronisation inside the bracket): the margin between this and
     # ms_per_step is how far the step is from being launch-bound on this box's host cores
@@ -208,9 +202,11 @@ def main():
     prof_steps = min(args.steps, bt)
     prof_plan = plan(prof_steps)
     barrier()
-    ops.profile_start()
+    stats["n0"], stats["n1"] = [], []
+    ops.profile_start()                       # per-launch HIP events: this pass runs the same launches EAGERLY (no replay)
     run(prof_steps, prof_plan)
     rec = ops.profile_stop()
+    n0_avg, n1_avg = float(np.mean(stats["n0"])), float(np.mean(stats["n1"]))
     if os.environ.get("OGL_BENCH_DUMP_CALLS") and rank == 0:        # every C-ABI call of the first profiled step, in order
         for name, meta, ms in rec[:len(rec) // prof_steps]:
             print("call %-28s %8.4f ms  %s" % (name, ms, meta), file=sys.stderr)
@@ -322,7 +318,7 @@ def main():
         pass
 
     if rank == 0:
-        value = args.steps * (B if strong else B * world) / elapsed
+        value = args.steps * B_global / elapsed
         hbm_copy = None
         if world == 1:          # the box's own streaming figure beside the nominal peak: 1 GiB device copy
             src_b = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()
@@ -347,7 +343,9 @@ def main():
                                    "sample+gather+fwd+CE+bwd+Adam" % (args.workload, wl["dataset"], arrays["stream"], g.n_present,
                                                                         int(h_nnz(g)), feat_size, H, n_classes, S,
                                                                         ("%d in total (%d on this rank)" % (B, B_local)) if strong else "%d/GPU" % B, bt),
-                       "global_batch": B if strong else B * world,
+                       "global_batch": B_global,
+                       "step_execution": ("captured hipGraph replays: %s" % forms_timed) if not args.no_graphs and world == 1
+                       else "eager launches from Python (%s)" % forms_timed,
                        "parallelism": "dp%d (seed-sharded replicas, two-bucket grad all-reduce overlapped with backward)" % world,
                        "avg_unique_input_nodes_n0": round(n0_avg, 1), "avg_n1": round(n1_avg, 1), "setup_s": round(setup_s, 1)},
             "roofline": roof_gemm if roof_gemm else roof_aggr,

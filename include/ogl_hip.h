@@ -280,6 +280,27 @@ int ogl_adam_step_multi(int count, float* const* p, const float* const* g, float
                         const int64_t* n, int step, double lr, double beta1, double beta2, double eps,
                         ogl_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Entry points for a CAPTURED step (hipGraph): everything a replay must see new values of lives in device memory.
+ * A train step of the small rungs (32 seeds) is ~40 microsecond-sized launches: enqueued one by one from the host it is
+ * launch- and sync-bound; captured once on upper-bound shapes and replayed, it costs one graph launch.
+ *   ogl_sample_layer_dev     = ogl_sample_layer with the Philox batch counter read from *ctr_dev on the device;
+ *   ogl_adam_step_multi_dev  = ogl_adam_step_multi with the step count in *step_dev (incremented by the call itself on the
+ *                              device, bias corrections derived from it there; scalars_dev = float[2] scratch);
+ *   ogl_stage_segments       copies the sampled batch of a loader into the static buffers of a captured step: up to 8
+ *                              segments of 4- or 8-byte elements in one launch, each copied for `count` elements and filled
+ *                              with `pad` (-1: "no vertex" / "no neighbour") up to `capacity`.
+ * Padding contract (what makes fixed shapes exact): a destination id of -1 samples no neighbour and keeps its block row;
+ * a source id of -1 gathers the all-zero row; padded rows therefore contribute exact zeros to every product and gradient.
+ * ---------------------------------------------------------------------------------------- */
+int ogl_sample_layer_dev(const ogl_graph_t* g, const int64_t* dst, int64_t n_dst, int fanout, uint64_t seed,
+                         const uint64_t* ctr_dev, int layer, int64_t* picks, ogl_stream_t stream);
+int ogl_adam_step_multi_dev(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
+                            const int64_t* n, int64_t* step_dev, float* scalars_dev, double lr, double beta1,
+                            double beta2, double eps, ogl_stream_t stream);
+int ogl_stage_segments(int nseg, const void* const* src, void* const* dst, const int64_t* count,
+                       const int64_t* capacity, const int* elem_bytes, int64_t pad, ogl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,9 @@ SIGNATURES = {
     "ogl_adam_step": (_i, [_p, _p, _p, _p, _i64, _i, _d, _d, _d, _d, _p]),
     "ogl_argmax_confusion": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p]),
     "ogl_adam_step_multi": (_i, [_i, _p, _p, _p, _p, _p, _i, _d, _d, _d, _d, _p]),
+    "ogl_sample_layer_dev": (_i, [_p, _p, _i64, _i, _u64, _p, _i, _p, _p]),
+    "ogl_adam_step_multi_dev": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _d, _d, _d, _d, _p]),
+    "ogl_stage_segments": (_i, [_i, _p, _p, _p, _p, _p, _i64, _p]),
 }
 
 _lib = None

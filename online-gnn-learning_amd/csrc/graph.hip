@@ -212,3 +212,93 @@ extern "C" int ogl_sample_layer_batched(const ogl_graph_t* g, const int64_t* dst
   }
   return OGL_OK;
 }
+
+
+// ---- sampler with a DEVICE-side batch counter: replayable inside a captured hipGraph ------------------------------------
+// Same draws as ogl_sample_layer(ctr = *ctr_dev); a host-side ctr would be frozen into the graph's kernel arguments.
+__global__ void __launch_bounds__(256) k_sample_layer_dev(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                          const int32_t* __restrict__ deg_t, int64_t n,
+                                                          const int64_t* __restrict__ dst, int64_t n_dst, int fanout, int quads,
+                                                          uint32_t seed_lo, uint32_t seed_hi, const uint64_t* __restrict__ ctr_dev,
+                                                          uint32_t layer_bits, int64_t* __restrict__ picks) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_dst * quads) return;
+  int64_t i = t / quads;
+  int q = (int)(t - i * quads);
+  int64_t d = dst[i];
+  uint32_t deg = 0;
+  int64_t base = 0;
+  if (d >= 0 && d < n) { deg = (uint32_t)deg_t[d]; base = indptr[d]; }
+  int j0 = q * 4;
+  int64_t* out = picks + i * fanout + j0;
+  int cnt = min(4, fanout - j0);
+  if (deg == 0) {
+    for (int j = 0; j < cnt; ++j) out[j] = -1;
+    return;
+  }
+  const uint64_t ctr = *ctr_dev;
+  philox4 r = philox4x32_10((uint32_t)q | layer_bits, (uint32_t)((uint64_t)d & 0xFFFFFFFFu), (uint32_t)((uint64_t)d >> 32),
+                            (uint32_t)(ctr & 0xFFFFFFFFu), seed_lo, seed_hi ^ (uint32_t)(ctr >> 32));
+  uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j < cnt) {
+      uint32_t off = (uint32_t)(((uint64_t)w[j] * (uint64_t)deg) >> 32);
+      out[j] = (int64_t)indices[base + off];
+    }
+  }
+}
+
+extern "C" int ogl_sample_layer_dev(const ogl_graph_t* g, const int64_t* dst, int64_t n_dst, int fanout, uint64_t seed,
+                                    const uint64_t* ctr_dev, int layer, int64_t* picks, ogl_stream_t stream) {
+  if (!g || n_dst < 0 || fanout < 0 || layer < 0 || layer > 0xFFFF) return OGL_EINVAL;
+  if (n_dst == 0 || fanout == 0) return OGL_OK;
+  if (!dst || !picks || !ctr_dev) return OGL_EINVAL;
+  const int quads = (fanout + 3) / 4;
+  hipLaunchKernelGGL(k_sample_layer_dev, dim3((unsigned)ogl_cdiv(n_dst * quads, 256)), dim3(256), 0, (hipStream_t)stream,
+                     g->indptr, g->indices, g->deg, g->n, dst, n_dst, fanout, quads, (uint32_t)(seed & 0xFFFFFFFFu),
+                     (uint32_t)(seed >> 32), ctr_dev, (uint32_t)layer << 16, picks);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+// ---- staging of a sampled batch into the static buffers of a captured step ------------------------------------------------
+// Up to OGL_STAGE_MAX segments in one launch: copy `count` elements, then fill with `pad` (as int32 / int64 pattern) up to
+// `capacity`.  elem = 4 or 8 bytes.
+#define OGL_STAGE_MAX 8
+struct StageDesc {
+  const void* src[OGL_STAGE_MAX];
+  void* dst[OGL_STAGE_MAX];
+  int64_t count[OGL_STAGE_MAX];
+  int64_t capacity[OGL_STAGE_MAX];
+  int elem[OGL_STAGE_MAX];
+};
+
+__global__ void __launch_bounds__(256) k_stage_segments(StageDesc d, int64_t pad) {
+  const int s = blockIdx.y;
+  const int64_t cap = d.capacity[s], cnt = d.count[s];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x) {
+    if (d.elem[s] == 8) ((int64_t*)d.dst[s])[i] = i < cnt ? ((const int64_t*)d.src[s])[i] : pad;
+    else ((int32_t*)d.dst[s])[i] = i < cnt ? ((const int32_t*)d.src[s])[i] : (int32_t)pad;
+  }
+}
+
+extern "C" int ogl_stage_segments(int nseg, const void* const* src, void* const* dst, const int64_t* count,
+                                  const int64_t* capacity, const int* elem_bytes, int64_t pad, ogl_stream_t stream) {
+  if (nseg < 0 || nseg > OGL_STAGE_MAX) return OGL_EINVAL;
+  if (nseg == 0) return OGL_OK;
+  if (!src || !dst || !count || !capacity || !elem_bytes) return OGL_EINVAL;
+  StageDesc d;
+  int64_t mx = 0;
+  for (int s = 0; s < nseg; ++s) {
+    if (count[s] < 0 || capacity[s] < count[s] || (elem_bytes[s] != 4 && elem_bytes[s] != 8)) return OGL_EINVAL;
+    if (capacity[s] > 0 && (!dst[s] || (count[s] > 0 && !src[s]))) return OGL_EINVAL;
+    d.src[s] = src[s]; d.dst[s] = dst[s]; d.count[s] = count[s]; d.capacity[s] = capacity[s]; d.elem[s] = elem_bytes[s];
+    mx = capacity[s] > mx ? capacity[s] : mx;
+  }
+  if (mx == 0) return OGL_OK;
+  dim3 grid((unsigned)std::min<int64_t>(ogl_cdiv(mx, 256), 1024), (unsigned)nseg);
+  hipLaunchKernelGGL(k_stage_segments, grid, dim3(256), 0, (hipStream_t)stream, d, pad);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}

@@ -147,6 +147,62 @@ extern "C" int ogl_adam_step_multi(int count, float* const* p, const float* cons
   return OGL_OK;
 }
 
+// ---- Adam with a DEVICE-side step count: replayable inside a captured hipGraph -------------------------------------------
+// (a host-side step would freeze the bias corrections into the graph's kernel arguments).  k_adam_prepare increments the
+// counter and writes {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)} in double arithmetic, rounded to fp32 once, like the host path.
+__global__ void k_adam_prepare(int64_t* step, double lr, double beta1, double beta2, float* scal) {
+  const int64_t t = *step + 1;
+  *step = t;
+  scal[0] = (float)(lr / (1.0 - pow(beta1, (double)t)));
+  scal[1] = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)t)));
+}
+
+__global__ void __launch_bounds__(256) k_adam_multi_dev(AdamBatch b, float one_minus_b1, float b2, float one_minus_b2,
+                                                        const float* __restrict__ scal, float eps) {
+  const float step_size = scal[0], inv_sqrt_bc2 = scal[1];
+  const int t = blockIdx.y;
+  float* __restrict__ p = b.p[t];
+  const float* __restrict__ g = b.g[t];
+  float* __restrict__ m = b.m[t];
+  float* __restrict__ v = b.v[t];
+  const int64_t n = b.n[t];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    float mi = m[i];
+    mi = mi + one_minus_b1 * (gi - mi);
+    const float vi = v[i] * b2 + one_minus_b2 * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+  }
+}
+
+extern "C" int ogl_adam_step_multi_dev(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
+                                       const int64_t* n, int64_t* step_dev, float* scalars_dev, double lr, double beta1,
+                                       double beta2, double eps, ogl_stream_t stream) {
+  if (count < 0) return OGL_EINVAL;
+  if (!step_dev || !scalars_dev) return OGL_EINVAL;
+  if (count > 0 && (!p || !g || !m || !v || !n)) return OGL_EINVAL;
+  hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, lr, beta1, beta2, scalars_dev);
+  OGL_CHECK_LAUNCH();
+  for (int base = 0; base < count; base += OGL_ADAM_MAX_TENSORS) {
+    AdamBatch b;
+    const int c = min(OGL_ADAM_MAX_TENSORS, count - base);
+    int64_t nmax = 0;
+    for (int i = 0; i < c; ++i) {
+      if (n[base + i] < 0 || (n[base + i] > 0 && (!p[base + i] || !g[base + i] || !m[base + i] || !v[base + i]))) return OGL_EINVAL;
+      b.p[i] = p[base + i]; b.g[i] = g[base + i]; b.m[i] = m[base + i]; b.v[i] = v[base + i]; b.n[i] = n[base + i];
+      nmax = n[base + i] > nmax ? n[base + i] : nmax;
+    }
+    if (nmax == 0) continue;
+    dim3 grid((unsigned)min((int64_t)256, ogl_cdiv(nmax, 256)), (unsigned)c);
+    hipLaunchKernelGGL(k_adam_multi_dev, grid, dim3(256), 0, (hipStream_t)stream, b, (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), (const float*)scalars_dev, (float)eps);
+    OGL_CHECK_LAUNCH();
+  }
+  return OGL_OK;
+}
+
 // Evaluation on the device: argmax of every logits row (first maximum, like numpy) and
 // the C x C confusion matrix confusion[true][pred], so only C*C counters cross PCIe instead of [n, C] logits.
 // Replaces output_data.argmax(axis=1) + sklearn.metrics.confusion_matrix (R/train/graphsage/model.py:84-87).

@@ -13,7 +13,7 @@ import time
 import numpy as np
 import torch
 
-from .. import ops, optim, parallel, sampling
+from .. import ops, optim, parallel, sampling, stepgraph
 from .sageconv import GatheredRows
 
 
@@ -52,6 +52,8 @@ class SupervisedGraphSage:
         self.fuse_gather = True     # read feature rows straight from the resident table inside the GEMM
         self.cache_projection = True  # inference passes reuse the layer-0 projection tables across batches
         self.partition_features = False  # N ranks: build those tables per vertex range + halo all-gather (parallel.py)
+        self.use_graphs = True      # one rank: train steps are captured hipGraphs (stepgraph.py)
+        self.step_hook = None       # instrumentation (tests, bench): called after every train step with a dict
 
     def build_optimizer(self):
         raise NotImplementedError
@@ -135,8 +137,14 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         self.xent = lambda scores, labels_: ops.cross_entropy(scores, labels_, reduction)
         self.gsync = None                      # set by build_optimizer() under torch.distributed
 
+    # a batch whose padded input block B (1 + S)^2 stays below this many rows is captured WITH its sampling (upper-bound
+    # shapes, no read-back at all); larger batches keep the loader and are captured per size bucket (stepgraph.py)
+    SAMPLED_GRAPH_MAX_ROWS = 65536
+
     def build_optimizer(self):
-        self.optimizer = optim.Adam(self.graphsage_model.parameters(), lr=0.001)
+        self._sg = None
+        capturable = self.use_graphs and not parallel.is_distributed()
+        self.optimizer = optim.Adam(self.graphsage_model.parameters(), lr=0.001, capturable=capturable)
         # Under torch.distributed (one process per GPU, identical replicas, identical host RNG seeds on every rank)
         # each rank trains on its shard_range slice of every replay batch; the weighted gradient all-reduce makes the
         # update that of the whole batch, and the sharded PBR passes all-gather their per-seed losses (parallel.py).
@@ -182,6 +190,69 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
                     p.grad = torch.zeros_like(p)
             self.gsync.sync()                                      # weight 1: the 1 / n_global is already in the loss
         self.optimizer.step()
+
+    def _graphs_ok(self):
+        """Captured steps apply on one rank, with the capturable optimiser build_optimizer() made, without dropout (its
+        stream counter is host-side) and outside per-kernel profiling."""
+        return (self.use_graphs and self.gsync is None and getattr(self.optimizer, "capturable", False)
+                and ops._PROFILE is None and all(l.feat_drop.p == 0 for l in self.graphsage_model.layers))
+
+    def _step_graphs(self):
+        if getattr(self, "_sg", None) is None:
+            if self.reduction == "mean":
+                loss_fn = lambda logits, labels: (ops.cross_entropy(logits, labels, "mean"), None)       # noqa: E731
+            else:
+                def loss_fn(logits, labels):
+                    rows = self.xent(logits, labels)
+                    return torch.mean(rows), rows
+            self._sg = stepgraph.StepGraphCache(self.graphsage_model, self.optimizer, self.samples, loss_fn)
+        return self._sg
+
+    def _train_batches(self, graph, train_vertices, batch_size, on_rows=None):
+        """The snapshot's train update.  One rank, batches small enough for upper-bound shapes: every full batch is ONE
+        captured step that samples for itself (no loader, no read-back); otherwise the loader + ``train_step`` (itself a
+        captured step per size bucket on one rank).  ``on_rows(seeds_device, loss_rows)`` receives the per-seed losses
+        (PBR).  Counters: one Philox batch counter per batch of the one-rank loader, in order, on either path."""
+        bs = int(batch_size)
+        n = len(train_vertices)
+        if (bs > 0 and self._graphs_ok() and bs * (1 + self.samples) ** 2 <= self.SAMPLED_GRAPH_MAX_ROWS and n >= bs):
+            seeds_np = np.asarray(train_vertices, dtype=np.int64).reshape(-1)
+            starts = list(range(0, n, bs))
+            ctrs = sampling.reserve_ctrs(len(starts))
+            for i, s0 in enumerate(starts):
+                sd = seeds_np[s0:s0 + bs]
+                if len(sd) == bs:
+                    sg = self._step_graphs().sampled(graph, bs)
+                    sg.run_sampled(sd, ctrs[i])
+                    if on_rows is not None:
+                        on_rows(sg.head[1:].clone(), sg.loss_rows.clone())
+                    if self.step_hook is not None:
+                        self.step_hook(dict(seeds=sd, loss=sg.loss, grads=sg.grads, form="sampled", ctr=ctrs[i]))
+                else:                                        # the ragged last batch: eager, with its own counter
+                    sdev = torch.as_tensor(sd).to(graph.device)
+                    (input_nodes, sdd, blocks), = self._sampler().sample_batches(graph, [sdev], ctrs=[ctrs[i]])
+                    loss = self._eager_step(graph, blocks, input_nodes, sdd, on_rows)
+                    if self.step_hook is not None:
+                        self.step_hook(dict(seeds=sd, loss=loss.detach(), grads=[p.grad for p in self.graphsage_model.parameters()],
+                                            form="eager", ctr=ctrs[i], n0=int(input_nodes.numel()), n1=blocks[1].number_of_src_nodes()))
+            return
+        for input_nodes, seeds, blocks, n_global in self._local_batches(graph, train_vertices, bs):
+            self.train_step(graph, blocks, input_nodes, seeds, None, n_global, on_rows=on_rows)
+
+    def _eager_step(self, graph, blocks, input_nodes, seeds, on_rows=None):
+        self.optimizer.zero_grad()
+        batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
+        scores = self.graphsage_model(blocks, self._inputs(graph, input_nodes))
+        if self.reduction == "mean":
+            loss = self.xent(scores, batch_labels)
+        else:
+            rows = self.xent(scores, batch_labels)
+            loss = torch.mean(rows)
+            if on_rows is not None:
+                on_rows(seeds, rows.detach())
+        ops.backward(loss)
+        self.optimizer.step()
+        return loss
 
     def _sampler(self):
         return sampling.MultiLayerNeighborSampler([self.samples for _ in range(2)], replace=True, return_eids=True)
@@ -288,25 +359,33 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
     def get_model(self):
         return "base_model"
 
-    def train_step(self, graph, blocks, input_nodes, seeds, subgraph_to_id, n_global=None):
+    def train_step(self, graph, blocks, input_nodes, seeds, subgraph_to_id, n_global=None, on_rows=None):
         if self.gsync is None and (n_global is None or n_global == seeds.numel()):
-            self.optimizer.zero_grad()
-            batch_inputs = self._inputs(graph, input_nodes)
-            batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
-            scores = self.graphsage_model(blocks, batch_inputs)
-            loss = self.xent(scores, batch_labels)
-            ops.backward(loss)
-            self.optimizer.step()
+            if self._graphs_ok():
+                n0, n1 = int(input_nodes.numel()), blocks[1].number_of_src_nodes()
+                sg = self._step_graphs().staged(graph, int(seeds.numel()), n0, n1)      # captured on first use of the bucket
+                loss = sg.run_staged(seeds, blocks, n0, n1)
+                if on_rows is not None:
+                    on_rows(seeds, sg.loss_rows.clone())
+                if self.step_hook is not None:
+                    self.step_hook(dict(seeds=seeds, loss=loss, grads=sg.grads, form="staged", n0=n0, n1=n1))
+                return loss
+            loss = self._eager_step(graph, blocks, input_nodes, seeds, on_rows)
+            if self.step_hook is not None:
+                self.step_hook(dict(seeds=seeds, loss=loss.detach(), grads=[p.grad for p in self.graphsage_model.parameters()],
+                                    form="eager", n0=int(input_nodes.numel()), n1=blocks[1].number_of_src_nodes()))
             return loss
         # rank-sharded batch: this rank's seeds only; the gradient is that of the mean over the whole batch
         n_local = int(seeds.numel())
-        loss_sum = None
+        loss_sum = rows = None
         if n_local > 0:
             batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
             scores = self.graphsage_model(blocks, self._inputs(graph, input_nodes))
-            loss_sum = ops.cross_entropy(scores, batch_labels, "none").sum() if self.reduction == "mean" \
-                else self.xent(scores, batch_labels).sum()
+            rows = ops.cross_entropy(scores, batch_labels, "none")
+            loss_sum = rows.sum()
         self._backward_and_step(loss_sum, n_local, n_global)
+        if on_rows is not None:
+            on_rows(seeds, rows.detach() if rows is not None else torch.zeros(0, device=graph.device))
         return loss_sum
 
 
@@ -325,9 +404,7 @@ class RandomHipSupervisedGraphSage(HipSupervisedGraphSage):
 
     def _run_custom_train(self, graph, subgraph_to_id, id_to_subgraph, train_vertices, graph_util):
         self.graphsage_model.train()
-        for input_nodes, seeds, blocks, n_global in self._local_batches(graph, train_vertices,
-                                                                       len(train_vertices) // self.batch_per_timestep):
-            self.train_step(graph, blocks, input_nodes, seeds, subgraph_to_id, n_global)
+        self._train_batches(graph, train_vertices, len(train_vertices) // self.batch_per_timestep)
 
     def get_model(self):
         return "random"
@@ -357,31 +434,13 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
         return batch_nodes
 
     def _run_custom_train(self, graph, subgraph_to_id, id_to_subgraph, train_vertices, graph_util):
-        train_vertices = torch.as_tensor(np.asarray(train_vertices), dtype=torch.int64)
-        bs = len(train_vertices) // self.batch_per_timestep
+        train_vertices = torch.as_tensor(np.asarray(train_vertices), dtype=torch.int64).reshape(-1)
+        n = int(train_vertices.numel())
+        bs = n // self.batch_per_timestep
         distributed = self.gsync is not None
-        pending, full_sizes = [], []
-        for input_nodes, seeds, blocks, n_global in self._local_batches(graph, train_vertices, bs):
-            full_sizes.append(n_global)
-            if seeds.numel() > 0:
-                batch_inputs = self._inputs(graph, input_nodes)
-                batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
-            if not distributed:
-                self.optimizer.zero_grad()
-                scores = self.graphsage_model(blocks, batch_inputs)
-                unaggregated_loss = self.xent(scores, batch_labels)
-                loss = torch.mean(unaggregated_loss)
-                ops.backward(loss)
-                self.optimizer.step()
-            else:
-                unaggregated_loss = None
-                if seeds.numel() > 0:
-                    unaggregated_loss = self.xent(self.graphsage_model(blocks, batch_inputs), batch_labels)
-                self._backward_and_step(unaggregated_loss.sum() if unaggregated_loss is not None else None,
-                                        int(seeds.numel()), n_global)
-                if unaggregated_loss is None:
-                    unaggregated_loss = torch.zeros(0, device=graph.device)
-            pending.append((seeds, unaggregated_loss.detach()))
+        pending = []
+        self._train_batches(graph, train_vertices.numpy(), bs, on_rows=lambda sd, rows: pending.append((sd, rows)))
+        full_sizes = [min(bs, n - s0) for s0 in range(0, n, bs)] if bs > 0 else []
         # The reference copies every batch's losses to the host right away (a device sync per batch).  Nothing reads the
         # buffer while the snapshot's batches train (they were drawn beforehand), so the per-batch updates are applied in
         # the same order after ONE transfer: identical buffer contents, no pipeline drain between batches.

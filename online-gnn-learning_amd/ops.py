@@ -156,14 +156,44 @@ def sample_layer(g: GraphHandle, dst: torch.Tensor, fanout: int, seed: int, ctr:
     return picks
 
 
-def build_block_async(dst: torch.Tensor, picks: torch.Tensor):
+def sample_layer_dev(g: GraphHandle, dst: torch.Tensor, fanout: int, seed: int, ctr_dev: torch.Tensor, layer: int) -> torch.Tensor:
+    """sample_layer with the Philox batch counter in device memory (``ctr_dev``: one int64 element): capturable in a hipGraph.
+    A destination id of -1 (padding) gets no pick."""
+    dst = _ids(dst)
+    assert ctr_dev.is_cuda and ctr_dev.dtype == torch.int64 and ctr_dev.numel() >= 1
+    picks = torch.empty((dst.numel(), fanout), dtype=torch.int64, device=dst.device)
+    _launch("ogl_sample_layer_dev", _lib.lib().ogl_sample_layer_dev, g._h, _ptr(dst), dst.numel(), int(fanout),
+            C.c_uint64(seed & (2 ** 64 - 1)), _ptr(ctr_dev), int(layer), _ptr(picks), _stream(), meta=dict(n_dst=dst.numel(), fanout=int(fanout)))
+    return picks
+
+
+def stage_segments(pairs, pad=-1):
+    """One launch: for every (src, dst, count) copy ``count`` leading elements of ``src`` into ``dst`` and fill the rest of
+    ``dst`` with ``pad``.  int32 / int64 tensors (contiguous); the staging step of a captured train step."""
+    k = len(pairs)
+    srcs = (C.c_void_p * k)(*[t[0].data_ptr() if t[2] > 0 else None for t in pairs])
+    dsts = (C.c_void_p * k)(*[t[1].data_ptr() for t in pairs])
+    cnt = (C.c_int64 * k)(*[int(t[2]) for t in pairs])
+    cap = (C.c_int64 * k)(*[t[1].numel() for t in pairs])
+    el = (C.c_int * k)(*[t[1].element_size() for t in pairs])
+    for src, dst, n in pairs:
+        assert dst.is_contiguous() and dst.is_cuda and (n == 0 or (src.is_contiguous() and src.dtype == dst.dtype and src.numel() >= n))
+    _launch("ogl_stage_segments", _lib.lib().ogl_stage_segments, k, srcs, dsts, cnt, cap, el, int(pad), _stream(), meta=dict(nseg=k))
+
+
+def build_block_async(dst: torch.Tensor, picks: torch.Tensor, pad_tail: bool = False):
     """Enqueue the relabelling; returns (src_ids[cap], n_src_dev[1], local_idx) without synchronising."""
     dst = _ids(dst)
     n_dst, fanout = picks.shape
     assert n_dst == dst.numel() and picks.dtype == torch.int64 and picks.is_contiguous()
     dev = dst.device
     cap = n_dst * (1 + fanout)
-    src_ids = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+    # pad_tail: the entries of src_ids past the (device-side) source count read -1 = "no vertex" (a captured step uses the
+    # whole capacity as its padded source list; the eager path slices by the read-back count and never looks at them)
+    if pad_tail:
+        src_ids = torch.full((max(cap, 1),), -1, dtype=torch.int64, device=dev)
+    else:
+        src_ids = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
     n_src = torch.zeros(1, dtype=torch.int64, device=dev)
     local_idx = torch.empty((n_dst, fanout), dtype=torch.int32, device=dev)
     nbytes = int(_lib.lib().ogl_block_workspace_bytes(n_dst, fanout))
@@ -602,6 +632,21 @@ def adam_step_multi(ps, gs, ms, vs, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1
     n = (C.c_int64 * k)(*[p.numel() for p in ps])
     _launch("ogl_adam_step_multi", _lib.lib().ogl_adam_step_multi, k, arr(ps), arr(gs), arr(ms), arr(vs), n, int(step),
             C.c_double(lr), C.c_double(beta1), C.c_double(beta2), C.c_double(eps), _stream(), meta=dict(n=sum(p.numel() for p in ps)))
+
+
+def adam_step_multi_dev(ps, gs, ms, vs, step_dev, scalars_dev, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
+    """adam_step_multi with the step count in device memory (``step_dev`` int64[1], incremented by the call on the device;
+    ``scalars_dev`` float32[2] scratch): capturable in a hipGraph."""
+    k = len(ps)
+    for p, g, m, v in zip(ps, gs, ms, vs):
+        for t in (p, g, m, v):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+    assert step_dev.dtype == torch.int64 and step_dev.is_cuda and scalars_dev.dtype == torch.float32 and scalars_dev.numel() >= 2
+    arr = lambda ts: (C.c_void_p * k)(*[t.data_ptr() for t in ts])
+    n = (C.c_int64 * k)(*[p.numel() for p in ps])
+    _launch("ogl_adam_step_multi_dev", _lib.lib().ogl_adam_step_multi_dev, k, arr(ps), arr(gs), arr(ms), arr(vs), n, _ptr(step_dev),
+            _ptr(scalars_dev), C.c_double(lr), C.c_double(beta1), C.c_double(beta2), C.c_double(eps), _stream(),
+            meta=dict(n=sum(p.numel() for p in ps)))
 
 
 # --------------------------------------------------------------------------------------------

@@ -1,0 +1,102 @@
+"""Captured train steps (stepgraph.py) against the eager launches of the same strategy: same seeds, same Philox counters,
+same initial weights -> the same losses and updates up to fp32 summation order (padded rows add exact zeros; split
+reductions may cut the padded length elsewhere).  The oracle parity of the captured path itself is in test_gpu_rungs.py
+(graphs=True).  Run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _twins(feat_size, H, n_classes, cls, *args, **kw):
+    from ogl_amd.graphsage import GraphSAGE
+    out = []
+    for graphs in (False, True):
+        torch.manual_seed(9)
+        model = GraphSAGE(feat_size, H, n_classes, 1, F.relu, 0, "pool", edge_feats=0, pool_feats=H).cuda()
+        st = cls(model, *args, **kw)
+        st.use_graphs = graphs
+        st.build_optimizer()
+        out.append(st)
+    return out
+
+
+def _weights_close(a, b, frac=1e-3):
+    """Adam turns a gradient within summation noise of zero into a step anywhere in [-lr, lr] (see test_gpu_rungs.py):
+    per entry 2e-5, at most ``frac`` of the entries outside, none by more than 2 lr per step."""
+    bad = total = 0
+    for x, y in zip(a.parameters(), b.parameters()):
+        d = (x.detach() - y.detach()).abs()
+        bad += int((d > 2e-5).sum()); total += d.numel()
+    assert bad <= frac * total, (bad, total)
+
+
+@pytest.mark.parametrize("name,B,S,H", [("toy", 16, 5, 16), ("pubmed", 32, 25, 32)])
+def test_sampled_graph_steps_equal_eager(name, B, S, H):
+    import ogl_amd  # noqa: F401
+    from ogl_amd import sampling, synthetic
+    from ogl_amd.graphsage.model import PrioritizedHipSupervisedGraphSage, RandomHipSupervisedGraphSage
+    from ogl_amd.prioritized_replay import LossPriority
+    feat_size, labels, dyn, n_classes, _ = synthetic.load(name, snapshots=4, device="cuda")
+    dyn.evolve(); dyn.evolve()
+    g = dyn.get_graph()
+    rng = np.random.default_rng(0)
+    for cls, extra in ((RandomHipSupervisedGraphSage, ()), (PrioritizedHipSupervisedGraphSage, (LossPriority(),))):
+        eager, graph = _twins(feat_size, H, n_classes, cls, 3, B, labels, S, *extra, cuda=True, batch_full=256)
+        seeds = [rng.choice(g.n_present, 3 * B + (5 if k == 1 else 0), replace=False).astype(np.int64) for k in range(3)]
+        out = {}
+        for st in (eager, graph):
+            rec = []
+            st.step_hook = lambda info, rec=rec: rec.append((info["form"], float(info["loss"])))
+            rows = []
+            sampling.seed(4)
+            for k, sd in enumerate(seeds):
+                if k == 2:
+                    dyn_n = g.n_present                      # the snapshot moves on under the SAME captured graph
+                    g.set_snapshot(max(dyn_n - 7, 1), max(dyn_n - 7, 1))
+                st._train_batches(g, sd, B, on_rows=(lambda s_, r_: rows.append(r_.cpu())) if extra else None)
+                if k == 2:
+                    g.set_snapshot(dyn_n, dyn_n)
+            out[st.use_graphs] = (rec, rows, sampling.get_state()["ctr"])
+        (rec_e, rows_e, ctr_e), (rec_g, rows_g, ctr_g) = out[False], out[True]
+        assert ctr_e == ctr_g == 3 + 4 + 3
+        assert [f for f, _ in rec_e] == ["eager"] * 10
+        # three full batches per snapshot replay the captured step; the ragged batch of snapshot 1 runs eagerly
+        assert [f for f, _ in rec_g] == ["sampled"] * 3 + ["sampled"] * 3 + ["eager"] + ["sampled"] * 3
+        np.testing.assert_allclose([l for _, l in rec_g], [l for _, l in rec_e], rtol=2e-4)
+        if extra:
+            assert len(rows_e) == len(rows_g) == 10
+            for a, b in zip(rows_e, rows_g):
+                np.testing.assert_allclose(b.numpy(), a.numpy(), rtol=2e-4, atol=1e-6)
+        _weights_close(eager.graphsage_model, graph.graphsage_model, frac=5e-3)
+        assert graph._step_graphs().captures == 1
+
+
+def test_staged_graph_steps_equal_eager_reddit_size():
+    """The Reddit rung: loader-sampled batches staged into per-bucket captured steps; 4 steps of 512 seeds."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops, sampling, synthetic
+    from ogl_amd.graphsage.model import RandomHipSupervisedGraphSage
+    feat_size, labels, dyn, n_classes, _ = synthetic.load("reddit", snapshots=2, device="cuda")
+    dyn.evolve()
+    g = dyn.get_graph()
+    ops.set_gemm_mode("auto")
+    try:
+        eager, graph = _twins(feat_size, 600, n_classes, RandomHipSupervisedGraphSage, 4, 512, labels, 25, cuda=True, batch_full=1024)
+        seeds = np.random.default_rng(1).choice(g.n_present, 4 * 512, replace=False).astype(np.int64)
+        losses = {}
+        for st in (eager, graph):
+            rec = []
+            st.step_hook = lambda info, rec=rec: rec.append((info["form"], float(info["loss"]), info["n0"], info["n1"]))
+            sampling.seed(8)
+            st._train_batches(g, seeds, 512)
+            losses[st.use_graphs] = rec
+        assert [r[0] for r in losses[True]] == ["staged"] * 4 and [r[0] for r in losses[False]] == ["eager"] * 4
+        assert [r[2:] for r in losses[True]] == [r[2:] for r in losses[False]]           # the same sampled blocks
+        np.testing.assert_allclose([r[1] for r in losses[True]], [r[1] for r in losses[False]], rtol=2e-4)
+        _weights_close(eager.graphsage_model, graph.graphsage_model, frac=5e-3)
+        assert 1 <= graph._step_graphs().captures <= 4
+    finally:
+        ops.set_gemm_mode("f32")
