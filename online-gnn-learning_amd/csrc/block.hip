@@ -7,6 +7,7 @@
 // id's minimum are "first appearances"; a 3-phase exclusive scan of those flags gives the local
 // index.  Integer/HBM-bound work, no MFMA.
 #include "ogl_common.h"
+#include <algorithm>
 
 #define BLK_SCAN 1024
 
@@ -34,6 +35,18 @@ static inline int64_t ws_bytes(int64_t P) {
 extern "C" int64_t ogl_block_workspace_bytes(int64_t n_dst, int fanout) {
   if (n_dst < 0 || fanout < 0) return OGL_EINVAL;
   return ws_bytes(n_dst * (1 + (int64_t)fanout));
+}
+
+// table reset as a KERNEL (tkey = -1, tmin = INT_MAX-ish): the two arrays are adjacent, one launch fills both.  (A
+// hipMemsetAsync node recorded into a captured hipGraph re-runs on only 1/16 of its range from the second replay on — ROCm
+// 7.2, shown by tools/graph_probe.py —: stale keys filled the table and every insert probed all of it, 17-57 ms per build.)
+__global__ void __launch_bounds__(256) k_block_reset(int32_t* __restrict__ tkey_tmin, int64_t T) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * T; i += (int64_t)gridDim.x * blockDim.x)
+    tkey_tmin[i] = i < T ? -1 : 0x7F7F7F7F;
+}
+
+static inline void launch_block_reset(int32_t* tkey, int64_t T, hipStream_t stream) {
+  hipLaunchKernelGGL(k_block_reset, dim3((unsigned)std::min<int64_t>(ogl_cdiv(2 * T, 256), 2048)), dim3(256), 0, stream, tkey, T);
 }
 
 __device__ __forceinline__ int64_t flat_id(const int64_t* __restrict__ dst, const int64_t* __restrict__ picks,
@@ -172,8 +185,8 @@ extern "C" int ogl_build_block(const int64_t* dst, int64_t n_dst, const int64_t*
   ws.tkey = base; ws.tmin = base + ws.T; ws.tlidx = base + 2 * ws.T; ws.slot = base + 3 * ws.T;
   ws.bsum = ws.slot + ogl_round_up(P, 4);
   int logT = 0; while (((int64_t)1 << logT) < ws.T) ++logT;
-  OGL_CHECK_HIP(hipMemsetAsync(ws.tkey, 0xFF, sizeof(int32_t) * ws.T, stream));   // -1
-  OGL_CHECK_HIP(hipMemsetAsync(ws.tmin, 0x7F, sizeof(int32_t) * ws.T, stream));   // 0x7F7F7F7F > P
+  launch_block_reset(ws.tkey, ws.T, stream);                                       // tkey = -1, tmin = 0x7F7F7F7F > P
+  OGL_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_block_insert, dim3((unsigned)ogl_cdiv(P, 256)), dim3(256), 0, stream, dst, picks,
                      n_dst, P, ws.tkey, ws.tmin, ws.slot, (uint32_t)(ws.T - 1), 32 - logT);
   OGL_CHECK_LAUNCH();
@@ -360,8 +373,8 @@ extern "C" int ogl_build_block_batched(const int64_t* dst_base, const int64_t* d
     w.bsum = slot0 + ogl_round_up(rows * (1 + (int64_t)fanout), 4);
     int logT = 0; while (((int64_t)1 << logT) < w.T) ++logT;
     w.mask = (uint32_t)(w.T - 1); w.shift = 32 - logT;
-    OGL_CHECK_HIP(hipMemsetAsync(w.tkey, 0xFF, sizeof(int32_t) * w.T * m, stream));   // -1
-    OGL_CHECK_HIP(hipMemsetAsync(w.tmin, 0x7F, sizeof(int32_t) * w.T * m, stream));   // 0x7F7F7F7F > P
+    launch_block_reset(w.tkey, w.T * m, stream);                                       // tkey = -1, tmin = 0x7F7F7F7F > P
+    OGL_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_block_insert_b, dim3((unsigned)ogl_cdiv(Pmax, 256), (unsigned)m), dim3(256), 0, stream, dst_base, picks, w);
     OGL_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_block_count_b, dim3((unsigned)w.NBmax, (unsigned)m), dim3(BLK_SCAN), 0, stream, w);

@@ -215,6 +215,11 @@ static PbDiv pb_make_div(unsigned G) {
   return v;
 }
 
+__global__ void __launch_bounds__(256) k_pb_zero16(uint4* __restrict__ p, int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 extern "C" int64_t ogl_pool_bwd_x3_workspace_bytes(int64_t n_dst, int fanout, int d, int64_t n_src) {
   if (n_dst < 0 || n_src < 0 || fanout < 0 || d < 0) return OGL_EINVAL;
   return pb_bitmap_bytes(n_dst, n_src) + pb_off_bytes(n_dst, fanout) + ogl_round_up(n_dst * (int64_t)d * 8 + 16, 256);
@@ -235,8 +240,13 @@ extern "C" int ogl_pool_bwd_x3(const float* dout, int64_t ldo, const int32_t* ar
   unsigned short* off = (unsigned short*)((unsigned char*)workspace + pb_bitmap_bytes(n_dst, n_src));
   uint2* ent = (uint2*)((unsigned char*)off + pb_off_bytes(n_dst, fanout));
   const int64_t gstride = ((int64_t)d + 1) * 192;                 // GROUP-MAJOR image: [group][d rows + zero row][192 B]
-  // the whole 256-B-rounded region: a size that is not a multiple of the runtime's fill width costs two extra launches
-  OGL_CHECK_HIP(hipMemsetAsync(bitmap, 0, (size_t)pb_bitmap_bytes(n_dst, n_src), st));
+  // zeroed by a KERNEL, not hipMemsetAsync: a memset node recorded into a captured hipGraph re-runs on only 1/16 of its
+  // range from the second replay on (ROCm 7.2; tools/graph_probe.py shows it), and the step is replayed as a graph
+  {
+    const int64_t n16 = pb_bitmap_bytes(n_dst, n_src) / 16;       // the region is 256-B rounded and 16-B aligned
+    hipLaunchKernelGGL(k_pb_zero16, dim3((unsigned)std::min<int64_t>(ogl_cdiv(n16, 256), 2048)), dim3(256), 0, st, (uint4*)bitmap, n16);
+    OGL_CHECK_LAUNCH();
+  }
   const PbDiv dv = pb_make_div((unsigned)groups);
   if (n_dst > 0 && fanout > 0) {
     hipLaunchKernelGGL(k_pool_bucket, dim3((unsigned)ogl_cdiv(n_dst, 4)), dim3(256), 0, st, dout, ldo, argmax, relu_out, ldr, idx32,

@@ -137,8 +137,9 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         self.xent = lambda scores, labels_: ops.cross_entropy(scores, labels_, reduction)
         self.gsync = None                      # set by build_optimizer() under torch.distributed
 
-    # a batch whose padded input block B (1 + S)^2 stays below this many rows is captured WITH its sampling (upper-bound
-    # shapes, no read-back at all); larger batches keep the loader and are captured per size bucket (stepgraph.py)
+    # a batch whose upper-bound input block B (1 + S)^2 stays below this many rows samples inside a captured graph of its own
+    # (one 16-byte read-back per step picks the train graph's size bucket); larger batches keep the loader, whose read-backs
+    # amortise over the snapshot's batches, and stage each batch into its bucket's train graph (stepgraph.py)
     SAMPLED_GRAPH_MAX_ROWS = 65536
 
     def build_optimizer(self):
@@ -222,12 +223,12 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             for i, s0 in enumerate(starts):
                 sd = seeds_np[s0:s0 + bs]
                 if len(sd) == bs:
-                    sg = self._step_graphs().sampled(graph, bs)
-                    sg.run_sampled(sd, ctrs[i])
+                    sg = self._step_graphs().sampled_step(graph, sd, ctrs[i])
                     if on_rows is not None:
-                        on_rows(sg.head[1:].clone(), sg.loss_rows.clone())
+                        on_rows(sg.buf.seeds.clone(), sg.loss_rows.clone())
                     if self.step_hook is not None:
-                        self.step_hook(dict(seeds=sd, loss=sg.loss, grads=sg.grads, form="sampled", ctr=ctrs[i]))
+                        self.step_hook(dict(seeds=sd, loss=sg.loss, grads=sg.grads, form="sampled", ctr=ctrs[i],
+                                            n0=sg.last_sizes[0], n1=sg.last_sizes[1]))
                 else:                                        # the ragged last batch: eager, with its own counter
                     sdev = torch.as_tensor(sd).to(graph.device)
                     (input_nodes, sdd, blocks), = self._sampler().sample_batches(graph, [sdev], ctrs=[ctrs[i]])
@@ -363,8 +364,8 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         if self.gsync is None and (n_global is None or n_global == seeds.numel()):
             if self._graphs_ok():
                 n0, n1 = int(input_nodes.numel()), blocks[1].number_of_src_nodes()
-                sg = self._step_graphs().staged(graph, int(seeds.numel()), n0, n1)      # captured on first use of the bucket
-                loss = sg.run_staged(seeds, blocks, n0, n1)
+                sg = self._step_graphs().staged_step(graph, seeds, blocks, n0, n1)       # captured on first use of the bucket
+                loss = sg.loss
                 if on_rows is not None:
                     on_rows(seeds, sg.loss_rows.clone())
                 if self.step_hook is not None:

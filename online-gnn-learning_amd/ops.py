@@ -181,21 +181,31 @@ def stage_segments(pairs, pad=-1):
     _launch("ogl_stage_segments", _lib.lib().ogl_stage_segments, k, srcs, dsts, cnt, cap, el, int(pad), _stream(), meta=dict(nseg=k))
 
 
-def build_block_async(dst: torch.Tensor, picks: torch.Tensor, pad_tail: bool = False):
-    """Enqueue the relabelling; returns (src_ids[cap], n_src_dev[1], local_idx) without synchronising."""
+def build_block_async(dst: torch.Tensor, picks: torch.Tensor, pad_tail: bool = False, out=None):
+    """Enqueue the relabelling; returns (src_ids[cap], n_src_dev[1], local_idx) without synchronising.
+
+    ``pad_tail``: the entries of src_ids past the (device-side) source count read -1 = "no vertex" (a captured step uses the
+    whole capacity as its padded source list; the eager path slices by the read-back count and never looks at them).
+    ``out = (src_ids, n_src, local_idx)``: caller-owned outputs (the static buffers of a captured step)."""
     dst = _ids(dst)
     n_dst, fanout = picks.shape
     assert n_dst == dst.numel() and picks.dtype == torch.int64 and picks.is_contiguous()
     dev = dst.device
     cap = n_dst * (1 + fanout)
-    # pad_tail: the entries of src_ids past the (device-side) source count read -1 = "no vertex" (a captured step uses the
-    # whole capacity as its padded source list; the eager path slices by the read-back count and never looks at them)
-    if pad_tail:
-        src_ids = torch.full((max(cap, 1),), -1, dtype=torch.int64, device=dev)
+    if out is not None:
+        src_ids, n_src, local_idx = out
+        assert src_ids.numel() >= cap and src_ids.dtype == torch.int64 and src_ids.is_contiguous()
+        assert n_src.dtype == torch.int64 and n_src.numel() >= 1
+        assert local_idx.dtype == torch.int32 and local_idx.is_contiguous() and local_idx.numel() >= n_dst * fanout
+        if pad_tail:
+            src_ids.fill_(-1)
     else:
-        src_ids = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
-    n_src = torch.zeros(1, dtype=torch.int64, device=dev)
-    local_idx = torch.empty((n_dst, fanout), dtype=torch.int32, device=dev)
+        if pad_tail:
+            src_ids = torch.full((max(cap, 1),), -1, dtype=torch.int64, device=dev)
+        else:
+            src_ids = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+        n_src = torch.zeros(1, dtype=torch.int64, device=dev)
+        local_idx = torch.empty((n_dst, fanout), dtype=torch.int32, device=dev)
     nbytes = int(_lib.lib().ogl_block_workspace_bytes(n_dst, fanout))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
     _launch("ogl_build_block", _lib.lib().ogl_build_block, _ptr(dst), n_dst, _ptr(picks), int(fanout), _ptr(src_ids), _ptr(n_src),

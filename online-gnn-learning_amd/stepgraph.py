@@ -1,25 +1,27 @@
-"""Captured train steps: one hipGraph launch per replay batch instead of ~40 launches enqueued from Python.
+"""Captured train steps: hipGraph launches per replay batch instead of ~40 launches enqueued from Python.
 
 The update path of a batch is a fixed sequence of microsecond-to-sub-millisecond kernels (sample x2, block build x2,
 forward, cross entropy, backward, Adam).  Enqueued one by one through ctypes + autograd it costs the host 0.8-0.9 ms per
 step — the small rungs (pubmed / arxiv, 32 seeds) are 100 % launch- and sync-bound that way, and the Reddit rung is within
-30 % of it.  ``TrainStepGraph`` records that sequence ONCE (``torch.cuda.graph``: a HIP stream capture of exactly the
-C-ABI launches the eager path makes, autograd backward and the optimiser step included) on static buffers of padded
-shapes and replays it.  What varies between replays lives in device memory: the seeds / block arrays (static input
-buffers), the Philox batch counter (``ogl_sample_layer_dev``), Adam's step count (``ogl_adam_step_multi_dev``).
+30 % of it.  The classes here record those launches ONCE (``torch.cuda.graph``: a HIP stream capture of exactly the C-ABI
+launches the eager path makes, autograd backward and the optimiser step included) on static buffers and replay them.
+What varies between replays lives in device memory: the seeds / block arrays (static buffers), the Philox batch counter
+(``ogl_sample_layer_dev``), Adam's step count (``ogl_adam_step_multi_dev``).
 
-Two forms:
+* ``TrainStepGraph`` — forward + loss + backward + Adam of ONE batch on block arrays of a size BUCKET (``n0`` rounded up;
+  id -1 pads).  Padding is exact, not approximate (include/ogl_hip.h, "Padding contract"): id -1 samples nothing / gathers
+  the zero row, so padded rows add exact zeros to every product and gradient; only the fp32 summation ORDER of split
+  reductions can differ from the unpadded eager step.
+* ``SampleGraph`` (small batches) — sampling + block construction of one batch on upper-bound buffers
+  (``n1 <= B (1 + S)``, ``n0 <= n1 (1 + S)``), straight into the static block arrays the train graphs read: a step is one
+  host->device copy of ``[counter | seeds]``, the sample graph, ONE 16-byte read-back (the two source counts: they choose
+  the train graph's bucket, so that the GEMMs run at the batch's size, not at 28x the upper bound), the train graph.
+* staged (Reddit rung): the loader samples the snapshot's batches as before (one read-back per layer per LOADER, amortised
+  over 50 batches); per batch ONE ``ogl_stage_segments`` launch copies the batch's block arrays into the static buffers
+  of the train graph captured for its bucket (``n1`` to 256, ``n0`` to 2 048 rows: <= 3 % padded rows).
 
-* ``sampled`` (small rungs): sampling and block construction are INSIDE the graph, shapes are the upper bounds
-  ``n1 = B (1 + S)``, ``n0 = n1 (1 + S)`` — no block-size read-back, no host synchronisation at all; a step is one
-  host->device copy of ``[counter | seeds]`` and one graph launch.
-* ``staged`` (Reddit rung): the loader samples the snapshot's batches as before (one read-back per layer per LOADER,
-  amortised over 50 batches); per batch, ONE ``ogl_stage_segments`` launch copies the batch's block arrays into the static
-  buffers of the graph captured for its size bucket (``n1`` rounded up to 256, ``n0`` to 2 048 rows: <= 3 % padded rows).
-
-Padding is exact, not approximate (include/ogl_hip.h, "Padding contract"): id -1 samples nothing / gathers the zero row,
-so padded rows add exact zeros to every product and gradient; only the fp32 summation ORDER of split reductions can
-differ from the unpadded eager step.
+hipMemsetAsync must not appear in captured code: on ROCm 7.2 a memset node re-runs on 1/16 of its range from the second
+replay on (tools/graph_probe.py); every fill on these paths is a kernel.
 
 Not captured: steps under torch.distributed (the gradient all-reduce stays eager), dropout > 0 (its counter is host-side).
 """
@@ -36,50 +38,46 @@ def round_up(x, m):
     return (int(x) + m - 1) // m * m
 
 
-N1_BUCKET = 256
+N1_BUCKET = 256          # staged form
 N0_BUCKET = 2048
+N0_BUCKET_SMALL = 256    # sampled form (input blocks of a few hundred to a few thousand rows)
 _WARMED = False
 
 
-class TrainStepGraph:
-    """One captured train step.  ``loss_fn(logits, labels) -> (scalar loss to differentiate, per-seed losses or None)``."""
+class BlockBuffers:
+    """The static block arrays of one batch shape: what a train graph reads, what staging / a sample graph writes."""
 
-    def __init__(self, model, optimizer, graph, B, S, loss_fn, form, n1_pad=None, n0_pad=None, pool=None):
-        assert form in ("sampled", "staged")
-        self.model, self.opt, self.graph, self.B, self.S, self.form = model, optimizer, graph, int(B), int(S), form
-        self.loss_fn = loss_fn
-        dev = graph.device
-        self.n1_pad = self.B * (1 + self.S) if form == "sampled" else int(n1_pad)
-        self.n0_pad = self.n1_pad * (1 + self.S) if form == "sampled" else int(n0_pad)
-        # static inputs
-        self.head = torch.zeros(1 + self.B, dtype=torch.int64, device=dev)          # [Philox batch counter | seeds]
-        self.head_host = torch.zeros(1 + self.B, dtype=torch.int64).pin_memory()
-        if form == "staged":
-            self.src0 = torch.full((self.n0_pad,), -1, dtype=torch.int64, device=dev)
-            self.src1 = torch.full((self.n1_pad,), -1, dtype=torch.int64, device=dev)
-            self.lidx0 = torch.full((self.n1_pad, self.S), -1, dtype=torch.int32, device=dev)
-            self.lidx1 = torch.full((self.B, self.S), -1, dtype=torch.int32, device=dev)
-        self.loss = None
-        self.loss_rows = None
+    def __init__(self, B, S, n1_cap, n0_cap, device):
+        self.B, self.S, self.n1_cap, self.n0_cap = int(B), int(S), int(n1_cap), int(n0_cap)
+        self.head = torch.zeros(1 + self.B, dtype=torch.int64, device=device)          # [Philox batch counter | seeds]
+        self.src0 = torch.full((self.n0_cap,), -1, dtype=torch.int64, device=device)
+        self.src1 = torch.full((self.n1_cap,), -1, dtype=torch.int64, device=device)
+        self.lidx0 = torch.full((self.n1_cap, self.S), -1, dtype=torch.int32, device=device)
+        self.lidx1 = torch.full((self.B, self.S), -1, dtype=torch.int32, device=device)
+
+    @property
+    def seeds(self):
+        return self.head[1:]
+
+
+class TrainStepGraph:
+    """One captured train step over ``buf`` restricted to (n1_pad, n0_pad) rows.
+    ``loss_fn(logits, labels) -> (scalar loss to differentiate, per-seed losses or None)``."""
+
+    def __init__(self, model, optimizer, graph, buf, n1_pad, n0_pad, loss_fn, pool=None):
+        self.model, self.opt, self.graph, self.buf, self.loss_fn = model, optimizer, graph, buf, loss_fn
+        self.n1_pad, self.n0_pad = int(n1_pad), int(n0_pad)
+        assert self.n1_pad <= buf.n1_cap and self.n0_pad <= buf.n0_cap
+        self.loss = self.loss_rows = None
         self.cuda_graph = torch.cuda.CUDAGraph()
         self._capture(pool)
 
-    # the step, written once: runs eagerly for nothing, only ever under capture
     def _body(self, apply=True):
-        g, S = self.graph, self.S
-        seeds = self.head[1:]
-        if self.form == "sampled":
-            ctr = self.head[:1]
-            seed = sampling.get_state()["seed"]
-            picks1 = ops.sample_layer_dev(g.handle, seeds, S, seed, ctr, 1)
-            src1, _, lidx1 = ops.build_block_async(seeds, picks1, pad_tail=True)           # [B (1 + S)], -1 past n1
-            picks0 = ops.sample_layer_dev(g.handle, src1, S, seed, ctr, 0)
-            src0, _, lidx0 = ops.build_block_async(src1, picks0, pad_tail=True)            # [n1_pad (1 + S)], -1 past n0
-        else:
-            src0, src1, lidx0, lidx1 = self.src0, self.src1, self.lidx0, self.lidx1
-        blocks = [sampling.Block(src0, src1, lidx0), sampling.Block(src1, seeds, lidx1)]
+        g, b = self.graph, self.buf
+        src0, src1, lidx0 = b.src0[:self.n0_pad], b.src1[:self.n1_pad], b.lidx0[:self.n1_pad]
+        blocks = [sampling.Block(src0, src1, lidx0), sampling.Block(src1, b.seeds, b.lidx1)]
         # the FULL tables: a snapshot view's row count would be frozen into the graph (ids are < n_present by construction)
-        labels = ops.gather_i64(g.target_table, seeds)
+        labels = ops.gather_i64(g.target_table, b.seeds)
         self.opt.zero_grad(set_to_none=True)
         logits = self.model(blocks, GatheredRows(g.feat_table, src0))
         loss, rows = self.loss_fn(logits, labels)
@@ -110,48 +108,94 @@ class TrainStepGraph:
             self._body()
         self.grads = [p.grad for p in self.model.parameters()]
 
-    # ---- replay --------------------------------------------------------------------------------------------------
-    def run_sampled(self, seeds_host, ctr):
-        """seeds_host: int64 array-like [B] (snapshot ids); ctr: this batch's Philox counter."""
+    def replay(self):
+        self.cuda_graph.replay()
+        return self.loss
+
+
+class SampleGraph:
+    """Sampling + block construction of one batch, captured on upper-bound shapes, writing ``buf``.
+
+    The output block is sampled for the B seeds; its source list (capacity B (1 + S), -1 past the n1 found) is the input
+    block's destination list AS IS — padded destinations sample nothing and keep their (all-zero) block rows, so the input
+    block always has ``n1_cap`` destination rows and ``n1_cap + #new`` sources.  ``run`` returns that source count."""
+
+    def __init__(self, graph, buf):
+        self.graph, self.buf = graph, buf
+        assert buf.n1_cap == buf.B * (1 + buf.S) and buf.n0_cap == buf.n1_cap * (1 + buf.S)
+        self.head_host = torch.zeros(1 + buf.B, dtype=torch.int64).pin_memory()
+        self.counts = torch.zeros(2, dtype=torch.int64, device=graph.device)
+        self.counts_host = torch.zeros(2, dtype=torch.int64).pin_memory()
+        self.seed = sampling.get_state()["seed"]
+        self.cuda_graph = torch.cuda.CUDAGraph()
+        self._body()                                         # once for real (helpers, workspaces), then recorded
+        torch.cuda.synchronize()
+        with torch.cuda.graph(self.cuda_graph):
+            self._body()
+
+    def _body(self):
+        g, b, S = self.graph, self.buf, self.buf.S
+        ctr = b.head[:1]
+        # straight into the static block arrays the train graphs read
+        picks1 = ops.sample_layer_dev(g.handle, b.seeds, S, self.seed, ctr, 1)
+        ops.build_block_async(b.seeds, picks1, pad_tail=True, out=(b.src1, self.counts[:1], b.lidx1))   # -1 past n1
+        picks0 = ops.sample_layer_dev(g.handle, b.src1, S, self.seed, ctr, 0)
+        ops.build_block_async(b.src1, picks0, pad_tail=True, out=(b.src0, self.counts[1:], b.lidx0))    # -1 past n0
+
+    def run(self, seeds_host, ctr):
+        """seeds_host: int64 array-like [B] (snapshot ids); ctr: this batch's Philox counter.  Returns (n1, n0)."""
         h = self.head_host
         h[0] = int(ctr)
         h[1:] = torch.as_tensor(np.asarray(seeds_host), dtype=torch.int64)
-        self.head.copy_(h, non_blocking=True)
+        self.buf.head.copy_(h, non_blocking=True)
         self.cuda_graph.replay()
-        return self.loss
-
-    def run_staged(self, seeds, blocks, n0, n1):
-        """seeds [B] (device), blocks = [input block, output block] of the loader; n0 / n1 their source counts."""
-        assert n0 <= self.n0_pad and n1 <= self.n1_pad
-        b0, b1 = blocks
-        ops.stage_segments([(b0.src_ids, self.src0, n0), (b1.src_ids, self.src1, n1),
-                            (b0.local_idx, self.lidx0, n1 * self.S), (b1.local_idx, self.lidx1, self.B * self.S),
-                            (seeds, self.head[1:], self.B)])
-        self.cuda_graph.replay()
-        return self.loss
+        self.counts_host.copy_(self.counts, non_blocking=True)
+        torch.cuda.current_stream().synchronize()            # the step's one read-back: 16 bytes
+        return int(self.counts_host[0]), int(self.counts_host[1])
 
 
 class StepGraphCache:
-    """The captured steps of one (model, optimiser): keyed by form and padded sizes, captured on first use."""
+    """The captured graphs of one (model, optimiser): keyed by form and padded sizes, captured on first use."""
 
     def __init__(self, model, optimizer, S, loss_fn):
         self.model, self.opt, self.S, self.loss_fn = model, optimizer, int(S), loss_fn
-        self.graphs = {}
+        self.bufs, self.samplers, self.graphs = {}, {}, {}
         self.captures = 0
 
-    def sampled(self, graph, B):
-        key = ("sampled", id(graph), int(B), sampling.get_state()["seed"])
+    def _train(self, graph, buf, key, n1_pad, n0_pad):
         sg = self.graphs.get(key)
         if sg is None:
-            sg = self.graphs[key] = TrainStepGraph(self.model, self.opt, graph, B, self.S, self.loss_fn, "sampled")
+            sg = self.graphs[key] = TrainStepGraph(self.model, self.opt, graph, buf, n1_pad, n0_pad, self.loss_fn)
             self.captures += 1
         return sg
 
-    def staged(self, graph, B, n0, n1):
+    def sampled_step(self, graph, seeds_host, ctr):
+        """One whole step of a small batch: sample graph -> 16-byte read-back -> the train graph of the size bucket."""
+        B = len(seeds_host)
+        bkey = ("sampled", id(graph), B, sampling.get_state()["seed"])
+        smp = self.samplers.get(bkey)
+        if smp is None:
+            n1_cap = B * (1 + self.S)
+            buf = self.bufs[bkey] = BlockBuffers(B, self.S, n1_cap, n1_cap * (1 + self.S), graph.device)
+            smp = self.samplers[bkey] = SampleGraph(graph, buf)
+        n1, n0 = smp.run(seeds_host, ctr)
+        n0_pad = min(round_up(n0, N0_BUCKET_SMALL), smp.buf.n0_cap)
+        sg = self._train(graph, smp.buf, bkey + (n0_pad,), smp.buf.n1_cap, n0_pad)
+        sg.replay()
+        sg.last_sizes = (n0, n1)
+        return sg
+
+    def staged_step(self, graph, seeds, blocks, n0, n1):
+        """One step of a loader batch: stage its block arrays into the bucket's static buffers, replay its train graph."""
+        B = int(seeds.numel())
         n0_pad, n1_pad = round_up(n0, N0_BUCKET), round_up(n1, N1_BUCKET)
-        key = ("staged", id(graph), int(B), n0_pad, n1_pad)
-        sg = self.graphs.get(key)
-        if sg is None:
-            sg = self.graphs[key] = TrainStepGraph(self.model, self.opt, graph, B, self.S, self.loss_fn, "staged", n1_pad, n0_pad)
-            self.captures += 1
+        bkey = ("staged", id(graph), B, n0_pad, n1_pad)
+        buf = self.bufs.get(bkey)
+        if buf is None:
+            buf = self.bufs[bkey] = BlockBuffers(B, self.S, n1_pad, n0_pad, graph.device)
+        sg = self._train(graph, buf, bkey, n1_pad, n0_pad)
+        b0, b1 = blocks
+        ops.stage_segments([(b0.src_ids, buf.src0, n0), (b1.src_ids, buf.src1, n1), (b0.local_idx, buf.lidx0, n1 * self.S),
+                            (b1.local_idx, buf.lidx1, B * self.S), (seeds, buf.seeds, B)])
+        sg.replay()
         return sg

@@ -45,7 +45,9 @@ def test_sampled_graph_steps_equal_eager(name, B, S, H):
     rng = np.random.default_rng(0)
     for cls, extra in ((RandomHipSupervisedGraphSage, ()), (PrioritizedHipSupervisedGraphSage, (LossPriority(),))):
         eager, graph = _twins(feat_size, H, n_classes, cls, 3, B, labels, S, *extra, cuda=True, batch_full=256)
-        seeds = [rng.choice(g.n_present, 3 * B + (5 if k == 1 else 0), replace=False).astype(np.int64) for k in range(3)]
+        # (snapshot 2 is run on a smaller cut, see below: its seeds must be present there)
+        seeds = [rng.choice(g.n_present - (7 if k == 2 else 0), 3 * B + (5 if k == 1 else 0), replace=False).astype(np.int64)
+                 for k in range(3)]
         out = {}
         for st in (eager, graph):
             rec = []
@@ -71,7 +73,7 @@ def test_sampled_graph_steps_equal_eager(name, B, S, H):
             for a, b in zip(rows_e, rows_g):
                 np.testing.assert_allclose(b.numpy(), a.numpy(), rtol=2e-4, atol=1e-6)
         _weights_close(eager.graphsage_model, graph.graphsage_model, frac=5e-3)
-        assert graph._step_graphs().captures == 1
+        assert 1 <= graph._step_graphs().captures <= 6          # train graphs: one per input-size bucket met
 
 
 def test_staged_graph_steps_equal_eager_reddit_size():

