@@ -169,6 +169,88 @@ __global__ void __launch_bounds__(256) k_block_lookup(const int32_t* __restrict_
   local_idx[e] = s >= 0 ? tlidx[s] : -1;
 }
 
+// ---- small blocks: the whole relabelling in ONE workgroup ------------------------------------------------------------------
+// A 32-seed batch relabels P = n_dst (1 + fanout) <= ~22 k positions: the six launches above are pure launch latency there
+// (4-5 us each inside a replayed graph).  One 1024-thread block walks the same phases with __syncthreads() between them —
+// table reset, insert (atomicMin of the flat position), first-appearance flags + scan (carried across 1024-position chunks),
+// assign, lookup — and, optionally, fills src_ids past the source count with -1.  Same results as the multi-launch path.
+#define BLK_SMALL_MAX_P 65536
+__global__ void __launch_bounds__(BLK_SCAN) k_block_build_small(const int64_t* __restrict__ dst, const int64_t* __restrict__ picks,
+                                                                int64_t n_dst, int64_t P, int32_t* tkey, int32_t* tmin,
+                                                                int32_t* tlidx, int32_t* slot, uint32_t mask, int shift, int64_t T,
+                                                                int64_t* __restrict__ src_ids, int64_t src_cap, int pad_tail,
+                                                                int64_t* __restrict__ n_src_out, int32_t* __restrict__ local_idx) {
+  __shared__ int carry_s;
+  const int tid = threadIdx.x;
+  for (int64_t i = tid; i < 2 * T; i += BLK_SCAN) tkey[i] = i < T ? -1 : 0x7F7F7F7F;     // tkey | tmin are adjacent
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t p = tid; p < P; p += BLK_SCAN) {
+    const int64_t id64 = flat_id(dst, picks, n_dst, p);
+    int32_t sl = -1;
+    if (id64 >= 0) {
+      const int32_t id = (int32_t)id64;
+      uint32_t h = ((uint32_t)id * 0x9E3779B1u) >> shift;
+      for (uint32_t probe = 0; probe <= mask; ++probe) {
+        const int32_t old = atomicCAS(&tkey[h], -1, id);
+        if (old == -1 || old == id) { atomicMin(&tmin[h], (int32_t)p); sl = (int32_t)h; break; }
+        h = (h + 1) & mask;
+      }
+    }
+    slot[p] = sl;
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int64_t base = 0; base < P; base += BLK_SCAN) {
+    const int64_t p = base + tid;
+    // tmin was last written by device-scope atomics of OTHER threads in this launch: read it with a device-coherent load
+    // (a plain load may be served from an L1 line fetched before those atomics; kernel boundaries did that job above)
+    const int32_t sp = p < P ? slot[p] : -1;
+    const bool own = sp >= 0 && __hip_atomic_load(&tmin[sp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)p;
+    const int f = p < P && (p < n_dst || own) ? 1 : 0;
+    int tot;
+    const int pre = block_scan_1024(f, &tot);
+    const int carry = carry_s;
+    if (f) {
+      const int32_t li = carry + pre;
+      src_ids[li] = flat_id(dst, picks, n_dst, p);
+      if (own) tlidx[sp] = li;
+    }
+    __syncthreads();
+    if (tid == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  const int n_src = carry_s;
+  if (tid == 0) *n_src_out = (int64_t)n_src;
+  if (pad_tail)
+    for (int64_t i = n_src + tid; i < src_cap; i += BLK_SCAN) src_ids[i] = -1;
+  __threadfence_block();
+  __syncthreads();
+  for (int64_t e = tid; e < P - n_dst; e += BLK_SCAN) {
+    const int32_t s = slot[n_dst + e];
+    local_idx[e] = s >= 0 ? tlidx[s] : -1;
+  }
+}
+
+// ogl_build_block with the tail of src_ids [n_src, src_cap) set to -1 ("no vertex"): what a captured step needs of a block
+// whose source count stays on the device.  src_cap >= n_dst (1 + fanout).
+extern "C" int ogl_build_block_padded(const int64_t* dst, int64_t n_dst, const int64_t* picks, int fanout, int64_t* src_ids,
+                                      int64_t src_cap, int64_t* n_src_out, int32_t* local_idx, void* workspace,
+                                      int64_t workspace_bytes, ogl_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_dst <= 0 || fanout <= 0 || !n_src_out || !dst || !src_ids || !picks || !local_idx) return OGL_EINVAL;
+  const int64_t P = n_dst * (1 + (int64_t)fanout);
+  if (src_cap < P || P > BLK_SMALL_MAX_P) return OGL_EINVAL;
+  if (!workspace || workspace_bytes < ws_bytes(P)) return OGL_EWORKSPACE;
+  const int64_t T = table_size(P);
+  int32_t* base = (int32_t*)workspace;
+  int logT = 0; while (((int64_t)1 << logT) < T) ++logT;
+  hipLaunchKernelGGL(k_block_build_small, dim3(1), dim3(BLK_SCAN), 0, stream, dst, picks, n_dst, P, base, base + T, base + 2 * T,
+                     base + 3 * T, (uint32_t)(T - 1), 32 - logT, T, src_ids, src_cap, 1, n_src_out, local_idx);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
 extern "C" int ogl_build_block(const int64_t* dst, int64_t n_dst, const int64_t* picks, int fanout,
                                int64_t* src_ids, int64_t* n_src_out, int32_t* local_idx,
                                void* workspace, int64_t workspace_bytes, ogl_stream_t stream_) {

