@@ -307,6 +307,34 @@ int ogl_adam_step_multi_dev(int count, float* const* p, const float* const* g, f
 int ogl_stage_segments(int nseg, const void* const* src, void* const* dst, const int64_t* count,
                        const int64_t* capacity, const int* elem_bytes, int64_t pad, ogl_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Device-side prioritised replay structure (replay.hip): the sum tree of R/train/prioritized_replay/segment_tree.py:69-125
+ * and the priority arithmetic of R/train/prioritized_replay/replay_buffer.py:110-245 on arrays in HBM, fed from the per-seed
+ * loss tensor of the PBR passes (R/train/graphsage/pytorch/model.py:204-207,248-254) without a device->host transfer.
+ *   node   double [2 * cap], cap a power of two: node i has children 2i, 2i + 1, leaves start at cap (zero-initialised);
+ *   state  double [4] = {max log-priority, min log-priority, max clipped priority, min clipped priority}: the reference's
+ *          running extrema; initialise to {-1, 99999999, -1, 99999999}.
+ *   ogl_replay_update   _normalize + _scaled + leaf writes + ancestor refresh for n entries: leaf idx[i] <-
+ *          ((log(clip(p_i)) - lo) / (hi - lo) + offset) ** alpha with the RUNNING extrema lo / hi (offset 1e-5 on insert, 1e-6
+ *          on update, as the reference).  p = prio32[i] or prio64[i]; both NULL = the admission priority of
+ *          R/train/graph/train_test_graph.py:78-93 (start_priority while nothing was scored, else min + 0.95 (max - min) of
+ *          the clipped priorities seen).  scratch: double [n].  *err_flag (device int, zero it first) becomes 1 when a scaled
+ *          priority is negative / NaN (the reference asserts), 2 when an index is outside [0, cap).
+ *   ogl_replay_rebuild  every internal node from the leaves (after growing the tree).
+ *   ogl_replay_sample   the tree walks of _sample_proportional for a batch: *out_ptotal = sum of leaves [0, n_items - 1) (the
+ *          reference's end-exclusive-twice quirk), out_idx[i] = find_prefixsum_idx(u_strat[i] * stride + i * stride) for
+ *          i < batch (stride = p_total / batch) and out_idx[batch + t] = find_prefixsum_idx(u_redraw[t] * p_total); the
+ *          uniforms come from the caller's stream (the reference draws them from Python's `random`).
+ *   ogl_replay_note_keys  map[keys[i]] = start + i: the vertex id -> leaf index map of the buffer.
+ * ---------------------------------------------------------------------------------------- */
+int ogl_replay_update(double* node, int64_t cap, const int64_t* idx, const float* prio32, const double* prio64, int64_t n,
+                      double clip_lo, double clip_hi, double offset, double alpha, double start_priority, double* state,
+                      double* scratch, int* err_flag, ogl_stream_t stream);
+int ogl_replay_rebuild(double* node, int64_t cap, ogl_stream_t stream);
+int ogl_replay_sample(const double* node, int64_t cap, int64_t n_items, int64_t batch, const double* u_strat,
+                      const double* u_redraw, int64_t n_redraw, int64_t* out_idx, double* out_ptotal, ogl_stream_t stream);
+int ogl_replay_note_keys(const int64_t* keys, int64_t n, int64_t start, int64_t* map, int64_t map_size, ogl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,14 @@ Behavioural parity with R/train/graph/train_test_graph.py:12-248 — the graph-s
   * ``draw_priority_train_nodes(n)`` is a uniform shuffle prefix whenever ``n <= |train|`` — the buffer is only
     consulted for larger requests;
   * a priority update covering the whole train set rebuilds the buffer with the current (annealed) alpha.
+Not carried over: the k-hop priority propagation to neighbours of new arrivals (``_get_affected_nodes`` +
+``increment_priorities``) — in the reference that half of ``_update_priority_struct`` sits inside string literals
+(R/train/graph/train_test_graph.py:98-135: the code between the triple quotes never runs), so the live behaviour is the
+admission rule alone.
+
+The buffer lives in HBM when the graph does (``prioritized_replay/device_buffer.py``): the PBR passes then
+write their per-seed losses into it without a device->host transfer (``update_priorities_device``); ``device_replay=False``
+keeps the host (numpy) buffer, which is also what a CPU-only graph object gets.
 """
 from __future__ import annotations
 
@@ -21,6 +29,7 @@ import numpy as np
 from sklearn.model_selection import train_test_split
 
 from ..prioritized_replay.replay_buffer import PrioritizedReplayBuffer
+from ..prioritized_replay.device_buffer import DevicePrioritizedReplayBuffer
 
 SIZE_BUFFER = 10000000   # nominal capacity the reference asks for; the sum tree here grows on demand
 
@@ -31,9 +40,12 @@ def _labelled(vertices, flags):
 
 class TrainTestGraph:
     def __init__(self, graph, split=0.25, start_prior_alpha=1, end_prior_alpha=2, scale=1, max_priority=3.0,
-                 start_priority=2, min_priority=0.0000001):
+                 start_priority=2, min_priority=0.0000001, device_replay=None):
         self.temporal_graph = graph
         self.graph = graph.get_graph()
+        dev = getattr(self.graph, "device", None)
+        on_gpu = dev is not None and getattr(dev, "type", None) == "cuda"
+        self.device_replay = on_gpu if device_replay is None else (bool(device_replay) and on_gpu)
         self.size_evolution = len(graph)
         self.split, self.scale = split, scale
         self.start_prior_alpha, self.end_prior_alpha = start_prior_alpha, end_prior_alpha
@@ -48,6 +60,10 @@ class TrainTestGraph:
 
     # ---- internal -------------------------------------------------------------------------------------------
     def _fresh_buffer(self):
+        if self.device_replay:
+            return DevicePrioritizedReplayBuffer(SIZE_BUFFER, self.prior_alpha, max_priority=self.max_priority,
+                                                 min_priority=self.min_priority, device=self.graph.device,
+                                                 key_space=getattr(self.graph, "n_total", 1024))
         return PrioritizedReplayBuffer(SIZE_BUFFER, self.prior_alpha, max_priority=self.max_priority,
                                        min_priority=self.min_priority)
 
@@ -64,13 +80,16 @@ class TrainTestGraph:
 
     def _update_priority_struct(self):
         buf = self.priority_replay_buffer
+        fresh = list(dict.fromkeys(self.train))
+        if self.device_replay:                           # the admission priority is derived from the extrema on the device
+            buf.admit(np.asarray(fresh, dtype=np.int64), self.start_priority) if fresh else None
+            return
         hi = buf.get_max_priority()
         if hi == -1:                                     # nothing scored yet
             entry = self.start_priority
         else:
             lo = buf.get_min_priority()
             entry = lo + (hi - lo) * 0.95
-        fresh = list(dict.fromkeys(self.train))
         buf.add_all_arrays(np.asarray(fresh, dtype=np.int64), np.full(len(fresh), float(entry))) if fresh else None
 
     # ---- stream ---------------------------------------------------------------------------------------------
@@ -146,6 +165,19 @@ class TrainTestGraph:
             self.priority_replay_buffer.add_all_arrays(ids, priorities)
         else:
             self.priority_replay_buffer.update_arrays(ids, priorities)
+
+    def update_priorities_device(self, ids, priorities_dev):
+        """``update_priorities_arrays`` with the priorities still on the device (a float32 / float64 CUDA tensor, e.g. the
+        per-seed losses of a PBR pass) and the distinct original vertex ids on the host: nothing is copied back."""
+        assert self.device_replay, "update_priorities_device needs the device-side buffer"
+        ids = np.asarray(ids, dtype=np.int64)
+        assert len(ids) <= len(self.train_set) and priorities_dev.numel() == len(ids)
+        if len(ids) == len(self.train_set):
+            self.priority_replay_buffer = self._fresh_buffer()
+            self.priority_replay_buffer.add_all_arrays(ids, priorities_dev)
+        else:
+            import torch
+            self.priority_replay_buffer.update_device(torch.as_tensor(ids).to(priorities_dev.device, non_blocking=True), priorities_dev)
 
     def update_priorities(self, d_priorities):
         """{original vertex id: new priority}.  A partial update rewrites leaves; a full one rebuilds the buffer."""

@@ -444,25 +444,28 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
         full_sizes = [min(bs, n - s0) for s0 in range(0, n, bs)] if bs > 0 else []
         # The reference copies every batch's losses to the host right away (a device sync per batch).  Nothing reads the
         # buffer while the snapshot's batches train (they were drawn beforehand), so the per-batch updates are applied in
-        # the same order after ONE transfer: identical buffer contents, no pipeline drain between batches.
+        # the same order afterwards: identical buffer contents, no pipeline drain between batches — and with the buffer in
+        # HBM (TrainTestGraph.device_replay) the losses never leave the device at all.
         if pending:
             if distributed:
                 # the exchange step of the sharded PBR update: every rank needs the losses of ALL seeds of every batch to
                 # keep its replay-buffer replica identical (one all-gather per snapshot)
                 losses = parallel.all_gather_sharded([ls for _, ls in pending], full_sizes)
-                all_seeds_t = train_vertices.reshape(-1)
                 sizes = full_sizes
-                all_seeds = all_seeds_t.numpy()
-                all_loss = torch.cat(losses).cpu().numpy()
             else:
-                sizes = [sd.numel() for sd, _ in pending]
-                all_seeds = torch.cat([sd for sd, _ in pending]).cpu().numpy()
-                all_loss = torch.cat([ls for _, ls in pending]).cpu().numpy()
+                losses = [ls for _, ls in pending]
+                sizes = [int(ls.numel()) for ls in losses]
+            all_seeds = train_vertices.numpy()               # the batches in loader order ARE the seed list, in order
+            on_device = (self._device_priorities(graph_util) and all(ls.is_cuda for ls in losses))
+            all_loss = None if on_device else torch.cat(losses).cpu().numpy()
             off = 0
-            for n in sizes:
-                batch_nodes_seed = subgraph_to_id[all_seeds[off:off + n]]
-                priorities = self.priority_strategy.get_priorities(batch_nodes_seed, all_loss[off:off + n])
-                graph_util.update_priorities_arrays(np.asarray(batch_nodes_seed), np.asarray(priorities, dtype=np.float64))
+            for b, n in enumerate(sizes):
+                batch_nodes_seed = np.asarray(subgraph_to_id[all_seeds[off:off + n]])
+                if on_device:
+                    graph_util.update_priorities_device(batch_nodes_seed, losses[b])
+                else:
+                    priorities = self.priority_strategy.get_priorities(batch_nodes_seed, all_loss[off:off + n])
+                    graph_util.update_priorities_arrays(batch_nodes_seed, np.asarray(priorities, dtype=np.float64))
                 off += n
         self.time_step += 1
 
@@ -497,10 +500,19 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
                 _, _, a, b = parallel.batch_shard(seeds_all.numel(), self.batch_full, r, world)
                 counts.append(b - a)
             local = parallel.all_gather_counts(local, counts)
-        unaggregated_loss = local.cpu().numpy()
         batch_nids_l = list(subgraph_to_id[seeds_all.numpy()])
+        if self._device_priorities(graph_util) and local.is_cuda:
+            graph_util.update_priorities_device(np.asarray(batch_nids_l), local)       # losses -> tree, all in HBM
+            return
+        unaggregated_loss = local.cpu().numpy()
         priorities = self.priority_strategy.get_priorities(batch_nids_l, unaggregated_loss)
         graph_util.update_priorities_arrays(np.asarray(batch_nids_l), np.asarray(priorities, dtype=np.float64))
+
+    def _device_priorities(self, graph_util):
+        """Losses go into the replay structure on the device when it lives there and priority == loss (LossPriority, the
+        strategy R/train/__main__.py:141 instantiates); the trend / hybrid strategies keep their host-side state."""
+        from ..prioritized_replay.priorities import LossPriority
+        return getattr(graph_util, "device_replay", False) and type(self.priority_strategy) is LossPriority
 
     def get_model(self):
         return "prioritized"
