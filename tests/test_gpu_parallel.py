@@ -130,8 +130,9 @@ def _run_reddit(rank, world, port, out_path, partition):
     pri.optimizer = torch.optim.SGD(model.parameters(), lr=0.05)
     train = np.asarray(sorted(gu.get_train_set()))
     seen = []
-    inner = gu.update_priorities_arrays
-    gu.update_priorities_arrays = lambda ids, pr: (seen.append((np.asarray(ids).copy(), np.asarray(pr).copy())), inner(ids, pr))
+    inner = gu.update_priorities_device                               # the replay structure lives in HBM: device losses in
+    gu.update_priorities_device = lambda ids, pr: (
+        seen.append((np.asarray(ids).copy(), pr.detach().cpu().numpy().astype(np.float64))), inner(ids, pr))
     # A — the priority forward on the initial weights (identical on every run): 2 full batches + a ragged one
     subset = train[:2 * 1024 + 100]
     sampling.seed(5)
@@ -190,4 +191,6 @@ def test_reddit_pbr_two_ranks_replicated_and_partitioned(tmp_path):
         for x, y in zip(a["weights"], other["weights"]):
             torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-5)     # the sharded update: fp32 summation order only
         np.testing.assert_allclose(a["prio"], other["prio"], rtol=1e-4, atol=1e-6)
-        np.testing.assert_allclose(a["loss_c"], other["loss_c"], rtol=1e-3, atol=1e-5)
+        # (the deliberately large SGD step leaves logits of a few hundred: a loss is a difference of numbers of that size,
+        # known to ~1e-4 absolute whatever its own magnitude)
+        np.testing.assert_allclose(a["loss_c"], other["loss_c"], rtol=1e-3, atol=1e-3)
