@@ -168,6 +168,7 @@ def main():
     run(args.warmup, plan(args.warmup))
     seeds_plan = plan(args.steps)
     stats["n0"], stats["n1"], stats["forms"] = [], [], {}
+    captures_before = strat._step_graphs().captures if strat._graphs_ok() else 0
     barrier()
     t1 = time.perf_counter()
     run(args.steps, seeds_plan)
@@ -178,6 +179,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     forms_timed = dict(stats["forms"])
+    captures_timed = (strat._step_graphs().captures - captures_before) if strat._graphs_ok() else 0
 
     # ---- host side: time to ENQUEUE a step (no synchronisation inside the bracket): the margin between this and
     # ms_per_step is how far the step is from being launch-bound on this box's host cores
@@ -344,7 +346,8 @@ def main():
                                                                         int(h_nnz(g)), feat_size, H, n_classes, S,
                                                                         ("%d in total (%d on this rank)" % (B, B_local)) if strong else "%d/GPU" % B, bt),
                        "global_batch": B_global,
-                       "step_execution": ("captured hipGraph replays: %s" % forms_timed) if not args.no_graphs and world == 1
+                       "step_execution": ("captured hipGraph replays: %s; %d new size bucket(s) captured inside the timed region"
+                                          % (forms_timed, captures_timed)) if not args.no_graphs and world == 1
                        else "eager launches from Python (%s)" % forms_timed,
                        "parallelism": "dp%d (seed-sharded replicas, two-bucket grad all-reduce overlapped with backward)" % world,
                        "avg_unique_input_nodes_n0": round(n0_avg, 1), "avg_n1": round(n1_avg, 1), "setup_s": round(setup_s, 1)},
