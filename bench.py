@@ -208,7 +208,8 @@ def main():
     ops.profile_start()                       # per-launch HIP events: this pass runs the same launches EAGERLY (no replay)
     run(prof_steps, prof_plan)
     rec = ops.profile_stop()
-    n0_avg, n1_avg = float(np.mean(stats["n0"])), float(np.mean(stats["n1"]))
+    n0_avg = float(np.mean(stats["n0"])) if stats["n0"] else float("nan")
+    n1_avg = float(np.mean(stats["n1"])) if stats["n1"] else float("nan")
     if os.environ.get("OGL_BENCH_DUMP_CALLS") and rank == 0:        # every C-ABI call of the first profiled step, in order
         for name, meta, ms in rec[:len(rec) // prof_steps]:
             print("call %-28s %8.4f ms  %s" % (name, ms, meta), file=sys.stderr)

@@ -387,6 +387,9 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         self._backward_and_step(loss_sum, n_local, n_global)
         if on_rows is not None:
             on_rows(seeds, rows.detach() if rows is not None else torch.zeros(0, device=graph.device))
+        if self.step_hook is not None and n_local > 0:
+            self.step_hook(dict(seeds=seeds, loss=loss_sum.detach() / n_global, grads=[p.grad for p in self.graphsage_model.parameters()],
+                                form="sharded", n0=int(input_nodes.numel()), n1=blocks[1].number_of_src_nodes()))
         return loss_sum
 
 
