@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--gemm", default="auto", choices=["f32", "bf16x6", "auto"],
                     help="projection arithmetic: exact fp32 MFMA, split-bf16 (x6, fp32-accurate) MFMA, or per-layout best")
     ap.add_argument("--no-graphs", action="store_true", help="enqueue every launch from Python instead of replaying captured steps")
+    ap.add_argument("--graphs", action="store_true", help="replay captured steps for every batch size (default: the strategy's "
+                    "'auto' policy — small batches always, large ones only when the host cannot keep ahead of the GPU)")
     ap.add_argument("--no-projection-cache", action="store_true", help="priority forward: recompute fc_pool_0 per batch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of EACH cpu_baseline leg (multi-thread, one thread)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -134,7 +136,7 @@ def main():
 
     from ogl_amd.graphsage.model import RandomHipSupervisedGraphSage
     strat = RandomHipSupervisedGraphSage(model, bt, B_global, None, S, cuda=True, batch_full=1024)
-    strat.use_graphs = not args.no_graphs
+    strat.use_graphs = False if args.no_graphs else (True if args.graphs else "auto")
     strat.build_optimizer()
     model.train()
     stats = dict(n0=[], n1=[], forms={})
@@ -180,6 +182,7 @@ def main():
         elapsed = float(tt.item())
     forms_timed = dict(stats["forms"])
     captures_timed = (strat._step_graphs().captures - captures_before) if strat._graphs_ok() else 0
+    timed_mode = "captured hipGraph replays" if set(forms_timed) & {"sampled", "staged"} else "eager launches from Python"
 
     # ---- host side: time to ENQUEUE a step (no synchronisation inside the bracket): the margin between this and
     # ms_per_step is how far the step is from being launch-bound on this box's host cores
@@ -190,6 +193,23 @@ def main():
     run(hsteps, hplan)
     host_ms = 1000 * (time.perf_counter() - th) / hsteps
     barrier()
+    # the OTHER execution mode of large batches, for the record: when the auto policy kept this workload eager (fast host),
+    # the same steps replayed as captured graphs (size buckets captured in an untimed warm-up first)
+    graph_mode = None
+    if world == 1 and timed_mode.startswith("eager") and strat.use_graphs == "auto" and getattr(strat.optimizer, "capturable", False):
+        strat.use_graphs = True
+        run(2 * bt, plan(2 * bt))
+        gsteps = min(args.steps, 2 * bt)
+        gplan = plan(gsteps)
+        barrier(); tg = time.perf_counter()
+        run(gsteps, gplan)
+        ghost = 1000 * (time.perf_counter() - tg) / gsteps
+        barrier()
+        gtot = 1000 * (time.perf_counter() - tg) / gsteps
+        graph_mode = dict(ms_per_step=round(gtot, 4), host_enqueue_ms_per_step=round(ghost, 4), steps=gsteps,
+                          note="the same train steps replayed as captured hipGraphs (staged form): what the auto policy switches to "
+                               "when a timed snapshot shows host enqueue time > %.2f x GPU time" % strat.STAGED_AUTO_HOST_FRACTION)
+        strat.use_graphs = "auto"
     if os.environ.get("OGL_BENCH_CPROFILE") and rank == 0:          # where the host time of a step goes (stderr)
         import cProfile, pstats
         torch.autograd.set_multithreading_enabled(False)            # backward in this thread, so that it is seen
@@ -347,15 +367,17 @@ def main():
                                                                         int(h_nnz(g)), feat_size, H, n_classes, S,
                                                                         ("%d in total (%d on this rank)" % (B, B_local)) if strong else "%d/GPU" % B, bt),
                        "global_batch": B_global,
-                       "step_execution": ("captured hipGraph replays: %s; %d new size bucket(s) captured inside the timed region"
-                                          % (forms_timed, captures_timed)) if not args.no_graphs and world == 1
-                       else "eager launches from Python (%s)" % forms_timed,
+                       "step_execution": "%s %s%s" % (timed_mode, forms_timed,
+                                                      ("; %d new size bucket(s) captured inside the timed region" % captures_timed)
+                                                      if timed_mode.startswith("captured") else "")
+                       + ("; auto policy probe: %s" % getattr(strat, "staged_auto_probe", None) if strat.use_graphs == "auto" else ""),
                        "parallelism": "dp%d (seed-sharded replicas, two-bucket grad all-reduce overlapped with backward)" % world,
                        "avg_unique_input_nodes_n0": round(n0_avg, 1), "avg_n1": round(n1_avg, 1), "setup_s": round(setup_s, 1)},
             "roofline": roof_gemm if roof_gemm else roof_aggr,
             "roofline_aggregator": roof_aggr,
             "hbm_copy_measured": hbm_copy,
             "host_enqueue_ms_per_step": round(host_ms, 4),
+            "graph_mode": graph_mode,
             "cpu_baseline": cpu_baseline,
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in sorted(kernels.items())},
         }
