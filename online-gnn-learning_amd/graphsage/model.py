@@ -59,6 +59,7 @@ class SupervisedGraphSage:
         # mode while the host's enqueue time per step stays under the GPU's time per step
         self.use_graphs = "auto"
         self._staged_auto = None    # "auto": None = undecided, True / False after the probe
+        self._staged_seen = 0       # eligible snapshots met so far (the first one is cold: images, code objects, allocator)
         self.STAGED_AUTO_HOST_FRACTION = 0.85
         self.step_hook = None       # instrumentation (tests, bench): called after every train step with a dict
 
@@ -250,6 +251,9 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
                                             form="eager", ctr=ctrs[i], n0=int(input_nodes.numel()), n1=blocks[1].number_of_src_nodes()))
             return
         probe = (self.use_graphs == "auto" and self._staged_auto is None and self._graphs_ok("sampled") and bs > 0 and n >= 8 * bs)
+        if probe:
+            self._staged_seen += 1
+            probe = self._staged_seen >= 2                   # never decide on the first (cold) snapshot
         if probe:                                            # time this snapshot's eager update: host enqueue vs GPU
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t_host, first = 0.0, True
