@@ -167,6 +167,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world == 1 and strat.use_graphs == "auto" and bt >= 8:
+        # set-up, not measurement: let the strategy's auto policy see a cold and a warm snapshot and settle on its execution
+        # mode (and, if that is replay, capture the common size buckets) before the W warm-up steps and the K timed steps
+        run(3 * bt, plan(3 * bt))
     run(args.warmup, plan(args.warmup))
     seeds_plan = plan(args.steps)
     stats["n0"], stats["n1"], stats["forms"] = [], [], {}
