@@ -154,6 +154,13 @@ int ogl_linear_fwd(const float* x, int64_t ldx, const int64_t* x_rows, int64_t x
                    const float* x2, int64_t ldx2, const int64_t* x2_rows, int64_t x2_nrows, int K2,
                    const float* w2, int64_t ldw2,
                    int relu, float* y, int64_t ldy, ogl_stream_t stream);
+/* ogl_linear_fwd with a per-ROW addend read from a table: y[i, :] = act(x[row(i)] . w^T + bias + add[add_rows[i], :])
+ * (add_rows nullable = row i; ids outside [0, add_nrows) add nothing).  The inference layers read their self term
+ * fc_self(x) + biases from a per-vertex table computed once per pass (R/inference_optimized.py:169,258 `h0proj`). */
+int ogl_linear_fwd_addrows(const float* x, int64_t ldx, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
+                           const float* w, int64_t ldw, int N, const float* bias, const float* add, int64_t ld_add,
+                           const int64_t* add_rows, int64_t add_nrows, int relu, float* y, int64_t ldy,
+                           ogl_stream_t stream);
 int ogl_relu_bwd(const float* dy, int64_t ldy, const float* y, int64_t ldyy, int64_t M, int N,
                  float* out, int64_t ldo, ogl_stream_t stream);
 int ogl_linear_bwd_input(const float* dy, int64_t ldy, int64_t M, int N, const float* w, int64_t ldw,

@@ -39,6 +39,7 @@ SIGNATURES = {
     "ogl_reduce_bwd": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i, _i, _i, _i64, _p, _i64, _p]),
     "ogl_linear_fwd": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p,
                             _p, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p]),
+    "ogl_linear_fwd_addrows": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p, _p, _i64, _p, _i64, _i, _p, _i64, _p]),
     "ogl_relu_bwd": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _p]),
     "ogl_linear_bwd_input": (_i, [_p, _i64, _i64, _i, _p, _i64, _i, _p, _i64, _p]),
     "ogl_linear_bwd_weight_workspace_bytes": (_i64, [_i64, _i, _i]),

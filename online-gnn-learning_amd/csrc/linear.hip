@@ -44,6 +44,9 @@ struct GemmArgs {
   int ones_col;     // B(r, N-1) == 1  -> column N-1 of the result = row sums of A (bias gradient)
   float* C; int64_t ldc;
   const float* bias;  // [N] or null, added per output column
+  // optional per-ROW addend (forward only, nsplit == 1): C[i, :] += add[row(i), :], row(i) = add_rows ? add_rows[i] : i; rows
+  // outside [0, add_nrows) add nothing.  The self term of an inference layer read from a per-vertex table (S0[dst]).
+  const float* add; int64_t ld_add; const int64_t* add_rows; int64_t add_nrows;
   int relu;
   float* db;        // destination of column N-1 when ones_col
   int nsplit;       // >1: partial sums go to ws[split][M][ws_ld], epilogue runs in k_splitk_reduce
@@ -450,6 +453,10 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
           g.ws[((int64_t)split * g.M + row) * g.ws_ld + col] = v;
         } else {
           v += bv;
+          if (g.add) {
+            const int64_t ar = g.add_rows ? g.add_rows[row] : row;
+            if (ar >= 0 && ar < g.add_nrows) v += g.add[ar * g.ld_add + col];
+          }
           if (g.relu) v = fmaxf(v, 0.f);
           if (g.ones_col && col == g.N - 1) { if (g.db) g.db[row] = v; }
           else g.C[row * g.ldc + col] = v;
@@ -709,6 +716,24 @@ extern "C" int ogl_linear_fwd(const float* x, int64_t ldx, const int64_t* x_rows
     OGL_CHECK_LAUNCH();
     return OGL_OK;
   }
+  return launch_gemm<true, true>(g, (hipStream_t)stream);
+}
+
+// y[M, N] = act(x[rows?] . w^T + bias + add[add_rows?[i], :]): ogl_linear_fwd with a per-row addend read from a table.
+extern "C" int ogl_linear_fwd_addrows(const float* x, int64_t ldx, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
+                                      const float* w, int64_t ldw, int N, const float* bias, const float* add, int64_t ld_add,
+                                      const int64_t* add_rows, int64_t add_nrows, int relu, float* y, int64_t ldy,
+                                      ogl_stream_t stream) {
+  if (M < 0 || K <= 0 || N < 0 || ldx < K || ldw < K || ldy < N || ld_add < N || add_nrows < 0) return OGL_EINVAL;
+  if (M == 0 || N == 0) return OGL_OK;
+  if (!y || !x || !w || !add) return OGL_EINVAL;
+  GemmArgs g; zero_args(g);
+  g.part[0].a = Operand{x, ldx, x_rows, x_nrows};
+  g.part[0].b = Operand{w, ldw, nullptr, 0};
+  g.part[0].R = K;
+  g.nparts = 1;
+  g.M = M; g.N = N; g.C = y; g.ldc = ldy; g.bias = bias; g.relu = relu;
+  g.add = add; g.ld_add = ld_add; g.add_rows = add_rows; g.add_nrows = add_nrows;
   return launch_gemm<true, true>(g, (hipStream_t)stream);
 }
 

@@ -395,6 +395,19 @@ def linear_fwd(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_ro
     return y
 
 
+def linear_fwd_addrows(x, w, add, add_rows=None, bias=None, relu=False, x_rows=None):
+    """y = act(x[rows] @ w.T + bias + add[add_rows]): a projection whose other term comes from a per-vertex table."""
+    x = as_mat(x); w = as_mat(w); add = as_mat(add)
+    M = x_rows.numel() if x_rows is not None else x.shape[0]
+    K, N = x.shape[1], w.shape[0]
+    assert w.shape[1] == K and add.shape[1] == N and (add_rows is None or add_rows.numel() == M)
+    y = empty_mat(M, N, x.device)
+    _launch("ogl_linear_fwd_addrows", _lib.lib().ogl_linear_fwd_addrows, _ptr(x), _ld(x), _ptr(x_rows), x.shape[0], M, K, _ptr(w), _ld(w),
+            N, _ptr(bias), _ptr(add), _ld(add), _ptr(_ids(add_rows) if add_rows is not None else None), add.shape[0], int(bool(relu)),
+            _ptr(y), _ld(y), _stream(), meta=dict(M=M, K=K, N=N, K2=0))
+    return y
+
+
 def relu_bwd(dy, y):
     """dy (.) [y > 0] (the mask of a fused-ReLU projection; applied once, the backward GEMMs stay mask-free)."""
     dy = as_mat(dy); y = as_mat(y)
