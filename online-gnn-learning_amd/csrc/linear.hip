@@ -288,12 +288,32 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
   }
 
   f32x16 acc[TM][TN];
+  if (g.add && g.nsplit == 1) {
+    // the per-row addend is the accumulators' INITIAL value (D layout, see the epilogue): its gathered loads go out with the
+    // first operand tiles instead of after the last MFMA — as an epilogue step this was slower than the product itself at
+    // K = 128 (arxiv rung: 41 vs 25 us)
 #pragma unroll
-  for (int a = 0; a < TM; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = i0 + wm * TM * 32 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        int64_t ar = -1;
+        if (row < g.M) ar = g.add_rows ? g.add_rows[row] : row;
+        const bool ok = ar >= 0 && ar < g.add_nrows;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+        for (int b = 0; b < TN; ++b) {
+          const int64_t col = j0 + wn * TN * 32 + b * 32 + l31;
+          acc[a][b][e] = (ok && col < g.N) ? g.add[ar * g.ld_add + col] : 0.f;
+        }
+      }
+  } else {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  }
 
   TileLoader<BM, A_RC> la;
   TileLoader<BN, B_RC, B_ONES> lb;   // the all-ones row exists only in the transposed weight-gradient product
@@ -453,10 +473,6 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
           g.ws[((int64_t)split * g.M + row) * g.ws_ld + col] = v;
         } else {
           v += bv;
-          if (g.add) {
-            const int64_t ar = g.add_rows ? g.add_rows[row] : row;
-            if (ar >= 0 && ar < g.add_nrows) v += g.add[ar * g.ld_add + col];
-          }
           if (g.relu) v = fmaxf(v, 0.f);
           if (g.ones_col && col == g.N - 1) { if (g.db) g.db[row] = v; }
           else g.C[row * g.ldc + col] = v;
