@@ -45,6 +45,21 @@ class GatheredRows:
         return ops.gather_rows(self.table, self.ids)
 
 
+# inference self term S0[dst]: from this output width on it is added by the neighbour GEMM (accumulators start at the table row:
+# half the reduction — Reddit H = 600: 0.20 -> 0.12 ms per 1 024-seed batch); below it the identity-weight dual product wins
+# (arxiv H = 32: 25 vs 36 us — the gathered 128-byte rows cost more than 32 extra reduction steps)
+ADDROWS_MIN_WIDTH = 128
+_EYE = {}
+
+
+def _eye(n, device):
+    key = (n, device.type, device.index)
+    t = _EYE.get(key)
+    if t is None:
+        t = _EYE[key] = ops.empty_mat(n, n, device).copy_(torch.eye(n, dtype=torch.float32, device=device))
+    return t
+
+
 def _is_relu(fn):
     return fn is F.relu or fn is torch.relu or isinstance(fn, nn.ReLU)
 
@@ -161,7 +176,7 @@ class SAGEConv(nn.Module):
         ``h0proj`` / ``neigh`` caches): the neighbour max reads ``P0[picks]`` directly and the self term is the row
         ``S0[dst]``, so a batch touches no raw feature row (what lets the tables be built per vertex range and exchanged,
         model.HipSupervisedGraphSage._projection_tables).  ``S0[dst] + fc_neigh(neigh)`` is ONE GEMM over the neighbour term
-        with the table row added in its epilogue (``ogl_linear_fwd_addrows``): half the reduction of the dual-input product."""
+        whose accumulators start at the table row (``ogl_linear_fwd_addrows``): half the reduction of the dual-input product."""
         t = self._aggre_type
         if t not in ("pool", "maxpool", "meanpool"):
             raise KeyError("cached projections apply to the pooling aggregators only, not {}".format(t))
@@ -170,7 +185,10 @@ class SAGEConv(nn.Module):
         P0, S0 = feat.proj
         h_neigh, _ = ops.reduce_fwd(P0, graph.picks, "mean" if t == "meanpool" else "max")
         w_neigh = self.fc_neigh.weight if t == "pool" else self.fc_neigh.weight[:, self._in_feats:]
-        rst = ops.linear_fwd_addrows(h_neigh, w_neigh, S0, add_rows=graph.dst_ids, relu=fuse_relu)
+        if S0.shape[1] >= ADDROWS_MIN_WIDTH:
+            rst = ops.linear_fwd_addrows(h_neigh, w_neigh, S0, add_rows=graph.dst_ids, relu=fuse_relu)
+        else:       # narrow layers: the dual-input product with an identity first weight (exact: x * 1 and zeros) is faster
+            rst = ops.linear_fwd(S0, _eye(S0.shape[1], S0.device), None, x2=h_neigh, w2=w_neigh, relu=fuse_relu, x_rows=graph.dst_ids)
         if self.activation is not None and not fuse_relu:
             rst = self.activation(rst)
         if self.norm is not None:
