@@ -207,9 +207,13 @@ def main():
         gplan = plan(gsteps)
         barrier(); tg = time.perf_counter()
         run(gsteps, gplan)
-        ghost = 1000 * (time.perf_counter() - tg) / gsteps
         barrier()
         gtot = 1000 * (time.perf_counter() - tg) / gsteps
+        hplan2 = plan(hsteps)                       # host enqueue: ONE snapshot (its loader's read-backs find an idle GPU)
+        barrier(); tg = time.perf_counter()
+        run(hsteps, hplan2)
+        ghost = 1000 * (time.perf_counter() - tg) / hsteps
+        barrier()
         graph_mode = dict(ms_per_step=round(gtot, 4), host_enqueue_ms_per_step=round(ghost, 4), steps=gsteps,
                           note="the same train steps replayed as captured hipGraphs (staged form): what the auto policy switches to "
                                "when a timed snapshot shows host enqueue time > %.2f x GPU time" % strat.STAGED_AUTO_HOST_FRACTION)
