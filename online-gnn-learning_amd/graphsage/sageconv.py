@@ -131,6 +131,10 @@ class SAGEConv(nn.Module):
         if (t == "pool" and not lazy and self.norm is None and (self.activation is None or fuse_relu)
                 and (self.fc_self.bias is None) == (self.fc_neigh.bias is None) and idx.dtype == torch.int32):
             if not torch.is_grad_enabled():
+                if ops.small_pool_layer_fits(feat.shape[0], n_dst, idx.shape[1], feat.shape[1], self._out_feats):
+                    return ops.small_pool_layer_fwd(feat, self.fc_pool.weight, self.fc_pool.bias, self.fc_self.weight,
+                                                    self.fc_neigh.weight, self.fc_self.bias, self.fc_neigh.bias, idx, n_dst,
+                                                    fuse_relu, want_argmax=False)[0]
                 # inference: the same three launches without the autograd node, the summed bias from the cache
                 p = ops.linear_fwd(feat, self.fc_pool.weight, self.fc_pool.bias, relu=True)
                 neigh, _ = ops.reduce_fwd(p, idx, "max", want_argmax=False)

@@ -853,7 +853,69 @@ class _SagePoolLayerFn(torch.autograd.Function):
                 db2 if ctx.has_bias else None, None, None, None)
 
 
+SMALL_LAYER = True      # small 'pool' layers run as one launch forward + one launch backward (small_layer.hip)
+
+
+def small_pool_layer_fits(n_src, n_dst, fanout, hin, hout):
+    return SMALL_LAYER and bool(_lib.lib().ogl_small_pool_layer_fits(int(n_src), int(n_dst), int(fanout), int(hin), int(hout)))
+
+
+def small_pool_layer_fwd(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu, want_argmax=True):
+    h = as_mat(h); w_pool = as_mat(w_pool); w_self = as_mat(w_self); w_neigh = as_mat(w_neigh)
+    n_src, hin = h.shape
+    hout = w_self.shape[0]
+    assert idx.dtype == torch.int32 and idx.is_contiguous() and idx.shape[0] == n_dst
+    neigh = empty_mat(n_dst, hin, h.device)
+    argmax = torch.empty((n_dst, hin), dtype=torch.int32, device=h.device) if want_argmax else None
+    y = empty_mat(n_dst, hout, h.device)
+    _launch("ogl_small_pool_layer_fwd", _lib.lib().ogl_small_pool_layer_fwd, _ptr(h), _ld(h), n_src, _ptr(idx), n_dst, idx.shape[1], hin,
+            _ptr(w_pool), _ld(w_pool), _ptr(b_pool), _ptr(w_self), _ld(w_self), _ptr(b_self), _ptr(w_neigh), _ld(w_neigh), _ptr(b_neigh),
+            hout, int(bool(relu)), _ptr(neigh), _ld(neigh), _ptr(argmax), _ptr(y), _ld(y), _stream(),
+            meta=dict(n_src=n_src, n_dst=n_dst, hin=hin, hout=hout))
+    return y, neigh, argmax
+
+
+class _SmallPoolLayerFn(torch.autograd.Function):
+    """The same layer as _SagePoolLayerFn on the one-workgroup kernels: two launches per layer per step instead of ~15."""
+
+    @staticmethod
+    def forward(ctx, h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu):
+        h = as_mat(h)
+        y, neigh, argmax = small_pool_layer_fwd(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu)
+        if _CAPTURE is not None:
+            _CAPTURE.append(dict(argmax=argmax, neigh=neigh, out=y if relu else None))
+        ctx.relu, ctx.n_dst, ctx.fanout = bool(relu), n_dst, idx.shape[1]
+        ctx.flags = (b_pool is not None, b_self is not None, b_neigh is not None)
+        ctx.save_for_backward(h, as_mat(w_pool), as_mat(w_self), as_mat(w_neigh), neigh, argmax, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, w_pool, w_self, w_neigh, neigh, argmax, y = ctx.saved_tensors
+        dy = as_mat(dy)
+        n_src, hin = h.shape
+        hout = w_self.shape[0]
+        need = ctx.needs_input_grad
+        dev = h.device
+        dh = empty_mat(n_src, hin, dev) if need[0] else None
+        dwp = torch.empty((hin, hin), dtype=torch.float32, device=dev)
+        dws = torch.empty((hout, hin), dtype=torch.float32, device=dev)
+        dwn = torch.empty((hout, hin), dtype=torch.float32, device=dev)
+        has_bp, has_bs, has_bn = ctx.flags
+        dbp = torch.empty(hin, dtype=torch.float32, device=dev) if has_bp else None
+        dbs = torch.empty(hout, dtype=torch.float32, device=dev) if has_bs else None
+        dbn = torch.empty(hout, dtype=torch.float32, device=dev) if has_bn else None
+        _launch("ogl_small_pool_layer_bwd", _lib.lib().ogl_small_pool_layer_bwd, _ptr(dy), _ld(dy), _ptr(y), _ld(y) if y is not None else 0,
+                int(ctx.relu), _ptr(h), _ld(h), n_src, ctx.n_dst, ctx.fanout, hin, hout, _ptr(neigh), _ld(neigh), _ptr(argmax),
+                _ptr(w_pool), _ld(w_pool), _ptr(w_self), _ld(w_self), _ptr(w_neigh), _ld(w_neigh), _ptr(dwp), hin, _ptr(dbp),
+                _ptr(dws), hin, _ptr(dbs), _ptr(dwn), hin, _ptr(dbn), _ptr(dh), _ld(dh) if dh is not None else 0, _stream(),
+                meta=dict(n_src=n_src, n_dst=ctx.n_dst, hin=hin, hout=hout))
+        return dh, dwp, dbp, dws, dwn, dbs, dbn, None, None, None
+
+
 def sage_pool_layer(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu):
+    if h.dim() == 2 and small_pool_layer_fits(h.shape[0], n_dst, idx.shape[1], h.shape[1], w_self.shape[0]):
+        return _SmallPoolLayerFn.apply(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu)
     return _SagePoolLayerFn.apply(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu)
 
 

@@ -1,0 +1,73 @@
+"""One-workgroup 'pool' layer (csrc/small_layer.hip) against the oracle's layer and against the multi-launch path it replaces.
+Run with -m gpu.  Tolerances: forward rtol 1e-4 / atol 1e-5 (fp32 FMA chain vs fp32 MFMA / CPU BLAS), gradients rtol 1e-3 /
+atol 1e-5; argmax equal wherever the two winners are not within rounding of each other."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n_src,n_dst,S,hin,hout,relu,bias", [
+    (832, 32, 25, 32, 40, False, True), (120, 32, 25, 32, 3, False, True), (300, 48, 7, 16, 16, True, True),
+    (90, 9, 5, 64, 64, True, False), (40, 40, 3, 8, 5, False, True)])
+def test_small_pool_layer_matches_oracle_and_unfused(n_src, n_dst, S, hin, hout, relu, bias):
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    rng = np.random.default_rng(n_src + hin)
+    assert ops.small_pool_layer_fits(n_src, n_dst, S, hin, hout)
+    h = rng.standard_normal((n_src, hin)).astype(np.float32)
+    idx = rng.integers(0, n_src, size=(n_dst, S)).astype(np.int32)
+    idx[rng.random(n_dst) < 0.15] = -1                                  # destinations without a sampled neighbour
+    prm = O.init_layer_params("pool", hin, hout)
+    if not bias:
+        for k in list(prm):
+            if k.endswith(".bias"):
+                prm[k] = torch.zeros_like(prm[k])
+    gy = rng.standard_normal((n_dst, hout)).astype(np.float32)
+
+    def run(small):
+        ops.SMALL_LAYER = small
+        try:
+            ht = ops.empty_mat(n_src, hin, "cuda").copy_(torch.as_tensor(h)).requires_grad_(True)
+            ps = {k: v.clone().cuda().requires_grad_(True) for k, v in prm.items()}
+            b = (lambda n: ps[n] if bias else None)
+            y = ops.sage_pool_layer(ht, ps["fc_pool.weight"], b("fc_pool.bias"), ps["fc_self.weight"], ps["fc_neigh.weight"],
+                                    b("fc_self.bias"), b("fc_neigh.bias"), torch.as_tensor(idx).cuda(), n_dst, relu)
+            y.backward(torch.as_tensor(gy).cuda())
+            return y.detach().cpu().numpy(), ht.grad.cpu().numpy(), {k: (v.grad.cpu().numpy() if v.grad is not None else None) for k, v in ps.items()}
+        finally:
+            ops.SMALL_LAYER = True
+    y1, dh1, g1 = run(True)
+    y0, dh0, g0 = run(False)
+    hr = torch.tensor(h, requires_grad=True)
+    pr = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
+    yr = O.sageconv_forward("pool", hr, n_dst, idx, pr, activation=F.relu if relu else None)
+    yr.backward(torch.as_tensor(gy))
+    np.testing.assert_allclose(y1, yr.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(y1, y0, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dh1, hr.grad.numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(dh1, dh0, rtol=1e-3, atol=1e-5)
+    for k in prm:
+        if k.endswith(".bias") and not bias:
+            continue
+        np.testing.assert_allclose(g1[k], pr[k].grad.numpy(), rtol=1e-3, atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(g1[k], g0[k], rtol=1e-3, atol=1e-5, err_msg=k)
+    # inference entry: same values, no autograd node
+    with torch.no_grad():
+        yi = ops.small_pool_layer_fwd(torch.as_tensor(h).cuda(), prm["fc_pool.weight"].cuda(), prm["fc_pool.bias"].cuda() if bias else None,
+                                      prm["fc_self.weight"].cuda(), prm["fc_neigh.weight"].cuda(), prm["fc_self.bias"].cuda() if bias else None,
+                                      prm["fc_neigh.bias"].cuda() if bias else None, torch.as_tensor(idx).cuda(), n_dst, relu, want_argmax=False)[0]
+    assert np.array_equal(yi.cpu().numpy(), y1)
+
+
+def test_small_layer_limits():
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    assert ops.small_pool_layer_fits(832, 32, 25, 32, 40)
+    assert not ops.small_pool_layer_fits(7060, 512, 25, 600, 41)          # the Reddit layer stays on the GEMM kernels
+    assert not ops.small_pool_layer_fits(2000, 32, 25, 32, 40)            # LDS budget
+    assert not ops.small_pool_layer_fits(100, 32, 25, 65, 8)
