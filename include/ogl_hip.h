@@ -315,27 +315,31 @@ int ogl_stage_segments(int nseg, const void* const* src, void* const* dst, const
                        const int64_t* capacity, const int* elem_bytes, int64_t pad, ogl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * A whole SMALL 'pool' SAGEConv layer per launch (small_layer.hip): forward
+ * A whole SMALL 'pool' SAGEConv layer in two launches forward, two launches backward (small_layer.hip):
  *     neigh = max_j relu(h . Wp^T + bp)[idx[:, j]],   y = act(h[:n_dst] . Ws^T + neigh . Wn^T + bs + bn)
- * and its complete backward, each in ONE workgroup (exact fp32 FMA on the vector ALU, the projected rows / the input gradient
- * held in LDS).  For the layers of the reference's small settings (R/settings/pubmed.json, arxiv.json: embedding_size 32,
- * batch 32 -> the output layer of a batch is <= 832 source rows x 32 features x <= 40 classes): there the 15 launches this
- * replaces are pure latency.  ogl_small_pool_layer_fits tells whether a shape qualifies (Hin, Hout <= 64 and the LDS budget).
+ * exact fp32 FMA on the vector ALU, one thread per output element.  For the layers of the reference's small settings
+ * (R/settings/pubmed.json, arxiv.json: embedding_size 32, batch 32 -> the output layer of a batch is <= 832 source rows x 32
+ * features x <= 40 classes): there the 15 general launches this replaces are pure latency.  ogl_small_pool_layer_fits tells
+ * whether a shape qualifies (Hin, Hout <= 64, n_dst * max(Hin, Hout) <= 8192, n_src <= 65536).
+ *   workspace: float [ogl_small_pool_layer_workspace_floats(n_src, n_dst, Hin)] (forward: the projected rows; backward: the
+ *        winners' routed gradient).
  *   fwd: neigh [n_dst, Hin] and argmax (int32 [n_dst, Hin], nullable: the winning block-local source row, -1 = none) are
  *        outputs kept for the backward; biases nullable.
  *   bwd: dy [n_dst, Hout] (masked here by y > 0 when relu_out); every gradient output nullable; dh [n_src, Hin] is written
- *        completely (zeros where nothing flows).
+ *        completely (zeros where nothing flows; the winners' rows by float atomics).
  * ---------------------------------------------------------------------------------------- */
 int ogl_small_pool_layer_fits(int64_t n_src, int64_t n_dst, int fanout, int Hin, int Hout);
+int64_t ogl_small_pool_layer_workspace_floats(int64_t n_src, int64_t n_dst, int Hin);
 int ogl_small_pool_layer_fwd(const float* h, int64_t ldh, int64_t n_src, const int32_t* idx, int64_t n_dst, int fanout, int Hin,
                              const float* Wp, int64_t ldwp, const float* bp, const float* Ws, int64_t ldws, const float* bs,
                              const float* Wn, int64_t ldwn, const float* bn, int Hout, int relu_out, float* neigh, int64_t ldn,
-                             int32_t* argmax, float* y, int64_t ldy, ogl_stream_t stream);
+                             int32_t* argmax, float* y, int64_t ldy, float* workspace, ogl_stream_t stream);
 int ogl_small_pool_layer_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, int relu_out, const float* h, int64_t ldh,
                              int64_t n_src, int64_t n_dst, int fanout, int Hin, int Hout, const float* neigh, int64_t ldn,
                              const int32_t* argmax, const float* Wp, int64_t ldwp, const float* Ws, int64_t ldws, const float* Wn,
                              int64_t ldwn, float* dWp, int64_t lddwp, float* dbp, float* dWs, int64_t lddws, float* dbs,
-                             float* dWn, int64_t lddwn, float* dbn, float* dh, int64_t lddh, ogl_stream_t stream);
+                             float* dWn, int64_t lddwn, float* dbn, float* dh, int64_t lddh, float* workspace,
+                             ogl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Device-side prioritised replay structure (replay.hip): the sum tree of R/train/prioritized_replay/segment_tree.py:69-125

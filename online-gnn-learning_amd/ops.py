@@ -868,9 +868,10 @@ def small_pool_layer_fwd(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, id
     neigh = empty_mat(n_dst, hin, h.device)
     argmax = torch.empty((n_dst, hin), dtype=torch.int32, device=h.device) if want_argmax else None
     y = empty_mat(n_dst, hout, h.device)
+    ws = torch.empty(max(n_src * hin, 4), dtype=torch.float32, device=h.device)
     _launch("ogl_small_pool_layer_fwd", _lib.lib().ogl_small_pool_layer_fwd, _ptr(h), _ld(h), n_src, _ptr(idx), n_dst, idx.shape[1], hin,
             _ptr(w_pool), _ld(w_pool), _ptr(b_pool), _ptr(w_self), _ld(w_self), _ptr(b_self), _ptr(w_neigh), _ld(w_neigh), _ptr(b_neigh),
-            hout, int(bool(relu)), _ptr(neigh), _ld(neigh), _ptr(argmax), _ptr(y), _ld(y), _stream(),
+            hout, int(bool(relu)), _ptr(neigh), _ld(neigh), _ptr(argmax), _ptr(y), _ld(y), _ptr(ws), _stream(),
             meta=dict(n_src=n_src, n_dst=n_dst, hin=hin, hout=hout))
     return y, neigh, argmax
 
@@ -905,10 +906,11 @@ class _SmallPoolLayerFn(torch.autograd.Function):
         dbp = torch.empty(hin, dtype=torch.float32, device=dev) if has_bp else None
         dbs = torch.empty(hout, dtype=torch.float32, device=dev) if has_bs else None
         dbn = torch.empty(hout, dtype=torch.float32, device=dev) if has_bn else None
+        ws = torch.empty(max(ctx.n_dst * hin, 4), dtype=torch.float32, device=dev)
         _launch("ogl_small_pool_layer_bwd", _lib.lib().ogl_small_pool_layer_bwd, _ptr(dy), _ld(dy), _ptr(y), _ld(y) if y is not None else 0,
                 int(ctx.relu), _ptr(h), _ld(h), n_src, ctx.n_dst, ctx.fanout, hin, hout, _ptr(neigh), _ld(neigh), _ptr(argmax),
                 _ptr(w_pool), _ld(w_pool), _ptr(w_self), _ld(w_self), _ptr(w_neigh), _ld(w_neigh), _ptr(dwp), hin, _ptr(dbp),
-                _ptr(dws), hin, _ptr(dbs), _ptr(dwn), hin, _ptr(dbn), _ptr(dh), _ld(dh) if dh is not None else 0, _stream(),
+                _ptr(dws), hin, _ptr(dbs), _ptr(dwn), hin, _ptr(dbn), _ptr(dh), _ld(dh) if dh is not None else 0, _ptr(ws), _stream(),
                 meta=dict(n_src=n_src, n_dst=ctx.n_dst, hin=hin, hout=hout))
         return dh, dwp, dbp, dws, dwn, dbs, dbn, None, None, None
 

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("n_src,n_dst,S,hin,hout,relu,bias", [
     (832, 32, 25, 32, 40, False, True), (120, 32, 25, 32, 3, False, True), (300, 48, 7, 16, 16, True, True),
-    (90, 9, 5, 64, 64, True, False), (40, 40, 3, 8, 5, False, True)])
+    (90, 9, 5, 64, 64, True, False), (40, 40, 3, 8, 5, False, True), (5000, 100, 25, 32, 40, False, True)])
 def test_small_pool_layer_matches_oracle_and_unfused(n_src, n_dst, S, hin, hout, relu, bias):
     import ogl_amd  # noqa: F401
     from ogl_amd import ops
@@ -69,5 +69,6 @@ def test_small_layer_limits():
     from ogl_amd import ops
     assert ops.small_pool_layer_fits(832, 32, 25, 32, 40)
     assert not ops.small_pool_layer_fits(7060, 512, 25, 600, 41)          # the Reddit layer stays on the GEMM kernels
-    assert not ops.small_pool_layer_fits(2000, 32, 25, 32, 40)            # LDS budget
+    assert ops.small_pool_layer_fits(20000, 32, 25, 32, 40) and not ops.small_pool_layer_fits(70000, 32, 25, 32, 40)
+    assert not ops.small_pool_layer_fits(4000, 512, 25, 32, 40)           # too many destinations to call it small
     assert not ops.small_pool_layer_fits(100, 32, 25, 65, 8)
