@@ -64,12 +64,12 @@ class GradSynchronizer:
     The sequence of collectives is the SAME on every rank whatever happened locally (collectives are matched by order and
     size): once the split is learnt — rank 0's split, broadcast in a step every rank takes part in — every ``sync()``
     issues early then late.  A rank whose hooks did not complete the early bucket (no seeds in its shard, so no
-    backward) launches it from ``sync()``.  The late bucket carries one extra element, a flag a rank raises when a
-    gradient of its early bucket changed after the launch (a second ``backward()`` before ``sync()``: gradient
-    accumulation); the reduced flag is the same on every rank, and when it is set every rank reduces the early bucket
-    again from its current gradients.  ``no_sync()`` suspends the hook launch for accumulation steps (then nothing is
-    wasted).  ``weight`` scales this rank's gradients before the sum: 1 / world (a mean) by default, 1.0 when the loss
-    already carries the 1 / n_global of a ragged shard (the strategies)."""
+    backward) launches it from ``sync()``.  Gradient accumulation (more than one ``backward()`` per ``sync()``) must run
+    its non-final passes under ``no_sync()`` (as with DistributedDataParallel): a gradient of the early bucket that changes
+    after the bucket was launched raises — detecting and repairing it collectively would cost a device->host read of a
+    reduced flag every step, i.e. a pipeline drain per step on every rank.  ``weight`` scales this rank's gradients before
+    the sum: 1 / world (a mean) by default, 1.0 when the loss already carries the 1 / n_global of a ragged shard (the
+    strategies).  ``sync()`` never blocks the host: the collectives are enqueued, and waited for on the stream."""
 
     def __init__(self, params, group=None, overlap=True, late_fraction=0.35, weight=None):
         self.params = [p for p in params if p.requires_grad]
@@ -100,7 +100,7 @@ class GradSynchronizer:
         if self._early is None or i not in self._early_set:
             return
         if self._pending is not None:
-            self._stale = True                       # accumulated into after the launch: sync() reduces the bucket again
+            self._stale = True                       # accumulated into after the launch: sync() raises (use no_sync())
             return
         if not self._suspended and all(self._fired.get(j, 0) >= 1 for j in self._early):
             self._launch_early(self.weight)
@@ -115,6 +115,7 @@ class GradSynchronizer:
 
             def __exit__(self_inner, *exc):
                 gs._suspended = False
+                gs._fired = {}                   # the launch condition counts the firings of the FINAL pass only
                 return False
         return _Ctx()
 
@@ -180,18 +181,19 @@ class GradSynchronizer:
             if self._pending is None:                # the hooks did not complete the bucket on this rank: same collective, here
                 self._launch_early(w)
             work, flat_e, w_used = self._pending
-            flat_l = self._flatten(self._late, w, extra=1)
-            if self._stale:
-                flat_l[-1] = 1.0
-            dist.all_reduce(flat_l, op=dist.ReduceOp.SUM, group=self.group)
+            stale = self._stale
+            flat_l = self._flatten(self._late, w)
+            dist.all_reduce(flat_l, op=dist.ReduceOp.SUM, group=self.group)      # (issued even when raising below: stays matched)
             work.wait()
-            if float(flat_l[-1]) > 0:                # on some rank the early gradients changed after the launch: every
-                flat_e = self._flatten(self._early, w)   # rank reduces the bucket again from what it holds now
-                dist.all_reduce(flat_e, op=dist.ReduceOp.SUM, group=self.group)
-            elif w_used != w:
+            if stale:
+                self._pending, self._stale, self._fired, self._order = None, False, {}, []
+                raise RuntimeError("GradSynchronizer: a gradient of the early bucket changed after the bucket's all-reduce was "
+                                   "launched (a second backward() before sync()); run the non-final passes of a gradient "
+                                   "accumulation under `with gsync.no_sync():`")
+            if w_used != w:
                 flat_e.mul_(w / w_used)
             self._scatter(self._early, flat_e)
-            self._scatter(self._late, flat_l[:-1])
+            self._scatter(self._late, flat_l)
         self._pending = None
         self._stale = False
         self._fired = {}
