@@ -2,6 +2,9 @@
 R/train/graphsage/pytorch/graphsage_dgl.py:5-59; state_dict keys
 ``layers.{i}.{fc_pool,fc_self,fc_neigh}.{weight,bias}`` (what R/export_model.py:107 saves and
 R/inference_optimized.py:136-139 reads)."""
+import contextlib
+
+import torch
 import torch.nn as nn
 
 from .sageconv import SAGEConv
@@ -21,6 +24,21 @@ class GraphSAGE(nn.Module):
         for _ in range(n_layers - 1):
             self.layers.append(SAGEConv(n_hidden, n_hidden, aggregator_type, feat_drop=dropout, activation=activation, **extra))
         self.layers.append(SAGEConv(n_hidden, n_classes, aggregator_type, feat_drop=dropout, activation=None, **extra))
+
+    @contextlib.contextmanager
+    def inference_pass(self):
+        """A pass over many batches with FIXED weights (evaluation, the PBR priority forward): per-layer constants derived
+        from the parameters (the summed combine bias) are computed once here instead of once per batch, and dropped at the
+        end — never kept across a weight update."""
+        try:
+            with torch.no_grad():
+                for layer in self.layers:
+                    if getattr(layer, "fc_self", None) is not None and layer.fc_self.bias is not None and layer.fc_neigh.bias is not None:
+                        layer._bias_sum = layer.fc_self.bias + layer.fc_neigh.bias
+            yield self
+        finally:
+            for layer in self.layers:
+                layer._bias_sum = None
 
     def forward(self, blocks, x):
         h = x

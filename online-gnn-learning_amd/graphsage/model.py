@@ -334,15 +334,16 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         per_batch_rows = min(bf * (1 + self.samples) ** 2 * self.UNIQUE_INPUT_FRACTION, graph.n_present)
         use_cache = (self.cache_projection and layer0.fc_pool is not None and not layer0.training
                      and nb * per_batch_rows > graph.n_present)          # a function of global quantities: same on every rank
-        tables = self._projection_tables(graph, layer0) if use_cache else None
-        if b_hi <= b_lo:
-            return
-        mine = seeds_all[s_lo:s_hi].to(graph.device, non_blocking=True).contiguous()
-        batches = [mine[s:s + bf] for s in range(0, mine.numel(), bf)]
-        for input_nodes, seeds, blocks in self._sampler().sample_batches(graph, batches, relabel_input=not use_cache,
-                                                                         ctrs=ctrs[b_lo:b_hi]):
-            x = GatheredRows(graph.ndata["feat"], None, tables) if use_cache else self._inputs(graph, input_nodes)
-            yield seeds, self.graphsage_model(blocks, x)
+        with self.graphsage_model.inference_pass():          # weights are fixed for the pass: per-layer constants once
+            tables = self._projection_tables(graph, layer0) if use_cache else None
+            if b_hi <= b_lo:
+                return
+            mine = seeds_all[s_lo:s_hi].to(graph.device, non_blocking=True).contiguous()
+            batches = [mine[s:s + bf] for s in range(0, mine.numel(), bf)]
+            for input_nodes, seeds, blocks in self._sampler().sample_batches(graph, batches, relabel_input=not use_cache,
+                                                                             ctrs=ctrs[b_lo:b_hi]):
+                x = GatheredRows(graph.ndata["feat"], None, tables) if use_cache else self._inputs(graph, input_nodes)
+                yield seeds, self.graphsage_model(blocks, x)
 
     def _run_custom_eval(self, graph, subgraph_to_id, id_to_subgraph, test_vertices):
         output_data = []

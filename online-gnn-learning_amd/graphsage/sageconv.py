@@ -200,18 +200,17 @@ class SAGEConv(nn.Module):
         return rst
 
     def _summed_bias(self):
-        """b_self + b_neigh for the inference paths, kept until either bias is written again (tensor version counters):
-        a priority forward runs hundreds of batches on one weight version, and the add is a launch per layer per batch."""
+        """b_self + b_neigh for the inference paths.  Inside an inference pass (``GraphSAGE.inference_pass()``: weights are
+        fixed for its duration) the sum is computed once and reused by every batch; outside one it is recomputed per call.
+        (Round 1 keyed a cache on the tensors' version counters — but the optimiser updates parameters through raw pointers
+        (ogl_adam_step*), which never bumps them: after the first evaluation every later one added a STALE bias sum.)"""
         bs, bn = self.fc_self.bias, self.fc_neigh.bias
         if bs is None:
             return None
-        key = (bs._version, bn._version, bs.data_ptr(), bn.data_ptr())
-        hit = getattr(self, "_bias_sum_cache", None)
-        if hit is None or hit[0] != key:
-            with torch.no_grad():
-                hit = (key, bs + bn)
-            self._bias_sum_cache = hit
-        return hit[1]
+        if getattr(self, "_bias_sum", None) is not None:
+            return self._bias_sum
+        with torch.no_grad():
+            return bs + bn
 
     def project_tables(self, table, rows=None, out=None):
         """The per-weight-version tables consumed by _forward_cached, for ``table[rows]`` (default: every row):

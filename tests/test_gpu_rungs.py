@@ -357,3 +357,52 @@ def test_torch_ops_namespace():
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.ogl.gather_rows(torch.zeros(3, 4), torch.zeros(2, dtype=torch.int64))     # no CPU kernel, no fallback
     assert ops.get_gemm_mode() == "f32"
+
+
+def test_inference_sees_weight_updates_between_passes():
+    """Round-1 bug: the inference layers cached b_self + b_neigh keyed on tensor version counters, which the raw-pointer
+    optimiser never bumps — every evaluation after the first added a stale bias sum.  Two priority passes with train steps in
+    between: both must match the oracle evaluated at the device's CURRENT weights."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import sampling, synthetic
+    from ogl_amd.graphsage import GraphSAGE
+    from ogl_amd.graphsage.model import PrioritizedHipSupervisedGraphSage
+    from ogl_amd.prioritized_replay import LossPriority
+    feat_size, labels, dyn, n_classes, _ = synthetic.load("toy", device="cuda")
+    for _ in range(8):
+        dyn.evolve()
+    g = dyn.get_graph()
+    cpu = O.CpuModel("pool", feat_size, 16, n_classes, seed=3)
+    model = GraphSAGE(feat_size, 16, n_classes, 1, F.relu, 0, "pool").cuda()
+    _copy_params(model, cpu.params)
+    strat = PrioritizedHipSupervisedGraphSage(model, 2, 16, labels, 5, LossPriority(), full_pass=1, cuda=True, batch_full=64)
+    strat.build_optimizer()
+    strat.optimizer.param_groups[0]["lr"] = 0.05                     # large steps: a stale bias would be far outside tolerance
+    indptr, indices, keys = _host_csr(g)
+    deg = O.snapshot_degrees_fast(indptr, keys, g.n_present, g.cut)
+    feat_cpu, lab_cpu = g.ndata["feat"].cpu().contiguous(), g.ndata["target"].cpu()
+    seeds = np.random.default_rng(0).choice(g.n_present, 100, replace=False).astype(np.int64)
+
+    class GU:                                                       # the graph-state surface recompute_priorities touches
+        device_replay = False
+        got = None
+        def get_original_to_subgraph_map(self): return dyn.get_original_to_subgraph_map()
+        def get_subgraph_to_original_map(self): return dyn.get_subgraph_to_original_map()
+        def get_graph(self): return g
+        def update_priorities_arrays(self, ids, pr): self.got = np.asarray(pr)
+    gu = GU()
+    s2o = dyn.get_subgraph_to_original_map()
+    for rnd in range(2):
+        sampling.seed(40 + rnd)
+        strat.recompute_priorities(gu, list(s2o[seeds]))
+        cpu_dev = O.CpuModel("pool", feat_size, 16, n_classes, seed=3)           # fresh oracle, the device's CURRENT weights
+        with torch.no_grad():
+            for l, prm in zip(model.layers, cpu_dev.params):
+                for k, v in prm.items():
+                    mod, attr = k.split(".")
+                    v.copy_(getattr(getattr(l, mod), attr).detach().cpu())
+        want = np.concatenate([cpu_dev.seed_losses(feat_cpu, lab_cpu, indptr, indices, deg, seeds[s:s + 64], 5, 40 + rnd, b)[0]
+                               for b, s in enumerate(range(0, 100, 64))])
+        np.testing.assert_allclose(gu.got, want, rtol=1e-4, atol=1e-6, err_msg="pass %d" % rnd)
+        model.train()
+        strat._train_batches(g, seeds[:64], 16)                    # 4 Adam steps at lr 0.05 move every bias by ~0.2
