@@ -235,12 +235,6 @@ int ogl_x3_split(const float* src, int64_t ld, const int64_t* rows, int64_t nrow
                  const float* append_vec, void* image, ogl_stream_t stream);
 int ogl_x3_split_t(const float* src, int64_t ld, const int64_t* rows, int64_t nrows, int64_t M, int N, int ones_row,
                    int64_t interleave, void* image, ogl_stream_t stream);
-/* Up to 8 small (weight) images in one launch: image s = the row-major image of src[s] [R rows over K columns] or, with
- * transpose[s] != 0, of its TRANSPOSE (image row r = column r of src[s], which then has K rows and >= R columns): the operand of an
- * input-gradient product dX = dY . W run on ogl_linear_fwd_x3.  append / append_vec as ogl_x3_split; size image s with
- * ogl_x3_image_bytes(R[s], K[s] + (append[s] != 0)).  All arrays are HOST arrays of length n. */
-int ogl_x3_split_multi(int n, const float* const* src, const int64_t* ld, const int64_t* R, const int* K, const int* append,
-                       const float* const* append_vec, const int* transpose, void* const* image, ogl_stream_t stream);
 /* Diagnostics (tools/gemm_x3_bench.py clock): while `buf` (device memory, >= 8 192 bytes) is set, every image-GEMM launch
  * records per block {s_memtime, s_memrealtime} at entry and exit (u64[4] per block); the shader clock the chip held inside
  * the kernel is d(s_memtime) / d(s_memrealtime) x 100 MHz.  Pass NULL to switch off.  `reserved` is ignored.  Not part of

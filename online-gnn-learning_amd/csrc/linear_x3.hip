@@ -623,80 +623,6 @@ __global__ void __launch_bounds__(256) k_x3_split(const float* __restrict__ src,
   }
 }
 
-// ---- several small images in ONE launch: the per-step weight images of the n1-row products ------------------------------------
-// Each descriptor builds the ROW-MAJOR image of src (transpose = 0: image row r = src row r, reduction over its K columns) or of
-// src^T (transpose = 1: image row r = src COLUMN r, reduction over the R_src rows — the operand of an input-gradient product
-// dX = dY . W run on the forward kernel).  append as in k_x3_split (the bias in the extra reduction slot).  Weights are a few
-// hundred rows: the strided reads of the transposed form are a few microseconds; what this kernel saves is one launch per image.
-#define X3_MULTI_MAX 8
-struct X3MultiDesc {
-  const float* src[X3_MULTI_MAX];
-  int64_t ld[X3_MULTI_MAX];
-  int64_t R[X3_MULTI_MAX];            // image rows
-  int K[X3_MULTI_MAX];                // reduction length without the appended element
-  int append[X3_MULTI_MAX];
-  const float* append_vec[X3_MULTI_MAX];
-  int transpose[X3_MULTI_MAX];
-  unsigned char* img[X3_MULTI_MAX];
-  int64_t row_bytes[X3_MULTI_MAX];
-};
-
-__global__ void __launch_bounds__(256) k_x3_split_multi(X3MultiDesc d) {
-  const int s = blockIdx.y;
-  const float* __restrict__ src = d.src[s];
-  const int64_t ld = d.ld[s], R = d.R[s], row_bytes = d.row_bytes[s];
-  const int K = d.K[s], append = d.append[s], tr = d.transpose[s];
-  const int cpr = (int)(row_bytes / X3_GROUP_BYTES) * 4;
-  const int64_t total = (R + 1) * cpr;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = t / cpr;
-    const int ch = (int)(t - r * cpr);
-    const int k = ch * 8;
-    float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (r < R && k < K) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (k + q < K) e[q] = tr ? src[(int64_t)(k + q) * ld + r] : src[r * ld + k + q];
-    }
-    if (append && K >= k && K < k + 8) {
-      const float av = append == 1 ? 1.f : (r < R ? d.append_vec[s][r] : 0.f);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) if (k + q == K) e[q] = av;
-    }
-    uint4 o[3];
-    split3(e[0], e[1], o[0].x, o[1].x, o[2].x);
-    split3(e[2], e[3], o[0].y, o[1].y, o[2].y);
-    split3(e[4], e[5], o[0].z, o[1].z, o[2].z);
-    split3(e[6], e[7], o[0].w, o[1].w, o[2].w);
-    unsigned char* p = d.img[s] + r * row_bytes + (int64_t)(ch >> 2) * X3_GROUP_BYTES;
-#pragma unroll
-    for (int sp = 0; sp < 3; ++sp) *(uint4*)(p + x3_piece(ch & 3, sp) * 16) = o[sp];
-  }
-}
-
-extern "C" int ogl_x3_split_multi(int n, const float* const* src, const int64_t* ld, const int64_t* R, const int* K,
-                                  const int* append, const float* const* append_vec, const int* transpose, void* const* image,
-                                  ogl_stream_t stream) {
-  if (n < 0 || n > X3_MULTI_MAX) return OGL_EINVAL;
-  if (n == 0) return OGL_OK;
-  if (!src || !ld || !R || !K || !append || !append_vec || !transpose || !image) return OGL_EINVAL;
-  X3MultiDesc d;
-  int64_t mx = 0;
-  for (int s = 0; s < n; ++s) {
-    if (R[s] <= 0 || K[s] <= 0 || append[s] < 0 || append[s] > 2 || (append[s] == 2 && !append_vec[s]) || !src[s] || !image[s] ||
-        ((uintptr_t)image[s] & 15) || ld[s] < (transpose[s] ? R[s] : (int64_t)K[s]))
-      return OGL_EINVAL;
-    const int Ki = K[s] + (append[s] ? 1 : 0);
-    d.src[s] = src[s]; d.ld[s] = ld[s]; d.R[s] = R[s]; d.K[s] = K[s]; d.append[s] = append[s]; d.append_vec[s] = append_vec[s];
-    d.transpose[s] = transpose[s]; d.img[s] = (unsigned char*)image[s]; d.row_bytes[s] = ogl_cdiv(Ki, 32) * X3_GROUP_BYTES;
-    mx = std::max<int64_t>(mx, (R[s] + 1) * (d.row_bytes[s] / X3_GROUP_BYTES) * 4);
-  }
-  dim3 grid((unsigned)std::min<int64_t>(ogl_cdiv(mx, 256), 4096), (unsigned)n);
-  hipLaunchKernelGGL(k_x3_split_multi, grid, dim3(256), 0, (hipStream_t)stream, d);
-  OGL_CHECK_LAUNCH();
-  return OGL_OK;
-}
-
 // image of the TRANSPOSE: image row n, reduction index m, stored GROUP-MAJOR (the rows of one 32-deep reduction step are
 // contiguous: one tile of this kernel writes two 12 KB runs, and a GEMM stage reads one run):
 // image[m/32][n][plane][m%32] = split(src[row(m), n]), 64 x 64 tiles through LDS.  ones_row: image row N is 1.0 for m < M (bias gradient operand).  Pad m >= M is zero.

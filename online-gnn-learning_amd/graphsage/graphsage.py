@@ -7,7 +7,6 @@ import contextlib
 import torch
 import torch.nn as nn
 
-from .. import ops
 from .sageconv import SAGEConv
 
 
@@ -41,29 +40,7 @@ class GraphSAGE(nn.Module):
             for layer in self.layers:
                 layer._bias_sum = None
 
-    # hidden width from which the n1-row products of a training step get per-step weight images (ops.prepare_step_images)
-    STEP_IMAGE_MIN_FEATS = 128
-
-    def _step_image_specs(self, blocks):
-        """The weight images this step's tall n1-row products consume: for every 'pool' layer after the first, [W_pool | b] (its
-        forward) and W_pool^T (its input gradient); for layer 0, W_neigh^T (the input gradient of its combine, whose rows are the
-        input block's destinations)."""
-        specs = []
-        for li, (layer, block) in enumerate(zip(self.layers, blocks)):
-            if layer._aggre_type != "pool" or layer._in_feats < self.STEP_IMAGE_MIN_FEATS:
-                continue
-            if li == 0:
-                if block.number_of_dst_nodes() >= ops.X3_N1_MIN_ROWS:
-                    specs.append(dict(kind="wT", src=layer.fc_neigh.weight, transpose=True))
-            elif block.number_of_src_nodes() >= ops.X3_N1_MIN_ROWS:
-                if layer.fc_pool.bias is not None:
-                    specs.append(dict(kind="w_b", src=layer.fc_pool.weight, append_vec=layer.fc_pool.bias))
-                specs.append(dict(kind="wT", src=layer.fc_pool.weight, transpose=True))
-        return specs[:8]
-
     def forward(self, blocks, x):
-        if torch.is_grad_enabled() and self.training:
-            ops.prepare_step_images(self._step_image_specs(blocks))      # one launch; cleared again at the next step
         h = x
         for layer, block in zip(self.layers, blocks):
             h = layer(block, h)

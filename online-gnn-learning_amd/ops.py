@@ -509,58 +509,6 @@ def x3_split(x, rows=None, append_ones=False, append_vec=None):
     return X3Image(buf, R, Ki)
 
 
-def x3_split_multi(specs):
-    """Several small images in ONE launch.  ``specs``: dicts with ``src`` (matrix), optional ``append_vec`` / ``append_ones``,
-    ``transpose`` (image of src.T: the operand of an input-gradient product on the forward kernel).  Returns X3Images."""
-    k = len(specs)
-    assert 0 < k <= 8
-    mats, outs = [], []
-    for sp in specs:
-        m = as_mat(sp["src"])
-        tr = bool(sp.get("transpose"))
-        R, K = (m.shape[1], m.shape[0]) if tr else (m.shape[0], m.shape[1])
-        av = sp.get("append_vec")
-        append = 2 if av is not None else (1 if sp.get("append_ones") else 0)
-        Ki = K + (1 if append else 0)
-        buf = _x3_alloc(R, Ki, m.device)
-        mats.append((m, R, K, append, av, tr, buf))
-        outs.append(X3Image(buf, R, Ki))
-    arr = lambda ty, vals: (ty * k)(*vals)
-    _launch("ogl_x3_split_multi", _lib.lib().ogl_x3_split_multi, k, arr(C.c_void_p, [m.data_ptr() for m, *_ in mats]),
-            arr(C.c_int64, [_ld(m) for m, *_ in mats]), arr(C.c_int64, [t[1] for t in mats]), arr(C.c_int, [t[2] for t in mats]),
-            arr(C.c_int, [t[3] for t in mats]), arr(C.c_void_p, [t[4].data_ptr() if t[4] is not None else None for t in mats]),
-            arr(C.c_int, [1 if t[5] else 0 for t in mats]), arr(C.c_void_p, [t[6].data_ptr() for t in mats]), _stream(), meta=dict(n=k))
-    return outs
-
-
-# Per-step weight images of the n1-row products (the hidden layers' fc_pool forward / input gradient, layer 0's fc_neigh input
-# gradient): built by ONE launch at the start of a training forward (GraphSAGE.forward -> prepare_step_images), consumed by
-# that step's forward and backward, dropped at the next step (the optimiser rewrites the weights through raw pointers).
-_STEP_IMAGES = {}
-X3_N1_MIN_ROWS = 2048      # products with at least this many rows run on the image kernel when their weight image is at hand
-
-
-def prepare_step_images(specs):
-    """specs: dicts as for x3_split_multi plus ``kind`` ('w_b': [W | bias] image, 'wT': image of W.T).  Clears the previous
-    step's images."""
-    _STEP_IMAGES.clear()
-    if specs and _MODE["name"] != "f32":
-        for sp, img in zip(specs, x3_split_multi(specs)):
-            _STEP_IMAGES[(sp["kind"], as_mat(sp["src"]).data_ptr())] = img
-
-
-def step_image(kind, w):
-    return _STEP_IMAGES.get((kind, w.data_ptr())) if _MODE["name"] != "f32" else None
-
-
-def _bwd_input_x3(dy, w):
-    """dX = dY . W on the image kernel when the step's image of W.T exists and the product is tall enough; else None."""
-    img = step_image("wT", w)
-    if img is None or dy.shape[0] < X3_N1_MIN_ROWS or img.K != dy.shape[1]:
-        return None
-    return linear_fwd_x3(x3_split(dy), None, img)
-
-
 def x3_split_t(x, rows=None, ones_row=False, interleave=0):
     """Image of x[rows].T (reduction over the M rows); ``ones_row`` appends the all-ones image row; ``interleave`` = G
     deals the reduction index round-robin over G groups of 32 (the layout of pool_bwd_x3)."""
@@ -775,9 +723,7 @@ class _LinearFn(torch.autograd.Function):
             if need[3]:
                 if x2_rows is not None:
                     raise RuntimeError("gradient w.r.t. a row-gathered table is not supported")
-                dx2 = _bwd_input_x3(dy, w2)
-                if dx2 is None:
-                    dx2 = linear_bwd_input(dy, w2, y)
+                dx2 = linear_bwd_input(dy, w2, y)
             if need[4] or ctx.has_bias2:
                 dw2, db2 = weight_grad(dy, x2, x2_rows, want_bias=ctx.has_bias2, dyT=dyT)
         return dx, dw, (db if ctx.has_bias else None), dx2, dw2, None, None, None, (db2 if ctx.has_bias2 else None)
@@ -871,13 +817,7 @@ class _SagePoolLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu):
         h = as_mat(h)
-        wimg = step_image("w_b", w_pool) if b_pool is not None else None
-        if wimg is not None and h.shape[0] >= X3_N1_MIN_ROWS and wimg.K == h.shape[1] + 1:
-            # tall hidden layer: fc_pool on the image kernel (its [W | b] image was built with the step's other weight images;
-            # the activations are split here: 8 us for [7 060, 600] against the 19 us the product saves)
-            p = linear_fwd_x3(x3_split(h, append_ones=True), None, wimg, relu=True)
-        else:
-            p = linear_fwd(h, w_pool, b_pool, relu=True)
+        p = linear_fwd(h, w_pool, b_pool, relu=True)
         need = any(t is not None and t.requires_grad for t in (h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh))
         neigh, argmax = reduce_fwd(p, idx, "max", want_argmax=need)
         bias = None
@@ -905,9 +845,7 @@ class _SagePoolLayerFn(torch.autograd.Function):
         dw_neigh, db2 = weight_grad(dy, neigh, None, want_bias=ctx.has_bias, dyT=dyT)
         dneigh = linear_bwd_input(dy, w_neigh, None)
         dp = reduce_bwd(dneigh, None, argmax, "max", n_src, fanout=ctx.fanout, relu_out=neigh)
-        dh = _bwd_input_x3(dp, w_pool)
-        if dh is None:
-            dh = linear_bwd_input(dp, w_pool, None)
+        dh = linear_bwd_input(dp, w_pool, None)
         dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias)
         dx_self = linear_bwd_input(dy, w_self, None)
         dh[:n_dst].add_(dx_self)                                  # the fc_self path, in place on the first n_dst rows
