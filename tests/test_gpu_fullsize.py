@@ -99,11 +99,22 @@ def test_fullsize_projection_gemm(reddit, mode):
         ops.set_gemm_mode("f32")
 
 
-def test_fullsize_train_step_matches_oracle(reddit):
-    """One RBR train step at the Reddit rung: loss and parameter updates against the torch-CPU oracle."""
+@pytest.mark.parametrize("mode", ["f32", "auto"])
+def test_fullsize_train_step_matches_oracle(reddit, mode):
+    """One RBR train step at the Reddit rung: loss and parameter updates against the torch-CPU oracle, in the exact-fp32 MFMA
+    arithmetic and in the arithmetic the bench runs (split-bf16 x6, image kernels for the layer-0 products)."""
+    from ogl_amd import ops
+    a, dyn, g, host = reddit
+    ops.set_gemm_mode(mode)
+    try:
+        _fullsize_step(a, dyn, g, host)
+    finally:
+        ops.set_gemm_mode("f32")
+
+
+def _fullsize_step(a, dyn, g, host):
     from ogl_amd import ops, optim, sampling
     from ogl_amd.graphsage import GatheredRows, GraphSAGE
-    a, dyn, g, host = reddit
     deg = O.snapshot_degrees_fast(host["indptr"], host["keys"], g.n_present, g.cut)
     cpu = O.CpuModel("pool", 602, 600, 41, seed=1)
     model = GraphSAGE(602, 600, 41, 1, F.relu, 0, "pool").cuda()
