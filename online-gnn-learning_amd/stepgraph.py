@@ -27,6 +27,8 @@ Not captured: steps under torch.distributed (the gradient all-reduce stays eager
 """
 from __future__ import annotations
 
+import collections
+
 import numpy as np
 import torch
 
@@ -158,18 +160,33 @@ class SampleGraph:
 
 
 class StepGraphCache:
-    """The captured graphs of one (model, optimiser): keyed by form and padded sizes, captured on first use."""
+    """The captured graphs of one (model, optimiser): keyed by form and padded sizes, captured on first use.
+
+    A captured step owns its intermediates (a private memory pool: ~1 GB at the Reddit rung), and a long stream walks
+    through many size buckets as the graph grows, so the train graphs are kept least-recently-used up to ``MAX_GRAPHS``;
+    an evicted bucket is simply captured again if it comes back."""
+
+    MAX_GRAPHS = 24
 
     def __init__(self, model, optimizer, S, loss_fn):
         self.model, self.opt, self.S, self.loss_fn = model, optimizer, int(S), loss_fn
-        self.bufs, self.samplers, self.graphs = {}, {}, {}
-        self.captures = 0
+        self.bufs, self.samplers = {}, {}
+        self.graphs = collections.OrderedDict()
+        self.captures = self.evictions = 0
 
     def _train(self, graph, buf, key, n1_pad, n0_pad):
         sg = self.graphs.get(key)
         if sg is None:
+            while len(self.graphs) >= self.MAX_GRAPHS:
+                old_key, old = self.graphs.popitem(last=False)
+                if old_key[0] == "staged":                    # its static buffers belong to that bucket alone
+                    self.bufs.pop(old_key, None)
+                del old
+                self.evictions += 1
             sg = self.graphs[key] = TrainStepGraph(self.model, self.opt, graph, buf, n1_pad, n0_pad, self.loss_fn)
             self.captures += 1
+        else:
+            self.graphs.move_to_end(key)
         return sg
 
     def sampled_step(self, graph, seeds_host, ctr):

@@ -135,3 +135,30 @@ def test_padded_small_block_build_bit_exact():
         gl = lidx.cpu().numpy()
         shifted = np.where(want_l >= n_valid, want_l + (n_dst - n_valid), want_l)
         assert np.array_equal(gl[:n_valid], shifted) and (gl[n_valid:] == -1).all()
+
+
+def test_graph_cache_is_bounded():
+    """Train graphs are kept least-recently-used: a stream that walks through many size buckets does not accumulate pools."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import sampling, synthetic
+    from ogl_amd.graphsage.model import RandomHipSupervisedGraphSage
+    feat_size, labels, dyn, n_classes, _ = synthetic.load("toy", snapshots=4, device="cuda")
+    dyn.evolve(); dyn.evolve()
+    g = dyn.get_graph()
+    (_, st) = _twins(feat_size, 8, n_classes, RandomHipSupervisedGraphSage, 1, 16, labels, 5, cuda=True, batch_full=64)
+    cache = st._step_graphs()
+    cache.MAX_GRAPHS = 2
+    import ogl_amd.stepgraph as sgm
+    keep = sgm.N0_BUCKET_SMALL
+    sgm.N0_BUCKET_SMALL = 4                                   # tiny buckets: nearly every batch is a new one
+    try:
+        rng = np.random.default_rng(0)
+        sampling.seed(1)
+        losses = []
+        st.step_hook = lambda info: losses.append(float(info["loss"]))
+        for _ in range(12):
+            st._train_batches(g, rng.choice(g.n_present, 16, replace=False).astype(np.int64), 16)
+        assert len(cache.graphs) <= 2 and cache.evictions >= 1 and cache.captures >= 3
+        assert np.isfinite(losses).all() and len(losses) == 12
+    finally:
+        sgm.N0_BUCKET_SMALL = keep
