@@ -12,7 +12,12 @@ MI355X-first differences (documented in DESIGN.md):
   one batched block-build sequence per layer (ogl_sample_layer_batched / ogl_build_block_batched) — so the host
   synchronises once per layer per loader (to learn the block sizes) instead of once per batch;
 * randomness is a counter-based Philox stream keyed by (seed, batch counter, layer, dst id, slot):
-  reproducible, independent of batch composition and of how seeds are sharded over GPUs.
+  reproducible, independent of batch composition and of how seeds are sharded over GPUs.  One consequence differs from
+  DGL: the key holds the destination's VERTEX ID, not its position in the batch, so a vertex that appears twice among the
+  destinations of one layer of one batch draws the same neighbours both times (DGL draws per occurrence).  The reference's
+  loaders never produce that case for the seeds (its draws are shuffle prefixes / dict keys: distinct vertices) and block
+  construction de-duplicates the inner layers' destinations, so it is unreachable on this path; it is what makes a
+  vertex's draws independent of which rank holds it.
 """
 from __future__ import annotations
 
