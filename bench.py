@@ -210,7 +210,9 @@ def main():
         barrier()
         gtot = 1000 * (time.perf_counter() - tg) / gsteps
         hplan2 = plan(hsteps)                       # host enqueue: ONE snapshot (its loader's read-backs find an idle GPU),
-        run(hsteps, hplan2)                         # run twice on the same seeds: the first pass captures any new size bucket
+        smp_state = sampling.get_state()            # run twice on the same seeds AND sampler counters: the first pass captures
+        run(hsteps, hplan2)                         # any new size bucket, the second replays exactly the same blocks
+        sampling.set_state(smp_state)
         barrier(); tg = time.perf_counter()
         run(hsteps, hplan2)
         ghost = 1000 * (time.perf_counter() - tg) / hsteps
