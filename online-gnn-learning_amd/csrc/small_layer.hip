@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(256) k_small_bwd_a(const float* __restrict__ d
     if (o < n_w) {
       const int c = o / Hin, k = o - c * Hin;
       float as = 0.f, an = 0.f;
+#pragma unroll 8
       for (int d = 0; d < n_dst; ++d) {
         const float g = sl_dy(dy, lddy, y, ldy, relu_out, d, c);
         as = fmaf(g, h[(int64_t)d * ldh + k], as);
@@ -141,12 +142,14 @@ __global__ void __launch_bounds__(256) k_small_bwd_a(const float* __restrict__ d
     } else if (o < n_w + n_b) {
       const int c = o - n_w;
       float a = 0.f;
+#pragma unroll 8
       for (int d = 0; d < n_dst; ++d) a += sl_dy(dy, lddy, y, ldy, relu_out, d, c);
       if (dbs) dbs[c] = a;
       if (dbn) dbn[c] = a;
     } else if (o < n_w + n_b + n_g) {
       const int q = o - n_w - n_b, d = q / Hin, k = q - d * Hin;
       float dn = 0.f, dx = 0.f;
+#pragma unroll 8
       for (int c = 0; c < Hout; ++c) {
         const float g = sl_dy(dy, lddy, y, ldy, relu_out, d, c);
         dn = fmaf(g, Wn[(int64_t)c * ldwn + k], dn);
@@ -162,35 +165,37 @@ __global__ void __launch_bounds__(256) k_small_bwd_a(const float* __restrict__ d
 }
 
 // ---- backward 2: fc_pool through the winners -------------------------------------------------------------------------------------
-// items [0, Hin*Hin) -> dWp[j, k] = sum_d G[d, j] h[argmax[d, j], k];  then Hin -> dbp;  then n_dst*Hin -> (d, j): dh[argmax, :] += G Wp[j, :]
+// items [0, Hin*Hin) -> dWp[j, k] = sum_d G[d, j] h[argmax[d, j], k];  then Hin -> dbp;  then n_dst*Hin*Hin -> (d, j, k): dh[argmax, k] += G Wp[j, k]
 __global__ void __launch_bounds__(256) k_small_bwd_b(const float* __restrict__ h, int64_t ldh, int n_dst, int Hin,
                                                      const int32_t* __restrict__ argmax, const float* __restrict__ G,
                                                      const float* __restrict__ Wp, int64_t ldwp, float* __restrict__ dWp, int64_t lddwp,
                                                      float* __restrict__ dbp, float* __restrict__ dh, int64_t lddh) {
-  const int n_w = Hin * Hin, n_b = Hin, n_s = dh ? n_dst * Hin : 0;
+  const int n_w = Hin * Hin, n_b = Hin, n_s = dh ? n_dst * Hin * Hin : 0;
   const int total = n_w + n_b + n_s;
   for (int o = blockIdx.x * 256 + threadIdx.x; o < total; o += gridDim.x * 256) {
     if (o < n_w) {
       const int j = o / Hin, k = o - j * Hin;
       float a = 0.f;
+#pragma unroll 8
       for (int d = 0; d < n_dst; ++d) {
         const float g = G[d * Hin + j];
-        if (g != 0.f) a = fmaf(g, h[(int64_t)argmax[d * Hin + j] * ldh + k], a);
+        const int32_t w = argmax[d * Hin + j];
+        a = fmaf(g, h[(int64_t)(w < 0 ? 0 : w) * ldh + k], a);            // g == 0 wherever there is no winner
       }
       if (dWp) dWp[(int64_t)j * lddwp + k] = a;
     } else if (o < n_w + n_b) {
       const int j = o - n_w;
       float a = 0.f;
+#pragma unroll 8
       for (int d = 0; d < n_dst; ++d) a += G[d * Hin + j];
       if (dbp) dbp[j] = a;
     } else {
-      const int q = o - n_w - n_b;
+      // one atomic per thread: (winner entry q = (d, j), column k); consecutive threads hit consecutive floats of one row
+      const int t = o - n_w - n_b, q = t / Hin, k = t - q * Hin;
       const float g = G[q];
       if (g == 0.f) continue;
       const int j = q % Hin;
-      float* row = dh + (int64_t)argmax[q] * lddh;
-      const float* wj = Wp + (int64_t)j * ldwp;
-      for (int k = 0; k < Hin; ++k) atomicAdd(&row[k], g * wj[k]);      // float atomics: summation order is not fixed
+      atomicAdd(&dh[(int64_t)argmax[q] * lddh + k], g * Wp[(int64_t)j * ldwp + k]);   // float atomics: summation order is not fixed
     }
   }
 }
@@ -210,7 +215,7 @@ extern "C" int ogl_small_pool_layer_bwd(const float* dy, int64_t lddy, const flo
                      dy, lddy, y, ldy, relu_out, h, ldh, (int)n_src, (int)n_dst, Hin, Hout, neigh, ldn, argmax, Ws, ldws, Wn, ldwn, dWs,
                      lddws, dbs, dWn, lddwn, dbn, G, dh, lddh);
   OGL_CHECK_LAUNCH();
-  const int64_t items_b = (int64_t)Hin * Hin + Hin + (dh ? n_dst * Hin : 0);
+  const int64_t items_b = (int64_t)Hin * Hin + Hin + (dh ? n_dst * Hin * (int64_t)Hin : 0);
   hipLaunchKernelGGL(k_small_bwd_b, dim3((unsigned)std::min<int64_t>(ogl_cdiv(items_b, 256), 1024)), dim3(256), 0, (hipStream_t)stream,
                      h, ldh, (int)n_dst, Hin, argmax, G, Wp, ldwp, dWp, lddwp, dbp, dh, lddh);
   OGL_CHECK_LAUNCH();
