@@ -299,9 +299,9 @@ int ogl_adam_step_multi(int count, float* const* p, const float* const* g, float
  *                              with `pad` (-1: "no vertex" / "no neighbour") up to `capacity`.
  * Padding contract (what makes fixed shapes exact): a destination id of -1 samples no neighbour and keeps its block row;
  * a source id of -1 gathers the all-zero row; padded rows therefore contribute exact zeros to every product and gradient.
- *   ogl_build_block_padded   = ogl_build_block for small blocks (n_dst (1 + fanout) <= 65 536 positions) in ONE launch, with
- *                              src_ids[n_src .. src_cap) set to -1 (the source count stays on the device; workspace as
- *                              ogl_block_workspace_bytes).
+ *   ogl_build_block_padded   = ogl_build_block with src_ids[n_src .. src_cap) set to -1 (the source count stays on the device;
+ *                              workspace as ogl_block_workspace_bytes): ONE launch up to 4 096 flat positions
+ *                              n_dst (1 + fanout), the parallel phases above that (the fill folded into the table reset).
  */
 int ogl_sample_layer_dev(const ogl_graph_t* g, const int64_t* dst, int64_t n_dst, int fanout, uint64_t seed,
                          const uint64_t* ctr_dev, int layer, int64_t* picks, ogl_stream_t stream);

@@ -40,13 +40,16 @@ extern "C" int64_t ogl_block_workspace_bytes(int64_t n_dst, int fanout) {
 // table reset as a KERNEL (tkey = -1, tmin = INT_MAX-ish): the two arrays are adjacent, one launch fills both.  (A
 // hipMemsetAsync node recorded into a captured hipGraph re-runs on only 1/16 of its range from the second replay on — ROCm
 // 7.2, shown by tools/graph_probe.py —: stale keys filled the table and every insert probed all of it, 17-57 ms per build.)
-__global__ void __launch_bounds__(256) k_block_reset(int32_t* __restrict__ tkey_tmin, int64_t T) {
+// (optionally also fills `pad` [0, n_pad) with -1: the source list of a padded build, so that the fill is not a launch of its own)
+__global__ void __launch_bounds__(256) k_block_reset(int32_t* __restrict__ tkey_tmin, int64_t T, int64_t* __restrict__ pad, int64_t n_pad) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * T; i += (int64_t)gridDim.x * blockDim.x)
     tkey_tmin[i] = i < T ? -1 : 0x7F7F7F7F;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) pad[i] = -1;
 }
 
-static inline void launch_block_reset(int32_t* tkey, int64_t T, hipStream_t stream) {
-  hipLaunchKernelGGL(k_block_reset, dim3((unsigned)std::min<int64_t>(ogl_cdiv(2 * T, 256), 2048)), dim3(256), 0, stream, tkey, T);
+static inline void launch_block_reset(int32_t* tkey, int64_t T, hipStream_t stream, int64_t* pad = nullptr, int64_t n_pad = 0) {
+  hipLaunchKernelGGL(k_block_reset, dim3((unsigned)std::min<int64_t>(ogl_cdiv(2 * T, 256), 2048)), dim3(256), 0, stream, tkey, T, pad,
+                     n_pad);
 }
 
 __device__ __forceinline__ int64_t flat_id(const int64_t* __restrict__ dst, const int64_t* __restrict__ picks,
@@ -175,6 +178,7 @@ __global__ void __launch_bounds__(256) k_block_lookup(const int32_t* __restrict_
 // table reset, insert (atomicMin of the flat position), first-appearance flags + scan (carried across 1024-position chunks),
 // assign, lookup — and, optionally, fills src_ids past the source count with -1.  Same results as the multi-launch path.
 #define BLK_SMALL_MAX_P 65536
+#define BLK_SMALL_ONE_WG_P 4096      // up to here the whole build runs in one workgroup (ogl_build_block_padded)
 __global__ void __launch_bounds__(BLK_SCAN) k_block_build_small(const int64_t* __restrict__ dst, const int64_t* __restrict__ picks,
                                                                 int64_t n_dst, int64_t P, int32_t* tkey, int32_t* tmin,
                                                                 int32_t* tlidx, int32_t* slot, uint32_t mask, int shift, int64_t T,
@@ -240,11 +244,35 @@ extern "C" int ogl_build_block_padded(const int64_t* dst, int64_t n_dst, const i
   hipStream_t stream = (hipStream_t)stream_;
   if (n_dst <= 0 || fanout <= 0 || !n_src_out || !dst || !src_ids || !picks || !local_idx) return OGL_EINVAL;
   const int64_t P = n_dst * (1 + (int64_t)fanout);
-  if (src_cap < P || P > BLK_SMALL_MAX_P) return OGL_EINVAL;
+  if (src_cap < P || P >= ((int64_t)1 << 30)) return OGL_EINVAL;
   if (!workspace || workspace_bytes < ws_bytes(P)) return OGL_EWORKSPACE;
   const int64_t T = table_size(P);
   int32_t* base = (int32_t*)workspace;
   int logT = 0; while (((int64_t)1 << logT) < T) ++logT;
+  if (P > BLK_SMALL_ONE_WG_P) {
+    // larger blocks: the parallel phases of ogl_build_block (one workgroup's throughput loses to them from a few thousand
+    // positions on: P = 21 632 is 35 us slower in one workgroup), with the -1 fill of src_ids folded into the table reset
+    block_ws ws;
+    ws.T = T; ws.P = P; ws.NB = ogl_cdiv(P, BLK_SCAN);
+    ws.tkey = base; ws.tmin = base + T; ws.tlidx = base + 2 * T; ws.slot = base + 3 * T;
+    ws.bsum = ws.slot + ogl_round_up(P, 4);
+    launch_block_reset(ws.tkey, T, stream, src_ids, src_cap);
+    OGL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_block_insert, dim3((unsigned)ogl_cdiv(P, 256)), dim3(256), 0, stream, dst, picks, n_dst, P, ws.tkey, ws.tmin,
+                       ws.slot, (uint32_t)(T - 1), 32 - logT);
+    OGL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_block_count, dim3((unsigned)ws.NB), dim3(BLK_SCAN), 0, stream, ws.tmin, ws.slot, n_dst, P, ws.bsum);
+    OGL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_block_scan_sums, dim3(1), dim3(BLK_SCAN), 0, stream, ws.bsum, ws.NB, n_src_out);
+    OGL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_block_assign, dim3((unsigned)ws.NB), dim3(BLK_SCAN), 0, stream, dst, picks, ws.tmin, ws.slot, ws.bsum, n_dst, P,
+                       src_ids, ws.tlidx);
+    OGL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_block_lookup, dim3((unsigned)ogl_cdiv(P - n_dst, 256)), dim3(256), 0, stream, ws.slot, ws.tlidx, n_dst, P,
+                       local_idx);
+    OGL_CHECK_LAUNCH();
+    return OGL_OK;
+  }
   hipLaunchKernelGGL(k_block_build_small, dim3(1), dim3(BLK_SCAN), 0, stream, dst, picks, n_dst, P, base, base + T, base + 2 * T,
                      base + 3 * T, (uint32_t)(T - 1), 32 - logT, T, src_ids, src_cap, 1, n_src_out, local_idx);
   OGL_CHECK_LAUNCH();

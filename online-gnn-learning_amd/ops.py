@@ -181,9 +181,9 @@ def stage_segments(pairs, pad=-1):
     _launch("ogl_stage_segments", _lib.lib().ogl_stage_segments, k, srcs, dsts, cnt, cap, el, int(pad), _stream(), meta=dict(nseg=k))
 
 
-# below this many flat positions n_dst (1 + fanout) the one-workgroup build wins (one launch instead of six + a fill); above
-# it one workgroup's throughput loses to the parallel phases (measured: P = 21 632 is 35 us slower in one workgroup)
-BLOCK_SMALL_MAX_P = 4096
+# pad_tail builds go through ogl_build_block_padded, which writes the -1 tail itself (one workgroup up to 4 096 flat positions,
+# the parallel phases above); tests raise / lower this to force either path
+BLOCK_SMALL_MAX_P = 1 << 30
 
 
 def build_block_async(dst: torch.Tensor, picks: torch.Tensor, pad_tail: bool = False, out=None):

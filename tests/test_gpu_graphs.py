@@ -117,13 +117,16 @@ def test_padded_small_block_build_bit_exact():
         picks = rng.integers(0, hi, size=(n_dst, fan)).astype(np.int64)
         picks[rng.random(n_dst) < 0.2] = -1
         picks[n_valid:] = -1
-        ops.BLOCK_SMALL_MAX_P, keep = 65536, ops.BLOCK_SMALL_MAX_P          # force the one-workgroup kernel at every size
+        # the padded entry point (one workgroup up to 4 096 flat positions, the parallel phases with the fill folded into the
+        # table reset above) ...
+        src, n_src, lidx = ops.build_block_async(torch.as_tensor(dst).cuda(), torch.as_tensor(picks).cuda(), pad_tail=True)
+        # ... against the plain multi-launch build + a separate fill
+        ops.BLOCK_SMALL_MAX_P, keep = 0, ops.BLOCK_SMALL_MAX_P
         try:
-            src, n_src, lidx = ops.build_block_async(torch.as_tensor(dst).cuda(), torch.as_tensor(picks).cuda(), pad_tail=True)
+            src2, n_src2, lidx2 = ops.build_block_async(torch.as_tensor(dst).cuda(), torch.as_tensor(picks).cuda(), pad_tail=True)
         finally:
             ops.BLOCK_SMALL_MAX_P = keep
-        src2, n_src2, lidx2 = ops.build_block_async(torch.as_tensor(dst).cuda(), torch.as_tensor(picks).cuda(), pad_tail=True)
-        assert torch.equal(src, src2) and torch.equal(lidx, lidx2) and torch.equal(n_src, n_src2)   # == the multi-launch path
+        assert torch.equal(src, src2) and torch.equal(lidx, lidx2) and torch.equal(n_src, n_src2)
         n = int(n_src.item())
         # oracle on the valid destinations only; padded destinations keep a row each (id -1), so new sources start at n_dst
         want_src, want_l = O.build_block(dst[:n_valid], picks[:n_valid])
