@@ -167,10 +167,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1 and strat.use_graphs == "auto" and bt >= 8:
+    if world == 1 and strat.use_graphs in ("auto", True):
         # set-up, not measurement: let the strategy's auto policy see a cold and a warm snapshot and settle on its execution
-        # mode (and, if that is replay, capture the common size buckets) before the W warm-up steps and the K timed steps
-        run(3 * bt, plan(3 * bt))
+        # mode, and let replayed steps capture their common size buckets (a capture is ~5 ms: a one-off per bucket over a
+        # stream of thousands of snapshots, but a visible share of a 100-step run) before the W warm-up and the K timed steps
+        run(max(3 * bt, 120), plan(max(3 * bt, 120)))
     run(args.warmup, plan(args.warmup))
     seeds_plan = plan(args.steps)
     stats["n0"], stats["n1"], stats["forms"] = [], [], {}
