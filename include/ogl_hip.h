@@ -313,6 +313,10 @@ int ogl_adam_step_multi_dev(int count, float* const* p, const float* const* g, f
                             double beta2, double eps, ogl_stream_t stream);
 int ogl_stage_segments(int nseg, const void* const* src, void* const* dst, const int64_t* count,
                        const int64_t* capacity, const int* elem_bytes, int64_t pad, ogl_stream_t stream);
+/* The read-back of a captured sample graph without a copy node: dst_host_mapped = int64 [n + 1] in pinned HOST memory (mapped
+ * into the device); the kernel stores src[0..n) there, then — behind a system-scope fence — the sequence number ++*seq_dev at
+ * dst_host_mapped[n], which the host polls for. */
+int ogl_publish_i64(const int64_t* src, int n, int64_t* seq_dev, int64_t* dst_host_mapped, ogl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * A whole SMALL 'pool' SAGEConv layer in two launches forward, two launches backward (small_layer.hip):

@@ -167,6 +167,16 @@ def sample_layer_dev(g: GraphHandle, dst: torch.Tensor, fanout: int, seed: int, 
     return picks
 
 
+def publish_i64(src_dev, seq_dev, dst_host_pinned):
+    """Store src_dev[:] and then ++seq into pinned host memory from a kernel (dst_host_pinned: int64 [n + 1]); the host polls the
+    last element.  The read-back of a captured sample graph (ogl_publish_i64)."""
+    n = int(src_dev.numel())
+    assert src_dev.dtype == torch.int64 and src_dev.is_cuda and seq_dev.dtype == torch.int64 and seq_dev.is_cuda
+    assert dst_host_pinned.dtype == torch.int64 and dst_host_pinned.is_pinned() and dst_host_pinned.numel() >= n + 1
+    _launch("ogl_publish_i64", _lib.lib().ogl_publish_i64, _ptr(src_dev), n, _ptr(seq_dev), dst_host_pinned.data_ptr(), _stream(),
+            meta=dict(n=n))
+
+
 def stage_segments(pairs, pad=-1):
     """One launch: for every (src, dst, count) copy ``count`` leading elements of ``src`` into ``dst`` and fill the rest of
     ``dst`` with ``pad``.  int32 / int64 tensors (contiguous); the staging step of a captured train step."""

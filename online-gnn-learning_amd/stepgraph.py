@@ -127,12 +127,16 @@ class SampleGraph:
         assert buf.n1_cap == buf.B * (1 + buf.S) and buf.n0_cap == buf.n1_cap * (1 + buf.S)
         self.head_host = torch.zeros(1 + buf.B, dtype=torch.int64).pin_memory()
         self.counts = torch.zeros(2, dtype=torch.int64, device=graph.device)
-        self.counts_host = torch.zeros(2, dtype=torch.int64).pin_memory()
+        # [n1, n0, sequence number]: pinned host memory the LAST kernel of the graph writes directly (ogl_publish_i64)
+        self.counts_host = torch.zeros(3, dtype=torch.int64).pin_memory()
+        self.counts_np = self.counts_host.numpy()
+        self.seq_dev = torch.zeros(1, dtype=torch.int64, device=graph.device)
+        self.seq = 0
         self.seed = sampling.get_state()["seed"]
-        self.done = torch.cuda.Event()
         self.cuda_graph = torch.cuda.CUDAGraph()
         self._body()                                         # once for real (helpers, workspaces), then recorded
         torch.cuda.synchronize()
+        self.seq = int(self.counts_np[2])
         with torch.cuda.graph(self.cuda_graph):
             self._body()
 
@@ -144,6 +148,7 @@ class SampleGraph:
         ops.build_block_async(b.seeds, picks1, pad_tail=True, out=(b.src1, self.counts[:1], b.lidx1))   # -1 past n1
         picks0 = ops.sample_layer_dev(g.handle, b.src1, S, self.seed, ctr, 0)
         ops.build_block_async(b.src1, picks0, pad_tail=True, out=(b.src0, self.counts[1:], b.lidx0))    # -1 past n0
+        ops.publish_i64(self.counts, self.seq_dev, self.counts_host)
 
     def run(self, seeds_host, ctr):
         """seeds_host: int64 array-like [B] (snapshot ids); ctr: this batch's Philox counter.  Returns (n1, n0)."""
@@ -152,11 +157,11 @@ class SampleGraph:
         h[1:] = torch.as_tensor(np.asarray(seeds_host), dtype=torch.int64)
         self.buf.head.copy_(h, non_blocking=True)
         self.cuda_graph.replay()
-        self.counts_host.copy_(self.counts, non_blocking=True)
-        self.done.record()
-        while not self.done.query():                         # the step's one read-back: 16 bytes.  Spinning on the event returns
-            pass                                             # ~20 us sooner than a blocking stream synchronise wakes up
-        return int(self.counts_host[0]), int(self.counts_host[1])
+        self.seq += 1
+        c, want = self.counts_np, self.seq
+        while c[2] != want:                                  # the step's one read-back: 16 bytes the graph's last kernel wrote
+            pass                                             # into pinned host memory; polled, no copy node, no event
+        return int(c[0]), int(c[1])
 
 
 class StepGraphCache:
