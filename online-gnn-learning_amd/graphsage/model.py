@@ -565,8 +565,7 @@ class FullHipSupervisedGraphSage(HipSupervisedGraphSage):
         train_set = torch.as_tensor(np.asarray(batch_nodes), dtype=torch.int64)
         for _ in range(self.batch_per_timestep):
             train_set = train_set.view(-1)[torch.randperm(train_set.nelement())].view(train_set.size())
-            for input_nodes, seeds, blocks, n_global in self._local_batches(graph, train_set, self.batch_size):
-                self.train_step(graph, blocks, input_nodes, seeds, subgraph_to_id, n_global)
+            self._train_batches(graph, train_set.numpy(), self.batch_size)
 
     def get_model(self):
         return "offline"
@@ -588,9 +587,9 @@ class NoRehHipSupervisedGraphSage(HipSupervisedGraphSage):
             idxs = graph_util.get_new_train_nodes(self.batch_size)
             if len(idxs) < 2:
                 return
-            batch_nodes = id_to_subgraph[idxs]
-            for input_nodes, seeds, blocks, n_global in self._local_batches(graph, batch_nodes, len(batch_nodes), shuffle=True):
-                self.train_step(graph, blocks, input_nodes, seeds, subgraph_to_id, n_global)
+            batch_nodes = np.asarray(id_to_subgraph[idxs], dtype=np.int64).reshape(-1)
+            batch_nodes = batch_nodes[torch.randperm(len(batch_nodes)).numpy()]      # the loader's shuffle=True (torch's CPU stream)
+            self._train_batches(graph, batch_nodes, len(batch_nodes))
 
     def get_model(self):
         return "no_rehersal"

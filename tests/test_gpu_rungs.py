@@ -258,20 +258,16 @@ def test_no_rehearsal_pubmed_matches_oracle_loop():
     strat = NoRehHipSupervisedGraphSage(model, 1, 32, labels, 10, cuda=True, batch_full=1024)      # S=10, B=32: config 1
     strat.build_optimizer()
     rec = []
-    inner = strat.train_step
-
-    def spy(graph, blocks, input_nodes, sd, s2id, n_global=None):
-        loss = inner(graph, blocks, input_nodes, sd, s2id, n_global)
-        rec.append((sd.cpu().numpy(), float(loss), _snapshot(model)))
-        return loss
-    strat.train_step = spy
+    strat.step_hook = lambda info: rec.append((np.asarray(torch.as_tensor(info["seeds"]).cpu()), float(info["loss"]), _snapshot(model),
+                                               info["form"]))
     for _ in range(3):
         strat.train_timestep(gu)
         gu.evolve()
     assert len(rec) == 3 and all(len(r[0]) == 32 for r in rec)
     stream = O.HostVertexStream(a["n"], a["src"], a["dst"], a["order"], a["snapshots"], a["feat"], a["labels"])
     # the strategy's seeds are snapshot ids of that snapshot's arrivals (new TRAIN vertices only)
-    for t, (sd, _, _) in enumerate(rec):
+    assert {r[3] for r in rec} == {"sampled"}            # every snapshot's batch ran as a captured step that samples for itself
+    for t, (sd, _, _, _) in enumerate(rec):
         assert sd.min() >= t * stream.per and sd.max() < (t + 1) * stream.per
     # after each snapshot's step: weights equal up to Adam's near-zero-gradient entries, then oracle <- device
     want = O.no_rehearsal_stream(stream, cpu, 10, [r[0] for r in rec], 31,
