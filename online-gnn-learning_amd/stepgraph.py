@@ -28,6 +28,7 @@ Not captured: steps under torch.distributed (the gradient all-reduce stays eager
 from __future__ import annotations
 
 import collections
+import time
 
 import numpy as np
 import torch
@@ -157,10 +158,14 @@ class SampleGraph:
         h[1:] = torch.as_tensor(np.asarray(seeds_host), dtype=torch.int64)
         self.buf.head.copy_(h, non_blocking=True)
         self.cuda_graph.replay()
+        t0 = time.perf_counter()
         self.seq += 1
         c, want = self.counts_np, self.seq
+        spins = 0
         while c[2] != want:                                  # the step's one read-back: 16 bytes the graph's last kernel wrote
-            pass                                             # into pinned host memory; polled, no copy node, no event
+            spins += 1                                       # into pinned host memory; polled, no copy node, no event
+            if spins & 0xFFFFF == 0 and time.perf_counter() - t0 > 30.0:
+                raise RuntimeError("sample graph: no block sizes from the device after 30 s (sequence %d, saw %d)" % (want, int(c[2])))
         return int(c[0]), int(c[1])
 
 
