@@ -15,7 +15,9 @@ What varies between replays lives in device memory: the seeds / block arrays (st
 * ``SampleGraph`` (small batches) — sampling + block construction of one batch on upper-bound buffers
   (``n1 <= B (1 + S)``, ``n0 <= n1 (1 + S)``), straight into the static block arrays the train graphs read: a step is one
   host->device copy of ``[counter | seeds]``, the sample graph, ONE 16-byte read-back (the two source counts: they choose
-  the train graph's bucket, so that the GEMMs run at the batch's size, not at 28x the upper bound), the train graph.
+  the train graph's bucket, so that the GEMMs run at the batch's size, not at 28x the upper bound), the train graph.  The
+  read-back is not a copy: the graph's last kernel stores the counts and a sequence number into pinned host memory
+  (``ogl_publish_i64``) and the host polls it (52 us for sample graph + read-back, 72 with a copy node + event).
 * staged (Reddit rung): the loader samples the snapshot's batches as before (one read-back per layer per LOADER, amortised
   over 50 batches); per batch ONE ``ogl_stage_segments`` launch copies the batch's block arrays into the static buffers
   of the train graph captured for its bucket (``n1`` to 256, ``n0`` to 2 048 rows: <= 3 % padded rows).
@@ -23,6 +25,9 @@ What varies between replays lives in device memory: the seeds / block arrays (st
 hipMemsetAsync must not appear in captured code: on ROCm 7.2 a memset node re-runs on 1/16 of its range from the second
 replay on (tools/graph_probe.py); every fill on these paths is a kernel.
 
+Which steps are replayed is the strategy's policy (``HipSupervisedGraphSage.use_graphs``): small batches always; large,
+loader-fed batches only when a timed snapshot shows the host cannot keep ahead of the GPU — replayed nodes run ~1 us
+further apart than eagerly queued launches, so on a fast host eager is 2-4 % faster at the Reddit rung.
 Not captured: steps under torch.distributed (the gradient all-reduce stays eager), dropout > 0 (its counter is host-side).
 """
 from __future__ import annotations
