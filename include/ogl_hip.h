@@ -243,6 +243,22 @@ int ogl_x3_debug_stamps(void* buf, int reserved);
 
 int ogl_linear_fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
                       const void* w_img, int N, int relu, float* y, int64_t ldy, ogl_stream_t stream);
+/* ogl_linear_fwd_x3 with a second A part, a per-row addend and / or an image of the output (k_gemm_x3p<..., EXT>):
+ *   y[i, :] = act( x_img[row(i)] . w[:, part 1]^T + x2_img[row2(i)] . w[:, part 2]^T + add[add_rows[i], :] )
+ * - x2_img (nullable, K2 = 0): the second part of a K-concatenated product — fc_self(x[dst]) + fc_neigh(neigh) of the combine
+ *   (R/train/graphsage/pytorch/aggregator_dgl.py:199-206) as ONE product; the w image has ceil(K1 / 32) + ceil(K2 / 32) groups per
+ *   row (build its parts with ogl_x3_split_into); K1 / K2 are the reduction lengths the A images were built with.
+ * - add (nullable): per-row addend from a table, as ogl_linear_fwd_addrows.
+ * - out_img (nullable): ALSO write the bf16x3 image of y (row-major, M + 1 rows, reduction length N, + 1 when out_append_ones:
+ *   1.0 at column N in every row incl. the zero row) = what ogl_x3_split(y, append = out_append_ones) would build: the A operand
+ *   of the next layer's product, without a pass of its own.  Size it with ogl_x3_image_bytes(M, N + out_append_ones). */
+int ogl_linear_fwd_x3_ext(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int K1,
+                          const void* x2_img, int64_t x2_img_rows, const int64_t* x2_rows, int64_t x2_nrows, int K2, int64_t M,
+                          const void* w_img, int N, const float* add, int64_t ld_add, const int64_t* add_rows, int64_t add_nrows,
+                          int relu, float* y, int64_t ldy, void* out_img, int out_append_ones, ogl_stream_t stream);
+/* One part of a K-concatenated (weight) image: rows image_row_bytes apart, this part from group `group_offset` on. */
+int ogl_x3_split_into(const float* src, int64_t ld, int64_t R, int K, int append, const float* append_vec, void* image,
+                      int64_t image_row_bytes, int64_t group_offset, ogl_stream_t stream);
 int64_t ogl_linear_bwd_weight_x3_workspace_bytes(int64_t M, int N, int K);
 int ogl_linear_bwd_weight_x3(const void* dyT_img, const void* xT_img, int64_t M, int N, int K, float* dw,
                              int64_t lddw, float* db, void* workspace, int64_t workspace_bytes,

@@ -50,6 +50,14 @@ struct X3Args {
   float* ws; int64_t ws_ld;
   int NI, NJ;
   unsigned long long* stamps;   // diagnostics only (ogl_x3_debug_stamps): per block {s_memtime, s_memrealtime} at entry and exit
+  // ---- extensions, k_gemm_x3p<..., EXT = true> only (forward products, nsplit == 1) ----
+  X3Operand a2;                 // optional SECOND part of the A operand: reduction steps [nsteps1, nsteps) read a2 (its own image,
+  int nsteps1;                  //   gather and zero row) — fc_self(x[dst]) + fc_neigh(neigh) as ONE product over a K-concatenated B
+  const float* add;             // optional per-row addend: C[i, :] += add[add_rows ? add_rows[i] : i, :] before the activation
+  int64_t ld_add; const int64_t* add_rows; int64_t add_nrows;
+  unsigned char* out_img;       // optional: ALSO write the bf16x3 image of the (activated) output, row-major, reduction length
+  int64_t out_row_bytes;        //   N (+ 1 when out_append_ones: 1.0 at column N) — the A operand of the next layer's product
+  int out_append_ones;
 };
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) — indices into register arrays stay constants
@@ -340,7 +348,7 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
 // One barrier per step.  Three waves per SIMD = 168 registers per wave: the multipliers keep accumulators (64), A
 // fragments (48) and a two-deep B ring (24), the movers their piece offsets.  Images must be < 4 GB (32-bit offsets).
 // Measured against k_gemm_x3: matrix pipe busy 73 % of the in-kernel cycles instead of 56 %.
-template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool EXT = false>
 __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(WAVES_M * WAVES_N == 8, "eight multiplier waves + four mover waves");
@@ -396,8 +404,28 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
     const int ml = (wid - 8) * 64 + lane;                  // lane of the 256-lane mover group
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)g.a.img, 0, 0xFFFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)g.b.img, 0, 0xFFFFFFFF, 0x00020000);
-    const unsigned step_a = (unsigned)g.a.step_bytes, step_b = (unsigned)g.b.step_bytes;
+    const __amdgpu_buffer_rsrc_t rsrc_a2 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((EXT && g.a2.img) ? g.a2.img : g.a.img), 0, 0xFFFFFFFF, 0x00020000);
+    const bool two = EXT && g.a2.img != nullptr;
+    bool part2 = false;                                    // wave-uniform: the fetch cursor is inside the second A part
+    unsigned step_a = (unsigned)g.a.step_bytes;
+    const unsigned step_b = (unsigned)g.b.step_bytes;
     unsigned src[NLP];
+    int cur_ti = 0;
+    // second part of A: the rows of tile row `ti` in a2 (its own gather / zero row), from a2's first reduction step
+    auto make_src_a2 = [&](int ti) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < NLP_A; ++u) {
+        const int i = u * 256 + ml;
+        const int r = i / 12, jp = i - r * 12;
+        const int j = (jp & ~3) | ((jp & 3) ^ swz(r));
+        const int64_t gi = (int64_t)ti * BM + r;
+        int64_t id = gi;
+        if (g.a2.rows) id = g.a2.rows[gi < g.M ? gi : g.M - 1];
+        const bool ok = gi < g.M && id >= 0 && id < g.a2.nrows;
+        src[u] = (unsigned)((ok ? id : g.a2.zero_row) * g.a2.row_bytes + j * 16);
+      }
+    };
     auto make_src = [&](const Tile& t) __attribute__((always_inline)) {
       int64_t rid[NLP_A];
 #pragma unroll
@@ -422,13 +450,19 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         }
         src[u] = (unsigned)(off + j * 16);
       }
+      if (EXT) { part2 = false; step_a = (unsigned)g.a.step_bytes; cur_ti = t.ti; }
     };
     int f_logical = first, fks, fks_end;
     { const Tile t = decode(first); make_src(t); fks = t.ks_begin; fks_end = t.ks_end; }
     auto fetch = [&](int stage) __attribute__((always_inline)) {
+      if (EXT && two && !part2 && fks >= g.nsteps1) {      // entering the second A part of this tile
+        make_src_a2(cur_ti);
+        part2 = true; step_a = (unsigned)g.a2.step_bytes;
+      }
+      const __amdgpu_buffer_rsrc_t rs_a = (EXT && part2) ? rsrc_a2 : rsrc_a;
       static_for<0, NLP>([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(u < NLP_A ? rsrc_a : rsrc_b,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(u < NLP_A ? rs_a : rsrc_b,
                                                  (lptr_t)(smem + (stage % NSTAGE) * STAGE + (u * 256 + (wid - 8) * 64) * 16), 16, src[u], 0, 0, 0);
         src[u] += u < NLP_A ? step_a : step_b;
       });
@@ -527,9 +561,43 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
           float v[4] = {acc[x][y][0], acc[x][y][1], acc[x][y][2], acc[x][y][3]};
           const bool rok = row < g.M;
           const bool has_oc = fin && g.ones_col && col + 3 >= g.N - 1 && col < g.N;
+          if (EXT && g.add && rok && col < g.N) {              // per-row addend (the self term S0[dst] of an inference layer)
+            const int64_t ar = g.add_rows ? g.add_rows[row] : row;
+            if (ar >= 0 && ar < g.add_nrows) {
+              const float* ap = g.add + ar * g.ld_add + col;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) if (col + c < g.N) v[c] += ap[c];
+            }
+          }
           if (fin && g.relu) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+          }
+          if (EXT && g.out_img && rok && col * 2 < g.out_row_bytes / 3) {
+            // the output's bf16x3 image beside the fp32 store: this thread's 4 columns are half a 16-byte piece of each plane;
+            // columns past N are the image's padding (zero; 1.0 at column N when out_append_ones), row M is the zero row
+            float e[4], z[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const bool one = g.out_append_ones && col + c == g.N;
+              e[c] = col + c < g.N ? v[c] : (one ? 1.f : 0.f);
+              z[c] = one ? 1.f : 0.f;
+            }
+            const int ch = (int)(col >> 2);
+            const int64_t off = (int64_t)(ch >> 3) * X3_GROUP_BYTES + (ch & 1) * 8;
+            unsigned h0, m0, l0, h1, m1, l1;
+            split3(e[0], e[1], h0, m0, l0); split3(e[2], e[3], h1, m1, l1);
+            unsigned char* rp = g.out_img + row * g.out_row_bytes + off;
+            *(uint2*)(rp + x3_piece((ch & 7) >> 1, 0) * 16) = make_uint2(h0, h1);
+            *(uint2*)(rp + x3_piece((ch & 7) >> 1, 1) * 16) = make_uint2(m0, m1);
+            *(uint2*)(rp + x3_piece((ch & 7) >> 1, 2) * 16) = make_uint2(l0, l1);
+            if (row == g.M - 1) {
+              split3(z[0], z[1], h0, m0, l0); split3(z[2], z[3], h1, m1, l1);
+              rp += g.out_row_bytes;
+              *(uint2*)(rp + x3_piece((ch & 7) >> 1, 0) * 16) = make_uint2(h0, h1);
+              *(uint2*)(rp + x3_piece((ch & 7) >> 1, 1) * 16) = make_uint2(m0, m1);
+              *(uint2*)(rp + x3_piece((ch & 7) >> 1, 2) * 16) = make_uint2(l0, l1);
+            }
           }
           const bool vec = rok && vec_ok && !has_oc && col < g.N && col + 4 <= ldd;
           if (vec) *(float4*)(dst + row * ldd + col) = make_float4(v[0], v[1], v[2], v[3]);
@@ -586,7 +654,9 @@ __global__ void __launch_bounds__(256) k_x3_splitk_reduce(X3Args g) {
 __global__ void __launch_bounds__(256) k_x3_split(const float* __restrict__ src, int64_t ld, const int64_t* __restrict__ rows,
                                                   int64_t nrows_src, int64_t R, int K, int append,
                                                   const float* __restrict__ append_vec, unsigned char* __restrict__ img,
-                                                  int64_t row_bytes) {
+                                                  int64_t row_bytes, int64_t img_row_bytes) {
+  // row_bytes = this matrix's own groups x 192; img_row_bytes = the distance between image rows (larger when the matrix is one
+  // part of a K-concatenated image: img then points at the part's first group)
   const int cpr = (int)(row_bytes / X3_GROUP_BYTES) * 4;   // 8-element chunks per row
   const int64_t total = (R + 1) * cpr;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -617,7 +687,7 @@ __global__ void __launch_bounds__(256) k_x3_split(const float* __restrict__ src,
     split3(e[2], e[3], o[0].y, o[1].y, o[2].y);
     split3(e[4], e[5], o[0].z, o[1].z, o[2].z);
     split3(e[6], e[7], o[0].w, o[1].w, o[2].w);
-    unsigned char* d = img + r * row_bytes + (int64_t)(ch >> 2) * X3_GROUP_BYTES;
+    unsigned char* d = img + r * img_row_bytes + (int64_t)(ch >> 2) * X3_GROUP_BYTES;
 #pragma unroll
     for (int sp = 0; sp < 3; ++sp) *(uint4*)(d + x3_piece(ch & 3, sp) * 16) = o[sp];
   }
@@ -749,7 +819,26 @@ extern "C" int ogl_x3_split(const float* src, int64_t ld, const int64_t* rows, i
   const int64_t row_bytes = ogl_cdiv(Ki, 32) * X3_GROUP_BYTES;
   const int64_t total = (R + 1) * (row_bytes / X3_GROUP_BYTES) * 4;
   hipLaunchKernelGGL(k_x3_split, dim3((unsigned)min((int64_t)65536, ogl_cdiv(total, 256))), dim3(256), 0, (hipStream_t)stream, src,
-                     ld, rows, nrows_src, R, K, append, append_vec, (unsigned char*)image, row_bytes);
+                     ld, rows, nrows_src, R, K, append, append_vec, (unsigned char*)image, row_bytes, row_bytes);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+// One PART of a K-concatenated image (the B operand of a two-part product, ogl_linear_fwd_x3_ext): the image rows are
+// image_row_bytes apart (= 192 x the groups of ALL parts) and this part starts at group `group_offset` of every row.
+extern "C" int ogl_x3_split_into(const float* src, int64_t ld, int64_t R, int K, int append, const float* append_vec, void* image,
+                                 int64_t image_row_bytes, int64_t group_offset, ogl_stream_t stream) {
+  if (R < 0 || K < 0 || ld < K || append < 0 || append > 2 || (append == 2 && R > 0 && !append_vec) || group_offset < 0) return OGL_EINVAL;
+  const int Ki = K + (append ? 1 : 0);
+  if (Ki == 0) return OGL_OK;
+  const int64_t row_bytes = ogl_cdiv(Ki, 32) * X3_GROUP_BYTES;
+  if (!image || (R > 0 && K > 0 && !src) || ((uintptr_t)image & 15) || image_row_bytes < group_offset * X3_GROUP_BYTES + row_bytes ||
+      image_row_bytes % X3_GROUP_BYTES)
+    return OGL_EINVAL;
+  const int64_t total = (R + 1) * (row_bytes / X3_GROUP_BYTES) * 4;
+  hipLaunchKernelGGL(k_x3_split, dim3((unsigned)min((int64_t)65536, ogl_cdiv(total, 256))), dim3(256), 0, (hipStream_t)stream, src,
+                     ld, nullptr, R, R, K, append, append_vec, (unsigned char*)image + group_offset * X3_GROUP_BYTES, row_bytes,
+                     image_row_bytes);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }
@@ -794,6 +883,7 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
   // (row-major image: rows x row_bytes; group-major image: groups x step_bytes)
   const int64_t a_bytes = std::max((g.a.zero_row + 1) * g.a.row_bytes, (int64_t)g.nsteps * g.a.step_bytes);
   const int64_t b_bytes = std::max((g.b.zero_row + 1) * g.b.row_bytes, (int64_t)g.nsteps * g.b.step_bytes);
+  if (g.a2.img && (g.a2.zero_row + 1) * g.a2.row_bytes >= (1ll << 32)) return OGL_EINVAL;
   int cfg = x3_config(g.M, g.N);
   // producer / consumer kernels (k_gemm_x3p) whenever both images fit 32-bit offsets; OGL_X3_PC=0 forces the
   // self-fetching kernels (experiments)
@@ -815,11 +905,18 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     dim3 grid((unsigned)(8 * std::min<int64_t>(32, ogl_cdiv(T, 8)))), block(768);
     // ring depth: two stages of the 256 x 128 tile fill the LDS (144 KB); the 128 x 128 tile takes three (144 KB): its movers
     // run two stages ahead (+4 % on the layer-0 weight gradient, whose operands both stream from HBM)
-    if (cfg == 0) hipLaunchKernelGGL((k_gemm_x3p<4, 2, 2, 2, 2>), grid, block, 0, stream, g);
+    const bool ext = g.a2.img || g.add || g.out_img;
+    if (ext) {
+      if (g.nsplit != 1 || g.ones_col) return OGL_EINVAL;
+      if (cfg == 0) hipLaunchKernelGGL((k_gemm_x3p<4, 2, 2, 2, 2, true>), grid, block, 0, stream, g);
+      else if (cfg == 2) hipLaunchKernelGGL((k_gemm_x3p<2, 4, 3, 1, 2, true>), grid, block, 0, stream, g);
+      else hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1, 3, true>), grid, block, 0, stream, g);
+    } else if (cfg == 0) hipLaunchKernelGGL((k_gemm_x3p<4, 2, 2, 2, 2>), grid, block, 0, stream, g);
     else if (cfg == 2) hipLaunchKernelGGL((k_gemm_x3p<2, 4, 3, 1, 2>), grid, block, 0, stream, g);
     else hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1, 3>), grid, block, 0, stream, g);
     OGL_CHECK_LAUNCH();
   } else {
+  if (g.a2.img || g.add || g.out_img) return OGL_EINVAL;   // the extensions live in the producer / consumer kernel (images < 4 GB)
   if (cfg == 2) cfg = 1;
   const int BM = cfg == 0 ? 256 : 128, BN = 128;
   g.NI = (int)ogl_cdiv(g.M, BM);
@@ -850,6 +947,37 @@ extern "C" int ogl_linear_fwd_x3(const void* x_img, int64_t x_img_rows, const in
   g.b = X3Operand{(const unsigned char*)w_img, rb, X3_GROUP_BYTES, nullptr, N, N};
   g.M = M; g.N = N; g.nsteps = (int)ogl_cdiv(K, 32);
   g.C = y; g.ldc = ldy; g.relu = relu; g.nsplit = 1;
+  return launch_x3(g, (hipStream_t)stream);
+}
+
+// ogl_linear_fwd_x3 with the extensions of k_gemm_x3p<..., EXT>: a second A part (K-concatenated product), a per-row addend, the
+// output's own bf16x3 image.  K1 / K2 = reduction lengths the A images were built with (their appended element included);
+// the w image is K-concatenated: ceil(K1 / 32) + ceil(K2 / 32) groups per row.
+extern "C" int ogl_linear_fwd_x3_ext(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int K1,
+                                     const void* x2_img, int64_t x2_img_rows, const int64_t* x2_rows, int64_t x2_nrows, int K2,
+                                     int64_t M, const void* w_img, int N, const float* add, int64_t ld_add, const int64_t* add_rows,
+                                     int64_t add_nrows, int relu, float* y, int64_t ldy, void* out_img, int out_append_ones,
+                                     ogl_stream_t stream) {
+  if (M < 0 || K1 <= 0 || K2 < 0 || N < 0 || x_img_rows < 0 || x_nrows < 0 || x_nrows > x_img_rows || ldy < N) return OGL_EINVAL;
+  if (M == 0 || N == 0) return OGL_OK;
+  if (!x_img || !w_img || !y || (!x_rows && M > x_img_rows)) return OGL_EINVAL;
+  if (K2 > 0 && (!x2_img || x2_img_rows < 0 || x2_nrows < 0 || x2_nrows > x2_img_rows || (!x2_rows && M > x2_img_rows))) return OGL_EINVAL;
+  if (add && (ld_add < N || add_nrows < 0)) return OGL_EINVAL;
+  if (out_img && ((uintptr_t)out_img & 15)) return OGL_EINVAL;
+  X3Args g = X3Args();
+  const int G1 = (int)ogl_cdiv(K1, 32), G2 = (int)ogl_cdiv(K2, 32);
+  g.a = X3Operand{(const unsigned char*)x_img, (int64_t)G1 * X3_GROUP_BYTES, X3_GROUP_BYTES, x_rows, x_rows ? x_nrows : x_img_rows,
+                  x_img_rows};
+  if (K2 > 0)
+    g.a2 = X3Operand{(const unsigned char*)x2_img, (int64_t)G2 * X3_GROUP_BYTES, X3_GROUP_BYTES, x2_rows,
+                     x2_rows ? x2_nrows : x2_img_rows, x2_img_rows};
+  g.nsteps1 = G1;
+  g.b = X3Operand{(const unsigned char*)w_img, (int64_t)(G1 + G2) * X3_GROUP_BYTES, X3_GROUP_BYTES, nullptr, N, N};
+  g.M = M; g.N = N; g.nsteps = G1 + G2;
+  g.C = y; g.ldc = ldy; g.relu = relu; g.nsplit = 1;
+  g.add = add; g.ld_add = ld_add; g.add_rows = add_rows; g.add_nrows = add_nrows;
+  g.out_img = (unsigned char*)out_img; g.out_append_ones = out_append_ones;
+  g.out_row_bytes = ogl_cdiv(N + (out_append_ones ? 1 : 0), 32) * X3_GROUP_BYTES;
   return launch_x3(g, (hipStream_t)stream);
 }
 

@@ -548,6 +548,53 @@ def linear_fwd_x3(x_img, x_rows, w_img, relu=False, x_nrows=None, M=None, out=No
     return y
 
 
+def x3_split_cat(parts):
+    """K-concatenated (weight) image: ``parts`` = [(matrix [N, K_p], bias-or-None), ...] with equal row counts; part p occupies
+    ceil((K_p + has_bias) / 32) groups of every image row, in order.  The B operand of ``linear_fwd_x3_ext``."""
+    mats = [(as_mat(m), b) for m, b in parts]
+    N = mats[0][0].shape[0]
+    groups = [-(-(m.shape[1] + (1 if b is not None else 0)) // 32) for m, b in mats]
+    G = sum(groups)
+    buf = torch.empty(max((N + 1) * G * 192, 16), dtype=torch.uint8, device=mats[0][0].device)
+    off = 0
+    for (m, b), gp in zip(mats, groups):
+        assert m.shape[0] == N
+        _launch("ogl_x3_split_into", _lib.lib().ogl_x3_split_into, _ptr(m), _ld(m), N, m.shape[1], 2 if b is not None else 0, _ptr(b),
+                _ptr(buf), G * 192, off, _stream(), meta=dict(R=N, K=m.shape[1]))
+        off += gp
+    return X3Image(buf, N, 32 * G)
+
+
+def linear_fwd_x3_ext(x_img, x_rows, w_img, x2_img=None, x2_rows=None, add=None, add_rows=None, relu=False, x_nrows=None,
+                      x2_nrows=None, M=None, want_image=False, image_append_ones=False, out=None):
+    """``linear_fwd_x3`` with a second A part (``w_img`` K-concatenated, x3_split_cat), a per-row addend ``add[add_rows]`` and /
+    or the bf16x3 image of the output (returned as the second value when ``want_image``)."""
+    M = x_rows.numel() if x_rows is not None else (x_img.rows if M is None else M)
+    x_nrows = x_img.rows if x_nrows is None else x_nrows
+    K1 = x_img.K
+    K2 = x2_img.K if x2_img is not None else 0
+    N = w_img.rows
+    assert w_img.K == 32 * (-(-K1 // 32) + -(-K2 // 32)), "the weight image must be K-concatenated over the A parts"
+    dev = x_img.buf.device
+    y = out if out is not None else empty_mat(M, N, dev)
+    if add is not None:
+        add = as_mat(add)
+        assert add.shape[1] == N and (add_rows is None or add_rows.numel() == M)
+    img = None
+    if want_image:
+        Ki = N + (1 if image_append_ones else 0)
+        img = X3Image(_x3_alloc(M, Ki, dev), M, Ki)
+    _launch("ogl_linear_fwd_x3_ext", _lib.lib().ogl_linear_fwd_x3_ext, _ptr(x_img.buf), x_img.rows,
+            _ptr(_ids(x_rows) if x_rows is not None else None), x_nrows, K1,
+            _ptr(x2_img.buf) if x2_img is not None else None, x2_img.rows if x2_img is not None else 0,
+            _ptr(_ids(x2_rows) if x2_rows is not None else None),
+            (x2_img.rows if x2_nrows is None else x2_nrows) if x2_img is not None else 0, K2, M, _ptr(w_img.buf), N,
+            _ptr(add), _ld(add) if add is not None else 0, _ptr(_ids(add_rows) if add_rows is not None else None),
+            add.shape[0] if add is not None else 0, 1 if relu else 0, _ptr(y), _ld(y), _ptr(img.buf) if img is not None else None,
+            1 if image_append_ones else 0, _stream(), meta=dict(M=M, K=K1, N=N, K2=K2))
+    return (y, img) if want_image else y
+
+
 def pool_bwd_x3(dout, argmax, relu_out, idx32, n_src):
     """Image of dP^T for the relu -> max-pool backward (see include/ogl_hip.h): rows = features, reduction = the source
     rows dealt round-robin over G = ceil(n_src / 32) groups (build the other operand with x3_split_t(interleave=G))."""

@@ -443,3 +443,52 @@ def test_self_fetching_kernels_parity():
                         "-k", "forward or weight or random or dispatch or limits", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# k_gemm_x3p<..., EXT>: a second A part (K-concatenated product), a per-row addend, the output's own image
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K1,K2,N", [(7060, 602, 602, 600), (300, 40, 70, 33), (14000, 602, 0, 600), (2049, 600, 0, 600)])
+def test_x3_ext_two_part_addend_and_output_image(M, K1, K2, N):
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    torch.manual_seed(M + K2)
+    dev = "cuda"
+    T = M + 500
+    table = ops.empty_mat(T, K1, dev).copy_(torch.randn(T, K1, device=dev))
+    rows = torch.randint(0, T, (M,), device=dev)
+    rows[::97] = -1                                                   # ids outside the table read the zero row
+    w1 = torch.randn(N, K1, device=dev) / K1 ** 0.5
+    b = torch.randn(N, device=dev)
+    t_img = ops.x3_split(table, append_ones=True)
+    parts = [(w1, b)]
+    x2 = x2_img = None
+    if K2:
+        x2 = ops.empty_mat(M, K2, dev).copy_(torch.randn(M, K2, device=dev))
+        w2 = torch.randn(N, K2, device=dev) / K2 ** 0.5
+        parts.append((w2, None))
+        x2_img = ops.x3_split(x2)
+    w_img = ops.x3_split_cat(parts)
+    S0 = ops.empty_mat(T, N, dev).copy_(torch.randn(T, N, device=dev))
+    add_rows = torch.randint(0, T, (M,), device=dev)
+    xg = torch.where((rows >= 0).unsqueeze(1), table[rows.clamp(min=0)], torch.zeros((), device=dev))
+    base = xg.double() @ w1.double().T + b.double() * (rows >= 0).double().unsqueeze(1) * 0 + b.double()   # the ones slot of the zero row is 1 too
+    if K2:
+        base = base + x2.double() @ w2.double().T
+    for use_add, relu in ((False, True), (True, False), (True, True)):
+        y, img = ops.linear_fwd_x3_ext(t_img, rows, w_img, x2_img=x2_img, add=S0 if use_add else None,
+                                       add_rows=add_rows if use_add else None, relu=relu, x_nrows=T, want_image=True,
+                                       image_append_ones=True)
+        want = base + (S0[add_rows].double() if use_add else 0)
+        if relu:
+            want = want.clamp(min=0)
+        np.testing.assert_allclose(y.cpu().numpy(), want.float().cpu().numpy(), rtol=1e-4, atol=2e-5)
+        # the emitted image is, byte for byte, what a split pass over the fp32 output would have built
+        ref_img = ops.x3_split(y, append_ones=True)
+        assert img.rows == ref_img.rows == M and img.K == ref_img.K == N + 1
+        assert torch.equal(img.buf[:ref_img.buf.numel()], ref_img.buf)
+    # without the extensions the EXT entry point equals the plain one bit for bit
+    if not K2:
+        y0 = ops.linear_fwd_x3(t_img, rows, w_img, relu=True, x_nrows=T)
+        y1 = ops.linear_fwd_x3_ext(t_img, rows, w_img, relu=True, x_nrows=T, add=torch.zeros_like(S0), add_rows=add_rows)
+        assert torch.equal(y0, y1)
