@@ -489,6 +489,6 @@ def test_x3_ext_two_part_addend_and_output_image(M, K1, K2, N):
         assert torch.equal(img.buf[:ref_img.buf.numel()], ref_img.buf)
     # without the extensions the EXT entry point equals the plain one bit for bit
     if not K2:
-        y0 = ops.linear_fwd_x3(t_img, rows, w_img, relu=True, x_nrows=T)
+        y0 = ops.linear_fwd_x3(t_img, rows, ops.x3_split(w1, append_vec=b), relu=True, x_nrows=T)
         y1 = ops.linear_fwd_x3_ext(t_img, rows, w_img, relu=True, x_nrows=T, add=torch.zeros_like(S0), add_rows=add_rows)
         assert torch.equal(y0, y1)
