@@ -36,6 +36,7 @@ SIGNATURES = {
     "ogl_gather_i64": (_i, [_p, _i64, _p, _i64, _p, _p]),
     "ogl_dropout_rows": (_i, [_p, _i64, _p, _i64, _i64, _i, _d, _u64, _u64, _p, _i64, _p]),
     "ogl_reduce_fwd": (_i, [_p, _i64, _i64, _p, _p, _i64, _i, _i, _i, _p, _i64, _p, _p]),
+    "ogl_reduce_fwd_img": (_i, [_p, _i64, _i64, _p, _p, _i64, _i, _i, _p, _i64, _p, _p, _p]),
     "ogl_reduce_bwd": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i, _i, _i, _i64, _p, _i64, _p]),
     "ogl_linear_fwd": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p,
                             _p, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p]),

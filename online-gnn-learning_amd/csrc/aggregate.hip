@@ -9,6 +9,7 @@
 // registers, one coalesced store per destination.  Algorithmic bytes per launch:
 // E*(4*D + idx) + n_dst*4*D  (SURVEY.md §8d).
 #include "ogl_common.h"
+#include "x6_arith.h"
 
 #define WAVES_PER_BLOCK 4
 
@@ -23,11 +24,14 @@ __device__ __forceinline__ int64_t bcast_idx(int64_t v, int j) {
 // One wave per (destination, column slice): `parts` waves share a destination, each reducing a contiguous slice of
 // ceil(d4 / parts) float4 columns.  A batch of 7 000 destinations is only 1.4 rounds of one-wave-per-destination on the
 // chip (256 CUs x 20 waves): two slices per destination make it 2 rounds of smaller waves — no half-empty tail round.
-template <int OP, typename IdxT, bool ARG, int NCH, int U = (NCH == 1 ? 8 : 4)>
+// IMG: ALSO write the bf16x3 image of the output (row-major, n_dst + 1 rows, reduction length d; x6_arith.h) — the A operand of the
+// projection that consumes the reduced rows, without a split pass of its own: a lane's float4 is half a 16-byte piece of each
+// plane (3 x 8-byte stores beside the 16-byte fp32 store).
+template <int OP, typename IdxT, bool ARG, int NCH, bool IMG = false, int U = (NCH == 1 ? 8 : 4)>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK)
 k_reduce_fwd_v4(const float* __restrict__ src, int64_t lds, int64_t n_src, const IdxT* __restrict__ idx,
                 int64_t n_dst, int S, int d, float* __restrict__ out, int64_t ldo,
-                int32_t* __restrict__ argmax, int parts) {
+                int32_t* __restrict__ argmax, int parts, unsigned char* __restrict__ img = nullptr, int64_t img_row_bytes = 0) {
   const int lane = threadIdx.x & 63;
   const int64_t wg = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   const int64_t w = wg / parts;
@@ -99,12 +103,41 @@ k_reduce_fwd_v4(const float* __restrict__ src, int64_t lds, int64_t n_src, const
       float4 o = acc[c];
       if (OP == OGL_REDUCE_MEAN && any) { o.x /= fS; o.y /= fS; o.z /= fS; o.w /= fS; }
       ((float4*)(out + w * ldo))[ch] = o;
+      if (IMG) {
+        const int b4 = ch * 4;
+        const float e0 = b4 < d ? o.x : 0.f, e1 = b4 + 1 < d ? o.y : 0.f, e2 = b4 + 2 < d ? o.z : 0.f, e3 = b4 + 3 < d ? o.w : 0.f;
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3(e0, e1, h0, m0, l0); split3(e2, e3, h1, m1, l1);
+        unsigned char* rp = img + w * img_row_bytes + (int64_t)(ch >> 3) * 192 + (ch & 1) * 8;
+        const int pc = (ch & 7) >> 1;
+        *(uint2*)(rp + x3_piece(pc, 0) * 16) = make_uint2(h0, h1);
+        *(uint2*)(rp + x3_piece(pc, 1) * 16) = make_uint2(m0, m1);
+        *(uint2*)(rp + x3_piece(pc, 2) * 16) = make_uint2(l0, l1);
+        if (w == n_dst - 1) {                               // the image's all-zero row sits behind the last destination
+          rp += img_row_bytes;
+          *(uint2*)(rp + x3_piece(pc, 0) * 16) = make_uint2(0u, 0u);
+          *(uint2*)(rp + x3_piece(pc, 1) * 16) = make_uint2(0u, 0u);
+          *(uint2*)(rp + x3_piece(pc, 2) * 16) = make_uint2(0u, 0u);
+        }
+      }
       if (ARG) {
         int base = ch * 4;
         int32_t* ap = argmax + w * (int64_t)d + base;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (base + e < d) ap[e] = arg[c][e];
+      }
+    }
+  }
+  if (IMG && part == parts - 1) {
+    const int kpad4 = (int)(img_row_bytes / 192) * 8;       // float4 columns of the padded image row
+    for (int ch = dall4 + lane; ch < kpad4; ch += 64) {
+      for (int rr = 0; rr < (w == n_dst - 1 ? 2 : 1); ++rr) {
+        unsigned char* rp = img + (w + rr) * img_row_bytes + (int64_t)(ch >> 3) * 192 + (ch & 1) * 8;
+        const int pc = (ch & 7) >> 1;
+        *(uint2*)(rp + x3_piece(pc, 0) * 16) = make_uint2(0u, 0u);
+        *(uint2*)(rp + x3_piece(pc, 1) * 16) = make_uint2(0u, 0u);
+        *(uint2*)(rp + x3_piece(pc, 2) * 16) = make_uint2(0u, 0u);
       }
     }
   }
@@ -142,7 +175,8 @@ k_reduce_fwd_generic(const float* __restrict__ src, int64_t lds, int64_t n_src, 
 
 template <int OP, typename IdxT, bool ARG>
 static int launch_reduce_fwd(const float* src, int64_t lds, int64_t n_src, const IdxT* idx, int64_t n_dst,
-                             int S, int d, float* out, int64_t ldo, int32_t* argmax, hipStream_t stream) {
+                             int S, int d, float* out, int64_t ldo, int32_t* argmax, hipStream_t stream,
+                             unsigned char* img = nullptr) {
   dim3 grid((unsigned)ogl_cdiv(n_dst, WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
   const int d4 = (d + 3) / 4;
   const bool vec = (lds % 4 == 0) && (ldo % 4 == 0) && (lds >= 4 * d4) && (ldo >= 4 * d4) &&
@@ -155,6 +189,16 @@ static int launch_reduce_fwd(const float* src, int64_t lds, int64_t n_src, const
   while (vec && parts < 4 && n_dst * parts < 2 * 256 * 20 && d4 / (parts + 1) >= 32) ++parts;
   const int cper = (d4 + parts - 1) / parts;
   if (vec) grid.x = (unsigned)ogl_cdiv(n_dst * parts, WAVES_PER_BLOCK);
+  if (img) {
+    if (!vec || OP != OGL_REDUCE_MAX) return OGL_EINVAL;     // the image form exists for the vectorised max (the 'pool' layers)
+    const int64_t irb = ogl_cdiv(d, 32) * 192;
+    if (cper <= 64) hipLaunchKernelGGL((k_reduce_fwd_v4<OGL_REDUCE_MAX, IdxT, ARG, 1, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb);
+    else if (cper <= 128) hipLaunchKernelGGL((k_reduce_fwd_v4<OGL_REDUCE_MAX, IdxT, ARG, 2, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb);
+    else if (cper <= 192) hipLaunchKernelGGL((k_reduce_fwd_v4<OGL_REDUCE_MAX, IdxT, ARG, 3, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb);
+    else hipLaunchKernelGGL((k_reduce_fwd_v4<OGL_REDUCE_MAX, IdxT, ARG, 4, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb);
+    OGL_CHECK_LAUNCH();
+    return OGL_OK;
+  }
   if (!vec) {
     hipLaunchKernelGGL((k_reduce_fwd_generic<OP, IdxT, ARG>), grid, block, 0, stream, src, lds, n_src, idx,
                        n_dst, S, d, out, ldo, argmax);
@@ -201,6 +245,23 @@ extern "C" int ogl_reduce_fwd(const float* src, int64_t lds, int64_t n_src, cons
   if (!out || (!src && n_src > 0)) return OGL_EINVAL;
   if (idx32) return dispatch_reduce_fwd<int32_t>(src, lds, n_src, idx32, n_dst, fanout, d, op, out, ldo, argmax, (hipStream_t)stream);
   return dispatch_reduce_fwd<int64_t>(src, lds, n_src, idx64, n_dst, fanout, d, op, out, ldo, argmax, (hipStream_t)stream);
+}
+
+// ogl_reduce_fwd(OGL_REDUCE_MAX) that ALSO writes the bf16x3 image of `out` (what ogl_x3_split(out) would build; n_dst + 1 image
+// rows over a reduction of d): the A operand of the projection that consumes the pooled rows.  16-byte-aligned, 4-float-strided
+// operands only (what this package allocates).
+extern "C" int ogl_reduce_fwd_img(const float* src, int64_t lds, int64_t n_src, const int32_t* idx32, const int64_t* idx64,
+                                  int64_t n_dst, int fanout, int d, float* out, int64_t ldo, int32_t* argmax, void* image,
+                                  ogl_stream_t stream) {
+  if (n_dst <= 0 || fanout <= 0 || d <= 0 || n_src <= 0 || lds < d || ldo < d) return OGL_EINVAL;
+  if ((idx32 != nullptr) == (idx64 != nullptr)) return OGL_EINVAL;
+  if (!out || !src || !image || ((uintptr_t)image & 15)) return OGL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned char* im = (unsigned char*)image;
+  if (idx32) return argmax ? launch_reduce_fwd<OGL_REDUCE_MAX, int32_t, true>(src, lds, n_src, idx32, n_dst, fanout, d, out, ldo, argmax, st, im)
+                           : launch_reduce_fwd<OGL_REDUCE_MAX, int32_t, false>(src, lds, n_src, idx32, n_dst, fanout, d, out, ldo, nullptr, st, im);
+  return argmax ? launch_reduce_fwd<OGL_REDUCE_MAX, int64_t, true>(src, lds, n_src, idx64, n_dst, fanout, d, out, ldo, argmax, st, im)
+                : launch_reduce_fwd<OGL_REDUCE_MAX, int64_t, false>(src, lds, n_src, idx64, n_dst, fanout, d, out, ldo, nullptr, st, im);
 }
 
 // ---- backward ----------------------------------------------------------------------------------

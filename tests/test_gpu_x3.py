@@ -492,3 +492,21 @@ def test_x3_ext_two_part_addend_and_output_image(M, K1, K2, N):
         y0 = ops.linear_fwd_x3(t_img, rows, ops.x3_split(w1, append_vec=b), relu=True, x_nrows=T)
         y1 = ops.linear_fwd_x3_ext(t_img, rows, w_img, relu=True, x_nrows=T, add=torch.zeros_like(S0), add_rows=add_rows)
         assert torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("n_src,n_dst,S,d,dtype", [(62000, 7060, 25, 602, torch.int32), (20000, 1500, 25, 128, torch.int64),
+                                                   (3000, 512, 25, 600, torch.int32), (500, 64, 7, 36, torch.int32)])
+def test_aggregator_emits_the_image_of_its_output(n_src, n_dst, S, d, dtype):
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    torch.manual_seed(n_dst)
+    src = ops.empty_mat(n_src, d, "cuda").copy_(torch.randn(n_src, d, device="cuda"))
+    idx = torch.randint(0, n_src, (n_dst, S), device="cuda").to(dtype)
+    idx[::13] = -1
+    out0, arg0 = ops.reduce_fwd(src, idx, "max", want_argmax=True)
+    out1, arg1, img = ops.reduce_fwd_img(src, idx, want_argmax=True)
+    assert torch.equal(out0, out1) and torch.equal(arg0, arg1)
+    ref = ops.x3_split(out0)
+    assert img.rows == ref.rows and img.K == ref.K and torch.equal(img.buf[:ref.buf.numel()], ref.buf)
+    out2, _, img2 = ops.reduce_fwd_img(src, idx, want_argmax=False)
+    assert torch.equal(out2, out0) and torch.equal(img2.buf[:ref.buf.numel()], ref.buf)
