@@ -7,6 +7,7 @@ import contextlib
 import torch
 import torch.nn as nn
 
+from .. import ops
 from .sageconv import SAGEConv
 
 
@@ -32,13 +33,22 @@ class GraphSAGE(nn.Module):
         end — never kept across a weight update."""
         try:
             with torch.no_grad():
-                for layer in self.layers:
+                for li, layer in enumerate(self.layers):
                     if getattr(layer, "fc_self", None) is not None and layer.fc_self.bias is not None and layer.fc_neigh.bias is not None:
                         layer._bias_sum = layer.fc_self.bias + layer.fc_neigh.bias
+                    # weight images of the tall projections of the pass (wide 'pool' layers, split-bf16 arithmetic): fc_neigh of
+                    # the cached first layer (its self term comes from the table S0), [fc_pool | b] of the layers after it
+                    if layer._aggre_type == "pool" and layer._in_feats >= 128 and ops.get_gemm_mode() != "f32":
+                        if li == 0:
+                            layer._pass_images = dict(w_neigh=ops.x3_split_cat([(layer.fc_neigh.weight, None)]))
+                        elif layer.fc_pool.bias is not None:
+                            layer._pass_images = dict(w_pool_b=ops.x3_split(layer.fc_pool.weight, append_vec=layer.fc_pool.bias))
             yield self
         finally:
             for layer in self.layers:
                 layer._bias_sum = None
+                layer._pass_images = None
+            ops._ACT_IMAGES.clear()
 
     def forward(self, blocks, x):
         h = x

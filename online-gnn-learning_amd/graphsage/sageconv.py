@@ -136,7 +136,12 @@ class SAGEConv(nn.Module):
                                                     self.fc_neigh.weight, self.fc_self.bias, self.fc_neigh.bias, idx, n_dst,
                                                     fuse_relu, want_argmax=False)[0]
                 # inference: the same three launches without the autograd node, the summed bias from the cache
-                p = ops.linear_fwd(feat, self.fc_pool.weight, self.fc_pool.bias, relu=True)
+                imgs = getattr(self, "_pass_images", None)
+                himg = ops.take_image(feat) if (imgs and "w_pool_b" in imgs) else None
+                if himg is not None and himg.K == imgs["w_pool_b"].K:
+                    p = ops.linear_fwd_x3(himg, None, imgs["w_pool_b"], relu=True)     # both images at hand: the image kernel
+                else:
+                    p = ops.linear_fwd(feat, self.fc_pool.weight, self.fc_pool.bias, relu=True)
                 neigh, _ = ops.reduce_fwd(p, idx, "max", want_argmax=False)
                 return ops.linear_fwd(feat[:n_dst], self.fc_self.weight, self._summed_bias(), x2=neigh, w2=self.fc_neigh.weight,
                                       relu=fuse_relu)
@@ -187,6 +192,21 @@ class SAGEConv(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise RuntimeError("the cached-projection path is inference only (run it under torch.no_grad())")
         P0, S0 = feat.proj
+        imgs = getattr(self, "_pass_images", None)
+        if (t == "pool" and imgs and "w_neigh" in imgs and graph.picks.shape[0] >= ops.X3_N1_MIN_ROWS
+                and S0.shape[1] >= ADDROWS_MIN_WIDTH):
+            # tall, wide layer: the aggregator writes the image of the pooled rows beside them, the neighbour projection runs on
+            # the image kernel with S0[dst] added in its epilogue, and that kernel writes the image of ITS output for the next
+            # layer's fc_pool — no split pass anywhere (the weight images were built once for the pass)
+            h_neigh, _, nimg = ops.reduce_fwd_img(P0, graph.picks)
+            rst, himg = ops.linear_fwd_x3_ext(nimg, None, imgs["w_neigh"], add=S0, add_rows=graph.dst_ids, relu=fuse_relu,
+                                              want_image=True, image_append_ones=True)
+            ops.attach_image(rst, himg)
+            if self.activation is not None and not fuse_relu:
+                rst = self.activation(rst)
+            if self.norm is not None:
+                rst = self.norm(rst)
+            return rst
         h_neigh, _ = ops.reduce_fwd(P0, graph.picks, "mean" if t == "meanpool" else "max")
         w_neigh = self.fc_neigh.weight if t == "pool" else self.fc_neigh.weight[:, self._in_feats:]
         if S0.shape[1] >= ADDROWS_MIN_WIDTH:

@@ -565,6 +565,22 @@ def linear_fwd_x3(x_img, x_rows, w_img, relu=False, x_nrows=None, M=None, out=No
     return y
 
 
+# bf16x3 images that travel beside an fp32 activation from the kernel that produced it to the projection that consumes it
+# (keyed by the activation's storage; consumed within the same layer sequence, see attach_image / take_image)
+_ACT_IMAGES = {}
+X3_N1_MIN_ROWS = 2048      # projections with at least this many rows run on the image kernel when their operand images exist
+
+
+def attach_image(t, img):
+    _ACT_IMAGES[(t.data_ptr(), t.shape[0], t.shape[1])] = img
+    return t
+
+
+def take_image(t, pop=True):
+    key = (t.data_ptr(), t.shape[0], t.shape[1])
+    return _ACT_IMAGES.pop(key, None) if pop else _ACT_IMAGES.get(key)
+
+
 def x3_split_cat(parts):
     """K-concatenated (weight) image: ``parts`` = [(matrix [N, K_p], bias-or-None), ...] with equal row counts; part p occupies
     ceil((K_p + has_bias) / 32) groups of every image row, in order.  The B operand of ``linear_fwd_x3_ext``."""
