@@ -459,7 +459,8 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         make_src_a2(cur_ti);
         part2 = true; step_a = (unsigned)g.a2.step_bytes;
       }
-      const __amdgpu_buffer_rsrc_t rs_a = (EXT && part2) ? rsrc_a2 : rsrc_a;
+      const __amdgpu_buffer_rsrc_t r1 = rsrc_a, r2 = rsrc_a2;   // copies first: a conditional over two captured
+      const __amdgpu_buffer_rsrc_t rs_a = (EXT && part2) ? r2 : r1;   // references indexes the closure dynamically and pins it in scratch
       static_for<0, NLP>([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(u < NLP_A ? rs_a : rsrc_b,
