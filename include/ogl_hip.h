@@ -261,6 +261,25 @@ int ogl_linear_fwd_x3_ext(const void* x_img, int64_t x_img_rows, const int64_t* 
                           const void* x2_img, int64_t x2_img_rows, const int64_t* x2_rows, int64_t x2_nrows, int K2, int64_t M,
                           const void* w_img, int N, const float* add, int64_t ld_add, const int64_t* add_rows, int64_t add_nrows,
                           int relu, float* y, int64_t ldy, void* out_img, int out_append_ones, ogl_stream_t stream);
+/* Up to 8 small images in ONE launch — the weight images of a train step (the parameters of nn.Linear in
+ * R/train/graphsage/pytorch/aggregator_dgl.py:75-84, re-split after every optimiser step).  Part i becomes groups
+ * [group_offset, group_offset + ceil((K + append) / 32)) of every row of `image` (rows image_row_bytes apart, R + 1 of them:
+ * the last one zero), so several parts can fill one K-concatenated image.  transpose = 1: image row r is COLUMN r of src
+ * (src is [K, R]: the image of W^T for an input-gradient product).  append = 1: reduction element K holds
+ * vec1[r] + vec2[r] (either may be NULL = 0): the (summed) bias. */
+typedef struct ogl_x3_split_part {
+  const float* src; int64_t ld;
+  int64_t R; int32_t K;
+  int32_t transpose, append;
+  const float* vec1; const float* vec2;
+  void* image; int64_t image_row_bytes; int64_t group_offset;
+} ogl_x3_split_part;
+int ogl_x3_split_multi(const ogl_x3_split_part* parts, int n_parts, ogl_stream_t stream);
+/* ogl_relu_bwd that also writes the bf16x3 image of its result (M + 1 rows, reduction length N, no appended slot) = what
+ * ogl_x3_split(out) would build: the masked gradient of a fused-ReLU projection (autograd of F.relu in
+ * R/train/graphsage/pytorch/graphsage_dgl.py:29-31) is the A operand of the input-gradient product that follows. */
+int ogl_relu_bwd_img(const float* dy, int64_t ldy, const float* y, int64_t ldyy, int64_t M, int N, float* out, int64_t ldo,
+                     void* image, ogl_stream_t stream);
 /* One part of a K-concatenated (weight) image: rows image_row_bytes apart, this part from group `group_offset` on. */
 int ogl_x3_split_into(const float* src, int64_t ld, int64_t R, int K, int append, const float* append_vec, void* image,
                       int64_t image_row_bytes, int64_t group_offset, ogl_stream_t stream);

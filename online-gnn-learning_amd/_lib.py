@@ -60,6 +60,8 @@ SIGNATURES = {
     "ogl_x3_debug_stamps": (_i, [_p, _i]),
     "ogl_linear_fwd_x3": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i, _i, _p, _i64, _p]),
     "ogl_linear_fwd_x3_ext": (_i, [_p, _i64, _p, _i64, _i, _p, _i64, _p, _i64, _i, _i64, _p, _i, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i, _p]),
+    "ogl_x3_split_multi": (_i, [_p, _i, _p]),
+    "ogl_relu_bwd_img": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _p, _p]),
     "ogl_x3_split_into": (_i, [_p, _i64, _i64, _i, _i, _p, _p, _i64, _i64, _p]),
     "ogl_linear_bwd_weight_x3_workspace_bytes": (_i64, [_i64, _i, _i]),
     "ogl_linear_bwd_weight_x3": (_i, [_p, _p, _i64, _i, _i, _p, _i64, _p, _p, _i64, _p]),

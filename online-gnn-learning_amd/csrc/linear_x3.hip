@@ -844,6 +844,158 @@ extern "C" int ogl_x3_split_into(const float* src, int64_t ld, int64_t R, int K,
   return OGL_OK;
 }
 
+// Several small images in ONE launch: the weight images of a train step (every one a ~600 x 600 matrix: as separate launches
+// each costs a launch-bound 6-7 us, and the transposed ones a transpose launch before that).  blockIdx.y = the part.
+// A transposed part reads the matrix column-wise (image row r = column r of src): its threads walk r fastest, so the loads
+// stay contiguous.  The appended slot holds vec1[r] + vec2[r] (either may be null: 0) — the summed bias of a dual projection.
+#define OGL_X3_SPLIT_MAX_PARTS 8
+struct X3SplitBatch {
+  const float* src[OGL_X3_SPLIT_MAX_PARTS];
+  int64_t ld[OGL_X3_SPLIT_MAX_PARTS];
+  int64_t R[OGL_X3_SPLIT_MAX_PARTS];
+  int K[OGL_X3_SPLIT_MAX_PARTS];
+  int flags[OGL_X3_SPLIT_MAX_PARTS];               // bit 0: transposed, bit 1: appended slot
+  const float* vec1[OGL_X3_SPLIT_MAX_PARTS];
+  const float* vec2[OGL_X3_SPLIT_MAX_PARTS];
+  unsigned char* img[OGL_X3_SPLIT_MAX_PARTS];      // at the part's first group
+  int64_t img_row_bytes[OGL_X3_SPLIT_MAX_PARTS];
+};
+
+__global__ void __launch_bounds__(256) k_x3_split_multi(X3SplitBatch b) {
+  const int part = blockIdx.y;
+  const float* __restrict__ src = b.src[part];
+  const int64_t ld = b.ld[part], R = b.R[part], img_row_bytes = b.img_row_bytes[part];
+  const int K = b.K[part], flags = b.flags[part];
+  const float* __restrict__ v1 = b.vec1[part];
+  const float* __restrict__ v2 = b.vec2[part];
+  unsigned char* __restrict__ img = b.img[part];
+  const bool tr = flags & 1, slot = flags & 2;
+  const int cpr = ((K + (slot ? 1 : 0) + 31) / 32) * 4;       // 8-element chunks per image row
+  const int64_t total = (R + 1) * cpr;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r; int ch;
+    if (tr) { ch = (int)(t / (R + 1)); r = t - (int64_t)ch * (R + 1); }
+    else { r = t / cpr; ch = (int)(t - r * cpr); }
+    const int k = ch * 8;
+    float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < R && k < K) {
+      if (tr) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (k + q < K) e[q] = src[(int64_t)(k + q) * ld + r];
+      } else {
+        const float* p = src + r * ld + k;
+        if (k + 8 <= K) {
+          const float4 lo = ld16(p), hi = ld16(p + 4);
+          e[0] = lo.x; e[1] = lo.y; e[2] = lo.z; e[3] = lo.w; e[4] = hi.x; e[5] = hi.y; e[6] = hi.z; e[7] = hi.w;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) if (k + q < K) e[q] = p[q];
+        }
+      }
+    }
+    if (slot && K >= k && K < k + 8) {
+      float av = 0.f;
+      if (r < R) { if (v1) av = v1[r]; if (v2) av += v2[r]; }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) if (k + q == K) e[q] = av;
+    }
+    uint4 o[3];
+    split3(e[0], e[1], o[0].x, o[1].x, o[2].x);
+    split3(e[2], e[3], o[0].y, o[1].y, o[2].y);
+    split3(e[4], e[5], o[0].z, o[1].z, o[2].z);
+    split3(e[6], e[7], o[0].w, o[1].w, o[2].w);
+    unsigned char* d = img + r * img_row_bytes + (int64_t)(ch >> 2) * X3_GROUP_BYTES;
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) *(uint4*)(d + x3_piece(ch & 3, sp) * 16) = o[sp];
+  }
+}
+
+extern "C" int ogl_x3_split_multi(const ogl_x3_split_part* parts, int n_parts, ogl_stream_t stream) {
+  if (n_parts < 0 || n_parts > OGL_X3_SPLIT_MAX_PARTS || (n_parts > 0 && !parts)) return OGL_EINVAL;
+  if (n_parts == 0) return OGL_OK;
+  X3SplitBatch b;
+  int64_t most = 0;
+  for (int i = 0; i < n_parts; ++i) {
+    const ogl_x3_split_part& q = parts[i];
+    const int Ki = q.K + (q.append ? 1 : 0);
+    if (q.R < 0 || q.K < 0 || Ki == 0 || q.group_offset < 0 || !q.image || ((uintptr_t)q.image & 15)) return OGL_EINVAL;
+    if (q.ld < (q.transpose ? q.R : (int64_t)q.K) || (q.R > 0 && q.K > 0 && !q.src)) return OGL_EINVAL;
+    if (!q.append && (q.vec1 || q.vec2)) return OGL_EINVAL;
+    const int64_t row_bytes = ogl_cdiv(Ki, 32) * X3_GROUP_BYTES;
+    if (q.image_row_bytes < q.group_offset * X3_GROUP_BYTES + row_bytes || q.image_row_bytes % X3_GROUP_BYTES) return OGL_EINVAL;
+    b.src[i] = q.src; b.ld[i] = q.ld; b.R[i] = q.R; b.K[i] = q.K;
+    b.flags[i] = (q.transpose ? 1 : 0) | (q.append ? 2 : 0);
+    b.vec1[i] = q.vec1; b.vec2[i] = q.vec2;
+    b.img[i] = (unsigned char*)q.image + q.group_offset * X3_GROUP_BYTES;
+    b.img_row_bytes[i] = q.image_row_bytes;
+    most = max(most, (q.R + 1) * (row_bytes / X3_GROUP_BYTES) * 4);
+  }
+  for (int i = n_parts; i < OGL_X3_SPLIT_MAX_PARTS; ++i) {
+    b.src[i] = nullptr; b.ld[i] = 0; b.R[i] = -1; b.K[i] = 0; b.flags[i] = 0; b.vec1[i] = b.vec2[i] = nullptr; b.img[i] = nullptr;
+    b.img_row_bytes[i] = 0;
+  }
+  hipLaunchKernelGGL(k_x3_split_multi, dim3((unsigned)min((int64_t)4096, ogl_cdiv(most, 256)), (unsigned)n_parts), dim3(256), 0,
+                     (hipStream_t)stream, b);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+// dy (.) [y > 0] (ogl_relu_bwd) that ALSO writes the bf16x3 image of its result: the masked gradient is the A operand of the
+// input-gradient product that follows (dX = dY . W on the image kernel), so its image costs no pass of its own.
+__global__ void __launch_bounds__(256) k_relu_bwd_img(const float* __restrict__ dy, int64_t ldy, const float* __restrict__ y,
+                                                      int64_t ldyy, int64_t M, int N, float* __restrict__ out, int64_t ldo,
+                                                      unsigned char* __restrict__ img, int64_t row_bytes) {
+  const int cpr = (int)(row_bytes / X3_GROUP_BYTES) * 4;   // 8-element chunks per image row
+  const int64_t total = (M + 1) * cpr;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / cpr;
+    const int ch = (int)(t - r * cpr);
+    const int k = ch * 8;
+    float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < M && k < N) {
+      const float* pd = dy + r * ldy + k;
+      const float* py = y + r * ldyy + k;
+      float* po = out + r * ldo + k;
+      if (k + 8 <= N) {
+        const float4 d0 = ld16(pd), d1 = ld16(pd + 4), y0 = ld16(py), y1 = ld16(py + 4);
+        e[0] = y0.x > 0.f ? d0.x : 0.f; e[1] = y0.y > 0.f ? d0.y : 0.f; e[2] = y0.z > 0.f ? d0.z : 0.f; e[3] = y0.w > 0.f ? d0.w : 0.f;
+        e[4] = y1.x > 0.f ? d1.x : 0.f; e[5] = y1.y > 0.f ? d1.y : 0.f; e[6] = y1.z > 0.f ? d1.z : 0.f; e[7] = y1.w > 0.f ? d1.w : 0.f;
+        if ((ldo & 3) == 0 && ((uintptr_t)out & 15) == 0) {
+          *(float4*)po = make_float4(e[0], e[1], e[2], e[3]);
+          *(float4*)(po + 4) = make_float4(e[4], e[5], e[6], e[7]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) po[q] = e[q];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (k + q < N) { e[q] = py[q] > 0.f ? pd[q] : 0.f; po[q] = e[q]; }
+      }
+    }
+    uint4 o[3];
+    split3(e[0], e[1], o[0].x, o[1].x, o[2].x);
+    split3(e[2], e[3], o[0].y, o[1].y, o[2].y);
+    split3(e[4], e[5], o[0].z, o[1].z, o[2].z);
+    split3(e[6], e[7], o[0].w, o[1].w, o[2].w);
+    unsigned char* d = img + r * row_bytes + (int64_t)(ch >> 2) * X3_GROUP_BYTES;
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) *(uint4*)(d + x3_piece(ch & 3, sp) * 16) = o[sp];
+  }
+}
+
+extern "C" int ogl_relu_bwd_img(const float* dy, int64_t ldy, const float* y, int64_t ldyy, int64_t M, int N, float* out,
+                                int64_t ldo, void* image, ogl_stream_t stream) {
+  if (M < 0 || N <= 0 || ldy < N || ldyy < N || ldo < N) return OGL_EINVAL;
+  if (!image || ((uintptr_t)image & 15) || (M > 0 && (!dy || !y || !out))) return OGL_EINVAL;
+  const int64_t row_bytes = ogl_cdiv(N, 32) * X3_GROUP_BYTES;
+  const int64_t total = (M + 1) * (row_bytes / X3_GROUP_BYTES) * 4;
+  hipLaunchKernelGGL(k_relu_bwd_img, dim3((unsigned)min((int64_t)65536, ogl_cdiv(total, 256))), dim3(256), 0, (hipStream_t)stream,
+                     dy, ldy, y, ldyy, M, N, out, ldo, (unsigned char*)image, row_bytes);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
 extern "C" int ogl_x3_split_t(const float* src, int64_t ld, const int64_t* rows, int64_t nrows_src, int64_t M, int N, int ones_row,
                               int64_t interleave, void* image, ogl_stream_t stream) {
   if (M < 0 || N < 0 || ld < N || interleave < 0 || (interleave > 0 && 32 * interleave < M)) return OGL_EINVAL;

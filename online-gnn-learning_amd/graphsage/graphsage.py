@@ -50,7 +50,36 @@ class GraphSAGE(nn.Module):
                 layer._pass_images = None
             ops._ACT_IMAGES.clear()
 
+    def _prepare_step_images(self, blocks, x):
+        """The weight images the tall products of this train step will ask for (ops.weight_images_prepare: one launch instead
+        of one split — and for the input gradients a transpose — per product).  Which products run on images is decided by
+        the same size rules the layers apply; a request nobody consumes costs a few microseconds, a missing one is built by
+        its consumer."""
+        from .sageconv import GatheredRows
+        req = []
+        n_src = x.shape[0]
+        for li, (layer, block) in enumerate(zip(self.layers, blocks)):
+            n_dst = block.number_of_dst_nodes()
+            if layer._aggre_type == "pool" and layer.fc_pool is not None and not (self.training and layer.feat_drop.p > 0):
+                wp, bp = layer.fc_pool.weight, layer.fc_pool.bias
+                if li == 0 and isinstance(x, GatheredRows) and x.proj is None:
+                    if ops._x3_forward_ok(ops.as_mat(x.table), n_src, None):
+                        req.append(("wb", (wp, bp)))
+                    if ops._n1_images_ok(n_dst, wp.shape[0], layer.fc_self.weight.shape[0]) and ops._static_key(x.table) in ops._X3_TABLES:
+                        req.append(("cat", (layer.fc_self.weight, layer.fc_neigh.weight, layer.fc_self.bias,
+                                            layer.fc_neigh.bias if layer.fc_self.bias is not None else None)))
+                        req.append(("T", (layer.fc_neigh.weight,)))
+                elif li > 0 and ops._n1_images_ok(n_src, wp.shape[1], wp.shape[0]):
+                    req.append(("wb", (wp, bp)))
+                    req.append(("T", (wp,)))
+            n_src = n_dst
+        if req:
+            ops.weight_images_prepare(req)
+
     def forward(self, blocks, x):
+        ops._ACT_IMAGES.clear()         # activation images live from their producer to the next projection of THIS pass only
+        if torch.is_grad_enabled() and ops.get_gemm_mode() != "f32" and ops.PREPARE_WEIGHT_IMAGES:
+            self._prepare_step_images(blocks, x)
         h = x
         for layer, block in zip(self.layers, blocks):
             h = layer(block, h)

@@ -7,6 +7,7 @@ the CPU or through ATen kernels except trivial reshapes / scalar reads.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -412,8 +413,11 @@ def linear_fwd(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_ro
         # appended slot) per call — 12 us for a 602 x 602 matrix
         img = _static_image(x)
         if img is not None:
-            bvec = bias if bias is not None else torch.zeros(N, dtype=torch.float32, device=x.device)
-            return linear_fwd_x3(img, x_rows, x3_split(w, append_vec=bvec), relu=relu, x_nrows=x.shape[0], M=M, out=out)
+            wimg = weight_image("wb", w, bias)
+            if wimg is None:
+                bvec = bias if bias is not None else torch.zeros(N, dtype=torch.float32, device=x.device)
+                wimg = x3_split(w, append_vec=bvec)
+            return linear_fwd_x3(img, x_rows, wimg, relu=relu, x_nrows=x.shape[0], M=M, out=out)
     y = out if out is not None else empty_mat(M, N, x.device)
     _launch("ogl_linear_fwd", _lib.lib().ogl_linear_fwd, 
         _ptr(x), _ld(x), _ptr(x_rows), x.shape[0], M, K, _ptr(w), _ld(w), N, _ptr(bias),
@@ -445,12 +449,29 @@ def relu_bwd(dy, y):
     return out
 
 
-def linear_bwd_input(dy, w, ymask=None):
+def relu_bwd_img(dy, y):
+    """relu_bwd that also returns the bf16x3 image of the masked gradient: (out, X3Image)."""
+    dy = as_mat(dy); y = as_mat(y)
+    M, N = dy.shape
+    out = empty_mat(M, N, dy.device)
+    img = X3Image(_x3_alloc(M, N, dy.device), M, N)
+    _launch("ogl_relu_bwd_img", _lib.lib().ogl_relu_bwd_img, _ptr(dy), _ld(dy), _ptr(y), _ld(y), M, N, _ptr(out), _ld(out),
+            _ptr(img.buf), _stream(), meta=dict(M=M, N=N))
+    return out, img
+
+
+def linear_bwd_input(dy, w, ymask=None, dy_img=None):
+    """dX = dY . W.  ``dy_img``: the bf16x3 image of dY when its producer wrote one — the product then runs on the image kernel
+    against the image of W^T (a 600 x 600 transpose + split: two small launches)."""
     dy = as_mat(dy); w = as_mat(w)
     if ymask is not None:
         dy = relu_bwd(dy, ymask)
+        dy_img = None
     M, N = dy.shape
     K = w.shape[1]
+    if dy_img is not None and dy_img.rows == M and dy_img.K == N:
+        wt = weight_image("T", w)
+        return linear_fwd_x3(dy_img, None, wt if wt is not None else x3_split(transpose(w)))
     if M >= BWD_INPUT_VIA_FWD_MIN_ROWS and get_gemm_mode() != "f32":
         # dX = dY . W as dY . (W^T)^T: with the (small) weight transposed first, both operands of the product are
         # reduction-contiguous and it runs on the forward kernel — 60 us against 75-84 us at the n1-row shapes (the
@@ -568,7 +589,8 @@ def linear_fwd_x3(x_img, x_rows, w_img, relu=False, x_nrows=None, M=None, out=No
 # bf16x3 images that travel beside an fp32 activation from the kernel that produced it to the projection that consumes it
 # (keyed by the activation's storage; consumed within the same layer sequence, see attach_image / take_image)
 _ACT_IMAGES = {}
-X3_N1_MIN_ROWS = 2048      # projections with at least this many rows run on the image kernel when their operand images exist
+N1_BWD_SPLIT = True        # the scattered pool gradient dP (atomics: no producer can write its image) gets a split pass of its own
+X3_N1_MIN_ROWS = (1 << 40) if os.environ.get("OGL_N1_IMAGES") == "0" else 2048      # projections with at least this many rows run on the image kernel when their operand images exist
 
 
 def attach_image(t, img):
@@ -628,6 +650,121 @@ def linear_fwd_x3_ext(x_img, x_rows, w_img, x2_img=None, x2_rows=None, add=None,
     return (y, img) if want_image else y
 
 
+# ---- weight images of a step -------------------------------------------------------------------------------------------
+# Every image product needs the bf16x3 image of its weight matrix, rebuilt after every optimiser step.  One at a time these are
+# launch-bound 6-7 us kernels (and a transpose before the input-gradient ones); a model that knows which products its step will
+# run asks for all of them at once (GraphSAGE.forward -> weight_images_prepare: ONE launch).  Entries are keyed by the
+# parameters' storage + version counter and dropped by the optimisers (which update through raw pointers).
+_W_IMAGES = {}
+PREPARE_WEIGHT_IMAGES = True
+
+
+class _X3SplitPart(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("ld", C.c_int64), ("R", C.c_int64), ("K", C.c_int32), ("transpose", C.c_int32),
+                ("append", C.c_int32), ("vec1", C.c_void_p), ("vec2", C.c_void_p), ("image", C.c_void_p),
+                ("image_row_bytes", C.c_int64), ("group_offset", C.c_int64)]
+
+
+def _wkey(kind, *tensors):
+    return (kind,) + tuple(None if t is None else (t.data_ptr(), t._version) for t in tensors)
+
+
+def invalidate_weight_images():
+    _W_IMAGES.clear()
+
+
+def _capturing():
+    return torch.cuda.is_current_stream_capturing()
+
+
+def weight_image(kind, *tensors):
+    """The prepared image for this request, or None.  An image built while a hipGraph was being captured exists only inside
+    that graph's replays (its split kernel did not run), and one built eagerly is not rebuilt by a replay: an entry serves
+    only the mode it was made in."""
+    ent = _W_IMAGES.get(_wkey(kind, *tensors))
+    return ent[0] if (ent is not None and ent[1] == _capturing()) else None
+
+
+def weight_images_prepare(requests):
+    """requests: [(kind, tensors)] with kind / tensors one of
+         ("wb", (w, b))                    image of w with the bias slot (b may be None: 0) — B operand against an activation image with a ones slot
+         ("cat", (w, w2, b, b2))           K-concatenated [w | b + b2] [w2]                 — B operand of the two-part combine product
+         ("T", (w,))                       image of w^T                                   — B operand of dX = dY . w
+       All of them in one launch (at most 8 parts; further requests are left to their consumers)."""
+    parts, made = [], []
+    cap = _capturing()
+    for kind, ts in requests:
+        key = _wkey(kind, *ts)
+        if key in _W_IMAGES and _W_IMAGES[key][1] == cap:
+            continue
+        w = as_mat(ts[0])
+        dev = w.device
+        if kind == "T":
+            need, R, groups = 1, w.shape[1], [-(-w.shape[0] // 32)]
+        elif kind == "wb":
+            need, R, groups = 1, w.shape[0], [-(-(w.shape[1] + 1) // 32)]
+        else:
+            w2 = as_mat(ts[1])
+            need, R, groups = 2, w.shape[0], [-(-(w.shape[1] + 1) // 32), -(-w2.shape[1] // 32)]
+        if len(parts) + need > 8:
+            break
+        G = sum(groups)
+        buf = torch.empty(max((R + 1) * G * 192, 16), dtype=torch.uint8, device=dev)
+        if kind == "T":
+            parts.append((w, w.shape[1], w.shape[0], 1, 0, None, None, buf, G, 0))
+        elif kind == "wb":
+            parts.append((w, R, w.shape[1], 0, 1, ts[1], None, buf, G, 0))
+        else:
+            parts.append((w, R, w.shape[1], 0, 1, ts[2], ts[3], buf, G, 0))
+            parts.append((w2, R, w2.shape[1], 0, 0, None, None, buf, G, groups[0]))
+        made.append((key, X3Image(buf, R, 32 * G if kind == "cat" else (w.shape[0] if kind == "T" else w.shape[1] + 1))))
+    if not parts:
+        return
+    arr = (_X3SplitPart * len(parts))()
+    for a, (m, R, K, tr, app, v1, v2, buf, G, off) in zip(arr, parts):
+        a.src, a.ld, a.R, a.K, a.transpose, a.append = _ptr(m), _ld(m), R, K, tr, app
+        a.vec1, a.vec2, a.image, a.image_row_bytes, a.group_offset = _ptr(v1), _ptr(v2), _ptr(buf), G * 192, off
+    _launch("ogl_x3_split_multi", _lib.lib().ogl_x3_split_multi, C.cast(arr, C.c_void_p), len(parts), _stream(),
+            meta=dict(parts=len(parts)))
+    if len(_W_IMAGES) > 32:
+        _W_IMAGES.clear()               # stale versions of re-assigned parameters: never let them pile up
+    for key, img in made:
+        _W_IMAGES[key] = (img, cap)
+
+
+def _n1_images_ok(M, *widths):
+    """The n1-row products of a step run on the image kernel when their operand images come for free (emitted by the kernel
+    that produced the operand) and the product is tall enough to fill the chip."""
+    return _MODE["name"] != "f32" and M >= X3_N1_MIN_ROWS and all(64 <= wd <= 640 for wd in widths)
+
+
+def _dual_fwd_images(x, w, bias, bias2, x2, w2, relu, x_rows, x2_rows):
+    """fc_self(table[dst]) + fc_neigh(neigh) (+ bias, ReLU) as ONE image product over a two-part A operand: the rows of the
+    resident table's image and the image the aggregator wrote beside ``neigh`` — and the image of the result goes out beside
+    it for the next layer's fc_pool.  None when the operands' images are not at hand (the caller runs the fp32-operand
+    kernel)."""
+    if x2 is None or x_rows is None or x2_rows is not None:
+        return None
+    x = as_mat(x); x2 = as_mat(x2)
+    M = x_rows.numel()
+    if not _n1_images_ok(M, x2.shape[1], w.shape[0]) or x2.shape[0] != M:
+        return None
+    x2img = take_image(x2, pop=False)
+    if x2img is None or (x.data_ptr(), _ld(x), x.shape[1]) not in _X3_TABLES:
+        return None
+    ximg = _static_image(x)
+    if ximg is None:
+        return None
+    take_image(x2)
+    wcat = weight_image("cat", w, w2, bias, bias2)
+    if wcat is None:
+        weight_images_prepare([("cat", (w, w2, bias, bias2))])
+        wcat = weight_image("cat", w, w2, bias, bias2)
+    y, yimg = linear_fwd_x3_ext(ximg, x_rows, wcat, x2_img=x2img, relu=relu, x_nrows=x.shape[0], want_image=True,
+                                image_append_ones=True)
+    return attach_image(y, yimg)
+
+
 def pool_bwd_x3(dout, argmax, relu_out, idx32, n_src):
     """Image of dP^T for the relu -> max-pool backward (see include/ogl_hip.h): rows = features, reduction = the source
     rows dealt round-robin over G = ceil(n_src / 32) groups (build the other operand with x3_split_t(interleave=G))."""
@@ -673,6 +810,10 @@ def register_static_table(table):
     (+ the bias slot) is built lazily on first use and reused by every forward pass."""
     table = as_mat(table)
     _X3_TABLES[(table.data_ptr(), _ld(table), table.shape[1])] = [table, None]
+
+
+def _static_key(x):
+    return (x.data_ptr(), _ld(x), x.shape[1]) if x.dim() == 2 else None
 
 
 def _static_image(x):
@@ -740,6 +881,7 @@ def argmax_confusion(logits, labels=None, confusion=None, want_pred=True):
 
 
 def adam_step(p, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
+    invalidate_weight_images()      # parameters change under raw pointers: no version bump to key on
     for t in (p, g, m, v):
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
     _launch("ogl_adam_step", _lib.lib().ogl_adam_step, _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(step), C.c_double(lr),
@@ -748,6 +890,7 @@ def adam_step(p, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
 
 def adam_step_multi(ps, gs, ms, vs, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
     """One launch for every parameter tensor (same step count for all)."""
+    invalidate_weight_images()      # parameters change under raw pointers: no version bump to key on
     k = len(ps)
     for p, g, m, v in zip(ps, gs, ms, vs):
         for t in (p, g, m, v):
@@ -761,6 +904,7 @@ def adam_step_multi(ps, gs, ms, vs, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1
 def adam_step_multi_dev(ps, gs, ms, vs, step_dev, scalars_dev, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
     """adam_step_multi with the step count in device memory (``step_dev`` int64[1], incremented by the call on the device;
     ``scalars_dev`` float32[2] scratch): capturable in a hipGraph."""
+    invalidate_weight_images()      # parameters change under raw pointers: no version bump to key on
     k = len(ps)
     for p, g, m, v in zip(ps, gs, ms, vs):
         for t in (p, g, m, v):
@@ -783,9 +927,11 @@ class _LinearFn(torch.autograd.Function):
         # gets its gradient from its own weight-gradient product in backward (their ones columns are free) — a tracked
         # `bias + bias2` outside would hand ONE gradient tensor to two parameters, which autograd clones (a launch)
         ctx.has_bias2 = bias2 is not None
-        if bias2 is not None:
-            bias = bias + bias2
-        y = linear_fwd(x, w, bias, x2, w2, relu, x_rows, x2_rows)
+        y = _dual_fwd_images(x, w, bias, bias2, x2, w2, relu, x_rows, x2_rows)
+        if y is None:
+            if bias2 is not None:
+                bias = bias + bias2
+            y = linear_fwd(x, w, bias, x2, w2, relu, x_rows, x2_rows)
         ctx.relu = bool(relu)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, w, x2, w2, y if relu else None, x_rows, x2_rows)
@@ -795,15 +941,21 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, x2, w2, y, x_rows, x2_rows = ctx.saved_tensors
         dy = as_mat(dy)
-        if y is not None:
-            dy = relu_bwd(dy, y)        # once; the (up to four) backward GEMMs below are mask-free
-            y = None
         need = ctx.needs_input_grad
+        dy_img = None
+        if y is not None:
+            # once; the (up to four) backward GEMMs below are mask-free.  Tall products with an input gradient to compute get
+            # the image of the masked gradient from the same pass
+            if (need[0] or (x2 is not None and need[3])) and _n1_images_ok(dy.shape[0], dy.shape[1], w.shape[1]):
+                dy, dy_img = relu_bwd_img(dy, y)
+            else:
+                dy = relu_bwd(dy, y)
+            y = None
         dx = dw = db = dx2 = dw2 = db2 = None
         if need[0]:
             if x_rows is not None:
                 raise RuntimeError("gradient w.r.t. a row-gathered table is not supported (features carry no grad)")
-            dx = linear_bwd_input(dy, w, y)
+            dx = linear_bwd_input(dy, w, y, dy_img=dy_img)
         dyT = None
         if _MODE["name"] != "f32" and dy.shape[0] >= 1024 and x2 is not None and need[1] and need[4]:
             dyT = transposed_operand(dy)   # shared by the two weight gradients of a dual-input projection
@@ -813,7 +965,7 @@ class _LinearFn(torch.autograd.Function):
             if need[3]:
                 if x2_rows is not None:
                     raise RuntimeError("gradient w.r.t. a row-gathered table is not supported")
-                dx2 = linear_bwd_input(dy, w2, y)
+                dx2 = linear_bwd_input(dy, w2, y, dy_img=dy_img)
             if need[4] or ctx.has_bias2:
                 dw2, db2 = weight_grad(dy, x2, x2_rows, want_bias=ctx.has_bias2, dyT=dyT)
         return dx, dw, (db if ctx.has_bias else None), dx2, dw2, None, None, None, (db2 if ctx.has_bias2 else None)
@@ -867,7 +1019,12 @@ class _PoolMaxFn(torch.autograd.Function):
     def forward(ctx, x, w, bias, x_rows, idx):
         p = linear_fwd(x, w, bias, relu=True, x_rows=x_rows)
         need = x.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad)
-        out, argmax = reduce_fwd(p, idx, "max", want_argmax=need)
+        if _n1_images_ok(idx.shape[0], p.shape[1]):
+            # the pooled rows feed the n1-row combine product: their bf16x3 image goes out beside them
+            out, argmax, img = reduce_fwd_img(p, idx, want_argmax=need)
+            attach_image(out, img)
+        else:
+            out, argmax = reduce_fwd(p, idx, "max", want_argmax=need)
         if _CAPTURE is not None:
             _CAPTURE.append(dict(argmax=argmax, neigh=out))
         ctx.n_src, ctx.fanout, ctx.has_bias = p.shape[0], idx.shape[1], bias is not None
@@ -907,7 +1064,16 @@ class _SagePoolLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu):
         h = as_mat(h)
-        p = linear_fwd(h, w_pool, b_pool, relu=True)
+        himg = take_image(h) if _n1_images_ok(h.shape[0], h.shape[1], w_pool.shape[0]) else None
+        if himg is not None and himg.K == h.shape[1] + 1:
+            # the projection that produced h wrote its image (ones slot included): fc_pool runs on the image kernel
+            wimg = weight_image("wb", w_pool, b_pool)
+            if wimg is None:
+                weight_images_prepare([("wb", (w_pool, b_pool))])
+                wimg = weight_image("wb", w_pool, b_pool)
+            p = linear_fwd_x3(himg, None, wimg, relu=True)
+        else:
+            p = linear_fwd(h, w_pool, b_pool, relu=True)
         need = any(t is not None and t.requires_grad for t in (h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh))
         neigh, argmax = reduce_fwd(p, idx, "max", want_argmax=need)
         bias = None
@@ -935,7 +1101,8 @@ class _SagePoolLayerFn(torch.autograd.Function):
         dw_neigh, db2 = weight_grad(dy, neigh, None, want_bias=ctx.has_bias, dyT=dyT)
         dneigh = linear_bwd_input(dy, w_neigh, None)
         dp = reduce_bwd(dneigh, None, argmax, "max", n_src, fanout=ctx.fanout, relu_out=neigh)
-        dh = linear_bwd_input(dp, w_pool, None)
+        dp_img = x3_split(dp) if (N1_BWD_SPLIT and _n1_images_ok(n_src, dp.shape[1], w_pool.shape[1])) else None
+        dh = linear_bwd_input(dp, w_pool, None, dy_img=dp_img)
         dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias)
         dx_self = linear_bwd_input(dy, w_self, None)
         dh[:n_dst].add_(dx_self)                                  # the fc_self path, in place on the first n_dst rows

@@ -109,6 +109,7 @@ class TrainStepGraph:
                 self._body(apply=False)
             torch.cuda.current_stream().wait_stream(side)
             self.opt.zero_grad(set_to_none=True)
+            ops.invalidate_weight_images()          # no optimiser step ran: drop the weight images that forward prepared
             _WARMED = True
         torch.cuda.synchronize()
         kw = {} if pool is None else dict(pool=pool)

@@ -79,8 +79,11 @@ def test_sampled_graph_steps_equal_eager(name, B, S, H):
 def test_staged_graph_steps_equal_eager_reddit_size():
     """The Reddit rung: loader-sampled batches staged into per-bucket captured steps; 4 steps of 512 seeds."""
     import ogl_amd  # noqa: F401
-    from ogl_amd import ops, sampling, synthetic
+    from ogl_amd import ops, sampling, stepgraph, synthetic
     from ogl_amd.graphsage.model import RandomHipSupervisedGraphSage
+    # as in a fresh process: the first capture is preceded by a real forward + backward WITHOUT an optimiser step — whatever that
+    # pass caches (weight images) must not leak into the capture
+    stepgraph._WARMED = False
     feat_size, labels, dyn, n_classes, _ = synthetic.load("reddit", snapshots=2, device="cuda")
     dyn.evolve()
     g = dyn.get_graph()

@@ -510,3 +510,109 @@ def test_aggregator_emits_the_image_of_its_output(n_src, n_dst, S, d, dtype):
     assert img.rows == ref.rows and img.K == ref.K and torch.equal(img.buf[:ref.buf.numel()], ref.buf)
     out2, _, img2 = ops.reduce_fwd_img(src, idx, want_argmax=False)
     assert torch.equal(out2, out0) and torch.equal(img2.buf[:ref.buf.numel()], ref.buf)
+
+
+@pytest.mark.parametrize("M,N", [(7060, 600), (2500, 602), (1, 1), (300, 33), (4096, 64)])
+def test_relu_backward_emits_the_image_of_its_output(M, N):
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    torch.manual_seed(M + N)
+    dy = ops.empty_mat(M, N, "cuda").copy_(torch.randn(M, N, device="cuda"))
+    y = ops.empty_mat(M, N, "cuda").copy_(torch.randn(M, N, device="cuda").clamp(min=0))
+    want = ops.relu_bwd(dy, y)
+    assert torch.equal(want, torch.where(y > 0, dy, torch.zeros((), device="cuda")))
+    got, img = ops.relu_bwd_img(dy, y)
+    assert torch.equal(got, want)
+    ref = ops.x3_split(want)
+    assert img.rows == ref.rows and img.K == ref.K and torch.equal(img.buf[:ref.buf.numel()], ref.buf)
+    # the input gradient on the image kernel = the fp32-operand kernel's, to fp32-GEMM accuracy
+    w = torch.randn(N, 70, device="cuda") / N ** 0.5
+    ops.set_gemm_mode("auto")
+    try:
+        dx = ops.linear_bwd_input(want, w, dy_img=img)
+    finally:
+        ops.set_gemm_mode("f32")
+    np.testing.assert_allclose(dx.cpu().numpy(), (want.double() @ w.double()).float().cpu().numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_training_layers_run_their_tall_products_on_images():
+    """The wiring: in the split-bf16 modes a Reddit-shaped two-layer step takes the two-part image product for the layer-0
+    combine, the image kernel for fc_pool of layer 1 and for both n1-row input gradients — and produces the same loss and
+    gradients as the fp32-operand kernels (fp32-GEMM accuracy either way)."""
+    import torch.nn.functional as F
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    from ogl_amd.graphsage import GatheredRows, GraphSAGE
+    torch.manual_seed(5)
+    dev = "cuda"
+    n_tab, Fi, H, C, n0, n1, B, S = 30000, 602, 600, 41, 20000, 3000, 512, 25
+    table = ops.empty_mat(n_tab, Fi, dev).copy_(torch.randn(n_tab, Fi, device=dev))
+    ops.register_static_table(table)
+    model = GraphSAGE(Fi, H, C, 1, F.relu, 0, "pool").to(dev)
+
+    class Blk:
+        def __init__(self, n_src, n_dst):
+            self.local_idx = torch.randint(0, n_src, (n_dst, S), device=dev, dtype=torch.int32)
+            self._n = n_dst
+        def number_of_dst_nodes(self):
+            return self._n
+    blocks = [Blk(n0, n1), Blk(n1, B)]
+    ids = torch.randperm(n_tab, device=dev)[:n0]
+    labels = torch.randint(0, C, (B,), device=dev)
+
+    def step(mode):
+        ops.set_gemm_mode(mode)
+        for p in model.parameters():
+            p.grad = None
+        ops.profile_start()
+        logits = model(blocks, GatheredRows(table, ids))
+        loss = ops.cross_entropy(logits, labels, "mean")
+        loss.backward()
+        names = [n for n, _, _ in ops.profile_stop()]
+        return float(loss.detach()), [p.grad.clone() for p in model.parameters()], names
+    floor = ops.X3_N1_MIN_ROWS
+    try:
+        l1, g1, on_images = step("auto")
+        ops.X3_N1_MIN_ROWS = 1 << 40          # same arithmetic (split-bf16 x6), operands split on the fly by k_gemm
+        l0, g0, seen = step("auto")
+    finally:
+        ops.X3_N1_MIN_ROWS = floor
+        ops.set_gemm_mode("f32")
+    assert on_images.count("ogl_linear_fwd_x3_ext") == 1 and "ogl_reduce_fwd_img" in on_images and "ogl_relu_bwd_img" in on_images
+    assert on_images.count("ogl_linear_fwd_x3") >= 4      # fc_pool of both layers + the two n1-row input gradients
+    # every weight image of the step from ONE launch, no transpose launches for the input gradients
+    assert on_images.count("ogl_x3_split_multi") == 1 and "ogl_x3_split_into" not in on_images and "ogl_transpose" not in on_images
+    assert "ogl_linear_fwd_x3_ext" not in seen
+    assert abs(l1 - l0) <= 1e-5 * max(1.0, abs(l0))
+    errs = [float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12) for a, b in zip(g1, g0)]
+    assert max(errs) <= 1e-3, errs
+
+
+def test_weight_images_in_one_launch_equal_the_single_splits():
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    torch.manual_seed(11)
+    dev = "cuda"
+    w = torch.randn(600, 602, device=dev); w2 = torch.randn(600, 600, device=dev)
+    b = torch.randn(600, device=dev); b2 = torch.randn(600, device=dev)
+    wp = torch.randn(33, 70, device=dev); bp = torch.randn(33, device=dev)
+    wn = torch.randn(41, 129, device=dev)
+    ops.invalidate_weight_images()
+    ops.profile_start()
+    ops.weight_images_prepare([("wb", (wp, bp)), ("cat", (w, w2, b, b2)), ("T", (w2,)), ("wb", (wn, None)), ("T", (wp,)),
+                               ("cat", (wp, wp, None, None))])
+    assert [n for n, _, _ in ops.profile_stop()] == ["ogl_x3_split_multi"]
+    same = lambda a, r: a.rows == r.rows and a.K == r.K and torch.equal(a.buf[:r.buf.numel()], r.buf)
+    assert same(ops.weight_image("wb", wp, bp), ops.x3_split(wp, append_vec=bp))
+    assert same(ops.weight_image("cat", w, w2, b, b2), ops.x3_split_cat([(w, b + b2), (w2, None)]))
+    assert same(ops.weight_image("T", w2), ops.x3_split(ops.transpose(w2)))
+    assert same(ops.weight_image("wb", wn, None), ops.x3_split(wn, append_vec=torch.zeros(41, device=dev)))
+    assert same(ops.weight_image("T", wp), ops.x3_split(ops.transpose(wp)))
+    assert same(ops.weight_image("cat", wp, wp, None, None), ops.x3_split_cat([(wp, torch.zeros(33, device=dev)), (wp, None)]))
+    # keyed by storage + version: an in-place update or an optimiser step drops the entry
+    wp.add_(1.0)
+    assert ops.weight_image("wb", wp, bp) is None
+    assert ops.weight_image("T", w2) is not None
+    m, v = torch.zeros_like(w2), torch.zeros_like(w2)
+    ops.adam_step(w2, torch.ones_like(w2), m, v, 1)
+    assert ops.weight_image("T", w2) is None
