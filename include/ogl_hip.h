@@ -284,6 +284,16 @@ int ogl_relu_bwd_img(const float* dy, int64_t ldy, const float* y, int64_t ldyy,
 int ogl_x3_split_into(const float* src, int64_t ld, int64_t R, int K, int append, const float* append_vec, void* image,
                       int64_t image_row_bytes, int64_t group_offset, ogl_stream_t stream);
 int64_t ogl_linear_bwd_weight_x3_workspace_bytes(int64_t M, int N, int K);
+/* ogl_linear_bwd_weight_x3 with x as a ROW-MAJOR image (what ogl_x3_split / the image emitters build): dw[N, K] = dy^T . x[x_rows],
+ * reduction over M rows of x, no transposed image of x (autograd of nn.Linear's weight in
+ * R/train/graphsage/pytorch/aggregator_dgl.py:199-206).  dyT_img as for ogl_linear_bwd_weight_x3 ([N rows, reduction], group-major;
+ * interleave = G when it is ogl_pool_bwd_x3's image: reduction index m then stands for row (m % 32) * G + m / 32 of x[x_rows]).
+ * x image [x_img_rows (+ zero row), K (+ 1 when has_ones: the ones slot, which yields db / db2 = both copies of the bias
+ * gradient)]; x_rows (nullable) gathers M rows, ids outside [0, x_nrows) read the zero row.  Images must be < 4 GB. */
+int64_t ogl_linear_bwd_weight_x3k_workspace_bytes(int64_t M, int64_t interleave, int N, int K, int has_ones);
+int ogl_linear_bwd_weight_x3k(const void* dyT_img, int64_t interleave, const void* x_img, int64_t x_img_rows, const int64_t* x_rows,
+                              int64_t x_nrows, int64_t M, int N, int K, int has_ones, float* dw, int64_t lddw, float* db, float* db2,
+                              void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
 int ogl_linear_bwd_weight_x3(const void* dyT_img, const void* xT_img, int64_t M, int N, int K, float* dw,
                              int64_t lddw, float* db, void* workspace, int64_t workspace_bytes,
                              ogl_stream_t stream);

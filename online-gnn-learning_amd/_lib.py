@@ -64,6 +64,8 @@ SIGNATURES = {
     "ogl_relu_bwd_img": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _p, _p]),
     "ogl_x3_split_into": (_i, [_p, _i64, _i64, _i, _i, _p, _p, _i64, _i64, _p]),
     "ogl_linear_bwd_weight_x3_workspace_bytes": (_i64, [_i64, _i, _i]),
+    "ogl_linear_bwd_weight_x3k_workspace_bytes": (_i64, [_i64, _i64, _i, _i, _i]),
+    "ogl_linear_bwd_weight_x3k": (_i, [_p, _i64, _p, _i64, _p, _i64, _i64, _i, _i, _i, _p, _i64, _p, _p, _p, _i64, _p]),
     "ogl_linear_bwd_weight_x3": (_i, [_p, _p, _i64, _i, _i, _p, _i64, _p, _p, _i64, _p]),
     "ogl_ce_fwd_bwd": (_i, [_p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p]),
     "ogl_adam_step": (_i, [_p, _p, _p, _p, _i64, _i, _d, _d, _d, _d, _p]),

@@ -55,6 +55,13 @@ struct X3Args {
   int nsteps1;                  //   gather and zero row) — fc_self(x[dst]) + fc_neigh(neigh) as ONE product over a K-concatenated B
   const float* add;             // optional per-row addend: C[i, :] += add[add_rows ? add_rows[i] : i, :] before the activation
   int64_t ld_add; const int64_t* add_rows; int64_t add_nrows;
+  float* db2;                   // optional second copy of the bias gradient (the two biases of a dual projection: one tensor each)
+  // ---- k_gemm_x3p<..., BK = true> only: the B operand is a ROW-MAJOR image whose ROWS are the reduction index (b.rows gathers them,
+  // b.nrows bounds the ids, b.zero_row / b.row_bytes as for a row-major A) and whose COLUMNS are the output columns: the
+  // weight-gradient products read the activations' images as they are (no transposed image of x) ----
+  int64_t bk_red;               // reduction positions s >= bk_red are padding (zero row)
+  int64_t bk_interleave;        // G > 0: reduction index m stands for position (m % 32) * G + m / 32 (the order of pool_bwd_x3's image)
+  int bk_groups;                // 32-column groups per image row (column groups past it read the zero row)
   unsigned char* out_img;       // optional: ALSO write the bf16x3 image of the (activated) output, row-major, reduction length
   int64_t out_row_bytes;        //   N (+ 1 when out_append_ones: 1.0 at column N) — the A operand of the next layer's product
   int out_append_ones;
@@ -348,7 +355,7 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
 // One barrier per step.  Three waves per SIMD = 168 registers per wave: the multipliers keep accumulators (64), A
 // fragments (48) and a two-deep B ring (24), the movers their piece offsets.  Images must be < 4 GB (32-bit offsets).
 // Measured against k_gemm_x3: matrix pipe busy 73 % of the in-kernel cycles instead of 56 %.
-template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool EXT = false>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool EXT = false, bool BK = false>
 __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(WAVES_M * WAVES_N == 8, "eight multiplier waves + four mover waves");
@@ -360,6 +367,9 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
   constexpr int NSTORE = RB * CB;
   static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
   static_assert(NSTAGE * STAGE <= 160 * 1024, "the ring fits one CU");
+  static_assert(!BK || (BN == 128 && NLP - NLP_A == 6), "k-major B: 128 columns = 48 (plane, 8-column chunk) pairs x 32 rows per stage");
+  static_assert(!(BK && EXT), "the k-major B operand belongs to the weight-gradient products");
+  constexpr int B_BASE = A_PIECES * 16;                    // byte offset of the B part inside a stage
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -412,6 +422,26 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
     const unsigned step_b = (unsigned)g.b.step_bytes;
     unsigned src[NLP];
     int cur_ti = 0;
+    // BK: a step's B tile is 32 reduction rows x 768 contiguous bytes (48 pieces: 4 column groups).  One DMA instruction of mover
+    // wave w moves 4 rows x 16 consecutive pieces (4 runs of 256 B): instruction ub covers rows 8w + 4 (ub / 3) + 0..3, pieces
+    // 16 (ub % 3) + 0..15; lane (rsub, i) = (lane >> 4, lane & 15) takes piece 16 t + (i ^ f) of row rsub, f = 2 rsub | 8 (w & 1):
+    // the XOR spreads the pieces one transposed read touches (8 rows x 2 adjacent pieces per 32-lane half) over the 16 sixteen-byte
+    // bank slots.  So a lane moves pieces of TWO rows per step; their ids are requested one step ahead, BEFORE that step's DMA
+    // pieces, so the wait that covers them leaves the pieces in flight.
+    const int bk_rsub = (lane >> 4) & 3, bk_w = wid - 8;
+    const int bk_ipc = (lane & 15) ^ ((bk_rsub << 1) | ((bk_w & 1) << 3));
+    int64_t bk_id[2] = {0, 0};                             // raw ids (or positions) of the rows the NEXT fetch moves
+    bool bk_ok[2] = {false, false};
+    unsigned bk_zmask = 0;                                 // pieces whose column group is past the image row
+    auto bk_request = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int kl = 8 * bk_w + 4 * h + bk_rsub;
+        const int64_t pos = g.bk_interleave ? (int64_t)kl * g.bk_interleave + ks : (int64_t)ks * 32 + kl;
+        bk_ok[h] = pos < g.bk_red && (!g.bk_interleave || ks < g.bk_interleave);
+        bk_id[h] = g.b.rows ? g.b.rows[bk_ok[h] ? pos : 0] : pos;
+      }
+    };
     // second part of A: the rows of tile row `ti` in a2 (its own gather / zero row), from a2's first reduction step
     auto make_src_a2 = [&](int ti) __attribute__((always_inline)) {
 #pragma unroll
@@ -434,6 +464,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         rid[u] = gi;
         if (g.a.rows) rid[u] = g.a.rows[gi < g.M ? gi : g.M - 1];
       }
+      if (BK) bk_zmask = 0;
 #pragma unroll
       for (int u = 0; u < NLP; ++u) {
         const int i = u * 256 + ml;
@@ -444,6 +475,12 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
           const int64_t id = rid[u < NLP_A ? u : 0];
           const bool ok = (int64_t)t.ti * BM + r < g.M && id >= 0 && id < g.a.nrows;
           off = (ok ? id : g.a.zero_row) * g.a.row_bytes + (int64_t)t.ks_begin * g.a.step_bytes;
+        } else if (BK) {
+          const int pc = 16 * ((u - NLP_A) % 3) + bk_ipc;     // piece 0 .. 47 of the row's 768-byte run
+          const int grp = t.tj * (BN / 32) + pc / 12;
+          if (grp >= g.bk_groups) bk_zmask |= 1u << (u - NLP_A);
+          src[u] = (unsigned)((grp < g.bk_groups ? grp : 0) * X3_GROUP_BYTES + (pc % 12) * 16);
+          continue;
         } else {
           const int64_t gj = (int64_t)t.tj * BN + (r - BM);
           off = (gj < g.N ? gj : g.b.zero_row) * g.b.row_bytes + (int64_t)t.ks_begin * g.b.step_bytes;
@@ -454,7 +491,18 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
     };
     int f_logical = first, fks, fks_end;
     { const Tile t = decode(first); make_src(t); fks = t.ks_begin; fks_end = t.ks_end; }
+    if (BK) bk_request(fks);
     auto fetch = [&](int stage) __attribute__((always_inline)) {
+      unsigned bk_row[2] = {0, 0}, bk_zero = 0;
+      if (BK) {
+        // this step's rows (requested a step ago), then the request for the step after it — ahead of this step's pieces
+        bk_zero = (unsigned)(g.b.zero_row * g.b.row_bytes);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          bk_row[h] = (bk_ok[h] && bk_id[h] >= 0 && bk_id[h] < g.b.nrows) ? (unsigned)(bk_id[h] * g.b.row_bytes) : bk_zero;
+        if (fks + 1 < fks_end) bk_request(fks + 1);
+        else if (f_logical + nslots < last_logical) bk_request(decode(f_logical + nslots).ks_begin);
+      }
       if (EXT && two && !part2 && fks >= g.nsteps1) {      // entering the second A part of this tile
         make_src_a2(cur_ti);
         part2 = true; step_a = (unsigned)g.a2.step_bytes;
@@ -463,9 +511,11 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
       const __amdgpu_buffer_rsrc_t rs_a = (EXT && part2) ? r2 : r1;   // references indexes the closure dynamically and pins it in scratch
       static_for<0, NLP>([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value;
+        unsigned so = src[u];
+        if (BK && u >= NLP_A) so += ((bk_zmask >> (u - NLP_A)) & 1) ? bk_zero : bk_row[(u - NLP_A) / 3];
         __builtin_amdgcn_raw_ptr_buffer_load_lds(u < NLP_A ? rs_a : rsrc_b,
-                                                 (lptr_t)(smem + (stage % NSTAGE) * STAGE + (u * 256 + (wid - 8) * 64) * 16), 16, src[u], 0, 0, 0);
-        src[u] += u < NLP_A ? step_a : step_b;
+                                                 (lptr_t)(smem + (stage % NSTAGE) * STAGE + (u * 256 + (wid - 8) * 64) * 16), 16, so, 0, 0, 0);
+        if (!(BK && u >= NLP_A)) src[u] += u < NLP_A ? step_a : step_b;
       });
       if (++fks == fks_end && f_logical + nslots < last_logical) {     // on to the next tile
         f_logical += nslots;
@@ -502,6 +552,24 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
       }
     }
     const int rowa = (wm * TM * 32 + l15) * 192, rowb = (BM + wn * TN * 32 + l15) * 192;
+    // BK: the B stage holds 32 reduction rows x 48 pieces; piece pc of row k sits at piece index
+    // (3 ((k >> 2) & 1) + (pc >> 4)) * 256 + (k >> 3) * 64 + (k & 3) * 16 + ((pc & 15) ^ (2 (k & 3) | 8 ((k >> 3) & 1))) of the B part (what
+    // the movers' lane-linear instructions produce).  A fragment (16 columns, 8 k per lane) is two ds_read_b64_tr_b16: lane
+    // 4q + p of a 16-lane group supplies row 8 quad + 4 h + q, columns 4p .. 4p + 3 of the block = half of piece
+    // 12 group + 4 plane + chunk.
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4;
+    const int pq = l15 >> 2, pp = l15 & 3;
+    const int bk_mask = (pp >> 1) | (pq << 1) | ((quad & 1) << 3);
+    const int bk_lane = B_BASE + (quad * 64 + pq * 16) * 16 + 8 * (pp & 1);
+    auto bk_frag = [&](const unsigned char* st, int y, int sp) __attribute__((always_inline)) {
+      const int n0 = wn * TN * 32 + y * 16;                // first column of the block inside the tile
+      const int pce = (n0 >> 5) * 12 + sp * 4 + ((n0 >> 3) & 3);     // its first piece (even)
+      const int at = bk_lane + ((pce >> 4) * 256 + ((pce & 15) ^ bk_mask)) * 16;
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(st + at));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(st + at + 3 * 256 * 16));
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 acc[RB][CB];
     auto zero_acc = [&]() __attribute__((always_inline)) {
@@ -520,7 +588,10 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
       bf16x8 a[RB][3], b[2][3];
       if (rbv <= 0 || cbv <= 0) return;
 #pragma unroll
-      for (int sp = 0; sp < 3; ++sp) b[0][sp] = *(const bf16x8*)(st + rowb + offp[sp]);
+      for (int sp = 0; sp < 3; ++sp) {
+        if constexpr (BK) b[0][sp] = bk_frag(st, 0, sp);
+        else b[0][sp] = *(const bf16x8*)(st + rowb + offp[sp]);
+      }
 #pragma unroll
       for (int t = 0; t < RB; ++t)
         if (t < rbv) {
@@ -533,7 +604,10 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
           if constexpr (y + 1 < CB) {
             if (y + 1 < cbv) {
 #pragma unroll
-              for (int sp = 0; sp < 3; ++sp) b[(y + 1) & 1][sp] = *(const bf16x8*)(st + rowb + (y + 1) * 16 * 192 + offp[sp]);
+              for (int sp = 0; sp < 3; ++sp) {
+                if constexpr (BK) b[(y + 1) & 1][sp] = bk_frag(st, y + 1, sp);
+                else b[(y + 1) & 1][sp] = *(const bf16x8*)(st + rowb + (y + 1) * 16 * 192 + offp[sp]);
+              }
             }
           }
 #pragma unroll
@@ -606,7 +680,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               if (col + c >= g.N) continue;
-              if (fin && g.ones_col && col + c == g.N - 1) { if (g.db) g.db[row] = v[c]; }
+              if (fin && g.ones_col && col + c == g.N - 1) { if (g.db) g.db[row] = v[c]; if (g.db2) g.db2[row] = v[c]; }
               else dst[row * ldd + col + c] = v[c];
             }
           }
@@ -642,7 +716,7 @@ __global__ void __launch_bounds__(256) k_x3_splitk_reduce(X3Args g) {
     for (int s = 0; s < g.nsplit; ++s) v += g.ws[((int64_t)s * g.M + row) * g.ws_ld + col];  // fixed order
     const bool oc = g.ones_col && col == g.N - 1;
     if (g.relu) v = fmaxf(v, 0.f);
-    if (oc) { if (g.db) g.db[row] = v; }
+    if (oc) { if (g.db) g.db[row] = v; if (g.db2) g.db2[row] = v; }
     else g.C[row * g.ldc + col] = v;
   }
 }
@@ -1038,16 +1112,19 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
   const int64_t b_bytes = std::max((g.b.zero_row + 1) * g.b.row_bytes, (int64_t)g.nsteps * g.b.step_bytes);
   if (g.a2.img && (g.a2.zero_row + 1) * g.a2.row_bytes >= (1ll << 32)) return OGL_EINVAL;
   int cfg = x3_config(g.M, g.N);
+  const bool bk = g.bk_groups > 0;                        // row-major B over the reduction: the 128 x 128 producer / consumer tile only
+  if (bk) cfg = 1;
   // producer / consumer kernels (k_gemm_x3p) whenever both images fit 32-bit offsets; OGL_X3_PC=0 forces the
   // self-fetching kernels (experiments)
   static const char* pc_env = getenv("OGL_X3_PC");
-  const bool pc = !(pc_env && pc_env[0] == '0') && a_bytes < (1ll << 32) && b_bytes < (1ll << 32);
+  const bool pc = (bk || !(pc_env && pc_env[0] == '0')) && a_bytes < (1ll << 32) && b_bytes < (1ll << 32);
+  if (bk && (!pc || g.a2.img || g.add || g.out_img)) return OGL_EINVAL;
   if (pc) {
     // a product that is one round of tiles either way takes the smallest tile that still is one round (one block per
     // CU): its critical path is one tile.  [7 199, 602] -> 600: 145 tiles of 256 x 128, 285 of 128 x 128, 190 of 192 x 128
     // (measured 45 us on 256 x 128, 37 us on 192 x 128).
     static const char* c2_env = getenv("OGL_X3_CFG2");
-    if (g.nsplit == 1 && !(c2_env && c2_env[0] == '0') && ogl_cdiv(g.M, 256) * ogl_cdiv(g.N, 128) <= 256) {
+    if (!bk && g.nsplit == 1 && !(c2_env && c2_env[0] == '0') && ogl_cdiv(g.M, 256) * ogl_cdiv(g.N, 128) <= 256) {
       if (ogl_cdiv(g.M, 128) * ogl_cdiv(g.N, 128) <= 256) cfg = 1;
       else if (ogl_cdiv(g.M, 192) * ogl_cdiv(g.N, 128) <= 256) cfg = 2;
     }
@@ -1059,7 +1136,8 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     // ring depth: two stages of the 256 x 128 tile fill the LDS (144 KB); the 128 x 128 tile takes three (144 KB): its movers
     // run two stages ahead (+4 % on the layer-0 weight gradient, whose operands both stream from HBM)
     const bool ext = g.a2.img || g.add || g.out_img;
-    if (ext) {
+    if (bk) hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1, 3, false, true>), grid, block, 0, stream, g);
+    else if (ext) {
       if (g.nsplit != 1 || g.ones_col) return OGL_EINVAL;
       if (cfg == 0) hipLaunchKernelGGL((k_gemm_x3p<4, 2, 2, 2, 2, true>), grid, block, 0, stream, g);
       else if (cfg == 2) hipLaunchKernelGGL((k_gemm_x3p<2, 4, 3, 1, 2, true>), grid, block, 0, stream, g);
@@ -1152,6 +1230,51 @@ extern "C" int64_t ogl_linear_bwd_weight_x3_workspace_bytes(int64_t M, int N, in
   x3_bww_plan(M, N, K, &nsplit, &sps);
   if (nsplit <= 1) return 16;
   return (int64_t)nsplit * N * ogl_round_up(K + 1, 4) * 4;
+}
+
+// The weight gradient with the activations' ROW-MAJOR image as it is (k_gemm_x3p<..., BK>): dw = dy^T . x[rows] without a
+// transposed image of x.  The split-K plan is the one of the 128 x 128 tile.
+static void x3_bwwk_plan(int64_t steps, int N, int Kc, int* nsplit, int* sps) {
+  const int64_t tiles = ogl_cdiv(N, 128) * ogl_cdiv(Kc, 128);
+  int64_t s = 256 / (tiles > 0 ? tiles : 1);
+  if (s < 1) s = 1;
+  if (steps / s < 8) s = steps / 8 > 0 ? steps / 8 : 1;
+  *sps = (int)ogl_cdiv(steps > 0 ? steps : 1, s);
+  *nsplit = (int)ogl_cdiv(steps > 0 ? steps : 1, *sps);
+}
+
+extern "C" int64_t ogl_linear_bwd_weight_x3k_workspace_bytes(int64_t M, int64_t interleave, int N, int K, int has_ones) {
+  if (M < 0 || N < 0 || K < 0 || interleave < 0) return OGL_EINVAL;
+  int nsplit, sps;
+  x3_bwwk_plan(interleave ? interleave : ogl_cdiv(M, 32), N, K + (has_ones ? 1 : 0), &nsplit, &sps);
+  if (nsplit <= 1) return 16;
+  return (int64_t)nsplit * N * ogl_round_up(K + 1, 4) * 4;
+}
+
+extern "C" int ogl_linear_bwd_weight_x3k(const void* dyT_img, int64_t interleave, const void* x_img, int64_t x_img_rows,
+                                         const int64_t* x_rows, int64_t x_nrows, int64_t M, int N, int K, int has_ones, float* dw,
+                                         int64_t lddw, float* db, float* db2, void* workspace, int64_t workspace_bytes,
+                                         ogl_stream_t stream) {
+  if (M <= 0 || N < 0 || K <= 0 || lddw < K || interleave < 0 || (interleave > 0 && 32 * interleave < M)) return OGL_EINVAL;
+  if (x_img_rows < 0 || x_nrows < 0 || x_nrows > x_img_rows || (!x_rows && M > x_img_rows)) return OGL_EINVAL;
+  if (N == 0) return OGL_OK;
+  if (!dw || !dyT_img || !x_img || ((db || db2) && !has_ones)) return OGL_EINVAL;
+  X3Args g = X3Args();
+  const int Kc = K + (has_ones ? 1 : 0);                   // columns of the product: dw and, from the ones slot, db
+  const int64_t xrb = ogl_cdiv(Kc, 32) * X3_GROUP_BYTES;
+  g.a = X3Operand{(const unsigned char*)dyT_img, X3_GROUP_BYTES, ((int64_t)N + 1) * X3_GROUP_BYTES, nullptr, N, N};
+  g.b = X3Operand{(const unsigned char*)x_img, xrb, 0, x_rows, x_rows ? x_nrows : x_img_rows, x_img_rows};
+  g.bk_red = M; g.bk_interleave = interleave; g.bk_groups = (int)ogl_cdiv(Kc, 32);
+  g.M = N; g.N = Kc; g.ones_col = has_ones ? 1 : 0;
+  g.nsteps = (int)(interleave ? interleave : ogl_cdiv(M, 32));
+  g.C = dw; g.ldc = lddw; g.db = db; g.db2 = db2;
+  x3_bwwk_plan(g.nsteps, N, Kc, &g.nsplit, &g.steps_per_split);
+  if (g.nsplit > 1) {
+    g.ws_ld = ogl_round_up(K + 1, 4);
+    if (!workspace || workspace_bytes < (int64_t)g.nsplit * N * g.ws_ld * 4) return OGL_EWORKSPACE;
+    g.ws = (float*)workspace;
+  }
+  return launch_x3(g, (hipStream_t)stream);
 }
 
 extern "C" int ogl_linear_bwd_weight_x3(const void* dyT_img, const void* xT_img, int64_t M, int N, int K, float* dw,

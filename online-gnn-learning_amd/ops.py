@@ -796,6 +796,25 @@ def linear_bwd_weight_x3(dyT_img, xT_img, want_bias=True):
     return dw, db
 
 
+def linear_bwd_weight_x3k(dyT_img, x_img, M, K, x_rows=None, x_nrows=None, interleave=0, want_bias=True, want_bias2=False):
+    """dw [N, K] (and db, db2: two copies of the bias gradient) from the image of dy.T and the ROW-MAJOR image of x (M reduction
+    rows, gathered by ``x_rows``): no transposed image of x.  The bias gradient needs the ones slot in ``x_img`` (K + 1)."""
+    N = dyT_img.rows
+    has_ones = x_img.K == K + 1
+    assert x_img.K in (K, K + 1) and (has_ones or not (want_bias or want_bias2))
+    assert dyT_img.K == (32 * interleave if interleave else M), (dyT_img.K, M, interleave)
+    dev = dyT_img.buf.device
+    dw = torch.empty((N, K), dtype=torch.float32, device=dev)
+    db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
+    db2 = torch.empty(N, dtype=torch.float32, device=dev) if want_bias2 else None
+    nbytes = int(_lib.lib().ogl_linear_bwd_weight_x3k_workspace_bytes(M, interleave, N, K, 1 if has_ones else 0))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    _launch("ogl_linear_bwd_weight_x3k", _lib.lib().ogl_linear_bwd_weight_x3k, _ptr(dyT_img.buf), interleave, _ptr(x_img.buf),
+            x_img.rows, _ptr(_ids(x_rows) if x_rows is not None else None), x_img.rows if x_nrows is None else x_nrows, M, N, K,
+            1 if has_ones else 0, _ptr(dw), _ld(dw), _ptr(db), _ptr(db2), _ptr(ws), nbytes, _stream(), meta=dict(M=M, K=K, N=N))
+    return dw, db, db2
+
+
 # Static tables (the resident feature table) are split ONCE; projections that gather their rows from such a table and
 # are large enough run on the pre-split kernels.  Keyed by the allocation, so row-prefix views (ndata['feat'] of a
 # snapshot) resolve to the same image.
@@ -830,14 +849,36 @@ def _x3_forward_ok(x, M, x2):
             and (x.data_ptr(), _ld(x), x.shape[1]) in _X3_TABLES)
 
 
-def weight_grad(dy, x, x_rows=None, want_bias=True, dyT=None):
-    """dW, db of a projection.  In the bf16x6 / auto arithmetic both operands are transposed first (two LDS-tiled
-    copies) so the product runs on the reduction-contiguous split-bf16 path; the exact-fp32 mode keeps the direct
-    k-major kernel.  ``dyT`` lets the two weight gradients of a dual-input Linear share one transpose."""
+K_MAJOR_WEIGHT_GRADS = os.environ.get("OGL_BWW_KMAJOR") != "0"    # weight gradients read the activations' row-major images as they are
+
+
+def _row_image_for(x, x_rows, x_img):
+    """The row-major bf16x3 image the weight gradient of a projection of ``x[x_rows]`` can read: the one its forward consumed
+    (``x_img``), or the resident table's."""
+    if not K_MAJOR_WEIGHT_GRADS:
+        return None
+    if x_img is not None:
+        return x_img
+    if x_rows is not None and _static_key(x) in _X3_TABLES:
+        return _static_image(x)
+    return None
+
+
+def weight_grad(dy, x, x_rows=None, want_bias=True, dyT=None, x_img=None):
+    """dW, db of a projection.  In the bf16x6 / auto arithmetic the product runs on the split-bf16 image kernel: dy^T as a
+    transposed image, x as the row-major image its forward already had (``x_img``, or the resident table's: read k-major, no
+    transposed copy) or else as a transposed image too; the exact-fp32 mode keeps the direct k-major kernel.  ``dyT`` lets the two
+    weight gradients of a dual-input Linear share one transpose."""
     if _MODE["name"] == "f32" or dy.shape[0] < 1024:
         return linear_bwd_weight(dy, x, None, x_rows, want_bias=want_bias)
     if dyT is None:
         dyT = transposed_operand(dy)
+    if isinstance(dyT, X3Image):
+        rimg = _row_image_for(x, x_rows, x_img)
+        K = x.shape[1]
+        if rimg is not None and (rimg.K == K + 1 or (rimg.K == K and not want_bias)):
+            return linear_bwd_weight_x3k(dyT, rimg, dy.shape[0], K, x_rows=x_rows, x_nrows=x.shape[0] if x_rows is not None else None,
+                                         want_bias=want_bias)[:2]
     if isinstance(dyT, X3Image):
         # both operands as bf16x3 images of their transposes (one fused gather + transpose + split pass each)
         return linear_bwd_weight_x3(dyT, x3_split_t(x, x_rows, ones_row=True), want_bias=want_bias)
@@ -927,6 +968,7 @@ class _LinearFn(torch.autograd.Function):
         # gets its gradient from its own weight-gradient product in backward (their ones columns are free) — a tracked
         # `bias + bias2` outside would hand ONE gradient tensor to two parameters, which autograd clones (a launch)
         ctx.has_bias2 = bias2 is not None
+        ctx.x2_img = take_image(x2, pop=False) if x2 is not None else None     # read again by the weight gradient (k-major)
         y = _dual_fwd_images(x, w, bias, bias2, x2, w2, relu, x_rows, x2_rows)
         if y is None:
             if bias2 is not None:
@@ -959,14 +1001,27 @@ class _LinearFn(torch.autograd.Function):
         dyT = None
         if _MODE["name"] != "f32" and dy.shape[0] >= 1024 and x2 is not None and need[1] and need[4]:
             dyT = transposed_operand(dy)   # shared by the two weight gradients of a dual-input projection
-        if need[1] or (need[2] and ctx.has_bias):
+        x2_img = ctx.x2_img if (x2 is not None and x2_rows is None) else None
+        both = None
+        if (isinstance(dyT, X3Image) and ctx.has_bias and ctx.has_bias2 and x2_img is not None and x2_img.K == x2.shape[1]
+                and need[1] and need[4]):
+            # the neighbour part's image has no ones slot: both copies of the bias gradient come from the first product
+            rimg = _row_image_for(x, x_rows, None)
+            if rimg is not None and rimg.K == x.shape[1] + 1:
+                both = linear_bwd_weight_x3k(dyT, rimg, dy.shape[0], x.shape[1], x_rows=x_rows,
+                                             x_nrows=x.shape[0] if x_rows is not None else None, want_bias=True, want_bias2=True)
+        if both is not None:
+            dw, db, db2 = both
+        elif need[1] or (need[2] and ctx.has_bias):
             dw, db = weight_grad(dy, x, x_rows, want_bias=ctx.has_bias, dyT=dyT)
         if x2 is not None:
             if need[3]:
                 if x2_rows is not None:
                     raise RuntimeError("gradient w.r.t. a row-gathered table is not supported")
                 dx2 = linear_bwd_input(dy, w2, y, dy_img=dy_img)
-            if need[4] or ctx.has_bias2:
+            if both is not None:
+                dw2 = weight_grad(dy, x2, None, want_bias=False, dyT=dyT, x_img=x2_img)[0]
+            elif need[4] or ctx.has_bias2:
                 dw2, db2 = weight_grad(dy, x2, x2_rows, want_bias=ctx.has_bias2, dyT=dyT)
         return dx, dw, (db if ctx.has_bias else None), dx2, dw2, None, None, None, (db2 if ctx.has_bias2 else None)
 
@@ -1040,8 +1095,14 @@ class _PoolMaxFn(torch.autograd.Function):
             # layer 0: the projection input carries no gradient, so dP has one consumer — the weight gradient — and goes
             # straight from (dout, argmax) to the image of its transpose
             dyT = pool_bwd_x3(dout, argmax, out, idx32, ctx.n_src)
-            dw, db = linear_bwd_weight_x3(dyT, x3_split_t(x, x_rows, ones_row=True, interleave=(ctx.n_src + 31) // 32),
-                                          want_bias=ctx.has_bias)
+            G = (ctx.n_src + 31) // 32
+            rimg = _row_image_for(x, x_rows, None)
+            if rimg is not None and rimg.K == x.shape[1] + 1:
+                # the resident table's own image, its rows gathered in the dealt order of dP^T: no X^T image
+                dw, db, _ = linear_bwd_weight_x3k(dyT, rimg, ctx.n_src, x.shape[1], x_rows=x_rows, x_nrows=x.shape[0], interleave=G,
+                                                  want_bias=ctx.has_bias)
+            else:
+                dw, db = linear_bwd_weight_x3(dyT, x3_split_t(x, x_rows, ones_row=True, interleave=G), want_bias=ctx.has_bias)
             return None, dw, (db if ctx.has_bias else None), None, None
         dp = reduce_bwd(dout, None, argmax, "max", ctx.n_src, fanout=ctx.fanout, relu_out=out)
         dx = dw = db = None
@@ -1065,6 +1126,7 @@ class _SagePoolLayerFn(torch.autograd.Function):
     def forward(ctx, h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu):
         h = as_mat(h)
         himg = take_image(h) if _n1_images_ok(h.shape[0], h.shape[1], w_pool.shape[0]) else None
+        ctx.h_img = himg if (himg is not None and himg.K == h.shape[1] + 1) else None   # read again by fc_pool's weight gradient
         if himg is not None and himg.K == h.shape[1] + 1:
             # the projection that produced h wrote its image (ones slot included): fc_pool runs on the image kernel
             wimg = weight_image("wb", w_pool, b_pool)
@@ -1103,7 +1165,7 @@ class _SagePoolLayerFn(torch.autograd.Function):
         dp = reduce_bwd(dneigh, None, argmax, "max", n_src, fanout=ctx.fanout, relu_out=neigh)
         dp_img = x3_split(dp) if (N1_BWD_SPLIT and _n1_images_ok(n_src, dp.shape[1], w_pool.shape[1])) else None
         dh = linear_bwd_input(dp, w_pool, None, dy_img=dp_img)
-        dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias)
+        dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias, x_img=ctx.h_img)
         dx_self = linear_bwd_input(dy, w_self, None)
         dh[:n_dst].add_(dx_self)                                  # the fc_self path, in place on the first n_dst rows
         return (dh, dw_pool, db_pool if ctx.has_pool_bias else None, dw_self, dw_neigh, db if ctx.has_bias else None,

@@ -189,7 +189,9 @@ def test_reddit_pbr_two_ranks_replicated_and_partitioned(tmp_path):
     assert a["ctr_a"] == b["ctr_a"] == c["ctr_a"] == 3 and a["ctr_b"] == b["ctr_b"] == c["ctr_b"] == 2
     for other in (b, c):
         for x, y in zip(a["weights"], other["weights"]):
-            torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-5)     # the sharded update: fp32 summation order only
+            # the sharded update: fp32 summation order only (a half batch may also take another kernel for the same product —
+            # image operands from 2 048 rows on — with its own, equally fp32-accurate, rounding; the step is deliberately large)
+            torch.testing.assert_close(x, y, rtol=1e-4, atol=5e-5)
         np.testing.assert_allclose(a["prio"], other["prio"], rtol=1e-4, atol=1e-6)
         # (the deliberately large SGD step leaves logits of a few hundred: a loss is a difference of numbers of that size,
         # known to ~1e-4 absolute whatever its own magnitude)

@@ -616,3 +616,87 @@ def test_weight_images_in_one_launch_equal_the_single_splits():
     m, v = torch.zeros_like(w2), torch.zeros_like(w2)
     ops.adam_step(w2, torch.ones_like(w2), m, v, 1)
     assert ops.weight_image("T", w2) is None
+
+
+@pytest.mark.parametrize("M,N,K,gather,interleave,ones", [(7060, 600, 602, True, False, True), (7060, 600, 600, False, False, False),
+                                                          (20000, 600, 602, True, True, True), (2500, 41, 130, True, True, True),
+                                                          (2049, 33, 70, False, False, True), (5000, 200, 31, True, False, True)])
+def test_weight_gradient_reads_the_row_major_image(M, N, K, gather, interleave, ones):
+    """dw = dy^T . x[rows] with x as its ROW-MAJOR image (k_gemm_x3p<BK>: k-major B operand through ds_read_b64_tr_b16) against
+    the transposed-image product: the same MFMAs on the same operands in the same order -> equal to the last bit wherever the
+    split-K plans agree, and always to fp32-GEMM accuracy against fp64."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    torch.manual_seed(M + K)
+    dev = "cuda"
+    T = M + 700
+    table = ops.empty_mat(T, K, dev).copy_(torch.randn(T, K, device=dev))
+    rows = None
+    if gather:
+        rows = torch.randint(0, T, (M,), device=dev)
+        rows[::53] = -1
+    dy = ops.empty_mat(M, N, dev).copy_(torch.randn(M, N, device=dev))
+    G = (M + 31) // 32 if interleave else 0
+    dyT = ops.x3_split_t(dy, interleave=G)
+    x_img = ops.x3_split(table if gather else table[:M], append_ones=ones)
+    dw, db, db2 = ops.linear_bwd_weight_x3k(dyT, x_img, M, K, x_rows=rows, x_nrows=T if gather else None, interleave=G,
+                                            want_bias=ones, want_bias2=ones)
+    xg = table[:M] if rows is None else torch.where((rows >= 0).unsqueeze(1), table[rows.clamp(min=0)], torch.zeros((), device=dev))
+    want = dy.double().T @ xg.double()
+    scale = float(want.abs().max())
+    assert float((dw.double() - want).abs().max()) <= 2e-5 * scale
+    if ones:
+        wantb = dy.double().sum(0)
+        assert float((db.double() - wantb).abs().max()) <= 2e-5 * float(wantb.abs().max())
+        assert torch.equal(db, db2)
+    ref_dw, ref_db = ops.linear_bwd_weight_x3(dyT, ops.x3_split_t(table, rows, ones_row=True, interleave=G) if gather
+                                              else ops.x3_split_t(table[:M], None, ones_row=True, interleave=G), want_bias=True)
+    assert float((dw - ref_dw).abs().max()) <= 1e-5 * scale
+
+
+def test_train_step_needs_no_transposed_activation_images():
+    """With the k-major weight-gradient product the Reddit-shaped step builds transposed images only of the two gradients
+    (dy^T of the layer-0 combine, dP^T of layer 1): x^T of the table rows, neigh^T and h1^T are gone."""
+    import torch.nn.functional as F
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    from ogl_amd.graphsage import GatheredRows, GraphSAGE
+    torch.manual_seed(6)
+    dev = "cuda"
+    n_tab, Fi, H, C, n0, n1, B, S = 30000, 602, 600, 41, 20000, 3000, 512, 25
+    table = ops.empty_mat(n_tab, Fi, dev).copy_(torch.randn(n_tab, Fi, device=dev))
+    ops.register_static_table(table)
+    model = GraphSAGE(Fi, H, C, 1, F.relu, 0, "pool").to(dev)
+
+    class Blk:
+        def __init__(self, n_src, n_dst):
+            self.local_idx = torch.randint(0, n_src, (n_dst, S), device=dev, dtype=torch.int32)
+            self._n = n_dst
+        def number_of_dst_nodes(self):
+            return self._n
+    blocks = [Blk(n0, n1), Blk(n1, B)]
+    ids = torch.randperm(n_tab, device=dev)[:n0]
+    labels = torch.randint(0, C, (B,), device=dev)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        ops.profile_start()
+        loss = ops.cross_entropy(model(blocks, GatheredRows(table, ids)), labels, "mean")
+        loss.backward()
+        names = [n for n, _, _ in ops.profile_stop()]
+        return float(loss.detach()), [p.grad.clone() for p in model.parameters()], names
+    ops.set_gemm_mode("auto")
+    flag = ops.K_MAJOR_WEIGHT_GRADS
+    try:
+        l1, g1, names = step()
+        ops.K_MAJOR_WEIGHT_GRADS = False
+        l0, g0, names0 = step()
+    finally:
+        ops.K_MAJOR_WEIGHT_GRADS = flag
+        ops.set_gemm_mode("f32")
+    assert names.count("ogl_x3_split_t") == 2 and names.count("ogl_linear_bwd_weight_x3k") == 4 and "ogl_linear_bwd_weight_x3" not in names
+    assert names0.count("ogl_x3_split_t") == 6 and "ogl_linear_bwd_weight_x3k" not in names0
+    assert l1 == l0
+    errs = [float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12) for a, b in zip(g1, g0)]
+    assert max(errs) <= 1e-5, errs
