@@ -251,11 +251,13 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
   // to store (rows >= M, columns >= N, unaligned destinations) aim theirs at a scratch line.  The static count is what
   // lets the next tile's first barrier wait for its DMA only (s_waitcnt vmcnt(NSTORE)) while these stores drain.
   auto epilogue = [&](const Tile& t) {
+    int l15 = lane & 15, quad = lane >> 4, lane_e = lane;     // opaque copies: see k_gemm_x3p's epilogue
+    asm volatile("" : "+v"(l15), "+v"(quad), "+v"(lane_e));
     float* const dst = g.nsplit > 1 ? g.ws + (int64_t)t.split * g.M * g.ws_ld : g.C;
     const int64_t ldd = g.nsplit > 1 ? g.ws_ld : g.ldc;
     const bool vec_ok = (ldd & 3) == 0 && ((uintptr_t)dst & 15) == 0;
     const bool fin = g.nsplit == 1;
-    float* const trash = (float*)&g_x3_trash[lane];
+    float* const trash = (float*)&g_x3_trash[lane_e];
     auto store_group = [&](int64_t row, int64_t col, float v0, float v1, float v2, float v3) {
       float v[4] = {v0, v1, v2, v3};
       const bool rok = row < g.M;
@@ -322,7 +324,7 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
       }
       // row ids of the NEXT tile: fetched after this tile's first barrier (behind the previous epilogue's stores, which
       // nothing waits for any more), consumed at the last step
-      if (ks == tc.ks_begin && has_next) load_rids(tn, rid_next);
+      if (has_next && ks == max(tc.ks_begin, tc.ks_end - 2)) load_rids(tn, rid_next);
       const bool more = ks + 1 < tc.ks_end;
       if (!more && has_next) make_src(tn, rid_next);
       if constexpr (!SPREAD) {
@@ -624,6 +626,10 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
       });
     };
     auto epilogue = [&](const Tile& t) __attribute__((always_inline)) {
+      // lane coordinates re-read here through an opaque copy: address arithmetic hoisted out of the tile loop would live in
+      // (and spill from) registers the main loop needs
+      int l15 = lane & 15, quad = lane >> 4;
+      asm volatile("" : "+v"(l15), "+v"(quad));
       float* const dst = g.nsplit > 1 ? g.ws + (int64_t)t.split * g.M * g.ws_ld : g.C;
       const int64_t ldd = g.nsplit > 1 ? g.ws_ld : g.ldc;
       const bool vec_ok = (ldd & 3) == 0 && ((uintptr_t)dst & 15) == 0;
@@ -1148,16 +1154,17 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     OGL_CHECK_LAUNCH();
   } else {
   if (g.a2.img || g.add || g.out_img) return OGL_EINVAL;   // the extensions live in the producer / consumer kernel (images < 4 GB)
-  if (cfg == 2) cfg = 1;
-  const int BM = cfg == 0 ? 256 : 128, BN = 128;
+  // (the 256 x 128 form of this kernel needs 64-bit piece addresses on top of 128 accumulators: it does not fit 256 registers
+  // without spilling, so images of 4 GB and more take the 128 x 128 tile)
+  cfg = 1;
+  const int BM = 128, BN = 128;
   g.NI = (int)ogl_cdiv(g.M, BM);
   g.NJ = (int)ogl_cdiv(g.N, BN);
   const int64_t T = (int64_t)g.NI * g.NJ * g.nsplit;
   dim3 grid((unsigned)(8 * std::min<int64_t>(32, ogl_cdiv(T, 8)))), block(512);   // persistent: at most one block per CU
   // DMA issue: spread between the MFMA groups for the 256 x 128 tile (2-3 % faster, A/B on one device), in one burst at
   // the top of the step for the 128 x 128 tile (its steps are too short to hide a late piece: spread measured 9 % slower)
-  if (cfg == 0) hipLaunchKernelGGL((k_gemm_x3<4, 2, 2, 2, true>), grid, block, 0, stream, g);
-  else hipLaunchKernelGGL((k_gemm_x3<2, 4, 2, 1, false>), grid, block, 0, stream, g);
+  hipLaunchKernelGGL((k_gemm_x3<2, 4, 2, 1, false>), grid, block, 0, stream, g);
   OGL_CHECK_LAUNCH();
   }
   if (g.nsplit > 1) {

@@ -174,7 +174,8 @@ def test_registered_table_dispatch(ops):
     finally:
         ops.set_gemm_mode(old)
         ops._X3_TABLES.clear()
-    assert names.count("ogl_linear_fwd_x3") == 2 and "ogl_linear_bwd_weight_x3" in names and "ogl_linear_fwd" not in names
+    # (the weight gradient reads the table's own row-major image: the k-major product, no transposed image of the rows)
+    assert names.count("ogl_linear_fwd_x3") == 2 and "ogl_linear_bwd_weight_x3k" in names and "ogl_linear_fwd" not in names
     np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
     want_full = (tab[:T - 100].double() @ w.double().T + b.double()).clamp_min(0).float()
     np.testing.assert_allclose(full.cpu().numpy(), want_full.cpu().numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL)
