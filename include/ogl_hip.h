@@ -368,6 +368,20 @@ int ogl_stage_segments(int nseg, const void* const* src, void* const* dst, const
  * dst_host_mapped[n], which the host polls for. */
 int ogl_publish_i64(const int64_t* src, int n, int64_t* seq_dev, int64_t* dst_host_mapped, ogl_stream_t stream);
 
+/* Backward of the combine of a 'pool' layer with few output columns (the output layer: N <= 64 classes), two launches (csrc/out_layer.hip;
+ * autograd of fc_self(h[:n_dst]) + fc_neigh(max-pooled rows), R/train/graphsage/pytorch/aggregator_dgl.py:171,199-206):
+ *   ogl_out_layer_bwd_inputs   dx_self[n_dst, K] = dy . w_self, and dy . w_neigh scattered to the max winners without being stored:
+ *                              dP[argmax[d, c], c] += (dy . w_neigh)[d, c] where neigh[d, c] > 0 (dP zero-initialised by the caller:
+ *                              what ogl_linear_bwd_input x 2 + ogl_reduce_bwd(max, relu_out = neigh) compute in three launches).
+ *   ogl_out_layer_bwd_weights  dw_self = dy^T . x_self, dw_neigh = dy^T . x_neigh (both [N, K]), db = db2 = column sums of dy (nullable),
+ *                              M <= 4096 rows; dy rows 16-byte aligned with lddy a multiple of 4 (as ogl_linear_bwd_weight's skinny path). */
+int ogl_out_layer_bwd_inputs(const float* dy, int64_t lddy, int64_t n_dst, int N, int K, const float* w_self, int64_t ldws,
+                             const float* w_neigh, int64_t ldwn, const int32_t* argmax, const float* neigh, int64_t ldn, int64_t n_src,
+                             float* dx_self, int64_t ldx, float* dP, int64_t ldp, ogl_stream_t stream);
+int ogl_out_layer_bwd_weights(const float* dy, int64_t lddy, int64_t M, int N, int K, const float* x_self, int64_t ldxs,
+                              const float* x_neigh, int64_t ldxn, float* dw_self, int64_t lddws, float* dw_neigh, int64_t lddwn,
+                              float* db, float* db2, ogl_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * A whole SMALL 'pool' SAGEConv layer in two launches forward, two launches backward (small_layer.hip):
  *     neigh = max_j relu(h . Wp^T + bp)[idx[:, j]],   y = act(h[:n_dst] . Ws^T + neigh . Wn^T + bs + bn)

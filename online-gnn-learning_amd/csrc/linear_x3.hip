@@ -634,6 +634,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
       const int64_t ldd = g.nsplit > 1 ? g.ws_ld : g.ldc;
       const bool vec_ok = (ldd & 3) == 0 && ((uintptr_t)dst & 15) == 0;
       const bool fin = g.nsplit == 1;
+      const bool add_vec = EXT && g.add && (g.ld_add & 3) == 0 && ((uintptr_t)g.add & 15) == 0;
 #pragma unroll
       for (int x = 0; x < RB; ++x)
 #pragma unroll
@@ -646,8 +647,13 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
             const int64_t ar = g.add_rows ? g.add_rows[row] : row;
             if (ar >= 0 && ar < g.add_nrows) {
               const float* ap = g.add + ar * g.ld_add + col;
+              if (add_vec && col + 4 <= g.N) {                   // one 16-byte load per group of four columns
+                const float4 a4 = *(const float4*)ap;
+                v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
+              } else {
 #pragma unroll
-              for (int c = 0; c < 4; ++c) if (col + c < g.N) v[c] += ap[c];
+                for (int c = 0; c < 4; ++c) if (col + c < g.N) v[c] += ap[c];
+              }
             }
           }
           if (fin && g.relu) {

@@ -449,6 +449,42 @@ def relu_bwd(dy, y):
     return out
 
 
+def out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src):
+    """(dx_self [n_dst, K], dP [n_src, K]): dy . w_self, and dy . w_neigh scattered to the max winners (csrc/out_layer.hip)."""
+    dy = as_mat(dy); w_self = as_mat(w_self); w_neigh = as_mat(w_neigh); neigh = as_mat(neigh)
+    n_dst, N = dy.shape
+    K = w_self.shape[1]
+    dx = empty_mat(n_dst, K, dy.device)
+    dp = empty_mat(n_src, K, dy.device, zero=True)
+    _launch("ogl_out_layer_bwd_inputs", _lib.lib().ogl_out_layer_bwd_inputs, _ptr(dy), _ld(dy), n_dst, N, K, _ptr(w_self), _ld(w_self),
+            _ptr(w_neigh), _ld(w_neigh), _ptr(argmax), _ptr(neigh), _ld(neigh), n_src, _ptr(dx), _ld(dx), _ptr(dp), _ld(dp), _stream(),
+            meta=dict(M=n_dst, N=N, K=K))
+    return dx, dp
+
+
+def out_layer_bwd_weights(dy, x_self, x_neigh, want_bias=True):
+    """(dw_self, dw_neigh [N, K], db, db2) of a few-column combine in one launch."""
+    dy = as_mat(dy); x_self = as_mat(x_self); x_neigh = as_mat(x_neigh)
+    M, N = dy.shape
+    K = x_self.shape[1]
+    dev = dy.device
+    dws = torch.empty((N, K), dtype=torch.float32, device=dev)
+    dwn = torch.empty((N, K), dtype=torch.float32, device=dev)
+    db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
+    db2 = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
+    _launch("ogl_out_layer_bwd_weights", _lib.lib().ogl_out_layer_bwd_weights, _ptr(dy), _ld(dy), M, N, K, _ptr(x_self), _ld(x_self),
+            _ptr(x_neigh), _ld(x_neigh), _ptr(dws), _ld(dws), _ptr(dwn), _ld(dwn), _ptr(db), _ptr(db2), _stream(), meta=dict(M=M, N=N, K=K))
+    return dws, dwn, db, db2
+
+
+OUT_LAYER_FUSED = os.environ.get("OGL_OUT_LAYER_FUSED") != "0"
+
+
+def _out_layer_fits(dy, h, w_self, w_neigh):
+    return (OUT_LAYER_FUSED and dy.shape[1] <= 64 and 0 < dy.shape[0] <= 4096 and h.shape[1] >= 64 and _ld(dy) % 4 == 0
+            and dy.data_ptr() % 16 == 0 and as_mat(w_self).data_ptr() % 16 == 0 and as_mat(w_neigh).data_ptr() % 16 == 0)
+
+
 def relu_bwd_img(dy, y):
     """relu_bwd that also returns the bf16x3 image of the masked gradient: (out, X3Image)."""
     dy = as_mat(dy); y = as_mat(y)
@@ -460,9 +496,11 @@ def relu_bwd_img(dy, y):
     return out, img
 
 
-def linear_bwd_input(dy, w, ymask=None, dy_img=None):
+def linear_bwd_input(dy, w, ymask=None, dy_img=None, add_head=None):
     """dX = dY . W.  ``dy_img``: the bf16x3 image of dY when its producer wrote one — the product then runs on the image kernel
-    against the image of W^T (a 600 x 600 transpose + split: two small launches)."""
+    against the image of W^T (a 600 x 600 transpose + split: two small launches, or one of the step's prepared weight images).
+    ``add_head`` [n, K]: added to the first n rows of dX (the fc_self path of a layer's input gradient) — in the epilogue of the
+    image kernel when that runs, in place otherwise."""
     dy = as_mat(dy); w = as_mat(w)
     if ymask is not None:
         dy = relu_bwd(dy, ymask)
@@ -471,7 +509,14 @@ def linear_bwd_input(dy, w, ymask=None, dy_img=None):
     K = w.shape[1]
     if dy_img is not None and dy_img.rows == M and dy_img.K == N:
         wt = weight_image("T", w)
-        return linear_fwd_x3(dy_img, None, wt if wt is not None else x3_split(transpose(w)))
+        wt = wt if wt is not None else x3_split(transpose(w))
+        if add_head is not None:
+            return linear_fwd_x3_ext(dy_img, None, wt, add=add_head)
+        return linear_fwd_x3(dy_img, None, wt)
+    if add_head is not None:
+        dx = linear_bwd_input(dy, w)
+        dx[:add_head.shape[0]].add_(add_head)
+        return dx
     if M >= BWD_INPUT_VIA_FWD_MIN_ROWS and get_gemm_mode() != "f32":
         # dX = dY . W as dY . (W^T)^T: with the (small) weight transposed first, both operands of the product are
         # reduction-contiguous and it runs on the forward kernel — 60 us against 75-84 us at the n1-row shapes (the
@@ -629,7 +674,7 @@ def linear_fwd_x3_ext(x_img, x_rows, w_img, x2_img=None, x2_rows=None, add=None,
     K1 = x_img.K
     K2 = x2_img.K if x2_img is not None else 0
     N = w_img.rows
-    assert w_img.K == 32 * (-(-K1 // 32) + -(-K2 // 32)), "the weight image must be K-concatenated over the A parts"
+    assert -(-w_img.K // 32) == -(-K1 // 32) + -(-K2 // 32), "the weight image must be K-concatenated over the A parts"
     dev = x_img.buf.device
     y = out if out is not None else empty_mat(M, N, dev)
     if add is not None:
@@ -1156,6 +1201,16 @@ class _SagePoolLayerFn(torch.autograd.Function):
             dy = relu_bwd(dy, out)
         n_dst, n_src = ctx.n_dst, h.shape[0]
         h_dst = h[:n_dst]
+        if _out_layer_fits(dy, h, w_self, w_neigh):
+            # few output columns (the output layer): the combine's backward in two launches, its input gradient for the pooled rows
+            # scattered to the winners as it is computed; the fc_self part joins dh in the epilogue of the fc_pool input gradient
+            dw_self, dw_neigh, db, db2 = out_layer_bwd_weights(dy, h_dst, neigh, want_bias=ctx.has_bias)
+            dx_self, dp = out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src)
+            dp_img = x3_split(dp) if (N1_BWD_SPLIT and _n1_images_ok(n_src, dp.shape[1], w_pool.shape[1])) else None
+            dh = linear_bwd_input(dp, w_pool, None, dy_img=dp_img, add_head=dx_self)
+            dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias, x_img=ctx.h_img)
+            return (dh, dw_pool, db_pool if ctx.has_pool_bias else None, dw_self, dw_neigh, db if ctx.has_bias else None,
+                    db2 if ctx.has_bias else None, None, None, None)
         dyT = transposed_operand(dy) if (_MODE["name"] != "f32" and dy.shape[0] >= 1024) else None
         dw_self, db = weight_grad(dy, h_dst, None, want_bias=ctx.has_bias, dyT=dyT)
         # the bias gradient once more from the second product (its ones column is free): two tensors for the two biases —

@@ -72,3 +72,35 @@ def test_small_layer_limits():
     assert ops.small_pool_layer_fits(20000, 32, 25, 32, 40) and not ops.small_pool_layer_fits(70000, 32, 25, 32, 40)
     assert not ops.small_pool_layer_fits(4000, 512, 25, 32, 40)           # too many destinations to call it small
     assert not ops.small_pool_layer_fits(100, 32, 25, 65, 8)
+
+
+@pytest.mark.parametrize("n_src,n_dst,S,K,N", [(7060, 512, 25, 600, 41), (300, 37, 5, 70, 3), (5000, 1000, 10, 128, 64), (900, 4, 25, 257, 40)])
+def test_output_layer_backward_in_two_launches(n_src, n_dst, S, K, N):
+    """csrc/out_layer.hip against the general launches it replaces (two input-gradient products + the max scatter; two skinny
+    weight gradients): same values up to fp32 summation order (the scatter adds in atomic order either way)."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    torch.manual_seed(n_src + N)
+    dev = "cuda"
+    P = ops.empty_mat(n_src, K, dev).copy_(torch.randn(n_src, K, device=dev).clamp(min=0))
+    idx = torch.randint(0, n_src, (n_dst, S), device=dev, dtype=torch.int32)
+    idx[::7] = -1
+    neigh, argmax = ops.reduce_fwd(P, idx, "max", want_argmax=True)
+    h_dst = ops.empty_mat(n_dst, K, dev).copy_(torch.randn(n_dst, K, device=dev))
+    dy = ops.empty_mat(n_dst, N, dev).copy_(torch.randn(n_dst, N, device=dev))
+    w_self = torch.randn(N, K, device=dev) / K ** 0.5
+    w_neigh = torch.randn(N, K, device=dev) / K ** 0.5
+    dx, dp = ops.out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src)
+    want_dx = dy.double() @ w_self.double()
+    np.testing.assert_allclose(dx.cpu().numpy(), want_dx.float().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    dneigh = (dy.double() @ w_neigh.double()).float()
+    want_dp = ops.reduce_bwd(ops.as_mat(dneigh), None, argmax, "max", n_src, fanout=S, relu_out=neigh)
+    np.testing.assert_allclose(dp.cpu().numpy(), want_dp.cpu().numpy(), rtol=1e-5, atol=2e-5)
+    dws, dwn, db, db2 = ops.out_layer_bwd_weights(dy, h_dst, neigh)
+    np.testing.assert_allclose(dws.cpu().numpy(), (dy.double().T @ h_dst.double()).float().cpu().numpy(), rtol=1e-5, atol=2e-5 * n_dst ** 0.5)
+    np.testing.assert_allclose(dwn.cpu().numpy(), (dy.double().T @ neigh.double()).float().cpu().numpy(), rtol=1e-5, atol=2e-5 * n_dst ** 0.5)
+    np.testing.assert_allclose(db.cpu().numpy(), dy.double().sum(0).float().cpu().numpy(), rtol=1e-5, atol=1e-4)
+    assert torch.equal(db, db2)
+    # same summation order as the one-product kernel it doubles
+    ref_dw, ref_db = ops.linear_bwd_weight(dy, h_dst, None, None, want_bias=True)
+    assert torch.equal(dws, ref_dw) and torch.equal(db, ref_db)
