@@ -7,8 +7,9 @@
 //     dWs = dy^T . h[:n_dst], dWn = dy^T . neigh, db = column sums of dy
 // As general launches that is two 41-deep GEMMs (10 us each: pure latency), a scatter kernel (14 us) over a [n_dst, K] matrix written
 // and read back in between, and two skinny weight-gradient launches (12 us each, 76 blocks).  Here:
-//   k_out_bwd_inputs   one wave per (4 destination rows, 256 columns): the four dy rows are wave-uniform (scalar loads), every lane
-//                      owns 4 columns of both products (2 x 4 x 4 accumulators, N x 2 float4 loads of W rows from L2), stores dx_self
+//   k_out_bwd_inputs   one wave per (2 destination rows, 256 columns): the dy rows sit in one register (lane n = dy[d, n]) and are
+//                      broadcast per term (v_readlane), every lane owns 4 columns of both products (2 x 2 x 4 accumulators, 16 float4
+//                      loads of W rows from L2 in flight per trip), stores dx_self
 //                      and adds the dneigh values straight into dP (float atomics, as the scatter kernel did) — dneigh never exists.
 //   k_out_bwd_weights  the skinny weight-gradient scheme (linear.hip: k_bwd_weight_skinny) for BOTH products in one grid.
 // fp32 FMA arithmetic on the vector ALU (50 MFLOP in all); HBM / L2-latency-bound integer + float work, no MFMA.
@@ -16,63 +17,83 @@
 
 #define OB_MAX_N 64
 
+#define OB_ROWS 2                   // destination rows per wave
+// VEC: K and the row strides of W are multiples of 4 (every lane owns 4 whole columns or none): 16-byte row loads.  Every load
+// is unconditional (clamped addresses, the value selected afterwards): a branch around a load makes the compiler drain the loads
+// in flight at its join.
+template <bool VEC>
 __global__ void __launch_bounds__(64) k_out_bwd_inputs(const float* __restrict__ dy, int64_t lddy, int64_t n_dst, int N, int K,
                                                        const float* __restrict__ Ws, int64_t ldws, const float* __restrict__ Wn,
                                                        int64_t ldwn, const int32_t* __restrict__ argmax,
                                                        const float* __restrict__ neigh, int64_t ldn, int64_t n_src,
                                                        float* __restrict__ dx_self, int64_t ldx, float* __restrict__ dP, int64_t ldp) {
   const int lane = threadIdx.x;
-  const int64_t d0 = (int64_t)blockIdx.x * 4;
+  const int64_t d0 = (int64_t)blockIdx.x * OB_ROWS;
   const int c = (blockIdx.y * 64 + lane) * 4;
   const bool cin = c < K;
-  const int cc = cin ? c : 0;
-  const bool vec = c + 4 <= K;
-  float as[4][4], an[4][4];
+  int ce[4];                                               // this lane's columns, clamped into the row
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int e = 0; e < 4; ++e) ce[e] = c + e < K ? c + e : K - 1;
+  // the wave's dy rows: lane n holds dy[d, n] (N <= 64), broadcast per term with v_readlane — no load inside the loop but W's
+  float dyv[OB_ROWS];
+  int am[OB_ROWS][4];
+  float nb[OB_ROWS][4];
+#pragma unroll
+  for (int r = 0; r < OB_ROWS; ++r) {
+    const int64_t dr = d0 + r < n_dst ? d0 + r : n_dst - 1;
+    const float v = dy[dr * lddy + (lane < N ? lane : 0)];
+    dyv[r] = (lane < N && d0 + r < n_dst) ? v : 0.f;
+    // what the epilogue needs, requested now: winners and ReLU masks of this lane's 4 columns
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      am[r][e] = argmax[dr * (int64_t)K + ce[e]];
+      nb[r][e] = neigh[dr * ldn + ce[e]];
+    }
+  }
+  float as[OB_ROWS][4], an[OB_ROWS][4];
+#pragma unroll
+  for (int r = 0; r < OB_ROWS; ++r)
 #pragma unroll
     for (int e = 0; e < 4; ++e) as[r][e] = an[r][e] = 0.f;
-  const float* dyr[4];
+  for (int n0 = 0; n0 < N; n0 += 8) {                      // 16 row loads of W in flight per trip
+    float ws[8][4], wn[8][4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) dyr[r] = dy + (d0 + r < n_dst ? d0 + r : d0) * lddy;     // wave-uniform rows (a row past the end re-reads d0)
-#pragma unroll 4
-  for (int n = 0; n < N; ++n) {
-    float ws[4], wn[4];
-    if (vec && (ldws & 3) == 0 && (ldwn & 3) == 0) {
-      const float4 a = *(const float4*)(Ws + (int64_t)n * ldws + cc), b = *(const float4*)(Wn + (int64_t)n * ldwn + cc);
-      ws[0] = a.x; ws[1] = a.y; ws[2] = a.z; ws[3] = a.w; wn[0] = b.x; wn[1] = b.y; wn[2] = b.z; wn[3] = b.w;
-    } else {
+    for (int u = 0; u < 8; ++u) {
+      const int n = n0 + u < N ? n0 + u : N - 1;           // a term past N re-reads the last row and is weighted by 0
+      if (VEC) {
+        const float4 a = *(const float4*)(Ws + (int64_t)n * ldws + ce[0]), b = *(const float4*)(Wn + (int64_t)n * ldwn + ce[0]);
+        ws[u][0] = a.x; ws[u][1] = a.y; ws[u][2] = a.z; ws[u][3] = a.w; wn[u][0] = b.x; wn[u][1] = b.y; wn[u][2] = b.z; wn[u][3] = b.w;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bool in = c + e < K;
-        ws[e] = in ? Ws[(int64_t)n * ldws + c + e] : 0.f;
-        wn[e] = in ? Wn[(int64_t)n * ldwn + c + e] : 0.f;
+        for (int e = 0; e < 4; ++e) { ws[u][e] = Ws[(int64_t)n * ldws + ce[e]]; wn[u][e] = Wn[(int64_t)n * ldwn + ce[e]]; }
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float g = dyr[r][n];
+    for (int u = 0; u < 8; ++u)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { as[r][e] += g * ws[e]; an[r][e] += g * wn[e]; }
-    }
+      for (int r = 0; r < OB_ROWS; ++r) {
+        // lanes >= N hold 0: a term past N contributes nothing (n0 + u <= 56 + 7)
+        const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dyv[r]), (n0 + u) & 63));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { as[r][e] += g * ws[u][e]; an[r][e] += g * wn[u][e]; }
+      }
   }
   if (!cin) return;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < OB_ROWS; ++r) {
     const int64_t d = d0 + r;
     if (d >= n_dst) break;
     float* xo = dx_self + d * ldx + c;
-    if (vec && (ldx & 3) == 0) *(float4*)xo = make_float4(as[r][0], as[r][1], as[r][2], as[r][3]);
+    if (VEC && (ldx & 3) == 0) *(float4*)xo = make_float4(as[r][0], as[r][1], as[r][2], as[r][3]);
     else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (c + e < K) xo[e] = as[r][e];
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if (c + e >= K) continue;
-      const int a = argmax[d * (int64_t)K + c + e];
-      if (a < 0 || a >= n_src) continue;
-      if (!(neigh[d * ldn + c + e] > 0.f)) continue;               // the winner's ReLU mask (see k_reduce_bwd_max)
+      const int a = am[r][e];
+      if (c + e >= K || a < 0 || a >= n_src) continue;
+      if (!(nb[r][e] > 0.f)) continue;                             // the winner's ReLU mask (see k_reduce_bwd_max)
       atomicAdd(&dP[(int64_t)a * ldp + c + e], an[r][e]);
     }
   }
@@ -86,9 +107,13 @@ extern "C" int ogl_out_layer_bwd_inputs(const float* dy, int64_t lddy, int64_t n
   if (n_dst == 0) return OGL_OK;
   if (!dy || !w_self || !w_neigh || !argmax || !neigh || !dx_self || !dP) return OGL_EINVAL;
   if (((uintptr_t)w_self & 15) || ((uintptr_t)w_neigh & 15) || ((uintptr_t)dx_self & 15)) return OGL_EINVAL;
-  dim3 grid((unsigned)ogl_cdiv(n_dst, 4), (unsigned)ogl_cdiv(K, 256));
-  hipLaunchKernelGGL(k_out_bwd_inputs, grid, dim3(64), 0, (hipStream_t)stream, dy, lddy, n_dst, N, K, w_self, ldws, w_neigh, ldwn, argmax,
-                     neigh, ldn, n_src, dx_self, ldx, dP, ldp);
+  dim3 grid((unsigned)ogl_cdiv(n_dst, OB_ROWS), (unsigned)ogl_cdiv(K, 256));
+  if ((K & 3) == 0 && (ldws & 3) == 0 && (ldwn & 3) == 0)
+    hipLaunchKernelGGL(k_out_bwd_inputs<true>, grid, dim3(64), 0, (hipStream_t)stream, dy, lddy, n_dst, N, K, w_self, ldws, w_neigh, ldwn,
+                       argmax, neigh, ldn, n_src, dx_self, ldx, dP, ldp);
+  else
+    hipLaunchKernelGGL(k_out_bwd_inputs<false>, grid, dim3(64), 0, (hipStream_t)stream, dy, lddy, n_dst, N, K, w_self, ldws, w_neigh, ldwn,
+                       argmax, neigh, ldn, n_src, dx_self, ldx, dP, ldp);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }
