@@ -100,6 +100,39 @@ struct AdamBatch {
   int64_t n[OGL_ADAM_MAX_TENSORS];
 };
 
+// one tensor, grid-strided over blockIdx.x: four elements per thread and trip (16-byte accesses) when the four arrays allow it
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float one_minus_b1, float b2, float one_minus_b2,
+                                         float inv_sqrt_bc2, float step_size, float eps) {
+  m = m + one_minus_b1 * (g - m);
+  v = v * b2 + one_minus_b2 * g * g;
+  p = p - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
+}
+
+__device__ __forceinline__ void adam_range(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                           float* __restrict__ v, int64_t n, float one_minus_b1, float b2, float one_minus_b2,
+                                           float inv_sqrt_bc2, float step_size, float eps) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+  int64_t done = 0;
+  if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      float4 p4 = ((float4*)p)[i], m4 = ((float4*)m)[i], v4 = ((float4*)v)[i];
+      const float4 g4 = ((const float4*)g)[i];
+      adam_one(p4.x, g4.x, m4.x, v4.x, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
+      adam_one(p4.y, g4.y, m4.y, v4.y, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
+      adam_one(p4.z, g4.z, m4.z, v4.z, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
+      adam_one(p4.w, g4.w, m4.w, v4.w, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
+      ((float4*)m)[i] = m4; ((float4*)v)[i] = v4; ((float4*)p)[i] = p4;
+    }
+    done = n4 << 2;
+  }
+  for (int64_t i = done + tid; i < n; i += nth) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_one(pi, g[i], mi, vi, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
+    m[i] = mi; v[i] = vi; p[i] = pi;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_adam_multi(AdamBatch b, float one_minus_b1, float b2, float one_minus_b2,
                                                     float inv_sqrt_bc2, float step_size, float eps) {
   const int t = blockIdx.y;
@@ -108,15 +141,7 @@ __global__ void __launch_bounds__(256) k_adam_multi(AdamBatch b, float one_minus
   float* __restrict__ m = b.m[t];
   float* __restrict__ v = b.v[t];
   const int64_t n = b.n[t];
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float gi = g[i];
-    float mi = m[i];
-    mi = mi + one_minus_b1 * (gi - mi);
-    const float vi = v[i] * b2 + one_minus_b2 * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    p[i] = p[i] - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
-  }
+  adam_range(p, g, m, v, n, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
 }
 
 extern "C" int ogl_adam_step_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
@@ -139,7 +164,7 @@ extern "C" int ogl_adam_step_multi(int count, float* const* p, const float* cons
       nmax = n[base + i] > nmax ? n[base + i] : nmax;
     }
     if (nmax == 0) continue;
-    dim3 grid((unsigned)min((int64_t)256, ogl_cdiv(nmax, 256)), (unsigned)c);
+    dim3 grid((unsigned)min((int64_t)512, ogl_cdiv(nmax, 1024)), (unsigned)c);
     hipLaunchKernelGGL(k_adam_multi, grid, dim3(256), 0, (hipStream_t)stream, b, (float)(1.0 - beta1), (float)beta2,
                        (float)(1.0 - beta2), inv_sqrt_bc2, step_size, (float)eps);
     OGL_CHECK_LAUNCH();
@@ -166,15 +191,7 @@ __global__ void __launch_bounds__(256) k_adam_multi_dev(AdamBatch b, float one_m
   float* __restrict__ m = b.m[t];
   float* __restrict__ v = b.v[t];
   const int64_t n = b.n[t];
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float gi = g[i];
-    float mi = m[i];
-    mi = mi + one_minus_b1 * (gi - mi);
-    const float vi = v[i] * b2 + one_minus_b2 * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    p[i] = p[i] - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
-  }
+  adam_range(p, g, m, v, n, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
 }
 
 extern "C" int ogl_adam_step_multi_dev(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
@@ -195,7 +212,7 @@ extern "C" int ogl_adam_step_multi_dev(int count, float* const* p, const float* 
       nmax = n[base + i] > nmax ? n[base + i] : nmax;
     }
     if (nmax == 0) continue;
-    dim3 grid((unsigned)min((int64_t)256, ogl_cdiv(nmax, 256)), (unsigned)c);
+    dim3 grid((unsigned)min((int64_t)512, ogl_cdiv(nmax, 1024)), (unsigned)c);
     hipLaunchKernelGGL(k_adam_multi_dev, grid, dim3(256), 0, (hipStream_t)stream, b, (float)(1.0 - beta1), (float)beta2,
                        (float)(1.0 - beta2), (const float*)scalars_dev, (float)eps);
     OGL_CHECK_LAUNCH();
