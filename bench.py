@@ -203,7 +203,7 @@ def main():
     graph_mode = None
     if world == 1 and timed_mode.startswith("eager") and strat.use_graphs == "auto" and getattr(strat.optimizer, "capturable", False):
         strat.use_graphs = True
-        run(2 * bt, plan(2 * bt))
+        run(max(3 * bt, 120), plan(max(3 * bt, 120)))        # untimed: the common size buckets are captured here
         gsteps = min(args.steps, 2 * bt)
         gplan = plan(gsteps)
         barrier(); tg = time.perf_counter()
@@ -248,18 +248,21 @@ def main():
     agg = {}
     for name, meta, ms in rec:
         key = name
-        if name == "ogl_reduce_fwd":
+        if name in ("ogl_reduce_fwd", "ogl_reduce_fwd_img"):       # (_img: the same pass + the bf16x3 image of its output)
             key = "reduce_fwd_L0" if meta["n_dst"] > B else "reduce_fwd_L1"
         elif name.startswith("ogl_linear"):
             key = name[4:] + ("_pool0" if meta["M"] > B * (1 + S) else "_other")
         a = agg.setdefault(key, dict(ms=0.0, calls=0, bytes=0.0, flops=0.0))
         a["ms"] += ms; a["calls"] += 1
-        if name == "ogl_reduce_fwd":
+        if name in ("ogl_reduce_fwd", "ogl_reduce_fwd_img"):
             E = meta["n_dst"] * meta["fanout"]
             a["bytes"] += E * (4 * meta["d"] + meta["idx_bytes"]) + meta["n_dst"] * 4 * meta["d"] * (2 if meta["argmax"] else 1)
-        if name in ("ogl_linear_fwd", "ogl_linear_fwd_x3"):
+            if name == "ogl_reduce_fwd_img":
+                a["bytes"] += meta["n_dst"] * 6 * meta["d"]          # + the image: three bf16 planes per element
+        if name in ("ogl_linear_fwd", "ogl_linear_fwd_x3", "ogl_linear_fwd_x3_ext"):
             a["flops"] += 2.0 * meta["M"] * meta["N"] * (meta["K"] + meta["K2"])
-        if name in ("ogl_linear_bwd_input", "ogl_linear_bwd_weight", "ogl_linear_bwd_weight_t", "ogl_linear_bwd_weight_x3"):
+        if name in ("ogl_linear_bwd_input", "ogl_linear_bwd_weight", "ogl_linear_bwd_weight_t", "ogl_linear_bwd_weight_x3",
+                    "ogl_linear_bwd_weight_x3k"):
             a["flops"] += 2.0 * meta["M"] * meta["N"] * meta["K"]
     kernels = {k: dict(avg_ms=v["ms"] / v["calls"], ms_per_step=v["ms"] / prof_steps, calls_per_step=v["calls"] / prof_steps,
                        gbs=(v["bytes"] / v["ms"] / 1e6) if v["bytes"] else None,
@@ -268,7 +271,7 @@ def main():
     roof_aggr = None
     if ragg:
         ach = ragg["bytes"] / ragg["ms"] / 1e6
-        roof_aggr = dict(kernel="k_reduce_fwd_v4 (layer-0 gather+max, argmax kept)", bound="hbm", achieved=round(ach, 1),
+        roof_aggr = dict(kernel="k_reduce_fwd_v4 (layer-0 gather+max, argmax kept, bf16x3 image of the output written beside it)", bound="hbm", achieved=round(ach, 1),
                          peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
                          avg_launch_ms=round(ragg["ms"] / ragg["calls"], 4),
                          algorithmic_bytes_per_launch=round(ragg["bytes"] / ragg["calls"]),
@@ -345,7 +348,8 @@ def main():
             roof_aggr["traffic"] = pmc["k_reduce_fwd_v4_L0"]["traffic_bytes"]
             roof_aggr["traffic_source"] = stamp + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
         if roof_gemm and args.workload == "reddit_rbr" and args.gemm == "auto":
-            key = {"linear_fwd_x3_pool0": "k_gemm_x3_fwd_pool0", "linear_bwd_weight_x3_pool0": "k_gemm_x3_bww_pool0"}.get(dom)
+            key = {"linear_fwd_x3_pool0": "k_gemm_x3_fwd_pool0", "linear_bwd_weight_x3_pool0": "k_gemm_x3_bww_pool0",
+                   "linear_bwd_weight_x3k_pool0": "k_gemm_x3_bwwk_pool0"}.get(dom)
             if key and key in pmc:
                 roof_gemm["traffic"] = pmc[key]["traffic_bytes"]
                 roof_gemm["traffic_source"] = stamp + " (HBM-side bytes per launch; an MFMA-bound kernel)"
@@ -406,9 +410,10 @@ def gemm_desc(mode):
     return {"f32": "fp32 MFMA (exact fp32 fma chain)",
             "bf16x6": "split-bf16 x6 MFMA, fp32 accumulate (fp32-GEMM accuracy, same test tolerances)",
             "auto": "split-bf16 x6 MFMA with fp32 accumulate everywhere it is faster (fp32-GEMM accuracy, same test tolerances): "
-                    "layer-0 products and all weight gradients with >= 2048 reduction rows on pre-split bf16x3 images "
-                    "(k_gemm_x3p: producer / consumer waves, LDS-DMA staged), the n1-row forward / input-gradient GEMMs with on-the-fly splitting "
-                    "(k_gemm), exact fp32 MFMA for the 512-row output layer"}[mode]
+                    "every product with >= 2048 rows (layer-0 and n1-row forwards, input gradients, all weight gradients) on pre-split "
+                    "bf16x3 images (k_gemm_x3p: producer / consumer waves, LDS-DMA staged; activation images written by the kernels that "
+                    "produce the activations, weight gradients read them k-major), exact fp32 (MFMA forward, vector-ALU backward) for "
+                    "the 512-row output layer"}[mode]
 
 
 def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size, n_classes, setup_s):
@@ -462,14 +467,14 @@ def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size,
     agg = {}
     for name, meta, ms in rec:
         key = name
-        if name == "ogl_reduce_fwd":
+        if name in ("ogl_reduce_fwd", "ogl_reduce_fwd_img"):
             key = "reduce_fwd_L0" if meta["n_dst"] > B else "reduce_fwd_L1"
         a = agg.setdefault(key, dict(ms=0.0, calls=0, bytes=0.0, flops=0.0))
         a["ms"] += ms; a["calls"] += 1
-        if name == "ogl_reduce_fwd":
+        if name in ("ogl_reduce_fwd", "ogl_reduce_fwd_img"):
             E = meta["n_dst"] * meta["fanout"]
-            a["bytes"] += E * (4 * meta["d"] + meta["idx_bytes"]) + meta["n_dst"] * 4 * meta["d"]
-        if name == "ogl_linear_fwd":
+            a["bytes"] += E * (4 * meta["d"] + meta["idx_bytes"]) + meta["n_dst"] * 4 * meta["d"] * (2.5 if name.endswith("_img") else 1)
+        if name in ("ogl_linear_fwd", "ogl_linear_fwd_x3", "ogl_linear_fwd_x3_ext"):
             a["flops"] += 2.0 * meta["M"] * meta["N"] * (meta["K"] + meta["K2"])
     kernels = {k: dict(ms_per_step=round(v["ms"] / nprof, 4), calls_per_step=round(v["calls"] / nprof, 2),
                        gbs=round(v["bytes"] / v["ms"] / 1e6, 1) if v["bytes"] else None,

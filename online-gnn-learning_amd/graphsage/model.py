@@ -60,7 +60,7 @@ class SupervisedGraphSage:
         self.use_graphs = "auto"
         self._staged_auto = None    # "auto": None = undecided, True / False after the probe
         self._staged_seen = 0       # eligible snapshots met so far (the first one is cold: images, code objects, allocator)
-        self.STAGED_AUTO_HOST_FRACTION = 0.85
+        self.STAGED_AUTO_HOST_FRACTION = 0.9
         self.step_hook = None       # instrumentation (tests, bench): called after every train step with a dict
 
     def build_optimizer(self):
@@ -253,7 +253,8 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         probe = (self.use_graphs == "auto" and self._staged_auto is None and self._graphs_ok("sampled") and bs > 0 and n >= 8 * bs)
         if probe:
             self._staged_seen += 1
-            probe = self._staged_seen >= 2                   # never decide on the first (cold) snapshot
+            probe = self._staged_seen >= 3                   # never decide on the first snapshots (cold: images, code objects,
+                                                             # allocator pools, Python's own caches — the host side warms up last)
         if probe:                                            # time this snapshot's eager update: host enqueue vs GPU
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t_host, first = 0.0, True
