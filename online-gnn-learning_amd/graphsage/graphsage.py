@@ -48,7 +48,6 @@ class GraphSAGE(nn.Module):
             for layer in self.layers:
                 layer._bias_sum = None
                 layer._pass_images = None
-            ops._ACT_IMAGES.clear()
 
     def _prepare_step_images(self, blocks, x):
         """The weight images the tall products of this train step will ask for (ops.weight_images_prepare: one launch instead
@@ -77,7 +76,6 @@ class GraphSAGE(nn.Module):
             ops.weight_images_prepare(req)
 
     def forward(self, blocks, x):
-        ops._ACT_IMAGES.clear()         # activation images live from their producer to the next projection of THIS pass only
         if torch.is_grad_enabled() and ops.get_gemm_mode() != "f32" and ops.PREPARE_WEIGHT_IMAGES:
             self._prepare_step_images(blocks, x)
         h = x

@@ -631,21 +631,26 @@ def linear_fwd_x3(x_img, x_rows, w_img, relu=False, x_nrows=None, M=None, out=No
     return y
 
 
-# bf16x3 images that travel beside an fp32 activation from the kernel that produced it to the projection that consumes it
-# (keyed by the activation's storage; consumed within the same layer sequence, see attach_image / take_image)
-_ACT_IMAGES = {}
+# bf16x3 images that travel beside an fp32 activation from the kernel that produced it to the projection that consumes it: an
+# attribute of the activation's tensor OBJECT (autograd.Function hands the same objects in and out), stamped with the tensor's
+# version counter — a different tensor at a recycled address, or this one after an in-place write, never inherits an image
 N1_BWD_SPLIT = True        # the scattered pool gradient dP (atomics: no producer can write its image) gets a split pass of its own
 X3_N1_MIN_ROWS = (1 << 40) if os.environ.get("OGL_N1_IMAGES") == "0" else 2048      # projections with at least this many rows run on the image kernel when their operand images exist
 
 
 def attach_image(t, img):
-    _ACT_IMAGES[(t.data_ptr(), t.shape[0], t.shape[1])] = img
+    t._ogl_image = (img, t._version, t.data_ptr())
     return t
 
 
 def take_image(t, pop=True):
-    key = (t.data_ptr(), t.shape[0], t.shape[1])
-    return _ACT_IMAGES.pop(key, None) if pop else _ACT_IMAGES.get(key)
+    ent = getattr(t, "_ogl_image", None)
+    if ent is None:
+        return None
+    if pop:
+        del t._ogl_image
+    img, version, ptr = ent
+    return img if (version == t._version and ptr == t.data_ptr() and img.rows == t.shape[0]) else None
 
 
 def x3_split_cat(parts):

@@ -701,3 +701,24 @@ def test_train_step_needs_no_transposed_activation_images():
     assert l1 == l0
     errs = [float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12) for a, b in zip(g1, g0)]
     assert max(errs) <= 1e-5, errs
+
+
+def test_activation_images_never_outlive_their_tensor_or_its_contents():
+    """An image travels as an attribute of the activation's tensor object, stamped with its version: a new tensor at a recycled
+    address or the same tensor after an in-place write has none."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    t = ops.empty_mat(300, 64, "cuda").copy_(torch.randn(300, 64, device="cuda"))
+    img = ops.x3_split(t)
+    ops.attach_image(t, img)
+    assert ops.take_image(t, pop=False) is img
+    ptr = t.data_ptr()
+    u = t
+    u.add_(1.0)                                     # contents changed: the image is stale
+    assert ops.take_image(t, pop=False) is None
+    ops.attach_image(t, img)
+    del t, u
+    v = ops.empty_mat(300, 64, "cuda")               # very likely the same address (caching allocator)
+    assert ops.take_image(v) is None or v.data_ptr() != ptr
+    ops.attach_image(v, img)
+    assert ops.take_image(v) is img and ops.take_image(v) is None      # popped
