@@ -1139,6 +1139,14 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     if (!bk && g.nsplit == 1 && !(c2_env && c2_env[0] == '0') && ogl_cdiv(g.M, 256) * ogl_cdiv(g.N, 128) <= 256) {
       if (ogl_cdiv(g.M, 128) * ogl_cdiv(g.N, 128) <= 256) cfg = 1;
       else if (ogl_cdiv(g.M, 192) * ogl_cdiv(g.N, 128) <= 256) cfg = 2;
+    } else if (!bk && g.nsplit == 1 && !(c2_env && c2_env[0] == '0') && ogl_cdiv(g.M, 256) * ogl_cdiv(g.N, 128) <= 1024) {
+      // a few rounds of tiles: the launch lasts (rounds of 256 tiles) x (tile height) / (the tile's efficiency in steady state:
+      // 1 : 0.93 : 0.86 for 256 : 192 : 128 rows) — e.g. [15 500, 600] is 2 rounds of 256 rows, 2 of 192 or 3 of 128
+      const int64_t nj = ogl_cdiv(g.N, 128);
+      const double c0 = (double)ogl_cdiv(ogl_cdiv(g.M, 256) * nj, 256) * 256.0;
+      const double c2 = (double)ogl_cdiv(ogl_cdiv(g.M, 192) * nj, 256) * 192.0 / 0.93;
+      const double c1 = (double)ogl_cdiv(ogl_cdiv(g.M, 128) * nj, 256) * 128.0 / 0.86;
+      cfg = (c0 <= c1 && c0 <= c2) ? 0 : (c2 <= c1 ? 2 : 1);
     }
     const int BMp = cfg == 0 ? 256 : cfg == 2 ? 192 : 128;
     g.NI = (int)ogl_cdiv(g.M, BMp);
