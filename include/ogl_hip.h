@@ -287,7 +287,9 @@ int64_t ogl_linear_bwd_weight_x3_workspace_bytes(int64_t M, int N, int K);
 /* ogl_linear_bwd_weight_x3 with x as a ROW-MAJOR image (what ogl_x3_split / the image emitters build): dw[N, K] = dy^T . x[x_rows],
  * reduction over M rows of x, no transposed image of x (autograd of nn.Linear's weight in
  * R/train/graphsage/pytorch/aggregator_dgl.py:199-206).  dyT_img as for ogl_linear_bwd_weight_x3 ([N rows, reduction], group-major;
- * interleave = G when it is ogl_pool_bwd_x3's image: reduction index m then stands for row (m % 32) * G + m / 32 of x[x_rows]).
+ * interleave = G when it is ogl_pool_bwd_x3's image: reduction index m then stands for row (m % 32) * G + m / 32 of x[x_rows];
+ * interleave = -1: `dyT_img` is the ROW-MAJOR image of dy itself ([M + 1 rows, N], as ogl_relu_bwd_img / ogl_x3_split write it) and is
+ * read k-major like x — no transposed image at all).
  * x image [x_img_rows (+ zero row), K (+ 1 when has_ones: the ones slot, which yields db / db2 = both copies of the bias
  * gradient)]; x_rows (nullable) gathers M rows, ids outside [0, x_nrows) read the zero row.  Images must be < 4 GB. */
 int64_t ogl_linear_bwd_weight_x3k_workspace_bytes(int64_t M, int64_t interleave, int N, int K, int has_ones);

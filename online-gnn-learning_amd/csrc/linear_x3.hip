@@ -62,6 +62,9 @@ struct X3Args {
   int64_t bk_red;               // reduction positions s >= bk_red are padding (zero row)
   int64_t bk_interleave;        // G > 0: reduction index m stands for position (m % 32) * G + m / 32 (the order of pool_bwd_x3's image)
   int bk_groups;                // 32-column groups per image row (column groups past it read the zero row)
+  // ---- k_gemm_x3p<..., BK, AK = true>: the A operand too is a ROW-MAJOR image over the reduction (dy as its producer wrote it): a.img /
+  // a.row_bytes / a.zero_row as for a row-major image, reduction position p = its row p (no gather, no dealing) ----
+  int ak_groups;                // 32-column groups per row of the A image
   unsigned char* out_img;       // optional: ALSO write the bf16x3 image of the (activated) output, row-major, reduction length
   int64_t out_row_bytes;        //   N (+ 1 when out_append_ones: 1.0 at column N) — the A operand of the next layer's product
   int out_append_ones;
@@ -357,7 +360,7 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
 // One barrier per step.  Three waves per SIMD = 168 registers per wave: the multipliers keep accumulators (64), A
 // fragments (48) and a two-deep B ring (24), the movers their piece offsets.  Images must be < 4 GB (32-bit offsets).
 // Measured against k_gemm_x3: matrix pipe busy 73 % of the in-kernel cycles instead of 56 %.
-template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool EXT = false, bool BK = false>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool EXT = false, bool BK = false, bool AK = false>
 __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(WAVES_M * WAVES_N == 8, "eight multiplier waves + four mover waves");
@@ -371,6 +374,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
   static_assert(NSTAGE * STAGE <= 160 * 1024, "the ring fits one CU");
   static_assert(!BK || (BN == 128 && NLP - NLP_A == 6), "k-major B: 128 columns = 48 (plane, 8-column chunk) pairs x 32 rows per stage");
   static_assert(!(BK && EXT), "the k-major B operand belongs to the weight-gradient products");
+  static_assert(!AK || (BK && BM == 128 && NLP_A == 6), "k-major A: with a k-major B, 128 rows");
   constexpr int B_BASE = A_PIECES * 16;                    // byte offset of the B part inside a stage
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
 
@@ -434,7 +438,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
     const int bk_ipc = (lane & 15) ^ ((bk_rsub << 1) | ((bk_w & 1) << 3));
     int64_t bk_id[2] = {0, 0};                             // raw ids (or positions) of the rows the NEXT fetch moves
     bool bk_ok[2] = {false, false};
-    unsigned bk_zmask = 0;                                 // pieces whose column group is past the image row
+    unsigned bk_zmask = 0, ak_zmask = 0;                   // pieces whose column group is past the image row
     auto bk_request = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -467,13 +471,20 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         if (g.a.rows) rid[u] = g.a.rows[gi < g.M ? gi : g.M - 1];
       }
       if (BK) bk_zmask = 0;
+      if (AK) ak_zmask = 0;
 #pragma unroll
       for (int u = 0; u < NLP; ++u) {
         const int i = u * 256 + ml;
         const int r = i / 12, jp = i - r * 12;
         const int j = (jp & ~3) | ((jp & 3) ^ swz(r));
         int64_t off;
-        if (u < NLP_A) {
+        if (AK && u < NLP_A) {
+          const int pc = 16 * (u % 3) + bk_ipc;                // as the B pieces below, over the A image's columns
+          const int grp = t.ti * (BM / 32) + pc / 12;
+          if (grp >= g.ak_groups) ak_zmask |= 1u << u;
+          src[u] = (unsigned)((grp < g.ak_groups ? grp : 0) * X3_GROUP_BYTES + (pc % 12) * 16);
+          continue;
+        } else if (u < NLP_A) {
           const int64_t id = rid[u < NLP_A ? u : 0];
           const bool ok = (int64_t)t.ti * BM + r < g.M && id >= 0 && id < g.a.nrows;
           off = (ok ? id : g.a.zero_row) * g.a.row_bytes + (int64_t)t.ks_begin * g.a.step_bytes;
@@ -505,6 +516,15 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         if (fks + 1 < fks_end) bk_request(fks + 1);
         else if (f_logical + nslots < last_logical) bk_request(decode(f_logical + nslots).ks_begin);
       }
+      unsigned ak_row[2] = {0, 0}, ak_zero = 0;
+      if (AK) {                                            // A rows of this step: reduction position = image row, nothing to fetch
+        ak_zero = (unsigned)(g.a.zero_row * g.a.row_bytes);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int64_t pos = (int64_t)fks * 32 + 8 * bk_w + 4 * h + bk_rsub;
+          ak_row[h] = pos < g.bk_red ? (unsigned)(pos * g.a.row_bytes) : ak_zero;
+        }
+      }
       if (EXT && two && !part2 && fks >= g.nsteps1) {      // entering the second A part of this tile
         make_src_a2(cur_ti);
         part2 = true; step_a = (unsigned)g.a2.step_bytes;
@@ -515,9 +535,10 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         constexpr int u = decltype(uc)::value;
         unsigned so = src[u];
         if (BK && u >= NLP_A) so += ((bk_zmask >> (u - NLP_A)) & 1) ? bk_zero : bk_row[(u - NLP_A) / 3];
+        if (AK && u < NLP_A) so += ((ak_zmask >> u) & 1) ? ak_zero : ak_row[u / 3];
         __builtin_amdgcn_raw_ptr_buffer_load_lds(u < NLP_A ? rs_a : rsrc_b,
                                                  (lptr_t)(smem + (stage % NSTAGE) * STAGE + (u * 256 + (wid - 8) * 64) * 16), 16, so, 0, 0, 0);
-        if (!(BK && u >= NLP_A)) src[u] += u < NLP_A ? step_a : step_b;
+        if (!(BK && u >= NLP_A) && !(AK && u < NLP_A)) src[u] += u < NLP_A ? step_a : step_b;
       });
       if (++fks == fks_end && f_logical + nslots < last_logical) {     // on to the next tile
         f_logical += nslots;
@@ -563,14 +584,16 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
     typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4;
     const int pq = l15 >> 2, pp = l15 & 3;
     const int bk_mask = (pp >> 1) | (pq << 1) | ((quad & 1) << 3);
-    const int bk_lane = B_BASE + (quad * 64 + pq * 16) * 16 + 8 * (pp & 1);
-    auto bk_frag = [&](const unsigned char* st, int y, int sp) __attribute__((always_inline)) {
-      const int n0 = wn * TN * 32 + y * 16;                // first column of the block inside the tile
-      const int pce = (n0 >> 5) * 12 + sp * 4 + ((n0 >> 3) & 3);     // its first piece (even)
+    const int bk_lane = (quad * 64 + pq * 16) * 16 + 8 * (pp & 1);
+    auto k_frag = [&](const unsigned char* st, int n0, int sp) __attribute__((always_inline)) {   // st: the operand's part of the stage
+      const int pce = (n0 >> 5) * 12 + sp * 4 + ((n0 >> 3) & 3);     // first piece (even) of the block whose first column is n0
       const int at = bk_lane + ((pce >> 4) * 256 + ((pce & 15) ^ bk_mask)) * 16;
       const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(st + at));
       const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(st + at + 3 * 256 * 16));
       return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto bk_frag = [&](const unsigned char* st, int y, int sp) __attribute__((always_inline)) {
+      return k_frag(st + B_BASE, wn * TN * 32 + y * 16, sp);
     };
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 acc[RB][CB];
@@ -598,7 +621,10 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
       for (int t = 0; t < RB; ++t)
         if (t < rbv) {
 #pragma unroll
-          for (int sp = 0; sp < 3; ++sp) a[t][sp] = *(const bf16x8*)(st + rowa + t * 16 * 192 + offp[sp]);
+          for (int sp = 0; sp < 3; ++sp) {
+            if constexpr (AK) a[t][sp] = k_frag(st, wm * TM * 32 + t * 16, sp);
+            else a[t][sp] = *(const bf16x8*)(st + rowa + t * 16 * 192 + offp[sp]);
+          }
         }
       static_for<0, CB>([&](auto yc) __attribute__((always_inline)) {
         constexpr int y = decltype(yc)::value;
@@ -1121,6 +1147,7 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
   g.stamps = g_x3_stamps;
   // (row-major image: rows x row_bytes; group-major image: groups x step_bytes)
   const int64_t a_bytes = std::max((g.a.zero_row + 1) * g.a.row_bytes, (int64_t)g.nsteps * g.a.step_bytes);
+  if (g.ak_groups > 0 && g.bk_groups <= 0) return OGL_EINVAL;
   const int64_t b_bytes = std::max((g.b.zero_row + 1) * g.b.row_bytes, (int64_t)g.nsteps * g.b.step_bytes);
   if (g.a2.img && (g.a2.zero_row + 1) * g.a2.row_bytes >= (1ll << 32)) return OGL_EINVAL;
   int cfg = x3_config(g.M, g.N);
@@ -1156,7 +1183,8 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     // ring depth: two stages of the 256 x 128 tile fill the LDS (144 KB); the 128 x 128 tile takes three (144 KB): its movers
     // run two stages ahead (+4 % on the layer-0 weight gradient, whose operands both stream from HBM)
     const bool ext = g.a2.img || g.add || g.out_img;
-    if (bk) hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1, 3, false, true>), grid, block, 0, stream, g);
+    if (bk && g.ak_groups > 0) hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1, 3, false, true, true>), grid, block, 0, stream, g);
+    else if (bk) hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1, 3, false, true>), grid, block, 0, stream, g);
     else if (ext) {
       if (g.nsplit != 1 || g.ones_col) return OGL_EINVAL;
       if (cfg == 0) hipLaunchKernelGGL((k_gemm_x3p<4, 2, 2, 2, 2, true>), grid, block, 0, stream, g);
@@ -1265,9 +1293,9 @@ static void x3_bwwk_plan(int64_t steps, int N, int Kc, int* nsplit, int* sps) {
 }
 
 extern "C" int64_t ogl_linear_bwd_weight_x3k_workspace_bytes(int64_t M, int64_t interleave, int N, int K, int has_ones) {
-  if (M < 0 || N < 0 || K < 0 || interleave < 0) return OGL_EINVAL;
+  if (M < 0 || N < 0 || K < 0 || interleave < -1) return OGL_EINVAL;
   int nsplit, sps;
-  x3_bwwk_plan(interleave ? interleave : ogl_cdiv(M, 32), N, K + (has_ones ? 1 : 0), &nsplit, &sps);
+  x3_bwwk_plan(interleave > 0 ? interleave : ogl_cdiv(M, 32), N, K + (has_ones ? 1 : 0), &nsplit, &sps);
   if (nsplit <= 1) return 16;
   return (int64_t)nsplit * N * ogl_round_up(K + 1, 4) * 4;
 }
@@ -1276,6 +1304,9 @@ extern "C" int ogl_linear_bwd_weight_x3k(const void* dyT_img, int64_t interleave
                                          const int64_t* x_rows, int64_t x_nrows, int64_t M, int N, int K, int has_ones, float* dw,
                                          int64_t lddw, float* db, float* db2, void* workspace, int64_t workspace_bytes,
                                          ogl_stream_t stream) {
+  // interleave == -1: `dyT_img` is the ROW-MAJOR image of dy itself ([M + 1 rows, N], ogl_relu_bwd_img / ogl_x3_split): read k-major too
+  const bool dy_rows = interleave == -1;
+  if (dy_rows) interleave = 0;
   if (M <= 0 || N < 0 || K <= 0 || lddw < K || interleave < 0 || (interleave > 0 && 32 * interleave < M)) return OGL_EINVAL;
   if (x_img_rows < 0 || x_nrows < 0 || x_nrows > x_img_rows || (!x_rows && M > x_img_rows)) return OGL_EINVAL;
   if (N == 0) return OGL_OK;
@@ -1286,6 +1317,10 @@ extern "C" int ogl_linear_bwd_weight_x3k(const void* dyT_img, int64_t interleave
   g.a = X3Operand{(const unsigned char*)dyT_img, X3_GROUP_BYTES, ((int64_t)N + 1) * X3_GROUP_BYTES, nullptr, N, N};
   g.b = X3Operand{(const unsigned char*)x_img, xrb, 0, x_rows, x_rows ? x_nrows : x_img_rows, x_img_rows};
   g.bk_red = M; g.bk_interleave = interleave; g.bk_groups = (int)ogl_cdiv(Kc, 32);
+  if (dy_rows) {
+    g.ak_groups = (int)ogl_cdiv(N, 32);
+    g.a = X3Operand{(const unsigned char*)dyT_img, (int64_t)g.ak_groups * X3_GROUP_BYTES, 0, nullptr, M, M};
+  }
   g.M = N; g.N = Kc; g.ones_col = has_ones ? 1 : 0;
   g.nsteps = (int)(interleave ? interleave : ogl_cdiv(M, 32));
   g.C = dw; g.ldc = lddw; g.db = db; g.db2 = db2;

@@ -846,13 +846,18 @@ def linear_bwd_weight_x3(dyT_img, xT_img, want_bias=True):
     return dw, db
 
 
-def linear_bwd_weight_x3k(dyT_img, x_img, M, K, x_rows=None, x_nrows=None, interleave=0, want_bias=True, want_bias2=False):
+def linear_bwd_weight_x3k(dyT_img, x_img, M, K, x_rows=None, x_nrows=None, interleave=0, want_bias=True, want_bias2=False, dy_rows=False):
     """dw [N, K] (and db, db2: two copies of the bias gradient) from the image of dy.T and the ROW-MAJOR image of x (M reduction
-    rows, gathered by ``x_rows``): no transposed image of x.  The bias gradient needs the ones slot in ``x_img`` (K + 1)."""
-    N = dyT_img.rows
+    rows, gathered by ``x_rows``): no transposed image of x.  The bias gradient needs the ones slot in ``x_img`` (K + 1).
+    ``dy_rows``: ``dyT_img`` is the row-major image of dy itself ([M, N]: what relu_bwd_img / x3_split build), read k-major too."""
     has_ones = x_img.K == K + 1
     assert x_img.K in (K, K + 1) and (has_ones or not (want_bias or want_bias2))
-    assert dyT_img.K == (32 * interleave if interleave else M), (dyT_img.K, M, interleave)
+    if dy_rows:
+        assert dyT_img.rows == M and not interleave
+        N, interleave = dyT_img.K, -1
+    else:
+        N = dyT_img.rows
+        assert dyT_img.K == (32 * interleave if interleave else M), (dyT_img.K, M, interleave)
     dev = dyT_img.buf.device
     dw = torch.empty((N, K), dtype=torch.float32, device=dev)
     db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
@@ -914,19 +919,36 @@ def _row_image_for(x, x_rows, x_img):
     return None
 
 
-def weight_grad(dy, x, x_rows=None, want_bias=True, dyT=None, x_img=None):
-    """dW, db of a projection.  In the bf16x6 / auto arithmetic the product runs on the split-bf16 image kernel: dy^T as a
-    transposed image, x as the row-major image its forward already had (``x_img``, or the resident table's: read k-major, no
-    transposed copy) or else as a transposed image too; the exact-fp32 mode keeps the direct k-major kernel.  ``dyT`` lets the two
-    weight gradients of a dual-input Linear share one transpose."""
+K_MAJOR_DY = os.environ.get("OGL_BWW_KMAJOR_DY") != "0"    # ... and dy's own row-major image when its producer wrote one
+
+
+def _dy_rows_image(dy, dy_img):
+    """``dy_img`` if it is the row-major image of ``dy`` and the k-major weight gradient may use it (no transposed image of dy)."""
+    if K_MAJOR_WEIGHT_GRADS and K_MAJOR_DY and dy_img is not None and dy_img.rows == dy.shape[0] and dy_img.K == dy.shape[1]:
+        return dy_img
+    return None
+
+
+def weight_grad(dy, x, x_rows=None, want_bias=True, dyT=None, x_img=None, dy_img=None):
+    """dW, db of a projection.  In the bf16x6 / auto arithmetic the product runs on the split-bf16 image kernel: x as the row-major
+    image its forward already had (``x_img``, or the resident table's: read k-major, no transposed copy), dy likewise when its
+    producer wrote its image (``dy_img``), else as the image of dy^T; without a row-major image of x both operands are transposed
+    images; the exact-fp32 mode keeps the direct k-major kernel.  ``dyT`` lets the two weight gradients of a dual-input Linear
+    share one transpose."""
     if _MODE["name"] == "f32" or dy.shape[0] < 1024:
         return linear_bwd_weight(dy, x, None, x_rows, want_bias=want_bias)
+    K = x.shape[1]
+    rimg = _row_image_for(x, x_rows, x_img) if dy.shape[0] >= X3_BWW_MIN_ROWS else None
+    if rimg is not None and not (rimg.K == K + 1 or (rimg.K == K and not want_bias)):
+        rimg = None
+    dyr = _dy_rows_image(dy, dy_img) if rimg is not None else None
+    if dyr is not None:
+        return linear_bwd_weight_x3k(dyr, rimg, dy.shape[0], K, x_rows=x_rows, x_nrows=x.shape[0] if x_rows is not None else None,
+                                     want_bias=want_bias, dy_rows=True)[:2]
     if dyT is None:
         dyT = transposed_operand(dy)
     if isinstance(dyT, X3Image):
-        rimg = _row_image_for(x, x_rows, x_img)
-        K = x.shape[1]
-        if rimg is not None and (rimg.K == K + 1 or (rimg.K == K and not want_bias)):
+        if rimg is not None:
             return linear_bwd_weight_x3k(dyT, rimg, dy.shape[0], K, x_rows=x_rows, x_nrows=x.shape[0] if x_rows is not None else None,
                                          want_bias=want_bias)[:2]
     if isinstance(dyT, X3Image):
@@ -1049,30 +1071,34 @@ class _LinearFn(torch.autograd.Function):
                 raise RuntimeError("gradient w.r.t. a row-gathered table is not supported (features carry no grad)")
             dx = linear_bwd_input(dy, w, y, dy_img=dy_img)
         dyT = None
-        if _MODE["name"] != "f32" and dy.shape[0] >= 1024 and x2 is not None and need[1] and need[4]:
-            dyT = transposed_operand(dy)   # shared by the two weight gradients of a dual-input projection
         x2_img = ctx.x2_img if (x2 is not None and x2_rows is None) else None
+        tall = _MODE["name"] != "f32" and dy.shape[0] >= X3_BWW_MIN_ROWS
+        rimg = _row_image_for(x, x_rows, None) if tall else None
+        # every operand's row-major image at hand (dy's from the ReLU backward): the k-major product needs no transposed image
+        dyr = _dy_rows_image(dy, dy_img) if (rimg is not None and x2_img is not None) else None
+        if dyr is None and _MODE["name"] != "f32" and dy.shape[0] >= 1024 and x2 is not None and need[1] and need[4]:
+            dyT = transposed_operand(dy)   # shared by the two weight gradients of a dual-input projection
         both = None
-        if (isinstance(dyT, X3Image) and ctx.has_bias and ctx.has_bias2 and x2_img is not None and x2_img.K == x2.shape[1]
-                and need[1] and need[4]):
+        if ((dyr is not None or isinstance(dyT, X3Image)) and ctx.has_bias and ctx.has_bias2 and x2_img is not None
+                and x2_img.K == x2.shape[1] and need[1] and need[4]):
             # the neighbour part's image has no ones slot: both copies of the bias gradient come from the first product
-            rimg = _row_image_for(x, x_rows, None)
             if rimg is not None and rimg.K == x.shape[1] + 1:
-                both = linear_bwd_weight_x3k(dyT, rimg, dy.shape[0], x.shape[1], x_rows=x_rows,
-                                             x_nrows=x.shape[0] if x_rows is not None else None, want_bias=True, want_bias2=True)
+                both = linear_bwd_weight_x3k(dyr if dyr is not None else dyT, rimg, dy.shape[0], x.shape[1], x_rows=x_rows,
+                                             x_nrows=x.shape[0] if x_rows is not None else None, want_bias=True, want_bias2=True,
+                                             dy_rows=dyr is not None)
         if both is not None:
             dw, db, db2 = both
         elif need[1] or (need[2] and ctx.has_bias):
-            dw, db = weight_grad(dy, x, x_rows, want_bias=ctx.has_bias, dyT=dyT)
+            dw, db = weight_grad(dy, x, x_rows, want_bias=ctx.has_bias, dyT=dyT, dy_img=dy_img)
         if x2 is not None:
             if need[3]:
                 if x2_rows is not None:
                     raise RuntimeError("gradient w.r.t. a row-gathered table is not supported")
                 dx2 = linear_bwd_input(dy, w2, y, dy_img=dy_img)
             if both is not None:
-                dw2 = weight_grad(dy, x2, None, want_bias=False, dyT=dyT, x_img=x2_img)[0]
+                dw2 = weight_grad(dy, x2, None, want_bias=False, dyT=dyT, x_img=x2_img, dy_img=dy_img)[0]
             elif need[4] or ctx.has_bias2:
-                dw2, db2 = weight_grad(dy, x2, x2_rows, want_bias=ctx.has_bias2, dyT=dyT)
+                dw2, db2 = weight_grad(dy, x2, x2_rows, want_bias=ctx.has_bias2, dyT=dyT, dy_img=dy_img)
         return dx, dw, (db if ctx.has_bias else None), dx2, dw2, None, None, None, (db2 if ctx.has_bias2 else None)
 
 
@@ -1213,7 +1239,7 @@ class _SagePoolLayerFn(torch.autograd.Function):
             dx_self, dp = out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src)
             dp_img = x3_split(dp) if (N1_BWD_SPLIT and _n1_images_ok(n_src, dp.shape[1], w_pool.shape[1])) else None
             dh = linear_bwd_input(dp, w_pool, None, dy_img=dp_img, add_head=dx_self)
-            dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias, x_img=ctx.h_img)
+            dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias, x_img=ctx.h_img, dy_img=dp_img)
             return (dh, dw_pool, db_pool if ctx.has_pool_bias else None, dw_self, dw_neigh, db if ctx.has_bias else None,
                     db2 if ctx.has_bias else None, None, None, None)
         dyT = transposed_operand(dy) if (_MODE["name"] != "f32" and dy.shape[0] >= 1024) else None
@@ -1225,7 +1251,7 @@ class _SagePoolLayerFn(torch.autograd.Function):
         dp = reduce_bwd(dneigh, None, argmax, "max", n_src, fanout=ctx.fanout, relu_out=neigh)
         dp_img = x3_split(dp) if (N1_BWD_SPLIT and _n1_images_ok(n_src, dp.shape[1], w_pool.shape[1])) else None
         dh = linear_bwd_input(dp, w_pool, None, dy_img=dp_img)
-        dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias, x_img=ctx.h_img)
+        dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias, x_img=ctx.h_img, dy_img=dp_img)
         dx_self = linear_bwd_input(dy, w_self, None)
         dh[:n_dst].add_(dx_self)                                  # the fc_self path, in place on the first n_dst rows
         return (dh, dw_pool, db_pool if ctx.has_pool_bias else None, dw_self, dw_neigh, db if ctx.has_bias else None,

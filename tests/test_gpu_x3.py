@@ -653,11 +653,18 @@ def test_weight_gradient_reads_the_row_major_image(M, N, K, gather, interleave, 
     ref_dw, ref_db = ops.linear_bwd_weight_x3(dyT, ops.x3_split_t(table, rows, ones_row=True, interleave=G) if gather
                                               else ops.x3_split_t(table[:M], None, ones_row=True, interleave=G), want_bias=True)
     assert float((dw - ref_dw).abs().max()) <= 1e-5 * scale
+    if not interleave:
+        # dy too as its own row-major image (what the ReLU backward / a split pass writes), read k-major: no transposed image at all
+        dw2, db3, _ = ops.linear_bwd_weight_x3k(ops.x3_split(dy), x_img, M, K, x_rows=rows, x_nrows=T if gather else None,
+                                                want_bias=ones, dy_rows=True)
+        assert float((dw2 - dw).abs().max()) <= 1e-5 * scale
+        if ones:
+            assert float((db3 - db).abs().max()) <= 1e-5 * float(wantb.abs().max())
 
 
 def test_train_step_needs_no_transposed_activation_images():
-    """With the k-major weight-gradient product the Reddit-shaped step builds transposed images only of the two gradients
-    (dy^T of the layer-0 combine, dP^T of layer 1): x^T of the table rows, neigh^T and h1^T are gone."""
+    """With the k-major weight-gradient product the Reddit-shaped step builds NO transposed image by a pass of its own (the fused
+    pool backward writes dP0^T directly): x^T of the table rows, neigh^T, h1^T and the gradients' dy^T / dP1^T are gone."""
     import torch.nn.functional as F
     import ogl_amd  # noqa: F401
     from ogl_amd import ops
@@ -696,7 +703,7 @@ def test_train_step_needs_no_transposed_activation_images():
     finally:
         ops.K_MAJOR_WEIGHT_GRADS = flag
         ops.set_gemm_mode("f32")
-    assert names.count("ogl_x3_split_t") == 2 and names.count("ogl_linear_bwd_weight_x3k") == 4 and "ogl_linear_bwd_weight_x3" not in names
+    assert "ogl_x3_split_t" not in names and names.count("ogl_linear_bwd_weight_x3k") == 4 and "ogl_linear_bwd_weight_x3" not in names
     assert names0.count("ogl_x3_split_t") == 6 and "ogl_linear_bwd_weight_x3k" not in names0
     assert l1 == l0
     errs = [float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12) for a, b in zip(g1, g0)]
