@@ -322,6 +322,10 @@ int ogl_build_block_batched(const int64_t* dst_base, const int64_t* dst_start, c
 int ogl_ce_fwd_bwd(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C,
                    float grad_scale, float* loss_rows, float* dlogits, int64_t lddl,
                    ogl_stream_t stream);
+/* The same for B <= 1024 rows in one workgroup, with loss_mean[0] = mean of the row losses from the same launch
+ * (reduction='mean', R/train/graphsage/pytorch/model.py:20: the loss the RBR / no-rehearsal strategies differentiate). */
+int ogl_ce_fwd_bwd_mean(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C, float grad_scale,
+                        float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean, ogl_stream_t stream);
 
 /* torch.optim.Adam(lr) single-tensor update (R/train/graphsage/pytorch/model.py:24-25,107).
  * Hyper-parameters are doubles (as Python floats are) so 1-beta is rounded to fp32 once, like torch. */
@@ -376,13 +380,15 @@ int ogl_publish_i64(const int64_t* src, int n, int64_t* seq_dev, int64_t* dst_ho
  *                              dP[argmax[d, c], c] += (dy . w_neigh)[d, c] where neigh[d, c] > 0 (dP zero-initialised by the caller:
  *                              what ogl_linear_bwd_input x 2 + ogl_reduce_bwd(max, relu_out = neigh) compute in three launches).
  *   ogl_out_layer_bwd_weights  dw_self = dy^T . x_self, dw_neigh = dy^T . x_neigh (both [N, K]), db = db2 = column sums of dy (nullable),
- *                              M <= 4096 rows; dy rows 16-byte aligned with lddy a multiple of 4 (as ogl_linear_bwd_weight's skinny path). */
+ *                              M <= 4096 rows; dy rows 16-byte aligned with lddy a multiple of 4 (as ogl_linear_bwd_weight's skinny path);
+ *                              x_self_rows (nullable) gathers x_self's M rows from a table (ids outside [0, x_self_nrows): zero rows) —
+ *                              the first layer's combine at the 32-seed rungs. */
 int ogl_out_layer_bwd_inputs(const float* dy, int64_t lddy, int64_t n_dst, int N, int K, const float* w_self, int64_t ldws,
                              const float* w_neigh, int64_t ldwn, const int32_t* argmax, const float* neigh, int64_t ldn, int64_t n_src,
                              float* dx_self, int64_t ldx, float* dP, int64_t ldp, ogl_stream_t stream);
 int ogl_out_layer_bwd_weights(const float* dy, int64_t lddy, int64_t M, int N, int K, const float* x_self, int64_t ldxs,
-                              const float* x_neigh, int64_t ldxn, float* dw_self, int64_t lddws, float* dw_neigh, int64_t lddwn,
-                              float* db, float* db2, ogl_stream_t stream);
+                              const int64_t* x_self_rows, int64_t x_self_nrows, const float* x_neigh, int64_t ldxn, float* dw_self,
+                              int64_t lddws, float* dw_neigh, int64_t lddwn, float* db, float* db2, ogl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * A whole SMALL 'pool' SAGEConv layer in two launches forward, two launches backward (small_layer.hip):

@@ -68,12 +68,13 @@ SIGNATURES = {
     "ogl_linear_bwd_weight_x3k": (_i, [_p, _i64, _p, _i64, _p, _i64, _i64, _i, _i, _i, _p, _i64, _p, _p, _p, _i64, _p]),
     "ogl_linear_bwd_weight_x3": (_i, [_p, _p, _i64, _i, _i, _p, _i64, _p, _p, _i64, _p]),
     "ogl_ce_fwd_bwd": (_i, [_p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p]),
+    "ogl_ce_fwd_bwd_mean": (_i, [_p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p]),
     "ogl_adam_step": (_i, [_p, _p, _p, _p, _i64, _i, _d, _d, _d, _d, _p]),
     "ogl_argmax_confusion": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p]),
     "ogl_adam_step_multi": (_i, [_i, _p, _p, _p, _p, _p, _i, _d, _d, _d, _d, _p]),
     "ogl_sample_layer_dev": (_i, [_p, _p, _i64, _i, _u64, _p, _i, _p, _p]),
     "ogl_out_layer_bwd_inputs": (_i, [_p, _i64, _i64, _i, _i, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _p]),
-    "ogl_out_layer_bwd_weights": (_i, [_p, _i64, _i64, _i, _i, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p]),
+    "ogl_out_layer_bwd_weights": (_i, [_p, _i64, _i64, _i, _i, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p]),
     "ogl_small_pool_layer_fits": (_i, [_i64, _i64, _i, _i, _i]),
     "ogl_small_pool_layer_workspace_floats": (_i64, [_i64, _i64, _i]),
     "ogl_small_pool_layer_fwd": (_i, [_p, _i64, _i64, _p, _i64, _i, _i, _p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _i, _i, _p, _i64, _p, _p,

@@ -55,6 +55,52 @@ extern "C" int ogl_ce_fwd_bwd(const float* logits, int64_t ldl, const int64_t* l
   return OGL_OK;
 }
 
+// The same for a SMALL batch with the mean of the row losses from the same launch (one workgroup: wave w takes rows w, w + 16, ...;
+// the row losses are summed in row order by one wave) — the mean as a second launch is pure latency on the 32-seed rungs.
+#define CE_SMALL_MAX_B 1024
+__global__ void __launch_bounds__(1024) k_ce_fwd_bwd_mean(const float* __restrict__ logits, int64_t ldl,
+                                                          const int64_t* __restrict__ labels, int B, int C, float grad_scale,
+                                                          float* __restrict__ loss_rows, float* __restrict__ dlogits, int64_t lddl,
+                                                          float* __restrict__ loss_mean) {
+  __shared__ float rows[CE_SMALL_MAX_B];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int row = wv; row < B; row += 16) {
+    const float* x = logits + (int64_t)row * ldl;
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, x[c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += expf(x[c] - m);
+    s = wave_sum(s);
+    const float lse = m + logf(s);
+    const int64_t y = labels[row];
+    const bool ok = y >= 0 && y < C;
+    const float l = ok ? lse - x[y] : 0.f;
+    if (lane == 0) { rows[row] = l; if (loss_rows) loss_rows[row] = l; }
+    if (dlogits) {
+      float* g = dlogits + (int64_t)row * lddl;
+      for (int c = lane; c < C; c += 64) g[c] = grad_scale * (expf(x[c] - lse) - ((ok && c == (int)y) ? 1.f : 0.f));
+    }
+  }
+  __syncthreads();
+  if (wv == 0) {                                                  // fixed order: lane l sums rows l, l + 64, ...; then the lanes
+    float t = 0.f;
+    for (int r = lane; r < B; r += 64) t += rows[r];
+    t = wave_sum(t);
+    if (lane == 0) *loss_mean = t / (float)B;
+  }
+}
+
+extern "C" int ogl_ce_fwd_bwd_mean(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C, float grad_scale,
+                                   float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean, ogl_stream_t stream) {
+  if (B <= 0 || B > CE_SMALL_MAX_B || C <= 0 || ldl < C || (dlogits && lddl < C)) return OGL_EINVAL;
+  if (!logits || !labels || !loss_mean) return OGL_EINVAL;
+  hipLaunchKernelGGL(k_ce_fwd_bwd_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ldl, labels, (int)B, C, grad_scale,
+                     loss_rows, dlogits, lddl, loss_mean);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
 // torch.optim.Adam single-tensor form: m.lerp_(g, 1-b1); v = b2*v + (1-b2)*g*g;
 // denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= (lr/(1-b1^t)) * m/denom
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g,

@@ -125,7 +125,9 @@ extern "C" int ogl_out_layer_bwd_inputs(const float* dy, int64_t lddy, int64_t n
 #define OB_MG 64
 template <int NV>
 __global__ void __launch_bounds__(OB_KT * OB_MG) k_out_bwd_weights(const float* __restrict__ dy, int64_t ldy, int64_t M, int N, int K,
-                                                                  const float* __restrict__ x0, int64_t ldx0, const float* __restrict__ x1,
+                                                                  const float* __restrict__ x0, int64_t ldx0,
+                                                                  const int64_t* __restrict__ x0_rows, int64_t x0_nrows,
+                                                                  const float* __restrict__ x1,
                                                                   int64_t ldx1, float* __restrict__ dw0, int64_t lddw0,
                                                                   float* __restrict__ dw1, int64_t lddw1, float* __restrict__ db,
                                                                   float* __restrict__ db2) {
@@ -150,8 +152,11 @@ __global__ void __launch_bounds__(OB_KT * OB_MG) k_out_bwd_weights(const float* 
       const int64_t m = m0 + u * OB_MG;
       const bool live = m < M;
       const int64_t mm = live ? m : mg;
-      const float xr = x[mm * ldx + (kx ? k : 0)];
-      xv[u] = kone ? (live ? 1.f : 0.f) : ((kx && live) ? xr : 0.f);
+      int64_t r = mm;
+      bool ok = live;
+      if (!second && x0_rows) { r = x0_rows[mm]; ok = ok && r >= 0 && r < x0_nrows; }     // product 0 may gather its rows from a table
+      const float xr = x[(ok ? r : 0) * ldx + (kx ? k : 0)];
+      xv[u] = kone ? (live ? 1.f : 0.f) : ((kx && ok) ? xr : 0.f);
       const float4* dr = (const float4*)(dy + mm * ldy);
 #pragma unroll
       for (int i = 0; i < NV; ++i) d4[u][i] = dr[i < nvr ? i : 0];
@@ -190,16 +195,18 @@ __global__ void __launch_bounds__(OB_KT * OB_MG) k_out_bwd_weights(const float* 
 }
 
 extern "C" int ogl_out_layer_bwd_weights(const float* dy, int64_t lddy, int64_t M, int N, int K, const float* x_self, int64_t ldxs,
-                                         const float* x_neigh, int64_t ldxn, float* dw_self, int64_t lddws, float* dw_neigh,
-                                         int64_t lddwn, float* db, float* db2, ogl_stream_t stream) {
+                                         const int64_t* x_self_rows, int64_t x_self_nrows, const float* x_neigh, int64_t ldxn,
+                                         float* dw_self, int64_t lddws, float* dw_neigh, int64_t lddwn, float* db, float* db2,
+                                         ogl_stream_t stream) {
   if (M <= 0 || M > 4096 || N <= 0 || N > OB_MAX_N || K <= 0 || ldxs < K || ldxn < K || lddws < K || lddwn < K) return OGL_EINVAL;
+  if (x_self_rows && x_self_nrows <= 0) return OGL_EINVAL;
   if (!dy || !x_self || !x_neigh || !dw_self || !dw_neigh) return OGL_EINVAL;
   if (lddy % 4 != 0 || lddy < (N + 3) / 4 * 4 || ((uintptr_t)dy & 15)) return OGL_EINVAL;     // dy rows are read as float4s
   dim3 grid((unsigned)ogl_cdiv((int64_t)K + 1, OB_KT), 2), block(OB_KT * OB_MG);
   const int nv = (N + 3) / 4;
 #define OGL_OBW(NV_)                                                                                                                \
-  hipLaunchKernelGGL(k_out_bwd_weights<NV_>, grid, block, 0, (hipStream_t)stream, dy, lddy, M, N, K, x_self, ldxs, x_neigh, ldxn, dw_self, \
-                     lddws, dw_neigh, lddwn, db, db2)
+  hipLaunchKernelGGL(k_out_bwd_weights<NV_>, grid, block, 0, (hipStream_t)stream, dy, lddy, M, N, K, x_self, ldxs, x_self_rows,            \
+                     x_self_nrows, x_neigh, ldxn, dw_self, lddws, dw_neigh, lddwn, db, db2)
   if (nv <= 4) OGL_OBW(4); else if (nv <= 8) OGL_OBW(8); else if (nv <= 12) OGL_OBW(12); else OGL_OBW(16);
 #undef OGL_OBW
   OGL_CHECK_LAUNCH();

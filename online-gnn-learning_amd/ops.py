@@ -462,10 +462,11 @@ def out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src):
     return dx, dp
 
 
-def out_layer_bwd_weights(dy, x_self, x_neigh, want_bias=True):
-    """(dw_self, dw_neigh [N, K], db, db2) of a few-column combine in one launch."""
+def out_layer_bwd_weights(dy, x_self, x_neigh, want_bias=True, x_self_rows=None):
+    """(dw_self, dw_neigh [N, K], db, db2) of a few-column combine in one launch; ``x_self_rows`` gathers x_self's rows from a table."""
     dy = as_mat(dy); x_self = as_mat(x_self); x_neigh = as_mat(x_neigh)
     M, N = dy.shape
+    assert x_neigh.shape[0] == M and (x_self_rows.numel() if x_self_rows is not None else x_self.shape[0]) == M
     K = x_self.shape[1]
     dev = dy.device
     dws = torch.empty((N, K), dtype=torch.float32, device=dev)
@@ -473,7 +474,7 @@ def out_layer_bwd_weights(dy, x_self, x_neigh, want_bias=True):
     db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
     db2 = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
     _launch("ogl_out_layer_bwd_weights", _lib.lib().ogl_out_layer_bwd_weights, _ptr(dy), _ld(dy), M, N, K, _ptr(x_self), _ld(x_self),
-            _ptr(x_neigh), _ld(x_neigh), _ptr(dws), _ld(dws), _ptr(dwn), _ld(dwn), _ptr(db), _ptr(db2), _stream(), meta=dict(M=M, N=N, K=K))
+            _ptr(_ids(x_self_rows) if x_self_rows is not None else None), x_self.shape[0], _ptr(x_neigh), _ld(x_neigh), _ptr(dws), _ld(dws), _ptr(dwn), _ld(dwn), _ptr(db), _ptr(db2), _stream(), meta=dict(M=M, N=N, K=K))
     return dws, dwn, db, db2
 
 
@@ -978,6 +979,23 @@ def ce_fwd_bwd(logits, labels, grad_scale=1.0, want_grad=True):
     return loss, dl
 
 
+CE_MEAN_SMALL_MAX_B = 128      # up to here the mean comes from the cross-entropy launch itself (one workgroup)
+
+
+def ce_fwd_bwd_mean(logits, labels, want_grad=True):
+    """(mean loss [scalar tensor], row losses, dlogits scaled by 1/B) of a small batch in ONE launch."""
+    logits = as_mat(logits)
+    labels = labels.reshape(-1)
+    assert labels.dtype == torch.int64 and labels.is_cuda and labels.is_contiguous() and labels.numel() == logits.shape[0]
+    B, Cc = logits.shape
+    loss = torch.empty(B, dtype=torch.float32, device=logits.device)
+    mean = torch.empty((), dtype=torch.float32, device=logits.device)
+    dl = empty_mat(B, Cc, logits.device) if want_grad else None
+    _launch("ogl_ce_fwd_bwd_mean", _lib.lib().ogl_ce_fwd_bwd_mean, _ptr(logits), _ld(logits), _ptr(labels), B, Cc, C.c_float(1.0 / B),
+            _ptr(loss), _ptr(dl), _ld(dl) if dl is not None else 0, _ptr(mean), _stream(), meta=dict(B=B, C=Cc))
+    return mean, loss, dl
+
+
 def argmax_confusion(logits, labels=None, confusion=None, want_pred=True):
     """pred = argmax over classes; ``confusion`` (int64 [C, C], accumulated in place) counts (true, pred) pairs."""
     logits = as_mat(logits)
@@ -1086,6 +1104,15 @@ class _LinearFn(torch.autograd.Function):
                 both = linear_bwd_weight_x3k(dyr if dyr is not None else dyT, rimg, dy.shape[0], x.shape[1], x_rows=x_rows,
                                              x_nrows=x.shape[0] if x_rows is not None else None, want_bias=True, want_bias2=True,
                                              dy_rows=dyr is not None)
+        if (both is None and x2 is not None and x2_rows is None and need[1] and need[4] and ctx.has_bias and ctx.has_bias2
+                and dy.shape[0] < 1024 and x.shape[1] == x2.shape[1] and _out_layer_fits(dy, x, w, w2)):
+            # a short, narrow combine (the first layer at the 32-seed rungs): both weight gradients and both bias-gradient copies
+            # from one launch instead of two latency-bound ones
+            dw, dw2, db, db2 = out_layer_bwd_weights(dy, x, x2, want_bias=True, x_self_rows=x_rows)
+            both = (dw, db, db2)
+            fused_small = True
+        else:
+            fused_small = False
         if both is not None:
             dw, db, db2 = both
         elif need[1] or (need[2] and ctx.has_bias):
@@ -1095,7 +1122,9 @@ class _LinearFn(torch.autograd.Function):
                 if x2_rows is not None:
                     raise RuntimeError("gradient w.r.t. a row-gathered table is not supported")
                 dx2 = linear_bwd_input(dy, w2, y, dy_img=dy_img)
-            if both is not None:
+            if fused_small:
+                pass
+            elif both is not None:
                 dw2 = weight_grad(dy, x2, None, want_bias=False, dyT=dyT, x_img=x2_img, dy_img=dy_img)[0]
             elif need[4] or ctx.has_bias2:
                 dw2, db2 = weight_grad(dy, x2, x2_rows, want_bias=ctx.has_bias2, dyT=dyT, dy_img=dy_img)
@@ -1374,6 +1403,10 @@ class _CrossEntropyMeanFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels):
         B = max(logits.shape[0], 1)
+        if 0 < logits.shape[0] <= CE_MEAN_SMALL_MAX_B:
+            mean, _, dl = ce_fwd_bwd_mean(logits, labels, want_grad=logits.requires_grad)
+            ctx.save_for_backward(dl)
+            return mean
         rows, dl = ce_fwd_bwd(logits, labels, 1.0 / B, want_grad=logits.requires_grad)
         ctx.save_for_backward(dl)
         return rows.mean()

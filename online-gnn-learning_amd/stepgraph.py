@@ -13,8 +13,8 @@ What varies between replays lives in device memory: the seeds / block arrays (st
   the zero row, so padded rows add exact zeros to every product and gradient; only the fp32 summation ORDER of split
   reductions can differ from the unpadded eager step.
 * ``SampleGraph`` (small batches) — sampling + block construction of one batch on upper-bound buffers
-  (``n1 <= B (1 + S)``, ``n0 <= n1 (1 + S)``), straight into the static block arrays the train graphs read: a step is one
-  host->device copy of ``[counter | seeds]``, the sample graph, ONE 16-byte read-back (the two source counts: they choose
+  (``n1 <= B (1 + S)``, ``n0 <= n1 (1 + S)``), straight into the static block arrays the train graphs read: a step is a
+  host write of ``[counter | seeds]`` into mapped pinned memory (the graph's first kernel reads it), the sample graph, ONE 16-byte read-back (the two source counts: they choose
   the train graph's bucket, so that the GEMMs run at the batch's size, not at 28x the upper bound), the train graph.  The
   read-back is not a copy: the graph's last kernel stores the counts and a sequence number into pinned host memory
   (``ogl_publish_i64``) and the host polls it (52 us for sample graph + read-back, 72 with a copy node + event).
@@ -150,6 +150,9 @@ class SampleGraph:
     def _body(self):
         g, b, S = self.graph, self.buf, self.buf.S
         ctr = b.head[:1]
+        # [counter | seeds]: read by the graph's first kernel straight from the pinned host buffer run() filled (mapped memory:
+        # no copy node — a 264-byte hipMemcpyAsync is an 18 us blit kernel on the device and a runtime call on the host)
+        ops.stage_segments([(self.head_host, b.head, 1 + b.B)])
         # straight into the static block arrays the train graphs read
         picks1 = ops.sample_layer_dev(g.handle, b.seeds, S, self.seed, ctr, 1)
         ops.build_block_async(b.seeds, picks1, pad_tail=True, out=(b.src1, self.counts[:1], b.lidx1))   # -1 past n1
@@ -161,8 +164,7 @@ class SampleGraph:
         """seeds_host: int64 array-like [B] (snapshot ids); ctr: this batch's Philox counter.  Returns (n1, n0)."""
         h = self.head_host
         h[0] = int(ctr)
-        h[1:] = torch.as_tensor(np.asarray(seeds_host), dtype=torch.int64)
-        self.buf.head.copy_(h, non_blocking=True)
+        h[1:] = torch.as_tensor(np.asarray(seeds_host), dtype=torch.int64)     # (not touched again until the graph's last store is seen)
         self.cuda_graph.replay()
         t0 = time.perf_counter()
         self.seq += 1

@@ -104,3 +104,28 @@ def test_output_layer_backward_in_two_launches(n_src, n_dst, S, K, N):
     # same summation order as the one-product kernel it doubles
     ref_dw, ref_db = ops.linear_bwd_weight(dy, h_dst, None, None, want_bias=True)
     assert torch.equal(dws, ref_dw) and torch.equal(db, ref_db)
+
+
+def test_fused_weight_gradients_gather_their_rows_and_small_ce_mean():
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    torch.manual_seed(3)
+    dev = "cuda"
+    T, M, K, N = 5000, 832, 128, 32
+    table = ops.empty_mat(T, K, dev).copy_(torch.randn(T, K, device=dev))
+    rows = torch.randint(0, T, (M,), device=dev); rows[::41] = -1
+    neigh = ops.empty_mat(M, K, dev).copy_(torch.randn(M, K, device=dev))
+    dy = ops.empty_mat(M, N, dev).copy_(torch.randn(M, N, device=dev))
+    dws, dwn, db, db2 = ops.out_layer_bwd_weights(dy, table, neigh, x_self_rows=rows)
+    ref_s, ref_b = ops.linear_bwd_weight(dy, table, None, rows, want_bias=True)
+    ref_n, _ = ops.linear_bwd_weight(dy, neigh, None, None, want_bias=True)
+    assert torch.equal(dws, ref_s) and torch.equal(dwn, ref_n) and torch.equal(db, ref_b) and torch.equal(db2, ref_b)
+    # cross entropy of a small batch with the mean from the same launch
+    for B, Cc in ((32, 40), (1, 3), (128, 41)):
+        logits = ops.empty_mat(B, Cc, dev).copy_(torch.randn(B, Cc, device=dev) * 3)
+        labels = torch.randint(0, Cc, (B,), device=dev)
+        mean, rows_l, dl = ops.ce_fwd_bwd_mean(logits, labels)
+        ref_rows, ref_dl = ops.ce_fwd_bwd(logits, labels, 1.0 / B)
+        assert torch.equal(rows_l, ref_rows) and torch.equal(dl, ref_dl)
+        want = torch.nn.functional.cross_entropy(logits.double(), labels)
+        assert abs(float(mean) - float(want)) <= 1e-6 * max(1.0, abs(float(want)))
