@@ -230,7 +230,7 @@ def main():
         pr.enable(); run(hsteps, hplan); pr.disable()
         torch.autograd.set_multithreading_enabled(True)
         barrier()
-        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(45)
+        pstats.Stats(pr, stream=sys.stderr).sort_stats(os.environ.get("OGL_BENCH_CPROFILE_SORT", "tottime")).print_stats(45)
 
     # ---- per-kernel HIP-event timing (same workload, separate instrumented pass) -----------------
     prof_steps = min(args.steps, bt)
