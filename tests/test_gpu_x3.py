@@ -729,3 +729,36 @@ def test_activation_images_never_outlive_their_tensor_or_its_contents():
     assert ops.take_image(v) is None or v.data_ptr() != ptr
     ops.attach_image(v, img)
     assert ops.take_image(v) is img and ops.take_image(v) is None      # popped
+
+
+def test_status_codes_of_the_round2_entry_points(ops):
+    """Wrong shapes are refused (OGL_EINVAL = -1) before anything is launched."""
+    import ctypes as C
+    from ogl_amd import _lib
+    h = _lib.lib()
+    x = torch.zeros(64, 64).cuda(); img = torch.zeros(1 << 16, dtype=torch.uint8).cuda()
+    i32 = torch.zeros(64, 64, dtype=torch.int32).cuda()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    f = C.c_float
+    # k-major weight gradient: a bias gradient needs the ones slot; interleave must cover M; gather bound within the image
+    assert h.ogl_linear_bwd_weight_x3k(p(img), 0, p(img), 64, None, 64, 64, 8, 8, 0, p(x), 64, p(x), None, None, 0, None) == -1
+    assert h.ogl_linear_bwd_weight_x3k(p(img), 1, p(img), 64, None, 64, 64, 8, 8, 1, p(x), 64, None, None, None, 0, None) == -1
+    assert h.ogl_linear_bwd_weight_x3k(p(img), 0, p(img), 64, p(img), 65, 64, 8, 8, 1, p(x), 64, None, None, None, 0, None) == -1
+    assert h.ogl_linear_bwd_weight_x3k(p(img), -2, p(img), 64, None, 64, 64, 8, 8, 1, p(x), 64, None, None, None, 0, None) == -1
+    # split-multi: more than 8 parts, a bias vector without the slot
+    assert h.ogl_x3_split_multi(p(img), 9, None) == -1
+    part = ops._X3SplitPart()
+    part.src, part.ld, part.R, part.K, part.transpose, part.append = x.data_ptr(), 64, 64, 64, 0, 0
+    part.vec1, part.image, part.image_row_bytes, part.group_offset = x.data_ptr(), img.data_ptr(), 2 * 192, 0
+    assert h.ogl_x3_split_multi(C.byref(part), 1, None) == -1
+    # ReLU backward + image: no image / bad strides
+    assert h.ogl_relu_bwd_img(p(x), 64, p(x), 64, 64, 64, p(x), 64, None, None) == -1
+    assert h.ogl_relu_bwd_img(p(x), 8, p(x), 64, 64, 64, p(x), 64, p(img), None) == -1
+    # output-layer backward: at most 64 columns, at most 4096 rows for the weights kernel
+    assert h.ogl_out_layer_bwd_inputs(p(x), 64, 64, 65, 64, p(x), 64, p(x), 64, p(i32), p(x), 64, 64, p(x), 64, p(x), 64, None) == -1
+    assert h.ogl_out_layer_bwd_weights(p(x), 64, 5000, 8, 64, p(x), 64, None, 0, p(x), 64, p(x), 64, p(x), 64, None, None, None) == -1
+    assert h.ogl_out_layer_bwd_weights(p(x), 64, 64, 8, 64, p(x), 64, p(img), 0, p(x), 64, p(x), 64, p(x), 64, None, None, None) == -1
+    # small cross entropy: one workgroup covers at most 1024 rows, and it needs the mean's address
+    lab = torch.zeros(64, dtype=torch.int64).cuda()
+    assert h.ogl_ce_fwd_bwd_mean(p(x), 64, p(lab), 1025, 8, f(1.0), None, None, 0, p(x), None) == -1
+    assert h.ogl_ce_fwd_bwd_mean(p(x), 64, p(lab), 64, 8, f(1.0), None, None, 0, None, None) == -1
