@@ -167,7 +167,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1 and strat.use_graphs in ("auto", True):
+    if strat.use_graphs in ("auto", True):
         # set-up, not measurement: let the strategy's auto policy see a cold and a warm snapshot and settle on its execution
         # mode, and let replayed steps capture their common size buckets (a capture is ~5 ms: a one-off per bucket over a
         # stream of thousands of snapshots, but a visible share of a 100-step run) before the W warm-up and the K timed steps
@@ -175,7 +175,8 @@ def main():
     run(args.warmup, plan(args.warmup))
     seeds_plan = plan(args.steps)
     stats["n0"], stats["n1"], stats["forms"] = [], [], {}
-    captures_before = strat._step_graphs().captures if strat._graphs_ok() else 0
+    graphs_on = strat._graphs_ok() or strat._graphs_ok("staged_dp")
+    captures_before = strat._step_graphs().captures if graphs_on else 0
     barrier()
     t1 = time.perf_counter()
     run(args.steps, seeds_plan)
@@ -186,8 +187,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     forms_timed = dict(stats["forms"])
-    captures_timed = (strat._step_graphs().captures - captures_before) if strat._graphs_ok() else 0
-    timed_mode = "captured hipGraph replays" if set(forms_timed) & {"sampled", "staged"} else "eager launches from Python"
+    captures_timed = (strat._step_graphs().captures - captures_before) if graphs_on else 0
+    timed_mode = "captured hipGraph replays" if set(forms_timed) & {"sampled", "staged", "staged_dp"} else "eager launches from Python"
 
     # ---- host side: time to ENQUEUE a step (no synchronisation inside the bracket): the margin between this and
     # ms_per_step is how far the step is from being launch-bound on this box's host cores
@@ -387,7 +388,9 @@ def main():
                                                       ("; %d new size bucket(s) captured inside the timed region" % captures_timed)
                                                       if timed_mode.startswith("captured") else "")
                        + ("; auto policy probe: %s" % getattr(strat, "staged_auto_probe", None) if strat.use_graphs == "auto" else ""),
-                       "parallelism": "dp%d (seed-sharded replicas, two-bucket grad all-reduce overlapped with backward)" % world,
+                       "parallelism": "dp%d (seed-sharded replicas, two-bucket grad all-reduce %s)" % (
+                           world, "after the replayed forward + backward graph; optimiser eager" if "staged_dp" in forms_timed
+                           else "overlapped with backward"),
                        "avg_unique_input_nodes_n0": round(n0_avg, 1), "avg_n1": round(n1_avg, 1), "setup_s": round(setup_s, 1)},
             "roofline": roof_gemm if roof_gemm else roof_aggr,
             "roofline_aggregator": roof_aggr,

@@ -8,6 +8,8 @@ aggregator, HIP cross-entropy and Adam — and the loader samples a whole snapsh
 """
 from __future__ import annotations
 
+import os
+import sys
 import time
 
 import numpy as np
@@ -204,8 +206,13 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         """Captured steps apply on one rank, with the capturable optimiser build_optimizer() made, without dropout (its
         stream counter is host-side) and outside per-kernel profiling; the staged form under "auto" only after the probe
         of ``_train_batches`` found the host too slow to stay ahead of the GPU."""
-        if not (self.use_graphs and self.gsync is None and getattr(self.optimizer, "capturable", False)
-                and ops._PROFILE is None and all(l.feat_drop.p == 0 for l in self.graphsage_model.layers)):
+        if not (self.use_graphs and ops._PROFILE is None and all(l.feat_drop.p == 0 for l in self.graphsage_model.layers)):
+            return False
+        if form == "staged_dp":
+            # a data-parallel replica: forward + backward captured, all-reduce and optimiser eager.  Each rank decides for itself
+            # (the collectives are the same two per step either way)
+            return self.gsync is not None and (bool(self._staged_auto) if self.use_graphs == "auto" else True)
+        if self.gsync is not None or not getattr(self.optimizer, "capturable", False):
             return False
         if form == "staged" and self.use_graphs == "auto":
             return bool(self._staged_auto)
@@ -250,7 +257,9 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
                         self.step_hook(dict(seeds=sd, loss=loss.detach(), grads=[p.grad for p in self.graphsage_model.parameters()],
                                             form="eager", ctr=ctrs[i], n0=int(input_nodes.numel()), n1=blocks[1].number_of_src_nodes()))
             return
-        probe = (self.use_graphs == "auto" and self._staged_auto is None and self._graphs_ok("sampled") and bs > 0 and n >= 8 * bs)
+        probe = (self.use_graphs == "auto" and self._staged_auto is None and bs > 0 and n >= 8 * bs
+                 and (self._graphs_ok("sampled") or (self.gsync is not None and self.use_graphs and ops._PROFILE is None
+                                                     and all(l.feat_drop.p == 0 for l in self.graphsage_model.layers))))
         if probe:
             self._staged_seen += 1
             probe = self._staged_seen >= 3                   # never decide on the first snapshots (cold: images, code objects,
@@ -408,6 +417,22 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             return loss
         # rank-sharded batch: this rank's seeds only; the gradient is that of the mean over the whole batch
         n_local = int(seeds.numel())
+        if (n_local > 0 and self.gsync is not None and self._graphs_ok("staged_dp")
+                and (on_rows is None or self.reduction != "mean")):
+            # replayed replica step: the captured graph ends with the gradients of the LOCAL mean loss in its static tensors; the
+            # all-reduce weights them by n_local / n_global (= the gradient of the mean over the whole batch), then the optimiser
+            n0, n1 = int(input_nodes.numel()), blocks[1].number_of_src_nodes()
+            with self.gsync.no_sync():                          # (a capture runs autograd for real: its hooks must not launch a collective)
+                sg = self._step_graphs().staged_step(graph, seeds, blocks, n0, n1, apply=False)
+            for p, gr in zip(self.graphsage_model.parameters(), sg.grads):
+                p.grad = gr                                   # (the previous sync left views of its flat buckets there)
+            self.gsync.sync(weight=n_local / float(n_global))
+            self.optimizer.step()
+            if on_rows is not None:
+                on_rows(seeds, sg.loss_rows.clone())
+            if self.step_hook is not None:
+                self.step_hook(dict(seeds=seeds, loss=sg.loss * (n_local / float(n_global)), grads=sg.grads, form="staged_dp", n0=n0, n1=n1))
+            return sg.loss * n_local
         loss_sum = rows = None
         if n_local > 0:
             batch_labels = ops.gather_i64(graph.ndata["target"], seeds)

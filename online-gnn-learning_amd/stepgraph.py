@@ -28,7 +28,8 @@ replay on (tools/graph_probe.py); every fill on these paths is a kernel.
 Which steps are replayed is the strategy's policy (``HipSupervisedGraphSage.use_graphs``): small batches always; large,
 loader-fed batches only when a timed snapshot shows the host cannot keep ahead of the GPU — replayed nodes run ~1 us
 further apart than eagerly queued launches, so on a fast host eager is 2-4 % faster at the Reddit rung.
-Not captured: steps under torch.distributed (the gradient all-reduce stays eager), dropout > 0 (its counter is host-side).
+Under torch.distributed a replica's step is captured up to and including backward (``apply=False``); the gradient all-reduce
+and the optimiser stay eager (two collectives + one launch per step).  Not captured: dropout > 0 (its counter is host-side).
 """
 from __future__ import annotations
 
@@ -72,15 +73,18 @@ class TrainStepGraph:
     """One captured train step over ``buf`` restricted to (n1_pad, n0_pad) rows.
     ``loss_fn(logits, labels) -> (scalar loss to differentiate, per-seed losses or None)``."""
 
-    def __init__(self, model, optimizer, graph, buf, n1_pad, n0_pad, loss_fn, pool=None):
-        self.model, self.opt, self.graph, self.buf, self.loss_fn = model, optimizer, graph, buf, loss_fn
+    def __init__(self, model, optimizer, graph, buf, n1_pad, n0_pad, loss_fn, pool=None, apply=True):
+        # apply=False: forward + loss + backward only — the step of a data-parallel replica, whose gradients are all-reduced
+        # (eagerly: the collective stays outside the graph) before the optimiser runs
+        self.model, self.opt, self.graph, self.buf, self.loss_fn, self.apply = model, optimizer, graph, buf, loss_fn, bool(apply)
         self.n1_pad, self.n0_pad = int(n1_pad), int(n0_pad)
         assert self.n1_pad <= buf.n1_cap and self.n0_pad <= buf.n0_cap
         self.loss = self.loss_rows = None
         self.cuda_graph = torch.cuda.CUDAGraph()
         self._capture(pool)
 
-    def _body(self, apply=True):
+    def _body(self, apply=None):
+        apply = self.apply if apply is None else apply
         g, b = self.graph, self.buf
         src0, src1, lidx0 = b.src0[:self.n0_pad], b.src1[:self.n1_pad], b.lidx0[:self.n1_pad]
         blocks = [sampling.Block(src0, src1, lidx0), sampling.Block(src1, b.seeds, b.lidx1)]
@@ -96,8 +100,9 @@ class TrainStepGraph:
 
     def _capture(self, pool):
         global _WARMED
-        assert getattr(self.opt, "capturable", False), "a captured step needs optim.Adam(capturable=True)"
-        self.opt.prepare_capture()
+        if self.apply:
+            assert getattr(self.opt, "capturable", False), "a captured step needs optim.Adam(capturable=True)"
+            self.opt.prepare_capture()
         ops.unit_grad(self.graph.device)
         ops._static_image(self.graph.feat_table)            # built outside the capture (a one-off 850 MB split pass)
         if not _WARMED:
@@ -192,7 +197,7 @@ class StepGraphCache:
         self.graphs = collections.OrderedDict()
         self.captures = self.evictions = 0
 
-    def _train(self, graph, buf, key, n1_pad, n0_pad):
+    def _train(self, graph, buf, key, n1_pad, n0_pad, apply=True):
         sg = self.graphs.get(key)
         if sg is None:
             while len(self.graphs) >= self.MAX_GRAPHS:
@@ -201,7 +206,7 @@ class StepGraphCache:
                     self.bufs.pop(old_key, None)
                 del old
                 self.evictions += 1
-            sg = self.graphs[key] = TrainStepGraph(self.model, self.opt, graph, buf, n1_pad, n0_pad, self.loss_fn)
+            sg = self.graphs[key] = TrainStepGraph(self.model, self.opt, graph, buf, n1_pad, n0_pad, self.loss_fn, apply=apply)
             self.captures += 1
         else:
             self.graphs.move_to_end(key)
@@ -223,15 +228,16 @@ class StepGraphCache:
         sg.last_sizes = (n0, n1)
         return sg
 
-    def staged_step(self, graph, seeds, blocks, n0, n1):
-        """One step of a loader batch: stage its block arrays into the bucket's static buffers, replay its train graph."""
+    def staged_step(self, graph, seeds, blocks, n0, n1, apply=True):
+        """One step of a loader batch: stage its block arrays into the bucket's static buffers, replay its train graph.
+        ``apply=False``: the graph stops after backward (the gradients are in ``sg.grads``)."""
         B = int(seeds.numel())
         n0_pad, n1_pad = round_up(n0, N0_BUCKET), round_up(n1, N1_BUCKET)
-        bkey = ("staged", id(graph), B, n0_pad, n1_pad)
+        bkey = ("staged", id(graph), B, n0_pad, n1_pad, bool(apply))
         buf = self.bufs.get(bkey)
         if buf is None:
             buf = self.bufs[bkey] = BlockBuffers(B, self.S, n1_pad, n0_pad, graph.device)
-        sg = self._train(graph, buf, bkey, n1_pad, n0_pad)
+        sg = self._train(graph, buf, bkey, n1_pad, n0_pad, apply=apply)
         b0, b1 = blocks
         ops.stage_segments([(b0.src_ids, buf.src0, n0), (b1.src_ids, buf.src1, n1), (b0.local_idx, buf.lidx0, n1 * self.S),
                             (b1.local_idx, buf.lidx1, B * self.S), (seeds, buf.seeds, B)])

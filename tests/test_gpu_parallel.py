@@ -196,3 +196,57 @@ def test_reddit_pbr_two_ranks_replicated_and_partitioned(tmp_path):
         # (the deliberately large SGD step leaves logits of a few hundred: a loss is a difference of numbers of that size,
         # known to ~1e-4 absolute whatever its own magnitude)
         np.testing.assert_allclose(a["loss_c"], other["loss_c"], rtol=1e-3, atol=1e-3)
+
+
+def _run_dp_steps(rank, world, port, out_path, graphs):
+    """Two replicas, RBR train updates of full batches: eager launches vs replayed (captured up to backward) steps."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops, sampling, synthetic
+    from ogl_amd.graphsage import GraphSAGE
+    from ogl_amd.graphsage.model import PrioritizedHipSupervisedGraphSage, RandomHipSupervisedGraphSage
+    from ogl_amd.prioritized_replay import LossPriority
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    np.random.seed(3); random.seed(3); torch.manual_seed(3); sampling.seed(3)
+    feat_size, labels, dyn, n_classes, _ = synthetic.load("pubmed", snapshots=3, device="cuda")
+    dyn.evolve()
+    g = dyn.get_graph()
+    res = {}
+    for name, cls, extra in (("rnd", RandomHipSupervisedGraphSage, ()), ("pri", PrioritizedHipSupervisedGraphSage, (LossPriority(),))):
+        torch.manual_seed(9)
+        model = GraphSAGE(feat_size, 32, n_classes, 1, F.relu, 0, "pool", edge_feats=0, pool_feats=32).cuda()
+        st = cls(model, 3, 64, labels, 10, *extra, cuda=True, batch_full=256)
+        st.use_graphs = graphs
+        st.build_optimizer()
+        st.optimizer = torch.optim.SGD(model.parameters(), lr=0.05)        # (Adam amplifies summation-order noise of ~0 gradients)
+        forms, rows = [], []
+        st.step_hook = lambda info: forms.append(info["form"])
+        seeds = np.random.default_rng(1).choice(g.n_present, 3 * 64 + 10, replace=False).astype(np.int64)
+        sampling.seed(8)
+        st._train_batches(g, seeds, 64, on_rows=(lambda s_, r_: rows.append(r_.cpu())) if extra else None)
+        res[name] = dict(weights=[p.detach().cpu().clone() for p in model.parameters()], forms=forms,
+                         rows=torch.cat(rows) if rows else None)
+    mine = torch.cat([w.reshape(-1) for w in res["rnd"]["weights"]])
+    other = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(other, mine)
+    assert all(torch.equal(o, other[0]) for o in other)                      # the replicas stay identical
+    dist.barrier(); dist.destroy_process_group()
+    if rank == 0:
+        torch.save(res, out_path)
+
+
+def test_data_parallel_steps_replayed_as_graphs_match_eager(tmp_path):
+    eager, graph = str(tmp_path / "eager.pt"), str(tmp_path / "graph.pt")
+    _spawn(_run_dp_steps, 2, (eager, False))
+    _spawn(_run_dp_steps, 2, (graph, True))
+    a, b = torch.load(eager, weights_only=False), torch.load(graph, weights_only=False)
+    for name in ("rnd", "pri"):
+        # 3 full batches of 64 (32 per rank) + a ragged one of 10 (5 per rank: its own bucket)
+        assert a[name]["forms"] == ["sharded"] * 4 and b[name]["forms"] == ["staged_dp"] * 4
+        for x, y in zip(a[name]["weights"], b[name]["weights"]):
+            torch.testing.assert_close(x, y, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(b["pri"]["rows"].numpy(), a["pri"]["rows"].numpy(), rtol=2e-4, atol=1e-6)
