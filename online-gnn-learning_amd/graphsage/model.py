@@ -209,9 +209,9 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         if not (self.use_graphs and ops._PROFILE is None and all(l.feat_drop.p == 0 for l in self.graphsage_model.layers)):
             return False
         if form == "staged_dp":
-            # a data-parallel replica: forward + backward captured, all-reduce and optimiser eager.  Each rank decides for itself
-            # (the collectives are the same two per step either way)
-            return self.gsync is not None and (bool(self._staged_auto) if self.use_graphs == "auto" else True)
+            # a data-parallel replica: forward + backward captured, all-reduce and optimiser eager.  OPT-IN (use_graphs = True):
+            # a stream capture next to RCCL's watchdog thread has not been rehearsed on real links, so "auto" never picks it
+            return self.gsync is not None and self.use_graphs is True
         if self.gsync is not None or not getattr(self.optimizer, "capturable", False):
             return False
         if form == "staged" and self.use_graphs == "auto":
@@ -257,9 +257,7 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
                         self.step_hook(dict(seeds=sd, loss=loss.detach(), grads=[p.grad for p in self.graphsage_model.parameters()],
                                             form="eager", ctr=ctrs[i], n0=int(input_nodes.numel()), n1=blocks[1].number_of_src_nodes()))
             return
-        probe = (self.use_graphs == "auto" and self._staged_auto is None and bs > 0 and n >= 8 * bs
-                 and (self._graphs_ok("sampled") or (self.gsync is not None and self.use_graphs and ops._PROFILE is None
-                                                     and all(l.feat_drop.p == 0 for l in self.graphsage_model.layers))))
+        probe = (self.use_graphs == "auto" and self._staged_auto is None and self._graphs_ok("sampled") and bs > 0 and n >= 8 * bs)
         if probe:
             self._staged_seen += 1
             probe = self._staged_seen >= 3                   # never decide on the first snapshots (cold: images, code objects,
