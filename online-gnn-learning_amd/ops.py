@@ -804,7 +804,7 @@ def _dual_fwd_images(x, w, bias, bias2, x2, w2, relu, x_rows, x2_rows):
     if x2img is None or (x.data_ptr(), _ld(x), x.shape[1]) not in _X3_TABLES:
         return None
     ximg = _static_image(x)
-    if ximg is None:
+    if ximg is None or ximg.nbytes >= (1 << 32):             # (the two-part product lives in the 32-bit-offset kernel)
         return None
     take_image(x2)
     wcat = weight_image("cat", w, w2, bias, bias2)
@@ -913,11 +913,11 @@ def _row_image_for(x, x_rows, x_img):
     (``x_img``), or the resident table's."""
     if not K_MAJOR_WEIGHT_GRADS:
         return None
-    if x_img is not None:
-        return x_img
-    if x_rows is not None and _static_key(x) in _X3_TABLES:
-        return _static_image(x)
-    return None
+    img = x_img
+    if img is None and x_rows is not None and _static_key(x) in _X3_TABLES:
+        img = _static_image(x)
+    # (the k-major product addresses its images with 32-bit offsets: a table image of 4 GB and more keeps the transposed-image form)
+    return img if (img is not None and img.nbytes < (1 << 32)) else None
 
 
 K_MAJOR_DY = os.environ.get("OGL_BWW_KMAJOR_DY") != "0"    # ... and dy's own row-major image when its producer wrote one
