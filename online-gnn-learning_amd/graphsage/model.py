@@ -8,8 +8,6 @@ aggregator, HIP cross-entropy and Adam — and the loader samples a whole snapsh
 """
 from __future__ import annotations
 
-import os
-import sys
 import time
 
 import numpy as np
