@@ -70,24 +70,57 @@ def parse():
     return ap.parse_args()
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start N ranks as FRESH child processes.  This parent never
+    touches HIP (no torch.cuda call except device_count(), which does not initialise the runtime on this image) and does not
+    exec: it waits for `python -m torch.distributed.run` and exits with its code; rank 0 of the children prints the JSON line."""
+    import socket
+    import subprocess
+    if args.dist_backend == "nccl":
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            print("bench.py: --gpus %d over RCCL needs %d GPUs, this node shows %d (use --dist-backend gloo to rehearse the "
+                  "N-rank control flow on fewer)" % (args.gpus, args.gpus, ndev), file=sys.stderr)
+            return 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); they must agree" % (args.gpus, world))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
     ndev = torch.cuda.device_count()
-    if args.dist_backend == "nccl" and world > 1 and local_rank >= ndev:
-        raise RuntimeError("rank %d needs its own GPU (found %d); use --dist-backend gloo to rehearse on one GPU" % (local_rank, ndev))
+    if args.dist_backend == "nccl" and world > 1 and ndev < world:
+        raise SystemExit("bench.py: %d ranks over RCCL need %d GPUs (found %d); use --dist-backend gloo to rehearse on one GPU"
+                         % (world, world, ndev))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
     torch.cuda.set_device(local_rank % max(ndev, 1))
+    ranks_seen = 1
     if world > 1:
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        one = torch.ones(1, dtype=torch.int64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(one)                                 # the first collective of the run: every rank is really there
+        ranks_seen = int(one.item())
+        if ranks_seen != args.gpus:
+            raise SystemExit("bench.py: %d rank(s) answered the first all-reduce, --gpus %d" % (ranks_seen, args.gpus))
+    args.ranks_seen = ranks_seen
 
     import ogl_amd  # noqa: F401
     from ogl_amd import ops, optim, parallel, sampling, synthetic
@@ -171,7 +204,7 @@ def main():
         # set-up, not measurement: let the strategy's auto policy see a cold and a warm snapshot and settle on its execution
         # mode, and let replayed steps capture their common size buckets (a capture is ~5 ms: a one-off per bucket over a
         # stream of thousands of snapshots, but a visible share of a 100-step run) before the W warm-up and the K timed steps
-        run(max(3 * bt, 120), plan(max(3 * bt, 120)))
+        run(max(6 * bt, 120), plan(max(6 * bt, 120)))        # (the policy times snapshots 3-5 and decides on their median)
     run(args.warmup, plan(args.warmup))
     seeds_plan = plan(args.steps)
     stats["n0"], stats["n1"], stats["forms"] = [], [], {}
@@ -326,16 +359,23 @@ def main():
 
         # the reference's own path is one Python thread driving torch-CPU intra-op threads (n_sampling_workers = 0,
         # R/train/__main__.py:39); more threads than physical cores (or than ~64) only oversubscribe its small GEMMs
-        cores = min(os.cpu_count() or 1, 64)
+        ncpu = os.cpu_count() or 1
+        cores = min(ncpu, 64)
         multi = cpu_leg(cores, B)
-        single = cpu_leg(1, max(32, B // 4))          # a quarter batch per step keeps the one-thread leg inside the budget
+        multi_all = None
+        if ncpu > cores:                              # a bigger host: also all of its threads, and the better of the two counts
+            multi_all = cpu_leg(ncpu, B)
+            if multi_all["value"] > multi["value"]:
+                multi, multi_all, cores = multi_all, multi, ncpu
+        single = cpu_leg(1, B)                        # the same batch as every other leg (>= 3 timed steps, ~2.5 s each)
         cpu_baseline = dict(value=multi["value"], unit="vertices/s", cores=cores, kind="port",
                             sample="1 warm-up + %d timed RBR train steps of %d seeds (same graph, shapes and sampler) in %.1f s; "
                                    "torch-CPU fp32, %d threads (host has %d)" % (multi["steps"], B, multi["seconds"], cores,
                                                                                 os.cpu_count() or 1),
+                            other_thread_count=(dict(value=multi_all["value"], cores=multi_all["threads"], steps=multi_all["steps"])
+                                                if multi_all else None),
                             single_thread=dict(value=single["value"], unit="vertices/s", cores=1,
-                                               sample="1 warm-up + %d timed steps of %d seeds in %.1f s, 1 thread (the per-seed cost "
-                                                      "of a smaller batch is slightly higher: fewer shared input rows)"
+                                               sample="1 warm-up + %d timed steps of %d seeds in %.1f s, 1 thread"
                                                       % (single["steps"], single["batch"], single["seconds"])))
         torch.set_num_threads(os.cpu_count() or 1)
 
@@ -374,7 +414,8 @@ def main():
             del src_b, dst_b
         line = {
             "metric": "streamed vertices/sec (RBR train update), %s-shaped stream depth=2 samples=%d" % (wl["dataset"], S),
-            "value": round(value, 1), "unit": "vertices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 1), "unit": "vertices/s", "n_gpus": world, "ranks_seen": args.ranks_seen,
+            "dist_backend": (args.dist_backend if world > 1 else None), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -497,7 +538,8 @@ def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size,
         assert out.numel() == total_batches(args.steps) * B and bool(torch.isfinite(out).all())
         print(json.dumps({
             "metric": "streamed vertices/sec (PBR priority forward), %s-shaped stream depth=2 samples=%d" % (wl["dataset"], S),
-            "value": round(total_batches(args.steps) * B / elapsed, 1), "unit": "vertices/s", "n_gpus": world, "steps": args.steps,
+            "value": round(total_batches(args.steps) * B / elapsed, 1), "unit": "vertices/s", "n_gpus": world,
+            "ranks_seen": args.ranks_seen, "dist_backend": (args.dist_backend if world > 1 else None), "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"gemm_arithmetic": gemm_desc(args.gemm), "workload": "%s: last snapshot (N=%d), F=%d H=%d C=%d, pool(max), batch_full=%d/GPU, inference sample+forward+CE(none), "

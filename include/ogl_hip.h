@@ -53,6 +53,9 @@ typedef struct ogl_graph ogl_graph_t;
 typedef void* ogl_stream_t; /* hipStream_t */
 
 int ogl_version(void);
+/* Hash of the sources (csrc/ and include/ plus compiler flags) this binary was built from; build.py compares it with the tree
+ * and rebuilds on mismatch ("unstamped" when compiled without the recipe). */
+const char* ogl_source_hash(void);
 const char* ogl_status_string(int status);
 int ogl_last_hip_error(void); /* hipError_t of the most recent OGL_EHIP on this thread */
 

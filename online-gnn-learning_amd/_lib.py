@@ -20,6 +20,7 @@ _u64 = C.c_uint64
 # name -> (restype, argtypes): mirrors include/ogl_hip.h one to one
 SIGNATURES = {
     "ogl_version": (_i, []),
+    "ogl_source_hash": (C.c_char_p, []),
     "ogl_status_string": (C.c_char_p, [_i]),
     "ogl_last_hip_error": (_i, []),
     "ogl_set_gemm_mode": (_i, [_i]),

@@ -8,6 +8,11 @@
 thread_local int g_ogl_last_hip_error = 0;
 
 extern "C" int ogl_version(void) { return OGL_VERSION; }
+#ifndef OGL_SOURCE_HASH
+#define OGL_SOURCE_HASH "unstamped"
+#endif
+static const char k_source_stamp[] = "OGL_SOURCE_STAMP:" OGL_SOURCE_HASH;     // (build.py finds the marker in the file's bytes)
+extern "C" const char* ogl_source_hash(void) { return k_source_stamp + 17; }
 extern "C" int ogl_last_hip_error(void) { return g_ogl_last_hip_error; }
 extern "C" const char* ogl_status_string(int s) {
   switch (s) {

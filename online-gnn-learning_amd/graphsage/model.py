@@ -59,8 +59,16 @@ class SupervisedGraphSage:
         # mode while the host's enqueue time per step stays under the GPU's time per step
         self.use_graphs = "auto"
         self._staged_auto = None    # "auto": None = undecided, True / False after the probe
-        self._staged_seen = 0       # eligible snapshots met so far (the first one is cold: images, code objects, allocator)
+        self._staged_seen = 0       # eligible snapshots met so far (the first ones are cold: images, code objects, allocator)
+        self._staged_probes = []    # (host seconds, GPU seconds) of the probed snapshots of the current decision
+        self._staged_decided_at = 0
+        self.staged_auto_log = []   # every decision taken (the run log of the policy)
         self.STAGED_AUTO_HOST_FRACTION = 0.9
+        self.STAGED_AUTO_PROBES = 3       # snapshots timed per decision; the MEDIAN host / GPU ratio decides (one snapshot's wall
+                                          # time carries allocator / GC hiccups and back-pressure)
+        self.STAGED_AUTO_REPROBE = 500    # eligible snapshots after which the decision is re-taken (0: never) — the graph grows
+                                          # and the host's load changes over a 5 000-snapshot stream.  use_graphs = True / False
+                                          # is the explicit override (bench.py --graphs / --no-graphs)
         self.step_hook = None       # instrumentation (tests, bench): called after every train step with a dict
 
     def build_optimizer(self):
@@ -173,8 +181,7 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         bs = int(batch_size)
         if bs <= 0:
             raise ValueError("batch_size should be a positive integer value, but got batch_size={}".format(bs))
-        if world > 1:
-            parallel.assert_replicated(seeds, "the snapshot's train seeds")
+        parallel.assert_replicated(seeds, "the snapshot's train seeds")          # (a no-op on one rank)
         seeds = seeds.to(graph.device).contiguous()
         full = [seeds[s0:s0 + bs] for s0 in range(0, seeds.numel(), bs)]
         local = [b[slice(*parallel.shard_range(b.numel(), rank, world))] for b in full]
@@ -255,11 +262,15 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
                         self.step_hook(dict(seeds=sd, loss=loss.detach(), grads=[p.grad for p in self.graphsage_model.parameters()],
                                             form="eager", ctr=ctrs[i], n0=int(input_nodes.numel()), n1=blocks[1].number_of_src_nodes()))
             return
-        probe = (self.use_graphs == "auto" and self._staged_auto is None and self._graphs_ok("sampled") and bs > 0 and n >= 8 * bs)
-        if probe:
+        probe = False
+        if self.use_graphs == "auto" and self._graphs_ok("sampled") and bs > 0 and n >= 8 * bs:
             self._staged_seen += 1
-            probe = self._staged_seen >= 3                   # never decide on the first snapshots (cold: images, code objects,
-                                                             # allocator pools, Python's own caches — the host side warms up last)
+            if (self._staged_auto is not None and self.STAGED_AUTO_REPROBE
+                    and self._staged_seen - self._staged_decided_at >= self.STAGED_AUTO_REPROBE):
+                self._staged_auto, self._staged_probes = None, []        # re-take the decision (this snapshot runs eagerly)
+            # never time the first snapshots (cold: images, code objects, allocator pools, Python's own caches — the host
+            # side warms up last)
+            probe = self._staged_auto is None and self._staged_seen >= 3
         if probe:                                            # time this snapshot's eager update: host enqueue vs GPU
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t_host, first = 0.0, True
@@ -271,8 +282,17 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             t_host = time.perf_counter() - t0
             ev1.record(); ev1.synchronize()
             t_gpu = ev0.elapsed_time(ev1) / 1e3
-            self._staged_auto = t_host > self.STAGED_AUTO_HOST_FRACTION * t_gpu
-            self.staged_auto_probe = dict(host_s=t_host, gpu_s=t_gpu, graphs=self._staged_auto)
+            self._staged_probes.append((t_host, t_gpu))
+            if len(self._staged_probes) >= self.STAGED_AUTO_PROBES:
+                ratios = sorted(h / max(g_, 1e-9) for h, g_ in self._staged_probes)
+                med = ratios[len(ratios) // 2]
+                self._staged_auto = med > self.STAGED_AUTO_HOST_FRACTION
+                self._staged_decided_at = self._staged_seen
+                self.staged_auto_probe = dict(host_s=round(float(np.median([h for h, _ in self._staged_probes])), 5),
+                                              gpu_s=round(float(np.median([g_ for _, g_ in self._staged_probes])), 5),
+                                              host_over_gpu=[round(r, 3) for r in ratios], graphs=self._staged_auto,
+                                              decided_at_snapshot=self._staged_seen)
+                self.staged_auto_log.append(self.staged_auto_probe)
 
     def _eager_step(self, graph, blocks, input_nodes, seeds, on_rows=None):
         self.optimizer.zero_grad()
@@ -372,8 +392,7 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             return None
         n_all = int(seeds_all.numel())
         rank, world = parallel.rank_world()
-        if world > 1:
-            parallel.assert_replicated(seeds_all, "the evaluation vertices")
+        parallel.assert_replicated(seeds_all, "the evaluation vertices")
         last = self.graphsage_model.layers[-1]
         C_ = int((last.fc_self if last.fc_self is not None else last.fc_neigh).weight.shape[0])
         cm = torch.zeros(C_ * C_, dtype=torch.int64, device=graph.device)
@@ -382,7 +401,7 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             for seeds, logits in self._inference_batches(graph, seeds_all, shard=True):
                 ops.argmax_confusion(logits, ops.gather_i64(graph.ndata["target"], seeds), cm, want_pred=False)
         cm = cm.cpu()
-        if world > 1:
+        if parallel.is_distributed():
             import torch.distributed as dist
             if dist.get_backend() == "gloo":
                 dist.all_reduce(cm, op=dist.ReduceOp.SUM)
@@ -539,8 +558,7 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
         # are all-gathered, so every replica of the replay buffer receives every priority (north star: "PBR sharded across
         # the GPUs"); the lengths every rank contributes follow from the partition, only values travel
         rank, world = parallel.rank_world()
-        if world > 1:
-            parallel.assert_replicated(seeds_all, "the priority-forward seeds")
+        parallel.assert_replicated(seeds_all, "the priority-forward seeds")
         losses = []
         with torch.no_grad():
             for seeds, scores in self._inference_batches(graph, seeds_all, shard=True):
@@ -548,7 +566,7 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
                 loss_rows, _ = ops.ce_fwd_bwd(scores, batch_labels, want_grad=False)
                 losses.append(loss_rows)
         local = torch.cat(losses) if losses else torch.zeros(0, device=graph.device)
-        if world > 1:
+        if parallel.is_distributed():
             counts = []
             for r in range(world):
                 _, _, a, b = parallel.batch_shard(seeds_all.numel(), self.batch_full, r, world)

@@ -462,15 +462,15 @@ def out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src):
     return dx, dp
 
 
-def out_layer_bwd_weights(dy, x_self, x_neigh, want_bias=True, x_self_rows=None):
+def out_layer_bwd_weights(dy, x_self, x_neigh, want_bias=True, x_self_rows=None, dws_out=None, dwn_out=None):
     """(dw_self, dw_neigh [N, K], db, db2) of a few-column combine in one launch; ``x_self_rows`` gathers x_self's rows from a table."""
     dy = as_mat(dy); x_self = as_mat(x_self); x_neigh = as_mat(x_neigh)
     M, N = dy.shape
     assert x_neigh.shape[0] == M and (x_self_rows.numel() if x_self_rows is not None else x_self.shape[0]) == M
     K = x_self.shape[1]
     dev = dy.device
-    dws = torch.empty((N, K), dtype=torch.float32, device=dev)
-    dwn = torch.empty((N, K), dtype=torch.float32, device=dev)
+    dws = dws_out if dws_out is not None else torch.empty((N, K), dtype=torch.float32, device=dev)
+    dwn = dwn_out if dwn_out is not None else torch.empty((N, K), dtype=torch.float32, device=dev)
     db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
     db2 = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
     _launch("ogl_out_layer_bwd_weights", _lib.lib().ogl_out_layer_bwd_weights, _ptr(dy), _ld(dy), M, N, K, _ptr(x_self), _ld(x_self),
@@ -556,14 +556,14 @@ def transpose(src, rows=None):
     return dst
 
 
-def linear_bwd_weight_t(dyT, xT, want_bias=True):
+def linear_bwd_weight_t(dyT, xT, want_bias=True, dw_out=None):
     """dw [N, K] = dyT [N, M] @ xT [K, M].T, db = dyT.sum(1): the weight gradient as a reduction-contiguous product."""
     dyT = as_mat(dyT); xT = as_mat(xT)
     N, M = dyT.shape
     K = xT.shape[0]
     assert xT.shape[1] == M
     dev = dyT.device
-    dw = torch.empty((N, K), dtype=torch.float32, device=dev)
+    dw = dw_out if dw_out is not None else torch.empty((N, K), dtype=torch.float32, device=dev)
     db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
     nbytes = int(_lib.lib().ogl_linear_bwd_weight_t_workspace_bytes(M, N, K))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
@@ -833,12 +833,12 @@ def pool_bwd_x3(dout, argmax, relu_out, idx32, n_src):
     return X3Image(buf, d, 32 * G)
 
 
-def linear_bwd_weight_x3(dyT_img, xT_img, want_bias=True):
+def linear_bwd_weight_x3(dyT_img, xT_img, want_bias=True, dw_out=None):
     """dw [N, K], db [N] from the images of dy.T ([N rows, M]) and [x | 1].T ([K + 1 rows, M])."""
     N, M, K = dyT_img.rows, dyT_img.K, xT_img.rows - 1
     assert xT_img.K == M
     dev = dyT_img.buf.device
-    dw = torch.empty((N, K), dtype=torch.float32, device=dev)
+    dw = dw_out if dw_out is not None else torch.empty((N, K), dtype=torch.float32, device=dev)
     db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
     nbytes = int(_lib.lib().ogl_linear_bwd_weight_x3_workspace_bytes(M, N, K))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
@@ -847,7 +847,8 @@ def linear_bwd_weight_x3(dyT_img, xT_img, want_bias=True):
     return dw, db
 
 
-def linear_bwd_weight_x3k(dyT_img, x_img, M, K, x_rows=None, x_nrows=None, interleave=0, want_bias=True, want_bias2=False, dy_rows=False):
+def linear_bwd_weight_x3k(dyT_img, x_img, M, K, x_rows=None, x_nrows=None, interleave=0, want_bias=True, want_bias2=False, dy_rows=False,
+                          dw_out=None):
     """dw [N, K] (and db, db2: two copies of the bias gradient) from the image of dy.T and the ROW-MAJOR image of x (M reduction
     rows, gathered by ``x_rows``): no transposed image of x.  The bias gradient needs the ones slot in ``x_img`` (K + 1).
     ``dy_rows``: ``dyT_img`` is the row-major image of dy itself ([M, N]: what relu_bwd_img / x3_split build), read k-major too."""
@@ -860,7 +861,7 @@ def linear_bwd_weight_x3k(dyT_img, x_img, M, K, x_rows=None, x_nrows=None, inter
         N = dyT_img.rows
         assert dyT_img.K == (32 * interleave if interleave else M), (dyT_img.K, M, interleave)
     dev = dyT_img.buf.device
-    dw = torch.empty((N, K), dtype=torch.float32, device=dev)
+    dw = dw_out if dw_out is not None else torch.empty((N, K), dtype=torch.float32, device=dev)
     db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
     db2 = torch.empty(N, dtype=torch.float32, device=dev) if want_bias2 else None
     nbytes = int(_lib.lib().ogl_linear_bwd_weight_x3k_workspace_bytes(M, interleave, N, K, 1 if has_ones else 0))
@@ -930,14 +931,14 @@ def _dy_rows_image(dy, dy_img):
     return None
 
 
-def weight_grad(dy, x, x_rows=None, want_bias=True, dyT=None, x_img=None, dy_img=None):
+def weight_grad(dy, x, x_rows=None, want_bias=True, dyT=None, x_img=None, dy_img=None, dw_out=None):
     """dW, db of a projection.  In the bf16x6 / auto arithmetic the product runs on the split-bf16 image kernel: x as the row-major
     image its forward already had (``x_img``, or the resident table's: read k-major, no transposed copy), dy likewise when its
     producer wrote its image (``dy_img``), else as the image of dy^T; without a row-major image of x both operands are transposed
     images; the exact-fp32 mode keeps the direct k-major kernel.  ``dyT`` lets the two weight gradients of a dual-input Linear
     share one transpose."""
     if _MODE["name"] == "f32" or dy.shape[0] < 1024:
-        return linear_bwd_weight(dy, x, None, x_rows, want_bias=want_bias)
+        return linear_bwd_weight(dy, x, None, x_rows, want_bias=want_bias, dw_out=dw_out)
     K = x.shape[1]
     rimg = _row_image_for(x, x_rows, x_img) if dy.shape[0] >= X3_BWW_MIN_ROWS else None
     if rimg is not None and not (rimg.K == K + 1 or (rimg.K == K and not want_bias)):
@@ -945,17 +946,17 @@ def weight_grad(dy, x, x_rows=None, want_bias=True, dyT=None, x_img=None, dy_img
     dyr = _dy_rows_image(dy, dy_img) if rimg is not None else None
     if dyr is not None:
         return linear_bwd_weight_x3k(dyr, rimg, dy.shape[0], K, x_rows=x_rows, x_nrows=x.shape[0] if x_rows is not None else None,
-                                     want_bias=want_bias, dy_rows=True)[:2]
+                                     want_bias=want_bias, dy_rows=True, dw_out=dw_out)[:2]
     if dyT is None:
         dyT = transposed_operand(dy)
     if isinstance(dyT, X3Image):
         if rimg is not None:
             return linear_bwd_weight_x3k(dyT, rimg, dy.shape[0], K, x_rows=x_rows, x_nrows=x.shape[0] if x_rows is not None else None,
-                                         want_bias=want_bias)[:2]
+                                         want_bias=want_bias, dw_out=dw_out)[:2]
     if isinstance(dyT, X3Image):
         # both operands as bf16x3 images of their transposes (one fused gather + transpose + split pass each)
-        return linear_bwd_weight_x3(dyT, x3_split_t(x, x_rows, ones_row=True), want_bias=want_bias)
-    return linear_bwd_weight_t(dyT, transpose(x, x_rows), want_bias=want_bias)
+        return linear_bwd_weight_x3(dyT, x3_split_t(x, x_rows, ones_row=True), want_bias=want_bias, dw_out=dw_out)
+    return linear_bwd_weight_t(dyT, transpose(x, x_rows), want_bias=want_bias, dw_out=dw_out)
 
 
 def transposed_operand(dy):
@@ -1051,6 +1052,32 @@ def adam_step_multi_dev(ps, gs, ms, vs, step_dev, scalars_dev, lr=1e-3, beta1=0.
 # --------------------------------------------------------------------------------------------
 # autograd glue
 # --------------------------------------------------------------------------------------------
+# Gradient sinks (data parallelism): a parameter registered here by parallel.GradSynchronizer has a slot in a persistent flat
+# all-reduce bucket; the weight-gradient kernels write dW straight into that slot (``dw_out``), autograd adopts the slot as
+# ``p.grad``, and the collective runs in place on the bucket: no torch.cat, no copy back, no allocation per step.
+_GRAD_SINKS = {}
+
+
+def register_grad_sink(param, owner, index):
+    import weakref
+    _GRAD_SINKS[param.data_ptr()] = (weakref.ref(owner), int(index))
+
+
+def _dw_out(w, N, K):
+    """The gradient slot of weight ``w`` ([N, K], contiguous) or None (then the kernel wrapper allocates)."""
+    if not _GRAD_SINKS or w is None:
+        return None
+    ent = _GRAD_SINKS.get(w.data_ptr())
+    if ent is None:
+        return None
+    owner = ent[0]()
+    if owner is None:
+        _GRAD_SINKS.pop(w.data_ptr(), None)
+        return None
+    t = owner.grad_slot(ent[1])
+    return t if (t is not None and tuple(t.shape) == (int(N), int(K)) and not _capturing()) else None
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, x2, w2, relu, x_rows, x2_rows, bias2=None):
@@ -1103,12 +1130,13 @@ class _LinearFn(torch.autograd.Function):
             if rimg is not None and rimg.K == x.shape[1] + 1:
                 both = linear_bwd_weight_x3k(dyr if dyr is not None else dyT, rimg, dy.shape[0], x.shape[1], x_rows=x_rows,
                                              x_nrows=x.shape[0] if x_rows is not None else None, want_bias=True, want_bias2=True,
-                                             dy_rows=dyr is not None)
+                                             dy_rows=dyr is not None, dw_out=_dw_out(w, *w.shape))
         if (both is None and x2 is not None and x2_rows is None and need[1] and need[4] and ctx.has_bias and ctx.has_bias2
                 and dy.shape[0] < 1024 and x.shape[1] == x2.shape[1] and _out_layer_fits(dy, x, w, w2)):
             # a short, narrow combine (the first layer at the 32-seed rungs): both weight gradients and both bias-gradient copies
             # from one launch instead of two latency-bound ones
-            dw, dw2, db, db2 = out_layer_bwd_weights(dy, x, x2, want_bias=True, x_self_rows=x_rows)
+            dw, dw2, db, db2 = out_layer_bwd_weights(dy, x, x2, want_bias=True, x_self_rows=x_rows, dws_out=_dw_out(w, *w.shape),
+                                                     dwn_out=_dw_out(w2, *w2.shape))
             both = (dw, db, db2)
             fused_small = True
         else:
@@ -1116,7 +1144,7 @@ class _LinearFn(torch.autograd.Function):
         if both is not None:
             dw, db, db2 = both
         elif need[1] or (need[2] and ctx.has_bias):
-            dw, db = weight_grad(dy, x, x_rows, want_bias=ctx.has_bias, dyT=dyT, dy_img=dy_img)
+            dw, db = weight_grad(dy, x, x_rows, want_bias=ctx.has_bias, dyT=dyT, dy_img=dy_img, dw_out=_dw_out(w, *w.shape))
         if x2 is not None:
             if need[3]:
                 if x2_rows is not None:
@@ -1125,9 +1153,9 @@ class _LinearFn(torch.autograd.Function):
             if fused_small:
                 pass
             elif both is not None:
-                dw2 = weight_grad(dy, x2, None, want_bias=False, dyT=dyT, x_img=x2_img, dy_img=dy_img)[0]
+                dw2 = weight_grad(dy, x2, None, want_bias=False, dyT=dyT, x_img=x2_img, dy_img=dy_img, dw_out=_dw_out(w2, *w2.shape))[0]
             elif need[4] or ctx.has_bias2:
-                dw2, db2 = weight_grad(dy, x2, x2_rows, want_bias=ctx.has_bias2, dyT=dyT, dy_img=dy_img)
+                dw2, db2 = weight_grad(dy, x2, x2_rows, want_bias=ctx.has_bias2, dyT=dyT, dy_img=dy_img, dw_out=_dw_out(w2, *w2.shape))
         return dx, dw, (db if ctx.has_bias else None), dx2, dw2, None, None, None, (db2 if ctx.has_bias2 else None)
 
 
@@ -1205,9 +1233,10 @@ class _PoolMaxFn(torch.autograd.Function):
             if rimg is not None and rimg.K == x.shape[1] + 1:
                 # the resident table's own image, its rows gathered in the dealt order of dP^T: no X^T image
                 dw, db, _ = linear_bwd_weight_x3k(dyT, rimg, ctx.n_src, x.shape[1], x_rows=x_rows, x_nrows=x.shape[0], interleave=G,
-                                                  want_bias=ctx.has_bias)
+                                                  want_bias=ctx.has_bias, dw_out=_dw_out(w, *w.shape))
             else:
-                dw, db = linear_bwd_weight_x3(dyT, x3_split_t(x, x_rows, ones_row=True, interleave=G), want_bias=ctx.has_bias)
+                dw, db = linear_bwd_weight_x3(dyT, x3_split_t(x, x_rows, ones_row=True, interleave=G), want_bias=ctx.has_bias,
+                                              dw_out=_dw_out(w, *w.shape))
             return None, dw, (db if ctx.has_bias else None), None, None
         dp = reduce_bwd(dout, None, argmax, "max", ctx.n_src, fanout=ctx.fanout, relu_out=out)
         dx = dw = db = None
@@ -1216,7 +1245,7 @@ class _PoolMaxFn(torch.autograd.Function):
                 raise RuntimeError("gradient w.r.t. a row-gathered table is not supported (features carry no grad)")
             dx = linear_bwd_input(dp, w, None)
         if need[1] or (need[2] and ctx.has_bias):
-            dw, db = weight_grad(dp, x, x_rows, want_bias=ctx.has_bias)
+            dw, db = weight_grad(dp, x, x_rows, want_bias=ctx.has_bias, dw_out=_dw_out(w, *w.shape))
         return dx, dw, (db if ctx.has_bias else None), None, None
 
 
@@ -1264,23 +1293,24 @@ class _SagePoolLayerFn(torch.autograd.Function):
         if _out_layer_fits(dy, h, w_self, w_neigh):
             # few output columns (the output layer): the combine's backward in two launches, its input gradient for the pooled rows
             # scattered to the winners as it is computed; the fc_self part joins dh in the epilogue of the fc_pool input gradient
-            dw_self, dw_neigh, db, db2 = out_layer_bwd_weights(dy, h_dst, neigh, want_bias=ctx.has_bias)
+            dw_self, dw_neigh, db, db2 = out_layer_bwd_weights(dy, h_dst, neigh, want_bias=ctx.has_bias,
+                                                               dws_out=_dw_out(w_self, *w_self.shape), dwn_out=_dw_out(w_neigh, *w_neigh.shape))
             dx_self, dp = out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src)
             dp_img = x3_split(dp) if (N1_BWD_SPLIT and _n1_images_ok(n_src, dp.shape[1], w_pool.shape[1])) else None
             dh = linear_bwd_input(dp, w_pool, None, dy_img=dp_img, add_head=dx_self)
-            dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias, x_img=ctx.h_img, dy_img=dp_img)
+            dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias, x_img=ctx.h_img, dy_img=dp_img, dw_out=_dw_out(w_pool, *w_pool.shape))
             return (dh, dw_pool, db_pool if ctx.has_pool_bias else None, dw_self, dw_neigh, db if ctx.has_bias else None,
                     db2 if ctx.has_bias else None, None, None, None)
         dyT = transposed_operand(dy) if (_MODE["name"] != "f32" and dy.shape[0] >= 1024) else None
-        dw_self, db = weight_grad(dy, h_dst, None, want_bias=ctx.has_bias, dyT=dyT)
+        dw_self, db = weight_grad(dy, h_dst, None, want_bias=ctx.has_bias, dyT=dyT, dw_out=_dw_out(w_self, *w_self.shape))
         # the bias gradient once more from the second product (its ones column is free): two tensors for the two biases —
         # one tensor returned for both makes autograd clone it (a launch)
-        dw_neigh, db2 = weight_grad(dy, neigh, None, want_bias=ctx.has_bias, dyT=dyT)
+        dw_neigh, db2 = weight_grad(dy, neigh, None, want_bias=ctx.has_bias, dyT=dyT, dw_out=_dw_out(w_neigh, *w_neigh.shape))
         dneigh = linear_bwd_input(dy, w_neigh, None)
         dp = reduce_bwd(dneigh, None, argmax, "max", n_src, fanout=ctx.fanout, relu_out=neigh)
         dp_img = x3_split(dp) if (N1_BWD_SPLIT and _n1_images_ok(n_src, dp.shape[1], w_pool.shape[1])) else None
         dh = linear_bwd_input(dp, w_pool, None, dy_img=dp_img)
-        dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias, x_img=ctx.h_img, dy_img=dp_img)
+        dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias, x_img=ctx.h_img, dy_img=dp_img, dw_out=_dw_out(w_pool, *w_pool.shape))
         dx_self = linear_bwd_input(dy, w_self, None)
         dh[:n_dst].add_(dx_self)                                  # the fc_self path, in place on the first n_dst rows
         return (dh, dw_pool, db_pool if ctx.has_pool_bias else None, dw_self, dw_neigh, db if ctx.has_bias else None,

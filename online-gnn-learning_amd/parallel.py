@@ -29,9 +29,25 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+_FORCE = False
+
+
+def force_distributed(on=True):
+    """Test switch: treat an initialised process group of ONE rank as distributed, so that every collective call, device-
+    tensor requirement and stream ordering of the N-rank code runs — over RCCL when the group's backend is ``nccl`` — on a
+    one-GPU box (tests/test_gpu_nccl.py).  Results are those of the one-rank path (sums over one rank)."""
+    global _FORCE
+    _FORCE = bool(on)
+
+
+def _single(world):
+    """True when the N-rank code has nothing to exchange (one rank, not forced)."""
+    return world == 1 and not _FORCE
+
+
 def is_distributed(group=None):
-    """True when torch.distributed is initialised with more than one rank."""
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    """True when torch.distributed is initialised with more than one rank (or with one and ``force_distributed()``)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or _FORCE)
 
 
 def rank_world(group=None):
@@ -75,7 +91,8 @@ class GradSynchronizer:
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.overlap = bool(overlap) and self.world > 1
+        self.active = dist.is_initialized() and not _single(self.world)
+        self.overlap = bool(overlap) and self.active
         self.late_fraction = late_fraction
         self.weight = (1.0 / self.world) if weight is None else float(weight)
         self._order = []            # arrival order of the current backward (indices into self.params)
@@ -88,9 +105,16 @@ class GradSynchronizer:
         self._suspended = False
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._hooks = []
+        self._buckets = {}          # name -> (flat tensor, index tuple, {param index: offset}): PERSISTENT across steps
+        self._where = {}            # param index -> bucket name (where its gradient is reduced from the next step on)
+        self.copied_in = 0          # instrumentation: gradient elements that had to be copied into a bucket (tests)
         if self.overlap:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        if self.active and self.params and self.params[0].is_cuda:
+            from . import ops
+            for i, p in enumerate(self.params):
+                ops.register_grad_sink(p, self, i)
 
     # -- hooks ----------------------------------------------------------------------------------------------------
     def _on_grad(self, p):
@@ -119,28 +143,76 @@ class GradSynchronizer:
                 return False
         return _Ctx()
 
-    def _flatten(self, idxs, w, extra=0):
-        pieces = [(self.params[i].grad if self.params[i].grad is not None else torch.zeros_like(self.params[i])).reshape(-1)
-                  for i in idxs]
-        if extra:
-            pieces.append(torch.zeros(extra, dtype=pieces[0].dtype, device=pieces[0].device) if pieces else torch.zeros(extra))
-        flat = torch.cat(pieces)
+    def _bucket(self, name, idxs):
+        """The persistent flat buffer of bucket ``name`` over the parameters ``idxs`` (allocated once per split)."""
+        ent = self._buckets.get(name)
+        if ent is None or ent[1] != tuple(idxs):
+            p0 = self.params[idxs[0]]
+            offs, total = {}, 0
+            for i in idxs:
+                offs[i] = total                                       # every slot 256-byte aligned: the kernels that write a
+                total += (self.params[i].numel() + 63) // 64 * 64     # gradient into its slot use 16-byte stores
+            ent = self._buckets[name] = (torch.zeros(total, dtype=p0.dtype, device=p0.device), tuple(idxs), offs)
+            for i in idxs:
+                self._where[i] = name
+        return ent
+
+    def grad_slot(self, i):
+        """A fresh view of parameter ``i``'s slot in its bucket, for a backward kernel to write the gradient into (so that
+        autograd's AccumulateGrad adopts the slot as ``p.grad`` and ``_fill`` has nothing to copy); None when the slot must
+        not be written: no bucket yet, a gradient already accumulated (``p.grad += new`` would alias), a collective of the
+        bucket in flight."""
+        p = self.params[i]
+        name = self._where.get(i)
+        if name is None or p.grad is not None or self._suspended or (name == "early" and self._pending is not None):
+            return None
+        flat, _, offs = self._buckets[name]
+        return flat.narrow(0, offs[i], p.numel()).view(p.shape)
+
+    def _fill(self, name, idxs, w):
+        """Bucket ``name`` <- w * the gradients of ``idxs``.  A gradient its producer already wrote into the bucket (see
+        ``grad_slot``) costs nothing; the others are copied in — one multi-segment launch per 8 tensors on the GPU —,
+        a missing one is a zero fill.  No allocation, no torch.cat."""
+        flat, _, offs = self._bucket(name, idxs)
+        todo = []
+        for i in idxs:
+            p = self.params[i]
+            n = p.numel()
+            sl = flat.narrow(0, offs[i], n)
+            g = p.grad
+            if g is None:
+                sl.zero_()
+            elif g.data_ptr() == sl.data_ptr() and g.is_contiguous():
+                continue
+            else:
+                todo.append((g.reshape(-1) if g.is_contiguous() else g.contiguous().reshape(-1), sl, n))
+                self.copied_in += n
+        if todo:
+            if flat.is_cuda and flat.dtype == torch.float32:
+                from . import ops
+                for k in range(0, len(todo), 8):
+                    ops.stage_segments(todo[k:k + 8])
+            else:
+                for src, dst, _ in todo:
+                    dst.copy_(src)
         if w != 1.0:
             flat.mul_(w)
         return flat
 
     def _launch_early(self, w):
-        flat = self._flatten(self._early, w)
+        flat = self._fill("early", self._early, w)
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending = (work, flat, w)
 
-    def _scatter(self, idxs, flat):
-        off = 0
+    def _scatter(self, name):
+        """p.grad <- the parameter's slot of the (reduced) bucket: a view, no copy back."""
+        flat, idxs, offs = self._buckets[name]
         for i in idxs:
             p = self.params[i]
-            n = p.numel()
-            p.grad = flat[off:off + n].view_as(p)
-            off += n
+            g = p.grad
+            if not (g is not None and g.data_ptr() == flat.data_ptr() + offs[i] * flat.element_size() and g.shape == p.shape
+                    and g.is_contiguous()):
+                p.grad = flat.narrow(0, offs[i], p.numel()).view_as(p)     # (already so when the producer wrote into the slot)
 
     def _learn(self):
         """Split by arrival order: the trailing gradients (at most late_fraction of the elements) form the late bucket.
@@ -163,18 +235,20 @@ class GradSynchronizer:
         early, late = box
         if early and late:
             self._early, self._late, self._early_set = early, late, set(early)
+            self._bucket("early", early); self._bucket("late", late)      # the slots the next backward writes into
+            self._buckets.pop("all", None)
 
     # -- the step's exchange ---------------------------------------------------------------------------------------
     def sync(self, weight=None):
         """grads <- sum_r w_r * grad_r, w_r = ``weight`` (default: the constructor's)."""
-        if self.world == 1:
+        if not self.active:
             return
         w = self.weight if weight is None else float(weight)
         if self._early is None:
             idxs = list(range(len(self.params)))
-            flat = self._flatten(idxs, w)
+            flat = self._fill("all", idxs, w)
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            self._scatter(idxs, flat)
+            self._scatter("all")
             if self.overlap:
                 self._learn()
         else:
@@ -182,7 +256,7 @@ class GradSynchronizer:
                 self._launch_early(w)
             work, flat_e, w_used = self._pending
             stale = self._stale
-            flat_l = self._flatten(self._late, w)
+            flat_l = self._fill("late", self._late, w)
             dist.all_reduce(flat_l, op=dist.ReduceOp.SUM, group=self.group)      # (issued even when raising below: stays matched)
             work.wait()
             if stale:
@@ -192,8 +266,8 @@ class GradSynchronizer:
                                    "accumulation under `with gsync.no_sync():`")
             if w_used != w:
                 flat_e.mul_(w / w_used)
-            self._scatter(self._early, flat_e)
-            self._scatter(self._late, flat_l)
+            self._scatter("early")
+            self._scatter("late")
         self._pending = None
         self._stale = False
         self._fired = {}
@@ -241,7 +315,7 @@ def all_gather_row_blocks(full, per, group=None):
     order, no copy-back.  xGMI is point-to-point: one all-gather of a rank's 1 / world of the table (Reddit P0: 70 MB per
     rank to each of 7 peers over 7 links in parallel)."""
     rank, world = rank_world(group)
-    if world == 1:
+    if _single(world):
         return full
     assert full.shape[0] == world * per
     blocks = [full[r * per:(r + 1) * per] for r in range(world)]
@@ -265,7 +339,7 @@ def build_row_tables(n, widths, project, device, partition=True, padded_ld=None,
     all-gather per table exchanges the blocks (``all_gather_row_blocks``): rows outside the range are the halo."""
     rank, world = rank_world(group)
     ld = padded_ld or (lambda c: c)
-    if world == 1 or not partition:
+    if _single(world) or not partition:
         bufs = [torch.empty((max(n, 0), ld(w)), dtype=torch.float32, device=device) for w in widths]
         views = [b[:, :w] for b, w in zip(bufs, widths)]
         if n > 0:
@@ -286,7 +360,7 @@ def all_gather_counts(local, counts, group=None):
     """all-gather(v) of 1-D tensors whose per-rank lengths ``counts`` every rank already knows; returns the concatenation
     in rank order on ``local``'s device."""
     rank, world = rank_world(group)
-    if world == 1:
+    if _single(world):
         return local
     assert local.numel() == counts[rank], "local length does not match the agreed count"
     mx = max(max(counts), 1)
@@ -305,7 +379,7 @@ def all_gather_sharded(local, full_sizes, group=None):
     order, on every rank.  ONE all-gather of the concatenated slices (the slice sizes follow from ``shard_range``, so
     nothing but the values travels).  This is the collective of the sharded PBR passes: per-seed losses -> priorities."""
     rank, world = rank_world(group)
-    if world == 1:
+    if _single(world):
         return list(local)
     per_rank = [[shard_range(n, r, world) for n in full_sizes] for r in range(world)]
     counts = [sum(hi - lo for lo, hi in pr) for pr in per_rank]
@@ -332,7 +406,7 @@ def all_gather_sharded(local, full_sizes, group=None):
 
 def all_gather_rows(t, group=None):
     """all-gather(v) of a per-rank 1-D tensor (per-seed losses of a sharded priority forward) to every rank."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or _single(dist.get_world_size(group)):
         return t
     world = dist.get_world_size(group)
     dev = t.device

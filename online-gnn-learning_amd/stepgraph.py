@@ -123,7 +123,14 @@ class TrainStepGraph:
         self.grads = [p.grad for p in self.model.parameters()]
 
     def replay(self):
+        """Replays the step.  ``self.loss`` / ``self.loss_rows`` / ``self.grads`` are STATIC tensors of the graph: the next replay
+        of this bucket (or its re-capture after an eviction) overwrites them — a caller that keeps per-step values clones them."""
         self.cuda_graph.replay()
+        if self.apply:
+            # the replayed optimiser moved the weights under raw pointers: bf16x3 weight images an EAGER pass built before
+            # (evaluation / priority forward between snapshots) are stale now — optim.Adam.step() drops them on the eager
+            # path, a replay has to do it here (keys are (data_ptr, _version): neither changes)
+            ops.invalidate_weight_images()
         return self.loss
 
 
@@ -134,8 +141,11 @@ class SampleGraph:
     block's destination list AS IS — padded destinations sample nothing and keep their (all-zero) block rows, so the input
     block always has ``n1_cap`` destination rows and ``n1_cap + #new`` sources.  ``run`` returns that source count."""
 
+    SPIN_SECONDS = 0.002     # polling budget before the synchronise fallback (a sample graph takes ~50 us)
+
     def __init__(self, graph, buf):
         self.graph, self.buf = graph, buf
+        self.sync_fallbacks = 0
         assert buf.n1_cap == buf.B * (1 + buf.S) and buf.n0_cap == buf.n1_cap * (1 + buf.S)
         self.head_host = torch.zeros(1 + buf.B, dtype=torch.int64).pin_memory()
         self.counts = torch.zeros(2, dtype=torch.int64, device=graph.device)
@@ -175,10 +185,19 @@ class SampleGraph:
         self.seq += 1
         c, want = self.counts_np, self.seq
         spins = 0
-        while c[2] != want:                                  # the step's one read-back: 16 bytes the graph's last kernel wrote
-            spins += 1                                       # into pinned host memory; polled, no copy node, no event
-            if spins & 0xFFFFF == 0 and time.perf_counter() - t0 > 30.0:
-                raise RuntimeError("sample graph: no block sizes from the device after 30 s (sequence %d, saw %d)" % (want, int(c[2])))
+        # The step's one read-back: 16 bytes the graph's last kernel wrote into pinned host memory (system-scope fences
+        # around the sequence number); polled, no copy node, no event.  This relies on torch's pinned allocations being
+        # host-coherent (fine-grained: hipHostMalloc's default, HIP_HOST_COHERENT unset or 1).  Where they are not, the
+        # store only becomes visible when the stream drains — so after SPIN_SECONDS of polling the host falls back to a
+        # stream synchronise (after which the data must be there) instead of burning a core until a timeout.
+        while c[2] != want:
+            spins += 1
+            if spins & 0x3FF == 0 and time.perf_counter() - t0 > self.SPIN_SECONDS:
+                torch.cuda.current_stream().synchronize()
+                self.sync_fallbacks += 1
+                if c[2] != want:
+                    raise RuntimeError("sample graph: no block sizes from the device (sequence %d, saw %d) although its stream "
+                                       "is idle" % (want, int(c[2])))
         return int(c[0]), int(c[1])
 
 

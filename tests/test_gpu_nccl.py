@@ -1,0 +1,163 @@
+"""The N-rank code over RCCL proper — on ONE rank.  A one-GPU box cannot run two RCCL ranks, but a process group of world size 1 with
+backend ``nccl`` still makes every call the N-rank path makes: communicator creation on the device, device-tensor collectives
+(async all-reduce launched from an autograd hook, broadcast_object_list, all-gather into row blocks, all-gather(v) of losses),
+their stream ordering against the HIP kernels of the step, and a hipGraph capture next to RCCL's watchdog thread.
+``parallel.force_distributed()`` routes the strategies through that code although there is nobody to exchange with; sums over
+one rank are the identity, so the results must equal the plain one-rank path's.
+
+(The gloo rehearsals in tests/test_parallel_gloo.py / tests/test_gpu_parallel.py cover N > 1 semantics; this file covers the
+backend the driver's scaling bench uses.)"""
+import os
+import random
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _setup(forced, port):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import ogl_amd  # noqa: F401
+    from ogl_amd import parallel
+    torch.cuda.set_device(0)
+    if forced:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        parallel.force_distributed(True)
+        assert parallel.is_distributed() and dist.get_backend() == "nccl"
+    return dist, parallel
+
+
+def _worker_reddit(forced, port, out_path):
+    """Reddit-size PBR: priority forward (replicated tables, then partitioned tables + halo all-gather), three sharded train
+    updates (bucket learning, then the overlapped early / late buckets with the gradients written straight into them)."""
+    dist, parallel = _setup(forced, port)
+    from ogl_amd import ops, sampling, synthetic
+    from ogl_amd.graph import TrainTestGraph
+    from ogl_amd.prioritized_replay import LossPriority
+    from ogl_amd.utils import Lib_supported, init
+    np.random.seed(3); random.seed(3); torch.manual_seed(3); sampling.seed(3)
+    GraphSAGE, Random, Prioritized, NoReh, Full, act = init(Lib_supported.HIP, True, 0)
+    feat_size, labels, graph, n_classes, _ = synthetic.load("reddit", snapshots=2, device="cuda")
+    gu = TrainTestGraph(graph, split=0.15, start_prior_alpha=4, end_prior_alpha=50, scale=1, max_priority=10)
+    graph.evolve()
+    ops.set_gemm_mode("auto")
+    model = GraphSAGE(feat_size, 600, n_classes, 1, act, 0, "pool", edge_feats=0, pool_feats=600).cuda()
+    pri = Prioritized(model, 3, 512, labels, 25, LossPriority(), cuda=True, full_pass=1, batch_full=1024)
+    pri.use_graphs = False
+    pri.build_optimizer()
+    assert (pri.gsync is not None) == forced
+    pri.optimizer = torch.optim.SGD(model.parameters(), lr=0.05)
+    train = np.asarray(sorted(gu.get_train_set()))
+    seen = []
+    inner = gu.update_priorities_device
+    gu.update_priorities_device = lambda ids, pr: (
+        seen.append((np.asarray(ids).copy(), pr.detach().cpu().numpy().astype(np.float64))), inner(ids, pr))
+    subset = train[:2 * 1024 + 100]
+    res = {}
+    for name, part in (("loss_rep", False), ("loss_par", True)):
+        pri.partition_features = part
+        sampling.seed(5)
+        pri.recompute_priorities(gu, list(subset))
+        res[name] = seen[-1][1]
+    pri.partition_features = False
+    id2s, s2id = gu.get_original_to_subgraph_map(), gu.get_subgraph_to_original_map()
+    fixed = train[5000:5000 + 3 * 512]
+    sampling.seed(6)
+    pri._run_custom_train(graph.get_graph(), s2id, id2s, id2s[fixed], gu)           # 3 batches: learn, then 2 overlapped steps
+    torch.cuda.synchronize()
+    res["weights"] = [p.detach().cpu().clone() for p in model.parameters()]
+    res["prio"] = np.asarray(gu.dump_priorities(list(fixed)))
+    if forced:
+        gs = pri.gsync
+        assert gs._early is not None and gs._late is not None, "the early / late split was not learnt"
+        # the last step's gradients live IN the persistent buckets: p.grad is a view of its slot
+        for i, p in enumerate(gs.params):
+            flat, _, offs = gs._buckets[gs._where[i]]
+            assert p.grad.data_ptr() == flat.data_ptr() + 4 * offs[i]
+        # ... and the weight gradients got there without a copy: over the two overlapped steps only biases were copied in
+        n_bias = sum(p.numel() for p in gs.params if p.dim() == 1)
+        n_all = sum(p.numel() for p in gs.params)
+        res["copied_in"], res["n_bias"], res["n_all"] = gs.copied_in, n_bias, n_all
+        t = parallel.all_gather_counts(torch.arange(5, dtype=torch.float32, device="cuda"), [5])
+        assert torch.equal(t.cpu(), torch.arange(5, dtype=torch.float32))
+        parallel.assert_replicated(np.arange(7), "a test vector")
+        dist.barrier(); dist.destroy_process_group()
+    torch.save(res, out_path)
+
+
+def _worker_graphs(forced, port, out_path):
+    """Pubmed-size replicas: eager sharded steps vs steps replayed as captured graphs (``staged_dp``: forward + backward
+    captured, the two all-reduces and the optimiser eager) with an RCCL communicator alive in the process."""
+    dist, parallel = _setup(True, port)
+    import torch.nn.functional as F
+    from ogl_amd import sampling, synthetic
+    from ogl_amd.graphsage import GraphSAGE
+    from ogl_amd.graphsage.model import RandomHipSupervisedGraphSage
+    np.random.seed(3); random.seed(3); torch.manual_seed(3); sampling.seed(3)
+    feat_size, labels, dyn, n_classes, _ = synthetic.load("pubmed", snapshots=3, device="cuda")
+    dyn.evolve()
+    g = dyn.get_graph()
+    res = {}
+    for graphs in (False, True):
+        torch.manual_seed(9)
+        model = GraphSAGE(feat_size, 32, n_classes, 1, F.relu, 0, "pool", edge_feats=0, pool_feats=32).cuda()
+        st = RandomHipSupervisedGraphSage(model, 4, 64, labels, 10, cuda=True, batch_full=256)
+        st.use_graphs = graphs
+        st.build_optimizer()
+        st.optimizer = torch.optim.SGD(model.parameters(), lr=0.05)
+        forms = []
+        st.step_hook = lambda info: forms.append(info["form"])
+        seeds = np.random.default_rng(1).choice(g.n_present, 4 * 64 + 10, replace=False).astype(np.int64)
+        sampling.seed(8)
+        st._train_batches(g, seeds, 64)
+        torch.cuda.synchronize()
+        res[graphs] = dict(weights=[p.detach().cpu().clone() for p in model.parameters()], forms=forms)
+    dist.barrier(); dist.destroy_process_group()
+    torch.save(res, out_path)
+
+
+def _spawn1(target, args):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=target, args=args)
+    p.start(); p.join(900)
+    assert p.exitcode == 0
+
+
+def test_sharded_pbr_over_rccl_world1_equals_plain_path(tmp_path):
+    plain, forced = str(tmp_path / "plain.pt"), str(tmp_path / "forced.pt")
+    _spawn1(_worker_reddit, (False, 0, plain))
+    _spawn1(_worker_reddit, (True, _free_port(), forced))
+    a, b = torch.load(plain, weights_only=False), torch.load(forced, weights_only=False)
+    # inference passes: whole batches, row-independent projections -> bit for bit, replicated or partitioned, forced or not
+    assert np.array_equal(a["loss_rep"], a["loss_par"])
+    assert np.array_equal(a["loss_rep"], b["loss_rep"]) and np.array_equal(a["loss_rep"], b["loss_par"])
+    # train updates: the sharded step differentiates sum(rows) / n instead of the mean kernel's output: fp32 rounding only
+    for x, y in zip(a["weights"], b["weights"]):
+        torch.testing.assert_close(x, y, rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(a["prio"], b["prio"], rtol=1e-4, atol=1e-6)
+    # step 0 reduces one flat bucket filled by copies (n_all elements); steps 1 and 2 copy only what no kernel could write in
+    # place (the bias gradients): the weight gradients were produced inside their bucket slots
+    assert b["copied_in"] <= b["n_all"] + 2 * b["n_bias"], b
+
+
+def test_dp_steps_replayed_as_graphs_beside_rccl(tmp_path):
+    out = str(tmp_path / "g.pt")
+    _spawn1(_worker_graphs, (True, _free_port(), out))
+    r = torch.load(out, weights_only=False)
+    assert r[False]["forms"] == ["sharded"] * 5 and r[True]["forms"] == ["staged_dp"] * 5
+    for x, y in zip(r[False]["weights"], r[True]["weights"]):
+        torch.testing.assert_close(x, y, rtol=1e-4, atol=2e-5)
