@@ -114,7 +114,16 @@ def main():
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            # (gloo's C++ side prints its connection banner on stdout: keep stdout for the one JSON line)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                dist.barrier()
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
         one = torch.ones(1, dtype=torch.int64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(one)                                 # the first collective of the run: every rank is really there
         ranks_seen = int(one.item())

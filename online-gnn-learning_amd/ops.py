@@ -1078,6 +1078,64 @@ def _dw_out(w, N, K):
     return t if (t is not None and tuple(t.shape) == (int(N), int(K)) and not _capturing()) else None
 
 
+# Forked backward: the weight gradients of the n1-row projections are leaves of the backward graph — nothing but the optimiser
+# reads them — while the input-gradient chain (dh1 -> relu mask -> dneigh0 -> pool backward -> dW_pool0) is the critical path.
+# ``side_section()`` runs its body on a second HIP stream that waits for everything enqueued so far; ``side_join()`` (before the
+# optimiser step) makes the main stream wait for it.  In a captured step the two become parallel branches of the hipGraph.
+# Tensors the side work reads were allocated on the main stream: ``side_keep`` holds them until the join, so the caching allocator
+# cannot hand their memory to a later main-stream kernel while the side stream still reads it.
+FORK_BACKWARD = os.environ.get("OGL_FORK_BWD", "1") != "0"
+_SIDE = {"streams": {}, "keep": [], "active": False, "off": 0}
+
+
+class _SideSection:
+    def __enter__(self):
+        dev = torch.cuda.current_device()
+        st = _SIDE["streams"].get(dev)
+        if st is None:
+            st = _SIDE["streams"][dev] = torch.cuda.Stream(device=dev)
+        st.wait_stream(torch.cuda.current_stream())
+        self._ctx = torch.cuda.stream(st)
+        self._ctx.__enter__()
+        if not _SIDE["active"]:
+            # joined when the backward pass that opened the section ends, whoever called it (loss.backward() of user code too)
+            torch.autograd.Variable._execution_engine.queue_callback(side_join)
+        _SIDE["active"] = True
+        return self
+
+    def __exit__(self, *exc):
+        self._ctx.__exit__(*exc)
+        return False
+
+
+class _NoSection:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def side_section(*keep):
+    """Context manager: the body's launches go to the side stream, ordered after everything enqueued so far (a no-op context when
+    the fork is off: under per-kernel profiling, data parallelism — gradient hooks launch collectives on the main stream — or
+    OGL_FORK_BWD=0)."""
+    if not FORK_BACKWARD or _PROFILE is not None or _SIDE["off"] or _GRAD_SINKS:
+        return _NoSection()
+    _SIDE["keep"].extend(t for t in keep if t is not None)
+    return _SideSection()
+
+
+def side_join():
+    """The main stream waits for the side stream's work (call before anything consumes what a side section produced)."""
+    if _SIDE["active"]:
+        st = _SIDE["streams"].get(torch.cuda.current_device())
+        if st is not None:
+            torch.cuda.current_stream().wait_stream(st)
+        _SIDE["active"] = False
+    _SIDE["keep"].clear()
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, x2, w2, relu, x_rows, x2_rows, bias2=None):
@@ -1115,6 +1173,20 @@ class _LinearFn(torch.autograd.Function):
             if x_rows is not None:
                 raise RuntimeError("gradient w.r.t. a row-gathered table is not supported (features carry no grad)")
             dx = linear_bwd_input(dy, w, y, dy_img=dy_img)
+        if x2 is not None and need[3]:
+            # the input gradients first: they are the critical path of the backward pass (the weight gradients below are leaves)
+            if x2_rows is not None:
+                raise RuntimeError("gradient w.r.t. a row-gathered table is not supported")
+            dx2 = linear_bwd_input(dy, w2, y, dy_img=dy_img)
+        forked = dy_img is not None and dy.shape[0] >= X3_BWW_MIN_ROWS
+        with (side_section(dy, dy_img, x, x2, ctx.x2_img) if forked else _NoSection()):
+            dw, db, dw2, db2 = _LinearFn._weight_grads(ctx, dy, dy_img, x, w, x2, w2, x_rows, x2_rows, need)
+        return dx, dw, (db if ctx.has_bias else None), dx2, dw2, None, None, None, (db2 if ctx.has_bias2 else None)
+
+    @staticmethod
+    def _weight_grads(ctx, dy, dy_img, x, w, x2, w2, x_rows, x2_rows, need):
+        y = None
+        dw = db = dw2 = db2 = None
         dyT = None
         x2_img = ctx.x2_img if (x2 is not None and x2_rows is None) else None
         tall = _MODE["name"] != "f32" and dy.shape[0] >= X3_BWW_MIN_ROWS
@@ -1146,17 +1218,13 @@ class _LinearFn(torch.autograd.Function):
         elif need[1] or (need[2] and ctx.has_bias):
             dw, db = weight_grad(dy, x, x_rows, want_bias=ctx.has_bias, dyT=dyT, dy_img=dy_img, dw_out=_dw_out(w, *w.shape))
         if x2 is not None:
-            if need[3]:
-                if x2_rows is not None:
-                    raise RuntimeError("gradient w.r.t. a row-gathered table is not supported")
-                dx2 = linear_bwd_input(dy, w2, y, dy_img=dy_img)
             if fused_small:
                 pass
             elif both is not None:
                 dw2 = weight_grad(dy, x2, None, want_bias=False, dyT=dyT, x_img=x2_img, dy_img=dy_img, dw_out=_dw_out(w2, *w2.shape))[0]
             elif need[4] or ctx.has_bias2:
                 dw2, db2 = weight_grad(dy, x2, x2_rows, want_bias=ctx.has_bias2, dyT=dyT, dy_img=dy_img, dw_out=_dw_out(w2, *w2.shape))
-        return dx, dw, (db if ctx.has_bias else None), dx2, dw2, None, None, None, (db2 if ctx.has_bias2 else None)
+        return dw, db, dw2, db2
 
 
 def linear(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_rows=None, bias2=None):
@@ -1293,12 +1361,14 @@ class _SagePoolLayerFn(torch.autograd.Function):
         if _out_layer_fits(dy, h, w_self, w_neigh):
             # few output columns (the output layer): the combine's backward in two launches, its input gradient for the pooled rows
             # scattered to the winners as it is computed; the fc_self part joins dh in the epilogue of the fc_pool input gradient
-            dw_self, dw_neigh, db, db2 = out_layer_bwd_weights(dy, h_dst, neigh, want_bias=ctx.has_bias,
-                                                               dws_out=_dw_out(w_self, *w_self.shape), dwn_out=_dw_out(w_neigh, *w_neigh.shape))
             dx_self, dp = out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src)
             dp_img = x3_split(dp) if (N1_BWD_SPLIT and _n1_images_ok(n_src, dp.shape[1], w_pool.shape[1])) else None
             dh = linear_bwd_input(dp, w_pool, None, dy_img=dp_img, add_head=dx_self)
-            dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias, x_img=ctx.h_img, dy_img=dp_img, dw_out=_dw_out(w_pool, *w_pool.shape))
+            # the layer's weight gradients: leaves of the backward graph, on the side stream when the layer is tall
+            with (side_section(dy, h, neigh, dp, dp_img, ctx.h_img) if dp_img is not None else _NoSection()):
+                dw_self, dw_neigh, db, db2 = out_layer_bwd_weights(dy, h_dst, neigh, want_bias=ctx.has_bias,
+                                                                   dws_out=_dw_out(w_self, *w_self.shape), dwn_out=_dw_out(w_neigh, *w_neigh.shape))
+                dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias, x_img=ctx.h_img, dy_img=dp_img, dw_out=_dw_out(w_pool, *w_pool.shape))
             return (dh, dw_pool, db_pool if ctx.has_pool_bias else None, dw_self, dw_neigh, db if ctx.has_bias else None,
                     db2 if ctx.has_bias else None, None, None, None)
         dyT = transposed_operand(dy) if (_MODE["name"] != "f32" and dy.shape[0] >= 1024) else None
@@ -1424,6 +1494,7 @@ def backward(loss):
     """loss.backward() with the cached unit root gradient: autograd then neither fills a ones_like(loss) nor does the
     mean-reduced cross entropy multiply its stored dlogits by it (two ~5 us launches per step)."""
     loss.backward(unit_grad(loss.device))
+    side_join()
 
 
 class _CrossEntropyMeanFn(torch.autograd.Function):

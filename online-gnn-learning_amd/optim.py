@@ -38,6 +38,7 @@ class Adam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        ops.side_join()                     # (a forked backward joins itself when it ends; this is for gradients made by hand)
         ops.invalidate_weight_images()      # the kernels below write the parameters through raw pointers (no version bump)
         for group in self.param_groups:
             b1, b2 = group["betas"]

@@ -59,7 +59,10 @@ def _worker_reddit(forced, port, out_path):
     pri.use_graphs = False
     pri.build_optimizer()
     assert (pri.gsync is not None) == forced
-    pri.optimizer = torch.optim.SGD(model.parameters(), lr=0.05)
+    # plain SGD with a SMALL step: float atomics make every backward pass differ in its last bits, and a large step turns that
+    # into flipped max-pool winners in the next forward (a finite re-routing of gradient entries) — here the two runs must
+    # stay comparable over three updates
+    pri.optimizer = torch.optim.SGD(model.parameters(), lr=1e-3)
     train = np.asarray(sorted(gu.get_train_set()))
     seen = []
     inner = gu.update_priorities_device
@@ -147,7 +150,7 @@ def test_sharded_pbr_over_rccl_world1_equals_plain_path(tmp_path):
     assert np.array_equal(a["loss_rep"], b["loss_rep"]) and np.array_equal(a["loss_rep"], b["loss_par"])
     # train updates: the sharded step differentiates sum(rows) / n instead of the mean kernel's output: fp32 rounding only
     for x, y in zip(a["weights"], b["weights"]):
-        torch.testing.assert_close(x, y, rtol=1e-4, atol=5e-5)
+        torch.testing.assert_close(x, y, rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(a["prio"], b["prio"], rtol=1e-4, atol=1e-6)
     # step 0 reduces one flat bucket filled by copies (n_all elements); steps 1 and 2 copy only what no kernel could write in
     # place (the bias gradients): the weight gradients were produced inside their bucket slots
