@@ -269,7 +269,9 @@ int ogl_linear_fwd_x3_ext(const void* x_img, int64_t x_img_rows, const int64_t* 
  * [group_offset, group_offset + ceil((K + append) / 32)) of every row of `image` (rows image_row_bytes apart, R + 1 of them:
  * the last one zero), so several parts can fill one K-concatenated image.  transpose = 1: image row r is COLUMN r of src
  * (src is [K, R]: the image of W^T for an input-gradient product).  append = 1: reduction element K holds
- * vec1[r] + vec2[r] (either may be NULL = 0): the (summed) bias. */
+ * vec1[r] + vec2[r] (either may be NULL = 0): the (summed) bias.
+ * transpose = 2: not an image at all but a VECTOR SUM riding in the same launch: image = float[R] <- vec1 + vec2 (the summed
+ * bias b_self + b_neigh of a dual projection that runs on fp32 operands; src / K / append / image_row_bytes / group_offset unused). */
 typedef struct ogl_x3_split_part {
   const float* src; int64_t ld;
   int64_t R; int32_t K;
@@ -329,6 +331,14 @@ int ogl_ce_fwd_bwd(const float* logits, int64_t ldl, const int64_t* labels, int6
  * (reduction='mean', R/train/graphsage/pytorch/model.py:20: the loss the RBR / no-rehearsal strategies differentiate). */
 int ogl_ce_fwd_bwd_mean(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C, float grad_scale,
                         float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean, ogl_stream_t stream);
+/* The same for ANY batch size (one wave per row over a grid): the mean is summed by the last block to finish, in the fixed
+ * order of the one-workgroup form (bit-identical to it).  `counter`: one zero-initialised device word the caller allocates once
+ * (the last block resets it; one counter per stream that may run this concurrently).  loss_rows is required.  zero_buf
+ * (nullable; 16-byte aligned, zero_floats a multiple of 4): ALSO filled with zeros by the same grid — the atomic-scatter target
+ * of the backward pass that follows (autograd of the max-pool in R/train/graphsage/pytorch/graphsage_dgl.py:3's SAGEConv). */
+int ogl_ce_fwd_bwd_mean_grid(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C, float grad_scale,
+                             float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean, unsigned int* counter,
+                             float* zero_buf, int64_t zero_floats, ogl_stream_t stream);
 
 /* torch.optim.Adam(lr) single-tensor update (R/train/graphsage/pytorch/model.py:24-25,107).
  * Hyper-parameters are doubles (as Python floats are) so 1-beta is rounded to fp32 once, like torch. */

@@ -981,6 +981,12 @@ __global__ void __launch_bounds__(256) k_x3_split_multi(X3SplitBatch b) {
   const float* __restrict__ v1 = b.vec1[part];
   const float* __restrict__ v2 = b.vec2[part];
   unsigned char* __restrict__ img = b.img[part];
+  if (flags & 4) {                                    // a vector-sum part: fp32 out[r] = vec1[r] + vec2[r] (the summed bias of a
+    float* out = (float*)img;                         // dual projection whose product runs on fp32 operands)
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < R; t += (int64_t)gridDim.x * blockDim.x)
+      out[t] = (v1 ? v1[t] : 0.f) + (v2 ? v2[t] : 0.f);
+    return;
+  }
   const bool tr = flags & 1, slot = flags & 2;
   const int cpr = ((K + (slot ? 1 : 0) + 31) / 32) * 4;       // 8-element chunks per image row
   const int64_t total = (R + 1) * cpr;
@@ -1029,6 +1035,13 @@ extern "C" int ogl_x3_split_multi(const ogl_x3_split_part* parts, int n_parts, o
   int64_t most = 0;
   for (int i = 0; i < n_parts; ++i) {
     const ogl_x3_split_part& q = parts[i];
+    if (q.transpose == 2) {                                // vector sum: image = float[R] <- vec1 + vec2
+      if (q.R < 0 || !q.image || (!q.vec1 && !q.vec2)) return OGL_EINVAL;
+      b.src[i] = nullptr; b.ld[i] = 0; b.R[i] = q.R; b.K[i] = 0; b.flags[i] = 4;
+      b.vec1[i] = q.vec1; b.vec2[i] = q.vec2; b.img[i] = (unsigned char*)q.image; b.img_row_bytes[i] = 0;
+      most = max(most, q.R);
+      continue;
+    }
     const int Ki = q.K + (q.append ? 1 : 0);
     if (q.R < 0 || q.K < 0 || Ki == 0 || q.group_offset < 0 || !q.image || ((uintptr_t)q.image & 15)) return OGL_EINVAL;
     if (q.ld < (q.transpose ? q.R : (int64_t)q.K) || (q.R > 0 && q.K > 0 && !q.src)) return OGL_EINVAL;

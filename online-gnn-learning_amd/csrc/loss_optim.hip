@@ -2,6 +2,7 @@
 // Replaces nn.CrossEntropyLoss(reduction='mean'|'none') (R/train/graphsage/pytorch/model.py:20,105,147,198,244)
 // and torch.optim.Adam(lr=1e-3).step() (R/train/graphsage/pytorch/model.py:24-25,107,202).
 // Both are tiny HBM-bound elementwise/row kernels.
+#include <algorithm>
 #include "ogl_common.h"
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -97,6 +98,69 @@ extern "C" int ogl_ce_fwd_bwd_mean(const float* logits, int64_t ldl, const int64
   if (!logits || !labels || !loss_mean) return OGL_EINVAL;
   hipLaunchKernelGGL(k_ce_fwd_bwd_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ldl, labels, (int)B, C, grad_scale,
                      loss_rows, dlogits, lddl, loss_mean);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+// Any batch size, the mean from the same launch: the multi-block kernel above plus (a) the mean of the row losses, summed by the
+// LAST block to finish in the same fixed order as the one-workgroup kernel (lane l takes rows l, l + 64, ...; then the lanes) — the
+// blocks count themselves on `counter` (a zeroed device word the last block resets, so the caller allocates it once), and
+// (b) an optional zero fill of a caller buffer by the same grid (the scatter target of the backward pass that follows needs
+// zeros; as a launch of its own that fill is a ~9 us hole in a ~1 ms step).  Replaces rows.mean() as a second launch.
+__global__ void __launch_bounds__(256) k_ce_fwd_bwd_mean_grid(const float* __restrict__ logits, int64_t ldl,
+                                                              const int64_t* __restrict__ labels, int64_t B, int C, float grad_scale,
+                                                              float* __restrict__ loss_rows, float* __restrict__ dlogits, int64_t lddl,
+                                                              float* __restrict__ loss_mean, unsigned* __restrict__ counter,
+                                                              int row_blocks, float4* __restrict__ zero_buf, int64_t zero_n4) {
+  if (zero_n4 > 0) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < zero_n4; i += (int64_t)gridDim.x * blockDim.x) zero_buf[i] = z;
+  }
+  if ((int)blockIdx.x >= row_blocks) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row < B) {
+    const float* x = logits + row * ldl;
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, x[c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += expf(x[c] - m);
+    s = wave_sum(s);
+    const float lse = m + logf(s);
+    const int64_t y = labels[row];
+    const bool ok = y >= 0 && y < C;
+    if (lane == 0) loss_rows[row] = ok ? lse - x[y] : 0.f;
+    if (dlogits) {
+      float* g = dlogits + row * lddl;
+      for (int c = lane; c < C; c += 64) g[c] = grad_scale * (expf(x[c] - lse) - ((ok && c == (int)y) ? 1.f : 0.f));
+    }
+  }
+  __shared__ int last;
+  __threadfence();                                             // this block's row losses are visible device-wide ...
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(counter, 1u) == (unsigned)row_blocks - 1u;   // ... before it counts itself
+  __syncthreads();
+  if (last && threadIdx.x < 64) {
+    __threadfence();
+    float t = 0.f;
+    for (int64_t r = lane; r < B; r += 64) t += __builtin_nontemporal_load(loss_rows + r);
+    t = wave_sum(t);
+    if (lane == 0) { *loss_mean = t / (float)B; *counter = 0u; }
+  }
+}
+
+extern "C" int ogl_ce_fwd_bwd_mean_grid(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C, float grad_scale,
+                                        float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean, unsigned int* counter,
+                                        float* zero_buf, int64_t zero_floats, ogl_stream_t stream) {
+  if (B <= 0 || C <= 0 || ldl < C || (dlogits && lddl < C) || zero_floats < 0) return OGL_EINVAL;
+  if (!logits || !labels || !loss_rows || !loss_mean || !counter) return OGL_EINVAL;
+  if (zero_floats > 0 && (!zero_buf || ((uintptr_t)zero_buf & 15) || (zero_floats & 3))) return OGL_EINVAL;
+  const int row_blocks = (int)ogl_cdiv(B, 4);
+  const int64_t fill_blocks = std::min<int64_t>(1024, ogl_cdiv(zero_floats / 4, 1024));
+  hipLaunchKernelGGL(k_ce_fwd_bwd_mean_grid, dim3((unsigned)std::max<int64_t>(row_blocks, fill_blocks)), dim3(256), 0,
+                     (hipStream_t)stream, logits, ldl, labels, B, C, grad_scale, loss_rows, dlogits, lddl, loss_mean, counter,
+                     row_blocks, (float4*)zero_buf, zero_floats / 4);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }

@@ -61,7 +61,7 @@ class GraphSAGE(nn.Module):
                     ws, wn, bs = layer.fc_self.weight, layer.fc_neigh.weight, layer.fc_self.bias
                     bn = layer.fc_neigh.bias if bs is not None else None
                     plan.append((layer.feat_drop, ("wb", (wp, bp)), ("cat", (ws, wn, bs, bn)), ("T", (wn,)), ("T", (wp,)),
-                                 wp.shape[0], wp.shape[1], ws.shape[0]))
+                                 wp.shape[0], wp.shape[1], ws.shape[0], ("bsum", (bs, bn)) if bn is not None else None))
                 else:
                     plan.append(None)
             self.__dict__["_img_plan"] = plan
@@ -83,7 +83,7 @@ class GraphSAGE(nn.Module):
         for li, (ent, block) in enumerate(zip(self._image_plan(), blocks)):
             n_dst = block.number_of_dst_nodes()
             if ent is not None and not (training and ent[0].p > 0):
-                _, r_wb, r_cat, r_tn, r_tp, p_out, p_in, s_out = ent
+                _, r_wb, r_cat, r_tn, r_tp, p_out, p_in, s_out, r_bsum = ent
                 if li == 0 and isinstance(x, GatheredRows) and x.proj is None:
                     if ops._x3_forward_ok(ops.as_mat(x.table), n_src, None):
                         req.append(r_wb)
@@ -93,6 +93,8 @@ class GraphSAGE(nn.Module):
                 elif li > 0 and ops._n1_images_ok(n_src, p_in, p_out):
                     req.append(r_wb)
                     req.append(r_tp)
+                    if r_bsum is not None and s_out <= 64:      # the few-column output layer: fp32 operands + a summed bias
+                        req.append(r_bsum)
             n_src = n_dst
         if req:
             ops.weight_images_prepare(req)

@@ -229,8 +229,7 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
                 loss_fn = lambda logits, labels: (ops.cross_entropy(logits, labels, "mean"), None)       # noqa: E731
             else:
                 def loss_fn(logits, labels):
-                    rows = self.xent(logits, labels)
-                    return torch.mean(rows), rows
+                    return ops.cross_entropy_mean_rows(logits, labels)
             self._sg = stepgraph.StepGraphCache(self.graphsage_model, self.optimizer, self.samples, loss_fn)
         return self._sg
 
@@ -301,8 +300,7 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         if self.reduction == "mean":
             loss = self.xent(scores, batch_labels)
         else:
-            rows = self.xent(scores, batch_labels)
-            loss = torch.mean(rows)
+            loss, rows = ops.cross_entropy_mean_rows(scores, batch_labels)      # the mean to train on + the rows, one launch
             if on_rows is not None:
                 on_rows(seeds, rows.detach())
         ops.backward(loss)

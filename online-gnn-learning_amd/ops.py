@@ -449,13 +449,14 @@ def relu_bwd(dy, y):
     return out
 
 
-def out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src):
-    """(dx_self [n_dst, K], dP [n_src, K]): dy . w_self, and dy . w_neigh scattered to the max winners (csrc/out_layer.hip)."""
+def out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src, dp_zeroed=None):
+    """(dx_self [n_dst, K], dP [n_src, K]): dy . w_self, and dy . w_neigh scattered to the max winners (csrc/out_layer.hip).
+    ``dp_zeroed``: an already zeroed [n_src, K] scatter target (``take_zeroed``)."""
     dy = as_mat(dy); w_self = as_mat(w_self); w_neigh = as_mat(w_neigh); neigh = as_mat(neigh)
     n_dst, N = dy.shape
     K = w_self.shape[1]
     dx = empty_mat(n_dst, K, dy.device)
-    dp = empty_mat(n_src, K, dy.device, zero=True)
+    dp = dp_zeroed if dp_zeroed is not None else empty_mat(n_src, K, dy.device, zero=True)
     _launch("ogl_out_layer_bwd_inputs", _lib.lib().ogl_out_layer_bwd_inputs, _ptr(dy), _ld(dy), n_dst, N, K, _ptr(w_self), _ld(w_self),
             _ptr(w_neigh), _ld(w_neigh), _ptr(argmax), _ptr(neigh), _ld(neigh), n_src, _ptr(dx), _ld(dx), _ptr(dp), _ld(dp), _stream(),
             meta=dict(M=n_dst, N=N, K=K))
@@ -741,12 +742,21 @@ def weight_images_prepare(requests):
          ("wb", (w, b))                    image of w with the bias slot (b may be None: 0) — B operand against an activation image with a ones slot
          ("cat", (w, w2, b, b2))           K-concatenated [w | b + b2] [w2]                 — B operand of the two-part combine product
          ("T", (w,))                       image of w^T                                   — B operand of dX = dY . w
+         ("bsum", (b, b2))                 not an image: the fp32 vector b + b2 (weight_image returns a tensor) — the summed bias of a
+                                           dual projection on fp32 operands, riding in the same launch
        All of them in one launch (at most 8 parts; further requests are left to their consumers)."""
     parts, made = [], []
     cap = _capturing()
     for kind, ts in requests:
         key = _wkey(kind, *ts)
         if key in _W_IMAGES and _W_IMAGES[key][1] == cap:
+            continue
+        if kind == "bsum":
+            if len(parts) + 1 > 8:
+                break
+            out = torch.empty(ts[0].numel(), dtype=torch.float32, device=ts[0].device)
+            parts.append((None, ts[0].numel(), 0, 2, 0, ts[0], ts[1], out, 0, 0))
+            made.append((key, out))
             continue
         w = as_mat(ts[0])
         dev = w.device
@@ -773,7 +783,7 @@ def weight_images_prepare(requests):
         return
     arr = (_X3SplitPart * len(parts))()
     for a, (m, R, K, tr, app, v1, v2, buf, G, off) in zip(arr, parts):
-        a.src, a.ld, a.R, a.K, a.transpose, a.append = _ptr(m), _ld(m), R, K, tr, app
+        a.src, a.ld, a.R, a.K, a.transpose, a.append = _ptr(m), (_ld(m) if m is not None else 0), R, K, tr, app
         a.vec1, a.vec2, a.image, a.image_row_bytes, a.group_offset = _ptr(v1), _ptr(v2), _ptr(buf), G * 192, off
     _launch("ogl_x3_split_multi", _lib.lib().ogl_x3_split_multi, C.cast(arr, C.c_void_p), len(parts), _stream(),
             meta=dict(parts=len(parts)))
@@ -994,6 +1004,76 @@ def ce_fwd_bwd_mean(logits, labels, want_grad=True):
     dl = empty_mat(B, Cc, logits.device) if want_grad else None
     _launch("ogl_ce_fwd_bwd_mean", _lib.lib().ogl_ce_fwd_bwd_mean, _ptr(logits), _ld(logits), _ptr(labels), B, Cc, C.c_float(1.0 / B),
             _ptr(loss), _ptr(dl), _ld(dl) if dl is not None else 0, _ptr(mean), _stream(), meta=dict(B=B, C=Cc))
+    return mean, loss, dl
+
+
+# The grid form (any batch size): its block counter is one zeroed word per (device, stream) — the last block resets it — and it can
+# zero a buffer on the side: a layer whose backward scatters with atomics parks its (empty) scatter target here in forward
+# (``request_zeroed``), the loss kernel that runs between forward and backward clears it, and the layer's backward finds it
+# zeroed (``take_zeroed``) instead of launching a fill of its own.
+_CE_COUNTERS = {}
+_PENDING_ZERO = []
+
+
+def request_zeroed(rows, cols, device):
+    """An EMPTY [rows, cols] matrix (padded rows) that the next cross-entropy launch on this device will zero; returns a handle
+    for ``take_zeroed``."""
+    buf = torch.empty((max(rows, 1), padded_ld(cols)), dtype=torch.float32, device=device)
+    ent = [buf, rows, cols, False, torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())]
+    del _PENDING_ZERO[:-3]                           # at most a few outstanding: requests nobody served are simply dropped
+    _PENDING_ZERO.append(ent)
+    return ent
+
+
+def take_zeroed(ent, rows, cols):
+    """The matrix of ``request_zeroed`` as a zeroed [rows, cols] view (zeroed here when no loss launch picked it up)."""
+    buf, r, c, done, _ = ent
+    assert r == rows and c == cols
+    if not done:
+        buf.zero_()
+    ent[3] = False
+    try:
+        _PENDING_ZERO.remove(ent)
+    except ValueError:
+        pass
+    return buf[:rows, :cols]
+
+
+def ce_counter(device, stream):
+    """Address of the block counter of (device, stream): one word of a zeroed 64-word array per device, allocated on first use
+    (stepgraph allocates it before a capture so that it never lives in a graph's private pool)."""
+    ent = _CE_COUNTERS.get(device.index)
+    if ent is None:
+        ent = _CE_COUNTERS[device.index] = (torch.zeros(64, dtype=torch.int32, device=device), {})
+    arr, slots = ent
+    i = slots.get(stream)
+    if i is None:
+        i = slots[stream] = len(slots) % 64
+    return arr.data_ptr() + 4 * i
+
+
+def ce_fwd_bwd_mean_grid(logits, labels, want_grad=True):
+    """(mean loss, row losses, dlogits / B) of a batch of any size in ONE launch (ogl_ce_fwd_bwd_mean_grid)."""
+    logits = as_mat(logits)
+    labels = labels.reshape(-1)
+    assert labels.dtype == torch.int64 and labels.is_cuda and labels.is_contiguous() and labels.numel() == logits.shape[0]
+    B, Cc = logits.shape
+    dev = logits.device
+    stream = _stream()
+    ctr = ce_counter(dev, stream)
+    loss = torch.empty(B, dtype=torch.float32, device=dev)
+    mean = torch.empty((), dtype=torch.float32, device=dev)
+    dl = empty_mat(B, Cc, dev) if want_grad else None
+    zbuf, zn = None, 0
+    if want_grad:
+        for ent in _PENDING_ZERO:
+            if not ent[3] and ent[4] == stream and ent[0].device == dev:
+                zbuf, zn = ent[0], ent[0].numel()
+                ent[3] = True
+                break
+    _launch("ogl_ce_fwd_bwd_mean_grid", _lib.lib().ogl_ce_fwd_bwd_mean_grid, _ptr(logits), _ld(logits), _ptr(labels), B, Cc,
+            C.c_float(1.0 / B), _ptr(loss), _ptr(dl), _ld(dl) if dl is not None else 0, _ptr(mean), ctr, _ptr(zbuf), zn,
+            _stream(), meta=dict(B=B, C=Cc))
     return mean, loss, dl
 
 
@@ -1342,11 +1422,18 @@ class _SagePoolLayerFn(torch.autograd.Function):
         neigh, argmax = reduce_fwd(p, idx, "max", want_argmax=need)
         bias = None
         if b_self is not None:
-            bias = b_self + b_neigh
+            bias = weight_image("bsum", b_self, b_neigh)          # from the step's one weight-image launch, when prepared
+            if bias is None:
+                bias = b_self + b_neigh
         out = linear_fwd(h[:n_dst], w_self, bias, x2=neigh, w2=w_neigh, relu=relu)
         if _CAPTURE is not None:
             _CAPTURE.append(dict(argmax=argmax, neigh=neigh, out=out if relu else None))
         ctx.relu, ctx.n_dst, ctx.fanout, ctx.has_bias, ctx.has_pool_bias = bool(relu), n_dst, idx.shape[1], b_self is not None, b_pool is not None
+        # the few-column output layer scatters its pooled-row gradient with atomics: park the (empty) target where the loss launch
+        # that comes next will zero it
+        ctx.dp_slot = None
+        if need and not relu and out.shape[1] <= 64 and OUT_LAYER_FUSED and h.shape[0] >= 1024:
+            ctx.dp_slot = request_zeroed(h.shape[0], h.shape[1], h.device)
         ctx.save_for_backward(h, w_pool, w_self, w_neigh, neigh, argmax, out if relu else None)
         return out
 
@@ -1361,7 +1448,9 @@ class _SagePoolLayerFn(torch.autograd.Function):
         if _out_layer_fits(dy, h, w_self, w_neigh):
             # few output columns (the output layer): the combine's backward in two launches, its input gradient for the pooled rows
             # scattered to the winners as it is computed; the fc_self part joins dh in the epilogue of the fc_pool input gradient
-            dx_self, dp = out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src)
+            slot = getattr(ctx, "dp_slot", None)
+            dx_self, dp = out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src,
+                                               dp_zeroed=take_zeroed(slot, n_src, h.shape[1]) if slot is not None else None)
             dp_img = x3_split(dp) if (N1_BWD_SPLIT and _n1_images_ok(n_src, dp.shape[1], w_pool.shape[1])) else None
             dh = linear_bwd_input(dp, w_pool, None, dy_img=dp_img, add_head=dx_self)
             # the layer's weight gradients: leaves of the backward graph, on the side stream when the layer is tall
@@ -1508,6 +1597,10 @@ class _CrossEntropyMeanFn(torch.autograd.Function):
             mean, _, dl = ce_fwd_bwd_mean(logits, labels, want_grad=logits.requires_grad)
             ctx.save_for_backward(dl)
             return mean
+        if logits.shape[0] > 0:
+            mean, _, dl = ce_fwd_bwd_mean_grid(logits, labels, want_grad=logits.requires_grad)
+            ctx.save_for_backward(dl)
+            return mean
         rows, dl = ce_fwd_bwd(logits, labels, 1.0 / B, want_grad=logits.requires_grad)
         ctx.save_for_backward(dl)
         return rows.mean()
@@ -1519,6 +1612,38 @@ class _CrossEntropyMeanFn(torch.autograd.Function):
         if unit is not None and dloss.data_ptr() == unit.data_ptr():
             return dl, None
         return dl * dloss, None
+
+
+class _CrossEntropyMeanRowsFn(torch.autograd.Function):
+    """(mean loss, per-seed losses) from one launch; only the mean is differentiable.  What the PBR update needs: it trains on
+    the mean of the 'none'-reduced loss and exports the rows as priorities (R/train/graphsage/pytorch/model.py:198-204)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        B = logits.shape[0]
+        if 0 < B <= CE_MEAN_SMALL_MAX_B:
+            mean, rows, dl = ce_fwd_bwd_mean(logits, labels, want_grad=logits.requires_grad)
+        else:
+            mean, rows, dl = ce_fwd_bwd_mean_grid(logits, labels, want_grad=logits.requires_grad)
+        ctx.save_for_backward(dl)
+        ctx.mark_non_differentiable(rows)
+        return mean, rows
+
+    @staticmethod
+    def backward(ctx, dloss, _drows):
+        (dl,) = ctx.saved_tensors
+        unit = _UNIT_GRAD.get((dloss.device.type, dloss.device.index))
+        if unit is not None and dloss.data_ptr() == unit.data_ptr():
+            return dl, None
+        return dl * dloss, None
+
+
+def cross_entropy_mean_rows(logits, labels):
+    """(mean, rows) of nn.CrossEntropyLoss(reduction='none') in one launch; differentiate the mean."""
+    if logits.shape[0] == 0:
+        rows = _CrossEntropyRowsFn.apply(logits, labels)
+        return rows.mean(), rows
+    return _CrossEntropyMeanRowsFn.apply(logits, labels)
 
 
 def cross_entropy(logits, labels, reduction="mean"):

@@ -104,6 +104,7 @@ class TrainStepGraph:
             assert getattr(self.opt, "capturable", False), "a captured step needs optim.Adam(capturable=True)"
             self.opt.prepare_capture()
         ops.unit_grad(self.graph.device)
+        ops.ce_counter(self.graph.device, 0)                 # (allocates the device's counter array outside the capture)
         ops._static_image(self.graph.feat_table)            # built outside the capture (a one-off 850 MB split pass)
         if not _WARMED:
             # once per process: run the step's forward + backward for real on a side stream (autograd's device thread, lazily
@@ -118,6 +119,12 @@ class TrainStepGraph:
             _WARMED = True
         torch.cuda.synchronize()
         kw = {} if pool is None else dict(pool=pool)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            # RCCL's watchdog thread polls its events (hipEventQuery) all the time; under the default "global" capture mode a
+            # query from ANY thread while this one captures is an error that invalidates the capture and kills the watchdog
+            # (found by tests/test_gpu_nccl.py).  "thread_local": only this thread's own calls are policed.
+            torch.cuda.synchronize()
+            kw["capture_error_mode"] = "thread_local"
         with torch.cuda.graph(self.cuda_graph, **kw):
             self._body()
         self.grads = [p.grad for p in self.model.parameters()]

@@ -1,0 +1,150 @@
+"""Round-3 additions, each against a reference computed another way on the same device or the CPU oracle:
+the grid-wide cross-entropy mean (+ its fused zero fill), the summed bias riding in the weight-image launch, the forked
+backward (side-stream weight gradients), and the advisor's stale-image scenario (eager inference between REPLAYED optimiser
+steps).  Run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,C", [(512, 41), (1024, 40), (1500, 7), (129, 3)])
+def test_ce_mean_grid_matches_rows_and_small_kernel(B, C):
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    g = torch.Generator().manual_seed(B)
+    logits = (torch.randn(B, C, generator=g) * 3).cuda()
+    labels = torch.randint(0, C, (B,), generator=g).cuda()
+    rows_ref, dl_ref = ops.ce_fwd_bwd(logits, labels, 1.0 / B)
+    slot = ops.request_zeroed(777, 600, logits.device)
+    slot[0].fill_(3.0)
+    mean, rows, dl = ops.ce_fwd_bwd_mean_grid(logits, labels)
+    assert torch.equal(rows, rows_ref) and torch.equal(dl, dl_ref)                 # the same per-row arithmetic
+    ref = F.cross_entropy(logits.double().cpu(), labels.cpu()).item()
+    assert abs(float(mean) - ref) <= 1e-6 * max(1.0, abs(ref))
+    if B <= 1024:                                                                  # the one-workgroup kernel sums in the same order
+        m2, _, _ = ops.ce_fwd_bwd_mean(logits, labels)
+        assert float(m2) == float(mean)
+    z = ops.take_zeroed(slot, 777, 600)                                            # the parked buffer was cleared by that launch
+    assert slot[0].abs().sum().item() == 0.0 and z.shape == (777, 600)
+    # the counter resets itself: a second launch gives the same mean
+    mean2, _, _ = ops.ce_fwd_bwd_mean_grid(logits, labels)
+    assert float(mean2) == float(mean)
+
+
+def test_mean_rows_function_is_differentiable_through_the_mean_only():
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    g = torch.Generator().manual_seed(1)
+    logits = (torch.randn(600, 41, generator=g)).cuda().requires_grad_(True)
+    labels = torch.randint(0, 41, (600,), generator=g).cuda()
+    mean, rows = ops.cross_entropy_mean_rows(logits, labels)
+    assert not rows.requires_grad and mean.requires_grad
+    ops.backward(mean)
+    ref_in = logits.detach().cpu().double().requires_grad_(True)
+    ref = F.cross_entropy(ref_in, labels.cpu())
+    ref.backward()
+    torch.testing.assert_close(logits.grad.cpu().double(), ref_in.grad, rtol=1e-5, atol=1e-8)
+    torch.testing.assert_close(rows.cpu().double(), F.cross_entropy(ref_in.detach(), labels.cpu(), reduction="none"), rtol=1e-5, atol=1e-6)
+
+
+def test_bias_sum_rides_in_the_weight_image_launch():
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    ops.set_gemm_mode("auto")
+    ops.invalidate_weight_images()
+    w = torch.randn(600, 600, device="cuda"); b = torch.randn(600, device="cuda")
+    b1 = torch.randn(41, device="cuda"); b2 = torch.randn(41, device="cuda")
+    ops.weight_images_prepare([("wb", (w, b)), ("bsum", (b1, b2)), ("T", (w,))])
+    s = ops.weight_image("bsum", b1, b2)
+    assert s is not None and torch.equal(s, b1 + b2)
+    img = ops.weight_image("wb", w, b)
+    ref = ops.x3_split(w, append_vec=b)
+    assert torch.equal(img.buf, ref.buf)
+    ops.invalidate_weight_images()
+
+
+def _reddit_like_small():
+    from ogl_amd import synthetic
+    feat_size, labels, dyn, n_classes, _ = synthetic.load("reddit", snapshots=2, device="cuda", scale=0.12)
+    dyn.evolve()
+    return feat_size, labels, dyn.get_graph(), n_classes
+
+
+def test_forked_backward_gives_the_serial_gradients():
+    """The weight gradients launched on the side stream are the serial ones bit for bit (deterministic split-K slabs; the
+    fork only changes which stream runs them)."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops, sampling
+    from ogl_amd.graphsage import GatheredRows, GraphSAGE
+    feat_size, labels, g, n_classes = _reddit_like_small()
+    ops.set_gemm_mode("auto")
+    torch.manual_seed(2)
+    model = GraphSAGE(feat_size, 600, n_classes, 1, F.relu, 0, "pool", edge_feats=0, pool_feats=600).cuda()
+    seeds = torch.as_tensor(np.random.default_rng(0).choice(g.n_present, 512, replace=False).astype(np.int64)).cuda()
+    grads = {}
+    for fork in (False, True):
+        ops.FORK_BACKWARD = fork
+        ops.invalidate_weight_images()
+        sampling.seed(11)
+        (input_nodes, sd, blocks), = list(sampling.NodeDataLoader(g, seeds.cpu(), sampling.MultiLayerNeighborSampler([25, 25]), batch_size=512))
+        assert blocks[1].number_of_src_nodes() >= 2048        # tall enough for the image kernels (and so for the fork)
+        for p in model.parameters():
+            p.grad = None
+        lab = ops.gather_i64(g.ndata["target"], sd)
+        loss = ops.cross_entropy(model(blocks, GatheredRows(g.ndata["feat"], input_nodes)), lab, "mean")
+        loss.backward()                                        # plain autograd entry: the fork must join by itself
+        grads[fork] = [p.grad.detach().clone() for p in model.parameters()]
+        assert ops._SIDE["active"] is False
+    ops.FORK_BACKWARD = True
+    names = [n for n, _ in model.named_parameters()]
+    for n, a, b in zip(names, grads[False], grads[True]):
+        if "layers.0.fc_pool" in n:
+            # its chain holds the LDS float atomics of the pool backward: equal up to their summation order
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+        else:
+            assert torch.equal(a, b), n
+
+
+def test_replayed_steps_invalidate_eagerly_built_weight_images():
+    """an eager inference pass builds bf16x3 weight images keyed by (data_ptr, version); replayed optimiser steps
+    move the weights under both.  A second inference pass must see the NEW weights: compare with a twin trained eagerly."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops, sampling
+    from ogl_amd.graphsage import GraphSAGE
+    from ogl_amd.graphsage.model import RandomHipSupervisedGraphSage
+    feat_size, labels, g, n_classes = _reddit_like_small()
+    ops.set_gemm_mode("auto")
+    rng = np.random.default_rng(3)
+    train_seeds = rng.choice(g.n_present, 4 * 512, replace=False).astype(np.int64)      # n % bs == 0: no eager ragged batch
+    eval_seeds = torch.as_tensor(rng.choice(g.n_present, 1024, replace=False).astype(np.int64))
+    outs = {}
+    for graphs in (False, True):
+        torch.manual_seed(5)
+        model = GraphSAGE(feat_size, 600, n_classes, 1, F.relu, 0, "pool", edge_feats=0, pool_feats=600).cuda()
+        st = RandomHipSupervisedGraphSage(model, 4, 512, labels, 25, cuda=True, batch_full=1024)
+        st.use_graphs = graphs
+        st.cache_projection = False                     # the per-batch inference path: layer 0 through the dual image product
+        st.build_optimizer()
+        forms = []
+        st.step_hook = lambda info, forms=forms: forms.append(info["form"])
+
+        def infer():
+            model.eval()
+            sampling.seed(21)
+            with torch.no_grad():
+                return torch.cat([lg for _, lg in st._inference_batches(g, eval_seeds)]).cpu()
+        before = infer()
+        model.train()
+        sampling.seed(22)
+        st._train_batches(g, train_seeds, 512)
+        assert forms == (["staged"] * 4 if graphs else ["eager"] * 4), forms
+        after = infer()
+        outs[graphs] = (before, after)
+    assert torch.equal(outs[False][0], outs[True][0])                       # same initial weights, same sampler state
+    moved = (outs[False][1] - outs[False][0]).abs().max().item()
+    assert moved > 1e-2, moved                                               # four Adam steps changed the logits visibly
+    # the replayed model's second pass reflects its four replayed updates (stale images would reproduce `before` in layer 0)
+    torch.testing.assert_close(outs[True][1], outs[False][1], rtol=2e-2, atol=0.1 * moved)
