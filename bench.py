@@ -37,6 +37,12 @@ WORKLOADS = {
     "arxiv_rbr": dict(dataset="arxiv", batch=32, samples=25, hidden=32, batch_timestep=1),
     "pubmed_rbr": dict(dataset="pubmed", batch=32, samples=25, hidden=32, batch_timestep=2),
     "toy_rbr": dict(dataset="toy", batch=32, samples=5, hidden=16, batch_timestep=2),
+    # the reference's OWN settings files (R/settings/*.json: samples / batch_size / embedding_size / batch_timestep / batch_full)
+    "pubmed_settings": dict(dataset="pubmed", batch=32, samples=45, hidden=32, batch_timestep=2),
+    "arxiv_settings": dict(dataset="arxiv", batch=32, samples=40, hidden=32, batch_timestep=1),
+    "bitcoin_settings": dict(dataset="bitcoin", batch=32, samples=45, hidden=256, batch_timestep=60),
+    "reddit_settings": dict(dataset="reddit", batch=1024, samples=30, hidden=600, batch_timestep=50),
+    "reddit_settings_pbr_forward": dict(dataset="reddit", batch=900, samples=30, hidden=600, batch_timestep=50, forward=True),
     # PBR priority forward: inference over the train set in batches of batch_full, per-seed CE loss
     "reddit_pbr_forward": dict(dataset="reddit", batch=1024, samples=25, hidden=600, batch_timestep=50, forward=True),
     "arxiv_pbr_forward": dict(dataset="arxiv", batch=1024, samples=25, hidden=32, batch_timestep=1, forward=True),

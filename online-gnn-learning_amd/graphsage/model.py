@@ -156,7 +156,9 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
     # a batch whose upper-bound input block B (1 + S)^2 stays below this many rows samples inside a captured graph of its own
     # (one 16-byte read-back per step picks the train graph's size bucket); larger batches keep the loader, whose read-backs
     # amortise over the snapshot's batches, and stage each batch into its bucket's train graph (stepgraph.py)
-    SAMPLED_GRAPH_MAX_ROWS = 65536
+    # (R/settings/pubmed.json and elliptic.json use samples = 45 at batch 32: 32 * 46^2 = 67 712 rows of upper bound — the buffers
+    # are index arrays, 0.5 MB; the GEMMs of the step run at the batch's own size bucket, not at the bound)
+    SAMPLED_GRAPH_MAX_ROWS = 1 << 18
 
     def build_optimizer(self):
         self._sg = None

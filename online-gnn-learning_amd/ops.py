@@ -1012,30 +1012,27 @@ def ce_fwd_bwd_mean(logits, labels, want_grad=True):
 # (``request_zeroed``), the loss kernel that runs between forward and backward clears it, and the layer's backward finds it
 # zeroed (``take_zeroed``) instead of launching a fill of its own.
 _CE_COUNTERS = {}
-_PENDING_ZERO = []
+_PENDING_ZERO = {}          # (device index, stream) -> the newest request not served yet (an older one is simply dropped)
 
 
 def request_zeroed(rows, cols, device):
     """An EMPTY [rows, cols] matrix (padded rows) that the next cross-entropy launch on this device will zero; returns a handle
     for ``take_zeroed``."""
     buf = torch.empty((max(rows, 1), padded_ld(cols)), dtype=torch.float32, device=device)
-    ent = [buf, rows, cols, False, torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())]
-    del _PENDING_ZERO[:-3]                           # at most a few outstanding: requests nobody served are simply dropped
-    _PENDING_ZERO.append(ent)
+    ent = [buf, rows, cols, False]
+    _PENDING_ZERO[(buf.device.index, _stream())] = ent
     return ent
 
 
 def take_zeroed(ent, rows, cols):
     """The matrix of ``request_zeroed`` as a zeroed [rows, cols] view (zeroed here when no loss launch picked it up)."""
-    buf, r, c, done, _ = ent
+    buf, r, c, done = ent
     assert r == rows and c == cols
     if not done:
         buf.zero_()
-    ent[3] = False
-    try:
-        _PENDING_ZERO.remove(ent)
-    except ValueError:
-        pass
+        for k, v in list(_PENDING_ZERO.items()):
+            if v is ent:
+                del _PENDING_ZERO[k]
     return buf[:rows, :cols]
 
 
@@ -1066,11 +1063,10 @@ def ce_fwd_bwd_mean_grid(logits, labels, want_grad=True):
     dl = empty_mat(B, Cc, dev) if want_grad else None
     zbuf, zn = None, 0
     if want_grad:
-        for ent in _PENDING_ZERO:
-            if not ent[3] and ent[4] == stream and ent[0].device == dev:
-                zbuf, zn = ent[0], ent[0].numel()
-                ent[3] = True
-                break
+        ent = _PENDING_ZERO.pop((dev.index, stream), None)
+        if ent is not None:
+            zbuf, zn = ent[0], ent[0].numel()
+            ent[3] = True
     _launch("ogl_ce_fwd_bwd_mean_grid", _lib.lib().ogl_ce_fwd_bwd_mean_grid, _ptr(logits), _ld(logits), _ptr(labels), B, Cc,
             C.c_float(1.0 / B), _ptr(loss), _ptr(dl), _ld(dl) if dl is not None else 0, _ptr(mean), ctr, _ptr(zbuf), zn,
             _stream(), meta=dict(B=B, C=Cc))
@@ -1165,6 +1161,9 @@ def _dw_out(w, N, K):
 # Tensors the side work reads were allocated on the main stream: ``side_keep`` holds them until the join, so the caching allocator
 # cannot hand their memory to a later main-stream kernel while the side stream still reads it.
 FORK_BACKWARD = os.environ.get("OGL_FORK_BWD", "1") != "0"
+# in a captured step the fork becomes parallel graph branches: measured SLOWER than the serial graph (1.108 vs 1.097 ms per Reddit
+# step: the branches' cross-stream edges cost more than the overlap returns), so captures stay serial unless asked
+FORK_IN_GRAPHS = os.environ.get("OGL_FORK_BWD_GRAPHS", "0") == "1"
 _SIDE = {"streams": {}, "keep": [], "active": False, "off": 0}
 
 
@@ -1200,7 +1199,7 @@ def side_section(*keep):
     """Context manager: the body's launches go to the side stream, ordered after everything enqueued so far (a no-op context when
     the fork is off: under per-kernel profiling, data parallelism — gradient hooks launch collectives on the main stream — or
     OGL_FORK_BWD=0)."""
-    if not FORK_BACKWARD or _PROFILE is not None or _SIDE["off"] or _GRAD_SINKS:
+    if not FORK_BACKWARD or _PROFILE is not None or _SIDE["off"] or _GRAD_SINKS or (not FORK_IN_GRAPHS and _capturing()):
         return _NoSection()
     _SIDE["keep"].extend(t for t in keep if t is not None)
     return _SideSection()

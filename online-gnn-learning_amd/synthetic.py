@@ -18,6 +18,9 @@ SPECS = {
     "pubmed": dict(n=19717, f=500, c=3, e=44338, snapshots=400, stream="vertex"),
     "arxiv": dict(n=169343, f=128, c=40, e=1166243, snapshots=3500, stream="vertex"),
     "reddit": dict(n=232965, f=602, c=41, e=11606919, snapshots=5000, stream="edge"),
+    # Elliptic bitcoin transactions (R/train/dataset_utils/bitcoin.py:55,78-113: 165 features, classes = unique targets incl. the
+    # unlabelled marker, vertex stream by time step; N / E are the public dataset's; R/settings/elliptic.json: 1000 snapshots)
+    "bitcoin": dict(n=203769, f=165, c=3, e=234355, snapshots=1000, stream="vertex"),
     "toy": dict(n=600, f=20, c=4, e=3000, snapshots=20, stream="vertex"),
     "toy_edge": dict(n=600, f=20, c=4, e=3000, snapshots=20, stream="edge"),
 }

@@ -28,10 +28,16 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 RUNGS = {
-    #          hidden  train batch  batch_timestep
+    #          hidden  train batch  batch_timestep  (samples: 25, BASELINE.json's configs)
     "pubmed": dict(H=32, B=32, bt=2),
     "arxiv": dict(H=32, B=32, bt=1),
     "reddit": dict(H=600, B=512, bt=50),
+    # the reference's own settings files (R/settings/pubmed.json:1, arxiv.json:1, elliptic.json:1): samples 45 / 40 / 45 at batch 32.
+    # 32 * 46^2 = 67 712 upper-bound rows: the captured 'sampled' form must cover them (it was gated at 65 536 until round 3).
+    # (bitcoin: batch_timestep is 60 in the settings file; 3 batches here keep the oracle's share of the test short)
+    "pubmed_settings": dict(data="pubmed", H=32, B=32, bt=2, S=45),
+    "arxiv_settings": dict(data="arxiv", H=32, B=32, bt=1, S=40),
+    "bitcoin_settings": dict(data="bitcoin", H=256, B=32, bt=3, S=45),
 }
 
 
@@ -98,7 +104,7 @@ def streams():
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("graphs", [False, True])
 @pytest.mark.parametrize("gemm", ["f32", "auto"])
-@pytest.mark.parametrize("name", ["pubmed", "arxiv"])
+@pytest.mark.parametrize("name", ["pubmed", "arxiv", "pubmed_settings", "arxiv_settings", "bitcoin_settings"])
 def test_rbr_train_steps_match_oracle(streams, name, gemm, graphs):
     """graphs=True: every step is ONE captured hipGraph that samples for itself on upper-bound shapes (stepgraph.py,
     'sampled' form) — the same oracle, the same tolerances as the eager launches."""
@@ -106,7 +112,8 @@ def test_rbr_train_steps_match_oracle(streams, name, gemm, graphs):
     from ogl_amd.graphsage import GraphSAGE
     from ogl_amd.graphsage.model import RandomHipSupervisedGraphSage
     cfg = RUNGS[name]
-    a, labels, dyn, feat_size, n_classes = streams(name, 4)
+    S = cfg.get("S", 25)
+    a, labels, dyn, feat_size, n_classes = streams(cfg.get("data", name), 4)
     while dyn.evolution_index < 3:                   # 3 of 4 snapshot groups present: a real prefix-degree cut
         dyn.evolve()
     g = dyn.get_graph()
@@ -118,7 +125,7 @@ def test_rbr_train_steps_match_oracle(streams, name, gemm, graphs):
         cpu = O.CpuModel("pool", feat_size, cfg["H"], n_classes, seed=7)
         model = GraphSAGE(feat_size, cfg["H"], n_classes, 1, F.relu, 0, "pool", edge_feats=0, pool_feats=cfg["H"]).cuda()
         _copy_params(model, cpu.params)
-        strat = RandomHipSupervisedGraphSage(model, cfg["bt"], cfg["B"], labels, 25, cuda=True, batch_full=1024)
+        strat = RandomHipSupervisedGraphSage(model, cfg["bt"], cfg["B"], labels, S, cuda=True, batch_full=1024)
         strat.use_graphs = graphs
         strat.build_optimizer()
         seeds = np.random.default_rng(3).choice(g.n_present, cfg["B"] * cfg["bt"], replace=False).astype(np.int64)
@@ -135,10 +142,10 @@ def test_rbr_train_steps_match_oracle(streams, name, gemm, graphs):
         names = [n for n, _ in model.named_parameters()]
         for ctr, r in enumerate(rec):
             assert np.array_equal(r["seeds"], seeds[ctr * cfg["B"]:(ctr + 1) * cfg["B"]])
-            in_ref, _, _ = O.sample_blocks(indptr, indices, deg, r["seeds"], [25, 25], 13, ctr)
+            in_ref, _, _ = O.sample_blocks(indptr, indices, deg, r["seeds"], [S, S], 13, ctr)
             if r["form"] == "eager":                 # (a captured sampled step keeps padded destination rows in its count)
                 assert len(in_ref) == r["n0"]
-            loss_ref = cpu.train_step(feat_cpu, lab_cpu, indptr, indices, deg, r["seeds"], 25, 13, ctr)
+            loss_ref = cpu.train_step(feat_cpu, lab_cpu, indptr, indices, deg, r["seeds"], S, 13, ctr)
             assert abs(r["loss"] - loss_ref) <= 1e-4 * abs(loss_ref), (ctr, r["loss"], loss_ref)
             ref_grads = {"layers.%d.%s" % (li, k): v.grad for li, prm in enumerate(cpu.params) for k, v in prm.items()}
             for n_, got in zip(names, r["grads"]):

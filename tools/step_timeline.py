@@ -1,0 +1,45 @@
+"""Timeline of ONE steady-state train step from a rocprofv3 kernel_trace.csv: every dispatch between two consecutive Adam
+launches with its start offset, duration, the idle gap on the device before it (no kernel of ANY queue running), and how much
+of it ran concurrently with a kernel of another queue (the forked backward).  Usage:
+  python tools/step_timeline.py <kernel_trace.csv> [step index, default: the median-length step]"""
+import csv
+import sys
+
+
+def short(n):
+    n = n.replace("void ", "")
+    return n if len(n) < 70 else n[:67] + "..."
+
+
+def main():
+    rows = []
+    for r in csv.DictReader(open(sys.argv[1])):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"), int(r.get("Grid_Size", 0) or 0)))
+    rows.sort()
+    adam = [i for i, r in enumerate(rows) if "k_adam" in r[2]]
+    steps = [(adam[k], adam[k + 1]) for k in range(len(adam) - 1)]
+    lens = sorted((rows[b][1] - rows[a][1], k) for k, (a, b) in enumerate(steps))
+    pick = int(sys.argv[2]) if len(sys.argv) > 2 else lens[len(lens) // 2][1]
+    a, b = steps[pick]
+    seg = rows[a + 1:b + 1]
+    t0 = rows[a][1]
+    print("step %d of %d: %.1f us from the end of one Adam launch to the end of the next; %d dispatches" % (pick, len(steps), (rows[b][1] - t0) / 1e3, len(seg)))
+    busy_until = t0
+    idle = overlap_total = 0.0
+    print("%9s %9s %8s %8s %5s  %s" % ("start_us", "dur_us", "gap_us", "ovl_us", "queue", "kernel [grid]"))
+    for i, (s, e, n, q, g) in enumerate(seg):
+        gap = max(0, s - busy_until) / 1e3
+        idle += gap
+        ovl = 0
+        for j, (s2, e2, n2, q2, g2) in enumerate(seg):
+            if j != i and q2 != q:
+                ovl += max(0, min(e, e2) - max(s, s2))
+        overlap_total += ovl / 1e3
+        print("%9.1f %9.1f %8.1f %8.1f %5s  %s [%d]" % ((s - t0) / 1e3, (e - s) / 1e3, gap, ovl / 1e3, q, short(n), g))
+        busy_until = max(busy_until, e)
+    print("device idle inside the step: %.1f us; kernel time summed: %.1f us; cross-queue overlap (counted on both sides): %.1f us"
+          % (idle, sum(e - s for s, e, *_ in seg) / 1e3, overlap_total))
+
+
+if __name__ == "__main__":
+    main()
