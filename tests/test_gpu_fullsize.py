@@ -126,11 +126,21 @@ def test_fullsize_reddit_settings_step_matches_oracle(reddit):
 
 def test_fullsize_free_running_steps_track_the_oracle(reddit):
     """Ten consecutive eager train steps at the Reddit rung WITHOUT re-synchronising the oracle's weights from the device
-    (the rung tests compare every step from identical parameters): the two trajectories — each side's own Adam state, own
-    fp32 rounding, own tie breaks — must stay within rtol 1e-3 on the loss of every step."""
+    (the rung tests compare every step from identical parameters): two trajectories, each with its own Adam state, fp32
+    rounding and tie breaks.
+
+    What separates them (tools/drift_probe.py, one step from identical weights): the forward agrees to 1e-7 — the oracle's
+    loss AT THE DEVICE'S WEIGHTS equals the device's — and so do the layer-1 gradients (2e-7 relative); but the layer-1 max /
+    ReLU decisions of two different fp32 evaluations differ on a few near-ties, each flip re-routes one finite gradient
+    contribution into layer 0 (1e-3 .. 3e-3 relative on its weight gradients), and Adam's lr * g / (|g| + eps) turns every
+    entry whose gradient changed sign into a 2 lr weight difference (~700 of 1.5 M entries after ONE step).  From there the
+    trajectories separate at a rate no arithmetic can influence.  The yardstick is therefore ANOTHER correct evaluation of the
+    same model: the oracle in float64.  The device must track the fp32 oracle about as closely as the fp64 oracle does, within
+    1e-2 on every loss in any case (measured: device 6e-5 after one step, 1e-3 after five, 2-4e-3 after ten)."""
     from ogl_amd import ops, optim, sampling
     from ogl_amd.graphsage import GatheredRows, GraphSAGE
     a, dyn, g, host = reddit
+    g.set_snapshot(g.n_total, len(a["src"]))                          # the last snapshot: every vertex and edge present
     ops.set_gemm_mode("auto")
     try:
         deg = O.snapshot_degrees_fast(host["indptr"], host["keys"], g.n_present, g.cut)
@@ -143,9 +153,15 @@ def test_fullsize_free_running_steps_track_the_oracle(reddit):
                     getattr(getattr(l, mod), attr).copy_(v)
         opt = optim.Adam(model.parameters(), lr=1e-3)
         feat_cpu, lab_cpu = a["feat"], torch.as_tensor(a["labels"]).reshape(-1, 1)
+        cpu64 = O.CpuModel("pool", 602, 600, 41, seed=3)              # the same model evaluated in float64
+        for prm in cpu64.params:
+            for k in prm:
+                prm[k] = prm[k].detach().double().requires_grad_(True)
+        cpu64.opt = torch.optim.Adam([t for prm in cpu64.params for t in prm.values()], lr=1e-3)
+        feat64 = feat_cpu.double()
         rng = np.random.default_rng(17)
         sampling.seed(9)
-        got, want = [], []
+        got, want, want64 = [], [], []
         for step in range(10):
             seeds = rng.choice(g.n_present, 512, replace=False).astype(np.int64)
             (input_nodes, sd, blocks), = list(sampling.NodeDataLoader(g, torch.as_tensor(seeds), sampling.MultiLayerNeighborSampler([25, 25]),
@@ -154,10 +170,16 @@ def test_fullsize_free_running_steps_track_the_oracle(reddit):
             loss = ops.cross_entropy(model(blocks, GatheredRows(g.ndata["feat"], input_nodes)), ops.gather_i64(g.ndata["target"], sd), "mean")
             ops.backward(loss)
             opt.step()
-            got.append(float(loss))
+            got.append(float(loss.detach()))
             want.append(cpu.train_step(feat_cpu, lab_cpu, host["indptr"], host["indices"], deg, seeds, 25, 9, step))
+            want64.append(cpu64.train_step(feat64, lab_cpu, host["indptr"], host["indices"], deg, seeds, 25, 9, step))
+        got, want, want64 = np.asarray(got), np.asarray(want), np.asarray(want64)
+        dev_drift, ref_drift = np.abs(got - want) / want, np.abs(want64 - want) / want
         print("free-running losses  device:", ["%.5f" % x for x in got], " oracle:", ["%.5f" % x for x in want])
-        np.testing.assert_allclose(got, want, rtol=1e-3)
+        print("relative drift  device vs oracle:", ["%.1e" % x for x in dev_drift], " fp64 oracle vs oracle:", ["%.1e" % x for x in ref_drift])
+        np.testing.assert_allclose(got, want, rtol=1e-2)
+        assert dev_drift[0] <= 1e-5                                   # the first step starts from identical weights
+        assert dev_drift.max() <= 1e-4 + 3 * ref_drift.max(), (dev_drift, ref_drift)
         assert got[-1] < got[0]                                       # and it trains
     finally:
         ops.set_gemm_mode("f32")
@@ -166,6 +188,7 @@ def test_fullsize_free_running_steps_track_the_oracle(reddit):
 def _fullsize_step(a, dyn, g, host, B=512, S=25):
     from ogl_amd import ops, optim, sampling
     from ogl_amd.graphsage import GatheredRows, GraphSAGE
+    g.set_snapshot(g.n_total, len(a["src"]))                          # the last snapshot, whichever test ran before
     deg = O.snapshot_degrees_fast(host["indptr"], host["keys"], g.n_present, g.cut)
     cpu = O.CpuModel("pool", 602, 600, 41, seed=1)
     model = GraphSAGE(602, 600, 41, 1, F.relu, 0, "pool").cuda()
@@ -222,7 +245,19 @@ def _fullsize_step(a, dyn, g, host, B=512, S=25):
         h1_dev = h1_seen[0].cpu()
         assert h1_dev.shape == h1_ref.shape
         bad_h1 = int((~torch.isclose(h1_dev, h1_ref, rtol=1e-4, atol=1e-5)).sum())
-        bad_lg = int((~torch.isclose(logits_dev.detach().cpu(), logits_free, rtol=1e-4, atol=1e-5)).sum())
+        lg_dev = logits_dev.detach().cpu()
+        off_lg = ~torch.isclose(lg_dev, logits_free, rtol=1e-4, atol=1e-5)
+        bad_lg = int(off_lg.sum())
+        # A logit is a 1 200-term fp32 dot product of operands of size ~1 that may cancel to ~0: two CORRECT fp32 evaluations in
+        # different summation orders differ by ~sqrt(K) eps sum|a||w| ~ 5e-5 absolute there, which atol 1e-5 cannot hold.  Entries
+        # outside the stated tolerance are therefore counted, reported, and held to the condition-number bound of the product
+        # (the bound tests/test_gpu_kernels.py::test_x6_split_is_exact_and_accurate uses): |diff| <= 2e-6 * sum_k |a_k| |w_k|.
+        prm1 = loss_free.params[1]
+        p1 = F.relu(F.linear(h1_ref, prm1["fc_pool.weight"], prm1["fc_pool.bias"])).numpy()
+        neigh1, _ = O.reduce_fwd(p1, blocks_ref[1]["local_idx"], "max")
+        s_abs = (h1_ref[:len(seeds)].abs() @ prm1["fc_self.weight"].abs().T + torch.as_tensor(neigh1).abs() @ prm1["fc_neigh.weight"].abs().T
+                 + prm1["fc_self.bias"].abs() + prm1["fc_neigh.bias"].abs())
+        worst_cond = float(((lg_dev - logits_free).abs() / s_abs).max())
         # ---- winner flips of the layer-0 max against the unforced oracle, counted and bounded
         p_ref = F.relu(F.linear(x_ref, prm0["fc_pool.weight"], prm0["fc_pool.bias"])).numpy()
         _, arg_ref = O.reduce_fwd(p_ref, blocks_ref[0]["local_idx"], "max")
@@ -232,14 +267,14 @@ def _fullsize_step(a, dyn, g, host, B=512, S=25):
         n_flip, n_pairs = int(flip.sum()), int(both.sum())
         cols = np.broadcast_to(np.arange(p_ref.shape[1]), arg_dev.shape)
         gap = np.abs(p_ref[arg_dev[flip], cols[flip]] - p_ref[arg_ref[flip], cols[flip]]) if n_flip else np.zeros(0)
-        print("forward parity vs the unforced oracle: h1 %d / %d entries outside rtol 1e-4 / atol 1e-5, logits %d / %d; layer-0 max "
-              "winners: %d of %d (dst, column) pairs flipped (%.2e), largest value gap between the two winners %.3g"
-              % (bad_h1, h1_ref.numel(), bad_lg, logits_free.numel(), n_flip, n_pairs, n_flip / max(n_pairs, 1),
-                 float(gap.max()) if n_flip else 0.0))
-        assert bad_h1 == 0 and bad_lg == 0
+        print("forward parity vs the unforced oracle: h1 %d / %d entries outside rtol 1e-4 / atol 1e-5, logits %d / %d (all cancellation "
+              "cases: worst |diff| / sum|a||w| = %.2e); layer-0 max winners: %d of %d (dst, column) pairs flipped (%.2e), largest value "
+              "gap between the two winners %.3g" % (bad_h1, h1_ref.numel(), bad_lg, logits_free.numel(), worst_cond, n_flip, n_pairs,
+                                                   n_flip / max(n_pairs, 1), float(gap.max()) if n_flip else 0.0))
+        assert bad_h1 == 0 and bad_lg <= 1e-3 * logits_free.numel() and worst_cond <= 2e-6
         # a flip is only legitimate between candidates that are equal to fp32 rounding (duplicates of one source, exact zeros after the
         # ReLU, values one ulp apart): few, and never between distinguishable values
-        assert n_flip <= 1e-3 * n_pairs and (n_flip == 0 or float(gap.max()) <= 1e-5), (n_flip, n_pairs)
+        assert n_flip <= 1e-5 * n_pairs and (n_flip == 0 or float(gap.max()) <= 1e-5), (n_flip, n_pairs)
     loss_ref = cpu.train_step(feat_cpu, lab_cpu, host["indptr"], host["indices"], deg, seeds, S, 5, 0, forced=forced)
     assert abs(float(loss) - free) <= 1e-4 * abs(free)             # the device's loss vs the plain oracle
     assert abs(loss_ref - free) <= 1e-5 * abs(free)                # forcing the winners does not move the forward value
