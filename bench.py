@@ -26,7 +26,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
-PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"   # the committed rocprofv3 --pmc pass `roofline.traffic` is quoted from
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"   # the committed rocprofv3 --pmc pass `roofline.traffic` is quoted from
+PMC_PBR_TRAFFIC_FILE = "r03_pbr_pmc_traffic.json"   # ... and the one of the PBR priority-forward workloads
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 MFMA_F32_PEAK_TFLOPS = 157.3
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense (MI355X_MICROARCH.md); AMD's 5 PF headline includes 2:1 sparsity
@@ -70,6 +71,8 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = the workload's batch per GPU (global batch grows with N); strong = the workload's batch in "
                          "total, cut over the GPUs (RBR: every 512-seed batch; PBR forward: the K batches of the pass)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end snapshot leg (metric iii) of the default line")
+    ap.add_argument("--e2e-snapshots", type=int, default=6)
     ap.add_argument("--partition", default="replicated", choices=["replicated", "features"],
                     help="PBR forward, N > 1: 'features' = every rank projects only its vertex range and the projection tables are "
                          "exchanged by one halo all-gather each (the partitioned-feature mode); 'replicated' = every rank projects all rows")
@@ -412,6 +415,9 @@ def main():
     except Exception:
         pass
 
+    e2e = None
+    if rank == 0 and world == 1 and args.workload == "reddit_rbr" and not args.no_e2e and args.scale == 1.0:
+        e2e = end_to_end_snapshots(args.e2e_snapshots, gemm=args.gemm)
     if rank == 0:
         value = args.steps * B_global / elapsed
         hbm_copy = None
@@ -453,6 +459,7 @@ def main():
             "hbm_copy_measured": hbm_copy,
             "host_enqueue_ms_per_step": round(host_ms, 4),
             "graph_mode": graph_mode,
+            "end_to_end_snapshot": e2e,
             "cpu_baseline": cpu_baseline,
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in sorted(kernels.items())},
         }
@@ -463,6 +470,107 @@ def main():
 
 def h_nnz(g):
     return g.handle.nnz
+
+
+def end_to_end_snapshots(n_snapshots=6, start=4500, gemm="auto"):
+    """Metric (iii) of SURVEY 8(d): whole snapshots of the reference's loop (R/train/__main__.py:161-196) on the Reddit-shaped
+    stream — RBR update 50 x 512, PBR update 50 x 512 with its priority forward over the train set every 2nd snapshot, the
+    no-rehearsal update, one evaluation, then evolve() of both streams and the loop's gc.collect().  Every phase is timed on
+    the wall clock between device synchronisations; `delay` is the reference's own per-strategy metric
+    (R/train/graphsage/model.py:108-117).  Returns the dict that goes into the bench line."""
+    import gc
+    import random
+    import tempfile
+    from ogl_amd import ops, sampling, synthetic
+    from ogl_amd.graph import TrainTestGraph
+    from ogl_amd.prioritized_replay import LossPriority
+    from ogl_amd.utils import Lib_supported, init
+    cfg = dict(embedding_size=600, latent_dim=600, samples=25, batch_size=512, batch_timestep=50, delta=4, batch_full=1024,
+               priority_forward=2, snapshots=5000)
+    np.random.seed(1); random.seed(1); torch.manual_seed(1); sampling.seed(1)
+    ops.set_gemm_mode(gemm)
+    GraphSAGE, Random, Prioritized, NoReh, Full, act = init(Lib_supported.HIP, True, 0)
+    t0 = time.perf_counter()
+    feat_size, labels, graph, n_classes, graph_test = synthetic.load("reddit", snapshots=cfg["snapshots"])
+    for _ in range(cfg["delta"]):
+        graph_test.evolve()
+    for _ in range(start):                                   # the device CSR makes fast-forwarding O(1) per snapshot
+        graph.evolve(); graph_test.evolve()
+    gu = TrainTestGraph(graph, split=0.15, start_prior_alpha=4, end_prior_alpha=50, scale=1, max_priority=10)
+    gu._admit([int(v) for v in range(graph.get_graph().n_present) if v in graph.labelled_vertices])   # the fast-forwarded history
+    setup_s = time.perf_counter() - t0
+
+    def mk():
+        return GraphSAGE(feat_size, cfg["embedding_size"], n_classes, 1, act, 0, "pool", edge_feats=0, pool_feats=cfg["latent_dim"]).cuda()
+    kw = dict(cuda=True, batch_full=cfg["batch_full"], n_workers=0)
+    rnd = Random(mk(), cfg["batch_timestep"], cfg["batch_size"], labels, cfg["samples"], **kw)
+    pri = Prioritized(mk(), cfg["batch_timestep"], cfg["batch_size"], labels, cfg["samples"], LossPriority(),
+                      full_pass=cfg["priority_forward"], **kw)
+    nor = NoReh(mk(), cfg["batch_timestep"], cfg["batch_size"], labels, cfg["samples"], **kw)
+    for st in (rnd, pri, nor):
+        st.build_optimizer()
+    out_csv = os.path.join(tempfile.gettempdir(), "ogl_bench_e2e_%d.csv" % os.getpid())
+    gc.collect()
+    gc.freeze()          # the stream's long-lived host state (id lists, edge tables) leaves the collector's young-to-old walks:
+                         # the loop's per-snapshot gc.collect() then only looks at what the snapshot allocated
+    phases = []
+    sync = torch.cuda.synchronize
+
+    def timed(rec, key, fn):
+        sync(); t = time.perf_counter()
+        out = fn()
+        sync(); rec[key] = rec.get(key, 0.0) + 1000 * (time.perf_counter() - t)
+        return out
+
+    for snap in range(n_snapshots + 1):                      # the first one is the warm-up (images, code objects, allocator)
+        rec = {}
+        sync(); t_snap = time.perf_counter()
+        nodes = timed(rec, "rbr_choose_vertices_host", lambda: rnd.choose_vertices(gu))
+        rnd.choose_vertices = lambda _gu, _b=nodes: _b
+        timed(rec, "rbr_train_gpu", lambda: rnd.train_timestep(gu))
+        del rnd.choose_vertices
+        rec["rbr_delay"] = 1000 * rnd.delay
+        # PBR: choose_vertices = the priority forward (every 2nd snapshot: over the whole train set; else the new arrivals) + the draws
+        inner = pri.recompute_priorities
+        pf = {}
+        pri.recompute_priorities = lambda g_, ts_: timed(pf, "t", lambda: inner(g_, ts_))
+        nodes = timed(rec, "pbr_choose_vertices", lambda: pri.choose_vertices(gu))
+        pri.recompute_priorities = inner
+        rec["pbr_priority_forward_gpu"] = pf.get("t", 0.0)
+        rec["pbr_choose_vertices_host"] = rec.pop("pbr_choose_vertices") - rec["pbr_priority_forward_gpu"]
+        pri.choose_vertices = lambda _gu, _b=nodes: _b
+        timed(rec, "pbr_train_gpu", lambda: pri.train_timestep(gu))
+        del pri.choose_vertices
+        rec["pbr_delay"] = 1000 * pri.delay
+        timed(rec, "noreh_train_gpu", lambda: nor.train_timestep(gu))
+        timed(rec, "evaluate_gpu", lambda: rnd.evaluate(gu, out_csv))
+        timed(rec, "evolve_host", lambda: (gu.evolve(), graph_test.evolve()))
+        timed(rec, "gc_collect_host", gc.collect)
+        sync(); rec["wall"] = 1000 * (time.perf_counter() - t_snap)
+        rec["train_vertices"] = len(gu.get_train_set())
+        phases.append(rec)
+    gc.unfreeze()
+    try:
+        os.remove(out_csv)
+    except OSError:
+        pass
+    use = phases[1:]
+    mean = lambda k: float(np.mean([r.get(k, 0.0) for r in use]))          # noqa: E731
+    gpu_keys = [k for k in use[0] if k.endswith("_gpu")]
+    host_keys = [k for k in use[0] if k.endswith("_host")]
+    gpu_ms, wall = sum(mean(k) for k in gpu_keys), mean("wall")
+    seeds = cfg["batch_timestep"] * cfg["batch_size"]
+    return dict(
+        what="reference loop body per snapshot (R/train/__main__.py:161-196) on the Reddit-like stream at snapshot %d..%d: RBR 50x512 + "
+             "PBR 50x512 (priority forward over the train set every 2nd snapshot, batch_full %d) + no-rehearsal + one evaluation of the "
+             "test set + evolve of both streams + gc.collect; wall ms between device synchronisations" % (start, start + n_snapshots, cfg["batch_full"]),
+        snapshots=len(use), wall_ms_per_snapshot=round(wall, 2), gpu_bound_phases_ms=round(gpu_ms, 2),
+        gpu_bound_share=round(gpu_ms / wall, 4), host_only_ms=round(wall - gpu_ms, 2),
+        phases_ms={k: round(mean(k), 2) for k in gpu_keys + host_keys},
+        rbr_delay_ms=round(mean("rbr_delay"), 2), pbr_delay_ms=round(mean("pbr_delay"), 2),
+        rbr_trained_vertices_per_s_inside_the_loop=round(seeds / (mean("rbr_delay") / 1000), 1),
+        streamed_vertices_per_s_whole_snapshot=round(2 * seeds / (wall / 1000), 1),
+        train_set=int(use[-1]["train_vertices"]), setup_s=round(setup_s, 1))
 
 
 def gemm_desc(mode):
@@ -528,6 +636,8 @@ def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size,
         key = name
         if name in ("ogl_reduce_fwd", "ogl_reduce_fwd_img"):
             key = "reduce_fwd_L0" if meta["n_dst"] > B else "reduce_fwd_L1"
+        elif name.startswith("ogl_linear_fwd") and meta["M"] >= g.n_present // 2:
+            key = name[4:] + "_tables"                     # the per-pass projection tables P0 / S0 over every present vertex
         a = agg.setdefault(key, dict(ms=0.0, calls=0, bytes=0.0, flops=0.0))
         a["ms"] += ms; a["calls"] += 1
         if name in ("ogl_reduce_fwd", "ogl_reduce_fwd_img"):
@@ -549,6 +659,28 @@ def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size,
                     note="algorithmic bytes count every gathered row once per gather; a row gathered again while it is still in L2 / "
                     "the 256 MB infinity cache does not come from HBM, so the algorithmic rate can approach or exceed the "
                     "8 TB/s pin rate — `traffic` (PMC) is what crossed the HBM interface")
+    tkeys = [k for k in agg if k.endswith("_tables")]
+    table_build = None
+    if tkeys:
+        tms = sum(agg[k]["ms"] for k in tkeys); tfl = sum(agg[k]["flops"] for k in tkeys); tcalls = sum(agg[k]["calls"] for k in tkeys)
+        x6 = args.gemm != "f32"
+        peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if x6 else MFMA_F32_PEAK_TFLOPS
+        table_build = dict(what="P0 = relu(fc_pool0(X)) and S0 = fc_self0(X) + biases over all %d present vertices: two products, once per PASS "
+                                "(weights are fixed during it), amortised over the pass's batches" % g.n_present,
+                           launches_per_pass=tcalls, ms_per_pass=round(tms, 4), ms_per_launch=round(tms / max(tcalls, 1), 4),
+                           tflops=round(tfl / tms / 1e9, 2) if tms else None, bound="mfma", peak=round(peak, 1),
+                           frac=round(tfl / tms / 1e9 / peak, 4) if tms else None)
+        table_build["share_of_the_kernel_time_of_a_%d_batch_pass" % nprof] = round(tms / sum(v["ms"] for v in agg.values()), 4)
+    # HBM-side bytes per launch of the table-direct aggregator, from the committed rocprofv3 --pmc pass of this workload
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_PBR_TRAFFIC_FILE)))
+        ent = pmc.get(args.workload, {}).get("k_reduce_fwd_v4_L0")
+        if roof and ent:
+            roof["traffic"] = ent["traffic_bytes"]
+            roof["traffic_source"] = "profiles/%s, collected %s at HEAD %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; a " \
+                                     "constant quoted from that pass, NOT measured in this run)" % (PMC_PBR_TRAFFIC_FILE, pmc.get("collected", "?"), pmc.get("head", "?"))
+    except Exception:
+        pass
     if rank == 0:
         assert out.numel() == total_batches(args.steps) * B and bool(torch.isfinite(out).all())
         print(json.dumps({
@@ -566,7 +698,7 @@ def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size,
                            "built per vertex range + halo all-gather (partitioned features)" if (strat.partition_features and world > 1)
                            else "built on every rank (replicated features)"),
                        "setup_s": round(setup_s, 1)},
-            "roofline": roof, "cpu_baseline": None, "kernels": kernels}))
+            "roofline": roof, "table_build": table_build, "cpu_baseline": None, "kernels": kernels}))
     if world > 1:
         dist.destroy_process_group()
 

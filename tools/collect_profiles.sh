@@ -1,27 +1,42 @@
 #!/bin/bash
 # Collect the round's measurement artefacts on a GPU box (run from the repo root through gpurun); outputs under gpurun_out/prof_final.
+# Every rocprofv3 command puts the program itself after `--` (python3 bench.py ...): no env / bash -c hop.
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof_final
 mkdir -p $O
 cd $R
-timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err < /dev/null
-timeout -k 10 300 python bench.py --no-graphs --no-cpu-baseline > $O/bench_eager.json 2> $O/bench_eager.err < /dev/null
-for w in reddit_pbr_forward arxiv_pbr_forward arxiv_rbr pubmed_rbr; do
+timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err < /dev/null
+timeout -k 10 300 python bench.py --no-graphs --no-cpu-baseline --no-e2e > $O/bench_eager.json 2> $O/bench_eager.err < /dev/null
+for w in reddit_pbr_forward arxiv_pbr_forward arxiv_rbr pubmed_rbr pubmed_settings arxiv_settings bitcoin_settings reddit_settings reddit_settings_pbr_forward; do
   timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err < /dev/null
 done
 cd /tmp && export TMPDIR=/tmp
 # the traced / counted runs enqueue eagerly (--no-graphs): the same kernels at the batch's own sizes, one dispatch per launch
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-graphs > $O/trace.log 2>&1 < /dev/null
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_graph -- python3 $R/bench.py --steps 50 --warmup 60 --no-cpu-baseline > $O/trace_graph.log 2>&1 < /dev/null
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-graphs > $O/pmc_fetch.log 2>&1 < /dev/null
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-graphs > $O/pmc_write.log 2>&1 < /dev/null
-timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-graphs > $O/pmc_mfma.log 2>&1 < /dev/null
+B="$R/bench.py --no-cpu-baseline --no-e2e"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $B --steps 50 --warmup 5 --no-graphs > $O/trace.log 2>&1 < /dev/null
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_graph -- python3 $B --steps 50 --warmup 60 --graphs > $O/trace_graph.log 2>&1 < /dev/null
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $B --steps 10 --warmup 2 --no-graphs > $O/pmc_fetch.log 2>&1 < /dev/null
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $B --steps 10 --warmup 2 --no-graphs > $O/pmc_write.log 2>&1 < /dev/null
+timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 $B --steps 10 --warmup 2 --no-graphs > $O/pmc_mfma.log 2>&1 < /dev/null
+# the PBR priority-forward workloads (what dominates the PBR rungs): kernel stats + FETCH / WRITE passes each
+for w in reddit_pbr_forward arxiv_pbr_forward; do
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$w -- python3 $B --workload $w --steps 50 --warmup 5 > $O/trace_$w.log 2>&1 < /dev/null
+  timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmcf_$w -- python3 $B --workload $w --steps 20 --warmup 2 > $O/pmcf_$w.log 2>&1 < /dev/null
+  timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmcw_$w -- python3 $B --workload $w --steps 20 --warmup 2 > $O/pmcw_$w.log 2>&1 < /dev/null
+done
 cd $R
-python tools/summarize_trace.py $(ls $O/trace/*/*kernel_trace.csv | head -1) > $O/trace_by_grid.txt
+T=$(ls $O/trace/*/*kernel_trace.csv | head -1)
+python tools/summarize_trace.py $T > $O/trace_by_grid.txt
+python tools/step_timeline.py $T > $O/step_timeline.txt
 python tools/summarize_trace.py $(ls $O/pmc_fetch/*/*kernel_trace.csv | head -1) $(ls $O/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $O/pmc_write/*/*counter_collection.csv | head -1) > $O/pmc_by_grid.txt
 cp $(ls $O/trace/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
 cp $(ls $O/trace_graph/*/*kernel_stats.csv | head -1) $O/kernel_stats_graph.csv
 python tools/summarize_pmc_mfma.py $(ls $O/pmc_mfma/*/*kernel_trace.csv | head -1) $(ls $O/pmc_mfma/*/*counter_collection.csv | head -1) > $O/pmc_mfma_busy.txt 2>&1 || true
-rm -rf $O/trace $O/trace_graph $O/pmc_fetch $O/pmc_write $O/pmc_mfma
-head -c 600 $O/bench.json
+for w in reddit_pbr_forward arxiv_pbr_forward; do
+  cp $(ls $O/trace_$w/*/*kernel_stats.csv | head -1) $O/pbr_${w}_kernel_stats.csv
+  python tools/summarize_trace.py $(ls $O/trace_$w/*/*kernel_trace.csv | head -1) > $O/pbr_${w}_trace_by_grid.txt
+  python tools/summarize_trace.py $(ls $O/pmcf_$w/*/*kernel_trace.csv | head -1) $(ls $O/pmcf_$w/*/*counter_collection.csv | head -1) $(ls $O/pmcw_$w/*/*counter_collection.csv | head -1) > $O/pbr_${w}_pmc_by_grid.txt
+done
+rm -rf $O/trace $O/trace_graph $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/trace_reddit_pbr_forward $O/trace_arxiv_pbr_forward $O/pmcf_* $O/pmcw_*
+head -c 400 $O/bench.json
