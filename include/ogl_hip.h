@@ -457,6 +457,15 @@ int ogl_replay_rebuild(double* node, int64_t cap, ogl_stream_t stream);
 int ogl_replay_sample(const double* node, int64_t cap, int64_t n_items, int64_t batch, const double* u_strat,
                       const double* u_redraw, int64_t n_redraw, int64_t* out_idx, double* out_ptotal, ogl_stream_t stream);
 int ogl_replay_note_keys(const int64_t* keys, int64_t n, int64_t start, int64_t* map, int64_t map_size, ogl_stream_t stream);
+/* TrendPriority / HybridPriority (R/train/prioritized_replay/generate_priority.py:11-58) with their per-vertex state in HBM:
+ * values / prev_loss double[n_vertices], init uint8[n_vertices] (1 = never scored), stats double[2] = {mean of the scored vertices'
+ * values, their count}.  For the n DISTINCT vertex ids of a batch and their per-seed losses (exactly one of loss32 / loss64):
+ * newcomers start from the running mean, values <- alpha values + (1 - alpha) max(0, loss - prev_loss), the mean is carried, and
+ * out[i] = the trend (loss_contrib < 0) or loss_contrib * loss + (1 - loss_contrib) * trend (HybridPriority).  *err is set to 1
+ * when an id is outside [0, n_vertices). */
+int ogl_priority_trend(const int64_t* ids, const float* loss32, const double* loss64, int64_t n, int64_t n_vertices, double* values,
+                       double* prev_loss, unsigned char* init, double* stats, double alpha, double loss_contrib, double* out, int* err,
+                       ogl_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -87,6 +87,7 @@ SIGNATURES = {
     "ogl_replay_rebuild": (_i, [_p, _i64, _p]),
     "ogl_replay_sample": (_i, [_p, _i64, _i64, _i64, _p, _p, _i64, _p, _p, _p]),
     "ogl_replay_note_keys": (_i, [_p, _i64, _i64, _p, _i64, _p]),
+    "ogl_priority_trend": (_i, [_p, _p, _p, _i64, _i64, _p, _p, _p, _p, _d, _d, _p, _p, _p]),
     "ogl_build_block_padded": (_i, [_p, _i64, _p, _i, _p, _i64, _p, _p, _p, _i64, _p]),
     "ogl_adam_step_multi_dev": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _d, _d, _d, _d, _p]),
     "ogl_publish_i64": (_i, [_p, _i, _p, _p, _p]),

@@ -200,3 +200,74 @@ extern "C" int ogl_replay_note_keys(const int64_t* keys, int64_t n, int64_t star
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }
+
+
+// ---- TrendPriority / HybridPriority on the device ----------------------------------------------------------------------------
+// R/train/prioritized_replay/generate_priority.py:11-58: per vertex an exponentially smoothed RISE of its loss,
+//   values[v] <- alpha values[v] + (1 - alpha) max(0, loss_v - prev_loss[v]),  a vertex scored for the first time starting from the
+// running mean `avg` of the scored vertices' values; HybridPriority mixes loss and trend.  State in HBM (fp64, as the reference's
+// np.float arrays): values[n_vertices], prev_loss[n_vertices], init[n_vertices] (1 until first scored), stats = {avg, n_items}.
+// One workgroup, the reference's phase order; the two sums over the batch are strided per thread and then reduced in a fixed
+// order (numpy sums pairwise: the mean agrees to fp64 rounding, not bit for bit).  ids must be distinct within a call.
+__device__ __forceinline__ double rp_block_sum(double v, double* sh) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wid] = v;
+  __syncthreads();
+  double r = 0.0;
+  for (int w = 0; w < RP_THREADS / 64; ++w) r += sh[w];
+  __syncthreads();
+  return r;
+}
+
+__global__ void __launch_bounds__(RP_THREADS) k_priority_trend(const int64_t* __restrict__ ids, const float* __restrict__ loss32,
+                                                               const double* __restrict__ loss64, int64_t n, int64_t n_vertices,
+                                                               double* __restrict__ values, double* __restrict__ prev_loss,
+                                                               unsigned char* __restrict__ init, double* __restrict__ stats,
+                                                               double alpha, double loss_contrib, double* __restrict__ out,
+                                                               int* __restrict__ err) {
+  __shared__ double sh[RP_THREADS / 64];
+  const int tid = threadIdx.x;
+  const double avg0 = stats[0];
+  double n_items = stats[1];
+  __syncthreads();
+  double fresh = 0.0;
+  for (int64_t i = tid; i < n; i += RP_THREADS) {
+    const int64_t v = ids[i];
+    if (v < 0 || v >= n_vertices) { atomicExch(err, 1); continue; }
+    if (init[v]) { init[v] = 0; values[v] = avg0; fresh += 1.0; }
+  }
+  n_items += rp_block_sum(fresh, sh);
+  double s_old = 0.0, s_new = 0.0;
+  for (int64_t i = tid; i < n; i += RP_THREADS) {
+    const int64_t v = ids[i];
+    if (v < 0 || v >= n_vertices) continue;
+    const double l = loss32 ? (double)loss32[i] : loss64[i];
+    const double old = values[v];
+    double rise = l - prev_loss[v];
+    rise = rise > 0.0 ? rise : 0.0;
+    const double nv = alpha * old + (1.0 - alpha) * rise;       // (values *= alpha; values += update * (1 - alpha))
+    values[v] = nv; prev_loss[v] = l;
+    s_old += old; s_new += nv;
+    out[i] = loss_contrib >= 0.0 ? nv * (1.0 - loss_contrib) + l * loss_contrib : nv;
+  }
+  s_old = rp_block_sum(s_old, sh);
+  s_new = rp_block_sum(s_new, sh);
+  if (tid == 0) {
+    stats[0] = n_items > 0.0 ? (avg0 * n_items - s_old + s_new) / n_items : avg0;
+    stats[1] = n_items;
+  }
+}
+
+extern "C" int ogl_priority_trend(const int64_t* ids, const float* loss32, const double* loss64, int64_t n, int64_t n_vertices,
+                                  double* values, double* prev_loss, unsigned char* init, double* stats, double alpha,
+                                  double loss_contrib, double* out, int* err, ogl_stream_t stream) {
+  if (n < 0 || n_vertices < 0 || !(alpha >= 0.0 && alpha <= 1.0) || loss_contrib > 1.0) return OGL_EINVAL;
+  if (n == 0) return OGL_OK;
+  if (!ids || (!loss32 == !loss64) || !values || !prev_loss || !init || !stats || !out || !err) return OGL_EINVAL;
+  hipLaunchKernelGGL(k_priority_trend, dim3(1), dim3(RP_THREADS), 0, (hipStream_t)stream, ids, loss32, loss64, n, n_vertices, values,
+                     prev_loss, init, stats, alpha, loss_contrib, out, err);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}

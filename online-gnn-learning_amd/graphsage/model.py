@@ -535,7 +535,7 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
             for b, n in enumerate(sizes):
                 batch_nodes_seed = np.asarray(subgraph_to_id[all_seeds[off:off + n]])
                 if on_device:
-                    graph_util.update_priorities_device(batch_nodes_seed, losses[b])
+                    graph_util.update_priorities_device(batch_nodes_seed, self._priorities_device(batch_nodes_seed, losses[b]))
                 else:
                     priorities = self.priority_strategy.get_priorities(batch_nodes_seed, all_loss[off:off + n])
                     graph_util.update_priorities_arrays(batch_nodes_seed, np.asarray(priorities, dtype=np.float64))
@@ -574,17 +574,31 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
             local = parallel.all_gather_counts(local, counts)
         batch_nids_l = list(subgraph_to_id[seeds_all.numpy()])
         if self._device_priorities(graph_util) and local.is_cuda:
-            graph_util.update_priorities_device(np.asarray(batch_nids_l), local)       # losses -> tree, all in HBM
+            ids = np.asarray(batch_nids_l)
+            graph_util.update_priorities_device(ids, self._priorities_device(ids, local))      # losses -> priorities -> tree, all in HBM
             return
         unaggregated_loss = local.cpu().numpy()
         priorities = self.priority_strategy.get_priorities(batch_nids_l, unaggregated_loss)
         graph_util.update_priorities_arrays(np.asarray(batch_nids_l), np.asarray(priorities, dtype=np.float64))
 
     def _device_priorities(self, graph_util):
-        """Losses go into the replay structure on the device when it lives there and priority == loss (LossPriority, the
-        strategy R/train/__main__.py:141 instantiates); the trend / hybrid strategies keep their host-side state."""
-        from ..prioritized_replay.priorities import LossPriority
-        return getattr(graph_util, "device_replay", False) and type(self.priority_strategy) is LossPriority
+        """Losses go into the replay structure on the device when it lives there: priority == loss (LossPriority, the strategy
+        R/train/__main__.py:141 instantiates) needs nothing in between; TrendPriority / HybridPriority keep their per-vertex state
+        in HBM too (priorities.DeviceTrend takes over the host object's arrays on first use)."""
+        from ..prioritized_replay.priorities import HybridPriority, LossPriority, TrendPriority
+        return getattr(graph_util, "device_replay", False) and type(self.priority_strategy) in (LossPriority, TrendPriority, HybridPriority)
+
+    def _priorities_device(self, ids_host, losses_dev):
+        """get_priorities(ids, losses) with both sides on the device."""
+        from ..prioritized_replay.priorities import DeviceTrend, LossPriority
+        if type(self.priority_strategy) is LossPriority:
+            return losses_dev
+        dt = getattr(self, "_device_trend", None)
+        if dt is None or dt.source is not self.priority_strategy:
+            dt = self._device_trend = DeviceTrend(self.priority_strategy, losses_dev.device)
+            dt.source = self.priority_strategy
+        ids_dev = torch.as_tensor(np.asarray(ids_host, dtype=np.int64)).to(losses_dev.device, non_blocking=True)
+        return dt.get_priorities_device(ids_dev, losses_dev)
 
     def get_model(self):
         return "prioritized"

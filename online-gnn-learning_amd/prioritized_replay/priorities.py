@@ -58,3 +58,59 @@ class HybridPriority(GeneratePriority):
         trend = self.trend_p.get_priorities(batch_nodes_seed, losses)
         return self.loss_contrib * np.asarray(self.loss_p.get_priorities(batch_nodes_seed, losses)) + \
             (1.0 - self.loss_contrib) * trend
+
+
+class DeviceTrend:
+    """The state of a ``TrendPriority`` / ``HybridPriority`` in HBM (``ogl_priority_trend``): the PBR passes' per-seed losses become
+    priorities without leaving the device.  Built from the host object the driver constructed (R/train/__main__.py:141 style:
+    ``TrendPriority(n_vertices)``), whose arrays it takes over; ``to_host()`` writes the state back into an equivalent host object."""
+
+    def __init__(self, strategy, device):
+        import torch
+        trend = strategy.trend_p if isinstance(strategy, HybridPriority) else strategy
+        assert isinstance(trend, TrendPriority)
+        self.loss_contrib = float(strategy.loss_contrib) if isinstance(strategy, HybridPriority) else -1.0
+        self.alpha = float(trend.alpha)
+        self.device = torch.device(device)
+        self.values = torch.as_tensor(trend.values, dtype=torch.float64).to(self.device)
+        self.prev_loss = torch.as_tensor(trend.prev_loss, dtype=torch.float64).to(self.device)
+        self.init = torch.as_tensor(trend.init.astype(np.uint8)).to(self.device)
+        self.stats = torch.tensor([float(trend.avg), float(trend.n_items)], dtype=torch.float64, device=self.device)
+        self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.n_vertices = int(self.values.numel())
+
+    def get_priorities_device(self, ids_dev, losses_dev):
+        """ids_dev int64 [n] (distinct original vertex ids, on the device), losses_dev float32 / float64 [n] -> float64 [n]."""
+        import torch
+        from .. import _lib
+        from ..ops import _ptr, _stream
+        n = int(ids_dev.numel())
+        assert ids_dev.dtype == torch.int64 and ids_dev.is_cuda and ids_dev.is_contiguous() and losses_dev.numel() == n
+        losses_dev = losses_dev.contiguous()
+        out = torch.empty(n, dtype=torch.float64, device=self.device)
+        l32 = losses_dev if losses_dev.dtype == torch.float32 else None
+        l64 = losses_dev if losses_dev.dtype == torch.float64 else None
+        if l32 is None and l64 is None:
+            l32 = losses_dev.float()
+        _lib.check(_lib.lib().ogl_priority_trend(_ptr(ids_dev), _ptr(l32), _ptr(l64), n, self.n_vertices, _ptr(self.values),
+                                                 _ptr(self.prev_loss), _ptr(self.init), _ptr(self.stats), self.alpha, self.loss_contrib,
+                                                 _ptr(out), _ptr(self.err), _stream()), "ogl_priority_trend")
+        return out
+
+    def check(self):
+        if int(self.err.item()):
+            raise IndexError("a vertex id outside [0, n_vertices) reached the trend priorities")
+
+    def to_host(self):
+        """A host strategy object in the state this one is in (tests; hand-over back to host-side code)."""
+        trend = TrendPriority(self.n_vertices, self.alpha)
+        trend.values = self.values.cpu().numpy().copy()
+        trend.prev_loss = self.prev_loss.cpu().numpy().copy()
+        trend.init = self.init.cpu().numpy().astype(bool)
+        st = self.stats.cpu().numpy()
+        trend.avg, trend.n_items = float(st[0]), int(round(st[1]))
+        if self.loss_contrib < 0:
+            return trend
+        hy = HybridPriority(self.n_vertices, self.alpha, self.loss_contrib)
+        hy.trend_p = trend
+        return hy

@@ -5,8 +5,8 @@ Needs /root/reference (not present on the GPU box); only the resulting small .np
 files are committed.  Nothing from the reference's sources is copied: the script imports
 ``graphsage.pytorch.aggregator_dgl.SAGEConv`` (R/train/graphsage/pytorch/aggregator_dgl.py:16-216),
 ``prioritized_replay.segment_tree.SumSegmentTree``, ``prioritized_replay.replay_buffer.
-PrioritizedReplayBuffer`` and ``prioritized_replay.generate_priority.LossPriority`` and records
-their inputs/outputs.
+PrioritizedReplayBuffer`` and ``prioritized_replay.generate_priority.{LossPriority, TrendPriority, HybridPriority}`` and
+records their inputs/outputs.
 
 The reference layer expects a DGL block.  DGL is absent, so ``FakeBlock`` below (our code) offers
 the handful of attributes the layer touches: ``local_scope``, ``is_block``,
@@ -149,6 +149,39 @@ def replay_cases():
     print("wrote replay.json")
 
 
+def priority_cases():
+    """TrendPriority / HybridPriority (R/train/prioritized_replay/generate_priority.py:11-58) over a sequence of batches with
+    recurring vertices: per-batch outputs and the final state.  The reference spells float64 ``np.float`` (generate_priority.py:13),
+    an alias numpy >= 1.24 no longer has: it is restored here, in the generating environment, so that the reference's own code
+    runs unchanged."""
+    if not hasattr(np, "float"):
+        np.float = float
+    from prioritized_replay.generate_priority import HybridPriority, TrendPriority
+    rng = np.random.default_rng(5)
+    n_vertices = 40
+    batches = []
+    for step in range(6):
+        ids = rng.choice(n_vertices, size=int(rng.integers(3, 12)), replace=False)
+        losses = rng.uniform(0.0, 4.0, len(ids)).astype(np.float32)          # float32 losses, as they come off the device
+        batches.append((ids, losses))
+    res = {}
+    for name, obj in (("trend_priority", TrendPriority(n_vertices, alpha=0.85)),
+                      ("hybrid_priority", HybridPriority(n_vertices, alpha=0.7, loss_contrib=0.4))):
+        outs = [np.asarray(obj.get_priorities(ids, losses), dtype=np.float64).tolist() for ids, losses in batches]
+        tp = obj.trend_p if name == "hybrid_priority" else obj
+        res[name] = dict(n_vertices=n_vertices, alpha=float(tp.alpha), loss_contrib=float(getattr(obj, "loss_contrib", -1.0)),
+                         batches=[dict(ids=[int(i) for i in ids], losses=[float(x) for x in losses]) for ids, losses in batches],
+                         outputs=outs, final_values=tp.values.tolist(), final_prev_loss=tp.prev_loss.tolist(),
+                         final_init=[bool(x) for x in tp.init], final_avg=float(tp.avg), final_n_items=int(tp.n_items))
+    path = os.path.join(OUT, "replay.json")
+    with open(path) as f:
+        allres = json.load(f)
+    allres.update(res)
+    with open(path, "w") as f:
+        json.dump(allres, f, indent=1)
+    print("added trend_priority / hybrid_priority to replay.json")
+
+
 if __name__ == "__main__":
     #            tag            mode      n_dst n_src fanout fin fout pool  iso   seed
     sageconv_case("mean_toy", "mean", 4, 9, 3, 6, 5, None, 0.25, 11)
@@ -158,3 +191,4 @@ if __name__ == "__main__":
     sageconv_case("meanpool_mid", "meanpool", 96, 700, 25, 50, 32, 40, 0.1, 22)
     sageconv_case("gcn_mid", "gcn", 96, 700, 25, 50, 32, None, 0.1, 23)
     replay_cases()
+    priority_cases()

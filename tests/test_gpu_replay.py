@@ -154,3 +154,74 @@ def test_pbr_passes_feed_the_device_buffer_without_host_copies():
     # two independent training runs: the backward's float atomics sum in a run-dependent order, so weights — and losses — agree
     # to ~1e-7 relative, not bit for bit; the buffer arithmetic itself is held to 1e-12 in the tests above
     np.testing.assert_allclose(outs[True], outs[False], rtol=1e-4, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["trend_priority", "hybrid_priority"])
+def test_device_trend_priorities_match_reference_golden(name):
+    """TrendPriority / HybridPriority with their state in HBM (ogl_priority_trend) against the reference's own outputs
+    (tests/golden/replay.json, generated by running R/train/prioritized_replay/generate_priority.py:11-58)."""
+    import json
+    import os
+    from ogl_amd.prioritized_replay import HybridPriority, TrendPriority
+    from ogl_amd.prioritized_replay.priorities import DeviceTrend
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "replay.json")))[name]
+    host = TrendPriority(g["n_vertices"], g["alpha"]) if name == "trend_priority" else HybridPriority(g["n_vertices"], g["alpha"], g["loss_contrib"])
+    dev = DeviceTrend(host, "cuda")
+    for b, want in zip(g["batches"], g["outputs"]):
+        ids = torch.as_tensor(b["ids"], dtype=torch.int64).cuda()
+        losses = torch.as_tensor(b["losses"], dtype=torch.float32).cuda()        # float32, as the CE kernel writes them
+        got = dev.get_priorities_device(ids, losses)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-12, atol=1e-14)
+    dev.check()
+    back = dev.to_host()
+    tp = back.trend_p if name == "hybrid_priority" else back
+    np.testing.assert_allclose(tp.values, g["final_values"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(tp.prev_loss, g["final_prev_loss"], rtol=0, atol=0)
+    assert [bool(x) for x in tp.init] == g["final_init"] and tp.n_items == g["final_n_items"]
+    assert abs(tp.avg - g["final_avg"]) <= 1e-12 * max(1.0, abs(g["final_avg"]))
+    # a large batch (many strided trips per thread) against the host class
+    rng = np.random.default_rng(2)
+    n = 50000
+    h2 = TrendPriority(n, 0.85) if name == "trend_priority" else HybridPriority(n, 0.85, 0.5)
+    d2 = DeviceTrend(h2, "cuda")
+    for _ in range(3):
+        ids = rng.choice(n, 30000, replace=False)
+        ls = rng.uniform(0, 5, len(ids)).astype(np.float32)
+        want = h2.get_priorities(ids, ls)
+        got = d2.get_priorities_device(torch.as_tensor(ids).cuda(), torch.as_tensor(ls).cuda())
+        np.testing.assert_allclose(got.cpu().numpy(), np.asarray(want, dtype=np.float64), rtol=1e-11, atol=1e-13)
+
+
+def test_pbr_strategy_keeps_trend_priorities_on_the_device():
+    """A PBR strategy built with HybridPriority: the priority forward's losses become priorities and reach the HBM buffer without
+    a host copy, and equal the host pipeline's (host class fed with the same losses)."""
+    import ogl_amd  # noqa: F401
+    import torch.nn.functional as F
+    from ogl_amd import sampling, synthetic
+    from ogl_amd.graph import TrainTestGraph
+    from ogl_amd.graphsage import GraphSAGE
+    from ogl_amd.graphsage.model import PrioritizedHipSupervisedGraphSage
+    from ogl_amd.prioritized_replay import HybridPriority
+    feat_size, labels, dyn, n_classes, _ = synthetic.load("toy", device="cuda")
+    gu = TrainTestGraph(dyn, split=0.15, start_prior_alpha=4, end_prior_alpha=50, scale=1, max_priority=10)
+    for _ in range(5):
+        gu.evolve()
+    torch.manual_seed(0)
+    model = GraphSAGE(feat_size, 16, n_classes, 1, F.relu, 0, "pool").cuda()
+    n_vertices = len(labels)
+    strat = PrioritizedHipSupervisedGraphSage(model, 2, 8, labels, 5, HybridPriority(n_vertices, 0.85, 0.5), full_pass=1, cuda=True, batch_full=64)
+    strat.build_optimizer()
+    twin = HybridPriority(n_vertices, 0.85, 0.5)
+    seen = []
+    inner = gu.update_priorities_device
+    gu.update_priorities_device = lambda ids, pr: (seen.append((np.asarray(ids).copy(), pr)), inner(ids, pr))
+    losses_seen = []
+    orig = strat._priorities_device
+    strat._priorities_device = lambda ids, ls: (losses_seen.append(ls.detach().cpu().numpy().copy()), orig(ids, ls))[1]
+    sampling.seed(3)
+    for _ in range(2):
+        strat.recompute_priorities(gu, gu.get_train_set())
+    assert len(seen) == 2 and all(pr.is_cuda and pr.dtype == torch.float64 for _, pr in seen)
+    for (ids, pr), ls in zip(seen, losses_seen):
+        want = twin.get_priorities(ids, ls)
+        np.testing.assert_allclose(pr.cpu().numpy(), np.asarray(want, dtype=np.float64), rtol=1e-11, atol=1e-13)

@@ -71,6 +71,24 @@ def test_priority_strategies():
     assert p1.shape == (2,) and p2[0] > p2[1] >= 0
 
 
+@pytest.mark.parametrize("name", ["trend_priority", "hybrid_priority"])
+def test_trend_and_hybrid_priorities_match_reference_golden(name):
+    """The host classes against outputs of the reference's own TrendPriority / HybridPriority
+    (R/train/prioritized_replay/generate_priority.py:11-58, run by tests/golden/make_golden.py): every batch's priorities and
+    the final per-vertex state."""
+    from ogl_amd.prioritized_replay import HybridPriority
+    g = GOLD[name]
+    obj = TrendPriority(g["n_vertices"], g["alpha"]) if name == "trend_priority" else HybridPriority(g["n_vertices"], g["alpha"], g["loss_contrib"])
+    for b, want in zip(g["batches"], g["outputs"]):
+        got = obj.get_priorities(np.asarray(b["ids"]), np.asarray(b["losses"], dtype=np.float32))
+        np.testing.assert_allclose(np.asarray(got, dtype=np.float64), want, rtol=1e-13, atol=1e-15)
+    tp = obj.trend_p if name == "hybrid_priority" else obj
+    np.testing.assert_allclose(tp.values, g["final_values"], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(tp.prev_loss, g["final_prev_loss"], rtol=0, atol=0)
+    assert [bool(x) for x in tp.init] == g["final_init"] and tp.n_items == g["final_n_items"]
+    assert abs(tp.avg - g["final_avg"]) <= 1e-13 * max(1.0, abs(g["final_avg"]))
+
+
 def test_time_ordered_csr_vertex_and_edge():
     rng = np.random.default_rng(1)
     n, e = 50, 400
