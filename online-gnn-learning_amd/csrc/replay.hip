@@ -250,7 +250,10 @@ __global__ void __launch_bounds__(RP_THREADS) k_priority_trend(const int64_t* __
     const double nv = alpha * old + (1.0 - alpha) * rise;       // (values *= alpha; values += update * (1 - alpha))
     values[v] = nv; prev_loss[v] = l;
     s_old += old; s_new += nv;
-    out[i] = loss_contrib >= 0.0 ? nv * (1.0 - loss_contrib) + l * loss_contrib : nv;
+    // HybridPriority: trend * (1 - c) + loss * c, where `loss * c` is evaluated in the losses' own precision (numpy: a float32 array
+    // times a Python float stays float32) and then added in float64
+    const double lc = loss32 ? (double)(loss32[i] * (float)loss_contrib) : l * loss_contrib;
+    out[i] = loss_contrib >= 0.0 ? nv * (1.0 - loss_contrib) + lc : nv;
   }
   s_old = rp_block_sum(s_old, sh);
   s_new = rp_block_sum(s_new, sh);
