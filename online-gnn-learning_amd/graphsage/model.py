@@ -63,7 +63,8 @@ class SupervisedGraphSage:
         self._staged_probes = []    # (host seconds, GPU seconds) of the probed snapshots of the current decision
         self._staged_decided_at = 0
         self.staged_auto_log = []   # every decision taken (the run log of the policy)
-        self.STAGED_AUTO_HOST_FRACTION = 0.9
+        self.STAGED_AUTO_HOST_FRACTION = 0.75     # replayed steps cost the GPU the same as eager ones since round 3 (forked branches
+                                                  # inside the graph): replay as soon as the host is within 25 % of being the bottleneck
         self.STAGED_AUTO_PROBES = 3       # snapshots timed per decision; the MEDIAN host / GPU ratio decides (one snapshot's wall
                                           # time carries allocator / GC hiccups and back-pressure)
         self.STAGED_AUTO_REPROBE = 500    # eligible snapshots after which the decision is re-taken (0: never) — the graph grows

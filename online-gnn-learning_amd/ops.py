@@ -729,12 +729,19 @@ def _capturing():
     return torch.cuda.is_current_stream_capturing()
 
 
+def _alive(ent):
+    """The tensors an entry was built from still exist.  The key is (address, version counter): a NEW tensor allocated at the
+    address of a freed one (another model's parameters in the same process) carries the same key — but then the old tensor,
+    which the entry remembers weakly, is gone."""
+    return all(r() is not None for r in ent[2])
+
+
 def weight_image(kind, *tensors):
     """The prepared image for this request, or None.  An image built while a hipGraph was being captured exists only inside
     that graph's replays (its split kernel did not run), and one built eagerly is not rebuilt by a replay: an entry serves
     only the mode it was made in."""
     ent = _W_IMAGES.get(_wkey(kind, *tensors))
-    return ent[0] if (ent is not None and ent[1] == _capturing()) else None
+    return ent[0] if (ent is not None and ent[1] == _capturing() and _alive(ent)) else None
 
 
 def weight_images_prepare(requests):
@@ -749,14 +756,14 @@ def weight_images_prepare(requests):
     cap = _capturing()
     for kind, ts in requests:
         key = _wkey(kind, *ts)
-        if key in _W_IMAGES and _W_IMAGES[key][1] == cap:
+        if key in _W_IMAGES and _W_IMAGES[key][1] == cap and _alive(_W_IMAGES[key]):
             continue
         if kind == "bsum":
             if len(parts) + 1 > 8:
                 break
             out = torch.empty(ts[0].numel(), dtype=torch.float32, device=ts[0].device)
             parts.append((None, ts[0].numel(), 0, 2, 0, ts[0], ts[1], out, 0, 0))
-            made.append((key, out))
+            made.append((key, out, ts))
             continue
         w = as_mat(ts[0])
         dev = w.device
@@ -778,7 +785,7 @@ def weight_images_prepare(requests):
         else:
             parts.append((w, R, w.shape[1], 0, 1, ts[2], ts[3], buf, G, 0))
             parts.append((w2, R, w2.shape[1], 0, 0, None, None, buf, G, groups[0]))
-        made.append((key, X3Image(buf, R, 32 * G if kind == "cat" else (w.shape[0] if kind == "T" else w.shape[1] + 1))))
+        made.append((key, X3Image(buf, R, 32 * G if kind == "cat" else (w.shape[0] if kind == "T" else w.shape[1] + 1)), ts))
     if not parts:
         return
     arr = (_X3SplitPart * len(parts))()
@@ -789,8 +796,9 @@ def weight_images_prepare(requests):
             meta=dict(parts=len(parts)))
     if len(_W_IMAGES) > 32:
         _W_IMAGES.clear()               # stale versions of re-assigned parameters: never let them pile up
-    for key, img in made:
-        _W_IMAGES[key] = (img, cap)
+    import weakref
+    for key, img, ts in made:
+        _W_IMAGES[key] = (img, cap, [weakref.ref(t) for t in ts if t is not None])
 
 
 def _n1_images_ok(M, *widths):
@@ -1161,19 +1169,36 @@ def _dw_out(w, N, K):
 # Tensors the side work reads were allocated on the main stream: ``side_keep`` holds them until the join, so the caching allocator
 # cannot hand their memory to a later main-stream kernel while the side stream still reads it.
 FORK_BACKWARD = os.environ.get("OGL_FORK_BWD", "1") != "0"
-# in a captured step the fork becomes parallel graph branches: measured SLOWER than the serial graph (1.108 vs 1.097 ms per Reddit
-# step: the branches' cross-stream edges cost more than the overlap returns), so captures stay serial unless asked
-FORK_IN_GRAPHS = os.environ.get("OGL_FORK_BWD_GRAPHS", "0") == "1"
+# in a captured step the fork becomes parallel graph branches (with the fork points placed where the side work's inputs are ready:
+# 1.10 -> 1.05-1.07 ms per replayed Reddit step, the eager figure; a first placement that forked late was 1 % slower than serial)
+FORK_IN_GRAPHS = os.environ.get("OGL_FORK_BWD_GRAPHS", "1") != "0"
 _SIDE = {"streams": {}, "keep": [], "active": False, "off": 0}
 
 
+def fork_point():
+    """Marks the place in the main stream a later ``side_section(at=...)`` has to wait for — everything enqueued up to HERE,
+    not up to where the section is opened: the section's work can then run beside what the main stream enqueues in between.
+    None when the fork is off."""
+    if not FORK_BACKWARD or _PROFILE is not None or _SIDE["off"] or _GRAD_SINKS or (not FORK_IN_GRAPHS and _capturing()):
+        return None
+    ev = torch.cuda.Event()
+    ev.record()
+    return ev
+
+
 class _SideSection:
+    def __init__(self, at=None):
+        self._at = at
+
     def __enter__(self):
         dev = torch.cuda.current_device()
         st = _SIDE["streams"].get(dev)
         if st is None:
             st = _SIDE["streams"][dev] = torch.cuda.Stream(device=dev)
-        st.wait_stream(torch.cuda.current_stream())
+        if self._at is not None:
+            st.wait_event(self._at)
+        else:
+            st.wait_stream(torch.cuda.current_stream())
         self._ctx = torch.cuda.stream(st)
         self._ctx.__enter__()
         if not _SIDE["active"]:
@@ -1195,14 +1220,14 @@ class _NoSection:
         return False
 
 
-def side_section(*keep):
-    """Context manager: the body's launches go to the side stream, ordered after everything enqueued so far (a no-op context when
-    the fork is off: under per-kernel profiling, data parallelism — gradient hooks launch collectives on the main stream — or
-    OGL_FORK_BWD=0)."""
+def side_section(*keep, at=None):
+    """Context manager: the body's launches go to the side stream, ordered after everything the main stream had enqueued at
+    ``at`` (a ``fork_point()``; default: so far).  A no-op context when the fork is off: under per-kernel profiling, data
+    parallelism — gradient hooks launch collectives on the main stream — or OGL_FORK_BWD=0."""
     if not FORK_BACKWARD or _PROFILE is not None or _SIDE["off"] or _GRAD_SINKS or (not FORK_IN_GRAPHS and _capturing()):
         return _NoSection()
     _SIDE["keep"].extend(t for t in keep if t is not None)
-    return _SideSection()
+    return _SideSection(at)
 
 
 def side_join():
@@ -1252,13 +1277,14 @@ class _LinearFn(torch.autograd.Function):
             if x_rows is not None:
                 raise RuntimeError("gradient w.r.t. a row-gathered table is not supported (features carry no grad)")
             dx = linear_bwd_input(dy, w, y, dy_img=dy_img)
+        forked = dy_img is not None and dy.shape[0] >= X3_BWW_MIN_ROWS
+        at = fork_point() if forked else None                  # dy and its image are ready here
         if x2 is not None and need[3]:
             # the input gradients first: they are the critical path of the backward pass (the weight gradients below are leaves)
             if x2_rows is not None:
                 raise RuntimeError("gradient w.r.t. a row-gathered table is not supported")
             dx2 = linear_bwd_input(dy, w2, y, dy_img=dy_img)
-        forked = dy_img is not None and dy.shape[0] >= X3_BWW_MIN_ROWS
-        with (side_section(dy, dy_img, x, x2, ctx.x2_img) if forked else _NoSection()):
+        with (side_section(dy, dy_img, x, x2, ctx.x2_img, at=at) if forked else _NoSection()):
             dw, db, dw2, db2 = _LinearFn._weight_grads(ctx, dy, dy_img, x, w, x2, w2, x_rows, x2_rows, need)
         return dx, dw, (db if ctx.has_bias else None), dx2, dw2, None, None, None, (db2 if ctx.has_bias2 else None)
 
@@ -1448,14 +1474,18 @@ class _SagePoolLayerFn(torch.autograd.Function):
             # few output columns (the output layer): the combine's backward in two launches, its input gradient for the pooled rows
             # scattered to the winners as it is computed; the fc_self part joins dh in the epilogue of the fc_pool input gradient
             slot = getattr(ctx, "dp_slot", None)
-            dx_self, dp = out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src,
-                                               dp_zeroed=take_zeroed(slot, n_src, h.shape[1]) if slot is not None else None)
-            dp_img = x3_split(dp) if (N1_BWD_SPLIT and _n1_images_ok(n_src, dp.shape[1], w_pool.shape[1])) else None
-            dh = linear_bwd_input(dp, w_pool, None, dy_img=dp_img, add_head=dx_self)
-            # the layer's weight gradients: leaves of the backward graph, on the side stream when the layer is tall
-            with (side_section(dy, h, neigh, dp, dp_img, ctx.h_img) if dp_img is not None else _NoSection()):
+            tall = N1_BWD_SPLIT and _n1_images_ok(n_src, h.shape[1], w_pool.shape[1])
+            # the layer's weight gradients are leaves of the backward graph: on the side stream when the layer is tall — the two
+            # few-column ones right away (beside the equally small input-gradient launch), fc_pool's once dP and its image exist
+            with (side_section(dy, h, neigh) if tall else _NoSection()):
                 dw_self, dw_neigh, db, db2 = out_layer_bwd_weights(dy, h_dst, neigh, want_bias=ctx.has_bias,
                                                                    dws_out=_dw_out(w_self, *w_self.shape), dwn_out=_dw_out(w_neigh, *w_neigh.shape))
+            dx_self, dp = out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src,
+                                               dp_zeroed=take_zeroed(slot, n_src, h.shape[1]) if slot is not None else None)
+            dp_img = x3_split(dp) if tall else None
+            at = fork_point() if tall else None
+            dh = linear_bwd_input(dp, w_pool, None, dy_img=dp_img, add_head=dx_self)
+            with (side_section(dp, dp_img, ctx.h_img, at=at) if tall else _NoSection()):
                 dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias, x_img=ctx.h_img, dy_img=dp_img, dw_out=_dw_out(w_pool, *w_pool.shape))
             return (dh, dw_pool, db_pool if ctx.has_pool_bias else None, dw_self, dw_neigh, db if ctx.has_bias else None,
                     db2 if ctx.has_bias else None, None, None, None)
