@@ -71,6 +71,10 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = the workload's batch per GPU (global batch grows with N); strong = the workload's batch in "
                          "total, cut over the GPUs (RBR: every 512-seed batch; PBR forward: the K batches of the pass)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="one rank only: initialise an RCCL process group of world size 1 and run the N-rank code path through it "
+                         "(seed shards, gradient buckets + all-reduce calls, sharded passes): what a rank of an N-GPU job costs on "
+                         "this GPU, minus the bytes on the links")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end snapshot leg (metric iii) of the default line")
     ap.add_argument("--e2e-snapshots", type=int, default=6)
     ap.add_argument("--partition", default="replicated", choices=["replicated", "features"],
@@ -119,23 +123,36 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
     torch.cuda.set_device(local_rank % max(ndev, 1))
     ranks_seen = 1
-    if world > 1:
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            # (gloo's C++ side prints its connection banner on stdout: keep stdout for the one JSON line)
-            sys.stdout.flush()
-            saved = os.dup(1)
-            os.dup2(2, 1)
-            try:
+    if args.force_dist:
+        if world != 1:
+            raise SystemExit("bench.py: --force-dist is a one-rank rehearsal")
+        import socket
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1 or args.force_dist:
+        # RCCL and gloo both print a banner (library versions / connection report) on STDOUT from their C++ side while the
+        # communicator comes up: stdout is kept for the one JSON line, so the group is created — and its first collective
+        # run — with file descriptor 1 pointed at stderr
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.dist_backend == "nccl" or args.force_dist:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
                 dist.init_process_group("gloo", rank=rank, world_size=world)
-                dist.barrier()
-            finally:
-                os.dup2(saved, 1)
-                os.close(saved)
-        one = torch.ones(1, dtype=torch.int64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(one)                                 # the first collective of the run: every rank is really there
-        ranks_seen = int(one.item())
+            nccl = dist.get_backend() == "nccl"
+            one = torch.ones(1, dtype=torch.int64, device="cuda" if nccl else "cpu")
+            dist.all_reduce(one)                             # the first collective of the run: every rank is really there
+            ranks_seen = int(one.item())
+            dist.barrier()
+            if nccl:
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
         if ranks_seen != args.gpus:
             raise SystemExit("bench.py: %d rank(s) answered the first all-reduce, --gpus %d" % (ranks_seen, args.gpus))
     args.ranks_seen = ranks_seen
@@ -144,6 +161,8 @@ def main():
     from ogl_amd import ops, optim, parallel, sampling, synthetic
     from ogl_amd.graphsage import GatheredRows, GraphSAGE
 
+    if args.force_dist:
+        parallel.force_distributed(True)
     ops.set_gemm_mode(args.gemm)
     wl = WORKLOADS[args.workload]
     B, S, H, bt = wl["batch"], wl["samples"], wl["hidden"], wl["batch_timestep"]
@@ -450,9 +469,10 @@ def main():
                                                       ("; %d new size bucket(s) captured inside the timed region" % captures_timed)
                                                       if timed_mode.startswith("captured") else "")
                        + ("; auto policy probe: %s" % getattr(strat, "staged_auto_probe", None) if strat.use_graphs == "auto" else ""),
-                       "parallelism": "dp%d (seed-sharded replicas, two-bucket grad all-reduce %s)" % (
+                       "parallelism": "dp%d (seed-sharded replicas, two-bucket grad all-reduce %s)%s" % (
                            world, "after the replayed forward + backward graph; optimiser eager" if "staged_dp" in forms_timed
-                           else "overlapped with backward"),
+                           else "overlapped with backward",
+                           " — FORCED through a world-size-1 RCCL group (--force-dist)" if args.force_dist else ""),
                        "avg_unique_input_nodes_n0": round(n0_avg, 1), "avg_n1": round(n1_avg, 1), "setup_s": round(setup_s, 1)},
             "roofline": roof_gemm if roof_gemm else roof_aggr,
             "roofline_aggregator": roof_aggr,
@@ -464,7 +484,7 @@ def main():
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in sorted(kernels.items())},
         }
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.destroy_process_group()
 
 
@@ -699,7 +719,7 @@ def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size,
                            else "built on every rank (replicated features)"),
                        "setup_s": round(setup_s, 1)},
             "roofline": roof, "table_build": table_build, "cpu_baseline": None, "kernels": kernels}))
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.destroy_process_group()
 
 

@@ -160,6 +160,9 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
     # (R/settings/pubmed.json and elliptic.json use samples = 45 at batch 32: 32 * 46^2 = 67 712 rows of upper bound — the buffers
     # are index arrays, 0.5 MB; the GEMMs of the step run at the batch's own size bucket, not at the bound)
     SAMPLED_GRAPH_MAX_ROWS = 1 << 18
+    # data-parallel replicas replay their forward + backward (form "staged_dp") from this many rows of GLOBAL upper bound
+    # n_global (1 + S) on: below it the staged form's size buckets (2 048 / 256 rows) would mostly multiply padding
+    STAGED_DP_MIN_ROWS = 4096
 
     def build_optimizer(self):
         self._sg = None
@@ -217,9 +220,12 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         if not (self.use_graphs and ops._PROFILE is None and all(l.feat_drop.p == 0 for l in self.graphsage_model.layers)):
             return False
         if form == "staged_dp":
-            # a data-parallel replica: forward + backward captured, all-reduce and optimiser eager.  OPT-IN (use_graphs = True):
-            # a stream capture next to RCCL's watchdog thread has not been rehearsed on real links, so "auto" never picks it
-            return self.gsync is not None and self.use_graphs is True
+            # a data-parallel replica: forward + backward captured, ONE all-reduce and the optimiser eager.  The eager replica step
+            # is host-bound (measured through a world-size-1 RCCL group, bench.py --force-dist: 1.39 ms of host time per 1.07 ms
+            # step — hooks, bucket views, two collectives from Python), the replayed one is not (0.45 ms): "auto" replays.  The
+            # decision must be the same on every rank (it fixes the sequence of collectives), so it is taken from configuration
+            # and GLOBAL quantities only — never from a rank's own timing or block sizes (train_step: n_global).
+            return self.gsync is not None and bool(self.use_graphs)
         if self.gsync is not None or not getattr(self.optimizer, "capturable", False):
             return False
         if form == "staged" and self.use_graphs == "auto":
@@ -433,17 +439,27 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             return loss
         # rank-sharded batch: this rank's seeds only; the gradient is that of the mean over the whole batch
         n_local = int(seeds.numel())
-        if (n_local > 0 and self.gsync is not None and self._graphs_ok("staged_dp")
-                and (on_rows is None or self.reduction != "mean")):
+        big = self.use_graphs is True or int(n_global) * (1 + self.samples) >= self.STAGED_DP_MIN_ROWS      # (global: same on every rank)
+        if self.gsync is not None and self._graphs_ok("staged_dp") and big and (on_rows is None or self.reduction != "mean"):
             # replayed replica step: the captured graph ends with the gradients of the LOCAL mean loss in its static tensors; the
             # all-reduce weights them by n_local / n_global (= the gradient of the mean over the whole batch), then the optimiser
-            n0, n1 = int(input_nodes.numel()), blocks[1].number_of_src_nodes()
-            with self.gsync.no_sync():                          # (a capture runs autograd for real: its hooks must not launch a collective)
-                sg = self._step_graphs().staged_step(graph, seeds, blocks, n0, n1, apply=False)
-            for p, gr in zip(self.graphsage_model.parameters(), sg.grads):
-                p.grad = gr                                   # (the previous sync left views of its flat buckets there)
-            self.gsync.sync(weight=n_local / float(n_global))
+            if n_local > 0:
+                n0, n1 = int(input_nodes.numel()), blocks[1].number_of_src_nodes()
+                with self.gsync.no_sync():                      # (a capture runs autograd for real: its hooks must not launch a collective)
+                    sg = self._step_graphs().staged_step(graph, seeds, blocks, n0, n1, apply=False)
+                for p, gr in zip(self.graphsage_model.parameters(), sg.grads):
+                    p.grad = gr                               # (the previous sync left views of its flat bucket there)
+            else:                                               # more ranks than seeds in this batch: zeros into the same collective
+                sg = None
+                for p in self.gsync.params:
+                    p.grad = None
+            # nothing overlaps the exchange here (the graph has ended), so it is ONE flat bucket: one collective's latency, not two
+            self.gsync.sync(weight=n_local / float(n_global), single=True)
             self.optimizer.step()
+            if sg is None:
+                if on_rows is not None:
+                    on_rows(seeds, torch.zeros(0, device=graph.device))
+                return None
             if on_rows is not None:
                 on_rows(seeds, sg.loss_rows.clone())
             if self.step_hook is not None:

@@ -1179,7 +1179,7 @@ def fork_point():
     """Marks the place in the main stream a later ``side_section(at=...)`` has to wait for — everything enqueued up to HERE,
     not up to where the section is opened: the section's work can then run beside what the main stream enqueues in between.
     None when the fork is off."""
-    if not FORK_BACKWARD or _PROFILE is not None or _SIDE["off"] or _GRAD_SINKS or (not FORK_IN_GRAPHS and _capturing()):
+    if not FORK_BACKWARD or _PROFILE is not None or _SIDE["off"] or (not FORK_IN_GRAPHS and _capturing()):
         return None
     ev = torch.cuda.Event()
     ev.record()
@@ -1223,11 +1223,21 @@ class _NoSection:
 def side_section(*keep, at=None):
     """Context manager: the body's launches go to the side stream, ordered after everything the main stream had enqueued at
     ``at`` (a ``fork_point()``; default: so far).  A no-op context when the fork is off: under per-kernel profiling, data
-    parallelism — gradient hooks launch collectives on the main stream — or OGL_FORK_BWD=0."""
-    if not FORK_BACKWARD or _PROFILE is not None or _SIDE["off"] or _GRAD_SINKS or (not FORK_IN_GRAPHS and _capturing()):
+    OGL_FORK_BWD=0.  (Data parallelism: the gradient hooks launch their bucket's collective FROM the side stream,
+    ``collective_section``, so the main stream's input-gradient chain is never made to wait for a weight gradient.)"""
+    if not FORK_BACKWARD or _PROFILE is not None or _SIDE["off"] or (not FORK_IN_GRAPHS and _capturing()):
         return _NoSection()
     _SIDE["keep"].extend(t for t in keep if t is not None)
     return _SideSection(at)
+
+
+def collective_section():
+    """Context for launching a gradient bucket's all-reduce in the middle of a forked backward: when side work is outstanding the
+    launch (and the bucket fill before it) happens on the side stream, after it has also caught up with the main stream — RCCL's
+    own stream then waits for the weight gradients without the main stream waiting for anything.  Otherwise a no-op context."""
+    if not _SIDE["active"]:
+        return _NoSection()
+    return _SideSection(None)
 
 
 def side_join():

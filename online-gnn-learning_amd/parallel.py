@@ -153,8 +153,9 @@ class GradSynchronizer:
                 offs[i] = total                                       # every slot 256-byte aligned: the kernels that write a
                 total += (self.params[i].numel() + 63) // 64 * 64     # gradient into its slot use 16-byte stores
             ent = self._buckets[name] = (torch.zeros(total, dtype=p0.dtype, device=p0.device), tuple(idxs), offs)
-            for i in idxs:
-                self._where[i] = name
+            if name != "single":                                      # (the single bucket is filled by copies, never written in place)
+                for i in idxs:
+                    self._where[i] = name
         return ent
 
     def grad_slot(self, i):
@@ -200,8 +201,17 @@ class GradSynchronizer:
         return flat
 
     def _launch_early(self, w):
-        flat = self._fill("early", self._early, w)
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        ctx = None
+        if self.params and self.params[0].is_cuda:
+            from . import ops
+            ctx = ops.collective_section()       # a forked backward: fill + launch from the side stream (weight gradients live there)
+        if ctx is None:
+            flat = self._fill("early", self._early, w)
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            with ctx:
+                flat = self._fill("early", self._early, w)
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending = (work, flat, w)
 
     def _scatter(self, name):
@@ -239,11 +249,20 @@ class GradSynchronizer:
             self._buckets.pop("all", None)
 
     # -- the step's exchange ---------------------------------------------------------------------------------------
-    def sync(self, weight=None):
-        """grads <- sum_r w_r * grad_r, w_r = ``weight`` (default: the constructor's)."""
+    def sync(self, weight=None, single=False):
+        """grads <- sum_r w_r * grad_r, w_r = ``weight`` (default: the constructor's).  ``single``: ONE flat bucket, one collective —
+        for steps whose backward cannot overlap the exchange anyway (a replayed replica step); every rank must make the same choice."""
         if not self.active:
             return
         w = self.weight if weight is None else float(weight)
+        if single:
+            assert self._pending is None, "single-bucket sync after an early bucket was launched"
+            idxs = list(range(len(self.params)))
+            flat = self._fill("single", idxs, w)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            self._scatter("single")
+            self._stale, self._fired, self._order = False, {}, []
+            return
         if self._early is None:
             idxs = list(range(len(self.params)))
             flat = self._fill("all", idxs, w)
