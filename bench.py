@@ -247,6 +247,7 @@ def main():
     stats["n0"], stats["n1"], stats["forms"] = [], [], {}
     graphs_on = strat._graphs_ok() or strat._graphs_ok("staged_dp")
     captures_before = strat._step_graphs().captures if graphs_on else 0
+    borrowed_before = strat._step_graphs().borrowed if graphs_on else 0
     barrier()
     t1 = time.perf_counter()
     run(args.steps, seeds_plan)
@@ -258,6 +259,7 @@ def main():
         elapsed = float(tt.item())
     forms_timed = dict(stats["forms"])
     captures_timed = (strat._step_graphs().captures - captures_before) if graphs_on else 0
+    borrowed_timed = (strat._step_graphs().borrowed - borrowed_before) if graphs_on else 0
     timed_mode = "captured hipGraph replays" if set(forms_timed) & {"sampled", "staged", "staged_dp"} else "eager launches from Python"
 
     # ---- host side: time to ENQUEUE a step (no synchronisation inside the bracket): the margin between this and
@@ -466,7 +468,8 @@ def main():
                                                                         ("%d in total (%d on this rank)" % (B, B_local)) if strong else "%d/GPU" % B, bt),
                        "global_batch": B_global,
                        "step_execution": "%s %s%s" % (timed_mode, forms_timed,
-                                                      ("; %d new size bucket(s) captured inside the timed region" % captures_timed)
+                                                      ("; %d new size bucket(s) captured inside the timed region, %d step(s) replayed on the next "
+                                                       "larger bucket's graph" % (captures_timed, borrowed_timed))
                                                       if timed_mode.startswith("captured") else "")
                        + ("; auto policy probe: %s" % getattr(strat, "staged_auto_probe", None) if strat.use_graphs == "auto" else ""),
                        "parallelism": "dp%d (seed-sharded replicas, two-bucket grad all-reduce %s)%s" % (

@@ -425,13 +425,15 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         if self.gsync is None and (n_global is None or n_global == seeds.numel()):
             if self._graphs_ok("staged"):
                 n0, n1 = int(input_nodes.numel()), blocks[1].number_of_src_nodes()
-                sg = self._step_graphs().staged_step(graph, seeds, blocks, n0, n1)       # captured on first use of the bucket
-                loss = sg.loss
-                if on_rows is not None:
-                    on_rows(seeds, sg.loss_rows.clone())
-                if self.step_hook is not None:
-                    self.step_hook(dict(seeds=seeds, loss=loss, grads=sg.grads, form="staged", n0=n0, n1=n1))
-                return loss
+                # (under "auto" a size bucket is captured on its second sighting: a rare bucket never costs a 5 ms capture)
+                sg = self._step_graphs().staged_step(graph, seeds, blocks, n0, n1, defer_first=self.use_graphs == "auto")
+                if sg is not None:
+                    loss = sg.loss
+                    if on_rows is not None:
+                        on_rows(seeds, sg.loss_rows.clone())
+                    if self.step_hook is not None:
+                        self.step_hook(dict(seeds=seeds, loss=loss, grads=sg.grads, form="staged", n0=n0, n1=n1))
+                    return loss
             loss = self._eager_step(graph, blocks, input_nodes, seeds, on_rows)
             if self.step_hook is not None:
                 self.step_hook(dict(seeds=seeds, loss=loss.detach(), grads=[p.grad for p in self.graphsage_model.parameters()],
@@ -443,12 +445,22 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         if self.gsync is not None and self._graphs_ok("staged_dp") and big and (on_rows is None or self.reduction != "mean"):
             # replayed replica step: the captured graph ends with the gradients of the LOCAL mean loss in its static tensors; the
             # all-reduce weights them by n_local / n_global (= the gradient of the mean over the whole batch), then the optimiser
+            eager_rows = None
             if n_local > 0:
                 n0, n1 = int(input_nodes.numel()), blocks[1].number_of_src_nodes()
                 with self.gsync.no_sync():                      # (a capture runs autograd for real: its hooks must not launch a collective)
-                    sg = self._step_graphs().staged_step(graph, seeds, blocks, n0, n1, apply=False)
-                for p, gr in zip(self.graphsage_model.parameters(), sg.grads):
-                    p.grad = gr                               # (the previous sync left views of its flat bucket there)
+                    sg = self._step_graphs().staged_step(graph, seeds, blocks, n0, n1, apply=False, defer_first=self.use_graphs == "auto")
+                    if sg is None:
+                        # first sighting of this size bucket: the same forward + backward eagerly (hooks suspended), then the
+                        # SAME exchange as the replayed steps — the sequence of collectives does not depend on which form ran
+                        self.optimizer.zero_grad()
+                        batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
+                        scores = self.graphsage_model(blocks, self._inputs(graph, input_nodes))
+                        loss_e, eager_rows = ops.cross_entropy_mean_rows(scores, batch_labels)
+                        ops.backward(loss_e)
+                if sg is not None:
+                    for p, gr in zip(self.graphsage_model.parameters(), sg.grads):
+                        p.grad = gr                           # (the previous sync left views of its flat bucket there)
             else:                                               # more ranks than seeds in this batch: zeros into the same collective
                 sg = None
                 for p in self.gsync.params:
@@ -456,6 +468,13 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             # nothing overlaps the exchange here (the graph has ended), so it is ONE flat bucket: one collective's latency, not two
             self.gsync.sync(weight=n_local / float(n_global), single=True)
             self.optimizer.step()
+            if sg is None and eager_rows is not None:
+                if on_rows is not None:
+                    on_rows(seeds, eager_rows.detach())
+                if self.step_hook is not None:
+                    self.step_hook(dict(seeds=seeds, loss=loss_e.detach() * (n_local / float(n_global)),
+                                        grads=[p.grad for p in self.graphsage_model.parameters()], form="staged_dp_eager", n0=n0, n1=n1))
+                return loss_e.detach() * n_local
             if sg is None:
                 if on_rows is not None:
                     on_rows(seeds, torch.zeros(0, device=graph.device))

@@ -221,7 +221,8 @@ class StepGraphCache:
         self.model, self.opt, self.S, self.loss_fn = model, optimizer, int(S), loss_fn
         self.bufs, self.samplers = {}, {}
         self.graphs = collections.OrderedDict()
-        self.captures = self.evictions = 0
+        self.captures = self.evictions = self.borrowed = self.deferred = 0
+        self.sightings = {}
 
     def _train(self, graph, buf, key, n1_pad, n0_pad, apply=True):
         sg = self.graphs.get(key)
@@ -254,12 +255,31 @@ class StepGraphCache:
         sg.last_sizes = (n0, n1)
         return sg
 
-    def staged_step(self, graph, seeds, blocks, n0, n1, apply=True):
+    def staged_step(self, graph, seeds, blocks, n0, n1, apply=True, defer_first=False):
         """One step of a loader batch: stage its block arrays into the bucket's static buffers, replay its train graph.
-        ``apply=False``: the graph stops after backward (the gradients are in ``sg.grads``)."""
+        ``apply=False``: the graph stops after backward (the gradients are in ``sg.grads``).
+
+        A capture costs ~5 ms — five steps' worth — so a bucket is not captured for one batch: the graph of the NEXT LARGER
+        bucket (one step of n0 and / or n1: <= 3.5 % more padded rows, exact) serves the batch when it exists, and with
+        ``defer_first`` a bucket met for the first time returns None (the caller runs that batch eagerly) and is captured
+        when it comes back.  Common buckets are captured within the first snapshots; rare ones never stall the stream."""
         B = int(seeds.numel())
         n0_pad, n1_pad = round_up(n0, N0_BUCKET), round_up(n1, N1_BUCKET)
         bkey = ("staged", id(graph), B, n0_pad, n1_pad, bool(apply))
+        if bkey not in self.graphs:
+            near = [k for k in self.graphs
+                    if k[0] == "staged" and k[1:3] == bkey[1:3] and k[5] == bkey[5]
+                    and n0_pad <= k[3] <= n0_pad + N0_BUCKET and n1_pad <= k[4] <= n1_pad + N1_BUCKET]
+            if near:
+                bkey = min(near, key=lambda k: (k[3] + 8 * k[4], k))
+                self.borrowed += 1
+            elif defer_first and self.sightings.get(bkey, 0) == 0:
+                self.sightings[bkey] = 1
+                if len(self.sightings) > 4096:
+                    self.sightings.clear()
+                self.deferred += 1
+                return None
+        n0_pad, n1_pad = bkey[3], bkey[4]
         buf = self.bufs.get(bkey)
         if buf is None:
             buf = self.bufs[bkey] = BlockBuffers(B, self.S, n1_pad, n0_pad, graph.device)

@@ -28,7 +28,9 @@ done
 cd $R
 T=$(ls $O/trace/*/*kernel_trace.csv | head -1)
 python tools/summarize_trace.py $T > $O/trace_by_grid.txt
-python tools/step_timeline.py $T > $O/step_timeline.txt
+python tools/step_timeline.py $T > $O/step_timeline_eager_traced.txt
+# the replayed step: no host in the loop (the eager step above is host-bound UNDER THE TRACER: ~130 us of device idle per step)
+python tools/step_timeline.py $(ls $O/trace_graph/*/*kernel_trace.csv | head -1) > $O/step_timeline.txt
 python tools/summarize_trace.py $(ls $O/pmc_fetch/*/*kernel_trace.csv | head -1) $(ls $O/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $O/pmc_write/*/*counter_collection.csv | head -1) > $O/pmc_by_grid.txt
 cp $(ls $O/trace/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
 cp $(ls $O/trace_graph/*/*kernel_stats.csv | head -1) $O/kernel_stats_graph.csv
@@ -39,4 +41,15 @@ for w in reddit_pbr_forward arxiv_pbr_forward; do
   python tools/summarize_trace.py $(ls $O/pmcf_$w/*/*kernel_trace.csv | head -1) $(ls $O/pmcf_$w/*/*counter_collection.csv | head -1) $(ls $O/pmcw_$w/*/*counter_collection.csv | head -1) > $O/pbr_${w}_pmc_by_grid.txt
 done
 rm -rf $O/trace $O/trace_graph $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/trace_reddit_pbr_forward $O/trace_arxiv_pbr_forward $O/pmcf_* $O/pmcw_*
+timeout -k 10 300 python bench.py --force-dist --steps 100 --warmup 10 --no-cpu-baseline --no-e2e > $O/bench_force_dist.json 2> $O/bench_force_dist.err < /dev/null
+timeout -k 10 300 python bench.py --force-dist --no-graphs --steps 100 --warmup 10 --no-cpu-baseline --no-e2e > $O/bench_force_dist_eager.json 2> /dev/null < /dev/null
+timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_2rank_gloo.json 2> /dev/null < /dev/null
+timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --steps 20 --warmup 2 --workload reddit_pbr_forward --partition features > $O/bench_2rank_gloo_pbr_partitioned.json 2> /dev/null < /dev/null
+timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --steps 50 --warmup 5 --scaling strong --no-cpu-baseline > $O/bench_2rank_gloo_strong.json 2> /dev/null < /dev/null
+for i in 1 2; do
+  OGL_FORK_BWD=0 timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --graphs > $O/ab_fork0_graphs_$i.json 2> /dev/null < /dev/null
+  OGL_FORK_BWD=1 timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --graphs > $O/ab_fork1_graphs_$i.json 2> /dev/null < /dev/null
+  OGL_FORK_BWD=0 timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-graphs > $O/ab_fork0_eager_$i.json 2> /dev/null < /dev/null
+  OGL_FORK_BWD=1 timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-graphs > $O/ab_fork1_eager_$i.json 2> /dev/null < /dev/null
+done
 head -c 400 $O/bench.json
