@@ -159,8 +159,10 @@ def test_rbr_train_steps_match_oracle(streams, name, gemm, graphs):
 # a8: the PBR priority forward, losses -> priorities -> buffer
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cached", [True, False])
-@pytest.mark.parametrize("name,n_seeds", [("arxiv", 3 * 1024 + 77), ("reddit", 2 * 1024 + 100)])
-def test_priority_forward_matches_oracle(streams, name, n_seeds, cached):
+@pytest.mark.parametrize("name,n_seeds,S,bf", [("arxiv", 3 * 1024 + 77, 25, 1024), ("reddit", 2 * 1024 + 100, 25, 1024),
+                                               # the reference's own Reddit settings (R/settings/reddit.json:1): samples 30, batch_full 900
+                                               ("reddit", 2 * 900 + 50, 30, 900)])
+def test_priority_forward_matches_oracle(streams, name, n_seeds, S, bf, cached):
     from ogl_amd import ops, sampling
     from ogl_amd.graph import TrainTestGraph
     from ogl_amd.graphsage import GraphSAGE
@@ -187,8 +189,8 @@ def test_priority_forward_matches_oracle(streams, name, n_seeds, cached):
         cpu = O.CpuModel("pool", feat_size, cfg["H"], n_classes, seed=11)
         model = GraphSAGE(feat_size, cfg["H"], n_classes, 1, F.relu, 0, "pool", edge_feats=0, pool_feats=cfg["H"]).cuda()
         _copy_params(model, cpu.params)
-        strat = PrioritizedHipSupervisedGraphSage(model, cfg["bt"], cfg["B"], labels, 25, LossPriority(), full_pass=1,
-                                                  cuda=True, batch_full=1024)
+        strat = PrioritizedHipSupervisedGraphSage(model, cfg["bt"], cfg["B"], labels, S, LossPriority(), full_pass=1,
+                                                  cuda=True, batch_full=bf)
         strat.cache_projection = cached
         assert gu.device_replay                              # the buffer lives in HBM; `before` = its host-class equivalent
         before = gu.priority_replay_buffer.to_host()
@@ -211,8 +213,8 @@ def test_priority_forward_matches_oracle(streams, name, n_seeds, cached):
         deg = O.snapshot_degrees_fast(indptr, keys, g.n_present, g.cut)
         feat_cpu = g.ndata["feat"].cpu().contiguous()
         lab_cpu = g.ndata["target"].cpu()
-        want = np.concatenate([cpu.seed_losses(feat_cpu, lab_cpu, indptr, indices, deg, sub_ids[s:s + 1024], 25, 21, b)[0]
-                               for b, s in enumerate(range(0, n_seeds, 1024))])
+        want = np.concatenate([cpu.seed_losses(feat_cpu, lab_cpu, indptr, indices, deg, sub_ids[s:s + bf], S, 21, b)[0]
+                               for b, s in enumerate(range(0, n_seeds, bf))])
         assert np.array_equal(seen["ids"], subset) and seen["on_device"]
         np.testing.assert_allclose(seen["pr"], want, rtol=1e-4, atol=1e-6)
         # losses -> LossPriority (identity, R/train/prioritized_replay/generate_priority.py:7-9) -> buffer.

@@ -31,8 +31,20 @@ def entry(r, **extra):
 
 
 def first(rows, pred):
-    c = [r for r in rows if r["fetch_kb"] is not None and pred(r)]
-    return max(c, key=lambda r: r["total_ms"]) if c else None
+    """The kernel (template instantiation) with the most total time among those `pred` accepts — its launches pooled over the
+    grid sizes they ran on (an aggregator's grid follows the batch's block size), counters averaged per launch."""
+    groups = {}
+    for r in rows:
+        if r["fetch_kb"] is not None and pred(r):
+            groups.setdefault(r["name"], []).append(r)
+    if not groups:
+        return None
+    name, rs = max(groups.items(), key=lambda kv: sum(r["total_ms"] for r in kv[1]))
+    n = sum(r["calls"] for r in rs)
+    avg = lambda k: sum((r[k] or 0.0) * r["calls"] for r in rs) / n          # noqa: E731
+    return dict(name=name, grid=("%d..%d" % (min(r["grid"] for r in rs), max(r["grid"] for r in rs))) if len(rs) > 1 else rs[0]["grid"],
+                calls=n, avg_us=round(avg("avg_us"), 2), total_ms=sum(r["total_ms"] for r in rs), fetch_kb=round(avg("fetch_kb"), 1),
+                write_kb=round(avg("write_kb"), 1))
 
 
 def main():

@@ -16,8 +16,9 @@ def main():
     for r in csv.DictReader(open(sys.argv[1])):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"), int(r.get("Grid_Size", 0) or 0)))
     rows.sort()
-    adam = [i for i, r in enumerate(rows) if "k_adam" in r[2]]
+    adam = [i for i, r in enumerate(rows) if "k_adam_multi" in r[2] or r[2].startswith("k_adam(")]     # (not k_adam_prepare)
     steps = [(adam[k], adam[k + 1]) for k in range(len(adam) - 1)]
+    steps = [(a, b) for a, b in steps if b - a >= 8] or steps       # (whole train steps, not the optimiser's own two launches)
     lens = sorted((rows[b][1] - rows[a][1], k) for k, (a, b) in enumerate(steps))
     pick = int(sys.argv[2]) if len(sys.argv) > 2 else lens[len(lens) // 2][1]
     a, b = steps[pick]
