@@ -659,7 +659,7 @@ def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size,
         key = name
         if name in ("ogl_reduce_fwd", "ogl_reduce_fwd_img"):
             key = "reduce_fwd_L0" if meta["n_dst"] > B else "reduce_fwd_L1"
-        elif name.startswith("ogl_linear_fwd") and meta["M"] >= g.n_present // 2:
+        elif name.startswith("ogl_linear_fwd") and meta["M"] == g.n_present:
             key = name[4:] + "_tables"                     # the per-pass projection tables P0 / S0 over every present vertex
         a = agg.setdefault(key, dict(ms=0.0, calls=0, bytes=0.0, flops=0.0))
         a["ms"] += ms; a["calls"] += 1

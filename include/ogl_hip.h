@@ -380,6 +380,14 @@ int ogl_build_block_padded(const int64_t* dst, int64_t n_dst, const int64_t* pic
 int ogl_adam_step_multi_dev(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
                             const int64_t* n, int64_t* step_dev, float* scalars_dev, double lr, double beta1,
                             double beta2, double eps, ogl_stream_t stream);
+/* K loader batches as ONE block (inference passes: every kernel of the forward is row-independent, so a pass runs them once per
+ * chunk of batches instead of once per batch of `batch_full` seeds, R/train/graphsage/pytorch/model.py:224-248).  local_idx is the
+ * packed [rows, fanout] index array of the chunk's output blocks, with destination rows [seg_row[s], seg_row[s + 1]) belonging to
+ * batch s (seg_row is relative to the array passed); every valid index gets seg_off[s] — the position of batch s's source list in the
+ * fused source list — added in place, and dst_pos[r] (nullable, [rows]) receives the fused position of destination r's own row
+ * (seg_off[s] + its rank inside the batch: a block's destinations are the first entries of its source list).  nseg <= 64. */
+int ogl_fuse_block_segments(int32_t* local_idx, int64_t* dst_pos, int nseg, const int64_t* seg_row, const int64_t* seg_off, int fanout,
+                            ogl_stream_t stream);
 int ogl_stage_segments(int nseg, const void* const* src, void* const* dst, const int64_t* count,
                        const int64_t* capacity, const int* elem_bytes, int64_t pad, ogl_stream_t stream);
 /* The read-back of a captured sample graph without a copy node: dst_host_mapped = int64 [n + 1] in pinned HOST memory (mapped

@@ -92,6 +92,7 @@ SIGNATURES = {
     "ogl_adam_step_multi_dev": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _d, _d, _d, _d, _p]),
     "ogl_publish_i64": (_i, [_p, _i, _p, _p, _p]),
     "ogl_stage_segments": (_i, [_i, _p, _p, _p, _p, _p, _i64, _p]),
+    "ogl_fuse_block_segments": (_i, [_p, _p, _i, _p, _p, _i, _p]),
 }
 
 _lib = None

@@ -309,6 +309,56 @@ extern "C" int ogl_stage_segments(int nseg, const void* const* src, void* const*
 }
 
 
+// ---- several loader batches as ONE block (inference passes) ---------------------------------------------------------------------
+// An inference pass runs the same row-independent kernels on every batch; K batches laid end to end are one block whose
+// sources are the K source lists end to end.  The batches' block-local indices (positions in their own source list) only need
+// their list's offset added, and a destination's own row — the FIRST rows of its batch's source list in a bipartite block, so
+// `h[:n_dst]` there — becomes an explicit position list.  seg_row[s] .. seg_row[s + 1]: the destination rows of batch s in the
+// packed index array; seg_off[s]: where its source list starts in the fused source list.
+#define OGL_FUSE_MAX 64
+struct FuseDesc {
+  int64_t row[OGL_FUSE_MAX + 1];
+  int64_t off[OGL_FUSE_MAX];
+  int n;
+};
+
+__global__ void __launch_bounds__(256) k_fuse_block_segments(int32_t* __restrict__ local_idx, int64_t* __restrict__ dst_pos, int fanout,
+                                                             FuseDesc d) {
+  const int64_t rows = d.row[d.n] - d.row[0];
+  const int64_t total = rows * fanout;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = d.row[0] + e / fanout;
+    int s = 0;
+    while (s + 1 < d.n && r >= d.row[s + 1]) ++s;
+    const int32_t v = local_idx[e];
+    if (v >= 0) local_idx[e] = v + (int32_t)d.off[s];
+    if (dst_pos && e % fanout == 0) dst_pos[e / fanout] = d.off[s] + (r - d.row[s]);
+  }
+}
+
+extern "C" int ogl_fuse_block_segments(int32_t* local_idx, int64_t* dst_pos, int nseg, const int64_t* seg_row, const int64_t* seg_off,
+                                       int fanout, ogl_stream_t stream) {
+  if (nseg < 0 || nseg > OGL_FUSE_MAX || fanout <= 0) return OGL_EINVAL;
+  if (nseg == 0) return OGL_OK;
+  if (!local_idx || !seg_row || !seg_off) return OGL_EINVAL;
+  FuseDesc d;
+  d.n = nseg;
+  for (int s = 0; s <= nseg; ++s) {
+    d.row[s] = seg_row[s];
+    if (s > 0 && seg_row[s] < seg_row[s - 1]) return OGL_EINVAL;
+  }
+  for (int s = 0; s < nseg; ++s) {
+    d.off[s] = seg_off[s];
+    if (seg_off[s] < 0 || seg_off[s] > 0x7FFFFFFF) return OGL_EINVAL;
+  }
+  const int64_t total = (seg_row[nseg] - seg_row[0]) * fanout;
+  if (total == 0) return OGL_OK;
+  hipLaunchKernelGGL(k_fuse_block_segments, dim3((unsigned)std::min<int64_t>(ogl_cdiv(total, 256), 2048)), dim3(256), 0,
+                     (hipStream_t)stream, local_idx, dst_pos, fanout, d);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
 // ---- the 16-byte read-back of a captured sample graph, without a copy node ----------------------------------------------------
 // dst is HOST memory mapped into the device (a pinned allocation): the kernel stores the n values, then a sequence number
 // (++*seq_dev) behind a system-scope fence; the host polls dst[n] for the number it expects.  Replaces a device->host copy

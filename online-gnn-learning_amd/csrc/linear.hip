@@ -725,7 +725,9 @@ extern "C" int ogl_linear_fwd(const float* x, int64_t ldx, const int64_t* x_rows
   // few output tiles and a long reduction: in-block split-K straight from global memory
   const int64_t Ktot = (int64_t)K + K2;
   // (every input at least one whole 8-deep chunk: a chunk past an input's end re-reads its chunk 0)
-  if (N <= 64 && M <= 4096 && Ktot >= 256 && K >= 8 && (K2 == 0 || (g.nparts == 2 && K2 >= 8))) {
+  // (M: up to a fused chunk of inference batches — a row's result must not depend on how many rows travel with it, so the kernel
+  // choice for this shape class does not either: the sharded passes are bit-identical to the one-rank pass whatever the chunking)
+  if (N <= 64 && M <= (1 << 17) && Ktot >= 256 && K >= 8 && (K2 == 0 || (g.nparts == 2 && K2 >= 8))) {
     dim3 grid((unsigned)ogl_cdiv(M, 32), (unsigned)ogl_cdiv(N, 32));
     if (g.nparts == 1) hipLaunchKernelGGL(k_gemm_skinny<1>, grid, dim3(64 * SK_WAVES), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(k_gemm_skinny<2>, grid, dim3(64 * SK_WAVES), 0, (hipStream_t)stream, g);

@@ -328,6 +328,10 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
     # 0.18 (Reddit-like, B = 512: n0 = 62.7 k of 346 k) to 0.3 (arxiv- / pubmed-like, B = 1024, before the n_present cap);
     # it only decides when a pass is long enough for the per-pass tables to pay — both paths give the same results.
     UNIQUE_INPUT_FRACTION = 0.3
+    # inference passes against the per-pass tables: batches fused into one launch sequence up to this many hidden-layer rows
+    # (0 = one launch sequence per batch of batch_full seeds, as the reference's loop).  131 072 rows x 608 floats = 320 MB per
+    # intermediate: the products run as several rounds of tiles instead of a fraction of one
+    FUSE_INFERENCE_ROWS = 131072
 
     def _projection_tables(self, graph, layer0):
         """(P0, S0) of ``SAGEConv.project_tables`` for every present vertex, once per pass (weights are fixed during it).
@@ -373,8 +377,12 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
                 return
             mine = seeds_all[s_lo:s_hi].to(graph.device, non_blocking=True).contiguous()
             batches = [mine[s:s + bf] for s in range(0, mine.numel(), bf)]
+            # against the per-pass tables every kernel of a batch's forward is row-independent: consecutive batches run as ONE
+            # block while their hidden-layer rows stay under FUSE_INFERENCE_ROWS (each batch still sampled with its own counter)
+            fuse = self.FUSE_INFERENCE_ROWS if (use_cache and len(self.graphsage_model.layers) == 2
+                                                and self.graphsage_model.layers[1]._aggre_type == "pool") else 0
             for input_nodes, seeds, blocks in self._sampler().sample_batches(graph, batches, relabel_input=not use_cache,
-                                                                             ctrs=ctrs[b_lo:b_hi]):
+                                                                             ctrs=ctrs[b_lo:b_hi], fuse_rows=fuse):
                 x = GatheredRows(graph.ndata["feat"], None, tables) if use_cache else self._inputs(graph, input_nodes)
                 yield seeds, self.graphsage_model(blocks, x)
 

@@ -126,6 +126,9 @@ class SAGEConv(nn.Module):
         fuse_relu = _is_relu(self.activation)
         if lazy and feat.proj is not None:
             return self._forward_cached(graph, feat, fuse_relu)
+        dst_pos = getattr(graph, "dst_pos", None)
+        if dst_pos is not None:
+            return self._forward_fused_batches(graph, feat, idx, dst_pos, fuse_relu)
         feat_dst = feat.head(n_dst) if lazy else feat[:n_dst]
 
         if (t == "pool" and not lazy and self.norm is None and (self.activation is None or fuse_relu)
@@ -180,6 +183,23 @@ class SAGEConv(nn.Module):
             rst = self.norm(rst)
         return rst
 
+    def _forward_fused_batches(self, graph, feat, idx, dst_pos, fuse_relu):
+        """Inference on several loader batches fused into one block (sampling.sample_batches(fuse_rows=...)): the same three
+        launches as the per-batch inference path, with a destination's own row gathered by position instead of ``feat[:n_dst]``."""
+        if self._aggre_type != "pool" or isinstance(feat, GatheredRows) or self.norm is not None or not (self.activation is None or fuse_relu):
+            raise RuntimeError("fused inference batches are built for the 'pool' layers behind a cached first layer")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("fused inference batches are inference only (run them under torch.no_grad())")
+        imgs = getattr(self, "_pass_images", None)
+        himg = ops.take_image(feat) if (imgs and "w_pool_b" in imgs) else None
+        if himg is not None and himg.K == imgs["w_pool_b"].K:
+            p = ops.linear_fwd_x3(himg, None, imgs["w_pool_b"], relu=True)
+        else:
+            p = ops.linear_fwd(feat, self.fc_pool.weight, self.fc_pool.bias, relu=True)
+        neigh, _ = ops.reduce_fwd(p, idx, "max", want_argmax=False)
+        return ops.linear_fwd(feat, self.fc_self.weight, self._summed_bias(), x2=neigh, w2=self.fc_neigh.weight, relu=fuse_relu,
+                              x_rows=dst_pos)
+
     def _forward_cached(self, graph, feat, fuse_relu):
         """Inference against the per-pass projection tables (the idea of R/inference_optimized.py:169,258 — its
         ``h0proj`` / ``neigh`` caches): the neighbour max reads ``P0[picks]`` directly and the self term is the row
@@ -193,8 +213,10 @@ class SAGEConv(nn.Module):
             raise RuntimeError("the cached-projection path is inference only (run it under torch.no_grad())")
         P0, S0 = feat.proj
         imgs = getattr(self, "_pass_images", None)
-        if (t == "pool" and imgs and "w_neigh" in imgs and graph.picks.shape[0] >= ops.X3_N1_MIN_ROWS
-                and S0.shape[1] >= ADDROWS_MIN_WIDTH):
+        # (whatever the number of rows: inside a pass the choice of kernels must not depend on how many batches share the
+        # launch — a row's result is then the same in any chunking, which keeps rank-sharded passes bit-identical to the
+        # one-rank pass; the weight images exist for the pass anyway)
+        if t == "pool" and imgs and "w_neigh" in imgs and S0.shape[1] >= ADDROWS_MIN_WIDTH:
             # tall, wide layer: the aggregator writes the image of the pooled rows beside them, the neighbour projection runs on
             # the image kernel with S0[dst] added in its epilogue, and that kernel writes the image of ITS output for the next
             # layer's fc_pool — no split pass anywhere (the weight images were built once for the pass)

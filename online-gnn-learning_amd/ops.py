@@ -192,6 +192,18 @@ def stage_segments(pairs, pad=-1):
     _launch("ogl_stage_segments", _lib.lib().ogl_stage_segments, k, srcs, dsts, cnt, cap, el, int(pad), _stream(), meta=dict(nseg=k))
 
 
+def fuse_block_segments(local_idx, seg_rows, seg_offs, want_dst_pos=True):
+    """In place: the packed block-local indices of several batches become indices into their source lists laid end to end
+    (``ogl_fuse_block_segments``); returns the position of every destination's own row in the fused source list (int64 [rows])."""
+    assert local_idx.dtype == torch.int32 and local_idx.is_cuda and local_idx.is_contiguous() and local_idx.dim() == 2
+    k = len(seg_offs)
+    assert len(seg_rows) == k + 1 and seg_rows[0] == 0 and seg_rows[-1] == local_idx.shape[0]
+    dst_pos = torch.empty(local_idx.shape[0], dtype=torch.int64, device=local_idx.device) if want_dst_pos else None
+    _launch("ogl_fuse_block_segments", _lib.lib().ogl_fuse_block_segments, _ptr(local_idx), _ptr(dst_pos), k, _host_i64(seg_rows),
+            _host_i64(seg_offs), int(local_idx.shape[1]), _stream(), meta=dict(rows=int(local_idx.shape[0]), nseg=k))
+    return dst_pos
+
+
 # pad_tail builds go through ogl_build_block_padded, which writes the -1 tail itself (one workgroup up to 4 096 flat positions,
 # the parallel phases above); tests raise / lower this to force either path
 BLOCK_SMALL_MAX_P = 1 << 30

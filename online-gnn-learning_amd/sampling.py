@@ -69,11 +69,14 @@ class Block:
     """
     is_block = True
 
-    def __init__(self, src_ids, dst_ids, local_idx, picks=None):
+    def __init__(self, src_ids, dst_ids, local_idx, picks=None, dst_pos=None):
         self.src_ids = src_ids            # int64 [n_src]  (dst nodes first)
         self.dst_ids = dst_ids            # int64 [n_dst]
         self.local_idx = local_idx        # int32 [n_dst, fanout], -1 = no neighbour
         self.picks = picks                # int64 [n_dst, fanout] global ids (kept for the cached-projection path)
+        # several loader batches fused into one block (sample_batches(fuse_rows=...)): the destinations are no longer the FIRST
+        # sources — dst_pos[d] is destination d's own row in the source list (None: the usual h[:n_dst])
+        self.dst_pos = dst_pos
         self.srcdata = {NID: src_ids}
         self.dstdata = {NID: dst_ids}
         self.edata = {}
@@ -120,12 +123,16 @@ class MultiLayerNeighborSampler:
         self.fanouts = [int(f) for f in fanouts]
         self.return_eids = return_eids
 
-    def sample_batches(self, graph, seed_batches, relabel_input=True, ctrs=None):
+    def sample_batches(self, graph, seed_batches, relabel_input=True, ctrs=None, fuse_rows=0):
         """Sample every batch, output layer first.  Returns a list of (input_nodes, seeds, blocks).
 
         ``relabel_input=False`` (inference against a cached layer-0 projection): the input block keeps only its
         global ``picks`` — no hash relabel, no size read-back; ``input_nodes`` is then ``None``.
-        ``ctrs``: the batches' Philox counters (default: the next ones of the stream, see ``reserve_ctrs``)."""
+        ``ctrs``: the batches' Philox counters (default: the next ones of the stream, see ``reserve_ctrs``).
+        ``fuse_rows`` > 0 (with ``relabel_input=False``, two layers, the seed batches consecutive slices of one tensor): consecutive
+        batches are laid end to end into ONE pair of blocks while their hidden-layer rows stay below ``fuse_rows`` — every batch is
+        sampled with its own counter exactly as before (same picks, same per-batch de-duplication), only the launches of the
+        forward pass are shared.  The returned list then has one entry per CHUNK: (None, the chunk's seeds, blocks)."""
         g = graph.handle
         L = len(self.fanouts)
         nb = len(seed_batches)
@@ -150,6 +157,8 @@ class MultiLayerNeighborSampler:
                 rows.append(acc); acc += c
             dsts = [dst_base[s:s + c] for s, c in zip(starts, counts)]
             if layer == 0 and not relabel_input:
+                if fuse_rows and L == 2:
+                    return self._fused(seed_batches, blocks, dsts, rows, counts, picks_all, int(fuse_rows))
                 for bi in range(nb):
                     blocks[bi][layer] = Block(None, dsts[bi], None, picks_all[rows[bi]:rows[bi] + counts[bi]])
                 return [(None, seeds, blk) for seeds, blk in zip(seed_batches, blocks)]
@@ -164,6 +173,50 @@ class MultiLayerNeighborSampler:
                 nstarts.append(s0)
             dst_base, starts, counts = src_all, nstarts, n_next
         return [(blk[0].src_ids, seeds, blk) for seeds, blk in zip(seed_batches, blocks)]
+
+
+    @staticmethod
+    def _fused(seed_batches, blocks, dsts, rows, counts, picks_all, fuse_rows):
+        """Chunks of consecutive batches as one (input block, output block) pair each — see ``sample_batches``.  rows / counts:
+        where batch b's hidden-layer rows sit in the packed layer-0 arrays (they are consecutive); the output blocks' index
+        arrays are consecutive row ranges of one packed array too (the seeds are)."""
+        nb = len(seed_batches)
+        out = []
+        b0 = 0
+        while b0 < nb:
+            b1, acc = b0, 0
+            while b1 < nb and b1 - b0 < 64 and (b1 == b0 or acc + counts[b1] <= fuse_rows):
+                acc += counts[b1]; b1 += 1
+            r0, r1 = rows[b0], rows[b1 - 1] + counts[b1 - 1]
+            dev = picks_all.device
+            seeds = [seed_batches[b] for b in range(b0, b1)]
+            # the chunk's seeds and output-block index rows: consecutive slices -> views of their parents
+            first, last = seeds[0], seeds[-1]
+            base = first._base if first._base is not None else first
+            s_lo = first.storage_offset() - base.storage_offset()
+            n_seeds = sum(int(t.numel()) for t in seeds)
+            seeds_chunk = base.reshape(-1)[s_lo:s_lo + n_seeds]
+            assert last.data_ptr() + last.numel() * 8 == seeds_chunk.data_ptr() + n_seeds * 8, "seed batches must be consecutive slices"
+            l_first = blocks[b0][1].local_idx
+            lbase = l_first._base if l_first._base is not None else l_first
+            S1 = l_first.shape[1]
+            l_lo = (l_first.storage_offset() - lbase.storage_offset()) // S1
+            lidx = lbase.reshape(-1, S1)[l_lo:l_lo + n_seeds]
+            seg_rows, seg_offs, acc_r = [0], [], 0
+            for b in range(b0, b1):
+                acc_r += int(seed_batches[b].numel())
+                seg_rows.append(acc_r)
+                seg_offs.append(rows[b] - r0)
+            dst_pos = ops.fuse_block_segments(lidx, seg_rows, seg_offs)            # (in place: the per-batch blocks are not handed out)
+            # the hidden layer's vertex ids of the chunk, end to end (the batches' source lists sit apart in the packed array)
+            ids0 = torch.empty(r1 - r0, dtype=torch.int64, device=dev)
+            for k in range(b0, b1, 8):
+                ops.stage_segments([(dsts[b], ids0[rows[b] - r0:rows[b] - r0 + counts[b]], counts[b]) for b in range(k, min(k + 8, b1))])
+            blk0 = Block(None, ids0, None, picks_all[r0:r1])
+            blk1 = Block(ids0, seeds_chunk, lidx, None, dst_pos=dst_pos)
+            out.append((None, seeds_chunk, [blk0, blk1]))
+            b0 = b1
+        return out
 
 
 class NodeDataLoader:

@@ -149,3 +149,61 @@ def test_replayed_steps_invalidate_eagerly_built_weight_images():
     assert moved > 1e-2, moved                                               # four Adam steps changed the logits visibly
     # the replayed model's second pass reflects its four replayed updates (stale images would reproduce `before` in layer 0)
     torch.testing.assert_close(outs[True][1], outs[False][1], rtol=2e-2, atol=0.1 * moved)
+
+
+def test_fused_inference_batches_equal_per_batch_launches_bit_for_bit():
+    """An inference pass against the per-pass tables runs consecutive batches as ONE block (sampling.sample_batches(fuse_rows=...)).
+    Every kernel on that path is row-independent — a row's result does not depend on how many rows share the launch — so the fused
+    pass reproduces the per-batch pass BIT FOR BIT, and so does any other chunking (what keeps rank-sharded passes bit-identical
+    to the one-rank pass: tests/test_gpu_parallel.py)."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops, sampling
+    from ogl_amd.graphsage import GraphSAGE
+    from ogl_amd.graphsage.model import HipSupervisedGraphSage
+    feat_size, labels, g, n_classes = _reddit_like_small()
+    ops.set_gemm_mode("auto")
+    torch.manual_seed(4)
+    model = GraphSAGE(feat_size, 600, n_classes, 1, F.relu, 0, "pool").cuda().eval()
+    st = HipSupervisedGraphSage(model, 2, 512, labels, 25, reduction="none", cuda=True, batch_full=256)
+    seeds = torch.as_tensor(np.random.default_rng(1).choice(g.n_present, 5 * 256 + 37, replace=False).astype(np.int64))
+    outs, chunks = {}, {}
+    for rows in (0, 4000, 8000, 12000, 10 ** 9):      # per batch; a few batches per chunk; the whole pass as one chunk
+        st.FUSE_INFERENCE_ROWS = rows
+        sampling.seed(5)
+        with torch.no_grad():
+            parts = [(sd.clone(), lg.clone()) for sd, lg in st._inference_batches(g, seeds)]
+        assert torch.equal(torch.cat([sd for sd, _ in parts]).cpu(), seeds)
+        outs[rows], chunks[rows] = torch.cat([lg for _, lg in parts]), len(parts)
+        assert sampling.get_state()["ctr"] == 6                      # one Philox counter per BATCH, whatever the chunking
+    assert chunks[0] == 6 and chunks[10 ** 9] == 1 and any(1 < chunks[r] < 6 for r in (4000, 8000, 12000)), chunks
+    for r in (4000, 8000, 12000, 10 ** 9):
+        assert torch.equal(outs[0], outs[r]), (r, chunks)
+
+
+@pytest.mark.parametrize("K,N,K2", [(32, 32, 0), (128, 32, 32), (600, 41, 600), (32, 40, 32), (600, 600, 0)])
+def test_projection_kernels_are_row_independent(K, N, K2):
+    """y[i, :] of every forward projection kernel depends on row i only: the first M rows of a tall product equal the M-row product
+    bit for bit, whichever tile configuration the launch picks for its size (on-the-fly, skinny and image kernels)."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    ops.set_gemm_mode("auto")
+    torch.manual_seed(0)
+    x = torch.randn(40000, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.randn(N, device="cuda")
+    x2 = torch.randn(12000, K2, device="cuda") if K2 else None
+    w2 = torch.randn(N, K2, device="cuda") / K2 ** 0.5 if K2 else None
+    rows = torch.randint(0, 40000, (12000,), device="cuda")
+    if K2:
+        full = ops.linear_fwd(x, w, b, x2=x2, w2=w2, relu=True, x_rows=rows)
+    else:
+        full = ops.linear_fwd(x[:12000].contiguous(), w, b, relu=True)
+    for M in (100, 1000, 2148, 5000, 9216):
+        if K2:
+            part = ops.linear_fwd(x, w, b, x2=x2[:M].contiguous(), w2=w2, relu=True, x_rows=rows[:M].contiguous())
+        else:
+            part = ops.linear_fwd(x[:M].contiguous(), w, b, relu=True)
+        assert torch.equal(part, full[:M]), (K, N, K2, M)
+    if K2 == 0 and K >= 64:
+        ximg = ops.x3_split(x[:12000].contiguous(), append_ones=True); wimg = ops.x3_split(w, append_vec=b)
+        fimg = ops.linear_fwd_x3(ximg, None, wimg, relu=True)
+        for M in (128, 2048, 7000, 9000):
+            assert torch.equal(ops.linear_fwd_x3(ximg, None, wimg, relu=True, M=M), fimg[:M]), M
