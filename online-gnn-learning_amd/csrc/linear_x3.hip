@@ -661,6 +661,42 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
       const bool vec_ok = (ldd & 3) == 0 && ((uintptr_t)dst & 15) == 0;
       const bool fin = g.nsplit == 1;
       const bool add_vec = EXT && g.add && (g.ld_add & 3) == 0 && ((uintptr_t)g.add & 15) == 0;
+      if constexpr (EXT) {
+        // The per-row addend (the self term S0[dst] of an inference layer) FIRST, every 16-byte load of the wave tile issued
+        // before anything is stored: written into the store loop below, each load sat behind the previous group's stores (the
+        // output and the table may alias for all the compiler knows) and a tile paid RB x CB memory latencies in a row.  Loads
+        // are unconditional — an invalid group reads the table's first row and is masked afterwards — so nothing between them
+        // needs a wait (the same rule as the aggregator's row loads).
+        if (add_vec) {
+          const float* ap[RB];
+          bool aok[RB];
+#pragma unroll
+          for (int x = 0; x < RB; ++x) {
+            const int64_t row = (int64_t)t.ti * BM + wm * TM * 32 + x * 16 + l15;
+            const bool rok = row < g.M;
+            const int64_t ar = g.add_rows ? g.add_rows[rok ? row : 0] : row;
+            aok[x] = rok && ar >= 0 && ar < g.add_nrows;
+            ap[x] = g.add + (aok[x] ? ar : 0) * g.ld_add;
+          }
+          float4 tv[RB][CB];
+#pragma unroll
+          for (int x = 0; x < RB; ++x)
+#pragma unroll
+            for (int y = 0; y < CB; ++y) {
+              const int64_t col = (int64_t)t.tj * BN + wn * TN * 32 + y * 16 + 4 * quad;
+              tv[x][y] = *(const float4*)(ap[x] + (col + 4 <= g.N ? col : 0));
+            }
+#pragma unroll
+          for (int x = 0; x < RB; ++x)
+#pragma unroll
+            for (int y = 0; y < CB; ++y) {
+              const int64_t col = (int64_t)t.tj * BN + wn * TN * 32 + y * 16 + 4 * quad;
+              if (aok[x] && col + 4 <= g.N) {
+                acc[x][y][0] += tv[x][y].x; acc[x][y][1] += tv[x][y].y; acc[x][y][2] += tv[x][y].z; acc[x][y][3] += tv[x][y].w;
+              }
+            }
+        }
+      }
 #pragma unroll
       for (int x = 0; x < RB; ++x)
 #pragma unroll
@@ -669,17 +705,12 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
           float v[4] = {acc[x][y][0], acc[x][y][1], acc[x][y][2], acc[x][y][3]};
           const bool rok = row < g.M;
           const bool has_oc = fin && g.ones_col && col + 3 >= g.N - 1 && col < g.N;
-          if (EXT && g.add && rok && col < g.N) {              // per-row addend (the self term S0[dst] of an inference layer)
+          if (EXT && g.add && rok && col < g.N && !(add_vec && col + 4 <= g.N)) {   // (partial column groups, unaligned tables)
             const int64_t ar = g.add_rows ? g.add_rows[row] : row;
             if (ar >= 0 && ar < g.add_nrows) {
               const float* ap = g.add + ar * g.ld_add + col;
-              if (add_vec && col + 4 <= g.N) {                   // one 16-byte load per group of four columns
-                const float4 a4 = *(const float4*)ap;
-                v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
-              } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) if (col + c < g.N) v[c] += ap[c];
-              }
+              for (int c = 0; c < 4; ++c) if (col + c < g.N) v[c] += ap[c];
             }
           }
           if (fin && g.relu) {
