@@ -259,11 +259,16 @@ int ogl_linear_fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_ro
  * - add (nullable): per-row addend from a table, as ogl_linear_fwd_addrows.
  * - out_img (nullable): ALSO write the bf16x3 image of y (row-major, M + 1 rows, reduction length N, + 1 when out_append_ones:
  *   1.0 at column N in every row incl. the zero row) = what ogl_x3_split(y, append = out_append_ones) would build: the A operand
- *   of the next layer's product, without a pass of its own.  Size it with ogl_x3_image_bytes(M, N + out_append_ones). */
+ *   of the next layer's product, without a pass of its own.  Size it with ogl_x3_image_bytes(M, N + out_append_ones).
+ * - mask (nullable; [M, N] fp32, ld_mask and N multiples of 4, 16-byte aligned): y[i, j] is zeroed where mask[i, j] <= 0, after the
+ *   addend — when this product is an INPUT GRADIENT dX = dY . W (+ head) and `mask` the forward output of the fused-ReLU layer that
+ *   produced X (autograd of F.relu, R/train/graphsage/pytorch/graphsage_dgl.py:29-31), the gradient leaves the kernel already
+ *   masked, with its image: no ogl_relu_bwd_img pass. */
 int ogl_linear_fwd_x3_ext(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int K1,
                           const void* x2_img, int64_t x2_img_rows, const int64_t* x2_rows, int64_t x2_nrows, int K2, int64_t M,
                           const void* w_img, int N, const float* add, int64_t ld_add, const int64_t* add_rows, int64_t add_nrows,
-                          int relu, float* y, int64_t ldy, void* out_img, int out_append_ones, ogl_stream_t stream);
+                          int relu, float* y, int64_t ldy, void* out_img, int out_append_ones, const float* mask, int64_t ld_mask,
+                          ogl_stream_t stream);
 /* Up to 8 small images in ONE launch — the weight images of a train step (the parameters of nn.Linear in
  * R/train/graphsage/pytorch/aggregator_dgl.py:75-84, re-split after every optimiser step).  Part i becomes groups
  * [group_offset, group_offset + ceil((K + append) / 32)) of every row of `image` (rows image_row_bytes apart, R + 1 of them:

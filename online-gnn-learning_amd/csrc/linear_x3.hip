@@ -55,6 +55,8 @@ struct X3Args {
   int nsteps1;                  //   gather and zero row) — fc_self(x[dst]) + fc_neigh(neigh) as ONE product over a K-concatenated B
   const float* add;             // optional per-row addend: C[i, :] += add[add_rows ? add_rows[i] : i, :] before the activation
   int64_t ld_add; const int64_t* add_rows; int64_t add_nrows;
+  const float* mask;            // optional: y[i, :] = (mask[i, :] > 0) ? y[i, :] : 0 after the addend — the ReLU backward of the layer
+  int64_t ld_mask;              //   whose output `mask` is, applied to the input gradient this product computes (M rows, N columns)
   float* db2;                   // optional second copy of the bias gradient (the two biases of a dual projection: one tensor each)
   // ---- k_gemm_x3p<..., BK = true> only: the B operand is a ROW-MAJOR image whose ROWS are the reduction index (b.rows gathers them,
   // b.nrows bounds the ids, b.zero_row / b.row_bytes as for a row-major A) and whose COLUMNS are the output columns: the
@@ -696,6 +698,28 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
               }
             }
         }
+        // ... then the ReLU mask (the forward output of the layer whose input gradient this is), the same way: all loads, then
+        // the selects — dX = (dY . W + head) (.) [y > 0] leaves the kernel already masked, with its image
+        if (g.mask && (g.ld_mask & 3) == 0 && ((uintptr_t)g.mask & 15) == 0 && (g.N & 3) == 0) {
+          float4 mv[RB][CB];
+#pragma unroll
+          for (int x = 0; x < RB; ++x) {
+            const int64_t row = (int64_t)t.ti * BM + wm * TM * 32 + x * 16 + l15;
+            const float* mp = g.mask + (row < g.M ? row : 0) * g.ld_mask;
+#pragma unroll
+            for (int y = 0; y < CB; ++y) {
+              const int64_t col = (int64_t)t.tj * BN + wn * TN * 32 + y * 16 + 4 * quad;
+              mv[x][y] = *(const float4*)(mp + (col + 4 <= g.N ? col : 0));
+            }
+          }
+#pragma unroll
+          for (int x = 0; x < RB; ++x)
+#pragma unroll
+            for (int y = 0; y < CB; ++y) {
+              acc[x][y][0] = mv[x][y].x > 0.f ? acc[x][y][0] : 0.f; acc[x][y][1] = mv[x][y].y > 0.f ? acc[x][y][1] : 0.f;
+              acc[x][y][2] = mv[x][y].z > 0.f ? acc[x][y][2] : 0.f; acc[x][y][3] = mv[x][y].w > 0.f ? acc[x][y][3] : 0.f;
+            }
+        }
       }
 #pragma unroll
       for (int x = 0; x < RB; ++x)
@@ -1226,7 +1250,7 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     dim3 grid((unsigned)(8 * std::min<int64_t>(32, ogl_cdiv(T, 8)))), block(768);
     // ring depth: two stages of the 256 x 128 tile fill the LDS (144 KB); the 128 x 128 tile takes three (144 KB): its movers
     // run two stages ahead (+4 % on the layer-0 weight gradient, whose operands both stream from HBM)
-    const bool ext = g.a2.img || g.add || g.out_img;
+    const bool ext = g.a2.img || g.add || g.out_img || g.mask;
     if (bk && g.ak_groups > 0) hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1, 3, false, true, true>), grid, block, 0, stream, g);
     else if (bk) hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1, 3, false, true>), grid, block, 0, stream, g);
     else if (ext) {
@@ -1239,7 +1263,7 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     else hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1, 3>), grid, block, 0, stream, g);
     OGL_CHECK_LAUNCH();
   } else {
-  if (g.a2.img || g.add || g.out_img) return OGL_EINVAL;   // the extensions live in the producer / consumer kernel (images < 4 GB)
+  if (g.a2.img || g.add || g.out_img || g.mask) return OGL_EINVAL;   // the extensions live in the producer / consumer kernel (images < 4 GB)
   // (the 256 x 128 form of this kernel needs 64-bit piece addresses on top of 128 accumulators: it does not fit 256 registers
   // without spilling, so images of 4 GB and more take the 128 x 128 tile)
   cfg = 1;
@@ -1281,13 +1305,14 @@ extern "C" int ogl_linear_fwd_x3_ext(const void* x_img, int64_t x_img_rows, cons
                                      const void* x2_img, int64_t x2_img_rows, const int64_t* x2_rows, int64_t x2_nrows, int K2,
                                      int64_t M, const void* w_img, int N, const float* add, int64_t ld_add, const int64_t* add_rows,
                                      int64_t add_nrows, int relu, float* y, int64_t ldy, void* out_img, int out_append_ones,
-                                     ogl_stream_t stream) {
+                                     const float* mask, int64_t ld_mask, ogl_stream_t stream) {
   if (M < 0 || K1 <= 0 || K2 < 0 || N < 0 || x_img_rows < 0 || x_nrows < 0 || x_nrows > x_img_rows || ldy < N) return OGL_EINVAL;
   if (M == 0 || N == 0) return OGL_OK;
   if (!x_img || !w_img || !y || (!x_rows && M > x_img_rows)) return OGL_EINVAL;
   if (K2 > 0 && (!x2_img || x2_img_rows < 0 || x2_nrows < 0 || x2_nrows > x2_img_rows || (!x2_rows && M > x2_img_rows))) return OGL_EINVAL;
   if (add && (ld_add < N || add_nrows < 0)) return OGL_EINVAL;
   if (out_img && ((uintptr_t)out_img & 15)) return OGL_EINVAL;
+  if (mask && (ld_mask < N || (ld_mask & 3) || ((uintptr_t)mask & 15) || (N & 3))) return OGL_EINVAL;   // whole 16-byte groups only
   X3Args g = X3Args();
   const int G1 = (int)ogl_cdiv(K1, 32), G2 = (int)ogl_cdiv(K2, 32);
   g.a = X3Operand{(const unsigned char*)x_img, (int64_t)G1 * X3_GROUP_BYTES, X3_GROUP_BYTES, x_rows, x_rows ? x_nrows : x_img_rows,
@@ -1302,6 +1327,7 @@ extern "C" int ogl_linear_fwd_x3_ext(const void* x_img, int64_t x_img_rows, cons
   g.add = add; g.ld_add = ld_add; g.add_rows = add_rows; g.add_nrows = add_nrows;
   g.out_img = (unsigned char*)out_img; g.out_append_ones = out_append_ones;
   g.out_row_bytes = ogl_cdiv(N + (out_append_ones ? 1 : 0), 32) * X3_GROUP_BYTES;
+  g.mask = mask; g.ld_mask = ld_mask;
   return launch_x3(g, (hipStream_t)stream);
 }
 

@@ -510,11 +510,22 @@ def relu_bwd_img(dy, y):
     return out, img
 
 
-def linear_bwd_input(dy, w, ymask=None, dy_img=None, add_head=None):
+# The ReLU backward of a layer's output in the epilogue of the product that computes that output's gradient (ogl_linear_fwd_x3_ext's
+# `mask`): removes the 16 us ogl_relu_bwd_img launch of the Reddit step and 60 MB of traffic — and measured NO gain (same box,
+# alternating replayed runs: 1.056 / 1.066 ms without, 1.063 / 1.078 with): the masked epilogue costs the product 10 us on the
+# critical path, while the separate pass ran beside the side stream's weight gradients.  Off by default; OGL_FUSE_RELU_BWD=1 and
+# tests/test_gpu_round3.py keep it exercised.
+FUSE_RELU_BWD = os.environ.get("OGL_FUSE_RELU_BWD", "0") == "1"
+
+
+def linear_bwd_input(dy, w, ymask=None, dy_img=None, add_head=None, out_relu_mask=None):
     """dX = dY . W.  ``dy_img``: the bf16x3 image of dY when its producer wrote one — the product then runs on the image kernel
     against the image of W^T (a 600 x 600 transpose + split: two small launches, or one of the step's prepared weight images).
     ``add_head`` [n, K]: added to the first n rows of dX (the fc_self path of a layer's input gradient) — in the epilogue of the
-    image kernel when that runs, in place otherwise."""
+    image kernel when that runs, in place otherwise.
+    ``out_relu_mask`` [M, K] (image path only; ignored elsewhere): X is the output of a fused-ReLU projection whose value this is —
+    dX leaves the kernel multiplied by [X > 0] with its bf16x3 image attached, and carries ``_ogl_premasked`` so that the ReLU's own
+    backward recognises it (masking twice would be harmless: the mask is idempotent)."""
     dy = as_mat(dy); w = as_mat(w)
     if ymask is not None:
         dy = relu_bwd(dy, ymask)
@@ -524,6 +535,11 @@ def linear_bwd_input(dy, w, ymask=None, dy_img=None, add_head=None):
     if dy_img is not None and dy_img.rows == M and dy_img.K == N:
         wt = weight_image("T", w)
         wt = wt if wt is not None else x3_split(transpose(w))
+        if out_relu_mask is not None and K % 4 == 0 and _ld(as_mat(out_relu_mask)) % 4 == 0 and out_relu_mask.data_ptr() % 16 == 0:
+            dx, img = linear_fwd_x3_ext(dy_img, None, wt, add=add_head, mask=out_relu_mask, want_image=True)
+            attach_image(dx, img)
+            dx._ogl_premasked = (out_relu_mask.data_ptr(), out_relu_mask._version)
+            return dx
         if add_head is not None:
             return linear_fwd_x3_ext(dy_img, None, wt, add=add_head)
         return linear_fwd_x3(dy_img, None, wt)
@@ -685,7 +701,7 @@ def x3_split_cat(parts):
 
 
 def linear_fwd_x3_ext(x_img, x_rows, w_img, x2_img=None, x2_rows=None, add=None, add_rows=None, relu=False, x_nrows=None,
-                      x2_nrows=None, M=None, want_image=False, image_append_ones=False, out=None):
+                      x2_nrows=None, M=None, want_image=False, image_append_ones=False, out=None, mask=None):
     """``linear_fwd_x3`` with a second A part (``w_img`` K-concatenated, x3_split_cat), a per-row addend ``add[add_rows]`` and /
     or the bf16x3 image of the output (returned as the second value when ``want_image``)."""
     M = x_rows.numel() if x_rows is not None else (x_img.rows if M is None else M)
@@ -699,6 +715,9 @@ def linear_fwd_x3_ext(x_img, x_rows, w_img, x2_img=None, x2_rows=None, add=None,
     if add is not None:
         add = as_mat(add)
         assert add.shape[1] == N and (add_rows is None or add_rows.numel() == M)
+    if mask is not None:
+        mask = as_mat(mask)
+        assert mask.shape == (M, N) and _ld(mask) % 4 == 0 and N % 4 == 0 and mask.data_ptr() % 16 == 0
     img = None
     if want_image:
         Ki = N + (1 if image_append_ones else 0)
@@ -710,7 +729,7 @@ def linear_fwd_x3_ext(x_img, x_rows, w_img, x2_img=None, x2_rows=None, add=None,
             (x2_img.rows if x2_nrows is None else x2_nrows) if x2_img is not None else 0, K2, M, _ptr(w_img.buf), N,
             _ptr(add), _ld(add) if add is not None else 0, _ptr(_ids(add_rows) if add_rows is not None else None),
             add.shape[0] if add is not None else 0, 1 if relu else 0, _ptr(y), _ld(y), _ptr(img.buf) if img is not None else None,
-            1 if image_append_ones else 0, _stream(), meta=dict(M=M, K=K1, N=N, K2=K2))
+            1 if image_append_ones else 0, _ptr(mask), _ld(mask) if mask is not None else 0, _stream(), meta=dict(M=M, K=K1, N=N, K2=K2))
     return (y, img) if want_image else y
 
 
@@ -1277,6 +1296,8 @@ class _LinearFn(torch.autograd.Function):
             y = linear_fwd(x, w, bias, x2, w2, relu, x_rows, x2_rows)
         ctx.relu = bool(relu)
         ctx.has_bias = bias is not None
+        if relu:
+            y._ogl_relu_out = True               # (read by the consumer layer: its input gradient may come back pre-masked)
         ctx.save_for_backward(x, w, x2, w2, y if relu else None, x_rows, x2_rows)
         return y
 
@@ -1286,6 +1307,10 @@ class _LinearFn(torch.autograd.Function):
         dy = as_mat(dy)
         need = ctx.needs_input_grad
         dy_img = None
+        if y is not None and getattr(dy, "_ogl_premasked", None) == (y.data_ptr(), y._version):
+            # the product that computed dy already applied [y > 0] in its epilogue and wrote the image (linear_bwd_input)
+            dy_img = take_image(dy)
+            y = None
         if y is not None:
             # once; the (up to four) backward GEMMs below are mask-free.  Tall products with an input gradient to compute get
             # the image of the masked gradient from the same pass
@@ -1454,6 +1479,7 @@ class _SagePoolLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu):
         h = as_mat(h)
+        ctx.h_relu_out = bool(getattr(h, "_ogl_relu_out", False))                    # h = relu(...) of the layer below
         himg = take_image(h) if _n1_images_ok(h.shape[0], h.shape[1], w_pool.shape[0]) else None
         ctx.h_img = himg if (himg is not None and himg.K == h.shape[1] + 1) else None   # read again by fc_pool's weight gradient
         if himg is not None and himg.K == h.shape[1] + 1:
@@ -1506,7 +1532,8 @@ class _SagePoolLayerFn(torch.autograd.Function):
                                                dp_zeroed=take_zeroed(slot, n_src, h.shape[1]) if slot is not None else None)
             dp_img = x3_split(dp) if tall else None
             at = fork_point() if tall else None
-            dh = linear_bwd_input(dp, w_pool, None, dy_img=dp_img, add_head=dx_self)
+            dh = linear_bwd_input(dp, w_pool, None, dy_img=dp_img, add_head=dx_self,
+                                  out_relu_mask=h if (FUSE_RELU_BWD and ctx.h_relu_out and tall) else None)
             with (side_section(dp, dp_img, ctx.h_img, at=at) if tall else _NoSection()):
                 dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias, x_img=ctx.h_img, dy_img=dp_img, dw_out=_dw_out(w_pool, *w_pool.shape))
             return (dh, dw_pool, db_pool if ctx.has_pool_bias else None, dw_self, dw_neigh, db if ctx.has_bias else None,

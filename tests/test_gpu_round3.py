@@ -207,3 +207,37 @@ def test_projection_kernels_are_row_independent(K, N, K2):
         fimg = ops.linear_fwd_x3(ximg, None, wimg, relu=True)
         for M in (128, 2048, 7000, 9000):
             assert torch.equal(ops.linear_fwd_x3(ximg, None, wimg, relu=True, M=M), fimg[:M]), M
+
+
+def test_relu_mask_in_the_input_gradient_epilogue_matches_the_separate_pass():
+    """ops.FUSE_RELU_BWD (off by default: measured no gain): dh1 leaves the image product already multiplied by [h1 > 0], image
+    attached, and the layer-0 combine's backward recognises it — same gradients as the separate ogl_relu_bwd_img pass."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops, sampling
+    from ogl_amd.graphsage import GatheredRows, GraphSAGE
+    feat_size, labels, g, n_classes = _reddit_like_small()
+    ops.set_gemm_mode("auto")
+    torch.manual_seed(2)
+    model = GraphSAGE(feat_size, 600, n_classes, 1, F.relu, 0, "pool").cuda()
+    seeds = torch.as_tensor(np.random.default_rng(0).choice(g.n_present, 512, replace=False).astype(np.int64))
+    grads, names = {}, {}
+    old = ops.FUSE_RELU_BWD
+    try:
+        for fuse in (False, True):
+            ops.FUSE_RELU_BWD = fuse
+            ops.invalidate_weight_images()
+            sampling.seed(11)
+            (input_nodes, sd, blocks), = list(sampling.NodeDataLoader(g, seeds, sampling.MultiLayerNeighborSampler([25, 25]), batch_size=512))
+            for p in model.parameters():
+                p.grad = None
+            lab = ops.gather_i64(g.ndata["target"], sd)
+            ops.profile_start()
+            loss = ops.cross_entropy(model(blocks, GatheredRows(g.ndata["feat"], input_nodes)), lab, "mean")
+            ops.backward(loss)          # (the unit root gradient keeps dlogits in its padded layout: the output layer's fused backward)
+            names[fuse] = [n for n, _, _ in ops.profile_stop()]
+            grads[fuse] = [p.grad.detach().clone() for p in model.parameters()]
+    finally:
+        ops.FUSE_RELU_BWD = old
+    assert "ogl_relu_bwd_img" in names[False] and "ogl_relu_bwd_img" not in names[True]
+    for a, b in zip(grads[False], grads[True]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)          # (downstream of the output layer's atomic scatter)
