@@ -30,7 +30,7 @@ def entry(r, **extra):
     return d
 
 
-def first(rows, pred):
+def first(rows, pred, full_only=False):
     """The kernel (template instantiation) with the most total time among those `pred` accepts — its launches pooled over the
     grid sizes they ran on (an aggregator's grid follows the batch's block size), counters averaged per launch."""
     groups = {}
@@ -40,6 +40,9 @@ def first(rows, pred):
     if not groups:
         return None
     name, rs = max(groups.items(), key=lambda kv: sum(r["total_ms"] for r in kv[1]))
+    if full_only:                       # a fused inference pass: its FULL chunks only (the last chunk of a pass is a partial one)
+        top = max(r["grid"] for r in rs)
+        rs = [r for r in rs if r["grid"] >= 0.85 * top]
     n = sum(r["calls"] for r in rs)
     avg = lambda k: sum((r[k] or 0.0) * r["calls"] for r in rs) / n          # noqa: E731
     return dict(name=name, grid=("%d..%d" % (min(r["grid"] for r in rs), max(r["grid"] for r in rs))) if len(rs) > 1 else rs[0]["grid"],
@@ -56,7 +59,7 @@ def main():
     for arg in sys.argv[3:]:
         wl, path = arg.split("=", 1)
         rows = parse(path)
-        agg = first(rows, lambda r: r["name"].startswith("k_reduce_fwd_v4"))
+        agg = first(rows, lambda r: r["name"].startswith("k_reduce_fwd_v4"), full_only=(wl != "rbr"))
         if wl == "rbr":
             if agg:
                 out["k_reduce_fwd_v4_L0"] = entry(agg)
