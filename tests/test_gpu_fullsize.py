@@ -135,8 +135,8 @@ def test_fullsize_free_running_steps_track_the_oracle(reddit):
     contribution into layer 0 (1e-3 .. 3e-3 relative on its weight gradients), and Adam's lr * g / (|g| + eps) turns every
     entry whose gradient changed sign into a 2 lr weight difference (~700 of 1.5 M entries after ONE step).  From there the
     trajectories separate at a rate no arithmetic can influence.  The yardstick is therefore ANOTHER correct evaluation of the
-    same model: the oracle in float64.  The device must track the fp32 oracle about as closely as the fp64 oracle does, within
-    1e-2 on every loss in any case (measured: device 6e-5 after one step, 1e-3 after five, 2-4e-3 after ten)."""
+    same model: the oracle in float64.  The device must track the fp32 oracle about as closely as the fp64 oracle does (within 4x its
+    worst drift), and within 1e-2 on every loss in any case (measured: device 6e-5 after one step, 1e-3 after five, 2-4e-3 after ten)."""
     from ogl_amd import ops, optim, sampling
     from ogl_amd.graphsage import GatheredRows, GraphSAGE
     a, dyn, g, host = reddit
@@ -179,7 +179,9 @@ def test_fullsize_free_running_steps_track_the_oracle(reddit):
         print("relative drift  device vs oracle:", ["%.1e" % x for x in dev_drift], " fp64 oracle vs oracle:", ["%.1e" % x for x in ref_drift])
         np.testing.assert_allclose(got, want, rtol=1e-2)
         assert dev_drift[0] <= 1e-5                                   # the first step starts from identical weights
-        assert dev_drift.max() <= 1e-4 + 3 * ref_drift.max(), (dev_drift, ref_drift)
+        # (measured: device 4.0e-3 at its worst step, fp64 oracle 1.7e-3; the device's own run-to-run spread — float atomics — is
+        # a few 1e-4, so the bound leaves room for it)
+        assert dev_drift.max() <= 1e-3 + 4 * ref_drift.max(), (dev_drift, ref_drift)
         assert got[-1] < got[0]                                       # and it trains
     finally:
         ops.set_gemm_mode("f32")
