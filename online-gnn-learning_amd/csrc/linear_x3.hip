@@ -49,6 +49,7 @@ struct X3Args {
   int nsplit, steps_per_split;
   float* ws; int64_t ws_ld;
   int NI, NJ;
+  int force_cfg0;               // the k-major weight gradient on the 256 x 128 tile (x3_bwwk_cfg0)
   unsigned long long* stamps;   // diagnostics only (ogl_x3_debug_stamps): per block {s_memtime, s_memrealtime} at entry and exit
   // ---- extensions, k_gemm_x3p<..., EXT = true> only (forward products, nsplit == 1) ----
   X3Operand a2;                 // optional SECOND part of the A operand: reduction steps [nsteps1, nsteps) read a2 (its own image,
@@ -1219,8 +1220,8 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
   const int64_t b_bytes = std::max((g.b.zero_row + 1) * g.b.row_bytes, (int64_t)g.nsteps * g.b.step_bytes);
   if (g.a2.img && (g.a2.zero_row + 1) * g.a2.row_bytes >= (1ll << 32)) return OGL_EINVAL;
   int cfg = x3_config(g.M, g.N);
-  const bool bk = g.bk_groups > 0;                        // row-major B over the reduction: the 128 x 128 producer / consumer tile only
-  if (bk) cfg = 1;
+  const bool bk = g.bk_groups > 0;                        // row-major B over the reduction: 128 x 128 (three stages) or 256 x 128 (two)
+  if (bk) cfg = g.force_cfg0 ? 0 : 1;
   // producer / consumer kernels (k_gemm_x3p) whenever both images fit 32-bit offsets; OGL_X3_PC=0 forces the
   // self-fetching kernels (experiments)
   static const char* pc_env = getenv("OGL_X3_PC");
@@ -1252,6 +1253,7 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     // run two stages ahead (+4 % on the layer-0 weight gradient, whose operands both stream from HBM)
     const bool ext = g.a2.img || g.add || g.out_img || g.mask;
     if (bk && g.ak_groups > 0) hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1, 3, false, true, true>), grid, block, 0, stream, g);
+    else if (bk && cfg == 0) hipLaunchKernelGGL((k_gemm_x3p<4, 2, 2, 2, 2, false, true>), grid, block, 0, stream, g);
     else if (bk) hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1, 3, false, true>), grid, block, 0, stream, g);
     else if (ext) {
       if (g.nsplit != 1 || g.ones_col) return OGL_EINVAL;
@@ -1353,8 +1355,18 @@ extern "C" int64_t ogl_linear_bwd_weight_x3_workspace_bytes(int64_t M, int N, in
 
 // The weight gradient with the activations' ROW-MAJOR image as it is (k_gemm_x3p<..., BK>): dw = dy^T . x[rows] without a
 // transposed image of x.  The split-K plan is the one of the 128 x 128 tile.
-static void x3_bwwk_plan(int64_t steps, int N, int Kc, int* nsplit, int* sps) {
-  const int64_t tiles = ogl_cdiv(N, 128) * ogl_cdiv(Kc, 128);
+// The k-major weight gradient of a WIDE layer (>= 512 output rows, dy^T a transposed image: layer 0's dW_pool) runs on the 256 x 128
+// two-stage tile: 72 KB of stage DMA per 256 x 128 x 32 step instead of 2 x 48 KB for the same work on 128 x 128 tiles — these
+// products are paced by the LDS-DMA issue rate, not by the matrix pipe (a tile whose padding blocks skip their MFMAs is no faster:
+// an uneven split-K that gave the 90-valid-row last tile longer reduction ranges was 15-40 % SLOWER, round 3) — measured
+// 0.2385 -> 0.2330 ms for the Reddit dW_pool0 in spite of 602 rows filling only 2.35 of 3 row tiles.  OGL_BWWK_CFG0=0: 128 x 128.
+static bool x3_bwwk_cfg0(int N, bool dy_rows) {
+  static const char* e = getenv("OGL_BWWK_CFG0");
+  return !(e && e[0] == '0') && !dy_rows && N >= 512;
+}
+
+static void x3_bwwk_plan(int64_t steps, int N, int Kc, int* nsplit, int* sps, bool cfg0 = false) {
+  const int64_t tiles = ogl_cdiv(N, cfg0 ? 256 : 128) * ogl_cdiv(Kc, 128);
   int64_t s = 256 / (tiles > 0 ? tiles : 1);
   if (s < 1) s = 1;
   if (steps / s < 8) s = steps / 8 > 0 ? steps / 8 : 1;
@@ -1365,7 +1377,7 @@ static void x3_bwwk_plan(int64_t steps, int N, int Kc, int* nsplit, int* sps) {
 extern "C" int64_t ogl_linear_bwd_weight_x3k_workspace_bytes(int64_t M, int64_t interleave, int N, int K, int has_ones) {
   if (M < 0 || N < 0 || K < 0 || interleave < -1) return OGL_EINVAL;
   int nsplit, sps;
-  x3_bwwk_plan(interleave > 0 ? interleave : ogl_cdiv(M, 32), N, K + (has_ones ? 1 : 0), &nsplit, &sps);
+  x3_bwwk_plan(interleave > 0 ? interleave : ogl_cdiv(M, 32), N, K + (has_ones ? 1 : 0), &nsplit, &sps, x3_bwwk_cfg0(N, interleave == -1));
   if (nsplit <= 1) return 16;
   return (int64_t)nsplit * N * ogl_round_up(K + 1, 4) * 4;
 }
@@ -1394,7 +1406,8 @@ extern "C" int ogl_linear_bwd_weight_x3k(const void* dyT_img, int64_t interleave
   g.M = N; g.N = Kc; g.ones_col = has_ones ? 1 : 0;
   g.nsteps = (int)(interleave ? interleave : ogl_cdiv(M, 32));
   g.C = dw; g.ldc = lddw; g.db = db; g.db2 = db2;
-  x3_bwwk_plan(g.nsteps, N, Kc, &g.nsplit, &g.steps_per_split);
+  x3_bwwk_plan(g.nsteps, N, Kc, &g.nsplit, &g.steps_per_split, x3_bwwk_cfg0(N, dy_rows));
+  g.force_cfg0 = x3_bwwk_cfg0(N, dy_rows) ? 1 : 0;
   if (g.nsplit > 1) {
     g.ws_ld = ogl_round_up(K + 1, 4);
     if (!workspace || workspace_bytes < (int64_t)g.nsplit * N * g.ws_ld * 4) return OGL_EWORKSPACE;

@@ -66,7 +66,8 @@ def main():
             f = first(rows, lambda r: re.match(r"k_gemm_x3p<4, 2, 2, 2, 2, false, false, false>", r["name"]))
             if f:
                 out["k_gemm_x3_fwd_pool0"] = entry(f)
-            w = first(rows, lambda r: re.match(r"k_gemm_x3p<2, 4, 2, 1, 3, false, true, false>", r["name"]))
+            # the layer-0 weight gradient: k-major B, dy^T a transposed image (256 x 128 tile since round 3, 128 x 128 before)
+            w = first(rows, lambda r: re.match(r"k_gemm_x3p<(2, 4, 2, 1, 3|4, 2, 2, 2, 2), false, true, false>", r["name"]))
             if w:
                 out["k_gemm_x3_bwwk_pool0"] = entry(w)
         else:
