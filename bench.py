@@ -167,7 +167,6 @@ def main():
     wl = WORKLOADS[args.workload]
     B, S, H, bt = wl["batch"], wl["samples"], wl["hidden"], wl["batch_timestep"]
     t0 = time.time()
-    feat_size, labels_np, dyn, n_classes, _unused = None, None, None, None, None
     arrays = synthetic.make_arrays(wl["dataset"], args.scale)
     feat_size, n_classes = arrays["f"], arrays["c"]
     # last snapshot of the stream: every vertex and edge present (the most work per seed)
@@ -512,7 +511,7 @@ def end_to_end_snapshots(n_snapshots=6, start=4500, gemm="auto"):
                priority_forward=2, snapshots=5000)
     np.random.seed(1); random.seed(1); torch.manual_seed(1); sampling.seed(1)
     ops.set_gemm_mode(gemm)
-    GraphSAGE, Random, Prioritized, NoReh, Full, act = init(Lib_supported.HIP, True, 0)
+    GraphSAGE, Random, Prioritized, NoReh, _Full, act = init(Lib_supported.HIP, True, 0)
     t0 = time.perf_counter()
     feat_size, labels, graph, n_classes, graph_test = synthetic.load("reddit", snapshots=cfg["snapshots"])
     for _ in range(cfg["delta"]):
@@ -545,7 +544,7 @@ def end_to_end_snapshots(n_snapshots=6, start=4500, gemm="auto"):
         sync(); rec[key] = rec.get(key, 0.0) + 1000 * (time.perf_counter() - t)
         return out
 
-    for snap in range(n_snapshots + 1):                      # the first one is the warm-up (images, code objects, allocator)
+    for _snap in range(n_snapshots + 1):                     # the first one is the warm-up (images, code objects, allocator)
         rec = {}
         sync(); t_snap = time.perf_counter()
         nodes = timed(rec, "rbr_choose_vertices_host", lambda: rnd.choose_vertices(gu))

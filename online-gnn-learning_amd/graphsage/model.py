@@ -406,7 +406,6 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         if seeds_all.numel() == 0:
             return None
         n_all = int(seeds_all.numel())
-        rank, world = parallel.rank_world()
         parallel.assert_replicated(seeds_all, "the evaluation vertices")
         last = self.graphsage_model.layers[-1]
         C_ = int((last.fc_self if last.fc_self is not None else last.fc_neigh).weight.shape[0])
@@ -601,7 +600,7 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
         # N ranks: whole batches of the pass are block-partitioned over the ranks (seed order kept) and the per-seed losses
         # are all-gathered, so every replica of the replay buffer receives every priority (north star: "PBR sharded across
         # the GPUs"); the lengths every rank contributes follow from the partition, only values travel
-        rank, world = parallel.rank_world()
+        world = parallel.rank_world()[1]
         parallel.assert_replicated(seeds_all, "the priority-forward seeds")
         losses = []
         with torch.no_grad():

@@ -1337,7 +1337,6 @@ class _LinearFn(torch.autograd.Function):
 
     @staticmethod
     def _weight_grads(ctx, dy, dy_img, x, w, x2, w2, x_rows, x2_rows, need):
-        y = None
         dw = db = dw2 = db2 = None
         dyT = None
         x2_img = ctx.x2_img if (x2 is not None and x2_rows is None) else None
