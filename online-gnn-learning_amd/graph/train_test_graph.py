@@ -139,6 +139,14 @@ class TrainTestGraph:
             random.shuffle(lst)
             return lst[:n_nodes]
         total = len(lst)
+        if n_nodes * 8 < total:
+            # a small subset of a long list (512 of 2e5, 100 times per Reddit snapshot): an ordered uniform sample of positions
+            # from a numpy Generator (Floyd's algorithm: O(n_nodes), in C) seeded ONCE from Python's `random` stream — the stream
+            # the reference draws from, so identically seeded replicas still draw identical batches
+            if getattr(self, "_draw_rng", None) is None:
+                self._draw_rng = np.random.default_rng(random.getrandbits(63))
+            idx = self._draw_rng.choice(total, size=n_nodes, replace=False, shuffle=True)
+            return [lst[i] for i in idx.tolist()]
         for i in range(n_nodes):
             j = random.randrange(i, total)
             lst[i], lst[j] = lst[j], lst[i]
