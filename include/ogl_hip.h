@@ -248,6 +248,11 @@ int ogl_x3_split_t(const float* src, int64_t ld, const int64_t* rows, int64_t nr
  * the kernel is d(s_memtime) / d(s_memrealtime) x 100 MHz.  Pass NULL to switch off.  `reserved` is ignored.  Not part of
  * the hot path. */
 int ogl_x3_debug_stamps(void* buf, int reserved);
+/* Diagnostics (A/B of tile shapes inside one process, tests): cfg >= 0 pins the tile of the plain / EXT one-split row-major image
+ * products — 0: 256 x 128, 1: 128 x 128, 2: 192 x 128, 3: 160 x 128, 4: 256 x 160 (plain only; EXT falls back to 0) — and -1
+ * returns to the automatic choice.  Every tile computes every output element with the same sequence of MFMAs: results are
+ * bit-identical across tiles.  OGL_EINVAL outside [-1, 4].  Not part of the hot path. */
+int ogl_x3_debug_tile(int cfg);
 
 int ogl_linear_fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
                       const void* w_img, int N, int relu, float* y, int64_t ldy, ogl_stream_t stream);

@@ -363,15 +363,21 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
 // One barrier per step.  Three waves per SIMD = 168 registers per wave: the multipliers keep accumulators (64), A
 // fragments (48) and a two-deep B ring (24), the movers their piece offsets.  Images must be < 4 GB (32-bit offsets).
 // Measured against k_gemm_x3: matrix pipe busy 73 % of the in-kernel cycles instead of 56 %.
-template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool EXT = false, bool BK = false, bool AK = false>
+// RH / CH: one more 16-row / 16-column block per wave tile on top of TM / TN pairs (tiles of 160 rows or 160 columns).  Such a stage is
+// not a whole number of 256-lane instructions (UNEVEN): the last instruction index is issued by the first mover waves only, and
+// the instruction that straddles the A / B boundary takes its operand per WAVE (piece counts are multiples of 64).
+template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool EXT = false, bool BK = false, bool AK = false, int RH = 0, int CH = 0>
 __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(WAVES_M * WAVES_N == 8, "eight multiplier waves + four mover waves");
-  constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32, RB = TM * 2, CB = TN * 2;
-  static_assert(((BM + BN) * 12) % 256 == 0 && (BM * 12) % 256 == 0, "pieces split evenly over the 256 mover lanes");
+  constexpr int RB = TM * 2 + RH, CB = TN * 2 + CH, WROWS = RB * 16, WCOLS = CB * 16;
+  constexpr int BM = WAVES_M * WROWS, BN = WAVES_N * WCOLS;
   constexpr int PIECES = (BM + BN) * 12, STAGE = PIECES * 16, A_PIECES = BM * 12;
-  constexpr int NLP = PIECES / 256;                        // 18 pieces per mover lane per stage
-  constexpr int NLP_A = A_PIECES / 256;                    // the first 12 are A rows
+  constexpr bool UNEVEN = (PIECES % 256) != 0 || (A_PIECES % 256) != 0;
+  static_assert(PIECES % 64 == 0 && A_PIECES % 64 == 0, "pieces split evenly over the lanes of a mover wave");
+  static_assert(!UNEVEN || (NSTAGE == 2 && !BK && !AK), "uneven stages: two-stage ring (vmcnt(0) waits), row-major operands");
+  constexpr int NLP = (PIECES + 255) / 256;                // 18 pieces per mover lane per stage (256 x 128)
+  constexpr int NLP_A = (A_PIECES + 255) / 256;            // the first 12 are A rows (UNEVEN: instruction NLP_A - 1 is A for some waves only)
   constexpr int NSTORE = RB * CB;
   static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
   static_assert(NSTAGE * STAGE <= 160 * 1024, "the ring fits one CU");
@@ -421,6 +427,9 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
   if (mover) {
     // ---- movers: the fetch cursor walks the block's stages in order, across tiles -------------------------------------
     const int ml = (wid - 8) * 64 + lane;                  // lane of the 256-lane mover group
+    const int wbase = (wid - 8) * 64;                      // this wave's first piece inside an instruction (wave-uniform)
+    auto u_is_a = [&](int u) __attribute__((always_inline)) { return UNEVEN ? u * 256 + wbase < A_PIECES : u < NLP_A; };
+    auto u_live = [&](int u) __attribute__((always_inline)) { return !UNEVEN || u * 256 + wbase < PIECES; };
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)g.a.img, 0, 0xFFFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)g.b.img, 0, 0xFFFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_a2 =
@@ -455,6 +464,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
     auto make_src_a2 = [&](int ti) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < NLP_A; ++u) {
+        if (!u_is_a(u)) continue;
         const int i = u * 256 + ml;
         const int r = i / 12, jp = i - r * 12;
         const int j = (jp & ~3) | ((jp & 3) ^ swz(r));
@@ -487,7 +497,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
           if (grp >= g.ak_groups) ak_zmask |= 1u << u;
           src[u] = (unsigned)((grp < g.ak_groups ? grp : 0) * X3_GROUP_BYTES + (pc % 12) * 16);
           continue;
-        } else if (u < NLP_A) {
+        } else if (u_is_a(u)) {
           const int64_t id = rid[u < NLP_A ? u : 0];
           const bool ok = (int64_t)t.ti * BM + r < g.M && id >= 0 && id < g.a.nrows;
           off = (ok ? id : g.a.zero_row) * g.a.row_bytes + (int64_t)t.ks_begin * g.a.step_bytes;
@@ -534,14 +544,17 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
       }
       const __amdgpu_buffer_rsrc_t r1 = rsrc_a, r2 = rsrc_a2;   // copies first: a conditional over two captured
       const __amdgpu_buffer_rsrc_t rs_a = (EXT && part2) ? r2 : r1;   // references indexes the closure dynamically and pins it in scratch
+      const __amdgpu_buffer_rsrc_t rs_b = rsrc_b;
       static_for<0, NLP>([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value;
         unsigned so = src[u];
         if (BK && u >= NLP_A) so += ((bk_zmask >> (u - NLP_A)) & 1) ? bk_zero : bk_row[(u - NLP_A) / 3];
         if (AK && u < NLP_A) so += ((ak_zmask >> u) & 1) ? ak_zero : ak_row[u / 3];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(u < NLP_A ? rs_a : rsrc_b,
-                                                 (lptr_t)(smem + (stage % NSTAGE) * STAGE + (u * 256 + (wid - 8) * 64) * 16), 16, so, 0, 0, 0);
-        if (!(BK && u >= NLP_A) && !(AK && u < NLP_A)) src[u] += u < NLP_A ? step_a : step_b;
+        const bool ia = u_is_a(u);                           // (compile-time unless UNEVEN; then uniform over the wave)
+        if (u_live(u))
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ia ? rs_a : rs_b,
+                                                   (lptr_t)(smem + (stage % NSTAGE) * STAGE + (u * 256 + (wid - 8) * 64) * 16), 16, so, 0, 0, 0);
+        if (!(BK && u >= NLP_A) && !(AK && u < NLP_A)) src[u] += ia ? step_a : step_b;
       });
       if (++fks == fks_end && f_logical + nslots < last_logical) {     // on to the next tile
         f_logical += nslots;
@@ -577,7 +590,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         offp[sp] = ((j & ~3) | ((j & 3) ^ q)) * 16;
       }
     }
-    const int rowa = (wm * TM * 32 + l15) * 192, rowb = (BM + wn * TN * 32 + l15) * 192;
+    const int rowa = (wm * WROWS + l15) * 192, rowb = (BM + wn * WCOLS + l15) * 192;
     // BK: the B stage holds 32 reduction rows x 48 pieces; piece pc of row k sits at piece index
     // (3 ((k >> 2) & 1) + (pc >> 4)) * 256 + (k >> 3) * 64 + (k & 3) * 16 + ((pc & 15) ^ (2 (k & 3) | 8 ((k >> 3) & 1))) of the B part (what
     // the movers' lane-linear instructions produce).  A fragment (16 columns, 8 k per lane) is two ds_read_b64_tr_b16: lane
@@ -596,7 +609,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
       return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
     auto bk_frag = [&](const unsigned char* st, int y, int sp) __attribute__((always_inline)) {
-      return k_frag(st + B_BASE, wn * TN * 32 + y * 16, sp);
+      return k_frag(st + B_BASE, wn * WCOLS + y * 16, sp);
     };
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 acc[RB][CB];
@@ -625,7 +638,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         if (t < rbv) {
 #pragma unroll
           for (int sp = 0; sp < 3; ++sp) {
-            if constexpr (AK) a[t][sp] = k_frag(st, wm * TM * 32 + t * 16, sp);
+            if constexpr (AK) a[t][sp] = k_frag(st, wm * WROWS + t * 16, sp);
             else a[t][sp] = *(const bf16x8*)(st + rowa + t * 16 * 192 + offp[sp]);
           }
         }
@@ -675,7 +688,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
           bool aok[RB];
 #pragma unroll
           for (int x = 0; x < RB; ++x) {
-            const int64_t row = (int64_t)t.ti * BM + wm * TM * 32 + x * 16 + l15;
+            const int64_t row = (int64_t)t.ti * BM + wm * WROWS + x * 16 + l15;
             const bool rok = row < g.M;
             const int64_t ar = g.add_rows ? g.add_rows[rok ? row : 0] : row;
             aok[x] = rok && ar >= 0 && ar < g.add_nrows;
@@ -686,14 +699,14 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
           for (int x = 0; x < RB; ++x)
 #pragma unroll
             for (int y = 0; y < CB; ++y) {
-              const int64_t col = (int64_t)t.tj * BN + wn * TN * 32 + y * 16 + 4 * quad;
+              const int64_t col = (int64_t)t.tj * BN + wn * WCOLS + y * 16 + 4 * quad;
               tv[x][y] = *(const float4*)(ap[x] + (col + 4 <= g.N ? col : 0));
             }
 #pragma unroll
           for (int x = 0; x < RB; ++x)
 #pragma unroll
             for (int y = 0; y < CB; ++y) {
-              const int64_t col = (int64_t)t.tj * BN + wn * TN * 32 + y * 16 + 4 * quad;
+              const int64_t col = (int64_t)t.tj * BN + wn * WCOLS + y * 16 + 4 * quad;
               if (aok[x] && col + 4 <= g.N) {
                 acc[x][y][0] += tv[x][y].x; acc[x][y][1] += tv[x][y].y; acc[x][y][2] += tv[x][y].z; acc[x][y][3] += tv[x][y].w;
               }
@@ -705,11 +718,11 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
           float4 mv[RB][CB];
 #pragma unroll
           for (int x = 0; x < RB; ++x) {
-            const int64_t row = (int64_t)t.ti * BM + wm * TM * 32 + x * 16 + l15;
+            const int64_t row = (int64_t)t.ti * BM + wm * WROWS + x * 16 + l15;
             const float* mp = g.mask + (row < g.M ? row : 0) * g.ld_mask;
 #pragma unroll
             for (int y = 0; y < CB; ++y) {
-              const int64_t col = (int64_t)t.tj * BN + wn * TN * 32 + y * 16 + 4 * quad;
+              const int64_t col = (int64_t)t.tj * BN + wn * WCOLS + y * 16 + 4 * quad;
               mv[x][y] = *(const float4*)(mp + (col + 4 <= g.N ? col : 0));
             }
           }
@@ -726,7 +739,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
       for (int x = 0; x < RB; ++x)
 #pragma unroll
         for (int y = 0; y < CB; ++y) {
-          const int64_t row = (int64_t)t.ti * BM + wm * TM * 32 + x * 16 + l15, col = (int64_t)t.tj * BN + wn * TN * 32 + y * 16 + 4 * quad;
+          const int64_t row = (int64_t)t.ti * BM + wm * WROWS + x * 16 + l15, col = (int64_t)t.tj * BN + wn * WCOLS + y * 16 + 4 * quad;
           float v[4] = {acc[x][y][0], acc[x][y][1], acc[x][y][2], acc[x][y][3]};
           const bool rok = row < g.M;
           const bool has_oc = fin && g.ones_col && col + 3 >= g.N - 1 && col < g.N;
@@ -784,7 +797,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
     int n = 0;
     for (int logical = first; logical < last_logical; logical += nslots) {
       const Tile tc = decode(logical);
-      const int64_t rleft = g.M - ((int64_t)tc.ti * BM + wm * TM * 32), cleft = g.N - ((int64_t)tc.tj * BN + wn * TN * 32);
+      const int64_t rleft = g.M - ((int64_t)tc.ti * BM + wm * WROWS), cleft = g.N - ((int64_t)tc.tj * BN + wn * WCOLS);
       const int rbv = rleft >= RB * 16 ? RB : (int)((rleft + 15) >> 4), cbv = cleft >= CB * 16 ? CB : (int)((cleft + 15) >> 4);
       for (int ks = tc.ks_begin; ks < tc.ks_end; ++ks, ++n) {
         barrier();                                         // stage n has landed (the movers waited for it)
@@ -1211,6 +1224,13 @@ extern "C" int ogl_x3_debug_stamps(void* buf, int reserved) {
   return OGL_OK;
 }
 
+static int g_x3_tile = -1;
+extern "C" int ogl_x3_debug_tile(int cfg) {
+  if (cfg < -1 || cfg > 4) return OGL_EINVAL;
+  g_x3_tile = cfg;
+  return OGL_OK;
+}
+
 static int launch_x3(X3Args& g, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0) return OGL_OK;
   g.stamps = g_x3_stamps;
@@ -1232,35 +1252,57 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     // CU): its critical path is one tile.  [7 199, 602] -> 600: 145 tiles of 256 x 128, 285 of 128 x 128, 190 of 192 x 128
     // (measured 45 us on 256 x 128, 37 us on 192 x 128).
     static const char* c2_env = getenv("OGL_X3_CFG2");
+    // The 160-row and 160-column tiles are OFF unless OGL_X3_CFG3=1 / OGL_X3_CFG4=1 (or ogl_x3_debug_tile pins them).  Round 3, same
+    // box, alternating runs: launched back to back on cache-hot operands they are the fastest tiles of their shapes ([7 060, 600]:
+    // 32.6 us on 160 x 128 vs 34.4 on 192 x 128; [62 495, 602]: 211-215 us on 256 x 160 vs 221 on 256 x 128), but inside the replayed
+    // train step, where a launch's operands were written by the launch before it, the step is 1.5-3 % SLOWER with either of them
+    // (1.054-1.058 ms without, 1.064-1.081 / 1.067-1.077 / 1.081-1.089 with the 160-column / 160-row / both): 225 blocks x 54 KB
+    // of stage bytes are more L2 -> LDS traffic than 185 x 60 KB, and the CUs a one-round launch leaves idle are the ones the
+    // weight-gradient branch runs on.  PBR forward: no difference (0.2717-0.2745 ms either way).
+    static const char* c3_env = getenv("OGL_X3_CFG3");
+    static const char* c4_env = getenv("OGL_X3_CFG4");
+    const bool c3 = c3_env && c3_env[0] == '1', c4 = c4_env && c4_env[0] == '1';
     if (!bk && g.nsplit == 1 && !(c2_env && c2_env[0] == '0') && ogl_cdiv(g.M, 256) * ogl_cdiv(g.N, 128) <= 256) {
+      // (a step's duration follows its DMA pieces — 12 per tile row and column: 3 072 / 3 456 / 3 840 / 4 608 for 128 / 160 / 192 /
+      // 256 rows x 128 columns — so the shortest one-round tile wins)
       if (ogl_cdiv(g.M, 128) * ogl_cdiv(g.N, 128) <= 256) cfg = 1;
+      else if (c3 && ogl_cdiv(g.M, 160) * ogl_cdiv(g.N, 128) <= 256) cfg = 3;
       else if (ogl_cdiv(g.M, 192) * ogl_cdiv(g.N, 128) <= 256) cfg = 2;
     } else if (!bk && g.nsplit == 1 && !(c2_env && c2_env[0] == '0') && ogl_cdiv(g.M, 256) * ogl_cdiv(g.N, 128) <= 1024) {
       // a few rounds of tiles: the launch lasts (rounds of 256 tiles) x (tile height) / (the tile's efficiency in steady state:
-      // 1 : 0.93 : 0.86 for 256 : 192 : 128 rows) — e.g. [15 500, 600] is 2 rounds of 256 rows, 2 of 192 or 3 of 128
+      // 1 : 0.93 : 0.895 : 0.86 for 256 : 192 : 160 : 128 rows) — e.g. [15 500, 600] is 2 rounds of 256 rows, 2 of 192 or 3 of 128
       const int64_t nj = ogl_cdiv(g.N, 128);
       const double c0 = (double)ogl_cdiv(ogl_cdiv(g.M, 256) * nj, 256) * 256.0;
       const double c2 = (double)ogl_cdiv(ogl_cdiv(g.M, 192) * nj, 256) * 192.0 / 0.93;
+      const double c3r = c3 ? (double)ogl_cdiv(ogl_cdiv(g.M, 160) * nj, 256) * 160.0 / 0.895 : 1e30;
       const double c1 = (double)ogl_cdiv(ogl_cdiv(g.M, 128) * nj, 256) * 128.0 / 0.86;
-      cfg = (c0 <= c1 && c0 <= c2) ? 0 : (c2 <= c1 ? 2 : 1);
+      cfg = (c0 <= c1 && c0 <= c2 && c0 <= c3r) ? 0 : (c2 <= c1 && c2 <= c3r) ? 2 : (c3r <= c1 ? 3 : 1);
     }
-    const int BMp = cfg == 0 ? 256 : cfg == 2 ? 192 : 128;
+    // tall products whose columns pad no further on 160-column tiles than on 128-column ones (N = 600: 4 x 160 = 5 x 128) take
+    // 256 x 160: 4 992 DMA pieces per 256 x 160 x 32 step, 13 % fewer per MAC than 4 608 per 256 x 128 x 32
+    // (not the EXT form: its epilogue spills at 80 accumulators)
+    const bool ext = g.a2.img || g.add || g.out_img || g.mask;
+    if (c4 && !bk && !ext && g.nsplit == 1 && cfg == 0 && ogl_cdiv(g.N, 160) * 160 <= ogl_cdiv(g.N, 128) * 128) cfg = 4;
+    if (g_x3_tile >= 0 && !bk && g.nsplit == 1) cfg = (g_x3_tile == 4 && ext) ? 0 : g_x3_tile;
+    const int BMp = (cfg == 0 || cfg == 4) ? 256 : cfg == 2 ? 192 : cfg == 3 ? 160 : 128;
     g.NI = (int)ogl_cdiv(g.M, BMp);
-    g.NJ = (int)ogl_cdiv(g.N, 128);
+    g.NJ = (int)ogl_cdiv(g.N, cfg == 4 ? 160 : 128);
     const int64_t T = (int64_t)g.NI * g.NJ * g.nsplit;
     dim3 grid((unsigned)(8 * std::min<int64_t>(32, ogl_cdiv(T, 8)))), block(768);
     // ring depth: two stages of the 256 x 128 tile fill the LDS (144 KB); the 128 x 128 tile takes three (144 KB): its movers
     // run two stages ahead (+4 % on the layer-0 weight gradient, whose operands both stream from HBM)
-    const bool ext = g.a2.img || g.add || g.out_img || g.mask;
     if (bk && g.ak_groups > 0) hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1, 3, false, true, true>), grid, block, 0, stream, g);
     else if (bk && cfg == 0) hipLaunchKernelGGL((k_gemm_x3p<4, 2, 2, 2, 2, false, true>), grid, block, 0, stream, g);
     else if (bk) hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1, 3, false, true>), grid, block, 0, stream, g);
     else if (ext) {
       if (g.nsplit != 1 || g.ones_col) return OGL_EINVAL;
       if (cfg == 0) hipLaunchKernelGGL((k_gemm_x3p<4, 2, 2, 2, 2, true>), grid, block, 0, stream, g);
+      else if (cfg == 3) hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1, 2, true, false, false, 1, 0>), grid, block, 0, stream, g);
       else if (cfg == 2) hipLaunchKernelGGL((k_gemm_x3p<2, 4, 3, 1, 2, true>), grid, block, 0, stream, g);
       else hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1, 3, true>), grid, block, 0, stream, g);
     } else if (cfg == 0) hipLaunchKernelGGL((k_gemm_x3p<4, 2, 2, 2, 2>), grid, block, 0, stream, g);
+    else if (cfg == 4) hipLaunchKernelGGL((k_gemm_x3p<4, 2, 2, 2, 2, false, false, false, 0, 1>), grid, block, 0, stream, g);
+    else if (cfg == 3) hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1, 2, false, false, false, 1, 0>), grid, block, 0, stream, g);
     else if (cfg == 2) hipLaunchKernelGGL((k_gemm_x3p<2, 4, 3, 1, 2>), grid, block, 0, stream, g);
     else hipLaunchKernelGGL((k_gemm_x3p<2, 4, 2, 1, 3>), grid, block, 0, stream, g);
     OGL_CHECK_LAUNCH();

@@ -91,7 +91,9 @@ def test_transposed_image_bit_exact(ops, M, N, ones):
 @pytest.mark.parametrize("M,K,N,relu", [(1, 1, 1, False), (37, 33, 5, True), (255, 602, 41, False), (257, 64, 129, True),
                                          (1000, 602, 602, True), (3000, 1204, 256, False), (513, 31, 600, True),
                                          (700, 32, 130, False), (2600, 608, 602, True),
-                                         (7199, 602, 600, True), (6700, 96, 640, False)])   # the last two: 192 x 128 tiles
+                                         (7199, 602, 600, True), (6700, 96, 640, False),    # 192 x 128 tiles (160 x 128 under OGL_X3_CFG3=1)
+                                         (9000, 602, 600, True),                             # 192 x 128 tiles
+                                         (53001, 70, 600, True), (140001, 40, 160, False)])  # tall, 160-column padding (256 x 160 under OGL_X3_CFG4=1)
 def test_forward_matches_on_the_fly_x6_and_fp64(ops, M, K, N, relu):
     torch.manual_seed(M * 7 + K + N)
     T = M + 50
@@ -355,6 +357,42 @@ def test_pool_backward_limits(ops):
     assert h.ogl_pool_bwd_x3(*args(64, 640)) == -1                 # fanout > 63
     assert h.ogl_pool_bwd_x3(*args(63, 641)) == -1                 # more columns than a bucket wave holds
     assert h.ogl_pool_bwd_x3(p(dm), 640, p(argmax), p(out), 640, p(idx), n_dst, S, D, n_src, p(img.buf), p(ws), 64, None) == -4
+
+
+@pytest.mark.parametrize("M,K,N", [(7060, 602, 600), (70000, 100, 602), (300, 33, 161), (1, 1, 1), (5000, 64, 321)])
+def test_every_tile_shape_computes_the_same_bits(ops, M, K, N):
+    """The five tiles of k_gemm_x3p (256 / 128 / 192 / 160 rows x 128 columns, 256 x 160) differ in what a block fetches per
+    step, not in the MFMA sequence behind an output element: pinned one after the other (ogl_x3_debug_tile) they return the
+    same bits — plain products and EXT products (addend, second A part, output image; 256 x 160 is plain only)."""
+    from ogl_amd import _lib
+    torch.manual_seed(M + N)
+    T = M + 10
+    tm = ops.empty_mat(T, K, "cuda").copy_(torch.randn(T, K, device="cuda"))
+    rows = torch.randint(0, T, (M,), device="cuda")
+    w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.randn(N, device="cuda")
+    xi, wi = ops.x3_split(tm, append_ones=True), ops.x3_split(w, append_vec=b)
+    x2 = ops.empty_mat(M, 40, "cuda").copy_(torch.randn(M, 40, device="cuda"))
+    w2 = torch.randn(N, 40, device="cuda")
+    wcat = ops.x3_split_cat([(w, b), (w2, None)])
+    S0 = ops.empty_mat(T, N, "cuda").copy_(torch.randn(T, N, device="cuda"))
+    outs = []
+    try:
+        for cfg in (0, 1, 2, 3, 4):
+            assert _lib.lib().ogl_x3_debug_tile(cfg) == 0
+            y = ops.linear_fwd_x3(xi, rows, wi, relu=True, x_nrows=T)
+            y2, img = ops.linear_fwd_x3_ext(xi, rows, wcat, x2_img=ops.x3_split(x2), add=S0, add_rows=rows, relu=True, x_nrows=T,
+                                            want_image=True, image_append_ones=True)
+            outs.append((y.clone(), y2.clone(), img.buf.clone()))
+    finally:
+        assert _lib.lib().ogl_x3_debug_tile(-1) == 0
+    assert _lib.lib().ogl_x3_debug_tile(5) != 0 and _lib.lib().ogl_x3_debug_tile(-2) != 0
+    want = (tm[rows].double() @ w.double().T + b.double()).clamp_min(0).float()
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), want.cpu().numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL)
+    for cfg in (1, 2, 3, 4):
+        for k in range(3):
+            assert torch.equal(outs[0][k], outs[cfg][k]), (cfg, k)
+    # and the automatic choice is one of them
+    assert torch.equal(ops.linear_fwd_x3(xi, rows, wi, relu=True, x_nrows=T), outs[0][0])
 
 
 def test_forward_degenerate_shapes(ops):
