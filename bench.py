@@ -158,8 +158,8 @@ def main():
     args.ranks_seen = ranks_seen
 
     import ogl_amd  # noqa: F401
-    from ogl_amd import ops, optim, parallel, sampling, synthetic
-    from ogl_amd.graphsage import GatheredRows, GraphSAGE
+    from ogl_amd import ops, parallel, sampling, synthetic
+    from ogl_amd.graphsage import GraphSAGE
 
     if args.force_dist:
         parallel.force_distributed(True)
