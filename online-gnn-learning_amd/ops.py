@@ -1524,11 +1524,15 @@ class _SagePoolLayerFn(torch.autograd.Function):
             tall = N1_BWD_SPLIT and _n1_images_ok(n_src, h.shape[1], w_pool.shape[1])
             # the layer's weight gradients are leaves of the backward graph: on the side stream when the layer is tall — the two
             # few-column ones right away (beside the equally small input-gradient launch), fc_pool's once dP and its image exist
-            with (side_section(dy, h, neigh) if tall else _NoSection()):
-                dw_self, dw_neigh, db, db2 = out_layer_bwd_weights(dy, h_dst, neigh, want_bias=ctx.has_bias,
-                                                                   dws_out=_dw_out(w_self, *w_self.shape), dwn_out=_dw_out(w_neigh, *w_neigh.shape))
+            # (the critical launch FIRST: in a captured step the first-created child of a fork node stays on its parent's queue, the
+            # others start ~5 us later on another one and every later cross-queue edge of their chain costs the same again —
+            # measured 1.075-1.084 -> 1.056-1.059 ms per replayed Reddit step, same box, alternating runs)
+            at0 = fork_point() if tall else None
             dx_self, dp = out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src,
                                                dp_zeroed=take_zeroed(slot, n_src, h.shape[1]) if slot is not None else None)
+            with (side_section(dy, h, neigh, at=at0) if tall else _NoSection()):
+                dw_self, dw_neigh, db, db2 = out_layer_bwd_weights(dy, h_dst, neigh, want_bias=ctx.has_bias,
+                                                                   dws_out=_dw_out(w_self, *w_self.shape), dwn_out=_dw_out(w_neigh, *w_neigh.shape))
             dp_img = x3_split(dp) if tall else None
             at = fork_point() if tall else None
             dh = linear_bwd_input(dp, w_pool, None, dy_img=dp_img, add_head=dx_self,

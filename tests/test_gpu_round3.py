@@ -241,3 +241,34 @@ def test_relu_mask_in_the_input_gradient_epilogue_matches_the_separate_pass():
     assert "ogl_relu_bwd_img" in names[False] and "ogl_relu_bwd_img" not in names[True]
     for a, b in zip(grads[False], grads[True]):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)          # (downstream of the output layer's atomic scatter)
+
+
+
+def test_adam_with_the_step_count_on_the_device():
+    """ogl_adam_step_multi_dev: the step count lives in device memory (k_adam_prepare bumps it and derives the bias corrections in
+    front of the update launch) — same results as the host-counted ogl_adam_step_multi at every step, the counter advances by
+    exactly one per call, also for parameter sets of more than 32 tensors (several update launches) and for a call with nothing
+    to update.  (A one-launch form — every block deriving the corrections itself, the last block bumping the count behind a
+    ticket — was parity-green and made the replayed Reddit step 3 % SLOWER: 6 144 blocks each start behind two double-precision
+    pow() calls of their first thread; round 3, OGL_ADAM_PREPARE A/B, 1.085 vs 1.045-1.059 ms.)"""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    torch.manual_seed(5)
+    for shapes in ([(602, 602), (602,), (600, 602), (41, 600), (41,), (1,), (0,)], [(7, 3)] * 40 + [(1000, 37)], [(0,), (0,)]):
+        ps = [torch.randn(*s, device="cuda") for s in shapes]
+        qs = [p.clone() for p in ps]
+        ms, vs = [torch.zeros_like(p) for p in ps], [torch.zeros_like(p) for p in ps]
+        ms2, vs2 = [torch.zeros_like(p) for p in ps], [torch.zeros_like(p) for p in ps]
+        step = torch.zeros(1, dtype=torch.int64, device="cuda")
+        scal = torch.zeros(2, dtype=torch.float32, device="cuda")
+        for t in range(1, 6):
+            gs = [torch.randn_like(p) for p in ps]
+            ops.adam_step_multi_dev(ps, gs, ms, vs, step, scal)
+            ops.adam_step_multi(qs, gs, ms2, vs2, t)
+            assert int(step.item()) == t
+            want0 = np.float32(1e-3 / (1.0 - 0.9 ** t)); want1 = np.float32(1.0 / np.sqrt(1.0 - 0.999 ** t))
+            np.testing.assert_allclose(scal[:2].cpu().numpy(), [want0, want1], rtol=2e-7)
+            for a, b in zip(ps, qs):
+                np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-6, atol=1e-8)
+            for a, b in zip(vs, vs2):
+                assert torch.equal(a, b)
