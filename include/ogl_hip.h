@@ -237,6 +237,17 @@ int64_t ogl_pool_bwd_x3_workspace_bytes(int64_t n_dst, int fanout, int d, int64_
 int ogl_pool_bwd_x3(const float* dout, int64_t ldo, const int32_t* argmax, const float* relu_out, int64_t ldr,
                     const int32_t* idx32, int64_t n_dst, int fanout, int d, int64_t n_src, void* image,
                     void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
+/* The same backward in two calls.  Everything ogl_pool_bwd_x3 derives from argmax / relu_out / idx32 — which source groups a
+ * destination touches, the order and the segment offsets of its columns — is known when the FORWARD aggregation has run:
+ * ogl_pool_bwd_x3_plan writes it into `workspace` (same size as above) and can be enqueued right after the forward pass, on another
+ * stream, beside the forward products; ogl_pool_bwd_x3_apply (the backward's critical path: autograd of the max-pool in
+ * R/train/graphsage/pytorch/aggregator_dgl.py:171 feeding fc_pool's weight gradient, :199-206) builds the image from `dout` and that
+ * workspace.  plan + apply on one stream = ogl_pool_bwd_x3 up to the order of its float additions.  The workspace must stay
+ * untouched between the two calls; n_dst / fanout / d / n_src / idx32 must be the same in both. */
+int ogl_pool_bwd_x3_plan(const int32_t* argmax, const float* relu_out, int64_t ldr, const int32_t* idx32, int64_t n_dst, int fanout,
+                         int d, int64_t n_src, void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
+int ogl_pool_bwd_x3_apply(const float* dout, int64_t ldo, const int32_t* idx32, int64_t n_dst, int fanout, int d, int64_t n_src,
+                          void* image, const void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
 int64_t ogl_x3_row_bytes(int64_t K);
 int64_t ogl_x3_image_bytes(int64_t rows, int64_t K);
 int ogl_x3_split(const float* src, int64_t ld, const int64_t* rows, int64_t nrows, int64_t R, int K, int append,

@@ -54,6 +54,8 @@ SIGNATURES = {
     "ogl_build_block_batched": (_i, [_p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _i64, _p]),
     "ogl_pool_bwd_x3_workspace_bytes": (_i64, [_i64, _i, _i, _i64]),
     "ogl_pool_bwd_x3": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i, _i, _i64, _p, _p, _i64, _p]),
+    "ogl_pool_bwd_x3_plan": (_i, [_p, _p, _i64, _p, _i64, _i, _i, _i64, _p, _i64, _p]),
+    "ogl_pool_bwd_x3_apply": (_i, [_p, _i64, _p, _i64, _i, _i, _i64, _p, _p, _i64, _p]),
     "ogl_x3_row_bytes": (_i64, [_i64]),
     "ogl_x3_image_bytes": (_i64, [_i64, _i64]),
     "ogl_x3_split": (_i, [_p, _i64, _p, _i64, _i64, _i, _i, _p, _p, _p]),

@@ -22,6 +22,12 @@
 //
 // HBM-bound integer/float streaming: 3 D floats read + 8 D bytes written per destination by the bucket pass, then
 // 8 bytes read per entry (each entry is read once) and 6 bytes written per slab element.
+//
+// PLAN / APPLY (ogl_pool_bwd_x3_plan / _apply): everything the bucket pass computes but the gradient VALUES — the bitmap, the slot
+// offsets, the order of a destination's columns — depends on the forward pass only (argmax, the ReLU sign of the pooled output, the
+// sampled indices).  The plan form of the bucket pass writes 2-byte column ids instead of (column, value) pairs and can run right
+// after the forward aggregation, beside the forward GEMMs; the apply form of the group pass fetches each value from dout[d, column].
+// What is left on the backward's critical path is the group pass alone.
 #include "x6_arith.h"
 
 #define PB_THREADS 640              // 10 waves = 40 teams of 16 lanes
@@ -33,6 +39,7 @@
 struct PbDiv { unsigned mul; unsigned shift; unsigned G; };   // floor(x / G) = (x * mul) >> shift for 0 <= x < 2^31
 __device__ __forceinline__ unsigned pb_div(unsigned x, PbDiv v) { return (unsigned)(((uint64_t)x * v.mul) >> v.shift); }
 
+template <bool PLAN>
 __global__ void __launch_bounds__(256) k_pool_bucket(const float* __restrict__ dout, int64_t ldo, const int32_t* __restrict__ argmax,
                                                      const float* __restrict__ relu_out, int64_t ldr,
                                                      const int32_t* __restrict__ idx, int64_t n_dst, int S, int D, int64_t n_src,
@@ -57,7 +64,7 @@ __global__ void __launch_bounds__(256) k_pool_bucket(const float* __restrict__ d
     const bool in = f < D;
     const int fc = in ? f : 0;
     const int a = argmax[d * D + fc];
-    gv[i] = dout[d * ldo + fc];
+    gv[i] = PLAN ? 0.f : dout[d * ldo + fc];
     const float m = relu_out ? relu_out[d * ldr + fc] : 1.f;
     const bool ok = in && a >= 0 && a < n_src && m > 0.f;
     slot[i] = ok ? a : -1;                        // winner's source id for now; the slot search follows
@@ -90,11 +97,15 @@ __global__ void __launch_bounds__(256) k_pool_bucket(const float* __restrict__ d
   cnt[wv][lane] = start;
 #pragma unroll
   for (int i = 0; i < NI; ++i)
-    if (slot[i] >= 0)
-      ent[d * D + cnt[wv][slot[i]] + pos[i]] = make_uint2((unsigned)(lane + 64 * i), __float_as_uint(gv[i]));
+    if (slot[i] >= 0) {
+      if constexpr (PLAN) ((unsigned short*)ent)[d * D + cnt[wv][slot[i]] + pos[i]] = (unsigned short)(lane + 64 * i);
+      else ent[d * D + cnt[wv][slot[i]] + pos[i]] = make_uint2((unsigned)(lane + 64 * i), __float_as_uint(gv[i]));
+    }
 }
 
-__global__ void __launch_bounds__(PB_THREADS) k_pool_bwd_x3(const int32_t* __restrict__ idx, int S, const unsigned short* __restrict__ off,
+template <bool PLAN>
+__global__ void __launch_bounds__(PB_THREADS) k_pool_bwd_x3(const float* __restrict__ dout, int64_t ldo,
+                                                            const int32_t* __restrict__ idx, int S, const unsigned short* __restrict__ off,
                                                             const uint2* __restrict__ ent, const unsigned* __restrict__ bitmap,
                                                             int64_t words, int64_t n_src, PbDiv dv, int D, int DP,
                                                             unsigned char* __restrict__ img, int64_t gstride) {
@@ -176,8 +187,13 @@ __global__ void __launch_bounds__(PB_THREADS) k_pool_bwd_x3(const int32_t* __res
             const int e0 = __shfl(lo, tshift + src_lane), e1 = __shfl(hi, tshift + src_lane);
             if (act)
               for (int e = e0 + tl; e < e1; e += 16) {
-                const uint2 en = ent[d * D + e];
-                __hip_atomic_fetch_add(&T[sl * DP + (int)en.x], __uint_as_float(en.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if constexpr (PLAN) {
+                  const int col = ((const unsigned short*)ent)[d * D + e];
+                  __hip_atomic_fetch_add(&T[sl * DP + col], dout[d * ldo + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                  const uint2 en = ent[d * D + e];
+                  __hip_atomic_fetch_add(&T[sl * DP + (int)en.x], __uint_as_float(en.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
               }
           }
         }
@@ -225,21 +241,22 @@ extern "C" int64_t ogl_pool_bwd_x3_workspace_bytes(int64_t n_dst, int fanout, in
   return pb_bitmap_bytes(n_dst, n_src) + pb_off_bytes(n_dst, fanout) + ogl_round_up(n_dst * (int64_t)d * 8 + 16, 256);
 }
 
-extern "C" int ogl_pool_bwd_x3(const float* dout, int64_t ldo, const int32_t* argmax, const float* relu_out, int64_t ldr,
-                               const int32_t* idx32, int64_t n_dst, int fanout, int d, int64_t n_src, void* image,
-                               void* workspace, int64_t workspace_bytes, ogl_stream_t stream) {
-  if (n_dst < 0 || fanout < 0 || d <= 0 || n_src <= 0 || ldo < d || (relu_out && ldr < d)) return OGL_EINVAL;
+static int pb_check(int64_t n_dst, int fanout, int d, int64_t n_src, const void* workspace, int64_t workspace_bytes) {
+  if (n_dst < 0 || fanout < 0 || d <= 0 || n_src <= 0) return OGL_EINVAL;
   if (d > PB_MAX_D || fanout > PB_MAX_S || n_src >= (1ll << 31) || n_dst * (int64_t)d >= (1ll << 31)) return OGL_EINVAL;
-  if (!image || ((uintptr_t)image & 15)) return OGL_EINVAL;
-  if (n_dst > 0 && fanout > 0 && (!dout || !argmax || !idx32)) return OGL_EINVAL;
-  const int64_t groups = ogl_cdiv(n_src, 32), words = pb_words(n_dst);
   if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < ogl_pool_bwd_x3_workspace_bytes(n_dst, fanout, d, n_src))
     return OGL_EWORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
+  return OGL_OK;
+}
+
+// bitmap reset + bucket pass (PLAN: structure only, no gradient read)
+template <bool PLAN>
+static int pb_bucket(const float* dout, int64_t ldo, const int32_t* argmax, const float* relu_out, int64_t ldr, const int32_t* idx32,
+                     int64_t n_dst, int fanout, int d, int64_t n_src, void* workspace, hipStream_t st) {
+  const int64_t groups = ogl_cdiv(n_src, 32), words = pb_words(n_dst);
   unsigned* bitmap = (unsigned*)workspace;
   unsigned short* off = (unsigned short*)((unsigned char*)workspace + pb_bitmap_bytes(n_dst, n_src));
   uint2* ent = (uint2*)((unsigned char*)off + pb_off_bytes(n_dst, fanout));
-  const int64_t gstride = ((int64_t)d + 1) * 192;                 // GROUP-MAJOR image: [group][d rows + zero row][192 B]
   // zeroed by a KERNEL, not hipMemsetAsync: a memset node recorded into a captured hipGraph re-runs on only 1/16 of its
   // range from the second replay on (ROCm 7.2; tools/graph_probe.py shows it), and the step is replayed as a graph
   {
@@ -249,19 +266,64 @@ extern "C" int ogl_pool_bwd_x3(const float* dout, int64_t ldo, const int32_t* ar
   }
   const PbDiv dv = pb_make_div((unsigned)groups);
   if (n_dst > 0 && fanout > 0) {
-    hipLaunchKernelGGL(k_pool_bucket, dim3((unsigned)ogl_cdiv(n_dst, 4)), dim3(256), 0, st, dout, ldo, argmax, relu_out, ldr, idx32,
+    hipLaunchKernelGGL((k_pool_bucket<PLAN>), dim3((unsigned)ogl_cdiv(n_dst, 4)), dim3(256), 0, st, dout, ldo, argmax, relu_out, ldr, idx32,
                        n_dst, fanout, d, n_src, dv, bitmap, words, off, ent);
     OGL_CHECK_LAUNCH();
   }
+  return OGL_OK;
+}
+
+// group pass (PLAN: entries are 2-byte column ids, values come from dout)
+template <bool PLAN>
+static int pb_groups(const float* dout, int64_t ldo, const int32_t* idx32, int64_t n_dst, int fanout, int d, int64_t n_src, void* image,
+                     void* workspace, hipStream_t st) {
+  const int64_t groups = ogl_cdiv(n_src, 32), words = pb_words(n_dst);
+  unsigned* bitmap = (unsigned*)workspace;
+  unsigned short* off = (unsigned short*)((unsigned char*)workspace + pb_bitmap_bytes(n_dst, n_src));
+  uint2* ent = (uint2*)((unsigned char*)off + pb_off_bytes(n_dst, fanout));
+  const int64_t gstride = ((int64_t)d + 1) * 192;                 // GROUP-MAJOR image: [group][d rows + zero row][192 B]
+  const PbDiv dv = pb_make_div((unsigned)groups);
   const int DP = d | 1;                                            // odd slab stride: conflict-free column reads in the emit phase
   const size_t lds = (size_t)32 * DP * 4 + PB_LIST * 2 + (PB_THREADS / 64) * 4 + 16;
   static bool attr_set = false;
   if (!attr_set) {
-    OGL_CHECK_HIP(hipFuncSetAttribute((const void*)k_pool_bwd_x3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OGL_CHECK_HIP(hipFuncSetAttribute((const void*)k_pool_bwd_x3<PLAN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_pool_bwd_x3, dim3((unsigned)groups), dim3(PB_THREADS), lds, st, idx32, fanout, off, ent, bitmap, words, n_src,
-                     dv, d, DP, (unsigned char*)image, gstride);
+  hipLaunchKernelGGL((k_pool_bwd_x3<PLAN>), dim3((unsigned)groups), dim3(PB_THREADS), lds, st, dout, ldo, idx32, fanout, off, ent, bitmap,
+                     words, n_src, dv, d, DP, (unsigned char*)image, gstride);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
+}
+
+extern "C" int ogl_pool_bwd_x3(const float* dout, int64_t ldo, const int32_t* argmax, const float* relu_out, int64_t ldr,
+                               const int32_t* idx32, int64_t n_dst, int fanout, int d, int64_t n_src, void* image,
+                               void* workspace, int64_t workspace_bytes, ogl_stream_t stream) {
+  if (ldo < d || (relu_out && ldr < d)) return OGL_EINVAL;
+  int rc = pb_check(n_dst, fanout, d, n_src, workspace, workspace_bytes);
+  if (rc != OGL_OK) return rc;
+  if (!image || ((uintptr_t)image & 15)) return OGL_EINVAL;
+  if (n_dst > 0 && fanout > 0 && (!dout || !argmax || !idx32)) return OGL_EINVAL;
+  rc = pb_bucket<false>(dout, ldo, argmax, relu_out, ldr, idx32, n_dst, fanout, d, n_src, workspace, (hipStream_t)stream);
+  if (rc != OGL_OK) return rc;
+  return pb_groups<false>(nullptr, 0, idx32, n_dst, fanout, d, n_src, image, workspace, (hipStream_t)stream);
+}
+
+extern "C" int ogl_pool_bwd_x3_plan(const int32_t* argmax, const float* relu_out, int64_t ldr, const int32_t* idx32, int64_t n_dst,
+                                    int fanout, int d, int64_t n_src, void* workspace, int64_t workspace_bytes, ogl_stream_t stream) {
+  if (relu_out && ldr < d) return OGL_EINVAL;
+  const int rc = pb_check(n_dst, fanout, d, n_src, workspace, workspace_bytes);
+  if (rc != OGL_OK) return rc;
+  if (n_dst > 0 && fanout > 0 && (!argmax || !idx32)) return OGL_EINVAL;
+  return pb_bucket<true>(nullptr, 0, argmax, relu_out, ldr, idx32, n_dst, fanout, d, n_src, workspace, (hipStream_t)stream);
+}
+
+extern "C" int ogl_pool_bwd_x3_apply(const float* dout, int64_t ldo, const int32_t* idx32, int64_t n_dst, int fanout, int d,
+                                     int64_t n_src, void* image, const void* workspace, int64_t workspace_bytes, ogl_stream_t stream) {
+  if (ldo < d) return OGL_EINVAL;
+  const int rc = pb_check(n_dst, fanout, d, n_src, workspace, workspace_bytes);
+  if (rc != OGL_OK) return rc;
+  if (!image || ((uintptr_t)image & 15)) return OGL_EINVAL;
+  if (n_dst > 0 && fanout > 0 && (!dout || !idx32)) return OGL_EINVAL;
+  return pb_groups<true>(dout, ldo, idx32, n_dst, fanout, d, n_src, image, (void*)workspace, (hipStream_t)stream);
 }

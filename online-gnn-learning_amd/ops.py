@@ -39,9 +39,21 @@ def profile_stop():
     return [(n, m, s.elapsed_time(e)) for n, m, s, e in rec]
 
 
+# Side work to enqueue right AFTER the next launch (see pool_bwd_x3_plan: in a captured step the first-created child of a node keeps
+# its parent's hardware queue, so the critical chain's next launch has to be created before a branch that forks off the same node).
+_DEFERRED = []
+
+
+def _flush_deferred():
+    while _DEFERRED:
+        _DEFERRED.pop(0)()
+
+
 def _launch(name, fn, *args, meta=None):
     if _PROFILE is None:
         check(fn(*args), name)
+        if _DEFERRED:
+            _flush_deferred()
         return
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
@@ -882,6 +894,75 @@ def pool_bwd_x3(dout, argmax, relu_out, idx32, n_src):
     return X3Image(buf, d, 32 * G)
 
 
+class PoolPlan:
+    """What ogl_pool_bwd_x3_plan left in its workspace, and the event (None: same stream) that marks the end of the plan launches."""
+    __slots__ = ("ws", "nbytes", "event", "shape", "pending")
+
+    def __init__(self, ws, nbytes, event, shape):
+        self.ws, self.nbytes, self.event, self.shape, self.pending = ws, nbytes, event, shape, False
+
+
+POOL_PLAN = os.environ.get("OGL_POOL_PLAN", "1") != "0"
+
+
+def pool_bwd_x3_plan(argmax, relu_out, idx32, n_src, side=True):
+    """The part of ``pool_bwd_x3`` that needs no gradient (bitmap, slot offsets, column order), enqueued NOW — by the forward pass,
+    on the side stream when the fork is on (beside the forward products: the backward then has the group pass alone on its
+    critical path).  Returns the PoolPlan ``pool_bwd_x3_apply`` consumes."""
+    n_dst, d = argmax.shape
+    assert idx32.dtype == torch.int32 and idx32.is_contiguous() and argmax.dtype == torch.int32 and argmax.is_contiguous()
+    nbytes = int(_lib.lib().ogl_pool_bwd_x3_workspace_bytes(n_dst, idx32.shape[1], d, n_src))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=argmax.device)         # (allocated on the main stream)
+    relu_out = as_mat(relu_out) if relu_out is not None else None
+
+    def launch():
+        _launch("ogl_pool_bwd_x3_plan", _lib.lib().ogl_pool_bwd_x3_plan, _ptr(argmax), _ptr(relu_out),
+                _ld(relu_out) if relu_out is not None else 0, _ptr(idx32), n_dst, idx32.shape[1], d, n_src, _ptr(ws), nbytes, _stream(),
+                meta=dict(n_dst=n_dst, d=d, n_src=n_src, fanout=idx32.shape[1]))
+
+    forked = side and FORK_BACKWARD and _PROFILE is None and not _SIDE["off"] and (FORK_IN_GRAPHS or not _capturing())
+    if not forked:
+        launch()
+        return PoolPlan(ws, nbytes, None, (n_dst, idx32.shape[1], d, n_src))
+    dev = torch.cuda.current_device()
+    st = _SIDE["streams"].get(dev)
+    if st is None:
+        st = _SIDE["streams"][dev] = torch.cuda.Stream(device=dev)
+    here = torch.cuda.Event()
+    here.record()                       # the plan's inputs exist from HERE on ...
+    plan = PoolPlan(ws, nbytes, None, (n_dst, idx32.shape[1], d, n_src))
+    plan.pending = True
+
+    def run():                          # ... but its launches are created after the main stream's next one (see _DEFERRED)
+        st.wait_event(here)
+        with torch.cuda.stream(st):
+            launch()
+            plan.event = torch.cuda.Event()
+            plan.event.record()
+        plan.pending = False
+        if not _capturing():
+            ws.record_stream(st)        # (a forward whose backward never runs frees `ws` with nothing having waited for the side stream)
+
+    _DEFERRED.append(run)
+    return plan
+
+
+def pool_bwd_x3_apply(dout, idx32, plan, n_src):
+    """``pool_bwd_x3`` from a plan: the group pass alone (values fetched from ``dout`` by the planned column ids)."""
+    dout = as_mat(dout)
+    n_dst, d = dout.shape
+    assert plan.shape == (n_dst, idx32.shape[1], d, n_src) and idx32.dtype == torch.int32 and idx32.is_contiguous()
+    if plan.pending:
+        _flush_deferred()
+    if plan.event is not None:
+        torch.cuda.current_stream().wait_event(plan.event)
+    G = (n_src + 31) // 32
+    buf = _x3_alloc(d, 32 * G, dout.device)
+    _launch("ogl_pool_bwd_x3_apply", _lib.lib().ogl_pool_bwd_x3_apply, _ptr(dout), _ld(dout), _ptr(idx32), n_dst, idx32.shape[1], d, n_src,
+            _ptr(buf), _ptr(plan.ws), plan.nbytes, _stream(), meta=dict(n_dst=n_dst, d=d, n_src=n_src, fanout=idx32.shape[1]))
+    return X3Image(buf, d, 32 * G)
+
+
 def linear_bwd_weight_x3(dyT_img, xT_img, want_bias=True, dw_out=None):
     """dw [N, K], db [N] from the images of dy.T ([N rows, M]) and [x | 1].T ([K + 1 rows, M])."""
     N, M, K = dyT_img.rows, dyT_img.K, xT_img.rows - 1
@@ -1435,6 +1516,12 @@ class _PoolMaxFn(torch.autograd.Function):
         if _CAPTURE is not None:
             _CAPTURE.append(dict(argmax=argmax, neigh=out))
         ctx.n_src, ctx.fanout, ctx.has_bias = p.shape[0], idx.shape[1], bias is not None
+        ctx.pool_plan = None
+        if (POOL_PLAN and need and not x.requires_grad and idx.dtype == torch.int32 and _MODE["name"] != "f32"
+                and ctx.n_src >= X3_BWW_MIN_ROWS and out.shape[1] <= 640 and ctx.fanout <= 63
+                and (w.requires_grad or (bias is not None and bias.requires_grad))):
+            # layer 0 (see backward): the gradient-free half of the pool backward starts here, beside the products that follow
+            ctx.pool_plan = pool_bwd_x3_plan(argmax, out, idx, ctx.n_src)
         ctx.save_for_backward(x, w, x_rows, out, argmax, idx if idx.dtype == torch.int32 else None)
         return out
 
@@ -1446,7 +1533,9 @@ class _PoolMaxFn(torch.autograd.Function):
                 and out.shape[1] <= 640 and ctx.fanout <= 63 and (need[1] or (need[2] and ctx.has_bias))):
             # layer 0: the projection input carries no gradient, so dP has one consumer — the weight gradient — and goes
             # straight from (dout, argmax) to the image of its transpose
-            dyT = pool_bwd_x3(dout, argmax, out, idx32, ctx.n_src)
+            plan = getattr(ctx, "pool_plan", None)
+            dyT = pool_bwd_x3_apply(dout, idx32, plan, ctx.n_src) if plan is not None else pool_bwd_x3(dout, argmax, out, idx32, ctx.n_src)
+            ctx.pool_plan = None
             G = (ctx.n_src + 31) // 32
             rimg = _row_image_for(x, x_rows, None)
             if rimg is not None and rimg.K == x.shape[1] + 1:
@@ -1457,6 +1546,12 @@ class _PoolMaxFn(torch.autograd.Function):
                 dw, db = linear_bwd_weight_x3(dyT, x3_split_t(x, x_rows, ones_row=True, interleave=G), want_bias=ctx.has_bias,
                                               dw_out=_dw_out(w, *w.shape))
             return None, dw, (db if ctx.has_bias else None), None, None
+        plan = getattr(ctx, "pool_plan", None)
+        if plan is not None and plan.pending:
+            _flush_deferred()
+        if plan is not None and plan.event is not None:            # (planned for the image path, which this call does not take)
+            torch.cuda.current_stream().wait_event(plan.event)
+        ctx.pool_plan = None
         dp = reduce_bwd(dout, None, argmax, "max", ctx.n_src, fanout=ctx.fanout, relu_out=out)
         dx = dw = db = None
         if need[0]:

@@ -300,6 +300,19 @@ def test_pool_backward_image(ops, n_dst, S, D, n_src, relu):
     # the unfused path agrees
     dP2 = ops.reduce_bwd(dm, None, argmax, "max", n_src, fanout=S, relu_out=out if relu else None)
     np.testing.assert_allclose(dP2.cpu().numpy(), dP, rtol=1e-4, atol=1e-4)
+    # plan (no gradient: could have run in the forward pass) + apply (the group pass alone) build the same image: identical where a
+    # cell has at most two contributions, fp32-order noise elsewhere; on the side stream or on the caller's
+    for side in (False, True):
+        plan = ops.pool_bwd_x3_plan(argmax, out if relu else None, torch.as_tensor(idx).cuda(), n_src, side=side)
+        assert plan.pending == (side and ops.FORK_BACKWARD)              # a side plan is enqueued behind the caller's next launch
+        dm2 = dm.clone()                                                  # (the plan never saw this tensor)
+        img2 = ops.pool_bwd_x3_apply(dm2, torch.as_tensor(idx).cuda(), plan, n_src)
+        got2 = image_decode_t(img2.buf, D, 32 * G).numpy()
+        got2_s = np.zeros((n_src, D), np.float32)
+        got2_s[s_of_m[ok]] = got2[:, ok].T
+        assert (got2[:, ~ok] == 0).all()
+        assert np.array_equal(got2_s[two], got_s[two])
+        np.testing.assert_allclose(got2_s, dP, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(dP).max()))
 
 
 def test_pool_max_autograd_uses_fused_backward(ops):
@@ -327,7 +340,12 @@ def test_pool_max_autograd_uses_fused_backward(ops):
     finally:
         ops.set_gemm_mode(old)
         ops._X3_TABLES.clear()
-    assert "ogl_pool_bwd_x3" in res["fused"][3] and "ogl_reduce_bwd" not in res["fused"][3]
+    names = res["fused"][3]
+    assert "ogl_reduce_bwd" not in names
+    if ops.POOL_PLAN:                      # the gradient-free half planned by the forward pass, the group pass in backward
+        assert names.index("ogl_pool_bwd_x3_plan") < names.index("ogl_pool_bwd_x3_apply") and "ogl_pool_bwd_x3" not in names
+    else:
+        assert "ogl_pool_bwd_x3" in names
     np.testing.assert_allclose(res["fused"][0].cpu().numpy(), res["unfused"][0].cpu().numpy(), rtol=1e-5, atol=1e-5)
     scale = float(res["unfused"][1].abs().max())
     np.testing.assert_allclose(res["fused"][1].cpu().numpy(), res["unfused"][1].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
@@ -357,6 +375,15 @@ def test_pool_backward_limits(ops):
     assert h.ogl_pool_bwd_x3(*args(64, 640)) == -1                 # fanout > 63
     assert h.ogl_pool_bwd_x3(*args(63, 641)) == -1                 # more columns than a bucket wave holds
     assert h.ogl_pool_bwd_x3(p(dm), 640, p(argmax), p(out), 640, p(idx), n_dst, S, D, n_src, p(img.buf), p(ws), 64, None) == -4
+    nb = int(h.ogl_pool_bwd_x3_workspace_bytes(n_dst, S, D, n_src))
+    assert h.ogl_pool_bwd_x3_plan(p(argmax), p(out), 640, p(idx), n_dst, 64, D, n_src, p(ws), nb, None) == -1
+    assert h.ogl_pool_bwd_x3_plan(p(argmax), p(out), D - 1, p(idx), n_dst, S, D, n_src, p(ws), nb, None) == -1
+    assert h.ogl_pool_bwd_x3_plan(p(argmax), p(out), 640, p(idx), n_dst, S, D, n_src, p(ws), 64, None) == -4
+    assert h.ogl_pool_bwd_x3_plan(None, p(out), 640, p(idx), n_dst, S, D, n_src, p(ws), nb, None) == -1
+    assert h.ogl_pool_bwd_x3_apply(p(dm), 640, p(idx), n_dst, S, 641, n_src, p(img.buf), p(ws), nb, None) == -1
+    assert h.ogl_pool_bwd_x3_apply(p(dm), 640, p(idx), n_dst, S, D, n_src, None, p(ws), nb, None) == -1
+    assert h.ogl_pool_bwd_x3_apply(p(dm), 640, p(idx), n_dst, S, D, n_src, p(img.buf), p(ws), 64, None) == -4
+    assert h.ogl_pool_bwd_x3_apply(None, 640, p(idx), n_dst, S, D, n_src, p(img.buf), p(ws), nb, None) == -1
 
 
 @pytest.mark.parametrize("M,K,N", [(7060, 602, 600), (70000, 100, 602), (300, 33, 161), (1, 1, 1), (5000, 64, 321)])
