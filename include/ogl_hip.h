@@ -243,7 +243,10 @@ int ogl_pool_bwd_x3(const float* dout, int64_t ldo, const int32_t* argmax, const
  * stream, beside the forward products; ogl_pool_bwd_x3_apply (the backward's critical path: autograd of the max-pool in
  * R/train/graphsage/pytorch/aggregator_dgl.py:171 feeding fc_pool's weight gradient, :199-206) builds the image from `dout` and that
  * workspace.  plan + apply on one stream = ogl_pool_bwd_x3 up to the order of its float additions.  The workspace must stay
- * untouched between the two calls; n_dst / fanout / d / n_src / idx32 must be the same in both. */
+ * untouched between the two calls; n_dst / fanout / d / n_src / idx32 must be the same in both; n_dst * d < 2^27.
+ * (plan: the row's columns in slot order + per-group record counts -> scan -> every (destination, slot) segment's place in a
+ * group-major record array; apply: one wave per destination writes its (column, lane, value) records into those places, then one
+ * block per source group streams its records into the slab — no dependent read on the backward's critical path.) */
 int ogl_pool_bwd_x3_plan(const int32_t* argmax, const float* relu_out, int64_t ldr, const int32_t* idx32, int64_t n_dst, int fanout,
                          int d, int64_t n_src, void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
 int ogl_pool_bwd_x3_apply(const float* dout, int64_t ldo, const int32_t* idx32, int64_t n_dst, int fanout, int d, int64_t n_src,

@@ -78,6 +78,8 @@ class GraphSAGE(nn.Module):
         its consumer."""
         from .sageconv import GatheredRows
         req = []
+        if isinstance(x, GatheredRows) and x.ids is None:
+            return                                             # (un-relabelled batches: the layers take, or in training mode refuse, them)
         n_src = x.shape[0]
         training = self.training
         for li, (ent, block) in enumerate(zip(self._image_plan(), blocks)):

@@ -1518,7 +1518,7 @@ class _PoolMaxFn(torch.autograd.Function):
         ctx.n_src, ctx.fanout, ctx.has_bias = p.shape[0], idx.shape[1], bias is not None
         ctx.pool_plan = None
         if (POOL_PLAN and need and not x.requires_grad and idx.dtype == torch.int32 and _MODE["name"] != "f32"
-                and ctx.n_src >= X3_BWW_MIN_ROWS and out.shape[1] <= 640 and ctx.fanout <= 63
+                and ctx.n_src >= X3_BWW_MIN_ROWS and out.shape[1] <= 640 and ctx.fanout <= 63 and idx.shape[0] * out.shape[1] < (1 << 27)
                 and (w.requires_grad or (bias is not None and bias.requires_grad))):
             # layer 0 (see backward): the gradient-free half of the pool backward starts here, beside the products that follow
             ctx.pool_plan = pool_bwd_x3_plan(argmax, out, idx, ctx.n_src)

@@ -261,7 +261,8 @@ def test_transposed_image_interleaved(ops, M, N, G):
 
 
 @pytest.mark.parametrize("n_dst,S,D,n_src,relu", [(1, 1, 1, 1, True), (50, 4, 33, 70, True), (300, 25, 602, 2000, True),
-                                                   (2500, 10, 130, 900, False), (700, 25, 64, 40, True), (4100, 25, 40, 5000, True)])
+                                                   (2500, 10, 130, 900, False), (700, 25, 64, 40, True), (4100, 25, 40, 5000, True),
+                                                   (7060, 25, 602, 62495, True), (3000, 63, 640, 40000, True)])   # the Reddit step's shape (1 953 groups: the scan's carry); the limits
 def test_pool_backward_image(ops, n_dst, S, D, n_src, relu):
     """Fused relu->max backward == fp32 scatter of the winners' gradients, as the dealt transposed image."""
     torch.manual_seed(n_dst + D)
@@ -300,8 +301,9 @@ def test_pool_backward_image(ops, n_dst, S, D, n_src, relu):
     # the unfused path agrees
     dP2 = ops.reduce_bwd(dm, None, argmax, "max", n_src, fanout=S, relu_out=out if relu else None)
     np.testing.assert_allclose(dP2.cpu().numpy(), dP, rtol=1e-4, atol=1e-4)
-    # plan (no gradient: could have run in the forward pass) + apply (the group pass alone) build the same image: identical where a
-    # cell has at most two contributions, fp32-order noise elsewhere; on the side stream or on the caller's
+    # plan (no gradient: could have run in the forward pass: column order, group totals -> scan -> every segment's place) + apply (the
+    # values pass + the streamed group pass) build the same image: identical where a cell has at most two contributions, fp32-order
+    # noise elsewhere; on the side stream or on the caller's
     for side in (False, True):
         plan = ops.pool_bwd_x3_plan(argmax, out if relu else None, torch.as_tensor(idx).cuda(), n_src, side=side)
         assert plan.pending == (side and ops.FORK_BACKWARD)              # a side plan is enqueued behind the caller's next launch

@@ -20,6 +20,14 @@ for f in sorted(glob.glob('gpurun_out/prof_final/ab_fork*.json')):
                                        step_execution=d['config']['step_execution'][:60])
 json.dump(dict(what="same box, alternating runs of `OGL_FORK_BWD=0|1 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --graphs|--no-graphs`",
                runs=rows), open('profiles/%s_ab_fork.json' % R, 'w'), indent=1)
+rows = {}
+for f in sorted(glob.glob('gpurun_out/prof_final/ab_plan*.json')):
+    d = json.load(open(f))
+    rows[f.split('/')[-1][:-5]] = dict(ms_per_step=d['ms_per_step'], vertices_per_s=d['value'])
+if rows:
+    json.dump(dict(what="same box, alternating runs of `OGL_POOL_PLAN=0|1 python bench.py --steps 200 --warmup 60 --no-cpu-baseline --no-e2e --graphs` "
+                        "(0: the pool backward's bucket pass on the backward's critical path; 1: planned by the forward pass on the side stream)",
+                   runs=rows), open('profiles/%s_ab_pool_plan.json' % R, 'w'), indent=1)
 PY
 cp $O/kernel_stats.csv $P/${R}_rocprofv3_kernel_stats.csv
 cp $O/kernel_stats_graph.csv $P/${R}_rocprofv3_kernel_stats_graph_replay.csv

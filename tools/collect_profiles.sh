@@ -52,4 +52,8 @@ for i in 1 2; do
   OGL_FORK_BWD=0 timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-graphs > $O/ab_fork0_eager_$i.json 2> /dev/null < /dev/null
   OGL_FORK_BWD=1 timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-graphs > $O/ab_fork1_eager_$i.json 2> /dev/null < /dev/null
 done
+for i in 1 2 3; do
+  OGL_POOL_PLAN=0 timeout -k 10 200 python bench.py --steps 200 --warmup 60 --no-cpu-baseline --no-e2e --graphs > $O/ab_plan0_graphs_$i.json 2> /dev/null < /dev/null
+  OGL_POOL_PLAN=1 timeout -k 10 200 python bench.py --steps 200 --warmup 60 --no-cpu-baseline --no-e2e --graphs > $O/ab_plan1_graphs_$i.json 2> /dev/null < /dev/null
+done
 head -c 400 $O/bench.json
