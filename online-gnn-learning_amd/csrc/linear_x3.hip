@@ -50,6 +50,7 @@ struct X3Args {
   float* ws; int64_t ws_ld;
   int NI, NJ;
   int force_cfg0;               // the k-major weight gradient on the 256 x 128 tile (x3_bwwk_cfg0)
+  int xcd_slabs;                // k_gemm_x3p: deal WHOLE split-K slabs to the XCDs (see decode)
   unsigned long long* stamps;   // diagnostics only (ogl_x3_debug_stamps): per block {s_memtime, s_memrealtime} at entry and exit
   // ---- extensions, k_gemm_x3p<..., EXT = true> only (forward products, nsplit == 1) ----
   X3Operand a2;                 // optional SECOND part of the A operand: reduction steps [nsteps1, nsteps) read a2 (its own image,
@@ -401,10 +402,26 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
   }
   const int first = chunk_begin + slot, last_logical = chunk_begin + chunk_len;
   struct Tile { int ti, tj, split, ks_begin, ks_end; };
+  // xcd_slabs: the tiles of one slab share their operands through ONE XCD's L2, so XCD x takes floor(nsplit / 8) whole slabs
+  // (x q .. x q + q - 1) and the slabs left over are dealt tile by tile over what remains of every XCD's run
+  const int tiles_per_slab = g.NI * g.NJ, q_slabs = g.nsplit >> 3;
   auto decode = [&](int logical) __attribute__((always_inline)) {
     Tile t;
-    t.split = logical / (g.NI * g.NJ);
-    const int tile = logical - t.split * (g.NI * g.NJ);
+    int tile;
+    if (g.xcd_slabs) {
+      const int local = logical - chunk_begin, whole = q_slabs * tiles_per_slab;
+      if (local < whole) {
+        t.split = xcd * q_slabs + local / tiles_per_slab;
+        tile = local % tiles_per_slab;
+      } else {
+        const int e = (chunk_begin - xcd * whole) + (local - whole);
+        t.split = 8 * q_slabs + e / tiles_per_slab;
+        tile = e % tiles_per_slab;
+      }
+    } else {
+      t.split = logical / tiles_per_slab;
+      tile = logical - t.split * tiles_per_slab;
+    }
     t.ti = tile / g.NJ; t.tj = tile - t.ti * g.NJ;
     t.ks_begin = 0; t.ks_end = g.nsteps;
     if (g.nsplit > 1) {
@@ -1450,6 +1467,8 @@ extern "C" int ogl_linear_bwd_weight_x3k(const void* dyT_img, int64_t interleave
   g.C = dw; g.ldc = lddw; g.db = db; g.db2 = db2;
   x3_bwwk_plan(g.nsteps, N, Kc, &g.nsplit, &g.steps_per_split, x3_bwwk_cfg0(N, dy_rows));
   g.force_cfg0 = x3_bwwk_cfg0(N, dy_rows) ? 1 : 0;
+  static const char* xs_env = getenv("OGL_BWWK_XCD_SLABS");
+  g.xcd_slabs = (!(xs_env && xs_env[0] == '0') && g.nsplit >= 8) ? 1 : 0;
   if (g.nsplit > 1) {
     g.ws_ld = ogl_round_up(K + 1, 4);
     if (!workspace || workspace_bytes < (int64_t)g.nsplit * N * g.ws_ld * 4) return OGL_EWORKSPACE;
