@@ -28,6 +28,7 @@ _PROFILE = None
 
 def profile_start():
     global _PROFILE
+    _flush_deferred()
     _PROFILE = []
 
 

@@ -117,6 +117,7 @@ class TrainStepGraph:
             self.opt.zero_grad(set_to_none=True)
             ops.invalidate_weight_images()          # no optimiser step ran: drop the weight images that forward prepared
             _WARMED = True
+        ops._flush_deferred()                       # (side work an earlier eager forward left for "after the next launch")
         torch.cuda.synchronize()
         kw = {} if pool is None else dict(pool=pool)
         if torch.distributed.is_available() and torch.distributed.is_initialized():
