@@ -89,6 +89,10 @@ def main():
 
     delays = {s.get_model(): [] for s in strategies}
     prio_forward, evolve_t, snap_t = [], [], []
+    # the loop keeps the reference's per-snapshot gc.collect(); the stream's long-lived id lists (millions of ints) are frozen out of
+    # it once, so that a collection looks at the snapshot's garbage only (0.1 s -> 1 ms per Reddit-like snapshot)
+    gc.collect()
+    gc.freeze()
     for step in range(args.steps):
         t_snap = time.time()
         for s in strategies:
