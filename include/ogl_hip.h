@@ -363,6 +363,13 @@ int ogl_ce_fwd_bwd_mean(const float* logits, int64_t ldl, const int64_t* labels,
 int ogl_ce_fwd_bwd_mean_grid(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C, float grad_scale,
                              float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean, unsigned int* counter,
                              float* zero_buf, int64_t zero_floats, ogl_stream_t stream);
+/* ogl_ce_fwd_bwd_mean_grid with the label gather inside the launch: label of row i = label_table[label_ids[i]] (an id outside
+ * [0, n_labels) = no label: what ogl_gather_i64 would have written as -1) — graph.ndata['target'][seeds]
+ * (R/train/graphsage/pytorch/model.py:91,183) costs no launch of its own. */
+int ogl_ce_fwd_bwd_mean_grid_gather(const float* logits, int64_t ldl, const int64_t* label_table, int64_t n_labels,
+                                    const int64_t* label_ids, int64_t B, int C, float grad_scale, float* loss_rows, float* dlogits,
+                                    int64_t lddl, float* loss_mean, unsigned int* counter, float* zero_buf, int64_t zero_floats,
+                                    ogl_stream_t stream);
 
 /* torch.optim.Adam(lr) single-tensor update (R/train/graphsage/pytorch/model.py:24-25,107).
  * Hyper-parameters are doubles (as Python floats are) so 1-beta is rounded to fp32 once, like torch. */

@@ -111,7 +111,8 @@ __global__ void __launch_bounds__(256) k_ce_fwd_bwd_mean_grid(const float* __res
                                                               const int64_t* __restrict__ labels, int64_t B, int C, float grad_scale,
                                                               float* __restrict__ loss_rows, float* __restrict__ dlogits, int64_t lddl,
                                                               float* __restrict__ loss_mean, unsigned* __restrict__ counter,
-                                                              int row_blocks, float4* __restrict__ zero_buf, int64_t zero_n4) {
+                                                              int row_blocks, float4* __restrict__ zero_buf, int64_t zero_n4,
+                                                              const int64_t* __restrict__ label_ids, int64_t n_labels) {
   if (zero_n4 > 0) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < zero_n4; i += (int64_t)gridDim.x * blockDim.x) zero_buf[i] = z;
@@ -128,7 +129,11 @@ __global__ void __launch_bounds__(256) k_ce_fwd_bwd_mean_grid(const float* __res
     for (int c = lane; c < C; c += 64) s += expf(x[c] - m);
     s = wave_sum(s);
     const float lse = m + logf(s);
-    const int64_t y = labels[row];
+    int64_t y;
+    if (label_ids) {                                           // the label gather of ogl_gather_i64 (an id outside the table: -1)
+      const int64_t id = label_ids[row];
+      y = (id >= 0 && id < n_labels) ? labels[id] : -1;
+    } else y = labels[row];
     const bool ok = y >= 0 && y < C;
     if (lane == 0) loss_rows[row] = ok ? lse - x[y] : 0.f;
     if (dlogits) {
@@ -150,19 +155,37 @@ __global__ void __launch_bounds__(256) k_ce_fwd_bwd_mean_grid(const float* __res
   }
 }
 
-extern "C" int ogl_ce_fwd_bwd_mean_grid(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C, float grad_scale,
-                                        float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean, unsigned int* counter,
-                                        float* zero_buf, int64_t zero_floats, ogl_stream_t stream) {
-  if (B <= 0 || C <= 0 || ldl < C || (dlogits && lddl < C) || zero_floats < 0) return OGL_EINVAL;
+static int ce_mean_grid(const float* logits, int64_t ldl, const int64_t* labels, const int64_t* label_ids, int64_t n_labels, int64_t B, int C,
+                        float grad_scale, float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean, unsigned int* counter,
+                        float* zero_buf, int64_t zero_floats, ogl_stream_t stream) {
+  if (B <= 0 || C <= 0 || ldl < C || (dlogits && lddl < C) || zero_floats < 0 || n_labels < 0) return OGL_EINVAL;
   if (!logits || !labels || !loss_rows || !loss_mean || !counter) return OGL_EINVAL;
   if (zero_floats > 0 && (!zero_buf || ((uintptr_t)zero_buf & 15) || (zero_floats & 3))) return OGL_EINVAL;
   const int row_blocks = (int)ogl_cdiv(B, 4);
   const int64_t fill_blocks = std::min<int64_t>(1024, ogl_cdiv(zero_floats / 4, 1024));
   hipLaunchKernelGGL(k_ce_fwd_bwd_mean_grid, dim3((unsigned)std::max<int64_t>(row_blocks, fill_blocks)), dim3(256), 0,
                      (hipStream_t)stream, logits, ldl, labels, B, C, grad_scale, loss_rows, dlogits, lddl, loss_mean, counter,
-                     row_blocks, (float4*)zero_buf, zero_floats / 4);
+                     row_blocks, (float4*)zero_buf, zero_floats / 4, label_ids, n_labels);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
+}
+
+extern "C" int ogl_ce_fwd_bwd_mean_grid(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C, float grad_scale,
+                                        float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean, unsigned int* counter,
+                                        float* zero_buf, int64_t zero_floats, ogl_stream_t stream) {
+  return ce_mean_grid(logits, ldl, labels, nullptr, 0, B, C, grad_scale, loss_rows, dlogits, lddl, loss_mean, counter, zero_buf, zero_floats,
+                      stream);
+}
+
+// The same with the labels gathered inside the launch: label of row i = label_table[label_ids[i]] (an id outside [0, n_labels): no
+// label, as ogl_gather_i64 writes -1) — graph.ndata['target'][seeds] (R/train/graphsage/pytorch/model.py:91,183) without a launch.
+extern "C" int ogl_ce_fwd_bwd_mean_grid_gather(const float* logits, int64_t ldl, const int64_t* label_table, int64_t n_labels,
+                                               const int64_t* label_ids, int64_t B, int C, float grad_scale, float* loss_rows,
+                                               float* dlogits, int64_t lddl, float* loss_mean, unsigned int* counter, float* zero_buf,
+                                               int64_t zero_floats, ogl_stream_t stream) {
+  if (!label_ids) return OGL_EINVAL;
+  return ce_mean_grid(logits, ldl, label_table, label_ids, n_labels, B, C, grad_scale, loss_rows, dlogits, lddl, loss_mean, counter, zero_buf,
+                      zero_floats, stream);
 }
 
 // torch.optim.Adam single-tensor form: m.lerp_(g, 1-b1); v = b2*v + (1-b2)*g*g;

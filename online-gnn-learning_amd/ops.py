@@ -1170,11 +1170,39 @@ def ce_counter(device, stream):
     return arr.data_ptr() + 4 * i
 
 
+class LazyLabels:
+    """``table[ids]`` not gathered yet: the losses that can (``ce_fwd_bwd_mean_grid``) read the labels through the ids inside their own
+    launch — graph.ndata['target'][seeds] (R/train/graphsage/pytorch/model.py:91,183) without a launch; every other consumer calls
+    ``materialize()`` (= ``gather_i64``)."""
+    __slots__ = ("table", "ids", "_out")
+
+    def __init__(self, table, ids):
+        table = table.reshape(-1)
+        assert table.dtype == torch.int64 and table.is_cuda and table.is_contiguous()
+        self.table, self.ids, self._out = table, _ids(ids), None
+
+    def numel(self):
+        return self.ids.numel()
+
+    def materialize(self):
+        if self._out is None:
+            self._out = gather_i64(self.table, self.ids)
+        return self._out
+
+
+def _labels_tensor(labels):
+    return labels.materialize() if isinstance(labels, LazyLabels) else labels
+
+
 def ce_fwd_bwd_mean_grid(logits, labels, want_grad=True):
-    """(mean loss, row losses, dlogits / B) of a batch of any size in ONE launch (ogl_ce_fwd_bwd_mean_grid)."""
+    """(mean loss, row losses, dlogits / B) of a batch of any size in ONE launch (ogl_ce_fwd_bwd_mean_grid; ``labels`` may be a
+    LazyLabels: the gather then happens inside the launch)."""
     logits = as_mat(logits)
-    labels = labels.reshape(-1)
-    assert labels.dtype == torch.int64 and labels.is_cuda and labels.is_contiguous() and labels.numel() == logits.shape[0]
+    lazy = labels if isinstance(labels, LazyLabels) else None
+    if lazy is None:
+        labels = labels.reshape(-1)
+        assert labels.dtype == torch.int64 and labels.is_cuda and labels.is_contiguous()
+    assert labels.numel() == logits.shape[0]
     B, Cc = logits.shape
     dev = logits.device
     stream = _stream()
@@ -1188,6 +1216,11 @@ def ce_fwd_bwd_mean_grid(logits, labels, want_grad=True):
         if ent is not None:
             zbuf, zn = ent[0], ent[0].numel()
             ent[3] = True
+    if lazy is not None:
+        _launch("ogl_ce_fwd_bwd_mean_grid", _lib.lib().ogl_ce_fwd_bwd_mean_grid_gather, _ptr(logits), _ld(logits), _ptr(lazy.table),
+                lazy.table.numel(), _ptr(lazy.ids), B, Cc, C.c_float(1.0 / B), _ptr(loss), _ptr(dl), _ld(dl) if dl is not None else 0,
+                _ptr(mean), ctr, _ptr(zbuf), zn, _stream(), meta=dict(B=B, C=Cc))
+        return mean, loss, dl
     _launch("ogl_ce_fwd_bwd_mean_grid", _lib.lib().ogl_ce_fwd_bwd_mean_grid, _ptr(logits), _ld(logits), _ptr(labels), B, Cc,
             C.c_float(1.0 / B), _ptr(loss), _ptr(dl), _ld(dl) if dl is not None else 0, _ptr(mean), ctr, _ptr(zbuf), zn,
             _stream(), meta=dict(B=B, C=Cc))
@@ -1771,14 +1804,14 @@ class _CrossEntropyMeanFn(torch.autograd.Function):
     def forward(ctx, logits, labels):
         B = max(logits.shape[0], 1)
         if 0 < logits.shape[0] <= CE_MEAN_SMALL_MAX_B:
-            mean, _, dl = ce_fwd_bwd_mean(logits, labels, want_grad=logits.requires_grad)
+            mean, _, dl = ce_fwd_bwd_mean(logits, _labels_tensor(labels), want_grad=logits.requires_grad)
             ctx.save_for_backward(dl)
             return mean
         if logits.shape[0] > 0:
             mean, _, dl = ce_fwd_bwd_mean_grid(logits, labels, want_grad=logits.requires_grad)
             ctx.save_for_backward(dl)
             return mean
-        rows, dl = ce_fwd_bwd(logits, labels, 1.0 / B, want_grad=logits.requires_grad)
+        rows, dl = ce_fwd_bwd(logits, _labels_tensor(labels), 1.0 / B, want_grad=logits.requires_grad)
         ctx.save_for_backward(dl)
         return rows.mean()
 
@@ -1799,7 +1832,7 @@ class _CrossEntropyMeanRowsFn(torch.autograd.Function):
     def forward(ctx, logits, labels):
         B = logits.shape[0]
         if 0 < B <= CE_MEAN_SMALL_MAX_B:
-            mean, rows, dl = ce_fwd_bwd_mean(logits, labels, want_grad=logits.requires_grad)
+            mean, rows, dl = ce_fwd_bwd_mean(logits, _labels_tensor(labels), want_grad=logits.requires_grad)
         else:
             mean, rows, dl = ce_fwd_bwd_mean_grid(logits, labels, want_grad=logits.requires_grad)
         ctx.save_for_backward(dl)
@@ -1818,7 +1851,7 @@ class _CrossEntropyMeanRowsFn(torch.autograd.Function):
 def cross_entropy_mean_rows(logits, labels):
     """(mean, rows) of nn.CrossEntropyLoss(reduction='none') in one launch; differentiate the mean."""
     if logits.shape[0] == 0:
-        rows = _CrossEntropyRowsFn.apply(logits, labels)
+        rows = _CrossEntropyRowsFn.apply(logits, _labels_tensor(labels))
         return rows.mean(), rows
     return _CrossEntropyMeanRowsFn.apply(logits, labels)
 
@@ -1827,7 +1860,7 @@ def cross_entropy(logits, labels, reduction="mean"):
     """nn.CrossEntropyLoss(reduction) on the HIP kernel; 'none' returns the per-seed vector."""
     if reduction == "mean":
         return _CrossEntropyMeanFn.apply(logits, labels)
-    rows = _CrossEntropyRowsFn.apply(logits, labels)
+    rows = _CrossEntropyRowsFn.apply(logits, _labels_tensor(labels))
     if reduction == "none":
         return rows
     if reduction == "mean":

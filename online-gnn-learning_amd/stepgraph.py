@@ -34,9 +34,11 @@ and the optimiser stay eager (two collectives + one launch per step).  Not captu
 from __future__ import annotations
 
 import collections
+import os
 import time
 
 import numpy as np
+
 import torch
 
 from . import ops, sampling
@@ -69,6 +71,9 @@ class BlockBuffers:
         return self.head[1:]
 
 
+LAZY_LABELS = os.environ.get("OGL_LAZY_LABELS", "1") != "0"     # the step's label gather inside the loss launch
+
+
 class TrainStepGraph:
     """One captured train step over ``buf`` restricted to (n1_pad, n0_pad) rows.
     ``loss_fn(logits, labels) -> (scalar loss to differentiate, per-seed losses or None)``."""
@@ -89,7 +94,7 @@ class TrainStepGraph:
         src0, src1, lidx0 = b.src0[:self.n0_pad], b.src1[:self.n1_pad], b.lidx0[:self.n1_pad]
         blocks = [sampling.Block(src0, src1, lidx0), sampling.Block(src1, b.seeds, b.lidx1)]
         # the FULL tables: a snapshot view's row count would be frozen into the graph (ids are < n_present by construction)
-        labels = ops.gather_i64(g.target_table, b.seeds)
+        labels = ops.LazyLabels(g.target_table, b.seeds) if LAZY_LABELS else ops.gather_i64(g.target_table, b.seeds)
         self.opt.zero_grad(set_to_none=True)
         logits = self.model(blocks, GatheredRows(g.feat_table, src0))
         loss, rows = self.loss_fn(logits, labels)

@@ -272,3 +272,33 @@ def test_adam_with_the_step_count_on_the_device():
                 np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-6, atol=1e-8)
             for a, b in zip(vs, vs2):
                 assert torch.equal(a, b)
+
+
+def test_loss_launch_gathers_its_labels():
+    """LazyLabels(table, ids): the grid cross entropy reads label_table[ids[i]] inside its launch (ogl_ce_fwd_bwd_mean_grid_gather) —
+    same bits as gathering first (ogl_gather_i64 + ogl_ce_fwd_bwd_mean_grid), ids outside the table are rows without a label in both
+    forms; the small-batch and 'none' paths materialise the gather themselves."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    torch.manual_seed(3)
+    T, B, Cc = 5000, 700, 41
+    table = torch.randint(0, Cc, (T,), device="cuda")
+    ids = torch.randint(0, T, (B,), device="cuda")
+    ids[5] = -1; ids[17] = T + 3                                    # no label
+    logits = ops.empty_mat(B, Cc, "cuda").copy_(torch.randn(B, Cc, device="cuda"))
+    want = ops.ce_fwd_bwd_mean_grid(logits, ops.gather_i64(table, ids))
+    got = ops.ce_fwd_bwd_mean_grid(logits, ops.LazyLabels(table, ids))
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    assert float(got[1][5]) == 0.0 and float(got[1][17]) == 0.0
+    # through the autograd entry points, every batch-size class
+    for n in (700, 64, 1):
+        lg = logits[:n].clone().requires_grad_(True); lg2 = logits[:n].clone().requires_grad_(True)
+        l1 = ops.cross_entropy(lg, ops.gather_i64(table, ids[:n]), "mean"); l1.backward()
+        l2 = ops.cross_entropy(lg2, ops.LazyLabels(table, ids[:n]), "mean"); l2.backward()
+        assert torch.equal(l1, l2) and torch.equal(lg.grad, lg2.grad)
+        m1, r1 = ops.cross_entropy_mean_rows(logits[:n], ops.gather_i64(table, ids[:n]))
+        m2, r2 = ops.cross_entropy_mean_rows(logits[:n], ops.LazyLabels(table, ids[:n]))
+        assert torch.equal(m1, m2) and torch.equal(r1, r2)
+        assert torch.equal(ops.cross_entropy(logits[:n], ops.LazyLabels(table, ids[:n]), "none"),
+                           ops.cross_entropy(logits[:n], ops.gather_i64(table, ids[:n]), "none"))
