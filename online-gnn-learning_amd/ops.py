@@ -896,7 +896,8 @@ def pool_bwd_x3(dout, argmax, relu_out, idx32, n_src):
 
 
 class PoolPlan:
-    """What ogl_pool_bwd_x3_plan left in its workspace, and the event (None: same stream) that marks the end of the plan launches."""
+    """What ogl_pool_bwd_x3_plan left in its workspace, and the event (None: same stream) that marks the end of the plan launches;
+    ``pending``: the plan's launches are still waiting for the caller's next launch to be created first (``_DEFERRED``)."""
     __slots__ = ("ws", "nbytes", "event", "shape", "pending")
 
     def __init__(self, ws, nbytes, event, shape):
@@ -907,9 +908,10 @@ POOL_PLAN = os.environ.get("OGL_POOL_PLAN", "1") != "0"
 
 
 def pool_bwd_x3_plan(argmax, relu_out, idx32, n_src, side=True):
-    """The part of ``pool_bwd_x3`` that needs no gradient (bitmap, slot offsets, column order), enqueued NOW — by the forward pass,
-    on the side stream when the fork is on (beside the forward products: the backward then has the group pass alone on its
-    critical path).  Returns the PoolPlan ``pool_bwd_x3_apply`` consumes."""
+    """The part of the layer-0 pool backward that needs no gradient (a destination's columns in slot order, the slot offsets, the
+    per-group record counts, their scan and every (destination, slot) segment's place in the group-major record array), enqueued NOW
+    — by the forward pass, on the side stream when the fork is on (beside the forward products: the backward then has the values
+    pass and the streamed group pass on its critical path).  Returns the PoolPlan ``pool_bwd_x3_apply`` consumes."""
     n_dst, d = argmax.shape
     assert idx32.dtype == torch.int32 and idx32.is_contiguous() and argmax.dtype == torch.int32 and argmax.is_contiguous()
     nbytes = int(_lib.lib().ogl_pool_bwd_x3_workspace_bytes(n_dst, idx32.shape[1], d, n_src))
@@ -949,7 +951,8 @@ def pool_bwd_x3_plan(argmax, relu_out, idx32, n_src, side=True):
 
 
 def pool_bwd_x3_apply(dout, idx32, plan, n_src):
-    """``pool_bwd_x3`` from a plan: the group pass alone (values fetched from ``dout`` by the planned column ids)."""
+    """``pool_bwd_x3`` from a plan: the gradient rows written into their planned places (one wave per destination), then one block
+    per source group streaming its records into the slab and out as the image."""
     dout = as_mat(dout)
     n_dst, d = dout.shape
     assert plan.shape == (n_dst, idx32.shape[1], d, n_src) and idx32.dtype == torch.int32 and idx32.is_contiguous()
