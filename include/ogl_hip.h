@@ -108,6 +108,9 @@ int ogl_build_block(const int64_t* dst, int64_t n_dst, const int64_t* picks, int
  * ---------------------------------------------------------------------------------------- */
 int ogl_gather_rows(const float* table, int64_t ld, int64_t n_rows, const int64_t* ids, int64_t n,
                     int d, float* out, int64_t ldo, ogl_stream_t stream);
+/* Zero fill of `bytes` bytes (any alignment): what the atomic-scatter backward kernels need in front of them (ogl_reduce_bwd,
+ * ogl_out_layer_bwd_inputs) when no loss launch cleared their target on the side.  A kernel launch (capturable). */
+int ogl_fill_zero(void* ptr, int64_t bytes, ogl_stream_t stream);
 int ogl_gather_i64(const int64_t* table, int64_t n_rows, const int64_t* ids, int64_t n,
                    int64_t* out, ogl_stream_t stream);
 
@@ -162,6 +165,13 @@ int ogl_linear_fwd(const float* x, int64_t ldx, const int64_t* x_rows, int64_t x
                    const float* x2, int64_t ldx2, const int64_t* x2_rows, int64_t x2_nrows, int K2,
                    const float* w2, int64_t ldw2,
                    int relu, float* y, int64_t ldy, ogl_stream_t stream);
+/* ogl_linear_fwd for a layer whose two projections each carry a bias — fc_self(h) + fc_neigh(neigh) with two nn.Linear(bias=True)
+ * (DGL SAGEConv('pool'), R/train/graphsage/pytorch/graphsage_dgl.py:3): y = act(x . w^T + x2 . w2^T + (bias + bias2)); the sum of
+ * the two biases is formed first (the rounding of the `bias + bias2` launch this replaces).  bias and bias2 are both required. */
+int ogl_linear_fwd_dual_bias(const float* x, int64_t ldx, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K, const float* w,
+                             int64_t ldw, int N, const float* bias, const float* bias2, const float* x2, int64_t ldx2,
+                             const int64_t* x2_rows, int64_t x2_nrows, int K2, const float* w2, int64_t ldw2, int relu, float* y,
+                             int64_t ldy, ogl_stream_t stream);
 /* ogl_linear_fwd with a per-ROW addend read from a table: y[i, :] = act(x[row(i)] . w^T + bias + add[add_rows[i], :])
  * (add_rows nullable = row i; ids outside [0, add_nrows) add nothing).  The inference layers read their self term
  * fc_self(x) + biases from a per-vertex table computed once per pass (R/inference_optimized.py:169,258 `h0proj`). */
@@ -355,6 +365,14 @@ int ogl_ce_fwd_bwd(const float* logits, int64_t ldl, const int64_t* labels, int6
  * (reduction='mean', R/train/graphsage/pytorch/model.py:20: the loss the RBR / no-rehearsal strategies differentiate). */
 int ogl_ce_fwd_bwd_mean(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C, float grad_scale,
                         float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean, ogl_stream_t stream);
+/* ogl_ce_fwd_bwd_mean with (a) the label gather inside the launch — label of row i = label_table[label_ids[i]], an id outside
+ * [0, n_labels) = no label (what ogl_gather_i64 writes as -1); label_ids null: label_table is the label vector itself — and (b) an
+ * optional zero fill of a small caller buffer (zero_floats <= 65 536, a multiple of 4, 16-byte aligned: the atomic-scatter target of
+ * the backward pass that follows).  graph.ndata['target'][seeds] (R/train/graphsage/pytorch/model.py:91,183) and that fill were a
+ * launch each on the 32-seed rungs. */
+int ogl_ce_fwd_bwd_mean_gather(const float* logits, int64_t ldl, const int64_t* label_table, int64_t n_labels, const int64_t* label_ids,
+                               int64_t B, int C, float grad_scale, float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean,
+                               float* zero_buf, int64_t zero_floats, ogl_stream_t stream);
 /* The same for ANY batch size (one wave per row over a grid): the mean is summed by the last block to finish, in the fixed
  * order of the one-workgroup form (bit-identical to it).  `counter`: one zero-initialised device word the caller allocates once
  * (the last block resets it; one counter per stream that may run this concurrently).  loss_rows is required.  zero_buf

@@ -34,6 +34,7 @@ SIGNATURES = {
     "ogl_block_workspace_bytes": (_i64, [_i64, _i]),
     "ogl_build_block": (_i, [_p, _i64, _p, _i, _p, _p, _p, _p, _i64, _p]),
     "ogl_gather_rows": (_i, [_p, _i64, _i64, _p, _i64, _i, _p, _i64, _p]),
+    "ogl_fill_zero": (_i, [_p, _i64, _p]),
     "ogl_gather_i64": (_i, [_p, _i64, _p, _i64, _p, _p]),
     "ogl_dropout_rows": (_i, [_p, _i64, _p, _i64, _i64, _i, _d, _u64, _u64, _p, _i64, _p]),
     "ogl_reduce_fwd": (_i, [_p, _i64, _i64, _p, _p, _i64, _i, _i, _i, _p, _i64, _p, _p]),
@@ -41,6 +42,8 @@ SIGNATURES = {
     "ogl_reduce_bwd": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i, _i, _i, _i64, _p, _i64, _p]),
     "ogl_linear_fwd": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p,
                             _p, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p]),
+    "ogl_linear_fwd_dual_bias": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p, _p,
+                                      _p, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p]),
     "ogl_linear_fwd_addrows": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p, _p, _i64, _p, _i64, _i, _p, _i64, _p]),
     "ogl_relu_bwd": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _p]),
     "ogl_linear_bwd_input": (_i, [_p, _i64, _i64, _i, _p, _i64, _i, _p, _i64, _p]),
@@ -75,6 +78,7 @@ SIGNATURES = {
     "ogl_ce_fwd_bwd": (_i, [_p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p]),
     "ogl_ce_fwd_bwd_mean": (_i, [_p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p]),
     "ogl_ce_fwd_bwd_mean_grid": (_i, [_p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p, _p, _i64, _p]),
+    "ogl_ce_fwd_bwd_mean_gather": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p, _i64, _p]),
     "ogl_ce_fwd_bwd_mean_grid_gather": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p, _p, _i64, _p]),
     "ogl_adam_step": (_i, [_p, _p, _p, _p, _i64, _i, _d, _d, _d, _d, _p]),
     "ogl_argmax_confusion": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p]),

@@ -388,6 +388,31 @@ extern "C" int ogl_gather_i64(const int64_t* table, int64_t n_rows, const int64_
   return OGL_OK;
 }
 
+// ---- zero fill (the scatter targets of the atomic backward kernels) ------------------------------------------------
+// A kernel, not hipMemsetAsync: a memset node recorded into a captured hipGraph re-runs on only 1/16 of its range from the second
+// replay on (ROCm 7.2; tools/graph_probe.py), and not an ATen fill: the step's launches are this library's.
+__global__ void __launch_bounds__(256) k_zero16(uint4* __restrict__ p, int64_t n16, unsigned char* __restrict__ tail, int ntail) {
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = t0; i < n16; i += (int64_t)gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (t0 < ntail) tail[t0] = 0;
+}
+
+extern "C" int ogl_fill_zero(void* ptr, int64_t bytes, ogl_stream_t stream) {
+  if (bytes < 0 || (bytes > 0 && !ptr)) return OGL_EINVAL;
+  if (bytes == 0) return OGL_OK;
+  unsigned char* b = (unsigned char*)ptr;
+  const int64_t head = std::min<int64_t>(bytes, (16 - ((uintptr_t)b & 15)) & 15);      // bytes up to the first 16-byte boundary
+  const int64_t n16 = (bytes - head) / 16, ntail = bytes - head - n16 * 16;
+  if (head > 0) {
+    hipLaunchKernelGGL(k_zero16, dim3(1), dim3(256), 0, (hipStream_t)stream, (uint4*)nullptr, (int64_t)0, b, (int)head);
+    OGL_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_zero16, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(ogl_cdiv(n16, 256), 2048))), dim3(256), 0, (hipStream_t)stream,
+                     (uint4*)(b + head), n16, b + head + n16 * 16, (int)ntail);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
 // ---- feat_drop: counter-based dropout, optionally fused with the row gather ------------------------------------
 // One thread per 4 consecutive columns of one output row = one Philox4x32-10 block (the sampler's keying with the
 // output row in place of the vertex id); keep iff draw >= thr; kept values are divided by keep_prob (one IEEE division,

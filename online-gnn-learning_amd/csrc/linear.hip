@@ -44,6 +44,7 @@ struct GemmArgs {
   int ones_col;     // B(r, N-1) == 1  -> column N-1 of the result = row sums of A (bias gradient)
   float* C; int64_t ldc;
   const float* bias;  // [N] or null, added per output column
+  const float* bias2; // [N] or null (with bias): the second projection's own bias — (bias + bias2) is formed first, then added
   // optional per-ROW addend (forward only, nsplit == 1): C[i, :] += add[row(i), :], row(i) = add_rows ? add_rows[i] : i; rows
   // outside [0, add_nrows) add nothing.  The self term of an inference layer read from a per-vertex table (S0[dst]).
   const float* add; int64_t ld_add; const int64_t* add_rows; int64_t add_nrows;
@@ -463,7 +464,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
     for (int y = 0; y < TN; ++y) {
       const int64_t col = j0 + wn * TN * 32 + y * 32 + l31;
       if (col >= g.N) continue;
-      const float bv = (g.nsplit == 1 && g.bias && !(g.ones_col && col == g.N - 1)) ? g.bias[col] : 0.f;
+      const float bv = (g.nsplit == 1 && g.bias && !(g.ones_col && col == g.N - 1)) ? (g.bias2 ? g.bias[col] + g.bias2[col] : g.bias[col]) : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int64_t row = i0 + wm * TM * 32 + x * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
@@ -575,7 +576,7 @@ __global__ void __launch_bounds__(64 * SK_WAVES) k_gemm_skinny(GemmArgs g) {
     const int64_t row = i0 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
     const int64_t col = j0 + (ln & 31);
     if (row < g.M && col < g.N) {
-      if (g.bias) sum += g.bias[col];
+      if (g.bias) sum += g.bias2 ? g.bias[col] + g.bias2[col] : g.bias[col];
       if (g.relu) sum = fmaxf(sum, 0.f);
       g.C[row * g.ldc + col] = sum;
     }
@@ -589,7 +590,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(GemmArgs g) {
     float v = 0.f;
     for (int s = 0; s < g.nsplit; ++s) v += g.ws[((int64_t)s * g.M + row) * g.ws_ld + col];  // fixed order
     const bool oc = g.ones_col && col == g.N - 1;
-    if (g.bias && !oc) v += g.bias[col];
+    if (g.bias && !oc) v += g.bias2 ? g.bias[col] + g.bias2[col] : g.bias[col];
     if (g.relu) v = fmaxf(v, 0.f);
     if (oc) { if (g.db) g.db[row] = v; }
     else g.C[row * g.ldc + col] = v;
@@ -619,7 +620,7 @@ __global__ void __launch_bounds__(256) k_gemm_empty(GemmArgs g) {
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = t / g.N, col = t - row * g.N;
     const bool oc = g.ones_col && col == g.N - 1;
-    float v = (g.bias && !oc) ? g.bias[col] : 0.f;
+    float v = (g.bias && !oc) ? (g.bias2 ? g.bias[col] + g.bias2[col] : g.bias[col]) : 0.f;
     if (g.relu) v = fmaxf(v, 0.f);
     if (oc) { if (g.db) g.db[row] = 0.f; }
     else g.C[row * g.ldc + col] = v;
@@ -702,12 +703,10 @@ extern "C" int ogl_relu_bwd(const float* dy, int64_t ldy, const float* y, int64_
   return OGL_OK;
 }
 
-extern "C" int ogl_linear_fwd(const float* x, int64_t ldx, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
-                              const float* w, int64_t ldw, int N, const float* bias,
-                              const float* x2, int64_t ldx2, const int64_t* x2_rows, int64_t x2_nrows, int K2,
-                              const float* w2, int64_t ldw2, int relu, float* y, int64_t ldy,
-                              ogl_stream_t stream) {
-  if (M < 0 || K < 0 || N < 0 || K2 < 0 || ldx < K || ldw < K || ldy < N) return OGL_EINVAL;
+static int linear_fwd_impl(const float* x, int64_t ldx, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K, const float* w, int64_t ldw,
+                           int N, const float* bias, const float* bias2, const float* x2, int64_t ldx2, const int64_t* x2_rows,
+                           int64_t x2_nrows, int K2, const float* w2, int64_t ldw2, int relu, float* y, int64_t ldy, ogl_stream_t stream) {
+  if (M < 0 || K < 0 || N < 0 || K2 < 0 || ldx < K || ldw < K || ldy < N || (bias2 && !bias)) return OGL_EINVAL;
   if (M == 0 || N == 0) return OGL_OK;
   if (!y || (K > 0 && (!x || !w)) || (K2 > 0 && (!x2 || !w2 || ldx2 < K2 || ldw2 < K2))) return OGL_EINVAL;
   GemmArgs g; zero_args(g);
@@ -721,7 +720,7 @@ extern "C" int ogl_linear_fwd(const float* x, int64_t ldx, const int64_t* x_rows
     g.part[1].R = K2;
     g.nparts = 2;
   }
-  g.M = M; g.N = N; g.C = y; g.ldc = ldy; g.bias = bias; g.relu = relu;
+  g.M = M; g.N = N; g.C = y; g.ldc = ldy; g.bias = bias; g.bias2 = bias2; g.relu = relu;
   // few output tiles and a long reduction: in-block split-K straight from global memory
   const int64_t Ktot = (int64_t)K + K2;
   // (every input at least one whole 8-deep chunk: a chunk past an input's end re-reads its chunk 0)
@@ -735,6 +734,24 @@ extern "C" int ogl_linear_fwd(const float* x, int64_t ldx, const int64_t* x_rows
     return OGL_OK;
   }
   return launch_gemm<true, true>(g, (hipStream_t)stream);
+}
+
+extern "C" int ogl_linear_fwd(const float* x, int64_t ldx, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
+                              const float* w, int64_t ldw, int N, const float* bias,
+                              const float* x2, int64_t ldx2, const int64_t* x2_rows, int64_t x2_nrows, int K2,
+                              const float* w2, int64_t ldw2, int relu, float* y, int64_t ldy,
+                              ogl_stream_t stream) {
+  return linear_fwd_impl(x, ldx, x_rows, x_nrows, M, K, w, ldw, N, bias, nullptr, x2, ldx2, x2_rows, x2_nrows, K2, w2, ldw2, relu, y, ldy, stream);
+}
+
+// ogl_linear_fwd for a layer whose two projections each carry a bias (fc_self(h) + fc_neigh(neigh), both nn.Linear(bias=True)):
+// y = act(x . w^T + x2 . w2^T + (bias + bias2)) — the sum of the two biases is formed first, as the separate launch it replaces did.
+extern "C" int ogl_linear_fwd_dual_bias(const float* x, int64_t ldx, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
+                                        const float* w, int64_t ldw, int N, const float* bias, const float* bias2,
+                                        const float* x2, int64_t ldx2, const int64_t* x2_rows, int64_t x2_nrows, int K2,
+                                        const float* w2, int64_t ldw2, int relu, float* y, int64_t ldy, ogl_stream_t stream) {
+  if (!bias || !bias2) return OGL_EINVAL;
+  return linear_fwd_impl(x, ldx, x_rows, x_nrows, M, K, w, ldw, N, bias, bias2, x2, ldx2, x2_rows, x2_nrows, K2, w2, ldw2, relu, y, ldy, stream);
 }
 
 // y[M, N] = act(x[rows?] . w^T + bias + add[add_rows?[i], :]): ogl_linear_fwd with a per-row addend read from a table.

@@ -62,9 +62,11 @@ extern "C" int ogl_ce_fwd_bwd(const float* logits, int64_t ldl, const int64_t* l
 __global__ void __launch_bounds__(1024) k_ce_fwd_bwd_mean(const float* __restrict__ logits, int64_t ldl,
                                                           const int64_t* __restrict__ labels, int B, int C, float grad_scale,
                                                           float* __restrict__ loss_rows, float* __restrict__ dlogits, int64_t lddl,
-                                                          float* __restrict__ loss_mean) {
+                                                          float* __restrict__ loss_mean, const int64_t* __restrict__ label_ids,
+                                                          int64_t n_labels, float4* __restrict__ zero_buf, int zero_n4) {
   __shared__ float rows[CE_SMALL_MAX_B];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < zero_n4; i += 1024) zero_buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // (a small scatter target: see the grid form)
   for (int row = wv; row < B; row += 16) {
     const float* x = logits + (int64_t)row * ldl;
     float m = -INFINITY;
@@ -74,7 +76,11 @@ __global__ void __launch_bounds__(1024) k_ce_fwd_bwd_mean(const float* __restric
     for (int c = lane; c < C; c += 64) s += expf(x[c] - m);
     s = wave_sum(s);
     const float lse = m + logf(s);
-    const int64_t y = labels[row];
+    int64_t y;
+    if (label_ids) {                                           // the label gather of ogl_gather_i64 (an id outside the table: -1)
+      const int64_t id = label_ids[row];
+      y = (id >= 0 && id < n_labels) ? labels[id] : -1;
+    } else y = labels[row];
     const bool ok = y >= 0 && y < C;
     const float l = ok ? lse - x[y] : 0.f;
     if (lane == 0) { rows[row] = l; if (loss_rows) loss_rows[row] = l; }
@@ -97,7 +103,24 @@ extern "C" int ogl_ce_fwd_bwd_mean(const float* logits, int64_t ldl, const int64
   if (B <= 0 || B > CE_SMALL_MAX_B || C <= 0 || ldl < C || (dlogits && lddl < C)) return OGL_EINVAL;
   if (!logits || !labels || !loss_mean) return OGL_EINVAL;
   hipLaunchKernelGGL(k_ce_fwd_bwd_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ldl, labels, (int)B, C, grad_scale,
-                     loss_rows, dlogits, lddl, loss_mean);
+                     loss_rows, dlogits, lddl, loss_mean, (const int64_t*)nullptr, (int64_t)0, (float4*)nullptr, 0);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+// The same with the label gather inside the launch (label of row i = label_table[label_ids[i]]; label_ids null: label_table IS the
+// label vector) and an optional zero fill of a SMALL caller buffer (zero_floats <= 65 536: the one workgroup clears it; the atomic-
+// scatter target of the backward pass that follows) — on the 32-seed rungs each of those was a ~5 us launch of a ~0.2 ms step.
+#define CE_SMALL_MAX_ZERO 65536
+extern "C" int ogl_ce_fwd_bwd_mean_gather(const float* logits, int64_t ldl, const int64_t* label_table, int64_t n_labels,
+                                          const int64_t* label_ids, int64_t B, int C, float grad_scale, float* loss_rows, float* dlogits,
+                                          int64_t lddl, float* loss_mean, float* zero_buf, int64_t zero_floats, ogl_stream_t stream) {
+  if (B <= 0 || B > CE_SMALL_MAX_B || C <= 0 || ldl < C || (dlogits && lddl < C) || n_labels < 0) return OGL_EINVAL;
+  if (!logits || !label_table || !loss_mean) return OGL_EINVAL;
+  if (zero_floats < 0 || zero_floats > CE_SMALL_MAX_ZERO || (zero_floats > 0 && (!zero_buf || ((uintptr_t)zero_buf & 15) || (zero_floats & 3))))
+    return OGL_EINVAL;
+  hipLaunchKernelGGL(k_ce_fwd_bwd_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ldl, label_table, (int)B, C, grad_scale,
+                     loss_rows, dlogits, lddl, loss_mean, label_ids, n_labels, (float4*)zero_buf, (int)(zero_floats / 4));
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }

@@ -94,8 +94,20 @@ def padded_ld(cols: int) -> int:
 def empty_mat(rows: int, cols: int, device, zero: bool = False):
     """[rows, cols] float32 view of a [rows, padded_ld(cols)] allocation (pad columns are don't-care)."""
     ld = padded_ld(cols)
-    buf = (torch.zeros if zero else torch.empty)((max(rows, 0), ld), dtype=torch.float32, device=device)
+    buf = torch.empty((max(rows, 0), ld), dtype=torch.float32, device=device)
+    if zero:
+        fill_zero(buf)
     return buf[:, :cols]
+
+
+def fill_zero(t):
+    """Zeroes a contiguous tensor in place (ogl_fill_zero on the device: the step's launches are this library's; torch on the host)."""
+    if not t.is_cuda:
+        return t.zero_()
+    assert t.is_contiguous()
+    if t.numel():
+        _launch("ogl_fill_zero", _lib.lib().ogl_fill_zero, _ptr(t), t.numel() * t.element_size(), _stream(), meta=dict(bytes=t.numel() * t.element_size()))
+    return t
 
 
 def as_mat(t: torch.Tensor) -> torch.Tensor:
@@ -406,11 +418,14 @@ def reduce_fwd_img(src: torch.Tensor, idx: torch.Tensor, want_argmax: bool = Fal
     return out, argmax, img
 
 
-def reduce_bwd(dout: torch.Tensor, idx32, argmax, op: str, n_src: int, fanout=None, relu_out=None) -> torch.Tensor:
+def reduce_bwd(dout: torch.Tensor, idx32, argmax, op: str, n_src: int, fanout=None, relu_out=None, dsrc=None) -> torch.Tensor:
+    """``dsrc``: an already ZEROED [n_src, d] matrix to scatter into (``take_zeroed``); default: allocated and cleared here."""
     dout = as_mat(dout)
     n_dst, d = dout.shape
     fanout = idx32.shape[1] if idx32 is not None else int(fanout)
-    dsrc = empty_mat(n_src, d, dout.device, zero=True)
+    if dsrc is None:
+        dsrc = empty_mat(n_src, d, dout.device, zero=True)
+    assert tuple(dsrc.shape) == (n_src, d)
     if relu_out is not None:
         relu_out = as_mat(relu_out)
     _launch("ogl_reduce_bwd", _lib.lib().ogl_reduce_bwd, _ptr(dout), _ld(dout), _ptr(idx32), _ptr(argmax), _ptr(relu_out),
@@ -422,7 +437,8 @@ def reduce_bwd(dout: torch.Tensor, idx32, argmax, op: str, n_src: int, fanout=No
 # --------------------------------------------------------------------------------------------
 # dense projections
 # --------------------------------------------------------------------------------------------
-def linear_fwd(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_rows=None, out=None):
+def linear_fwd(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_rows=None, out=None, bias2=None):
+    """``bias2``: the second projection's own bias (dual-input form only): (bias + bias2) is formed inside the launch."""
     x = as_mat(x); w = as_mat(w)
     M = x_rows.numel() if x_rows is not None else x.shape[0]
     K, N = x.shape[1], w.shape[0]
@@ -444,6 +460,13 @@ def linear_fwd(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_ro
                 wimg = x3_split(w, append_vec=bvec)
             return linear_fwd_x3(img, x_rows, wimg, relu=relu, x_nrows=x.shape[0], M=M, out=out)
     y = out if out is not None else empty_mat(M, N, x.device)
+    if bias2 is not None:
+        assert bias is not None and x2 is not None
+        _launch("ogl_linear_fwd", _lib.lib().ogl_linear_fwd_dual_bias,
+                _ptr(x), _ld(x), _ptr(x_rows), x.shape[0], M, K, _ptr(w), _ld(w), N, _ptr(bias), _ptr(bias2),
+                _ptr(x2), _ld(x2), _ptr(x2_rows), x2.shape[0], K2, _ptr(w2), _ld(w2), int(bool(relu)), _ptr(y), _ld(y), _stream(),
+                meta=dict(M=M, K=K, N=N, K2=K2))
+        return y
     _launch("ogl_linear_fwd", _lib.lib().ogl_linear_fwd, 
         _ptr(x), _ld(x), _ptr(x_rows), x.shape[0], M, K, _ptr(w), _ld(w), N, _ptr(bias),
         _ptr(x2), _ld(x2) if x2 is not None else 0, _ptr(x2_rows), x2.shape[0] if x2 is not None else 0, K2,
@@ -1117,17 +1140,34 @@ def ce_fwd_bwd(logits, labels, grad_scale=1.0, want_grad=True):
 CE_MEAN_SMALL_MAX_B = 128      # up to here the mean comes from the cross-entropy launch itself (one workgroup)
 
 
+CE_SMALL_MAX_ZERO = 65536       # floats the one-workgroup loss launch clears on the side (ogl_ce_fwd_bwd_mean_gather)
+
+
 def ce_fwd_bwd_mean(logits, labels, want_grad=True):
-    """(mean loss [scalar tensor], row losses, dlogits scaled by 1/B) of a small batch in ONE launch."""
+    """(mean loss [scalar tensor], row losses, dlogits scaled by 1/B) of a small batch in ONE launch; ``labels`` may be a LazyLabels
+    (gathered inside the launch), and a small pending ``request_zeroed`` buffer is cleared by the same launch."""
     logits = as_mat(logits)
-    labels = labels.reshape(-1)
-    assert labels.dtype == torch.int64 and labels.is_cuda and labels.is_contiguous() and labels.numel() == logits.shape[0]
+    lazy = labels if isinstance(labels, LazyLabels) else None
+    if lazy is None:
+        labels = labels.reshape(-1)
+        assert labels.dtype == torch.int64 and labels.is_cuda and labels.is_contiguous()
+    assert labels.numel() == logits.shape[0]
     B, Cc = logits.shape
     loss = torch.empty(B, dtype=torch.float32, device=logits.device)
     mean = torch.empty((), dtype=torch.float32, device=logits.device)
     dl = empty_mat(B, Cc, logits.device) if want_grad else None
-    _launch("ogl_ce_fwd_bwd_mean", _lib.lib().ogl_ce_fwd_bwd_mean, _ptr(logits), _ld(logits), _ptr(labels), B, Cc, C.c_float(1.0 / B),
-            _ptr(loss), _ptr(dl), _ld(dl) if dl is not None else 0, _ptr(mean), _stream(), meta=dict(B=B, C=Cc))
+    zbuf, zn = None, 0
+    if want_grad:
+        key = (logits.device.index, _stream())
+        ent = _PENDING_ZERO.get(key)
+        if ent is not None and ent[0].numel() <= CE_SMALL_MAX_ZERO and ent[0].numel() % 4 == 0:
+            del _PENDING_ZERO[key]
+            zbuf, zn = ent[0], ent[0].numel()
+            ent[3] = True
+    table, ids = (lazy.table, lazy.ids) if lazy is not None else (labels, None)
+    _launch("ogl_ce_fwd_bwd_mean", _lib.lib().ogl_ce_fwd_bwd_mean_gather, _ptr(logits), _ld(logits), _ptr(table), table.numel(), _ptr(ids), B, Cc,
+            C.c_float(1.0 / B), _ptr(loss), _ptr(dl), _ld(dl) if dl is not None else 0, _ptr(mean), _ptr(zbuf), zn, _stream(),
+            meta=dict(B=B, C=Cc))
     return mean, loss, dl
 
 
@@ -1153,7 +1193,7 @@ def take_zeroed(ent, rows, cols):
     buf, r, c, done = ent
     assert r == rows and c == cols
     if not done:
-        buf.zero_()
+        fill_zero(buf)
         for k, v in list(_PENDING_ZERO.items()):
             if v is ent:
                 del _PENDING_ZERO[k]
@@ -1409,9 +1449,9 @@ class _LinearFn(torch.autograd.Function):
         ctx.x2_img = take_image(x2, pop=False) if x2 is not None else None     # read again by the weight gradient (k-major)
         y = _dual_fwd_images(x, w, bias, bias2, x2, w2, relu, x_rows, x2_rows)
         if y is None:
-            if bias2 is not None:
-                bias = bias + bias2
-            y = linear_fwd(x, w, bias, x2, w2, relu, x_rows, x2_rows)
+            # (bias2 comes with x2, and a dual-input product never takes linear_fwd's table-image path: the two biases are summed
+            # inside the launch — ogl_linear_fwd_dual_bias — instead of by an ATen add in front of it)
+            y = linear_fwd(x, w, bias, x2, w2, relu, x_rows, x2_rows, bias2=bias2)
         ctx.relu = bool(relu)
         ctx.has_bias = bias is not None
         if relu:
@@ -1559,6 +1599,10 @@ class _PoolMaxFn(torch.autograd.Function):
                 and (w.requires_grad or (bias is not None and bias.requires_grad))):
             # layer 0 (see backward): the gradient-free half of the pool backward starts here, beside the products that follow
             ctx.pool_plan = pool_bwd_x3_plan(argmax, out, idx, ctx.n_src)
+        ctx.dp_slot = None
+        if need and ctx.pool_plan is None and max(ctx.n_src, 1) * padded_ld(out.shape[1]) <= CE_SMALL_MAX_ZERO:
+            # a small scatter target: the loss launch that runs between this forward and its backward clears it on the side
+            ctx.dp_slot = request_zeroed(ctx.n_src, out.shape[1], out.device)
         ctx.save_for_backward(x, w, x_rows, out, argmax, idx if idx.dtype == torch.int32 else None)
         return out
 
@@ -1589,7 +1633,9 @@ class _PoolMaxFn(torch.autograd.Function):
         if plan is not None and plan.event is not None:            # (planned for the image path, which this call does not take)
             torch.cuda.current_stream().wait_event(plan.event)
         ctx.pool_plan = None
-        dp = reduce_bwd(dout, None, argmax, "max", ctx.n_src, fanout=ctx.fanout, relu_out=out)
+        slot, ctx.dp_slot = getattr(ctx, "dp_slot", None), None
+        dp = reduce_bwd(dout, None, argmax, "max", ctx.n_src, fanout=ctx.fanout, relu_out=out,
+                        dsrc=take_zeroed(slot, ctx.n_src, out.shape[1]) if slot is not None else None)
         dx = dw = db = None
         if need[0]:
             if x_rows is not None:
@@ -1807,7 +1853,7 @@ class _CrossEntropyMeanFn(torch.autograd.Function):
     def forward(ctx, logits, labels):
         B = max(logits.shape[0], 1)
         if 0 < logits.shape[0] <= CE_MEAN_SMALL_MAX_B:
-            mean, _, dl = ce_fwd_bwd_mean(logits, _labels_tensor(labels), want_grad=logits.requires_grad)
+            mean, _, dl = ce_fwd_bwd_mean(logits, labels, want_grad=logits.requires_grad)
             ctx.save_for_backward(dl)
             return mean
         if logits.shape[0] > 0:
@@ -1835,7 +1881,7 @@ class _CrossEntropyMeanRowsFn(torch.autograd.Function):
     def forward(ctx, logits, labels):
         B = logits.shape[0]
         if 0 < B <= CE_MEAN_SMALL_MAX_B:
-            mean, rows, dl = ce_fwd_bwd_mean(logits, _labels_tensor(labels), want_grad=logits.requires_grad)
+            mean, rows, dl = ce_fwd_bwd_mean(logits, labels, want_grad=logits.requires_grad)
         else:
             mean, rows, dl = ce_fwd_bwd_mean_grid(logits, labels, want_grad=logits.requires_grad)
         ctx.save_for_backward(dl)

@@ -302,3 +302,80 @@ def test_loss_launch_gathers_its_labels():
         assert torch.equal(m1, m2) and torch.equal(r1, r2)
         assert torch.equal(ops.cross_entropy(logits[:n], ops.LazyLabels(table, ids[:n]), "none"),
                            ops.cross_entropy(logits[:n], ops.gather_i64(table, ids[:n]), "none"))
+
+
+@pytest.mark.parametrize("M,K,K2,N,relu", [(512, 600, 600, 41, False), (832, 500, 500, 32, True), (37, 33, 9, 5, True), (3000, 64, 70, 130, False),
+                                            (40, 5000, 4000, 3, False)])
+def test_dual_projection_adds_both_biases_in_its_launch(M, K, K2, N, relu):
+    """ogl_linear_fwd_dual_bias: fc_self(x) + fc_neigh(x2) with each projection's own bias — (bias + bias2) is formed inside the
+    launch, with the rounding of the separate add it replaces: same bits as ogl_linear_fwd on the pre-summed bias (skinny, general
+    and split-K shapes)."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    torch.manual_seed(M + N)
+    x = ops.empty_mat(M, K, "cuda").copy_(torch.randn(M, K, device="cuda"))
+    x2 = ops.empty_mat(M, K2, "cuda").copy_(torch.randn(M, K2, device="cuda"))
+    w = torch.randn(N, K, device="cuda") / K ** 0.5; w2 = torch.randn(N, K2, device="cuda") / K2 ** 0.5
+    b = torch.randn(N, device="cuda"); b2 = torch.randn(N, device="cuda")
+    want = ops.linear_fwd(x, w, b + b2, x2, w2, relu=relu)
+    got = ops.linear_fwd(x, w, b, x2, w2, relu=relu, bias2=b2)
+    assert torch.equal(want, got)
+    ref = x.double() @ w.double().T + x2.double() @ w2.double().T + (b + b2).double()
+    if relu:
+        ref = ref.clamp_min(0)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    # through autograd: both biases get their gradient, no ATen add in the forward
+    xs = [t.clone().requires_grad_(True) for t in (w, b, w2, b2)]
+    ops.profile_start()
+    y = ops.linear(x, xs[0], xs[1], x2, xs[2], relu=relu, bias2=xs[3])
+    names = [r[0] for r in ops.profile_stop()]
+    y.sum().backward()
+    assert torch.equal(y.detach(), got) and names == ["ogl_linear_fwd"]
+    np.testing.assert_allclose(xs[1].grad.cpu().numpy(), xs[3].grad.cpu().numpy(), rtol=0, atol=0)
+
+
+def test_small_loss_launch_gathers_labels_and_clears_a_scatter_target():
+    """ogl_ce_fwd_bwd_mean_gather (batches up to 1 024 rows, one workgroup): labels read through ids inside the launch, and a small
+    pending request_zeroed buffer cleared on the side — same bits as gather + loss + fill as three launches."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    torch.manual_seed(9)
+    T, B, Cc = 3000, 64, 7
+    table = torch.randint(0, Cc, (T,), device="cuda")
+    ids = torch.randint(0, T, (B,), device="cuda"); ids[3] = -5
+    logits = ops.empty_mat(B, Cc, "cuda").copy_(torch.randn(B, Cc, device="cuda"))
+    want = ops.ce_fwd_bwd_mean(logits, ops.gather_i64(table, ids))
+    slot = ops.request_zeroed(832, 32, "cuda")
+    slot[0].fill_(7.0)
+    got = ops.ce_fwd_bwd_mean(logits, ops.LazyLabels(table, ids))
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    assert slot[3] is True and float(slot[0].abs().max()) == 0.0
+    z = ops.take_zeroed(slot, 832, 32)
+    assert z.shape == (832, 32) and float(z.abs().max()) == 0.0
+    # a request too large for one workgroup stays pending (its taker clears it)
+    big = ops.request_zeroed(5000, 600, "cuda")
+    big[0].fill_(1.0)
+    ops.ce_fwd_bwd_mean(logits, ops.gather_i64(table, ids))
+    assert big[3] is False
+    assert float(ops.take_zeroed(big, 5000, 600).abs().max()) == 0.0
+    h = ogl_amd._lib.lib()
+    assert h.ogl_ce_fwd_bwd_mean_gather(logits.data_ptr(), 8, table.data_ptr(), T, ids.data_ptr(), B, Cc, 1.0, None, None, 0, got[0].data_ptr(),
+                                        slot[0].data_ptr(), 1 << 20, None) == -1
+    assert h.ogl_ce_fwd_bwd_mean_gather(logits.data_ptr(), 8, None, T, ids.data_ptr(), B, Cc, 1.0, None, None, 0, got[0].data_ptr(), None, 0, None) == -1
+
+
+def test_fill_zero_any_alignment_and_size():
+    """ogl_fill_zero: bytes before the first 16-byte boundary, whole 16-byte words, the tail — nothing outside the range is touched."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    base = torch.full((1 << 16,), 0x5A, dtype=torch.uint8, device="cuda")
+    for off, n in [(0, 0), (0, 1), (3, 5), (1, 15), (16, 16), (7, 4096), (13, 65000), (0, 1 << 16)]:
+        base.fill_(0x5A)
+        assert ogl_amd._lib.lib().ogl_fill_zero(base.data_ptr() + off, n, None) == 0
+        torch.cuda.synchronize()
+        want = torch.full_like(base, 0x5A); want[off:off + n] = 0
+        assert torch.equal(base, want), (off, n)
+    m = ops.empty_mat(333, 70, "cuda", zero=True)
+    assert float(m.abs().max()) == 0.0
+    assert ogl_amd._lib.lib().ogl_fill_zero(None, 16, None) == -1 and ogl_amd._lib.lib().ogl_fill_zero(base.data_ptr(), -1, None) == -1
