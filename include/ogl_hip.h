@@ -292,12 +292,15 @@ int ogl_linear_fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_ro
  * - mask (nullable; [M, N] fp32, ld_mask and N multiples of 4, 16-byte aligned): y[i, j] is zeroed where mask[i, j] <= 0, after the
  *   addend — when this product is an INPUT GRADIENT dX = dY . W (+ head) and `mask` the forward output of the fused-ReLU layer that
  *   produced X (autograd of F.relu, R/train/graphsage/pytorch/graphsage_dgl.py:29-31), the gradient leaves the kernel already
- *   masked, with its image: no ogl_relu_bwd_img pass. */
+ *   masked, with its image: no ogl_relu_bwd_img pass.
+ * - y_keep (nullable, [M] bytes; needs out_img): the fp32 row i of y is stored only where y_keep[i] != 0 — the hidden layer of an
+ *   inference pass is read as an IMAGE by the next layer's fc_pool and as fp32 only at the next block's destination rows
+ *   (`h[:n_dst]` feeding fc_self, R/train/graphsage/pytorch/aggregator_dgl.py:145-146): 96 % of the fp32 rows are never read. */
 int ogl_linear_fwd_x3_ext(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int K1,
                           const void* x2_img, int64_t x2_img_rows, const int64_t* x2_rows, int64_t x2_nrows, int K2, int64_t M,
                           const void* w_img, int N, const float* add, int64_t ld_add, const int64_t* add_rows, int64_t add_nrows,
                           int relu, float* y, int64_t ldy, void* out_img, int out_append_ones, const float* mask, int64_t ld_mask,
-                          ogl_stream_t stream);
+                          const unsigned char* y_keep, ogl_stream_t stream);
 /* Up to 8 small images in ONE launch — the weight images of a train step (the parameters of nn.Linear in
  * R/train/graphsage/pytorch/aggregator_dgl.py:75-84, re-split after every optimiser step).  Part i becomes groups
  * [group_offset, group_offset + ceil((K + append) / 32)) of every row of `image` (rows image_row_bytes apart, R + 1 of them:
@@ -434,9 +437,11 @@ int ogl_adam_step_multi_dev(int count, float* const* p, const float* const* g, f
  * packed [rows, fanout] index array of the chunk's output blocks, with destination rows [seg_row[s], seg_row[s + 1]) belonging to
  * batch s (seg_row is relative to the array passed); every valid index gets seg_off[s] — the position of batch s's source list in the
  * fused source list — added in place, and dst_pos[r] (nullable, [rows]) receives the fused position of destination r's own row
- * (seg_off[s] + its rank inside the batch: a block's destinations are the first entries of its source list).  nseg <= 64. */
+ * (seg_off[s] + its rank inside the batch: a block's destinations are the first entries of its source list).  nseg <= 64.
+ * dst_flag (nullable; one byte per row of the fused SOURCE list, zeroed by the caller): set to 1 at every destination's own row —
+ * the rows of the hidden layer whose fp32 values the next layer's self term reads (ogl_linear_fwd_x3_ext's y_keep). */
 int ogl_fuse_block_segments(int32_t* local_idx, int64_t* dst_pos, int nseg, const int64_t* seg_row, const int64_t* seg_off, int fanout,
-                            ogl_stream_t stream);
+                            unsigned char* dst_flag, ogl_stream_t stream);
 int ogl_stage_segments(int nseg, const void* const* src, void* const* dst, const int64_t* count,
                        const int64_t* capacity, const int* elem_bytes, int64_t pad, ogl_stream_t stream);
 /* The read-back of a captured sample graph without a copy node: dst_host_mapped = int64 [n + 1] in pinned HOST memory (mapped

@@ -67,7 +67,7 @@ SIGNATURES = {
     "ogl_x3_debug_tile": (_i, [_i]),
     "ogl_linear_fwd_x3": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i, _i, _p, _i64, _p]),
     "ogl_linear_fwd_x3_ext": (_i, [_p, _i64, _p, _i64, _i, _p, _i64, _p, _i64, _i, _i64, _p, _i, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i, _p, _i64,
-                                   _p]),
+                                   _p, _p]),
     "ogl_x3_split_multi": (_i, [_p, _i, _p]),
     "ogl_relu_bwd_img": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _p, _p]),
     "ogl_x3_split_into": (_i, [_p, _i64, _i64, _i, _i, _p, _p, _i64, _i64, _p]),
@@ -101,7 +101,7 @@ SIGNATURES = {
     "ogl_adam_step_multi_dev": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _d, _d, _d, _d, _p]),
     "ogl_publish_i64": (_i, [_p, _i, _p, _p, _p]),
     "ogl_stage_segments": (_i, [_i, _p, _p, _p, _p, _p, _i64, _p]),
-    "ogl_fuse_block_segments": (_i, [_p, _p, _i, _p, _p, _i, _p]),
+    "ogl_fuse_block_segments": (_i, [_p, _p, _i, _p, _p, _i, _p, _p]),
 }
 
 _lib = None

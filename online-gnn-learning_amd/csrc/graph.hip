@@ -323,7 +323,7 @@ struct FuseDesc {
 };
 
 __global__ void __launch_bounds__(256) k_fuse_block_segments(int32_t* __restrict__ local_idx, int64_t* __restrict__ dst_pos, int fanout,
-                                                             FuseDesc d) {
+                                                             FuseDesc d, unsigned char* __restrict__ dst_flag) {
   const int64_t rows = d.row[d.n] - d.row[0];
   const int64_t total = rows * fanout;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -332,12 +332,16 @@ __global__ void __launch_bounds__(256) k_fuse_block_segments(int32_t* __restrict
     while (s + 1 < d.n && r >= d.row[s + 1]) ++s;
     const int32_t v = local_idx[e];
     if (v >= 0) local_idx[e] = v + (int32_t)d.off[s];
-    if (dst_pos && e % fanout == 0) dst_pos[e / fanout] = d.off[s] + (r - d.row[s]);
+    if (e % fanout == 0) {
+      const int64_t pos = d.off[s] + (r - d.row[s]);
+      if (dst_pos) dst_pos[e / fanout] = pos;
+      if (dst_flag) dst_flag[pos] = 1;
+    }
   }
 }
 
 extern "C" int ogl_fuse_block_segments(int32_t* local_idx, int64_t* dst_pos, int nseg, const int64_t* seg_row, const int64_t* seg_off,
-                                       int fanout, ogl_stream_t stream) {
+                                       int fanout, unsigned char* dst_flag, ogl_stream_t stream) {
   if (nseg < 0 || nseg > OGL_FUSE_MAX || fanout <= 0) return OGL_EINVAL;
   if (nseg == 0) return OGL_OK;
   if (!local_idx || !seg_row || !seg_off) return OGL_EINVAL;
@@ -354,7 +358,7 @@ extern "C" int ogl_fuse_block_segments(int32_t* local_idx, int64_t* dst_pos, int
   const int64_t total = (seg_row[nseg] - seg_row[0]) * fanout;
   if (total == 0) return OGL_OK;
   hipLaunchKernelGGL(k_fuse_block_segments, dim3((unsigned)std::min<int64_t>(ogl_cdiv(total, 256), 2048)), dim3(256), 0,
-                     (hipStream_t)stream, local_idx, dst_pos, fanout, d);
+                     (hipStream_t)stream, local_idx, dst_pos, fanout, d, dst_flag);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }

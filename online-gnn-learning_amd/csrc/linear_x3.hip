@@ -59,6 +59,7 @@ struct X3Args {
   int64_t ld_add; const int64_t* add_rows; int64_t add_nrows;
   const float* mask;            // optional: y[i, :] = (mask[i, :] > 0) ? y[i, :] : 0 after the addend — the ReLU backward of the layer
   int64_t ld_mask;              //   whose output `mask` is, applied to the input gradient this product computes (M rows, N columns)
+  const unsigned char* y_keep;  // optional [M]: the fp32 output row i is stored only where y_keep[i] != 0 (its image always is)
   float* db2;                   // optional second copy of the bias gradient (the two biases of a dual projection: one tensor each)
   // ---- k_gemm_x3p<..., BK = true> only: the B operand is a ROW-MAJOR image whose ROWS are the reduction index (b.rows gathers them,
   // b.nrows bounds the ids, b.zero_row / b.row_bytes as for a row-major A) and whose COLUMNS are the output columns: the
@@ -798,6 +799,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
               *(uint2*)(rp + x3_piece((ch & 7) >> 1, 2) * 16) = make_uint2(l0, l1);
             }
           }
+          if (EXT && g.y_keep && rok && !g.y_keep[row]) continue;   // (a row only the next layer's image product reads)
           const bool vec = rok && vec_ok && !has_oc && col < g.N && col + 4 <= ldd;
           if (vec) *(float4*)(dst + row * ldd + col) = make_float4(v[0], v[1], v[2], v[3]);
           else if (rok && col < g.N) {
@@ -1298,7 +1300,7 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     // tall products whose columns pad no further on 160-column tiles than on 128-column ones (N = 600: 4 x 160 = 5 x 128) take
     // 256 x 160: 4 992 DMA pieces per 256 x 160 x 32 step, 13 % fewer per MAC than 4 608 per 256 x 128 x 32
     // (not the EXT form: its epilogue spills at 80 accumulators)
-    const bool ext = g.a2.img || g.add || g.out_img || g.mask;
+    const bool ext = g.a2.img || g.add || g.out_img || g.mask || g.y_keep;
     if (c4 && !bk && !ext && g.nsplit == 1 && cfg == 0 && ogl_cdiv(g.N, 160) * 160 <= ogl_cdiv(g.N, 128) * 128) cfg = 4;
     if (g_x3_tile >= 0 && !bk && g.nsplit == 1) cfg = (g_x3_tile == 4 && ext) ? 0 : g_x3_tile;
     const int BMp = (cfg == 0 || cfg == 4) ? 256 : cfg == 2 ? 192 : cfg == 3 ? 160 : 128;
@@ -1366,7 +1368,7 @@ extern "C" int ogl_linear_fwd_x3_ext(const void* x_img, int64_t x_img_rows, cons
                                      const void* x2_img, int64_t x2_img_rows, const int64_t* x2_rows, int64_t x2_nrows, int K2,
                                      int64_t M, const void* w_img, int N, const float* add, int64_t ld_add, const int64_t* add_rows,
                                      int64_t add_nrows, int relu, float* y, int64_t ldy, void* out_img, int out_append_ones,
-                                     const float* mask, int64_t ld_mask, ogl_stream_t stream) {
+                                     const float* mask, int64_t ld_mask, const unsigned char* y_keep, ogl_stream_t stream) {
   if (M < 0 || K1 <= 0 || K2 < 0 || N < 0 || x_img_rows < 0 || x_nrows < 0 || x_nrows > x_img_rows || ldy < N) return OGL_EINVAL;
   if (M == 0 || N == 0) return OGL_OK;
   if (!x_img || !w_img || !y || (!x_rows && M > x_img_rows)) return OGL_EINVAL;
@@ -1389,6 +1391,8 @@ extern "C" int ogl_linear_fwd_x3_ext(const void* x_img, int64_t x_img_rows, cons
   g.out_img = (unsigned char*)out_img; g.out_append_ones = out_append_ones;
   g.out_row_bytes = ogl_cdiv(N + (out_append_ones ? 1 : 0), 32) * X3_GROUP_BYTES;
   g.mask = mask; g.ld_mask = ld_mask;
+  if (y_keep && !out_img) return OGL_EINVAL;                // (rows without an fp32 copy must at least have their image)
+  g.y_keep = y_keep;
   return launch_x3(g, (hipStream_t)stream);
 }
 

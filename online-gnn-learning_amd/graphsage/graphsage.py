@@ -105,6 +105,16 @@ class GraphSAGE(nn.Module):
         if torch.is_grad_enabled() and ops.get_gemm_mode() != "f32" and ops.PREPARE_WEIGHT_IMAGES:
             self._prepare_step_images(blocks, x)
         h = x
+        if not torch.is_grad_enabled():
+            # inference on fused batches: a layer's fp32 output is read by the next layer only at that block's destination rows (its
+            # fc_pool reads the image) — tell the layer below which rows those are
+            for i, (below, above) in enumerate(zip(blocks[:-1], blocks[1:])):
+                imgs = getattr(self.layers[i + 1], "_pass_images", None) if i + 1 < len(self.layers) else None
+                # (only when the layer above is sure to read the IMAGE of this output: its fc_pool weight image of the pass, with the
+                # reduction length the emitted image has)
+                if (getattr(above, "dst_flag", None) is not None and imgs and "w_pool_b" in imgs
+                        and imgs["w_pool_b"].K == getattr(self.layers[i], "_out_feats", -2) + 1):
+                    below.out_keep = above.dst_flag
         for layer, block in zip(self.layers, blocks):
             h = layer(block, h)
         return h

@@ -221,8 +221,12 @@ class SAGEConv(nn.Module):
             # the image kernel with S0[dst] added in its epilogue, and that kernel writes the image of ITS output for the next
             # layer's fc_pool — no split pass anywhere (the weight images were built once for the pass)
             h_neigh, _, nimg = ops.reduce_fwd_img(P0, graph.picks)
+            keep = getattr(graph, "out_keep", None)          # (fused batches: the rows whose fp32 values the next layer reads)
+            if keep is not None and (keep.numel() != graph.dst_ids.numel() or (self.activation is not None and not fuse_relu)
+                                     or self.norm is not None):
+                keep = None
             rst, himg = ops.linear_fwd_x3_ext(nimg, None, imgs["w_neigh"], add=S0, add_rows=graph.dst_ids, relu=fuse_relu,
-                                              want_image=True, image_append_ones=True)
+                                              want_image=True, image_append_ones=True, y_keep=keep)
             ops.attach_image(rst, himg)
             if self.activation is not None and not fuse_relu:
                 rst = self.activation(rst)

@@ -217,15 +217,17 @@ def stage_segments(pairs, pad=-1):
     _launch("ogl_stage_segments", _lib.lib().ogl_stage_segments, k, srcs, dsts, cnt, cap, el, int(pad), _stream(), meta=dict(nseg=k))
 
 
-def fuse_block_segments(local_idx, seg_rows, seg_offs, want_dst_pos=True):
+def fuse_block_segments(local_idx, seg_rows, seg_offs, want_dst_pos=True, dst_flag=None):
     """In place: the packed block-local indices of several batches become indices into their source lists laid end to end
     (``ogl_fuse_block_segments``); returns the position of every destination's own row in the fused source list (int64 [rows])."""
     assert local_idx.dtype == torch.int32 and local_idx.is_cuda and local_idx.is_contiguous() and local_idx.dim() == 2
     k = len(seg_offs)
     assert len(seg_rows) == k + 1 and seg_rows[0] == 0 and seg_rows[-1] == local_idx.shape[0]
     dst_pos = torch.empty(local_idx.shape[0], dtype=torch.int64, device=local_idx.device) if want_dst_pos else None
+    if dst_flag is not None:            # (ZEROED uint8 [rows of the fused source list]: set to 1 at every destination's own row)
+        assert dst_flag.dtype == torch.uint8 and dst_flag.is_cuda and dst_flag.is_contiguous()
     _launch("ogl_fuse_block_segments", _lib.lib().ogl_fuse_block_segments, _ptr(local_idx), _ptr(dst_pos), k, _host_i64(seg_rows),
-            _host_i64(seg_offs), int(local_idx.shape[1]), _stream(), meta=dict(rows=int(local_idx.shape[0]), nseg=k))
+            _host_i64(seg_offs), int(local_idx.shape[1]), _ptr(dst_flag), _stream(), meta=dict(rows=int(local_idx.shape[0]), nseg=k))
     return dst_pos
 
 
@@ -737,9 +739,10 @@ def x3_split_cat(parts):
 
 
 def linear_fwd_x3_ext(x_img, x_rows, w_img, x2_img=None, x2_rows=None, add=None, add_rows=None, relu=False, x_nrows=None,
-                      x2_nrows=None, M=None, want_image=False, image_append_ones=False, out=None, mask=None):
+                      x2_nrows=None, M=None, want_image=False, image_append_ones=False, out=None, mask=None, y_keep=None):
     """``linear_fwd_x3`` with a second A part (``w_img`` K-concatenated, x3_split_cat), a per-row addend ``add[add_rows]`` and /
-    or the bf16x3 image of the output (returned as the second value when ``want_image``)."""
+    or the bf16x3 image of the output (returned as the second value when ``want_image``).  ``y_keep`` (uint8 [M], with
+    ``want_image``): fp32 rows are stored only where it is non-zero — the other rows of the returned matrix are UNDEFINED."""
     M = x_rows.numel() if x_rows is not None else (x_img.rows if M is None else M)
     x_nrows = x_img.rows if x_nrows is None else x_nrows
     K1 = x_img.K
@@ -754,6 +757,8 @@ def linear_fwd_x3_ext(x_img, x_rows, w_img, x2_img=None, x2_rows=None, add=None,
     if mask is not None:
         mask = as_mat(mask)
         assert mask.shape == (M, N) and _ld(mask) % 4 == 0 and N % 4 == 0 and mask.data_ptr() % 16 == 0
+    if y_keep is not None:
+        assert want_image and y_keep.dtype == torch.uint8 and y_keep.is_cuda and y_keep.is_contiguous() and y_keep.numel() == M
     img = None
     if want_image:
         Ki = N + (1 if image_append_ones else 0)
@@ -765,7 +770,8 @@ def linear_fwd_x3_ext(x_img, x_rows, w_img, x2_img=None, x2_rows=None, add=None,
             (x2_img.rows if x2_nrows is None else x2_nrows) if x2_img is not None else 0, K2, M, _ptr(w_img.buf), N,
             _ptr(add), _ld(add) if add is not None else 0, _ptr(_ids(add_rows) if add_rows is not None else None),
             add.shape[0] if add is not None else 0, 1 if relu else 0, _ptr(y), _ld(y), _ptr(img.buf) if img is not None else None,
-            1 if image_append_ones else 0, _ptr(mask), _ld(mask) if mask is not None else 0, _stream(), meta=dict(M=M, K=K1, N=N, K2=K2))
+            1 if image_append_ones else 0, _ptr(mask), _ld(mask) if mask is not None else 0, _ptr(y_keep), _stream(),
+            meta=dict(M=M, K=K1, N=N, K2=K2))
     return (y, img) if want_image else y
 
 

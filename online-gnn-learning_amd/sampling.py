@@ -21,9 +21,15 @@ MI355X-first differences (documented in DESIGN.md):
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
+
+# fused inference batches carry a byte per hidden-layer row: 1 where the next layer reads the row's fp32 values (its destinations'
+# own rows) — the layer below then stores fp32 only there (OGL_FUSED_KEEP_ROWS=0: every row, as before)
+FUSED_KEEP_ROWS = os.environ.get("OGL_FUSED_KEEP_ROWS", "1") != "0"
 
 NID = "_ID"   # same key DGL uses for block.srcdata[dgl.NID]
 EID = "_EID"
@@ -69,7 +75,7 @@ class Block:
     """
     is_block = True
 
-    def __init__(self, src_ids, dst_ids, local_idx, picks=None, dst_pos=None):
+    def __init__(self, src_ids, dst_ids, local_idx, picks=None, dst_pos=None, dst_flag=None):
         self.src_ids = src_ids            # int64 [n_src]  (dst nodes first)
         self.dst_ids = dst_ids            # int64 [n_dst]
         self.local_idx = local_idx        # int32 [n_dst, fanout], -1 = no neighbour
@@ -77,6 +83,10 @@ class Block:
         # several loader batches fused into one block (sample_batches(fuse_rows=...)): the destinations are no longer the FIRST
         # sources — dst_pos[d] is destination d's own row in the source list (None: the usual h[:n_dst])
         self.dst_pos = dst_pos
+        # fused batches: uint8 [n_src], 1 at the rows dst_pos lists — the only rows of the layer below whose fp32 values this block's
+        # layer reads (its fc_pool reads that layer's image); `out_keep` on the block BELOW is the same array, set by GraphSAGE.forward
+        self.dst_flag = dst_flag
+        self.out_keep = None
         self.srcdata = {NID: src_ids}
         self.dstdata = {NID: dst_ids}
         self.edata = {}
@@ -207,13 +217,14 @@ class MultiLayerNeighborSampler:
                 acc_r += int(seed_batches[b].numel())
                 seg_rows.append(acc_r)
                 seg_offs.append(rows[b] - r0)
-            dst_pos = ops.fuse_block_segments(lidx, seg_rows, seg_offs)            # (in place: the per-batch blocks are not handed out)
+            flag = ops.fill_zero(torch.empty(r1 - r0, dtype=torch.uint8, device=picks_all.device)) if FUSED_KEEP_ROWS else None
+            dst_pos = ops.fuse_block_segments(lidx, seg_rows, seg_offs, dst_flag=flag)  # (in place: the per-batch blocks are not handed out)
             # the hidden layer's vertex ids of the chunk, end to end (the batches' source lists sit apart in the packed array)
             ids0 = torch.empty(r1 - r0, dtype=torch.int64, device=dev)
             for k in range(b0, b1, 8):
                 ops.stage_segments([(dsts[b], ids0[rows[b] - r0:rows[b] - r0 + counts[b]], counts[b]) for b in range(k, min(k + 8, b1))])
             blk0 = Block(None, ids0, None, picks_all[r0:r1])
-            blk1 = Block(ids0, seeds_chunk, lidx, None, dst_pos=dst_pos)
+            blk1 = Block(ids0, seeds_chunk, lidx, None, dst_pos=dst_pos, dst_flag=flag)
             out.append((None, seeds_chunk, [blk0, blk1]))
             b0 = b1
         return out
