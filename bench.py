@@ -665,7 +665,7 @@ def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size,
         a["ms"] += ms; a["calls"] += 1
         if name in ("ogl_reduce_fwd", "ogl_reduce_fwd_img"):
             E = meta["n_dst"] * meta["fanout"]
-            a["bytes"] += E * (4 * meta["d"] + meta["idx_bytes"]) + meta["n_dst"] * 4 * meta["d"] * (2.5 if name.endswith("_img") else 1)
+            a["bytes"] += E * (4 * meta["d"] + meta["idx_bytes"]) + meta["n_dst"] * 4 * meta["d"] * ((2.5 if meta.get("out", True) else 1.5) if name.endswith("_img") else 1)
         if name in ("ogl_linear_fwd", "ogl_linear_fwd_x3", "ogl_linear_fwd_x3_ext"):
             a["flops"] += 2.0 * meta["M"] * meta["N"] * (meta["K"] + meta["K2"])
     kernels = {k: dict(ms_per_step=round(v["ms"] / nprof, 4), calls_per_step=round(v["calls"] / nprof, 2),
@@ -680,7 +680,7 @@ def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size,
               if n_ in ("ogl_reduce_fwd", "ogl_reduce_fwd_img") and (m["idx_bytes"] == 8 or m["n_dst"] > 64 * B)]
         top = max(m["n_dst"] for _, m, _ in l0)
         fullc = [(n_, m, ms) for n_, m, ms in l0 if m["n_dst"] >= 0.85 * top]
-        full_bytes = sum(m["n_dst"] * m["fanout"] * (4 * m["d"] + m["idx_bytes"]) + m["n_dst"] * 4 * m["d"] * (2.5 if n_.endswith("_img") else 1)
+        full_bytes = sum(m["n_dst"] * m["fanout"] * (4 * m["d"] + m["idx_bytes"]) + m["n_dst"] * 4 * m["d"] * ((2.5 if m.get("out", True) else 1.5) if n_.endswith("_img") else 1)
                          for n_, m, _ in fullc) / len(fullc)
         full_ms = sum(ms for _, _, ms in fullc) / len(fullc)
         per_launch = top / (sum(m["n_dst"] for _, m, _ in l0) / nprof)

@@ -142,7 +142,8 @@ int ogl_reduce_fwd(const float* src, int64_t lds, int64_t n_src, const int32_t* 
                    int64_t ldo, int32_t* argmax, ogl_stream_t stream);
 /* ogl_reduce_fwd(OGL_REDUCE_MAX) that ALSO writes the bf16x3 image of `out` (ogl_x3_image_bytes(n_dst, d) bytes; byte for byte
  * what ogl_x3_split(out) builds): the pooled rows' consumer (fc_neigh, R/train/graphsage/pytorch/aggregator_dgl.py:206) then
- * runs on the image kernel without a split pass.  Vectorised path only (16-byte-aligned operands, ld multiples of 4). */
+ * runs on the image kernel without a split pass.  Vectorised path only (16-byte-aligned operands, ld multiples of 4).  `out` may be
+ * NULL (pass ldo as for a real one): the image only — a consumer that reads nothing else (the cached inference layers). */
 int ogl_reduce_fwd_img(const float* src, int64_t lds, int64_t n_src, const int32_t* idx32, const int64_t* idx64, int64_t n_dst,
                        int fanout, int d, float* out, int64_t ldo, int32_t* argmax, void* image, ogl_stream_t stream);
 int ogl_reduce_bwd(const float* dout, int64_t ldo, const int32_t* idx32, const int32_t* argmax,

@@ -102,7 +102,7 @@ k_reduce_fwd_v4(const float* __restrict__ src, int64_t lds, int64_t n_src, const
     if (ch < d4) {
       float4 o = acc[c];
       if (OP == OGL_REDUCE_MEAN && any) { o.x /= fS; o.y /= fS; o.z /= fS; o.w /= fS; }
-      ((float4*)(out + w * ldo))[ch] = o;
+      if (!IMG || out) ((float4*)(out + w * ldo))[ch] = o;     // (IMG: `out` may be null — a consumer that reads the image only)
       if (IMG) {
         const int b4 = ch * 4;
         const float e0 = b4 < d ? o.x : 0.f, e1 = b4 + 1 < d ? o.y : 0.f, e2 = b4 + 2 < d ? o.z : 0.f, e3 = b4 + 3 < d ? o.w : 0.f;
@@ -253,9 +253,9 @@ extern "C" int ogl_reduce_fwd(const float* src, int64_t lds, int64_t n_src, cons
 extern "C" int ogl_reduce_fwd_img(const float* src, int64_t lds, int64_t n_src, const int32_t* idx32, const int64_t* idx64,
                                   int64_t n_dst, int fanout, int d, float* out, int64_t ldo, int32_t* argmax, void* image,
                                   ogl_stream_t stream) {
-  if (n_dst <= 0 || fanout <= 0 || d <= 0 || n_src <= 0 || lds < d || ldo < d) return OGL_EINVAL;
+  if (n_dst <= 0 || fanout <= 0 || d <= 0 || n_src <= 0 || lds < d || (out && ldo < d)) return OGL_EINVAL;
   if ((idx32 != nullptr) == (idx64 != nullptr)) return OGL_EINVAL;
-  if (!out || !src || !image || ((uintptr_t)image & 15)) return OGL_EINVAL;
+  if (!src || !image || ((uintptr_t)image & 15)) return OGL_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   unsigned char* im = (unsigned char*)image;
   if (idx32) return argmax ? launch_reduce_fwd<OGL_REDUCE_MAX, int32_t, true>(src, lds, n_src, idx32, n_dst, fanout, d, out, ldo, argmax, st, im)

@@ -17,6 +17,8 @@ Unknown types raise ``KeyError`` from ``forward`` like the reference (:196-197).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -49,6 +51,8 @@ class GatheredRows:
 # half the reduction — Reddit H = 600: 0.20 -> 0.12 ms per 1 024-seed batch); below it the identity-weight dual product wins
 # (arxiv H = 32: 25 vs 36 us — the gathered 128-byte rows cost more than 32 extra reduction steps)
 ADDROWS_MIN_WIDTH = 128
+# the cached layers' aggregator writes the image of the pooled rows only (OGL_IMAGE_ONLY_POOL=0: the fp32 rows too, which nobody reads)
+POOL_FP32_OUT = os.environ.get("OGL_IMAGE_ONLY_POOL", "1") == "0"
 _EYE = {}
 
 
@@ -220,7 +224,7 @@ class SAGEConv(nn.Module):
             # tall, wide layer: the aggregator writes the image of the pooled rows beside them, the neighbour projection runs on
             # the image kernel with S0[dst] added in its epilogue, and that kernel writes the image of ITS output for the next
             # layer's fc_pool — no split pass anywhere (the weight images were built once for the pass)
-            h_neigh, _, nimg = ops.reduce_fwd_img(P0, graph.picks)
+            _, _, nimg = ops.reduce_fwd_img(P0, graph.picks, want_out=POOL_FP32_OUT)     # (the product below reads the image only)
             keep = getattr(graph, "out_keep", None)          # (fused batches: the rows whose fp32 values the next layer reads)
             if keep is not None and (keep.numel() != graph.dst_ids.numel() or (self.activation is not None and not fuse_relu)
                                      or self.norm is not None):

@@ -403,20 +403,21 @@ def reduce_fwd(src: torch.Tensor, idx: torch.Tensor, op: str, want_argmax: bool 
     return out, argmax
 
 
-def reduce_fwd_img(src: torch.Tensor, idx: torch.Tensor, want_argmax: bool = False):
-    """max-reduce that also returns the bf16x3 image of its output: (out, argmax, X3Image)."""
+def reduce_fwd_img(src: torch.Tensor, idx: torch.Tensor, want_argmax: bool = False, want_out: bool = True):
+    """max-reduce that also returns the bf16x3 image of its output: (out, argmax, X3Image).  ``want_out=False``: the image only
+    (``out`` is None: a consumer that reads nothing but the image — the cached inference layers — saves 40 % of the launch's writes)."""
     src = as_mat(src)
     assert idx.is_cuda and idx.dim() == 2 and idx.is_contiguous()
     n_dst, fanout = idx.shape
     d = src.shape[1]
-    out = empty_mat(n_dst, d, src.device)
+    out = empty_mat(n_dst, d, src.device) if want_out else None
     argmax = torch.empty((n_dst, d), dtype=torch.int32, device=src.device) if want_argmax else None
     img = X3Image(_x3_alloc(n_dst, d, src.device), n_dst, d)
     i32 = idx if idx.dtype == torch.int32 else None
     i64 = idx if idx.dtype == torch.int64 else None
     _launch("ogl_reduce_fwd_img", _lib.lib().ogl_reduce_fwd_img, _ptr(src), _ld(src), src.shape[0], _ptr(i32), _ptr(i64), n_dst, fanout, d,
-            _ptr(out), _ld(out), _ptr(argmax), _ptr(img.buf), _stream(),
-            meta=dict(n_dst=n_dst, fanout=fanout, d=d, op="max", argmax=argmax is not None, idx_bytes=idx.element_size()))
+            _ptr(out), _ld(out) if out is not None else padded_ld(d), _ptr(argmax), _ptr(img.buf), _stream(),
+            meta=dict(n_dst=n_dst, fanout=fanout, d=d, op="max", argmax=argmax is not None, idx_bytes=idx.element_size(), out=out is not None))
     return out, argmax, img
 
 
