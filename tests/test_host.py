@@ -274,3 +274,34 @@ def test_replay_array_entry_points_equal_dict_api(helper, monkeypatch):
         assert ia == ib
     with pytest.raises(KeyError):
         b.update_arrays(np.array([10 ** 7], dtype=np.int64), np.array([1.0]))
+
+
+def test_whole_slab_dealing_is_a_bijection():
+    """The tile walk of the k-major weight gradients (k_gemm_x3p `decode`, X3Args.xcd_slabs): XCD x owns the
+    logical blocks [x T / 8 .. ) of T = tiles x nsplit, takes floor(nsplit / 8) WHOLE slabs and a share of the left-over slabs tile by
+    tile.  Restated here in Python: every (slab, tile) pair is produced exactly once, and a whole slab's tiles stay on one XCD."""
+    def decode(logical, tiles, nsplit):
+        T = tiles * nsplit
+        q = nsplit >> 3
+        # the XCD whose run holds `logical`
+        for xcd in range(8):
+            begin = xcd * (T >> 3) + min(xcd, T & 7)
+            length = (T >> 3) + (1 if xcd < (T & 7) else 0)
+            if begin <= logical < begin + length:
+                break
+        local, whole = logical - begin, q * tiles
+        if local < whole:
+            return xcd, xcd * q + local // tiles, local % tiles
+        e = (begin - xcd * whole) + (local - whole)
+        return xcd, 8 * q + e // tiles, e % tiles
+
+    for tiles in (1, 3, 15, 25, 40):
+        for nsplit in (8, 9, 10, 16, 17, 23, 64):
+            seen, home = set(), {}
+            for l in range(tiles * nsplit):
+                xcd, slab, tile = decode(l, tiles, nsplit)
+                assert 0 <= slab < nsplit and 0 <= tile < tiles and (slab, tile) not in seen
+                seen.add((slab, tile))
+                if slab < 8 * (nsplit >> 3):
+                    assert home.setdefault(slab, xcd) == xcd              # a whole slab never straddles two XCDs
+            assert len(seen) == tiles * nsplit
