@@ -288,9 +288,11 @@ __global__ void __launch_bounds__(1024) k_pool_plan_place(const int32_t* __restr
       const int64_t i = i0 + u * 1024 + tid;
       if (i >= total) continue;
       unsigned info = 0xFFFFFFFFu;
-      if (len[u] > 0) {                                            // a winner's slot: a[u] is a valid source id
+      if (len[u] > 0 && a[u] < 0x80000000u) {                      // a winner's slot: a[u] is a valid source id
         const unsigned q = pb_div(a[u], dv), g = a[u] - q * dv.G;
-        info = (gbase[g] + atomicAdd(&gcur[g], len[u])) | (q << PB_POS_BITS);
+        // (g < G by construction; the guard keeps a re-read index that is no longer what the bucket pass saw — inputs recycled
+        // under a plan whose backward never ran — from writing outside the group arrays)
+        if (g < dv.G) info = (gbase[g] + atomicAdd(&gcur[g], len[u])) | (q << PB_POS_BITS);
       }
       seginfo[i] = info;
     }

@@ -537,7 +537,22 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
         self.time_step = 0
         self.pass_var = 0
         self.full_pass = full_pass
+        self._device_trend = None
         self.priority_strategy = priority_strategy
+
+    @property
+    def priority_strategy(self):
+        """The strategy object the driver passed in.  While its per-vertex state lives in HBM (``_priorities_device``) the host
+        object is brought up to date before anyone outside reads it (one device->host copy, only when the state has moved)."""
+        dt = self._device_trend
+        if dt is not None and dt.dirty and dt.source is self._priority_strategy:
+            dt.write_back(self._priority_strategy)
+        return self._priority_strategy
+
+    @priority_strategy.setter
+    def priority_strategy(self, value):
+        self._priority_strategy = value
+        self._device_trend = None
 
     def choose_vertices(self, graph_util):
         if self.time_step % self.full_pass == 0:
@@ -580,7 +595,7 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
                 if on_device:
                     graph_util.update_priorities_device(batch_nodes_seed, self._priorities_device(batch_nodes_seed, losses[b]))
                 else:
-                    priorities = self.priority_strategy.get_priorities(batch_nodes_seed, all_loss[off:off + n])
+                    priorities = self._host_strategy().get_priorities(batch_nodes_seed, all_loss[off:off + n])
                     graph_util.update_priorities_arrays(batch_nodes_seed, np.asarray(priorities, dtype=np.float64))
                 off += n
         self.time_step += 1
@@ -621,7 +636,7 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
             graph_util.update_priorities_device(ids, self._priorities_device(ids, local))      # losses -> priorities -> tree, all in HBM
             return
         unaggregated_loss = local.cpu().numpy()
-        priorities = self.priority_strategy.get_priorities(batch_nids_l, unaggregated_loss)
+        priorities = self._host_strategy().get_priorities(batch_nids_l, unaggregated_loss)
         graph_util.update_priorities_arrays(np.asarray(batch_nids_l), np.asarray(priorities, dtype=np.float64))
 
     def _device_priorities(self, graph_util):
@@ -629,17 +644,27 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
         R/train/__main__.py:141 instantiates) needs nothing in between; TrendPriority / HybridPriority keep their per-vertex state
         in HBM too (priorities.DeviceTrend takes over the host object's arrays on first use)."""
         from ..prioritized_replay.priorities import HybridPriority, LossPriority, TrendPriority
-        return getattr(graph_util, "device_replay", False) and type(self.priority_strategy) in (LossPriority, TrendPriority, HybridPriority)
+        return getattr(graph_util, "device_replay", False) and type(self._priority_strategy) in (LossPriority, TrendPriority, HybridPriority)
+
+    def _host_strategy(self):
+        """The strategy object for a HOST-side update: current (the property writes a live device state back) and from now on the
+        only copy — a device state taken earlier is dropped, the next device update takes the host arrays over again."""
+        st = self.priority_strategy
+        self._device_trend = None
+        return st
 
     def _priorities_device(self, ids_host, losses_dev):
         """get_priorities(ids, losses) with both sides on the device."""
         from ..prioritized_replay.priorities import DeviceTrend, LossPriority
-        if type(self.priority_strategy) is LossPriority:
+        strategy = self._priority_strategy
+        if type(strategy) is LossPriority:
             return losses_dev
-        dt = getattr(self, "_device_trend", None)
-        if dt is None or dt.source is not self.priority_strategy:
-            dt = self._device_trend = DeviceTrend(self.priority_strategy, losses_dev.device)
-            dt.source = self.priority_strategy
+        dt = self._device_trend
+        if dt is None or dt.source is not strategy:
+            dt = self._device_trend = DeviceTrend(strategy, losses_dev.device)
+            dt.source = strategy
+        # the kernel's preconditions, checked on the host copy the ids come from (no device sync): in range, distinct
+        DeviceTrend.check_ids_host(ids_host, dt.n_vertices)
         ids_dev = torch.as_tensor(np.asarray(ids_host, dtype=np.int64)).to(losses_dev.device, non_blocking=True)
         return dt.get_priorities_device(ids_dev, losses_dev)
 

@@ -974,7 +974,11 @@ def pool_bwd_x3_plan(argmax, relu_out, idx32, n_src, side=True):
             plan.event.record()
         plan.pending = False
         if not _capturing():
-            ws.record_stream(st)        # (a forward whose backward never runs frees `ws` with nothing having waited for the side stream)
+            # (a forward whose backward never runs frees these with nothing having waited for the side stream: the caching allocator
+            # must not hand their memory to a later main-stream kernel while the plan's kernels still read it)
+            for t in (ws, argmax, relu_out, idx32):
+                if t is not None:
+                    t.record_stream(st)
 
     _DEFERRED.append(run)
     return plan
@@ -1705,7 +1709,8 @@ class _SagePoolLayerFn(torch.autograd.Function):
         if _out_layer_fits(dy, h, w_self, w_neigh):
             # few output columns (the output layer): the combine's backward in two launches, its input gradient for the pooled rows
             # scattered to the winners as it is computed; the fc_self part joins dh in the epilogue of the fc_pool input gradient
-            slot = getattr(ctx, "dp_slot", None)
+            # (taken once: a second backward through the same graph — retain_graph=True — must not scatter into the first one's sums)
+            slot, ctx.dp_slot = getattr(ctx, "dp_slot", None), None
             tall = N1_BWD_SPLIT and _n1_images_ok(n_src, h.shape[1], w_pool.shape[1])
             # the layer's weight gradients are leaves of the backward graph: on the side stream when the layer is tall — the two
             # few-column ones right away (beside the equally small input-gradient launch), fc_pool's once dP and its image exist

@@ -108,6 +108,7 @@ class GradSynchronizer:
         self._buckets = {}          # name -> (flat tensor, index tuple, {param index: offset}): PERSISTENT across steps
         self._where = {}            # param index -> bucket name (where its gradient is reduced from the next step on)
         self.copied_in = 0          # instrumentation: gradient elements that had to be copied into a bucket (tests)
+        self._handed = set()        # parameter indices whose slot a kernel of the CURRENT backward already writes into
         if self.overlap:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -140,6 +141,7 @@ class GradSynchronizer:
             def __exit__(self_inner, *exc):
                 gs._suspended = False
                 gs._fired = {}                   # the launch condition counts the firings of the FINAL pass only
+                gs._handed.clear()
                 return False
         return _Ctx()
 
@@ -162,11 +164,16 @@ class GradSynchronizer:
         """A fresh view of parameter ``i``'s slot in its bucket, for a backward kernel to write the gradient into (so that
         autograd's AccumulateGrad adopts the slot as ``p.grad`` and ``_fill`` has nothing to copy); None when the slot must
         not be written: no bucket yet, a gradient already accumulated (``p.grad += new`` would alias), a collective of the
-        bucket in flight."""
+        bucket in flight — or the slot was ALREADY handed out since the last ``sync()``: inside one backward ``p.grad`` stays
+        None until AccumulateGrad has every contribution, so a weight used by two products of the same graph (shared weights,
+        two forwards summed into one loss) would otherwise get the same slot twice, the second kernel would overwrite the
+        first and the engine would then add the slot to itself.  The second product allocates; autograd sums the two."""
         p = self.params[i]
         name = self._where.get(i)
-        if name is None or p.grad is not None or self._suspended or (name == "early" and self._pending is not None):
+        if (name is None or p.grad is not None or self._suspended or i in self._handed
+                or (name == "early" and self._pending is not None)):
             return None
+        self._handed.add(i)
         flat, _, offs = self._buckets[name]
         return flat.narrow(0, offs[i], p.numel()).view(p.shape)
 
@@ -262,6 +269,7 @@ class GradSynchronizer:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             self._scatter("single")
             self._stale, self._fired, self._order = False, {}, []
+            self._handed.clear()
             return
         if self._early is None:
             idxs = list(range(len(self.params)))
@@ -280,6 +288,7 @@ class GradSynchronizer:
             work.wait()
             if stale:
                 self._pending, self._stale, self._fired, self._order = None, False, {}, []
+                self._handed.clear()
                 raise RuntimeError("GradSynchronizer: a gradient of the early bucket changed after the bucket's all-reduce was "
                                    "launched (a second backward() before sync()); run the non-final passes of a gradient "
                                    "accumulation under `with gsync.no_sync():`")
@@ -291,6 +300,7 @@ class GradSynchronizer:
         self._stale = False
         self._fired = {}
         self._order = []
+        self._handed.clear()
 
 
 def assert_replicated(values, what="value", group=None):

@@ -78,6 +78,7 @@ class DeviceTrend:
         self.stats = torch.tensor([float(trend.avg), float(trend.n_items)], dtype=torch.float64, device=self.device)
         self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.n_vertices = int(self.values.numel())
+        self.dirty = False            # the device state has moved past the host object's (write_back() brings it up to date)
 
     def get_priorities_device(self, ids_dev, losses_dev):
         """ids_dev int64 [n] (distinct original vertex ids, on the device), losses_dev float32 / float64 [n] -> float64 [n]."""
@@ -87,7 +88,11 @@ class DeviceTrend:
         n = int(ids_dev.numel())
         assert ids_dev.dtype == torch.int64 and ids_dev.is_cuda and ids_dev.is_contiguous() and losses_dev.numel() == n
         losses_dev = losses_dev.contiguous()
-        out = torch.empty(n, dtype=torch.float64, device=self.device)
+        # zeros, not empty: the kernel skips a row whose id is outside [0, n_vertices) (and raises `err`, see check()); such a row
+        # must not carry whatever the allocation held into the replay tree
+        from ..ops import fill_zero
+        out = fill_zero(torch.empty(n, dtype=torch.float64, device=self.device))
+        self.dirty = True
         l32 = losses_dev if losses_dev.dtype == torch.float32 else None
         l64 = losses_dev if losses_dev.dtype == torch.float64 else None
         if l32 is None and l64 is None:
@@ -100,6 +105,32 @@ class DeviceTrend:
     def check(self):
         if int(self.err.item()):
             raise IndexError("a vertex id outside [0, n_vertices) reached the trend priorities")
+
+    @staticmethod
+    def check_ids_host(ids_host, n_vertices):
+        """The kernel's preconditions on the HOST copy of the ids (they come from the host: subgraph_to_id[seeds]): inside
+        [0, n_vertices) and distinct (one thread per row updates that vertex's state: duplicates would race).  O(n), no sync."""
+        ids = np.asarray(ids_host, dtype=np.int64).reshape(-1)
+        if ids.size == 0:
+            return
+        lo, hi = int(ids.min()), int(ids.max())
+        if lo < 0 or hi >= n_vertices:
+            raise IndexError("a vertex id outside [0, %d) reached the trend priorities (min %d, max %d)" % (n_vertices, lo, hi))
+        if ids.size > 1 and int(np.bincount(ids - lo, minlength=1).max()) > 1:
+            raise ValueError("duplicate vertex ids in one trend-priority batch (the reference's dict update keeps the last one; "
+                             "the device kernel requires distinct ids)")
+
+    def write_back(self, strategy):
+        """Bring the host object this state was taken from up to date IN PLACE (anything that reads the strategy object on the
+        host — logging, a checkpoint, a hand-over to host-side code — sees the current state)."""
+        trend = strategy.trend_p if isinstance(strategy, HybridPriority) else strategy
+        self.check()
+        trend.values[:] = self.values.cpu().numpy()
+        trend.prev_loss[:] = self.prev_loss.cpu().numpy()
+        trend.init[:] = self.init.cpu().numpy().astype(bool)
+        st = self.stats.cpu().numpy()
+        trend.avg, trend.n_items = float(st[0]), int(round(st[1]))
+        self.dirty = False
 
     def to_host(self):
         """A host strategy object in the state this one is in (tests; hand-over back to host-side code)."""

@@ -132,6 +132,37 @@ def _worker_graphs(forced, port, out_path):
     torch.save(res, out_path)
 
 
+def _worker_shared_weight(forced, port, out_path):
+    """A weight used by TWO products of one autograd graph under data parallelism (round-3 advisor finding): inside one backward
+    ``p.grad`` stays None until AccumulateGrad has both contributions, so the gradient sink must not hand the same bucket slot to
+    both weight-gradient kernels (the second would overwrite the first and the engine would add the slot to itself: 2 x the last
+    gradient).  Three steps: bucket learning, then two steps whose weight gradients are written into their slots."""
+    dist, parallel = _setup(True, port)
+    from ogl_amd import ops
+    torch.manual_seed(4)
+    dev = torch.device("cuda", 0)
+    wa = torch.nn.Parameter(torch.randn(48, 64, device=dev) * 0.1)
+    wb = torch.nn.Parameter(torch.randn(48, 64, device=dev) * 0.1)
+    wc = torch.nn.Parameter(torch.randn(8, 48, device=dev) * 0.1)
+    gs = parallel.GradSynchronizer([wa, wb, wc], overlap=True, weight=1.0)
+    res = []
+    for step in range(3):
+        x1, x2 = torch.randn(96, 64, device=dev), torch.randn(96, 64, device=dev)
+        for p in (wa, wb, wc):
+            p.grad = None
+        h = ops.linear(x1, wa) + ops.linear(x2, wa) + ops.linear(x1, wb)          # wa feeds two products of the same graph
+        loss = ops.linear(h, wc).square().sum()
+        ops.backward(loss)
+        gs.sync()
+        got = [p.grad.detach().cpu().clone() for p in (wa, wb, wc)]
+        wa_, wb_, wc_ = (p.detach().clone().requires_grad_(True) for p in (wa, wb, wc))
+        h_ = x1 @ wa_.T + x2 @ wa_.T + x1 @ wb_.T
+        (h_ @ wc_.T).square().sum().backward()
+        res.append(dict(got=got, want=[p.grad.cpu() for p in (wa_, wb_, wc_)], learnt=gs._early is not None))
+    dist.barrier(); dist.destroy_process_group()
+    torch.save(res, out_path)
+
+
 def _spawn1(target, args):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -164,3 +195,13 @@ def test_dp_steps_replayed_as_graphs_beside_rccl(tmp_path):
     assert r[False]["forms"] == ["sharded"] * 5 and r[True]["forms"] == ["staged_dp"] * 5
     for x, y in zip(r[False]["weights"], r[True]["weights"]):
         torch.testing.assert_close(x, y, rtol=1e-4, atol=2e-5)
+
+
+def test_weight_used_twice_gets_its_bucket_slot_once(tmp_path):
+    out = str(tmp_path / "s.pt")
+    _spawn1(_worker_shared_weight, (True, _free_port(), out))
+    res = torch.load(out, weights_only=False)
+    assert res[1]["learnt"] and res[2]["learnt"]           # steps 1 and 2 ran with persistent buckets + gradient sinks
+    for r in res:
+        for g, w in zip(r["got"], r["want"]):
+            torch.testing.assert_close(g, w, rtol=1e-4, atol=1e-5)

@@ -225,3 +225,16 @@ def test_pbr_strategy_keeps_trend_priorities_on_the_device():
     for (ids, pr), ls in zip(seen, losses_seen):
         want = twin.get_priorities(ids, ls)
         np.testing.assert_allclose(pr.cpu().numpy(), np.asarray(want, dtype=np.float64), rtol=1e-11, atol=1e-13)
+    # the host object the driver handed in is not left stale (round-3 advisor finding): read through the strategy it is brought
+    # up to date from the device state — and equals the twin that lived on the host all along
+    host = strat.priority_strategy
+    assert host is strat._priority_strategy and not strat._device_trend.dirty
+    np.testing.assert_allclose(host.trend_p.values, twin.trend_p.values, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(host.trend_p.prev_loss, twin.trend_p.prev_loss, rtol=0, atol=0)
+    assert host.trend_p.n_items == twin.trend_p.n_items and np.array_equal(host.trend_p.init, twin.trend_p.init)
+    # the kernel's preconditions are checked where the ids come from (the host): out of range / duplicates never reach the tree
+    ls = torch.zeros(2, device="cuda")
+    with pytest.raises(IndexError):
+        strat._priorities_device(np.array([0, n_vertices]), ls)
+    with pytest.raises(ValueError):
+        strat._priorities_device(np.array([3, 3]), ls)
