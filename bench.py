@@ -32,6 +32,20 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/
 MFMA_F32_PEAK_TFLOPS = 157.3
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense (MI355X_MICROARCH.md); AMD's 5 PF headline includes 2:1 sparsity
 
+def norm_kernel(name):
+    """Canonical (kernel, template arguments...) of an image-GEMM instantiation, from either spelling: what ogl_x3_last_kernel() reports
+    ('k_gemm_x3p<4, 2, 2, 2, 2, false, true>': arguments as written at the launch site) or what rocprofv3 prints
+    ('k_gemm_x3p<4, 2, 2, 2, 2, false, true, false, 0, 0>(X3Args)': every argument).  None when it is not a template-id."""
+    import re
+    m = re.match(r"\s*(\w+)<([^>]*)>", name or "")
+    if not m:
+        return None
+    a = [x.strip() for x in m.group(2).split(",")]
+    if m.group(1) == "k_gemm_x3p" and 5 <= len(a) < 10:
+        a += ["false", "false", "false", "0", "0"][len(a) - 5:]           # EXT, BK, AK, RH, CH (csrc/linear_x3.hip)
+    return (m.group(1),) + tuple(a)
+
+
 WORKLOADS = {
     # name:     dataset  B    S   H    batch_timestep
     "reddit_rbr": dict(dataset="reddit", batch=512, samples=25, hidden=600, batch_timestep=50),
@@ -326,11 +340,28 @@ def main():
             key = name[4:] + ("_pool0" if meta["M"] > B * (1 + S) else "_other")
         a = agg.setdefault(key, dict(ms=0.0, calls=0, bytes=0.0, flops=0.0))
         a["ms"] += ms; a["calls"] += 1
+        if meta and meta.get("kernel"):
+            a.setdefault("kernel_names", set()).add(meta["kernel"])
         if name in ("ogl_reduce_fwd", "ogl_reduce_fwd_img"):
             E = meta["n_dst"] * meta["fanout"]
             a["bytes"] += E * (4 * meta["d"] + meta["idx_bytes"]) + meta["n_dst"] * 4 * meta["d"] * (2 if meta["argmax"] else 1)
             if name == "ogl_reduce_fwd_img":
                 a["bytes"] += meta["n_dst"] * 6 * meta["d"]          # + the image: three bf16 planes per element
+        # mandatory bytes of the other HBM-bound launches (for roofline.composite_floor_ms; every matrix counted once per pass over it)
+        if name in ("ogl_pool_bwd_x3", "ogl_pool_bwd_x3_apply"):     # dout read + the group-major bf16x3 image of dP^T written
+            a["bytes"] += meta["n_dst"] * 4 * meta["d"] + (meta["n_src"] + 31) // 32 * 32 * 6 * meta["d"]
+        elif name == "ogl_pool_bwd_x3_plan":                         # argmax + pooled rows read, 2-byte (column, slot) ids written
+            a["bytes"] += meta["n_dst"] * meta["d"] * (4 + 4 + 2)
+        elif name == "ogl_relu_bwd_img":                             # dy, y read; masked dy + its image written
+            a["bytes"] += meta["M"] * meta["N"] * (4 + 4 + 4 + 6)
+        elif name == "ogl_x3_split":
+            a["bytes"] += meta["R"] * meta["K"] * (4 + 6)
+        elif name in ("ogl_adam_step_multi", "ogl_adam_step_multi_dev", "ogl_adam_step"):
+            a["bytes"] += meta["n"] * 4 * 7                           # p, g, m, v read; p, m, v written
+        elif name == "ogl_out_layer_bwd_inputs":                     # dy . W scattered with float atomics into an [n_src, K] target
+            a["bytes"] += meta["M"] * meta["K"] * 4 * 2
+        elif name == "ogl_fill_zero":
+            a["bytes"] += meta["bytes"]
         if name in ("ogl_linear_fwd", "ogl_linear_fwd_x3", "ogl_linear_fwd_x3_ext"):
             a["flops"] += 2.0 * meta["M"] * meta["N"] * (meta["K"] + meta["K2"])
         if name in ("ogl_linear_bwd_input", "ogl_linear_bwd_weight", "ogl_linear_bwd_weight_t", "ogl_linear_bwd_weight_x3",
@@ -347,9 +378,12 @@ def main():
                          peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
                          avg_launch_ms=round(ragg["ms"] / ragg["calls"], 4),
                          algorithmic_bytes_per_launch=round(ragg["bytes"] / ragg["calls"]),
+                         frac_kind="algorithmic bytes / launch time / 8 TB/s (SURVEY 8(d)): cache re-serves count as bytes, so this is NOT a pin rate",
                          note="algorithmic bytes count every gathered row once per gather; a row gathered again while it is still in L2 / "
-                         "the 256 MB infinity cache does not come from HBM, so the algorithmic rate can approach or exceed the "
-                         "8 TB/s pin rate — `traffic` (PMC) is what crossed the HBM interface")
+                         "the 256 MB Infinity Cache does not come from HBM, so the algorithmic rate can approach or exceed the "
+                         "8 TB/s pin rate.  `traffic` (PMC FETCH_SIZE x 2 + WRITE_SIZE) is the L2's fabric-side request bytes: "
+                         "Infinity-Cache hits are included (MI355X_MICROARCH.md), so traffic / time bounds the HBM rate from above — "
+                         "a plain streamed copy tops out at ~6.3 TB/s on this part")
     gemm_keys = [k for k in agg if k.startswith("linear") and agg[k]["flops"] > 0]
     gflops = sum(agg[k]["flops"] for k in gemm_keys); gms = sum(agg[k]["ms"] for k in gemm_keys)
     # the dominant GEMM = the single LAUNCH (one shape, one kernel) with the longest duration; the "*_other" keys pool
@@ -370,6 +404,29 @@ def main():
                          peak_note=("fp32-equivalent roof of the x6 arithmetic: dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per "
                                     "product (vs 157.3 TFLOP/s for the exact-fp32 MFMA)") if x6 else "dense fp32 MFMA peak",
                          all_gemms_tflops=round(gflops / gms / 1e9, 2) if gms else None)
+
+    # ---- the whole step against its COMPOSITE roofline: every GEMM at the MFMA roof of its arithmetic + every HBM-bound launch at the
+    # HBM peak, summed (no overlap assumed between the two: the step's launches are dependent) — ms_per_step / this = how far the step
+    # as a whole is from its kernels' rooflines
+    composite = None
+    if gemm_keys:
+        x6_roof, f32_roof = BF16_MFMA_PEAK_TFLOPS / 6.0, MFMA_F32_PEAK_TFLOPS
+        fl_x6 = sum(v["flops"] for k, v in agg.items() if v["flops"] and args.gemm != "f32" and ("_x3" in k or "bwd_weight" not in k))
+        fl_f32 = sum(v["flops"] for v in agg.values()) - fl_x6
+        mfma_ms = (fl_x6 / (x6_roof * 1e9) + fl_f32 / (f32_roof * 1e9)) / prof_steps
+        hbm_bytes = sum(v["bytes"] for k, v in agg.items() if v["bytes"] and not v["flops"])
+        hbm_ms = hbm_bytes / (HBM_PEAK_GBS * 1e6) / prof_steps
+        composite = dict(mfma_floor_ms=round(mfma_ms, 4), hbm_floor_ms=round(hbm_ms, 4), composite_floor_ms=round(mfma_ms + hbm_ms, 4),
+                         gemm_gflop_per_step=round(sum(v["flops"] for v in agg.values()) / prof_steps / 1e9, 2),
+                         hbm_algorithmic_mb_per_step=round(hbm_bytes / prof_steps / 1e6, 1),
+                         counted_hbm_launches=sorted(k for k, v in agg.items() if v["bytes"] and not v["flops"]),
+                         what="sum over the step's launches of (GEMM flops / MFMA roof of the launch's arithmetic: %.0f TFLOP/s fp32-equivalent "
+                              "for split-bf16 x6, %.1f for exact fp32) + (algorithmic bytes of the HBM-bound launches / %.0f GB/s)"
+                              % (x6_roof, f32_roof, HBM_PEAK_GBS))
+
+        if roof_gemm:                                  # (also inside `roofline`: the whole-step fraction beside the dominant launch's)
+            roof_gemm["composite_floor_ms"] = composite["composite_floor_ms"]
+            roof_gemm["step_frac_of_composite_floor"] = round(composite["composite_floor_ms"] / (1000 * elapsed / args.steps), 4)
 
     # ---- CPU baseline: the oracle ("port" of the reference path) on this node's host cores ---------
     cpu_baseline = None
@@ -425,13 +482,24 @@ def main():
             "profiles/" + PMC_TRAFFIC_FILE, pmc.get("collected", "?"), pmc.get("head", "?"))
         if roof_aggr and args.workload == "reddit_rbr":
             roof_aggr["traffic"] = pmc["k_reduce_fwd_v4_L0"]["traffic_bytes"]
-            roof_aggr["traffic_source"] = stamp + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+            roof_aggr["traffic_source"] = stamp + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes: fabric-side requests of the L2 — " \
+                                                  "Infinity-Cache hits are counted, so this bounds the HBM bytes from above)"
         if roof_gemm and args.workload == "reddit_rbr" and args.gemm == "auto":
             key = {"linear_fwd_x3_pool0": "k_gemm_x3_fwd_pool0", "linear_bwd_weight_x3_pool0": "k_gemm_x3_bww_pool0",
                    "linear_bwd_weight_x3k_pool0": "k_gemm_x3_bwwk_pool0"}.get(dom)
             if key and key in pmc:
-                roof_gemm["traffic"] = pmc[key]["traffic_bytes"]
-                roof_gemm["traffic_source"] = stamp + " (HBM-side bytes per launch; an MFMA-bound kernel)"
+                # the constant is only quoted beside the instantiation it was counted on: a tile / kernel change since the PMC pass
+                # makes it stale, and then the line says so instead of carrying the old bytes
+                ran = {norm_kernel(n) for n in agg[dom].get("kernel_names", ())}
+                counted = norm_kernel(pmc[key].get("kernel"))
+                roof_gemm["kernel_instantiation"] = sorted(agg[dom].get("kernel_names", ()))
+                if ran == {counted}:
+                    roof_gemm["traffic"] = pmc[key]["traffic_bytes"]
+                    roof_gemm["traffic_source"] = stamp + " (fabric-side bytes per launch — L2 misses, Infinity-Cache hits included; an " \
+                                                          "MFMA-bound kernel; same instantiation as timed here: %s)" % pmc[key].get("kernel")
+                else:
+                    roof_gemm["traffic_source"] = "DROPPED: profiles/%s counted %s, this run timed %s — re-collect the PMC pass" % (
+                        PMC_TRAFFIC_FILE, pmc[key].get("kernel"), sorted(agg[dom].get("kernel_names", ())))
     except Exception:
         pass
 
@@ -478,6 +546,8 @@ def main():
                        "avg_unique_input_nodes_n0": round(n0_avg, 1), "avg_n1": round(n1_avg, 1), "setup_s": round(setup_s, 1)},
             "roofline": roof_gemm if roof_gemm else roof_aggr,
             "roofline_aggregator": roof_aggr,
+            "roofline_step": (dict(composite, ms_per_step=round(1000 * elapsed / args.steps, 4),
+                                   frac=round(composite["composite_floor_ms"] / (1000 * elapsed / args.steps), 4)) if composite else None),
             "hbm_copy_measured": hbm_copy,
             "host_enqueue_ms_per_step": round(host_ms, 4),
             "graph_mode": graph_mode,
@@ -690,9 +760,11 @@ def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size,
                     achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
                     avg_launch_ms=round(full_ms, 4),
                     algorithmic_bytes_per_launch=round(full_bytes),
-                    note="algorithmic bytes count every gathered row once per gather; a row gathered again while it is still in L2 / "
-                    "the 256 MB infinity cache does not come from HBM, so the algorithmic rate can approach or exceed the "
-                    "8 TB/s pin rate — `traffic` (PMC) is what crossed the HBM interface")
+                    frac_kind="algorithmic bytes / launch time / 8 TB/s (SURVEY 8(d)): rows gathered again within a chunk are re-served by "
+                              "L2 / the Infinity Cache and still count, so frac can exceed 1 — it is NOT a pin rate",
+                    note="`traffic` (PMC FETCH_SIZE x 2 + WRITE_SIZE) is the L2's fabric-side request bytes per launch: Infinity-Cache (MALL) "
+                    "hits are included (MI355X_MICROARCH.md), so traffic / time is an upper bound on the HBM rate (a plain streamed copy "
+                    "reaches ~6.3 TB/s on this part; anything above that in traffic / time is MALL-served)")
     tkeys = [k for k in agg if k.endswith("_tables")]
     table_build = None
     if tkeys:

@@ -278,6 +278,11 @@ int ogl_x3_debug_stamps(void* buf, int reserved);
  * returns to the automatic choice.  Every tile computes every output element with the same sequence of MFMAs: results are
  * bit-identical across tiles.  OGL_EINVAL outside [-1, 4].  Not part of the hot path. */
 int ogl_x3_debug_tile(int cfg);
+/* Diagnostics (bench.py): the image-GEMM instantiation the LAST ogl_linear_*_x3* call launched, template arguments as written at the
+ * launch site (trailing defaults omitted), e.g. "k_gemm_x3p<4, 2, 2, 2, 2, false, true>"; "" before the first launch.  Static storage.
+ * bench.py compares it with the kernel name recorded in the committed rocprofv3 --pmc pass before quoting that pass's HBM-side
+ * traffic beside a launch it timed (a tile / kernel change makes the quoted constant stale).  Not part of the hot path. */
+const char* ogl_x3_last_kernel(void);
 
 int ogl_linear_fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
                       const void* w_img, int N, int relu, float* y, int64_t ldy, ogl_stream_t stream);

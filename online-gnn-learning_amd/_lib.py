@@ -65,6 +65,7 @@ SIGNATURES = {
     "ogl_x3_split_t": (_i, [_p, _i64, _p, _i64, _i64, _i, _i, _i64, _p, _p]),
     "ogl_x3_debug_stamps": (_i, [_p, _i]),
     "ogl_x3_debug_tile": (_i, [_i]),
+    "ogl_x3_last_kernel": (C.c_char_p, []),
     "ogl_linear_fwd_x3": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i, _i, _p, _i64, _p]),
     "ogl_linear_fwd_x3_ext": (_i, [_p, _i64, _p, _i64, _i, _p, _i64, _p, _i64, _i, _i64, _p, _i, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i, _p, _i64,
                                    _p, _p]),

@@ -105,6 +105,29 @@ def sageconv_case(tag, mode, n_dst, n_src, fanout, fin, fout, pool, frac_iso, se
     print("wrote sageconv_%s.npz" % tag, {k: getattr(v, "shape", v) for k, v in out.items()})
 
 
+def sageconv_fullsize_case(mode):
+    """The BASELINE shape: 512 destinations x 25 neighbours over 602 features, pool_feats 600, 600 outputs,
+    through the reference's own SAGEConv (R/train/graphsage/pytorch/aggregator_dgl.py:128-216).  Inputs and weights come from
+    ``fullsize_inputs.make`` (a PCG64 stream the tests regenerate); committed: the reference's outputs, digested (see there)."""
+    import fullsize_inputs as FI
+    inp = FI.make(mode)
+    layer = SAGEConv(FI.FIN, FI.FOUT, mode, feat_drop=0.0, activation=torch.nn.functional.relu, edge_feats=0,
+                     pool_feats=FI.POOL if mode == "meanpool" else None)
+    layer.load_state_dict({k: torch.tensor(v) for k, v in inp["params"].items()})
+    x = torch.tensor(inp["x"], requires_grad=True)
+    blk = FakeBlock(FI.N_SRC, inp["local_idx"])
+    y = layer(blk, x)
+    y.backward(torch.tensor(inp["gy"]))
+    proj, norms, rows = FI.digest(x.grad.numpy(), inp)
+    out = dict(mode=mode, y=y.detach().numpy(), gx_proj=proj.astype(np.float32), gx_norms=norms.astype(np.float32),
+               gx_rows=rows.astype(np.float32))
+    for k, p in layer.named_parameters():
+        g = p.grad.numpy()
+        out["grad." + k] = g[::FI.GRAD_ROW_STRIDE] if g.ndim == 2 else g
+    np.savez_compressed(os.path.join(OUT, "fullsize_%s.npz" % mode), **out)
+    print("wrote fullsize_%s.npz" % mode, {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 def replay_cases():
     res = {}
     # segment tree
@@ -190,5 +213,8 @@ if __name__ == "__main__":
     sageconv_case("mean_mid", "mean", 96, 700, 25, 50, 32, None, 0.1, 21)
     sageconv_case("meanpool_mid", "meanpool", 96, 700, 25, 50, 32, 40, 0.1, 22)
     sageconv_case("gcn_mid", "gcn", 96, 700, 25, 50, 32, None, 0.1, 23)
+    sys.path.insert(0, OUT)
+    sageconv_fullsize_case("mean")
+    sageconv_fullsize_case("meanpool")
     replay_cases()
     priority_cases()

@@ -100,6 +100,43 @@ def test_sageconv_matches_reference_golden(pkg, path):
         np.testing.assert_allclose(p.grad.cpu().numpy(), g["grad." + k], rtol=1e-3, atol=2e-5)
 
 
+@pytest.mark.parametrize("gemm", ["f32", "auto"])
+@pytest.mark.parametrize("mode", ["mean", "meanpool"])
+def test_sageconv_matches_reference_golden_at_the_baseline_shape(pkg, mode, gemm):
+    """SURVEY.md §8(c) G1 at the BASELINE shape: the HIP layer against the reference's own SAGEConv on the 512 x 25 x 602 block
+    (pool_feats 600, 600 outputs).  Inputs / weights: the PCG64 stream of tests/golden/fullsize_inputs.py, regenerated here; the
+    reference's outputs: tests/golden/fullsize_<mode>.npz.  §8(c) tolerances: rtol 1e-4 / atol 1e-5 on the embeddings, gradients
+    1e-3 (atomics reorder sums) with the absolute part scaled to each tensor's size."""
+    import sys
+    from ogl_amd import ops
+    from ogl_amd.graphsage import SAGEConv
+    from ogl_amd.sampling import Block
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import fullsize_inputs as FI
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fullsize_%s.npz" % mode))
+    inp = FI.make(mode)
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode(gemm)
+    try:
+        layer = SAGEConv(FI.FIN, FI.FOUT, mode, activation=F.relu, pool_feats=FI.POOL if mode == "meanpool" else None).cuda()
+        layer.load_state_dict({k: torch.tensor(v) for k, v in inp["params"].items()})
+        blk = Block(torch.arange(FI.N_SRC).cuda(), torch.arange(FI.N_DST).cuda(), cuda(inp["local_idx"]))
+        x = cuda(inp["x"]).requires_grad_(True)
+        y = layer(blk, x)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), g["y"], rtol=1e-4, atol=1e-5)
+        y.backward(cuda(inp["gy"]))
+        proj, norms, rows = FI.digest(x.grad.cpu().numpy(), inp)
+        np.testing.assert_allclose(proj, g["gx_proj"], rtol=1e-3, atol=1e-5 * float(np.abs(g["gx_proj"]).max()))
+        np.testing.assert_allclose(norms, g["gx_norms"], rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(rows, g["gx_rows"], rtol=1e-3, atol=1e-5)
+        for k, p in layer.named_parameters():
+            got = p.grad.cpu().numpy()
+            got = got[::FI.GRAD_ROW_STRIDE] if got.ndim == 2 else got
+            np.testing.assert_allclose(got, g["grad." + k], rtol=1e-3, atol=2e-5 * float(np.abs(g["grad." + k]).max()))
+    finally:
+        ops.set_gemm_mode(prev)
+
+
 def _copy_params(model, layer_params):
     with torch.no_grad():
         for l, prm in zip(model.layers, layer_params):

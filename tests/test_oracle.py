@@ -108,6 +108,32 @@ def test_layer_matches_reference_golden(path):
         np.testing.assert_allclose(p.grad.numpy(), g["grad." + k], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("mode", ["mean", "meanpool"])
+def test_layer_matches_reference_golden_at_the_baseline_shape(mode):
+    """the 512 x 25 x 602 block (pool_feats 600, 600 outputs) through the reference's own SAGEConv
+    (tests/golden/make_golden.py::sageconv_fullsize_case; inputs regenerated from the PCG64 stream of fullsize_inputs.py):
+    the oracle reproduces its output in full and every stored piece of its gradients."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import fullsize_inputs as FI
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fullsize_%s.npz" % mode))
+    inp = FI.make(mode)
+    params = {k: torch.tensor(v, requires_grad=True) for k, v in inp["params"].items()}
+    x = torch.tensor(inp["x"], requires_grad=True)
+    y = O.sageconv_forward(mode, x, FI.N_DST, inp["local_idx"], params, activation=F.relu)
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-4, atol=1e-5)
+    y.backward(torch.tensor(inp["gy"]))
+    proj, norms, rows = FI.digest(x.grad.numpy(), inp)
+    scale = float(np.abs(g["gx_proj"]).max())
+    np.testing.assert_allclose(proj, g["gx_proj"], rtol=1e-4, atol=1e-5 * scale)
+    np.testing.assert_allclose(norms, g["gx_norms"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(rows, g["gx_rows"], rtol=1e-4, atol=1e-5)
+    for k, p in params.items():
+        got = p.grad.numpy()
+        got = got[::FI.GRAD_ROW_STRIDE] if got.ndim == 2 else got
+        np.testing.assert_allclose(got, g["grad." + k], rtol=1e-4, atol=1e-5 * float(np.abs(g["grad." + k]).max()))
+
+
 def test_pool_layer_shapes_and_zero_degree():
     torch.manual_seed(0)
     prm = O.init_layer_params("pool", 6, 4)
