@@ -149,6 +149,23 @@ int ogl_reduce_fwd_img(const float* src, int64_t lds, int64_t n_src, const int32
 int ogl_reduce_bwd(const float* dout, int64_t ldo, const int32_t* idx32, const int32_t* argmax,
                    const float* relu_out, int64_t ldr, int64_t n_dst, int fanout, int d, int op,
                    int64_t n_src, float* dsrc, int64_t lds, ogl_stream_t stream);
+/* The same backward for mean / sum WITHOUT float atomics and without a zero fill: the edges are sorted by source once per block
+ * (a plan that needs the indices only — it can run beside the forward pass) and the backward is a load-balanced segmented gather
+ * (csrc/reduce_seg.hip), reproducible from run to run:
+ *     dsrc[s, :] = (1 / divisor) * sum_{(dst, j): idx[dst, j] = s} dout[dst, :]      (in edge order; divisor = fanout for the mean)
+ *   ogl_reduce_bwd_seg_plan    counts, scan, placement and ranking of the edges by source into `workspace`
+ *                              (ogl_reduce_bwd_seg_workspace_bytes; 16-byte aligned; ids outside [0, n_src) are skipped);
+ *   ogl_reduce_bwd_seg_apply   the gather, from a planned workspace: rows optionally multiplied by [mask[s, :] > 0] (the ReLU in
+ *                              front of a pooling mean, aggregator_dgl.py:181-185), written as fp32 (`out`, nullable) and / or as
+ *                              the row-major bf16x3 image of [n_src, d] (`image`, ogl_x3_image_bytes(n_src, d), nullable): what
+ *                              ogl_linear_bwd_weight_x3k reads as its dy operand (interleave -1) — the first layer's pooled-row
+ *                              gradient is then never materialised in fp32.  d a multiple of 4, <= 1024; 16-byte aligned rows. */
+int64_t ogl_reduce_bwd_seg_workspace_bytes(int64_t n_dst, int fanout, int d, int64_t n_src);
+int ogl_reduce_bwd_seg_plan(const int32_t* idx, int64_t n_dst, int fanout, int64_t n_src, void* workspace, int64_t workspace_bytes,
+                            ogl_stream_t stream);
+int ogl_reduce_bwd_seg_apply(const float* dout, int64_t ldd, const int32_t* idx, int64_t n_dst, int fanout, int d, int op, int64_t n_src,
+                             const float* mask, int64_t ldm, float* out, int64_t ldo, void* image, void* workspace,
+                             int64_t workspace_bytes, ogl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense projections (torch.nn.Linear inside SAGEConv: fc_pool / fc_self / fc_neigh), fp32 MFMA.
@@ -438,6 +455,34 @@ int ogl_build_block_padded(const int64_t* dst, int64_t n_dst, const int64_t* pic
 int ogl_adam_step_multi_dev(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
                             const int64_t* n, int64_t* step_dev, float* scalars_dev, double lr, double beta1,
                             double beta2, double eps, ogl_stream_t stream);
+
+/* Split-K weight gradients whose reduction is left to the optimiser launch (csrc/linear_x3.hip, csrc/loss_optim.hip).  A k-major
+ * weight gradient runs as nsplit partial products over ranges of the reduction, each written to its own slab, and a reduction launch
+ * then sums the slabs — four ~8 us launches per Reddit train step whose only reader is the optimiser (zero_grad / backward / step,
+ * R/train/graphsage/pytorch/model.py:87,106-107,193,201-202).
+ *   ogl_linear_bwd_weight_x3k_slabs   = ogl_linear_bwd_weight_x3k without that launch: *nsplit_out > 1 -> workspace holds
+ *                                       nsplit slabs [N rows][*ws_ld_out floats] (column K of a row: the bias gradient) and dw / db /
+ *                                       db2 are NOT written; *nsplit_out == 1 -> dw / db / db2 are final.
+ *   ogl_adam_step_multi_slabs         Adam over `count` tensors; tensor i with ws[i] != NULL takes its gradient from slabs:
+ *                                       g_i[r, c] = sum_s ws[i][s * slab_stride[i] + r * ws_ld[i] + col0[i] + c]  (slab order: the bits
+ *                                       of the reduction launch), stores it into g[i] (p.grad holds the gradient afterwards) and
+ *                                       applies it; rows = n[i] / ncols[i].  A bias takes column K of its weight's slabs: ncols 1,
+ *                                       col0 K.  step_dev NULL: host step count `step`; else the device-side count of
+ *                                       ogl_adam_step_multi_dev, incremented (and the scalars refreshed) only when `prepare` != 0 —
+ *                                       a step applied in two launches (gradients that are ready early on a side branch, the rest
+ *                                       at the end) prepares once.
+ *   ogl_x3_slab_reduce                the plain reduction of such slabs into out[rows, ncols] (a gradient somebody reads before
+ *                                       the optimiser runs). */
+int ogl_linear_bwd_weight_x3k_slabs(const void* dyT_img, int64_t interleave, const void* x_img, int64_t x_img_rows,
+                                    const int64_t* x_rows, int64_t x_nrows, int64_t M, int N, int K, int has_ones, float* dw,
+                                    int64_t lddw, float* db, float* db2, void* workspace, int64_t workspace_bytes, int* nsplit_out,
+                                    int64_t* ws_ld_out, ogl_stream_t stream);
+int ogl_adam_step_multi_slabs(int count, float* const* p, float* const* g, float* const* m, float* const* v, const int64_t* n,
+                              const float* const* ws, const int64_t* slab_stride, const int* ws_ld, const int* nsplit,
+                              const int* ncols, const int* col0, int step, int64_t* step_dev, float* scalars_dev, int prepare,
+                              double lr, double beta1, double beta2, double eps, ogl_stream_t stream);
+int ogl_x3_slab_reduce(const float* ws, int64_t slab_stride, int64_t ws_ld, int nsplit, int64_t rows, int ncols, int col0, float* out,
+                       int64_t ldo, ogl_stream_t stream);
 /* K loader batches as ONE block (inference passes: every kernel of the forward is row-independent, so a pass runs them once per
  * chunk of batches instead of once per batch of `batch_full` seeds, R/train/graphsage/pytorch/model.py:224-248).  local_idx is the
  * packed [rows, fanout] index array of the chunk's output blocks, with destination rows [seg_row[s], seg_row[s + 1]) belonging to
@@ -467,9 +512,37 @@ int ogl_publish_i64(const int64_t* src, int n, int64_t* seq_dev, int64_t* dst_ho
 int ogl_out_layer_bwd_inputs(const float* dy, int64_t lddy, int64_t n_dst, int N, int K, const float* w_self, int64_t ldws,
                              const float* w_neigh, int64_t ldwn, const int32_t* argmax, const float* neigh, int64_t ldn, int64_t n_src,
                              float* dx_self, int64_t ldx, float* dP, int64_t ldp, ogl_stream_t stream);
+/* ogl_out_layer_bwd_inputs that also finishes the loss of the forward launch before it (ogl_out_layer_fwd_ce with loss_mean == NULL):
+ * *loss_mean = sum(loss_rows[0 .. n_loss)) / n_loss in the one-workgroup order of ogl_ce_fwd_bwd_mean — a kernel boundary instead of a
+ * last-block-done count (which costs every block of the forward a device-scope fence: an L2 write-back per block on this part). */
+int ogl_out_layer_bwd_inputs_mean(const float* dy, int64_t lddy, int64_t n_dst, int N, int K, const float* w_self, int64_t ldws,
+                                  const float* w_neigh, int64_t ldwn, const int32_t* argmax, const float* neigh, int64_t ldn,
+                                  int64_t n_src, float* dx_self, int64_t ldx, float* dP, int64_t ldp, const float* loss_rows,
+                                  int64_t n_loss, float* loss_mean, ogl_stream_t stream);
 int ogl_out_layer_bwd_weights(const float* dy, int64_t lddy, int64_t M, int N, int K, const float* x_self, int64_t ldxs,
                               const int64_t* x_self_rows, int64_t x_self_nrows, const float* x_neigh, int64_t ldxn, float* dw_self,
                               int64_t lddws, float* dw_neigh, int64_t lddwn, float* db, float* db2, ogl_stream_t stream);
+/* FORWARD of that layer fused with the loss, one launch (csrc/out_layer.hip: k_out_fwd_ce) — the tail of a train step's forward pass:
+ *     neigh[d, :]  = max_j P[idx[d, j], :]            (P = relu(fc_pool(h)) [n_src, K]; argmax[d, c] = first winning row, -1: no neighbour;
+ *                                                      neigh = 0 there: ogl_reduce_fwd(OGL_REDUCE_MAX)'s rule)
+ *     logits[d, :] = h[d, :] . w_self^T + neigh[d, :] . w_neigh^T + b_self + b_neigh          (N <= 64 classes; biases nullable)
+ *     loss_rows[d] = logsumexp(logits[d, :]) - logits[d, label(d)],  label(d) = label_table[label_ids ? label_ids[d] : d]
+ *                    (a label / id out of range: loss 0, no target term — ogl_ce_fwd_bwd's rule)
+ *     dlogits      = grad_scale * (softmax - onehot)        (nullable)
+ *     *loss_mean   = sum(loss_rows) / n_dst, summed by the last block in the one-workgroup order of ogl_ce_fwd_bwd_mean (nullable;
+ *                    `counter`: one zeroed device word, reset by the call)
+ * and zero_buf[0 .. zero_floats) cleared by the same grid (the atomic-scatter target of ogl_out_layer_bwd_inputs; nullable).
+ * Replaces ogl_reduce_fwd + ogl_linear_fwd (dual input) + ogl_ce_fwd_bwd_mean_grid: three latency-bound launches for 512 seeds.
+ * Requirements (ogl_out_layer_fwd_ce_fits): K a multiple of 4 and <= 1024, fanout <= 64, N <= 64; every matrix 16-byte aligned with a
+ * row stride that is a multiple of 4 floats; argmax dense (row stride K).  rows_per_block: 0 = automatic (1, 2 or 4 to pin it).
+ * fp32 FMA arithmetic on the vector ALU; the summation order of a logit differs from ogl_linear_fwd's (same tolerances). */
+int ogl_out_layer_fwd_ce_fits(int64_t n_dst, int fanout, int K, int N);
+int ogl_out_layer_fwd_ce(const float* P, int64_t ldp, int64_t n_src, const int32_t* idx, int64_t n_dst, int fanout, const float* h,
+                         int64_t ldh, int K, const float* w_self, int64_t ldws, const float* w_neigh, int64_t ldwn, const float* b_self,
+                         const float* b_neigh, int N, float* neigh, int64_t ldn, int32_t* argmax, float* logits, int64_t ldl,
+                         const int64_t* label_table, int64_t n_labels, const int64_t* label_ids, float grad_scale, float* loss_rows,
+                         float* dlogits, int64_t lddl, float* loss_mean, unsigned int* counter, float* zero_buf, int64_t zero_floats,
+                         int rows_per_block, ogl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * A whole SMALL 'pool' SAGEConv layer in two launches forward, two launches backward (small_layer.hip):

@@ -40,6 +40,9 @@ SIGNATURES = {
     "ogl_reduce_fwd": (_i, [_p, _i64, _i64, _p, _p, _i64, _i, _i, _i, _p, _i64, _p, _p]),
     "ogl_reduce_fwd_img": (_i, [_p, _i64, _i64, _p, _p, _i64, _i, _i, _p, _i64, _p, _p, _p]),
     "ogl_reduce_bwd": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i, _i, _i, _i64, _p, _i64, _p]),
+    "ogl_reduce_bwd_seg_workspace_bytes": (_i64, [_i64, _i, _i, _i64]),
+    "ogl_reduce_bwd_seg_plan": (_i, [_p, _i64, _i, _i64, _p, _i64, _p]),
+    "ogl_reduce_bwd_seg_apply": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p]),
     "ogl_linear_fwd": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p,
                             _p, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p]),
     "ogl_linear_fwd_dual_bias": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p, _p,
@@ -66,6 +69,9 @@ SIGNATURES = {
     "ogl_x3_debug_stamps": (_i, [_p, _i]),
     "ogl_x3_debug_tile": (_i, [_i]),
     "ogl_x3_last_kernel": (C.c_char_p, []),
+    "ogl_out_layer_fwd_ce_fits": (_i, [_i64, _i, _i, _i]),
+    "ogl_out_layer_fwd_ce": (_i, [_p, _i64, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p, _i64, _p, _p, _i, _p, _i64, _p, _p, _i64,
+                                  _p, _i64, _p, _f, _p, _p, _i64, _p, _p, _p, _i64, _i, _p]),
     "ogl_linear_fwd_x3": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i, _i, _p, _i64, _p]),
     "ogl_linear_fwd_x3_ext": (_i, [_p, _i64, _p, _i64, _i, _p, _i64, _p, _i64, _i, _i64, _p, _i, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i, _p, _i64,
                                    _p, _p]),
@@ -86,6 +92,7 @@ SIGNATURES = {
     "ogl_adam_step_multi": (_i, [_i, _p, _p, _p, _p, _p, _i, _d, _d, _d, _d, _p]),
     "ogl_sample_layer_dev": (_i, [_p, _p, _i64, _i, _u64, _p, _i, _p, _p]),
     "ogl_out_layer_bwd_inputs": (_i, [_p, _i64, _i64, _i, _i, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _p]),
+    "ogl_out_layer_bwd_inputs_mean": (_i, [_p, _i64, _i64, _i, _i, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p]),
     "ogl_out_layer_bwd_weights": (_i, [_p, _i64, _i64, _i, _i, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p]),
     "ogl_small_pool_layer_fits": (_i, [_i64, _i64, _i, _i, _i]),
     "ogl_small_pool_layer_workspace_floats": (_i64, [_i64, _i64, _i]),
@@ -100,6 +107,10 @@ SIGNATURES = {
     "ogl_priority_trend": (_i, [_p, _p, _p, _i64, _i64, _p, _p, _p, _p, _d, _d, _p, _p, _p]),
     "ogl_build_block_padded": (_i, [_p, _i64, _p, _i, _p, _i64, _p, _p, _p, _i64, _p]),
     "ogl_adam_step_multi_dev": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _d, _d, _d, _d, _p]),
+    "ogl_linear_bwd_weight_x3k_slabs": (_i, [_p, _i64, _p, _i64, _p, _i64, _i64, _i, _i, _i, _p, _i64, _p, _p, _p, _i64,
+                                             C.POINTER(C.c_int), C.POINTER(C.c_int64), _p]),
+    "ogl_adam_step_multi_slabs": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _d, _d, _d, _d, _p]),
+    "ogl_x3_slab_reduce": (_i, [_p, _i64, _i64, _i, _i64, _i, _i, _p, _i64, _p]),
     "ogl_publish_i64": (_i, [_p, _i, _p, _p, _p]),
     "ogl_stage_segments": (_i, [_i, _p, _p, _p, _p, _p, _i64, _p]),
     "ogl_fuse_block_segments": (_i, [_p, _p, _i, _p, _p, _i, _p, _p]),

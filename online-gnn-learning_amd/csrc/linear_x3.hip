@@ -50,6 +50,7 @@ struct X3Args {
   float* ws; int64_t ws_ld;
   int NI, NJ;
   int force_cfg0;               // the k-major weight gradient on the 256 x 128 tile (x3_bwwk_cfg0)
+  int defer_reduce;             // host side only: launch_x3 leaves the split-K slabs unreduced (the optimiser launch sums them)
   int xcd_slabs;                // k_gemm_x3p: deal WHOLE split-K slabs to the XCDs (see decode)
   unsigned long long* stamps;   // diagnostics only (ogl_x3_debug_stamps): per block {s_memtime, s_memrealtime} at entry and exit
   // ---- extensions, k_gemm_x3p<..., EXT = true> only (forward products, nsplit == 1) ----
@@ -1351,7 +1352,7 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
   hipLaunchKernelGGL((k_gemm_x3<2, 4, 2, 1, false>), grid, block, 0, stream, g);
   OGL_CHECK_LAUNCH();
   }
-  if (g.nsplit > 1) {
+  if (g.nsplit > 1 && !g.defer_reduce) {
     hipLaunchKernelGGL(k_x3_splitk_reduce, dim3((unsigned)min((int64_t)2048, ogl_cdiv(g.M * g.N, 256))), dim3(256), 0, stream, g);
     OGL_CHECK_LAUNCH();
   }
@@ -1456,10 +1457,10 @@ extern "C" int64_t ogl_linear_bwd_weight_x3k_workspace_bytes(int64_t M, int64_t 
   return (int64_t)nsplit * N * ogl_round_up(K + 1, 4) * 4;
 }
 
-extern "C" int ogl_linear_bwd_weight_x3k(const void* dyT_img, int64_t interleave, const void* x_img, int64_t x_img_rows,
-                                         const int64_t* x_rows, int64_t x_nrows, int64_t M, int N, int K, int has_ones, float* dw,
-                                         int64_t lddw, float* db, float* db2, void* workspace, int64_t workspace_bytes,
-                                         ogl_stream_t stream) {
+static int bwd_weight_x3k(const void* dyT_img, int64_t interleave, const void* x_img, int64_t x_img_rows,
+                          const int64_t* x_rows, int64_t x_nrows, int64_t M, int N, int K, int has_ones, float* dw,
+                          int64_t lddw, float* db, float* db2, void* workspace, int64_t workspace_bytes,
+                          ogl_stream_t stream, int defer, int* nsplit_out, int64_t* ws_ld_out) {
   // interleave == -1: `dyT_img` is the ROW-MAJOR image of dy itself ([M + 1 rows, N], ogl_relu_bwd_img / ogl_x3_split): read k-major too
   const bool dy_rows = interleave == -1;
   if (dy_rows) interleave = 0;
@@ -1489,7 +1490,57 @@ extern "C" int ogl_linear_bwd_weight_x3k(const void* dyT_img, int64_t interleave
     if (!workspace || workspace_bytes < (int64_t)g.nsplit * N * g.ws_ld * 4) return OGL_EWORKSPACE;
     g.ws = (float*)workspace;
   }
+  g.defer_reduce = defer;
+  if (nsplit_out) *nsplit_out = g.nsplit;
+  if (ws_ld_out) *ws_ld_out = g.nsplit > 1 ? g.ws_ld : 0;
   return launch_x3(g, (hipStream_t)stream);
+}
+
+extern "C" int ogl_linear_bwd_weight_x3k(const void* dyT_img, int64_t interleave, const void* x_img, int64_t x_img_rows,
+                                         const int64_t* x_rows, int64_t x_nrows, int64_t M, int N, int K, int has_ones, float* dw,
+                                         int64_t lddw, float* db, float* db2, void* workspace, int64_t workspace_bytes,
+                                         ogl_stream_t stream) {
+  return bwd_weight_x3k(dyT_img, interleave, x_img, x_img_rows, x_rows, x_nrows, M, N, K, has_ones, dw, lddw, db, db2, workspace,
+                        workspace_bytes, stream, 0, nullptr, nullptr);
+}
+
+// The same product with its split-K reduction LEFT TO THE CONSUMER: when *nsplit_out > 1 the call has written nsplit slabs
+// workspace[s][N rows][*ws_ld_out floats] (s-th partial sum of [dw | db] over its range of the reduction, column K = the bias gradient)
+// and NOTHING into dw / db / db2; the gradient is sum_s slab_s in slab order — what ogl_adam_step_multi*_slabs and ogl_x3_slab_reduce
+// compute (the same order as the reduction launch of ogl_linear_bwd_weight_x3k: identical bits).  *nsplit_out == 1: dw / db / db2
+// are final, as after ogl_linear_bwd_weight_x3k.  Four ~8 us reduction launches per Reddit train step exist only to sum slabs the
+// optimiser is about to read.
+extern "C" int ogl_linear_bwd_weight_x3k_slabs(const void* dyT_img, int64_t interleave, const void* x_img, int64_t x_img_rows,
+                                               const int64_t* x_rows, int64_t x_nrows, int64_t M, int N, int K, int has_ones,
+                                               float* dw, int64_t lddw, float* db, float* db2, void* workspace,
+                                               int64_t workspace_bytes, int* nsplit_out, int64_t* ws_ld_out, ogl_stream_t stream) {
+  if (!nsplit_out || !ws_ld_out) return OGL_EINVAL;
+  return bwd_weight_x3k(dyT_img, interleave, x_img, x_img_rows, x_rows, x_nrows, M, N, K, has_ones, dw, lddw, db, db2, workspace,
+                        workspace_bytes, stream, 1, nsplit_out, ws_ld_out);
+}
+
+// out[r, c] = sum_s ws[s * slab_stride + r * ws_ld + col0 + c] (slab order): the reduction of deferred slabs for a consumer that is
+// not the optimiser launch (a gradient somebody reads before the step).
+__global__ void __launch_bounds__(256) k_x3_slab_reduce(const float* __restrict__ ws, int64_t slab_stride, int64_t ws_ld, int nsplit,
+                                                        int64_t rows, int ncols, int col0, float* __restrict__ out, int64_t ldo) {
+  const int64_t total = rows * ncols;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = t / ncols, col = t - row * ncols;
+    float v = 0.f;
+    for (int s = 0; s < nsplit; ++s) v += ws[(int64_t)s * slab_stride + row * ws_ld + col0 + col];
+    out[row * ldo + col] = v;
+  }
+}
+
+extern "C" int ogl_x3_slab_reduce(const float* ws, int64_t slab_stride, int64_t ws_ld, int nsplit, int64_t rows, int ncols, int col0,
+                                  float* out, int64_t ldo, ogl_stream_t stream) {
+  if (nsplit <= 0 || rows < 0 || ncols <= 0 || col0 < 0 || ws_ld < col0 + ncols || ldo < ncols || slab_stride < rows * ws_ld) return OGL_EINVAL;
+  if (rows == 0) return OGL_OK;
+  if (!ws || !out) return OGL_EINVAL;
+  hipLaunchKernelGGL(k_x3_slab_reduce, dim3((unsigned)min((int64_t)2048, ogl_cdiv(rows * ncols, 256))), dim3(256), 0, (hipStream_t)stream,
+                     ws, slab_stride, ws_ld, nsplit, rows, ncols, col0, out, ldo);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
 }
 
 extern "C" int ogl_linear_bwd_weight_x3(const void* dyT_img, const void* xT_img, int64_t M, int N, int K, float* dw,

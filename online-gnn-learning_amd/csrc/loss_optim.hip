@@ -4,6 +4,7 @@
 // Both are tiny HBM-bound elementwise/row kernels.
 #include <algorithm>
 #include "ogl_common.h"
+#include "x6_arith.h"
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -211,6 +212,18 @@ extern "C" int ogl_ce_fwd_bwd_mean_grid_gather(const float* logits, int64_t ldl,
                       zero_floats, stream);
 }
 
+// The update of one element, with every rounding spelled out (explicit fused multiply-adds, no contraction left to the compiler):
+// the kernels below inline this into different loops — plain gradients, gradients summed from split-K slabs, one or two launches per
+// step — and all of them must produce the same bits from the same inputs.
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float one_minus_b1, float b2, float one_minus_b2,
+                                         float inv_sqrt_bc2, float step_size, float eps) {
+#pragma clang fp contract(off)
+  m = __fmaf_rn(one_minus_b1, g - m, m);                     // exp_avg.lerp_(g, 1 - beta1)
+  v = __fmaf_rn(one_minus_b2 * g, g, v * b2);                // exp_avg_sq.mul_(beta2).addcmul_(g, g, value = 1 - beta2)
+  const float denom = __fmaf_rn(sqrtf(v), inv_sqrt_bc2, eps);
+  p = __fmaf_rn(-step_size, m / denom, p);
+}
+
 // torch.optim.Adam single-tensor form: m.lerp_(g, 1-b1); v = b2*v + (1-b2)*g*g;
 // denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= (lr/(1-b1^t)) * m/denom
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g,
@@ -218,14 +231,9 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
                                               float one_minus_b1, float b2, float one_minus_b2,
                                               float inv_sqrt_bc2, float step_size, float eps) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float gi = g[i];
-    float mi = m[i];
-    mi = mi + one_minus_b1 * (gi - mi);
-    float vi = v[i] * b2 + one_minus_b2 * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-    p[i] = p[i] - step_size * (mi / denom);
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_one(pi, g[i], mi, vi, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
+    m[i] = mi; v[i] = vi; p[i] = pi;
   }
 }
 
@@ -256,14 +264,16 @@ struct AdamBatch {
   int64_t n[OGL_ADAM_MAX_TENSORS];
 };
 
-// one tensor, grid-strided over blockIdx.x: four elements per thread and trip (16-byte accesses) when the four arrays allow it
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float one_minus_b1, float b2, float one_minus_b2,
-                                         float inv_sqrt_bc2, float step_size, float eps) {
-  m = m + one_minus_b1 * (g - m);
-  v = v * b2 + one_minus_b2 * g * g;
-  p = p - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
-}
+// ... with, per tensor, optional split-K SLABS of its gradient (ogl_linear_bwd_weight_x3k_slabs): the gradient of element
+// (row r, column c) of a [rows, ncols] tensor is sum_s ws[s * slab_stride + r * ws_ld + col0 + c] in slab order — summed here, written
+// to g (so that p.grad holds the gradient afterwards, as if a reduction launch had run) and applied.  ws null: g is read as usual.
+struct AdamSlabs {
+  const float* ws[OGL_ADAM_MAX_TENSORS];
+  int64_t slab_stride[OGL_ADAM_MAX_TENSORS];
+  int32_t ws_ld[OGL_ADAM_MAX_TENSORS], nsplit[OGL_ADAM_MAX_TENSORS], ncols[OGL_ADAM_MAX_TENSORS], col0[OGL_ADAM_MAX_TENSORS];
+};
 
+// one tensor, grid-strided over blockIdx.x: four elements per thread and trip (16-byte accesses) when the four arrays allow it
 __device__ __forceinline__ void adam_range(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                            float* __restrict__ v, int64_t n, float one_minus_b1, float b2, float one_minus_b2,
                                            float inv_sqrt_bc2, float step_size, float eps) {
@@ -287,6 +297,75 @@ __device__ __forceinline__ void adam_range(float* __restrict__ p, const float* _
     adam_one(pi, g[i], mi, vi, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
     m[i] = mi; v[i] = vi; p[i] = pi;
   }
+}
+
+// a slab-backed tensor: one thread per 4 consecutive ELEMENTS of the tensor (its own arrays in aligned 16-byte accesses, fully
+// coalesced); the elements' slab entries are 4 consecutive floats of a slab row (rows are ws_ld floats apart, the tensor's ncols:
+// only 4-byte alignment in common — one unaligned 16-byte load per slab, gfx950 runs in unaligned-access mode) unless the four
+// straddle a row end (once per row: element by element).  Slab order per element: the bits of k_x3_splitk_reduce.
+__device__ __forceinline__ float slab_sum1(const float* __restrict__ src, int64_t slab_stride, int nsplit) {
+  float a = 0.f;
+  for (int s = 0; s < nsplit; ++s) a += src[(int64_t)s * slab_stride];
+  return a;
+}
+
+__device__ __forceinline__ void adam_range_slabs(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                 float* __restrict__ v, int64_t n, const float* __restrict__ ws, int64_t slab_stride,
+                                                 int ws_ld, int nsplit, int ncols, int col0, float one_minus_b1, float b2,
+                                                 float one_minus_b2, float inv_sqrt_bc2, float step_size, float eps) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+  int64_t done = 0;
+  if (ncols >= 4 && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      const int64_t e0 = i << 2;
+      const int64_t row = e0 / ncols;
+      const int col = (int)(e0 - row * ncols);
+      float a[4];
+      if (col + 4 <= ncols) {
+        const float* src = ws + row * ws_ld + col0 + col;
+        a[0] = a[1] = a[2] = a[3] = 0.f;
+        for (int s = 0; s < nsplit; ++s) {
+          const float4 t = ld16(src + (int64_t)s * slab_stride);
+          a[0] += t.x; a[1] += t.y; a[2] += t.z; a[3] += t.w;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int64_t r = (e0 + e) / ncols;
+          a[e] = slab_sum1(ws + r * ws_ld + col0 + (int)(e0 + e - r * ncols), slab_stride, nsplit);
+        }
+      }
+      float4 p4 = ((float4*)p)[i], m4 = ((float4*)m)[i], v4 = ((float4*)v)[i];
+      adam_one(p4.x, a[0], m4.x, v4.x, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
+      adam_one(p4.y, a[1], m4.y, v4.y, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
+      adam_one(p4.z, a[2], m4.z, v4.z, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
+      adam_one(p4.w, a[3], m4.w, v4.w, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
+      ((float4*)g)[i] = make_float4(a[0], a[1], a[2], a[3]);
+      ((float4*)m)[i] = m4; ((float4*)v)[i] = v4; ((float4*)p)[i] = p4;
+    }
+    done = n4 << 2;
+  }
+  for (int64_t i = done + tid; i < n; i += nth) {
+    const int64_t row = i / ncols;
+    const float a = slab_sum1(ws + row * ws_ld + col0 + (int)(i - row * ncols), slab_stride, nsplit);
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_one(pi, a, mi, vi, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
+    g[i] = a; m[i] = mi; v[i] = vi; p[i] = pi;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_adam_multi_slabs(AdamBatch b, AdamSlabs sl, float one_minus_b1, float b2, float one_minus_b2,
+                                                          float inv_sqrt_bc2_host, float step_size_host, const float* __restrict__ scal,
+                                                          float eps) {
+  // scal (device): {step size, 1 / sqrt(1 - beta2^t)} of the device-side step count; null: the host's values
+  const float step_size = scal ? scal[0] : step_size_host, inv_sqrt_bc2 = scal ? scal[1] : inv_sqrt_bc2_host;
+  const int t = blockIdx.y;
+  if (sl.ws[t])
+    adam_range_slabs(b.p[t], (float*)b.g[t], b.m[t], b.v[t], b.n[t], sl.ws[t], sl.slab_stride[t], sl.ws_ld[t], sl.nsplit[t],
+                     sl.ncols[t], sl.col0[t], one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
+  else
+    adam_range(b.p[t], b.g[t], b.m[t], b.v[t], b.n[t], one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
 }
 
 __global__ void __launch_bounds__(256) k_adam_multi(AdamBatch b, float one_minus_b1, float b2, float one_minus_b2,
@@ -371,6 +450,56 @@ extern "C" int ogl_adam_step_multi_dev(int count, float* const* p, const float* 
     dim3 grid((unsigned)min((int64_t)512, ogl_cdiv(nmax, 1024)), (unsigned)c);
     hipLaunchKernelGGL(k_adam_multi_dev, grid, dim3(256), 0, (hipStream_t)stream, b, (float)(1.0 - beta1), (float)beta2,
                        (float)(1.0 - beta2), (const float*)scalars_dev, (float)eps);
+    OGL_CHECK_LAUNCH();
+  }
+  return OGL_OK;
+}
+
+// Adam over tensors some of whose gradients still are split-K slabs (AdamSlabs; all-null slab pointers: plain Adam).
+//   step_dev == null: host step count `step` (as ogl_adam_step_multi);
+//   step_dev != null: the device-side count (as ogl_adam_step_multi_dev); `prepare` != 0 increments it and refreshes the two
+//                     scalars first, prepare == 0 applies with the scalars as they are — a step's SECOND launch (the optimiser
+//                     applied in two parts: everything whose gradient is ready early on a side branch, the rest at the end).
+// ws / slab_stride / ws_ld / nsplit / ncols / col0: host arrays of `count` entries (ws[i] null: tensor i has a plain gradient).
+extern "C" int ogl_adam_step_multi_slabs(int count, float* const* p, float* const* g, float* const* m, float* const* v, const int64_t* n,
+                                         const float* const* ws, const int64_t* slab_stride, const int* ws_ld, const int* nsplit,
+                                         const int* ncols, const int* col0, int step, int64_t* step_dev, float* scalars_dev,
+                                         int prepare, double lr, double beta1, double beta2, double eps, ogl_stream_t stream) {
+  if (count < 0 || (!step_dev && step < 1) || (step_dev && !scalars_dev)) return OGL_EINVAL;
+  if (count > 0 && (!p || !g || !m || !v || !n || !ws || !slab_stride || !ws_ld || !nsplit || !ncols || !col0)) return OGL_EINVAL;
+  float step_size = 0.f, inv_sqrt_bc2 = 0.f;
+  if (step_dev) {
+    if (prepare) {
+      hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, lr, beta1, beta2, scalars_dev);
+      OGL_CHECK_LAUNCH();
+    }
+  } else {
+    step_size = (float)(lr / (1.0 - pow(beta1, step)));
+    inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(beta2, step)));
+  }
+  for (int base = 0; base < count; base += OGL_ADAM_MAX_TENSORS) {
+    AdamBatch b;
+    AdamSlabs sl;
+    const int c = min(OGL_ADAM_MAX_TENSORS, count - base);
+    int64_t nmax = 0;
+    for (int i = 0; i < c; ++i) {
+      const int j = base + i;
+      if (n[j] < 0 || (n[j] > 0 && (!p[j] || !g[j] || !m[j] || !v[j]))) return OGL_EINVAL;
+      b.p[i] = p[j]; b.g[i] = g[j]; b.m[i] = m[j]; b.v[i] = v[j]; b.n[i] = n[j];
+      sl.ws[i] = ws[j]; sl.slab_stride[i] = slab_stride[j]; sl.ws_ld[i] = ws_ld[j]; sl.nsplit[i] = nsplit[j]; sl.ncols[i] = ncols[j];
+      sl.col0[i] = col0[j];
+      if (ws[j]) {
+        if (nsplit[j] < 1 || ncols[j] < 1 || col0[j] < 0 || ws_ld[j] < col0[j] + ncols[j] || n[j] % ncols[j] != 0 ||
+            slab_stride[j] < (n[j] / ncols[j]) * (int64_t)ws_ld[j])
+          return OGL_EINVAL;
+      }
+      nmax = n[j] > nmax ? n[j] : nmax;
+    }
+    for (int i = c; i < OGL_ADAM_MAX_TENSORS; ++i) sl.ws[i] = nullptr;
+    if (nmax == 0) continue;
+    dim3 grid((unsigned)min((int64_t)512, ogl_cdiv(nmax, 1024)), (unsigned)c);
+    hipLaunchKernelGGL(k_adam_multi_slabs, grid, dim3(256), 0, (hipStream_t)stream, b, sl, (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), inv_sqrt_bc2, step_size, (const float*)(step_dev ? scalars_dev : nullptr), (float)eps);
     OGL_CHECK_LAUNCH();
   }
   return OGL_OK;

@@ -1,0 +1,330 @@
+// Segmented backward of the fixed-fanout mean / sum neighbour reduction.
+//
+//     out[d, :] = (1 / S) sum_j src[idx[d, j], :]          (mailbox.mean(axis=1) / .sum(axis=1), R/train/graphsage/pytorch/
+//                                                            aggregator_dgl.py:158,165,185; the autograd of it is what this replaces)
+//     dsrc[s, :] = (1 / S) sum_{(d, j): idx[d, j] = s} dout[d, :]
+//
+// Round 1 scattered dout along the edges with E x D float atomics (Reddit meanpool layer 0: 176 k edges x 600 = 106 M atomics at the
+// ~1.3 TB/s atomic rate: 0.3 ms, behind a 150 MB zero fill, in an order that changes from run to run).  Here the edges are sorted by
+// SOURCE once per block (a plan built from the indices alone: it can run beside the forward pass) and the backward is a gather:
+//
+//   plan   k_seg_count     cnt[s] = #edges into s                         (integer atomics: counts do not depend on their order)
+//          k_seg_bsum / k_seg_scan_sums / k_seg_apply   start[s] = exclusive prefix of cnt (three-phase scan), cursors zeroed
+//          k_seg_place     every edge takes a place in its source's range (atomic cursor: the order INSIDE a range is arbitrary)
+//          k_seg_rank      ... and is moved to its rank among the range's edge ids: sorted[] lists every source's edges in edge
+//                          order — the same list whatever order the atomics ran in, so the sums below are reproducible
+//   apply  k_seg_reduce    one block per TILE of 64 consecutive entries of the sorted list (load-balanced: a hub referenced by a
+//                          thousand destinations is spread over many tiles, no serial tail): the 64 gradient rows are gathered 8 at
+//                          a time (a thread owns one 16-byte column chunk), runs of equal source are summed in list order; a run
+//                          that lies inside the tile is finished on the spot, the (at most two) runs that cross a tile boundary
+//                          leave partial rows
+//          k_seg_fixup     one wave per source: a source whose range spans several tiles sums its partial rows in tile order; a
+//                          source nobody sampled gets its zero row
+// A finished row is scaled by 1 / S (mean), optionally masked by [relu_out[s, :] > 0] (the ReLU in front of a pooling mean:
+// 'meanpool', aggregator_dgl.py:181-185) and written as fp32 and / or as the row-major bf16x3 image the weight-gradient product reads
+// (ogl_linear_bwd_weight_x3k, dy_rows): for the first layer (no input gradient) dsrc itself is never materialised.
+// HBM-bound: E rows of 4 D bytes gathered (from an [n_dst, D] matrix that mostly stays in L2 / MALL) + n_src rows written.
+#include <algorithm>
+#include "ogl_common.h"
+#include "x6_arith.h"
+
+#define SG_TILE 64
+#define SG_THREADS 256
+#define SG_U 8
+#define SG_SCAN 1024
+
+__global__ void __launch_bounds__(256) k_seg_count(const int32_t* __restrict__ idx, int64_t E, int64_t n_src, int* __restrict__ cnt) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+    const int s = idx[e];
+    if (s >= 0 && s < n_src) atomicAdd(&cnt[s], 1);
+  }
+}
+
+// block b: sum of cnt[b * SG_SCAN ..)
+__global__ void __launch_bounds__(SG_SCAN) k_seg_bsum(const int* __restrict__ cnt, int64_t n, int* __restrict__ bsum) {
+  __shared__ int part[SG_SCAN / 64];
+  const int64_t i = (int64_t)blockIdx.x * SG_SCAN + threadIdx.x;
+  int v = i < n ? cnt[i] : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < SG_SCAN / 64; ++w) t += part[w];
+    bsum[blockIdx.x] = t;
+  }
+}
+
+// exclusive scan of the block sums in place (one block; NB <= a few thousand)
+__global__ void __launch_bounds__(SG_SCAN) k_seg_scan_sums(int* __restrict__ bsum, int NB) {
+  __shared__ int buf[SG_SCAN];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < NB; base += SG_SCAN) {
+    const int i = base + threadIdx.x;
+    const int v = i < NB ? bsum[i] : 0;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < SG_SCAN; o <<= 1) {                 // Hillis-Steele inclusive scan
+      const int t = threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
+      __syncthreads();
+      buf[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < NB) bsum[i] = carry + buf[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == SG_SCAN - 1) carry += buf[threadIdx.x];
+    __syncthreads();
+  }
+}
+
+// start[i] = bsum[block] + exclusive prefix inside the block (i in [0, n]: n = n_src, start[n_src] = the number of valid edges);
+// cursors zeroed
+__global__ void __launch_bounds__(SG_SCAN) k_seg_apply(const int* __restrict__ cnt, int64_t n, const int* __restrict__ bsum,
+                                                       int* __restrict__ start, int* __restrict__ cur) {
+  __shared__ int buf[SG_SCAN];
+  const int64_t i = (int64_t)blockIdx.x * SG_SCAN + threadIdx.x;
+  const int v = i < n ? cnt[i] : 0;
+  buf[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 1; o < SG_SCAN; o <<= 1) {
+    const int t = threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
+    __syncthreads();
+    buf[threadIdx.x] += t;
+    __syncthreads();
+  }
+  if (i <= n) start[i] = bsum[blockIdx.x] + buf[threadIdx.x] - v;
+  if (i < n) cur[i] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_seg_place(const int32_t* __restrict__ idx, int64_t E, int64_t n_src, const int* __restrict__ start,
+                                                   int* __restrict__ cur, int* __restrict__ U) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+    const int s = idx[e];
+    if (s >= 0 && s < n_src) U[start[s] + atomicAdd(&cur[s], 1)] = (int)e;
+  }
+}
+
+// thread per placed position: its entry moves to its rank among the entries of the same source (edge ids are distinct)
+__global__ void __launch_bounds__(256) k_seg_rank(const int32_t* __restrict__ idx, const int* __restrict__ U, const int* __restrict__ start,
+                                                  int64_t n_src, int* __restrict__ sorted) {
+  const int total = start[n_src];
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int e = U[t];
+    const int s = idx[e];
+    const int a = start[s], b = start[s + 1];
+    int rank = 0;
+    for (int k = a; k < b; ++k) rank += U[k] < e ? 1 : 0;     // (neighbouring threads walk the same range: broadcast loads)
+    sorted[a + rank] = e;
+  }
+}
+
+struct SegOut {
+  float* out; int64_t ldo;                    // fp32 rows [n_src, D] (nullable)
+  unsigned char* img; int64_t img_row_bytes;  // row-major bf16x3 image, n_src + 1 rows (nullable)
+  const float* mask; int64_t ldm;             // optional: row s is multiplied by [mask[s, :] > 0]
+  float divisor;                              // S for the mean, 1 for the sum
+};
+
+// one finished row chunk (this thread's 4 columns of source s): scale, mask, store
+__device__ __forceinline__ void seg_store(const SegOut& o, int64_t s, int ch, int D, float4 a) {
+  const int b4 = ch * 4;
+  if (o.divisor != 1.f) { a.x /= o.divisor; a.y /= o.divisor; a.z /= o.divisor; a.w /= o.divisor; }
+  if (o.mask && b4 < D) {
+    const float4 m = *(const float4*)(o.mask + s * o.ldm + b4);
+    a.x = m.x > 0.f ? a.x : 0.f; a.y = m.y > 0.f ? a.y : 0.f; a.z = m.z > 0.f ? a.z : 0.f; a.w = m.w > 0.f ? a.w : 0.f;
+  }
+  const float e0 = b4 < D ? a.x : 0.f, e1 = b4 + 1 < D ? a.y : 0.f, e2 = b4 + 2 < D ? a.z : 0.f, e3 = b4 + 3 < D ? a.w : 0.f;
+  if (o.out && b4 < D) {
+    float* p = o.out + s * o.ldo + b4;
+    if (b4 + 4 <= D) *(float4*)p = make_float4(e0, e1, e2, e3);
+    else { p[0] = e0; if (b4 + 1 < D) p[1] = e1; if (b4 + 2 < D) p[2] = e2; }
+  }
+  if (o.img) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3(e0, e1, h0, m0, l0); split3(e2, e3, h1, m1, l1);
+    unsigned char* rp = o.img + s * o.img_row_bytes + (int64_t)(ch >> 3) * 192 + (ch & 1) * 8;
+    const int pc = (ch & 7) >> 1;
+    *(uint2*)(rp + x3_piece(pc, 0) * 16) = make_uint2(h0, h1);
+    *(uint2*)(rp + x3_piece(pc, 1) * 16) = make_uint2(m0, m1);
+    *(uint2*)(rp + x3_piece(pc, 2) * 16) = make_uint2(l0, l1);
+  }
+}
+
+__global__ void __launch_bounds__(SG_THREADS) k_seg_reduce(const float* __restrict__ dout, int64_t ldd, int64_t n_dst, int S, int D,
+                                                           const int32_t* __restrict__ idx, const int* __restrict__ sorted,
+                                                           const int* __restrict__ start, int64_t n_src, SegOut o,
+                                                           float* __restrict__ partial, int64_t ldpart) {
+  __shared__ int se[SG_TILE], ss[SG_TILE];
+  const int total = start[n_src];
+  const int t0 = blockIdx.x * SG_TILE;
+  if (t0 >= total) return;
+  const int t1 = min(total, t0 + SG_TILE), cntk = t1 - t0;
+  const int tid = threadIdx.x;
+  if (tid < SG_TILE) {
+    const int e = tid < cntk ? sorted[t0 + tid] : 0;
+    se[tid] = e / S;                                          // the destination row of the entry
+    ss[tid] = tid < cntk ? idx[e] : -1;
+  }
+  __syncthreads();
+  const int D4 = (D + 3) >> 2;
+  const int Kp4 = o.img ? (int)(o.img_row_bytes / 192) * 8 : D4;   // chunks of the padded image row
+  if (tid >= max(D4, Kp4)) return;
+  const bool cin = tid < D4;
+  const int ch = cin ? tid : D4 - 1;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int cur_s = ss[0], run_k0 = 0;
+  auto flush = [&](int s, int k_begin, int k_end) __attribute__((always_inline)) {
+    // entries [t0 + k_begin, t0 + k_end) of source s
+    const int a = start[s], b = start[s + 1];
+    const float4 v = cin ? acc : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a >= t0 && b <= t1) seg_store(o, s, tid, D, v);
+    else if (cin) *(float4*)(partial + ((int64_t)blockIdx.x * 2 + (k_begin == 0 ? 0 : 1)) * ldpart + 4 * tid) = v;
+  };
+  for (int k0 = 0; k0 < cntk; k0 += SG_U) {
+    float4 v[SG_U];
+#pragma unroll
+    for (int u = 0; u < SG_U; ++u) {                          // unconditional loads (a slot past the tile re-reads its last row)
+      const int k = k0 + u < cntk ? k0 + u : cntk - 1;
+      v[u] = *(const float4*)(dout + (int64_t)se[k] * ldd + 4 * ch);
+    }
+#pragma unroll
+    for (int u = 0; u < SG_U; ++u) {
+      const int k = k0 + u;
+      if (k >= cntk) break;                                   // (block-uniform)
+      if (ss[k] != cur_s) {
+        flush(cur_s, run_k0, k);
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        cur_s = ss[k]; run_k0 = k;
+      }
+      acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+    }
+  }
+  flush(cur_s, run_k0, cntk);
+}
+
+// wave per source (+ one wave for the image's zero row): sources spanning several tiles, sources without an edge
+__global__ void __launch_bounds__(256) k_seg_fixup(const int* __restrict__ start, int64_t n_src, int D, SegOut o,
+                                                   const float* __restrict__ partial, int64_t ldpart) {
+  const int lane = threadIdx.x & 63;
+  const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s > n_src) return;
+  const int D4 = (D + 3) >> 2;
+  const int Kp4 = o.img ? (int)(o.img_row_bytes / 192) * 8 : D4;
+  const int nch = max(D4, Kp4);
+  if (s == n_src) {                                           // the image's all-zero row
+    if (o.img) {
+      SegOut z = o; z.out = nullptr; z.mask = nullptr;
+      for (int ch = lane; ch < nch; ch += 64) seg_store(z, s, ch, D, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    return;
+  }
+  const int a = start[s], b = start[s + 1];
+  if (a == b) {
+    SegOut z = o; z.mask = nullptr;
+    for (int ch = lane; ch < nch; ch += 64) seg_store(z, s, ch, D, make_float4(0.f, 0.f, 0.f, 0.f));
+    return;
+  }
+  const int tf = a / SG_TILE, tl = (b - 1) / SG_TILE;
+  if (tf == tl) return;                                       // finished by its tile
+  for (int ch = lane; ch < nch; ch += 64) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ch < D4) {
+      for (int t = tf; t <= tl; ++t) {                        // tile order: the order of the sorted list
+        const int slot = (t == tf && a > t * SG_TILE) ? 1 : 0;
+        const float4 v = *(const float4*)(partial + ((int64_t)t * 2 + slot) * ldpart + 4 * ch);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    seg_store(o, s, ch, D, acc);
+  }
+}
+
+static int64_t seg_ints(int64_t E, int64_t n_src) {
+  const int64_t nb = ogl_cdiv(n_src + 1, SG_SCAN);
+  // cnt [n_src + 1] | start [n_src + 1] | cur [n_src] | bsum [nb] | U [E] | sorted [E]
+  return (n_src + 1) * 2 + n_src + nb + 2 * E + 16;
+}
+
+extern "C" int64_t ogl_reduce_bwd_seg_workspace_bytes(int64_t n_dst, int fanout, int d, int64_t n_src) {
+  if (n_dst < 0 || fanout < 0 || d < 0 || n_src < 0) return OGL_EINVAL;
+  const int64_t E = n_dst * fanout;
+  const int64_t tiles = ogl_cdiv(E, SG_TILE) + 1;
+  return ogl_round_up(seg_ints(E, n_src) * 4, 256) + tiles * 2 * ogl_round_up(d, 4) * 4;
+}
+
+// Plan: needs the indices only (run it beside the forward pass).  workspace: ogl_reduce_bwd_seg_workspace_bytes, 16-byte aligned.
+extern "C" int ogl_reduce_bwd_seg_plan(const int32_t* idx, int64_t n_dst, int fanout, int64_t n_src, void* workspace,
+                                       int64_t workspace_bytes, ogl_stream_t stream) {
+  if (n_dst < 0 || fanout < 0 || n_src <= 0 || n_src >= (1ll << 31) || n_dst * (int64_t)fanout >= (1ll << 31)) return OGL_EINVAL;
+  const int64_t E = n_dst * fanout;
+  if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < ogl_round_up(seg_ints(E, n_src) * 4, 256)) return OGL_EWORKSPACE;
+  if (E > 0 && !idx) return OGL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int* cnt = (int*)workspace;
+  int* start = cnt + (n_src + 1);
+  int* cur = start + (n_src + 1);
+  const int64_t nb = ogl_cdiv(n_src + 1, SG_SCAN);
+  int* bsum = cur + n_src;
+  int* U = bsum + nb;
+  int* sorted = U + E;
+  // (a kernel, not hipMemsetAsync: a memset node of a captured graph re-runs on 1/16 of its range on ROCm 7.2, tools/graph_probe.py)
+  const int rc = ogl_fill_zero(cnt, (n_src + 1) * 4, stream);
+  if (rc != OGL_OK) return rc;
+  if (E > 0) {
+    hipLaunchKernelGGL(k_seg_count, dim3((unsigned)std::min<int64_t>(2048, ogl_cdiv(E, 256))), dim3(256), 0, st, idx, E, n_src, cnt);
+    OGL_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_seg_bsum, dim3((unsigned)nb), dim3(SG_SCAN), 0, st, (const int*)cnt, n_src + 1, bsum);
+  OGL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_seg_scan_sums, dim3(1), dim3(SG_SCAN), 0, st, bsum, (int)nb);
+  OGL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_seg_apply, dim3((unsigned)nb), dim3(SG_SCAN), 0, st, (const int*)cnt, n_src, (const int*)bsum, start, cur);
+  OGL_CHECK_LAUNCH();
+  if (E > 0) {
+    hipLaunchKernelGGL(k_seg_place, dim3((unsigned)std::min<int64_t>(2048, ogl_cdiv(E, 256))), dim3(256), 0, st, idx, E, n_src,
+                       (const int*)start, cur, U);
+    OGL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_seg_rank, dim3((unsigned)std::min<int64_t>(4096, ogl_cdiv(E, 256))), dim3(256), 0, st, idx, (const int*)U,
+                       (const int*)start, n_src, sorted);
+    OGL_CHECK_LAUNCH();
+  }
+  return OGL_OK;
+}
+
+// Apply: dsrc = (sum over the planned edge lists of dout rows) / divisor, masked by [mask > 0] when given; written as fp32 rows
+// (`out`, nullable) and / or as the row-major bf16x3 image of [n_src, d] (`image`: ogl_x3_image_bytes(n_src, d), nullable).
+// op: OGL_REDUCE_MEAN (divisor fanout) or OGL_REDUCE_SUM.  d a multiple of 4 <= 1024; 16-byte aligned rows.
+extern "C" int ogl_reduce_bwd_seg_apply(const float* dout, int64_t ldd, const int32_t* idx, int64_t n_dst, int fanout, int d, int op,
+                                        int64_t n_src, const float* mask, int64_t ldm, float* out, int64_t ldo, void* image,
+                                        void* workspace, int64_t workspace_bytes, ogl_stream_t stream) {
+  if (n_dst < 0 || fanout <= 0 || d <= 0 || d > 1024 || (d & 3) || n_src <= 0 || ldd < d || (ldd & 3)) return OGL_EINVAL;
+  if (op != OGL_REDUCE_MEAN && op != OGL_REDUCE_SUM) return OGL_EINVAL;
+  if ((!out && !image) || (out && (ldo < d || (ldo & 3) || ((uintptr_t)out & 15))) || (mask && (ldm < d || (ldm & 3) || ((uintptr_t)mask & 15))))
+    return OGL_EINVAL;
+  if ((image && ((uintptr_t)image & 15)) || ((uintptr_t)dout & 15)) return OGL_EINVAL;
+  const int64_t E = n_dst * fanout;
+  if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < ogl_reduce_bwd_seg_workspace_bytes(n_dst, fanout, d, n_src)) return OGL_EWORKSPACE;
+  if (n_dst > 0 && (!dout || !idx)) return OGL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int* cnt = (int*)workspace;
+  int* start = cnt + (n_src + 1);
+  const int64_t nb = ogl_cdiv(n_src + 1, SG_SCAN);
+  int* sorted = start + (n_src + 1) + n_src + nb + E;
+  float* partial = (float*)((unsigned char*)workspace + ogl_round_up(seg_ints(E, n_src) * 4, 256));
+  const int64_t ldpart = ogl_round_up(d, 4);
+  SegOut o;
+  o.out = out; o.ldo = ldo; o.img = (unsigned char*)image; o.img_row_bytes = ogl_cdiv(d, 32) * 192; o.mask = mask; o.ldm = ldm;
+  o.divisor = op == OGL_REDUCE_MEAN ? (float)fanout : 1.f;
+  if (E > 0) {
+    hipLaunchKernelGGL(k_seg_reduce, dim3((unsigned)ogl_cdiv(E, SG_TILE)), dim3(SG_THREADS), 0, st, dout, ldd, n_dst, fanout, d, idx,
+                       (const int*)sorted, (const int*)start, n_src, o, partial, ldpart);
+    OGL_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_seg_fixup, dim3((unsigned)ogl_cdiv(n_src + 1, 4)), dim3(256), 0, st, (const int*)start, n_src, d, o,
+                     (const float*)partial, ldpart);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}

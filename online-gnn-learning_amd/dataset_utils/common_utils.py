@@ -77,13 +77,12 @@ def load_vertex_stream(path, feat_file, ts_file, snapshots=100, cuda=True, copy_
     timestamps = read_timestamps(os.path.join(path, ts_file))
     labelled = set(np.argwhere(targets != -1)[:, 0].tolist())
     n_classes = len(np.unique(targets))
-    out = []
-    for _ in range(2):      # the training stream and the look-ahead test stream (both advance independently)
-        gd = FullGraphData(len(feat), src, dst, feat, targets)
-        g = DynamicGraphVertex(gd, snapshots, labelled)
-        g.build(vertex_timestamps=timestamps, ensure_labelled=ensure_labelled)
-        out.append(g)
-    return feat.shape[1], targets.reshape(-1, 1), out[0], n_classes, out[1]
+    # the training stream and the look-ahead test stream advance independently over the SAME static data: one CSR, one feature
+    # table (+ its bf16x3 image) and one label table in HBM, two snapshot views
+    gd = FullGraphData(len(feat), src, dst, feat, targets)
+    g = DynamicGraphVertex(gd, snapshots, labelled)
+    g.build(vertex_timestamps=timestamps, ensure_labelled=ensure_labelled)
+    return feat.shape[1], targets.reshape(-1, 1), g, n_classes, g.twin()
 
 
 def load_edge_stream(path, snapshots=100, cuda=True, copy_to_gpu=True, restrict=None):
@@ -96,9 +95,6 @@ def load_edge_stream(path, snapshots=100, cuda=True, copy_to_gpu=True, restrict=
     table = read_edge_table(os.path.join(path, "edges_dataframe.csv"))
     labelled = set(np.argwhere(targets != -1)[:, 0].tolist())
     n_classes = len(np.unique(targets))
-    out = []
-    for _ in range(2):
-        g = DynamicGraphEdge(snapshots, labelled)
-        g.build(feat, targets, True, edge_timestamps=table, restrict=restrict)
-        out.append(g)
-    return feat.shape[1], targets.reshape(-1, 1), out[0], n_classes, out[1]
+    g = DynamicGraphEdge(snapshots, labelled)
+    g.build(feat, targets, True, edge_timestamps=table, restrict=restrict)
+    return feat.shape[1], targets.reshape(-1, 1), g, n_classes, g.twin()          # (one resident copy, two snapshot views)

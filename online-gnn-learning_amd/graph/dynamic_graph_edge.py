@@ -70,6 +70,20 @@ class DynamicGraphEdge(DynamicGraph):
         self._n_present_prev = 0
         self._apply()
 
+    def twin(self):
+        """A second stream over the same edge table, back at its first snapshot and advancing on its own (the look-ahead test
+        stream): the host-side edge arrays are shared (read-only after ``build``), the device tables too (``SnapshotGraph.shared``)."""
+        import copy
+        t = copy.copy(self)
+        t.current_subgraph = SnapshotGraph.shared(self.current_subgraph)
+        t.evolution_index = 1
+        t.subgraph_to_original_map = Wrap()
+        t.original_to_subgraph_map = t.subgraph_to_original_map
+        t.new_vertices, t.evolving_vertices = set(), set()
+        t._n_present_prev = 0
+        t._apply()
+        return t
+
     def _n_present_at(self, cut):
         cut = min(int(cut), len(self.src))
         return int(self._rmax[cut - 1]) + 1 if cut > 0 else 0

@@ -76,6 +76,17 @@ class DynamicGraphVertex(DynamicGraph):
         self.evolution_index = 1
         self._apply()
 
+    def twin(self):
+        """A second stream over the same data, back at its first snapshot and advancing on its own (the look-ahead test stream):
+        host-side snapshot lists and id maps are shared (read-only after ``build``), the device tables too (``SnapshotGraph.shared``)."""
+        import copy
+        t = copy.copy(self)
+        t.sub_g = SnapshotGraph.shared(self.sub_g)
+        t.evolving_vertices = list(self.snapshot_vertices[0])
+        t.evolution_index = 1
+        t._apply()
+        return t
+
     def _apply(self):
         n_present = int(self._cum[self.evolution_index - 1])
         self.sub_g.set_snapshot(n_present, n_present)

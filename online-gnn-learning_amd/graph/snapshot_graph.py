@@ -65,6 +65,23 @@ class SnapshotGraph:
         self.cut = 0
         self.ndata = {"feat": self.feat_table[:0], "target": self.target_table[:0]}
 
+    @classmethod
+    def shared(cls, other):
+        """A second snapshot view of the SAME stream: the CSR arrays, the feature table (and with it its bf16x3 image,
+        ``ops.register_static_table``) and the label table are ``other``'s — static data, never written after the upload — and only
+        the sampler handle (its per-snapshot degree array) is this view's own.  What the look-ahead test stream of a dataset is to
+        its train stream (R/train/dataset_utils/pubmed.py:85-86 builds the graph twice): one resident copy of 0.57 + 0.85 GB at the
+        Reddit size instead of two."""
+        g = cls.__new__(cls)
+        g.device, g.n_total = other.device, other.n_total
+        g._indptr, g._indices, g._keys = other._indptr, other._indices, other._keys
+        g.handle = ops.GraphHandle(g._indptr, g._indices, g._keys)
+        g.feat_table, g.target_table = other.feat_table, other.target_table
+        g.edata = {}
+        g.n_present = g.cut = 0
+        g.ndata = {"feat": g.feat_table[:0], "target": g.target_table[:0]}
+        return g
+
     def set_snapshot(self, n_present, cut):
         self.handle.set_snapshot(n_present, cut)
         self.n_present, self.cut = int(n_present), int(cut)

@@ -101,6 +101,25 @@ class GraphSAGE(nn.Module):
         if req:
             ops.weight_images_prepare(req)
 
+    def forward_loss(self, blocks, x, labels, rows=False):
+        """``CrossEntropyLoss(self(blocks, x), labels)`` for a train step — the per-batch body R/train/graphsage/pytorch/model.py:87-105
+        (``reduction='mean'``) and :193-200 (``'none'`` + ``.mean()``: ``rows=True`` also returns the per-seed losses) — with the last
+        layer and the loss as ONE autograd node when that layer is a tall few-column 'pool' layer (``SAGEConv.forward_loss``).
+        ``labels``: int64 tensor or ``ops.LazyLabels``.  Returns (loss, per-seed losses or None, logits)."""
+        if torch.is_grad_enabled() and ops.get_gemm_mode() != "f32" and ops.PREPARE_WEIGHT_IMAGES:
+            self._prepare_step_images(blocks, x)
+        h = x
+        for layer, block in zip(self.layers[:-1], blocks[:-1]):
+            h = layer(block, h)
+        out = self.layers[-1].forward_loss(blocks[-1], h, labels) if len(self.layers) == len(blocks) else None
+        if out is not None:
+            return out[0], (out[1] if rows else None), out[2]
+        logits = self.layers[-1](blocks[-1], h)
+        if rows:
+            loss, r = ops.cross_entropy_mean_rows(logits, labels)
+            return loss, r, logits
+        return ops.cross_entropy(logits, labels, "mean"), None, logits
+
     def forward(self, blocks, x):
         if torch.is_grad_enabled() and ops.get_gemm_mode() != "f32" and ops.PREPARE_WEIGHT_IMAGES:
             self._prepare_step_images(blocks, x)

@@ -239,7 +239,8 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             else:
                 def loss_fn(logits, labels):
                     return ops.cross_entropy_mean_rows(logits, labels)
-            self._sg = stepgraph.StepGraphCache(self.graphsage_model, self.optimizer, self.samples, loss_fn)
+            self._sg = stepgraph.StepGraphCache(self.graphsage_model, self.optimizer, self.samples, loss_fn,
+                                                loss_kind="mean" if self.reduction == "mean" else "mean_rows")
         return self._sg
 
     def _train_batches(self, graph, train_vertices, batch_size, on_rows=None):
@@ -304,16 +305,17 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
 
     def _eager_step(self, graph, blocks, input_nodes, seeds, on_rows=None):
         self.optimizer.zero_grad()
-        batch_labels = ops.gather_i64(graph.ndata["target"], seeds)
-        scores = self.graphsage_model(blocks, self._inputs(graph, input_nodes))
-        if self.reduction == "mean":
-            loss = self.xent(scores, batch_labels)
-        else:
-            loss, rows = ops.cross_entropy_mean_rows(scores, batch_labels)      # the mean to train on + the rows, one launch
-            if on_rows is not None:
-                on_rows(seeds, rows.detach())
-        ops.backward(loss)
-        self.optimizer.step()
+        # (the labels are gathered inside the loss launch; the last layer and the loss are one node where that applies)
+        batch_labels = ops.LazyLabels(graph.ndata["target"], seeds)
+        loss, rows, _ = self.graphsage_model.forward_loss(blocks, self._inputs(graph, input_nodes), batch_labels,
+                                                          rows=self.reduction != "mean")
+        if rows is not None and on_rows is not None:
+            on_rows(seeds, rows.detach())
+        if hasattr(self.optimizer, "backward_and_step"):
+            self.optimizer.backward_and_step(loss)     # (split-K slabs summed by the optimiser launch, its early part beside the backward)
+        else:                                          # any torch optimiser
+            ops.backward(loss)
+            self.optimizer.step()
         return loss
 
     def _sampler(self):

@@ -502,14 +502,21 @@ def relu_bwd(dy, y):
     return out
 
 
-def out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src, dp_zeroed=None):
+def out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src, dp_zeroed=None, finish_loss=None):
     """(dx_self [n_dst, K], dP [n_src, K]): dy . w_self, and dy . w_neigh scattered to the max winners (csrc/out_layer.hip).
-    ``dp_zeroed``: an already zeroed [n_src, K] scatter target (``take_zeroed``)."""
+    ``dp_zeroed``: an already zeroed [n_src, K] scatter target (``take_zeroed``).  ``finish_loss = (loss_rows, mean)``: the launch
+    also writes mean <- sum(loss_rows) / n (the loss of a fused forward whose mean was left to its successor)."""
     dy = as_mat(dy); w_self = as_mat(w_self); w_neigh = as_mat(w_neigh); neigh = as_mat(neigh)
     n_dst, N = dy.shape
     K = w_self.shape[1]
     dx = empty_mat(n_dst, K, dy.device)
     dp = dp_zeroed if dp_zeroed is not None else empty_mat(n_src, K, dy.device, zero=True)
+    if finish_loss is not None:
+        rows, mean = finish_loss
+        _launch("ogl_out_layer_bwd_inputs", _lib.lib().ogl_out_layer_bwd_inputs_mean, _ptr(dy), _ld(dy), n_dst, N, K, _ptr(w_self),
+                _ld(w_self), _ptr(w_neigh), _ld(w_neigh), _ptr(argmax), _ptr(neigh), _ld(neigh), n_src, _ptr(dx), _ld(dx), _ptr(dp),
+                _ld(dp), _ptr(rows), rows.numel(), _ptr(mean), _stream(), meta=dict(M=n_dst, N=N, K=K))
+        return dx, dp
     _launch("ogl_out_layer_bwd_inputs", _lib.lib().ogl_out_layer_bwd_inputs, _ptr(dy), _ld(dy), n_dst, N, K, _ptr(w_self), _ld(w_self),
             _ptr(w_neigh), _ld(w_neigh), _ptr(argmax), _ptr(neigh), _ld(neigh), n_src, _ptr(dx), _ld(dx), _ptr(dp), _ld(dp), _stream(),
             meta=dict(M=n_dst, N=N, K=K))
@@ -533,6 +540,52 @@ def out_layer_bwd_weights(dy, x_self, x_neigh, want_bias=True, x_self_rows=None,
 
 
 OUT_LAYER_FUSED = os.environ.get("OGL_OUT_LAYER_FUSED") != "0"
+# the output layer's forward tail — neighbour max, [n_dst, 2K] -> N projection, cross entropy — as ONE launch (ogl_out_layer_fwd_ce)
+FUSED_OUT_FWD = os.environ.get("OGL_FUSED_OUT_FWD", "1") != "0"
+DEFER_LOSS_MEAN = os.environ.get("OGL_DEFER_LOSS_MEAN", "1") != "0"     # the fused loss's mean is finished by the backward's first launch
+OUT_FWD_ROWS = int(os.environ.get("OGL_OUT_FWD_R", "0"))        # destinations per block (0: automatic)
+
+
+def out_loss_fits(h, n_dst, idx, w_self, w_neigh, p_width):
+    """The fused forward + loss of a few-column 'pool' layer applies (and so does its two-launch backward, ``_out_layer_fits``)."""
+    N, K = w_self.shape
+    return (FUSED_OUT_FWD and OUT_LAYER_FUSED and idx.dtype == torch.int32 and idx.dim() == 2 and p_width == K and h.shape[1] == K
+            and 0 < n_dst <= 4096 and K >= 64 and h.shape[0] >= n_dst and w_self.is_contiguous() and w_neigh.is_contiguous()
+            and w_self.data_ptr() % 16 == 0 and w_neigh.data_ptr() % 16 == 0
+            and bool(_lib.lib().ogl_out_layer_fwd_ce_fits(int(n_dst), int(idx.shape[1]), int(K), int(N))))
+
+
+def out_layer_fwd_ce(p, idx, h, n_dst, w_self, w_neigh, b_self, b_neigh, labels, want_grad=True, zero=None, want_mean=True):
+    """(mean loss, row losses, logits, neigh, argmax, dlogits / n_dst) of the output layer from its pooled projection rows ``p`` =
+    relu(fc_pool(h)) in ONE launch; ``labels``: int64 tensor or LazyLabels; ``zero``: a contiguous fp32 buffer the grid clears on
+    the side (the scatter target of the layer's backward).  ``want_mean=False``: the returned mean tensor is NOT written by this
+    launch (no last-block-done count, no device-scope fences): ``out_layer_bwd_inputs(finish_loss=...)`` writes it."""
+    p = as_mat(p); h = as_mat(h); w_self = as_mat(w_self); w_neigh = as_mat(w_neigh)
+    K, N = p.shape[1], w_self.shape[0]
+    dev = p.device
+    lazy = labels if isinstance(labels, LazyLabels) else None
+    if lazy is None:
+        labels = labels.reshape(-1)
+        assert labels.dtype == torch.int64 and labels.is_cuda and labels.is_contiguous()
+    assert labels.numel() == n_dst and idx.shape[0] == n_dst and idx.is_contiguous()
+    neigh = empty_mat(n_dst, K, dev)
+    argmax = torch.empty((n_dst, K), dtype=torch.int32, device=dev) if want_grad else None
+    logits = empty_mat(n_dst, N, dev)
+    loss = torch.empty(n_dst, dtype=torch.float32, device=dev)
+    mean = torch.empty((), dtype=torch.float32, device=dev)
+    dl = empty_mat(n_dst, N, dev) if want_grad else None
+    stream = _stream()
+    table, ids = (lazy.table, lazy.ids) if lazy is not None else (labels, None)
+    zn = 0
+    if zero is not None:
+        assert zero.is_contiguous() and zero.dtype == torch.float32 and zero.numel() % 4 == 0
+        zn = zero.numel()
+    _launch("ogl_out_layer_fwd_ce", _lib.lib().ogl_out_layer_fwd_ce, _ptr(p), _ld(p), p.shape[0], _ptr(idx), n_dst, int(idx.shape[1]),
+            _ptr(h), _ld(h), K, _ptr(w_self), _ld(w_self), _ptr(w_neigh), _ld(w_neigh), _ptr(b_self), _ptr(b_neigh), N, _ptr(neigh),
+            _ld(neigh), _ptr(argmax), _ptr(logits), _ld(logits), _ptr(table), table.numel(), _ptr(ids), C.c_float(1.0 / n_dst),
+            _ptr(loss), _ptr(dl), _ld(dl) if dl is not None else 0, _ptr(mean) if want_mean else None, ce_counter(dev, stream), _ptr(zero), zn,
+            OUT_FWD_ROWS, stream, meta=dict(n_dst=n_dst, fanout=int(idx.shape[1]), d=K, N=N, zero_bytes=4 * zn))
+    return mean, loss, logits, neigh, argmax, dl
 
 
 def _out_layer_fits(dy, h, w_self, w_neigh):
@@ -1017,11 +1070,67 @@ def linear_bwd_weight_x3(dyT_img, xT_img, want_bias=True, dw_out=None):
     return dw, db
 
 
+# Split-K weight gradients whose reduction is left to the optimiser launch: inside ``deferred_splitk(optimizer)`` a k-major weight
+# gradient that knows which PARAMETERS its results belong to (``defer_for``) runs without its reduction launch and leaves a SlabGrad
+# per parameter here (keyed by the parameter's address: autograd may hand p.grad a clone of the — then unwritten — gradient tensor, the
+# parameter itself stays put); ``optim.Adam`` sums the slabs inside its own launch and writes the gradient into p.grad as it goes.
+# What is left when the context ends (an optimiser that does not know slabs, a gradient nobody stepped on) is reduced into p.grad then.
+SLAB_ADAM = os.environ.get("OGL_SLAB_ADAM", "1") != "0"
+_SLABS = {"on": False, "pending": {}}
+
+
+class SlabGrad:
+    __slots__ = ("ws", "stride", "ws_ld", "nsplit", "rows", "ncols", "col0")
+
+    def __init__(self, ws, stride, ws_ld, nsplit, rows, ncols, col0):
+        self.ws, self.stride, self.ws_ld, self.nsplit, self.rows, self.ncols, self.col0 = ws, stride, ws_ld, nsplit, rows, ncols, col0
+
+
+def take_slabs(param):
+    """The pending SlabGrad of ``param`` (removed from the table) or None."""
+    return _SLABS["pending"].pop(param.data_ptr(), None) if _SLABS["pending"] else None
+
+
+def slab_reduce(sg, out):
+    """out[rows, ncols] <- the plain reduction of the slabs (slab order)."""
+    assert out.is_contiguous() and out.numel() == sg.rows * sg.ncols
+    _launch("ogl_x3_slab_reduce", _lib.lib().ogl_x3_slab_reduce, _ptr(sg.ws), sg.stride, sg.ws_ld, sg.nsplit, sg.rows, sg.ncols, sg.col0,
+            _ptr(out), sg.ncols, _stream(), meta=dict(n=sg.rows * sg.ncols, nsplit=sg.nsplit))
+
+
+class deferred_splitk:
+    """Context: backward passes inside it may leave split-K slabs for ``optimizer`` (an ``optim.Adam``; None / any other optimiser:
+    nothing is deferred).  On exit every slab set still pending is reduced into its parameter's ``.grad``."""
+
+    def __init__(self, optimizer=None):
+        self.opt = optimizer
+        self.on = SLAB_ADAM and optimizer is not None and getattr(optimizer, "consumes_slabs", False)
+
+    def __enter__(self):
+        self.prev = _SLABS["on"]
+        _SLABS["on"] = bool(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        _SLABS["on"] = self.prev
+        pend = _SLABS["pending"]
+        if pend and self.on:
+            for group in self.opt.param_groups:
+                for p in group["params"]:
+                    sg = pend.pop(p.data_ptr(), None)
+                    if sg is not None and p.grad is not None and exc[0] is None:
+                        slab_reduce(sg, p.grad if p.grad.is_contiguous() else p.grad.contiguous())
+            pend.clear()
+        return False
+
+
 def linear_bwd_weight_x3k(dyT_img, x_img, M, K, x_rows=None, x_nrows=None, interleave=0, want_bias=True, want_bias2=False, dy_rows=False,
-                          dw_out=None):
+                          dw_out=None, defer_for=None):
     """dw [N, K] (and db, db2: two copies of the bias gradient) from the image of dy.T and the ROW-MAJOR image of x (M reduction
     rows, gathered by ``x_rows``): no transposed image of x.  The bias gradient needs the ones slot in ``x_img`` (K + 1).
-    ``dy_rows``: ``dyT_img`` is the row-major image of dy itself ([M, N]: what relu_bwd_img / x3_split build), read k-major too."""
+    ``dy_rows``: ``dyT_img`` is the row-major image of dy itself ([M, N]: what relu_bwd_img / x3_split build), read k-major too.
+    ``defer_for = (w, b, b2)``: the PARAMETERS dw / db / db2 are the gradients of (b / b2 None where that gradient is not asked for):
+    inside ``deferred_splitk`` the split-K reduction is left to the optimiser — the returned tensors are then UNWRITTEN until it ran."""
     has_ones = x_img.K == K + 1
     assert x_img.K in (K, K + 1) and (has_ones or not (want_bias or want_bias2))
     if dy_rows:
@@ -1036,6 +1145,21 @@ def linear_bwd_weight_x3k(dyT_img, x_img, M, K, x_rows=None, x_nrows=None, inter
     db2 = torch.empty(N, dtype=torch.float32, device=dev) if want_bias2 else None
     nbytes = int(_lib.lib().ogl_linear_bwd_weight_x3k_workspace_bytes(M, interleave, N, K, 1 if has_ones else 0))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    if (defer_for is not None and _SLABS["on"] and dw_out is None and defer_for[0] is not None and tuple(defer_for[0].shape) == (N, K)
+            and (db is None or defer_for[1] is not None) and (db2 is None or defer_for[2] is not None)):
+        ns, wl = C.c_int(0), C.c_int64(0)
+        _launch("ogl_linear_bwd_weight_x3k", _lib.lib().ogl_linear_bwd_weight_x3k_slabs, _ptr(dyT_img.buf), interleave, _ptr(x_img.buf),
+                x_img.rows, _ptr(_ids(x_rows) if x_rows is not None else None), x_img.rows if x_nrows is None else x_nrows, M, N, K,
+                1 if has_ones else 0, _ptr(dw), _ld(dw), _ptr(db), _ptr(db2), _ptr(ws), nbytes, C.byref(ns), C.byref(wl), _stream(),
+                meta=dict(M=M, K=K, N=N, deferred=True))
+        if ns.value > 1:
+            pend, stride = _SLABS["pending"], N * wl.value
+            pend[defer_for[0].data_ptr()] = SlabGrad(ws, stride, wl.value, ns.value, N, K, 0)
+            if db is not None:
+                pend[defer_for[1].data_ptr()] = SlabGrad(ws, stride, wl.value, ns.value, N, 1, K)
+            if db2 is not None:
+                pend[defer_for[2].data_ptr()] = SlabGrad(ws, stride, wl.value, ns.value, N, 1, K)
+        return dw, db, db2
     _launch("ogl_linear_bwd_weight_x3k", _lib.lib().ogl_linear_bwd_weight_x3k, _ptr(dyT_img.buf), interleave, _ptr(x_img.buf),
             x_img.rows, _ptr(_ids(x_rows) if x_rows is not None else None), x_img.rows if x_nrows is None else x_nrows, M, N, K,
             1 if has_ones else 0, _ptr(dw), _ld(dw), _ptr(db), _ptr(db2), _ptr(ws), nbytes, _stream(), meta=dict(M=M, K=K, N=N))
@@ -1101,7 +1225,7 @@ def _dy_rows_image(dy, dy_img):
     return None
 
 
-def weight_grad(dy, x, x_rows=None, want_bias=True, dyT=None, x_img=None, dy_img=None, dw_out=None):
+def weight_grad(dy, x, x_rows=None, want_bias=True, dyT=None, x_img=None, dy_img=None, dw_out=None, defer_for=None):
     """dW, db of a projection.  In the bf16x6 / auto arithmetic the product runs on the split-bf16 image kernel: x as the row-major
     image its forward already had (``x_img``, or the resident table's: read k-major, no transposed copy), dy likewise when its
     producer wrote its image (``dy_img``), else as the image of dy^T; without a row-major image of x both operands are transposed
@@ -1116,13 +1240,13 @@ def weight_grad(dy, x, x_rows=None, want_bias=True, dyT=None, x_img=None, dy_img
     dyr = _dy_rows_image(dy, dy_img) if rimg is not None else None
     if dyr is not None:
         return linear_bwd_weight_x3k(dyr, rimg, dy.shape[0], K, x_rows=x_rows, x_nrows=x.shape[0] if x_rows is not None else None,
-                                     want_bias=want_bias, dy_rows=True, dw_out=dw_out)[:2]
+                                     want_bias=want_bias, dy_rows=True, dw_out=dw_out, defer_for=defer_for)[:2]
     if dyT is None:
         dyT = transposed_operand(dy)
     if isinstance(dyT, X3Image):
         if rimg is not None:
             return linear_bwd_weight_x3k(dyT, rimg, dy.shape[0], K, x_rows=x_rows, x_nrows=x.shape[0] if x_rows is not None else None,
-                                         want_bias=want_bias, dw_out=dw_out)[:2]
+                                         want_bias=want_bias, dw_out=dw_out, defer_for=defer_for)[:2]
     if isinstance(dyT, X3Image):
         # both operands as bf16x3 images of their transposes (one fused gather + transpose + split pass each)
         return linear_bwd_weight_x3(dyT, x3_split_t(x, x_rows, ones_row=True), want_bias=want_bias, dw_out=dw_out)
@@ -1335,6 +1459,31 @@ def adam_step_multi_dev(ps, gs, ms, vs, step_dev, scalars_dev, lr=1e-3, beta1=0.
             meta=dict(n=sum(p.numel() for p in ps)))
 
 
+def adam_step_multi_slabs(ps, gs, ms, vs, slabs, step=0, step_dev=None, scalars_dev=None, prepare=True, lr=1e-3, beta1=0.9, beta2=0.999,
+                          eps=1e-8):
+    """Adam over several tensors in one launch; ``slabs[i]`` (a SlabGrad or None): tensor i's gradient still is a set of split-K
+    slabs — summed inside the launch, written to ``gs[i]`` and applied.  ``step_dev`` None: host step count ``step``; else the
+    device-side count, incremented only when ``prepare`` (a step applied in two launches prepares once)."""
+    invalidate_weight_images()      # parameters change under raw pointers: no version bump to key on
+    k = len(ps)
+    for p, g, m, v in zip(ps, gs, ms, vs):
+        for t in (p, g, m, v):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+    arr = lambda ts: (C.c_void_p * k)(*[t.data_ptr() for t in ts])
+    n = (C.c_int64 * k)(*[p.numel() for p in ps])
+    for sg, p in zip(slabs, ps):
+        assert sg is None or sg.rows * sg.ncols == p.numel()
+    ws = (C.c_void_p * k)(*[(sg.ws.data_ptr() if sg is not None else None) for sg in slabs])
+    stride = (C.c_int64 * k)(*[(sg.stride if sg is not None else 0) for sg in slabs])
+    i32 = lambda f: (C.c_int * k)(*[(getattr(sg, f) if sg is not None else 0) for sg in slabs])
+    if _SIDE["active"]:
+        _SIDE["keep"].extend(sg.ws for sg in slabs if sg is not None)       # (read on the side stream: held until the join)
+    _launch("ogl_adam_step_multi_slabs", _lib.lib().ogl_adam_step_multi_slabs, k, arr(ps), arr(gs), arr(ms), arr(vs), n, ws, stride,
+            i32("ws_ld"), i32("nsplit"), i32("ncols"), i32("col0"), int(step), _ptr(step_dev), _ptr(scalars_dev), 1 if prepare else 0,
+            C.c_double(lr), C.c_double(beta1), C.c_double(beta2), C.c_double(eps), _stream(),
+            meta=dict(n=sum(p.numel() for p in ps), slab_tensors=sum(sg is not None for sg in slabs)))
+
+
 # --------------------------------------------------------------------------------------------
 # autograd glue
 # --------------------------------------------------------------------------------------------
@@ -1442,6 +1591,15 @@ def collective_section():
     return _SideSection(None)
 
 
+def early_section():
+    """Context for work launched from a gradient hook in the middle of a backward pass that only the END of the step needs (the
+    optimiser's early part): on the side stream, after everything both streams have enqueued so far, when the fork is on; otherwise
+    a no-op context (the work then sits in the main stream where the hook fired)."""
+    if not FORK_BACKWARD or _PROFILE is not None or _SIDE["off"] or (not FORK_IN_GRAPHS and _capturing()):
+        return _NoSection()
+    return _SideSection(None)
+
+
 def side_join():
     """The main stream waits for the side stream's work (call before anything consumes what a side section produced)."""
     if _SIDE["active"]:
@@ -1459,6 +1617,7 @@ class _LinearFn(torch.autograd.Function):
         # gets its gradient from its own weight-gradient product in backward (their ones columns are free) — a tracked
         # `bias + bias2` outside would hand ONE gradient tensor to two parameters, which autograd clones (a launch)
         ctx.has_bias2 = bias2 is not None
+        ctx.bias_t, ctx.bias2_t = bias, bias2                    # (the parameters themselves: who a deferred gradient belongs to)
         ctx.x2_img = take_image(x2, pop=False) if x2 is not None else None     # read again by the weight gradient (k-major)
         y = _dual_fwd_images(x, w, bias, bias2, x2, w2, relu, x_rows, x2_rows)
         if y is None:
@@ -1524,7 +1683,8 @@ class _LinearFn(torch.autograd.Function):
             if rimg is not None and rimg.K == x.shape[1] + 1:
                 both = linear_bwd_weight_x3k(dyr if dyr is not None else dyT, rimg, dy.shape[0], x.shape[1], x_rows=x_rows,
                                              x_nrows=x.shape[0] if x_rows is not None else None, want_bias=True, want_bias2=True,
-                                             dy_rows=dyr is not None, dw_out=_dw_out(w, *w.shape))
+                                             dy_rows=dyr is not None, dw_out=_dw_out(w, *w.shape),
+                                             defer_for=(w, ctx.bias_t, ctx.bias2_t))
         if (both is None and x2 is not None and x2_rows is None and need[1] and need[4] and ctx.has_bias and ctx.has_bias2
                 and dy.shape[0] < 1024 and x.shape[1] == x2.shape[1] and _out_layer_fits(dy, x, w, w2)):
             # a short, narrow combine (the first layer at the 32-seed rungs): both weight gradients and both bias-gradient copies
@@ -1538,14 +1698,17 @@ class _LinearFn(torch.autograd.Function):
         if both is not None:
             dw, db, db2 = both
         elif need[1] or (need[2] and ctx.has_bias):
-            dw, db = weight_grad(dy, x, x_rows, want_bias=ctx.has_bias, dyT=dyT, dy_img=dy_img, dw_out=_dw_out(w, *w.shape))
+            dw, db = weight_grad(dy, x, x_rows, want_bias=ctx.has_bias, dyT=dyT, dy_img=dy_img, dw_out=_dw_out(w, *w.shape),
+                                 defer_for=(w, ctx.bias_t, None))
         if x2 is not None:
             if fused_small:
                 pass
             elif both is not None:
-                dw2 = weight_grad(dy, x2, None, want_bias=False, dyT=dyT, x_img=x2_img, dy_img=dy_img, dw_out=_dw_out(w2, *w2.shape))[0]
+                dw2 = weight_grad(dy, x2, None, want_bias=False, dyT=dyT, x_img=x2_img, dy_img=dy_img, dw_out=_dw_out(w2, *w2.shape),
+                                  defer_for=(w2, None, None))[0]
             elif need[4] or ctx.has_bias2:
-                dw2, db2 = weight_grad(dy, x2, x2_rows, want_bias=ctx.has_bias2, dyT=dyT, dy_img=dy_img, dw_out=_dw_out(w2, *w2.shape))
+                dw2, db2 = weight_grad(dy, x2, x2_rows, want_bias=ctx.has_bias2, dyT=dyT, dy_img=dy_img, dw_out=_dw_out(w2, *w2.shape),
+                                       defer_for=(w2, ctx.bias2_t, None))
         return dw, db, dw2, db2
 
 
@@ -1606,6 +1769,7 @@ class _PoolMaxFn(torch.autograd.Function):
         if _CAPTURE is not None:
             _CAPTURE.append(dict(argmax=argmax, neigh=out))
         ctx.n_src, ctx.fanout, ctx.has_bias = p.shape[0], idx.shape[1], bias is not None
+        ctx.bias_t = bias
         ctx.pool_plan = None
         if (POOL_PLAN and need and not x.requires_grad and idx.dtype == torch.int32 and _MODE["name"] != "f32"
                 and ctx.n_src >= X3_BWW_MIN_ROWS and out.shape[1] <= 640 and ctx.fanout <= 63 and idx.shape[0] * out.shape[1] < (1 << 27)
@@ -1635,7 +1799,8 @@ class _PoolMaxFn(torch.autograd.Function):
             if rimg is not None and rimg.K == x.shape[1] + 1:
                 # the resident table's own image, its rows gathered in the dealt order of dP^T: no X^T image
                 dw, db, _ = linear_bwd_weight_x3k(dyT, rimg, ctx.n_src, x.shape[1], x_rows=x_rows, x_nrows=x.shape[0], interleave=G,
-                                                  want_bias=ctx.has_bias, dw_out=_dw_out(w, *w.shape))
+                                                  want_bias=ctx.has_bias, dw_out=_dw_out(w, *w.shape),
+                                                  defer_for=(w, ctx.bias_t, None))
             else:
                 dw, db = linear_bwd_weight_x3(dyT, x3_split_t(x, x_rows, ones_row=True, interleave=G), want_bias=ctx.has_bias,
                                               dw_out=_dw_out(w, *w.shape))
@@ -1692,6 +1857,7 @@ class _SagePoolLayerFn(torch.autograd.Function):
         if _CAPTURE is not None:
             _CAPTURE.append(dict(argmax=argmax, neigh=neigh, out=out if relu else None))
         ctx.relu, ctx.n_dst, ctx.fanout, ctx.has_bias, ctx.has_pool_bias = bool(relu), n_dst, idx.shape[1], b_self is not None, b_pool is not None
+        ctx.b_pool_t = b_pool
         # the few-column output layer scatters its pooled-row gradient with atomics: park the (empty) target where the loss launch
         # that comes next will zero it
         ctx.dp_slot = None
@@ -1709,30 +1875,7 @@ class _SagePoolLayerFn(torch.autograd.Function):
         n_dst, n_src = ctx.n_dst, h.shape[0]
         h_dst = h[:n_dst]
         if _out_layer_fits(dy, h, w_self, w_neigh):
-            # few output columns (the output layer): the combine's backward in two launches, its input gradient for the pooled rows
-            # scattered to the winners as it is computed; the fc_self part joins dh in the epilogue of the fc_pool input gradient
-            # (taken once: a second backward through the same graph — retain_graph=True — must not scatter into the first one's sums)
-            slot, ctx.dp_slot = getattr(ctx, "dp_slot", None), None
-            tall = N1_BWD_SPLIT and _n1_images_ok(n_src, h.shape[1], w_pool.shape[1])
-            # the layer's weight gradients are leaves of the backward graph: on the side stream when the layer is tall — the two
-            # few-column ones right away (beside the equally small input-gradient launch), fc_pool's once dP and its image exist
-            # (the critical launch FIRST: in a captured step the first-created child of a fork node stays on its parent's queue, the
-            # others start ~5 us later on another one and every later cross-queue edge of their chain costs the same again —
-            # measured 1.075-1.084 -> 1.056-1.059 ms per replayed Reddit step, same box, alternating runs)
-            at0 = fork_point() if tall else None
-            dx_self, dp = out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src,
-                                               dp_zeroed=take_zeroed(slot, n_src, h.shape[1]) if slot is not None else None)
-            with (side_section(dy, h, neigh, at=at0) if tall else _NoSection()):
-                dw_self, dw_neigh, db, db2 = out_layer_bwd_weights(dy, h_dst, neigh, want_bias=ctx.has_bias,
-                                                                   dws_out=_dw_out(w_self, *w_self.shape), dwn_out=_dw_out(w_neigh, *w_neigh.shape))
-            dp_img = x3_split(dp) if tall else None
-            at = fork_point() if tall else None
-            dh = linear_bwd_input(dp, w_pool, None, dy_img=dp_img, add_head=dx_self,
-                                  out_relu_mask=h if (FUSE_RELU_BWD and ctx.h_relu_out and tall) else None)
-            with (side_section(dp, dp_img, ctx.h_img, at=at) if tall else _NoSection()):
-                dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias, x_img=ctx.h_img, dy_img=dp_img, dw_out=_dw_out(w_pool, *w_pool.shape))
-            return (dh, dw_pool, db_pool if ctx.has_pool_bias else None, dw_self, dw_neigh, db if ctx.has_bias else None,
-                    db2 if ctx.has_bias else None, None, None, None)
+            return _out_layer_backward(ctx, dy, h, w_pool, w_self, w_neigh, neigh, argmax) + (None, None, None)
         dyT = transposed_operand(dy) if (_MODE["name"] != "f32" and dy.shape[0] >= 1024) else None
         dw_self, db = weight_grad(dy, h_dst, None, want_bias=ctx.has_bias, dyT=dyT, dw_out=_dw_out(w_self, *w_self.shape))
         # the bias gradient once more from the second product (its ones column is free): two tensors for the two biases —
@@ -1747,6 +1890,106 @@ class _SagePoolLayerFn(torch.autograd.Function):
         dh[:n_dst].add_(dx_self)                                  # the fc_self path, in place on the first n_dst rows
         return (dh, dw_pool, db_pool if ctx.has_pool_bias else None, dw_self, dw_neigh, db if ctx.has_bias else None,
                 db2 if ctx.has_bias else None, None, None, None)
+
+
+def _out_layer_backward(ctx, dy, h, w_pool, w_self, w_neigh, neigh, argmax):
+    """Backward of a 'pool' layer with few output columns (the output layer), shared by ``_SagePoolLayerFn`` and ``_SagePoolLossFn``:
+    (dh, dw_pool, db_pool, dw_self, dw_neigh, db_self, db_neigh).  The combine's backward in two launches, its input gradient for
+    the pooled rows scattered to the winners as it is computed; the fc_self part joins dh in the epilogue of the fc_pool input
+    gradient."""
+    n_dst, n_src = ctx.n_dst, h.shape[0]
+    h_dst = h[:n_dst]
+    # (taken once: a second backward through the same graph — retain_graph=True — must not scatter into the first one's sums)
+    slot, ctx.dp_slot = getattr(ctx, "dp_slot", None), None
+    tall = N1_BWD_SPLIT and _n1_images_ok(n_src, h.shape[1], w_pool.shape[1])
+    # the layer's weight gradients are leaves of the backward graph: on the side stream when the layer is tall — the two
+    # few-column ones right away (beside the equally small input-gradient launch), fc_pool's once dP and its image exist
+    # (the critical launch FIRST: in a captured step the first-created child of a fork node stays on its parent's queue, the
+    # others start ~5 us later on another one and every later cross-queue edge of their chain costs the same again —
+    # measured 1.075-1.084 -> 1.056-1.059 ms per replayed Reddit step, same box, alternating runs)
+    at0 = fork_point() if tall else None
+    finish, ctx.loss_out = getattr(ctx, "loss_out", None), None
+    dx_self, dp = out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src,
+                                       dp_zeroed=take_zeroed(slot, n_src, h.shape[1]) if slot is not None else None, finish_loss=finish)
+    with (side_section(dy, h, neigh, at=at0) if tall else _NoSection()):
+        dw_self, dw_neigh, db, db2 = out_layer_bwd_weights(dy, h_dst, neigh, want_bias=ctx.has_bias,
+                                                           dws_out=_dw_out(w_self, *w_self.shape), dwn_out=_dw_out(w_neigh, *w_neigh.shape))
+    dp_img = x3_split(dp) if tall else None
+    at = fork_point() if tall else None
+    dh = linear_bwd_input(dp, w_pool, None, dy_img=dp_img, add_head=dx_self,
+                          out_relu_mask=h if (FUSE_RELU_BWD and ctx.h_relu_out and tall) else None)
+    with (side_section(dp, dp_img, ctx.h_img, at=at) if tall else _NoSection()):
+        dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias, x_img=ctx.h_img, dy_img=dp_img, dw_out=_dw_out(w_pool, *w_pool.shape),
+                                       defer_for=(w_pool, getattr(ctx, "b_pool_t", None), None))
+    return (dh, dw_pool, db_pool if ctx.has_pool_bias else None, dw_self, dw_neigh, db if ctx.has_bias else None,
+            db2 if ctx.has_bias else None)
+
+
+class _SagePoolLossFn(torch.autograd.Function):
+    """The LAST 'pool' layer of a train step together with its loss, one autograd node:
+        logits = fc_self(h[:n_dst]) + fc_neigh(max_j relu(fc_pool(h))[idx]) + b_self + b_neigh;  loss = mean_d CE(logits[d], label(d)).
+    Forward = the fc_pool product + ONE launch for everything after it (``out_layer_fwd_ce``: neighbour max, projection, cross
+    entropy, the zero fill of the backward's scatter target); backward = ``_out_layer_backward`` from the stored dlogits.
+    Returns (mean loss, per-seed losses, logits); only the mean is differentiable."""
+
+    @staticmethod
+    def forward(ctx, h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels):
+        h = as_mat(h)
+        ctx.h_relu_out = bool(getattr(h, "_ogl_relu_out", False))
+        himg = take_image(h) if _n1_images_ok(h.shape[0], h.shape[1], w_pool.shape[0]) else None
+        ctx.h_img = himg if (himg is not None and himg.K == h.shape[1] + 1) else None
+        if ctx.h_img is not None:
+            wimg = weight_image("wb", w_pool, b_pool)
+            if wimg is None:
+                weight_images_prepare([("wb", (w_pool, b_pool))])
+                wimg = weight_image("wb", w_pool, b_pool)
+            p = linear_fwd_x3(himg, None, wimg, relu=True)
+        else:
+            p = linear_fwd(h, w_pool, b_pool, relu=True)
+        need = any(t is not None and t.requires_grad for t in (h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh))
+        ent = None
+        if need and h.shape[0] >= 1024:
+            # the backward scatters its pooled-row gradient with float atomics into a zeroed [n_src, K] matrix: cleared by this launch
+            buf = torch.empty((h.shape[0], padded_ld(h.shape[1])), dtype=torch.float32, device=h.device)
+            ent = [buf, h.shape[0], h.shape[1], True]
+        # The VALUE of the mean loss is written by the first launch of this node's backward (``finish_loss``): inside the forward
+        # launch it costs a device-scope fence per block (58 us instead of ~20 for 512 seeds, measured).  A loss nobody calls
+        # backward() on (``need`` false, or DEFER_LOSS_MEAN off) gets its mean from the forward launch.
+        ctx.defer_mean = bool(need and DEFER_LOSS_MEAN)
+        ctx.set_materialize_grads(False)             # (the gradients of the two non-differentiable outputs stay None: no zero fills)
+        mean, rows, logits, neigh, argmax, dl = out_layer_fwd_ce(p, idx, h, n_dst, w_self, w_neigh, b_self, b_neigh, labels,
+                                                                want_grad=need, zero=ent[0] if ent is not None else None,
+                                                                want_mean=not ctx.defer_mean)
+        ctx.loss_out = (rows, mean) if ctx.defer_mean else None
+        if _CAPTURE is not None:
+            _CAPTURE.append(dict(argmax=argmax, neigh=neigh, out=None))
+        ctx.n_dst, ctx.fanout, ctx.has_bias, ctx.has_pool_bias = n_dst, idx.shape[1], b_self is not None, b_pool is not None
+        ctx.b_pool_t = b_pool
+        ctx.dp_slot = ent
+        ctx.save_for_backward(h, w_pool, w_self, w_neigh, neigh, argmax, dl)
+        ctx.mark_non_differentiable(rows, logits)
+        return mean, rows, logits
+
+    @staticmethod
+    def backward(ctx, dloss, _drows, _dlogits):
+        h, w_pool, w_self, w_neigh, neigh, argmax, dl = ctx.saved_tensors
+        unit = _UNIT_GRAD.get((dloss.device.type, dloss.device.index))
+        if unit is not None and dloss.data_ptr() == unit.data_ptr():
+            dy = dl
+        else:                                    # (a user's own root gradient: scaled into a matrix with the padded row stride)
+            dy = empty_mat(dl.shape[0], dl.shape[1], dl.device)
+            torch.mul(dl, dloss, out=dy)
+        return _out_layer_backward(ctx, dy, h, w_pool, w_self, w_neigh, neigh, argmax) + (None, None, None)
+
+
+def sage_pool_layer_loss(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels):
+    """(mean CE loss, per-seed losses, logits) of the last 'pool' layer + nn.CrossEntropyLoss, or None when the fused form does not
+    apply (the caller then runs the layer and the loss separately)."""
+    if h.dim() != 2 or small_pool_layer_fits(h.shape[0], n_dst, idx.shape[1], h.shape[1], w_self.shape[0]):
+        return None
+    if (b_self is None) != (b_neigh is None) or not out_loss_fits(h, n_dst, idx, w_self, w_neigh, w_pool.shape[0]):
+        return None
+    return _SagePoolLossFn.apply(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels)
 
 
 SMALL_LAYER = True      # small 'pool' layers run as one launch forward + one launch backward (small_layer.hip)
@@ -1900,6 +2143,7 @@ class _CrossEntropyMeanRowsFn(torch.autograd.Function):
             mean, rows, dl = ce_fwd_bwd_mean_grid(logits, labels, want_grad=logits.requires_grad)
         ctx.save_for_backward(dl)
         ctx.mark_non_differentiable(rows)
+        ctx.set_materialize_grads(False)             # (the rows' gradient stays None: no zero fill in front of backward)
         return mean, rows
 
     @staticmethod

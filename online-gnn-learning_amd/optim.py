@@ -1,19 +1,59 @@
-"""Adam on the HIP kernel (ogl_adam_step_multi) behind the torch.optim.Optimizer surface the strategies use
+"""Adam on the HIP kernel (ogl_adam_step_multi_slabs) behind the torch.optim.Optimizer surface the strategies use
 (``torch.optim.Adam(params, lr=0.001)``, R/train/graphsage/pytorch/model.py:24-25).
 
-``capturable=True`` keeps ONE step count for the whole parameter set in device memory (``ogl_adam_step_multi_dev``), so
-that ``step()`` can be recorded into a hipGraph and replayed (stepgraph.py); the arithmetic is the same."""
+``capturable=True`` keeps ONE step count for the whole parameter set in device memory, so that ``step()`` can be recorded into a
+hipGraph and replayed (stepgraph.py); the arithmetic is the same.
+
+Two things a train step's ``zero_grad / backward / step`` (R/.../pytorch/model.py:87,106-107,193,201-202) gains when it goes through
+``backward_and_step(loss)`` instead of ``loss.backward(); step()`` — same update, bit for bit:
+
+* **split-K slabs are summed by the optimiser launch** (``consumes_slabs``): inside ``ops.deferred_splitk`` the k-major weight gradients
+  skip their reduction launch and leave their partial sums; the Adam kernel adds them in slab order (the reduction launch's bits), writes
+  the gradient into ``p.grad`` and applies it.  Four ~8 us launches per Reddit step existed only to sum slabs Adam was about to read.
+* **the optimiser runs in two parts** (``early``): the first armed backward pass records the order in which gradients arrive; from then
+  on everything but the trailing arrivals (layer 0's ``fc_pool``: its weight gradient is the step's longest launch) is updated from the
+  gradient hook of the last early parameter — on the side stream of a forked backward, after everything both streams had enqueued, so
+  beside the layer-0 pool backward and weight gradient — and ``step()`` updates the rest.  No launch after that point reads an early
+  parameter (the input-gradient products read weight IMAGES built at the start of the step), and the side stream waits for the main
+  stream before the update.  The end of the step shrinks from reduce + prepare + Adam over 1.5 M parameters to Adam over 0.36 M."""
+import os
+
 import torch
 
 from . import ops
 
+EARLY = os.environ.get("OGL_ADAM_EARLY", "1") != "0"
+
 
 class Adam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
+    consumes_slabs = True
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False, early=None, late_fraction=0.35):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.capturable = bool(capturable)
         self._step_dev = None
         self._scalars_dev = None
+        self.early = EARLY if early is None else bool(early)
+        self.late_fraction = float(late_fraction)
+        self._armed = False          # hooks act only inside backward_and_step / backward_learn
+        self._learn_only = False
+        self._order = []             # arrival order (id(p)) of the armed backward pass
+        self._early_ids = None       # None: not learnt yet; frozenset (possibly empty: no early part) afterwards
+        self._early_seen = 0
+        self._early_done = False     # the early part of the CURRENT step has been applied
+        self._by_id = {}
+        if self.early:
+            for group in self.param_groups:
+                for p in group["params"]:
+                    if p.requires_grad and p.is_cuda:
+                        self._by_id[id(p)] = (p, group)
+                        p.register_post_accumulate_grad_hook(self._on_grad)
+
+    # ---- state ------------------------------------------------------------------------------------------------------------
+    @property
+    def needs_order(self):
+        """The early / late split has not been learnt yet (the next armed backward pass records the arrival order)."""
+        return self.early and self._early_ids is None and bool(self._by_id)
 
     def _device_state(self, device):
         if self._step_dev is None:
@@ -32,6 +72,98 @@ class Adam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 self._device_state(p.device)
 
+    # ---- the two-part step ------------------------------------------------------------------------------------------------
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        self._order.append(id(p))
+        if self._learn_only or not self._early_ids or self._early_done or id(p) not in self._early_ids:
+            return
+        self._early_seen += 1
+        if self._early_seen == len(self._early_ids):
+            # every early gradient exists (its kernels are enqueued): update those parameters now, beside the rest of the backward
+            with ops.early_section():
+                self._apply([self._by_id[i] for i in self._early_ids], prepare=True)
+            self._early_done = True
+
+    def _learn_split(self):
+        order = list(dict.fromkeys(self._order))
+        with_grad = [i for i, (p, _) in self._by_id.items() if p.grad is not None]
+        if len(order) != len(with_grad) or not order:
+            return                                      # (not every gradient arrived through a hook: try again next time)
+        total = sum(self._by_id[i][0].numel() for i in order)
+        late, acc = [], 0
+        for i in reversed(order):
+            n = self._by_id[i][0].numel()
+            if late and acc + n > self.late_fraction * total:
+                break
+            late.append(i); acc += n
+        early = [i for i in order if i not in set(late)]
+        self._early_ids = frozenset(early) if (early and late) else frozenset()
+
+    def _arm(self, learn_only=False):
+        self._armed, self._learn_only = True, bool(learn_only)
+        self._order, self._early_seen, self._early_done = [], 0, False
+
+    def backward_learn(self, loss):
+        """A backward pass that only records the arrival order of the gradients (no update): what a captured step runs once,
+        outside its capture, so that the capture itself already has the two-part form."""
+        self._arm(learn_only=True)
+        try:
+            ops.backward(loss)
+        finally:
+            self._armed = False
+        if self.needs_order:
+            self._learn_split()
+
+    def backward_and_step(self, loss):
+        """``loss.backward(); self.step()`` with the split-K slabs left to this optimiser and its early part launched from the
+        gradient hooks (module docstring).  Gradients must start from zero_grad(): one backward pass per step."""
+        with ops.deferred_splitk(self):
+            self._arm()
+            try:
+                ops.backward(loss)
+            finally:
+                self._armed = False
+            self.step()
+
+    # ---- the update -------------------------------------------------------------------------------------------------------
+    def _apply(self, items, prepare):
+        """Adam on ``items`` = [(parameter, its group)]: one launch per (group, host step count)."""
+        by_group = {}
+        for p, group in items:
+            if p.grad is not None:
+                by_group.setdefault(id(group), (group, []))[1].append(p)
+        first = True
+        for group, params in by_group.values():
+            b1, b2 = group["betas"]
+            buckets = {}
+            for p in params:
+                st = self.state[p]
+                if "exp_avg" not in st:
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                sg = ops.take_slabs(p)
+                g = p.grad
+                if not g.is_contiguous():
+                    if sg is not None:                      # (never for this package's kernels: the slab sum is written into g)
+                        ops.slab_reduce(sg, g.contiguous()); sg = None
+                    g = g.contiguous()
+                key = 0
+                if not self.capturable:
+                    st["step"] = st.get("step", 0) + 1
+                    key = st["step"]
+                buckets.setdefault(key, []).append((p.data, g, st["exp_avg"], st["exp_avg_sq"], sg))
+            for step, its in buckets.items():               # normally one bucket: every tensor in ONE launch
+                ps, gs, ms, vs, sgs = zip(*its)
+                if self.capturable:
+                    step_dev, scal = self._device_state(ps[0].device)
+                    ops.adam_step_multi_slabs(ps, gs, ms, vs, sgs, step_dev=step_dev, scalars_dev=scal, prepare=prepare and first,
+                                              lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"])
+                else:
+                    ops.adam_step_multi_slabs(ps, gs, ms, vs, sgs, step=step, lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"])
+                first = False
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -40,37 +172,10 @@ class Adam(torch.optim.Optimizer):
                 loss = closure()
         ops.side_join()                     # (a forked backward joins itself when it ends; this is for gradients made by hand)
         ops.invalidate_weight_images()      # the kernels below write the parameters through raw pointers (no version bump)
-        for group in self.param_groups:
-            b1, b2 = group["betas"]
-            if self.capturable:
-                items = []
-                for p in group["params"]:
-                    if p.grad is None:
-                        continue
-                    st = self.state[p]
-                    if "exp_avg" not in st:
-                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                    items.append((p.data, g, st["exp_avg"], st["exp_avg_sq"]))
-                if items:
-                    step_dev, scal = self._device_state(items[0][0].device)
-                    ps, gs, ms, vs = zip(*items)
-                    ops.adam_step_multi_dev(ps, gs, ms, vs, step_dev, scal, group["lr"], b1, b2, group["eps"])
-                continue
-            buckets = {}
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st["step"] += 1
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                buckets.setdefault(st["step"], []).append((p.data, g, st["exp_avg"], st["exp_avg_sq"]))
-            for step, items in buckets.items():      # normally one bucket: every tensor in ONE launch
-                ps, gs, ms, vs = zip(*items)
-                ops.adam_step_multi(ps, gs, ms, vs, step, group["lr"], b1, b2, group["eps"])
+        done = self._early_ids if self._early_done else frozenset()
+        items = [(p, group) for group in self.param_groups for p in group["params"] if p.grad is not None and id(p) not in done]
+        self._apply(items, prepare=not self._early_done)
+        if self.needs_order and self._order:
+            self._learn_split()
+        self._early_done, self._order = False, []
         return loss

@@ -78,17 +78,20 @@ class TrainStepGraph:
     """One captured train step over ``buf`` restricted to (n1_pad, n0_pad) rows.
     ``loss_fn(logits, labels) -> (scalar loss to differentiate, per-seed losses or None)``."""
 
-    def __init__(self, model, optimizer, graph, buf, n1_pad, n0_pad, loss_fn, pool=None, apply=True):
+    def __init__(self, model, optimizer, graph, buf, n1_pad, n0_pad, loss_fn, pool=None, apply=True, loss_kind=None):
         # apply=False: forward + loss + backward only — the step of a data-parallel replica, whose gradients are all-reduced
         # (eagerly: the collective stays outside the graph) before the optimiser runs
         self.model, self.opt, self.graph, self.buf, self.loss_fn, self.apply = model, optimizer, graph, buf, loss_fn, bool(apply)
+        # "mean" / "mean_rows": the loss is nn.CrossEntropyLoss — the model may run its last layer and the loss as one node
+        # (GraphSAGE.forward_loss); None: an arbitrary loss_fn(logits, labels)
+        self.loss_kind = loss_kind if hasattr(model, "forward_loss") else None
         self.n1_pad, self.n0_pad = int(n1_pad), int(n0_pad)
         assert self.n1_pad <= buf.n1_cap and self.n0_pad <= buf.n0_cap
         self.loss = self.loss_rows = None
         self.cuda_graph = torch.cuda.CUDAGraph()
         self._capture(pool)
 
-    def _body(self, apply=None):
+    def _body(self, apply=None, learn=False):
         apply = self.apply if apply is None else apply
         g, b = self.graph, self.buf
         src0, src1, lidx0 = b.src0[:self.n0_pad], b.src1[:self.n1_pad], b.lidx0[:self.n1_pad]
@@ -96,11 +99,19 @@ class TrainStepGraph:
         # the FULL tables: a snapshot view's row count would be frozen into the graph (ids are < n_present by construction)
         labels = ops.LazyLabels(g.target_table, b.seeds) if LAZY_LABELS else ops.gather_i64(g.target_table, b.seeds)
         self.opt.zero_grad(set_to_none=True)
-        logits = self.model(blocks, GatheredRows(g.feat_table, src0))
-        loss, rows = self.loss_fn(logits, labels)
-        ops.backward(loss)
-        if apply:
-            self.opt.step()
+        if self.loss_kind is not None:
+            loss, rows, _ = self.model.forward_loss(blocks, GatheredRows(g.feat_table, src0), labels, rows=self.loss_kind == "mean_rows")
+        else:
+            logits = self.model(blocks, GatheredRows(g.feat_table, src0))
+            loss, rows = self.loss_fn(logits, labels)
+        if apply and hasattr(self.opt, "backward_and_step"):
+            self.opt.backward_and_step(loss)          # split-K slabs summed by the optimiser launch, its early part on the side branch
+        elif learn and hasattr(self.opt, "backward_learn"):
+            self.opt.backward_learn(loss)             # (the warm-up pass: records the order in which the gradients arrive)
+        else:
+            ops.backward(loss)
+            if apply:
+                self.opt.step()
         self.loss, self.loss_rows = loss.detach(), (rows.detach() if rows is not None else None)
 
     def _capture(self, pool):
@@ -111,13 +122,16 @@ class TrainStepGraph:
         ops.unit_grad(self.graph.device)
         ops.ce_counter(self.graph.device, 0)                 # (allocates the device's counter array outside the capture)
         ops._static_image(self.graph.feat_table)            # built outside the capture (a one-off 850 MB split pass)
-        if not _WARMED:
+        learn = self.apply and getattr(self.opt, "needs_order", False)
+        if not _WARMED or learn:
             # once per process: run the step's forward + backward for real on a side stream (autograd's device thread, lazily
-            # created helpers), WITHOUT the optimiser step and with the gradients dropped — the weights do not move
+            # created helpers), WITHOUT the optimiser step and with the gradients dropped — the weights do not move.  (Also once
+            # per optimiser that applies its update in two parts: the pass tells it the order in which the gradients arrive, so
+            # that the capture below already has the early part on its side branch.)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                self._body(apply=False)
+                self._body(apply=False, learn=learn)
             torch.cuda.current_stream().wait_stream(side)
             self.opt.zero_grad(set_to_none=True)
             ops.invalidate_weight_images()          # no optimiser step ran: drop the weight images that forward prepared
@@ -223,8 +237,8 @@ class StepGraphCache:
 
     MAX_GRAPHS = 24
 
-    def __init__(self, model, optimizer, S, loss_fn):
-        self.model, self.opt, self.S, self.loss_fn = model, optimizer, int(S), loss_fn
+    def __init__(self, model, optimizer, S, loss_fn, loss_kind=None):
+        self.model, self.opt, self.S, self.loss_fn, self.loss_kind = model, optimizer, int(S), loss_fn, loss_kind
         self.bufs, self.samplers = {}, {}
         self.graphs = collections.OrderedDict()
         self.captures = self.evictions = self.borrowed = self.deferred = 0
@@ -239,7 +253,8 @@ class StepGraphCache:
                     self.bufs.pop(old_key, None)
                 del old
                 self.evictions += 1
-            sg = self.graphs[key] = TrainStepGraph(self.model, self.opt, graph, buf, n1_pad, n0_pad, self.loss_fn, apply=apply)
+            sg = self.graphs[key] = TrainStepGraph(self.model, self.opt, graph, buf, n1_pad, n0_pad, self.loss_fn, apply=apply,
+                                                   loss_kind=self.loss_kind)
             self.captures += 1
         else:
             self.graphs.move_to_end(key)

@@ -74,16 +74,14 @@ def load(name, snapshots=None, device="cuda", scale=1.0):
     a = make_arrays(name, scale)
     snapshots = snapshots or a["snapshots"]
     labelled = set(range(a["n"]))
-    graphs = []
-    for _ in range(2):                       # the train graph and the look-ahead test graph
-        if a["stream"] == "vertex":
-            gd = FullGraphData(a["n"], np.concatenate([a["src"], a["dst"]]), np.concatenate([a["dst"], a["src"]]),
-                               a["feat"], a["labels"])
-            g = DynamicGraphVertex(gd, snapshots, labelled, device=device)
-            ts = {int(v): int(t) for t, v in enumerate(a["order"])}
-            g.build(vertex_timestamps=ts)
-        else:
-            g = DynamicGraphEdge(snapshots, labelled, device=device)
-            g.build(a["feat"], a["labels"], True, edge_timestamps={"src": a["src"], "dst": a["dst"]})
-        graphs.append(g)
-    return a["f"], a["labels"].reshape(-1, 1), graphs[0], a["c"], graphs[1]
+    # the train graph and the look-ahead test graph: two snapshot views of ONE resident copy of the static data (twin())
+    if a["stream"] == "vertex":
+        gd = FullGraphData(a["n"], np.concatenate([a["src"], a["dst"]]), np.concatenate([a["dst"], a["src"]]),
+                           a["feat"], a["labels"])
+        g = DynamicGraphVertex(gd, snapshots, labelled, device=device)
+        ts = {int(v): int(t) for t, v in enumerate(a["order"])}
+        g.build(vertex_timestamps=ts)
+    else:
+        g = DynamicGraphEdge(snapshots, labelled, device=device)
+        g.build(a["feat"], a["labels"], True, edge_timestamps={"src": a["src"], "dst": a["dst"]})
+    return a["f"], a["labels"].reshape(-1, 1), g, a["c"], g.twin()

@@ -217,7 +217,19 @@ def test_fullsize_free_running_steps_track_the_oracle(reddit):
         ops.set_gemm_mode("f32")
 
 
-def _fullsize_step(a, dyn, g, host, B=512, S=25):
+def test_fullsize_fused_output_layer_step_matches_oracle(reddit):
+    """The same full-size step with the last layer and the loss as ONE autograd node (GraphSAGE.forward_loss: what the
+    strategies run): same oracle, same tolerances, same forced-winner gradient check."""
+    from ogl_amd import ops
+    a, dyn, g, host = reddit
+    ops.set_gemm_mode("auto")
+    try:
+        _fullsize_step(a, dyn, g, host, fused_loss=True)
+    finally:
+        ops.set_gemm_mode("f32")
+
+
+def _fullsize_step(a, dyn, g, host, B=512, S=25, fused_loss=False):
     from ogl_amd import ops, optim, sampling
     from ogl_amd.graphsage import GatheredRows, GraphSAGE
     g.set_snapshot(g.n_total, len(a["src"]))                          # the last snapshot, whichever test ran before
@@ -240,8 +252,12 @@ def _fullsize_step(a, dyn, g, host, B=512, S=25):
     winners = []
     ops.capture_pool_winners(winners)            # test hook: the winners / ReLU masks the device chose, per pool layer
     try:
-        logits_dev = model(blocks, GatheredRows(g.ndata["feat"], input_nodes))
-        loss = ops.cross_entropy(logits_dev, labels, "mean")
+        if fused_loss:
+            loss, _, logits_dev = model.forward_loss(blocks, GatheredRows(g.ndata["feat"], input_nodes), labels)
+            assert isinstance(loss.grad_fn, ops._SagePoolLossFn._backward_cls)          # the fused node really ran
+        else:
+            logits_dev = model(blocks, GatheredRows(g.ndata["feat"], input_nodes))
+            loss = ops.cross_entropy(logits_dev, labels, "mean")
     finally:
         ops.capture_pool_winners(None)
     loss.backward()

@@ -335,6 +335,13 @@ def test_on_disk_loaders_roundtrip(pkg, tmp_path):
     assert np.array_equal(dyn.get_subgraph_to_original_map(), order)
     dyn.evolve(); dyn_test.evolve(); dyn_test.evolve()
     assert dyn.get_graph().n_present == 60 and dyn_test.get_graph().n_present == 90
+    # the two streams are snapshot views of ONE resident copy of the static data (feature / label tables, CSR), each with its own
+    # per-snapshot degrees
+    gt = dyn_test.get_graph()
+    assert gt is not dyn.get_graph() and gt.feat_table.data_ptr() == dyn.get_graph().feat_table.data_ptr()
+    assert gt.target_table.data_ptr() == dyn.get_graph().target_table.data_ptr() and gt.handle._h.value != dyn.get_graph().handle._h.value
+    d60, d90 = dyn.get_graph().handle.degrees().cpu().numpy(), gt.handle.degrees().cpu().numpy()
+    assert (d60[60:] == 0).all() and (d90[:60] >= d60[:60]).all() and d90.sum() > d60.sum()
     # edge stream
     e = synthetic.make_arrays("toy_edge")
     d2 = tmp_path / "reddit"; d2.mkdir()

@@ -1,0 +1,262 @@
+"""Round-4 additions, each against a reference computed another way on the same device or the CPU oracle: the output layer's forward
+fused with the loss (one launch for neighbour max + projection + cross entropy), split-K weight gradients consumed by the optimiser
+launch, the optimiser's early (side-branch) part.  Run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _mat(x, dev="cuda"):
+    from ogl_amd import ops
+    t = torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32)
+    return ops.empty_mat(t.shape[0], t.shape[1], dev).copy_(t)
+
+
+@pytest.mark.parametrize("rows_per_block", [0, 1, 2, 4])
+@pytest.mark.parametrize("n_dst,n_src,S,K,N", [(512, 7054, 25, 600, 41), (513, 3000, 30, 600, 41), (37, 500, 1, 64, 3),
+                                               (1024, 9000, 64, 1024, 64), (200, 2000, 7, 256, 2)])
+def test_fused_output_layer_forward_and_loss(n_dst, n_src, S, K, N, rows_per_block):
+    """ogl_out_layer_fwd_ce against (a) the three launches it replaces — neighbour max and argmax BIT-exact, the loss arithmetic
+    bit-exact GIVEN the logits — and (b) the oracle (numpy max, torch-CPU linear + cross entropy) at the stated tolerances.
+    Edge cases in every shape: destinations without neighbours (-1 rows), neighbour ids equal to the destination, labels out of
+    range (no target term, loss 0), an odd destination count under 2 / 4 rows per block, the zero fill on the side."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    rng = np.random.default_rng(n_dst + K)
+    p = np.maximum(rng.standard_normal((n_src, K)), 0).astype(np.float32)            # relu(fc_pool(h)): many exact zeros -> ties
+    h = rng.standard_normal((n_src, K)).astype(np.float32)
+    li = rng.integers(0, n_src, size=(n_dst, S)).astype(np.int32)
+    li[rng.random(n_dst) < 0.05] = -1
+    li[3 % n_dst, :] = 3 % n_dst
+    ws = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    wn = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bs, bn = rng.standard_normal(N).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+    labels = rng.integers(0, N, size=n_dst).astype(np.int64)
+    labels[5 % n_dst] = N + 3
+    labels[7 % n_dst] = -1
+    pt, ht, idx = _mat(p), _mat(h), torch.as_tensor(li).cuda()
+    wst, wnt, bst, bnt = torch.as_tensor(ws).cuda(), torch.as_tensor(wn).cuda(), torch.as_tensor(bs).cuda(), torch.as_tensor(bn).cuda()
+    lab = torch.as_tensor(labels).cuda()
+    zero = torch.full((4096,), 7.0, device="cuda")
+    prev = ops.OUT_FWD_ROWS
+    ops.OUT_FWD_ROWS = rows_per_block
+    try:
+        mean, rows, logits, neigh, argmax, dl = ops.out_layer_fwd_ce(pt, idx, ht, n_dst, wst, wnt, bst, bnt, lab, zero=zero)
+        # the label gather inside the launch
+        table = torch.full((n_dst + 50,), -7, dtype=torch.int64, device="cuda")
+        ids = torch.randperm(n_dst + 50, device="cuda")[:n_dst].contiguous()
+        table[ids] = lab
+        mean_l, rows_l, logits_l, _, _, dl_l = ops.out_layer_fwd_ce(pt, idx, ht, n_dst, wst, wnt, bst, bnt, ops.LazyLabels(table, ids))
+    finally:
+        ops.OUT_FWD_ROWS = prev
+    assert float(zero.abs().sum()) == 0.0
+    assert torch.equal(rows_l, rows) and torch.equal(logits_l, logits) and torch.equal(dl_l, dl) and float(mean_l) == float(mean)
+    # (a) the launches it replaces
+    neigh_ref, arg_ref = ops.reduce_fwd(pt, idx, "max", want_argmax=True)
+    assert torch.equal(neigh, neigh_ref) and torch.equal(argmax, arg_ref)
+    rows_ref, dl_ref = ops.ce_fwd_bwd(logits, lab, 1.0 / n_dst)
+    assert torch.equal(rows, rows_ref) and torch.equal(dl, dl_ref)
+    mean_ref, _, _ = ops.ce_fwd_bwd_mean_grid(logits, lab, want_grad=False)
+    assert float(mean) == float(mean_ref)
+    logits_3 = ops.linear_fwd(ht[:n_dst], wst, bst + bnt, x2=neigh_ref, w2=wnt)
+    torch.testing.assert_close(logits, logits_3, rtol=1e-4, atol=1e-5)
+    # (b) the oracle
+    want_neigh, want_arg = O.reduce_fwd(p, li, "max")
+    assert np.array_equal(neigh.cpu().numpy(), want_neigh) and np.array_equal(argmax.cpu().numpy(), want_arg)
+    want_logits = F.linear(torch.as_tensor(h[:n_dst]), torch.as_tensor(ws), torch.as_tensor(bs)) + \
+        F.linear(torch.as_tensor(want_neigh), torch.as_tensor(wn), torch.as_tensor(bn))
+    torch.testing.assert_close(logits.cpu(), want_logits, rtol=1e-4, atol=1e-5)
+    ok = (labels >= 0) & (labels < N)
+    want_rows = np.zeros(n_dst, dtype=np.float64)
+    want_rows[ok] = F.cross_entropy(want_logits[ok].double(), torch.as_tensor(labels[ok]), reduction="none").numpy()
+    np.testing.assert_allclose(rows.cpu().numpy(), want_rows, rtol=1e-4, atol=1e-5)
+    assert abs(float(mean) - want_rows.sum() / n_dst) <= 1e-5 * max(1.0, abs(want_rows.mean()))
+
+
+@pytest.mark.parametrize("rows", [False, True])
+def test_fused_last_layer_and_loss_equals_layer_then_loss(rows):
+    """GraphSAGE.forward_loss (the last 'pool' layer + nn.CrossEntropyLoss as one autograd node) against model(...) followed by
+    ops.cross_entropy, same weights and blocks at the Reddit shape: loss / per-seed losses / logits to fp32 summation-order
+    differences (the fused projection sums its 1 200 terms in another order), every gradient to the rung tests' tolerance."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops, sampling
+    from ogl_amd.graphsage import GraphSAGE
+    from ogl_amd.sampling import Block
+    ops.set_gemm_mode("auto")
+    prev = ops.FUSED_OUT_FWD
+    try:
+        torch.manual_seed(5)
+        rng = np.random.default_rng(5)
+        n0, n1, B, S, Fin, H, C = 20000, 7054, 512, 25, 602, 600, 41
+        x = _mat(rng.standard_normal((n0, Fin)))
+        li0 = torch.as_tensor(rng.integers(0, n0, size=(n1, S)).astype(np.int32)).cuda()
+        li1 = torch.as_tensor(rng.integers(0, n1, size=(B, S)).astype(np.int32)).cuda()
+        li1[11] = -1
+        blocks = [Block(torch.arange(n0).cuda(), torch.arange(n1).cuda(), li0), Block(torch.arange(n1).cuda(), torch.arange(B).cuda(), li1)]
+        labels = torch.as_tensor(rng.integers(0, C, size=B)).cuda()
+        model = GraphSAGE(Fin, H, C, 1, F.relu, 0, "pool").cuda()
+        res = {}
+        for fused in (False, True):
+            ops.FUSED_OUT_FWD = fused
+            model.zero_grad(set_to_none=True)
+            ops.invalidate_weight_images()
+            loss, r, logits = model.forward_loss(blocks, x, labels, rows=rows)
+            ops.backward(loss)
+            res[fused] = dict(loss=float(loss), rows=None if r is None else r.detach().clone(), logits=logits.detach().clone(),
+                              grads=[p.grad.detach().clone() for p in model.parameters()])
+        a, b = res[False], res[True]
+        assert abs(a["loss"] - b["loss"]) <= 1e-5 * abs(a["loss"])
+        torch.testing.assert_close(b["logits"], a["logits"], rtol=1e-4, atol=1e-5)
+        if rows:
+            torch.testing.assert_close(b["rows"], a["rows"], rtol=1e-4, atol=1e-5)
+        for (n_, _), ga, gb in zip(model.named_parameters(), a["grads"], b["grads"]):
+            rel = float((ga - gb).norm() / ga.norm())
+            assert rel <= 2e-4, (n_, rel)           # (a max / ReLU near-tie may flip between the two evaluations of layer 1's input)
+    finally:
+        ops.FUSED_OUT_FWD = prev
+        ops.set_gemm_mode("f32")
+
+
+def test_adam_sums_split_k_slabs_in_its_own_launch():
+    """ogl_adam_step_multi_slabs against ogl_x3_slab_reduce + ogl_adam_step_multi: the gradient it writes and the parameters / moments
+    after the step are BIT-identical (same slab order, same update arithmetic) — weights [N, K] with 16-byte-aligned and odd row
+    lengths, a bias taken from the ones column, a plain tensor in the same launch, host and device-side step counts."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    g = torch.Generator().manual_seed(3)
+    dev = "cuda"
+    cases = [(600, 602, 17), (41, 600, 3), (33, 7, 5)]           # (rows N, columns K, slabs)
+    ps, sgs, refs = [], [], []
+    for N, K, ns in cases:
+        ld = (K + 1 + 3) // 4 * 4
+        ws = torch.randn(ns, N, ld, generator=g).to(dev).contiguous()
+        w = torch.randn(N, K, generator=g).to(dev)
+        b = torch.randn(N, generator=g).to(dev)
+        for p_, sg in ((w, ops.SlabGrad(ws, N * ld, ld, ns, N, K, 0)), (b, ops.SlabGrad(ws, N * ld, ld, ns, N, 1, K))):
+            want_g = torch.empty_like(p_)
+            ops.slab_reduce(sg, want_g)
+            host = ws[0, :, sg.col0:sg.col0 + sg.ncols].clone()
+            for s_ in range(1, ns):
+                host = host + ws[s_, :, sg.col0:sg.col0 + sg.ncols]
+            assert torch.equal(want_g.reshape(N, -1), host)                      # the reduction launch = the slab-order sum
+            ps.append(p_); sgs.append(sg); refs.append(want_g)
+    plain, plain_g = torch.randn(1000, generator=g).to(dev), torch.randn(1000, generator=g).to(dev)
+    ps.append(plain); sgs.append(None); refs.append(plain_g)
+    for device_count in (False, True):
+        a = [p_.clone() for p_ in ps]; am = [torch.zeros_like(p_) for p_ in ps]; av = [torch.zeros_like(p_) for p_ in ps]
+        b_ = [p_.clone() for p_ in ps]; bm = [torch.zeros_like(p_) for p_ in ps]; bv = [torch.zeros_like(p_) for p_ in ps]
+        gs = [torch.full_like(p_, float("nan")) if sg is not None else r.clone() for p_, sg, r in zip(ps, sgs, refs)]
+        step_dev, scal = torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(2, device=dev)
+        for step in (1, 2, 3):
+            ops.adam_step_multi(a, refs, am, av, step)
+            if device_count:            # applied in two launches: the second one does not prepare again
+                ops.adam_step_multi_slabs(b_[:3], gs[:3], bm[:3], bv[:3], sgs[:3], step_dev=step_dev, scalars_dev=scal, prepare=True)
+                ops.adam_step_multi_slabs(b_[3:], gs[3:], bm[3:], bv[3:], sgs[3:], step_dev=step_dev, scalars_dev=scal, prepare=False)
+            else:
+                ops.adam_step_multi_slabs(b_, gs, bm, bv, sgs, step=step)
+            for x, y in zip(a + am + av, b_ + bm + bv):
+                assert torch.equal(x, y)
+            for got, want in zip(gs, refs):
+                assert torch.equal(got, want)
+        if device_count:
+            assert int(step_dev) == 3
+
+
+def test_deferred_split_k_reduction_equals_the_reduction_launch():
+    """A k-major weight gradient inside ops.deferred_splitk leaves slabs; reduced at the context's end (no optimiser took them)
+    they give the gradient of the plain call bit for bit — dw and both bias-gradient copies."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    ops.set_gemm_mode("auto")
+    try:
+        torch.manual_seed(2)
+        M, N, K = 7054, 600, 602
+        dy = torch.randn(M, N, device="cuda"); x = torch.randn(M, K, device="cuda")
+        dy_img, x_img = ops.x3_split(dy), ops.x3_split(x, append_ones=True)
+        want = ops.linear_bwd_weight_x3k(dy_img, x_img, M, K, want_bias=True, want_bias2=True, dy_rows=True)
+        w = torch.nn.Parameter(torch.zeros(N, K, device="cuda"))
+        b = torch.nn.Parameter(torch.zeros(N, device="cuda")); b2 = torch.nn.Parameter(torch.zeros(N, device="cuda"))
+
+        class Opt:                       # the surface deferred_splitk looks at
+            consumes_slabs = True
+            param_groups = [dict(params=[w, b, b2])]
+        with ops.deferred_splitk(Opt()):
+            got = ops.linear_bwd_weight_x3k(dy_img, x_img, M, K, want_bias=True, want_bias2=True, dy_rows=True, defer_for=(w, b, b2))
+            assert len(ops._SLABS["pending"]) == 3                      # nothing reduced yet
+            w.grad, b.grad, b2.grad = got
+        assert not ops._SLABS["pending"]
+        for g_, w_ in zip(got, want):
+            assert torch.equal(g_, w_)
+        # outside the context nothing is deferred
+        again = ops.linear_bwd_weight_x3k(dy_img, x_img, M, K, want_bias=True, want_bias2=True, dy_rows=True, defer_for=(w, b, b2))
+        assert not ops._SLABS["pending"] and all(torch.equal(g_, w_) for g_, w_ in zip(again, want))
+    finally:
+        ops.set_gemm_mode("f32")
+
+
+def test_two_part_optimiser_step_equals_the_plain_step():
+    """backward_and_step (slabs summed by the optimiser launch, everything but layer 0's fc_pool updated from the gradient hooks)
+    against loss.backward(); step() with the reduction launches: three Reddit-shaped steps from the same weights.  The two runs
+    share every kernel but the reductions' placement, so the first step's gradients agree to the float atomics' noise and the
+    weights to the rung tests' Adam-aware bound; the launch sequence shows the two parts and no reduction launch."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops, optim
+    from ogl_amd.graphsage import GraphSAGE
+    from ogl_amd.sampling import Block
+    ops.set_gemm_mode("auto")
+    try:
+        rng = np.random.default_rng(9)
+        n0, n1, B, S, Fin, H, C = 20000, 7054, 512, 25, 602, 600, 41
+        x = _mat(rng.standard_normal((n0, Fin)))
+        ops.register_static_table(x)
+        from ogl_amd.graphsage import GatheredRows
+        ids0 = torch.arange(n0, device="cuda")
+        li0 = torch.as_tensor(rng.integers(0, n0, size=(n1, S)).astype(np.int32)).cuda()
+        li1 = torch.as_tensor(rng.integers(0, n1, size=(B, S)).astype(np.int32)).cuda()
+        blocks = [Block(ids0, torch.arange(n1).cuda(), li0), Block(torch.arange(n1).cuda(), torch.arange(B).cuda(), li1)]
+        labels = torch.as_tensor(rng.integers(0, C, size=B)).cuda()
+        torch.manual_seed(4)
+        base = GraphSAGE(Fin, H, C, 1, F.relu, 0, "pool").cuda()
+        init = [p.detach().clone() for p in base.parameters()]
+        out = {}
+        for two_part in (False, True):
+            model = GraphSAGE(Fin, H, C, 1, F.relu, 0, "pool").cuda()
+            with torch.no_grad():
+                for p, v in zip(model.parameters(), init):
+                    p.copy_(v)
+            opt = optim.Adam(model.parameters(), lr=1e-3, early=two_part)
+            grads1, calls = None, []
+            for step in range(3):
+                opt.zero_grad()
+                loss, _, _ = model.forward_loss(blocks, GatheredRows(x, ids0), labels)
+                if step == 2:
+                    ops.profile_start()
+                if two_part:
+                    opt.backward_and_step(loss)
+                else:
+                    ops.backward(loss); opt.step()
+                if step == 2:
+                    calls = [n for n, _, _ in ops.profile_stop()]
+                if step == 0:
+                    grads1 = [p.grad.detach().clone() for p in model.parameters()]
+            out[two_part] = dict(grads=grads1, weights=[p.detach().clone() for p in model.parameters()], calls=calls,
+                                 early=len(opt._early_ids or ()))
+        a, b = out[False], out[True]
+        assert a["early"] == 0 and b["early"] == 10, (a["early"], b["early"])       # all but layer 0's fc_pool weight + bias
+        assert a["calls"].count("ogl_adam_step_multi_slabs") == 1 and b["calls"].count("ogl_adam_step_multi_slabs") == 2
+        assert "ogl_x3_slab_reduce" not in b["calls"]
+        for ga, gb in zip(a["grads"], b["grads"]):
+            assert float((ga - gb).norm() / ga.norm()) <= 1e-5
+        bad = total = 0
+        for wa, wb in zip(a["weights"], b["weights"]):
+            d = (wa - wb).abs()
+            bad += int((d > 2e-5).sum()); total += d.numel()
+            assert float(d.max()) <= 3 * 2.5e-3
+        assert bad <= 3e-3 * total, (bad, total)
+    finally:
+        ops.set_gemm_mode("f32")

@@ -61,9 +61,11 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_update_equals_one_rank(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_two_rank_update_equals_one_rank(tmp_path, world):
+    """world 2: ragged shards (19 + 18 seeds); world 8 — the node the scaling bench runs on: shards of 5 / 4 seeds."""
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     got = torch.load(out)
     indptr, indices, deg_t, feat, labels, seeds, F, C = _problem()
     model = O.CpuModel("pool", F, 8, C, seed=3)
@@ -335,7 +337,7 @@ def _worker_partitioned(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])                 # (8: five batches over eight ranks — three ranks without a batch)
 def test_partitioned_equals_replicated_equals_one_rank(tmp_path, world):
     out = str(tmp_path / "part.pt")
     mp.spawn(_worker_partitioned, args=(world, _free_port(), out), nprocs=world, join=True)

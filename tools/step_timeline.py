@@ -16,7 +16,13 @@ def main():
     for r in csv.DictReader(open(sys.argv[1])):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"), int(r.get("Grid_Size", 0) or 0)))
     rows.sort()
+    # a step ends with its LAST optimiser launch (since round 4 the optimiser may run in two parts: an early one on the side branch,
+    # the rest at the end): the Adam launch that is followed by the next step's staging / weight-image launch (or by nothing)
     adam = [i for i, r in enumerate(rows) if "k_adam_multi" in r[2] or r[2].startswith("k_adam(")]     # (not k_adam_prepare)
+    firsts = ("k_stage_segments", "k_x3_split_multi", "k_sample_layer", "k_block_")
+    last = [i for i in adam if i + 1 >= len(rows) or any(f in rows[i + 1][2] for f in firsts)]
+    if len(last) >= 2:
+        adam = last
     steps = [(adam[k], adam[k + 1]) for k in range(len(adam) - 1)]
     steps = [(a, b) for a, b in steps if b - a >= 8] or steps       # (whole train steps, not the optimiser's own two launches)
     lens = sorted((rows[b][1] - rows[a][1], k) for k, (a, b) in enumerate(steps))
@@ -24,7 +30,7 @@ def main():
     a, b = steps[pick]
     seg = rows[a + 1:b + 1]
     t0 = rows[a][1]
-    print("step %d of %d: %.1f us from the end of one Adam launch to the end of the next; %d dispatches" % (pick, len(steps), (rows[b][1] - t0) / 1e3, len(seg)))
+    print("step %d of %d: %.1f us from the end of one step's last Adam launch to the end of the next's; %d dispatches" % (pick, len(steps), (rows[b][1] - t0) / 1e3, len(seg)))
     busy_until = t0
     idle = overlap_total = 0.0
     print("%9s %9s %8s %8s %5s  %s" % ("start_us", "dur_us", "gap_us", "ovl_us", "queue", "kernel [grid]"))
