@@ -77,6 +77,9 @@ def parse():
                     help="nccl = RCCL over xGMI (one GPU per rank); gloo = rehearsal of the N>1 path with several ranks on one GPU")
     ap.add_argument("--gemm", default="auto", choices=["f32", "bf16x6", "auto"],
                     help="projection arithmetic: exact fp32 MFMA, split-bf16 (x6, fp32-accurate) MFMA, or per-layout best")
+    ap.add_argument("--aggregator", default="pool", choices=["pool", "meanpool", "mean", "maxpool", "gcn"],
+                    help="aggregator_type of the model (R/train/__main__.py:124-127 passes 'pool': DGL's SAGEConv; the others are the "
+                         "in-repo layer's modes, R/train/graphsage/pytorch/aggregator_dgl.py:128-216, with pool_feats = the hidden size)")
     ap.add_argument("--no-graphs", action="store_true", help="enqueue every launch from Python instead of replaying captured steps")
     ap.add_argument("--graphs", action="store_true", help="replay captured steps for every batch size (default: the strategy's "
                     "'auto' policy — small batches always, large ones only when the host cannot keep ahead of the GPU)")
@@ -201,7 +204,7 @@ def main():
     setup_s = time.time() - t0
 
     torch.manual_seed(1)                                     # identical replicas on every rank
-    model = GraphSAGE(feat_size, H, n_classes, 1, F.relu, 0, "pool", edge_feats=0, pool_feats=H).cuda()
+    model = GraphSAGE(feat_size, H, n_classes, 1, F.relu, 0, args.aggregator, edge_feats=0, pool_feats=H).cuda()
     sampling.seed(1)
     split_rng = np.random.default_rng(synthetic.SEEDS["split"])
     train_set = np.sort(split_rng.permutation(g.n_present)[: int(0.85 * g.n_present)])
@@ -352,6 +355,10 @@ def main():
             a["bytes"] += meta["n_dst"] * 4 * meta["d"] + (meta["n_src"] + 31) // 32 * 32 * 6 * meta["d"]
         elif name == "ogl_pool_bwd_x3_plan":                         # argmax + pooled rows read, 2-byte (column, slot) ids written
             a["bytes"] += meta["n_dst"] * meta["d"] * (4 + 4 + 2)
+        elif name == "ogl_reduce_bwd_seg_apply":                     # SURVEY 8(d) style: E gathered rows + n_src rows written (+ image / mask)
+            a["bytes"] += (meta["n_dst"] * meta["fanout"] * 4 * meta["d"] + meta["n_src"] * meta["d"] * ((4 if meta["out"] else 0) +
+                           (6 if meta["image"] else 0) + (4 if meta["mask"] else 0)))
+            a["bytes_8d"] = a.get("bytes_8d", 0.0) + meta["n_dst"] * meta["fanout"] * 4 * meta["d"] + meta["n_src"] * 4 * meta["d"]
         elif name == "ogl_relu_bwd_img":                             # dy, y read; masked dy + its image written
             a["bytes"] += meta["M"] * meta["N"] * (4 + 4 + 4 + 6)
         elif name == "ogl_x3_split":
@@ -384,6 +391,19 @@ def main():
                          "8 TB/s pin rate.  `traffic` (PMC FETCH_SIZE x 2 + WRITE_SIZE) is the L2's fabric-side request bytes: "
                          "Infinity-Cache hits are included (MI355X_MICROARCH.md), so traffic / time bounds the HBM rate from above — "
                          "a plain streamed copy tops out at ~6.3 TB/s on this part")
+    roof_mean_bwd = None
+    sagg = agg.get("ogl_reduce_bwd_seg_apply")
+    if sagg:
+        # the longest launch class dominates: report the pooled figure over the step's launches (layer 0's is >= 95 % of the bytes)
+        ach8 = sagg["bytes_8d"] / sagg["ms"] / 1e6
+        roof_mean_bwd = dict(kernel="k_seg_reduce + k_seg_fixup (mean backward as a planned segmented gather: edges sorted by source, "
+                                    "64-entry tiles, no atomics)", bound="hbm", achieved=round(ach8, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=round(ach8 / HBM_PEAK_GBS, 4), traffic=None, ms_per_step=round(sagg["ms"] / prof_steps, 4),
+                             algorithmic_bytes_per_step=round(sagg["bytes_8d"] / prof_steps),
+                             bytes_moved_per_step=round(sagg["bytes"] / prof_steps),
+                             frac_kind="algorithmic bytes E * 4D read + n_src * 4D written (VERDICT r3 item 3) / launch time / 8 TB/s; the [n_dst, D] "
+                                       "gradient matrix the rows are gathered from stays in L2 / MALL, so this is not a pin rate; bytes_moved "
+                                       "counts what the launch really writes (the bf16x3 image instead of fp32 rows, + the ReLU mask it reads)")
     gemm_keys = [k for k in agg if k.startswith("linear") and agg[k]["flops"] > 0]
     gflops = sum(agg[k]["flops"] for k in gemm_keys); gms = sum(agg[k]["ms"] for k in gemm_keys)
     # the dominant GEMM = the single LAUNCH (one shape, one kernel) with the longest duration; the "*_other" keys pool
@@ -442,7 +462,7 @@ def main():
         def cpu_leg(threads, batch, min_steps=3):
             """One untimed warm-up step (thread pool, allocator, first-touch), then >= min_steps timed steps within the budget."""
             torch.set_num_threads(threads)
-            cpu = O.CpuModel("pool", feat_size, H, n_classes, pool_feats=H, seed=1)
+            cpu = O.CpuModel(args.aggregator, feat_size, H, n_classes, pool_feats=H, seed=1)
             cpu.train_step(feat_cpu, lab_cpu, indptr, indices, deg, seed_rng.choice(train_set, batch, replace=False), S, 1, 10 ** 6)
             tc, nstep = time.perf_counter(), 0
             while nstep < min_steps or (time.perf_counter() - tc < args.cpu_seconds and nstep < 8):
@@ -529,9 +549,10 @@ def main():
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"gemm_arithmetic": gemm_desc(args.gemm), "workload": "%s: %s-like %s stream, last snapshot (N=%d, CSR nnz=%d), F=%d H=%d C=%d, "
-                                   "aggregator=pool(max), depth=2 samples=%d batch=%s batch_timestep=%d, "
+                                   "aggregator=%s, depth=2 samples=%d batch=%s batch_timestep=%d, "
                                    "sample+gather+fwd+CE+bwd+Adam" % (args.workload, wl["dataset"], arrays["stream"], g.n_present,
-                                                                        int(h_nnz(g)), feat_size, H, n_classes, S,
+                                                                        int(h_nnz(g)), feat_size, H, n_classes,
+                                                                        {"pool": "pool(max)"}.get(args.aggregator, args.aggregator + " (in-repo layer, pool_feats=%d)" % H), S,
                                                                         ("%d in total (%d on this rank)" % (B, B_local)) if strong else "%d/GPU" % B, bt),
                        "global_batch": B_global,
                        "step_execution": "%s %s%s" % (timed_mode, forms_timed,
@@ -546,6 +567,7 @@ def main():
                        "avg_unique_input_nodes_n0": round(n0_avg, 1), "avg_n1": round(n1_avg, 1), "setup_s": round(setup_s, 1)},
             "roofline": roof_gemm if roof_gemm else roof_aggr,
             "roofline_aggregator": roof_aggr,
+            "roofline_mean_backward": roof_mean_bwd,
             "roofline_step": (dict(composite, ms_per_step=round(1000 * elapsed / args.steps, 4),
                                    frac=round(composite["composite_floor_ms"] / (1000 * elapsed / args.steps), 4)) if composite else None),
             "hbm_copy_measured": hbm_copy,

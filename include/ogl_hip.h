@@ -146,6 +146,10 @@ int ogl_reduce_fwd(const float* src, int64_t lds, int64_t n_src, const int32_t* 
  * NULL (pass ldo as for a real one): the image only — a consumer that reads nothing else (the cached inference layers). */
 int ogl_reduce_fwd_img(const float* src, int64_t lds, int64_t n_src, const int32_t* idx32, const int64_t* idx64, int64_t n_dst,
                        int fanout, int d, float* out, int64_t ldo, int32_t* argmax, void* image, ogl_stream_t stream);
+/* ... and for the MEAN (mailbox.mean(axis=1) of the in-repo 'meanpool' / 'mean' layers, aggregator_dgl.py:156-159,181-185): the slot-order
+ * sum divided by the fanout, + the bf16x3 image of the result (no argmax). */
+int ogl_reduce_fwd_mean_img(const float* src, int64_t lds, int64_t n_src, const int32_t* idx32, const int64_t* idx64, int64_t n_dst,
+                            int fanout, int d, float* out, int64_t ldo, void* image, ogl_stream_t stream);
 int ogl_reduce_bwd(const float* dout, int64_t ldo, const int32_t* idx32, const int32_t* argmax,
                    const float* relu_out, int64_t ldr, int64_t n_dst, int fanout, int d, int op,
                    int64_t n_src, float* dsrc, int64_t lds, ogl_stream_t stream);

@@ -190,12 +190,12 @@ static int launch_reduce_fwd(const float* src, int64_t lds, int64_t n_src, const
   const int cper = (d4 + parts - 1) / parts;
   if (vec) grid.x = (unsigned)ogl_cdiv(n_dst * parts, WAVES_PER_BLOCK);
   if (img) {
-    if (!vec || OP != OGL_REDUCE_MAX) return OGL_EINVAL;     // the image form exists for the vectorised max (the 'pool' layers)
+    if (!vec) return OGL_EINVAL;     // the image form exists for the vectorised kernels (the 'pool' / 'meanpool' layers)
     const int64_t irb = ogl_cdiv(d, 32) * 192;
-    if (cper <= 64) hipLaunchKernelGGL((k_reduce_fwd_v4<OGL_REDUCE_MAX, IdxT, ARG, 1, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb);
-    else if (cper <= 128) hipLaunchKernelGGL((k_reduce_fwd_v4<OGL_REDUCE_MAX, IdxT, ARG, 2, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb);
-    else if (cper <= 192) hipLaunchKernelGGL((k_reduce_fwd_v4<OGL_REDUCE_MAX, IdxT, ARG, 3, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb);
-    else hipLaunchKernelGGL((k_reduce_fwd_v4<OGL_REDUCE_MAX, IdxT, ARG, 4, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb);
+    if (cper <= 64) hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 1, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb);
+    else if (cper <= 128) hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 2, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb);
+    else if (cper <= 192) hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 3, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb);
+    else hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 4, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb);
     OGL_CHECK_LAUNCH();
     return OGL_OK;
   }
@@ -262,6 +262,19 @@ extern "C" int ogl_reduce_fwd_img(const float* src, int64_t lds, int64_t n_src, 
                            : launch_reduce_fwd<OGL_REDUCE_MAX, int32_t, false>(src, lds, n_src, idx32, n_dst, fanout, d, out, ldo, nullptr, st, im);
   return argmax ? launch_reduce_fwd<OGL_REDUCE_MAX, int64_t, true>(src, lds, n_src, idx64, n_dst, fanout, d, out, ldo, argmax, st, im)
                 : launch_reduce_fwd<OGL_REDUCE_MAX, int64_t, false>(src, lds, n_src, idx64, n_dst, fanout, d, out, ldo, nullptr, st, im);
+}
+
+// The same for the MEAN (the 'meanpool' / 'mean' layers of the in-repo SAGEConv, R/train/graphsage/pytorch/aggregator_dgl.py:156-159,
+// 181-185): out = mailbox.mean(axis=1) in slot order + the bf16x3 image of it for the combine product that consumes it.
+extern "C" int ogl_reduce_fwd_mean_img(const float* src, int64_t lds, int64_t n_src, const int32_t* idx32, const int64_t* idx64,
+                                       int64_t n_dst, int fanout, int d, float* out, int64_t ldo, void* image, ogl_stream_t stream) {
+  if (n_dst <= 0 || fanout <= 0 || d <= 0 || n_src <= 0 || lds < d || (out && ldo < d)) return OGL_EINVAL;
+  if ((idx32 != nullptr) == (idx64 != nullptr)) return OGL_EINVAL;
+  if (!src || !image || ((uintptr_t)image & 15)) return OGL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned char* im = (unsigned char*)image;
+  if (idx32) return launch_reduce_fwd<OGL_REDUCE_MEAN, int32_t, false>(src, lds, n_src, idx32, n_dst, fanout, d, out, ldo, nullptr, st, im);
+  return launch_reduce_fwd<OGL_REDUCE_MEAN, int64_t, false>(src, lds, n_src, idx64, n_dst, fanout, d, out, ldo, nullptr, st, im);
 }
 
 // ---- backward ----------------------------------------------------------------------------------

@@ -157,7 +157,10 @@ __global__ void __launch_bounds__(SG_THREADS) k_seg_reduce(const float* __restri
                                                            const int32_t* __restrict__ idx, const int* __restrict__ sorted,
                                                            const int* __restrict__ start, int64_t n_src, SegOut o,
                                                            float* __restrict__ partial, int64_t ldpart) {
+  // per entry of the tile: its destination row, its source, and whether the source's whole range lies inside the tile (then the
+  // run is finished here) — fetched once, in parallel, so that the walk below never waits for a dependent scalar load
   __shared__ int se[SG_TILE], ss[SG_TILE];
+  __shared__ unsigned char whole[SG_TILE];
   const int total = start[n_src];
   const int t0 = blockIdx.x * SG_TILE;
   if (t0 >= total) return;
@@ -165,8 +168,10 @@ __global__ void __launch_bounds__(SG_THREADS) k_seg_reduce(const float* __restri
   const int tid = threadIdx.x;
   if (tid < SG_TILE) {
     const int e = tid < cntk ? sorted[t0 + tid] : 0;
+    const int s = tid < cntk ? idx[e] : -1;
     se[tid] = e / S;                                          // the destination row of the entry
-    ss[tid] = tid < cntk ? idx[e] : -1;
+    ss[tid] = s;
+    whole[tid] = (s >= 0 && start[s] >= t0 && start[s + 1] <= t1) ? 1 : 0;
   }
   __syncthreads();
   const int D4 = (D + 3) >> 2;
@@ -174,35 +179,43 @@ __global__ void __launch_bounds__(SG_THREADS) k_seg_reduce(const float* __restri
   if (tid >= max(D4, Kp4)) return;
   const bool cin = tid < D4;
   const int ch = cin ? tid : D4 - 1;
+  SegOut plain = o;                                           // (the mask is applied here, from a prefetched value)
+  plain.mask = nullptr;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  int cur_s = ss[0], run_k0 = 0;
-  auto flush = [&](int s, int k_begin, int k_end) __attribute__((always_inline)) {
-    // entries [t0 + k_begin, t0 + k_end) of source s
-    const int a = start[s], b = start[s + 1];
-    const float4 v = cin ? acc : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a >= t0 && b <= t1) seg_store(o, s, tid, D, v);
-    else if (cin) *(float4*)(partial + ((int64_t)blockIdx.x * 2 + (k_begin == 0 ? 0 : 1)) * ldpart + 4 * tid) = v;
-  };
+  int run_k0 = 0;
   for (int k0 = 0; k0 < cntk; k0 += SG_U) {
-    float4 v[SG_U];
+    float4 v[SG_U], mv[SG_U];
+    bool ends[SG_U];
 #pragma unroll
     for (int u = 0; u < SG_U; ++u) {                          // unconditional loads (a slot past the tile re-reads its last row)
       const int k = k0 + u < cntk ? k0 + u : cntk - 1;
       v[u] = *(const float4*)(dout + (int64_t)se[k] * ldd + 4 * ch);
+      ends[u] = k0 + u < cntk && (k0 + u + 1 == cntk || ss[k + 1] != ss[k]);
+      // the ReLU mask of a run that ENDS at this entry, requested with the batch's rows (any other entry re-reads row 0: cached)
+      if (o.mask) mv[u] = *(const float4*)(o.mask + (int64_t)((ends[u] && whole[k]) ? ss[k] : 0) * o.ldm + 4 * ch);
     }
 #pragma unroll
     for (int u = 0; u < SG_U; ++u) {
       const int k = k0 + u;
       if (k >= cntk) break;                                   // (block-uniform)
-      if (ss[k] != cur_s) {
-        flush(cur_s, run_k0, k);
-        acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        cur_s = ss[k]; run_k0 = k;
-      }
       acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+      if (ends[u]) {                                          // (block-uniform) entries [run_k0, k] of source ss[k]
+        float4 r = cin ? acc : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (whole[k]) {
+          if (o.mask && cin) {
+            if (o.divisor != 1.f) { r.x /= o.divisor; r.y /= o.divisor; r.z /= o.divisor; r.w /= o.divisor; }
+            r.x = mv[u].x > 0.f ? r.x : 0.f; r.y = mv[u].y > 0.f ? r.y : 0.f; r.z = mv[u].z > 0.f ? r.z : 0.f; r.w = mv[u].w > 0.f ? r.w : 0.f;
+            SegOut q = plain; q.divisor = 1.f;
+            seg_store(q, ss[k], tid, D, r);
+          } else seg_store(plain, ss[k], tid, D, r);
+        } else if (cin) {
+          *(float4*)(partial + ((int64_t)blockIdx.x * 2 + (run_k0 == 0 ? 0 : 1)) * ldpart + 4 * tid) = r;
+        }
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        run_k0 = k + 1;
+      }
     }
   }
-  flush(cur_s, run_k0, cntk);
 }
 
 // wave per source (+ one wave for the image's zero row): sources spanning several tiles, sources without an edge

@@ -162,6 +162,10 @@ class SAGEConv(nn.Module):
         elif t in ("meanpool", "maxpool"):
             if t == "maxpool":
                 h_neigh = self._pool_max(feat, idx)
+            elif ops.pool_mean_fits(feat.table if lazy else feat, idx, self.fc_pool.weight.shape[0], feat.shape[0]) and torch.is_grad_enabled():
+                # an input without a gradient (the first layer): projection + mean as one node whose backward goes from the pooled-row
+                # gradient straight to the operand of fc_pool's weight gradient (a planned segmented gather, no atomics)
+                h_neigh = ops.pool_mean(feat.table if lazy else feat, self.fc_pool.weight, self.fc_pool.bias, idx, feat.ids if lazy else None)
             else:
                 p = self._project(self.fc_pool, feat, relu=True)
                 h_neigh = ops.neighbor_reduce(p, idx, "mean")

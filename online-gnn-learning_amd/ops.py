@@ -423,6 +423,22 @@ def reduce_fwd_img(src: torch.Tensor, idx: torch.Tensor, want_argmax: bool = Fal
     return out, argmax, img
 
 
+def reduce_fwd_mean_img(src: torch.Tensor, idx: torch.Tensor):
+    """mean-reduce that also returns the bf16x3 image of its output: (out, X3Image)."""
+    src = as_mat(src)
+    assert idx.is_cuda and idx.dim() == 2 and idx.is_contiguous()
+    n_dst, fanout = idx.shape
+    d = src.shape[1]
+    out = empty_mat(n_dst, d, src.device)
+    img = X3Image(_x3_alloc(n_dst, d, src.device), n_dst, d)
+    i32 = idx if idx.dtype == torch.int32 else None
+    i64 = idx if idx.dtype == torch.int64 else None
+    _launch("ogl_reduce_fwd_img", _lib.lib().ogl_reduce_fwd_mean_img, _ptr(src), _ld(src), src.shape[0], _ptr(i32), _ptr(i64), n_dst, fanout,
+            d, _ptr(out), _ld(out), _ptr(img.buf), _stream(),
+            meta=dict(n_dst=n_dst, fanout=fanout, d=d, op="mean", argmax=False, idx_bytes=idx.element_size(), out=True))
+    return out, img
+
+
 def reduce_bwd(dout: torch.Tensor, idx32, argmax, op: str, n_src: int, fanout=None, relu_out=None, dsrc=None) -> torch.Tensor:
     """``dsrc``: an already ZEROED [n_src, d] matrix to scatter into (``take_zeroed``); default: allocated and cleared here."""
     dout = as_mat(dout)
@@ -1008,35 +1024,127 @@ def pool_bwd_x3_plan(argmax, relu_out, idx32, n_src, side=True):
                 _ld(relu_out) if relu_out is not None else 0, _ptr(idx32), n_dst, idx32.shape[1], d, n_src, _ptr(ws), nbytes, _stream(),
                 meta=dict(n_dst=n_dst, d=d, n_src=n_src, fanout=idx32.shape[1]))
 
+    plan = PoolPlan(ws, nbytes, None, (n_dst, idx32.shape[1], d, n_src))
+    return _plan_on_side(plan, launch, (ws, argmax, relu_out, idx32), side, late=POOL_PLAN_LATE)
+
+
+# Where in the forward pass the layer-0 pool backward's plan runs.  Started right behind the aggregator it shares the chip with the
+# n1-row combine product (79 us instead of 58 alone in the step's timeline); started LATE — behind the next layer's fc_pool product,
+# at ``release_late_plans()`` — its 63 us bucket pass runs beside the output layer's few-hundred-block launches (the fused forward +
+# loss, the small input-gradient launch, an image pass: ~60 us during which the chip is mostly idle) and its scan / place passes
+# beside a 185-tile product that leaves 71 CUs free.
+# Measured (round 4, tools/ab_env.sh OGL_POOL_PLAN_LATE 3, one box): 1.005 / 1.007 / 1.008 ms early, 1.015 / 1.017 / 1.013 late — the combine does
+# run alone (72 us) and the bucket pass beside the 25 us loss launch, but the plan then occupies the ONE side stream until 506 us of the
+# step and the backward's weight-gradient branch starts 60 us later: its last product collides with the layer-0 weight gradient
+# (250 us instead of 225).  Off by default.
+POOL_PLAN_LATE = os.environ.get("OGL_POOL_PLAN_LATE", "0") == "1"
+_LATE_PLANS = []
+PLAN_STREAM = os.environ.get("OGL_PLAN_STREAM", "0") == "1"
+
+
+def release_late_plans():
+    """Plans parked by ``_plan_on_side(late=True)`` start from HERE: behind everything the current stream has enqueued so far, their
+    launches created after the stream's next launch (``_DEFERRED``)."""
+    if not _LATE_PLANS:
+        return
+    here = torch.cuda.Event()
+    here.record()
+    while _LATE_PLANS:
+        _DEFERRED.append(_LATE_PLANS.pop(0)(here))
+
+
+def _plan_on_side(plan, launch, tensors, side=True, late=False):
+    """Run ``launch()`` — the gradient-free half of a backward pass, enqueued by the FORWARD pass — on the side stream when the fork
+    is on (else right here); ``plan.event`` then marks its end, ``plan.pending`` that its launches still wait for the caller's next
+    launch to be created first (``_DEFERRED``: in a captured step the first-created child of a node keeps its parent's queue)."""
     forked = side and FORK_BACKWARD and _PROFILE is None and not _SIDE["off"] and (FORK_IN_GRAPHS or not _capturing())
     if not forked:
         launch()
-        return PoolPlan(ws, nbytes, None, (n_dst, idx32.shape[1], d, n_src))
+        return plan
     dev = torch.cuda.current_device()
-    st = _SIDE["streams"].get(dev)
+    key = ("plan", dev) if (late and PLAN_STREAM) else dev      # (a late plan on a stream of its own: the backward's side branch is not held up)
+    st = _SIDE["streams"].get(key)
     if st is None:
-        st = _SIDE["streams"][dev] = torch.cuda.Stream(device=dev)
-    here = torch.cuda.Event()
-    here.record()                       # the plan's inputs exist from HERE on ...
-    plan = PoolPlan(ws, nbytes, None, (n_dst, idx32.shape[1], d, n_src))
+        st = _SIDE["streams"][key] = torch.cuda.Stream(device=dev)
     plan.pending = True
 
-    def run():                          # ... but its launches are created after the main stream's next one (see _DEFERRED)
-        st.wait_event(here)
-        with torch.cuda.stream(st):
-            launch()
-            plan.event = torch.cuda.Event()
-            plan.event.record()
-        plan.pending = False
-        if not _capturing():
-            # (a forward whose backward never runs frees these with nothing having waited for the side stream: the caching allocator
-            # must not hand their memory to a later main-stream kernel while the plan's kernels still read it)
-            for t in (ws, argmax, relu_out, idx32):
-                if t is not None:
-                    t.record_stream(st)
+    def make(here):
+        def run():                      # its launches are created after the main stream's next one (see _DEFERRED)
+            st.wait_event(here)
+            with torch.cuda.stream(st):
+                launch()
+                plan.event = torch.cuda.Event()
+                plan.event.record()
+            plan.pending = False
+            if not _capturing():
+                # (a forward whose backward never runs frees these with nothing having waited for the side stream: the caching
+                # allocator must not hand their memory to a later main-stream kernel while the plan's kernels still read it)
+                for t in tensors:
+                    if t is not None:
+                        t.record_stream(st)
+        return run
 
-    _DEFERRED.append(run)
+    if late:
+        _LATE_PLANS.append(make)        # (starts at release_late_plans(), or when its consumer asks for it: _plan_ready)
+        return plan
+    here = torch.cuda.Event()
+    here.record()                       # the plan's inputs exist from HERE on ...
+    _DEFERRED.append(make(here))
     return plan
+
+
+def _plan_ready(plan):
+    """Make the current stream wait for a plan enqueued by ``_plan_on_side``."""
+    if plan.pending:
+        release_late_plans()
+        _flush_deferred()
+    if plan.event is not None:
+        torch.cuda.current_stream().wait_event(plan.event)
+
+
+SEG_REDUCE_BWD = os.environ.get("OGL_SEG_REDUCE_BWD", "1") != "0"    # mean / sum backward as a planned segmented gather (no atomics)
+SEG_MIN_EDGES = 4096
+
+
+def seg_bwd_fits(idx, d, n_src):
+    return (SEG_REDUCE_BWD and idx is not None and idx.dtype == torch.int32 and idx.dim() == 2 and idx.numel() >= SEG_MIN_EDGES
+            and d % 4 == 0 and 4 <= d <= 1024 and 0 < n_src < (1 << 31))
+
+
+def reduce_bwd_seg_plan(idx32, d, n_src, side=True):
+    """The gradient-free half of the segmented mean / sum backward (``ogl_reduce_bwd_seg_plan``: the block's edges sorted by source),
+    enqueued NOW — by the forward pass, on the side stream when the fork is on.  Returns the plan ``reduce_bwd_seg_apply`` consumes."""
+    n_dst, fanout = idx32.shape
+    assert idx32.dtype == torch.int32 and idx32.is_contiguous()
+    nbytes = int(_lib.lib().ogl_reduce_bwd_seg_workspace_bytes(n_dst, fanout, d, n_src))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=idx32.device)
+
+    def launch():
+        _launch("ogl_reduce_bwd_seg_plan", _lib.lib().ogl_reduce_bwd_seg_plan, _ptr(idx32), n_dst, fanout, n_src, _ptr(ws), nbytes, _stream(),
+                meta=dict(n_dst=n_dst, fanout=fanout, n_src=n_src))
+
+    plan = PoolPlan(ws, nbytes, None, (n_dst, fanout, d, n_src))
+    return _plan_on_side(plan, launch, (ws, idx32), side)
+
+
+def reduce_bwd_seg_apply(dout, idx32, plan, op, mask=None, want_out=True, want_image=False):
+    """(dsrc [n_src, d] or None, its row-major bf16x3 image or None) from a plan: dsrc[s] = (1 / fanout for 'mean') sum of dout over
+    the edges into s, in edge order (no atomics, reproducible), optionally times [mask[s] > 0]."""
+    dout = as_mat(dout)
+    n_dst, d = dout.shape
+    fanout, n_src = idx32.shape[1], plan.shape[3]
+    assert plan.shape == (n_dst, fanout, d, n_src) and op in ("mean", "sum") and (want_out or want_image)
+    _plan_ready(plan)
+    out = empty_mat(n_src, d, dout.device) if want_out else None
+    img = X3Image(_x3_alloc(n_src, d, dout.device), n_src, d) if want_image else None
+    if mask is not None:
+        mask = as_mat(mask)
+        assert tuple(mask.shape) == (n_src, d)
+    _launch("ogl_reduce_bwd_seg_apply", _lib.lib().ogl_reduce_bwd_seg_apply, _ptr(dout), _ld(dout), _ptr(idx32), n_dst, fanout, d,
+            REDUCE_OPS[op], n_src, _ptr(mask), _ld(mask) if mask is not None else 0, _ptr(out), _ld(out) if out is not None else 0,
+            _ptr(img.buf) if img is not None else None, _ptr(plan.ws), plan.nbytes, _stream(),
+            meta=dict(n_dst=n_dst, fanout=fanout, d=d, n_src=n_src, op=op, out=out is not None, image=img is not None, mask=mask is not None))
+    return out, img
 
 
 def pool_bwd_x3_apply(dout, idx32, plan, n_src):
@@ -1045,10 +1153,7 @@ def pool_bwd_x3_apply(dout, idx32, plan, n_src):
     dout = as_mat(dout)
     n_dst, d = dout.shape
     assert plan.shape == (n_dst, idx32.shape[1], d, n_src) and idx32.dtype == torch.int32 and idx32.is_contiguous()
-    if plan.pending:
-        _flush_deferred()
-    if plan.event is not None:
-        torch.cuda.current_stream().wait_event(plan.event)
+    _plan_ready(plan)
     G = (n_src + 31) // 32
     buf = _x3_alloc(d, 32 * G, dout.device)
     _launch("ogl_pool_bwd_x3_apply", _lib.lib().ogl_pool_bwd_x3_apply, _ptr(dout), _ld(dout), _ptr(idx32), n_dst, idx32.shape[1], d, n_src,
@@ -1146,7 +1251,9 @@ def linear_bwd_weight_x3k(dyT_img, x_img, M, K, x_rows=None, x_nrows=None, inter
     nbytes = int(_lib.lib().ogl_linear_bwd_weight_x3k_workspace_bytes(M, interleave, N, K, 1 if has_ones else 0))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
     if (defer_for is not None and _SLABS["on"] and dw_out is None and defer_for[0] is not None and tuple(defer_for[0].shape) == (N, K)
-            and (db is None or defer_for[1] is not None) and (db2 is None or defer_for[2] is not None)):
+            and (db is None or defer_for[1] is not None) and (db2 is None or defer_for[2] is not None)
+            # (whole PARAMETERS only: a view of one — the column slices of a concat -> Linear weight — shares its address)
+            and all(t is None or (t.is_leaf and t.is_contiguous()) for t in defer_for)):
         ns, wl = C.c_int(0), C.c_int64(0)
         _launch("ogl_linear_bwd_weight_x3k", _lib.lib().ogl_linear_bwd_weight_x3k_slabs, _ptr(dyT_img.buf), interleave, _ptr(x_img.buf),
                 x_img.rows, _ptr(_ids(x_rows) if x_rows is not None else None), x_img.rows if x_nrows is None else x_nrows, M, N, K,
@@ -1554,7 +1661,10 @@ class _SideSection:
         self._ctx.__enter__()
         if not _SIDE["active"]:
             # joined when the backward pass that opened the section ends, whoever called it (loss.backward() of user code too)
-            torch.autograd.Variable._execution_engine.queue_callback(side_join)
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(side_join)
+            except RuntimeError:
+                pass            # (opened outside a backward pass — deferred work flushed by the optimiser's step(), which joins itself)
         _SIDE["active"] = True
         return self
 
@@ -1591,13 +1701,13 @@ def collective_section():
     return _SideSection(None)
 
 
-def early_section():
+def early_section(at=None):
     """Context for work launched from a gradient hook in the middle of a backward pass that only the END of the step needs (the
-    optimiser's early part): on the side stream, after everything both streams have enqueued so far, when the fork is on; otherwise
-    a no-op context (the work then sits in the main stream where the hook fired)."""
+    optimiser's early part): on the side stream — behind its own queue and behind the main stream up to ``at`` (a ``fork_point()``;
+    default: up to now) — when the fork is on; otherwise a no-op context (the work then sits in the main stream)."""
     if not FORK_BACKWARD or _PROFILE is not None or _SIDE["off"] or (not FORK_IN_GRAPHS and _capturing()):
         return _NoSection()
-    return _SideSection(None)
+    return _SideSection(at)
 
 
 def side_join():
@@ -1608,6 +1718,7 @@ def side_join():
             torch.cuda.current_stream().wait_stream(st)
         _SIDE["active"] = False
     _SIDE["keep"].clear()
+    _LATE_PLANS.clear()             # (a plan parked by a forward pass whose backward has ended without asking for it: dropped)
 
 
 class _LinearFn(torch.autograd.Function):
@@ -1723,8 +1834,17 @@ class _ReduceFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, idx, op):
         need_grad = src.requires_grad
-        out, argmax = reduce_fwd(src, idx, op, want_argmax=need_grad)
+        if op == "mean" and _n1_images_ok(idx.shape[0], src.shape[1]) and as_mat(src).shape[1] % 4 == 0:
+            out, img = reduce_fwd_mean_img(src, idx)         # tall: the combine product reads the image of the pooled rows
+            attach_image(out, img)
+            argmax = None
+        else:
+            out, argmax = reduce_fwd(src, idx, op, want_argmax=need_grad)
         ctx.op, ctx.n_src, ctx.fanout = op, src.shape[0], idx.shape[1]
+        ctx.seg_plan = None
+        if need_grad and op in ("mean", "sum") and seg_bwd_fits(idx, src.shape[1], src.shape[0]):
+            # the backward as a segmented gather over the edges sorted by source: the sort needs the indices only — planned here
+            ctx.seg_plan = reduce_bwd_seg_plan(idx, src.shape[1], src.shape[0])
         ctx.save_for_backward(idx if idx.dtype == torch.int32 else None, argmax)
         return out
 
@@ -1735,7 +1855,57 @@ class _ReduceFn(torch.autograd.Function):
             raise RuntimeError("max-reduce backward needs the argmax recorded in forward")
         if ctx.op != "max" and idx32 is None:
             raise RuntimeError("mean/sum-reduce backward needs block-local int32 indices")
+        plan, ctx.seg_plan = getattr(ctx, "seg_plan", None), None
+        if plan is not None:
+            return reduce_bwd_seg_apply(dout, idx32, plan, ctx.op)[0], None, None
         return reduce_bwd(dout, idx32, argmax, ctx.op, ctx.n_src, fanout=ctx.fanout), None, None
+
+
+class _PoolMeanFn(torch.autograd.Function):
+    """relu(fc_pool(x[rows])) -> mean over the sampled neighbours, as one autograd node, for a projection input WITHOUT a gradient (the
+    first layer of the in-repo 'meanpool' mode, R/train/graphsage/pytorch/aggregator_dgl.py:178-186): the pooled-row gradient dP has
+    one consumer, fc_pool's weight gradient, and goes from dout straight to the row-major bf16x3 image that product reads —
+    scaled, ReLU-masked, never materialised in fp32 (``reduce_bwd_seg_apply``); the edge sort it needs is planned by the forward."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, x_rows, idx):
+        p = linear_fwd(x, w, bias, relu=True, x_rows=x_rows)
+        need = w.requires_grad or (bias is not None and bias.requires_grad)
+        if _n1_images_ok(idx.shape[0], p.shape[1]) and p.shape[1] % 4 == 0:
+            out, img = reduce_fwd_mean_img(p, idx)
+            attach_image(out, img)
+        else:
+            out, _ = reduce_fwd(p, idx, "mean")
+        ctx.n_src, ctx.fanout, ctx.has_bias, ctx.bias_t = p.shape[0], idx.shape[1], bias is not None, bias
+        ctx.seg_plan = reduce_bwd_seg_plan(idx, p.shape[1], p.shape[0]) if need else None
+        ctx.save_for_backward(x, w, x_rows, p, idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, x_rows, p, idx = ctx.saved_tensors
+        plan, ctx.seg_plan = ctx.seg_plan, None
+        K = x.shape[1]
+        rimg = _row_image_for(x, x_rows, None) if (_MODE["name"] != "f32" and ctx.n_src >= X3_BWW_MIN_ROWS) else None
+        if rimg is not None and rimg.K == K + 1:
+            # dP as the image the k-major weight gradient reads; x as the resident table's own image, gathered by the block's ids
+            _, dp_img = reduce_bwd_seg_apply(dout, idx, plan, "mean", mask=p, want_out=False, want_image=True)
+            dw, db, _ = linear_bwd_weight_x3k(dp_img, rimg, ctx.n_src, K, x_rows=x_rows, x_nrows=x.shape[0] if x_rows is not None else None,
+                                              want_bias=ctx.has_bias, dy_rows=True, dw_out=_dw_out(w, *w.shape),
+                                              defer_for=(w, ctx.bias_t, None))
+        else:
+            dp, _ = reduce_bwd_seg_apply(dout, idx, plan, "mean", mask=p)
+            dw, db = weight_grad(dp, x, x_rows, want_bias=ctx.has_bias, dw_out=_dw_out(w, *w.shape))
+        return None, dw, (db if ctx.has_bias else None), None, None
+
+
+def pool_mean_fits(x, idx, pool_width, n_src):
+    return (not x.requires_grad) and seg_bwd_fits(idx, pool_width, n_src)
+
+
+def pool_mean(x, w, bias, idx, x_rows=None):
+    """mean_j relu(fc_pool(x))[idx[:, j]] for an input without a gradient — the aggregator of the in-repo 'meanpool' first layer."""
+    return _PoolMeanFn.apply(x, w, bias, x_rows, idx)
 
 
 # Test hook: while a list is installed, every differentiable pool layer appends dict(argmax, neigh[, out]) — the winners and
@@ -1806,10 +1976,8 @@ class _PoolMaxFn(torch.autograd.Function):
                                               dw_out=_dw_out(w, *w.shape))
             return None, dw, (db if ctx.has_bias else None), None, None
         plan = getattr(ctx, "pool_plan", None)
-        if plan is not None and plan.pending:
-            _flush_deferred()
-        if plan is not None and plan.event is not None:            # (planned for the image path, which this call does not take)
-            torch.cuda.current_stream().wait_event(plan.event)
+        if plan is not None:                                       # (planned for the image path, which this call does not take)
+            _plan_ready(plan)
         ctx.pool_plan = None
         slot, ctx.dp_slot = getattr(ctx, "dp_slot", None), None
         dp = reduce_bwd(dout, None, argmax, "max", ctx.n_src, fanout=ctx.fanout, relu_out=out,
@@ -1846,6 +2014,7 @@ class _SagePoolLayerFn(torch.autograd.Function):
             p = linear_fwd_x3(himg, None, wimg, relu=True)
         else:
             p = linear_fwd(h, w_pool, b_pool, relu=True)
+        release_late_plans()
         need = any(t is not None and t.requires_grad for t in (h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh))
         neigh, argmax = reduce_fwd(p, idx, "max", want_argmax=need)
         bias = None
@@ -1946,6 +2115,7 @@ class _SagePoolLossFn(torch.autograd.Function):
             p = linear_fwd_x3(himg, None, wimg, relu=True)
         else:
             p = linear_fwd(h, w_pool, b_pool, relu=True)
+        release_late_plans()      # (a first layer's parked backward plan starts behind this layer's fc_pool product: see POOL_PLAN_LATE)
         need = any(t is not None and t.requires_grad for t in (h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh))
         ent = None
         if need and h.shape[0] >= 1024:

@@ -22,7 +22,13 @@ import torch
 
 from . import ops
 
-EARLY = os.environ.get("OGL_ADAM_EARLY", "1") != "0"
+# Off by default — measured (round 4, replayed Reddit step, tools/ab_env.sh OGL_ADAM_EARLY 3, two boxes): 0.993-1.007 ms without, 1.020-1.032 with
+# the early part created first at its fork (it took the critical chain's hardware queue: the pool backward started 65 us late); created
+# after the critical launch: 1.014-1.028 without, 1.019-1.021 with — the end of the step does shrink (reduce + prepare + Adam 42 us -> Adam
+# over fc_pool0 alone 16-18 us), but the side branch's three weight-gradient products end AFTER the layer-0 weight gradient has taken every
+# CU (their reductions are gone, they still share the chip with the pool backward), so the early update waits for a CU for 190 us and
+# the layer-0 weight gradient runs 250 us instead of 225 beside it.  It pays once that branch ends before the layer-0 weight gradient starts.
+EARLY = os.environ.get("OGL_ADAM_EARLY", "0") == "1"
 
 
 class Adam(torch.optim.Optimizer):
@@ -35,6 +41,7 @@ class Adam(torch.optim.Optimizer):
         self._scalars_dev = None
         self.early = EARLY if early is None else bool(early)
         self.late_fraction = float(late_fraction)
+        self.late_min = 0.15
         self._armed = False          # hooks act only inside backward_and_step / backward_learn
         self._learn_only = False
         self._order = []             # arrival order (id(p)) of the armed backward pass
@@ -81,21 +88,32 @@ class Adam(torch.optim.Optimizer):
             return
         self._early_seen += 1
         if self._early_seen == len(self._early_ids):
-            # every early gradient exists (its kernels are enqueued): update those parameters now, beside the rest of the backward
-            with ops.early_section():
-                self._apply([self._by_id[i] for i in self._early_ids], prepare=True)
-            self._early_done = True
+            # every early gradient exists (its kernels are enqueued): update those parameters beside the rest of the backward.  The
+            # update waits for everything the MAIN stream has enqueued up to here (the last reader of an early parameter's weight
+            # image is behind us) and for the side stream's own queue — but its launches are CREATED after the main stream's next
+            # launch (ops._DEFERRED): in a captured step the first-created child of a node keeps its parent's hardware queue, and
+            # created first the update took the critical chain's queue — the pool backward then sat behind the side branch's
+            # weight gradients on the other one (measured: its first launch 65 us late).
+            here = ops.fork_point()
+
+            def run():
+                with ops.early_section(here):
+                    self._apply([self._by_id[i] for i in self._early_ids], prepare=True)
+                self._early_done = True
+            ops._DEFERRED.append(run)
 
     def _learn_split(self):
         order = list(dict.fromkeys(self._order))
         with_grad = [i for i, (p, _) in self._by_id.items() if p.grad is not None]
         if len(order) != len(with_grad) or not order:
             return                                      # (not every gradient arrived through a hook: try again next time)
+        # late = the SHORTEST suffix of the arrival order that holds a worthwhile share of the elements (>= late_min: the tensors
+        # whose gradients come out of the step's last, longest launches), never more than late_fraction of them
         total = sum(self._by_id[i][0].numel() for i in order)
         late, acc = [], 0
         for i in reversed(order):
             n = self._by_id[i][0].numel()
-            if late and acc + n > self.late_fraction * total:
+            if late and (acc >= self.late_min * total or acc + n > self.late_fraction * total):
                 break
             late.append(i); acc += n
         early = [i for i in order if i not in set(late)]
@@ -170,6 +188,7 @@ class Adam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        ops._flush_deferred()               # (an early part still waiting for "the main stream's next launch": there is none)
         ops.side_join()                     # (a forked backward joins itself when it ends; this is for gradients made by hand)
         ops.invalidate_weight_images()      # the kernels below write the parameters through raw pointers (no version bump)
         done = self._early_ids if self._early_done else frozenset()

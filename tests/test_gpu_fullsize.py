@@ -217,6 +217,55 @@ def test_fullsize_free_running_steps_track_the_oracle(reddit):
         ops.set_gemm_mode("f32")
 
 
+@pytest.mark.parametrize("mode", ["meanpool", "mean"])
+def test_fullsize_inrepo_modes_step_matches_oracle(reddit, mode):
+    """One RBR train step at the Reddit rung in the in-repo aggregator modes (R/train/graphsage/pytorch/aggregator_dgl.py:156-159,
+    178-186; latent_dim 600 as R/settings/reddit.json:1) against the torch-CPU oracle: the loss at rtol 1e-4, every gradient at
+    1e-3 relative Frobenius norm (a mean has no winners to flip; what remains are ReLU decisions of units within rounding of 0),
+    the weights after the Adam step at the rung tests' Adam-aware bound."""
+    from ogl_amd import ops, optim, sampling
+    from ogl_amd.graphsage import GatheredRows, GraphSAGE
+    a, dyn, g, host = reddit
+    g.set_snapshot(g.n_total, len(a["src"]))
+    ops.set_gemm_mode("auto")
+    try:
+        B, S = 512, 25
+        deg = O.snapshot_degrees_fast(host["indptr"], host["keys"], g.n_present, g.cut)
+        pool = 600 if mode == "meanpool" else None
+        cpu = O.CpuModel(mode, 602, 600, 41, pool_feats=pool, seed=2)
+        model = GraphSAGE(602, 600, 41, 1, F.relu, 0, mode, edge_feats=0, pool_feats=pool).cuda()
+        with torch.no_grad():
+            for l, prm in zip(model.layers, cpu.params):
+                for k, v in prm.items():
+                    mod, attr = k.split(".")
+                    getattr(getattr(l, mod), attr).copy_(v)
+        opt = optim.Adam(model.parameters(), lr=1e-3)
+        seeds = np.random.default_rng(13).choice(g.n_present, B, replace=False).astype(np.int64)
+        sampling.seed(6)
+        (input_nodes, sd, blocks), = list(sampling.NodeDataLoader(g, torch.as_tensor(seeds), sampling.MultiLayerNeighborSampler([S, S]), batch_size=B))
+        opt.zero_grad()
+        loss, _, _ = model.forward_loss(blocks, GatheredRows(g.ndata["feat"], input_nodes), ops.gather_i64(g.ndata["target"], sd))
+        ops.backward(loss)
+        opt.step()
+        feat_cpu, lab_cpu = a["feat"], torch.as_tensor(a["labels"]).reshape(-1, 1)
+        want = cpu.train_step(feat_cpu, lab_cpu, host["indptr"], host["indices"], deg, seeds, S, 6, 0)
+        assert abs(float(loss) - want) <= 1e-4 * abs(want), (float(loss), want)
+        rels, bad, total = {}, 0, 0
+        for li, (l, prm) in enumerate(zip(model.layers, cpu.params)):
+            for k, v in prm.items():
+                mod, attr = k.split(".")
+                p = getattr(getattr(l, mod), attr)
+                rels["layers.%d.%s" % (li, k)] = float(np.linalg.norm(p.grad.cpu().numpy() - v.grad.numpy()) / np.linalg.norm(v.grad.numpy()))
+                d = np.abs(p.detach().cpu().numpy() - v.detach().numpy())
+                bad += int((d > 2e-5).sum()); total += d.size
+        print("relative gradient errors (%s):" % mode, rels)
+        for k, r in rels.items():
+            assert r < 1e-3, (k, r, rels)
+        assert bad <= 1e-4 * total, (bad, total)
+    finally:
+        ops.set_gemm_mode("f32")
+
+
 def test_fullsize_fused_output_layer_step_matches_oracle(reddit):
     """The same full-size step with the last layer and the loss as ONE autograd node (GraphSAGE.forward_loss: what the
     strategies run): same oracle, same tolerances, same forced-winner gradient check."""

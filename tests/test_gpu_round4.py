@@ -224,12 +224,12 @@ def test_two_part_optimiser_step_equals_the_plain_step():
         base = GraphSAGE(Fin, H, C, 1, F.relu, 0, "pool").cuda()
         init = [p.detach().clone() for p in base.parameters()]
         out = {}
-        for two_part in (False, True):
+        for two_part in (False, True, None):              # None: the plain step once more — the yardstick for run-to-run differences
             model = GraphSAGE(Fin, H, C, 1, F.relu, 0, "pool").cuda()
             with torch.no_grad():
                 for p, v in zip(model.parameters(), init):
                     p.copy_(v)
-            opt = optim.Adam(model.parameters(), lr=1e-3, early=two_part)
+            opt = optim.Adam(model.parameters(), lr=1e-3, early=bool(two_part))
             grads1, calls = None, []
             for step in range(3):
                 opt.zero_grad()
@@ -252,11 +252,104 @@ def test_two_part_optimiser_step_equals_the_plain_step():
         assert "ogl_x3_slab_reduce" not in b["calls"]
         for ga, gb in zip(a["grads"], b["grads"]):
             assert float((ga - gb).norm() / ga.norm()) <= 1e-5
-        bad = total = 0
-        for wa, wb in zip(a["weights"], b["weights"]):
-            d = (wa - wb).abs()
-            bad += int((d > 2e-5).sum()); total += d.numel()
-            assert float(d.max()) <= 3 * 2.5e-3
-        assert bad <= 3e-3 * total, (bad, total)
+        # three Adam steps turn every near-zero gradient whose sign the float atomics' order decides into a 2 lr weight difference: two
+        # PLAIN runs differ by that too — the two-part run must not differ from a plain one by more than plain runs do among themselves
+        def outside(x, y):
+            bad = total = 0
+            for wa, wb in zip(x["weights"], y["weights"]):
+                d = (wa - wb).abs()
+                bad += int((d > 2e-5).sum()); total += d.numel()
+                assert float(d.max()) <= 3 * 2.5e-3
+            return bad, total
+        bad, total = outside(a, b)
+        ref, _ = outside(a, out[None])
+        print("weights outside 2e-5 after three steps: two-part vs plain %d, plain vs plain %d of %d" % (bad, ref, total))
+        assert bad <= 4 * ref + 1e-3 * total, (bad, ref, total)          # (measured: 2 625 vs 1 041 of 1.5 M)
+    finally:
+        ops.set_gemm_mode("f32")
+
+
+def _hub_block(rng, n_dst, S, n_src, hubs=8, hub_share=0.3, iso=0.03):
+    li = rng.integers(0, n_src, size=(n_dst, S)).astype(np.int32)
+    hub_ids = rng.choice(n_src, hubs, replace=False).astype(np.int32)
+    m = rng.random((n_dst, S)) < hub_share
+    li[m] = hub_ids[rng.integers(0, hubs, int(m.sum()))]
+    li[rng.random(n_dst) < iso] = -1
+    return li
+
+
+@pytest.mark.parametrize("n_dst,S,D,n_src", [(7054, 25, 600, 62750), (512, 25, 600, 7054), (100, 5, 64, 300), (3000, 30, 256, 1200)])
+@pytest.mark.parametrize("op", ["mean", "sum"])
+def test_segmented_reduce_backward(n_dst, S, D, n_src, op):
+    """ogl_reduce_bwd_seg_plan + _apply (edges sorted by source, tiled segmented gather) against the oracle (float64 scatter-add over
+    the edges) and the float-atomic kernel it replaces: blocks with hubs referenced by a third of all edges (ranges spanning dozens
+    of tiles), destinations without neighbours, sources nobody sampled; the ReLU-masked form; the bf16x3 image written beside / instead
+    of the fp32 rows bit-identical to ogl_x3_split of them (zero row and pad columns included); and two runs of plan + apply give the
+    same bits although the plan places edges with atomics."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    rng = np.random.default_rng(n_dst + D)
+    li = _hub_block(rng, n_dst, S, n_src)
+    dout = rng.standard_normal((n_dst, D)).astype(np.float32)
+    mask = rng.standard_normal((n_src, D)).astype(np.float32)
+    idx, dt, mt = torch.as_tensor(li).cuda(), _mat(dout), _mat(mask)
+    want = np.zeros((n_src, D), dtype=np.float64)
+    valid = li >= 0
+    np.add.at(want, li[valid], np.repeat(dout.astype(np.float64), S, axis=0).reshape(n_dst, S, D)[valid])
+    if op == "mean":
+        want /= S
+    scale = np.abs(want).max()
+    runs = []
+    for _ in range(2):
+        plan = ops.reduce_bwd_seg_plan(idx, D, n_src)
+        out, img = ops.reduce_bwd_seg_apply(dt, idx, plan, op, want_out=True, want_image=True)
+        runs.append((out.clone(), img.buf.clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])         # reproducible
+    out, imgbuf = runs[0]
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=2e-6 * scale)
+    atom = ops.reduce_bwd(dt, idx, None, op, n_src)
+    np.testing.assert_allclose(out.cpu().numpy(), atom.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+    ref_img = ops.x3_split(out)
+    assert ref_img.buf.numel() == imgbuf.numel() and torch.equal(ref_img.buf, imgbuf)
+    # masked, image only (what the first 'meanpool' layer's backward asks for)
+    plan = ops.reduce_bwd_seg_plan(idx, D, n_src)
+    none, mimg = ops.reduce_bwd_seg_apply(dt, idx, plan, op, mask=mt, want_out=False, want_image=True)
+    assert none is None
+    masked = ops.empty_mat(n_src, D, "cuda").copy_(torch.where(mt > 0, out, torch.zeros((), device="cuda")))
+    assert torch.equal(ops.x3_split(masked).buf, mimg.buf)
+
+
+@pytest.mark.parametrize("mode", ["meanpool", "mean"])
+def test_inrepo_first_layer_without_input_gradient(mode):
+    """The first layer of the in-repo modes on a resident table (no input gradient: projection + mean as ONE node whose backward
+    writes the weight-gradient operand directly, 'meanpool'; the planned segmented backward, both) against the same layer on a
+    materialised input that carries a gradient (the generic nodes): outputs equal, parameter gradients to 1e-4."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    from ogl_amd.graphsage import GatheredRows, SAGEConv
+    from ogl_amd.sampling import Block
+    ops.set_gemm_mode("auto")
+    try:
+        rng = np.random.default_rng(12)
+        n0, n1, S, Fin, H = 30000, 7054, 25, 602, 600
+        table = _mat(rng.standard_normal((n0 + 500, Fin)))
+        ops.register_static_table(table)
+        ids = torch.as_tensor(rng.permutation(n0 + 500)[:n0].astype(np.int64)).cuda()
+        li = torch.as_tensor(_hub_block(rng, n1, S, n0)).cuda()
+        blk = Block(ids, ids[:n1], li)
+        torch.manual_seed(1)
+        layer = SAGEConv(Fin, H, mode, activation=F.relu, pool_feats=600 if mode == "meanpool" else None).cuda()
+        gy = torch.randn(n1, H, device="cuda")
+        y1 = layer(blk, GatheredRows(table, ids))
+        y1.backward(gy)
+        g1 = {k: p.grad.clone() for k, p in layer.named_parameters()}
+        layer.zero_grad(set_to_none=True)
+        x = ops.gather_rows(table, ids).requires_grad_(True)
+        y2 = layer(blk, x)
+        y2.backward(gy)
+        torch.testing.assert_close(y1, y2, rtol=1e-4, atol=1e-5)
+        for k, p in layer.named_parameters():
+            rel = float((p.grad - g1[k]).norm() / p.grad.norm())
+            assert rel <= 1e-4, (k, rel)
     finally:
         ops.set_gemm_mode("f32")
