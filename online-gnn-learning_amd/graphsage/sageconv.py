@@ -169,15 +169,11 @@ class SAGEConv(nn.Module):
             else:
                 p = self._project(self.fc_pool, feat, relu=True)
                 h_neigh = ops.neighbor_reduce(p, idx, "mean")
-            W = self.fc_neigh.weight
-            rst = self._linear2(feat_dst, W[:, :self._in_feats], h_neigh, W[:, self._in_feats:], self.fc_neigh.bias,
-                                fuse_relu)
+            rst = self._linear_cat(feat_dst, h_neigh, fuse_relu)
         elif t == "mean":
             src = feat.materialize() if lazy else feat
             h_neigh = ops.neighbor_reduce(src, idx, "mean")
-            W = self.fc_neigh.weight
-            rst = self._linear2(feat_dst, W[:, :self._in_feats], h_neigh, W[:, self._in_feats:], self.fc_neigh.bias,
-                                fuse_relu)
+            rst = self._linear_cat(feat_dst, h_neigh, fuse_relu)
         else:  # gcn
             src = feat.materialize() if lazy else feat
             s = ops.neighbor_reduce(src, idx, "sum")
@@ -296,6 +292,13 @@ class SAGEConv(nn.Module):
         if isinstance(feat, GatheredRows):
             return ops.pool_max(feat.table, self.fc_pool.weight, self.fc_pool.bias, idx, feat.ids)
         return ops.pool_max(feat, self.fc_pool.weight, self.fc_pool.bias, idx, None)
+
+    def _linear_cat(self, x1, x2, relu):
+        """fc_neigh(cat(h_self, h_neigh)) (aggregator_dgl.py:206): one dual-input product over the two column blocks of the weight,
+        one gradient tensor for it (``ops.linear_cat``)."""
+        if isinstance(x1, GatheredRows):
+            return ops.linear_cat(x1.table, x2, self.fc_neigh.weight, self._in_feats, self.fc_neigh.bias, relu, x1.ids)
+        return ops.linear_cat(x1, x2, self.fc_neigh.weight, self._in_feats, self.fc_neigh.bias, relu)
 
     @staticmethod
     def _linear2(x1, w1, x2, w2, bias, relu, bias2=None):

@@ -1723,10 +1723,20 @@ def side_join():
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, x2, w2, relu, x_rows, x2_rows, bias2=None):
+    def forward(ctx, x, w, bias, x2, w2, relu, x_rows, x2_rows, bias2=None, split=None):
         # bias2: the second projection's own bias (a layer with fc_self.bias and fc_neigh.bias): summed here, and each
         # gets its gradient from its own weight-gradient product in backward (their ones columns are free) — a tracked
         # `bias + bias2` outside would hand ONE gradient tensor to two parameters, which autograd clones (a launch)
+        # split: `w` is the weight of a concat -> Linear, [N, split + K2] (fc_neigh(cat(h_self, h_neigh)) of the in-repo layer,
+        # aggregator_dgl.py:206): its two column blocks are the two projections.  Sliced HERE — as autograd views outside, each
+        # block's gradient would pass through a SliceBackward node (zero fill + copy of the whole [N, K1 + K2] matrix, twice, + an add:
+        # ATen launches on the main stream that READ the weight gradients while the forked backward is still computing them on the
+        # side stream: layers.0.fc_neigh.weight.grad came out zero / garbage in its neighbour half at the Reddit shape).
+        ctx.split = None if split is None else int(split)
+        w_full = w
+        if ctx.split is not None:
+            assert w2 is None and x2 is not None and 0 < ctx.split < w.shape[1]
+            w, w2 = w_full[:, :ctx.split], w_full[:, ctx.split:]
         ctx.has_bias2 = bias2 is not None
         ctx.bias_t, ctx.bias2_t = bias, bias2                    # (the parameters themselves: who a deferred gradient belongs to)
         ctx.x2_img = take_image(x2, pop=False) if x2 is not None else None     # read again by the weight gradient (k-major)
@@ -1739,7 +1749,10 @@ class _LinearFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         if relu:
             y._ogl_relu_out = True               # (read by the consumer layer: its input gradient may come back pre-masked)
-        ctx.save_for_backward(x, w, x2, w2, y if relu else None, x_rows, x2_rows)
+        if ctx.split is not None:
+            ctx.save_for_backward(x, w_full, x2, None, y if relu else None, x_rows, x2_rows)
+        else:
+            ctx.save_for_backward(x, w, x2, w2, y if relu else None, x_rows, x2_rows)
         return y
 
     @staticmethod
@@ -1747,6 +1760,16 @@ class _LinearFn(torch.autograd.Function):
         x, w, x2, w2, y, x_rows, x2_rows = ctx.saved_tensors
         dy = as_mat(dy)
         need = ctx.needs_input_grad
+        dw_cat, w_leaf = None, w.is_leaf and (w2 is None or w2.is_leaf)
+        ctx.dw_views = None
+        if ctx.split is not None:
+            w_full = w
+            w, w2 = w_full[:, :ctx.split], w_full[:, ctx.split:]
+            need = (need[0], need[1], need[2], need[3], need[1])
+            if need[1]:
+                # ONE gradient tensor for the concat weight: each block's product writes its columns (strided rows)
+                dw_cat = torch.empty_like(w_full, memory_format=torch.contiguous_format)
+                ctx.dw_views = (dw_cat[:, :ctx.split], dw_cat[:, ctx.split:])
         dy_img = None
         if y is not None and getattr(dy, "_ogl_premasked", None) == (y.data_ptr(), y._version):
             # the product that computed dy already applied [y > 0] in its epilogue and wrote the image (linear_bwd_input)
@@ -1765,7 +1788,9 @@ class _LinearFn(torch.autograd.Function):
             if x_rows is not None:
                 raise RuntimeError("gradient w.r.t. a row-gathered table is not supported (features carry no grad)")
             dx = linear_bwd_input(dy, w, y, dy_img=dy_img)
-        forked = dy_img is not None and dy.shape[0] >= X3_BWW_MIN_ROWS
+        # (the weight gradients go to the side stream only when nothing but the optimiser reads them: parameters themselves — a
+        # weight that is an autograd VIEW of one has a backward node behind it that reads the gradient on the main stream at once)
+        forked = dy_img is not None and dy.shape[0] >= X3_BWW_MIN_ROWS and w_leaf
         at = fork_point() if forked else None                  # dy and its image are ready here
         if x2 is not None and need[3]:
             # the input gradients first: they are the critical path of the backward pass (the weight gradients below are leaves)
@@ -1774,12 +1799,24 @@ class _LinearFn(torch.autograd.Function):
             dx2 = linear_bwd_input(dy, w2, y, dy_img=dy_img)
         with (side_section(dy, dy_img, x, x2, ctx.x2_img, at=at) if forked else _NoSection()):
             dw, db, dw2, db2 = _LinearFn._weight_grads(ctx, dy, dy_img, x, w, x2, w2, x_rows, x2_rows, need)
-        return dx, dw, (db if ctx.has_bias else None), dx2, dw2, None, None, None, (db2 if ctx.has_bias2 else None)
+        # (no reference to the concat gradient but the one returned: AccumulateGrad adopts a gradient tensor only when nobody else
+        # holds it — the two column views do, through their base — and otherwise CLONES it, on the main stream, while a forked
+        # backward is still writing it on the side stream)
+        ctx.dw_views = None
+        if ctx.split is not None:
+            return dx, dw_cat, (db if ctx.has_bias else None), dx2, None, None, None, None, None, None
+        return dx, dw, (db if ctx.has_bias else None), dx2, dw2, None, None, None, (db2 if ctx.has_bias2 else None), None
 
     @staticmethod
     def _weight_grads(ctx, dy, dy_img, x, w, x2, w2, x_rows, x2_rows, need):
         dw = db = dw2 = db2 = None
         dyT = None
+        views = getattr(ctx, "dw_views", None)
+
+        def _dw_out(t, *_shape):          # (shadows the module's: a concat weight's two blocks write into ONE gradient tensor)
+            if views is not None:
+                return views[0] if t is w else views[1]
+            return globals()["_dw_out"](t, *_shape)
         x2_img = ctx.x2_img if (x2 is not None and x2_rows is None) else None
         tall = _MODE["name"] != "f32" and dy.shape[0] >= X3_BWW_MIN_ROWS
         rimg = _row_image_for(x, x_rows, None) if tall else None
@@ -1818,8 +1855,11 @@ class _LinearFn(torch.autograd.Function):
                 dw2 = weight_grad(dy, x2, None, want_bias=False, dyT=dyT, x_img=x2_img, dy_img=dy_img, dw_out=_dw_out(w2, *w2.shape),
                                   defer_for=(w2, None, None))[0]
             elif need[4] or ctx.has_bias2:
-                dw2, db2 = weight_grad(dy, x2, x2_rows, want_bias=ctx.has_bias2, dyT=dyT, dy_img=dy_img, dw_out=_dw_out(w2, *w2.shape),
-                                       defer_for=(w2, ctx.bias2_t, None))
+                # (the pooled rows' own image, when their producer wrote one and no bias gradient has to come out of this product:
+                # read k-major — no transposed images of dy and x2)
+                x2i = x2_img if (x2_img is not None and not ctx.has_bias2 and x2_img.K == x2.shape[1]) else None
+                dw2, db2 = weight_grad(dy, x2, x2_rows, want_bias=ctx.has_bias2, dyT=dyT, x_img=x2i, dy_img=dy_img,
+                                       dw_out=_dw_out(w2, *w2.shape), defer_for=(w2, ctx.bias2_t, None))
         return dw, db, dw2, db2
 
 
@@ -1828,6 +1868,13 @@ def linear(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_rows=N
     if bias2 is not None and (bias is None or x2 is None):
         raise ValueError("bias2 belongs to the second projection of a dual-input Linear that has a first bias")
     return _LinearFn.apply(x, w, bias, x2, w2, relu, x_rows, x2_rows, bias2)
+
+
+def linear_cat(x, x2, w, split, bias=None, relu=False, x_rows=None):
+    """y = act(cat(x[rows], x2) @ w.T + bias) for w [N, split + K2] WITHOUT materialising the concatenation or slicing the
+    parameter outside: fc_neigh(cat(h_self, h_neigh)) (R/train/graphsage/pytorch/aggregator_dgl.py:206) as one dual-input product
+    whose backward returns ONE gradient tensor for w."""
+    return _LinearFn.apply(x, w, bias, x2, None, relu, x_rows, None, None, int(split))
 
 
 class _ReduceFn(torch.autograd.Function):
