@@ -561,8 +561,11 @@ def main():
                                                       if timed_mode.startswith("captured") else "")
                        + ("; auto policy probe: %s" % getattr(strat, "staged_auto_probe", None) if strat.use_graphs == "auto" else ""),
                        "parallelism": "dp%d (seed-sharded replicas, two-bucket grad all-reduce %s)%s" % (
-                           world, "after the replayed forward + backward graph; optimiser eager" if "staged_dp" in forms_timed
-                           else "overlapped with backward",
+                           world, ("INSIDE the replayed step graph: the early bucket's RCCL all-reduce on the side branch under the layer-0 "
+                                   "backward, the late bucket and the optimiser (device-side step count) behind it"
+                                   if (dist.is_initialized() and dist.get_backend() == "nccl") else
+                                   "after the replayed forward + backward graph; optimiser eager (host-staged backend)")
+                           if "staged_dp" in forms_timed else "overlapped with backward",
                            " — FORCED through a world-size-1 RCCL group (--force-dist)" if args.force_dist else ""),
                        "avg_unique_input_nodes_n0": round(n0_avg, 1), "avg_n1": round(n1_avg, 1), "setup_s": round(setup_s, 1)},
             "roofline": roof_gemm if roof_gemm else roof_aggr,

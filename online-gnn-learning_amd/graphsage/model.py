@@ -166,8 +166,11 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
 
     def build_optimizer(self):
         self._sg = None
-        capturable = self.use_graphs and not parallel.is_distributed()
-        self.optimizer = optim.Adam(self.graphsage_model.parameters(), lr=0.001, capturable=capturable)
+        # (a replica's whole step — exchange included — is one captured graph too: the optimiser keeps its step count on the device;
+        # its own two-part form is for the one-rank step: under data parallelism the early part would run before the all-reduce)
+        capturable = bool(self.use_graphs)
+        self.optimizer = optim.Adam(self.graphsage_model.parameters(), lr=0.001, capturable=capturable,
+                                    early=False if parallel.is_distributed() else None)
         # Under torch.distributed (one process per GPU, identical replicas, identical host RNG seeds on every rank)
         # each rank trains on its shard_range slice of every replay batch; the weighted gradient all-reduce makes the
         # update that of the whole batch, and the sharded PBR passes all-gather their per-seed losses (parallel.py).
@@ -451,7 +454,52 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         # rank-sharded batch: this rank's seeds only; the gradient is that of the mean over the whole batch
         n_local = int(seeds.numel())
         big = self.use_graphs is True or int(n_global) * (1 + self.samples) >= self.STAGED_DP_MIN_ROWS      # (global: same on every rank)
+        import torch.distributed as dist
+        if (self.gsync is not None and self._graphs_ok("staged_dp") and big and (on_rows is None or self.reduction != "mean")
+                and dist.get_backend(self.gsync.group) == "nccl"):
+            # A replica's step as ONE replayed graph (form "staged_dp"): forward, loss, backward, the gradient exchange — the early
+            # bucket's RCCL all-reduce launched from the gradient hooks on the side branch, under the layer-0 pool backward and weight
+            # gradient; the late bucket (layer 0's fc_pool) behind it — and Adam on the reduced buckets.  The local mean loss's
+            # gradients are weighted by n_local / n_global inside the graph (= the gradient of the mean over the whole batch).
+            # The sequence of collectives is the same on every rank whatever it runs — a replay, the eager twin below (a size bucket on
+            # its first sighting, a ragged or empty shard): before the split is learnt ONE bucket, afterwards early then late.
+            w = n_local / float(n_global)
+            sg = None
+            if n_local > 0:
+                n0, n1 = int(input_nodes.numel()), blocks[1].number_of_src_nodes()
+                if self.gsync.learnt:            # (the step that learns the bucket split runs eagerly, on every rank: it broadcasts)
+                    sg = self._step_graphs().staged_step(graph, seeds, blocks, n0, n1, defer_first=self.use_graphs == "auto",
+                                                         dp=(self.gsync, w))
+            if sg is not None:
+                if on_rows is not None:
+                    on_rows(seeds, sg.loss_rows.clone())
+                if self.step_hook is not None:
+                    self.step_hook(dict(seeds=seeds, loss=sg.loss * w, grads=sg.grads, form="staged_dp", n0=n0, n1=n1))
+                return sg.loss * n_local
+            # the eager twin: the same launches and the same collectives, enqueued from Python
+            self.optimizer.zero_grad()
+            loss_e = eager_rows = None
+            self.gsync.begin_step(w)
+            if n_local > 0:
+                batch_labels = ops.LazyLabels(graph.ndata["target"], seeds)
+                loss_e, eager_rows, _ = self.graphsage_model.forward_loss(blocks, self._inputs(graph, input_nodes), batch_labels, rows=True)
+                ops.backward(loss_e)
+            else:                                               # more ranks than seeds in this batch: zeros into the same collectives
+                for p in self.gsync.params:
+                    p.grad = None
+            self.gsync.sync(weight=w)
+            self.optimizer.step()
+            if on_rows is not None:
+                on_rows(seeds, eager_rows.detach() if eager_rows is not None else torch.zeros(0, device=graph.device))
+            if loss_e is None:
+                return None
+            if self.step_hook is not None:
+                self.step_hook(dict(seeds=seeds, loss=loss_e.detach() * w, grads=[p.grad for p in self.graphsage_model.parameters()],
+                                    form="staged_dp_eager", n0=n0, n1=n1))
+            return loss_e.detach() * n_local
         if self.gsync is not None and self._graphs_ok("staged_dp") and big and (on_rows is None or self.reduction != "mean"):
+            # (a backend whose collectives cannot be recorded into a hipGraph — the gloo rehearsals: forward + backward replayed,
+            # the exchange and the optimiser enqueued from Python)
             # replayed replica step: the captured graph ends with the gradients of the LOCAL mean loss in its static tensors; the
             # all-reduce weights them by n_local / n_global (= the gradient of the mean over the whole batch), then the optimiser
             eager_rows = None

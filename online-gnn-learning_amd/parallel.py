@@ -128,7 +128,18 @@ class GradSynchronizer:
             self._stale = True                       # accumulated into after the launch: sync() raises (use no_sync())
             return
         if not self._suspended and all(self._fired.get(j, 0) >= 1 for j in self._early):
-            self._launch_early(self.weight)
+            self._launch_early(getattr(self, "_step_weight", self.weight))
+
+    @property
+    def learnt(self):
+        """The early / late split is known (from then on every exchange is early bucket, then late bucket)."""
+        return self._early is not None
+
+    def begin_step(self, weight=None):
+        """Start of a step whose backward pass may launch the early bucket from its hooks: they scale this rank's gradients by
+        ``weight`` (default: the constructor's)."""
+        self._step_weight = self.weight if weight is None else float(weight)
+        self._fired, self._order = {}, []
 
     def no_sync(self):
         """Context manager for gradient-accumulation steps: backward passes inside it never launch the early bucket."""
@@ -276,8 +287,8 @@ class GradSynchronizer:
             flat = self._fill("all", idxs, w)
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             self._scatter("all")
-            if self.overlap:
-                self._learn()
+            if self.overlap and not (flat.is_cuda and torch.cuda.is_current_stream_capturing()):
+                self._learn()                     # (never while a step is being recorded: it broadcasts through the host)
         else:
             if self._pending is None:                # the hooks did not complete the bucket on this rank: same collective, here
                 self._launch_early(w)
@@ -301,6 +312,7 @@ class GradSynchronizer:
         self._fired = {}
         self._order = []
         self._handed.clear()
+        self._step_weight = self.weight
 
 
 def assert_replicated(values, what="value", group=None):

@@ -78,10 +78,13 @@ class TrainStepGraph:
     """One captured train step over ``buf`` restricted to (n1_pad, n0_pad) rows.
     ``loss_fn(logits, labels) -> (scalar loss to differentiate, per-seed losses or None)``."""
 
-    def __init__(self, model, optimizer, graph, buf, n1_pad, n0_pad, loss_fn, pool=None, apply=True, loss_kind=None):
-        # apply=False: forward + loss + backward only — the step of a data-parallel replica, whose gradients are all-reduced
-        # (eagerly: the collective stays outside the graph) before the optimiser runs
+    def __init__(self, model, optimizer, graph, buf, n1_pad, n0_pad, loss_fn, pool=None, apply=True, loss_kind=None, dp=None):
+        # apply=False: forward + loss + backward only (the gradients are in ``grads``; exchange and optimiser are the caller's).
+        # dp = (GradSynchronizer, weight): the WHOLE step of a data-parallel replica — forward, loss, backward, the gradient exchange
+        # (RCCL all-reduces recorded into the graph: the early bucket launched from the gradient hooks on the side branch, under the
+        # layer-0 backward; the late one after it) and the optimiser (device-side step count) — replayed with one host call.
         self.model, self.opt, self.graph, self.buf, self.loss_fn, self.apply = model, optimizer, graph, buf, loss_fn, bool(apply)
+        self.dp = dp if apply else None
         # "mean" / "mean_rows": the loss is nn.CrossEntropyLoss — the model may run its last layer and the loss as one node
         # (GraphSAGE.forward_loss); None: an arbitrary loss_fn(logits, labels)
         self.loss_kind = loss_kind if hasattr(model, "forward_loss") else None
@@ -104,7 +107,13 @@ class TrainStepGraph:
         else:
             logits = self.model(blocks, GatheredRows(g.feat_table, src0))
             loss, rows = self.loss_fn(logits, labels)
-        if apply and hasattr(self.opt, "backward_and_step"):
+        if apply and self.dp is not None:
+            gsync, weight = self.dp
+            gsync.begin_step(weight)                  # (the hooks launch the early bucket's all-reduce with this rank's weight)
+            ops.backward(loss)
+            gsync.sync(weight)                        # late bucket, wait for the early one, p.grad <- views of the reduced buckets
+            self.opt.step()
+        elif apply and hasattr(self.opt, "backward_and_step"):
             self.opt.backward_and_step(loss)          # split-K slabs summed by the optimiser launch, its early part on the side branch
         elif learn and hasattr(self.opt, "backward_learn"):
             self.opt.backward_learn(loss)             # (the warm-up pass: records the order in which the gradients arrive)
@@ -116,13 +125,14 @@ class TrainStepGraph:
 
     def _capture(self, pool):
         global _WARMED
-        if self.apply:
+        if self.apply and hasattr(self.opt, "prepare_capture"):
             assert getattr(self.opt, "capturable", False), "a captured step needs optim.Adam(capturable=True)"
             self.opt.prepare_capture()
+        # (any other optimiser is recorded as it is: its step() must not synchronise — torch.optim.SGD without momentum does not)
         ops.unit_grad(self.graph.device)
         ops.ce_counter(self.graph.device, 0)                 # (allocates the device's counter array outside the capture)
         ops._static_image(self.graph.feat_table)            # built outside the capture (a one-off 850 MB split pass)
-        learn = self.apply and getattr(self.opt, "needs_order", False)
+        learn = self.apply and self.dp is None and getattr(self.opt, "needs_order", False)
         if not _WARMED or learn:
             # once per process: run the step's forward + backward for real on a side stream (autograd's device thread, lazily
             # created helpers), WITHOUT the optimiser step and with the gradients dropped — the weights do not move.  (Also once
@@ -131,7 +141,11 @@ class TrainStepGraph:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                self._body(apply=False, learn=learn)
+                if self.dp is not None:                 # (a replica: the warm-up pass must not talk to the other ranks)
+                    with self.dp[0].no_sync():
+                        self._body(apply=False)
+                else:
+                    self._body(apply=False, learn=learn)
             torch.cuda.current_stream().wait_stream(side)
             self.opt.zero_grad(set_to_none=True)
             ops.invalidate_weight_images()          # no optimiser step ran: drop the weight images that forward prepared
@@ -244,7 +258,7 @@ class StepGraphCache:
         self.captures = self.evictions = self.borrowed = self.deferred = 0
         self.sightings = {}
 
-    def _train(self, graph, buf, key, n1_pad, n0_pad, apply=True):
+    def _train(self, graph, buf, key, n1_pad, n0_pad, apply=True, dp=None):
         sg = self.graphs.get(key)
         if sg is None:
             while len(self.graphs) >= self.MAX_GRAPHS:
@@ -254,7 +268,7 @@ class StepGraphCache:
                 del old
                 self.evictions += 1
             sg = self.graphs[key] = TrainStepGraph(self.model, self.opt, graph, buf, n1_pad, n0_pad, self.loss_fn, apply=apply,
-                                                   loss_kind=self.loss_kind)
+                                                   loss_kind=self.loss_kind, dp=dp)
             self.captures += 1
         else:
             self.graphs.move_to_end(key)
@@ -276,7 +290,7 @@ class StepGraphCache:
         sg.last_sizes = (n0, n1)
         return sg
 
-    def staged_step(self, graph, seeds, blocks, n0, n1, apply=True, defer_first=False):
+    def staged_step(self, graph, seeds, blocks, n0, n1, apply=True, defer_first=False, dp=None):
         """One step of a loader batch: stage its block arrays into the bucket's static buffers, replay its train graph.
         ``apply=False``: the graph stops after backward (the gradients are in ``sg.grads``).
 
@@ -286,7 +300,9 @@ class StepGraphCache:
         when it comes back.  Common buckets are captured within the first snapshots; rare ones never stall the stream."""
         B = int(seeds.numel())
         n0_pad, n1_pad = round_up(n0, N0_BUCKET), round_up(n1, N1_BUCKET)
-        bkey = ("staged", id(graph), B, n0_pad, n1_pad, bool(apply))
+        # (dp = (GradSynchronizer, weight): the weight n_local / n_global is a constant of the recorded bucket scaling, and whether
+        # the exchange runs in one bucket or two is frozen too: both are part of the key)
+        bkey = ("staged", id(graph), B, n0_pad, n1_pad, bool(apply) if dp is None else ("dp", round(float(dp[1]), 9), dp[0].learnt))
         if bkey not in self.graphs:
             near = [k for k in self.graphs
                     if k[0] == "staged" and k[1:3] == bkey[1:3] and k[5] == bkey[5]
@@ -304,7 +320,7 @@ class StepGraphCache:
         buf = self.bufs.get(bkey)
         if buf is None:
             buf = self.bufs[bkey] = BlockBuffers(B, self.S, n1_pad, n0_pad, graph.device)
-        sg = self._train(graph, buf, bkey, n1_pad, n0_pad, apply=apply)
+        sg = self._train(graph, buf, bkey, n1_pad, n0_pad, apply=apply, dp=dp)
         b0, b1 = blocks
         ops.stage_segments([(b0.src_ids, buf.src0, n0), (b1.src_ids, buf.src1, n1), (b0.local_idx, buf.lidx0, n1 * self.S),
                             (b1.local_idx, buf.lidx1, B * self.S), (seeds, buf.seeds, B)])

@@ -102,8 +102,9 @@ def _worker_reddit(forced, port, out_path):
 
 
 def _worker_graphs(forced, port, out_path):
-    """Pubmed-size replicas: eager sharded steps vs steps replayed as captured graphs (``staged_dp``: forward + backward
-    captured, the two all-reduces and the optimiser eager) with an RCCL communicator alive in the process."""
+    """Pubmed-size replicas: eager sharded steps vs steps replayed as captured graphs (``staged_dp``: forward, backward, BOTH RCCL
+    all-reduces — the early bucket launched from the gradient hooks on the side branch — and the optimiser recorded into one
+    hipGraph) with an RCCL communicator and its watchdog thread alive in the process."""
     dist, parallel = _setup(True, port)
     import torch.nn.functional as F
     from ogl_amd import sampling, synthetic
@@ -192,7 +193,9 @@ def test_dp_steps_replayed_as_graphs_beside_rccl(tmp_path):
     out = str(tmp_path / "g.pt")
     _spawn1(_worker_graphs, (True, _free_port(), out))
     r = torch.load(out, weights_only=False)
-    assert r[False]["forms"] == ["sharded"] * 5 and r[True]["forms"] == ["staged_dp"] * 5
+    # (the first step learns the bucket split — a broadcast through the host — and runs as the eager twin; from then on every step,
+    # the ragged last batch included, is ONE replayed graph that contains both all-reduces and the optimiser)
+    assert r[False]["forms"] == ["sharded"] * 5 and r[True]["forms"] == ["staged_dp_eager"] + ["staged_dp"] * 4
     for x, y in zip(r[False]["weights"], r[True]["weights"]):
         torch.testing.assert_close(x, y, rtol=1e-4, atol=2e-5)
 
