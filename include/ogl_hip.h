@@ -344,6 +344,12 @@ typedef struct ogl_x3_split_part {
   void* image; int64_t image_row_bytes; int64_t group_offset;
 } ogl_x3_split_part;
 int ogl_x3_split_multi(const ogl_x3_split_part* parts, int n_parts, ogl_stream_t stream);
+/* ogl_x3_split_multi with the optimiser's per-step scalars riding in the same launch (what ogl_adam_step_multi_dev computes in a
+ * one-thread launch of its own at the END of a step: ++*step_dev, scalars_dev[0] = lr / (1 - beta1^t), scalars_dev[1] =
+ * 1 / sqrt(1 - beta2^t), double arithmetic): moved to the launch that STARTS the step; the step's optimiser launch then passes
+ * prepare = 0 to ogl_adam_step_multi_slabs.  n_parts >= 1. */
+int ogl_x3_split_multi_adam(const ogl_x3_split_part* parts, int n_parts, int64_t* step_dev, float* scalars_dev, double lr, double beta1,
+                            double beta2, ogl_stream_t stream);
 /* ogl_relu_bwd that also writes the bf16x3 image of its result (M + 1 rows, reduction length N, no appended slot) = what
  * ogl_x3_split(out) would build: the masked gradient of a fused-ReLU projection (autograd of F.relu in
  * R/train/graphsage/pytorch/graphsage_dgl.py:29-31) is the A operand of the input-gradient product that follows. */

@@ -77,6 +77,7 @@ SIGNATURES = {
     "ogl_linear_fwd_x3_ext": (_i, [_p, _i64, _p, _i64, _i, _p, _i64, _p, _i64, _i, _i64, _p, _i, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i, _p, _i64,
                                    _p, _p]),
     "ogl_x3_split_multi": (_i, [_p, _i, _p]),
+    "ogl_x3_split_multi_adam": (_i, [_p, _i, _p, _p, _d, _d, _d, _p]),
     "ogl_relu_bwd_img": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _p, _p]),
     "ogl_x3_split_into": (_i, [_p, _i64, _i64, _i, _i, _p, _p, _i64, _i64, _p]),
     "ogl_linear_bwd_weight_x3_workspace_bytes": (_i64, [_i64, _i, _i]),

@@ -1060,9 +1060,19 @@ struct X3SplitBatch {
   const float* vec2[OGL_X3_SPLIT_MAX_PARTS];
   unsigned char* img[OGL_X3_SPLIT_MAX_PARTS];      // at the part's first group
   int64_t img_row_bytes[OGL_X3_SPLIT_MAX_PARTS];
+  // optional passenger (ogl_x3_split_multi_adam): the optimiser's per-step scalars — ++*adam_step and {lr / (1 - beta1^t),
+  // 1 / sqrt(1 - beta2^t)} in double arithmetic, what k_adam_prepare (loss_optim.hip) does as a launch of its own at the END of the
+  // step, computed by one thread of this launch at its START
+  int64_t* adam_step; float* adam_scal; double adam_lr, adam_b1, adam_b2;
 };
 
 __global__ void __launch_bounds__(256) k_x3_split_multi(X3SplitBatch b) {
+  if (b.adam_step && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    const int64_t t = *b.adam_step + 1;
+    *b.adam_step = t;
+    b.adam_scal[0] = (float)(b.adam_lr / (1.0 - pow(b.adam_b1, (double)t)));
+    b.adam_scal[1] = (float)(1.0 / sqrt(1.0 - pow(b.adam_b2, (double)t)));
+  }
   const int part = blockIdx.y;
   const float* __restrict__ src = b.src[part];
   const int64_t ld = b.ld[part], R = b.R[part], img_row_bytes = b.img_row_bytes[part];
@@ -1117,10 +1127,12 @@ __global__ void __launch_bounds__(256) k_x3_split_multi(X3SplitBatch b) {
   }
 }
 
-extern "C" int ogl_x3_split_multi(const ogl_x3_split_part* parts, int n_parts, ogl_stream_t stream) {
+static int x3_split_multi(const ogl_x3_split_part* parts, int n_parts, int64_t* adam_step, float* adam_scal, double lr, double beta1,
+                          double beta2, ogl_stream_t stream) {
   if (n_parts < 0 || n_parts > OGL_X3_SPLIT_MAX_PARTS || (n_parts > 0 && !parts)) return OGL_EINVAL;
-  if (n_parts == 0) return OGL_OK;
+  if (n_parts == 0) return adam_step ? OGL_EINVAL : OGL_OK;       // (the passenger needs a launch to ride in)
   X3SplitBatch b;
+  b.adam_step = adam_step; b.adam_scal = adam_scal; b.adam_lr = lr; b.adam_b1 = beta1; b.adam_b2 = beta2;
   int64_t most = 0;
   for (int i = 0; i < n_parts; ++i) {
     const ogl_x3_split_part& q = parts[i];
@@ -1152,6 +1164,20 @@ extern "C" int ogl_x3_split_multi(const ogl_x3_split_part* parts, int n_parts, o
                      (hipStream_t)stream, b);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
+}
+
+extern "C" int ogl_x3_split_multi(const ogl_x3_split_part* parts, int n_parts, ogl_stream_t stream) {
+  return x3_split_multi(parts, n_parts, nullptr, nullptr, 0.0, 0.0, 0.0, stream);
+}
+
+// ... with the optimiser's per-step scalars riding along (ogl_adam_step_multi_dev's first launch, k_adam_prepare, moved from the END
+// of the step — where its 5 us and the gap in front of it are on the critical path — into the launch that STARTS the step):
+// ++*step_dev; scalars_dev[0] = lr / (1 - beta1^t), scalars_dev[1] = 1 / sqrt(1 - beta2^t).  The optimiser launch of the same step
+// then runs with prepare = 0 (ogl_adam_step_multi_slabs).
+extern "C" int ogl_x3_split_multi_adam(const ogl_x3_split_part* parts, int n_parts, int64_t* step_dev, float* scalars_dev, double lr,
+                                       double beta1, double beta2, ogl_stream_t stream) {
+  if (!step_dev || !scalars_dev) return OGL_EINVAL;
+  return x3_split_multi(parts, n_parts, step_dev, scalars_dev, lr, beta1, beta2, stream);
 }
 
 // dy (.) [y > 0] (ogl_relu_bwd) that ALSO writes the bf16x3 image of its result: the masked gradient is the A operand of the

@@ -308,6 +308,8 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
 
     def _eager_step(self, graph, blocks, input_nodes, seeds, on_rows=None):
         self.optimizer.zero_grad()
+        if hasattr(self.optimizer, "prime"):
+            self.optimizer.prime()                     # (its per-step scalars ride in the forward's weight-image launch)
         # (the labels are gathered inside the loss launch; the last layer and the loss are one node where that applies)
         batch_labels = ops.LazyLabels(graph.ndata["target"], seeds)
         loss, rows, _ = self.graphsage_model.forward_loss(blocks, self._inputs(graph, input_nodes), batch_labels,

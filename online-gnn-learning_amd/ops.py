@@ -854,6 +854,23 @@ def linear_fwd_x3_ext(x_img, x_rows, w_img, x2_img=None, x2_rows=None, add=None,
 # parameters' storage + version counter and dropped by the optimisers (which update through raw pointers).
 _W_IMAGES = {}
 PREPARE_WEIGHT_IMAGES = True
+# optim.Adam (device-side step count) may ask the step's weight-image launch to compute its per-step scalars: ``req`` = (step_dev,
+# scalars_dev, lr, beta1, beta2) until a launch takes it, ``served`` = (step_dev address, made while capturing?) afterwards
+ADAM_PRIME_IN_SPLIT = os.environ.get("OGL_ADAM_PRIME", "1") != "0"
+_ADAM_PRIME = {"req": None, "served": None}
+
+
+def adam_prime(step_dev, scalars_dev, lr, beta1, beta2):
+    """The NEXT weight-image launch also prepares this optimiser's step (++step count, bias-correction scalars)."""
+    _ADAM_PRIME["req"], _ADAM_PRIME["served"] = (step_dev, scalars_dev, float(lr), float(beta1), float(beta2)), None
+
+
+def adam_primed(step_dev):
+    """True (once) when a weight-image launch since ``adam_prime`` prepared this optimiser's step — in the mode we are in now
+    (a launch recorded into a graph prepares that graph's replays, not an eager step, and vice versa)."""
+    served, _ADAM_PRIME["served"] = _ADAM_PRIME["served"], None
+    _ADAM_PRIME["req"] = None
+    return served is not None and served == (step_dev.data_ptr(), _capturing())
 
 
 class _X3SplitPart(C.Structure):
@@ -937,8 +954,17 @@ def weight_images_prepare(requests):
     for a, (m, R, K, tr, app, v1, v2, buf, G, off) in zip(arr, parts):
         a.src, a.ld, a.R, a.K, a.transpose, a.append = _ptr(m), (_ld(m) if m is not None else 0), R, K, tr, app
         a.vec1, a.vec2, a.image, a.image_row_bytes, a.group_offset = _ptr(v1), _ptr(v2), _ptr(buf), G * 192, off
-    _launch("ogl_x3_split_multi", _lib.lib().ogl_x3_split_multi, C.cast(arr, C.c_void_p), len(parts), _stream(),
-            meta=dict(parts=len(parts)))
+    prime = _ADAM_PRIME.get("req")
+    if prime is not None and ADAM_PRIME_IN_SPLIT:
+        # the optimiser's per-step scalars ride in this launch (the step's first): its own one-thread launch at the END of the step,
+        # and the gap in front of it, leave the critical path
+        step_dev, scal, lr, b1, b2 = prime
+        _launch("ogl_x3_split_multi", _lib.lib().ogl_x3_split_multi_adam, C.cast(arr, C.c_void_p), len(parts), _ptr(step_dev), _ptr(scal),
+                C.c_double(lr), C.c_double(b1), C.c_double(b2), _stream(), meta=dict(parts=len(parts), adam_prepare=True))
+        _ADAM_PRIME["req"], _ADAM_PRIME["served"] = None, (step_dev.data_ptr(), _capturing())
+    else:
+        _launch("ogl_x3_split_multi", _lib.lib().ogl_x3_split_multi, C.cast(arr, C.c_void_p), len(parts), _stream(),
+                meta=dict(parts=len(parts)))
     if len(_W_IMAGES) > 32:
         _W_IMAGES.clear()               # stale versions of re-assigned parameters: never let them pile up
     import weakref

@@ -134,6 +134,17 @@ class Adam(torch.optim.Optimizer):
         if self.needs_order:
             self._learn_split()
 
+    def prime(self):
+        """Call BEFORE the step's forward pass: the step's first launch (the weight images, ops.weight_images_prepare) then also
+        advances the device-side step count and computes the bias-correction scalars — the one-thread launch ``step()`` would put
+        in front of the update, at the end of the step, goes.  Without such a launch in the forward pass ``step()`` prepares as usual."""
+        if self.capturable and len(self.param_groups) == 1:
+            g = self.param_groups[0]
+            dev = next((p.device for p in g["params"] if p.is_cuda), None)
+            if dev is not None:
+                step_dev, scal = self._device_state(dev)
+                ops.adam_prime(step_dev, scal, g["lr"], g["betas"][0], g["betas"][1])
+
     def backward_and_step(self, loss):
         """``loss.backward(); self.step()`` with the split-K slabs left to this optimiser and its early part launched from the
         gradient hooks (module docstring).  Gradients must start from zero_grad(): one backward pass per step."""
@@ -176,6 +187,8 @@ class Adam(torch.optim.Optimizer):
                 ps, gs, ms, vs, sgs = zip(*its)
                 if self.capturable:
                     step_dev, scal = self._device_state(ps[0].device)
+                    if prepare and first and ops.adam_primed(step_dev):
+                        prepare = False                     # (the step's weight-image launch already did: see prime())
                     ops.adam_step_multi_slabs(ps, gs, ms, vs, sgs, step_dev=step_dev, scalars_dev=scal, prepare=prepare and first,
                                               lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"])
                 else:

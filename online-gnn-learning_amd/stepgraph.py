@@ -102,6 +102,8 @@ class TrainStepGraph:
         # the FULL tables: a snapshot view's row count would be frozen into the graph (ids are < n_present by construction)
         labels = ops.LazyLabels(g.target_table, b.seeds) if LAZY_LABELS else ops.gather_i64(g.target_table, b.seeds)
         self.opt.zero_grad(set_to_none=True)
+        if apply and hasattr(self.opt, "prime"):
+            self.opt.prime()                          # (the optimiser's per-step scalars ride in the step's first launch)
         if self.loss_kind is not None:
             loss, rows, _ = self.model.forward_loss(blocks, GatheredRows(g.feat_table, src0), labels, rows=self.loss_kind == "mean_rows")
         else:

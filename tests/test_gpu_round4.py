@@ -369,3 +369,36 @@ def test_inrepo_first_layer_without_input_gradient(mode):
                     assert rel <= 1e-3, (k, blk_, rel)
     finally:
         ops.set_gemm_mode("f32")
+
+
+def test_adam_scalars_ride_in_the_weight_image_launch():
+    """optim.Adam.prime(): the step's weight-image launch (ogl_x3_split_multi_adam) advances the device-side step count and computes
+    the bias-correction scalars; the optimiser launch then runs without its own prepare launch — same bits as the two-launch form,
+    over several steps, and an un-served request falls back to it."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops, optim
+    ops.set_gemm_mode("auto")
+    try:
+        torch.manual_seed(7)
+        w0 = torch.randn(64, 96, device="cuda")
+        grads = [torch.randn(64, 96, device="cuda") for _ in range(4)]
+        res = {}
+        for primed in (False, True):
+            w = torch.nn.Parameter(w0.clone())
+            opt = optim.Adam([w], lr=1e-3, capturable=True, early=False)
+            launches = []
+            for step, g_ in enumerate(grads):
+                ops.invalidate_weight_images()
+                if primed and step != 2:                      # (step 2: nothing serves the request -> step() prepares itself)
+                    opt.prime()
+                    ops.weight_images_prepare([("wb", (w, None))])
+                elif primed:
+                    opt.prime()
+                w.grad = g_.clone()
+                ops.profile_start()
+                opt.step()
+                launches.append([m for n, m, _ in ops.profile_stop() if n == "ogl_adam_step_multi_slabs"])
+            res[primed] = (w.detach().clone(), int(opt._step_dev), launches)
+        assert torch.equal(res[False][0], res[True][0]) and res[False][1] == res[True][1] == 4
+    finally:
+        ops.set_gemm_mode("f32")

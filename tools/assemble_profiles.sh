@@ -2,7 +2,7 @@
 # Copy what tools/collect_profiles.sh left under gpurun_out/prof_final into profiles/ under the round's names and derive the
 # traffic JSONs bench.py quotes.  Usage: bash tools/assemble_profiles.sh r03 2026-10-04
 set -e
-R=${1:-r03}; D=${2:-$(date +%F)}
+R=${1:-r04}; D=${2:-$(date +%F)}
 O=gpurun_out/prof_final; P=profiles; H=$(git rev-parse --short HEAD)
 cp $O/bench.json $P/${R}_bench_final.json
 cp $O/bench_eager.json $P/${R}_bench_eager.json
@@ -28,6 +28,24 @@ if rows:
     json.dump(dict(what="same box, alternating runs of `OGL_POOL_PLAN=0|1 python bench.py --steps 200 --warmup 60 --no-cpu-baseline --no-e2e --graphs` "
                         "(0: the pool backward's bucket pass on the backward's critical path; 1: planned by the forward pass on the side stream)",
                    runs=rows), open('profiles/%s_ab_pool_plan.json' % R, 'w'), indent=1)
+PY
+[ -f $O/parity_numbers.log ] && grep -E "200-step curve|accumulated gradient|out-of-tolerance logits|relative gradient errors|weights outside|forward parity|passed|failed" $O/parity_numbers.log > $P/${R}_parity_numbers.txt || true
+[ -f $O/ab_r04.txt ] && python - "$R" <<'PY' || true
+import glob, json, re, sys
+R = sys.argv[1]
+txt = open('gpurun_out/prof_final/ab_r04.txt').read()
+combos = dict(re.findall(r"^(c\d+) = (.*)$", txt, flags=re.M))
+runs = {}
+for f in sorted(glob.glob('gpurun_out/prof_final/ab_r04/*.json')):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+    except Exception:
+        continue
+    k = f.split('/')[-1][:-5]
+    runs[k] = dict(env=combos.get(k.split('_')[0], '?'), ms_per_step=d['ms_per_step'], vertices_per_s=d['value'])
+json.dump(dict(what="same box, alternating runs of `env <switches> python bench.py --steps 200 --warmup 60 --graphs --no-cpu-baseline --no-e2e` "
+                    "(tools/ab_combo.sh): the round's switches against the default (OGL_X=0 is a no-op)", runs=runs),
+          open('profiles/%s_ab_experiments.json' % R, 'w'), indent=1)
 PY
 cp $O/kernel_stats.csv $P/${R}_rocprofv3_kernel_stats.csv
 cp $O/kernel_stats_graph.csv $P/${R}_rocprofv3_kernel_stats_graph_replay.csv

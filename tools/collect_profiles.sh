@@ -11,6 +11,15 @@ timeout -k 10 300 python bench.py --no-graphs --no-cpu-baseline --no-e2e > $O/be
 for w in reddit_pbr_forward arxiv_pbr_forward arxiv_rbr pubmed_rbr pubmed_settings arxiv_settings bitcoin_settings reddit_settings reddit_settings_pbr_forward; do
   timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err < /dev/null
 done
+# the in-repo aggregator modes at the Reddit rung (round 4: first-class workloads, mean backward as a planned segmented gather)
+for a in meanpool mean; do
+  timeout -k 10 300 python bench.py --aggregator $a --no-cpu-baseline --no-e2e > $O/bench_reddit_rbr_$a.json 2> $O/bench_reddit_rbr_$a.err < /dev/null
+done
+# the numbers the round-4 parity tests print (loss curves, x6-vs-fp32 counts, gradient errors at the Reddit rung)
+timeout -k 10 600 python -m pytest tests/test_gpu_rungs.py tests/test_gpu_fullsize.py tests/test_gpu_round4.py -q -s -k "200_step or no_worse or inrepo_modes or two_part or fused_output_layer_step" > $O/parity_numbers.log 2>&1 < /dev/null || true
+# same-box A/B of the round's switches inside the replayed step (kept and dropped ones)
+bash tools/ab_combo.sh r04 3 "OGL_X=0" "OGL_FUSED_OUT_FWD=0" "OGL_SLAB_ADAM=0" "OGL_ADAM_EARLY=1" "OGL_POOL_PLAN_LATE=1" > $O/ab_r04.txt 2>&1 || true
+cp -r gpurun_out/ab_r04 $O/ab_r04 2> /dev/null || true
 cd /tmp && export TMPDIR=/tmp
 # the traced / counted runs enqueue eagerly (--no-graphs): the same kernels at the batch's own sizes, one dispatch per launch
 B="$R/bench.py --no-cpu-baseline --no-e2e"
