@@ -388,6 +388,14 @@ int64_t ogl_block_workspace_bytes_batched(const int64_t* dst_count, int nb, int 
 int ogl_build_block_batched(const int64_t* dst_base, const int64_t* dst_start, const int64_t* dst_count, int nb,
                             const int64_t* picks, int fanout, int64_t* src_ids, int64_t* n_src_out,
                             int32_t* local_idx, void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
+/* The same build when the caller knows an upper bound of the vertex ids (every id in dst / picks is < n_ids, e.g. the graph's
+ * vertex count; ids outside [0, n_ids) are treated like negative ones: no source row, local index -1): a direct-address table of
+ * n_ids entries per batch replaces the hash — one no-return atomicMin per position instead of atomicCAS + atomicMin + probing.
+ * Results are bit-identical to ogl_build_block_batched.  Workspace: 8 bytes x n_ids per batch of a 64-batch chunk. */
+int64_t ogl_block_workspace_bytes_batched_ids(const int64_t* dst_count, int nb, int fanout, int64_t n_ids);
+int ogl_build_block_batched_ids(const int64_t* dst_base, const int64_t* dst_start, const int64_t* dst_count, int nb,
+                                const int64_t* picks, int fanout, int64_t n_ids, int64_t* src_ids, int64_t* n_src_out,
+                                int32_t* local_idx, void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * nn.CrossEntropyLoss (R/train/graphsage/pytorch/model.py:20,105,147,198,244):

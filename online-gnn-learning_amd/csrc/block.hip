@@ -500,3 +500,149 @@ extern "C" int ogl_build_block_batched(const int64_t* dst_base, const int64_t* d
   }
   return OGL_OK;
 }
+
+// ---- the same build with a DIRECT-ADDRESS table (the caller knows that every id is < n_ids) --------------------------------
+// Per batch one int32 per vertex id instead of a 2 P-slot hash: tmin[id] = the smallest flat position at which the id appears.
+// One no-return atomicMin per position (the hash form needs an atomicCAS whose result it waits for, then the atomicMin, then
+// probes), no slot array, and the first-appearance tests of the count / assign passes gather from a table of n_ids entries
+// instead of 4 P.  Same first-appearance order, hence the same src_ids / local_idx bit for bit.  block_batch is reused with
+// T = n_ids (tkey / slot unused).
+__global__ void __launch_bounds__(256) k_block_fill_d(int4* __restrict__ t, int64_t n16) {
+  const int4 v = make_int4(0x7F7F7F7F, 0x7F7F7F7F, 0x7F7F7F7F, 0x7F7F7F7F);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) t[i] = v;
+}
+
+__device__ __forceinline__ int32_t direct_id(const int64_t* __restrict__ dst_base, const int64_t* __restrict__ picks, const block_batch& w,
+                                             int b, int64_t n_dst, int64_t p) {
+  const int64_t id = flat_id(dst_base + w.bd.dst_start[b], picks + w.bd.row_off[b] * w.fanout, n_dst, p);
+  return (id >= 0 && id < w.T) ? (int32_t)id : -1;
+}
+
+__global__ void __launch_bounds__(256) k_block_min_d(const int64_t* __restrict__ dst_base, const int64_t* __restrict__ picks, block_batch w) {
+  const int b = blockIdx.y;
+  const int64_t n_dst = w.bd.row_off[b + 1] - w.bd.row_off[b];
+  const int64_t P = n_dst * (1 + (int64_t)w.fanout);
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int32_t id = direct_id(dst_base, picks, w, b, n_dst, p);
+  if (id >= 0) atomicMin(&w.tmin[(int64_t)b * w.T + id], (int32_t)p);       // (result unused: a no-return atomic)
+}
+
+__device__ __forceinline__ int is_first_d(const int64_t* __restrict__ dst_base, const int64_t* __restrict__ picks, const block_batch& w,
+                                          int b, int64_t n_dst, int64_t P, int64_t p, int32_t* id_out) {
+  *id_out = -1;
+  if (p >= P) return 0;
+  const int32_t id = direct_id(dst_base, picks, w, b, n_dst, p);
+  *id_out = id;
+  if (p < n_dst) return 1;                                                  // every dst keeps its own source row
+  return (id >= 0 && w.tmin[(int64_t)b * w.T + id] == (int32_t)p) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(BLK_SCAN) k_block_count_d(const int64_t* __restrict__ dst_base, const int64_t* __restrict__ picks,
+                                                            block_batch w) {
+  const int b = blockIdx.y;
+  const int64_t n_dst = w.bd.row_off[b + 1] - w.bd.row_off[b];
+  const int64_t P = n_dst * (1 + (int64_t)w.fanout);
+  if ((int64_t)blockIdx.x * BLK_SCAN >= P) return;               // block-uniform
+  const int64_t p = (int64_t)blockIdx.x * BLK_SCAN + threadIdx.x;
+  int tot; int32_t id;
+  (void)block_scan_1024(is_first_d(dst_base, picks, w, b, n_dst, P, p, &id), &tot);
+  if (threadIdx.x == 0) w.bsum[(int64_t)b * (w.NBmax + 1) + blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(BLK_SCAN) k_block_assign_d(const int64_t* __restrict__ dst_base, const int64_t* __restrict__ picks,
+                                                             block_batch w, int64_t* __restrict__ src_ids) {
+  const int b = blockIdx.y;
+  const int64_t n_dst = w.bd.row_off[b + 1] - w.bd.row_off[b];
+  const int64_t P = n_dst * (1 + (int64_t)w.fanout);
+  if ((int64_t)blockIdx.x * BLK_SCAN >= P) return;               // block-uniform
+  const int64_t p = (int64_t)blockIdx.x * BLK_SCAN + threadIdx.x;
+  int32_t id;
+  const int f = is_first_d(dst_base, picks, w, b, n_dst, P, p, &id);
+  int tot;
+  const int pre = block_scan_1024(f, &tot);
+  if (f) {
+    const int32_t li = w.bsum[(int64_t)b * (w.NBmax + 1) + blockIdx.x] + pre;
+    src_ids[w.bd.row_off[b] * (1 + (int64_t)w.fanout) + li] =
+        flat_id(dst_base + w.bd.dst_start[b], picks + w.bd.row_off[b] * w.fanout, n_dst, p);
+    if (id >= 0 && w.tmin[(int64_t)b * w.T + id] == (int32_t)p) w.tlidx[(int64_t)b * w.T + id] = li;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_block_lookup_d(const int64_t* __restrict__ picks, block_batch w, int32_t* __restrict__ local_idx) {
+  const int b = blockIdx.y;
+  const int64_t n_dst = w.bd.row_off[b + 1] - w.bd.row_off[b];
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_dst * w.fanout) return;
+  const int64_t id = picks[w.bd.row_off[b] * w.fanout + e];
+  local_idx[w.bd.row_off[b] * w.fanout + e] = (id >= 0 && id < w.T) ? w.tlidx[(int64_t)b * w.T + id] : -1;
+}
+
+static int64_t batched_ws_bytes_ids(const int64_t* dst_count, int nb, int fanout, int64_t n_ids) {
+  int64_t worst = 16;
+  const int64_t Tn = ogl_round_up(n_ids, 4);
+  for (int b0 = 0; b0 < nb; b0 += OGL_MAX_BATCH) {
+    const int m = nb - b0 < OGL_MAX_BATCH ? nb - b0 : OGL_MAX_BATCH;
+    int64_t mx = 0;
+    for (int b = 0; b < m; ++b) mx = mx > dst_count[b0 + b] ? mx : dst_count[b0 + b];
+    const int64_t NBmax = ogl_cdiv(mx * (1 + (int64_t)fanout), BLK_SCAN);
+    const int64_t bytes = 4 * (2 * Tn * m + ogl_round_up((NBmax + 1) * m, 4));
+    worst = worst > bytes ? worst : bytes;
+  }
+  return worst;
+}
+
+extern "C" int64_t ogl_block_workspace_bytes_batched_ids(const int64_t* dst_count, int nb, int fanout, int64_t n_ids) {
+  if (nb < 0 || fanout < 0 || n_ids <= 0 || n_ids >= ((int64_t)1 << 31) || (nb > 0 && !dst_count)) return OGL_EINVAL;
+  for (int b = 0; b < nb; ++b) if (dst_count[b] < 0) return OGL_EINVAL;
+  return batched_ws_bytes_ids(dst_count, nb, fanout, n_ids);
+}
+
+extern "C" int ogl_build_block_batched_ids(const int64_t* dst_base, const int64_t* dst_start, const int64_t* dst_count, int nb,
+                                           const int64_t* picks, int fanout, int64_t n_ids, int64_t* src_ids, int64_t* n_src_out,
+                                           int32_t* local_idx, void* workspace, int64_t workspace_bytes, ogl_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (nb < 0 || fanout < 0 || n_ids <= 0 || n_ids >= ((int64_t)1 << 31)) return OGL_EINVAL;
+  if (nb == 0) return OGL_OK;
+  if (!dst_start || !dst_count || !n_src_out) return OGL_EINVAL;
+  for (int b = 0; b < nb; ++b) if (dst_count[b] < 0 || dst_start[b] < 0) return OGL_EINVAL;
+  if (!workspace || workspace_bytes < batched_ws_bytes_ids(dst_count, nb, fanout, n_ids)) return OGL_EWORKSPACE;
+  const int64_t Tn = ogl_round_up(n_ids, 4);
+  int64_t row = 0;
+  for (int b0 = 0; b0 < nb; b0 += OGL_MAX_BATCH) {
+    const int m = nb - b0 < OGL_MAX_BATCH ? nb - b0 : OGL_MAX_BATCH;
+    block_batch w;
+    int64_t mx = 0;
+    for (int b = 0; b < m; ++b) {
+      w.bd.dst_start[b] = dst_start[b0 + b]; w.bd.row_off[b] = row; w.bd.ctr[b] = 0;
+      row += dst_count[b0 + b];
+      mx = mx > dst_count[b0 + b] ? mx : dst_count[b0 + b];
+    }
+    w.bd.row_off[m] = row;
+    if (mx == 0) { OGL_CHECK_HIP(hipMemsetAsync(n_src_out + b0, 0, sizeof(int64_t) * m, stream)); continue; }
+    if (!dst_base || !src_ids || (fanout > 0 && (!picks || !local_idx))) return OGL_EINVAL;
+    const int64_t Pmax = mx * (1 + (int64_t)fanout);
+    if (Pmax >= ((int64_t)1 << 30)) return OGL_EINVAL;
+    w.fanout = fanout; w.T = Tn; w.NBmax = ogl_cdiv(Pmax, BLK_SCAN);
+    int32_t* base = (int32_t*)workspace;
+    w.tkey = nullptr; w.slot = nullptr; w.mask = 0; w.shift = 0;
+    w.tmin = base; w.tlidx = base + Tn * m; w.bsum = base + 2 * Tn * m;
+    const int64_t n16 = Tn * m / 4;
+    hipLaunchKernelGGL(k_block_fill_d, dim3((unsigned)std::min<int64_t>(ogl_cdiv(n16, 256), 4096)), dim3(256), 0, stream, (int4*)w.tmin, n16);
+    OGL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_block_min_d, dim3((unsigned)ogl_cdiv(Pmax, 256), (unsigned)m), dim3(256), 0, stream, dst_base, picks, w);
+    OGL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_block_count_d, dim3((unsigned)w.NBmax, (unsigned)m), dim3(BLK_SCAN), 0, stream, dst_base, picks, w);
+    OGL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_block_scan_sums_b, dim3((unsigned)m), dim3(BLK_SCAN), 0, stream, w, n_src_out + b0);
+    OGL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_block_assign_d, dim3((unsigned)w.NBmax, (unsigned)m), dim3(BLK_SCAN), 0, stream, dst_base, picks, w, src_ids);
+    OGL_CHECK_LAUNCH();
+    if (fanout > 0) {
+      hipLaunchKernelGGL(k_block_lookup_d, dim3((unsigned)ogl_cdiv(mx * fanout, 256), (unsigned)m), dim3(256), 0, stream, picks, w, local_idx);
+      OGL_CHECK_LAUNCH();
+    }
+  }
+  return OGL_OK;
+}
+

@@ -196,7 +196,8 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         local = [b[slice(*parallel.shard_range(b.numel(), rank, world))] for b in full]
         live = [i for i, b in enumerate(local) if b.numel() > 0]
         ctrs = sampling.reserve_ctrs(len(full))           # every batch of the one-rank loader, also those empty here
-        out = iter(self._sampler().sample_batches(graph, [local[i] for i in live], ctrs=[ctrs[i] for i in live]))
+        # (a generator: the first batches as soon as they are sampled, the rest sampled on a second stream while those train)
+        out = self._sampler().sample_batches_stream(graph, [local[i] for i in live], ctrs=[ctrs[i] for i in live])
         for i, b in enumerate(full):
             if local[i].numel() > 0:
                 input_nodes, sd, blocks = next(out)

@@ -294,9 +294,16 @@ def sample_layer_batched(g: GraphHandle, dst_base: torch.Tensor, starts, counts,
     return picks
 
 
-def build_block_batched_async(dst_base: torch.Tensor, starts, counts, picks: torch.Tensor):
+# the batched block build on a direct-address table (one int32 pair per vertex id and batch) instead of the hash when the caller passes
+# the id bound and the tables of a 64-batch chunk stay below this many bytes (OGL_BLOCK_DIRECT=0: always the hash)
+BLOCK_DIRECT = os.environ.get("OGL_BLOCK_DIRECT", "1") != "0"
+BLOCK_DIRECT_MAX_BYTES = 2 << 30
+
+
+def build_block_batched_async(dst_base: torch.Tensor, starts, counts, picks: torch.Tensor, n_ids=None):
     """Relabel every batch in one set of launches.  Returns (src_ids packed at row_off * (1 + fanout), n_src_dev [nb],
-    local_idx packed like picks) without synchronising; row_off = running sum of counts."""
+    local_idx packed like picks) without synchronising; row_off = running sum of counts.  ``n_ids``: every id is < n_ids (the
+    graph's vertex count) — the build then uses a direct-address table (ogl_build_block_batched_ids: same results)."""
     dst_base = _ids(dst_base)
     nb, total = len(counts), int(sum(counts))
     fanout = picks.shape[1]
@@ -306,6 +313,13 @@ def build_block_batched_async(dst_base: torch.Tensor, starts, counts, picks: tor
     n_src = torch.zeros(max(nb, 1), dtype=torch.int64, device=dev)
     local_idx = torch.empty((total, fanout), dtype=torch.int32, device=dev)
     h_counts = _host_i64(counts)
+    if BLOCK_DIRECT and n_ids and 0 < int(n_ids) < 2 ** 31 and 8 * int(n_ids) * min(nb, 64) <= BLOCK_DIRECT_MAX_BYTES:
+        nbytes = int(_lib.lib().ogl_block_workspace_bytes_batched_ids(h_counts, nb, int(fanout), int(n_ids)))
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        _launch("ogl_build_block_batched", _lib.lib().ogl_build_block_batched_ids, _ptr(dst_base), _host_i64(starts), h_counts, nb, _ptr(picks),
+                int(fanout), int(n_ids), _ptr(src_ids), _ptr(n_src), _ptr(local_idx), _ptr(ws), nbytes, _stream(),
+                meta=dict(n_dst=total, fanout=int(fanout), nb=nb, direct=1))
+        return src_ids, n_src, local_idx
     nbytes = int(_lib.lib().ogl_block_workspace_bytes_batched(h_counts, nb, int(fanout)))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
     _launch("ogl_build_block_batched", _lib.lib().ogl_build_block_batched, _ptr(dst_base), _host_i64(starts), h_counts, nb, _ptr(picks),

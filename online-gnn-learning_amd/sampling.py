@@ -31,6 +31,13 @@ from . import ops
 # own rows) — the layer below then stores fp32 only there (OGL_FUSED_KEEP_ROWS=0: every row, as before)
 FUSED_KEEP_ROWS = os.environ.get("OGL_FUSED_KEEP_ROWS", "1") != "0"
 
+# A training loader hands out its first PIPELINE_FIRST batches as soon as they are sampled and samples the rest on a second stream
+# while those train (what the reference's ``num_workers`` does with forked CPU samplers): the blocks are the same — every batch
+# is sampled with its own Philox counter either way.  OGL_SAMPLE_PIPELINE=0: the whole loader up front, on the caller's stream.
+PIPELINE = os.environ.get("OGL_SAMPLE_PIPELINE", "1") != "0"
+PIPELINE_FIRST = int(os.environ.get("OGL_SAMPLE_PIPELINE_FIRST", "4"))
+_PIPE = {"stream": None}
+
 NID = "_ID"   # same key DGL uses for block.srcdata[dgl.NID]
 EID = "_EID"
 
@@ -151,6 +158,14 @@ class MultiLayerNeighborSampler:
         assert len(ctrs) == nb
         if nb == 0:
             return []
+        if relabel_input:
+            job = self._job(graph, seed_batches, ctrs)
+            try:
+                sizes = next(job)
+                while True:
+                    sizes = job.send(sizes.cpu().tolist())            # the one sync of this layer
+            except StopIteration as done:
+                return done.value
         blocks = [[None] * L for _ in seed_batches]
         # every batch of a layer goes through ONE sampler launch and ONE block-build sequence (batched C-ABI entry points):
         # batch b's destinations are dst_base[starts[b] : starts[b] + counts[b]]
@@ -172,7 +187,7 @@ class MultiLayerNeighborSampler:
                 for bi in range(nb):
                     blocks[bi][layer] = Block(None, dsts[bi], None, picks_all[rows[bi]:rows[bi] + counts[bi]])
                 return [(None, seeds, blk) for seeds, blk in zip(seed_batches, blocks)]
-            src_all, n_src, lidx_all = ops.build_block_batched_async(dst_base, starts, counts, picks_all)
+            src_all, n_src, lidx_all = ops.build_block_batched_async(dst_base, starts, counts, picks_all, n_ids=g.n)
             n_next = n_src[:nb].cpu().tolist()                            # the one sync of this layer
             nstarts = []
             for bi in range(nb):
@@ -182,7 +197,105 @@ class MultiLayerNeighborSampler:
                 blocks[bi][layer] = Block(src, dsts[bi], lidx_all[r0:r0 + c], picks_all[r0:r0 + c])
                 nstarts.append(s0)
             dst_base, starts, counts = src_all, nstarts, n_next
+        raise AssertionError("unreachable: a loader that relabels its input layer goes through _job")
+
+    def _job(self, graph, seed_batches, ctrs):
+        """The relabelled loader as a resumable job: launches one layer (sampler + block build, batched over every batch), YIELDS the
+        device tensor of that layer's block sizes and is sent their host copy — the caller decides how to wait (``sample_batches``:
+        on the spot; ``sample_batches_stream``: on a second stream, between train steps).  Returns the loader's list."""
+        g = graph.handle
+        L = len(self.fanouts)
+        nb = len(seed_batches)
+        blocks = [[None] * L for _ in seed_batches]
+        counts = [int(t.numel()) for t in seed_batches]
+        dst_base = seed_batches[0] if nb == 1 else torch.cat([t.reshape(-1) for t in seed_batches])
+        starts, acc = [], 0
+        for c in counts:
+            starts.append(acc); acc += c
+        for layer in reversed(range(L)):
+            S = self.fanouts[layer]
+            picks_all = ops.sample_layer_batched(g, dst_base, starts, counts, S, _STATE["seed"], ctrs, layer)
+            rows, acc = [], 0
+            for c in counts:
+                rows.append(acc); acc += c
+            dsts = [dst_base[s:s + c] for s, c in zip(starts, counts)]
+            src_all, n_src, lidx_all = ops.build_block_batched_async(dst_base, starts, counts, picks_all, n_ids=g.n)
+            n_next = yield n_src[:nb]
+            nstarts = []
+            for bi in range(nb):
+                r0, c = rows[bi], counts[bi]
+                s0 = r0 * (1 + S)
+                src = src_all[s0:s0 + n_next[bi]]
+                blocks[bi][layer] = Block(src, dsts[bi], lidx_all[r0:r0 + c], picks_all[r0:r0 + c])
+                nstarts.append(s0)
+            dst_base, starts, counts = src_all, nstarts, n_next
         return [(blk[0].src_ids, seeds, blk) for seeds, blk in zip(seed_batches, blocks)]
+
+    def sample_batches_stream(self, graph, seed_batches, ctrs=None, first=None):
+        """``sample_batches`` as a generator that starts yielding after the first ``first`` batches are sampled; the rest is sampled
+        on a second HIP stream while the consumer trains on those (module header: PIPELINE).  Same blocks, same counters."""
+        nb = len(seed_batches)
+        if ctrs is None:
+            ctrs = reserve_ctrs(nb)
+        first = PIPELINE_FIRST if first is None else int(first)
+        dev = seed_batches[0].device if nb else None
+        if not PIPELINE or first <= 0 or nb < 2 * first or dev is None or dev.type != "cuda" or ops._PROFILE is not None:
+            yield from self.sample_batches(graph, seed_batches, ctrs=ctrs)
+            return
+        head = self.sample_batches(graph, seed_batches[:first], ctrs=ctrs[:first])
+        rest = _StreamJob(self._job(graph, seed_batches[first:], ctrs[first:]), dev)
+        for item in head:
+            yield item
+            rest.poll()                      # (between two train steps: never inside a graph capture)
+        yield from rest.finish()
+
+
+class _StreamJob:
+    """Drives a sampler job (``MultiLayerNeighborSampler._job``) on the sampling stream: its launches are enqueued there, the block
+    sizes come back through pinned memory + an event the host polls between train steps and waits for only when it has run out of
+    sampled batches.  The consumer's stream waits for the job's last event before the first of its batches is handed out; the
+    tensors are marked as used by that stream (the caching allocator must not recycle them for the sampling stream while queued
+    train steps still read them)."""
+
+    def __init__(self, job, device):
+        if _PIPE["stream"] is None:
+            _PIPE["stream"] = torch.cuda.Stream(device=device)
+        self.side = _PIPE["stream"]
+        self.main = torch.cuda.current_stream(device)
+        self.job, self.out, self.pending = job, None, None
+        self.side.wait_stream(self.main)     # the seeds' upload, the previous loader's last reads of recycled memory
+        self._advance(None)
+
+    def _advance(self, value):
+        with torch.cuda.stream(self.side):
+            try:
+                sizes = next(self.job) if value is None else self.job.send(value)
+            except StopIteration as done:
+                self.out, self.pending = done.value, None
+                self.done_event = torch.cuda.Event()
+                self.done_event.record(self.side)
+                return
+            host = torch.empty(sizes.shape, dtype=sizes.dtype, pin_memory=True)
+            host.copy_(sizes, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.pending = (host, ev)
+
+    def poll(self):
+        if self.pending is not None and self.pending[1].query():
+            self._advance(self.pending[0].tolist())
+
+    def finish(self):
+        while self.pending is not None:
+            self.pending[1].synchronize()
+            self._advance(self.pending[0].tolist())
+        self.main.wait_event(self.done_event)
+        for _, seeds, blocks in self.out:
+            for blk in blocks:
+                for t in (blk.src_ids, blk.dst_ids, blk.local_idx, blk.picks):
+                    if t is not None and t.is_cuda:
+                        t.record_stream(self.main)
+        return self.out
 
 
     @staticmethod
@@ -257,4 +370,6 @@ class NodeDataLoader:
         n, bs = nids.numel(), self.batch_size
         stops = list(range(0, n, bs))
         batches = [nids[s:s + bs] for s in stops if not (self.drop_last and s + bs > n)]
-        return iter(self.sampler.sample_batches(self.graph, batches, relabel_input=self.relabel_input))
+        if self.relabel_input:
+            return self.sampler.sample_batches_stream(self.graph, batches)
+        return iter(self.sampler.sample_batches(self.graph, batches, relabel_input=False))

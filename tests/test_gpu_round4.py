@@ -404,3 +404,84 @@ def test_adam_scalars_ride_in_the_weight_image_launch():
         assert torch.equal(res[False][0], res[True][0]) and res[False][1] == res[True][1] == 4
     finally:
         ops.set_gemm_mode("f32")
+
+
+def test_pipelined_loader_hands_out_the_same_blocks():
+    """sampling.sample_batches_stream (the first batches at once, the rest sampled on a second stream while the consumer works):
+    the same (input_nodes, seeds, blocks) as the up-front loader, bit for bit, whatever the consumer does between two batches —
+    here it keeps the main stream busy with launches that recycle memory, and reads every block after the generator is done."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import sampling, synthetic
+    _, _, dyn, _, _ = synthetic.load("reddit", snapshots=2, device="cuda", scale=0.12)
+    dyn.evolve()
+    g = dyn.get_graph()
+    smp = sampling.MultiLayerNeighborSampler([25, 25], replace=True, return_eids=True)
+    rng = np.random.default_rng(3)
+    seeds = torch.as_tensor(rng.choice(g.n_present, 13 * 200 + 57, replace=False).astype(np.int64)).cuda()
+    batches = [seeds[s:s + 200] for s in range(0, seeds.numel(), 200)]             # 14 batches, the last one ragged
+    sampling.seed(21)
+    ref = smp.sample_batches(g, batches)
+    state = sampling.get_state()
+    for first in (1, 3, 6):
+        sampling.seed(21)
+        got = []
+        for item in smp.sample_batches_stream(g, batches, first=first):
+            got.append(item)
+            junk = [torch.randn(1 << 20, device="cuda") for _ in range(3)]          # main-stream work + allocator churn between batches
+            del junk
+        assert sampling.get_state() == state
+        torch.cuda.synchronize()
+        assert len(got) == len(ref)
+        for (i0, s0, b0), (i1, s1, b1) in zip(ref, got):
+            assert torch.equal(i0, i1) and torch.equal(s0, s1)
+            for x, y in zip(b0, b1):
+                assert torch.equal(x.src_ids, y.src_ids) and torch.equal(x.dst_ids, y.dst_ids)
+                assert torch.equal(x.local_idx, y.local_idx) and torch.equal(x.picks, y.picks)
+    # the switch: the whole loader up front on the caller's stream
+    old = sampling.PIPELINE
+    sampling.PIPELINE = False
+    try:
+        sampling.seed(21)
+        got = list(smp.sample_batches_stream(g, batches))
+        assert all(torch.equal(a[0], b[0]) for a, b in zip(ref, got))
+    finally:
+        sampling.PIPELINE = old
+
+
+@pytest.mark.parametrize("fanout", [25, 5])
+def test_direct_address_block_build_equals_the_hash_build(fanout):
+    """ogl_build_block_batched_ids (a table of n_ids entries per batch, one no-return atomicMin per position) returns what the hash
+    build returns, bit for bit: ragged batches, an empty batch, duplicated picks, missing neighbours (-1) and ids at both ends of
+    the range; and more than one 64-batch chunk."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    rng = np.random.default_rng(fanout)
+    n_ids = 50_000
+    counts = [int(c) for c in rng.integers(1, 900, size=70)]
+    counts[3] = 0
+    counts[10] = 4000
+    starts, dst_parts, acc = [], [], 0
+    for c in counts:
+        starts.append(acc); acc += c
+        dst_parts.append(rng.choice(n_ids, c, replace=False))
+    dst_base = torch.as_tensor(np.concatenate(dst_parts).astype(np.int64)).cuda()
+    picks = rng.integers(0, n_ids, size=(acc, fanout))
+    picks[rng.random(picks.shape) < 0.05] = -1
+    picks[rng.random(picks.shape) < 0.3] = rng.integers(0, 50)                 # hubs: heavy duplication
+    picks[0, 0], picks[1, 0] = 0, n_ids - 1
+    picks = torch.as_tensor(picks.astype(np.int64)).cuda()
+    old = ops.BLOCK_DIRECT
+    try:
+        ops.BLOCK_DIRECT = False
+        s0, n0, l0 = ops.build_block_batched_async(dst_base, starts, counts, picks, n_ids=n_ids)
+        ops.BLOCK_DIRECT = True
+        s1, n1, l1 = ops.build_block_batched_async(dst_base, starts, counts, picks, n_ids=n_ids)
+    finally:
+        ops.BLOCK_DIRECT = old
+    torch.cuda.synchronize()
+    assert torch.equal(n0, n1) and torch.equal(l0, l1)
+    row = 0
+    for b, c in enumerate(counts):                                             # (src_ids beyond a batch's n_src is scratch)
+        o = row * (1 + fanout)
+        assert torch.equal(s0[o:o + int(n0[b])], s1[o:o + int(n1[b])]), b
+        row += c
