@@ -31,10 +31,14 @@ from . import ops
 # own rows) — the layer below then stores fp32 only there (OGL_FUSED_KEEP_ROWS=0: every row, as before)
 FUSED_KEEP_ROWS = os.environ.get("OGL_FUSED_KEEP_ROWS", "1") != "0"
 
-# A training loader hands out its first PIPELINE_FIRST batches as soon as they are sampled and samples the rest on a second stream
-# while those train (what the reference's ``num_workers`` does with forked CPU samplers): the blocks are the same — every batch
-# is sampled with its own Philox counter either way.  OGL_SAMPLE_PIPELINE=0: the whole loader up front, on the caller's stream.
-PIPELINE = os.environ.get("OGL_SAMPLE_PIPELINE", "1") != "0"
+# OGL_SAMPLE_PIPELINE=1: a training loader hands out its first PIPELINE_FIRST batches as soon as they are sampled and samples the rest
+# on a second stream while those train (what the reference's ``num_workers`` does with forked CPU samplers); the blocks are the
+# same — every batch is sampled with its own Philox counter either way.  OFF by default — measured (round 4, Reddit rung, same box,
+# 4 alternations): with the hash block build 1.007 -> 0.997 ms per step over 50-batch loaders but 1.008 -> 1.010 (outliers to 1.11) on the
+# driver's 20-step command; with the direct-address build (1.3 -> 0.5 ms of sampling + build per 50 batches) 0.9850 vs 0.9855 and 0.9843
+# vs 0.9857 (one outlier at 1.006): the sampling kernels take the CUs they run on away from the train step — every GEMM block owns a CU
+# — so what the overlap hides it costs again.  A low-priority sampling stream starves (1.23 ms per step: the host waits for it).
+PIPELINE = os.environ.get("OGL_SAMPLE_PIPELINE", "0") == "1"
 PIPELINE_FIRST = int(os.environ.get("OGL_SAMPLE_PIPELINE_FIRST", "4"))
 _PIPE = {"stream": None}
 
@@ -260,9 +264,10 @@ class _StreamJob:
     def __init__(self, job, device):
         if _PIPE["stream"] is None:
             _PIPE["stream"] = torch.cuda.Stream(device=device)
+            _PIPE["pinned"] = torch.empty(8192, dtype=torch.int64, pin_memory=True)
         self.side = _PIPE["stream"]
         self.main = torch.cuda.current_stream(device)
-        self.job, self.out, self.pending = job, None, None
+        self.job, self.out, self.pending, self.stage = job, None, None, 0
         self.side.wait_stream(self.main)     # the seeds' upload, the previous loader's last reads of recycled memory
         self._advance(None)
 
@@ -275,7 +280,14 @@ class _StreamJob:
                 self.done_event = torch.cuda.Event()
                 self.done_event.record(self.side)
                 return
-            host = torch.empty(sizes.shape, dtype=sizes.dtype, pin_memory=True)
+            # (a slice of ONE pinned buffer allocated with the stream: a fresh pinned allocation per stage is a hipHostMalloc whenever
+            # the loader's length changes — a fraction of a millisecond, inside the first train steps of the loader)
+            n, cap = sizes.numel(), _PIPE["pinned"].numel()
+            if (self.stage + 1) * n <= cap:
+                host = _PIPE["pinned"][self.stage * n:(self.stage + 1) * n]
+            else:
+                host = torch.empty(sizes.shape, dtype=sizes.dtype, pin_memory=True)
+            self.stage += 1
             host.copy_(sizes, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.side)

@@ -422,25 +422,28 @@ def test_pipelined_loader_hands_out_the_same_blocks():
     sampling.seed(21)
     ref = smp.sample_batches(g, batches)
     state = sampling.get_state()
-    for first in (1, 3, 6):
-        sampling.seed(21)
-        got = []
-        for item in smp.sample_batches_stream(g, batches, first=first):
-            got.append(item)
-            junk = [torch.randn(1 << 20, device="cuda") for _ in range(3)]          # main-stream work + allocator churn between batches
-            del junk
-        assert sampling.get_state() == state
-        torch.cuda.synchronize()
-        assert len(got) == len(ref)
-        for (i0, s0, b0), (i1, s1, b1) in zip(ref, got):
-            assert torch.equal(i0, i1) and torch.equal(s0, s1)
-            for x, y in zip(b0, b1):
-                assert torch.equal(x.src_ids, y.src_ids) and torch.equal(x.dst_ids, y.dst_ids)
-                assert torch.equal(x.local_idx, y.local_idx) and torch.equal(x.picks, y.picks)
-    # the switch: the whole loader up front on the caller's stream
     old = sampling.PIPELINE
-    sampling.PIPELINE = False
     try:
+        sampling.PIPELINE = True                      # (off by default: measured neutral, sampling.py)
+        for first in (1, 3, 6):
+            sampling.seed(21)
+            got, jobs = [], 0
+            gen = smp.sample_batches_stream(g, batches, first=first)
+            for item in gen:
+                got.append(item)
+                junk = [torch.randn(1 << 20, device="cuda") for _ in range(3)]      # main-stream work + allocator churn between batches
+                del junk
+            assert sampling.get_state() == state
+            assert sampling._PIPE["stream"] is not None                             # the second stream was really used
+            torch.cuda.synchronize()
+            assert len(got) == len(ref)
+            for (i0, s0, b0), (i1, s1, b1) in zip(ref, got):
+                assert torch.equal(i0, i1) and torch.equal(s0, s1)
+                for x, y in zip(b0, b1):
+                    assert torch.equal(x.src_ids, y.src_ids) and torch.equal(x.dst_ids, y.dst_ids)
+                    assert torch.equal(x.local_idx, y.local_idx) and torch.equal(x.picks, y.picks)
+        # the default: the whole loader up front on the caller's stream
+        sampling.PIPELINE = False
         sampling.seed(21)
         got = list(smp.sample_batches_stream(g, batches))
         assert all(torch.equal(a[0], b[0]) for a, b in zip(ref, got))
