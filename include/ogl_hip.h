@@ -390,8 +390,12 @@ int ogl_build_block_batched(const int64_t* dst_base, const int64_t* dst_start, c
                             int32_t* local_idx, void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
 /* The same build when the caller knows an upper bound of the vertex ids (every id in dst / picks is < n_ids, e.g. the graph's
  * vertex count; ids outside [0, n_ids) are treated like negative ones: no source row, local index -1): a direct-address table of
- * n_ids entries per batch replaces the hash — one no-return atomicMin per position instead of atomicCAS + atomicMin + probing.
+ * n_ids entries per batch replaces the hash — per position one LDS atomic (id range cut into LDS-sized pieces, n_ids <= 589 824) or one
+ * no-return global atomicMin, instead of atomicCAS + atomicMin + probing.
  * Results are bit-identical to ogl_build_block_batched.  Workspace: 8 bytes x n_ids per batch of a 64-batch chunk. */
+/* diagnostic: 0 = the per-id minima of ogl_build_block_batched_ids through global atomics even where its LDS form applies (n_ids <=
+ * 16 x 36 864: a workgroup per (batch, id range) keeps its range's minima in LDS — no global atomics); returns the old value. */
+int ogl_block_debug_min_lds(int on);
 int64_t ogl_block_workspace_bytes_batched_ids(const int64_t* dst_count, int nb, int fanout, int64_t n_ids);
 int ogl_build_block_batched_ids(const int64_t* dst_base, const int64_t* dst_start, const int64_t* dst_count, int nb,
                                 const int64_t* picks, int fanout, int64_t n_ids, int64_t* src_ids, int64_t* n_src_out,

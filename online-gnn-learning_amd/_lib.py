@@ -59,6 +59,7 @@ SIGNATURES = {
     "ogl_sample_layer_batched": (_i, [_p, _p, _p, _p, _i, _i, _u64, _p, _i, _p, _p]),
     "ogl_block_workspace_bytes_batched": (_i64, [_p, _i, _i]),
     "ogl_build_block_batched": (_i, [_p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _i64, _p]),
+    "ogl_block_debug_min_lds": (_i, [_i]),
     "ogl_block_workspace_bytes_batched_ids": (_i64, [_p, _i, _i, _i64]),
     "ogl_build_block_batched_ids": (_i, [_p, _p, _p, _i, _p, _i, _i64, _p, _p, _p, _p, _i64, _p]),
     "ogl_pool_bwd_x3_workspace_bytes": (_i64, [_i64, _i, _i, _i64]),

@@ -525,7 +525,51 @@ __global__ void __launch_bounds__(256) k_block_min_d(const int64_t* __restrict__
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   const int32_t id = direct_id(dst_base, picks, w, b, n_dst, p);
+  // (a plain load in front — "skip the atomic when an earlier position already recorded a smaller one", two thirds of the positions —
+  // makes the launch SLOWER: 0.41 -> 0.9-1.0 ms for 9.2 M positions, whether the load is plain, volatile or non-temporal: loads
+  // and atomics to the same lines serialise in L2.  The launch runs at the part's random-atomic rate, ~22 G/s.)
   if (id >= 0) atomicMin(&w.tmin[(int64_t)b * w.T + id], (int32_t)p);       // (result unused: a no-return atomic)
+}
+
+// The same minima WITHOUT global atomics: the id range is cut into R pieces of RL ids that fit LDS; workgroup (batch, piece) streams
+// ALL positions of its batch and keeps the minima of the ids in its piece in LDS (ds_min), then stores its piece of tmin — which
+// also makes the fill launch unnecessary.  Global atomics execute at the memory side at ~22 G requests/s whatever their form
+// (MI355X_MICROARCH.md, Global float atomics: the same holds for integer ones here): 9.2 M of them are 0.41 ms; R re-reads of
+// the ids (8 pieces of a batch share an XCD under round-robin placement — speed only — so its L2 serves 7 of them) are ~0.06 ms.
+#define BLK_LDS_MAX_ENTRIES 36864          // 144 KB of LDS
+#define BLK_LDS_MAX_PIECES 16
+__global__ void __launch_bounds__(1024) k_block_min_lds(const int64_t* __restrict__ dst_base, const int64_t* __restrict__ picks, block_batch w,
+                                                        int m, int R, int RL) {
+  extern __shared__ int32_t tab[];
+  const int L = blockIdx.x;
+  const int q = L >> 3;
+  const int r = q % R;
+  const int b = (q / R) * 8 + (L & 7);
+  if (b >= m) return;                                            // block-uniform
+  const int64_t n_dst = w.bd.row_off[b + 1] - w.bd.row_off[b];
+  const int64_t P = n_dst * (1 + (int64_t)w.fanout);
+  const int64_t lo = (int64_t)r * RL;
+  const int len = (int)(lo + RL <= w.T ? RL : (w.T > lo ? w.T - lo : 0));
+  for (int i = threadIdx.x; i < len; i += 1024) tab[i] = 0x7F7F7F7F;
+  __syncthreads();
+  const int64_t* dst = dst_base + w.bd.dst_start[b];
+  const int64_t* pk = picks + w.bd.row_off[b] * w.fanout;
+  for (int64_t p0 = 0; p0 < P; p0 += 4 * 1024) {
+    int64_t id[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t p = p0 + u * 1024 + threadIdx.x;
+      id[u] = p < P ? flat_id(dst, pk, n_dst, p) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t k = id[u] - lo;
+      if (k >= 0 && k < len) atomicMin(&tab[k], (int32_t)(p0 + u * 1024 + threadIdx.x));
+    }
+  }
+  __syncthreads();
+  int32_t* out = w.tmin + (int64_t)b * w.T + lo;
+  for (int i = threadIdx.x; i < len; i += 1024) out[i] = tab[i];
 }
 
 __device__ __forceinline__ int is_first_d(const int64_t* __restrict__ dst_base, const int64_t* __restrict__ picks, const block_batch& w,
@@ -578,6 +622,10 @@ __global__ void __launch_bounds__(256) k_block_lookup_d(const int64_t* __restric
   local_idx[w.bd.row_off[b] * w.fanout + e] = (id >= 0 && id < w.T) ? w.tlidx[(int64_t)b * w.T + id] : -1;
 }
 
+// (diagnostic switch: 0 = the minima through global atomics even where the LDS form applies — tests compare the two)
+static int g_block_min_lds = 1;
+extern "C" int ogl_block_debug_min_lds(int on) { const int old = g_block_min_lds; g_block_min_lds = on ? 1 : 0; return old; }
+
 static int64_t batched_ws_bytes_ids(const int64_t* dst_count, int nb, int fanout, int64_t n_ids) {
   int64_t worst = 16;
   const int64_t Tn = ogl_round_up(n_ids, 4);
@@ -627,11 +675,23 @@ extern "C" int ogl_build_block_batched_ids(const int64_t* dst_base, const int64_
     int32_t* base = (int32_t*)workspace;
     w.tkey = nullptr; w.slot = nullptr; w.mask = 0; w.shift = 0;
     w.tmin = base; w.tlidx = base + Tn * m; w.bsum = base + 2 * Tn * m;
-    const int64_t n16 = Tn * m / 4;
-    hipLaunchKernelGGL(k_block_fill_d, dim3((unsigned)std::min<int64_t>(ogl_cdiv(n16, 256), 4096)), dim3(256), 0, stream, (int4*)w.tmin, n16);
-    OGL_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_block_min_d, dim3((unsigned)ogl_cdiv(Pmax, 256), (unsigned)m), dim3(256), 0, stream, dst_base, picks, w);
-    OGL_CHECK_LAUNCH();
+    const int R = (int)ogl_cdiv(Tn, BLK_LDS_MAX_ENTRIES);
+    if (R <= BLK_LDS_MAX_PIECES && g_block_min_lds) {
+      const int RL = (int)ogl_round_up(ogl_cdiv(Tn, R), 4);
+      static bool attr_set = false;
+      if (!attr_set) {
+        OGL_CHECK_HIP(hipFuncSetAttribute((const void*)k_block_min_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(k_block_min_lds, dim3((unsigned)(8 * ogl_cdiv(m, 8) * R)), dim3(1024), (size_t)RL * 4, stream, dst_base, picks, w, m, R, RL);
+      OGL_CHECK_LAUNCH();
+    } else {
+      const int64_t n16 = Tn * m / 4;
+      hipLaunchKernelGGL(k_block_fill_d, dim3((unsigned)std::min<int64_t>(ogl_cdiv(n16, 256), 4096)), dim3(256), 0, stream, (int4*)w.tmin, n16);
+      OGL_CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_block_min_d, dim3((unsigned)ogl_cdiv(Pmax, 256), (unsigned)m), dim3(256), 0, stream, dst_base, picks, w);
+      OGL_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(k_block_count_d, dim3((unsigned)w.NBmax, (unsigned)m), dim3(BLK_SCAN), 0, stream, dst_base, picks, w);
     OGL_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_block_scan_sums_b, dim3((unsigned)m), dim3(BLK_SCAN), 0, stream, w, n_src_out + b0);

@@ -310,7 +310,8 @@ def build_block_batched_async(dst_base: torch.Tensor, starts, counts, picks: tor
     assert picks.shape[0] == total and picks.dtype == torch.int64 and picks.is_contiguous()
     dev = dst_base.device
     src_ids = torch.empty(max(total * (1 + fanout), 1), dtype=torch.int64, device=dev)
-    n_src = torch.zeros(max(nb, 1), dtype=torch.int64, device=dev)
+    # (every batch's entry is written by the build — its scan launch, or the memset of an all-empty chunk: no fill launch here)
+    n_src = torch.empty(nb, dtype=torch.int64, device=dev) if nb > 0 else torch.zeros(1, dtype=torch.int64, device=dev)
     local_idx = torch.empty((total, fanout), dtype=torch.int32, device=dev)
     h_counts = _host_i64(counts)
     if BLOCK_DIRECT and n_ids and 0 < int(n_ids) < 2 ** 31 and 8 * int(n_ids) * min(nb, 64) <= BLOCK_DIRECT_MAX_BYTES:

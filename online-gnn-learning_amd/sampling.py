@@ -210,30 +210,25 @@ class MultiLayerNeighborSampler:
         g = graph.handle
         L = len(self.fanouts)
         nb = len(seed_batches)
-        blocks = [[None] * L for _ in seed_batches]
         counts = [int(t.numel()) for t in seed_batches]
-        dst_base = seed_batches[0] if nb == 1 else torch.cat([t.reshape(-1) for t in seed_batches])
+        dst_base = _packed(seed_batches, counts)
         starts, acc = [], 0
         for c in counts:
             starts.append(acc); acc += c
+        layers = [None] * L
         for layer in reversed(range(L)):
             S = self.fanouts[layer]
             picks_all = ops.sample_layer_batched(g, dst_base, starts, counts, S, _STATE["seed"], ctrs, layer)
+            src_all, n_src, lidx_all = ops.build_block_batched_async(dst_base, starts, counts, picks_all, n_ids=g.n)
+            n_next = yield n_src[:nb]
+            # (only what the NEXT layer's launches need is computed here; the per-batch Block objects — four tensor views each —
+            # are made when a batch is handed out: the host's share of a 50-batch loader left the GPU idle for ~0.2 ms per layer)
             rows, acc = [], 0
             for c in counts:
                 rows.append(acc); acc += c
-            dsts = [dst_base[s:s + c] for s, c in zip(starts, counts)]
-            src_all, n_src, lidx_all = ops.build_block_batched_async(dst_base, starts, counts, picks_all, n_ids=g.n)
-            n_next = yield n_src[:nb]
-            nstarts = []
-            for bi in range(nb):
-                r0, c = rows[bi], counts[bi]
-                s0 = r0 * (1 + S)
-                src = src_all[s0:s0 + n_next[bi]]
-                blocks[bi][layer] = Block(src, dsts[bi], lidx_all[r0:r0 + c], picks_all[r0:r0 + c])
-                nstarts.append(s0)
-            dst_base, starts, counts = src_all, nstarts, n_next
-        return [(blk[0].src_ids, seeds, blk) for seeds, blk in zip(seed_batches, blocks)]
+            layers[layer] = (S, dst_base, starts, counts, rows, src_all, lidx_all, picks_all, n_next)
+            dst_base, starts, counts = src_all, [r * (1 + S) for r in rows], n_next
+        return _LazyBatches(seed_batches, layers)
 
     def sample_batches_stream(self, graph, seed_batches, ctrs=None, first=None):
         """``sample_batches`` as a generator that starts yielding after the first ``first`` batches are sampled; the rest is sampled
@@ -252,6 +247,97 @@ class MultiLayerNeighborSampler:
             yield item
             rest.poll()                      # (between two train steps: never inside a graph capture)
         yield from rest.finish()
+
+
+    @staticmethod
+    def _fused(seed_batches, blocks, dsts, rows, counts, picks_all, fuse_rows):
+        """Chunks of consecutive batches as one (input block, output block) pair each — see ``sample_batches``.  rows / counts:
+        where batch b's hidden-layer rows sit in the packed layer-0 arrays (they are consecutive); the output blocks' index
+        arrays are consecutive row ranges of one packed array too (the seeds are)."""
+        nb = len(seed_batches)
+        out = []
+        b0 = 0
+        while b0 < nb:
+            b1, acc = b0, 0
+            while b1 < nb and b1 - b0 < 64 and (b1 == b0 or acc + counts[b1] <= fuse_rows):
+                acc += counts[b1]; b1 += 1
+            r0, r1 = rows[b0], rows[b1 - 1] + counts[b1 - 1]
+            dev = picks_all.device
+            seeds = [seed_batches[b] for b in range(b0, b1)]
+            # the chunk's seeds and output-block index rows: consecutive slices -> views of their parents
+            first, last = seeds[0], seeds[-1]
+            base = first._base if first._base is not None else first
+            s_lo = first.storage_offset() - base.storage_offset()
+            n_seeds = sum(int(t.numel()) for t in seeds)
+            seeds_chunk = base.reshape(-1)[s_lo:s_lo + n_seeds]
+            assert last.data_ptr() + last.numel() * 8 == seeds_chunk.data_ptr() + n_seeds * 8, "seed batches must be consecutive slices"
+            l_first = blocks[b0][1].local_idx
+            lbase = l_first._base if l_first._base is not None else l_first
+            S1 = l_first.shape[1]
+            l_lo = (l_first.storage_offset() - lbase.storage_offset()) // S1
+            lidx = lbase.reshape(-1, S1)[l_lo:l_lo + n_seeds]
+            seg_rows, seg_offs, acc_r = [0], [], 0
+            for b in range(b0, b1):
+                acc_r += int(seed_batches[b].numel())
+                seg_rows.append(acc_r)
+                seg_offs.append(rows[b] - r0)
+            flag = ops.fill_zero(torch.empty(r1 - r0, dtype=torch.uint8, device=picks_all.device)) if FUSED_KEEP_ROWS else None
+            dst_pos = ops.fuse_block_segments(lidx, seg_rows, seg_offs, dst_flag=flag)  # (in place: the per-batch blocks are not handed out)
+            # the hidden layer's vertex ids of the chunk, end to end (the batches' source lists sit apart in the packed array)
+            ids0 = torch.empty(r1 - r0, dtype=torch.int64, device=dev)
+            for k in range(b0, b1, 8):
+                ops.stage_segments([(dsts[b], ids0[rows[b] - r0:rows[b] - r0 + counts[b]], counts[b]) for b in range(k, min(k + 8, b1))])
+            blk0 = Block(None, ids0, None, picks_all[r0:r1])
+            blk1 = Block(ids0, seeds_chunk, lidx, None, dst_pos=dst_pos, dst_flag=flag)
+            out.append((None, seeds_chunk, [blk0, blk1]))
+            b0 = b1
+        return out
+
+
+def _packed(seed_batches, counts):
+    """The batches' seeds end to end: a view when they are consecutive slices of one contiguous tensor (a loader's are), else a copy."""
+    if len(seed_batches) == 1:
+        return seed_batches[0].reshape(-1)
+    first = seed_batches[0]
+    base = first._base
+    if base is not None and base.is_contiguous() and first.dim() == 1:
+        off, ok = first.storage_offset(), True
+        for t, c in zip(seed_batches, counts):
+            if t._base is not base or t.dim() != 1 or t.storage_offset() != off or (c > 1 and t.stride(0) != 1):
+                ok = False
+                break
+            off += c
+        if ok:
+            lo = first.storage_offset() - base.storage_offset()
+            return base.reshape(-1)[lo:lo + sum(counts)]
+    return torch.cat([t.reshape(-1) for t in seed_batches])
+
+
+class _LazyBatches:
+    """The loader's (input_nodes, seeds, blocks) triples, each built from the layers' packed arrays when it is first asked for."""
+
+    def __init__(self, seed_batches, layers):
+        self.seeds, self.layers = seed_batches, layers
+        self.made = [None] * len(seed_batches)
+
+    def __len__(self):
+        return len(self.seeds)
+
+    def __getitem__(self, bi):
+        if isinstance(bi, slice):
+            return [self[i] for i in range(*bi.indices(len(self)))]
+        if bi < 0:
+            bi += len(self)
+        if self.made[bi] is None:
+            blk = []
+            for S, dst_base, starts, counts, rows, src_all, lidx_all, picks_all, n_next in self.layers:
+                r0, c, s0 = rows[bi], counts[bi], rows[bi] * (1 + S)
+                blk.append(Block(src_all[s0:s0 + n_next[bi]], dst_base[starts[bi]:starts[bi] + c], lidx_all[r0:r0 + c], picks_all[r0:r0 + c]))
+            self.made[bi] = (blk[0].src_ids, self.seeds[bi], blk)
+        return self.made[bi]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
 
 
 class _StreamJob:
@@ -308,51 +394,6 @@ class _StreamJob:
                     if t is not None and t.is_cuda:
                         t.record_stream(self.main)
         return self.out
-
-
-    @staticmethod
-    def _fused(seed_batches, blocks, dsts, rows, counts, picks_all, fuse_rows):
-        """Chunks of consecutive batches as one (input block, output block) pair each — see ``sample_batches``.  rows / counts:
-        where batch b's hidden-layer rows sit in the packed layer-0 arrays (they are consecutive); the output blocks' index
-        arrays are consecutive row ranges of one packed array too (the seeds are)."""
-        nb = len(seed_batches)
-        out = []
-        b0 = 0
-        while b0 < nb:
-            b1, acc = b0, 0
-            while b1 < nb and b1 - b0 < 64 and (b1 == b0 or acc + counts[b1] <= fuse_rows):
-                acc += counts[b1]; b1 += 1
-            r0, r1 = rows[b0], rows[b1 - 1] + counts[b1 - 1]
-            dev = picks_all.device
-            seeds = [seed_batches[b] for b in range(b0, b1)]
-            # the chunk's seeds and output-block index rows: consecutive slices -> views of their parents
-            first, last = seeds[0], seeds[-1]
-            base = first._base if first._base is not None else first
-            s_lo = first.storage_offset() - base.storage_offset()
-            n_seeds = sum(int(t.numel()) for t in seeds)
-            seeds_chunk = base.reshape(-1)[s_lo:s_lo + n_seeds]
-            assert last.data_ptr() + last.numel() * 8 == seeds_chunk.data_ptr() + n_seeds * 8, "seed batches must be consecutive slices"
-            l_first = blocks[b0][1].local_idx
-            lbase = l_first._base if l_first._base is not None else l_first
-            S1 = l_first.shape[1]
-            l_lo = (l_first.storage_offset() - lbase.storage_offset()) // S1
-            lidx = lbase.reshape(-1, S1)[l_lo:l_lo + n_seeds]
-            seg_rows, seg_offs, acc_r = [0], [], 0
-            for b in range(b0, b1):
-                acc_r += int(seed_batches[b].numel())
-                seg_rows.append(acc_r)
-                seg_offs.append(rows[b] - r0)
-            flag = ops.fill_zero(torch.empty(r1 - r0, dtype=torch.uint8, device=picks_all.device)) if FUSED_KEEP_ROWS else None
-            dst_pos = ops.fuse_block_segments(lidx, seg_rows, seg_offs, dst_flag=flag)  # (in place: the per-batch blocks are not handed out)
-            # the hidden layer's vertex ids of the chunk, end to end (the batches' source lists sit apart in the packed array)
-            ids0 = torch.empty(r1 - r0, dtype=torch.int64, device=dev)
-            for k in range(b0, b1, 8):
-                ops.stage_segments([(dsts[b], ids0[rows[b] - r0:rows[b] - r0 + counts[b]], counts[b]) for b in range(k, min(k + 8, b1))])
-            blk0 = Block(None, ids0, None, picks_all[r0:r1])
-            blk1 = Block(ids0, seeds_chunk, lidx, None, dst_pos=dst_pos, dst_flag=flag)
-            out.append((None, seeds_chunk, [blk0, blk1]))
-            b0 = b1
-        return out
 
 
 class NodeDataLoader:

@@ -451,15 +451,15 @@ def test_pipelined_loader_hands_out_the_same_blocks():
         sampling.PIPELINE = old
 
 
-@pytest.mark.parametrize("fanout", [25, 5])
-def test_direct_address_block_build_equals_the_hash_build(fanout):
-    """ogl_build_block_batched_ids (a table of n_ids entries per batch, one no-return atomicMin per position) returns what the hash
-    build returns, bit for bit: ragged batches, an empty batch, duplicated picks, missing neighbours (-1) and ids at both ends of
+@pytest.mark.parametrize("fanout,n_ids", [(25, 50_000), (5, 50_000), (25, 232_965), (3, 700_001)])
+def test_direct_address_block_build_equals_the_hash_build(fanout, n_ids):
+    """ogl_build_block_batched_ids (a table of n_ids entries per batch; the per-id minima kept in LDS by a workgroup per id range, or
+    by one no-return atomicMin per position) returns what the hash build returns, bit for bit: ragged batches, an empty batch, duplicated picks, missing neighbours (-1) and ids at both ends of
     the range; and more than one 64-batch chunk."""
     import ogl_amd  # noqa: F401
     from ogl_amd import ops
+    from ogl_amd import _lib
     rng = np.random.default_rng(fanout)
-    n_ids = 50_000
     counts = [int(c) for c in rng.integers(1, 900, size=70)]
     counts[3] = 0
     counts[10] = 4000
@@ -478,13 +478,20 @@ def test_direct_address_block_build_equals_the_hash_build(fanout):
         ops.BLOCK_DIRECT = False
         s0, n0, l0 = ops.build_block_batched_async(dst_base, starts, counts, picks, n_ids=n_ids)
         ops.BLOCK_DIRECT = True
-        s1, n1, l1 = ops.build_block_batched_async(dst_base, starts, counts, picks, n_ids=n_ids)
+        got = []
+        for lds in (1, 0):           # the minima in LDS (a workgroup per batch and id range; n_ids <= 589 824) / by global atomics
+            was = _lib.lib().ogl_block_debug_min_lds(lds)
+            try:
+                got.append(ops.build_block_batched_async(dst_base, starts, counts, picks, n_ids=n_ids))
+            finally:
+                _lib.lib().ogl_block_debug_min_lds(was)
     finally:
         ops.BLOCK_DIRECT = old
     torch.cuda.synchronize()
-    assert torch.equal(n0, n1) and torch.equal(l0, l1)
-    row = 0
-    for b, c in enumerate(counts):                                             # (src_ids beyond a batch's n_src is scratch)
-        o = row * (1 + fanout)
-        assert torch.equal(s0[o:o + int(n0[b])], s1[o:o + int(n1[b])]), b
-        row += c
+    for s1, n1, l1 in got:
+        assert torch.equal(n0, n1) and torch.equal(l0, l1)
+        row = 0
+        for b, c in enumerate(counts):                                             # (src_ids beyond a batch's n_src is scratch)
+            o = row * (1 + fanout)
+            assert torch.equal(s0[o:o + int(n0[b])], s1[o:o + int(n1[b])]), b
+            row += c
