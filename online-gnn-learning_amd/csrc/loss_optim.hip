@@ -322,27 +322,56 @@ __device__ __forceinline__ void adam_range_slabs(float* __restrict__ p, float* _
       const int64_t row = e0 / ncols;
       const int col = (int)(e0 - row * ncols);
       float a[4];
+      // (the parameter's own loads go out first, then the slabs four at a time: a thread has ONE group of four elements, so every
+      // load it does not overlap is latency it pays in full — the launch sits at the end of the step, nothing runs beside it.
+      // The sum keeps the slab order: the reduction launch's bits.)
+      const float4 p4 = ((const float4*)p)[i], m4 = ((const float4*)m)[i], v4 = ((const float4*)v)[i];
       if (col + 4 <= ncols) {
         const float* src = ws + row * ws_ld + col0 + col;
         a[0] = a[1] = a[2] = a[3] = 0.f;
-        for (int s = 0; s < nsplit; ++s) {
+        int s = 0;
+        for (; s + 4 <= nsplit; s += 4) {
+          float4 t[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) t[u] = ld16(src + (int64_t)(s + u) * slab_stride);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { a[0] += t[u].x; a[1] += t[u].y; a[2] += t[u].z; a[3] += t[u].w; }
+        }
+        for (; s < nsplit; ++s) {
           const float4 t = ld16(src + (int64_t)s * slab_stride);
           a[0] += t.x; a[1] += t.y; a[2] += t.z; a[3] += t.w;
         }
-      } else {
+      } else {                                                 // the four straddle a row end (one group per row; its wave waits for it)
+        const float* q[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int64_t r = (e0 + e) / ncols;
-          a[e] = slab_sum1(ws + r * ws_ld + col0 + (int)(e0 + e - r * ncols), slab_stride, nsplit);
+          q[e] = ws + r * ws_ld + col0 + (int)(e0 + e - r * ncols);
+          a[e] = 0.f;
         }
+        int s = 0;
+        for (; s + 4 <= nsplit; s += 4) {
+          float t[4][4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[u][e] = q[e][(int64_t)(s + u) * slab_stride];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += t[u][e];
+        }
+        for (; s < nsplit; ++s)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[e] += q[e][(int64_t)s * slab_stride];
       }
-      float4 p4 = ((float4*)p)[i], m4 = ((float4*)m)[i], v4 = ((float4*)v)[i];
-      adam_one(p4.x, a[0], m4.x, v4.x, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
-      adam_one(p4.y, a[1], m4.y, v4.y, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
-      adam_one(p4.z, a[2], m4.z, v4.z, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
-      adam_one(p4.w, a[3], m4.w, v4.w, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
+      float4 pn = p4, mn = m4, vn = v4;
+      adam_one(pn.x, a[0], mn.x, vn.x, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
+      adam_one(pn.y, a[1], mn.y, vn.y, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
+      adam_one(pn.z, a[2], mn.z, vn.z, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
+      adam_one(pn.w, a[3], mn.w, vn.w, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
       ((float4*)g)[i] = make_float4(a[0], a[1], a[2], a[3]);
-      ((float4*)m)[i] = m4; ((float4*)v)[i] = v4; ((float4*)p)[i] = p4;
+      ((float4*)m)[i] = mn; ((float4*)v)[i] = vn; ((float4*)p)[i] = pn;
     }
     done = n4 << 2;
   }
