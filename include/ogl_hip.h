@@ -367,6 +367,9 @@ int64_t ogl_linear_bwd_weight_x3_workspace_bytes(int64_t M, int N, int K);
  * read k-major like x — no transposed image at all).
  * x image [x_img_rows (+ zero row), K (+ 1 when has_ones: the ones slot, which yields db / db2 = both copies of the bias
  * gradient)]; x_rows (nullable) gathers M rows, ids outside [0, x_nrows) read the zero row.  Images must be < 4 GB. */
+/* diagnostic: 1 / 0 = the UNEVEN split-K plan of the wide k-major weight gradient on / off, -1 = the environment's choice
+ * (OGL_BWWK_UNEVEN=1; off by default: measured slower inside the train step, linear_x3.hip); returns the old value. */
+int ogl_x3_debug_bwwk_uneven(int on);
 int64_t ogl_linear_bwd_weight_x3k_workspace_bytes(int64_t M, int64_t interleave, int N, int K, int has_ones);
 int ogl_linear_bwd_weight_x3k(const void* dyT_img, int64_t interleave, const void* x_img, int64_t x_img_rows, const int64_t* x_rows,
                               int64_t x_nrows, int64_t M, int N, int K, int has_ones, float* dw, int64_t lddw, float* db, float* db2,

@@ -52,6 +52,12 @@ struct X3Args {
   int force_cfg0;               // the k-major weight gradient on the 256 x 128 tile (x3_bwwk_cfg0)
   int defer_reduce;             // host side only: launch_x3 leaves the split-K slabs unreduced (the optimiser launch sums them)
   int xcd_slabs;                // k_gemm_x3p: deal WHOLE split-K slabs to the XCDs (see decode)
+  // UNEVEN split-K (k_gemm_x3p<4, 2, 2, 2, 2, false, true>: the wide k-major weight gradient): the LAST row tile holds few valid rows
+  // (602 = 256 + 256 + 90); its movers do not fetch the A rows past the last valid 16-row block (skip_pad: nothing reads them — the
+  // multipliers skip those blocks), so its steps are shorter, and it gets nsplit2 < nsplit LONGER reduction ranges (steps_per_split2).
+  // The slabs [nsplit2, nsplit) of its rows are written as zeros by its first nsplit - nsplit2 blocks: consumers sum nsplit slabs.
+  int nsplit2, steps_per_split2;
+  int skip_pad;
   unsigned long long* stamps;   // diagnostics only (ogl_x3_debug_stamps): per block {s_memtime, s_memrealtime} at entry and exit
   // ---- extensions, k_gemm_x3p<..., EXT = true> only (forward products, nsplit == 1) ----
   X3Operand a2;                 // optional SECOND part of the A operand: reduction steps [nsteps1, nsteps) read a2 (its own image,
@@ -393,7 +399,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool mover = wid >= 8;
-  const int T = g.NI * g.NJ * g.nsplit;
+  const int T = g.nsplit2 ? (g.NI - 1) * g.NJ * g.nsplit + g.NJ * g.nsplit2 : g.NI * g.NJ * g.nsplit;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   const int chunk_begin = xcd * (T >> 3) + min(xcd, T & 7), chunk_len = (T >> 3) + (xcd < (T & 7) ? 1 : 0);
   if (slot >= chunk_len) return;
@@ -410,6 +416,25 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
   auto decode = [&](int logical) __attribute__((always_inline)) {
     Tile t;
     int tile;
+    if (BK && !AK && NSTAGE == 2 && g.nsplit2) {
+      // uneven: "full" slabs of (NI - 1) NJ tiles and "short" slabs of NJ tiles (the last row tile); an XCD takes floor(nsplit / 8)
+      // whole full slabs and floor(nsplit2 / 8) whole short ones, the slabs left over are dealt tile by tile (full ones first)
+      const int t1 = (g.NI - 1) * g.NJ, t2 = g.NJ, q1 = g.nsplit >> 3, q2 = g.nsplit2 >> 3;
+      const int whole = q1 * t1 + q2 * t2, local = logical - chunk_begin;
+      bool shrt;
+      if (local < q1 * t1) { shrt = false; t.split = xcd * q1 + local / t1; tile = local % t1; }
+      else if (local < whole) { shrt = true; t.split = xcd * q2 + (local - q1 * t1) / t2; tile = (local - q1 * t1) % t2; }
+      else {
+        const int e = (chunk_begin - xcd * whole) + (local - whole), r1 = (g.nsplit - 8 * q1) * t1;
+        if (e < r1) { shrt = false; t.split = 8 * q1 + e / t1; tile = e % t1; }
+        else { shrt = true; t.split = 8 * q2 + (e - r1) / t2; tile = (e - r1) % t2; }
+      }
+      if (shrt) { t.ti = g.NI - 1; t.tj = tile; } else { t.ti = tile / g.NJ; t.tj = tile - t.ti * g.NJ; }
+      const int sps = shrt ? g.steps_per_split2 : g.steps_per_split;
+      t.ks_begin = min(g.nsteps, t.split * sps);
+      t.ks_end = min(g.nsteps, t.ks_begin + sps);
+      return t;
+    }
     if (g.xcd_slabs) {
       const int local = logical - chunk_begin, whole = q_slabs * tiles_per_slab;
       if (local < whole) {
@@ -459,6 +484,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
     const unsigned step_b = (unsigned)g.b.step_bytes;
     unsigned src[NLP];
     int cur_ti = 0;
+    int a_vr = BM;                                         // skip_pad: A rows >= a_vr of the fetch cursor's tile are not fetched
     // BK: a step's B tile is 32 reduction rows x 768 contiguous bytes (48 pieces: 4 column groups).  One DMA instruction of mover
     // wave w moves 4 rows x 16 consecutive pieces (4 runs of 256 B): instruction ub covers rows 8w + 4 (ub / 3) + 0..3, pieces
     // 16 (ub % 3) + 0..15; lane (rsub, i) = (lane >> 4, lane & 15) takes piece 16 t + (i ^ f) of row rsub, f = 2 rsub | 8 (w & 1):
@@ -533,6 +559,10 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         src[u] = (unsigned)(off + j * 16);
       }
       if (EXT) { part2 = false; step_a = (unsigned)g.a.step_bytes; cur_ti = t.ti; }
+      if (NSTAGE == 2 && !AK && !UNEVEN && g.skip_pad) {
+        const int64_t left = g.M - (int64_t)t.ti * BM;
+        a_vr = left >= BM ? BM : (int)((left + 15) & ~(int64_t)15);
+      }
     };
     int f_logical = first, fks, fks_end;
     { const Tile t = decode(first); make_src(t); fks = t.ks_begin; fks_end = t.ks_end; }
@@ -570,7 +600,9 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         if (BK && u >= NLP_A) so += ((bk_zmask >> (u - NLP_A)) & 1) ? bk_zero : bk_row[(u - NLP_A) / 3];
         if (AK && u < NLP_A) so += ((ak_zmask >> u) & 1) ? ak_zero : ak_row[u / 3];
         const bool ia = u_is_a(u);                           // (compile-time unless UNEVEN; then uniform over the wave)
-        if (u_live(u))
+        // (skip_pad: an A instruction whose first row is past the tile's last valid 16-row block moves only rows no multiplier reads)
+        const bool pad = NSTAGE == 2 && !AK && !UNEVEN && u < NLP_A && (u * 256 + wbase) / 12 >= a_vr;
+        if (u_live(u) && !pad)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(ia ? rs_a : rs_b,
                                                    (lptr_t)(smem + (stage % NSTAGE) * STAGE + (u * 256 + (wid - 8) * 64) * 16), 16, so, 0, 0, 0);
         if (!(BK && u >= NLP_A) && !(AK && u < NLP_A)) src[u] += ia ? step_a : step_b;
@@ -823,8 +855,20 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         barrier();                                         // stage n has landed (the movers waited for it)
         compute(n % NSTAGE, rbv, cbv);
       }
-      epilogue(tc);
-      zero_acc();
+      if constexpr (BK && !AK && NSTAGE == 2) {
+        // uneven split-K: slab nsplit2 + j of the short row tile's rows is all zeros, written by that tile's j-th block (a second
+        // pass of the SAME epilogue code over the cleared accumulators)
+        Tile te = tc;
+        const int reps = (g.nsplit2 && tc.ti == g.NI - 1 && tc.split < g.nsplit - g.nsplit2) ? 2 : 1;
+        for (int r = 0; r < reps; ++r) {
+          epilogue(te);
+          zero_acc();
+          te.split = g.nsplit2 + tc.split;
+        }
+      } else {
+        epilogue(tc);
+        zero_acc();
+      }
     }
   }
   (void)NSTORE;
@@ -1343,7 +1387,8 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     const int BMp = (cfg == 0 || cfg == 4) ? 256 : cfg == 2 ? 192 : cfg == 3 ? 160 : 128;
     g.NI = (int)ogl_cdiv(g.M, BMp);
     g.NJ = (int)ogl_cdiv(g.N, cfg == 4 ? 160 : 128);
-    const int64_t T = (int64_t)g.NI * g.NJ * g.nsplit;
+    if (g.nsplit2 && !(bk && cfg == 0 && g.ak_groups == 0 && g.NI >= 2)) g.nsplit2 = 0;   // (the uneven split lives in one instantiation)
+    const int64_t T = g.nsplit2 ? (int64_t)(g.NI - 1) * g.NJ * g.nsplit + (int64_t)g.NJ * g.nsplit2 : (int64_t)g.NI * g.NJ * g.nsplit;
     dim3 grid((unsigned)(8 * std::min<int64_t>(32, ogl_cdiv(T, 8)))), block(768);
     // ring depth: two stages of the 256 x 128 tile fill the LDS (144 KB); the 128 x 128 tile takes three (144 KB): its movers
     // run two stages ahead (+4 % on the layer-0 weight gradient, whose operands both stream from HBM)
@@ -1466,19 +1511,58 @@ static bool x3_bwwk_cfg0(int N, bool dy_rows) {
   return !(e && e[0] == '0') && !dy_rows && N >= 512;
 }
 
-static void x3_bwwk_plan(int64_t steps, int N, int Kc, int* nsplit, int* sps, bool cfg0 = false) {
+// The uneven plan is OFF unless OGL_BWWK_UNEVEN=1 (or ogl_x3_debug_bwwk_uneven(1): tests).  Measured, round 4, Reddit dW_pool0 (600 x 603
+// outputs over 62.6 k reduction rows; per-block durations by ogl_x3_debug_stamps, tools/dw_pool0_probe.py): even plan 17 x 15 blocks of
+// 116 steps: full-tile blocks 261 us, the 88-row tile's blocks 216 us (190 with skip_pad); uneven 19 x 10 blocks of 103 steps + 13 x 5 of
+// 151: 237 / 241 us per block — 8 % less at the block level — and yet the launch is no shorter alone (0.273 ms both) and 15 us LONGER
+// inside the train step (0.232 -> 0.247 ms; step 0.963 -> 0.976): with its own reduction ranges the short tile no longer shares its
+// B rows with the two tiles above it through the XCD's L2 (the gathered table rows are read a second time from the fabric), and a
+// full tile's step got slower too (2.25 -> 2.30 us).  skip_pad with the EVEN plan: inside the noise.  Round 3's attempt (no skip_pad)
+// was 15-40 % slower.
+static int g_bwwk_uneven = -1;
+extern "C" int ogl_x3_debug_bwwk_uneven(int on) { const int old = g_bwwk_uneven; g_bwwk_uneven = on; return old; }
+
+// nsplit2 (optional out): > 0 = the uneven plan (X3Args.nsplit2).  A step of the 256 x 128 tile issues 12 + 6 DMA instructions per mover
+// wave; a last row tile with v valid rows needs the first ceil16(v) * 12 / 256 of the 12 A ones, so its steps cost f = (that + 6) / 18 of
+// a full step (the products are paced by the DMA issue).  s1 ranges for the full row tiles, s2 <= s1 for the short one, chosen to
+// minimise max(steps / s1, f * steps / s2) over the plans that fit one block per CU.
+static void x3_bwwk_plan(int64_t steps, int N, int Kc, int* nsplit, int* sps, bool cfg0 = false, int* nsplit2 = nullptr, int* sps2 = nullptr) {
   const int64_t tiles = ogl_cdiv(N, cfg0 ? 256 : 128) * ogl_cdiv(Kc, 128);
   int64_t s = 256 / (tiles > 0 ? tiles : 1);
   if (s < 1) s = 1;
   if (steps / s < 8) s = steps / 8 > 0 ? steps / 8 : 1;
   *sps = (int)ogl_cdiv(steps > 0 ? steps : 1, s);
   *nsplit = (int)ogl_cdiv(steps > 0 ? steps : 1, *sps);
+  if (nsplit2) { *nsplit2 = 0; *sps2 = 0; }
+  static const char* ue = getenv("OGL_BWWK_UNEVEN");
+  const bool on = g_bwwk_uneven >= 0 ? g_bwwk_uneven != 0 : (ue && ue[0] == '1');
+  const int NI = (int)ogl_cdiv(N, 256), NJ = (int)ogl_cdiv(Kc, 128), v = N - 256 * (NI - 1);
+  if (!nsplit2 || !cfg0 || !on || NI < 2 || v > 160 || steps < 64) return;
+  const int v16 = (v + 15) & ~15;
+  static const char* fe = getenv("OGL_BWWK_UNEVEN_F");
+  const double f = fe ? atof(fe) : ((double)((v16 * 12 + 255) / 256) + 6.0) / 18.0;
+  double best = (double)*sps;                                // the even plan's makespan in full steps
+  int b1 = 0, b2 = 0;
+  for (int s1 = 2; s1 * (NI - 1) * NJ < 256; ++s1) {
+    int s2 = (256 - s1 * (NI - 1) * NJ) / NJ;
+    if (s2 > s1) s2 = s1;
+    if (s2 < 1 || s1 - s2 > s2) continue;
+    const int p1 = (int)ogl_cdiv(steps, s1), p2 = (int)ogl_cdiv(steps, s2);
+    if (p1 < 8 || (int64_t)(s1 - 1) * p1 >= steps || (int64_t)(s2 - 1) * p2 >= steps) continue;   // every range holds work
+    const double cost = std::max((double)p1, f * p2);
+    if (cost < best * 0.97) { best = cost; b1 = s1; b2 = s2; }
+  }
+  if (b1) {
+    *nsplit = b1; *sps = (int)ogl_cdiv(steps, b1);
+    *nsplit2 = b2; *sps2 = (int)ogl_cdiv(steps, b2);
+  }
 }
 
 extern "C" int64_t ogl_linear_bwd_weight_x3k_workspace_bytes(int64_t M, int64_t interleave, int N, int K, int has_ones) {
   if (M < 0 || N < 0 || K < 0 || interleave < -1) return OGL_EINVAL;
-  int nsplit, sps;
-  x3_bwwk_plan(interleave > 0 ? interleave : ogl_cdiv(M, 32), N, K + (has_ones ? 1 : 0), &nsplit, &sps, x3_bwwk_cfg0(N, interleave == -1));
+  int nsplit, sps, nsplit2, sps2;
+  x3_bwwk_plan(interleave > 0 ? interleave : ogl_cdiv(M, 32), N, K + (has_ones ? 1 : 0), &nsplit, &sps, x3_bwwk_cfg0(N, interleave == -1),
+               &nsplit2, &sps2);
   if (nsplit <= 1) return 16;
   return (int64_t)nsplit * N * ogl_round_up(K + 1, 4) * 4;
 }
@@ -1507,8 +1591,10 @@ static int bwd_weight_x3k(const void* dyT_img, int64_t interleave, const void* x
   g.M = N; g.N = Kc; g.ones_col = has_ones ? 1 : 0;
   g.nsteps = (int)(interleave ? interleave : ogl_cdiv(M, 32));
   g.C = dw; g.ldc = lddw; g.db = db; g.db2 = db2;
-  x3_bwwk_plan(g.nsteps, N, Kc, &g.nsplit, &g.steps_per_split, x3_bwwk_cfg0(N, dy_rows));
+  x3_bwwk_plan(g.nsteps, N, Kc, &g.nsplit, &g.steps_per_split, x3_bwwk_cfg0(N, dy_rows), &g.nsplit2, &g.steps_per_split2);
   g.force_cfg0 = x3_bwwk_cfg0(N, dy_rows) ? 1 : 0;
+  static const char* sp_env = getenv("OGL_BWWK_SKIP_PAD");                 // (experiments: 1 = also with the even plan, 0 = never)
+  g.skip_pad = sp_env ? (sp_env[0] == '1' && g.force_cfg0 ? 1 : 0) : (g.nsplit2 > 0 ? 1 : 0);
   static const char* xs_env = getenv("OGL_BWWK_XCD_SLABS");
   g.xcd_slabs = (!(xs_env && xs_env[0] == '0') && g.nsplit >= 8) ? 1 : 0;
   if (g.nsplit > 1) {
