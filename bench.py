@@ -77,7 +77,7 @@ def parse():
                     help="nccl = RCCL over xGMI (one GPU per rank); gloo = rehearsal of the N>1 path with several ranks on one GPU")
     ap.add_argument("--gemm", default="auto", choices=["f32", "bf16x6", "auto"],
                     help="projection arithmetic: exact fp32 MFMA, split-bf16 (x6, fp32-accurate) MFMA, or per-layout best")
-    ap.add_argument("--aggregator", default="pool", choices=["pool", "meanpool", "mean", "maxpool", "gcn"],
+    ap.add_argument("--aggregator", default="pool", choices=["pool", "meanpool", "mean", "maxpool", "gcn", "lstm"],
                     help="aggregator_type of the model (R/train/__main__.py:124-127 passes 'pool': DGL's SAGEConv; the others are the "
                          "in-repo layer's modes, R/train/graphsage/pytorch/aggregator_dgl.py:128-216, with pool_feats = the hidden size)")
     ap.add_argument("--no-graphs", action="store_true", help="enqueue every launch from Python instead of replaying captured steps")

@@ -7,12 +7,12 @@ Two parameterisations, selected by ``aggregator_type`` exactly as in the referen
   constructed at :41-46 with ``"pool"`` from R/train/__main__.py:124-127).  ``fc_pool: in->in``,
   ReLU, elementwise MAX over the sampled in-neighbours, ``fc_self(h_dst) + fc_neigh(neigh)``.
   Parameter names/shapes corroborated by R/inference_optimized.py:136-139,260,276.
-* ``'mean' | 'gcn' | 'meanpool' | 'maxpool'`` — the in-repo layer
+* ``'mean' | 'gcn' | 'meanpool' | 'maxpool' | 'lstm'`` — the in-repo layer
   R/train/graphsage/pytorch/aggregator_dgl.py:49-216: ``fc_pool: in->pool_feats`` (pool modes),
   reduce, ``fc_neigh(cat(h_self, h_neigh))`` (gcn: ``fc_neigh((sum + h_dst)/(deg+1))``).
   ``cat -> Linear`` runs as ONE dual-input GEMM over two column slices of ``fc_neigh.weight``.
   (``maxpool`` is implemented as the elementwise max it documents; the reference's
-  ``.max(axis=1)`` at :175 returns a namedtuple and fails.)  ``'lstm'`` is outside the hot path.
+  ``.max(axis=1)`` at :175 returns a namedtuple and fails.)  ``'lstm'``: the library LSTM (MIOpen) over the gathered mailbox.
 Unknown types raise ``KeyError`` from ``forward`` like the reference (:196-197).
 """
 from __future__ import annotations
@@ -78,8 +78,11 @@ class SAGEConv(nn.Module):
         self.fc_pool = self.fc_self = self.fc_neigh = None
         if edge_feats:
             raise NotImplementedError("edge features are outside the hot path (settings use edge_feats=0)")
-        if aggregator_type == "lstm":
-            raise NotImplementedError("the lstm aggregator is outside the hot path")
+        self.lstm = None
+        if aggregator_type == "lstm" and in_feats > 0:
+            # (aggregator_dgl.py:76-77; outside the hot path — no setting file uses it: the library LSTM (MIOpen) over the gathered
+            # mailbox, no kernel of this package's own)
+            self.lstm = nn.LSTM(in_feats, in_feats, batch_first=True)
         in_neigh = in_feats
         if aggregator_type == "pool":
             self.fc_pool = nn.Linear(in_feats, in_feats)
@@ -104,6 +107,8 @@ class SAGEConv(nn.Module):
         for lin in (self.fc_pool, self.fc_self, self.fc_neigh):
             if lin is not None:
                 nn.init.xavier_uniform_(lin.weight, gain=gain)
+        if self.lstm is not None:
+            self.lstm.reset_parameters()
 
     # ------------------------------------------------------------------------------------------
     def _project(self, lin, x, relu=False, x2=None, w2=None, bias=None, w=None):
@@ -115,7 +120,7 @@ class SAGEConv(nn.Module):
 
     def forward(self, graph, feat):
         t = self._aggre_type
-        if t not in ("pool", "mean", "gcn", "meanpool", "maxpool"):
+        if t not in ("pool", "mean", "gcn", "meanpool", "maxpool", "lstm"):
             raise KeyError("Aggregator type {} not recognized.".format(t))
         lazy = isinstance(feat, GatheredRows)
         if self.training and self.feat_drop.p > 0:
@@ -173,6 +178,21 @@ class SAGEConv(nn.Module):
         elif t == "mean":
             src = feat.materialize() if lazy else feat
             h_neigh = ops.neighbor_reduce(src, idx, "mean")
+            rst = self._linear_cat(feat_dst, h_neigh, fuse_relu)
+        elif t == "lstm":
+            # aggregator_dgl.py:116-126,195-199: h_n of nn.LSTM over each destination's mailbox (slot order), zero initial state;
+            # a destination without edges keeps zeros.  Library path: ATen gather -> MIOpen LSTM (the mailbox [n_dst, S, D] is
+            # materialised, as the reference's degree bucketing does)
+            src = feat.materialize() if lazy else feat
+            S = idx.shape[1]
+            if S == 0 or self.lstm is None:
+                h_neigh = src.new_zeros((n_dst, self.in_neigh_feats))
+            else:
+                li = idx.long()
+                has = li[:, 0] >= 0
+                m = src.index_select(0, li.clamp(min=0).reshape(-1)).view(n_dst, S, src.shape[1])
+                _, (hn, _) = self.lstm(m)
+                h_neigh = torch.where(has.unsqueeze(1), hn.squeeze(0), torch.zeros((), dtype=src.dtype, device=src.device))
             rst = self._linear_cat(feat_dst, h_neigh, fuse_relu)
         else:  # gcn
             src = feat.materialize() if lazy else feat

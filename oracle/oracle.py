@@ -271,11 +271,28 @@ def _neigh_torch(p, local_idx, op, forced=None, connect_empty=False):
     return out
 
 
+def _lstm_last_hidden(rows, params):
+    """Final hidden state of a one-layer LSTM over the mailbox rows [n, S, D] (slot order = sequence order) from zero initial
+    state: R/train/graphsage/pytorch/aggregator_dgl.py:116-126 (``nn.LSTM(D, D, batch_first=True)``; the reducer returns h_n).
+    Gate order of the stacked weights: input, forget, cell, output (torch.nn.LSTM)."""
+    w_ih, w_hh = params["lstm.weight_ih_l0"], params["lstm.weight_hh_l0"]
+    b_ih, b_hh = params["lstm.bias_ih_l0"], params["lstm.bias_hh_l0"]
+    n, S, D = rows.shape
+    h = rows.new_zeros((n, D))
+    c = rows.new_zeros((n, D))
+    for t in range(S):
+        gates = F.linear(rows[:, t, :], w_ih, b_ih) + F.linear(h, w_hh, b_hh)
+        i, f, g, o = gates.chunk(4, dim=1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+        h = torch.sigmoid(o) * torch.tanh(c)
+    return h
+
+
 def sageconv_forward(mode, h_src, n_dst, local_idx, params, activation=None, forced=None, dropout=None):
     """One SAGEConv layer on a fixed-fanout block.
 
     mode ``pool``      — live DGL layer (max; fc_pool in->in; fc_self + fc_neigh).
-    mode ``meanpool``/``maxpool``/``mean``/``gcn`` — R/train/graphsage/pytorch/aggregator_dgl.py:156-206
+    mode ``meanpool``/``maxpool``/``mean``/``gcn``/``lstm`` — R/train/graphsage/pytorch/aggregator_dgl.py:156-206
     (fc_pool in->pool_feats; ``fc_neigh(cat(h_self, h_neigh))``; gcn: ``(sum + h_dst)/(deg+1)``).
     ``params``: dict of torch tensors named like the reference state_dict
     (fc_pool.weight, fc_pool.bias, fc_self.*, fc_neigh.*).
@@ -303,6 +320,14 @@ def sageconv_forward(mode, h_src, n_dst, local_idx, params, activation=None, for
         rst = F.linear(torch.cat((h_dst, neigh), 1), params["fc_neigh.weight"], params["fc_neigh.bias"])
     elif mode == "mean":
         neigh = _neigh_torch(h_src, li, "mean")
+        rst = F.linear(torch.cat((h_dst, neigh), 1), params["fc_neigh.weight"], params["fc_neigh.bias"])
+    elif mode == "lstm":
+        # (aggregator_dgl.py:195-199: the LSTM reducer over each destination's mailbox; a destination without edges keeps zeros)
+        lt = torch.as_tensor(li, dtype=torch.long)
+        has = (lt[:, 0] >= 0) if lt.shape[1] > 0 else torch.zeros(len(lt), dtype=torch.bool)
+        neigh = h_src.new_zeros((n_dst, h_src.shape[1]))
+        if has.any():
+            neigh = neigh.index_put((torch.nonzero(has)[:, 0],), _lstm_last_hidden(h_src[lt[has]], params))
         rst = F.linear(torch.cat((h_dst, neigh), 1), params["fc_neigh.weight"], params["fc_neigh.bias"])
     elif mode == "gcn":
         s = _neigh_torch(h_src, li, "sum")
@@ -387,6 +412,11 @@ def init_layer_params(mode, in_feats, out_feats, pool_feats=None, gen=None):
         lin("fc_neigh", 2 * in_feats, out_feats)
     elif mode == "gcn":
         lin("fc_neigh", in_feats, out_feats)
+    elif mode == "lstm":
+        m = torch.nn.LSTM(in_feats, in_feats, batch_first=True)          # (default init: aggregator_dgl.py:108-109)
+        for k, v in m.state_dict().items():
+            prm["lstm." + k] = v.detach().clone()
+        lin("fc_neigh", 2 * in_feats, out_feats)
     else:
         raise KeyError("Aggregator type {} not recognized.".format(mode))
     return prm

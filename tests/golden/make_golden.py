@@ -213,6 +213,8 @@ if __name__ == "__main__":
     sageconv_case("mean_mid", "mean", 96, 700, 25, 50, 32, None, 0.1, 21)
     sageconv_case("meanpool_mid", "meanpool", 96, 700, 25, 50, 32, 40, 0.1, 22)
     sageconv_case("gcn_mid", "gcn", 96, 700, 25, 50, 32, None, 0.1, 23)
+    sageconv_case("lstm_toy", "lstm", 4, 9, 3, 6, 5, None, 0.25, 14)
+    sageconv_case("lstm_mid", "lstm", 96, 700, 25, 50, 32, None, 0.1, 24)
     sys.path.insert(0, OUT)
     sageconv_fullsize_case("mean")
     sageconv_fullsize_case("meanpool")

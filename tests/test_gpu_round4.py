@@ -549,3 +549,40 @@ def test_uneven_split_k_of_the_wide_weight_gradient(M, N, K):
     finally:
         _lib.lib().ogl_x3_debug_bwwk_uneven(was)
         ops.set_gemm_mode("f32")
+
+
+def test_lstm_aggregator_model_matches_oracle():
+    """A two-layer 'lstm' model (aggregator_dgl.py:116-126,195-199: h_n of nn.LSTM over each destination's mailbox) — forward, loss and
+    every gradient against the oracle's explicit cell loop (itself pinned by tests/golden/sageconv_lstm_*.npz, generated by the
+    reference's layer).  The library LSTM (MIOpen) runs the recurrence; gather, concat -> Linear, loss are this package's kernels."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    from ogl_amd.graphsage import GraphSAGE
+    from ogl_amd.sampling import Block
+    rng = np.random.default_rng(5)
+    n0, n1, B, S, Fin, H, C = 900, 120, 16, 7, 24, 20, 5
+    x = torch.as_tensor(rng.standard_normal((n0, Fin)).astype(np.float32))
+    li0 = rng.integers(0, n0, size=(n1, S)).astype(np.int32); li0[rng.random(n1) < 0.1] = -1
+    li1 = rng.integers(0, n1, size=(B, S)).astype(np.int32); li1[3] = -1
+    labels = torch.as_tensor(rng.integers(0, C, size=B))
+    torch.manual_seed(3)
+    model = GraphSAGE(Fin, H, C, 1, F.relu, 0, "lstm").cuda()
+    params = [{k[len("layers.%d." % l):]: v.detach().cpu().clone() for k, v in model.state_dict().items() if k.startswith("layers.%d." % l)}
+              for l in range(2)]
+    for prm in params:
+        for v in prm.values():
+            v.requires_grad_(True)
+    blocks_o = [dict(dst_ids=np.arange(n1), local_idx=li0), dict(dst_ids=np.arange(B), local_idx=li1)]
+    want = O.graphsage_forward("lstm", x, blocks_o, params)
+    loss_o = O.cross_entropy(want, labels)
+    loss_o.backward()
+    blocks = [Block(torch.arange(n0).cuda(), torch.arange(n1).cuda(), torch.as_tensor(li0).cuda()),
+              Block(torch.arange(n1).cuda(), torch.arange(B).cuda(), torch.as_tensor(li1).cuda())]
+    got = model(blocks, x.cuda())
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-4, atol=1e-5)
+    loss = ops.cross_entropy(got, labels.cuda(), "mean")
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_o.detach())) <= 1e-5 * max(1.0, abs(float(loss_o.detach())))
+    for name, p in model.named_parameters():
+        l, key = int(name.split(".")[1]), name.split(".", 2)[2]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), params[l][key].grad.numpy(), rtol=1e-3, atol=2e-6, err_msg=name)
