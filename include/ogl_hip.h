@@ -294,6 +294,10 @@ int ogl_x3_split_t(const float* src, int64_t ld, const int64_t* rows, int64_t nr
  * the kernel is d(s_memtime) / d(s_memrealtime) x 100 MHz.  Pass NULL to switch off.  `reserved` is ignored.  Not part of
  * the hot path. */
 int ogl_x3_debug_stamps(void* buf, int reserved);
+/* diagnostic: 1 / 0 = the two-stage image-GEMM tiles in their early-A form (a second barrier per step returns the A part of a stage
+ * buffer to the movers as soon as the multipliers hold it in registers) / in the one-barrier form; -1 = OGL_X3_EARLY_A (default on).
+ * Both forms compute the same bits.  Returns the old value. */
+int ogl_x3_debug_early_a(int on);
 /* Diagnostics (A/B of tile shapes inside one process, tests): cfg >= 0 pins the tile of the plain / EXT one-split row-major image
  * products — 0: 256 x 128, 1: 128 x 128, 2: 192 x 128, 3: 160 x 128, 4: 256 x 160 (plain only; EXT falls back to 0) — and -1
  * returns to the automatic choice.  Every tile computes every output element with the same sequence of MFMAs: results are

@@ -375,7 +375,13 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
 // RH / CH: one more 16-row / 16-column block per wave tile on top of TM / TN pairs (tiles of 160 rows or 160 columns).  Such a stage is
 // not a whole number of 256-lane instructions (UNEVEN): the last instruction index is issued by the first mover waves only, and
 // the instruction that straddles the A / B boundary takes its operand per WAVE (piece counts are multiples of 64).
-template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool EXT = false, bool BK = false, bool AK = false, int RH = 0, int CH = 0>
+// EA ("early A", two-stage rings only): the multipliers hold a step's A fragments in registers from the step's first MFMA group on, so
+// the A part of that stage buffer (2/3 of its bytes) is dead for the rest of the step.  A second barrier per step (`mid`), behind the
+// first column block's MFMAs, hands it back to the movers, who issue the A part of stage n + 2 there and then — most of a step earlier
+// than the B part of its stage.  Without it a step is one DMA latency long whatever the matrix pipe does (the movers issue stage
+// n + 1 at the barrier that opens step n and wait for all of it): 2.25-2.33 us per 256 x 128 x 32 step against ~1.6 us of MFMA issue.
+template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool EXT = false, bool BK = false, bool AK = false, int RH = 0, int CH = 0,
+          bool EA = false>
 __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(WAVES_M * WAVES_N == 8, "eight multiplier waves + four mover waves");
@@ -393,6 +399,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
   static_assert(!BK || (BN == 128 && NLP - NLP_A == 6), "k-major B: 128 columns = 48 (plane, 8-column chunk) pairs x 32 rows per stage");
   static_assert(!(BK && EXT), "the k-major B operand belongs to the weight-gradient products");
   static_assert(!AK || (BK && BM == 128 && NLP_A == 6), "k-major A: with a k-major B, 128 rows");
+  static_assert(!EA || (NSTAGE == 2 && !UNEVEN && !AK), "early A: a two-stage ring whose instructions are all-A or all-B");
   constexpr int B_BASE = A_PIECES * 16;                    // byte offset of the B part inside a stage
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
 
@@ -520,18 +527,22 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         src[u] = (unsigned)((ok ? id : g.a2.zero_row) * g.a2.row_bytes + j * 16);
       }
     };
-    auto make_src = [&](const Tile& t) __attribute__((always_inline)) {
+    auto make_src = [&](const Tile& t, auto doA_, auto doB_) __attribute__((always_inline)) {
+      constexpr bool doA = decltype(doA_)::value, doB = decltype(doB_)::value;   // (compile-time: a runtime flag here sends src[] to scratch)
       int64_t rid[NLP_A];
+      if (doA) {
 #pragma unroll
-      for (int u = 0; u < NLP_A; ++u) {
-        const int64_t gi = (int64_t)t.ti * BM + (u * 256 + ml) / 12;
-        rid[u] = gi;
-        if (g.a.rows) rid[u] = g.a.rows[gi < g.M ? gi : g.M - 1];
+        for (int u = 0; u < NLP_A; ++u) {
+          const int64_t gi = (int64_t)t.ti * BM + (u * 256 + ml) / 12;
+          rid[u] = gi;
+          if (g.a.rows) rid[u] = g.a.rows[gi < g.M ? gi : g.M - 1];
+        }
       }
-      if (BK) bk_zmask = 0;
-      if (AK) ak_zmask = 0;
+      if (BK && doB) bk_zmask = 0;
+      if (AK && doA) ak_zmask = 0;
 #pragma unroll
       for (int u = 0; u < NLP; ++u) {
+        if (EA && (u < NLP_A ? !doA : !doB)) continue;         // (EA: this call sets up one operand's part only)
         const int i = u * 256 + ml;
         const int r = i / 12, jp = i - r * 12;
         const int j = (jp & ~3) | ((jp & 3) ^ swz(r));
@@ -558,28 +569,34 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         }
         src[u] = (unsigned)(off + j * 16);
       }
-      if (EXT) { part2 = false; step_a = (unsigned)g.a.step_bytes; cur_ti = t.ti; }
-      if (NSTAGE == 2 && !AK && !UNEVEN && g.skip_pad) {
+      if (EXT && doA) { part2 = false; step_a = (unsigned)g.a.step_bytes; cur_ti = t.ti; }
+      if (NSTAGE == 2 && !AK && !UNEVEN && !EA && g.skip_pad) {
         const int64_t left = g.M - (int64_t)t.ti * BM;
         a_vr = left >= BM ? BM : (int)((left + 15) & ~(int64_t)15);
       }
     };
-    int f_logical = first, fks, fks_end;
-    { const Tile t = decode(first); make_src(t); fks = t.ks_begin; fks_end = t.ks_end; }
-    if (BK) bk_request(fks);
-    auto fetch = [&](int stage) __attribute__((always_inline)) {
+    // fetch cursors: (tile, reduction step) of the next A part / the next B part to be issued (EA: A runs one stage ahead of B;
+    // otherwise they move together and only `ca` is advanced)
+    typedef std::integral_constant<bool, true> yes_t;
+    typedef std::integral_constant<bool, false> no_t;
+    int a_logical = first, a_ks, a_end, b_logical = first, b_ks, b_end;
+    { const Tile t = decode(first); make_src(t, yes_t(), yes_t()); a_ks = b_ks = t.ks_begin; a_end = b_end = t.ks_end; }
+    if (BK) bk_request(b_ks);
+    auto fetch = [&](int stage, auto doA_, auto doB_) __attribute__((always_inline)) {
+      constexpr bool doA = decltype(doA_)::value, doB = decltype(doB_)::value;
+      const int fks = doA ? a_ks : b_ks;
       unsigned bk_row[2] = {0, 0}, bk_zero = 0;
-      if (BK) {
+      if (BK && doB) {
         // this step's rows (requested a step ago), then the request for the step after it — ahead of this step's pieces
         bk_zero = (unsigned)(g.b.zero_row * g.b.row_bytes);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
           bk_row[h] = (bk_ok[h] && bk_id[h] >= 0 && bk_id[h] < g.b.nrows) ? (unsigned)(bk_id[h] * g.b.row_bytes) : bk_zero;
-        if (fks + 1 < fks_end) bk_request(fks + 1);
-        else if (f_logical + nslots < last_logical) bk_request(decode(f_logical + nslots).ks_begin);
+        if (b_ks + 1 < b_end) bk_request(b_ks + 1);
+        else if (b_logical + nslots < last_logical) bk_request(decode(b_logical + nslots).ks_begin);
       }
       unsigned ak_row[2] = {0, 0}, ak_zero = 0;
-      if (AK) {                                            // A rows of this step: reduction position = image row, nothing to fetch
+      if (AK && doA) {                                     // A rows of this step: reduction position = image row, nothing to fetch
         ak_zero = (unsigned)(g.a.zero_row * g.a.row_bytes);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -587,7 +604,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
           ak_row[h] = pos < g.bk_red ? (unsigned)(pos * g.a.row_bytes) : ak_zero;
         }
       }
-      if (EXT && two && !part2 && fks >= g.nsteps1) {      // entering the second A part of this tile
+      if (EXT && doA && two && !part2 && fks >= g.nsteps1) {      // entering the second A part of this tile
         make_src_a2(cur_ti);
         part2 = true; step_a = (unsigned)g.a2.step_bytes;
       }
@@ -601,32 +618,74 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         if (AK && u < NLP_A) so += ((ak_zmask >> u) & 1) ? ak_zero : ak_row[u / 3];
         const bool ia = u_is_a(u);                           // (compile-time unless UNEVEN; then uniform over the wave)
         // (skip_pad: an A instruction whose first row is past the tile's last valid 16-row block moves only rows no multiplier reads)
-        const bool pad = NSTAGE == 2 && !AK && !UNEVEN && u < NLP_A && (u * 256 + wbase) / 12 >= a_vr;
-        if (u_live(u) && !pad)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(ia ? rs_a : rs_b,
-                                                   (lptr_t)(smem + (stage % NSTAGE) * STAGE + (u * 256 + (wid - 8) * 64) * 16), 16, so, 0, 0, 0);
-        if (!(BK && u >= NLP_A) && !(AK && u < NLP_A)) src[u] += ia ? step_a : step_b;
+        const bool pad = NSTAGE == 2 && !AK && !UNEVEN && !EA && u < NLP_A && (u * 256 + wbase) / 12 >= a_vr;
+        const bool mine = !EA || (u < NLP_A ? doA : doB);    // (EA: this call issues one operand's part)
+        if (mine) {
+          if (u_live(u) && !pad)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ia ? rs_a : rs_b,
+                                                     (lptr_t)(smem + (stage % NSTAGE) * STAGE + (u * 256 + (wid - 8) * 64) * 16), 16, so, 0, 0, 0);
+          if (!(BK && u >= NLP_A) && !(AK && u < NLP_A)) src[u] += ia ? step_a : step_b;
+        }
       });
-      if (++fks == fks_end && f_logical + nslots < last_logical) {     // on to the next tile
-        f_logical += nslots;
-        const Tile t = decode(f_logical);
-        make_src(t);
-        fks = t.ks_begin; fks_end = t.ks_end;
+      // on to the next tile when a cursor has issued its tile's last step (EA: each operand has its own cursor)
+      if constexpr (doA) {
+        if (++a_ks == a_end && a_logical + nslots < last_logical) {
+          a_logical += nslots;
+          const Tile t = decode(a_logical);
+          make_src(t, yes_t(), std::integral_constant<bool, doB>());
+          a_ks = t.ks_begin; a_end = t.ks_end;
+        }
+        if constexpr (doB) { b_logical = a_logical; b_ks = a_ks; b_end = a_end; }
+      } else {
+        if (++b_ks == b_end && b_logical + nslots < last_logical) {
+          b_logical += nslots;
+          const Tile t = decode(b_logical);
+          make_src(t, no_t(), yes_t());
+          b_ks = t.ks_begin; b_end = t.ks_end;
+        }
       }
     };
     // the movers run NSTAGE - 1 stages ahead of the multipliers: after the barrier that opens step n they issue stage
     // n + NSTAGE - 1 into the buffer step n - 1 released, then wait for stage n + 1 only (with three stages the newest
     // NLP pieces stay in flight across the barrier: a stage has two steps to land)
+    if constexpr (EA) {
+      // A(n) / B(n): the A / B part of stage n.  Issue order: A(0) B(0) A(1) | step n: B(n + 1) after the barrier that opens it (the B
+      // region of the other buffer was last read in step n - 1), A(n + 2) after its SECOND barrier (the multipliers have this
+      // step's A fragments in registers).  Before the next step opens, A(n + 1) and B(n + 1) must have landed; A(n + 2) — the
+      // youngest NLP_A instructions — may stay in flight.
+      // (n = -1 is the prologue: B(0), A(0), A(1).  One call site per operand: each inlined copy of the fetch code costs registers.)
+      // A(n) / B(n): the A / B part of stage n.  Step n: B(n + 1) after the barrier that opens it (the B region of the other buffer was
+      // last read in step n - 1), A(n + 2) after `mid`.  Before the next step opens, A(n + 1) and B(n + 1) must have landed; A(n + 2) —
+      // the youngest NLP_A instructions — may stay in flight.
+      // (Also tried: a THIRD barrier before the last column block's MFMAs that returns the B part as well, so that all of stage n + 2
+      // is issued during step n — the step got 6 % SLOWER (0.970 -> 1.026 ms per train step) where `mid` alone gains 2.7 %: every
+      // barrier puts the eight multiplier waves back in lockstep, and two waves of a SIMD that issue their MFMA groups together wait
+      // for each other's matrix pipe.)
+      int ia = 0, ib = 0;
+      for (int n = -1; n < total; ++n) {
+        if (n >= 0) barrier();                             // opens step n
+        if (ib < total) { fetch(ib, no_t(), yes_t()); ++ib; }
+        if (n >= 0) barrier();                             // mid: the A part of step n's buffer is free
+        bool young = false;
+        for (int r = (n < 0 ? 0 : 1); r < 2; ++r) {
+          young = false;
+          if (ia < total) { fetch(ia, yes_t(), no_t()); ++ia; young = true; }
+        }
+        if (young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLP_A) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    } else {
     int issued = 0;
-    for (; issued < NSTAGE - 1 && issued < total; ++issued) fetch(issued);
+    for (; issued < NSTAGE - 1 && issued < total; ++issued) fetch(issued, yes_t(), yes_t());
     if (NSTAGE == 3 && issued == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLP) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int n = 0; n < total; ++n) {
       barrier();                                           // opens step n: the buffer of step n - 1 is free
-      if (issued < total) { fetch(issued); ++issued; }
+      if (issued < total) { fetch(issued, yes_t(), yes_t()); ++issued; }
       // stage n + 1 must have landed before the next barrier; what was issued after it may stay in flight
       if (NSTAGE == 3 && issued >= n + 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLP) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     }
   } else {
     // ---- multipliers: 4 x 2 waves of 64 x 64 ------------------------------------------------------------------------------
@@ -675,27 +734,33 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
     // rbv / cbv: how many of the wave tile's 16-row / 16-column blocks hold any real output (the rest is tile padding:
     // M or N not a multiple of the tile).  Padding blocks are not multiplied: the kernel is paced by power, not by the
     // busiest SIMD, so every MFMA not issued comes back as clock (N = 602: 2 of 40 column blocks, 5-10 % of the MFMAs).
+    // (EA: `mid` = the step's second barrier, met by every wave of the block — ONE call site, behind the first column block's MFMAs,
+    // which have consumed every A fragment of the step: all of them are in registers and the A part of this stage buffer goes back
+    // to the movers.  A second call site on the early-return path cost 40-80 spilled registers.)
     auto compute = [&](int buf, int rbv, int cbv) __attribute__((always_inline)) {
       const unsigned char* st = smem + buf * STAGE;
       bf16x8 a[RB][3], b[2][3];
-      if (rbv <= 0 || cbv <= 0) return;
+      const bool work = rbv > 0 && cbv > 0;
+      if (!EA && !work) return;
+      if (work) {
 #pragma unroll
-      for (int sp = 0; sp < 3; ++sp) {
-        if constexpr (BK) b[0][sp] = bk_frag(st, 0, sp);
-        else b[0][sp] = *(const bf16x8*)(st + rowb + offp[sp]);
-      }
-#pragma unroll
-      for (int t = 0; t < RB; ++t)
-        if (t < rbv) {
-#pragma unroll
-          for (int sp = 0; sp < 3; ++sp) {
-            if constexpr (AK) a[t][sp] = k_frag(st, wm * WROWS + t * 16, sp);
-            else a[t][sp] = *(const bf16x8*)(st + rowa + t * 16 * 192 + offp[sp]);
-          }
+        for (int sp = 0; sp < 3; ++sp) {
+          if constexpr (BK) b[0][sp] = bk_frag(st, 0, sp);
+          else b[0][sp] = *(const bf16x8*)(st + rowb + offp[sp]);
         }
+#pragma unroll
+        for (int t = 0; t < RB; ++t)
+          if (t < rbv) {
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) {
+              if constexpr (AK) a[t][sp] = k_frag(st, wm * WROWS + t * 16, sp);
+              else a[t][sp] = *(const bf16x8*)(st + rowa + t * 16 * 192 + offp[sp]);
+            }
+          }
+      }
       static_for<0, CB>([&](auto yc) __attribute__((always_inline)) {
         constexpr int y = decltype(yc)::value;
-        if (y < cbv) {
+        if (work && y < cbv) {
           if constexpr (y + 1 < CB) {
             if (y + 1 < cbv) {
 #pragma unroll
@@ -716,6 +781,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
               acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][0], acc[x][y], 0, 0, 0);
             }
         }
+        if constexpr (EA && y == 0) barrier();                // mid
       });
     };
     auto epilogue = [&](const Tile& t) __attribute__((always_inline)) {
@@ -1323,6 +1389,8 @@ extern "C" int ogl_x3_debug_tile(int cfg) {
 
 // Which instantiation the LAST launch_x3 call ran (template arguments as written at the launch site; trailing defaults omitted):
 // bench.py compares it with the kernel name of the committed PMC pass before quoting that pass's traffic beside a launch it timed.
+static int g_x3_early_a = -1;            // -1: OGL_X3_EARLY_A (default on); 0 / 1: pinned (tests, A/B runs)
+extern "C" int ogl_x3_debug_early_a(int on) { const int old = g_x3_early_a; g_x3_early_a = on; return old; }
 static const char* g_x3_last_kernel = "";
 extern "C" const char* ogl_x3_last_kernel(void) { return g_x3_last_kernel; }
 #define X3P_LAUNCH(...)                                                                           \
@@ -1392,19 +1460,22 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     dim3 grid((unsigned)(8 * std::min<int64_t>(32, ogl_cdiv(T, 8)))), block(768);
     // ring depth: two stages of the 256 x 128 tile fill the LDS (144 KB); the 128 x 128 tile takes three (144 KB): its movers
     // run two stages ahead (+4 % on the layer-0 weight gradient, whose operands both stream from HBM)
+    // the two-stage tiles (256 x 128, 192 x 128) in their early-A form (template parameter EA) unless switched off
+    static const char* ea_env = getenv("OGL_X3_EARLY_A");
+    const bool ea = (g_x3_early_a >= 0 ? g_x3_early_a != 0 : !(ea_env && ea_env[0] == '0')) && !g.skip_pad;
     if (bk && g.ak_groups > 0) X3P_LAUNCH(2, 4, 2, 1, 3, false, true, true);
-    else if (bk && cfg == 0) X3P_LAUNCH(4, 2, 2, 2, 2, false, true);
+    else if (bk && cfg == 0) { if (ea) X3P_LAUNCH(4, 2, 2, 2, 2, false, true, false, 0, 0, true); else X3P_LAUNCH(4, 2, 2, 2, 2, false, true); }
     else if (bk) X3P_LAUNCH(2, 4, 2, 1, 3, false, true);
     else if (ext) {
       if (g.nsplit != 1 || g.ones_col) return OGL_EINVAL;
-      if (cfg == 0) X3P_LAUNCH(4, 2, 2, 2, 2, true);
+      if (cfg == 0) { if (ea) X3P_LAUNCH(4, 2, 2, 2, 2, true, false, false, 0, 0, true); else X3P_LAUNCH(4, 2, 2, 2, 2, true); }
       else if (cfg == 3) X3P_LAUNCH(2, 4, 2, 1, 2, true, false, false, 1, 0);
-      else if (cfg == 2) X3P_LAUNCH(2, 4, 3, 1, 2, true);
+      else if (cfg == 2) { if (ea) X3P_LAUNCH(2, 4, 3, 1, 2, true, false, false, 0, 0, true); else X3P_LAUNCH(2, 4, 3, 1, 2, true); }
       else X3P_LAUNCH(2, 4, 2, 1, 3, true);
-    } else if (cfg == 0) X3P_LAUNCH(4, 2, 2, 2, 2);
+    } else if (cfg == 0) { if (ea) X3P_LAUNCH(4, 2, 2, 2, 2, false, false, false, 0, 0, true); else X3P_LAUNCH(4, 2, 2, 2, 2); }
     else if (cfg == 4) X3P_LAUNCH(4, 2, 2, 2, 2, false, false, false, 0, 1);
     else if (cfg == 3) X3P_LAUNCH(2, 4, 2, 1, 2, false, false, false, 1, 0);
-    else if (cfg == 2) X3P_LAUNCH(2, 4, 3, 1, 2);
+    else if (cfg == 2) { if (ea) X3P_LAUNCH(2, 4, 3, 1, 2, false, false, false, 0, 0, true); else X3P_LAUNCH(2, 4, 3, 1, 2); }
     else X3P_LAUNCH(2, 4, 2, 1, 3);
     OGL_CHECK_LAUNCH();
   } else {
