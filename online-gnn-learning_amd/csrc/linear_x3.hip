@@ -660,7 +660,10 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
       // (Also tried: a THIRD barrier before the last column block's MFMAs that returns the B part as well, so that all of stage n + 2
       // is issued during step n — the step got 6 % SLOWER (0.970 -> 1.026 ms per train step) where `mid` alone gains 2.7 %: every
       // barrier puts the eight multiplier waves back in lockstep, and two waves of a SIMD that issue their MFMA groups together wait
-      // for each other's matrix pipe.)
+      // for each other's matrix pipe.  And NO barrier at all — six LDS counters, per stage buffer `full` / `A taken` / `B read`, added to
+      // by ds_add and polled by ds_read_b32 + s_sleep, every wave waiting only for what it needs: parity-green and 22-45 % slower
+      // (dW_pool0 0.227 -> 0.330 ms with s_sleep 1, block durations 260 -> 317 us with s_sleep 4): gfx950 has no blocking wait but
+      // s_barrier, and four mover waves polling LDS take the cycles the fragment reads need.)
       int ia = 0, ib = 0;
       for (int n = -1; n < total; ++n) {
         if (n >= 0) barrier();                             // opens step n
