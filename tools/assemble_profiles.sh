@@ -47,6 +47,8 @@ json.dump(dict(what="same box, alternating runs of `env <switches> python bench.
                     "(tools/ab_combo.sh): the round's switches against the default (OGL_X=0 is a no-op)", runs=runs),
           open('profiles/%s_ab_experiments.json' % R, 'w'), indent=1)
 PY
+[ -f $O/block_build_probe.txt ] && grep -v amdgpu.ids $O/block_build_probe.txt > $P/${R}_block_build_probe.txt || true
+[ -f $O/dw_pool0_probe.txt ] && cp $O/dw_pool0_probe.txt $P/${R}_dw_pool0_probe.txt || true
 cp $O/kernel_stats.csv $P/${R}_rocprofv3_kernel_stats.csv
 cp $O/kernel_stats_graph.csv $P/${R}_rocprofv3_kernel_stats_graph_replay.csv
 cp $O/trace_by_grid.txt $P/${R}_kernel_trace_by_grid.txt

@@ -18,7 +18,10 @@ done
 # the numbers the round-4 parity tests print (loss curves, x6-vs-fp32 counts, gradient errors at the Reddit rung)
 timeout -k 10 600 python -m pytest tests/test_gpu_rungs.py tests/test_gpu_fullsize.py tests/test_gpu_round4.py -q -s -k "200_step or no_worse or inrepo_modes or two_part or fused_output_layer_step" > $O/parity_numbers.log 2>&1 < /dev/null || true
 # same-box A/B of the round's switches inside the replayed step (kept and dropped ones)
-bash tools/ab_combo.sh r04 3 "OGL_X=0" "OGL_FUSED_OUT_FWD=0" "OGL_SLAB_ADAM=0" "OGL_ADAM_EARLY=1" "OGL_POOL_PLAN_LATE=1" > $O/ab_r04.txt 2>&1 || true
+bash tools/ab_combo.sh r04 3 "OGL_X=0" "OGL_FUSED_OUT_FWD=0" "OGL_SLAB_ADAM=0" "OGL_ADAM_EARLY=1" "OGL_POOL_PLAN_LATE=1" "OGL_BLOCK_DIRECT=0" "OGL_X3_EARLY_A=0" "OGL_SAMPLE_PIPELINE=1" "OGL_BWWK_UNEVEN=1" > $O/ab_r04.txt 2>&1 || true
+# the loader phase (sampler + block build, hash / direct table / minima in LDS) and the layer-0 weight gradient block by block (even / uneven split-K)
+timeout -k 10 200 python tools/block_build_probe.py > $O/block_build_probe.txt 2>&1 || true
+(OGL_BWWK_UNEVEN=0 timeout -k 10 200 python tools/dw_pool0_probe.py; OGL_BWWK_UNEVEN=1 timeout -k 10 200 python tools/dw_pool0_probe.py; OGL_X3_EARLY_A=0 timeout -k 10 200 python tools/dw_pool0_probe.py) 2>&1 | grep -v amdgpu.ids > $O/dw_pool0_probe.txt || true
 cp -r gpurun_out/ab_r04 $O/ab_r04 2> /dev/null || true
 cd /tmp && export TMPDIR=/tmp
 # the traced / counted runs enqueue eagerly (--no-graphs): the same kernels at the batch's own sizes, one dispatch per launch

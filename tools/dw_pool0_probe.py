@@ -35,7 +35,7 @@ ts = []
 for _ in range(10):
     e0.record(); run(); e1.record(); e1.synchronize()
     ts.append(e0.elapsed_time(e1))
-print("env %s: product + reduction launch, best %.3f ms, median %.3f ms" % ({k: v for k, v in os.environ.items() if k.startswith("OGL_BWWK")},
+print("env %s: product + reduction launch, best %.3f ms, median %.3f ms" % ({k: v for k, v in os.environ.items() if k.startswith("OGL_BWWK") or k.startswith("OGL_X3")},
                                                                             min(ts), sorted(ts)[len(ts) // 2]))
 stamps = torch.zeros(1024, dtype=torch.int64, device=dev)
 _lib.lib().ogl_x3_debug_stamps(stamps.data_ptr(), 0)
