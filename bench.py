@@ -41,8 +41,8 @@ def norm_kernel(name):
     if not m:
         return None
     a = [x.strip() for x in m.group(2).split(",")]
-    if m.group(1) == "k_gemm_x3p" and 5 <= len(a) < 10:
-        a += ["false", "false", "false", "0", "0"][len(a) - 5:]           # EXT, BK, AK, RH, CH (csrc/linear_x3.hip)
+    if m.group(1) == "k_gemm_x3p" and 5 <= len(a) < 11:
+        a += ["false", "false", "false", "0", "0", "false"][len(a) - 5:]  # EXT, BK, AK, RH, CH, EA (csrc/linear_x3.hip)
     return (m.group(1),) + tuple(a)
 
 
