@@ -17,6 +17,12 @@ from .. import ops, optim, parallel, sampling, stepgraph
 from .sageconv import GatheredRows
 
 
+# OGL_DP_CAPTURE_COLLECTIVES=0: a replica's step keeps its RCCL all-reduces and the optimiser OUT of the replayed graph (round 3's form:
+# forward + backward replayed, exchange and Adam enqueued from Python) — the fallback if a multi-GPU node's RCCL refuses the capture
+# (the captured form has run on one rank through a world-size-1 RCCL group only: tests/test_gpu_nccl.py)
+DP_CAPTURE_COLLECTIVES = __import__("os").environ.get("OGL_DP_CAPTURE_COLLECTIVES", "1") != "0"
+
+
 def _to_numpy(t):
     return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
 
@@ -459,7 +465,7 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         big = self.use_graphs is True or int(n_global) * (1 + self.samples) >= self.STAGED_DP_MIN_ROWS      # (global: same on every rank)
         import torch.distributed as dist
         if (self.gsync is not None and self._graphs_ok("staged_dp") and big and (on_rows is None or self.reduction != "mean")
-                and dist.get_backend(self.gsync.group) == "nccl"):
+                and dist.get_backend(self.gsync.group) == "nccl" and DP_CAPTURE_COLLECTIVES):
             # A replica's step as ONE replayed graph (form "staged_dp"): forward, loss, backward, the gradient exchange — the early
             # bucket's RCCL all-reduce launched from the gradient hooks on the side branch, under the layer-0 pool backward and weight
             # gradient; the late bucket (layer 0's fc_pool) behind it — and Adam on the reduced buckets.  The local mean loss's
