@@ -663,7 +663,9 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
       // for each other's matrix pipe.  And NO barrier at all — six LDS counters, per stage buffer `full` / `A taken` / `B read`, added to
       // by ds_add and polled by ds_read_b32 + s_sleep, every wave waiting only for what it needs: parity-green and 22-45 % slower
       // (dW_pool0 0.227 -> 0.330 ms with s_sleep 1, block durations 260 -> 317 us with s_sleep 4): gfx950 has no blocking wait but
-      // s_barrier, and four mover waves polling LDS take the cycles the fragment reads need.)
+      // s_barrier, and four mover waves polling LDS take the cycles the fragment reads need.  And `mid` moved to the HALF of the step
+      // (column block 3's fragments requested ahead of it, so that it returns the whole buffer and all of stage n + 2 is issued there,
+      // same two barriers per step): 0.955 -> 1.106 ms per train step.)
       int ia = 0, ib = 0;
       for (int n = -1; n < total; ++n) {
         if (n >= 0) barrier();                             // opens step n
