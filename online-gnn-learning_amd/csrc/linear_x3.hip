@@ -747,32 +747,34 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
       bf16x8 a[RB][3], b[2][3];
       const bool work = rbv > 0 && cbv > 0;
       if (!EA && !work) return;
-      if (work) {
-#pragma unroll
+      {                                                       // (no branch around the loads: a control-flow join in front of the first
+#pragma unroll                                                //  MFMA makes the compiler wait for every load in flight — lgkmcnt(0))
         for (int sp = 0; sp < 3; ++sp) {
           if constexpr (BK) b[0][sp] = bk_frag(st, 0, sp);
           else b[0][sp] = *(const bf16x8*)(st + rowb + offp[sp]);
         }
+        // (EVERY fragment of the wave tile is requested, padding blocks too — their rows exist in the stage, as zero rows or stale
+        // bytes nobody multiplies: with the loads under `t < rbv` / `y + 1 < cbv` branches the compiler cannot count what is in
+        // flight, so the first MFMA waited for 16 of the step's 18 fragment loads (`s_waitcnt lgkmcnt(2)`) although it needs the
+        // first four — with eight waves in lockstep behind the barrier that is ~150 KB through LDS, a quarter of the step, before
+        // any matrix instruction issues)
 #pragma unroll
-        for (int t = 0; t < RB; ++t)
-          if (t < rbv) {
+        for (int t = 0; t < RB; ++t) {
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) {
-              if constexpr (AK) a[t][sp] = k_frag(st, wm * WROWS + t * 16, sp);
-              else a[t][sp] = *(const bf16x8*)(st + rowa + t * 16 * 192 + offp[sp]);
-            }
+          for (int sp = 0; sp < 3; ++sp) {
+            if constexpr (AK) a[t][sp] = k_frag(st, wm * WROWS + t * 16, sp);
+            else a[t][sp] = *(const bf16x8*)(st + rowa + t * 16 * 192 + offp[sp]);
           }
+        }
       }
       static_for<0, CB>([&](auto yc) __attribute__((always_inline)) {
         constexpr int y = decltype(yc)::value;
         if (work && y < cbv) {
           if constexpr (y + 1 < CB) {
-            if (y + 1 < cbv) {
 #pragma unroll
-              for (int sp = 0; sp < 3; ++sp) {
-                if constexpr (BK) b[(y + 1) & 1][sp] = bk_frag(st, y + 1, sp);
-                else b[(y + 1) & 1][sp] = *(const bf16x8*)(st + rowb + (y + 1) * 16 * 192 + offp[sp]);
-              }
+            for (int sp = 0; sp < 3; ++sp) {
+              if constexpr (BK) b[(y + 1) & 1][sp] = bk_frag(st, y + 1, sp);
+              else b[(y + 1) & 1][sp] = *(const bf16x8*)(st + rowb + (y + 1) * 16 * 192 + offp[sp]);
             }
           }
 #pragma unroll
