@@ -92,6 +92,10 @@ def parse():
                     help="one rank only: initialise an RCCL process group of world size 1 and run the N-rank code path through it "
                          "(seed shards, gradient buckets + all-reduce calls, sharded passes): what a rank of an N-GPU job costs on "
                          "this GPU, minus the bytes on the links")
+    ap.add_argument("--dp-capture", type=int, default=None, choices=[0, 1],
+                    help="N > 1 / --force-dist: 1 = the replica's whole step (both RCCL all-reduces + Adam) inside the replayed hipGraph "
+                         "(round 4's form; rehearsed on one rank only), 0 = forward + backward replayed, exchange and optimiser eager "
+                         "(the default: graphsage/model.py DP_CAPTURE_COLLECTIVES)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end snapshot leg (metric iii) of the default line")
     ap.add_argument("--e2e-snapshots", type=int, default=6)
     ap.add_argument("--partition", default="replicated", choices=["replicated", "features"],
@@ -180,6 +184,9 @@ def main():
 
     if args.force_dist:
         parallel.force_distributed(True)
+    if args.dp_capture is not None:
+        from ogl_amd.graphsage import model as _model_mod
+        _model_mod.DP_CAPTURE_COLLECTIVES = bool(args.dp_capture)
     ops.set_gemm_mode(args.gemm)
     wl = WORKLOADS[args.workload]
     B, S, H, bt = wl["batch"], wl["samples"], wl["hidden"], wl["batch_timestep"]
@@ -563,8 +570,9 @@ def main():
                        "parallelism": "dp%d (seed-sharded replicas, two-bucket grad all-reduce %s)%s" % (
                            world, ("INSIDE the replayed step graph: the early bucket's RCCL all-reduce on the side branch under the layer-0 "
                                    "backward, the late bucket and the optimiser (device-side step count) behind it"
-                                   if (dist.is_initialized() and dist.get_backend() == "nccl") else
-                                   "after the replayed forward + backward graph; optimiser eager (host-staged backend)")
+                                   if (dist.is_initialized() and dist.get_backend() == "nccl" and _dp_capture_on()) else
+                                   "after the replayed forward + backward graph as ONE flat bucket; optimiser eager (the default since round 5; "
+                                   "--dp-capture 1 records both into the graph)")
                            if "staged_dp" in forms_timed else "overlapped with backward",
                            " — FORCED through a world-size-1 RCCL group (--force-dist)" if args.force_dist else ""),
                        "avg_unique_input_nodes_n0": round(n0_avg, 1), "avg_n1": round(n1_avg, 1), "setup_s": round(setup_s, 1)},
@@ -583,6 +591,11 @@ def main():
         print(json.dumps(line))
     if world > 1 or args.force_dist:
         dist.destroy_process_group()
+
+
+def _dp_capture_on():
+    from ogl_amd.graphsage import model as _m
+    return bool(_m.DP_CAPTURE_COLLECTIVES)
 
 
 def h_nnz(g):

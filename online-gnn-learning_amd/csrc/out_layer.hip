@@ -422,6 +422,11 @@ __global__ void __launch_bounds__(OF_THREADS) k_out_fwd_ce(OutFwdArgs a) {
     if (a.dlogits && lane < a.N) a.dlogits[row * a.lddl + lane] = a.grad_scale * (expf(x - lse) - ((ok && lane == (int)y) ? 1.f : 0.f));
   }
   if (!a.loss_mean) return;
+  if (!a.counter) {
+    // the mean is left to the successor launch (ogl_out_layer_bwd_inputs_mean): until then the tensor reads NaN, not stale memory
+    if (blockIdx.x == 0 && tid == 0) *a.loss_mean = __builtin_nanf("");
+    return;
+  }
   __threadfence();
   __syncthreads();
   if (tid == 0) last = atomicAdd(a.counter, 1u) == gridDim.x - 1u;
@@ -449,7 +454,7 @@ extern "C" int ogl_out_layer_fwd_ce(const float* P, int64_t ldp, int64_t n_src, 
   if (!ogl_out_layer_fwd_ce_fits(n_dst, fanout, K, N) || n_src <= 0 || n_src < n_dst) return OGL_EINVAL;
   if (ldp < K || ldh < K || ldws < K || ldwn < K || ldn < K || ldl < N || (dlogits && lddl < N) || n_labels < 0) return OGL_EINVAL;
   if (!P || !idx || !h || !w_self || !w_neigh || !neigh || !logits || !label_table || !loss_rows) return OGL_EINVAL;
-  if (loss_mean && !counter) return OGL_EINVAL;
+  // (loss_mean without a counter: the mean is DEFERRED — this launch writes NaN there, ogl_out_layer_bwd_inputs_mean the value)
   // 16-byte row accesses everywhere
   if (((ldp | ldh | ldws | ldwn | ldn) & 3) || (((uintptr_t)P | (uintptr_t)h | (uintptr_t)w_self | (uintptr_t)w_neigh | (uintptr_t)neigh |
                                                  (uintptr_t)argmax) & 15))

@@ -101,17 +101,22 @@ class GraphSAGE(nn.Module):
         if req:
             ops.weight_images_prepare(req)
 
-    def forward_loss(self, blocks, x, labels, rows=False):
+    def forward_loss(self, blocks, x, labels, rows=False, defer_mean=False):
         """``CrossEntropyLoss(self(blocks, x), labels)`` for a train step — the per-batch body R/train/graphsage/pytorch/model.py:87-105
         (``reduction='mean'``) and :193-200 (``'none'`` + ``.mean()``: ``rows=True`` also returns the per-seed losses) — with the last
         layer and the loss as ONE autograd node when that layer is a tall few-column 'pool' layer (``SAGEConv.forward_loss``).
-        ``labels``: int64 tensor or ``ops.LazyLabels``.  Returns (loss, per-seed losses or None, logits)."""
+        ``labels``: int64 tensor or ``ops.LazyLabels``.  Returns (loss, per-seed losses or None, logits).
+        ``defer_mean=True`` is a contract for callers that run ``backward()`` on the returned loss THEMSELVES before anything reads its
+        value (the strategies' train steps, the captured step body): the fused node then leaves the VALUE of the mean to the first
+        launch of its backward (a device-scope fence per block inside the forward launch costs 33 us at 512 seeds) — until that
+        backward has run the loss tensor holds NaN.  The default writes the value in the forward launch: a loss that is only
+        logged, guarded or evaluated is always valid."""
         if torch.is_grad_enabled() and ops.get_gemm_mode() != "f32" and ops.PREPARE_WEIGHT_IMAGES:
             self._prepare_step_images(blocks, x)
         h = x
         for layer, block in zip(self.layers[:-1], blocks[:-1]):
             h = layer(block, h)
-        out = self.layers[-1].forward_loss(blocks[-1], h, labels) if len(self.layers) == len(blocks) else None
+        out = self.layers[-1].forward_loss(blocks[-1], h, labels, defer_mean=defer_mean) if len(self.layers) == len(blocks) else None
         if out is not None:
             return out[0], (out[1] if rows else None), out[2]
         logits = self.layers[-1](blocks[-1], h)

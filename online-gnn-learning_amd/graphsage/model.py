@@ -17,10 +17,15 @@ from .. import ops, optim, parallel, sampling, stepgraph
 from .sageconv import GatheredRows
 
 
-# OGL_DP_CAPTURE_COLLECTIVES=0: a replica's step keeps its RCCL all-reduces and the optimiser OUT of the replayed graph (round 3's form:
-# forward + backward replayed, exchange and Adam enqueued from Python) — the fallback if a multi-GPU node's RCCL refuses the capture
-# (the captured form has run on one rank through a world-size-1 RCCL group only: tests/test_gpu_nccl.py)
-DP_CAPTURE_COLLECTIVES = __import__("os").environ.get("OGL_DP_CAPTURE_COLLECTIVES", "1") != "0"
+# OGL_DP_CAPTURE_COLLECTIVES=1 (or ``model.DP_CAPTURE_COLLECTIVES = True``; bench.py --dp-capture 1): a replica's WHOLE step — both RCCL
+# all-reduces, launched from the gradient hooks on the side branch, and the optimiser — is recorded into the replayed hipGraph (round 4:
+# 1.011 ms per step against 1.085 for the form below, measured through a world-size-1 RCCL group).  OFF by default since round 5: that
+# form has run on ONE rank only (tests/test_gpu_nccl.py), and with two or more ranks each rank decides from its OWN block sizes whether a
+# step is a replay, a capture (a size bucket's second sighting) or the eager twin — the collective SEQUENCE is the same in all three, but
+# a replayed collective meeting an eagerly enqueued one on a peer is exactly what no multi-GPU run has covered yet, and a mismatch there
+# is a hang, not an error.  The default keeps the exchange and the optimiser OUT of the graph (round 3's form: forward + backward
+# replayed, ONE flat-bucket all-reduce and Adam enqueued from Python — every rank enqueues its collectives the same way).
+DP_CAPTURE_COLLECTIVES = __import__("os").environ.get("OGL_DP_CAPTURE_COLLECTIVES", "0") == "1"
 
 
 def _to_numpy(t):
@@ -319,8 +324,9 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             self.optimizer.prime()                     # (its per-step scalars ride in the forward's weight-image launch)
         # (the labels are gathered inside the loss launch; the last layer and the loss are one node where that applies)
         batch_labels = ops.LazyLabels(graph.ndata["target"], seeds)
+        # (defer_mean: this step runs the backward itself, right below — the loss VALUE exists from its first launch on)
         loss, rows, _ = self.graphsage_model.forward_loss(blocks, self._inputs(graph, input_nodes), batch_labels,
-                                                          rows=self.reduction != "mean")
+                                                          rows=self.reduction != "mean", defer_mean=True)
         if rows is not None and on_rows is not None:
             on_rows(seeds, rows.detach())
         if hasattr(self.optimizer, "backward_and_step"):
@@ -465,7 +471,7 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         big = self.use_graphs is True or int(n_global) * (1 + self.samples) >= self.STAGED_DP_MIN_ROWS      # (global: same on every rank)
         import torch.distributed as dist
         if (self.gsync is not None and self._graphs_ok("staged_dp") and big and (on_rows is None or self.reduction != "mean")
-                and dist.get_backend(self.gsync.group) == "nccl" and DP_CAPTURE_COLLECTIVES):
+                and dist.get_backend(self.gsync.group) == "nccl" and DP_CAPTURE_COLLECTIVES):    # (module global: read at call time)
             # A replica's step as ONE replayed graph (form "staged_dp"): forward, loss, backward, the gradient exchange — the early
             # bucket's RCCL all-reduce launched from the gradient hooks on the side branch, under the layer-0 pool backward and weight
             # gradient; the late bucket (layer 0's fc_pool) behind it — and Adam on the reduced buckets.  The local mean loss's
@@ -491,7 +497,8 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             self.gsync.begin_step(w)
             if n_local > 0:
                 batch_labels = ops.LazyLabels(graph.ndata["target"], seeds)
-                loss_e, eager_rows, _ = self.graphsage_model.forward_loss(blocks, self._inputs(graph, input_nodes), batch_labels, rows=True)
+                loss_e, eager_rows, _ = self.graphsage_model.forward_loss(blocks, self._inputs(graph, input_nodes), batch_labels, rows=True,
+                                                                          defer_mean=True)
                 ops.backward(loss_e)
             else:                                               # more ranks than seeds in this batch: zeros into the same collectives
                 for p in self.gsync.params:

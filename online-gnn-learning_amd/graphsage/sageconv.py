@@ -207,16 +207,18 @@ class SAGEConv(nn.Module):
             rst = self.norm(rst)
         return rst
 
-    def forward_loss(self, graph, feat, labels):
+    def forward_loss(self, graph, feat, labels, defer_mean=False):
         """This layer as the LAST layer of a train step, fused with nn.CrossEntropyLoss: (mean loss, per-seed losses, logits) from
         one autograd node whose forward is the fc_pool product + ONE launch (``ops.sage_pool_layer_loss``) — or None when that form
-        does not apply (the caller runs ``forward`` and the loss separately; same values, same gradients)."""
+        does not apply (the caller runs ``forward`` and the loss separately; same values, same gradients).
+        ``defer_mean``: see ``GraphSAGE.forward_loss`` (only a caller that runs the backward itself may ask for it)."""
         if (self._aggre_type != "pool" or isinstance(feat, GatheredRows) or self.norm is not None or self.activation is not None
                 or (self.training and self.feat_drop.p > 0) or not torch.is_grad_enabled() or getattr(graph, "dst_pos", None) is not None
                 or (self.fc_self.bias is None) != (self.fc_neigh.bias is None)):
             return None
         return ops.sage_pool_layer_loss(feat, self.fc_pool.weight, self.fc_pool.bias, self.fc_self.weight, self.fc_neigh.weight,
-                                        self.fc_self.bias, self.fc_neigh.bias, graph.local_idx, graph.number_of_dst_nodes(), labels)
+                                        self.fc_self.bias, self.fc_neigh.bias, graph.local_idx, graph.number_of_dst_nodes(), labels,
+                                        defer_mean=defer_mean)
 
     def _forward_fused_batches(self, graph, feat, idx, dst_pos, fuse_relu):
         """Inference on several loader batches fused into one block (sampling.sample_batches(fuse_rows=...)): the same three

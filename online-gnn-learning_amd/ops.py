@@ -298,6 +298,10 @@ def sample_layer_batched(g: GraphHandle, dst_base: torch.Tensor, starts, counts,
 # the id bound and the tables of a 64-batch chunk stay below this many bytes (OGL_BLOCK_DIRECT=0: always the hash)
 BLOCK_DIRECT = os.environ.get("OGL_BLOCK_DIRECT", "1") != "0"
 BLOCK_DIRECT_MAX_BYTES = 2 << 30
+# ... and only when the table is not much larger than what the batches put into it: the direct build touches 8 * n_ids bytes per batch
+# whatever the batch holds, the hash O(positions) — a 32-seed batch (21 k positions) on a 170 k-vertex graph stays on the hash, a
+# 512-seed one (9.2 M positions over 50 batches of a 233 k-vertex graph) takes the table (measured there: 1.23 -> 0.30 ms)
+BLOCK_DIRECT_IDS_PER_POSITION = 4
 
 
 def build_block_batched_async(dst_base: torch.Tensor, starts, counts, picks: torch.Tensor, n_ids=None):
@@ -314,7 +318,8 @@ def build_block_batched_async(dst_base: torch.Tensor, starts, counts, picks: tor
     n_src = torch.empty(nb, dtype=torch.int64, device=dev) if nb > 0 else torch.zeros(1, dtype=torch.int64, device=dev)
     local_idx = torch.empty((total, fanout), dtype=torch.int32, device=dev)
     h_counts = _host_i64(counts)
-    if BLOCK_DIRECT and n_ids and 0 < int(n_ids) < 2 ** 31 and 8 * int(n_ids) * min(nb, 64) <= BLOCK_DIRECT_MAX_BYTES:
+    if (BLOCK_DIRECT and n_ids and 0 < int(n_ids) < 2 ** 31 and 8 * int(n_ids) * min(nb, 64) <= BLOCK_DIRECT_MAX_BYTES
+            and int(n_ids) * nb <= BLOCK_DIRECT_IDS_PER_POSITION * total * (1 + fanout)):
         nbytes = int(_lib.lib().ogl_block_workspace_bytes_batched_ids(h_counts, nb, int(fanout), int(n_ids)))
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
         _launch("ogl_build_block_batched", _lib.lib().ogl_build_block_batched_ids, _ptr(dst_base), _host_i64(starts), h_counts, nb, _ptr(picks),
@@ -589,8 +594,8 @@ def out_loss_fits(h, n_dst, idx, w_self, w_neigh, p_width):
 def out_layer_fwd_ce(p, idx, h, n_dst, w_self, w_neigh, b_self, b_neigh, labels, want_grad=True, zero=None, want_mean=True):
     """(mean loss, row losses, logits, neigh, argmax, dlogits / n_dst) of the output layer from its pooled projection rows ``p`` =
     relu(fc_pool(h)) in ONE launch; ``labels``: int64 tensor or LazyLabels; ``zero``: a contiguous fp32 buffer the grid clears on
-    the side (the scatter target of the layer's backward).  ``want_mean=False``: the returned mean tensor is NOT written by this
-    launch (no last-block-done count, no device-scope fences): ``out_layer_bwd_inputs(finish_loss=...)`` writes it."""
+    the side (the scatter target of the layer's backward).  ``want_mean=False``: the returned mean tensor gets NaN from this launch
+    (no last-block-done count, no device-scope fences) and its value from ``out_layer_bwd_inputs(finish_loss=...)``."""
     p = as_mat(p); h = as_mat(h); w_self = as_mat(w_self); w_neigh = as_mat(w_neigh)
     K, N = p.shape[1], w_self.shape[0]
     dev = p.device
@@ -614,7 +619,7 @@ def out_layer_fwd_ce(p, idx, h, n_dst, w_self, w_neigh, b_self, b_neigh, labels,
     _launch("ogl_out_layer_fwd_ce", _lib.lib().ogl_out_layer_fwd_ce, _ptr(p), _ld(p), p.shape[0], _ptr(idx), n_dst, int(idx.shape[1]),
             _ptr(h), _ld(h), K, _ptr(w_self), _ld(w_self), _ptr(w_neigh), _ld(w_neigh), _ptr(b_self), _ptr(b_neigh), N, _ptr(neigh),
             _ld(neigh), _ptr(argmax), _ptr(logits), _ld(logits), _ptr(table), table.numel(), _ptr(ids), C.c_float(1.0 / n_dst),
-            _ptr(loss), _ptr(dl), _ld(dl) if dl is not None else 0, _ptr(mean) if want_mean else None, ce_counter(dev, stream), _ptr(zero), zn,
+            _ptr(loss), _ptr(dl), _ld(dl) if dl is not None else 0, _ptr(mean), ce_counter(dev, stream) if want_mean else None, _ptr(zero), zn,
             OUT_FWD_ROWS, stream, meta=dict(n_dst=n_dst, fanout=int(idx.shape[1]), d=K, N=N, zero_bytes=4 * zn))
     return mean, loss, logits, neigh, argmax, dl
 
@@ -1226,15 +1231,36 @@ _SLABS = {"on": False, "pending": {}}
 
 
 class SlabGrad:
-    __slots__ = ("ws", "stride", "ws_ld", "nsplit", "rows", "ncols", "col0")
+    """``out``: the (still unwritten) gradient tensor the product handed to autograd — where the plain reduction goes when the slabs
+    cannot be left to the optimiser after all (a second product for the same parameter in one backward pass)."""
+    __slots__ = ("ws", "stride", "ws_ld", "nsplit", "rows", "ncols", "col0", "out")
 
-    def __init__(self, ws, stride, ws_ld, nsplit, rows, ncols, col0):
+    def __init__(self, ws, stride, ws_ld, nsplit, rows, ncols, col0, out=None):
         self.ws, self.stride, self.ws_ld, self.nsplit, self.rows, self.ncols, self.col0 = ws, stride, ws_ld, nsplit, rows, ncols, col0
+        self.out = out
 
 
 def take_slabs(param):
     """The pending SlabGrad of ``param`` (removed from the table) or None."""
     return _SLABS["pending"].pop(param.data_ptr(), None) if _SLABS["pending"] else None
+
+
+def _slabs_settle(params):
+    """A SECOND weight-gradient product for a parameter whose slabs are still pending (shared weights, two forward passes summed into
+    one loss): the pending slabs are reduced into the tensor their product returned — autograd then adds two WRITTEN gradients — and
+    the caller runs its own product with the reduction launch.  True when the caller must not defer."""
+    pend, hit = _SLABS["pending"], False
+    for t in params:
+        if t is None:
+            continue
+        sg = pend.pop(t.data_ptr(), None)
+        if sg is not None:
+            hit = True
+            if sg.out is not None:
+                slab_reduce(sg, sg.out)
+        if t.grad is not None:                # gradient accumulation: the optimiser launch would overwrite what is already there
+            hit = True
+    return hit
 
 
 def slab_reduce(sg, out):
@@ -1265,7 +1291,12 @@ class deferred_splitk:
                 for p in group["params"]:
                     sg = pend.pop(p.data_ptr(), None)
                     if sg is not None and p.grad is not None and exc[0] is None:
-                        slab_reduce(sg, p.grad if p.grad.is_contiguous() else p.grad.contiguous())
+                        if p.grad.is_contiguous():
+                            slab_reduce(sg, p.grad)
+                        else:                                      # (reduced into a contiguous temporary, then copied into place)
+                            tmp = torch.empty(p.grad.shape, dtype=torch.float32, device=p.grad.device)
+                            slab_reduce(sg, tmp)
+                            p.grad.copy_(tmp)
             pend.clear()
         return False
 
@@ -1294,7 +1325,9 @@ def linear_bwd_weight_x3k(dyT_img, x_img, M, K, x_rows=None, x_nrows=None, inter
     if (defer_for is not None and _SLABS["on"] and dw_out is None and defer_for[0] is not None and tuple(defer_for[0].shape) == (N, K)
             and (db is None or defer_for[1] is not None) and (db2 is None or defer_for[2] is not None)
             # (whole PARAMETERS only: a view of one — the column slices of a concat -> Linear weight — shares its address)
-            and all(t is None or (t.is_leaf and t.is_contiguous()) for t in defer_for)):
+            and all(t is None or (t.is_leaf and t.is_contiguous()) for t in defer_for)
+            # (one product per parameter and backward pass, nothing accumulated yet: see _slabs_settle)
+            and not _slabs_settle(defer_for)):
         ns, wl = C.c_int(0), C.c_int64(0)
         _launch("ogl_linear_bwd_weight_x3k", _lib.lib().ogl_linear_bwd_weight_x3k_slabs, _ptr(dyT_img.buf), interleave, _ptr(x_img.buf),
                 x_img.rows, _ptr(_ids(x_rows) if x_rows is not None else None), x_img.rows if x_nrows is None else x_nrows, M, N, K,
@@ -1302,11 +1335,11 @@ def linear_bwd_weight_x3k(dyT_img, x_img, M, K, x_rows=None, x_nrows=None, inter
                 meta=dict(M=M, K=K, N=N, deferred=True))
         if ns.value > 1:
             pend, stride = _SLABS["pending"], N * wl.value
-            pend[defer_for[0].data_ptr()] = SlabGrad(ws, stride, wl.value, ns.value, N, K, 0)
+            pend[defer_for[0].data_ptr()] = SlabGrad(ws, stride, wl.value, ns.value, N, K, 0, dw)
             if db is not None:
-                pend[defer_for[1].data_ptr()] = SlabGrad(ws, stride, wl.value, ns.value, N, 1, K)
+                pend[defer_for[1].data_ptr()] = SlabGrad(ws, stride, wl.value, ns.value, N, 1, K, db)
             if db2 is not None:
-                pend[defer_for[2].data_ptr()] = SlabGrad(ws, stride, wl.value, ns.value, N, 1, K)
+                pend[defer_for[2].data_ptr()] = SlabGrad(ws, stride, wl.value, ns.value, N, 1, K, db2)
         return dw, db, db2
     _launch("ogl_linear_bwd_weight_x3k", _lib.lib().ogl_linear_bwd_weight_x3k, _ptr(dyT_img.buf), interleave, _ptr(x_img.buf),
             x_img.rows, _ptr(_ids(x_rows) if x_rows is not None else None), x_img.rows if x_nrows is None else x_nrows, M, N, K,
@@ -1973,6 +2006,8 @@ class _PoolMeanFn(torch.autograd.Function):
     def backward(ctx, dout):
         x, w, x_rows, p, idx = ctx.saved_tensors
         plan, ctx.seg_plan = ctx.seg_plan, None
+        if plan is None:                                  # (a second backward pass over a retained graph: the plan was consumed)
+            plan = reduce_bwd_seg_plan(idx, p.shape[1], p.shape[0], side=False)
         K = x.shape[1]
         rimg = _row_image_for(x, x_rows, None) if (_MODE["name"] != "f32" and ctx.n_src >= X3_BWW_MIN_ROWS) else None
         if rimg is not None and rimg.K == K + 1:
@@ -2190,7 +2225,7 @@ class _SagePoolLossFn(torch.autograd.Function):
     Returns (mean loss, per-seed losses, logits); only the mean is differentiable."""
 
     @staticmethod
-    def forward(ctx, h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels):
+    def forward(ctx, h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels, defer_mean=False):
         h = as_mat(h)
         ctx.h_relu_out = bool(getattr(h, "_ogl_relu_out", False))
         himg = take_image(h) if _n1_images_ok(h.shape[0], h.shape[1], w_pool.shape[0]) else None
@@ -2211,9 +2246,10 @@ class _SagePoolLossFn(torch.autograd.Function):
             buf = torch.empty((h.shape[0], padded_ld(h.shape[1])), dtype=torch.float32, device=h.device)
             ent = [buf, h.shape[0], h.shape[1], True]
         # The VALUE of the mean loss is written by the first launch of this node's backward (``finish_loss``): inside the forward
-        # launch it costs a device-scope fence per block (58 us instead of ~20 for 512 seeds, measured).  A loss nobody calls
-        # backward() on (``need`` false, or DEFER_LOSS_MEAN off) gets its mean from the forward launch.
-        ctx.defer_mean = bool(need and DEFER_LOSS_MEAN)
+        # launch it costs a device-scope fence per block (58 us instead of ~20 for 512 seeds, measured).  Only a caller that owns the
+        # backward may ask for that (``defer_mean``: the strategies' train steps, the captured step body); any other loss — one that is
+        # logged, guarded or never backpropagated — gets its mean from the forward launch.  A deferred mean reads NaN until it exists.
+        ctx.defer_mean = bool(need and DEFER_LOSS_MEAN and defer_mean)
         ctx.set_materialize_grads(False)             # (the gradients of the two non-differentiable outputs stay None: no zero fills)
         mean, rows, logits, neigh, argmax, dl = out_layer_fwd_ce(p, idx, h, n_dst, w_self, w_neigh, b_self, b_neigh, labels,
                                                                 want_grad=need, zero=ent[0] if ent is not None else None,
@@ -2237,17 +2273,17 @@ class _SagePoolLossFn(torch.autograd.Function):
         else:                                    # (a user's own root gradient: scaled into a matrix with the padded row stride)
             dy = empty_mat(dl.shape[0], dl.shape[1], dl.device)
             torch.mul(dl, dloss, out=dy)
-        return _out_layer_backward(ctx, dy, h, w_pool, w_self, w_neigh, neigh, argmax) + (None, None, None)
+        return _out_layer_backward(ctx, dy, h, w_pool, w_self, w_neigh, neigh, argmax) + (None, None, None, None)
 
 
-def sage_pool_layer_loss(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels):
+def sage_pool_layer_loss(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels, defer_mean=False):
     """(mean CE loss, per-seed losses, logits) of the last 'pool' layer + nn.CrossEntropyLoss, or None when the fused form does not
     apply (the caller then runs the layer and the loss separately)."""
     if h.dim() != 2 or small_pool_layer_fits(h.shape[0], n_dst, idx.shape[1], h.shape[1], w_self.shape[0]):
         return None
     if (b_self is None) != (b_neigh is None) or not out_loss_fits(h, n_dst, idx, w_self, w_neigh, w_pool.shape[0]):
         return None
-    return _SagePoolLossFn.apply(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels)
+    return _SagePoolLossFn.apply(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels, bool(defer_mean))
 
 
 SMALL_LAYER = True      # small 'pool' layers run as one launch forward + one launch backward (small_layer.hip)

@@ -105,7 +105,8 @@ class TrainStepGraph:
         if apply and hasattr(self.opt, "prime"):
             self.opt.prime()                          # (the optimiser's per-step scalars ride in the step's first launch)
         if self.loss_kind is not None:
-            loss, rows, _ = self.model.forward_loss(blocks, GatheredRows(g.feat_table, src0), labels, rows=self.loss_kind == "mean_rows")
+            loss, rows, _ = self.model.forward_loss(blocks, GatheredRows(g.feat_table, src0), labels, rows=self.loss_kind == "mean_rows",
+                                                    defer_mean=True)    # (every branch below runs the backward before anything reads it)
         else:
             logits = self.model(blocks, GatheredRows(g.feat_table, src0))
             loss, rows = self.loss_fn(logits, labels)

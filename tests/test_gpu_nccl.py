@@ -101,7 +101,7 @@ def _worker_reddit(forced, port, out_path):
     torch.save(res, out_path)
 
 
-def _worker_graphs(forced, port, out_path):
+def _worker_graphs(forced, port, out_path, capture_collectives=True):
     """Pubmed-size replicas: eager sharded steps vs steps replayed as captured graphs (``staged_dp``: forward, backward, BOTH RCCL
     all-reduces — the early bucket launched from the gradient hooks on the side branch — and the optimiser recorded into one
     hipGraph) with an RCCL communicator and its watchdog thread alive in the process."""
@@ -110,6 +110,8 @@ def _worker_graphs(forced, port, out_path):
     from ogl_amd import sampling, synthetic
     from ogl_amd.graphsage import GraphSAGE
     from ogl_amd.graphsage.model import RandomHipSupervisedGraphSage
+    from ogl_amd.graphsage import model as model_mod
+    model_mod.DP_CAPTURE_COLLECTIVES = bool(capture_collectives)      # (off by default since round 5: see graphsage/model.py)
     np.random.seed(3); random.seed(3); torch.manual_seed(3); sampling.seed(3)
     feat_size, labels, dyn, n_classes, _ = synthetic.load("pubmed", snapshots=3, device="cuda")
     dyn.evolve()
@@ -196,6 +198,17 @@ def test_dp_steps_replayed_as_graphs_beside_rccl(tmp_path):
     # (the first step learns the bucket split — a broadcast through the host — and runs as the eager twin; from then on every step,
     # the ragged last batch included, is ONE replayed graph that contains both all-reduces and the optimiser)
     assert r[False]["forms"] == ["sharded"] * 5 and r[True]["forms"] == ["staged_dp_eager"] + ["staged_dp"] * 4
+    for x, y in zip(r[False]["weights"], r[True]["weights"]):
+        torch.testing.assert_close(x, y, rtol=1e-4, atol=2e-5)
+
+
+def test_dp_steps_default_form_keeps_the_exchange_outside_the_graph(tmp_path):
+    """The DEFAULT replica step since round 5 (OGL_DP_CAPTURE_COLLECTIVES unset): forward + backward replayed, one flat-bucket RCCL
+    all-reduce and the optimiser enqueued from Python — the same weights as the sharded eager steps."""
+    out = str(tmp_path / "g0.pt")
+    _spawn1(_worker_graphs, (True, _free_port(), out, False))
+    r = torch.load(out, weights_only=False)
+    assert r[False]["forms"] == ["sharded"] * 5 and set(r[True]["forms"]) <= {"staged_dp", "staged_dp_eager"} and "staged_dp" in r[True]["forms"]
     for x, y in zip(r[False]["weights"], r[True]["weights"]):
         torch.testing.assert_close(x, y, rtol=1e-4, atol=2e-5)
 
