@@ -299,9 +299,9 @@ def sample_layer_batched(g: GraphHandle, dst_base: torch.Tensor, starts, counts,
 BLOCK_DIRECT = os.environ.get("OGL_BLOCK_DIRECT", "1") != "0"
 BLOCK_DIRECT_MAX_BYTES = 2 << 30
 # ... and only when the table is not much larger than what the batches put into it: the direct build touches 8 * n_ids bytes per batch
-# whatever the batch holds, the hash O(positions) — a 32-seed batch (21 k positions) on a 170 k-vertex graph stays on the hash, a
+# whatever the batch holds, the hash O(positions) — a 32-seed output block (832 positions) on a 170 k-vertex graph stays on the hash, a
 # 512-seed one (9.2 M positions over 50 batches of a 233 k-vertex graph) takes the table (measured there: 1.23 -> 0.30 ms)
-BLOCK_DIRECT_IDS_PER_POSITION = 4
+BLOCK_DIRECT_IDS_PER_POSITION = 16
 
 
 def build_block_batched_async(dst_base: torch.Tensor, starts, counts, picks: torch.Tensor, n_ids=None):
