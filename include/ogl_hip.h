@@ -283,6 +283,22 @@ int ogl_pool_bwd_x3_plan(const int32_t* argmax, const float* relu_out, int64_t l
                          int d, int64_t n_src, void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
 int ogl_pool_bwd_x3_apply(const float* dout, int64_t ldo, const int32_t* idx32, int64_t n_dst, int fanout, int d, int64_t n_src,
                           void* image, const void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
+/* The planned backward WITHOUT the dense image (round 5): dw[d, K] (and db[d], nullable) = dP^T . [x[x_rows] | 1], the weight gradient of
+ * fc_pool whose input carries no gradient (layer 0; autograd of relu -> max -> nn.Linear, R/train/graphsage/pytorch/aggregator_dgl.py:
+ * 85-94,171,199-206; live parameterisation R/inference_optimized.py:136-139,256-282) straight from `dout` and the plan
+ * ogl_pool_bwd_x3_plan left in `plan_workspace`: the values pass writes the (column, lane, value) records into their planned places, and
+ * the product's mover waves build every reduction step's dP^T tile in LDS from the records of that step's source group (pool_bwd_x3.hip,
+ * k_gemm_x3rf) — ogl_pool_bwd_x3_apply's 226 MB image (Reddit rung; 89 % zeros) is neither written nor read.
+ * x_img: the row-major bf16x3 image of x WITH the ones slot ([x_img_rows + zero row, K + 1], < 4 GB), x_rows (nullable) the block's
+ * source ids (ids outside [0, x_nrows) read the zero row).  `workspace` (ogl_pool_bwd_x3_dw_workspace_bytes) receives the split-K slabs
+ * [nsplit][d][ws_ld] (column K = the bias gradient); defer = 0: they are summed into dw / db (slab order); defer = 1: left to the
+ * consumer (ogl_adam_step_multi_slabs / ogl_x3_slab_reduce), *nsplit_out / *ws_ld_out say how many and how wide.
+ * Same results as ogl_pool_bwd_x3_apply + ogl_linear_bwd_weight_x3k up to the order of fp32 additions. */
+int64_t ogl_pool_bwd_x3_dw_workspace_bytes(int64_t n_src, int d, int K);
+int ogl_pool_bwd_x3_dw(const float* dout, int64_t ldo, int64_t n_dst, int fanout, int d, int64_t n_src, const void* plan_workspace,
+                       int64_t plan_workspace_bytes, const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int K,
+                       float* dw, int64_t lddw, float* db, void* workspace, int64_t workspace_bytes, int defer, int* nsplit_out,
+                       int64_t* ws_ld_out, ogl_stream_t stream);
 int64_t ogl_x3_row_bytes(int64_t K);
 int64_t ogl_x3_image_bytes(int64_t rows, int64_t K);
 int ogl_x3_split(const float* src, int64_t ld, const int64_t* rows, int64_t nrows, int64_t R, int K, int append,

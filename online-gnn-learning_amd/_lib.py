@@ -66,6 +66,9 @@ SIGNATURES = {
     "ogl_pool_bwd_x3": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i, _i, _i64, _p, _p, _i64, _p]),
     "ogl_pool_bwd_x3_plan": (_i, [_p, _p, _i64, _p, _i64, _i, _i, _i64, _p, _i64, _p]),
     "ogl_pool_bwd_x3_apply": (_i, [_p, _i64, _p, _i64, _i, _i, _i64, _p, _p, _i64, _p]),
+    "ogl_pool_bwd_x3_dw_workspace_bytes": (_i64, [_i64, _i, _i]),
+    "ogl_pool_bwd_x3_dw": (_i, [_p, _i64, _i64, _i, _i, _i64, _p, _i64, _p, _i64, _p, _i64, _i, _p, _i64, _p, _p, _i64, _i,
+                              C.POINTER(C.c_int), C.POINTER(C.c_int64), _p]),
     "ogl_x3_row_bytes": (_i64, [_i64]),
     "ogl_x3_image_bytes": (_i64, [_i64, _i64]),
     "ogl_x3_split": (_i, [_p, _i64, _p, _i64, _i64, _i, _i, _p, _p, _p]),

@@ -1207,6 +1207,45 @@ def pool_bwd_x3_apply(dout, idx32, plan, n_src):
     return X3Image(buf, d, 32 * G)
 
 
+# The layer-0 pool backward WITHOUT the dense dP^T image: the weight-gradient product's builder waves make each step's tile in LDS
+# from the plan's records (csrc/pool_bwd_x3.hip, k_gemm_x3rf).  Parity-green and OFF (OGL_POOL_RF=1 to take it): measured on a Reddit
+# block, alone, HIP events (tools/rf_probe.py, profiles/r05_rf_probe.txt) — round-4 pair (values + groups + dW_pool0 + slab sum)
+# 333-342 us; record-fed 602 us; its multipliers with nothing else running 212 us, + B pieces 250, + conversion 293, + the records
+# 560: LDS float atomics run at ~0.3 lane-operations per clock per CU on this part, every one of a slab's five column tiles
+# re-accumulates the same records, and the k-major 128 x 128 multipliers alone already take what the whole 256 x 128 image product takes.
+POOL_RF = os.environ.get("OGL_POOL_RF", "0") == "1"
+
+
+def pool_bwd_x3_dw(dout, idx32, plan, n_src, x_img, K, x_rows=None, x_nrows=None, want_bias=True, dw_out=None, defer_for=None):
+    """dw [d, K], db [d] of fc_pool from the pooled rows' gradient ``dout`` and a PoolPlan: ``ogl_pool_bwd_x3_dw`` (values pass + the
+    record-fed product).  ``x_img``: the row-major image of the projection input with the ones slot (K + 1), gathered by ``x_rows``.
+    ``defer_for`` as in ``linear_bwd_weight_x3k``."""
+    dout = as_mat(dout)
+    n_dst, d = dout.shape
+    assert plan.shape == (n_dst, idx32.shape[1], d, n_src) and idx32.dtype == torch.int32 and idx32.is_contiguous()
+    assert x_img.K == K + 1
+    _plan_ready(plan)
+    dev = dout.device
+    dw = dw_out if dw_out is not None else torch.empty((d, K), dtype=torch.float32, device=dev)
+    db = torch.empty(d, dtype=torch.float32, device=dev) if want_bias else None
+    nbytes = int(_lib.lib().ogl_pool_bwd_x3_dw_workspace_bytes(n_src, d, K))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    defer = (defer_for is not None and _SLABS["on"] and dw_out is None and defer_for[0] is not None and tuple(defer_for[0].shape) == (d, K)
+             and (db is None or defer_for[1] is not None)
+             and all(t is None or (t.is_leaf and t.is_contiguous()) for t in defer_for) and not _slabs_settle(defer_for))
+    ns, wl = C.c_int(0), C.c_int64(0)
+    _launch("ogl_pool_bwd_x3_dw", _lib.lib().ogl_pool_bwd_x3_dw, _ptr(dout), _ld(dout), n_dst, idx32.shape[1], d, n_src, _ptr(plan.ws),
+            plan.nbytes, _ptr(x_img.buf), x_img.rows, _ptr(_ids(x_rows) if x_rows is not None else None),
+            x_img.rows if x_nrows is None else x_nrows, K, _ptr(dw), _ld(dw), _ptr(db), _ptr(ws), nbytes, 1 if defer else 0,
+            C.byref(ns), C.byref(wl), _stream(), meta=dict(n_dst=n_dst, d=d, n_src=n_src, fanout=idx32.shape[1], M=n_src, K=K, N=d))
+    if defer:
+        pend, stride = _SLABS["pending"], d * wl.value
+        pend[defer_for[0].data_ptr()] = SlabGrad(ws, stride, wl.value, ns.value, d, K, 0, dw)
+        if db is not None:
+            pend[defer_for[1].data_ptr()] = SlabGrad(ws, stride, wl.value, ns.value, d, 1, K, db)
+    return dw, db
+
+
 def linear_bwd_weight_x3(dyT_img, xT_img, want_bias=True, dw_out=None):
     """dw [N, K], db [N] from the images of dy.T ([N rows, M]) and [x | 1].T ([K + 1 rows, M])."""
     N, M, K = dyT_img.rows, dyT_img.K, xT_img.rows - 1
@@ -2085,10 +2124,16 @@ class _PoolMaxFn(torch.autograd.Function):
             # layer 0: the projection input carries no gradient, so dP has one consumer — the weight gradient — and goes
             # straight from (dout, argmax) to the image of its transpose
             plan = getattr(ctx, "pool_plan", None)
-            dyT = pool_bwd_x3_apply(dout, idx32, plan, ctx.n_src) if plan is not None else pool_bwd_x3(dout, argmax, out, idx32, ctx.n_src)
             ctx.pool_plan = None
             G = (ctx.n_src + 31) // 32
             rimg = _row_image_for(x, x_rows, None)
+            if (POOL_RF and plan is not None and rimg is not None and rimg.K == x.shape[1] + 1
+                    and rimg.buf.numel() < (1 << 32)):
+                # the record-fed product: dP^T is built tile by tile in LDS from the plan's records, its 226 MB image never exists
+                dw, db = pool_bwd_x3_dw(dout, idx32, plan, ctx.n_src, rimg, x.shape[1], x_rows=x_rows, x_nrows=x.shape[0],
+                                        want_bias=ctx.has_bias, dw_out=_dw_out(w, *w.shape), defer_for=(w, ctx.bias_t, None))
+                return None, dw, (db if ctx.has_bias else None), None, None
+            dyT = pool_bwd_x3_apply(dout, idx32, plan, ctx.n_src) if plan is not None else pool_bwd_x3(dout, argmax, out, idx32, ctx.n_src)
             if rimg is not None and rimg.K == x.shape[1] + 1:
                 # the resident table's own image, its rows gathered in the dealt order of dP^T: no X^T image
                 dw, db, _ = linear_bwd_weight_x3k(dyT, rimg, ctx.n_src, x.shape[1], x_rows=x_rows, x_nrows=x.shape[0], interleave=G,

@@ -1,0 +1,112 @@
+"""Round 5: the record-fed layer-0 weight gradient, the deferred-mean contract, slab settling."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops as o
+    return o
+
+
+def _dP_reference(a, o, g, n_src, relu):
+    n_dst, D = a.shape
+    dP = np.zeros((n_src, D), np.float64)
+    cols = np.arange(D)
+    for d in range(n_dst):
+        m = a[d] >= 0
+        if relu:
+            m &= o[d] > 0
+        np.add.at(dP, (a[d, m], cols[m]), g[d, m])
+    return dP
+
+
+@pytest.mark.parametrize("n_dst,S,D,n_src,K,relu", [(1, 1, 1, 1, 3, True), (50, 4, 33, 70, 20, True), (300, 25, 602, 2000, 602, True),
+                                                     (2500, 10, 130, 900, 64, False), (700, 25, 64, 40, 31, True),
+                                                     (4100, 25, 40, 5000, 200, True), (7060, 25, 602, 62495, 602, True),
+                                                     (3000, 63, 640, 40000, 128, True)])
+def test_record_fed_weight_gradient(ops, n_dst, S, D, n_src, K, relu):
+    """ogl_pool_bwd_x3_dw (values pass + k_gemm_x3rf: the product's movers build dP^T tile by tile in LDS from the plan's records) ==
+    dP^T . [X[rows] | 1] in float64, and == the round-4 pair (dense image + k-major product) to fp32 summation order — hub sources,
+    missing neighbours, ReLU-dead winners, ragged tiles (D, K + 1 not multiples of 128), one-group and many-slab reductions."""
+    torch.manual_seed(n_dst + D)
+    rng = np.random.default_rng(n_dst * 3 + D)
+    idx = rng.integers(0, n_src, (n_dst, S)).astype(np.int32)
+    hubs = rng.random((n_dst, S)) < 0.3                                # a few heavily referenced sources (one group's lane 0 .. 2)
+    idx[hubs] = rng.integers(0, min(3, n_src), int(hubs.sum()))
+    idx[rng.random((n_dst, S)) < 0.05] = -1
+    idx_t = torch.as_tensor(idx).cuda()
+    p = torch.randn(n_src, D).clamp_min(0)
+    pm = ops.empty_mat(n_src, D, "cuda"); pm.copy_(p)
+    out, argmax = ops.reduce_fwd(pm, idx_t, "max", want_argmax=True)
+    dout = torch.randn(n_dst, D)
+    dm = ops.empty_mat(n_dst, D, "cuda"); dm.copy_(dout)
+    T = n_src + 37
+    tab = torch.randn(T, K)
+    tm = ops.empty_mat(T, K, "cuda"); tm.copy_(tab)
+    rows = torch.as_tensor(rng.permutation(T)[:n_src].astype(np.int64))
+    rimg = ops.x3_split(tm, append_ones=True)
+    dP = _dP_reference(argmax.cpu().numpy(), out.cpu().numpy(), dout.numpy().astype(np.float64), n_src, relu)
+    X = tab.numpy().astype(np.float64)[rows.numpy()]
+    dw_ref, db_ref = dP.T @ X, dP.sum(0)
+    scale = max(1.0, float(np.abs(dw_ref).max()))
+    got = {}
+    for side in (False, True):
+        plan = ops.pool_bwd_x3_plan(argmax, out if relu else None, idx_t, n_src, side=side)
+        dw, db = ops.pool_bwd_x3_dw(dm.clone(), idx_t, plan, n_src, rimg, K, x_rows=rows.cuda(), x_nrows=T)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(dw.cpu().numpy(), dw_ref, rtol=2e-5, atol=2e-5 * scale)
+        np.testing.assert_allclose(db.cpu().numpy(), db_ref, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(db_ref).max())))
+        got[side] = dw.cpu().numpy()
+    # the round-4 pair on the same inputs
+    plan = ops.pool_bwd_x3_plan(argmax, out if relu else None, idx_t, n_src, side=False)
+    dyT = ops.pool_bwd_x3_apply(dm.clone(), idx_t, plan, n_src)
+    G = (n_src + 31) // 32
+    dw4, db4, _ = ops.linear_bwd_weight_x3k(dyT, rimg, n_src, K, x_rows=rows.cuda(), x_nrows=T, interleave=G, want_bias=True)
+    np.testing.assert_allclose(got[False], dw4.cpu().numpy(), rtol=1e-5, atol=1e-5 * scale)
+    # repeatable: the same plan applied twice gives the same bits where every cell of dP has at most two contributions; run to run
+    # the sums may differ in the last place otherwise (ds_add_f32 order) — bounded here
+    np.testing.assert_allclose(got[False], got[True], rtol=1e-6, atol=2e-6 * scale)
+
+
+def test_pool_max_autograd_takes_the_record_fed_product(ops):
+    """pool_max over a registered table: its backward is plan (forward) + ogl_pool_bwd_x3_dw — no dense dP^T image, no separate
+    weight-gradient launch — and matches the unfused path; OGL_POOL_RF off restores the round-4 pair."""
+    torch.manual_seed(8)
+    T, K, H, n_src, n_dst, S = 40000, 50, 48, 20000, 1500, 25
+    tab = ops.empty_mat(T, K, "cuda"); tab.normal_()
+    rows = torch.randperm(T)[:n_src].cuda()
+    idx = torch.randint(0, n_src, (n_dst, S), dtype=torch.int32).cuda()
+    w = (torch.randn(H, K) / 7).cuda(); b = torch.randn(H).cuda()
+    gout = torch.randn(n_dst, H).cuda()
+    res = {}
+    old, old_rf = ops.get_gemm_mode(), ops.POOL_RF
+    try:
+        ops.set_gemm_mode("auto")
+        for tag in ("unfused", "rf", "image"):
+            if tag != "unfused":
+                ops.register_static_table(tab)
+            ops.POOL_RF = tag == "rf"
+            wv, bv = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            ops.profile_start()
+            out = ops.pool_max(tab, wv, bv, idx, rows)
+            out.backward(gout)
+            names = [r[0] for r in ops.profile_stop()]
+            res[tag] = (out.detach(), wv.grad, bv.grad, names)
+    finally:
+        ops.set_gemm_mode(old)
+        ops.POOL_RF = old_rf
+        ops._X3_TABLES.clear()
+    if ops.POOL_PLAN:
+        assert "ogl_pool_bwd_x3_dw" in res["rf"][3] and "ogl_pool_bwd_x3_apply" not in res["rf"][3]
+        assert "ogl_linear_bwd_weight_x3k" not in res["rf"][3]
+        assert "ogl_pool_bwd_x3_apply" in res["image"][3] and "ogl_pool_bwd_x3_dw" not in res["image"][3]
+    scale = float(res["unfused"][1].abs().max())
+    for tag in ("rf", "image"):
+        np.testing.assert_allclose(res[tag][0].cpu().numpy(), res["unfused"][0].cpu().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(res[tag][1].cpu().numpy(), res["unfused"][1].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+        np.testing.assert_allclose(res[tag][2].cpu().numpy(), res["unfused"][2].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)

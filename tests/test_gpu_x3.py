@@ -344,8 +344,9 @@ def test_pool_max_autograd_uses_fused_backward(ops):
         ops._X3_TABLES.clear()
     names = res["fused"][3]
     assert "ogl_reduce_bwd" not in names
-    if ops.POOL_PLAN:                      # the gradient-free half planned by the forward pass, the group pass in backward
-        assert names.index("ogl_pool_bwd_x3_plan") < names.index("ogl_pool_bwd_x3_apply") and "ogl_pool_bwd_x3" not in names
+    if ops.POOL_PLAN:                      # the gradient-free half planned by the forward pass; the backward consumes the plan
+        consumer = "ogl_pool_bwd_x3_dw" if ops.POOL_RF else "ogl_pool_bwd_x3_apply"     # (round 5: the record-fed product)
+        assert names.index("ogl_pool_bwd_x3_plan") < names.index(consumer) and "ogl_pool_bwd_x3" not in names
     else:
         assert "ogl_pool_bwd_x3" in names
     np.testing.assert_allclose(res["fused"][0].cpu().numpy(), res["unfused"][0].cpu().numpy(), rtol=1e-5, atol=1e-5)
