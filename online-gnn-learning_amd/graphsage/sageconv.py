@@ -173,6 +173,8 @@ class SAGEConv(nn.Module):
                 h_neigh = ops.pool_mean(feat.table if lazy else feat, self.fc_pool.weight, self.fc_pool.bias, idx, feat.ids if lazy else None)
             else:
                 p = self._project(self.fc_pool, feat, relu=True)
+                if ops._CAPTURE is not None:
+                    ops._CAPTURE.append(dict(pool_out=p.detach()))      # (test hook, see ops.capture_pool_winners)
                 h_neigh = ops.neighbor_reduce(p, idx, "mean")
             rst = self._linear_cat(feat_dst, h_neigh, fuse_relu)
         elif t == "mean":

@@ -2036,6 +2036,8 @@ class _PoolMeanFn(torch.autograd.Function):
             attach_image(out, img)
         else:
             out, _ = reduce_fwd(p, idx, "mean")
+        if _CAPTURE is not None:
+            _CAPTURE.append(dict(pool_out=p))          # (test hook: the device's own ReLU decisions of the pooled projection)
         ctx.n_src, ctx.fanout, ctx.has_bias, ctx.bias_t = p.shape[0], idx.shape[1], bias is not None, bias
         ctx.seg_plan = reduce_bwd_seg_plan(idx, p.shape[1], p.shape[0]) if need else None
         ctx.save_for_backward(x, w, x_rows, p, idx)
@@ -2072,7 +2074,8 @@ def pool_mean(x, w, bias, idx, x_rows=None):
 
 # Test hook: while a list is installed, every differentiable pool layer appends dict(argmax, neigh[, out]) — the winners and
 # ReLU masks the device chose — so that a parity test can route the oracle's backward through the same winners
-# (tests/test_gpu_fullsize.py).  Not used by the product path.
+# (tests/test_gpu_fullsize.py); the in-repo 'meanpool' layers append dict(pool_out) (the ReLU'd pooled projection).  Not used by
+# the product path.
 _CAPTURE = None
 
 

@@ -288,7 +288,7 @@ def _lstm_last_hidden(rows, params):
     return h
 
 
-def sageconv_forward(mode, h_src, n_dst, local_idx, params, activation=None, forced=None, dropout=None):
+def sageconv_forward(mode, h_src, n_dst, local_idx, params, activation=None, forced=None, dropout=None, trace=None):
     """One SAGEConv layer on a fixed-fanout block.
 
     mode ``pool``      — live DGL layer (max; fc_pool in->in; fc_self + fc_neigh).
@@ -296,8 +296,12 @@ def sageconv_forward(mode, h_src, n_dst, local_idx, params, activation=None, for
     (fc_pool in->pool_feats; ``fc_neigh(cat(h_self, h_neigh))``; gcn: ``(sum + h_dst)/(deg+1)``).
     ``params``: dict of torch tensors named like the reference state_dict
     (fc_pool.weight, fc_pool.bias, fc_self.*, fc_neigh.*).
-    ``forced`` (mode ``pool`` only): the device's winners / ReLU masks, see :func:`_neigh_torch`; an optional
-    ``act_mask`` replaces the output ReLU by the device's mask of it.
+    ``forced`` (mode ``pool``): the device's winners / ReLU masks, see :func:`_neigh_torch`; an optional
+    ``act_mask`` replaces the output ReLU by the device's mask of it (any mode).  In-repo pooling modes: an optional ``pool_mask``
+    (bool [n_src, pool_feats]) replaces ``relu(fc_pool(h))`` by ``where(pool_mask, fc_pool(h), 0)`` — the same function wherever the
+    two evaluations agree on the sign, and a unit within rounding of 0 is routed the way the device routed it.
+    ``trace`` (a list): appends dict(pool_mask=..., act_mask=...) — THIS evaluation's own ReLU decisions (numpy bool, None where the
+    layer has none) — so that a test can count where two evaluations disagree.
     ``dropout``: dict(p, seed, ctr) — ``feat_drop`` on the layer input (R/.../graphsage_dgl.py:41 passes
     ``feat_drop=dropout``), with the counter-based mask of :func:`dropout_mask`.
     """
@@ -306,6 +310,7 @@ def sageconv_forward(mode, h_src, n_dst, local_idx, params, activation=None, for
         h_src = torch.where(keep, h_src / np.float32(1.0 - dropout["p"]), torch.zeros((), dtype=h_src.dtype))
     h_dst = h_src[:n_dst]
     li = np.asarray(local_idx)
+    own_pool_mask = None
     if mode == "pool":
         pre = F.linear(h_src, params["fc_pool.weight"], params["fc_pool.bias"])
         if forced is not None:
@@ -315,7 +320,12 @@ def sageconv_forward(mode, h_src, n_dst, local_idx, params, activation=None, for
         rst = F.linear(h_dst, params["fc_self.weight"], params["fc_self.bias"]) + \
             F.linear(neigh, params["fc_neigh.weight"], params["fc_neigh.bias"])
     elif mode in ("meanpool", "maxpool"):
-        p = F.relu(F.linear(h_src, params["fc_pool.weight"], params["fc_pool.bias"]))
+        pre = F.linear(h_src, params["fc_pool.weight"], params["fc_pool.bias"])
+        own_pool_mask = (pre.detach() > 0).numpy()
+        if forced is not None and forced.get("pool_mask") is not None:
+            p = torch.where(torch.as_tensor(np.asarray(forced["pool_mask"]), dtype=torch.bool), pre, torch.zeros((), dtype=pre.dtype))
+        else:
+            p = F.relu(pre)
         neigh = _neigh_torch(p, li, "mean" if mode == "meanpool" else "max")
         rst = F.linear(torch.cat((h_dst, neigh), 1), params["fc_neigh.weight"], params["fc_neigh.bias"])
     elif mode == "mean":
@@ -337,6 +347,8 @@ def sageconv_forward(mode, h_src, n_dst, local_idx, params, activation=None, for
         rst = F.linear(neigh, params["fc_neigh.weight"], params["fc_neigh.bias"])
     else:
         raise KeyError("Aggregator type {} not recognized.".format(mode))
+    if trace is not None:
+        trace.append(dict(pool_mask=own_pool_mask, act_mask=(rst.detach() > 0).numpy() if activation is not None else None))
     if activation is not None:
         if forced is not None and forced.get("act_mask") is not None:
             rst = torch.where(torch.as_tensor(np.asarray(forced["act_mask"]), dtype=torch.bool), rst,
@@ -346,16 +358,16 @@ def sageconv_forward(mode, h_src, n_dst, local_idx, params, activation=None, for
     return rst
 
 
-def graphsage_forward(mode, x, blocks, layer_params, forced=None, dropout=None):
+def graphsage_forward(mode, x, blocks, layer_params, forced=None, dropout=None, trace=None):
     """R/train/graphsage/pytorch/graphsage_dgl.py:48-59 — relu on every layer but the last.
-    ``forced`` / ``dropout``: per-layer lists (entries may be None), see :func:`sageconv_forward`."""
+    ``forced`` / ``dropout``: per-layer lists (entries may be None), see :func:`sageconv_forward`; ``trace``: one entry per layer."""
     h = x
     L = len(layer_params)
     for l, (blk, prm) in enumerate(zip(blocks, layer_params)):
         h = sageconv_forward(mode, h, len(blk["dst_ids"]), blk["local_idx"], prm,
                              activation=F.relu if l < L - 1 else None,
                              forced=forced[l] if forced is not None else None,
-                             dropout=dropout[l] if dropout is not None else None)
+                             dropout=dropout[l] if dropout is not None else None, trace=trace)
     return h
 
 
@@ -449,8 +461,20 @@ class CpuModel:
                 prm[k].requires_grad_(True)
         self.opt = torch.optim.Adam([t for prm in self.params for t in prm.values()], lr=1e-3)
 
-    def forward(self, x, blocks, forced=None, dropout=None):
-        return graphsage_forward(self.mode, x, blocks, self.params, forced=forced, dropout=dropout)
+    def forward(self, x, blocks, forced=None, dropout=None, trace=None):
+        return graphsage_forward(self.mode, x, blocks, self.params, forced=forced, dropout=dropout, trace=trace)
+
+    def loss_and_grads(self, feat, labels, indptr, indices, deg_t, seeds, fanout, seed, ctr, forced=None, trace=None):
+        """Loss and gradients of ONE batch WITHOUT the optimiser step (the weights stay): (loss, {"layers.i.name": grad clone})."""
+        input_nodes, seeds, blocks = sample_blocks(indptr, indices, deg_t, seeds, [fanout, fanout], seed, ctr)
+        x = feat[torch.as_tensor(input_nodes)]
+        y = labels[torch.as_tensor(seeds)]
+        self.opt.zero_grad()
+        loss = cross_entropy(self.forward(x, blocks, forced=forced, trace=trace), y, "mean")
+        loss.backward()
+        grads = {"layers.%d.%s" % (i, k): v.grad.detach().clone() for i, prm in enumerate(self.params) for k, v in prm.items()}
+        self.opt.zero_grad()
+        return float(loss.detach()), grads
 
     def train_step(self, feat, labels, indptr, indices, deg_t, seeds, fanout, seed, ctr, forced=None):
         input_nodes, seeds, blocks = sample_blocks(indptr, indices, deg_t, seeds, [fanout, fanout], seed, ctr)

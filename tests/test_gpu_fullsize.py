@@ -220,9 +220,10 @@ def test_fullsize_free_running_steps_track_the_oracle(reddit):
 @pytest.mark.parametrize("mode", ["meanpool", "mean"])
 def test_fullsize_inrepo_modes_step_matches_oracle(reddit, mode):
     """One RBR train step at the Reddit rung in the in-repo aggregator modes (R/train/graphsage/pytorch/aggregator_dgl.py:156-159,
-    178-186; latent_dim 600 as R/settings/reddit.json:1) against the torch-CPU oracle: the loss at rtol 1e-4, every gradient at
-    1e-3 relative Frobenius norm (a mean has no winners to flip; what remains are ReLU decisions of units within rounding of 0),
-    the weights after the Adam step at the rung tests' Adam-aware bound."""
+    178-186, 199-206; latent_dim 600 as R/settings/reddit.json:1) against the torch-CPU oracle: the loss at rtol 1e-4; every gradient at
+    1e-5 relative Frobenius norm against the oracle's backward evaluated through the DEVICE's ReLU masks (at most 64 of the ~42 M
+    decisions differ), and at 1e-3 against the unforced oracle (a mean has no winners to flip; what remains there are exactly those
+    units within rounding of 0); the weights after the Adam step at the rung tests' Adam-aware bound."""
     from ogl_amd import ops, optim, sampling
     from ogl_amd.graphsage import GatheredRows, GraphSAGE
     a, dyn, g, host = reddit
@@ -244,10 +245,41 @@ def test_fullsize_inrepo_modes_step_matches_oracle(reddit, mode):
         sampling.seed(6)
         (input_nodes, sd, blocks), = list(sampling.NodeDataLoader(g, torch.as_tensor(seeds), sampling.MultiLayerNeighborSampler([S, S]), batch_size=B))
         opt.zero_grad()
-        loss, _, _ = model.forward_loss(blocks, GatheredRows(g.ndata["feat"], input_nodes), ops.gather_i64(g.ndata["target"], sd))
+        store, h1_seen = [], []
+        hook = model.layers[0].register_forward_hook(lambda mod, inp, out: h1_seen.append(out.detach()))
+        ops.capture_pool_winners(store)
+        try:
+            loss, _, _ = model.forward_loss(blocks, GatheredRows(g.ndata["feat"], input_nodes), ops.gather_i64(g.ndata["target"], sd))
+        finally:
+            ops.capture_pool_winners(None)
+            hook.remove()
         ops.backward(loss)
+        dev_grads = {"layers.%d.%s" % (li, k): getattr(getattr(l, k.split(".")[0]), k.split(".")[1]).grad.detach().cpu().clone()
+                     for li, (l, prm) in enumerate(zip(model.layers, cpu.params)) for k in prm}
         opt.step()
         feat_cpu, lab_cpu = a["feat"], torch.as_tensor(a["labels"]).reshape(-1, 1)
+        # ---- the SHARP gradient check (round 5): the oracle's backward routed through the DEVICE's own ReLU decisions — the pooled
+        # projections' masks of both layers ('meanpool') and the hidden layer's activation mask — exactly as the 'pool' test routes
+        # the device's winners.  What two fp32 evaluations disagree on is then counted, not averaged into a tolerance.
+        pools = [e["pool_out"] for e in store if "pool_out" in e]
+        assert len(pools) == (2 if mode == "meanpool" else 0) and len(h1_seen) == 1
+        forced = [dict(pool_mask=(pools[0] > 0).cpu().numpy() if pools else None, act_mask=(h1_seen[0] > 0).cpu().numpy()),
+                  dict(pool_mask=(pools[1] > 0).cpu().numpy() if pools else None)]
+        trace = []
+        loss_plain, _ = cpu.loss_and_grads(feat_cpu, lab_cpu, host["indptr"], host["indices"], deg, seeds, S, 6, 0, trace=trace)
+        loss_forced, g_forced = cpu.loss_and_grads(feat_cpu, lab_cpu, host["indptr"], host["indices"], deg, seeds, S, 6, 0, forced=forced)
+        flips = 0
+        for f, t in zip(forced, trace):
+            for key in ("pool_mask", "act_mask"):
+                if f.get(key) is not None:
+                    flips += int((np.asarray(f[key]) != t[key]).sum())
+        rel_forced = {k: float(np.linalg.norm(dev_grads[k].numpy() - v.numpy()) / np.linalg.norm(v.numpy())) for k, v in g_forced.items()}
+        print("%s: ReLU decisions on which device and oracle disagree: %d; loss plain %.7f forced %.7f device %.7f; forced-mask relative "
+              "gradient errors: %s" % (mode, flips, loss_plain, loss_forced, float(loss), {k: "%.2e" % r for k, r in rel_forced.items()}))
+        assert flips <= 64, flips
+        assert abs(loss_forced - loss_plain) <= 1e-5 * abs(loss_plain)       # (forcing moves the value by less than its rounding)
+        for k, r in rel_forced.items():
+            assert r <= 1e-5, (k, r, rel_forced)
         want = cpu.train_step(feat_cpu, lab_cpu, host["indptr"], host["indices"], deg, seeds, S, 6, 0)
         assert abs(float(loss) - want) <= 1e-4 * abs(want), (float(loss), want)
         rels, bad, total = {}, 0, 0
