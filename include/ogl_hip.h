@@ -150,6 +150,13 @@ int ogl_reduce_fwd_img(const float* src, int64_t lds, int64_t n_src, const int32
  * sum divided by the fanout, + the bf16x3 image of the result (no argmax). */
 int ogl_reduce_fwd_mean_img(const float* src, int64_t lds, int64_t n_src, const int32_t* idx32, const int64_t* idx64, int64_t n_dst,
                             int fanout, int d, float* out, int64_t ldo, void* image, ogl_stream_t stream);
+/* ... over rows of a resident TABLE through a block's local indices: out[d] = mean_j table[rows[idx32[d, j]]] (slot order; an index
+ * outside [0, n_rows) or a row id outside [0, n_table) counts as no neighbour) + the bf16x3 image of out — the first layer of the
+ * in-repo 'mean' mode (R/train/graphsage/pytorch/aggregator_dgl.py:156-159) reading graph.ndata['feat'] where it lies
+ * (R/train/graphsage/pytorch/model.py:88 gathers feat[input_nodes] first).  n_table < 2^31; operands as for ogl_reduce_fwd_img. */
+int ogl_reduce_fwd_rows_mean_img(const float* table, int64_t ldt, int64_t n_table, const int32_t* idx32, const int64_t* rows,
+                                 int64_t n_rows, int64_t n_dst, int fanout, int d, float* out, int64_t ldo, void* image,
+                                 ogl_stream_t stream);
 int ogl_reduce_bwd(const float* dout, int64_t ldo, const int32_t* idx32, const int32_t* argmax,
                    const float* relu_out, int64_t ldr, int64_t n_dst, int fanout, int d, int op,
                    int64_t n_src, float* dsrc, int64_t lds, ogl_stream_t stream);

@@ -31,7 +31,10 @@ template <int OP, typename IdxT, bool ARG, int NCH, bool IMG = false, int U = (N
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK)
 k_reduce_fwd_v4(const float* __restrict__ src, int64_t lds, int64_t n_src, const IdxT* __restrict__ idx,
                 int64_t n_dst, int S, int d, float* __restrict__ out, int64_t ldo,
-                int32_t* __restrict__ argmax, int parts, unsigned char* __restrict__ img = nullptr, int64_t img_row_bytes = 0) {
+                int32_t* __restrict__ argmax, int parts, unsigned char* __restrict__ img = nullptr, int64_t img_row_bytes = 0,
+                const int64_t* __restrict__ rows = nullptr, int64_t n_rows = 0) {
+  // rows (optional): idx holds positions into `rows`, the reduced row is src[rows[idx]] — a block's local indices over the
+  // resident table through the block's source ids (one more dependent load per WAVE, not per neighbour row)
   const int lane = threadIdx.x & 63;
   const int64_t wg = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   const int64_t w = wg / parts;
@@ -51,6 +54,10 @@ k_reduce_fwd_v4(const float* __restrict__ src, int64_t lds, int64_t n_src, const
   for (int s0 = 0; s0 < S; s0 += 64) {
     const int sc = min(64, S - s0);
     IdxT mine = lane < sc ? idx[w * S + s0 + lane] : (IdxT)-1;
+    if (rows) {
+      const int64_t m = (int64_t)mine;
+      mine = (m >= 0 && m < n_rows) ? (IdxT)rows[m] : (IdxT)-1;
+    }
     for (int j0 = 0; j0 < sc; j0 += U) {
       // The U x NCH row loads are issued back to back with nothing between them that needs a wait: all row ids are
       // broadcast first (scalars), a missing row (past S, id -1, id >= n_src) reads row 0 and is skipped below, a lane
@@ -176,7 +183,7 @@ k_reduce_fwd_generic(const float* __restrict__ src, int64_t lds, int64_t n_src, 
 template <int OP, typename IdxT, bool ARG>
 static int launch_reduce_fwd(const float* src, int64_t lds, int64_t n_src, const IdxT* idx, int64_t n_dst,
                              int S, int d, float* out, int64_t ldo, int32_t* argmax, hipStream_t stream,
-                             unsigned char* img = nullptr) {
+                             unsigned char* img = nullptr, const int64_t* rows = nullptr, int64_t n_rows = 0) {
   dim3 grid((unsigned)ogl_cdiv(n_dst, WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
   const int d4 = (d + 3) / 4;
   const bool vec = (lds % 4 == 0) && (ldo % 4 == 0) && (lds >= 4 * d4) && (ldo >= 4 * d4) &&
@@ -192,13 +199,14 @@ static int launch_reduce_fwd(const float* src, int64_t lds, int64_t n_src, const
   if (img) {
     if (!vec) return OGL_EINVAL;     // the image form exists for the vectorised kernels (the 'pool' / 'meanpool' layers)
     const int64_t irb = ogl_cdiv(d, 32) * 192;
-    if (cper <= 64) hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 1, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb);
-    else if (cper <= 128) hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 2, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb);
-    else if (cper <= 192) hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 3, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb);
-    else hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 4, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb);
+    if (cper <= 64) hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 1, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb, rows, n_rows);
+    else if (cper <= 128) hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 2, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb, rows, n_rows);
+    else if (cper <= 192) hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 3, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb, rows, n_rows);
+    else hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 4, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb, rows, n_rows);
     OGL_CHECK_LAUNCH();
     return OGL_OK;
   }
+  if (rows) return OGL_EINVAL;       // (the indirection exists in the image form)
   if (!vec) {
     hipLaunchKernelGGL((k_reduce_fwd_generic<OP, IdxT, ARG>), grid, block, 0, stream, src, lds, n_src, idx,
                        n_dst, S, d, out, ldo, argmax);
@@ -275,6 +283,18 @@ extern "C" int ogl_reduce_fwd_mean_img(const float* src, int64_t lds, int64_t n_
   unsigned char* im = (unsigned char*)image;
   if (idx32) return launch_reduce_fwd<OGL_REDUCE_MEAN, int32_t, false>(src, lds, n_src, idx32, n_dst, fanout, d, out, ldo, nullptr, st, im);
   return launch_reduce_fwd<OGL_REDUCE_MEAN, int64_t, false>(src, lds, n_src, idx64, n_dst, fanout, d, out, ldo, nullptr, st, im);
+}
+
+// The MEAN over rows of a resident TABLE through a block's local indices: out[d] = mean_j table[rows[idx32[d, j]]] + its image — the
+// aggregator of the in-repo 'mean' mode's first layer (aggregator_dgl.py:156-159) without materialising feat[input_nodes]
+// (R/train/graphsage/pytorch/model.py:88): the gathered copy (n0 x 2.4 KB written and read back) never exists.  Table ids < 2^31.
+extern "C" int ogl_reduce_fwd_rows_mean_img(const float* table, int64_t ldt, int64_t n_table, const int32_t* idx32, const int64_t* rows,
+                                            int64_t n_rows, int64_t n_dst, int fanout, int d, float* out, int64_t ldo, void* image,
+                                            ogl_stream_t stream) {
+  if (n_dst <= 0 || fanout <= 0 || d <= 0 || n_table <= 0 || n_table >= (1ll << 31) || n_rows < 0 || ldt < d || (out && ldo < d)) return OGL_EINVAL;
+  if (!table || !idx32 || !rows || !image || ((uintptr_t)image & 15)) return OGL_EINVAL;
+  return launch_reduce_fwd<OGL_REDUCE_MEAN, int32_t, false>(table, ldt, n_table, idx32, n_dst, fanout, d, out, ldo, nullptr, (hipStream_t)stream,
+                                                            (unsigned char*)image, rows, n_rows);
 }
 
 // ---- backward ----------------------------------------------------------------------------------

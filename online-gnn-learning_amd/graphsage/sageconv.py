@@ -178,8 +178,16 @@ class SAGEConv(nn.Module):
                 h_neigh = ops.neighbor_reduce(p, idx, "mean")
             rst = self._linear_cat(feat_dst, h_neigh, fuse_relu)
         elif t == "mean":
-            src = feat.materialize() if lazy else feat
-            h_neigh = ops.neighbor_reduce(src, idx, "mean")
+            if (lazy and idx.dtype == torch.int32 and ops._n1_images_ok(n_dst, feat.shape[1], self._out_feats)
+                    and not feat.table.requires_grad and ops._static_key(feat.table) in ops._X3_TABLES):
+                # the first layer over the resident table (features carry no gradient): the mean straight from the table's rows
+                # through the block's source ids, its image beside it — no feat[input_nodes] copy, and the combine below takes the
+                # image kernel (the table's own image rows for h_self, this image for h_neigh)
+                h_neigh, img = ops.reduce_fwd_rows_mean_img(feat.table, feat.ids, idx)
+                ops.attach_image(h_neigh, img)
+            else:
+                src = feat.materialize() if lazy else feat
+                h_neigh = ops.neighbor_reduce(src, idx, "mean")
             rst = self._linear_cat(feat_dst, h_neigh, fuse_relu)
         elif t == "lstm":
             # aggregator_dgl.py:116-126,195-199: h_n of nn.LSTM over each destination's mailbox (slot order), zero initial state;

@@ -459,6 +459,22 @@ def reduce_fwd_mean_img(src: torch.Tensor, idx: torch.Tensor):
     return out, img
 
 
+def reduce_fwd_rows_mean_img(table: torch.Tensor, rows: torch.Tensor, idx: torch.Tensor):
+    """(mean_j table[rows[idx[d, j]]], its X3Image): the mean over rows of a resident table through a block's local indices — the
+    gathered copy ``table[rows]`` is never made."""
+    table = as_mat(table)
+    assert idx.is_cuda and idx.dim() == 2 and idx.is_contiguous() and idx.dtype == torch.int32 and table.shape[0] < (1 << 31)
+    rows = _ids(rows)
+    n_dst, fanout = idx.shape
+    d = table.shape[1]
+    out = empty_mat(n_dst, d, table.device)
+    img = X3Image(_x3_alloc(n_dst, d, table.device), n_dst, d)
+    _launch("ogl_reduce_fwd_img", _lib.lib().ogl_reduce_fwd_rows_mean_img, _ptr(table), _ld(table), table.shape[0], _ptr(idx), _ptr(rows),
+            rows.numel(), n_dst, fanout, d, _ptr(out), _ld(out), _ptr(img.buf), _stream(),
+            meta=dict(n_dst=n_dst, fanout=fanout, d=d, op="mean", argmax=False, idx_bytes=4, out=True, table_rows=True))
+    return out, img
+
+
 def reduce_bwd(dout: torch.Tensor, idx32, argmax, op: str, n_src: int, fanout=None, relu_out=None, dsrc=None) -> torch.Tensor:
     """``dsrc``: an already ZEROED [n_src, d] matrix to scatter into (``take_zeroed``); default: allocated and cleared here."""
     dout = as_mat(dout)
@@ -1994,7 +2010,7 @@ class _ReduceFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, idx, op):
         need_grad = src.requires_grad
-        if op == "mean" and _n1_images_ok(idx.shape[0], src.shape[1]) and as_mat(src).shape[1] % 4 == 0:
+        if op == "mean" and _n1_images_ok(idx.shape[0], src.shape[1]):
             out, img = reduce_fwd_mean_img(src, idx)         # tall: the combine product reads the image of the pooled rows
             attach_image(out, img)
             argmax = None

@@ -110,3 +110,25 @@ def test_pool_max_autograd_takes_the_record_fed_product(ops):
         np.testing.assert_allclose(res[tag][0].cpu().numpy(), res["unfused"][0].cpu().numpy(), rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(res[tag][1].cpu().numpy(), res["unfused"][1].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
         np.testing.assert_allclose(res[tag][2].cpu().numpy(), res["unfused"][2].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+
+
+@pytest.mark.parametrize("n_dst,S,D,n_rows,T", [(1, 1, 4, 1, 3), (300, 25, 602, 2000, 5000), (7060, 25, 602, 62495, 232965), (700, 10, 128, 40, 90)])
+def test_table_direct_mean_equals_the_mean_over_gathered_rows(ops, n_dst, S, D, n_rows, T):
+    """ogl_reduce_fwd_rows_mean_img: mean_j table[rows[idx[d, j]]] read where the table lies == the mean over the materialised
+    feat[input_nodes] copy (R/train/graphsage/pytorch/model.py:88 + aggregator_dgl.py:156-159), bit for bit, values and image;
+    out-of-range positions and row ids count as missing neighbours."""
+    rng = np.random.default_rng(n_dst + D)
+    tab = ops.empty_mat(T, D, "cuda"); tab.normal_()
+    rows = torch.as_tensor(rng.integers(0, T, n_rows).astype(np.int64)).cuda()
+    idx = rng.integers(0, n_rows, (n_dst, S)).astype(np.int32)
+    idx[rng.random((n_dst, S)) < 0.05] = -1
+    if n_dst > 1:
+        idx[1, :] = -1                                              # a destination without neighbours: zeros
+    idx_t = torch.as_tensor(idx).cuda()
+    got, gimg = ops.reduce_fwd_rows_mean_img(tab, rows, idx_t)
+    gathered = ops.gather_rows(tab, rows)
+    want, wimg = ops.reduce_fwd_mean_img(gathered, idx_t)
+    assert torch.equal(got, want)
+    assert torch.equal(gimg.buf, wimg.buf)
+    if n_dst > 1:
+        assert float(got[1].abs().max()) == 0.0
