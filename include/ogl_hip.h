@@ -551,6 +551,18 @@ int ogl_stage_segments(int nseg, const void* const* src, void* const* dst, const
  * into the device); the kernel stores src[0..n) there, then — behind a system-scope fence — the sequence number ++*seq_dev at
  * dst_host_mapped[n], which the host polls for. */
 int ogl_publish_i64(const int64_t* src, int n, int64_t* seq_dev, int64_t* dst_host_mapped, ogl_stream_t stream);
+/* The whole SAMPLING phase of a small batch in one launch (block.hip, k_sample_blocks_small): [Philox batch counter | B seeds] is read
+ * from host-mapped memory into head_dev, the output block (fanout picks per seed, layer 1) and the input block (fanout picks per
+ * source found, layer 0) are sampled and relabelled, and the two source counts go to the host as ogl_publish_i64 would send them
+ * (counts_host_mapped[0 .. 1], then ++*seq_dev behind a system-scope fence into [2]).  Results as ogl_sample_layer_dev +
+ * ogl_build_block_padded on the same shapes: src1 [B (1 + fanout)] / src0 [B (1 + fanout)^2] padded with -1, lidx1 [B, fanout],
+ * lidx0 [B (1 + fanout), fanout] (-1 rows for the padded destinations), counts[0] = n1, counts[1] = n0 = B (1 + fanout) + new sources.
+ * One 1024-thread workgroup; B (1 + fanout)^2 <= 65 536.  Replaces the per-batch NodeDataLoader iteration of
+ * R/train/graphsage/pytorch/model.py:76-117 for the 32-seed rungs (R/settings/pubmed.json, arxiv.json). */
+int64_t ogl_sample_blocks_small_workspace_bytes(int B, int fanout);
+int ogl_sample_blocks_small(const ogl_graph_t* g, const int64_t* head_host_mapped, int64_t* head_dev, int B, int fanout, uint64_t seed,
+                            int64_t* src1, int32_t* lidx1, int64_t* src0, int32_t* lidx0, int64_t* counts, int64_t* seq_dev,
+                            int64_t* counts_host_mapped, void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
 
 /* Backward of the combine of a 'pool' layer with few output columns (the output layer: N <= 64 classes), two launches (csrc/out_layer.hip;
  * autograd of fc_self(h[:n_dst]) + fc_neigh(max-pooled rows), R/train/graphsage/pytorch/aggregator_dgl.py:171,199-206):

@@ -706,3 +706,183 @@ extern "C" int ogl_build_block_batched_ids(const int64_t* dst_base, const int64_
   return OGL_OK;
 }
 
+
+// ======================================================================================================================
+// The WHOLE sampling phase of a small batch in ONE launch (round 5): what a captured 32-seed step ran as eleven 4-5 us graph nodes —
+// stage [counter | seeds] from mapped host memory, sample the output block, relabel it, sample the input block for the sources found,
+// relabel it, publish the two source counts to the host — is one 1024-thread workgroup walking the same phases with
+// __syncthreads() between them (60 -> ~25 us of a 216 us pubmed-rung step; R/train/graphsage/pytorch/model.py:76-117 runs this
+// as DGL's NodeDataLoader + two to_block calls per batch on the host).
+// Same draws as ogl_sample_layer_dev (Philox key = seed, counter = (quad | layer << 16, vertex id, batch counter)), same blocks as
+// ogl_build_block_padded on the same shapes: the output block over the B seeds (sources padded with -1 up to n1_cap = B (1 + S)), the
+// input block over ALL n1_cap rows of that source list (padded destinations sample nothing: their index rows are -1, their own rows
+// stay in the source list), sources padded with -1 up to n0_cap = n1_cap (1 + S).  Positions that cannot hold a vertex (the picks of
+// padded destinations) are never visited, the hash table is sized by the positions that can: first-appearance order is unchanged.
+struct SmallSampleArgs {
+  const int64_t* indptr; const int32_t* indices; const int32_t* deg; int64_t n;
+  const int64_t* head_host;               // mapped pinned memory [1 + B]: Philox batch counter | seeds
+  int64_t* head_dev;                      // [1 + B]: the static buffer the train graph reads
+  int B, S;
+  uint32_t seed_lo, seed_hi;
+  int64_t* picks1; int64_t* picks0;       // workspace: [B, S], [n1_cap, S]
+  int64_t* src1; int32_t* lidx1;          // [n1_cap], [B, S]
+  int64_t* src0; int32_t* lidx0;          // [n0_cap], [n1_cap, S]
+  int32_t* table;                         // workspace: tkey | tmin | tlidx (T_max each) | slot (n1_cap (1 + S))
+  int64_t T_max;
+  int64_t* counts;                        // device [2]: n1, n0
+  int64_t* seq_dev; volatile int64_t* counts_host;   // host-mapped [3]: n1, n0, sequence number (ogl_publish_i64's protocol)
+};
+
+// one layer's picks for rows [0, n_live) of dst (one thread per (row, 4 slots): k_sample_layer_dev's arithmetic)
+__device__ __forceinline__ void wg_sample(const SmallSampleArgs& a, const int64_t* __restrict__ dst, int64_t n_live, uint64_t ctr,
+                                          uint32_t layer_bits, int64_t* __restrict__ picks) {
+  const int quads = (a.S + 3) / 4;
+  for (int64_t t = threadIdx.x; t < n_live * quads; t += BLK_SCAN) {
+    const int64_t i = t / quads;
+    const int q = (int)(t - i * quads);
+    const int64_t d = dst[i];
+    uint32_t deg = 0;
+    int64_t base = 0;
+    if (d >= 0 && d < a.n) { deg = (uint32_t)a.deg[d]; base = a.indptr[d]; }
+    const int j0 = q * 4, cnt = min(4, a.S - j0);
+    int64_t* out = picks + i * a.S + j0;
+    if (deg == 0) {
+      for (int j = 0; j < cnt; ++j) out[j] = -1;
+      continue;
+    }
+    const philox4 r = philox4x32_10((uint32_t)q | layer_bits, (uint32_t)((uint64_t)d & 0xFFFFFFFFu), (uint32_t)((uint64_t)d >> 32),
+                                    (uint32_t)(ctr & 0xFFFFFFFFu), a.seed_lo, a.seed_hi ^ (uint32_t)(ctr >> 32));
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < cnt) out[j] = (int64_t)a.indices[base + (uint32_t)(((uint64_t)w[j] * (uint64_t)deg) >> 32)];
+  }
+}
+
+// relabel one block inside the workgroup: destinations dst[0 .. n_dst) first (rows >= n_live hold -1 and have no picks), then the
+// picks of rows [0, n_live) in row-major order; returns the source count.  Compact position q: q < n_dst the destination q, else pick
+// q - n_dst — the same ORDER as the flat positions of ogl_build_block, which is all first-appearance relabelling depends on.
+__device__ __forceinline__ int wg_build(const SmallSampleArgs& a, const int64_t* __restrict__ dst, int64_t n_dst, int64_t n_live,
+                                        const int64_t* __restrict__ picks, int64_t* __restrict__ src_ids, int64_t src_cap,
+                                        int32_t* __restrict__ local_idx, int* carry_s) {
+  const int tid = threadIdx.x;
+  const int64_t Q = n_dst + n_live * a.S;
+  int64_t T = 1024;
+  while (T < 2 * Q && T < a.T_max) T <<= 1;
+  int logT = 0;
+  while (((int64_t)1 << logT) < T) ++logT;
+  const uint32_t mask = (uint32_t)(T - 1);
+  const int shift = 32 - logT;
+  int32_t* tkey = a.table; int32_t* tmin = a.table + a.T_max; int32_t* tlidx = a.table + 2 * a.T_max; int32_t* slot = a.table + 3 * a.T_max;
+  for (int64_t i = tid; i < T; i += BLK_SCAN) { tkey[i] = -1; tmin[i] = 0x7F7F7F7F; }
+  if (tid == 0) *carry_s = 0;
+  __threadfence_block();
+  __syncthreads();
+  for (int64_t q = tid; q < Q; q += BLK_SCAN) {
+    const int64_t id64 = q < n_dst ? dst[q] : picks[q - n_dst];
+    int32_t sl = -1;
+    if (id64 >= 0) {
+      const int32_t id = (int32_t)id64;
+      uint32_t h = ((uint32_t)id * 0x9E3779B1u) >> shift;
+      for (uint32_t probe = 0; probe <= mask; ++probe) {
+        const int32_t old = atomicCAS(&tkey[h], -1, id);
+        if (old == -1 || old == id) { atomicMin(&tmin[h], (int32_t)q); sl = (int32_t)h; break; }
+        h = (h + 1) & mask;
+      }
+    }
+    slot[q] = sl;
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int64_t base = 0; base < Q; base += BLK_SCAN) {
+    const int64_t q = base + tid;
+    const int32_t sp = q < Q ? slot[q] : -1;
+    const bool own = sp >= 0 && __hip_atomic_load(&tmin[sp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)q;
+    const int f = q < Q && (q < n_dst || own) ? 1 : 0;
+    int tot;
+    const int pre = block_scan_1024(f, &tot);
+    const int carry = *carry_s;
+    if (f) {
+      const int32_t li = carry + pre;
+      src_ids[li] = q < n_dst ? dst[q] : picks[q - n_dst];
+      if (own) tlidx[sp] = li;
+    }
+    __syncthreads();
+    if (tid == 0) *carry_s = carry + tot;
+    __syncthreads();
+  }
+  const int n_src = *carry_s;
+  for (int64_t i = n_src + tid; i < src_cap; i += BLK_SCAN) src_ids[i] = -1;
+  __threadfence_block();
+  __syncthreads();
+  for (int64_t e = tid; e < n_dst * a.S; e += BLK_SCAN) {
+    int32_t v = -1;
+    if (e < n_live * a.S) { const int32_t s = slot[n_dst + e]; v = s >= 0 ? tlidx[s] : -1; }
+    local_idx[e] = v;
+  }
+  __syncthreads();
+  return n_src;
+}
+
+__global__ void __launch_bounds__(BLK_SCAN) k_sample_blocks_small(SmallSampleArgs a) {
+  __shared__ int carry_s;
+  const int tid = threadIdx.x;
+  // [counter | seeds] from the mapped host buffer into the static device buffer (the train graph gathers its labels by these seeds)
+  if (tid < 1 + a.B) a.head_dev[tid] = a.head_host[tid];
+  __threadfence_block();
+  __syncthreads();
+  const uint64_t ctr = (uint64_t)a.head_dev[0];
+  const int64_t* seeds = a.head_dev + 1;
+  const int64_t n1_cap = (int64_t)a.B * (1 + a.S), n0_cap = n1_cap * (1 + a.S);
+  // ---- the output block: every seed is live
+  wg_sample(a, seeds, a.B, ctr, 1u << 16, a.picks1);
+  __threadfence_block();
+  __syncthreads();
+  const int n1 = wg_build(a, seeds, a.B, a.B, a.picks1, a.src1, n1_cap, a.lidx1, &carry_s);
+  // ---- the input block: ALL n1_cap rows of src1 are its destinations, the first n1 of them real
+  wg_sample(a, a.src1, n1, ctr, 0u, a.picks0);
+  __threadfence_block();
+  __syncthreads();
+  const int n0 = wg_build(a, a.src1, n1_cap, n1, a.picks0, a.src0, n0_cap, a.lidx0, &carry_s);
+  if (tid == 0) {
+    a.counts[0] = n1; a.counts[1] = n0;
+    a.counts_host[0] = n1; a.counts_host[1] = n0;
+    const int64_t s = *a.seq_dev + 1;
+    *a.seq_dev = s;
+    __threadfence_system();
+    a.counts_host[2] = s;
+    __threadfence_system();
+  }
+}
+
+extern "C" int64_t ogl_sample_blocks_small_workspace_bytes(int B, int fanout) {
+  if (B <= 0 || fanout <= 0) return OGL_EINVAL;
+  const int64_t n1_cap = (int64_t)B * (1 + fanout), P0 = n1_cap * (1 + fanout);
+  if (P0 > BLK_SMALL_MAX_P) return OGL_EINVAL;
+  const int64_t T = table_size(P0);
+  return 8 * ((int64_t)B * fanout + n1_cap * fanout) + 4 * (3 * T + ogl_round_up(P0, 4)) + 64;
+}
+
+extern "C" int ogl_sample_blocks_small(const ogl_graph_t* g, const int64_t* head_host_mapped, int64_t* head_dev, int B, int fanout,
+                                       uint64_t seed, int64_t* src1, int32_t* lidx1, int64_t* src0, int32_t* lidx0, int64_t* counts,
+                                       int64_t* seq_dev, int64_t* counts_host_mapped, void* workspace, int64_t workspace_bytes,
+                                       ogl_stream_t stream) {
+  if (!g || B <= 0 || fanout <= 0 || B > 1023) return OGL_EINVAL;
+  const int64_t need = ogl_sample_blocks_small_workspace_bytes(B, fanout);
+  if (need < 0) return OGL_EINVAL;
+  if (!head_host_mapped || !head_dev || !src1 || !lidx1 || !src0 || !lidx0 || !counts || !seq_dev || !counts_host_mapped) return OGL_EINVAL;
+  if (!workspace || ((uintptr_t)workspace & 7) || workspace_bytes < need) return OGL_EWORKSPACE;
+  const int64_t n1_cap = (int64_t)B * (1 + fanout), P0 = n1_cap * (1 + fanout);
+  SmallSampleArgs a;
+  a.indptr = g->indptr; a.indices = g->indices; a.deg = g->deg; a.n = g->n;
+  a.head_host = head_host_mapped; a.head_dev = head_dev; a.B = B; a.S = fanout;
+  a.seed_lo = (uint32_t)(seed & 0xFFFFFFFFu); a.seed_hi = (uint32_t)(seed >> 32);
+  a.picks1 = (int64_t*)workspace; a.picks0 = a.picks1 + (int64_t)B * fanout;
+  a.table = (int32_t*)(a.picks0 + n1_cap * fanout);
+  a.T_max = table_size(P0);
+  a.src1 = src1; a.lidx1 = lidx1; a.src0 = src0; a.lidx0 = lidx0;
+  a.counts = counts; a.seq_dev = seq_dev; a.counts_host = (volatile int64_t*)counts_host_mapped;
+  hipLaunchKernelGGL(k_sample_blocks_small, dim3(1), dim3(BLK_SCAN), 0, (hipStream_t)stream, a);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}

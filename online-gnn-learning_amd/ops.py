@@ -205,6 +205,31 @@ def publish_i64(src_dev, seq_dev, dst_host_pinned):
             meta=dict(n=n))
 
 
+SAMPLE_FUSED = os.environ.get("OGL_SAMPLE_FUSED", "1") != "0"      # the sampling phase of a small batch as ONE launch
+
+
+def sample_blocks_small_fits(B, fanout):
+    return SAMPLE_FUSED and 0 < B <= 1023 and int(_lib.lib().ogl_sample_blocks_small_workspace_bytes(int(B), int(fanout))) > 0
+
+
+def sample_blocks_small(g: GraphHandle, head_host_pinned, head_dev, B, fanout, seed, src1, lidx1, src0, lidx0, counts, seq_dev,
+                        counts_host_pinned, ws=None):
+    """The whole sampling phase of one small batch (``ogl_sample_blocks_small``): stage [counter | seeds] from pinned host memory,
+    sample + relabel both blocks into the static arrays, publish (n1, n0, ++seq) to pinned host memory.  Returns the workspace
+    (keep it alive with the captured graph)."""
+    nbytes = int(_lib.lib().ogl_sample_blocks_small_workspace_bytes(int(B), int(fanout)))
+    assert nbytes > 0 and head_host_pinned.is_pinned() and counts_host_pinned.is_pinned() and counts_host_pinned.numel() >= 3
+    n1_cap = B * (1 + fanout)
+    assert head_dev.numel() >= 1 + B and src1.numel() >= n1_cap and src0.numel() >= n1_cap * (1 + fanout)
+    assert tuple(lidx1.shape) == (B, fanout) and tuple(lidx0.shape) == (n1_cap, fanout) and lidx0.is_contiguous() and lidx1.is_contiguous()
+    if ws is None:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=head_dev.device)
+    _launch("ogl_sample_blocks_small", _lib.lib().ogl_sample_blocks_small, g._h, head_host_pinned.data_ptr(), _ptr(head_dev), int(B),
+            int(fanout), C.c_uint64(seed & (2 ** 64 - 1)), _ptr(src1), _ptr(lidx1), _ptr(src0), _ptr(lidx0), _ptr(counts), _ptr(seq_dev),
+            counts_host_pinned.data_ptr(), _ptr(ws), nbytes, _stream(), meta=dict(n_dst=int(B), fanout=int(fanout)))
+    return ws
+
+
 def stage_segments(pairs, pad=-1):
     """One launch: for every (src, dst, count) copy ``count`` leading elements of ``src`` into ``dst`` and fill the rest of
     ``dst`` with ``pad``.  int32 / int64 tensors (contiguous); the staging step of a captured train step."""

@@ -208,6 +208,11 @@ class SampleGraph:
 
     def _body(self):
         g, b, S = self.graph, self.buf, self.buf.S
+        if ops.sample_blocks_small_fits(b.B, S):
+            # ONE launch for the whole phase (round 5: eleven 4-5 us graph nodes before — stage, 2 x sample, 2 x block build, publish)
+            self._ws = ops.sample_blocks_small(g.handle, self.head_host, b.head, b.B, S, self.seed, b.src1, b.lidx1, b.src0, b.lidx0,
+                                               self.counts, self.seq_dev, self.counts_host, ws=getattr(self, "_ws", None))
+            return
         ctr = b.head[:1]
         # [counter | seeds]: read by the graph's first kernel straight from the pinned host buffer run() filled (mapped memory:
         # no copy node — a 264-byte hipMemcpyAsync is an 18 us blit kernel on the device and a runtime call on the host)

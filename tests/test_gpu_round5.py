@@ -132,3 +132,38 @@ def test_table_direct_mean_equals_the_mean_over_gathered_rows(ops, n_dst, S, D, 
     assert torch.equal(gimg.buf, wimg.buf)
     if n_dst > 1:
         assert float(got[1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dataset,B,S", [("pubmed", 32, 25), ("arxiv", 32, 25), ("pubmed", 32, 45), ("toy", 7, 3)])
+def test_fused_small_sampling_phase_equals_the_launch_sequence(ops, dataset, B, S):
+    """ogl_sample_blocks_small (one workgroup: stage + 2 x sample + 2 x relabel + publish) writes the SAME static block arrays, counts
+    and head as the eleven-node sequence it replaces (ogl_stage_segments, ogl_sample_layer_dev, ogl_build_block_padded,
+    ogl_publish_i64): bit for bit, over several batches incl. seeds without neighbours."""
+    from ogl_amd import sampling, stepgraph, synthetic
+    sampling.seed(4)
+    _, _, dyn, _, _ = synthetic.load(dataset, snapshots=4, device="cuda")
+    dyn.evolve(); dyn.evolve()
+    g = dyn.get_graph()
+    old = ops.SAMPLE_FUSED
+    res = {}
+    try:
+        for fused in (False, True):
+            ops.SAMPLE_FUSED = fused
+            buf = stepgraph.BlockBuffers(B, S, B * (1 + S), B * (1 + S) ** 2, g.device)
+            sg = stepgraph.SampleGraph(g, buf)
+            out = []
+            rng = np.random.default_rng(5)
+            for it in range(4):
+                seeds = rng.choice(g.n_present, B, replace=False).astype(np.int64)
+                n1, n0 = sg.run(seeds, 100 + it)
+                torch.cuda.synchronize()
+                out.append((n1, n0, buf.head.cpu().clone(), buf.src1.cpu().clone(), buf.lidx1.cpu().clone(), buf.src0.cpu().clone(),
+                            buf.lidx0.cpu().clone()))
+            res[fused] = out
+    finally:
+        ops.SAMPLE_FUSED = old
+    for a, b in zip(res[False], res[True]):
+        assert a[0] == b[0] and a[1] == b[1], (a[:2], b[:2])
+        for x, y in zip(a[2:], b[2:]):
+            assert torch.equal(x, y)
+    assert res[True][0][0] > B        # (the blocks are not trivial)
