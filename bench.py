@@ -294,6 +294,30 @@ def main():
     run(hsteps, hplan)
     host_ms = 1000 * (time.perf_counter() - th) / hsteps
     barrier()
+    # ---- N ranks (or --force-dist): device time of the step's collectives, term by term of DESIGN section 6's model T(N) = T1' + L(N) + S(N).
+    # An instrumented pass AFTER the timed region: hipEvent pairs around every collective the step issues from Python (the default
+    # replica step keeps its exchange outside the replayed graph; --dp-capture 1 records it inside, where events cannot see it).
+    collectives = None
+    if getattr(strat, "gsync", None) is not None and not _dp_capture_on():
+        strat.gsync.enable_timing(True)
+        csteps = min(args.steps, max(bt, 20))
+        cplan = plan(csteps)
+        barrier()
+        tc = time.perf_counter()
+        run(csteps, cplan)
+        barrier()
+        c_ms = 1000 * (time.perf_counter() - tc) / csteps
+        tm = strat.gsync.timings()
+        strat.gsync.enable_timing(False)
+        exposed = sum(tm[k][0] * tm[k][1] for k in ("single", "all", "late") if k in tm) / csteps
+        collectives = {"ms_per_step_instrumented": round(c_ms, 4),
+                       "per_kind": {k: {"mean_ms": round(v[0], 4), "per_step": round(v[1] / csteps, 2)} for k, v in tm.items()},
+                       "exposed_exchange_ms_per_step": round(exposed, 4),
+                       "t1_prime_ms": round(c_ms - exposed, 4),
+                       "what": "hipEvent pairs on the issuing stream: 'single' / 'all' / 'late' = from the all-reduce call to the point where "
+                               "the stream may continue (exposed: Adam waits for it); 'early' = from its launch in the gradient hook to the wait "
+                               "in sync() (mostly hidden under the layer-0 backward).  t1_prime = the instrumented step minus the exposed exchange: "
+                               "what one rank's step costs with zero link time"}
     # the OTHER execution mode of large batches, for the record: when the auto policy kept this workload eager (fast host),
     # the same steps replayed as captured graphs (size buckets captured in an untimed warm-up first)
     graph_mode = None
@@ -583,6 +607,7 @@ def main():
                                    frac=round(composite["composite_floor_ms"] / (1000 * elapsed / args.steps), 4)) if composite else None),
             "hbm_copy_measured": hbm_copy,
             "host_enqueue_ms_per_step": round(host_ms, 4),
+            "collectives": collectives,
             "graph_mode": graph_mode,
             "end_to_end_snapshot": e2e,
             "cpu_baseline": cpu_baseline,

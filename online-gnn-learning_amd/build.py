@@ -10,6 +10,7 @@ import glob
 import hashlib
 import os
 import subprocess
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -90,8 +91,11 @@ def _compile_one(src, stamp, verbose):
         cmd.insert(1, '-DOGL_SOURCE_HASH="%s"' % stamp)
     if verbose:
         print(" ".join(cmd), flush=True)
+    t0 = time.perf_counter()
     subprocess.run(cmd, check=True)
     os.replace(obj + ".tmp", obj)
+    if verbose:
+        print("compiled %s in %.1f s" % (os.path.basename(src), time.perf_counter() - t0), flush=True)
     return obj, True
 
 

@@ -762,18 +762,25 @@ __device__ __forceinline__ void wg_sample(const SmallSampleArgs& a, const int64_
 // relabel one block inside the workgroup: destinations dst[0 .. n_dst) first (rows >= n_live hold -1 and have no picks), then the
 // picks of rows [0, n_live) in row-major order; returns the source count.  Compact position q: q < n_dst the destination q, else pick
 // q - n_dst — the same ORDER as the flat positions of ogl_build_block, which is all first-appearance relabelling depends on.
-__device__ __forceinline__ int wg_build(const SmallSampleArgs& a, const int64_t* __restrict__ dst, int64_t n_dst, int64_t n_live,
-                                        const int64_t* __restrict__ picks, int64_t* __restrict__ src_ids, int64_t src_cap,
-                                        int32_t* __restrict__ local_idx, int* carry_s) {
+// The hash table lives in LDS while it fits (keys + minima, 2 x 64 KB for 16 384 entries: positions <= 10 922, i.e. up to ~400 real
+// destinations at fanout 25): a global-memory table costs one L2 round trip per atomic, ~1.5 us per 1 024 positions and phase — the
+// one-workgroup kernel then took the 60 us of the eleven launches it replaced.  Larger blocks keep the global table.
+#define SS_LDS_T 16384
+template <bool LDS_TABLE>
+__device__ __forceinline__ int wg_build_t(const SmallSampleArgs& a, const int64_t* __restrict__ dst, int64_t n_dst, int64_t n_live,
+                                          const int64_t* __restrict__ picks, int64_t* __restrict__ src_ids, int64_t src_cap,
+                                          int32_t* __restrict__ local_idx, int* carry_s, int32_t* lkey, int32_t* lmin, int64_t T) {
   const int tid = threadIdx.x;
   const int64_t Q = n_dst + n_live * a.S;
-  int64_t T = 1024;
-  while (T < 2 * Q && T < a.T_max) T <<= 1;
   int logT = 0;
   while (((int64_t)1 << logT) < T) ++logT;
   const uint32_t mask = (uint32_t)(T - 1);
   const int shift = 32 - logT;
-  int32_t* tkey = a.table; int32_t* tmin = a.table + a.T_max; int32_t* tlidx = a.table + 2 * a.T_max; int32_t* slot = a.table + 3 * a.T_max;
+  // (LDS form: `tmin` doubles as `tlidx` once the scan has read a slot's minimum — one thread owns each slot's minimum)
+  int32_t* tkey = LDS_TABLE ? lkey : a.table;
+  int32_t* tmin = LDS_TABLE ? lmin : a.table + a.T_max;
+  int32_t* tlidx = LDS_TABLE ? lmin : a.table + 2 * a.T_max;
+  int32_t* slot = a.table + 3 * a.T_max;
   for (int64_t i = tid; i < T; i += BLK_SCAN) { tkey[i] = -1; tmin[i] = 0x7F7F7F7F; }
   if (tid == 0) *carry_s = 0;
   __threadfence_block();
@@ -797,21 +804,40 @@ __device__ __forceinline__ int wg_build(const SmallSampleArgs& a, const int64_t*
   for (int64_t base = 0; base < Q; base += BLK_SCAN) {
     const int64_t q = base + tid;
     const int32_t sp = q < Q ? slot[q] : -1;
-    const bool own = sp >= 0 && __hip_atomic_load(&tmin[sp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)q;
+    int32_t mn = -1;
+    if (sp >= 0) mn = LDS_TABLE ? tmin[sp] : __hip_atomic_load(&tmin[sp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool own = sp >= 0 && mn == (int32_t)q;
     const int f = q < Q && (q < n_dst || own) ? 1 : 0;
     int tot;
-    const int pre = block_scan_1024(f, &tot);
+    const int pre = block_scan_1024(f, &tot);               // (its barriers order every read of tmin above before the writes below)
     const int carry = *carry_s;
     if (f) {
       const int32_t li = carry + pre;
       src_ids[li] = q < n_dst ? dst[q] : picks[q - n_dst];
-      if (own) tlidx[sp] = li;
+      // (LDS form: minima and local indices share one array, and later chunks still compare positions against the minima)
+      if (own && !LDS_TABLE) tlidx[sp] = li;
+      if (own && LDS_TABLE) slot[q] = -2 - li;               // (remembered per POSITION; applied to the table after the scan)
     }
     __syncthreads();
     if (tid == 0) *carry_s = carry + tot;
     __syncthreads();
   }
   const int n_src = *carry_s;
+  if (LDS_TABLE) {
+    // second pass of the owners: slot[q] = -2 - li marks "q owns its table slot, local index li"; re-probe for the slot (read-only)
+    __syncthreads();
+    for (int64_t q = tid; q < Q; q += BLK_SCAN) {
+      const int32_t sv = slot[q];
+      if (sv <= -2) {
+        const int64_t id64 = q < n_dst ? dst[q] : picks[q - n_dst];
+        const int32_t id = (int32_t)id64;
+        uint32_t h = ((uint32_t)id * 0x9E3779B1u) >> shift;
+        while (tkey[h] != id) h = (h + 1) & mask;
+        tlidx[h] = -2 - sv;
+        slot[q] = (int32_t)h;
+      }
+    }
+  }
   for (int64_t i = n_src + tid; i < src_cap; i += BLK_SCAN) src_ids[i] = -1;
   __threadfence_block();
   __syncthreads();
@@ -824,8 +850,20 @@ __device__ __forceinline__ int wg_build(const SmallSampleArgs& a, const int64_t*
   return n_src;
 }
 
+__device__ __forceinline__ int wg_build(const SmallSampleArgs& a, const int64_t* __restrict__ dst, int64_t n_dst, int64_t n_live,
+                                        const int64_t* __restrict__ picks, int64_t* __restrict__ src_ids, int64_t src_cap,
+                                        int32_t* __restrict__ local_idx, int* carry_s, int32_t* lkey, int32_t* lmin) {
+  const int64_t Q = n_dst + n_live * a.S;
+  int64_t T = 1024;
+  while (2 * T < 3 * Q && T < a.T_max) T <<= 1;            // load factor <= 2/3
+  if (T <= SS_LDS_T) return wg_build_t<true>(a, dst, n_dst, n_live, picks, src_ids, src_cap, local_idx, carry_s, lkey, lmin, T);
+  while (T < 2 * Q && T < a.T_max) T <<= 1;
+  return wg_build_t<false>(a, dst, n_dst, n_live, picks, src_ids, src_cap, local_idx, carry_s, lkey, lmin, T);
+}
+
 __global__ void __launch_bounds__(BLK_SCAN) k_sample_blocks_small(SmallSampleArgs a) {
   __shared__ int carry_s;
+  __shared__ int32_t lkey[SS_LDS_T], lmin[SS_LDS_T];
   const int tid = threadIdx.x;
   // [counter | seeds] from the mapped host buffer into the static device buffer (the train graph gathers its labels by these seeds)
   if (tid < 1 + a.B) a.head_dev[tid] = a.head_host[tid];
@@ -838,12 +876,12 @@ __global__ void __launch_bounds__(BLK_SCAN) k_sample_blocks_small(SmallSampleArg
   wg_sample(a, seeds, a.B, ctr, 1u << 16, a.picks1);
   __threadfence_block();
   __syncthreads();
-  const int n1 = wg_build(a, seeds, a.B, a.B, a.picks1, a.src1, n1_cap, a.lidx1, &carry_s);
+  const int n1 = wg_build(a, seeds, a.B, a.B, a.picks1, a.src1, n1_cap, a.lidx1, &carry_s, lkey, lmin);
   // ---- the input block: ALL n1_cap rows of src1 are its destinations, the first n1 of them real
   wg_sample(a, a.src1, n1, ctr, 0u, a.picks0);
   __threadfence_block();
   __syncthreads();
-  const int n0 = wg_build(a, a.src1, n1_cap, n1, a.picks0, a.src0, n0_cap, a.lidx0, &carry_s);
+  const int n0 = wg_build(a, a.src1, n1_cap, n1, a.picks0, a.src0, n0_cap, a.lidx0, &carry_s, lkey, lmin);
   if (tid == 0) {
     a.counts[0] = n1; a.counts[1] = n0;
     a.counts_host[0] = n1; a.counts_host[1] = n0;

@@ -26,6 +26,8 @@ from .sageconv import GatheredRows
 # is a hang, not an error.  The default keeps the exchange and the optimiser OUT of the graph (round 3's form: forward + backward
 # replayed, ONE flat-bucket all-reduce and Adam enqueued from Python — every rank enqueues its collectives the same way).
 DP_CAPTURE_COLLECTIVES = __import__("os").environ.get("OGL_DP_CAPTURE_COLLECTIVES", "0") == "1"
+# OGL_SHARDED_FUSED=0: the eager replica step differentiates sum(rows) / n_global through the unfused output layer (rounds 1-4)
+SHARDED_FUSED = __import__("os").environ.get("OGL_SHARDED_FUSED", "1") != "0"
 
 
 def _to_numpy(t):
@@ -557,6 +559,32 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             if self.step_hook is not None:
                 self.step_hook(dict(seeds=seeds, loss=sg.loss * (n_local / float(n_global)), grads=sg.grads, form="staged_dp", n0=n0, n1=n1))
             return sg.loss * n_local
+        if self.gsync is not None and SHARDED_FUSED:
+            # The eager replica step (form "sharded"; round 5): the SAME launches as the replayed graph records — the fused output layer +
+            # loss (GraphSAGE.forward_loss), the gradients weighted by n_local / n_global inside the exchange instead of by an ATen
+            # division of the summed rows — so that what bench.py --force-dist itemises per kernel IS the replayed step.
+            w = n_local / float(n_global)
+            self.optimizer.zero_grad()
+            loss_e = rows = None
+            self.gsync.begin_step(w)
+            if n_local > 0:
+                batch_labels = ops.LazyLabels(graph.ndata["target"], seeds)
+                loss_e, rows, _ = self.graphsage_model.forward_loss(blocks, self._inputs(graph, input_nodes), batch_labels, rows=True,
+                                                                    defer_mean=True)
+                ops.backward(loss_e)
+            else:                                               # more ranks than seeds in this batch: zeros into the same collectives
+                for p in self.gsync.params:
+                    p.grad = None
+            self.gsync.sync(weight=w)
+            self.optimizer.step()
+            if on_rows is not None:
+                on_rows(seeds, rows.detach() if rows is not None else torch.zeros(0, device=graph.device))
+            if loss_e is None:
+                return None
+            if self.step_hook is not None:
+                self.step_hook(dict(seeds=seeds, loss=loss_e.detach() * w, grads=[p.grad for p in self.graphsage_model.parameters()],
+                                    form="sharded", n0=int(input_nodes.numel()), n1=blocks[1].number_of_src_nodes()))
+            return loss_e.detach() * n_local
         loss_sum = rows = None
         if n_local > 0:
             batch_labels = ops.gather_i64(graph.ndata["target"], seeds)

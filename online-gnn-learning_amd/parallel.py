@@ -225,10 +225,12 @@ class GradSynchronizer:
             ctx = ops.collective_section()       # a forked backward: fill + launch from the side stream (weight gradients live there)
         if ctx is None:
             flat = self._fill("early", self._early, w)
+            self._early_t0 = self._t0(flat)
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             with ctx:
                 flat = self._fill("early", self._early, w)
+                self._early_t0 = self._t0(flat)
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending = (work, flat, w)
 
@@ -266,6 +268,36 @@ class GradSynchronizer:
             self._bucket("early", early); self._bucket("late", late)      # the slots the next backward writes into
             self._buckets.pop("all", None)
 
+    # -- measurement (bench.py --gpus N / --force-dist): device time of the step's collectives ---------------------------------------
+    def enable_timing(self, on=True):
+        """Record a hipEvent pair around every collective ``sync()`` issues from Python (never inside a stream capture): ``timings()``
+        then gives the mean device time per kind — 'single' / 'all' / 'late': from the call to the point where the calling stream may
+        continue (the EXPOSED time of that exchange); 'early': from its launch in the gradient hook to the wait in ``sync()`` (hidden
+        under the backward kernels between the two + whatever is left exposed)."""
+        self._timing = {} if on else None
+
+    def _t0(self, flat):
+        if getattr(self, "_timing", None) is None or not flat.is_cuda or torch.cuda.is_current_stream_capturing():
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def _t1(self, kind, e0):
+        if e0 is None or torch.cuda.is_current_stream_capturing():
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self._timing.setdefault(kind, []).append((e0, e1))
+
+    def timings(self):
+        """{kind: (mean milliseconds, count)} of the collectives recorded since ``enable_timing()``; synchronises the device."""
+        t = getattr(self, "_timing", None)
+        if not t:
+            return {}
+        torch.cuda.synchronize()
+        return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v), len(v)) for k, v in t.items() if v}
+
     # -- the step's exchange ---------------------------------------------------------------------------------------
     def sync(self, weight=None, single=False):
         """grads <- sum_r w_r * grad_r, w_r = ``weight`` (default: the constructor's).  ``single``: ONE flat bucket, one collective —
@@ -277,7 +309,9 @@ class GradSynchronizer:
             assert self._pending is None, "single-bucket sync after an early bucket was launched"
             idxs = list(range(len(self.params)))
             flat = self._fill("single", idxs, w)
+            e0 = self._t0(flat)
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            self._t1("single", e0)
             self._scatter("single")
             self._stale, self._fired, self._order = False, {}, []
             self._handed.clear()
@@ -285,7 +319,9 @@ class GradSynchronizer:
         if self._early is None:
             idxs = list(range(len(self.params)))
             flat = self._fill("all", idxs, w)
+            e0 = self._t0(flat)
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            self._t1("all", e0)
             self._scatter("all")
             if self.overlap and not (flat.is_cuda and torch.cuda.is_current_stream_capturing()):
                 self._learn()                     # (never while a step is being recorded: it broadcasts through the host)
@@ -295,8 +331,12 @@ class GradSynchronizer:
             work, flat_e, w_used = self._pending
             stale = self._stale
             flat_l = self._fill("late", self._late, w)
+            e0 = self._t0(flat_l)
             dist.all_reduce(flat_l, op=dist.ReduceOp.SUM, group=self.group)      # (issued even when raising below: stays matched)
+            self._t1("late", e0)
             work.wait()
+            self._t1("early", getattr(self, "_early_t0", None))
+            self._early_t0 = None
             if stale:
                 self._pending, self._stale, self._fired, self._order = None, False, {}, []
                 self._handed.clear()
