@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -1317,7 +1318,10 @@ class SlabGrad:
 
     def __init__(self, ws, stride, ws_ld, nsplit, rows, ncols, col0, out=None):
         self.ws, self.stride, self.ws_ld, self.nsplit, self.rows, self.ncols, self.col0 = ws, stride, ws_ld, nsplit, rows, ncols, col0
-        self.out = out
+        # a WEAK reference: AccumulateGrad adopts a gradient tensor only while nobody else holds it — a strong reference here made
+        # autograd CLONE every deferred gradient (eight device-to-device copies per Reddit step, +27 us: found by a same-box A/B against
+        # the round-4 tree and the copy launches in the traced step)
+        self.out = weakref.ref(out) if out is not None else None
 
 
 def take_slabs(param):
@@ -1336,8 +1340,9 @@ def _slabs_settle(params):
         sg = pend.pop(t.data_ptr(), None)
         if sg is not None:
             hit = True
-            if sg.out is not None:
-                slab_reduce(sg, sg.out)
+            o = sg.out() if sg.out is not None else None
+            if o is not None:
+                slab_reduce(sg, o)
         if t.grad is not None:                # gradient accumulation: the optimiser launch would overwrite what is already there
             hit = True
     return hit
