@@ -177,6 +177,10 @@ int ogl_reduce_bwd_seg_plan(const int32_t* idx, int64_t n_dst, int fanout, int64
 int ogl_reduce_bwd_seg_apply(const float* dout, int64_t ldd, const int32_t* idx, int64_t n_dst, int fanout, int d, int op, int64_t n_src,
                              const float* mask, int64_t ldm, float* out, int64_t ldo, void* image, void* workspace,
                              int64_t workspace_bytes, ogl_stream_t stream);
+/* ... with the mask given as sign bits (ogl_linear_fwd_x3_bits' layout: one byte per 4-column group, row stride ldmb bytes). */
+int ogl_reduce_bwd_seg_apply_bits(const float* dout, int64_t ldd, const int32_t* idx, int64_t n_dst, int fanout, int d, int op,
+                                  int64_t n_src, const unsigned char* mask_bits, int64_t ldmb, float* out, int64_t ldo, void* image,
+                                  void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense projections (torch.nn.Linear inside SAGEConv: fc_pool / fc_self / fc_neigh), fp32 MFMA.
@@ -334,6 +338,12 @@ const char* ogl_x3_last_kernel(void);
 
 int ogl_linear_fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
                       const void* w_img, int N, int relu, float* y, int64_t ldy, ogl_stream_t stream);
+/* ogl_linear_fwd_x3 that also emits the SIGN BITS of its output: relu_bits[i * relu_bits_ld + g] bit c = [y[i, 4 g + c] > 0], one byte
+ * per 4-column group (relu_bits_ld >= ceil(N / 4) bytes) — the ReLU mask of relu(fc_pool(x)) for the mean-pool backward
+ * (R/train/graphsage/pytorch/aggregator_dgl.py:181-185; consumed by ogl_reduce_bwd_seg_apply_bits), 1/16 of the fp32 matrix. */
+int ogl_linear_fwd_x3_bits(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
+                           const void* w_img, int N, int relu, float* y, int64_t ldy, unsigned char* relu_bits, int64_t relu_bits_ld,
+                           ogl_stream_t stream);
 /* ogl_linear_fwd_x3 with a second A part, a per-row addend and / or an image of the output (k_gemm_x3p<..., EXT>):
  *   y[i, :] = act( x_img[row(i)] . w[:, part 1]^T + x2_img[row2(i)] . w[:, part 2]^T + add[add_rows[i], :] )
  * - x2_img (nullable, K2 = 0): the second part of a K-concatenated product — fc_self(x[dst]) + fc_neigh(neigh) of the combine

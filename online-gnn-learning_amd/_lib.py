@@ -45,6 +45,7 @@ SIGNATURES = {
     "ogl_reduce_bwd_seg_workspace_bytes": (_i64, [_i64, _i, _i, _i64]),
     "ogl_reduce_bwd_seg_plan": (_i, [_p, _i64, _i, _i64, _p, _i64, _p]),
     "ogl_reduce_bwd_seg_apply": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p]),
+    "ogl_reduce_bwd_seg_apply_bits": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p]),
     "ogl_linear_fwd": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p,
                             _p, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p]),
     "ogl_linear_fwd_dual_bias": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p, _p,
@@ -83,6 +84,7 @@ SIGNATURES = {
     "ogl_out_layer_fwd_ce": (_i, [_p, _i64, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p, _i64, _p, _p, _i, _p, _i64, _p, _p, _i64,
                                   _p, _i64, _p, _f, _p, _p, _i64, _p, _p, _p, _i64, _i, _p]),
     "ogl_linear_fwd_x3": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i, _i, _p, _i64, _p]),
+    "ogl_linear_fwd_x3_bits": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i, _i, _p, _i64, _p, _i64, _p]),
     "ogl_linear_fwd_x3_ext": (_i, [_p, _i64, _p, _i64, _i, _p, _i64, _p, _i64, _i, _i64, _p, _i, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i, _p, _i64,
                                    _p, _p]),
     "ogl_x3_split_multi": (_i, [_p, _i, _p]),

@@ -80,6 +80,9 @@ struct X3Args {
   unsigned char* out_img;       // optional: ALSO write the bf16x3 image of the (activated) output, row-major, reduction length
   int64_t out_row_bytes;        //   N (+ 1 when out_append_ones: 1.0 at column N) — the A operand of the next layer's product
   int out_append_ones;
+  // ---- plain forward products (nsplit == 1): optional SIGN BITS of the output, one byte per 4-column group (bit c = [y[i, 4 g + c] > 0]),
+  // row stride relu_bits_ld bytes — the ReLU mask a later backward pass needs, 1/16 of the fp32 matrix it would otherwise re-read ----
+  unsigned char* relu_bits; int64_t relu_bits_ld;
 };
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) — indices into register arrays stay constants
@@ -906,6 +909,9 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
             }
           }
           if (EXT && g.y_keep && rok && !g.y_keep[row]) continue;   // (a row only the next layer's image product reads)
+          if (!EXT && !BK && g.relu_bits && rok && col < g.N)
+            g.relu_bits[row * g.relu_bits_ld + (col >> 2)] = (unsigned char)((v[0] > 0.f ? 1 : 0) | (v[1] > 0.f ? 2 : 0) | (v[2] > 0.f ? 4 : 0) |
+                                                                             (v[3] > 0.f ? 8 : 0));
           const bool vec = rok && vec_ok && !has_oc && col < g.N && col + 4 <= ldd;
           if (vec) *(float4*)(dst + row * ldd + col) = make_float4(v[0], v[1], v[2], v[3]);
           else if (rok && col < g.N) {
@@ -1531,12 +1537,31 @@ __global__ void __launch_bounds__(256) k_x3_image_tail(unsigned char* __restrict
   }
 }
 
+static int fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K, const void* w_img, int N,
+                  int relu, float* y, int64_t ldy, unsigned char* relu_bits, int64_t relu_bits_ld, ogl_stream_t stream);
+
 extern "C" int ogl_linear_fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M,
                                  int K, const void* w_img, int N, int relu, float* y, int64_t ldy, ogl_stream_t stream) {
+  return fwd_x3(x_img, x_img_rows, x_rows, x_nrows, M, K, w_img, N, relu, y, ldy, nullptr, 0, stream);
+}
+
+// ... that ALSO emits the sign bits of its output: relu_bits[i * relu_bits_ld + g] bit c = [y[i, 4 g + c] > 0] (one byte per 4-column
+// group, relu_bits_ld >= ceil(N / 4) bytes) — the ReLU mask of relu(fc_pool(x)) that the mean-pool backward needs
+// (R/train/graphsage/pytorch/aggregator_dgl.py:181-185), 1/16 of the fp32 matrix it would otherwise read back.
+extern "C" int ogl_linear_fwd_x3_bits(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
+                                      const void* w_img, int N, int relu, float* y, int64_t ldy, unsigned char* relu_bits,
+                                      int64_t relu_bits_ld, ogl_stream_t stream) {
+  if (!relu_bits || relu_bits_ld < (N + 3) / 4) return OGL_EINVAL;
+  return fwd_x3(x_img, x_img_rows, x_rows, x_nrows, M, K, w_img, N, relu, y, ldy, relu_bits, relu_bits_ld, stream);
+}
+
+static int fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K, const void* w_img, int N,
+                  int relu, float* y, int64_t ldy, unsigned char* relu_bits, int64_t relu_bits_ld, ogl_stream_t stream) {
   if (M < 0 || K <= 0 || N < 0 || x_img_rows < 0 || x_nrows < 0 || x_nrows > x_img_rows || ldy < N) return OGL_EINVAL;
   if (M == 0 || N == 0) return OGL_OK;
   if (!x_img || !w_img || !y || (!x_rows && M > x_img_rows)) return OGL_EINVAL;
   X3Args g = X3Args();
+  g.relu_bits = relu_bits; g.relu_bits_ld = relu_bits_ld;
   const int64_t rb = ogl_cdiv(K, 32) * X3_GROUP_BYTES;
   g.a = X3Operand{(const unsigned char*)x_img, rb, X3_GROUP_BYTES, x_rows, x_rows ? x_nrows : x_img_rows, x_img_rows};
   g.b = X3Operand{(const unsigned char*)w_img, rb, X3_GROUP_BYTES, nullptr, N, N};

@@ -520,8 +520,9 @@ def reduce_bwd(dout: torch.Tensor, idx32, argmax, op: str, n_src: int, fanout=No
 # --------------------------------------------------------------------------------------------
 # dense projections
 # --------------------------------------------------------------------------------------------
-def linear_fwd(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_rows=None, out=None, bias2=None):
-    """``bias2``: the second projection's own bias (dual-input form only): (bias + bias2) is formed inside the launch."""
+def linear_fwd(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_rows=None, out=None, bias2=None, want_bits=False):
+    """``bias2``: the second projection's own bias (dual-input form only): (bias + bias2) is formed inside the launch.
+    ``want_bits``: when the product takes the image kernel, its epilogue also emits the sign bits of y (``y._ogl_bits``)."""
     x = as_mat(x); w = as_mat(w)
     M = x_rows.numel() if x_rows is not None else x.shape[0]
     K, N = x.shape[1], w.shape[0]
@@ -541,7 +542,7 @@ def linear_fwd(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_ro
             if wimg is None:
                 bvec = bias if bias is not None else torch.zeros(N, dtype=torch.float32, device=x.device)
                 wimg = x3_split(w, append_vec=bvec)
-            return linear_fwd_x3(img, x_rows, wimg, relu=relu, x_nrows=x.shape[0], M=M, out=out)
+            return linear_fwd_x3(img, x_rows, wimg, relu=relu, x_nrows=x.shape[0], M=M, out=out, want_bits=want_bits)
     y = out if out is not None else empty_mat(M, N, x.device)
     if bias2 is not None:
         assert bias is not None and x2 is not None
@@ -818,15 +819,32 @@ def x3_split_t(x, rows=None, ones_row=False, interleave=0):
     return X3Image(buf, nimg, Mi)
 
 
-def linear_fwd_x3(x_img, x_rows, w_img, relu=False, x_nrows=None, M=None, out=None):
+class SignBits:
+    """[y > 0] of a matrix as one byte per 4-column group (bit c = column 4 g + c): ``buf`` uint8 [rows, ld]."""
+    __slots__ = ("buf", "rows", "cols", "ld")
+
+    def __init__(self, rows, cols, device):
+        self.rows, self.cols, self.ld = int(rows), int(cols), (int(cols) + 3) // 4
+        self.buf = torch.empty((self.rows, self.ld), dtype=torch.uint8, device=device)
+
+
+def linear_fwd_x3(x_img, x_rows, w_img, relu=False, x_nrows=None, M=None, out=None, want_bits=False):
     """y = act(x_img[x_rows] @ w_img.T); a bias is folded into the images (x3_split append_ones / append_vec).
-    ``x_nrows`` bounds the valid gather ids (default: every image row); without a gather ``M`` selects a row prefix."""
+    ``x_nrows`` bounds the valid gather ids (default: every image row); without a gather ``M`` selects a row prefix.
+    ``want_bits``: also the SignBits of y (attached to it as ``y._ogl_bits``): the ReLU mask a backward pass needs, from the epilogue."""
     M = x_rows.numel() if x_rows is not None else (x_img.rows if M is None else M)
     x_nrows = x_img.rows if x_nrows is None else x_nrows
     K, N = x_img.K, w_img.rows
     assert w_img.K == K, "both images must be built with the same append choice"
     y = out if out is not None else empty_mat(M, N, x_img.buf.device)
     assert y.shape[0] == M and y.shape[1] == N
+    if want_bits:
+        bits = SignBits(M, N, y.device)
+        _launch("ogl_linear_fwd_x3", _lib.lib().ogl_linear_fwd_x3_bits, _ptr(x_img.buf), x_img.rows,
+                _ptr(_ids(x_rows) if x_rows is not None else None), x_nrows, M, K, _ptr(w_img.buf), N, 1 if relu else 0, _ptr(y),
+                _ld(y), _ptr(bits.buf), bits.ld, _stream(), meta=dict(M=M, K=K, N=N, K2=0, bits=True))
+        y._ogl_bits = (bits, y._version, y.data_ptr())
+        return y
     _launch("ogl_linear_fwd_x3", _lib.lib().ogl_linear_fwd_x3, _ptr(x_img.buf), x_img.rows,
             _ptr(_ids(x_rows) if x_rows is not None else None), x_nrows, M, K, _ptr(w_img.buf), N, 1 if relu else 0, _ptr(y),
             _ld(y), _stream(), meta=dict(M=M, K=K, N=N, K2=0))
@@ -1225,6 +1243,13 @@ def reduce_bwd_seg_apply(dout, idx32, plan, op, mask=None, want_out=True, want_i
     _plan_ready(plan)
     out = empty_mat(n_src, d, dout.device) if want_out else None
     img = X3Image(_x3_alloc(n_src, d, dout.device), n_src, d) if want_image else None
+    if isinstance(mask, SignBits):
+        assert mask.rows == n_src and mask.cols == d
+        _launch("ogl_reduce_bwd_seg_apply", _lib.lib().ogl_reduce_bwd_seg_apply_bits, _ptr(dout), _ld(dout), _ptr(idx32), n_dst, fanout, d,
+                REDUCE_OPS[op], n_src, _ptr(mask.buf), mask.ld, _ptr(out), _ld(out) if out is not None else 0,
+                _ptr(img.buf) if img is not None else None, _ptr(plan.ws), plan.nbytes, _stream(),
+                meta=dict(n_dst=n_dst, fanout=fanout, d=d, n_src=n_src, op=op, out=out is not None, image=img is not None, mask="bits"))
+        return out, img
     if mask is not None:
         mask = as_mat(mask)
         assert tuple(mask.shape) == (n_src, d)
@@ -1256,6 +1281,12 @@ def pool_bwd_x3_apply(dout, idx32, plan, n_src):
 # 560: LDS float atomics run at ~0.3 lane-operations per clock per CU on this part, every one of a slab's five column tiles
 # re-accumulates the same records, and the k-major 128 x 128 multipliers alone already take what the whole 256 x 128 image product takes.
 POOL_RF = os.environ.get("OGL_POOL_RF", "0") == "1"
+# 'meanpool' first layer: the ReLU mask of relu(fc_pool(x)) as sign bits emitted by the product's epilogue (ogl_linear_fwd_x3_bits ->
+# ogl_reduce_bwd_seg_apply_bits: 9 MB instead of the 150 MB fp32 matrix at the Reddit rung).  Bit-identical and OFF: measured same box,
+# alternating (bench.py --aggregator meanpool): 1.211 / 1.208 ms per step without, 1.238 / 1.235 with — the mean backward does not
+# get faster (0.2073 -> 0.2097 ms: it is paced by its gathered gradient rows, not by the mask stream) and the forward product's epilogue
+# pays for the byte stores.  OGL_POOL_MEAN_BITS=1 to take it.
+POOL_MEAN_BITS = os.environ.get("OGL_POOL_MEAN_BITS", "0") == "1"
 
 
 def pool_bwd_x3_dw(dout, idx32, plan, n_src, x_img, K, x_rows=None, x_nrows=None, want_bias=True, dw_out=None, defer_for=None):
@@ -2075,8 +2106,11 @@ class _PoolMeanFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, x_rows, idx):
-        p = linear_fwd(x, w, bias, relu=True, x_rows=x_rows)
         need = w.requires_grad or (bias is not None and bias.requires_grad)
+        # (the ReLU mask the backward needs as sign bits from the product's epilogue: 1/16 of the bytes of p, which is then free to go)
+        p = linear_fwd(x, w, bias, relu=True, x_rows=x_rows, want_bits=need and POOL_MEAN_BITS)
+        ent = getattr(p, "_ogl_bits", None)
+        ctx.p_bits = ent[0] if (ent is not None and ent[1] == p._version and ent[2] == p.data_ptr()) else None
         if _n1_images_ok(idx.shape[0], p.shape[1]) and p.shape[1] % 4 == 0:
             out, img = reduce_fwd_mean_img(p, idx)
             attach_image(out, img)
@@ -2086,7 +2120,8 @@ class _PoolMeanFn(torch.autograd.Function):
             _CAPTURE.append(dict(pool_out=p))          # (test hook: the device's own ReLU decisions of the pooled projection)
         ctx.n_src, ctx.fanout, ctx.has_bias, ctx.bias_t = p.shape[0], idx.shape[1], bias is not None, bias
         ctx.seg_plan = reduce_bwd_seg_plan(idx, p.shape[1], p.shape[0]) if need else None
-        ctx.save_for_backward(x, w, x_rows, p, idx)
+        ctx.p_shape = tuple(p.shape)
+        ctx.save_for_backward(x, w, x_rows, p if ctx.p_bits is None else None, idx)
         return out
 
     @staticmethod
@@ -2094,7 +2129,9 @@ class _PoolMeanFn(torch.autograd.Function):
         x, w, x_rows, p, idx = ctx.saved_tensors
         plan, ctx.seg_plan = ctx.seg_plan, None
         if plan is None:                                  # (a second backward pass over a retained graph: the plan was consumed)
-            plan = reduce_bwd_seg_plan(idx, p.shape[1], p.shape[0], side=False)
+            plan = reduce_bwd_seg_plan(idx, ctx.p_shape[1], ctx.p_shape[0], side=False)
+        if ctx.p_bits is not None:
+            p = ctx.p_bits                                # (the mask as sign bits: reduce_bwd_seg_apply takes either)
         K = x.shape[1]
         rimg = _row_image_for(x, x_rows, None) if (_MODE["name"] != "f32" and ctx.n_src >= X3_BWW_MIN_ROWS) else None
         if rimg is not None and rimg.K == K + 1:

@@ -287,3 +287,39 @@ def test_hidden_width_256_train_step_matches_oracle(ops):
             got = getattr(getattr(l, mod), attr).grad.cpu().numpy()
             ref = grads["layers.%d.%s" % (li, k)].numpy()
             assert np.linalg.norm(got - ref) <= 2e-2 * np.linalg.norm(ref) + 1e-6, (li, k)     # (unforced winners: round-1 tolerance)
+
+
+@pytest.mark.parametrize("M,K,N", [(9000, 64, 600), (8200, 100, 130), (8300, 50, 37)])
+def test_sign_bits_from_the_product_epilogue(ops, M, K, N):
+    """ogl_linear_fwd_x3_bits: the byte per 4-column group the image product's epilogue emits == [y > 0] of the matrix it stores, and
+    the segmented mean backward masked by those bits == the one masked by the fp32 matrix, bit for bit (values and image)."""
+    torch.manual_seed(N)
+    rng = np.random.default_rng(N)
+    old = ops.get_gemm_mode()
+    ops.set_gemm_mode("auto")
+    try:
+        T = M + 500
+        tab = ops.empty_mat(T, K, "cuda"); tab.normal_()
+        ops.register_static_table(tab)
+        rows = torch.as_tensor(rng.permutation(T)[:M].astype(np.int64)).cuda()
+        w = (torch.randn(N, K) / 6).cuda(); b = torch.randn(N).cuda()
+        p = ops.linear_fwd(tab, w, b, relu=True, x_rows=rows, want_bits=True)
+        ent = getattr(p, "_ogl_bits", None)
+        assert ent is not None, "the product did not take the image kernel"
+        bits = ent[0]
+        got = bits.buf.cpu().numpy()
+        y = p.cpu().numpy()[:, :N]
+        pad = np.zeros((M, bits.ld * 4), bool); pad[:, :N] = y > 0
+        want = (pad[:, 0::4] * 1 + pad[:, 1::4] * 2 + pad[:, 2::4] * 4 + pad[:, 3::4] * 8).astype(np.uint8)
+        assert np.array_equal(got & 15, want)
+        if N % 4 == 0:
+            n_dst, S = 700, 10
+            idx = torch.as_tensor(rng.integers(0, M, (n_dst, S)).astype(np.int32)).cuda()
+            dout = ops.empty_mat(n_dst, N, "cuda"); dout.normal_()
+            a_out, a_img = ops.reduce_bwd_seg_apply(dout, idx, ops.reduce_bwd_seg_plan(idx, N, M, side=False), "mean", mask=p, want_image=True)
+            b_out, b_img = ops.reduce_bwd_seg_apply(dout, idx, ops.reduce_bwd_seg_plan(idx, N, M, side=False), "mean", mask=bits, want_image=True)
+            assert torch.equal(a_out, b_out) and torch.equal(a_img.buf, b_img.buf)
+    finally:
+        ops.set_gemm_mode(old)
+        ops._X3_TABLES.clear()
+        ops.invalidate_weight_images()
