@@ -2,7 +2,7 @@
 # Copy what tools/collect_profiles.sh left under gpurun_out/prof_final into profiles/ under the round's names and derive the
 # traffic JSONs bench.py quotes.  Usage: bash tools/assemble_profiles.sh r03 2026-10-04
 set -e
-R=${1:-r04}; D=${2:-$(date +%F)}
+R=${1:-r05}; D=${2:-$(date +%F)}
 O=gpurun_out/prof_final; P=profiles; H=$(git rev-parse --short HEAD)
 cp $O/bench.json $P/${R}_bench_final.json
 cp $O/bench_eager.json $P/${R}_bench_eager.json
@@ -30,13 +30,13 @@ if rows:
                    runs=rows), open('profiles/%s_ab_pool_plan.json' % R, 'w'), indent=1)
 PY
 [ -f $O/parity_numbers.log ] && grep -E "200-step curve|accumulated gradient|out-of-tolerance logits|relative gradient errors|weights outside|forward parity|passed|failed" $O/parity_numbers.log > $P/${R}_parity_numbers.txt || true
-[ -f $O/ab_r04.txt ] && python - "$R" <<'PY' || true
+[ -f $O/ab_$R.txt ] && python - "$R" <<'PY' || true
 import glob, json, re, sys
 R = sys.argv[1]
-txt = open('gpurun_out/prof_final/ab_r04.txt').read()
+txt = open('gpurun_out/prof_final/ab_%s.txt' % R).read()
 combos = dict(re.findall(r"^(c\d+) = (.*)$", txt, flags=re.M))
 runs = {}
-for f in sorted(glob.glob('gpurun_out/prof_final/ab_r04/*.json')):
+for f in sorted(glob.glob('gpurun_out/prof_final/ab_%s/*.json' % R)):
     try:
         d = json.loads(open(f).read().strip().splitlines()[-1])
     except Exception:
@@ -46,6 +46,24 @@ for f in sorted(glob.glob('gpurun_out/prof_final/ab_r04/*.json')):
 json.dump(dict(what="same box, alternating runs of `env <switches> python bench.py --steps 200 --warmup 60 --graphs --no-cpu-baseline --no-e2e` "
                     "(tools/ab_combo.sh): the round's switches against the default (OGL_X=0 is a no-op)", runs=runs),
           open('profiles/%s_ab_experiments.json' % R, 'w'), indent=1)
+PY
+for f in ab_vs_r04.txt rf_probe.txt micro.txt pmc_waits.txt step_timeline_pubmed_rbr.txt step_timeline_arxiv_rbr.txt ab_sample_fused_pubmed_rbr.txt ab_sample_fused_arxiv_rbr.txt; do
+  [ -f $O/$f ] && grep -v amdgpu.ids $O/$f > $P/${R}_$f || true
+done
+python - "$R" <<'PY' || true
+import glob, json, sys
+R = sys.argv[1]
+rows = {}
+for f in sorted(glob.glob('gpurun_out/prof_final/ab_meanbits*.json')):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+    except Exception:
+        continue
+    rows[f.split('/')[-1][:-5]] = dict(ms_per_step=d['ms_per_step'], vertices_per_s=d['value'],
+                                       mean_backward_apply_ms=(d['kernels'].get('ogl_reduce_bwd_seg_apply') or {}).get('ms_per_step'))
+if rows:
+    json.dump(dict(what="same box, alternating runs of `OGL_POOL_MEAN_BITS=0|1 python bench.py --aggregator meanpool --steps 100 --warmup 20`", runs=rows),
+              open('profiles/%s_ab_meanpool_sign_bits.json' % R, 'w'), indent=1)
 PY
 [ -f $O/block_build_probe.txt ] && grep -v amdgpu.ids $O/block_build_probe.txt > $P/${R}_block_build_probe.txt || true
 [ -f $O/dw_pool0_probe.txt ] && cp $O/dw_pool0_probe.txt $P/${R}_dw_pool0_probe.txt || true
