@@ -26,8 +26,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
-PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"   # the committed rocprofv3 --pmc pass `roofline.traffic` is quoted from
-PMC_PBR_TRAFFIC_FILE = "r04_pbr_pmc_traffic.json"   # ... and the one of the PBR priority-forward workloads
+PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"   # the committed rocprofv3 --pmc pass `roofline.traffic` is quoted from
+PMC_PBR_TRAFFIC_FILE = "r05_pbr_pmc_traffic.json"   # ... and the one of the PBR priority-forward workloads
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 MFMA_F32_PEAK_TFLOPS = 157.3
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense (MI355X_MICROARCH.md); AMD's 5 PF headline includes 2:1 sparsity

@@ -6,84 +6,96 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof_final
 mkdir -p $O
 cd $R
-timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err < /dev/null
-timeout -k 10 300 python bench.py --no-graphs --no-cpu-baseline --no-e2e > $O/bench_eager.json 2> $O/bench_eager.err < /dev/null
-for w in reddit_pbr_forward arxiv_pbr_forward arxiv_rbr pubmed_rbr pubmed_settings arxiv_settings bitcoin_settings reddit_settings reddit_settings_pbr_forward; do
-  timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err < /dev/null
-done
-# the in-repo aggregator modes at the Reddit rung (round 4: first-class workloads, mean backward as a planned segmented gather)
-for a in meanpool mean; do
-  timeout -k 10 300 python bench.py --aggregator $a --no-cpu-baseline --no-e2e > $O/bench_reddit_rbr_$a.json 2> $O/bench_reddit_rbr_$a.err < /dev/null
-done
-# the numbers the round-4 parity tests print (loss curves, x6-vs-fp32 counts, gradient errors at the Reddit rung)
-timeout -k 10 600 python -m pytest tests/test_gpu_rungs.py tests/test_gpu_fullsize.py tests/test_gpu_round4.py -q -s -k "200_step or no_worse or inrepo_modes or two_part or fused_output_layer_step" > $O/parity_numbers.log 2>&1 < /dev/null || true
-# same-box A/B of the round's switches inside the replayed step (kept and dropped ones)
-bash tools/ab_combo.sh r05 3 "OGL_X=0" "OGL_POOL_RF=1" "OGL_BWWK_BLOCKS=128" "OGL_BWWK_BLOCKS=192" "OGL_SLAB_ADAM=0" "OGL_X3_EARLY_A=0" "OGL_FUSED_OUT_FWD=0" > $O/ab_r05.txt 2>&1 || true
-# round 5: this tree against the round-4 tree on the same box (a git worktree under _r04/, when present)
-[ -d _r04 ] && (bash tools/ab_r04.sh 3 > $O/ab_vs_r04.txt 2>&1; cp -r gpurun_out/ab_r04 $O/ab_vs_r04) || true
-# round 5: the 32-seed rungs with the sampling phase as one launch / as eleven graph nodes, and their traced steps
-for w in pubmed_rbr arxiv_rbr; do
-  bash tools/ab_wl.sh OGL_SAMPLE_FUSED $w 3 > $O/ab_sample_fused_$w.txt 2>&1 || true
-  bash tools/trace_wl.sh $w > /dev/null 2>&1 || true
-  cp gpurun_out/trace_$w/timeline.txt $O/step_timeline_$w.txt 2> /dev/null || true
-done
-# round 5: 'meanpool' with the ReLU mask as sign bits from the product's epilogue (off by default)
-for i in 1 2 3; do for c in 0 1; do
-  OGL_POOL_MEAN_BITS=$c timeout -k 10 300 python bench.py --aggregator meanpool --no-cpu-baseline --no-e2e --steps 100 --warmup 20 > $O/ab_meanbits${c}_$i.json 2> /dev/null < /dev/null
-done; done
-# round 5: the record-fed layer-0 weight gradient against the round-4 pair, alone, with its timing-only ablations; micro-benchmarks
-(for d in 0 1 2 4 6 7; do echo "== OGL_RF_DBG=$d (1: no B pieces, 2: no records, 4: no conversion; wrong results, timing only)"; OGL_RF_DBG=$d timeout -k 10 200 python tools/rf_probe.py 2>&1 | grep -v amdgpu.ids; done) > $O/rf_probe.txt 2>&1 || true
-(timeout -k 5 60 tools/micro/lds_atomics; timeout -k 5 60 tools/micro/grid_barrier) > $O/micro.txt 2>&1 || true
-bash tools/pmc_waits.sh > /dev/null 2>&1 || true
-cp gpurun_out/pmc_waits.txt $O/pmc_waits.txt 2> /dev/null || true
-# the loader phase (sampler + block build, hash / direct table / minima in LDS) and the layer-0 weight gradient block by block (even / uneven split-K)
-timeout -k 10 200 python tools/block_build_probe.py > $O/block_build_probe.txt 2>&1 || true
-(OGL_BWWK_UNEVEN=0 timeout -k 10 200 python tools/dw_pool0_probe.py; OGL_BWWK_UNEVEN=1 timeout -k 10 200 python tools/dw_pool0_probe.py; OGL_X3_EARLY_A=0 timeout -k 10 200 python tools/dw_pool0_probe.py) 2>&1 | grep -v amdgpu.ids > $O/dw_pool0_probe.txt || true
-cp -r gpurun_out/ab_r05 $O/ab_r05 2> /dev/null || true
-cd /tmp && export TMPDIR=/tmp
-# the traced / counted runs enqueue eagerly (--no-graphs): the same kernels at the batch's own sizes, one dispatch per launch
-B="$R/bench.py --no-cpu-baseline --no-e2e"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $B --steps 50 --warmup 5 --no-graphs > $O/trace.log 2>&1 < /dev/null
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_graph -- python3 $B --steps 50 --warmup 60 --graphs > $O/trace_graph.log 2>&1 < /dev/null
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $B --steps 10 --warmup 2 --no-graphs > $O/pmc_fetch.log 2>&1 < /dev/null
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $B --steps 10 --warmup 2 --no-graphs > $O/pmc_write.log 2>&1 < /dev/null
-timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 $B --steps 10 --warmup 2 --no-graphs > $O/pmc_mfma.log 2>&1 < /dev/null
-# the PBR priority-forward workloads (what dominates the PBR rungs): kernel stats + FETCH / WRITE passes each
-for w in reddit_pbr_forward arxiv_pbr_forward; do
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$w -- python3 $B --workload $w --steps 50 --warmup 5 > $O/trace_$w.log 2>&1 < /dev/null
-  timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmcf_$w -- python3 $B --workload $w --steps 20 --warmup 2 > $O/pmcf_$w.log 2>&1 < /dev/null
-  timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmcw_$w -- python3 $B --workload $w --steps 20 --warmup 2 > $O/pmcw_$w.log 2>&1 < /dev/null
-done
-cd $R
-T=$(ls $O/trace/*/*kernel_trace.csv | head -1)
-python tools/summarize_trace.py $T > $O/trace_by_grid.txt
-python tools/step_timeline.py $T > $O/step_timeline_eager_traced.txt
-# the replayed step: no host in the loop (the eager step above is host-bound UNDER THE TRACER: ~130 us of device idle per step)
-python tools/step_timeline.py $(ls $O/trace_graph/*/*kernel_trace.csv | head -1) > $O/step_timeline.txt
-python tools/summarize_trace.py $(ls $O/pmc_fetch/*/*kernel_trace.csv | head -1) $(ls $O/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $O/pmc_write/*/*counter_collection.csv | head -1) > $O/pmc_by_grid.txt
-cp $(ls $O/trace/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
-cp $(ls $O/trace_graph/*/*kernel_stats.csv | head -1) $O/kernel_stats_graph.csv
-python tools/summarize_pmc_mfma.py $(ls $O/pmc_mfma/*/*kernel_trace.csv | head -1) $(ls $O/pmc_mfma/*/*counter_collection.csv | head -1) > $O/pmc_mfma_busy.txt 2>&1 || true
-for w in reddit_pbr_forward arxiv_pbr_forward; do
-  cp $(ls $O/trace_$w/*/*kernel_stats.csv | head -1) $O/pbr_${w}_kernel_stats.csv
-  python tools/summarize_trace.py $(ls $O/trace_$w/*/*kernel_trace.csv | head -1) > $O/pbr_${w}_trace_by_grid.txt
-  python tools/summarize_trace.py $(ls $O/pmcf_$w/*/*kernel_trace.csv | head -1) $(ls $O/pmcf_$w/*/*counter_collection.csv | head -1) $(ls $O/pmcw_$w/*/*counter_collection.csv | head -1) > $O/pbr_${w}_pmc_by_grid.txt
-done
-rm -rf $O/trace $O/trace_graph $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/trace_reddit_pbr_forward $O/trace_arxiv_pbr_forward $O/pmcf_* $O/pmcw_*
-timeout -k 10 300 python bench.py --force-dist --steps 100 --warmup 10 --no-cpu-baseline --no-e2e > $O/bench_force_dist.json 2> $O/bench_force_dist.err < /dev/null
-timeout -k 10 300 python bench.py --force-dist --dp-capture 1 --steps 100 --warmup 10 --no-cpu-baseline --no-e2e > $O/bench_force_dist_captured.json 2> /dev/null < /dev/null
-timeout -k 10 300 python bench.py --force-dist --no-graphs --steps 100 --warmup 10 --no-cpu-baseline --no-e2e > $O/bench_force_dist_eager.json 2> /dev/null < /dev/null
-timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_2rank_gloo.json 2> /dev/null < /dev/null
-timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --steps 20 --warmup 2 --workload reddit_pbr_forward --partition features > $O/bench_2rank_gloo_pbr_partitioned.json 2> /dev/null < /dev/null
-timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --steps 50 --warmup 5 --scaling strong --no-cpu-baseline > $O/bench_2rank_gloo_strong.json 2> /dev/null < /dev/null
-for i in 1 2; do
-  OGL_FORK_BWD=0 timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --graphs > $O/ab_fork0_graphs_$i.json 2> /dev/null < /dev/null
-  OGL_FORK_BWD=1 timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --graphs > $O/ab_fork1_graphs_$i.json 2> /dev/null < /dev/null
-  OGL_FORK_BWD=0 timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-graphs > $O/ab_fork0_eager_$i.json 2> /dev/null < /dev/null
-  OGL_FORK_BWD=1 timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-graphs > $O/ab_fork1_eager_$i.json 2> /dev/null < /dev/null
-done
-for i in 1 2 3; do
-  OGL_POOL_PLAN=0 timeout -k 10 200 python bench.py --steps 200 --warmup 60 --no-cpu-baseline --no-e2e --graphs > $O/ab_plan0_graphs_$i.json 2> /dev/null < /dev/null
-  OGL_POOL_PLAN=1 timeout -k 10 200 python bench.py --steps 200 --warmup 60 --no-cpu-baseline --no-e2e --graphs > $O/ab_plan1_graphs_$i.json 2> /dev/null < /dev/null
-done
-head -c 400 $O/bench.json
+PART=${1:-all}
+part_A1() {
+  timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err < /dev/null
+  timeout -k 10 300 python bench.py --no-graphs --no-cpu-baseline --no-e2e > $O/bench_eager.json 2> $O/bench_eager.err < /dev/null
+  for w in reddit_pbr_forward arxiv_pbr_forward arxiv_rbr pubmed_rbr pubmed_settings arxiv_settings bitcoin_settings reddit_settings reddit_settings_pbr_forward; do
+    timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err < /dev/null
+  done
+  # the in-repo aggregator modes at the Reddit rung (round 4: first-class workloads, mean backward as a planned segmented gather)
+  for a in meanpool mean; do
+    timeout -k 10 300 python bench.py --aggregator $a --no-cpu-baseline --no-e2e > $O/bench_reddit_rbr_$a.json 2> $O/bench_reddit_rbr_$a.err < /dev/null
+  done
+  # the numbers the round-4 parity tests print (loss curves, x6-vs-fp32 counts, gradient errors at the Reddit rung)
+  timeout -k 10 600 python -m pytest tests/test_gpu_rungs.py tests/test_gpu_fullsize.py tests/test_gpu_round4.py -q -s -k "200_step or no_worse or inrepo_modes or two_part or fused_output_layer_step" > $O/parity_numbers.log 2>&1 < /dev/null || true
+}
+part_A2() {
+  # same-box A/B of the round's switches inside the replayed step (kept and dropped ones)
+  bash tools/ab_combo.sh r05 3 "OGL_X=0" "OGL_POOL_RF=1" "OGL_BWWK_BLOCKS=128" "OGL_BWWK_BLOCKS=192" "OGL_SLAB_ADAM=0" "OGL_X3_EARLY_A=0" "OGL_FUSED_OUT_FWD=0" > $O/ab_r05.txt 2>&1 || true
+  # round 5: this tree against the round-4 tree on the same box (a git worktree under _r04/, when present)
+  [ -d _r04 ] && (bash tools/ab_r04.sh 3 > $O/ab_vs_r04.txt 2>&1; cp -r gpurun_out/ab_r04 $O/ab_vs_r04) || true
+  # round 5: the 32-seed rungs with the sampling phase as one launch / as eleven graph nodes, and their traced steps
+  for w in pubmed_rbr arxiv_rbr; do
+    bash tools/ab_wl.sh OGL_SAMPLE_FUSED $w 3 > $O/ab_sample_fused_$w.txt 2>&1 || true
+    bash tools/trace_wl.sh $w > /dev/null 2>&1 || true
+    cp gpurun_out/trace_$w/timeline.txt $O/step_timeline_$w.txt 2> /dev/null || true
+  done
+  # round 5: 'meanpool' with the ReLU mask as sign bits from the product's epilogue (off by default)
+  for i in 1 2 3; do for c in 0 1; do
+    OGL_POOL_MEAN_BITS=$c timeout -k 10 300 python bench.py --aggregator meanpool --no-cpu-baseline --no-e2e --steps 100 --warmup 20 > $O/ab_meanbits${c}_$i.json 2> /dev/null < /dev/null
+  done; done
+  # round 5: the record-fed layer-0 weight gradient against the round-4 pair, alone, with its timing-only ablations; micro-benchmarks
+  (for d in 0 1 2 4 6 7; do echo "== OGL_RF_DBG=$d (1: no B pieces, 2: no records, 4: no conversion; wrong results, timing only)"; OGL_RF_DBG=$d timeout -k 10 200 python tools/rf_probe.py 2>&1 | grep -v amdgpu.ids; done) > $O/rf_probe.txt 2>&1 || true
+  (timeout -k 5 60 tools/micro/lds_atomics; timeout -k 5 60 tools/micro/grid_barrier) > $O/micro.txt 2>&1 || true
+  bash tools/pmc_waits.sh > /dev/null 2>&1 || true
+  cp gpurun_out/pmc_waits.txt $O/pmc_waits.txt 2> /dev/null || true
+  # the loader phase (sampler + block build, hash / direct table / minima in LDS) and the layer-0 weight gradient block by block (even / uneven split-K)
+  timeout -k 10 200 python tools/block_build_probe.py > $O/block_build_probe.txt 2>&1 || true
+  (OGL_BWWK_UNEVEN=0 timeout -k 10 200 python tools/dw_pool0_probe.py; OGL_BWWK_UNEVEN=1 timeout -k 10 200 python tools/dw_pool0_probe.py; OGL_X3_EARLY_A=0 timeout -k 10 200 python tools/dw_pool0_probe.py) 2>&1 | grep -v amdgpu.ids > $O/dw_pool0_probe.txt || true
+  cp -r gpurun_out/ab_r05 $O/ab_r05 2> /dev/null || true
+}
+part_B() {
+  cd /tmp && export TMPDIR=/tmp
+  # the traced / counted runs enqueue eagerly (--no-graphs): the same kernels at the batch's own sizes, one dispatch per launch
+  B="$R/bench.py --no-cpu-baseline --no-e2e"
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $B --steps 50 --warmup 5 --no-graphs > $O/trace.log 2>&1 < /dev/null
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_graph -- python3 $B --steps 50 --warmup 60 --graphs > $O/trace_graph.log 2>&1 < /dev/null
+  timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $B --steps 10 --warmup 2 --no-graphs > $O/pmc_fetch.log 2>&1 < /dev/null
+  timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $B --steps 10 --warmup 2 --no-graphs > $O/pmc_write.log 2>&1 < /dev/null
+  timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 $B --steps 10 --warmup 2 --no-graphs > $O/pmc_mfma.log 2>&1 < /dev/null
+  # the PBR priority-forward workloads (what dominates the PBR rungs): kernel stats + FETCH / WRITE passes each
+  for w in reddit_pbr_forward arxiv_pbr_forward; do
+    timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$w -- python3 $B --workload $w --steps 50 --warmup 5 > $O/trace_$w.log 2>&1 < /dev/null
+    timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmcf_$w -- python3 $B --workload $w --steps 20 --warmup 2 > $O/pmcf_$w.log 2>&1 < /dev/null
+    timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmcw_$w -- python3 $B --workload $w --steps 20 --warmup 2 > $O/pmcw_$w.log 2>&1 < /dev/null
+  done
+  cd $R
+  T=$(ls $O/trace/*/*kernel_trace.csv | head -1)
+  python tools/summarize_trace.py $T > $O/trace_by_grid.txt
+  python tools/step_timeline.py $T > $O/step_timeline_eager_traced.txt
+  # the replayed step: no host in the loop (the eager step above is host-bound UNDER THE TRACER: ~130 us of device idle per step)
+  python tools/step_timeline.py $(ls $O/trace_graph/*/*kernel_trace.csv | head -1) > $O/step_timeline.txt
+  python tools/summarize_trace.py $(ls $O/pmc_fetch/*/*kernel_trace.csv | head -1) $(ls $O/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $O/pmc_write/*/*counter_collection.csv | head -1) > $O/pmc_by_grid.txt
+  cp $(ls $O/trace/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
+  cp $(ls $O/trace_graph/*/*kernel_stats.csv | head -1) $O/kernel_stats_graph.csv
+  python tools/summarize_pmc_mfma.py $(ls $O/pmc_mfma/*/*kernel_trace.csv | head -1) $(ls $O/pmc_mfma/*/*counter_collection.csv | head -1) > $O/pmc_mfma_busy.txt 2>&1 || true
+  for w in reddit_pbr_forward arxiv_pbr_forward; do
+    cp $(ls $O/trace_$w/*/*kernel_stats.csv | head -1) $O/pbr_${w}_kernel_stats.csv
+    python tools/summarize_trace.py $(ls $O/trace_$w/*/*kernel_trace.csv | head -1) > $O/pbr_${w}_trace_by_grid.txt
+    python tools/summarize_trace.py $(ls $O/pmcf_$w/*/*kernel_trace.csv | head -1) $(ls $O/pmcf_$w/*/*counter_collection.csv | head -1) $(ls $O/pmcw_$w/*/*counter_collection.csv | head -1) > $O/pbr_${w}_pmc_by_grid.txt
+  done
+  rm -rf $O/trace $O/trace_graph $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/trace_reddit_pbr_forward $O/trace_arxiv_pbr_forward $O/pmcf_* $O/pmcw_*
+}
+part_C() {
+  timeout -k 10 300 python bench.py --force-dist --steps 100 --warmup 10 --no-cpu-baseline --no-e2e > $O/bench_force_dist.json 2> $O/bench_force_dist.err < /dev/null
+  timeout -k 10 300 python bench.py --force-dist --dp-capture 1 --steps 100 --warmup 10 --no-cpu-baseline --no-e2e > $O/bench_force_dist_captured.json 2> /dev/null < /dev/null
+  timeout -k 10 300 python bench.py --force-dist --no-graphs --steps 100 --warmup 10 --no-cpu-baseline --no-e2e > $O/bench_force_dist_eager.json 2> /dev/null < /dev/null
+  timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_2rank_gloo.json 2> /dev/null < /dev/null
+  timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --steps 20 --warmup 2 --workload reddit_pbr_forward --partition features > $O/bench_2rank_gloo_pbr_partitioned.json 2> /dev/null < /dev/null
+  timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --steps 50 --warmup 5 --scaling strong --no-cpu-baseline > $O/bench_2rank_gloo_strong.json 2> /dev/null < /dev/null
+  for i in 1 2; do
+    OGL_FORK_BWD=0 timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --graphs > $O/ab_fork0_graphs_$i.json 2> /dev/null < /dev/null
+    OGL_FORK_BWD=1 timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --graphs > $O/ab_fork1_graphs_$i.json 2> /dev/null < /dev/null
+    OGL_FORK_BWD=0 timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-graphs > $O/ab_fork0_eager_$i.json 2> /dev/null < /dev/null
+    OGL_FORK_BWD=1 timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-graphs > $O/ab_fork1_eager_$i.json 2> /dev/null < /dev/null
+  done
+  for i in 1 2 3; do
+    OGL_POOL_PLAN=0 timeout -k 10 200 python bench.py --steps 200 --warmup 60 --no-cpu-baseline --no-e2e --graphs > $O/ab_plan0_graphs_$i.json 2> /dev/null < /dev/null
+    OGL_POOL_PLAN=1 timeout -k 10 200 python bench.py --steps 200 --warmup 60 --no-cpu-baseline --no-e2e --graphs > $O/ab_plan1_graphs_$i.json 2> /dev/null < /dev/null
+  done
+}
+# a gpurun call lasts at most 20 minutes: collect in parts (A1: bench lines + parity numbers, A2: A/Bs + probes, B: rocprofv3 traces + counters,
+# C: replica / two-rank lines + fork / plan A/Bs); "all" runs them in order (for a box without that limit)
+case $PART in A1) part_A1;; A2) part_A2;; B) part_B;; C) part_C;; all) part_A1; part_A2; part_B; part_C;; esac
+head -c 300 $O/bench.json 2> /dev/null || true
