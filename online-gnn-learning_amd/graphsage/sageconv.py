@@ -76,8 +76,12 @@ class SAGEConv(nn.Module):
         self.norm, self.activation = norm, activation
         self.feat_drop = nn.Dropout(feat_drop)
         self.fc_pool = self.fc_self = self.fc_neigh = None
-        if edge_feats:
-            raise NotImplementedError("edge features are outside the hot path (settings use edge_feats=0)")
+        edge_feats = int(edge_feats or 0)
+        if edge_feats and aggregator_type not in ("mean", "meanpool", "maxpool"):
+            # (the reference's own gcn / lstm reducers do not survive edge features either: the gcn sum is added to h_dst of another
+            # width, the LSTM's initial state has in_feats columns — aggregator_dgl.py:123-125,165-167; the live DGL layer has none)
+            raise NotImplementedError("edge features: 'mean', 'meanpool' and 'maxpool' only")
+        self._edge_feats = edge_feats
         self.lstm = None
         if aggregator_type == "lstm" and in_feats > 0:
             # (aggregator_dgl.py:76-77; outside the hot path — no setting file uses it: the library LSTM (MIOpen) over the gathered
@@ -96,7 +100,8 @@ class SAGEConv(nn.Module):
             if aggregator_type == "gcn":
                 self.fc_neigh = nn.Linear(in_neigh, out_feats, bias=bias)
             else:
-                self.fc_neigh = nn.Linear(in_neigh + in_feats, out_feats, bias=bias)
+                # fc_neigh(cat(h_self, reduce(cat(h, e)))): Linear(in_neigh + edge + in, out) (aggregator_dgl.py:94)
+                self.fc_neigh = nn.Linear(in_neigh + edge_feats + in_feats, out_feats, bias=bias)
         self.in_neigh_feats = in_neigh
         self.reset_parameters()
 
@@ -176,7 +181,7 @@ class SAGEConv(nn.Module):
                 if ops._CAPTURE is not None:
                     ops._CAPTURE.append(dict(pool_out=p.detach()))      # (test hook, see ops.capture_pool_winners)
                 h_neigh = ops.neighbor_reduce(p, idx, "mean")
-            rst = self._linear_cat(feat_dst, h_neigh, fuse_relu)
+            rst = self._linear_cat(feat_dst, self._with_edges(graph, h_neigh, "max" if t == "maxpool" else "mean"), fuse_relu)
         elif t == "mean":
             if (lazy and idx.dtype == torch.int32 and ops._n1_images_ok(n_dst, feat.shape[1], self._out_feats)
                     and not feat.table.requires_grad and ops._static_key(feat.table) in ops._X3_TABLES):
@@ -188,7 +193,7 @@ class SAGEConv(nn.Module):
             else:
                 src = feat.materialize() if lazy else feat
                 h_neigh = ops.neighbor_reduce(src, idx, "mean")
-            rst = self._linear_cat(feat_dst, h_neigh, fuse_relu)
+            rst = self._linear_cat(feat_dst, self._with_edges(graph, h_neigh, "mean"), fuse_relu)
         elif t == "lstm":
             # aggregator_dgl.py:116-126,195-199: h_n of nn.LSTM over each destination's mailbox (slot order), zero initial state;
             # a destination without edges keeps zeros.  Library path: ATen gather -> MIOpen LSTM (the mailbox [n_dst, S, D] is
@@ -324,6 +329,27 @@ class SAGEConv(nn.Module):
         if isinstance(feat, GatheredRows):
             return ops.pool_max(feat.table, self.fc_pool.weight, self.fc_pool.bias, idx, feat.ids)
         return ops.pool_max(feat, self.fc_pool.weight, self.fc_pool.bias, idx, None)
+
+    def _with_edges(self, graph, h_neigh, op):
+        """``cat(h_neigh, reduce_j edge_feat[d, j])`` when the layer was built with edge features (the message of an edge is
+        ``cat(src h, edge feat)``, aggregator_dgl.py:7-13: the reduction of the concatenation is the concatenation of the
+        reductions), else ``h_neigh``.  ``graph.edata['feat']``: [n_dst, S, E] or [n_dst * S, E], one row per (destination, slot).
+        The edge half is reduced by the package's aggregator over an identity index (a destination without edges: zeros)."""
+        if not self._edge_feats:
+            return h_neigh
+        e = graph.edata.get("feat") if hasattr(graph, "edata") else None
+        if e is None:
+            raise KeyError("this layer was built with edge_feats=%d: the block needs edata['feat']" % self._edge_feats)
+        idx = graph.local_idx
+        n_dst, S = idx.shape
+        e = ops.as_mat(e.reshape(n_dst * S, -1))
+        assert e.shape[1] == self._edge_feats
+        eidx = torch.arange(n_dst * S, dtype=torch.int32, device=idx.device).view(n_dst, S)
+        eidx = torch.where(idx[:, :1] >= 0, eidx, torch.full_like(eidx, -1)).contiguous()    # (all S edges exist, or none)
+        e_red, _ = ops.reduce_fwd(e, eidx, op)
+        if ops.take_image(h_neigh, pop=False) is not None:
+            ops.take_image(h_neigh)               # (the pooled rows' image does not cover the appended columns)
+        return torch.cat((h_neigh, e_red[:, :self._edge_feats]), 1)
 
     def _linear_cat(self, x1, x2, relu):
         """fc_neigh(cat(h_self, h_neigh)) (aggregator_dgl.py:206): one dual-input product over the two column blocks of the weight,

@@ -271,6 +271,26 @@ def _neigh_torch(p, local_idx, op, forced=None, connect_empty=False):
     return out
 
 
+def _edge_reduce(edge_feat, local_idx, op):
+    """The edge-feature half of a reduced mailbox: mean / max over a destination's S edges of ``edge_feat[d, j]`` (slot order),
+    zeros for a destination without edges (the reference's mailbox reduction runs over destinations that have edges only)."""
+    e = torch.as_tensor(np.asarray(edge_feat), dtype=torch.float32)
+    li = np.asarray(local_idx)
+    has = torch.as_tensor(li[:, 0] >= 0) if li.shape[1] > 0 else torch.zeros(len(li), dtype=torch.bool)
+    out = e.new_zeros((e.shape[0], e.shape[2]))
+    if has.any():
+        rows = e[has]
+        if op == "max":
+            red = rows.amax(dim=1)
+        else:
+            acc = rows[:, 0, :]
+            for j in range(1, rows.shape[1]):
+                acc = acc + rows[:, j, :]
+            red = acc / rows.shape[1]
+        out = out.index_put((torch.nonzero(has)[:, 0],), red)
+    return out
+
+
 def _lstm_last_hidden(rows, params):
     """Final hidden state of a one-layer LSTM over the mailbox rows [n, S, D] (slot order = sequence order) from zero initial
     state: R/train/graphsage/pytorch/aggregator_dgl.py:116-126 (``nn.LSTM(D, D, batch_first=True)``; the reducer returns h_n).
@@ -288,7 +308,7 @@ def _lstm_last_hidden(rows, params):
     return h
 
 
-def sageconv_forward(mode, h_src, n_dst, local_idx, params, activation=None, forced=None, dropout=None, trace=None):
+def sageconv_forward(mode, h_src, n_dst, local_idx, params, activation=None, forced=None, dropout=None, trace=None, edge_feat=None):
     """One SAGEConv layer on a fixed-fanout block.
 
     mode ``pool``      — live DGL layer (max; fc_pool in->in; fc_self + fc_neigh).
@@ -300,6 +320,9 @@ def sageconv_forward(mode, h_src, n_dst, local_idx, params, activation=None, for
     ``act_mask`` replaces the output ReLU by the device's mask of it (any mode).  In-repo pooling modes: an optional ``pool_mask``
     (bool [n_src, pool_feats]) replaces ``relu(fc_pool(h))`` by ``where(pool_mask, fc_pool(h), 0)`` — the same function wherever the
     two evaluations agree on the sign, and a unit within rounding of 0 is routed the way the device routed it.
+    ``edge_feat`` ([n_dst, S, E], in-repo modes ``mean`` / ``meanpool`` / ``maxpool`` only): the message of edge (d, j) is
+    ``cat(h_src[idx[d, j]], edge_feat[d, j])`` (R/.../aggregator_dgl.py:7-13), so the reduced vector gains E columns and
+    ``fc_neigh`` takes ``cat(h_self, reduce(h), reduce(e))`` (``Linear(in_neigh + E + in, out)``, :94).
     ``trace`` (a list): appends dict(pool_mask=..., act_mask=...) — THIS evaluation's own ReLU decisions (numpy bool, None where the
     layer has none) — so that a test can count where two evaluations disagree.
     ``dropout``: dict(p, seed, ctr) — ``feat_drop`` on the layer input (R/.../graphsage_dgl.py:41 passes
@@ -327,9 +350,13 @@ def sageconv_forward(mode, h_src, n_dst, local_idx, params, activation=None, for
         else:
             p = F.relu(pre)
         neigh = _neigh_torch(p, li, "mean" if mode == "meanpool" else "max")
+        if edge_feat is not None:
+            neigh = torch.cat((neigh, _edge_reduce(edge_feat, li, "mean" if mode == "meanpool" else "max")), 1)
         rst = F.linear(torch.cat((h_dst, neigh), 1), params["fc_neigh.weight"], params["fc_neigh.bias"])
     elif mode == "mean":
         neigh = _neigh_torch(h_src, li, "mean")
+        if edge_feat is not None:
+            neigh = torch.cat((neigh, _edge_reduce(edge_feat, li, "mean")), 1)
         rst = F.linear(torch.cat((h_dst, neigh), 1), params["fc_neigh.weight"], params["fc_neigh.bias"])
     elif mode == "lstm":
         # (aggregator_dgl.py:195-199: the LSTM reducer over each destination's mailbox; a destination without edges keeps zeros)

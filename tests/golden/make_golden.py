@@ -65,7 +65,10 @@ class FakeBlock:
         if has.any():
             idx = torch.as_tensor(li[has].astype(np.int64))            # [n, S]
             n, S = idx.shape
-            edges = types.SimpleNamespace(src={"h": self.srcdata["h"][idx.reshape(-1)]}, data={})
+            data = {}
+            if "feat" in self.edata:                                   # edge features [n_dst, S, E]: the mailbox keeps slot order
+                data["feat"] = self.edata["feat"][torch.as_tensor(has)].reshape(n * S, -1)
+            edges = types.SimpleNamespace(src={"h": self.srcdata["h"][idx.reshape(-1)]}, data=data)
             m = message_fn(edges)["m"].reshape(n, S, -1)
             nodes = types.SimpleNamespace(mailbox={"m": m})
             red = reduce_fn(nodes)
@@ -84,19 +87,26 @@ def make_block(rng, n_dst, n_src, fanout, frac_isolated):
     return li
 
 
-def sageconv_case(tag, mode, n_dst, n_src, fanout, fin, fout, pool, frac_iso, seed):
+def sageconv_case(tag, mode, n_dst, n_src, fanout, fin, fout, pool, frac_iso, seed, edge=0):
     torch.manual_seed(seed)
     rng = np.random.default_rng(seed)
     layer = SAGEConv(fin, fout, mode, feat_drop=0.0, activation=torch.nn.functional.relu,
-                     edge_feats=0, pool_feats=pool)
+                     edge_feats=edge, pool_feats=pool)
     li = make_block(rng, n_dst, n_src, fanout, frac_iso)
     x = torch.randn(n_src, fin, requires_grad=True)
     blk = FakeBlock(n_src, li)
+    e = None
+    if edge:
+        # edge features of every (destination, slot) edge: message = cat(src h, edge feat) (aggregator_dgl.py:7-13)
+        e = torch.randn(n_dst, fanout, edge)
+        blk.edata["feat"] = e
     y = layer(blk, x)
     gy = torch.randn_like(y)
     y.backward(gy)
     out = dict(mode=mode, local_idx=li, x=x.detach().numpy(), y=y.detach().numpy(), gy=gy.numpy(),
                gx=x.grad.numpy(), pool_feats=-1 if pool is None else pool)
+    if e is not None:
+        out["edge"] = e.numpy()
     for k, v in layer.state_dict().items():
         out["param." + k] = v.numpy()
     for k, p in layer.named_parameters():
@@ -205,7 +215,19 @@ def priority_cases():
     print("added trend_priority / hybrid_priority to replay.json")
 
 
+def edge_cases():
+    """Round 5: the in-repo layer WITH edge features (edge_feats > 0: fc_neigh takes cat(h_self, reduce(cat(h_src, e))))."""
+    sageconv_case("edge_mean_toy", "mean", 4, 9, 3, 6, 5, None, 0.25, 31, edge=2)
+    sageconv_case("edge_meanpool_toy", "meanpool", 4, 9, 3, 6, 5, 7, 0.25, 32, edge=3)
+    sageconv_case("edge_mean_mid", "mean", 96, 700, 25, 50, 32, None, 0.1, 33, edge=5)
+    sageconv_case("edge_meanpool_mid", "meanpool", 96, 700, 25, 50, 32, 40, 0.1, 34, edge=8)
+
+
 if __name__ == "__main__":
+    if "--edge-only" in sys.argv:
+        edge_cases()
+        sys.exit(0)
+    edge_cases()
     #            tag            mode      n_dst n_src fanout fin fout pool  iso   seed
     sageconv_case("mean_toy", "mean", 4, 9, 3, 6, 5, None, 0.25, 11)
     sageconv_case("meanpool_toy", "meanpool", 4, 9, 3, 6, 5, 7, 0.25, 12)

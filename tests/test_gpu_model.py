@@ -86,10 +86,14 @@ def test_sageconv_matches_reference_golden(pkg, path):
     n_dst, n_src = li.shape[0], g["x"].shape[0]
     fin, fout = g["x"].shape[1], g["y"].shape[1]
     pool = int(g["pool_feats"])
-    layer = SAGEConv(fin, fout, mode, activation=F.relu, pool_feats=None if pool < 0 else pool).cuda()
+    edge = g["edge"] if "edge" in g.files else None               # (round 5: the layer with edge features)
+    layer = SAGEConv(fin, fout, mode, activation=F.relu, pool_feats=None if pool < 0 else pool,
+                     edge_feats=0 if edge is None else edge.shape[2]).cuda()
     sd = {k[len("param."):]: torch.tensor(g[k]) for k in g.files if k.startswith("param.")}
     layer.load_state_dict(sd)
     blk = Block(torch.arange(n_src).cuda(), torch.arange(n_dst).cuda(), cuda(li))
+    if edge is not None:
+        blk.edata["feat"] = cuda(edge)
     x = cuda(g["x"]).requires_grad_(True)
     y = layer(blk, x)
     np.testing.assert_allclose(y.detach().cpu().numpy(), g["y"], rtol=1e-4, atol=1e-5)

@@ -100,7 +100,7 @@ def test_layer_matches_reference_golden(path):
     params = {k[len("param."):]: torch.tensor(g[k], requires_grad=True) for k in g.files if k.startswith("param.")}
     x = torch.tensor(g["x"], requires_grad=True)
     li = g["local_idx"]
-    y = O.sageconv_forward(mode, x, li.shape[0], li, params, activation=F.relu)
+    y = O.sageconv_forward(mode, x, li.shape[0], li, params, activation=F.relu, edge_feat=g["edge"] if "edge" in g.files else None)
     np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-5, atol=1e-6)
     y.backward(torch.tensor(g["gy"]))
     np.testing.assert_allclose(x.grad.numpy(), g["gx"], rtol=1e-4, atol=1e-6)
