@@ -461,6 +461,13 @@ int ogl_ce_fwd_bwd_mean(const float* logits, int64_t ldl, const int64_t* labels,
 int ogl_ce_fwd_bwd_mean_gather(const float* logits, int64_t ldl, const int64_t* label_table, int64_t n_labels, const int64_t* label_ids,
                                int64_t B, int C, float grad_scale, float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean,
                                float* zero_buf, int64_t zero_floats, ogl_stream_t stream);
+/* ... that also prepares the optimiser's step (what ogl_x3_split_multi_adam does for steps that have a weight-image launch): ++*step_dev,
+ * scalars_dev[0] = lr / (1 - beta1^t), scalars_dev[1] = 1 / sqrt(1 - beta2^t) — torch.optim.Adam's bias corrections
+ * (R/train/graphsage/pytorch/model.py:24-25) in double arithmetic; the optimiser launch of the step then runs with prepare = 0. */
+int ogl_ce_fwd_bwd_mean_gather_adam(const float* logits, int64_t ldl, const int64_t* label_table, int64_t n_labels, const int64_t* label_ids,
+                                    int64_t B, int C, float grad_scale, float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean,
+                                    float* zero_buf, int64_t zero_floats, int64_t* step_dev, float* scalars_dev, double lr, double beta1,
+                                    double beta2, ogl_stream_t stream);
 /* The same for ANY batch size (one wave per row over a grid): the mean is summed by the last block to finish, in the fixed
  * order of the one-workgroup form (bit-identical to it).  `counter`: one zero-initialised device word the caller allocates once
  * (the last block resets it; one counter per stream that may run this concurrently).  loss_rows is required.  zero_buf

@@ -99,6 +99,7 @@ SIGNATURES = {
     "ogl_ce_fwd_bwd_mean": (_i, [_p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p]),
     "ogl_ce_fwd_bwd_mean_grid": (_i, [_p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p, _p, _i64, _p]),
     "ogl_ce_fwd_bwd_mean_gather": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p, _i64, _p]),
+    "ogl_ce_fwd_bwd_mean_gather_adam": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p, _i64, _p, _p, _d, _d, _d, _p]),
     "ogl_ce_fwd_bwd_mean_grid_gather": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p, _p, _i64, _p]),
     "ogl_adam_step": (_i, [_p, _p, _p, _p, _i64, _i, _d, _d, _d, _d, _p]),
     "ogl_argmax_confusion": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p]),

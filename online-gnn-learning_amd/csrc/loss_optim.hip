@@ -64,9 +64,19 @@ __global__ void __launch_bounds__(1024) k_ce_fwd_bwd_mean(const float* __restric
                                                           const int64_t* __restrict__ labels, int B, int C, float grad_scale,
                                                           float* __restrict__ loss_rows, float* __restrict__ dlogits, int64_t lddl,
                                                           float* __restrict__ loss_mean, const int64_t* __restrict__ label_ids,
-                                                          int64_t n_labels, float4* __restrict__ zero_buf, int zero_n4) {
+                                                          int64_t n_labels, float4* __restrict__ zero_buf, int zero_n4,
+                                                          int64_t* __restrict__ adam_step = nullptr, float* __restrict__ adam_scal = nullptr,
+                                                          double adam_lr = 0.0, double adam_b1 = 0.0, double adam_b2 = 0.0) {
   __shared__ float rows[CE_SMALL_MAX_B];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (adam_step && threadIdx.x == 1023) {
+    // optional passenger (ogl_ce_fwd_bwd_mean_gather_adam): the optimiser's per-step scalars — what k_adam_prepare does as a launch of
+    // its own at the END of the step — computed by one otherwise idle thread of the loss launch
+    const int64_t t = *adam_step + 1;
+    *adam_step = t;
+    adam_scal[0] = (float)(adam_lr / (1.0 - pow(adam_b1, (double)t)));
+    adam_scal[1] = (float)(1.0 / sqrt(1.0 - pow(adam_b2, (double)t)));
+  }
   for (int i = threadIdx.x; i < zero_n4; i += 1024) zero_buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // (a small scatter target: see the grid form)
   for (int row = wv; row < B; row += 16) {
     const float* x = logits + (int64_t)row * ldl;
@@ -122,6 +132,25 @@ extern "C" int ogl_ce_fwd_bwd_mean_gather(const float* logits, int64_t ldl, cons
     return OGL_EINVAL;
   hipLaunchKernelGGL(k_ce_fwd_bwd_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ldl, label_table, (int)B, C, grad_scale,
                      loss_rows, dlogits, lddl, loss_mean, label_ids, n_labels, (float4*)zero_buf, (int)(zero_floats / 4));
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+// ... with the optimiser's per-step scalars riding along (the 32-seed steps have no weight-image launch for them to ride in:
+// ogl_x3_split_multi_adam): ++*step_dev; scalars_dev[0] = lr / (1 - beta1^t), scalars_dev[1] = 1 / sqrt(1 - beta2^t).  The optimiser launch
+// of the same step then runs with prepare = 0.
+extern "C" int ogl_ce_fwd_bwd_mean_gather_adam(const float* logits, int64_t ldl, const int64_t* label_table, int64_t n_labels,
+                                               const int64_t* label_ids, int64_t B, int C, float grad_scale, float* loss_rows,
+                                               float* dlogits, int64_t lddl, float* loss_mean, float* zero_buf, int64_t zero_floats,
+                                               int64_t* step_dev, float* scalars_dev, double lr, double beta1, double beta2,
+                                               ogl_stream_t stream) {
+  if (B <= 0 || B > CE_SMALL_MAX_B || C <= 0 || ldl < C || (dlogits && lddl < C) || n_labels < 0) return OGL_EINVAL;
+  if (!logits || !label_table || !loss_mean || !step_dev || !scalars_dev) return OGL_EINVAL;
+  if (zero_floats < 0 || zero_floats > CE_SMALL_MAX_ZERO || (zero_floats > 0 && (!zero_buf || ((uintptr_t)zero_buf & 15) || (zero_floats & 3))))
+    return OGL_EINVAL;
+  hipLaunchKernelGGL(k_ce_fwd_bwd_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ldl, label_table, (int)B, C, grad_scale,
+                     loss_rows, dlogits, lddl, loss_mean, label_ids, n_labels, (float4*)zero_buf, (int)(zero_floats / 4), step_dev,
+                     scalars_dev, lr, beta1, beta2);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }

@@ -1599,6 +1599,15 @@ def ce_fwd_bwd_mean(logits, labels, want_grad=True):
             zbuf, zn = ent[0], ent[0].numel()
             ent[3] = True
     table, ids = (lazy.table, lazy.ids) if lazy is not None else (labels, None)
+    prime = _ADAM_PRIME.get("req")
+    if prime is not None and ADAM_PRIME_IN_SPLIT and want_grad:
+        # a step without a weight-image launch (the 32-seed rungs): the optimiser's per-step scalars ride in the loss launch instead
+        step_dev, scal, lr, b1, b2 = prime
+        _launch("ogl_ce_fwd_bwd_mean", _lib.lib().ogl_ce_fwd_bwd_mean_gather_adam, _ptr(logits), _ld(logits), _ptr(table), table.numel(),
+                _ptr(ids), B, Cc, C.c_float(1.0 / B), _ptr(loss), _ptr(dl), _ld(dl) if dl is not None else 0, _ptr(mean), _ptr(zbuf), zn,
+                _ptr(step_dev), _ptr(scal), C.c_double(lr), C.c_double(b1), C.c_double(b2), _stream(), meta=dict(B=B, C=Cc, adam_prepare=True))
+        _ADAM_PRIME["req"], _ADAM_PRIME["served"] = None, (step_dev.data_ptr(), _capturing())
+        return mean, loss, dl
     _launch("ogl_ce_fwd_bwd_mean", _lib.lib().ogl_ce_fwd_bwd_mean_gather, _ptr(logits), _ld(logits), _ptr(table), table.numel(), _ptr(ids), B, Cc,
             C.c_float(1.0 / B), _ptr(loss), _ptr(dl), _ld(dl) if dl is not None else 0, _ptr(mean), _ptr(zbuf), zn, _stream(),
             meta=dict(B=B, C=Cc))

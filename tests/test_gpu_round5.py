@@ -134,7 +134,8 @@ def test_table_direct_mean_equals_the_mean_over_gathered_rows(ops, n_dst, S, D, 
         assert float(got[1].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("dataset,B,S", [("pubmed", 32, 25), ("arxiv", 32, 25), ("pubmed", 32, 45), ("toy", 7, 3)])
+@pytest.mark.parametrize("dataset,B,S", [("pubmed", 32, 25), ("arxiv", 32, 25), ("pubmed", 32, 45), ("toy", 7, 3),
+                                         ("toy", 40, 39)])     # (the last: > 10 922 positions, the table in global memory)
 def test_fused_small_sampling_phase_equals_the_launch_sequence(ops, dataset, B, S):
     """ogl_sample_blocks_small (one workgroup: stage + 2 x sample + 2 x relabel + publish) writes the SAME static block arrays, counts
     and head as the eleven-node sequence it replaces (ogl_stage_segments, ogl_sample_layer_dev, ogl_build_block_padded,
