@@ -411,6 +411,18 @@ int64_t ogl_linear_bwd_weight_x3k_workspace_bytes(int64_t M, int64_t interleave,
 int ogl_linear_bwd_weight_x3k(const void* dyT_img, int64_t interleave, const void* x_img, int64_t x_img_rows, const int64_t* x_rows,
                               int64_t x_nrows, int64_t M, int N, int K, int has_ones, float* dw, int64_t lddw, float* db, float* db2,
                               void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
+/* BOTH weight gradients of a dual-input projection y = x[x_rows] . w1^T + x2 . w2^T in ONE product (linear_x3.hip, two-part B operand):
+ * slabs [nsplit][N][ws_ld] with dw1 in columns [0, K1), the bias gradient in column K1 (has_ones: the x image carries the ones slot), dw2
+ * in columns [*col2_out, *col2_out + K2).  dy_img: row-major image of dy [M + 1 rows, N]; x_img: row-major image of x (gathered by x_rows);
+ * x2_img: row-major image of x2 [>= M rows, K2] (no gather).  autograd of fc_self / fc_neigh of the live layer's combine
+ * (R/inference_optimized.py:136-139,276) and of fc_neigh(cat(h_self, h_neigh)) of the in-repo layer (R/train/graphsage/pytorch/
+ * aggregator_dgl.py:206).  The workspace query returns 0 and the launch OGL_EINVAL when the plan has a single split (two single
+ * products then). */
+int64_t ogl_linear_bwd_weight_x3k_dual_workspace_bytes(int64_t M, int N, int K1, int has_ones, int K2);
+int ogl_linear_bwd_weight_x3k_dual_slabs(const void* dy_img, int64_t M, int N, const void* x_img, int64_t x_img_rows, const int64_t* x_rows,
+                                         int64_t x_nrows, int K1, int has_ones, const void* x2_img, int64_t x2_img_rows, int K2,
+                                         void* workspace, int64_t workspace_bytes, int* nsplit_out, int64_t* ws_ld_out, int* col2_out,
+                                         ogl_stream_t stream);
 int ogl_linear_bwd_weight_x3(const void* dyT_img, const void* xT_img, int64_t M, int N, int K, float* dw,
                              int64_t lddw, float* db, void* workspace, int64_t workspace_bytes,
                              ogl_stream_t stream);

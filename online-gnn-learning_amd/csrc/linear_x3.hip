@@ -83,6 +83,10 @@ struct X3Args {
   // ---- plain forward products (nsplit == 1): optional SIGN BITS of the output, one byte per 4-column group (bit c = [y[i, 4 g + c] > 0]),
   // row stride relu_bits_ld bytes — the ReLU mask a later backward pass needs, 1/16 of the fp32 matrix it would otherwise re-read ----
   unsigned char* relu_bits; int64_t relu_bits_ld;
+  // ---- k_gemm_x3p<..., BK, AK> only: a TWO-PART B operand by column tile — tiles tj >= NJ1 read the row-major image b2 (its own row
+  // gather / zero row / column groups) where tiles tj < NJ1 read b: both weight gradients of a dual-input projection, dy^T . x[rows] and
+  // dy^T . x2, as ONE product over [x[rows] | x2] without a concatenated image (output columns: part 1 at 0, part 2 at 128 NJ1) ----
+  X3Operand b2; int bk2_groups; int NJ1;
 };
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) — indices into register arrays stay constants
@@ -489,6 +493,11 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
     const __amdgpu_buffer_rsrc_t rsrc_a2 =
         __builtin_amdgcn_make_buffer_rsrc((void*)((EXT && g.a2.img) ? g.a2.img : g.a.img), 0, 0xFFFFFFFF, 0x00020000);
     const bool two = EXT && g.a2.img != nullptr;
+    constexpr bool B2 = BK && AK;                          // (the two-part B operand lives in the k-major x k-major instantiation)
+    const bool two_b = B2 && g.b2.img != nullptr;
+    const __amdgpu_buffer_rsrc_t rsrc_b2 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((B2 && g.b2.img) ? g.b2.img : g.b.img), 0, 0xFFFFFFFF, 0x00020000);
+    bool bc_p2 = false;                                    // wave-uniform: the B cursor's tile reads the second B part
     bool part2 = false;                                    // wave-uniform: the fetch cursor is inside the second A part
     unsigned step_a = (unsigned)g.a.step_bytes;
     const unsigned step_b = (unsigned)g.b.step_bytes;
@@ -506,13 +515,14 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
     int64_t bk_id[2] = {0, 0};                             // raw ids (or positions) of the rows the NEXT fetch moves
     bool bk_ok[2] = {false, false};
     unsigned bk_zmask = 0, ak_zmask = 0;                   // pieces whose column group is past the image row
-    auto bk_request = [&](int ks) __attribute__((always_inline)) {
+    auto bk_request = [&](int ks, bool p2 = false) __attribute__((always_inline)) {
+      const int64_t* const rows = (B2 && p2) ? g.b2.rows : g.b.rows;     // (the rows of the part the requested step's tile reads)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int kl = 8 * bk_w + 4 * h + bk_rsub;
         const int64_t pos = g.bk_interleave ? (int64_t)kl * g.bk_interleave + ks : (int64_t)ks * 32 + kl;
         bk_ok[h] = pos < g.bk_red && (!g.bk_interleave || ks < g.bk_interleave);
-        bk_id[h] = g.b.rows ? g.b.rows[bk_ok[h] ? pos : 0] : pos;
+        bk_id[h] = rows ? rows[bk_ok[h] ? pos : 0] : pos;
       }
     };
     // second part of A: the rows of tile row `ti` in a2 (its own gather / zero row), from a2's first reduction step
@@ -562,9 +572,12 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
           off = (ok ? id : g.a.zero_row) * g.a.row_bytes + (int64_t)t.ks_begin * g.a.step_bytes;
         } else if (BK) {
           const int pc = 16 * ((u - NLP_A) % 3) + bk_ipc;     // piece 0 .. 47 of the row's 768-byte run
-          const int grp = t.tj * (BN / 32) + pc / 12;
-          if (grp >= g.bk_groups) bk_zmask |= 1u << (u - NLP_A);
-          src[u] = (unsigned)((grp < g.bk_groups ? grp : 0) * X3_GROUP_BYTES + (pc % 12) * 16);
+          const bool p2 = two_b && t.tj >= g.NJ1;             // (tile-uniform: the second B part's column tiles)
+          const int grp = (p2 ? t.tj - g.NJ1 : t.tj) * (BN / 32) + pc / 12;
+          const int lim = p2 ? g.bk2_groups : g.bk_groups;
+          if (grp >= lim) bk_zmask |= 1u << (u - NLP_A);
+          src[u] = (unsigned)((grp < lim ? grp : 0) * X3_GROUP_BYTES + (pc % 12) * 16);
+          if (B2) bc_p2 = p2;
           continue;
         } else {
           const int64_t gj = (int64_t)t.tj * BN + (r - BM);
@@ -584,19 +597,24 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
     typedef std::integral_constant<bool, false> no_t;
     int a_logical = first, a_ks, a_end, b_logical = first, b_ks, b_end;
     { const Tile t = decode(first); make_src(t, yes_t(), yes_t()); a_ks = b_ks = t.ks_begin; a_end = b_end = t.ks_end; }
-    if (BK) bk_request(b_ks);
+    if (BK) bk_request(b_ks, bc_p2);
     auto fetch = [&](int stage, auto doA_, auto doB_) __attribute__((always_inline)) {
       constexpr bool doA = decltype(doA_)::value, doB = decltype(doB_)::value;
       const int fks = doA ? a_ks : b_ks;
       unsigned bk_row[2] = {0, 0}, bk_zero = 0;
+      const bool b_p2 = B2 && bc_p2;                          // (this step's tile: make_src set it when the cursor reached the tile)
       if (BK && doB) {
         // this step's rows (requested a step ago), then the request for the step after it — ahead of this step's pieces
-        bk_zero = (unsigned)(g.b.zero_row * g.b.row_bytes);
+        const int64_t b_rb = b_p2 ? g.b2.row_bytes : g.b.row_bytes, b_nr = b_p2 ? g.b2.nrows : g.b.nrows;
+        bk_zero = (unsigned)((b_p2 ? g.b2.zero_row : g.b.zero_row) * b_rb);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-          bk_row[h] = (bk_ok[h] && bk_id[h] >= 0 && bk_id[h] < g.b.nrows) ? (unsigned)(bk_id[h] * g.b.row_bytes) : bk_zero;
-        if (b_ks + 1 < b_end) bk_request(b_ks + 1);
-        else if (b_logical + nslots < last_logical) bk_request(decode(b_logical + nslots).ks_begin);
+          bk_row[h] = (bk_ok[h] && bk_id[h] >= 0 && bk_id[h] < b_nr) ? (unsigned)(bk_id[h] * b_rb) : bk_zero;
+        if (b_ks + 1 < b_end) bk_request(b_ks + 1, b_p2);
+        else if (b_logical + nslots < last_logical) {
+          const Tile tnx = decode(b_logical + nslots);
+          bk_request(tnx.ks_begin, two_b && tnx.tj >= g.NJ1);
+        }
       }
       unsigned ak_row[2] = {0, 0}, ak_zero = 0;
       if (AK && doA) {                                     // A rows of this step: reduction position = image row, nothing to fetch
@@ -613,7 +631,8 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
       }
       const __amdgpu_buffer_rsrc_t r1 = rsrc_a, r2 = rsrc_a2;   // copies first: a conditional over two captured
       const __amdgpu_buffer_rsrc_t rs_a = (EXT && part2) ? r2 : r1;   // references indexes the closure dynamically and pins it in scratch
-      const __amdgpu_buffer_rsrc_t rs_b = rsrc_b;
+      const __amdgpu_buffer_rsrc_t r3 = rsrc_b, r4 = rsrc_b2;
+      const __amdgpu_buffer_rsrc_t rs_b = b_p2 ? r4 : r3;
       static_for<0, NLP>([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value;
         unsigned so = src[u];
@@ -1420,6 +1439,7 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
   if (g.ak_groups > 0 && g.bk_groups <= 0) return OGL_EINVAL;
   const int64_t b_bytes = std::max((g.b.zero_row + 1) * g.b.row_bytes, (int64_t)g.nsteps * g.b.step_bytes);
   if (g.a2.img && (g.a2.zero_row + 1) * g.a2.row_bytes >= (1ll << 32)) return OGL_EINVAL;
+  if (g.b2.img && ((g.b2.zero_row + 1) * g.b2.row_bytes >= (1ll << 32) || g.ak_groups <= 0 || g.NJ1 <= 0)) return OGL_EINVAL;
   int cfg = x3_config(g.M, g.N);
   const bool bk = g.bk_groups > 0;                        // row-major B over the reduction: 128 x 128 (three stages) or 256 x 128 (two)
   if (bk) cfg = g.force_cfg0 ? 0 : 1;
@@ -1772,6 +1792,55 @@ extern "C" int ogl_linear_bwd_weight_x3k_slabs(const void* dyT_img, int64_t inte
   if (!nsplit_out || !ws_ld_out) return OGL_EINVAL;
   return bwd_weight_x3k(dyT_img, interleave, x_img, x_img_rows, x_rows, x_nrows, M, N, K, has_ones, dw, lddw, db, db2, workspace,
                         workspace_bytes, stream, 1, nsplit_out, ws_ld_out);
+}
+
+// BOTH weight gradients of a dual-input projection y = x[x_rows] . w1^T + x2 . w2^T (+ biases) in ONE product (round 5):
+// [dw1 | db | pad | dw2] = dy^T . [x[x_rows] | 1 | x2] with the two activations read where they lie — x as the resident table's
+// row-major image (K1 + ones slot when has_ones), x2 as the image its producer wrote (K2) — through a two-part B operand by column tile
+// (X3Args.b2): fc_self / fc_neigh of the live layer's combine (R/inference_optimized.py:136-139,276), fc_neigh(cat(h_self, h_neigh)) of the
+// in-repo layer (R/train/graphsage/pytorch/aggregator_dgl.py:206).  dy_img: the ROW-MAJOR image of dy [M + 1 rows, N] (ogl_relu_bwd_img /
+// ogl_x3_split).  The result is left as split-K slabs in `workspace`: slab s = workspace[s][N rows][*ws_ld_out floats] with dw1 in
+// columns [0, K1), the bias gradient in column K1 (has_ones), dw2 in columns [*col2_out, *col2_out + K2); consumers sum the
+// *nsplit_out slabs in slab order (ogl_adam_step_multi_slabs, ogl_x3_slab_reduce).  One launch of 50 tiles x 5 slabs x 44 steps where
+// the two separate products were 2 x (25 tiles x 10 slabs x 22 steps): the same MFMAs, half the pipeline fills and epilogues.
+extern "C" int64_t ogl_linear_bwd_weight_x3k_dual_workspace_bytes(int64_t M, int N, int K1, int has_ones, int K2) {
+  if (M <= 0 || N <= 0 || K1 <= 0 || K2 <= 0) return OGL_EINVAL;
+  const int64_t cols = ogl_cdiv(K1 + (has_ones ? 1 : 0), 128) * 128 + ogl_round_up(K2, 4);
+  int nsplit, sps;
+  x3_bwwk_plan(ogl_cdiv(M, 32), N, (int)cols, &nsplit, &sps);
+  if (nsplit < 2) return 0;                                 // (no slab form for this shape: the caller runs two products)
+  return (int64_t)nsplit * N * ogl_round_up(cols, 4) * 4 + 16;
+}
+
+extern "C" int ogl_linear_bwd_weight_x3k_dual_slabs(const void* dy_img, int64_t M, int N, const void* x_img, int64_t x_img_rows,
+                                                    const int64_t* x_rows, int64_t x_nrows, int K1, int has_ones, const void* x2_img,
+                                                    int64_t x2_img_rows, int K2, void* workspace, int64_t workspace_bytes, int* nsplit_out,
+                                                    int64_t* ws_ld_out, int* col2_out, ogl_stream_t stream) {
+  if (M <= 0 || N <= 0 || K1 <= 0 || K2 <= 0 || !nsplit_out || !ws_ld_out || !col2_out) return OGL_EINVAL;
+  if (!dy_img || !x_img || !x2_img || x_img_rows < 0 || x_nrows < 0 || x_nrows > x_img_rows || (!x_rows && M > x_img_rows) || M > x2_img_rows)
+    return OGL_EINVAL;
+  X3Args g = X3Args();
+  const int Kc1 = K1 + (has_ones ? 1 : 0);
+  g.NJ1 = (int)ogl_cdiv(Kc1, 128);
+  const int col2 = g.NJ1 * 128;
+  g.ak_groups = (int)ogl_cdiv(N, 32);
+  g.a = X3Operand{(const unsigned char*)dy_img, (int64_t)g.ak_groups * X3_GROUP_BYTES, 0, nullptr, M, M};
+  g.b = X3Operand{(const unsigned char*)x_img, ogl_cdiv(Kc1, 32) * X3_GROUP_BYTES, 0, x_rows, x_rows ? x_nrows : x_img_rows, x_img_rows};
+  g.b2 = X3Operand{(const unsigned char*)x2_img, ogl_cdiv(K2, 32) * X3_GROUP_BYTES, 0, nullptr, x2_img_rows, x2_img_rows};
+  g.bk_red = M; g.bk_interleave = 0; g.bk_groups = (int)ogl_cdiv(Kc1, 32); g.bk2_groups = (int)ogl_cdiv(K2, 32);
+  g.M = N; g.N = col2 + K2; g.ones_col = 0;
+  g.nsteps = (int)ogl_cdiv(M, 32);
+  x3_bwwk_plan(g.nsteps, N, (int)g.N, &g.nsplit, &g.steps_per_split);
+  if (g.nsplit < 2) return OGL_EINVAL;                      // (the slab form only: a one-split product has one output pointer)
+  g.ws_ld = ogl_round_up(g.N, 4);
+  if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < (int64_t)g.nsplit * N * g.ws_ld * 4) return OGL_EWORKSPACE;
+  g.ws = (float*)workspace;
+  g.C = g.ws; g.ldc = g.ws_ld;                              // (never written: nsplit > 1)
+  static const char* xs_env = getenv("OGL_BWWK_XCD_SLABS");
+  g.xcd_slabs = (!(xs_env && xs_env[0] == '0') && g.nsplit >= 8) ? 1 : 0;
+  g.defer_reduce = 1;
+  *nsplit_out = g.nsplit; *ws_ld_out = g.ws_ld; *col2_out = col2;
+  return launch_x3(g, (hipStream_t)stream);
 }
 
 // out[r, c] = sum_s ws[s * slab_stride + r * ws_ld + col0 + c] (slab order): the reduction of deferred slabs for a consumer that is

@@ -1380,10 +1380,42 @@ def _slabs_settle(params):
 
 
 def slab_reduce(sg, out):
-    """out[rows, ncols] <- the plain reduction of the slabs (slab order)."""
-    assert out.is_contiguous() and out.numel() == sg.rows * sg.ncols
+    """out[rows, ncols] <- the plain reduction of the slabs (slab order).  ``out``: contiguous, or a 2-D view whose rows are contiguous
+    (a column block of a wider matrix: its row stride is passed on)."""
+    if out.dim() == 2 and not out.is_contiguous():
+        assert tuple(out.shape) == (sg.rows, sg.ncols) and out.stride(1) == 1 and out.stride(0) >= sg.ncols
+        ld = out.stride(0)
+    else:
+        assert out.is_contiguous() and out.numel() == sg.rows * sg.ncols
+        ld = sg.ncols
     _launch("ogl_x3_slab_reduce", _lib.lib().ogl_x3_slab_reduce, _ptr(sg.ws), sg.stride, sg.ws_ld, sg.nsplit, sg.rows, sg.ncols, sg.col0,
-            _ptr(out), sg.ncols, _stream(), meta=dict(n=sg.rows * sg.ncols, nsplit=sg.nsplit))
+            _ptr(out), ld, _stream(), meta=dict(n=sg.rows * sg.ncols, nsplit=sg.nsplit))
+
+
+# Both weight gradients of a dual-input projection as ONE k-major product over a two-part B operand (ogl_linear_bwd_weight_x3k_dual_slabs).
+# OGL_DUAL_DW=0: two products.
+DUAL_DW = os.environ.get("OGL_DUAL_DW", "1") != "0"
+# ... and for the in-repo layer's ONE concat weight (its two column blocks summed out of the slabs by three small launches): measured
+# on MI355X `mean` 0.4322 -> 0.4322 ms, `meanpool` 1.220 -> 1.237 ms — off.
+DUAL_DW_CAT = os.environ.get("OGL_DUAL_DW_CAT", "0") == "1"
+
+
+def linear_bwd_weight_x3k_dual(dy_img, x_img, x_rows, x_nrows, M, K1, x2_img, K2):
+    """Slabs of [dw1 | db | pad | dw2] = dy^T . [x[x_rows] | 1 | x2]: returns (ws, stride, ws_ld, nsplit, col2, N) or None when the plan
+    has a single split.  ``dy_img``: row-major image of dy [M, N]; ``x_img``: row-major image of x with the ones slot (K1 + 1);
+    ``x2_img``: row-major image of x2 [M, K2]."""
+    N = dy_img.K
+    assert dy_img.rows == M and x_img.K == K1 + 1 and x2_img.K == K2 and x2_img.rows >= M
+    nbytes = int(_lib.lib().ogl_linear_bwd_weight_x3k_dual_workspace_bytes(M, N, K1, 1, K2))
+    if nbytes <= 0:
+        return None
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dy_img.buf.device)
+    ns, wl, c2 = C.c_int(0), C.c_int64(0), C.c_int(0)
+    rc = _lib.lib().ogl_linear_bwd_weight_x3k_dual_slabs
+    _launch("ogl_linear_bwd_weight_x3k", rc, _ptr(dy_img.buf), M, N, _ptr(x_img.buf), x_img.rows,
+            _ptr(_ids(x_rows) if x_rows is not None else None), x_img.rows if x_nrows is None else x_nrows, K1, 1, _ptr(x2_img.buf),
+            x2_img.rows, K2, _ptr(ws), nbytes, C.byref(ns), C.byref(wl), C.byref(c2), _stream(), meta=dict(M=M, K=K1 + K2, N=N, dual=True))
+    return ws, N * wl.value, wl.value, ns.value, c2.value, N
 
 
 class deferred_splitk:
@@ -2024,6 +2056,42 @@ class _LinearFn(torch.autograd.Function):
         if dyr is None and _MODE["name"] != "f32" and dy.shape[0] >= 1024 and x2 is not None and need[1] and need[4]:
             dyT = transposed_operand(dy)   # shared by the two weight gradients of a dual-input projection
         both = None
+        if (DUAL_DW and dyr is not None and rimg is not None and rimg.K == x.shape[1] + 1 and x2_img is not None and x2_img.K == x2.shape[1]
+                and x2_img.rows >= dy.shape[0] and need[1] and need[4] and rimg.buf.numel() < (1 << 32)):
+            # ONE product for both weight gradients (round 5): dy^T . [x[rows] | 1 | x2] over a two-part B operand — the table's image
+            # rows and the image the aggregator wrote, read where they lie
+            K1, K2, N_ = x.shape[1], x2.shape[1], dy.shape[1]
+            if views is not None:
+                # the in-repo layer's ONE concat weight [N, K1 + K2]: the two column blocks of its gradient are summed out of the slabs
+                res = None if not DUAL_DW_CAT else linear_bwd_weight_x3k_dual(dyr, rimg, x_rows, x.shape[0] if x_rows is not None else None, dy.shape[0], K1, x2_img, K2)
+                if res is not None:
+                    ws_, stride, wl, ns, c2, _ = res
+                    slab_reduce(SlabGrad(ws_, stride, wl, ns, N_, K1, 0), views[0])
+                    slab_reduce(SlabGrad(ws_, stride, wl, ns, N_, K2, c2), views[1])
+                    db = None
+                    if ctx.has_bias:
+                        db = torch.empty(N_, dtype=torch.float32, device=dy.device)
+                        slab_reduce(SlabGrad(ws_, stride, wl, ns, N_, 1, K1), db)
+                    return views[0], db, views[1], None
+            elif (_SLABS["on"] and ctx.has_bias and ctx.has_bias2 and globals()["_dw_out"](w, *w.shape) is None
+                  and globals()["_dw_out"](w2, *w2.shape) is None
+                  and all(t is not None and t.is_leaf and t.is_contiguous() for t in (w, w2, ctx.bias_t, ctx.bias2_t))
+                  and tuple(w.shape) == (N_, K1) and tuple(w2.shape) == (N_, K2)
+                  and not _slabs_settle((w, w2, ctx.bias_t, ctx.bias2_t))):
+                res = linear_bwd_weight_x3k_dual(dyr, rimg, x_rows, x.shape[0] if x_rows is not None else None, dy.shape[0], K1, x2_img, K2)
+                if res is not None:
+                    ws_, stride, wl, ns, c2, _ = res
+                    dev = dy.device
+                    dw = torch.empty((N_, K1), dtype=torch.float32, device=dev)
+                    dw2 = torch.empty((N_, K2), dtype=torch.float32, device=dev)
+                    db = torch.empty(N_, dtype=torch.float32, device=dev)
+                    db2 = torch.empty(N_, dtype=torch.float32, device=dev)
+                    pend = _SLABS["pending"]
+                    pend[w.data_ptr()] = SlabGrad(ws_, stride, wl, ns, N_, K1, 0, dw)
+                    pend[w2.data_ptr()] = SlabGrad(ws_, stride, wl, ns, N_, K2, c2, dw2)
+                    pend[ctx.bias_t.data_ptr()] = SlabGrad(ws_, stride, wl, ns, N_, 1, K1, db)
+                    pend[ctx.bias2_t.data_ptr()] = SlabGrad(ws_, stride, wl, ns, N_, 1, K1, db2)
+                    return dw, db, dw2, db2
         if ((dyr is not None or isinstance(dyT, X3Image)) and ctx.has_bias and ctx.has_bias2 and x2_img is not None
                 and x2_img.K == x2.shape[1] and need[1] and need[4]):
             # the neighbour part's image has no ones slot: both copies of the bias gradient come from the first product

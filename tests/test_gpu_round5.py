@@ -324,3 +324,115 @@ def test_sign_bits_from_the_product_epilogue(ops, M, K, N):
         ops.set_gemm_mode(old)
         ops._X3_TABLES.clear()
         ops.invalidate_weight_images()
+
+
+# ---- both weight gradients of a dual-input projection from ONE product (two-part B operand) ----------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K1,K2,T", [(7060, 128, 602, 128, 232965), (2100, 64, 50, 70, 5000), (2637, 41, 127, 128, 3000),
+                                         (4000, 256, 256, 256, 0), (2050, 128, 128, 33, 9000), (176500, 128, 602, 128, 232965)])
+def test_dual_weight_gradient_product(ops, M, N, K1, K2, T):
+    """dy^T . [x[rows] | 1 | x2] as one launch: the three column blocks of the summed slabs against float64 (the bf16x6 arithmetic's
+    bound: 2e-6 of the column's absolute sum), and — the image kernels being deterministic — against the two single products within
+    float32 summation-order noise."""
+    if M > 100000:
+        T = 232965
+    torch.manual_seed(M + N)
+    dev = "cuda:0"
+    dy = torch.randn(M, N, device=dev) * (torch.rand(M, N, device=dev) < 0.5)
+    x2 = torch.randn(M, K2, device=dev)
+    if T:
+        table = torch.randn(T, K1, device=dev)
+        rows = torch.randint(0, T, (M,), device=dev, dtype=torch.int64)
+        x_img = ops.x3_split(table, append_ones=True)
+        xs = table[rows]
+    else:
+        rows = None
+        xs = torch.randn(M, K1, device=dev)
+        x_img = ops.x3_split(xs, append_ones=True)
+    dy_img, x2_img = ops.x3_split(dy), ops.x3_split(x2)
+    res = ops.linear_bwd_weight_x3k_dual(dy_img, x_img, rows, T if T else None, M, K1, x2_img, K2)
+    if res is None:
+        pytest.skip("single-split plan at this shape: the caller keeps two products")
+    ws, stride, wl, ns, c2, _ = res
+    assert ns >= 2 and c2 % 128 == 0 and c2 >= K1 + 1
+    dw = torch.empty(N, K1, device=dev); dw2 = torch.empty(N, K2, device=dev); db = torch.empty(N, device=dev)
+    ops.slab_reduce(ops.SlabGrad(ws, stride, wl, ns, N, K1, 0), dw)
+    ops.slab_reduce(ops.SlabGrad(ws, stride, wl, ns, N, K2, c2), dw2)
+    ops.slab_reduce(ops.SlabGrad(ws, stride, wl, ns, N, 1, K1), db)
+    # a strided destination (a column block of a concat weight's gradient)
+    cat = torch.zeros(N, K1 + K2, device=dev)
+    ops.slab_reduce(ops.SlabGrad(ws, stride, wl, ns, N, K1, 0), cat[:, :K1])
+    ops.slab_reduce(ops.SlabGrad(ws, stride, wl, ns, N, K2, c2), cat[:, K1:])
+    assert torch.equal(cat[:, :K1], dw) and torch.equal(cat[:, K1:], dw2)
+    d64 = dy.double()
+    for got, ref, absref in ((dw, d64.T @ xs.double(), d64.abs().T @ xs.double().abs()),
+                             (dw2, d64.T @ x2.double(), d64.abs().T @ x2.double().abs()),
+                             (db, d64.sum(0), d64.abs().sum(0))):
+        err = (got.double() - ref).abs()
+        assert bool((err <= 2e-6 * absref + 1e-30).all()), float((err / (absref + 1e-30)).max())
+    one, b1, _ = ops.linear_bwd_weight_x3k(dy_img, x_img, M, K1, x_rows=rows, x_nrows=T if T else None, want_bias=True, dy_rows=True)
+    two = ops.linear_bwd_weight_x3k(dy_img, x2_img, M, K2, want_bias=False, dy_rows=True)[0]
+    for got, ref in ((dw, one), (dw2, two), (db, b1)):
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cat_weight", [False, True])
+def test_dual_projection_backward_takes_the_one_launch_product(ops, cat_weight):
+    """ops.linear(x, w, b, x2, w2, bias2=b2) — and its concat-weight form (split=) — backward with OGL_DUAL_DW on and off: the same
+    gradients (deferred slabs settled through the optimiser's reduction) and the launch log shows ONE weight-gradient product."""
+    torch.manual_seed(5)
+    dev = "cuda:0"
+    T, M, K1, K2, N = 40000, 7060, 602, 128, 128
+    table = torch.randn(T, K1, device=dev)
+    ops.register_static_table(table)
+    rows = torch.randint(0, T, (M,), device=dev, dtype=torch.int64)
+    x2 = torch.randn(M, K2, device=dev)
+    g = torch.randn(M, N, device=dev)
+    outs, calls = {}, []
+    old, old_cat, old_mode, real = ops.DUAL_DW, ops.DUAL_DW_CAT, ops.get_gemm_mode(), ops.linear_bwd_weight_x3k_dual
+    ops.set_gemm_mode("auto")
+    ops.DUAL_DW_CAT = True          # (the concat-weight form is off by default: slower at the Reddit shape)
+
+    def spy(*a, **k):
+        calls.append(ops.DUAL_DW)
+        return real(*a, **k)
+    ops.linear_bwd_weight_x3k_dual = spy
+    try:
+        for on in (True, False):
+            ops.DUAL_DW = on
+            torch.manual_seed(6)
+            if cat_weight:
+                w = torch.nn.Parameter(torch.randn(N, K1 + K2, device=dev) * 0.05)
+                b = torch.nn.Parameter(torch.randn(N, device=dev))
+                params = [w, b]
+            else:
+                w = torch.nn.Parameter(torch.randn(N, K1, device=dev) * 0.05)
+                w2 = torch.nn.Parameter(torch.randn(N, K2, device=dev) * 0.05)
+                b = torch.nn.Parameter(torch.randn(N, device=dev))
+                b2 = torch.nn.Parameter(torch.randn(N, device=dev))
+                params = [w, b, w2, b2]
+            x2i = x2.clone().requires_grad_(True)      # (the aggregator's output: its gradient is asked for, so dy's image exists)
+            x2i._ogl_image = (ops.x3_split(x2i), x2i._version, x2i.data_ptr())
+            fake = type("SlabOptimizer", (), dict(consumes_slabs=True, param_groups=[dict(params=params)]))()
+            if cat_weight:
+                y = ops.linear_cat(table, x2i, w, K1, bias=b, relu=True, x_rows=rows)
+            else:
+                y = ops.linear(table, w, b, x2=x2i, w2=w2, relu=True, x_rows=rows, bias2=b2)
+            with ops.deferred_splitk(fake):
+                y.backward(g)
+                ops.side_join()
+                pend = dict(ops._SLABS["pending"])
+            # (leaving the context reduced every pending slab set into its parameter's .grad)
+            torch.cuda.synchronize()
+            outs[on] = ([p.grad.clone() for p in params], len(pend))
+    finally:
+        ops.DUAL_DW, ops.DUAL_DW_CAT = old, old_cat
+        ops.linear_bwd_weight_x3k_dual = real
+        ops.set_gemm_mode(old_mode)
+    assert calls == [True], "the one-launch product was not taken (or taken with the switch off)"
+    for a, r in zip(outs[True][0], outs[False][0]):
+        assert torch.isfinite(a).all()
+        assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max())
+    if not cat_weight:
+        assert outs[True][1] == 4
