@@ -87,6 +87,7 @@ struct X3Args {
   // gather / zero row / column groups) where tiles tj < NJ1 read b: both weight gradients of a dual-input projection, dy^T . x[rows] and
   // dy^T . x2, as ONE product over [x[rows] | x2] without a concatenated image (output columns: part 1 at 0, part 2 at 128 NJ1) ----
   X3Operand b2; int bk2_groups; int NJ1;
+  int bd_dbg;                   // k_gemm_x3bd, timing experiments only (OGL_X3_BD_DBG; wrong results): 1 = no B loads, 2 = no A DMA
 };
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) — indices into register arrays stay constants
@@ -977,6 +978,238 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
 #endif
 }
 
+// ---- B-DIRECT form (plain forward products, nsplit == 1): 4 multiplier waves + 4 mover waves ------------------------------------
+// The B operand of a forward product is the WEIGHT image: 2.2 MB for [602, 608], resident in every XCD's L2.  Here it never touches
+// the LDS: each multiplier wave loads the B fragments of its 64 columns straight into registers (buffer_load_dwordx4: lane (l15, quad)
+// reads the 16 bytes of image row `column`, plane p, chunk quad — exactly the MFMA operand), one whole step ahead, into the register
+// set the previous step multiplied from.  What that changes against k_gemm_x3p's 256 x 128 tile (per 32-deep step and CU):
+//   LDS bytes     264 KB (192 read as fragments + 72 written by the DMA)  ->  RB = 6: 108 KB (72 + 36) for 3/4 of the MACs
+//   ring          2 stages of 72 KB, early-A second barrier               ->  4 stages of 36 KB (A rows only), ONE barrier per step, the
+//                                                                             movers run three stages ahead
+//   multipliers   2 waves per SIMD of 64 x 64 (in lockstep behind the     ->  ONE wave per SIMD of (16 RB) x 64: accumulators 16 RB
+//                 barrier: both read fragments, then both want the pipe)      registers, B double buffer 96, A ring (two row blocks) 24
+// Each step: a[0] <- row block 0; for row block x: request row block x + 1's fragments, 24 MFMAs of row block x (4 column blocks x 6
+// terms, the same term order as every other tile: bit-identical results); the B loads of step n + 1 go out behind row block 0's MFMAs.
+// Full wave tiles run a branch-free step (every load counted by the compiler); edge tiles (rows past M, columns past N) a guarded one.
+template <int RB>
+__global__ void __launch_bounds__(512) k_gemm_x3bd(X3Args g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int CB = 4, WROWS = RB * 16, WCOLS = 64, BM = 2 * WROWS, BN = 128;
+  constexpr int A_PIECES = BM * 12, STAGE = A_PIECES * 16;
+  constexpr int NSTAGE = (4 * STAGE <= 160 * 1024) ? 4 : 3;
+  static_assert(A_PIECES % 256 == 0, "a stage is a whole number of 256-lane instructions");
+  constexpr int NLP = A_PIECES / 256;                      // DMA instructions per mover lane and stage (9 / 12)
+  static_assert((NSTAGE - 2) * NLP < 64, "vmcnt immediate");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool mover = wid >= 4;
+  const int T = g.NI * g.NJ;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int chunk_begin = xcd * (T >> 3) + min(xcd, T & 7), chunk_len = (T >> 3) + (xcd < (T & 7) ? 1 : 0);
+  if (slot >= chunk_len) return;
+  const int first = chunk_begin + slot, last_logical = chunk_begin + chunk_len;
+  int total = 0;
+  for (int l = first; l < last_logical; l += nslots) total += g.nsteps;
+  auto swz = [](int r) __attribute__((always_inline)) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; };
+  auto barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+  };
+
+  if (mover) {
+    const int ml = (wid - 4) * 64 + lane;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)g.a.img, 0, 0xFFFFFFFF, 0x00020000);
+    const unsigned step_a = (unsigned)g.a.step_bytes;
+    unsigned src[NLP];
+    auto make_src = [&](int ti) __attribute__((always_inline)) {
+      int64_t rid[NLP];
+#pragma unroll
+      for (int u = 0; u < NLP; ++u) {
+        const int64_t gi = (int64_t)ti * BM + (u * 256 + ml) / 12;
+        rid[u] = gi;
+        if (g.a.rows) rid[u] = g.a.rows[gi < g.M ? gi : g.M - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < NLP; ++u) {
+        const int i = u * 256 + ml;
+        const int r = i / 12, jp = i - r * 12;
+        const int j = (jp & ~3) | ((jp & 3) ^ swz(r));
+        const bool ok = (int64_t)ti * BM + r < g.M && rid[u] >= 0 && rid[u] < g.a.nrows;
+        src[u] = (unsigned)((ok ? rid[u] : g.a.zero_row) * g.a.row_bytes + j * 16);
+      }
+    };
+    int a_logical = first, a_ks = 0;
+    make_src(first / g.NJ);
+    auto fetch = [&](int stage) __attribute__((always_inline)) {
+      static_for<0, NLP>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value;
+        if (!(g.bd_dbg & 2))
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(smem + (stage % NSTAGE) * STAGE + (u * 256 + (wid - 4) * 64) * 16), 16,
+                                                   src[u], 0, 0, 0);
+        src[u] += step_a;
+      });
+      if (++a_ks == g.nsteps && a_logical + nslots < last_logical) {
+        a_logical += nslots;
+        make_src(a_logical / g.NJ);
+        a_ks = 0;
+      }
+    };
+    // the movers run NSTAGE - 1 stages ahead: after the barrier that opens step n they issue stage n + NSTAGE - 1 into the buffer step
+    // n - 1 released and wait for stage n + 1 only (the youngest NSTAGE - 2 stages stay in flight across the barrier)
+    int issued = 0;
+    for (; issued < NSTAGE - 1 && issued < total; ++issued) fetch(issued);
+    if (issued == NSTAGE - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * NLP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int n = 0; n < total; ++n) {
+      barrier();
+      if (issued < total) { fetch(issued); ++issued; }
+      if (issued == n + NSTAGE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * NLP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  } else {
+    const int wm = wid >> 1, wn = wid & 1;
+    const int l15 = lane & 15, quad = lane >> 4;
+    int offp[3];
+    {
+      const int q = swz(l15);
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp) {
+        const int j = x3_piece(quad, sp);
+        offp[sp] = ((j & ~3) | ((j & 3) ^ q)) * 16;
+      }
+    }
+    const int rowa = (wm * WROWS + l15) * 192;
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)g.b.img, 0, 0xFFFFFFFF, 0x00020000);
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc[RB][CB];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int a = 0; a < RB; ++a)
+#pragma unroll
+        for (int b = 0; b < CB; ++b)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.f;
+    };
+    bf16x8 bq[CB][3], bn[CB][3];                            // B fragments: the step's, and the next step's on their way
+    // the B fragments of (column tile tj, step ks) into `bn`: columns past N read the image's zero row
+    const int zoff = (int)(g.b.zero_row * g.b.row_bytes) + quad * 16, rb_b = (int)g.b.row_bytes, sb_b = (int)g.b.step_bytes;
+    auto b_issue = [&](int tj, int ks) __attribute__((always_inline)) {
+      const int so = ks * sb_b;
+      const int col0 = tj * BN + wn * WCOLS + l15;
+#pragma unroll
+      for (int y = 0; y < CB; ++y) {
+        const int col = col0 + y * 16;
+        const int vo = col < (int)g.N ? col * rb_b + quad * 16 : zoff;
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp)
+          bn[y][sp] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, vo + x3_piece(0, sp) * 16, so, 0));
+      }
+    };
+    auto b_take = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int y = 0; y < CB; ++y)
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) bq[y][sp] = bn[y][sp];
+    };
+    // one step on stage buffer `buf`: GUARD = false for full wave tiles (no branch between the loads and the MFMAs)
+    auto step = [&](auto gc, int buf, int rbv, int cbv, int ntj, int nks) __attribute__((always_inline)) {
+      constexpr bool GUARD = decltype(gc)::value;
+      const unsigned char* st = smem + buf * STAGE + rowa;
+      bf16x8 a[2][3];
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp) a[0][sp] = *(const bf16x8*)(st + offp[sp]);
+      static_for<0, RB>([&](auto xc) __attribute__((always_inline)) {
+        constexpr int x = decltype(xc)::value;
+        if constexpr (x + 1 < RB) {
+#pragma unroll
+          for (int sp = 0; sp < 3; ++sp) a[(x + 1) & 1][sp] = *(const bf16x8*)(st + (x + 1) * 16 * 192 + offp[sp]);
+        }
+        if constexpr (x == 1) { if (!(g.bd_dbg & 1)) b_issue(ntj, nks); }
+        if constexpr (!GUARD) __builtin_amdgcn_sched_barrier(0);
+        // (term-major: ONE wave feeds its SIMD's matrix pipe, and the six terms of an accumulator depend on each other — the four
+        // column blocks' chains interleaved put four independent instructions between two dependent ones; per accumulator the term
+        // order is the one every other tile uses)
+        if (!GUARD || x < rbv) {
+          static_for<0, 6>([&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int bt = t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0, at = (t == 0 || t == 3 || t == 5) ? 0 : (t == 1 || t == 4) ? 1 : 2;
+#pragma unroll
+            for (int y = 0; y < CB; ++y)
+              if (!GUARD || y < cbv) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[y][bt], a[x & 1][at], acc[x][y], 0, 0, 0);
+          });
+        }
+        if constexpr (!GUARD) __builtin_amdgcn_sched_barrier(0);
+      });
+      b_take();
+    };
+    auto epilogue = [&](int ti, int tj) __attribute__((always_inline)) {
+      int l15e = lane & 15, quade = lane >> 4;
+      asm volatile("" : "+v"(l15e), "+v"(quade));
+      float* const dst = g.C;
+      const int64_t ldd = g.ldc;
+      const bool vec_ok = (ldd & 3) == 0 && ((uintptr_t)dst & 15) == 0;
+#pragma unroll
+      for (int x = 0; x < RB; ++x)
+#pragma unroll
+        for (int y = 0; y < CB; ++y) {
+          const int64_t row = (int64_t)ti * BM + wm * WROWS + x * 16 + l15e, col = (int64_t)tj * BN + wn * WCOLS + y * 16 + 4 * quade;
+          float v[4] = {acc[x][y][0], acc[x][y][1], acc[x][y][2], acc[x][y][3]};
+          const bool rok = row < g.M;
+          if (g.relu) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+          }
+          if (g.relu_bits && rok && col < g.N)
+            g.relu_bits[row * g.relu_bits_ld + (col >> 2)] = (unsigned char)((v[0] > 0.f ? 1 : 0) | (v[1] > 0.f ? 2 : 0) | (v[2] > 0.f ? 4 : 0) |
+                                                                             (v[3] > 0.f ? 8 : 0));
+          const bool vec = rok && vec_ok && col < g.N && col + 4 <= ldd;
+          if (vec) *(float4*)(dst + row * ldd + col) = make_float4(v[0], v[1], v[2], v[3]);
+          else if (rok && col < g.N) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (col + c < g.N) dst[row * ldd + col + c] = v[c];
+          }
+        }
+    };
+    typedef std::integral_constant<bool, true> yes_t;
+    typedef std::integral_constant<bool, false> no_t;
+    zero_acc();
+    b_issue(first % g.NJ, 0);
+    b_take();
+    int n = 0;
+    for (int logical = first; logical < last_logical; logical += nslots) {
+      const int ti = logical / g.NJ, tj = logical - ti * g.NJ;
+      const bool more = logical + nslots < last_logical;
+      const int tj_next = more ? (logical + nslots) % g.NJ : tj;  // (the block's very last step reloads its tile's first: unused)
+      const int64_t rleft = g.M - ((int64_t)ti * BM + wm * WROWS), cleft = g.N - ((int64_t)tj * BN + wn * WCOLS);
+      const int rbv = rleft >= RB * 16 ? RB : (rleft <= 0 ? 0 : (int)((rleft + 15) >> 4));
+      const int cbv = cleft >= CB * 16 ? CB : (cleft <= 0 ? 0 : (int)((cleft + 15) >> 4));
+      if (rbv == RB && cbv == CB) {
+#pragma unroll 1
+        for (int ks = 0; ks < g.nsteps; ++ks, ++n) {
+          barrier();                                       // stage n has landed (the movers waited for it)
+          step(no_t(), n % NSTAGE, rbv, cbv, ks + 1 == g.nsteps ? tj_next : tj, ks + 1 == g.nsteps ? 0 : ks + 1);
+        }
+      } else {
+#pragma unroll 1
+        for (int ks = 0; ks < g.nsteps; ++ks, ++n) {
+          barrier();
+          step(yes_t(), n % NSTAGE, rbv, cbv, ks + 1 == g.nsteps ? tj_next : tj, ks + 1 == g.nsteps ? 0 : ks + 1);
+        }
+      }
+      epilogue(ti, tj);
+      zero_acc();
+    }
+  }
+#endif
+}
+
 __global__ void __launch_bounds__(256) k_x3_splitk_reduce(X3Args g) {
   const int64_t total = g.M * g.N;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -1414,7 +1647,7 @@ extern "C" int ogl_x3_debug_stamps(void* buf, int reserved) {
 
 static int g_x3_tile = -1;
 extern "C" int ogl_x3_debug_tile(int cfg) {
-  if (cfg < -1 || cfg > 4) return OGL_EINVAL;
+  if (cfg < -1 || cfg > 6) return OGL_EINVAL;
   g_x3_tile = cfg;
   return OGL_OK;
 }
@@ -1484,8 +1717,14 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     // (not the EXT form: its epilogue spills at 80 accumulators)
     const bool ext = g.a2.img || g.add || g.out_img || g.mask || g.y_keep;
     if (c4 && !bk && !ext && g.nsplit == 1 && cfg == 0 && ogl_cdiv(g.N, 160) * 160 <= ogl_cdiv(g.N, 128) * 128) cfg = 4;
-    if (g_x3_tile >= 0 && !bk && g.nsplit == 1) cfg = (g_x3_tile == 4 && ext) ? 0 : g_x3_tile;
-    const int BMp = (cfg == 0 || cfg == 4) ? 256 : cfg == 2 ? 192 : cfg == 3 ? 160 : 128;
+    if (g_x3_tile >= 0 && !bk && g.nsplit == 1) cfg = (g_x3_tile >= 4 && ext) ? 0 : g_x3_tile;
+    // the B-direct kernel (k_gemm_x3bd: 5 = 192 x 128, 6 = 256 x 128) for plain tall products: OGL_X3_BD=6 / 8 (rows / 32 of its wave tile)
+    static const char* bd_env = getenv("OGL_X3_BD");
+    const int bd = bd_env ? atoi(bd_env) : 0;
+    const bool plain = !bk && !ext && g.nsplit == 1 && !g.ones_col && !g.db && !g.db2;
+    if (plain && cfg == 0 && g_x3_tile < 0 && (bd == 6 || bd == 8)) cfg = bd == 8 ? 6 : 5;
+    if ((cfg == 5 || cfg == 6) && !plain) cfg = 0;
+    const int BMp = (cfg == 0 || cfg == 4 || cfg == 6) ? 256 : (cfg == 2 || cfg == 5) ? 192 : cfg == 3 ? 160 : 128;
     g.NI = (int)ogl_cdiv(g.M, BMp);
     g.NJ = (int)ogl_cdiv(g.N, cfg == 4 ? 160 : 128);
     if (g.nsplit2 && !(bk && cfg == 0 && g.ak_groups == 0 && g.NI >= 2)) g.nsplit2 = 0;   // (the uneven split lives in one instantiation)
@@ -1496,7 +1735,13 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     // the two-stage tiles (256 x 128, 192 x 128) in their early-A form (template parameter EA) unless switched off
     static const char* ea_env = getenv("OGL_X3_EARLY_A");
     const bool ea = (g_x3_early_a >= 0 ? g_x3_early_a != 0 : !(ea_env && ea_env[0] == '0')) && !g.skip_pad;
-    if (bk && g.ak_groups > 0) X3P_LAUNCH(2, 4, 2, 1, 3, false, true, true);
+    if (cfg == 5 || cfg == 6) {
+      block = dim3(512);
+      static const char* bdd_env = getenv("OGL_X3_BD_DBG");
+      g.bd_dbg = bdd_env ? atoi(bdd_env) : 0;
+      if (cfg == 5) { g_x3_last_kernel = "k_gemm_x3bd<6>"; hipLaunchKernelGGL((k_gemm_x3bd<6>), grid, block, 0, stream, g); }
+      else { g_x3_last_kernel = "k_gemm_x3bd<8>"; hipLaunchKernelGGL((k_gemm_x3bd<8>), grid, block, 0, stream, g); }
+    } else if (bk && g.ak_groups > 0) X3P_LAUNCH(2, 4, 2, 1, 3, false, true, true);
     else if (bk && cfg == 0) { if (ea) X3P_LAUNCH(4, 2, 2, 2, 2, false, true, false, 0, 0, true); else X3P_LAUNCH(4, 2, 2, 2, 2, false, true); }
     else if (bk) X3P_LAUNCH(2, 4, 2, 1, 3, false, true);
     else if (ext) {

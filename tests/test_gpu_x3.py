@@ -389,11 +389,12 @@ def test_pool_backward_limits(ops):
     assert h.ogl_pool_bwd_x3_apply(None, 640, p(idx), n_dst, S, D, n_src, p(img.buf), p(ws), nb, None) == -1
 
 
-@pytest.mark.parametrize("M,K,N", [(7060, 602, 600), (70000, 100, 602), (300, 33, 161), (1, 1, 1), (5000, 64, 321)])
+@pytest.mark.parametrize("M,K,N", [(7060, 602, 600), (70000, 100, 602), (300, 33, 161), (1, 1, 1), (5000, 64, 321), (62495, 602, 602)])
 def test_every_tile_shape_computes_the_same_bits(ops, M, K, N):
-    """The five tiles of k_gemm_x3p (256 / 128 / 192 / 160 rows x 128 columns, 256 x 160) differ in what a block fetches per
-    step, not in the MFMA sequence behind an output element: pinned one after the other (ogl_x3_debug_tile) they return the
-    same bits — plain products and EXT products (addend, second A part, output image; 256 x 160 is plain only)."""
+    """The five tiles of k_gemm_x3p (256 / 128 / 192 / 160 rows x 128 columns, 256 x 160) and the two of the B-direct kernel
+    k_gemm_x3bd (5: 192 x 128, 6: 256 x 128 — the weight image's fragments straight from L2 into registers) differ in what a block
+    fetches per step, not in the MFMA sequence behind an output element: pinned one after the other (ogl_x3_debug_tile) they return
+    the same bits — plain products and EXT products (addend, second A part, output image; 256 x 160 and B-direct are plain only)."""
     from ogl_amd import _lib
     torch.manual_seed(M + N)
     T = M + 10
@@ -407,7 +408,7 @@ def test_every_tile_shape_computes_the_same_bits(ops, M, K, N):
     S0 = ops.empty_mat(T, N, "cuda").copy_(torch.randn(T, N, device="cuda"))
     outs = []
     try:
-        for cfg in (0, 1, 2, 3, 4):
+        for cfg in (0, 1, 2, 3, 4, 5, 6):
             assert _lib.lib().ogl_x3_debug_tile(cfg) == 0
             y = ops.linear_fwd_x3(xi, rows, wi, relu=True, x_nrows=T)
             y2, img = ops.linear_fwd_x3_ext(xi, rows, wcat, x2_img=ops.x3_split(x2), add=S0, add_rows=rows, relu=True, x_nrows=T,
@@ -415,10 +416,10 @@ def test_every_tile_shape_computes_the_same_bits(ops, M, K, N):
             outs.append((y.clone(), y2.clone(), img.buf.clone()))
     finally:
         assert _lib.lib().ogl_x3_debug_tile(-1) == 0
-    assert _lib.lib().ogl_x3_debug_tile(5) != 0 and _lib.lib().ogl_x3_debug_tile(-2) != 0
+    assert _lib.lib().ogl_x3_debug_tile(7) != 0 and _lib.lib().ogl_x3_debug_tile(-2) != 0
     want = (tm[rows].double() @ w.double().T + b.double()).clamp_min(0).float()
     np.testing.assert_allclose(outs[0][0].cpu().numpy(), want.cpu().numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL)
-    for cfg in (1, 2, 3, 4):
+    for cfg in (1, 2, 3, 4, 5, 6):
         for k in range(3):
             assert torch.equal(outs[0][k], outs[cfg][k]), (cfg, k)
     # and the automatic choice is one of them
