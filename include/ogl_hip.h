@@ -344,6 +344,12 @@ int ogl_linear_fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_ro
 int ogl_linear_fwd_x3_bits(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
                            const void* w_img, int N, int relu, float* y, int64_t ldy, unsigned char* relu_bits, int64_t relu_bits_ld,
                            ogl_stream_t stream);
+/* ogl_linear_fwd_x3 with a zero fill riding in the launch: zero_buf[0 .. zero_bytes) (16-byte aligned, a multiple of 16 bytes) is cleared by
+ * the blocks of the persistent grid that own no tile (a one-round product leaves CUs idle), or by a fill launch in front of the product when
+ * there are fewer than 16 of them.  The atomic-scatter target of the output layer's backward, cleared beside that layer's fc_pool product. */
+int ogl_linear_fwd_x3_zero(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
+                           const void* w_img, int N, int relu, float* y, int64_t ldy, void* zero_buf, int64_t zero_bytes,
+                           ogl_stream_t stream);
 /* ogl_linear_fwd_x3 with a second A part, a per-row addend and / or an image of the output (k_gemm_x3p<..., EXT>):
  *   y[i, :] = act( x_img[row(i)] . w[:, part 1]^T + x2_img[row2(i)] . w[:, part 2]^T + add[add_rows[i], :] )
  * - x2_img (nullable, K2 = 0): the second part of a K-concatenated product — fc_self(x[dst]) + fc_neigh(neigh) of the combine
@@ -638,6 +644,19 @@ int ogl_out_layer_fwd_ce(const float* P, int64_t ldp, int64_t n_src, const int32
                          const int64_t* label_table, int64_t n_labels, const int64_t* label_ids, float grad_scale, float* loss_rows,
                          float* dlogits, int64_t lddl, float* loss_mean, unsigned int* counter, float* zero_buf, int64_t zero_floats,
                          int rows_per_block, ogl_stream_t stream);
+/* ogl_out_layer_fwd_ce + ogl_out_layer_bwd_inputs in ONE launch (round 5): the gradient of the mean loss w.r.t. the logits is known as
+ * soon as a row's softmax is (grad_scale = 1 / n_dst), so the block that finished destination d also computes dx_self[d, :] =
+ * dlogits[d] . w_self (stored) and dlogits[d] . w_neigh, added to dP[argmax[d, c], c] where neigh[d, c] > 0 (float atomics; dP [n_src, K]
+ * ZEROED BY THE CALLER before this launch — no zero fill rides here).  rows_per_block 0 / 1 / 2.  The backward of the loss node then
+ * starts at the pooled rows' gradient (autograd of R/train/graphsage/pytorch/model.py:105-107,198-200 through the last SAGEConv). */
+int ogl_out_layer_fwd_ce_bwd(const float* P, int64_t ldp, int64_t n_src, const int32_t* idx, int64_t n_dst, int fanout, const float* h,
+                             int64_t ldh, int K, const float* w_self, int64_t ldws, const float* w_neigh, int64_t ldwn, const float* b_self,
+                             const float* b_neigh, int N, float* neigh, int64_t ldn, int32_t* argmax, float* logits, int64_t ldl,
+                             const int64_t* label_table, int64_t n_labels, const int64_t* label_ids, float grad_scale, float* loss_rows,
+                             float* dlogits, int64_t lddl, float* loss_mean, unsigned int* counter, int rows_per_block, float* dx_self,
+                             int64_t ldx, float* dP, int64_t ldpp, ogl_stream_t stream);
+/* *loss_mean = sum(loss_rows[0 .. n)) / n in ogl_out_layer_bwd_inputs_mean's order: the deferred mean when no such launch follows. */
+int ogl_loss_mean_finish(const float* loss_rows, int64_t n, float* loss_mean, ogl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * A whole SMALL 'pool' SAGEConv layer in two launches forward, two launches backward (small_layer.hip):

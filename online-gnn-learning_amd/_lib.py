@@ -83,7 +83,11 @@ SIGNATURES = {
     "ogl_out_layer_fwd_ce_fits": (_i, [_i64, _i, _i, _i]),
     "ogl_out_layer_fwd_ce": (_i, [_p, _i64, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p, _i64, _p, _p, _i, _p, _i64, _p, _p, _i64,
                                   _p, _i64, _p, _f, _p, _p, _i64, _p, _p, _p, _i64, _i, _p]),
+    "ogl_out_layer_fwd_ce_bwd": (_i, [_p, _i64, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p, _i64, _p, _p, _i, _p, _i64, _p, _p, _i64,
+                                      _p, _i64, _p, _f, _p, _p, _i64, _p, _p, _i, _p, _i64, _p, _i64, _p]),
+    "ogl_loss_mean_finish": (_i, [_p, _i64, _p, _p]),
     "ogl_linear_fwd_x3": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i, _i, _p, _i64, _p]),
+    "ogl_linear_fwd_x3_zero": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i, _i, _p, _i64, _p, _i64, _p]),
     "ogl_linear_fwd_x3_bits": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i, _i, _p, _i64, _p, _i64, _p]),
     "ogl_linear_fwd_x3_ext": (_i, [_p, _i64, _p, _i64, _i, _p, _i64, _p, _i64, _i, _i64, _p, _i, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i, _p, _i64,
                                    _p, _p]),

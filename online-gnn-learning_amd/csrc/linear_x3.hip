@@ -87,6 +87,9 @@ struct X3Args {
   // gather / zero row / column groups) where tiles tj < NJ1 read b: both weight gradients of a dual-input projection, dy^T . x[rows] and
   // dy^T . x2, as ONE product over [x[rows] | x2] without a concatenated image (output columns: part 1 at 0, part 2 at 128 NJ1) ----
   X3Operand b2; int bk2_groups; int NJ1;
+  // ---- a ZERO FILL riding in the launch: the blocks of the persistent grid that own no tile (a one-round product of 185 tiles leaves 71
+  // of 256 CUs idle) clear zero_buf[0 .. zero_n16) 16-byte words — launch_x3 takes it only when such blocks exist, else fills first ----
+  uint4* zero_buf; int64_t zero_n16;
   int bd_dbg;                   // k_gemm_x3bd, timing experiments only (OGL_X3_BD_DBG; wrong results): 1 = no B loads, 2 = no A DMA
 };
 
@@ -417,7 +420,17 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
   const int T = g.nsplit2 ? (g.NI - 1) * g.NJ * g.nsplit + g.NJ * g.nsplit2 : g.NI * g.NJ * g.nsplit;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   const int chunk_begin = xcd * (T >> 3) + min(xcd, T & 7), chunk_len = (T >> 3) + (xcd < (T & 7) ? 1 : 0);
-  if (slot >= chunk_len) return;
+  if (slot >= chunk_len) {
+    if (g.zero_n16 > 0) {
+      // idle blocks, numbered densely over the XCDs: rank = idle blocks of the XCDs before this one + this block's place among its own
+      int rank = slot - chunk_len;
+      for (int x = 0; x < xcd; ++x) rank += nslots - ((T >> 3) + (x < (T & 7) ? 1 : 0));
+      const int64_t idle = (int64_t)gridDim.x - T;
+      const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+      for (int64_t i = (int64_t)rank * 768 + tid; i < g.zero_n16; i += idle * 768) g.zero_buf[i] = z;
+    }
+    return;
+  }
   if (g.stamps && tid == 0) {
     g.stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
     g.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
@@ -1664,6 +1677,11 @@ extern "C" const char* ogl_x3_last_kernel(void) { return g_x3_last_kernel; }
     hipLaunchKernelGGL((k_gemm_x3p<__VA_ARGS__>), grid, block, 0, stream, g);                     \
   } while (0)
 
+__global__ void __launch_bounds__(256) k_x3_zero16(uint4* __restrict__ p, int64_t n16) {
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = z;
+}
+
 static int launch_x3(X3Args& g, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0) return OGL_OK;
   g.stamps = g_x3_stamps;
@@ -1730,6 +1748,17 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     if (g.nsplit2 && !(bk && cfg == 0 && g.ak_groups == 0 && g.NI >= 2)) g.nsplit2 = 0;   // (the uneven split lives in one instantiation)
     const int64_t T = g.nsplit2 ? (int64_t)(g.NI - 1) * g.NJ * g.nsplit + (int64_t)g.NJ * g.nsplit2 : (int64_t)g.NI * g.NJ * g.nsplit;
     dim3 grid((unsigned)(8 * std::min<int64_t>(32, ogl_cdiv(T, 8)))), block(768);
+    if (g.zero_n16 > 0) {
+      if (cfg == 5 || cfg == 6 || T > 240) {
+        // (no CU left idle by the tiles — or the B-direct kernel, which has no such path: the fill goes first, as its own launch)
+        hipLaunchKernelGGL(k_x3_zero16, dim3((unsigned)std::min<int64_t>(2048, ogl_cdiv(g.zero_n16, 256))), dim3(256), 0, stream, g.zero_buf,
+                           g.zero_n16);
+        OGL_CHECK_LAUNCH();
+        g.zero_n16 = 0;
+      } else {
+        grid = dim3(256);                                   // one block per CU: the 256 - T blocks without a tile do the fill
+      }
+    }
     // ring depth: two stages of the 256 x 128 tile fill the LDS (144 KB); the 128 x 128 tile takes three (144 KB): its movers
     // run two stages ahead (+4 % on the layer-0 weight gradient, whose operands both stream from HBM)
     // the two-stage tiles (256 x 128, 192 x 128) in their early-A form (template parameter EA) unless switched off
@@ -1758,6 +1787,11 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     OGL_CHECK_LAUNCH();
   } else {
   if (g.a2.img || g.add || g.out_img || g.mask) return OGL_EINVAL;   // the extensions live in the producer / consumer kernel (images < 4 GB)
+  if (g.zero_n16 > 0) {
+    hipLaunchKernelGGL(k_x3_zero16, dim3((unsigned)std::min<int64_t>(2048, ogl_cdiv(g.zero_n16, 256))), dim3(256), 0, stream, g.zero_buf, g.zero_n16);
+    OGL_CHECK_LAUNCH();
+    g.zero_n16 = 0;
+  }
   // (the 256 x 128 form of this kernel needs 64-bit piece addresses on top of 128 accumulators: it does not fit 256 registers
   // without spilling, so images of 4 GB and more take the 128 x 128 tile)
   cfg = 1;
@@ -1803,7 +1837,8 @@ __global__ void __launch_bounds__(256) k_x3_image_tail(unsigned char* __restrict
 }
 
 static int fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K, const void* w_img, int N,
-                  int relu, float* y, int64_t ldy, unsigned char* relu_bits, int64_t relu_bits_ld, ogl_stream_t stream);
+                  int relu, float* y, int64_t ldy, unsigned char* relu_bits, int64_t relu_bits_ld, ogl_stream_t stream,
+                  void* zero_buf = nullptr, int64_t zero_bytes = 0);
 
 extern "C" int ogl_linear_fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M,
                                  int K, const void* w_img, int N, int relu, float* y, int64_t ldy, ogl_stream_t stream) {
@@ -1820,13 +1855,33 @@ extern "C" int ogl_linear_fwd_x3_bits(const void* x_img, int64_t x_img_rows, con
   return fwd_x3(x_img, x_img_rows, x_rows, x_nrows, M, K, w_img, N, relu, y, ldy, relu_bits, relu_bits_ld, stream);
 }
 
+// ogl_linear_fwd_x3 with a ZERO FILL riding in the launch: zero_buf[0 .. zero_bytes) (16-byte aligned, a multiple of 16) is cleared by the
+// blocks of the product's grid that own no tile (a one-round product leaves CUs idle: [7 060, 600] x [600, 600] is 185 tiles on 256),
+// or by a fill launch in front of the product when there are none.  The scatter target of the output layer's backward, cleared beside
+// the fc_pool product of that layer (ops._SagePoolLossFn).
+extern "C" int ogl_linear_fwd_x3_zero(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
+                                      const void* w_img, int N, int relu, float* y, int64_t ldy, void* zero_buf, int64_t zero_bytes,
+                                      ogl_stream_t stream) {
+  return fwd_x3(x_img, x_img_rows, x_rows, x_nrows, M, K, w_img, N, relu, y, ldy, nullptr, 0, stream, zero_buf, zero_bytes);
+}
+
 static int fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K, const void* w_img, int N,
-                  int relu, float* y, int64_t ldy, unsigned char* relu_bits, int64_t relu_bits_ld, ogl_stream_t stream) {
+                  int relu, float* y, int64_t ldy, unsigned char* relu_bits, int64_t relu_bits_ld, ogl_stream_t stream, void* zero_buf,
+                  int64_t zero_bytes) {
   if (M < 0 || K <= 0 || N < 0 || x_img_rows < 0 || x_nrows < 0 || x_nrows > x_img_rows || ldy < N) return OGL_EINVAL;
-  if (M == 0 || N == 0) return OGL_OK;
+  if (zero_bytes < 0 || (zero_bytes > 0 && (!zero_buf || ((uintptr_t)zero_buf & 15) || (zero_bytes & 15)))) return OGL_EINVAL;
+  if (M == 0 || N == 0) {
+    if (zero_bytes > 0) {
+      hipLaunchKernelGGL(k_x3_zero16, dim3((unsigned)std::min<int64_t>(2048, ogl_cdiv(zero_bytes / 16, 256))), dim3(256), 0, (hipStream_t)stream,
+                         (uint4*)zero_buf, zero_bytes / 16);
+      OGL_CHECK_LAUNCH();
+    }
+    return OGL_OK;
+  }
   if (!x_img || !w_img || !y || (!x_rows && M > x_img_rows)) return OGL_EINVAL;
   X3Args g = X3Args();
   g.relu_bits = relu_bits; g.relu_bits_ld = relu_bits_ld;
+  g.zero_buf = (uint4*)zero_buf; g.zero_n16 = zero_bytes / 16;
   const int64_t rb = ogl_cdiv(K, 32) * X3_GROUP_BYTES;
   g.a = X3Operand{(const unsigned char*)x_img, rb, X3_GROUP_BYTES, x_rows, x_rows ? x_nrows : x_img_rows, x_img_rows};
   g.b = X3Operand{(const unsigned char*)w_img, rb, X3_GROUP_BYTES, nullptr, N, N};

@@ -634,11 +634,13 @@ def out_loss_fits(h, n_dst, idx, w_self, w_neigh, p_width):
             and bool(_lib.lib().ogl_out_layer_fwd_ce_fits(int(n_dst), int(idx.shape[1]), int(K), int(N))))
 
 
-def out_layer_fwd_ce(p, idx, h, n_dst, w_self, w_neigh, b_self, b_neigh, labels, want_grad=True, zero=None, want_mean=True):
+def out_layer_fwd_ce(p, idx, h, n_dst, w_self, w_neigh, b_self, b_neigh, labels, want_grad=True, zero=None, want_mean=True, bwd_into=None):
     """(mean loss, row losses, logits, neigh, argmax, dlogits / n_dst) of the output layer from its pooled projection rows ``p`` =
     relu(fc_pool(h)) in ONE launch; ``labels``: int64 tensor or LazyLabels; ``zero``: a contiguous fp32 buffer the grid clears on
     the side (the scatter target of the layer's backward).  ``want_mean=False``: the returned mean tensor gets NaN from this launch
-    (no last-block-done count, no device-scope fences) and its value from ``out_layer_bwd_inputs(finish_loss=...)``."""
+    (no last-block-done count, no device-scope fences) and its value from ``out_layer_bwd_inputs(finish_loss=...)``.
+    ``bwd_into = (dx_self [n_dst, K], dP [n_src, K] ALREADY ZERO)``: the combine's input gradients from the same launch
+    (ogl_out_layer_fwd_ce_bwd) — no ``zero`` then."""
     p = as_mat(p); h = as_mat(h); w_self = as_mat(w_self); w_neigh = as_mat(w_neigh)
     K, N = p.shape[1], w_self.shape[0]
     dev = p.device
@@ -659,6 +661,17 @@ def out_layer_fwd_ce(p, idx, h, n_dst, w_self, w_neigh, b_self, b_neigh, labels,
     if zero is not None:
         assert zero.is_contiguous() and zero.dtype == torch.float32 and zero.numel() % 4 == 0
         zn = zero.numel()
+    if bwd_into is not None:
+        assert zero is None and want_grad
+        dxs, dP = bwd_into
+        assert tuple(dxs.shape) == (n_dst, K) and dP.shape[0] == p.shape[0] and dP.shape[1] >= K
+        _launch("ogl_out_layer_fwd_ce", _lib.lib().ogl_out_layer_fwd_ce_bwd, _ptr(p), _ld(p), p.shape[0], _ptr(idx), n_dst, int(idx.shape[1]),
+                _ptr(h), _ld(h), K, _ptr(w_self), _ld(w_self), _ptr(w_neigh), _ld(w_neigh), _ptr(b_self), _ptr(b_neigh), N, _ptr(neigh),
+                _ld(neigh), _ptr(argmax), _ptr(logits), _ld(logits), _ptr(table), table.numel(), _ptr(ids), C.c_float(1.0 / n_dst),
+                _ptr(loss), _ptr(dl), _ld(dl), _ptr(mean), ce_counter(dev, stream) if want_mean else None, OUT_FWD_ROWS,
+                _ptr(dxs), _ld(dxs), _ptr(dP), _ld(dP), stream,
+                meta=dict(n_dst=n_dst, fanout=int(idx.shape[1]), d=K, N=N, zero_bytes=0, with_bwd=True))
+        return mean, loss, logits, neigh, argmax, dl
     _launch("ogl_out_layer_fwd_ce", _lib.lib().ogl_out_layer_fwd_ce, _ptr(p), _ld(p), p.shape[0], _ptr(idx), n_dst, int(idx.shape[1]),
             _ptr(h), _ld(h), K, _ptr(w_self), _ld(w_self), _ptr(w_neigh), _ld(w_neigh), _ptr(b_self), _ptr(b_neigh), N, _ptr(neigh),
             _ld(neigh), _ptr(argmax), _ptr(logits), _ld(logits), _ptr(table), table.numel(), _ptr(ids), C.c_float(1.0 / n_dst),
@@ -689,6 +702,12 @@ def relu_bwd_img(dy, y):
 # critical path, while the separate pass ran beside the side stream's weight gradients.  Off by default; OGL_FUSE_RELU_BWD=1 and
 # tests/test_gpu_round3.py keep it exercised.
 FUSE_RELU_BWD = os.environ.get("OGL_FUSE_RELU_BWD", "0") == "1"
+# The output layer's input gradients from its forward + loss launch (ogl_out_layer_fwd_ce_bwd; their scatter target cleared by the
+# tile-less blocks of the fc_pool product, ogl_linear_fwd_x3_zero).  Bit-identical, one launch and 6 us of kernel time fewer — and
+# measured SLOWER inside the replayed Reddit step (same box, alternating: 0.9228 / 0.9241 / 0.9275 ms without, 0.9301 / 0.9374 / 0.9327
+# with; 0.9407 / 0.9364 against 0.9533 / 0.9558 on a second box): the chain reaches k_pool_values 7 us earlier, where it now meets the
+# side branch's dual weight-gradient product head-on (61 us instead of 37).  Off; OGL_OUT_FWD_BWD=1.
+OUT_FWD_BWD = os.environ.get("OGL_OUT_FWD_BWD", "0") == "1"
 
 
 def linear_bwd_input(dy, w, ymask=None, dy_img=None, add_head=None, out_relu_mask=None):
@@ -828,7 +847,7 @@ class SignBits:
         self.buf = torch.empty((self.rows, self.ld), dtype=torch.uint8, device=device)
 
 
-def linear_fwd_x3(x_img, x_rows, w_img, relu=False, x_nrows=None, M=None, out=None, want_bits=False):
+def linear_fwd_x3(x_img, x_rows, w_img, relu=False, x_nrows=None, M=None, out=None, want_bits=False, zero=None):
     """y = act(x_img[x_rows] @ w_img.T); a bias is folded into the images (x3_split append_ones / append_vec).
     ``x_nrows`` bounds the valid gather ids (default: every image row); without a gather ``M`` selects a row prefix.
     ``want_bits``: also the SignBits of y (attached to it as ``y._ogl_bits``): the ReLU mask a backward pass needs, from the epilogue."""
@@ -838,6 +857,13 @@ def linear_fwd_x3(x_img, x_rows, w_img, relu=False, x_nrows=None, M=None, out=No
     assert w_img.K == K, "both images must be built with the same append choice"
     y = out if out is not None else empty_mat(M, N, x_img.buf.device)
     assert y.shape[0] == M and y.shape[1] == N
+    if zero is not None:
+        # ``zero``: a contiguous buffer cleared by the launch's tile-less blocks (ogl_linear_fwd_x3_zero)
+        assert not want_bits and zero.is_contiguous() and zero.data_ptr() % 16 == 0 and (zero.numel() * zero.element_size()) % 16 == 0
+        _launch("ogl_linear_fwd_x3", _lib.lib().ogl_linear_fwd_x3_zero, _ptr(x_img.buf), x_img.rows,
+                _ptr(_ids(x_rows) if x_rows is not None else None), x_nrows, M, K, _ptr(w_img.buf), N, 1 if relu else 0, _ptr(y),
+                _ld(y), _ptr(zero), zero.numel() * zero.element_size(), _stream(), meta=dict(M=M, K=K, N=N, K2=0, zero_bytes=zero.numel() * zero.element_size()))
+        return y
     if want_bits:
         bits = SignBits(M, N, y.device)
         _launch("ogl_linear_fwd_x3", _lib.lib().ogl_linear_fwd_x3_bits, _ptr(x_img.buf), x_img.rows,
@@ -2392,7 +2418,7 @@ class _SagePoolLayerFn(torch.autograd.Function):
                 db2 if ctx.has_bias else None, None, None, None)
 
 
-def _out_layer_backward(ctx, dy, h, w_pool, w_self, w_neigh, neigh, argmax):
+def _out_layer_backward(ctx, dy, h, w_pool, w_self, w_neigh, neigh, argmax, pre=None):
     """Backward of a 'pool' layer with few output columns (the output layer), shared by ``_SagePoolLayerFn`` and ``_SagePoolLossFn``:
     (dh, dw_pool, db_pool, dw_self, dw_neigh, db_self, db_neigh).  The combine's backward in two launches, its input gradient for
     the pooled rows scattered to the winners as it is computed; the fc_self part joins dh in the epilogue of the fc_pool input
@@ -2409,12 +2435,26 @@ def _out_layer_backward(ctx, dy, h, w_pool, w_self, w_neigh, neigh, argmax):
     # measured 1.075-1.084 -> 1.056-1.059 ms per replayed Reddit step, same box, alternating runs)
     at0 = fork_point() if tall else None
     finish, ctx.loss_out = getattr(ctx, "loss_out", None), None
-    dx_self, dp = out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src,
-                                       dp_zeroed=take_zeroed(slot, n_src, h.shape[1]) if slot is not None else None, finish_loss=finish)
+    if pre is not None:
+        # (``pre``: both input gradients came out of the forward launch — _SagePoolLossFn; dp as a [n_src, K] view of its padded buffer)
+        dx_self, dp = pre[0], pre[1][:, :h.shape[1]]
+    else:
+        dx_self, dp = out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src,
+                                           dp_zeroed=take_zeroed(slot, n_src, h.shape[1]) if slot is not None else None, finish_loss=finish)
+        finish = None
+    dp_img = None
+    if pre is not None and tall:
+        # (the critical launch FIRST — see above: with no input-gradient launch in front of it the side section would be the fork's
+        # first child and take the main queue)
+        dp_img = x3_split(dp)
     with (side_section(dy, h, neigh, at=at0) if tall else _NoSection()):
+        if finish is not None:                   # the deferred mean of the forward launch: one wave, off the critical path
+            _launch("ogl_loss_mean_finish", _lib.lib().ogl_loss_mean_finish, _ptr(finish[0]), finish[0].numel(), _ptr(finish[1]), _stream(),
+                    meta=dict(n=finish[0].numel()))
         dw_self, dw_neigh, db, db2 = out_layer_bwd_weights(dy, h_dst, neigh, want_bias=ctx.has_bias,
                                                            dws_out=_dw_out(w_self, *w_self.shape), dwn_out=_dw_out(w_neigh, *w_neigh.shape))
-    dp_img = x3_split(dp) if tall else None
+    if dp_img is None:
+        dp_img = x3_split(dp) if tall else None
     at = fork_point() if tall else None
     dh = linear_bwd_input(dp, w_pool, None, dy_img=dp_img, add_head=dx_self,
                           out_relu_mask=h if (FUSE_RELU_BWD and ctx.h_relu_out and tall) else None)
@@ -2438,18 +2478,29 @@ class _SagePoolLossFn(torch.autograd.Function):
         ctx.h_relu_out = bool(getattr(h, "_ogl_relu_out", False))
         himg = take_image(h) if _n1_images_ok(h.shape[0], h.shape[1], w_pool.shape[0]) else None
         ctx.h_img = himg if (himg is not None and himg.K == h.shape[1] + 1) else None
+        pre_zero = None
+        # round 5: the combine's input gradients come out of the forward + loss launch; their scatter target is cleared by the CUs the
+        # fc_pool product leaves idle (185 tiles on 256 CUs at the Reddit shape)
+        fuse = OUT_FWD_BWD and h.requires_grad and ctx.h_img is not None and OUT_FWD_ROWS in (0, 1, 2)
         if ctx.h_img is not None:
             wimg = weight_image("wb", w_pool, b_pool)
             if wimg is None:
                 weight_images_prepare([("wb", (w_pool, b_pool))])
                 wimg = weight_image("wb", w_pool, b_pool)
-            p = linear_fwd_x3(himg, None, wimg, relu=True)
+            if fuse:
+                pre_zero = torch.empty((h.shape[0], padded_ld(h.shape[1])), dtype=torch.float32, device=h.device)
+            p = linear_fwd_x3(himg, None, wimg, relu=True, zero=pre_zero)
         else:
             p = linear_fwd(h, w_pool, b_pool, relu=True)
         release_late_plans()      # (a first layer's parked backward plan starts behind this layer's fc_pool product: see POOL_PLAN_LATE)
         need = any(t is not None and t.requires_grad for t in (h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh))
         ent = None
-        if need and h.shape[0] >= 1024:
+        ctx.pre = None
+        if need and pre_zero is not None:
+            # (the loss's own gradient is 1 / n_dst whatever the loss turns out to be)
+            dxs = empty_mat(n_dst, h.shape[1], h.device)
+            ctx.pre = (dxs, pre_zero)
+        elif need and h.shape[0] >= 1024:
             # the backward scatters its pooled-row gradient with float atomics into a zeroed [n_src, K] matrix: cleared by this launch
             buf = torch.empty((h.shape[0], padded_ld(h.shape[1])), dtype=torch.float32, device=h.device)
             ent = [buf, h.shape[0], h.shape[1], True]
@@ -2461,7 +2512,7 @@ class _SagePoolLossFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)             # (the gradients of the two non-differentiable outputs stay None: no zero fills)
         mean, rows, logits, neigh, argmax, dl = out_layer_fwd_ce(p, idx, h, n_dst, w_self, w_neigh, b_self, b_neigh, labels,
                                                                 want_grad=need, zero=ent[0] if ent is not None else None,
-                                                                want_mean=not ctx.defer_mean)
+                                                                want_mean=not ctx.defer_mean, bwd_into=ctx.pre)
         ctx.loss_out = (rows, mean) if ctx.defer_mean else None
         if _CAPTURE is not None:
             _CAPTURE.append(dict(argmax=argmax, neigh=neigh, out=None))
@@ -2476,12 +2527,14 @@ class _SagePoolLossFn(torch.autograd.Function):
     def backward(ctx, dloss, _drows, _dlogits):
         h, w_pool, w_self, w_neigh, neigh, argmax, dl = ctx.saved_tensors
         unit = _UNIT_GRAD.get((dloss.device.type, dloss.device.index))
+        pre, ctx.pre = getattr(ctx, "pre", None), None          # (taken once: see _out_layer_backward's dp_slot)
         if unit is not None and dloss.data_ptr() == unit.data_ptr():
             dy = dl
         else:                                    # (a user's own root gradient: scaled into a matrix with the padded row stride)
             dy = empty_mat(dl.shape[0], dl.shape[1], dl.device)
             torch.mul(dl, dloss, out=dy)
-        return _out_layer_backward(ctx, dy, h, w_pool, w_self, w_neigh, neigh, argmax) + (None, None, None, None)
+            pre = None                           # (the forward launch's input gradients assumed a unit root gradient)
+        return _out_layer_backward(ctx, dy, h, w_pool, w_self, w_neigh, neigh, argmax, pre=pre) + (None, None, None, None)
 
 
 def sage_pool_layer_loss(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels, defer_mean=False):

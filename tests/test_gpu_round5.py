@@ -436,3 +436,118 @@ def test_dual_projection_backward_takes_the_one_launch_product(ops, cat_weight):
         assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max())
     if not cat_weight:
         assert outs[True][1] == 4
+
+
+# ---- the output layer's input gradients from its forward + loss launch ------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_src,n_dst,S,K,N,R", [(7060, 512, 25, 600, 41, 0), (7060, 512, 25, 600, 41, 2), (2000, 300, 10, 128, 7, 1),
+                                                 (1500, 1100, 5, 64, 64, 0), (1030, 1, 3, 4, 1, 0)])
+def test_output_layer_forward_with_input_gradients(ops, n_src, n_dst, S, K, N, R):
+    """ogl_out_layer_fwd_ce_bwd against the two launches it replaces (ogl_out_layer_fwd_ce, then ogl_out_layer_bwd_inputs on its
+    dlogits): every forward output and dx_self bit for bit (the same terms in the same order), the scattered pooled-row gradient within
+    float-atomic order noise — and against float64."""
+    torch.manual_seed(n_src + N)
+    dev = "cuda:0"
+    p = ops.empty_mat(n_src, K, dev).copy_(torch.randn(n_src, K, device=dev).clamp_min(0))
+    h = ops.empty_mat(n_src, K, dev).copy_(torch.randn(n_src, K, device=dev))
+    idx = torch.randint(0, n_src, (n_dst, S), device=dev, dtype=torch.int32)
+    idx[0, 1:] = -1
+    ws = torch.randn(N, K, device=dev) / K ** 0.5; wn = torch.randn(N, K, device=dev) / K ** 0.5
+    bs = torch.randn(N, device=dev); bn = torch.randn(N, device=dev)
+    labels = torch.randint(0, N, (n_dst,), device=dev)
+    old = ops.OUT_FWD_ROWS
+    ops.OUT_FWD_ROWS = R
+    try:
+        dP = ops.empty_mat(n_src, K, dev, zero=True)
+        dxs = ops.empty_mat(n_dst, K, dev)
+        got = ops.out_layer_fwd_ce(p, idx, h, n_dst, ws, wn, bs, bn, labels, want_grad=True, bwd_into=(dxs, dP))
+        ref = ops.out_layer_fwd_ce(p, idx, h, n_dst, ws, wn, bs, bn, labels, want_grad=True)
+    finally:
+        ops.OUT_FWD_ROWS = old
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    mean, rows, logits, neigh, argmax, dl = ref
+    dx_ref, dp_ref = ops.out_layer_bwd_inputs(dl, ws, wn, argmax, neigh, n_src)
+    assert torch.equal(dxs, dx_ref)
+    scale = float(dp_ref.abs().max()) + 1e-30
+    assert float((dP[:, :K] - dp_ref).abs().max()) <= 2e-6 * scale
+    # float64: dP[a, c] = sum over destinations whose winner of column c is a (and whose maximum is positive) of (dl . wn)[d, c]
+    dn = dl[:, :N].double() @ wn.double()
+    want = torch.zeros(n_src, K, dtype=torch.float64, device=dev)
+    am = argmax.long()
+    ok = (am >= 0) & (neigh[:, :K] > 0)
+    cols = torch.arange(K, device=dev).expand(n_dst, K)
+    want.index_put_((am[ok], cols[ok]), dn[ok], accumulate=True)
+    assert float((dP[:, :K].double() - want).abs().max()) <= 1e-5 * (float(want.abs().max()) + 1e-30)
+    assert float((dxs.double() - dl[:, :N].double() @ ws.double()).abs().max()) <= 1e-5 * float(dxs.abs().max() + 1e-30)
+
+
+@pytest.mark.gpu
+def test_loss_node_with_forward_side_input_gradients_matches_two_launch_form(ops):
+    """The Reddit-shaped 'pool' model's train step with OGL_OUT_FWD_BWD on and off: the same loss bits, parameter gradients equal within
+    float-atomic order noise; a non-unit root gradient falls back to the two-launch form and scales."""
+    import torch.nn.functional as F
+    from ogl_amd import sampling, synthetic
+    from ogl_amd.graphsage import GatheredRows, GraphSAGE
+    sampling.seed(3); torch.manual_seed(3)
+    feat_size, _, dyn, n_classes, _ = synthetic.load("arxiv", snapshots=2, device="cuda")
+    dyn.evolve()
+    g = dyn.get_graph()
+    old_mode, old = ops.get_gemm_mode(), ops.OUT_FWD_BWD
+    ops.set_gemm_mode("auto")
+    try:
+        model = GraphSAGE(feat_size, 256, n_classes, 1, F.relu, 0, "pool").cuda()
+        seeds = torch.as_tensor(np.random.default_rng(0).choice(g.n_present, 512, replace=False))
+        (input_nodes, sd, blocks), = list(sampling.NodeDataLoader(g, seeds, sampling.MultiLayerNeighborSampler([25, 25]), batch_size=512))
+        res = {}
+        for on, scale in ((True, None), (False, None), (True, 3.0), (False, 3.0)):
+            ops.OUT_FWD_BWD = on
+            model.zero_grad(set_to_none=True)
+            launches = []
+            real = ops._launch
+
+            def spy(name, *a, **k):
+                launches.append(name)
+                return real(name, *a, **k)
+            ops._launch = spy
+            try:
+                loss, _, _ = model.forward_loss(blocks, GatheredRows(g.ndata["feat"], input_nodes), ops.gather_i64(g.ndata["target"], sd))
+                if scale is None:
+                    ops.backward(loss)
+                else:
+                    (loss * scale).backward()
+            finally:
+                ops._launch = real
+            torch.cuda.synchronize()
+            res[(on, scale)] = (float(loss), [p.grad.clone() for p in model.parameters()], launches)
+        assert "ogl_out_layer_bwd_inputs" not in res[(True, None)][2] and "ogl_out_layer_bwd_inputs" in res[(False, None)][2]
+        assert "ogl_out_layer_bwd_inputs" in res[(True, 3.0)][2]
+        for key_a, key_b in (((True, None), (False, None)), ((True, 3.0), (False, 3.0))):
+            assert res[key_a][0] == res[key_b][0]
+            for a, b in zip(res[key_a][1], res[key_b][1]):
+                assert torch.isfinite(a).all()
+                assert float((a - b).abs().max()) <= 2e-5 * (float(b.abs().max()) + 1e-30)
+        for a, b in zip(res[(True, 3.0)][1], res[(True, None)][1]):
+            assert float((a - 3.0 * b).abs().max()) <= 1e-4 * (float(b.abs().max()) * 3.0 + 1e-30)
+    finally:
+        ops.set_gemm_mode(old_mode)
+        ops.OUT_FWD_BWD = old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,zfloats", [(7060, 600, 600, 7060 * 608), (62495, 602, 602, 1 << 20), (300, 33, 161, 4), (7060, 600, 600, 12),
+                                           (30000, 64, 128, 3000 * 128)])
+def test_zero_fill_riding_in_a_product(ops, M, K, N, zfloats):
+    """ogl_linear_fwd_x3_zero: the product's bits are those of ogl_linear_fwd_x3 and the buffer is cleared — by the tile-less blocks of a
+    one-round grid ([7 060, 600] x [600, 600]: 185 tiles, 71 blocks fill), or by a fill launch in front of a product without such blocks."""
+    torch.manual_seed(M + N)
+    x = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") / K ** 0.5
+    b = torch.randn(N, device="cuda")
+    xi, wi = ops.x3_split(x, append_ones=True), ops.x3_split(w, append_vec=b)
+    ref = ops.linear_fwd_x3(xi, None, wi, relu=True)
+    z = torch.full((zfloats + 8,), 7.0, device="cuda")
+    y = ops.linear_fwd_x3(xi, None, wi, relu=True, zero=z[:zfloats])
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref)
+    assert float(z[:zfloats].abs().max()) == 0.0 and bool((z[zfloats:] == 7.0).all())
