@@ -11,7 +11,8 @@
 //   plan   k_seg_count     cnt[s] = #edges into s                         (integer atomics: counts do not depend on their order)
 //          k_seg_bsum / k_seg_scan_sums / k_seg_apply   start[s] = exclusive prefix of cnt (three-phase scan), cursors zeroed
 //          k_seg_place     every edge takes a place in its source's range (atomic cursor: the order INSIDE a range is arbitrary)
-//          k_seg_rank      ... and is moved to its rank among the range's edge ids: sorted[] lists every source's edges in edge
+//          k_seg_sort_chunks / k_seg_rank   ... and is moved to its rank among the range's edge ids (ranges of more than 64 entries —
+//                          hub sources — sorted in chunks through LDS, shorter ones by a walk): sorted[] lists every source's edges in edge
 //                          order — the same list whatever order the atomics ran in, so the sums below are reproducible
 //   apply  k_seg_reduce    one block per TILE of 64 consecutive entries of the sorted list (load-balanced: a hub referenced by a
 //                          thousand destinations is spread over many tiles, no serial tail): the 64 gradient rows are gathered 8 at
@@ -57,10 +58,13 @@ __global__ void __launch_bounds__(SG_SCAN) k_seg_bsum(const int* __restrict__ cn
 }
 
 // exclusive scan of the block sums in place (one block; NB <= a few thousand)
-__global__ void __launch_bounds__(SG_SCAN) k_seg_scan_sums(int* __restrict__ bsum, int NB) {
+#define SR_LONG 64        // ranges up to this many entries are ranked by k_seg_rank's quadratic walk, longer ones sorted through LDS
+#define SR_CHUNK 4096
+
+__global__ void __launch_bounds__(SG_SCAN) k_seg_scan_sums(int* __restrict__ bsum, int NB, int* __restrict__ nlong) {
   __shared__ int buf[SG_SCAN];
   __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
+  if (threadIdx.x == 0) { carry = 0; *nlong = 0; }            // (the long-source list k_seg_apply fills next)
   __syncthreads();
   for (int base = 0; base < NB; base += SG_SCAN) {
     const int i = base + threadIdx.x;
@@ -83,7 +87,8 @@ __global__ void __launch_bounds__(SG_SCAN) k_seg_scan_sums(int* __restrict__ bsu
 // start[i] = bsum[block] + exclusive prefix inside the block (i in [0, n]: n = n_src, start[n_src] = the number of valid edges);
 // cursors zeroed
 __global__ void __launch_bounds__(SG_SCAN) k_seg_apply(const int* __restrict__ cnt, int64_t n, const int* __restrict__ bsum,
-                                                       int* __restrict__ start, int* __restrict__ cur) {
+                                                       int* __restrict__ start, int* __restrict__ cur, int* __restrict__ nlong,
+                                                       int* __restrict__ longs) {
   __shared__ int buf[SG_SCAN];
   const int64_t i = (int64_t)blockIdx.x * SG_SCAN + threadIdx.x;
   const int v = i < n ? cnt[i] : 0;
@@ -97,6 +102,7 @@ __global__ void __launch_bounds__(SG_SCAN) k_seg_apply(const int* __restrict__ c
   }
   if (i <= n) start[i] = bsum[blockIdx.x] + buf[threadIdx.x] - v;
   if (i < n) cur[i] = 0;
+  if (i < n && v > SR_LONG) longs[atomicAdd(nlong, 1)] = (int)i;          // (at most E / SR_LONG of them)
 }
 
 __global__ void __launch_bounds__(256) k_seg_place(const int32_t* __restrict__ idx, int64_t E, int64_t n_src, const int* __restrict__ start,
@@ -107,6 +113,43 @@ __global__ void __launch_bounds__(256) k_seg_place(const int32_t* __restrict__ i
   }
 }
 
+// Ranges of more than SR_LONG entries — a source sampled by hundreds or thousands of destinations of the block: a hub of a power-law
+// graph under replace = True sampling — would cost k_seg_rank's walk count^2 loads in one wave.  They are sorted in chunks of SR_CHUNK
+// edge ids through LDS (bitonic), one workgroup per (source, chunk): a range of one chunk goes straight to sorted[]; a longer one is
+// sorted chunk by chunk IN PLACE in U, and k_seg_rank then gives every entry its place in its own chunk + its lower bounds in the
+// others (edge ids are distinct).  The long sources come as a list k_seg_apply collected (any order: every range is sorted by itself).
+__global__ void __launch_bounds__(256) k_seg_sort_chunks(int* __restrict__ U, const int* __restrict__ start, const int* __restrict__ nlong,
+                                                         const int* __restrict__ longs, int* __restrict__ sorted) {
+  __shared__ int key[SR_CHUNK];
+  const int tid = threadIdx.x, nl = *nlong;
+  for (int q = 0; q < nl; ++q) {
+    const int src = longs[q];
+    const int a = start[src], c = start[src + 1] - a;
+    const int nch = (c + SR_CHUNK - 1) / SR_CHUNK;
+    for (int j = 0; j < nch; ++j) {
+      if ((unsigned)(q + j) % gridDim.x != blockIdx.x) continue;            // (block-uniform)
+      const int c0 = j * SR_CHUNK, cn = min(SR_CHUNK, c - c0);
+      int P = 64;
+      while (P < cn) P <<= 1;                                 // the chunk padded to a power of two with +infinity keys
+      for (int i = tid; i < P; i += 256) key[i] = i < cn ? U[a + c0 + i] : 0x7FFFFFFF;
+      __syncthreads();
+      for (int k = 2; k <= P; k <<= 1)
+        for (int h = k >> 1; h > 0; h >>= 1) {
+          for (int i = tid; i < (P >> 1); i += 256) {
+            const int lo = ((i & ~(h - 1)) << 1) | (i & (h - 1)), hi = lo | h;
+            const bool up = (lo & k) == 0;
+            const int x = key[lo], y = key[hi];
+            if ((x > y) == up) { key[lo] = y; key[hi] = x; }
+          }
+          __syncthreads();
+        }
+      int* const dst = nch == 1 ? sorted : U;
+      for (int i = tid; i < cn; i += 256) dst[a + c0 + i] = key[i];
+      __syncthreads();
+    }
+  }
+}
+
 // thread per placed position: its entry moves to its rank among the entries of the same source (edge ids are distinct)
 __global__ void __launch_bounds__(256) k_seg_rank(const int32_t* __restrict__ idx, const int* __restrict__ U, const int* __restrict__ start,
                                                   int64_t n_src, int* __restrict__ sorted) {
@@ -114,9 +157,23 @@ __global__ void __launch_bounds__(256) k_seg_rank(const int32_t* __restrict__ id
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int e = U[t];
     const int s = idx[e];
-    const int a = start[s], b = start[s + 1];
+    const int a = start[s], b = start[s + 1], c = b - a;
     int rank = 0;
-    for (int k = a; k < b; ++k) rank += U[k] < e ? 1 : 0;     // (neighbouring threads walk the same range: broadcast loads)
+    if (c <= SR_LONG) {
+      for (int k = a; k < b; ++k) rank += U[k] < e ? 1 : 0;   // (neighbouring threads walk the same range: broadcast loads)
+    } else if (c <= SR_CHUNK) {
+      continue;                                               // (one sorted chunk: k_seg_sort_chunks wrote it to sorted[] itself)
+    } else {
+      const int mine = ((int)t - a) / SR_CHUNK;               // U holds the range as sorted chunks: the place in its own chunk ...
+      rank = (int)t - a - mine * SR_CHUNK;
+      for (int j = 0; j * SR_CHUNK < c; ++j) {                // ... + the entries below e in every other chunk
+        if (j == mine) continue;
+        const int* ch = U + a + j * SR_CHUNK;
+        int lo = 0, hi = min(SR_CHUNK, c - j * SR_CHUNK);
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (ch[m] < e) lo = m + 1; else hi = m; }
+        rank += lo;
+      }
+    }
     sorted[a + rank] = e;
   }
 }
@@ -269,8 +326,8 @@ __global__ void __launch_bounds__(256) k_seg_fixup(const int* __restrict__ start
 
 static int64_t seg_ints(int64_t E, int64_t n_src) {
   const int64_t nb = ogl_cdiv(n_src + 1, SG_SCAN);
-  // cnt [n_src + 1] | start [n_src + 1] | cur [n_src] | bsum [nb] | U [E] | sorted [E]
-  return (n_src + 1) * 2 + n_src + nb + 2 * E + 16;
+  // cnt [n_src + 1] | start [n_src + 1] | cur [n_src] | bsum [nb] | U [E] | sorted [E] | nlong [4] | longs [E / 64 + 1]
+  return (n_src + 1) * 2 + n_src + nb + 2 * E + 4 + (E / 64 + 1) + 16;
 }
 
 extern "C" int64_t ogl_reduce_bwd_seg_workspace_bytes(int64_t n_dst, int fanout, int d, int64_t n_src) {
@@ -295,6 +352,8 @@ extern "C" int ogl_reduce_bwd_seg_plan(const int32_t* idx, int64_t n_dst, int fa
   int* bsum = cur + n_src;
   int* U = bsum + nb;
   int* sorted = U + E;
+  int* nlong = sorted + E;
+  int* longs = nlong + 4;
   // (a kernel, not hipMemsetAsync: a memset node of a captured graph re-runs on 1/16 of its range on ROCm 7.2, tools/graph_probe.py)
   const int rc = ogl_fill_zero(cnt, (n_src + 1) * 4, stream);
   if (rc != OGL_OK) return rc;
@@ -304,13 +363,15 @@ extern "C" int ogl_reduce_bwd_seg_plan(const int32_t* idx, int64_t n_dst, int fa
   }
   hipLaunchKernelGGL(k_seg_bsum, dim3((unsigned)nb), dim3(SG_SCAN), 0, st, (const int*)cnt, n_src + 1, bsum);
   OGL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_seg_scan_sums, dim3(1), dim3(SG_SCAN), 0, st, bsum, (int)nb);
+  hipLaunchKernelGGL(k_seg_scan_sums, dim3(1), dim3(SG_SCAN), 0, st, bsum, (int)nb, nlong);
   OGL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_seg_apply, dim3((unsigned)nb), dim3(SG_SCAN), 0, st, (const int*)cnt, n_src, (const int*)bsum, start, cur);
+  hipLaunchKernelGGL(k_seg_apply, dim3((unsigned)nb), dim3(SG_SCAN), 0, st, (const int*)cnt, n_src, (const int*)bsum, start, cur, nlong, longs);
   OGL_CHECK_LAUNCH();
   if (E > 0) {
     hipLaunchKernelGGL(k_seg_place, dim3((unsigned)std::min<int64_t>(2048, ogl_cdiv(E, 256))), dim3(256), 0, st, idx, E, n_src,
                        (const int*)start, cur, U);
+    OGL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_seg_sort_chunks, dim3(64), dim3(256), 0, st, U, (const int*)start, (const int*)nlong, (const int*)longs, sorted);
     OGL_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_seg_rank, dim3((unsigned)std::min<int64_t>(4096, ogl_cdiv(E, 256))), dim3(256), 0, st, idx, (const int*)U,
                        (const int*)start, n_src, sorted);

@@ -1235,7 +1235,7 @@ def _plan_ready(plan):
 
 
 SEG_REDUCE_BWD = os.environ.get("OGL_SEG_REDUCE_BWD", "1") != "0"    # mean / sum backward as a planned segmented gather (no atomics)
-SEG_MIN_EDGES = 4096
+SEG_MIN_EDGES = int(os.environ.get("OGL_SEG_MIN_EDGES", "4096"))
 
 
 def seg_bwd_fits(idx, d, n_src):
@@ -1580,13 +1580,16 @@ def _dy_rows_image(dy, dy_img):
     return None
 
 
+BWW_DIRECT_MAX_ROWS = int(os.environ.get("OGL_BWW_DIRECT_MAX_ROWS", "1024"))   # below this many reduction rows: the direct k-major kernel
+
+
 def weight_grad(dy, x, x_rows=None, want_bias=True, dyT=None, x_img=None, dy_img=None, dw_out=None, defer_for=None):
     """dW, db of a projection.  In the bf16x6 / auto arithmetic the product runs on the split-bf16 image kernel: x as the row-major
     image its forward already had (``x_img``, or the resident table's: read k-major, no transposed copy), dy likewise when its
     producer wrote its image (``dy_img``), else as the image of dy^T; without a row-major image of x both operands are transposed
     images; the exact-fp32 mode keeps the direct k-major kernel.  ``dyT`` lets the two weight gradients of a dual-input Linear
     share one transpose."""
-    if _MODE["name"] == "f32" or dy.shape[0] < 1024:
+    if _MODE["name"] == "f32" or dy.shape[0] < BWW_DIRECT_MAX_ROWS:
         return linear_bwd_weight(dy, x, None, x_rows, want_bias=want_bias, dw_out=dw_out)
     K = x.shape[1]
     rimg = _row_image_for(x, x_rows, x_img) if dy.shape[0] >= X3_BWW_MIN_ROWS else None

@@ -551,3 +551,37 @@ def test_zero_fill_riding_in_a_product(ops, M, K, N, zfloats):
     torch.cuda.synchronize()
     assert torch.equal(y, ref)
     assert float(z[:zfloats].abs().max()) == 0.0 and bool((z[zfloats:] == 7.0).all())
+
+
+@pytest.mark.gpu
+def test_segmented_plan_with_one_huge_hub(ops):
+    """A source sampled 60 000 times in one block (k_seg_rank's walk would cost 3.6e9 loads in one wave): k_seg_rank_long sorts its range
+    in 15 chunks through LDS and ranks every entry by lower bounds — the same reproducible edge-order sums as for short ranges, and the
+    plan stays in the tens of microseconds."""
+    rng = np.random.default_rng(11)
+    n_dst, S, D, n_src = 4000, 25, 64, 5000
+    li = rng.integers(0, n_src, size=(n_dst, S)).astype(np.int32)
+    m = rng.random((n_dst, S)) < 0.6
+    li[m] = 77
+    li[(~m) & (rng.random((n_dst, S)) < 0.01)] = 78            # ... and one of a few hundred entries (one chunk)
+    assert int((li == 77).sum()) > 50000 and 100 < int((li == 78).sum()) < 4096
+    dout = rng.standard_normal((n_dst, D)).astype(np.float32)
+    idx = torch.as_tensor(li).cuda()
+    dt = ops.empty_mat(n_dst, D, "cuda").copy_(torch.as_tensor(dout).cuda())
+    want = np.zeros((n_src, D), dtype=np.float64)
+    np.add.at(want, li, np.repeat(dout.astype(np.float64), S, axis=0).reshape(n_dst, S, D))
+    outs = []
+    for _ in range(2):
+        plan = ops.reduce_bwd_seg_plan(idx, D, n_src, side=False)
+        out, _ = ops.reduce_bwd_seg_apply(dt, idx, plan, "sum")
+        outs.append(out.clone())
+    assert torch.equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[0].cpu().numpy(), want, rtol=1e-5, atol=3e-6 * np.abs(want).max())
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        ops.reduce_bwd_seg_plan(idx, D, n_src, side=False)
+    e1.record()
+    torch.cuda.synchronize()
+    assert e0.elapsed_time(e1) / 5 < 5.0, "the plan of a block with a 60 000-entry hub took %.2f ms" % (e0.elapsed_time(e1) / 5)
