@@ -292,6 +292,17 @@ int ogl_pool_bwd_x3(const float* dout, int64_t ldo, const int32_t* argmax, const
  * block per source group streams its records into the slab — no dependent read on the backward's critical path.) */
 int ogl_pool_bwd_x3_plan(const int32_t* argmax, const float* relu_out, int64_t ldr, const int32_t* idx32, int64_t n_dst, int fanout,
                          int d, int64_t n_src, void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
+/* The bucket pass of the plan INSIDE the max aggregator (round 5): ogl_reduce_fwd_img_plan = ogl_reduce_fwd_img (max, int32 indices, argmax
+ * kept) whose waves also counting-sort their destination's columns by the winner's sampling slot — they hold the slot and the sign of the
+ * maximum in registers — and write the plan's slot offsets and columns-in-slot-order (plan_off / plan_col: the two arrays
+ * ogl_pool_bwd_x3_plan_slots locates inside a plan workspace, byte offsets from its start); ogl_pool_bwd_x3_plan_finish then runs the rest
+ * of ogl_pool_bwd_x3_plan (group totals from the offsets, scan, place).  The separate bucket pass re-read argmax and the pooled output
+ * (34 MB) and ran 65-70 us on the CUs the combine product leaves free; a second copy of it costs the replayed Reddit step 30 us. */
+int ogl_reduce_fwd_img_plan(const float* src, int64_t lds, int64_t n_src, const int32_t* idx32, int64_t n_dst, int fanout, int d, float* out,
+                            int64_t ldo, int32_t* argmax, void* image, void* plan_off, void* plan_col, ogl_stream_t stream);
+int ogl_pool_bwd_x3_plan_slots(int64_t n_dst, int fanout, int d, int64_t n_src, int64_t* off_bytes, int64_t* colperm_bytes);
+int ogl_pool_bwd_x3_plan_finish(const int32_t* idx32, int64_t n_dst, int fanout, int d, int64_t n_src, void* workspace,
+                                int64_t workspace_bytes, ogl_stream_t stream);
 int ogl_pool_bwd_x3_apply(const float* dout, int64_t ldo, const int32_t* idx32, int64_t n_dst, int fanout, int d, int64_t n_src,
                           void* image, const void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
 /* The planned backward WITHOUT the dense image (round 5): dw[d, K] (and db[d], nullable) = dP^T . [x[x_rows] | 1], the weight gradient of

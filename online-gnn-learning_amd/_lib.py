@@ -87,6 +87,9 @@ SIGNATURES = {
                                       _p, _i64, _p, _f, _p, _p, _i64, _p, _p, _i, _p, _i64, _p, _i64, _p]),
     "ogl_loss_mean_finish": (_i, [_p, _i64, _p, _p]),
     "ogl_linear_fwd_x3": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i, _i, _p, _i64, _p]),
+    "ogl_reduce_fwd_img_plan": (_i, [_p, _i64, _i64, _p, _i64, _i, _i, _p, _i64, _p, _p, _p, _p, _p]),
+    "ogl_pool_bwd_x3_plan_slots": (_i, [_i64, _i, _i, _i64, _p, _p]),
+    "ogl_pool_bwd_x3_plan_finish": (_i, [_p, _i64, _i, _i, _i64, _p, _i64, _p]),
     "ogl_linear_fwd_x3_zero": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i, _i, _p, _i64, _p, _i64, _p]),
     "ogl_linear_fwd_x3_bits": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i, _i, _p, _i64, _p, _i64, _p]),
     "ogl_linear_fwd_x3_ext": (_i, [_p, _i64, _p, _i64, _i, _p, _i64, _p, _i64, _i, _i64, _p, _i, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i, _p, _i64,

@@ -8,6 +8,7 @@
 // in flight per wave, row bases wave-uniform (v_readlane -> scalar address), max/sum kept in
 // registers, one coalesced store per destination.  Algorithmic bytes per launch:
 // E*(4*D + idx) + n_dst*4*D  (SURVEY.md §8d).
+#include <type_traits>
 #include "ogl_common.h"
 #include "x6_arith.h"
 
@@ -27,19 +28,32 @@ __device__ __forceinline__ int64_t bcast_idx(int64_t v, int j) {
 // IMG: ALSO write the bf16x3 image of the output (row-major, n_dst + 1 rows, reduction length d; x6_arith.h) — the A operand of the
 // projection that consumes the reduced rows, without a split pass of its own: a lane's float4 is half a 16-byte piece of each
 // plane (3 x 8-byte stores beside the 16-byte fp32 store).
-template <int OP, typename IdxT, bool ARG, int NCH, bool IMG = false, int U = (NCH == 1 ? 8 : 4)>
+// PB (max with argmax, S <= 63, d <= 1023, parts in {1, 2, 4}: every wave of a destination sits in one block): ALSO the bucket pass of the
+// layer-0 pool backward's plan (pool_bwd_x3.hip, k_pool_bucket<true>) — the wave knows the winner's SLOT and the sign of the maximum, so
+// the destination's columns are counting-sorted by slot here (LDS counters shared by the destination's waves): pb_off[w][0 .. S] = the
+// slot offsets, pb_col[w][...] = the columns in slot order (10 bits column, 6 bits slot); columns whose maximum is not positive own nothing.
+template <int OP, typename IdxT, bool ARG, int NCH, bool IMG = false, int U = (NCH == 1 ? 8 : 4), bool PB = false>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK)
 k_reduce_fwd_v4(const float* __restrict__ src, int64_t lds, int64_t n_src, const IdxT* __restrict__ idx,
                 int64_t n_dst, int S, int d, float* __restrict__ out, int64_t ldo,
                 int32_t* __restrict__ argmax, int parts, unsigned char* __restrict__ img = nullptr, int64_t img_row_bytes = 0,
-                const int64_t* __restrict__ rows = nullptr, int64_t n_rows = 0) {
+                const int64_t* __restrict__ rows = nullptr, int64_t n_rows = 0, unsigned short* __restrict__ pb_off = nullptr,
+                unsigned short* __restrict__ pb_col = nullptr) {
   // rows (optional): idx holds positions into `rows`, the reduced row is src[rows[idx]] — a block's local indices over the
   // resident table through the block's source ids (one more dependent load per WAVE, not per neighbour row)
+  __shared__ int pb_cnt[PB ? WAVES_PER_BLOCK : 1][64];
+  __shared__ unsigned short pb_row[PB ? WAVES_PER_BLOCK : 1][PB ? 1024 : 2];   // PB: a destination's columns in slot order, staged
   const int lane = threadIdx.x & 63;
   const int64_t wg = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   const int64_t w = wg / parts;
-  if (w >= n_dst) return;
+  const bool live = w < n_dst;
+  if (!PB && !live) return;
   const int part = (int)(wg - w * parts);
+  const int dl = (int)(threadIdx.x >> 6) / parts;          // PB: the destination's place inside the block
+  int sl[PB ? NCH : 1][4];                                 // PB: the sampling slot of every column's winner
+  if constexpr (PB) {
+    if (part == 0) pb_cnt[dl][lane] = 0;
+  }
   const int dall4 = (d + 3) >> 2, cper = (dall4 + parts - 1) / parts;
   const int c0 = part * cper;
   const int d4 = min(dall4, c0 + cper);            // this wave's slice: float4 columns [c0, d4)
@@ -51,7 +65,7 @@ k_reduce_fwd_v4(const float* __restrict__ src, int64_t lds, int64_t n_src, const
     acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     arg[c][0] = arg[c][1] = arg[c][2] = arg[c][3] = -1;
   }
-  for (int s0 = 0; s0 < S; s0 += 64) {
+  for (int s0 = 0; s0 < S && live; s0 += 64) {
     const int sc = min(64, S - s0);
     IdxT mine = lane < sc ? idx[w * S + s0 + lane] : (IdxT)-1;
     if (rows) {
@@ -88,11 +102,12 @@ k_reduce_fwd_v4(const float* __restrict__ src, int64_t lds, int64_t n_src, const
             if (!any) {
               acc[c] = v[u][c];
               if (ARG) arg[c][0] = arg[c][1] = arg[c][2] = arg[c][3] = (int)r[u];
+              if constexpr (PB) sl[c][0] = sl[c][1] = sl[c][2] = sl[c][3] = s0 + j0 + u;
             } else {
-              if (v[u][c].x > acc[c].x) { acc[c].x = v[u][c].x; if (ARG) arg[c][0] = (int)r[u]; }
-              if (v[u][c].y > acc[c].y) { acc[c].y = v[u][c].y; if (ARG) arg[c][1] = (int)r[u]; }
-              if (v[u][c].z > acc[c].z) { acc[c].z = v[u][c].z; if (ARG) arg[c][2] = (int)r[u]; }
-              if (v[u][c].w > acc[c].w) { acc[c].w = v[u][c].w; if (ARG) arg[c][3] = (int)r[u]; }
+              if (v[u][c].x > acc[c].x) { acc[c].x = v[u][c].x; if (ARG) arg[c][0] = (int)r[u]; if constexpr (PB) sl[c][0] = s0 + j0 + u; }
+              if (v[u][c].y > acc[c].y) { acc[c].y = v[u][c].y; if (ARG) arg[c][1] = (int)r[u]; if constexpr (PB) sl[c][1] = s0 + j0 + u; }
+              if (v[u][c].z > acc[c].z) { acc[c].z = v[u][c].z; if (ARG) arg[c][2] = (int)r[u]; if constexpr (PB) sl[c][2] = s0 + j0 + u; }
+              if (v[u][c].w > acc[c].w) { acc[c].w = v[u][c].w; if (ARG) arg[c][3] = (int)r[u]; if constexpr (PB) sl[c][3] = s0 + j0 + u; }
             }
           } else {
             acc[c].x += v[u][c].x; acc[c].y += v[u][c].y; acc[c].z += v[u][c].z; acc[c].w += v[u][c].w;
@@ -100,6 +115,51 @@ k_reduce_fwd_v4(const float* __restrict__ src, int64_t lds, int64_t n_src, const
         }
         any = true;
       }
+    }
+  }
+  if constexpr (PB) {
+    // (a wave past the last destination takes part in the barriers only)
+    __syncthreads();                                        // the counters are cleared
+    int pos[NCH][4], slt[NCH][4];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = c0 + c * 64 + lane;
+      const float av[4] = {acc[c].x, acc[c].y, acc[c].z, acc[c].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool own = live && any && ch < d4 && ch * 4 + e < d && av[e] > 0.f && arg[c][e] >= 0;
+        slt[c][e] = own ? sl[c][e] : -1;
+        pos[c][e] = own ? atomicAdd(&pb_cnt[dl][sl[c][e] & 63], 1) : 0;
+      }
+    }
+    __syncthreads();                                        // every column of the destination is counted
+    if (part == 0) {                                        // exclusive scan of the S bucket sizes (lane j = slot j, lane S = the end)
+      const int cn = pb_cnt[dl][lane];
+      int sc = cn;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(sc, o);
+        if (lane >= o) sc += t;
+      }
+      if (live && lane <= S) pb_off[w * (S + 1) + lane] = (unsigned short)(sc - cn);
+      pb_cnt[dl][lane] = sc - cn;
+    }
+    __syncthreads();
+    // the row goes through LDS: 2-byte stores scattered over a 1.2 KB row cost the aggregator 10 us as global stores (112 k wave
+    // instructions of 64 distinct addresses); staged, the destination's waves write it out in 128-byte runs
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = c0 + c * 64 + lane;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (slt[c][e] >= 0) pb_row[dl][pb_cnt[dl][slt[c][e]] + pos[c][e]] = (unsigned short)((ch * 4 + e) | (slt[c][e] << 10));
+    }
+    __syncthreads();
+    if (!live) return;
+    {
+      const int n = pb_cnt[dl][S];                          // (the end offset: lane S of the scan)
+      unsigned short* const row = pb_col + w * (int64_t)d;
+      for (int i = part * 64 + lane; i < n; i += parts * 64) row[i] = pb_row[dl][i];
     }
   }
   const float fS = (float)S;
@@ -183,7 +243,8 @@ k_reduce_fwd_generic(const float* __restrict__ src, int64_t lds, int64_t n_src, 
 template <int OP, typename IdxT, bool ARG>
 static int launch_reduce_fwd(const float* src, int64_t lds, int64_t n_src, const IdxT* idx, int64_t n_dst,
                              int S, int d, float* out, int64_t ldo, int32_t* argmax, hipStream_t stream,
-                             unsigned char* img = nullptr, const int64_t* rows = nullptr, int64_t n_rows = 0) {
+                             unsigned char* img = nullptr, const int64_t* rows = nullptr, int64_t n_rows = 0,
+                             unsigned short* pb_off = nullptr, unsigned short* pb_col = nullptr) {
   dim3 grid((unsigned)ogl_cdiv(n_dst, WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
   const int d4 = (d + 3) / 4;
   const bool vec = (lds % 4 == 0) && (ldo % 4 == 0) && (lds >= 4 * d4) && (ldo >= 4 * d4) &&
@@ -194,8 +255,23 @@ static int launch_reduce_fwd(const float* src, int64_t lds, int64_t n_src, const
   // 3 slices 0.0586 ms; 512 x 600: 1 slice 0.0168 ms, 2 slices 0.0148 ms, 4 slices 0.0137 ms.
   int parts = 1;
   while (vec && parts < 4 && n_dst * parts < 2 * 256 * 20 && d4 / (parts + 1) >= 32) ++parts;
+  if (pb_off && parts == 3) parts = 2;                    // (PB: the waves of a destination share a block)
   const int cper = (d4 + parts - 1) / parts;
   if (vec) grid.x = (unsigned)ogl_cdiv(n_dst * parts, WAVES_PER_BLOCK);
+  if (pb_off) {
+    if constexpr (OP == OGL_REDUCE_MAX && ARG && std::is_same<IdxT, int32_t>::value) {
+      if (!vec || !img || !pb_col || S > 63 || d > 1023 || rows) return OGL_EINVAL;
+      const int64_t irb = ogl_cdiv(d, 32) * 192;
+      if (cper <= 64) hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 1, true, 8, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb, rows, n_rows, pb_off, pb_col);
+      else if (cper <= 128) hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 2, true, 4, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb, rows, n_rows, pb_off, pb_col);
+      else if (cper <= 192) hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 3, true, 4, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb, rows, n_rows, pb_off, pb_col);
+      else hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 4, true, 4, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb, rows, n_rows, pb_off, pb_col);
+      OGL_CHECK_LAUNCH();
+      return OGL_OK;
+    } else {
+      return OGL_EINVAL;
+    }
+  }
   if (img) {
     if (!vec) return OGL_EINVAL;     // the image form exists for the vectorised kernels (the 'pool' / 'meanpool' layers)
     const int64_t irb = ogl_cdiv(d, 32) * 192;
@@ -258,6 +334,21 @@ extern "C" int ogl_reduce_fwd(const float* src, int64_t lds, int64_t n_src, cons
 // ogl_reduce_fwd(OGL_REDUCE_MAX) that ALSO writes the bf16x3 image of `out` (what ogl_x3_split(out) would build; n_dst + 1 image
 // rows over a reduction of d): the A operand of the projection that consumes the pooled rows.  16-byte-aligned, 4-float-strided
 // operands only (what this package allocates).
+// ogl_reduce_fwd_img (max, int32 indices, argmax kept) that ALSO runs the bucket pass of the layer-0 pool backward's plan: plan_off /
+// plan_col = the two arrays ogl_pool_bwd_x3_plan_slots locates inside a plan workspace; ogl_pool_bwd_x3_plan_finish does the rest.
+// fanout <= 63, d <= 640 (the plan's limits), 16-byte aligned rows (the vectorised kernel only).
+extern "C" int ogl_reduce_fwd_img_plan(const float* src, int64_t lds, int64_t n_src, const int32_t* idx32, int64_t n_dst, int fanout, int d,
+                                       float* out, int64_t ldo, int32_t* argmax, void* image, void* plan_off, void* plan_col,
+                                       ogl_stream_t stream) {
+  if (n_dst <= 0 || fanout <= 0 || fanout > 63 || d <= 0 || d > 640 || n_src <= 0 || lds < d || (out && ldo < d)) return OGL_EINVAL;
+  if (!src || !idx32 || !argmax || !image || ((uintptr_t)image & 15) || !plan_off || !plan_col || ((uintptr_t)plan_off & 1) ||
+      ((uintptr_t)plan_col & 1))
+    return OGL_EINVAL;
+  return launch_reduce_fwd<OGL_REDUCE_MAX, int32_t, true>(src, lds, n_src, idx32, n_dst, fanout, d, out, ldo, argmax, (hipStream_t)stream,
+                                                          (unsigned char*)image, nullptr, 0, (unsigned short*)plan_off,
+                                                          (unsigned short*)plan_col);
+}
+
 extern "C" int ogl_reduce_fwd_img(const float* src, int64_t lds, int64_t n_src, const int32_t* idx32, const int64_t* idx64,
                                   int64_t n_dst, int fanout, int d, float* out, int64_t ldo, int32_t* argmax, void* image,
                                   ogl_stream_t stream) {

@@ -475,6 +475,87 @@ extern "C" int ogl_pool_bwd_x3_plan(const int32_t* argmax, const float* relu_out
   return OGL_OK;
 }
 
+// ---- the bucket pass INSIDE the aggregator (round 5) --------------------------------------------------------------------------------
+// k_pool_bucket<true> re-reads what the max aggregator had in registers a moment earlier (the winner of every column, its sampling slot,
+// the sign of the maximum) and runs on the 71 CUs a 185-tile product leaves free: 65-70 us beside the combine product, and a second copy of
+// it costs the replayed step 30 us (measured).  ogl_reduce_fwd_img_plan (aggregate.hip) therefore writes the plan's slot offsets and the
+// columns in slot order itself; what is left for the side stream is the per-group totals (from the offsets), the scan and the place pass.
+#define PB_TOT_BLOCKS 16
+#define PB_TOT_MAXG 8192            // groups whose totals fit a block's LDS histogram (n_src <= 262 144); more: global atomics
+__global__ void __launch_bounds__(1024) k_pool_group_totals(const int32_t* __restrict__ idx, int64_t n_dst, int S, int64_t n_src,
+                                                            const unsigned short* __restrict__ off, PbDiv dv, unsigned* __restrict__ gcount) {
+  // (a block-local histogram first: 176 k atomic adds onto 1 958 addresses took this pass 21 us and slowed the product beside it)
+  __shared__ unsigned hist[PB_TOT_MAXG];
+  const bool local = dv.G <= PB_TOT_MAXG;
+  if (local) {
+    for (unsigned g = threadIdx.x; g < dv.G; g += 1024) hist[g] = 0;
+    __syncthreads();
+  }
+  const int64_t n = n_dst * S;
+  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 1024) {
+    const int64_t d = i / S;
+    const int j = (int)(i - d * S);
+    const unsigned len = (unsigned)off[d * (S + 1) + j + 1] - (unsigned)off[d * (S + 1) + j];
+    if (len == 0) continue;
+    const int my = idx[i];                                        // len > 0: slot j holds a winner, so `my` is a valid source
+    const unsigned q = pb_div((unsigned)my, dv);
+    const unsigned g = (unsigned)my - q * dv.G;
+    if (local) atomicAdd(&hist[g], len);
+    else atomicAdd(&gcount[g], len);
+  }
+  if (local) {
+    __syncthreads();
+    for (unsigned g = threadIdx.x; g < dv.G; g += 1024)
+      if (hist[g]) atomicAdd(&gcount[g], hist[g]);
+  }
+}
+
+// where ogl_reduce_fwd_img_plan writes inside a plan workspace: byte offsets of the slot offsets [n_dst][fanout + 1] (uint16) and of the
+// columns in slot order [n_dst][d] (uint16: 10 bits column, 6 bits slot)
+extern "C" int ogl_pool_bwd_x3_plan_slots(int64_t n_dst, int fanout, int d, int64_t n_src, int64_t* off_bytes, int64_t* colperm_bytes) {
+  if (!off_bytes || !colperm_bytes || n_dst < 0 || fanout < 0 || fanout > PB_MAX_S || d <= 0 || d > PB_MAX_D || n_src <= 0) return OGL_EINVAL;
+  const PbPlanLayout L = pb_plan_layout(n_dst, fanout, d, n_src);
+  *off_bytes = L.off; *colperm_bytes = L.colperm;
+  return OGL_OK;
+}
+
+// the rest of ogl_pool_bwd_x3_plan when the aggregator already wrote the slot offsets and the columns in slot order
+extern "C" int ogl_pool_bwd_x3_plan_finish(const int32_t* idx32, int64_t n_dst, int fanout, int d, int64_t n_src, void* workspace,
+                                           int64_t workspace_bytes, ogl_stream_t stream) {
+  const int rc = pb_check(n_dst, fanout, d, n_src, workspace, workspace_bytes);
+  if (rc != OGL_OK) return rc;
+  if (n_dst * (int64_t)d >= (1ll << PB_POS_BITS)) return OGL_EINVAL;
+  if (n_dst > 0 && fanout > 0 && !idx32) return OGL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t G = ogl_cdiv(n_src, 32);
+  const PbPlanLayout L = pb_plan_layout(n_dst, fanout, d, n_src);
+  unsigned char* w = (unsigned char*)workspace;
+  unsigned* gcount = (unsigned*)(w + L.counts);
+  unsigned* gbase = gcount + G;
+  unsigned* gcur = gbase + G + 1;
+  unsigned short* off = (unsigned short*)(w + L.off);
+  unsigned* seginfo = (unsigned*)(w + L.seginfo);
+  {
+    const int64_t n16 = L.off / 16;
+    hipLaunchKernelGGL(k_pb_zero16, dim3((unsigned)std::min<int64_t>(ogl_cdiv(n16, 256), 2048)), dim3(256), 0, st, (uint4*)w, n16);
+    OGL_CHECK_LAUNCH();
+  }
+  const PbDiv dv = pb_make_div((unsigned)G);
+  if (n_dst > 0 && fanout > 0) {
+    hipLaunchKernelGGL(k_pool_group_totals, dim3((unsigned)std::min<int64_t>(PB_TOT_BLOCKS, ogl_cdiv(n_dst * fanout, 1024))), dim3(1024), 0, st,
+                       idx32, n_dst, fanout, n_src, (const unsigned short*)off, dv, gcount);
+    OGL_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_pool_plan_scan, dim3(1), dim3(1024), 0, st, (const unsigned*)gcount, gbase, gcur, (int)G);
+  OGL_CHECK_LAUNCH();
+  if (n_dst > 0 && fanout > 0) {
+    hipLaunchKernelGGL(k_pool_plan_place, dim3((unsigned)std::min<int64_t>(PB_PLACE_BLOCKS, ogl_cdiv(n_dst * fanout, 4096))), dim3(1024), 0, st,
+                       idx32, n_dst, fanout, (const unsigned short*)off, dv, (const unsigned*)gbase, gcur, seginfo);
+    OGL_CHECK_LAUNCH();
+  }
+  return OGL_OK;
+}
+
 extern "C" int ogl_pool_bwd_x3_apply(const float* dout, int64_t ldo, const int32_t* idx32, int64_t n_dst, int fanout, int d,
                                      int64_t n_src, void* image, const void* workspace, int64_t workspace_bytes, ogl_stream_t stream) {
   (void)idx32;                                                    // (the plan already holds what the indices say)

@@ -451,7 +451,7 @@ def reduce_fwd(src: torch.Tensor, idx: torch.Tensor, op: str, want_argmax: bool 
     return out, argmax
 
 
-def reduce_fwd_img(src: torch.Tensor, idx: torch.Tensor, want_argmax: bool = False, want_out: bool = True):
+def reduce_fwd_img(src: torch.Tensor, idx: torch.Tensor, want_argmax: bool = False, want_out: bool = True, plan_ws=None):
     """max-reduce that also returns the bf16x3 image of its output: (out, argmax, X3Image).  ``want_out=False``: the image only
     (``out`` is None: a consumer that reads nothing but the image — the cached inference layers — saves 40 % of the launch's writes)."""
     src = as_mat(src)
@@ -463,6 +463,15 @@ def reduce_fwd_img(src: torch.Tensor, idx: torch.Tensor, want_argmax: bool = Fal
     img = X3Image(_x3_alloc(n_dst, d, src.device), n_dst, d)
     i32 = idx if idx.dtype == torch.int32 else None
     i64 = idx if idx.dtype == torch.int64 else None
+    if plan_ws is not None:
+        # ``plan_ws``: a pool-backward plan workspace — the launch also runs the plan's bucket pass into it (ogl_reduce_fwd_img_plan)
+        assert i32 is not None and want_argmax and want_out
+        o1, o2 = C.c_int64(0), C.c_int64(0)
+        check(_lib.lib().ogl_pool_bwd_x3_plan_slots(n_dst, fanout, d, src.shape[0], C.byref(o1), C.byref(o2)), "ogl_pool_bwd_x3_plan_slots")
+        _launch("ogl_reduce_fwd_img", _lib.lib().ogl_reduce_fwd_img_plan, _ptr(src), _ld(src), src.shape[0], _ptr(i32), n_dst, fanout, d,
+                _ptr(out), _ld(out), _ptr(argmax), _ptr(img.buf), plan_ws.data_ptr() + o1.value, plan_ws.data_ptr() + o2.value, _stream(),
+                meta=dict(n_dst=n_dst, fanout=fanout, d=d, op="max", argmax=True, idx_bytes=4, out=True, plan=True))
+        return out, argmax, img
     _launch("ogl_reduce_fwd_img", _lib.lib().ogl_reduce_fwd_img, _ptr(src), _ld(src), src.shape[0], _ptr(i32), _ptr(i64), n_dst, fanout, d,
             _ptr(out), _ld(out) if out is not None else padded_ld(d), _ptr(argmax), _ptr(img.buf), _stream(),
             meta=dict(n_dst=n_dst, fanout=fanout, d=d, op="max", argmax=argmax is not None, idx_bytes=idx.element_size(), out=out is not None))
@@ -1138,6 +1147,25 @@ class PoolPlan:
 
 
 POOL_PLAN = os.environ.get("OGL_POOL_PLAN", "1") != "0"
+# ... with its bucket pass inside the max aggregator's launch (ogl_reduce_fwd_img_plan: the waves hold every winner's slot and the sign of
+# the maximum; the 65 us side pass and its 34 MB of re-reads disappear).  Parity-green (tests/test_gpu_x3.py::
+# test_plan_bucket_pass_inside_the_aggregator) and OFF: the aggregator — on the critical path, at the HBM wall — takes 71 us instead of
+# 62 with the counting sort in it, and nothing comes back: the combine product beside the old side pass takes 70 us either way (its
+# operands are cold, not crowded), and the plan chain had ~35 us of slack before the backward's side branch needs its stream (a SECOND
+# copy of the bucket pass costs the step 30 us — by delaying that branch —, which is what suggested this).  Same box, alternating:
+# 0.942 / 0.947 / 0.964 ms without, 0.947 / 0.962 / 0.960 with.  OGL_POOL_PLAN_FUSED=1.
+POOL_PLAN_FUSED = os.environ.get("OGL_POOL_PLAN_FUSED", "0") == "1"
+
+
+def pool_bwd_x3_plan_finish(ws, nbytes, idx32, n_dst, d, n_src, side=True):
+    """The rest of ``pool_bwd_x3_plan`` for a workspace whose slot offsets / columns the aggregator already wrote: group totals, scan,
+    place — on the side stream when the fork is on.  Returns the PoolPlan."""
+    def launch():
+        _launch("ogl_pool_bwd_x3_plan", _lib.lib().ogl_pool_bwd_x3_plan_finish, _ptr(idx32), n_dst, idx32.shape[1], d, n_src, _ptr(ws), nbytes,
+                _stream(), meta=dict(n_dst=n_dst, d=d, n_src=n_src, fanout=idx32.shape[1], finish=True))
+
+    plan = PoolPlan(ws, nbytes, None, (n_dst, idx32.shape[1], d, n_src))
+    return _plan_on_side(plan, launch, (ws, idx32), side, late=POOL_PLAN_LATE)
 
 
 def pool_bwd_x3_plan(argmax, relu_out, idx32, n_src, side=True):
@@ -2284,20 +2312,28 @@ class _PoolMaxFn(torch.autograd.Function):
     def forward(ctx, x, w, bias, x_rows, idx):
         p = linear_fwd(x, w, bias, relu=True, x_rows=x_rows)
         need = x.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad)
+        ctx.n_src, ctx.fanout, ctx.has_bias = p.shape[0], idx.shape[1], bias is not None
+        plan_ok = (POOL_PLAN and need and not x.requires_grad and idx.dtype == torch.int32 and _MODE["name"] != "f32"
+                   and ctx.n_src >= X3_BWW_MIN_ROWS and p.shape[1] <= 640 and ctx.fanout <= 63 and idx.shape[0] * p.shape[1] < (1 << 27)
+                   and (w.requires_grad or (bias is not None and bias.requires_grad)))
+        fused_ws = None
         if _n1_images_ok(idx.shape[0], p.shape[1]):
             # the pooled rows feed the n1-row combine product: their bf16x3 image goes out beside them
-            out, argmax, img = reduce_fwd_img(p, idx, want_argmax=need)
+            if plan_ok and POOL_PLAN_FUSED and idx.is_contiguous() and _ld(p) % 4 == 0:
+                # ... and the bucket pass of the backward's plan runs in the same waves (they hold every winner's slot)
+                nbytes = int(_lib.lib().ogl_pool_bwd_x3_workspace_bytes(idx.shape[0], idx.shape[1], p.shape[1], ctx.n_src))
+                fused_ws = (torch.empty(max(nbytes, 16), dtype=torch.uint8, device=p.device), nbytes)
+            out, argmax, img = reduce_fwd_img(p, idx, want_argmax=need, plan_ws=fused_ws[0] if fused_ws is not None else None)
             attach_image(out, img)
         else:
             out, argmax = reduce_fwd(p, idx, "max", want_argmax=need)
         if _CAPTURE is not None:
             _CAPTURE.append(dict(argmax=argmax, neigh=out))
-        ctx.n_src, ctx.fanout, ctx.has_bias = p.shape[0], idx.shape[1], bias is not None
         ctx.bias_t = bias
         ctx.pool_plan = None
-        if (POOL_PLAN and need and not x.requires_grad and idx.dtype == torch.int32 and _MODE["name"] != "f32"
-                and ctx.n_src >= X3_BWW_MIN_ROWS and out.shape[1] <= 640 and ctx.fanout <= 63 and idx.shape[0] * out.shape[1] < (1 << 27)
-                and (w.requires_grad or (bias is not None and bias.requires_grad))):
+        if fused_ws is not None:
+            ctx.pool_plan = pool_bwd_x3_plan_finish(fused_ws[0], fused_ws[1], idx, idx.shape[0], out.shape[1], ctx.n_src)
+        elif plan_ok:
             # layer 0 (see backward): the gradient-free half of the pool backward starts here, beside the products that follow
             ctx.pool_plan = pool_bwd_x3_plan(argmax, out, idx, ctx.n_src)
         ctx.dp_slot = None

@@ -831,3 +831,67 @@ def test_status_codes_of_the_round2_entry_points(ops):
     lab = torch.zeros(64, dtype=torch.int64).cuda()
     assert h.ogl_ce_fwd_bwd_mean(p(x), 64, p(lab), 1025, 8, f(1.0), None, None, 0, p(x), None) == -1
     assert h.ogl_ce_fwd_bwd_mean(p(x), 64, p(lab), 64, 8, f(1.0), None, None, 0, None, None) == -1
+
+
+@pytest.mark.parametrize("n_dst,S,D,n_src", [(1, 1, 4, 1), (50, 4, 36, 70), (300, 25, 600, 2000), (700, 25, 64, 40), (4100, 25, 40, 5000),
+                                             (7060, 25, 602, 62495), (3000, 63, 640, 40000), (2047, 7, 132, 300)])
+def test_plan_bucket_pass_inside_the_aggregator(ops, n_dst, S, D, n_src):
+    """ogl_reduce_fwd_img_plan + ogl_pool_bwd_x3_plan_finish against ogl_reduce_fwd_img + ogl_pool_bwd_x3_plan: the aggregator's own
+    outputs bit for bit; the plan's slot offsets equal; every slot segment holds the same SET of columns (their order inside a segment
+    follows LDS atomics in both forms); the applied image equal where a cell has at most two contributions and within fp32-order noise
+    of the float64 scatter elsewhere.  Blocks with duplicate samples, missing neighbours and non-positive maxima (which own nothing)."""
+    from ogl_amd import _lib
+    import ctypes as C
+    rng = np.random.default_rng(n_dst * 5 + D)
+    idx = rng.integers(0, n_src, (n_dst, S)).astype(np.int32)
+    idx[rng.random((n_dst, S)) < 0.05] = -1
+    if S > 2:
+        idx[:, 2] = idx[:, 0]                                            # a duplicate sample: its slot owns nothing
+    it = torch.as_tensor(idx).cuda()
+    torch.manual_seed(n_dst + D)
+    p = torch.randn(n_src, D).clamp_min(0)
+    p[:, ::7] = 0                                                       # columns whose maximum is never positive
+    pm = ops.empty_mat(n_src, D, "cuda"); pm.copy_(p)
+    nbytes = int(_lib.lib().ogl_pool_bwd_x3_workspace_bytes(n_dst, S, D, n_src))
+    ws = torch.zeros(max(nbytes, 16), dtype=torch.uint8, device="cuda")
+    out_a, arg_a, img_a = ops.reduce_fwd_img(pm, it, want_argmax=True, plan_ws=ws)
+    plan_a = ops.pool_bwd_x3_plan_finish(ws, nbytes, it, n_dst, D, n_src, side=False)
+    out_b, arg_b, img_b = ops.reduce_fwd_img(pm, it, want_argmax=True)
+    plan_b = ops.pool_bwd_x3_plan(arg_b, out_b, it, n_src, side=False)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b) and torch.equal(arg_a, arg_b) and torch.equal(img_a.buf, img_b.buf)
+    o1, o2 = C.c_int64(0), C.c_int64(0)
+    assert _lib.lib().ogl_pool_bwd_x3_plan_slots(n_dst, S, D, n_src, C.byref(o1), C.byref(o2)) == 0
+    offs = [pl.ws[o1.value:o1.value + n_dst * (S + 1) * 2].cpu().numpy().view(np.uint16).reshape(n_dst, S + 1) for pl in (plan_a, plan_b)]
+    assert np.array_equal(offs[0], offs[1])
+    cols = [pl.ws[o2.value:o2.value + n_dst * D * 2].cpu().numpy().view(np.uint16).reshape(n_dst, D) for pl in (plan_a, plan_b)]
+    for d in range(0, n_dst, max(1, n_dst // 97)):
+        n = int(offs[0][d, S])
+        for j in range(S):
+            a, b = int(offs[0][d, j]), int(offs[0][d, j + 1])
+            assert b <= n and np.array_equal(np.sort(cols[0][d, a:b]), np.sort(cols[1][d, a:b])), (d, j)
+    dout = torch.randn(n_dst, D)
+    dm = ops.empty_mat(n_dst, D, "cuda"); dm.copy_(dout)
+    G = (n_src + 31) // 32
+    a = arg_b.cpu().numpy(); o = out_b.cpu().numpy(); g = dout.numpy()
+    dP = np.zeros((n_src, D), np.float64)
+    cnt = np.zeros((n_src, D), np.int64)
+    cc = np.arange(D)
+    for d in range(n_dst):
+        m = (a[d] >= 0) & (o[d] > 0)
+        dP[a[d, m], cc[m]] += g[d, m]
+        cnt[a[d, m], cc[m]] += 1
+    mm = np.arange(32 * G)
+    s_of_m = (mm % 32) * G + mm // 32
+    ok = s_of_m < n_src
+    got = []
+    for pl in (plan_a, plan_b):
+        im = ops.pool_bwd_x3_apply(dm.clone(), it, pl, n_src)
+        dec = image_decode_t(im.buf, D, 32 * G).numpy()
+        assert (dec[:, ~ok] == 0).all()
+        gs = np.zeros((n_src, D), np.float32)
+        gs[s_of_m[ok]] = dec[:, ok].T
+        got.append(gs)
+    two = cnt <= 2
+    assert np.array_equal(got[0][two], got[1][two])
+    np.testing.assert_allclose(got[0], dP, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(dP).max()))
