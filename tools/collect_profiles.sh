@@ -22,7 +22,7 @@ part_A1() {
 }
 part_A2() {
   # same-box A/B of the round's switches inside the replayed step (kept and dropped ones)
-  bash tools/ab_combo.sh r05 3 "OGL_X=0" "OGL_POOL_RF=1" "OGL_BWWK_BLOCKS=128" "OGL_BWWK_BLOCKS=192" "OGL_SLAB_ADAM=0" "OGL_X3_EARLY_A=0" "OGL_FUSED_OUT_FWD=0" > $O/ab_r05.txt 2>&1 || true
+  bash tools/ab_combo.sh r05 2 "OGL_X=0" "OGL_DUAL_DW=0" "OGL_OUT_FWD_BWD=1" "OGL_POOL_PLAN_FUSED=1" "OGL_X3_BD=6" "OGL_POOL_RF=1" "OGL_BWWK_BLOCKS=192" "OGL_SLAB_ADAM=0" "OGL_X3_EARLY_A=0" "OGL_X3_CFG3=1" "OGL_X3_CFG4=1" > $O/ab_r05.txt 2>&1 || true
   # round 5: this tree against the round-4 tree on the same box (a git worktree under _r04/, when present)
   [ -d _r04 ] && (bash tools/ab_r04.sh 3 > $O/ab_vs_r04.txt 2>&1; cp -r gpurun_out/ab_r04 $O/ab_vs_r04) || true
   # round 5: the 32-seed rungs with the sampling phase as one launch / as eleven graph nodes, and their traced steps
@@ -37,7 +37,7 @@ part_A2() {
   done; done
   # round 5: the record-fed layer-0 weight gradient against the round-4 pair, alone, with its timing-only ablations; micro-benchmarks
   (for d in 0 1 2 4 6 7; do echo "== OGL_RF_DBG=$d (1: no B pieces, 2: no records, 4: no conversion; wrong results, timing only)"; OGL_RF_DBG=$d timeout -k 10 200 python tools/rf_probe.py 2>&1 | grep -v amdgpu.ids; done) > $O/rf_probe.txt 2>&1 || true
-  (timeout -k 5 60 tools/micro/lds_atomics; timeout -k 5 60 tools/micro/grid_barrier) > $O/micro.txt 2>&1 || true
+  (timeout -k 5 60 tools/micro/lds_atomics; timeout -k 5 60 tools/micro/grid_barrier; timeout -k 5 60 tools/micro/mfma_rate) > $O/micro.txt 2>&1 || true
   bash tools/pmc_waits.sh > /dev/null 2>&1 || true
   cp gpurun_out/pmc_waits.txt $O/pmc_waits.txt 2> /dev/null || true
   # the loader phase (sampler + block build, hash / direct table / minima in LDS) and the layer-0 weight gradient block by block (even / uneven split-K)
