@@ -28,6 +28,9 @@ from .sageconv import GatheredRows
 DP_CAPTURE_COLLECTIVES = __import__("os").environ.get("OGL_DP_CAPTURE_COLLECTIVES", "0") == "1"
 # OGL_SHARDED_FUSED=0: the eager replica step differentiates sum(rows) / n_global through the unfused output layer (rounds 1-4)
 SHARDED_FUSED = __import__("os").environ.get("OGL_SHARDED_FUSED", "1") != "0"
+# The 32-seed rungs' captured steps sample batch i + 1 on a second stream while batch i trains (stepgraph.sampled_step_pipelined);
+# OGL_SAMPLE_PIPELINE=0: sample, read back, train, one after the other.
+SAMPLE_PIPELINE = __import__("os").environ.get("OGL_SAMPLE_PIPELINE", "1") != "0"
 
 
 def _to_numpy(t):
@@ -274,7 +277,12 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             for i, s0 in enumerate(starts):
                 sd = seeds_np[s0:s0 + bs]
                 if len(sd) == bs:
-                    sg = self._step_graphs().sampled_step(graph, sd, ctrs[i])
+                    if SAMPLE_PIPELINE and len(starts) >= 2:   # (a one-batch snapshot has nothing to sample ahead: the plain form)
+                        j = i + 1
+                        nxt = (seeds_np[starts[j]:starts[j] + bs], ctrs[j]) if j < len(starts) else None
+                        sg = self._step_graphs().sampled_step_pipelined(graph, sd, ctrs[i], nxt)
+                    else:
+                        sg = self._step_graphs().sampled_step(graph, sd, ctrs[i])
                     if on_rows is not None:
                         on_rows(sg.buf.seeds.clone(), sg.loss_rows.clone())
                     if self.step_hook is not None:

@@ -226,12 +226,25 @@ class SampleGraph:
 
     def run(self, seeds_host, ctr):
         """seeds_host: int64 array-like [B] (snapshot ids); ctr: this batch's Philox counter.  Returns (n1, n0)."""
+        self.launch(seeds_host, ctr)
+        return self.wait()
+
+    def launch(self, seeds_host, ctr, stream=None):
+        """Enqueue the sample graph (on ``stream``: the pipelined steps run it beside the previous batch's train graph)."""
         h = self.head_host
         h[0] = int(ctr)
         h[1:] = torch.as_tensor(np.asarray(seeds_host), dtype=torch.int64)     # (not touched again until the graph's last store is seen)
-        self.cuda_graph.replay()
-        t0 = time.perf_counter()
+        if stream is None:
+            self.cuda_graph.replay()
+        else:
+            with torch.cuda.stream(stream):
+                self.cuda_graph.replay()
+        self._stream = stream
         self.seq += 1
+
+    def wait(self):
+        """(n1, n0) of the launched batch, once the graph's last kernel has published them."""
+        t0 = time.perf_counter()
         c, want = self.counts_np, self.seq
         spins = 0
         # The step's one read-back: 16 bytes the graph's last kernel wrote into pinned host memory (system-scope fences
@@ -242,7 +255,7 @@ class SampleGraph:
         while c[2] != want:
             spins += 1
             if spins & 0x3FF == 0 and time.perf_counter() - t0 > self.SPIN_SECONDS:
-                torch.cuda.current_stream().synchronize()
+                (self._stream if getattr(self, "_stream", None) is not None else torch.cuda.current_stream()).synchronize()
                 self.sync_fallbacks += 1
                 if c[2] != want:
                     raise RuntimeError("sample graph: no block sizes from the device (sequence %d, saw %d) although its stream "
@@ -280,6 +293,52 @@ class StepGraphCache:
             self.captures += 1
         else:
             self.graphs.move_to_end(key)
+        return sg
+
+    def sampled_step_pipelined(self, graph, seeds_host, ctr, nxt=None):
+        """``sampled_step`` with the NEXT batch's sampling (``nxt = (seeds_host, ctr)`` or None) enqueued on a second stream before
+        this batch's train graph is waited for: sampling does not depend on the weights, so batch i + 1 is sampled (36 us of one
+        workgroup + the host's read-back and launch: ~55 us at the arxiv-like rung) while batch i trains.  Two sets of block arrays
+        and two sets of train graphs (a sample graph must not write what a train graph in flight still reads): set i % 2; the side
+        stream waits for the train graph that last read its set, the main stream for the sample graph that filled it.  Same blocks,
+        same counters, same results as ``sampled_step``."""
+        B = len(seeds_host)
+        bkey = ("sampled2", id(graph), B, sampling.get_state()["seed"])
+        pipe = self.samplers.get(bkey)
+        if pipe is None:
+            n1_cap = B * (1 + self.S)
+            bufs = [BlockBuffers(B, self.S, n1_cap, n1_cap * (1 + self.S), graph.device) for _ in range(2)]
+            self.bufs[bkey] = bufs
+            pipe = self.samplers[bkey] = dict(smp=[SampleGraph(graph, b) for b in bufs], side=torch.cuda.Stream(device=graph.device),
+                                              sampled=[None, None], trained=[None, None], cur=0, ahead=None)
+        cur = pipe["cur"]
+        smp = pipe["smp"][cur]
+        main = torch.cuda.current_stream()
+        if pipe["ahead"] is not None and pipe["ahead"][0] == cur and pipe["ahead"][1] == int(ctr):
+            n1, n0 = smp.wait()                              # launched while the previous batch trained
+            main.wait_event(pipe["sampled"][cur])
+        else:
+            if pipe["ahead"] is not None:                    # (a prefetch nobody came for: let it finish before its set is reused)
+                pipe["smp"][pipe["ahead"][0]].wait()
+                main.wait_event(pipe["sampled"][pipe["ahead"][0]])
+            n1, n0 = smp.run(seeds_host, ctr)
+        pipe["ahead"] = None
+        n0_pad = min(round_up(n0, N0_BUCKET_SMALL), smp.buf.n0_cap)
+        sg = self._train(graph, smp.buf, bkey + (n0_pad, cur), smp.buf.n1_cap, n0_pad)
+        sg.replay()
+        ev = pipe["trained"][cur] = torch.cuda.Event()
+        ev.record()
+        sg.last_sizes = (n0, n1)
+        other = 1 - cur
+        if nxt is not None and len(nxt[0]) == B:
+            side = pipe["side"]
+            if pipe["trained"][other] is not None:
+                side.wait_event(pipe["trained"][other])      # the train graph that read set `other` has finished
+            pipe["smp"][other].launch(nxt[0], nxt[1], stream=side)
+            es = pipe["sampled"][other] = torch.cuda.Event()
+            es.record(side)
+            pipe["ahead"] = (other, int(nxt[1]))
+        pipe["cur"] = other
         return sg
 
     def sampled_step(self, graph, seeds_host, ctr):
