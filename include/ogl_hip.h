@@ -603,7 +603,7 @@ int ogl_publish_i64(const int64_t* src, int n, int64_t* seq_dev, int64_t* dst_ho
  * (counts_host_mapped[0 .. 1], then ++*seq_dev behind a system-scope fence into [2]).  Results as ogl_sample_layer_dev +
  * ogl_build_block_padded on the same shapes: src1 [B (1 + fanout)] / src0 [B (1 + fanout)^2] padded with -1, lidx1 [B, fanout],
  * lidx0 [B (1 + fanout), fanout] (-1 rows for the padded destinations), counts[0] = n1, counts[1] = n0 = B (1 + fanout) + new sources.
- * One 1024-thread workgroup; B (1 + fanout)^2 <= 65 536.  Replaces the per-batch NodeDataLoader iteration of
+ * One 1024-thread workgroup; B (1 + fanout)^2 <= 131 072 (B = 32 at fanout 45: 67 712).  Replaces the per-batch NodeDataLoader iteration of
  * R/train/graphsage/pytorch/model.py:76-117 for the 32-seed rungs (R/settings/pubmed.json, arxiv.json). */
 int64_t ogl_sample_blocks_small_workspace_bytes(int B, int fanout);
 int ogl_sample_blocks_small(const ogl_graph_t* g, const int64_t* head_host_mapped, int64_t* head_dev, int B, int fanout, uint64_t seed,

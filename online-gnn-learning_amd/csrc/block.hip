@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256) k_block_lookup(const int32_t* __restrict_
 // (4-5 us each inside a replayed graph).  One 1024-thread block walks the same phases with __syncthreads() between them —
 // table reset, insert (atomicMin of the flat position), first-appearance flags + scan (carried across 1024-position chunks),
 // assign, lookup — and, optionally, fills src_ids past the source count with -1.  Same results as the multi-launch path.
-#define BLK_SMALL_MAX_P 65536
+#define BLK_SMALL_MAX_P 131072          // (B = 32, fanout 45 — R/settings/pubmed.json, bitcoin.json — is 67 712 positions)
 #define BLK_SMALL_ONE_WG_P 4096      // up to here the whole build runs in one workgroup (ogl_build_block_padded)
 __global__ void __launch_bounds__(BLK_SCAN) k_block_build_small(const int64_t* __restrict__ dst, const int64_t* __restrict__ picks,
                                                                 int64_t n_dst, int64_t P, int32_t* tkey, int32_t* tmin,
