@@ -318,8 +318,9 @@ __global__ void __launch_bounds__(256) k_pool_values(const float* __restrict__ d
   const int oj = lane <= S ? (int)off[d * (S + 1) + lane] : 0;
   const int n = __builtin_amdgcn_readlane(oj, S);                  // S <= 63: lane S holds the end offset
   // (this wave's LDS row is written and read by the same wave: no barrier, the compiler's lgkmcnt wait orders them)
-  // every trip's column entry is requested before the first one is used: with the load inside the loop a wave paid one memory latency
-  // per 64 entries, ten in a row for a 602-column row (the kernel is one wave's dependent chain long: all 7 038 waves are resident)
+  // HOIST: every trip's column entry is requested before the first one is used — with the load inside the loop a wave paid one memory
+  // latency per 64 entries, ten in a row for a 602-column row, and the kernel is one wave's dependent chain long (all 7 038 waves are
+  // resident at once): -7 us per replayed Reddit step, same box, three alternations (0.9821 -> 0.9754 ms); OGL_PB_VALUES_HOIST=0
   unsigned cpv[PB_MAX_D / 64];
   if constexpr (HOIST) {
 #pragma unroll
@@ -350,157 +351,13 @@ __global__ void __launch_bounds__(PB_THREADS) k_pool_groups(const uint2* __restr
   const unsigned r0 = gbase[b], r1 = gbase[b + 1];
   uint2 first = make_uint2(0u, 0u);
   if (r0 + tid < r1) first = gent[r0 + tid];                      // in flight while the slab is cleared
-  // (the later trips' records — a group holds ~2 150 = 3.4 trips of 640 threads — requested ahead as well: no change, 0.9371 against
-  // 0.9376 ms per step: the pass is paced by its image writes)
+  // (the later trips' records — a group holds ~2 150 = 3.4 trips of 640 threads — requested ahead as well: 0.9371 against 0.9376 ms
+  // per step, no change: this pass is paced by its image writes)
   for (int i = tid; i < 8 * DP; i += PB_THREADS) ((float4*)T)[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // 32 * DP floats
   __syncthreads();
   if (r0 + tid < r1)
     __hip_atomic_fetch_add(&T[(first.x >> 16) * DP + (int)(first.x & 0xFFFFu)], __uint_as_float(first.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   for (unsigned r = r0 + PB_THREADS + tid; r < r1; r += PB_THREADS) {
-    const uint2 en = gent[r];
-    __hip_atomic_fetch_add(&T[(en.x >> 16) * DP + (int)(en.x & 0xFFFFu)], __uint_as_float(en.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  __syncthreads();
-  pb_emit(T, D, DP, b, img, gstride, tid, PB_THREADS);
-}
-
-// ---- the planned form -------------------------------------------------------------------------------------------------
-#define PB_POS_BITS 27              // a record's place in the group-major array (n_dst * D < 2^27); the source's lane above it
-
-// gbase[g] = first record of group g (exclusive scan of the totals k_pool_bucket<true> accumulated), gbase[G] = all records;
-// the cursors the place pass advances start at zero.  One block.
-__global__ void __launch_bounds__(1024) k_pool_plan_scan(const unsigned* __restrict__ gcount, unsigned* __restrict__ gbase,
-                                                         unsigned* __restrict__ gcur, int G) {
-  __shared__ unsigned wsum[16];
-  __shared__ unsigned carry;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  for (int g0 = 0; g0 < G; g0 += 1024) {
-    const int g = g0 + tid;
-    const unsigned c = g < G ? gcount[g] : 0u;
-    unsigned s = c;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const unsigned v = __shfl_up(s, o);
-      if (lane >= o) s += v;
-    }
-    if (lane == 63) wsum[wv] = s;
-    __syncthreads();
-    unsigned before = carry;
-    for (int k = 0; k < wv; ++k) before += wsum[k];
-    if (g < G) { gbase[g] = before + s - c; gcur[g] = 0u; }
-    __syncthreads();
-    if (tid == 1023) carry = before + s;
-    __syncthreads();
-  }
-  if (tid == 0) gbase[G] = carry;
-}
-
-// every non-empty (destination, slot) segment takes `len` places of its group's range (atomic cursor; four segments per thread in
-// flight).  A FEW blocks on purpose (PB_PLACE_BLOCKS): this runs beside the forward products, whose blocks need whole CUs — a grid
-// of 689 short blocks kept cycling through every CU and the 185-tile product beside it took 52 us instead of 36 (round 3).
-#define PB_PLACE_BLOCKS 16
-__global__ void __launch_bounds__(1024) k_pool_plan_place(const int32_t* __restrict__ idx, int64_t n_dst, int S,
-                                                          const unsigned short* __restrict__ off, PbDiv dv, const unsigned* __restrict__ gbase,
-                                                          unsigned* __restrict__ gcur, unsigned* __restrict__ seginfo) {
-  const int tid = threadIdx.x;
-  const int64_t total = n_dst * S;
-  constexpr int U = 4;
-  for (int64_t i0 = (int64_t)blockIdx.x * 1024 * U; i0 < total; i0 += (int64_t)gridDim.x * 1024 * U) {
-    unsigned len[U], a[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t i = i0 + u * 1024 + tid;
-      len[u] = 0; a[u] = 0;
-      if (i < total) {
-        const int64_t d = i / S;
-        const int j = (int)(i - d * S);
-        len[u] = (unsigned)off[d * (S + 1) + j + 1] - (unsigned)off[d * (S + 1) + j];
-        a[u] = (unsigned)idx[i];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t i = i0 + u * 1024 + tid;
-      if (i >= total) continue;
-      unsigned info = 0xFFFFFFFFu;
-      if (len[u] > 0 && a[u] < 0x80000000u) {                      // a winner's slot: a[u] is a valid source id
-        const unsigned q = pb_div(a[u], dv), g = a[u] - q * dv.G;
-        // (g < G by construction; the guard keeps a re-read index that is no longer what the bucket pass saw — inputs recycled
-        // under a plan whose backward never ran — from writing outside the group arrays)
-        if (g < dv.G) info = (gbase[g] + atomicAdd(&gcur[g], len[u])) | (q << PB_POS_BITS);
-      }
-      seginfo[i] = info;
-    }
-  }
-}
-
-// backward, one wave per destination: the gradient row goes through LDS into the planned places
-template <bool HOIST>
-__global__ void __launch_bounds__(256) k_pool_values(const float* __restrict__ dout, int64_t ldo, int64_t n_dst, int S, int D,
-                                                     const unsigned short* __restrict__ off, const unsigned short* __restrict__ colperm,
-                                                     const unsigned* __restrict__ seginfo, uint2* __restrict__ gent) {
-  __shared__ float row[4][PB_MAX_D];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t d = (int64_t)blockIdx.x * 4 + wv;
-  if (d >= n_dst) return;
-#pragma unroll
-  for (int i = 0; i < PB_MAX_D / 64; ++i) {
-    const int f = lane + 64 * i;
-    if (f < D) row[wv][f] = dout[d * ldo + f];
-  }
-  const unsigned si = lane < S ? seginfo[d * S + lane] : 0u;
-  const int oj = lane <= S ? (int)off[d * (S + 1) + lane] : 0;
-  const int n = __builtin_amdgcn_readlane(oj, S);                  // S <= 63: lane S holds the end offset
-  // (this wave's LDS row is written and read by the same wave: no barrier, the compiler's lgkmcnt wait orders them)
-  // every trip's column entry is requested before the first one is used: with the load inside the loop a wave paid one memory latency
-  // per 64 entries, ten in a row for a 602-column row (the kernel is one wave's dependent chain long: all 7 038 waves are resident)
-  unsigned cpv[PB_MAX_D / 64];
-  if constexpr (HOIST) {
-#pragma unroll
-    for (int i = 0; i < PB_MAX_D / 64; ++i) {
-      const int e = 64 * i + lane;
-      cpv[i] = colperm[d * D + (e < n ? e : 0)];
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < PB_MAX_D / 64; ++i) {                        // whole waves: the shuffles below need every lane
-    const int e = 64 * i + lane;
-    if (64 * i >= n) break;                                        // (wave-uniform)
-    const bool live = e < n;
-    const unsigned cp = live ? (HOIST ? cpv[i] : (unsigned)colperm[d * D + e]) : 0u;
-    const int col = cp & 1023, j = cp >> 10;
-    const unsigned sij = __shfl(si, j);
-    const int o = __shfl(oj, j);
-    if (live) gent[(sij & ((1u << PB_POS_BITS) - 1u)) + (unsigned)(e - o)] = make_uint2((unsigned)col | ((sij >> PB_POS_BITS) << 16), __float_as_uint(row[wv][col]));
-  }
-}
-
-// backward, one block per source group: its records are one contiguous run
-__global__ void __launch_bounds__(PB_THREADS) k_pool_groups(const uint2* __restrict__ gent, const unsigned* __restrict__ gbase, int D, int DP,
-                                                            unsigned char* __restrict__ img, int64_t gstride) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char pb_smem[];
-  float* T = (float*)pb_smem;                                     // [32][DP] slab of dP for this source group
-  const int tid = threadIdx.x, b = blockIdx.x;
-  const unsigned r0 = gbase[b], r1 = gbase[b + 1];
-  // the first PB_PRE trips' records in flight while the slab is cleared (a group holds ~2 150 records = 3.4 trips of 640 threads: with
-  // one load per trip inside the loop a block paid a memory latency per trip)
-  const int PB_PRE_ON = pre_on;
-  constexpr int PB_PRE = 4;
-  uint2 pre[PB_PRE];
-#pragma unroll
-  for (int k = 0; k < PB_PRE; ++k) {
-    const unsigned r = r0 + k * PB_THREADS + tid;
-    if (k == 0 || PB_PRE_ON) pre[k] = gent[r < r1 ? r : r0];      // (clamped: an empty group reads a neighbour's first record, unused)
-  }
-  for (int i = tid; i < 8 * DP; i += PB_THREADS) ((float4*)T)[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // 32 * DP floats
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < PB_PRE; ++k)
-    if ((k == 0 || PB_PRE_ON) && r0 + k * PB_THREADS + tid < r1)
-      __hip_atomic_fetch_add(&T[(pre[k].x >> 16) * DP + (int)(pre[k].x & 0xFFFFu)], __uint_as_float(pre[k].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  for (unsigned r = r0 + (PB_PRE_ON ? PB_PRE : 1) * PB_THREADS + tid; r < r1; r += PB_THREADS) {
     const uint2 en = gent[r];
     __hip_atomic_fetch_add(&T[(en.x >> 16) * DP + (int)(en.x & 0xFFFFu)], __uint_as_float(en.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
