@@ -53,6 +53,8 @@ class GatheredRows:
 ADDROWS_MIN_WIDTH = 128
 # the cached layers' aggregator writes the image of the pooled rows only (OGL_IMAGE_ONLY_POOL=0: the fp32 rows too, which nobody reads)
 POOL_FP32_OUT = os.environ.get("OGL_IMAGE_ONLY_POOL", "1") == "0"
+# in-repo 'mean' layers behind the first: the destinations' own rows and the neighbour mean from ONE autograd node (ops._SelfNeighFn)
+SELF_NEIGH_NODE = os.environ.get("OGL_SELF_NEIGH_NODE", "1") != "0"
 _EYE = {}
 
 
@@ -192,7 +194,11 @@ class SAGEConv(nn.Module):
                 ops.attach_image(h_neigh, img)
             else:
                 src = feat.materialize() if lazy else feat
-                h_neigh = ops.neighbor_reduce(src, idx, "mean")
+                if SELF_NEIGH_NODE and not lazy and src.requires_grad and torch.is_grad_enabled():
+                    # (an input with a gradient, read twice: one autograd node hands back ONE gradient — ops._SelfNeighFn)
+                    feat_dst, h_neigh = ops.self_and_neighbors(src, idx, n_dst, "mean")
+                else:
+                    h_neigh = ops.neighbor_reduce(src, idx, "mean")
             rst = self._linear_cat(feat_dst, self._with_edges(graph, h_neigh, "mean"), fuse_relu)
         elif t == "lstm":
             # aggregator_dgl.py:116-126,195-199: h_n of nn.LSTM over each destination's mailbox (slot order), zero initial state;

@@ -2664,6 +2664,38 @@ def neighbor_reduce(src, idx, op):
     return _ReduceFn.apply(src, idx, op)
 
 
+class _SelfNeighFn(torch.autograd.Function):
+    """(src[:n_dst], reduce_j src[idx[:, j]]) as ONE autograd node: a layer input that is read twice — the destinations' own rows and
+    the neighbour reduction (the in-repo 'mean' layer, R/train/graphsage/pytorch/aggregator_dgl.py:156-159,199-206) — otherwise gets
+    its gradient from autograd as zeros([n_src, d]) + a copy of the head rows + an add of two [n_src, d] matrices: three ATen launches,
+    21 us of the Reddit-rung 'mean' step.  Here the head rows' gradient is added into the reduction's gradient in place."""
+
+    @staticmethod
+    def forward(ctx, src, idx, n_dst, op):
+        out = _ReduceFn.forward(ctx, src, idx, op)
+        ctx.n_dst = int(n_dst)
+        head = src[:ctx.n_dst].clone() if ctx.n_dst * src.shape[1] <= (1 << 22) else src[:ctx.n_dst].contiguous()
+        return head, out
+
+    @staticmethod
+    def backward(ctx, dhead, dout):
+        n_dst = ctx.n_dst
+        if dout is None:
+            dsrc = None
+        else:
+            dsrc = _ReduceFn.backward(ctx, dout)[0]
+        if dhead is not None:
+            if dsrc is None:
+                dsrc = torch.zeros((ctx.n_src, dhead.shape[1]), dtype=dhead.dtype, device=dhead.device)
+            dsrc[:n_dst].add_(dhead)
+        return dsrc, None, None, None
+
+
+def self_and_neighbors(src, idx, n_dst, op):
+    """(src[:n_dst], neighbor_reduce(src, idx, op)) from one autograd node (see ``_SelfNeighFn``)."""
+    return _SelfNeighFn.apply(src, idx, int(n_dst), op)
+
+
 class _CrossEntropyRowsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels):
