@@ -579,6 +579,14 @@ int ogl_adam_step_multi_slabs(int count, float* const* p, float* const* g, float
                               const float* const* ws, const int64_t* slab_stride, const int* ws_ld, const int* nsplit,
                               const int* ncols, const int* col0, int step, int64_t* step_dev, float* scalars_dev, int prepare,
                               double lr, double beta1, double beta2, double eps, ogl_stream_t stream);
+/* ... with TWO-RANGE tensors: tensor i with split[i] > 0 takes its columns [0, split) from slab column col0[i] and its columns
+ * [split, ncols) from slab column col0b[i] — the concat weight [N, K1 + K2] of the in-repo layer
+ * (R/train/graphsage/pytorch/aggregator_dgl.py:94,206) behind ogl_linear_bwd_weight_x3k_dual_slabs, whose slabs are laid out
+ * [dw1 | db | pad | dw2]: no reduction launch between the product and the optimiser.  split / col0b NULL: ogl_adam_step_multi_slabs. */
+int ogl_adam_step_multi_slabs2(int count, float* const* p, float* const* g, float* const* m, float* const* v, const int64_t* n,
+                               const float* const* ws, const int64_t* slab_stride, const int* ws_ld, const int* nsplit, const int* ncols,
+                               const int* col0, const int* split, const int* col0b, int step, int64_t* step_dev, float* scalars_dev,
+                               int prepare, double lr, double beta1, double beta2, double eps, ogl_stream_t stream);
 int ogl_x3_slab_reduce(const float* ws, int64_t slab_stride, int64_t ws_ld, int nsplit, int64_t rows, int ncols, int col0, float* out,
                        int64_t ldo, ogl_stream_t stream);
 /* K loader batches as ONE block (inference passes: every kernel of the forward is row-independent, so a pass runs them once per

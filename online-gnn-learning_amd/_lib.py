@@ -131,6 +131,7 @@ SIGNATURES = {
     "ogl_linear_bwd_weight_x3k_slabs": (_i, [_p, _i64, _p, _i64, _p, _i64, _i64, _i, _i, _i, _p, _i64, _p, _p, _p, _i64,
                                              C.POINTER(C.c_int), C.POINTER(C.c_int64), _p]),
     "ogl_adam_step_multi_slabs": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _d, _d, _d, _d, _p]),
+    "ogl_adam_step_multi_slabs2": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _d, _d, _d, _d, _p]),
     "ogl_linear_bwd_weight_x3k_dual_workspace_bytes": (_i64, [_i64, _i, _i, _i, _i]),
     "ogl_linear_bwd_weight_x3k_dual_slabs": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, _i, _i, _p, _i64, _i, _p, _i64, C.POINTER(C.c_int),
                                                 C.POINTER(C.c_int64), C.POINTER(C.c_int), _p]),

@@ -300,6 +300,9 @@ struct AdamSlabs {
   const float* ws[OGL_ADAM_MAX_TENSORS];
   int64_t slab_stride[OGL_ADAM_MAX_TENSORS];
   int32_t ws_ld[OGL_ADAM_MAX_TENSORS], nsplit[OGL_ADAM_MAX_TENSORS], ncols[OGL_ADAM_MAX_TENSORS], col0[OGL_ADAM_MAX_TENSORS];
+  // a TWO-RANGE tensor (the in-repo layer's concat weight [N, K1 + K2] behind ogl_linear_bwd_weight_x3k_dual_slabs): its columns
+  // [0, split) sit at slab column col0, its columns [split, ncols) at slab column col0b; split == 0: one range
+  int32_t split[OGL_ADAM_MAX_TENSORS], col0b[OGL_ADAM_MAX_TENSORS];
 };
 
 // one tensor, grid-strided over blockIdx.x: four elements per thread and trip (16-byte accesses) when the four arrays allow it
@@ -341,8 +344,10 @@ __device__ __forceinline__ float slab_sum1(const float* __restrict__ src, int64_
 __device__ __forceinline__ void adam_range_slabs(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                  float* __restrict__ v, int64_t n, const float* __restrict__ ws, int64_t slab_stride,
                                                  int ws_ld, int nsplit, int ncols, int col0, float one_minus_b1, float b2,
-                                                 float one_minus_b2, float inv_sqrt_bc2, float step_size, float eps) {
+                                                 float one_minus_b2, float inv_sqrt_bc2, float step_size, float eps, int split = 0,
+                                                 int col0b = 0) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+  auto scol = [&](int col) __attribute__((always_inline)) { return (split == 0 || col < split) ? col0 + col : col0b + (col - split); };
   int64_t done = 0;
   if (ncols >= 4 && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) {
     const int64_t n4 = n >> 2;
@@ -355,8 +360,8 @@ __device__ __forceinline__ void adam_range_slabs(float* __restrict__ p, float* _
       // load it does not overlap is latency it pays in full — the launch sits at the end of the step, nothing runs beside it.
       // The sum keeps the slab order: the reduction launch's bits.)
       const float4 p4 = ((const float4*)p)[i], m4 = ((const float4*)m)[i], v4 = ((const float4*)v)[i];
-      if (col + 4 <= ncols) {
-        const float* src = ws + row * ws_ld + col0 + col;
+      if (col + 4 <= ncols && (split == 0 || col + 4 <= split || col >= split)) {
+        const float* src = ws + row * ws_ld + scol(col);
         a[0] = a[1] = a[2] = a[3] = 0.f;
         int s = 0;
         for (; s + 4 <= nsplit; s += 4) {
@@ -375,7 +380,7 @@ __device__ __forceinline__ void adam_range_slabs(float* __restrict__ p, float* _
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int64_t r = (e0 + e) / ncols;
-          q[e] = ws + r * ws_ld + col0 + (int)(e0 + e - r * ncols);
+          q[e] = ws + r * ws_ld + scol((int)(e0 + e - r * ncols));
           a[e] = 0.f;
         }
         int s = 0;
@@ -406,7 +411,7 @@ __device__ __forceinline__ void adam_range_slabs(float* __restrict__ p, float* _
   }
   for (int64_t i = done + tid; i < n; i += nth) {
     const int64_t row = i / ncols;
-    const float a = slab_sum1(ws + row * ws_ld + col0 + (int)(i - row * ncols), slab_stride, nsplit);
+    const float a = slab_sum1(ws + row * ws_ld + scol((int)(i - row * ncols)), slab_stride, nsplit);
     float pi = p[i], mi = m[i], vi = v[i];
     adam_one(pi, a, mi, vi, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
     g[i] = a; m[i] = mi; v[i] = vi; p[i] = pi;
@@ -421,7 +426,7 @@ __global__ void __launch_bounds__(256) k_adam_multi_slabs(AdamBatch b, AdamSlabs
   const int t = blockIdx.y;
   if (sl.ws[t])
     adam_range_slabs(b.p[t], (float*)b.g[t], b.m[t], b.v[t], b.n[t], sl.ws[t], sl.slab_stride[t], sl.ws_ld[t], sl.nsplit[t],
-                     sl.ncols[t], sl.col0[t], one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
+                     sl.ncols[t], sl.col0[t], one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps, sl.split[t], sl.col0b[t]);
   else
     adam_range(b.p[t], b.g[t], b.m[t], b.v[t], b.n[t], one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
 }
@@ -519,10 +524,10 @@ extern "C" int ogl_adam_step_multi_dev(int count, float* const* p, const float* 
 //                     scalars first, prepare == 0 applies with the scalars as they are — a step's SECOND launch (the optimiser
 //                     applied in two parts: everything whose gradient is ready early on a side branch, the rest at the end).
 // ws / slab_stride / ws_ld / nsplit / ncols / col0: host arrays of `count` entries (ws[i] null: tensor i has a plain gradient).
-extern "C" int ogl_adam_step_multi_slabs(int count, float* const* p, float* const* g, float* const* m, float* const* v, const int64_t* n,
-                                         const float* const* ws, const int64_t* slab_stride, const int* ws_ld, const int* nsplit,
-                                         const int* ncols, const int* col0, int step, int64_t* step_dev, float* scalars_dev,
-                                         int prepare, double lr, double beta1, double beta2, double eps, ogl_stream_t stream) {
+static int adam_step_multi_slabs(int count, float* const* p, float* const* g, float* const* m, float* const* v, const int64_t* n,
+                                 const float* const* ws, const int64_t* slab_stride, const int* ws_ld, const int* nsplit,
+                                 const int* ncols, const int* col0, const int* split, const int* col0b, int step, int64_t* step_dev,
+                                 float* scalars_dev, int prepare, double lr, double beta1, double beta2, double eps, ogl_stream_t stream) {
   if (count < 0 || (!step_dev && step < 1) || (step_dev && !scalars_dev)) return OGL_EINVAL;
   if (count > 0 && (!p || !g || !m || !v || !n || !ws || !slab_stride || !ws_ld || !nsplit || !ncols || !col0)) return OGL_EINVAL;
   float step_size = 0.f, inv_sqrt_bc2 = 0.f;
@@ -546,9 +551,13 @@ extern "C" int ogl_adam_step_multi_slabs(int count, float* const* p, float* cons
       b.p[i] = p[j]; b.g[i] = g[j]; b.m[i] = m[j]; b.v[i] = v[j]; b.n[i] = n[j];
       sl.ws[i] = ws[j]; sl.slab_stride[i] = slab_stride[j]; sl.ws_ld[i] = ws_ld[j]; sl.nsplit[i] = nsplit[j]; sl.ncols[i] = ncols[j];
       sl.col0[i] = col0[j];
+      sl.split[i] = split ? split[j] : 0; sl.col0b[i] = col0b ? col0b[j] : 0;
       if (ws[j]) {
-        if (nsplit[j] < 1 || ncols[j] < 1 || col0[j] < 0 || ws_ld[j] < col0[j] + ncols[j] || n[j] % ncols[j] != 0 ||
-            slab_stride[j] < (n[j] / ncols[j]) * (int64_t)ws_ld[j])
+        const int sp = sl.split[i];
+        if (nsplit[j] < 1 || ncols[j] < 1 || col0[j] < 0 || n[j] % ncols[j] != 0 || slab_stride[j] < (n[j] / ncols[j]) * (int64_t)ws_ld[j])
+          return OGL_EINVAL;
+        if (sp == 0 ? ws_ld[j] < col0[j] + ncols[j]
+                    : (sp < 0 || sp >= ncols[j] || sl.col0b[i] < col0[j] + sp || ws_ld[j] < sl.col0b[i] + (ncols[j] - sp)))
           return OGL_EINVAL;
       }
       nmax = n[j] > nmax ? n[j] : nmax;
@@ -561,6 +570,26 @@ extern "C" int ogl_adam_step_multi_slabs(int count, float* const* p, float* cons
     OGL_CHECK_LAUNCH();
   }
   return OGL_OK;
+}
+
+extern "C" int ogl_adam_step_multi_slabs(int count, float* const* p, float* const* g, float* const* m, float* const* v, const int64_t* n,
+                                         const float* const* ws, const int64_t* slab_stride, const int* ws_ld, const int* nsplit,
+                                         const int* ncols, const int* col0, int step, int64_t* step_dev, float* scalars_dev,
+                                         int prepare, double lr, double beta1, double beta2, double eps, ogl_stream_t stream) {
+  return adam_step_multi_slabs(count, p, g, m, v, n, ws, slab_stride, ws_ld, nsplit, ncols, col0, nullptr, nullptr, step, step_dev,
+                               scalars_dev, prepare, lr, beta1, beta2, eps, stream);
+}
+
+// ... with TWO-RANGE tensors: tensor i with split[i] > 0 has its columns [0, split) at slab column col0[i] and its columns
+// [split, ncols) at slab column col0b[i] — the concat weight [N, K1 + K2] of the in-repo layer behind
+// ogl_linear_bwd_weight_x3k_dual_slabs (slab layout [dw1 | db | pad | dw2]): no reduction launch between the product and the optimiser
+extern "C" int ogl_adam_step_multi_slabs2(int count, float* const* p, float* const* g, float* const* m, float* const* v, const int64_t* n,
+                                          const float* const* ws, const int64_t* slab_stride, const int* ws_ld, const int* nsplit,
+                                          const int* ncols, const int* col0, const int* split, const int* col0b, int step,
+                                          int64_t* step_dev, float* scalars_dev, int prepare, double lr, double beta1, double beta2,
+                                          double eps, ogl_stream_t stream) {
+  return adam_step_multi_slabs(count, p, g, m, v, n, ws, slab_stride, ws_ld, nsplit, ncols, col0, split, col0b, step, step_dev,
+                               scalars_dev, prepare, lr, beta1, beta2, eps, stream);
 }
 
 // Evaluation on the device: argmax of every logits row (first maximum, like numpy) and

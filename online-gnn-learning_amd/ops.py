@@ -1399,10 +1399,13 @@ _SLABS = {"on": False, "pending": {}}
 class SlabGrad:
     """``out``: the (still unwritten) gradient tensor the product handed to autograd — where the plain reduction goes when the slabs
     cannot be left to the optimiser after all (a second product for the same parameter in one backward pass)."""
-    __slots__ = ("ws", "stride", "ws_ld", "nsplit", "rows", "ncols", "col0", "out")
+    __slots__ = ("ws", "stride", "ws_ld", "nsplit", "rows", "ncols", "col0", "out", "split", "col0b")
 
-    def __init__(self, ws, stride, ws_ld, nsplit, rows, ncols, col0, out=None):
+    def __init__(self, ws, stride, ws_ld, nsplit, rows, ncols, col0, out=None, split=0, col0b=0):
         self.ws, self.stride, self.ws_ld, self.nsplit, self.rows, self.ncols, self.col0 = ws, stride, ws_ld, nsplit, rows, ncols, col0
+        # a TWO-RANGE gradient (a concat weight [rows, split + K2] behind the dual weight-gradient product): columns [0, split) at slab
+        # column col0, columns [split, ncols) at slab column col0b; split == 0: one range
+        self.split, self.col0b = int(split), int(col0b)
         # a WEAK reference: AccumulateGrad adopts a gradient tensor only while nobody else holds it — a strong reference here made
         # autograd CLONE every deferred gradient (eight device-to-device copies per Reddit step, +27 us: found by a same-box A/B against
         # the round-4 tree and the copy launches in the traced step)
@@ -1436,6 +1439,12 @@ def _slabs_settle(params):
 def slab_reduce(sg, out):
     """out[rows, ncols] <- the plain reduction of the slabs (slab order).  ``out``: contiguous, or a 2-D view whose rows are contiguous
     (a column block of a wider matrix: its row stride is passed on)."""
+    if sg.split:
+        # (two ranges: each into its column block of ``out``)
+        assert out.dim() == 2 and tuple(out.shape) == (sg.rows, sg.ncols)
+        slab_reduce(SlabGrad(sg.ws, sg.stride, sg.ws_ld, sg.nsplit, sg.rows, sg.split, sg.col0), out[:, :sg.split])
+        slab_reduce(SlabGrad(sg.ws, sg.stride, sg.ws_ld, sg.nsplit, sg.rows, sg.ncols - sg.split, sg.col0b), out[:, sg.split:])
+        return
     if out.dim() == 2 and not out.is_contiguous():
         assert tuple(out.shape) == (sg.rows, sg.ncols) and out.stride(1) == 1 and out.stride(0) >= sg.ncols
         ld = out.stride(0)
@@ -1449,9 +1458,13 @@ def slab_reduce(sg, out):
 # Both weight gradients of a dual-input projection as ONE k-major product over a two-part B operand (ogl_linear_bwd_weight_x3k_dual_slabs).
 # OGL_DUAL_DW=0: two products.
 DUAL_DW = os.environ.get("OGL_DUAL_DW", "1") != "0"
-# ... and for the in-repo layer's ONE concat weight (its two column blocks summed out of the slabs by three small launches): measured
-# on MI355X `mean` 0.4322 -> 0.4322 ms, `meanpool` 1.220 -> 1.237 ms — off.
-DUAL_DW_CAT = os.environ.get("OGL_DUAL_DW_CAT", "0") == "1"
+# ... and for the in-repo layer's ONE concat weight: its gradient stays in the slabs as a TWO-RANGE tensor the optimiser sums
+# (SlabGrad.split; ogl_adam_step_multi_slabs2).  "auto" (default): when the layer has NO input gradient to compute — the first layer of
+# 'mean', whose weight gradients are all that is left of its backward: 0.4208 -> 0.3867 ms per step, same box (relu_bwd_img + one
+# k-major product where relu_bwd + a transposed image + two products + two reduction launches ran); with an input gradient on the
+# critical path beside it ('meanpool') the one big product is in the way: 1.2057 -> 1.2172 ms.  OGL_DUAL_DW_CAT=1 / 0: always / never.
+DUAL_DW_CAT_MODE = os.environ.get("OGL_DUAL_DW_CAT", "auto")
+DUAL_DW_CAT = DUAL_DW_CAT_MODE != "0"
 
 
 def linear_bwd_weight_x3k_dual(dy_img, x_img, x_rows, x_nrows, M, K1, x2_img, K2):
@@ -1873,8 +1886,9 @@ def adam_step_multi_slabs(ps, gs, ms, vs, slabs, step=0, step_dev=None, scalars_
     i32 = lambda f: (C.c_int * k)(*[(getattr(sg, f) if sg is not None else 0) for sg in slabs])
     if _SIDE["active"]:
         _SIDE["keep"].extend(sg.ws for sg in slabs if sg is not None)       # (read on the side stream: held until the join)
-    _launch("ogl_adam_step_multi_slabs", _lib.lib().ogl_adam_step_multi_slabs, k, arr(ps), arr(gs), arr(ms), arr(vs), n, ws, stride,
-            i32("ws_ld"), i32("nsplit"), i32("ncols"), i32("col0"), int(step), _ptr(step_dev), _ptr(scalars_dev), 1 if prepare else 0,
+    _launch("ogl_adam_step_multi_slabs", _lib.lib().ogl_adam_step_multi_slabs2, k, arr(ps), arr(gs), arr(ms), arr(vs), n, ws, stride,
+            i32("ws_ld"), i32("nsplit"), i32("ncols"), i32("col0"), i32("split"), i32("col0b"), int(step), _ptr(step_dev), _ptr(scalars_dev),
+            1 if prepare else 0,
             C.c_double(lr), C.c_double(beta1), C.c_double(beta2), C.c_double(eps), _stream(),
             meta=dict(n=sum(p.numel() for p in ps), slab_tensors=sum(sg is not None for sg in slabs)))
 
@@ -2058,6 +2072,7 @@ class _LinearFn(torch.autograd.Function):
                 # ONE gradient tensor for the concat weight: each block's product writes its columns (strided rows)
                 dw_cat = torch.empty_like(w_full, memory_format=torch.contiguous_format)
                 ctx.dw_views = (dw_cat[:, :ctx.split], dw_cat[:, ctx.split:])
+                ctx.w_full_t, ctx.dw_cat_t = w_full, dw_cat
         dy_img = None
         if y is not None and getattr(dy, "_ogl_premasked", None) == (y.data_ptr(), y._version):
             # the product that computed dy already applied [y > 0] in its epilogue and wrote the image (linear_bwd_input)
@@ -2066,7 +2081,12 @@ class _LinearFn(torch.autograd.Function):
         if y is not None:
             # once; the (up to four) backward GEMMs below are mask-free.  Tall products with an input gradient to compute get
             # the image of the masked gradient from the same pass
-            if (need[0] or (x2 is not None and need[3])) and _n1_images_ok(dy.shape[0], dy.shape[1], w.shape[1]):
+            # (... or when both weight gradients can run as ONE k-major product over dy's row-major image: the dual product)
+            cat_ok = DUAL_DW_CAT_MODE == "1" or (DUAL_DW_CAT_MODE == "auto" and not need[0] and not (x2 is not None and need[3]))
+            ctx.dual_cat_ok = cat_ok
+            dual_img = (DUAL_DW and x2 is not None and ctx.x2_img is not None and x2_rows is None and need[1] and dy.shape[0] >= X3_BWW_MIN_ROWS
+                        and (ctx.split is None or cat_ok))
+            if (need[0] or (x2 is not None and need[3]) or dual_img) and _n1_images_ok(dy.shape[0], dy.shape[1], w.shape[1]):
                 dy, dy_img = relu_bwd_img(dy, y)
             else:
                 dy = relu_bwd(dy, y)
@@ -2091,6 +2111,7 @@ class _LinearFn(torch.autograd.Function):
         # holds it — the two column views do, through their base — and otherwise CLONES it, on the main stream, while a forked
         # backward is still writing it on the side stream)
         ctx.dw_views = None
+        ctx.w_full_t = ctx.dw_cat_t = None
         if ctx.split is not None:
             return dx, dw_cat, (db if ctx.has_bias else None), dx2, None, None, None, None, None, None
         return dx, dw, (db if ctx.has_bias else None), dx2, dw2, None, None, None, (db2 if ctx.has_bias2 else None), None
@@ -2100,6 +2121,7 @@ class _LinearFn(torch.autograd.Function):
         dw = db = dw2 = db2 = None
         dyT = None
         views = getattr(ctx, "dw_views", None)
+        _dw_out_mod = globals()["_dw_out"]
 
         def _dw_out(t, *_shape):          # (shadows the module's: a concat weight's two blocks write into ONE gradient tensor)
             if views is not None:
@@ -2118,9 +2140,26 @@ class _LinearFn(torch.autograd.Function):
             # ONE product for both weight gradients (round 5): dy^T . [x[rows] | 1 | x2] over a two-part B operand — the table's image
             # rows and the image the aggregator wrote, read where they lie
             K1, K2, N_ = x.shape[1], x2.shape[1], dy.shape[1]
-            if views is not None:
-                # the in-repo layer's ONE concat weight [N, K1 + K2]: the two column blocks of its gradient are summed out of the slabs
-                res = None if not DUAL_DW_CAT else linear_bwd_weight_x3k_dual(dyr, rimg, x_rows, x.shape[0] if x_rows is not None else None, dy.shape[0], K1, x2_img, K2)
+            wf = getattr(ctx, "w_full_t", None)
+            if (views is not None and getattr(ctx, "dual_cat_ok", False) and _SLABS["on"] and wf is not None and wf.is_leaf and wf.is_contiguous()
+                    and _dw_out_mod(wf, *wf.shape) is None and (not ctx.has_bias or (ctx.bias_t is not None and ctx.bias_t.is_leaf))
+                    and not _slabs_settle((wf, ctx.bias_t))):
+                # the in-repo layer's ONE concat weight [N, K1 + K2]: its gradient stays in the slabs as a TWO-RANGE tensor the optimiser
+                # sums (columns [0, K1) at slab column 0, [K1, K1 + K2) at col2): no reduction launch at all
+                res = linear_bwd_weight_x3k_dual(dyr, rimg, x_rows, x.shape[0] if x_rows is not None else None, dy.shape[0], K1, x2_img, K2)
+                if res is not None:
+                    ws_, stride, wl, ns, c2, _ = res
+                    pend = _SLABS["pending"]
+                    dcat = ctx.dw_cat_t
+                    pend[wf.data_ptr()] = SlabGrad(ws_, stride, wl, ns, N_, K1 + K2, 0, dcat, split=K1, col0b=c2)
+                    db = None
+                    if ctx.has_bias:
+                        db = torch.empty(N_, dtype=torch.float32, device=dy.device)
+                        pend[ctx.bias_t.data_ptr()] = SlabGrad(ws_, stride, wl, ns, N_, 1, K1, db)
+                    return views[0], db, views[1], None
+            elif views is not None:
+                # (outside a slab-consuming optimiser step: the two column blocks summed out of the slabs by reduction launches)
+                res = None if DUAL_DW_CAT_MODE != "1" else linear_bwd_weight_x3k_dual(dyr, rimg, x_rows, x.shape[0] if x_rows is not None else None, dy.shape[0], K1, x2_img, K2)
                 if res is not None:
                     ws_, stride, wl, ns, c2, _ = res
                     slab_reduce(SlabGrad(ws_, stride, wl, ns, N_, K1, 0), views[0])

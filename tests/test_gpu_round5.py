@@ -379,8 +379,9 @@ def test_dual_weight_gradient_product(ops, M, N, K1, K2, T):
 @pytest.mark.gpu
 @pytest.mark.parametrize("cat_weight", [False, True])
 def test_dual_projection_backward_takes_the_one_launch_product(ops, cat_weight):
-    """ops.linear(x, w, b, x2, w2, bias2=b2) — and its concat-weight form (split=) — backward with OGL_DUAL_DW on and off: the same
-    gradients (deferred slabs settled through the optimiser's reduction) and the launch log shows ONE weight-gradient product."""
+    """ops.linear(x, w, b, x2, w2, bias2=b2) — and its concat-weight form (split=: the gradient of the ONE weight [N, K1 + K2] left in the
+    slabs as a two-range tensor) — backward with OGL_DUAL_DW on and off: the same gradients (deferred slabs settled through the
+    optimiser's reduction) and the launch log shows ONE weight-gradient product."""
     torch.manual_seed(5)
     dev = "cuda:0"
     T, M, K1, K2, N = 40000, 7060, 602, 128, 128
@@ -390,9 +391,9 @@ def test_dual_projection_backward_takes_the_one_launch_product(ops, cat_weight):
     x2 = torch.randn(M, K2, device=dev)
     g = torch.randn(M, N, device=dev)
     outs, calls = {}, []
-    old, old_cat, old_mode, real = ops.DUAL_DW, ops.DUAL_DW_CAT, ops.get_gemm_mode(), ops.linear_bwd_weight_x3k_dual
+    old, old_cat, old_mode, real = ops.DUAL_DW, ops.DUAL_DW_CAT_MODE, ops.get_gemm_mode(), ops.linear_bwd_weight_x3k_dual
     ops.set_gemm_mode("auto")
-    ops.DUAL_DW_CAT = True          # (the concat-weight form is off by default: slower at the Reddit shape)
+    ops.DUAL_DW_CAT_MODE = "1"      # (the concat-weight form is automatic only for layers without an input gradient: forced here)
 
     def spy(*a, **k):
         calls.append(ops.DUAL_DW)
@@ -427,7 +428,7 @@ def test_dual_projection_backward_takes_the_one_launch_product(ops, cat_weight):
             torch.cuda.synchronize()
             outs[on] = ([p.grad.clone() for p in params], len(pend))
     finally:
-        ops.DUAL_DW, ops.DUAL_DW_CAT = old, old_cat
+        ops.DUAL_DW, ops.DUAL_DW_CAT_MODE = old, old_cat
         ops.linear_bwd_weight_x3k_dual = real
         ops.set_gemm_mode(old_mode)
     assert calls == [True], "the one-launch product was not taken (or taken with the switch off)"
@@ -585,3 +586,39 @@ def test_segmented_plan_with_one_huge_hub(ops):
     e1.record()
     torch.cuda.synchronize()
     assert e0.elapsed_time(e1) / 5 < 5.0, "the plan of a block with a 60 000-entry hub took %.2f ms" % (e0.elapsed_time(e1) / 5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K1,K2,nsplit", [(600, 602, 602, 5), (41, 7, 9, 3), (128, 128, 64, 20), (5, 1, 1, 1)])
+def test_adam_over_a_two_range_slab_tensor(ops, N, K1, K2, nsplit):
+    """ogl_adam_step_multi_slabs2: a concat weight [N, K1 + K2] whose gradient lies in split-K slabs as two column ranges
+    ([dw1 | db | pad | dw2], as ogl_linear_bwd_weight_x3k_dual_slabs leaves them) against the plain Adam on the summed gradient:
+    the same parameter, moments and gradient bits (slab order is the reduction launch's)."""
+    torch.manual_seed(N + K1)
+    dev = "cuda:0"
+    c2 = -(-(K1 + 1) // 128) * 128
+    wl = (c2 + K2 + 3) // 4 * 4
+    ws = torch.randn(nsplit, N, wl, device=dev)
+    p0 = torch.randn(N, K1 + K2, device=dev); m0 = torch.rand(N, K1 + K2, device=dev) * 0.1; v0 = torch.rand(N, K1 + K2, device=dev) * 0.01
+    b0 = torch.randn(N, device=dev); mb0 = torch.zeros(N, device=dev); vb0 = torch.zeros(N, device=dev)
+    g = torch.empty(N, K1 + K2, device=dev)
+    gsum = torch.zeros(N, wl, device=dev)
+    for s_ in range(nsplit):                      # slab order, as the kernels sum
+        gsum += ws[s_]
+    g[:, :K1] = gsum[:, :K1]; g[:, K1:] = gsum[:, c2:c2 + K2]
+    gb = gsum[:, K1].clone()
+    pa, ma, va, ba, mba, vba = (t.clone() for t in (p0, m0, v0, b0, mb0, vb0))
+    ops.adam_step_multi([pa, ba], [g, gb], [ma, mba], [va, vba], 3)
+    pb, mb, vb, bb, mbb, vbb = (t.clone() for t in (p0, m0, v0, b0, mb0, vb0))
+    gout, gbout = torch.empty_like(g), torch.empty_like(gb)
+    sg = ops.SlabGrad(ws, N * wl, wl, nsplit, N, K1 + K2, 0, None, split=K1, col0b=c2)
+    sgb = ops.SlabGrad(ws, N * wl, wl, nsplit, N, 1, K1, None)
+    ops.adam_step_multi_slabs([pb, bb], [gout, gbout], [mb, mbb], [vb, vbb], [sg, sgb], step=3)
+    torch.cuda.synchronize()
+    assert torch.equal(gout, g) and torch.equal(gbout, gb)
+    for a, b in ((pa, pb), (ma, mb), (va, vb), (ba, bb), (mba, mbb), (vba, vbb)):
+        assert torch.equal(a, b)
+    # the plain reduction of a two-range tensor (what deferred_splitk's exit and a second product fall back to)
+    out = torch.zeros(N, K1 + K2, device=dev)
+    ops.slab_reduce(sg, out)
+    assert torch.equal(out, g)
