@@ -674,6 +674,21 @@ int ogl_out_layer_fwd_ce_bwd(const float* P, int64_t ldp, int64_t n_src, const i
                              const int64_t* label_table, int64_t n_labels, const int64_t* label_ids, float grad_scale, float* loss_rows,
                              float* dlogits, int64_t lddl, float* loss_mean, unsigned int* counter, int rows_per_block, float* dx_self,
                              int64_t ldx, float* dP, int64_t ldpp, ogl_stream_t stream);
+/* The in-repo 'mean' layer as the LAST layer of a train step (round 5): ogl_out_layer_fwd_ce with the neighbour MEAN over the sampled rows
+ * of P = the layer's own input (slot order, divided by fanout: ogl_reduce_fwd(OGL_REDUCE_MEAN)'s arithmetic) and w_self / w_neigh = the two
+ * column blocks of fc_neigh's concat weight (ldws = ldwn = its width; b_neigh NULL) — mailbox.mean + torch.cat + nn.Linear +
+ * nn.CrossEntropyLoss, R/train/graphsage/pytorch/aggregator_dgl.py:156-159,199-206, pytorch/model.py:105 — and
+ * ogl_out_layer_bwd_inputs_dense: dx_self = dy . w_self and dneigh = dy . w_neigh both stored ([n_dst, K]; the mean's own backward,
+ * ogl_reduce_bwd_seg_apply, follows), optionally finishing the deferred loss mean (loss_rows / loss_mean NULL together). */
+int ogl_out_layer_fwd_ce_mean(const float* P, int64_t ldp, int64_t n_src, const int32_t* idx, int64_t n_dst, int fanout, const float* h,
+                              int64_t ldh, int K, const float* w_self, int64_t ldws, const float* w_neigh, int64_t ldwn,
+                              const float* b_self, const float* b_neigh, int N, float* neigh, int64_t ldn, float* logits, int64_t ldl,
+                              const int64_t* label_table, int64_t n_labels, const int64_t* label_ids, float grad_scale, float* loss_rows,
+                              float* dlogits, int64_t lddl, float* loss_mean, unsigned int* counter, int rows_per_block,
+                              ogl_stream_t stream);
+int ogl_out_layer_bwd_inputs_dense(const float* dy, int64_t lddy, int64_t n_dst, int N, int K, const float* w_self, int64_t ldws,
+                                   const float* w_neigh, int64_t ldwn, float* dx_self, int64_t ldx, float* dneigh, int64_t lddn,
+                                   const float* loss_rows, int64_t n_loss, float* loss_mean, ogl_stream_t stream);
 /* *loss_mean = sum(loss_rows[0 .. n)) / n in ogl_out_layer_bwd_inputs_mean's order: the deferred mean when no such launch follows. */
 int ogl_loss_mean_finish(const float* loss_rows, int64_t n, float* loss_mean, ogl_stream_t stream);
 

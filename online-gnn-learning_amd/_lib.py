@@ -86,6 +86,9 @@ SIGNATURES = {
     "ogl_out_layer_fwd_ce_bwd": (_i, [_p, _i64, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p, _i64, _p, _p, _i, _p, _i64, _p, _p, _i64,
                                       _p, _i64, _p, _f, _p, _p, _i64, _p, _p, _i, _p, _i64, _p, _i64, _p]),
     "ogl_loss_mean_finish": (_i, [_p, _i64, _p, _p]),
+    "ogl_out_layer_fwd_ce_mean": (_i, [_p, _i64, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p, _i64, _p, _p, _i, _p, _i64, _p, _i64,
+                                       _p, _i64, _p, _f, _p, _p, _i64, _p, _p, _i, _p]),
+    "ogl_out_layer_bwd_inputs_dense": (_i, [_p, _i64, _i64, _i, _i, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p]),
     "ogl_linear_fwd_x3": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i, _i, _p, _i64, _p]),
     "ogl_reduce_fwd_img_plan": (_i, [_p, _i64, _i64, _p, _i64, _i, _i, _p, _i64, _p, _p, _p, _p, _p]),
     "ogl_pool_bwd_x3_plan_slots": (_i, [_i64, _i, _i, _i64, _p, _p]),

@@ -57,8 +57,8 @@ __global__ void __launch_bounds__(64) k_out_bwd_inputs(const float* __restrict__
     // what the epilogue needs, requested now: winners and ReLU masks of this lane's 4 columns
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      am[r][e] = argmax[dr * (int64_t)K + ce[e]];
-      nb[r][e] = neigh[dr * ldn + ce[e]];
+      am[r][e] = argmax ? argmax[dr * (int64_t)K + ce[e]] : 0;
+      nb[r][e] = argmax ? neigh[dr * ldn + ce[e]] : 1.f;
     }
   }
   float as[OB_ROWS][4], an[OB_ROWS][4];
@@ -99,6 +99,15 @@ __global__ void __launch_bounds__(64) k_out_bwd_inputs(const float* __restrict__
     else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (c + e < K) xo[e] = as[r][e];
+    }
+    if (!argmax) {                                                 // DENSE form: dneigh[d, :] stored (a mean / sum aggregator's backward follows)
+      float* no = dP + d * ldp + c;
+      if (VEC && (ldp & 3) == 0) *(float4*)no = make_float4(an[r][0], an[r][1], an[r][2], an[r][3]);
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (c + e < K) no[e] = an[r][e];
+      }
+      continue;
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -290,7 +299,10 @@ __device__ __forceinline__ float of_wave_max(float v) {
   return v;
 }
 
-template <int R, bool BWD = false>
+// MEAN: the neighbour reduction is the MEAN over the S sampled rows of P (the in-repo 'mean' layer's aggregator over its own input,
+// R/train/graphsage/pytorch/aggregator_dgl.py:156-159: P = h, w_self / w_neigh = the two column blocks of fc_neigh's concat weight),
+// summed in slot order and divided by S as ogl_reduce_fwd(OGL_REDUCE_MEAN) does; no argmax.
+template <int R, bool BWD = false, bool MEAN = false>
 __global__ void __launch_bounds__(OF_THREADS) k_out_fwd_ce(OutFwdArgs a) {
   __shared__ float4 hrow[R][OF_MAX_K / 4], nrow[R][OF_MAX_K / 4];
   __shared__ int sidx[R][OF_MAX_S];
@@ -338,7 +350,9 @@ __global__ void __launch_bounds__(OF_THREADS) k_out_fwd_ce(OutFwdArgs a) {
 #pragma unroll
       for (int u = 0; u < OF_U; ++u) {
         if (!ok[u]) continue;                                           // block-uniform
-        if (!any) {
+        if constexpr (MEAN) {
+          acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+        } else if (!any) {
           acc = v[u];
           arg[0] = arg[1] = arg[2] = arg[3] = q[u];
         } else {
@@ -353,6 +367,9 @@ __global__ void __launch_bounds__(OF_THREADS) k_out_fwd_ce(OutFwdArgs a) {
     if constexpr (BWD) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) argk[r][e] = arg[e];
+    }
+    if constexpr (MEAN) {
+      if (any) { const float fS = (float)a.S; acc.x /= fS; acc.y /= fS; acc.z /= fS; acc.w /= fS; }
     }
     if (cin) {
       hrow[r][tid] = live ? hv : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -497,7 +514,7 @@ static int out_fwd_ce(const float* P, int64_t ldp, int64_t n_src, const int32_t*
                       int32_t* argmax, float* logits, int64_t ldl, const int64_t* label_table, int64_t n_labels,
                       const int64_t* label_ids, float grad_scale, float* loss_rows, float* dlogits, int64_t lddl,
                       float* loss_mean, unsigned int* counter, float* zero_buf, int64_t zero_floats, int rows_per_block,
-                      float* dx_self, int64_t ldx, float* dP, int64_t ldpp, ogl_stream_t stream) {
+                      float* dx_self, int64_t ldx, float* dP, int64_t ldpp, ogl_stream_t stream, int mean = 0) {
   if (!ogl_out_layer_fwd_ce_fits(n_dst, fanout, K, N) || n_src <= 0 || n_src < n_dst) return OGL_EINVAL;
   if (ldp < K || ldh < K || ldws < K || ldwn < K || ldn < K || ldl < N || (dlogits && lddl < N) || n_labels < 0) return OGL_EINVAL;
   if (!P || !idx || !h || !w_self || !w_neigh || !neigh || !logits || !label_table || !loss_rows) return OGL_EINVAL;
@@ -517,6 +534,14 @@ static int out_fwd_ce(const float* P, int64_t ldp, int64_t n_src, const int32_t*
   a.dx_self = dx_self; a.ldx = ldx; a.dP = dP; a.ldpp = ldpp;
   // one destination per block while that still is at most two blocks per CU; two beyond
   const int R = rows_per_block > 0 ? rows_per_block : (n_dst <= 512 ? 1 : 2);
+  if (mean) {
+    if (dx_self || argmax) return OGL_EINVAL;
+    if (R == 1) hipLaunchKernelGGL((k_out_fwd_ce<1, false, true>), dim3((unsigned)n_dst), dim3(OF_THREADS), 0, (hipStream_t)stream, a);
+    else if (R == 2) hipLaunchKernelGGL((k_out_fwd_ce<2, false, true>), dim3((unsigned)ogl_cdiv(n_dst, 2)), dim3(OF_THREADS), 0, (hipStream_t)stream, a);
+    else return OGL_EINVAL;
+    OGL_CHECK_LAUNCH();
+    return OGL_OK;
+  }
   if (dx_self) {
     if (!dP || ldx < K || ldpp < K || (ldx & 3) || ((uintptr_t)dx_self & 15) || zero_floats > 0) return OGL_EINVAL;
     if (R == 1) hipLaunchKernelGGL((k_out_fwd_ce<1, true>), dim3((unsigned)n_dst), dim3(OF_THREADS), 0, (hipStream_t)stream, a);
@@ -576,6 +601,47 @@ __global__ void __launch_bounds__(64) k_loss_mean_finish(const float* __restrict
 extern "C" int ogl_loss_mean_finish(const float* loss_rows, int64_t n, float* loss_mean, ogl_stream_t stream) {
   if (!loss_rows || !loss_mean || n <= 0) return OGL_EINVAL;
   hipLaunchKernelGGL(k_loss_mean_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_rows, n, loss_mean);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+// The in-repo 'mean' layer as the LAST layer of a train step, fused with the loss (k_out_fwd_ce<R, false, true>): neigh[d, :] = the mean
+// over the fanout sampled rows of P (slot order, divided by fanout: ogl_reduce_fwd(OGL_REDUCE_MEAN)'s arithmetic), logits = h[d] . w_self^T
+// + neigh[d] . w_neigh^T + b_self (+ b_neigh) where w_self / w_neigh are the two column blocks of fc_neigh's concat weight (row stride
+// ldws = ldwn = its width), then the cross entropy as ogl_out_layer_fwd_ce (deferred mean with counter == NULL).  Replaces
+// mailbox.mean + torch.cat + nn.Linear + nn.CrossEntropyLoss (R/train/graphsage/pytorch/aggregator_dgl.py:156-159,199-206;
+// pytorch/model.py:105).
+extern "C" int ogl_out_layer_fwd_ce_mean(const float* P, int64_t ldp, int64_t n_src, const int32_t* idx, int64_t n_dst, int fanout,
+                                         const float* h, int64_t ldh, int K, const float* w_self, int64_t ldws, const float* w_neigh,
+                                         int64_t ldwn, const float* b_self, const float* b_neigh, int N, float* neigh, int64_t ldn,
+                                         float* logits, int64_t ldl, const int64_t* label_table, int64_t n_labels,
+                                         const int64_t* label_ids, float grad_scale, float* loss_rows, float* dlogits, int64_t lddl,
+                                         float* loss_mean, unsigned int* counter, int rows_per_block, ogl_stream_t stream) {
+  return out_fwd_ce(P, ldp, n_src, idx, n_dst, fanout, h, ldh, K, w_self, ldws, w_neigh, ldwn, b_self, b_neigh, N, neigh, ldn, nullptr, logits,
+                    ldl, label_table, n_labels, label_ids, grad_scale, loss_rows, dlogits, lddl, loss_mean, counter, nullptr, 0,
+                    rows_per_block, nullptr, 0, nullptr, 0, stream, 1);
+}
+
+// ogl_out_layer_bwd_inputs for an aggregator WITHOUT winners (mean / sum): dx_self [n_dst, K] = dy . w_self and dneigh [n_dst, K] =
+// dy . w_neigh both STORED (the aggregator's own backward — ogl_reduce_bwd_seg_apply — follows); optionally finishes the deferred loss
+// mean like ogl_out_layer_bwd_inputs_mean (loss_rows / loss_mean nullable together).
+extern "C" int ogl_out_layer_bwd_inputs_dense(const float* dy, int64_t lddy, int64_t n_dst, int N, int K, const float* w_self, int64_t ldws,
+                                              const float* w_neigh, int64_t ldwn, float* dx_self, int64_t ldx, float* dneigh, int64_t lddn,
+                                              const float* loss_rows, int64_t n_loss, float* loss_mean, ogl_stream_t stream) {
+  if (n_dst < 0 || N <= 0 || N > OB_MAX_N || K <= 0 || lddy < N || ldws < K || ldwn < K || ldx < K || lddn < K) return OGL_EINVAL;
+  if ((loss_rows == nullptr) != (loss_mean == nullptr) || (loss_mean && n_loss <= 0)) return OGL_EINVAL;
+  if (n_dst == 0) return OGL_OK;
+  if (!dy || !w_self || !w_neigh || !dx_self || !dneigh) return OGL_EINVAL;
+  if (((uintptr_t)w_self & 15) || ((uintptr_t)w_neigh & 15) || ((uintptr_t)dx_self & 15) || ((uintptr_t)dneigh & 15)) return OGL_EINVAL;
+  dim3 grid((unsigned)ogl_cdiv(n_dst, OB_ROWS), (unsigned)ogl_cdiv(K, 256));
+  if ((K & 3) == 0 && (ldws & 3) == 0 && (ldwn & 3) == 0)
+    hipLaunchKernelGGL(k_out_bwd_inputs<true>, grid, dim3(64), 0, (hipStream_t)stream, dy, lddy, n_dst, N, K, w_self, ldws, w_neigh, ldwn,
+                       (const int32_t*)nullptr, (const float*)nullptr, (int64_t)0, (int64_t)0, dx_self, ldx, dneigh, lddn, loss_rows, n_loss,
+                       loss_mean);
+  else
+    hipLaunchKernelGGL(k_out_bwd_inputs<false>, grid, dim3(64), 0, (hipStream_t)stream, dy, lddy, n_dst, N, K, w_self, ldws, w_neigh, ldwn,
+                       (const int32_t*)nullptr, (const float*)nullptr, (int64_t)0, (int64_t)0, dx_self, ldx, dneigh, lddn, loss_rows, n_loss,
+                       loss_mean);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }

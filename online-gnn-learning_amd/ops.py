@@ -2615,6 +2615,113 @@ class _SagePoolLossFn(torch.autograd.Function):
         return _out_layer_backward(ctx, dy, h, w_pool, w_self, w_neigh, neigh, argmax, pre=pre) + (None, None, None, None)
 
 
+def out_layer_fwd_ce_mean(h, idx, n_dst, w_cat, split, bias, labels, want_mean=True):
+    """(mean loss, row losses, logits, neigh, dlogits / n_dst) of the in-repo 'mean' output layer in ONE launch
+    (``ogl_out_layer_fwd_ce_mean``): neigh = mean_j h[idx[:, j]], logits = cat(h[:n_dst], neigh) . w_cat^T + bias."""
+    h = as_mat(h); w_cat = as_mat(w_cat)
+    K, N = h.shape[1], w_cat.shape[0]
+    assert split == K and w_cat.shape[1] == 2 * K and w_cat.is_contiguous()
+    dev = h.device
+    lazy = labels if isinstance(labels, LazyLabels) else None
+    if lazy is None:
+        labels = labels.reshape(-1)
+        assert labels.dtype == torch.int64 and labels.is_cuda and labels.is_contiguous()
+    assert labels.numel() == n_dst and idx.shape[0] == n_dst and idx.is_contiguous() and idx.dtype == torch.int32
+    neigh = empty_mat(n_dst, K, dev)
+    logits = empty_mat(n_dst, N, dev)
+    loss = torch.empty(n_dst, dtype=torch.float32, device=dev)
+    mean = torch.empty((), dtype=torch.float32, device=dev)
+    dl = empty_mat(n_dst, N, dev)
+    stream = _stream()
+    table, ids = (lazy.table, lazy.ids) if lazy is not None else (labels, None)
+    ws_ptr, wn_ptr = w_cat.data_ptr(), w_cat.data_ptr() + 4 * K
+    _launch("ogl_out_layer_fwd_ce", _lib.lib().ogl_out_layer_fwd_ce_mean, _ptr(h), _ld(h), h.shape[0], _ptr(idx), n_dst, int(idx.shape[1]),
+            _ptr(h), _ld(h), K, ws_ptr, 2 * K, wn_ptr, 2 * K, _ptr(bias), None, N, _ptr(neigh), _ld(neigh), _ptr(logits), _ld(logits),
+            _ptr(table), table.numel(), _ptr(ids), C.c_float(1.0 / n_dst), _ptr(loss), _ptr(dl), _ld(dl), _ptr(mean),
+            ce_counter(dev, stream) if want_mean else None, OUT_FWD_ROWS if OUT_FWD_ROWS in (0, 1, 2) else 0, stream,
+            meta=dict(n_dst=n_dst, fanout=int(idx.shape[1]), d=K, N=N, zero_bytes=0, mean=True))
+    return mean, loss, logits, neigh, dl
+
+
+def out_layer_bwd_inputs_dense(dy, w_cat, K, finish_loss=None):
+    """(dx_self, dneigh) [n_dst, K] = dy . w_cat[:, :K], dy . w_cat[:, K:] in one launch (``ogl_out_layer_bwd_inputs_dense``)."""
+    dy = as_mat(dy); w_cat = as_mat(w_cat)
+    n_dst, N = dy.shape
+    dx = empty_mat(n_dst, K, dy.device)
+    dn = empty_mat(n_dst, K, dy.device)
+    rows, mean = finish_loss if finish_loss is not None else (None, None)
+    _launch("ogl_out_layer_bwd_inputs", _lib.lib().ogl_out_layer_bwd_inputs_dense, _ptr(dy), _ld(dy), n_dst, N, K, w_cat.data_ptr(), 2 * K,
+            w_cat.data_ptr() + 4 * K, 2 * K, _ptr(dx), _ld(dx), _ptr(dn), _ld(dn), _ptr(rows), rows.numel() if rows is not None else 0,
+            _ptr(mean), _stream(), meta=dict(M=n_dst, N=N, K=K, dense=True))
+    return dx, dn
+
+
+class _SageMeanLossFn(torch.autograd.Function):
+    """The LAST in-repo 'mean' layer of a train step together with its loss, one autograd node (round 5):
+        logits = fc_neigh(cat(h[:n_dst], mean_j h[idx[:, j]]));  loss = mean_d CE(logits[d], label(d))
+    (R/train/graphsage/pytorch/aggregator_dgl.py:156-159,199-206; pytorch/model.py:105).  Forward = ONE launch
+    (``out_layer_fwd_ce_mean``); backward = the dense input gradients (one launch), the two weight-gradient blocks and the bias
+    gradient (one launch, on the side branch), the mean's planned segmented backward with the head rows' gradient added in place.
+    Before: mean reduce + clone + skinny product + loss + two input-gradient products + two skinny weight gradients + three ATen adds."""
+
+    @staticmethod
+    def forward(ctx, h, w_cat, bias, idx, n_dst, labels, defer_mean=False):
+        h = as_mat(h)
+        K = h.shape[1]
+        need = any(t is not None and t.requires_grad for t in (h, w_cat, bias))
+        ctx.defer_mean = bool(need and DEFER_LOSS_MEAN and defer_mean)
+        ctx.set_materialize_grads(False)
+        ctx.seg_plan = reduce_bwd_seg_plan(idx, K, h.shape[0]) if (need and h.requires_grad) else None
+        mean, rows, logits, neigh, dl = out_layer_fwd_ce_mean(h, idx, n_dst, w_cat, K, bias, labels, want_mean=not ctx.defer_mean)
+        ctx.loss_out = (rows, mean) if ctx.defer_mean else None
+        ctx.n_dst, ctx.K, ctx.has_bias, ctx.n_src = n_dst, K, bias is not None, h.shape[0]
+        ctx.save_for_backward(h, w_cat, neigh, dl, idx)
+        ctx.mark_non_differentiable(rows, logits)
+        return mean, rows, logits
+
+    @staticmethod
+    def backward(ctx, dloss, _drows, _dlogits):
+        h, w_cat, neigh, dl, idx = ctx.saved_tensors
+        unit = _UNIT_GRAD.get((dloss.device.type, dloss.device.index))
+        if unit is not None and dloss.data_ptr() == unit.data_ptr():
+            dy = dl
+        else:
+            dy = empty_mat(dl.shape[0], dl.shape[1], dl.device)
+            torch.mul(dl, dloss, out=dy)
+        n_dst, K = ctx.n_dst, ctx.K
+        finish, ctx.loss_out = getattr(ctx, "loss_out", None), None
+        need = ctx.needs_input_grad
+        at0 = fork_point()
+        dx_self, dneigh = out_layer_bwd_inputs_dense(dy, w_cat, K, finish_loss=finish)
+        dw_cat = db = None
+        if need[1] or (need[2] and ctx.has_bias):
+            with (side_section(dy, h, neigh, at=at0) if at0 is not None else _NoSection()):
+                dw_cat = torch.empty_like(w_cat, memory_format=torch.contiguous_format)
+                _, _, db, _ = out_layer_bwd_weights(dy, h[:n_dst], neigh, want_bias=ctx.has_bias, dws_out=dw_cat[:, :K], dwn_out=dw_cat[:, K:])
+        dh = None
+        if need[0]:
+            plan, ctx.seg_plan = getattr(ctx, "seg_plan", None), None
+            if plan is None:
+                plan = reduce_bwd_seg_plan(idx, K, ctx.n_src, side=False)
+            dh = reduce_bwd_seg_apply(dneigh, idx, plan, "mean")[0]
+            dh[:n_dst].add_(dx_self)
+        return dh, dw_cat, (db if ctx.has_bias else None), None, None, None, None
+
+
+MEAN_LOSS_FUSED = os.environ.get("OGL_MEAN_LOSS_FUSED", "1") != "0"
+
+
+def sage_mean_layer_loss(h, w_cat, bias, idx, n_dst, labels, defer_mean=False):
+    """(mean CE loss, per-seed losses, logits) of the last in-repo 'mean' layer + nn.CrossEntropyLoss as one node, or None when the fused
+    form does not apply."""
+    if (not MEAN_LOSS_FUSED or h.dim() != 2 or idx.dtype != torch.int32 or not idx.is_contiguous() or w_cat.shape[1] != 2 * h.shape[1]
+            or not w_cat.is_contiguous() or not _lib.lib().ogl_out_layer_fwd_ce_fits(n_dst, idx.shape[1], h.shape[1], w_cat.shape[0])
+            or n_dst > 4096 or h.shape[0] < n_dst or _ld(as_mat(h)) % 4 or as_mat(h).data_ptr() % 16 or w_cat.data_ptr() % 16
+            or h.shape[1] % 4 or not seg_bwd_fits(idx, h.shape[1], h.shape[0])):
+        return None
+    return _SageMeanLossFn.apply(h, w_cat, bias, idx, n_dst, labels, bool(defer_mean))
+
+
 def sage_pool_layer_loss(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels, defer_mean=False):
     """(mean CE loss, per-seed losses, logits) of the last 'pool' layer + nn.CrossEntropyLoss, or None when the fused form does not
     apply (the caller then runs the layer and the loss separately)."""

@@ -622,3 +622,51 @@ def test_adam_over_a_two_range_slab_tensor(ops, N, K1, K2, nsplit):
     out = torch.zeros(N, K1 + K2, device=dev)
     ops.slab_reduce(sg, out)
     assert torch.equal(out, g)
+
+
+@pytest.mark.gpu
+def test_mean_output_layer_with_loss_as_one_node(ops):
+    """The in-repo 'mean' model's train step with the last layer + loss as one node (ogl_out_layer_fwd_ce_mean,
+    ogl_out_layer_bwd_inputs_dense) and as the separate launches it replaces: the same loss (1e-6) and parameter gradients (1e-5 of
+    each tensor's maximum), and the fused form's launch log has neither the mean reduce nor the skinny products of the last layer."""
+    import torch.nn.functional as F
+    from ogl_amd import sampling, synthetic
+    from ogl_amd.graphsage import GatheredRows, GraphSAGE
+    sampling.seed(5); torch.manual_seed(5)
+    feat_size, _, dyn, n_classes, _ = synthetic.load("arxiv", snapshots=2, device="cuda")
+    dyn.evolve()
+    g = dyn.get_graph()
+    old_mode, old = ops.get_gemm_mode(), ops.MEAN_LOSS_FUSED
+    ops.set_gemm_mode("auto")
+    try:
+        model = GraphSAGE(feat_size, 128, n_classes, 1, F.relu, 0, "mean").cuda()
+        seeds = torch.as_tensor(np.random.default_rng(1).choice(g.n_present, 512, replace=False))
+        (input_nodes, sd, blocks), = list(sampling.NodeDataLoader(g, seeds, sampling.MultiLayerNeighborSampler([25, 25]), batch_size=512))
+        res = {}
+        for on in (True, False):
+            ops.MEAN_LOSS_FUSED = on
+            model.zero_grad(set_to_none=True)
+            launches = []
+            real = ops._launch
+
+            def spy(name, *a, **k):
+                launches.append((name, (k.get("meta") or {}).get("mean", False)))
+                return real(name, *a, **k)
+            ops._launch = spy
+            try:
+                loss, rows, logits = model.forward_loss(blocks, GatheredRows(g.ndata["feat"], input_nodes), ops.gather_i64(g.ndata["target"], sd),
+                                                        rows=True)
+                ops.backward(loss)
+            finally:
+                ops._launch = real
+            torch.cuda.synchronize()
+            res[on] = (float(loss.detach()), rows.detach().clone(), logits.detach().clone(), [p.grad.clone() for p in model.parameters()], launches)
+        assert ("ogl_out_layer_fwd_ce", True) in res[True][4] and not any(n == "ogl_out_layer_fwd_ce" for n, _ in res[False][4])
+        assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
+        assert float((res[True][1] - res[False][1]).abs().max()) <= 1e-5
+        assert float((res[True][2] - res[False][2]).abs().max()) <= 1e-5 * float(res[False][2].abs().max())
+        for a, b in zip(res[True][3], res[False][3]):
+            assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 1e-5 * (float(b.abs().max()) + 1e-30)
+    finally:
+        ops.set_gemm_mode(old_mode)
+        ops.MEAN_LOSS_FUSED = old
