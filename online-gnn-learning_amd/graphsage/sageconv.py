@@ -239,6 +239,11 @@ class SAGEConv(nn.Module):
             # the in-repo 'mean' layer as the last layer: aggregator, concat projection and loss in one launch (ops._SageMeanLossFn)
             return ops.sage_mean_layer_loss(feat, self.fc_neigh.weight, self.fc_neigh.bias, graph.local_idx, graph.number_of_dst_nodes(),
                                             labels, defer_mean=defer_mean)
+        if (self._aggre_type == "meanpool" and not isinstance(feat, GatheredRows) and self.norm is None and self.activation is None
+                and not (self.training and self.feat_drop.p > 0) and torch.is_grad_enabled() and getattr(graph, "dst_pos", None) is None
+                and self._edge_feats == 0):
+            return ops.sage_meanpool_layer_loss(feat, self.fc_pool.weight, self.fc_pool.bias, self.fc_neigh.weight, self.fc_neigh.bias,
+                                                graph.local_idx, graph.number_of_dst_nodes(), labels, defer_mean=defer_mean)
         if (self._aggre_type != "pool" or isinstance(feat, GatheredRows) or self.norm is not None or self.activation is not None
                 or (self.training and self.feat_drop.p > 0) or not torch.is_grad_enabled() or getattr(graph, "dst_pos", None) is not None
                 or (self.fc_self.bias is None) != (self.fc_neigh.bias is None)):

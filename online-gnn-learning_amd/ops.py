@@ -2615,10 +2615,13 @@ class _SagePoolLossFn(torch.autograd.Function):
         return _out_layer_backward(ctx, dy, h, w_pool, w_self, w_neigh, neigh, argmax, pre=pre) + (None, None, None, None)
 
 
-def out_layer_fwd_ce_mean(h, idx, n_dst, w_cat, split, bias, labels, want_mean=True):
+def out_layer_fwd_ce_mean(h, idx, n_dst, w_cat, split, bias, labels, want_mean=True, p=None):
     """(mean loss, row losses, logits, neigh, dlogits / n_dst) of the in-repo 'mean' output layer in ONE launch
-    (``ogl_out_layer_fwd_ce_mean``): neigh = mean_j h[idx[:, j]], logits = cat(h[:n_dst], neigh) . w_cat^T + bias."""
+    (``ogl_out_layer_fwd_ce_mean``): neigh = mean_j P[idx[:, j]], logits = cat(h[:n_dst], neigh) . w_cat^T + bias; ``p`` = the rows the
+    mean runs over (default ``h`` itself: 'mean'; relu(fc_pool(h)): 'meanpool'), same width as ``h``."""
     h = as_mat(h); w_cat = as_mat(w_cat)
+    p = h if p is None else as_mat(p)
+    assert p.shape == h.shape and _ld(p) % 4 == 0 and p.data_ptr() % 16 == 0
     K, N = h.shape[1], w_cat.shape[0]
     assert split == K and w_cat.shape[1] == 2 * K and w_cat.is_contiguous()
     dev = h.device
@@ -2635,7 +2638,7 @@ def out_layer_fwd_ce_mean(h, idx, n_dst, w_cat, split, bias, labels, want_mean=T
     stream = _stream()
     table, ids = (lazy.table, lazy.ids) if lazy is not None else (labels, None)
     ws_ptr, wn_ptr = w_cat.data_ptr(), w_cat.data_ptr() + 4 * K
-    _launch("ogl_out_layer_fwd_ce", _lib.lib().ogl_out_layer_fwd_ce_mean, _ptr(h), _ld(h), h.shape[0], _ptr(idx), n_dst, int(idx.shape[1]),
+    _launch("ogl_out_layer_fwd_ce", _lib.lib().ogl_out_layer_fwd_ce_mean, _ptr(p), _ld(p), h.shape[0], _ptr(idx), n_dst, int(idx.shape[1]),
             _ptr(h), _ld(h), K, ws_ptr, 2 * K, wn_ptr, 2 * K, _ptr(bias), None, N, _ptr(neigh), _ld(neigh), _ptr(logits), _ld(logits),
             _ptr(table), table.numel(), _ptr(ids), C.c_float(1.0 / n_dst), _ptr(loss), _ptr(dl), _ld(dl), _ptr(mean),
             ce_counter(dev, stream) if want_mean else None, OUT_FWD_ROWS if OUT_FWD_ROWS in (0, 1, 2) else 0, stream,
@@ -2708,7 +2711,84 @@ class _SageMeanLossFn(torch.autograd.Function):
         return dh, dw_cat, (db if ctx.has_bias else None), None, None, None, None
 
 
+class _SageMeanPoolLossFn(torch.autograd.Function):
+    """The LAST in-repo 'meanpool' layer of a train step together with its loss (R/train/graphsage/pytorch/aggregator_dgl.py:178-186,
+    199-206): p = relu(fc_pool(h)); logits = fc_neigh(cat(h[:n_dst], mean_j p[idx[:, j]])); the mean CE.  Forward = the fc_pool product +
+    ONE launch; backward = ``_SageMeanLossFn``'s, with the mean's planned backward masked by [p > 0] and followed by fc_pool's two
+    gradients (the head rows' gradient joins dh in the epilogue of the input-gradient product, as in ``_out_layer_backward``)."""
+
+    @staticmethod
+    def forward(ctx, h, w_pool, b_pool, w_cat, bias, idx, n_dst, labels, defer_mean=False):
+        h = as_mat(h)
+        K = h.shape[1]
+        ctx.h_relu_out = bool(getattr(h, "_ogl_relu_out", False))
+        himg = take_image(h) if _n1_images_ok(h.shape[0], K, w_pool.shape[0]) else None
+        ctx.h_img = himg if (himg is not None and himg.K == K + 1) else None
+        if ctx.h_img is not None:
+            wimg = weight_image("wb", w_pool, b_pool)
+            if wimg is None:
+                weight_images_prepare([("wb", (w_pool, b_pool))])
+                wimg = weight_image("wb", w_pool, b_pool)
+            p = linear_fwd_x3(himg, None, wimg, relu=True)
+        else:
+            p = linear_fwd(h, w_pool, b_pool, relu=True)
+        if _CAPTURE is not None:
+            _CAPTURE.append(dict(pool_out=p))
+        need = any(t is not None and t.requires_grad for t in (h, w_pool, b_pool, w_cat, bias))
+        ctx.defer_mean = bool(need and DEFER_LOSS_MEAN and defer_mean)
+        ctx.set_materialize_grads(False)
+        ctx.seg_plan = reduce_bwd_seg_plan(idx, K, h.shape[0]) if need else None
+        mean, rows, logits, neigh, dl = out_layer_fwd_ce_mean(h, idx, n_dst, w_cat, K, bias, labels, want_mean=not ctx.defer_mean, p=p)
+        ctx.loss_out = (rows, mean) if ctx.defer_mean else None
+        ctx.n_dst, ctx.K, ctx.has_bias, ctx.has_pool_bias, ctx.n_src = n_dst, K, bias is not None, b_pool is not None, h.shape[0]
+        ctx.b_pool_t = b_pool
+        ctx.save_for_backward(h, w_pool, w_cat, neigh, dl, idx, p)
+        ctx.mark_non_differentiable(rows, logits)
+        return mean, rows, logits
+
+    @staticmethod
+    def backward(ctx, dloss, _drows, _dlogits):
+        h, w_pool, w_cat, neigh, dl, idx, p = ctx.saved_tensors
+        unit = _UNIT_GRAD.get((dloss.device.type, dloss.device.index))
+        if unit is not None and dloss.data_ptr() == unit.data_ptr():
+            dy = dl
+        else:
+            dy = empty_mat(dl.shape[0], dl.shape[1], dl.device)
+            torch.mul(dl, dloss, out=dy)
+        n_dst, K = ctx.n_dst, ctx.K
+        finish, ctx.loss_out = getattr(ctx, "loss_out", None), None
+        tall = N1_BWD_SPLIT and _n1_images_ok(ctx.n_src, K, w_pool.shape[1])
+        at0 = fork_point() if tall else None
+        dx_self, dneigh = out_layer_bwd_inputs_dense(dy, w_cat, K, finish_loss=finish)
+        with (side_section(dy, h, neigh, at=at0) if at0 is not None else _NoSection()):
+            dw_cat = torch.empty_like(w_cat, memory_format=torch.contiguous_format)
+            _, _, db, _ = out_layer_bwd_weights(dy, h[:n_dst], neigh, want_bias=ctx.has_bias, dws_out=dw_cat[:, :K], dwn_out=dw_cat[:, K:])
+        plan, ctx.seg_plan = getattr(ctx, "seg_plan", None), None
+        if plan is None:
+            plan = reduce_bwd_seg_plan(idx, K, ctx.n_src, side=False)
+        # dP = the mean's backward masked by [p > 0], with its image beside it for the two products that follow
+        dp, dp_img = reduce_bwd_seg_apply(dneigh, idx, plan, "mean", mask=p, want_out=True, want_image=tall)
+        at = fork_point() if tall else None
+        dh = linear_bwd_input(dp, w_pool, None, dy_img=dp_img, add_head=dx_self,
+                              out_relu_mask=h if (FUSE_RELU_BWD and ctx.h_relu_out and tall) else None)
+        with (side_section(dp, dp_img, ctx.h_img, at=at) if at is not None else _NoSection()):
+            dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias, x_img=ctx.h_img, dy_img=dp_img,
+                                           dw_out=_dw_out(w_pool, *w_pool.shape), defer_for=(w_pool, getattr(ctx, "b_pool_t", None), None))
+        return (dh, dw_pool, db_pool if ctx.has_pool_bias else None, dw_cat, (db if ctx.has_bias else None), None, None, None, None)
+
+
 MEAN_LOSS_FUSED = os.environ.get("OGL_MEAN_LOSS_FUSED", "1") != "0"
+
+
+def sage_meanpool_layer_loss(h, w_pool, b_pool, w_cat, bias, idx, n_dst, labels, defer_mean=False):
+    """(mean CE loss, per-seed losses, logits) of the last in-repo 'meanpool' layer + nn.CrossEntropyLoss as one node, or None."""
+    if (not MEAN_LOSS_FUSED or h.dim() != 2 or idx.dtype != torch.int32 or not idx.is_contiguous() or w_cat.shape[1] != 2 * h.shape[1]
+            or w_pool.shape[0] != h.shape[1] or w_pool.shape[1] != h.shape[1]
+            or not w_cat.is_contiguous() or not _lib.lib().ogl_out_layer_fwd_ce_fits(n_dst, idx.shape[1], h.shape[1], w_cat.shape[0])
+            or n_dst > 4096 or h.shape[0] < n_dst or _ld(as_mat(h)) % 4 or as_mat(h).data_ptr() % 16 or w_cat.data_ptr() % 16
+            or h.shape[1] % 4 or not seg_bwd_fits(idx, h.shape[1], h.shape[0])):
+        return None
+    return _SageMeanPoolLossFn.apply(h, w_pool, b_pool, w_cat, bias, idx, n_dst, labels, bool(defer_mean))
 
 
 def sage_mean_layer_loss(h, w_cat, bias, idx, n_dst, labels, defer_mean=False):

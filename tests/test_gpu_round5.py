@@ -625,8 +625,9 @@ def test_adam_over_a_two_range_slab_tensor(ops, N, K1, K2, nsplit):
 
 
 @pytest.mark.gpu
-def test_mean_output_layer_with_loss_as_one_node(ops):
-    """The in-repo 'mean' model's train step with the last layer + loss as one node (ogl_out_layer_fwd_ce_mean,
+@pytest.mark.parametrize("mode", ["mean", "meanpool"])
+def test_mean_output_layer_with_loss_as_one_node(ops, mode):
+    """The in-repo 'mean' / 'meanpool' model's train step with the last layer + loss as one node (ogl_out_layer_fwd_ce_mean,
     ogl_out_layer_bwd_inputs_dense) and as the separate launches it replaces: the same loss (1e-6) and parameter gradients (1e-5 of
     each tensor's maximum), and the fused form's launch log has neither the mean reduce nor the skinny products of the last layer."""
     import torch.nn.functional as F
@@ -639,7 +640,7 @@ def test_mean_output_layer_with_loss_as_one_node(ops):
     old_mode, old = ops.get_gemm_mode(), ops.MEAN_LOSS_FUSED
     ops.set_gemm_mode("auto")
     try:
-        model = GraphSAGE(feat_size, 128, n_classes, 1, F.relu, 0, "mean").cuda()
+        model = GraphSAGE(feat_size, 128, n_classes, 1, F.relu, 0, mode).cuda()
         seeds = torch.as_tensor(np.random.default_rng(1).choice(g.n_present, 512, replace=False))
         (input_nodes, sd, blocks), = list(sampling.NodeDataLoader(g, seeds, sampling.MultiLayerNeighborSampler([25, 25]), batch_size=512))
         res = {}
