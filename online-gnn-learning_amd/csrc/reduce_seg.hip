@@ -30,6 +30,9 @@
 #include "x6_arith.h"
 
 #define SG_TILE 64
+#define SG_TILE_SMALL 16     // blocks of at most SG_SMALL_E entries: a 64-entry tile is eight dependent batches of row loads in 200 blocks
+#define SG_SMALL_E 32768     //   (31 us for the 12 800 edges of a 512-seed output block); 16-entry tiles are two batches in 800 blocks
+static inline int seg_tile(int64_t E) { return E <= SG_SMALL_E ? SG_TILE_SMALL : SG_TILE; }
 #define SG_THREADS 256
 #define SG_U 8
 #define SG_SCAN 1024
@@ -221,20 +224,21 @@ __device__ __forceinline__ void seg_store(const SegOut& o, int64_t s, int ch, in
   }
 }
 
+template <int TILE>
 __global__ void __launch_bounds__(SG_THREADS) k_seg_reduce(const float* __restrict__ dout, int64_t ldd, int64_t n_dst, int S, int D,
                                                            const int32_t* __restrict__ idx, const int* __restrict__ sorted,
                                                            const int* __restrict__ start, int64_t n_src, SegOut o,
                                                            float* __restrict__ partial, int64_t ldpart) {
   // per entry of the tile: its destination row, its source, and whether the source's whole range lies inside the tile (then the
   // run is finished here) — fetched once, in parallel, so that the walk below never waits for a dependent scalar load
-  __shared__ int se[SG_TILE], ss[SG_TILE];
-  __shared__ unsigned char whole[SG_TILE];
+  __shared__ int se[TILE], ss[TILE];
+  __shared__ unsigned char whole[TILE];
   const int total = start[n_src];
-  const int t0 = blockIdx.x * SG_TILE;
+  const int t0 = blockIdx.x * TILE;
   if (t0 >= total) return;
-  const int t1 = min(total, t0 + SG_TILE), cntk = t1 - t0;
+  const int t1 = min(total, t0 + TILE), cntk = t1 - t0;
   const int tid = threadIdx.x;
-  if (tid < SG_TILE) {
+  if (tid < TILE) {
     const int e = tid < cntk ? sorted[t0 + tid] : 0;
     const int s = tid < cntk ? idx[e] : -1;
     se[tid] = e / S;                                          // the destination row of the entry
@@ -289,7 +293,7 @@ __global__ void __launch_bounds__(SG_THREADS) k_seg_reduce(const float* __restri
 
 // wave per source (+ one wave for the image's zero row): sources spanning several tiles, sources without an edge
 __global__ void __launch_bounds__(256) k_seg_fixup(const int* __restrict__ start, int64_t n_src, int D, SegOut o,
-                                                   const float* __restrict__ partial, int64_t ldpart) {
+                                                   const float* __restrict__ partial, int64_t ldpart, int TILE) {
   const int lane = threadIdx.x & 63;
   const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s > n_src) return;
@@ -309,13 +313,13 @@ __global__ void __launch_bounds__(256) k_seg_fixup(const int* __restrict__ start
     for (int ch = lane; ch < nch; ch += 64) seg_store(z, s, ch, D, make_float4(0.f, 0.f, 0.f, 0.f));
     return;
   }
-  const int tf = a / SG_TILE, tl = (b - 1) / SG_TILE;
+  const int tf = a / TILE, tl = (b - 1) / TILE;
   if (tf == tl) return;                                       // finished by its tile
   for (int ch = lane; ch < nch; ch += 64) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ch < D4) {
       for (int t = tf; t <= tl; ++t) {                        // tile order: the order of the sorted list
-        const int slot = (t == tf && a > t * SG_TILE) ? 1 : 0;
+        const int slot = (t == tf && a > t * TILE) ? 1 : 0;
         const float4 v = *(const float4*)(partial + ((int64_t)t * 2 + slot) * ldpart + 4 * ch);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
@@ -333,7 +337,7 @@ static int64_t seg_ints(int64_t E, int64_t n_src) {
 extern "C" int64_t ogl_reduce_bwd_seg_workspace_bytes(int64_t n_dst, int fanout, int d, int64_t n_src) {
   if (n_dst < 0 || fanout < 0 || d < 0 || n_src < 0) return OGL_EINVAL;
   const int64_t E = n_dst * fanout;
-  const int64_t tiles = ogl_cdiv(E, SG_TILE) + 1;
+  const int64_t tiles = ogl_cdiv(E, seg_tile(E)) + 1;
   return ogl_round_up(seg_ints(E, n_src) * 4, 256) + tiles * 2 * ogl_round_up(d, 4) * 4;
 }
 
@@ -405,13 +409,18 @@ static int seg_apply(const float* dout, int64_t ldd, const int32_t* idx, int64_t
   o.out = out; o.ldo = ldo; o.img = (unsigned char*)image; o.img_row_bytes = ogl_cdiv(d, 32) * 192; o.mask = mask; o.ldm = ldm;
   o.mbits = mbits; o.ldmb = ldmb;
   o.divisor = op == OGL_REDUCE_MEAN ? (float)fanout : 1.f;
+  const int tile = seg_tile(E);
   if (E > 0) {
-    hipLaunchKernelGGL(k_seg_reduce, dim3((unsigned)ogl_cdiv(E, SG_TILE)), dim3(SG_THREADS), 0, st, dout, ldd, n_dst, fanout, d, idx,
-                       (const int*)sorted, (const int*)start, n_src, o, partial, ldpart);
+    if (tile == SG_TILE_SMALL)
+      hipLaunchKernelGGL(k_seg_reduce<SG_TILE_SMALL>, dim3((unsigned)ogl_cdiv(E, SG_TILE_SMALL)), dim3(SG_THREADS), 0, st, dout, ldd, n_dst, fanout,
+                         d, idx, (const int*)sorted, (const int*)start, n_src, o, partial, ldpart);
+    else
+      hipLaunchKernelGGL(k_seg_reduce<SG_TILE>, dim3((unsigned)ogl_cdiv(E, SG_TILE)), dim3(SG_THREADS), 0, st, dout, ldd, n_dst, fanout, d, idx,
+                         (const int*)sorted, (const int*)start, n_src, o, partial, ldpart);
     OGL_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(k_seg_fixup, dim3((unsigned)ogl_cdiv(n_src + 1, 4)), dim3(256), 0, st, (const int*)start, n_src, d, o,
-                     (const float*)partial, ldpart);
+                     (const float*)partial, ldpart, tile);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }
