@@ -114,9 +114,13 @@ class GraphSAGE(nn.Module):
         if torch.is_grad_enabled() and ops.get_gemm_mode() != "f32" and ops.PREPARE_WEIGHT_IMAGES:
             self._prepare_step_images(blocks, x)
         h = x
+        if len(self.layers) == len(blocks) and len(blocks) > 1 and hasattr(self.layers[-1], "preplan_loss"):
+            self.layers[-1].preplan_loss(blocks[-1])
         for layer, block in zip(self.layers[:-1], blocks[:-1]):
             h = layer(block, h)
         out = self.layers[-1].forward_loss(blocks[-1], h, labels, defer_mean=defer_mean) if len(self.layers) == len(blocks) else None
+        if len(blocks) > 0 and hasattr(blocks[-1], "_ogl_seg_plan"):
+            del blocks[-1]._ogl_seg_plan
         if out is not None:
             return out[0], (out[1] if rows else None), out[2]
         logits = self.layers[-1](blocks[-1], h)

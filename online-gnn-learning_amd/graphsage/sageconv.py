@@ -228,6 +228,16 @@ class SAGEConv(nn.Module):
             rst = self.norm(rst)
         return rst
 
+    def preplan_loss(self, graph):
+        """Called by GraphSAGE.forward_loss at the TOP of a train step for its last layer: the in-repo 'mean' / 'meanpool' layer's
+        mean backward needs a plan that depends on the block's indices only — started here, its launches run beside the first layer."""
+        if (ops.MEAN_LOSS_FUSED and self._aggre_type in ("mean", "meanpool") and torch.is_grad_enabled() and self._edge_feats == 0
+                and getattr(graph, "dst_pos", None) is None):
+            idx = graph.local_idx
+            n_src = graph.number_of_src_nodes()
+            if idx.dtype == torch.int32 and idx.is_contiguous() and ops.seg_bwd_fits(idx, self._in_feats, n_src):
+                graph._ogl_seg_plan = ops.reduce_bwd_seg_plan(idx, self._in_feats, n_src)
+
     def forward_loss(self, graph, feat, labels, defer_mean=False):
         """This layer as the LAST layer of a train step, fused with nn.CrossEntropyLoss: (mean loss, per-seed losses, logits) from
         one autograd node whose forward is the fc_pool product + ONE launch (``ops.sage_pool_layer_loss``) — or None when that form
@@ -238,12 +248,13 @@ class SAGEConv(nn.Module):
                 and self._edge_feats == 0 and self._in_feats == self.in_neigh_feats):
             # the in-repo 'mean' layer as the last layer: aggregator, concat projection and loss in one launch (ops._SageMeanLossFn)
             return ops.sage_mean_layer_loss(feat, self.fc_neigh.weight, self.fc_neigh.bias, graph.local_idx, graph.number_of_dst_nodes(),
-                                            labels, defer_mean=defer_mean)
+                                            labels, defer_mean=defer_mean, plan=getattr(graph, "_ogl_seg_plan", None))
         if (self._aggre_type == "meanpool" and not isinstance(feat, GatheredRows) and self.norm is None and self.activation is None
                 and not (self.training and self.feat_drop.p > 0) and torch.is_grad_enabled() and getattr(graph, "dst_pos", None) is None
                 and self._edge_feats == 0):
             return ops.sage_meanpool_layer_loss(feat, self.fc_pool.weight, self.fc_pool.bias, self.fc_neigh.weight, self.fc_neigh.bias,
-                                                graph.local_idx, graph.number_of_dst_nodes(), labels, defer_mean=defer_mean)
+                                                graph.local_idx, graph.number_of_dst_nodes(), labels, defer_mean=defer_mean,
+                                                plan=getattr(graph, "_ogl_seg_plan", None))
         if (self._aggre_type != "pool" or isinstance(feat, GatheredRows) or self.norm is not None or self.activation is not None
                 or (self.training and self.feat_drop.p > 0) or not torch.is_grad_enabled() or getattr(graph, "dst_pos", None) is not None
                 or (self.fc_self.bias is None) != (self.fc_neigh.bias is None)):

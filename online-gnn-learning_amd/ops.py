@@ -2668,13 +2668,17 @@ class _SageMeanLossFn(torch.autograd.Function):
     Before: mean reduce + clone + skinny product + loss + two input-gradient products + two skinny weight gradients + three ATen adds."""
 
     @staticmethod
-    def forward(ctx, h, w_cat, bias, idx, n_dst, labels, defer_mean=False):
+    def forward(ctx, h, w_cat, bias, idx, n_dst, labels, defer_mean=False, plan=None):
         h = as_mat(h)
         K = h.shape[1]
         need = any(t is not None and t.requires_grad for t in (h, w_cat, bias))
         ctx.defer_mean = bool(need and DEFER_LOSS_MEAN and defer_mean)
         ctx.set_materialize_grads(False)
-        ctx.seg_plan = reduce_bwd_seg_plan(idx, K, h.shape[0]) if (need and h.requires_grad) else None
+        # (``plan``: the mean's backward plan when the caller started it earlier — GraphSAGE.forward_loss does, at the top of the step:
+        # its eight small launches then run beside the first layer instead of in front of this node's backward)
+        if plan is not None and plan.shape != (n_dst, idx.shape[1], K, h.shape[0]):
+            plan = None
+        ctx.seg_plan = (plan if plan is not None else reduce_bwd_seg_plan(idx, K, h.shape[0])) if (need and h.requires_grad) else None
         mean, rows, logits, neigh, dl = out_layer_fwd_ce_mean(h, idx, n_dst, w_cat, K, bias, labels, want_mean=not ctx.defer_mean)
         ctx.loss_out = (rows, mean) if ctx.defer_mean else None
         ctx.n_dst, ctx.K, ctx.has_bias, ctx.n_src = n_dst, K, bias is not None, h.shape[0]
@@ -2708,7 +2712,7 @@ class _SageMeanLossFn(torch.autograd.Function):
                 plan = reduce_bwd_seg_plan(idx, K, ctx.n_src, side=False)
             dh = reduce_bwd_seg_apply(dneigh, idx, plan, "mean")[0]
             dh[:n_dst].add_(dx_self)
-        return dh, dw_cat, (db if ctx.has_bias else None), None, None, None, None
+        return dh, dw_cat, (db if ctx.has_bias else None), None, None, None, None, None
 
 
 class _SageMeanPoolLossFn(torch.autograd.Function):
@@ -2718,9 +2722,11 @@ class _SageMeanPoolLossFn(torch.autograd.Function):
     gradients (the head rows' gradient joins dh in the epilogue of the input-gradient product, as in ``_out_layer_backward``)."""
 
     @staticmethod
-    def forward(ctx, h, w_pool, b_pool, w_cat, bias, idx, n_dst, labels, defer_mean=False):
+    def forward(ctx, h, w_pool, b_pool, w_cat, bias, idx, n_dst, labels, defer_mean=False, plan=None):
         h = as_mat(h)
         K = h.shape[1]
+        if plan is not None and plan.shape != (n_dst, idx.shape[1], K, h.shape[0]):
+            plan = None
         ctx.h_relu_out = bool(getattr(h, "_ogl_relu_out", False))
         himg = take_image(h) if _n1_images_ok(h.shape[0], K, w_pool.shape[0]) else None
         ctx.h_img = himg if (himg is not None and himg.K == K + 1) else None
@@ -2737,7 +2743,7 @@ class _SageMeanPoolLossFn(torch.autograd.Function):
         need = any(t is not None and t.requires_grad for t in (h, w_pool, b_pool, w_cat, bias))
         ctx.defer_mean = bool(need and DEFER_LOSS_MEAN and defer_mean)
         ctx.set_materialize_grads(False)
-        ctx.seg_plan = reduce_bwd_seg_plan(idx, K, h.shape[0]) if need else None
+        ctx.seg_plan = (plan if plan is not None else reduce_bwd_seg_plan(idx, K, h.shape[0])) if need else None
         mean, rows, logits, neigh, dl = out_layer_fwd_ce_mean(h, idx, n_dst, w_cat, K, bias, labels, want_mean=not ctx.defer_mean, p=p)
         ctx.loss_out = (rows, mean) if ctx.defer_mean else None
         ctx.n_dst, ctx.K, ctx.has_bias, ctx.has_pool_bias, ctx.n_src = n_dst, K, bias is not None, b_pool is not None, h.shape[0]
@@ -2774,13 +2780,13 @@ class _SageMeanPoolLossFn(torch.autograd.Function):
         with (side_section(dp, dp_img, ctx.h_img, at=at) if at is not None else _NoSection()):
             dw_pool, db_pool = weight_grad(dp, h, None, want_bias=ctx.has_pool_bias, x_img=ctx.h_img, dy_img=dp_img,
                                            dw_out=_dw_out(w_pool, *w_pool.shape), defer_for=(w_pool, getattr(ctx, "b_pool_t", None), None))
-        return (dh, dw_pool, db_pool if ctx.has_pool_bias else None, dw_cat, (db if ctx.has_bias else None), None, None, None, None)
+        return (dh, dw_pool, db_pool if ctx.has_pool_bias else None, dw_cat, (db if ctx.has_bias else None), None, None, None, None, None)
 
 
 MEAN_LOSS_FUSED = os.environ.get("OGL_MEAN_LOSS_FUSED", "1") != "0"
 
 
-def sage_meanpool_layer_loss(h, w_pool, b_pool, w_cat, bias, idx, n_dst, labels, defer_mean=False):
+def sage_meanpool_layer_loss(h, w_pool, b_pool, w_cat, bias, idx, n_dst, labels, defer_mean=False, plan=None):
     """(mean CE loss, per-seed losses, logits) of the last in-repo 'meanpool' layer + nn.CrossEntropyLoss as one node, or None."""
     if (not MEAN_LOSS_FUSED or h.dim() != 2 or idx.dtype != torch.int32 or not idx.is_contiguous() or w_cat.shape[1] != 2 * h.shape[1]
             or w_pool.shape[0] != h.shape[1] or w_pool.shape[1] != h.shape[1]
@@ -2788,10 +2794,10 @@ def sage_meanpool_layer_loss(h, w_pool, b_pool, w_cat, bias, idx, n_dst, labels,
             or n_dst > 4096 or h.shape[0] < n_dst or _ld(as_mat(h)) % 4 or as_mat(h).data_ptr() % 16 or w_cat.data_ptr() % 16
             or h.shape[1] % 4 or not seg_bwd_fits(idx, h.shape[1], h.shape[0])):
         return None
-    return _SageMeanPoolLossFn.apply(h, w_pool, b_pool, w_cat, bias, idx, n_dst, labels, bool(defer_mean))
+    return _SageMeanPoolLossFn.apply(h, w_pool, b_pool, w_cat, bias, idx, n_dst, labels, bool(defer_mean), plan)
 
 
-def sage_mean_layer_loss(h, w_cat, bias, idx, n_dst, labels, defer_mean=False):
+def sage_mean_layer_loss(h, w_cat, bias, idx, n_dst, labels, defer_mean=False, plan=None):
     """(mean CE loss, per-seed losses, logits) of the last in-repo 'mean' layer + nn.CrossEntropyLoss as one node, or None when the fused
     form does not apply."""
     if (not MEAN_LOSS_FUSED or h.dim() != 2 or idx.dtype != torch.int32 or not idx.is_contiguous() or w_cat.shape[1] != 2 * h.shape[1]
@@ -2799,7 +2805,7 @@ def sage_mean_layer_loss(h, w_cat, bias, idx, n_dst, labels, defer_mean=False):
             or n_dst > 4096 or h.shape[0] < n_dst or _ld(as_mat(h)) % 4 or as_mat(h).data_ptr() % 16 or w_cat.data_ptr() % 16
             or h.shape[1] % 4 or not seg_bwd_fits(idx, h.shape[1], h.shape[0])):
         return None
-    return _SageMeanLossFn.apply(h, w_cat, bias, idx, n_dst, labels, bool(defer_mean))
+    return _SageMeanLossFn.apply(h, w_cat, bias, idx, n_dst, labels, bool(defer_mean), plan)
 
 
 def sage_pool_layer_loss(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels, defer_mean=False):
