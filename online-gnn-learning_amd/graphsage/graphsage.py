@@ -11,6 +11,9 @@ from .. import ops
 from .sageconv import SAGEConv
 
 
+INREPO_T_IMAGES = __import__("os").environ.get("OGL_INREPO_T_IMAGES", "1") != "0"   # in-repo pooling layers: W^T images prepared with the step's others
+
+
 class GraphSAGE(nn.Module):
     def __init__(self, in_feats, n_hidden, n_classes, n_layers, activation, dropout, aggregator_type, edge_feats=None,
                  pool_feats=None):
@@ -97,6 +100,25 @@ class GraphSAGE(nn.Module):
                     req.append(r_tp)
                     if r_bsum is not None and s_out <= 64:      # the few-column output layer: fp32 operands + a summed bias
                         req.append(r_bsum)
+            n_src = n_dst
+        # the in-repo pooling layers behind the first ('meanpool' / 'maxpool'): the images of W_pool^T and of the neighbour block of
+        # fc_neigh's weight, transposed — what their two input-gradient products read (a transpose + a split launch each, on the critical
+        # path of the backward pass, when nobody prepared them: 4 launches, 20 us of the Reddit-rung 'meanpool' step)
+        n_src = x.shape[0]
+        for li, (layer, block) in enumerate(zip(self.layers, blocks)):
+            n_dst = block.number_of_dst_nodes()
+            if (INREPO_T_IMAGES and getattr(layer, "_aggre_type", None) in ("meanpool", "maxpool") and not (training and layer.feat_drop.p > 0)
+                    and getattr(layer, "_edge_feats", 0) == 0):
+                K = layer._in_feats
+                if li > 0 and ops._n1_images_ok(n_src, K, layer.fc_pool.weight.shape[0]):
+                    req.append(("T", (layer.fc_pool.weight,)))
+                if ops._n1_images_ok(n_dst, layer.fc_neigh.weight.shape[0], K) and len(req) < 7:
+                    # (the neighbour block as ONE view object kept on the layer: a prepared image lives as long as the tensor it was
+                    # built from, and the consumer's own slice has the same address and version)
+                    wv = layer.__dict__.get("_wn_view")
+                    if wv is None or wv._base is not layer.fc_neigh.weight:
+                        wv = layer.__dict__["_wn_view"] = layer.fc_neigh.weight[:, K:]
+                    req.append(("T", (wv,)))
             n_src = n_dst
         if req:
             ops.weight_images_prepare(req)
