@@ -116,8 +116,11 @@ class GraphSAGE(nn.Module):
                     # (the neighbour block as ONE view object kept on the layer: a prepared image lives as long as the tensor it was
                     # built from, and the consumer's own slice has the same address and version)
                     wv = layer.__dict__.get("_wn_view")
-                    if wv is None or wv._base is not layer.fc_neigh.weight:
-                        wv = layer.__dict__["_wn_view"] = layer.fc_neigh.weight[:, K:]
+                    wfull = layer.fc_neigh.weight
+                    if wv is None or wv.data_ptr() != wfull.data_ptr() + 4 * K or wv.shape[0] != wfull.shape[0]:
+                        # (detached: a slice taken under grad mode carries an autograd node — kept across steps it reached into a
+                        # later step's capture and hipStreamEndCapture crashed; the detached tensor shares address and version counter)
+                        wv = layer.__dict__["_wn_view"] = wfull.detach()[:, K:]
                     req.append(("T", (wv,)))
             n_src = n_dst
         if req:

@@ -671,3 +671,38 @@ def test_mean_output_layer_with_loss_as_one_node(ops, mode):
     finally:
         ops.set_gemm_mode(old_mode)
         ops.MEAN_LOSS_FUSED = old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["meanpool", "mean"])
+def test_inrepo_mode_eager_steps_then_captured_steps(ops, mode):
+    """An in-repo model trained eagerly for a few batches and THEN through captured steps (what the strategies' automatic policy does:
+    eager snapshots first, graphs once they pay): the per-step state the eager steps leave behind — prepared weight images, a cached
+    view of fc_neigh's neighbour block, backward plans — must not reach into a later capture (a slice kept with its autograd node made
+    hipStreamEndCapture crash).  Losses stay finite and fall in line with the eager ones."""
+    import torch.nn.functional as F
+    from ogl_amd import sampling, synthetic
+    from ogl_amd.graphsage import GraphSAGE
+    from ogl_amd.graphsage.model import RandomHipSupervisedGraphSage
+    sampling.seed(9); torch.manual_seed(9)
+    feat_size, labels, dyn, n_classes, _ = synthetic.load("arxiv", snapshots=2, device="cuda")
+    dyn.evolve()
+    g = dyn.get_graph()
+    old_mode = ops.get_gemm_mode()
+    ops.set_gemm_mode("auto")
+    try:
+        model = GraphSAGE(feat_size, 128, n_classes, 1, F.relu, 0, mode).cuda()
+        strat = RandomHipSupervisedGraphSage(model, 3, 512, labels, 25, cuda=True, batch_full=1024)
+        strat.build_optimizer()
+        losses = []
+        strat.step_hook = lambda info: losses.append((info["form"], float(info["loss"])))
+        seeds = np.random.default_rng(2).choice(g.n_present, 512 * 3, replace=False).astype(np.int64)
+        for graphs in (False, True, False, True):
+            strat.use_graphs = graphs
+            strat._run_custom_train(g, dyn.get_subgraph_to_original_map(), dyn.get_original_to_subgraph_map(), seeds, None)
+        torch.cuda.synchronize()
+        forms = {f for f, _ in losses}
+        assert "eager" in forms and ("staged" in forms or "sampled" in forms), forms
+        assert all(np.isfinite(v) for _, v in losses) and losses[-1][1] < losses[0][1]
+    finally:
+        ops.set_gemm_mode(old_mode)
