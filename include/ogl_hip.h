@@ -719,6 +719,36 @@ int ogl_small_pool_layer_bwd(const float* dy, int64_t lddy, const float* y, int6
                              float* dWn, int64_t lddwn, float* dbn, float* dh, int64_t lddh, float* workspace,
                              ogl_stream_t stream);
 
+/* The LAST small 'pool' layer of a train step together with nn.CrossEntropyLoss(reduction='mean') (R/train/graphsage/pytorch/
+ * model.py:87-107: logits = model(blocks, x); loss = loss_fcn(logits, labels); loss.backward()) as TWO launches, cut where the data
+ * crosses destinations (before: ogl_small_pool_layer_fwd + ogl_ce_fwd_bwd_mean_gather + ogl_small_pool_layer_bwd = five launches and
+ * a fill; the same bits).  ogl_small_pool_loss_fits: ogl_small_pool_layer_fits and n_dst <= 128, fanout <= 64.
+ *   ogl_small_pool_layer_fwd_ce_bwd: one workgroup per destination projects that destination's neighbour rows, takes the max, forms
+ *        the logits and the row's cross entropy, dlogits = (softmax - onehot) * grad_scale, and the two input gradients of the combine.
+ *        labels: label of row d = label_table[label_ids[d]] (label_ids NULL: label_table[d]); an id outside [0, n_labels) = no label.
+ *        Outputs: y = logits [n_dst, Hout], loss_rows [n_dst], dlogits [n_dst, Hout], neigh [n_dst, Hin], argmax int32 [n_dst, Hin],
+ *        G float [n_dst * Hin] (the winners' routed gradient), dh [n_src, Hin] (nullable; written completely: the fc_self path in the
+ *        destinations' rows, zeros behind them).  *loss_mean is set to NaN: its value is the backward launch's.
+ *        zero_buf / zero_floats (multiple of 4, 16-byte aligned, nullable): a caller buffer cleared by fill-only blocks of the grid.
+ *   ogl_small_pool_layer_bwd_pool: block 0 sums what crosses destinations — dWs / dWn [Hout, Hin], dbs / dbn [Hout] (nullable) from
+ *        dlogits, h's head rows and neigh; *loss_mean = mean(loss_rows); step_dev / scalars_dev (both or neither): the optimiser's
+ *        per-step scalars as in ogl_ce_fwd_bwd_mean_gather_adam — the other blocks run fc_pool through the winners: dWp [Hin, Hin],
+ *        dbp (nullable), the winners' rows added into dh with float atomics.  A root gradient other than 1: scale dlogits, G and dh
+ *        before this call. */
+int ogl_small_pool_loss_fits(int64_t n_src, int64_t n_dst, int fanout, int Hin, int Hout);
+int ogl_small_pool_layer_fwd_ce_bwd(const float* h, int64_t ldh, int64_t n_src, const int32_t* idx, int64_t n_dst, int fanout, int Hin,
+                                    const float* Wp, int64_t ldwp, const float* bp, const float* Ws, int64_t ldws, const float* bs,
+                                    const float* Wn, int64_t ldwn, const float* bn, int Hout, const int64_t* label_table,
+                                    int64_t n_labels, const int64_t* label_ids, float grad_scale, float* neigh, int64_t ldn,
+                                    int32_t* argmax, float* y, int64_t ldy, float* loss_rows, float* loss_mean, float* dlogits,
+                                    int64_t lddl, float* G, float* dh, int64_t lddh, float* zero_buf, int64_t zero_floats,
+                                    ogl_stream_t stream);
+int ogl_small_pool_layer_bwd_pool(const float* h, int64_t ldh, int64_t n_dst, int Hin, int Hout, const int32_t* argmax, const float* G,
+                                  const float* Wp, int64_t ldwp, const float* neigh, int64_t ldn, const float* dlogits, int64_t lddl,
+                                  const float* loss_rows, float* dWp, int64_t lddwp, float* dbp, float* dWs, int64_t lddws, float* dbs,
+                                  float* dWn, int64_t lddwn, float* dbn, float* dh, int64_t lddh, float* loss_mean, int64_t* step_dev,
+                                  float* scalars_dev, double lr, double beta1, double beta2, ogl_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Device-side prioritised replay structure (replay.hip): the sum tree of R/train/prioritized_replay/segment_tree.py:69-125
  * and the priority arithmetic of R/train/prioritized_replay/replay_buffer.py:110-245 on arrays in HBM, fed from the per-seed

@@ -124,6 +124,11 @@ SIGNATURES = {
                                       _i64, _p, _p]),
     "ogl_small_pool_layer_bwd": (_i, [_p, _i64, _p, _i64, _i, _p, _i64, _i64, _i64, _i, _i, _i, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64,
                                       _p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _p]),
+    "ogl_small_pool_loss_fits": (_i, [_i64, _i64, _i, _i, _i]),
+    "ogl_small_pool_layer_fwd_ce_bwd": (_i, [_p, _i64, _i64, _p, _i64, _i, _i, _p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _i, _p, _i64, _p, _f,
+                                             _p, _i64, _p, _p, _i64, _p, _p, _p, _i64, _p, _p, _i64, _p, _i64, _p]),
+    "ogl_small_pool_layer_bwd_pool": (_i, [_p, _i64, _i64, _i, _i, _p, _p, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _i64, _p,
+                                           _p, _i64, _p, _p, _i64, _p, _p, _p, _d, _d, _d, _p]),
     "ogl_replay_update": (_i, [_p, _i64, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _p, _p, _p, _p]),
     "ogl_replay_rebuild": (_i, [_p, _i64, _p]),
     "ogl_replay_sample": (_i, [_p, _i64, _i64, _i64, _p, _p, _i64, _p, _p, _p]),

@@ -222,6 +222,350 @@ extern "C" int ogl_small_pool_layer_bwd(const float* dy, int64_t lddy, const flo
   return OGL_OK;
 }
 
+// ---- the LAST small 'pool' layer of a train step together with nn.CrossEntropyLoss(reduction='mean') -------------------------------
+// (R/train/graphsage/pytorch/model.py:87-107: logits = model(blocks, x); loss = loss_fcn(logits, labels); loss.backward()).
+// At the 32-seed rungs that tail of the step was five launches at the dispatch floor and a fill — k_small_proj, k_small_combine, the
+// one-workgroup cross entropy, k_small_bwd_a, k_small_bwd_b, the zero fill of the first layer's scatter target: 43 us of a 0.2 ms step.
+// Here it is TWO launches, cut where the data crosses destinations:
+//   forward (k_small_loss), one workgroup per destination d: the S neighbour rows of h staged in LDS, P = relu(rows . Wp^T + bp) for
+//     THOSE rows only (a source picked by two destinations is projected twice: 800 row products instead of <= 832, and no [n_src, Hin]
+//     intermediate), neighbour max, logits, the row's cross entropy, dlogits = (softmax - onehot) * grad_scale, and from dlogits the
+//     two input gradients of the combine (G = dneigh masked by the winners, dh[d] = the fc_self path).  The combine's weights are
+//     requested at the top of the block and parked in LDS over Wp / the neighbour rows once those are done with (a lane walking a
+//     weight row in global memory is a chain of L2 latencies: what k_small_combine's 8 us are).  dh's rows behind the destinations
+//     are zeroed by the row blocks; a caller buffer (the first layer's scatter target: megabytes at these rungs) by fill-only
+//     blocks behind them.  No block waits for another: the sums over destinations are the next launch's.
+//     (A first version finished them in the last block to count itself: a device-scope release per block writes back the L2 the
+//     fill blocks are dirtying — the launch took 23 us, and 30 beside a 10 MB fill.)
+//   backward (k_small_bwd_b2): block 0 sums what crosses destinations — dWs, dWn, dbs, dbn (rows staged through LDS in chunks of 32
+//     destinations, destination order), the mean of the row losses (the order of k_ce_fwd_bwd_mean) and the optimiser's per-step
+//     scalars (the passenger of ogl_ce_fwd_bwd_mean_gather_adam); the other blocks are k_small_bwd_b (fc_pool through the winners).
+// Every sum runs in the order of the kernels above, so the bits are theirs.  The VALUE of the mean loss exists after the backward
+// launch (NaN until then: the contract of GraphSAGE.forward_loss(defer_mean=True)).  The root gradient of the loss is taken to be 1
+// (ops.backward's unit gradient); the caller scales dlogits / G / dh for any other before the backward launch.
+#define SLL_CHUNK 32
+#define SLL_MAX_DST 128
+#define SLL_MAX_S 64
+
+struct SmallLossArgs {
+  const float* h; int64_t ldh; int n_src; const int32_t* idx; int n_dst, S, Hin;
+  const float* Wp; int64_t ldwp; const float* bp;
+  const float* Ws; int64_t ldws; const float* bs;
+  const float* Wn; int64_t ldwn; const float* bn; int Hout;
+  const int64_t* labels; int64_t n_labels; const int64_t* label_ids; float grad_scale;
+  float* neigh; int64_t ldn; int32_t* argmax; float* y; int64_t ldy; float* loss_rows; float* loss_mean; float* dl; int64_t lddl;
+  float* G; float* dh; int64_t lddh;
+  float4* zero_buf; int64_t zero_n4;
+};
+
+__device__ __forceinline__ float sll_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float sll_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ void __launch_bounds__(256) k_small_loss(SmallLossArgs a) {
+  __shared__ float W[SL_MAX_H * (SL_MAX_H + 1)];            // Wp, row stride Hin + 1;    then Ws
+  __shared__ float R[SLL_MAX_S * (SL_MAX_H + 1)];           // the neighbours' rows of h; then Wn
+  __shared__ float P[SLL_MAX_S * (SL_MAX_H + 1)];           // relu(fc_pool) of those rows
+  __shared__ float NB[SL_MAX_H], DY[SL_MAX_H], HD[SL_MAX_H];
+  __shared__ int ARG[SL_MAX_H];
+  const int tid = threadIdx.x, Hin = a.Hin, Hout = a.Hout, S = a.S, ldw = Hin + 1;
+  const int n_w = Hout * Hin;
+  if ((int)blockIdx.x >= a.n_dst) {                          // fill-only blocks: the caller's buffer
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t nb = (int64_t)gridDim.x - a.n_dst;
+    for (int64_t i = ((int64_t)blockIdx.x - a.n_dst) * 256 + tid; i < a.zero_n4; i += nb * 256) a.zero_buf[i] = z;
+    return;
+  }
+  const int d = blockIdx.x;
+  const int32_t* row = a.idx + (int64_t)d * S;
+  // requested first, used last: the combine's weights (registers now, LDS once Wp and the neighbour rows are done with)
+  float ws_r[16], wn_r[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int o = tid + 256 * q;
+    ws_r[q] = wn_r[q] = 0.f;
+    if (o < n_w) {
+      const int c = o / Hin, k = o - c * Hin;
+      ws_r[q] = a.Ws[(int64_t)c * a.ldws + k];
+      wn_r[q] = a.Wn[(int64_t)c * a.ldwn + k];
+    }
+  }
+  const float bias_c = (tid < Hout) ? (a.bs ? a.bs[tid] : 0.f) + (a.bn ? a.bn[tid] : 0.f) : 0.f;
+  if (tid < Hin) HD[tid] = a.h[(int64_t)d * a.ldh + tid];
+  for (int i = tid; i < Hin * Hin; i += 256) {
+    const int j = i / Hin, k = i - j * Hin;
+    W[j * ldw + k] = a.Wp[(int64_t)j * a.ldwp + k];
+  }
+  for (int i = tid; i < S * Hin; i += 256) {
+    const int s = i / Hin, k = i - s * Hin;
+    const int32_t r = row[s];
+    R[s * ldw + k] = (r >= 0 && r < a.n_src) ? a.h[(int64_t)r * a.ldh + k] : 0.f;
+  }
+  if (a.dh) {                                                // dh rows behind the destinations: zeros (the row blocks share them)
+    const int64_t nz = (int64_t)(a.n_src - a.n_dst) * Hin;
+    for (int64_t i = (int64_t)d * 256 + tid; i < nz; i += (int64_t)a.n_dst * 256)
+      a.dh[(a.n_dst + i / Hin) * a.lddh + i % Hin] = 0.f;
+  }
+  if (gridDim.x == (unsigned)a.n_dst) {                      // (no fill-only blocks: the caller's buffer too)
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = (int64_t)d * 256 + tid; i < a.zero_n4; i += (int64_t)a.n_dst * 256) a.zero_buf[i] = z;
+  }
+  __syncthreads();
+  for (int o = tid; o < S * Hin; o += 256) {                 // the arithmetic of k_small_proj
+    const int s = o / Hin, j = o - s * Hin;
+    const float* hr = R + s * ldw;
+    const float* wj = W + j * ldw;
+    float acc = a.bp ? a.bp[j] : 0.f;
+#pragma unroll 8
+    for (int k = 0; k < Hin; ++k) acc = fmaf(hr[k], wj[k], acc);
+    P[s * ldw + j] = fmaxf(acc, 0.f);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {                             // Ws over Wp, Wn over the neighbour rows (row stride Hin + 1)
+    const int o = tid + 256 * q;
+    if (o < n_w) {
+      const int c = o / Hin, k = o - c * Hin;
+      W[c * ldw + k] = ws_r[q];
+      R[c * ldw + k] = wn_r[q];
+    }
+  }
+  if (tid < Hin) {                                           // the neighbour max of k_small_combine (first slot wins ties)
+    float best = 0.f;
+    int32_t arg = -1;
+    if (row[0] >= 0) {
+      best = -INFINITY;
+      for (int s = 0; s < S; ++s) {
+        const int32_t r = row[s];
+        if (r < 0 || r >= a.n_src) continue;
+        const float v = P[s * ldw + tid];
+        if (v > best) { best = v; arg = r; }
+      }
+      if (arg < 0) best = 0.f;
+    }
+    NB[tid] = best;
+    ARG[tid] = arg;
+    a.neigh[(int64_t)d * a.ldn + tid] = best;
+    a.argmax[(int64_t)d * Hin + tid] = arg;
+  }
+  __syncthreads();
+  if (tid < 64) {                                            // wave 0: logits of row d, then its cross entropy (k_ce_fwd_bwd_mean's)
+    const int c = tid;
+    float x = -INFINITY;
+    if (c < Hout) {
+      const float* ws = W + c * ldw;
+      const float* wn = R + c * ldw;
+      float acc = bias_c;
+#pragma unroll 8
+      for (int k = 0; k < Hin; ++k) acc = fmaf(HD[k], ws[k], acc);
+#pragma unroll 8
+      for (int k = 0; k < Hin; ++k) acc = fmaf(NB[k], wn[k], acc);
+      a.y[(int64_t)d * a.ldy + c] = acc;
+      x = acc;
+    }
+    const float m = sll_wave_max(x);
+    const float s = sll_wave_sum(c < Hout ? expf(x - m) : 0.f);
+    const float lse = m + logf(s);
+    int64_t yl;
+    if (a.label_ids) {
+      const int64_t id = a.label_ids[d];
+      yl = (id >= 0 && id < a.n_labels) ? a.labels[id] : -1;
+    } else yl = a.labels[d];
+    const bool ok = yl >= 0 && yl < Hout;
+    const float xy = __shfl(x, ok ? (int)yl : 0);
+    if (c == 0) a.loss_rows[d] = ok ? lse - xy : 0.f;
+    if (c < Hout) {
+      const float g = a.grad_scale * (expf(x - lse) - ((ok && c == (int)yl) ? 1.f : 0.f));
+      a.dl[(int64_t)d * a.lddl + c] = g;
+      DY[c] = g;
+    }
+  }
+  __syncthreads();
+  if (tid < Hin) {                                           // the (d, k) items of k_small_bwd_a
+    const int k = tid;
+    float dn = 0.f, dx = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < Hout; ++c) {
+      const float g = DY[c];
+      dn = fmaf(g, R[c * ldw + k], dn);
+      dx = fmaf(g, W[c * ldw + k], dx);
+    }
+    a.G[d * Hin + k] = (NB[k] > 0.f && ARG[k] >= 0) ? dn : 0.f;
+    if (a.dh) a.dh[(int64_t)d * a.lddh + k] = dx;
+  }
+  if (d == 0 && tid == 0) *a.loss_mean = __builtin_nanf("");     // (its value is the backward launch's)
+}
+
+struct SmallBwdArgs {
+  const float* h; int64_t ldh; int n_dst, Hin, Hout;
+  const int32_t* argmax; const float* G; const float* Wp; int64_t ldwp;
+  const float* neigh; int64_t ldn; const float* dl; int64_t lddl; const float* loss_rows;
+  float* dWp; int64_t lddwp; float* dbp; float* dWs; int64_t lddws; float* dbs; float* dWn; int64_t lddwn; float* dbn;
+  float* dh; int64_t lddh; float* loss_mean;
+  int64_t* adam_step; float* adam_scal; double adam_lr, adam_b1, adam_b2;
+};
+
+__global__ void __launch_bounds__(256) k_small_bwd_b2(SmallBwdArgs a) {
+  const int tid = threadIdx.x, Hin = a.Hin, Hout = a.Hout;
+  if (blockIdx.x == 0) {
+    // ---- everything that sums over destinations of the combine, in destination order ----
+    __shared__ float DYc[SLL_CHUNK * SL_MAX_H], Hc[SLL_CHUNK * SL_MAX_H], Nc[SLL_CHUNK * SL_MAX_H];
+    if (a.adam_step && tid == 255) {
+      const int64_t t = *a.adam_step + 1;
+      *a.adam_step = t;
+      a.adam_scal[0] = (float)(a.adam_lr / (1.0 - pow(a.adam_b1, (double)t)));
+      a.adam_scal[1] = (float)(1.0 / sqrt(1.0 - pow(a.adam_b2, (double)t)));
+    }
+    if (tid >= 192) {                                        // wave 3, fixed order: lane l sums rows l, l + 64, ...; then the lanes
+      const int lane = tid - 192;
+      float t = 0.f;
+      for (int r = lane; r < a.n_dst; r += 64) t += a.loss_rows[r];
+      t = sll_wave_sum(t);
+      if (lane == 0) *a.loss_mean = t / (float)a.n_dst;
+    }
+    float as[16], an[16];                                    // outputs o = tid + 256 q of the [Hout, Hin] weight gradients
+#pragma unroll
+    for (int q = 0; q < 16; ++q) as[q] = an[q] = 0.f;
+    float ab = 0.f;
+    const int n_w = Hout * Hin;
+    for (int d0 = 0; d0 < a.n_dst; d0 += SLL_CHUNK) {
+      const int nd = min(SLL_CHUNK, a.n_dst - d0);
+      __syncthreads();
+      for (int i = tid; i < nd * Hout; i += 256) {
+        const int dd = i / Hout, c = i - dd * Hout;
+        DYc[i] = a.dl[(int64_t)(d0 + dd) * a.lddl + c];
+      }
+      for (int i = tid; i < nd * Hin; i += 256) {
+        const int dd = i / Hin, k = i - dd * Hin;
+        Hc[i] = a.h[(int64_t)(d0 + dd) * a.ldh + k];
+        Nc[i] = a.neigh[(int64_t)(d0 + dd) * a.ldn + k];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int o = tid + 256 * q;
+        if (o < n_w) {
+          const int c = o / Hin, k = o - c * Hin;
+          float s0 = as[q], s1 = an[q];
+          for (int dd = 0; dd < nd; ++dd) {
+            const float g = DYc[dd * Hout + c];
+            s0 = fmaf(g, Hc[dd * Hin + k], s0);
+            s1 = fmaf(g, Nc[dd * Hin + k], s1);
+          }
+          as[q] = s0; an[q] = s1;
+        }
+      }
+      if (tid < Hout)
+        for (int dd = 0; dd < nd; ++dd) ab += DYc[dd * Hout + tid];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int o = tid + 256 * q;
+      if (o < n_w) {
+        const int c = o / Hin, k = o - c * Hin;
+        if (a.dWs) a.dWs[(int64_t)c * a.lddws + k] = as[q];
+        if (a.dWn) a.dWn[(int64_t)c * a.lddwn + k] = an[q];
+      }
+    }
+    if (tid < Hout) {
+      if (a.dbs) a.dbs[tid] = ab;
+      if (a.dbn) a.dbn[tid] = ab;
+    }
+    return;
+  }
+  // ---- the other blocks: k_small_bwd_b's flat item space ----
+  const int n_w = Hin * Hin, n_b = Hin, n_s = a.dh ? a.n_dst * Hin * Hin : 0;
+  const int total = n_w + n_b + n_s;
+  const int nblk = gridDim.x - 1;
+  for (int o = (blockIdx.x - 1) * 256 + tid; o < total; o += nblk * 256) {
+    if (o < n_w) {
+      const int j = o / Hin, k = o - j * Hin;
+      float acc = 0.f;
+#pragma unroll 8
+      for (int d = 0; d < a.n_dst; ++d) {
+        const float g = a.G[d * Hin + j];
+        const int32_t w = a.argmax[d * Hin + j];
+        acc = fmaf(g, a.h[(int64_t)(w < 0 ? 0 : w) * a.ldh + k], acc);
+      }
+      if (a.dWp) a.dWp[(int64_t)j * a.lddwp + k] = acc;
+    } else if (o < n_w + n_b) {
+      const int j = o - n_w;
+      float acc = 0.f;
+#pragma unroll 8
+      for (int d = 0; d < a.n_dst; ++d) acc += a.G[d * Hin + j];
+      if (a.dbp) a.dbp[j] = acc;
+    } else {
+      const int t = o - n_w - n_b, q = t / Hin, k = t - q * Hin;
+      const float g = a.G[q];
+      if (g == 0.f) continue;
+      const int j = q % Hin;
+      atomicAdd(&a.dh[(int64_t)a.argmax[q] * a.lddh + k], g * a.Wp[(int64_t)j * a.ldwp + k]);
+    }
+  }
+}
+
+extern "C" int ogl_small_pool_loss_fits(int64_t n_src, int64_t n_dst, int fanout, int Hin, int Hout) {
+  return ogl_small_pool_layer_fits(n_src, n_dst, fanout, Hin, Hout) && n_dst <= SLL_MAX_DST && fanout <= SLL_MAX_S;
+}
+
+extern "C" int ogl_small_pool_layer_fwd_ce_bwd(const float* h, int64_t ldh, int64_t n_src, const int32_t* idx, int64_t n_dst, int fanout,
+                                               int Hin, const float* Wp, int64_t ldwp, const float* bp, const float* Ws, int64_t ldws,
+                                               const float* bs, const float* Wn, int64_t ldwn, const float* bn, int Hout,
+                                               const int64_t* label_table, int64_t n_labels, const int64_t* label_ids, float grad_scale,
+                                               float* neigh, int64_t ldn, int32_t* argmax, float* y, int64_t ldy, float* loss_rows,
+                                               float* loss_mean, float* dlogits, int64_t lddl, float* G, float* dh, int64_t lddh,
+                                               float* zero_buf, int64_t zero_floats, ogl_stream_t stream) {
+  if (!ogl_small_pool_loss_fits(n_src, n_dst, fanout, Hin, Hout)) return OGL_EINVAL;
+  if (!h || !idx || !Wp || !Ws || !Wn || !label_table || !neigh || !argmax || !y || !loss_rows || !loss_mean || !dlogits || !G)
+    return OGL_EINVAL;
+  if (ldh < Hin || ldwp < Hin || ldws < Hin || ldwn < Hin || ldn < Hin || ldy < Hout || lddl < Hout || (dh && lddh < Hin) || n_labels < 0)
+    return OGL_EINVAL;
+  if (zero_floats < 0 || (zero_floats > 0 && (!zero_buf || ((uintptr_t)zero_buf & 15) || (zero_floats & 3)))) return OGL_EINVAL;
+  SmallLossArgs a;
+  a.h = h; a.ldh = ldh; a.n_src = (int)n_src; a.idx = idx; a.n_dst = (int)n_dst; a.S = fanout; a.Hin = Hin;
+  a.Wp = Wp; a.ldwp = ldwp; a.bp = bp; a.Ws = Ws; a.ldws = ldws; a.bs = bs; a.Wn = Wn; a.ldwn = ldwn; a.bn = bn; a.Hout = Hout;
+  a.labels = label_table; a.n_labels = n_labels; a.label_ids = label_ids; a.grad_scale = grad_scale;
+  a.neigh = neigh; a.ldn = ldn; a.argmax = argmax; a.y = y; a.ldy = ldy; a.loss_rows = loss_rows; a.loss_mean = loss_mean;
+  a.dl = dlogits; a.lddl = lddl; a.G = G; a.dh = dh; a.lddh = lddh; a.zero_buf = (float4*)zero_buf; a.zero_n4 = zero_floats / 4;
+  const int64_t extra = std::min<int64_t>(768, ogl_cdiv(zero_floats, 4096));     // fill-only blocks behind the n_dst row blocks
+  hipLaunchKernelGGL(k_small_loss, dim3((unsigned)(n_dst + extra)), dim3(256), 0, (hipStream_t)stream, a);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+// the rest of that layer's backward: the sums over destinations of the combine (dWs, dWn, dbs, dbn, the mean loss, the optimiser's
+// per-step scalars) in block 0, fc_pool through the winners (dWp, dbp, the atomics into dh) in the others
+extern "C" int ogl_small_pool_layer_bwd_pool(const float* h, int64_t ldh, int64_t n_dst, int Hin, int Hout, const int32_t* argmax,
+                                             const float* G, const float* Wp, int64_t ldwp, const float* neigh, int64_t ldn,
+                                             const float* dlogits, int64_t lddl, const float* loss_rows, float* dWp, int64_t lddwp,
+                                             float* dbp, float* dWs, int64_t lddws, float* dbs, float* dWn, int64_t lddwn, float* dbn,
+                                             float* dh, int64_t lddh, float* loss_mean, int64_t* step_dev, float* scalars_dev, double lr,
+                                             double beta1, double beta2, ogl_stream_t stream) {
+  if (n_dst <= 0 || n_dst > SLL_MAX_DST || Hin <= 0 || Hin > SL_MAX_H || Hout <= 0 || Hout > SL_MAX_H) return OGL_EINVAL;
+  if (n_dst * (int64_t)(Hin > Hout ? Hin : Hout) > 8192) return OGL_EINVAL;
+  if (!h || !argmax || !G || !Wp || !neigh || !dlogits || !loss_rows || !loss_mean) return OGL_EINVAL;
+  if (ldh < Hin || ldwp < Hin || ldn < Hin || lddl < Hout || (dWp && lddwp < Hin) || (dWs && lddws < Hin) || (dWn && lddwn < Hin) ||
+      (dh && lddh < Hin) || (step_dev != nullptr) != (scalars_dev != nullptr))
+    return OGL_EINVAL;
+  SmallBwdArgs a;
+  a.h = h; a.ldh = ldh; a.n_dst = (int)n_dst; a.Hin = Hin; a.Hout = Hout; a.argmax = argmax; a.G = G; a.Wp = Wp; a.ldwp = ldwp;
+  a.neigh = neigh; a.ldn = ldn; a.dl = dlogits; a.lddl = lddl; a.loss_rows = loss_rows; a.dWp = dWp; a.lddwp = lddwp; a.dbp = dbp;
+  a.dWs = dWs; a.lddws = lddws; a.dbs = dbs; a.dWn = dWn; a.lddwn = lddwn; a.dbn = dbn; a.dh = dh; a.lddh = lddh; a.loss_mean = loss_mean;
+  a.adam_step = step_dev; a.adam_scal = scalars_dev; a.adam_lr = lr; a.adam_b1 = beta1; a.adam_b2 = beta2;
+  const int64_t items_b = (int64_t)Hin * Hin + Hin + (dh ? n_dst * Hin * (int64_t)Hin : 0);
+  hipLaunchKernelGGL(k_small_bwd_b2, dim3((unsigned)(1 + std::min<int64_t>(ogl_cdiv(items_b, 256), 1024))), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
 // workspace (floats): forward n_src * Hin (the projected rows), backward n_dst * Hin (the routed gradient)
 extern "C" int64_t ogl_small_pool_layer_workspace_floats(int64_t n_src, int64_t n_dst, int Hin) {
   if (n_src < 0 || n_dst < 0 || Hin < 0) return OGL_EINVAL;

@@ -1677,6 +1677,8 @@ CE_MEAN_SMALL_MAX_B = 128      # up to here the mean comes from the cross-entrop
 
 
 CE_SMALL_MAX_ZERO = 65536       # floats the one-workgroup loss launch clears on the side (ogl_ce_fwd_bwd_mean_gather)
+SMALL_LOSS_FUSED = os.environ.get("OGL_SMALL_LOSS_FUSED", "1") != "0"    # the last small 'pool' layer + its loss + the dlogits-only gradients: ONE launch
+SMALL_LOSS_ZERO_MAX = 1 << 23   # floats the fused small output layer + loss launch clears on the side (ogl_small_pool_layer_fwd_ce_bwd)
 
 
 def ce_fwd_bwd_mean(logits, labels, want_grad=True):
@@ -2376,8 +2378,10 @@ class _PoolMaxFn(torch.autograd.Function):
             # layer 0 (see backward): the gradient-free half of the pool backward starts here, beside the products that follow
             ctx.pool_plan = pool_bwd_x3_plan(argmax, out, idx, ctx.n_src)
         ctx.dp_slot = None
-        if need and ctx.pool_plan is None and max(ctx.n_src, 1) * padded_ld(out.shape[1]) <= CE_SMALL_MAX_ZERO:
-            # a small scatter target: the loss launch that runs between this forward and its backward clears it on the side
+        if need and ctx.pool_plan is None and max(ctx.n_src, 1) * padded_ld(out.shape[1]) <= (SMALL_LOSS_ZERO_MAX if SMALL_LOSS_FUSED else CE_SMALL_MAX_ZERO):
+            # a small scatter target: the loss launch that runs between this forward and its backward clears it on the side (the
+            # one-workgroup loss up to CE_SMALL_MAX_ZERO floats, the fused small output layer + loss — a grid — up to SMALL_LOSS_ZERO_MAX;
+            # a request nobody serves is filled by ``take_zeroed``)
             ctx.dp_slot = request_zeroed(ctx.n_src, out.shape[1], out.device)
         ctx.save_for_backward(x, w, x_rows, out, argmax, idx if idx.dtype == torch.int32 else None)
         return out
@@ -2811,7 +2815,12 @@ def sage_mean_layer_loss(h, w_cat, bias, idx, n_dst, labels, defer_mean=False, p
 def sage_pool_layer_loss(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels, defer_mean=False):
     """(mean CE loss, per-seed losses, logits) of the last 'pool' layer + nn.CrossEntropyLoss, or None when the fused form does not
     apply (the caller then runs the layer and the loss separately)."""
-    if h.dim() != 2 or small_pool_layer_fits(h.shape[0], n_dst, idx.shape[1], h.shape[1], w_self.shape[0]):
+    if h.dim() != 2:
+        return None
+    if small_pool_layer_fits(h.shape[0], n_dst, idx.shape[1], h.shape[1], w_self.shape[0]):
+        # (two launches for the layer, its loss and their backward; the mean's VALUE comes from the second: deferring callers only)
+        if defer_mean and DEFER_LOSS_MEAN and small_pool_loss_fits(h, w_pool, w_self, w_neigh, idx, n_dst, labels):
+            return _SmallPoolLossFn.apply(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels)
         return None
     if (b_self is None) != (b_neigh is None) or not out_loss_fits(h, n_dst, idx, w_self, w_neigh, w_pool.shape[0]):
         return None
@@ -2877,6 +2886,115 @@ class _SmallPoolLayerFn(torch.autograd.Function):
                 _ptr(w_pool), _ld(w_pool), _ptr(w_self), _ld(w_self), _ptr(w_neigh), _ld(w_neigh), _ptr(dwp), hin, _ptr(dbp),
                 _ptr(dws), hin, _ptr(dbs), _ptr(dwn), hin, _ptr(dbn), _ptr(dh), _ld(dh) if dh is not None else 0, _ptr(ws), _stream(),
                 meta=dict(n_src=n_src, n_dst=ctx.n_dst, hin=hin, hout=hout))
+        return dh, dwp, dbp, dws, dwn, dbs, dbn, None, None, None
+
+
+
+
+def small_pool_loss_fits(h, w_pool, w_self, w_neigh, idx, n_dst, labels):
+    """The last layer of a 32-seed step qualifies for ``_SmallPoolLossFn`` (ogl_small_pool_loss_fits + every weight differentiable)."""
+    if not (SMALL_LOSS_FUSED and torch.is_grad_enabled() and w_pool.requires_grad and w_self.requires_grad and w_neigh.requires_grad):
+        return False
+    if idx.dtype != torch.int32 or not idx.is_contiguous() or idx.shape[0] != n_dst or labels.numel() != n_dst:
+        return False
+    return bool(_lib.lib().ogl_small_pool_loss_fits(int(h.shape[0]), int(n_dst), int(idx.shape[1]), int(h.shape[1]), int(w_self.shape[0])))
+
+
+class _SmallPoolLossFn(torch.autograd.Function):
+    """The LAST small 'pool' layer of a train step with nn.CrossEntropyLoss(reduction='mean'), one autograd node of TWO launches
+    (R/train/graphsage/pytorch/model.py:87-107 on the 32-seed rungs), cut where the data crosses destinations: forward =
+    ogl_small_pool_layer_fwd_ce_bwd — one workgroup per destination: layer, row loss, dlogits, the combine's two input gradients, and on
+    the side the zero fill a first layer parked for its scatter target (``request_zeroed``, any size); backward =
+    ogl_small_pool_layer_bwd_pool — the sums over destinations (dWs, dWn, bias gradients, the MEAN LOSS, the optimiser's per-step
+    scalars) in one block, fc_pool through the winners in the others.  Before: 2 + 1 + 2 launches and a fill.  Same bits as those.
+    Only for callers that own the backward (``defer_mean``): the loss tensor holds NaN until the backward launch has run.
+    Returns (mean loss, per-seed losses, logits); only the mean is differentiable."""
+
+    @staticmethod
+    def forward(ctx, h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels):
+        h = as_mat(h); w_pool = as_mat(w_pool); w_self = as_mat(w_self); w_neigh = as_mat(w_neigh)
+        n_src, hin = h.shape
+        hout = w_self.shape[0]
+        dev = h.device
+        lazy = labels if isinstance(labels, LazyLabels) else None
+        if lazy is None:
+            labels = labels.reshape(-1)
+            assert labels.dtype == torch.int64 and labels.is_cuda and labels.is_contiguous()
+        table, ids = (lazy.table, lazy.ids) if lazy is not None else (labels, None)
+        neigh = empty_mat(n_dst, hin, dev)
+        argmax = torch.empty((n_dst, hin), dtype=torch.int32, device=dev)
+        logits = empty_mat(n_dst, hout, dev)
+        rows = torch.empty(n_dst, dtype=torch.float32, device=dev)
+        mean = torch.empty((), dtype=torch.float32, device=dev)
+        dl = empty_mat(n_dst, hout, dev)
+        G = torch.empty(max(n_dst * hin, 4), dtype=torch.float32, device=dev)
+        dh = empty_mat(n_src, hin, dev) if h.requires_grad else None
+        stream = _stream()
+        zbuf, zn = None, 0
+        key = (dev.index, stream)
+        ent = _PENDING_ZERO.get(key)
+        if ent is not None and ent[0].numel() % 4 == 0:       # (any size: fill-only blocks of the grid)
+            del _PENDING_ZERO[key]
+            zbuf, zn = ent[0], ent[0].numel()
+            ent[3] = True
+        _launch("ogl_small_pool_layer_fwd_ce_bwd", _lib.lib().ogl_small_pool_layer_fwd_ce_bwd, _ptr(h), _ld(h), n_src, _ptr(idx), n_dst,
+                int(idx.shape[1]), hin, _ptr(w_pool), _ld(w_pool), _ptr(b_pool), _ptr(w_self), _ld(w_self), _ptr(b_self), _ptr(w_neigh),
+                _ld(w_neigh), _ptr(b_neigh), hout, _ptr(table), table.numel(), _ptr(ids), C.c_float(1.0 / n_dst), _ptr(neigh), _ld(neigh),
+                _ptr(argmax), _ptr(logits), _ld(logits), _ptr(rows), _ptr(mean), _ptr(dl), _ld(dl), _ptr(G), _ptr(dh),
+                _ld(dh) if dh is not None else 0, _ptr(zbuf), zn, stream,
+                meta=dict(n_src=n_src, n_dst=n_dst, hin=hin, hout=hout, zero_bytes=4 * zn))
+        # the optimiser's per-step scalars ride in this node's BACKWARD launch (the 32-seed steps have no weight-image launch): the
+        # request is taken here so that no launch in between serves it twice; without a backward the optimiser prepares itself
+        ctx.prime = None
+        prime = _ADAM_PRIME.get("req")
+        if prime is not None and ADAM_PRIME_IN_SPLIT:
+            ctx.prime, _ADAM_PRIME["req"] = prime, None
+        if _CAPTURE is not None:
+            _CAPTURE.append(dict(argmax=argmax, neigh=neigh, out=None))
+        ctx.n_dst, ctx.hout = n_dst, hout
+        ctx.flags = (b_pool is not None, b_self is not None, b_neigh is not None)
+        ctx.pre = (G, dh, rows, mean)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(h, w_pool, argmax, neigh, dl)
+        ctx.mark_non_differentiable(rows, logits)
+        return mean, rows, logits
+
+    @staticmethod
+    def backward(ctx, dloss, _drows, _dlogits):
+        h, w_pool, argmax, neigh, dl = ctx.saved_tensors
+        G, dh, rows, mean = ctx.pre
+        n_src, hin = h.shape
+        hout = ctx.hout
+        dev = h.device
+        unit = _UNIT_GRAD.get((dloss.device.type, dloss.device.index))
+        if not (unit is not None and dloss.data_ptr() == unit.data_ptr()):
+            # (a root gradient of the caller's own: everything the forward launch wrote is linear in it)
+            dls = empty_mat(dl.shape[0], dl.shape[1], dev)
+            torch.mul(dl, dloss, out=dls)
+            dl, G = dls, G * dloss
+            if dh is not None:
+                dhs = empty_mat(n_src, hin, dev)
+                torch.mul(dh, dloss, out=dhs)
+                dh = dhs
+        has_bp, has_bs, has_bn = ctx.flags
+        dwp = torch.empty((hin, hin), dtype=torch.float32, device=dev)
+        dbp = torch.empty(hin, dtype=torch.float32, device=dev) if has_bp else None
+        dws = torch.empty((hout, hin), dtype=torch.float32, device=dev)
+        dwn = torch.empty((hout, hin), dtype=torch.float32, device=dev)
+        dbs = torch.empty(hout, dtype=torch.float32, device=dev) if has_bs else None
+        dbn = torch.empty(hout, dtype=torch.float32, device=dev) if has_bn else None
+        step_dev = scal = None
+        lr = b1 = b2 = 0.0
+        if ctx.prime is not None:
+            step_dev, scal, lr, b1, b2 = ctx.prime
+            ctx.prime = None
+        _launch("ogl_small_pool_layer_bwd_pool", _lib.lib().ogl_small_pool_layer_bwd_pool, _ptr(h), _ld(h), ctx.n_dst, hin, hout, _ptr(argmax),
+                _ptr(G), _ptr(w_pool), _ld(w_pool), _ptr(neigh), _ld(neigh), _ptr(dl), _ld(dl), _ptr(rows), _ptr(dwp), hin, _ptr(dbp),
+                _ptr(dws), hin, _ptr(dbs), _ptr(dwn), hin, _ptr(dbn), _ptr(dh), _ld(dh) if dh is not None else 0, _ptr(mean), _ptr(step_dev),
+                _ptr(scal), C.c_double(lr), C.c_double(b1), C.c_double(b2), _stream(),
+                meta=dict(n_src=n_src, n_dst=ctx.n_dst, hin=hin, hout=hout, adam_prepare=step_dev is not None))
+        if step_dev is not None:
+            _ADAM_PRIME["served"] = (step_dev.data_ptr(), _capturing())
         return dh, dwp, dbp, dws, dwn, dbs, dbn, None, None, None
 
 

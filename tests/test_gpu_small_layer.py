@@ -129,3 +129,140 @@ def test_fused_weight_gradients_gather_their_rows_and_small_ce_mean():
         assert torch.equal(rows_l, ref_rows) and torch.equal(dl, ref_dl)
         want = torch.nn.functional.cross_entropy(logits.double(), labels)
         assert abs(float(mean) - float(want)) <= 1e-6 * max(1.0, abs(float(want)))
+
+
+@pytest.mark.parametrize("n_src,n_dst,S,hin,hout,bias,lazy", [
+    (832, 32, 25, 32, 40, True, True), (120, 32, 25, 32, 3, True, False), (300, 48, 7, 16, 16, True, True),
+    (90, 9, 5, 64, 64, False, False), (40, 40, 3, 8, 5, True, True), (5000, 100, 45, 32, 40, True, True), (64, 1, 64, 32, 2, True, False)])
+def test_small_output_layer_with_loss_in_one_launch(n_src, n_dst, S, hin, hout, bias, lazy):
+    """ogl_small_pool_layer_fwd_ce_bwd + ogl_small_pool_layer_bwd_pool (the last layer of a 32-seed step + its loss as two launches)
+    against the five launches they replace — bit for bit except where float atomics sum (dh) — and against the oracle's layer +
+    torch's cross entropy (forward rtol 1e-4 / atol 1e-5, gradients rtol 1e-3 / atol 1e-5).  Passengers: the zero fill of a parked
+    scatter target (any size; forward launch) and the optimiser's per-step scalars (backward launch)."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    rng = np.random.default_rng(7 * n_src + hin + S)
+    h = rng.standard_normal((n_src, hin)).astype(np.float32)
+    idx = rng.integers(0, n_src, size=(n_dst, S)).astype(np.int32)
+    idx[rng.random(n_dst) < 0.15] = -1
+    prm = O.init_layer_params("pool", hin, hout)
+    if not bias:
+        for k in list(prm):
+            if k.endswith(".bias"):
+                prm[k] = torch.zeros_like(prm[k])
+    T = 3 * n_dst + 5
+    table = torch.as_tensor(rng.integers(0, hout, size=T)).cuda()
+    ids = torch.as_tensor(rng.integers(0, T, size=n_dst)).cuda()
+    lab = torch.where((ids >= 0) & (ids < T), table[ids.clamp(0, T - 1)], torch.full_like(ids, -1))
+    idx_d = torch.as_tensor(idx).cuda()
+
+    def run(fused):
+        ops.SMALL_LOSS_FUSED = fused
+        try:
+            ht = ops.empty_mat(n_src, hin, "cuda").copy_(torch.as_tensor(h)).requires_grad_(True)
+            ps = {k: v.clone().cuda().requires_grad_(True) for k, v in prm.items()}
+            b = (lambda n: ps[n] if bias else None)
+            labels = ops.LazyLabels(table, ids) if lazy else lab
+            zrows, zcols = 700, 500                                      # a parked scatter target larger than the one-workgroup loss clears
+            ent = ops.request_zeroed(zrows, zcols, ht.device)
+            ent[0].fill_(float("nan"))
+            step_dev = torch.zeros(1, dtype=torch.int64, device="cuda") + 4
+            scal = torch.zeros(2, dtype=torch.float32, device="cuda")
+            ops.adam_prime(step_dev, scal, 1e-3, 0.9, 0.999)
+            args = (ht, ps["fc_pool.weight"], b("fc_pool.bias"), ps["fc_self.weight"], ps["fc_neigh.weight"], b("fc_self.bias"),
+                    b("fc_neigh.bias"), idx_d, n_dst)
+            assert ops.sage_pool_layer_loss(*args, labels) is None       # (a caller that does not own the backward: the separate launches)
+            out = ops.sage_pool_layer_loss(*args, labels, defer_mean=True)
+            assert (out is not None) == fused
+            if out is None:
+                logits = ops.sage_pool_layer(*args, False)
+                loss, rows = ops.cross_entropy_mean_rows(logits, labels)
+            else:
+                loss, rows, logits = out
+                assert torch.isnan(loss).all()                           # the mean's value is the backward launch's
+            z = ops.take_zeroed(ent, zrows, zcols)
+            assert ent[3] == fused and float(z.abs().max()) == 0.0 and not torch.isnan(ent[0]).any()
+            ops.backward(loss)
+            primed = ops.adam_primed(step_dev)
+            if fused:
+                assert primed and int(step_dev) == 5
+                np.testing.assert_allclose(scal.cpu().numpy(), [1e-3 / (1 - 0.9 ** 5), 1 / (1 - 0.999 ** 5) ** 0.5], rtol=1e-6)
+            g = {k: (v.grad.clone() if v.grad is not None else None) for k, v in ps.items()}
+            return loss.detach().clone(), rows.detach().clone(), logits.detach().clone(), ht.grad.clone(), g
+        finally:
+            ops.SMALL_LOSS_FUSED = True
+    l1, r1, y1, dh1, g1 = run(True)
+    l0, r0, y0, dh0, g0 = run(False)
+    assert torch.equal(y1, y0) and torch.equal(r1, r0) and torch.equal(l1, l0)
+    for k in prm:
+        if k.endswith(".bias") and not bias:
+            continue
+        assert torch.equal(g1[k], g0[k]), k
+    np.testing.assert_allclose(dh1.cpu().numpy(), dh0.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # the oracle's layer + torch's loss
+    hr = torch.tensor(h, requires_grad=True)
+    pr = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
+    yr = O.sageconv_forward("pool", hr, n_dst, idx, pr, activation=None)
+    labc = lab.cpu()
+    rows_ref = F.cross_entropy(yr, labc.clamp(min=0), reduction="none") * (labc >= 0)
+    (rows_ref.sum() / n_dst).backward()
+    np.testing.assert_allclose(y1.cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(r1.cpu().numpy(), rows_ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    assert abs(float(l1) - float(rows_ref.sum() / n_dst)) <= 1e-5 * max(1.0, abs(float(l1)))
+    np.testing.assert_allclose(dh1.cpu().numpy(), hr.grad.numpy(), rtol=1e-3, atol=1e-5)
+    for k in prm:
+        if k.endswith(".bias") and not bias:
+            continue
+        np.testing.assert_allclose(g1[k].cpu().numpy(), pr[k].grad.numpy(), rtol=1e-3, atol=1e-5, err_msg=k)
+
+
+def test_small_output_layer_loss_with_a_root_gradient_and_replayed():
+    """A root gradient that is not ops.backward's unit scalar scales what the forward launch already wrote; and the two launches
+    replay inside a hipGraph."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    torch.manual_seed(5)
+    n_src, n_dst, S, hin, hout = 400, 32, 25, 32, 7
+    prm = {k: v.cuda() for k, v in O.init_layer_params("pool", hin, hout).items()}
+    idx = torch.randint(0, n_src, (n_dst, S), dtype=torch.int32, device="cuda")
+    lab = torch.randint(0, hout, (n_dst,), device="cuda")
+    h0 = ops.empty_mat(n_src, hin, "cuda").copy_(torch.randn(n_src, hin, device="cuda"))
+
+    def step(h, scale):
+        ps = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
+        ht = h.detach().requires_grad_(True)
+        loss, rows, logits = ops.sage_pool_layer_loss(ht, ps["fc_pool.weight"], ps["fc_pool.bias"], ps["fc_self.weight"], ps["fc_neigh.weight"],
+                                                      ps["fc_self.bias"], ps["fc_neigh.bias"], idx, n_dst, lab, defer_mean=True)
+        if scale is None:
+            ops.backward(loss)
+        else:
+            loss.backward(torch.full((), scale, device="cuda"))
+        return loss.detach(), ht.grad, {k: v.grad for k, v in ps.items()}
+    l1, dh1, g1 = step(h0, None)
+    l3, dh3, g3 = step(h0, 3.0)
+    assert torch.equal(l1, l3)
+    np.testing.assert_allclose(dh3.cpu().numpy(), 3.0 * dh1.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    for k in g1:
+        np.testing.assert_allclose(g3[k].cpu().numpy(), 3.0 * g1[k].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+    # replayed: static input, three replays with different rows
+    hs = h0.clone()
+    ops.unit_grad(hs.device)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step(hs, None)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ls, dhs, gs = step(hs, None)
+    for seed in (1, 2, 3):
+        torch.manual_seed(seed)
+        hs.copy_(torch.randn(n_src, hin, device="cuda"))
+        g.replay()
+        torch.cuda.synchronize()
+        le, dhe, ge = step(hs.clone(), None)
+        assert torch.equal(ls, le)
+        for k in ge:
+            assert torch.equal(gs[k], ge[k]), k
+        np.testing.assert_allclose(dhs.cpu().numpy(), dhe.cpu().numpy(), rtol=1e-5, atol=1e-6)
