@@ -96,6 +96,10 @@ def parse():
                     help="N > 1 / --force-dist: 1 = the replica's whole step (both RCCL all-reduces + Adam) inside the replayed hipGraph "
                          "(round 4's form; rehearsed on one rank only), 0 = forward + backward replayed, exchange and optimiser eager "
                          "(the default: graphsage/model.py DP_CAPTURE_COLLECTIVES)")
+    ap.add_argument("--dp-sharded-update", type=int, default=None, choices=[0, 1],
+                    help="N > 1 / --force-dist: 1 = the replica's exchange + optimiser as reduce-scatter -> Adam on this rank's 1 / N of the "
+                         "parameters -> all-gather of the weights (parallel.ShardedAdam: the late-exchange lever of DESIGN section 6), "
+                         "0 = all-reduce + the identical Adam on every rank (the default)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end snapshot leg (metric iii) of the default line")
     ap.add_argument("--e2e-snapshots", type=int, default=6)
     ap.add_argument("--partition", default="replicated", choices=["replicated", "features"],
@@ -187,6 +191,8 @@ def main():
     if args.dp_capture is not None:
         from ogl_amd.graphsage import model as _model_mod
         _model_mod.DP_CAPTURE_COLLECTIVES = bool(args.dp_capture)
+    if args.dp_sharded_update is not None:
+        parallel.SHARDED_UPDATE = bool(args.dp_sharded_update)
     ops.set_gemm_mode(args.gemm)
     wl = WORKLOADS[args.workload]
     B, S, H, bt = wl["batch"], wl["samples"], wl["hidden"], wl["batch_timestep"]
@@ -300,6 +306,9 @@ def main():
     collectives = None
     if getattr(strat, "gsync", None) is not None and not _dp_capture_on():
         strat.gsync.enable_timing(True)
+        shd = getattr(strat, "sharded", None)
+        if shd is not None:
+            shd.enable_timing(True)
         csteps = min(args.steps, max(bt, 20))
         cplan = plan(csteps)
         barrier()
@@ -309,7 +318,10 @@ def main():
         c_ms = 1000 * (time.perf_counter() - tc) / csteps
         tm = strat.gsync.timings()
         strat.gsync.enable_timing(False)
-        exposed = sum(tm[k][0] * tm[k][1] for k in ("single", "all", "late") if k in tm) / csteps
+        if shd is not None:                    # (the sharded update: both of its collectives are exposed — Adam sits between them)
+            tm.update(shd.timings())
+            shd.enable_timing(False)
+        exposed = sum(tm[k][0] * tm[k][1] for k in ("single", "all", "late", "reduce_scatter", "all_gather") if k in tm) / csteps
         collectives = {"ms_per_step_instrumented": round(c_ms, 4),
                        "per_kind": {k: {"mean_ms": round(v[0], 4), "per_step": round(v[1] / csteps, 2)} for k, v in tm.items()},
                        "exposed_exchange_ms_per_step": round(exposed, 4),
@@ -591,13 +603,15 @@ def main():
                                                        "larger bucket's graph" % (captures_timed, borrowed_timed))
                                                       if timed_mode.startswith("captured") else "")
                        + ("; auto policy probe: %s" % getattr(strat, "staged_auto_probe", None) if strat.use_graphs == "auto" else ""),
-                       "parallelism": "dp%d (seed-sharded replicas, two-bucket grad all-reduce %s)%s" % (
+                       "parallelism": "dp%d (seed-sharded replicas, two-bucket grad all-reduce %s)%s%s" % (
                            world, ("INSIDE the replayed step graph: the early bucket's RCCL all-reduce on the side branch under the layer-0 "
                                    "backward, the late bucket and the optimiser (device-side step count) behind it"
                                    if (dist.is_initialized() and dist.get_backend() == "nccl" and _dp_capture_on()) else
                                    "after the replayed forward + backward graph as ONE flat bucket; optimiser eager (the default since round 5; "
                                    "--dp-capture 1 records both into the graph)")
                            if "staged_dp" in forms_timed else "overlapped with backward",
+                           "; SHARDED UPDATE: reduce-scatter -> Adam on 1 / N of the flat parameters -> all-gather of the weights "
+                           "(--dp-sharded-update 1) instead of all-reduce + full Adam" if getattr(strat, "sharded", None) is not None else "",
                            " — FORCED through a world-size-1 RCCL group (--force-dist)" if args.force_dist else ""),
                        "avg_unique_input_nodes_n0": round(n0_avg, 1), "avg_n1": round(n1_avg, 1), "setup_s": round(setup_s, 1)},
             "roofline": roof_gemm if roof_gemm else roof_aggr,

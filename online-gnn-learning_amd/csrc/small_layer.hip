@@ -566,6 +566,251 @@ extern "C" int ogl_small_pool_layer_bwd_pool(const float* h, int64_t ldh, int64_
   return OGL_OK;
 }
 
+// ---- the FIRST 'pool' layer of a 32-seed step behind its fc_pool product: neighbour max + combine in one launch, and the head of its
+// backward in one launch --------------------------------------------------------------------------------------------------------------
+// The live layer's first layer (R/train/graphsage/pytorch/graphsage_dgl.py:26-31 -> DGL SAGEConv 'pool'; the reference's small settings:
+// in_feats 500 / 128, embedding_size 32, <= 832 destinations): P = relu(fc_pool(X[src])) is a real product and stays on the GEMM kernel;
+// everything behind it is latency.  Before: the max aggregator (9 us) + a skinny dual-input product (14 us) forward; the ReLU mask
+// (5 us) + the [n1, 32] x [32, F] input-gradient product (8 us) + the winners' scatter (11 us) backward.
+//   forward, one wave per destination d (lanes = float4 columns of a row, F <= 1024):
+//     neigh[d] = max_j P[idx[d, j]] with its argmax (the order of k_reduce_fwd_v4: first valid slot, then strictly greater), then
+//     y[d, c] = act(bs[c] + bn[c] + sum_k X[ids[d], k] Ws[c, k] + neigh[d, k] Wn[c, k]) for the 32 (padded) output columns: a lane
+//     forms its columns' share of all 32 sums, a halving butterfly (32 shuffles instead of 32 x 6) leaves column c in lane 2c;
+//   backward, one wave per destination: dy = dout . [y > 0];  dneigh[k] = sum_c dy[c] Wn[c, k] (lanes = columns k, dy[c] broadcast);
+//     then EITHER the dense dneigh row (the planned image path of the layer-0 weight gradient consumes it) OR the winners' scatter
+//     dP[argmax[d, k], k] += dneigh[k] . [neigh[d, k] > 0] with float atomics into a zeroed [n_src, F] matrix (k_reduce_bwd_max's).
+// Sums over k run lane-parallel and are joined by the butterfly: fp32 rounding differs from the GEMM kernels' order (tolerances of
+// tests/test_gpu_small_layer.py), the max / argmax are exact.
+#define SFL_H 32
+
+template <int NCH>
+__global__ void __launch_bounds__(256) k_small_first_fwd(const float* __restrict__ P, int64_t ldp, int n_src, const int32_t* __restrict__ idx,
+                                                         int n_dst, int S, int F, const float* __restrict__ table, int64_t ldt,
+                                                         const int64_t* __restrict__ ids, int64_t n_table, const float* __restrict__ Ws,
+                                                         int64_t ldws, const float* __restrict__ bs, const float* __restrict__ Wn,
+                                                         int64_t ldwn, const float* __restrict__ bn, int H, int relu_out,
+                                                         float* __restrict__ neigh, int64_t ldn, int32_t* __restrict__ argmax,
+                                                         float* __restrict__ y, int64_t ldy) {
+  const int lane = threadIdx.x & 63;
+  const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d >= n_dst) return;
+  const int f4 = (F + 3) >> 2;
+  float4 acc[NCH];
+  int arg[NCH][4];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    arg[c][0] = arg[c][1] = arg[c][2] = arg[c][3] = -1;
+  }
+  bool any = false;
+  const int32_t mine = lane < S ? idx[(int64_t)d * S + lane] : -1;         // S <= 64
+  for (int j0 = 0; j0 < S; j0 += 4) {
+    float4 v[4][NCH];
+    int r[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u;
+      const int q = __shfl(mine, j < S ? j : S - 1);
+      ok[u] = j < S && q >= 0 && q < n_src;
+      r[u] = ok[u] ? q : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float4* rp = (const float4*)(P + (int64_t)r[u] * ldp);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) v[u][c] = rp[min(c * 64 + lane, f4 - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!ok[u]) continue;                                             // wave-uniform
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (!any) {
+          acc[c] = v[u][c];
+          arg[c][0] = arg[c][1] = arg[c][2] = arg[c][3] = r[u];
+        } else {
+          if (v[u][c].x > acc[c].x) { acc[c].x = v[u][c].x; arg[c][0] = r[u]; }
+          if (v[u][c].y > acc[c].y) { acc[c].y = v[u][c].y; arg[c][1] = r[u]; }
+          if (v[u][c].z > acc[c].z) { acc[c].z = v[u][c].z; arg[c][2] = r[u]; }
+          if (v[u][c].w > acc[c].w) { acc[c].w = v[u][c].w; arg[c][3] = r[u]; }
+        }
+      }
+      any = true;
+    }
+  }
+  // the destination's own row (X[ids[d]]; an id outside the table: zeros) and the stores of neigh / argmax
+  const int64_t id = ids ? ids[d] : (int64_t)d;
+  const bool have = id >= 0 && id < n_table;
+  float4 xs[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = c * 64 + lane;
+    xs[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ch < f4) {
+      if (have) xs[c] = ((const float4*)(table + id * ldt))[ch];
+      const float av[4] = {acc[c].x, acc[c].y, acc[c].z, acc[c].w};
+      float xv[4] = {xs[c].x, xs[c].y, xs[c].z, xs[c].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = ch * 4 + e;
+        if (k < F) {
+          neigh[(int64_t)d * ldn + k] = av[e];
+          if (argmax) argmax[(int64_t)d * F + k] = arg[c][e];
+        } else {
+          xv[e] = 0.f;                                                  // (columns past F: padding of the last float4)
+        }
+      }
+      xs[c] = make_float4(xv[0], xv[1], xv[2], xv[3]);
+      if (ch * 4 + 3 >= F) {                                            // ... and of the reduced row
+        if (ch * 4 + 0 >= F) acc[c].x = 0.f;
+        if (ch * 4 + 1 >= F) acc[c].y = 0.f;
+        if (ch * 4 + 2 >= F) acc[c].z = 0.f;
+        if (ch * 4 + 3 >= F) acc[c].w = 0.f;
+      }
+    } else {
+      acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  // the combine: this lane's share of the 32 column sums
+  float part[SFL_H];
+#pragma unroll
+  for (int c = 0; c < SFL_H; ++c) {
+    float a = 0.f;
+    if (c < H) {
+#pragma unroll
+      for (int q = 0; q < NCH; ++q) {
+        const int ch = q * 64 + lane;
+        if (ch < f4) {
+          // (rows of Ws / Wn are contiguous, 16-byte aligned when ld % 4 == 0; the last float4 of a row whose length is not a multiple
+          // of 4 reaches into the next row: its x / neigh factors are zero)
+          const float4 w1 = *(const float4*)(Ws + (int64_t)c * ldws + ch * 4);
+          const float4 w2 = *(const float4*)(Wn + (int64_t)c * ldwn + ch * 4);
+          a = fmaf(xs[q].x, w1.x, a); a = fmaf(xs[q].y, w1.y, a); a = fmaf(xs[q].z, w1.z, a); a = fmaf(xs[q].w, w1.w, a);
+          a = fmaf(acc[q].x, w2.x, a); a = fmaf(acc[q].y, w2.y, a); a = fmaf(acc[q].z, w2.z, a); a = fmaf(acc[q].w, w2.w, a);
+        }
+      }
+    }
+    part[c] = a;
+  }
+  // halving butterfly: 32 values over 64 lanes -> column c in lanes 2c, 2c + 1
+#pragma unroll
+  for (int n = 16, off = 32; n >= 1; n >>= 1, off >>= 1) {
+    const bool hi = (lane & off) != 0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      const float keep = hi ? part[i + n] : part[i];
+      const float send = hi ? part[i] : part[i + n];
+      part[i] = keep + __shfl_xor(send, off);
+    }
+  }
+  part[0] += __shfl_xor(part[0], 1);
+  const int c = lane >> 1;
+  if ((lane & 1) == 0 && c < H) {
+    float o = part[0] + ((bs ? bs[c] : 0.f) + (bn ? bn[c] : 0.f));
+    y[(int64_t)d * ldy + c] = relu_out ? fmaxf(o, 0.f) : o;
+  }
+}
+
+template <int NCH>
+__global__ void __launch_bounds__(256) k_small_first_bwd(const float* __restrict__ dout, int64_t lddo, const float* __restrict__ y, int64_t ldy,
+                                                         int relu_out, int n_dst, int H, int F, const float* __restrict__ Wn, int64_t ldwn,
+                                                         const float* __restrict__ neigh, int64_t ldn, const int32_t* __restrict__ argmax,
+                                                         float* __restrict__ dy, int64_t lddy, float* __restrict__ dneigh, int64_t lddn,
+                                                         float* __restrict__ dP, int64_t lddp, int n_src) {
+  const int lane = threadIdx.x & 63;
+  const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d >= n_dst) return;
+  const int f4 = (F + 3) >> 2;
+  float g = 0.f;                                                          // lane c < H: dy[d, c]
+  if (lane < H) {
+    g = dout[(int64_t)d * lddo + lane];
+    if (relu_out && !(y[(int64_t)d * ldy + lane] > 0.f)) g = 0.f;
+    dy[(int64_t)d * lddy + lane] = g;
+  }
+  float4 acc[NCH];
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int c = 0; c < H; ++c) {                                           // (c ascending: the order of the input-gradient product's k loop)
+    const float gc = __shfl(g, c);
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int ch = q * 64 + lane;
+      if (ch < f4) {
+        const float4 w = *(const float4*)(Wn + (int64_t)c * ldwn + ch * 4);
+        acc[q].x = fmaf(gc, w.x, acc[q].x); acc[q].y = fmaf(gc, w.y, acc[q].y);
+        acc[q].z = fmaf(gc, w.z, acc[q].z); acc[q].w = fmaf(gc, w.w, acc[q].w);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const int ch = q * 64 + lane;
+    if (ch >= f4) continue;
+    const float av[4] = {acc[q].x, acc[q].y, acc[q].z, acc[q].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = ch * 4 + e;
+      if (k >= F) continue;
+      if (dneigh) dneigh[(int64_t)d * lddn + k] = av[e];
+      if (dP) {
+        const int32_t w = argmax[(int64_t)d * F + k];
+        if (w >= 0 && w < n_src && neigh[(int64_t)d * ldn + k] > 0.f) atomicAdd(&dP[(int64_t)w * lddp + k], av[e]);
+      }
+    }
+  }
+}
+
+extern "C" int ogl_small_first_layer_fits(int64_t n_src, int64_t n_dst, int fanout, int F, int H) {
+  return n_src > 0 && n_dst > 0 && n_dst <= n_src && n_dst <= 8192 && fanout > 0 && fanout <= 64 && F >= 16 && F <= 1024 && H > 0 &&
+         H <= SFL_H && n_src < (1 << 30);
+}
+
+extern "C" int ogl_small_first_layer_fwd(const float* P, int64_t ldp, int64_t n_src, const int32_t* idx, int64_t n_dst, int fanout, int F,
+                                         const float* table, int64_t ldt, const int64_t* ids, int64_t n_table, const float* Ws,
+                                         int64_t ldws, const float* bs, const float* Wn, int64_t ldwn, const float* bn, int H,
+                                         int relu_out, float* neigh, int64_t ldn, int32_t* argmax, float* y, int64_t ldy,
+                                         ogl_stream_t stream) {
+  if (!ogl_small_first_layer_fits(n_src, n_dst, fanout, F, H)) return OGL_EINVAL;
+  if (!P || !idx || !table || !Ws || !Wn || !neigh || !y || n_table <= 0) return OGL_EINVAL;
+  const int64_t f4x4 = ((int64_t)F + 3) / 4 * 4;
+  // float4 access: 16-byte rows everywhere a row is read or written as float4 (P, the table, the two weights)
+  if (ldp < f4x4 || ldt < f4x4 || (ldp & 3) || (ldt & 3) || (ldws & 3) || (ldwn & 3) || ldws < F || ldwn < F || ldn < F || ldy < H)
+    return OGL_EINVAL;
+  if (((uintptr_t)P & 15) || ((uintptr_t)table & 15) || ((uintptr_t)Ws & 15) || ((uintptr_t)Wn & 15)) return OGL_EINVAL;
+  const dim3 grid((unsigned)ogl_cdiv(n_dst, 4)), block(256);
+  const int nch = (int)ogl_cdiv(ogl_cdiv(F, 4), 64);
+#define SFL_FWD(N)                                                                                                                      \
+  hipLaunchKernelGGL(k_small_first_fwd<N>, grid, block, 0, (hipStream_t)stream, P, ldp, (int)n_src, idx, (int)n_dst, fanout, F, table, \
+                     ldt, ids, n_table, Ws, ldws, bs, Wn, ldwn, bn, H, relu_out, neigh, ldn, argmax, y, ldy)
+  if (nch == 1) SFL_FWD(1); else if (nch == 2) SFL_FWD(2); else if (nch == 3) SFL_FWD(3); else SFL_FWD(4);
+#undef SFL_FWD
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+// dy [n_dst, H] always; dneigh [n_dst, F] (nullable) and / or dP [n_src, F] (nullable, ZEROED by the caller: float atomics add into it)
+extern "C" int ogl_small_first_layer_bwd(const float* dout, int64_t lddo, const float* y, int64_t ldy, int relu_out, int64_t n_dst, int H,
+                                         int F, const float* Wn, int64_t ldwn, const float* neigh, int64_t ldn, const int32_t* argmax,
+                                         float* dy, int64_t lddy, float* dneigh, int64_t lddn, float* dP, int64_t lddp, int64_t n_src,
+                                         ogl_stream_t stream) {
+  if (n_dst <= 0 || n_dst > 8192 || H <= 0 || H > SFL_H || F < 16 || F > 1024 || n_src <= 0 || n_src >= (1 << 30)) return OGL_EINVAL;
+  if (!dout || !Wn || !dy || (relu_out && !y) || (!dneigh && !dP) || (dP && (!argmax || !neigh))) return OGL_EINVAL;
+  if (lddo < H || (relu_out && ldy < H) || lddy < H || ldwn < F || (ldwn & 3) || ((uintptr_t)Wn & 15) || (dneigh && lddn < F) ||
+      (dP && (lddp < F || ldn < F)))
+    return OGL_EINVAL;
+  const dim3 grid((unsigned)ogl_cdiv(n_dst, 4)), block(256);
+  const int nch = (int)ogl_cdiv(ogl_cdiv(F, 4), 64);
+#define SFL_BWD(N)                                                                                                                        \
+  hipLaunchKernelGGL(k_small_first_bwd<N>, grid, block, 0, (hipStream_t)stream, dout, lddo, y, ldy, relu_out, (int)n_dst, H, F, Wn, ldwn, \
+                     neigh, ldn, argmax, dy, lddy, dneigh, lddn, dP, lddp, (int)n_src)
+  if (nch == 1) SFL_BWD(1); else if (nch == 2) SFL_BWD(2); else if (nch == 3) SFL_BWD(3); else SFL_BWD(4);
+#undef SFL_BWD
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
 // workspace (floats): forward n_src * Hin (the projected rows), backward n_dst * Hin (the routed gradient)
 extern "C" int64_t ogl_small_pool_layer_workspace_floats(int64_t n_src, int64_t n_dst, int Hin) {
   if (n_src < 0 || n_dst < 0 || Hin < 0) return OGL_EINVAL;

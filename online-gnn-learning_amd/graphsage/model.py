@@ -185,6 +185,11 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         # (a replica's whole step — exchange included — is one captured graph too: the optimiser keeps its step count on the device;
         # its own two-part form is for the one-rank step: under data parallelism the early part would run before the all-reduce)
         capturable = bool(self.use_graphs)
+        # OGL_DP_SHARDED_UPDATE=1 (parallel.SHARDED_UPDATE; bench.py --dp-sharded-update 1): a replica's exchange + optimiser as
+        # reduce-scatter -> Adam on this rank's 1 / N of the parameters -> all-gather of the weights (parallel.ShardedAdam; it REBASES
+        # the parameters into one flat buffer, so it comes before everything that keys on their addresses)
+        self.sharded = parallel.ShardedAdam(self.graphsage_model.parameters(), lr=0.001) \
+            if (parallel.is_distributed() and parallel.SHARDED_UPDATE) else None
         self.optimizer = optim.Adam(self.graphsage_model.parameters(), lr=0.001, capturable=capturable,
                                     early=False if parallel.is_distributed() else None)
         # Under torch.distributed (one process per GPU, identical replicas, identical host RNG seeds on every rank)
@@ -192,8 +197,17 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         # update that of the whole batch, and the sharded PBR passes all-gather their per-seed losses (parallel.py).
         # (the loss of a shard already carries 1 / n_global, hence weight 1; the two-bucket overlap works for ragged and
         # empty shards alike: every rank issues the same two collectives per step)
-        self.gsync = parallel.GradSynchronizer(self.graphsage_model.parameters(), overlap=True, weight=1.0) \
+        self.gsync = parallel.GradSynchronizer(self.graphsage_model.parameters(), overlap=self.sharded is None, weight=1.0) \
             if parallel.is_distributed() else None
+
+    def _exchange_and_step(self, weight=None, single=False):
+        """The end of a replica's step: grads <- sum_r weight_r * grad_r, then the optimiser — or, with the sharded update on, the
+        reduce-scatter / sharded Adam / all-gather that replaces both (the same collectives on every rank either way)."""
+        if getattr(self, "sharded", None) is not None:
+            self.sharded.step(self.gsync.weight if weight is None else weight)
+            return
+        self.gsync.sync(weight=weight, single=single)
+        self.optimizer.step()
 
     def _local_batches(self, graph, seeds, batch_size, shuffle=False):
         """The snapshot's train batches as this rank sees them: yields (input_nodes, local_seeds, blocks, n_global).
@@ -230,7 +244,8 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             for p in self.gsync.params:                            # a rank without seeds contributes zeros
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
-            self.gsync.sync()                                      # weight 1: the 1 / n_global is already in the loss
+            self._exchange_and_step()                              # weight 1: the 1 / n_global is already in the loss
+            return
         self.optimizer.step()
 
     def _graphs_ok(self, form="sampled"):
@@ -481,7 +496,8 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         big = self.use_graphs is True or int(n_global) * (1 + self.samples) >= self.STAGED_DP_MIN_ROWS      # (global: same on every rank)
         import torch.distributed as dist
         if (self.gsync is not None and self._graphs_ok("staged_dp") and big and (on_rows is None or self.reduction != "mean")
-                and dist.get_backend(self.gsync.group) == "nccl" and DP_CAPTURE_COLLECTIVES):    # (module global: read at call time)
+                and dist.get_backend(self.gsync.group) == "nccl" and DP_CAPTURE_COLLECTIVES       # (module global: read at call time)
+                and self.sharded is None):
             # A replica's step as ONE replayed graph (form "staged_dp"): forward, loss, backward, the gradient exchange — the early
             # bucket's RCCL all-reduce launched from the gradient hooks on the side branch, under the layer-0 pool backward and weight
             # gradient; the late bucket (layer 0's fc_pool) behind it — and Adam on the reduced buckets.  The local mean loss's
@@ -549,8 +565,7 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
                 for p in self.gsync.params:
                     p.grad = None
             # nothing overlaps the exchange here (the graph has ended), so it is ONE flat bucket: one collective's latency, not two
-            self.gsync.sync(weight=n_local / float(n_global), single=True)
-            self.optimizer.step()
+            self._exchange_and_step(n_local / float(n_global), single=True)
             if sg is None and eager_rows is not None:
                 if on_rows is not None:
                     on_rows(seeds, eager_rows.detach())
@@ -583,8 +598,7 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
             else:                                               # more ranks than seeds in this batch: zeros into the same collectives
                 for p in self.gsync.params:
                     p.grad = None
-            self.gsync.sync(weight=w)
-            self.optimizer.step()
+            self._exchange_and_step(w)
             if on_rows is not None:
                 on_rows(seeds, rows.detach() if rows is not None else torch.zeros(0, device=graph.device))
             if loss_e is None:

@@ -355,6 +355,155 @@ class GradSynchronizer:
         self._step_weight = self.weight
 
 
+SHARDED_UPDATE = __import__("os").environ.get("OGL_DP_SHARDED_UPDATE", "0") == "1"
+
+
+class ShardedAdam:
+    """The gradient exchange and the optimiser of a data-parallel replica as reduce-scatter -> Adam on this rank's 1 / N of the flat
+    parameter space -> all-gather of the updated weights (the ZeRO-1 shape), instead of all-reduce -> the identical Adam over all
+    1.5 M parameters on every rank.  The lever DESIGN.md §6 names for the exposed late exchange at N = 8: a ring
+    all-reduce IS a reduce-scatter followed by an all-gather, so the bytes on the links are the same; what changes is that the optimiser
+    runs between the two halves on 1 / N of the elements (26 us -> ~4 us of Adam at N = 8 for the Reddit model) and that a rank keeps
+    1 / N of the moments.  Off by default (``OGL_DP_SHARDED_UPDATE=1`` / ``bench.py --dp-sharded-update 1``): it costs one more
+    collective launch per step, which at 6 MB over point-to-point xGMI is about what the shorter Adam saves — measured nowhere yet (no
+    multi-GPU node); it exists so that the first scaling run can A/B it.
+
+    Layout: the parameters are REBASED into one flat buffer (``p.data`` becomes a view of its 64-element-aligned slot; the total is
+    padded to a multiple of 64 * world), so a rank's segment is ONE contiguous range of weights, of gradients and of moments: one Adam
+    launch (ops.adam_step_multi_slabs: the arithmetic of optim.Adam, bit for bit), an in-place ``reduce_scatter_tensor`` and an
+    in-place ``all_gather_into_tensor``.  Padding elements have zero gradients and stay zero.  Construct it BEFORE anything that keys
+    on parameter addresses (GradSynchronizer's gradient sinks, captured graphs).  gloo has no reduce-scatter: the rehearsal backend
+    all-reduces the flat gradient and reads its own segment (same sums).  ``step(weight)`` leaves ``p.grad`` as the LOCAL gradient.
+    Every rank must call ``step`` every step (a rank without a backward contributes zeros)."""
+
+    def __init__(self, params, group=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params if p.requires_grad]
+        assert self.params, "no parameters"
+        self.group = group
+        self.rank, self.world = rank_world(group)
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        p0 = self.params[0]
+        self.offs, total = [], 0
+        for p in self.params:
+            assert p.dtype == p0.dtype and p.device == p0.device
+            self.offs.append(total)
+            total += (p.numel() + 63) // 64 * 64
+        unit = 64 * self.world
+        total = (total + unit - 1) // unit * unit
+        self.seg = total // self.world
+        self.lo, self.hi = self.rank * self.seg, (self.rank + 1) * self.seg
+        self.wflat = torch.zeros(total, dtype=p0.dtype, device=p0.device)
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offs):
+                slot = self.wflat.narrow(0, off, p.numel())
+                slot.copy_(p.data.reshape(-1))
+                p.data = slot.view(p.shape)
+        self.gflat = torch.zeros(total, dtype=p0.dtype, device=p0.device)
+        self.m = torch.zeros(self.seg, dtype=p0.dtype, device=p0.device)      # the moments of this rank's segment only
+        self.v = torch.zeros(self.seg, dtype=p0.dtype, device=p0.device)
+        self.t = 0
+        self._timing = None
+
+    # -- measurement (bench.py --gpus N / --force-dist): device time of the two collectives, as GradSynchronizer.enable_timing ------
+    def enable_timing(self, on=True):
+        self._timing = {} if on else None
+
+    def _ev(self):
+        if self._timing is None or not self.gflat.is_cuda or torch.cuda.is_current_stream_capturing():
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def _mark(self, kind, e0):
+        e1 = self._ev()
+        if e0 is not None and e1 is not None:
+            self._timing.setdefault(kind, []).append((e0, e1))
+
+    def timings(self):
+        if not self._timing:
+            return {}
+        torch.cuda.synchronize()
+        return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v), len(v)) for k, v in self._timing.items() if v}
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def _fill(self, w):
+        todo = []
+        for p, off in zip(self.params, self.offs):
+            sl = self.gflat.narrow(0, off, p.numel())
+            g = p.grad
+            if g is None:
+                sl.zero_()
+            else:
+                todo.append((g.reshape(-1) if g.is_contiguous() else g.contiguous().reshape(-1), sl, p.numel()))
+        if todo and self.gflat.is_cuda and self.gflat.dtype == torch.float32:
+            from . import ops
+            for k in range(0, len(todo), 8):
+                ops.stage_segments(todo[k:k + 8])
+        else:
+            for src, dst, _ in todo:
+                dst.copy_(src)
+        if w != 1.0:
+            self.gflat.mul_(w)
+
+    def _adam(self, pw, g):
+        self.t += 1
+        b1, b2 = self.betas
+        if pw.is_cuda:
+            from . import ops
+            ops.adam_step_multi_slabs([pw], [g], [self.m], [self.v], [None], step=self.t, lr=self.lr, beta1=b1, beta2=b2, eps=self.eps)
+            return
+        # (the CPU rehearsal: the update of csrc/loss_optim.hip's adam_one spelled with tensor ops)
+        self.m.add_(g - self.m, alpha=1.0 - b1)
+        self.v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+        denom = self.v.sqrt().mul_(1.0 / (1.0 - b2 ** self.t) ** 0.5).add_(self.eps)
+        pw.addcdiv_(self.m, denom, value=-(self.lr / (1.0 - b1 ** self.t)))
+
+    @torch.no_grad()
+    def step(self, weight=1.0):
+        """weights <- Adam(weights, sum_r weight_r * grad_r), every rank ending with identical weights."""
+        self._fill(float(weight))
+        mine_g = self.gflat.narrow(0, self.lo, self.seg)
+        mine_w = self.wflat.narrow(0, self.lo, self.seg)
+        single = _single(self.world) or not dist.is_initialized()
+        nccl = (not single) and dist.get_backend(self.group) == "nccl"
+        e0 = self._ev()
+        if nccl:
+            dist.reduce_scatter_tensor(mine_g, self.gflat, op=dist.ReduceOp.SUM, group=self.group)     # in place: my slice of the input
+        elif not single:
+            if self.gflat.is_cuda:                                   # gloo with device tensors: through the host
+                h = self.gflat.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                mine_g.copy_(h.narrow(0, self.lo, self.seg))
+            else:
+                dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.group)
+        self._mark("reduce_scatter", e0)
+        self._adam(mine_w, mine_g)
+        e0 = self._ev()
+        if nccl:
+            dist.all_gather_into_tensor(self.wflat, mine_w, group=self.group)                           # in place likewise
+        elif not single:
+            if self.wflat.is_cuda:
+                mine = mine_w.cpu()
+                out = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.all_gather(out, mine, group=self.group)
+                for r in range(self.world):
+                    if r != self.rank:
+                        self.wflat.narrow(0, r * self.seg, self.seg).copy_(out[r])
+            else:
+                dist.all_gather([self.wflat.narrow(0, r * self.seg, self.seg) for r in range(self.world)], mine_w.clone(), group=self.group)
+        self._mark("all_gather", e0)
+        if self.wflat.is_cuda:
+            from . import ops
+            ops.invalidate_weight_images()
+
+
 def assert_replicated(values, what="value", group=None):
     """Raise when ``values`` (array-like of integers) is not identical on every rank: the sharded passes pair losses
     computed by other ranks with THIS rank's seed list, which is only right while every rank drew the same seeds (identical
