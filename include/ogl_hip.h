@@ -749,6 +749,26 @@ int ogl_small_pool_layer_bwd_pool(const float* h, int64_t ldh, int64_t n_dst, in
                                   float* dWn, int64_t lddwn, float* dbn, float* dh, int64_t lddh, float* loss_mean, int64_t* step_dev,
                                   float* scalars_dev, double lr, double beta1, double beta2, ogl_stream_t stream);
 
+/* The FIRST 'pool' layer of a 32-seed step behind its fc_pool product (the live layer, R/train/graphsage/pytorch/graphsage_dgl.py:26-31
+ * -> DGL SAGEConv 'pool', at the reference's small settings: in_feats 500 / 128, embedding_size 32, <= 832 destinations):
+ *   ogl_small_first_layer_fwd: neigh[d] = max_j P[idx[d, j]] (+ argmax: the winning row of P, -1 = none; the order of ogl_reduce_fwd) and
+ *        y[d] = act(X[ids[d]] . Ws^T + neigh[d] . Wn^T + bs + bn) in ONE launch, one wave per destination (before: the max aggregator + a
+ *        skinny dual-input product).  P [n_src, F] and the table X [n_table, F] with 16-byte rows (ld % 4 == 0, ld >= 4 ceil(F / 4));
+ *        ids int64 [>= n_dst] (NULL: row d); Ws / Wn [H, F] with ld % 4 == 0; argmax int32 [n_dst, F] (nullable).
+ *   ogl_small_first_layer_bwd: dy = dout . [y > 0] (relu_out) and dneigh[d] = dy[d] . Wn in ONE launch (before: the ReLU mask + an
+ *        input-gradient product), then the dense dneigh [n_dst, F] and / or the winners' scatter dP[argmax[d, k], k] += dneigh[d, k]
+ *        . [neigh[d, k] > 0] with float atomics into a ZEROED dP [n_src, F] (before: a third launch).
+ *   ogl_small_first_layer_fits: n_dst <= 8192, fanout <= 64, 16 <= F <= 1024, H <= 32.
+ *   Sums over F run lane-parallel: fp32 rounding differs from the GEMM kernels' order; max / argmax are exact. */
+int ogl_small_first_layer_fits(int64_t n_src, int64_t n_dst, int fanout, int F, int H);
+int ogl_small_first_layer_fwd(const float* P, int64_t ldp, int64_t n_src, const int32_t* idx, int64_t n_dst, int fanout, int F,
+                              const float* table, int64_t ldt, const int64_t* ids, int64_t n_table, const float* Ws, int64_t ldws,
+                              const float* bs, const float* Wn, int64_t ldwn, const float* bn, int H, int relu_out, float* neigh,
+                              int64_t ldn, int32_t* argmax, float* y, int64_t ldy, ogl_stream_t stream);
+int ogl_small_first_layer_bwd(const float* dout, int64_t lddo, const float* y, int64_t ldy, int relu_out, int64_t n_dst, int H, int F,
+                              const float* Wn, int64_t ldwn, const float* neigh, int64_t ldn, const int32_t* argmax, float* dy,
+                              int64_t lddy, float* dneigh, int64_t lddn, float* dP, int64_t lddp, int64_t n_src, ogl_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Device-side prioritised replay structure (replay.hip): the sum tree of R/train/prioritized_replay/segment_tree.py:69-125
  * and the priority arithmetic of R/train/prioritized_replay/replay_buffer.py:110-245 on arrays in HBM, fed from the per-seed

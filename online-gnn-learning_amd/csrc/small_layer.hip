@@ -572,11 +572,11 @@ extern "C" int ogl_small_pool_layer_bwd_pool(const float* h, int64_t ldh, int64_
 // in_feats 500 / 128, embedding_size 32, <= 832 destinations): P = relu(fc_pool(X[src])) is a real product and stays on the GEMM kernel;
 // everything behind it is latency.  Before: the max aggregator (9 us) + a skinny dual-input product (14 us) forward; the ReLU mask
 // (5 us) + the [n1, 32] x [32, F] input-gradient product (8 us) + the winners' scatter (11 us) backward.
-//   forward, one wave per destination d (lanes = float4 columns of a row, F <= 1024):
+//   forward, one workgroup per destination d (thread t = float4 column t of a row, F <= 1024):
 //     neigh[d] = max_j P[idx[d, j]] with its argmax (the order of k_reduce_fwd_v4: first valid slot, then strictly greater), then
-//     y[d, c] = act(bs[c] + bn[c] + sum_k X[ids[d], k] Ws[c, k] + neigh[d, k] Wn[c, k]) for the 32 (padded) output columns: a lane
-//     forms its columns' share of all 32 sums, a halving butterfly (32 shuffles instead of 32 x 6) leaves column c in lane 2c;
-//   backward, one wave per destination: dy = dout . [y > 0];  dneigh[k] = sum_c dy[c] Wn[c, k] (lanes = columns k, dy[c] broadcast);
+//     y[d, c] = act(bs[c] + bn[c] + sum_k X[ids[d], k] Ws[c, k] + neigh[d, k] Wn[c, k]): wave w forms output columns 8w .. 8w + 7, a
+//     lane its float4 columns' share of the 8 sums, a halving butterfly (7 + 3 shuffles instead of 8 x 6) joins them;
+//   backward, one workgroup per destination: dy = dout . [y > 0];  dneigh[k] = sum_c dy[c] Wn[c, k] (thread = float4 column);
 //     then EITHER the dense dneigh row (the planned image path of the layer-0 weight gradient consumes it) OR the winners' scatter
 //     dP[argmax[d, k], k] += dneigh[k] . [neigh[d, k] > 0] with float atomics into a zeroed [n_src, F] matrix (k_reduce_bwd_max's).
 // Sums over k run lane-parallel and are joined by the butterfly: fp32 rounding differs from the GEMM kernels' order (tolerances of
@@ -591,21 +591,21 @@ __global__ void __launch_bounds__(256) k_small_first_fwd(const float* __restrict
                                                          int64_t ldwn, const float* __restrict__ bn, int H, int relu_out,
                                                          float* __restrict__ neigh, int64_t ldn, int32_t* __restrict__ argmax,
                                                          float* __restrict__ y, int64_t ldy) {
-  const int lane = threadIdx.x & 63;
-  const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (d >= n_dst) return;
+  // one WORKGROUP per destination (a first version gave it one wave: 128 weight loads in a row per wave, 42 us for 101 destinations):
+  // phase 1 — thread t owns float4 column t of the row: the S neighbour rows of P, all loads of four rows in flight, max + argmax;
+  // phase 2 — wave w owns output columns 8w .. 8w + 7: its lanes cover the float4 columns, 32 weight loads in flight per lane,
+  // the lane sums joined by a halving butterfly.
+  __shared__ float4 NB4[256], XS4[256];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int d = blockIdx.x;
   const int f4 = (F + 3) >> 2;
-  float4 acc[NCH];
-  int arg[NCH][4];
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    arg[c][0] = arg[c][1] = arg[c][2] = arg[c][3] = -1;
-  }
+  const int col = min(t, f4 - 1);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int arg[4] = {-1, -1, -1, -1};
   bool any = false;
-  const int32_t mine = lane < S ? idx[(int64_t)d * S + lane] : -1;         // S <= 64
+  const int32_t mine = lane < S ? idx[(int64_t)d * S + lane] : -1;         // S <= 64 (every wave holds the row)
   for (int j0 = 0; j0 < S; j0 += 4) {
-    float4 v[4][NCH];
+    float4 v[4];
     int r[4];
     bool ok[4];
 #pragma unroll
@@ -616,86 +616,68 @@ __global__ void __launch_bounds__(256) k_small_first_fwd(const float* __restrict
       r[u] = ok[u] ? q : 0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float4* rp = (const float4*)(P + (int64_t)r[u] * ldp);
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) v[u][c] = rp[min(c * 64 + lane, f4 - 1)];
-    }
+    for (int u = 0; u < 4; ++u) v[u] = ((const float4*)(P + (int64_t)r[u] * ldp))[col];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (!ok[u]) continue;                                             // wave-uniform
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        if (!any) {
-          acc[c] = v[u][c];
-          arg[c][0] = arg[c][1] = arg[c][2] = arg[c][3] = r[u];
-        } else {
-          if (v[u][c].x > acc[c].x) { acc[c].x = v[u][c].x; arg[c][0] = r[u]; }
-          if (v[u][c].y > acc[c].y) { acc[c].y = v[u][c].y; arg[c][1] = r[u]; }
-          if (v[u][c].z > acc[c].z) { acc[c].z = v[u][c].z; arg[c][2] = r[u]; }
-          if (v[u][c].w > acc[c].w) { acc[c].w = v[u][c].w; arg[c][3] = r[u]; }
-        }
+      if (!ok[u]) continue;                                             // block-uniform
+      if (!any) {
+        acc = v[u];
+        arg[0] = arg[1] = arg[2] = arg[3] = r[u];
+      } else {
+        if (v[u].x > acc.x) { acc.x = v[u].x; arg[0] = r[u]; }
+        if (v[u].y > acc.y) { acc.y = v[u].y; arg[1] = r[u]; }
+        if (v[u].z > acc.z) { acc.z = v[u].z; arg[2] = r[u]; }
+        if (v[u].w > acc.w) { acc.w = v[u].w; arg[3] = r[u]; }
       }
       any = true;
     }
   }
-  // the destination's own row (X[ids[d]]; an id outside the table: zeros) and the stores of neigh / argmax
+  // the destination's own row (X[ids[d]]; an id outside the table: zeros); neigh / argmax out; both rows to LDS, zero past F
   const int64_t id = ids ? ids[d] : (int64_t)d;
   const bool have = id >= 0 && id < n_table;
-  float4 xs[NCH];
+  if (t < f4) {
+    float4 xs = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (have) xs = ((const float4*)(table + id * ldt))[t];
+    float av[4] = {acc.x, acc.y, acc.z, acc.w};
+    float xv[4] = {xs.x, xs.y, xs.z, xs.w};
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int ch = c * 64 + lane;
-    xs[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ch < f4) {
-      if (have) xs[c] = ((const float4*)(table + id * ldt))[ch];
-      const float av[4] = {acc[c].x, acc[c].y, acc[c].z, acc[c].w};
-      float xv[4] = {xs[c].x, xs[c].y, xs[c].z, xs[c].w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = ch * 4 + e;
-        if (k < F) {
-          neigh[(int64_t)d * ldn + k] = av[e];
-          if (argmax) argmax[(int64_t)d * F + k] = arg[c][e];
-        } else {
-          xv[e] = 0.f;                                                  // (columns past F: padding of the last float4)
-        }
+    for (int e = 0; e < 4; ++e) {
+      const int k = t * 4 + e;
+      if (k < F) {
+        neigh[(int64_t)d * ldn + k] = av[e];
+        if (argmax) argmax[(int64_t)d * F + k] = arg[e];
+      } else {
+        av[e] = 0.f; xv[e] = 0.f;
       }
-      xs[c] = make_float4(xv[0], xv[1], xv[2], xv[3]);
-      if (ch * 4 + 3 >= F) {                                            // ... and of the reduced row
-        if (ch * 4 + 0 >= F) acc[c].x = 0.f;
-        if (ch * 4 + 1 >= F) acc[c].y = 0.f;
-        if (ch * 4 + 2 >= F) acc[c].z = 0.f;
-        if (ch * 4 + 3 >= F) acc[c].w = 0.f;
-      }
-    } else {
-      acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    NB4[t] = make_float4(av[0], av[1], av[2], av[3]);
+    XS4[t] = make_float4(xv[0], xv[1], xv[2], xv[3]);
   }
-  // the combine: this lane's share of the 32 column sums
-  float part[SFL_H];
+  __syncthreads();
+  float part[8];
 #pragma unroll
-  for (int c = 0; c < SFL_H; ++c) {
+  for (int i = 0; i < 8; ++i) {
+    const int c = wv * 8 + i;
     float a = 0.f;
     if (c < H) {
 #pragma unroll
       for (int q = 0; q < NCH; ++q) {
         const int ch = q * 64 + lane;
         if (ch < f4) {
-          // (rows of Ws / Wn are contiguous, 16-byte aligned when ld % 4 == 0; the last float4 of a row whose length is not a multiple
-          // of 4 reaches into the next row: its x / neigh factors are zero)
+          // (rows of Ws / Wn are 16-byte aligned; the last float4 of a row may reach past F: its x / neigh factors are zero)
           const float4 w1 = *(const float4*)(Ws + (int64_t)c * ldws + ch * 4);
           const float4 w2 = *(const float4*)(Wn + (int64_t)c * ldwn + ch * 4);
-          a = fmaf(xs[q].x, w1.x, a); a = fmaf(xs[q].y, w1.y, a); a = fmaf(xs[q].z, w1.z, a); a = fmaf(xs[q].w, w1.w, a);
-          a = fmaf(acc[q].x, w2.x, a); a = fmaf(acc[q].y, w2.y, a); a = fmaf(acc[q].z, w2.z, a); a = fmaf(acc[q].w, w2.w, a);
+          const float4 xs = XS4[ch], nb = NB4[ch];
+          a = fmaf(xs.x, w1.x, a); a = fmaf(xs.y, w1.y, a); a = fmaf(xs.z, w1.z, a); a = fmaf(xs.w, w1.w, a);
+          a = fmaf(nb.x, w2.x, a); a = fmaf(nb.y, w2.y, a); a = fmaf(nb.z, w2.z, a); a = fmaf(nb.w, w2.w, a);
         }
       }
     }
-    part[c] = a;
+    part[i] = a;
   }
-  // halving butterfly: 32 values over 64 lanes -> column c in lanes 2c, 2c + 1
+  // halving butterfly: 8 values over 64 lanes -> value i in the lanes with (lane >> 3) == i, then the 8 lanes of a group summed
 #pragma unroll
-  for (int n = 16, off = 32; n >= 1; n >>= 1, off >>= 1) {
+  for (int n = 4, off = 32; n >= 1; n >>= 1, off >>= 1) {
     const bool hi = (lane & off) != 0;
 #pragma unroll
     for (int i = 0; i < n; ++i) {
@@ -704,60 +686,51 @@ __global__ void __launch_bounds__(256) k_small_first_fwd(const float* __restrict
       part[i] = keep + __shfl_xor(send, off);
     }
   }
+  part[0] += __shfl_xor(part[0], 4);
+  part[0] += __shfl_xor(part[0], 2);
   part[0] += __shfl_xor(part[0], 1);
-  const int c = lane >> 1;
-  if ((lane & 1) == 0 && c < H) {
-    float o = part[0] + ((bs ? bs[c] : 0.f) + (bn ? bn[c] : 0.f));
+  const int c = wv * 8 + (lane >> 3);
+  if ((lane & 7) == 0 && c < H) {
+    const float o = part[0] + ((bs ? bs[c] : 0.f) + (bn ? bn[c] : 0.f));
     y[(int64_t)d * ldy + c] = relu_out ? fmaxf(o, 0.f) : o;
   }
 }
 
-template <int NCH>
 __global__ void __launch_bounds__(256) k_small_first_bwd(const float* __restrict__ dout, int64_t lddo, const float* __restrict__ y, int64_t ldy,
                                                          int relu_out, int n_dst, int H, int F, const float* __restrict__ Wn, int64_t ldwn,
                                                          const float* __restrict__ neigh, int64_t ldn, const int32_t* __restrict__ argmax,
                                                          float* __restrict__ dy, int64_t lddy, float* __restrict__ dneigh, int64_t lddn,
                                                          float* __restrict__ dP, int64_t lddp, int n_src) {
-  const int lane = threadIdx.x & 63;
-  const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (d >= n_dst) return;
+  // one workgroup per destination, thread t = float4 column t of the row (F <= 1024): H independent weight loads per thread
+  __shared__ float G[SFL_H];
+  const int t = threadIdx.x;
+  const int d = blockIdx.x;
   const int f4 = (F + 3) >> 2;
-  float g = 0.f;                                                          // lane c < H: dy[d, c]
-  if (lane < H) {
-    g = dout[(int64_t)d * lddo + lane];
-    if (relu_out && !(y[(int64_t)d * ldy + lane] > 0.f)) g = 0.f;
-    dy[(int64_t)d * lddy + lane] = g;
+  if (t < H) {
+    float g = dout[(int64_t)d * lddo + t];
+    if (relu_out && !(y[(int64_t)d * ldy + t] > 0.f)) g = 0.f;
+    dy[(int64_t)d * lddy + t] = g;
+    G[t] = g;
   }
-  float4 acc[NCH];
-#pragma unroll
-  for (int q = 0; q < NCH; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
+  __syncthreads();
+  if (t >= f4) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
   for (int c = 0; c < H; ++c) {                                           // (c ascending: the order of the input-gradient product's k loop)
-    const float gc = __shfl(g, c);
-#pragma unroll
-    for (int q = 0; q < NCH; ++q) {
-      const int ch = q * 64 + lane;
-      if (ch < f4) {
-        const float4 w = *(const float4*)(Wn + (int64_t)c * ldwn + ch * 4);
-        acc[q].x = fmaf(gc, w.x, acc[q].x); acc[q].y = fmaf(gc, w.y, acc[q].y);
-        acc[q].z = fmaf(gc, w.z, acc[q].z); acc[q].w = fmaf(gc, w.w, acc[q].w);
-      }
-    }
+    const float gc = G[c];
+    const float4 w = *(const float4*)(Wn + (int64_t)c * ldwn + t * 4);
+    acc.x = fmaf(gc, w.x, acc.x); acc.y = fmaf(gc, w.y, acc.y);
+    acc.z = fmaf(gc, w.z, acc.z); acc.w = fmaf(gc, w.w, acc.w);
   }
+  const float av[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
-  for (int q = 0; q < NCH; ++q) {
-    const int ch = q * 64 + lane;
-    if (ch >= f4) continue;
-    const float av[4] = {acc[q].x, acc[q].y, acc[q].z, acc[q].w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int k = ch * 4 + e;
-      if (k >= F) continue;
-      if (dneigh) dneigh[(int64_t)d * lddn + k] = av[e];
-      if (dP) {
-        const int32_t w = argmax[(int64_t)d * F + k];
-        if (w >= 0 && w < n_src && neigh[(int64_t)d * ldn + k] > 0.f) atomicAdd(&dP[(int64_t)w * lddp + k], av[e]);
-      }
+  for (int e = 0; e < 4; ++e) {
+    const int k = t * 4 + e;
+    if (k >= F) continue;
+    if (dneigh) dneigh[(int64_t)d * lddn + k] = av[e];
+    if (dP) {
+      const int32_t w = argmax[(int64_t)d * F + k];
+      if (w >= 0 && w < n_src && neigh[(int64_t)d * ldn + k] > 0.f) atomicAdd(&dP[(int64_t)w * lddp + k], av[e]);
     }
   }
 }
@@ -779,7 +752,7 @@ extern "C" int ogl_small_first_layer_fwd(const float* P, int64_t ldp, int64_t n_
   if (ldp < f4x4 || ldt < f4x4 || (ldp & 3) || (ldt & 3) || (ldws & 3) || (ldwn & 3) || ldws < F || ldwn < F || ldn < F || ldy < H)
     return OGL_EINVAL;
   if (((uintptr_t)P & 15) || ((uintptr_t)table & 15) || ((uintptr_t)Ws & 15) || ((uintptr_t)Wn & 15)) return OGL_EINVAL;
-  const dim3 grid((unsigned)ogl_cdiv(n_dst, 4)), block(256);
+  const dim3 grid((unsigned)n_dst), block(256);
   const int nch = (int)ogl_cdiv(ogl_cdiv(F, 4), 64);
 #define SFL_FWD(N)                                                                                                                      \
   hipLaunchKernelGGL(k_small_first_fwd<N>, grid, block, 0, (hipStream_t)stream, P, ldp, (int)n_src, idx, (int)n_dst, fanout, F, table, \
@@ -800,13 +773,8 @@ extern "C" int ogl_small_first_layer_bwd(const float* dout, int64_t lddo, const 
   if (lddo < H || (relu_out && ldy < H) || lddy < H || ldwn < F || (ldwn & 3) || ((uintptr_t)Wn & 15) || (dneigh && lddn < F) ||
       (dP && (lddp < F || ldn < F)))
     return OGL_EINVAL;
-  const dim3 grid((unsigned)ogl_cdiv(n_dst, 4)), block(256);
-  const int nch = (int)ogl_cdiv(ogl_cdiv(F, 4), 64);
-#define SFL_BWD(N)                                                                                                                        \
-  hipLaunchKernelGGL(k_small_first_bwd<N>, grid, block, 0, (hipStream_t)stream, dout, lddo, y, ldy, relu_out, (int)n_dst, H, F, Wn, ldwn, \
-                     neigh, ldn, argmax, dy, lddy, dneigh, lddn, dP, lddp, (int)n_src)
-  if (nch == 1) SFL_BWD(1); else if (nch == 2) SFL_BWD(2); else if (nch == 3) SFL_BWD(3); else SFL_BWD(4);
-#undef SFL_BWD
+  hipLaunchKernelGGL(k_small_first_bwd, dim3((unsigned)n_dst), dim3(256), 0, (hipStream_t)stream, dout, lddo, y, ldy, relu_out, (int)n_dst, H, F,
+                     Wn, ldwn, neigh, ldn, argmax, dy, lddy, dneigh, lddn, dP, lddp, (int)n_src);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }

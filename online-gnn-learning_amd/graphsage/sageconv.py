@@ -167,6 +167,12 @@ class SAGEConv(nn.Module):
             # input with a gradient (every layer but the first): the whole layer is one autograd node
             return ops.sage_pool_layer(feat, self.fc_pool.weight, self.fc_pool.bias, self.fc_self.weight, self.fc_neigh.weight,
                                        self.fc_self.bias, self.fc_neigh.bias, idx, n_dst, fuse_relu)
+        if (t == "pool" and lazy and feat.proj is None and self.norm is None and (self.activation is None or fuse_relu)
+                and ops.small_first_layer_fits(feat.table, feat.ids, idx, n_dst, self.fc_pool.weight, self.fc_pool.bias, self.fc_self.weight,
+                                               self.fc_neigh.weight, self.fc_self.bias, self.fc_neigh.bias)):
+            # the first layer of a small (32-seed) step: everything behind the fc_pool product is one launch each way
+            return ops.small_first_pool_layer(feat.table, feat.ids, self.fc_pool.weight, self.fc_pool.bias, self.fc_self.weight,
+                                              self.fc_neigh.weight, self.fc_self.bias, self.fc_neigh.bias, idx, n_dst, fuse_relu)
         if t == "pool":
             h_neigh = self._pool_max(feat, idx)
             rst = self._linear2(feat_dst, self.fc_self.weight, h_neigh, self.fc_neigh.weight, self.fc_self.bias, fuse_relu,

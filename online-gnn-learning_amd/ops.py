@@ -2998,6 +2998,112 @@ class _SmallPoolLossFn(torch.autograd.Function):
         return dh, dwp, dbp, dws, dwn, dbs, dbn, None, None, None
 
 
+SMALL_FIRST_FUSED = os.environ.get("OGL_SMALL_FIRST_FUSED", "1") != "0"   # the first 'pool' layer of a 32-seed step: max + combine in one launch
+SMALL_FIRST_MAX_DST = 2048
+
+
+def small_first_layer_fits(table, ids, idx, n_dst, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh):
+    """The first 'pool' layer of a small step qualifies for ``_SmallFirstLayerFn`` (ogl_small_first_layer_fits + layouts)."""
+    if not (SMALL_FIRST_FUSED and torch.is_grad_enabled() and ids is not None and table.dim() == 2 and not table.requires_grad):
+        return False
+    F, H = table.shape[1], w_self.shape[0]
+    tm = as_mat(table)
+    if (idx.dtype != torch.int32 or not idx.is_contiguous() or idx.shape[0] != n_dst or n_dst > SMALL_FIRST_MAX_DST or F % 4
+            or (b_self is None) != (b_neigh is None) or tuple(w_pool.shape) != (F, F) or tuple(w_neigh.shape) != (H, F)
+            or tuple(w_self.shape) != (H, F) or not (w_self.is_contiguous() and w_neigh.is_contiguous())
+            or w_self.data_ptr() % 16 or w_neigh.data_ptr() % 16 or _ld(tm) % 4 or tm.data_ptr() % 16 or ids.numel() < n_dst
+            or _n1_images_ok(n_dst, F, H)):
+        return False
+    return bool(_lib.lib().ogl_small_first_layer_fits(int(ids.numel()), int(n_dst), int(idx.shape[1]), int(F), int(H)))
+
+
+class _SmallFirstLayerFn(torch.autograd.Function):
+    """The FIRST 'pool' layer of a 32-seed train step (input = rows of the resident table: no input gradient) as one autograd node:
+    fc_pool on the GEMM kernel, then neighbour max + combine in ONE launch (ogl_small_first_layer_fwd; before: the max aggregator and a
+    skinny dual-input product, two autograd nodes); backward: the ReLU mask, dneigh = dy . Wn and — on the scatter path — the winners'
+    scatter in ONE launch (ogl_small_first_layer_bwd; before: three), the combine's two weight gradients + bias gradients in one
+    (ogl_out_layer_bwd_weights, as before), fc_pool's weight gradient as ``_PoolMaxFn`` computes it.
+    y = act(X[ids[:n_dst]] . Ws^T + max_j relu(X[ids] . Wp^T + bp)[idx] . Wn^T + bs + bn) (DGL SAGEConv 'pool')."""
+
+    @staticmethod
+    def forward(ctx, table, ids, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu):
+        x = as_mat(table)
+        ids = _ids(ids)
+        p = linear_fwd(x, w_pool, b_pool, relu=True, x_rows=ids)
+        n_src, F = p.shape
+        H = w_self.shape[0]
+        dev = p.device
+        need_pool = w_pool.requires_grad or (b_pool is not None and b_pool.requires_grad)
+        neigh = empty_mat(n_dst, F, dev)
+        argmax = torch.empty((n_dst, F), dtype=torch.int32, device=dev)
+        y = empty_mat(n_dst, H, dev)
+        _launch("ogl_small_first_layer_fwd", _lib.lib().ogl_small_first_layer_fwd, _ptr(p), _ld(p), n_src, _ptr(idx), n_dst, int(idx.shape[1]), F,
+                _ptr(x), _ld(x), _ptr(ids), x.shape[0], _ptr(w_self), _ld(as_mat(w_self)), _ptr(b_self), _ptr(w_neigh), _ld(as_mat(w_neigh)),
+                _ptr(b_neigh), H, int(bool(relu)), _ptr(neigh), _ld(neigh), _ptr(argmax), _ptr(y), _ld(y), _stream(),
+                meta=dict(n_src=n_src, n_dst=n_dst, fanout=int(idx.shape[1]), d=F, H=H))
+        if _CAPTURE is not None:
+            _CAPTURE.append(dict(argmax=argmax, neigh=neigh))
+        ctx.n_src, ctx.n_dst, ctx.fanout, ctx.relu = n_src, n_dst, int(idx.shape[1]), bool(relu)
+        ctx.has_bias, ctx.has_pool_bias = b_self is not None, b_pool is not None
+        ctx.bias_t = b_pool
+        # fc_pool's weight gradient is _PoolMaxFn's: its planned image path (the gradient-free half starts here) or the scatter path
+        ctx.x3_path = bool(need_pool and _MODE["name"] != "f32" and n_src >= X3_BWW_MIN_ROWS and F <= 640 and ctx.fanout <= 63)
+        ctx.pool_plan = None
+        if ctx.x3_path and POOL_PLAN and n_dst * F < (1 << 27):
+            ctx.pool_plan = pool_bwd_x3_plan(argmax, neigh, idx, n_src)
+        ctx.dp_slot = None
+        if need_pool and not ctx.x3_path and max(n_src, 1) * padded_ld(F) <= (SMALL_LOSS_ZERO_MAX if SMALL_LOSS_FUSED else CE_SMALL_MAX_ZERO):
+            ctx.dp_slot = request_zeroed(n_src, F, dev)            # (the scatter target: cleared by the loss launch on the side)
+        if relu:
+            y._ogl_relu_out = True
+        ctx.save_for_backward(x, ids, w_pool, w_self, w_neigh, neigh, argmax, y if relu else None, idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, ids, w_pool, w_self, w_neigh, neigh, argmax, y, idx = ctx.saved_tensors
+        dout = as_mat(dout)
+        n_src, n_dst = ctx.n_src, ctx.n_dst
+        F, H = neigh.shape[1], w_self.shape[0]
+        dev = dout.device
+        need = ctx.needs_input_grad                               # (table, ids, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, ...)
+        need_pool = need[2] or (need[3] and ctx.has_pool_bias)
+        dy = empty_mat(n_dst, H, dev)
+        dneigh = dP = None
+        if need_pool and ctx.x3_path:
+            dneigh = empty_mat(n_dst, F, dev)
+        elif need_pool:
+            slot, ctx.dp_slot = ctx.dp_slot, None
+            dP = take_zeroed(slot, n_src, F) if slot is not None else \
+                fill_zero(torch.empty((max(n_src, 1), padded_ld(F)), dtype=torch.float32, device=dev))[:n_src, :F]
+        else:
+            dneigh = empty_mat(n_dst, F, dev)                      # (nobody reads it: the kernel writes at least one of the two)
+        _launch("ogl_small_first_layer_bwd", _lib.lib().ogl_small_first_layer_bwd, _ptr(dout), _ld(dout), _ptr(y), _ld(y) if y is not None else 0,
+                int(ctx.relu), n_dst, H, F, _ptr(w_neigh), _ld(as_mat(w_neigh)), _ptr(neigh), _ld(neigh), _ptr(argmax), _ptr(dy), _ld(dy),
+                _ptr(dneigh), _ld(dneigh) if dneigh is not None else 0, _ptr(dP), _ld(dP) if dP is not None else 0, n_src, _stream(),
+                meta=dict(n_src=n_src, n_dst=n_dst, d=F, H=H, scatter=dP is not None))
+        dws = dwn = db = db2 = None
+        if need[4] or need[5]:
+            dws, dwn, db, db2 = out_layer_bwd_weights(dy, x, neigh, want_bias=ctx.has_bias, x_self_rows=ids[:n_dst],
+                                                      dws_out=_dw_out(w_self, *w_self.shape), dwn_out=_dw_out(w_neigh, *w_neigh.shape))
+        dwp = dbp = None
+        if need_pool and ctx.x3_path:
+            import types
+            shim = types.SimpleNamespace(saved_tensors=(x, w_pool, ids, neigh, argmax, idx), needs_input_grad=(False, need[2], need[3], False, False),
+                                         n_src=n_src, fanout=ctx.fanout, has_bias=ctx.has_pool_bias, pool_plan=ctx.pool_plan, dp_slot=None,
+                                         bias_t=ctx.bias_t)
+            ctx.pool_plan = None
+            _, dwp, dbp, _, _ = _PoolMaxFn.backward(shim, dneigh)
+        elif need_pool:
+            dwp, dbp = weight_grad(dP, x, ids, want_bias=ctx.has_pool_bias, dw_out=_dw_out(w_pool, *w_pool.shape))
+        return (None, None, dwp, dbp if ctx.has_pool_bias else None, dws, dwn, db if ctx.has_bias else None,
+                db2 if ctx.has_bias else None, None, None, None)
+
+
+def small_first_pool_layer(table, ids, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu):
+    return _SmallFirstLayerFn.apply(table, ids, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu)
+
+
 def sage_pool_layer(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu):
     if h.dim() == 2 and small_pool_layer_fits(h.shape[0], n_dst, idx.shape[1], h.shape[1], w_self.shape[0]):
         return _SmallPoolLayerFn.apply(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu)

@@ -266,3 +266,61 @@ def test_small_output_layer_loss_with_a_root_gradient_and_replayed():
         for k in ge:
             assert torch.equal(gs[k], ge[k]), k
         np.testing.assert_allclose(dhs.cpu().numpy(), dhe.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("T,n_src,n_dst,S,F_in,H,relu,bias,mode", [
+    (3000, 832, 32, 25, 500, 32, True, True, "f32"), (9000, 4200, 700, 25, 500, 32, True, True, "auto"), (6000, 2500, 832, 25, 128, 32, True, True, "auto"),
+    (500, 300, 48, 7, 64, 16, False, True, "f32"), (700, 120, 9, 64, 1024, 32, True, False, "f32"), (400, 90, 40, 3, 20, 5, True, True, "auto")])
+def test_small_first_layer_max_and_combine_in_one_launch(T, n_src, n_dst, S, F_in, H, relu, bias, mode):
+    """ogl_small_first_layer_fwd / _bwd (the first 'pool' layer of a 32-seed step behind its fc_pool product: max + combine forward,
+    ReLU mask + dneigh (+ the winners' scatter) backward, one launch each) against the launches they replace and against the oracle's
+    layer: forward rtol 1e-4 / atol 1e-5, gradients rtol 1e-3 / atol 2e-5 (lane-parallel sums + float atomics).  Both forms of
+    fc_pool's weight gradient: the scatter path (f32 mode / short blocks) and the planned image path (>= 2 048 source rows, 'auto')."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops, sampling
+    from ogl_amd.graphsage.sageconv import GatheredRows, SAGEConv
+    rng = np.random.default_rng(T + F_in + S)
+    table = ops.empty_mat(T, F_in, "cuda").copy_(torch.as_tensor(rng.standard_normal((T, F_in)).astype(np.float32)))
+    ids = torch.as_tensor(rng.choice(T, n_src, replace=False).astype(np.int64)).cuda()
+    idx = rng.integers(0, n_src, size=(n_dst, S)).astype(np.int32)
+    idx[rng.random(n_dst) < 0.15] = -1
+    idx_d = torch.as_tensor(idx).cuda()
+    prm = O.init_layer_params("pool", F_in, H)
+    gy = torch.as_tensor(rng.standard_normal((n_dst, H)).astype(np.float32)).cuda()
+    ops.set_gemm_mode(mode)
+    if mode != "f32":
+        ops.register_static_table(table)                                     # (the resident feature table: its image feeds the planned path)
+    try:
+        def run(fused):
+            ops.SMALL_FIRST_FUSED = fused
+            layer = SAGEConv(F_in, H, "pool", activation=F.relu if relu else None, bias=True).cuda()
+            with torch.no_grad():
+                for name, lin in (("fc_pool", layer.fc_pool), ("fc_self", layer.fc_self), ("fc_neigh", layer.fc_neigh)):
+                    lin.weight.copy_(prm[name + ".weight"])
+                    lin.bias.copy_(prm[name + ".bias"] if bias else torch.zeros_like(lin.bias))
+            blk = sampling.Block(ids, ids[:n_dst], idx_d)
+            assert ops.small_first_layer_fits(table, ids, idx_d, n_dst, layer.fc_pool.weight, layer.fc_pool.bias, layer.fc_self.weight,
+                                              layer.fc_neigh.weight, layer.fc_self.bias, layer.fc_neigh.bias) == fused
+            y = layer(blk, GatheredRows(table, ids))
+            y.backward(gy)
+            torch.cuda.synchronize()
+            return y.detach().cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in layer.named_parameters()}
+        y1, g1 = run(True)
+        y0, g0 = run(False)
+    finally:
+        ops.SMALL_FIRST_FUSED = True
+        ops.set_gemm_mode("f32")
+    hr = table[:, :F_in][ids].cpu()
+    pr = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
+    if not bias:
+        for k in pr:
+            if k.endswith(".bias"):
+                pr[k] = torch.zeros_like(pr[k]).requires_grad_(True)
+    yr = O.sageconv_forward("pool", hr, n_dst, idx, pr, activation=F.relu if relu else None)
+    yr.backward(gy.cpu())
+    np.testing.assert_allclose(y1, yr.detach().numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(y1, y0, rtol=1e-4, atol=2e-5)
+    for k in g1:
+        scale = max(1.0, float(np.abs(pr[k].grad.numpy()).max()))
+        np.testing.assert_allclose(g1[k], pr[k].grad.numpy(), rtol=1e-3, atol=2e-5 * scale, err_msg=k)
+        np.testing.assert_allclose(g1[k], g0[k], rtol=1e-3, atol=2e-5 * scale, err_msg=k)
