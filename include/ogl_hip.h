@@ -756,8 +756,9 @@ int ogl_small_pool_layer_bwd_pool(const float* h, int64_t ldh, int64_t n_dst, in
  *        skinny dual-input product).  P [n_src, F] and the table X [n_table, F] with 16-byte rows (ld % 4 == 0, ld >= 4 ceil(F / 4));
  *        ids int64 [>= n_dst] (NULL: row d); Ws / Wn [H, F] with ld % 4 == 0; argmax int32 [n_dst, F] (nullable).
  *   ogl_small_first_layer_bwd: dy = dout . [y > 0] (relu_out) and dneigh[d] = dy[d] . Wn in ONE launch (before: the ReLU mask + an
- *        input-gradient product), then the dense dneigh [n_dst, F] and / or the winners' scatter dP[argmax[d, k], k] += dneigh[d, k]
- *        . [neigh[d, k] > 0] with float atomics into a ZEROED dP [n_src, F] (before: a third launch).
+ *        input-gradient product), then the dense dneigh [n_dst, F] (mask_dneigh: zero where no winner takes it) and / or the winners'
+ *        scatter dP[argmax[d, k], k] += dneigh[d, k] . [neigh[d, k] > 0] with float atomics into a ZEROED dP [n_src, F] (before: a
+ *        third launch).
  *   ogl_small_first_layer_fits: n_dst <= 8192, fanout <= 64, 16 <= F <= 1024, H <= 32.
  *   Sums over F run lane-parallel: fp32 rounding differs from the GEMM kernels' order; max / argmax are exact. */
 int ogl_small_first_layer_fits(int64_t n_src, int64_t n_dst, int fanout, int F, int H);
@@ -767,7 +768,19 @@ int ogl_small_first_layer_fwd(const float* P, int64_t ldp, int64_t n_src, const 
                               int64_t ldn, int32_t* argmax, float* y, int64_t ldy, ogl_stream_t stream);
 int ogl_small_first_layer_bwd(const float* dout, int64_t lddo, const float* y, int64_t ldy, int relu_out, int64_t n_dst, int H, int F,
                               const float* Wn, int64_t ldwn, const float* neigh, int64_t ldn, const int32_t* argmax, float* dy,
-                              int64_t lddy, float* dneigh, int64_t lddn, float* dP, int64_t lddp, int64_t n_src, ogl_stream_t stream);
+                              int64_t lddy, float* dneigh, int64_t lddn, float* dP, int64_t lddp, int64_t n_src, int mask_dneigh,
+                              ogl_stream_t stream);
+/* The three weight gradients of that layer from records, ONE launch (n_dst <= 2048), each "output row r = sum_d g(d, r) . row(d, r)":
+ *   dWp[j, :] = sum_d G[d, j] X[ids[argmax[d, j]], :], dbp[j] = sum_d G[d, j]   (G [n_dst, F] = the MASKED dneigh: ogl_small_first_layer_bwd
+ *        with mask_dneigh = 1) — n_dst F records of F MACs instead of the dense [F, n_src] x [n_src, F] product, its zeroed scatter target
+ *        and its operand images (callers gate it: n_dst F^2 floats of L2 reads, ops.SMALL_FIRST_DW_MAX_BYTES);
+ *   dWs[c, :] = sum_d dy[d, c] X[ids[d], :],  dWn[c, :] = sum_d dy[d, c] neigh[d, :],  dbs[c] = dbn[c] = sum_d dy[d, c]   (before:
+ *        ogl_out_layer_bwd_weights, a launch of its own).
+ * Every output group nullable (at least one); one workgroup per output row; sums in destination order (reproducible, no atomics). */
+int ogl_small_first_layer_dw(const float* G, int64_t ldg, const int32_t* argmax, const float* dy, int64_t lddy, int64_t n_dst, int F, int H,
+                             const float* table, int64_t ldt, const int64_t* ids, int64_t n_table, int64_t n_src, const float* neigh,
+                             int64_t ldn, float* dWp, int64_t lddwp, float* dbp, float* dWs, int64_t lddws, float* dbs, float* dWn,
+                             int64_t lddwn, float* dbn, ogl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Device-side prioritised replay structure (replay.hip): the sum tree of R/train/prioritized_replay/segment_tree.py:69-125

@@ -132,7 +132,9 @@ SIGNATURES = {
     "ogl_small_first_layer_fits": (_i, [_i64, _i64, _i, _i, _i]),
     "ogl_small_first_layer_fwd": (_i, [_p, _i64, _i64, _p, _i64, _i, _i, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i, _i, _p, _i64,
                                        _p, _p, _i64, _p]),
-    "ogl_small_first_layer_bwd": (_i, [_p, _i64, _p, _i64, _i, _i64, _i, _i, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _p]),
+    "ogl_small_first_layer_bwd": (_i, [_p, _i64, _p, _i64, _i, _i64, _i, _i, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i, _p]),
+    "ogl_small_first_layer_dw": (_i, [_p, _i64, _p, _p, _i64, _i64, _i, _i, _p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p,
+                                      _p, _i64, _p, _p]),
     "ogl_replay_update": (_i, [_p, _i64, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _p, _p, _p, _p]),
     "ogl_replay_rebuild": (_i, [_p, _i64, _p]),
     "ogl_replay_sample": (_i, [_p, _i64, _i64, _i64, _p, _p, _i64, _p, _p, _p]),

@@ -700,7 +700,7 @@ __global__ void __launch_bounds__(256) k_small_first_bwd(const float* __restrict
                                                          int relu_out, int n_dst, int H, int F, const float* __restrict__ Wn, int64_t ldwn,
                                                          const float* __restrict__ neigh, int64_t ldn, const int32_t* __restrict__ argmax,
                                                          float* __restrict__ dy, int64_t lddy, float* __restrict__ dneigh, int64_t lddn,
-                                                         float* __restrict__ dP, int64_t lddp, int n_src) {
+                                                         float* __restrict__ dP, int64_t lddp, int n_src, int mask_dneigh) {
   // one workgroup per destination, thread t = float4 column t of the row (F <= 1024): H independent weight loads per thread
   __shared__ float G[SFL_H];
   const int t = threadIdx.x;
@@ -727,11 +727,14 @@ __global__ void __launch_bounds__(256) k_small_first_bwd(const float* __restrict
   for (int e = 0; e < 4; ++e) {
     const int k = t * 4 + e;
     if (k >= F) continue;
-    if (dneigh) dneigh[(int64_t)d * lddn + k] = av[e];
-    if (dP) {
-      const int32_t w = argmax[(int64_t)d * F + k];
-      if (w >= 0 && w < n_src && neigh[(int64_t)d * ldn + k] > 0.f) atomicAdd(&dP[(int64_t)w * lddp + k], av[e]);
+    bool win = true;
+    int32_t w = 0;
+    if (dP || mask_dneigh) {
+      w = argmax[(int64_t)d * F + k];
+      win = w >= 0 && w < n_src && neigh[(int64_t)d * ldn + k] > 0.f;
     }
+    if (dneigh) dneigh[(int64_t)d * lddn + k] = (mask_dneigh && !win) ? 0.f : av[e];
+    if (dP && win) atomicAdd(&dP[(int64_t)w * lddp + k], av[e]);
   }
 }
 
@@ -763,18 +766,147 @@ extern "C" int ogl_small_first_layer_fwd(const float* P, int64_t ldp, int64_t n_
   return OGL_OK;
 }
 
-// dy [n_dst, H] always; dneigh [n_dst, F] (nullable) and / or dP [n_src, F] (nullable, ZEROED by the caller: float atomics add into it)
+// dy [n_dst, H] always; dneigh [n_dst, F] (nullable; mask_dneigh: zero where no winner takes it) and / or dP [n_src, F] (nullable, ZEROED
+// by the caller: float atomics add into it)
 extern "C" int ogl_small_first_layer_bwd(const float* dout, int64_t lddo, const float* y, int64_t ldy, int relu_out, int64_t n_dst, int H,
                                          int F, const float* Wn, int64_t ldwn, const float* neigh, int64_t ldn, const int32_t* argmax,
                                          float* dy, int64_t lddy, float* dneigh, int64_t lddn, float* dP, int64_t lddp, int64_t n_src,
-                                         ogl_stream_t stream) {
+                                         int mask_dneigh, ogl_stream_t stream) {
   if (n_dst <= 0 || n_dst > 8192 || H <= 0 || H > SFL_H || F < 16 || F > 1024 || n_src <= 0 || n_src >= (1 << 30)) return OGL_EINVAL;
-  if (!dout || !Wn || !dy || (relu_out && !y) || (!dneigh && !dP) || (dP && (!argmax || !neigh))) return OGL_EINVAL;
+  if (!dout || !Wn || !dy || (relu_out && !y) || (!dneigh && !dP) || ((dP || mask_dneigh) && (!argmax || !neigh))) return OGL_EINVAL;
   if (lddo < H || (relu_out && ldy < H) || lddy < H || ldwn < F || (ldwn & 3) || ((uintptr_t)Wn & 15) || (dneigh && lddn < F) ||
-      (dP && (lddp < F || ldn < F)))
+      (dP && lddp < F) || ((dP || mask_dneigh) && ldn < F))
     return OGL_EINVAL;
   hipLaunchKernelGGL(k_small_first_bwd, dim3((unsigned)n_dst), dim3(256), 0, (hipStream_t)stream, dout, lddo, y, ldy, relu_out, (int)n_dst, H, F,
-                     Wn, ldwn, neigh, ldn, argmax, dy, lddy, dneigh, lddn, dP, lddp, (int)n_src);
+                     Wn, ldwn, neigh, ldn, argmax, dy, lddy, dneigh, lddn, dP, lddp, (int)n_src, mask_dneigh);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+// The three weight gradients of that layer from RECORDS, one launch.  Each is "output row r = sum_d g(d, r) . row(d, r)":
+//   dWp[j, :] = sum_d G[d, j]  X[ids[argmax[d, j]], :]   (G = the masked dneigh of ogl_small_first_layer_bwd: the winners' records —
+//               n_dst F records of F MACs each instead of the dense [F, n_src] x [n_src, F] product, its zeroed scatter target and its
+//               transposes / plan + image: at the 32-seed rungs, 101-228 destinations, 4-25 M MACs against 170-420 M)
+//   dWs[c, :] = sum_d dy[d, c] X[ids[d], :]              dWn[c, :] = sum_d dy[d, c] neigh[d, :]      (+ the three bias gradients)
+// One workgroup per output row: its column of weights compacted in destination order into LDS (the ReLU leaves about half, padded
+// destinations nothing), then thread t = float4 column t of the gathered rows, eight row loads in flight.  Sums in destination order:
+// reproducible, no atomics.  (The record idea fed to the MFMA tiles lost at the Reddit shape — 4.2 M records re-read per column tile,
+// DESIGN section 8; here the rows come from L2 and there is nothing to tile.)
+#define SFD_MAX_DST 2048
+struct SfdSeg {
+  const float* G; int64_t ldg;                 // weights: G[d * ldg + r]
+  const int32_t* arg; int64_t ldarg; int n_idx;   // optional indirection: w = arg[d * ldarg + r] in [0, n_idx); NULL: w = d
+  const int64_t* ids;                          // optional second indirection: row id = ids[w]; NULL: w
+  const float* rows; int64_t ldr; int64_t n_rows;
+  float* dW; int64_t lddw; float* db; float* db2;
+  int first, count;                            // its blocks: [first, first + count)
+};
+struct SfdArgs { SfdSeg seg[3]; int nseg; int n_dst; int F; };
+
+__global__ void __launch_bounds__(256) k_small_first_dw(SfdArgs a) {
+  __shared__ float GS[SFD_MAX_DST + 8];
+  __shared__ int64_t RS[SFD_MAX_DST + 8];
+  __shared__ int cnt_w[4];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  int si = 0;
+  if (a.nseg > 1 && (int)blockIdx.x >= a.seg[1].first) si = 1;
+  if (a.nseg > 2 && (int)blockIdx.x >= a.seg[2].first) si = 2;
+  const SfdSeg& sg = a.seg[si];
+  const int j = blockIdx.x - sg.first;
+  const int F = a.F, n_dst = a.n_dst;
+  const int f4 = (F + 3) >> 2;
+  int base = 0;                                              // (block-uniform: every thread keeps the same count)
+  for (int d0 = 0; d0 < n_dst; d0 += 256) {
+    const int d = d0 + t;
+    float g = 0.f;
+    int64_t row = -1;
+    if (d < n_dst) {
+      g = sg.G[(int64_t)d * sg.ldg + j];
+      if (g != 0.f) {
+        int64_t w = d;
+        if (sg.arg) {
+          const int32_t q = sg.arg[(int64_t)d * sg.ldarg + j];
+          w = (q >= 0 && q < sg.n_idx) ? q : -1;
+        }
+        if (w >= 0) {
+          const int64_t id = sg.ids ? sg.ids[w] : w;
+          if (id >= 0 && id < sg.n_rows) row = id;
+        }
+      }
+    }
+    const bool flag = row >= 0;
+    const unsigned long long bal = __ballot(flag);
+    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) cnt_w[wv] = __popcll(bal);
+    __syncthreads();
+    int off = base;
+    for (int q = 0; q < wv; ++q) off += cnt_w[q];
+    if (flag) { GS[off + pre] = g; RS[off + pre] = row; }
+    base += cnt_w[0] + cnt_w[1] + cnt_w[2] + cnt_w[3];
+    __syncthreads();
+  }
+  const int n = base;
+  if (t < 8) { GS[n + t] = 0.f; RS[n + t] = 0; }             // padding of the last group of eight: zero weight, row 0
+  __syncthreads();
+  if (t < f4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < n; i += 8) {
+      float4 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = ((const float4*)(sg.rows + RS[i + u] * sg.ldr))[t];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float g = GS[i + u];
+        acc.x = fmaf(g, x[u].x, acc.x); acc.y = fmaf(g, x[u].y, acc.y);
+        acc.z = fmaf(g, x[u].z, acc.z); acc.w = fmaf(g, x[u].w, acc.w);
+      }
+    }
+    const float av[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (t * 4 + e < F) sg.dW[(int64_t)j * sg.lddw + t * 4 + e] = av[e];
+  }
+  if ((sg.db || sg.db2) && wv == 3) {                        // fixed order: lane l sums entries l, l + 64, ...; then the lanes
+    float b = 0.f;
+    for (int i = lane; i < n; i += 64) b += GS[i];
+    b = sll_wave_sum(b);
+    if (lane == 0) {
+      if (sg.db) sg.db[j] = b;
+      if (sg.db2) sg.db2[j] = b;
+    }
+  }
+}
+
+// G [n_dst, F] = the masked dneigh (NULL with dWp: no fc_pool segment); dy [n_dst, H]; dWp [F, F], dWs / dWn [H, F] (each nullable, with its
+// bias gradient dbp [F] / dbs, dbn [H]: the same sum written twice, one tensor per parameter); table rows X[ids[.]] (ids NULL: the row
+// index itself); neigh [n_dst, F].  Rows are read as float4: ldt, ldn multiples of 4, 16-byte aligned bases.
+extern "C" int ogl_small_first_layer_dw(const float* G, int64_t ldg, const int32_t* argmax, const float* dy, int64_t lddy, int64_t n_dst, int F,
+                                        int H, const float* table, int64_t ldt, const int64_t* ids, int64_t n_table, int64_t n_src,
+                                        const float* neigh, int64_t ldn, float* dWp, int64_t lddwp, float* dbp, float* dWs, int64_t lddws,
+                                        float* dbs, float* dWn, int64_t lddwn, float* dbn, ogl_stream_t stream) {
+  if (n_dst <= 0 || n_dst > SFD_MAX_DST || F < 16 || F > 1024 || H <= 0 || H > 64 || n_table <= 0 || n_src <= 0 || n_src >= (1 << 30))
+    return OGL_EINVAL;
+  if (!table || (!dWp && !dWs && !dWn)) return OGL_EINVAL;
+  const int64_t f4x4 = ((int64_t)F + 3) / 4 * 4;
+  if (ldt < f4x4 || (ldt & 3) || ((uintptr_t)table & 15)) return OGL_EINVAL;
+  if (dWp && (!G || !argmax || ldg < F || lddwp < F)) return OGL_EINVAL;
+  if ((dWs || dWn) && (!dy || lddy < H)) return OGL_EINVAL;
+  if (dWs && lddws < F) return OGL_EINVAL;
+  if (dWn && (!neigh || lddwn < F || ldn < f4x4 || (ldn & 3) || ((uintptr_t)neigh & 15))) return OGL_EINVAL;
+  SfdArgs a;
+  a.nseg = 0; a.n_dst = (int)n_dst; a.F = F;
+  int blocks = 0;
+  auto add = [&](const float* g, int64_t ld, const int32_t* arg, int n_idx, const int64_t* idp, const float* rows, int64_t ldr, int64_t n_rows,
+                 float* dW, int64_t lddw, float* db, float* db2, int count) {
+    SfdSeg& s = a.seg[a.nseg++];
+    s.G = g; s.ldg = ld; s.arg = arg; s.ldarg = F; s.n_idx = n_idx; s.ids = idp; s.rows = rows; s.ldr = ldr; s.n_rows = n_rows;
+    s.dW = dW; s.lddw = lddw; s.db = db; s.db2 = db2; s.first = blocks; s.count = count;
+    blocks += count;
+  };
+  if (dWp) add(G, ldg, argmax, (int)n_src, ids, table, ldt, n_table, dWp, lddwp, dbp, nullptr, F);
+  if (dWs) add(dy, lddy, nullptr, 0, ids, table, ldt, n_table, dWs, lddws, dbs, dWn ? nullptr : dbn, H);
+  if (dWn) add(dy, lddy, nullptr, 0, nullptr, neigh, ldn, n_dst, dWn, lddwn, dbn, dWs ? nullptr : dbs, H);
+  hipLaunchKernelGGL(k_small_first_dw, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }

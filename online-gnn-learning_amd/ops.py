@@ -3000,6 +3000,11 @@ class _SmallPoolLossFn(torch.autograd.Function):
 
 SMALL_FIRST_FUSED = os.environ.get("OGL_SMALL_FIRST_FUSED", "1") != "0"   # the first 'pool' layer of a 32-seed step: max + combine in one launch
 SMALL_FIRST_MAX_DST = 2048
+# fc_pool's weight gradient of that layer from the winners' records (ogl_small_first_layer_dw) while the rows it would gather from L2 if
+# EVERY destination row were live — n_dst * F * F floats — stay below this many bytes.  (A captured 32-seed step runs on the upper-bound
+# block, 832 destination rows of which 100-230 are live: padded rows have no records and cost nothing, so the bound covers 832 x 500^2.)
+SMALL_FIRST_DW = os.environ.get("OGL_SMALL_FIRST_DW", "1") != "0"
+SMALL_FIRST_DW_MAX_BYTES = int(os.environ.get("OGL_SMALL_FIRST_DW_MAX_BYTES", str(1 << 30)))
 
 
 def small_first_layer_fits(table, ids, idx, n_dst, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh):
@@ -3022,7 +3027,8 @@ class _SmallFirstLayerFn(torch.autograd.Function):
     fc_pool on the GEMM kernel, then neighbour max + combine in ONE launch (ogl_small_first_layer_fwd; before: the max aggregator and a
     skinny dual-input product, two autograd nodes); backward: the ReLU mask, dneigh = dy . Wn and — on the scatter path — the winners'
     scatter in ONE launch (ogl_small_first_layer_bwd; before: three), the combine's two weight gradients + bias gradients in one
-    (ogl_out_layer_bwd_weights, as before), fc_pool's weight gradient as ``_PoolMaxFn`` computes it.
+    (ogl_out_layer_bwd_weights, as before), fc_pool's weight gradient from the winners' records in one (ogl_small_first_layer_dwpool:
+    n_dst F records instead of the dense product — while n_dst F^2 floats of gathered rows stay small) or as ``_PoolMaxFn`` computes it.
     y = act(X[ids[:n_dst]] . Ws^T + max_j relu(X[ids] . Wp^T + bp)[idx] . Wn^T + bs + bn) (DGL SAGEConv 'pool')."""
 
     @staticmethod
@@ -3047,12 +3053,15 @@ class _SmallFirstLayerFn(torch.autograd.Function):
         ctx.has_bias, ctx.has_pool_bias = b_self is not None, b_pool is not None
         ctx.bias_t = b_pool
         # fc_pool's weight gradient is _PoolMaxFn's: its planned image path (the gradient-free half starts here) or the scatter path
-        ctx.x3_path = bool(need_pool and _MODE["name"] != "f32" and n_src >= X3_BWW_MIN_ROWS and F <= 640 and ctx.fanout <= 63)
+        ctx.rec_path = bool(need_pool and SMALL_FIRST_DW and n_dst <= 2048 and 4 * n_dst * F * F <= SMALL_FIRST_DW_MAX_BYTES)
+        ctx.x3_path = bool(need_pool and not ctx.rec_path and _MODE["name"] != "f32" and n_src >= X3_BWW_MIN_ROWS and F <= 640
+                           and ctx.fanout <= 63)
         ctx.pool_plan = None
         if ctx.x3_path and POOL_PLAN and n_dst * F < (1 << 27):
             ctx.pool_plan = pool_bwd_x3_plan(argmax, neigh, idx, n_src)
         ctx.dp_slot = None
-        if need_pool and not ctx.x3_path and max(n_src, 1) * padded_ld(F) <= (SMALL_LOSS_ZERO_MAX if SMALL_LOSS_FUSED else CE_SMALL_MAX_ZERO):
+        if (need_pool and not ctx.x3_path and not ctx.rec_path
+                and max(n_src, 1) * padded_ld(F) <= (SMALL_LOSS_ZERO_MAX if SMALL_LOSS_FUSED else CE_SMALL_MAX_ZERO)):
             ctx.dp_slot = request_zeroed(n_src, F, dev)            # (the scatter target: cleared by the loss launch on the side)
         if relu:
             y._ogl_relu_out = True
@@ -3070,7 +3079,7 @@ class _SmallFirstLayerFn(torch.autograd.Function):
         need_pool = need[2] or (need[3] and ctx.has_pool_bias)
         dy = empty_mat(n_dst, H, dev)
         dneigh = dP = None
-        if need_pool and ctx.x3_path:
+        if need_pool and (ctx.x3_path or ctx.rec_path):
             dneigh = empty_mat(n_dst, F, dev)
         elif need_pool:
             slot, ctx.dp_slot = ctx.dp_slot, None
@@ -3080,14 +3089,34 @@ class _SmallFirstLayerFn(torch.autograd.Function):
             dneigh = empty_mat(n_dst, F, dev)                      # (nobody reads it: the kernel writes at least one of the two)
         _launch("ogl_small_first_layer_bwd", _lib.lib().ogl_small_first_layer_bwd, _ptr(dout), _ld(dout), _ptr(y), _ld(y) if y is not None else 0,
                 int(ctx.relu), n_dst, H, F, _ptr(w_neigh), _ld(as_mat(w_neigh)), _ptr(neigh), _ld(neigh), _ptr(argmax), _ptr(dy), _ld(dy),
-                _ptr(dneigh), _ld(dneigh) if dneigh is not None else 0, _ptr(dP), _ld(dP) if dP is not None else 0, n_src, _stream(),
+                _ptr(dneigh), _ld(dneigh) if dneigh is not None else 0, _ptr(dP), _ld(dP) if dP is not None else 0, n_src,
+                1 if (need_pool and ctx.rec_path) else 0, _stream(),
                 meta=dict(n_src=n_src, n_dst=n_dst, d=F, H=H, scatter=dP is not None))
-        dws = dwn = db = db2 = None
-        if need[4] or need[5]:
-            dws, dwn, db, db2 = out_layer_bwd_weights(dy, x, neigh, want_bias=ctx.has_bias, x_self_rows=ids[:n_dst],
-                                                      dws_out=_dw_out(w_self, *w_self.shape), dwn_out=_dw_out(w_neigh, *w_neigh.shape))
-        dwp = dbp = None
-        if need_pool and ctx.x3_path:
+        # the combine's two weight gradients (+ both bias gradients) and — on the record path — fc_pool's, ONE launch
+        dws = dwn = db = db2 = dwp = dbp = None
+        rec = need_pool and ctx.rec_path
+        if need[4] or need[5] or rec:
+            if need[4] or need[5]:
+                dws = _dw_out(w_self, *w_self.shape)
+                dwn = _dw_out(w_neigh, *w_neigh.shape)
+                dws = dws if dws is not None else torch.empty((H, F), dtype=torch.float32, device=dev)
+                dwn = dwn if dwn is not None else torch.empty((H, F), dtype=torch.float32, device=dev)
+                if ctx.has_bias:
+                    db = torch.empty(H, dtype=torch.float32, device=dev)
+                    db2 = torch.empty(H, dtype=torch.float32, device=dev)
+            if rec:
+                # from the winners' records: no scatter target, no transposed operands, no plan; sums in destination order
+                dwp = _dw_out(w_pool, *w_pool.shape)
+                dwp = dwp if dwp is not None else torch.empty((F, F), dtype=torch.float32, device=dev)
+                dbp = torch.empty(F, dtype=torch.float32, device=dev) if ctx.has_pool_bias else None
+            _launch("ogl_small_first_layer_dw", _lib.lib().ogl_small_first_layer_dw, _ptr(dneigh) if rec else None,
+                    _ld(dneigh) if rec else 0, _ptr(argmax), _ptr(dy), _ld(dy), n_dst, F, H, _ptr(x), _ld(x), _ptr(ids), x.shape[0], n_src,
+                    _ptr(neigh), _ld(neigh), _ptr(dwp), _ld(as_mat(dwp)) if dwp is not None else 0, _ptr(dbp), _ptr(dws),
+                    _ld(as_mat(dws)) if dws is not None else 0, _ptr(db), _ptr(dwn), _ld(as_mat(dwn)) if dwn is not None else 0, _ptr(db2),
+                    _stream(), meta=dict(n_src=n_src, n_dst=n_dst, d=F, H=H, records=bool(rec)))
+        if rec:
+            pass
+        elif need_pool and ctx.x3_path:
             import types
             shim = types.SimpleNamespace(saved_tensors=(x, w_pool, ids, neigh, argmax, idx), needs_input_grad=(False, need[2], need[3], False, False),
                                          n_src=n_src, fanout=ctx.fanout, has_bias=ctx.has_pool_bias, pool_plan=ctx.pool_plan, dp_slot=None,

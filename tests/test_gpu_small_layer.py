@@ -268,18 +268,26 @@ def test_small_output_layer_loss_with_a_root_gradient_and_replayed():
         np.testing.assert_allclose(dhs.cpu().numpy(), dhe.cpu().numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("rec", [True, False])
 @pytest.mark.parametrize("T,n_src,n_dst,S,F_in,H,relu,bias,mode", [
     (3000, 832, 32, 25, 500, 32, True, True, "f32"), (9000, 4200, 700, 25, 500, 32, True, True, "auto"), (6000, 2500, 832, 25, 128, 32, True, True, "auto"),
-    (500, 300, 48, 7, 64, 16, False, True, "f32"), (700, 120, 9, 64, 1024, 32, True, False, "f32"), (400, 90, 40, 3, 20, 5, True, True, "auto")])
-def test_small_first_layer_max_and_combine_in_one_launch(T, n_src, n_dst, S, F_in, H, relu, bias, mode):
+    (500, 300, 48, 7, 64, 16, False, True, "f32"), (700, 120, 9, 64, 1024, 32, True, False, "f32"), (400, 90, 40, 3, 20, 5, True, True, "auto"),
+    (5000, 3000, 300, 25, 128, 32, True, True, "auto")])
+def test_small_first_layer_max_and_combine_in_one_launch(T, n_src, n_dst, S, F_in, H, relu, bias, mode, rec):
     """ogl_small_first_layer_fwd / _bwd (the first 'pool' layer of a 32-seed step behind its fc_pool product: max + combine forward,
     ReLU mask + dneigh (+ the winners' scatter) backward, one launch each) against the launches they replace and against the oracle's
     layer: forward rtol 1e-4 / atol 1e-5, gradients rtol 1e-3 / atol 2e-5 (lane-parallel sums + float atomics).  Both forms of
-    fc_pool's weight gradient: the scatter path (f32 mode / short blocks) and the planned image path (>= 2 048 source rows, 'auto')."""
+    fc_pool's weight gradient: the scatter path (f32 mode / short blocks) and the planned image path (>= 2 048 source rows, 'auto') —
+    and (``rec``) that gradient from the winners' records (ogl_small_first_layer_dwpool; 700 x 500^2 floats is past its gate: that case
+    keeps the dense form either way)."""
     import ogl_amd  # noqa: F401
     from ogl_amd import ops, sampling
     from ogl_amd.graphsage.sageconv import GatheredRows, SAGEConv
     rng = np.random.default_rng(T + F_in + S)
+    # (seeded: the oracle picks its winners from fp32 CPU products, the device from its own — among 350 000 maxima over 25 candidates a
+    # pair within rounding of each other turns up every few draws of the weights and moves one row of fc_pool's gradient; the parity
+    # tests at full size route the device's winners into the oracle for that reason, here the draw is fixed instead)
+    torch.manual_seed(1000 + T + n_dst)
     table = ops.empty_mat(T, F_in, "cuda").copy_(torch.as_tensor(rng.standard_normal((T, F_in)).astype(np.float32)))
     ids = torch.as_tensor(rng.choice(T, n_src, replace=False).astype(np.int64)).cuda()
     idx = rng.integers(0, n_src, size=(n_dst, S)).astype(np.int32)
@@ -291,6 +299,8 @@ def test_small_first_layer_max_and_combine_in_one_launch(T, n_src, n_dst, S, F_i
     if mode != "f32":
         ops.register_static_table(table)                                     # (the resident feature table: its image feeds the planned path)
     try:
+        ops.SMALL_FIRST_DW = rec
+
         def run(fused):
             ops.SMALL_FIRST_FUSED = fused
             layer = SAGEConv(F_in, H, "pool", activation=F.relu if relu else None, bias=True).cuda()
@@ -309,6 +319,7 @@ def test_small_first_layer_max_and_combine_in_one_launch(T, n_src, n_dst, S, F_i
         y0, g0 = run(False)
     finally:
         ops.SMALL_FIRST_FUSED = True
+        ops.SMALL_FIRST_DW = True
         ops.set_gemm_mode("f32")
     hr = table[:, :F_in][ids].cpu()
     pr = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
