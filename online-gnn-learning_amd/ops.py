@@ -2962,7 +2962,14 @@ class _SmallPoolLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss, _drows, _dlogits):
         h, w_pool, argmax, neigh, dl = ctx.saved_tensors
+        # (taken once and dropped: ``rows`` / ``mean`` are OUTPUTS of this node — kept on ctx past the backward they close a reference
+        # cycle output -> grad_fn -> ctx -> output that keeps the step's autograd graph alive until the garbage collector runs; a
+        # graph of an eager step still alive inside the capture of the next one crashed hipStreamEndCapture of a replica's step)
+        if ctx.pre is None:
+            raise RuntimeError("the fused small output layer + loss node was already backpropagated (its forward launch's gradients are "
+                               "consumed once: no retain_graph)")
         G, dh, rows, mean = ctx.pre
+        ctx.pre = None
         n_src, hin = h.shape
         hout = ctx.hout
         dev = h.device
@@ -3002,9 +3009,10 @@ SMALL_FIRST_FUSED = os.environ.get("OGL_SMALL_FIRST_FUSED", "1") != "0"   # the 
 SMALL_FIRST_MAX_DST = 2048
 # fc_pool's weight gradient of that layer from the winners' records (ogl_small_first_layer_dw) while the rows it would gather from L2 if
 # EVERY destination row were live — n_dst * F * F floats — stay below this many bytes.  (A captured 32-seed step runs on the upper-bound
-# block, 832 destination rows of which 100-230 are live: padded rows have no records and cost nothing, so the bound covers 832 x 500^2.)
+# block, 832 destination rows — 1 472 at the reference's pubmed setting, fanout 45 — of which 100-300 are live: padded rows have no records
+# and cost nothing, so the bound covers 1 472 x 500^2.  Measured, pubmed setting: 0.194 ms per step at 1 GiB (dense form), 0.1455 at 2 GiB.)
 SMALL_FIRST_DW = os.environ.get("OGL_SMALL_FIRST_DW", "1") != "0"
-SMALL_FIRST_DW_MAX_BYTES = int(os.environ.get("OGL_SMALL_FIRST_DW_MAX_BYTES", str(1 << 30)))
+SMALL_FIRST_DW_MAX_BYTES = int(os.environ.get("OGL_SMALL_FIRST_DW_MAX_BYTES", str(1 << 31)))
 
 
 def small_first_layer_fits(table, ids, idx, n_dst, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh):
