@@ -728,7 +728,9 @@ int ogl_small_pool_layer_bwd(const float* dy, int64_t lddy, const float* y, int6
  *        labels: label of row d = label_table[label_ids[d]] (label_ids NULL: label_table[d]); an id outside [0, n_labels) = no label.
  *        Outputs: y = logits [n_dst, Hout], loss_rows [n_dst], dlogits [n_dst, Hout], neigh [n_dst, Hin], argmax int32 [n_dst, Hin],
  *        G float [n_dst * Hin] (the winners' routed gradient), dh [n_src, Hin] (nullable; written completely: the fc_self path in the
- *        destinations' rows, zeros behind them).  *loss_mean is set to NaN: its value is the backward launch's.
+ *        destinations' rows, zeros behind them; dh_head_only: dh is [n_dst, Hin], only those head rows are written — for a consumer
+ *        that gathers the rest itself, ogl_small_first_layer_bwd's route).  *loss_mean is set to NaN: its value is the backward
+ *        launch's.
  *        zero_buf / zero_floats (multiple of 4, 16-byte aligned, nullable): a caller buffer cleared by fill-only blocks of the grid.
  *   ogl_small_pool_layer_bwd_pool: block 0 sums what crosses destinations — dWs / dWn [Hout, Hin], dbs / dbn [Hout] (nullable) from
  *        dlogits, h's head rows and neigh; *loss_mean = mean(loss_rows); step_dev / scalars_dev (both or neither): the optimiser's
@@ -741,8 +743,8 @@ int ogl_small_pool_layer_fwd_ce_bwd(const float* h, int64_t ldh, int64_t n_src, 
                                     const float* Wn, int64_t ldwn, const float* bn, int Hout, const int64_t* label_table,
                                     int64_t n_labels, const int64_t* label_ids, float grad_scale, float* neigh, int64_t ldn,
                                     int32_t* argmax, float* y, int64_t ldy, float* loss_rows, float* loss_mean, float* dlogits,
-                                    int64_t lddl, float* G, float* dh, int64_t lddh, float* zero_buf, int64_t zero_floats,
-                                    ogl_stream_t stream);
+                                    int64_t lddl, float* G, float* dh, int64_t lddh, int dh_head_only, float* zero_buf,
+                                    int64_t zero_floats, ogl_stream_t stream);
 int ogl_small_pool_layer_bwd_pool(const float* h, int64_t ldh, int64_t n_dst, int Hin, int Hout, const int32_t* argmax, const float* G,
                                   const float* Wp, int64_t ldwp, const float* neigh, int64_t ldn, const float* dlogits, int64_t lddl,
                                   const float* loss_rows, float* dWp, int64_t lddwp, float* dbp, float* dWs, int64_t lddws, float* dbs,
@@ -759,6 +761,11 @@ int ogl_small_pool_layer_bwd_pool(const float* h, int64_t ldh, int64_t n_dst, in
  *        input-gradient product), then the dense dneigh [n_dst, F] (mask_dneigh: zero where no winner takes it) and / or the winners'
  *        scatter dP[argmax[d, k], k] += dneigh[d, k] . [neigh[d, k] > 0] with float atomics into a ZEROED dP [n_src, F] (before: a
  *        third launch).
+ *        route_* (route_arg NULL: none; then dout is read): the gradient of y ROUTED IN from the small last layer that consumed it —
+ *        dout[d, k] = route_head[d, k] (d < route_n_head) + sum over the records q < route_n with route_arg[q] == d of route_G[q] .
+ *        route_W[q % route_H, k] (route_arg / route_G = that layer's argmax / G from ogl_small_pool_layer_fwd_ce_bwd with dh_head_only,
+ *        route_W its fc_pool weight, route_head its dh head rows): the winners' scatter of that layer as a gather by its consumer, in
+ *        record order — no atomics, no zeroed [n_src, H] matrix, and ogl_small_pool_layer_bwd_pool leaves the step.  route_n <= 2048.
  *   ogl_small_first_layer_fits: n_dst <= 8192, fanout <= 64, 16 <= F <= 1024, H <= 32.
  *   Sums over F run lane-parallel: fp32 rounding differs from the GEMM kernels' order; max / argmax are exact. */
 int ogl_small_first_layer_fits(int64_t n_src, int64_t n_dst, int fanout, int F, int H);
@@ -769,7 +776,27 @@ int ogl_small_first_layer_fwd(const float* P, int64_t ldp, int64_t n_src, const 
 int ogl_small_first_layer_bwd(const float* dout, int64_t lddo, const float* y, int64_t ldy, int relu_out, int64_t n_dst, int H, int F,
                               const float* Wn, int64_t ldwn, const float* neigh, int64_t ldn, const int32_t* argmax, float* dy,
                               int64_t lddy, float* dneigh, int64_t lddn, float* dP, int64_t lddp, int64_t n_src, int mask_dneigh,
-                              ogl_stream_t stream);
+                              const int32_t* route_arg, const float* route_G, int64_t route_n, int route_H, const float* route_W,
+                              int64_t route_ldw, const float* route_head, int64_t route_ldh, int64_t route_n_head, ogl_stream_t stream);
+/* Weight gradients from RECORDS, the general form: up to six row groups in ONE launch.  Group i writes, for r < n_out,
+ *     dW[r, :] = sum_{d < n_dst} G[d * ldg + r] . rows[id(d, r), :],   db[r] = db2[r] = sum_d G[d * ldg + r]  (db, db2 nullable)
+ * where id(d, r) = ids[w] (ids NULL: w), w = arg[d * ldarg + r] (arg NULL: d); a record whose weight is zero, whose w is outside
+ * [0, n_idx) or whose id is outside [0, n_rows) contributes nothing.  rows: [n_rows, F] read as float4 (ldr % 4 == 0, 16-byte aligned);
+ * n_dst <= 2048; sums in destination order (reproducible, no atomics).  The optional tail (loss_mean and / or step_dev non-NULL):
+ * *loss_mean = mean(loss_rows[0 .. n_loss)) in the order of ogl_ce_fwd_bwd_mean, and the optimiser's per-step scalars as in
+ * ogl_ce_fwd_bwd_mean_gather_adam.  What a 32-seed step uses it for: the first layer's three weight gradients AND the last layer's
+ * three (G = its routed gradient / dlogits, rows = its input rows / neigh), the deferred mean and Adam's scalars — one launch. */
+typedef struct {
+  const float* G; int64_t ldg;
+  const int32_t* arg; int64_t ldarg; int64_t n_idx;
+  const int64_t* ids;
+  const float* rows; int64_t ldr; int64_t n_rows; int F;
+  int64_t n_dst; int n_out;
+  float* dW; int64_t lddw; float* db; float* db2;
+} ogl_rec_seg_t;
+int ogl_record_weight_grads(const ogl_rec_seg_t* segs, int nseg, const float* loss_rows, int64_t n_loss, float* loss_mean,
+                            int64_t* step_dev, float* scalars_dev, double lr, double beta1, double beta2, ogl_stream_t stream);
+
 /* The three weight gradients of that layer from records, ONE launch (n_dst <= 2048), each "output row r = sum_d g(d, r) . row(d, r)":
  *   dWp[j, :] = sum_d G[d, j] X[ids[argmax[d, j]], :], dbp[j] = sum_d G[d, j]   (G [n_dst, F] = the MASKED dneigh: ogl_small_first_layer_bwd
  *        with mask_dneigh = 1) — n_dst F records of F MACs instead of the dense [F, n_src] x [n_src, F] product, its zeroed scatter target

@@ -16,6 +16,7 @@
 //
 // Limits (ogl_small_pool_layer_fits): Hin, Hout <= 64, n_dst * max(Hin, Hout) <= 8192, n_src <= 65536.
 #include "ogl_common.h"
+#include "ogl_hip.h"
 #include <algorithm>
 
 #define SL_MAX_H 64
@@ -254,7 +255,7 @@ struct SmallLossArgs {
   const float* Wn; int64_t ldwn; const float* bn; int Hout;
   const int64_t* labels; int64_t n_labels; const int64_t* label_ids; float grad_scale;
   float* neigh; int64_t ldn; int32_t* argmax; float* y; int64_t ldy; float* loss_rows; float* loss_mean; float* dl; int64_t lddl;
-  float* G; float* dh; int64_t lddh;
+  float* G; float* dh; int64_t lddh; int dh_head_only;
   float4* zero_buf; int64_t zero_n4;
 };
 
@@ -308,7 +309,7 @@ __global__ void __launch_bounds__(256) k_small_loss(SmallLossArgs a) {
     const int32_t r = row[s];
     R[s * ldw + k] = (r >= 0 && r < a.n_src) ? a.h[(int64_t)r * a.ldh + k] : 0.f;
   }
-  if (a.dh) {                                                // dh rows behind the destinations: zeros (the row blocks share them)
+  if (a.dh && !a.dh_head_only) {                             // dh rows behind the destinations: zeros (the row blocks share them)
     const int64_t nz = (int64_t)(a.n_src - a.n_dst) * Hin;
     for (int64_t i = (int64_t)d * 256 + tid; i < nz; i += (int64_t)a.n_dst * 256)
       a.dh[(a.n_dst + i / Hin) * a.lddh + i % Hin] = 0.f;
@@ -521,7 +522,7 @@ extern "C" int ogl_small_pool_layer_fwd_ce_bwd(const float* h, int64_t ldh, int6
                                                const int64_t* label_table, int64_t n_labels, const int64_t* label_ids, float grad_scale,
                                                float* neigh, int64_t ldn, int32_t* argmax, float* y, int64_t ldy, float* loss_rows,
                                                float* loss_mean, float* dlogits, int64_t lddl, float* G, float* dh, int64_t lddh,
-                                               float* zero_buf, int64_t zero_floats, ogl_stream_t stream) {
+                                               int dh_head_only, float* zero_buf, int64_t zero_floats, ogl_stream_t stream) {
   if (!ogl_small_pool_loss_fits(n_src, n_dst, fanout, Hin, Hout)) return OGL_EINVAL;
   if (!h || !idx || !Wp || !Ws || !Wn || !label_table || !neigh || !argmax || !y || !loss_rows || !loss_mean || !dlogits || !G)
     return OGL_EINVAL;
@@ -533,7 +534,8 @@ extern "C" int ogl_small_pool_layer_fwd_ce_bwd(const float* h, int64_t ldh, int6
   a.Wp = Wp; a.ldwp = ldwp; a.bp = bp; a.Ws = Ws; a.ldws = ldws; a.bs = bs; a.Wn = Wn; a.ldwn = ldwn; a.bn = bn; a.Hout = Hout;
   a.labels = label_table; a.n_labels = n_labels; a.label_ids = label_ids; a.grad_scale = grad_scale;
   a.neigh = neigh; a.ldn = ldn; a.argmax = argmax; a.y = y; a.ldy = ldy; a.loss_rows = loss_rows; a.loss_mean = loss_mean;
-  a.dl = dlogits; a.lddl = lddl; a.G = G; a.dh = dh; a.lddh = lddh; a.zero_buf = (float4*)zero_buf; a.zero_n4 = zero_floats / 4;
+  a.dl = dlogits; a.lddl = lddl; a.G = G; a.dh = dh; a.lddh = lddh; a.dh_head_only = dh_head_only;
+  a.zero_buf = (float4*)zero_buf; a.zero_n4 = zero_floats / 4;
   const int64_t extra = std::min<int64_t>(768, ogl_cdiv(zero_floats, 4096));     // fill-only blocks behind the n_dst row blocks
   hipLaunchKernelGGL(k_small_loss, dim3((unsigned)(n_dst + extra)), dim3(256), 0, (hipStream_t)stream, a);
   OGL_CHECK_LAUNCH();
@@ -696,18 +698,52 @@ __global__ void __launch_bounds__(256) k_small_first_fwd(const float* __restrict
   }
 }
 
+// The gradient of the layer's OUTPUT routed in from the small last layer that consumed it (ogl_small_pool_layer_fwd_ce_bwd's G / head
+// rows / argmax): dout[d, k] = head[d, k] (d < n_head) + sum over the records q = (d1, j) with arg[q] == d of G[q] W[j, k] — the
+// winners' scatter of that layer's fc_pool as a GATHER by the consumer: no atomics (record order), no zeroed [n_src, H] matrix, and
+// that layer's backward launch (k_small_bwd_b2) disappears from the step.  n <= SFB_ROUTE_MAX records.
+#define SFB_ROUTE_MAX 2048
+struct SfbRoute { const int32_t* arg; const float* G; const float* W; int64_t ldw; const float* head; int64_t ldh; int n_head, Hr, n; };
+
 __global__ void __launch_bounds__(256) k_small_first_bwd(const float* __restrict__ dout, int64_t lddo, const float* __restrict__ y, int64_t ldy,
                                                          int relu_out, int n_dst, int H, int F, const float* __restrict__ Wn, int64_t ldwn,
                                                          const float* __restrict__ neigh, int64_t ldn, const int32_t* __restrict__ argmax,
                                                          float* __restrict__ dy, int64_t lddy, float* __restrict__ dneigh, int64_t lddn,
-                                                         float* __restrict__ dP, int64_t lddp, int n_src, int mask_dneigh) {
+                                                         float* __restrict__ dP, int64_t lddp, int n_src, int mask_dneigh, SfbRoute rt) {
   // one workgroup per destination, thread t = float4 column t of the row (F <= 1024): H independent weight loads per thread
   __shared__ float G[SFL_H];
-  const int t = threadIdx.x;
+  __shared__ float MG[SFB_ROUTE_MAX];
+  __shared__ short MJ[SFB_ROUTE_MAX];
+  __shared__ int cnt_w[4];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int d = blockIdx.x;
   const int f4 = (F + 3) >> 2;
+  int nm = 0;
+  if (rt.arg) {                                              // this destination's records, compacted in record order
+    for (int q0 = 0; q0 < rt.n; q0 += 256) {
+      const int q = q0 + t;
+      float g = 0.f;
+      bool flag = false;
+      if (q < rt.n && rt.arg[q] == d) { g = rt.G[q]; flag = g != 0.f; }
+      const unsigned long long bal = __ballot(flag);
+      const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) cnt_w[wv] = __popcll(bal);
+      __syncthreads();
+      int off = nm;
+      for (int w = 0; w < wv; ++w) off += cnt_w[w];
+      if (flag) { MG[off + pre] = g; MJ[off + pre] = (short)(q % rt.Hr); }
+      nm += cnt_w[0] + cnt_w[1] + cnt_w[2] + cnt_w[3];
+      __syncthreads();
+    }
+  }
   if (t < H) {
-    float g = dout[(int64_t)d * lddo + t];
+    float g;
+    if (rt.arg) {
+      g = d < rt.n_head ? rt.head[(int64_t)d * rt.ldh + t] : 0.f;
+      for (int m = 0; m < nm; ++m) g = fmaf(MG[m], rt.W[(int64_t)MJ[m] * rt.ldw + t], g);
+    } else {
+      g = dout[(int64_t)d * lddo + t];
+    }
     if (relu_out && !(y[(int64_t)d * ldy + t] > 0.f)) g = 0.f;
     dy[(int64_t)d * lddy + t] = g;
     G[t] = g;
@@ -771,14 +807,23 @@ extern "C" int ogl_small_first_layer_fwd(const float* P, int64_t ldp, int64_t n_
 extern "C" int ogl_small_first_layer_bwd(const float* dout, int64_t lddo, const float* y, int64_t ldy, int relu_out, int64_t n_dst, int H,
                                          int F, const float* Wn, int64_t ldwn, const float* neigh, int64_t ldn, const int32_t* argmax,
                                          float* dy, int64_t lddy, float* dneigh, int64_t lddn, float* dP, int64_t lddp, int64_t n_src,
-                                         int mask_dneigh, ogl_stream_t stream) {
+                                         int mask_dneigh, const int32_t* route_arg, const float* route_G, int64_t route_n, int route_H,
+                                         const float* route_W, int64_t route_ldw, const float* route_head, int64_t route_ldh,
+                                         int64_t route_n_head, ogl_stream_t stream) {
   if (n_dst <= 0 || n_dst > 8192 || H <= 0 || H > SFL_H || F < 16 || F > 1024 || n_src <= 0 || n_src >= (1 << 30)) return OGL_EINVAL;
-  if (!dout || !Wn || !dy || (relu_out && !y) || (!dneigh && !dP) || ((dP || mask_dneigh) && (!argmax || !neigh))) return OGL_EINVAL;
-  if (lddo < H || (relu_out && ldy < H) || lddy < H || ldwn < F || (ldwn & 3) || ((uintptr_t)Wn & 15) || (dneigh && lddn < F) ||
+  if ((!dout && !route_arg) || !Wn || !dy || (relu_out && !y) || (!dneigh && !dP) || ((dP || mask_dneigh) && (!argmax || !neigh)))
+    return OGL_EINVAL;
+  if (route_arg && (!route_G || !route_W || !route_head || route_n <= 0 || route_n > SFB_ROUTE_MAX || route_H <= 0 || route_H > 64 ||
+                    route_ldw < H || route_ldh < H || route_n_head < 0 || route_n % route_H))
+    return OGL_EINVAL;
+  if ((!route_arg && lddo < H) || (relu_out && ldy < H) || lddy < H || ldwn < F || (ldwn & 3) || ((uintptr_t)Wn & 15) || (dneigh && lddn < F) ||
       (dP && lddp < F) || ((dP || mask_dneigh) && ldn < F))
     return OGL_EINVAL;
+  SfbRoute rt;
+  rt.arg = route_arg; rt.G = route_G; rt.W = route_W; rt.ldw = route_ldw; rt.head = route_head; rt.ldh = route_ldh;
+  rt.n_head = (int)route_n_head; rt.Hr = route_H > 0 ? route_H : 1; rt.n = (int)route_n;
   hipLaunchKernelGGL(k_small_first_bwd, dim3((unsigned)n_dst), dim3(256), 0, (hipStream_t)stream, dout, lddo, y, ldy, relu_out, (int)n_dst, H, F,
-                     Wn, ldwn, neigh, ldn, argmax, dy, lddy, dneigh, lddn, dP, lddp, (int)n_src, mask_dneigh);
+                     Wn, ldwn, neigh, ldn, argmax, dy, lddy, dneigh, lddn, dP, lddp, (int)n_src, mask_dneigh, rt);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }
@@ -793,27 +838,42 @@ extern "C" int ogl_small_first_layer_bwd(const float* dout, int64_t lddo, const 
 // reproducible, no atomics.  (The record idea fed to the MFMA tiles lost at the Reddit shape — 4.2 M records re-read per column tile,
 // DESIGN section 8; here the rows come from L2 and there is nothing to tile.)
 #define SFD_MAX_DST 2048
-struct SfdSeg {
-  const float* G; int64_t ldg;                 // weights: G[d * ldg + r]
-  const int32_t* arg; int64_t ldarg; int n_idx;   // optional indirection: w = arg[d * ldarg + r] in [0, n_idx); NULL: w = d
-  const int64_t* ids;                          // optional second indirection: row id = ids[w]; NULL: w
-  const float* rows; int64_t ldr; int64_t n_rows;
-  float* dW; int64_t lddw; float* db; float* db2;
-  int first, count;                            // its blocks: [first, first + count)
+#define SFD_MAX_SEG 6
+struct SfdArgs {
+  ogl_rec_seg_t seg[SFD_MAX_SEG];
+  int first[SFD_MAX_SEG + 1];                  // segment i owns blocks [first[i], first[i + 1]); one more block = the tail
+  int nseg;
+  const float* loss_rows; int n_loss; float* loss_mean;       // tail block (optional): the mean of the row losses ...
+  int64_t* adam_step; float* adam_scal; double adam_lr, adam_b1, adam_b2;   // ... and the optimiser's per-step scalars
 };
-struct SfdArgs { SfdSeg seg[3]; int nseg; int n_dst; int F; };
 
 __global__ void __launch_bounds__(256) k_small_first_dw(SfdArgs a) {
   __shared__ float GS[SFD_MAX_DST + 8];
   __shared__ int64_t RS[SFD_MAX_DST + 8];
   __shared__ int cnt_w[4];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if ((int)blockIdx.x >= a.first[a.nseg]) {                  // the tail block
+    if (a.loss_mean && wv == 0) {                            // fixed order: lane l sums rows l, l + 64, ...; then the lanes (k_ce_fwd_bwd_mean's)
+      float s = 0.f;
+      for (int r = lane; r < a.n_loss; r += 64) s += a.loss_rows[r];
+      s = sll_wave_sum(s);
+      if (lane == 0) *a.loss_mean = s / (float)a.n_loss;
+    }
+    if (a.adam_step && t == 255) {
+      const int64_t st = *a.adam_step + 1;
+      *a.adam_step = st;
+      a.adam_scal[0] = (float)(a.adam_lr / (1.0 - pow(a.adam_b1, (double)st)));
+      a.adam_scal[1] = (float)(1.0 / sqrt(1.0 - pow(a.adam_b2, (double)st)));
+    }
+    return;
+  }
   int si = 0;
-  if (a.nseg > 1 && (int)blockIdx.x >= a.seg[1].first) si = 1;
-  if (a.nseg > 2 && (int)blockIdx.x >= a.seg[2].first) si = 2;
-  const SfdSeg& sg = a.seg[si];
-  const int j = blockIdx.x - sg.first;
-  const int F = a.F, n_dst = a.n_dst;
+#pragma unroll
+  for (int q = 1; q < SFD_MAX_SEG; ++q)
+    if (q < a.nseg && (int)blockIdx.x >= a.first[q]) si = q;
+  const ogl_rec_seg_t& sg = a.seg[si];
+  const int j = blockIdx.x - a.first[si];
+  const int F = sg.F, n_dst = (int)sg.n_dst;
   const int f4 = (F + 3) >> 2;
   int base = 0;                                              // (block-uniform: every thread keeps the same count)
   for (int d0 = 0; d0 < n_dst; d0 += 256) {
@@ -877,6 +937,37 @@ __global__ void __launch_bounds__(256) k_small_first_dw(SfdArgs a) {
   }
 }
 
+// The general form: up to six row groups ("segments", include/ogl_hip.h: ogl_rec_seg_t) in one launch, + an optional tail block that
+// finishes a deferred mean loss and advances the optimiser's step count — what lets a 32-seed step's LAST layer hand its whole
+// backward (weight gradients from its own records, the mean, Adam's scalars) to the first layer's launch.
+extern "C" int ogl_record_weight_grads(const ogl_rec_seg_t* segs, int nseg, const float* loss_rows, int64_t n_loss, float* loss_mean,
+                                       int64_t* step_dev, float* scalars_dev, double lr, double beta1, double beta2, ogl_stream_t stream) {
+  if (!segs || nseg <= 0 || nseg > SFD_MAX_SEG) return OGL_EINVAL;
+  if ((loss_mean && (!loss_rows || n_loss <= 0)) || (step_dev != nullptr) != (scalars_dev != nullptr)) return OGL_EINVAL;
+  SfdArgs a;
+  a.nseg = nseg;
+  int blocks = 0;
+  for (int i = 0; i < nseg; ++i) {
+    const ogl_rec_seg_t& s = segs[i];
+    if (!s.G || !s.rows || !s.dW || s.n_out <= 0 || s.n_dst <= 0 || s.n_dst > SFD_MAX_DST || s.F < 4 || s.F > 1024 || s.n_rows <= 0)
+      return OGL_EINVAL;
+    const int64_t f4x4 = ((int64_t)s.F + 3) / 4 * 4;
+    if (s.ldg < s.n_out || s.lddw < s.F || s.ldr < f4x4 || (s.ldr & 3) || ((uintptr_t)s.rows & 15) || (s.arg && (s.ldarg < s.n_out || s.n_idx <= 0)))
+      return OGL_EINVAL;
+    a.seg[i] = s;
+    a.first[i] = blocks;
+    blocks += s.n_out;
+  }
+  a.first[nseg] = blocks;
+  for (int i = nseg + 1; i <= SFD_MAX_SEG; ++i) a.first[i] = blocks;
+  a.loss_rows = loss_rows; a.n_loss = (int)n_loss; a.loss_mean = loss_mean;
+  a.adam_step = step_dev; a.adam_scal = scalars_dev; a.adam_lr = lr; a.adam_b1 = beta1; a.adam_b2 = beta2;
+  const int tail = (loss_mean || step_dev) ? 1 : 0;
+  hipLaunchKernelGGL(k_small_first_dw, dim3((unsigned)(blocks + tail)), dim3(256), 0, (hipStream_t)stream, a);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
 // G [n_dst, F] = the masked dneigh (NULL with dWp: no fc_pool segment); dy [n_dst, H]; dWp [F, F], dWs / dWn [H, F] (each nullable, with its
 // bias gradient dbp [F] / dbs, dbn [H]: the same sum written twice, one tensor per parameter); table rows X[ids[.]] (ids NULL: the row
 // index itself); neigh [n_dst, F].  Rows are read as float4: ldt, ldn multiples of 4, 16-byte aligned bases.
@@ -887,28 +978,21 @@ extern "C" int ogl_small_first_layer_dw(const float* G, int64_t ldg, const int32
   if (n_dst <= 0 || n_dst > SFD_MAX_DST || F < 16 || F > 1024 || H <= 0 || H > 64 || n_table <= 0 || n_src <= 0 || n_src >= (1 << 30))
     return OGL_EINVAL;
   if (!table || (!dWp && !dWs && !dWn)) return OGL_EINVAL;
-  const int64_t f4x4 = ((int64_t)F + 3) / 4 * 4;
-  if (ldt < f4x4 || (ldt & 3) || ((uintptr_t)table & 15)) return OGL_EINVAL;
-  if (dWp && (!G || !argmax || ldg < F || lddwp < F)) return OGL_EINVAL;
-  if ((dWs || dWn) && (!dy || lddy < H)) return OGL_EINVAL;
-  if (dWs && lddws < F) return OGL_EINVAL;
-  if (dWn && (!neigh || lddwn < F || ldn < f4x4 || (ldn & 3) || ((uintptr_t)neigh & 15))) return OGL_EINVAL;
-  SfdArgs a;
-  a.nseg = 0; a.n_dst = (int)n_dst; a.F = F;
-  int blocks = 0;
-  auto add = [&](const float* g, int64_t ld, const int32_t* arg, int n_idx, const int64_t* idp, const float* rows, int64_t ldr, int64_t n_rows,
-                 float* dW, int64_t lddw, float* db, float* db2, int count) {
-    SfdSeg& s = a.seg[a.nseg++];
-    s.G = g; s.ldg = ld; s.arg = arg; s.ldarg = F; s.n_idx = n_idx; s.ids = idp; s.rows = rows; s.ldr = ldr; s.n_rows = n_rows;
-    s.dW = dW; s.lddw = lddw; s.db = db; s.db2 = db2; s.first = blocks; s.count = count;
-    blocks += count;
+  if (dWp && (!G || !argmax)) return OGL_EINVAL;
+  if ((dWs || dWn) && !dy) return OGL_EINVAL;
+  if (dWn && !neigh) return OGL_EINVAL;
+  ogl_rec_seg_t segs[3];
+  int n = 0;
+  auto add = [&](const float* g, int64_t ld, const int32_t* arg, int64_t n_idx, const int64_t* idp, const float* rows, int64_t ldr,
+                 int64_t n_rows, float* dW, int64_t lddw, float* db, float* db2, int count) {
+    ogl_rec_seg_t& s = segs[n++];
+    s.G = g; s.ldg = ld; s.arg = arg; s.ldarg = F; s.n_idx = n_idx; s.ids = idp; s.rows = rows; s.ldr = ldr; s.n_rows = n_rows; s.F = F;
+    s.n_dst = n_dst; s.n_out = count; s.dW = dW; s.lddw = lddw; s.db = db; s.db2 = db2;
   };
-  if (dWp) add(G, ldg, argmax, (int)n_src, ids, table, ldt, n_table, dWp, lddwp, dbp, nullptr, F);
+  if (dWp) add(G, ldg, argmax, n_src, ids, table, ldt, n_table, dWp, lddwp, dbp, nullptr, F);
   if (dWs) add(dy, lddy, nullptr, 0, ids, table, ldt, n_table, dWs, lddws, dbs, dWn ? nullptr : dbn, H);
   if (dWn) add(dy, lddy, nullptr, 0, nullptr, neigh, ldn, n_dst, dWn, lddwn, dbn, dWs ? nullptr : dbs, H);
-  hipLaunchKernelGGL(k_small_first_dw, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
-  OGL_CHECK_LAUNCH();
-  return OGL_OK;
+  return ogl_record_weight_grads(segs, n, nullptr, 0, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, stream);
 }
 
 // workspace (floats): forward n_src * Hin (the projected rows), backward n_dst * Hin (the routed gradient)

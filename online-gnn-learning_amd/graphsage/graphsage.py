@@ -143,7 +143,9 @@ class GraphSAGE(nn.Module):
             self.layers[-1].preplan_loss(blocks[-1])
         for layer, block in zip(self.layers[:-1], blocks[:-1]):
             h = layer(block, h)
-        out = self.layers[-1].forward_loss(blocks[-1], h, labels, defer_mean=defer_mean) if len(self.layers) == len(blocks) else None
+        # (``h`` was made here and goes to the last layer only: that layer may hand its whole backward to the node that made ``h``)
+        out = self.layers[-1].forward_loss(blocks[-1], h, labels, defer_mean=defer_mean, h_single_use=len(blocks) > 1) \
+            if len(self.layers) == len(blocks) else None
         if len(blocks) > 0 and hasattr(blocks[-1], "_ogl_seg_plan"):
             del blocks[-1]._ogl_seg_plan
         if out is not None:

@@ -244,7 +244,7 @@ class SAGEConv(nn.Module):
             if idx.dtype == torch.int32 and idx.is_contiguous() and ops.seg_bwd_fits(idx, self._in_feats, n_src):
                 graph._ogl_seg_plan = ops.reduce_bwd_seg_plan(idx, self._in_feats, n_src)
 
-    def forward_loss(self, graph, feat, labels, defer_mean=False):
+    def forward_loss(self, graph, feat, labels, defer_mean=False, h_single_use=False):
         """This layer as the LAST layer of a train step, fused with nn.CrossEntropyLoss: (mean loss, per-seed losses, logits) from
         one autograd node whose forward is the fc_pool product + ONE launch (``ops.sage_pool_layer_loss``) — or None when that form
         does not apply (the caller runs ``forward`` and the loss separately; same values, same gradients).
@@ -267,7 +267,7 @@ class SAGEConv(nn.Module):
             return None
         return ops.sage_pool_layer_loss(feat, self.fc_pool.weight, self.fc_pool.bias, self.fc_self.weight, self.fc_neigh.weight,
                                         self.fc_self.bias, self.fc_neigh.bias, graph.local_idx, graph.number_of_dst_nodes(), labels,
-                                        defer_mean=defer_mean)
+                                        defer_mean=defer_mean, h_single_use=h_single_use)
 
     def _forward_fused_batches(self, graph, feat, idx, dst_pos, fuse_relu):
         """Inference on several loader batches fused into one block (sampling.sample_batches(fuse_rows=...)): the same three

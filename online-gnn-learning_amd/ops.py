@@ -2812,7 +2812,7 @@ def sage_mean_layer_loss(h, w_cat, bias, idx, n_dst, labels, defer_mean=False, p
     return _SageMeanLossFn.apply(h, w_cat, bias, idx, n_dst, labels, bool(defer_mean), plan)
 
 
-def sage_pool_layer_loss(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels, defer_mean=False):
+def sage_pool_layer_loss(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels, defer_mean=False, h_single_use=False):
     """(mean CE loss, per-seed losses, logits) of the last 'pool' layer + nn.CrossEntropyLoss, or None when the fused form does not
     apply (the caller then runs the layer and the loss separately)."""
     if h.dim() != 2:
@@ -2820,7 +2820,11 @@ def sage_pool_layer_loss(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, id
     if small_pool_layer_fits(h.shape[0], n_dst, idx.shape[1], h.shape[1], w_self.shape[0]):
         # (two launches for the layer, its loss and their backward; the mean's VALUE comes from the second: deferring callers only)
         if defer_mean and DEFER_LOSS_MEAN and small_pool_loss_fits(h, w_pool, w_self, w_neigh, idx, n_dst, labels):
-            return _SmallPoolLossFn.apply(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels)
+            # (``h_single_use``: the caller made ``h`` and hands it to this layer only — GraphSAGE.forward_loss.  When it came out of the
+            # small first layer, this node's whole backward moves into that layer's two launches: see ``_SmallPoolLossFn``)
+            lazy = bool(SMALL_ROUTE and h_single_use and h.requires_grad and type(h.grad_fn).__name__ == "_SmallFirstLayerFnBackward"
+                        and n_dst * h.shape[1] <= 2048)
+            return _SmallPoolLossFn.apply(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels, lazy)
         return None
     if (b_self is None) != (b_neigh is None) or not out_loss_fits(h, n_dst, idx, w_self, w_neigh, w_pool.shape[0]):
         return None
@@ -2911,9 +2915,10 @@ class _SmallPoolLossFn(torch.autograd.Function):
     Returns (mean loss, per-seed losses, logits); only the mean is differentiable."""
 
     @staticmethod
-    def forward(ctx, h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels):
+    def forward(ctx, h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels, lazy=False):
         h = as_mat(h); w_pool = as_mat(w_pool); w_self = as_mat(w_self); w_neigh = as_mat(w_neigh)
         n_src, hin = h.shape
+        ctx.lazy = bool(lazy)
         hout = w_self.shape[0]
         dev = h.device
         lazy = labels if isinstance(labels, LazyLabels) else None
@@ -2928,7 +2933,8 @@ class _SmallPoolLossFn(torch.autograd.Function):
         mean = torch.empty((), dtype=torch.float32, device=dev)
         dl = empty_mat(n_dst, hout, dev)
         G = torch.empty(max(n_dst * hin, 4), dtype=torch.float32, device=dev)
-        dh = empty_mat(n_src, hin, dev) if h.requires_grad else None
+        # (lazy: only the destinations' head rows of dh — the fc_self path; the consumer gathers the winners' rows itself)
+        dh = (empty_mat(n_dst if ctx.lazy else n_src, hin, dev)) if h.requires_grad else None
         stream = _stream()
         zbuf, zn = None, 0
         key = (dev.index, stream)
@@ -2941,7 +2947,7 @@ class _SmallPoolLossFn(torch.autograd.Function):
                 int(idx.shape[1]), hin, _ptr(w_pool), _ld(w_pool), _ptr(b_pool), _ptr(w_self), _ld(w_self), _ptr(b_self), _ptr(w_neigh),
                 _ld(w_neigh), _ptr(b_neigh), hout, _ptr(table), table.numel(), _ptr(ids), C.c_float(1.0 / n_dst), _ptr(neigh), _ld(neigh),
                 _ptr(argmax), _ptr(logits), _ld(logits), _ptr(rows), _ptr(mean), _ptr(dl), _ld(dl), _ptr(G), _ptr(dh),
-                _ld(dh) if dh is not None else 0, _ptr(zbuf), zn, stream,
+                _ld(dh) if dh is not None else 0, 1 if ctx.lazy else 0, _ptr(zbuf), zn, stream,
                 meta=dict(n_src=n_src, n_dst=n_dst, hin=hin, hout=hout, zero_bytes=4 * zn))
         # the optimiser's per-step scalars ride in this node's BACKWARD launch (the 32-seed steps have no weight-image launch): the
         # request is taken here so that no launch in between serves it twice; without a backward the optimiser prepares itself
@@ -2980,7 +2986,7 @@ class _SmallPoolLossFn(torch.autograd.Function):
             torch.mul(dl, dloss, out=dls)
             dl, G = dls, G * dloss
             if dh is not None:
-                dhs = empty_mat(n_src, hin, dev)
+                dhs = empty_mat(dh.shape[0], hin, dev)
                 torch.mul(dh, dloss, out=dhs)
                 dh = dhs
         has_bp, has_bs, has_bn = ctx.flags
@@ -2995,6 +3001,21 @@ class _SmallPoolLossFn(torch.autograd.Function):
         if ctx.prime is not None:
             step_dev, scal, lr, b1, b2 = ctx.prime
             ctx.prime = None
+        if ctx.lazy:
+            # NO launch here: the gradient handed to the first layer is an EMPTY [n_src, hin] matrix that stands for the route (its
+            # consumer, _SmallFirstLayerFn.backward, finds the route by the matrix' address, gathers the winners' rows inside its own
+            # launch and never reads the matrix); this node's weight gradients, the mean loss and the optimiser's scalars are written by
+            # that layer's record launch (ogl_record_weight_grads) — the tensors returned below are filled by it, in stream order before
+            # anything reads them (the optimiser, a collective: both are enqueued after the first layer's backward)
+            dh_full = empty_mat(n_src, hin, dev)
+            _PENDING_ROUTES.clear()
+            _PENDING_ROUTES[dh_full.data_ptr()] = dict(argmax=argmax, G=G, w_pool=w_pool, head=dh, n_head=ctx.n_dst, hin=hin, hout=hout, dl=dl,
+                                                       neigh=neigh, h=h, rows=rows, mean=mean, prime=(step_dev, scal, lr, b1, b2) if step_dev is not None else None,
+                                                       # (ADDRESSES, not tensors: AccumulateGrad adopts a gradient only when nobody else
+                                                       # holds it and otherwise CLONES it — here: a copy of memory nothing has written yet)
+                                                       out=tuple(t.data_ptr() if t is not None else None for t in (dwp, dbp, dws, dbs, dwn, dbn)),
+                                                       keep=dh_full)
+            return dh_full, dwp, dbp, dws, dwn, dbs, dbn, None, None, None, None
         _launch("ogl_small_pool_layer_bwd_pool", _lib.lib().ogl_small_pool_layer_bwd_pool, _ptr(h), _ld(h), ctx.n_dst, hin, hout, _ptr(argmax),
                 _ptr(G), _ptr(w_pool), _ld(w_pool), _ptr(neigh), _ld(neigh), _ptr(dl), _ld(dl), _ptr(rows), _ptr(dwp), hin, _ptr(dbp),
                 _ptr(dws), hin, _ptr(dbs), _ptr(dwn), hin, _ptr(dbn), _ptr(dh), _ld(dh) if dh is not None else 0, _ptr(mean), _ptr(step_dev),
@@ -3002,9 +3023,13 @@ class _SmallPoolLossFn(torch.autograd.Function):
                 meta=dict(n_src=n_src, n_dst=ctx.n_dst, hin=hin, hout=hout, adam_prepare=step_dev is not None))
         if step_dev is not None:
             _ADAM_PRIME["served"] = (step_dev.data_ptr(), _capturing())
-        return dh, dwp, dbp, dws, dwn, dbs, dbn, None, None, None
+        return dh, dwp, dbp, dws, dwn, dbs, dbn, None, None, None, None
 
 
+# the small last layer's whole backward inside the small first layer's two launches (its input gradient gathered by the consumer, its
+# weight gradients as three more row groups of the record launch): no launch of its own, no float atomics
+SMALL_ROUTE = os.environ.get("OGL_SMALL_ROUTE", "1") != "0"
+_PENDING_ROUTES = {}
 SMALL_FIRST_FUSED = os.environ.get("OGL_SMALL_FIRST_FUSED", "1") != "0"   # the first 'pool' layer of a 32-seed step: max + combine in one launch
 SMALL_FIRST_MAX_DST = 2048
 # fc_pool's weight gradient of that layer from the winners' records (ogl_small_first_layer_dw) while the rows it would gather from L2 if
@@ -3079,6 +3104,7 @@ class _SmallFirstLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x, ids, w_pool, w_self, w_neigh, neigh, argmax, y, idx = ctx.saved_tensors
+        route = _PENDING_ROUTES.pop(dout.data_ptr(), None)      # (the small last layer's backward, handed over: see _SmallPoolLossFn)
         dout = as_mat(dout)
         n_src, n_dst = ctx.n_src, ctx.n_dst
         F, H = neigh.shape[1], w_self.shape[0]
@@ -3098,8 +3124,11 @@ class _SmallFirstLayerFn(torch.autograd.Function):
         _launch("ogl_small_first_layer_bwd", _lib.lib().ogl_small_first_layer_bwd, _ptr(dout), _ld(dout), _ptr(y), _ld(y) if y is not None else 0,
                 int(ctx.relu), n_dst, H, F, _ptr(w_neigh), _ld(as_mat(w_neigh)), _ptr(neigh), _ld(neigh), _ptr(argmax), _ptr(dy), _ld(dy),
                 _ptr(dneigh), _ld(dneigh) if dneigh is not None else 0, _ptr(dP), _ld(dP) if dP is not None else 0, n_src,
-                1 if (need_pool and ctx.rec_path) else 0, _stream(),
-                meta=dict(n_src=n_src, n_dst=n_dst, d=F, H=H, scatter=dP is not None))
+                1 if (need_pool and ctx.rec_path) else 0,
+                _ptr(route["argmax"]) if route else None, _ptr(route["G"]) if route else None, route["n_head"] * route["hin"] if route else 0,
+                route["hin"] if route else 0, _ptr(route["w_pool"]) if route else None, _ld(route["w_pool"]) if route else 0,
+                _ptr(route["head"]) if route else None, _ld(route["head"]) if route else 0, route["n_head"] if route else 0, _stream(),
+                meta=dict(n_src=n_src, n_dst=n_dst, d=F, H=H, scatter=dP is not None, routed=route is not None))
         # the combine's two weight gradients (+ both bias gradients) and — on the record path — fc_pool's, ONE launch
         dws = dwn = db = db2 = dwp = dbp = None
         rec = need_pool and ctx.rec_path
@@ -3117,11 +3146,10 @@ class _SmallFirstLayerFn(torch.autograd.Function):
                 dwp = _dw_out(w_pool, *w_pool.shape)
                 dwp = dwp if dwp is not None else torch.empty((F, F), dtype=torch.float32, device=dev)
                 dbp = torch.empty(F, dtype=torch.float32, device=dev) if ctx.has_pool_bias else None
-            _launch("ogl_small_first_layer_dw", _lib.lib().ogl_small_first_layer_dw, _ptr(dneigh) if rec else None,
-                    _ld(dneigh) if rec else 0, _ptr(argmax), _ptr(dy), _ld(dy), n_dst, F, H, _ptr(x), _ld(x), _ptr(ids), x.shape[0], n_src,
-                    _ptr(neigh), _ld(neigh), _ptr(dwp), _ld(as_mat(dwp)) if dwp is not None else 0, _ptr(dbp), _ptr(dws),
-                    _ld(as_mat(dws)) if dws is not None else 0, _ptr(db), _ptr(dwn), _ld(as_mat(dwn)) if dwn is not None else 0, _ptr(db2),
-                    _stream(), meta=dict(n_src=n_src, n_dst=n_dst, d=F, H=H, records=bool(rec)))
+            _record_launch(rec, dneigh, argmax, dy, n_dst, F, H, x, ids, n_src, neigh, dwp, dbp, dws, db, dwn, db2, route)
+            route = None
+        if route is not None:                                  # (nothing of this layer's to sum: the handed-over groups alone)
+            _record_launch(False, None, None, None, n_dst, F, H, x, ids, n_src, neigh, None, None, None, None, None, None, route)
         if rec:
             pass
         elif need_pool and ctx.x3_path:
@@ -3135,6 +3163,51 @@ class _SmallFirstLayerFn(torch.autograd.Function):
             dwp, dbp = weight_grad(dP, x, ids, want_bias=ctx.has_pool_bias, dw_out=_dw_out(w_pool, *w_pool.shape))
         return (None, None, dwp, dbp if ctx.has_pool_bias else None, dws, dwn, db if ctx.has_bias else None,
                 db2 if ctx.has_bias else None, None, None, None)
+
+
+def _record_launch(rec, dneigh, argmax, dy, n_dst, F, H, x, ids, n_src, neigh, dwp, dbp, dws, db, dwn, db2, route):
+    """ONE ogl_record_weight_grads launch: the small first layer's row groups (fc_pool from the winners' records when ``rec``; fc_self,
+    fc_neigh) and, when the small last layer handed its backward over (``route``), that layer's three + the deferred mean loss + the
+    optimiser's per-step scalars."""
+    segs = []
+
+    def seg(G, arg, ldarg, n_idx, idp, rows, n_rows, Fw, nd, n_out, dW, b1_, b2_):
+        sg = _lib.RecSeg()
+        sg.G, sg.ldg = _ptr(G), _ld(as_mat(G)) if G.dim() == 2 else n_out
+        sg.arg, sg.ldarg, sg.n_idx = _ptr(arg), ldarg, n_idx
+        sg.ids, sg.rows, sg.ldr, sg.n_rows, sg.F = _ptr(idp), _ptr(rows), _ld(rows), n_rows, Fw
+        if isinstance(dW, torch.Tensor):
+            sg.dW, sg.lddw, sg.db, sg.db2 = _ptr(dW), _ld(as_mat(dW)), _ptr(b1_), _ptr(b2_)
+        else:                                                   # (raw addresses of contiguous [n_out, Fw] / [n_out] gradients: a route's)
+            sg.dW, sg.lddw, sg.db, sg.db2 = dW, Fw, b1_, b2_
+        sg.n_dst, sg.n_out = nd, n_out
+        segs.append(sg)
+    if rec:
+        seg(dneigh, argmax, F, n_src, ids, x, x.shape[0], F, n_dst, F, dwp, dbp, None)
+    if dws is not None:
+        seg(dy, None, 0, 0, ids, x, x.shape[0], F, n_dst, H, dws, db, None)
+    if dwn is not None:
+        seg(dy, None, 0, 0, None, neigh, n_dst, F, n_dst, H, dwn, db2, None)
+    rows_l = mean_l = None
+    step_dev = scal = None
+    lr = b1 = b2 = 0.0
+    if route is not None:
+        nh, hin, hout = route["n_head"], route["hin"], route["hout"]
+        rdwp, rdbp, rdws, rdbs, rdwn, rdbn = route["out"]
+        h1 = route["h"]
+        seg(route["G"].view(nh, hin) if route["G"].numel() == nh * hin else route["G"][:nh * hin].view(nh, hin), route["argmax"], hin, h1.shape[0],
+            None, h1, h1.shape[0], hin, nh, hin, rdwp, rdbp, None)
+        seg(route["dl"], None, 0, 0, None, h1, h1.shape[0], hin, nh, hout, rdws, rdbs, None)
+        seg(route["dl"], None, 0, 0, None, route["neigh"], nh, hin, nh, hout, rdwn, rdbn, None)
+        rows_l, mean_l = route["rows"], route["mean"]
+        if route["prime"] is not None:
+            step_dev, scal, lr, b1, b2 = route["prime"]
+    arr = (_lib.RecSeg * len(segs))(*segs)
+    _launch("ogl_record_weight_grads", _lib.lib().ogl_record_weight_grads, C.addressof(arr), len(segs), _ptr(rows_l),
+            rows_l.numel() if rows_l is not None else 0, _ptr(mean_l), _ptr(step_dev), _ptr(scal), C.c_double(lr), C.c_double(b1), C.c_double(b2),
+            _stream(), meta=dict(n_src=n_src, n_dst=n_dst, d=F, H=H, records=bool(rec), routed=route is not None, groups=len(segs)))
+    if step_dev is not None:
+        _ADAM_PRIME["served"] = (step_dev.data_ptr(), _capturing())
 
 
 def small_first_pool_layer(table, ids, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu):

@@ -335,3 +335,51 @@ def test_small_first_layer_max_and_combine_in_one_launch(T, n_src, n_dst, S, F_i
         scale = max(1.0, float(np.abs(pr[k].grad.numpy()).max()))
         np.testing.assert_allclose(g1[k], pr[k].grad.numpy(), rtol=1e-3, atol=2e-5 * scale, err_msg=k)
         np.testing.assert_allclose(g1[k], g0[k], rtol=1e-3, atol=2e-5 * scale, err_msg=k)
+
+
+@pytest.mark.parametrize("T,n0,n1,B,S,F_in,C_out", [(4000, 900, 120, 32, 25, 500, 3), (9000, 2600, 230, 32, 25, 128, 40), (600, 200, 64, 16, 7, 64, 5),
+                                                    (3000, 1472, 1472, 32, 45, 500, 3)])
+def test_small_step_last_layer_backward_inside_the_first_layers_launches(T, n0, n1, B, S, F_in, C_out):
+    """A 32-seed step whose last layer hands its WHOLE backward to the first layer's two launches (ops.SMALL_ROUTE: the gradient of the
+    hidden rows gathered by the consumer from the last layer's records — ogl_small_first_layer_bwd's route —, its three weight gradients,
+    the deferred mean loss and Adam's scalars as row groups / the tail of ogl_record_weight_grads) against the same step with that
+    layer's own backward launch: loss equal, every gradient rtol 1e-4 / atol 1e-6 x its scale (gather order instead of float atomics)."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops, sampling
+    from ogl_amd.graphsage import GraphSAGE
+    from ogl_amd.graphsage.sageconv import GatheredRows
+    rng = np.random.default_rng(T + n1)
+    torch.manual_seed(T + B)
+    table = ops.empty_mat(T, F_in, "cuda").copy_(torch.randn(T, F_in, device="cuda"))
+    ids0 = torch.as_tensor(rng.choice(T, n0, replace=False).astype(np.int64)).cuda()
+    lidx0 = rng.integers(0, n0, size=(n1, S)).astype(np.int32)
+    live1 = min(n1, max(B, n1 // 3))
+    lidx0[live1:] = -1                                                   # the padded destination rows of a captured step's upper-bound block
+    lidx1 = rng.integers(0, live1, size=(B, S)).astype(np.int32)
+    lidx1[rng.random(B) < 0.1] = -1
+    blocks = [sampling.Block(ids0, ids0[:n1], torch.as_tensor(lidx0).cuda()), sampling.Block(ids0[:n1], ids0[:B], torch.as_tensor(lidx1).cuda())]
+    labels = torch.randint(0, C_out, (B,), device="cuda")
+    model = GraphSAGE(F_in, 32, C_out, 1, F.relu, 0, "pool").cuda()
+
+    def run(route):
+        ops.SMALL_ROUTE = route
+        try:
+            for p in model.parameters():
+                p.grad = None
+            step_dev = torch.zeros(1, dtype=torch.int64, device="cuda") + 2
+            scal = torch.zeros(2, dtype=torch.float32, device="cuda")
+            ops.adam_prime(step_dev, scal, 1e-3, 0.9, 0.999)
+            loss, rows, logits = model.forward_loss(blocks, GatheredRows(table, ids0), labels, rows=True, defer_mean=True)
+            assert type(loss.grad_fn).__name__ == "_SmallPoolLossFnBackward"
+            ops.backward(loss)
+            assert ops.adam_primed(step_dev) and int(step_dev) == 3
+            torch.cuda.synchronize()
+            return float(loss), rows.clone(), {k: v.grad.clone() for k, v in model.named_parameters()}
+        finally:
+            ops.SMALL_ROUTE = True
+    l1, r1, g1 = run(True)
+    l0, r0, g0 = run(False)
+    assert l1 == l0 and torch.equal(r1, r0)
+    for k in g0:
+        scale = max(1.0, float(g0[k].abs().max()))
+        np.testing.assert_allclose(g1[k].cpu().numpy(), g0[k].cpu().numpy(), rtol=1e-4, atol=1e-6 * scale, err_msg=k)
