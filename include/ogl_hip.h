@@ -751,6 +751,14 @@ int ogl_small_pool_layer_bwd_pool(const float* h, int64_t ldh, int64_t n_dst, in
                                   float* dWn, int64_t lddwn, float* dbn, float* dh, int64_t lddh, float* loss_mean, int64_t* step_dev,
                                   float* scalars_dev, double lr, double beta1, double beta2, ogl_stream_t stream);
 
+/* y = act(x[x_rows] . w^T + bias) for a SMALL product (fc_pool of a 32-seed step's first layer: 700-2 800 gathered rows x 128-500
+ * features, `nn.Linear` + relu of DGL SAGEConv 'pool', R/train/graphsage/pytorch/graphsage_dgl.py:26-31) on the exact-fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32: fp32 products, fp32 accumulate) with 32 x 64 tiles whose four waves split columns and every k-slab — where the
+ * general kernels' tiles leave most of the chip idle and pay an operand conversion per step.  x [n_table, K] (x_rows NULL: row m itself; a row id outside the table: zeros), w [N, K]; K % 4 == 0, ldx % 4 == 0,
+ * ldw % 4 == 0, 16-byte aligned bases; M <= 65 536, N <= 4 096. */
+int ogl_small_proj_rows(const float* x, int64_t ldx, const int64_t* x_rows, int64_t n_table, int64_t M, int K, const float* w, int64_t ldw,
+                        int N, const float* bias, int relu, float* y, int64_t ldy, ogl_stream_t stream);
+
 /* The FIRST 'pool' layer of a 32-seed step behind its fc_pool product (the live layer, R/train/graphsage/pytorch/graphsage_dgl.py:26-31
  * -> DGL SAGEConv 'pool', at the reference's small settings: in_feats 500 / 128, embedding_size 32, <= 832 destinations):
  *   ogl_small_first_layer_fwd: neigh[d] = max_j P[idx[d, j]] (+ argmax: the winning row of P, -1 = none; the order of ogl_reduce_fwd) and

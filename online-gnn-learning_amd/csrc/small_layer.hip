@@ -568,6 +568,130 @@ extern "C" int ogl_small_pool_layer_bwd_pool(const float* h, int64_t ldh, int64_
   return OGL_OK;
 }
 
+// ---- fc_pool of the FIRST layer of a 32-seed step: P = relu(X[ids] . W^T + b) on the exact-fp32 MFMA, small tiles ----------------------
+// 700-2 800 gathered rows x 128-500 features x as many outputs: 0.05-0.4 GFLOP.  On the on-the-fly split-bf16 GEMM (k_gemm, 64 x 64 tiles)
+// that is 96 blocks of 32 dependent k-steps — 25 us at the pubmed-like rung, the largest launch of the step — because every step
+// converts its operands to three bf16 planes before its MFMAs.  Here: v_mfma_f32_32x32x2_f32 on fp32 operands as they are (no
+// conversion; one b32 LDS read per operand per 2 048 MACs), 32 x 64 block tiles (192 blocks for 768 x 500) whose FOUR waves are two
+// column halves x two halves of every 64-deep k-slab — so all four SIMDs of a CU multiply although the tile is two MFMA tiles wide —,
+// the k-halves summed through LDS in the epilogue, the next slab's six float4 loads per thread in flight under the current slab's
+// MFMAs.  (Two vector-ALU versions came first: 16-deep slabs waited out a global-load latency per slab, 27 us; 64-deep slabs were
+// LDS-bound at 3 B of fragment reads per FMA, 25 us.)  Exact fp32 products, fp32 accumulate; k ascending inside a half.
+#define SPR_BM 32
+#define SPR_BN 64
+#define SPR_BK 64
+typedef float spr_f32x16 __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(256) k_small_proj_rows(const float* __restrict__ X, int64_t ldx, const int64_t* __restrict__ ids,
+                                                         int64_t n_table, int M, int K, const float* __restrict__ W, int64_t ldw, int N,
+                                                         const float* __restrict__ bias, int relu, float* __restrict__ Y, int64_t ldy) {
+  __shared__ float As[2][SPR_BK][SPR_BM + 2];
+  __shared__ float Bs[2][SPR_BK][SPR_BN + 4];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int wx = wv & 1, kh = wv >> 1;                       // column half, k half
+  const int m0 = blockIdx.y * SPR_BM, n0 = blockIdx.x * SPR_BN;
+  // loaders: A row (t >> 3), float4s at k = 4 (t & 7) + {0, 32};  B row (t >> 2), float4s at k = 4 (t & 3) + {0, 16, 32, 48}
+  const int ar = t >> 3, ak = (t & 7) * 4, br = t >> 2, bk = (t & 3) * 4;
+  const float* arow = nullptr;
+  {
+    const int m = m0 + ar;
+    if (m < M) {
+      const int64_t id = ids ? ids[m] : (int64_t)m;
+      if (id >= 0 && id < n_table) arow = X + id * ldx;
+    }
+  }
+  const float* brow = (n0 + br < N) ? W + (int64_t)(n0 + br) * ldw : nullptr;
+  // two slabs ahead in registers: slab kt + 1 is parked from one register set while slab kt + 2 is still in flight in the other
+  // (one slab ahead left every slab waiting out most of a global-load latency: 18 us for 8 slabs whose MFMAs take 0.4 us each)
+  float4 pa[2][2], pb[2][4];
+  auto fetch = [&](int k0, float4* qa, float4* qb) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = k0 + ak + 32 * u;                        // (K % 4 == 0: a float4 is inside the row or outside it)
+      qa[u] = (arow && k < K) ? *(const float4*)(arow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + bk + 16 * u;
+      qb[u] = (brow && k < K) ? *(const float4*)(brow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto park = [&](int buf, const float4* qa, const float4* qb) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = ak + 32 * u;
+      As[buf][k + 0][ar] = qa[u].x; As[buf][k + 1][ar] = qa[u].y; As[buf][k + 2][ar] = qa[u].z; As[buf][k + 3][ar] = qa[u].w;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = bk + 16 * u;
+      Bs[buf][k + 0][br] = qb[u].x; Bs[buf][k + 1][br] = qb[u].y; Bs[buf][k + 2][br] = qb[u].z; Bs[buf][k + 3][br] = qb[u].w;
+    }
+  };
+  spr_f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int nk = (K + SPR_BK - 1) / SPR_BK;
+  const int fr = lane & 31, fk = lane >> 5;                  // MFMA operand lane map: A[i = l & 31][k = l >> 5], B[k = l >> 5][j = l & 31]
+  fetch(0, pa[0], pb[0]);
+  if (nk > 1) fetch(SPR_BK, pa[1], pb[1]);
+  park(0, pa[0], pb[0]);
+  if (nk > 2) fetch(2 * SPR_BK, pa[0], pb[0]);
+  __syncthreads();
+  auto slab = [&](int buf) {
+    float fa[16], fb[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {                           // this wave's half of the slab: k = 32 kh + 2 q + fk
+      fa[q] = As[buf][kh * 32 + 2 * q + fk][fr];
+      fb[q] = Bs[buf][kh * 32 + 2 * q + fk][wx * 32 + fr];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q], fb[q], acc, 0, 0, 0);
+  };
+  // slab kt lives in LDS buffer kt & 1; slab kt + 1 in register set (kt + 1) & 1, slab kt + 2 in set kt & 1 (two trips per turn: the
+  // register sets alternate at compile time)
+  for (int kt = 0; kt < nk; kt += 2) {
+    slab(0);
+    if (kt + 1 < nk) park(1, pa[1], pb[1]);
+    if (kt + 3 < nk) fetch((kt + 3) * SPR_BK, pa[1], pb[1]);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    slab(1);
+    if (kt + 2 < nk) park(0, pa[0], pb[0]);
+    if (kt + 4 < nk) fetch((kt + 4) * SPR_BK, pa[0], pb[0]);
+    __syncthreads();
+  }
+  // epilogue: the upper k-halves through LDS (the operand buffers are done with), the lower ones add, finish and store
+  float* red = &As[0][0][0];                                 // [2 column halves][16 regs][64 lanes] floats = 8 KB
+  if (kh == 1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[(wx * 16 + i) * 64 + lane] = acc[i];
+  }
+  __syncthreads();
+  if (kh == 0) {
+    const int n = n0 + wx * 32 + fr;
+    const float bv = (bias && n < N) ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int m = m0 + (i & 3) + 8 * (i >> 2) + 4 * fk;    // C/D lane map: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)
+      if (m < M && n < N) {
+        const float v = (acc[i] + red[(wx * 16 + i) * 64 + lane]) + bv;
+        Y[(int64_t)m * ldy + n] = relu ? fmaxf(v, 0.f) : v;
+      }
+    }
+  }
+}
+
+extern "C" int ogl_small_proj_rows(const float* x, int64_t ldx, const int64_t* x_rows, int64_t n_table, int64_t M, int K, const float* w,
+                                   int64_t ldw, int N, const float* bias, int relu, float* y, int64_t ldy, ogl_stream_t stream) {
+  if (M < 0 || M > 65536 || K <= 0 || (K & 3) || N <= 0 || N > 4096 || n_table <= 0) return OGL_EINVAL;
+  if (M == 0) return OGL_OK;
+  if (!x || !w || !y || ldx < K || ldw < K || ldy < N || (ldx & 3) || (ldw & 3) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return OGL_EINVAL;
+  hipLaunchKernelGGL(k_small_proj_rows, dim3((unsigned)ogl_cdiv(N, SPR_BN), (unsigned)ogl_cdiv(M, SPR_BM)), dim3(256), 0, (hipStream_t)stream,
+                     x, ldx, x_rows, n_table, (int)M, K, w, ldw, N, bias, relu, y, ldy);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
 // ---- the FIRST 'pool' layer of a 32-seed step behind its fc_pool product: neighbour max + combine in one launch, and the head of its
 // backward in one launch --------------------------------------------------------------------------------------------------------------
 // The live layer's first layer (R/train/graphsage/pytorch/graphsage_dgl.py:26-31 -> DGL SAGEConv 'pool'; the reference's small settings:

@@ -3030,6 +3030,8 @@ class _SmallPoolLossFn(torch.autograd.Function):
 # weight gradients as three more row groups of the record launch): no launch of its own, no float atomics
 SMALL_ROUTE = os.environ.get("OGL_SMALL_ROUTE", "1") != "0"
 _PENDING_ROUTES = {}
+SMALL_PROJ = os.environ.get("OGL_SMALL_PROJ", "1") != "0"      # fc_pool of a small step's first layer on the small-tile fp32-MFMA kernel
+SMALL_PROJ_MAX_ROWS = int(os.environ.get("OGL_SMALL_PROJ_MAX_ROWS", "4096"))
 SMALL_FIRST_FUSED = os.environ.get("OGL_SMALL_FIRST_FUSED", "1") != "0"   # the first 'pool' layer of a 32-seed step: max + combine in one launch
 SMALL_FIRST_MAX_DST = 2048
 # fc_pool's weight gradient of that layer from the winners' records (ogl_small_first_layer_dw) while the rows it would gather from L2 if
@@ -3068,7 +3070,15 @@ class _SmallFirstLayerFn(torch.autograd.Function):
     def forward(ctx, table, ids, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu):
         x = as_mat(table)
         ids = _ids(ids)
-        p = linear_fwd(x, w_pool, b_pool, relu=True, x_rows=ids)
+        if SMALL_PROJ and ids.numel() <= SMALL_PROJ_MAX_ROWS and w_pool.is_contiguous() and w_pool.data_ptr() % 16 == 0:
+            # the product itself on the exact-fp32 MFMA with 32 x 64 tiles (ogl_small_proj_rows): at these sizes the general kernel's
+            # 64 x 64 tiles leave most of the chip idle and convert their operands on the fly (25 us for 0.38 GFLOP, pubmed-like rung)
+            p = empty_mat(ids.numel(), w_pool.shape[0], x.device)
+            _launch("ogl_small_proj_rows", _lib.lib().ogl_small_proj_rows, _ptr(x), _ld(x), _ptr(ids), x.shape[0], ids.numel(), x.shape[1],
+                    _ptr(w_pool), _ld(as_mat(w_pool)), w_pool.shape[0], _ptr(b_pool), 1, _ptr(p), _ld(p), _stream(),
+                    meta=dict(M=ids.numel(), N=w_pool.shape[0], K=x.shape[1]))
+        else:
+            p = linear_fwd(x, w_pool, b_pool, relu=True, x_rows=ids)
         n_src, F = p.shape
         H = w_self.shape[0]
         dev = p.device
