@@ -774,18 +774,22 @@ int ogl_small_proj_rows(const float* x, int64_t ldx, const int64_t* x_rows, int6
  *        route_W[q % route_H, k] (route_arg / route_G = that layer's argmax / G from ogl_small_pool_layer_fwd_ce_bwd with dh_head_only,
  *        route_W its fc_pool weight, route_head its dh head rows): the winners' scatter of that layer as a gather by its consumer, in
  *        record order — no atomics, no zeroed [n_src, H] matrix, and ogl_small_pool_layer_bwd_pool leaves the step.  route_n <= 2048.
+ *   n_live_dev (nullable, both calls): a device scalar — destinations d >= *n_live_dev are PADDED rows of a captured step's upper-bound
+ *        block (index row all -1, source id -1): they get what the full path would write (forward: zeros, no winners, act(bias);
+ *        backward with a route: zero gradients) without its loads.
  *   ogl_small_first_layer_fits: n_dst <= 8192, fanout <= 64, 16 <= F <= 1024, H <= 32.
  *   Sums over F run lane-parallel: fp32 rounding differs from the GEMM kernels' order; max / argmax are exact. */
 int ogl_small_first_layer_fits(int64_t n_src, int64_t n_dst, int fanout, int F, int H);
 int ogl_small_first_layer_fwd(const float* P, int64_t ldp, int64_t n_src, const int32_t* idx, int64_t n_dst, int fanout, int F,
                               const float* table, int64_t ldt, const int64_t* ids, int64_t n_table, const float* Ws, int64_t ldws,
                               const float* bs, const float* Wn, int64_t ldwn, const float* bn, int H, int relu_out, float* neigh,
-                              int64_t ldn, int32_t* argmax, float* y, int64_t ldy, ogl_stream_t stream);
+                              int64_t ldn, int32_t* argmax, float* y, int64_t ldy, const int64_t* n_live_dev, ogl_stream_t stream);
 int ogl_small_first_layer_bwd(const float* dout, int64_t lddo, const float* y, int64_t ldy, int relu_out, int64_t n_dst, int H, int F,
                               const float* Wn, int64_t ldwn, const float* neigh, int64_t ldn, const int32_t* argmax, float* dy,
                               int64_t lddy, float* dneigh, int64_t lddn, float* dP, int64_t lddp, int64_t n_src, int mask_dneigh,
                               const int32_t* route_arg, const float* route_G, int64_t route_n, int route_H, const float* route_W,
-                              int64_t route_ldw, const float* route_head, int64_t route_ldh, int64_t route_n_head, ogl_stream_t stream);
+                              int64_t route_ldw, const float* route_head, int64_t route_ldh, int64_t route_n_head,
+                              const int64_t* n_live_dev, ogl_stream_t stream);
 /* Weight gradients from RECORDS, the general form: up to six row groups in ONE launch.  Group i writes, for r < n_out,
  *     dW[r, :] = sum_{d < n_dst} G[d * ldg + r] . rows[id(d, r), :],   db[r] = db2[r] = sum_d G[d * ldg + r]  (db, db2 nullable)
  * where id(d, r) = ids[w] (ids NULL: w), w = arg[d * ldarg + r] (arg NULL: d); a record whose weight is zero, whose w is outside
@@ -801,6 +805,7 @@ typedef struct {
   const float* rows; int64_t ldr; int64_t n_rows; int F;
   int64_t n_dst; int n_out;
   float* dW; int64_t lddw; float* db; float* db2;
+  const int64_t* n_live;   /* optional device scalar: only destinations d < min(n_dst, *n_live) are visited (the rest have zero weights) */
 } ogl_rec_seg_t;
 int ogl_record_weight_grads(const ogl_rec_seg_t* segs, int nseg, const float* loss_rows, int64_t n_loss, float* loss_mean,
                             int64_t* step_dev, float* scalars_dev, double lr, double beta1, double beta2, ogl_stream_t stream);

@@ -132,9 +132,9 @@ SIGNATURES = {
     "ogl_small_proj_rows": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p, _i, _p, _i64, _p]),
     "ogl_small_first_layer_fits": (_i, [_i64, _i64, _i, _i, _i]),
     "ogl_small_first_layer_fwd": (_i, [_p, _i64, _i64, _p, _i64, _i, _i, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i, _i, _p, _i64,
-                                       _p, _p, _i64, _p]),
+                                       _p, _p, _i64, _p, _p]),
     "ogl_small_first_layer_bwd": (_i, [_p, _i64, _p, _i64, _i, _i64, _i, _i, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i,
-                                       _p, _p, _i64, _i, _p, _i64, _p, _i64, _i64, _p]),
+                                       _p, _p, _i64, _i, _p, _i64, _p, _i64, _i64, _p, _p]),
     "ogl_record_weight_grads": (_i, [_p, _i, _p, _i64, _p, _p, _p, _d, _d, _d, _p]),
     "ogl_small_first_layer_dw": (_i, [_p, _i64, _p, _p, _i64, _i64, _i, _i, _p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p,
                                       _p, _i64, _p, _p]),
@@ -163,7 +163,8 @@ SIGNATURES = {
 class RecSeg(C.Structure):
     """ogl_rec_seg_t (include/ogl_hip.h): one row group of ogl_record_weight_grads."""
     _fields_ = [("G", _p), ("ldg", _i64), ("arg", _p), ("ldarg", _i64), ("n_idx", _i64), ("ids", _p), ("rows", _p), ("ldr", _i64),
-                ("n_rows", _i64), ("F", _i), ("n_dst", _i64), ("n_out", _i), ("dW", _p), ("lddw", _i64), ("db", _p), ("db2", _p)]
+                ("n_rows", _i64), ("F", _i), ("n_dst", _i64), ("n_out", _i), ("dW", _p), ("lddw", _i64), ("db", _p), ("db2", _p),
+                ("n_live", _p)]
 
 
 _lib = None

@@ -716,7 +716,7 @@ __global__ void __launch_bounds__(256) k_small_first_fwd(const float* __restrict
                                                          int64_t ldws, const float* __restrict__ bs, const float* __restrict__ Wn,
                                                          int64_t ldwn, const float* __restrict__ bn, int H, int relu_out,
                                                          float* __restrict__ neigh, int64_t ldn, int32_t* __restrict__ argmax,
-                                                         float* __restrict__ y, int64_t ldy) {
+                                                         float* __restrict__ y, int64_t ldy, const int64_t* __restrict__ n_live) {
   // one WORKGROUP per destination (a first version gave it one wave: 128 weight loads in a row per wave, 42 us for 101 destinations):
   // phase 1 — thread t owns float4 column t of the row: the S neighbour rows of P, all loads of four rows in flight, max + argmax;
   // phase 2 — wave w owns output columns 8w .. 8w + 7: its lanes cover the float4 columns, 32 weight loads in flight per lane,
@@ -725,6 +725,19 @@ __global__ void __launch_bounds__(256) k_small_first_fwd(const float* __restrict
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int d = blockIdx.x;
   const int f4 = (F + 3) >> 2;
+  if (n_live && d >= *n_live) {
+    // a PADDED destination row of a captured step's upper-bound block (no neighbours, no row of its own): what the full path would
+    // write — zeros, no winners, act(bias) — without its loads (832 rows of which 100-230 are live at the 32-seed rungs)
+    for (int k = t; k < F; k += 256) {
+      neigh[(int64_t)d * ldn + k] = 0.f;
+      if (argmax) argmax[(int64_t)d * F + k] = -1;
+    }
+    if (t < H) {
+      const float o = (bs ? bs[t] : 0.f) + (bn ? bn[t] : 0.f);
+      y[(int64_t)d * ldy + t] = relu_out ? fmaxf(o, 0.f) : o;
+    }
+    return;
+  }
   const int col = min(t, f4 - 1);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int arg[4] = {-1, -1, -1, -1};
@@ -833,7 +846,8 @@ __global__ void __launch_bounds__(256) k_small_first_bwd(const float* __restrict
                                                          int relu_out, int n_dst, int H, int F, const float* __restrict__ Wn, int64_t ldwn,
                                                          const float* __restrict__ neigh, int64_t ldn, const int32_t* __restrict__ argmax,
                                                          float* __restrict__ dy, int64_t lddy, float* __restrict__ dneigh, int64_t lddn,
-                                                         float* __restrict__ dP, int64_t lddp, int n_src, int mask_dneigh, SfbRoute rt) {
+                                                         float* __restrict__ dP, int64_t lddp, int n_src, int mask_dneigh, SfbRoute rt,
+                                                         const int64_t* __restrict__ n_live) {
   // one workgroup per destination, thread t = float4 column t of the row (F <= 1024): H independent weight loads per thread
   __shared__ float G[SFL_H];
   __shared__ float MG[SFB_ROUTE_MAX];
@@ -842,6 +856,13 @@ __global__ void __launch_bounds__(256) k_small_first_bwd(const float* __restrict
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int d = blockIdx.x;
   const int f4 = (F + 3) >> 2;
+  if (n_live && rt.arg && d >= *n_live && d >= rt.n_head) {
+    // a padded row: nobody's winner, no head row — its gradient is zero; written without scanning the route
+    if (t < H) dy[(int64_t)d * lddy + t] = 0.f;
+    if (dneigh)
+      for (int k = t; k < F; k += 256) dneigh[(int64_t)d * lddn + k] = 0.f;
+    return;
+  }
   int nm = 0;
   if (rt.arg) {                                              // this destination's records, compacted in record order
     for (int q0 = 0; q0 < rt.n; q0 += 256) {
@@ -907,7 +928,7 @@ extern "C" int ogl_small_first_layer_fwd(const float* P, int64_t ldp, int64_t n_
                                          const float* table, int64_t ldt, const int64_t* ids, int64_t n_table, const float* Ws,
                                          int64_t ldws, const float* bs, const float* Wn, int64_t ldwn, const float* bn, int H,
                                          int relu_out, float* neigh, int64_t ldn, int32_t* argmax, float* y, int64_t ldy,
-                                         ogl_stream_t stream) {
+                                         const int64_t* n_live_dev, ogl_stream_t stream) {
   if (!ogl_small_first_layer_fits(n_src, n_dst, fanout, F, H)) return OGL_EINVAL;
   if (!P || !idx || !table || !Ws || !Wn || !neigh || !y || n_table <= 0) return OGL_EINVAL;
   const int64_t f4x4 = ((int64_t)F + 3) / 4 * 4;
@@ -919,7 +940,7 @@ extern "C" int ogl_small_first_layer_fwd(const float* P, int64_t ldp, int64_t n_
   const int nch = (int)ogl_cdiv(ogl_cdiv(F, 4), 64);
 #define SFL_FWD(N)                                                                                                                      \
   hipLaunchKernelGGL(k_small_first_fwd<N>, grid, block, 0, (hipStream_t)stream, P, ldp, (int)n_src, idx, (int)n_dst, fanout, F, table, \
-                     ldt, ids, n_table, Ws, ldws, bs, Wn, ldwn, bn, H, relu_out, neigh, ldn, argmax, y, ldy)
+                     ldt, ids, n_table, Ws, ldws, bs, Wn, ldwn, bn, H, relu_out, neigh, ldn, argmax, y, ldy, n_live_dev)
   if (nch == 1) SFL_FWD(1); else if (nch == 2) SFL_FWD(2); else if (nch == 3) SFL_FWD(3); else SFL_FWD(4);
 #undef SFL_FWD
   OGL_CHECK_LAUNCH();
@@ -933,7 +954,7 @@ extern "C" int ogl_small_first_layer_bwd(const float* dout, int64_t lddo, const 
                                          float* dy, int64_t lddy, float* dneigh, int64_t lddn, float* dP, int64_t lddp, int64_t n_src,
                                          int mask_dneigh, const int32_t* route_arg, const float* route_G, int64_t route_n, int route_H,
                                          const float* route_W, int64_t route_ldw, const float* route_head, int64_t route_ldh,
-                                         int64_t route_n_head, ogl_stream_t stream) {
+                                         int64_t route_n_head, const int64_t* n_live_dev, ogl_stream_t stream) {
   if (n_dst <= 0 || n_dst > 8192 || H <= 0 || H > SFL_H || F < 16 || F > 1024 || n_src <= 0 || n_src >= (1 << 30)) return OGL_EINVAL;
   if ((!dout && !route_arg) || !Wn || !dy || (relu_out && !y) || (!dneigh && !dP) || ((dP || mask_dneigh) && (!argmax || !neigh)))
     return OGL_EINVAL;
@@ -947,7 +968,7 @@ extern "C" int ogl_small_first_layer_bwd(const float* dout, int64_t lddo, const 
   rt.arg = route_arg; rt.G = route_G; rt.W = route_W; rt.ldw = route_ldw; rt.head = route_head; rt.ldh = route_ldh;
   rt.n_head = (int)route_n_head; rt.Hr = route_H > 0 ? route_H : 1; rt.n = (int)route_n;
   hipLaunchKernelGGL(k_small_first_bwd, dim3((unsigned)n_dst), dim3(256), 0, (hipStream_t)stream, dout, lddo, y, ldy, relu_out, (int)n_dst, H, F,
-                     Wn, ldwn, neigh, ldn, argmax, dy, lddy, dneigh, lddn, dP, lddp, (int)n_src, mask_dneigh, rt);
+                     Wn, ldwn, neigh, ldn, argmax, dy, lddy, dneigh, lddn, dP, lddp, (int)n_src, mask_dneigh, rt, n_live_dev);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }
@@ -997,7 +1018,9 @@ __global__ void __launch_bounds__(256) k_small_first_dw(SfdArgs a) {
     if (q < a.nseg && (int)blockIdx.x >= a.first[q]) si = q;
   const ogl_rec_seg_t& sg = a.seg[si];
   const int j = blockIdx.x - a.first[si];
-  const int F = sg.F, n_dst = (int)sg.n_dst;
+  const int F = sg.F;
+  // (n_live: the live destination rows of a captured step's upper-bound block — rows behind them have zero weights anyway)
+  const int n_dst = sg.n_live ? (int)min((int64_t)sg.n_dst, max((int64_t)0, *sg.n_live)) : (int)sg.n_dst;
   const int f4 = (F + 3) >> 2;
   int base = 0;                                              // (block-uniform: every thread keeps the same count)
   for (int d0 = 0; d0 < n_dst; d0 += 256) {
@@ -1111,7 +1134,7 @@ extern "C" int ogl_small_first_layer_dw(const float* G, int64_t ldg, const int32
                  int64_t n_rows, float* dW, int64_t lddw, float* db, float* db2, int count) {
     ogl_rec_seg_t& s = segs[n++];
     s.G = g; s.ldg = ld; s.arg = arg; s.ldarg = F; s.n_idx = n_idx; s.ids = idp; s.rows = rows; s.ldr = ldr; s.n_rows = n_rows; s.F = F;
-    s.n_dst = n_dst; s.n_out = count; s.dW = dW; s.lddw = lddw; s.db = db; s.db2 = db2;
+    s.n_dst = n_dst; s.n_out = count; s.dW = dW; s.lddw = lddw; s.db = db; s.db2 = db2; s.n_live = nullptr;
   };
   if (dWp) add(G, ldg, argmax, n_src, ids, table, ldt, n_table, dWp, lddwp, dbp, nullptr, F);
   if (dWs) add(dy, lddy, nullptr, 0, ids, table, ldt, n_table, dWs, lddws, dbs, dWn ? nullptr : dbn, H);

@@ -3030,6 +3030,7 @@ class _SmallPoolLossFn(torch.autograd.Function):
 # weight gradients as three more row groups of the record launch): no launch of its own, no float atomics
 SMALL_ROUTE = os.environ.get("OGL_SMALL_ROUTE", "1") != "0"
 _PENDING_ROUTES = {}
+SMALL_LIVE = os.environ.get("OGL_SMALL_LIVE", "1") != "0"      # padded rows of a captured step's upper-bound block take the kernels' early exits
 SMALL_PROJ = os.environ.get("OGL_SMALL_PROJ", "1") != "0"      # fc_pool of a small step's first layer on the small-tile fp32-MFMA kernel
 SMALL_PROJ_MAX_ROWS = int(os.environ.get("OGL_SMALL_PROJ_MAX_ROWS", "4096"))
 SMALL_FIRST_FUSED = os.environ.get("OGL_SMALL_FIRST_FUSED", "1") != "0"   # the first 'pool' layer of a 32-seed step: max + combine in one launch
@@ -3067,7 +3068,10 @@ class _SmallFirstLayerFn(torch.autograd.Function):
     y = act(X[ids[:n_dst]] . Ws^T + max_j relu(X[ids] . Wp^T + bp)[idx] . Wn^T + bs + bn) (DGL SAGEConv 'pool')."""
 
     @staticmethod
-    def forward(ctx, table, ids, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu):
+    def forward(ctx, table, ids, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu, n_live=None):
+        # n_live (optional device int64 scalar): the LIVE destination rows of a captured step's upper-bound block — rows behind them are
+        # padding (index rows all -1, source id -1) and take the kernels' early exits
+        ctx.n_live = n_live
         x = as_mat(table)
         ids = _ids(ids)
         if SMALL_PROJ and ids.numel() <= SMALL_PROJ_MAX_ROWS and w_pool.is_contiguous() and w_pool.data_ptr() % 16 == 0:
@@ -3088,7 +3092,7 @@ class _SmallFirstLayerFn(torch.autograd.Function):
         y = empty_mat(n_dst, H, dev)
         _launch("ogl_small_first_layer_fwd", _lib.lib().ogl_small_first_layer_fwd, _ptr(p), _ld(p), n_src, _ptr(idx), n_dst, int(idx.shape[1]), F,
                 _ptr(x), _ld(x), _ptr(ids), x.shape[0], _ptr(w_self), _ld(as_mat(w_self)), _ptr(b_self), _ptr(w_neigh), _ld(as_mat(w_neigh)),
-                _ptr(b_neigh), H, int(bool(relu)), _ptr(neigh), _ld(neigh), _ptr(argmax), _ptr(y), _ld(y), _stream(),
+                _ptr(b_neigh), H, int(bool(relu)), _ptr(neigh), _ld(neigh), _ptr(argmax), _ptr(y), _ld(y), _ptr(n_live), _stream(),
                 meta=dict(n_src=n_src, n_dst=n_dst, fanout=int(idx.shape[1]), d=F, H=H))
         if _CAPTURE is not None:
             _CAPTURE.append(dict(argmax=argmax, neigh=neigh))
@@ -3137,7 +3141,8 @@ class _SmallFirstLayerFn(torch.autograd.Function):
                 1 if (need_pool and ctx.rec_path) else 0,
                 _ptr(route["argmax"]) if route else None, _ptr(route["G"]) if route else None, route["n_head"] * route["hin"] if route else 0,
                 route["hin"] if route else 0, _ptr(route["w_pool"]) if route else None, _ld(route["w_pool"]) if route else 0,
-                _ptr(route["head"]) if route else None, _ld(route["head"]) if route else 0, route["n_head"] if route else 0, _stream(),
+                _ptr(route["head"]) if route else None, _ld(route["head"]) if route else 0, route["n_head"] if route else 0,
+                _ptr(ctx.n_live), _stream(),
                 meta=dict(n_src=n_src, n_dst=n_dst, d=F, H=H, scatter=dP is not None, routed=route is not None))
         # the combine's two weight gradients (+ both bias gradients) and — on the record path — fc_pool's, ONE launch
         dws = dwn = db = db2 = dwp = dbp = None
@@ -3156,7 +3161,7 @@ class _SmallFirstLayerFn(torch.autograd.Function):
                 dwp = _dw_out(w_pool, *w_pool.shape)
                 dwp = dwp if dwp is not None else torch.empty((F, F), dtype=torch.float32, device=dev)
                 dbp = torch.empty(F, dtype=torch.float32, device=dev) if ctx.has_pool_bias else None
-            _record_launch(rec, dneigh, argmax, dy, n_dst, F, H, x, ids, n_src, neigh, dwp, dbp, dws, db, dwn, db2, route)
+            _record_launch(rec, dneigh, argmax, dy, n_dst, F, H, x, ids, n_src, neigh, dwp, dbp, dws, db, dwn, db2, route, ctx.n_live)
             route = None
         if route is not None:                                  # (nothing of this layer's to sum: the handed-over groups alone)
             _record_launch(False, None, None, None, n_dst, F, H, x, ids, n_src, neigh, None, None, None, None, None, None, route)
@@ -3172,17 +3177,18 @@ class _SmallFirstLayerFn(torch.autograd.Function):
         elif need_pool:
             dwp, dbp = weight_grad(dP, x, ids, want_bias=ctx.has_pool_bias, dw_out=_dw_out(w_pool, *w_pool.shape))
         return (None, None, dwp, dbp if ctx.has_pool_bias else None, dws, dwn, db if ctx.has_bias else None,
-                db2 if ctx.has_bias else None, None, None, None)
+                db2 if ctx.has_bias else None, None, None, None, None)
 
 
-def _record_launch(rec, dneigh, argmax, dy, n_dst, F, H, x, ids, n_src, neigh, dwp, dbp, dws, db, dwn, db2, route):
+def _record_launch(rec, dneigh, argmax, dy, n_dst, F, H, x, ids, n_src, neigh, dwp, dbp, dws, db, dwn, db2, route, n_live=None):
     """ONE ogl_record_weight_grads launch: the small first layer's row groups (fc_pool from the winners' records when ``rec``; fc_self,
     fc_neigh) and, when the small last layer handed its backward over (``route``), that layer's three + the deferred mean loss + the
     optimiser's per-step scalars."""
     segs = []
 
-    def seg(G, arg, ldarg, n_idx, idp, rows, n_rows, Fw, nd, n_out, dW, b1_, b2_):
+    def seg(G, arg, ldarg, n_idx, idp, rows, n_rows, Fw, nd, n_out, dW, b1_, b2_, live=None):
         sg = _lib.RecSeg()
+        sg.n_live = _ptr(live)
         sg.G, sg.ldg = _ptr(G), _ld(as_mat(G)) if G.dim() == 2 else n_out
         sg.arg, sg.ldarg, sg.n_idx = _ptr(arg), ldarg, n_idx
         sg.ids, sg.rows, sg.ldr, sg.n_rows, sg.F = _ptr(idp), _ptr(rows), _ld(rows), n_rows, Fw
@@ -3193,11 +3199,11 @@ def _record_launch(rec, dneigh, argmax, dy, n_dst, F, H, x, ids, n_src, neigh, d
         sg.n_dst, sg.n_out = nd, n_out
         segs.append(sg)
     if rec:
-        seg(dneigh, argmax, F, n_src, ids, x, x.shape[0], F, n_dst, F, dwp, dbp, None)
+        seg(dneigh, argmax, F, n_src, ids, x, x.shape[0], F, n_dst, F, dwp, dbp, None, n_live)
     if dws is not None:
-        seg(dy, None, 0, 0, ids, x, x.shape[0], F, n_dst, H, dws, db, None)
+        seg(dy, None, 0, 0, ids, x, x.shape[0], F, n_dst, H, dws, db, None, n_live)
     if dwn is not None:
-        seg(dy, None, 0, 0, None, neigh, n_dst, F, n_dst, H, dwn, db2, None)
+        seg(dy, None, 0, 0, None, neigh, n_dst, F, n_dst, H, dwn, db2, None, n_live)
     rows_l = mean_l = None
     step_dev = scal = None
     lr = b1 = b2 = 0.0
@@ -3220,8 +3226,9 @@ def _record_launch(rec, dneigh, argmax, dy, n_dst, F, H, x, ids, n_src, neigh, d
         _ADAM_PRIME["served"] = (step_dev.data_ptr(), _capturing())
 
 
-def small_first_pool_layer(table, ids, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu):
-    return _SmallFirstLayerFn.apply(table, ids, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu)
+def small_first_pool_layer(table, ids, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu, n_live=None):
+    return _SmallFirstLayerFn.apply(table, ids, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu,
+                                    n_live if SMALL_LIVE else None)
 
 
 def sage_pool_layer(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu):

@@ -65,6 +65,7 @@ class BlockBuffers:
         self.src1 = torch.full((self.n1_cap,), -1, dtype=torch.int64, device=device)
         self.lidx0 = torch.full((self.n1_cap, self.S), -1, dtype=torch.int32, device=device)
         self.lidx1 = torch.full((self.B, self.S), -1, dtype=torch.int32, device=device)
+        self.counts = None          # sampled form: the device [n1, n0] the sample graph writes (SampleGraph sets it)
 
     @property
     def seeds(self):
@@ -99,6 +100,10 @@ class TrainStepGraph:
         g, b = self.graph, self.buf
         src0, src1, lidx0 = b.src0[:self.n0_pad], b.src1[:self.n1_pad], b.lidx0[:self.n1_pad]
         blocks = [sampling.Block(src0, src1, lidx0), sampling.Block(src1, b.seeds, b.lidx1)]
+        if b.counts is not None:
+            # the sampled form runs on the upper-bound block: n1_cap destination rows of which counts[0] are live — the small first layer's
+            # kernels skip the padded ones (a device scalar the sample graph rewrites before every replay)
+            blocks[0].n_live_dev = b.counts[:1]
         # the FULL tables: a snapshot view's row count would be frozen into the graph (ids are < n_present by construction)
         labels = ops.LazyLabels(g.target_table, b.seeds) if LAZY_LABELS else ops.gather_i64(g.target_table, b.seeds)
         self.opt.zero_grad(set_to_none=True)
@@ -193,6 +198,7 @@ class SampleGraph:
         assert buf.n1_cap == buf.B * (1 + buf.S) and buf.n0_cap == buf.n1_cap * (1 + buf.S)
         self.head_host = torch.zeros(1 + buf.B, dtype=torch.int64).pin_memory()
         self.counts = torch.zeros(2, dtype=torch.int64, device=graph.device)
+        buf.counts = self.counts
         # [n1, n0, sequence number]: pinned host memory the LAST kernel of the graph writes directly (ogl_publish_i64)
         self.counts_host = torch.zeros(3, dtype=torch.int64).pin_memory()
         self.counts_np = self.counts_host.numpy()

@@ -368,8 +368,11 @@ def test_small_step_last_layer_backward_inside_the_first_layers_launches(T, n0, 
     labels = torch.randint(0, C_out, (B,), device="cuda")
     model = GraphSAGE(F_in, 32, C_out, 1, F.relu, 0, "pool").cuda()
 
-    def run(route):
+    n_live = torch.tensor([live1], dtype=torch.int64, device="cuda")
+
+    def run(route, live=False):
         ops.SMALL_ROUTE = route
+        blocks[0].n_live_dev = n_live if live else None                  # (what a captured sampled step passes: the device's own count)
         try:
             for p in model.parameters():
                 p.grad = None
@@ -386,7 +389,9 @@ def test_small_step_last_layer_backward_inside_the_first_layers_launches(T, n0, 
             ops.SMALL_ROUTE = True
     l1, r1, g1 = run(True)
     l0, r0, g0 = run(False)
-    assert l1 == l0 and torch.equal(r1, r0)
+    l2, r2, g2 = run(True, live=True)                                    # padded rows on the kernels' early exits: the same bits
+    assert l1 == l0 and torch.equal(r1, r0) and l2 == l1 and torch.equal(r2, r1)
     for k in g0:
         scale = max(1.0, float(g0[k].abs().max()))
         np.testing.assert_allclose(g1[k].cpu().numpy(), g0[k].cpu().numpy(), rtol=1e-4, atol=1e-6 * scale, err_msg=k)
+        assert torch.equal(g2[k], g1[k]), k
