@@ -300,6 +300,13 @@ __global__ void __launch_bounds__(256) k_small_loss(SmallLossArgs a) {
     }
   }
   const float bias_c = (tid < Hout) ? (a.bs ? a.bs[tid] : 0.f) + (a.bn ? a.bn[tid] : 0.f) : 0.f;
+  int64_t yl_pre = -1;                                       // the row's label (two dependent loads): requested here, used by wave 0 at the end
+  if (tid < 64) {
+    if (a.label_ids) {
+      const int64_t id = a.label_ids[d];
+      yl_pre = (id >= 0 && id < a.n_labels) ? a.labels[id] : -1;
+    } else yl_pre = a.labels[d];
+  }
   if (tid < Hin) HD[tid] = a.h[(int64_t)d * a.ldh + tid];
   for (int i = tid; i < Hin * Hin; i += 256) {
     const int j = i / Hin, k = i - j * Hin;
@@ -375,11 +382,7 @@ __global__ void __launch_bounds__(256) k_small_loss(SmallLossArgs a) {
     const float m = sll_wave_max(x);
     const float s = sll_wave_sum(c < Hout ? expf(x - m) : 0.f);
     const float lse = m + logf(s);
-    int64_t yl;
-    if (a.label_ids) {
-      const int64_t id = a.label_ids[d];
-      yl = (id >= 0 && id < a.n_labels) ? a.labels[id] : -1;
-    } else yl = a.labels[d];
+    const int64_t yl = yl_pre;
     const bool ok = yl >= 0 && yl < Hout;
     const float xy = __shfl(x, ok ? (int)yl : 0);
     if (c == 0) a.loss_rows[d] = ok ? lse - xy : 0.f;
@@ -791,6 +794,22 @@ __global__ void __launch_bounds__(256) k_small_first_fwd(const float* __restrict
   int arg[4] = {-1, -1, -1, -1};
   bool any = false;
   const int32_t mine = lane < S ? idx[(int64_t)d * S + lane] : -1;         // S <= 64 (every wave holds the row)
+  // phase 2's weights do not depend on phase 1: requested HERE (NCH <= 2: 16 NCH float4 per lane), they arrive under the index ->
+  // row -> max chain instead of behind it
+  constexpr bool EARLY_W = NCH <= 2;
+  float4 ew1[EARLY_W ? 8 : 1][EARLY_W ? NCH : 1], ew2[EARLY_W ? 8 : 1][EARLY_W ? NCH : 1];
+  if constexpr (EARLY_W) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = min(wv * 8 + i, H - 1);
+#pragma unroll
+      for (int q = 0; q < NCH; ++q) {
+        const int ch = min(q * 64 + lane, f4 - 1);
+        ew1[i][q] = *(const float4*)(Ws + (int64_t)c * ldws + ch * 4);
+        ew2[i][q] = *(const float4*)(Wn + (int64_t)c * ldwn + ch * 4);
+      }
+    }
+  }
   for (int j0 = 0; j0 < S; j0 += 4) {
     float4 v[4];
     int r[4];
@@ -852,8 +871,12 @@ __global__ void __launch_bounds__(256) k_small_first_fwd(const float* __restrict
         const int ch = q * 64 + lane;
         if (ch < f4) {
           // (rows of Ws / Wn are 16-byte aligned; the last float4 of a row may reach past F: its x / neigh factors are zero)
-          const float4 w1 = *(const float4*)(Ws + (int64_t)c * ldws + ch * 4);
-          const float4 w2 = *(const float4*)(Wn + (int64_t)c * ldwn + ch * 4);
+          float4 w1, w2;
+          if constexpr (EARLY_W) { w1 = ew1[i][q]; w2 = ew2[i][q]; }
+          else {
+            w1 = *(const float4*)(Ws + (int64_t)c * ldws + ch * 4);
+            w2 = *(const float4*)(Wn + (int64_t)c * ldwn + ch * 4);
+          }
           const float4 xs = XS4[ch], nb = NB4[ch];
           a = fmaf(xs.x, w1.x, a); a = fmaf(xs.y, w1.y, a); a = fmaf(xs.z, w1.z, a); a = fmaf(xs.w, w1.w, a);
           a = fmaf(nb.x, w2.x, a); a = fmaf(nb.y, w2.y, a); a = fmaf(nb.z, w2.z, a); a = fmaf(nb.w, w2.w, a);

@@ -19,12 +19,13 @@ def main():
     # a step ends with its LAST optimiser launch (since round 4 the optimiser may run in two parts: an early one on the side branch,
     # the rest at the end): the Adam launch that is followed by the next step's staging / weight-image launch (or by nothing)
     adam = [i for i, r in enumerate(rows) if "k_adam_multi" in r[2] or r[2].startswith("k_adam(")]     # (not k_adam_prepare)
-    firsts = ("k_stage_segments", "k_x3_split_multi", "k_sample_layer", "k_block_")
+    firsts = ("k_stage_segments", "k_x3_split_multi", "k_sample_layer", "k_block_", "k_sample_blocks_small")
     last = [i for i in adam if i + 1 >= len(rows) or any(f in rows[i + 1][2] for f in firsts)]
     if len(last) >= 2:
         adam = last
     steps = [(adam[k], adam[k + 1]) for k in range(len(adam) - 1)]
-    steps = [(a, b) for a, b in steps if b - a >= 8] or steps       # (whole train steps, not the optimiser's own two launches)
+    steps = [(a, b) for a, b in steps if b - a >= 5] or steps       # (whole train steps, not the optimiser's own two launches; a 32-seed
+    # step is seven dispatches since the end of round 5)
     lens = sorted((rows[b][1] - rows[a][1], k) for k, (a, b) in enumerate(steps))
     pick = int(sys.argv[2]) if len(sys.argv) > 2 else lens[len(lens) // 2][1]
     a, b = steps[pick]
