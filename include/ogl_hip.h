@@ -617,6 +617,12 @@ int64_t ogl_sample_blocks_small_workspace_bytes(int B, int fanout);
 int ogl_sample_blocks_small(const ogl_graph_t* g, const int64_t* head_host_mapped, int64_t* head_dev, int B, int fanout, uint64_t seed,
                             int64_t* src1, int32_t* lidx1, int64_t* src0, int32_t* lidx0, int64_t* counts, int64_t* seq_dev,
                             int64_t* counts_host_mapped, void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
+/* ... with src0 padded with -1 only up to round_up(n0, src0_fill_multiple) (0: up to its capacity, as above): for a caller that reads
+ * the input block's source list up to the size bucket of the train graph it replays and no further (21 632 entries per step otherwise). */
+int ogl_sample_blocks_small_fill(const ogl_graph_t* g, const int64_t* head_host_mapped, int64_t* head_dev, int B, int fanout, uint64_t seed,
+                                 int64_t* src1, int32_t* lidx1, int64_t* src0, int32_t* lidx0, int64_t* counts, int64_t* seq_dev,
+                                 int64_t* counts_host_mapped, void* workspace, int64_t workspace_bytes, int64_t src0_fill_multiple,
+                                 ogl_stream_t stream);
 
 /* Backward of the combine of a 'pool' layer with few output columns (the output layer: N <= 64 classes), two launches (csrc/out_layer.hip;
  * autograd of fc_self(h[:n_dst]) + fc_neigh(max-pooled rows), R/train/graphsage/pytorch/aggregator_dgl.py:171,199-206):

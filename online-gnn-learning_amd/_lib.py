@@ -156,6 +156,7 @@ SIGNATURES = {
     "ogl_publish_i64": (_i, [_p, _i, _p, _p, _p]),
     "ogl_sample_blocks_small_workspace_bytes": (_i64, [_i, _i]),
     "ogl_sample_blocks_small": (_i, [_p, _p, _p, _i, _i, C.c_uint64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
+    "ogl_sample_blocks_small_fill": (_i, [_p, _p, _p, _i, _i, C.c_uint64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     "ogl_stage_segments": (_i, [_i, _p, _p, _p, _p, _p, _i64, _p]),
     "ogl_fuse_block_segments": (_i, [_p, _p, _i, _p, _p, _i, _p, _p]),
 }

@@ -731,6 +731,7 @@ struct SmallSampleArgs {
   int64_t T_max;
   int64_t* counts;                        // device [2]: n1, n0
   int64_t* seq_dev; volatile int64_t* counts_host;   // host-mapped [3]: n1, n0, sequence number (ogl_publish_i64's protocol)
+  int64_t fill0;                          // 0: src0 is padded with -1 up to its capacity; m > 0: up to round_up(n0, m) only
 };
 
 // one layer's picks for rows [0, n_live) of dst (one thread per (row, 4 slots): k_sample_layer_dev's arithmetic)
@@ -769,7 +770,8 @@ __device__ __forceinline__ void wg_sample(const SmallSampleArgs& a, const int64_
 template <bool LDS_TABLE>
 __device__ __forceinline__ int wg_build_t(const SmallSampleArgs& a, const int64_t* __restrict__ dst, int64_t n_dst, int64_t n_live,
                                           const int64_t* __restrict__ picks, int64_t* __restrict__ src_ids, int64_t src_cap,
-                                          int32_t* __restrict__ local_idx, int* carry_s, int32_t* lkey, int32_t* lmin, int64_t T) {
+                                          int32_t* __restrict__ local_idx, int* carry_s, int32_t* lkey, int32_t* lmin, int64_t T,
+                                          int64_t fill_mult = 0) {
   const int tid = threadIdx.x;
   const int64_t Q = n_dst + n_live * a.S;
   int logT = 0;
@@ -838,7 +840,10 @@ __device__ __forceinline__ int wg_build_t(const SmallSampleArgs& a, const int64_
       }
     }
   }
-  for (int64_t i = n_src + tid; i < src_cap; i += BLK_SCAN) src_ids[i] = -1;
+  // (fill_mult: the caller reads the source list up to round_up(n_src, fill_mult) only — the size bucket of the train graph it replays —,
+  // so the -1 padding stops there: 21 632 entries per 32-seed step otherwise, for ~2 600 sources)
+  const int64_t fill_end = fill_mult > 0 ? min(src_cap, (n_src + fill_mult - 1) / fill_mult * fill_mult) : src_cap;
+  for (int64_t i = n_src + tid; i < fill_end; i += BLK_SCAN) src_ids[i] = -1;
   __threadfence_block();
   __syncthreads();
   for (int64_t e = tid; e < n_dst * a.S; e += BLK_SCAN) {
@@ -852,13 +857,13 @@ __device__ __forceinline__ int wg_build_t(const SmallSampleArgs& a, const int64_
 
 __device__ __forceinline__ int wg_build(const SmallSampleArgs& a, const int64_t* __restrict__ dst, int64_t n_dst, int64_t n_live,
                                         const int64_t* __restrict__ picks, int64_t* __restrict__ src_ids, int64_t src_cap,
-                                        int32_t* __restrict__ local_idx, int* carry_s, int32_t* lkey, int32_t* lmin) {
+                                        int32_t* __restrict__ local_idx, int* carry_s, int32_t* lkey, int32_t* lmin, int64_t fill_mult = 0) {
   const int64_t Q = n_dst + n_live * a.S;
   int64_t T = 1024;
   while (2 * T < 3 * Q && T < a.T_max) T <<= 1;            // load factor <= 2/3
-  if (T <= SS_LDS_T) return wg_build_t<true>(a, dst, n_dst, n_live, picks, src_ids, src_cap, local_idx, carry_s, lkey, lmin, T);
+  if (T <= SS_LDS_T) return wg_build_t<true>(a, dst, n_dst, n_live, picks, src_ids, src_cap, local_idx, carry_s, lkey, lmin, T, fill_mult);
   while (T < 2 * Q && T < a.T_max) T <<= 1;
-  return wg_build_t<false>(a, dst, n_dst, n_live, picks, src_ids, src_cap, local_idx, carry_s, lkey, lmin, T);
+  return wg_build_t<false>(a, dst, n_dst, n_live, picks, src_ids, src_cap, local_idx, carry_s, lkey, lmin, T, fill_mult);
 }
 
 __global__ void __launch_bounds__(BLK_SCAN) k_sample_blocks_small(SmallSampleArgs a) {
@@ -881,7 +886,7 @@ __global__ void __launch_bounds__(BLK_SCAN) k_sample_blocks_small(SmallSampleArg
   wg_sample(a, a.src1, n1, ctr, 0u, a.picks0);
   __threadfence_block();
   __syncthreads();
-  const int n0 = wg_build(a, a.src1, n1_cap, n1, a.picks0, a.src0, n0_cap, a.lidx0, &carry_s, lkey, lmin);
+  const int n0 = wg_build(a, a.src1, n1_cap, n1, a.picks0, a.src0, n0_cap, a.lidx0, &carry_s, lkey, lmin, a.fill0);
   if (tid == 0) {
     a.counts[0] = n1; a.counts[1] = n0;
     a.counts_host[0] = n1; a.counts_host[1] = n0;
@@ -901,11 +906,24 @@ extern "C" int64_t ogl_sample_blocks_small_workspace_bytes(int B, int fanout) {
   return 8 * ((int64_t)B * fanout + n1_cap * fanout) + 4 * (3 * T + ogl_round_up(P0, 4)) + 64;
 }
 
+extern "C" int ogl_sample_blocks_small_fill(const ogl_graph_t* g, const int64_t* head_host_mapped, int64_t* head_dev, int B, int fanout,
+                                            uint64_t seed, int64_t* src1, int32_t* lidx1, int64_t* src0, int32_t* lidx0, int64_t* counts,
+                                            int64_t* seq_dev, int64_t* counts_host_mapped, void* workspace, int64_t workspace_bytes,
+                                            int64_t src0_fill_multiple, ogl_stream_t stream);
+
 extern "C" int ogl_sample_blocks_small(const ogl_graph_t* g, const int64_t* head_host_mapped, int64_t* head_dev, int B, int fanout,
                                        uint64_t seed, int64_t* src1, int32_t* lidx1, int64_t* src0, int32_t* lidx0, int64_t* counts,
                                        int64_t* seq_dev, int64_t* counts_host_mapped, void* workspace, int64_t workspace_bytes,
                                        ogl_stream_t stream) {
-  if (!g || B <= 0 || fanout <= 0 || B > 1023) return OGL_EINVAL;
+  return ogl_sample_blocks_small_fill(g, head_host_mapped, head_dev, B, fanout, seed, src1, lidx1, src0, lidx0, counts, seq_dev,
+                                      counts_host_mapped, workspace, workspace_bytes, 0, stream);
+}
+
+extern "C" int ogl_sample_blocks_small_fill(const ogl_graph_t* g, const int64_t* head_host_mapped, int64_t* head_dev, int B, int fanout,
+                                            uint64_t seed, int64_t* src1, int32_t* lidx1, int64_t* src0, int32_t* lidx0, int64_t* counts,
+                                            int64_t* seq_dev, int64_t* counts_host_mapped, void* workspace, int64_t workspace_bytes,
+                                            int64_t src0_fill_multiple, ogl_stream_t stream) {
+  if (!g || B <= 0 || fanout <= 0 || B > 1023 || src0_fill_multiple < 0) return OGL_EINVAL;
   const int64_t need = ogl_sample_blocks_small_workspace_bytes(B, fanout);
   if (need < 0) return OGL_EINVAL;
   if (!head_host_mapped || !head_dev || !src1 || !lidx1 || !src0 || !lidx0 || !counts || !seq_dev || !counts_host_mapped) return OGL_EINVAL;
@@ -920,6 +938,7 @@ extern "C" int ogl_sample_blocks_small(const ogl_graph_t* g, const int64_t* head
   a.T_max = table_size(P0);
   a.src1 = src1; a.lidx1 = lidx1; a.src0 = src0; a.lidx0 = lidx0;
   a.counts = counts; a.seq_dev = seq_dev; a.counts_host = (volatile int64_t*)counts_host_mapped;
+  a.fill0 = src0_fill_multiple;
   hipLaunchKernelGGL(k_sample_blocks_small, dim3(1), dim3(BLK_SCAN), 0, (hipStream_t)stream, a);
   OGL_CHECK_LAUNCH();
   return OGL_OK;

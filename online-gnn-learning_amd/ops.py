@@ -214,7 +214,7 @@ def sample_blocks_small_fits(B, fanout):
 
 
 def sample_blocks_small(g: GraphHandle, head_host_pinned, head_dev, B, fanout, seed, src1, lidx1, src0, lidx0, counts, seq_dev,
-                        counts_host_pinned, ws=None):
+                        counts_host_pinned, ws=None, src0_fill=0):
     """The whole sampling phase of one small batch (``ogl_sample_blocks_small``): stage [counter | seeds] from pinned host memory,
     sample + relabel both blocks into the static arrays, publish (n1, n0, ++seq) to pinned host memory.  Returns the workspace
     (keep it alive with the captured graph)."""
@@ -225,9 +225,10 @@ def sample_blocks_small(g: GraphHandle, head_host_pinned, head_dev, B, fanout, s
     assert tuple(lidx1.shape) == (B, fanout) and tuple(lidx0.shape) == (n1_cap, fanout) and lidx0.is_contiguous() and lidx1.is_contiguous()
     if ws is None:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=head_dev.device)
-    _launch("ogl_sample_blocks_small", _lib.lib().ogl_sample_blocks_small, g._h, head_host_pinned.data_ptr(), _ptr(head_dev), int(B),
+    # (src0_fill: pad src0 with -1 up to round_up(n0, src0_fill) only — stepgraph reads it up to its train graph's size bucket)
+    _launch("ogl_sample_blocks_small", _lib.lib().ogl_sample_blocks_small_fill, g._h, head_host_pinned.data_ptr(), _ptr(head_dev), int(B),
             int(fanout), C.c_uint64(seed & (2 ** 64 - 1)), _ptr(src1), _ptr(lidx1), _ptr(src0), _ptr(lidx0), _ptr(counts), _ptr(seq_dev),
-            counts_host_pinned.data_ptr(), _ptr(ws), nbytes, _stream(), meta=dict(n_dst=int(B), fanout=int(fanout)))
+            counts_host_pinned.data_ptr(), _ptr(ws), nbytes, int(src0_fill), _stream(), meta=dict(n_dst=int(B), fanout=int(fanout)))
     return ws
 
 

@@ -52,6 +52,7 @@ def round_up(x, m):
 N1_BUCKET = 256          # staged form
 N0_BUCKET = 2048
 N0_BUCKET_SMALL = 256    # sampled form (input blocks of a few hundred to a few thousand rows)
+SAMPLE_FILL_BUCKET = os.environ.get("OGL_SAMPLE_FILL_BUCKET", "1") != "0"    # the sample graph pads src0 up to that bucket only
 _WARMED = False
 
 
@@ -216,8 +217,10 @@ class SampleGraph:
         g, b, S = self.graph, self.buf, self.buf.S
         if ops.sample_blocks_small_fits(b.B, S):
             # ONE launch for the whole phase (round 5: eleven 4-5 us graph nodes before — stage, 2 x sample, 2 x block build, publish)
+            # (src0 is read up to the train graph's size bucket, round_up(n0, N0_BUCKET_SMALL): its -1 padding stops there)
             self._ws = ops.sample_blocks_small(g.handle, self.head_host, b.head, b.B, S, self.seed, b.src1, b.lidx1, b.src0, b.lidx0,
-                                               self.counts, self.seq_dev, self.counts_host, ws=getattr(self, "_ws", None))
+                                               self.counts, self.seq_dev, self.counts_host, ws=getattr(self, "_ws", None),
+                                               src0_fill=N0_BUCKET_SMALL if SAMPLE_FILL_BUCKET else 0)
             return
         ctr = b.head[:1]
         # [counter | seeds]: read by the graph's first kernel straight from the pinned host buffer run() filled (mapped memory:

@@ -145,11 +145,14 @@ def test_fused_small_sampling_phase_equals_the_launch_sequence(ops, dataset, B, 
     _, _, dyn, _, _ = synthetic.load(dataset, snapshots=4, device="cuda")
     dyn.evolve(); dyn.evolve()
     g = dyn.get_graph()
-    old = ops.SAMPLE_FUSED
+    old, old_fill = ops.SAMPLE_FUSED, stepgraph.SAMPLE_FILL_BUCKET
     res = {}
     try:
-        for fused in (False, True):
-            ops.SAMPLE_FUSED = fused
+        # (third arm, "bucket": the fused launch as the train loop runs it — src0 padded with -1 only up to the size bucket of the train
+        # graph that reads it, round_up(n0, N0_BUCKET_SMALL); everything the graph reads is the same)
+        for fused in (False, True, "bucket"):
+            ops.SAMPLE_FUSED = bool(fused)
+            stepgraph.SAMPLE_FILL_BUCKET = fused == "bucket"
             buf = stepgraph.BlockBuffers(B, S, B * (1 + S), B * (1 + S) ** 2, g.device)
             sg = stepgraph.SampleGraph(g, buf)
             out = []
@@ -162,11 +165,16 @@ def test_fused_small_sampling_phase_equals_the_launch_sequence(ops, dataset, B, 
                             buf.lidx0.cpu().clone()))
             res[fused] = out
     finally:
-        ops.SAMPLE_FUSED = old
+        ops.SAMPLE_FUSED, stepgraph.SAMPLE_FILL_BUCKET = old, old_fill
     for a, b in zip(res[False], res[True]):
         assert a[0] == b[0] and a[1] == b[1], (a[:2], b[:2])
         for x, y in zip(a[2:], b[2:]):
             assert torch.equal(x, y)
+    for a, b in zip(res[False], res["bucket"]):
+        assert a[0] == b[0] and a[1] == b[1], (a[:2], b[:2])
+        end = min(a[5].numel(), stepgraph.round_up(a[1], stepgraph.N0_BUCKET_SMALL))
+        for k, (x, y) in enumerate(zip(a[2:], b[2:])):
+            assert torch.equal(x[:end], y[:end]) if k == 3 else torch.equal(x, y)      # (k == 3: src0)
     assert res[True][0][0] > B        # (the blocks are not trivial)
 
 
