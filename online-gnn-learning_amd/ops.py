@@ -2823,8 +2823,10 @@ def sage_pool_layer_loss(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, id
         if defer_mean and DEFER_LOSS_MEAN and small_pool_loss_fits(h, w_pool, w_self, w_neigh, idx, n_dst, labels):
             # (``h_single_use``: the caller made ``h`` and hands it to this layer only — GraphSAGE.forward_loss.  When it came out of the
             # small first layer, this node's whole backward moves into that layer's two launches: see ``_SmallPoolLossFn``)
+            # (not under a gradient exchange that launches collectives from gradient hooks: this node's gradient tensors are filled by
+            # a launch enqueued AFTER their hooks fire — a bucket made of them alone would be reduced before it is written)
             lazy = bool(SMALL_ROUTE and h_single_use and h.requires_grad and type(h.grad_fn).__name__ == "_SmallFirstLayerFnBackward"
-                        and n_dst * h.shape[1] <= 2048)
+                        and n_dst * h.shape[1] <= 2048 and not _GRAD_SINKS)
             return _SmallPoolLossFn.apply(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels, lazy)
         return None
     if (b_self is None) != (b_neigh is None) or not out_loss_fits(h, n_dst, idx, w_self, w_neigh, w_pool.shape[0]):
