@@ -384,6 +384,10 @@ def main():
             key = "reduce_fwd_L0" if meta["n_dst"] > B else "reduce_fwd_L1"
         elif name.startswith("ogl_linear"):
             key = name[4:] + ("_pool0" if meta["M"] > B * (1 + S) else "_other")
+        elif name == "ogl_small_proj_rows":                         # fc_pool of a 32-seed step's first layer: exact-fp32 MFMA, small tiles
+            key = "linear_fwd_f32small_pool0"
+        elif name == "ogl_small_first_layer_fwd":                   # the same step's aggregator (max + combine in one launch)
+            key = "reduce_fwd_L0"
         a = agg.setdefault(key, dict(ms=0.0, calls=0, bytes=0.0, flops=0.0))
         a["ms"] += ms; a["calls"] += 1
         if meta and meta.get("kernel"):
@@ -393,6 +397,12 @@ def main():
             a["bytes"] += E * (4 * meta["d"] + meta["idx_bytes"]) + meta["n_dst"] * 4 * meta["d"] * (2 if meta["argmax"] else 1)
             if name == "ogl_reduce_fwd_img":
                 a["bytes"] += meta["n_dst"] * 6 * meta["d"]          # + the image: three bf16 planes per element
+        if name == "ogl_small_first_layer_fwd":                      # E gathered rows + indices, the reduced rows + argmax written
+            E = meta["n_dst"] * meta["fanout"]
+            a["bytes"] += E * (4 * meta["d"] + 4) + meta["n_dst"] * 4 * meta["d"] * 2
+            a["small"] = True
+        if name == "ogl_small_proj_rows":
+            a["flops"] += 2.0 * meta["M"] * meta["N"] * meta["K"]
         # mandatory bytes of the other HBM-bound launches (for roofline.composite_floor_ms; every matrix counted once per pass over it)
         if name in ("ogl_pool_bwd_x3", "ogl_pool_bwd_x3_apply"):     # dout read + the group-major bf16x3 image of dP^T written
             a["bytes"] += meta["n_dst"] * 4 * meta["d"] + (meta["n_src"] + 31) // 32 * 32 * 6 * meta["d"]
@@ -424,7 +434,9 @@ def main():
     roof_aggr = None
     if ragg:
         ach = ragg["bytes"] / ragg["ms"] / 1e6
-        roof_aggr = dict(kernel="k_reduce_fwd_v4 (layer-0 gather+max, argmax kept, bf16x3 image of the output written beside it)", bound="hbm", achieved=round(ach, 1),
+        roof_aggr = dict(kernel=("k_small_first_fwd (32-seed step: layer-0 gather + max + combine in one launch, argmax kept; latency-bound at these sizes)"
+                                 if ragg.get("small") else
+                                 "k_reduce_fwd_v4 (layer-0 gather+max, argmax kept, bf16x3 image of the output written beside it)"), bound="hbm", achieved=round(ach, 1),
                          peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
                          avg_launch_ms=round(ragg["ms"] / ragg["calls"], 4),
                          algorithmic_bytes_per_launch=round(ragg["bytes"] / ragg["calls"]),
@@ -457,8 +469,10 @@ def main():
         ach = agg[dom]["flops"] / agg[dom]["ms"] / 1e9
         # which arithmetic did this launch run on?  (ops.weight_grad / linear.hip AUTO policy)
         x6 = args.gemm == "bf16x6" or (args.gemm == "auto" and ("_x3" in dom or "bwd_weight_t" in dom or "bwd_weight" not in dom))
+        if "f32small" in dom:
+            x6 = False                                               # (ogl_small_proj_rows: exact fp32 products whatever the mode)
         peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if x6 else MFMA_F32_PEAK_TFLOPS
-        roof_gemm = dict(kernel="%s (%s; %s)" % ("k_gemm_x3p" if "_x3" in dom else "k_gemm", dom, ("split-bf16 x6 on v_mfma_f32_16x16x32_bf16, fp32 accumulate" if "_x3" in dom else
+        roof_gemm = dict(kernel="%s (%s; %s)" % ("k_gemm_x3p" if "_x3" in dom else ("k_small_proj_rows" if "f32small" in dom else "k_gemm"), dom, ("split-bf16 x6 on v_mfma_f32_16x16x32_bf16, fp32 accumulate" if "_x3" in dom else
                                                        "split-bf16 x6 on v_mfma_f32_32x32x16_bf16, fp32 accumulate") if x6
                                                       else "v_mfma_f32_32x32x2_f32"),
                          bound="mfma", achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
@@ -474,7 +488,8 @@ def main():
     composite = None
     if gemm_keys:
         x6_roof, f32_roof = BF16_MFMA_PEAK_TFLOPS / 6.0, MFMA_F32_PEAK_TFLOPS
-        fl_x6 = sum(v["flops"] for k, v in agg.items() if v["flops"] and args.gemm != "f32" and ("_x3" in k or "bwd_weight" not in k))
+        fl_x6 = sum(v["flops"] for k, v in agg.items() if v["flops"] and args.gemm != "f32" and ("_x3" in k or "bwd_weight" not in k)
+                    and "f32small" not in k)
         fl_f32 = sum(v["flops"] for v in agg.values()) - fl_x6
         mfma_ms = (fl_x6 / (x6_roof * 1e9) + fl_f32 / (f32_roof * 1e9)) / prof_steps
         hbm_bytes = sum(v["bytes"] for k, v in agg.items() if v["bytes"] and not v["flops"])
