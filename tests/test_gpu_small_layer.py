@@ -142,6 +142,7 @@ def test_small_output_layer_with_loss_in_one_launch(n_src, n_dst, S, hin, hout, 
     import ogl_amd  # noqa: F401
     from ogl_amd import ops
     rng = np.random.default_rng(7 * n_src + hin + S)
+    torch.manual_seed(7 * n_src + hin + S)                               # (the layer's weights: a fixed draw, see the first-layer test)
     h = rng.standard_normal((n_src, hin)).astype(np.float32)
     idx = rng.integers(0, n_src, size=(n_dst, S)).astype(np.int32)
     idx[rng.random(n_dst) < 0.15] = -1
