@@ -761,9 +761,10 @@ int ogl_small_pool_layer_bwd_pool(const float* h, int64_t ldh, int64_t n_dst, in
  * features, `nn.Linear` + relu of DGL SAGEConv 'pool', R/train/graphsage/pytorch/graphsage_dgl.py:26-31) on the exact-fp32 MFMA
  * (v_mfma_f32_32x32x2_f32: fp32 products, fp32 accumulate) with 32 x 64 tiles whose four waves split columns and every k-slab — where the
  * general kernels' tiles leave most of the chip idle and pay an operand conversion per step.  x [n_table, K] (x_rows NULL: row m itself; a row id outside the table: zeros), w [N, K]; K % 4 == 0, ldx % 4 == 0,
- * ldw % 4 == 0, 16-byte aligned bases; M <= 65 536, N <= 4 096. */
+ * ldw % 4 == 0, 16-byte aligned bases; M <= 65 536, N <= 4 096.  m_live_dev (nullable): a device scalar — only rows below
+ * round_up(*m_live_dev, 32) are computed (the rest of y is left untouched): an upper-bound launch whose real size lives on the device. */
 int ogl_small_proj_rows(const float* x, int64_t ldx, const int64_t* x_rows, int64_t n_table, int64_t M, int K, const float* w, int64_t ldw,
-                        int N, const float* bias, int relu, float* y, int64_t ldy, ogl_stream_t stream);
+                        int N, const float* bias, int relu, float* y, int64_t ldy, const int64_t* m_live_dev, ogl_stream_t stream);
 
 /* The FIRST 'pool' layer of a 32-seed step behind its fc_pool product (the live layer, R/train/graphsage/pytorch/graphsage_dgl.py:26-31
  * -> DGL SAGEConv 'pool', at the reference's small settings: in_feats 500 / 128, embedding_size 32, <= 832 destinations):

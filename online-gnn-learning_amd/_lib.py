@@ -129,7 +129,7 @@ SIGNATURES = {
                                              _p, _i64, _p, _p, _i64, _p, _p, _p, _i64, _p, _p, _i64, _i, _p, _i64, _p]),
     "ogl_small_pool_layer_bwd_pool": (_i, [_p, _i64, _i64, _i, _i, _p, _p, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _i64, _p,
                                            _p, _i64, _p, _p, _i64, _p, _p, _p, _d, _d, _d, _p]),
-    "ogl_small_proj_rows": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p, _i, _p, _i64, _p]),
+    "ogl_small_proj_rows": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p, _i, _p, _i64, _p, _p]),
     "ogl_small_first_layer_fits": (_i, [_i64, _i64, _i, _i, _i]),
     "ogl_small_first_layer_fwd": (_i, [_p, _i64, _i64, _p, _i64, _i, _i, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i, _i, _p, _i64,
                                        _p, _p, _i64, _p, _p]),

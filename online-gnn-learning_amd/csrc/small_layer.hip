@@ -591,7 +591,13 @@ typedef float spr_f32x16 __attribute__((ext_vector_type(16)));
 template <bool ARES>
 __global__ void __launch_bounds__(256) k_small_proj_rows(const float* __restrict__ X, int64_t ldx, const int64_t* __restrict__ ids,
                                                          int64_t n_table, int M, int K, const float* __restrict__ W, int64_t ldw, int N,
-                                                         const float* __restrict__ bias, int relu, float* __restrict__ Y, int64_t ldy) {
+                                                         const float* __restrict__ bias, int relu, float* __restrict__ Y, int64_t ldy,
+                                                         const int64_t* __restrict__ m_live) {
+  // (m_live: a device scalar — the rows at or behind it are padding of an upper-bound launch: a captured 32-seed step sized for the
+  // largest input block it can ever see needs no size read-back before its train graph.  The grid's y extent is capped and a block
+  // walks the row tiles y, y + gridDim.y, ... below the live count: an upper bound of 21 632 rows would otherwise dispatch 5 408
+  // workgroups, 52 KB of LDS each, to do the work of 700 — measured +10 us per step)
+  const int64_t m_eff = m_live ? min((int64_t)M, max((int64_t)0, *m_live)) : (int64_t)M;
   extern __shared__ __attribute__((aligned(16))) float spr_smem[];
   typedef float (*ATile)[SPR_BM + 2];
   typedef float (*BTile)[SPR_BK][SPR_BN + 4];
@@ -601,7 +607,8 @@ __global__ void __launch_bounds__(256) k_small_proj_rows(const float* __restrict
   BTile Bs = (BTile)(spr_smem + (size_t)(ARES ? nk : 2) * SPR_BK * (SPR_BM + 2));
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int wx = wv & 1, kh = wv >> 1;                       // column half, k half
-  const int m0 = blockIdx.y * SPR_BM, n0 = blockIdx.x * SPR_BN;
+  const int n0 = blockIdx.x * SPR_BN;
+  for (int m0 = blockIdx.y * SPR_BM; m0 < m_eff; m0 += gridDim.y * SPR_BM) {
   // loaders: A row (t >> 3), float4s at k = 4 (t & 7) + {0, 32};  B row (t >> 2), float4s at k = 4 (t & 3) + {0, 16, 32, 48}
   const int ar = t >> 3, ak = (t & 7) * 4, br = t >> 2, bk = (t & 3) * 4;
   const float* arow = nullptr;
@@ -713,10 +720,13 @@ __global__ void __launch_bounds__(256) k_small_proj_rows(const float* __restrict
       }
     }
   }
+  __syncthreads();                                           // (the next row tile parks its first slabs where `red` lives)
+  }
 }
 
 extern "C" int ogl_small_proj_rows(const float* x, int64_t ldx, const int64_t* x_rows, int64_t n_table, int64_t M, int K, const float* w,
-                                   int64_t ldw, int N, const float* bias, int relu, float* y, int64_t ldy, ogl_stream_t stream) {
+                                   int64_t ldw, int N, const float* bias, int relu, float* y, int64_t ldy, const int64_t* m_live_dev,
+                                   ogl_stream_t stream) {
   if (M < 0 || M > 65536 || K <= 0 || (K & 3) || N <= 0 || N > 4096 || n_table <= 0) return OGL_EINVAL;
   if (M == 0) return OGL_OK;
   if (!x || !w || !y || ldx < K || ldw < K || ldy < N || (ldx & 3) || (ldw & 3) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return OGL_EINVAL;
@@ -724,7 +734,7 @@ extern "C" int ogl_small_proj_rows(const float* x, int64_t ldx, const int64_t* x
   const size_t b_bytes = sizeof(float) * 2 * SPR_BK * (SPR_BN + 4);
   const size_t ares_bytes = sizeof(float) * (size_t)nk * SPR_BK * (SPR_BM + 2) + b_bytes;
   const size_t strm_bytes = sizeof(float) * 2 * SPR_BK * (SPR_BM + 2) + b_bytes;
-  const dim3 grid((unsigned)ogl_cdiv(N, SPR_BN), (unsigned)ogl_cdiv(M, SPR_BM));
+  const dim3 grid((unsigned)ogl_cdiv(N, SPR_BN), (unsigned)std::min<int64_t>(ogl_cdiv(M, SPR_BM), m_live_dev ? 96 : 65535));
   static bool attr_set = false;
   if (!attr_set) {
     OGL_CHECK_HIP(hipFuncSetAttribute((const void*)k_small_proj_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -735,10 +745,10 @@ extern "C" int ogl_small_proj_rows(const float* x, int64_t ldx, const int64_t* x
   static const bool ares_on = getenv("OGL_SPR_ARES") && getenv("OGL_SPR_ARES")[0] == '1';
   if (ares_on && ares_bytes <= 160 * 1024)
     hipLaunchKernelGGL(k_small_proj_rows<true>, grid, dim3(256), ares_bytes, (hipStream_t)stream, x, ldx, x_rows, n_table, (int)M, K, w, ldw,
-                       N, bias, relu, y, ldy);
+                       N, bias, relu, y, ldy, m_live_dev);
   else
     hipLaunchKernelGGL(k_small_proj_rows<false>, grid, dim3(256), strm_bytes, (hipStream_t)stream, x, ldx, x_rows, n_table, (int)M, K, w,
-                       ldw, N, bias, relu, y, ldy);
+                       ldw, N, bias, relu, y, ldy, m_live_dev);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }

@@ -90,9 +90,12 @@ class GraphSAGE(nn.Module):
             if ent is not None and not (training and ent[0].p > 0):
                 _, r_wb, r_cat, r_tn, r_tp, p_out, p_in, s_out, r_bsum = ent
                 if li == 0 and isinstance(x, GatheredRows) and x.proj is None:
-                    if ops._x3_forward_ok(ops.as_mat(x.table), n_src, None):
+                    if getattr(block, "n_src_live_dev", None) is not None:
+                        pass        # (an upper-bound block of a captured small step: its first layer runs on the small kernels, no images)
+                    elif ops._x3_forward_ok(ops.as_mat(x.table), n_src, None):
                         req.append(r_wb)
-                    if ops._n1_images_ok(n_dst, p_out, s_out) and ops._static_key(x.table) in ops._X3_TABLES:
+                    if (getattr(block, "n_src_live_dev", None) is None and ops._n1_images_ok(n_dst, p_out, s_out)
+                            and ops._static_key(x.table) in ops._X3_TABLES):
                         req.append(r_cat)
                         req.append(r_tn)
                 elif li > 0 and ops._n1_images_ok(n_src, p_in, p_out):

@@ -173,7 +173,7 @@ class SAGEConv(nn.Module):
             # the first layer of a small (32-seed) step: everything behind the fc_pool product is one launch each way
             return ops.small_first_pool_layer(feat.table, feat.ids, self.fc_pool.weight, self.fc_pool.bias, self.fc_self.weight,
                                               self.fc_neigh.weight, self.fc_self.bias, self.fc_neigh.bias, idx, n_dst, fuse_relu,
-                                              n_live=getattr(graph, "n_live_dev", None))
+                                              n_live=getattr(graph, "n_live_dev", None), n_src_live=getattr(graph, "n_src_live_dev", None))
         if t == "pool":
             h_neigh = self._pool_max(feat, idx)
             rst = self._linear2(feat_dst, self.fc_self.weight, h_neigh, self.fc_neigh.weight, self.fc_self.bias, fuse_relu,

@@ -3033,6 +3033,7 @@ class _SmallPoolLossFn(torch.autograd.Function):
 # weight gradients as three more row groups of the record launch): no launch of its own, no float atomics
 SMALL_ROUTE = os.environ.get("OGL_SMALL_ROUTE", "1") != "0"
 _PENDING_ROUTES = {}
+_SMALL_AGNOSTIC = {"seen": False}      # set by a forward whose first layer ran on the device's own source count (stepgraph reads it)
 SMALL_LIVE = os.environ.get("OGL_SMALL_LIVE", "1") != "0"      # padded rows of a captured step's upper-bound block take the kernels' early exits
 SMALL_PROJ = os.environ.get("OGL_SMALL_PROJ", "1") != "0"      # fc_pool of a small step's first layer on the small-tile fp32-MFMA kernel
 SMALL_PROJ_MAX_ROWS = int(os.environ.get("OGL_SMALL_PROJ_MAX_ROWS", "4096"))
@@ -3071,18 +3072,23 @@ class _SmallFirstLayerFn(torch.autograd.Function):
     y = act(X[ids[:n_dst]] . Ws^T + max_j relu(X[ids] . Wp^T + bp)[idx] . Wn^T + bs + bn) (DGL SAGEConv 'pool')."""
 
     @staticmethod
-    def forward(ctx, table, ids, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu, n_live=None):
+    def forward(ctx, table, ids, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu, n_live=None, n_src_live=None):
         # n_live (optional device int64 scalar): the LIVE destination rows of a captured step's upper-bound block — rows behind them are
         # padding (index rows all -1, source id -1) and take the kernels' early exits
+        # n_src_live (optional device int64 scalar): the LIVE source rows — the block's source list is an upper bound (a captured step
+        # sized for the largest input block it can see: stepgraph's size-agnostic form), fc_pool computes the live rows only
         ctx.n_live = n_live
         x = as_mat(table)
         ids = _ids(ids)
-        if SMALL_PROJ and ids.numel() <= SMALL_PROJ_MAX_ROWS and w_pool.is_contiguous() and w_pool.data_ptr() % 16 == 0:
+        if (SMALL_PROJ and (ids.numel() <= SMALL_PROJ_MAX_ROWS or (n_src_live is not None and ids.numel() <= 65536))
+                and w_pool.is_contiguous() and w_pool.data_ptr() % 16 == 0):
+            if n_src_live is not None:
+                _SMALL_AGNOSTIC["seen"] = True          # (read by stepgraph: this step's launches do not depend on the block's size)
             # the product itself on the exact-fp32 MFMA with 32 x 64 tiles (ogl_small_proj_rows): at these sizes the general kernel's
             # 64 x 64 tiles leave most of the chip idle and convert their operands on the fly (25 us for 0.38 GFLOP, pubmed-like rung)
             p = empty_mat(ids.numel(), w_pool.shape[0], x.device)
             _launch("ogl_small_proj_rows", _lib.lib().ogl_small_proj_rows, _ptr(x), _ld(x), _ptr(ids), x.shape[0], ids.numel(), x.shape[1],
-                    _ptr(w_pool), _ld(as_mat(w_pool)), w_pool.shape[0], _ptr(b_pool), 1, _ptr(p), _ld(p), _stream(),
+                    _ptr(w_pool), _ld(as_mat(w_pool)), w_pool.shape[0], _ptr(b_pool), 1, _ptr(p), _ld(p), _ptr(n_src_live), _stream(),
                     meta=dict(M=ids.numel(), N=w_pool.shape[0], K=x.shape[1]))
         else:
             p = linear_fwd(x, w_pool, b_pool, relu=True, x_rows=ids)
@@ -3180,7 +3186,7 @@ class _SmallFirstLayerFn(torch.autograd.Function):
         elif need_pool:
             dwp, dbp = weight_grad(dP, x, ids, want_bias=ctx.has_pool_bias, dw_out=_dw_out(w_pool, *w_pool.shape))
         return (None, None, dwp, dbp if ctx.has_pool_bias else None, dws, dwn, db if ctx.has_bias else None,
-                db2 if ctx.has_bias else None, None, None, None, None)
+                db2 if ctx.has_bias else None, None, None, None, None, None)
 
 
 def _record_launch(rec, dneigh, argmax, dy, n_dst, F, H, x, ids, n_src, neigh, dwp, dbp, dws, db, dwn, db2, route, n_live=None):
@@ -3229,9 +3235,9 @@ def _record_launch(rec, dneigh, argmax, dy, n_dst, F, H, x, ids, n_src, neigh, d
         _ADAM_PRIME["served"] = (step_dev.data_ptr(), _capturing())
 
 
-def small_first_pool_layer(table, ids, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu, n_live=None):
+def small_first_pool_layer(table, ids, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu, n_live=None, n_src_live=None):
     return _SmallFirstLayerFn.apply(table, ids, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu,
-                                    n_live if SMALL_LIVE else None)
+                                    n_live if SMALL_LIVE else None, n_src_live)
 
 
 def sage_pool_layer(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, relu):

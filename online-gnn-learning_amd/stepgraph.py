@@ -53,6 +53,11 @@ N1_BUCKET = 256          # staged form
 N0_BUCKET = 2048
 N0_BUCKET_SMALL = 256    # sampled form (input blocks of a few hundred to a few thousand rows)
 SAMPLE_FILL_BUCKET = os.environ.get("OGL_SAMPLE_FILL_BUCKET", "1") != "0"    # the sample graph pads src0 up to that bucket only
+# A sampled step whose launches take their sizes from the DEVICE (the small first layer on the sample graph's own counts: ops._SMALL_AGNOSTIC)
+# is captured ONCE on the upper-bound block and replayed right behind its sample graph — no read-back in front of the train graph (it picked
+# the size bucket), no host in the device's critical path: the counts are read after both graphs are enqueued.
+SIZE_AGNOSTIC = os.environ.get("OGL_SIZE_AGNOSTIC", "1") != "0"
+SIZE_AGNOSTIC_PIPE = os.environ.get("OGL_SIZE_AGNOSTIC_PIPE", "0") == "1"
 _WARMED = False
 
 
@@ -80,13 +85,16 @@ class TrainStepGraph:
     """One captured train step over ``buf`` restricted to (n1_pad, n0_pad) rows.
     ``loss_fn(logits, labels) -> (scalar loss to differentiate, per-seed losses or None)``."""
 
-    def __init__(self, model, optimizer, graph, buf, n1_pad, n0_pad, loss_fn, pool=None, apply=True, loss_kind=None, dp=None):
+    def __init__(self, model, optimizer, graph, buf, n1_pad, n0_pad, loss_fn, pool=None, apply=True, loss_kind=None, dp=None, sampler=None):
         # apply=False: forward + loss + backward only (the gradients are in ``grads``; exchange and optimiser are the caller's).
         # dp = (GradSynchronizer, weight): the WHOLE step of a data-parallel replica — forward, loss, backward, the gradient exchange
         # (RCCL all-reduces recorded into the graph: the early bucket launched from the gradient hooks on the side branch, under the
         # layer-0 backward; the late one after it) and the optimiser (device-side step count) — replayed with one host call.
         self.model, self.opt, self.graph, self.buf, self.loss_fn, self.apply = model, optimizer, graph, buf, loss_fn, bool(apply)
         self.dp = dp if apply else None
+        # sampler (a SampleGraph over ``buf``): its one launch is recorded at the TOP of this graph — sampling and training of a batch
+        # are ONE graph launch (for a train graph that takes the block's size from the device: StepGraphCache._agnostic_graph)
+        self.sampler = sampler
         # "mean" / "mean_rows": the loss is nn.CrossEntropyLoss — the model may run its last layer and the loss as one node
         # (GraphSAGE.forward_loss); None: an arbitrary loss_fn(logits, labels)
         self.loss_kind = loss_kind if hasattr(model, "forward_loss") else None
@@ -99,12 +107,16 @@ class TrainStepGraph:
     def _body(self, apply=None, learn=False):
         apply = self.apply if apply is None else apply
         g, b = self.graph, self.buf
+        if self.sampler is not None:
+            self.sampler._body()
         src0, src1, lidx0 = b.src0[:self.n0_pad], b.src1[:self.n1_pad], b.lidx0[:self.n1_pad]
         blocks = [sampling.Block(src0, src1, lidx0), sampling.Block(src1, b.seeds, b.lidx1)]
         if b.counts is not None:
             # the sampled form runs on the upper-bound block: n1_cap destination rows of which counts[0] are live — the small first layer's
             # kernels skip the padded ones (a device scalar the sample graph rewrites before every replay)
             blocks[0].n_live_dev = b.counts[:1]
+            if self.n0_pad == b.n0_cap:
+                blocks[0].n_src_live_dev = b.counts[1:2]      # ... and, sized for the whole source list, its live length too
         # the FULL tables: a snapshot view's row count would be frozen into the graph (ids are < n_present by construction)
         labels = ops.LazyLabels(g.target_table, b.seeds) if LAZY_LABELS else ops.gather_i64(g.target_table, b.seeds)
         self.opt.zero_grad(set_to_none=True)
@@ -168,9 +180,16 @@ class TrainStepGraph:
             # (found by tests/test_gpu_nccl.py).  "thread_local": only this thread's own calls are policed.
             torch.cuda.synchronize()
             kw["capture_error_mode"] = "thread_local"
+        ops._SMALL_AGNOSTIC["seen"] = False
         with torch.cuda.graph(self.cuda_graph, **kw):
             self._body()
+        # (True: the recorded launches take the input block's size from the device — this graph serves every batch of its shape)
+        self.size_agnostic = bool(ops._SMALL_AGNOSTIC["seen"]) and self.n0_pad == self.buf.n0_cap
         self.grads = [p.grad for p in self.model.parameters()]
+        if self.sampler is not None:
+            # (the warm-up pass above ran the sampler's launch for real: its device-side sequence number moved without the host's)
+            torch.cuda.synchronize()
+            self.sampler.seq = int(self.sampler.counts_np[2])
 
     def replay(self):
         """Replays the step.  ``self.loss`` / ``self.loss_rows`` / ``self.grads`` are STATIC tensors of the graph: the next replay
@@ -238,6 +257,15 @@ class SampleGraph:
         self.launch(seeds_host, ctr)
         return self.wait()
 
+    def prepare(self, seeds_host, ctr):
+        """[counter | seeds] into the mapped host buffer the sampling launch reads — for a caller that replays a graph which CONTAINS
+        that launch (TrainStepGraph(sampler=...)); ``wait()`` afterwards as after ``launch``."""
+        h = self.head_host
+        h[0] = int(ctr)
+        h[1:] = torch.as_tensor(np.asarray(seeds_host), dtype=torch.int64)     # (not touched again until the graph's last store is seen)
+        self._stream = None
+        self.seq += 1
+
     def launch(self, seeds_host, ctr, stream=None):
         """Enqueue the sample graph (on ``stream``: the pipelined steps run it beside the previous batch's train graph)."""
         h = self.head_host
@@ -284,11 +312,12 @@ class StepGraphCache:
     def __init__(self, model, optimizer, S, loss_fn, loss_kind=None):
         self.model, self.opt, self.S, self.loss_fn, self.loss_kind = model, optimizer, int(S), loss_fn, loss_kind
         self.bufs, self.samplers = {}, {}
+        self.agnostic = {}            # sampler key -> True / False once known (SIZE_AGNOSTIC)
         self.graphs = collections.OrderedDict()
         self.captures = self.evictions = self.borrowed = self.deferred = 0
         self.sightings = {}
 
-    def _train(self, graph, buf, key, n1_pad, n0_pad, apply=True, dp=None):
+    def _train(self, graph, buf, key, n1_pad, n0_pad, apply=True, dp=None, sampler=None):
         sg = self.graphs.get(key)
         if sg is None:
             while len(self.graphs) >= self.MAX_GRAPHS:
@@ -298,7 +327,7 @@ class StepGraphCache:
                 del old
                 self.evictions += 1
             sg = self.graphs[key] = TrainStepGraph(self.model, self.opt, graph, buf, n1_pad, n0_pad, self.loss_fn, apply=apply,
-                                                   loss_kind=self.loss_kind, dp=dp)
+                                                   loss_kind=self.loss_kind, dp=dp, sampler=sampler)
             self.captures += 1
         else:
             self.graphs.move_to_end(key)
@@ -323,21 +352,36 @@ class StepGraphCache:
         cur = pipe["cur"]
         smp = pipe["smp"][cur]
         main = torch.cuda.current_stream()
+        # (the size-agnostic train graph is for the one-graph step of ``sampled_step``: here the sampling of batch i + 1 already hides
+        # behind batch i's train graph, and an upper-bound graph behind a separate sample graph measured slower — OGL_SIZE_AGNOSTIC_PIPE=1)
+        agn = SIZE_AGNOSTIC_PIPE and self.agnostic.get(bkey) is not False
         if pipe["ahead"] is not None and pipe["ahead"][0] == cur and pipe["ahead"][1] == int(ctr):
-            n1, n0 = smp.wait()                              # launched while the previous batch trained
+            if not agn:
+                n1, n0 = smp.wait()                          # launched while the previous batch trained
             main.wait_event(pipe["sampled"][cur])
         else:
             if pipe["ahead"] is not None:                    # (a prefetch nobody came for: let it finish before its set is reused)
                 pipe["smp"][pipe["ahead"][0]].wait()
                 main.wait_event(pipe["sampled"][pipe["ahead"][0]])
-            n1, n0 = smp.run(seeds_host, ctr)
+            if agn:
+                smp.launch(seeds_host, ctr)
+            else:
+                n1, n0 = smp.run(seeds_host, ctr)
         pipe["ahead"] = None
-        n0_pad = min(round_up(n0, N0_BUCKET_SMALL), smp.buf.n0_cap)
-        sg = self._train(graph, smp.buf, bkey + (n0_pad, cur), smp.buf.n1_cap, n0_pad)
+        sg = None
+        if agn:
+            # the train graph of the UPPER-BOUND block right behind the sample graph: no read-back in front of it
+            sg = self._agnostic_graph(graph, smp, bkey, (bkey + ("cap", cur)))
+            if sg is None:
+                n1, n0 = smp.wait()
+        if sg is None:
+            n0_pad = min(round_up(n0, N0_BUCKET_SMALL), smp.buf.n0_cap)
+            sg = self._train(graph, smp.buf, bkey + (n0_pad, cur), smp.buf.n1_cap, n0_pad)
         sg.replay()
         ev = pipe["trained"][cur] = torch.cuda.Event()
         ev.record()
-        sg.last_sizes = (n0, n1)
+        if not (agn and sg.size_agnostic):
+            sg.last_sizes = (n0, n1)
         other = 1 - cur
         if nxt is not None and len(nxt[0]) == B:
             side = pipe["side"]
@@ -348,6 +392,9 @@ class StepGraphCache:
             es.record(side)
             pipe["ahead"] = (other, int(nxt[1]))
         pipe["cur"] = other
+        if agn and sg.size_agnostic:
+            n1, n0 = smp.wait()                              # (after everything is enqueued: the device never waits for this)
+            sg.last_sizes = (n0, n1)
         return sg
 
     def sampled_step(self, graph, seeds_host, ctr):
@@ -359,12 +406,41 @@ class StepGraphCache:
             n1_cap = B * (1 + self.S)
             buf = self.bufs[bkey] = BlockBuffers(B, self.S, n1_cap, n1_cap * (1 + self.S), graph.device)
             smp = self.samplers[bkey] = SampleGraph(graph, buf)
+        if SIZE_AGNOSTIC and self.agnostic.get(bkey) is not False:
+            # ONE graph per step: the sampling launch recorded at the top of a train graph sized for the upper-bound block (its first
+            # layer takes the live sizes from the device) — one host call, no read-back and no graph-to-graph hand-over (8 us on this
+            # part) between sampling and training
+            smp.prepare(seeds_host, ctr)
+            sg = self._agnostic_graph(graph, smp, bkey, bkey + ("cap", "merged"), merged=True)
+            if sg is not None:
+                sg.replay()
+                n1, n0 = smp.wait()                          # (after the step is enqueued: the device never waits for this)
+                sg.last_sizes = (n0, n1)
+                return sg
+            torch.cuda.synchronize()                         # (not size-agnostic: back to sample graph -> read-back -> bucket's graph)
+            smp.seq = int(smp.counts_np[2])
         n1, n0 = smp.run(seeds_host, ctr)
         n0_pad = min(round_up(n0, N0_BUCKET_SMALL), smp.buf.n0_cap)
         sg = self._train(graph, smp.buf, bkey + (n0_pad,), smp.buf.n1_cap, n0_pad)
         sg.replay()
         sg.last_sizes = (n0, n1)
         return sg
+
+    def _agnostic_graph(self, graph, smp, bkey, key, merged=False):
+        """The train graph captured on the sampler's UPPER-BOUND block, if its launches take the block's size from the device (the first
+        use captures it and finds out: ``TrainStepGraph.size_agnostic``); None when they do not — the caller then reads the counts back
+        and replays the graph of their size bucket, as before."""
+        known = self.agnostic.get(bkey)
+        samp = smp if merged else None
+        if known is None or key not in self.graphs:
+            sg = self._train(graph, smp.buf, key, smp.buf.n1_cap, smp.buf.n0_cap, sampler=samp)
+            if not sg.size_agnostic:
+                self.agnostic[bkey] = False
+                self.graphs.pop(key, None)                   # (it ran the general launches on 28 x the rows: never again)
+                return None
+            self.agnostic[bkey] = True
+            return sg
+        return self._train(graph, smp.buf, key, smp.buf.n1_cap, smp.buf.n0_cap, sampler=samp)
 
     def staged_step(self, graph, seeds, blocks, n0, n1, apply=True, defer_first=False, dp=None):
         """One step of a loader batch: stage its block arrays into the bucket's static buffers, replay its train graph.

@@ -155,8 +155,9 @@ def test_graph_cache_is_bounded():
     cache = st._step_graphs()
     cache.MAX_GRAPHS = 2
     import ogl_amd.stepgraph as sgm
-    keep = sgm.N0_BUCKET_SMALL
+    keep, keep_agn = sgm.N0_BUCKET_SMALL, sgm.SIZE_AGNOSTIC
     sgm.N0_BUCKET_SMALL = 4                                   # tiny buckets: nearly every batch is a new one
+    sgm.SIZE_AGNOSTIC = False                                 # (the bucketed form: a size-agnostic step is ONE graph whatever the batch)
     try:
         rng = np.random.default_rng(0)
         sampling.seed(1)
@@ -167,4 +168,4 @@ def test_graph_cache_is_bounded():
         assert len(cache.graphs) <= 2 and cache.evictions >= 1 and cache.captures >= 3
         assert np.isfinite(losses).all() and len(losses) == 12
     finally:
-        sgm.N0_BUCKET_SMALL = keep
+        sgm.N0_BUCKET_SMALL, sgm.SIZE_AGNOSTIC = keep, keep_agn
