@@ -57,6 +57,10 @@ SAMPLE_FILL_BUCKET = os.environ.get("OGL_SAMPLE_FILL_BUCKET", "1") != "0"    # t
 # is captured ONCE on the upper-bound block and replayed right behind its sample graph — no read-back in front of the train graph (it picked
 # the size bucket), no host in the device's critical path: the counts are read after both graphs are enqueued.
 SIZE_AGNOSTIC = os.environ.get("OGL_SIZE_AGNOSTIC", "1") != "0"
+# ... and the PIPELINED step as one graph per batch (_merged_pipelined: [own sampling] -> [train || next batch's sampling on a forked
+# branch]).  Off: measured slower than the two-graph pipelined form — pubmed-like 0.0933 -> 0.102 ms per step, same box (the fork / join
+# edges inside the graph and the upper-bound launches cost more than the hand-over and read-back they remove when sampling already hides
+# behind the previous batch's train graph).
 SIZE_AGNOSTIC_PIPE = os.environ.get("OGL_SIZE_AGNOSTIC_PIPE", "0") == "1"
 _WARMED = False
 
@@ -85,7 +89,8 @@ class TrainStepGraph:
     """One captured train step over ``buf`` restricted to (n1_pad, n0_pad) rows.
     ``loss_fn(logits, labels) -> (scalar loss to differentiate, per-seed losses or None)``."""
 
-    def __init__(self, model, optimizer, graph, buf, n1_pad, n0_pad, loss_fn, pool=None, apply=True, loss_kind=None, dp=None, sampler=None):
+    def __init__(self, model, optimizer, graph, buf, n1_pad, n0_pad, loss_fn, pool=None, apply=True, loss_kind=None, dp=None, sampler=None,
+                 side_sampler=None):
         # apply=False: forward + loss + backward only (the gradients are in ``grads``; exchange and optimiser are the caller's).
         # dp = (GradSynchronizer, weight): the WHOLE step of a data-parallel replica — forward, loss, backward, the gradient exchange
         # (RCCL all-reduces recorded into the graph: the early bucket launched from the gradient hooks on the side branch, under the
@@ -95,6 +100,9 @@ class TrainStepGraph:
         # sampler (a SampleGraph over ``buf``): its one launch is recorded at the TOP of this graph — sampling and training of a batch
         # are ONE graph launch (for a train graph that takes the block's size from the device: StepGraphCache._agnostic_graph)
         self.sampler = sampler
+        # side_sampler (a SampleGraph over the OTHER set of block arrays): the NEXT batch's sampling launch on a forked branch of this
+        # graph, beside this batch's train launches (StepGraphCache._merged_pipelined)
+        self.side_sampler = side_sampler
         # "mean" / "mean_rows": the loss is nn.CrossEntropyLoss — the model may run its last layer and the loss as one node
         # (GraphSAGE.forward_loss); None: an arbitrary loss_fn(logits, labels)
         self.loss_kind = loss_kind if hasattr(model, "forward_loss") else None
@@ -107,6 +115,12 @@ class TrainStepGraph:
     def _body(self, apply=None, learn=False):
         apply = self.apply if apply is None else apply
         g, b = self.graph, self.buf
+        side = None
+        if self.side_sampler is not None:
+            side = self._side_stream = getattr(self, "_side_stream", None) or torch.cuda.Stream(device=g.device)
+            side.wait_stream(torch.cuda.current_stream())    # fork: nothing in this graph depends on it, it on nothing in this graph
+            with torch.cuda.stream(side):
+                self.side_sampler._body()
         if self.sampler is not None:
             self.sampler._body()
         src0, src1, lidx0 = b.src0[:self.n0_pad], b.src1[:self.n1_pad], b.lidx0[:self.n1_pad]
@@ -143,6 +157,8 @@ class TrainStepGraph:
             if apply:
                 self.opt.step()
         self.loss, self.loss_rows = loss.detach(), (rows.detach() if rows is not None else None)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)    # join
 
     def _capture(self, pool):
         global _WARMED
@@ -186,10 +202,14 @@ class TrainStepGraph:
         # (True: the recorded launches take the input block's size from the device — this graph serves every batch of its shape)
         self.size_agnostic = bool(ops._SMALL_AGNOSTIC["seen"]) and self.n0_pad == self.buf.n0_cap
         self.grads = [p.grad for p in self.model.parameters()]
-        if self.sampler is not None:
-            # (the warm-up pass above ran the sampler's launch for real: its device-side sequence number moved without the host's)
-            torch.cuda.synchronize()
-            self.sampler.seq = int(self.sampler.counts_np[2])
+        for sm in (self.sampler, self.side_sampler):
+            if sm is not None:
+                # The caller has prepare()d this sampler for the replay that follows (host sequence number = device's + 1).  A warm-up
+                # pass above runs the sampler's launch for real: the device's number then moves without the host's — and a host that
+                # is one behind would see the PREVIOUS launch's publication as this one's, i.e. overwrite the mapped seed buffer
+                # before the launch that reads it has run.  Re-based on what the device holds now.
+                torch.cuda.synchronize()
+                sm.seq = int(sm.counts_np[2]) + 1
 
     def replay(self):
         """Replays the step.  ``self.loss`` / ``self.loss_rows`` / ``self.grads`` are STATIC tensors of the graph: the next replay
@@ -317,7 +337,7 @@ class StepGraphCache:
         self.captures = self.evictions = self.borrowed = self.deferred = 0
         self.sightings = {}
 
-    def _train(self, graph, buf, key, n1_pad, n0_pad, apply=True, dp=None, sampler=None):
+    def _train(self, graph, buf, key, n1_pad, n0_pad, apply=True, dp=None, sampler=None, side_sampler=None):
         sg = self.graphs.get(key)
         if sg is None:
             while len(self.graphs) >= self.MAX_GRAPHS:
@@ -327,7 +347,7 @@ class StepGraphCache:
                 del old
                 self.evictions += 1
             sg = self.graphs[key] = TrainStepGraph(self.model, self.opt, graph, buf, n1_pad, n0_pad, self.loss_fn, apply=apply,
-                                                   loss_kind=self.loss_kind, dp=dp, sampler=sampler)
+                                                   loss_kind=self.loss_kind, dp=dp, sampler=sampler, side_sampler=side_sampler)
             self.captures += 1
         else:
             self.graphs.move_to_end(key)
@@ -349,39 +369,28 @@ class StepGraphCache:
             self.bufs[bkey] = bufs
             pipe = self.samplers[bkey] = dict(smp=[SampleGraph(graph, b) for b in bufs], side=torch.cuda.Stream(device=graph.device),
                                               sampled=[None, None], trained=[None, None], cur=0, ahead=None)
+        if SIZE_AGNOSTIC and SIZE_AGNOSTIC_PIPE and self.agnostic.get(bkey) is not False:
+            sg = self._merged_pipelined(graph, pipe, bkey, seeds_host, ctr, nxt, B)
+            if sg is not None:
+                return sg
         cur = pipe["cur"]
         smp = pipe["smp"][cur]
         main = torch.cuda.current_stream()
-        # (the size-agnostic train graph is for the one-graph step of ``sampled_step``: here the sampling of batch i + 1 already hides
-        # behind batch i's train graph, and an upper-bound graph behind a separate sample graph measured slower — OGL_SIZE_AGNOSTIC_PIPE=1)
-        agn = SIZE_AGNOSTIC_PIPE and self.agnostic.get(bkey) is not False
         if pipe["ahead"] is not None and pipe["ahead"][0] == cur and pipe["ahead"][1] == int(ctr):
-            if not agn:
-                n1, n0 = smp.wait()                          # launched while the previous batch trained
+            n1, n0 = smp.wait()                              # launched while the previous batch trained
             main.wait_event(pipe["sampled"][cur])
         else:
             if pipe["ahead"] is not None:                    # (a prefetch nobody came for: let it finish before its set is reused)
                 pipe["smp"][pipe["ahead"][0]].wait()
                 main.wait_event(pipe["sampled"][pipe["ahead"][0]])
-            if agn:
-                smp.launch(seeds_host, ctr)
-            else:
-                n1, n0 = smp.run(seeds_host, ctr)
+            n1, n0 = smp.run(seeds_host, ctr)
         pipe["ahead"] = None
-        sg = None
-        if agn:
-            # the train graph of the UPPER-BOUND block right behind the sample graph: no read-back in front of it
-            sg = self._agnostic_graph(graph, smp, bkey, (bkey + ("cap", cur)))
-            if sg is None:
-                n1, n0 = smp.wait()
-        if sg is None:
-            n0_pad = min(round_up(n0, N0_BUCKET_SMALL), smp.buf.n0_cap)
-            sg = self._train(graph, smp.buf, bkey + (n0_pad, cur), smp.buf.n1_cap, n0_pad)
+        n0_pad = min(round_up(n0, N0_BUCKET_SMALL), smp.buf.n0_cap)
+        sg = self._train(graph, smp.buf, bkey + (n0_pad, cur), smp.buf.n1_cap, n0_pad)
         sg.replay()
         ev = pipe["trained"][cur] = torch.cuda.Event()
         ev.record()
-        if not (agn and sg.size_agnostic):
-            sg.last_sizes = (n0, n1)
+        sg.last_sizes = (n0, n1)
         other = 1 - cur
         if nxt is not None and len(nxt[0]) == B:
             side = pipe["side"]
@@ -392,9 +401,46 @@ class StepGraphCache:
             es.record(side)
             pipe["ahead"] = (other, int(nxt[1]))
         pipe["cur"] = other
-        if agn and sg.size_agnostic:
-            n1, n0 = smp.wait()                              # (after everything is enqueued: the device never waits for this)
-            sg.last_sizes = (n0, n1)
+        return sg
+
+    def _merged_pipelined(self, graph, pipe, bkey, seeds_host, ctr, nxt, B):
+        """The pipelined step as ONE graph launch per batch, for train graphs that take the block's size from the device (the upper-bound
+        block: ``_agnostic_graph``): batch i's graph holds [its own sampling launch unless the previous graph prefetched it] -> [its train
+        launches || the sampling launch of batch i + 1 on a forked branch, into the OTHER set of block arrays].  Four variants per set
+        (own sampling yes / no x prefetch yes / no), captured on first use; the graphs run back to back on one stream, so a set is never
+        written while a train graph reads it.  No count read-back in front of any launch: the counts are read after the enqueue.
+        Returns None when the model's launches are not size-agnostic (the caller falls back to the bucketed two-graph form)."""
+        cur = pipe["cur"]
+        other = 1 - cur
+        smp, smp_o = pipe["smp"][cur], pipe["smp"][other]
+        ahead = pipe["ahead"]
+        have = ahead is not None and ahead[0] == cur and ahead[1] == int(ctr)
+        if ahead is not None and not have:                   # (a prefetch nobody came for: its sequence number must be seen first)
+            pipe["smp"][ahead[0]].wait()
+        want = nxt is not None and len(nxt[0]) == B
+        if not have:
+            smp.prepare(seeds_host, ctr)
+        if want:
+            smp_o.prepare(nxt[0], nxt[1])
+        key = bkey + ("cap", "merged", cur, not have, want)
+        known = self.agnostic.get(bkey)
+        sg = self._train(graph, smp.buf, key, smp.buf.n1_cap, smp.buf.n0_cap, sampler=None if have else smp, side_sampler=smp_o if want else None)
+        if known is None:
+            if not sg.size_agnostic:
+                # not size-agnostic: forget the graph, put the samplers' bookkeeping back in step with the device, sample the old way
+                self.agnostic[bkey] = False
+                self.graphs.pop(key, None)
+                torch.cuda.synchronize()
+                for sm in pipe["smp"]:
+                    sm.seq = int(sm.counts_np[2])
+                pipe["ahead"] = None
+                return None
+            self.agnostic[bkey] = True
+        sg.replay()
+        pipe["ahead"] = (other, int(nxt[1])) if want else None
+        pipe["cur"] = other
+        n1, n0 = smp.wait()                                  # (after the step is enqueued: the device never waits for this)
+        sg.last_sizes = (n0, n1)
         return sg
 
     def sampled_step(self, graph, seeds_host, ctr):
