@@ -7,6 +7,7 @@
 // id's minimum are "first appearances"; a 3-phase exclusive scan of those flags gives the local
 // index.  Integer/HBM-bound work, no MFMA.
 #include "ogl_common.h"
+#include <cstdlib>
 #include <algorithm>
 
 #define BLK_SCAN 1024
@@ -732,6 +733,7 @@ struct SmallSampleArgs {
   int64_t* counts;                        // device [2]: n1, n0
   int64_t* seq_dev; volatile int64_t* counts_host;   // host-mapped [3]: n1, n0, sequence number (ogl_publish_i64's protocol)
   int64_t fill0;                          // 0: src0 is padded with -1 up to its capacity; m > 0: up to round_up(n0, m) only
+  int reg_build;                          // 1: the relabelling with its positions in registers where it applies (wg_build_reg)
 };
 
 // one layer's picks for rows [0, n_live) of dst (one thread per (row, 4 slots): k_sample_layer_dev's arithmetic)
@@ -855,12 +857,115 @@ __device__ __forceinline__ int wg_build_t(const SmallSampleArgs& a, const int64_
   return n_src;
 }
 
+// The same relabelling with every position in REGISTERS (LDS table, at most SS_KMAX positions per thread: every block of the 32-seed rungs):
+// thread t owns the CONTIGUOUS positions [t K, (t + 1) K), K = ceil(Q / 1024) — so ONE block scan of the per-thread counts orders all
+// first appearances (the chunked form above scans once per 1 024 positions, and because later chunks still compare positions against the
+// table's minima it parks local ids in the global `slot` array and re-probes the table in a second pass: 2 writes + 3 reads of global
+// memory per position and ceil(Q / 1024) x 4 barriers).  Here a position's id and table slot never leave registers, the minima are
+// overwritten by the local ids right after the one scan (its barriers separate the last read of a minimum from the first write), and the
+// index rows are written from the registers.  Same order, same arrays, bit for bit (tests/test_gpu_round5.py, test_gpu_graphs.py).
+#define SS_KMAX 11
+__device__ __forceinline__ int block_scan_counts_1024(int v, int* total) {
+  __shared__ int wsum2[16];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) wsum2[wid] = x;
+  __syncthreads();
+  int woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const int sv = wsum2[w];
+    if (w < wid) woff += sv;
+    tot += sv;
+  }
+  *total = tot;
+  __syncthreads();
+  return x - v + woff;
+}
+
+__device__ __forceinline__ int wg_build_reg(const SmallSampleArgs& a, const int64_t* __restrict__ dst, int64_t n_dst, int64_t n_live,
+                                            const int64_t* __restrict__ picks, int64_t* __restrict__ src_ids, int64_t src_cap,
+                                            int32_t* __restrict__ local_idx, int32_t* lkey, int32_t* lmin, int64_t T, int64_t fill_mult) {
+  const int tid = threadIdx.x;
+  const int Q = (int)(n_dst + n_live * a.S);
+  const int K = (Q + BLK_SCAN - 1) / BLK_SCAN;               // <= SS_KMAX (the caller checks)
+  const int q0 = tid * K;
+  int logT = 0;
+  while (((int64_t)1 << logT) < T) ++logT;
+  const uint32_t mask = (uint32_t)(T - 1);
+  const int shift = 32 - logT;
+  for (int64_t i = tid; i < T; i += BLK_SCAN) { lkey[i] = -1; lmin[i] = 0x7F7F7F7F; }
+  int64_t id[SS_KMAX];
+  int sl[SS_KMAX];
+#pragma unroll
+  for (int r = 0; r < SS_KMAX; ++r) {
+    const int q = q0 + r;
+    id[r] = (r < K && q < Q) ? (q < n_dst ? dst[q] : picks[q - n_dst]) : -1;
+    sl[r] = -1;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < SS_KMAX; ++r) {
+    if (r < K && id[r] >= 0) {
+      const int32_t v = (int32_t)id[r];
+      uint32_t h = ((uint32_t)v * 0x9E3779B1u) >> shift;
+      for (uint32_t probe = 0; probe <= mask; ++probe) {
+        const int32_t old = atomicCAS(&lkey[h], -1, v);
+        if (old == -1 || old == v) { atomicMin(&lmin[h], (int32_t)(q0 + r)); sl[r] = (int)h; break; }
+        h = (h + 1) & mask;
+      }
+    }
+  }
+  __syncthreads();
+  unsigned fl = 0, ow = 0;
+  int cnt = 0;
+#pragma unroll
+  for (int r = 0; r < SS_KMAX; ++r) {
+    const int q = q0 + r;
+    const bool valid = r < K && q < Q;
+    const bool own = valid && sl[r] >= 0 && lmin[sl[r]] == q;
+    const bool f = valid && (q < n_dst || own);
+    fl |= (f ? 1u : 0u) << r;
+    ow |= (own ? 1u : 0u) << r;
+    cnt += f ? 1 : 0;
+  }
+  int tot;
+  int li = block_scan_counts_1024(cnt, &tot);               // (its barriers: every read of a minimum above, before any write below)
+#pragma unroll
+  for (int r = 0; r < SS_KMAX; ++r) {
+    if ((fl >> r) & 1u) {
+      src_ids[li] = id[r];                                   // (a padded destination keeps its row in the source list: id -1)
+      if ((ow >> r) & 1u) lmin[sl[r]] = li;                  // the table's minimum becomes the local id of its key
+      ++li;
+    }
+  }
+  const int n_src = tot;
+  const int64_t fill_end = fill_mult > 0 ? min(src_cap, ((int64_t)n_src + fill_mult - 1) / fill_mult * fill_mult) : src_cap;
+  for (int64_t i = n_src + tid; i < fill_end; i += BLK_SCAN) src_ids[i] = -1;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < SS_KMAX; ++r) {
+    const int q = q0 + r;
+    if (r < K && q < Q && q >= n_dst) local_idx[q - n_dst] = sl[r] >= 0 ? lmin[sl[r]] : -1;
+  }
+  for (int64_t e = n_live * a.S + tid; e < n_dst * a.S; e += BLK_SCAN) local_idx[e] = -1;     // the padded destinations' rows
+  __syncthreads();
+  return n_src;
+}
+
 __device__ __forceinline__ int wg_build(const SmallSampleArgs& a, const int64_t* __restrict__ dst, int64_t n_dst, int64_t n_live,
                                         const int64_t* __restrict__ picks, int64_t* __restrict__ src_ids, int64_t src_cap,
                                         int32_t* __restrict__ local_idx, int* carry_s, int32_t* lkey, int32_t* lmin, int64_t fill_mult = 0) {
   const int64_t Q = n_dst + n_live * a.S;
   int64_t T = 1024;
   while (2 * T < 3 * Q && T < a.T_max) T <<= 1;            // load factor <= 2/3
+  if (T <= SS_LDS_T && Q <= (int64_t)SS_KMAX * BLK_SCAN && a.reg_build)
+    return wg_build_reg(a, dst, n_dst, n_live, picks, src_ids, src_cap, local_idx, lkey, lmin, T, fill_mult);
   if (T <= SS_LDS_T) return wg_build_t<true>(a, dst, n_dst, n_live, picks, src_ids, src_cap, local_idx, carry_s, lkey, lmin, T, fill_mult);
   while (T < 2 * Q && T < a.T_max) T <<= 1;
   return wg_build_t<false>(a, dst, n_dst, n_live, picks, src_ids, src_cap, local_idx, carry_s, lkey, lmin, T, fill_mult);
@@ -939,6 +1044,8 @@ extern "C" int ogl_sample_blocks_small_fill(const ogl_graph_t* g, const int64_t*
   a.src1 = src1; a.lidx1 = lidx1; a.src0 = src0; a.lidx0 = lidx0;
   a.counts = counts; a.seq_dev = seq_dev; a.counts_host = (volatile int64_t*)counts_host_mapped;
   a.fill0 = src0_fill_multiple;
+  static const bool reg_off = getenv("OGL_SAMPLE_REG_BUILD") && getenv("OGL_SAMPLE_REG_BUILD")[0] == '0';
+  a.reg_build = reg_off ? 0 : 1;
   hipLaunchKernelGGL(k_sample_blocks_small, dim3(1), dim3(BLK_SCAN), 0, (hipStream_t)stream, a);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
