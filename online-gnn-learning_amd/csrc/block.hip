@@ -736,29 +736,57 @@ struct SmallSampleArgs {
   int reg_build;                          // 1: the relabelling with its positions in registers where it applies (wg_build_reg)
 };
 
-// one layer's picks for rows [0, n_live) of dst (one thread per (row, 4 slots): k_sample_layer_dev's arithmetic)
+// one layer's picks for rows [0, n_live) of dst (one thread per (row, 4 slots): k_sample_layer_dev's arithmetic).  TWO items per
+// thread and trip, their loads issued together: an item is a chain of two dependent cold loads (degree / row offset, then the picked
+// neighbours), and the input block of a 32-seed batch has more items than the workgroup has threads (228 live rows x 7 quads = 1 596):
+// walked one per trip that is two chains in a row.
 __device__ __forceinline__ void wg_sample(const SmallSampleArgs& a, const int64_t* __restrict__ dst, int64_t n_live, uint64_t ctr,
                                           uint32_t layer_bits, int64_t* __restrict__ picks) {
   const int quads = (a.S + 3) / 4;
-  for (int64_t t = threadIdx.x; t < n_live * quads; t += BLK_SCAN) {
-    const int64_t i = t / quads;
-    const int q = (int)(t - i * quads);
-    const int64_t d = dst[i];
-    uint32_t deg = 0;
-    int64_t base = 0;
-    if (d >= 0 && d < a.n) { deg = (uint32_t)a.deg[d]; base = a.indptr[d]; }
-    const int j0 = q * 4, cnt = min(4, a.S - j0);
-    int64_t* out = picks + i * a.S + j0;
-    if (deg == 0) {
-      for (int j = 0; j < cnt; ++j) out[j] = -1;
-      continue;
-    }
-    const philox4 r = philox4x32_10((uint32_t)q | layer_bits, (uint32_t)((uint64_t)d & 0xFFFFFFFFu), (uint32_t)((uint64_t)d >> 32),
-                                    (uint32_t)(ctr & 0xFFFFFFFFu), a.seed_lo, a.seed_hi ^ (uint32_t)(ctr >> 32));
-    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+  const int64_t total = n_live * quads;
+  for (int64_t t0 = threadIdx.x; t0 < total; t0 += 2 * BLK_SCAN) {
+    int64_t ti[2], d[2], base[2];
+    uint32_t deg[2];
+    int q[2];
+    bool on[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (j < cnt) out[j] = (int64_t)a.indices[base + (uint32_t)(((uint64_t)w[j] * (uint64_t)deg) >> 32)];
+    for (int u = 0; u < 2; ++u) {
+      const int64_t t = t0 + (int64_t)u * BLK_SCAN;
+      on[u] = t < total;
+      ti[u] = on[u] ? t / quads : 0;
+      q[u] = on[u] ? (int)(t - ti[u] * quads) : 0;
+      d[u] = on[u] ? dst[ti[u]] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      deg[u] = 0; base[u] = 0;
+      if (on[u] && d[u] >= 0 && d[u] < a.n) { deg[u] = (uint32_t)a.deg[d[u]]; base[u] = a.indptr[d[u]]; }
+    }
+    int64_t pk[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j0 = q[u] * 4, cnt = min(4, a.S - j0);
+      if (on[u] && deg[u] != 0) {
+        const philox4 r = philox4x32_10((uint32_t)q[u] | layer_bits, (uint32_t)((uint64_t)d[u] & 0xFFFFFFFFu), (uint32_t)((uint64_t)d[u] >> 32),
+                                        (uint32_t)(ctr & 0xFFFFFFFFu), a.seed_lo, a.seed_hi ^ (uint32_t)(ctr >> 32));
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          pk[u][j] = j < cnt ? (int64_t)a.indices[base[u] + (uint32_t)(((uint64_t)w[j] * (uint64_t)deg[u]) >> 32)] : -1;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk[u][j] = -1;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!on[u]) continue;
+      const int j0 = q[u] * 4, cnt = min(4, a.S - j0);
+      int64_t* out = picks + ti[u] * a.S + j0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < cnt) out[j] = pk[u][j];
+    }
   }
 }
 
