@@ -62,6 +62,9 @@ SIZE_AGNOSTIC = os.environ.get("OGL_SIZE_AGNOSTIC", "1") != "0"
 # edges inside the graph and the upper-bound launches cost more than the hand-over and read-back they remove when sampling already hides
 # behind the previous batch's train graph).
 SIZE_AGNOSTIC_PIPE = os.environ.get("OGL_SIZE_AGNOSTIC_PIPE", "0") == "1"
+# ... or: the pipelined step with its two graphs kept apart (batch i + 1 sampled by its own sample graph on the side stream while batch i
+# trains) but the TRAIN graph size-agnostic, replayed without waiting for the counts
+SIZE_AGNOSTIC_PIPE2 = os.environ.get("OGL_SIZE_AGNOSTIC_PIPE", "0") == "2"
 _WARMED = False
 
 
@@ -376,21 +379,34 @@ class StepGraphCache:
         cur = pipe["cur"]
         smp = pipe["smp"][cur]
         main = torch.cuda.current_stream()
+        agn = SIZE_AGNOSTIC and SIZE_AGNOSTIC_PIPE2 and self.agnostic.get(bkey) is not False
         if pipe["ahead"] is not None and pipe["ahead"][0] == cur and pipe["ahead"][1] == int(ctr):
-            n1, n0 = smp.wait()                              # launched while the previous batch trained
+            if not agn:
+                n1, n0 = smp.wait()                          # launched while the previous batch trained
             main.wait_event(pipe["sampled"][cur])
         else:
             if pipe["ahead"] is not None:                    # (a prefetch nobody came for: let it finish before its set is reused)
                 pipe["smp"][pipe["ahead"][0]].wait()
                 main.wait_event(pipe["sampled"][pipe["ahead"][0]])
-            n1, n0 = smp.run(seeds_host, ctr)
+            if agn:
+                smp.launch(seeds_host, ctr)
+            else:
+                n1, n0 = smp.run(seeds_host, ctr)
         pipe["ahead"] = None
-        n0_pad = min(round_up(n0, N0_BUCKET_SMALL), smp.buf.n0_cap)
-        sg = self._train(graph, smp.buf, bkey + (n0_pad, cur), smp.buf.n1_cap, n0_pad)
+        sg = None
+        if agn:
+            sg = self._agnostic_graph(graph, smp, bkey, bkey + ("cap", cur))
+            if sg is None:
+                n1, n0 = smp.wait()
+        late = sg is not None
+        if sg is None:
+            n0_pad = min(round_up(n0, N0_BUCKET_SMALL), smp.buf.n0_cap)
+            sg = self._train(graph, smp.buf, bkey + (n0_pad, cur), smp.buf.n1_cap, n0_pad)
         sg.replay()
         ev = pipe["trained"][cur] = torch.cuda.Event()
         ev.record()
-        sg.last_sizes = (n0, n1)
+        if not late:
+            sg.last_sizes = (n0, n1)
         other = 1 - cur
         if nxt is not None and len(nxt[0]) == B:
             side = pipe["side"]
@@ -401,6 +417,9 @@ class StepGraphCache:
             es.record(side)
             pipe["ahead"] = (other, int(nxt[1]))
         pipe["cur"] = other
+        if late:
+            n1, n0 = smp.wait()                              # (after everything is enqueued: the device never waits for this)
+            sg.last_sizes = (n0, n1)
         return sg
 
     def _merged_pipelined(self, graph, pipe, bkey, seeds_host, ctr, nxt, B):
