@@ -65,6 +65,9 @@ SIZE_AGNOSTIC_PIPE = os.environ.get("OGL_SIZE_AGNOSTIC_PIPE", "0") == "1"
 # ... or: the pipelined step with its two graphs kept apart (batch i + 1 sampled by its own sample graph on the side stream while batch i
 # trains) but the TRAIN graph size-agnostic, replayed without waiting for the counts
 SIZE_AGNOSTIC_PIPE2 = os.environ.get("OGL_SIZE_AGNOSTIC_PIPE", "0") == "2"
+# ... or (3): only the FIRST batch of a snapshot — the one whose sampling nothing hides — as the one-graph step of ``sampled_step`` (on this
+# pipeline's block arrays), the following batches pipelined and bucketed as before
+SIZE_AGNOSTIC_PIPE3 = os.environ.get("OGL_SIZE_AGNOSTIC_PIPE", "0") == "3"
 _WARMED = False
 
 
@@ -380,6 +383,36 @@ class StepGraphCache:
         smp = pipe["smp"][cur]
         main = torch.cuda.current_stream()
         agn = SIZE_AGNOSTIC and SIZE_AGNOSTIC_PIPE2 and self.agnostic.get(bkey) is not False
+        first_merged = (SIZE_AGNOSTIC and SIZE_AGNOSTIC_PIPE3 and self.agnostic.get(bkey) is not False
+                        and not (pipe["ahead"] is not None and pipe["ahead"][0] == cur and pipe["ahead"][1] == int(ctr)))
+        if first_merged:
+            if pipe["ahead"] is not None:
+                pipe["smp"][pipe["ahead"][0]].wait()
+                main.wait_event(pipe["sampled"][pipe["ahead"][0]])
+                pipe["ahead"] = None
+            smp.prepare(seeds_host, ctr)
+            sgm = self._agnostic_graph(graph, smp, bkey, bkey + ("cap", "merged", cur), merged=True)
+            if sgm is None:
+                torch.cuda.synchronize()
+                smp.seq = int(smp.counts_np[2])
+                first_merged = False
+        if first_merged:
+            sgm.replay()
+            ev = pipe["trained"][cur] = torch.cuda.Event()
+            ev.record()
+            other = 1 - cur
+            if nxt is not None and len(nxt[0]) == B:
+                side = pipe["side"]
+                if pipe["trained"][other] is not None:
+                    side.wait_event(pipe["trained"][other])
+                pipe["smp"][other].launch(nxt[0], nxt[1], stream=side)
+                es = pipe["sampled"][other] = torch.cuda.Event()
+                es.record(side)
+                pipe["ahead"] = (other, int(nxt[1]))
+            pipe["cur"] = other
+            n1, n0 = smp.wait()
+            sgm.last_sizes = (n0, n1)
+            return sgm
         if pipe["ahead"] is not None and pipe["ahead"][0] == cur and pipe["ahead"][1] == int(ctr):
             if not agn:
                 n1, n0 = smp.wait()                          # launched while the previous batch trained
