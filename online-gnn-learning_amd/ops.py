@@ -3174,16 +3174,14 @@ class _SmallFirstLayerFn(torch.autograd.Function):
             route = None
         if route is not None:                                  # (nothing of this layer's to sum: the handed-over groups alone)
             _record_launch(False, None, None, None, n_dst, F, H, x, ids, n_src, neigh, None, None, None, None, None, None, route)
-        if rec:
-            pass
-        elif need_pool and ctx.x3_path:
+        if need_pool and not rec and ctx.x3_path:
             import types
             shim = types.SimpleNamespace(saved_tensors=(x, w_pool, ids, neigh, argmax, idx), needs_input_grad=(False, need[2], need[3], False, False),
                                          n_src=n_src, fanout=ctx.fanout, has_bias=ctx.has_pool_bias, pool_plan=ctx.pool_plan, dp_slot=None,
                                          bias_t=ctx.bias_t)
             ctx.pool_plan = None
             _, dwp, dbp, _, _ = _PoolMaxFn.backward(shim, dneigh)
-        elif need_pool:
+        elif need_pool and not rec:
             dwp, dbp = weight_grad(dP, x, ids, want_bias=ctx.has_pool_bias, dw_out=_dw_out(w_pool, *w_pool.shape))
         return (None, None, dwp, dbp if ctx.has_pool_bias else None, dws, dwn, db if ctx.has_bias else None,
                 db2 if ctx.has_bias else None, None, None, None, None, None)
