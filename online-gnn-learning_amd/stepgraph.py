@@ -56,6 +56,10 @@ SAMPLE_FILL_BUCKET = os.environ.get("OGL_SAMPLE_FILL_BUCKET", "1") != "0"    # t
 # A sampled step whose launches take their sizes from the DEVICE (the small first layer on the sample graph's own counts: ops._SMALL_AGNOSTIC)
 # is captured ONCE on the upper-bound block and replayed right behind its sample graph — no read-back in front of the train graph (it picked
 # the size bucket), no host in the device's critical path: the counts are read after both graphs are enqueued.
+# pipelined steps: the next batch's sample graph enqueued BEFORE this batch's train graph.  Off: measured, pubmed-like rung, same box:
+# 0.0923 -> 0.1046 ms per step — the ~35 us the host needs to enqueue the side stream's sample graph then sit in front of the train
+# graph, which is the critical path
+PREFETCH_FIRST = os.environ.get("OGL_PREFETCH_FIRST", "0") == "1"
 SIZE_AGNOSTIC = os.environ.get("OGL_SIZE_AGNOSTIC", "1") != "0"
 # ... and the PIPELINED step as one graph per batch (_merged_pipelined: [own sampling] -> [train || next batch's sampling on a forked
 # branch]).  Off: measured slower than the two-graph pipelined form — pubmed-like 0.0933 -> 0.102 ms per step, same box (the fork / join
@@ -435,20 +439,28 @@ class StepGraphCache:
         if sg is None:
             n0_pad = min(round_up(n0, N0_BUCKET_SMALL), smp.buf.n0_cap)
             sg = self._train(graph, smp.buf, bkey + (n0_pad, cur), smp.buf.n1_cap, n0_pad)
+        other = 1 - cur
+
+        def prefetch():
+            if nxt is not None and len(nxt[0]) == B:
+                side = pipe["side"]
+                if pipe["trained"][other] is not None:
+                    side.wait_event(pipe["trained"][other])  # the train graph that read set `other` has finished
+                pipe["smp"][other].launch(nxt[0], nxt[1], stream=side)
+                es = pipe["sampled"][other] = torch.cuda.Event()
+                es.record(side)
+                pipe["ahead"] = (other, int(nxt[1]))
+        # (PREFETCH_FIRST: the next batch's sample graph enqueued before this batch's train graph — it depends on nothing this batch
+        # does — so that its counts reach the host while this batch still trains; an experiment, slower: see the switch)
+        if PREFETCH_FIRST:
+            prefetch()
         sg.replay()
         ev = pipe["trained"][cur] = torch.cuda.Event()
         ev.record()
         if not late:
             sg.last_sizes = (n0, n1)
-        other = 1 - cur
-        if nxt is not None and len(nxt[0]) == B:
-            side = pipe["side"]
-            if pipe["trained"][other] is not None:
-                side.wait_event(pipe["trained"][other])      # the train graph that read set `other` has finished
-            pipe["smp"][other].launch(nxt[0], nxt[1], stream=side)
-            es = pipe["sampled"][other] = torch.cuda.Event()
-            es.record(side)
-            pipe["ahead"] = (other, int(nxt[1]))
+        if not PREFETCH_FIRST:
+            prefetch()
         pipe["cur"] = other
         if late:
             n1, n0 = smp.wait()                              # (after everything is enqueued: the device never waits for this)
