@@ -247,6 +247,7 @@ class SampleGraph:
         self.sync_fallbacks = 0
         assert buf.n1_cap == buf.B * (1 + buf.S) and buf.n0_cap == buf.n1_cap * (1 + buf.S)
         self.head_host = torch.zeros(1 + buf.B, dtype=torch.int64).pin_memory()
+        self.head_np = self.head_host.numpy()                # (written through numpy: a torch tensor per step costs the host ~10 us)
         self.counts = torch.zeros(2, dtype=torch.int64, device=graph.device)
         buf.counts = self.counts
         # [n1, n0, sequence number]: pinned host memory the LAST kernel of the graph writes directly (ogl_publish_i64)
@@ -290,17 +291,17 @@ class SampleGraph:
     def prepare(self, seeds_host, ctr):
         """[counter | seeds] into the mapped host buffer the sampling launch reads — for a caller that replays a graph which CONTAINS
         that launch (TrainStepGraph(sampler=...)); ``wait()`` afterwards as after ``launch``."""
-        h = self.head_host
+        h = self.head_np
         h[0] = int(ctr)
-        h[1:] = torch.as_tensor(np.asarray(seeds_host), dtype=torch.int64)     # (not touched again until the graph's last store is seen)
+        h[1:] = seeds_host                                   # (not touched again until the graph's last store is seen)
         self._stream = None
         self.seq += 1
 
     def launch(self, seeds_host, ctr, stream=None):
         """Enqueue the sample graph (on ``stream``: the pipelined steps run it beside the previous batch's train graph)."""
-        h = self.head_host
+        h = self.head_np
         h[0] = int(ctr)
-        h[1:] = torch.as_tensor(np.asarray(seeds_host), dtype=torch.int64)     # (not touched again until the graph's last store is seen)
+        h[1:] = seeds_host                                   # (not touched again until the graph's last store is seen)
         if stream is None:
             self.cuda_graph.replay()
         else:
