@@ -41,6 +41,19 @@ def test_argument_validation_without_gpu():
     assert h.ogl_linear_fwd(None, 2, None, 0, 4, 8, None, 8, 4, None, None, 0, None, 0, 0, None, 0, 0, None, 4, None) == -1
     assert h.ogl_adam_step(None, None, None, None, 10, 0, 1e-3, 0.9, 0.999, 1e-8, None) == -1   # step < 1
     assert h.ogl_linear_bwd_weight_workspace_bytes(233000, 602, 602) > 0
+    # round 5, the 32-seed kernels: shape gates and argument checks answer before anything is launched
+    assert h.ogl_small_pool_loss_fits(832, 32, 25, 32, 40) == 1 and h.ogl_small_pool_loss_fits(832, 32, 65, 32, 40) == 0
+    assert h.ogl_small_pool_loss_fits(4000, 200, 25, 32, 40) == 0                       # more than 128 destinations
+    assert h.ogl_small_first_layer_fits(21632, 832, 25, 500, 32) == 1 and h.ogl_small_first_layer_fits(21632, 832, 25, 500, 33) == 0
+    assert h.ogl_small_first_layer_fits(21632, 832, 25, 1028, 32) == 0
+    assert h.ogl_record_weight_grads(None, 1, None, 0, None, None, None, 0.0, 0.0, 0.0, None) == -1
+    seg = _lib.RecSeg()                                                                    # (all NULL: rejected, not dereferenced)
+    assert h.ogl_record_weight_grads(ctypes.addressof(seg), 1, None, 0, None, None, None, 0.0, 0.0, 0.0, None) == -1
+    assert h.ogl_record_weight_grads(ctypes.addressof(seg), 7, None, 0, None, None, None, 0.0, 0.0, 0.0, None) == -1
+    assert h.ogl_small_proj_rows(None, 512, None, 10, 64, 500, None, 500, 500, None, 1, None, 512, None, None) == -1
+    assert h.ogl_small_proj_rows(None, 512, None, 10, 0, 500, None, 500, 500, None, 1, None, 512, None, None) == 0    # no rows: nothing to do
+    assert h.ogl_small_proj_rows(None, 512, None, 10, 64, 502, None, 502, 500, None, 1, None, 512, None, None) == -1  # K % 4
+    assert h.ogl_sample_blocks_small_fill(None, None, None, 32, 25, 1, None, None, None, None, None, None, None, None, 0, 256, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
