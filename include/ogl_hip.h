@@ -336,6 +336,11 @@ int ogl_x3_debug_stamps(void* buf, int reserved);
  * buffer to the movers as soon as the multipliers hold it in registers) / in the one-barrier form; -1 = OGL_X3_EARLY_A (default on).
  * Both forms compute the same bits.  Returns the old value. */
 int ogl_x3_debug_early_a(int on);
+/* 1 / 0 = the producer / consumer image GEMM with STAGGERED multiplier waves (waves 4-7 run the last column block of every step but a
+ * tile's last one behind the next step's opening barrier, on fragments kept in registers: the matrix pipe has work while its SIMD
+ * partner's fragments arrive) / with every wave opening a step on its fragment loads; -1 = OGL_X3_STAGGER (default on).  Every
+ * accumulator sees its reduction steps in the same order either way: the same bits.  Returns the old value. */
+int ogl_x3_debug_stagger(int on);
 /* Diagnostics (A/B of tile shapes inside one process, tests): cfg >= 0 pins the tile of the plain / EXT one-split row-major image
  * products — 0: 256 x 128, 1: 128 x 128, 2: 192 x 128, 3: 160 x 128, 4: 256 x 160 (plain only; EXT falls back to 0) — and -1
  * returns to the automatic choice.  Every tile computes every output element with the same sequence of MFMAs: results are

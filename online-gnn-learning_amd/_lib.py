@@ -77,6 +77,7 @@ SIGNATURES = {
     "ogl_x3_split_t": (_i, [_p, _i64, _p, _i64, _i64, _i, _i, _i64, _p, _p]),
     "ogl_x3_debug_stamps": (_i, [_p, _i]),
     "ogl_x3_debug_early_a": (_i, [_i]),
+    "ogl_x3_debug_stagger": (_i, [_i]),
     "ogl_x3_debug_bwwk_uneven": (_i, [_i]),
     "ogl_x3_debug_tile": (_i, [_i]),
     "ogl_x3_last_kernel": (C.c_char_p, []),

@@ -91,6 +91,7 @@ struct X3Args {
   // of 256 CUs idle) clear zero_buf[0 .. zero_n16) 16-byte words — launch_x3 takes it only when such blocks exist, else fills first ----
   uint4* zero_buf; int64_t zero_n16;
   int bd_dbg;                   // k_gemm_x3bd, timing experiments only (OGL_X3_BD_DBG; wrong results): 1 = no B loads, 2 = no A DMA
+  int stagger;                  // k_gemm_x3p: multiplier waves 4-7 run a step's LAST column block behind the next step's opening barrier
 };
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) — indices into register arrays stay constants
@@ -106,6 +107,19 @@ __device__ float4 g_x3_trash[64];   // where epilogue lanes with nothing to stor
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Diagnostic build only (-DOGL_X3_PHASE_STAMPS, tools/x3_phase_probe.py; never in the product library): where a step of
+// k_gemm_x3p goes.  A wave-uniform cycle stamp (s_memtime, waited for in place: the stamps sit where the wave has no LDS read in
+// flight) at the arrival at / release from each of a step's barriers; per-phase SUMS over the block's steps stay in scalar registers
+// and waves 0, 4 (the two multipliers of one SIMD) and 8 (a mover) write them once, behind the block's last step, to
+// stamps[1024 + 32 blockIdx + 8 role ..].
+#ifdef OGL_X3_PHASE_STAMPS
+#define X3_PH_T(var) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); var = t_; } while (0)
+#define X3_PH(...) __VA_ARGS__
+#else
+#define X3_PH_T(var)
+#define X3_PH(...)
+#endif
 
 // TM, TN: the wave tile in units of 32 rows / columns; SPREAD: the next stage's DMA pieces go out between the MFMA groups
 // of the first half of a step instead of in one burst at its top.
@@ -703,18 +717,27 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
       // (column block 3's fragments requested ahead of it, so that it returns the whole buffer and all of stage n + 2 is issued there,
       // same two barriers per step): 0.955 -> 1.106 ms per train step.)
       int ia = 0, ib = 0;
+      X3_PH(unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0;)
       for (int n = -1; n < total; ++n) {
+        X3_PH_T(m0);
         if (n >= 0) barrier();                             // opens step n
+        X3_PH_T(m1);
         if (ib < total) { fetch(ib, no_t(), yes_t()); ++ib; }
+        X3_PH_T(m2);
         if (n >= 0) barrier();                             // mid: the A part of step n's buffer is free
+        X3_PH_T(m3);
         bool young = false;
         for (int r = (n < 0 ? 0 : 1); r < 2; ++r) {
           young = false;
           if (ia < total) { fetch(ia, yes_t(), no_t()); ++ia; young = true; }
         }
+        X3_PH_T(m4);
         if (young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLP_A) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        X3_PH_T(m5);
+        X3_PH(if (n >= 0) { ph[0] += m1 - m0; ph[1] += m2 - m1; ph[2] += m3 - m2; ph[3] += m4 - m3; ph[4] += m5 - m4; ph[5] += 1; })
       }
+      X3_PH(if (g.stamps && wid == 8 && lane == 0) for (int i = 0; i < 6; ++i) g.stamps[1024 + 32 * blockIdx.x + 16 + i] = ph[i];)
     } else {
     int issued = 0;
     for (; issued < NSTAGE - 1 && issued < total; ++issued) fetch(issued, yes_t(), yes_t());
@@ -778,9 +801,25 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
     // (EA: `mid` = the step's second barrier, met by every wave of the block — ONE call site, behind the first column block's MFMAs,
     // which have consumed every A fragment of the step: all of them are in registers and the A part of this stage buffer goes back
     // to the movers.  A second call site on the early-return path cost 40-80 spilled registers.)
-    auto compute = [&](int buf, int rbv, int cbv) __attribute__((always_inline)) {
+    X3_PH(unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0;)
+    // STAGGER (g.stagger; measured with the phase stamps of tools/x3_phase_probe.py): the two multiplier waves of a SIMD (w, w + 4) open a
+    // step together — both request their fragments behind the barrier and the matrix pipe idles for an LDS round trip (~370 of a 256 x
+    // 128 x 32 step's ~4 500 cycles) before either can issue.  Waves 4-7 therefore keep the LAST column block of every step but a
+    // tile's last one for AFTER the next step's opening barrier: its operands (all A fragments, ring slot 1 of B) stay in registers
+    // across the barrier, its MFMAs fill the pipe while the partner's fragments arrive, and the wave requests its own A fragments
+    // row block by row block as those MFMAs release the registers.  Every accumulator still sees its steps in order: same bits.
+    constexpr bool STAG_OK = (CB % 2) == 0;                   // (the deferred block reads ring slot 1; slot 0 takes the new step's first block)
+    const bool late = STAG_OK && g.stagger && wid >= 4;
+    bf16x8 a[RB][3], b[2][3];
+#pragma unroll
+    for (int t = 0; t < RB; ++t)
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp) a[t][sp] = bf16x8{};
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) { b[0][sp] = bf16x8{}; b[1][sp] = bf16x8{}; }
+    auto compute = [&](int buf, int rbv, int cbv, bool pend, bool defer) __attribute__((always_inline)) {
       const unsigned char* st = smem + buf * STAGE;
-      bf16x8 a[RB][3], b[2][3];
+      constexpr int YL = CB - 1;                              // the column block a late wave defers (ring slot YL & 1 = 1)
       const bool work = rbv > 0 && cbv > 0;
       if (!EA && !work) return;
       {                                                       // (no branch around the loads: a control-flow join in front of the first
@@ -796,6 +835,17 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         // any matrix instruction issues)
 #pragma unroll
         for (int t = 0; t < RB; ++t) {
+          if constexpr (STAG_OK) {
+            // the previous step's deferred column block, row block t, on the fragments still in registers — then their reload
+            if (pend && work && t < rbv && YL < cbv) {
+              acc[t][YL] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1][2], a[t][0], acc[t][YL], 0, 0, 0);
+              acc[t][YL] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1][1], a[t][1], acc[t][YL], 0, 0, 0);
+              acc[t][YL] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1][0], a[t][2], acc[t][YL], 0, 0, 0);
+              acc[t][YL] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1][1], a[t][0], acc[t][YL], 0, 0, 0);
+              acc[t][YL] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1][0], a[t][1], acc[t][YL], 0, 0, 0);
+              acc[t][YL] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1][0], a[t][0], acc[t][YL], 0, 0, 0);
+            }
+          }
 #pragma unroll
           for (int sp = 0; sp < 3; ++sp) {
             if constexpr (AK) a[t][sp] = k_frag(st, wm * WROWS + t * 16, sp);
@@ -813,18 +863,24 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
               else b[(y + 1) & 1][sp] = *(const bf16x8*)(st + rowb + (y + 1) * 16 * 192 + offp[sp]);
             }
           }
+          if (!(STAG_OK && y == YL && defer)) {
 #pragma unroll
-          for (int x = 0; x < RB; ++x)
-            if (x < rbv) {
-              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][2], a[x][0], acc[x][y], 0, 0, 0);
-              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][1], a[x][1], acc[x][y], 0, 0, 0);
-              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][2], acc[x][y], 0, 0, 0);
-              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][1], a[x][0], acc[x][y], 0, 0, 0);
-              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][1], acc[x][y], 0, 0, 0);
-              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][0], acc[x][y], 0, 0, 0);
-            }
+            for (int x = 0; x < RB; ++x)
+              if (x < rbv) {
+                acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][2], a[x][0], acc[x][y], 0, 0, 0);
+                acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][1], a[x][1], acc[x][y], 0, 0, 0);
+                acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][2], acc[x][y], 0, 0, 0);
+                acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][1], a[x][0], acc[x][y], 0, 0, 0);
+                acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][1], acc[x][y], 0, 0, 0);
+                acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y & 1][0], a[x][0], acc[x][y], 0, 0, 0);
+              }
+          }
         }
-        if constexpr (EA && y == 0) barrier();                // mid
+        if constexpr (EA && y == 0) {
+          X3_PH_T(p2);
+          barrier();                                          // mid
+          X3_PH_T(p3);
+        }
       });
     };
     auto epilogue = [&](const Tile& t) __attribute__((always_inline)) {
@@ -963,10 +1019,28 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
       const Tile tc = decode(logical);
       const int64_t rleft = g.M - ((int64_t)tc.ti * BM + wm * WROWS), cleft = g.N - ((int64_t)tc.tj * BN + wn * WCOLS);
       const int rbv = rleft >= RB * 16 ? RB : (int)((rleft + 15) >> 4), cbv = cleft >= CB * 16 ? CB : (int)((cleft + 15) >> 4);
+      bool pend = false;
       for (int ks = tc.ks_begin; ks < tc.ks_end; ++ks, ++n) {
+        X3_PH_T(p0);
+        X3_PH(if (n > 0) ph[3] += p0 - p4;)                // (the step's tail: behind `mid` up to the arrival at the next opening barrier)
+        // (a deferred block's fragments were requested a column block ago; they must have LEFT the stage before the barrier hands its
+        // B part to the movers)
+        if (late) __builtin_amdgcn_s_waitcnt(0xC07F);
         barrier();                                         // stage n has landed (the movers waited for it)
-        compute(n % NSTAGE, rbv, cbv);
+        X3_PH_T(p1);
+        const bool defer = late && ks + 1 < tc.ks_end;     // (a tile's last step runs whole: the epilogue follows)
+        compute(n % NSTAGE, rbv, cbv, pend, defer);
+        pend = defer;
+        X3_PH_T(p4);
+        X3_PH(ph[0] += p1 - p0; ph[1] += p2 - p1; ph[2] += p3 - p2; ph[4] += p4 - p3; ph[5] += 1;)
       }
+      // (nothing is deferred across a tile's end: the fragment registers are dead through the epilogue)
+#pragma unroll
+      for (int t = 0; t < RB; ++t)
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) a[t][sp] = bf16x8{};
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp) { b[0][sp] = bf16x8{}; b[1][sp] = bf16x8{}; }
       if constexpr (BK && !AK && NSTAGE == 2) {
         // uneven split-K: slab nsplit2 + j of the short row tile's rows is all zeros, written by that tile's j-th block (a second
         // pass of the SAME epilogue code over the cleared accumulators)
@@ -982,6 +1056,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         zero_acc();
       }
     }
+    X3_PH(if (g.stamps && (wid == 0 || wid == 4) && lane == 0) for (int i = 0; i < 6; ++i) g.stamps[1024 + 32 * blockIdx.x + 2 * wid + i] = ph[i];)
   }
   (void)NSTORE;
   if (g.stamps && tid == 0) {
@@ -1669,6 +1744,8 @@ extern "C" int ogl_x3_debug_tile(int cfg) {
 // bench.py compares it with the kernel name of the committed PMC pass before quoting that pass's traffic beside a launch it timed.
 static int g_x3_early_a = -1;            // -1: OGL_X3_EARLY_A (default on); 0 / 1: pinned (tests, A/B runs)
 extern "C" int ogl_x3_debug_early_a(int on) { const int old = g_x3_early_a; g_x3_early_a = on; return old; }
+static int g_x3_stagger = -1;            // -1: OGL_X3_STAGGER; 0 / 1: pinned (tests, A/B runs)
+extern "C" int ogl_x3_debug_stagger(int on) { const int old = g_x3_stagger; g_x3_stagger = on; return old; }
 static const char* g_x3_last_kernel = "";
 extern "C" const char* ogl_x3_last_kernel(void) { return g_x3_last_kernel; }
 #define X3P_LAUNCH(...)                                                                           \
@@ -1762,6 +1839,8 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     // ring depth: two stages of the 256 x 128 tile fill the LDS (144 KB); the 128 x 128 tile takes three (144 KB): its movers
     // run two stages ahead (+4 % on the layer-0 weight gradient, whose operands both stream from HBM)
     // the two-stage tiles (256 x 128, 192 x 128) in their early-A form (template parameter EA) unless switched off
+    static const char* stag_env = getenv("OGL_X3_STAGGER");
+    g.stagger = g_x3_stagger >= 0 ? g_x3_stagger : ((stag_env && stag_env[0] == '0') ? 0 : 1);
     static const char* ea_env = getenv("OGL_X3_EARLY_A");
     const bool ea = (g_x3_early_a >= 0 ? g_x3_early_a != 0 : !(ea_env && ea_env[0] == '0')) && !g.skip_pad;
     if (cfg == 5 || cfg == 6) {

@@ -2813,6 +2813,12 @@ def sage_mean_layer_loss(h, w_cat, bias, idx, n_dst, labels, defer_mean=False, p
     return _SageMeanLossFn.apply(h, w_cat, bias, idx, n_dst, labels, bool(defer_mean), plan)
 
 
+def _adopts_gradient(p):
+    """AccumulateGrad will ADOPT the gradient tensor a node returns for ``p`` and nobody sees it on the way: ``p`` holds no gradient
+    yet (else: ``grad += new``) and carries no gradient hook of either kind (a hook reads the tensor when autograd hands it over)."""
+    return p is None or (p.grad is None and not p._backward_hooks and not getattr(p, "_post_accumulate_grad_hooks", None))
+
+
 def sage_pool_layer_loss(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels, defer_mean=False, h_single_use=False):
     """(mean CE loss, per-seed losses, logits) of the last 'pool' layer + nn.CrossEntropyLoss, or None when the fused form does not
     apply (the caller then runs the layer and the loss separately)."""
@@ -2825,8 +2831,12 @@ def sage_pool_layer_loss(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, id
             # small first layer, this node's whole backward moves into that layer's two launches: see ``_SmallPoolLossFn``)
             # (not under a gradient exchange that launches collectives from gradient hooks: this node's gradient tensors are filled by
             # a launch enqueued AFTER their hooks fire — a bucket made of them alone would be reduced before it is written)
-            lazy = bool(SMALL_ROUTE and h_single_use and h.requires_grad and type(h.grad_fn).__name__ == "_SmallFirstLayerFnBackward"
-                        and n_dst * h.shape[1] <= 2048 and not _GRAD_SINKS)
+            # (and only while every gradient it would hand out is ADOPTED by AccumulateGrad — ``p.grad is None`` — and nobody else can
+            # see the gradient of ``h``: no retain_grad, no tensor hook.  All of it is checked again when the backward runs, which
+            # takes the route only inside ``ops.backward`` and otherwise finishes the node with its own launch.)
+            lazy = bool(SMALL_ROUTE and h_single_use and h.requires_grad and type(h.grad_fn) is _SmallFirstLayerFn._backward_cls
+                        and n_dst * h.shape[1] <= 2048 and not _GRAD_SINKS and not h.retains_grad and not h._backward_hooks
+                        and all(_adopts_gradient(p) for p in (w_pool, b_pool, w_self, w_neigh, b_self, b_neigh)))
             return _SmallPoolLossFn.apply(h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels, lazy)
         return None
     if (b_self is None) != (b_neigh is None) or not out_loss_fits(h, n_dst, idx, w_self, w_neigh, w_pool.shape[0]):
@@ -2919,6 +2929,7 @@ class _SmallPoolLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh, idx, n_dst, labels, lazy=False):
+        ctx.param_refs = [weakref.ref(p) for p in (w_pool, b_pool, w_self, w_neigh, b_self, b_neigh) if p is not None]
         h = as_mat(h); w_pool = as_mat(w_pool); w_self = as_mat(w_self); w_neigh = as_mat(w_neigh)
         n_src, hin = h.shape
         ctx.lazy = bool(lazy)
@@ -3004,7 +3015,18 @@ class _SmallPoolLossFn(torch.autograd.Function):
         if ctx.prime is not None:
             step_dev, scal, lr, b1, b2 = ctx.prime
             ctx.prime = None
+        route_ok = False
         if ctx.lazy:
+            # the route is a promise — gradient tensors a LATER node's launch fills — and is taken only where it is certain to be
+            # kept: inside ``ops.backward`` (which raises if the route is still pending when the pass ends) and while AccumulateGrad
+            # ADOPTS what this node returns (a parameter that already holds a gradient would get `grad += <unwritten memory>`)
+            route_ok = _OWN_BWD["depth"] > 0 and all(_adopts_gradient(r()) for r in ctx.param_refs)
+            if not route_ok and dh is not None:
+                # finished by this node's own launch after all: the forward wrote the destinations' head rows only
+                full = fill_zero(torch.empty((max(n_src, 1), padded_ld(hin)), dtype=torch.float32, device=dev))[:n_src, :hin]
+                full[:dh.shape[0]].copy_(dh)
+                dh = full
+        if route_ok:
             # NO launch here: the gradient handed to the first layer is an EMPTY [n_src, hin] matrix that stands for the route (its
             # consumer, _SmallFirstLayerFn.backward, finds the route by the matrix' address, gathers the winners' rows inside its own
             # launch and never reads the matrix); this node's weight gradients, the mean loss and the optimiser's scalars are written by
@@ -3314,8 +3336,31 @@ def unit_grad(device):
 def backward(loss):
     """loss.backward() with the cached unit root gradient: autograd then neither fills a ones_like(loss) nor does the
     mean-reduced cross entropy multiply its stored dlogits by it (two ~5 us launches per step)."""
-    loss.backward(unit_grad(loss.device))
+    # (the region in which this package owns the whole backward pass: the only place where a node may hand out a gradient tensor that
+    # a LATER node's launch fills — ``_SmallPoolLossFn``'s route.  A route nobody consumed by the end of the pass is an error, never
+    # silently unwritten gradients.)
+    _OWN_BWD["depth"] += 1
+    try:
+        loss.backward(unit_grad(loss.device))
+    finally:
+        _OWN_BWD["depth"] -= 1
+        stale = bool(_PENDING_ROUTES)
+        _PENDING_ROUTES.clear()
+    if stale:
+        raise RuntimeError("the fused last layer handed its backward to the first layer's launches (ops.SMALL_ROUTE) and that node never "
+                           "ran or received a different gradient tensor (a tensor hook on the hidden rows?): the last layer's weight "
+                           "gradients were NOT written.  Set OGL_SMALL_ROUTE=0 for such a graph.")
     side_join()
+
+
+_OWN_BWD = {"depth": 0}
+
+
+def assert_no_pending_gradients():
+    """Raises when a gradient promised by a fused node was never written (checked by the optimiser and the gradient exchange)."""
+    if _PENDING_ROUTES:
+        _PENDING_ROUTES.clear()
+        raise RuntimeError("a gradient route of the fused last layer was never consumed: its weight gradients are unwritten memory")
 
 
 class _CrossEntropyMeanFn(torch.autograd.Function):

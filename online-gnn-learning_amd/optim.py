@@ -201,6 +201,7 @@ class Adam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        ops.assert_no_pending_gradients()   # (a gradient a fused node promised and nobody wrote must never reach the update)
         ops._flush_deferred()               # (an early part still waiting for "the main stream's next launch": there is none)
         ops.side_join()                     # (a forked backward joins itself when it ends; this is for gradients made by hand)
         ops.invalidate_weight_images()      # the kernels below write the parameters through raw pointers (no version bump)

@@ -304,6 +304,8 @@ class GradSynchronizer:
         for steps whose backward cannot overlap the exchange anyway (a replayed replica step); every rank must make the same choice."""
         if not self.active:
             return
+        from . import ops
+        ops.assert_no_pending_gradients()
         w = self.weight if weight is None else float(weight)
         if single:
             assert self._pending is None, "single-bucket sync after an early bucket was launched"

@@ -379,7 +379,7 @@ class StepGraphCache:
             bufs = [BlockBuffers(B, self.S, n1_cap, n1_cap * (1 + self.S), graph.device) for _ in range(2)]
             self.bufs[bkey] = bufs
             pipe = self.samplers[bkey] = dict(smp=[SampleGraph(graph, b) for b in bufs], side=torch.cuda.Stream(device=graph.device),
-                                              sampled=[None, None], trained=[None, None], cur=0, ahead=None)
+                                              sampled=[None, None], trained=[None, None], cur=0, ahead=None, last=None)
         if SIZE_AGNOSTIC and SIZE_AGNOSTIC_PIPE and self.agnostic.get(bkey) is not False:
             sg = self._merged_pipelined(graph, pipe, bkey, seeds_host, ctr, nxt, B)
             if sg is not None:
@@ -387,6 +387,16 @@ class StepGraphCache:
         cur = pipe["cur"]
         smp = pipe["smp"][cur]
         main = torch.cuda.current_stream()
+        # What the side stream waits for before it re-samples a set is recorded HERE, at the top of the call that follows the set's
+        # train graph — not right behind that graph's replay: the caller reads the step's static outputs (seeds, per-seed losses) on
+        # the main stream after the replay returns, and the sampling launch's first act is to overwrite the seeds.  An event
+        # recorded behind the replay left those reads unordered against the re-sampling (PBR could pair batch i's losses with
+        # batch i + 2's seeds once the host ran a step ahead).
+        last = pipe.get("last")
+        if last is not None:
+            ev = pipe["trained"][last] = torch.cuda.Event()
+            ev.record(main)
+            pipe["last"] = None
         agn = SIZE_AGNOSTIC and SIZE_AGNOSTIC_PIPE2 and self.agnostic.get(bkey) is not False
         first_merged = (SIZE_AGNOSTIC and SIZE_AGNOSTIC_PIPE3 and self.agnostic.get(bkey) is not False
                         and not (pipe["ahead"] is not None and pipe["ahead"][0] == cur and pipe["ahead"][1] == int(ctr)))
@@ -403,8 +413,7 @@ class StepGraphCache:
                 first_merged = False
         if first_merged:
             sgm.replay()
-            ev = pipe["trained"][cur] = torch.cuda.Event()
-            ev.record()
+            pipe["last"] = cur
             other = 1 - cur
             if nxt is not None and len(nxt[0]) == B:
                 side = pipe["side"]
@@ -456,8 +465,7 @@ class StepGraphCache:
         if PREFETCH_FIRST:
             prefetch()
         sg.replay()
-        ev = pipe["trained"][cur] = torch.cuda.Event()
-        ev.record()
+        pipe["last"] = cur                                   # (its `trained` event: at the top of the next call, behind the caller's reads)
         if not late:
             sg.last_sizes = (n0, n1)
         if not PREFETCH_FIRST:

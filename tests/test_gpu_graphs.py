@@ -76,6 +76,36 @@ def test_sampled_graph_steps_equal_eager(name, B, S, H):
         assert 1 <= graph._step_graphs().captures <= 6          # train graphs: one per input-size bucket met
 
 
+def test_pipelined_steps_hand_out_their_own_seeds():
+    """The pipelined captured step (batch i + 1 sampled on a second stream while batch i trains, two sets of block arrays): what
+    ``on_rows`` receives for batch i — seeds AND per-seed losses, read from the step's static buffers without a host sync — are batch
+    i's, also when the host runs far ahead of the device (the re-sampling of a set is ordered behind the caller's reads of it)."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import sampling, synthetic
+    from ogl_amd.graphsage import model as M
+    from ogl_amd.prioritized_replay import LossPriority
+    assert M.SAMPLE_PIPELINE
+    B, S, nb = 32, 25, 12
+    feat_size, labels, dyn, n_classes, _ = synthetic.load("pubmed", snapshots=4, device="cuda")
+    dyn.evolve(); dyn.evolve()
+    g = dyn.get_graph()
+    eager, graph = _twins(feat_size, 32, n_classes, M.PrioritizedHipSupervisedGraphSage, nb, B, labels, S, LossPriority(), cuda=True,
+                          batch_full=256)
+    seeds = np.random.default_rng(3).choice(g.n_present, nb * B, replace=False).astype(np.int64)
+    got = {}
+    for st in (eager, graph):
+        for rep in range(2):                                  # (second pass: every graph is captured, the host only enqueues)
+            rows = []
+            sampling.seed(11)
+            st._train_batches(g, seeds, B, on_rows=lambda s_, r_: rows.append((s_, r_)))
+        torch.cuda.synchronize()
+        got[st.use_graphs] = [(a.cpu().numpy(), b.cpu().numpy()) for a, b in rows]
+    assert len(got[True]) == len(got[False]) == nb
+    for i, ((sd_g, _), (sd_e, _)) in enumerate(zip(got[True], got[False])):
+        np.testing.assert_array_equal(sd_g, seeds[i * B:(i + 1) * B], err_msg="batch %d" % i)
+        np.testing.assert_array_equal(sd_e, seeds[i * B:(i + 1) * B])
+
+
 def test_staged_graph_steps_equal_eager_reddit_size():
     """The Reddit rung: loader-sampled batches staged into per-bucket captured steps; 4 steps of 512 seeds."""
     import ogl_amd  # noqa: F401
