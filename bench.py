@@ -62,6 +62,12 @@ WORKLOADS = {
     "reddit_pbr_forward": dict(dataset="reddit", batch=1024, samples=25, hidden=600, batch_timestep=50, forward=True),
     "arxiv_pbr_forward": dict(dataset="arxiv", batch=1024, samples=25, hidden=32, batch_timestep=1, forward=True),
     "toy_pbr_forward": dict(dataset="toy", batch=64, samples=5, hidden=16, batch_timestep=2, forward=True),
+    # BASELINE config 3 end to end: the reference's loop body for the PBR strategy on the arxiv-like stream — priority forward over the
+    # train set EVERY snapshot (batch_full 1024), one 32-seed update, evolve — whole snapshots on the wall clock
+    "arxiv_pbr_snapshot": dict(dataset="arxiv", batch=32, samples=25, hidden=32, batch_timestep=1, snapshot=True, batch_full=1024,
+                               priority_forward=1, snapshots=3500, start=3300),
+    "toy_pbr_snapshot": dict(dataset="toy", batch=16, samples=5, hidden=16, batch_timestep=2, snapshot=True, batch_full=64,
+                             priority_forward=1, snapshots=12, start=2),
 }
 
 
@@ -101,6 +107,8 @@ def parse():
                          "parameters -> all-gather of the weights (parallel.ShardedAdam: the late-exchange lever of DESIGN section 6), "
                          "0 = all-reduce + the identical Adam on every rank (the default)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end snapshot leg (metric iii) of the default line")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="N > 1 / --force-dist: skip the other two forms of the gradient exchange (`collectives_variants`) after the headline")
     ap.add_argument("--e2e-snapshots", type=int, default=6)
     ap.add_argument("--partition", default="replicated", choices=["replicated", "features"],
                     help="PBR forward, N > 1: 'features' = every rank projects only its vertex range and the projection tables are "
@@ -196,6 +204,11 @@ def main():
     ops.set_gemm_mode(args.gemm)
     wl = WORKLOADS[args.workload]
     B, S, H, bt = wl["batch"], wl["samples"], wl["hidden"], wl["batch_timestep"]
+    if wl.get("snapshot"):
+        if world != 1:
+            raise SystemExit("bench.py: the snapshot workloads are one-rank lines")
+        print(json.dumps(pbr_snapshot_bench(args, wl)))
+        return
     t0 = time.time()
     arrays = synthetic.make_arrays(wl["dataset"], args.scale)
     feat_size, n_classes = arrays["f"], arrays["c"]
@@ -234,24 +247,29 @@ def main():
         return
 
     from ogl_amd.graphsage.model import RandomHipSupervisedGraphSage
-    strat = RandomHipSupervisedGraphSage(model, bt, B_global, None, S, cuda=True, batch_full=1024)
-    strat.use_graphs = False if args.no_graphs else (True if args.graphs else "auto")
-    strat.build_optimizer()
-    model.train()
     stats = dict(n0=[], n1=[], forms={})
 
     def hook(info):
         stats["forms"][info["form"]] = stats["forms"].get(info["form"], 0) + 1
         if "n0" in info:
             stats["n0"].append(info["n0"]); stats["n1"].append(info["n1"])
-    strat.step_hook = hook
+
+    def make_strategy(mdl, batch):
+        st = RandomHipSupervisedGraphSage(mdl, bt, batch, None, S, cuda=True, batch_full=1024)
+        st.use_graphs = False if args.no_graphs else (True if args.graphs else "auto")
+        st.build_optimizer()
+        mdl.train()
+        st.step_hook = hook
+        return st
+
+    state = dict(strat=None, batch=B_global)
 
     def draw(nb):
-        return np.concatenate([seed_rng.choice(train_set, B_global, replace=False) for _ in range(nb)])
+        return np.concatenate([seed_rng.choice(train_set, state["batch"], replace=False) for _ in range(nb)])
 
     def run(nsteps, seeds_per_snapshot):
         for seeds in seeds_per_snapshot:          # one snapshot's update: batch_timestep batches of B_global seeds
-            strat._train_batches(g, seeds, B_global)
+            state["strat"]._train_batches(g, seeds, state["batch"])
 
     def plan(nsteps):
         out, left = [], nsteps
@@ -265,6 +283,76 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def settle_and_time(steps):
+        """Untimed: the auto policy settles and the common size buckets are captured, W warm-up steps; then K steps between barriers,
+        MAX over ranks.  Returns seconds."""
+        st = state["strat"]
+        if st.use_graphs in ("auto", True):
+            run(max(6 * bt, 120), plan(max(6 * bt, 120)))
+        run(args.warmup, plan(args.warmup))
+        sp = plan(steps)
+        barrier()
+        t_ = time.perf_counter()
+        run(steps, sp)
+        barrier()
+        el = time.perf_counter() - t_
+        if world > 1:
+            tt_ = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            el = float(tt_.item())
+        return el
+
+    def instrumented_collectives(steps):
+        """hipEvent pairs around every collective the strategy issues from Python (None when the exchange is recorded inside the graph)."""
+        st = state["strat"]
+        if getattr(st, "gsync", None) is None or _dp_capture_on():
+            return None
+        st.gsync.enable_timing(True)
+        shd = getattr(st, "sharded", None)
+        if shd is not None:
+            shd.enable_timing(True)
+        csteps = min(steps, max(bt, 20))
+        cplan = plan(csteps)
+        barrier()
+        tc = time.perf_counter()
+        run(csteps, cplan)
+        barrier()
+        c_ms = 1000 * (time.perf_counter() - tc) / csteps
+        tm = st.gsync.timings()
+        st.gsync.enable_timing(False)
+        if shd is not None:                    # (the sharded update: both of its collectives are exposed — Adam sits between them)
+            tm.update(shd.timings())
+            shd.enable_timing(False)
+        exposed = sum(tm[k][0] * tm[k][1] for k in ("single", "all", "late", "reduce_scatter", "all_gather") if k in tm) / csteps
+        return {"ms_per_step_instrumented": round(c_ms, 4),
+                "per_kind": {k: {"mean_ms": round(v[0], 4), "per_step": round(v[1] / csteps, 2)} for k, v in tm.items()},
+                "exposed_exchange_ms_per_step": round(exposed, 4),
+                "t1_prime_ms": round(c_ms - exposed, 4),
+                "what": "hipEvent pairs on the issuing stream: 'single' / 'all' / 'late' = from the all-reduce call to the point where "
+                        "the stream may continue (exposed: Adam waits for it); 'early' = from its launch in the gradient hook to the wait "
+                        "in sync() (mostly hidden under the layer-0 backward).  t1_prime = the instrumented step minus the exposed exchange: "
+                        "what one rank's step costs with zero link time"}
+
+    # ---- N ranks: the ONE-RANK step first, on every rank of this same invocation (no shard, no exchange: `parallel.local_only`), B seeds
+    # per rank — the T1 a scaling curve divides by, measured on the same boxes in the same process group as TN
+    one_rank_reference = None
+    if world > 1 or args.force_dist:
+        with parallel.local_only():
+            torch.manual_seed(1)
+            sampling.seed(1)
+            m1 = GraphSAGE(feat_size, H, n_classes, 1, F.relu, 0, args.aggregator, edge_feats=0, pool_feats=H).cuda()
+            state["strat"], state["batch"] = make_strategy(m1, B), B
+            el1 = settle_and_time(args.steps)
+        one_rank_reference = dict(ms_per_step=round(1000 * el1 / args.steps, 4), vertices_per_s_per_rank=round(args.steps * B / el1, 1),
+                                  what="the one-rank step (B = %d seeds, no shard, no exchange) timed on every rank inside this invocation, "
+                                       "MAX over ranks: `--gpus 1` of the same command line" % B)
+        state["strat"] = None
+        del m1
+        sampling.seed(1)
+        torch.manual_seed(1)
+    strat = state["strat"] = make_strategy(model, B_global)
+    state["batch"] = B_global
 
     if strat.use_graphs in ("auto", True):
         # set-up, not measurement: let the strategy's auto policy see a cold and a warm snapshot and settle on its execution
@@ -303,33 +391,39 @@ def main():
     # ---- N ranks (or --force-dist): device time of the step's collectives, term by term of DESIGN section 6's model T(N) = T1' + L(N) + S(N).
     # An instrumented pass AFTER the timed region: hipEvent pairs around every collective the step issues from Python (the default
     # replica step keeps its exchange outside the replayed graph; --dp-capture 1 records it inside, where events cannot see it).
-    collectives = None
-    if getattr(strat, "gsync", None) is not None and not _dp_capture_on():
-        strat.gsync.enable_timing(True)
-        shd = getattr(strat, "sharded", None)
-        if shd is not None:
-            shd.enable_timing(True)
-        csteps = min(args.steps, max(bt, 20))
-        cplan = plan(csteps)
+    collectives = instrumented_collectives(args.steps)
+    # ---- N ranks: the OTHER forms of the exchange, timed in this same invocation on the same ranks (the driver gives one run per N):
+    # (a) = the headline above (all-reduce after the replayed forward + backward, one flat bucket; two overlapped buckets when eager),
+    # (b) the sharded update (reduce-scatter -> Adam on 1 / N of the flat parameters -> all-gather), (c) the exchange and the optimiser
+    # recorded INSIDE the replayed step graph (RCCL only).  Each on a fresh model + strategy, sequentially, nothing re-executed.
+    collectives_variants = None
+    if (world > 1 or args.force_dist) and not args.no_variants:
+        from ogl_amd.graphsage import model as _mm
+        nccl_on = dist.is_initialized() and dist.get_backend() == "nccl"
+        base_flags = (bool(parallel.SHARDED_UPDATE), bool(_mm.DP_CAPTURE_COLLECTIVES))
+        collectives_variants = {"a_allreduce" if base_flags == (False, False) else "headline": dict(
+            ms_per_step=round(1000 * elapsed / args.steps, 4), sharded_update=base_flags[0], captured_exchange=base_flags[1], collectives=collectives)}
+        todo = [("a_allreduce", False, False), ("b_sharded_update", True, False), ("c_captured_exchange", False, True)]
+        for name, shd_on, cap_on in todo:
+            if (shd_on, cap_on) == base_flags:
+                continue
+            if cap_on and not nccl_on:
+                collectives_variants[name] = dict(skipped="collectives are recorded into a hipGraph over RCCL only (backend %s)" % dist.get_backend())
+                continue
+            parallel.SHARDED_UPDATE, _mm.DP_CAPTURE_COLLECTIVES = shd_on, cap_on
+            try:
+                torch.manual_seed(1)
+                sampling.seed(1)
+                mv = GraphSAGE(feat_size, H, n_classes, 1, F.relu, 0, args.aggregator, edge_feats=0, pool_feats=H).cuda()
+                state["strat"] = make_strategy(mv, B_global)
+                elv = settle_and_time(args.steps)
+                collectives_variants[name] = dict(ms_per_step=round(1000 * elv / args.steps, 4), sharded_update=shd_on, captured_exchange=cap_on,
+                                                  collectives=instrumented_collectives(args.steps))
+            finally:
+                parallel.SHARDED_UPDATE, _mm.DP_CAPTURE_COLLECTIVES = base_flags
+                state["strat"] = strat
+            del mv
         barrier()
-        tc = time.perf_counter()
-        run(csteps, cplan)
-        barrier()
-        c_ms = 1000 * (time.perf_counter() - tc) / csteps
-        tm = strat.gsync.timings()
-        strat.gsync.enable_timing(False)
-        if shd is not None:                    # (the sharded update: both of its collectives are exposed — Adam sits between them)
-            tm.update(shd.timings())
-            shd.enable_timing(False)
-        exposed = sum(tm[k][0] * tm[k][1] for k in ("single", "all", "late", "reduce_scatter", "all_gather") if k in tm) / csteps
-        collectives = {"ms_per_step_instrumented": round(c_ms, 4),
-                       "per_kind": {k: {"mean_ms": round(v[0], 4), "per_step": round(v[1] / csteps, 2)} for k, v in tm.items()},
-                       "exposed_exchange_ms_per_step": round(exposed, 4),
-                       "t1_prime_ms": round(c_ms - exposed, 4),
-                       "what": "hipEvent pairs on the issuing stream: 'single' / 'all' / 'late' = from the all-reduce call to the point where "
-                               "the stream may continue (exposed: Adam waits for it); 'early' = from its launch in the gradient hook to the wait "
-                               "in sync() (mostly hidden under the layer-0 backward).  t1_prime = the instrumented step minus the exposed exchange: "
-                               "what one rank's step costs with zero link time"}
     # the OTHER execution mode of large batches, for the record: when the auto policy kept this workload eager (fast host),
     # the same steps replayed as captured graphs (size buckets captured in an untimed warm-up first)
     graph_mode = None
@@ -596,8 +690,19 @@ def main():
             for _ in range(10):
                 dst_b.copy_(src_b)
             e1.record(); torch.cuda.synchronize()
-            hbm_copy = dict(gbs=round(10 * 2 * src_b.numel() * 4 / e0.elapsed_time(e1) / 1e6, 1),
-                            what="1 GiB fp32 device-to-device copy (read + write bytes), 10 repeats, same process")
+            torch_gbs = round(10 * 2 * src_b.numel() * 4 / e0.elapsed_time(e1) / 1e6, 1)
+            from ogl_amd import _lib as _l
+            st_ = torch.cuda.current_stream().cuda_stream
+            _l.check(_l.lib().ogl_stream_copy(src_b.data_ptr(), dst_b.data_ptr(), src_b.numel() * 4, st_), "ogl_stream_copy")
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                _l.lib().ogl_stream_copy(src_b.data_ptr(), dst_b.data_ptr(), src_b.numel() * 4, st_)
+            e1.record(); torch.cuda.synchronize()
+            hbm_copy = dict(gbs=round(10 * 2 * src_b.numel() * 4 / e0.elapsed_time(e1) / 1e6, 1), torch_copy_gbs=torch_gbs,
+                            what="1 GiB fp32 device-to-device copy (read + write bytes), 10 repeats, same process: `gbs` = the package's "
+                                 "float4 stream-copy kernel (ogl_stream_copy; MI355X_MICROARCH.md quotes ~6.3 TB/s for this form), "
+                                 "`torch_copy_gbs` = torch's copy_ of the same buffers.  The roofline denominators stay the 8 TB/s spec figure")
             del src_b, dst_b
         line = {
             "metric": "streamed vertices/sec (RBR train update), %s-shaped stream depth=2 samples=%d" % (wl["dataset"], S),
@@ -637,6 +742,8 @@ def main():
             "hbm_copy_measured": hbm_copy,
             "host_enqueue_ms_per_step": round(host_ms, 4),
             "collectives": collectives,
+            "collectives_variants": collectives_variants,
+            "one_rank_reference": one_rank_reference,
             "graph_mode": graph_mode,
             "end_to_end_snapshot": e2e,
             "cpu_baseline": cpu_baseline,
@@ -766,6 +873,92 @@ def end_to_end_snapshots(n_snapshots=6, start=4500, gemm="auto"):
         rbr_trained_vertices_per_s_inside_the_loop=round(seeds / (mean("rbr_delay") / 1000), 1),
         streamed_vertices_per_s_whole_snapshot=round(2 * seeds / (wall / 1000), 1),
         train_set=int(use[-1]["train_vertices"]), setup_s=round(setup_s, 1))
+
+
+def pbr_snapshot_bench(args, wl):
+    """BASELINE config 3 as whole snapshots: what `PrioritizedPytorchSupervisedGraphSage` does per snapshot of the reference's loop
+    (R/train/__main__.py:161-196; R/train/graphsage/pytorch/model.py:153-159,210-254): choose_vertices = the priority forward over the
+    train set (every `priority_forward`-th snapshot; batches of batch_full, inference, per-seed CE -> LossPriority -> the replay buffer)
+    + the prioritised draws, then the train update (batch_timestep batches), then evolve().  --steps = timed snapshots, --warmup =
+    untimed ones (at least 6: captures, the auto policy).  Wall clock between device synchronisations, phases itemised."""
+    import gc
+    import random
+    from ogl_amd import ops, sampling, synthetic
+    from ogl_amd.graph import TrainTestGraph
+    from ogl_amd.prioritized_replay import LossPriority
+    from ogl_amd.utils import Lib_supported, init
+    np.random.seed(1); random.seed(1); torch.manual_seed(1); sampling.seed(1)
+    ops.set_gemm_mode(args.gemm)
+    GraphSAGE, _Random, Prioritized, _NoReh, _Full, act = init(Lib_supported.HIP, True, 0)
+    t0 = time.perf_counter()
+    feat_size, labels, graph, n_classes, _graph_test = synthetic.load(wl["dataset"], snapshots=wl["snapshots"])
+    for _ in range(wl["start"]):                             # (the device CSR makes fast-forwarding O(1) per snapshot)
+        graph.evolve()
+    gu = TrainTestGraph(graph, split=0.15, start_prior_alpha=4, end_prior_alpha=50, scale=1, max_priority=10)
+    gu._admit([int(v) for v in range(graph.get_graph().n_present) if v in graph.labelled_vertices])
+    setup_s = time.perf_counter() - t0
+    model = GraphSAGE(feat_size, wl["hidden"], n_classes, 1, act, 0, "pool", edge_feats=0, pool_feats=wl["hidden"]).cuda()
+    pri = Prioritized(model, wl["batch_timestep"], wl["batch"], labels, wl["samples"], LossPriority(), full_pass=wl["priority_forward"],
+                      cuda=True, batch_full=wl["batch_full"], n_workers=0)
+    pri.build_optimizer()
+    forms = {}
+    pri.step_hook = lambda info: forms.__setitem__(info["form"], forms.get(info["form"], 0) + 1)
+    gc.collect(); gc.freeze()
+    sync = torch.cuda.synchronize
+
+    def timed(rec, key, fn):
+        sync(); t = time.perf_counter()
+        out = fn()
+        sync(); rec[key] = rec.get(key, 0.0) + 1000 * (time.perf_counter() - t)
+        return out
+
+    warm = max(6, args.warmup)
+    phases = []
+    for snap in range(warm + args.steps):
+        if snap == warm:
+            forms.clear()
+        rec = {}
+        sync(); t_snap = time.perf_counter()
+        inner = pri.recompute_priorities
+        pf = {}
+        pri.recompute_priorities = lambda g_, ts_: timed(pf, "t", lambda: inner(g_, ts_))
+        nodes = timed(rec, "choose_vertices", lambda: pri.choose_vertices(gu))
+        pri.recompute_priorities = inner
+        rec["priority_forward_gpu"] = pf.get("t", 0.0)
+        rec["choose_vertices_host"] = rec.pop("choose_vertices") - rec["priority_forward_gpu"]
+        pri.choose_vertices = lambda _gu, _b=nodes: _b
+        timed(rec, "train_gpu", lambda: pri.train_timestep(gu))
+        del pri.choose_vertices
+        rec["train_vertices"] = len(gu.get_train_set())
+        timed(rec, "evolve_host", lambda: gu.evolve())
+        timed(rec, "gc_collect_host", gc.collect)
+        sync(); rec["wall"] = 1000 * (time.perf_counter() - t_snap)
+        phases.append(rec)
+    gc.unfreeze()
+    use = phases[warm:]
+    mean = lambda k: float(np.mean([r.get(k, 0.0) for r in use]))          # noqa: E731
+    wall = mean("wall")
+    fwd_seeds = mean("train_vertices") / wl["priority_forward"]
+    upd_seeds = wl["batch_timestep"] * wl["batch"]
+    return {
+        "metric": "streamed vertices/sec (PBR snapshot: priority forward over the train set + update), %s-shaped stream depth=2 samples=%d"
+                  % (wl["dataset"], wl["samples"]),
+        "value": round((fwd_seeds + upd_seeds) / (wall / 1000), 1), "unit": "vertices/s", "n_gpus": 1, "steps": args.steps, "warmup": warm,
+        "ms_per_step": round(wall, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: the reference loop body of the PBR strategy per snapshot on the %s-like stream at snapshots %d..%d "
+                               "(train set %d vertices): priority forward over the train set every %s snapshot (batch_full %d, inference, "
+                               "per-seed CE -> LossPriority -> replay buffer on the device), prioritised draw, %d x %d-seed update, evolve, "
+                               "gc.collect; a step = one snapshot" % (args.workload, wl["dataset"], wl["start"] + warm,
+                                                                        wl["start"] + warm + args.steps, int(use[-1]["train_vertices"]),
+                                                                        {1: "", 2: "2nd"}.get(wl["priority_forward"], "n-th"), wl["batch_full"],
+                                                                        wl["batch_timestep"], wl["batch"]),
+                   "gemm_arithmetic": gemm_desc(args.gemm), "setup_s": round(setup_s, 1)},
+        "phases_ms": {k: round(mean(k), 3) for k in ("priority_forward_gpu", "choose_vertices_host", "train_gpu", "evolve_host", "gc_collect_host")},
+        "priority_forward_vertices_per_s": round(fwd_seeds / (mean("priority_forward_gpu") / 1000), 1) if mean("priority_forward_gpu") > 0 else None,
+        "update_step_execution": dict(forms),
+        "roofline": None, "cpu_baseline": None,
+        "note": "an end-to-end line (metric iii of SURVEY 8(d)): its kernels' roofline figures are in the arxiv_pbr_forward and arxiv_rbr lines",
+    }
 
 
 def gemm_desc(mode):

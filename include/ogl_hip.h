@@ -111,6 +111,12 @@ int ogl_gather_rows(const float* table, int64_t ld, int64_t n_rows, const int64_
 /* Zero fill of `bytes` bytes (any alignment): what the atomic-scatter backward kernels need in front of them (ogl_reduce_bwd,
  * ogl_out_layer_bwd_inputs) when no loss launch cleared their target on the side.  A kernel launch (capturable). */
 int ogl_fill_zero(void* ptr, int64_t bytes, ogl_stream_t stream);
+/* Measurement only (bench.py `hbm_copy_measured`; SURVEY.md section 8(d): "re-measure with a stream-copy microbench on the box"): dst[0 ..
+ * bytes) = src[0 .. bytes) as a float4 grid-stride copy, four loads in flight per lane.  16-byte aligned, bytes a multiple of 16. */
+int ogl_stream_copy(const void* src, void* dst, int64_t bytes, ogl_stream_t stream);
+/* diagnostic: 1 / 0 = the max aggregator WITHOUT argmax over rows of <= 128 floats (the inference passes over a narrow projection
+ * table) reads two neighbour rows per wave-instruction (half a wave per row) / one; the same bits.  Returns the old value. */
+int ogl_reduce_debug_half(int on);
 int ogl_gather_i64(const int64_t* table, int64_t n_rows, const int64_t* ids, int64_t n,
                    int64_t* out, ogl_stream_t stream);
 
@@ -177,10 +183,6 @@ int ogl_reduce_bwd_seg_plan(const int32_t* idx, int64_t n_dst, int fanout, int64
 int ogl_reduce_bwd_seg_apply(const float* dout, int64_t ldd, const int32_t* idx, int64_t n_dst, int fanout, int d, int op, int64_t n_src,
                              const float* mask, int64_t ldm, float* out, int64_t ldo, void* image, void* workspace,
                              int64_t workspace_bytes, ogl_stream_t stream);
-/* ... with the mask given as sign bits (ogl_linear_fwd_x3_bits' layout: one byte per 4-column group, row stride ldmb bytes). */
-int ogl_reduce_bwd_seg_apply_bits(const float* dout, int64_t ldd, const int32_t* idx, int64_t n_dst, int fanout, int d, int op,
-                                  int64_t n_src, const unsigned char* mask_bits, int64_t ldmb, float* out, int64_t ldo, void* image,
-                                  void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense projections (torch.nn.Linear inside SAGEConv: fc_pool / fc_self / fc_neigh), fp32 MFMA.
@@ -292,35 +294,8 @@ int ogl_pool_bwd_x3(const float* dout, int64_t ldo, const int32_t* argmax, const
  * block per source group streams its records into the slab — no dependent read on the backward's critical path.) */
 int ogl_pool_bwd_x3_plan(const int32_t* argmax, const float* relu_out, int64_t ldr, const int32_t* idx32, int64_t n_dst, int fanout,
                          int d, int64_t n_src, void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
-/* The bucket pass of the plan INSIDE the max aggregator (round 5): ogl_reduce_fwd_img_plan = ogl_reduce_fwd_img (max, int32 indices, argmax
- * kept) whose waves also counting-sort their destination's columns by the winner's sampling slot — they hold the slot and the sign of the
- * maximum in registers — and write the plan's slot offsets and columns-in-slot-order (plan_off / plan_col: the two arrays
- * ogl_pool_bwd_x3_plan_slots locates inside a plan workspace, byte offsets from its start); ogl_pool_bwd_x3_plan_finish then runs the rest
- * of ogl_pool_bwd_x3_plan (group totals from the offsets, scan, place).  The separate bucket pass re-read argmax and the pooled output
- * (34 MB) and ran 65-70 us on the CUs the combine product leaves free; a second copy of it costs the replayed Reddit step 30 us. */
-int ogl_reduce_fwd_img_plan(const float* src, int64_t lds, int64_t n_src, const int32_t* idx32, int64_t n_dst, int fanout, int d, float* out,
-                            int64_t ldo, int32_t* argmax, void* image, void* plan_off, void* plan_col, ogl_stream_t stream);
-int ogl_pool_bwd_x3_plan_slots(int64_t n_dst, int fanout, int d, int64_t n_src, int64_t* off_bytes, int64_t* colperm_bytes);
-int ogl_pool_bwd_x3_plan_finish(const int32_t* idx32, int64_t n_dst, int fanout, int d, int64_t n_src, void* workspace,
-                                int64_t workspace_bytes, ogl_stream_t stream);
 int ogl_pool_bwd_x3_apply(const float* dout, int64_t ldo, const int32_t* idx32, int64_t n_dst, int fanout, int d, int64_t n_src,
                           void* image, const void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
-/* The planned backward WITHOUT the dense image (round 5): dw[d, K] (and db[d], nullable) = dP^T . [x[x_rows] | 1], the weight gradient of
- * fc_pool whose input carries no gradient (layer 0; autograd of relu -> max -> nn.Linear, R/train/graphsage/pytorch/aggregator_dgl.py:
- * 85-94,171,199-206; live parameterisation R/inference_optimized.py:136-139,256-282) straight from `dout` and the plan
- * ogl_pool_bwd_x3_plan left in `plan_workspace`: the values pass writes the (column, lane, value) records into their planned places, and
- * the product's mover waves build every reduction step's dP^T tile in LDS from the records of that step's source group (pool_bwd_x3.hip,
- * k_gemm_x3rf) — ogl_pool_bwd_x3_apply's 226 MB image (Reddit rung; 89 % zeros) is neither written nor read.
- * x_img: the row-major bf16x3 image of x WITH the ones slot ([x_img_rows + zero row, K + 1], < 4 GB), x_rows (nullable) the block's
- * source ids (ids outside [0, x_nrows) read the zero row).  `workspace` (ogl_pool_bwd_x3_dw_workspace_bytes) receives the split-K slabs
- * [nsplit][d][ws_ld] (column K = the bias gradient); defer = 0: they are summed into dw / db (slab order); defer = 1: left to the
- * consumer (ogl_adam_step_multi_slabs / ogl_x3_slab_reduce), *nsplit_out / *ws_ld_out say how many and how wide.
- * Same results as ogl_pool_bwd_x3_apply + ogl_linear_bwd_weight_x3k up to the order of fp32 additions. */
-int64_t ogl_pool_bwd_x3_dw_workspace_bytes(int64_t n_src, int d, int K);
-int ogl_pool_bwd_x3_dw(const float* dout, int64_t ldo, int64_t n_dst, int fanout, int d, int64_t n_src, const void* plan_workspace,
-                       int64_t plan_workspace_bytes, const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int K,
-                       float* dw, int64_t lddw, float* db, void* workspace, int64_t workspace_bytes, int defer, int* nsplit_out,
-                       int64_t* ws_ld_out, ogl_stream_t stream);
 int64_t ogl_x3_row_bytes(int64_t K);
 int64_t ogl_x3_image_bytes(int64_t rows, int64_t K);
 int ogl_x3_split(const float* src, int64_t ld, const int64_t* rows, int64_t nrows, int64_t R, int K, int append,
@@ -342,9 +317,8 @@ int ogl_x3_debug_early_a(int on);
  * accumulator sees its reduction steps in the same order either way: the same bits.  Returns the old value. */
 int ogl_x3_debug_stagger(int on);
 /* Diagnostics (A/B of tile shapes inside one process, tests): cfg >= 0 pins the tile of the plain / EXT one-split row-major image
- * products — 0: 256 x 128, 1: 128 x 128, 2: 192 x 128, 3: 160 x 128, 4: 256 x 160 (plain only; EXT falls back to 0) — and -1
- * returns to the automatic choice.  Every tile computes every output element with the same sequence of MFMAs: results are
- * bit-identical across tiles.  OGL_EINVAL outside [-1, 4].  Not part of the hot path. */
+ * products — 0: 256 x 128, 1: 128 x 128, 2: 192 x 128 — and -1 returns to the automatic choice.  Every tile computes every output
+ * element with the same sequence of MFMAs: results are bit-identical across tiles.  OGL_EINVAL outside [-1, 2].  Not part of the hot path. */
 int ogl_x3_debug_tile(int cfg);
 /* Diagnostics (bench.py): the image-GEMM instantiation the LAST ogl_linear_*_x3* call launched, template arguments as written at the
  * launch site (trailing defaults omitted), e.g. "k_gemm_x3p<4, 2, 2, 2, 2, false, true>"; "" before the first launch.  Static storage.
@@ -354,18 +328,6 @@ const char* ogl_x3_last_kernel(void);
 
 int ogl_linear_fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
                       const void* w_img, int N, int relu, float* y, int64_t ldy, ogl_stream_t stream);
-/* ogl_linear_fwd_x3 that also emits the SIGN BITS of its output: relu_bits[i * relu_bits_ld + g] bit c = [y[i, 4 g + c] > 0], one byte
- * per 4-column group (relu_bits_ld >= ceil(N / 4) bytes) — the ReLU mask of relu(fc_pool(x)) for the mean-pool backward
- * (R/train/graphsage/pytorch/aggregator_dgl.py:181-185; consumed by ogl_reduce_bwd_seg_apply_bits), 1/16 of the fp32 matrix. */
-int ogl_linear_fwd_x3_bits(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
-                           const void* w_img, int N, int relu, float* y, int64_t ldy, unsigned char* relu_bits, int64_t relu_bits_ld,
-                           ogl_stream_t stream);
-/* ogl_linear_fwd_x3 with a zero fill riding in the launch: zero_buf[0 .. zero_bytes) (16-byte aligned, a multiple of 16 bytes) is cleared by
- * the blocks of the persistent grid that own no tile (a one-round product leaves CUs idle), or by a fill launch in front of the product when
- * there are fewer than 16 of them.  The atomic-scatter target of the output layer's backward, cleared beside that layer's fc_pool product. */
-int ogl_linear_fwd_x3_zero(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
-                           const void* w_img, int N, int relu, float* y, int64_t ldy, void* zero_buf, int64_t zero_bytes,
-                           ogl_stream_t stream);
 /* ogl_linear_fwd_x3 with a second A part, a per-row addend and / or an image of the output (k_gemm_x3p<..., EXT>):
  *   y[i, :] = act( x_img[row(i)] . w[:, part 1]^T + x2_img[row2(i)] . w[:, part 2]^T + add[add_rows[i], :] )
  * - x2_img (nullable, K2 = 0): the second part of a K-concatenated product — fc_self(x[dst]) + fc_neigh(neigh) of the combine
@@ -426,9 +388,6 @@ int64_t ogl_linear_bwd_weight_x3_workspace_bytes(int64_t M, int N, int K);
  * read k-major like x — no transposed image at all).
  * x image [x_img_rows (+ zero row), K (+ 1 when has_ones: the ones slot, which yields db / db2 = both copies of the bias
  * gradient)]; x_rows (nullable) gathers M rows, ids outside [0, x_nrows) read the zero row.  Images must be < 4 GB. */
-/* diagnostic: 1 / 0 = the UNEVEN split-K plan of the wide k-major weight gradient on / off, -1 = the environment's choice
- * (OGL_BWWK_UNEVEN=1; off by default: measured slower inside the train step, linear_x3.hip); returns the old value. */
-int ogl_x3_debug_bwwk_uneven(int on);
 int64_t ogl_linear_bwd_weight_x3k_workspace_bytes(int64_t M, int64_t interleave, int N, int K, int has_ones);
 int ogl_linear_bwd_weight_x3k(const void* dyT_img, int64_t interleave, const void* x_img, int64_t x_img_rows, const int64_t* x_rows,
                               int64_t x_nrows, int64_t M, int N, int K, int has_ones, float* dw, int64_t lddw, float* db, float* db2,
@@ -674,17 +633,6 @@ int ogl_out_layer_fwd_ce(const float* P, int64_t ldp, int64_t n_src, const int32
                          const int64_t* label_table, int64_t n_labels, const int64_t* label_ids, float grad_scale, float* loss_rows,
                          float* dlogits, int64_t lddl, float* loss_mean, unsigned int* counter, float* zero_buf, int64_t zero_floats,
                          int rows_per_block, ogl_stream_t stream);
-/* ogl_out_layer_fwd_ce + ogl_out_layer_bwd_inputs in ONE launch (round 5): the gradient of the mean loss w.r.t. the logits is known as
- * soon as a row's softmax is (grad_scale = 1 / n_dst), so the block that finished destination d also computes dx_self[d, :] =
- * dlogits[d] . w_self (stored) and dlogits[d] . w_neigh, added to dP[argmax[d, c], c] where neigh[d, c] > 0 (float atomics; dP [n_src, K]
- * ZEROED BY THE CALLER before this launch — no zero fill rides here).  rows_per_block 0 / 1 / 2.  The backward of the loss node then
- * starts at the pooled rows' gradient (autograd of R/train/graphsage/pytorch/model.py:105-107,198-200 through the last SAGEConv). */
-int ogl_out_layer_fwd_ce_bwd(const float* P, int64_t ldp, int64_t n_src, const int32_t* idx, int64_t n_dst, int fanout, const float* h,
-                             int64_t ldh, int K, const float* w_self, int64_t ldws, const float* w_neigh, int64_t ldwn, const float* b_self,
-                             const float* b_neigh, int N, float* neigh, int64_t ldn, int32_t* argmax, float* logits, int64_t ldl,
-                             const int64_t* label_table, int64_t n_labels, const int64_t* label_ids, float grad_scale, float* loss_rows,
-                             float* dlogits, int64_t lddl, float* loss_mean, unsigned int* counter, int rows_per_block, float* dx_self,
-                             int64_t ldx, float* dP, int64_t ldpp, ogl_stream_t stream);
 /* The in-repo 'mean' layer as the LAST layer of a train step (round 5): ogl_out_layer_fwd_ce with the neighbour MEAN over the sampled rows
  * of P = the layer's own input (slot order, divided by fanout: ogl_reduce_fwd(OGL_REDUCE_MEAN)'s arithmetic) and w_self / w_neigh = the two
  * column blocks of fc_neigh's concat weight (ldws = ldwn = its width; b_neigh NULL) — mailbox.mean + torch.cat + nn.Linear +

@@ -35,6 +35,8 @@ SIGNATURES = {
     "ogl_build_block": (_i, [_p, _i64, _p, _i, _p, _p, _p, _p, _i64, _p]),
     "ogl_gather_rows": (_i, [_p, _i64, _i64, _p, _i64, _i, _p, _i64, _p]),
     "ogl_fill_zero": (_i, [_p, _i64, _p]),
+    "ogl_stream_copy": (_i, [_p, _p, _i64, _p]),
+    "ogl_reduce_debug_half": (_i, [_i]),
     "ogl_gather_i64": (_i, [_p, _i64, _p, _i64, _p, _p]),
     "ogl_dropout_rows": (_i, [_p, _i64, _p, _i64, _i64, _i, _d, _u64, _u64, _p, _i64, _p]),
     "ogl_reduce_fwd": (_i, [_p, _i64, _i64, _p, _p, _i64, _i, _i, _i, _p, _i64, _p, _p]),
@@ -45,7 +47,6 @@ SIGNATURES = {
     "ogl_reduce_bwd_seg_workspace_bytes": (_i64, [_i64, _i, _i, _i64]),
     "ogl_reduce_bwd_seg_plan": (_i, [_p, _i64, _i, _i64, _p, _i64, _p]),
     "ogl_reduce_bwd_seg_apply": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p]),
-    "ogl_reduce_bwd_seg_apply_bits": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p]),
     "ogl_linear_fwd": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p,
                             _p, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p]),
     "ogl_linear_fwd_dual_bias": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p, _p,
@@ -68,9 +69,6 @@ SIGNATURES = {
     "ogl_pool_bwd_x3": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i, _i, _i64, _p, _p, _i64, _p]),
     "ogl_pool_bwd_x3_plan": (_i, [_p, _p, _i64, _p, _i64, _i, _i, _i64, _p, _i64, _p]),
     "ogl_pool_bwd_x3_apply": (_i, [_p, _i64, _p, _i64, _i, _i, _i64, _p, _p, _i64, _p]),
-    "ogl_pool_bwd_x3_dw_workspace_bytes": (_i64, [_i64, _i, _i]),
-    "ogl_pool_bwd_x3_dw": (_i, [_p, _i64, _i64, _i, _i, _i64, _p, _i64, _p, _i64, _p, _i64, _i, _p, _i64, _p, _p, _i64, _i,
-                              C.POINTER(C.c_int), C.POINTER(C.c_int64), _p]),
     "ogl_x3_row_bytes": (_i64, [_i64]),
     "ogl_x3_image_bytes": (_i64, [_i64, _i64]),
     "ogl_x3_split": (_i, [_p, _i64, _p, _i64, _i64, _i, _i, _p, _p, _p]),
@@ -78,24 +76,16 @@ SIGNATURES = {
     "ogl_x3_debug_stamps": (_i, [_p, _i]),
     "ogl_x3_debug_early_a": (_i, [_i]),
     "ogl_x3_debug_stagger": (_i, [_i]),
-    "ogl_x3_debug_bwwk_uneven": (_i, [_i]),
     "ogl_x3_debug_tile": (_i, [_i]),
     "ogl_x3_last_kernel": (C.c_char_p, []),
     "ogl_out_layer_fwd_ce_fits": (_i, [_i64, _i, _i, _i]),
     "ogl_out_layer_fwd_ce": (_i, [_p, _i64, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p, _i64, _p, _p, _i, _p, _i64, _p, _p, _i64,
                                   _p, _i64, _p, _f, _p, _p, _i64, _p, _p, _p, _i64, _i, _p]),
-    "ogl_out_layer_fwd_ce_bwd": (_i, [_p, _i64, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p, _i64, _p, _p, _i, _p, _i64, _p, _p, _i64,
-                                      _p, _i64, _p, _f, _p, _p, _i64, _p, _p, _i, _p, _i64, _p, _i64, _p]),
     "ogl_loss_mean_finish": (_i, [_p, _i64, _p, _p]),
     "ogl_out_layer_fwd_ce_mean": (_i, [_p, _i64, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p, _i64, _p, _p, _i, _p, _i64, _p, _i64,
                                        _p, _i64, _p, _f, _p, _p, _i64, _p, _p, _i, _p]),
     "ogl_out_layer_bwd_inputs_dense": (_i, [_p, _i64, _i64, _i, _i, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p]),
     "ogl_linear_fwd_x3": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i, _i, _p, _i64, _p]),
-    "ogl_reduce_fwd_img_plan": (_i, [_p, _i64, _i64, _p, _i64, _i, _i, _p, _i64, _p, _p, _p, _p, _p]),
-    "ogl_pool_bwd_x3_plan_slots": (_i, [_i64, _i, _i, _i64, _p, _p]),
-    "ogl_pool_bwd_x3_plan_finish": (_i, [_p, _i64, _i, _i, _i64, _p, _i64, _p]),
-    "ogl_linear_fwd_x3_zero": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i, _i, _p, _i64, _p, _i64, _p]),
-    "ogl_linear_fwd_x3_bits": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i, _i, _p, _i64, _p, _i64, _p]),
     "ogl_linear_fwd_x3_ext": (_i, [_p, _i64, _p, _i64, _i, _p, _i64, _p, _i64, _i, _i64, _p, _i, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i, _p, _i64,
                                    _p, _p]),
     "ogl_x3_split_multi": (_i, [_p, _i, _p]),

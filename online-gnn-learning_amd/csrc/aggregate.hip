@@ -28,32 +28,20 @@ __device__ __forceinline__ int64_t bcast_idx(int64_t v, int j) {
 // IMG: ALSO write the bf16x3 image of the output (row-major, n_dst + 1 rows, reduction length d; x6_arith.h) — the A operand of the
 // projection that consumes the reduced rows, without a split pass of its own: a lane's float4 is half a 16-byte piece of each
 // plane (3 x 8-byte stores beside the 16-byte fp32 store).
-// PB (max with argmax, S <= 63, d <= 1023, parts in {1, 2, 4}: every wave of a destination sits in one block): ALSO the bucket pass of the
-// layer-0 pool backward's plan (pool_bwd_x3.hip, k_pool_bucket<true>) — the wave knows the winner's SLOT and the sign of the maximum, so
-// the destination's columns are counting-sorted by slot here (LDS counters shared by the destination's waves): pb_off[w][0 .. S] = the
-// slot offsets, pb_col[w][...] = the columns in slot order (10 bits column, 6 bits slot); columns whose maximum is not positive own nothing.
-template <int OP, typename IdxT, bool ARG, int NCH, bool IMG = false, int U = (NCH == 1 ? 8 : 4), bool PB = false>
+template <int OP, typename IdxT, bool ARG, int NCH, bool IMG = false, int U = (NCH == 1 ? 8 : 4)>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK)
 k_reduce_fwd_v4(const float* __restrict__ src, int64_t lds, int64_t n_src, const IdxT* __restrict__ idx,
                 int64_t n_dst, int S, int d, float* __restrict__ out, int64_t ldo,
                 int32_t* __restrict__ argmax, int parts, unsigned char* __restrict__ img = nullptr, int64_t img_row_bytes = 0,
-                const int64_t* __restrict__ rows = nullptr, int64_t n_rows = 0, unsigned short* __restrict__ pb_off = nullptr,
-                unsigned short* __restrict__ pb_col = nullptr) {
+                const int64_t* __restrict__ rows = nullptr, int64_t n_rows = 0) {
   // rows (optional): idx holds positions into `rows`, the reduced row is src[rows[idx]] — a block's local indices over the
   // resident table through the block's source ids (one more dependent load per WAVE, not per neighbour row)
-  __shared__ int pb_cnt[PB ? WAVES_PER_BLOCK : 1][64];
-  __shared__ unsigned short pb_row[PB ? WAVES_PER_BLOCK : 1][PB ? 1024 : 2];   // PB: a destination's columns in slot order, staged
   const int lane = threadIdx.x & 63;
   const int64_t wg = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   const int64_t w = wg / parts;
   const bool live = w < n_dst;
-  if (!PB && !live) return;
+  if (!live) return;
   const int part = (int)(wg - w * parts);
-  const int dl = (int)(threadIdx.x >> 6) / parts;          // PB: the destination's place inside the block
-  int sl[PB ? NCH : 1][4];                                 // PB: the sampling slot of every column's winner
-  if constexpr (PB) {
-    if (part == 0) pb_cnt[dl][lane] = 0;
-  }
   const int dall4 = (d + 3) >> 2, cper = (dall4 + parts - 1) / parts;
   const int c0 = part * cper;
   const int d4 = min(dall4, c0 + cper);            // this wave's slice: float4 columns [c0, d4)
@@ -102,12 +90,12 @@ k_reduce_fwd_v4(const float* __restrict__ src, int64_t lds, int64_t n_src, const
             if (!any) {
               acc[c] = v[u][c];
               if (ARG) arg[c][0] = arg[c][1] = arg[c][2] = arg[c][3] = (int)r[u];
-              if constexpr (PB) sl[c][0] = sl[c][1] = sl[c][2] = sl[c][3] = s0 + j0 + u;
+             
             } else {
-              if (v[u][c].x > acc[c].x) { acc[c].x = v[u][c].x; if (ARG) arg[c][0] = (int)r[u]; if constexpr (PB) sl[c][0] = s0 + j0 + u; }
-              if (v[u][c].y > acc[c].y) { acc[c].y = v[u][c].y; if (ARG) arg[c][1] = (int)r[u]; if constexpr (PB) sl[c][1] = s0 + j0 + u; }
-              if (v[u][c].z > acc[c].z) { acc[c].z = v[u][c].z; if (ARG) arg[c][2] = (int)r[u]; if constexpr (PB) sl[c][2] = s0 + j0 + u; }
-              if (v[u][c].w > acc[c].w) { acc[c].w = v[u][c].w; if (ARG) arg[c][3] = (int)r[u]; if constexpr (PB) sl[c][3] = s0 + j0 + u; }
+              if (v[u][c].x > acc[c].x) { acc[c].x = v[u][c].x; if (ARG) arg[c][0] = (int)r[u]; }
+              if (v[u][c].y > acc[c].y) { acc[c].y = v[u][c].y; if (ARG) arg[c][1] = (int)r[u]; }
+              if (v[u][c].z > acc[c].z) { acc[c].z = v[u][c].z; if (ARG) arg[c][2] = (int)r[u]; }
+              if (v[u][c].w > acc[c].w) { acc[c].w = v[u][c].w; if (ARG) arg[c][3] = (int)r[u]; }
             }
           } else {
             acc[c].x += v[u][c].x; acc[c].y += v[u][c].y; acc[c].z += v[u][c].z; acc[c].w += v[u][c].w;
@@ -115,51 +103,6 @@ k_reduce_fwd_v4(const float* __restrict__ src, int64_t lds, int64_t n_src, const
         }
         any = true;
       }
-    }
-  }
-  if constexpr (PB) {
-    // (a wave past the last destination takes part in the barriers only)
-    __syncthreads();                                        // the counters are cleared
-    int pos[NCH][4], slt[NCH][4];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int ch = c0 + c * 64 + lane;
-      const float av[4] = {acc[c].x, acc[c].y, acc[c].z, acc[c].w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bool own = live && any && ch < d4 && ch * 4 + e < d && av[e] > 0.f && arg[c][e] >= 0;
-        slt[c][e] = own ? sl[c][e] : -1;
-        pos[c][e] = own ? atomicAdd(&pb_cnt[dl][sl[c][e] & 63], 1) : 0;
-      }
-    }
-    __syncthreads();                                        // every column of the destination is counted
-    if (part == 0) {                                        // exclusive scan of the S bucket sizes (lane j = slot j, lane S = the end)
-      const int cn = pb_cnt[dl][lane];
-      int sc = cn;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(sc, o);
-        if (lane >= o) sc += t;
-      }
-      if (live && lane <= S) pb_off[w * (S + 1) + lane] = (unsigned short)(sc - cn);
-      pb_cnt[dl][lane] = sc - cn;
-    }
-    __syncthreads();
-    // the row goes through LDS: 2-byte stores scattered over a 1.2 KB row cost the aggregator 10 us as global stores (112 k wave
-    // instructions of 64 distinct addresses); staged, the destination's waves write it out in 128-byte runs
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int ch = c0 + c * 64 + lane;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (slt[c][e] >= 0) pb_row[dl][pb_cnt[dl][slt[c][e]] + pos[c][e]] = (unsigned short)((ch * 4 + e) | (slt[c][e] << 10));
-    }
-    __syncthreads();
-    if (!live) return;
-    {
-      const int n = pb_cnt[dl][S];                          // (the end offset: lane S of the scan)
-      unsigned short* const row = pb_col + w * (int64_t)d;
-      for (int i = part * 64 + lane; i < n; i += parts * 64) row[i] = pb_row[dl][i];
     }
   }
   const float fS = (float)S;
@@ -210,6 +153,101 @@ k_reduce_fwd_v4(const float* __restrict__ src, int64_t lds, int64_t n_src, const
   }
 }
 
+// ---- narrow rows (d <= 128 floats, max without argmax: the inference passes over a cached projection table of <= 512-byte rows) ----
+// A 512-byte row fills HALF a wave's 16-byte-per-lane load: with one destination per wave, lanes 32-63 re-read the row's last float4.
+// Here the two halves of the wave walk the destination's EVEN and ODD sampling slots: lane l reads float4 column l & 31 of the row of
+// slot 2 u + (l >> 5), 2 U rows in flight per wave-instruction pair instead of U, and the halves meet in one shuffle at the end.  max
+// is exact and order-free (no argmax here: the first-winner rule of the training path needs the slot order), so the result has the bits
+// of k_reduce_fwd_v4.  The arxiv-like priority forward (D = 128, 87 MB table in the Infinity Cache): see DESIGN.md section 4.
+template <typename IdxT, bool IMG, int U = 8>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK)
+k_reduce_fwd_max_half(const float* __restrict__ src, int64_t lds, int64_t n_src, const IdxT* __restrict__ idx, int64_t n_dst, int S, int d,
+                      float* __restrict__ out, int64_t ldo, unsigned char* __restrict__ img, int64_t img_row_bytes,
+                      const int64_t* __restrict__ rows, int64_t n_rows) {
+  const int lane = threadIdx.x & 63, hl = lane & 31, hh = lane >> 5;
+  const int64_t w = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (w >= n_dst) return;
+  const int d4 = (d + 3) >> 2;                       // <= 32
+  const int col = min(hl, d4 - 1);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool any = false;                                  // (per half)
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int sc = min(64, S - s0);
+    IdxT mine = lane < sc ? idx[w * S + s0 + lane] : (IdxT)-1;
+    if (rows) {
+      const int64_t m = (int64_t)mine;
+      mine = (m >= 0 && m < n_rows) ? (IdxT)rows[m] : (IdxT)-1;
+    }
+    for (int j0 = 0; j0 < sc; j0 += 2 * U) {
+      // (as in k_reduce_fwd_v4: every row id first, then every load, nothing between them that needs a wait; a missing row reads
+      // row 0 and is skipped)
+      float4 v[U];
+      bool ok[U];
+      const float4* rp[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int je = j0 + 2 * u, jo = je + 1;
+        const int64_t qe = bcast_idx(mine, je < sc ? je : sc - 1), qo = bcast_idx(mine, jo < sc ? jo : sc - 1);
+        const int64_t q = hh ? qo : qe;
+        ok[u] = ((hh ? jo : je) < sc) && q >= 0 && q < n_src;
+        rp[u] = (const float4*)(src + (ok[u] ? q : 0) * lds);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = rp[u][col];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;                        // (uniform over a half)
+        if (!any) acc = v[u];
+        else {
+          acc.x = v[u].x > acc.x ? v[u].x : acc.x; acc.y = v[u].y > acc.y ? v[u].y : acc.y;
+          acc.z = v[u].z > acc.z ? v[u].z : acc.z; acc.w = v[u].w > acc.w ? v[u].w : acc.w;
+        }
+        any = true;
+      }
+    }
+  }
+  // the halves meet: the lower half (even slots, slot 0 among them) keeps its value on ties, as the sequential walk does
+  float4 o;
+  o.x = __shfl_xor(acc.x, 32); o.y = __shfl_xor(acc.y, 32); o.z = __shfl_xor(acc.z, 32); o.w = __shfl_xor(acc.w, 32);
+  const bool any_o = __shfl_xor((int)any, 32) != 0;
+  if (any && any_o) {
+    acc.x = o.x > acc.x ? o.x : acc.x; acc.y = o.y > acc.y ? o.y : acc.y; acc.z = o.z > acc.z ? o.z : acc.z; acc.w = o.w > acc.w ? o.w : acc.w;
+  } else if (any_o) acc = o;
+  if (hh == 0 && hl < d4) {
+    const int ch = hl;
+    if (!IMG || out) ((float4*)(out + w * ldo))[ch] = acc;
+    if (IMG) {
+      const int b4 = ch * 4;
+      const float e0 = b4 < d ? acc.x : 0.f, e1 = b4 + 1 < d ? acc.y : 0.f, e2 = b4 + 2 < d ? acc.z : 0.f, e3 = b4 + 3 < d ? acc.w : 0.f;
+      unsigned h0, m0, l0, h1, m1, l1;
+      split3(e0, e1, h0, m0, l0); split3(e2, e3, h1, m1, l1);
+      unsigned char* rq = img + w * img_row_bytes + (int64_t)(ch >> 3) * 192 + (ch & 1) * 8;
+      const int pc = (ch & 7) >> 1;
+      *(uint2*)(rq + x3_piece(pc, 0) * 16) = make_uint2(h0, h1);
+      *(uint2*)(rq + x3_piece(pc, 1) * 16) = make_uint2(m0, m1);
+      *(uint2*)(rq + x3_piece(pc, 2) * 16) = make_uint2(l0, l1);
+      if (w == n_dst - 1) {                               // the image's all-zero row sits behind the last destination
+        rq += img_row_bytes;
+        *(uint2*)(rq + x3_piece(pc, 0) * 16) = make_uint2(0u, 0u);
+        *(uint2*)(rq + x3_piece(pc, 1) * 16) = make_uint2(0u, 0u);
+        *(uint2*)(rq + x3_piece(pc, 2) * 16) = make_uint2(0u, 0u);
+      }
+    }
+  }
+  if (IMG) {
+    const int kpad4 = (int)(img_row_bytes / 192) * 8;       // float4 columns of the padded image row
+    for (int ch = d4 + lane; ch < kpad4; ch += 64) {
+      for (int rr = 0; rr < (w == n_dst - 1 ? 2 : 1); ++rr) {
+        unsigned char* rq = img + (w + rr) * img_row_bytes + (int64_t)(ch >> 3) * 192 + (ch & 1) * 8;
+        const int pc = (ch & 7) >> 1;
+        *(uint2*)(rq + x3_piece(pc, 0) * 16) = make_uint2(0u, 0u);
+        *(uint2*)(rq + x3_piece(pc, 1) * 16) = make_uint2(0u, 0u);
+        *(uint2*)(rq + x3_piece(pc, 2) * 16) = make_uint2(0u, 0u);
+      }
+    }
+  }
+}
+
 // ---- generic forward (any d / alignment): one wave per destination, dword accesses ------------
 template <int OP, typename IdxT, bool ARG>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK)
@@ -240,11 +278,13 @@ k_reduce_fwd_generic(const float* __restrict__ src, int64_t lds, int64_t n_src, 
   }
 }
 
+static int g_reduce_half = 1;      // (ogl_reduce_debug_half: tests and A/B runs pin the one-row-per-wave form)
+extern "C" int ogl_reduce_debug_half(int on) { const int old = g_reduce_half; g_reduce_half = on ? 1 : 0; return old; }
+
 template <int OP, typename IdxT, bool ARG>
 static int launch_reduce_fwd(const float* src, int64_t lds, int64_t n_src, const IdxT* idx, int64_t n_dst,
                              int S, int d, float* out, int64_t ldo, int32_t* argmax, hipStream_t stream,
-                             unsigned char* img = nullptr, const int64_t* rows = nullptr, int64_t n_rows = 0,
-                             unsigned short* pb_off = nullptr, unsigned short* pb_col = nullptr) {
+                             unsigned char* img = nullptr, const int64_t* rows = nullptr, int64_t n_rows = 0) {
   dim3 grid((unsigned)ogl_cdiv(n_dst, WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
   const int d4 = (d + 3) / 4;
   const bool vec = (lds % 4 == 0) && (ldo % 4 == 0) && (lds >= 4 * d4) && (ldo >= 4 * d4) &&
@@ -255,22 +295,18 @@ static int launch_reduce_fwd(const float* src, int64_t lds, int64_t n_src, const
   // 3 slices 0.0586 ms; 512 x 600: 1 slice 0.0168 ms, 2 slices 0.0148 ms, 4 slices 0.0137 ms.
   int parts = 1;
   while (vec && parts < 4 && n_dst * parts < 2 * 256 * 20 && d4 / (parts + 1) >= 32) ++parts;
-  if (pb_off && parts == 3) parts = 2;                    // (PB: the waves of a destination share a block)
   const int cper = (d4 + parts - 1) / parts;
   if (vec) grid.x = (unsigned)ogl_cdiv(n_dst * parts, WAVES_PER_BLOCK);
-  if (pb_off) {
-    if constexpr (OP == OGL_REDUCE_MAX && ARG && std::is_same<IdxT, int32_t>::value) {
-      if (!vec || !img || !pb_col || S > 63 || d > 1023 || rows) return OGL_EINVAL;
-      const int64_t irb = ogl_cdiv(d, 32) * 192;
-      if (cper <= 64) hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 1, true, 8, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb, rows, n_rows, pb_off, pb_col);
-      else if (cper <= 128) hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 2, true, 4, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb, rows, n_rows, pb_off, pb_col);
-      else if (cper <= 192) hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 3, true, 4, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb, rows, n_rows, pb_off, pb_col);
-      else hipLaunchKernelGGL((k_reduce_fwd_v4<OP, IdxT, ARG, 4, true, 4, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, argmax, parts, img, irb, rows, n_rows, pb_off, pb_col);
-      OGL_CHECK_LAUNCH();
-      return OGL_OK;
-    } else {
-      return OGL_EINVAL;
-    }
+  // rows of <= 512 bytes, max without argmax (the inference passes): two rows per wave-instruction (k_reduce_fwd_max_half)
+  const bool half = vec && OP == OGL_REDUCE_MAX && !ARG && d4 <= 32 && S >= 2 && g_reduce_half;
+  if (half) {
+    grid.x = (unsigned)ogl_cdiv(n_dst, WAVES_PER_BLOCK);
+    const int64_t irb = ogl_cdiv(d, 32) * 192;
+    if (img) hipLaunchKernelGGL((k_reduce_fwd_max_half<IdxT, true>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, img, irb, rows, n_rows);
+    else if (rows) return OGL_EINVAL;
+    else hipLaunchKernelGGL((k_reduce_fwd_max_half<IdxT, false>), grid, block, 0, stream, src, lds, n_src, idx, n_dst, S, d, out, ldo, (unsigned char*)nullptr, (int64_t)0, (const int64_t*)nullptr, (int64_t)0);
+    OGL_CHECK_LAUNCH();
+    return OGL_OK;
   }
   if (img) {
     if (!vec) return OGL_EINVAL;     // the image form exists for the vectorised kernels (the 'pool' / 'meanpool' layers)
@@ -334,21 +370,6 @@ extern "C" int ogl_reduce_fwd(const float* src, int64_t lds, int64_t n_src, cons
 // ogl_reduce_fwd(OGL_REDUCE_MAX) that ALSO writes the bf16x3 image of `out` (what ogl_x3_split(out) would build; n_dst + 1 image
 // rows over a reduction of d): the A operand of the projection that consumes the pooled rows.  16-byte-aligned, 4-float-strided
 // operands only (what this package allocates).
-// ogl_reduce_fwd_img (max, int32 indices, argmax kept) that ALSO runs the bucket pass of the layer-0 pool backward's plan: plan_off /
-// plan_col = the two arrays ogl_pool_bwd_x3_plan_slots locates inside a plan workspace; ogl_pool_bwd_x3_plan_finish does the rest.
-// fanout <= 63, d <= 640 (the plan's limits), 16-byte aligned rows (the vectorised kernel only).
-extern "C" int ogl_reduce_fwd_img_plan(const float* src, int64_t lds, int64_t n_src, const int32_t* idx32, int64_t n_dst, int fanout, int d,
-                                       float* out, int64_t ldo, int32_t* argmax, void* image, void* plan_off, void* plan_col,
-                                       ogl_stream_t stream) {
-  if (n_dst <= 0 || fanout <= 0 || fanout > 63 || d <= 0 || d > 640 || n_src <= 0 || lds < d || (out && ldo < d)) return OGL_EINVAL;
-  if (!src || !idx32 || !argmax || !image || ((uintptr_t)image & 15) || !plan_off || !plan_col || ((uintptr_t)plan_off & 1) ||
-      ((uintptr_t)plan_col & 1))
-    return OGL_EINVAL;
-  return launch_reduce_fwd<OGL_REDUCE_MAX, int32_t, true>(src, lds, n_src, idx32, n_dst, fanout, d, out, ldo, argmax, (hipStream_t)stream,
-                                                          (unsigned char*)image, nullptr, 0, (unsigned short*)plan_off,
-                                                          (unsigned short*)plan_col);
-}
-
 extern "C" int ogl_reduce_fwd_img(const float* src, int64_t lds, int64_t n_src, const int32_t* idx32, const int64_t* idx64,
                                   int64_t n_dst, int fanout, int d, float* out, int64_t ldo, int32_t* argmax, void* image,
                                   ogl_stream_t stream) {
@@ -533,6 +554,27 @@ extern "C" int ogl_fill_zero(void* ptr, int64_t bytes, ogl_stream_t stream) {
   }
   hipLaunchKernelGGL(k_zero16, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(ogl_cdiv(n16, 256), 2048))), dim3(256), 0, (hipStream_t)stream,
                      (uint4*)(b + head), n16, b + head + n16 * 16, (int)ntail);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+// ---- stream copy: the box's own streaming rate (measurement only: bench.py's `hbm_copy_measured`) ----
+// A float4 copy, four 16-byte loads in flight per lane, 2 048 blocks of 256 lanes: what MI355X_MICROARCH.md quotes as the achievable
+// HBM rate of this part (~6.3 TB/s of read + write bytes) — a torch copy_ of the same buffers reads 4.7 TB/s.
+__global__ void __launch_bounds__(256) k_stream_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+extern "C" int ogl_stream_copy(const void* src, void* dst, int64_t bytes, ogl_stream_t stream) {
+  if (bytes < 0 || (bytes & 15) || (bytes > 0 && (!src || !dst)) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return OGL_EINVAL;
+  if (bytes == 0) return OGL_OK;
+  hipLaunchKernelGGL(k_stream_copy, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, bytes / 16);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }

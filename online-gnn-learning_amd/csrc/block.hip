@@ -1072,8 +1072,7 @@ extern "C" int ogl_sample_blocks_small_fill(const ogl_graph_t* g, const int64_t*
   a.src1 = src1; a.lidx1 = lidx1; a.src0 = src0; a.lidx0 = lidx0;
   a.counts = counts; a.seq_dev = seq_dev; a.counts_host = (volatile int64_t*)counts_host_mapped;
   a.fill0 = src0_fill_multiple;
-  static const bool reg_off = getenv("OGL_SAMPLE_REG_BUILD") && getenv("OGL_SAMPLE_REG_BUILD")[0] == '0';
-  a.reg_build = reg_off ? 0 : 1;
+  a.reg_build = 1;
   hipLaunchKernelGGL(k_sample_blocks_small, dim3(1), dim3(BLK_SCAN), 0, (hipStream_t)stream, a);
   OGL_CHECK_LAUNCH();
   return OGL_OK;

@@ -52,12 +52,6 @@ struct X3Args {
   int force_cfg0;               // the k-major weight gradient on the 256 x 128 tile (x3_bwwk_cfg0)
   int defer_reduce;             // host side only: launch_x3 leaves the split-K slabs unreduced (the optimiser launch sums them)
   int xcd_slabs;                // k_gemm_x3p: deal WHOLE split-K slabs to the XCDs (see decode)
-  // UNEVEN split-K (k_gemm_x3p<4, 2, 2, 2, 2, false, true>: the wide k-major weight gradient): the LAST row tile holds few valid rows
-  // (602 = 256 + 256 + 90); its movers do not fetch the A rows past the last valid 16-row block (skip_pad: nothing reads them — the
-  // multipliers skip those blocks), so its steps are shorter, and it gets nsplit2 < nsplit LONGER reduction ranges (steps_per_split2).
-  // The slabs [nsplit2, nsplit) of its rows are written as zeros by its first nsplit - nsplit2 blocks: consumers sum nsplit slabs.
-  int nsplit2, steps_per_split2;
-  int skip_pad;
   unsigned long long* stamps;   // diagnostics only (ogl_x3_debug_stamps): per block {s_memtime, s_memrealtime} at entry and exit
   // ---- extensions, k_gemm_x3p<..., EXT = true> only (forward products, nsplit == 1) ----
   X3Operand a2;                 // optional SECOND part of the A operand: reduction steps [nsteps1, nsteps) read a2 (its own image,
@@ -80,17 +74,10 @@ struct X3Args {
   unsigned char* out_img;       // optional: ALSO write the bf16x3 image of the (activated) output, row-major, reduction length
   int64_t out_row_bytes;        //   N (+ 1 when out_append_ones: 1.0 at column N) — the A operand of the next layer's product
   int out_append_ones;
-  // ---- plain forward products (nsplit == 1): optional SIGN BITS of the output, one byte per 4-column group (bit c = [y[i, 4 g + c] > 0]),
-  // row stride relu_bits_ld bytes — the ReLU mask a later backward pass needs, 1/16 of the fp32 matrix it would otherwise re-read ----
-  unsigned char* relu_bits; int64_t relu_bits_ld;
   // ---- k_gemm_x3p<..., BK, AK> only: a TWO-PART B operand by column tile — tiles tj >= NJ1 read the row-major image b2 (its own row
   // gather / zero row / column groups) where tiles tj < NJ1 read b: both weight gradients of a dual-input projection, dy^T . x[rows] and
   // dy^T . x2, as ONE product over [x[rows] | x2] without a concatenated image (output columns: part 1 at 0, part 2 at 128 NJ1) ----
   X3Operand b2; int bk2_groups; int NJ1;
-  // ---- a ZERO FILL riding in the launch: the blocks of the persistent grid that own no tile (a one-round product of 185 tiles leaves 71
-  // of 256 CUs idle) clear zero_buf[0 .. zero_n16) 16-byte words — launch_x3 takes it only when such blocks exist, else fills first ----
-  uint4* zero_buf; int64_t zero_n16;
-  int bd_dbg;                   // k_gemm_x3bd, timing experiments only (OGL_X3_BD_DBG; wrong results): 1 = no B loads, 2 = no A DMA
   int stagger;                  // k_gemm_x3p: multiplier waves 4-7 run a step's LAST column block behind the next step's opening barrier
 };
 
@@ -397,54 +384,38 @@ __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64) k_gemm_x3(X3Args g) {
 // One barrier per step.  Three waves per SIMD = 168 registers per wave: the multipliers keep accumulators (64), A
 // fragments (48) and a two-deep B ring (24), the movers their piece offsets.  Images must be < 4 GB (32-bit offsets).
 // Measured against k_gemm_x3: matrix pipe busy 73 % of the in-kernel cycles instead of 56 %.
-// RH / CH: one more 16-row / 16-column block per wave tile on top of TM / TN pairs (tiles of 160 rows or 160 columns).  Such a stage is
-// not a whole number of 256-lane instructions (UNEVEN): the last instruction index is issued by the first mover waves only, and
-// the instruction that straddles the A / B boundary takes its operand per WAVE (piece counts are multiples of 64).
 // EA ("early A", two-stage rings only): the multipliers hold a step's A fragments in registers from the step's first MFMA group on, so
 // the A part of that stage buffer (2/3 of its bytes) is dead for the rest of the step.  A second barrier per step (`mid`), behind the
 // first column block's MFMAs, hands it back to the movers, who issue the A part of stage n + 2 there and then — most of a step earlier
 // than the B part of its stage.  Without it a step is one DMA latency long whatever the matrix pipe does (the movers issue stage
 // n + 1 at the barrier that opens step n and wait for all of it): 2.25-2.33 us per 256 x 128 x 32 step against ~1.6 us of MFMA issue.
-template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool EXT = false, bool BK = false, bool AK = false, int RH = 0, int CH = 0,
-          bool EA = false>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool EXT = false, bool BK = false, bool AK = false, bool EA = false>
 __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(WAVES_M * WAVES_N == 8, "eight multiplier waves + four mover waves");
-  constexpr int RB = TM * 2 + RH, CB = TN * 2 + CH, WROWS = RB * 16, WCOLS = CB * 16;
+  constexpr int RB = TM * 2, CB = TN * 2, WROWS = RB * 16, WCOLS = CB * 16;
   constexpr int BM = WAVES_M * WROWS, BN = WAVES_N * WCOLS;
   constexpr int PIECES = (BM + BN) * 12, STAGE = PIECES * 16, A_PIECES = BM * 12;
-  constexpr bool UNEVEN = (PIECES % 256) != 0 || (A_PIECES % 256) != 0;
-  static_assert(PIECES % 64 == 0 && A_PIECES % 64 == 0, "pieces split evenly over the lanes of a mover wave");
-  static_assert(!UNEVEN || (NSTAGE == 2 && !BK && !AK), "uneven stages: two-stage ring (vmcnt(0) waits), row-major operands");
-  constexpr int NLP = (PIECES + 255) / 256;                // 18 pieces per mover lane per stage (256 x 128)
-  constexpr int NLP_A = (A_PIECES + 255) / 256;            // the first 12 are A rows (UNEVEN: instruction NLP_A - 1 is A for some waves only)
+  static_assert(PIECES % 256 == 0 && A_PIECES % 256 == 0, "a stage is a whole number of 256-lane instructions, each all-A or all-B");
+  constexpr int NLP = PIECES / 256;                        // 18 pieces per mover lane per stage (256 x 128)
+  constexpr int NLP_A = A_PIECES / 256;                    // the first 12 are A rows
   constexpr int NSTORE = RB * CB;
   static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
   static_assert(NSTAGE * STAGE <= 160 * 1024, "the ring fits one CU");
   static_assert(!BK || (BN == 128 && NLP - NLP_A == 6), "k-major B: 128 columns = 48 (plane, 8-column chunk) pairs x 32 rows per stage");
   static_assert(!(BK && EXT), "the k-major B operand belongs to the weight-gradient products");
   static_assert(!AK || (BK && BM == 128 && NLP_A == 6), "k-major A: with a k-major B, 128 rows");
-  static_assert(!EA || (NSTAGE == 2 && !UNEVEN && !AK), "early A: a two-stage ring whose instructions are all-A or all-B");
+  static_assert(!EA || (NSTAGE == 2 && !AK), "early A: a two-stage ring");
   constexpr int B_BASE = A_PIECES * 16;                    // byte offset of the B part inside a stage
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool mover = wid >= 8;
-  const int T = g.nsplit2 ? (g.NI - 1) * g.NJ * g.nsplit + g.NJ * g.nsplit2 : g.NI * g.NJ * g.nsplit;
+  const int T = g.NI * g.NJ * g.nsplit;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   const int chunk_begin = xcd * (T >> 3) + min(xcd, T & 7), chunk_len = (T >> 3) + (xcd < (T & 7) ? 1 : 0);
-  if (slot >= chunk_len) {
-    if (g.zero_n16 > 0) {
-      // idle blocks, numbered densely over the XCDs: rank = idle blocks of the XCDs before this one + this block's place among its own
-      int rank = slot - chunk_len;
-      for (int x = 0; x < xcd; ++x) rank += nslots - ((T >> 3) + (x < (T & 7) ? 1 : 0));
-      const int64_t idle = (int64_t)gridDim.x - T;
-      const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-      for (int64_t i = (int64_t)rank * 768 + tid; i < g.zero_n16; i += idle * 768) g.zero_buf[i] = z;
-    }
-    return;
-  }
+  if (slot >= chunk_len) return;
   if (g.stamps && tid == 0) {
     g.stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
     g.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
@@ -458,25 +429,6 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
   auto decode = [&](int logical) __attribute__((always_inline)) {
     Tile t;
     int tile;
-    if (BK && !AK && NSTAGE == 2 && g.nsplit2) {
-      // uneven: "full" slabs of (NI - 1) NJ tiles and "short" slabs of NJ tiles (the last row tile); an XCD takes floor(nsplit / 8)
-      // whole full slabs and floor(nsplit2 / 8) whole short ones, the slabs left over are dealt tile by tile (full ones first)
-      const int t1 = (g.NI - 1) * g.NJ, t2 = g.NJ, q1 = g.nsplit >> 3, q2 = g.nsplit2 >> 3;
-      const int whole = q1 * t1 + q2 * t2, local = logical - chunk_begin;
-      bool shrt;
-      if (local < q1 * t1) { shrt = false; t.split = xcd * q1 + local / t1; tile = local % t1; }
-      else if (local < whole) { shrt = true; t.split = xcd * q2 + (local - q1 * t1) / t2; tile = (local - q1 * t1) % t2; }
-      else {
-        const int e = (chunk_begin - xcd * whole) + (local - whole), r1 = (g.nsplit - 8 * q1) * t1;
-        if (e < r1) { shrt = false; t.split = 8 * q1 + e / t1; tile = e % t1; }
-        else { shrt = true; t.split = 8 * q2 + (e - r1) / t2; tile = (e - r1) % t2; }
-      }
-      if (shrt) { t.ti = g.NI - 1; t.tj = tile; } else { t.ti = tile / g.NJ; t.tj = tile - t.ti * g.NJ; }
-      const int sps = shrt ? g.steps_per_split2 : g.steps_per_split;
-      t.ks_begin = min(g.nsteps, t.split * sps);
-      t.ks_end = min(g.nsteps, t.ks_begin + sps);
-      return t;
-    }
     if (g.xcd_slabs) {
       const int local = logical - chunk_begin, whole = q_slabs * tiles_per_slab;
       if (local < whole) {
@@ -513,9 +465,7 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
   if (mover) {
     // ---- movers: the fetch cursor walks the block's stages in order, across tiles -------------------------------------
     const int ml = (wid - 8) * 64 + lane;                  // lane of the 256-lane mover group
-    const int wbase = (wid - 8) * 64;                      // this wave's first piece inside an instruction (wave-uniform)
-    auto u_is_a = [&](int u) __attribute__((always_inline)) { return UNEVEN ? u * 256 + wbase < A_PIECES : u < NLP_A; };
-    auto u_live = [&](int u) __attribute__((always_inline)) { return !UNEVEN || u * 256 + wbase < PIECES; };
+    auto u_is_a = [&](int u) __attribute__((always_inline)) { return u < NLP_A; };
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)g.a.img, 0, 0xFFFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)g.b.img, 0, 0xFFFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_a2 =
@@ -531,7 +481,6 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
     const unsigned step_b = (unsigned)g.b.step_bytes;
     unsigned src[NLP];
     int cur_ti = 0;
-    int a_vr = BM;                                         // skip_pad: A rows >= a_vr of the fetch cursor's tile are not fetched
     // BK: a step's B tile is 32 reduction rows x 768 contiguous bytes (48 pieces: 4 column groups).  One DMA instruction of mover
     // wave w moves 4 rows x 16 consecutive pieces (4 runs of 256 B): instruction ub covers rows 8w + 4 (ub / 3) + 0..3, pieces
     // 16 (ub % 3) + 0..15; lane (rsub, i) = (lane >> 4, lane & 15) takes piece 16 t + (i ^ f) of row rsub, f = 2 rsub | 8 (w & 1):
@@ -614,10 +563,6 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         src[u] = (unsigned)(off + j * 16);
       }
       if (EXT && doA) { part2 = false; step_a = (unsigned)g.a.step_bytes; cur_ti = t.ti; }
-      if (NSTAGE == 2 && !AK && !UNEVEN && !EA && g.skip_pad) {
-        const int64_t left = g.M - (int64_t)t.ti * BM;
-        a_vr = left >= BM ? BM : (int)((left + 15) & ~(int64_t)15);
-      }
     };
     // fetch cursors: (tile, reduction step) of the next A part / the next B part to be issued (EA: A runs one stage ahead of B;
     // otherwise they move together and only `ca` is advanced)
@@ -666,14 +611,11 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         unsigned so = src[u];
         if (BK && u >= NLP_A) so += ((bk_zmask >> (u - NLP_A)) & 1) ? bk_zero : bk_row[(u - NLP_A) / 3];
         if (AK && u < NLP_A) so += ((ak_zmask >> u) & 1) ? ak_zero : ak_row[u / 3];
-        const bool ia = u_is_a(u);                           // (compile-time unless UNEVEN; then uniform over the wave)
-        // (skip_pad: an A instruction whose first row is past the tile's last valid 16-row block moves only rows no multiplier reads)
-        const bool pad = NSTAGE == 2 && !AK && !UNEVEN && !EA && u < NLP_A && (u * 256 + wbase) / 12 >= a_vr;
+        const bool ia = u_is_a(u);
         const bool mine = !EA || (u < NLP_A ? doA : doB);    // (EA: this call issues one operand's part)
         if (mine) {
-          if (u_live(u) && !pad)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ia ? rs_a : rs_b,
-                                                     (lptr_t)(smem + (stage % NSTAGE) * STAGE + (u * 256 + (wid - 8) * 64) * 16), 16, so, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ia ? rs_a : rs_b,
+                                                   (lptr_t)(smem + (stage % NSTAGE) * STAGE + (u * 256 + (wid - 8) * 64) * 16), 16, so, 0, 0, 0);
           if (!(BK && u >= NLP_A) && !(AK && u < NLP_A)) src[u] += ia ? step_a : step_b;
         }
       });
@@ -998,9 +940,6 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
             }
           }
           if (EXT && g.y_keep && rok && !g.y_keep[row]) continue;   // (a row only the next layer's image product reads)
-          if (!EXT && !BK && g.relu_bits && rok && col < g.N)
-            g.relu_bits[row * g.relu_bits_ld + (col >> 2)] = (unsigned char)((v[0] > 0.f ? 1 : 0) | (v[1] > 0.f ? 2 : 0) | (v[2] > 0.f ? 4 : 0) |
-                                                                             (v[3] > 0.f ? 8 : 0));
           const bool vec = rok && vec_ok && !has_oc && col < g.N && col + 4 <= ldd;
           if (vec) *(float4*)(dst + row * ldd + col) = make_float4(v[0], v[1], v[2], v[3]);
           else if (rok && col < g.N) {
@@ -1041,20 +980,8 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
         for (int sp = 0; sp < 3; ++sp) a[t][sp] = bf16x8{};
 #pragma unroll
       for (int sp = 0; sp < 3; ++sp) { b[0][sp] = bf16x8{}; b[1][sp] = bf16x8{}; }
-      if constexpr (BK && !AK && NSTAGE == 2) {
-        // uneven split-K: slab nsplit2 + j of the short row tile's rows is all zeros, written by that tile's j-th block (a second
-        // pass of the SAME epilogue code over the cleared accumulators)
-        Tile te = tc;
-        const int reps = (g.nsplit2 && tc.ti == g.NI - 1 && tc.split < g.nsplit - g.nsplit2) ? 2 : 1;
-        for (int r = 0; r < reps; ++r) {
-          epilogue(te);
-          zero_acc();
-          te.split = g.nsplit2 + tc.split;
-        }
-      } else {
-        epilogue(tc);
-        zero_acc();
-      }
+      epilogue(tc);
+      zero_acc();
     }
     X3_PH(if (g.stamps && (wid == 0 || wid == 4) && lane == 0) for (int i = 0; i < 6; ++i) g.stamps[1024 + 32 * blockIdx.x + 2 * wid + i] = ph[i];)
   }
@@ -1062,238 +989,6 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
   if (g.stamps && tid == 0) {
     g.stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
     g.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
-  }
-#endif
-}
-
-// ---- B-DIRECT form (plain forward products, nsplit == 1): 4 multiplier waves + 4 mover waves ------------------------------------
-// The B operand of a forward product is the WEIGHT image: 2.2 MB for [602, 608], resident in every XCD's L2.  Here it never touches
-// the LDS: each multiplier wave loads the B fragments of its 64 columns straight into registers (buffer_load_dwordx4: lane (l15, quad)
-// reads the 16 bytes of image row `column`, plane p, chunk quad — exactly the MFMA operand), one whole step ahead, into the register
-// set the previous step multiplied from.  What that changes against k_gemm_x3p's 256 x 128 tile (per 32-deep step and CU):
-//   LDS bytes     264 KB (192 read as fragments + 72 written by the DMA)  ->  RB = 6: 108 KB (72 + 36) for 3/4 of the MACs
-//   ring          2 stages of 72 KB, early-A second barrier               ->  4 stages of 36 KB (A rows only), ONE barrier per step, the
-//                                                                             movers run three stages ahead
-//   multipliers   2 waves per SIMD of 64 x 64 (in lockstep behind the     ->  ONE wave per SIMD of (16 RB) x 64: accumulators 16 RB
-//                 barrier: both read fragments, then both want the pipe)      registers, B double buffer 96, A ring (two row blocks) 24
-// Each step: a[0] <- row block 0; for row block x: request row block x + 1's fragments, 24 MFMAs of row block x (4 column blocks x 6
-// terms, the same term order as every other tile: bit-identical results); the B loads of step n + 1 go out behind row block 0's MFMAs.
-// Full wave tiles run a branch-free step (every load counted by the compiler); edge tiles (rows past M, columns past N) a guarded one.
-template <int RB>
-__global__ void __launch_bounds__(512) k_gemm_x3bd(X3Args g) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int CB = 4, WROWS = RB * 16, WCOLS = 64, BM = 2 * WROWS, BN = 128;
-  constexpr int A_PIECES = BM * 12, STAGE = A_PIECES * 16;
-  constexpr int NSTAGE = (4 * STAGE <= 160 * 1024) ? 4 : 3;
-  static_assert(A_PIECES % 256 == 0, "a stage is a whole number of 256-lane instructions");
-  constexpr int NLP = A_PIECES / 256;                      // DMA instructions per mover lane and stage (9 / 12)
-  static_assert((NSTAGE - 2) * NLP < 64, "vmcnt immediate");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool mover = wid >= 4;
-  const int T = g.NI * g.NJ;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-  const int chunk_begin = xcd * (T >> 3) + min(xcd, T & 7), chunk_len = (T >> 3) + (xcd < (T & 7) ? 1 : 0);
-  if (slot >= chunk_len) return;
-  const int first = chunk_begin + slot, last_logical = chunk_begin + chunk_len;
-  int total = 0;
-  for (int l = first; l < last_logical; l += nslots) total += g.nsteps;
-  auto swz = [](int r) __attribute__((always_inline)) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; };
-  auto barrier = [&]() __attribute__((always_inline)) {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" ::: "memory");
-  };
-
-  if (mover) {
-    const int ml = (wid - 4) * 64 + lane;
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)g.a.img, 0, 0xFFFFFFFF, 0x00020000);
-    const unsigned step_a = (unsigned)g.a.step_bytes;
-    unsigned src[NLP];
-    auto make_src = [&](int ti) __attribute__((always_inline)) {
-      int64_t rid[NLP];
-#pragma unroll
-      for (int u = 0; u < NLP; ++u) {
-        const int64_t gi = (int64_t)ti * BM + (u * 256 + ml) / 12;
-        rid[u] = gi;
-        if (g.a.rows) rid[u] = g.a.rows[gi < g.M ? gi : g.M - 1];
-      }
-#pragma unroll
-      for (int u = 0; u < NLP; ++u) {
-        const int i = u * 256 + ml;
-        const int r = i / 12, jp = i - r * 12;
-        const int j = (jp & ~3) | ((jp & 3) ^ swz(r));
-        const bool ok = (int64_t)ti * BM + r < g.M && rid[u] >= 0 && rid[u] < g.a.nrows;
-        src[u] = (unsigned)((ok ? rid[u] : g.a.zero_row) * g.a.row_bytes + j * 16);
-      }
-    };
-    int a_logical = first, a_ks = 0;
-    make_src(first / g.NJ);
-    auto fetch = [&](int stage) __attribute__((always_inline)) {
-      static_for<0, NLP>([&](auto uc) __attribute__((always_inline)) {
-        constexpr int u = decltype(uc)::value;
-        if (!(g.bd_dbg & 2))
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(smem + (stage % NSTAGE) * STAGE + (u * 256 + (wid - 4) * 64) * 16), 16,
-                                                   src[u], 0, 0, 0);
-        src[u] += step_a;
-      });
-      if (++a_ks == g.nsteps && a_logical + nslots < last_logical) {
-        a_logical += nslots;
-        make_src(a_logical / g.NJ);
-        a_ks = 0;
-      }
-    };
-    // the movers run NSTAGE - 1 stages ahead: after the barrier that opens step n they issue stage n + NSTAGE - 1 into the buffer step
-    // n - 1 released and wait for stage n + 1 only (the youngest NSTAGE - 2 stages stay in flight across the barrier)
-    int issued = 0;
-    for (; issued < NSTAGE - 1 && issued < total; ++issued) fetch(issued);
-    if (issued == NSTAGE - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * NLP) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int n = 0; n < total; ++n) {
-      barrier();
-      if (issued < total) { fetch(issued); ++issued; }
-      if (issued == n + NSTAGE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * NLP) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  } else {
-    const int wm = wid >> 1, wn = wid & 1;
-    const int l15 = lane & 15, quad = lane >> 4;
-    int offp[3];
-    {
-      const int q = swz(l15);
-#pragma unroll
-      for (int sp = 0; sp < 3; ++sp) {
-        const int j = x3_piece(quad, sp);
-        offp[sp] = ((j & ~3) | ((j & 3) ^ q)) * 16;
-      }
-    }
-    const int rowa = (wm * WROWS + l15) * 192;
-    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)g.b.img, 0, 0xFFFFFFFF, 0x00020000);
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    f32x4 acc[RB][CB];
-    auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-      for (int a = 0; a < RB; ++a)
-#pragma unroll
-        for (int b = 0; b < CB; ++b)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.f;
-    };
-    bf16x8 bq[CB][3], bn[CB][3];                            // B fragments: the step's, and the next step's on their way
-    // the B fragments of (column tile tj, step ks) into `bn`: columns past N read the image's zero row
-    const int zoff = (int)(g.b.zero_row * g.b.row_bytes) + quad * 16, rb_b = (int)g.b.row_bytes, sb_b = (int)g.b.step_bytes;
-    auto b_issue = [&](int tj, int ks) __attribute__((always_inline)) {
-      const int so = ks * sb_b;
-      const int col0 = tj * BN + wn * WCOLS + l15;
-#pragma unroll
-      for (int y = 0; y < CB; ++y) {
-        const int col = col0 + y * 16;
-        const int vo = col < (int)g.N ? col * rb_b + quad * 16 : zoff;
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp)
-          bn[y][sp] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, vo + x3_piece(0, sp) * 16, so, 0));
-      }
-    };
-    auto b_take = [&]() __attribute__((always_inline)) {
-#pragma unroll
-      for (int y = 0; y < CB; ++y)
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp) bq[y][sp] = bn[y][sp];
-    };
-    // one step on stage buffer `buf`: GUARD = false for full wave tiles (no branch between the loads and the MFMAs)
-    auto step = [&](auto gc, int buf, int rbv, int cbv, int ntj, int nks) __attribute__((always_inline)) {
-      constexpr bool GUARD = decltype(gc)::value;
-      const unsigned char* st = smem + buf * STAGE + rowa;
-      bf16x8 a[2][3];
-#pragma unroll
-      for (int sp = 0; sp < 3; ++sp) a[0][sp] = *(const bf16x8*)(st + offp[sp]);
-      static_for<0, RB>([&](auto xc) __attribute__((always_inline)) {
-        constexpr int x = decltype(xc)::value;
-        if constexpr (x + 1 < RB) {
-#pragma unroll
-          for (int sp = 0; sp < 3; ++sp) a[(x + 1) & 1][sp] = *(const bf16x8*)(st + (x + 1) * 16 * 192 + offp[sp]);
-        }
-        if constexpr (x == 1) { if (!(g.bd_dbg & 1)) b_issue(ntj, nks); }
-        if constexpr (!GUARD) __builtin_amdgcn_sched_barrier(0);
-        // (term-major: ONE wave feeds its SIMD's matrix pipe, and the six terms of an accumulator depend on each other — the four
-        // column blocks' chains interleaved put four independent instructions between two dependent ones; per accumulator the term
-        // order is the one every other tile uses)
-        if (!GUARD || x < rbv) {
-          static_for<0, 6>([&](auto tc) __attribute__((always_inline)) {
-            constexpr int t = decltype(tc)::value;
-            constexpr int bt = t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0, at = (t == 0 || t == 3 || t == 5) ? 0 : (t == 1 || t == 4) ? 1 : 2;
-#pragma unroll
-            for (int y = 0; y < CB; ++y)
-              if (!GUARD || y < cbv) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[y][bt], a[x & 1][at], acc[x][y], 0, 0, 0);
-          });
-        }
-        if constexpr (!GUARD) __builtin_amdgcn_sched_barrier(0);
-      });
-      b_take();
-    };
-    auto epilogue = [&](int ti, int tj) __attribute__((always_inline)) {
-      int l15e = lane & 15, quade = lane >> 4;
-      asm volatile("" : "+v"(l15e), "+v"(quade));
-      float* const dst = g.C;
-      const int64_t ldd = g.ldc;
-      const bool vec_ok = (ldd & 3) == 0 && ((uintptr_t)dst & 15) == 0;
-#pragma unroll
-      for (int x = 0; x < RB; ++x)
-#pragma unroll
-        for (int y = 0; y < CB; ++y) {
-          const int64_t row = (int64_t)ti * BM + wm * WROWS + x * 16 + l15e, col = (int64_t)tj * BN + wn * WCOLS + y * 16 + 4 * quade;
-          float v[4] = {acc[x][y][0], acc[x][y][1], acc[x][y][2], acc[x][y][3]};
-          const bool rok = row < g.M;
-          if (g.relu) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
-          }
-          if (g.relu_bits && rok && col < g.N)
-            g.relu_bits[row * g.relu_bits_ld + (col >> 2)] = (unsigned char)((v[0] > 0.f ? 1 : 0) | (v[1] > 0.f ? 2 : 0) | (v[2] > 0.f ? 4 : 0) |
-                                                                             (v[3] > 0.f ? 8 : 0));
-          const bool vec = rok && vec_ok && col < g.N && col + 4 <= ldd;
-          if (vec) *(float4*)(dst + row * ldd + col) = make_float4(v[0], v[1], v[2], v[3]);
-          else if (rok && col < g.N) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-              if (col + c < g.N) dst[row * ldd + col + c] = v[c];
-          }
-        }
-    };
-    typedef std::integral_constant<bool, true> yes_t;
-    typedef std::integral_constant<bool, false> no_t;
-    zero_acc();
-    b_issue(first % g.NJ, 0);
-    b_take();
-    int n = 0;
-    for (int logical = first; logical < last_logical; logical += nslots) {
-      const int ti = logical / g.NJ, tj = logical - ti * g.NJ;
-      const bool more = logical + nslots < last_logical;
-      const int tj_next = more ? (logical + nslots) % g.NJ : tj;  // (the block's very last step reloads its tile's first: unused)
-      const int64_t rleft = g.M - ((int64_t)ti * BM + wm * WROWS), cleft = g.N - ((int64_t)tj * BN + wn * WCOLS);
-      const int rbv = rleft >= RB * 16 ? RB : (rleft <= 0 ? 0 : (int)((rleft + 15) >> 4));
-      const int cbv = cleft >= CB * 16 ? CB : (cleft <= 0 ? 0 : (int)((cleft + 15) >> 4));
-      if (rbv == RB && cbv == CB) {
-#pragma unroll 1
-        for (int ks = 0; ks < g.nsteps; ++ks, ++n) {
-          barrier();                                       // stage n has landed (the movers waited for it)
-          step(no_t(), n % NSTAGE, rbv, cbv, ks + 1 == g.nsteps ? tj_next : tj, ks + 1 == g.nsteps ? 0 : ks + 1);
-        }
-      } else {
-#pragma unroll 1
-        for (int ks = 0; ks < g.nsteps; ++ks, ++n) {
-          barrier();
-          step(yes_t(), n % NSTAGE, rbv, cbv, ks + 1 == g.nsteps ? tj_next : tj, ks + 1 == g.nsteps ? 0 : ks + 1);
-        }
-      }
-      epilogue(ti, tj);
-      zero_acc();
-    }
   }
 #endif
 }
@@ -1735,7 +1430,7 @@ extern "C" int ogl_x3_debug_stamps(void* buf, int reserved) {
 
 static int g_x3_tile = -1;
 extern "C" int ogl_x3_debug_tile(int cfg) {
-  if (cfg < -1 || cfg > 6) return OGL_EINVAL;
+  if (cfg < -1 || cfg > 2) return OGL_EINVAL;
   g_x3_tile = cfg;
   return OGL_OK;
 }
@@ -1754,11 +1449,6 @@ extern "C" const char* ogl_x3_last_kernel(void) { return g_x3_last_kernel; }
     hipLaunchKernelGGL((k_gemm_x3p<__VA_ARGS__>), grid, block, 0, stream, g);                     \
   } while (0)
 
-__global__ void __launch_bounds__(256) k_x3_zero16(uint4* __restrict__ p, int64_t n16) {
-  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = z;
-}
-
 static int launch_x3(X3Args& g, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0) return OGL_OK;
   g.stamps = g_x3_stamps;
@@ -1768,122 +1458,75 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
   const int64_t b_bytes = std::max((g.b.zero_row + 1) * g.b.row_bytes, (int64_t)g.nsteps * g.b.step_bytes);
   if (g.a2.img && (g.a2.zero_row + 1) * g.a2.row_bytes >= (1ll << 32)) return OGL_EINVAL;
   if (g.b2.img && ((g.b2.zero_row + 1) * g.b2.row_bytes >= (1ll << 32) || g.ak_groups <= 0 || g.NJ1 <= 0)) return OGL_EINVAL;
-  int cfg = x3_config(g.M, g.N);
+  int cfg = x3_config(g.M, g.N);                          // 0: 256 x 128, 1: 128 x 128, 2: 192 x 128
   const bool bk = g.bk_groups > 0;                        // row-major B over the reduction: 128 x 128 (three stages) or 256 x 128 (two)
   if (bk) cfg = g.force_cfg0 ? 0 : 1;
-  // producer / consumer kernels (k_gemm_x3p) whenever both images fit 32-bit offsets; OGL_X3_PC=0 forces the
-  // self-fetching kernels (experiments)
+  // producer / consumer kernels (k_gemm_x3p) whenever both images fit 32-bit offsets; OGL_X3_PC=0 forces the self-fetching kernel
+  // (the form images of 4 GB and more take) for the plain products: tests/test_gpu_x3.py::test_self_fetching_kernels_parity
   static const char* pc_env = getenv("OGL_X3_PC");
-  const bool pc = (bk || !(pc_env && pc_env[0] == '0')) && a_bytes < (1ll << 32) && b_bytes < (1ll << 32);
-  if (bk && (!pc || g.a2.img || g.add || g.out_img)) return OGL_EINVAL;
+  const bool ext = g.a2.img || g.add || g.out_img || g.mask || g.y_keep;
+  const bool pc = (bk || ext || !(pc_env && pc_env[0] == '0')) && a_bytes < (1ll << 32) && b_bytes < (1ll << 32);
+  if ((bk || ext) && !pc) return OGL_EINVAL;              // (k-major operands and the extensions live in the producer / consumer kernel)
+  if (bk && ext) return OGL_EINVAL;
   if (pc) {
     // a product that is one round of tiles either way takes the smallest tile that still is one round (one block per
     // CU): its critical path is one tile.  [7 199, 602] -> 600: 145 tiles of 256 x 128, 285 of 128 x 128, 190 of 192 x 128
     // (measured 45 us on 256 x 128, 37 us on 192 x 128).
-    static const char* c2_env = getenv("OGL_X3_CFG2");
-    // The 160-row and 160-column tiles are OFF unless OGL_X3_CFG3=1 / OGL_X3_CFG4=1 (or ogl_x3_debug_tile pins them).  Round 3, same
-    // box, alternating runs: launched back to back on cache-hot operands they are the fastest tiles of their shapes ([7 060, 600]:
-    // 32.6 us on 160 x 128 vs 34.4 on 192 x 128; [62 495, 602]: 211-215 us on 256 x 160 vs 221 on 256 x 128), but inside the replayed
-    // train step, where a launch's operands were written by the launch before it, the step is 1.5-3 % SLOWER with either of them
-    // (1.054-1.058 ms without, 1.064-1.081 / 1.067-1.077 / 1.081-1.089 with the 160-column / 160-row / both): 225 blocks x 54 KB
-    // of stage bytes are more L2 -> LDS traffic than 185 x 60 KB, and the CUs a one-round launch leaves idle are the ones the
-    // weight-gradient branch runs on.  PBR forward: no difference (0.2717-0.2745 ms either way).
-    static const char* c3_env = getenv("OGL_X3_CFG3");
-    static const char* c4_env = getenv("OGL_X3_CFG4");
-    const bool c3 = c3_env && c3_env[0] == '1', c4 = c4_env && c4_env[0] == '1';
-    if (!bk && g.nsplit == 1 && !(c2_env && c2_env[0] == '0') && ogl_cdiv(g.M, 256) * ogl_cdiv(g.N, 128) <= 256) {
-      // (a step's duration follows its DMA pieces — 12 per tile row and column: 3 072 / 3 456 / 3 840 / 4 608 for 128 / 160 / 192 /
-      // 256 rows x 128 columns — so the shortest one-round tile wins)
+    // (160-row and 160-column tiles were built in round 3 — the fastest tiles of their shapes alone, 1.5-3 % slower inside the
+    // replayed train step — and left the library in round 6: DESIGN.md section 8.)
+    if (!bk && g.nsplit == 1 && ogl_cdiv(g.M, 256) * ogl_cdiv(g.N, 128) <= 256) {
+      // (a step's duration follows its DMA pieces — 12 per tile row and column: 3 072 / 3 840 / 4 608 for 128 / 192 / 256 rows x 128
+      // columns — so the shortest one-round tile wins)
       if (ogl_cdiv(g.M, 128) * ogl_cdiv(g.N, 128) <= 256) cfg = 1;
-      else if (c3 && ogl_cdiv(g.M, 160) * ogl_cdiv(g.N, 128) <= 256) cfg = 3;
       else if (ogl_cdiv(g.M, 192) * ogl_cdiv(g.N, 128) <= 256) cfg = 2;
-    } else if (!bk && g.nsplit == 1 && !(c2_env && c2_env[0] == '0') && ogl_cdiv(g.M, 256) * ogl_cdiv(g.N, 128) <= 1024) {
+    } else if (!bk && g.nsplit == 1 && ogl_cdiv(g.M, 256) * ogl_cdiv(g.N, 128) <= 1024) {
       // a few rounds of tiles: the launch lasts (rounds of 256 tiles) x (tile height) / (the tile's efficiency in steady state:
-      // 1 : 0.93 : 0.895 : 0.86 for 256 : 192 : 160 : 128 rows) — e.g. [15 500, 600] is 2 rounds of 256 rows, 2 of 192 or 3 of 128
+      // 1 : 0.93 : 0.86 for 256 : 192 : 128 rows) — e.g. [15 500, 600] is 2 rounds of 256 rows, 2 of 192 or 3 of 128
       const int64_t nj = ogl_cdiv(g.N, 128);
       const double c0 = (double)ogl_cdiv(ogl_cdiv(g.M, 256) * nj, 256) * 256.0;
       const double c2 = (double)ogl_cdiv(ogl_cdiv(g.M, 192) * nj, 256) * 192.0 / 0.93;
-      const double c3r = c3 ? (double)ogl_cdiv(ogl_cdiv(g.M, 160) * nj, 256) * 160.0 / 0.895 : 1e30;
       const double c1 = (double)ogl_cdiv(ogl_cdiv(g.M, 128) * nj, 256) * 128.0 / 0.86;
-      cfg = (c0 <= c1 && c0 <= c2 && c0 <= c3r) ? 0 : (c2 <= c1 && c2 <= c3r) ? 2 : (c3r <= c1 ? 3 : 1);
+      cfg = (c0 <= c1 && c0 <= c2) ? 0 : (c2 <= c1 ? 2 : 1);
     }
-    // tall products whose columns pad no further on 160-column tiles than on 128-column ones (N = 600: 4 x 160 = 5 x 128) take
-    // 256 x 160: 4 992 DMA pieces per 256 x 160 x 32 step, 13 % fewer per MAC than 4 608 per 256 x 128 x 32
-    // (not the EXT form: its epilogue spills at 80 accumulators)
-    const bool ext = g.a2.img || g.add || g.out_img || g.mask || g.y_keep;
-    if (c4 && !bk && !ext && g.nsplit == 1 && cfg == 0 && ogl_cdiv(g.N, 160) * 160 <= ogl_cdiv(g.N, 128) * 128) cfg = 4;
-    if (g_x3_tile >= 0 && !bk && g.nsplit == 1) cfg = (g_x3_tile >= 4 && ext) ? 0 : g_x3_tile;
-    // the B-direct kernel (k_gemm_x3bd: 5 = 192 x 128, 6 = 256 x 128) for plain tall products: OGL_X3_BD=6 / 8 (rows / 32 of its wave tile)
-    static const char* bd_env = getenv("OGL_X3_BD");
-    const int bd = bd_env ? atoi(bd_env) : 0;
-    const bool plain = !bk && !ext && g.nsplit == 1 && !g.ones_col && !g.db && !g.db2;
-    if (plain && cfg == 0 && g_x3_tile < 0 && (bd == 6 || bd == 8)) cfg = bd == 8 ? 6 : 5;
-    if ((cfg == 5 || cfg == 6) && !plain) cfg = 0;
-    const int BMp = (cfg == 0 || cfg == 4 || cfg == 6) ? 256 : (cfg == 2 || cfg == 5) ? 192 : cfg == 3 ? 160 : 128;
+    if (g_x3_tile >= 0 && !bk && g.nsplit == 1) cfg = g_x3_tile;
+    const int BMp = cfg == 0 ? 256 : cfg == 2 ? 192 : 128;
     g.NI = (int)ogl_cdiv(g.M, BMp);
-    g.NJ = (int)ogl_cdiv(g.N, cfg == 4 ? 160 : 128);
-    if (g.nsplit2 && !(bk && cfg == 0 && g.ak_groups == 0 && g.NI >= 2)) g.nsplit2 = 0;   // (the uneven split lives in one instantiation)
-    const int64_t T = g.nsplit2 ? (int64_t)(g.NI - 1) * g.NJ * g.nsplit + (int64_t)g.NJ * g.nsplit2 : (int64_t)g.NI * g.NJ * g.nsplit;
+    g.NJ = (int)ogl_cdiv(g.N, 128);
+    const int64_t T = (int64_t)g.NI * g.NJ * g.nsplit;
     dim3 grid((unsigned)(8 * std::min<int64_t>(32, ogl_cdiv(T, 8)))), block(768);
-    if (g.zero_n16 > 0) {
-      if (cfg == 5 || cfg == 6 || T > 240) {
-        // (no CU left idle by the tiles — or the B-direct kernel, which has no such path: the fill goes first, as its own launch)
-        hipLaunchKernelGGL(k_x3_zero16, dim3((unsigned)std::min<int64_t>(2048, ogl_cdiv(g.zero_n16, 256))), dim3(256), 0, stream, g.zero_buf,
-                           g.zero_n16);
-        OGL_CHECK_LAUNCH();
-        g.zero_n16 = 0;
-      } else {
-        grid = dim3(256);                                   // one block per CU: the 256 - T blocks without a tile do the fill
-      }
-    }
+    // staggered multiplier waves (see k_gemm_x3p) unless switched off
+    static const char* stag_env = getenv("OGL_X3_STAGGER");
+    g.stagger = g_x3_stagger >= 0 ? g_x3_stagger : ((stag_env && stag_env[0] == '0') ? 0 : 1);
     // ring depth: two stages of the 256 x 128 tile fill the LDS (144 KB); the 128 x 128 tile takes three (144 KB): its movers
     // run two stages ahead (+4 % on the layer-0 weight gradient, whose operands both stream from HBM)
     // the two-stage tiles (256 x 128, 192 x 128) in their early-A form (template parameter EA) unless switched off
-    static const char* stag_env = getenv("OGL_X3_STAGGER");
-    g.stagger = g_x3_stagger >= 0 ? g_x3_stagger : ((stag_env && stag_env[0] == '0') ? 0 : 1);
     static const char* ea_env = getenv("OGL_X3_EARLY_A");
-    const bool ea = (g_x3_early_a >= 0 ? g_x3_early_a != 0 : !(ea_env && ea_env[0] == '0')) && !g.skip_pad;
-    if (cfg == 5 || cfg == 6) {
-      block = dim3(512);
-      static const char* bdd_env = getenv("OGL_X3_BD_DBG");
-      g.bd_dbg = bdd_env ? atoi(bdd_env) : 0;
-      if (cfg == 5) { g_x3_last_kernel = "k_gemm_x3bd<6>"; hipLaunchKernelGGL((k_gemm_x3bd<6>), grid, block, 0, stream, g); }
-      else { g_x3_last_kernel = "k_gemm_x3bd<8>"; hipLaunchKernelGGL((k_gemm_x3bd<8>), grid, block, 0, stream, g); }
-    } else if (bk && g.ak_groups > 0) X3P_LAUNCH(2, 4, 2, 1, 3, false, true, true);
-    else if (bk && cfg == 0) { if (ea) X3P_LAUNCH(4, 2, 2, 2, 2, false, true, false, 0, 0, true); else X3P_LAUNCH(4, 2, 2, 2, 2, false, true); }
+    const bool ea = g_x3_early_a >= 0 ? g_x3_early_a != 0 : !(ea_env && ea_env[0] == '0');
+    if (bk && g.ak_groups > 0) X3P_LAUNCH(2, 4, 2, 1, 3, false, true, true);
+    else if (bk && cfg == 0) { if (ea) X3P_LAUNCH(4, 2, 2, 2, 2, false, true, false, true); else X3P_LAUNCH(4, 2, 2, 2, 2, false, true); }
     else if (bk) X3P_LAUNCH(2, 4, 2, 1, 3, false, true);
     else if (ext) {
       if (g.nsplit != 1 || g.ones_col) return OGL_EINVAL;
-      if (cfg == 0) { if (ea) X3P_LAUNCH(4, 2, 2, 2, 2, true, false, false, 0, 0, true); else X3P_LAUNCH(4, 2, 2, 2, 2, true); }
-      else if (cfg == 3) X3P_LAUNCH(2, 4, 2, 1, 2, true, false, false, 1, 0);
-      else if (cfg == 2) { if (ea) X3P_LAUNCH(2, 4, 3, 1, 2, true, false, false, 0, 0, true); else X3P_LAUNCH(2, 4, 3, 1, 2, true); }
+      if (cfg == 0) { if (ea) X3P_LAUNCH(4, 2, 2, 2, 2, true, false, false, true); else X3P_LAUNCH(4, 2, 2, 2, 2, true); }
+      else if (cfg == 2) { if (ea) X3P_LAUNCH(2, 4, 3, 1, 2, true, false, false, true); else X3P_LAUNCH(2, 4, 3, 1, 2, true); }
       else X3P_LAUNCH(2, 4, 2, 1, 3, true);
-    } else if (cfg == 0) { if (ea) X3P_LAUNCH(4, 2, 2, 2, 2, false, false, false, 0, 0, true); else X3P_LAUNCH(4, 2, 2, 2, 2); }
-    else if (cfg == 4) X3P_LAUNCH(4, 2, 2, 2, 2, false, false, false, 0, 1);
-    else if (cfg == 3) X3P_LAUNCH(2, 4, 2, 1, 2, false, false, false, 1, 0);
-    else if (cfg == 2) { if (ea) X3P_LAUNCH(2, 4, 3, 1, 2, false, false, false, 0, 0, true); else X3P_LAUNCH(2, 4, 3, 1, 2); }
+    } else if (cfg == 0) { if (ea) X3P_LAUNCH(4, 2, 2, 2, 2, false, false, false, true); else X3P_LAUNCH(4, 2, 2, 2, 2); }
+    else if (cfg == 2) { if (ea) X3P_LAUNCH(2, 4, 3, 1, 2, false, false, false, true); else X3P_LAUNCH(2, 4, 3, 1, 2); }
     else X3P_LAUNCH(2, 4, 2, 1, 3);
     OGL_CHECK_LAUNCH();
   } else {
-  if (g.a2.img || g.add || g.out_img || g.mask) return OGL_EINVAL;   // the extensions live in the producer / consumer kernel (images < 4 GB)
-  if (g.zero_n16 > 0) {
-    hipLaunchKernelGGL(k_x3_zero16, dim3((unsigned)std::min<int64_t>(2048, ogl_cdiv(g.zero_n16, 256))), dim3(256), 0, stream, g.zero_buf, g.zero_n16);
+    // (the 256 x 128 form of this kernel needs 64-bit piece addresses on top of 128 accumulators: it does not fit 256 registers
+    // without spilling, so images of 4 GB and more take the 128 x 128 tile)
+    const int BM = 128, BN = 128;
+    g.NI = (int)ogl_cdiv(g.M, BM);
+    g.NJ = (int)ogl_cdiv(g.N, BN);
+    const int64_t T = (int64_t)g.NI * g.NJ * g.nsplit;
+    dim3 grid((unsigned)(8 * std::min<int64_t>(32, ogl_cdiv(T, 8)))), block(512);   // persistent: at most one block per CU
+    // DMA issue: spread between the MFMA groups for the 256 x 128 tile (2-3 % faster, A/B on one device), in one burst at
+    // the top of the step for the 128 x 128 tile (its steps are too short to hide a late piece: spread measured 9 % slower)
+    g_x3_last_kernel = "k_gemm_x3<2, 4, 2, 1, false>";
+    hipLaunchKernelGGL((k_gemm_x3<2, 4, 2, 1, false>), grid, block, 0, stream, g);
     OGL_CHECK_LAUNCH();
-    g.zero_n16 = 0;
-  }
-  // (the 256 x 128 form of this kernel needs 64-bit piece addresses on top of 128 accumulators: it does not fit 256 registers
-  // without spilling, so images of 4 GB and more take the 128 x 128 tile)
-  cfg = 1;
-  const int BM = 128, BN = 128;
-  g.NI = (int)ogl_cdiv(g.M, BM);
-  g.NJ = (int)ogl_cdiv(g.N, BN);
-  const int64_t T = (int64_t)g.NI * g.NJ * g.nsplit;
-  dim3 grid((unsigned)(8 * std::min<int64_t>(32, ogl_cdiv(T, 8)))), block(512);   // persistent: at most one block per CU
-  // DMA issue: spread between the MFMA groups for the 256 x 128 tile (2-3 % faster, A/B on one device), in one burst at
-  // the top of the step for the 128 x 128 tile (its steps are too short to hide a late piece: spread measured 9 % slower)
-  g_x3_last_kernel = "k_gemm_x3<2, 4, 2, 1, false>";
-  hipLaunchKernelGGL((k_gemm_x3<2, 4, 2, 1, false>), grid, block, 0, stream, g);
-  OGL_CHECK_LAUNCH();
   }
   if (g.nsplit > 1 && !g.defer_reduce) {
     hipLaunchKernelGGL(k_x3_splitk_reduce, dim3((unsigned)min((int64_t)2048, ogl_cdiv(g.M * g.N, 256))), dim3(256), 0, stream, g);
@@ -1915,52 +1558,12 @@ __global__ void __launch_bounds__(256) k_x3_image_tail(unsigned char* __restrict
   }
 }
 
-static int fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K, const void* w_img, int N,
-                  int relu, float* y, int64_t ldy, unsigned char* relu_bits, int64_t relu_bits_ld, ogl_stream_t stream,
-                  void* zero_buf = nullptr, int64_t zero_bytes = 0);
-
 extern "C" int ogl_linear_fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M,
                                  int K, const void* w_img, int N, int relu, float* y, int64_t ldy, ogl_stream_t stream) {
-  return fwd_x3(x_img, x_img_rows, x_rows, x_nrows, M, K, w_img, N, relu, y, ldy, nullptr, 0, stream);
-}
-
-// ... that ALSO emits the sign bits of its output: relu_bits[i * relu_bits_ld + g] bit c = [y[i, 4 g + c] > 0] (one byte per 4-column
-// group, relu_bits_ld >= ceil(N / 4) bytes) — the ReLU mask of relu(fc_pool(x)) that the mean-pool backward needs
-// (R/train/graphsage/pytorch/aggregator_dgl.py:181-185), 1/16 of the fp32 matrix it would otherwise read back.
-extern "C" int ogl_linear_fwd_x3_bits(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
-                                      const void* w_img, int N, int relu, float* y, int64_t ldy, unsigned char* relu_bits,
-                                      int64_t relu_bits_ld, ogl_stream_t stream) {
-  if (!relu_bits || relu_bits_ld < (N + 3) / 4) return OGL_EINVAL;
-  return fwd_x3(x_img, x_img_rows, x_rows, x_nrows, M, K, w_img, N, relu, y, ldy, relu_bits, relu_bits_ld, stream);
-}
-
-// ogl_linear_fwd_x3 with a ZERO FILL riding in the launch: zero_buf[0 .. zero_bytes) (16-byte aligned, a multiple of 16) is cleared by the
-// blocks of the product's grid that own no tile (a one-round product leaves CUs idle: [7 060, 600] x [600, 600] is 185 tiles on 256),
-// or by a fill launch in front of the product when there are none.  The scatter target of the output layer's backward, cleared beside
-// the fc_pool product of that layer (ops._SagePoolLossFn).
-extern "C" int ogl_linear_fwd_x3_zero(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K,
-                                      const void* w_img, int N, int relu, float* y, int64_t ldy, void* zero_buf, int64_t zero_bytes,
-                                      ogl_stream_t stream) {
-  return fwd_x3(x_img, x_img_rows, x_rows, x_nrows, M, K, w_img, N, relu, y, ldy, nullptr, 0, stream, zero_buf, zero_bytes);
-}
-
-static int fwd_x3(const void* x_img, int64_t x_img_rows, const int64_t* x_rows, int64_t x_nrows, int64_t M, int K, const void* w_img, int N,
-                  int relu, float* y, int64_t ldy, unsigned char* relu_bits, int64_t relu_bits_ld, ogl_stream_t stream, void* zero_buf,
-                  int64_t zero_bytes) {
   if (M < 0 || K <= 0 || N < 0 || x_img_rows < 0 || x_nrows < 0 || x_nrows > x_img_rows || ldy < N) return OGL_EINVAL;
-  if (zero_bytes < 0 || (zero_bytes > 0 && (!zero_buf || ((uintptr_t)zero_buf & 15) || (zero_bytes & 15)))) return OGL_EINVAL;
-  if (M == 0 || N == 0) {
-    if (zero_bytes > 0) {
-      hipLaunchKernelGGL(k_x3_zero16, dim3((unsigned)std::min<int64_t>(2048, ogl_cdiv(zero_bytes / 16, 256))), dim3(256), 0, (hipStream_t)stream,
-                         (uint4*)zero_buf, zero_bytes / 16);
-      OGL_CHECK_LAUNCH();
-    }
-    return OGL_OK;
-  }
+  if (M == 0 || N == 0) return OGL_OK;
   if (!x_img || !w_img || !y || (!x_rows && M > x_img_rows)) return OGL_EINVAL;
   X3Args g = X3Args();
-  g.relu_bits = relu_bits; g.relu_bits_ld = relu_bits_ld;
-  g.zero_buf = (uint4*)zero_buf; g.zero_n16 = zero_bytes / 16;
   const int64_t rb = ogl_cdiv(K, 32) * X3_GROUP_BYTES;
   g.a = X3Operand{(const unsigned char*)x_img, rb, X3_GROUP_BYTES, x_rows, x_rows ? x_nrows : x_img_rows, x_img_rows};
   g.b = X3Operand{(const unsigned char*)w_img, rb, X3_GROUP_BYTES, nullptr, N, N};
@@ -2044,67 +1647,25 @@ extern "C" int64_t ogl_linear_bwd_weight_x3_workspace_bytes(int64_t M, int N, in
 // two-stage tile: 72 KB of stage DMA per 256 x 128 x 32 step instead of 2 x 48 KB for the same work on 128 x 128 tiles — these
 // products are paced by the LDS-DMA issue rate, not by the matrix pipe (a tile whose padding blocks skip their MFMAs is no faster:
 // an uneven split-K that gave the 90-valid-row last tile longer reduction ranges was 15-40 % SLOWER, round 3) — measured
-// 0.2385 -> 0.2330 ms for the Reddit dW_pool0 in spite of 602 rows filling only 2.35 of 3 row tiles.  OGL_BWWK_CFG0=0: 128 x 128.
-static bool x3_bwwk_cfg0(int N, bool dy_rows) {
-  static const char* e = getenv("OGL_BWWK_CFG0");
-  return !(e && e[0] == '0') && !dy_rows && N >= 512;
-}
+// 0.2385 -> 0.2330 ms for the Reddit dW_pool0 in spite of 602 rows filling only 2.35 of 3 row tiles.
+static bool x3_bwwk_cfg0(int N, bool dy_rows) { return !dy_rows && N >= 512; }
 
-// The uneven plan is OFF unless OGL_BWWK_UNEVEN=1 (or ogl_x3_debug_bwwk_uneven(1): tests).  Measured, round 4, Reddit dW_pool0 (600 x 603
-// outputs over 62.6 k reduction rows; per-block durations by ogl_x3_debug_stamps, tools/dw_pool0_probe.py): even plan 17 x 15 blocks of
-// 116 steps: full-tile blocks 261 us, the 88-row tile's blocks 216 us (190 with skip_pad); uneven 19 x 10 blocks of 103 steps + 13 x 5 of
-// 151: 237 / 241 us per block — 8 % less at the block level — and yet the launch is no shorter alone (0.273 ms both) and 15 us LONGER
-// inside the train step (0.232 -> 0.247 ms; step 0.963 -> 0.976): with its own reduction ranges the short tile no longer shares its
-// B rows with the two tiles above it through the XCD's L2 (the gathered table rows are read a second time from the fabric), and a
-// full tile's step got slower too (2.25 -> 2.30 us).  skip_pad with the EVEN plan: inside the noise.  Round 3's attempt (no skip_pad)
-// was 15-40 % slower.
-static int g_bwwk_uneven = -1;
-extern "C" int ogl_x3_debug_bwwk_uneven(int on) { const int old = g_bwwk_uneven; g_bwwk_uneven = on; return old; }
-
-// nsplit2 (optional out): > 0 = the uneven plan (X3Args.nsplit2).  A step of the 256 x 128 tile issues 12 + 6 DMA instructions per mover
-// wave; a last row tile with v valid rows needs the first ceil16(v) * 12 / 256 of the 12 A ones, so its steps cost f = (that + 6) / 18 of
-// a full step (the products are paced by the DMA issue).  s1 ranges for the full row tiles, s2 <= s1 for the short one, chosen to
-// minimise max(steps / s1, f * steps / s2) over the plans that fit one block per CU.
-static void x3_bwwk_plan(int64_t steps, int N, int Kc, int* nsplit, int* sps, bool cfg0 = false, int* nsplit2 = nullptr, int* sps2 = nullptr) {
+// split plan of a k-major weight gradient: one round of blocks (one per CU), >= 8 steps per block.
+// (An UNEVEN plan — longer reduction ranges for a last row tile that holds few valid rows and skips their DMA — was built in rounds
+// 3-4, bit-checked, 8 % shorter per block and 15 us LONGER inside the train step: it left the library in round 6)
+static void x3_bwwk_plan(int64_t steps, int N, int Kc, int* nsplit, int* sps, bool cfg0 = false) {
   const int64_t tiles = ogl_cdiv(N, cfg0 ? 256 : 128) * ogl_cdiv(Kc, 128);
-  // (OGL_BWWK_BLOCKS: how many blocks a 128 x 128 k-major weight gradient may spread over — experiments; default one per CU)
-  static const char* be = getenv("OGL_BWWK_BLOCKS");
-  const int64_t cap = (be && !cfg0) ? std::max(32, atoi(be)) : 256;
-  int64_t s = cap / (tiles > 0 ? tiles : 1);
+  int64_t s = 256 / (tiles > 0 ? tiles : 1);
   if (s < 1) s = 1;
   if (steps / s < 8) s = steps / 8 > 0 ? steps / 8 : 1;
   *sps = (int)ogl_cdiv(steps > 0 ? steps : 1, s);
   *nsplit = (int)ogl_cdiv(steps > 0 ? steps : 1, *sps);
-  if (nsplit2) { *nsplit2 = 0; *sps2 = 0; }
-  static const char* ue = getenv("OGL_BWWK_UNEVEN");
-  const bool on = g_bwwk_uneven >= 0 ? g_bwwk_uneven != 0 : (ue && ue[0] == '1');
-  const int NI = (int)ogl_cdiv(N, 256), NJ = (int)ogl_cdiv(Kc, 128), v = N - 256 * (NI - 1);
-  if (!nsplit2 || !cfg0 || !on || NI < 2 || v > 160 || steps < 64) return;
-  const int v16 = (v + 15) & ~15;
-  static const char* fe = getenv("OGL_BWWK_UNEVEN_F");
-  const double f = fe ? atof(fe) : ((double)((v16 * 12 + 255) / 256) + 6.0) / 18.0;
-  double best = (double)*sps;                                // the even plan's makespan in full steps
-  int b1 = 0, b2 = 0;
-  for (int s1 = 2; s1 * (NI - 1) * NJ < 256; ++s1) {
-    int s2 = (256 - s1 * (NI - 1) * NJ) / NJ;
-    if (s2 > s1) s2 = s1;
-    if (s2 < 1 || s1 - s2 > s2) continue;
-    const int p1 = (int)ogl_cdiv(steps, s1), p2 = (int)ogl_cdiv(steps, s2);
-    if (p1 < 8 || (int64_t)(s1 - 1) * p1 >= steps || (int64_t)(s2 - 1) * p2 >= steps) continue;   // every range holds work
-    const double cost = std::max((double)p1, f * p2);
-    if (cost < best * 0.97) { best = cost; b1 = s1; b2 = s2; }
-  }
-  if (b1) {
-    *nsplit = b1; *sps = (int)ogl_cdiv(steps, b1);
-    *nsplit2 = b2; *sps2 = (int)ogl_cdiv(steps, b2);
-  }
 }
 
 extern "C" int64_t ogl_linear_bwd_weight_x3k_workspace_bytes(int64_t M, int64_t interleave, int N, int K, int has_ones) {
   if (M < 0 || N < 0 || K < 0 || interleave < -1) return OGL_EINVAL;
-  int nsplit, sps, nsplit2, sps2;
-  x3_bwwk_plan(interleave > 0 ? interleave : ogl_cdiv(M, 32), N, K + (has_ones ? 1 : 0), &nsplit, &sps, x3_bwwk_cfg0(N, interleave == -1),
-               &nsplit2, &sps2);
+  int nsplit, sps;
+  x3_bwwk_plan(interleave > 0 ? interleave : ogl_cdiv(M, 32), N, K + (has_ones ? 1 : 0), &nsplit, &sps, x3_bwwk_cfg0(N, interleave == -1));
   if (nsplit <= 1) return 16;
   return (int64_t)nsplit * N * ogl_round_up(K + 1, 4) * 4;
 }
@@ -2133,12 +1694,9 @@ static int bwd_weight_x3k(const void* dyT_img, int64_t interleave, const void* x
   g.M = N; g.N = Kc; g.ones_col = has_ones ? 1 : 0;
   g.nsteps = (int)(interleave ? interleave : ogl_cdiv(M, 32));
   g.C = dw; g.ldc = lddw; g.db = db; g.db2 = db2;
-  x3_bwwk_plan(g.nsteps, N, Kc, &g.nsplit, &g.steps_per_split, x3_bwwk_cfg0(N, dy_rows), &g.nsplit2, &g.steps_per_split2);
+  x3_bwwk_plan(g.nsteps, N, Kc, &g.nsplit, &g.steps_per_split, x3_bwwk_cfg0(N, dy_rows));
   g.force_cfg0 = x3_bwwk_cfg0(N, dy_rows) ? 1 : 0;
-  static const char* sp_env = getenv("OGL_BWWK_SKIP_PAD");                 // (experiments: 1 = also with the even plan, 0 = never)
-  g.skip_pad = sp_env ? (sp_env[0] == '1' && g.force_cfg0 ? 1 : 0) : (g.nsplit2 > 0 ? 1 : 0);
-  static const char* xs_env = getenv("OGL_BWWK_XCD_SLABS");
-  g.xcd_slabs = (!(xs_env && xs_env[0] == '0') && g.nsplit >= 8) ? 1 : 0;
+  g.xcd_slabs = g.nsplit >= 8 ? 1 : 0;                      // whole slabs per XCD (round 3: 1.014-1.017 -> 1.002-1.011 ms per step)
   if (g.nsplit > 1) {
     g.ws_ld = ogl_round_up(K + 1, 4);
     if (!workspace || workspace_bytes < (int64_t)g.nsplit * N * g.ws_ld * 4) return OGL_EWORKSPACE;
@@ -2215,8 +1773,7 @@ extern "C" int ogl_linear_bwd_weight_x3k_dual_slabs(const void* dy_img, int64_t 
   if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < (int64_t)g.nsplit * N * g.ws_ld * 4) return OGL_EWORKSPACE;
   g.ws = (float*)workspace;
   g.C = g.ws; g.ldc = g.ws_ld;                              // (never written: nsplit > 1)
-  static const char* xs_env = getenv("OGL_BWWK_XCD_SLABS");
-  g.xcd_slabs = (!(xs_env && xs_env[0] == '0') && g.nsplit >= 8) ? 1 : 0;
+  g.xcd_slabs = g.nsplit >= 8 ? 1 : 0;
   g.defer_reduce = 1;
   *nsplit_out = g.nsplit; *ws_ld_out = g.ws_ld; *col2_out = col2;
   return launch_x3(g, (hipStream_t)stream);

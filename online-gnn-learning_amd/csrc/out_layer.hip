@@ -283,9 +283,6 @@ struct OutFwdArgs {
   float grad_scale;
   float* loss_rows; float* dlogits; int64_t lddl; float* loss_mean; unsigned* counter;   // dlogits / loss_mean nullable
   float4* zero_buf; int64_t zero_n4;
-  // BWD (k_out_fwd_ce<R, true>): the combine's INPUT gradients from the same launch — dx_self[d, :] = dlogits[d] . Ws stored,
-  // dlogits[d] . Wn added to dP at the winners (float atomics into a matrix the CALLER zeroed before this launch)
-  float* dx_self; int64_t ldx; float* dP; int64_t ldpp;
 };
 
 __device__ __forceinline__ float of_wave_sum(float v) {
@@ -302,7 +299,7 @@ __device__ __forceinline__ float of_wave_max(float v) {
 // MEAN: the neighbour reduction is the MEAN over the S sampled rows of P (the in-repo 'mean' layer's aggregator over its own input,
 // R/train/graphsage/pytorch/aggregator_dgl.py:156-159: P = h, w_self / w_neigh = the two column blocks of fc_neigh's concat weight),
 // summed in slot order and divided by S as ogl_reduce_fwd(OGL_REDUCE_MEAN) does; no argmax.
-template <int R, bool BWD = false, bool MEAN = false>
+template <int R, bool MEAN = false>
 __global__ void __launch_bounds__(OF_THREADS) k_out_fwd_ce(OutFwdArgs a) {
   __shared__ float4 hrow[R][OF_MAX_K / 4], nrow[R][OF_MAX_K / 4];
   __shared__ int sidx[R][OF_MAX_S];
@@ -324,7 +321,6 @@ __global__ void __launch_bounds__(OF_THREADS) k_out_fwd_ce(OutFwdArgs a) {
   const bool cin = tid < K4;
   const int ch = cin ? tid : K4 - 1;
   // ---- A: neighbour max of the pooled rows, the destination's own row
-  int argk[BWD ? R : 1][4];                                             // (BWD: the winners of this thread's 4 columns, kept for phase D)
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int64_t d = d0 + r;
@@ -333,7 +329,6 @@ __global__ void __launch_bounds__(OF_THREADS) k_out_fwd_ce(OutFwdArgs a) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int arg[4] = {-1, -1, -1, -1};
     bool any = false;
-    (void)argk;
     for (int j0 = 0; j0 < a.S && live; j0 += OF_U) {
       float4 v[OF_U];
       int q[OF_U];
@@ -363,10 +358,6 @@ __global__ void __launch_bounds__(OF_THREADS) k_out_fwd_ce(OutFwdArgs a) {
         }
         any = true;
       }
-    }
-    if constexpr (BWD) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) argk[r][e] = arg[e];
     }
     if constexpr (MEAN) {
       if (any) { const float fS = (float)a.S; acc.x /= fS; acc.y /= fS; acc.z /= fS; acc.w /= fS; }
@@ -447,43 +438,6 @@ __global__ void __launch_bounds__(OF_THREADS) k_out_fwd_ce(OutFwdArgs a) {
     if (lane == 0) a.loss_rows[row] = ok ? lse - xy : 0.f;
     const float dl = a.grad_scale * (expf(x - lse) - ((ok && lane == (int)y) ? 1.f : 0.f));
     if (a.dlogits && lane < a.N) a.dlogits[row * a.lddl + lane] = dl;
-    if constexpr (BWD) slog[wv][lane] = lane < a.N ? dl : 0.f;           // (this wave read its logits above: the row now holds dlogits)
-  }
-  if constexpr (BWD) {
-    // ---- D: the input gradients of the combine (k_out_bwd_inputs' arithmetic: terms in class order, 16 row loads of W in flight)
-    __syncthreads();
-    if (cin) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int64_t d = d0 + r;
-        if (d >= a.n_dst) break;
-        float as[4] = {0.f, 0.f, 0.f, 0.f}, an[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int n0 = 0; n0 < a.N; n0 += 8) {
-          float4 ws[8], wn[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int n = n0 + u < a.N ? n0 + u : a.N - 1;              // a term past N re-reads the last row and is weighted by 0
-            ws[u] = ((const float4*)(a.Ws + (int64_t)n * a.ldws))[tid];
-            wn[u] = ((const float4*)(a.Wn + (int64_t)n * a.ldwn))[tid];
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const float g = n0 + u < a.N ? slog[r][(n0 + u) & 63] : 0.f;
-            as[0] += g * ws[u].x; as[1] += g * ws[u].y; as[2] += g * ws[u].z; as[3] += g * ws[u].w;
-            an[0] += g * wn[u].x; an[1] += g * wn[u].y; an[2] += g * wn[u].z; an[3] += g * wn[u].w;
-          }
-        }
-        ((float4*)(a.dx_self + d * a.ldx))[tid] = make_float4(as[0], as[1], as[2], as[3]);
-        const float4 nv = nrow[r][tid];
-        const float nb[4] = {nv.x, nv.y, nv.z, nv.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int w = argk[r][e];
-          if (w < 0 || w >= a.n_src || !(nb[e] > 0.f)) continue;        // the winner's ReLU mask (see k_reduce_bwd_max)
-          atomicAdd(&a.dP[(int64_t)w * a.ldpp + 4 * tid + e], an[e]);
-        }
-      }
-    }
   }
   if (!a.loss_mean) return;
   if (!a.counter) {
@@ -514,7 +468,7 @@ static int out_fwd_ce(const float* P, int64_t ldp, int64_t n_src, const int32_t*
                       int32_t* argmax, float* logits, int64_t ldl, const int64_t* label_table, int64_t n_labels,
                       const int64_t* label_ids, float grad_scale, float* loss_rows, float* dlogits, int64_t lddl,
                       float* loss_mean, unsigned int* counter, float* zero_buf, int64_t zero_floats, int rows_per_block,
-                      float* dx_self, int64_t ldx, float* dP, int64_t ldpp, ogl_stream_t stream, int mean = 0) {
+                      ogl_stream_t stream, int mean = 0) {
   if (!ogl_out_layer_fwd_ce_fits(n_dst, fanout, K, N) || n_src <= 0 || n_src < n_dst) return OGL_EINVAL;
   if (ldp < K || ldh < K || ldws < K || ldwn < K || ldn < K || ldl < N || (dlogits && lddl < N) || n_labels < 0) return OGL_EINVAL;
   if (!P || !idx || !h || !w_self || !w_neigh || !neigh || !logits || !label_table || !loss_rows) return OGL_EINVAL;
@@ -531,19 +485,10 @@ static int out_fwd_ce(const float* P, int64_t ldp, int64_t n_src, const int32_t*
   a.labels = label_table; a.label_ids = label_ids; a.n_labels = n_labels; a.grad_scale = grad_scale;
   a.loss_rows = loss_rows; a.dlogits = dlogits; a.lddl = lddl; a.loss_mean = loss_mean; a.counter = counter;
   a.zero_buf = (float4*)zero_buf; a.zero_n4 = zero_floats / 4;
-  a.dx_self = dx_self; a.ldx = ldx; a.dP = dP; a.ldpp = ldpp;
   // one destination per block while that still is at most two blocks per CU; two beyond
   const int R = rows_per_block > 0 ? rows_per_block : (n_dst <= 512 ? 1 : 2);
   if (mean) {
-    if (dx_self || argmax) return OGL_EINVAL;
-    if (R == 1) hipLaunchKernelGGL((k_out_fwd_ce<1, false, true>), dim3((unsigned)n_dst), dim3(OF_THREADS), 0, (hipStream_t)stream, a);
-    else if (R == 2) hipLaunchKernelGGL((k_out_fwd_ce<2, false, true>), dim3((unsigned)ogl_cdiv(n_dst, 2)), dim3(OF_THREADS), 0, (hipStream_t)stream, a);
-    else return OGL_EINVAL;
-    OGL_CHECK_LAUNCH();
-    return OGL_OK;
-  }
-  if (dx_self) {
-    if (!dP || ldx < K || ldpp < K || (ldx & 3) || ((uintptr_t)dx_self & 15) || zero_floats > 0) return OGL_EINVAL;
+    if (argmax) return OGL_EINVAL;
     if (R == 1) hipLaunchKernelGGL((k_out_fwd_ce<1, true>), dim3((unsigned)n_dst), dim3(OF_THREADS), 0, (hipStream_t)stream, a);
     else if (R == 2) hipLaunchKernelGGL((k_out_fwd_ce<2, true>), dim3((unsigned)ogl_cdiv(n_dst, 2)), dim3(OF_THREADS), 0, (hipStream_t)stream, a);
     else return OGL_EINVAL;
@@ -567,24 +512,7 @@ extern "C" int ogl_out_layer_fwd_ce(const float* P, int64_t ldp, int64_t n_src, 
                                     ogl_stream_t stream) {
   return out_fwd_ce(P, ldp, n_src, idx, n_dst, fanout, h, ldh, K, w_self, ldws, w_neigh, ldwn, b_self, b_neigh, N, neigh, ldn, argmax, logits,
                     ldl, label_table, n_labels, label_ids, grad_scale, loss_rows, dlogits, lddl, loss_mean, counter, zero_buf, zero_floats,
-                    rows_per_block, nullptr, 0, nullptr, 0, stream);
-}
-
-// ... and the combine's input gradients from the SAME launch (k_out_fwd_ce<R, true>; the loss's own gradient 1 / n_dst is known before the
-// loss is): dx_self [n_dst, K] = dlogits . w_self stored, dlogits . w_neigh added to dP [n_src, K] at the winners where the pooled
-// maximum is positive — dP zeroed by the caller BEFORE this launch (no zero fill rides here).  The mean is deferred (NaN until
-// ogl_loss_mean_finish or a successor launch writes it) or, with a counter, summed by the last block.
-extern "C" int ogl_out_layer_fwd_ce_bwd(const float* P, int64_t ldp, int64_t n_src, const int32_t* idx, int64_t n_dst, int fanout,
-                                        const float* h, int64_t ldh, int K, const float* w_self, int64_t ldws, const float* w_neigh,
-                                        int64_t ldwn, const float* b_self, const float* b_neigh, int N, float* neigh, int64_t ldn,
-                                        int32_t* argmax, float* logits, int64_t ldl, const int64_t* label_table, int64_t n_labels,
-                                        const int64_t* label_ids, float grad_scale, float* loss_rows, float* dlogits, int64_t lddl,
-                                        float* loss_mean, unsigned int* counter, int rows_per_block, float* dx_self, int64_t ldx,
-                                        float* dP, int64_t ldpp, ogl_stream_t stream) {
-  if (!dx_self || !dP || !argmax) return OGL_EINVAL;
-  return out_fwd_ce(P, ldp, n_src, idx, n_dst, fanout, h, ldh, K, w_self, ldws, w_neigh, ldwn, b_self, b_neigh, N, neigh, ldn, argmax, logits,
-                    ldl, label_table, n_labels, label_ids, grad_scale, loss_rows, dlogits, lddl, loss_mean, counter, nullptr, 0,
-                    rows_per_block, dx_self, ldx, dP, ldpp, stream);
+                    rows_per_block, stream);
 }
 
 // *loss_mean = sum(loss_rows[0 .. n)) / n in the order of ogl_out_layer_bwd_inputs_mean (lane l sums rows l, l + 64, ...; then the lanes):
@@ -605,7 +533,7 @@ extern "C" int ogl_loss_mean_finish(const float* loss_rows, int64_t n, float* lo
   return OGL_OK;
 }
 
-// The in-repo 'mean' layer as the LAST layer of a train step, fused with the loss (k_out_fwd_ce<R, false, true>): neigh[d, :] = the mean
+// The in-repo 'mean' layer as the LAST layer of a train step, fused with the loss (k_out_fwd_ce<R, true>): neigh[d, :] = the mean
 // over the fanout sampled rows of P (slot order, divided by fanout: ogl_reduce_fwd(OGL_REDUCE_MEAN)'s arithmetic), logits = h[d] . w_self^T
 // + neigh[d] . w_neigh^T + b_self (+ b_neigh) where w_self / w_neigh are the two column blocks of fc_neigh's concat weight (row stride
 // ldws = ldwn = its width), then the cross entropy as ogl_out_layer_fwd_ce (deferred mean with counter == NULL).  Replaces
@@ -619,7 +547,7 @@ extern "C" int ogl_out_layer_fwd_ce_mean(const float* P, int64_t ldp, int64_t n_
                                          float* loss_mean, unsigned int* counter, int rows_per_block, ogl_stream_t stream) {
   return out_fwd_ce(P, ldp, n_src, idx, n_dst, fanout, h, ldh, K, w_self, ldws, w_neigh, ldwn, b_self, b_neigh, N, neigh, ldn, nullptr, logits,
                     ldl, label_table, n_labels, label_ids, grad_scale, loss_rows, dlogits, lddl, loss_mean, counter, nullptr, 0,
-                    rows_per_block, nullptr, 0, nullptr, 0, stream, 1);
+                    rows_per_block, stream, 1);
 }
 
 // ogl_out_layer_bwd_inputs for an aggregator WITHOUT winners (mean / sum): dx_self [n_dst, K] = dy . w_self and dneigh [n_dst, K] =

@@ -301,7 +301,6 @@ __global__ void __launch_bounds__(1024) k_pool_plan_place(const int32_t* __restr
 }
 
 // backward, one wave per destination: the gradient row goes through LDS into the planned places
-template <bool HOIST>
 __global__ void __launch_bounds__(256) k_pool_values(const float* __restrict__ dout, int64_t ldo, int64_t n_dst, int S, int D,
                                                      const unsigned short* __restrict__ off, const unsigned short* __restrict__ colperm,
                                                      const unsigned* __restrict__ seginfo, uint2* __restrict__ gent) {
@@ -320,21 +319,19 @@ __global__ void __launch_bounds__(256) k_pool_values(const float* __restrict__ d
   // (this wave's LDS row is written and read by the same wave: no barrier, the compiler's lgkmcnt wait orders them)
   // HOIST: every trip's column entry is requested before the first one is used — with the load inside the loop a wave paid one memory
   // latency per 64 entries, ten in a row for a 602-column row, and the kernel is one wave's dependent chain long (all 7 038 waves are
-  // resident at once): -7 us per replayed Reddit step, same box, three alternations (0.9821 -> 0.9754 ms); OGL_PB_VALUES_HOIST=0
+  // resident at once): -7 us per replayed Reddit step, same box, three alternations (0.9821 -> 0.9754 ms)
   unsigned cpv[PB_MAX_D / 64];
-  if constexpr (HOIST) {
 #pragma unroll
-    for (int i = 0; i < PB_MAX_D / 64; ++i) {
-      const int e = 64 * i + lane;
-      cpv[i] = colperm[d * D + (e < n ? e : 0)];
-    }
+  for (int i = 0; i < PB_MAX_D / 64; ++i) {
+    const int e = 64 * i + lane;
+    cpv[i] = colperm[d * D + (e < n ? e : 0)];
   }
 #pragma unroll
   for (int i = 0; i < PB_MAX_D / 64; ++i) {                        // whole waves: the shuffles below need every lane
     const int e = 64 * i + lane;
     if (64 * i >= n) break;                                        // (wave-uniform)
     const bool live = e < n;
-    const unsigned cp = live ? (HOIST ? cpv[i] : (unsigned)colperm[d * D + e]) : 0u;
+    const unsigned cp = live ? cpv[i] : 0u;
     const int col = cp & 1023, j = cp >> 10;
     const unsigned sij = __shfl(si, j);
     const int o = __shfl(oj, j);
@@ -491,87 +488,6 @@ extern "C" int ogl_pool_bwd_x3_plan(const int32_t* argmax, const float* relu_out
   return OGL_OK;
 }
 
-// ---- the bucket pass INSIDE the aggregator (round 5) --------------------------------------------------------------------------------
-// k_pool_bucket<true> re-reads what the max aggregator had in registers a moment earlier (the winner of every column, its sampling slot,
-// the sign of the maximum) and runs on the 71 CUs a 185-tile product leaves free: 65-70 us beside the combine product, and a second copy of
-// it costs the replayed step 30 us (measured).  ogl_reduce_fwd_img_plan (aggregate.hip) therefore writes the plan's slot offsets and the
-// columns in slot order itself; what is left for the side stream is the per-group totals (from the offsets), the scan and the place pass.
-#define PB_TOT_BLOCKS 16
-#define PB_TOT_MAXG 8192            // groups whose totals fit a block's LDS histogram (n_src <= 262 144); more: global atomics
-__global__ void __launch_bounds__(1024) k_pool_group_totals(const int32_t* __restrict__ idx, int64_t n_dst, int S, int64_t n_src,
-                                                            const unsigned short* __restrict__ off, PbDiv dv, unsigned* __restrict__ gcount) {
-  // (a block-local histogram first: 176 k atomic adds onto 1 958 addresses took this pass 21 us and slowed the product beside it)
-  __shared__ unsigned hist[PB_TOT_MAXG];
-  const bool local = dv.G <= PB_TOT_MAXG;
-  if (local) {
-    for (unsigned g = threadIdx.x; g < dv.G; g += 1024) hist[g] = 0;
-    __syncthreads();
-  }
-  const int64_t n = n_dst * S;
-  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 1024) {
-    const int64_t d = i / S;
-    const int j = (int)(i - d * S);
-    const unsigned len = (unsigned)off[d * (S + 1) + j + 1] - (unsigned)off[d * (S + 1) + j];
-    if (len == 0) continue;
-    const int my = idx[i];                                        // len > 0: slot j holds a winner, so `my` is a valid source
-    const unsigned q = pb_div((unsigned)my, dv);
-    const unsigned g = (unsigned)my - q * dv.G;
-    if (local) atomicAdd(&hist[g], len);
-    else atomicAdd(&gcount[g], len);
-  }
-  if (local) {
-    __syncthreads();
-    for (unsigned g = threadIdx.x; g < dv.G; g += 1024)
-      if (hist[g]) atomicAdd(&gcount[g], hist[g]);
-  }
-}
-
-// where ogl_reduce_fwd_img_plan writes inside a plan workspace: byte offsets of the slot offsets [n_dst][fanout + 1] (uint16) and of the
-// columns in slot order [n_dst][d] (uint16: 10 bits column, 6 bits slot)
-extern "C" int ogl_pool_bwd_x3_plan_slots(int64_t n_dst, int fanout, int d, int64_t n_src, int64_t* off_bytes, int64_t* colperm_bytes) {
-  if (!off_bytes || !colperm_bytes || n_dst < 0 || fanout < 0 || fanout > PB_MAX_S || d <= 0 || d > PB_MAX_D || n_src <= 0) return OGL_EINVAL;
-  const PbPlanLayout L = pb_plan_layout(n_dst, fanout, d, n_src);
-  *off_bytes = L.off; *colperm_bytes = L.colperm;
-  return OGL_OK;
-}
-
-// the rest of ogl_pool_bwd_x3_plan when the aggregator already wrote the slot offsets and the columns in slot order
-extern "C" int ogl_pool_bwd_x3_plan_finish(const int32_t* idx32, int64_t n_dst, int fanout, int d, int64_t n_src, void* workspace,
-                                           int64_t workspace_bytes, ogl_stream_t stream) {
-  const int rc = pb_check(n_dst, fanout, d, n_src, workspace, workspace_bytes);
-  if (rc != OGL_OK) return rc;
-  if (n_dst * (int64_t)d >= (1ll << PB_POS_BITS)) return OGL_EINVAL;
-  if (n_dst > 0 && fanout > 0 && !idx32) return OGL_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  const int64_t G = ogl_cdiv(n_src, 32);
-  const PbPlanLayout L = pb_plan_layout(n_dst, fanout, d, n_src);
-  unsigned char* w = (unsigned char*)workspace;
-  unsigned* gcount = (unsigned*)(w + L.counts);
-  unsigned* gbase = gcount + G;
-  unsigned* gcur = gbase + G + 1;
-  unsigned short* off = (unsigned short*)(w + L.off);
-  unsigned* seginfo = (unsigned*)(w + L.seginfo);
-  {
-    const int64_t n16 = L.off / 16;
-    hipLaunchKernelGGL(k_pb_zero16, dim3((unsigned)std::min<int64_t>(ogl_cdiv(n16, 256), 2048)), dim3(256), 0, st, (uint4*)w, n16);
-    OGL_CHECK_LAUNCH();
-  }
-  const PbDiv dv = pb_make_div((unsigned)G);
-  if (n_dst > 0 && fanout > 0) {
-    hipLaunchKernelGGL(k_pool_group_totals, dim3((unsigned)std::min<int64_t>(PB_TOT_BLOCKS, ogl_cdiv(n_dst * fanout, 1024))), dim3(1024), 0, st,
-                       idx32, n_dst, fanout, n_src, (const unsigned short*)off, dv, gcount);
-    OGL_CHECK_LAUNCH();
-  }
-  hipLaunchKernelGGL(k_pool_plan_scan, dim3(1), dim3(1024), 0, st, (const unsigned*)gcount, gbase, gcur, (int)G);
-  OGL_CHECK_LAUNCH();
-  if (n_dst > 0 && fanout > 0) {
-    hipLaunchKernelGGL(k_pool_plan_place, dim3((unsigned)std::min<int64_t>(PB_PLACE_BLOCKS, ogl_cdiv(n_dst * fanout, 4096))), dim3(1024), 0, st,
-                       idx32, n_dst, fanout, (const unsigned short*)off, dv, (const unsigned*)gbase, gcur, seginfo);
-    OGL_CHECK_LAUNCH();
-  }
-  return OGL_OK;
-}
-
 extern "C" int ogl_pool_bwd_x3_apply(const float* dout, int64_t ldo, const int32_t* idx32, int64_t n_dst, int fanout, int d,
                                      int64_t n_src, void* image, const void* workspace, int64_t workspace_bytes, ogl_stream_t stream) {
   (void)idx32;                                                    // (the plan already holds what the indices say)
@@ -588,13 +504,8 @@ extern "C" int ogl_pool_bwd_x3_apply(const float* dout, int64_t ldo, const int32
   const unsigned* gbase = (const unsigned*)(w + L.counts) + G;
   uint2* gent = (uint2*)(w + L.gent);
   if (n_dst > 0 && fanout > 0) {
-    {
-      static const char* vh = getenv("OGL_PB_VALUES_HOIST");
-      if (vh && vh[0] == '0') hipLaunchKernelGGL(k_pool_values<false>, dim3((unsigned)ogl_cdiv(n_dst, 4)), dim3(256), 0, st, dout, ldo, n_dst, fanout, d,
-                         (const unsigned short*)(w + L.off), (const unsigned short*)(w + L.colperm), (const unsigned*)(w + L.seginfo), gent);
-      else hipLaunchKernelGGL(k_pool_values<true>, dim3((unsigned)ogl_cdiv(n_dst, 4)), dim3(256), 0, st, dout, ldo, n_dst, fanout, d,
-                         (const unsigned short*)(w + L.off), (const unsigned short*)(w + L.colperm), (const unsigned*)(w + L.seginfo), gent);
-    }
+    hipLaunchKernelGGL(k_pool_values, dim3((unsigned)ogl_cdiv(n_dst, 4)), dim3(256), 0, st, dout, ldo, n_dst, fanout, d,
+                       (const unsigned short*)(w + L.off), (const unsigned short*)(w + L.colperm), (const unsigned*)(w + L.seginfo), gent);
     OGL_CHECK_LAUNCH();
   }
   const int64_t gstride = ((int64_t)d + 1) * 192;
@@ -607,428 +518,5 @@ extern "C" int ogl_pool_bwd_x3_apply(const float* dout, int64_t ldo, const int32
   }
   hipLaunchKernelGGL(k_pool_groups, dim3((unsigned)G), dim3(PB_THREADS), lds, st, (const uint2*)gent, gbase, d, DP, (unsigned char*)image, gstride);
   OGL_CHECK_LAUNCH();
-  return OGL_OK;
-}
-
-// ======================================================================================================================
-// RECORD-FED layer-0 weight gradient (round 5): dW_pool = dP^T . [X[rows] | 1] with the dense bf16x3 image of dP^T NEVER written.
-//
-// ogl_pool_bwd_x3_apply ends in k_pool_groups: 226 MB of image (89 % zeros) written at the streaming-write rate of the part, 52 us
-// alone / 85 us inside the step, on the critical path, only for the weight-gradient product to read it back.  Here the product's
-// mover waves build the A part of every stage THEMSELVES, in LDS, from the group-major (column, lane, value) records the values pass
-// (k_pool_values) left: one reduction step of the product IS one source group of the plan (32 sources dealt round-robin, source
-// a = lane * G + group), so the records of step g are the contiguous run gbase[g] .. gbase[g + 1].
-//
-// Tile 128 x 128 x 32, both operands k-major (the A / B stage layouts of k_gemm_x3p<2, 4, 2, 1, 3, false, true, true>: 32 reduction
-// rows x 48 sixteen-byte pieces, read by ds_read_b64_tr_b16), 8 multiplier waves (2 x 4 of 64 x 32) + 4 mover waves, ONE barrier per
-// step.  LDS (152 KB): B ring 3 x 24 KB (LDS-DMA of gathered table-image rows, two stages ahead) | A buffers 2 x 24 KB | fp32 slabs
-// 2 x 16 KB ([32 sources][128 columns]).  A mover wave's step n (after the barrier that opens step n):
-//     issue the B pieces of stage n + 2                                     (6 buffer_load ... lds per lane, as k_gemm_x3p's movers)
-//     CONVERT slab[(n + 1) & 1] -> A buffer (n + 1) & 1                     (its own 8 source rows: read 2 x 32 B of fp32 per lane, exact
-//                                                                             3-term bf16 split, 2 x 3 ds_write_b128 into the k-major
-//                                                                             piece positions) and clear what it read
-//     ADD the records of stage n + 2 into slab[n & 1]                       (all four waves share the run evenly: ds_add_f32; records
-//                                                                             whose column lies outside this tile's 128 are dropped)
-//     load the records of stage n + 3 into registers, the record range of stage n + 4
-// so every hand-over between waves (cleared slab -> adds -> conversion -> fragments) crosses exactly one barrier, and a step's A
-// stage is built while the multipliers work on the two steps before it.  Hub groups (one source referenced by hundreds of
-// destinations) cost nothing special: a group's records are shared by 256 lanes whatever their lanes' sources are.
-// Every one of a slab's 25 tiles reads the slab's records (15 KB per step from the XCD's L2, beside 24 KB of B pieces — the image
-// product it replaces moved 48 KB per step) and keeps the 21 % that fall into its rows.
-// Output: split-K slabs [nsplit][M][ws_ld] like ogl_linear_bwd_weight_x3k_slabs (column K = the bias gradient).
-#define RF_B_STAGE 24576
-#define RF_A_STAGE 24576
-#define RF_SLAB 16384
-#define RF_A_BASE (3 * RF_B_STAGE)
-#define RF_S_BASE (RF_A_BASE + 2 * RF_A_STAGE)
-#define RF_SMEM (RF_S_BASE + 2 * RF_SLAB)
-#define RF_NREC 16                  // records per builder lane held in registers (4 096 per group; longer runs loop)
-
-struct RfArgs {
-  const uint2* gent; const unsigned* gbase; int G;
-  const unsigned char* b_img; int64_t b_row_bytes; const int64_t* b_rows; int64_t b_nrows; int64_t b_zero_row; int bk_groups;
-  int64_t n_src;
-  int M, N;                         // output rows (the pooled width d) / columns (K + ones slot)
-  int nsplit, steps_per_split; float* ws; int64_t ws_ld;
-  int NI, NJ, xcd_slabs;
-  int dbg;                          // timing-only builds (OGL_RF_DBG; wrong results): 1 = no B pieces, 2 = no record loads / adds, 4 = no conversion
-};
-
-typedef __attribute__((address_space(3))) void* rf_lptr_t;
-
-// 16 waves: 0-7 multiply, 8-11 issue the B pieces (and never touch LDS themselves: the compiler orders every LDS access of a wave
-// behind its outstanding LDS-DMA — `s_waitcnt vmcnt(0)` — so a wave that both fetched and built waited for its own pieces to land
-// before every slab access: 3.1 us per step), 12-15 build the A stages.  Four waves per SIMD: 128 registers per wave.
-__global__ void __launch_bounds__(1024) k_gemm_x3rf(RfArgs g) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[RF_SMEM];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int T = g.NI * g.NJ * g.nsplit;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-  const int chunk_begin = xcd * (T >> 3) + min(xcd, T & 7), chunk_len = (T >> 3) + (xcd < (T & 7) ? 1 : 0);
-  if (slot >= chunk_len) return;
-  const int first = chunk_begin + slot, last_logical = chunk_begin + chunk_len;
-  struct Tile { int ti, tj, split, ks_begin, ks_end; };
-  const int tiles_per_slab = g.NI * g.NJ, q_slabs = g.nsplit >> 3;
-  auto decode = [&](int logical) __attribute__((always_inline)) {   // (k_gemm_x3p's walk: whole slabs per XCD, the rest tile by tile)
-    Tile t;
-    int tile;
-    if (g.xcd_slabs) {
-      const int local = logical - chunk_begin, whole = q_slabs * tiles_per_slab;
-      if (local < whole) { t.split = xcd * q_slabs + local / tiles_per_slab; tile = local % tiles_per_slab; }
-      else {
-        const int e = (chunk_begin - xcd * whole) + (local - whole);
-        t.split = 8 * q_slabs + e / tiles_per_slab; tile = e % tiles_per_slab;
-      }
-    } else { t.split = logical / tiles_per_slab; tile = logical - t.split * tiles_per_slab; }
-    t.ti = tile / g.NJ; t.tj = tile - t.ti * g.NJ;
-    t.ks_begin = t.split * g.steps_per_split;
-    t.ks_end = min(g.G, t.ks_begin + g.steps_per_split);
-    return t;
-  };
-  int total = 0;
-  for (int l = first; l < last_logical; l += nslots) { const Tile t = decode(l); total += t.ks_end - t.ks_begin; }
-  auto barrier = [&]() __attribute__((always_inline)) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" ::: "memory");
-  };
-  struct Cur { int logical, ks, ke, ti, tj; bool live; };
-  auto cur_set = [&](Cur& c, int logical) __attribute__((always_inline)) {
-    c.logical = logical;
-    c.live = logical < last_logical;
-    if (c.live) { const Tile t = decode(logical); c.ks = t.ks_begin; c.ke = t.ks_end; c.ti = t.ti; c.tj = t.tj; }
-    else { c.ks = 0; c.ke = 0; c.ti = 0; c.tj = 0; }
-  };
-  auto cur_next = [&](Cur& c) __attribute__((always_inline)) {
-    if (!c.live) return;
-    if (++c.ks >= c.ke) cur_set(c, c.logical + nslots);
-  };
-
-  if (wid >= 12) {
-    // ---- builders: records -> fp32 slab -> k-major bf16x3 A stage -----------------------------------------------------------------
-    const int w = wid - 12, ml = w * 64 + lane;
-    auto zero_own = [&](int s) __attribute__((always_inline)) {
-      unsigned char* slab = smem + RF_S_BASE + (s & 1) * RF_SLAB;
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int u = lane + 64 * r, k = 8 * w + (u >> 4), c8 = u & 15;
-        float4* p = (float4*)(slab + k * 512 + c8 * 32);
-        p[0] = make_float4(0.f, 0.f, 0.f, 0.f); p[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    };
-    auto convert = [&](int s) __attribute__((always_inline)) {
-      if (g.dbg & 4) return;
-      unsigned char* slab = smem + RF_S_BASE + (s & 1) * RF_SLAB;
-      unsigned char* abuf = smem + RF_A_BASE + (s & 1) * RF_A_STAGE;
-      float4 v[2][2];
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int u = lane + 64 * r, k = 8 * w + (u >> 4), c8 = u & 15;
-        const float4* p = (const float4*)(slab + k * 512 + c8 * 32);
-        v[r][0] = p[0]; v[r][1] = p[1];
-      }
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int u = lane + 64 * r, k = 8 * w + (u >> 4), c8 = u & 15;
-        uint4 o[3];
-        split3(v[r][0].x, v[r][0].y, o[0].x, o[1].x, o[2].x);
-        split3(v[r][0].z, v[r][0].w, o[0].y, o[1].y, o[2].y);
-        split3(v[r][1].x, v[r][1].y, o[0].z, o[1].z, o[2].z);
-        split3(v[r][1].z, v[r][1].w, o[0].w, o[1].w, o[2].w);
-        const int f = (2 * (k & 3)) | (8 * ((k >> 3) & 1));
-        const int rowbase = (k >> 3) * 64 + (k & 3) * 16, hblk = 3 * ((k >> 2) & 1);
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp) {
-          const int pc = (c8 >> 2) * 12 + sp * 4 + (c8 & 3);
-          const int P = (hblk + (pc >> 4)) * 256 + rowbase + ((pc & 15) ^ f);
-          *(uint4*)(abuf + P * 16) = o[sp];
-        }
-        float4* p = (float4*)(slab + k * 512 + c8 * 32);
-        p[0] = make_float4(0.f, 0.f, 0.f, 0.f); p[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    };
-    // BRANCH-FREE: a record outside this tile's 128 columns (or past the run's end) adds 0.0 to the cell its low column bits name —
-    // under an `if` the compiler cannot count the loads in flight and waits for all of them (vmcnt(0)) in front of every ds_add
-    auto add_one = [&](float* slab, uint2 en, int ti, bool live) __attribute__((always_inline)) {
-      const int j = (int)(en.x & 0xFFFFu) - ti * 128, q = (int)(en.x >> 16) & 31;
-      if (g.dbg & 8) {
-        const float v = (live && (unsigned)j < 128u) ? __uint_as_float(en.y) : 0.f;
-        __hip_atomic_fetch_add(&slab[q * 128 + (j & 127)], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      } else if (live && (unsigned)j < 128u) {
-        __hip_atomic_fetch_add(&slab[q * 128 + j], __uint_as_float(en.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    };
-    // pipeline slots: `rec` = the records of the next stage to be added (range rlo .. rhi, row tile rti), `nlo / nhi / nti` = the range
-    // of the stage after it (its records are not requested yet)
-    uint2 rec[RF_NREC];
-    unsigned rlo = 0, rhi = 0, nlo = 0, nhi = 0;
-    int rti = 0, nti = 0;
-    Cur cR; cur_set(cR, first);                             // the next stage whose RANGE is to be loaded
-    auto load_range = [&]() __attribute__((always_inline)) {
-      nti = cR.ti;
-      const int ks = cR.live ? cR.ks : 0;
-      const unsigned a = g.gbase[ks], b = g.gbase[ks + 1];  // (unconditional: gbase has G + 1 >= 2 entries)
-      nlo = cR.live ? a : 0u; nhi = cR.live ? b : 0u;
-      cur_next(cR);
-    };
-    auto load_records = [&]() __attribute__((always_inline)) {   // range slot -> record slot
-      rlo = nlo; rhi = nhi; rti = nti;
-      if (g.dbg & 2) { rhi = rlo; return; }
-#pragma unroll
-      for (int i = 0; i < RF_NREC; ++i) {
-        const unsigned r = rlo + (unsigned)(i * 256 + ml);
-        rec[i] = g.gent[r < rhi ? r : 0u];                  // (unconditional: the record array is never empty — 16 spare bytes)
-      }
-    };
-    auto adds = [&](int s) __attribute__((always_inline)) {
-      float* slab = (float*)(smem + RF_S_BASE + (s & 1) * RF_SLAB);
-      if (g.dbg & 2) return;
-#pragma unroll
-      for (int i = 0; i < RF_NREC; ++i) add_one(slab, rec[i], rti, rlo + (unsigned)(i * 256 + ml) < rhi);
-      // (runs longer than the register slot: four records per lane and trip, whole waves)
-      for (unsigned r0 = rlo + (unsigned)(RF_NREC * 256); r0 < rhi; r0 += 1024u) {
-        uint2 e[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { const unsigned r = r0 + (unsigned)(i * 256 + ml); e[i] = g.gent[r < rhi ? r : 0u]; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) add_one(slab, e[i], rti, r0 + (unsigned)(i * 256 + ml) < rhi);
-      }
-    };
-    // ---- prologue: slab 0 <- stage 0 -> A buffer 0; slab 1 <- stage 1; record slot = stage 2, range slot = stage 3
-    zero_own(0); zero_own(1);
-    load_range();                                           // stage 0
-    load_records();
-    load_range();                                           // stage 1
-    barrier();
-    if (total > 0) adds(0);
-    load_records();
-    load_range();                                           // stage 2
-    if (total > 1) adds(1);
-    load_records();                                         // stage 2's records stay in the slot
-    load_range();                                           // stage 3
-    barrier();
-    if (total > 0) convert(0);
-    for (int n = 0; n < total; ++n) {
-      barrier();                                            // opens step n
-      if (n + 1 < total) convert(n + 1);
-      if (n + 2 < total) adds(n + 2);
-      load_records();                                       // stage n + 3
-      load_range();                                         // stage n + 4
-    }
-  } else if (wid >= 8) {
-    // ---- movers: the B pieces (gathered rows of the table image, k-major: see k_gemm_x3p<..., BK>), two stages ahead -------------
-    const int w = wid - 8;
-    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)g.b_img, 0, 0xFFFFFFFF, 0x00020000);
-    const int rsub = (lane >> 4) & 3;
-    const int ipc = (lane & 15) ^ ((rsub << 1) | ((w & 1) << 3));
-    const unsigned zero_off = (unsigned)(g.b_zero_row * g.b_row_bytes);
-    int64_t bid[2] = {0, 0};
-    bool bok[2] = {false, false};
-    auto b_request = [&](const Cur& c) __attribute__((always_inline)) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int kl = 8 * w + 4 * h + rsub;
-        const int64_t pos = (int64_t)kl * g.G + c.ks;
-        bok[h] = c.live && pos < g.n_src;
-        bid[h] = g.b_rows ? g.b_rows[bok[h] ? pos : 0] : pos;
-      }
-    };
-    Cur cB; cur_set(cB, first);
-    b_request(cB);
-    auto fetchB = [&](int stage) __attribute__((always_inline)) {
-      if (!cB.live || (g.dbg & 1)) return;
-      unsigned row[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) row[h] = (bok[h] && bid[h] >= 0 && bid[h] < g.b_nrows) ? (unsigned)(bid[h] * g.b_row_bytes) : zero_off;
-      const int tj = cB.tj;
-      cur_next(cB);
-      b_request(cB);                                         // the NEXT stage's row ids, ahead of this stage's pieces
-      unsigned char* dst = smem + (stage % 3) * RF_B_STAGE;
-#pragma unroll
-      for (int ub = 0; ub < 6; ++ub) {
-        const int pc = 16 * (ub % 3) + ipc;
-        const int grp = tj * 4 + pc / 12;
-        const unsigned so = grp < g.bk_groups ? row[ub / 3] + (unsigned)(grp * 192 + (pc % 12) * 16) : zero_off + (unsigned)((pc % 12) * 16);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (rf_lptr_t)(dst + (ub * 256 + w * 64) * 16), 16, so, 0, 0, 0);
-      }
-    };
-    fetchB(0); fetchB(1);
-    barrier();
-    barrier();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int n = 0; n < total; ++n) {
-      barrier();                                            // opens step n: the buffer of step n - 1 is free
-      fetchB(n + 2);
-      // stage n + 1 must have landed before the next barrier; the youngest stage (6 pieces) and the row ids requested in front of
-      // it (2 loads) may stay in flight
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
-    // ---- multipliers: 2 x 4 waves of 64 x 32 ------------------------------------------------------------------------------------
-    const int wm = wid >> 2, wn = wid & 3;
-    const int l15 = lane & 15, quad = lane >> 4;
-    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4;
-    const int pq = l15 >> 2, pp = l15 & 3;
-    const int bk_mask = (pp >> 1) | (pq << 1) | ((quad & 1) << 3);
-    const int bk_lane = (quad * 64 + pq * 16) * 16 + 8 * (pp & 1);
-    auto k_frag = [&](const unsigned char* st, int n0, int sp) __attribute__((always_inline)) {
-      const int pce = (n0 >> 5) * 12 + sp * 4 + ((n0 >> 3) & 3);
-      const int at = bk_lane + ((pce >> 4) * 256 + ((pce & 15) ^ bk_mask)) * 16;
-      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(st + at));
-      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(st + at + 3 * 256 * 16));
-      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    };
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    f32x4 acc[4][2];
-    auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.f;
-    };
-    auto compute = [&](int n, int rbv, int cbv) __attribute__((always_inline)) {
-      if (rbv <= 0 || cbv <= 0) return;
-      const unsigned char* sa = smem + RF_A_BASE + (n & 1) * RF_A_STAGE;
-      const unsigned char* sb = smem + (n % 3) * RF_B_STAGE;
-      bf16x8 a[4][3], b[2][3];
-#pragma unroll
-      for (int sp = 0; sp < 3; ++sp) b[0][sp] = k_frag(sb, wn * 32, sp);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp) a[t][sp] = k_frag(sa, wm * 64 + t * 16, sp);
-#pragma unroll
-      for (int sp = 0; sp < 3; ++sp) b[1][sp] = k_frag(sb, wn * 32 + 16, sp);
-#pragma unroll
-      for (int y = 0; y < 2; ++y) {
-        if (y < cbv) {
-#pragma unroll
-          for (int x = 0; x < 4; ++x)
-            if (x < rbv) {
-              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y][2], a[x][0], acc[x][y], 0, 0, 0);
-              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y][1], a[x][1], acc[x][y], 0, 0, 0);
-              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y][0], a[x][2], acc[x][y], 0, 0, 0);
-              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y][1], a[x][0], acc[x][y], 0, 0, 0);
-              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y][0], a[x][1], acc[x][y], 0, 0, 0);
-              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[y][0], a[x][0], acc[x][y], 0, 0, 0);
-            }
-        }
-      }
-    };
-    auto epilogue = [&](const Tile& t) __attribute__((always_inline)) {
-      int l15e = lane & 15, quade = lane >> 4;
-      asm volatile("" : "+v"(l15e), "+v"(quade));
-      float* const dst = g.ws + (int64_t)t.split * g.M * g.ws_ld;
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) {
-          const int64_t row = (int64_t)t.ti * 128 + wm * 64 + x * 16 + l15e, col = (int64_t)t.tj * 128 + wn * 32 + y * 16 + 4 * quade;
-          if (row >= g.M || col >= g.N) continue;
-          if (col + 4 <= g.ws_ld) *(float4*)(dst + row * g.ws_ld + col) = make_float4(acc[x][y][0], acc[x][y][1], acc[x][y][2], acc[x][y][3]);
-          else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) if (col + c < g.N) dst[row * g.ws_ld + col + c] = acc[x][y][c];
-          }
-        }
-    };
-    zero_acc();
-    barrier();                                              // (the builders' two prologue hand-overs)
-    barrier();
-    int n = 0;
-    for (int logical = first; logical < last_logical; logical += nslots) {
-      const Tile tc = decode(logical);
-      const int rleft = g.M - (tc.ti * 128 + wm * 64), cleft = g.N - (tc.tj * 128 + wn * 32);
-      const int rbv = rleft >= 64 ? 4 : (rleft <= 0 ? 0 : (rleft + 15) >> 4), cbv = cleft >= 32 ? 2 : (cleft <= 0 ? 0 : (cleft + 15) >> 4);
-      for (int ks = tc.ks_begin; ks < tc.ks_end; ++ks, ++n) {
-        barrier();
-        compute(n, rbv, cbv);
-      }
-      epilogue(tc);
-      zero_acc();
-    }
-  }
-#endif
-}
-
-static void rf_plan(int64_t steps, int M, int N, int* nsplit, int* sps) {
-  const int64_t tiles = ogl_cdiv(M, 128) * ogl_cdiv(N, 128);
-  int64_t s = 256 / (tiles > 0 ? tiles : 1);
-  if (s < 1) s = 1;
-  if (steps / s < 8) s = steps / 8 > 0 ? steps / 8 : 1;
-  *sps = (int)ogl_cdiv(steps > 0 ? steps : 1, s);
-  *nsplit = (int)ogl_cdiv(steps > 0 ? steps : 1, *sps);
-}
-
-extern "C" int64_t ogl_pool_bwd_x3_dw_workspace_bytes(int64_t n_src, int d, int K) {
-  if (n_src < 0 || d < 0 || K < 0) return OGL_EINVAL;
-  int nsplit, sps;
-  rf_plan(ogl_cdiv(n_src, 32), d, K + 1, &nsplit, &sps);
-  return (int64_t)nsplit * d * ogl_round_up(K + 1, 4) * 4 + 16;
-}
-
-extern "C" int ogl_pool_bwd_x3_dw(const float* dout, int64_t ldo, int64_t n_dst, int fanout, int d, int64_t n_src,
-                                  const void* plan_workspace, int64_t plan_workspace_bytes, const void* x_img, int64_t x_img_rows,
-                                  const int64_t* x_rows, int64_t x_nrows, int K, float* dw, int64_t lddw, float* db,
-                                  void* workspace, int64_t workspace_bytes, int defer, int* nsplit_out, int64_t* ws_ld_out,
-                                  ogl_stream_t stream) {
-  if (ldo < d || K <= 0 || lddw < K) return OGL_EINVAL;
-  const int rc = pb_check(n_dst, fanout, d, n_src, plan_workspace, plan_workspace_bytes);
-  if (rc != OGL_OK) return rc;
-  if (n_dst * (int64_t)d >= (1ll << PB_POS_BITS)) return OGL_EINVAL;
-  if (n_dst > 0 && fanout > 0 && !dout) return OGL_EINVAL;
-  if (!x_img || !dw || x_img_rows < 0 || x_nrows < 0 || x_nrows > x_img_rows || (!x_rows && n_src > x_img_rows)) return OGL_EINVAL;
-  if (defer && (!nsplit_out || !ws_ld_out)) return OGL_EINVAL;
-  const int64_t xrb = ogl_cdiv(K + 1, 32) * 192;           // the x image carries the ones slot (K + 1): column K of the product = db
-  if ((x_img_rows + 1) * xrb >= (1ll << 32)) return OGL_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  const int64_t G = ogl_cdiv(n_src, 32);
-  const PbPlanLayout L = pb_plan_layout(n_dst, fanout, d, n_src);
-  const unsigned char* w = (const unsigned char*)plan_workspace;
-  const unsigned* gbase = (const unsigned*)(w + L.counts) + G;
-  uint2* gent = (uint2*)(w + L.gent);
-  if (n_dst > 0 && fanout > 0) {
-    {
-      static const char* vh = getenv("OGL_PB_VALUES_HOIST");
-      if (vh && vh[0] == '0') hipLaunchKernelGGL(k_pool_values<false>, dim3((unsigned)ogl_cdiv(n_dst, 4)), dim3(256), 0, st, dout, ldo, n_dst, fanout, d,
-                         (const unsigned short*)(w + L.off), (const unsigned short*)(w + L.colperm), (const unsigned*)(w + L.seginfo), gent);
-      else hipLaunchKernelGGL(k_pool_values<true>, dim3((unsigned)ogl_cdiv(n_dst, 4)), dim3(256), 0, st, dout, ldo, n_dst, fanout, d,
-                         (const unsigned short*)(w + L.off), (const unsigned short*)(w + L.colperm), (const unsigned*)(w + L.seginfo), gent);
-    }
-    OGL_CHECK_LAUNCH();
-  }
-  RfArgs g;
-  g.gent = gent; g.gbase = gbase; g.G = (int)G;
-  g.b_img = (const unsigned char*)x_img; g.b_row_bytes = xrb; g.b_rows = x_rows; g.b_nrows = x_rows ? x_nrows : x_img_rows;
-  g.b_zero_row = x_img_rows; g.bk_groups = (int)ogl_cdiv(K + 1, 32);
-  g.n_src = n_src; g.M = d; g.N = K + 1;
-  rf_plan(G, d, K + 1, &g.nsplit, &g.steps_per_split);
-  g.ws_ld = ogl_round_up(K + 1, 4);
-  if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < (int64_t)g.nsplit * d * g.ws_ld * 4) return OGL_EWORKSPACE;
-  g.ws = (float*)workspace;
-  g.NI = (int)ogl_cdiv(d, 128); g.NJ = (int)ogl_cdiv(K + 1, 128);
-  g.xcd_slabs = g.nsplit >= 8 ? 1 : 0;
-  { const char* e = getenv("OGL_RF_DBG"); g.dbg = e ? atoi(e) : 0; }
-  const int64_t T = (int64_t)g.NI * g.NJ * g.nsplit;
-  hipLaunchKernelGGL(k_gemm_x3rf, dim3((unsigned)(8 * std::min<int64_t>(32, ogl_cdiv(T, 8)))), dim3(1024), 0, st, g);
-  OGL_CHECK_LAUNCH();
-  if (nsplit_out) *nsplit_out = g.nsplit;
-  if (ws_ld_out) *ws_ld_out = g.ws_ld;
-  if (!defer) {
-    const int r1 = ogl_x3_slab_reduce(g.ws, (int64_t)d * g.ws_ld, g.ws_ld, g.nsplit, d, K, 0, dw, lddw, stream);
-    if (r1 != OGL_OK) return r1;
-    if (db) {
-      const int r2 = ogl_x3_slab_reduce(g.ws, (int64_t)d * g.ws_ld, g.ws_ld, g.nsplit, d, 1, K, db, 1, stream);
-      if (r2 != OGL_OK) return r2;
-    }
-  }
   return OGL_OK;
 }

@@ -185,17 +185,11 @@ struct SegOut {
   float* out; int64_t ldo;                    // fp32 rows [n_src, D] (nullable)
   unsigned char* img; int64_t img_row_bytes;  // row-major bf16x3 image, n_src + 1 rows (nullable)
   const float* mask; int64_t ldm;             // optional: row s is multiplied by [mask[s, :] > 0]
-  const unsigned char* mbits; int64_t ldmb;   // ... or by the SIGN BITS of that matrix: one byte per 4-column group (bit c = column 4 g + c),
-                                              //     as the product that computed it emitted them (ogl_linear_fwd_x3_bits): 1/16 of the bytes
   float divisor;                              // S for the mean, 1 for the sum
 };
 
 // the mask of this thread's 4 columns of source s as {> 0 : keep}
 __device__ __forceinline__ float4 seg_mask4(const SegOut& o, int64_t s, int ch) {
-  if (o.mbits) {
-    const unsigned b = o.mbits[s * o.ldmb + ch];
-    return make_float4((b & 1u) ? 1.f : 0.f, (b & 2u) ? 1.f : 0.f, (b & 4u) ? 1.f : 0.f, (b & 8u) ? 1.f : 0.f);
-  }
   return *(const float4*)(o.mask + s * o.ldm + 4 * ch);
 }
 
@@ -203,7 +197,7 @@ __device__ __forceinline__ float4 seg_mask4(const SegOut& o, int64_t s, int ch) 
 __device__ __forceinline__ void seg_store(const SegOut& o, int64_t s, int ch, int D, float4 a) {
   const int b4 = ch * 4;
   if (o.divisor != 1.f) { a.x /= o.divisor; a.y /= o.divisor; a.z /= o.divisor; a.w /= o.divisor; }
-  if ((o.mask || o.mbits) && b4 < D) {
+  if (o.mask && b4 < D) {
     const float4 m = seg_mask4(o, s, ch);
     a.x = m.x > 0.f ? a.x : 0.f; a.y = m.y > 0.f ? a.y : 0.f; a.z = m.z > 0.f ? a.z : 0.f; a.w = m.w > 0.f ? a.w : 0.f;
   }
@@ -252,8 +246,8 @@ __global__ void __launch_bounds__(SG_THREADS) k_seg_reduce(const float* __restri
   const bool cin = tid < D4;
   const int ch = cin ? tid : D4 - 1;
   SegOut plain = o;                                           // (the mask is applied here, from a prefetched value)
-  plain.mask = nullptr; plain.mbits = nullptr;
-  const bool masked = o.mask != nullptr || o.mbits != nullptr;
+  plain.mask = nullptr;
+  const bool masked = o.mask != nullptr;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int run_k0 = 0;
   for (int k0 = 0; k0 < cntk; k0 += SG_U) {
@@ -302,14 +296,14 @@ __global__ void __launch_bounds__(256) k_seg_fixup(const int* __restrict__ start
   const int nch = max(D4, Kp4);
   if (s == n_src) {                                           // the image's all-zero row
     if (o.img) {
-      SegOut z = o; z.out = nullptr; z.mask = nullptr; z.mbits = nullptr;
+      SegOut z = o; z.out = nullptr; z.mask = nullptr;
       for (int ch = lane; ch < nch; ch += 64) seg_store(z, s, ch, D, make_float4(0.f, 0.f, 0.f, 0.f));
     }
     return;
   }
   const int a = start[s], b = start[s + 1];
   if (a == b) {
-    SegOut z = o; z.mask = nullptr; z.mbits = nullptr;
+    SegOut z = o; z.mask = nullptr;
     for (int ch = lane; ch < nch; ch += 64) seg_store(z, s, ch, D, make_float4(0.f, 0.f, 0.f, 0.f));
     return;
   }
@@ -388,7 +382,7 @@ extern "C" int ogl_reduce_bwd_seg_plan(const int32_t* idx, int64_t n_dst, int fa
 // (`out`, nullable) and / or as the row-major bf16x3 image of [n_src, d] (`image`: ogl_x3_image_bytes(n_src, d), nullable).
 // op: OGL_REDUCE_MEAN (divisor fanout) or OGL_REDUCE_SUM.  d a multiple of 4 <= 1024; 16-byte aligned rows.
 static int seg_apply(const float* dout, int64_t ldd, const int32_t* idx, int64_t n_dst, int fanout, int d, int op, int64_t n_src,
-                     const float* mask, int64_t ldm, const unsigned char* mbits, int64_t ldmb, float* out, int64_t ldo, void* image,
+                     const float* mask, int64_t ldm, float* out, int64_t ldo, void* image,
                      void* workspace, int64_t workspace_bytes, ogl_stream_t stream) {
   if (n_dst < 0 || fanout <= 0 || d <= 0 || d > 1024 || (d & 3) || n_src <= 0 || ldd < d || (ldd & 3)) return OGL_EINVAL;
   if (op != OGL_REDUCE_MEAN && op != OGL_REDUCE_SUM) return OGL_EINVAL;
@@ -407,7 +401,6 @@ static int seg_apply(const float* dout, int64_t ldd, const int32_t* idx, int64_t
   const int64_t ldpart = ogl_round_up(d, 4);
   SegOut o;
   o.out = out; o.ldo = ldo; o.img = (unsigned char*)image; o.img_row_bytes = ogl_cdiv(d, 32) * 192; o.mask = mask; o.ldm = ldm;
-  o.mbits = mbits; o.ldmb = ldmb;
   o.divisor = op == OGL_REDUCE_MEAN ? (float)fanout : 1.f;
   const int tile = seg_tile(E);
   if (E > 0) {
@@ -428,14 +421,5 @@ static int seg_apply(const float* dout, int64_t ldd, const int32_t* idx, int64_t
 extern "C" int ogl_reduce_bwd_seg_apply(const float* dout, int64_t ldd, const int32_t* idx, int64_t n_dst, int fanout, int d, int op,
                                         int64_t n_src, const float* mask, int64_t ldm, float* out, int64_t ldo, void* image,
                                         void* workspace, int64_t workspace_bytes, ogl_stream_t stream) {
-  return seg_apply(dout, ldd, idx, n_dst, fanout, d, op, n_src, mask, ldm, nullptr, 0, out, ldo, image, workspace, workspace_bytes, stream);
-}
-
-// ... with the mask as SIGN BITS (one byte per 4-column group, row stride ldmb >= ceil(d / 4) bytes): what ogl_linear_fwd_x3_bits emits
-extern "C" int ogl_reduce_bwd_seg_apply_bits(const float* dout, int64_t ldd, const int32_t* idx, int64_t n_dst, int fanout, int d, int op,
-                                             int64_t n_src, const unsigned char* mask_bits, int64_t ldmb, float* out, int64_t ldo,
-                                             void* image, void* workspace, int64_t workspace_bytes, ogl_stream_t stream) {
-  if (!mask_bits || ldmb < (d + 3) / 4) return OGL_EINVAL;
-  return seg_apply(dout, ldd, idx, n_dst, fanout, d, op, n_src, nullptr, 0, mask_bits, ldmb, out, ldo, image, workspace, workspace_bytes,
-                   stream);
+  return seg_apply(dout, ldd, idx, n_dst, fanout, d, op, n_src, mask, ldm, out, ldo, image, workspace, workspace_bytes, stream);
 }

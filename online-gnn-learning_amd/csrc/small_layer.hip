@@ -585,10 +585,8 @@ extern "C" int ogl_small_pool_layer_bwd_pool(const float* h, int64_t ldh, int64_
 #define SPR_BN 64
 #define SPR_BK 64
 typedef float spr_f32x16 __attribute__((ext_vector_type(16)));
-// ARES (an experiment, OGL_SPR_ARES=1; off): the block's 32 gathered A rows resident in LDS for the whole product (dynamic LDS:
-// round_up(K, 64) x 34 floats + the two B slabs; K <= 896), all their loads requested up front, only the weight slabs streaming —
-// against 17.5 us for K = 500 with both operands streamed two slabs ahead.  Measured slower in the step (see the launch).
-template <bool ARES>
+// (A form with the block's 32 gathered A rows RESIDENT in LDS for the whole product — all their loads requested up front, only the
+// weight slabs streaming — was measured slower in the step, round 5: 0.1027 against 0.0958-0.0985 ms per pubmed-like step; removed.)
 __global__ void __launch_bounds__(256) k_small_proj_rows(const float* __restrict__ X, int64_t ldx, const int64_t* __restrict__ ids,
                                                          int64_t n_table, int M, int K, const float* __restrict__ W, int64_t ldw, int N,
                                                          const float* __restrict__ bias, int relu, float* __restrict__ Y, int64_t ldy,
@@ -602,9 +600,9 @@ __global__ void __launch_bounds__(256) k_small_proj_rows(const float* __restrict
   typedef float (*ATile)[SPR_BM + 2];
   typedef float (*BTile)[SPR_BK][SPR_BN + 4];
   const int nk = (K + SPR_BK - 1) / SPR_BK;
-  // layout: ARES: A [nk * 64][34] then B [2][64][68];  else: A [2 * 64][34] (two slabs) then B [2][64][68]
+  // layout: A [2 * 64][34] (two slabs) then B [2][64][68]
   ATile As = (ATile)spr_smem;
-  BTile Bs = (BTile)(spr_smem + (size_t)(ARES ? nk : 2) * SPR_BK * (SPR_BM + 2));
+  BTile Bs = (BTile)(spr_smem + (size_t)2 * SPR_BK * (SPR_BM + 2));
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int wx = wv & 1, kh = wv >> 1;                       // column half, k half
   const int n0 = blockIdx.x * SPR_BN;
@@ -622,12 +620,10 @@ __global__ void __launch_bounds__(256) k_small_proj_rows(const float* __restrict
   const float* brow = (n0 + br < N) ? W + (int64_t)(n0 + br) * ldw : nullptr;
   float4 pa[2][2], pb[2][4];
   auto fetch = [&](int k0, float4* qa, float4* qb) {
-    if (!ARES) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int k = k0 + ak + 32 * u;                      // (K % 4 == 0: a float4 is inside the row or outside it)
-        qa[u] = (arow && k < K) ? *(const float4*)(arow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+    for (int u = 0; u < 2; ++u) {
+      const int k = k0 + ak + 32 * u;                        // (K % 4 == 0: a float4 is inside the row or outside it)
+      qa[u] = (arow && k < K) ? *(const float4*)(arow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -636,12 +632,10 @@ __global__ void __launch_bounds__(256) k_small_proj_rows(const float* __restrict
     }
   };
   auto park = [&](int buf, const float4* qa, const float4* qb) {
-    if (!ARES) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int k = buf * SPR_BK + ak + 32 * u;
-        As[k + 0][ar] = qa[u].x; As[k + 1][ar] = qa[u].y; As[k + 2][ar] = qa[u].z; As[k + 3][ar] = qa[u].w;
-      }
+    for (int u = 0; u < 2; ++u) {
+      const int k = buf * SPR_BK + ak + 32 * u;
+      As[k + 0][ar] = qa[u].x; As[k + 1][ar] = qa[u].y; As[k + 2][ar] = qa[u].z; As[k + 3][ar] = qa[u].w;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -655,30 +649,11 @@ __global__ void __launch_bounds__(256) k_small_proj_rows(const float* __restrict
   const int fr = lane & 31, fk = lane >> 5;                  // MFMA operand lane map: A[i = l & 31][k = l >> 5], B[k = l >> 5][j = l & 31]
   fetch(0, pa[0], pb[0]);
   if (nk > 1) fetch(SPR_BK, pa[1], pb[1]);
-  if (ARES) {
-    // every float4 of this thread's A row: k = ak + 32 u, u < 2 nk — eight in flight at a time
-    const int nu = 2 * nk;
-    for (int u0 = 0; u0 < nu; u0 += 8) {
-      float4 q[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int k = ak + 32 * (u0 + u);
-        q[u] = (arow && u0 + u < nu && k < K) ? *(const float4*)(arow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (u0 + u < nu) {
-          const int k = ak + 32 * (u0 + u);
-          As[k + 0][ar] = q[u].x; As[k + 1][ar] = q[u].y; As[k + 2][ar] = q[u].z; As[k + 3][ar] = q[u].w;
-        }
-      }
-    }
-  }
   park(0, pa[0], pb[0]);
   if (nk > 2) fetch(2 * SPR_BK, pa[0], pb[0]);
   __syncthreads();
   auto slab = [&](int kt, int buf) {
-    const int abase = (ARES ? kt : buf) * SPR_BK;
+    const int abase = buf * SPR_BK;
     float fa[16], fb[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {                           // this wave's half of the slab: k = 32 kh + 2 q + fk
@@ -730,25 +705,11 @@ extern "C" int ogl_small_proj_rows(const float* x, int64_t ldx, const int64_t* x
   if (M < 0 || M > 65536 || K <= 0 || (K & 3) || N <= 0 || N > 4096 || n_table <= 0) return OGL_EINVAL;
   if (M == 0) return OGL_OK;
   if (!x || !w || !y || ldx < K || ldw < K || ldy < N || (ldx & 3) || (ldw & 3) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return OGL_EINVAL;
-  const int nk = (int)ogl_cdiv(K, SPR_BK);
   const size_t b_bytes = sizeof(float) * 2 * SPR_BK * (SPR_BN + 4);
-  const size_t ares_bytes = sizeof(float) * (size_t)nk * SPR_BK * (SPR_BM + 2) + b_bytes;
   const size_t strm_bytes = sizeof(float) * 2 * SPR_BK * (SPR_BM + 2) + b_bytes;
   const dim3 grid((unsigned)ogl_cdiv(N, SPR_BN), (unsigned)std::min<int64_t>(ogl_cdiv(M, SPR_BM), m_live_dev ? 96 : 65535));
-  static bool attr_set = false;
-  if (!attr_set) {
-    OGL_CHECK_HIP(hipFuncSetAttribute((const void*)k_small_proj_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
-  // (measured, pubmed-like rung, same box: streaming both operands two slabs ahead 0.0958-0.0985 ms per step, A resident 0.1027 — all of
-  // a block's A loads and their 64 LDS stores per thread in front of its first MFMA cost more than the slab waits they remove: off)
-  static const bool ares_on = getenv("OGL_SPR_ARES") && getenv("OGL_SPR_ARES")[0] == '1';
-  if (ares_on && ares_bytes <= 160 * 1024)
-    hipLaunchKernelGGL(k_small_proj_rows<true>, grid, dim3(256), ares_bytes, (hipStream_t)stream, x, ldx, x_rows, n_table, (int)M, K, w, ldw,
-                       N, bias, relu, y, ldy, m_live_dev);
-  else
-    hipLaunchKernelGGL(k_small_proj_rows<false>, grid, dim3(256), strm_bytes, (hipStream_t)stream, x, ldx, x_rows, n_table, (int)M, K, w,
-                       ldw, N, bias, relu, y, ldy, m_live_dev);
+  hipLaunchKernelGGL(k_small_proj_rows, grid, dim3(256), strm_bytes, (hipStream_t)stream, x, ldx, x_rows, n_table, (int)M, K, w, ldw, N, bias,
+                     relu, y, ldy, m_live_dev);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }

@@ -11,7 +11,7 @@ from .. import ops
 from .sageconv import SAGEConv
 
 
-INREPO_T_IMAGES = __import__("os").environ.get("OGL_INREPO_T_IMAGES", "1") != "0"   # in-repo pooling layers: W^T images prepared with the step's others
+INREPO_T_IMAGES = True   # in-repo pooling layers: W^T images prepared with the step's others
 
 
 class GraphSAGE(nn.Module):

@@ -200,6 +200,22 @@ class HipSupervisedGraphSage(SupervisedGraphSage):
         self.gsync = parallel.GradSynchronizer(self.graphsage_model.parameters(), overlap=self.sharded is None, weight=1.0) \
             if parallel.is_distributed() else None
 
+    def optimizer_state_dict(self):
+        """The state a resumed stream needs beside the model's ``state_dict`` (R/export_model.py:107 saves the weights only): the
+        optimiser's moments and step count — from the sharded update when it is on (every rank must call this then: its moments
+        are gathered from their owning ranks), else from ``optim.Adam``."""
+        if getattr(self, "sharded", None) is not None:
+            return dict(kind="sharded", state=self.sharded.state_dict())
+        return dict(kind="adam", state=self.optimizer.state_dict())
+
+    def load_optimizer_state_dict(self, sd):
+        if sd["kind"] == "sharded":
+            if getattr(self, "sharded", None) is None:
+                raise RuntimeError("this checkpoint was taken with the sharded update (OGL_DP_SHARDED_UPDATE=1): build the optimiser the same way")
+            self.sharded.load_state_dict(sd["state"])
+        else:
+            self.optimizer.load_state_dict(sd["state"])
+
     def _exchange_and_step(self, weight=None, single=False):
         """The end of a replica's step: grads <- sum_r weight_r * grad_r, then the optimiser — or, with the sharded update on, the
         reduce-scatter / sharded Adam / all-gather that replaces both (the same collectives on every rank either way)."""

@@ -52,9 +52,9 @@ class GatheredRows:
 # (arxiv H = 32: 25 vs 36 us — the gathered 128-byte rows cost more than 32 extra reduction steps)
 ADDROWS_MIN_WIDTH = 128
 # the cached layers' aggregator writes the image of the pooled rows only (OGL_IMAGE_ONLY_POOL=0: the fp32 rows too, which nobody reads)
-POOL_FP32_OUT = os.environ.get("OGL_IMAGE_ONLY_POOL", "1") == "0"
+POOL_FP32_OUT = False
 # in-repo 'mean' layers behind the first: the destinations' own rows and the neighbour mean from ONE autograd node (ops._SelfNeighFn)
-SELF_NEIGH_NODE = os.environ.get("OGL_SELF_NEIGH_NODE", "1") != "0"
+SELF_NEIGH_NODE = True
 _EYE = {}
 
 
@@ -380,8 +380,12 @@ class SAGEConv(nn.Module):
         e = ops.as_mat(e.reshape(n_dst * S, -1))
         assert e.shape[1] == self._edge_feats
         eidx = torch.arange(n_dst * S, dtype=torch.int32, device=idx.device).view(n_dst, S)
-        eidx = torch.where(idx[:, :1] >= 0, eidx, torch.full_like(eidx, -1)).contiguous()    # (all S edges exist, or none)
-        e_red, _ = ops.reduce_fwd(e, eidx, op)
+        eidx = torch.where(idx >= 0, eidx, torch.full_like(eidx, -1)).contiguous()    # (an edge exists where its slot holds a source)
+        if e.requires_grad:
+            # learned edge features: the differentiable aggregator (the reference's edge features flow through autograd with the message)
+            e_red = ops.neighbor_reduce(e, eidx, op)
+        else:
+            e_red, _ = ops.reduce_fwd(e, eidx, op)
         if ops.take_image(h_neigh, pop=False) is not None:
             ops.take_image(h_neigh)               # (the pooled rows' image does not cover the appended columns)
         return torch.cat((h_neigh, e_red[:, :self._edge_feats]), 1)

@@ -206,7 +206,7 @@ def publish_i64(src_dev, seq_dev, dst_host_pinned):
             meta=dict(n=n))
 
 
-SAMPLE_FUSED = os.environ.get("OGL_SAMPLE_FUSED", "1") != "0"      # the sampling phase of a small batch as ONE launch
+SAMPLE_FUSED = True      # the sampling phase of a small batch as ONE launch
 
 
 def sample_blocks_small_fits(B, fanout):
@@ -452,7 +452,7 @@ def reduce_fwd(src: torch.Tensor, idx: torch.Tensor, op: str, want_argmax: bool 
     return out, argmax
 
 
-def reduce_fwd_img(src: torch.Tensor, idx: torch.Tensor, want_argmax: bool = False, want_out: bool = True, plan_ws=None):
+def reduce_fwd_img(src: torch.Tensor, idx: torch.Tensor, want_argmax: bool = False, want_out: bool = True):
     """max-reduce that also returns the bf16x3 image of its output: (out, argmax, X3Image).  ``want_out=False``: the image only
     (``out`` is None: a consumer that reads nothing but the image — the cached inference layers — saves 40 % of the launch's writes)."""
     src = as_mat(src)
@@ -464,15 +464,6 @@ def reduce_fwd_img(src: torch.Tensor, idx: torch.Tensor, want_argmax: bool = Fal
     img = X3Image(_x3_alloc(n_dst, d, src.device), n_dst, d)
     i32 = idx if idx.dtype == torch.int32 else None
     i64 = idx if idx.dtype == torch.int64 else None
-    if plan_ws is not None:
-        # ``plan_ws``: a pool-backward plan workspace — the launch also runs the plan's bucket pass into it (ogl_reduce_fwd_img_plan)
-        assert i32 is not None and want_argmax and want_out
-        o1, o2 = C.c_int64(0), C.c_int64(0)
-        check(_lib.lib().ogl_pool_bwd_x3_plan_slots(n_dst, fanout, d, src.shape[0], C.byref(o1), C.byref(o2)), "ogl_pool_bwd_x3_plan_slots")
-        _launch("ogl_reduce_fwd_img", _lib.lib().ogl_reduce_fwd_img_plan, _ptr(src), _ld(src), src.shape[0], _ptr(i32), n_dst, fanout, d,
-                _ptr(out), _ld(out), _ptr(argmax), _ptr(img.buf), plan_ws.data_ptr() + o1.value, plan_ws.data_ptr() + o2.value, _stream(),
-                meta=dict(n_dst=n_dst, fanout=fanout, d=d, op="max", argmax=True, idx_bytes=4, out=True, plan=True))
-        return out, argmax, img
     _launch("ogl_reduce_fwd_img", _lib.lib().ogl_reduce_fwd_img, _ptr(src), _ld(src), src.shape[0], _ptr(i32), _ptr(i64), n_dst, fanout, d,
             _ptr(out), _ld(out) if out is not None else padded_ld(d), _ptr(argmax), _ptr(img.buf), _stream(),
             meta=dict(n_dst=n_dst, fanout=fanout, d=d, op="max", argmax=argmax is not None, idx_bytes=idx.element_size(), out=out is not None))
@@ -530,9 +521,9 @@ def reduce_bwd(dout: torch.Tensor, idx32, argmax, op: str, n_src: int, fanout=No
 # --------------------------------------------------------------------------------------------
 # dense projections
 # --------------------------------------------------------------------------------------------
-def linear_fwd(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_rows=None, out=None, bias2=None, want_bits=False):
+def linear_fwd(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_rows=None, out=None, bias2=None):
     """``bias2``: the second projection's own bias (dual-input form only): (bias + bias2) is formed inside the launch.
-    ``want_bits``: when the product takes the image kernel, its epilogue also emits the sign bits of y (``y._ogl_bits``)."""
+    """
     x = as_mat(x); w = as_mat(w)
     M = x_rows.numel() if x_rows is not None else x.shape[0]
     K, N = x.shape[1], w.shape[0]
@@ -552,7 +543,7 @@ def linear_fwd(x, w, bias=None, x2=None, w2=None, relu=False, x_rows=None, x2_ro
             if wimg is None:
                 bvec = bias if bias is not None else torch.zeros(N, dtype=torch.float32, device=x.device)
                 wimg = x3_split(w, append_vec=bvec)
-            return linear_fwd_x3(img, x_rows, wimg, relu=relu, x_nrows=x.shape[0], M=M, out=out, want_bits=want_bits)
+            return linear_fwd_x3(img, x_rows, wimg, relu=relu, x_nrows=x.shape[0], M=M, out=out)
     y = out if out is not None else empty_mat(M, N, x.device)
     if bias2 is not None:
         assert bias is not None and x2 is not None
@@ -630,9 +621,9 @@ def out_layer_bwd_weights(dy, x_self, x_neigh, want_bias=True, x_self_rows=None,
 
 OUT_LAYER_FUSED = os.environ.get("OGL_OUT_LAYER_FUSED") != "0"
 # the output layer's forward tail — neighbour max, [n_dst, 2K] -> N projection, cross entropy — as ONE launch (ogl_out_layer_fwd_ce)
-FUSED_OUT_FWD = os.environ.get("OGL_FUSED_OUT_FWD", "1") != "0"
-DEFER_LOSS_MEAN = os.environ.get("OGL_DEFER_LOSS_MEAN", "1") != "0"     # the fused loss's mean is finished by the backward's first launch
-OUT_FWD_ROWS = int(os.environ.get("OGL_OUT_FWD_R", "0"))        # destinations per block (0: automatic)
+FUSED_OUT_FWD = True
+DEFER_LOSS_MEAN = True     # the fused loss's mean is finished by the backward's first launch
+OUT_FWD_ROWS = 0        # destinations per block (0: automatic)
 
 
 def out_loss_fits(h, n_dst, idx, w_self, w_neigh, p_width):
@@ -644,13 +635,11 @@ def out_loss_fits(h, n_dst, idx, w_self, w_neigh, p_width):
             and bool(_lib.lib().ogl_out_layer_fwd_ce_fits(int(n_dst), int(idx.shape[1]), int(K), int(N))))
 
 
-def out_layer_fwd_ce(p, idx, h, n_dst, w_self, w_neigh, b_self, b_neigh, labels, want_grad=True, zero=None, want_mean=True, bwd_into=None):
+def out_layer_fwd_ce(p, idx, h, n_dst, w_self, w_neigh, b_self, b_neigh, labels, want_grad=True, zero=None, want_mean=True):
     """(mean loss, row losses, logits, neigh, argmax, dlogits / n_dst) of the output layer from its pooled projection rows ``p`` =
     relu(fc_pool(h)) in ONE launch; ``labels``: int64 tensor or LazyLabels; ``zero``: a contiguous fp32 buffer the grid clears on
     the side (the scatter target of the layer's backward).  ``want_mean=False``: the returned mean tensor gets NaN from this launch
-    (no last-block-done count, no device-scope fences) and its value from ``out_layer_bwd_inputs(finish_loss=...)``.
-    ``bwd_into = (dx_self [n_dst, K], dP [n_src, K] ALREADY ZERO)``: the combine's input gradients from the same launch
-    (ogl_out_layer_fwd_ce_bwd) — no ``zero`` then."""
+    (no last-block-done count, no device-scope fences) and its value from ``out_layer_bwd_inputs(finish_loss=...)``."""
     p = as_mat(p); h = as_mat(h); w_self = as_mat(w_self); w_neigh = as_mat(w_neigh)
     K, N = p.shape[1], w_self.shape[0]
     dev = p.device
@@ -671,17 +660,6 @@ def out_layer_fwd_ce(p, idx, h, n_dst, w_self, w_neigh, b_self, b_neigh, labels,
     if zero is not None:
         assert zero.is_contiguous() and zero.dtype == torch.float32 and zero.numel() % 4 == 0
         zn = zero.numel()
-    if bwd_into is not None:
-        assert zero is None and want_grad
-        dxs, dP = bwd_into
-        assert tuple(dxs.shape) == (n_dst, K) and dP.shape[0] == p.shape[0] and dP.shape[1] >= K
-        _launch("ogl_out_layer_fwd_ce", _lib.lib().ogl_out_layer_fwd_ce_bwd, _ptr(p), _ld(p), p.shape[0], _ptr(idx), n_dst, int(idx.shape[1]),
-                _ptr(h), _ld(h), K, _ptr(w_self), _ld(w_self), _ptr(w_neigh), _ld(w_neigh), _ptr(b_self), _ptr(b_neigh), N, _ptr(neigh),
-                _ld(neigh), _ptr(argmax), _ptr(logits), _ld(logits), _ptr(table), table.numel(), _ptr(ids), C.c_float(1.0 / n_dst),
-                _ptr(loss), _ptr(dl), _ld(dl), _ptr(mean), ce_counter(dev, stream) if want_mean else None, OUT_FWD_ROWS,
-                _ptr(dxs), _ld(dxs), _ptr(dP), _ld(dP), stream,
-                meta=dict(n_dst=n_dst, fanout=int(idx.shape[1]), d=K, N=N, zero_bytes=0, with_bwd=True))
-        return mean, loss, logits, neigh, argmax, dl
     _launch("ogl_out_layer_fwd_ce", _lib.lib().ogl_out_layer_fwd_ce, _ptr(p), _ld(p), p.shape[0], _ptr(idx), n_dst, int(idx.shape[1]),
             _ptr(h), _ld(h), K, _ptr(w_self), _ld(w_self), _ptr(w_neigh), _ld(w_neigh), _ptr(b_self), _ptr(b_neigh), N, _ptr(neigh),
             _ld(neigh), _ptr(argmax), _ptr(logits), _ld(logits), _ptr(table), table.numel(), _ptr(ids), C.c_float(1.0 / n_dst),
@@ -709,15 +687,9 @@ def relu_bwd_img(dy, y):
 # The ReLU backward of a layer's output in the epilogue of the product that computes that output's gradient (ogl_linear_fwd_x3_ext's
 # `mask`): removes the 16 us ogl_relu_bwd_img launch of the Reddit step and 60 MB of traffic — and measured NO gain (same box,
 # alternating replayed runs: 1.056 / 1.066 ms without, 1.063 / 1.078 with): the masked epilogue costs the product 10 us on the
-# critical path, while the separate pass ran beside the side stream's weight gradients.  Off by default; OGL_FUSE_RELU_BWD=1 and
-# tests/test_gpu_round3.py keep it exercised.
-FUSE_RELU_BWD = os.environ.get("OGL_FUSE_RELU_BWD", "0") == "1"
-# The output layer's input gradients from its forward + loss launch (ogl_out_layer_fwd_ce_bwd; their scatter target cleared by the
-# tile-less blocks of the fc_pool product, ogl_linear_fwd_x3_zero).  Bit-identical, one launch and 6 us of kernel time fewer — and
-# measured SLOWER inside the replayed Reddit step (same box, alternating: 0.9228 / 0.9241 / 0.9275 ms without, 0.9301 / 0.9374 / 0.9327
-# with; 0.9407 / 0.9364 against 0.9533 / 0.9558 on a second box): the chain reaches k_pool_values 7 us earlier, where it now meets the
-# side branch's dual weight-gradient product head-on (61 us instead of 37).  Off; OGL_OUT_FWD_BWD=1.
-OUT_FWD_BWD = os.environ.get("OGL_OUT_FWD_BWD", "0") == "1"
+# critical path, while the separate pass ran beside the side stream's weight gradients.  Off (a module constant: tests/test_gpu_round3.py
+# flips it to keep the masked epilogue of ogl_linear_fwd_x3_ext exercised).
+FUSE_RELU_BWD = False
 
 
 def linear_bwd_input(dy, w, ymask=None, dy_img=None, add_head=None, out_relu_mask=None):
@@ -848,39 +820,15 @@ def x3_split_t(x, rows=None, ones_row=False, interleave=0):
     return X3Image(buf, nimg, Mi)
 
 
-class SignBits:
-    """[y > 0] of a matrix as one byte per 4-column group (bit c = column 4 g + c): ``buf`` uint8 [rows, ld]."""
-    __slots__ = ("buf", "rows", "cols", "ld")
-
-    def __init__(self, rows, cols, device):
-        self.rows, self.cols, self.ld = int(rows), int(cols), (int(cols) + 3) // 4
-        self.buf = torch.empty((self.rows, self.ld), dtype=torch.uint8, device=device)
-
-
-def linear_fwd_x3(x_img, x_rows, w_img, relu=False, x_nrows=None, M=None, out=None, want_bits=False, zero=None):
+def linear_fwd_x3(x_img, x_rows, w_img, relu=False, x_nrows=None, M=None, out=None):
     """y = act(x_img[x_rows] @ w_img.T); a bias is folded into the images (x3_split append_ones / append_vec).
-    ``x_nrows`` bounds the valid gather ids (default: every image row); without a gather ``M`` selects a row prefix.
-    ``want_bits``: also the SignBits of y (attached to it as ``y._ogl_bits``): the ReLU mask a backward pass needs, from the epilogue."""
+    ``x_nrows`` bounds the valid gather ids (default: every image row); without a gather ``M`` selects a row prefix."""
     M = x_rows.numel() if x_rows is not None else (x_img.rows if M is None else M)
     x_nrows = x_img.rows if x_nrows is None else x_nrows
     K, N = x_img.K, w_img.rows
     assert w_img.K == K, "both images must be built with the same append choice"
     y = out if out is not None else empty_mat(M, N, x_img.buf.device)
     assert y.shape[0] == M and y.shape[1] == N
-    if zero is not None:
-        # ``zero``: a contiguous buffer cleared by the launch's tile-less blocks (ogl_linear_fwd_x3_zero)
-        assert not want_bits and zero.is_contiguous() and zero.data_ptr() % 16 == 0 and (zero.numel() * zero.element_size()) % 16 == 0
-        _launch("ogl_linear_fwd_x3", _lib.lib().ogl_linear_fwd_x3_zero, _ptr(x_img.buf), x_img.rows,
-                _ptr(_ids(x_rows) if x_rows is not None else None), x_nrows, M, K, _ptr(w_img.buf), N, 1 if relu else 0, _ptr(y),
-                _ld(y), _ptr(zero), zero.numel() * zero.element_size(), _stream(), meta=dict(M=M, K=K, N=N, K2=0, zero_bytes=zero.numel() * zero.element_size()))
-        return y
-    if want_bits:
-        bits = SignBits(M, N, y.device)
-        _launch("ogl_linear_fwd_x3", _lib.lib().ogl_linear_fwd_x3_bits, _ptr(x_img.buf), x_img.rows,
-                _ptr(_ids(x_rows) if x_rows is not None else None), x_nrows, M, K, _ptr(w_img.buf), N, 1 if relu else 0, _ptr(y),
-                _ld(y), _ptr(bits.buf), bits.ld, _stream(), meta=dict(M=M, K=K, N=N, K2=0, bits=True))
-        y._ogl_bits = (bits, y._version, y.data_ptr())
-        return y
     _launch("ogl_linear_fwd_x3", _lib.lib().ogl_linear_fwd_x3, _ptr(x_img.buf), x_img.rows,
             _ptr(_ids(x_rows) if x_rows is not None else None), x_nrows, M, K, _ptr(w_img.buf), N, 1 if relu else 0, _ptr(y),
             _ld(y), _stream(), meta=dict(M=M, K=K, N=N, K2=0))
@@ -972,7 +920,7 @@ _W_IMAGES = {}
 PREPARE_WEIGHT_IMAGES = True
 # optim.Adam (device-side step count) may ask the step's weight-image launch to compute its per-step scalars: ``req`` = (step_dev,
 # scalars_dev, lr, beta1, beta2) until a launch takes it, ``served`` = (step_dev address, made while capturing?) afterwards
-ADAM_PRIME_IN_SPLIT = os.environ.get("OGL_ADAM_PRIME", "1") != "0"
+ADAM_PRIME_IN_SPLIT = True
 _ADAM_PRIME = {"req": None, "served": None}
 
 
@@ -1148,27 +1096,6 @@ class PoolPlan:
 
 
 POOL_PLAN = os.environ.get("OGL_POOL_PLAN", "1") != "0"
-# ... with its bucket pass inside the max aggregator's launch (ogl_reduce_fwd_img_plan: the waves hold every winner's slot and the sign of
-# the maximum; the 65 us side pass and its 34 MB of re-reads disappear).  Parity-green (tests/test_gpu_x3.py::
-# test_plan_bucket_pass_inside_the_aggregator) and OFF: the aggregator — on the critical path, at the HBM wall — takes 71 us instead of
-# 62 with the counting sort in it, and nothing comes back: the combine product beside the old side pass takes 70 us either way (its
-# operands are cold, not crowded), and the plan chain had ~35 us of slack before the backward's side branch needs its stream (a SECOND
-# copy of the bucket pass costs the step 30 us — by delaying that branch —, which is what suggested this).  Same box, alternating:
-# 0.942 / 0.947 / 0.964 ms without, 0.947 / 0.962 / 0.960 with.  OGL_POOL_PLAN_FUSED=1.
-POOL_PLAN_FUSED = os.environ.get("OGL_POOL_PLAN_FUSED", "0") == "1"
-
-
-def pool_bwd_x3_plan_finish(ws, nbytes, idx32, n_dst, d, n_src, side=True):
-    """The rest of ``pool_bwd_x3_plan`` for a workspace whose slot offsets / columns the aggregator already wrote: group totals, scan,
-    place — on the side stream when the fork is on.  Returns the PoolPlan."""
-    def launch():
-        _launch("ogl_pool_bwd_x3_plan", _lib.lib().ogl_pool_bwd_x3_plan_finish, _ptr(idx32), n_dst, idx32.shape[1], d, n_src, _ptr(ws), nbytes,
-                _stream(), meta=dict(n_dst=n_dst, d=d, n_src=n_src, fanout=idx32.shape[1], finish=True))
-
-    plan = PoolPlan(ws, nbytes, None, (n_dst, idx32.shape[1], d, n_src))
-    return _plan_on_side(plan, launch, (ws, idx32), side, late=POOL_PLAN_LATE)
-
-
 def pool_bwd_x3_plan(argmax, relu_out, idx32, n_src, side=True):
     """The part of the layer-0 pool backward that needs no gradient (a destination's columns in slot order, the slot offsets, the
     per-group record counts, their scan and every (destination, slot) segment's place in the group-major record array), enqueued NOW
@@ -1186,35 +1113,12 @@ def pool_bwd_x3_plan(argmax, relu_out, idx32, n_src, side=True):
                 meta=dict(n_dst=n_dst, d=d, n_src=n_src, fanout=idx32.shape[1]))
 
     plan = PoolPlan(ws, nbytes, None, (n_dst, idx32.shape[1], d, n_src))
-    return _plan_on_side(plan, launch, (ws, argmax, relu_out, idx32), side, late=POOL_PLAN_LATE)
+    return _plan_on_side(plan, launch, (ws, argmax, relu_out, idx32), side)
 
 
-# Where in the forward pass the layer-0 pool backward's plan runs.  Started right behind the aggregator it shares the chip with the
-# n1-row combine product (79 us instead of 58 alone in the step's timeline); started LATE — behind the next layer's fc_pool product,
-# at ``release_late_plans()`` — its 63 us bucket pass runs beside the output layer's few-hundred-block launches (the fused forward +
-# loss, the small input-gradient launch, an image pass: ~60 us during which the chip is mostly idle) and its scan / place passes
-# beside a 185-tile product that leaves 71 CUs free.
-# Measured (round 4, tools/ab_env.sh OGL_POOL_PLAN_LATE 3, one box): 1.005 / 1.007 / 1.008 ms early, 1.015 / 1.017 / 1.013 late — the combine does
-# run alone (72 us) and the bucket pass beside the 25 us loss launch, but the plan then occupies the ONE side stream until 506 us of the
-# step and the backward's weight-gradient branch starts 60 us later: its last product collides with the layer-0 weight gradient
-# (250 us instead of 225).  Off by default.
-POOL_PLAN_LATE = os.environ.get("OGL_POOL_PLAN_LATE", "0") == "1"
-_LATE_PLANS = []
-PLAN_STREAM = os.environ.get("OGL_PLAN_STREAM", "0") == "1"
-
-
-def release_late_plans():
-    """Plans parked by ``_plan_on_side(late=True)`` start from HERE: behind everything the current stream has enqueued so far, their
-    launches created after the stream's next launch (``_DEFERRED``)."""
-    if not _LATE_PLANS:
-        return
-    here = torch.cuda.Event()
-    here.record()
-    while _LATE_PLANS:
-        _DEFERRED.append(_LATE_PLANS.pop(0)(here))
-
-
-def _plan_on_side(plan, launch, tensors, side=True, late=False):
+# (Two later starts of the layer-0 pool backward's plan were measured in round 4 and removed in round 6: parked until the next layer's
+# fc_pool product was enqueued, 1.005-1.008 -> 1.013-1.017 ms per step; on a third stream of its own, +100 us: DESIGN.md section 8.)
+def _plan_on_side(plan, launch, tensors, side=True):
     """Run ``launch()`` — the gradient-free half of a backward pass, enqueued by the FORWARD pass — on the side stream when the fork
     is on (else right here); ``plan.event`` then marks its end, ``plan.pending`` that its launches still wait for the caller's next
     launch to be created first (``_DEFERRED``: in a captured step the first-created child of a node keeps its parent's queue)."""
@@ -1223,10 +1127,9 @@ def _plan_on_side(plan, launch, tensors, side=True, late=False):
         launch()
         return plan
     dev = torch.cuda.current_device()
-    key = ("plan", dev) if (late and PLAN_STREAM) else dev      # (a late plan on a stream of its own: the backward's side branch is not held up)
-    st = _SIDE["streams"].get(key)
+    st = _SIDE["streams"].get(dev)
     if st is None:
-        st = _SIDE["streams"][key] = torch.cuda.Stream(device=dev)
+        st = _SIDE["streams"][dev] = torch.cuda.Stream(device=dev)
     plan.pending = True
 
     def make(here):
@@ -1245,9 +1148,6 @@ def _plan_on_side(plan, launch, tensors, side=True, late=False):
                         t.record_stream(st)
         return run
 
-    if late:
-        _LATE_PLANS.append(make)        # (starts at release_late_plans(), or when its consumer asks for it: _plan_ready)
-        return plan
     here = torch.cuda.Event()
     here.record()                       # the plan's inputs exist from HERE on ...
     _DEFERRED.append(make(here))
@@ -1257,14 +1157,13 @@ def _plan_on_side(plan, launch, tensors, side=True, late=False):
 def _plan_ready(plan):
     """Make the current stream wait for a plan enqueued by ``_plan_on_side``."""
     if plan.pending:
-        release_late_plans()
         _flush_deferred()
     if plan.event is not None:
         torch.cuda.current_stream().wait_event(plan.event)
 
 
 SEG_REDUCE_BWD = os.environ.get("OGL_SEG_REDUCE_BWD", "1") != "0"    # mean / sum backward as a planned segmented gather (no atomics)
-SEG_MIN_EDGES = int(os.environ.get("OGL_SEG_MIN_EDGES", "4096"))
+SEG_MIN_EDGES = 4096
 
 
 def seg_bwd_fits(idx, d, n_src):
@@ -1298,13 +1197,6 @@ def reduce_bwd_seg_apply(dout, idx32, plan, op, mask=None, want_out=True, want_i
     _plan_ready(plan)
     out = empty_mat(n_src, d, dout.device) if want_out else None
     img = X3Image(_x3_alloc(n_src, d, dout.device), n_src, d) if want_image else None
-    if isinstance(mask, SignBits):
-        assert mask.rows == n_src and mask.cols == d
-        _launch("ogl_reduce_bwd_seg_apply", _lib.lib().ogl_reduce_bwd_seg_apply_bits, _ptr(dout), _ld(dout), _ptr(idx32), n_dst, fanout, d,
-                REDUCE_OPS[op], n_src, _ptr(mask.buf), mask.ld, _ptr(out), _ld(out) if out is not None else 0,
-                _ptr(img.buf) if img is not None else None, _ptr(plan.ws), plan.nbytes, _stream(),
-                meta=dict(n_dst=n_dst, fanout=fanout, d=d, n_src=n_src, op=op, out=out is not None, image=img is not None, mask="bits"))
-        return out, img
     if mask is not None:
         mask = as_mat(mask)
         assert tuple(mask.shape) == (n_src, d)
@@ -1327,51 +1219,6 @@ def pool_bwd_x3_apply(dout, idx32, plan, n_src):
     _launch("ogl_pool_bwd_x3_apply", _lib.lib().ogl_pool_bwd_x3_apply, _ptr(dout), _ld(dout), _ptr(idx32), n_dst, idx32.shape[1], d, n_src,
             _ptr(buf), _ptr(plan.ws), plan.nbytes, _stream(), meta=dict(n_dst=n_dst, d=d, n_src=n_src, fanout=idx32.shape[1]))
     return X3Image(buf, d, 32 * G)
-
-
-# The layer-0 pool backward WITHOUT the dense dP^T image: the weight-gradient product's builder waves make each step's tile in LDS
-# from the plan's records (csrc/pool_bwd_x3.hip, k_gemm_x3rf).  Parity-green and OFF (OGL_POOL_RF=1 to take it): measured on a Reddit
-# block, alone, HIP events (tools/rf_probe.py, profiles/r05_rf_probe.txt) — round-4 pair (values + groups + dW_pool0 + slab sum)
-# 333-342 us; record-fed 602 us; its multipliers with nothing else running 212 us, + B pieces 250, + conversion 293, + the records
-# 560: LDS float atomics run at ~0.3 lane-operations per clock per CU on this part, every one of a slab's five column tiles
-# re-accumulates the same records, and the k-major 128 x 128 multipliers alone already take what the whole 256 x 128 image product takes.
-POOL_RF = os.environ.get("OGL_POOL_RF", "0") == "1"
-# 'meanpool' first layer: the ReLU mask of relu(fc_pool(x)) as sign bits emitted by the product's epilogue (ogl_linear_fwd_x3_bits ->
-# ogl_reduce_bwd_seg_apply_bits: 9 MB instead of the 150 MB fp32 matrix at the Reddit rung).  Bit-identical and OFF: measured same box,
-# alternating (bench.py --aggregator meanpool): 1.211 / 1.208 ms per step without, 1.238 / 1.235 with — the mean backward does not
-# get faster (0.2073 -> 0.2097 ms: it is paced by its gathered gradient rows, not by the mask stream) and the forward product's epilogue
-# pays for the byte stores.  OGL_POOL_MEAN_BITS=1 to take it.
-POOL_MEAN_BITS = os.environ.get("OGL_POOL_MEAN_BITS", "0") == "1"
-
-
-def pool_bwd_x3_dw(dout, idx32, plan, n_src, x_img, K, x_rows=None, x_nrows=None, want_bias=True, dw_out=None, defer_for=None):
-    """dw [d, K], db [d] of fc_pool from the pooled rows' gradient ``dout`` and a PoolPlan: ``ogl_pool_bwd_x3_dw`` (values pass + the
-    record-fed product).  ``x_img``: the row-major image of the projection input with the ones slot (K + 1), gathered by ``x_rows``.
-    ``defer_for`` as in ``linear_bwd_weight_x3k``."""
-    dout = as_mat(dout)
-    n_dst, d = dout.shape
-    assert plan.shape == (n_dst, idx32.shape[1], d, n_src) and idx32.dtype == torch.int32 and idx32.is_contiguous()
-    assert x_img.K == K + 1
-    _plan_ready(plan)
-    dev = dout.device
-    dw = dw_out if dw_out is not None else torch.empty((d, K), dtype=torch.float32, device=dev)
-    db = torch.empty(d, dtype=torch.float32, device=dev) if want_bias else None
-    nbytes = int(_lib.lib().ogl_pool_bwd_x3_dw_workspace_bytes(n_src, d, K))
-    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
-    defer = (defer_for is not None and _SLABS["on"] and dw_out is None and defer_for[0] is not None and tuple(defer_for[0].shape) == (d, K)
-             and (db is None or defer_for[1] is not None)
-             and all(t is None or (t.is_leaf and t.is_contiguous()) for t in defer_for) and not _slabs_settle(defer_for))
-    ns, wl = C.c_int(0), C.c_int64(0)
-    _launch("ogl_pool_bwd_x3_dw", _lib.lib().ogl_pool_bwd_x3_dw, _ptr(dout), _ld(dout), n_dst, idx32.shape[1], d, n_src, _ptr(plan.ws),
-            plan.nbytes, _ptr(x_img.buf), x_img.rows, _ptr(_ids(x_rows) if x_rows is not None else None),
-            x_img.rows if x_nrows is None else x_nrows, K, _ptr(dw), _ld(dw), _ptr(db), _ptr(ws), nbytes, 1 if defer else 0,
-            C.byref(ns), C.byref(wl), _stream(), meta=dict(n_dst=n_dst, d=d, n_src=n_src, fanout=idx32.shape[1], M=n_src, K=K, N=d))
-    if defer:
-        pend, stride = _SLABS["pending"], d * wl.value
-        pend[defer_for[0].data_ptr()] = SlabGrad(ws, stride, wl.value, ns.value, d, K, 0, dw)
-        if db is not None:
-            pend[defer_for[1].data_ptr()] = SlabGrad(ws, stride, wl.value, ns.value, d, 1, K, db)
-    return dw, db
 
 
 def linear_bwd_weight_x3(dyT_img, xT_img, want_bias=True, dw_out=None):
@@ -1464,7 +1311,7 @@ DUAL_DW = os.environ.get("OGL_DUAL_DW", "1") != "0"
 # 'mean', whose weight gradients are all that is left of its backward: 0.4208 -> 0.3867 ms per step, same box (relu_bwd_img + one
 # k-major product where relu_bwd + a transposed image + two products + two reduction launches ran); with an input gradient on the
 # critical path beside it ('meanpool') the one big product is in the way: 1.2057 -> 1.2172 ms.  OGL_DUAL_DW_CAT=1 / 0: always / never.
-DUAL_DW_CAT_MODE = os.environ.get("OGL_DUAL_DW_CAT", "auto")
+DUAL_DW_CAT_MODE = "auto"
 DUAL_DW_CAT = DUAL_DW_CAT_MODE != "0"
 
 
@@ -1612,7 +1459,7 @@ def _row_image_for(x, x_rows, x_img):
     return img if (img is not None and img.nbytes < (1 << 32)) else None
 
 
-K_MAJOR_DY = os.environ.get("OGL_BWW_KMAJOR_DY") != "0"    # ... and dy's own row-major image when its producer wrote one
+K_MAJOR_DY = True    # ... and dy's own row-major image when its producer wrote one
 
 
 def _dy_rows_image(dy, dy_img):
@@ -1622,7 +1469,7 @@ def _dy_rows_image(dy, dy_img):
     return None
 
 
-BWW_DIRECT_MAX_ROWS = int(os.environ.get("OGL_BWW_DIRECT_MAX_ROWS", "1024"))   # below this many reduction rows: the direct k-major kernel
+BWW_DIRECT_MAX_ROWS = 1024   # below this many reduction rows: the direct k-major kernel
 
 
 def weight_grad(dy, x, x_rows=None, want_bias=True, dyT=None, x_img=None, dy_img=None, dw_out=None, defer_for=None):
@@ -1678,7 +1525,7 @@ CE_MEAN_SMALL_MAX_B = 128      # up to here the mean comes from the cross-entrop
 
 
 CE_SMALL_MAX_ZERO = 65536       # floats the one-workgroup loss launch clears on the side (ogl_ce_fwd_bwd_mean_gather)
-SMALL_LOSS_FUSED = os.environ.get("OGL_SMALL_LOSS_FUSED", "1") != "0"    # the last small 'pool' layer + its loss + the dlogits-only gradients: ONE launch
+SMALL_LOSS_FUSED = True    # the last small 'pool' layer + its loss + the dlogits-only gradients: ONE launch
 SMALL_LOSS_ZERO_MAX = 1 << 23   # floats the fused small output layer + loss launch clears on the side (ogl_small_pool_layer_fwd_ce_bwd)
 
 
@@ -1934,7 +1781,7 @@ def _dw_out(w, N, K):
 FORK_BACKWARD = os.environ.get("OGL_FORK_BWD", "1") != "0"
 # in a captured step the fork becomes parallel graph branches (with the fork points placed where the side work's inputs are ready:
 # 1.10 -> 1.05-1.07 ms per replayed Reddit step, the eager figure; a first placement that forked late was 1 % slower than serial)
-FORK_IN_GRAPHS = os.environ.get("OGL_FORK_BWD_GRAPHS", "1") != "0"
+FORK_IN_GRAPHS = True
 _SIDE = {"streams": {}, "keep": [], "active": False, "off": 0}
 
 
@@ -2023,7 +1870,6 @@ def side_join():
             torch.cuda.current_stream().wait_stream(st)
         _SIDE["active"] = False
     _SIDE["keep"].clear()
-    _LATE_PLANS.clear()             # (a plan parked by a forward pass whose backward has ended without asking for it: dropped)
 
 
 class _LinearFn(torch.autograd.Function):
@@ -2283,10 +2129,7 @@ class _PoolMeanFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, x_rows, idx):
         need = w.requires_grad or (bias is not None and bias.requires_grad)
-        # (the ReLU mask the backward needs as sign bits from the product's epilogue: 1/16 of the bytes of p, which is then free to go)
-        p = linear_fwd(x, w, bias, relu=True, x_rows=x_rows, want_bits=need and POOL_MEAN_BITS)
-        ent = getattr(p, "_ogl_bits", None)
-        ctx.p_bits = ent[0] if (ent is not None and ent[1] == p._version and ent[2] == p.data_ptr()) else None
+        p = linear_fwd(x, w, bias, relu=True, x_rows=x_rows)
         if _n1_images_ok(idx.shape[0], p.shape[1]) and p.shape[1] % 4 == 0:
             out, img = reduce_fwd_mean_img(p, idx)
             attach_image(out, img)
@@ -2297,7 +2140,7 @@ class _PoolMeanFn(torch.autograd.Function):
         ctx.n_src, ctx.fanout, ctx.has_bias, ctx.bias_t = p.shape[0], idx.shape[1], bias is not None, bias
         ctx.seg_plan = reduce_bwd_seg_plan(idx, p.shape[1], p.shape[0]) if need else None
         ctx.p_shape = tuple(p.shape)
-        ctx.save_for_backward(x, w, x_rows, p if ctx.p_bits is None else None, idx)
+        ctx.save_for_backward(x, w, x_rows, p, idx)
         return out
 
     @staticmethod
@@ -2306,8 +2149,6 @@ class _PoolMeanFn(torch.autograd.Function):
         plan, ctx.seg_plan = ctx.seg_plan, None
         if plan is None:                                  # (a second backward pass over a retained graph: the plan was consumed)
             plan = reduce_bwd_seg_plan(idx, ctx.p_shape[1], ctx.p_shape[0], side=False)
-        if ctx.p_bits is not None:
-            p = ctx.p_bits                                # (the mask as sign bits: reduce_bwd_seg_apply takes either)
         K = x.shape[1]
         rimg = _row_image_for(x, x_rows, None) if (_MODE["name"] != "f32" and ctx.n_src >= X3_BWW_MIN_ROWS) else None
         if rimg is not None and rimg.K == K + 1:
@@ -2358,14 +2199,9 @@ class _PoolMaxFn(torch.autograd.Function):
         plan_ok = (POOL_PLAN and need and not x.requires_grad and idx.dtype == torch.int32 and _MODE["name"] != "f32"
                    and ctx.n_src >= X3_BWW_MIN_ROWS and p.shape[1] <= 640 and ctx.fanout <= 63 and idx.shape[0] * p.shape[1] < (1 << 27)
                    and (w.requires_grad or (bias is not None and bias.requires_grad)))
-        fused_ws = None
         if _n1_images_ok(idx.shape[0], p.shape[1]):
             # the pooled rows feed the n1-row combine product: their bf16x3 image goes out beside them
-            if plan_ok and POOL_PLAN_FUSED and idx.is_contiguous() and _ld(p) % 4 == 0:
-                # ... and the bucket pass of the backward's plan runs in the same waves (they hold every winner's slot)
-                nbytes = int(_lib.lib().ogl_pool_bwd_x3_workspace_bytes(idx.shape[0], idx.shape[1], p.shape[1], ctx.n_src))
-                fused_ws = (torch.empty(max(nbytes, 16), dtype=torch.uint8, device=p.device), nbytes)
-            out, argmax, img = reduce_fwd_img(p, idx, want_argmax=need, plan_ws=fused_ws[0] if fused_ws is not None else None)
+            out, argmax, img = reduce_fwd_img(p, idx, want_argmax=need)
             attach_image(out, img)
         else:
             out, argmax = reduce_fwd(p, idx, "max", want_argmax=need)
@@ -2373,9 +2209,7 @@ class _PoolMaxFn(torch.autograd.Function):
             _CAPTURE.append(dict(argmax=argmax, neigh=out))
         ctx.bias_t = bias
         ctx.pool_plan = None
-        if fused_ws is not None:
-            ctx.pool_plan = pool_bwd_x3_plan_finish(fused_ws[0], fused_ws[1], idx, idx.shape[0], out.shape[1], ctx.n_src)
-        elif plan_ok:
+        if plan_ok:
             # layer 0 (see backward): the gradient-free half of the pool backward starts here, beside the products that follow
             ctx.pool_plan = pool_bwd_x3_plan(argmax, out, idx, ctx.n_src)
         ctx.dp_slot = None
@@ -2399,12 +2233,6 @@ class _PoolMaxFn(torch.autograd.Function):
             ctx.pool_plan = None
             G = (ctx.n_src + 31) // 32
             rimg = _row_image_for(x, x_rows, None)
-            if (POOL_RF and plan is not None and rimg is not None and rimg.K == x.shape[1] + 1
-                    and rimg.buf.numel() < (1 << 32)):
-                # the record-fed product: dP^T is built tile by tile in LDS from the plan's records, its 226 MB image never exists
-                dw, db = pool_bwd_x3_dw(dout, idx32, plan, ctx.n_src, rimg, x.shape[1], x_rows=x_rows, x_nrows=x.shape[0],
-                                        want_bias=ctx.has_bias, dw_out=_dw_out(w, *w.shape), defer_for=(w, ctx.bias_t, None))
-                return None, dw, (db if ctx.has_bias else None), None, None
             dyT = pool_bwd_x3_apply(dout, idx32, plan, ctx.n_src) if plan is not None else pool_bwd_x3(dout, argmax, out, idx32, ctx.n_src)
             if rimg is not None and rimg.K == x.shape[1] + 1:
                 # the resident table's own image, its rows gathered in the dealt order of dP^T: no X^T image
@@ -2454,7 +2282,6 @@ class _SagePoolLayerFn(torch.autograd.Function):
             p = linear_fwd_x3(himg, None, wimg, relu=True)
         else:
             p = linear_fwd(h, w_pool, b_pool, relu=True)
-        release_late_plans()
         need = any(t is not None and t.requires_grad for t in (h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh))
         neigh, argmax = reduce_fwd(p, idx, "max", want_argmax=need)
         bias = None
@@ -2501,7 +2328,7 @@ class _SagePoolLayerFn(torch.autograd.Function):
                 db2 if ctx.has_bias else None, None, None, None)
 
 
-def _out_layer_backward(ctx, dy, h, w_pool, w_self, w_neigh, neigh, argmax, pre=None):
+def _out_layer_backward(ctx, dy, h, w_pool, w_self, w_neigh, neigh, argmax):
     """Backward of a 'pool' layer with few output columns (the output layer), shared by ``_SagePoolLayerFn`` and ``_SagePoolLossFn``:
     (dh, dw_pool, db_pool, dw_self, dw_neigh, db_self, db_neigh).  The combine's backward in two launches, its input gradient for
     the pooled rows scattered to the winners as it is computed; the fc_self part joins dh in the epilogue of the fc_pool input
@@ -2518,26 +2345,16 @@ def _out_layer_backward(ctx, dy, h, w_pool, w_self, w_neigh, neigh, argmax, pre=
     # measured 1.075-1.084 -> 1.056-1.059 ms per replayed Reddit step, same box, alternating runs)
     at0 = fork_point() if tall else None
     finish, ctx.loss_out = getattr(ctx, "loss_out", None), None
-    if pre is not None:
-        # (``pre``: both input gradients came out of the forward launch — _SagePoolLossFn; dp as a [n_src, K] view of its padded buffer)
-        dx_self, dp = pre[0], pre[1][:, :h.shape[1]]
-    else:
-        dx_self, dp = out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src,
-                                           dp_zeroed=take_zeroed(slot, n_src, h.shape[1]) if slot is not None else None, finish_loss=finish)
-        finish = None
-    dp_img = None
-    if pre is not None and tall:
-        # (the critical launch FIRST — see above: with no input-gradient launch in front of it the side section would be the fork's
-        # first child and take the main queue)
-        dp_img = x3_split(dp)
+    dx_self, dp = out_layer_bwd_inputs(dy, w_self, w_neigh, argmax, neigh, n_src,
+                                       dp_zeroed=take_zeroed(slot, n_src, h.shape[1]) if slot is not None else None, finish_loss=finish)
+    finish = None
     with (side_section(dy, h, neigh, at=at0) if tall else _NoSection()):
         if finish is not None:                   # the deferred mean of the forward launch: one wave, off the critical path
             _launch("ogl_loss_mean_finish", _lib.lib().ogl_loss_mean_finish, _ptr(finish[0]), finish[0].numel(), _ptr(finish[1]), _stream(),
                     meta=dict(n=finish[0].numel()))
         dw_self, dw_neigh, db, db2 = out_layer_bwd_weights(dy, h_dst, neigh, want_bias=ctx.has_bias,
                                                            dws_out=_dw_out(w_self, *w_self.shape), dwn_out=_dw_out(w_neigh, *w_neigh.shape))
-    if dp_img is None:
-        dp_img = x3_split(dp) if tall else None
+    dp_img = x3_split(dp) if tall else None
     at = fork_point() if tall else None
     dh = linear_bwd_input(dp, w_pool, None, dy_img=dp_img, add_head=dx_self,
                           out_relu_mask=h if (FUSE_RELU_BWD and ctx.h_relu_out and tall) else None)
@@ -2561,29 +2378,17 @@ class _SagePoolLossFn(torch.autograd.Function):
         ctx.h_relu_out = bool(getattr(h, "_ogl_relu_out", False))
         himg = take_image(h) if _n1_images_ok(h.shape[0], h.shape[1], w_pool.shape[0]) else None
         ctx.h_img = himg if (himg is not None and himg.K == h.shape[1] + 1) else None
-        pre_zero = None
-        # round 5: the combine's input gradients come out of the forward + loss launch; their scatter target is cleared by the CUs the
-        # fc_pool product leaves idle (185 tiles on 256 CUs at the Reddit shape)
-        fuse = OUT_FWD_BWD and h.requires_grad and ctx.h_img is not None and OUT_FWD_ROWS in (0, 1, 2)
         if ctx.h_img is not None:
             wimg = weight_image("wb", w_pool, b_pool)
             if wimg is None:
                 weight_images_prepare([("wb", (w_pool, b_pool))])
                 wimg = weight_image("wb", w_pool, b_pool)
-            if fuse:
-                pre_zero = torch.empty((h.shape[0], padded_ld(h.shape[1])), dtype=torch.float32, device=h.device)
-            p = linear_fwd_x3(himg, None, wimg, relu=True, zero=pre_zero)
+            p = linear_fwd_x3(himg, None, wimg, relu=True)
         else:
             p = linear_fwd(h, w_pool, b_pool, relu=True)
-        release_late_plans()      # (a first layer's parked backward plan starts behind this layer's fc_pool product: see POOL_PLAN_LATE)
         need = any(t is not None and t.requires_grad for t in (h, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh))
         ent = None
-        ctx.pre = None
-        if need and pre_zero is not None:
-            # (the loss's own gradient is 1 / n_dst whatever the loss turns out to be)
-            dxs = empty_mat(n_dst, h.shape[1], h.device)
-            ctx.pre = (dxs, pre_zero)
-        elif need and h.shape[0] >= 1024:
+        if need and h.shape[0] >= 1024:
             # the backward scatters its pooled-row gradient with float atomics into a zeroed [n_src, K] matrix: cleared by this launch
             buf = torch.empty((h.shape[0], padded_ld(h.shape[1])), dtype=torch.float32, device=h.device)
             ent = [buf, h.shape[0], h.shape[1], True]
@@ -2595,7 +2400,7 @@ class _SagePoolLossFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)             # (the gradients of the two non-differentiable outputs stay None: no zero fills)
         mean, rows, logits, neigh, argmax, dl = out_layer_fwd_ce(p, idx, h, n_dst, w_self, w_neigh, b_self, b_neigh, labels,
                                                                 want_grad=need, zero=ent[0] if ent is not None else None,
-                                                                want_mean=not ctx.defer_mean, bwd_into=ctx.pre)
+                                                                want_mean=not ctx.defer_mean)
         ctx.loss_out = (rows, mean) if ctx.defer_mean else None
         if _CAPTURE is not None:
             _CAPTURE.append(dict(argmax=argmax, neigh=neigh, out=None))
@@ -2610,14 +2415,12 @@ class _SagePoolLossFn(torch.autograd.Function):
     def backward(ctx, dloss, _drows, _dlogits):
         h, w_pool, w_self, w_neigh, neigh, argmax, dl = ctx.saved_tensors
         unit = _UNIT_GRAD.get((dloss.device.type, dloss.device.index))
-        pre, ctx.pre = getattr(ctx, "pre", None), None          # (taken once: see _out_layer_backward's dp_slot)
         if unit is not None and dloss.data_ptr() == unit.data_ptr():
             dy = dl
         else:                                    # (a user's own root gradient: scaled into a matrix with the padded row stride)
             dy = empty_mat(dl.shape[0], dl.shape[1], dl.device)
             torch.mul(dl, dloss, out=dy)
-            pre = None                           # (the forward launch's input gradients assumed a unit root gradient)
-        return _out_layer_backward(ctx, dy, h, w_pool, w_self, w_neigh, neigh, argmax, pre=pre) + (None, None, None, None)
+        return _out_layer_backward(ctx, dy, h, w_pool, w_self, w_neigh, neigh, argmax) + (None, None, None, None)
 
 
 def out_layer_fwd_ce_mean(h, idx, n_dst, w_cat, split, bias, labels, want_mean=True, p=None):
@@ -2788,7 +2591,7 @@ class _SageMeanPoolLossFn(torch.autograd.Function):
         return (dh, dw_pool, db_pool if ctx.has_pool_bias else None, dw_cat, (db if ctx.has_bias else None), None, None, None, None, None)
 
 
-MEAN_LOSS_FUSED = os.environ.get("OGL_MEAN_LOSS_FUSED", "1") != "0"
+MEAN_LOSS_FUSED = True
 
 
 def sage_meanpool_layer_loss(h, w_pool, b_pool, w_cat, bias, idx, n_dst, labels, defer_mean=False, plan=None):
@@ -3056,17 +2859,17 @@ class _SmallPoolLossFn(torch.autograd.Function):
 SMALL_ROUTE = os.environ.get("OGL_SMALL_ROUTE", "1") != "0"
 _PENDING_ROUTES = {}
 _SMALL_AGNOSTIC = {"seen": False}      # set by a forward whose first layer ran on the device's own source count (stepgraph reads it)
-SMALL_LIVE = os.environ.get("OGL_SMALL_LIVE", "1") != "0"      # padded rows of a captured step's upper-bound block take the kernels' early exits
-SMALL_PROJ = os.environ.get("OGL_SMALL_PROJ", "1") != "0"      # fc_pool of a small step's first layer on the small-tile fp32-MFMA kernel
-SMALL_PROJ_MAX_ROWS = int(os.environ.get("OGL_SMALL_PROJ_MAX_ROWS", "4096"))
-SMALL_FIRST_FUSED = os.environ.get("OGL_SMALL_FIRST_FUSED", "1") != "0"   # the first 'pool' layer of a 32-seed step: max + combine in one launch
+SMALL_LIVE = True      # padded rows of a captured step's upper-bound block take the kernels' early exits
+SMALL_PROJ = True      # fc_pool of a small step's first layer on the small-tile fp32-MFMA kernel
+SMALL_PROJ_MAX_ROWS = 4096
+SMALL_FIRST_FUSED = True   # the first 'pool' layer of a 32-seed step: max + combine in one launch
 SMALL_FIRST_MAX_DST = 2048
 # fc_pool's weight gradient of that layer from the winners' records (ogl_small_first_layer_dw) while the rows it would gather from L2 if
 # EVERY destination row were live — n_dst * F * F floats — stay below this many bytes.  (A captured 32-seed step runs on the upper-bound
 # block, 832 destination rows — 1 472 at the reference's pubmed setting, fanout 45 — of which 100-300 are live: padded rows have no records
 # and cost nothing, so the bound covers 1 472 x 500^2.  Measured, pubmed setting: 0.194 ms per step at 1 GiB (dense form), 0.1455 at 2 GiB.)
-SMALL_FIRST_DW = os.environ.get("OGL_SMALL_FIRST_DW", "1") != "0"
-SMALL_FIRST_DW_MAX_BYTES = int(os.environ.get("OGL_SMALL_FIRST_DW_MAX_BYTES", str(1 << 31)))
+SMALL_FIRST_DW = True
+SMALL_FIRST_DW_MAX_BYTES = (1 << 31)
 
 
 def small_first_layer_fits(table, ids, idx, n_dst, w_pool, b_pool, w_self, w_neigh, b_self, b_neigh):

@@ -28,7 +28,7 @@ from . import ops
 # over fc_pool0 alone 16-18 us), but the side branch's three weight-gradient products end AFTER the layer-0 weight gradient has taken every
 # CU (their reductions are gone, they still share the chip with the pool backward), so the early update waits for a CU for 190 us and
 # the layer-0 weight gradient runs 250 us instead of 225 beside it.  It pays once that branch ends before the layer-0 weight gradient starts.
-EARLY = os.environ.get("OGL_ADAM_EARLY", "0") == "1"
+EARLY = False
 
 
 class Adam(torch.optim.Optimizer):

@@ -40,18 +40,38 @@ def force_distributed(on=True):
     _FORCE = bool(on)
 
 
+_LOCAL_ONLY = False
+
+
+class local_only:
+    """``with parallel.local_only():`` — inside an initialised process group, behave as ONE rank: no shard, no exchange
+    (``is_distributed()`` False, ``rank_world()`` (0, 1)).  What ``bench.py --gpus N`` uses to time the one-rank step on every rank of the
+    SAME invocation (the T1 of a scaling curve measured beside its TN); strategies read these at ``build_optimizer`` / per batch, so a
+    strategy built and run inside the context is a plain one-rank strategy."""
+
+    def __enter__(self):
+        global _LOCAL_ONLY
+        self._was, _LOCAL_ONLY = _LOCAL_ONLY, True
+        return self
+
+    def __exit__(self, *exc):
+        global _LOCAL_ONLY
+        _LOCAL_ONLY = self._was
+        return False
+
+
 def _single(world):
     """True when the N-rank code has nothing to exchange (one rank, not forced)."""
-    return world == 1 and not _FORCE
+    return _LOCAL_ONLY or (world == 1 and not _FORCE)
 
 
 def is_distributed(group=None):
     """True when torch.distributed is initialised with more than one rank (or with one and ``force_distributed()``)."""
-    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or _FORCE)
+    return (not _LOCAL_ONLY) and dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or _FORCE)
 
 
 def rank_world(group=None):
-    if dist.is_available() and dist.is_initialized():
+    if (not _LOCAL_ONLY) and dist.is_available() and dist.is_initialized():
         return dist.get_rank(group), dist.get_world_size(group)
     return 0, 1
 
@@ -504,6 +524,49 @@ class ShardedAdam:
         if self.wflat.is_cuda:
             from . import ops
             ops.invalidate_weight_images()
+
+
+    # -- checkpointing: the moments live here, 1 / N per rank, not in the (never stepped) optim.Adam beside this object ---------------
+    def _gather_flat(self, mine):
+        """The full flat vector whose rank-r segment is rank r's ``mine`` (every rank gets it)."""
+        full = torch.zeros(self.seg * self.world, dtype=mine.dtype, device=mine.device)
+        single = _single(self.world) or not dist.is_initialized()
+        if single:
+            full.narrow(0, self.lo, self.seg).copy_(mine)
+        elif dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(full, mine.contiguous(), group=self.group)
+        else:
+            out = [torch.empty(self.seg, dtype=mine.dtype) for _ in range(self.world)]
+            dist.all_gather(out, mine.detach().cpu().contiguous(), group=self.group)
+            for r in range(self.world):
+                full.narrow(0, r * self.seg, self.seg).copy_(out[r])
+        return full
+
+    def state_dict(self):
+        """Rank-independent optimiser state: per PARAMETER (in ``params`` order) its first and second moment, the step count and the
+        hyper-parameters — the moments all-gathered from their owning ranks (a collective: every rank must call it), so a checkpoint
+        written by rank 0 restores onto any world size."""
+        m, v = self._gather_flat(self.m), self._gather_flat(self.v)
+        state = []
+        for p, off in zip(self.params, self.offs):
+            n = p.numel()
+            state.append(dict(exp_avg=m.narrow(0, off, n).view(p.shape).clone(), exp_avg_sq=v.narrow(0, off, n).view(p.shape).clone()))
+        return dict(step=int(self.t), lr=self.lr, betas=tuple(self.betas), eps=self.eps, state=state)
+
+    def load_state_dict(self, sd):
+        """Inverse of ``state_dict`` on THIS object's layout (any world size): every rank keeps its own segment of the moments."""
+        assert len(sd["state"]) == len(self.params), "the checkpoint was written for another model"
+        self.t = int(sd["step"])
+        self.lr, self.betas, self.eps = float(sd["lr"]), (float(sd["betas"][0]), float(sd["betas"][1])), float(sd["eps"])
+        m = torch.zeros(self.seg * self.world, dtype=self.m.dtype, device=self.m.device)
+        v = torch.zeros_like(m)
+        for p, off, ent in zip(self.params, self.offs, sd["state"]):
+            n = p.numel()
+            assert tuple(ent["exp_avg"].shape) == tuple(p.shape)
+            m.narrow(0, off, n).copy_(ent["exp_avg"].reshape(-1))
+            v.narrow(0, off, n).copy_(ent["exp_avg_sq"].reshape(-1))
+        self.m.copy_(m.narrow(0, self.lo, self.seg))
+        self.v.copy_(v.narrow(0, self.lo, self.seg))
 
 
 def assert_replicated(values, what="value", group=None):

@@ -29,7 +29,7 @@ from . import ops
 
 # fused inference batches carry a byte per hidden-layer row: 1 where the next layer reads the row's fp32 values (its destinations'
 # own rows) — the layer below then stores fp32 only there (OGL_FUSED_KEEP_ROWS=0: every row, as before)
-FUSED_KEEP_ROWS = os.environ.get("OGL_FUSED_KEEP_ROWS", "1") != "0"
+FUSED_KEEP_ROWS = True
 
 # OGL_SAMPLE_PIPELINE=1: a training loader hands out its first PIPELINE_FIRST batches as soon as they are sampled and samples the rest
 # on a second stream while those train (what the reference's ``num_workers`` does with forked CPU samplers); the blocks are the
@@ -38,8 +38,8 @@ FUSED_KEEP_ROWS = os.environ.get("OGL_FUSED_KEEP_ROWS", "1") != "0"
 # driver's 20-step command; with the direct-address build (1.3 -> 0.5 ms of sampling + build per 50 batches) 0.9850 vs 0.9855 and 0.9843
 # vs 0.9857 (one outlier at 1.006): the sampling kernels take the CUs they run on away from the train step — every GEMM block owns a CU
 # — so what the overlap hides it costs again.  A low-priority sampling stream starves (1.23 ms per step: the host waits for it).
-PIPELINE = os.environ.get("OGL_SAMPLE_PIPELINE", "0") == "1"
-PIPELINE_FIRST = int(os.environ.get("OGL_SAMPLE_PIPELINE_FIRST", "4"))
+PIPELINE = False
+PIPELINE_FIRST = 4
 _PIPE = {"stream": None}
 
 NID = "_ID"   # same key DGL uses for block.srcdata[dgl.NID]

@@ -52,26 +52,14 @@ def round_up(x, m):
 N1_BUCKET = 256          # staged form
 N0_BUCKET = 2048
 N0_BUCKET_SMALL = 256    # sampled form (input blocks of a few hundred to a few thousand rows)
-SAMPLE_FILL_BUCKET = os.environ.get("OGL_SAMPLE_FILL_BUCKET", "1") != "0"    # the sample graph pads src0 up to that bucket only
+SAMPLE_FILL_BUCKET = True   # the sample graph pads src0 up to that bucket only
 # A sampled step whose launches take their sizes from the DEVICE (the small first layer on the sample graph's own counts: ops._SMALL_AGNOSTIC)
 # is captured ONCE on the upper-bound block and replayed right behind its sample graph — no read-back in front of the train graph (it picked
 # the size bucket), no host in the device's critical path: the counts are read after both graphs are enqueued.
-# pipelined steps: the next batch's sample graph enqueued BEFORE this batch's train graph.  Off: measured, pubmed-like rung, same box:
-# 0.0923 -> 0.1046 ms per step — the ~35 us the host needs to enqueue the side stream's sample graph then sit in front of the train
-# graph, which is the critical path
-PREFETCH_FIRST = os.environ.get("OGL_PREFETCH_FIRST", "0") == "1"
 SIZE_AGNOSTIC = os.environ.get("OGL_SIZE_AGNOSTIC", "1") != "0"
-# ... and the PIPELINED step as one graph per batch (_merged_pipelined: [own sampling] -> [train || next batch's sampling on a forked
-# branch]).  Off: measured slower than the two-graph pipelined form — pubmed-like 0.0933 -> 0.102 ms per step, same box (the fork / join
-# edges inside the graph and the upper-bound launches cost more than the hand-over and read-back they remove when sampling already hides
-# behind the previous batch's train graph).
-SIZE_AGNOSTIC_PIPE = os.environ.get("OGL_SIZE_AGNOSTIC_PIPE", "0") == "1"
-# ... or: the pipelined step with its two graphs kept apart (batch i + 1 sampled by its own sample graph on the side stream while batch i
-# trains) but the TRAIN graph size-agnostic, replayed without waiting for the counts
-SIZE_AGNOSTIC_PIPE2 = os.environ.get("OGL_SIZE_AGNOSTIC_PIPE", "0") == "2"
-# ... or (3): only the FIRST batch of a snapshot — the one whose sampling nothing hides — as the one-graph step of ``sampled_step`` (on this
-# pipeline's block arrays), the following batches pipelined and bucketed as before
-SIZE_AGNOSTIC_PIPE3 = os.environ.get("OGL_SIZE_AGNOSTIC_PIPE", "0") == "3"
+# (Three forms of the PIPELINED step on a size-agnostic train graph — one graph per batch with the next batch's sampling on a forked
+# branch; two graphs with only the train graph size-agnostic; only a snapshot's first batch as the one-graph step — and the next batch's
+# sample graph enqueued BEFORE the train graph were measured slower in round 5 and removed in round 6: DESIGN.md section 8.)
 _WARMED = False
 
 
@@ -92,15 +80,14 @@ class BlockBuffers:
         return self.head[1:]
 
 
-LAZY_LABELS = os.environ.get("OGL_LAZY_LABELS", "1") != "0"     # the step's label gather inside the loss launch
+LAZY_LABELS = True     # the step's label gather inside the loss launch
 
 
 class TrainStepGraph:
     """One captured train step over ``buf`` restricted to (n1_pad, n0_pad) rows.
     ``loss_fn(logits, labels) -> (scalar loss to differentiate, per-seed losses or None)``."""
 
-    def __init__(self, model, optimizer, graph, buf, n1_pad, n0_pad, loss_fn, pool=None, apply=True, loss_kind=None, dp=None, sampler=None,
-                 side_sampler=None):
+    def __init__(self, model, optimizer, graph, buf, n1_pad, n0_pad, loss_fn, pool=None, apply=True, loss_kind=None, dp=None, sampler=None):
         # apply=False: forward + loss + backward only (the gradients are in ``grads``; exchange and optimiser are the caller's).
         # dp = (GradSynchronizer, weight): the WHOLE step of a data-parallel replica — forward, loss, backward, the gradient exchange
         # (RCCL all-reduces recorded into the graph: the early bucket launched from the gradient hooks on the side branch, under the
@@ -110,9 +97,6 @@ class TrainStepGraph:
         # sampler (a SampleGraph over ``buf``): its one launch is recorded at the TOP of this graph — sampling and training of a batch
         # are ONE graph launch (for a train graph that takes the block's size from the device: StepGraphCache._agnostic_graph)
         self.sampler = sampler
-        # side_sampler (a SampleGraph over the OTHER set of block arrays): the NEXT batch's sampling launch on a forked branch of this
-        # graph, beside this batch's train launches (StepGraphCache._merged_pipelined)
-        self.side_sampler = side_sampler
         # "mean" / "mean_rows": the loss is nn.CrossEntropyLoss — the model may run its last layer and the loss as one node
         # (GraphSAGE.forward_loss); None: an arbitrary loss_fn(logits, labels)
         self.loss_kind = loss_kind if hasattr(model, "forward_loss") else None
@@ -125,12 +109,6 @@ class TrainStepGraph:
     def _body(self, apply=None, learn=False):
         apply = self.apply if apply is None else apply
         g, b = self.graph, self.buf
-        side = None
-        if self.side_sampler is not None:
-            side = self._side_stream = getattr(self, "_side_stream", None) or torch.cuda.Stream(device=g.device)
-            side.wait_stream(torch.cuda.current_stream())    # fork: nothing in this graph depends on it, it on nothing in this graph
-            with torch.cuda.stream(side):
-                self.side_sampler._body()
         if self.sampler is not None:
             self.sampler._body()
         src0, src1, lidx0 = b.src0[:self.n0_pad], b.src1[:self.n1_pad], b.lidx0[:self.n1_pad]
@@ -167,8 +145,6 @@ class TrainStepGraph:
             if apply:
                 self.opt.step()
         self.loss, self.loss_rows = loss.detach(), (rows.detach() if rows is not None else None)
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)    # join
 
     def _capture(self, pool):
         global _WARMED
@@ -212,7 +188,7 @@ class TrainStepGraph:
         # (True: the recorded launches take the input block's size from the device — this graph serves every batch of its shape)
         self.size_agnostic = bool(ops._SMALL_AGNOSTIC["seen"]) and self.n0_pad == self.buf.n0_cap
         self.grads = [p.grad for p in self.model.parameters()]
-        for sm in (self.sampler, self.side_sampler):
+        for sm in (self.sampler,):
             if sm is not None:
                 # The caller has prepare()d this sampler for the replay that follows (host sequence number = device's + 1).  A warm-up
                 # pass above runs the sampler's launch for real: the device's number then moves without the host's — and a host that
@@ -348,7 +324,7 @@ class StepGraphCache:
         self.captures = self.evictions = self.borrowed = self.deferred = 0
         self.sightings = {}
 
-    def _train(self, graph, buf, key, n1_pad, n0_pad, apply=True, dp=None, sampler=None, side_sampler=None):
+    def _train(self, graph, buf, key, n1_pad, n0_pad, apply=True, dp=None, sampler=None):
         sg = self.graphs.get(key)
         if sg is None:
             while len(self.graphs) >= self.MAX_GRAPHS:
@@ -358,7 +334,7 @@ class StepGraphCache:
                 del old
                 self.evictions += 1
             sg = self.graphs[key] = TrainStepGraph(self.model, self.opt, graph, buf, n1_pad, n0_pad, self.loss_fn, apply=apply,
-                                                   loss_kind=self.loss_kind, dp=dp, sampler=sampler, side_sampler=side_sampler)
+                                                   loss_kind=self.loss_kind, dp=dp, sampler=sampler)
             self.captures += 1
         else:
             self.graphs.move_to_end(key)
@@ -380,10 +356,6 @@ class StepGraphCache:
             self.bufs[bkey] = bufs
             pipe = self.samplers[bkey] = dict(smp=[SampleGraph(graph, b) for b in bufs], side=torch.cuda.Stream(device=graph.device),
                                               sampled=[None, None], trained=[None, None], cur=0, ahead=None, last=None)
-        if SIZE_AGNOSTIC and SIZE_AGNOSTIC_PIPE and self.agnostic.get(bkey) is not False:
-            sg = self._merged_pipelined(graph, pipe, bkey, seeds_host, ctr, nxt, B)
-            if sg is not None:
-                return sg
         cur = pipe["cur"]
         smp = pipe["smp"][cur]
         main = torch.cuda.current_stream()
@@ -397,123 +369,30 @@ class StepGraphCache:
             ev = pipe["trained"][last] = torch.cuda.Event()
             ev.record(main)
             pipe["last"] = None
-        agn = SIZE_AGNOSTIC and SIZE_AGNOSTIC_PIPE2 and self.agnostic.get(bkey) is not False
-        first_merged = (SIZE_AGNOSTIC and SIZE_AGNOSTIC_PIPE3 and self.agnostic.get(bkey) is not False
-                        and not (pipe["ahead"] is not None and pipe["ahead"][0] == cur and pipe["ahead"][1] == int(ctr)))
-        if first_merged:
-            if pipe["ahead"] is not None:
-                pipe["smp"][pipe["ahead"][0]].wait()
-                main.wait_event(pipe["sampled"][pipe["ahead"][0]])
-                pipe["ahead"] = None
-            smp.prepare(seeds_host, ctr)
-            sgm = self._agnostic_graph(graph, smp, bkey, bkey + ("cap", "merged", cur), merged=True)
-            if sgm is None:
-                torch.cuda.synchronize()
-                smp.seq = int(smp.counts_np[2])
-                first_merged = False
-        if first_merged:
-            sgm.replay()
-            pipe["last"] = cur
-            other = 1 - cur
-            if nxt is not None and len(nxt[0]) == B:
-                side = pipe["side"]
-                if pipe["trained"][other] is not None:
-                    side.wait_event(pipe["trained"][other])
-                pipe["smp"][other].launch(nxt[0], nxt[1], stream=side)
-                es = pipe["sampled"][other] = torch.cuda.Event()
-                es.record(side)
-                pipe["ahead"] = (other, int(nxt[1]))
-            pipe["cur"] = other
-            n1, n0 = smp.wait()
-            sgm.last_sizes = (n0, n1)
-            return sgm
         if pipe["ahead"] is not None and pipe["ahead"][0] == cur and pipe["ahead"][1] == int(ctr):
-            if not agn:
-                n1, n0 = smp.wait()                          # launched while the previous batch trained
+            n1, n0 = smp.wait()                              # launched while the previous batch trained
             main.wait_event(pipe["sampled"][cur])
         else:
             if pipe["ahead"] is not None:                    # (a prefetch nobody came for: let it finish before its set is reused)
                 pipe["smp"][pipe["ahead"][0]].wait()
                 main.wait_event(pipe["sampled"][pipe["ahead"][0]])
-            if agn:
-                smp.launch(seeds_host, ctr)
-            else:
-                n1, n0 = smp.run(seeds_host, ctr)
+            n1, n0 = smp.run(seeds_host, ctr)
         pipe["ahead"] = None
-        sg = None
-        if agn:
-            sg = self._agnostic_graph(graph, smp, bkey, bkey + ("cap", cur))
-            if sg is None:
-                n1, n0 = smp.wait()
-        late = sg is not None
-        if sg is None:
-            n0_pad = min(round_up(n0, N0_BUCKET_SMALL), smp.buf.n0_cap)
-            sg = self._train(graph, smp.buf, bkey + (n0_pad, cur), smp.buf.n1_cap, n0_pad)
+        n0_pad = min(round_up(n0, N0_BUCKET_SMALL), smp.buf.n0_cap)
+        sg = self._train(graph, smp.buf, bkey + (n0_pad, cur), smp.buf.n1_cap, n0_pad)
         other = 1 - cur
-
-        def prefetch():
-            if nxt is not None and len(nxt[0]) == B:
-                side = pipe["side"]
-                if pipe["trained"][other] is not None:
-                    side.wait_event(pipe["trained"][other])  # the train graph that read set `other` has finished
-                pipe["smp"][other].launch(nxt[0], nxt[1], stream=side)
-                es = pipe["sampled"][other] = torch.cuda.Event()
-                es.record(side)
-                pipe["ahead"] = (other, int(nxt[1]))
-        # (PREFETCH_FIRST: the next batch's sample graph enqueued before this batch's train graph — it depends on nothing this batch
-        # does — so that its counts reach the host while this batch still trains; an experiment, slower: see the switch)
-        if PREFETCH_FIRST:
-            prefetch()
         sg.replay()
         pipe["last"] = cur                                   # (its `trained` event: at the top of the next call, behind the caller's reads)
-        if not late:
-            sg.last_sizes = (n0, n1)
-        if not PREFETCH_FIRST:
-            prefetch()
-        pipe["cur"] = other
-        if late:
-            n1, n0 = smp.wait()                              # (after everything is enqueued: the device never waits for this)
-            sg.last_sizes = (n0, n1)
-        return sg
-
-    def _merged_pipelined(self, graph, pipe, bkey, seeds_host, ctr, nxt, B):
-        """The pipelined step as ONE graph launch per batch, for train graphs that take the block's size from the device (the upper-bound
-        block: ``_agnostic_graph``): batch i's graph holds [its own sampling launch unless the previous graph prefetched it] -> [its train
-        launches || the sampling launch of batch i + 1 on a forked branch, into the OTHER set of block arrays].  Four variants per set
-        (own sampling yes / no x prefetch yes / no), captured on first use; the graphs run back to back on one stream, so a set is never
-        written while a train graph reads it.  No count read-back in front of any launch: the counts are read after the enqueue.
-        Returns None when the model's launches are not size-agnostic (the caller falls back to the bucketed two-graph form)."""
-        cur = pipe["cur"]
-        other = 1 - cur
-        smp, smp_o = pipe["smp"][cur], pipe["smp"][other]
-        ahead = pipe["ahead"]
-        have = ahead is not None and ahead[0] == cur and ahead[1] == int(ctr)
-        if ahead is not None and not have:                   # (a prefetch nobody came for: its sequence number must be seen first)
-            pipe["smp"][ahead[0]].wait()
-        want = nxt is not None and len(nxt[0]) == B
-        if not have:
-            smp.prepare(seeds_host, ctr)
-        if want:
-            smp_o.prepare(nxt[0], nxt[1])
-        key = bkey + ("cap", "merged", cur, not have, want)
-        known = self.agnostic.get(bkey)
-        sg = self._train(graph, smp.buf, key, smp.buf.n1_cap, smp.buf.n0_cap, sampler=None if have else smp, side_sampler=smp_o if want else None)
-        if known is None:
-            if not sg.size_agnostic:
-                # not size-agnostic: forget the graph, put the samplers' bookkeeping back in step with the device, sample the old way
-                self.agnostic[bkey] = False
-                self.graphs.pop(key, None)
-                torch.cuda.synchronize()
-                for sm in pipe["smp"]:
-                    sm.seq = int(sm.counts_np[2])
-                pipe["ahead"] = None
-                return None
-            self.agnostic[bkey] = True
-        sg.replay()
-        pipe["ahead"] = (other, int(nxt[1])) if want else None
-        pipe["cur"] = other
-        n1, n0 = smp.wait()                                  # (after the step is enqueued: the device never waits for this)
         sg.last_sizes = (n0, n1)
+        if nxt is not None and len(nxt[0]) == B:
+            side = pipe["side"]
+            if pipe["trained"][other] is not None:
+                side.wait_event(pipe["trained"][other])      # the train graph that read set `other` has finished, and its caller's reads
+            pipe["smp"][other].launch(nxt[0], nxt[1], stream=side)
+            es = pipe["sampled"][other] = torch.cuda.Event()
+            es.record(side)
+            pipe["ahead"] = (other, int(nxt[1]))
+        pipe["cur"] = other
         return sg
 
     def sampled_step(self, graph, seeds_host, ctr):

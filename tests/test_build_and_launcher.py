@@ -54,3 +54,29 @@ def test_bench_launcher_needs_one_gpu_per_rccl_rank():
         pytest.skip("this box could really start two RCCL ranks")
     r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {})
     assert r.returncode == 2 and "needs 2 GPUs" in r.stderr
+
+
+def test_forced_distributed_bench_line_carries_every_exchange_form():
+    """`bench.py --force-dist` (a world-size-1 RCCL group running the N-rank code): ONE invocation times the headline exchange, the sharded
+    update and the exchange captured inside the step graph (`collectives_variants`), and the one-rank step beside them
+    (`one_rank_reference`) — what the driver's single run per N must deliver on a multi-GPU node."""
+    import json
+    import pytest
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    r = _bench(["--force-dist", "--workload", "pubmed_rbr", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-e2e"], {})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    v = line["collectives_variants"]
+    assert set(v) == {"a_allreduce", "b_sharded_update", "c_captured_exchange"}, sorted(v)
+    for name, ent in v.items():
+        assert ent.get("ms_per_step", 0) > 0, (name, ent)
+    assert v["b_sharded_update"]["sharded_update"] and v["c_captured_exchange"]["captured_exchange"]
+    assert v["a_allreduce"]["collectives"] is not None and "t1_prime_ms" in v["a_allreduce"]["collectives"]
+    assert line["one_rank_reference"]["ms_per_step"] > 0
+    assert abs(v["a_allreduce"]["ms_per_step"] - line["ms_per_step"]) < 1e-9          # (form (a) IS the headline)
+
+
+test_forced_distributed_bench_line_carries_every_exchange_form = __import__("pytest").mark.gpu(
+    test_forced_distributed_bench_line_carries_every_exchange_form)

@@ -497,60 +497,6 @@ def test_direct_address_block_build_equals_the_hash_build(fanout, n_ids):
             row += c
 
 
-@pytest.mark.parametrize("M,N,K", [(62600, 600, 602), (20000, 600, 602), (40000, 520, 300)])
-def test_uneven_split_k_of_the_wide_weight_gradient(M, N, K):
-    """Layer 0's dW_pool (k-major, 256 x 128 tiles, dy^T from the pool backward's dealt image): the last row tile holds 88 of 256
-    rows, so its movers skip the A rows nobody reads and it gets FEWER, LONGER reduction ranges than the full row tiles; the slabs it
-    does not fill are written as zeros.  Against fp64, against the transposed-image product, and deferred (slabs summed by the
-    consumer) against the reduction launch, bit for bit."""
-    import ogl_amd  # noqa: F401
-    from ogl_amd import _lib, ops
-    ops.set_gemm_mode("auto")
-    was = _lib.lib().ogl_x3_debug_bwwk_uneven(1)         # (off by default: measured slower inside the train step, linear_x3.hip)
-    try:
-        torch.manual_seed(M + N)
-        dev = "cuda"
-        T = M + 500
-        table = ops.empty_mat(T, K, dev).copy_(torch.randn(T, K, device=dev))
-        rows = torch.randint(0, T, (M,), device=dev)
-        rows[::97] = -1
-        dy = ops.empty_mat(M, N, dev).copy_(torch.randn(M, N, device=dev) * (torch.rand(M, N, device=dev) < 0.15))   # sparse like dP
-        G = (M + 31) // 32
-        dyT = ops.x3_split_t(dy, interleave=G)
-        x_img = ops.x3_split(table, append_ones=True)
-        dw, db, db2 = ops.linear_bwd_weight_x3k(dyT, x_img, M, K, x_rows=rows, x_nrows=T, interleave=G, want_bias=True, want_bias2=True)
-        xg = torch.where((rows >= 0).unsqueeze(1), table[rows.clamp(min=0)], torch.zeros((), device=dev))
-        want = dy.double().T @ xg.double()
-        scale = float(want.abs().max())
-        assert float((dw.double() - want).abs().max()) <= 2e-5 * scale
-        wantb = dy.double().sum(0)
-        assert float((db.double() - wantb).abs().max()) <= 2e-5 * float(wantb.abs().max()) and torch.equal(db, db2)
-        w = torch.nn.Parameter(torch.zeros(N, K, device=dev))
-        b = torch.nn.Parameter(torch.zeros(N, device=dev)); b2 = torch.nn.Parameter(torch.zeros(N, device=dev))
-
-        class Opt:
-            consumes_slabs = True
-            param_groups = [dict(params=[w, b, b2])]
-        with ops.deferred_splitk(Opt()):
-            got = ops.linear_bwd_weight_x3k(dyT, x_img, M, K, x_rows=rows, x_nrows=T, interleave=G, want_bias=True, want_bias2=True,
-                                            defer_for=(w, b, b2))
-            pend = list(ops._SLABS["pending"].values()) if isinstance(ops._SLABS["pending"], dict) else list(ops._SLABS["pending"])
-            assert len(pend) == 3
-            w.grad, b.grad, b2.grad = got
-        for g_, w_ in zip(got, (dw, db, db2)):
-            assert torch.equal(g_, w_)
-        # run to run: the same bits (no atomics anywhere in the product)
-        dw3, _, _ = ops.linear_bwd_weight_x3k(dyT, x_img, M, K, x_rows=rows, x_nrows=T, interleave=G, want_bias=True, want_bias2=True)
-        assert torch.equal(dw3, dw)
-        # the even plan (the default): the same product to fp32-GEMM accuracy (another association of the split-K sums)
-        _lib.lib().ogl_x3_debug_bwwk_uneven(0)
-        dw4, db4, _ = ops.linear_bwd_weight_x3k(dyT, x_img, M, K, x_rows=rows, x_nrows=T, interleave=G, want_bias=True, want_bias2=True)
-        assert float((dw4 - dw).abs().max()) <= 1e-5 * scale and not torch.equal(dw4, dw)
-    finally:
-        _lib.lib().ogl_x3_debug_bwwk_uneven(was)
-        ops.set_gemm_mode("f32")
-
-
 def test_lstm_aggregator_model_matches_oracle():
     """A two-layer 'lstm' model (aggregator_dgl.py:116-126,195-199: h_n of nn.LSTM over each destination's mailbox) — forward, loss and
     every gradient against the oracle's explicit cell loop (itself pinned by tests/golden/sageconv_lstm_*.npz, generated by the

@@ -25,93 +25,6 @@ def _dP_reference(a, o, g, n_src, relu):
     return dP
 
 
-@pytest.mark.parametrize("n_dst,S,D,n_src,K,relu", [(1, 1, 1, 1, 3, True), (50, 4, 33, 70, 20, True), (300, 25, 602, 2000, 602, True),
-                                                     (2500, 10, 130, 900, 64, False), (700, 25, 64, 40, 31, True),
-                                                     (4100, 25, 40, 5000, 200, True), (7060, 25, 602, 62495, 602, True),
-                                                     (3000, 63, 640, 40000, 128, True)])
-def test_record_fed_weight_gradient(ops, n_dst, S, D, n_src, K, relu):
-    """ogl_pool_bwd_x3_dw (values pass + k_gemm_x3rf: the product's movers build dP^T tile by tile in LDS from the plan's records) ==
-    dP^T . [X[rows] | 1] in float64, and == the round-4 pair (dense image + k-major product) to fp32 summation order — hub sources,
-    missing neighbours, ReLU-dead winners, ragged tiles (D, K + 1 not multiples of 128), one-group and many-slab reductions."""
-    torch.manual_seed(n_dst + D)
-    rng = np.random.default_rng(n_dst * 3 + D)
-    idx = rng.integers(0, n_src, (n_dst, S)).astype(np.int32)
-    hubs = rng.random((n_dst, S)) < 0.3                                # a few heavily referenced sources (one group's lane 0 .. 2)
-    idx[hubs] = rng.integers(0, min(3, n_src), int(hubs.sum()))
-    idx[rng.random((n_dst, S)) < 0.05] = -1
-    idx_t = torch.as_tensor(idx).cuda()
-    p = torch.randn(n_src, D).clamp_min(0)
-    pm = ops.empty_mat(n_src, D, "cuda"); pm.copy_(p)
-    out, argmax = ops.reduce_fwd(pm, idx_t, "max", want_argmax=True)
-    dout = torch.randn(n_dst, D)
-    dm = ops.empty_mat(n_dst, D, "cuda"); dm.copy_(dout)
-    T = n_src + 37
-    tab = torch.randn(T, K)
-    tm = ops.empty_mat(T, K, "cuda"); tm.copy_(tab)
-    rows = torch.as_tensor(rng.permutation(T)[:n_src].astype(np.int64))
-    rimg = ops.x3_split(tm, append_ones=True)
-    dP = _dP_reference(argmax.cpu().numpy(), out.cpu().numpy(), dout.numpy().astype(np.float64), n_src, relu)
-    X = tab.numpy().astype(np.float64)[rows.numpy()]
-    dw_ref, db_ref = dP.T @ X, dP.sum(0)
-    scale = max(1.0, float(np.abs(dw_ref).max()))
-    got = {}
-    for side in (False, True):
-        plan = ops.pool_bwd_x3_plan(argmax, out if relu else None, idx_t, n_src, side=side)
-        dw, db = ops.pool_bwd_x3_dw(dm.clone(), idx_t, plan, n_src, rimg, K, x_rows=rows.cuda(), x_nrows=T)
-        torch.cuda.synchronize()
-        np.testing.assert_allclose(dw.cpu().numpy(), dw_ref, rtol=2e-5, atol=2e-5 * scale)
-        np.testing.assert_allclose(db.cpu().numpy(), db_ref, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(db_ref).max())))
-        got[side] = dw.cpu().numpy()
-    # the round-4 pair on the same inputs
-    plan = ops.pool_bwd_x3_plan(argmax, out if relu else None, idx_t, n_src, side=False)
-    dyT = ops.pool_bwd_x3_apply(dm.clone(), idx_t, plan, n_src)
-    G = (n_src + 31) // 32
-    dw4, db4, _ = ops.linear_bwd_weight_x3k(dyT, rimg, n_src, K, x_rows=rows.cuda(), x_nrows=T, interleave=G, want_bias=True)
-    np.testing.assert_allclose(got[False], dw4.cpu().numpy(), rtol=1e-5, atol=1e-5 * scale)
-    # repeatable: the same plan applied twice gives the same bits where every cell of dP has at most two contributions; run to run
-    # the sums may differ in the last place otherwise (ds_add_f32 order) — bounded here
-    np.testing.assert_allclose(got[False], got[True], rtol=1e-6, atol=2e-6 * scale)
-
-
-def test_pool_max_autograd_takes_the_record_fed_product(ops):
-    """pool_max over a registered table: its backward is plan (forward) + ogl_pool_bwd_x3_dw — no dense dP^T image, no separate
-    weight-gradient launch — and matches the unfused path; OGL_POOL_RF off restores the round-4 pair."""
-    torch.manual_seed(8)
-    T, K, H, n_src, n_dst, S = 40000, 50, 48, 20000, 1500, 25
-    tab = ops.empty_mat(T, K, "cuda"); tab.normal_()
-    rows = torch.randperm(T)[:n_src].cuda()
-    idx = torch.randint(0, n_src, (n_dst, S), dtype=torch.int32).cuda()
-    w = (torch.randn(H, K) / 7).cuda(); b = torch.randn(H).cuda()
-    gout = torch.randn(n_dst, H).cuda()
-    res = {}
-    old, old_rf = ops.get_gemm_mode(), ops.POOL_RF
-    try:
-        ops.set_gemm_mode("auto")
-        for tag in ("unfused", "rf", "image"):
-            if tag != "unfused":
-                ops.register_static_table(tab)
-            ops.POOL_RF = tag == "rf"
-            wv, bv = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
-            ops.profile_start()
-            out = ops.pool_max(tab, wv, bv, idx, rows)
-            out.backward(gout)
-            names = [r[0] for r in ops.profile_stop()]
-            res[tag] = (out.detach(), wv.grad, bv.grad, names)
-    finally:
-        ops.set_gemm_mode(old)
-        ops.POOL_RF = old_rf
-        ops._X3_TABLES.clear()
-    if ops.POOL_PLAN:
-        assert "ogl_pool_bwd_x3_dw" in res["rf"][3] and "ogl_pool_bwd_x3_apply" not in res["rf"][3]
-        assert "ogl_linear_bwd_weight_x3k" not in res["rf"][3]
-        assert "ogl_pool_bwd_x3_apply" in res["image"][3] and "ogl_pool_bwd_x3_dw" not in res["image"][3]
-    scale = float(res["unfused"][1].abs().max())
-    for tag in ("rf", "image"):
-        np.testing.assert_allclose(res[tag][0].cpu().numpy(), res["unfused"][0].cpu().numpy(), rtol=1e-5, atol=1e-5)
-        np.testing.assert_allclose(res[tag][1].cpu().numpy(), res["unfused"][1].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
-        np.testing.assert_allclose(res[tag][2].cpu().numpy(), res["unfused"][2].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
-
-
 @pytest.mark.parametrize("n_dst,S,D,n_rows,T", [(1, 1, 4, 1, 3), (300, 25, 602, 2000, 5000), (7060, 25, 602, 62495, 232965), (700, 10, 128, 40, 90)])
 def test_table_direct_mean_equals_the_mean_over_gathered_rows(ops, n_dst, S, D, n_rows, T):
     """ogl_reduce_fwd_rows_mean_img: mean_j table[rows[idx[d, j]]] read where the table lies == the mean over the materialised
@@ -298,42 +211,6 @@ def test_hidden_width_256_train_step_matches_oracle(ops):
             assert np.linalg.norm(got - ref) <= 2e-2 * np.linalg.norm(ref) + 1e-6, (li, k)     # (unforced winners: round-1 tolerance)
 
 
-@pytest.mark.parametrize("M,K,N", [(9000, 64, 600), (8200, 100, 130), (8300, 50, 37)])
-def test_sign_bits_from_the_product_epilogue(ops, M, K, N):
-    """ogl_linear_fwd_x3_bits: the byte per 4-column group the image product's epilogue emits == [y > 0] of the matrix it stores, and
-    the segmented mean backward masked by those bits == the one masked by the fp32 matrix, bit for bit (values and image)."""
-    torch.manual_seed(N)
-    rng = np.random.default_rng(N)
-    old = ops.get_gemm_mode()
-    ops.set_gemm_mode("auto")
-    try:
-        T = M + 500
-        tab = ops.empty_mat(T, K, "cuda"); tab.normal_()
-        ops.register_static_table(tab)
-        rows = torch.as_tensor(rng.permutation(T)[:M].astype(np.int64)).cuda()
-        w = (torch.randn(N, K) / 6).cuda(); b = torch.randn(N).cuda()
-        p = ops.linear_fwd(tab, w, b, relu=True, x_rows=rows, want_bits=True)
-        ent = getattr(p, "_ogl_bits", None)
-        assert ent is not None, "the product did not take the image kernel"
-        bits = ent[0]
-        got = bits.buf.cpu().numpy()
-        y = p.cpu().numpy()[:, :N]
-        pad = np.zeros((M, bits.ld * 4), bool); pad[:, :N] = y > 0
-        want = (pad[:, 0::4] * 1 + pad[:, 1::4] * 2 + pad[:, 2::4] * 4 + pad[:, 3::4] * 8).astype(np.uint8)
-        assert np.array_equal(got & 15, want)
-        if N % 4 == 0:
-            n_dst, S = 700, 10
-            idx = torch.as_tensor(rng.integers(0, M, (n_dst, S)).astype(np.int32)).cuda()
-            dout = ops.empty_mat(n_dst, N, "cuda"); dout.normal_()
-            a_out, a_img = ops.reduce_bwd_seg_apply(dout, idx, ops.reduce_bwd_seg_plan(idx, N, M, side=False), "mean", mask=p, want_image=True)
-            b_out, b_img = ops.reduce_bwd_seg_apply(dout, idx, ops.reduce_bwd_seg_plan(idx, N, M, side=False), "mean", mask=bits, want_image=True)
-            assert torch.equal(a_out, b_out) and torch.equal(a_img.buf, b_img.buf)
-    finally:
-        ops.set_gemm_mode(old)
-        ops._X3_TABLES.clear()
-        ops.invalidate_weight_images()
-
-
 # ---- both weight gradients of a dual-input projection from ONE product (two-part B operand) ----------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K1,K2,T", [(7060, 128, 602, 128, 232965), (2100, 64, 50, 70, 5000), (2637, 41, 127, 128, 3000),
@@ -448,118 +325,6 @@ def test_dual_projection_backward_takes_the_one_launch_product(ops, cat_weight):
 
 
 # ---- the output layer's input gradients from its forward + loss launch ------------------------------------------------------------
-@pytest.mark.gpu
-@pytest.mark.parametrize("n_src,n_dst,S,K,N,R", [(7060, 512, 25, 600, 41, 0), (7060, 512, 25, 600, 41, 2), (2000, 300, 10, 128, 7, 1),
-                                                 (1500, 1100, 5, 64, 64, 0), (1030, 1, 3, 4, 1, 0)])
-def test_output_layer_forward_with_input_gradients(ops, n_src, n_dst, S, K, N, R):
-    """ogl_out_layer_fwd_ce_bwd against the two launches it replaces (ogl_out_layer_fwd_ce, then ogl_out_layer_bwd_inputs on its
-    dlogits): every forward output and dx_self bit for bit (the same terms in the same order), the scattered pooled-row gradient within
-    float-atomic order noise — and against float64."""
-    torch.manual_seed(n_src + N)
-    dev = "cuda:0"
-    p = ops.empty_mat(n_src, K, dev).copy_(torch.randn(n_src, K, device=dev).clamp_min(0))
-    h = ops.empty_mat(n_src, K, dev).copy_(torch.randn(n_src, K, device=dev))
-    idx = torch.randint(0, n_src, (n_dst, S), device=dev, dtype=torch.int32)
-    idx[0, 1:] = -1
-    ws = torch.randn(N, K, device=dev) / K ** 0.5; wn = torch.randn(N, K, device=dev) / K ** 0.5
-    bs = torch.randn(N, device=dev); bn = torch.randn(N, device=dev)
-    labels = torch.randint(0, N, (n_dst,), device=dev)
-    old = ops.OUT_FWD_ROWS
-    ops.OUT_FWD_ROWS = R
-    try:
-        dP = ops.empty_mat(n_src, K, dev, zero=True)
-        dxs = ops.empty_mat(n_dst, K, dev)
-        got = ops.out_layer_fwd_ce(p, idx, h, n_dst, ws, wn, bs, bn, labels, want_grad=True, bwd_into=(dxs, dP))
-        ref = ops.out_layer_fwd_ce(p, idx, h, n_dst, ws, wn, bs, bn, labels, want_grad=True)
-    finally:
-        ops.OUT_FWD_ROWS = old
-    for a, b in zip(got, ref):
-        assert torch.equal(a, b)
-    mean, rows, logits, neigh, argmax, dl = ref
-    dx_ref, dp_ref = ops.out_layer_bwd_inputs(dl, ws, wn, argmax, neigh, n_src)
-    assert torch.equal(dxs, dx_ref)
-    scale = float(dp_ref.abs().max()) + 1e-30
-    assert float((dP[:, :K] - dp_ref).abs().max()) <= 2e-6 * scale
-    # float64: dP[a, c] = sum over destinations whose winner of column c is a (and whose maximum is positive) of (dl . wn)[d, c]
-    dn = dl[:, :N].double() @ wn.double()
-    want = torch.zeros(n_src, K, dtype=torch.float64, device=dev)
-    am = argmax.long()
-    ok = (am >= 0) & (neigh[:, :K] > 0)
-    cols = torch.arange(K, device=dev).expand(n_dst, K)
-    want.index_put_((am[ok], cols[ok]), dn[ok], accumulate=True)
-    assert float((dP[:, :K].double() - want).abs().max()) <= 1e-5 * (float(want.abs().max()) + 1e-30)
-    assert float((dxs.double() - dl[:, :N].double() @ ws.double()).abs().max()) <= 1e-5 * float(dxs.abs().max() + 1e-30)
-
-
-@pytest.mark.gpu
-def test_loss_node_with_forward_side_input_gradients_matches_two_launch_form(ops):
-    """The Reddit-shaped 'pool' model's train step with OGL_OUT_FWD_BWD on and off: the same loss bits, parameter gradients equal within
-    float-atomic order noise; a non-unit root gradient falls back to the two-launch form and scales."""
-    import torch.nn.functional as F
-    from ogl_amd import sampling, synthetic
-    from ogl_amd.graphsage import GatheredRows, GraphSAGE
-    sampling.seed(3); torch.manual_seed(3)
-    feat_size, _, dyn, n_classes, _ = synthetic.load("arxiv", snapshots=2, device="cuda")
-    dyn.evolve()
-    g = dyn.get_graph()
-    old_mode, old = ops.get_gemm_mode(), ops.OUT_FWD_BWD
-    ops.set_gemm_mode("auto")
-    try:
-        model = GraphSAGE(feat_size, 256, n_classes, 1, F.relu, 0, "pool").cuda()
-        seeds = torch.as_tensor(np.random.default_rng(0).choice(g.n_present, 512, replace=False))
-        (input_nodes, sd, blocks), = list(sampling.NodeDataLoader(g, seeds, sampling.MultiLayerNeighborSampler([25, 25]), batch_size=512))
-        res = {}
-        for on, scale in ((True, None), (False, None), (True, 3.0), (False, 3.0)):
-            ops.OUT_FWD_BWD = on
-            model.zero_grad(set_to_none=True)
-            launches = []
-            real = ops._launch
-
-            def spy(name, *a, **k):
-                launches.append(name)
-                return real(name, *a, **k)
-            ops._launch = spy
-            try:
-                loss, _, _ = model.forward_loss(blocks, GatheredRows(g.ndata["feat"], input_nodes), ops.gather_i64(g.ndata["target"], sd))
-                if scale is None:
-                    ops.backward(loss)
-                else:
-                    (loss * scale).backward()
-            finally:
-                ops._launch = real
-            torch.cuda.synchronize()
-            res[(on, scale)] = (float(loss), [p.grad.clone() for p in model.parameters()], launches)
-        assert "ogl_out_layer_bwd_inputs" not in res[(True, None)][2] and "ogl_out_layer_bwd_inputs" in res[(False, None)][2]
-        assert "ogl_out_layer_bwd_inputs" in res[(True, 3.0)][2]
-        for key_a, key_b in (((True, None), (False, None)), ((True, 3.0), (False, 3.0))):
-            assert res[key_a][0] == res[key_b][0]
-            for a, b in zip(res[key_a][1], res[key_b][1]):
-                assert torch.isfinite(a).all()
-                assert float((a - b).abs().max()) <= 2e-5 * (float(b.abs().max()) + 1e-30)
-        for a, b in zip(res[(True, 3.0)][1], res[(True, None)][1]):
-            assert float((a - 3.0 * b).abs().max()) <= 1e-4 * (float(b.abs().max()) * 3.0 + 1e-30)
-    finally:
-        ops.set_gemm_mode(old_mode)
-        ops.OUT_FWD_BWD = old
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("M,K,N,zfloats", [(7060, 600, 600, 7060 * 608), (62495, 602, 602, 1 << 20), (300, 33, 161, 4), (7060, 600, 600, 12),
-                                           (30000, 64, 128, 3000 * 128)])
-def test_zero_fill_riding_in_a_product(ops, M, K, N, zfloats):
-    """ogl_linear_fwd_x3_zero: the product's bits are those of ogl_linear_fwd_x3 and the buffer is cleared — by the tile-less blocks of a
-    one-round grid ([7 060, 600] x [600, 600]: 185 tiles, 71 blocks fill), or by a fill launch in front of a product without such blocks."""
-    torch.manual_seed(M + N)
-    x = torch.randn(M, K, device="cuda")
-    w = torch.randn(N, K, device="cuda") / K ** 0.5
-    b = torch.randn(N, device="cuda")
-    xi, wi = ops.x3_split(x, append_ones=True), ops.x3_split(w, append_vec=b)
-    ref = ops.linear_fwd_x3(xi, None, wi, relu=True)
-    z = torch.full((zfloats + 8,), 7.0, device="cuda")
-    y = ops.linear_fwd_x3(xi, None, wi, relu=True, zero=z[:zfloats])
-    torch.cuda.synchronize()
-    assert torch.equal(y, ref)
-    assert float(z[:zfloats].abs().max()) == 0.0 and bool((z[zfloats:] == 7.0).all())
 
 
 @pytest.mark.gpu

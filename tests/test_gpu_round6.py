@@ -65,7 +65,9 @@ def test_staggered_multiplier_waves_compute_the_same_bits():
                 dual = ops.linear_bwd_weight_x3k_dual(dy_img, xi_big, rows, 40000, 30001, 602, x2_img, 600)
                 if dual is not None:
                     ws, stride, ws_ld, nsplit, col2, N = dual
-                    take(ws.clone())
+                    slabs = ws[:4 * nsplit * N * ws_ld].view(torch.float32).view(nsplit, N, ws_ld)
+                    # (the columns the product writes: [dw1 | db] and dw2 — the padding between them is never written)
+                    take([slabs[:, :, :603].clone(), slabs[:, :, col2:col2 + 600].clone()])
                 outs[(ea, stag)] = (got, names)
         for ea in (1, 0):
             (g0, n0), (g1, n1) = outs[(ea, 0)], outs[(ea, 1)]
@@ -234,3 +236,180 @@ def test_unconsumed_route_raises():
     with pytest.raises(RuntimeError, match="(?i)route"):
         opt.step()
     assert not ops._PENDING_ROUTES
+
+
+@pytest.mark.parametrize("n_src,n_dst,S,d,i64", [(5000, 3000, 25, 128, True), (5000, 3000, 25, 128, False), (300, 257, 2, 4, True), (90, 40, 70, 100, False),
+                                                (169343, 20480, 25, 128, True), (64, 5, 3, 32, True), (1000, 600, 25, 124, False)])
+def test_half_wave_max_aggregator_has_the_same_bits(n_src, n_dst, S, d, i64):
+    """The max aggregator without argmax over rows of <= 128 floats (the inference passes: priority forward, evaluation) with two
+    neighbour rows per wave-instruction (k_reduce_fwd_max_half: the wave's halves walk the even and the odd slots) == the one-row form,
+    bit for bit — values and the bf16x3 image beside them; missing neighbours (-1, ids past the table), destinations without any."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import _lib, ops
+    rng = np.random.default_rng(n_src + d)
+    src = ops.empty_mat(n_src, d, "cuda").copy_(torch.as_tensor(rng.standard_normal((n_src, d)).astype(np.float32)).cuda())
+    idx = rng.integers(0, n_src, size=(n_dst, S))
+    idx[rng.random((n_dst, S)) < 0.1] = -1
+    idx[rng.random(n_dst) < 0.05] = -1
+    idx[0, 0] = n_src + 7                                                # (past the table: skipped)
+    idx_t = torch.as_tensor(idx.astype(np.int64 if i64 else np.int32)).cuda()
+    lib = _lib.lib()
+    was = lib.ogl_reduce_debug_half(1)
+    try:
+        res = {}
+        for half in (0, 1):
+            lib.ogl_reduce_debug_half(half)
+            out, _ = ops.reduce_fwd(src, idx_t, "max")
+            o2, _, img = ops.reduce_fwd_img(src, idx_t, want_argmax=False)
+            res[half] = (out.clone(), o2.clone(), img.buf.clone())
+        for a, c in zip(res[0], res[1]):
+            assert torch.equal(a, c)
+        # and against numpy
+        valid = (idx >= 0) & (idx < n_src)
+        g = src.cpu().numpy()[np.where(valid, idx, 0)]                   # [n_dst, S, d]
+        g = np.where(valid[:, :, None], g, -np.inf)
+        want = g.max(axis=1)
+        want[~valid.any(axis=1)] = 0.0
+        np.testing.assert_array_equal(res[1][0].cpu().numpy(), want.astype(np.float32))
+    finally:
+        lib.ogl_reduce_debug_half(was)
+
+
+def test_size_agnostic_first_layer_ignores_what_lies_behind_the_live_sources():
+    """A captured 32-seed step sized for the upper-bound block reads its source list up to CAPACITY; behind the live count lie the -1
+    padding of the current bucket and, behind that, stale ids of earlier batches (the advisor's round-5 finding).  The invariant: every
+    consumer of the first layer honours the device's own counts — so poisoning everything behind the live sources (ids far outside the
+    table, negative ids, ids of other valid rows) changes no output and no gradient bit."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops, sampling
+    from ogl_amd.graphsage import GraphSAGE
+    from ogl_amd.graphsage.sageconv import GatheredRows
+    T, F_in, C_out, B, S = 6000, 500, 3, 32, 25
+    n1_cap, n0_cap = B * (1 + S), B * (1 + S) * (1 + S)
+    n1_live, n0_live = 211, 2309
+    rng = np.random.default_rng(5)
+    torch.manual_seed(5)
+    table = ops.empty_mat(T, F_in, "cuda").copy_(torch.randn(T, F_in, device="cuda"))
+    ids_live = rng.choice(T, n0_live, replace=False).astype(np.int64)
+    lidx0 = np.full((n1_cap, S), -1, dtype=np.int32)
+    lidx0[:n1_live] = rng.integers(0, n0_live, size=(n1_live, S))
+    lidx1 = rng.integers(0, n1_live, size=(B, S)).astype(np.int32)
+    labels = torch.randint(0, C_out, (B,), device="cuda")
+    model = GraphSAGE(F_in, 32, C_out, 1, F.relu, 0, "pool").cuda()
+    counts = torch.tensor([n1_live, n0_live], dtype=torch.int64, device="cuda")
+
+    def run(tail):
+        ids = np.concatenate([ids_live, tail]).astype(np.int64)
+        assert ids.size == n0_cap
+        ids_t = torch.as_tensor(ids).cuda()
+        b0 = sampling.Block(ids_t, ids_t[:n1_cap], torch.as_tensor(lidx0).cuda())
+        b0.n_live_dev, b0.n_src_live_dev = counts[:1], counts[1:2]
+        b1 = sampling.Block(ids_t[:n1_cap], ids_t[:B], torch.as_tensor(lidx1).cuda())
+        for p in model.parameters():
+            p.grad = None
+        loss, rows, logits = model.forward_loss([b0, b1], GatheredRows(table, ids_t), labels, rows=True, defer_mean=True)
+        ops.backward(loss)
+        torch.cuda.synchronize()
+        return float(loss), rows.clone(), logits.clone(), {k: v.grad.clone() for k, v in model.named_parameters()}
+    pad = np.full(n0_cap - n0_live, -1, dtype=np.int64)
+    poison = rng.choice(np.array([-7, 10 ** 12, T, T + 5] + list(rng.choice(T, 50))), n0_cap - n0_live)
+    # (the destination prefix of the source list, rows [n1_live, n1_cap), is padding too: those rows' index rows are all -1)
+    l0, r0, y0, g0 = run(pad)
+    l1, r1, y1, g1 = run(poison)
+    assert l0 == l1 and torch.equal(r0, r1) and torch.equal(y0, y1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+
+
+# Exported entry points that the default train / inference paths of the BASELINE configurations do not call, each with its reason to be
+# in the library.  Everything else in include/ogl_hip.h must be reached by test_every_exported_symbol_is_reached_or_allow_listed.
+ALLOW_UNREACHED = {
+    # identification / errors / diagnostics (never on a hot path)
+    "ogl_version", "ogl_source_hash", "ogl_status_string", "ogl_last_hip_error", "ogl_set_gemm_mode", "ogl_get_gemm_mode",
+    "ogl_x3_debug_stamps", "ogl_x3_debug_early_a", "ogl_x3_debug_stagger", "ogl_x3_debug_tile", "ogl_x3_last_kernel",
+    "ogl_block_debug_min_lds", "ogl_reduce_debug_half", "ogl_stream_copy", "ogl_graph_degrees", "ogl_graph_copy_degrees",
+}
+
+
+def test_every_exported_symbol_is_reached_or_allow_listed():
+    """no entry point rides in the library unused.  A counting proxy over the ctypes handle records every C-ABI call
+    while the package runs what a user of the five BASELINE configurations runs — 32-seed RBR steps (pubmed-like, captured), the PBR
+    strategy with its priority forward every snapshot (arxiv-like), Reddit-size RBR / PBR / no-rehearsal updates with the priority
+    forward and an evaluation, the in-repo 'meanpool' and 'mean' layers, exact-fp32 mode — and every symbol of
+    include/ogl_hip.h is then either reached or on ALLOW_UNREACHED with its reason."""
+    import re
+    import os
+    import random
+    import tempfile
+    import ogl_amd  # noqa: F401
+    from ogl_amd import _lib, ops, sampling, synthetic
+    from ogl_amd.graph import TrainTestGraph
+    from ogl_amd.prioritized_replay import LossPriority
+    from ogl_amd.utils import Lib_supported, init
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "ogl_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*|void)\s+(ogl_[a-z0-9_]+)\(", header, re.M))
+    assert declared == set(_lib.SIGNATURES), sorted(declared ^ set(_lib.SIGNATURES))
+    real = _lib.lib()
+    seen = set()
+
+    class Proxy:
+        def __getattr__(self, name):
+            fn = getattr(real, name)
+            if not name.startswith("ogl_"):
+                return fn
+
+            def call(*a, **k):
+                seen.add(name)
+                return fn(*a, **k)
+            return call
+    _lib._lib = Proxy()
+    try:
+        GraphSAGE, Random, Prioritized, NoReh, _Full, act = init(Lib_supported.HIP, True, 0)
+        out_csv = os.path.join(tempfile.gettempdir(), "ogl_symbols_%d.csv" % os.getpid())
+
+        def stream(dataset, hidden, S, B, bt, batch_full, snaps, start, agg="pool", strategies=("rbr", "pbr", "noreh"), evaluate=True):
+            np.random.seed(1); random.seed(1); torch.manual_seed(1); sampling.seed(1)
+            feat_size, labels, graph, n_classes, graph_test = synthetic.load(dataset)
+            for _ in range(start):
+                graph.evolve(); graph_test.evolve()
+            gu = TrainTestGraph(graph, split=0.15, start_prior_alpha=4, end_prior_alpha=50, scale=1, max_priority=10)
+            gu._admit([int(v) for v in range(graph.get_graph().n_present) if v in graph.labelled_vertices])
+            mk = lambda: GraphSAGE(feat_size, hidden, n_classes, 1, act, 0, agg, edge_feats=0, pool_feats=hidden).cuda()   # noqa: E731
+            kw = dict(cuda=True, batch_full=batch_full, n_workers=0)
+            sts = []
+            if "rbr" in strategies:
+                sts.append(Random(mk(), bt, B, labels, S, **kw))
+            if "pbr" in strategies:
+                sts.append(Prioritized(mk(), bt, B, labels, S, LossPriority(), full_pass=1, **kw))
+            if "noreh" in strategies:
+                sts.append(NoReh(mk(), bt, B, labels, S, **kw))
+            for st in sts:
+                st.use_graphs = True
+                st.build_optimizer()
+            for _ in range(snaps):
+                for st in sts:
+                    st.train_timestep(gu)
+                if evaluate:
+                    sts[0].evaluate(gu, out_csv)
+                gu.evolve(); graph_test.evolve()
+            torch.cuda.synchronize()
+        ops.set_gemm_mode("auto")
+        stream("pubmed", 32, 25, 32, 2, 256, snaps=4, start=200)                            # configs 2 (+ 1's no-rehearsal strategy)
+        stream("arxiv", 32, 25, 32, 1, 1024, snaps=3, start=2000, strategies=("pbr",))       # config 3
+        stream("reddit", 600, 25, 512, 4, 1024, snaps=3, start=4800)                         # configs 4 / 5 (one rank), evaluation
+        stream("reddit", 600, 25, 512, 2, 1024, snaps=2, start=4800, agg="meanpool", strategies=("rbr",), evaluate=False)
+        stream("reddit", 600, 25, 512, 2, 1024, snaps=2, start=4800, agg="mean", strategies=("rbr",), evaluate=False)
+        ops.set_gemm_mode("f32")
+        stream("pubmed", 32, 25, 32, 2, 256, snaps=2, start=200, strategies=("rbr",))
+        stream("reddit", 600, 25, 512, 1, 1024, snaps=1, start=4800, strategies=("rbr",), evaluate=False)
+    finally:
+        _lib._lib = real
+        ops.set_gemm_mode("f32")
+        try:
+            os.remove(out_csv)
+        except OSError:
+            pass
+    unreached = declared - seen - ALLOW_UNREACHED
+    assert not unreached, "exported but never called by the default paths (remove them or allow-list them with a reason): %s" % sorted(unreached)
+    assert not (ALLOW_UNREACHED - declared), sorted(ALLOW_UNREACHED - declared)

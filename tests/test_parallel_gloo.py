@@ -385,20 +385,39 @@ def _worker_sharded_update(rank, world, port, out):
     sa = parallel.ShardedAdam(params, lr=1e-3)
     assert all(p.data_ptr() == sa.wflat.data_ptr() + 4 * off for p, off in zip(params, sa.offs))      # rebased into the flat buffer
     assert sa.m.numel() == sa.wflat.numel() // world                                                  # 1 / N of the moments
-    for step, sd in enumerate((seeds, seeds[::-1].copy(), seeds[:world - 1] if world > 2 else seeds[:3])):
+    batches = (seeds, seeds[::-1].copy(), seeds[:world - 1] if world > 2 else seeds[:3])
+
+    def one(mdl, opt, prm, sd):
         mine = parallel.shard_seeds(sd)
         if len(mine) > 0:
-            _grads(model, feat, labels, indptr, indices, deg_t, mine)
+            _grads(mdl, feat, labels, indptr, indices, deg_t, mine)
         else:
-            for p in params:
+            for p in prm:
                 p.grad = None
-        sa.step(len(mine) / len(sd))
+        opt.step(len(mine) / len(sd))
+    ckpt = None
+    for step, sd in enumerate(batches):
+        if step == 2:
+            # a checkpoint in front of the last step: the moments (1 / N per rank) are gathered into a rank-independent state
+            ckpt = (sa.state_dict(), [p.detach().clone() for p in params])
+        one(model, sa, params, sd)
     ws = [p.detach().clone() for p in params]
+    # ... resumed on a fresh replica: the last step from the checkpoint gives the same weights, bit for bit
+    model2 = O.CpuModel("pool", F, 8, C, seed=3)
+    params2 = model2.opt.param_groups[0]["params"]
+    sa2 = parallel.ShardedAdam(params2, lr=1e-3)
+    with torch.no_grad():
+        for p, w in zip(params2, ckpt[1]):
+            p.copy_(w)
+    sa2.load_state_dict(ckpt[0])
+    assert sa2.t == 2 and len(ckpt[0]["state"]) == len(params)
+    one(model2, sa2, params2, batches[2])
+    resumed = all(torch.equal(a.detach(), b) for a, b in zip(params2, ws))
     flat = [torch.empty_like(sa.wflat) for _ in range(world)]
     dist.all_gather(flat, sa.wflat)
     same = all(torch.equal(f, flat[0]) for f in flat)
     if rank == 0:
-        torch.save(dict(weights=ws, same=same), out)
+        torch.save(dict(weights=ws, same=same, resumed=resumed), out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -411,6 +430,7 @@ def test_sharded_update_equals_one_rank_adam(tmp_path, world):
     mp.spawn(_worker_sharded_update, args=(world, _free_port(), out), nprocs=world, join=True)
     got = torch.load(out)
     assert got["same"]
+    assert got["resumed"]                                   # (state_dict / load_state_dict: a resumed replica takes the same last step)
     indptr, indices, deg_t, feat, labels, seeds, F, C = _problem()
     model = O.CpuModel("pool", F, 8, C, seed=3)
     params = model.opt.param_groups[0]["params"]
