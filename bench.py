@@ -26,8 +26,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
-PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"   # the committed rocprofv3 --pmc pass `roofline.traffic` is quoted from
-PMC_PBR_TRAFFIC_FILE = "r05_pbr_pmc_traffic.json"   # ... and the one of the PBR priority-forward workloads
+PMC_TRAFFIC_FILE = "r06_pmc_traffic.json"   # the committed rocprofv3 --pmc pass `roofline.traffic` is quoted from
+PMC_PBR_TRAFFIC_FILE = "r06_pbr_pmc_traffic.json"   # ... and the one of the PBR priority-forward workloads
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 MFMA_F32_PEAK_TFLOPS = 157.3
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense (MI355X_MICROARCH.md); AMD's 5 PF headline includes 2:1 sparsity
@@ -895,7 +895,8 @@ def pbr_snapshot_bench(args, wl):
     for _ in range(wl["start"]):                             # (the device CSR makes fast-forwarding O(1) per snapshot)
         graph.evolve()
     gu = TrainTestGraph(graph, split=0.15, start_prior_alpha=4, end_prior_alpha=50, scale=1, max_priority=10)
-    gu._admit([int(v) for v in range(graph.get_graph().n_present) if v in graph.labelled_vertices])
+    present = np.asarray(gu.get_subgraph_to_original_map()[np.arange(graph.get_graph().n_present)]).reshape(-1)   # (original ids)
+    gu._admit([int(v) for v in present if int(v) in graph.labelled_vertices])
     setup_s = time.perf_counter() - t0
     model = GraphSAGE(feat_size, wl["hidden"], n_classes, 1, act, 0, "pool", edge_feats=0, pool_feats=wl["hidden"]).cuda()
     pri = Prioritized(model, wl["batch_timestep"], wl["batch"], labels, wl["samples"], LossPriority(), full_pass=wl["priority_forward"],

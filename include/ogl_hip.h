@@ -296,7 +296,6 @@ int ogl_pool_bwd_x3_plan(const int32_t* argmax, const float* relu_out, int64_t l
                          int d, int64_t n_src, void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
 int ogl_pool_bwd_x3_apply(const float* dout, int64_t ldo, const int32_t* idx32, int64_t n_dst, int fanout, int d, int64_t n_src,
                           void* image, const void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
-int64_t ogl_x3_row_bytes(int64_t K);
 int64_t ogl_x3_image_bytes(int64_t rows, int64_t K);
 int ogl_x3_split(const float* src, int64_t ld, const int64_t* rows, int64_t nrows, int64_t R, int K, int append,
                  const float* append_vec, void* image, ogl_stream_t stream);
@@ -307,10 +306,6 @@ int ogl_x3_split_t(const float* src, int64_t ld, const int64_t* rows, int64_t nr
  * the kernel is d(s_memtime) / d(s_memrealtime) x 100 MHz.  Pass NULL to switch off.  `reserved` is ignored.  Not part of
  * the hot path. */
 int ogl_x3_debug_stamps(void* buf, int reserved);
-/* diagnostic: 1 / 0 = the two-stage image-GEMM tiles in their early-A form (a second barrier per step returns the A part of a stage
- * buffer to the movers as soon as the multipliers hold it in registers) / in the one-barrier form; -1 = OGL_X3_EARLY_A (default on).
- * Both forms compute the same bits.  Returns the old value. */
-int ogl_x3_debug_early_a(int on);
 /* 1 / 0 = the producer / consumer image GEMM with STAGGERED multiplier waves (waves 4-7 run the last column block of every step but a
  * tile's last one behind the next step's opening barrier, on fragments kept in registers: the matrix pipe has work while its SIMD
  * partner's fragments arrive) / with every wave opening a step on its fragment loads; -1 = OGL_X3_STAGGER (default on).  Every
@@ -365,8 +360,8 @@ typedef struct ogl_x3_split_part {
   void* image; int64_t image_row_bytes; int64_t group_offset;
 } ogl_x3_split_part;
 int ogl_x3_split_multi(const ogl_x3_split_part* parts, int n_parts, ogl_stream_t stream);
-/* ogl_x3_split_multi with the optimiser's per-step scalars riding in the same launch (what ogl_adam_step_multi_dev computes in a
- * one-thread launch of its own at the END of a step: ++*step_dev, scalars_dev[0] = lr / (1 - beta1^t), scalars_dev[1] =
+/* ogl_x3_split_multi with the optimiser's per-step scalars riding in the same launch (what ogl_adam_step_multi_slabs with prepare = 1
+ * computes in a one-thread launch of its own at the END of a step: ++*step_dev, scalars_dev[0] = lr / (1 - beta1^t), scalars_dev[1] =
  * 1 / sqrt(1 - beta2^t), double arithmetic): moved to the launch that STARTS the step; the step's optimiser launch then passes
  * prepare = 0 to ogl_adam_step_multi_slabs.  n_parts >= 1. */
 int ogl_x3_split_multi_adam(const ogl_x3_split_part* parts, int n_parts, int64_t* step_dev, float* scalars_dev, double lr, double beta1,
@@ -442,11 +437,9 @@ int ogl_build_block_batched_ids(const int64_t* dst_base, const int64_t* dst_star
 int ogl_ce_fwd_bwd(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C,
                    float grad_scale, float* loss_rows, float* dlogits, int64_t lddl,
                    ogl_stream_t stream);
-/* The same for B <= 1024 rows in one workgroup, with loss_mean[0] = mean of the row losses from the same launch
- * (reduction='mean', R/train/graphsage/pytorch/model.py:20: the loss the RBR / no-rehearsal strategies differentiate). */
-int ogl_ce_fwd_bwd_mean(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C, float grad_scale,
-                        float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean, ogl_stream_t stream);
-/* ogl_ce_fwd_bwd_mean with (a) the label gather inside the launch — label of row i = label_table[label_ids[i]], an id outside
+/* The same for B <= 1024 rows in ONE workgroup, with loss_mean[0] = mean of the row losses from the same launch
+ * (reduction='mean', R/train/graphsage/pytorch/model.py:20: the loss the RBR / no-rehearsal strategies differentiate), with (a) the
+ * label gather inside the launch — label of row i = label_table[label_ids[i]], an id outside
  * [0, n_labels) = no label (what ogl_gather_i64 writes as -1); label_ids null: label_table is the label vector itself — and (b) an
  * optional zero fill of a small caller buffer (zero_floats <= 65 536, a multiple of 4, 16-byte aligned: the atomic-scatter target of
  * the backward pass that follows).  graph.ndata['target'][seeds] (R/train/graphsage/pytorch/model.py:91,183) and that fill were a
@@ -488,18 +481,16 @@ int ogl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int s
 int ogl_argmax_confusion(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C,
                          int64_t* pred, int64_t* confusion, ogl_stream_t stream);
 
-/* The same update for `count` tensors in one launch; p/g/m/v/n are HOST arrays of device pointers / lengths. */
-int ogl_adam_step_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
-                        const int64_t* n, int step, double lr, double beta1, double beta2, double eps,
-                        ogl_stream_t stream);
+/* (The same update for `count` tensors in one launch: ogl_adam_step_multi_slabs, below; p/g/m/v/n are HOST arrays of device pointers /
+ * lengths.) */
 
 /* ------------------------------------------------------------------------------------------
  * Entry points for a CAPTURED step (hipGraph): everything a replay must see new values of lives in device memory.
  * A train step of the small rungs (32 seeds) is ~40 microsecond-sized launches: enqueued one by one from the host it is
  * launch- and sync-bound; captured once on upper-bound shapes and replayed, it costs one graph launch.
  *   ogl_sample_layer_dev     = ogl_sample_layer with the Philox batch counter read from *ctr_dev on the device;
- *   ogl_adam_step_multi_dev  = ogl_adam_step_multi with the step count in *step_dev (incremented by the call itself on the
- *                              device, bias corrections derived from it there; scalars_dev = float[2] scratch);
+ *   ogl_adam_step_multi_slabs(…, step_dev, scalars_dev, prepare = 1, …) = Adam with the step count in *step_dev (incremented by the
+ *                              call itself on the device, bias corrections derived from it there; scalars_dev = float[2] scratch);
  *   ogl_stage_segments       copies the sampled batch of a loader into the static buffers of a captured step: up to 8
  *                              segments of 4- or 8-byte elements in one launch, each copied for `count` elements and filled
  *                              with `pad` (-1: "no vertex" / "no neighbour") up to `capacity`.
@@ -514,9 +505,6 @@ int ogl_sample_layer_dev(const ogl_graph_t* g, const int64_t* dst, int64_t n_dst
 int ogl_build_block_padded(const int64_t* dst, int64_t n_dst, const int64_t* picks, int fanout, int64_t* src_ids,
                            int64_t src_cap, int64_t* n_src_out, int32_t* local_idx, void* workspace,
                            int64_t workspace_bytes, ogl_stream_t stream);
-int ogl_adam_step_multi_dev(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
-                            const int64_t* n, int64_t* step_dev, float* scalars_dev, double lr, double beta1,
-                            double beta2, double eps, ogl_stream_t stream);
 
 /* Split-K weight gradients whose reduction is left to the optimiser launch (csrc/linear_x3.hip, csrc/loss_optim.hip).  A k-major
  * weight gradient runs as nsplit partial products over ranges of the reduction, each written to its own slab, and a reduction launch
@@ -529,8 +517,9 @@ int ogl_adam_step_multi_dev(int count, float* const* p, const float* const* g, f
  *                                       g_i[r, c] = sum_s ws[i][s * slab_stride[i] + r * ws_ld[i] + col0[i] + c]  (slab order: the bits
  *                                       of the reduction launch), stores it into g[i] (p.grad holds the gradient afterwards) and
  *                                       applies it; rows = n[i] / ncols[i].  A bias takes column K of its weight's slabs: ncols 1,
- *                                       col0 K.  step_dev NULL: host step count `step`; else the device-side count of
- *                                       ogl_adam_step_multi_dev, incremented (and the scalars refreshed) only when `prepare` != 0 —
+ *                                       col0 K.  A tensor with ws[i] == NULL reads g[i] as it is (plain Adam).  step_dev NULL:
+ *                                       host step count `step`; else the device-side count, incremented (and the scalars refreshed)
+ *                                       only when `prepare` != 0 —
  *                                       a step applied in two launches (gradients that are ready early on a side branch, the rest
  *                                       at the end) prepares once.
  *   ogl_x3_slab_reduce                the plain reduction of such slabs into out[rows, ncols] (a gradient somebody reads before
@@ -539,15 +528,11 @@ int ogl_linear_bwd_weight_x3k_slabs(const void* dyT_img, int64_t interleave, con
                                     const int64_t* x_rows, int64_t x_nrows, int64_t M, int N, int K, int has_ones, float* dw,
                                     int64_t lddw, float* db, float* db2, void* workspace, int64_t workspace_bytes, int* nsplit_out,
                                     int64_t* ws_ld_out, ogl_stream_t stream);
-int ogl_adam_step_multi_slabs(int count, float* const* p, float* const* g, float* const* m, float* const* v, const int64_t* n,
-                              const float* const* ws, const int64_t* slab_stride, const int* ws_ld, const int* nsplit,
-                              const int* ncols, const int* col0, int step, int64_t* step_dev, float* scalars_dev, int prepare,
-                              double lr, double beta1, double beta2, double eps, ogl_stream_t stream);
-/* ... with TWO-RANGE tensors: tensor i with split[i] > 0 takes its columns [0, split) from slab column col0[i] and its columns
+/* TWO-RANGE tensors (split / col0b, both nullable): tensor i with split[i] > 0 takes its columns [0, split) from slab column col0[i] and its columns
  * [split, ncols) from slab column col0b[i] — the concat weight [N, K1 + K2] of the in-repo layer
  * (R/train/graphsage/pytorch/aggregator_dgl.py:94,206) behind ogl_linear_bwd_weight_x3k_dual_slabs, whose slabs are laid out
- * [dw1 | db | pad | dw2]: no reduction launch between the product and the optimiser.  split / col0b NULL: ogl_adam_step_multi_slabs. */
-int ogl_adam_step_multi_slabs2(int count, float* const* p, float* const* g, float* const* m, float* const* v, const int64_t* n,
+ * [dw1 | db | pad | dw2]: no reduction launch between the product and the optimiser. */
+int ogl_adam_step_multi_slabs(int count, float* const* p, float* const* g, float* const* m, float* const* v, const int64_t* n,
                                const float* const* ws, const int64_t* slab_stride, const int* ws_ld, const int* nsplit, const int* ncols,
                                const int* col0, const int* split, const int* col0b, int step, int64_t* step_dev, float* scalars_dev,
                                int prepare, double lr, double beta1, double beta2, double eps, ogl_stream_t stream);
@@ -578,9 +563,6 @@ int ogl_publish_i64(const int64_t* src, int n, int64_t* seq_dev, int64_t* dst_ho
  * One 1024-thread workgroup; B (1 + fanout)^2 <= 131 072 (B = 32 at fanout 45: 67 712).  Replaces the per-batch NodeDataLoader iteration of
  * R/train/graphsage/pytorch/model.py:76-117 for the 32-seed rungs (R/settings/pubmed.json, arxiv.json). */
 int64_t ogl_sample_blocks_small_workspace_bytes(int B, int fanout);
-int ogl_sample_blocks_small(const ogl_graph_t* g, const int64_t* head_host_mapped, int64_t* head_dev, int B, int fanout, uint64_t seed,
-                            int64_t* src1, int32_t* lidx1, int64_t* src0, int32_t* lidx0, int64_t* counts, int64_t* seq_dev,
-                            int64_t* counts_host_mapped, void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
 /* ... with src0 padded with -1 only up to round_up(n0, src0_fill_multiple) (0: up to its capacity, as above): for a caller that reads
  * the input block's source list up to the size bucket of the train graph it replays and no further (21 632 entries per step otherwise). */
 int ogl_sample_blocks_small_fill(const ogl_graph_t* g, const int64_t* head_host_mapped, int64_t* head_dev, int B, int fanout, uint64_t seed,
@@ -658,15 +640,13 @@ int ogl_loss_mean_finish(const float* loss_rows, int64_t n, float* loss_mean, og
  * (R/settings/pubmed.json, arxiv.json: embedding_size 32, batch 32 -> the output layer of a batch is <= 832 source rows x 32
  * features x <= 40 classes): there the 15 general launches this replaces are pure latency.  ogl_small_pool_layer_fits tells
  * whether a shape qualifies (Hin, Hout <= 64, n_dst * max(Hin, Hout) <= 8192, n_src <= 65536).
- *   workspace: float [ogl_small_pool_layer_workspace_floats(n_src, n_dst, Hin)] (forward: the projected rows; backward: the
- *        winners' routed gradient).
+ *   workspace: float [n_src * Hin] (forward: the projected rows; backward: the winners' routed gradient, n_dst * Hin of them).
  *   fwd: neigh [n_dst, Hin] and argmax (int32 [n_dst, Hin], nullable: the winning block-local source row, -1 = none) are
  *        outputs kept for the backward; biases nullable.
  *   bwd: dy [n_dst, Hout] (masked here by y > 0 when relu_out); every gradient output nullable; dh [n_src, Hin] is written
  *        completely (zeros where nothing flows; the winners' rows by float atomics).
  * ---------------------------------------------------------------------------------------- */
 int ogl_small_pool_layer_fits(int64_t n_src, int64_t n_dst, int fanout, int Hin, int Hout);
-int64_t ogl_small_pool_layer_workspace_floats(int64_t n_src, int64_t n_dst, int Hin);
 int ogl_small_pool_layer_fwd(const float* h, int64_t ldh, int64_t n_src, const int32_t* idx, int64_t n_dst, int fanout, int Hin,
                              const float* Wp, int64_t ldwp, const float* bp, const float* Ws, int64_t ldws, const float* bs,
                              const float* Wn, int64_t ldwn, const float* bn, int Hout, int relu_out, float* neigh, int64_t ldn,
@@ -777,10 +757,6 @@ int ogl_record_weight_grads(const ogl_rec_seg_t* segs, int nseg, const float* lo
  *   dWs[c, :] = sum_d dy[d, c] X[ids[d], :],  dWn[c, :] = sum_d dy[d, c] neigh[d, :],  dbs[c] = dbn[c] = sum_d dy[d, c]   (before:
  *        ogl_out_layer_bwd_weights, a launch of its own).
  * Every output group nullable (at least one); one workgroup per output row; sums in destination order (reproducible, no atomics). */
-int ogl_small_first_layer_dw(const float* G, int64_t ldg, const int32_t* argmax, const float* dy, int64_t lddy, int64_t n_dst, int F, int H,
-                             const float* table, int64_t ldt, const int64_t* ids, int64_t n_table, int64_t n_src, const float* neigh,
-                             int64_t ldn, float* dWp, int64_t lddwp, float* dbp, float* dWs, int64_t lddws, float* dbs, float* dWn,
-                             int64_t lddwn, float* dbn, ogl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Device-side prioritised replay structure (replay.hip): the sum tree of R/train/prioritized_replay/segment_tree.py:69-125

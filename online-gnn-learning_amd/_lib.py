@@ -69,12 +69,10 @@ SIGNATURES = {
     "ogl_pool_bwd_x3": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i, _i, _i64, _p, _p, _i64, _p]),
     "ogl_pool_bwd_x3_plan": (_i, [_p, _p, _i64, _p, _i64, _i, _i, _i64, _p, _i64, _p]),
     "ogl_pool_bwd_x3_apply": (_i, [_p, _i64, _p, _i64, _i, _i, _i64, _p, _p, _i64, _p]),
-    "ogl_x3_row_bytes": (_i64, [_i64]),
     "ogl_x3_image_bytes": (_i64, [_i64, _i64]),
     "ogl_x3_split": (_i, [_p, _i64, _p, _i64, _i64, _i, _i, _p, _p, _p]),
     "ogl_x3_split_t": (_i, [_p, _i64, _p, _i64, _i64, _i, _i, _i64, _p, _p]),
     "ogl_x3_debug_stamps": (_i, [_p, _i]),
-    "ogl_x3_debug_early_a": (_i, [_i]),
     "ogl_x3_debug_stagger": (_i, [_i]),
     "ogl_x3_debug_tile": (_i, [_i]),
     "ogl_x3_last_kernel": (C.c_char_p, []),
@@ -97,20 +95,17 @@ SIGNATURES = {
     "ogl_linear_bwd_weight_x3k": (_i, [_p, _i64, _p, _i64, _p, _i64, _i64, _i, _i, _i, _p, _i64, _p, _p, _p, _i64, _p]),
     "ogl_linear_bwd_weight_x3": (_i, [_p, _p, _i64, _i, _i, _p, _i64, _p, _p, _i64, _p]),
     "ogl_ce_fwd_bwd": (_i, [_p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p]),
-    "ogl_ce_fwd_bwd_mean": (_i, [_p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p]),
     "ogl_ce_fwd_bwd_mean_grid": (_i, [_p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p, _p, _i64, _p]),
     "ogl_ce_fwd_bwd_mean_gather": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p, _i64, _p]),
     "ogl_ce_fwd_bwd_mean_gather_adam": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p, _i64, _p, _p, _d, _d, _d, _p]),
     "ogl_ce_fwd_bwd_mean_grid_gather": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p, _p, _i64, _p]),
     "ogl_adam_step": (_i, [_p, _p, _p, _p, _i64, _i, _d, _d, _d, _d, _p]),
     "ogl_argmax_confusion": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p]),
-    "ogl_adam_step_multi": (_i, [_i, _p, _p, _p, _p, _p, _i, _d, _d, _d, _d, _p]),
     "ogl_sample_layer_dev": (_i, [_p, _p, _i64, _i, _u64, _p, _i, _p, _p]),
     "ogl_out_layer_bwd_inputs": (_i, [_p, _i64, _i64, _i, _i, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _p]),
     "ogl_out_layer_bwd_inputs_mean": (_i, [_p, _i64, _i64, _i, _i, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p]),
     "ogl_out_layer_bwd_weights": (_i, [_p, _i64, _i64, _i, _i, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p]),
     "ogl_small_pool_layer_fits": (_i, [_i64, _i64, _i, _i, _i]),
-    "ogl_small_pool_layer_workspace_floats": (_i64, [_i64, _i64, _i]),
     "ogl_small_pool_layer_fwd": (_i, [_p, _i64, _i64, _p, _i64, _i, _i, _p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _i, _i, _p, _i64, _p, _p,
                                       _i64, _p, _p]),
     "ogl_small_pool_layer_bwd": (_i, [_p, _i64, _p, _i64, _i, _p, _i64, _i64, _i64, _i, _i, _i, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64,
@@ -127,26 +122,21 @@ SIGNATURES = {
     "ogl_small_first_layer_bwd": (_i, [_p, _i64, _p, _i64, _i, _i64, _i, _i, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i,
                                        _p, _p, _i64, _i, _p, _i64, _p, _i64, _i64, _p, _p]),
     "ogl_record_weight_grads": (_i, [_p, _i, _p, _i64, _p, _p, _p, _d, _d, _d, _p]),
-    "ogl_small_first_layer_dw": (_i, [_p, _i64, _p, _p, _i64, _i64, _i, _i, _p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p,
-                                      _p, _i64, _p, _p]),
     "ogl_replay_update": (_i, [_p, _i64, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _p, _p, _p, _p]),
     "ogl_replay_rebuild": (_i, [_p, _i64, _p]),
     "ogl_replay_sample": (_i, [_p, _i64, _i64, _i64, _p, _p, _i64, _p, _p, _p]),
     "ogl_replay_note_keys": (_i, [_p, _i64, _i64, _p, _i64, _p]),
     "ogl_priority_trend": (_i, [_p, _p, _p, _i64, _i64, _p, _p, _p, _p, _d, _d, _p, _p, _p]),
     "ogl_build_block_padded": (_i, [_p, _i64, _p, _i, _p, _i64, _p, _p, _p, _i64, _p]),
-    "ogl_adam_step_multi_dev": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _d, _d, _d, _d, _p]),
     "ogl_linear_bwd_weight_x3k_slabs": (_i, [_p, _i64, _p, _i64, _p, _i64, _i64, _i, _i, _i, _p, _i64, _p, _p, _p, _i64,
                                              C.POINTER(C.c_int), C.POINTER(C.c_int64), _p]),
-    "ogl_adam_step_multi_slabs": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _d, _d, _d, _d, _p]),
-    "ogl_adam_step_multi_slabs2": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _d, _d, _d, _d, _p]),
+    "ogl_adam_step_multi_slabs": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _d, _d, _d, _d, _p]),
     "ogl_linear_bwd_weight_x3k_dual_workspace_bytes": (_i64, [_i64, _i, _i, _i, _i]),
     "ogl_linear_bwd_weight_x3k_dual_slabs": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, _i, _i, _p, _i64, _i, _p, _i64, C.POINTER(C.c_int),
                                                 C.POINTER(C.c_int64), C.POINTER(C.c_int), _p]),
     "ogl_x3_slab_reduce": (_i, [_p, _i64, _i64, _i, _i64, _i, _i, _p, _i64, _p]),
     "ogl_publish_i64": (_i, [_p, _i, _p, _p, _p]),
     "ogl_sample_blocks_small_workspace_bytes": (_i64, [_i, _i]),
-    "ogl_sample_blocks_small": (_i, [_p, _p, _p, _i, _i, C.c_uint64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "ogl_sample_blocks_small_fill": (_i, [_p, _p, _p, _i, _i, C.c_uint64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     "ogl_stage_segments": (_i, [_i, _p, _p, _p, _p, _p, _i64, _p]),
     "ogl_fuse_block_segments": (_i, [_p, _p, _i, _p, _p, _i, _p, _p]),

@@ -1042,19 +1042,6 @@ extern "C" int64_t ogl_sample_blocks_small_workspace_bytes(int B, int fanout) {
 extern "C" int ogl_sample_blocks_small_fill(const ogl_graph_t* g, const int64_t* head_host_mapped, int64_t* head_dev, int B, int fanout,
                                             uint64_t seed, int64_t* src1, int32_t* lidx1, int64_t* src0, int32_t* lidx0, int64_t* counts,
                                             int64_t* seq_dev, int64_t* counts_host_mapped, void* workspace, int64_t workspace_bytes,
-                                            int64_t src0_fill_multiple, ogl_stream_t stream);
-
-extern "C" int ogl_sample_blocks_small(const ogl_graph_t* g, const int64_t* head_host_mapped, int64_t* head_dev, int B, int fanout,
-                                       uint64_t seed, int64_t* src1, int32_t* lidx1, int64_t* src0, int32_t* lidx0, int64_t* counts,
-                                       int64_t* seq_dev, int64_t* counts_host_mapped, void* workspace, int64_t workspace_bytes,
-                                       ogl_stream_t stream) {
-  return ogl_sample_blocks_small_fill(g, head_host_mapped, head_dev, B, fanout, seed, src1, lidx1, src0, lidx0, counts, seq_dev,
-                                      counts_host_mapped, workspace, workspace_bytes, 0, stream);
-}
-
-extern "C" int ogl_sample_blocks_small_fill(const ogl_graph_t* g, const int64_t* head_host_mapped, int64_t* head_dev, int B, int fanout,
-                                            uint64_t seed, int64_t* src1, int32_t* lidx1, int64_t* src0, int32_t* lidx0, int64_t* counts,
-                                            int64_t* seq_dev, int64_t* counts_host_mapped, void* workspace, int64_t workspace_bytes,
                                             int64_t src0_fill_multiple, ogl_stream_t stream) {
   if (!g || B <= 0 || fanout <= 0 || B > 1023 || src0_fill_multiple < 0) return OGL_EINVAL;
   const int64_t need = ogl_sample_blocks_small_workspace_bytes(B, fanout);

@@ -751,7 +751,9 @@ __global__ void __launch_bounds__(768) k_gemm_x3p(X3Args g) {
     // across the barrier, its MFMAs fill the pipe while the partner's fragments arrive, and the wave requests its own A fragments
     // row block by row block as those MFMAs release the registers.  Every accumulator still sees its steps in order: same bits.
     constexpr bool STAG_OK = (CB % 2) == 0;                   // (the deferred block reads ring slot 1; slot 0 takes the new step's first block)
-    const bool late = STAG_OK && g.stagger && wid >= 4;
+    const bool late = STAG_OK && (g.stagger & 1) && wid >= 4;
+    // (A/B, g.stagger & 2: a static issue priority for the second-dispatched half — MI355X_MICROARCH.md, "Two waves per SIMD" item 4)
+    if ((g.stagger & 2) && wid >= 4) __builtin_amdgcn_s_setprio(1);
     bf16x8 a[RB][3], b[2][3];
 #pragma unroll
     for (int t = 0; t < RB; ++t)
@@ -1160,11 +1162,6 @@ __global__ void __launch_bounds__(256) k_x3_split_t(const float* __restrict__ sr
   }
 }
 
-extern "C" int64_t ogl_x3_row_bytes(int64_t K) {
-  if (K < 0) return OGL_EINVAL;
-  return ogl_cdiv(K, 32) * X3_GROUP_BYTES;
-}
-
 extern "C" int64_t ogl_x3_image_bytes(int64_t rows, int64_t K) {
   if (rows < 0 || K < 0) return OGL_EINVAL;
   return (rows + 1) * ogl_cdiv(K, 32) * X3_GROUP_BYTES;
@@ -1437,8 +1434,6 @@ extern "C" int ogl_x3_debug_tile(int cfg) {
 
 // Which instantiation the LAST launch_x3 call ran (template arguments as written at the launch site; trailing defaults omitted):
 // bench.py compares it with the kernel name of the committed PMC pass before quoting that pass's traffic beside a launch it timed.
-static int g_x3_early_a = -1;            // -1: OGL_X3_EARLY_A (default on); 0 / 1: pinned (tests, A/B runs)
-extern "C" int ogl_x3_debug_early_a(int on) { const int old = g_x3_early_a; g_x3_early_a = on; return old; }
 static int g_x3_stagger = -1;            // -1: OGL_X3_STAGGER; 0 / 1: pinned (tests, A/B runs)
 extern "C" int ogl_x3_debug_stagger(int on) { const int old = g_x3_stagger; g_x3_stagger = on; return old; }
 static const char* g_x3_last_kernel = "";
@@ -1496,22 +1491,23 @@ static int launch_x3(X3Args& g, hipStream_t stream) {
     dim3 grid((unsigned)(8 * std::min<int64_t>(32, ogl_cdiv(T, 8)))), block(768);
     // staggered multiplier waves (see k_gemm_x3p) unless switched off
     static const char* stag_env = getenv("OGL_X3_STAGGER");
-    g.stagger = g_x3_stagger >= 0 ? g_x3_stagger : ((stag_env && stag_env[0] == '0') ? 0 : 1);
+    // (3 = staggered + a static issue priority for waves 4-7: 0.9300-0.9366 / 0.9203-0.9259 / 0.9202-0.9219 ms per step at 0 / 1 / 3, one
+    // box, three alternations — profiles/r06_ab_stagger.txt)
+    g.stagger = g_x3_stagger >= 0 ? g_x3_stagger : (stag_env ? atoi(stag_env) : 3);
     // ring depth: two stages of the 256 x 128 tile fill the LDS (144 KB); the 128 x 128 tile takes three (144 KB): its movers
     // run two stages ahead (+4 % on the layer-0 weight gradient, whose operands both stream from HBM)
-    // the two-stage tiles (256 x 128, 192 x 128) in their early-A form (template parameter EA) unless switched off
-    static const char* ea_env = getenv("OGL_X3_EARLY_A");
-    const bool ea = g_x3_early_a >= 0 ? g_x3_early_a != 0 : !(ea_env && ea_env[0] == '0');
+    // the two-stage tiles (256 x 128, 192 x 128) run in their early-A form (template parameter EA; the one-barrier form of the same
+    // tiles — the same bits, 2.7 % slower per step, round 4 — left the library in round 6)
     if (bk && g.ak_groups > 0) X3P_LAUNCH(2, 4, 2, 1, 3, false, true, true);
-    else if (bk && cfg == 0) { if (ea) X3P_LAUNCH(4, 2, 2, 2, 2, false, true, false, true); else X3P_LAUNCH(4, 2, 2, 2, 2, false, true); }
+    else if (bk && cfg == 0) X3P_LAUNCH(4, 2, 2, 2, 2, false, true, false, true);
     else if (bk) X3P_LAUNCH(2, 4, 2, 1, 3, false, true);
     else if (ext) {
       if (g.nsplit != 1 || g.ones_col) return OGL_EINVAL;
-      if (cfg == 0) { if (ea) X3P_LAUNCH(4, 2, 2, 2, 2, true, false, false, true); else X3P_LAUNCH(4, 2, 2, 2, 2, true); }
-      else if (cfg == 2) { if (ea) X3P_LAUNCH(2, 4, 3, 1, 2, true, false, false, true); else X3P_LAUNCH(2, 4, 3, 1, 2, true); }
+      if (cfg == 0) X3P_LAUNCH(4, 2, 2, 2, 2, true, false, false, true);
+      else if (cfg == 2) X3P_LAUNCH(2, 4, 3, 1, 2, true, false, false, true);
       else X3P_LAUNCH(2, 4, 2, 1, 3, true);
-    } else if (cfg == 0) { if (ea) X3P_LAUNCH(4, 2, 2, 2, 2, false, false, false, true); else X3P_LAUNCH(4, 2, 2, 2, 2); }
-    else if (cfg == 2) { if (ea) X3P_LAUNCH(2, 4, 3, 1, 2, false, false, false, true); else X3P_LAUNCH(2, 4, 3, 1, 2); }
+    } else if (cfg == 0) X3P_LAUNCH(4, 2, 2, 2, 2, false, false, false, true);
+    else if (cfg == 2) X3P_LAUNCH(2, 4, 3, 1, 2, false, false, false, true);
     else X3P_LAUNCH(2, 4, 2, 1, 3);
     OGL_CHECK_LAUNCH();
   } else {

@@ -109,16 +109,6 @@ __global__ void __launch_bounds__(1024) k_ce_fwd_bwd_mean(const float* __restric
   }
 }
 
-extern "C" int ogl_ce_fwd_bwd_mean(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C, float grad_scale,
-                                   float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean, ogl_stream_t stream) {
-  if (B <= 0 || B > CE_SMALL_MAX_B || C <= 0 || ldl < C || (dlogits && lddl < C)) return OGL_EINVAL;
-  if (!logits || !labels || !loss_mean) return OGL_EINVAL;
-  hipLaunchKernelGGL(k_ce_fwd_bwd_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ldl, labels, (int)B, C, grad_scale,
-                     loss_rows, dlogits, lddl, loss_mean, (const int64_t*)nullptr, (int64_t)0, (float4*)nullptr, 0);
-  OGL_CHECK_LAUNCH();
-  return OGL_OK;
-}
-
 // The same with the label gather inside the launch (label of row i = label_table[label_ids[i]]; label_ids null: label_table IS the
 // label vector) and an optional zero fill of a SMALL caller buffer (zero_floats <= 65 536: the one workgroup clears it; the atomic-
 // scatter target of the backward pass that follows) — on the 32-seed rungs each of those was a ~5 us launch of a ~0.2 ms step.
@@ -431,45 +421,6 @@ __global__ void __launch_bounds__(256) k_adam_multi_slabs(AdamBatch b, AdamSlabs
     adam_range(b.p[t], b.g[t], b.m[t], b.v[t], b.n[t], one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
 }
 
-__global__ void __launch_bounds__(256) k_adam_multi(AdamBatch b, float one_minus_b1, float b2, float one_minus_b2,
-                                                    float inv_sqrt_bc2, float step_size, float eps) {
-  const int t = blockIdx.y;
-  float* __restrict__ p = b.p[t];
-  const float* __restrict__ g = b.g[t];
-  float* __restrict__ m = b.m[t];
-  float* __restrict__ v = b.v[t];
-  const int64_t n = b.n[t];
-  adam_range(p, g, m, v, n, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
-}
-
-extern "C" int ogl_adam_step_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
-                                   const int64_t* n, int step, double lr, double beta1, double beta2, double eps,
-                                   ogl_stream_t stream) {
-  if (count < 0 || step < 1) return OGL_EINVAL;
-  if (count == 0) return OGL_OK;
-  if (!p || !g || !m || !v || !n) return OGL_EINVAL;
-  const double bc1 = 1.0 - pow(beta1, step);
-  const double bc2 = 1.0 - pow(beta2, step);
-  const float step_size = (float)(lr / bc1);
-  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-  for (int base = 0; base < count; base += OGL_ADAM_MAX_TENSORS) {
-    AdamBatch b;
-    const int c = min(OGL_ADAM_MAX_TENSORS, count - base);
-    int64_t nmax = 0;
-    for (int i = 0; i < c; ++i) {
-      if (n[base + i] < 0 || (n[base + i] > 0 && (!p[base + i] || !g[base + i] || !m[base + i] || !v[base + i]))) return OGL_EINVAL;
-      b.p[i] = p[base + i]; b.g[i] = g[base + i]; b.m[i] = m[base + i]; b.v[i] = v[base + i]; b.n[i] = n[base + i];
-      nmax = n[base + i] > nmax ? n[base + i] : nmax;
-    }
-    if (nmax == 0) continue;
-    dim3 grid((unsigned)min((int64_t)512, ogl_cdiv(nmax, 1024)), (unsigned)c);
-    hipLaunchKernelGGL(k_adam_multi, grid, dim3(256), 0, (hipStream_t)stream, b, (float)(1.0 - beta1), (float)beta2,
-                       (float)(1.0 - beta2), inv_sqrt_bc2, step_size, (float)eps);
-    OGL_CHECK_LAUNCH();
-  }
-  return OGL_OK;
-}
-
 // ---- Adam with a DEVICE-side step count: replayable inside a captured hipGraph -------------------------------------------
 // (a host-side step would freeze the bias corrections into the graph's kernel arguments).  k_adam_prepare increments the
 // counter and writes {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)} in double arithmetic, rounded to fp32 once, like the host path.
@@ -478,44 +429,6 @@ __global__ void k_adam_prepare(int64_t* step, double lr, double beta1, double be
   *step = t;
   scal[0] = (float)(lr / (1.0 - pow(beta1, (double)t)));
   scal[1] = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)t)));
-}
-
-__global__ void __launch_bounds__(256) k_adam_multi_dev(AdamBatch b, float one_minus_b1, float b2, float one_minus_b2,
-                                                        const float* __restrict__ scal, float eps) {
-  const float step_size = scal[0], inv_sqrt_bc2 = scal[1];
-  const int t = blockIdx.y;
-  float* __restrict__ p = b.p[t];
-  const float* __restrict__ g = b.g[t];
-  float* __restrict__ m = b.m[t];
-  float* __restrict__ v = b.v[t];
-  const int64_t n = b.n[t];
-  adam_range(p, g, m, v, n, one_minus_b1, b2, one_minus_b2, inv_sqrt_bc2, step_size, eps);
-}
-
-extern "C" int ogl_adam_step_multi_dev(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
-                                       const int64_t* n, int64_t* step_dev, float* scalars_dev, double lr, double beta1,
-                                       double beta2, double eps, ogl_stream_t stream) {
-  if (count < 0) return OGL_EINVAL;
-  if (!step_dev || !scalars_dev) return OGL_EINVAL;
-  if (count > 0 && (!p || !g || !m || !v || !n)) return OGL_EINVAL;
-  hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, lr, beta1, beta2, scalars_dev);
-  OGL_CHECK_LAUNCH();
-  for (int base = 0; base < count; base += OGL_ADAM_MAX_TENSORS) {
-    AdamBatch b;
-    const int c = min(OGL_ADAM_MAX_TENSORS, count - base);
-    int64_t nmax = 0;
-    for (int i = 0; i < c; ++i) {
-      if (n[base + i] < 0 || (n[base + i] > 0 && (!p[base + i] || !g[base + i] || !m[base + i] || !v[base + i]))) return OGL_EINVAL;
-      b.p[i] = p[base + i]; b.g[i] = g[base + i]; b.m[i] = m[base + i]; b.v[i] = v[base + i]; b.n[i] = n[base + i];
-      nmax = n[base + i] > nmax ? n[base + i] : nmax;
-    }
-    if (nmax == 0) continue;
-    dim3 grid((unsigned)min((int64_t)512, ogl_cdiv(nmax, 1024)), (unsigned)c);
-    hipLaunchKernelGGL(k_adam_multi_dev, grid, dim3(256), 0, (hipStream_t)stream, b, (float)(1.0 - beta1), (float)beta2,
-                       (float)(1.0 - beta2), (const float*)scalars_dev, (float)eps);
-    OGL_CHECK_LAUNCH();
-  }
-  return OGL_OK;
 }
 
 // Adam over tensors some of whose gradients still are split-K slabs (AdamSlabs; all-null slab pointers: plain Adam).
@@ -572,18 +485,10 @@ static int adam_step_multi_slabs(int count, float* const* p, float* const* g, fl
   return OGL_OK;
 }
 
-extern "C" int ogl_adam_step_multi_slabs(int count, float* const* p, float* const* g, float* const* m, float* const* v, const int64_t* n,
-                                         const float* const* ws, const int64_t* slab_stride, const int* ws_ld, const int* nsplit,
-                                         const int* ncols, const int* col0, int step, int64_t* step_dev, float* scalars_dev,
-                                         int prepare, double lr, double beta1, double beta2, double eps, ogl_stream_t stream) {
-  return adam_step_multi_slabs(count, p, g, m, v, n, ws, slab_stride, ws_ld, nsplit, ncols, col0, nullptr, nullptr, step, step_dev,
-                               scalars_dev, prepare, lr, beta1, beta2, eps, stream);
-}
-
-// ... with TWO-RANGE tensors: tensor i with split[i] > 0 has its columns [0, split) at slab column col0[i] and its columns
+// TWO-RANGE tensors (split / col0b, both nullable): tensor i with split[i] > 0 has its columns [0, split) at slab column col0[i] and its columns
 // [split, ncols) at slab column col0b[i] — the concat weight [N, K1 + K2] of the in-repo layer behind
 // ogl_linear_bwd_weight_x3k_dual_slabs (slab layout [dw1 | db | pad | dw2]): no reduction launch between the product and the optimiser
-extern "C" int ogl_adam_step_multi_slabs2(int count, float* const* p, float* const* g, float* const* m, float* const* v, const int64_t* n,
+extern "C" int ogl_adam_step_multi_slabs(int count, float* const* p, float* const* g, float* const* m, float* const* v, const int64_t* n,
                                           const float* const* ws, const int64_t* slab_stride, const int* ws_ld, const int* nsplit,
                                           const int* ncols, const int* col0, const int* split, const int* col0b, int step,
                                           int64_t* step_dev, float* scalars_dev, int prepare, double lr, double beta1, double beta2,

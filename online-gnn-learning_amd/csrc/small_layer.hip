@@ -1157,35 +1157,3 @@ extern "C" int ogl_record_weight_grads(const ogl_rec_seg_t* segs, int nseg, cons
   return OGL_OK;
 }
 
-// G [n_dst, F] = the masked dneigh (NULL with dWp: no fc_pool segment); dy [n_dst, H]; dWp [F, F], dWs / dWn [H, F] (each nullable, with its
-// bias gradient dbp [F] / dbs, dbn [H]: the same sum written twice, one tensor per parameter); table rows X[ids[.]] (ids NULL: the row
-// index itself); neigh [n_dst, F].  Rows are read as float4: ldt, ldn multiples of 4, 16-byte aligned bases.
-extern "C" int ogl_small_first_layer_dw(const float* G, int64_t ldg, const int32_t* argmax, const float* dy, int64_t lddy, int64_t n_dst, int F,
-                                        int H, const float* table, int64_t ldt, const int64_t* ids, int64_t n_table, int64_t n_src,
-                                        const float* neigh, int64_t ldn, float* dWp, int64_t lddwp, float* dbp, float* dWs, int64_t lddws,
-                                        float* dbs, float* dWn, int64_t lddwn, float* dbn, ogl_stream_t stream) {
-  if (n_dst <= 0 || n_dst > SFD_MAX_DST || F < 16 || F > 1024 || H <= 0 || H > 64 || n_table <= 0 || n_src <= 0 || n_src >= (1 << 30))
-    return OGL_EINVAL;
-  if (!table || (!dWp && !dWs && !dWn)) return OGL_EINVAL;
-  if (dWp && (!G || !argmax)) return OGL_EINVAL;
-  if ((dWs || dWn) && !dy) return OGL_EINVAL;
-  if (dWn && !neigh) return OGL_EINVAL;
-  ogl_rec_seg_t segs[3];
-  int n = 0;
-  auto add = [&](const float* g, int64_t ld, const int32_t* arg, int64_t n_idx, const int64_t* idp, const float* rows, int64_t ldr,
-                 int64_t n_rows, float* dW, int64_t lddw, float* db, float* db2, int count) {
-    ogl_rec_seg_t& s = segs[n++];
-    s.G = g; s.ldg = ld; s.arg = arg; s.ldarg = F; s.n_idx = n_idx; s.ids = idp; s.rows = rows; s.ldr = ldr; s.n_rows = n_rows; s.F = F;
-    s.n_dst = n_dst; s.n_out = count; s.dW = dW; s.lddw = lddw; s.db = db; s.db2 = db2; s.n_live = nullptr;
-  };
-  if (dWp) add(G, ldg, argmax, n_src, ids, table, ldt, n_table, dWp, lddwp, dbp, nullptr, F);
-  if (dWs) add(dy, lddy, nullptr, 0, ids, table, ldt, n_table, dWs, lddws, dbs, dWn ? nullptr : dbn, H);
-  if (dWn) add(dy, lddy, nullptr, 0, nullptr, neigh, ldn, n_dst, dWn, lddwn, dbn, dWs ? nullptr : dbs, H);
-  return ogl_record_weight_grads(segs, n, nullptr, 0, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, stream);
-}
-
-// workspace (floats): forward n_src * Hin (the projected rows), backward n_dst * Hin (the routed gradient)
-extern "C" int64_t ogl_small_pool_layer_workspace_floats(int64_t n_src, int64_t n_dst, int Hin) {
-  if (n_src < 0 || n_dst < 0 || Hin < 0) return OGL_EINVAL;
-  return n_src * Hin;
-}

@@ -1690,31 +1690,14 @@ def adam_step(p, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
 
 def adam_step_multi(ps, gs, ms, vs, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
     """One launch for every parameter tensor (same step count for all)."""
-    invalidate_weight_images()      # parameters change under raw pointers: no version bump to key on
-    k = len(ps)
-    for p, g, m, v in zip(ps, gs, ms, vs):
-        for t in (p, g, m, v):
-            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
-    arr = lambda ts: (C.c_void_p * k)(*[t.data_ptr() for t in ts])
-    n = (C.c_int64 * k)(*[p.numel() for p in ps])
-    _launch("ogl_adam_step_multi", _lib.lib().ogl_adam_step_multi, k, arr(ps), arr(gs), arr(ms), arr(vs), n, int(step),
-            C.c_double(lr), C.c_double(beta1), C.c_double(beta2), C.c_double(eps), _stream(), meta=dict(n=sum(p.numel() for p in ps)))
+    adam_step_multi_slabs(ps, gs, ms, vs, [None] * len(ps), step=step, lr=lr, beta1=beta1, beta2=beta2, eps=eps)
 
 
 def adam_step_multi_dev(ps, gs, ms, vs, step_dev, scalars_dev, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
     """adam_step_multi with the step count in device memory (``step_dev`` int64[1], incremented by the call on the device;
     ``scalars_dev`` float32[2] scratch): capturable in a hipGraph."""
-    invalidate_weight_images()      # parameters change under raw pointers: no version bump to key on
-    k = len(ps)
-    for p, g, m, v in zip(ps, gs, ms, vs):
-        for t in (p, g, m, v):
-            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
-    assert step_dev.dtype == torch.int64 and step_dev.is_cuda and scalars_dev.dtype == torch.float32 and scalars_dev.numel() >= 2
-    arr = lambda ts: (C.c_void_p * k)(*[t.data_ptr() for t in ts])
-    n = (C.c_int64 * k)(*[p.numel() for p in ps])
-    _launch("ogl_adam_step_multi_dev", _lib.lib().ogl_adam_step_multi_dev, k, arr(ps), arr(gs), arr(ms), arr(vs), n, _ptr(step_dev),
-            _ptr(scalars_dev), C.c_double(lr), C.c_double(beta1), C.c_double(beta2), C.c_double(eps), _stream(),
-            meta=dict(n=sum(p.numel() for p in ps)))
+    adam_step_multi_slabs(ps, gs, ms, vs, [None] * len(ps), step_dev=step_dev, scalars_dev=scalars_dev, prepare=True, lr=lr, beta1=beta1,
+                          beta2=beta2, eps=eps)
 
 
 def adam_step_multi_slabs(ps, gs, ms, vs, slabs, step=0, step_dev=None, scalars_dev=None, prepare=True, lr=1e-3, beta1=0.9, beta2=0.999,
@@ -1736,7 +1719,7 @@ def adam_step_multi_slabs(ps, gs, ms, vs, slabs, step=0, step_dev=None, scalars_
     i32 = lambda f: (C.c_int * k)(*[(getattr(sg, f) if sg is not None else 0) for sg in slabs])
     if _SIDE["active"]:
         _SIDE["keep"].extend(sg.ws for sg in slabs if sg is not None)       # (read on the side stream: held until the join)
-    _launch("ogl_adam_step_multi_slabs", _lib.lib().ogl_adam_step_multi_slabs2, k, arr(ps), arr(gs), arr(ms), arr(vs), n, ws, stride,
+    _launch("ogl_adam_step_multi_slabs", _lib.lib().ogl_adam_step_multi_slabs, k, arr(ps), arr(gs), arr(ms), arr(vs), n, ws, stride,
             i32("ws_ld"), i32("nsplit"), i32("ncols"), i32("col0"), i32("split"), i32("col0b"), int(step), _ptr(step_dev), _ptr(scalars_dev),
             1 if prepare else 0,
             C.c_double(lr), C.c_double(beta1), C.c_double(beta2), C.c_double(eps), _stream(),

@@ -532,40 +532,3 @@ def test_lstm_aggregator_model_matches_oracle():
     for name, p in model.named_parameters():
         l, key = int(name.split(".")[1]), name.split(".", 2)[2]
         np.testing.assert_allclose(p.grad.cpu().numpy(), params[l][key].grad.numpy(), rtol=1e-3, atol=2e-6, err_msg=name)
-
-
-def test_early_a_tiles_compute_the_same_bits():
-    """The two-stage image-GEMM tiles with and without the second barrier per step (k_gemm_x3p<..., EA>: the A part of a stage buffer
-    handed back to the movers early) run the same MFMAs on the same operands in the same order: forward (256- and 192-row tiles),
-    the two-part / addend form, and the wide k-major weight gradient — bit for bit."""
-    import ogl_amd  # noqa: F401
-    from ogl_amd import _lib, ops
-    ops.set_gemm_mode("auto")
-    was = _lib.lib().ogl_x3_debug_early_a(-1)
-    try:
-        torch.manual_seed(11)
-        dev = "cuda"
-        outs = {}
-        x_big = ops.empty_mat(40000, 602, dev).copy_(torch.randn(40000, 602, device=dev))
-        x_mid = ops.empty_mat(7061, 600, dev).copy_(torch.randn(7061, 600, device=dev))
-        w = torch.randn(600, 602, device=dev) / 25; b = torch.randn(600, device=dev)
-        w2 = torch.randn(600, 600, device=dev) / 25
-        xi_big, xi_mid = ops.x3_split(x_big, append_ones=True), ops.x3_split(x_mid, append_ones=True)
-        wi, w2i = ops.x3_split(w, append_vec=b), ops.x3_split(w2, append_vec=b)
-        rows = torch.randint(0, 40000, (30000,), device=dev)
-        dy = ops.empty_mat(30000, 600, dev).copy_(torch.randn(30000, 600, device=dev))
-        G = (30000 + 31) // 32
-        dyT = ops.x3_split_t(dy, interleave=G)
-        for ea in (0, 1):
-            _lib.lib().ogl_x3_debug_early_a(ea)
-            got = [ops.linear_fwd_x3(xi_big, None, wi, relu=True),                                  # 256 x 128 tiles, several rounds
-                   ops.linear_fwd_x3(xi_mid, None, w2i, relu=False),                                # 192 x 128 tiles, one round
-                   ops.linear_bwd_weight_x3k(dyT, xi_big, 30000, 602, x_rows=rows, x_nrows=40000, interleave=G, want_bias=True)[0]]
-            names = [_lib.lib().ogl_x3_last_kernel().decode()]
-            outs[ea] = (got, names)
-        assert outs[0][1] != outs[1][1], outs[0][1]                     # (two different instantiations really ran)
-        for a, c in zip(outs[0][0], outs[1][0]):
-            assert torch.equal(a, c)
-    finally:
-        _lib.lib().ogl_x3_debug_early_a(was)
-        ops.set_gemm_mode("f32")

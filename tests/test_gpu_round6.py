@@ -14,12 +14,12 @@ def test_staggered_multiplier_waves_compute_the_same_bits():
     against every wave opening a step on its fragment loads: the same MFMAs on the same operands, every accumulator in the same
     order — bit for bit on every instantiation the train step and the inference passes launch (256 / 192 / 128-row tiles, early-A
     and one-barrier forms, the two-part / addend / image-writing form, the k-major weight gradients incl. the dual product), on
-    ragged shapes, one-step and two-step reductions, several tiles per block."""
+    ragged shapes, one-step and two-step reductions, several tiles per block (stagger 3 = staggered + a static issue priority for waves 4-7)."""
     import ogl_amd  # noqa: F401
     from ogl_amd import _lib, ops
     ops.set_gemm_mode("auto")
     lib = _lib.lib()
-    was, was_ea = lib.ogl_x3_debug_stagger(-1), lib.ogl_x3_debug_early_a(-1)
+    was = lib.ogl_x3_debug_stagger(-1)
     try:
         torch.manual_seed(21)
         dev = "cuda"
@@ -44,9 +44,8 @@ def test_staggered_multiplier_waves_compute_the_same_bits():
         x2_img = ops.x3_split(x2)
         add = ops.empty_mat(40000, 600, dev).copy_(torch.randn(40000, 600, device=dev))
         outs = {}
-        for ea in (1, 0):
-            lib.ogl_x3_debug_early_a(ea)
-            for stag in (0, 1):
+        for ea in (1,):
+            for stag in (0, 3):
                 lib.ogl_x3_debug_stagger(stag)
                 got, names = [], []
 
@@ -69,8 +68,8 @@ def test_staggered_multiplier_waves_compute_the_same_bits():
                     # (the columns the product writes: [dw1 | db] and dw2 — the padding between them is never written)
                     take([slabs[:, :, :603].clone(), slabs[:, :, col2:col2 + 600].clone()])
                 outs[(ea, stag)] = (got, names)
-        for ea in (1, 0):
-            (g0, n0), (g1, n1) = outs[(ea, 0)], outs[(ea, 1)]
+        for ea in (1,):
+            (g0, n0), (g1, n1) = outs[(ea, 0)], outs[(ea, 3)]
             assert n0 == n1                                                   # (the same instantiations, with and without the stagger)
             for i, (a, c) in enumerate(zip(g0, g1)):
                 if a is None:
@@ -79,7 +78,6 @@ def test_staggered_multiplier_waves_compute_the_same_bits():
         assert len(set(outs[(1, 0)][1])) >= 5, outs[(1, 0)][1]                 # (at least five different instantiations ran)
     finally:
         lib.ogl_x3_debug_stagger(was)
-        lib.ogl_x3_debug_early_a(was_ea)
         ops.set_gemm_mode("f32")
 
 
@@ -324,10 +322,35 @@ def test_size_agnostic_first_layer_ignores_what_lies_behind_the_live_sources():
 # Exported entry points that the default train / inference paths of the BASELINE configurations do not call, each with its reason to be
 # in the library.  Everything else in include/ogl_hip.h must be reached by test_every_exported_symbol_is_reached_or_allow_listed.
 ALLOW_UNREACHED = {
-    # identification / errors / diagnostics (never on a hot path)
+    # identification / errors / diagnostics / measurement (never on a hot path)
     "ogl_version", "ogl_source_hash", "ogl_status_string", "ogl_last_hip_error", "ogl_set_gemm_mode", "ogl_get_gemm_mode",
-    "ogl_x3_debug_stamps", "ogl_x3_debug_early_a", "ogl_x3_debug_stagger", "ogl_x3_debug_tile", "ogl_x3_last_kernel",
+    "ogl_x3_debug_stamps", "ogl_x3_debug_stagger", "ogl_x3_debug_tile", "ogl_x3_last_kernel",
     "ogl_block_debug_min_lds", "ogl_reduce_debug_half", "ogl_stream_copy", "ogl_graph_degrees", "ogl_graph_copy_degrees",
+    # the per-batch C-ABI SURVEY.md section 8(b) names (one sampler call, one block build, one gather, one Adam tensor per call): what a
+    # reference-side binding calls batch by batch; the package's own loaders use the batched / captured forms of the same kernels
+    "ogl_sample_layer", "ogl_build_block", "ogl_block_workspace_bytes", "ogl_gather_rows", "ogl_adam_step",
+    # the multi-launch sample graph: batches past the one-launch sampler's limits (B > 1 023 or an upper-bound block of > 2^18 rows)
+    "ogl_sample_layer_dev", "ogl_build_block_padded", "ogl_publish_i64",
+    # loss launches of steps whose last layer is NOT fused with nn.CrossEntropyLoss (an arbitrary loss_fn, shapes past the fused
+    # kernels' limits, reduction='none' training): tests/test_gpu_kernels.py, test_gpu_round3.py, test_gpu_round4.py
+    "ogl_ce_fwd_bwd_mean_gather", "ogl_ce_fwd_bwd_mean_gather_adam", "ogl_ce_fwd_bwd_mean_grid", "ogl_ce_fwd_bwd_mean_grid_gather",
+    "ogl_loss_mean_finish", "ogl_out_layer_bwd_inputs",
+    # feat_drop > 0 (every settings file of the reference uses 0): tests/test_gpu_kernels.py
+    "ogl_dropout_rows",
+    # weight gradients of products between the direct kernel's and the image kernels' sizes, or without a row-major image of x
+    # (transposed operands): tests/test_gpu_x3.py, test_gpu_kernels.py
+    "ogl_linear_bwd_weight_t", "ogl_linear_bwd_weight_t_workspace_bytes", "ogl_transpose", "ogl_linear_bwd_weight_x3",
+    "ogl_linear_bwd_weight_x3_workspace_bytes", "ogl_x3_split_t", "ogl_x3_slab_reduce",
+    # the layer-0 pool backward without a plan (OGL_POOL_PLAN=0, or n_dst * d >= 2^27): tests/test_gpu_x3.py
+    "ogl_pool_bwd_x3",
+    # the inference layer over cached tables with a per-row addend outside the image kernel's sizes: tests/test_gpu_rungs.py
+    "ogl_linear_fwd_addrows",
+    # the one-workgroup 'pool' layer as a NON-last layer / in inference, and the last layer's own backward launch when its route is
+    # not taken (a backward the package does not own, gradients already in place, hooks): tests/test_gpu_small_layer.py, this file
+    "ogl_small_pool_layer_fwd", "ogl_small_pool_layer_bwd", "ogl_small_pool_layer_bwd_pool",
+    # TrendPriority / HybridPriority (the reference's other priority strategies) and the device-side proportional draw
+    # (draw_priority_train_nodes with more draws than train vertices): tests/test_gpu_replay.py
+    "ogl_priority_trend", "ogl_replay_sample",
 }
 
 
@@ -374,7 +397,8 @@ def test_every_exported_symbol_is_reached_or_allow_listed():
             for _ in range(start):
                 graph.evolve(); graph_test.evolve()
             gu = TrainTestGraph(graph, split=0.15, start_prior_alpha=4, end_prior_alpha=50, scale=1, max_priority=10)
-            gu._admit([int(v) for v in range(graph.get_graph().n_present) if v in graph.labelled_vertices])
+            present = np.asarray(gu.get_subgraph_to_original_map()[np.arange(graph.get_graph().n_present)]).reshape(-1)   # (original ids)
+            gu._admit([int(v) for v in present if int(v) in graph.labelled_vertices])
             mk = lambda: GraphSAGE(feat_size, hidden, n_classes, 1, act, 0, agg, edge_feats=0, pool_feats=hidden).cuda()   # noqa: E731
             kw = dict(cuda=True, batch_full=batch_full, n_workers=0)
             sts = []

@@ -221,8 +221,8 @@ def test_status_codes(ops):
     import ctypes as C
     from ogl_amd import _lib
     h = _lib.lib()
-    assert h.ogl_x3_row_bytes(602) == 19 * 192 and h.ogl_x3_image_bytes(10, 33) == 11 * 2 * 192
-    assert h.ogl_x3_row_bytes(-1) == -1
+    assert h.ogl_x3_image_bytes(1, 602) == 2 * 19 * 192 and h.ogl_x3_image_bytes(10, 33) == 11 * 2 * 192
+    assert h.ogl_x3_image_bytes(-1, 8) == -1
     x = torch.zeros(4, 8).cuda(); img = torch.zeros(4096, dtype=torch.uint8).cuda()
     p = lambda t: C.c_void_p(t.data_ptr())
     assert h.ogl_x3_split(p(x), 4, None, 0, 4, 8, 0, None, p(img), None) == -1   # ld < K
@@ -828,5 +828,5 @@ def test_status_codes_of_the_round2_entry_points(ops):
     assert h.ogl_out_layer_bwd_weights(p(x), 64, 64, 8, 64, p(x), 64, p(img), 0, p(x), 64, p(x), 64, p(x), 64, None, None, None) == -1
     # small cross entropy: one workgroup covers at most 1024 rows, and it needs the mean's address
     lab = torch.zeros(64, dtype=torch.int64).cuda()
-    assert h.ogl_ce_fwd_bwd_mean(p(x), 64, p(lab), 1025, 8, f(1.0), None, None, 0, p(x), None) == -1
-    assert h.ogl_ce_fwd_bwd_mean(p(x), 64, p(lab), 64, 8, f(1.0), None, None, 0, None, None) == -1
+    assert h.ogl_ce_fwd_bwd_mean_gather(p(x), 64, p(lab), 64, None, 1025, 8, f(1.0), None, None, 0, p(x), None, 0, None) == -1
+    assert h.ogl_ce_fwd_bwd_mean_gather(p(x), 64, p(lab), 64, None, 64, 8, f(1.0), None, None, 0, None, None, 0, None) == -1

@@ -13,6 +13,7 @@ part_A1() {
   for w in reddit_pbr_forward arxiv_pbr_forward arxiv_rbr pubmed_rbr pubmed_settings arxiv_settings bitcoin_settings reddit_settings reddit_settings_pbr_forward; do
     timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err < /dev/null
   done
+  timeout -k 10 300 python bench.py --workload arxiv_pbr_snapshot --steps 30 --warmup 8 > $O/bench_arxiv_pbr_snapshot.json 2> $O/bench_arxiv_pbr_snapshot.err < /dev/null
   # the in-repo aggregator modes at the Reddit rung (round 4: first-class workloads, mean backward as a planned segmented gather)
   for a in meanpool mean; do
     timeout -k 10 300 python bench.py --aggregator $a --no-cpu-baseline --no-e2e > $O/bench_reddit_rbr_$a.json 2> $O/bench_reddit_rbr_$a.err < /dev/null
@@ -21,29 +22,24 @@ part_A1() {
   timeout -k 10 600 python -m pytest tests/test_gpu_rungs.py tests/test_gpu_fullsize.py tests/test_gpu_round4.py -q -s -k "200_step or no_worse or inrepo_modes or two_part or fused_output_layer_step" > $O/parity_numbers.log 2>&1 < /dev/null || true
 }
 part_A2() {
-  # same-box A/B of the round's switches inside the replayed step (kept and dropped ones)
-  bash tools/ab_combo.sh r05 2 "OGL_X=0" "OGL_DUAL_DW=0" "OGL_OUT_FWD_BWD=1" "OGL_POOL_PLAN_FUSED=1" "OGL_X3_BD=6" "OGL_POOL_RF=1" "OGL_BWWK_BLOCKS=192" "OGL_SLAB_ADAM=0" "OGL_X3_EARLY_A=0" "OGL_X3_CFG3=1" "OGL_X3_CFG4=1" > $O/ab_r05.txt 2>&1 || true
-  # round 5: this tree against the round-4 tree on the same box (a git worktree under _r04/, when present)
-  [ -d _r04 ] && (bash tools/ab_r04.sh 3 > $O/ab_vs_r04.txt 2>&1; cp -r gpurun_out/ab_r04 $O/ab_vs_r04) || true
-  # round 5: the 32-seed rungs with the sampling phase as one launch / as eleven graph nodes, and their traced steps
+  # same-box A/B of the switches that are left, inside the replayed step
+  bash tools/ab_combo.sh r06 2 "OGL_X=0" "OGL_X3_STAGGER=0" "OGL_X3_STAGGER=1" "OGL_DUAL_DW=0" "OGL_SLAB_ADAM=0" "OGL_POOL_PLAN=0" "OGL_FORK_BWD=0" > $O/ab_r06.txt 2>&1 || true
+  cp -r gpurun_out/ab_r06 $O/ab_r06 2> /dev/null || true
+  # where a step of the layer-0 image GEMMs goes: per-phase cycle sums from the diagnostic build (tools/build_variant.py phase -DOGL_X3_PHASE_STAMPS),
+  # staggered and in lockstep; the in-kernel clock on random and on all-zero operands (the chip's power management, not the kernel)
+  (for st in 1 0; do echo "== OGL_X3_STAGGER=$st"; OGL_X3_STAGGER=$st timeout -k 10 150 python tools/x3_phase_probe.py 2>&1 | grep -v amdgpu.ids; done) > $O/x3_phase_probe.txt 2>&1 || true
+  (timeout -k 10 100 python tools/gemm_x3_bench.py clock; X3_ZERO=1 timeout -k 10 100 python tools/gemm_x3_bench.py clock) 2>&1 | grep -v amdgpu.ids > $O/x3_clock_probe.txt || true
+  # the 32-seed rungs' traced steps
   for w in pubmed_rbr arxiv_rbr; do
-    bash tools/ab_wl.sh OGL_SAMPLE_FUSED $w 3 > $O/ab_sample_fused_$w.txt 2>&1 || true
     bash tools/trace_wl.sh $w > /dev/null 2>&1 || true
     cp gpurun_out/trace_$w/timeline.txt $O/step_timeline_$w.txt 2> /dev/null || true
   done
-  # round 5: 'meanpool' with the ReLU mask as sign bits from the product's epilogue (off by default)
-  for i in 1 2 3; do for c in 0 1; do
-    OGL_POOL_MEAN_BITS=$c timeout -k 10 300 python bench.py --aggregator meanpool --no-cpu-baseline --no-e2e --steps 100 --warmup 20 > $O/ab_meanbits${c}_$i.json 2> /dev/null < /dev/null
-  done; done
-  # round 5: the record-fed layer-0 weight gradient against the round-4 pair, alone, with its timing-only ablations; micro-benchmarks
-  (for d in 0 1 2 4 6 7; do echo "== OGL_RF_DBG=$d (1: no B pieces, 2: no records, 4: no conversion; wrong results, timing only)"; OGL_RF_DBG=$d timeout -k 10 200 python tools/rf_probe.py 2>&1 | grep -v amdgpu.ids; done) > $O/rf_probe.txt 2>&1 || true
+  # the narrow-row max aggregator: two rows per wave-instruction against one (arxiv-like priority forward)
+  timeout -k 10 200 python tools/half_wave_probe.py > $O/half_wave_probe.txt 2>&1 || true
   (timeout -k 5 60 tools/micro/lds_atomics; timeout -k 5 60 tools/micro/grid_barrier; timeout -k 5 60 tools/micro/mfma_rate) > $O/micro.txt 2>&1 || true
   bash tools/pmc_waits.sh > /dev/null 2>&1 || true
   cp gpurun_out/pmc_waits.txt $O/pmc_waits.txt 2> /dev/null || true
-  # the loader phase (sampler + block build, hash / direct table / minima in LDS) and the layer-0 weight gradient block by block (even / uneven split-K)
-  timeout -k 10 200 python tools/block_build_probe.py > $O/block_build_probe.txt 2>&1 || true
-  (OGL_BWWK_UNEVEN=0 timeout -k 10 200 python tools/dw_pool0_probe.py; OGL_BWWK_UNEVEN=1 timeout -k 10 200 python tools/dw_pool0_probe.py; OGL_X3_EARLY_A=0 timeout -k 10 200 python tools/dw_pool0_probe.py) 2>&1 | grep -v amdgpu.ids > $O/dw_pool0_probe.txt || true
-  cp -r gpurun_out/ab_r05 $O/ab_r05 2> /dev/null || true
+  timeout -k 10 200 python tools/dw_pool0_probe.py 2>&1 | grep -v amdgpu.ids > $O/dw_pool0_probe.txt || true
 }
 part_B() {
   cd /tmp && export TMPDIR=/tmp
@@ -79,8 +75,7 @@ part_B() {
 }
 part_C() {
   timeout -k 10 300 python bench.py --force-dist --steps 100 --warmup 10 --no-cpu-baseline --no-e2e > $O/bench_force_dist.json 2> $O/bench_force_dist.err < /dev/null
-  timeout -k 10 300 python bench.py --force-dist --dp-capture 1 --steps 100 --warmup 10 --no-cpu-baseline --no-e2e > $O/bench_force_dist_captured.json 2> /dev/null < /dev/null
-  timeout -k 10 300 python bench.py --force-dist --no-graphs --steps 100 --warmup 10 --no-cpu-baseline --no-e2e > $O/bench_force_dist_eager.json 2> /dev/null < /dev/null
+  timeout -k 10 300 python bench.py --force-dist --no-graphs --no-variants --steps 100 --warmup 10 --no-cpu-baseline --no-e2e > $O/bench_force_dist_eager.json 2> /dev/null < /dev/null
   timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_2rank_gloo.json 2> /dev/null < /dev/null
   timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --steps 20 --warmup 2 --workload reddit_pbr_forward --partition features > $O/bench_2rank_gloo_pbr_partitioned.json 2> /dev/null < /dev/null
   timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --steps 50 --warmup 5 --scaling strong --no-cpu-baseline > $O/bench_2rank_gloo_strong.json 2> /dev/null < /dev/null
