@@ -41,8 +41,8 @@ def norm_kernel(name):
     if not m:
         return None
     a = [x.strip() for x in m.group(2).split(",")]
-    if m.group(1) == "k_gemm_x3p" and 5 <= len(a) < 11:
-        a += ["false", "false", "false", "0", "0", "false"][len(a) - 5:]  # EXT, BK, AK, RH, CH, EA (csrc/linear_x3.hip)
+    if m.group(1) == "k_gemm_x3p" and 5 <= len(a) < 9:
+        a += ["false", "false", "false", "false"][len(a) - 5:]  # EXT, BK, AK, EA (csrc/linear_x3.hip; rounds 3-5 also had RH, CH)
     return (m.group(1),) + tuple(a)
 
 
@@ -107,6 +107,8 @@ def parse():
                          "parameters -> all-gather of the weights (parallel.ShardedAdam: the late-exchange lever of DESIGN section 6), "
                          "0 = all-reduce + the identical Adam on every rank (the default)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end snapshot leg (metric iii) of the default line")
+    ap.add_argument("--reduce-half", type=int, default=None, choices=[0, 1],
+                    help="A/B: pin the narrow-row max aggregator to one (0) / two (1) neighbour rows per wave-instruction (ogl_reduce_debug_half)")
     ap.add_argument("--no-variants", action="store_true",
                     help="N > 1 / --force-dist: skip the other two forms of the gradient exchange (`collectives_variants`) after the headline")
     ap.add_argument("--e2e-snapshots", type=int, default=6)
@@ -202,6 +204,9 @@ def main():
     if args.dp_sharded_update is not None:
         parallel.SHARDED_UPDATE = bool(args.dp_sharded_update)
     ops.set_gemm_mode(args.gemm)
+    if args.reduce_half is not None:
+        from ogl_amd import _lib as _l0
+        _l0.lib().ogl_reduce_debug_half(args.reduce_half)
     wl = WORKLOADS[args.workload]
     B, S, H, bt = wl["batch"], wl["samples"], wl["hidden"], wl["batch_timestep"]
     if wl.get("snapshot"):
@@ -575,6 +580,11 @@ def main():
                          peak_note=("fp32-equivalent roof of the x6 arithmetic: dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per "
                                     "product (vs 157.3 TFLOP/s for the exact-fp32 MFMA)") if x6 else "dense fp32 MFMA peak",
                          all_gemms_tflops=round(gflops / gms / 1e9, 2) if gms else None)
+        if x6:
+            roof_gemm["power_note"] = ("the 2500 TFLOP/s peak is 1024 SIMDs x 1024 FLOP/clk at the 2.4 GHz maximum clock; under this kernel's load on random "
+                                       "operands the part holds 1.9-2.0 GHz (in-kernel s_memtime / s_memrealtime; the same binary on all-zero operands: "
+                                       "2.39 GHz and +14-17 % TFLOP/s) with the matrix pipe busy 70-72 % of the in-kernel cycles — "
+                                       "profiles/r06_x3_clock_probe.txt, r06_x3_phase_probe.txt, DESIGN.md section 0")
 
     # ---- the whole step against its COMPOSITE roofline: every GEMM at the MFMA roof of its arithmetic + every HBM-bound launch at the
     # HBM peak, summed (no overlap assumed between the two: the step's launches are dependent) — ms_per_step / this = how far the step

@@ -112,7 +112,8 @@ int ogl_gather_rows(const float* table, int64_t ld, int64_t n_rows, const int64_
  * ogl_out_layer_bwd_inputs) when no loss launch cleared their target on the side.  A kernel launch (capturable). */
 int ogl_fill_zero(void* ptr, int64_t bytes, ogl_stream_t stream);
 /* Measurement only (bench.py `hbm_copy_measured`; SURVEY.md section 8(d): "re-measure with a stream-copy microbench on the box"): dst[0 ..
- * bytes) = src[0 .. bytes) as a float4 grid-stride copy, four loads in flight per lane.  16-byte aligned, bytes a multiple of 16. */
+ * bytes) = src[0 .. bytes) as one float4 per thread (the fastest form on this part: tools/micro/stream_copy.hip).  16-byte aligned, bytes a
+ * multiple of 16. */
 int ogl_stream_copy(const void* src, void* dst, int64_t bytes, ogl_stream_t stream);
 /* diagnostic: 1 / 0 = the max aggregator WITHOUT argmax over rows of <= 128 floats (the inference passes over a narrow projection
  * table) reads two neighbour rows per wave-instruction (half a wave per row) / one; the same bits.  Returns the old value. */

@@ -559,22 +559,20 @@ extern "C" int ogl_fill_zero(void* ptr, int64_t bytes, ogl_stream_t stream) {
 }
 
 // ---- stream copy: the box's own streaming rate (measurement only: bench.py's `hbm_copy_measured`) ----
-// A float4 copy, four 16-byte loads in flight per lane, 2 048 blocks of 256 lanes: what MI355X_MICROARCH.md quotes as the achievable
-// HBM rate of this part (~6.3 TB/s of read + write bytes) — a torch copy_ of the same buffers reads 4.7 TB/s.
+// ONE float4 per thread, no loop: of the forms tools/micro/stream_copy.hip tries on 1 GiB -> 1 GiB (profiles/r06_stream_copy.txt) this is
+// the fastest — 6.17 TB/s of read + write bytes, what MI355X_MICROARCH.md quotes as achievable (6.29) — against 5.3-5.7 for a block-contiguous
+// loop, 4.1-5.2 for a grid-stride loop, 5.14 for hipMemcpyAsync and 4.7 for torch's copy_.
 __global__ void __launch_bounds__(256) k_stream_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < n16; i += 4 * stride) {
-    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-  }
-  for (; i < n16; i += stride) dst[i] = src[i];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
 }
 
 extern "C" int ogl_stream_copy(const void* src, void* dst, int64_t bytes, ogl_stream_t stream) {
   if (bytes < 0 || (bytes & 15) || (bytes > 0 && (!src || !dst)) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return OGL_EINVAL;
   if (bytes == 0) return OGL_OK;
-  hipLaunchKernelGGL(k_stream_copy, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, bytes / 16);
+  const int64_t n16 = bytes / 16;
+  if (ogl_cdiv(n16, 256) > 0x7FFFFFFFll) return OGL_EINVAL;
+  hipLaunchKernelGGL(k_stream_copy, dim3((unsigned)ogl_cdiv(n16, 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, n16);
   OGL_CHECK_LAUNCH();
   return OGL_OK;
 }

@@ -689,7 +689,9 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
     def choose_vertices(self, graph_util):
         if self.time_step % self.full_pass == 0:
             self.pass_var += 1
-            self.recompute_priorities(graph_util, graph_util.get_train_set())
+            # (the whole train set: as an array when the graph state keeps one — no 1e5-element list <-> array conversions)
+            self.recompute_priorities(graph_util, graph_util.get_train_array() if hasattr(graph_util, "get_train_array")
+                                      else graph_util.get_train_set())
         elif len(graph_util.get_new_train_nodes()) > 1:
             self.recompute_priorities(graph_util, graph_util.get_new_train_nodes())
         batch_nodes = []
@@ -739,10 +741,11 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
         self.graphsage_model.eval()
         id_to_subgraph = graph_util.get_original_to_subgraph_map()
         subgraph_to_id = graph_util.get_subgraph_to_original_map()
-        train_set = list(train_set)
-        if len(train_set) == 0:
+        train_arr = train_set if isinstance(train_set, np.ndarray) else np.asarray(list(train_set), dtype=np.int64)
+        if train_arr.size == 0:
             return
-        seeds_all = torch.as_tensor(np.asarray(id_to_subgraph[train_set]), dtype=torch.int64)
+        seeds_np = np.ascontiguousarray(np.asarray(id_to_subgraph[train_arr], dtype=np.int64).reshape(-1))
+        seeds_all = torch.from_numpy(seeds_np)
         graph = graph_util.get_graph()
         # N ranks: whole batches of the pass are block-partitioned over the ranks (seed order kept) and the per-seed losses
         # are all-gathered, so every replica of the replay buffer receives every priority (north star: "PBR sharded across
@@ -762,11 +765,11 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
                 _, _, a, b = parallel.batch_shard(seeds_all.numel(), self.batch_full, r, world)
                 counts.append(b - a)
             local = parallel.all_gather_counts(local, counts)
-        batch_nids_l = list(subgraph_to_id[seeds_all.numpy()])
+        ids = np.asarray(subgraph_to_id[seeds_np], dtype=np.int64).reshape(-1)
         if self._device_priorities(graph_util) and local.is_cuda:
-            ids = np.asarray(batch_nids_l)
             graph_util.update_priorities_device(ids, self._priorities_device(ids, local))      # losses -> priorities -> tree, all in HBM
             return
+        batch_nids_l = ids.tolist()
         unaggregated_loss = local.cpu().numpy()
         priorities = self._host_strategy().get_priorities(batch_nids_l, unaggregated_loss)
         graph_util.update_priorities_arrays(np.asarray(batch_nids_l), np.asarray(priorities, dtype=np.float64))

@@ -163,6 +163,12 @@ def test_train_test_graph_behaviour():
     g.evolve()
     assert len(g.get_train_set()) == 16 and g.prior_alpha == pytest.approx(4 + (46 / 6) * 1)
     assert len(g.get_new_train_nodes()) == 8 and len(g.get_new_train_nodes(3)) == 3
+    # the train set as an incrementally kept array (arrival order): the same members as the reference's list(set), every one once;
+    # the list itself is rebuilt on first use after an admission and is then ONE object until the next admission
+    arr = g.get_train_array()
+    assert arr.dtype == np.int64 and len(arr) == 16 and set(arr.tolist()) == set(g.get_train_set()) and not arr.flags.writeable
+    assert set(arr[8:].tolist()) == set(g.get_new_train_nodes())                  # (the latest arrivals at its end)
+    assert g.get_train_set() is g.get_train_set() and g.get_train_set() == list(g.train_set)
     # partial Fisher-Yates == full shuffle in distribution; exact_shuffle reproduces the reference's draws bit for bit
     g.exact_shuffle = True
     random.seed(5); ref_list = list(g.train_set_list); random.shuffle(ref_list)

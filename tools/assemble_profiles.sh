@@ -2,7 +2,7 @@
 # Copy what tools/collect_profiles.sh left under gpurun_out/prof_final into profiles/ under the round's names and derive the
 # traffic JSONs bench.py quotes.  Usage: bash tools/assemble_profiles.sh r03 2026-10-04
 set -e
-R=${1:-r05}; D=${2:-$(date +%F)}
+R=${1:-r06}; D=${2:-$(date +%F)}
 O=gpurun_out/prof_final; P=profiles; H=$(git rev-parse --short HEAD)
 cp $O/bench.json $P/${R}_bench_final.json
 cp $O/bench_eager.json $P/${R}_bench_eager.json
@@ -47,7 +47,7 @@ json.dump(dict(what="same box, alternating runs of `env <switches> python bench.
                     "(tools/ab_combo.sh): the round's switches against the default (OGL_X=0 is a no-op)", runs=runs),
           open('profiles/%s_ab_experiments.json' % R, 'w'), indent=1)
 PY
-for f in ab_vs_r04.txt rf_probe.txt micro.txt pmc_waits.txt step_timeline_pubmed_rbr.txt step_timeline_arxiv_rbr.txt ab_sample_fused_pubmed_rbr.txt ab_sample_fused_arxiv_rbr.txt; do
+for f in micro.txt pmc_waits.txt step_timeline_pubmed_rbr.txt step_timeline_arxiv_rbr.txt x3_phase_probe.txt x3_clock_probe.txt half_wave_probe.txt; do
   [ -f $O/$f ] && grep -v amdgpu.ids $O/$f > $P/${R}_$f || true
 done
 python - "$R" <<'PY' || true

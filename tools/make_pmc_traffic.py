@@ -59,15 +59,15 @@ def main():
     for arg in sys.argv[3:]:
         wl, path = arg.split("=", 1)
         rows = parse(path)
-        agg = first(rows, lambda r: r["name"].startswith("k_reduce_fwd_v4"), full_only=(wl != "rbr"))
+        agg = first(rows, lambda r: r["name"].startswith("k_reduce_fwd_v4") or r["name"].startswith("k_reduce_fwd_max_half"), full_only=(wl != "rbr"))
         if wl == "rbr":
             if agg:
                 out["k_reduce_fwd_v4_L0"] = entry(agg)
-            f = first(rows, lambda r: re.match(r"k_gemm_x3p<4, 2, 2, 2, 2, false, false, false(, 0, [01](, (true|false))?)?>", r["name"]))
+            f = first(rows, lambda r: re.match(r"k_gemm_x3p<4, 2, 2, 2, 2, false, false, false(, 0, [01])?(, (true|false))?>", r["name"]))
             if f:
                 out["k_gemm_x3_fwd_pool0"] = entry(f)
             # the layer-0 weight gradient: k-major B, dy^T a transposed image (256 x 128 tile since round 3, 128 x 128 before)
-            w = first(rows, lambda r: re.match(r"k_gemm_x3p<(2, 4, 2, 1, 3|4, 2, 2, 2, 2), false, true, false(, 0, 0(, (true|false))?)?>", r["name"]))
+            w = first(rows, lambda r: re.match(r"k_gemm_x3p<(2, 4, 2, 1, 3|4, 2, 2, 2, 2), false, true, false(, 0, 0)?(, (true|false))?>", r["name"]))
             if w:
                 out["k_gemm_x3_bwwk_pool0"] = entry(w)
         else:
