@@ -109,6 +109,8 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end snapshot leg (metric iii) of the default line")
     ap.add_argument("--reduce-half", type=int, default=None, choices=[0, 1],
                     help="A/B: pin the narrow-row max aggregator to one (0) / two (1) neighbour rows per wave-instruction (ogl_reduce_debug_half)")
+    ap.add_argument("--variants-timeout", type=int, default=240,
+                    help="seconds the exchange variants may take in all before every rank prints / exits with what it has")
     ap.add_argument("--no-variants", action="store_true",
                     help="N > 1 / --force-dist: skip the other two forms of the gradient exchange (`collectives_variants`) after the headline")
     ap.add_argument("--e2e-snapshots", type=int, default=6)
@@ -401,13 +403,17 @@ def main():
     # (a) = the headline above (all-reduce after the replayed forward + backward, one flat bucket; two overlapped buckets when eager),
     # (b) the sharded update (reduce-scatter -> Adam on 1 / N of the flat parameters -> all-gather), (c) the exchange and the optimiser
     # recorded INSIDE the replayed step graph (RCCL only).  Each on a fresh model + strategy, sequentially, nothing re-executed.
-    collectives_variants = None
-    if (world > 1 or args.force_dist) and not args.no_variants:
+    # They run LAST — after every other measurement of this invocation, with the finished line in hand and a watchdog on every rank: a form
+    # that has never run on more than one GPU (the captured exchange) must not be able to cost the run its headline.
+    want_variants = (world > 1 or args.force_dist) and not args.no_variants
+    collectives_variants = {} if want_variants else None
+
+    def measure_variants():
         from ogl_amd.graphsage import model as _mm
         nccl_on = dist.is_initialized() and dist.get_backend() == "nccl"
         base_flags = (bool(parallel.SHARDED_UPDATE), bool(_mm.DP_CAPTURE_COLLECTIVES))
-        collectives_variants = {"a_allreduce" if base_flags == (False, False) else "headline": dict(
-            ms_per_step=round(1000 * elapsed / args.steps, 4), sharded_update=base_flags[0], captured_exchange=base_flags[1], collectives=collectives)}
+        collectives_variants["a_allreduce" if base_flags == (False, False) else "headline"] = dict(
+            ms_per_step=round(1000 * elapsed / args.steps, 4), sharded_update=base_flags[0], captured_exchange=base_flags[1], collectives=collectives)
         todo = [("a_allreduce", False, False), ("b_sharded_update", True, False), ("c_captured_exchange", False, True)]
         for name, shd_on, cap_on in todo:
             if (shd_on, cap_on) == base_flags:
@@ -424,10 +430,12 @@ def main():
                 elv = settle_and_time(args.steps)
                 collectives_variants[name] = dict(ms_per_step=round(1000 * elv / args.steps, 4), sharded_update=shd_on, captured_exchange=cap_on,
                                                   collectives=instrumented_collectives(args.steps))
+                del mv
+            except Exception as ex:                          # (recorded, never fatal: the headline is already measured)
+                collectives_variants[name] = dict(error="%s: %s" % (type(ex).__name__, str(ex)[:300]))
             finally:
                 parallel.SHARDED_UPDATE, _mm.DP_CAPTURE_COLLECTIVES = base_flags
                 state["strat"] = strat
-            del mv
         barrier()
     # the OTHER execution mode of large batches, for the record: when the auto policy kept this workload eager (fast host),
     # the same steps replayed as captured graphs (size buckets captured in an untimed warm-up first)
@@ -759,6 +767,36 @@ def main():
             "cpu_baseline": cpu_baseline,
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in sorted(kernels.items())},
         }
+    else:
+        line = None
+    if want_variants:
+        import threading
+        done = {"v": False}
+
+        def emit(note=None):
+            if done["v"]:
+                return
+            done["v"] = True
+            if rank == 0:
+                line["collectives_variants"] = collectives_variants
+                if note:
+                    line["collectives_variants_note"] = note
+                print(json.dumps(line))
+                sys.stdout.flush()
+
+        def bail():                                           # (every rank: a hung collective never returns to Python)
+            emit("watchdog: a variant did not finish within %d s; the line carries what was measured before it" % args.variants_timeout)
+            os._exit(0)
+        dog = threading.Timer(args.variants_timeout, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            measure_variants()
+        except Exception as ex:
+            collectives_variants["error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
+        dog.cancel()
+        emit()
+    elif rank == 0:
         print(json.dumps(line))
     if world > 1 or args.force_dist:
         dist.destroy_process_group()
