@@ -341,23 +341,6 @@ def main():
                         "in sync() (mostly hidden under the layer-0 backward).  t1_prime = the instrumented step minus the exposed exchange: "
                         "what one rank's step costs with zero link time"}
 
-    # ---- N ranks: the ONE-RANK step first, on every rank of this same invocation (no shard, no exchange: `parallel.local_only`), B seeds
-    # per rank — the T1 a scaling curve divides by, measured on the same boxes in the same process group as TN
-    one_rank_reference = None
-    if world > 1 or args.force_dist:
-        with parallel.local_only():
-            torch.manual_seed(1)
-            sampling.seed(1)
-            m1 = GraphSAGE(feat_size, H, n_classes, 1, F.relu, 0, args.aggregator, edge_feats=0, pool_feats=H).cuda()
-            state["strat"], state["batch"] = make_strategy(m1, B), B
-            el1 = settle_and_time(args.steps)
-        one_rank_reference = dict(ms_per_step=round(1000 * el1 / args.steps, 4), vertices_per_s_per_rank=round(args.steps * B / el1, 1),
-                                  what="the one-rank step (B = %d seeds, no shard, no exchange) timed on every rank inside this invocation, "
-                                       "MAX over ranks: `--gpus 1` of the same command line" % B)
-        state["strat"] = None
-        del m1
-        sampling.seed(1)
-        torch.manual_seed(1)
     strat = state["strat"] = make_strategy(model, B_global)
     state["batch"] = B_global
 
@@ -399,6 +382,22 @@ def main():
     # An instrumented pass AFTER the timed region: hipEvent pairs around every collective the step issues from Python (the default
     # replica step keeps its exchange outside the replayed graph; --dp-capture 1 records it inside, where events cannot see it).
     collectives = instrumented_collectives(args.steps)
+    # ---- N ranks: the ONE-RANK step on every rank of this same invocation (no shard, no exchange: `parallel.local_only`), B seeds per
+    # rank — the T1 a scaling curve divides by, measured on the same boxes in the same process group as TN, right BEHIND the headline
+    # (a warm chip either way: in front of it the first run of a fresh box read 5-15 % slow)
+    one_rank_reference = None
+    if world > 1 or args.force_dist:
+        with parallel.local_only():
+            torch.manual_seed(1)
+            sampling.seed(1)
+            m1 = GraphSAGE(feat_size, H, n_classes, 1, F.relu, 0, args.aggregator, edge_feats=0, pool_feats=H).cuda()
+            state["strat"], state["batch"] = make_strategy(m1, B), B
+            el1 = settle_and_time(args.steps)
+        one_rank_reference = dict(ms_per_step=round(1000 * el1 / args.steps, 4), vertices_per_s_per_rank=round(args.steps * B / el1, 1),
+                                  what="the one-rank step (B = %d seeds, no shard, no exchange) timed on every rank inside this invocation, "
+                                       "MAX over ranks: `--gpus 1` of the same command line" % B)
+        state["strat"], state["batch"] = strat, B_global
+        del m1
     # ---- N ranks: the OTHER forms of the exchange, timed in this same invocation on the same ranks (the driver gives one run per N):
     # (a) = the headline above (all-reduce after the replayed forward + backward, one flat bucket; two overlapped buckets when eager),
     # (b) the sharded update (reduce-scatter -> Adam on 1 / N of the flat parameters -> all-gather), (c) the exchange and the optimiser
@@ -1100,8 +1099,10 @@ def forward_bench(args, wl, g, model, train_set, world, rank, arrays, feat_size,
         full_ms = sum(ms for _, _, ms in fullc) / len(fullc)
         per_launch = top / (sum(m["n_dst"] for _, m, _ in l0) / nprof)
         ach = ragg["bytes"] / ragg["ms"] / 1e6
-        roof = dict(kernel="k_reduce_fwd_v4 (layer-0 max over the cached projection table, int64 global picks; a full chunk = %.1f batches "
-                           "of %d seeds per launch)" % (per_launch, B), bound="hbm",
+        narrow = fullc[0][1]["d"] <= 128 and args.reduce_half != 0
+        roof = dict(kernel="%s (layer-0 max over the cached projection table, int64 global picks; a full chunk = %.1f batches "
+                           "of %d seeds per launch)" % ("k_reduce_fwd_max_half: two <= 512-byte rows per wave-instruction" if narrow else "k_reduce_fwd_v4",
+                                                        per_launch, B), bound="hbm",
                     achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
                     avg_launch_ms=round(full_ms, 4),
                     algorithmic_bytes_per_launch=round(full_bytes),
