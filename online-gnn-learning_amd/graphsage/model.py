@@ -744,7 +744,7 @@ class PrioritizedHipSupervisedGraphSage(HipSupervisedGraphSage):
         train_arr = train_set if isinstance(train_set, np.ndarray) else np.asarray(list(train_set), dtype=np.int64)
         if train_arr.size == 0:
             return
-        seeds_np = np.ascontiguousarray(np.asarray(id_to_subgraph[train_arr], dtype=np.int64).reshape(-1))
+        seeds_np = np.array(id_to_subgraph[train_arr], dtype=np.int64).reshape(-1)       # (a copy: the train array is read-only, tensors are not)
         seeds_all = torch.from_numpy(seeds_np)
         graph = graph_util.get_graph()
         # N ranks: whole batches of the pass are block-partitioned over the ranks (seed order kept) and the per-seed losses
