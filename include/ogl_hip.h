@@ -184,6 +184,18 @@ int ogl_reduce_bwd_seg_plan(const int32_t* idx, int64_t n_dst, int fanout, int64
 int ogl_reduce_bwd_seg_apply(const float* dout, int64_t ldd, const int32_t* idx, int64_t n_dst, int fanout, int d, int op, int64_t n_src,
                              const float* mask, int64_t ldm, float* out, int64_t ldo, void* image, void* workspace,
                              int64_t workspace_bytes, ogl_stream_t stream);
+/* ... and as the TRANSPOSED, group-major bf16x3 image of dsrc (sources dealt round-robin over G = ceil(n_src / 32) groups of 32; the
+ * layout ogl_pool_bwd_x3 writes: ogl_x3_image_bytes(d, 32 G) bytes): the dy operand of ogl_linear_bwd_weight_x3k with interleave = G,
+ * i.e. the 'meanpool' first layer's fc_pool weight gradient on the same 256 x 128 product as the 'pool' mode's
+ * (R/train/graphsage/pytorch/aggregator_dgl.py:178-186).
+ *   ogl_reduce_bwd_seg_plan_groups   after ogl_reduce_bwd_seg_plan, on a stream ordered behind it: the planned lists copied GROUP-MAJOR into
+ *                                    the same workspace (gradient-free like the plan: beside the forward pass);
+ *   ogl_reduce_bwd_seg_apply_t       one block per source group, a thread per two columns, the group's entries read as one block-uniform
+ *                                    run, sums in the plan's list order, no partial rows and no fix-up launch.  d <= 640; rows 8-byte
+ *                                    aligned (even leading dimensions); mask nullable. */
+int ogl_reduce_bwd_seg_plan_groups(int64_t n_dst, int fanout, int64_t n_src, void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
+int ogl_reduce_bwd_seg_apply_t(const float* dout, int64_t ldd, int64_t n_dst, int fanout, int d, int op, int64_t n_src, const float* mask,
+                               int64_t ldm, void* image, const void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense projections (torch.nn.Linear inside SAGEConv: fc_pool / fc_self / fc_neigh), fp32 MFMA.

@@ -47,6 +47,8 @@ SIGNATURES = {
     "ogl_reduce_bwd_seg_workspace_bytes": (_i64, [_i64, _i, _i, _i64]),
     "ogl_reduce_bwd_seg_plan": (_i, [_p, _i64, _i, _i64, _p, _i64, _p]),
     "ogl_reduce_bwd_seg_apply": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p]),
+    "ogl_reduce_bwd_seg_plan_groups": (_i, [_i64, _i, _i64, _p, _i64, _p]),
+    "ogl_reduce_bwd_seg_apply_t": (_i, [_p, _i64, _i64, _i, _i, _i, _i64, _p, _i64, _p, _p, _i64, _p]),
     "ogl_linear_fwd": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p,
                             _p, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p]),
     "ogl_linear_fwd_dual_bias": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p, _p,

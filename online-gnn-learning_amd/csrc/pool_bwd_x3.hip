@@ -117,23 +117,6 @@ __global__ void __launch_bounds__(256) k_pool_bucket(const float* __restrict__ d
     }
 }
 
-// emit: image row f, group b = split(T[0..31][f]); the whole slab is one contiguous (D + 1) * 192-byte run
-__device__ __forceinline__ void pb_emit(const float* T, int D, int DP, int b, unsigned char* __restrict__ img, int64_t gstride, int tid, int nthreads) {
-  for (int u = tid; u < D * 4; u += nthreads) {                   // unit = (row f, 8-source chunk c): one split, three stores
-    const int fo = u >> 2, c = u & 3;
-    const float* col = T + (8 * c) * DP + fo;
-    uint4 o[3];
-    split3(col[0], col[DP], o[0].x, o[1].x, o[2].x);
-    split3(col[2 * DP], col[3 * DP], o[0].y, o[1].y, o[2].y);
-    split3(col[4 * DP], col[5 * DP], o[0].z, o[1].z, o[2].z);
-    split3(col[6 * DP], col[7 * DP], o[0].w, o[1].w, o[2].w);
-    unsigned char* d = img + (int64_t)b * gstride + (int64_t)fo * 192;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) *(uint4*)(d + x3_piece(c, p) * 16) = o[p];
-  }
-  if (tid < 12) *(uint4*)(img + (int64_t)b * gstride + (int64_t)D * 192 + tid * 16) = make_uint4(0, 0, 0, 0);   // the zero row
-}
-
 __global__ void __launch_bounds__(PB_THREADS) k_pool_bwd_x3(const int32_t* __restrict__ idx, int S, const unsigned short* __restrict__ off,
                                                             const uint2* __restrict__ ent, const unsigned* __restrict__ bitmap,
                                                             int64_t words, int64_t n_src, PbDiv dv, int D, int DP,

@@ -322,11 +322,154 @@ __global__ void __launch_bounds__(256) k_seg_fixup(const int* __restrict__ start
   }
 }
 
-static int64_t seg_ints(int64_t E, int64_t n_src) {
+
+// ---- the same backward, written as the TRANSPOSED group-major image (x6_arith.h) ------------------------------------------------
+// The first layer of 'meanpool' has ONE consumer for dP — fc_pool's weight gradient dW = dP^T . X — and that product is fastest on the
+// 256 x 128 tile whose A operand is the image of dP^T (what the 'pool' mode's backward writes, pool_bwd_x3.hip): sources dealt round-robin
+// over G groups of 32 (source = lane * G + group), group b one contiguous slab of (D + 1) x 192 bytes.
+//
+//   plan   k_seg_gscan     gbase[g] = first entry of group g in a GROUP-MAJOR copy of the sorted lists (one block: totals + exclusive scan)
+//          k_seg_gplace    one wave per group: its 32 sources' lists, lane after lane, as (destination row, lane | last-of-source) entries
+//   apply  k_seg_groups    one block per group, thread = two columns: the group's entries are ONE contiguous run read with scalar
+//                          loads (block-uniform: no per-entry vector instruction besides the row load and the add), SGG_U row loads in
+//                          flight; a finished source is scaled, masked and parked in the group's 32 x D slab in LDS (which starts out
+//                          holding the ReLU mask's rows), and the slab leaves as the group's 192-byte pieces of every image row.
+// What the first two versions of this kernel taught (tools/seg_t_probe.py; both 157-230 us alone, like the row-wise launch): with a
+// thread per column, TEN waves repeat every entry's bookkeeping (list entry from LDS, end-of-source test, branch) — 100 us of issue
+// slots for 176 k edges with every memory access ablated; and cutting the columns into eight XCD-local slices made the gathers L2 hits
+// (74 % hit rate) but the image writes 16-byte islands.  Hence: entries in SGPRs, few waves per row, whole 192-byte pieces per store run:
+// 121 us alone (the row-wise launch: 163), of which the mask rows 32, the gathers 18 and the image 47 with the others ablated — the launch
+// moves what the fabric delivers (FETCH + WRITE ~ 6 TB/s).  Column parts of a group as separate blocks (2, 3, 4 per group; 8 = one per
+// XCD, the L2-resident slices again) measured 128 / 130 / 146 / 138 us: the parts repeat the walk, the walk is what is not free.
+#define SGG_THREADS 320              // thread = two columns (D <= 640)
+#define SGG_U 16
+
+// one block: group totals and their exclusive scan (gbase[G] = all entries)
+__global__ void __launch_bounds__(1024) k_seg_gscan(const int* __restrict__ start, int64_t n_src, int G, int* __restrict__ gbase,
+                                                    int2* __restrict__ gent) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int g0 = 0; g0 < G; g0 += 1024) {
+    const int g = g0 + tid;
+    int c = 0;
+    if (g < G)
+      for (int l = 0; l < 32; ++l) {
+        const int64_t s = (int64_t)l * G + g;
+        if (s < n_src) c += start[s + 1] - start[s];
+      }
+    int inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(inc, o);
+      if (lane >= o) inc += v;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int before = carry;
+    for (int k = 0; k < wv; ++k) before += wsum[k];
+    if (g < G) gbase[g] = before + inc - c;
+    __syncthreads();
+    if (tid == 1023) carry = before + inc;
+    __syncthreads();
+  }
+  if (tid == 0) gbase[G] = carry;
+  if (tid < SGG_U) gent[carry + tid] = make_int2(0, 0);          // the padding behind the last group's run (row 0, no flag)
+}
+
+// one wave per group: entry = (destination row, lane | 0x100 on the source's last edge), sources in lane order, edges in list order
+__global__ void __launch_bounds__(256) k_seg_gplace(const int* __restrict__ start, const int* __restrict__ sorted, int64_t n_src, int G, int S,
+                                                    const int* __restrict__ gbase, int2* __restrict__ gent) {
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= G) return;
+  const int64_t s = (int64_t)lane * G + g;
+  int a = 0, c = 0;
+  if (lane < 32 && s < n_src) { a = start[s]; c = start[s + 1] - a; }
+  int inc = c;
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) {
+    const int v = __shfl_up(inc, o);
+    if (lane >= o) inc += v;
+  }
+  int2* out = gent + gbase[g] + inc - c;
+  for (int j = 0; j < c; ++j) out[j] = make_int2(sorted[a + j] / S, lane | (j + 1 == c ? 0x100 : 0));
+}
+
+template <bool OFF32>                // (n_dst * ldd < 2^31: 32-bit row offsets, one scalar multiply per entry)
+__global__ void __launch_bounds__(SGG_THREADS) k_seg_groups(const float* __restrict__ dout, int64_t ldd, int D, int DP,
+                                                            const int* __restrict__ gbase, const int2* __restrict__ gent, int64_t n_src,
+                                                            int G, const float* __restrict__ mask, int64_t ldm, float scale,
+                                                            unsigned char* __restrict__ img, int64_t gstride) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sgg_smem[];
+  float* T = (float*)sgg_smem;                                    // [32][DP] (DP even)
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  const int c2 = 2 * tid;
+  const bool col = c2 < D;
+  const int r0 = gbase[b], n = gbase[b + 1] - r0;                 // (block-uniform: scalar loads)
+  if (col) {                                                      // the slab starts as the mask rows (1 without a mask, 0 past n_src)
+    float2 m[32];
+#pragma unroll
+    for (int l = 0; l < 32; ++l) {
+      const int64_t s = (int64_t)l * G + b;
+      m[l] = s < n_src ? (mask ? *(const float2*)(mask + s * ldm + c2) : make_float2(1.f, 1.f)) : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int l = 0; l < 32; ++l) *(float2*)(T + l * DP + c2) = m[l];
+  }
+  // (every thread touches its own two columns of the slab until the emit: no barrier before it)
+  const int2* __restrict__ ge = gent + r0;
+  const float* src = dout + (col ? c2 : 0);                       // (threads past the last column load column 0 and drop it)
+  float2 acc = make_float2(0.f, 0.f);
+  unsigned seen = 0u;                                             // lanes of the group that had an edge (block-uniform)
+  for (int k0 = 0; k0 < n; k0 += SGG_U) {
+    int fl[SGG_U];
+    float2 v[SGG_U];
+#pragma unroll
+    for (int u = 0; u < SGG_U; ++u) {                             // (a slot past the group's run reads the next group's entry — or the
+      const int2 e = ge[k0 + u];                                  //  list's SGG_U entries of padding —: a valid row, dropped)
+      const int d = __builtin_amdgcn_readfirstlane(e.x);
+      fl[u] = __builtin_amdgcn_readfirstlane(e.y);
+      v[u] = OFF32 ? *(const float2*)(src + (unsigned)d * (unsigned)ldd) : *(const float2*)(src + (int64_t)d * ldd);
+    }
+#pragma unroll
+    for (int u = 0; u < SGG_U; ++u) {
+      if (k0 + u < n) {                                           // (block-uniform)
+        acc.x += v[u].x; acc.y += v[u].y;
+        if (fl[u] & 0x100) {                                      // (block-uniform) the source's last edge: scale, mask, park
+          const int l = fl[u] & 31;
+          seen |= 1u << l;
+          if (col) {
+            float2* t = (float2*)(T + l * DP + c2);
+            const float2 mk = *t;
+            *t = make_float2(mk.x > 0.f ? acc.x * scale : 0.f, mk.y > 0.f ? acc.y * scale : 0.f);
+          }
+          acc = make_float2(0.f, 0.f);
+        }
+      }
+    }
+  }
+  if (col) {
+#pragma unroll
+    for (int l = 0; l < 32; ++l)
+      if (!((seen >> l) & 1u)) *(float2*)(T + l * DP + c2) = make_float2(0.f, 0.f);   // a source nobody sampled (still holds the mask)
+  }
+  __syncthreads();
+  pb_emit(T, D, DP, b, img, gstride, tid, SGG_THREADS);
+}
+
+static int64_t seg_ints_lists(int64_t E, int64_t n_src) {
   const int64_t nb = ogl_cdiv(n_src + 1, SG_SCAN);
   // cnt [n_src + 1] | start [n_src + 1] | cur [n_src] | bsum [nb] | U [E] | sorted [E] | nlong [4] | longs [E / 64 + 1]
   return (n_src + 1) * 2 + n_src + nb + 2 * E + 4 + (E / 64 + 1) + 16;
 }
+// ... | gbase [G + 1] | gent [E] x int2 (8-byte aligned): the group-major lists of ogl_reduce_bwd_seg_plan_groups
+static int64_t seg_gbase_off(int64_t E, int64_t n_src) { return ogl_round_up(seg_ints_lists(E, n_src), 2); }
+static int64_t seg_gent_off(int64_t E, int64_t n_src) { return ogl_round_up(seg_gbase_off(E, n_src) + ogl_cdiv(n_src, 32) + 1, 2); }
+static int64_t seg_ints(int64_t E, int64_t n_src) { return seg_gent_off(E, n_src) + 2 * (E + SGG_U); }   // (+ SGG_U entries of padding)
 
 extern "C" int64_t ogl_reduce_bwd_seg_workspace_bytes(int64_t n_dst, int fanout, int d, int64_t n_src) {
   if (n_dst < 0 || fanout < 0 || d < 0 || n_src < 0) return OGL_EINVAL;
@@ -422,4 +565,66 @@ extern "C" int ogl_reduce_bwd_seg_apply(const float* dout, int64_t ldd, const in
                                         int64_t n_src, const float* mask, int64_t ldm, float* out, int64_t ldo, void* image,
                                         void* workspace, int64_t workspace_bytes, ogl_stream_t stream) {
   return seg_apply(dout, ldd, idx, n_dst, fanout, d, op, n_src, mask, ldm, out, ldo, image, workspace, workspace_bytes, stream);
+}
+
+// The group-major copy of a planned workspace's lists (after ogl_reduce_bwd_seg_plan, same stream or ordered behind it): what
+// ogl_reduce_bwd_seg_apply_t walks.  Gradient-free like the plan itself.
+extern "C" int ogl_reduce_bwd_seg_plan_groups(int64_t n_dst, int fanout, int64_t n_src, void* workspace, int64_t workspace_bytes,
+                                              ogl_stream_t stream) {
+  if (n_dst < 0 || fanout <= 0 || n_src <= 0 || n_src >= (1ll << 31) || n_dst * (int64_t)fanout >= (1ll << 31)) return OGL_EINVAL;
+  const int64_t E = n_dst * fanout;
+  if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < ogl_round_up(seg_ints(E, n_src) * 4, 256)) return OGL_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  int* cnt = (int*)workspace;
+  const int* start = cnt + (n_src + 1);
+  const int64_t nb = ogl_cdiv(n_src + 1, SG_SCAN);
+  const int* sorted = start + (n_src + 1) + n_src + nb + E;
+  int* gbase = cnt + seg_gbase_off(E, n_src);
+  int2* gent = (int2*)(cnt + seg_gent_off(E, n_src));
+  const int64_t G = ogl_cdiv(n_src, 32);
+  hipLaunchKernelGGL(k_seg_gscan, dim3(1), dim3(1024), 0, st, start, n_src, (int)G, gbase, gent);
+  OGL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_seg_gplace, dim3((unsigned)ogl_cdiv(G, 4)), dim3(256), 0, st, start, sorted, n_src, (int)G, fanout, (const int*)gbase, gent);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
+}
+
+// The masked mean / sum backward as the transposed group-major image of [d rows, 32 * ceil(n_src / 32)] (ogl_x3_image_bytes(d, 32 G)):
+// what ogl_linear_bwd_weight_x3k reads as its dy operand with interleave = G.  d <= 640; rows 8-byte aligned (even leading dimensions
+// that cover an even number of columns); mask nullable.  The workspace holds the plan AND its group lists.
+extern "C" int ogl_reduce_bwd_seg_apply_t(const float* dout, int64_t ldd, int64_t n_dst, int fanout, int d, int op, int64_t n_src,
+                                          const float* mask, int64_t ldm, void* image, const void* workspace, int64_t workspace_bytes,
+                                          ogl_stream_t stream) {
+  const int d2 = (d + 1) & ~1;
+  if (n_dst < 0 || fanout <= 0 || d <= 0 || d > 2 * SGG_THREADS || n_src <= 0 || n_src >= (1ll << 31) || ldd < d2 || (ldd & 1)) return OGL_EINVAL;
+  if (op != OGL_REDUCE_MEAN && op != OGL_REDUCE_SUM) return OGL_EINVAL;
+  if (!image || ((uintptr_t)image & 15) || ((uintptr_t)dout & 7) || (mask && (ldm < d2 || (ldm & 1) || ((uintptr_t)mask & 7)))) return OGL_EINVAL;
+  const int64_t E = n_dst * fanout;
+  if (E >= (1ll << 31)) return OGL_EINVAL;
+  if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < ogl_round_up(seg_ints(E, n_src) * 4, 256)) return OGL_EWORKSPACE;
+  if (n_dst > 0 && !dout) return OGL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int* cnt = (const int*)workspace;
+  const int* gbase = cnt + seg_gbase_off(E, n_src);
+  const int2* gent = (const int2*)(cnt + seg_gent_off(E, n_src));
+  const int64_t G = ogl_cdiv(n_src, 32);
+  const int DP = d2 + 2;
+  const size_t lds = (size_t)32 * DP * 4;
+  const bool off32 = n_dst * ldd < (1ll << 31);
+  static bool attr_set = false;
+  if (!attr_set) {
+    OGL_CHECK_HIP(hipFuncSetAttribute((const void*)k_seg_groups<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OGL_CHECK_HIP(hipFuncSetAttribute((const void*)k_seg_groups<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)G), threads(SGG_THREADS);
+  const float scale = op == OGL_REDUCE_MEAN ? 1.f / (float)fanout : 1.f;
+  if (off32)
+    hipLaunchKernelGGL(k_seg_groups<true>, grid, threads, lds, st, dout, ldd, d, DP, gbase, gent, n_src, (int)G, mask, ldm, scale,
+                       (unsigned char*)image, ((int64_t)d + 1) * 192);
+  else
+    hipLaunchKernelGGL(k_seg_groups<false>, grid, threads, lds, st, dout, ldd, d, DP, gbase, gent, n_src, (int)G, mask, ldm, scale,
+                       (unsigned char*)image, ((int64_t)d + 1) * 192);
+  OGL_CHECK_LAUNCH();
+  return OGL_OK;
 }

@@ -34,6 +34,26 @@ __device__ __forceinline__ void split3(float x, float y, unsigned& h, unsigned& 
 // slower in the image producers: their 16-byte stores then come in 32-byte runs instead of 64-byte ones.)
 __host__ __device__ __forceinline__ constexpr int x3_piece(int c, int p) { return p * 4 + c; }
 
+// The TRANSPOSED, group-major image of a gradient matrix dP [n_src, D] (what the layer-0 weight-gradient product reads as its A operand:
+// pool_bwd_x3.hip, reduce_seg.hip): sources dealt round-robin over G = ceil(n_src / 32) groups (source s = lane * G + group), group b
+// one contiguous slab of (D + 1) rows x 192 bytes — row f = the split of dP[the group's 32 sources, f], row D all zero.
+// emit: image row f, group b = split(T[0..31][f]); the whole slab is one contiguous (D + 1) * 192-byte run
+__device__ __forceinline__ void pb_emit(const float* T, int D, int DP, int b, unsigned char* __restrict__ img, int64_t gstride, int tid, int nthreads) {
+  for (int u = tid; u < D * 4; u += nthreads) {                   // unit = (row f, 8-source chunk c): one split, three stores
+    const int fo = u >> 2, c = u & 3;
+    const float* col = T + (8 * c) * DP + fo;
+    uint4 o[3];
+    split3(col[0], col[DP], o[0].x, o[1].x, o[2].x);
+    split3(col[2 * DP], col[3 * DP], o[0].y, o[1].y, o[2].y);
+    split3(col[4 * DP], col[5 * DP], o[0].z, o[1].z, o[2].z);
+    split3(col[6 * DP], col[7 * DP], o[0].w, o[1].w, o[2].w);
+    unsigned char* d = img + (int64_t)b * gstride + (int64_t)fo * 192;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *(uint4*)(d + x3_piece(c, p) * 16) = o[p];
+  }
+  if (tid < 12) *(uint4*)(img + (int64_t)b * gstride + (int64_t)D * 192 + tid * 16) = make_uint4(0, 0, 0, 0);   // the zero row
+}
+
 // 16-byte load from a 4-byte-aligned address: gfx950 under HSA runs in unaligned-access mode, the
 // compiler emits one global_load_dwordx4 (rows such as K = 602 floats are only 8-B aligned).
 __device__ __forceinline__ float4 ld16(const float* p) {

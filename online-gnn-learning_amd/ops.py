@@ -1089,10 +1089,10 @@ def pool_bwd_x3(dout, argmax, relu_out, idx32, n_src):
 class PoolPlan:
     """What ogl_pool_bwd_x3_plan left in its workspace, and the event (None: same stream) that marks the end of the plan launches;
     ``pending``: the plan's launches are still waiting for the caller's next launch to be created first (``_DEFERRED``)."""
-    __slots__ = ("ws", "nbytes", "event", "shape", "pending")
+    __slots__ = ("ws", "nbytes", "event", "shape", "pending", "groups")
 
     def __init__(self, ws, nbytes, event, shape):
-        self.ws, self.nbytes, self.event, self.shape, self.pending = ws, nbytes, event, shape, False
+        self.ws, self.nbytes, self.event, self.shape, self.pending, self.groups = ws, nbytes, event, shape, False, False
 
 
 POOL_PLAN = os.environ.get("OGL_POOL_PLAN", "1") != "0"
@@ -1163,6 +1163,8 @@ def _plan_ready(plan):
 
 
 SEG_REDUCE_BWD = os.environ.get("OGL_SEG_REDUCE_BWD", "1") != "0"    # mean / sum backward as a planned segmented gather (no atomics)
+SEG_T = os.environ.get("OGL_SEG_T", "1") != "0"      # 'meanpool' layer 0: the pooled rows' gradient as the transposed group-major image (one launch)
+SEG_T_MAX_D = 640
 SEG_MIN_EDGES = 4096
 
 
@@ -1171,9 +1173,10 @@ def seg_bwd_fits(idx, d, n_src):
             and d % 4 == 0 and 4 <= d <= 1024 and 0 < n_src < (1 << 31))
 
 
-def reduce_bwd_seg_plan(idx32, d, n_src, side=True):
+def reduce_bwd_seg_plan(idx32, d, n_src, side=True, groups=False):
     """The gradient-free half of the segmented mean / sum backward (``ogl_reduce_bwd_seg_plan``: the block's edges sorted by source),
-    enqueued NOW — by the forward pass, on the side stream when the fork is on.  Returns the plan ``reduce_bwd_seg_apply`` consumes."""
+    enqueued NOW — by the forward pass, on the side stream when the fork is on.  Returns the plan ``reduce_bwd_seg_apply`` consumes;
+    ``groups``: + the group-major copy of the lists ``reduce_bwd_seg_apply_t`` walks."""
     n_dst, fanout = idx32.shape
     assert idx32.dtype == torch.int32 and idx32.is_contiguous()
     nbytes = int(_lib.lib().ogl_reduce_bwd_seg_workspace_bytes(n_dst, fanout, d, n_src))
@@ -1182,8 +1185,12 @@ def reduce_bwd_seg_plan(idx32, d, n_src, side=True):
     def launch():
         _launch("ogl_reduce_bwd_seg_plan", _lib.lib().ogl_reduce_bwd_seg_plan, _ptr(idx32), n_dst, fanout, n_src, _ptr(ws), nbytes, _stream(),
                 meta=dict(n_dst=n_dst, fanout=fanout, n_src=n_src))
+        if groups:
+            _launch("ogl_reduce_bwd_seg_plan", _lib.lib().ogl_reduce_bwd_seg_plan_groups, n_dst, fanout, n_src, _ptr(ws), nbytes, _stream(),
+                    meta=dict(n_dst=n_dst, fanout=fanout, n_src=n_src, groups=True))
 
     plan = PoolPlan(ws, nbytes, None, (n_dst, fanout, d, n_src))
+    plan.groups = bool(groups)
     return _plan_on_side(plan, launch, (ws, idx32), side)
 
 
@@ -1205,6 +1212,25 @@ def reduce_bwd_seg_apply(dout, idx32, plan, op, mask=None, want_out=True, want_i
             _ptr(img.buf) if img is not None else None, _ptr(plan.ws), plan.nbytes, _stream(),
             meta=dict(n_dst=n_dst, fanout=fanout, d=d, n_src=n_src, op=op, out=out is not None, image=img is not None, mask=mask is not None))
     return out, img
+
+
+def reduce_bwd_seg_apply_t(dout, idx32, plan, op, mask=None):
+    """``reduce_bwd_seg_apply`` written as the TRANSPOSED group-major image (the layout of ``pool_bwd_x3``: sources dealt over
+    G = ceil(n_src / 32) groups) — the dy operand of ``linear_bwd_weight_x3k(..., interleave=G)``."""
+    dout = as_mat(dout)
+    n_dst, d = dout.shape
+    fanout, n_src = idx32.shape[1], plan.shape[3]
+    assert plan.shape == (n_dst, fanout, d, n_src) and op in ("mean", "sum") and d <= SEG_T_MAX_D and getattr(plan, "groups", False)
+    _plan_ready(plan)
+    G = (n_src + 31) // 32
+    buf = _x3_alloc(d, 32 * G, dout.device)
+    if mask is not None:
+        mask = as_mat(mask)
+        assert tuple(mask.shape) == (n_src, d)
+    _launch("ogl_reduce_bwd_seg_apply_t", _lib.lib().ogl_reduce_bwd_seg_apply_t, _ptr(dout), _ld(dout), n_dst, fanout, d,
+            REDUCE_OPS[op], n_src, _ptr(mask), _ld(mask) if mask is not None else 0, _ptr(buf), _ptr(plan.ws), plan.nbytes, _stream(),
+            meta=dict(n_dst=n_dst, fanout=fanout, d=d, n_src=n_src, op=op, mask=mask is not None))
+    return X3Image(buf, d, 32 * G)
 
 
 def pool_bwd_x3_apply(dout, idx32, plan, n_src):
@@ -2121,7 +2147,7 @@ class _PoolMeanFn(torch.autograd.Function):
         if _CAPTURE is not None:
             _CAPTURE.append(dict(pool_out=p))          # (test hook: the device's own ReLU decisions of the pooled projection)
         ctx.n_src, ctx.fanout, ctx.has_bias, ctx.bias_t = p.shape[0], idx.shape[1], bias is not None, bias
-        ctx.seg_plan = reduce_bwd_seg_plan(idx, p.shape[1], p.shape[0]) if need else None
+        ctx.seg_plan = reduce_bwd_seg_plan(idx, p.shape[1], p.shape[0], groups=SEG_T and p.shape[1] <= SEG_T_MAX_D) if need else None
         ctx.p_shape = tuple(p.shape)
         ctx.save_for_backward(x, w, x_rows, p, idx)
         return out
@@ -2131,10 +2157,16 @@ class _PoolMeanFn(torch.autograd.Function):
         x, w, x_rows, p, idx = ctx.saved_tensors
         plan, ctx.seg_plan = ctx.seg_plan, None
         if plan is None:                                  # (a second backward pass over a retained graph: the plan was consumed)
-            plan = reduce_bwd_seg_plan(idx, ctx.p_shape[1], ctx.p_shape[0], side=False)
+            plan = reduce_bwd_seg_plan(idx, ctx.p_shape[1], ctx.p_shape[0], side=False, groups=SEG_T and ctx.p_shape[1] <= SEG_T_MAX_D)
         K = x.shape[1]
         rimg = _row_image_for(x, x_rows, None) if (_MODE["name"] != "f32" and ctx.n_src >= X3_BWW_MIN_ROWS) else None
         if rimg is not None and rimg.K == K + 1:
+            if getattr(plan, "groups", False) and x_rows is not None:
+                # dP^T as the dealt group-major image the 'pool' mode's backward writes: the same 256 x 128 product (round 6)
+                dyT = reduce_bwd_seg_apply_t(dout, idx, plan, "mean", mask=p)
+                dw, db, _ = linear_bwd_weight_x3k(dyT, rimg, ctx.n_src, K, x_rows=x_rows, x_nrows=x.shape[0], interleave=(ctx.n_src + 31) // 32,
+                                                  want_bias=ctx.has_bias, dw_out=_dw_out(w, *w.shape), defer_for=(w, ctx.bias_t, None))
+                return None, dw, (db if ctx.has_bias else None), None, None
             # dP as the image the k-major weight gradient reads; x as the resident table's own image, gathered by the block's ids
             _, dp_img = reduce_bwd_seg_apply(dout, idx, plan, "mean", mask=p, want_out=False, want_image=True)
             dw, db, _ = linear_bwd_weight_x3k(dp_img, rimg, ctx.n_src, K, x_rows=x_rows, x_nrows=x.shape[0] if x_rows is not None else None,

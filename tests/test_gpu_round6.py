@@ -437,3 +437,113 @@ def test_every_exported_symbol_is_reached_or_allow_listed():
     unreached = declared - seen - ALLOW_UNREACHED
     assert not unreached, "exported but never called by the default paths (remove them or allow-list them with a reason): %s" % sorted(unreached)
     assert not (ALLOW_UNREACHED - declared), sorted(ALLOW_UNREACHED - declared)
+
+
+def _decode_group_major(buf, rows, K):
+    """uint8 transposed group-major bf16x3 image -> [rows, 32 * ceil(K / 32)] fp32 (three planes summed; exact), zero rows checked."""
+    G = (K + 31) // 32
+    raw = torch.as_tensor(buf.cpu().numpy().view(np.int16).reshape(G, rows + 1, 3, 32).copy()).view(torch.bfloat16).float()
+    val = (raw[:, :, 0] + raw[:, :, 1]) + raw[:, :, 2]
+    assert (val[:, rows] == 0).all()
+    return val[:, :rows].permute(1, 0, 2).reshape(rows, G * 32)
+
+
+@pytest.mark.parametrize("n_dst,S,D,n_src,masked", [(1, 1, 1, 1, True), (50, 4, 33, 70, True), (300, 25, 600, 2000, True),
+                                                    (2500, 10, 130, 900, False), (700, 25, 64, 40, True), (4100, 25, 40, 5000, True),
+                                                    (7060, 25, 600, 62495, True), (3000, 63, 640, 40000, True)])
+def test_mean_backward_as_the_transposed_image(n_dst, S, D, n_src, masked):
+    """ogl_reduce_bwd_seg_apply_t (one block per source group, one thread per column, sums in the plan's list order) against the
+    row-wise segmented backward and float64: integer-valued gradients make every order of summation exact, so the image is the
+    exact sum times fp32(1 / S) bit for bit (incl. hubs of several hundred edges — more rounds than one list buffer —, sources nobody sampled,
+    missing neighbours, the ragged last group); random gradients against float64."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    rng = np.random.default_rng(n_dst * 7 + D)
+    idx = rng.integers(0, n_src, (n_dst, S)).astype(np.int32)
+    if n_src > 100:
+        idx[rng.random((n_dst, S)) < 0.2] = rng.integers(0, 3)          # a hub: a fifth of all edges
+        idx[:, 0][rng.random(n_dst) < 0.5] = n_src - 1                   # ... and one in the last (ragged) group
+    idx[rng.random((n_dst, S)) < 0.05] = -1                              # missing neighbours
+    idx_d = torch.as_tensor(idx).cuda()
+    p = torch.randn(n_src, D).clamp_min(0)
+    pm = ops.empty_mat(n_src, D, "cuda"); pm.copy_(p)
+    G = (n_src + 31) // 32
+    mm = np.arange(32 * G)
+    s_of_m = (mm % 32) * G + mm // 32
+    ok = s_of_m < n_src
+    for kind in ("int", "float"):
+        dout = torch.randint(-8, 9, (n_dst, D)).float() if kind == "int" else torch.randn(n_dst, D)
+        dm = ops.empty_mat(n_dst, D, "cuda"); dm.copy_(dout)
+        plan = ops.reduce_bwd_seg_plan(idx_d, D, n_src, side=False, groups=True)
+        img = ops.reduce_bwd_seg_apply_t(dm, idx_d, plan, "mean", mask=pm if masked else None)
+        assert img.rows == D and img.K == 32 * G
+        got = _decode_group_major(img.buf, D, 32 * G).numpy()
+        assert (got[:, ~ok] == 0).all()
+        got_s = np.zeros((n_src, D), np.float32)
+        got_s[s_of_m[ok]] = got[:, ok].T
+        ref = np.zeros((n_src, D), np.float64)
+        valid = idx >= 0
+        np.add.at(ref, idx[valid], np.repeat(dout.numpy().astype(np.float64)[:, None, :], S, axis=1)[valid])
+        if kind == "int":
+            want = (ref.astype(np.float32) * (np.float32(1) / np.float32(S))).astype(np.float32)   # (the launch multiplies by 1 / S)
+        else:
+            want = ref / S
+        if masked:
+            want = np.where(p.numpy() > 0, want, 0)
+        if kind == "int":
+            assert np.array_equal(got_s, want.astype(np.float32))
+            if D % 4 == 0 and D >= 4:                                    # the row-wise launch (which divides by S) agrees to an ulp
+                rows_out, _ = ops.reduce_bwd_seg_apply(dm, idx_d, plan, "mean", mask=pm if masked else None)
+                np.testing.assert_allclose(rows_out.cpu().numpy(), got_s, rtol=3e-7, atol=0)
+        else:
+            # (fp32 sums in list order: the test's hub adds a fifth of all edges — up to 37 800 rows — one after the other)
+            np.testing.assert_allclose(got_s, want, rtol=5e-5, atol=5e-5 * max(1.0, np.abs(want).max()))
+
+
+def test_meanpool_first_layer_weight_gradient_through_the_transposed_image():
+    """pool_mean's backward with the transposed image (the 'pool' mode's 256 x 128 product) against the row-major image form it replaces
+    and float64, at the Reddit rung's shape."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    ops.set_gemm_mode("auto")
+    try:
+        torch.manual_seed(5)
+        T, K, H, n_src, n_dst, S = 80000, 602, 600, 62495, 7060, 25
+        tab = ops.empty_mat(T, K, "cuda"); tab.normal_()
+        ops.register_static_table(tab)
+        rows = torch.randperm(T, device="cuda")[:n_src]
+        idx = torch.randint(0, n_src, (n_dst, S), dtype=torch.int32, device="cuda")
+        w0 = (torch.randn(H, K, device="cuda") / 25)
+        b0 = torch.randn(H, device="cuda") / 10
+        g = torch.randn(n_dst, H, device="cuda")
+        grads = {}
+        was = ops.SEG_T
+        for flag in (True, False):
+            ops.SEG_T = flag
+            w = w0.clone().requires_grad_(True); b = b0.clone().requires_grad_(True)
+            seen = []
+            ops.capture_pool_winners(seen)
+            try:
+                out = ops.pool_mean(tab, w, b, idx, x_rows=rows)
+            finally:
+                ops.capture_pool_winners(None)
+            keep = (seen[0]["pool_out"] > 0).cpu()                # the device's own ReLU decisions (entries at the rounding edge differ from float64's)
+            ops.backward((out * g).sum())
+            grads[flag] = (w.grad.clone(), b.grad.clone())
+        ops.SEG_T = was
+        # float64 on the host
+        x = tab[rows].double().cpu(); wd = w0.double().cpu(); bd = b0.double().cpu()
+        p = torch.relu(x @ wd.T + bd)
+        dp = torch.zeros_like(p)
+        dp.index_add_(0, idx.cpu().long().reshape(-1), (g.double().cpu() / S).repeat_interleave(S, dim=0))
+        dp = dp * keep
+        dw = dp.T @ x
+        db = dp.sum(0)
+        for flag in (True, False):
+            gw, gb = grads[flag]
+            scale = float(dw.abs().max())
+            assert float((gw.double().cpu() - dw).abs().max()) <= 2e-5 * scale, flag
+            assert float((gb.double().cpu() - db).abs().max()) <= 2e-5 * float(db.abs().max()), flag
+        assert float((grads[True][0] - grads[False][0]).abs().max()) <= 2e-5 * float(dw.abs().max())
+    finally:
+        ops.set_gemm_mode("f32")
