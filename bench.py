@@ -108,7 +108,7 @@ def parse():
                          "0 = all-reduce + the identical Adam on every rank (the default)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end snapshot leg (metric iii) of the default line")
     ap.add_argument("--reduce-half", type=int, default=None, choices=[0, 1],
-                    help="A/B: pin the narrow-row max aggregator to one (0) / two (1) neighbour rows per wave-instruction (ogl_reduce_debug_half)")
+                    help="A/B: pin the narrow-row max aggregator to one (0) / two (1) neighbour rows per wave-instruction (ogl_debug_set: OGL_KNOB_REDUCE_HALF)")
     ap.add_argument("--variants-timeout", type=int, default=240,
                     help="seconds the exchange variants may take in all before every rank prints / exits with what it has")
     ap.add_argument("--no-variants", action="store_true",
@@ -207,8 +207,7 @@ def main():
         parallel.SHARDED_UPDATE = bool(args.dp_sharded_update)
     ops.set_gemm_mode(args.gemm)
     if args.reduce_half is not None:
-        from ogl_amd import _lib as _l0
-        _l0.lib().ogl_reduce_debug_half(args.reduce_half)
+        ops.debug_set("reduce_half", args.reduce_half)
     wl = WORKLOADS[args.workload]
     B, S, H, bt = wl["batch"], wl["samples"], wl["hidden"], wl["batch_timestep"]
     if wl.get("snapshot"):
@@ -518,6 +517,9 @@ def main():
             a["bytes"] += (meta["n_dst"] * meta["fanout"] * 4 * meta["d"] + meta["n_src"] * meta["d"] * ((4 if meta["out"] else 0) +
                            (6 if meta["image"] else 0) + (4 if meta["mask"] else 0)))
             a["bytes_8d"] = a.get("bytes_8d", 0.0) + meta["n_dst"] * meta["fanout"] * 4 * meta["d"] + meta["n_src"] * 4 * meta["d"]
+        elif name == "ogl_reduce_bwd_seg_apply_t":                   # the same backward written as the transposed group-major image (k_seg_groups)
+            a["bytes"] += (meta["n_dst"] * meta["fanout"] * 4 * meta["d"] + meta["n_src"] * meta["d"] * (6 + (4 if meta["mask"] else 0)))
+            a["bytes_8d"] = a.get("bytes_8d", 0.0) + meta["n_dst"] * meta["fanout"] * 4 * meta["d"] + meta["n_src"] * 4 * meta["d"]
         elif name == "ogl_relu_bwd_img":                             # dy, y read; masked dy + its image written
             a["bytes"] += meta["M"] * meta["N"] * (4 + 4 + 4 + 6)
         elif name == "ogl_x3_split":
@@ -553,12 +555,15 @@ def main():
                          "Infinity-Cache hits are included (MI355X_MICROARCH.md), so traffic / time bounds the HBM rate from above — "
                          "a plain streamed copy tops out at ~6.3 TB/s on this part")
     roof_mean_bwd = None
-    sagg = agg.get("ogl_reduce_bwd_seg_apply")
+    sagg = agg.get("ogl_reduce_bwd_seg_apply_t") or agg.get("ogl_reduce_bwd_seg_apply")
     if sagg:
-        # the longest launch class dominates: report the pooled figure over the step's launches (layer 0's is >= 95 % of the bytes)
+        # the longest launch class dominates: the first layer's launch ('meanpool': the group-wise one, alone in its class; 'mean': the
+        # pooled figure over the step's row-wise launches)
         ach8 = sagg["bytes_8d"] / sagg["ms"] / 1e6
-        roof_mean_bwd = dict(kernel="k_seg_reduce + k_seg_fixup (mean backward as a planned segmented gather: edges sorted by source, "
-                                    "64-entry tiles, no atomics)", bound="hbm", achieved=round(ach8, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+        seg_kernel = ("k_seg_groups (mean backward of the first layer as the transposed group-major image: one block per source group, the "
+                      "planned lists as scalar loads, no atomics)" if "ogl_reduce_bwd_seg_apply_t" in agg else
+                      "k_seg_reduce + k_seg_fixup (mean backward as a planned segmented gather: edges sorted by source, 64-entry tiles, no atomics)")
+        roof_mean_bwd = dict(kernel=seg_kernel, bound="hbm", achieved=round(ach8, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                              frac=round(ach8 / HBM_PEAK_GBS, 4), traffic=None, ms_per_step=round(sagg["ms"] / prof_steps, 4),
                              algorithmic_bytes_per_step=round(sagg["bytes_8d"] / prof_steps),
                              bytes_moved_per_step=round(sagg["bytes"] / prof_steps),

@@ -45,9 +45,8 @@ enum { OGL_REDUCE_MEAN = 0, OGL_REDUCE_MAX = 1, OGL_REDUCE_SUM = 2 };
  *                   <= 2^-23 |a*b|), same tolerances in the tests; 1.2-1.4x faster where an operand is
  *                   reduction-contiguous, slower for the weight-gradient layout;
  *   OGL_GEMM_AUTO   BF16X6 for forward / input-gradient GEMMs, F32 for weight-gradient GEMMs. */
-enum { OGL_GEMM_F32 = 0, OGL_GEMM_BF16X6 = 1, OGL_GEMM_AUTO = 2 };
-int ogl_set_gemm_mode(int mode);
-int ogl_get_gemm_mode(void);
+enum { OGL_GEMM_F32 = 0, OGL_GEMM_BF16X6 = 1, OGL_GEMM_AUTO = 2, OGL_GEMM_QUERY = -1 };
+int ogl_set_gemm_mode(int mode); /* OGL_OK / OGL_EINVAL; OGL_GEMM_QUERY changes nothing and returns the current mode */
 
 typedef struct ogl_graph ogl_graph_t;
 typedef void* ogl_stream_t; /* hipStream_t */
@@ -58,6 +57,20 @@ int ogl_version(void);
 const char* ogl_source_hash(void);
 const char* ogl_status_string(int status);
 int ogl_last_hip_error(void); /* hipError_t of the most recent OGL_EHIP on this thread */
+/* Diagnostics (tests and same-process A/B runs; never on a hot path): pin which of two forms of a kernel runs — every form returns the
+ * same bits.  `previous` (nullable) receives the old setting.  OGL_EINVAL for an unknown knob or a value outside its range.
+ *   OGL_KNOB_X3_TILE        tile of the plain / EXT one-split row-major image products — 0: 256 x 128, 1: 128 x 128, 2: 192 x 128; -1 returns
+ *                           to the automatic choice.  Every tile computes every output element with the same sequence of MFMAs.
+ *   OGL_KNOB_X3_STAGGER     1 / 0 = the producer / consumer image GEMM with STAGGERED multiplier waves (waves 4-7 run the last column
+ *                           block of every step but a tile's last one behind the next step's opening barrier, on fragments kept in
+ *                           registers: the matrix pipe has work while its SIMD partner's fragments arrive) / with every wave opening a
+ *                           step on its fragment loads; 3 = staggered + a static issue priority for waves 4-7; -1 = OGL_X3_STAGGER
+ *                           (default 3).  Every accumulator sees its reduction steps in the same order either way.
+ *   OGL_KNOB_BLOCK_MIN_LDS  0 = the per-id minima of ogl_build_block_batched (n_ids > 0) through global atomics even where its LDS form applies.
+ *   OGL_KNOB_REDUCE_HALF    1 / 0 = the max aggregator WITHOUT argmax over rows of <= 128 floats (the inference passes over a narrow
+ *                           projection table) reads two neighbour rows per wave-instruction (half a wave per row) / one. */
+enum { OGL_KNOB_X3_TILE = 0, OGL_KNOB_X3_STAGGER = 1, OGL_KNOB_BLOCK_MIN_LDS = 2, OGL_KNOB_REDUCE_HALF = 3 };
+int ogl_debug_set(int knob, int value, int* previous);
 
 /* ------------------------------------------------------------------------------------------
  * Snapshot adjacency (replaces the DGLGraph the sampler reads:
@@ -115,9 +128,6 @@ int ogl_fill_zero(void* ptr, int64_t bytes, ogl_stream_t stream);
  * bytes) = src[0 .. bytes) as one float4 per thread (the fastest form on this part: tools/micro/stream_copy.hip).  16-byte aligned, bytes a
  * multiple of 16. */
 int ogl_stream_copy(const void* src, void* dst, int64_t bytes, ogl_stream_t stream);
-/* diagnostic: 1 / 0 = the max aggregator WITHOUT argmax over rows of <= 128 floats (the inference passes over a narrow projection
- * table) reads two neighbour rows per wave-instruction (half a wave per row) / one; the same bits.  Returns the old value. */
-int ogl_reduce_debug_half(int on);
 int ogl_gather_i64(const int64_t* table, int64_t n_rows, const int64_t* ids, int64_t n,
                    int64_t* out, ogl_stream_t stream);
 
@@ -179,8 +189,8 @@ int ogl_reduce_bwd(const float* dout, int64_t ldo, const int32_t* idx32, const i
  *                              ogl_linear_bwd_weight_x3k reads as its dy operand (interleave -1) — the first layer's pooled-row
  *                              gradient is then never materialised in fp32.  d a multiple of 4, <= 1024; 16-byte aligned rows. */
 int64_t ogl_reduce_bwd_seg_workspace_bytes(int64_t n_dst, int fanout, int d, int64_t n_src);
-int ogl_reduce_bwd_seg_plan(const int32_t* idx, int64_t n_dst, int fanout, int64_t n_src, void* workspace, int64_t workspace_bytes,
-                            ogl_stream_t stream);
+int ogl_reduce_bwd_seg_plan(const int32_t* idx, int64_t n_dst, int fanout, int64_t n_src, int group_lists, void* workspace,
+                            int64_t workspace_bytes, ogl_stream_t stream);
 int ogl_reduce_bwd_seg_apply(const float* dout, int64_t ldd, const int32_t* idx, int64_t n_dst, int fanout, int d, int op, int64_t n_src,
                              const float* mask, int64_t ldm, float* out, int64_t ldo, void* image, void* workspace,
                              int64_t workspace_bytes, ogl_stream_t stream);
@@ -188,12 +198,11 @@ int ogl_reduce_bwd_seg_apply(const float* dout, int64_t ldd, const int32_t* idx,
  * layout ogl_pool_bwd_x3 writes: ogl_x3_image_bytes(d, 32 G) bytes): the dy operand of ogl_linear_bwd_weight_x3k with interleave = G,
  * i.e. the 'meanpool' first layer's fc_pool weight gradient on the same 256 x 128 product as the 'pool' mode's
  * (R/train/graphsage/pytorch/aggregator_dgl.py:178-186).
- *   ogl_reduce_bwd_seg_plan_groups   after ogl_reduce_bwd_seg_plan, on a stream ordered behind it: the planned lists copied GROUP-MAJOR into
- *                                    the same workspace (gradient-free like the plan: beside the forward pass);
+ *   ogl_reduce_bwd_seg_plan(..., group_lists = 1, ...)   the plan + its lists copied GROUP-MAJOR into the same workspace (two more launches,
+ *                                    gradient-free like the plan: beside the forward pass);
  *   ogl_reduce_bwd_seg_apply_t       one block per source group, a thread per two columns, the group's entries read as one block-uniform
  *                                    run, sums in the plan's list order, no partial rows and no fix-up launch.  d <= 640; rows 8-byte
  *                                    aligned (even leading dimensions); mask nullable. */
-int ogl_reduce_bwd_seg_plan_groups(int64_t n_dst, int fanout, int64_t n_src, void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
 int ogl_reduce_bwd_seg_apply_t(const float* dout, int64_t ldd, int64_t n_dst, int fanout, int d, int op, int64_t n_src, const float* mask,
                                int64_t ldm, void* image, const void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
 
@@ -319,15 +328,6 @@ int ogl_x3_split_t(const float* src, int64_t ld, const int64_t* rows, int64_t nr
  * the kernel is d(s_memtime) / d(s_memrealtime) x 100 MHz.  Pass NULL to switch off.  `reserved` is ignored.  Not part of
  * the hot path. */
 int ogl_x3_debug_stamps(void* buf, int reserved);
-/* 1 / 0 = the producer / consumer image GEMM with STAGGERED multiplier waves (waves 4-7 run the last column block of every step but a
- * tile's last one behind the next step's opening barrier, on fragments kept in registers: the matrix pipe has work while its SIMD
- * partner's fragments arrive) / with every wave opening a step on its fragment loads; -1 = OGL_X3_STAGGER (default on).  Every
- * accumulator sees its reduction steps in the same order either way: the same bits.  Returns the old value. */
-int ogl_x3_debug_stagger(int on);
-/* Diagnostics (A/B of tile shapes inside one process, tests): cfg >= 0 pins the tile of the plain / EXT one-split row-major image
- * products — 0: 256 x 128, 1: 128 x 128, 2: 192 x 128 — and -1 returns to the automatic choice.  Every tile computes every output
- * element with the same sequence of MFMAs: results are bit-identical across tiles.  OGL_EINVAL outside [-1, 2].  Not part of the hot path. */
-int ogl_x3_debug_tile(int cfg);
 /* Diagnostics (bench.py): the image-GEMM instantiation the LAST ogl_linear_*_x3* call launched, template arguments as written at the
  * launch site (trailing defaults omitted), e.g. "k_gemm_x3p<4, 2, 2, 2, 2, false, true>"; "" before the first launch.  Static storage.
  * bench.py compares it with the kernel name recorded in the committed rocprofv3 --pmc pass before quoting that pass's HBM-side
@@ -372,13 +372,12 @@ typedef struct ogl_x3_split_part {
   const float* vec1; const float* vec2;
   void* image; int64_t image_row_bytes; int64_t group_offset;
 } ogl_x3_split_part;
-int ogl_x3_split_multi(const ogl_x3_split_part* parts, int n_parts, ogl_stream_t stream);
-/* ogl_x3_split_multi with the optimiser's per-step scalars riding in the same launch (what ogl_adam_step_multi_slabs with prepare = 1
- * computes in a one-thread launch of its own at the END of a step: ++*step_dev, scalars_dev[0] = lr / (1 - beta1^t), scalars_dev[1] =
- * 1 / sqrt(1 - beta2^t), double arithmetic): moved to the launch that STARTS the step; the step's optimiser launch then passes
- * prepare = 0 to ogl_adam_step_multi_slabs.  n_parts >= 1. */
-int ogl_x3_split_multi_adam(const ogl_x3_split_part* parts, int n_parts, int64_t* step_dev, float* scalars_dev, double lr, double beta1,
-                            double beta2, ogl_stream_t stream);
+/* step_dev / scalars_dev (both or neither; NULL: a plain split launch): the optimiser's per-step scalars riding in the same launch (what
+ * ogl_adam_step_multi_slabs with prepare = 1 computes in a one-thread launch of its own at the END of a step: ++*step_dev, scalars_dev[0] =
+ * lr / (1 - beta1^t), scalars_dev[1] = 1 / sqrt(1 - beta2^t), double arithmetic) moved to the launch that STARTS the step; the step's
+ * optimiser launch then passes prepare = 0 to ogl_adam_step_multi_slabs.  n_parts >= 1. */
+int ogl_x3_split_multi(const ogl_x3_split_part* parts, int n_parts, int64_t* step_dev, float* scalars_dev, double lr, double beta1,
+                       double beta2, ogl_stream_t stream);
 /* ogl_relu_bwd that also writes the bf16x3 image of its result (M + 1 rows, reduction length N, no appended slot) = what
  * ogl_x3_split(out) would build: the masked gradient of a fused-ReLU projection (autograd of F.relu in
  * R/train/graphsage/pytorch/graphsage_dgl.py:29-31) is the A operand of the input-gradient product that follows. */
@@ -425,22 +424,15 @@ int ogl_linear_bwd_weight_x3(const void* dyT_img, const void* xT_img, int64_t M,
 int ogl_sample_layer_batched(const ogl_graph_t* g, const int64_t* dst_base, const int64_t* dst_start,
                              const int64_t* dst_count, int nb, int fanout, uint64_t seed, const uint64_t* ctr,
                              int layer, int64_t* picks, ogl_stream_t stream);
-int64_t ogl_block_workspace_bytes_batched(const int64_t* dst_count, int nb, int fanout);
+/* n_ids <= 0: no bound on the vertex ids (an open-addressing hash table per batch).  n_ids > 0: the caller knows an upper bound of
+ * the vertex ids (every id in dst / picks is < n_ids, e.g. the graph's vertex count; ids outside [0, n_ids) are treated like negative
+ * ones: no source row, local index -1): a direct-address table of n_ids entries per batch replaces the hash — per position one LDS atomic
+ * (id range cut into LDS-sized pieces, n_ids <= 589 824) or one no-return global atomicMin, instead of atomicCAS + atomicMin + probing;
+ * the same results bit for bit.  Workspace then: 8 bytes x n_ids per batch of a 64-batch chunk. */
+int64_t ogl_block_workspace_bytes_batched(const int64_t* dst_count, int nb, int fanout, int64_t n_ids);
 int ogl_build_block_batched(const int64_t* dst_base, const int64_t* dst_start, const int64_t* dst_count, int nb,
-                            const int64_t* picks, int fanout, int64_t* src_ids, int64_t* n_src_out,
+                            const int64_t* picks, int fanout, int64_t n_ids, int64_t* src_ids, int64_t* n_src_out,
                             int32_t* local_idx, void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
-/* The same build when the caller knows an upper bound of the vertex ids (every id in dst / picks is < n_ids, e.g. the graph's
- * vertex count; ids outside [0, n_ids) are treated like negative ones: no source row, local index -1): a direct-address table of
- * n_ids entries per batch replaces the hash — per position one LDS atomic (id range cut into LDS-sized pieces, n_ids <= 589 824) or one
- * no-return global atomicMin, instead of atomicCAS + atomicMin + probing.
- * Results are bit-identical to ogl_build_block_batched.  Workspace: 8 bytes x n_ids per batch of a 64-batch chunk. */
-/* diagnostic: 0 = the per-id minima of ogl_build_block_batched_ids through global atomics even where its LDS form applies (n_ids <=
- * 16 x 36 864: a workgroup per (batch, id range) keeps its range's minima in LDS — no global atomics); returns the old value. */
-int ogl_block_debug_min_lds(int on);
-int64_t ogl_block_workspace_bytes_batched_ids(const int64_t* dst_count, int nb, int fanout, int64_t n_ids);
-int ogl_build_block_batched_ids(const int64_t* dst_base, const int64_t* dst_start, const int64_t* dst_count, int nb,
-                                const int64_t* picks, int fanout, int64_t n_ids, int64_t* src_ids, int64_t* n_src_out,
-                                int32_t* local_idx, void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * nn.CrossEntropyLoss (R/train/graphsage/pytorch/model.py:20,105,147,198,244):
@@ -459,29 +451,23 @@ int ogl_ce_fwd_bwd(const float* logits, int64_t ldl, const int64_t* labels, int6
  * launch each on the 32-seed rungs. */
 int ogl_ce_fwd_bwd_mean_gather(const float* logits, int64_t ldl, const int64_t* label_table, int64_t n_labels, const int64_t* label_ids,
                                int64_t B, int C, float grad_scale, float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean,
-                               float* zero_buf, int64_t zero_floats, ogl_stream_t stream);
-/* ... that also prepares the optimiser's step (what ogl_x3_split_multi_adam does for steps that have a weight-image launch): ++*step_dev,
- * scalars_dev[0] = lr / (1 - beta1^t), scalars_dev[1] = 1 / sqrt(1 - beta2^t) — torch.optim.Adam's bias corrections
- * (R/train/graphsage/pytorch/model.py:24-25) in double arithmetic; the optimiser launch of the step then runs with prepare = 0. */
-int ogl_ce_fwd_bwd_mean_gather_adam(const float* logits, int64_t ldl, const int64_t* label_table, int64_t n_labels, const int64_t* label_ids,
-                                    int64_t B, int C, float grad_scale, float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean,
-                                    float* zero_buf, int64_t zero_floats, int64_t* step_dev, float* scalars_dev, double lr, double beta1,
-                                    double beta2, ogl_stream_t stream);
+                               float* zero_buf, int64_t zero_floats, int64_t* step_dev, float* scalars_dev, double lr, double beta1,
+                               double beta2, ogl_stream_t stream);
+/* (step_dev / scalars_dev, both or neither: the launch also prepares the optimiser's step — what ogl_x3_split_multi does for steps that
+ * have a weight-image launch —: ++*step_dev, scalars_dev[0] = lr / (1 - beta1^t), scalars_dev[1] = 1 / sqrt(1 - beta2^t) — torch.optim.Adam's
+ * bias corrections (R/train/graphsage/pytorch/model.py:24-25) in double arithmetic; the optimiser launch of the step then runs with
+ * prepare = 0.) */
 /* The same for ANY batch size (one wave per row over a grid): the mean is summed by the last block to finish, in the fixed
  * order of the one-workgroup form (bit-identical to it).  `counter`: one zero-initialised device word the caller allocates once
  * (the last block resets it; one counter per stream that may run this concurrently).  loss_rows is required.  zero_buf
  * (nullable; 16-byte aligned, zero_floats a multiple of 4): ALSO filled with zeros by the same grid — the atomic-scatter target
  * of the backward pass that follows (autograd of the max-pool in R/train/graphsage/pytorch/graphsage_dgl.py:3's SAGEConv). */
-int ogl_ce_fwd_bwd_mean_grid(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C, float grad_scale,
-                             float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean, unsigned int* counter,
-                             float* zero_buf, int64_t zero_floats, ogl_stream_t stream);
-/* ogl_ce_fwd_bwd_mean_grid with the label gather inside the launch: label of row i = label_table[label_ids[i]] (an id outside
- * [0, n_labels) = no label: what ogl_gather_i64 would have written as -1) — graph.ndata['target'][seeds]
- * (R/train/graphsage/pytorch/model.py:91,183) costs no launch of its own. */
-int ogl_ce_fwd_bwd_mean_grid_gather(const float* logits, int64_t ldl, const int64_t* label_table, int64_t n_labels,
-                                    const int64_t* label_ids, int64_t B, int C, float grad_scale, float* loss_rows, float* dlogits,
-                                    int64_t lddl, float* loss_mean, unsigned int* counter, float* zero_buf, int64_t zero_floats,
-                                    ogl_stream_t stream);
+int ogl_ce_fwd_bwd_mean_grid(const float* logits, int64_t ldl, const int64_t* label_table, int64_t n_labels, const int64_t* label_ids,
+                             int64_t B, int C, float grad_scale, float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean,
+                             unsigned int* counter, float* zero_buf, int64_t zero_floats, ogl_stream_t stream);
+/* (label_ids NULL: label_table holds the B labels themselves.  Else the label gather is inside the launch: label of row i =
+ * label_table[label_ids[i]] (an id outside [0, n_labels) = no label: what ogl_gather_i64 would have written as -1) —
+ * graph.ndata['target'][seeds] (R/train/graphsage/pytorch/model.py:91,183) costs no launch of its own.) */
 
 /* torch.optim.Adam(lr) single-tensor update (R/train/graphsage/pytorch/model.py:24-25,107).
  * Hyper-parameters are doubles (as Python floats are) so 1-beta is rounded to fp32 once, like torch. */
@@ -686,7 +672,7 @@ int ogl_small_pool_layer_bwd(const float* dy, int64_t lddy, const float* y, int6
  *        zero_buf / zero_floats (multiple of 4, 16-byte aligned, nullable): a caller buffer cleared by fill-only blocks of the grid.
  *   ogl_small_pool_layer_bwd_pool: block 0 sums what crosses destinations — dWs / dWn [Hout, Hin], dbs / dbn [Hout] (nullable) from
  *        dlogits, h's head rows and neigh; *loss_mean = mean(loss_rows); step_dev / scalars_dev (both or neither): the optimiser's
- *        per-step scalars as in ogl_ce_fwd_bwd_mean_gather_adam — the other blocks run fc_pool through the winners: dWp [Hin, Hin],
+ *        per-step scalars as in ogl_ce_fwd_bwd_mean_gather — the other blocks run fc_pool through the winners: dWp [Hin, Hin],
  *        dbp (nullable), the winners' rows added into dh with float atomics.  A root gradient other than 1: scale dlogits, G and dh
  *        before this call. */
 int ogl_small_pool_loss_fits(int64_t n_src, int64_t n_dst, int fanout, int Hin, int Hout);
@@ -749,7 +735,7 @@ int ogl_small_first_layer_bwd(const float* dout, int64_t lddo, const float* y, i
  * [0, n_idx) or whose id is outside [0, n_rows) contributes nothing.  rows: [n_rows, F] read as float4 (ldr % 4 == 0, 16-byte aligned);
  * n_dst <= 2048; sums in destination order (reproducible, no atomics).  The optional tail (loss_mean and / or step_dev non-NULL):
  * *loss_mean = mean(loss_rows[0 .. n_loss)) in the order of ogl_ce_fwd_bwd_mean, and the optimiser's per-step scalars as in
- * ogl_ce_fwd_bwd_mean_gather_adam.  What a 32-seed step uses it for: the first layer's three weight gradients AND the last layer's
+ * ogl_ce_fwd_bwd_mean_gather.  What a 32-seed step uses it for: the first layer's three weight gradients AND the last layer's
  * three (G = its routed gradient / dlogits, rows = its input rows / neigh), the deferred mean and Adam's scalars — one launch. */
 typedef struct {
   const float* G; int64_t ldg;

@@ -21,10 +21,10 @@ _u64 = C.c_uint64
 SIGNATURES = {
     "ogl_version": (_i, []),
     "ogl_source_hash": (C.c_char_p, []),
+    "ogl_debug_set": (_i, [_i, _i, _p]),
     "ogl_status_string": (C.c_char_p, [_i]),
     "ogl_last_hip_error": (_i, []),
     "ogl_set_gemm_mode": (_i, [_i]),
-    "ogl_get_gemm_mode": (_i, []),
     "ogl_graph_create": (_i, [_p, _p, _p, _i64, _i64, C.POINTER(_p)]),
     "ogl_graph_set_snapshot": (_i, [_p, _i64, _i64, _p]),
     "ogl_graph_degrees": (_i, [_p, C.POINTER(_p)]),
@@ -36,7 +36,6 @@ SIGNATURES = {
     "ogl_gather_rows": (_i, [_p, _i64, _i64, _p, _i64, _i, _p, _i64, _p]),
     "ogl_fill_zero": (_i, [_p, _i64, _p]),
     "ogl_stream_copy": (_i, [_p, _p, _i64, _p]),
-    "ogl_reduce_debug_half": (_i, [_i]),
     "ogl_gather_i64": (_i, [_p, _i64, _p, _i64, _p, _p]),
     "ogl_dropout_rows": (_i, [_p, _i64, _p, _i64, _i64, _i, _d, _u64, _u64, _p, _i64, _p]),
     "ogl_reduce_fwd": (_i, [_p, _i64, _i64, _p, _p, _i64, _i, _i, _i, _p, _i64, _p, _p]),
@@ -45,9 +44,8 @@ SIGNATURES = {
     "ogl_reduce_fwd_mean_img": (_i, [_p, _i64, _i64, _p, _p, _i64, _i, _i, _p, _i64, _p, _p]),
     "ogl_reduce_fwd_rows_mean_img": (_i, [_p, _i64, _i64, _p, _p, _i64, _i64, _i, _i, _p, _i64, _p, _p]),
     "ogl_reduce_bwd_seg_workspace_bytes": (_i64, [_i64, _i, _i, _i64]),
-    "ogl_reduce_bwd_seg_plan": (_i, [_p, _i64, _i, _i64, _p, _i64, _p]),
+    "ogl_reduce_bwd_seg_plan": (_i, [_p, _i64, _i, _i64, _i, _p, _i64, _p]),
     "ogl_reduce_bwd_seg_apply": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p]),
-    "ogl_reduce_bwd_seg_plan_groups": (_i, [_i64, _i, _i64, _p, _i64, _p]),
     "ogl_reduce_bwd_seg_apply_t": (_i, [_p, _i64, _i64, _i, _i, _i, _i64, _p, _i64, _p, _p, _i64, _p]),
     "ogl_linear_fwd": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p,
                             _p, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p]),
@@ -62,11 +60,8 @@ SIGNATURES = {
     "ogl_linear_bwd_weight_t": (_i, [_p, _i64, _p, _i64, _i64, _i, _i, _p, _i64, _p, _p, _i64, _p]),
     "ogl_transpose": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _p]),
     "ogl_sample_layer_batched": (_i, [_p, _p, _p, _p, _i, _i, _u64, _p, _i, _p, _p]),
-    "ogl_block_workspace_bytes_batched": (_i64, [_p, _i, _i]),
-    "ogl_build_block_batched": (_i, [_p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _i64, _p]),
-    "ogl_block_debug_min_lds": (_i, [_i]),
-    "ogl_block_workspace_bytes_batched_ids": (_i64, [_p, _i, _i, _i64]),
-    "ogl_build_block_batched_ids": (_i, [_p, _p, _p, _i, _p, _i, _i64, _p, _p, _p, _p, _i64, _p]),
+    "ogl_block_workspace_bytes_batched": (_i64, [_p, _i, _i, _i64]),
+    "ogl_build_block_batched": (_i, [_p, _p, _p, _i, _p, _i, _i64, _p, _p, _p, _p, _i64, _p]),
     "ogl_pool_bwd_x3_workspace_bytes": (_i64, [_i64, _i, _i, _i64]),
     "ogl_pool_bwd_x3": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i, _i, _i64, _p, _p, _i64, _p]),
     "ogl_pool_bwd_x3_plan": (_i, [_p, _p, _i64, _p, _i64, _i, _i, _i64, _p, _i64, _p]),
@@ -75,8 +70,6 @@ SIGNATURES = {
     "ogl_x3_split": (_i, [_p, _i64, _p, _i64, _i64, _i, _i, _p, _p, _p]),
     "ogl_x3_split_t": (_i, [_p, _i64, _p, _i64, _i64, _i, _i, _i64, _p, _p]),
     "ogl_x3_debug_stamps": (_i, [_p, _i]),
-    "ogl_x3_debug_stagger": (_i, [_i]),
-    "ogl_x3_debug_tile": (_i, [_i]),
     "ogl_x3_last_kernel": (C.c_char_p, []),
     "ogl_out_layer_fwd_ce_fits": (_i, [_i64, _i, _i, _i]),
     "ogl_out_layer_fwd_ce": (_i, [_p, _i64, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p, _i64, _p, _p, _i, _p, _i64, _p, _p, _i64,
@@ -88,8 +81,7 @@ SIGNATURES = {
     "ogl_linear_fwd_x3": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i, _i, _p, _i64, _p]),
     "ogl_linear_fwd_x3_ext": (_i, [_p, _i64, _p, _i64, _i, _p, _i64, _p, _i64, _i, _i64, _p, _i, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i, _p, _i64,
                                    _p, _p]),
-    "ogl_x3_split_multi": (_i, [_p, _i, _p]),
-    "ogl_x3_split_multi_adam": (_i, [_p, _i, _p, _p, _d, _d, _d, _p]),
+    "ogl_x3_split_multi": (_i, [_p, _i, _p, _p, _d, _d, _d, _p]),
     "ogl_relu_bwd_img": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _p, _p]),
     "ogl_x3_split_into": (_i, [_p, _i64, _i64, _i, _i, _p, _p, _i64, _i64, _p]),
     "ogl_linear_bwd_weight_x3_workspace_bytes": (_i64, [_i64, _i, _i]),
@@ -97,10 +89,8 @@ SIGNATURES = {
     "ogl_linear_bwd_weight_x3k": (_i, [_p, _i64, _p, _i64, _p, _i64, _i64, _i, _i, _i, _p, _i64, _p, _p, _p, _i64, _p]),
     "ogl_linear_bwd_weight_x3": (_i, [_p, _p, _i64, _i, _i, _p, _i64, _p, _p, _i64, _p]),
     "ogl_ce_fwd_bwd": (_i, [_p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p]),
-    "ogl_ce_fwd_bwd_mean_grid": (_i, [_p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p, _p, _i64, _p]),
-    "ogl_ce_fwd_bwd_mean_gather": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p, _i64, _p]),
-    "ogl_ce_fwd_bwd_mean_gather_adam": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p, _i64, _p, _p, _d, _d, _d, _p]),
-    "ogl_ce_fwd_bwd_mean_grid_gather": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p, _p, _i64, _p]),
+    "ogl_ce_fwd_bwd_mean_grid": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p, _p, _i64, _p]),
+    "ogl_ce_fwd_bwd_mean_gather": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _f, _p, _p, _i64, _p, _p, _i64, _p, _p, _d, _d, _d, _p]),
     "ogl_adam_step": (_i, [_p, _p, _p, _p, _i64, _i, _d, _d, _d, _d, _p]),
     "ogl_argmax_confusion": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p]),
     "ogl_sample_layer_dev": (_i, [_p, _p, _i64, _i, _u64, _p, _i, _p, _p]),

@@ -278,8 +278,8 @@ k_reduce_fwd_generic(const float* __restrict__ src, int64_t lds, int64_t n_src, 
   }
 }
 
-static int g_reduce_half = 1;      // (ogl_reduce_debug_half: tests and A/B runs pin the one-row-per-wave form)
-extern "C" int ogl_reduce_debug_half(int on) { const int old = g_reduce_half; g_reduce_half = on ? 1 : 0; return old; }
+static int g_reduce_half = 1;      // (ogl_debug_set(OGL_KNOB_REDUCE_HALF): tests and A/B runs pin the one-row-per-wave form)
+int oglx_knob_reduce_half(int on, int* prev) { *prev = g_reduce_half; g_reduce_half = on ? 1 : 0; return OGL_OK; }
 
 template <int OP, typename IdxT, bool ARG>
 static int launch_reduce_fwd(const float* src, int64_t lds, int64_t n_src, const IdxT* idx, int64_t n_dst,

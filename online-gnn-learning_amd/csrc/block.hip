@@ -444,15 +444,15 @@ static int64_t batched_ws_bytes(const int64_t* dst_count, int nb, int fanout) {
   return worst;
 }
 
-extern "C" int64_t ogl_block_workspace_bytes_batched(const int64_t* dst_count, int nb, int fanout) {
+static int64_t block_workspace_bytes_hash(const int64_t* dst_count, int nb, int fanout) {
   if (nb < 0 || fanout < 0 || (nb > 0 && !dst_count)) return OGL_EINVAL;
   for (int b = 0; b < nb; ++b) if (dst_count[b] < 0) return OGL_EINVAL;
   return batched_ws_bytes(dst_count, nb, fanout);
 }
 
-extern "C" int ogl_build_block_batched(const int64_t* dst_base, const int64_t* dst_start, const int64_t* dst_count, int nb,
-                                       const int64_t* picks, int fanout, int64_t* src_ids, int64_t* n_src_out,
-                                       int32_t* local_idx, void* workspace, int64_t workspace_bytes, ogl_stream_t stream_) {
+static int build_block_hash(const int64_t* dst_base, const int64_t* dst_start, const int64_t* dst_count, int nb,
+                            const int64_t* picks, int fanout, int64_t* src_ids, int64_t* n_src_out,
+                            int32_t* local_idx, void* workspace, int64_t workspace_bytes, ogl_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (nb < 0 || fanout < 0) return OGL_EINVAL;
   if (nb == 0) return OGL_OK;
@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(256) k_block_lookup_d(const int64_t* __restric
 
 // (diagnostic switch: 0 = the minima through global atomics even where the LDS form applies — tests compare the two)
 static int g_block_min_lds = 1;
-extern "C" int ogl_block_debug_min_lds(int on) { const int old = g_block_min_lds; g_block_min_lds = on ? 1 : 0; return old; }
+int oglx_knob_block_min_lds(int on, int* prev) { *prev = g_block_min_lds; g_block_min_lds = on ? 1 : 0; return OGL_OK; }   // (ogl_debug_set)
 
 static int64_t batched_ws_bytes_ids(const int64_t* dst_count, int nb, int fanout, int64_t n_ids) {
   int64_t worst = 16;
@@ -641,17 +641,20 @@ static int64_t batched_ws_bytes_ids(const int64_t* dst_count, int nb, int fanout
   return worst;
 }
 
-extern "C" int64_t ogl_block_workspace_bytes_batched_ids(const int64_t* dst_count, int nb, int fanout, int64_t n_ids) {
-  if (nb < 0 || fanout < 0 || n_ids <= 0 || n_ids >= ((int64_t)1 << 31) || (nb > 0 && !dst_count)) return OGL_EINVAL;
+extern "C" int64_t ogl_block_workspace_bytes_batched(const int64_t* dst_count, int nb, int fanout, int64_t n_ids) {
+  if (n_ids <= 0) return block_workspace_bytes_hash(dst_count, nb, fanout);       // (no bound on the ids: the hash-table form)
+  if (nb < 0 || fanout < 0 || n_ids >= ((int64_t)1 << 31) || (nb > 0 && !dst_count)) return OGL_EINVAL;
   for (int b = 0; b < nb; ++b) if (dst_count[b] < 0) return OGL_EINVAL;
   return batched_ws_bytes_ids(dst_count, nb, fanout, n_ids);
 }
 
-extern "C" int ogl_build_block_batched_ids(const int64_t* dst_base, const int64_t* dst_start, const int64_t* dst_count, int nb,
-                                           const int64_t* picks, int fanout, int64_t n_ids, int64_t* src_ids, int64_t* n_src_out,
-                                           int32_t* local_idx, void* workspace, int64_t workspace_bytes, ogl_stream_t stream_) {
+extern "C" int ogl_build_block_batched(const int64_t* dst_base, const int64_t* dst_start, const int64_t* dst_count, int nb,
+                                       const int64_t* picks, int fanout, int64_t n_ids, int64_t* src_ids, int64_t* n_src_out,
+                                       int32_t* local_idx, void* workspace, int64_t workspace_bytes, ogl_stream_t stream_) {
+  if (n_ids <= 0)                                                 // (no bound on the ids: the hash-table form)
+    return build_block_hash(dst_base, dst_start, dst_count, nb, picks, fanout, src_ids, n_src_out, local_idx, workspace, workspace_bytes, stream_);
   hipStream_t stream = (hipStream_t)stream_;
-  if (nb < 0 || fanout < 0 || n_ids <= 0 || n_ids >= ((int64_t)1 << 31)) return OGL_EINVAL;
+  if (nb < 0 || fanout < 0 || n_ids >= ((int64_t)1 << 31)) return OGL_EINVAL;
   if (nb == 0) return OGL_OK;
   if (!dst_start || !dst_count || !n_src_out) return OGL_EINVAL;
   for (int b = 0; b < nb; ++b) if (dst_count[b] < 0 || dst_start[b] < 0) return OGL_EINVAL;

@@ -14,6 +14,18 @@ extern "C" int ogl_version(void) { return OGL_VERSION; }
 static const char k_source_stamp[] = "OGL_SOURCE_STAMP:" OGL_SOURCE_HASH;     // (build.py finds the marker in the file's bytes)
 extern "C" const char* ogl_source_hash(void) { return k_source_stamp + 17; }
 extern "C" int ogl_last_hip_error(void) { return g_ogl_last_hip_error; }
+extern "C" int ogl_debug_set(int knob, int value, int* previous) {
+  int prev = 0, rc = OGL_EINVAL;
+  switch (knob) {
+    case OGL_KNOB_X3_TILE: rc = oglx_knob_x3_tile(value, &prev); break;
+    case OGL_KNOB_X3_STAGGER: rc = oglx_knob_x3_stagger(value, &prev); break;
+    case OGL_KNOB_BLOCK_MIN_LDS: rc = oglx_knob_block_min_lds(value, &prev); break;
+    case OGL_KNOB_REDUCE_HALF: rc = oglx_knob_reduce_half(value, &prev); break;
+    default: break;
+  }
+  if (rc == OGL_OK && previous) *previous = prev;
+  return rc;
+}
 extern "C" const char* ogl_status_string(int s) {
   switch (s) {
     case OGL_OK: return "OGL_OK";

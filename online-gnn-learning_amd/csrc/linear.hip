@@ -600,11 +600,11 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(GemmArgs g) {
 static int g_gemm_mode = OGL_GEMM_F32;
 
 extern "C" int ogl_set_gemm_mode(int mode) {
+  if (mode == OGL_GEMM_QUERY) return g_gemm_mode;
   if (mode != OGL_GEMM_F32 && mode != OGL_GEMM_BF16X6 && mode != OGL_GEMM_AUTO) return OGL_EINVAL;
   g_gemm_mode = mode;
   return OGL_OK;
 }
-extern "C" int ogl_get_gemm_mode(void) { return g_gemm_mode; }
 
 // 0: 128x128 (2x2 waves of 64x64)   1: 256x64 (narrow N)   2: 64x64 (few tiles: fill the chip / cut the tail)
 static inline int gemm_config(int64_t M, int64_t N, int nsplit, int* BM, int* BN) {

@@ -1215,7 +1215,7 @@ struct X3SplitBatch {
   const float* vec2[OGL_X3_SPLIT_MAX_PARTS];
   unsigned char* img[OGL_X3_SPLIT_MAX_PARTS];      // at the part's first group
   int64_t img_row_bytes[OGL_X3_SPLIT_MAX_PARTS];
-  // optional passenger (ogl_x3_split_multi_adam): the optimiser's per-step scalars — ++*adam_step and {lr / (1 - beta1^t),
+  // optional passenger (ogl_x3_split_multi with step_dev): the optimiser's per-step scalars — ++*adam_step and {lr / (1 - beta1^t),
   // 1 / sqrt(1 - beta2^t)} in double arithmetic, what k_adam_prepare (loss_optim.hip) does as a launch of its own at the END of the
   // step, computed by one thread of this launch at its START
   int64_t* adam_step; float* adam_scal; double adam_lr, adam_b1, adam_b2;
@@ -1321,17 +1321,13 @@ static int x3_split_multi(const ogl_x3_split_part* parts, int n_parts, int64_t* 
   return OGL_OK;
 }
 
-extern "C" int ogl_x3_split_multi(const ogl_x3_split_part* parts, int n_parts, ogl_stream_t stream) {
-  return x3_split_multi(parts, n_parts, nullptr, nullptr, 0.0, 0.0, 0.0, stream);
-}
-
-// ... with the optimiser's per-step scalars riding along (ogl_adam_step_multi_dev's first launch, k_adam_prepare, moved from the END
-// of the step — where its 5 us and the gap in front of it are on the critical path — into the launch that STARTS the step):
-// ++*step_dev; scalars_dev[0] = lr / (1 - beta1^t), scalars_dev[1] = 1 / sqrt(1 - beta2^t).  The optimiser launch of the same step
-// then runs with prepare = 0 (ogl_adam_step_multi_slabs).
-extern "C" int ogl_x3_split_multi_adam(const ogl_x3_split_part* parts, int n_parts, int64_t* step_dev, float* scalars_dev, double lr,
-                                       double beta1, double beta2, ogl_stream_t stream) {
-  if (!step_dev || !scalars_dev) return OGL_EINVAL;
+// step_dev / scalars_dev (both or neither): the optimiser's per-step scalars ride along (k_adam_prepare moved from the END of the step —
+// where its 5 us and the gap in front of it are on the critical path — into the launch that STARTS the step): ++*step_dev;
+// scalars_dev[0] = lr / (1 - beta1^t), scalars_dev[1] = 1 / sqrt(1 - beta2^t).  The optimiser launch of the same step then runs with
+// prepare = 0 (ogl_adam_step_multi_slabs).
+extern "C" int ogl_x3_split_multi(const ogl_x3_split_part* parts, int n_parts, int64_t* step_dev, float* scalars_dev, double lr,
+                                  double beta1, double beta2, ogl_stream_t stream) {
+  if ((step_dev == nullptr) != (scalars_dev == nullptr)) return OGL_EINVAL;
   return x3_split_multi(parts, n_parts, step_dev, scalars_dev, lr, beta1, beta2, stream);
 }
 
@@ -1426,8 +1422,9 @@ extern "C" int ogl_x3_debug_stamps(void* buf, int reserved) {
 }
 
 static int g_x3_tile = -1;
-extern "C" int ogl_x3_debug_tile(int cfg) {
+int oglx_knob_x3_tile(int cfg, int* prev) {                      // (ogl_debug_set, csrc/graph.hip)
   if (cfg < -1 || cfg > 2) return OGL_EINVAL;
+  *prev = g_x3_tile;
   g_x3_tile = cfg;
   return OGL_OK;
 }
@@ -1435,7 +1432,12 @@ extern "C" int ogl_x3_debug_tile(int cfg) {
 // Which instantiation the LAST launch_x3 call ran (template arguments as written at the launch site; trailing defaults omitted):
 // bench.py compares it with the kernel name of the committed PMC pass before quoting that pass's traffic beside a launch it timed.
 static int g_x3_stagger = -1;            // -1: OGL_X3_STAGGER; 0 / 1: pinned (tests, A/B runs)
-extern "C" int ogl_x3_debug_stagger(int on) { const int old = g_x3_stagger; g_x3_stagger = on; return old; }
+int oglx_knob_x3_stagger(int on, int* prev) {
+  if (on < -1 || on > 3) return OGL_EINVAL;
+  *prev = g_x3_stagger;
+  g_x3_stagger = on;
+  return OGL_OK;
+}
 static const char* g_x3_last_kernel = "";
 extern "C" const char* ogl_x3_last_kernel(void) { return g_x3_last_kernel; }
 #define X3P_LAUNCH(...)                                                                           \

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(1024) k_ce_fwd_bwd_mean(const float* __restric
   __shared__ float rows[CE_SMALL_MAX_B];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (adam_step && threadIdx.x == 1023) {
-    // optional passenger (ogl_ce_fwd_bwd_mean_gather_adam): the optimiser's per-step scalars — what k_adam_prepare does as a launch of
+    // optional passenger (ogl_ce_fwd_bwd_mean_gather with step_dev): the optimiser's per-step scalars — what k_adam_prepare does as a launch of
     // its own at the END of the step — computed by one otherwise idle thread of the loss launch
     const int64_t t = *adam_step + 1;
     *adam_step = t;
@@ -115,29 +115,15 @@ __global__ void __launch_bounds__(1024) k_ce_fwd_bwd_mean(const float* __restric
 #define CE_SMALL_MAX_ZERO 65536
 extern "C" int ogl_ce_fwd_bwd_mean_gather(const float* logits, int64_t ldl, const int64_t* label_table, int64_t n_labels,
                                           const int64_t* label_ids, int64_t B, int C, float grad_scale, float* loss_rows, float* dlogits,
-                                          int64_t lddl, float* loss_mean, float* zero_buf, int64_t zero_floats, ogl_stream_t stream) {
+                                          int64_t lddl, float* loss_mean, float* zero_buf, int64_t zero_floats, int64_t* step_dev,
+                                          float* scalars_dev, double lr, double beta1, double beta2, ogl_stream_t stream) {
   if (B <= 0 || B > CE_SMALL_MAX_B || C <= 0 || ldl < C || (dlogits && lddl < C) || n_labels < 0) return OGL_EINVAL;
-  if (!logits || !label_table || !loss_mean) return OGL_EINVAL;
+  if (!logits || !label_table || !loss_mean || ((step_dev == nullptr) != (scalars_dev == nullptr))) return OGL_EINVAL;
   if (zero_floats < 0 || zero_floats > CE_SMALL_MAX_ZERO || (zero_floats > 0 && (!zero_buf || ((uintptr_t)zero_buf & 15) || (zero_floats & 3))))
     return OGL_EINVAL;
-  hipLaunchKernelGGL(k_ce_fwd_bwd_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ldl, label_table, (int)B, C, grad_scale,
-                     loss_rows, dlogits, lddl, loss_mean, label_ids, n_labels, (float4*)zero_buf, (int)(zero_floats / 4));
-  OGL_CHECK_LAUNCH();
-  return OGL_OK;
-}
-
-// ... with the optimiser's per-step scalars riding along (the 32-seed steps have no weight-image launch for them to ride in:
-// ogl_x3_split_multi_adam): ++*step_dev; scalars_dev[0] = lr / (1 - beta1^t), scalars_dev[1] = 1 / sqrt(1 - beta2^t).  The optimiser launch
-// of the same step then runs with prepare = 0.
-extern "C" int ogl_ce_fwd_bwd_mean_gather_adam(const float* logits, int64_t ldl, const int64_t* label_table, int64_t n_labels,
-                                               const int64_t* label_ids, int64_t B, int C, float grad_scale, float* loss_rows,
-                                               float* dlogits, int64_t lddl, float* loss_mean, float* zero_buf, int64_t zero_floats,
-                                               int64_t* step_dev, float* scalars_dev, double lr, double beta1, double beta2,
-                                               ogl_stream_t stream) {
-  if (B <= 0 || B > CE_SMALL_MAX_B || C <= 0 || ldl < C || (dlogits && lddl < C) || n_labels < 0) return OGL_EINVAL;
-  if (!logits || !label_table || !loss_mean || !step_dev || !scalars_dev) return OGL_EINVAL;
-  if (zero_floats < 0 || zero_floats > CE_SMALL_MAX_ZERO || (zero_floats > 0 && (!zero_buf || ((uintptr_t)zero_buf & 15) || (zero_floats & 3))))
-    return OGL_EINVAL;
+  // step_dev / scalars_dev (both or neither): the optimiser's per-step scalars ride along (the 32-seed steps have no weight-image
+  // launch for them to ride in: ogl_x3_split_multi): ++*step_dev; scalars_dev[0] = lr / (1 - beta1^t), scalars_dev[1] = 1 / sqrt(1 -
+  // beta2^t).  The optimiser launch of the same step then runs with prepare = 0.
   hipLaunchKernelGGL(k_ce_fwd_bwd_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ldl, label_table, (int)B, C, grad_scale,
                      loss_rows, dlogits, lddl, loss_mean, label_ids, n_labels, (float4*)zero_buf, (int)(zero_floats / 4), step_dev,
                      scalars_dev, lr, beta1, beta2);
@@ -213,22 +199,15 @@ static int ce_mean_grid(const float* logits, int64_t ldl, const int64_t* labels,
   return OGL_OK;
 }
 
-extern "C" int ogl_ce_fwd_bwd_mean_grid(const float* logits, int64_t ldl, const int64_t* labels, int64_t B, int C, float grad_scale,
-                                        float* loss_rows, float* dlogits, int64_t lddl, float* loss_mean, unsigned int* counter,
-                                        float* zero_buf, int64_t zero_floats, ogl_stream_t stream) {
-  return ce_mean_grid(logits, ldl, labels, nullptr, 0, B, C, grad_scale, loss_rows, dlogits, lddl, loss_mean, counter, zero_buf, zero_floats,
-                      stream);
-}
-
-// The same with the labels gathered inside the launch: label of row i = label_table[label_ids[i]] (an id outside [0, n_labels): no
-// label, as ogl_gather_i64 writes -1) — graph.ndata['target'][seeds] (R/train/graphsage/pytorch/model.py:91,183) without a launch.
-extern "C" int ogl_ce_fwd_bwd_mean_grid_gather(const float* logits, int64_t ldl, const int64_t* label_table, int64_t n_labels,
-                                               const int64_t* label_ids, int64_t B, int C, float grad_scale, float* loss_rows,
-                                               float* dlogits, int64_t lddl, float* loss_mean, unsigned int* counter, float* zero_buf,
-                                               int64_t zero_floats, ogl_stream_t stream) {
-  if (!label_ids) return OGL_EINVAL;
-  return ce_mean_grid(logits, ldl, label_table, label_ids, n_labels, B, C, grad_scale, loss_rows, dlogits, lddl, loss_mean, counter, zero_buf,
-                      zero_floats, stream);
+// label_ids NULL: label_table holds the B labels themselves (n_labels ignored); else the labels are gathered inside the launch: label of
+// row i = label_table[label_ids[i]] (an id outside [0, n_labels): no label, as ogl_gather_i64 writes -1) — graph.ndata['target'][seeds]
+// (R/train/graphsage/pytorch/model.py:91,183) without a launch.
+extern "C" int ogl_ce_fwd_bwd_mean_grid(const float* logits, int64_t ldl, const int64_t* label_table, int64_t n_labels,
+                                        const int64_t* label_ids, int64_t B, int C, float grad_scale, float* loss_rows,
+                                        float* dlogits, int64_t lddl, float* loss_mean, unsigned int* counter, float* zero_buf,
+                                        int64_t zero_floats, ogl_stream_t stream) {
+  return ce_mean_grid(logits, ldl, label_table, label_ids, label_ids ? n_labels : 0, B, C, grad_scale, loss_rows, dlogits, lddl, loss_mean, counter,
+                      zero_buf, zero_floats, stream);
 }
 
 // The update of one element, with every rounding spelled out (explicit fused multiply-adds, no contraction left to the compiler):

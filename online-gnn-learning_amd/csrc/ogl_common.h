@@ -17,6 +17,13 @@ extern thread_local int g_ogl_last_hip_error;
 
 #define OGL_CHECK_LAUNCH() OGL_CHECK_HIP(hipGetLastError())
 
+// the diagnostic knobs behind ogl_debug_set (csrc/graph.hip), each next to the kernel it pins; library-internal
+#define OGL_INTERNAL __attribute__((visibility("hidden")))
+OGL_INTERNAL int oglx_knob_x3_tile(int cfg, int* prev);          // linear_x3.hip
+OGL_INTERNAL int oglx_knob_x3_stagger(int on, int* prev);        // linear_x3.hip
+OGL_INTERNAL int oglx_knob_block_min_lds(int on, int* prev);     // block.hip
+OGL_INTERNAL int oglx_knob_reduce_half(int on, int* prev);       // aggregate.hip
+
 static inline int64_t ogl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t ogl_round_up(int64_t a, int64_t b) { return ogl_cdiv(a, b) * b; }
 __device__ static inline int64_t ogl_cdiv_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -466,7 +466,7 @@ static int64_t seg_ints_lists(int64_t E, int64_t n_src) {
   // cnt [n_src + 1] | start [n_src + 1] | cur [n_src] | bsum [nb] | U [E] | sorted [E] | nlong [4] | longs [E / 64 + 1]
   return (n_src + 1) * 2 + n_src + nb + 2 * E + 4 + (E / 64 + 1) + 16;
 }
-// ... | gbase [G + 1] | gent [E] x int2 (8-byte aligned): the group-major lists of ogl_reduce_bwd_seg_plan_groups
+// ... | gbase [G + 1] | gent [E] x int2 (8-byte aligned): the group-major lists (ogl_reduce_bwd_seg_plan with group_lists = 1)
 static int64_t seg_gbase_off(int64_t E, int64_t n_src) { return ogl_round_up(seg_ints_lists(E, n_src), 2); }
 static int64_t seg_gent_off(int64_t E, int64_t n_src) { return ogl_round_up(seg_gbase_off(E, n_src) + ogl_cdiv(n_src, 32) + 1, 2); }
 static int64_t seg_ints(int64_t E, int64_t n_src) { return seg_gent_off(E, n_src) + 2 * (E + SGG_U); }   // (+ SGG_U entries of padding)
@@ -479,7 +479,9 @@ extern "C" int64_t ogl_reduce_bwd_seg_workspace_bytes(int64_t n_dst, int fanout,
 }
 
 // Plan: needs the indices only (run it beside the forward pass).  workspace: ogl_reduce_bwd_seg_workspace_bytes, 16-byte aligned.
-extern "C" int ogl_reduce_bwd_seg_plan(const int32_t* idx, int64_t n_dst, int fanout, int64_t n_src, void* workspace,
+static int seg_plan_groups(int64_t n_dst, int fanout, int64_t n_src, void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
+
+extern "C" int ogl_reduce_bwd_seg_plan(const int32_t* idx, int64_t n_dst, int fanout, int64_t n_src, int group_lists, void* workspace,
                                        int64_t workspace_bytes, ogl_stream_t stream) {
   if (n_dst < 0 || fanout < 0 || n_src <= 0 || n_src >= (1ll << 31) || n_dst * (int64_t)fanout >= (1ll << 31)) return OGL_EINVAL;
   const int64_t E = n_dst * fanout;
@@ -518,7 +520,7 @@ extern "C" int ogl_reduce_bwd_seg_plan(const int32_t* idx, int64_t n_dst, int fa
                        (const int*)start, n_src, sorted);
     OGL_CHECK_LAUNCH();
   }
-  return OGL_OK;
+  return group_lists ? seg_plan_groups(n_dst, fanout, n_src, workspace, workspace_bytes, stream) : OGL_OK;
 }
 
 // Apply: dsrc = (sum over the planned edge lists of dout rows) / divisor, masked by [mask > 0] when given; written as fp32 rows
@@ -567,10 +569,9 @@ extern "C" int ogl_reduce_bwd_seg_apply(const float* dout, int64_t ldd, const in
   return seg_apply(dout, ldd, idx, n_dst, fanout, d, op, n_src, mask, ldm, out, ldo, image, workspace, workspace_bytes, stream);
 }
 
-// The group-major copy of a planned workspace's lists (after ogl_reduce_bwd_seg_plan, same stream or ordered behind it): what
-// ogl_reduce_bwd_seg_apply_t walks.  Gradient-free like the plan itself.
-extern "C" int ogl_reduce_bwd_seg_plan_groups(int64_t n_dst, int fanout, int64_t n_src, void* workspace, int64_t workspace_bytes,
-                                              ogl_stream_t stream) {
+// The group-major copy of a planned workspace's lists (ogl_reduce_bwd_seg_plan with group_lists = 1): what ogl_reduce_bwd_seg_apply_t
+// walks.  Gradient-free like the plan itself.
+static int seg_plan_groups(int64_t n_dst, int fanout, int64_t n_src, void* workspace, int64_t workspace_bytes, ogl_stream_t stream) {
   if (n_dst < 0 || fanout <= 0 || n_src <= 0 || n_src >= (1ll << 31) || n_dst * (int64_t)fanout >= (1ll << 31)) return OGL_EINVAL;
   const int64_t E = n_dst * fanout;
   if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < ogl_round_up(seg_ints(E, n_src) * 4, 256)) return OGL_EWORKSPACE;

@@ -241,7 +241,7 @@ extern "C" int ogl_small_pool_layer_bwd(const float* dy, int64_t lddy, const flo
 //     fill blocks are dirtying — the launch took 23 us, and 30 beside a 10 MB fill.)
 //   backward (k_small_bwd_b2): block 0 sums what crosses destinations — dWs, dWn, dbs, dbn (rows staged through LDS in chunks of 32
 //     destinations, destination order), the mean of the row losses (the order of k_ce_fwd_bwd_mean) and the optimiser's per-step
-//     scalars (the passenger of ogl_ce_fwd_bwd_mean_gather_adam); the other blocks are k_small_bwd_b (fc_pool through the winners).
+//     scalars (the passenger of ogl_ce_fwd_bwd_mean_gather); the other blocks are k_small_bwd_b (fc_pool through the winners).
 // Every sum runs in the order of the kernels above, so the bits are theirs.  The VALUE of the mean loss exists after the backward
 // launch (NaN until then: the contract of GraphSAGE.forward_loss(defer_mean=True)).  The root gradient of the loss is taken to be 1
 // (ops.backward's unit gradient); the caller scales dlogits / G / dh for any other before the backward launch.

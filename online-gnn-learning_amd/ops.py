@@ -85,8 +85,19 @@ def set_gemm_mode(mode: str):
 
 
 def get_gemm_mode() -> str:
-    m = _lib.lib().ogl_get_gemm_mode()
+    m = _lib.lib().ogl_set_gemm_mode(-1)                  # (OGL_GEMM_QUERY)
     return [k for k, v in GEMM_MODES.items() if v == m][0]
+
+
+KNOBS = {"x3_tile": 0, "x3_stagger": 1, "block_min_lds": 2, "reduce_half": 3}
+
+
+def debug_set(knob: str, value: int) -> int:
+    """Pin a kernel form (``ogl_debug_set``: diagnostics for tests and same-process A/B runs — every form returns the same bits);
+    returns the previous setting."""
+    prev = C.c_int(0)
+    check(_lib.lib().ogl_debug_set(KNOBS[knob], int(value), C.byref(prev)), "ogl_debug_set(%s, %d)" % (knob, value))
+    return prev.value
 
 
 def padded_ld(cols: int) -> int:
@@ -334,7 +345,7 @@ BLOCK_DIRECT_IDS_PER_POSITION = 16
 def build_block_batched_async(dst_base: torch.Tensor, starts, counts, picks: torch.Tensor, n_ids=None):
     """Relabel every batch in one set of launches.  Returns (src_ids packed at row_off * (1 + fanout), n_src_dev [nb],
     local_idx packed like picks) without synchronising; row_off = running sum of counts.  ``n_ids``: every id is < n_ids (the
-    graph's vertex count) — the build then uses a direct-address table (ogl_build_block_batched_ids: same results)."""
+    graph's vertex count) — the build then uses a direct-address table (ogl_build_block_batched with n_ids > 0: same results)."""
     dst_base = _ids(dst_base)
     nb, total = len(counts), int(sum(counts))
     fanout = picks.shape[1]
@@ -347,16 +358,16 @@ def build_block_batched_async(dst_base: torch.Tensor, starts, counts, picks: tor
     h_counts = _host_i64(counts)
     if (BLOCK_DIRECT and n_ids and 0 < int(n_ids) < 2 ** 31 and 8 * int(n_ids) * min(nb, 64) <= BLOCK_DIRECT_MAX_BYTES
             and int(n_ids) * nb <= BLOCK_DIRECT_IDS_PER_POSITION * total * (1 + fanout)):
-        nbytes = int(_lib.lib().ogl_block_workspace_bytes_batched_ids(h_counts, nb, int(fanout), int(n_ids)))
+        nbytes = int(_lib.lib().ogl_block_workspace_bytes_batched(h_counts, nb, int(fanout), int(n_ids)))
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
-        _launch("ogl_build_block_batched", _lib.lib().ogl_build_block_batched_ids, _ptr(dst_base), _host_i64(starts), h_counts, nb, _ptr(picks),
+        _launch("ogl_build_block_batched", _lib.lib().ogl_build_block_batched, _ptr(dst_base), _host_i64(starts), h_counts, nb, _ptr(picks),
                 int(fanout), int(n_ids), _ptr(src_ids), _ptr(n_src), _ptr(local_idx), _ptr(ws), nbytes, _stream(),
                 meta=dict(n_dst=total, fanout=int(fanout), nb=nb, direct=1))
         return src_ids, n_src, local_idx
-    nbytes = int(_lib.lib().ogl_block_workspace_bytes_batched(h_counts, nb, int(fanout)))
+    nbytes = int(_lib.lib().ogl_block_workspace_bytes_batched(h_counts, nb, int(fanout), 0))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
     _launch("ogl_build_block_batched", _lib.lib().ogl_build_block_batched, _ptr(dst_base), _host_i64(starts), h_counts, nb, _ptr(picks),
-            int(fanout), _ptr(src_ids), _ptr(n_src), _ptr(local_idx), _ptr(ws), nbytes, _stream(),
+            int(fanout), 0, _ptr(src_ids), _ptr(n_src), _ptr(local_idx), _ptr(ws), nbytes, _stream(),
             meta=dict(n_dst=total, fanout=int(fanout), nb=nb))
     return src_ids, n_src, local_idx
 
@@ -1023,12 +1034,12 @@ def weight_images_prepare(requests):
         # the optimiser's per-step scalars ride in this launch (the step's first): its own one-thread launch at the END of the step,
         # and the gap in front of it, leave the critical path
         step_dev, scal, lr, b1, b2 = prime
-        _launch("ogl_x3_split_multi", _lib.lib().ogl_x3_split_multi_adam, C.cast(arr, C.c_void_p), len(parts), _ptr(step_dev), _ptr(scal),
+        _launch("ogl_x3_split_multi", _lib.lib().ogl_x3_split_multi, C.cast(arr, C.c_void_p), len(parts), _ptr(step_dev), _ptr(scal),
                 C.c_double(lr), C.c_double(b1), C.c_double(b2), _stream(), meta=dict(parts=len(parts), adam_prepare=True))
         _ADAM_PRIME["req"], _ADAM_PRIME["served"] = None, (step_dev.data_ptr(), _capturing())
     else:
-        _launch("ogl_x3_split_multi", _lib.lib().ogl_x3_split_multi, C.cast(arr, C.c_void_p), len(parts), _stream(),
-                meta=dict(parts=len(parts)))
+        _launch("ogl_x3_split_multi", _lib.lib().ogl_x3_split_multi, C.cast(arr, C.c_void_p), len(parts), None, None, C.c_double(0.0),
+                C.c_double(0.0), C.c_double(0.0), _stream(), meta=dict(parts=len(parts)))
     if len(_W_IMAGES) > 32:
         _W_IMAGES.clear()               # stale versions of re-assigned parameters: never let them pile up
     import weakref
@@ -1183,11 +1194,8 @@ def reduce_bwd_seg_plan(idx32, d, n_src, side=True, groups=False):
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=idx32.device)
 
     def launch():
-        _launch("ogl_reduce_bwd_seg_plan", _lib.lib().ogl_reduce_bwd_seg_plan, _ptr(idx32), n_dst, fanout, n_src, _ptr(ws), nbytes, _stream(),
-                meta=dict(n_dst=n_dst, fanout=fanout, n_src=n_src))
-        if groups:
-            _launch("ogl_reduce_bwd_seg_plan", _lib.lib().ogl_reduce_bwd_seg_plan_groups, n_dst, fanout, n_src, _ptr(ws), nbytes, _stream(),
-                    meta=dict(n_dst=n_dst, fanout=fanout, n_src=n_src, groups=True))
+        _launch("ogl_reduce_bwd_seg_plan", _lib.lib().ogl_reduce_bwd_seg_plan, _ptr(idx32), n_dst, fanout, n_src, 1 if groups else 0, _ptr(ws),
+                nbytes, _stream(), meta=dict(n_dst=n_dst, fanout=fanout, n_src=n_src, groups=bool(groups)))
 
     plan = PoolPlan(ws, nbytes, None, (n_dst, fanout, d, n_src))
     plan.groups = bool(groups)
@@ -1581,14 +1589,14 @@ def ce_fwd_bwd_mean(logits, labels, want_grad=True):
     if prime is not None and ADAM_PRIME_IN_SPLIT and want_grad:
         # a step without a weight-image launch (the 32-seed rungs): the optimiser's per-step scalars ride in the loss launch instead
         step_dev, scal, lr, b1, b2 = prime
-        _launch("ogl_ce_fwd_bwd_mean", _lib.lib().ogl_ce_fwd_bwd_mean_gather_adam, _ptr(logits), _ld(logits), _ptr(table), table.numel(),
+        _launch("ogl_ce_fwd_bwd_mean", _lib.lib().ogl_ce_fwd_bwd_mean_gather, _ptr(logits), _ld(logits), _ptr(table), table.numel(),
                 _ptr(ids), B, Cc, C.c_float(1.0 / B), _ptr(loss), _ptr(dl), _ld(dl) if dl is not None else 0, _ptr(mean), _ptr(zbuf), zn,
                 _ptr(step_dev), _ptr(scal), C.c_double(lr), C.c_double(b1), C.c_double(b2), _stream(), meta=dict(B=B, C=Cc, adam_prepare=True))
         _ADAM_PRIME["req"], _ADAM_PRIME["served"] = None, (step_dev.data_ptr(), _capturing())
         return mean, loss, dl
     _launch("ogl_ce_fwd_bwd_mean", _lib.lib().ogl_ce_fwd_bwd_mean_gather, _ptr(logits), _ld(logits), _ptr(table), table.numel(), _ptr(ids), B, Cc,
-            C.c_float(1.0 / B), _ptr(loss), _ptr(dl), _ld(dl) if dl is not None else 0, _ptr(mean), _ptr(zbuf), zn, _stream(),
-            meta=dict(B=B, C=Cc))
+            C.c_float(1.0 / B), _ptr(loss), _ptr(dl), _ld(dl) if dl is not None else 0, _ptr(mean), _ptr(zbuf), zn, None, None,
+            C.c_double(0.0), C.c_double(0.0), C.c_double(0.0), _stream(), meta=dict(B=B, C=Cc))
     return mean, loss, dl
 
 
@@ -1681,11 +1689,11 @@ def ce_fwd_bwd_mean_grid(logits, labels, want_grad=True):
             zbuf, zn = ent[0], ent[0].numel()
             ent[3] = True
     if lazy is not None:
-        _launch("ogl_ce_fwd_bwd_mean_grid", _lib.lib().ogl_ce_fwd_bwd_mean_grid_gather, _ptr(logits), _ld(logits), _ptr(lazy.table),
+        _launch("ogl_ce_fwd_bwd_mean_grid", _lib.lib().ogl_ce_fwd_bwd_mean_grid, _ptr(logits), _ld(logits), _ptr(lazy.table),
                 lazy.table.numel(), _ptr(lazy.ids), B, Cc, C.c_float(1.0 / B), _ptr(loss), _ptr(dl), _ld(dl) if dl is not None else 0,
                 _ptr(mean), ctr, _ptr(zbuf), zn, _stream(), meta=dict(B=B, C=Cc))
         return mean, loss, dl
-    _launch("ogl_ce_fwd_bwd_mean_grid", _lib.lib().ogl_ce_fwd_bwd_mean_grid, _ptr(logits), _ld(logits), _ptr(labels), B, Cc,
+    _launch("ogl_ce_fwd_bwd_mean_grid", _lib.lib().ogl_ce_fwd_bwd_mean_grid, _ptr(logits), _ld(logits), _ptr(labels), 0, None, B, Cc,
             C.c_float(1.0 / B), _ptr(loss), _ptr(dl), _ld(dl) if dl is not None else 0, _ptr(mean), ctr, _ptr(zbuf), zn,
             _stream(), meta=dict(B=B, C=Cc))
     return mean, loss, dl

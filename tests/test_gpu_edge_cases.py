@@ -104,7 +104,7 @@ def test_status_codes(ops):
     assert h.ogl_linear_fwd(p(x), 4, None, 0, 4, 8, p(x), 8, 4, None, None, 0, None, 0, 0, None, 0, 0, p(x), 8, None) == -1  # ldx < K
     with pytest.raises(_lib.OglError, match="OGL_EINVAL"):
         _lib.check(-1, "probe")
-    assert h.ogl_set_gemm_mode(9) == -1 and h.ogl_get_gemm_mode() in (0, 1, 2)
+    assert h.ogl_set_gemm_mode(9) == -1 and h.ogl_set_gemm_mode(-1) in (0, 1, 2)        # (-1 = OGL_GEMM_QUERY)
 
 
 def test_ragged_batches_and_tiny_training_steps(ops):

@@ -275,7 +275,7 @@ def test_adam_with_the_step_count_on_the_device():
 
 
 def test_loss_launch_gathers_its_labels():
-    """LazyLabels(table, ids): the grid cross entropy reads label_table[ids[i]] inside its launch (ogl_ce_fwd_bwd_mean_grid_gather) —
+    """LazyLabels(table, ids): the grid cross entropy reads label_table[ids[i]] inside its launch (ogl_ce_fwd_bwd_mean_grid with label_ids) —
     same bits as gathering first (ogl_gather_i64 + ogl_ce_fwd_bwd_mean_grid), ids outside the table are rows without a label in both
     forms; the small-batch and 'none' paths materialise the gather themselves."""
     import ogl_amd  # noqa: F401
@@ -361,8 +361,8 @@ def test_small_loss_launch_gathers_labels_and_clears_a_scatter_target():
     assert float(ops.take_zeroed(big, 5000, 600).abs().max()) == 0.0
     h = ogl_amd._lib.lib()
     assert h.ogl_ce_fwd_bwd_mean_gather(logits.data_ptr(), 8, table.data_ptr(), T, ids.data_ptr(), B, Cc, 1.0, None, None, 0, got[0].data_ptr(),
-                                        slot[0].data_ptr(), 1 << 20, None) == -1
-    assert h.ogl_ce_fwd_bwd_mean_gather(logits.data_ptr(), 8, None, T, ids.data_ptr(), B, Cc, 1.0, None, None, 0, got[0].data_ptr(), None, 0, None) == -1
+                                        slot[0].data_ptr(), 1 << 20, None, None, 0.0, 0.0, 0.0, None) == -1
+    assert h.ogl_ce_fwd_bwd_mean_gather(logits.data_ptr(), 8, None, T, ids.data_ptr(), B, Cc, 1.0, None, None, 0, got[0].data_ptr(), None, 0, None, None, 0.0, 0.0, 0.0, None) == -1
 
 
 def test_fill_zero_any_alignment_and_size():

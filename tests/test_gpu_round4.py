@@ -374,7 +374,7 @@ def test_inrepo_first_layer_without_input_gradient(mode):
 
 
 def test_adam_scalars_ride_in_the_weight_image_launch():
-    """optim.Adam.prime(): the step's weight-image launch (ogl_x3_split_multi_adam) advances the device-side step count and computes
+    """optim.Adam.prime(): the step's weight-image launch (ogl_x3_split_multi with step_dev) advances the device-side step count and computes
     the bias-correction scalars; the optimiser launch then runs without its own prepare launch — same bits as the two-launch form,
     over several steps, and an un-served request falls back to it."""
     import ogl_amd  # noqa: F401
@@ -453,7 +453,7 @@ def test_pipelined_loader_hands_out_the_same_blocks():
 
 @pytest.mark.parametrize("fanout,n_ids", [(25, 50_000), (5, 50_000), (25, 232_965), (3, 700_001)])
 def test_direct_address_block_build_equals_the_hash_build(fanout, n_ids):
-    """ogl_build_block_batched_ids (a table of n_ids entries per batch; the per-id minima kept in LDS by a workgroup per id range, or
+    """ogl_build_block_batched with n_ids > 0 (a table of n_ids entries per batch; the per-id minima kept in LDS by a workgroup per id range, or
     by one no-return atomicMin per position) returns what the hash build returns, bit for bit: ragged batches, an empty batch, duplicated picks, missing neighbours (-1) and ids at both ends of
     the range; and more than one 64-batch chunk."""
     import ogl_amd  # noqa: F401
@@ -480,11 +480,11 @@ def test_direct_address_block_build_equals_the_hash_build(fanout, n_ids):
         ops.BLOCK_DIRECT = True
         got = []
         for lds in (1, 0):           # the minima in LDS (a workgroup per batch and id range; n_ids <= 589 824) / by global atomics
-            was = _lib.lib().ogl_block_debug_min_lds(lds)
+            was = ops.debug_set("block_min_lds", lds)
             try:
                 got.append(ops.build_block_batched_async(dst_base, starts, counts, picks, n_ids=n_ids))
             finally:
-                _lib.lib().ogl_block_debug_min_lds(was)
+                ops.debug_set("block_min_lds", was)
     finally:
         ops.BLOCK_DIRECT = old
     torch.cuda.synchronize()

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_staggered_multiplier_waves_compute_the_same_bits():
-    """k_gemm_x3p with waves 4-7 running each step's last column block behind the NEXT step's opening barrier (ogl_x3_debug_stagger)
+    """k_gemm_x3p with waves 4-7 running each step's last column block behind the NEXT step's opening barrier (ogl_debug_set: OGL_KNOB_X3_STAGGER)
     against every wave opening a step on its fragment loads: the same MFMAs on the same operands, every accumulator in the same
     order — bit for bit on every instantiation the train step and the inference passes launch (256 / 192 / 128-row tiles, early-A
     and one-barrier forms, the two-part / addend / image-writing form, the k-major weight gradients incl. the dual product), on
@@ -19,7 +19,7 @@ def test_staggered_multiplier_waves_compute_the_same_bits():
     from ogl_amd import _lib, ops
     ops.set_gemm_mode("auto")
     lib = _lib.lib()
-    was = lib.ogl_x3_debug_stagger(-1)
+    was = ops.debug_set("x3_stagger", -1)
     try:
         torch.manual_seed(21)
         dev = "cuda"
@@ -46,7 +46,7 @@ def test_staggered_multiplier_waves_compute_the_same_bits():
         outs = {}
         for ea in (1,):
             for stag in (0, 3):
-                lib.ogl_x3_debug_stagger(stag)
+                ops.debug_set("x3_stagger", stag)
                 got, names = [], []
 
                 def take(t):
@@ -77,7 +77,7 @@ def test_staggered_multiplier_waves_compute_the_same_bits():
                 assert torch.equal(a, c), (ea, i)
         assert len(set(outs[(1, 0)][1])) >= 5, outs[(1, 0)][1]                 # (at least five different instantiations ran)
     finally:
-        lib.ogl_x3_debug_stagger(was)
+        ops.debug_set("x3_stagger", was)
         ops.set_gemm_mode("f32")
 
 
@@ -252,11 +252,11 @@ def test_half_wave_max_aggregator_has_the_same_bits(n_src, n_dst, S, d, i64):
     idx[0, 0] = n_src + 7                                                # (past the table: skipped)
     idx_t = torch.as_tensor(idx.astype(np.int64 if i64 else np.int32)).cuda()
     lib = _lib.lib()
-    was = lib.ogl_reduce_debug_half(1)
+    was = ops.debug_set("reduce_half", 1)
     try:
         res = {}
         for half in (0, 1):
-            lib.ogl_reduce_debug_half(half)
+            ops.debug_set("reduce_half", half)
             out, _ = ops.reduce_fwd(src, idx_t, "max")
             o2, _, img = ops.reduce_fwd_img(src, idx_t, want_argmax=False)
             res[half] = (out.clone(), o2.clone(), img.buf.clone())
@@ -270,7 +270,7 @@ def test_half_wave_max_aggregator_has_the_same_bits(n_src, n_dst, S, d, i64):
         want[~valid.any(axis=1)] = 0.0
         np.testing.assert_array_equal(res[1][0].cpu().numpy(), want.astype(np.float32))
     finally:
-        lib.ogl_reduce_debug_half(was)
+        ops.debug_set("reduce_half", was)
 
 
 def test_size_agnostic_first_layer_ignores_what_lies_behind_the_live_sources():
@@ -323,9 +323,8 @@ def test_size_agnostic_first_layer_ignores_what_lies_behind_the_live_sources():
 # in the library.  Everything else in include/ogl_hip.h must be reached by test_every_exported_symbol_is_reached_or_allow_listed.
 ALLOW_UNREACHED = {
     # identification / errors / diagnostics / measurement (never on a hot path)
-    "ogl_version", "ogl_source_hash", "ogl_status_string", "ogl_last_hip_error", "ogl_set_gemm_mode", "ogl_get_gemm_mode",
-    "ogl_x3_debug_stamps", "ogl_x3_debug_stagger", "ogl_x3_debug_tile", "ogl_x3_last_kernel",
-    "ogl_block_debug_min_lds", "ogl_reduce_debug_half", "ogl_stream_copy", "ogl_graph_degrees", "ogl_graph_copy_degrees",
+    "ogl_version", "ogl_source_hash", "ogl_status_string", "ogl_last_hip_error", "ogl_set_gemm_mode", "ogl_debug_set",
+    "ogl_x3_debug_stamps", "ogl_x3_last_kernel", "ogl_stream_copy", "ogl_graph_degrees", "ogl_graph_copy_degrees",
     # the per-batch C-ABI SURVEY.md section 8(b) names (one sampler call, one block build, one gather, one Adam tensor per call): what a
     # reference-side binding calls batch by batch; the package's own loaders use the batched / captured forms of the same kernels
     "ogl_sample_layer", "ogl_build_block", "ogl_block_workspace_bytes", "ogl_gather_rows", "ogl_adam_step",
@@ -333,8 +332,7 @@ ALLOW_UNREACHED = {
     "ogl_sample_layer_dev", "ogl_build_block_padded", "ogl_publish_i64",
     # loss launches of steps whose last layer is NOT fused with nn.CrossEntropyLoss (an arbitrary loss_fn, shapes past the fused
     # kernels' limits, reduction='none' training): tests/test_gpu_kernels.py, test_gpu_round3.py, test_gpu_round4.py
-    "ogl_ce_fwd_bwd_mean_gather", "ogl_ce_fwd_bwd_mean_gather_adam", "ogl_ce_fwd_bwd_mean_grid", "ogl_ce_fwd_bwd_mean_grid_gather",
-    "ogl_loss_mean_finish", "ogl_out_layer_bwd_inputs",
+    "ogl_ce_fwd_bwd_mean_gather", "ogl_ce_fwd_bwd_mean_grid", "ogl_loss_mean_finish", "ogl_out_layer_bwd_inputs",
     # feat_drop > 0 (every settings file of the reference uses 0): tests/test_gpu_kernels.py
     "ogl_dropout_rows",
     # weight gradients of products between the direct kernel's and the image kernels' sizes, or without a row-major image of x

@@ -392,7 +392,7 @@ def test_pool_backward_limits(ops):
 @pytest.mark.parametrize("M,K,N", [(7060, 602, 600), (70000, 100, 602), (300, 33, 161), (1, 1, 1), (5000, 64, 321), (62495, 602, 602)])
 def test_every_tile_shape_computes_the_same_bits(ops, M, K, N):
     """The three tiles of k_gemm_x3p (256 / 128 / 192 rows x 128 columns) differ in what a block fetches per step, not in the MFMA
-    sequence behind an output element: pinned one after the other (ogl_x3_debug_tile) they return the same bits — plain products and
+    sequence behind an output element: pinned one after the other (ogl_debug_set: OGL_KNOB_X3_TILE) they return the same bits — plain products and
     EXT products (addend, second A part, output image)."""
     from ogl_amd import _lib
     torch.manual_seed(M + N)
@@ -408,14 +408,14 @@ def test_every_tile_shape_computes_the_same_bits(ops, M, K, N):
     outs = []
     try:
         for cfg in (0, 1, 2):
-            assert _lib.lib().ogl_x3_debug_tile(cfg) == 0
+            ops.debug_set("x3_tile", cfg)
             y = ops.linear_fwd_x3(xi, rows, wi, relu=True, x_nrows=T)
             y2, img = ops.linear_fwd_x3_ext(xi, rows, wcat, x2_img=ops.x3_split(x2), add=S0, add_rows=rows, relu=True, x_nrows=T,
                                             want_image=True, image_append_ones=True)
             outs.append((y.clone(), y2.clone(), img.buf.clone()))
     finally:
-        assert _lib.lib().ogl_x3_debug_tile(-1) == 0
-    assert _lib.lib().ogl_x3_debug_tile(3) != 0 and _lib.lib().ogl_x3_debug_tile(-2) != 0
+        ops.debug_set("x3_tile", -1)
+    assert _lib.lib().ogl_debug_set(0, 3, None) != 0 and _lib.lib().ogl_debug_set(0, -2, None) != 0 and _lib.lib().ogl_debug_set(9, 0, None) != 0
     want = (tm[rows].double() @ w.double().T + b.double()).clamp_min(0).float()
     np.testing.assert_allclose(outs[0][0].cpu().numpy(), want.cpu().numpy(), rtol=GEMM_RTOL, atol=GEMM_ATOL)
     for cfg in (1, 2):
@@ -814,11 +814,12 @@ def test_status_codes_of_the_round2_entry_points(ops):
     assert h.ogl_linear_bwd_weight_x3k(p(img), 0, p(img), 64, p(img), 65, 64, 8, 8, 1, p(x), 64, None, None, None, 0, None) == -1
     assert h.ogl_linear_bwd_weight_x3k(p(img), -2, p(img), 64, None, 64, 64, 8, 8, 1, p(x), 64, None, None, None, 0, None) == -1
     # split-multi: more than 8 parts, a bias vector without the slot
-    assert h.ogl_x3_split_multi(p(img), 9, None) == -1
+    assert h.ogl_x3_split_multi(p(img), 9, None, None, 0.0, 0.0, 0.0, None) == -1
     part = ops._X3SplitPart()
     part.src, part.ld, part.R, part.K, part.transpose, part.append = x.data_ptr(), 64, 64, 64, 0, 0
     part.vec1, part.image, part.image_row_bytes, part.group_offset = x.data_ptr(), img.data_ptr(), 2 * 192, 0
-    assert h.ogl_x3_split_multi(C.byref(part), 1, None) == -1
+    assert h.ogl_x3_split_multi(C.byref(part), 1, None, None, 0.0, 0.0, 0.0, None) == -1
+    assert h.ogl_x3_split_multi(C.byref(part), 1, p(x), None, 0.0, 0.0, 0.0, None) == -1         # the optimiser's scalars: both addresses or neither
     # ReLU backward + image: no image / bad strides
     assert h.ogl_relu_bwd_img(p(x), 64, p(x), 64, 64, 64, p(x), 64, None, None) == -1
     assert h.ogl_relu_bwd_img(p(x), 8, p(x), 64, 64, 64, p(x), 64, p(img), None) == -1
@@ -828,5 +829,5 @@ def test_status_codes_of_the_round2_entry_points(ops):
     assert h.ogl_out_layer_bwd_weights(p(x), 64, 64, 8, 64, p(x), 64, p(img), 0, p(x), 64, p(x), 64, p(x), 64, None, None, None) == -1
     # small cross entropy: one workgroup covers at most 1024 rows, and it needs the mean's address
     lab = torch.zeros(64, dtype=torch.int64).cuda()
-    assert h.ogl_ce_fwd_bwd_mean_gather(p(x), 64, p(lab), 64, None, 1025, 8, f(1.0), None, None, 0, p(x), None, 0, None) == -1
-    assert h.ogl_ce_fwd_bwd_mean_gather(p(x), 64, p(lab), 64, None, 64, 8, f(1.0), None, None, 0, None, None, 0, None) == -1
+    assert h.ogl_ce_fwd_bwd_mean_gather(p(x), 64, p(lab), 64, None, 1025, 8, f(1.0), None, None, 0, p(x), None, 0, None, None, 0.0, 0.0, 0.0, None) == -1
+    assert h.ogl_ce_fwd_bwd_mean_gather(p(x), 64, p(lab), 64, None, 64, 8, f(1.0), None, None, 0, None, None, 0, None, None, 0.0, 0.0, 0.0, None) == -1

@@ -47,7 +47,7 @@ for nb in (50, 20):
     from ogl_amd import _lib
     for direct, lds in ((False, 0), (True, 0), (True, 1)):
         ops.BLOCK_DIRECT = direct
-        _lib.lib().ogl_block_debug_min_lds(lds)
+        ops.debug_set("block_min_lds", lds)
         t = timed(lambda: ops.build_block_batched_async(src1, st0, n1h, p0, n_ids=g.handle.n))
         t1 = timed(lambda: ops.build_block_batched_async(seeds, starts, counts, p1, n_ids=g.handle.n))
         print("  build L0 %s %.3f ms   L1 %.3f ms" % (("direct, minima in LDS" if lds else "direct, global atomics") if direct else "hash", t, t1))

@@ -21,7 +21,7 @@ alg = n_dst * S * (4 * D + 8) + n_dst * 4 * D
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for rep in range(3):
     for half in (0, 1):
-        lib.ogl_reduce_debug_half(half)
+        ops.debug_set("reduce_half", half)
         for _ in range(3):
             ops.reduce_fwd(table, idx, "max")
         torch.cuda.synchronize()
@@ -32,4 +32,4 @@ for rep in range(3):
         ms = e0.elapsed_time(e1) / 20
         print("rows per wave-instruction %d: %.1f us per launch, %.0f GB/s of algorithmic bytes (%d destinations x %d picks x %d floats, %d MB table)"
               % (1 + half, 1000 * ms, alg / ms / 1e6, n_dst, S, D, N * D * 4 >> 20), flush=True)
-lib.ogl_reduce_debug_half(1)
+ops.debug_set("reduce_half", 1)

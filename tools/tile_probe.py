@@ -1,4 +1,4 @@
-"""A/B of the image-GEMM tile shapes (ogl_x3_debug_tile) at the step's shapes, one process, alternating runs.
+"""A/B of the image-GEMM tile shapes (ogl_debug_set: OGL_KNOB_X3_TILE) at the step's shapes, one process, alternating runs.
   python tools/tile_probe.py            # prints a JSON line per (shape, tile)"""
 import json, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -36,10 +36,10 @@ def main():
         res = {c: [] for c in cfgs}
         for rnd in range(4):
             for c in cfgs:
-                _lib.lib().ogl_x3_debug_tile(c)
+                ops.debug_set("x3_tile", c)
                 timed(fn, 3)
                 res[c].append(timed(fn, 20))
-        _lib.lib().ogl_x3_debug_tile(-1)
+        ops.debug_set("x3_tile", -1)
         print(json.dumps({"shape": name, "M": M, "K": K, "N": N, "us_by_tile": {str(c): [round(v, 1) for v in res[c]] for c in cfgs}}), flush=True)
         del tm, xi
 
