@@ -899,7 +899,7 @@ def end_to_end_snapshots(n_snapshots=6, start=4500, gemm="auto"):
         timed(rec, "evolve_host", lambda: (gu.evolve(), graph_test.evolve()))
         timed(rec, "gc_collect_host", gc.collect)
         sync(); rec["wall"] = 1000 * (time.perf_counter() - t_snap)
-        rec["train_vertices"] = len(gu.get_train_set())
+        rec["train_vertices"] = len(gu.train_set)        # (not get_train_set(): that materialises the list form)
         phases.append(rec)
     gc.unfreeze()
     try:
@@ -962,6 +962,7 @@ def pbr_snapshot_bench(args, wl):
     def timed(rec, key, fn):
         sync(); t = time.perf_counter()
         out = fn()
+        rec[key + "_enqueue"] = rec.get(key + "_enqueue", 0.0) + 1000 * (time.perf_counter() - t)     # the host's share: fn() returned
         sync(); rec[key] = rec.get(key, 0.0) + 1000 * (time.perf_counter() - t)
         return out
 
@@ -978,11 +979,12 @@ def pbr_snapshot_bench(args, wl):
         nodes = timed(rec, "choose_vertices", lambda: pri.choose_vertices(gu))
         pri.recompute_priorities = inner
         rec["priority_forward_gpu"] = pf.get("t", 0.0)
+        rec["priority_forward_host_enqueue"] = pf.get("t_enqueue", 0.0)
         rec["choose_vertices_host"] = rec.pop("choose_vertices") - rec["priority_forward_gpu"]
         pri.choose_vertices = lambda _gu, _b=nodes: _b
         timed(rec, "train_gpu", lambda: pri.train_timestep(gu))
         del pri.choose_vertices
-        rec["train_vertices"] = len(gu.get_train_set())
+        rec["train_vertices"] = len(gu.train_set)        # (not get_train_set(): that materialises the list form)
         timed(rec, "evolve_host", lambda: gu.evolve())
         timed(rec, "gc_collect_host", gc.collect)
         sync(); rec["wall"] = 1000 * (time.perf_counter() - t_snap)
@@ -1006,7 +1008,8 @@ def pbr_snapshot_bench(args, wl):
                                                                         {1: "", 2: "2nd"}.get(wl["priority_forward"], "n-th"), wl["batch_full"],
                                                                         wl["batch_timestep"], wl["batch"]),
                    "gemm_arithmetic": gemm_desc(args.gemm), "setup_s": round(setup_s, 1)},
-        "phases_ms": {k: round(mean(k), 3) for k in ("priority_forward_gpu", "choose_vertices_host", "train_gpu", "evolve_host", "gc_collect_host")},
+        "phases_ms": {k: round(mean(k), 3) for k in ("priority_forward_gpu", "priority_forward_host_enqueue", "choose_vertices_host", "train_gpu",
+                                                     "evolve_host", "gc_collect_host")},
         "priority_forward_vertices_per_s": round(fwd_seeds / (mean("priority_forward_gpu") / 1000), 1) if mean("priority_forward_gpu") > 0 else None,
         "update_step_execution": dict(forms),
         "roofline": None, "cpu_baseline": None,

@@ -166,19 +166,21 @@ class TrainTestGraph:
         and slices (``random.shuffle`` of 2e5 ids, 100 times per Reddit snapshot: ~0.1 s each); a partial Fisher-Yates
         pass over the first ``n_nodes`` positions yields the same distribution in O(n_nodes).  ``exact_shuffle=True``
         restores the reference's RNG consumption (identical draws under the same ``random.seed``)."""
+        total = len(self.train_set)
+        if not self.exact_shuffle and n_nodes * 8 < total:
+            # a small subset of a long list (512 of 2e5, 100 times per Reddit snapshot): an ordered uniform sample of positions
+            # from a numpy Generator (Floyd's algorithm: O(n_nodes), in C) seeded ONCE from Python's `random` stream — the stream
+            # the reference draws from, so identically seeded replicas still draw identical batches.  The positions index the
+            # arrival-order array (a uniform subset whatever the order): the list form — rebuilt after every admission, 0.7 ms at the
+            # arxiv-like stream's 136 k vertices — is not touched (round 6: it was most of a PBR snapshot's host time outside the forward)
+            if getattr(self, "_draw_rng", None) is None:
+                self._draw_rng = np.random.default_rng(random.getrandbits(63))
+            idx = self._draw_rng.choice(total, size=n_nodes, replace=False, shuffle=True)
+            return self._train_arr[:self._train_n][idx].tolist()
         lst = self.train_set_list
         if self.exact_shuffle:
             random.shuffle(lst)
             return lst[:n_nodes]
-        total = len(lst)
-        if n_nodes * 8 < total:
-            # a small subset of a long list (512 of 2e5, 100 times per Reddit snapshot): an ordered uniform sample of positions
-            # from a numpy Generator (Floyd's algorithm: O(n_nodes), in C) seeded ONCE from Python's `random` stream — the stream
-            # the reference draws from, so identically seeded replicas still draw identical batches
-            if getattr(self, "_draw_rng", None) is None:
-                self._draw_rng = np.random.default_rng(random.getrandbits(63))
-            idx = self._draw_rng.choice(total, size=n_nodes, replace=False, shuffle=True)
-            return [lst[i] for i in idx.tolist()]
         for i in range(n_nodes):
             j = random.randrange(i, total)
             lst[i], lst[j] = lst[j], lst[i]
