@@ -1345,7 +1345,7 @@ DUAL_DW = os.environ.get("OGL_DUAL_DW", "1") != "0"
 # 'mean', whose weight gradients are all that is left of its backward: 0.4208 -> 0.3867 ms per step, same box (relu_bwd_img + one
 # k-major product where relu_bwd + a transposed image + two products + two reduction launches ran); with an input gradient on the
 # critical path beside it ('meanpool') the one big product is in the way: 1.2057 -> 1.2172 ms.  OGL_DUAL_DW_CAT=1 / 0: always / never.
-DUAL_DW_CAT_MODE = "auto"
+DUAL_DW_CAT_MODE = "auto"       # (round 6, after k_seg_groups: "1" for 'meanpool' 1.0406-1.0435 against 1.0344-1.0378 ms, same box: still in the way)
 DUAL_DW_CAT = DUAL_DW_CAT_MODE != "0"
 
 
