@@ -107,6 +107,8 @@ def parse():
                          "parameters -> all-gather of the weights (parallel.ShardedAdam: the late-exchange lever of DESIGN section 6), "
                          "0 = all-reduce + the identical Adam on every rank (the default)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end snapshot leg (metric iii) of the default line")
+    ap.add_argument("--knob", action="append", default=None, metavar="NAME=VALUE",
+                    help="A/B: pin a kernel form through ogl_debug_set (ops.KNOBS: x3_tile, x3_stagger, block_min_lds, reduce_half, seg_rows)")
     ap.add_argument("--reduce-half", type=int, default=None, choices=[0, 1],
                     help="A/B: pin the narrow-row max aggregator to one (0) / two (1) neighbour rows per wave-instruction (ogl_debug_set: OGL_KNOB_REDUCE_HALF)")
     ap.add_argument("--variants-timeout", type=int, default=240,
@@ -208,6 +210,9 @@ def main():
     ops.set_gemm_mode(args.gemm)
     if args.reduce_half is not None:
         ops.debug_set("reduce_half", args.reduce_half)
+    for kv in args.knob or []:                                 # same-process A/B of a kernel form: --knob seg_rows=0
+        name, _, val = kv.partition("=")
+        ops.debug_set(name, int(val))
     wl = WORKLOADS[args.workload]
     B, S, H, bt = wl["batch"], wl["samples"], wl["hidden"], wl["batch_timestep"]
     if wl.get("snapshot"):

@@ -68,8 +68,11 @@ int ogl_last_hip_error(void); /* hipError_t of the most recent OGL_EHIP on this 
  *                           (default 3).  Every accumulator sees its reduction steps in the same order either way.
  *   OGL_KNOB_BLOCK_MIN_LDS  0 = the per-id minima of ogl_build_block_batched (n_ids > 0) through global atomics even where its LDS form applies.
  *   OGL_KNOB_REDUCE_HALF    1 / 0 = the max aggregator WITHOUT argmax over rows of <= 128 floats (the inference passes over a narrow
- *                           projection table) reads two neighbour rows per wave-instruction (half a wave per row) / one. */
-enum { OGL_KNOB_X3_TILE = 0, OGL_KNOB_X3_STAGGER = 1, OGL_KNOB_BLOCK_MIN_LDS = 2, OGL_KNOB_REDUCE_HALF = 3 };
+ *                           projection table) reads two neighbour rows per wave-instruction (half a wave per row) / one.
+ *   OGL_KNOB_SEG_ROWS       1 / 0 = ogl_reduce_bwd_seg_apply on blocks of at most 32 768 edges as ONE launch (a block per 8 sources) / as
+ *                           the tiled launch + its fix-up launch (sums in the same list order: the same bits where a source's edges
+ *                           sit in one tile). */
+enum { OGL_KNOB_X3_TILE = 0, OGL_KNOB_X3_STAGGER = 1, OGL_KNOB_BLOCK_MIN_LDS = 2, OGL_KNOB_REDUCE_HALF = 3, OGL_KNOB_SEG_ROWS = 4 };
 int ogl_debug_set(int knob, int value, int* previous);
 
 /* ------------------------------------------------------------------------------------------
@@ -187,13 +190,17 @@ int ogl_reduce_bwd(const float* dout, int64_t ldo, const int32_t* idx32, const i
  *                              front of a pooling mean, aggregator_dgl.py:181-185), written as fp32 (`out`, nullable) and / or as
  *                              the row-major bf16x3 image of [n_src, d] (`image`, ogl_x3_image_bytes(n_src, d), nullable): what
  *                              ogl_linear_bwd_weight_x3k reads as its dy operand (interleave -1) — the first layer's pooled-row
- *                              gradient is then never materialised in fp32.  d a multiple of 4, <= 1024; 16-byte aligned rows. */
+ *                              gradient is then never materialised in fp32.  `add` (nullable; needs `out`): rows s < n_add of `out`
+ *                              get add[s, :] on top — the head rows' own gradient of a SAGE layer (h[:n_dst] feeds fc_self, every
+ *                              row feeds the mean) joins inside the launch instead of through an add launch behind it; the image
+ *                              (dsrc's OTHER consumer reads the sum too) carries it as well.  d a multiple of 4, <= 1024; 16-byte
+ *                              aligned rows. */
 int64_t ogl_reduce_bwd_seg_workspace_bytes(int64_t n_dst, int fanout, int d, int64_t n_src);
 int ogl_reduce_bwd_seg_plan(const int32_t* idx, int64_t n_dst, int fanout, int64_t n_src, int group_lists, void* workspace,
                             int64_t workspace_bytes, ogl_stream_t stream);
 int ogl_reduce_bwd_seg_apply(const float* dout, int64_t ldd, const int32_t* idx, int64_t n_dst, int fanout, int d, int op, int64_t n_src,
-                             const float* mask, int64_t ldm, float* out, int64_t ldo, void* image, void* workspace,
-                             int64_t workspace_bytes, ogl_stream_t stream);
+                             const float* mask, int64_t ldm, const float* add, int64_t lda, int64_t n_add, float* out, int64_t ldo,
+                             void* image, void* workspace, int64_t workspace_bytes, ogl_stream_t stream);
 /* ... and as the TRANSPOSED, group-major bf16x3 image of dsrc (sources dealt round-robin over G = ceil(n_src / 32) groups of 32; the
  * layout ogl_pool_bwd_x3 writes: ogl_x3_image_bytes(d, 32 G) bytes): the dy operand of ogl_linear_bwd_weight_x3k with interleave = G,
  * i.e. the 'meanpool' first layer's fc_pool weight gradient on the same 256 x 128 product as the 'pool' mode's

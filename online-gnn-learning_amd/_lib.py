@@ -45,7 +45,7 @@ SIGNATURES = {
     "ogl_reduce_fwd_rows_mean_img": (_i, [_p, _i64, _i64, _p, _p, _i64, _i64, _i, _i, _p, _i64, _p, _p]),
     "ogl_reduce_bwd_seg_workspace_bytes": (_i64, [_i64, _i, _i, _i64]),
     "ogl_reduce_bwd_seg_plan": (_i, [_p, _i64, _i, _i64, _i, _p, _i64, _p]),
-    "ogl_reduce_bwd_seg_apply": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p]),
+    "ogl_reduce_bwd_seg_apply": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _p, _p, _i64, _p]),
     "ogl_reduce_bwd_seg_apply_t": (_i, [_p, _i64, _i64, _i, _i, _i, _i64, _p, _i64, _p, _p, _i64, _p]),
     "ogl_linear_fwd": (_i, [_p, _i64, _p, _i64, _i64, _i, _p, _i64, _i, _p,
                             _p, _i64, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p]),

@@ -21,6 +21,7 @@ extern "C" int ogl_debug_set(int knob, int value, int* previous) {
     case OGL_KNOB_X3_STAGGER: rc = oglx_knob_x3_stagger(value, &prev); break;
     case OGL_KNOB_BLOCK_MIN_LDS: rc = oglx_knob_block_min_lds(value, &prev); break;
     case OGL_KNOB_REDUCE_HALF: rc = oglx_knob_reduce_half(value, &prev); break;
+    case OGL_KNOB_SEG_ROWS: rc = oglx_knob_seg_rows(value, &prev); break;
     default: break;
   }
   if (rc == OGL_OK && previous) *previous = prev;

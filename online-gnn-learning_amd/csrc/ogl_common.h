@@ -23,6 +23,7 @@ OGL_INTERNAL int oglx_knob_x3_tile(int cfg, int* prev);          // linear_x3.hi
 OGL_INTERNAL int oglx_knob_x3_stagger(int on, int* prev);        // linear_x3.hip
 OGL_INTERNAL int oglx_knob_block_min_lds(int on, int* prev);     // block.hip
 OGL_INTERNAL int oglx_knob_reduce_half(int on, int* prev);       // aggregate.hip
+OGL_INTERNAL int oglx_knob_seg_rows(int on, int* prev);          // reduce_seg.hip
 
 static inline int64_t ogl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t ogl_round_up(int64_t a, int64_t b) { return ogl_cdiv(a, b) * b; }

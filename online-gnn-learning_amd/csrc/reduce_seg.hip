@@ -186,6 +186,7 @@ struct SegOut {
   unsigned char* img; int64_t img_row_bytes;  // row-major bf16x3 image, n_src + 1 rows (nullable)
   const float* mask; int64_t ldm;             // optional: row s is multiplied by [mask[s, :] > 0]
   float divisor;                              // S for the mean, 1 for the sum
+  const float* add; int64_t lda; int64_t n_add;   // optional: rows s < n_add of the fp32 output get add[s, :] on top (after scale and mask)
 };
 
 // the mask of this thread's 4 columns of source s as {> 0 : keep}
@@ -200,6 +201,10 @@ __device__ __forceinline__ void seg_store(const SegOut& o, int64_t s, int ch, in
   if (o.mask && b4 < D) {
     const float4 m = seg_mask4(o, s, ch);
     a.x = m.x > 0.f ? a.x : 0.f; a.y = m.y > 0.f ? a.y : 0.f; a.z = m.z > 0.f ? a.z : 0.f; a.w = m.w > 0.f ? a.w : 0.f;
+  }
+  if (o.add && s < o.n_add && b4 < D) {       // (the head rows' own gradient joins here: no add launch behind the backward)
+    const float4 t = *(const float4*)(o.add + s * o.lda + b4);
+    a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
   }
   const float e0 = b4 < D ? a.x : 0.f, e1 = b4 + 1 < D ? a.y : 0.f, e2 = b4 + 2 < D ? a.z : 0.f, e3 = b4 + 3 < D ? a.w : 0.f;
   if (o.out && b4 < D) {
@@ -282,6 +287,66 @@ __global__ void __launch_bounds__(SG_THREADS) k_seg_reduce(const float* __restri
         run_k0 = k + 1;
       }
     }
+  }
+}
+
+// Blocks of at most SG_SMALL_E entries (the 512-seed output block's 12 800 edges): ONE launch, a block per SGR_SRC consecutive sources —
+// their planned lists are one contiguous range of sorted[] (block-uniform: scalar loads of the range bounds and of the entries), a thread
+// per 16-byte column chunk, SGR_U row loads in flight, a source's row finished and stored (scale, mask, addend, fp32 / image: seg_store)
+// at its last entry; sources nobody sampled get their zero row; the block that holds source n_src writes the image's zero row.  No
+// partial rows, no fix-up launch, no add launch behind it: in the traced 'mean' step at the Reddit rung 16.8 us where k_seg_reduce<16>,
+// k_seg_fixup and the add of the head rows' gradient took 15.0 + 6.4 + 5.0 (8 sources and 8 loads per trip measured the same: the launch is
+// three dependent round trips — bounds, entries, rows — long, not bandwidth- or trip-bound).
+#define SGR_SRC 4
+#define SGR_U 16
+__global__ void __launch_bounds__(256) k_seg_rows(const float* __restrict__ dout, int64_t ldd, int S, int D, const int* __restrict__ sorted,
+                                                  const int* __restrict__ start, int64_t n_src, SegOut o) {
+  __shared__ int bnd[SGR_SRC + 1];                                // start[s0 .. s0 + SGR_SRC] (clamped: sources past n_src are empty)
+  const int tid = threadIdx.x;
+  const int64_t s0 = (int64_t)blockIdx.x * SGR_SRC;
+  if (tid <= SGR_SRC) bnd[tid] = start[s0 + tid < n_src ? s0 + tid : n_src];
+  __syncthreads();
+  const int D4 = (D + 3) >> 2;
+  const int Kp4 = o.img ? (int)(o.img_row_bytes / 192) * 8 : D4;
+  if (tid >= max(D4, Kp4)) return;
+  const bool cin = tid < D4;
+  const float* src = dout + 4 * (cin ? tid : D4 - 1);
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc = zero;
+  int cur = 0, lo = bnd[0], nxt = bnd[1];                         // the source the walk is in, its range [lo, nxt)
+  const int k_end = bnd[SGR_SRC];
+  // (block-uniform control flow throughout: every thread sees the same bounds and entries)
+  while (cur < SGR_SRC && nxt == lo) {                            // sources without an edge in front of the first entry
+    if (s0 + cur < n_src) seg_store(o, s0 + cur, tid, D, zero);
+    ++cur; nxt = cur < SGR_SRC ? bnd[cur + 1] : -1;
+  }
+  for (int k0 = bnd[0]; k0 < k_end; k0 += SGR_U) {
+    float4 v[SGR_U];
+#pragma unroll
+    for (int u = 0; u < SGR_U; ++u) {                             // (a slot past the range re-reads its last entry's row)
+      const int e = __builtin_amdgcn_readfirstlane(sorted[k0 + u < k_end ? k0 + u : k_end - 1]);
+      v[u] = *(const float4*)(src + (int64_t)(e / S) * ldd);
+    }
+#pragma unroll
+    for (int u = 0; u < SGR_U; ++u) {
+      const int k = k0 + u;
+      if (k < k_end) {
+        acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+        if (k + 1 == nxt) {                                       // the source's last entry
+          seg_store(o, s0 + cur, tid, D, cin ? acc : zero);
+          acc = zero;
+          ++cur; lo = nxt; nxt = cur < SGR_SRC ? bnd[cur + 1] : -1;
+          while (cur < SGR_SRC && nxt == lo) {                    // sources without an edge behind it
+            if (s0 + cur < n_src) seg_store(o, s0 + cur, tid, D, zero);
+            ++cur; nxt = cur < SGR_SRC ? bnd[cur + 1] : -1;
+          }
+        }
+      }
+    }
+  }
+  if (o.img && s0 <= n_src && n_src < s0 + SGR_SRC) {             // the image's all-zero row (row n_src)
+    SegOut z = o; z.out = nullptr; z.mask = nullptr; z.add = nullptr;
+    seg_store(z, n_src, tid, D, zero);
   }
 }
 
@@ -526,9 +591,13 @@ extern "C" int ogl_reduce_bwd_seg_plan(const int32_t* idx, int64_t n_dst, int fa
 // Apply: dsrc = (sum over the planned edge lists of dout rows) / divisor, masked by [mask > 0] when given; written as fp32 rows
 // (`out`, nullable) and / or as the row-major bf16x3 image of [n_src, d] (`image`: ogl_x3_image_bytes(n_src, d), nullable).
 // op: OGL_REDUCE_MEAN (divisor fanout) or OGL_REDUCE_SUM.  d a multiple of 4 <= 1024; 16-byte aligned rows.
+static int g_seg_rows = 1;          // (ogl_debug_set(OGL_KNOB_SEG_ROWS): 0 = small blocks through k_seg_reduce<16> + k_seg_fixup as before)
+int oglx_knob_seg_rows(int on, int* prev) { *prev = g_seg_rows; g_seg_rows = on ? 1 : 0; return OGL_OK; }
+
 static int seg_apply(const float* dout, int64_t ldd, const int32_t* idx, int64_t n_dst, int fanout, int d, int op, int64_t n_src,
-                     const float* mask, int64_t ldm, float* out, int64_t ldo, void* image,
+                     const float* mask, int64_t ldm, const float* add, int64_t lda, int64_t n_add, float* out, int64_t ldo, void* image,
                      void* workspace, int64_t workspace_bytes, ogl_stream_t stream) {
+  if (add && (!out || n_add < 0 || n_add > n_src || lda < d || (lda & 3) || ((uintptr_t)add & 15))) return OGL_EINVAL;
   if (n_dst < 0 || fanout <= 0 || d <= 0 || d > 1024 || (d & 3) || n_src <= 0 || ldd < d || (ldd & 3)) return OGL_EINVAL;
   if (op != OGL_REDUCE_MEAN && op != OGL_REDUCE_SUM) return OGL_EINVAL;
   if ((!out && !image) || (out && (ldo < d || (ldo & 3) || ((uintptr_t)out & 15))) || (mask && (ldm < d || (ldm & 3) || ((uintptr_t)mask & 15))))
@@ -547,7 +616,14 @@ static int seg_apply(const float* dout, int64_t ldd, const int32_t* idx, int64_t
   SegOut o;
   o.out = out; o.ldo = ldo; o.img = (unsigned char*)image; o.img_row_bytes = ogl_cdiv(d, 32) * 192; o.mask = mask; o.ldm = ldm;
   o.divisor = op == OGL_REDUCE_MEAN ? (float)fanout : 1.f;
+  o.add = add; o.lda = lda; o.n_add = add ? n_add : 0;
   const int tile = seg_tile(E);
+  if (tile == SG_TILE_SMALL && g_seg_rows) {                      // small blocks: one launch, a block per SGR_SRC sources
+    hipLaunchKernelGGL(k_seg_rows, dim3((unsigned)ogl_cdiv(n_src + 1, SGR_SRC)), dim3(256), 0, st, dout, ldd, fanout, d, (const int*)sorted,
+                       (const int*)start, n_src, o);
+    OGL_CHECK_LAUNCH();
+    return OGL_OK;
+  }
   if (E > 0) {
     if (tile == SG_TILE_SMALL)
       hipLaunchKernelGGL(k_seg_reduce<SG_TILE_SMALL>, dim3((unsigned)ogl_cdiv(E, SG_TILE_SMALL)), dim3(SG_THREADS), 0, st, dout, ldd, n_dst, fanout,
@@ -564,9 +640,10 @@ static int seg_apply(const float* dout, int64_t ldd, const int32_t* idx, int64_t
 }
 
 extern "C" int ogl_reduce_bwd_seg_apply(const float* dout, int64_t ldd, const int32_t* idx, int64_t n_dst, int fanout, int d, int op,
-                                        int64_t n_src, const float* mask, int64_t ldm, float* out, int64_t ldo, void* image,
-                                        void* workspace, int64_t workspace_bytes, ogl_stream_t stream) {
-  return seg_apply(dout, ldd, idx, n_dst, fanout, d, op, n_src, mask, ldm, out, ldo, image, workspace, workspace_bytes, stream);
+                                        int64_t n_src, const float* mask, int64_t ldm, const float* add, int64_t lda, int64_t n_add,
+                                        float* out, int64_t ldo, void* image, void* workspace, int64_t workspace_bytes,
+                                        ogl_stream_t stream) {
+  return seg_apply(dout, ldd, idx, n_dst, fanout, d, op, n_src, mask, ldm, add, lda, n_add, out, ldo, image, workspace, workspace_bytes, stream);
 }
 
 // The group-major copy of a planned workspace's lists (ogl_reduce_bwd_seg_plan with group_lists = 1): what ogl_reduce_bwd_seg_apply_t

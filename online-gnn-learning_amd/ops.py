@@ -89,7 +89,7 @@ def get_gemm_mode() -> str:
     return [k for k, v in GEMM_MODES.items() if v == m][0]
 
 
-KNOBS = {"x3_tile": 0, "x3_stagger": 1, "block_min_lds": 2, "reduce_half": 3}
+KNOBS = {"x3_tile": 0, "x3_stagger": 1, "block_min_lds": 2, "reduce_half": 3, "seg_rows": 4}
 
 
 def debug_set(knob: str, value: int) -> int:
@@ -1202,9 +1202,10 @@ def reduce_bwd_seg_plan(idx32, d, n_src, side=True, groups=False):
     return _plan_on_side(plan, launch, (ws, idx32), side)
 
 
-def reduce_bwd_seg_apply(dout, idx32, plan, op, mask=None, want_out=True, want_image=False):
+def reduce_bwd_seg_apply(dout, idx32, plan, op, mask=None, want_out=True, want_image=False, add=None):
     """(dsrc [n_src, d] or None, its row-major bf16x3 image or None) from a plan: dsrc[s] = (1 / fanout for 'mean') sum of dout over
-    the edges into s, in edge order (no atomics, reproducible), optionally times [mask[s] > 0]."""
+    the edges into s, in edge order (no atomics, reproducible), optionally times [mask[s] > 0]; ``add`` [n_add <= n_src, d]: added onto
+    the first n_add rows inside the launch (the head rows' own gradient of a SAGE layer)."""
     dout = as_mat(dout)
     n_dst, d = dout.shape
     fanout, n_src = idx32.shape[1], plan.shape[3]
@@ -1215,8 +1216,12 @@ def reduce_bwd_seg_apply(dout, idx32, plan, op, mask=None, want_out=True, want_i
     if mask is not None:
         mask = as_mat(mask)
         assert tuple(mask.shape) == (n_src, d)
+    if add is not None:
+        add = as_mat(add)
+        assert want_out and add.shape[1] == d and add.shape[0] <= n_src
     _launch("ogl_reduce_bwd_seg_apply", _lib.lib().ogl_reduce_bwd_seg_apply, _ptr(dout), _ld(dout), _ptr(idx32), n_dst, fanout, d,
-            REDUCE_OPS[op], n_src, _ptr(mask), _ld(mask) if mask is not None else 0, _ptr(out), _ld(out) if out is not None else 0,
+            REDUCE_OPS[op], n_src, _ptr(mask), _ld(mask) if mask is not None else 0, _ptr(add), _ld(add) if add is not None else 0,
+            add.shape[0] if add is not None else 0, _ptr(out), _ld(out) if out is not None else 0,
             _ptr(img.buf) if img is not None else None, _ptr(plan.ws), plan.nbytes, _stream(),
             meta=dict(n_dst=n_dst, fanout=fanout, d=d, n_src=n_src, op=op, out=out is not None, image=img is not None, mask=mask is not None))
     return out, img
@@ -2541,8 +2546,7 @@ class _SageMeanLossFn(torch.autograd.Function):
             plan, ctx.seg_plan = getattr(ctx, "seg_plan", None), None
             if plan is None:
                 plan = reduce_bwd_seg_plan(idx, K, ctx.n_src, side=False)
-            dh = reduce_bwd_seg_apply(dneigh, idx, plan, "mean")[0]
-            dh[:n_dst].add_(dx_self)
+            dh = reduce_bwd_seg_apply(dneigh, idx, plan, "mean", add=dx_self)[0]      # (the head rows' own gradient joins inside the launch)
         return dh, dw_cat, (db if ctx.has_bias else None), None, None, None, None, None
 
 

@@ -545,3 +545,53 @@ def test_meanpool_first_layer_weight_gradient_through_the_transposed_image():
         assert float((grads[True][0] - grads[False][0]).abs().max()) <= 2e-5 * float(dw.abs().max())
     finally:
         ops.set_gemm_mode("f32")
+
+
+@pytest.mark.parametrize("n_dst,S,D,n_src,n_add", [(1, 1, 4, 1, 1), (50, 4, 36, 70, 50), (512, 25, 600, 7060, 512), (512, 25, 600, 7063, 0),
+                                                    (1200, 10, 132, 30, 30), (300, 63, 640, 5000, 300)])
+def test_small_block_mean_backward_in_one_launch(n_dst, S, D, n_src, n_add):
+    """ogl_reduce_bwd_seg_apply on blocks of at most 32 768 edges: ONE launch (k_seg_rows: a block per 8 consecutive sources, their
+    planned lists read as one block-uniform range) against the tiled launch + fix-up it replaces (ogl_debug_set: OGL_KNOB_SEG_ROWS) and
+    float64 — fp32 rows, the row-major image, the ReLU mask, a hub (more edges than one trip), sources nobody sampled, the ragged last
+    block, and the head rows' addend joined inside the launch.  Integer-valued gradients: every summation order is exact, so the two
+    forms agree bit for bit."""
+    import ogl_amd  # noqa: F401
+    from ogl_amd import ops
+    rng = np.random.default_rng(n_dst + 3 * D)
+    idx = rng.integers(0, n_src, (n_dst, S)).astype(np.int32)
+    if n_src > 20:
+        idx[rng.random((n_dst, S)) < 0.2] = 3                            # a hub
+        idx[idx == 5] = 6                                                  # ... and a source nobody samples
+    idx[rng.random((n_dst, S)) < 0.05] = -1
+    idx_d = torch.as_tensor(idx).cuda()
+    p = torch.randn(n_src, D).clamp_min(0)
+    pm = ops.empty_mat(n_src, D, "cuda"); pm.copy_(p)
+    dout = torch.randint(-8, 9, (n_dst, D)).float()
+    dm = ops.empty_mat(n_dst, D, "cuda"); dm.copy_(dout)
+    addend = torch.randint(-4, 5, (n_add, D)).float() if n_add else None
+    am = None
+    if n_add:
+        am = ops.empty_mat(n_add, D, "cuda"); am.copy_(addend)
+    plan = ops.reduce_bwd_seg_plan(idx_d, D, n_src, side=False)
+    ref = np.zeros((n_src, D), np.float64)
+    valid = idx >= 0
+    np.add.at(ref, idx[valid], np.repeat(dout.numpy().astype(np.float64)[:, None, :], S, axis=1)[valid])
+    got = {}
+    was = ops.debug_set("seg_rows", 1)
+    try:
+        for form in (1, 0):
+            ops.debug_set("seg_rows", form)
+            for masked in (False, True):
+                out, img = ops.reduce_bwd_seg_apply(dm, idx_d, plan, "mean", mask=pm if masked else None, want_out=True, want_image=True, add=am)
+                got[(form, masked)] = (out.cpu().numpy().copy(), img.buf.cpu().numpy().copy())
+    finally:
+        ops.debug_set("seg_rows", was)
+    for masked in (False, True):
+        want = (ref.astype(np.float32) / np.float32(S)).astype(np.float32)
+        if masked:
+            want = np.where(p.numpy() > 0, want, np.float32(0))
+        if n_add:
+            want[:n_add] += addend.numpy()
+        assert np.array_equal(got[(1, masked)][0], want)
+        assert np.array_equal(got[(1, masked)][0], got[(0, masked)][0])
+        assert np.array_equal(got[(1, masked)][1], got[(0, masked)][1])    # the image too, incl. its zero row and pad chunks
