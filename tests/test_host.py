@@ -311,3 +311,38 @@ def test_whole_slab_dealing_is_a_bijection():
                 if slab < 8 * (nsplit >> 3):
                     assert home.setdefault(slab, xcd) == xcd              # a whole slab never straddles two XCDs
             assert len(seen) == tiles * nsplit
+
+
+def test_small_draws_from_a_long_train_set_do_not_rebuild_the_list():
+    """A draw of n with 8 n < |train set| (32 of 1.4e5 at the arxiv-like rung, 512 of 2e5 at the Reddit one) indexes the arrival-order array
+    with positions from a numpy Generator seeded once from Python's `random` stream: distinct members of the train set, uniform, the same
+    batches under the same seed — and the list form (rebuilt after every admission: 0.7 ms at 136 k vertices, twice per PBR snapshot before
+    round 6) is never materialised.  exact_shuffle keeps the reference's list and RNG consumption."""
+    from ogl_amd.graph.train_test_graph import TrainTestGraph
+
+    def make():
+        np.random.seed(2); random.seed(2)
+        return TrainTestGraph(_StubDynamicGraph(snapshots=6, per=400), split=0.15, start_prior_alpha=4, end_prior_alpha=50, scale=1, max_priority=10)
+    g = make()
+    g.evolve()
+    assert len(g.train_set) == 680 and g._train_n == 680 and g._train_list is None
+    random.seed(11)
+    a = [g.draw_random_train_nodes(16) for _ in range(3)] + [g.draw_priority_train_nodes(16)]
+    assert g._train_list is None                                       # (no list(train_set) behind any of the four draws)
+    for d in a:
+        assert len(d) == 16 and len(set(d)) == 16 and set(d) <= g.train_set and all(isinstance(v, int) for v in d)
+    g2 = make()
+    g2.evolve()
+    random.seed(11)
+    assert [g2.draw_random_train_nodes(16) for _ in range(3)] + [g2.draw_priority_train_nodes(16)] == a    # identically seeded replicas
+    counts = np.zeros(800, np.int64)
+    for _ in range(3000):
+        counts[g.draw_random_train_nodes(16)] += 1
+    seen = counts[sorted(g.train_set)]
+    assert counts.sum() == seen.sum() and seen.min() > 0.5 * seen.mean() and seen.max() < 1.6 * seen.mean()      # 70.6 expected per vertex
+    g.evolve()                                                          # an admission: the array grows, still no list
+    assert g._train_n == len(g.train_set) == 1020 and g._train_list is None
+    assert set(g.draw_random_train_nodes(16)) <= g.train_set and g._train_list is None
+    g.exact_shuffle = True                                              # the reference's own draw: shuffles the list form
+    random.seed(5); ref_list = list(g.train_set); random.shuffle(ref_list)
+    random.seed(5); assert g.draw_random_train_nodes(16) == ref_list[:16]
