@@ -54,6 +54,30 @@ def test_argument_validation_without_gpu():
     assert h.ogl_small_proj_rows(None, 512, None, 10, 0, 500, None, 500, 500, None, 1, None, 512, None, None) == 0    # no rows: nothing to do
     assert h.ogl_small_proj_rows(None, 512, None, 10, 64, 502, None, 502, 500, None, 1, None, 512, None, None) == -1  # K % 4
     assert h.ogl_sample_blocks_small_fill(None, None, None, 32, 25, 1, None, None, None, None, None, None, None, None, 0, 256, None) == -1
+    # round 6: the diagnostic knobs behind ONE entry point; the merged entry points' optional parts come in pairs; the mean backward as the
+    # transposed image and its addend are refused before anything is launched
+    prev = ctypes.c_int(-7)
+    assert h.ogl_debug_set(9, 0, None) == -1 and h.ogl_debug_set(0, 3, None) == -1 and h.ogl_debug_set(1, 4, None) == -1
+    assert h.ogl_debug_set(3, 1, ctypes.byref(prev)) == 0 and prev.value in (0, 1)
+    assert h.ogl_debug_set(4, 1, ctypes.byref(prev)) == 0 and prev.value in (0, 1)
+    assert h.ogl_debug_set(0, -1, ctypes.byref(prev)) == 0 and prev.value in (-1, 0, 1, 2)
+    assert h.ogl_set_gemm_mode(-1) in (0, 1, 2) and h.ogl_set_gemm_mode(7) == -1        # OGL_GEMM_QUERY changes nothing
+    buf = (ctypes.c_char * 64)()
+    p64 = ctypes.cast(buf, ctypes.c_void_p)
+    assert h.ogl_x3_split_multi(p64, 1, p64, None, 0.0, 0.0, 0.0, None) == -1            # the optimiser's scalars: both addresses or neither
+    assert h.ogl_ce_fwd_bwd_mean_gather(p64, 8, p64, 4, None, 4, 8, ctypes.c_float(1.0), None, None, 0, p64, None, 0, p64, None, 0.0, 0.0, 0.0, None) == -1
+    assert h.ogl_block_workspace_bytes_batched(None, 1, 25, 0) == -1 and h.ogl_block_workspace_bytes_batched(None, 1, 25, 1000) == -1
+    assert h.ogl_reduce_bwd_seg_workspace_bytes(7060, 25, 600, 62495) > 8 * 7060 * 25                       # (incl. the group-major lists)
+    assert h.ogl_reduce_bwd_seg_plan(None, 10, 25, 0, 1, p64, 64, None) == -1                               # no sources
+    assert h.ogl_reduce_bwd_seg_plan(None, 10, 25, 100, 1, p64, 64, None) == -4                             # workspace too small
+    ok = (p64, 608, 10, 25, 600, 0, 100, None, 0, p64, p64, 1 << 30, None)
+    assert h.ogl_reduce_bwd_seg_apply_t(*(ok[:4] + (642,) + ok[5:])) == -1                                   # more than 640 columns
+    assert h.ogl_reduce_bwd_seg_apply_t(*((ok[0], 607) + ok[2:])) == -1                                      # an odd leading dimension
+    assert h.ogl_reduce_bwd_seg_apply_t(*(ok[:9] + (None,) + ok[10:])) == -1                                 # no image
+    assert h.ogl_reduce_bwd_seg_apply_t(*(ok[:11] + (64,) + ok[12:])) == -4                                  # workspace too small
+    rows = (p64, 608, p64, 10, 25, 600, 0, 100, None, 0, p64, 608, 5, None, 0, p64, p64, 1 << 30, None)
+    assert h.ogl_reduce_bwd_seg_apply(*rows) == -1                                                           # an addend without fp32 rows
+    assert h.ogl_reduce_bwd_seg_apply(*(rows[:12] + (101,) + (p64, 608) + rows[15:])) == -1                  # more addend rows than sources
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
